@@ -1,0 +1,11 @@
+"""MI355X-native coloured sparse-Jacobian finite differencing (FiniteDiff.jl hot path).
+
+Host-side mirror of the reference's interface for this one path
+(``JacobianCache`` + ``finite_difference_jacobian!``; reference: src/jacobians.jl:1-128,
+446-471, 504-653) on top of the C-ABI library ``libfdjac`` (include/fdjac.h), whose kernels
+are hand-written HIP for gfx950.  There is no CPU fallback: every compute entry point
+raises if the HIP library or a GPU is missing.
+"""
+from . import patterns  # noqa: F401  (numpy-only helpers; safe without a GPU)
+
+__all__ = ["patterns"]

@@ -1,0 +1,244 @@
+"""ctypes front-end of the CPU oracle (oracle/fd_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+
+Everything here speaks the reference's conventions: 1-based Int64 indices,
+column-major matrices, colours 1..C.  See fd_oracle.c for the reference
+file:line each routine follows.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libfd_oracle.so")
+
+FORWARD, CENTRAL, COMPLEX = 0, 1, 2
+FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
+
+(PAT_NONE, PAT_CSC_COMMON, PAT_CSC_DENSEJ, PAT_COO_DENSEJ, PAT_COO_TRIDIAG, PAT_BANDED,
+ PAT_BLOCKBANDED) = range(7)
+
+F_REAL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+F_CPLX = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+class Pattern(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("M", C.c_int64), ("N", C.c_int64),
+        ("colptr", _i64p), ("rowval", _i64p),
+        ("rows_index", _i64p), ("cols_index", _i64p), ("ncoo", C.c_int64),
+        ("l", C.c_int64), ("u", C.c_int64),
+        ("nblk", C.c_int64), ("blk_sizes", _i64p), ("bl", C.c_int64), ("bu", C.c_int64),
+        ("block_starts", _i64p), ("block_strides", _i64p),
+        ("out0", _f64p), ("out1", _f64p), ("out2", _f64p), ("out_len", C.c_int64),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/fd_oracle.c -> oracle/_build/libfd_oracle.so (gcc)."""
+    src = os.path.join(_HERE, "fd_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.fdo_jacobian_cached.restype = C.c_int
+        L.fdo_jacobian_cached.argtypes = [
+            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p,
+            C.c_void_p, C.c_void_p, _f64p, _i64p, C.c_double, C.c_double, C.c_double,
+            C.POINTER(Pattern), _i64p]
+        L.fdo_default_relstep.restype = C.c_double
+        L.fdo_default_relstep.argtypes = [C.c_int]
+        L.fdo_findstructralnz_dense.restype = C.c_int64
+        L.fdo_findstructralnz_dense.argtypes = [_f64p, C.c_int64, C.c_int64, _i64p, _i64p]
+        L.fdo_jacobian_oop_dense_forward.restype = None
+        L.fdo_jacobian_oop_dense_forward.argtypes = [
+            C.c_void_p, C.c_void_p, _f64p, C.c_int64, C.c_int64, C.c_double, C.c_double,
+            C.c_double, _f64p]
+        L.fdo_build_tridiag_csc.restype = None
+        L.fdo_build_tridiag_csc.argtypes = [C.c_int64, _i64p, _i64p]
+        _lib = L
+    return _lib
+
+
+def default_relstep(fdtype):
+    return lib().fdo_default_relstep(FDTYPES[fdtype])
+
+
+def _p64(a):
+    return a.ctypes.data_as(_i64p) if a is not None else None
+
+
+def _pf(a):
+    return a.ctypes.data_as(_f64p) if a is not None else None
+
+
+class Fixture:
+    """One of the C fixture f!s: (real fn, complex fn, ctx int64 array)."""
+
+    def __init__(self, name, *ctx):
+        L = lib()
+        self.name = name
+        self.ctx = np.asarray(ctx, dtype=np.int64)
+        self.f = C.cast(getattr(L, "fdo_f_" + name), C.c_void_p)
+        fc = getattr(L, "fdo_fc_" + name, None)
+        self.fc = C.cast(fc, C.c_void_p) if fc is not None else None
+        self.ctxp = self.ctx.ctypes.data_as(C.c_void_p)
+
+    def __call__(self, x):
+        """Evaluate on a numpy vector (real or complex); M inferred by the caller via out=."""
+        raise NotImplementedError
+
+
+class PyF:
+    """A Python f!(fx, x) on numpy arrays (real and complex) as oracle callbacks."""
+
+    def __init__(self, fn, M, N):
+        self.fn, self.M, self.N = fn, M, N
+        self.calls = 0
+
+        def _real(_ctx, fxp, xp):
+            fx = np.ctypeslib.as_array(fxp, shape=(M,))
+            x = np.ctypeslib.as_array(xp, shape=(N,))
+            self.calls += 1
+            fn(fx, x)
+
+        def _cplx(_ctx, fxp, xp):
+            fx = np.ctypeslib.as_array(C.cast(fxp, _f64p), shape=(2 * M,)).view(np.complex128)
+            x = np.ctypeslib.as_array(C.cast(xp, _f64p), shape=(2 * N,)).view(np.complex128)
+            self.calls += 1
+            fn(fx, x)
+
+        self._keep = (F_REAL(_real), F_CPLX(_cplx))
+        self.f = C.cast(self._keep[0], C.c_void_p)
+        self.fc = C.cast(self._keep[1], C.c_void_p)
+        self.ctxp = None
+
+
+def findstructralnz_dense(A):
+    A = np.asfortranarray(A, dtype=np.float64)
+    m, n = A.shape
+    cnt = int(np.count_nonzero(A))
+    rows = np.empty(cnt, np.int64)
+    cols = np.empty(cnt, np.int64)
+    got = lib().fdo_findstructralnz_dense(_pf(A), m, n, _p64(rows), _p64(cols))
+    assert got == cnt
+    return rows, cols
+
+
+def tridiag_csc(n):
+    colptr = np.empty(n + 1, np.int64)
+    rowval = np.empty(3 * n - 2 if n > 1 else 1, np.int64)
+    lib().fdo_build_tridiag_csc(n, _p64(colptr), _p64(rowval))
+    return colptr, rowval
+
+
+def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowval=None,
+             rows_index=None, cols_index=None, l=0, u=0, blk_sizes=None, bl=0, bu=0,
+             block_starts=None, block_strides=None, out_len=None, f_in=None, relstep=None,
+             absstep=None, dir=1.0, cache=None, mutate_x=False):
+    """Run the cached in-place path.  Returns dict(out=..., fcalls=..., x_after=...).
+
+    out: nzval (CSC_COMMON) | dense col-major M x N (NONE / *_DENSEJ) | banded data (l+u+1, N)
+         | flat block data | (dl, d, du) for COO_TRIDIAG.
+    cache: optional dict of pre-poisoned arrays x1,x2,fx,fx1 (test/cache_reuse_tests.jl).
+    """
+    L = lib()
+    fd = FDTYPES[fdtype]
+    x = np.array(x, dtype=np.float64) if not mutate_x else x
+    N = x.size
+    M = N if M is None else M
+    colorvec = np.ascontiguousarray(colorvec, dtype=np.int64)
+    assert colorvec.size == N, "DimensionMismatch (src/jacobians.jl:516)"
+    relstep = default_relstep(fdtype) if relstep is None else relstep
+    absstep = relstep if absstep is None else absstep
+
+    pat = Pattern()
+    pat.kind, pat.M, pat.N = kind, M, N
+    keep = []
+
+    def i64(a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        keep.append(a)
+        return a
+
+    out1 = out2 = None
+    if kind in (PAT_CSC_COMMON, PAT_CSC_DENSEJ):
+        colptr, rowval = i64(colptr), i64(rowval)
+        pat.colptr, pat.rowval = _p64(colptr), _p64(rowval)
+        nnz = int(colptr[-1] - 1)
+        out0 = np.full(nnz if kind == PAT_CSC_COMMON else M * N, np.nan)
+    elif kind in (PAT_COO_DENSEJ, PAT_COO_TRIDIAG):
+        rows_index, cols_index = i64(rows_index), i64(cols_index)
+        pat.rows_index, pat.cols_index, pat.ncoo = _p64(rows_index), _p64(cols_index), rows_index.size
+        if kind == PAT_COO_DENSEJ:
+            out0 = np.full(M * N, np.nan)
+        else:
+            out0 = np.full(N, np.nan)
+            out1 = np.full(max(N - 1, 0), np.nan)
+            out2 = np.full(max(N - 1, 0), np.nan)
+    elif kind == PAT_BANDED:
+        pat.l, pat.u = l, u
+        out0 = np.full((l + u + 1) * N, np.nan)
+    elif kind == PAT_BLOCKBANDED:
+        blk_sizes, block_starts, block_strides = i64(blk_sizes), i64(block_starts), i64(block_strides)
+        pat.nblk, pat.blk_sizes, pat.bl, pat.bu = blk_sizes.size, _p64(blk_sizes), bl, bu
+        pat.block_starts, pat.block_strides = _p64(block_starts), _p64(block_strides)
+        out0 = np.full(out_len, np.nan)
+    else:
+        out0 = np.full(M * N, np.nan)
+    pat.out0, pat.out_len = _pf(out0), out0.size
+    if out1 is not None:
+        pat.out1, pat.out2 = _pf(out1), _pf(out2)
+
+    cache = cache or {}
+    x1 = np.array(cache.get("x1", np.zeros(N)), dtype=np.float64)
+    x2 = np.zeros(N)
+    fx = np.array(cache.get("fx", np.zeros(M)), dtype=np.float64)
+    fx1 = np.array(cache.get("fx1", np.zeros(M)), dtype=np.float64)
+    cx1 = np.zeros(N, np.complex128)
+    cfx = np.zeros(M, np.complex128)
+    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=np.float64)
+    fcalls = np.zeros(1, np.int64)
+
+    rc = L.fdo_jacobian_cached(fd, f.f, f.fc, f.ctxp, _pf(x), _pf(x1), _pf(x2), _pf(fx), _pf(fx1),
+                               cx1.ctypes.data_as(C.c_void_p), cfx.ctypes.data_as(C.c_void_p),
+                               _pf(fin), _p64(colorvec), relstep, absstep, float(dir),
+                               C.byref(pat), _p64(fcalls))
+    if rc != 0:
+        raise ValueError("fdtype_error")
+    if kind == PAT_COO_TRIDIAG:
+        out = (out1, out0, out2)
+    elif kind in (PAT_NONE, PAT_CSC_DENSEJ, PAT_COO_DENSEJ):
+        out = out0.reshape((M, N), order="F")
+    elif kind == PAT_BANDED:
+        out = out0.reshape((l + u + 1, N), order="F")
+    else:
+        out = out0
+    return {"out": out, "fcalls": int(fcalls[0]), "x_after": x, "x1": x1, "fx": fx, "fx1": fx1}
+
+
+def jacobian_oop_dense_forward(f, x, M=None, relstep=None, absstep=None, dir=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    N = x.size
+    M = N if M is None else M
+    relstep = default_relstep("forward") if relstep is None else relstep
+    absstep = relstep if absstep is None else absstep
+    J = np.empty(M * N)
+    lib().fdo_jacobian_oop_dense_forward(f.f, f.ctxp, _pf(x), M, N, relstep, absstep, float(dir), _pf(J))
+    return J.reshape((M, N), order="F")
