@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Jacobian columns/s of the coloured sparse-Jacobian path on MI355X.
+
+Workload (BASELINE.json `metric`, config "N=10^7 tridiagonal"): forward-difference Jacobian of the
+second-difference f! (test/coloring_tests.jl:5-13) at N = 10^7 states, SparseMatrixCSC pattern
+(3N-2 stored values), colorvec[i] = mod1(i,3), x ~ U(0,1) (numpy PCG64 seed 4).  A "step" is one
+complete `finite_difference_jacobian!`: step-size reduction, perturbation, 1 + 3 f! evaluations,
+fused difference + decompression into nzval; plan (pattern, colours) reused, x / nzval resident in
+HBM.  With --gpus P the SAME problem is split into P contiguous column ranges (strong scaling),
+one process per GPU, and the step ends with the RCCL all-gather that assembles nzval.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (schema in the task contract) with `roofline` (fused diff+decompress
+kernel, algorithmic bytes / HIP-event time on the launch stream) and `cpu_baseline` (the CPU
+restatement of the reference path, 1 core, same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+BYTES_PER_COL_DS = 89.0     # fused diff+scatter, tridiagonal CSC, f64/int32, C = 3
+BYTES_PER_COL_MIN = 71.0    # what this implementation must move at minimum (fx read once, 1-B colours per entry)
+BYTES_PER_COL_CALL = 210.0  # whole forward Jacobian with an opaque streaming f!
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10 ** 7, help="states (columns); default = BASELINE headline size")
+    ap.add_argument("--no-gather", action="store_true", help="leave nzval sharded (compute-only scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=0, help="columns for the CPU baseline sample (0 = same as --n)")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(n, reps):
+    """The oracle (pass-for-pass restatement of src/jacobians.jl:504-653 + ext/SparseArrays:38-47,
+    Int64 indices, one thread) timed on this host on the same workload."""
+    from oracle import oracle
+    x = np.random.default_rng(4).random(n)
+    colors = ((np.arange(n, dtype=np.int64) % 3) + 1)
+    colptr, rowval = oracle.tridiag_csc(n)
+    fx = oracle.Fixture("tridiag", n)
+    best = float("inf")
+    t_all = time.perf_counter()
+    for _ in range(max(reps, 1)):
+        t0 = time.perf_counter()
+        oracle.jacobian("forward", fx, x, colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+        best = min(best, time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 30:
+            break
+    # oracle.jacobian allocates its cache arrays per call (like the reference's cache-less wrapper):
+    # that is inside the timed region, as it is for FiniteDiff.finite_difference_jacobian!(J,f,x;colorvec).
+    return {"value": n / best, "unit": "Jacobian columns/s", "cores": 1, "kind": "port",
+            "sample": "N=%d tridiagonal forward, full Jacobian, best of %d, gcc -O3 single thread" % (n, reps),
+            "seconds_per_jacobian": best}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import finitediff_jl_amd as fd
+    from finitediff_jl_amd import patterns as P
+    from finitediff_jl_amd import sharded as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N = args.n
+    x_host = np.random.default_rng(4).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    cuts = S.partition_columns(colptr, world)
+    ranges = S.entry_ranges(colptr, cuts)
+    counts = [b - a for a, b in ranges]
+    c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
+
+    ctx = fd.Context(local_rank)
+    x = torch.as_tensor(x_host, device=dev)
+    pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    xw = S.x_window(cuts, rank, N, 1, 1, 1)
+    plan = fd.make_plan(pattern, pattern, colors, "forward", ctx=ctx, col_window=(c0, c1) if world > 1 else None,
+                        x_window=xw if world > 1 else None)
+    f = fd.BuiltinF("tridiag", N, ctx=ctx)
+    gather = world > 1 and not args.no_gather
+    bufs = S.AllGatherBuffers(counts, dev, torch.float64)
+    out = bufs.local_view(rank)[: counts[rank]] if world > 1 else bufs.buf
+    del rowval  # pattern now lives on the device
+    pattern.rowval = None
+
+    def step():
+        plan.jacobian(f, x, [out], sync=False)
+        if gather:
+            bufs.gather(rank, dist)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    plan.enable_timing(True)
+    # gather time measured on its own with HIP events on torch's current stream (= the plan's stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)] if gather else []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        plan.jacobian(f, x, [out], sync=False)
+        if gather:
+            ev[2 * k].record()
+            bufs.gather(rank, dist)
+            ev[2 * k + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = plan.timings()
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    ms_step = elapsed / args.steps * 1e3
+    ms_gather = (sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)) / args.steps) if gather else 0.0
+
+    # sanity on the result of the last step (linear fixture => exact stencil), not timed
+    full = bufs.compact() if gather or world == 1 else None
+    check = None
+    if full is not None:
+        v = full if world > 1 else out
+        sample = v[:: max(1, v.numel() // 1000003)].cpu().numpy()
+        check = float(np.max(np.minimum(np.abs(sample + 2.0), np.abs(sample - 1.0))))
+
+    if rank == 0:
+        n_local = c1 - c0
+        dec = tm["decompress"]
+        dec_ms = dec["ms_sum"] / max(dec["launches"], 1)
+        achieved = BYTES_PER_COL_DS * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        tot_ms = tm["total"]["ms_sum"] / max(tm["total"]["launches"], 1)
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                j = json.load(open(pmc_path))
+                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world:
+                    pmc = j.get("decompress_hbm_bytes_per_launch")
+            except Exception:
+                pmc = None
+        res = {
+            "metric": "Jacobian columns/s (forward-difference coloured sparse Jacobian, N=10^7 tridiagonal)",
+            "value": N / (ms_step * 1e-3),
+            "unit": "columns/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, "
+                                   "x~U(0,1) seed 4" % N,
+                       "parallelism": "columns x%d%s" % (world, "+allgather" if gather else ""),
+                       "f_mode": "built-in device f! behind fd_f_launch (batched: 1 + 3 points)",
+                       "gather_in_step": bool(gather)},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
+                "kernel": "k_decompress_list<u8,forward> (fused difference + CSC decompression)",
+                "avg_launch_ms": dec_ms, "launches_timed": dec["launches"],
+                "algorithmic_bytes_per_launch": BYTES_PER_COL_DS * n_local,
+                "min_traffic_bytes_per_launch": BYTES_PER_COL_MIN * n_local,
+                "achieved_on_min_traffic": BYTES_PER_COL_MIN * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0,
+            },
+            "stages_ms": {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in tm.items()},
+            "whole_call": {"gpu_ms": tot_ms, "algorithmic_bytes": BYTES_PER_COL_CALL * n_local,
+                           "gbps": BYTES_PER_COL_CALL * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0},
+            "ms_gather": ms_gather,
+            "value_compute_only": N / ((ms_step - ms_gather) * 1e-3) if ms_step > ms_gather else None,
+            "result_check_max_dev": check,
+        }
+        try:
+            res["stream_copy_gbps"] = ctx.stream_copy_gbps(1 << 30, 10)
+        except Exception as e:  # pragma: no cover
+            res["stream_copy_gbps"] = None
+            res["stream_copy_error"] = str(e)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.cpu_n or N, args.cpu_reps)
+            except Exception as e:  # pragma: no cover
+                res["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

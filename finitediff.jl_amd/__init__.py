@@ -7,5 +7,10 @@ are hand-written HIP for gfx950.  There is no CPU fallback: every compute entry 
 raises if the HIP library or a GPU is missing.
 """
 from . import patterns  # noqa: F401  (numpy-only helpers; safe without a GPU)
+from . import lib  # noqa: F401  (ctypes binding; loads libfdjac.so on first use)
+from .api import (BandedMatrix, BlockBandedMatrix, BuiltinF, Context, JacobianCache, Plan,  # noqa: F401
+                  SparseMatrixCSC, TorchF, Tridiagonal, default_relstep, finite_difference_jacobian_b,
+                  make_plan)
 
-__all__ = ["patterns"]
+__all__ = ["patterns", "lib", "BandedMatrix", "BlockBandedMatrix", "BuiltinF", "Context", "JacobianCache", "Plan",
+           "SparseMatrixCSC", "TorchF", "Tridiagonal", "default_relstep", "finite_difference_jacobian_b", "make_plan"]

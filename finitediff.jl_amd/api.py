@@ -1,0 +1,528 @@
+"""Host-side mirror of the reference interface for the coloured-Jacobian path.
+
+Julia is not available in the build image, so the host layer that a Julia shim would provide
+(``finitediff.jl_amd/julia/FiniteDiffMI355X.jl``) is mirrored here in Python with the reference's
+names and argument meaning:
+
+* ``JacobianCache``                   -- src/jacobians.jl:1-128
+* ``finite_difference_jacobian_b``    -- ``finite_difference_jacobian!`` (PyJulia spelling of ``!``),
+                                         cache-less src/jacobians.jl:446-471 and cached :504-653
+* ``SparseMatrixCSC / Tridiagonal / BandedMatrix / BlockBandedMatrix`` -- thin storage holders with
+  Julia's field names and 1-based Int64 index arrays; dispatch on (J, sparsity) follows the
+  reference's ``_colorediteration!`` overloads (ext/*.jl).
+
+All arithmetic happens in libfdjac's HIP kernels; arrays are torch CUDA tensors (device
+pointers are handed over as-is) or numpy arrays (staged through the C ABI's host path).
+"""
+import ctypes as C
+import threading
+import weakref
+
+import numpy as np
+
+from . import lib as _l
+
+_EPS = float(np.finfo(np.float64).eps)
+
+
+def default_relstep(fdtype, T=np.float64):
+    """src/epsilons.jl:133-144"""
+    fdtype = _norm_fdtype(fdtype)
+    if fdtype == "forward":
+        return float(np.sqrt(_EPS))
+    if fdtype == "central":
+        return float(np.cbrt(_EPS))
+    return 1.0
+
+
+def _norm_fdtype(fdtype):
+    """Accepts "forward" / ":forward" / "Val{:forward}" / "Val(:forward)"."""
+    s = str(fdtype).replace("Val", "").strip("{}():, ").lower()
+    if s not in _l.FDTYPES:
+        # fdtype_error, src/epsilons.jl:159-167
+        raise ValueError("Unrecognized fdtype: valid values are Val{:forward}, Val{:central} and Val{:complex}.")
+    return s
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a, what):
+    """(pointer, FD_HOST|FD_DEVICE, keepalive) of a float64 vector-like."""
+    if _is_torch(a):
+        import torch
+        if a.dtype != torch.float64:
+            raise TypeError("%s must be float64" % what)
+        if a.is_cuda:
+            if not _colmajor_contig(a):
+                raise ValueError("%s must be contiguous (column-major for matrices)" % what)
+            return a.data_ptr(), _l.DEVICE, a
+        a = a.numpy()
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64:
+        raise TypeError("%s must be a float64 numpy array or torch tensor" % what)
+    if not (a.flags.f_contiguous or a.ndim <= 1 and a.flags.c_contiguous):
+        raise ValueError("%s must be contiguous (column-major for matrices)" % what)
+    return a.ctypes.data, _l.HOST, a
+
+
+def _colmajor_contig(t):
+    if t.dim() <= 1:
+        return t.is_contiguous()
+    return t.t().is_contiguous()
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# matrix holders (Julia field names)
+# ----------------------------------------------------------------------------------------------
+class SparseMatrixCSC:
+    """SparseArrays.SparseMatrixCSC{Float64,Int64}: m, n, colptr, rowval (1-based), nzval."""
+
+    def __init__(self, m, n, colptr, rowval, nzval=None):
+        self.m, self.n = int(m), int(n)
+        self.colptr, self.rowval = _i64(colptr), _i64(rowval)
+        self.nzval = nzval  # None for a pure pattern (a `sparsity` argument)
+
+    def size(self):
+        return self.m, self.n
+
+    def similar(self, like=None):
+        return SparseMatrixCSC(self.m, self.n, self.colptr, self.rowval, _similar(self.nzval if like is None else like,
+                                                                                   self.rowval.size))
+
+
+class Tridiagonal:
+    """LinearAlgebra.Tridiagonal: dl (n-1), d (n), du (n-1)."""
+
+    def __init__(self, dl, d, du):
+        self.dl, self.d, self.du = dl, d, du
+
+    def size(self):
+        n = int(self.d.shape[0])
+        return n, n
+
+
+class BandedMatrix:
+    """BandedMatrices.BandedMatrix: data is (l+u+1) x n column-major, data[u+i-j, j] = A[i,j] (0-based)."""
+
+    def __init__(self, data, m, l, u):
+        self.data, self.m, self.l, self.u = data, int(m), int(l), int(u)
+
+    def size(self):
+        return self.m, int(self.data.shape[1]) if hasattr(self.data, "shape") and len(self.data.shape) == 2 else None
+
+
+class BlockBandedMatrix:
+    """BlockBandedMatrices.BlockBandedMatrix: flat data + (blk_sizes, bl, bu, block_starts, block_strides)
+    as produced by ``patterns.BlockBandedLayout`` (the BlockSkylineSizes layout)."""
+
+    def __init__(self, data, layout):
+        self.data, self.layout = data, layout
+
+    def size(self):
+        return self.layout.N, self.layout.N
+
+
+def _similar(a, n):
+    if _is_torch(a):
+        import torch
+        return torch.zeros(n, dtype=torch.float64, device=a.device)
+    return np.zeros(n)
+
+
+# ----------------------------------------------------------------------------------------------
+# context / f launchers / plans
+# ----------------------------------------------------------------------------------------------
+class Context:
+    """fd_ctx: a device + the stream every launch is enqueued on (torch's current stream by default)."""
+
+    _default = {}
+    _lock = threading.Lock()
+
+    def __init__(self, device=0, stream="torch"):
+        L = _l.load()
+        self.L = L
+        h = C.c_void_p()
+        sp = None
+        if stream == "torch":
+            import torch
+            if not torch.cuda.is_available():
+                raise RuntimeError("libfdjac needs an MI355X (no HIP device visible); there is no CPU fallback")
+            with torch.cuda.device(device):
+                sp = torch.cuda.current_stream().cuda_stream
+        elif stream is not None:
+            sp = int(stream)
+        _l.check(L.fd_ctx_create(int(device), C.c_void_p(sp) if sp else None, C.byref(h)))
+        self.handle, self.device = h, int(device)
+        self._fin = weakref.finalize(self, L.fd_ctx_destroy, h)
+
+    @classmethod
+    def default(cls, device=0):
+        with cls._lock:
+            if device not in cls._default:
+                cls._default[device] = cls(device)
+            return cls._default[device]
+
+    @property
+    def stream(self):
+        return self.L.fd_ctx_stream(self.handle)
+
+    def synchronize(self):
+        _l.check(self.L.fd_ctx_synchronize(self.handle))
+
+    def stream_copy_gbps(self, nbytes=1 << 30, iters=10):
+        out = C.c_double()
+        _l.check(self.L.fd_stream_copy_gbps(self.handle, int(nbytes), int(iters), C.byref(out)))
+        return out.value
+
+
+class BuiltinF:
+    """One of libfdjac's device f! families (fd_builtin_f_create): the reference's fixtures."""
+
+    def __init__(self, family, *params, ctx=None):
+        self.ctx = ctx or Context.default()
+        L = self.ctx.L
+        prm = (C.c_int64 * max(len(params), 1))(*[int(p) for p in params])
+        self.fn = _l.F_LAUNCH()
+        self.fctx = C.c_void_p()
+        _l.check(L.fd_builtin_f_create(self.ctx.handle, _l.FAMILIES[family], prm, len(params), C.byref(self.fn),
+                                       C.byref(self.fctx)))
+        self.family, self.params = family, params
+        self._fin = weakref.finalize(self, L.fd_builtin_f_destroy, self.fctx)
+
+    def counts(self):
+        a, b = C.c_int64(), C.c_int64()
+        _l.check(self.ctx.L.fd_builtin_f_counts(self.fctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def fcalls(self):
+        return self.counts()[1]
+
+
+class _DevView:
+    """__cuda_array_interface__ holder so torch can view library-owned device memory."""
+
+    def __init__(self, ptr, n, complex_):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<c16" if complex_ else "<f8",
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class TorchF:
+    """A user f!(fx, x) written with torch ops on CUDA tensors, as an fd_f_launch callback.
+
+    The callable receives 1-D views of library-owned device memory (complex128 in the
+    complex-step arm) and must write fx in place, exactly like a Julia ``f!(fx, x)`` operating on
+    ROCArrays.  Work is enqueued on the context's stream; nothing synchronises.
+    """
+
+    def __init__(self, fn, M, N, ctx=None):
+        import torch
+        self.ctx = ctx or Context.default()
+        self.fn_py, self.M, self.N = fn, int(M), int(N)
+        self.fcalls = 0
+        self.error = None
+        ext = torch.cuda.ExternalStream(self.ctx.stream, device=self.ctx.device) if self.ctx.stream else None
+
+        def _launch(_fctx, fx, x, nbatch, xs, fs, r0, r1, is_complex, stream):
+            try:
+                sz = 16 if is_complex else 8
+                cm = torch.cuda.stream(ext) if ext is not None else _nullctx()
+                with cm:
+                    for b in range(nbatch):
+                        xv = torch.as_tensor(_DevView(x + b * xs * sz, self.N, is_complex), device="cuda")
+                        fv = torch.as_tensor(_DevView(fx + b * fs * sz, self.M, is_complex), device="cuda")
+                        self.fcalls += 1
+                        fn(fv, xv)
+                return 0
+            except BaseException as e:  # never let an exception cross the C ABI
+                self.error = e
+                return 1
+
+        self.fn = _l.F_LAUNCH(_launch)
+        self.fctx = C.c_void_p()
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class Plan:
+    """fd_plan handle."""
+
+    def __init__(self, ctx, handle, fdtype):
+        self.ctx, self.handle, self.fdtype = ctx, handle, fdtype
+        self._fin = weakref.finalize(self, ctx.L.fd_plan_destroy, handle)
+
+    def info(self, key):
+        v = C.c_int64()
+        _l.check(self.ctx.L.fd_plan_info(self.handle, key, C.byref(v)))
+        return v.value
+
+    @property
+    def ncolors(self):
+        return self.info(_l.INFO_NCOLORS)
+
+    @property
+    def nouts(self):
+        return self.info(_l.INFO_NOUTS)
+
+    def out_len(self, k=0):
+        return self.info(_l.INFO_OUT0_LEN + k)
+
+    @property
+    def row_window(self):
+        return self.info(_l.INFO_ROW_BEGIN), self.info(_l.INFO_ROW_END)
+
+    @property
+    def fcalls_last(self):
+        return self.info(_l.INFO_FCALLS_LAST)
+
+    def epsilons(self):
+        n = self.ncolors
+        buf = (C.c_double * max(n, 1))()
+        _l.check(self.ctx.L.fd_plan_get_epsilons(self.handle, buf))
+        return np.array(buf[:n])
+
+    def enable_timing(self, on=True):
+        _l.check(self.ctx.L.fd_plan_enable_timing(self.handle, 1 if on else 0))
+
+    def timings(self):
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        _l.check(self.ctx.L.fd_plan_get_timings(self.handle, ms, cnt))
+        return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
+
+    def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
+        """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""
+        L = self.ctx.L
+        xp, xk, _k1 = _ptr(x, "x")
+        ptrs, kinds, keep = [], set(), []
+        for o in outs:
+            p, k, ka = _ptr(o, "output")
+            ptrs.append(p)
+            kinds.add(k)
+            keep.append(ka)
+        if len(kinds) != 1:
+            raise ValueError("outputs must all be host or all be device arrays")
+        ok = kinds.pop()
+        arr = (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
+        fp, fk = None, _l.DEVICE
+        if f_in is not None:
+            fp, fk, _k2 = _ptr(f_in, "f_in")
+        rel = -1.0 if relstep is None else float(relstep)
+        ab = -1.0 if absstep is None else float(absstep)
+        if not sync:
+            if xk != _l.DEVICE or ok != _l.DEVICE or (f_in is not None and fk != _l.DEVICE):
+                raise ValueError("the async path needs device arrays")
+            rc = L.fd_jacobian_async(self.handle, f.fn, f.fctx, xp, fp, rel, ab, float(dir), arr)
+        else:
+            rc = L.fd_jacobian(self.handle, f.fn, f.fctx, xp, xk, fp, fk, rel, ab, float(dir), arr, ok)
+        err = getattr(f, "error", None)
+        if err is not None:
+            f.error = None
+            raise err
+        _l.check(rc)
+
+
+def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0):
+    o = _l.PlanOpts()
+    o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
+    if col_window is not None:
+        o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
+    if x_window is not None:
+        o.x_begin, o.x_end = int(x_window[0]), int(x_window[1])
+    o.scratch_bytes = int(scratch_bytes)
+    return o
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0):
+    """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
+    per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
+    (src/jacobians.jl:524-535; ext/*.jl)."""
+    ctx = ctx or Context.default()
+    L = ctx.L
+    fdtype = _norm_fdtype(fdtype)
+    o = _opts(fdtype, col_window, x_window, scratch_bytes)
+    h = C.c_void_p()
+    cv = _i64(colorvec)
+    if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):
+        m, n = J.size()
+        if cv.size != n:
+            raise ValueError("DimensionMismatch: length(colorvec) != length(x)")  # src/jacobians.jl:516
+        common = (J is sparsity) or (np.array_equal(J.colptr, sparsity.colptr) and np.array_equal(J.rowval, sparsity.rowval))
+        if common:  # ext/FiniteDiffSparseArraysExt.jl:51-52
+            _l.check(L.fd_plan_create_csc(ctx.handle, m, n, _vp(J.colptr), _vp(J.rowval), 8, 1, _vp(cv), 8,
+                                          C.byref(o), C.byref(h)))
+        else:  # J[row,col] = v into J's own pattern (ext/FiniteDiffSparseArraysExt.jl:20-28)
+            from .patterns import csc_cols
+            cols = csc_cols(sparsity.colptr)
+            dest = _csc_positions(J, sparsity.rowval, cols)
+            _l.check(L.fd_plan_create_entries(ctx.handle, m, n, _vp(sparsity.rowval), _vp(cols), _vp(dest), dest.size,
+                                              J.rowval.size, 8, 1, _vp(cv), 8, C.byref(o), C.byref(h)))
+    elif isinstance(J, Tridiagonal):
+        n = J.size()[0]
+        if cv.size != n:
+            raise ValueError("DimensionMismatch: length(colorvec) != length(x)")
+        _l.check(L.fd_plan_create_tridiagonal(ctx.handle, n, _vp(cv), 8, C.byref(o), C.byref(h)))
+    elif isinstance(J, BandedMatrix):
+        n = cv.size
+        _l.check(L.fd_plan_create_banded(ctx.handle, J.m, n, J.l, J.u, _vp(cv), 8, C.byref(o), C.byref(h)))
+    elif isinstance(J, BlockBandedMatrix):
+        lay = J.layout
+        bs, st, sr = _i64(lay.blk_sizes), _i64(lay.block_starts), _i64(lay.block_strides)
+        _l.check(L.fd_plan_create_blockbanded(ctx.handle, lay.nblk, _vp(bs), lay.bl, lay.bu, _vp(st), _vp(sr), 8, 1,
+                                              _vp(cv), 8, C.byref(o), C.byref(h)))
+    else:  # dense J
+        m, n = J.shape
+        if cv.size != n:
+            raise ValueError("DimensionMismatch: length(colorvec) != length(x)")
+        if isinstance(sparsity, SparseMatrixCSC):
+            _l.check(L.fd_plan_create_csc_dense(ctx.handle, m, n, _vp(sparsity.colptr), _vp(sparsity.rowval), 8, 1,
+                                                _vp(cv), 8, C.byref(o), C.byref(h)))
+        elif sparsity is not None:  # dense matrix pattern: _findstructralnz, src/jacobians.jl:473-488
+            rows, cols = _findstructralnz(np.asarray(sparsity))
+            _l.check(L.fd_plan_create_coo_dense(ctx.handle, m, n, _vp(rows), _vp(cols), rows.size, 8, 1, _vp(cv), 8,
+                                                C.byref(o), C.byref(h)))
+        else:
+            raise NotImplementedError("sparsity === nothing (uncoloured dense arm, src/jacobians.jl:548-557) is "
+                                      "outside the accelerated path")
+    return Plan(ctx, h, fdtype)
+
+
+def _findstructralnz(A):
+    """src/jacobians.jl:473-488: (I, J) of A != 0 in column-major order, 1-based."""
+    cols, rows = np.nonzero(np.asarray(A).T)
+    return _i64(rows + 1), _i64(cols + 1)
+
+
+def _csc_positions(J, rows, cols):
+    """0-based positions in J.nzval of entries (rows, cols) (1-based); KeyError-like if absent."""
+    dest = np.empty(rows.size, np.int64)
+    for k in range(rows.size):
+        a, b = J.colptr[cols[k] - 1] - 1, J.colptr[cols[k]] - 1
+        q = a + np.searchsorted(J.rowval[a:b], rows[k])
+        if q >= b or J.rowval[q] != rows[k]:
+            raise IndexError("J has no stored entry (%d,%d)" % (rows[k], cols[k]))
+        dest[k] = q
+    return dest
+
+
+def _outs_of(J):
+    if isinstance(J, SparseMatrixCSC):
+        return [J.nzval]
+    if isinstance(J, Tridiagonal):
+        return [J.dl, J.d, J.du]
+    if isinstance(J, (BandedMatrix, BlockBandedMatrix)):
+        return [J.data]
+    return [J]
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference-facing API
+# ----------------------------------------------------------------------------------------------
+class JacobianCache:
+    """FiniteDiff.JacobianCache (src/jacobians.jl:1-128).
+
+    JacobianCache(x, fdtype="forward", returntype=float; colorvec=1:length(x), sparsity=None)
+    JacobianCache(x, fx, fdtype, ...)            allocating, non-square
+    JacobianCache(x1, fx, fx1, fdtype, ...)      non-allocating
+
+    The device implementation keeps its perturbed points / values in the plan's scratch, so x1,
+    fx, fx1 are carried only for interface fidelity (their contents never influence a result --
+    the property test/cache_reuse_tests.jl pins).
+    """
+
+    def __init__(self, x1, fx=None, fx1=None, fdtype="forward", returntype=np.float64, *, colorvec=None,
+                 sparsity=None):
+        if isinstance(fx, str):  # JacobianCache(x, fdtype, ...)
+            fdtype, fx = fx, None
+        if isinstance(fx1, str):  # JacobianCache(x, fx, fdtype, ...)
+            fdtype, fx1 = fx1, None
+        self.fdtype = _norm_fdtype(fdtype)
+        self.returntype = returntype
+        if self.fdtype == "complex" and np.dtype(returntype).kind == "c":
+            # fdtype_error(returntype), src/jacobians.jl:106
+            raise ValueError("Unrecognized fdtype: valid values are Val{:forward} or Val{:central}.")
+        self.x1 = x1
+        self.x2 = None
+        self.fx = fx if fx is not None else x1
+        self.fx1 = None if self.fdtype == "complex" else (fx1 if fx1 is not None else self.fx)
+        n = int(np.prod(x1.shape))
+        self.colorvec = np.arange(1, n + 1, dtype=np.int64) if colorvec is None else colorvec
+        self.sparsity = sparsity
+        self._plans = {}
+
+    def _plan_for(self, J, sparsity, colorvec, ctx):
+        key = (type(J).__name__, id(sparsity), id(colorvec), self.fdtype, tuple(getattr(J, "shape", ())))
+        ent = self._plans.get(key)
+        if ent is None or ent[1] is not sparsity or ent[2] is not colorvec:
+            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx), sparsity, colorvec)
+            self._plans[key] = ent
+        return ent[0]
+
+
+def _has_sparsestruct(J):
+    """ArrayInterface.has_sparsestruct for the holders above."""
+    return isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix))
+
+
+def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=np.float64, f_in=None, *,
+                                 relstep=None, absstep=None, colorvec=None, sparsity="default", dir=True,
+                                 ctx=None):
+    """``FiniteDiff.finite_difference_jacobian!`` for the coloured path.
+
+    Cache-less form (src/jacobians.jl:446-471):
+        finite_difference_jacobian_b(J, f, x, fdtype="forward", returntype, f_in; relstep, absstep,
+                                     colorvec=1:length(x), sparsity=has_sparsestruct(J) ? J : nothing)
+    Cached form (src/jacobians.jl:504-514):
+        finite_difference_jacobian_b(J, f, x, cache, f_in; relstep, absstep, colorvec=cache.colorvec,
+                                     sparsity=cache.sparsity, dir=True)
+    f is a ``BuiltinF`` or ``TorchF`` launcher.  Returns None; fills J's own storage.
+    """
+    if isinstance(cache_or_fdtype, JacobianCache):
+        cache = cache_or_fdtype
+        if sparsity == "default":
+            sparsity = cache.sparsity
+        if colorvec is None:
+            colorvec = cache.colorvec
+    else:
+        fdtype = _norm_fdtype(cache_or_fdtype)
+        n = int(np.prod(x.shape))
+        if colorvec is None:
+            colorvec = np.arange(1, n + 1, dtype=np.int64)
+        if sparsity == "default":
+            sparsity = J if _has_sparsestruct(J) else None
+        cache = JacobianCache(x, fdtype, returntype, colorvec=colorvec, sparsity=sparsity)
+    if sparsity is None and _has_sparsestruct(J):
+        sparsity = J
+    if relstep is None:
+        relstep = default_relstep(cache.fdtype)
+    if absstep is None:
+        absstep = relstep
+    plan = cache._plan_for(J, sparsity, colorvec, ctx or getattr(f, "ctx", None))
+    outs = _outs_of(J)
+    staged = None
+    if not isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix)):
+        # dense J must be column-major for the library; stage a C-order numpy array
+        if isinstance(J, np.ndarray) and not J.flags.f_contiguous:
+            staged = np.zeros(J.shape, order="F")
+            outs = [staged]
+    plan.jacobian(f, x, outs, f_in=f_in if cache.fdtype == "forward" else None, relstep=relstep, absstep=absstep,
+                  dir=dir)
+    if staged is not None:
+        J[...] = staged
+    cache.last_plan = plan
+    return None

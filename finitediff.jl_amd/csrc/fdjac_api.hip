@@ -1,0 +1,831 @@
+// libfdjac C ABI (include/fdjac.h): contexts, plan construction, and the orchestration of one
+// coloured Jacobian evaluation -- the device-side body of the reference's cached in-place
+// finite_difference_jacobian! (src/jacobians.jl:504-653).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "fdjac_internal.h"
+
+namespace fdjac {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir);
+int launch_perturb(fd_plan *p, const double *x, int c_lo, int B);
+int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs);
+int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v);
+int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16);
+
+static inline int64_t load_idx(const void *p, int bytes, int64_t i)
+{
+    return bytes == 8 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i];
+}
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+template <typename T> static int dev_upload(T **dst, const std::vector<T> &src)
+{
+    *dst = nullptr;
+    if (src.empty()) return FD_OK;
+    FD_HIP_CHECK(hipMalloc((void **)dst, sizeof(T) * src.size()));
+    FD_HIP_CHECK(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return FD_OK;
+}
+
+static int dev_alloc(double **dst, int64_t nelem)
+{
+    *dst = nullptr;
+    if (nelem <= 0) nelem = 1;
+    hipError_t e = hipMalloc((void **)dst, sizeof(double) * (size_t)nelem);
+    if (e == hipErrorOutOfMemory) {
+        set_error("hipMalloc of %lld bytes failed: out of memory", (long long)(nelem * 8));
+        return FD_ERR_NOMEM;
+    }
+    FD_HIP_CHECK(e);
+    return FD_OK;
+}
+
+// Colours: validate, find C = maximum(colorvec), convert to 0-based with "none" for < 1.
+static int ingest_colors(fd_plan *p, const void *colorvec, int color_bytes, std::vector<int32_t> &col0)
+{
+    FD_REQUIRE(colorvec != nullptr, FD_ERR_ARG, "colorvec is NULL");
+    FD_REQUIRE(color_bytes == 4 || color_bytes == 8, FD_ERR_ARG, "color_bytes must be 4 or 8");
+    const int64_t N = p->N;
+    col0.resize((size_t)N);
+    int64_t C = 0;
+    for (int64_t j = 0; j < N; ++j) {
+        const int64_t c = load_idx(colorvec, color_bytes, j);
+        if (c > C) C = c;
+        FD_REQUIRE(c <= std::numeric_limits<int32_t>::max(), FD_ERR_ARG, "colour %lld too large", (long long)c);
+        col0[(size_t)j] = c >= 1 ? (int32_t)(c - 1) : -1;
+    }
+    p->C = C;
+    p->color8 = C <= 254;
+    return FD_OK;
+}
+
+static int upload_colors(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &nzc)
+{
+    if (p->color8) {
+        std::vector<uint8_t> a(col0.size()), b(nzc.size());
+        for (size_t i = 0; i < col0.size(); ++i) a[i] = col0[i] < 0 ? 0xFF : (uint8_t)col0[i];
+        for (size_t i = 0; i < nzc.size(); ++i) b[i] = nzc[i] < 0 ? 0xFF : (uint8_t)nzc[i];
+        uint8_t *d = nullptr;
+        int rc = dev_upload(&d, a);
+        if (rc) return rc;
+        p->d_color = d;
+        rc = dev_upload(&d, b);
+        if (rc) return rc;
+        p->d_nzcolor = d;
+    } else {
+        int32_t *d = nullptr;
+        int rc = dev_upload(&d, col0);
+        if (rc) return rc;
+        p->d_color = d;
+        rc = dev_upload(&d, nzc);
+        if (rc) return rc;
+        p->d_nzcolor = d;
+    }
+    return FD_OK;
+}
+
+static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
+{
+    FD_REQUIRE(opts != nullptr, FD_ERR_ARG, "opts is NULL");
+    FD_REQUIRE(opts->fdtype == FD_FORWARD || opts->fdtype == FD_CENTRAL || opts->fdtype == FD_COMPLEX,
+               FD_ERR_UNSUPPORTED,
+               "Unrecognized fdtype: valid values are Val{:forward}, Val{:central} and Val{:complex}.");
+    p->fdtype = opts->fdtype;
+    p->col0 = 0;
+    p->col1 = p->N;
+    if (!(opts->col_begin == 0 && opts->col_end == 0)) {
+        FD_REQUIRE(opts->col_begin >= 0 && opts->col_begin <= opts->col_end && opts->col_end <= p->N, FD_ERR_ARG,
+                   "column window [%lld,%lld) outside [0,%lld)", (long long)opts->col_begin,
+                   (long long)opts->col_end, (long long)p->N);
+        p->col0 = opts->col_begin;
+        p->col1 = opts->col_end;
+    }
+    p->x0 = 0;
+    p->x1 = p->N;
+    if (!(opts->x_begin == 0 && opts->x_end == 0)) {
+        FD_REQUIRE(opts->x_begin >= 0 && opts->x_begin <= opts->x_end && opts->x_end <= p->N, FD_ERR_ARG,
+                   "x window [%lld,%lld) outside [0,%lld)", (long long)opts->x_begin, (long long)opts->x_end,
+                   (long long)p->N);
+        p->x0 = opts->x_begin;
+        p->x1 = opts->x_end;
+    }
+    p->scratch_bytes = opts->scratch_bytes > 0 ? opts->scratch_bytes : ((int64_t)64 << 30);
+    return FD_OK;
+}
+
+// Scratch for the batched perturbed points / f! values and the epsilon reduction.
+static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
+{
+    p->cplx = p->fdtype == FD_COMPLEX ? 2 : 1;
+    p->pts = p->fdtype == FD_CENTRAL ? 2 : 1;
+    p->ldx = round_up(p->N, 32);
+    p->ldf = round_up(p->M, 32);
+    const int64_t per_color = (int64_t)p->pts * p->cplx * 8 * (p->ldx + p->ldf);
+    int64_t B = p->C > 0 ? p->scratch_bytes / std::max<int64_t>(per_color, 1) : 1;
+    B = std::max<int64_t>(1, std::min<int64_t>(B, std::max<int64_t>(p->C, 1)));
+    B = std::min<int64_t>(B, 32768);  // keeps the f! batch within one grid dimension
+    p->chunkB = B;
+    p->nchunks = p->C > 0 ? (p->C + B - 1) / B : 0;
+    int rc;
+    if ((rc = dev_alloc(&p->d_X, B * p->pts * p->cplx * p->ldx))) return rc;
+    if ((rc = dev_alloc(&p->d_FX, B * p->pts * p->cplx * p->ldf))) return rc;
+    if ((rc = dev_alloc(&p->d_fx, p->ldf))) return rc;
+    if ((rc = dev_alloc(&p->d_eps, std::max<int64_t>(p->C, 1)))) return rc;
+    if ((rc = dev_alloc(&p->d_xstage, p->ldx))) return rc;
+    if ((rc = dev_alloc(&p->d_finstage, p->ldf))) return rc;
+
+    if (p->fdtype == FD_COMPLEX) {
+        // eps(Float64) for every colour (src/epsilons.jl:104-107, src/jacobians.jl:624)
+        FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+        int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), 2.220446049250313e-16);
+        if (r2) return r2;
+    } else if (p->C > 0) {
+        if (p->C <= kRegColors) {
+            p->n_partial_blocks = (int)std::min<int64_t>((p->N / 2 + kBlock - 1) / kBlock + 1, (int64_t)p->ctx->num_cus * 8);
+            if ((rc = dev_alloc(&p->d_partial, (int64_t)p->n_partial_blocks * kRegColors))) return rc;
+        } else {
+            // counting sort of the columns by colour
+            std::vector<int64_t> cptr((size_t)p->C + 1, 0);
+            for (int64_t j = 0; j < p->N; ++j)
+                if (col0[(size_t)j] >= 0) cptr[(size_t)col0[(size_t)j] + 1]++;
+            for (int64_t c = 0; c < p->C; ++c) cptr[(size_t)c + 1] += cptr[(size_t)c];
+            std::vector<int32_t> perm((size_t)cptr[(size_t)p->C]);
+            std::vector<int64_t> fillp(cptr.begin(), cptr.end() - 1);
+            for (int64_t j = 0; j < p->N; ++j)
+                if (col0[(size_t)j] >= 0) perm[(size_t)fillp[(size_t)col0[(size_t)j]]++] = (int32_t)j;
+            if ((rc = dev_upload(&p->d_perm, perm))) return rc;
+            if ((rc = dev_upload(&p->d_cptr, cptr))) return rc;
+            int64_t chunks = (p->N / std::max<int64_t>(p->C, 1) + 4095) / 4096;
+            p->seg_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, 256));
+            FD_REQUIRE((int64_t)p->C * p->seg_chunks < ((int64_t)1 << 31), FD_ERR_UNSUPPORTED, "too many colours");
+            if ((rc = dev_alloc(&p->d_partial, (int64_t)p->seg_chunks * p->C))) return rc;
+        }
+    }
+    return FD_OK;
+}
+
+static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
+{
+    FD_REQUIRE(ctx != nullptr && out != nullptr, FD_ERR_ARG, "ctx/out is NULL");
+    FD_REQUIRE(M >= 0 && N >= 1, FD_ERR_SHAPE, "bad shape %lld x %lld", (long long)M, (long long)N);
+    FD_REQUIRE(M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), FD_ERR_UNSUPPORTED,
+               "dimensions >= 2^31 are not supported");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    fd_plan *p = new (std::nothrow) fd_plan();
+    FD_REQUIRE(p != nullptr, FD_ERR_NOMEM, "out of host memory");
+    p->ctx = ctx;
+    p->kind = kind;
+    p->M = M;
+    p->N = N;
+    *out = p;
+    return FD_OK;
+}
+
+#define FD_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != FD_OK) {          \
+            fd_plan_destroy(p);      \
+            *out = nullptr;          \
+            return _rc;              \
+        }                            \
+    } while (0)
+
+// Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
+static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows,
+                            const std::vector<int32_t> &nzc, const std::vector<int64_t> &dest)
+{
+    int rc;
+    p->nnz_local = (int64_t)rows.size();
+    if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
+    if ((rc = upload_colors(p, col0, nzc))) return rc;
+    if (!dest.empty() && (rc = dev_upload(&p->d_dest, dest))) return rc;
+    int64_t r0 = p->M, r1 = 0;
+    for (int32_t r : rows) {
+        if (r < r0) r0 = r;
+        if (r + 1 > r1) r1 = (int64_t)r + 1;
+    }
+    if (rows.empty()) r0 = r1 = 0;
+    p->row0 = r0;
+    p->row1 = r1;
+    return alloc_scratch(p, col0);
+}
+
+}  // namespace fdjac
+
+using namespace fdjac;
+
+extern "C" {
+
+int fd_version(void) { return FDJAC_VERSION; }
+const char *fd_last_error(void) { return g_err; }
+
+int fd_ctx_create(int device, void *stream, fd_ctx **out)
+{
+    FD_REQUIRE(out != nullptr, FD_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return FD_ERR_NODEVICE;
+    }
+    FD_REQUIRE(device >= 0 && device < ndev, FD_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+    FD_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FD_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    fd_ctx *c = new (std::nothrow) fd_ctx();
+    FD_REQUIRE(c != nullptr, FD_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+            return FD_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return FD_OK;
+}
+
+int fd_ctx_destroy(fd_ctx *ctx)
+{
+    if (!ctx) return FD_OK;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FD_OK;
+}
+
+void *fd_ctx_stream(fd_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int fd_ctx_synchronize(fd_ctx *ctx)
+{
+    FD_REQUIRE(ctx != nullptr, FD_ERR_ARG, "ctx is NULL");
+    FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return FD_OK;
+}
+
+int fd_plan_destroy(fd_plan *p)
+{
+    if (!p) return FD_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+                    p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    for (auto &sp : p->spans) {
+        p->event_pool.push_back(sp.a);
+        p->event_pool.push_back(sp.b);
+    }
+    for (hipEvent_t ev : p->event_pool) (void)hipEventDestroy(ev);
+    delete p;
+    return FD_OK;
+}
+
+static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *colptr, const void *rowval,
+                      int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                      const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(colptr && rowval, FD_ERR_ARG, "colptr/rowval is NULL");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(idx_base == 0 || idx_base == 1, FD_ERR_ARG, "idx_base must be 0 or 1");
+    int rc = new_plan(ctx, kind, M, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    const int64_t e0 = load_idx(colptr, idx_bytes, p->col0) - idx_base;
+    const int64_t e1 = load_idx(colptr, idx_bytes, p->col1) - idx_base;
+    if (!(e0 >= 0 && e1 >= e0)) {
+        set_error("colptr is not monotone");
+        fd_plan_destroy(p);
+        *out = nullptr;
+        return FD_ERR_SHAPE;
+    }
+    p->entry_begin = e0;
+    std::vector<int32_t> rows((size_t)(e1 - e0)), nzc((size_t)(e1 - e0));
+    std::vector<int64_t> dest;
+    if (kind == K_CSC_DENSE) dest.resize((size_t)(e1 - e0));
+    for (int64_t j = p->col0; j < p->col1; ++j) {
+        const int64_t a = load_idx(colptr, idx_bytes, j) - idx_base, b = load_idx(colptr, idx_bytes, j + 1) - idx_base;
+        if (!(a <= b && a >= e0 && b <= e1)) {
+            set_error("colptr is not monotone at column %lld", (long long)j);
+            fd_plan_destroy(p);
+            *out = nullptr;
+            return FD_ERR_SHAPE;
+        }
+        for (int64_t q = a; q < b; ++q) {
+            const int64_t r = load_idx(rowval, idx_bytes, q) - idx_base;
+            if (r < 0 || r >= M) {
+                set_error("rowval[%lld] = %lld outside 1..%lld", (long long)q, (long long)(r + idx_base), (long long)M);
+                fd_plan_destroy(p);
+                *out = nullptr;
+                return FD_ERR_SHAPE;
+            }
+            rows[(size_t)(q - e0)] = (int32_t)r;
+            nzc[(size_t)(q - e0)] = col0[(size_t)j];
+            if (kind == K_CSC_DENSE) dest[(size_t)(q - e0)] = r + M * j;
+        }
+    }
+    FD_TRY(finish_list_plan(p, col0, rows, nzc, dest));
+    p->nouts = 1;
+    p->out_len[0] = kind == K_CSC ? (e1 - e0) : M * N;
+    return FD_OK;
+}
+
+int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes,
+                       int idx_base, const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                       fd_plan **out)
+{
+    return csc_common(ctx, K_CSC, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+}
+
+int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
+                             int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                             const fd_plan_opts *opts, fd_plan **out)
+{
+    if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
+        set_error("column windows are not supported for dense J");
+        return FD_ERR_UNSUPPORTED;
+    }
+    return csc_common(ctx, K_CSC_DENSE, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+}
+
+static int entries_common(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index,
+                          const int64_t *dest_in, int64_t nnz, int64_t out_len, int idx_bytes, int idx_base,
+                          const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE((rows_index && cols_index) || nnz == 0, FD_ERR_ARG, "rows_index/cols_index is NULL");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(idx_base == 0 || idx_base == 1, FD_ERR_ARG, "idx_base must be 0 or 1");
+    FD_REQUIRE(nnz >= 0 && out_len >= 0, FD_ERR_ARG, "nnz/out_len < 0");
+    if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
+        set_error("column windows are not supported for entry-list plans");
+        return FD_ERR_UNSUPPORTED;
+    }
+    int rc = new_plan(ctx, K_COO_DENSE, M, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    std::vector<int32_t> rows((size_t)nnz), nzc((size_t)nnz);
+    std::vector<int64_t> dest((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t r = load_idx(rows_index, idx_bytes, k) - idx_base, c = load_idx(cols_index, idx_bytes, k) - idx_base;
+        const int64_t d = dest_in ? dest_in[k] : r + M * c;
+        if (r < 0 || r >= M || c < 0 || c >= N || d < 0 || d >= out_len) {
+            set_error("entry %lld: index (%lld,%lld) / destination %lld outside the %lld x %lld matrix / %lld values",
+                      (long long)k, (long long)(r + idx_base), (long long)(c + idx_base), (long long)d, (long long)M,
+                      (long long)N, (long long)out_len);
+            fd_plan_destroy(p);
+            *out = nullptr;
+            return FD_ERR_SHAPE;
+        }
+        rows[(size_t)k] = (int32_t)r;
+        nzc[(size_t)k] = col0[(size_t)c];
+        dest[(size_t)k] = d;
+    }
+    if (nnz == 0) dest.clear();
+    FD_TRY(finish_list_plan(p, col0, rows, nzc, dest));
+    p->nouts = 1;
+    p->out_len[0] = out_len;
+    return FD_OK;
+}
+
+int fd_plan_create_coo_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index,
+                             int64_t nnz, int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                             const fd_plan_opts *opts, fd_plan **out)
+{
+    return entries_common(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec,
+                          color_bytes, opts, out);
+}
+
+int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index,
+                           const int64_t *dest, int64_t nnz, int64_t out_len, int idx_bytes, int idx_base,
+                           const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(dest || nnz == 0, FD_ERR_ARG, "dest is NULL");
+    return entries_common(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec,
+                          color_bytes, opts, out);
+}
+
+int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd_plan **out)
+{
+    int rc = new_plan(ctx, K_TRIDIAG, N, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    FD_TRY(upload_colors(p, col0, {}));
+    p->row0 = std::max<int64_t>(p->col0 - 1, 0);
+    p->row1 = std::min<int64_t>(p->col1 + 1, N);
+    if (p->col1 == p->col0) p->row0 = p->row1 = 0;
+    FD_TRY(alloc_scratch(p, col0));
+    p->nouts = 3;
+    const int64_t j0 = p->col0, j1 = p->col1;
+    p->out_len[1] = j1 - j0;                                           // d
+    p->out_len[0] = std::max<int64_t>(std::min<int64_t>(j1, N - 1) - j0, 0);  // dl
+    p->out_len[2] = j1 > j0 ? (j1 - 1) - std::max<int64_t>(j0 - 1, 0) : 0;     // du
+    return FD_OK;
+}
+
+int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, const void *colorvec,
+                          int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(l + u + 1 >= 1 && l > -N && u > -M, FD_ERR_ARG, "bad bandwidths (%lld,%lld)", (long long)l, (long long)u);
+    int rc = new_plan(ctx, K_BANDED, M, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    p->l = l;
+    p->u = u;
+    FD_TRY(apply_opts(p, opts));
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    FD_TRY(upload_colors(p, col0, {}));
+    p->row0 = std::min<int64_t>(std::max<int64_t>(p->col0 - u, 0), M);
+    p->row1 = std::max<int64_t>(std::min<int64_t>(p->col1 + l, M), p->row0);
+    FD_TRY(alloc_scratch(p, col0));
+    p->nouts = 1;
+    p->out_len[0] = (p->col1 - p->col0) * (l + u + 1);
+    return FD_OK;
+}
+
+int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu,
+                               const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
+                               const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(blk_sizes && block_starts && block_strides, FD_ERR_ARG, "NULL block layout array");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(nblk >= 1 && bl >= 0 && bu >= 0, FD_ERR_ARG, "bad block structure");
+    std::vector<int64_t> off((size_t)nblk + 1, 0);
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t s = load_idx(blk_sizes, idx_bytes, b);
+        FD_REQUIRE(s >= 0, FD_ERR_SHAPE, "negative block size");
+        off[(size_t)b + 1] = off[(size_t)b] + s;
+    }
+    const int64_t N = off[(size_t)nblk];
+    int rc = new_plan(ctx, K_COLRANGE, N, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    FD_TRY(upload_colors(p, col0, {}));
+    const int64_t nloc = p->col1 - p->col0;
+    std::vector<int32_t> rlo((size_t)nloc), cnt((size_t)nloc);
+    std::vector<int64_t> offs((size_t)nloc);
+    const int64_t w = bl + bu + 1;
+    int64_t r0 = N, r1 = 0, dmin = std::numeric_limits<int64_t>::max(), dmax = 0;
+    int64_t J = 0;
+    for (int64_t j = p->col0; j < p->col1; ++j) {
+        while (off[(size_t)J + 1] <= j) ++J;
+        const int64_t K0 = std::max<int64_t>(J - bu, 0), K1 = std::min<int64_t>(J + bl, nblk - 1);
+        const int64_t stride = load_idx(block_strides, idx_bytes, J);
+        const int64_t start0 = load_idx(block_starts, idx_bytes, (bu + K0 - J) + w * J) - idx_base;
+        // the in-band blocks of a block-column must be stacked contiguously (the BlockSkyline layout)
+        int64_t expect = start0;
+        for (int64_t K = K0; K <= K1; ++K) {
+            const int64_t st = load_idx(block_starts, idx_bytes, (bu + K - J) + w * J) - idx_base;
+            if (st != expect) {
+                set_error("block (%lld,%lld) is not stacked under its block-column (start %lld, expected %lld)",
+                          (long long)K, (long long)J, (long long)st, (long long)expect);
+                fd_plan_destroy(p);
+                *out = nullptr;
+                return FD_ERR_UNSUPPORTED;
+            }
+            expect += off[(size_t)K + 1] - off[(size_t)K];
+        }
+        const int64_t rows_n = off[(size_t)K1 + 1] - off[(size_t)K0];
+        if (stride < rows_n) {
+            set_error("block_strides[%lld] = %lld < rows in band %lld", (long long)J, (long long)stride, (long long)rows_n);
+            fd_plan_destroy(p);
+            *out = nullptr;
+            return FD_ERR_SHAPE;
+        }
+        const size_t jj = (size_t)(j - p->col0);
+        rlo[jj] = (int32_t)off[(size_t)K0];
+        cnt[jj] = (int32_t)rows_n;
+        offs[jj] = start0 + (j - off[(size_t)J]) * stride;
+        r0 = std::min<int64_t>(r0, off[(size_t)K0]);
+        r1 = std::max<int64_t>(r1, off[(size_t)K1 + 1]);
+        dmin = std::min<int64_t>(dmin, offs[jj]);
+        dmax = std::max<int64_t>(dmax, offs[jj] + rows_n);
+    }
+    if (nloc == 0) { r0 = r1 = 0; dmin = dmax = 0; }
+    // outputs are relative to the first local stored value
+    for (auto &o : offs) o -= dmin;
+    p->entry_begin = dmin;
+    p->row0 = r0;
+    p->row1 = r1;
+    FD_TRY(dev_upload(&p->d_cr_rlo, rlo));
+    FD_TRY(dev_upload(&p->d_cr_cnt, cnt));
+    FD_TRY(dev_upload(&p->d_cr_off, offs));
+    FD_TRY(alloc_scratch(p, col0));
+    p->nouts = 1;
+    p->out_len[0] = dmax - dmin;
+    return FD_OK;
+}
+
+int fd_plan_info(const fd_plan *p, int key, int64_t *value)
+{
+    FD_REQUIRE(p && value, FD_ERR_ARG, "NULL argument");
+    switch (key) {
+    case FD_INFO_M: *value = p->M; break;
+    case FD_INFO_N: *value = p->N; break;
+    case FD_INFO_NCOLORS: *value = p->C; break;
+    case FD_INFO_NOUTS: *value = p->nouts; break;
+    case FD_INFO_OUT0_LEN: *value = p->out_len[0]; break;
+    case FD_INFO_OUT1_LEN: *value = p->out_len[1]; break;
+    case FD_INFO_OUT2_LEN: *value = p->out_len[2]; break;
+    case FD_INFO_ROW_BEGIN: *value = p->row0; break;
+    case FD_INFO_ROW_END: *value = p->row1; break;
+    case FD_INFO_NCHUNKS: *value = p->nchunks; break;
+    case FD_INFO_SCRATCH_BYTES:
+        *value = 8 * (p->chunkB * p->pts * p->cplx * (p->ldx + p->ldf) + 2 * p->ldf + p->ldx);
+        break;
+    case FD_INFO_NNZ_LOCAL: *value = p->nnz_local; break;
+    case FD_INFO_FCALLS_LAST: *value = p->fcalls_last; break;
+    case FD_INFO_ENTRY_BEGIN: *value = p->entry_begin; break;
+    default: set_error("unknown info key %d", key); return FD_ERR_ARG;
+    }
+    return FD_OK;
+}
+
+// ---- timing spans ---------------------------------------------------------------------------
+static hipEvent_t take_event(fd_plan *p)
+{
+    if (!p->event_pool.empty()) {
+        hipEvent_t e = p->event_pool.back();
+        p->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Span {
+    fd_plan *p;
+    int idx = -1;
+    Span(fd_plan *pl, int stage) : p(pl)
+    {
+        if (!p->timing) return;
+        fdjac::TimedSpan s{stage, take_event(p), take_event(p)};
+        (void)hipEventRecord(s.a, p->ctx->stream);
+        p->spans.push_back(s);
+        idx = (int)p->spans.size() - 1;
+    }
+    void stop()
+    {
+        if (idx >= 0) (void)hipEventRecord(p->spans[(size_t)idx].b, p->ctx->stream);
+        idx = -1;
+    }
+    ~Span() { stop(); }
+};
+
+static int collect_spans(fd_plan *p)
+{
+    if (p->spans.empty()) return FD_OK;
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    for (auto &s : p->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            p->ms_sum[s.stage] += ms;
+            p->launches[s.stage] += 1;
+        }
+        p->event_pool.push_back(s.a);
+        p->event_pool.push_back(s.b);
+    }
+    p->spans.clear();
+    return FD_OK;
+}
+
+int fd_plan_enable_timing(fd_plan *p, int on)
+{
+    FD_REQUIRE(p, FD_ERR_ARG, "plan is NULL");
+    int rc = collect_spans(p);
+    if (rc) return rc;
+    p->timing = on != 0;
+    for (int i = 0; i < FD_NSTAGES; ++i) {
+        p->ms_sum[i] = 0;
+        p->launches[i] = 0;
+    }
+    return FD_OK;
+}
+
+int fd_plan_get_timings(fd_plan *p, double *ms_sum, int64_t *launches)
+{
+    FD_REQUIRE(p && ms_sum && launches, FD_ERR_ARG, "NULL argument");
+    int rc = collect_spans(p);
+    if (rc) return rc;
+    for (int i = 0; i < FD_NSTAGES; ++i) {
+        ms_sum[i] = p->ms_sum[i];
+        launches[i] = p->launches[i];
+    }
+    return FD_OK;
+}
+
+// ---- the hot path ---------------------------------------------------------------------------
+static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double *x_dev, const double *fin_dev,
+                            double relstep, double absstep, double dir, double *const *outs)
+{
+    fd_ctx *ctx = p->ctx;
+    hipStream_t s = ctx->stream;
+    FD_REQUIRE(f != nullptr, FD_ERR_ARG, "f launcher is NULL");
+    if (!(relstep > 0)) {
+        // default_relstep, src/epsilons.jl:133-144
+        const double e = 2.220446049250313e-16;
+        relstep = p->fdtype == FD_FORWARD ? std::sqrt(e) : p->fdtype == FD_CENTRAL ? std::cbrt(e) : 1.0;
+    }
+    if (absstep < 0) absstep = relstep;
+    p->relstep_last = relstep;
+    p->absstep_last = absstep;
+    p->fcalls_last = 0;
+    if (collect_spans(p) != FD_OK) return FD_ERR_HIP;  // keeps the event list bounded
+    Span total(p, FD_STAGE_TOTAL);
+
+    // x must be 16-B aligned for the vector loads; stage it otherwise
+    if (((uintptr_t)x_dev) & 15) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x_dev, sizeof(double) * (size_t)p->N, hipMemcpyDeviceToDevice, s));
+        x_dev = p->d_xstage;
+    }
+
+    // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
+    if (p->fdtype != FD_COMPLEX && p->C > 0) {
+        Span sp(p, FD_STAGE_EPS);
+        int rc = launch_eps(p, x_dev, relstep, absstep, dir);
+        if (rc) return rc;
+    }
+
+    // f(x) for forward differences (src/jacobians.jl:540-545)
+    const double *fx = nullptr;
+    if (p->fdtype == FD_FORWARD) {
+        if (fin_dev) {
+            fx = fin_dev;
+        } else {
+            Span sp(p, FD_STAGE_F);
+            const int rc = f(fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
+            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+            p->fcalls_last += 1;
+            fx = p->d_fx;
+        }
+    }
+
+    // dense J / list kinds with several chunks or uncovered entries start from zero (fill_matrix!,
+    // src/jacobians.jl:530-532).  Kinds that write every stored value in one chunk skip the fill.
+    if (p->kind == K_CSC_DENSE || p->kind == K_COO_DENSE) {
+        FD_HIP_CHECK(hipMemsetAsync(outs[0], 0, sizeof(double) * (size_t)p->out_len[0], s));
+    } else if (p->C == 0) {
+        for (int k = 0; k < p->nouts; ++k)
+            FD_HIP_CHECK(hipMemsetAsync(outs[k], 0, sizeof(double) * (size_t)p->out_len[k], s));
+    }
+
+    for (int64_t ch = 0; ch < p->nchunks; ++ch) {
+        const int c_lo = (int)(ch * p->chunkB);
+        const int c_hi = (int)std::min<int64_t>(p->C, (int64_t)c_lo + p->chunkB);
+        const int B = c_hi - c_lo;
+        {
+            Span sp(p, FD_STAGE_PERTURB);
+            int rc = launch_perturb(p, x_dev, c_lo, B);
+            if (rc) return rc;
+        }
+        {
+            Span sp(p, FD_STAGE_F);
+            const int rc = f(fctx, p->d_FX, p->d_X, (int64_t)B * p->pts, p->ldx, p->ldf, p->row0, p->row1,
+                             p->fdtype == FD_COMPLEX ? 1 : 0, (void *)s);
+            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+            p->fcalls_last += (int64_t)B * p->pts;
+        }
+        {
+            Span sp(p, FD_STAGE_DECOMPRESS);
+            int rc = launch_decompress(p, fx, c_lo, c_hi, outs);
+            if (rc) return rc;
+        }
+    }
+    return FD_OK;
+}
+
+int fd_jacobian_async(fd_plan *p, fd_f_launch f, void *fctx, const void *x, const void *f_in, double relstep,
+                      double absstep, double dir, void *const *outs)
+{
+    FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
+    for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    double *o[3] = {(double *)outs[0], p->nouts > 1 ? (double *)outs[1] : nullptr,
+                    p->nouts > 2 ? (double *)outs[2] : nullptr};
+    return jacobian_enqueue(p, f, fctx, (const double *)x, (const double *)f_in, relstep, absstep, dir, o);
+}
+
+int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind, const void *f_in, int f_in_kind,
+                double relstep, double absstep, double dir, void *const *outs, int out_kind)
+{
+    FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
+    for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const double *x_dev = (const double *)x;
+    if (x_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        x_dev = p->d_xstage;
+    }
+    const double *fin_dev = (const double *)f_in;
+    if (f_in && f_in_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_finstage, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
+        fin_dev = p->d_finstage;
+    }
+    double *o[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < p->nouts; ++k) {
+        if (out_kind == FD_DEVICE) {
+            o[k] = (double *)outs[k];
+        } else {
+            if (!p->d_outstage[k]) {
+                int rc = dev_alloc(&p->d_outstage[k], p->out_len[k]);
+                if (rc) return rc;
+            }
+            o[k] = p->d_outstage[k];
+        }
+    }
+    int rc = jacobian_enqueue(p, f, fctx, x_dev, fin_dev, relstep, absstep, dir, o);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    if (out_kind == FD_HOST)
+        for (int k = 0; k < p->nouts; ++k)
+            if (p->out_len[k] > 0)
+                FD_HIP_CHECK(hipMemcpyAsync(outs[k], o[k], sizeof(double) * (size_t)p->out_len[k], hipMemcpyDeviceToHost, s));
+    FD_HIP_CHECK(hipStreamSynchronize(s));
+    return FD_OK;
+}
+
+int fd_plan_get_epsilons(fd_plan *p, double *eps_out)
+{
+    FD_REQUIRE(p && eps_out, FD_ERR_ARG, "NULL argument");
+    if (p->C == 0) return FD_OK;
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    FD_HIP_CHECK(hipMemcpy(eps_out, p->d_eps, sizeof(double) * (size_t)p->C, hipMemcpyDeviceToHost));
+    return FD_OK;
+}
+
+int fd_stream_copy_gbps(fd_ctx *ctx, int64_t bytes, int iters, double *gbps_out)
+{
+    FD_REQUIRE(ctx && gbps_out && bytes >= 16 && iters >= 1, FD_ERR_ARG, "bad argument");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n16 = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    FD_HIP_CHECK(hipMalloc(&a, (size_t)n16 * 16));
+    if (hipMalloc(&b, (size_t)n16 * 16) != hipSuccess) {
+        (void)hipFree(a);
+        set_error("hipMalloc failed");
+        return FD_ERR_NOMEM;
+    }
+    (void)hipMemsetAsync(a, 1, (size_t)n16 * 16, ctx->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    launch_stream_copy(ctx, a, b, n16);  // warm-up
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < iters; ++i) launch_stream_copy(ctx, a, b, n16);
+    (void)hipEventRecord(e1, ctx->stream);
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    FD_REQUIRE(se == hipSuccess && ms > 0, FD_ERR_HIP, "stream copy probe failed: %s", hipGetErrorString(se));
+    *gbps_out = 2.0 * (double)n16 * 16.0 * iters / (ms * 1e-3) / 1e9;
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Built-in device f! families behind the fd_f_launch boundary: the reference's own test
+// fixtures (test/coloring_tests.jl:5-13, 99-108, 124-133) and the benchmark configurations of
+// BASELINE.json.  Each kernel evaluates `nbatch` independent points (grid.y = point index) and
+// only the rows [row_begin,row_end) the plan will consume.  Real and complex (for the
+// complex-step arm, src/jacobians.jl:623-648) instantiations share one template.
+//
+// Operation order follows the fixtures literally (e.g. (x[i-1] - 2x[i]) + x[i+1]) and the
+// library is built with -ffp-contract=off, so a linear fixture reproduces the CPU values bit
+// for bit.
+#include <atomic>
+#include <new>
+
+#include "fdjac_internal.h"
+
+namespace fdjac {
+
+struct cd {
+    double re, im;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cd operator*(cd a, cd b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cd operator*(double s, cd a) { return {s * a.re, s * a.im}; }
+__device__ __forceinline__ cd operator+(cd a, double s) { return {a.re + s, a.im}; }
+__device__ __forceinline__ cd operator-(cd a, double s) { return {a.re - s, a.im}; }
+
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ cd zero_of<cd>() { return {0.0, 0.0}; }
+
+__device__ __forceinline__ double sin_of(double a) { return sin(a); }
+__device__ __forceinline__ cd sin_of(cd a)
+{
+    // sin(a+ib) = sin a cosh b + i cos a sinh b
+    return {sin(a.re) * cosh(a.im), cos(a.re) * sinh(a.im)};
+}
+
+// dx[i] = x[i-1] - 2x[i] + x[i+1]  (+ x[i]^2 * x[i+1] when NL), zero beyond the ends.
+template <typename T, bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag(T *__restrict__ fx, const T *__restrict__ x, int64_t n, int64_t xs, int64_t fs, int64_t r0, int64_t r1)
+{
+    const T *xb = x + (int64_t)blockIdx.y * xs;
+    T *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < r1; i += stride) {
+        const T xm = i > 0 ? xb[i - 1] : zero_of<T>();
+        const T xp = i + 1 < n ? xb[i + 1] : zero_of<T>();
+        const T xi = xb[i];
+        T v = (xm - 2.0 * xi) + xp;
+        if (NL) v = v + (xi * xi) * xp;
+        fb[i] = v;
+    }
+}
+
+// 5-point stencils on an nx (fast) x ny grid.  CLAMP = false: zero-Dirichlet Laplacian
+// w + e + s + n - 4x ; CLAMP = true: the reference's clamped-edge sum x + x[i-1] + x[i+1] + x[j-1] + x[j+1].
+template <typename T, bool CLAMP>
+__global__ void __launch_bounds__(kBlock)
+k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
+             int64_t r0, int64_t r1)
+{
+    const T *xb = x + (int64_t)blockIdx.y * xs;
+    T *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = r0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < r1; k += stride) {
+        const int64_t j = k / nx, i = k - j * nx;
+        if (CLAMP) {
+            const int64_t im = i > 0 ? i - 1 : 0, ip = i + 1 < nx ? i + 1 : nx - 1;
+            const int64_t jm = j > 0 ? j - 1 : 0, jp = j + 1 < ny ? j + 1 : ny - 1;
+            fb[k] = (((xb[k] + xb[im + nx * j]) + xb[ip + nx * j]) + xb[i + nx * jm]) + xb[i + nx * jp];
+        } else {
+            const T w = i > 0 ? xb[k - 1] : zero_of<T>();
+            const T e = i + 1 < nx ? xb[k + 1] : zero_of<T>();
+            const T s = j > 0 ? xb[k - nx] : zero_of<T>();
+            const T n = j + 1 < ny ? xb[k + nx] : zero_of<T>();
+            fb[k] = (((w + e) + s) + n) - 4.0 * xb[k];
+        }
+    }
+}
+
+// block-coupled: sig_b = sum_j w_j x_b[j], w_j = (j+1)/bs; one wave per block, fixed-order tree.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_f_block_sigma(T *__restrict__ sig, const T *__restrict__ x, int64_t nb, int64_t bs, int64_t xs, int64_t b0, int64_t b1)
+{
+    const T *xb = x + (int64_t)blockIdx.y * xs;
+    T *sb = sig + (int64_t)blockIdx.y * nb;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t b = b0 + wave; b < b1; b += nw) {
+        T acc = zero_of<T>();
+        for (int64_t j = lane; j < bs; j += 64) acc = acc + ((double)(j + 1) / (double)bs) * xb[b * bs + j];
+        // serial-order-independent but fixed: tree over lanes
+        for (int off = 32; off > 0; off >>= 1) {
+            if constexpr (sizeof(T) == 8) {
+                double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+                acc = acc + *reinterpret_cast<T *>(&o);
+            } else {
+                cd *a = reinterpret_cast<cd *>(&acc);
+                cd o{__shfl_down(a->re, off, 64), __shfl_down(a->im, off, 64)};
+                acc = acc + *reinterpret_cast<T *>(&o);
+            }
+        }
+        if (lane == 0) sb[b] = acc;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_f_block_apply(T *__restrict__ fx, const T *__restrict__ x, const T *__restrict__ sig, int64_t nb, int64_t bs,
+                int64_t xs, int64_t fs, int64_t r0, int64_t r1)
+{
+    const T *xb = x + (int64_t)blockIdx.y * xs;
+    const T *sb = sig + (int64_t)blockIdx.y * nb;
+    T *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = r0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < r1; k += stride) {
+        const int64_t b = k / bs;
+        const T sm = b > 0 ? sb[b - 1] : zero_of<T>();
+        const T sp = b + 1 < nb ? sb[b + 1] : zero_of<T>();
+        const T S = (sm + sb[b]) + sp;
+        fb[k] = xb[k] * S + sin_of(xb[k]);
+    }
+}
+
+// y[k] = (x1-3)^2 + x1*x2 + (x2+4)^2 - 3 with x1 = x[k], x2 = x[n+k]
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_f_nonsquare(T *__restrict__ fx, const T *__restrict__ x, int64_t n, int64_t xs, int64_t fs, int64_t r0, int64_t r1)
+{
+    const T *xb = x + (int64_t)blockIdx.y * xs;
+    T *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = r0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < r1; k += stride) {
+        const T a = xb[k], b = xb[n + k];
+        fb[k] = ((((a - 3.0) * (a - 3.0)) + a * b) + ((b + 4.0) * (b + 4.0))) - 3.0;
+    }
+}
+
+struct BuiltinF {
+    uint32_t magic = 0xFD0F00D5u;
+    fd_ctx *ctx = nullptr;
+    int family = 0;
+    int64_t prm[2] = {0, 0};
+    int64_t M = 0, N = 0;
+    std::atomic<int64_t> launches{0}, points{0};
+    void *d_sig = nullptr;  // block-coupled sigma scratch
+    int64_t sig_cap = 0;    // in (re,im)-capable elements
+};
+
+static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
+{
+    int64_t gx = (rows + kBlock - 1) / kBlock;
+    const int64_t cap = std::max<int64_t>(1, (int64_t)num_cus * 8 / std::max<int64_t>(nbatch, 1));
+    if (gx > cap && nbatch > 1) gx = std::max<int64_t>(cap, 64);
+    if (gx > (int64_t)num_cus * 16) gx = (int64_t)num_cus * 16;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)nbatch, 1);
+}
+
+template <typename T>
+static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0,
+                         int64_t r1, hipStream_t s)
+{
+    if (r1 <= r0) return 0;
+    const int ncu = b->ctx->num_cus;
+    T *fxp = (T *)fx;
+    const T *xp = (const T *)x;
+    const dim3 g = grid2(r1 - r0, nbatch, ncu);
+    switch (b->family) {
+    case FD_F_TRIDIAG:
+        hipLaunchKernelGGL((k_f_tridiag<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
+        break;
+    case FD_F_TRIDIAG_NL:
+        hipLaunchKernelGGL((k_f_tridiag<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
+        break;
+    case FD_F_LAP5:
+        hipLaunchKernelGGL((k_f_stencil5<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
+        break;
+    case FD_F_CLAMP5:
+        hipLaunchKernelGGL((k_f_stencil5<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
+        break;
+    case FD_F_BLOCKCOUPLED: {
+        const int64_t nb = b->prm[0], bs = b->prm[1];
+        if (b->sig_cap < nbatch * nb) {
+            if (b->d_sig) (void)hipFree(b->d_sig);
+            b->d_sig = nullptr;
+            if (hipMalloc(&b->d_sig, (size_t)(nbatch * nb) * 16) != hipSuccess) return 2;
+            b->sig_cap = nbatch * nb;
+        }
+        const int64_t b0 = std::max<int64_t>(r0 / bs - 1, 0), b1 = std::min<int64_t>((r1 + bs - 1) / bs + 1, nb);
+        const dim3 gs = grid2((b1 - b0) * 64, nbatch, ncu);
+        hipLaunchKernelGGL((k_f_block_sigma<T>), gs, dim3(kBlock), 0, s, (T *)b->d_sig, xp, nb, bs, xs, b0, b1);
+        hipLaunchKernelGGL((k_f_block_apply<T>), g, dim3(kBlock), 0, s, fxp, xp, (const T *)b->d_sig, nb, bs, xs, fs, r0, r1);
+        break;
+    }
+    case FD_F_NONSQUARE:
+        hipLaunchKernelGGL((k_f_nonsquare<T>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
+        break;
+    default: return 3;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+static int builtin_launch(void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride, int64_t fx_stride,
+                          int64_t row_begin, int64_t row_end, int is_complex, void *stream)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    if (!b || b->magic != 0xFD0F00D5u) return 1;
+    if (nbatch <= 0) return 0;
+    if (nbatch > 65535) return 5;
+    b->launches.fetch_add(1);
+    b->points.fetch_add(nbatch);
+    const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
+    if (is_complex)
+        return launch_family<cd>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
+    return launch_family<double>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
+}
+
+}  // namespace fdjac
+
+using namespace fdjac;
+
+extern "C" {
+
+int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams, fd_f_launch *fn_out,
+                        void **fctx_out)
+{
+    FD_REQUIRE(ctx && params && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
+    BuiltinF *b = new (std::nothrow) BuiltinF();
+    FD_REQUIRE(b != nullptr, FD_ERR_NOMEM, "out of host memory");
+    b->ctx = ctx;
+    b->family = family;
+    int need = 1;
+    switch (family) {
+    case FD_F_TRIDIAG:
+    case FD_F_TRIDIAG_NL: need = 1; break;
+    case FD_F_LAP5:
+    case FD_F_CLAMP5:
+    case FD_F_BLOCKCOUPLED: need = 2; break;
+    case FD_F_NONSQUARE: need = 1; break;
+    default:
+        delete b;
+        set_error("unknown built-in f family %d", family);
+        return FD_ERR_ARG;
+    }
+    if (nparams < need) {
+        delete b;
+        set_error("family %d needs %d parameters", family, need);
+        return FD_ERR_ARG;
+    }
+    for (int i = 0; i < need; ++i) b->prm[i] = params[i];
+    for (int i = 0; i < need; ++i)
+        if (b->prm[i] < 1) {
+            delete b;
+            set_error("parameters must be >= 1");
+            return FD_ERR_ARG;
+        }
+    switch (family) {
+    case FD_F_TRIDIAG:
+    case FD_F_TRIDIAG_NL: b->M = b->N = b->prm[0]; break;
+    case FD_F_NONSQUARE: b->M = b->prm[0]; b->N = 2 * b->prm[0]; break;
+    default: b->M = b->N = b->prm[0] * b->prm[1]; break;
+    }
+    *fn_out = builtin_launch;
+    *fctx_out = b;
+    return FD_OK;
+}
+
+int fd_builtin_f_destroy(void *fctx)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    if (!b) return FD_OK;
+    FD_REQUIRE(b->magic == 0xFD0F00D5u, FD_ERR_ARG, "not a built-in f context");
+    if (b->d_sig) (void)hipFree(b->d_sig);
+    b->magic = 0;
+    delete b;
+    return FD_OK;
+}
+
+int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    FD_REQUIRE(b && b->magic == 0xFD0F00D5u, FD_ERR_ARG, "not a built-in f context");
+    if (launches) *launches = b->launches.load();
+    if (points) *points = b->points.load();
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Internal declarations shared by the libfdjac translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "fdjac.h"
+
+namespace fdjac {
+
+void set_error(const char *fmt, ...);
+
+#define FD_HIP_CHECK(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            ::fdjac::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                               __LINE__);                                                      \
+            return FD_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define FD_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::fdjac::set_error(__VA_ARGS__); \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLRANGE };
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup
+constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
+constexpr int64_t kTile = 8192;      // stored entries per workgroup in the decompression kernels
+constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
+
+struct TimedSpan {
+    int stage;
+    hipEvent_t a, b;
+};
+
+}  // namespace fdjac
+
+struct fd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+};
+
+struct fd_plan {
+    fd_ctx *ctx = nullptr;
+    int kind = 0;
+    int fdtype = 0;
+    int64_t M = 0, N = 0;
+    int64_t C = 0;        // maximum(colorvec)
+    bool color8 = true;   // colours stored as uint8 (C <= 254) else int32
+    int64_t col0 = 0, col1 = 0, x0 = 0, x1 = 0, row0 = 0, row1 = 0;
+
+    // pattern (device)
+    void *d_color = nullptr;       // per column, 0-based colour, "none" = all-ones
+    int32_t *d_rowval = nullptr;   // per local stored entry, 0-based row
+    void *d_nzcolor = nullptr;     // per local stored entry
+    int64_t *d_dest = nullptr;     // per local stored entry destination offset (dense-J kinds)
+    int64_t nnz_local = 0;
+    int64_t entry_begin = 0;       // global index of the first local stored entry
+    int64_t l = 0, u = 0;          // banded
+    int32_t *d_cr_rlo = nullptr;   // colrange (block-banded): first row of each local column
+    int32_t *d_cr_cnt = nullptr;   //   number of contiguous rows
+    int64_t *d_cr_off = nullptr;   //   destination offset of the first row
+    // segmented epsilon reduction (C > kRegColors)
+    int32_t *d_perm = nullptr;     // columns sorted by colour
+    int64_t *d_cptr = nullptr;     // C+1 offsets into perm
+    int seg_chunks = 1;
+
+    // scratch (device)
+    int64_t ldx = 0, ldf = 0;      // leading dimensions (elements) of the batched point / value arrays
+    int64_t chunkB = 0, nchunks = 0;
+    int pts = 1;                   // f! points per colour (2 for central)
+    int cplx = 0;                  // elements are (re,im) pairs
+    double *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr, *d_partial = nullptr;
+    double *d_xstage = nullptr, *d_finstage = nullptr;
+    int n_partial_blocks = 0;
+    int64_t scratch_bytes = 0;
+
+    int nouts = 1;
+    int64_t out_len[3] = {0, 0, 0};
+    double *d_outstage[3] = {nullptr, nullptr, nullptr};
+
+    int64_t fcalls_last = 0;
+    double relstep_last = 0, absstep_last = 0;
+
+    bool timing = false;
+    std::vector<fdjac::TimedSpan> spans;       // recorded, not yet collected
+    std::vector<hipEvent_t> event_pool;
+    double ms_sum[FD_NSTAGES] = {0, 0, 0, 0, 0};
+    int64_t launches[FD_NSTAGES] = {0, 0, 0, 0, 0};
+};

@@ -1,0 +1,525 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the coloured-Jacobian hot path.
+//
+// Every stage is HBM-bandwidth bound (no dense contraction => no MFMA).  Layout rules:
+//   * all streams are read / written with 16 B per lane where alignment allows (double2),
+//   * a workgroup (256 threads = 4 waves) owns a contiguous tile of its stream so that the
+//     lines it gathers from the batched f! outputs are not shared with other XCDs' L2s,
+//   * the step sizes eps[] of the current colour chunk are staged in LDS.
+//
+// Reference loops each kernel replaces are cited per kernel (paths relative to /root/reference).
+#include "fdjac_internal.h"
+
+namespace fdjac {
+
+template <typename CT> struct ColorTraits;
+template <> struct ColorTraits<uint8_t> { static constexpr int none = 0xFF; };
+template <> struct ColorTraits<int32_t> { static constexpr int none = -1; };
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a  masked sums of squares for ALL colours in one pass over x (C <= kRegColors).
+//   Replaces, for every colour at once:  @. x2 = x1*(_color==color_i); tmp = norm(x2)
+//   (src/jacobians.jl:559-560, 600-601).  Deterministic: fixed per-thread order, fixed
+//   shuffle tree, per-block partials reduced by k_eps_finalize in fixed order.
+//   partial layout: partial[block * ldp + c].
+// ---------------------------------------------------------------------------------------------
+template <typename CT, int NC>
+__global__ void __launch_bounds__(kBlock)
+k_eps_partial_reg(const double *__restrict__ x, const CT *__restrict__ color, int64_t n,
+                  double *__restrict__ partial, int ldp)
+{
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+
+    const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
+    int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+    for (; i + 1 < n; i += stride) {
+        const double2 v = *reinterpret_cast<const double2 *>(x + i);
+        const int c0 = color[i], c1 = color[i + 1];
+        const double s0 = v.x * v.x, s1 = v.y * v.y;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] += (c0 == c) ? s0 : 0.0;
+            acc[c] += (c1 == c) ? s1 : 0.0;
+        }
+    }
+    if (i < n) {  // odd tail element
+        const double v = x[i];
+        const int c0 = color[i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += (c0 == c) ? v * v : 0.0;
+    }
+
+    __shared__ double red[kBlock / 64][NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double s = wave_sum(acc[c]);
+        if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * ldp + threadIdx.x] = s;
+    }
+}
+
+// K1b  same reduction for many colours: block (chunk k, colour c) walks colour c's column list
+//   (perm sorted by colour, built once at plan time) -- deterministic for any C.
+__global__ void __launch_bounds__(kBlock)
+k_eps_partial_seg(const double *__restrict__ x, const int32_t *__restrict__ perm,
+                  const int64_t *__restrict__ cptr, int64_t C, int nchunks,
+                  double *__restrict__ partial)
+{
+    const int64_t b = blockIdx.x;
+    const int64_t c = b / nchunks;
+    const int k = (int)(b - c * nchunks);
+    const int64_t lo = cptr[c], hi = cptr[c + 1];
+    const int64_t len = hi - lo;
+    const int64_t per = (len + nchunks - 1) / nchunks;
+    const int64_t s = lo + per * k;
+    const int64_t e = (s + per < hi) ? s + per : hi;
+    double acc = 0.0;
+    for (int64_t i = s + threadIdx.x; i < e; i += kBlock) {
+        const double v = x[perm[i]];
+        acc += v * v;
+    }
+    __shared__ double red[kBlock / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        partial[(int64_t)k * C + c] = t;
+    }
+}
+
+// K1c  eps[c] from the partial sums.  One block per colour.
+//   forward: max(relstep*abs(sqrt(norm)), absstep)*dir   (src/epsilons.jl:26-29; the sqrt of the
+//            2-norm is src/jacobians.jl:561)
+//   central: max(relstep*abs(sqrt(norm)), absstep)       (src/epsilons.jl:50-53; jacobians.jl:602)
+__global__ void __launch_bounds__(kBlock)
+k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double relstep,
+               double absstep, double dir, int is_forward, double *__restrict__ eps)
+{
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += kBlock) acc += partial[(int64_t)k * ldp + c];
+    __shared__ double red[kBlock / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        const double nrm = sqrt(t);             // norm(x2)
+        const double xs = fabs(sqrt(nrm));      // abs(sqrt(tmp))
+        const double a = relstep * xs;
+        double e = (a > absstep) ? a : absstep;
+        if (is_forward) e = e * dir;
+        eps[c] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  perturbed points for a whole chunk of colours, written from the pristine x:
+//   forward  X[b][j]   = x[j] + eps_b*(color[j]==b)                 (src/jacobians.jl:562)
+//   central  X[b][j]   = x[j] + eps_b*mask ; X[B+b][j] = x[j] - eps_b*mask   (:603-604)
+//   complex  X[b][j]   = (x[j], eps*mask)                                     (:633)
+//   One pass over x and colour; no un-perturb pass is needed (:584,:619-620,:646) because x is
+//   never modified.  MODE 0/1/2 as fd_fdtype.
+// ---------------------------------------------------------------------------------------------
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_perturb(const double *__restrict__ x, const CT *__restrict__ color,
+          const double *__restrict__ eps, int c_lo, int B, int64_t j0, int64_t j1,
+          double *__restrict__ X, int64_t ldx)
+{
+    // j0 is even by construction (host rounds the window down), so pairs are 16-B aligned.
+    const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
+    for (int64_t j = j0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; j < j1; j += stride) {
+        const bool pair = (j + 1 < j1);
+        double v0, v1 = 0.0;
+        if (pair) {
+            const double2 v = *reinterpret_cast<const double2 *>(x + j);
+            v0 = v.x; v1 = v.y;
+        } else {
+            v0 = x[j];
+        }
+        // colours outside the chunk (and "none") never equal a b in [0,B)
+        const int c0 = (int)color[j] - c_lo, c1 = pair ? (int)color[j + 1] - c_lo : -1;
+        for (int b = 0; b < B; ++b) {
+            const double e = eps[c_lo + b];
+            const double e0 = (c0 == b) ? e : 0.0, e1 = (c1 == b) ? e : 0.0;
+            if (MODE == 2) {
+                double *dst = X + ((int64_t)b * ldx + j) * 2;
+                *reinterpret_cast<double2 *>(dst) = make_double2(v0, e0);
+                if (pair) *reinterpret_cast<double2 *>(dst + 2) = make_double2(v1, e1);
+            } else {
+                double *dp = X + (int64_t)b * ldx + j;
+                if (pair) *reinterpret_cast<double2 *>(dp) = make_double2(v0 + e0, v1 + e1);
+                else dp[0] = v0 + e0;
+                if (MODE == 1) {
+                    double *dm = X + (int64_t)(B + b) * ldx + j;
+                    if (pair) *reinterpret_cast<double2 *>(dm) = make_double2(v0 - e0, v1 - e1);
+                    else dm[0] = v0 - e0;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// value of one stored entry: the fused difference (src/jacobians.jl:565 / 607 / 635) evaluated
+// only at the rows the pattern needs, for the colour that owns the entry's column.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ double entry_value(const double *__restrict__ FXa,
+                                              const double *__restrict__ FXb, int64_t ld, int cb,
+                                              int64_t r, double e)
+{
+    if (MODE == 0) {
+        const double a = FXa[(int64_t)cb * ld + r];
+        const double b = FXb[r];
+        return (a - b) / e;
+    } else if (MODE == 1) {
+        const double a = FXa[(int64_t)cb * ld + r];
+        const double b = FXb[(int64_t)cb * ld + r];
+        return (a - b) / (2 * e);
+    } else {
+        const double a = FXa[((int64_t)cb * ld + r) * 2 + 1];
+        return a / e;
+    }
+}
+
+// K3  fused difference + decompression in STORAGE ORDER for index-list patterns (CSC nzval, or
+//   dense J through dest[]).  For every stored entry p:
+//       nzval[p] = (fx1_c[rowval[p]] - fx[rowval[p]]) / eps_c ,  c = colour of p's column
+//   which is `_colorediteration!` (ext/FiniteDiffSparseArraysExt.jl:38-47; :20-28 with dest;
+//   src/iteration_utils.jl:25-32 for COO lists) for all colours of the chunk at once: rowval,
+//   the per-entry colour and nzval are each streamed exactly once, fully coalesced, and the
+//   batched f! outputs are gathered near-sequentially (banded patterns) out of L2.
+//   LDS stages the chunk's eps[] slice.
+template <typename CT, int MODE, bool HAS_DEST>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzcolor,
+                  const int64_t *__restrict__ dest, const double *__restrict__ FXa,
+                  const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
+                  int c_lo, int c_hi, double *__restrict__ out, int64_t n, int vec_ok)
+{
+    extern __shared__ double s_eps[];
+    const int nB = c_hi - c_lo;
+    const bool lds = nB <= kEpsLdsMax;
+    if (lds) {
+        for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
+        __syncthreads();
+    }
+    const int none = ColorTraits<CT>::none;
+    const int64_t t0 = (int64_t)blockIdx.x * kTile;
+    const int64_t t1 = (t0 + kTile < n) ? t0 + kTile : n;
+
+    for (int64_t p = t0 + (int64_t)threadIdx.x * 2; p < t1; p += kBlock * 2) {
+        const bool pair = (p + 1 < t1);
+        int r0, r1 = 0;
+        if (pair) {
+            const int2 rr = *reinterpret_cast<const int2 *>(rowval + p);
+            r0 = rr.x; r1 = rr.y;
+        } else {
+            r0 = rowval[p];
+        }
+        const int c0 = nzcolor[p];
+        const int c1 = pair ? (int)nzcolor[p + 1] : none;
+        // 0: skip (another chunk's colour), 1: value, 2: zero (column without colour)
+        const int w0 = (c0 == none) ? (c_lo == 0 ? 2 : 0) : ((c0 >= c_lo && c0 < c_hi) ? 1 : 0);
+        const int w1 = !pair ? 0 : (c1 == none) ? (c_lo == 0 ? 2 : 0) : ((c1 >= c_lo && c1 < c_hi) ? 1 : 0);
+        double v0 = 0.0, v1 = 0.0;
+        if (w0 == 1) {
+            const double e = lds ? s_eps[c0 - c_lo] : eps[c0];
+            v0 = entry_value<MODE>(FXa, FXb, ld, c0 - c_lo, r0, e);
+        }
+        if (w1 == 1) {
+            const double e = lds ? s_eps[c1 - c_lo] : eps[c1];
+            v1 = entry_value<MODE>(FXa, FXb, ld, c1 - c_lo, r1, e);
+        }
+        if (HAS_DEST) {
+            if (w0) out[dest[p]] = v0;
+            if (w1) out[dest[p + 1]] = v1;
+        } else {
+            if (w0 && w1 && vec_ok) {
+                *reinterpret_cast<double2 *>(out + p) = make_double2(v0, v1);
+            } else {
+                if (w0) out[p] = v0;
+                if (w1) out[p + 1] = v1;
+            }
+        }
+    }
+}
+
+// K4a  Tridiagonal J: three dense diagonals, no index traffic at all.
+//   d[j] = D_c(j)[j] ; dl[j] = D_c(j)[j+1] ; du[j-1] = D_c(j)[j-1],  D_c = (fx1_c - fx)/eps_c
+//   (what src/iteration_utils.jl:25-32 stores through Tridiagonal's setindex!).
+//   j runs over the local column window [j0,j1); outputs are indexed relative to the window:
+//   d[j-j0], dl[j-j0], du[j-1-du0] with du0 = max(j0-1,0).
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_tridiag(const CT *__restrict__ color, const double *__restrict__ FXa,
+                     const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
+                     int c_lo, int c_hi, int64_t N, int64_t j0, int64_t j1,
+                     double *__restrict__ dl, double *__restrict__ d, double *__restrict__ du)
+{
+    const int none = ColorTraits<CT>::none;
+    const int64_t du0 = j0 > 0 ? j0 - 1 : 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = j0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < j1; j += stride) {
+        const int c = color[j];
+        if (c == none) {
+            if (c_lo == 0) {
+                d[j - j0] = 0.0;
+                if (j + 1 < N) dl[j - j0] = 0.0;
+                if (j > 0) du[j - 1 - du0] = 0.0;
+            }
+            continue;
+        }
+        if (c < c_lo || c >= c_hi) continue;
+        const double e = eps[c];
+        const int cb = c - c_lo;
+        d[j - j0] = entry_value<MODE>(FXa, FXb, ld, cb, j, e);
+        if (j + 1 < N) dl[j - j0] = entry_value<MODE>(FXa, FXb, ld, cb, j + 1, e);
+        if (j > 0) du[j - 1 - du0] = entry_value<MODE>(FXa, FXb, ld, cb, j - 1, e);
+    }
+}
+
+// K4b  BandedMatrix J: data is (l+u+1) x N column-major; slot k of column j holds row j-u+k
+//   (ext/FiniteDiffBandedMatricesExt.jl:13-27, storage per its line 22).  One thread per data
+//   slot => dense coalesced stores, implicit indices, one colour byte per column (L1-resident).
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_banded(const CT *__restrict__ color, const double *__restrict__ FXa,
+                    const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
+                    int c_lo, int c_hi, int64_t M, int64_t l, int64_t u, int64_t j0, int64_t j1,
+                    double *__restrict__ data)
+{
+    const int none = ColorTraits<CT>::none;
+    const int64_t w = l + u + 1;
+    const int64_t total = (j1 - j0) * w;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+        const int64_t jj = e / w;
+        const int64_t k = e - jj * w;
+        const int64_t j = j0 + jj;
+        const int64_t r = j - u + k;
+        const int c = color[j];
+        if (r < 0 || r >= M || c == none) {
+            if (c_lo == 0) data[e] = 0.0;
+            continue;
+        }
+        if (c < c_lo || c >= c_hi) continue;
+        data[e] = entry_value<MODE>(FXa, FXb, ld, c - c_lo, r, eps[c]);
+    }
+}
+
+// K5  column-range patterns (BlockBandedMatrix with dense in-band blocks): local column jj owns
+//   the contiguous rows [rlo, rlo+cnt) stored contiguously at off
+//   (ext/FiniteDiffBlockBandedMatricesExt.jl:44-68: V[k,j] = b_v[k] over blockcolrange).
+//   One wave per column: 64 lanes sweep the rows => contiguous 512-B stores and gathers.
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ rlo,
+                      const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
+                      const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld,
+                      const double *__restrict__ eps, int c_lo, int c_hi, int64_t j0,
+                      int64_t ncols, double *__restrict__ data)
+{
+    const int none = ColorTraits<CT>::none;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t jj = wave; jj < ncols; jj += nwaves) {
+        const int c = color[j0 + jj];
+        const int64_t o = off[jj];
+        const int r0 = rlo[jj], n = cnt[jj];
+        if (c == none) {
+            if (c_lo == 0)
+                for (int k = lane; k < n; k += 64) data[o + k] = 0.0;
+            continue;
+        }
+        if (c < c_lo || c >= c_hi) continue;
+        const double e = eps[c];
+        for (int k = lane; k < n; k += 64)
+            data[o + k] = entry_value<MODE>(FXa, FXb, ld, c - c_lo, r0 + k, e);
+    }
+}
+
+// Stream-copy ceiling probe (16 B per lane, grid-stride).
+__global__ void __launch_bounds__(kBlock)
+k_stream_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(kBlock) k_fill(double *__restrict__ p, int64_t n, double v)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (called from fdjac_api.hip)
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t work_items, int per_block, int num_cus)
+{
+    int64_t g = (work_items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)num_cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename CT>
+static int launch_eps_t(fd_plan *p, const double *x, double relstep, double absstep, double dir)
+{
+    hipStream_t s = p->ctx->stream;
+    const int C = (int)p->C;
+    int nparts, ldp;
+    if (C <= kRegColors) {
+        nparts = p->n_partial_blocks;
+        ldp = kRegColors;
+        if (C <= 4)
+            hipLaunchKernelGGL((k_eps_partial_reg<CT, 4>), dim3(nparts), dim3(kBlock), 0, s, x,
+                               (const CT *)p->d_color, p->N, p->d_partial, ldp);
+        else
+            hipLaunchKernelGGL((k_eps_partial_reg<CT, kRegColors>), dim3(nparts), dim3(kBlock), 0, s,
+                               x, (const CT *)p->d_color, p->N, p->d_partial, ldp);
+    } else {
+        nparts = p->seg_chunks;
+        ldp = C;
+        hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,
+                           x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial);
+    }
+    hipLaunchKernelGGL(k_eps_finalize, dim3(C), dim3(kBlock), 0, s, p->d_partial, nparts, ldp, relstep,
+                       absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir)
+{
+    return p->color8 ? launch_eps_t<uint8_t>(p, x, relstep, absstep, dir)
+                     : launch_eps_t<int32_t>(p, x, relstep, absstep, dir);
+}
+
+template <typename CT, int MODE>
+static int launch_perturb_tm(fd_plan *p, const double *x, int c_lo, int B)
+{
+    const int64_t j0 = p->x0 & ~(int64_t)1;  // even start => 16-B aligned pairs
+    const int64_t j1 = p->x1;
+    const int g = grid_for((j1 - j0 + 1) / 2, kBlock, p->ctx->num_cus);
+    hipLaunchKernelGGL((k_perturb<CT, MODE>), dim3(g), dim3(kBlock), 0, p->ctx->stream, x,
+                       (const CT *)p->d_color, p->d_eps, c_lo, B, j0, j1, p->d_X, p->ldx);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int launch_perturb(fd_plan *p, const double *x, int c_lo, int B)
+{
+#define FD_DISPATCH(CT)                                                        \
+    switch (p->fdtype) {                                                       \
+    case FD_FORWARD: return launch_perturb_tm<CT, 0>(p, x, c_lo, B);           \
+    case FD_CENTRAL: return launch_perturb_tm<CT, 1>(p, x, c_lo, B);           \
+    default: return launch_perturb_tm<CT, 2>(p, x, c_lo, B);                   \
+    }
+    if (p->color8) { FD_DISPATCH(uint8_t) } else { FD_DISPATCH(int32_t) }
+#undef FD_DISPATCH
+}
+
+template <typename CT, int MODE>
+static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs)
+{
+    hipStream_t s = p->ctx->stream;
+    const int B = c_hi - c_lo;
+    const double *FXa = p->d_FX;
+    const double *FXb = (MODE == 0) ? fx : p->d_FX + (int64_t)B * p->ldf;  // central: minus points
+    const CT *color = (const CT *)p->d_color;
+    switch (p->kind) {
+    case K_CSC:
+    case K_CSC_DENSE:
+    case K_COO_DENSE: {
+        if (p->nnz_local == 0) break;
+        const int64_t g = (p->nnz_local + kTile - 1) / kTile;
+        const size_t shm = (B <= kEpsLdsMax) ? sizeof(double) * (size_t)B : 0;
+        const int vec_ok = (((uintptr_t)outs[0]) & 15) == 0;
+        if (p->kind == K_CSC)
+            hipLaunchKernelGGL((k_decompress_list<CT, MODE, false>), dim3((unsigned)g), dim3(kBlock), shm, s,
+                               p->d_rowval, (const CT *)p->d_nzcolor, nullptr, FXa, FXb, p->ldf, p->d_eps,
+                               c_lo, c_hi, outs[0], p->nnz_local, vec_ok);
+        else
+            hipLaunchKernelGGL((k_decompress_list<CT, MODE, true>), dim3((unsigned)g), dim3(kBlock), shm, s,
+                               p->d_rowval, (const CT *)p->d_nzcolor, p->d_dest, FXa, FXb, p->ldf, p->d_eps,
+                               c_lo, c_hi, outs[0], p->nnz_local, 0);
+        break;
+    }
+    case K_TRIDIAG: {
+        const int g = grid_for(p->col1 - p->col0, kBlock, p->ctx->num_cus);
+        hipLaunchKernelGGL((k_decompress_tridiag<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
+                           p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0], outs[1], outs[2]);
+        break;
+    }
+    case K_BANDED: {
+        const int g = grid_for((p->col1 - p->col0) * (p->l + p->u + 1), kBlock, p->ctx->num_cus);
+        hipLaunchKernelGGL((k_decompress_banded<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
+                           p->ldf, p->d_eps, c_lo, c_hi, p->M, p->l, p->u, p->col0, p->col1, outs[0]);
+        break;
+    }
+    case K_COLRANGE: {
+        const int g = grid_for(p->col1 - p->col0, kBlock / 64, p->ctx->num_cus);
+        hipLaunchKernelGGL((k_decompress_colrange<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, p->d_cr_rlo,
+                           p->d_cr_cnt, p->d_cr_off, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->col0,
+                           p->col1 - p->col0, outs[0]);
+        break;
+    }
+    default: break;
+    }
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs)
+{
+#define FD_DISPATCH(CT)                                                                 \
+    switch (p->fdtype) {                                                                \
+    case FD_FORWARD: return launch_decompress_tm<CT, 0>(p, fx, c_lo, c_hi, outs);       \
+    case FD_CENTRAL: return launch_decompress_tm<CT, 1>(p, fx, c_lo, c_hi, outs);       \
+    default: return launch_decompress_tm<CT, 2>(p, fx, c_lo, c_hi, outs);               \
+    }
+    if (p->color8) { FD_DISPATCH(uint8_t) } else { FD_DISPATCH(int32_t) }
+#undef FD_DISPATCH
+}
+
+int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v)
+{
+    if (n <= 0) return FD_OK;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, kBlock, ctx->num_cus)), dim3(kBlock), 0, ctx->stream, ptr, n, v);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16)
+{
+    hipLaunchKernelGGL(k_stream_copy, dim3(grid_for(n16, kBlock, ctx->num_cus)), dim3(kBlock), 0, ctx->stream,
+                       (const double2 *)src, (double2 *)dst, n16);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+}  // namespace fdjac

@@ -1,0 +1,114 @@
+"""ctypes binding of libfdjac (include/fdjac.h) -- the same stub a Julia `ccall` shim uses.
+
+The library is built in-tree by ``csrc/Makefile`` (``hipcc --offload-arch=gfx950``) into
+``finitediff.jl_amd/lib/libfdjac.so``.  There is no fallback: if the shared object is missing
+``load()`` raises, and every compute entry point needs a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libfdjac.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FD_OK = 0
+FORWARD, CENTRAL, COMPLEX = 0, 1, 2
+HOST, DEVICE = 0, 1
+FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
+STAGES = ("eps", "perturb", "f", "decompress", "total")
+(INFO_M, INFO_N, INFO_NCOLORS, INFO_NOUTS, INFO_OUT0_LEN, INFO_OUT1_LEN, INFO_OUT2_LEN, INFO_ROW_BEGIN,
+ INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN) = range(14)
+(F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE) = range(6)
+FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
+            "blockcoupled": F_BLOCKCOUPLED, "nonsquare": F_NONSQUARE}
+
+# int f(fctx, fx, x, nbatch, x_stride, fx_stride, row_begin, row_end, is_complex, stream)
+F_LAUNCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                       C.c_int64, C.c_int, C.c_void_p)
+
+EXPORTS = (
+    "fd_version", "fd_last_error", "fd_ctx_create", "fd_ctx_destroy", "fd_ctx_stream", "fd_ctx_synchronize",
+    "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
+    "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
+    "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
+    "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
+    "fd_stream_copy_gbps",
+)
+
+
+class PlanOpts(C.Structure):
+    _fields_ = [("fdtype", C.c_int32), ("reserved0", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
+                ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64)]
+
+
+class FdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfdjac error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s", "-j4"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen libfdjac.so and declare the prototypes.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `make -C %s` (hipcc, gfx950). There is no CPU fallback." % (SO_PATH, CSRC))
+    try:  # share torch's HIP runtime (same SONAME) so device pointers are interchangeable
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the raw ABI
+        pass
+    L = C.CDLL(SO_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    pp = C.POINTER(C.c_void_p)
+    L.fd_version.restype = i32
+    L.fd_last_error.restype = C.c_char_p
+    L.fd_ctx_create.argtypes = [i32, vp, pp]
+    L.fd_ctx_destroy.argtypes = [vp]
+    L.fd_ctx_stream.argtypes = [vp]
+    L.fd_ctx_stream.restype = vp
+    L.fd_ctx_synchronize.argtypes = [vp]
+    po = C.POINTER(PlanOpts)
+    L.fd_plan_create_csc.argtypes = [vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_csc_dense.argtypes = [vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_coo_dense.argtypes = [vp, i64, i64, vp, vp, i64, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_entries.argtypes = [vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_tridiagonal.argtypes = [vp, i64, vp, i32, po, pp]
+    L.fd_plan_create_banded.argtypes = [vp, i64, i64, i64, i64, vp, i32, po, pp]
+    L.fd_plan_create_blockbanded.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_destroy.argtypes = [vp]
+    L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]
+    L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
+    L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
+    L.fd_plan_get_epsilons.argtypes = [vp, C.POINTER(dbl)]
+    L.fd_plan_enable_timing.argtypes = [vp, i32]
+    L.fd_plan_get_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.fd_builtin_f_create.argtypes = [vp, i32, C.POINTER(i64), i32, C.POINTER(F_LAUNCH), pp]
+    L.fd_builtin_f_destroy.argtypes = [vp]
+    L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.fd_stream_copy_gbps.argtypes = [vp, i64, i32, C.POINTER(dbl)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("fd_last_error", "fd_ctx_stream"):
+            fn.restype = i32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != FD_OK:
+        raise FdError(rc, load().fd_last_error().decode("utf-8", "replace"))

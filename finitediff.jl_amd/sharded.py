@@ -1,0 +1,90 @@
+"""Multi-GPU decomposition of one coloured Jacobian (one process per GPU, torch.distributed).
+
+The path shards by **contiguous column ranges** (all colours on every rank): for CSC storage a
+column range owns a contiguous slice of nzval, so the only exchange step is one gather of
+slices over RCCL/xGMI -- no data-path collective before it.  Colour-only sharding (as the
+north-star words it) would cap at C ranks (3 for a tridiagonal pattern), so colours x column
+range it is.  x is replicated; every rank reduces the full x for the
+step sizes with the same deterministic kernel, so eps is bit-identical across ranks without
+communication.
+
+Nothing here touches the GPU directly: the local compute is a libfdjac plan with a column
+window (fd_plan_opts.col_begin/col_end); the gather is torch.distributed (backend "nccl" is
+RCCL on ROCm; "gloo" for the CPU tests).
+"""
+import numpy as np
+
+
+def partition_columns(colptr, world):
+    """Column cuts (world+1,) balancing stored entries per rank; colptr is 1-based Int64 (N+1,)."""
+    colptr = np.asarray(colptr, dtype=np.int64)
+    n = colptr.size - 1
+    nnz = int(colptr[-1] - colptr[0])
+    targets = colptr[0] + (nnz * np.arange(world + 1, dtype=np.int64)) // world
+    cuts = np.searchsorted(colptr, targets, side="left").astype(np.int64)
+    cuts[0], cuts[-1] = 0, n
+    return np.maximum.accumulate(np.minimum(cuts, n))
+
+
+def entry_ranges(colptr, cuts):
+    """0-based [begin,end) of each rank's stored entries."""
+    colptr = np.asarray(colptr, dtype=np.int64)
+    return [(int(colptr[a] - 1), int(colptr[b] - 1)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def x_window(cuts, rank, n, lower_bw, upper_bw, f_halo):
+    """Entries of x a windowed stencil f! needs for the rows touched by the rank's columns:
+    rows [c0-upper_bw, c1+lower_bw) widened by the f!'s own stencil radius."""
+    c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
+    return max(c0 - upper_bw - f_halo, 0), min(c1 + lower_bw + f_halo, n)
+
+
+def all_gather_slices(local, counts, dist=None, group=None):
+    """Assemble the full value vector from per-rank slices of lengths `counts`.
+
+    One collective: slices are padded to the longest and all-gathered into a (world, maxlen)
+    buffer (ncclAllGather on RCCL), then compacted.  Returns the full vector on every rank.
+    """
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    world = len(counts)
+    maxlen = int(max(counts)) if counts else 0
+    if world == 1:
+        return local
+    send = local
+    if local.numel() != maxlen:
+        send = torch.zeros(maxlen, dtype=local.dtype, device=local.device)
+        send[: local.numel()] = local
+    buf = torch.empty(world * maxlen, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, send, group=group)
+    if all(int(c) == maxlen for c in counts):
+        return buf
+    return torch.cat([buf[r * maxlen: r * maxlen + int(counts[r])] for r in range(world)])
+
+
+class AllGatherBuffers:
+    """Pre-allocated buffers for the steady-state gather (no allocation inside the timed step)."""
+
+    def __init__(self, counts, device, dtype):
+        import torch
+        self.counts = [int(c) for c in counts]
+        self.world = len(counts)
+        self.maxlen = max(self.counts) if self.counts else 0
+        self.buf = torch.empty(self.world * self.maxlen, dtype=dtype, device=device)
+        self.uniform = all(c == self.maxlen for c in self.counts)
+
+    def local_view(self, rank):
+        """The rank's own padded slot: computing straight into it makes the gather in-place."""
+        return self.buf[rank * self.maxlen: (rank + 1) * self.maxlen]
+
+    def gather(self, rank, dist, group=None):
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.buf, self.local_view(rank), group=group)
+        return self.buf
+
+    def compact(self):
+        import torch
+        if self.uniform:
+            return self.buf
+        return torch.cat([self.buf[r * self.maxlen: r * self.maxlen + self.counts[r]] for r in range(self.world)])

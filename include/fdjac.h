@@ -1,0 +1,194 @@
+/*
+ * fdjac.h -- C ABI of libfdjac: the MI355X (gfx950) implementation of FiniteDiff.jl's
+ * coloured sparse-Jacobian hot path.
+ *
+ * One entry point, fd_jacobian(), replaces the body of the cached in-place
+ *     FiniteDiff.finite_difference_jacobian!(J, f, x, cache::JacobianCache, f_in; relstep,
+ *                                            absstep, colorvec, sparsity, dir)
+ * (reference: src/jacobians.jl:504-653) for a cache whose `sparsity`/`colorvec` have been
+ * compiled into a device-resident *plan*.  Plans play the role of the reference's
+ * per-matrix-type `_colorediteration!` overloads (the package-extension plugin surface):
+ *
+ *   fd_plan_create_csc          ext/FiniteDiffSparseArraysExt.jl:38-47,51-52 (common-pattern fast path)
+ *   fd_plan_create_csc_dense    ext/FiniteDiffSparseArraysExt.jl:20-28       (sparse pattern, dense J)
+ *   fd_plan_create_coo_dense    src/iteration_utils.jl:25-32 + src/jacobians.jl:473-488,524-528
+ *   fd_plan_create_entries      any J storage enumerated by the caller (incl. ext/FiniteDiffBlockBandedMatricesExt.jl:16-42)
+ *   fd_plan_create_tridiagonal  src/iteration_utils.jl:25-32 on a LinearAlgebra.Tridiagonal J
+ *   fd_plan_create_banded       ext/FiniteDiffBandedMatricesExt.jl:13-27
+ *   fd_plan_create_blockbanded  ext/FiniteDiffBlockBandedMatricesExt.jl:44-68
+ *
+ * Step sizes follow src/epsilons.jl:26-29,50-53,104-107 with the masked-norm rule of
+ * src/jacobians.jl:559-561 / 600-602 / 624.  Arithmetic is Float64.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no exceptions, int status returns (0 = FD_OK);
+ *     fd_last_error() returns the calling thread's last message.
+ *   - pattern / colour arrays are HOST pointers read once at plan creation; idx_bytes is 4 or
+ *     8, idx_base 0 or 1 (Julia passes its own Int64 1-based arrays untouched).
+ *   - colorvec holds colours 1..C (the reference's convention); columns whose colour is < 1
+ *     are never perturbed and their stored entries are written as 0 (fill_matrix!).
+ *   - x, f_in and the outputs are HOST or DEVICE pointers as stated by the FD_HOST/FD_DEVICE
+ *     argument next to them.  Device pointers should be 16-byte aligned (others are staged).
+ *   - x is never written (stronger than the reference, whose central arm perturbs and
+ *     restores the caller's x: src/jacobians.jl:604,620).
+ *   - one in-flight fd_jacobian per plan; different plans may be used from different threads.
+ */
+#ifndef FDJAC_H
+#define FDJAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDJAC_VERSION 100
+
+typedef struct fd_ctx fd_ctx;
+typedef struct fd_plan fd_plan;
+
+enum fd_status {
+    FD_OK = 0,
+    FD_ERR_ARG = 1,         /* null / out-of-range argument */
+    FD_ERR_SHAPE = 2,       /* DimensionMismatch (src/jacobians.jl:516) or inconsistent pattern */
+    FD_ERR_UNSUPPORTED = 3, /* fdtype_error (src/epsilons.jl:159-167) / not built */
+    FD_ERR_HIP = 4,         /* HIP runtime failure (message has the hipError string) */
+    FD_ERR_CALLBACK = 5,    /* the f! launcher returned non-zero */
+    FD_ERR_NOMEM = 6,
+    FD_ERR_NODEVICE = 7     /* no usable gfx950 device */
+};
+
+enum fd_fdtype { FD_FORWARD = 0, FD_CENTRAL = 1, FD_COMPLEX = 2 }; /* Val(:forward|:central|:complex) */
+enum fd_memkind { FD_HOST = 0, FD_DEVICE = 1 };
+
+/*
+ * The user's f!(fx, x) as a *launcher*: enqueue on `stream` (a hipStream_t) the evaluation of
+ * nbatch independent points  fx[b*fx_stride + r] = f(x[b*x_stride + :])[r],  b = 0..nbatch-1.
+ * Strides are in elements; elements are double, or (re,im) double pairs when is_complex != 0.
+ * Only rows row_begin <= r < row_end are consumed by the library (the whole range unless the
+ * plan has a column window); writing the other rows is allowed.  Must not synchronise; return
+ * 0 on success.  Replaces the calls at src/jacobians.jl:541,563,605-606,634.
+ */
+typedef int (*fd_f_launch)(void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride,
+                           int64_t fx_stride, int64_t row_begin, int64_t row_end, int is_complex,
+                           void *stream);
+
+typedef struct fd_plan_opts {
+    int32_t fdtype;        /* enum fd_fdtype */
+    int32_t reserved0;
+    int64_t col_begin;     /* column window [col_begin, col_end), 0-based; 0,0 = all columns.   */
+    int64_t col_end;       /*   outputs then hold only the window's stored entries (multi-GPU)  */
+    int64_t x_begin;       /* entries of x the windowed f! reads, [x_begin, x_end); 0,0 = all   */
+    int64_t x_end;
+    int64_t scratch_bytes; /* cap for the batched perturbed-point scratch; 0 = default (64 GiB) */
+} fd_plan_opts;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* stream: an existing hipStream_t to enqueue on (e.g. the caller's), or NULL to create one. */
+int fd_ctx_create(int device, void *stream, fd_ctx **out);
+int fd_ctx_destroy(fd_ctx *ctx);
+void *fd_ctx_stream(fd_ctx *ctx);
+int fd_ctx_synchronize(fd_ctx *ctx);
+const char *fd_last_error(void);
+int fd_version(void);
+
+/* ---- plans ------------------------------------------------------------------------------ */
+/* SparseMatrixCSC J sharing colptr/rowval with `sparsity`: outs[0] = nzval (nnz of the window). */
+int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
+                       int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                       const fd_plan_opts *opts, fd_plan **out);
+/* SparseMatrixCSC sparsity, dense column-major J (M x N): outs[0] = J. */
+int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr,
+                             const void *rowval, int idx_bytes, int idx_base, const void *colorvec,
+                             int color_bytes, const fd_plan_opts *opts, fd_plan **out);
+/* rows_index / cols_index lists (findstructralnz), dense column-major J: outs[0] = J. */
+int fd_plan_create_coo_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index,
+                             const void *cols_index, int64_t nnz, int idx_bytes, int idx_base,
+                             const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                             fd_plan **out);
+/* The general form: stored entry k lives at row rows_index[k], column cols_index[k] and is
+   written to outs[0][dest[k]] (dest 0-based, < out_len).  outs[0] is zero-filled first.  Any
+   matrix type whose storage the caller can enumerate goes through here -- e.g. a
+   BandedBlockBandedMatrix (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42) or a SparseMatrixCSC
+   J whose pattern differs from `sparsity` (ext/FiniteDiffSparseArraysExt.jl:20-28). */
+int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index,
+                           const void *cols_index, const int64_t *dest, int64_t nnz,
+                           int64_t out_len, int idx_bytes, int idx_base, const void *colorvec,
+                           int color_bytes, const fd_plan_opts *opts, fd_plan **out);
+/* LinearAlgebra.Tridiagonal J (N x N): outs = {dl (N-1), d (N), du (N-1)}. */
+int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd_plan **out);
+/* BandedMatrix J (M x N, bandwidths l,u): outs[0] = data, (l+u+1) x N column-major,
+   data[(u + i - j) + (l+u+1)*j] = J[i,j] (0-based), out-of-matrix slots written as 0. */
+int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u,
+                          const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                          fd_plan **out);
+/* BlockBandedMatrix J: square block structure blk_sizes[nblk], block bandwidths (bl,bu),
+   block_starts = (bl+bu+1) x nblk band storage of the idx_base-based start of block (K,J) in
+   data: block_starts[(bu + K - J) + (bl+bu+1)*J] (0-based K,J); block_strides[J] = column
+   stride of block-column J.  outs[0] = data. */
+int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl,
+                               int64_t bu, const void *block_starts, const void *block_strides,
+                               int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd_plan **out);
+int fd_plan_destroy(fd_plan *plan);
+
+/* Introspection: what[] selectors for fd_plan_info. */
+enum fd_plan_info_key {
+    FD_INFO_M = 0, FD_INFO_N = 1, FD_INFO_NCOLORS = 2, FD_INFO_NOUTS = 3,
+    FD_INFO_OUT0_LEN = 4, FD_INFO_OUT1_LEN = 5, FD_INFO_OUT2_LEN = 6,
+    FD_INFO_ROW_BEGIN = 7, FD_INFO_ROW_END = 8, FD_INFO_NCHUNKS = 9, FD_INFO_SCRATCH_BYTES = 10,
+    FD_INFO_NNZ_LOCAL = 11, FD_INFO_FCALLS_LAST = 12, FD_INFO_ENTRY_BEGIN = 13
+};
+int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/*
+ * Fill the Jacobian's stored values.  f_in may be NULL (forward: f!(fx,x) is then evaluated
+ * once, src/jacobians.jl:540-545); it is ignored for central / complex.  relstep <= 0 selects
+ * default_relstep (src/epsilons.jl:133-144); absstep < 0 selects absstep = relstep.  dir is
+ * the reference's `dir` (true/+1 or -1; forward only).  Blocks until outs are complete.
+ */
+int fd_jacobian(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, int x_kind,
+                const void *f_in, int f_in_kind, double relstep, double absstep, double dir,
+                void *const *outs, int out_kind);
+/* Same, but only enqueues on the context's stream (device x / f_in / outs only). */
+int fd_jacobian_async(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *f_in,
+                      double relstep, double absstep, double dir, void *const *outs);
+
+/* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
+int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
+
+/* Per-stage GPU time of the calls made since timing was enabled (HIP events on the plan's
+   stream).  stage: 0 eps-reduce, 1 perturb, 2 f!, 3 diff+decompress, 4 whole call.
+   ms_sum / launches accumulate; collect implies a stream synchronise. */
+enum fd_stage { FD_STAGE_EPS = 0, FD_STAGE_PERTURB = 1, FD_STAGE_F = 2, FD_STAGE_DECOMPRESS = 3,
+                FD_STAGE_TOTAL = 4, FD_NSTAGES = 5 };
+int fd_plan_enable_timing(fd_plan *plan, int on);
+int fd_plan_get_timings(fd_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+
+/* ---- built-in device f! families (the reference's test fixtures + benchmark configs) ---- */
+enum fd_builtin_family {
+    FD_F_TRIDIAG = 0,      /* params {n}: dx[i] = x[i-1] - 2x[i] + x[i+1]   (test/coloring_tests.jl:5-13) */
+    FD_F_TRIDIAG_NL = 1,   /* params {n}: ... + x[i]^2 * x[i+1]             (J depends on x)              */
+    FD_F_LAP5 = 2,         /* params {nx,ny}: zero-Dirichlet 5-point Laplacian                              */
+    FD_F_CLAMP5 = 3,       /* params {nx,ny}: clamped-edge sum stencil       (test/coloring_tests.jl:99-108) */
+    FD_F_BLOCKCOUPLED = 4, /* params {nblk,bs}: x_b[k]*(sig_{b-1}+sig_b+sig_{b+1}) + sin(x_b[k])            */
+    FD_F_NONSQUARE = 5     /* params {n}: (x1-3)^2 + x1*x2 + (x2+4)^2 - 3    (test/coloring_tests.jl:124-133) */
+};
+int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,
+                        fd_f_launch *fn_out, void **fctx_out);
+int fd_builtin_f_destroy(void *fctx);
+/* number of launcher invocations / points evaluated since creation (call-count parity tests) */
+int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
+
+/* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
+   16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
+   the achieved figures are quoted against. */
+int fd_stream_copy_gbps(fd_ctx *ctx, int64_t bytes, int iters, double *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDJAC_H */

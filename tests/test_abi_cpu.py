@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: libfdjac.so builds for gfx950, loads, exports every
+symbol include/fdjac.h declares, and fails loudly (no fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    fd.lib.build()
+    return fd.lib.load()
+
+
+def test_header_symbols_all_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "fdjac.h")).read()
+    declared = set(re.findall(r"^(?:int|void \*|const char \*)\s*(fd_[a-z0-9_]+)\(", hdr, re.M))
+    assert len(declared) >= 20
+    assert declared == set(fd.lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.fd_version() == 100
+
+
+def test_no_gpu_fails_loudly(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = L.fd_ctx_create(0, None, C.byref(h))
+    assert rc == 7 and b"no HIP device" in L.fd_last_error()  # FD_ERR_NODEVICE
+    with pytest.raises(RuntimeError):
+        fd.Context(0)
+    with pytest.raises(RuntimeError):
+        fd.BuiltinF("tridiag", 10)
+
+
+def test_plan_opts_layout():
+    # struct fd_plan_opts: int32 x2 then five int64 (include/fdjac.h)
+    assert C.sizeof(fd.lib.PlanOpts) == 8 + 5 * 8
+    assert fd.lib.PlanOpts.col_begin.offset == 8 and fd.lib.PlanOpts.scratch_bytes.offset == 40
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under the product package may reference it
+    pkg = os.path.join(ROOT, "finitediff.jl_amd")
+    for dp, _dn, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".jl")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dp, fn)
+
+
+def test_pattern_builders():
+    P = fd.patterns
+    colptr, rowval = P.tridiag_csc(6)
+    assert colptr.tolist() == [1, 3, 6, 9, 12, 15, 17]
+    assert rowval.tolist() == [1, 2, 1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6, 5, 6]
+    # lap5 colouring is a valid distance-2 colouring: no two columns of one colour share a row
+    nx, ny = 7, 6
+    colptr, rowval = P.lap5_csc(nx, ny)
+    colors = P.lap5_colors(nx, ny)
+    cols = P.csc_cols(colptr)
+    seen = set()
+    for r, c in zip(rowval, cols):
+        key = (int(r), int(colors[c - 1]))
+        assert key not in seen
+        seen.add(key)
+    lay = P.BlockBandedLayout([2, 3, 2, 4], 1, 1)
+    assert lay.data_len == 2 * 5 + 3 * 7 + 2 * 9 + 4 * 6
+    d = np.arange(lay.data_len, dtype=float)
+    A = lay.to_dense(d)
+    r, c = np.nonzero(A + (A == 0) * 0)  # positions; entry 0 of data maps to A[0,0]
+    assert A[0, 0] == 0 and A[1, 0] == 1 and A[4, 0] == 4 and A[0, 2] == 10
+    assert lay.index_of(np.array([4]), np.array([0]))[0] == 4
+
+
+def test_default_relstep_and_fdtype_names():
+    assert fd.default_relstep("forward") == np.sqrt(np.finfo(float).eps)
+    assert fd.default_relstep("Val{:central}") == np.cbrt(np.finfo(float).eps)
+    with pytest.raises(ValueError):
+        fd.default_relstep("backward")

@@ -1,0 +1,405 @@
+"""GPU parity: libfdjac (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): per stored entry
+    |J_gpu - J_cpu| <= 1e-6*|J_cpu| + 16*eps(Float64)*max|f| / |eps_c|
+i.e. 1e-6 relative with an epsilon-scaled absolute floor: the oracle perturbs x in place and
+un-perturbs it (as the reference does), the GPU perturbs from the pristine x, and a forward
+difference amplifies ulp(f) by 1/eps.  The step sizes themselves must agree to 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+EPS64 = np.finfo(np.float64).eps
+FDTYPES = ["forward", "central", "complex"]
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def _tol_ok(g, c, eps_min, fscale, what):
+    g, c = np.asarray(g), np.asarray(c)
+    atol = 16 * EPS64 * fscale / abs(eps_min)
+    bad = np.abs(g - c) > 1e-6 * np.abs(c) + atol
+    assert not bad.any(), "%s: %d entries off, worst %.3e (atol %.1e)" % (
+        what, int(bad.sum()), float(np.max(np.abs(g - c))), atol)
+
+
+def _oracle_eps(x, colors, fdtype):
+    if fdtype == "complex":
+        return np.full(int(colors.max()), EPS64)
+    rel = fd.default_relstep(fdtype)
+    out = []
+    for c in range(1, int(colors.max()) + 1):
+        out.append(max(rel * np.sqrt(np.linalg.norm(x * (colors == c))), rel))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("fdtype,ncalls", [("forward", 4), ("central", 6), ("complex", 3)])
+def test_tridiag_csc_reference_fixture(oracle, fdtype, ncalls):
+    # test/coloring_tests.jl:33-49 on the device, through the mirrored Julia API
+    N = 30
+    x = np.random.default_rng(11).random(N)
+    colors = np.tile([1, 2, 3], 10)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+    f = fd.BuiltinF("tridiag", N)
+    cache = fd.JacobianCache(_dev(x), fdtype, colorvec=colors, sparsity=J)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), cache)
+    assert f.fcalls == ncalls
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    got = J.nzval.cpu().numpy()
+    eps = cache.last_plan.epsilons()
+    assert np.allclose(eps, _oracle_eps(x, colors, fdtype), rtol=1e-12, atol=0)
+    _tol_ok(got, ref["out"], np.min(np.abs(eps)), 4.0, "tridiag csc " + fdtype)
+    # and the exact answer (-2 / 1), as the reference asserts with isapprox
+    dense = P.csc_to_dense(N, N, colptr, rowval, got)
+    exact = np.diag(np.full(N, -2.0)) + np.diag(np.ones(N - 1), 1) + np.diag(np.ones(N - 1), -1)
+    assert np.linalg.norm(dense - exact) <= 1.5e-8 * np.linalg.norm(exact) * 4
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("N", [1, 2, 3, 257, 100003])
+def test_tridiag_csc_sizes_nonlinear(oracle, fdtype, N):
+    x = np.random.default_rng(100 + N).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    f = fd.BuiltinF("tridiag_nl", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors)
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    assert f.fcalls == ref["fcalls"]
+    eps_min = np.min(np.abs(_oracle_eps(x, colors, fdtype)))
+    _tol_ok(J.nzval.cpu().numpy(), ref["out"], eps_min, 5.0, "tridiag_nl N=%d %s" % (N, fdtype))
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_host_arrays_and_f_in(oracle, fdtype):
+    # numpy in / numpy out through the ABI's host path; f_in reuse (src/jacobians.jl:540-545)
+    N = 1000
+    x = np.random.default_rng(5).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, np.zeros(rowval.size))
+    f = fd.BuiltinF("tridiag_nl", N)
+    ofx = oracle.Fixture("tridiag_nl", N)
+    fin = None
+    if fdtype == "forward":
+        xm, xp = np.concatenate([[0.0], x[:-1]]), np.concatenate([x[1:], [0.0]])
+        fin = (xm - 2 * x) + xp + (x * x) * xp
+    fd.finite_difference_jacobian_b(J, f, x, fdtype, np.float64, fin, colorvec=colors)
+    ref = oracle.jacobian(fdtype, ofx, x, colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval, f_in=fin)
+    assert f.fcalls == ref["fcalls"]
+    _tol_ok(J.nzval, ref["out"], np.min(np.abs(_oracle_eps(x, colors, fdtype))), 5.0, "host path " + fdtype)
+
+
+@pytest.mark.parametrize("fdtype,ncalls", [("forward", 4), ("central", 6), ("complex", 3)])
+def test_dense_J_sparse_pattern(oracle, fdtype, ncalls):
+    # test/coloring_tests.jl:51-70
+    N = 30
+    x = np.random.default_rng(12).random(N)
+    colors = np.tile([1, 2, 3], 10)
+    colptr, rowval = P.tridiag_csc(N)
+    sp = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    J = torch.full((N, N), float("nan"), dtype=torch.float64, device="cuda").t()  # column-major
+    f = fd.BuiltinF("tridiag", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors, sparsity=sp)
+    assert f.fcalls == ncalls
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag", N), x, colors, kind=oracle.PAT_CSC_DENSEJ,
+                          colptr=colptr, rowval=rowval)
+    _tol_ok(J.cpu().numpy(), ref["out"], np.min(np.abs(_oracle_eps(x, colors, fdtype))), 4.0, "dense J " + fdtype)
+
+
+@pytest.mark.parametrize("fdtype,ncalls", [("forward", 4), ("central", 6), ("complex", 3)])
+def test_tridiagonal_type(oracle, fdtype, ncalls):
+    # test/coloring_tests.jl:72-88,94-96
+    N = 30
+    x = np.random.default_rng(13).random(N)
+    colors = np.tile([1, 2, 3], 10)
+    J = fd.Tridiagonal(_dev(np.full(N - 1, np.nan)), _dev(np.full(N, np.nan)), _dev(np.full(N - 1, np.nan)))
+    f = fd.BuiltinF("tridiag", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors)
+    assert f.fcalls == ncalls
+    colptr, rowval = P.tridiag_csc(N)
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag", N), x, colors, kind=oracle.PAT_COO_TRIDIAG,
+                          rows_index=rowval, cols_index=P.csc_cols(colptr))
+    em = np.min(np.abs(_oracle_eps(x, colors, fdtype)))
+    for got, want, nm in zip((J.dl, J.d, J.du), ref["out"], ("dl", "d", "du")):
+        _tol_ok(got.cpu().numpy(), want, em, 4.0, "Tridiagonal." + nm)
+
+
+@pytest.mark.parametrize("l,u,M,N", [(1, 1, 30, 30), (2, 1, 40, 37), (0, 3, 25, 31), (3, 0, 33, 20)])
+def test_banded(oracle, l, u, M, N):
+    # test/coloring_tests.jl:90-92 plus rectangular / asymmetric bands
+    rng = np.random.default_rng(14)
+    x = rng.random(N)
+    colors = P.cyclic_colors(N, l + u + 1)
+    A = rng.random((M, N))  # linear f(x) = A_band x so every band entry is exercised
+
+    def band_mask():
+        i, j = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+        return (i - j <= l) & (j - i <= u)
+
+    Ab = A * band_mask()
+    At = _dev(Ab)
+    f = fd.TorchF(lambda fx, xx: fx.copy_((At.to(xx.dtype) @ xx)), M, N)
+    data = torch.full((N, l + u + 1), float("nan"), dtype=torch.float64, device="cuda").t()
+    J = fd.BandedMatrix(data, M, l, u)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), "forward", colorvec=colors)
+    of = oracle.PyF(lambda fx, xx: fx.__setitem__(slice(None), Ab @ xx), M, N)
+    ref = oracle.jacobian("forward", of, x, colors, M=M, kind=oracle.PAT_BANDED, l=l, u=u)
+    got = data.cpu().numpy()
+    inside = np.zeros_like(got, dtype=bool)
+    for j in range(N):
+        for k in range(l + u + 1):
+            r = j - u + k
+            inside[k, j] = 0 <= r < M
+    em = np.min(np.abs(_oracle_eps(x, colors, "forward")))
+    _tol_ok(got[inside], ref["out"][inside], em, float(np.abs(Ab @ x).max()) + 1.0, "banded")
+    assert np.all(got[~inside] == 0.0)
+    assert np.allclose(P.banded_to_dense(got, M, N, l, u), Ab, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "complex"])
+def test_stencil_blockbanded_and_sparse(oracle, fdtype):
+    # test/coloring_tests.jl:99-119 : clamped 5-point stencil; block-banded J and sparse J agree
+    nx = ny = 100
+    N = nx * ny
+    x = np.random.default_rng(15).random(N)
+    colptr, rowval = P.lap5_csc(nx, ny)
+    k = np.arange(N)
+    colors9 = 3 * ((k // nx) % 3) + (k % nx) % 3 + 1
+    f = fd.BuiltinF("clamp5", nx, ny)
+    Js = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    fd.finite_difference_jacobian_b(Js, f, _dev(x), fdtype, colorvec=colors9)
+    refs = oracle.jacobian(fdtype, oracle.Fixture("clamp5", nx, ny), x, colors9, kind=oracle.PAT_CSC_COMMON,
+                           colptr=colptr, rowval=rowval)
+    em = np.min(np.abs(_oracle_eps(x, colors9, fdtype)))
+    _tol_ok(Js.nzval.cpu().numpy(), refs["out"], em, 5.0, "stencil csc")
+
+    lay = P.BlockBandedLayout(np.full(ny, nx), 1, 1)
+    colorsbb = lay.colors()
+    Jb = fd.BlockBandedMatrix(_dev(np.full(lay.data_len, np.nan)), lay)
+    f2 = fd.BuiltinF("clamp5", nx, ny)
+    fd.finite_difference_jacobian_b(Jb, f2, _dev(x), fdtype, colorvec=colorsbb)
+    assert f2.fcalls == (301 if fdtype == "forward" else 300)
+    refb = oracle.jacobian(fdtype, oracle.Fixture("clamp5", nx, ny), x, colorsbb, kind=oracle.PAT_BLOCKBANDED,
+                           blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts,
+                           block_strides=lay.block_strides, out_len=lay.data_len)
+    emb = np.min(np.abs(_oracle_eps(x, colorsbb, fdtype)))
+    gotb = Jb.data.cpu().numpy()
+    _tol_ok(gotb, refb["out"], emb, 5.0, "stencil block-banded")
+    at = lay.index_of(rowval - 1, P.csc_cols(colptr) - 1)
+    assert np.linalg.norm(gotb[at] - Js.nzval.cpu().numpy()) <= 1.5e-8 * np.linalg.norm(gotb[at]) * 10
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_nonsquare_with_cache(oracle, fdtype):
+    # test/coloring_tests.jl:124-159
+    n = 4
+    x0 = np.concatenate([np.arange(1, n + 1) + 0.5, np.arange(1, n + 1) + 1.5])
+    A = np.zeros((n, 2 * n))
+    A[np.arange(n), np.arange(n)] = 1
+    A[np.arange(n), np.arange(n) + n] = 1
+    colptr, rowval = P.csc_from_dense(A)
+    colorvec = np.concatenate([np.full(n, 1), np.full(n, 2)])
+    sp = fd.SparseMatrixCSC(n, 2 * n, colptr, rowval, _dev(np.zeros(rowval.size)))
+    cache = fd.JacobianCache(_dev(x0.copy()), _dev(np.zeros(n)), _dev(np.zeros(n)), fdtype, sparsity=sp,
+                             colorvec=colorvec)
+    f = fd.BuiltinF("nonsquare", n)
+    fd.finite_difference_jacobian_b(sp, f, _dev(x0), cache)
+    assert f.fcalls == {"forward": 3, "central": 4, "complex": 2}[fdtype]
+    x1, x2 = x0[:n], x0[n:]
+    Jex = np.hstack([np.diag(2 * (x1 - 3) + x2), np.diag(x1 + 2 * (x2 + 4))])
+    J2 = P.csc_to_dense(n, 2 * n, colptr, rowval, sp.nzval.cpu().numpy())
+    assert np.linalg.norm(J2 - Jex) <= 1e-6 * np.linalg.norm(Jex)
+    ref = oracle.jacobian(fdtype, oracle.Fixture("nonsquare", n), x0, colorvec, M=n, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    _tol_ok(sp.nzval.cpu().numpy(), ref["out"], np.min(np.abs(_oracle_eps(x0, colorvec, fdtype))), 200.0, "nonsquare")
+
+
+DENSE_CASES = [
+    (lambda dx, x: dx.copy_(torch.stack([x[0] ** 2 + x[1] ** 2, x[0] + x[1]])), [5.0, 3.0], 2,
+     [[1, 1], [1, 1]], [[10, 6], [1, 1]]),
+    (lambda dx, x: dx.copy_(torch.stack([x[0] ** 2 + x[1] ** 2, x[0]])), [-3.0, 2.0], 2,
+     [[1, 1], [1, 0]], [[-6, 4], [1, 0]]),
+    (lambda dx, x: dx.copy_(torch.stack([x[0] ** 2 + x[1] ** 2 - x[0]])), [-3.0, 2.0], 1, [[1, 1]], [[-7, 4]]),
+    (lambda dx, x: dx.copy_(torch.stack([x[0] ** 2 + x[1] ** 2 - x[0], x[0] * x[1], x[0] * x[2], x[0]])),
+     [-3.0, 2.0, 13.3], 4, [[1, 1, 0], [1, 1, 0], [1, 0, 1], [1, 0, 0]],
+     [[-7.0, 4.0, 0], [2.0, -3.0, 0.0], [13.3, 0.0, -3.0], [1.0, 0.0, 0.0]]),
+    (lambda dx, x: dx.copy_(torch.stack([x[0] ** 2 + x[1] ** 2])), [5.0, 3.0], 1, [[1, 1]], [[10.0, 6.0]]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(DENSE_CASES)))
+def test_dense_matrix_sparsity_known_answers(case):
+    # test/coloring_tests.jl:171-219 with a user f! written in torch (the TorchF launcher)
+    fn, theta, M, sp, expected = DENSE_CASES[case]
+    N = len(theta)
+    J = np.full((M, N), np.nan)
+    f = fd.TorchF(fn, M, N)
+    cache = fd.JacobianCache(_dev(np.array(theta)), _dev(np.zeros(M)), _dev(np.zeros(M)), "forward",
+                             sparsity=np.array(sp))
+    fd.finite_difference_jacobian_b(J, f, np.array(theta), cache)
+    E = np.array(expected, float)
+    assert np.linalg.norm(J - E) <= 1.5e-8 * np.linalg.norm(E) * 10
+    assert f.fcalls == N + 1
+
+
+def test_poisoned_cache_and_x_untouched():
+    # test/cache_reuse_tests.jl:64-83 : garbage in the cache arrays must not matter; x stays bitwise intact
+    J_REF = np.array([[2.0, 0.0], [0.0, 3.0], [4.0, 0.0]])
+    colptr, rowval = P.csc_from_dense(J_REF)
+    sp = fd.SparseMatrixCSC(3, 2, colptr, rowval)
+
+    def foo(y, x):
+        y.copy_(torch.stack([2 * x[0], 3 * x[1], 4 * x[0]]))
+
+    for fdtype in FDTYPES:
+        cache = fd.JacobianCache(_dev(np.full(2, 1e10)), _dev(np.full(3, 1e10)),
+                                 None if fdtype == "complex" else _dev(np.full(3, 1e10)), fdtype)
+        x = _dev(np.array([1.0, 2.0]))
+        x_orig = x.clone()
+        J = np.zeros((3, 2))
+        fd.finite_difference_jacobian_b(J, fd.TorchF(foo, 3, 2), x, cache, sparsity=sp, colorvec=np.array([1, 2]))
+        assert np.allclose(J, J_REF, rtol=0, atol=1e-6), fdtype
+        assert torch.equal(x, x_orig)
+
+
+def test_colors_chunked_and_many(oracle):
+    # scratch cap forces several colour chunks; C > 8 exercises the segmented epsilon reduction; C > 254 int32 colours
+    N = 3000
+    x = np.random.default_rng(21).random(N)
+    colptr, rowval = P.tridiag_csc(N)
+    for C, cap in ((3, 1), (12, 200_000), (300, 0)):
+        colors = P.cyclic_colors(N, C)
+        for fdtype in FDTYPES:
+            J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+            plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
+            f = fd.BuiltinF("tridiag_nl", N)
+            plan.jacobian(f, _dev(x), [J.nzval])
+            if cap:
+                assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+            ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                                  colptr=colptr, rowval=rowval)
+            assert f.fcalls == ref["fcalls"]
+            eps = plan.epsilons()
+            assert np.allclose(eps, _oracle_eps(x, colors, fdtype), rtol=1e-12, atol=0)
+            _tol_ok(J.nzval.cpu().numpy(), ref["out"], np.min(np.abs(eps)), 5.0, "C=%d %s" % (C, fdtype))
+
+
+def test_uncoloured_columns_are_zero_filled(oracle):
+    # colour < 1 => column never perturbed; fill_matrix! leaves its stored entries at 0
+    N = 50
+    x = np.random.default_rng(3).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colors[[4, 17]] = 0
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+    fd.finite_difference_jacobian_b(J, fd.BuiltinF("tridiag", N), _dev(x), "forward", colorvec=colors)
+    ref = oracle.jacobian("forward", oracle.Fixture("tridiag", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    _tol_ok(J.nzval.cpu().numpy(), ref["out"], 1.5e-8, 4.0, "uncoloured")
+    cols = P.csc_cols(colptr)
+    assert np.all(J.nzval.cpu().numpy()[(cols == 5) | (cols == 18)] == 0.0)
+
+
+def test_dir_and_steps(oracle):
+    # dir = -1 and explicit relstep/absstep (src/epsilons.jl:26-29)
+    N = 300
+    x = np.random.default_rng(8).random(N) + 0.5
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    cache = fd.JacobianCache(_dev(x), "forward", colorvec=colors, sparsity=J)
+    fd.finite_difference_jacobian_b(J, fd.BuiltinF("tridiag_nl", N), _dev(x), cache, relstep=1e-6, absstep=1e-9, dir=-1)
+    eps = cache.last_plan.epsilons()
+    assert np.all(eps < 0)
+    ref = oracle.jacobian("forward", oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval, relstep=1e-6, absstep=1e-9, dir=-1.0)
+    _tol_ok(J.nzval.cpu().numpy(), ref["out"], np.min(np.abs(eps)), 6.0, "dir=-1")
+
+
+def test_config3_shape_lap5_central(oracle):
+    # BASELINE config 3 shape at a size the oracle finishes quickly: 5-point Laplacian, 5 colours, central
+    nx, ny = 400, 250
+    N = nx * ny
+    x = np.random.default_rng(3).random(N)
+    colptr, rowval = P.lap5_csc(nx, ny)
+    colors = P.lap5_colors(nx, ny)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    f = fd.BuiltinF("lap5", nx, ny)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), "central", colorvec=colors)
+    assert f.fcalls == 10
+    ref = oracle.jacobian("central", oracle.Fixture("lap5", nx, ny), x, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    _tol_ok(J.nzval.cpu().numpy(), ref["out"], np.min(np.abs(_oracle_eps(x, colors, "central"))), 8.0, "lap5")
+    got = J.nzval.cpu().numpy()
+    isdiag = rowval == P.csc_cols(colptr)
+    assert np.allclose(got[isdiag], -4.0, rtol=0, atol=1e-8) and np.allclose(got[~isdiag], 1.0, rtol=0, atol=1e-8)
+
+
+def test_config5_shape_blockbanded_complex(oracle):
+    # BASELINE config 5 shape (reduced): block-tridiagonal dense 32x32 blocks, complex step, 96 colours
+    nb, bs = 60, 32
+    N = nb * bs
+    x = np.random.default_rng(5).random(N)
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    colors = lay.colors()
+    assert colors.max() == 96
+    Jb = fd.BlockBandedMatrix(_dev(np.full(lay.data_len, np.nan)), lay)
+    f = fd.BuiltinF("blockcoupled", nb, bs)
+    fd.finite_difference_jacobian_b(Jb, f, _dev(x), "complex", colorvec=colors)
+    assert f.fcalls == 96
+    ref = oracle.jacobian("complex", oracle.Fixture("blockcoupled", nb, bs), x, colors, kind=oracle.PAT_BLOCKBANDED,
+                          blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts,
+                          block_strides=lay.block_strides, out_len=lay.data_len)
+    got = Jb.data.cpu().numpy()
+    # complex step has no subtractive cancellation: a few ulp of |J| (sum order of sigma differs)
+    assert np.max(np.abs(got - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
+
+
+def test_column_window_matches_full(oracle):
+    # multi-GPU sharding primitive: windows of columns reproduce the slices of the full result bit for bit
+    N = 10007
+    x = np.random.default_rng(9).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    Jfull = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    full = fd.make_plan(Jfull, Jfull, colors, "forward")
+    full.jacobian(fd.BuiltinF("tridiag_nl", N), _dev(x), [Jfull.nzval])
+    want = Jfull.nzval.cpu().numpy()
+    cuts = [0, 2500, 2501, 7000, N]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        plan = fd.make_plan(Jfull, Jfull, colors, "forward", col_window=(a, b), x_window=(max(a - 2, 0), min(b + 2, N)))
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.BuiltinF("tridiag_nl", N), _dev(x), [out])
+        e0 = plan.info(fd.lib.INFO_ENTRY_BEGIN)
+        assert e0 == colptr[a] - 1 and plan.out_len(0) == colptr[b] - colptr[a]
+        assert np.array_equal(out.cpu().numpy(), want[e0:e0 + plan.out_len(0)])
+
+
+def test_large_properties_headline_size():
+    # BASELINE config 2/4 sizes: N = 10^6 (exact), property checks that do not need the oracle:
+    # linear fixture => J is the constant stencil regardless of x; call count 1 + C; x untouched.
+    N = 10 ** 6
+    x = _dev(np.random.default_rng(2).random(N))
+    xc = x.clone()
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, torch.full((rowval.size,), float("nan"), dtype=torch.float64,
+                                                            device="cuda"))
+    f = fd.BuiltinF("tridiag", N)
+    fd.finite_difference_jacobian_b(J, f, x, "forward", colorvec=colors)
+    assert f.fcalls == 4 and torch.equal(x, xc)
+    got = J.nzval.cpu().numpy()
+    isdiag = rowval == P.csc_cols(colptr)
+    assert np.max(np.abs(got[isdiag] + 2.0)) < 5e-8 and np.max(np.abs(got[~isdiag] - 1.0)) < 5e-8
