@@ -71,7 +71,7 @@ static int ingest_colors(fd_plan *p, const void *colorvec, int color_bytes, std:
         col0[(size_t)j] = c >= 1 ? (int32_t)(c - 1) : -1;
     }
     p->C = C;
-    p->color8 = C <= 254;
+    p->color8 = C <= 253;  // 0xFF = no colour, 0xFE = padding
     return FD_OK;
 }
 
@@ -80,7 +80,7 @@ static int upload_colors(fd_plan *p, const std::vector<int32_t> &col0, const std
     if (p->color8) {
         std::vector<uint8_t> a(col0.size()), b(nzc.size());
         for (size_t i = 0; i < col0.size(); ++i) a[i] = col0[i] < 0 ? 0xFF : (uint8_t)col0[i];
-        for (size_t i = 0; i < nzc.size(); ++i) b[i] = nzc[i] < 0 ? 0xFF : (uint8_t)nzc[i];
+        for (size_t i = 0; i < nzc.size(); ++i) b[i] = nzc[i] == -2 ? 0xFE : nzc[i] < 0 ? 0xFF : (uint8_t)nzc[i];
         uint8_t *d = nullptr;
         int rc = dev_upload(&d, a);
         if (rc) return rc;
@@ -157,7 +157,10 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
         if (r2) return r2;
     } else if (p->C > 0) {
         if (p->C <= kRegColors) {
-            p->n_partial_blocks = (int)std::min<int64_t>((p->N / 2 + kBlock - 1) / kBlock + 1, (int64_t)p->ctx->num_cus * 8);
+            const char *cm = getenv("FDJAC_GRID_CAP");
+            const int64_t mult = (cm && *cm) ? atoll(cm) : 8;
+            p->n_partial_blocks = (int)std::min<int64_t>((p->N / 2 + kBlock - 1) / kBlock + 1,
+                                                         mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
             if ((rc = dev_alloc(&p->d_partial, (int64_t)p->n_partial_blocks * kRegColors))) return rc;
         } else {
             // counting sort of the columns by colour
@@ -208,14 +211,11 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
     } while (0)
 
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
-static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows,
-                            const std::vector<int32_t> &nzc, const std::vector<int64_t> &dest)
+static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
+                            std::vector<int32_t> &nzc, std::vector<int64_t> &dest)
 {
     int rc;
     p->nnz_local = (int64_t)rows.size();
-    if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
-    if ((rc = upload_colors(p, col0, nzc))) return rc;
-    if (!dest.empty() && (rc = dev_upload(&p->d_dest, dest))) return rc;
     int64_t r0 = p->M, r1 = 0;
     for (int32_t r : rows) {
         if (r < r0) r0 = r;
@@ -224,6 +224,15 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, const 
     if (rows.empty()) r0 = r1 = 0;
     p->row0 = r0;
     p->row1 = r1;
+    // pad the lists to whole tiles: row 0, colour "pad" (-2), destination 0 -- never written
+    const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
+    const bool has_dest = !dest.empty() || p->kind != K_CSC;
+    rows.resize(padded, 0);
+    nzc.resize(padded, -2);
+    if (has_dest) dest.resize(padded, 0);
+    if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
+    if ((rc = upload_colors(p, col0, nzc))) return rc;
+    if (has_dest && (rc = dev_upload(&p->d_dest, dest))) return rc;
     return alloc_scratch(p, col0);
 }
 
@@ -411,7 +420,6 @@ static int entries_common(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_in
         nzc[(size_t)k] = col0[(size_t)c];
         dest[(size_t)k] = d;
     }
-    if (nnz == 0) dest.clear();
     FD_TRY(finish_list_plan(p, col0, rows, nzc, dest));
     p->nouts = 1;
     p->out_len[0] = out_len;

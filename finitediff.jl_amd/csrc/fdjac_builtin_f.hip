@@ -8,6 +8,7 @@
 // library is built with -ffp-contract=off, so a linear fixture reproduces the CPU values bit
 // for bit.
 #include <atomic>
+#include <cstdlib>
 #include <new>
 
 #include "fdjac_internal.h"
@@ -50,6 +51,36 @@ k_f_tridiag(T *__restrict__ fx, const T *__restrict__ x, int64_t n, int64_t xs, 
         T v = (xm - 2.0 * xi) + xp;
         if (NL) v = v + (xi * xi) * xp;
         fb[i] = v;
+    }
+}
+
+// Same fixture, two rows per thread: one aligned 16-B load of (x[i], x[i+1]) plus the two scalar
+// neighbours (L1 hits), one 16-B store.  Needs even i and 16-B aligned batch bases.
+template <bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t n, int64_t xs, int64_t fs, int64_t r0,
+               int64_t r1)
+{
+    const double *xb = x + (int64_t)blockIdx.y * xs;
+    double *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
+    for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
+        if (i + 1 < n) {
+            const double2 c = *reinterpret_cast<const double2 *>(xb + i);
+            const double xm = i > 0 ? xb[i - 1] : 0.0;
+            const double xq = i + 2 < n ? xb[i + 2] : 0.0;
+            double v0 = (xm - 2.0 * c.x) + c.y;
+            double v1 = (c.x - 2.0 * c.y) + xq;
+            if (NL) {
+                v0 = v0 + (c.x * c.x) * c.y;
+                v1 = v1 + (c.y * c.y) * xq;
+            }
+            *reinterpret_cast<double2 *>(fb + i) = make_double2(v0, v1);
+        } else {
+            const double xm = i > 0 ? xb[i - 1] : 0.0;
+            const double xi = xb[i];
+            fb[i] = (xm - 2.0 * xi) + 0.0;
+        }
     }
 }
 
@@ -154,8 +185,12 @@ static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
 {
     int64_t gx = (rows + kBlock - 1) / kBlock;
     const int64_t cap = std::max<int64_t>(1, (int64_t)num_cus * 8 / std::max<int64_t>(nbatch, 1));
-    if (gx > cap && nbatch > 1) gx = std::max<int64_t>(cap, 64);
-    if (gx > (int64_t)num_cus * 16) gx = (int64_t)num_cus * 16;
+    static int64_t capmult = -1;
+    if (capmult < 0) { const char *v = getenv("FDJAC_F_GRID_CAP"); capmult = (v && *v) ? atoll(v) : 16; }
+    if (capmult > 0) {
+        if (gx > cap && nbatch > 1) gx = std::max<int64_t>(cap, 64);
+        if (gx > (int64_t)num_cus * capmult) gx = (int64_t)num_cus * capmult;
+    }
     if (gx < 1) gx = 1;
     return dim3((unsigned)gx, (unsigned)nbatch, 1);
 }
@@ -171,11 +206,29 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
     const dim3 g = grid2(r1 - r0, nbatch, ncu);
     switch (b->family) {
     case FD_F_TRIDIAG:
-        hipLaunchKernelGGL((k_f_tridiag<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
+    case FD_F_TRIDIAG_NL: {
+        const bool nl = b->family == FD_F_TRIDIAG_NL;
+        if constexpr (sizeof(T) == 8) {
+            const bool aligned = ((((uintptr_t)fx) | ((uintptr_t)x)) & 15) == 0 && (xs % 2 == 0 || nbatch == 1) &&
+                                 (fs % 2 == 0 || nbatch == 1);
+            if (aligned) {
+                const int64_t r0e = r0 & ~(int64_t)1;
+                const dim3 g2 = grid2((r1 - r0e + 1) / 2, nbatch, ncu);
+                if (nl)
+                    hipLaunchKernelGGL((k_f_tridiag_v2<true>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                                       b->prm[0], xs, fs, r0e, r1);
+                else
+                    hipLaunchKernelGGL((k_f_tridiag_v2<false>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                                       b->prm[0], xs, fs, r0e, r1);
+                break;
+            }
+        }
+        if (nl)
+            hipLaunchKernelGGL((k_f_tridiag<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
+        else
+            hipLaunchKernelGGL((k_f_tridiag<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
         break;
-    case FD_F_TRIDIAG_NL:
-        hipLaunchKernelGGL((k_f_tridiag<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], xs, fs, r0, r1);
-        break;
+    }
     case FD_F_LAP5:
         hipLaunchKernelGGL((k_f_stencil5<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
         break;

@@ -35,7 +35,7 @@ enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLR
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
-constexpr int64_t kTile = 8192;      // stored entries per workgroup in the decompression kernels
+constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 
 struct TimedSpan {

@@ -7,13 +7,19 @@
 //   * the step sizes eps[] of the current colour chunk are staged in LDS.
 //
 // Reference loops each kernel replaces are cited per kernel (paths relative to /root/reference).
+#include <cstdlib>
+
 #include "fdjac_internal.h"
 
 namespace fdjac {
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
 template <typename CT> struct ColorTraits;
-template <> struct ColorTraits<uint8_t> { static constexpr int none = 0xFF; };
-template <> struct ColorTraits<int32_t> { static constexpr int none = -1; };
+// "none": the column has no colour (stored entries are written as 0); "pad": not a stored entry at all
+// (index lists are padded to a whole number of tiles so the hot loads need no bounds checks).
+template <> struct ColorTraits<uint8_t> { static constexpr int none = 0xFF; static constexpr int pad = 0xFE; };
+template <> struct ColorTraits<int32_t> { static constexpr int none = -1; static constexpr int pad = -2; };
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -29,6 +35,22 @@ __device__ __forceinline__ double wave_sum(double v)
 //   shuffle tree, per-block partials reduced by k_eps_finalize in fixed order.
 //   partial layout: partial[block * ldp + c].
 // ---------------------------------------------------------------------------------------------
+template <typename CT> __device__ __forceinline__ void load_color_pair(const CT *p, int &c0, int &c1);
+template <> __device__ __forceinline__ void load_color_pair<uint8_t>(const uint8_t *p, int &c0, int &c1)
+{
+    const unsigned v = *reinterpret_cast<const uint16_t *>(p);  // p is 2-B aligned (even index)
+    c0 = (int)(v & 0xFF);
+    c1 = (int)(v >> 8);
+}
+template <> __device__ __forceinline__ void load_color_pair<int32_t>(const int32_t *p, int &c0, int &c1)
+{
+    const int2 v = *reinterpret_cast<const int2 *>(p);
+    c0 = v.x;
+    c1 = v.y;
+}
+
+constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
+
 template <typename CT, int NC>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const double *__restrict__ x, const CT *__restrict__ color, int64_t n,
@@ -38,23 +60,35 @@ k_eps_partial_reg(const double *__restrict__ x, const CT *__restrict__ color, in
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
 
-    const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
-    int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
-    for (; i + 1 < n; i += stride) {
-        const double2 v = *reinterpret_cast<const double2 *>(x + i);
-        const int c0 = color[i], c1 = color[i + 1];
-        const double s0 = v.x * v.x, s1 = v.y * v.y;
+    // block tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
+    const int64_t tile = (int64_t)kEpsU * kBlock * 2;
+    for (int64_t base = (int64_t)blockIdx.x * tile; base < n; base += (int64_t)gridDim.x * tile) {
+        double2 v[kEpsU];
+        int c0[kEpsU], c1[kEpsU];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            acc[c] += (c0 == c) ? s0 : 0.0;
-            acc[c] += (c1 == c) ? s1 : 0.0;
+        for (int u = 0; u < kEpsU; ++u) {
+            const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+            if (i + 1 < n) {
+                v[u] = *reinterpret_cast<const double2 *>(x + i);
+                load_color_pair<CT>(color + i, c0[u], c1[u]);
+            } else if (i < n) {
+                v[u] = make_double2(x[i], 0.0);
+                c0[u] = color[i];
+                c1[u] = -2;
+            } else {
+                v[u] = make_double2(0.0, 0.0);
+                c0[u] = c1[u] = -2;
+            }
         }
-    }
-    if (i < n) {  // odd tail element
-        const double v = x[i];
-        const int c0 = color[i];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] += (c0 == c) ? v * v : 0.0;
+        for (int u = 0; u < kEpsU; ++u) {
+            const double s0 = v[u].x * v[u].x, s1 = v[u].y * v[u].y;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                acc[c] += (c0[u] == c) ? s0 : 0.0;
+                acc[c] += (c1[u] == c) ? s1 : 0.0;
+            }
+        }
     }
 
     __shared__ double red[kBlock / 64][NC];
@@ -157,7 +191,14 @@ k_perturb(const double *__restrict__ x, const CT *__restrict__ color,
             v0 = x[j];
         }
         // colours outside the chunk (and "none") never equal a b in [0,B)
-        const int c0 = (int)color[j] - c_lo, c1 = pair ? (int)color[j + 1] - c_lo : -1;
+        int c0, c1 = -1;
+        if (pair) {
+            load_color_pair<CT>(color + j, c0, c1);
+            c1 -= c_lo;
+        } else {
+            c0 = (int)color[j];
+        }
+        c0 -= c_lo;
         for (int b = 0; b < B; ++b) {
             const double e = eps[c_lo + b];
             const double e0 = (c0 == b) ? e : 0.0, e1 = (c1 == b) ? e : 0.0;
@@ -210,7 +251,7 @@ __device__ __forceinline__ double entry_value(const double *__restrict__ FXa,
 //   the per-entry colour and nzval are each streamed exactly once, fully coalesced, and the
 //   batched f! outputs are gathered near-sequentially (banded patterns) out of L2.
 //   LDS stages the chunk's eps[] slice.
-template <typename CT, int MODE, bool HAS_DEST>
+template <typename CT, int MODE, bool HAS_DEST, int U, bool LDS_EPS>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzcolor,
                   const int64_t *__restrict__ dest, const double *__restrict__ FXa,
@@ -219,47 +260,69 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
 {
     extern __shared__ double s_eps[];
     const int nB = c_hi - c_lo;
-    const bool lds = nB <= kEpsLdsMax;
-    if (lds) {
+    if (LDS_EPS) {
         for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
         __syncthreads();
     }
     const int none = ColorTraits<CT>::none;
-    const int64_t t0 = (int64_t)blockIdx.x * kTile;
-    const int64_t t1 = (t0 + kTile < n) ? t0 + kTile : n;
+    // block tile = U*512 stored entries; pair u of thread t sits at tile + u*512 + 2t, so every
+    // wave instruction (index load, colour load, value store) touches one dense 512-B / 1-KiB run.
+    const int64_t t0 = (int64_t)blockIdx.x * (U * kBlock * 2);
 
-    for (int64_t p = t0 + (int64_t)threadIdx.x * 2; p < t1; p += kBlock * 2) {
-        const bool pair = (p + 1 < t1);
-        int r0, r1 = 0;
-        if (pair) {
-            const int2 rr = *reinterpret_cast<const int2 *>(rowval + p);
-            r0 = rr.x; r1 = rr.y;
-        } else {
-            r0 = rowval[p];
-        }
-        const int c0 = nzcolor[p];
-        const int c1 = pair ? (int)nzcolor[p + 1] : none;
-        // 0: skip (another chunk's colour), 1: value, 2: zero (column without colour)
-        const int w0 = (c0 == none) ? (c_lo == 0 ? 2 : 0) : ((c0 >= c_lo && c0 < c_hi) ? 1 : 0);
-        const int w1 = !pair ? 0 : (c1 == none) ? (c_lo == 0 ? 2 : 0) : ((c1 >= c_lo && c1 < c_hi) ? 1 : 0);
-        double v0 = 0.0, v1 = 0.0;
-        if (w0 == 1) {
-            const double e = lds ? s_eps[c0 - c_lo] : eps[c0];
-            v0 = entry_value<MODE>(FXa, FXb, ld, c0 - c_lo, r0, e);
-        }
-        if (w1 == 1) {
-            const double e = lds ? s_eps[c1 - c_lo] : eps[c1];
-            v1 = entry_value<MODE>(FXa, FXb, ld, c1 - c_lo, r1, e);
-        }
+    // phase 1: indices and colours (independent coalesced loads; the lists are padded to whole tiles)
+    int r[2 * U], c[2 * U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t p = t0 + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+        const int2 rr = *reinterpret_cast<const int2 *>(rowval + p);
+        r[2 * u] = rr.x; r[2 * u + 1] = rr.y;
+        load_color_pair<CT>(nzcolor + p, c[2 * u], c[2 * u + 1]);
+    }
+    // phase 2: branch-free gathers.  Entries that will not be written (another chunk's colour, a
+    // column without colour, past the end) gather from slot 0 / their own valid row and are discarded.
+    double a[2 * U], b[2 * U], e[2 * U];
+    bool valid[2 * U];
+#pragma unroll
+    for (int k = 0; k < 2 * U; ++k) {
+        const int cb = c[k] - c_lo;
+        valid[k] = (c[k] != none) & (c[k] != ColorTraits<CT>::pad) & ((unsigned)cb < (unsigned)nB);
+        const int cs = valid[k] ? cb : 0;
+        const int64_t at = (int64_t)cs * ld + r[k];
+        e[k] = LDS_EPS ? s_eps[cs] : eps[c_lo + cs];
+        if (MODE == 0) { a[k] = FXa[at]; b[k] = FXb[r[k]]; }
+        else if (MODE == 1) { a[k] = FXa[at]; b[k] = FXb[at]; }
+        else { a[k] = FXa[at * 2 + 1]; b[k] = 0.0; }
+    }
+    // phase 3: the difference (src/jacobians.jl:565 / 607 / 635), IEEE division
+    double v[2 * U];
+#pragma unroll
+    for (int k = 0; k < 2 * U; ++k) {
+        double q;
+        if (MODE == 0) q = (a[k] - b[k]) / e[k];
+        else if (MODE == 1) q = (a[k] - b[k]) / (2 * e[k]);
+        else q = a[k] / e[k];
+        v[k] = valid[k] ? q : 0.0;
+    }
+    // phase 4: stores.  valid -> value; column without colour -> 0 (first chunk only); else untouched.
+    // The whole wave takes the 16-B store path except at the array end / uncoloured columns / chunked runs.
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t p = t0 + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+        const bool w0 = valid[2 * u] | ((c[2 * u] == none) & (c_lo == 0));
+        const bool w1 = valid[2 * u + 1] | ((c[2 * u + 1] == none) & (c_lo == 0));
+        double q0 = v[2 * u], q1 = v[2 * u + 1];
+        asm volatile("" : "+v"(q0), "+v"(q1));  // keep the divisions above the branch (no sinking / duplication)
         if (HAS_DEST) {
-            if (w0) out[dest[p]] = v0;
-            if (w1) out[dest[p + 1]] = v1;
+            if (w0) out[dest[p]] = q0;
+            if (w1) out[dest[p + 1]] = q1;
         } else {
-            if (w0 && w1 && vec_ok) {
-                *reinterpret_cast<double2 *>(out + p) = make_double2(v0, v1);
+            const bool both = w0 & w1 & (vec_ok != 0);
+            if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
+                d2_t pk = {q0, q1};
+                *reinterpret_cast<d2_t *>(out + p) = pk;
             } else {
-                if (w0) out[p] = v0;
-                if (w1) out[p + 1] = v1;
+                if (w0) out[p] = q0;
+                if (w1) out[p + 1] = q1;
             }
         }
     }
@@ -377,10 +440,19 @@ __global__ void __launch_bounds__(kBlock) k_fill(double *__restrict__ p, int64_t
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from fdjac_api.hip)
 // ---------------------------------------------------------------------------------------------
+static int64_t env_i64(const char *name, int64_t dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoll(v) : dflt;
+}
+static int64_t g_tile = -1, g_capmult = -1;
+static inline int64_t tune_tile() { if (g_tile < 0) { g_tile = env_i64("FDJAC_TILE", 2); if (g_tile != 1 && g_tile != 2) g_tile = 4; } return g_tile; }
+static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
+
 static inline int grid_for(int64_t work_items, int per_block, int num_cus)
 {
     int64_t g = (work_items + per_block - 1) / per_block;
-    const int64_t cap = (int64_t)num_cus * 8;
+    const int64_t cap = tune_capmult() > 0 ? (int64_t)num_cus * tune_capmult() : ((int64_t)1 << 30);
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
@@ -456,17 +528,28 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
     case K_CSC_DENSE:
     case K_COO_DENSE: {
         if (p->nnz_local == 0) break;
-        const int64_t g = (p->nnz_local + kTile - 1) / kTile;
-        const size_t shm = (B <= kEpsLdsMax) ? sizeof(double) * (size_t)B : 0;
+        const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)
+        const int64_t tile = (int64_t)U * kBlock * 2;
+        const int64_t g = (p->nnz_local + tile - 1) / tile;
+        const bool lds = B <= kEpsLdsMax;
+        const size_t shm = lds ? sizeof(double) * (size_t)B : 0;
         const int vec_ok = (((uintptr_t)outs[0]) & 15) == 0;
-        if (p->kind == K_CSC)
-            hipLaunchKernelGGL((k_decompress_list<CT, MODE, false>), dim3((unsigned)g), dim3(kBlock), shm, s,
-                               p->d_rowval, (const CT *)p->d_nzcolor, nullptr, FXa, FXb, p->ldf, p->d_eps,
-                               c_lo, c_hi, outs[0], p->nnz_local, vec_ok);
-        else
-            hipLaunchKernelGGL((k_decompress_list<CT, MODE, true>), dim3((unsigned)g), dim3(kBlock), shm, s,
-                               p->d_rowval, (const CT *)p->d_nzcolor, p->d_dest, FXa, FXb, p->ldf, p->d_eps,
-                               c_lo, c_hi, outs[0], p->nnz_local, 0);
+#define FD_LAUNCH_LIST(HD, UU, LL, DEST, VOK)                                                                    \
+        hipLaunchKernelGGL((k_decompress_list<CT, MODE, HD, UU, LL>), dim3((unsigned)g), dim3(kBlock), shm, s,   \
+                           p->d_rowval, (const CT *)p->d_nzcolor, DEST, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, \
+                           outs[0], p->nnz_local, VOK)
+        if (p->kind == K_CSC) {
+            if (U == 1 && lds) FD_LAUNCH_LIST(false, 1, true, nullptr, vec_ok);
+            else if (U == 1) FD_LAUNCH_LIST(false, 1, false, nullptr, vec_ok);
+            else if (U == 2 && lds) FD_LAUNCH_LIST(false, 2, true, nullptr, vec_ok);
+            else if (U == 2) FD_LAUNCH_LIST(false, 2, false, nullptr, vec_ok);
+            else if (lds) FD_LAUNCH_LIST(false, 4, true, nullptr, vec_ok);
+            else FD_LAUNCH_LIST(false, 4, false, nullptr, vec_ok);
+        } else {
+            if (lds) FD_LAUNCH_LIST(true, 2, true, p->d_dest, 0);
+            else FD_LAUNCH_LIST(true, 2, false, p->d_dest, 0);
+        }
+#undef FD_LAUNCH_LIST
         break;
     }
     case K_TRIDIAG: {
