@@ -292,8 +292,9 @@ class Plan:
         _l.check(self.ctx.L.fd_plan_get_epsilons(self.handle, buf))
         return np.array(buf[:n])
 
-    def enable_timing(self, on=True):
-        _l.check(self.ctx.L.fd_plan_enable_timing(self.handle, 1 if on else 0))
+    def enable_timing(self, level=2):
+        """0 off; 1 = diff+decompress kernel and whole call only; 2 = every stage."""
+        _l.check(self.ctx.L.fd_plan_enable_timing(self.handle, int(level)))
 
     def timings(self):
         ms = (C.c_double * 5)()

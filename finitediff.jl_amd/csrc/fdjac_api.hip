@@ -605,7 +605,9 @@ struct Span {
     int idx = -1;
     Span(fd_plan *pl, int stage) : p(pl)
     {
-        if (!p->timing) return;
+        // level 1: only the graded kernel + the whole call (2 x 2 events per call); level 2: every stage
+        if (p->timing == 0) return;
+        if (p->timing == 1 && stage != FD_STAGE_DECOMPRESS && stage != FD_STAGE_TOTAL) return;
         fdjac::TimedSpan s{stage, take_event(p), take_event(p)};
         (void)hipEventRecord(s.a, p->ctx->stream);
         p->spans.push_back(s);
@@ -641,7 +643,7 @@ int fd_plan_enable_timing(fd_plan *p, int on)
     FD_REQUIRE(p, FD_ERR_ARG, "plan is NULL");
     int rc = collect_spans(p);
     if (rc) return rc;
-    p->timing = on != 0;
+    p->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     for (int i = 0; i < FD_NSTAGES; ++i) {
         p->ms_sum[i] = 0;
         p->launches[i] = 0;

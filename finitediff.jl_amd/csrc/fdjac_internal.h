@@ -94,7 +94,7 @@ struct fd_plan {
     int64_t fcalls_last = 0;
     double relstep_last = 0, absstep_last = 0;
 
-    bool timing = false;
+    int timing = 0;   // 0 off, 1 decompress + total, 2 all stages
     std::vector<fdjac::TimedSpan> spans;       // recorded, not yet collected
     std::vector<hipEvent_t> event_pool;
     double ms_sum[FD_NSTAGES] = {0, 0, 0, 0, 0};

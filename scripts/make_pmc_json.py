@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_latest.json.
+
+Correction as MI355X_MICROARCH.md (HBM section) prescribes: on gfx950 FETCH_SIZE under-reports wide coalesced
+streaming reads by exactly 2x and WRITE_SIZE is uncalibrated, so both are calibrated IN THE SAME RUN against
+k_stream_copy, whose true traffic is known (bench.py's ceiling probe copies exactly 1 GiB per launch).
+usage: make_pmc_json.py pmc_fetch.db pmc_write.db N GPUS > profiles/pmc_latest.json
+"""
+import json
+import sqlite3
+import sys
+
+
+def mean_counter(db, kernel_like, counter):
+    cur = sqlite3.connect(db).cursor()
+    cur.execute("select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?",
+                ("%" + kernel_like + "%", counter))
+    v, n = cur.fetchone()
+    return (v or 0.0), n
+
+
+fetch_db, write_db, n, gpus = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+copy_bytes = float(1 << 30)
+cf, _ = mean_counter(fetch_db, "k_stream_copy", "FETCH_SIZE")
+cw, _ = mean_counter(write_db, "k_stream_copy", "WRITE_SIZE")
+kf = copy_bytes / (cf * 1024.0)  # expected 2.0
+kw = copy_bytes / (cw * 1024.0)  # expected 1.0
+df, nf = mean_counter(fetch_db, "k_decompress_list", "FETCH_SIZE")
+dw, nw = mean_counter(write_db, "k_decompress_list", "WRITE_SIZE")
+out = {
+    "n": n, "gpus": gpus,
+    "calibration": {"kernel": "k_stream_copy (1 GiB read + 1 GiB write per launch)", "fetch_factor": kf, "write_factor": kw,
+                    "fetch_kb_raw": cf, "write_kb_raw": cw},
+    "decompress_fetch_kb_raw": df, "decompress_write_kb_raw": dw, "dispatches": [nf, nw],
+    "decompress_hbm_read_bytes_per_launch": df * 1024.0 * kf,
+    "decompress_hbm_write_bytes_per_launch": dw * 1024.0 * kw,
+    "decompress_hbm_bytes_per_launch": df * 1024.0 * kf + dw * 1024.0 * kw,
+}
+print(json.dumps(out, indent=1))

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the column partition, per-rank windows and
+the single all-gather that assembles nzval (finitediff.jl_amd/sharded.py).  The per-rank compute is
+stood in for by the CPU oracle (tests may use it): each rank fills only ITS slice, so a wrong
+partition / window / gather order cannot produce the full reference vector."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd  # noqa: F401
+from finitediff_jl_amd import patterns as P
+from finitediff_jl_amd import sharded as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_properties():
+    for n, world in ((10, 1), (10, 3), (1000, 8), (7, 8), (100003, 4)):
+        colptr, _ = P.tridiag_csc(n)
+        cuts = S.partition_columns(colptr, world)
+        assert cuts[0] == 0 and cuts[-1] == n and np.all(np.diff(cuts) >= 0)
+        rng = S.entry_ranges(colptr, cuts)
+        assert rng[0][0] == 0 and rng[-1][1] == 3 * n - 2
+        assert all(a[1] == b[0] for a, b in zip(rng[:-1], rng[1:]))
+        counts = np.array([b - a for a, b in rng])
+        if n >= 50 * world:
+            assert counts.max() - counts.min() <= 3  # balanced by stored entries
+    # skewed pattern: a dense first column must not starve the other ranks
+    colptr = np.array([1, 101] + list(range(102, 202)), dtype=np.int64)
+    cuts = S.partition_columns(colptr, 2)
+    assert cuts.tolist() == [0, 1, 101]
+
+
+def test_x_window():
+    cuts = np.array([0, 40, 100])
+    assert S.x_window(cuts, 0, 100, 1, 1, 1) == (0, 42)
+    assert S.x_window(cuts, 1, 100, 1, 1, 1) == (38, 100)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    import finitediff_jl_amd as fd
+    from finitediff_jl_amd import patterns as P, sharded as S
+    from oracle import oracle
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N = 1001
+    x = np.random.default_rng(4).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    cuts = S.partition_columns(colptr, world)
+    ranges = S.entry_ranges(colptr, cuts)
+    counts = [b - a for a, b in ranges]
+    full = oracle.jacobian("forward", oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                           colptr=colptr, rowval=rowval)["out"]
+    # this rank "computes" only its own slice, straight into its slot of the gather buffer
+    bufs = S.AllGatherBuffers(counts, torch.device("cpu"), torch.float64)
+    bufs.buf.fill_(float("nan"))
+    a, b = ranges[rank]
+    bufs.local_view(rank)[: counts[rank]] = torch.from_numpy(full[a:b])
+    bufs.gather(rank, dist)
+    got = bufs.compact().numpy()
+    assert got.shape == full.shape and np.array_equal(got, full), "rank %%d: gathered vector differs" %% rank
+    # the allocation-per-call variant gives the same answer
+    got2 = S.all_gather_slices(torch.from_numpy(full[a:b].copy()), counts, dist).numpy()
+    assert np.array_equal(got2, full)
+    # every rank derives the same windows
+    xw = S.x_window(cuts, rank, N, 1, 1, 1)
+    assert xw[0] <= max(cuts[rank] - 2, 0) and xw[1] >= min(cuts[rank + 1] + 2, N)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_gloo(tmp_path, oracle):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("ok") == 2
