@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=10 ** 7, help="states (columns); default = BASELINE headline size")
+    ap.add_argument("--f-mode", choices=["lazy", "materialized"], default="lazy",
+                    help="lazy: f! perturbs while loading (fd_f_launch_lazy); materialized: perturbed points written to HBM")
     ap.add_argument("--no-gather", action="store_true", help="leave nzval sharded (compute-only scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="columns for the CPU baseline sample (0 = same as --n)")
@@ -107,6 +109,8 @@ def main():
     plan = fd.make_plan(pattern, pattern, colors, "forward", ctx=ctx, col_window=(c0, c1) if world > 1 else None,
                         x_window=xw if world > 1 else None)
     f = fd.BuiltinF("tridiag", N, ctx=ctx)
+    if args.f_mode == "lazy":
+        plan.set_lazy(f)
     gather = world > 1 and not args.no_gather
     bufs = S.AllGatherBuffers(counts, dev, torch.float64)
     out = bufs.local_view(rank)[: counts[rank]] if world > 1 else bufs.buf
@@ -193,7 +197,9 @@ def main():
             "config": {"workload": "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, "
                                    "x~U(0,1) seed 4" % N,
                        "parallelism": "columns x%d%s" % (world, "+allgather" if gather else ""),
-                       "f_mode": "built-in device f! behind fd_f_launch (batched: 1 + 3 points)",
+                       "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + 3 lazily perturbed points)"
+                                  if args.f_mode == "lazy" else
+                                  "built-in device f! behind fd_f_launch (materialised points, batched: 1 + 3)"),
                        "gather_in_step": bool(gather)},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -194,6 +194,13 @@ class BuiltinF:
         self.family, self.params = family, params
         self._fin = weakref.finalize(self, L.fd_builtin_f_destroy, self.fctx)
 
+    @property
+    def lazy_fn(self):
+        """The family's lazy-point launcher (fd_builtin_f_lazy) or None if it has none."""
+        fn = _l.F_LAUNCH_LAZY()
+        rc = self.ctx.L.fd_builtin_f_lazy(self.fctx, C.byref(fn))
+        return fn if rc == 0 else None
+
     def counts(self):
         a, b = C.c_int64(), C.c_int64()
         _l.check(self.ctx.L.fd_builtin_f_counts(self.fctx, C.byref(a), C.byref(b)))
@@ -301,6 +308,14 @@ class Plan:
         cnt = (C.c_int64 * 5)()
         _l.check(self.ctx.L.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
+
+    def set_lazy(self, f):
+        """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it."""
+        fn = getattr(f, "lazy_fn", None) if f is not None else None
+        if f is not None and fn is None:
+            raise ValueError("this f! has no lazy-point launcher")
+        self._lazy_keep = fn
+        _l.check(self.ctx.L.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
 
     def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
         """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""

@@ -695,11 +695,16 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
         if (rc) return rc;
     }
 
-    // f(x) for forward differences (src/jacobians.jl:540-545)
+    // f(x) for forward differences (src/jacobians.jl:540-545).  With a lazy-point launcher the base
+    // evaluation rides along with the first perturbed batch (one launch fewer).
     const double *fx = nullptr;
+    bool base_pending = false;
     if (p->fdtype == FD_FORWARD) {
         if (fin_dev) {
             fx = fin_dev;
+        } else if (p->lazy_fn && p->nchunks > 0) {
+            base_pending = true;
+            fx = p->d_fx;
         } else {
             Span sp(p, FD_STAGE_F);
             const int rc = f(fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
@@ -722,12 +727,29 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
         const int c_lo = (int)(ch * p->chunkB);
         const int c_hi = (int)std::min<int64_t>(p->C, (int64_t)c_lo + p->chunkB);
         const int B = c_hi - c_lo;
-        {
-            Span sp(p, FD_STAGE_PERTURB);
-            int rc = launch_perturb(p, x_dev, c_lo, B);
-            if (rc) return rc;
-        }
-        {
+        if (p->lazy_fn) {
+            Span sp(p, FD_STAGE_F);
+            fd_lazy_points lp;
+            lp.x = x_dev;
+            lp.color = p->d_color;
+            lp.eps = p->d_eps;
+            lp.base_out = base_pending ? p->d_fx : nullptr;
+            lp.color_bytes = p->color8 ? 1 : 4;
+            lp.c_lo = c_lo;
+            lp.ncolors = B;
+            lp.pts = p->pts;
+            lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
+            lp.reserved0 = 0;
+            const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);
+            p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
+            base_pending = false;
+        } else {
+            {
+                Span sp(p, FD_STAGE_PERTURB);
+                int rc = launch_perturb(p, x_dev, c_lo, B);
+                if (rc) return rc;
+            }
             Span sp(p, FD_STAGE_F);
             const int rc = f(fctx, p->d_FX, p->d_X, (int64_t)B * p->pts, p->ldx, p->ldf, p->row0, p->row1,
                              p->fdtype == FD_COMPLEX ? 1 : 0, (void *)s);
@@ -793,6 +815,13 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
             if (p->out_len[k] > 0)
                 FD_HIP_CHECK(hipMemcpyAsync(outs[k], o[k], sizeof(double) * (size_t)p->out_len[k], hipMemcpyDeviceToHost, s));
     FD_HIP_CHECK(hipStreamSynchronize(s));
+    return FD_OK;
+}
+
+int fd_plan_set_lazy_f(fd_plan *p, fd_f_launch_lazy lazy)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    p->lazy_fn = lazy;
     return FD_OK;
 }
 

@@ -91,6 +91,7 @@ struct fd_plan {
     int64_t out_len[3] = {0, 0, 0};
     double *d_outstage[3] = {nullptr, nullptr, nullptr};
 
+    fd_f_launch_lazy lazy_fn = nullptr;
     int64_t fcalls_last = 0;
     double relstep_last = 0, absstep_last = 0;
 

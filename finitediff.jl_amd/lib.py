@@ -27,13 +27,23 @@ FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "c
 F_LAUNCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                        C.c_int64, C.c_int, C.c_void_p)
 
+class LazyPoints(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("color", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p),
+                ("color_bytes", C.c_int32), ("c_lo", C.c_int32), ("ncolors", C.c_int32), ("pts", C.c_int32),
+                ("is_complex", C.c_int32), ("reserved0", C.c_int32)]
+
+
+# int f(fctx, fx, const fd_lazy_points*, fx_stride, row_begin, row_end, stream)
+F_LAUNCH_LAZY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyPoints), C.c_int64, C.c_int64, C.c_int64,
+                            C.c_void_p)
+
 EXPORTS = (
     "fd_version", "fd_last_error", "fd_ctx_create", "fd_ctx_destroy", "fd_ctx_stream", "fd_ctx_synchronize",
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
-    "fd_stream_copy_gbps",
+    "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy",
 )
 
 
@@ -101,6 +111,8 @@ def load():
     L.fd_builtin_f_destroy.argtypes = [vp]
     L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.fd_stream_copy_gbps.argtypes = [vp, i64, i32, C.POINTER(dbl)]
+    L.fd_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY]
+    L.fd_builtin_f_lazy.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("fd_last_error", "fd_ctx_stream"):

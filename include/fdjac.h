@@ -74,6 +74,33 @@ typedef int (*fd_f_launch)(void *fctx, void *fx, const void *x, int64_t nbatch, 
                            int64_t fx_stride, int64_t row_begin, int64_t row_end, int is_complex,
                            void *stream);
 
+/*
+ * Optional fast path: f! at LAZILY perturbed points.  A coloured finite difference only ever
+ * evaluates f! at x + eps_c * [color == c]; instead of materialising those points
+ * (src/jacobians.jl:562 does it in place) the launcher receives the base x plus the perturbation
+ * rule and applies it while loading.  Point b (0 <= b < ncolors*pts) of the batch is
+ *     forward :  x[j] + eps[c_lo+b] * (color[j] == c_lo+b)
+ *     central :  x[j] +/- eps[c_lo + b%ncolors] * (color[j] == c_lo + b%ncolors),  minus for b >= ncolors
+ *     complex :  (x[j],  eps[c_lo+b] * (color[j] == c_lo+b))           [outputs are (re,im) pairs]
+ * written to fx[b*fx_stride + r].  If base_out != NULL the unperturbed f!(x) is also written to
+ * base_out (forward differences without f_in; saves one launch).  Results are bit-identical to the
+ * materialised path.  In Julia the same thing is a lazy AbstractVector wrapper handed to f!.
+ */
+typedef struct fd_lazy_points {
+    const void *x;        /* base point, double[N]                                           */
+    const void *color;    /* per-column colour, 0-based; none = 0xFF (1-byte) / -1 (4-byte)  */
+    const double *eps;    /* step size per colour (device), indexed by 0-based colour         */
+    void *base_out;       /* NULL or double[M] for f!(x)                                      */
+    int32_t color_bytes;  /* 1 or 4                                                           */
+    int32_t c_lo;         /* first colour of the batch                                        */
+    int32_t ncolors;      /* colours in the batch                                             */
+    int32_t pts;          /* 1 forward/complex, 2 central                                     */
+    int32_t is_complex;
+    int32_t reserved0;
+} fd_lazy_points;
+typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
+                                int64_t row_begin, int64_t row_end, void *stream);
+
 typedef struct fd_plan_opts {
     int32_t fdtype;        /* enum fd_fdtype */
     int32_t reserved0;
@@ -157,6 +184,11 @@ int fd_jacobian(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, int x_k
 int fd_jacobian_async(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *f_in,
                       double relstep, double absstep, double dir, void *const *outs);
 
+/* Install (or clear, with NULL) the lazy-point launcher used for the perturbed batches of this
+   plan; it shares the fctx passed to fd_jacobian.  The plain launcher is still required (it is
+   used whenever the lazy one cannot be: f_in given to a central plan never happens; chunking is fine). */
+int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
+
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
 int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
 
@@ -183,6 +215,8 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
 int fd_builtin_f_destroy(void *fctx);
 /* number of launcher invocations / points evaluated since creation (call-count parity tests) */
 int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
+/* The lazy-point launcher of a built-in family (FD_ERR_UNSUPPORTED if the family has none). */
+int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
 
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline

@@ -403,3 +403,27 @@ def test_large_properties_headline_size():
     got = J.nzval.cpu().numpy()
     isdiag = rowval == P.csc_cols(colptr)
     assert np.max(np.abs(got[isdiag] + 2.0)) < 5e-8 and np.max(np.abs(got[~isdiag] - 1.0)) < 5e-8
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("N,C,cap", [(1, 1, 0), (2, 2, 0), (1001, 3, 0), (4096, 3, 0), (3000, 12, 100_000), (5000, 300, 0)])
+def test_lazy_points_bit_identical(fdtype, N, C, cap):
+    # fd_f_launch_lazy: perturbing while loading must reproduce the materialised path bit for bit,
+    # including the fused base evaluation, colour chunking and int32 colours
+    x = _dev(np.random.default_rng(N + C).random(N))
+    colors = P.cyclic_colors(N, C)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    outs = []
+    calls = []
+    for lazy in (False, True):
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
+        f = fd.BuiltinF("tridiag_nl", N)
+        if lazy:
+            plan.set_lazy(f)
+        out = _dev(np.full(rowval.size, np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out.cpu().numpy())
+        calls.append((f.fcalls, plan.fcalls_last))
+    assert np.array_equal(outs[0], outs[1])
+    assert calls[0] == calls[1]
