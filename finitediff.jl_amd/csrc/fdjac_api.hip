@@ -26,6 +26,7 @@ int launch_perturb(fd_plan *p, const double *x, int c_lo, int B);
 int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs);
 int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v);
 int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16);
+int balanced_grid(int64_t tiles, int64_t cap);
 
 static inline int64_t load_idx(const void *p, int bytes, int64_t i)
 {
@@ -159,8 +160,8 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
         if (p->C <= kRegColors) {
             const char *cm = getenv("FDJAC_GRID_CAP");
             const int64_t mult = (cm && *cm) ? atoll(cm) : 8;
-            p->n_partial_blocks = (int)std::min<int64_t>((p->N / 2 + kBlock - 1) / kBlock + 1,
-                                                         mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
+            const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
+            p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
             if ((rc = dev_alloc(&p->d_partial, (int64_t)p->n_partial_blocks * kRegColors))) return rc;
         } else {
             // counting sort of the columns by colour

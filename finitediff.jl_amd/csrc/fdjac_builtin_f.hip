@@ -260,18 +260,17 @@ struct BuiltinF {
     int64_t sig_cap = 0;    // in (re,im)-capable elements
 };
 
+int balanced_grid(int64_t tiles, int64_t cap);
+
+// grid.x covers `rows` work items of one point, grid.y = points; whole rounds (see balanced_grid)
 static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
 {
-    int64_t gx = (rows + kBlock - 1) / kBlock;
-    const int64_t cap = std::max<int64_t>(1, (int64_t)num_cus * 8 / std::max<int64_t>(nbatch, 1));
     static int64_t capmult = -1;
     if (capmult < 0) { const char *v = getenv("FDJAC_F_GRID_CAP"); capmult = (v && *v) ? atoll(v) : 16; }
-    if (capmult > 0) {
-        if (gx > cap && nbatch > 1) gx = std::max<int64_t>(cap, 64);
-        if (gx > (int64_t)num_cus * capmult) gx = (int64_t)num_cus * capmult;
-    }
-    if (gx < 1) gx = 1;
-    return dim3((unsigned)gx, (unsigned)nbatch, 1);
+    const int64_t tiles = (rows + kBlock - 1) / kBlock;
+    int64_t cap = capmult > 0 ? std::max<int64_t>((int64_t)num_cus * capmult / std::max<int64_t>(nbatch, 1), 64)
+                              : ((int64_t)1 << 30);
+    return dim3((unsigned)balanced_grid(tiles, cap), (unsigned)nbatch, 1);
 }
 
 template <typename T>
@@ -356,6 +355,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
                                hipStream_t s)
 {
     const int64_t r0e = r0 & ~(int64_t)1;
+    // one pair of rows per thread, uncapped grid (measured faster than a capped grid-stride launch here)
     int64_t g = ((r1 - r0e + 1) / 2 + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
     const bool nl = b->family == FD_F_TRIDIAG_NL;

@@ -449,13 +449,22 @@ static int64_t g_tile = -1, g_capmult = -1;
 static inline int64_t tune_tile() { if (g_tile < 0) { g_tile = env_i64("FDJAC_TILE", 2); if (g_tile != 1 && g_tile != 2) g_tile = 4; } return g_tile; }
 static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
 
+// Grid for a grid-stride kernel: at most cap resident workgroups, and -- because these kernels are
+// bandwidth bound with identical work per tile -- a block count that divides the tiles into whole
+// rounds (e.g. 4883 tiles, cap 2048 -> 3 rounds -> 1628 blocks) so no round runs partly empty.
+int balanced_grid(int64_t tiles, int64_t cap)
+{
+    if (tiles < 1) tiles = 1;
+    if (cap < 1) cap = 1;
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    return (int)((tiles + rounds - 1) / rounds);
+}
+
 static inline int grid_for(int64_t work_items, int per_block, int num_cus)
 {
-    int64_t g = (work_items + per_block - 1) / per_block;
+    const int64_t tiles = (work_items + per_block - 1) / per_block;
     const int64_t cap = tune_capmult() > 0 ? (int64_t)num_cus * tune_capmult() : ((int64_t)1 << 30);
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    return (int)g;
+    return balanced_grid(tiles, cap);
 }
 
 template <typename CT>
@@ -599,7 +608,8 @@ int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v)
 
 int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16)
 {
-    hipLaunchKernelGGL(k_stream_copy, dim3(grid_for(n16, kBlock, ctx->num_cus)), dim3(kBlock), 0, ctx->stream,
+    // one 16-B element per thread, uncapped grid: the fastest copy geometry measured on MI355X (scripts/ubench)
+    hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
                        (const double2 *)src, (double2 *)dst, n16);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
