@@ -38,7 +38,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10 ** 7, help="states (columns); default = BASELINE headline size")
+    ap.add_argument("--n", type=int, default=0, help="override the number of states (columns)")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c4",
+                    help="BASELINE.json configs: c4 = headline (N=10^7 tridiagonal forward; --gpus N shards it), "
+                         "c2 = N=10^6 tridiagonal forward, c3 = N=10^7 5-point Laplacian central, "
+                         "c5 = 10^4 dense 32x32 blocks block-banded complex step (c3/c5: 1 GPU, parity/side lines)")
     ap.add_argument("--f-mode", choices=["lazy", "materialized"], default="lazy",
                     help="lazy: f! perturbs while loading (fd_f_launch_lazy); materialized: perturbed points written to HBM")
     ap.add_argument("--no-gather", action="store_true", help="leave nzval sharded (compute-only scaling)")
@@ -93,29 +97,80 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    N = args.n
-    x_host = np.random.default_rng(4).random(N)
-    colors = P.cyclic_colors(N, 3)
-    colptr, rowval = P.tridiag_csc(N)
-    cuts = S.partition_columns(colptr, world)
-    ranges = S.entry_ranges(colptr, cuts)
-    counts = [b - a for a, b in ranges]
-    c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
-
+    cfg = args.config
+    if cfg in ("c3", "c5") and world > 1:
+        raise SystemExit("--config %s is a single-GPU line" % cfg)
     ctx = fd.Context(local_rank)
+    lazy_ok = False
+    if cfg in ("c2", "c4"):
+        N = args.n or (10 ** 6 if cfg == "c2" else 10 ** 7)
+        seed, fdtype, C = (2 if cfg == "c2" else 4), "forward", 3
+        x_host = np.random.default_rng(seed).random(N)
+        colors = P.cyclic_colors(N, 3)
+        colptr, rowval = P.tridiag_csc(N)
+        nnz = rowval.size
+        cuts = S.partition_columns(colptr, world)
+        ranges = S.entry_ranges(colptr, cuts)
+        counts = [b - a for a, b in ranges]
+        c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
+        pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+        xw = S.x_window(cuts, rank, N, 1, 1, 1)
+        plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
+                            x_window=xw if world > 1 else None)
+        f = fd.BuiltinF("tridiag", N, ctx=ctx)
+        lazy_ok = True
+        bytes_ds, bytes_min, bytes_call = 89.0, 71.0, 210.0   # per column, SURVEY 8(d)
+        wl = "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, x~U(0,1) seed %d" % (N, seed)
+        kern = "k_decompress_list<u8,forward>"
+        exact = (-2.0, 1.0)
+        del rowval
+        pattern.rowval = None
+    elif cfg == "c3":
+        nx, ny = (4000, 2500) if not args.n else (int(args.n ** 0.5), int(args.n ** 0.5))
+        N = nx * ny
+        fdtype, C = "central", 5
+        x_host = np.random.default_rng(3).random(N)
+        colors = P.lap5_colors(nx, ny)
+        colptr, rowval = P.lap5_csc(nx, ny)
+        nnz = rowval.size
+        counts, c0, c1 = [nnz], 0, N
+        pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+        plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx)
+        f = fd.BuiltinF("lap5", nx, ny, ctx=ctx)
+        bytes_ds = (2 * C * 8 * N + nnz * 12 + 4 * (N + 1) + N) / N      # 145 B/col
+        bytes_min = (2 * C * 8 * N + nnz * 13) / N
+        bytes_call = (2 * C * 16 * N + 9 * N + 2 * C * 8 * N + 9 * N) / N + bytes_ds
+        wl = "N=%d (%dx%d) 5-point Laplacian CSC (nnz=%d), colours (i+2j)%%5+1, central, x~U(0,1) seed 3" % (N, nx, ny, nnz)
+        kern = "k_decompress_list<u8,central>"
+        exact = (-4.0, 1.0)
+        del rowval
+        pattern.rowval = None
+    else:  # c5
+        nb, bs = (args.n // 32 if args.n else 10 ** 4), 32
+        N = nb * bs
+        fdtype = "complex"
+        x_host = np.random.default_rng(5).random(N)
+        lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+        colors = lay.colors()
+        C = int(colors.max())
+        nnz = lay.data_len
+        counts, c0, c1 = [nnz], 0, N
+        Jbb = fd.BlockBandedMatrix(None, lay)
+        plan = fd.make_plan(Jbb, Jbb, colors, fdtype, ctx=ctx)
+        f = fd.BuiltinF("blockcoupled", nb, bs, ctx=ctx)
+        bytes_ds = (C * N * 16 + nnz * 8) / N
+        bytes_min = (nnz * 16 + nnz * 8 + N) / N                          # every stored value reads one complex f value
+        bytes_call = bytes_ds + (C * N * 16 * 3 + 9 * N) / N
+        wl = "%d dense %dx%d blocks, block-tridiagonal BlockBandedMatrix (N=%d, %d stored values), %d colours, complex step, x~U(0,1) seed 5" % (nb, bs, bs, N, nnz, C)
+        kern = "k_decompress_colrange<u8,complex>"
+        exact = None
     x = torch.as_tensor(x_host, device=dev)
-    pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
-    xw = S.x_window(cuts, rank, N, 1, 1, 1)
-    plan = fd.make_plan(pattern, pattern, colors, "forward", ctx=ctx, col_window=(c0, c1) if world > 1 else None,
-                        x_window=xw if world > 1 else None)
-    f = fd.BuiltinF("tridiag", N, ctx=ctx)
-    if args.f_mode == "lazy":
+    if args.f_mode == "lazy" and lazy_ok:
         plan.set_lazy(f)
+    f_mode = "lazy" if (args.f_mode == "lazy" and lazy_ok) else "materialized"
     gather = world > 1 and not args.no_gather
     bufs = S.AllGatherBuffers(counts, dev, torch.float64)
     out = bufs.local_view(rank)[: counts[rank]] if world > 1 else bufs.buf
-    del rowval  # pattern now lives on the device
-    pattern.rowval = None
 
     def step():
         plan.jacobian(f, x, [out], sync=False)
@@ -164,25 +219,28 @@ def main():
     if full is not None:
         v = full if world > 1 else out
         sample = v[:: max(1, v.numel() // 1000003)].cpu().numpy()
-        check = float(np.max(np.minimum(np.abs(sample + 2.0), np.abs(sample - 1.0))))
+        if exact is not None:  # linear fixture => the stored values are exactly the stencil weights
+            check = float(np.max(np.minimum(np.abs(sample - exact[0]), np.abs(sample - exact[1]))))
+        else:
+            check = float(np.isfinite(sample).all()) - 1.0
 
     if rank == 0:
         n_local = c1 - c0
         dec = tm["decompress"]
         dec_ms = dec["ms_sum"] / max(dec["launches"], 1)
-        achieved = BYTES_PER_COL_DS * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        achieved = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         tot_ms = tm["total"]["ms_sum"] / max(tm["total"]["launches"], 1)
         pmc = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 j = json.load(open(pmc_path))
-                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world:
+                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and cfg in ("c2", "c4"):
                     pmc = j.get("decompress_hbm_bytes_per_launch")
             except Exception:
                 pmc = None
         res = {
-            "metric": "Jacobian columns/s (forward-difference coloured sparse Jacobian, N=10^7 tridiagonal)",
+            "metric": "Jacobian columns/s (coloured sparse finite-difference Jacobian; headline config N=10^7 tridiagonal forward)",
             "value": N / (ms_step * 1e-3),
             "unit": "columns/s",
             "n_gpus": world,
@@ -194,25 +252,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, "
-                                   "x~U(0,1) seed 4" % N,
+            "config": {"workload": wl, "name": cfg, "fdtype": fdtype, "colors": C,
                        "parallelism": "columns x%d%s" % (world, "+allgather" if gather else ""),
-                       "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + 3 lazily perturbed points)"
-                                  if args.f_mode == "lazy" else
-                                  "built-in device f! behind fd_f_launch (materialised points, batched: 1 + 3)"),
+                       "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
+                                  if f_mode == "lazy" else
+                                  "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
                        "gather_in_step": bool(gather)},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
-                "kernel": "k_decompress_list<u8,forward> (fused difference + CSC decompression)",
+                "kernel": kern + " (fused difference + decompression)",
                 "avg_launch_ms": dec_ms, "launches_timed": dec["launches"],
-                "algorithmic_bytes_per_launch": BYTES_PER_COL_DS * n_local,
-                "min_traffic_bytes_per_launch": BYTES_PER_COL_MIN * n_local,
-                "achieved_on_min_traffic": BYTES_PER_COL_MIN * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0,
+                "algorithmic_bytes_per_launch": bytes_ds * n_local,
+                "min_traffic_bytes_per_launch": bytes_min * n_local,
+                "achieved_on_min_traffic": bytes_min * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0,
             },
             "stages_ms": {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in tm_all.items()},
-            "whole_call": {"gpu_ms": tot_ms, "algorithmic_bytes": BYTES_PER_COL_CALL * n_local,
-                           "gbps": BYTES_PER_COL_CALL * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0},
+            "whole_call": {"gpu_ms": tot_ms, "algorithmic_bytes": bytes_call * n_local,
+                           "gbps": bytes_call * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0},
             "ms_gather": ms_gather,
             "value_compute_only": N / ((ms_step - ms_gather) * 1e-3) if ms_step > ms_gather else None,
             "result_check_max_dev": check,
@@ -222,7 +279,7 @@ def main():
         except Exception as e:  # pragma: no cover
             res["stream_copy_gbps"] = None
             res["stream_copy_error"] = str(e)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cfg in ("c2", "c4"):
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n or N, args.cpu_reps)
             except Exception as e:  # pragma: no cover

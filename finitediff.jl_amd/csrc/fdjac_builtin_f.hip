@@ -189,6 +189,43 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
     }
 }
 
+// Same stencils, two rows per thread (nx even): 16-B loads of the centre / south / north pairs, two
+// scalar loads for the west / east neighbours, one 16-B store.  One-shot launch with the XCD-aware
+// tile mapping: the rows k-nx, k, k+nx that share x lines are evaluated by the same XCD, so each
+// line of x enters one L2 instead of three.
+template <bool CLAMP>
+__global__ void __launch_bounds__(kBlock)
+k_f_stencil5_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
+                int64_t r0, int64_t r1)
+{
+    const double *xb = x + (int64_t)blockIdx.y * xs;
+    double *fb = fx + (int64_t)blockIdx.y * fs;
+    const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int64_t k = r0 + tile * (2 * kBlock) + threadIdx.x * 2;   // r0 even, nx even => k, k+1 share a grid row
+    if (k >= r1) return;
+    const int64_t j = k / nx, i = k - j * nx;
+    const double2 c = *reinterpret_cast<const double2 *>(xb + k);
+    const bool hs = j > 0, hn = j + 1 < ny, hw = i > 0, he = i + 2 < nx;
+    double2 s = make_double2(0.0, 0.0), n = make_double2(0.0, 0.0);
+    if (hs) s = *reinterpret_cast<const double2 *>(xb + k - nx);
+    if (hn) n = *reinterpret_cast<const double2 *>(xb + k + nx);
+    const double w = hw ? xb[k - 1] : 0.0;
+    const double e = he ? xb[k + 2] : 0.0;
+    double v0, v1;
+    if (CLAMP) {
+        const double w0 = hw ? w : c.x, e1 = he ? e : c.y;
+        const double s0 = hs ? s.x : c.x, s1 = hs ? s.y : c.y, n0 = hn ? n.x : c.x, n1 = hn ? n.y : c.y;
+        v0 = (((c.x + w0) + c.y) + s0) + n0;
+        v1 = (((c.y + c.x) + e1) + s1) + n1;
+    } else {
+        v0 = (((w + c.y) + s.x) + n.x) - 4.0 * c.x;
+        v1 = (((c.x + e) + s.y) + n.y) - 4.0 * c.y;
+    }
+    *reinterpret_cast<double2 *>(fb + k) = make_double2(v0, v1);
+}
+
 // block-coupled: sig_b = sum_j w_j x_b[j], w_j = (j+1)/bs; one wave per block, fixed-order tree.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -308,11 +345,30 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
         break;
     }
     case FD_F_LAP5:
-        hipLaunchKernelGGL((k_f_stencil5<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
+    case FD_F_CLAMP5: {
+        const bool clamp = b->family == FD_F_CLAMP5;
+        if constexpr (sizeof(T) == 8) {
+            const bool ok = ((((uintptr_t)fx) | ((uintptr_t)x)) & 15) == 0 && (xs % 2 == 0 || nbatch == 1) &&
+                            (fs % 2 == 0 || nbatch == 1) && (b->prm[0] % 2 == 0);
+            if (ok) {
+                const int64_t r0e = r0 & ~(int64_t)1;
+                const int64_t ntiles = (r1 - r0e + 2 * kBlock - 1) / (2 * kBlock);
+                const dim3 g2((unsigned)(8 * xcd_chunks(ntiles)), (unsigned)nbatch, 1);
+                if (clamp)
+                    hipLaunchKernelGGL((k_f_stencil5_v2<true>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                                       b->prm[0], b->prm[1], xs, fs, r0e, r1);
+                else
+                    hipLaunchKernelGGL((k_f_stencil5_v2<false>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                                       b->prm[0], b->prm[1], xs, fs, r0e, r1);
+                break;
+            }
+        }
+        if (clamp)
+            hipLaunchKernelGGL((k_f_stencil5<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
+        else
+            hipLaunchKernelGGL((k_f_stencil5<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
         break;
-    case FD_F_CLAMP5:
-        hipLaunchKernelGGL((k_f_stencil5<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
-        break;
+    }
     case FD_F_BLOCKCOUPLED: {
         const int64_t nb = b->prm[0], bs = b->prm[1];
         if (b->sig_cap < nbatch * nb) {

@@ -38,6 +38,18 @@ constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many col
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 
+// XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
+// 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
+// (5-point stencils: rows k-nx, k, k+nx) would otherwise fetch every line into up to 3 different
+// L2s.  Giving XCD x the contiguous tile range [x*q, (x+1)*q) keeps each revisit in the L2 that
+// already holds the line.  Launch 8*q workgroups (q = ceil(ntiles/8)); tiles >= ntiles exit.
+// Placement is a performance assumption only -- results never depend on it.
+__host__ __device__ inline int64_t xcd_chunks(int64_t ntiles) { return (ntiles + 7) / 8; }
+__device__ inline int64_t xcd_tile(int64_t block, int64_t ntiles)
+{
+    return (block & 7) * xcd_chunks(ntiles) + (block >> 3);
+}
+
 struct TimedSpan {
     int stage;
     hipEvent_t a, b;

@@ -267,7 +267,10 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
     const int none = ColorTraits<CT>::none;
     // block tile = U*512 stored entries; pair u of thread t sits at tile + u*512 + 2t, so every
     // wave instruction (index load, colour load, value store) touches one dense 512-B / 1-KiB run.
-    const int64_t t0 = (int64_t)blockIdx.x * (U * kBlock * 2);
+    const int64_t ntiles = (n + (U * kBlock * 2) - 1) / (U * kBlock * 2);
+    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);   // XCD x walks its own contiguous range of tiles
+    if (tile_id >= ntiles) return;
+    const int64_t t0 = tile_id * (U * kBlock * 2);
 
     // phase 1: indices and colours (independent coalesced loads; the lists are padded to whole tiles)
     int r[2 * U], c[2 * U];
@@ -539,7 +542,7 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
         if (p->nnz_local == 0) break;
         const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)
         const int64_t tile = (int64_t)U * kBlock * 2;
-        const int64_t g = (p->nnz_local + tile - 1) / tile;
+        const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);
         const bool lds = B <= kEpsLdsMax;
         const size_t shm = lds ? sizeof(double) * (size_t)B : 0;
         const int vec_ok = (((uintptr_t)outs[0]) & 15) == 0;
