@@ -137,6 +137,7 @@ def main():
         pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
         plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx)
         f = fd.BuiltinF("lap5", nx, ny, ctx=ctx)
+        lazy_ok = True
         bytes_ds = (2 * C * 8 * N + nnz * 12 + 4 * (N + 1) + N) / N      # 145 B/col
         bytes_min = (2 * C * 8 * N + nnz * 13) / N
         bytes_call = (2 * C * 16 * N + 9 * N + 2 * C * 8 * N + 9 * N) / N + bytes_ds

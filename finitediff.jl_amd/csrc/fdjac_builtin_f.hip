@@ -226,6 +226,81 @@ k_f_stencil5_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t n
     *reinterpret_cast<double2 *>(fb + k) = make_double2(v0, v1);
 }
 
+// Lazy-point version of the 5-point stencils (see k_f_tridiag_lazy): the 8 base values a pair of rows
+// depends on are loaded once, every point of the batch is evaluated from registers.
+// v[8] = {c0, c1, s0, s1, n0, n1, w, e} = x at {k, k+1, k-nx, k-nx+1, k+nx, k+nx+1, k-1, k+2}.
+template <typename T, bool CLAMP>
+__device__ __forceinline__ void stencil5_pair(const T *v, bool hs, bool hn, bool hw, bool he, T &o0, T &o1)
+{
+    if (CLAMP) {
+        const T w0 = hw ? v[6] : v[0], e1 = he ? v[7] : v[1];
+        const T s0 = hs ? v[2] : v[0], s1 = hs ? v[3] : v[1], n0 = hn ? v[4] : v[0], n1 = hn ? v[5] : v[1];
+        o0 = (((v[0] + w0) + v[1]) + s0) + n0;
+        o1 = (((v[1] + v[0]) + e1) + s1) + n1;
+    } else {
+        const T z = zero_of<T>();
+        const T w = hw ? v[6] : z, e = he ? v[7] : z;
+        const T s0 = hs ? v[2] : z, s1 = hs ? v[3] : z, n0 = hn ? v[4] : z, n1 = hn ? v[5] : z;
+        o0 = (((w + v[1]) + s0) + n0) - 4.0 * v[0];
+        o1 = (((v[0] + e) + s1) + n1) - 4.0 * v[1];
+    }
+}
+
+template <typename CT, int MODE, bool CLAMP>
+__global__ void __launch_bounds__(kBlock)
+k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
+                  const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
+                  int64_t r0, int64_t r1)
+{
+    const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int64_t k = r0 + tile * (2 * kBlock) + threadIdx.x * 2;
+    if (k >= r1) return;
+    const int64_t j = k / nx, i = k - j * nx;
+    const bool hs = j > 0, hn = j + 1 < ny, hw = i > 0, he = i + 2 < nx;
+    const int64_t idx[8] = {k, k + 1, k - nx, k - nx + 1, k + nx, k + nx + 1, k - 1, k + 2};
+    const bool ok[8] = {true, true, hs, hs, hn, hn, hw, he};
+    double xv[8];
+    int cv[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int64_t at = ok[m] ? idx[m] : k;
+        xv[m] = x[at];
+        const int c = (int)color[at];
+        cv[m] = (!ok[m] || c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+    }
+    if (base_out) {
+        double b0, b1;
+        stencil5_pair<double, CLAMP>(xv, hs, hn, hw, he, b0, b1);
+        *reinterpret_cast<double2 *>(base_out + k) = make_double2(b0, b1);
+    }
+    for (int b = 0; b < B; ++b) {
+        const double e = eps[c_lo + b];
+        double d[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) d[m] = (cv[m] == b) ? e : 0.0;
+        if (MODE == 2) {
+            cd p[8], o0, o1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) p[m] = cd{xv[m], d[m]};
+            stencil5_pair<cd, CLAMP>(p, hs, hn, hw, he, o0, o1);
+            double *dst = fx + ((int64_t)b * fs + k) * 2;
+            *reinterpret_cast<double2 *>(dst) = make_double2(o0.re, o0.im);
+            *reinterpret_cast<double2 *>(dst + 2) = make_double2(o1.re, o1.im);
+        } else {
+#pragma unroll
+            for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
+                double p[8], o0, o1;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) p[m] = sgn == 0 ? xv[m] + d[m] : xv[m] - d[m];
+                stencil5_pair<double, CLAMP>(p, hs, hn, hw, he, o0, o1);
+                *reinterpret_cast<double2 *>(fx + (int64_t)(sgn * B + b) * fs + k) = make_double2(o0, o1);
+            }
+        }
+    }
+}
+
 // block-coupled: sig_b = sum_j w_j x_b[j], w_j = (j+1)/bs; one wave per block, fixed-order tree.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -427,12 +502,38 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
+template <typename CT>
+static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, int64_t fs, int64_t r0, int64_t r1,
+                                hipStream_t s)
+{
+    const int64_t r0e = r0 & ~(int64_t)1;
+    const int64_t ntiles = (r1 - r0e + 2 * kBlock - 1) / (2 * kBlock);
+    const unsigned g = (unsigned)(8 * xcd_chunks(ntiles));
+    const bool clamp = b->family == FD_F_CLAMP5;
+    const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
+#define FD_LAZY(MODE, CL)                                                                                          \
+    hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (double *)fx, fs,            \
+                       (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,    \
+                       lp->ncolors, b->prm[0], b->prm[1], r0e, r1)
+    if (mode == 0) { if (clamp) FD_LAZY(0, true); else FD_LAZY(0, false); }
+    else if (mode == 1) { if (clamp) FD_LAZY(1, true); else FD_LAZY(1, false); }
+    else { if (clamp) FD_LAZY(2, true); else FD_LAZY(2, false); }
+#undef FD_LAZY
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
+static bool has_lazy(const BuiltinF *b)
+{
+    if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
+    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
+}
+
 static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64_t fx_stride, int64_t row_begin,
                                int64_t row_end, void *stream)
 {
     BuiltinF *b = (BuiltinF *)fctx;
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
-    if (b->family != FD_F_TRIDIAG && b->family != FD_F_TRIDIAG_NL) return 6;
+    if (!has_lazy(b)) return 6;
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & 15) != 0 || (fx_stride & 1)) return 7;
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + (lp->base_out ? 1 : 0);
@@ -440,8 +541,12 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     b->points.fetch_add(npts);
     const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
     if (r1 <= r0 || lp->ncolors <= 0) return 0;
-    if (lp->color_bytes == 1) return lazy_tridiag_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, (hipStream_t)stream);
-    return lazy_tridiag_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, (hipStream_t)stream);
+    const hipStream_t s = (hipStream_t)stream;
+    if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5)
+        return lp->color_bytes == 1 ? lazy_stencil5_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                    : lazy_stencil5_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
+    return lp->color_bytes == 1 ? lazy_tridiag_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                : lazy_tridiag_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
 }
 
 }  // namespace fdjac
@@ -509,8 +614,8 @@ int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out)
 {
     BuiltinF *b = (BuiltinF *)fctx;
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && fn_out, FD_ERR_ARG, "not a built-in f context");
-    if (b->family != FD_F_TRIDIAG && b->family != FD_F_TRIDIAG_NL) {
-        set_error("family %d has no lazy-point launcher", b->family);
+    if (!has_lazy(b)) {
+        set_error("family %d has no lazy-point launcher (5-point stencils need an even nx)", b->family);
         return FD_ERR_UNSUPPORTED;
     }
     *fn_out = builtin_launch_lazy;

@@ -427,3 +427,28 @@ def test_lazy_points_bit_identical(fdtype, N, C, cap):
         calls.append((f.fcalls, plan.fcalls_last))
     assert np.array_equal(outs[0], outs[1])
     assert calls[0] == calls[1]
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("family", ["lap5", "clamp5"])
+def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
+    nx, ny = 64, 37
+    N = nx * ny
+    xh = np.random.default_rng(77).random(N)
+    x = _dev(xh)
+    colors = P.lap5_colors(nx, ny)
+    colptr, rowval = P.lap5_csc(nx, ny)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    outs = []
+    for lazy in (False, True):
+        plan = fd.make_plan(J, J, colors, fdtype)
+        f = fd.BuiltinF(family, nx, ny)
+        if lazy:
+            plan.set_lazy(f)
+        out = _dev(np.full(rowval.size, np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    ref = oracle.jacobian(fdtype, oracle.Fixture(family, nx, ny), xh, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)
+    _tol_ok(outs[1], ref["out"], np.min(np.abs(_oracle_eps(xh, colors, fdtype))), 8.0, "lazy " + family)
