@@ -231,6 +231,68 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     rows.resize(padded, 0);
     nzc.resize(padded, -2);
     if (has_dest) dest.resize(padded, 0);
+    for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
+
+    // Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of
+    // tiles: distinct 128-B lines touched by one wave-level gather (64 lanes, the kernels' lane->entry maps).
+    std::vector<uint16_t> spos;
+    if (!has_dest && p->nnz_local >= 4 * kSortTile) {
+        const char *force = getenv("FDJAC_SORTED");
+        const size_t ntiles = padded / kSortTile;
+        const size_t step = std::max<size_t>(1, ntiles / 64);
+        auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
+        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
+        auto sort_key = [&](size_t e, int k) {
+            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
+            return (c << 32) | ((int64_t)(uint32_t)rows[e]);
+            (void)k;
+        };
+        std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+        auto sort_tile = [&](size_t b0) {
+            for (int k = 0; k < kSortTile; ++k) ord[(size_t)k] = {sort_key(b0 + (size_t)k, k), k};
+            std::sort(ord.begin(), ord.end());
+        };
+        double ld = 0, ls = 0;
+        size_t ninstr = 0;
+        std::vector<int64_t> keys;
+        for (size_t t = 0; t < ntiles; t += step) {
+            const size_t b0 = t * kSortTile;
+            sort_tile(b0);
+            for (int g = 0; g < kSortTile / 128; ++g)
+                for (int half = 0; half < 2; ++half) {
+                    keys.clear();
+                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)(g * 128 + 2 * l + half); keys.push_back(line_key(nzc[e], rows[e])); }
+                    std::sort(keys.begin(), keys.end());
+                    ld += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                    keys.clear();
+                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)ord[(size_t)(g * 128 + 64 * half + l)].second; keys.push_back(line_key(nzc[e], rows[e])); }
+                    std::sort(keys.begin(), keys.end());
+                    ls += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                    ++ninstr;
+                }
+        }
+        p->lines_direct = ld / std::max<size_t>(ninstr, 1);
+        p->lines_sorted = ls / std::max<size_t>(ninstr, 1);
+        p->sorted_gather = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
+        if (force && *force) p->sorted_gather = atoi(force) != 0;
+        if (p->sorted_gather) {
+            spos.resize(padded);
+            std::vector<int32_t> r2(kSortTile), c2(kSortTile);
+            for (size_t t = 0; t < ntiles; ++t) {
+                const size_t b0 = t * kSortTile;
+                sort_tile(b0);
+                for (int q = 0; q < kSortTile; ++q) {
+                    const int k = ord[(size_t)q].second;
+                    r2[(size_t)q] = rows[b0 + (size_t)k];
+                    c2[(size_t)q] = nzc[b0 + (size_t)k];
+                    spos[b0 + (size_t)q] = (uint16_t)k;
+                }
+                std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
+                std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
+            }
+            if ((rc = dev_upload(&p->d_spos, spos))) return rc;
+        }
+    }
     if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
     if ((rc = upload_colors(p, col0, nzc))) return rc;
     if (has_dest && (rc = dev_upload(&p->d_dest, dest))) return rc;
@@ -302,7 +364,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
     for (void *q : ptrs)
@@ -583,6 +645,9 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_NNZ_LOCAL: *value = p->nnz_local; break;
     case FD_INFO_FCALLS_LAST: *value = p->fcalls_last; break;
     case FD_INFO_ENTRY_BEGIN: *value = p->entry_begin; break;
+    case FD_INFO_SORTED_GATHER: *value = p->sorted_gather ? 1 : 0; break;
+    case FD_INFO_LINES_DIRECT_X100: *value = (int64_t)(p->lines_direct * 100); break;
+    case FD_INFO_LINES_SORTED_X100: *value = (int64_t)(p->lines_sorted * 100); break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;

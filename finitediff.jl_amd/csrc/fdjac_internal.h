@@ -37,6 +37,7 @@ constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
+constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
 
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
@@ -78,6 +79,11 @@ struct fd_plan {
     int32_t *d_rowval = nullptr;   // per local stored entry, 0-based row
     void *d_nzcolor = nullptr;     // per local stored entry
     int64_t *d_dest = nullptr;     // per local stored entry destination offset (dense-J kinds)
+    // sorted-gather variant (scattered patterns): per tile of kSortTile entries, entries ordered by colour
+    bool sorted_gather = false;
+    uint16_t *d_spos = nullptr;    //   local output position (within the tile) of each sorted entry
+    bool has_none = false;         //   some column has no colour (its entries are written as 0)
+    double lines_direct = 0, lines_sorted = 0;  // plan-time estimate: distinct 128-B lines per wave gather
     int64_t nnz_local = 0;
     int64_t entry_begin = 0;       // global index of the first local stored entry
     int64_t l = 0, u = 0;          // banded

@@ -331,6 +331,85 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
     }
 }
 
+// K3b  the same decompression for SCATTERED patterns (e.g. 5-point stencils, where one wave of
+//   storage-ordered entries gathers from ~40 different 128-B lines per instruction and the kernel
+//   becomes texture-addresser bound).  At plan time every tile of kSortTile entries is reordered by
+//   colour, so a wave's gathers walk one batched f! output array with near-consecutive rows; the
+//   values are then scattered to their storage position *inside LDS* and written to nzval with
+//   dense 16-B stores.  This is the north-star's "LDS staging + sparse scatter", done per tile.
+//   spos[q] = position (0..kSortTile-1) of sorted entry q inside its tile.
+//   ALLW: every entry of every tile is written (single colour chunk, no uncoloured column) -> no flags.
+template <typename CT, int MODE, bool LDS_EPS, bool ALLW, bool SORTED>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ scol,
+                    const uint16_t *__restrict__ spos, const double *__restrict__ FXa,
+                    const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps, int c_lo,
+                    int c_hi, double *__restrict__ out, int64_t n, int vec_ok)
+{
+    constexpr int E = kSortTile / kBlock;   // entries per thread (8); entry e of thread t is tile + e*256 + t,
+                                            // so one wave-level gather covers 64 CONSECUTIVE sorted entries
+    extern __shared__ double s_mem[];
+    double *s_val = s_mem;                                             // kSortTile values
+    uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_mem + kSortTile);  // kSortTile flags (ALLW: unused)
+    const int nB = c_hi - c_lo;
+    double *s_eps = s_mem + kSortTile + (ALLW ? 0 : kSortTile / 8);
+    if (LDS_EPS)
+        for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
+    const int none = ColorTraits<CT>::none;
+    const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
+    if (tile_id >= ntiles) return;
+    const int64_t t0 = tile_id * kSortTile;
+    if (LDS_EPS) __syncthreads();
+
+    int r[E], c[E], pos[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int lq = k * kBlock + threadIdx.x;
+        r[k] = srow[t0 + lq];
+        c[k] = (int)scol[t0 + lq];
+        pos[k] = SORTED ? (int)spos[t0 + lq] : lq;
+    }
+    double a[E], b[E], e[E];
+    bool valid[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int cb = c[k] - c_lo;
+        valid[k] = (c[k] != none) & (c[k] != ColorTraits<CT>::pad) & ((unsigned)cb < (unsigned)nB);
+        const int cs = valid[k] ? cb : 0;
+        const int64_t at = (int64_t)cs * ld + r[k];
+        e[k] = LDS_EPS ? s_eps[cs] : eps[c_lo + cs];
+        if (MODE == 0) { a[k] = FXa[at]; b[k] = FXb[r[k]]; }
+        else if (MODE == 1) { a[k] = FXa[at]; b[k] = FXb[at]; }
+        else { a[k] = FXa[at * 2 + 1]; b[k] = 0.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        double q;
+        if (MODE == 0) q = (a[k] - b[k]) / e[k];
+        else if (MODE == 1) q = (a[k] - b[k]) / (2 * e[k]);
+        else q = a[k] / e[k];
+        s_val[pos[k]] = valid[k] ? q : 0.0;
+        if (!ALLW) s_flag[pos[k]] = (uint8_t)(valid[k] | ((c[k] == none) & (c_lo == 0)));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E / 2; ++u) {
+        const int lp = u * kBlock * 2 + threadIdx.x * 2;
+        const int64_t p = t0 + lp;
+        const d2_t pk = *reinterpret_cast<const d2_t *>(s_val + lp);
+        bool w0 = p < n, w1 = p + 1 < n;
+        if (!ALLW) { w0 = w0 & (s_flag[lp] != 0); w1 = w1 & (s_flag[lp + 1] != 0); }
+        const bool both = w0 & w1 & (vec_ok != 0);
+        if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
+            *reinterpret_cast<d2_t *>(out + p) = pk;
+        } else {
+            if (w0) out[p] = pk.x;
+            if (w1) out[p + 1] = pk.y;
+        }
+    }
+}
+
 // K4a  Tridiagonal J: three dense diagonals, no index traffic at all.
 //   d[j] = D_c(j)[j] ; dl[j] = D_c(j)[j+1] ; du[j-1] = D_c(j)[j-1],  D_c = (fx1_c - fx)/eps_c
 //   (what src/iteration_utils.jl:25-32 stores through Tridiagonal's setindex!).
@@ -540,6 +619,31 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
     case K_CSC_DENSE:
     case K_COO_DENSE: {
         if (p->nnz_local == 0) break;
+        const int lds_stage = (int)env_i64("FDJAC_LDS_STAGE", 0);   // experiment: LDS-staged stores in storage order
+        if ((p->sorted_gather || lds_stage) && p->kind == K_CSC) {
+            const bool ldsq = B <= kEpsLdsMax;
+            const bool allw = (p->nchunks == 1) && !p->has_none;
+            const int64_t gq = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
+            const size_t shmq = sizeof(double) * (size_t)(kSortTile + (allw ? 0 : kSortTile / 8) + (ldsq ? B : 0));
+            const int vok = (((uintptr_t)outs[0]) & 15) == 0;
+#define FD_LAUNCH_SORTED(LL, AW, SS)                                                                                 \
+            hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
+                               p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
+                               c_hi, outs[0], p->nnz_local, vok)
+            if (p->sorted_gather) {
+                if (ldsq && allw) FD_LAUNCH_SORTED(true, true, true);
+                else if (ldsq) FD_LAUNCH_SORTED(true, false, true);
+                else if (allw) FD_LAUNCH_SORTED(false, true, true);
+                else FD_LAUNCH_SORTED(false, false, true);
+            } else {
+                if (ldsq && allw) FD_LAUNCH_SORTED(true, true, false);
+                else if (ldsq) FD_LAUNCH_SORTED(true, false, false);
+                else if (allw) FD_LAUNCH_SORTED(false, true, false);
+                else FD_LAUNCH_SORTED(false, false, false);
+            }
+#undef FD_LAUNCH_SORTED
+            break;
+        }
         const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)
         const int64_t tile = (int64_t)U * kBlock * 2;
         const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);

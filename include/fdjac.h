@@ -166,7 +166,10 @@ enum fd_plan_info_key {
     FD_INFO_M = 0, FD_INFO_N = 1, FD_INFO_NCOLORS = 2, FD_INFO_NOUTS = 3,
     FD_INFO_OUT0_LEN = 4, FD_INFO_OUT1_LEN = 5, FD_INFO_OUT2_LEN = 6,
     FD_INFO_ROW_BEGIN = 7, FD_INFO_ROW_END = 8, FD_INFO_NCHUNKS = 9, FD_INFO_SCRATCH_BYTES = 10,
-    FD_INFO_NNZ_LOCAL = 11, FD_INFO_FCALLS_LAST = 12, FD_INFO_ENTRY_BEGIN = 13
+    FD_INFO_NNZ_LOCAL = 11, FD_INFO_FCALLS_LAST = 12, FD_INFO_ENTRY_BEGIN = 13,
+    FD_INFO_SORTED_GATHER = 14,       /* 1 if the LDS-transposed (colour-sorted) decompression kernel is used */
+    FD_INFO_LINES_DIRECT_X100 = 15,   /* plan-time estimate, x100: 128-B lines per wave gather, storage order */
+    FD_INFO_LINES_SORTED_X100 = 16    /*   ... colour-sorted order */
 };
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 

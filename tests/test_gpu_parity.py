@@ -452,3 +452,50 @@ def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
     ref = oracle.jacobian(fdtype, oracle.Fixture(family, nx, ny), xh, colors, kind=oracle.PAT_CSC_COMMON,
                           colptr=colptr, rowval=rowval)
     _tol_ok(outs[1], ref["out"], np.min(np.abs(_oracle_eps(xh, colors, fdtype))), 8.0, "lazy " + family)
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "lap5"])
+def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
+    # the LDS-transposed (colour-sorted) decompression must equal the storage-order kernel bit for bit
+    if case == "lap5":
+        nx, ny = 128, 96
+        N = nx * ny
+        colptr, rowval = P.lap5_csc(nx, ny)
+        colors = P.lap5_colors(nx, ny)
+        fam, prm, cap = "lap5", (nx, ny), 0
+    else:
+        N = 9001
+        colptr, rowval = P.tridiag_csc(N)
+        colors = P.cyclic_colors(N, 3)
+        fam, prm = "tridiag_nl", (N,)
+        cap = 300_000 if case == "tridiag_chunked" else 0
+        if case == "tridiag_none":
+            colors[[0, 77, 4096, N - 1]] = 0
+    x = _dev(np.random.default_rng(31).random(N))
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    outs = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FDJAC_SORTED", forced)
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
+        assert plan.info(fd.lib.INFO_SORTED_GATHER) == int(forced)
+        out = _dev(np.full(rowval.size, np.nan))
+        plan.jacobian(fd.BuiltinF(fam, *prm), x, [out])
+        outs.append(out.cpu().numpy())
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_sorted_gather_heuristic(monkeypatch):
+    monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    N = 20000
+    colptr, rowval = P.tridiag_csc(N)
+    Jt = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    pt = fd.make_plan(Jt, Jt, P.cyclic_colors(N, 3), "forward")
+    assert pt.info(fd.lib.INFO_SORTED_GATHER) == 0          # banded: storage order is already coherent
+    nx, ny = 400, 100
+    colptr, rowval = P.lap5_csc(nx, ny)
+    Jl = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
+    pl = fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central")
+    assert pl.info(fd.lib.INFO_SORTED_GATHER) == 1          # 5-point stencil: scattered
+    assert pl.info(fd.lib.INFO_LINES_DIRECT_X100) > 1.5 * pl.info(fd.lib.INFO_LINES_SORTED_X100)
