@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="override the number of states (columns)")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="override the number of states (columns)")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c4",
                     help="BASELINE.json configs: c4 = headline (N=10^7 tridiagonal forward; --gpus N shards it), "
                          "c2 = N=10^6 tridiagonal forward, c3 = N=10^7 5-point Laplacian central, "
@@ -91,11 +91,19 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FDJAC_BENCH_BACKEND=gloo is a functional dry run of the N>1 path on fewer GPUs than ranks (ranks
+    # share devices, the gather is staged through host memory); the measured configuration is "nccl" (RCCL).
+    backend = os.environ.get("FDJAC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = args.config
     if cfg in ("c3", "c5") and world > 1:
@@ -173,10 +181,20 @@ def main():
     bufs = S.AllGatherBuffers(counts, dev, torch.float64)
     out = bufs.local_view(rank)[: counts[rank]] if world > 1 else bufs.buf
 
+    host_bufs = S.AllGatherBuffers(counts, torch.device("cpu"), torch.float64) if (gather and backend != "nccl") else None
+
+    def do_gather():
+        if backend == "nccl":
+            bufs.gather(rank, dist)          # one ncclAllGather, in place in the padded buffer
+        else:                                # dry run: stage through host memory
+            host_bufs.local_view(rank).copy_(bufs.local_view(rank))
+            host_bufs.gather(rank, dist)
+            bufs.buf.copy_(host_bufs.buf)
+
     def step():
         plan.jacobian(f, x, [out], sync=False)
         if gather:
-            bufs.gather(rank, dist)
+            do_gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -195,7 +213,7 @@ def main():
         plan.jacobian(f, x, [out], sync=False)
         if gather:
             ev[2 * k].record()
-            bufs.gather(rank, dist)
+            do_gather()
             ev[2 * k + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
@@ -258,7 +276,7 @@ def main():
                        "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
                                   if f_mode == "lazy" else
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
-                       "gather_in_step": bool(gather)},
+                       "gather_in_step": bool(gather), "collective_backend": backend if world > 1 else None},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
