@@ -542,3 +542,54 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
         J[...] = staged
     cache.last_plan = plan
     return None
+
+
+class JVPCache:
+    """FiniteDiff.JVPCache (src/jvp.jl:1-60): JVPCache(x, fdtype="forward") / JVPCache(x, fx1, fdtype)."""
+
+    def __init__(self, x1, fx1=None, fdtype="forward"):
+        if isinstance(fx1, str):
+            fdtype, fx1 = fx1, None
+        self.fdtype = _norm_fdtype(fdtype)
+        self.x1, self.fx1 = x1, (fx1 if fx1 is not None else x1)
+        self._plan = None
+
+    def _plan_for(self, M, N, ctx):
+        if self.fdtype == "complex":
+            raise ValueError("finite_difference_jvp doesn't support :complex-mode finite diff")  # src/jvp.jl:248-250
+        key = (M, N, id(ctx))
+        if self._plan is None or self._plan[0] != key:
+            h = C.c_void_p()
+            _l.check(ctx.L.fd_jvp_plan_create(ctx.handle, M, N, _l.FDTYPES[self.fdtype], C.byref(h)))
+            fin = weakref.finalize(self, ctx.L.fd_jvp_plan_destroy, h)
+            self._plan = (key, h, fin, ctx)
+        return self._plan[1]
+
+
+def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None, absstep=None, dir=True, ctx=None):
+    """``FiniteDiff.finite_difference_jvp!(jvp, f, x, v, cache, f_in; relstep, absstep, dir)`` (src/jvp.jl:238-274);
+    cache may be a JVPCache or an fdtype name (cache-less form).  Fills jvp, returns None."""
+    if not isinstance(cache, JVPCache):
+        cache = JVPCache(x, "forward" if cache is None else cache)
+    ctx = ctx or getattr(f, "ctx", None) or Context.default()
+    M, N = int(np.prod(jvp.shape)), int(np.prod(x.shape))
+    h = cache._plan_for(M, N, ctx)
+    xp, xk, _a = _ptr(x, "x")
+    vp_, vk, _b = _ptr(v, "v")
+    if xk != vk:
+        raise ValueError("x and v must both be host or both be device arrays")
+    op, ok, _c = _ptr(jvp, "jvp")
+    fp, fk = None, _l.DEVICE
+    if f_in is not None and cache.fdtype == "forward":
+        fp, fk, _d = _ptr(f_in, "f_in")
+    rc = ctx.L.fd_jvp(h, f.fn, f.fctx, xp, vp_, xk, fp, fk, -1.0 if relstep is None else float(relstep),
+                      -1.0 if absstep is None else float(absstep), float(dir), op, ok)
+    err = getattr(f, "error", None)
+    if err is not None:
+        f.error = None
+        raise err
+    _l.check(rc)
+    e = C.c_double()
+    _l.check(ctx.L.fd_jvp_get_epsilon(h, C.byref(e)))
+    cache.last_epsilon = e.value
+    return None

@@ -1,0 +1,208 @@
+// Jacobian-vector products by finite differences on the device: FiniteDiff.finite_difference_jvp!
+// (reference: src/jvp.jl:238-274).  A coloured-Jacobian colour step IS a JVP with v = colour mask,
+// so this reuses the same pieces: a deterministic reduction for the step size, a perturbation pass
+// written from the pristine x, the fd_f_launch boundary, and a fused difference.
+//   eps     = compute_epsilon(fdtype, sqrt(abs(dot(x, v))), relstep, absstep, dir)   (src/jvp.jl:253-254)
+//   forward : jvp = (f(x + eps v) - f(x)) / eps                                     (:255-263)
+//   central : jvp = (f(x + eps v) - f(x - eps v)) / (2 eps)                         (:264-269)
+#include <cmath>
+#include <new>
+
+#include "fdjac_internal.h"
+
+namespace fdjac {
+
+int balanced_grid(int64_t tiles, int64_t cap);
+
+__device__ __forceinline__ double wave_sum_j(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_dot_partial(const double *__restrict__ x, const double *__restrict__ v, int64_t n, double *__restrict__ partial)
+{
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += x[i] * v[i];
+    __shared__ double red[kBlock / 64];
+    acc = wave_sum_j(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_jvp_eps(const double *__restrict__ partial, int nparts, double relstep, double absstep, double dir, int is_forward,
+          double *__restrict__ eps)
+{
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += kBlock) acc += partial[k];
+    __shared__ double red[kBlock / 64];
+    acc = wave_sum_j(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+        const double tmp = sqrt(fabs(t));
+        const double a = relstep * fabs(tmp);
+        double e = (a > absstep) ? a : absstep;   // src/epsilons.jl:26-29,50-53
+        if (is_forward) e = e * dir;
+        eps[0] = e;
+    }
+}
+
+// forward: X[0] = x + eps v ; central: X[0] = x - eps v, X[1] = x + eps v   (src/jvp.jl:260,265,267)
+__global__ void __launch_bounds__(kBlock)
+k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const double *__restrict__ eps, int central,
+             int64_t n, double *__restrict__ X, int64_t ld)
+{
+    const double e = eps[0];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double xi = x[i], ev = e * v[i];
+        if (central) {
+            X[i] = xi - ev;
+            X[ld + i] = xi + ev;
+        } else {
+            X[i] = xi + ev;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_jvp_diff(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ eps, int central,
+           int64_t m, double *__restrict__ out)
+{
+    const double e = central ? 2 * eps[0] : eps[0];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) out[i] = (a[i] - b[i]) / e;
+}
+
+}  // namespace fdjac
+
+struct fd_jvp_plan {
+    fd_ctx *ctx = nullptr;
+    int fdtype = 0;
+    int64_t M = 0, N = 0, ldx = 0, ldf = 0;
+    double *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr, *d_partial = nullptr;
+    double *d_xs = nullptr, *d_vs = nullptr, *d_fin = nullptr, *d_out = nullptr;
+    int nparts = 1;
+};
+
+using namespace fdjac;
+
+extern "C" {
+
+int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_plan **out)
+{
+    FD_REQUIRE(ctx && out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(M >= 1 && N >= 1, FD_ERR_SHAPE, "bad shape");
+    if (fdtype != FD_FORWARD && fdtype != FD_CENTRAL) {
+        // src/jvp.jl:248-250, :270-271
+        set_error("finite_difference_jvp doesn't support :complex-mode finite diff");
+        return FD_ERR_UNSUPPORTED;
+    }
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    fd_jvp_plan *p = new (std::nothrow) fd_jvp_plan();
+    FD_REQUIRE(p, FD_ERR_NOMEM, "out of host memory");
+    p->ctx = ctx; p->fdtype = fdtype; p->M = M; p->N = N;
+    p->ldx = (N + 31) / 32 * 32; p->ldf = (M + 31) / 32 * 32;
+    p->nparts = balanced_grid((N + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8);
+    const int pts = fdtype == FD_CENTRAL ? 2 : 1;
+    void **slots[] = {(void **)&p->d_X, (void **)&p->d_FX, (void **)&p->d_fx, (void **)&p->d_eps, (void **)&p->d_partial,
+                      (void **)&p->d_xs, (void **)&p->d_vs, (void **)&p->d_fin, (void **)&p->d_out};
+    const int64_t sizes[] = {pts * p->ldx, pts * p->ldf, p->ldf, 1, p->nparts, p->ldx, p->ldx, p->ldf, p->ldf};
+    for (int k = 0; k < 9; ++k)
+        if (hipMalloc(slots[k], sizeof(double) * (size_t)sizes[k]) != hipSuccess) {
+            set_error("hipMalloc failed in fd_jvp_plan_create");
+            for (int q = 0; q < k; ++q) (void)hipFree(*slots[q]);
+            delete p;
+            return FD_ERR_NOMEM;
+        }
+    *out = p;
+    return FD_OK;
+}
+
+int fd_jvp_plan_destroy(fd_jvp_plan *p)
+{
+    if (!p) return FD_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    void *ptrs[] = {p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xs, p->d_vs, p->d_fin, p->d_out};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+    return FD_OK;
+}
+
+int fd_jvp(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind, const void *f_in,
+           int f_in_kind, double relstep, double absstep, double dir, void *jvp_out, int out_kind)
+{
+    FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int central = p->fdtype == FD_CENTRAL;
+    if (!(relstep > 0)) relstep = central ? std::cbrt(2.220446049250313e-16) : std::sqrt(2.220446049250313e-16);
+    if (absstep < 0) absstep = relstep;
+    const double *xd = (const double *)x, *vd = (const double *)v, *fin = (const double *)f_in;
+    if (xv_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xs, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_vs, v, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        xd = p->d_xs; vd = p->d_vs;
+    }
+    if (f_in && f_in_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_fin, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
+        fin = p->d_fin;
+    }
+    double *out = out_kind == FD_DEVICE ? (double *)jvp_out : p->d_out;
+    const int g = balanced_grid((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
+    const int gm = balanced_grid((p->M + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_dot_partial, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+    hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
+                       central ? 0 : 1, p->d_eps);
+    hipLaunchKernelGGL(k_jvp_points, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    FD_HIP_CHECK(hipGetLastError());
+    const double *a, *b;
+    int rc;
+    if (central) {
+        rc = f(fctx, p->d_FX, p->d_X, 2, p->ldx, p->ldf, 0, p->M, 0, (void *)s);
+        FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+        a = p->d_FX + p->ldf;  // f(x + eps v)
+        b = p->d_FX;           // f(x - eps v)
+    } else {
+        if (fin) {
+            b = fin;
+        } else {
+            rc = f(fctx, p->d_fx, xd, 1, p->N, p->ldf, 0, p->M, 0, (void *)s);
+            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+            b = p->d_fx;
+        }
+        rc = f(fctx, p->d_FX, p->d_X, 1, p->ldx, p->ldf, 0, p->M, 0, (void *)s);
+        FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+        a = p->d_FX;
+    }
+    hipLaunchKernelGGL(k_jvp_diff, dim3(gm), dim3(kBlock), 0, s, a, b, p->d_eps, central, p->M, out);
+    FD_HIP_CHECK(hipGetLastError());
+    if (out_kind == FD_HOST)
+        FD_HIP_CHECK(hipMemcpyAsync(jvp_out, out, sizeof(double) * (size_t)p->M, hipMemcpyDeviceToHost, s));
+    FD_HIP_CHECK(hipStreamSynchronize(s));
+    return FD_OK;
+}
+
+int fd_jvp_get_epsilon(fd_jvp_plan *p, double *eps_out)
+{
+    FD_REQUIRE(p && eps_out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    FD_HIP_CHECK(hipMemcpy(eps_out, p->d_eps, sizeof(double), hipMemcpyDeviceToHost));
+    return FD_OK;
+}
+
+}  // extern "C"

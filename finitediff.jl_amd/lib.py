@@ -45,6 +45,7 @@ EXPORTS = (
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy",
+    "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_get_epsilon",
 )
 
 
@@ -112,6 +113,10 @@ def load():
     L.fd_builtin_f_destroy.argtypes = [vp]
     L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.fd_stream_copy_gbps.argtypes = [vp, i64, i32, C.POINTER(dbl)]
+    L.fd_jvp_plan_create.argtypes = [vp, i64, i64, i32, pp]
+    L.fd_jvp_plan_destroy.argtypes = [vp]
+    L.fd_jvp.argtypes = [vp, F_LAUNCH, vp, vp, vp, i32, vp, i32, dbl, dbl, dbl, vp, i32]
+    L.fd_jvp_get_epsilon.argtypes = [vp, C.POINTER(dbl)]
     L.fd_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY]
     L.fd_builtin_f_lazy.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY)]
     for name in EXPORTS:

@@ -221,6 +221,17 @@ int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
 /* The lazy-point launcher of a built-in family (FD_ERR_UNSUPPORTED if the family has none). */
 int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
 
+/* ---- Jacobian-vector products: finite_difference_jvp!, src/jvp.jl:238-274 ---- */
+typedef struct fd_jvp_plan fd_jvp_plan;
+/* fdtype: FD_FORWARD or FD_CENTRAL (complex mode is rejected as the reference does, src/jvp.jl:248-250). */
+int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_plan **out);
+int fd_jvp_plan_destroy(fd_jvp_plan *plan);
+/* jvp_out[M] = J(x) v by finite differences.  x, v share xv_kind; f_in (forward only) may be NULL. */
+int fd_jvp(fd_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind,
+           const void *f_in, int f_in_kind, double relstep, double absstep, double dir, void *jvp_out,
+           int out_kind);
+int fd_jvp_get_epsilon(fd_jvp_plan *plan, double *eps_out);
+
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */

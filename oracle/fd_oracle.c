@@ -19,6 +19,7 @@
  *   src/jacobians.jl:277-331   out-of-place dense forward (config 1 plumbing)
  *   src/epsilons.jl:26-29,50-53,104-107,133-144   step-size rules
  *   src/iteration_utils.jl:25-32                  generic COO decompression
+ *   src/jvp.jl:238-274                            finite_difference_jvp!
  *   ext/FiniteDiffSparseArraysExt.jl:20-28,38-47  CSC decompression (general / common pattern)
  *   ext/FiniteDiffBandedMatricesExt.jl:13-27      banded decompression
  *   ext/FiniteDiffBlockBandedMatricesExt.jl:44-68 block-banded decompression
@@ -318,6 +319,36 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, doub
         return 1; /* fdtype_error, src/epsilons.jl:159-167 */
     }
     if (fcalls) *fcalls = nf;
+    return 0;
+}
+
+/* finite_difference_jvp!  (src/jvp.jl:238-274).  x1, fx1 are the cache arrays; jvp is the output.
+   Returns 0, or 1 for :complex (rejected by the reference, :248-250 / :270-271). */
+int fdo_jvp(int fdtype, fdo_f_real f, void *ctx, const double *x, const double *v, int64_t M, int64_t N,
+            const double *f_in, double relstep, double absstep, double dir, double *x1, double *fx1, double *jvp,
+            double *eps_out)
+{
+    if (fdtype != FDO_FORWARD && fdtype != FDO_CENTRAL) return 1;
+    double dot = 0.0;
+    for (int64_t i = 0; i < N; ++i) dot += x[i] * v[i];
+    const double tmp = sqrt(fabs(dot));                         /* :253 */
+    double epsilon;
+    if (fdtype == FDO_FORWARD) {
+        epsilon = eps_forward(tmp, relstep, absstep, dir);      /* :254 */
+        const double *b;
+        if (f_in == NULL) { f(ctx, fx1, x); b = fx1; } else b = f_in;
+        for (int64_t i = 0; i < N; ++i) x1[i] = x[i] + epsilon * v[i];
+        f(ctx, jvp, x1);
+        for (int64_t r = 0; r < M; ++r) jvp[r] = (jvp[r] - b[r]) / epsilon;
+    } else {
+        epsilon = eps_central(tmp, relstep, absstep);
+        for (int64_t i = 0; i < N; ++i) x1[i] = x[i] - epsilon * v[i];
+        f(ctx, fx1, x1);
+        for (int64_t i = 0; i < N; ++i) x1[i] = x[i] + epsilon * v[i];
+        f(ctx, jvp, x1);
+        for (int64_t r = 0; r < M; ++r) jvp[r] = (jvp[r] - fx1[r]) / (2 * epsilon);
+    }
+    if (eps_out) *eps_out = epsilon;
     return 0;
 }
 

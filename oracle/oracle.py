@@ -70,6 +70,9 @@ def lib():
         L.fdo_jacobian_oop_dense_forward.argtypes = [
             C.c_void_p, C.c_void_p, _f64p, C.c_int64, C.c_int64, C.c_double, C.c_double,
             C.c_double, _f64p]
+        L.fdo_jvp.restype = C.c_int
+        L.fdo_jvp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, _f64p, _f64p, C.c_int64, C.c_int64, _f64p, C.c_double,
+                              C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p]
         L.fdo_build_tridiag_csc.restype = None
         L.fdo_build_tridiag_csc.argtypes = [C.c_int64, _i64p, _i64p]
         _lib = L
@@ -242,3 +245,20 @@ def jacobian_oop_dense_forward(f, x, M=None, relstep=None, absstep=None, dir=1.0
     J = np.empty(M * N)
     lib().fdo_jacobian_oop_dense_forward(f.f, f.ctxp, _pf(x), M, N, relstep, absstep, float(dir), _pf(J))
     return J.reshape((M, N), order="F")
+
+
+def jvp(fdtype, f, x, v, M=None, f_in=None, relstep=None, absstep=None, dir=1.0):
+    """finite_difference_jvp! (src/jvp.jl:238-274) -> dict(jvp=..., eps=...)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    N = x.size
+    M = N if M is None else M
+    relstep = default_relstep(fdtype) if relstep is None else relstep
+    absstep = relstep if absstep is None else absstep
+    x1, fx1, out, eps = np.zeros(N), np.zeros(M), np.zeros(M), np.zeros(1)
+    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=np.float64)
+    rc = lib().fdo_jvp(FDTYPES[fdtype], f.f, f.ctxp, _pf(x), _pf(v), M, N, _pf(fin), relstep, absstep, float(dir),
+                       _pf(x1), _pf(fx1), _pf(out), _pf(eps))
+    if rc != 0:
+        raise ValueError("finite_difference_jvp doesn't support :complex-mode finite diff")
+    return {"jvp": out, "eps": float(eps[0])}

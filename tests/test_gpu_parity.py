@@ -499,3 +499,46 @@ def test_sorted_gather_heuristic(monkeypatch):
     pl = fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central")
     assert pl.info(fd.lib.INFO_SORTED_GATHER) == 1          # 5-point stencil: scattered
     assert pl.info(fd.lib.INFO_LINES_DIRECT_X100) > 1.5 * pl.info(fd.lib.INFO_LINES_SORTED_X100)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("N", [1, 2, 1000, 100003])
+def test_jvp_parity(oracle, fdtype, N):
+    # finite_difference_jvp! (src/jvp.jl:238-274) on the device vs the oracle, same x, v
+    rng = np.random.default_rng(N)
+    x, v = rng.random(N), rng.random(N) - 0.5
+    out = _dev(np.full(N, np.nan))
+    cache = fd.JVPCache(_dev(x), fdtype)
+    fd.finite_difference_jvp_b(out, fd.BuiltinF("tridiag_nl", N), _dev(x), _dev(v), cache)
+    ref = oracle.jvp(fdtype, oracle.Fixture("tridiag_nl", N), x, v)
+    assert abs(cache.last_epsilon - ref["eps"]) <= 1e-12 * abs(ref["eps"])
+    _tol_ok(out.cpu().numpy(), ref["jvp"], ref["eps"], 5.0, "jvp %s N=%d" % (fdtype, N))
+    # host arrays + f_in through the ABI's staging path
+    if fdtype == "forward":
+        xm, xp = np.concatenate([[0.0], x[:-1]]), np.concatenate([x[1:], [0.0]])
+        fin = (xm - 2 * x) + xp + (x * x) * xp
+        outh = np.zeros(N)
+        f2 = fd.BuiltinF("tridiag_nl", N)
+        fd.finite_difference_jvp_b(outh, f2, x, v, "forward", fin)
+        assert f2.fcalls == 1
+        refh = oracle.jvp("forward", oracle.Fixture("tridiag_nl", N), x, v, f_in=fin)
+        _tol_ok(outh, refh["jvp"], refh["eps"], 5.0, "jvp host f_in")
+
+
+def test_jvp_reference_fixture_and_errors():
+    # test/finitedifftests.jl:440-448 with a user f! in torch; :complex is rejected (src/jvp.jl:248-250)
+    rng = np.random.default_rng(17)
+    x, vdir = rng.random(2), rng.random(2)
+    e = np.exp(x[0])
+    J_ref = np.array([[-7 + x[1] ** 3, 3 * (3 + x[0]) * x[1] ** 2],
+                      [e * x[1] * np.cos(1 - e * x[1]), e * np.cos(1 - e * x[1])]])
+
+    def iipf(fv, xx):
+        fv.copy_(torch.stack([(xx[0] + 3) * (xx[1] ** 3 - 7) + 18, torch.sin(xx[1] * torch.exp(xx[0]) - 1)]))
+
+    for fdtype, tol in (("forward", 1e-6), ("central", 1e-8)):
+        out = np.zeros(2)
+        fd.finite_difference_jvp_b(out, fd.TorchF(iipf, 2, 2), x, vdir, fdtype)
+        assert np.max(np.abs(out - J_ref @ vdir)) < tol
+    with pytest.raises(ValueError):
+        fd.finite_difference_jvp_b(np.zeros(2), fd.TorchF(iipf, 2, 2), x, vdir, "complex")

@@ -245,3 +245,22 @@ def test_epsilon_rule(oracle):
     for c in (1, 2, 3):
         eps = max(rel * np.sqrt(np.linalg.norm(x * (colors == c))), rel)
         assert 1e-8 < eps < 1e-7
+
+
+def test_jvp_reference_fixture(oracle):
+    # test/finitedifftests.jl:399-424,440-448 : JVP of iipf, forward < 1e-6, central < 1e-8, dir=-1, f_in
+    rng = np.random.default_rng(17)
+    x, vdir = rng.random(2), rng.random(2)
+    e = np.exp(x[0])
+    J_ref = np.array([[-7 + x[1] ** 3, 3 * (3 + x[0]) * x[1] ** 2],
+                      [e * x[1] * np.cos(1 - e * x[1]), e * np.cos(1 - e * x[1])]])
+    jvp_ref = J_ref @ vdir
+    f = oracle.PyF(_iipf, 2, 2)
+    assert np.max(np.abs(oracle.jvp("forward", f, x, vdir)["jvp"] - jvp_ref)) < 1e-6
+    assert np.max(np.abs(oracle.jvp("forward", f, x, vdir, dir=-1.0)["jvp"] - jvp_ref)) < 1e-6
+    assert np.max(np.abs(oracle.jvp("central", f, x, vdir)["jvp"] - jvp_ref)) < 1e-8
+    fin = np.zeros(2)
+    _iipf(fin, x)
+    assert np.max(np.abs(oracle.jvp("forward", f, x, vdir, f_in=fin)["jvp"] - jvp_ref)) < 1e-6
+    with pytest.raises(ValueError):
+        oracle.jvp("complex", f, x, vdir)
