@@ -593,3 +593,30 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     _l.check(ctx.L.fd_jvp_get_epsilon(h, C.byref(e)))
     cache.last_epsilon = e.value
     return None
+
+
+def matrix_colors(A):
+    """Colour vector for a sparsity pattern -- the role ``ArrayInterface.matrix_colors`` plays in the
+    reference's tests (test/coloring_tests.jl:112,117).  SparseMatrixCSC: greedy column colouring
+    (fd_color_columns_greedy); Tridiagonal / BandedMatrix: closed form mod1(j, l+u+1);
+    BlockBandedMatrix: the layout's block colouring.  Host-side; needs no GPU."""
+    L = _l.load()
+    nc = C.c_int64()
+    if isinstance(A, SparseMatrixCSC):
+        out = np.empty(A.n, np.int64)
+        _l.check(L.fd_color_columns_greedy(A.m, A.n, _vp(A.colptr), _vp(A.rowval), 8, 1,
+                                           out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nc)))
+        return out
+    if isinstance(A, Tridiagonal):
+        n = A.size()[0]
+        out = np.empty(n, np.int64)
+        _l.check(L.fd_color_banded(n, 1, 1, out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nc)))
+        return out
+    if isinstance(A, BandedMatrix):
+        n = int(A.data.shape[1])
+        out = np.empty(n, np.int64)
+        _l.check(L.fd_color_banded(n, A.l, A.u, out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nc)))
+        return out
+    if isinstance(A, BlockBandedMatrix):
+        return A.layout.colors()
+    raise TypeError("matrix_colors: unsupported matrix type %r" % type(A).__name__)

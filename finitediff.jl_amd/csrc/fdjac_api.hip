@@ -901,6 +901,64 @@ int fd_plan_get_epsilons(fd_plan *p, double *eps_out)
     return FD_OK;
 }
 
+int fd_color_banded(int64_t N, int64_t l, int64_t u, int64_t *colorvec_out, int64_t *ncolors_out)
+{
+    FD_REQUIRE(colorvec_out && N >= 1 && l + u + 1 >= 1, FD_ERR_ARG, "bad argument");
+    const int64_t w = l + u + 1;
+    for (int64_t j = 0; j < N; ++j) colorvec_out[j] = j % w + 1;
+    if (ncolors_out) *ncolors_out = std::min<int64_t>(w, N);
+    return FD_OK;
+}
+
+int fd_color_columns_greedy(int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes, int idx_base,
+                            int64_t *colorvec_out, int64_t *ncolors_out)
+{
+    FD_REQUIRE(colptr && rowval && colorvec_out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(M >= 0 && N >= 1, FD_ERR_SHAPE, "bad shape");
+    const int64_t nnz = load_idx(colptr, idx_bytes, N) - idx_base;
+    FD_REQUIRE(nnz >= 0, FD_ERR_SHAPE, "colptr is not monotone");
+    // CSR view: for every row the columns that touch it
+    std::vector<int64_t> rptr((size_t)M + 1, 0);
+    for (int64_t q = 0; q < nnz; ++q) {
+        const int64_t r = load_idx(rowval, idx_bytes, q) - idx_base;
+        FD_REQUIRE(r >= 0 && r < M, FD_ERR_SHAPE, "rowval[%lld] outside 1..%lld", (long long)q, (long long)M);
+        rptr[(size_t)r + 1]++;
+    }
+    for (int64_t r = 0; r < M; ++r) rptr[(size_t)r + 1] += rptr[(size_t)r];
+    std::vector<int32_t> rcols((size_t)nnz);
+    {
+        std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
+        for (int64_t j = 0; j < N; ++j) {
+            const int64_t a = load_idx(colptr, idx_bytes, j) - idx_base, b = load_idx(colptr, idx_bytes, j + 1) - idx_base;
+            FD_REQUIRE(a <= b && b <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
+            for (int64_t q = a; q < b; ++q) rcols[(size_t)fill[(size_t)(load_idx(rowval, idx_bytes, q) - idx_base)]++] = (int32_t)j;
+        }
+    }
+    std::vector<int64_t> stamp;  // stamp[c] == j+1  <=> colour c is forbidden for column j
+    int64_t C = 0;
+    for (int64_t j = 0; j < N; ++j) {
+        const int64_t a = load_idx(colptr, idx_bytes, j) - idx_base, b = load_idx(colptr, idx_bytes, j + 1) - idx_base;
+        for (int64_t q = a; q < b; ++q) {
+            const int64_t r = load_idx(rowval, idx_bytes, q) - idx_base;
+            for (int64_t t = rptr[(size_t)r]; t < rptr[(size_t)r + 1]; ++t) {
+                const int32_t k = rcols[(size_t)t];
+                if (k < j) {  // already coloured neighbour
+                    const int64_t ck = colorvec_out[k];
+                    if ((int64_t)stamp.size() <= ck) stamp.resize((size_t)ck + 1, 0);
+                    stamp[(size_t)ck] = j + 1;
+                }
+            }
+        }
+        int64_t c = 1;
+        while (c < (int64_t)stamp.size() && stamp[(size_t)c] == j + 1) ++c;
+        colorvec_out[j] = c;
+        if (c > C) C = c;
+    }
+    if (ncolors_out) *ncolors_out = C;
+    return FD_OK;
+}
+
 int fd_stream_copy_gbps(fd_ctx *ctx, int64_t bytes, int iters, double *gbps_out)
 {
     FD_REQUIRE(ctx && gbps_out && bytes >= 16 && iters >= 1, FD_ERR_ARG, "bad argument");

@@ -232,6 +232,16 @@ int fd_jvp(fd_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const vo
            int out_kind);
 int fd_jvp_get_epsilon(fd_jvp_plan *plan, double *eps_out);
 
+/* ---- plan-time colouring: the step BEFORE the path ------------------------- */
+/* Greedy distance-1 column colouring of the column intersection graph of a CSC pattern (two columns
+   conflict when they share a row) -- what ArrayInterface.matrix_colors / SparseDiffTools hand to
+   `colorvec` in the reference's tutorials (docs/src/tutorials.md:117-126).  Host-side, O(sum of
+   row_degree * column_degree).  colorvec_out[N] receives colours 1..C (int64); *ncolors_out = C. */
+int fd_color_columns_greedy(int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes,
+                            int idx_base, int64_t *colorvec_out, int64_t *ncolors_out);
+/* Closed-form colouring of a band: colorvec[j] = mod1(j, l+u+1) (valid for any matrix inside the band). */
+int fd_color_banded(int64_t N, int64_t l, int64_t u, int64_t *colorvec_out, int64_t *ncolors_out);
+
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */

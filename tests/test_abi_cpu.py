@@ -86,3 +86,38 @@ def test_default_relstep_and_fdtype_names():
     assert fd.default_relstep("Val{:central}") == np.cbrt(np.finfo(float).eps)
     with pytest.raises(ValueError):
         fd.default_relstep("backward")
+
+
+def _valid_coloring(colptr, rowval, colors):
+    cols = fd.patterns.csc_cols(colptr)
+    seen = set()
+    for r, c in zip(rowval, cols):
+        key = (int(r), int(colors[c - 1]))
+        if key in seen:
+            return False
+        seen.add(key)
+    return True
+
+
+def test_matrix_colors_plan_time_colouring(L):
+    # colourings generated from the pattern alone (host side, no GPU needed)
+    P = fd.patterns
+    colptr, rowval = P.tridiag_csc(101)
+    c = fd.matrix_colors(fd.SparseMatrixCSC(101, 101, colptr, rowval))
+    assert c.min() == 1 and c.max() == 3 and _valid_coloring(colptr, rowval, c)
+    colptr, rowval = P.lap5_csc(23, 17)
+    c = fd.matrix_colors(fd.SparseMatrixCSC(23 * 17, 23 * 17, colptr, rowval))
+    assert 5 <= c.max() <= 8 and _valid_coloring(colptr, rowval, c)
+    # random rectangular pattern
+    rng = np.random.default_rng(0)
+    A = (rng.random((40, 60)) < 0.08).astype(float)
+    colptr, rowval = P.csc_from_dense(A)
+    c = fd.matrix_colors(fd.SparseMatrixCSC(40, 60, colptr, rowval))
+    assert _valid_coloring(colptr, rowval, c) and c.max() <= 60
+    # a dense row forces N colours
+    A = np.zeros((3, 7)); A[1, :] = 1
+    colptr, rowval = P.csc_from_dense(A)
+    assert fd.matrix_colors(fd.SparseMatrixCSC(3, 7, colptr, rowval)).tolist() == [1, 2, 3, 4, 5, 6, 7]
+    # closed forms
+    assert fd.matrix_colors(fd.Tridiagonal(np.zeros(9), np.zeros(10), np.zeros(9))).tolist() == [1, 2, 3, 1, 2, 3, 1, 2, 3, 1]
+    assert fd.matrix_colors(fd.BandedMatrix(np.zeros((4, 6), order="F"), 6, 2, 1)).tolist() == [1, 2, 3, 4, 1, 2]
