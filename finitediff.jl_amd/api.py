@@ -412,9 +412,11 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
             rows, cols = _findstructralnz(np.asarray(sparsity))
             _l.check(L.fd_plan_create_coo_dense(ctx.handle, m, n, _vp(rows), _vp(cols), rows.size, 8, 1, _vp(cv), 8,
                                                 C.byref(o), C.byref(h)))
-        else:
-            raise NotImplementedError("sparsity === nothing (uncoloured dense arm, src/jacobians.jl:548-557) is "
-                                      "outside the accelerated path")
+        else:  # sparsity === nothing: colour index == column index (src/jacobians.jl:548-557)
+            ncols = int(cv.max()) if cv.size else 0
+            if ncols > n:
+                raise IndexError("BoundsError: maximum(colorvec) > length(x)")
+            _l.check(L.fd_plan_create_dense(ctx.handle, m, n, ncols, C.byref(o), C.byref(h)))
     return Plan(ctx, h, fdtype)
 
 

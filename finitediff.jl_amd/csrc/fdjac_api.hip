@@ -156,7 +156,7 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
         FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
         int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), 2.220446049250313e-16);
         if (r2) return r2;
-    } else if (p->C > 0) {
+    } else if (p->C > 0 && p->kind != K_DENSE) {
         if (p->C <= kRegColors) {
             const char *cm = getenv("FDJAC_GRID_CAP");
             const int64_t mult = (cm && *cm) ? atoll(cm) : 8;
@@ -546,6 +546,31 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
     FD_TRY(alloc_scratch(p, col0));
     p->nouts = 1;
     p->out_len[0] = (p->col1 - p->col0) * (l + u + 1);
+    return FD_OK;
+}
+
+int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(ncols >= 0 && ncols <= N, FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
+    if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
+        set_error("column windows are not supported for the dense arm");
+        return FD_ERR_UNSUPPORTED;
+    }
+    int rc = new_plan(ctx, K_DENSE, M, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    // "colour" i == column i: identity colours drive the shared perturbation kernel
+    std::vector<int32_t> col0((size_t)N);
+    for (int64_t j = 0; j < N; ++j) col0[(size_t)j] = j < ncols ? (int32_t)j : -1;
+    p->C = ncols;
+    p->color8 = false;
+    FD_TRY(upload_colors(p, col0, {}));
+    p->row0 = 0;
+    p->row1 = M;
+    FD_TRY(alloc_scratch(p, col0));
+    p->nouts = 1;
+    p->out_len[0] = M * ncols;
     return FD_OK;
 }
 

@@ -505,6 +505,36 @@ k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ 
     }
 }
 
+// K6  dense, uncoloured arm (sparsity === nothing, src/jacobians.jl:548-557 / 590-598 / 626-631):
+//   "colour" i perturbs the single entry x[i] with the PER-ELEMENT step
+//   eps_i = compute_epsilon(fdtype, x[i], relstep, absstep, dir)  (src/epsilons.jl:26-29,50-53)
+//   and J[:, i] = (f(x + eps_i e_i) - f(x)) / eps_i.
+__global__ void __launch_bounds__(kBlock)
+k_eps_element(const double *__restrict__ x, int64_t ncols, double relstep, double absstep, double dir,
+              int is_forward, double *__restrict__ eps)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ncols; i += stride) {
+        const double a = relstep * fabs(x[i]);
+        double e = (a > absstep) ? a : absstep;
+        if (is_forward) e = e * dir;
+        eps[i] = e;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_dense(const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld,
+                   const double *__restrict__ eps, int c_lo, int c_hi, int64_t M, double *__restrict__ J)
+{
+    const int64_t total = (int64_t)(c_hi - c_lo) * M;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const int64_t cb = t / M, r = t - cb * M;
+        J[(int64_t)(c_lo + cb) * M + r] = entry_value<MODE>(FXa, FXb, ld, (int)cb, r, eps[c_lo + cb]);
+    }
+}
+
 // Stream-copy ceiling probe (16 B per lane, grid-stride).
 __global__ void __launch_bounds__(kBlock)
 k_stream_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n)
@@ -578,6 +608,12 @@ static int launch_eps_t(fd_plan *p, const double *x, double relstep, double abss
 
 int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir)
 {
+    if (p->kind == K_DENSE) {
+        hipLaunchKernelGGL(k_eps_element, dim3(grid_for(p->C, kBlock, p->ctx->num_cus)), dim3(kBlock), 0, p->ctx->stream,
+                           x, p->C, relstep, absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
+        FD_HIP_CHECK(hipGetLastError());
+        return FD_OK;
+    }
     return p->color8 ? launch_eps_t<uint8_t>(p, x, relstep, absstep, dir)
                      : launch_eps_t<int32_t>(p, x, relstep, absstep, dir);
 }
@@ -678,6 +714,12 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
         const int g = grid_for((p->col1 - p->col0) * (p->l + p->u + 1), kBlock, p->ctx->num_cus);
         hipLaunchKernelGGL((k_decompress_banded<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
                            p->ldf, p->d_eps, c_lo, c_hi, p->M, p->l, p->u, p->col0, p->col1, outs[0]);
+        break;
+    }
+    case K_DENSE: {
+        const int g = grid_for((int64_t)B * p->M, kBlock, p->ctx->num_cus);
+        hipLaunchKernelGGL((k_decompress_dense<MODE>), dim3(g), dim3(kBlock), 0, s, FXa, FXb, p->ldf, p->d_eps, c_lo,
+                           c_hi, p->M, outs[0]);
         break;
     }
     case K_COLRANGE: {

@@ -41,7 +41,7 @@ F_LAUNCH_LAZY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyPoint
 EXPORTS = (
     "fd_version", "fd_last_error", "fd_ctx_create", "fd_ctx_destroy", "fd_ctx_stream", "fd_ctx_synchronize",
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
-    "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
+    "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy",
@@ -101,6 +101,7 @@ def load():
     L.fd_plan_create_coo_dense.argtypes = [vp, i64, i64, vp, vp, i64, i32, i32, vp, i32, po, pp]
     L.fd_plan_create_entries.argtypes = [vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp, i32, po, pp]
     L.fd_plan_create_tridiagonal.argtypes = [vp, i64, vp, i32, po, pp]
+    L.fd_plan_create_dense.argtypes = [vp, i64, i64, i64, po, pp]
     L.fd_plan_create_banded.argtypes = [vp, i64, i64, i64, i64, vp, i32, po, pp]
     L.fd_plan_create_blockbanded.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
     L.fd_plan_destroy.argtypes = [vp]

@@ -14,6 +14,7 @@
  *   fd_plan_create_coo_dense    src/iteration_utils.jl:25-32 + src/jacobians.jl:473-488,524-528
  *   fd_plan_create_entries      any J storage enumerated by the caller (incl. ext/FiniteDiffBlockBandedMatricesExt.jl:16-42)
  *   fd_plan_create_tridiagonal  src/iteration_utils.jl:25-32 on a LinearAlgebra.Tridiagonal J
+ *   fd_plan_create_dense        sparsity === nothing: src/jacobians.jl:548-557,590-598,626-631
  *   fd_plan_create_banded       ext/FiniteDiffBandedMatricesExt.jl:13-27
  *   fd_plan_create_blockbanded  ext/FiniteDiffBlockBandedMatricesExt.jl:44-68
  *
@@ -143,6 +144,12 @@ int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_i
                            const void *cols_index, const int64_t *dest, int64_t nnz,
                            int64_t out_len, int idx_bytes, int idx_base, const void *colorvec,
                            int color_bytes, const fd_plan_opts *opts, fd_plan **out);
+/* Dense uncoloured arm, `sparsity === nothing` (src/jacobians.jl:548-557, 590-598, 626-631): column i
+   (1 <= i <= ncols = maximum(colorvec)) perturbs x[i] alone with the per-element step
+   compute_epsilon(fdtype, x[i], relstep, absstep, dir); outs[0] = J[:, 1:ncols], column-major M x ncols.
+   (BASELINE config 1's family.) */
+int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const fd_plan_opts *opts,
+                         fd_plan **out);
 /* LinearAlgebra.Tridiagonal J (N x N): outs = {dl (N-1), d (N), du (N-1)}. */
 int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
                                const fd_plan_opts *opts, fd_plan **out);

@@ -542,3 +542,44 @@ def test_jvp_reference_fixture_and_errors():
         assert np.max(np.abs(out - J_ref @ vdir)) < tol
     with pytest.raises(ValueError):
         fd.finite_difference_jvp_b(np.zeros(2), fd.TorchF(iipf, 2, 2), x, vdir, "complex")
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_dense_uncoloured_arm(oracle, fdtype):
+    # sparsity === nothing (src/jacobians.jl:548-557, 590-598, 626-631): per-element eps, J[:, i] column by column
+    N = 300
+    x = np.random.default_rng(41).random(N) + 0.1
+    J = torch.full((N, N), float("nan"), dtype=torch.float64, device="cuda").t()   # column-major
+    f = fd.BuiltinF("tridiag_nl", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype)          # cache-less, colorvec = 1:N, no sparsity
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N), x, np.arange(1, N + 1))
+    assert f.fcalls == ref["fcalls"] == {"forward": N + 1, "central": 2 * N, "complex": N}[fdtype]
+    rel = fd.default_relstep(fdtype)
+    eps_min = EPS64 if fdtype == "complex" else rel * 0.1
+    _tol_ok(J.cpu().numpy(), ref["out"], eps_min, 5.0, "dense arm " + fdtype)
+
+
+def test_dense_arm_reference_tolerances_and_config1():
+    # test/finitedifftests.jl:455-462 with a torch f!; BASELINE config 1 (f = sin.(x), N = 1000) on the device
+    x = np.random.default_rng(7).random(2)
+    e = np.exp(x[0])
+    J_ref = np.array([[-7 + x[1] ** 3, 3 * (3 + x[0]) * x[1] ** 2],
+                      [e * x[1] * np.cos(1 - e * x[1]), e * np.cos(1 - e * x[1])]])
+
+    def iipf(fv, xx):
+        fv.copy_(torch.stack([(xx[0] + 3) * (xx[1] ** 3 - 7) + 18, torch.sin(xx[1] * torch.exp(xx[0]) - 1)]))
+
+    for fdtype, tol in (("forward", 1e-6), ("central", 1e-8), ("complex", 1e-14)):
+        J = np.zeros((2, 2))
+        fd.finite_difference_jacobian_b(J, fd.TorchF(iipf, 2, 2), x, fdtype)
+        assert np.max(np.abs(J - J_ref)) < tol, fdtype
+    J = np.zeros((2, 2))
+    fd.finite_difference_jacobian_b(J, fd.TorchF(iipf, 2, 2), x, "forward", dir=-1)
+    assert np.max(np.abs(J - J_ref)) < 1e-6
+    N = 1000
+    xs = np.random.default_rng(1).random(N)
+    Js = np.zeros((N, N), order="F")
+    fs = fd.TorchF(lambda fv, xx: torch.sin(xx, out=fv), N, N)
+    fd.finite_difference_jacobian_b(Js, fs, xs, "forward")
+    assert fs.fcalls == N + 1
+    assert np.max(np.abs(Js - np.diag(np.cos(xs)))) < 1e-6
