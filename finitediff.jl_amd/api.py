@@ -622,3 +622,51 @@ def matrix_colors(A):
     if isinstance(A, BlockBandedMatrix):
         return A.layout.colors()
     raise TypeError("matrix_colors: unsupported matrix type %r" % type(A).__name__)
+
+
+def finite_difference_jacobian(f, x, cache_or_fdtype="forward", returntype=np.float64, f_in=None, *, M=None,
+                               relstep=None, absstep=None, colorvec=None, sparsity=None, jac_prototype=None,
+                               dir=True, ctx=None):
+    """Out-of-place ``FiniteDiff.finite_difference_jacobian(f, x, ...; sparsity, jac_prototype, colorvec)``
+    (src/jacobians.jl:240-259, 277-429): allocates J like ``jac_prototype`` (else dense ``size(sparsity)``,
+    else dense M x maximum(colorvec)) on x's device and fills it through the in-place device path -- the
+    reference builds J by summing per-colour ``_make_Ji`` matrices, which yields the same entries.
+    f is a device launcher (``BuiltinF`` / ``TorchF``) with the in-place signature; M = length(f(x)) when
+    it cannot be inferred from jac_prototype / sparsity (defaults to length(x))."""
+    n = int(np.prod(x.shape))
+    if isinstance(cache_or_fdtype, JacobianCache):
+        if colorvec is None:
+            colorvec = cache_or_fdtype.colorvec
+        if sparsity is None:
+            sparsity = cache_or_fdtype.sparsity
+    if colorvec is None:
+        colorvec = np.arange(1, n + 1, dtype=np.int64)
+    proto = jac_prototype   # only the prototype fixes J's type; `sparsity` alone gives a dense zeros(size(sparsity))
+    if isinstance(proto, SparseMatrixCSC):
+        J = proto.similar(like=x)
+    elif isinstance(proto, Tridiagonal):
+        J = Tridiagonal(_similar(x, n - 1), _similar(x, n), _similar(x, n - 1))
+    elif isinstance(proto, BandedMatrix):
+        w = proto.l + proto.u + 1
+        J = BandedMatrix(_similar(x, w * n).reshape(n, w).T if _is_torch(x) else np.zeros((w, n), order="F"),
+                         proto.m, proto.l, proto.u)
+    elif isinstance(proto, BlockBandedMatrix):
+        J = BlockBandedMatrix(_similar(x, proto.layout.data_len), proto.layout)
+    else:
+        if proto is not None:
+            m, ncol = np.asarray(proto).shape
+        elif sparsity is not None:
+            m, ncol = sparsity.size() if hasattr(sparsity, "size") and callable(sparsity.size) else np.asarray(sparsity).shape
+        else:
+            m, ncol = (n if M is None else int(M)), int(np.max(colorvec))
+        if _is_torch(x):
+            import torch
+            J = torch.zeros((ncol, m), dtype=torch.float64, device=x.device).t()   # column-major
+        else:
+            J = np.zeros((m, ncol), order="F")
+    sp = sparsity if sparsity is not None else (J if _has_sparsestruct(J) else None)
+    if isinstance(J, SparseMatrixCSC) and isinstance(sp, SparseMatrixCSC) and sp is not J:
+        sp = J if (np.array_equal(sp.colptr, J.colptr) and np.array_equal(sp.rowval, J.rowval)) else sp
+    finite_difference_jacobian_b(J, f, x, cache_or_fdtype, returntype, f_in, relstep=relstep, absstep=absstep,
+                                 colorvec=colorvec, sparsity=sp if sp is not None else "default", dir=dir, ctx=ctx)
+    return J

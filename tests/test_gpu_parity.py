@@ -583,3 +583,30 @@ def test_dense_arm_reference_tolerances_and_config1():
     fd.finite_difference_jacobian_b(Js, fs, xs, "forward")
     assert fs.fcalls == N + 1
     assert np.max(np.abs(Js - np.diag(np.cos(xs)))) < 1e-6
+
+
+def test_out_of_place_api(oracle):
+    # finite_difference_jacobian (src/jacobians.jl:240-259, 277-429): J allocated like jac_prototype / sparsity
+    N = 30
+    x = np.random.default_rng(2).random(N)
+    colors = np.tile([1, 2, 3], 10)
+    colptr, rowval = P.tridiag_csc(N)
+    sp = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    exact = np.diag(np.full(N, -2.0)) + np.diag(np.ones(N - 1), 1) + np.diag(np.ones(N - 1), -1)
+    # dense, no sparsity: test/coloring_tests.jl:28-31 (31 f calls)
+    f = fd.BuiltinF("tridiag", N)
+    J = fd.finite_difference_jacobian(f, _dev(x))
+    assert f.fcalls == 31 and np.linalg.norm(J.cpu().numpy() - exact) <= 1.5e-8 * np.linalg.norm(exact) * 4
+    # sparse prototype: result type preserved (test/out_of_place_tests.jl:28-35), 4 f calls
+    f = fd.BuiltinF("tridiag", N)
+    Js = fd.finite_difference_jacobian(f, _dev(x), colorvec=colors, sparsity=sp, jac_prototype=sp)
+    assert isinstance(Js, fd.SparseMatrixCSC) and f.fcalls == 4
+    assert np.linalg.norm(P.csc_to_dense(N, N, colptr, rowval, Js.nzval.cpu().numpy()) - exact) <= 1e-7
+    # sparsity without prototype -> dense zeros(size(sparsity)) (src/jacobians.jl:305-307), host arrays
+    Jd = fd.finite_difference_jacobian(fd.BuiltinF("tridiag", N), x, "central", colorvec=colors, sparsity=sp)
+    assert isinstance(Jd, np.ndarray) and np.linalg.norm(Jd - exact) <= 1e-8
+    # cache reuse at a new x (test/cache_reuse_tests.jl:30-39)
+    cache = fd.JacobianCache(_dev(np.zeros(N)), "forward", colorvec=colors, sparsity=sp)
+    fd.finite_difference_jacobian(fd.BuiltinF("tridiag", N), _dev(np.zeros(N)), cache, jac_prototype=sp)
+    J2 = fd.finite_difference_jacobian(fd.BuiltinF("tridiag", N), _dev(x), cache, jac_prototype=sp)
+    assert np.linalg.norm(P.csc_to_dense(N, N, colptr, rowval, J2.nzval.cpu().numpy()) - exact) <= 1e-6
