@@ -293,6 +293,52 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             if ((rc = dev_upload(&p->d_spos, spos))) return rc;
         }
     }
+    // Row windows (k_decompress_window): per tile the rows / colours its coloured entries touch.  Used when
+    // every tile's window is short, has few colours, fits LDS with >= 4 workgroups per CU, and loading the
+    // windows densely reads at most 25 % more elements than there are stored entries.
+    if (!has_dest && !p->sorted_gather && p->nnz_local > 0) {
+        const char *force = getenv("FDJAC_WINDOW");
+        const size_t ntiles = padded / kSortTile;
+        std::vector<int4> wt(ntiles);
+        int max_pairs = 0, max_ncol = 0;
+        double elems = 0;
+        bool ok = !(force && *force && atoi(force) == 0);
+        for (size_t t = 0; t < ntiles && ok; ++t) {
+            int32_t rmin = std::numeric_limits<int32_t>::max(), rmax = -1, cmin = rmin, cmax = -1;
+            for (size_t e = t * kSortTile; e < (t + 1) * kSortTile; ++e) {
+                if (nzc[e] < 0) continue;   // uncoloured / padding entries load nothing
+                rmin = std::min(rmin, rows[e]); rmax = std::max(rmax, rows[e]);
+                cmin = std::min(cmin, nzc[e]); cmax = std::max(cmax, nzc[e]);
+            }
+            if (rmax < 0) { wt[t] = int4{0, 0, 0, 0}; continue; }
+            rmin &= ~1;   // even first row => 16-B aligned pair loads
+            const int npairs = (rmax - rmin) / 2 + 1, ncol = cmax - cmin + 1;
+            if (npairs > kWinMaxKR * kBlock || ncol > kWinMaxCol) { ok = false; break; }
+            wt[t] = int4{rmin, npairs, cmin, ncol};
+            max_pairs = std::max(max_pairs, npairs);
+            max_ncol = std::max(max_ncol, ncol);
+            elems += 2.0 * npairs * ncol;
+        }
+        p->win_overread = ok ? elems / (double)p->nnz_local : 0.0;
+        ok = ok && max_pairs > 0 && (size_t)max_pairs * 2 * (size_t)max_ncol * 8 <= (size_t)40 * 1024 &&
+             (p->win_overread <= 1.25 || (force && *force && atoi(force) == 1));
+        if (ok) {
+            p->window = true;
+            p->win_pairs = max_pairs;
+            p->win_ncol = max_ncol;
+            std::vector<uint16_t> code(padded);
+            for (size_t e = 0; e < padded; ++e) {
+                const int4 &td = wt[e / kSortTile];
+                code[e] = nzc[e] == -2 ? (uint16_t)0x8000 : nzc[e] < 0 ? (uint16_t)0x4000
+                        : (uint16_t)((rows[e] - td.x) | ((nzc[e] - td.z) << 11));
+            }
+            if ((rc = dev_upload(&p->d_wtiles, wt))) return rc;
+            if ((rc = dev_upload(&p->d_wcode, code))) return rc;
+            // the window kernel needs neither rowval nor the per-entry colours on the device
+            rows.clear();
+            nzc.clear();
+        }
+    }
     if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
     if ((rc = upload_colors(p, col0, nzc))) return rc;
     if (has_dest && (rc = dev_upload(&p->d_dest, dest))) return rc;
@@ -364,7 +410,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
     for (void *q : ptrs)
@@ -673,6 +719,8 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_SORTED_GATHER: *value = p->sorted_gather ? 1 : 0; break;
     case FD_INFO_LINES_DIRECT_X100: *value = (int64_t)(p->lines_direct * 100); break;
     case FD_INFO_LINES_SORTED_X100: *value = (int64_t)(p->lines_sorted * 100); break;
+    case FD_INFO_WINDOW: *value = p->window ? 1 : 0; break;
+    case FD_INFO_WIN_OVERREAD_X100: *value = (int64_t)(p->win_overread * 100); break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;

@@ -38,6 +38,8 @@ constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many col
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
+constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many colours per tile ...
+constexpr int kWinMaxKR = 4;         //   ... and at most kWinMaxKR*kBlock row pairs per tile
 
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
@@ -84,6 +86,14 @@ struct fd_plan {
     uint16_t *d_spos = nullptr;    //   local output position (within the tile) of each sorted entry
     bool has_none = false;         //   some column has no colour (its entries are written as 0)
     double lines_direct = 0, lines_sorted = 0;  // plan-time estimate: distinct 128-B lines per wave gather
+    // row-window variant (locally banded patterns): per tile of kSortTile entries the rows fall into a
+    // short window and few colours, so the f! values are loaded DENSELY into LDS and gathered from there
+    bool window = false;
+    int4 *d_wtiles = nullptr;      //   {first row (even), row pairs, first colour, colours} per tile
+    uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
+    int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
+    int win_ncol = 0;              //   max colours of any tile
+    double win_overread = 0;       //   dense window elements loaded per stored entry (1 = no waste)
     int64_t nnz_local = 0;
     int64_t entry_begin = 0;       // global index of the first local stored entry
     int64_t l = 0, u = 0;          // banded

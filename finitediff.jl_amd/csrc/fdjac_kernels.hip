@@ -410,6 +410,121 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     }
 }
 
+// K3c  the same decompression for LOCALLY BANDED patterns (tridiagonal / banded CSC, block patterns
+//   with few colours per tile): the rows of a tile of kSortTile storage-ordered entries fall into a
+//   short window [rmin, rmin + 2*npairs) and use ncol <= NCT consecutive colours (both found at plan
+//   time).  The workgroup loads that window of fx and of the ncol batched f! arrays DENSELY (16 B per
+//   lane, every 128-B line exactly once, no address divergence), forms the difference quotient
+//   (src/jacobians.jl:565 / 607 / 635) once per (colour,row) into LDS, and the stored entries then
+//   gather from LDS and leave with dense 16-B stores.  For a band of width C coloured with C colours
+//   every (colour,row) quotient is used by exactly one stored entry, so nothing is loaded twice or in
+//   vain.  Because row and colour are tile-relative, the per-entry index shrinks from rowval (4 B) +
+//   colour (1 B) to ONE 16-bit code:  bits 0-10 row - rmin, bits 11-13 colour - cmin, bit 14 "column
+//   has no colour" (entry is written as 0), bit 15 "padding" (not a stored entry).
+//   Same operations on the same operands as k_decompress_list => bit-identical results.
+template <int MODE, int NCT, bool FXB_VEC>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
+                    const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
+                    const double *__restrict__ eps, int c_lo, int c_hi, double *__restrict__ out, int64_t n,
+                    int vec_ok, int wp)
+{
+    constexpr int U = kSortTile / (kBlock * 2);   // pairs of entries per thread
+    extern __shared__ double s_win[];             // [ncol][wp] difference quotients of the tile's row window
+    const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
+    if (tile_id >= ntiles) return;
+    const int64_t t0 = tile_id * kSortTile;
+    const int4 td = wtiles[tile_id];
+    const int rmin = __builtin_amdgcn_readfirstlane(td.x);
+    const int npairs = __builtin_amdgcn_readfirstlane(td.y);
+    const int cmin = __builtin_amdgcn_readfirstlane(td.z);
+    int cb0 = cmin;
+    int cb1 = cb0 + __builtin_amdgcn_readfirstlane(td.w);
+    cb0 = cb0 > c_lo ? cb0 : c_lo;                // colours of this tile that belong to the current chunk
+    cb1 = cb1 < c_hi ? cb1 : c_hi;
+    const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;   // 0: nothing to load, entries only get their zeros
+
+    // phase 1: the packed (row, colour) codes of the stored entries (in flight while the window is loaded)
+    uint32_t code[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];
+    double ev[NCT];
+#pragma unroll
+    for (int cc = 0; cc < NCT; ++cc) ev[cc] = (cc < ncol) ? eps[cb0 + cc] : 1.0;
+
+    // phase 2: dense window loads -> difference quotients -> LDS
+#pragma unroll 1
+    for (int i = threadIdx.x; i < npairs; i += kBlock) {
+        const int64_t row = (int64_t)rmin + 2 * i;
+        d2_t b = {0.0, 0.0};
+        if (MODE == 0) {
+            if (FXB_VEC) {
+                b = *reinterpret_cast<const d2_t *>(FXb + row);
+            } else {   // caller's f_in: no padding / alignment guarantees
+                if (row < M) b.x = FXb[row];
+                if (row + 1 < M) b.y = FXb[row + 1];
+            }
+        }
+        d2_t a[NCT], bm[NCT];
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
+            a[cc] = d2_t{0.0, 0.0};
+            bm[cc] = b;
+            if (cc < ncol) {
+                if (MODE == 2) {
+                    const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                    const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                    a[cc] = d2_t{p0.y, p1.y};
+                } else {
+                    a[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
+                    if (MODE == 1) bm[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            if (cc < ncol) {
+                d2_t q;
+                if (MODE == 0) q = d2_t{(a[cc].x - bm[cc].x) / ev[cc], (a[cc].y - bm[cc].y) / ev[cc]};
+                else if (MODE == 1) q = d2_t{(a[cc].x - bm[cc].x) / (2 * ev[cc]), (a[cc].y - bm[cc].y) / (2 * ev[cc])};
+                else q = d2_t{a[cc].x / ev[cc], a[cc].y / ev[cc]};
+                *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = q;
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 3 + 4: entries pick their quotient out of LDS; dense stores as in k_decompress_list
+    const int cshift = cmin - cb0;   // tile-relative colour -> chunk-window-relative colour
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t p = t0 + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+        double q[2];
+        bool w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned cd = (code[u] >> (16 * h)) & 0xFFFFu;
+            const int cs = (int)((cd >> 11) & 7u) + cshift;
+            const bool colored = (cd & 0xC000u) == 0;
+            const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
+            const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
+            const double v = s_win[at];
+            q[h] = valid ? v : 0.0;
+            w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
+        }
+        const bool both = w[0] & w[1] & (vec_ok != 0);
+        if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
+            d2_t pk = {q[0], q[1]};
+            *reinterpret_cast<d2_t *>(out + p) = pk;
+        } else {
+            if (w[0]) out[p] = q[0];
+            if (w[1]) out[p + 1] = q[1];
+        }
+    }
+}
+
 // K4a  Tridiagonal J: three dense diagonals, no index traffic at all.
 //   d[j] = D_c(j)[j] ; dl[j] = D_c(j)[j+1] ; du[j-1] = D_c(j)[j-1],  D_c = (fx1_c - fx)/eps_c
 //   (what src/iteration_utils.jl:25-32 stores through Tridiagonal's setindex!).
@@ -655,8 +770,7 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
     case K_CSC_DENSE:
     case K_COO_DENSE: {
         if (p->nnz_local == 0) break;
-        const int lds_stage = (int)env_i64("FDJAC_LDS_STAGE", 0);   // experiment: LDS-staged stores in storage order
-        if ((p->sorted_gather || lds_stage) && p->kind == K_CSC) {
+        if (p->sorted_gather && p->kind == K_CSC) {
             const bool ldsq = B <= kEpsLdsMax;
             const bool allw = (p->nchunks == 1) && !p->has_none;
             const int64_t gq = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
@@ -678,6 +792,22 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
                 else FD_LAUNCH_SORTED(false, false, false);
             }
 #undef FD_LAUNCH_SORTED
+            break;
+        }
+        if (p->window && p->kind == K_CSC) {
+            const int64_t gw = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
+            const int wp = 2 * p->win_pairs;
+            const size_t shmw = sizeof(double) * (size_t)wp * (size_t)p->win_ncol;
+            const int vok = (((uintptr_t)outs[0]) & 15) == 0;
+            // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
+            const bool fxvec = (MODE != 0) || (fx == p->d_fx);
+#define FD_LAUNCH_WIN(NCT, FV)                                                                                   \
+            hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV>), dim3((unsigned)gw), dim3(kBlock), shmw, s,  \
+                               (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo, \
+                               c_hi, outs[0], p->nnz_local, vok, wp)
+            if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN(4, true); else FD_LAUNCH_WIN(4, false); }
+            else { if (fxvec) FD_LAUNCH_WIN(kWinMaxCol, true); else FD_LAUNCH_WIN(kWinMaxCol, false); }
+#undef FD_LAUNCH_WIN
             break;
         }
         const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)

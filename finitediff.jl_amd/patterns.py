@@ -27,6 +27,22 @@ def tridiag_csc(n):
     return colptr, rowval
 
 
+def banded_csc(m, n, l, u):
+    """SparseMatrixCSC pattern of an m x n band matrix with bandwidths (l, u) -> (colptr, rowval), 1-based."""
+    m, n, l, u = int(m), int(n), int(l), int(u)
+    j = np.arange(n, dtype=np.int64)
+    lo = np.maximum(j - u, 0)
+    hi = np.minimum(j + l, m - 1)
+    cnt = np.maximum(hi - lo + 1, 0)
+    colptr = np.empty(n + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(cnt, out=colptr[1:])
+    colptr[1:] += 1
+    col = np.repeat(j, cnt)
+    rowval = np.arange(col.size, dtype=np.int64) - (colptr[col] - 1) + lo[col] + 1
+    return colptr, rowval
+
+
 def cyclic_colors(n, c):
     """colorvec[i] = mod1(i, c) (1-based) -- the valid colouring of a band of width c."""
     return (np.arange(n, dtype=np.int64) % c) + 1

@@ -176,7 +176,9 @@ enum fd_plan_info_key {
     FD_INFO_NNZ_LOCAL = 11, FD_INFO_FCALLS_LAST = 12, FD_INFO_ENTRY_BEGIN = 13,
     FD_INFO_SORTED_GATHER = 14,       /* 1 if the LDS-transposed (colour-sorted) decompression kernel is used */
     FD_INFO_LINES_DIRECT_X100 = 15,   /* plan-time estimate, x100: 128-B lines per wave gather, storage order */
-    FD_INFO_LINES_SORTED_X100 = 16    /*   ... colour-sorted order */
+    FD_INFO_LINES_SORTED_X100 = 16,   /*   ... colour-sorted order */
+    FD_INFO_WINDOW = 17,              /* 1 if the row-window (dense loads -> LDS) decompression kernel is used */
+    FD_INFO_WIN_OVERREAD_X100 = 18    /*   x100: f! values loaded per stored entry by that kernel (100 = none wasted) */
 };
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 

@@ -475,15 +475,73 @@ def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
     x = _dev(np.random.default_rng(31).random(N))
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     outs = []
+    monkeypatch.setenv("FDJAC_WINDOW", "0")
     for forced in ("0", "1"):
         monkeypatch.setenv("FDJAC_SORTED", forced)
         plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
         assert plan.info(fd.lib.INFO_SORTED_GATHER) == int(forced)
+        assert plan.info(fd.lib.INFO_WINDOW) == 0
         out = _dev(np.full(rowval.size, np.nan))
         plan.jacobian(fd.BuiltinF(fam, *prm), x, [out])
         outs.append(out.cpu().numpy())
     assert not np.isnan(outs[0]).any()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "tridiag_f_in", "band5", "bidiag_window"])
+def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
+    # the row-window kernel (dense f! loads -> LDS -> entries) must equal the storage-order gather kernel bit for bit
+    monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    N = 9001
+    cap, c0, c1 = 0, None, None
+    if case == "band5":
+        colptr, rowval = P.banded_csc(N, N, 2, 2)
+        colors = P.cyclic_colors(N, 5)
+    elif case == "bidiag_window":      # odd column window start: the local rows begin at an odd row
+        colptr, rowval = P.banded_csc(N, N, 1, 0)
+        colors = P.cyclic_colors(N, 2)
+        c0, c1 = 1235, 8000
+    else:
+        colptr, rowval = P.tridiag_csc(N)
+        colors = P.cyclic_colors(N, 3)
+        cap = 300_000 if case == "tridiag_chunked" else 0
+        if case == "tridiag_none":
+            colors[[0, 77, 4096, N - 1]] = 0
+    xh = np.random.default_rng(37).random(N)
+    x = _dev(xh)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    f_in = None
+    if case == "tridiag_f_in":         # caller's f_in: unpadded, deliberately only 8-B aligned
+        f_in = _dev(np.random.default_rng(38).random(N + 1))[1:]   # any values: both kernels see the same f_in
+    outs = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FDJAC_WINDOW", forced)
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=(c0, c1) if c0 is not None else None)
+        assert plan.info(fd.lib.INFO_WINDOW) == int(forced)
+        if forced == "1":
+            assert 100 <= plan.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 125
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        f = fd.BuiltinF("tridiag_nl", N)
+        plan.jacobian(f, x, [out], f_in=f_in)
+        outs.append(out.cpu().numpy())
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_row_window_heuristic(monkeypatch):
+    monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    N = 20000
+    colptr, rowval = P.tridiag_csc(N)
+    Jt = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    assert fd.make_plan(Jt, Jt, P.cyclic_colors(N, 3), "forward").info(fd.lib.INFO_WINDOW) == 1
+    # 9 colours on a tridiagonal pattern: 3x more f! values than stored entries -> gathers are cheaper
+    assert fd.make_plan(Jt, Jt, P.cyclic_colors(N, 9), "forward").info(fd.lib.INFO_WINDOW) == 0
+    nx, ny = 400, 100
+    colptr, rowval = P.lap5_csc(nx, ny)
+    Jl = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
+    assert fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central").info(fd.lib.INFO_WINDOW) == 0
 
 
 def test_sorted_gather_heuristic(monkeypatch):
