@@ -127,9 +127,12 @@ def main():
                             x_window=xw if world > 1 else None)
         f = fd.BuiltinF("tridiag", N, ctx=ctx)
         lazy_ok = True
-        bytes_ds, bytes_min, bytes_call = 89.0, 71.0, 210.0   # per column, SURVEY 8(d)
+        # per column: SURVEY 8(d) algorithmic bytes; what this implementation must move at minimum (fx and the three
+        # f! arrays read once = 32 B, 3 values written = 24 B, index = 3 x 2-B packed (row,colour) codes with the
+        # row-window kernel, 3 x (4-B row + 1-B colour) with the gather kernel); whole call with a streaming f!
+        bytes_ds, bytes_min, bytes_call = 89.0, (62.0 if plan.info(fd.lib.INFO_WINDOW) else 71.0), 210.0
         wl = "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, x~U(0,1) seed %d" % (N, seed)
-        kern = "k_decompress_list<u8,forward>"
+        kern = "k_decompress_window<forward>" if plan.info(fd.lib.INFO_WINDOW) else "k_decompress_list<u8,forward>"
         exact = (-2.0, 1.0)
         del rowval
         pattern.rowval = None
@@ -150,7 +153,7 @@ def main():
         bytes_min = (2 * C * 8 * N + nnz * 13) / N
         bytes_call = (2 * C * 16 * N + 9 * N + 2 * C * 8 * N + 9 * N) / N + bytes_ds
         wl = "N=%d (%dx%d) 5-point Laplacian CSC (nnz=%d), colours (i+2j)%%5+1, central, x~U(0,1) seed 3" % (N, nx, ny, nnz)
-        kern = "k_decompress_list<u8,central>"
+        kern = "k_decompress_sorted<u8,central>" if plan.info(fd.lib.INFO_SORTED_GATHER) else "k_decompress_list<u8,central>"
         exact = (-4.0, 1.0)
         del rowval
         pattern.rowval = None
@@ -250,11 +253,13 @@ def main():
         achieved = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         tot_ms = tm["total"]["ms_sum"] / max(tm["total"]["launches"], 1)
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        # HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes of this same command
+        # (scripts/profile.sh + scripts/make_pmc_json.py; counters cannot be read from inside the process)
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg)
         if os.path.exists(pmc_path):
             try:
                 j = json.load(open(pmc_path))
-                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and cfg in ("c2", "c4"):
+                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and j.get("kernel", "") in kern:
                     pmc = j.get("decompress_hbm_bytes_per_launch")
             except Exception:
                 pmc = None

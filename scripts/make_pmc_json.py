@@ -4,7 +4,7 @@
 Correction as MI355X_MICROARCH.md (HBM section) prescribes: on gfx950 FETCH_SIZE under-reports wide coalesced
 streaming reads by exactly 2x and WRITE_SIZE is uncalibrated, so both are calibrated IN THE SAME RUN against
 k_stream_copy, whose true traffic is known (bench.py's ceiling probe copies exactly 1 GiB per launch).
-usage: make_pmc_json.py pmc_fetch.db pmc_write.db N GPUS > profiles/pmc_latest.json
+usage: make_pmc_json.py pmc_fetch.db pmc_write.db N GPUS KERNEL > profiles/pmc_<config>.json   (KERNEL e.g. k_decompress_window)
 """
 import json
 import sqlite3
@@ -20,15 +20,16 @@ def mean_counter(db, kernel_like, counter):
 
 
 fetch_db, write_db, n, gpus = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+kernel = sys.argv[5] if len(sys.argv) > 5 else "k_decompress"
 copy_bytes = float(1 << 30)
 cf, _ = mean_counter(fetch_db, "k_stream_copy", "FETCH_SIZE")
 cw, _ = mean_counter(write_db, "k_stream_copy", "WRITE_SIZE")
 kf = copy_bytes / (cf * 1024.0)  # expected 2.0
 kw = copy_bytes / (cw * 1024.0)  # expected 1.0
-df, nf = mean_counter(fetch_db, "k_decompress_list", "FETCH_SIZE")
-dw, nw = mean_counter(write_db, "k_decompress_list", "WRITE_SIZE")
+df, nf = mean_counter(fetch_db, kernel, "FETCH_SIZE")
+dw, nw = mean_counter(write_db, kernel, "WRITE_SIZE")
 out = {
-    "n": n, "gpus": gpus,
+    "n": n, "gpus": gpus, "kernel": kernel,
     "calibration": {"kernel": "k_stream_copy (1 GiB read + 1 GiB write per launch)", "fetch_factor": kf, "write_factor": kw,
                     "fetch_kb_raw": cf, "write_kb_raw": cw},
     "decompress_fetch_kb_raw": df, "decompress_write_kb_raw": dw, "dispatches": [nf, nw],

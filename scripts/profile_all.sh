@@ -1,0 +1,14 @@
+#!/bin/bash
+# One gpurun call: rocprofv3 stats + PMC passes of bench.py for a config, summarised on the box.
+# usage: profile_all.sh NAME CONFIG N KERNEL [bench args...]   -> gpurun_out/NAME/{summary.md,pmc.json,bench.json}
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+NAME=$1; CFG=$2; N=$3; KERN=$4; shift 4
+OUT=$REPO/gpurun_out/$NAME
+bash $REPO/scripts/profile.sh $NAME --config $CFG "$@"
+S=$(find $OUT/stats -name '*.db' | head -1); F=$(find $OUT/pmc_fetch -name '*.db' | head -1); W=$(find $OUT/pmc_write -name '*.db' | head -1)
+python $REPO/scripts/rocpd_summary.py $S $F $W > $OUT/summary.md 2> $OUT/summary.err
+python $REPO/scripts/make_pmc_json.py $F $W $N 1 $KERN > $OUT/pmc.json 2>> $OUT/summary.err
+cd $REPO && python bench.py --config $CFG "$@" > $OUT/bench.json 2> $OUT/bench.err
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
+tail -3 $OUT/summary.err; head -12 $OUT/summary.md; cat $OUT/pmc.json | head -30
