@@ -235,23 +235,21 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
 
     // Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of
     // tiles: distinct 128-B lines touched by one wave-level gather (64 lanes, the kernels' lane->entry maps).
-    std::vector<uint16_t> spos;
+    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+    auto sort_tile = [&](size_t b0) {
+        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
+        for (int k = 0; k < kSortTile; ++k) {
+            const size_t e = b0 + (size_t)k;
+            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
+            ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[e]), k};
+        }
+        std::sort(ord.begin(), ord.end());
+    };
+    bool scattered = false;
     if (!has_dest && p->nnz_local >= 4 * kSortTile) {
-        const char *force = getenv("FDJAC_SORTED");
         const size_t ntiles = padded / kSortTile;
         const size_t step = std::max<size_t>(1, ntiles / 64);
         auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
-        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
-        auto sort_key = [&](size_t e, int k) {
-            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
-            return (c << 32) | ((int64_t)(uint32_t)rows[e]);
-            (void)k;
-        };
-        std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
-        auto sort_tile = [&](size_t b0) {
-            for (int k = 0; k < kSortTile; ++k) ord[(size_t)k] = {sort_key(b0 + (size_t)k, k), k};
-            std::sort(ord.begin(), ord.end());
-        };
         double ld = 0, ls = 0;
         size_t ninstr = 0;
         std::vector<int64_t> keys;
@@ -273,71 +271,150 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         }
         p->lines_direct = ld / std::max<size_t>(ninstr, 1);
         p->lines_sorted = ls / std::max<size_t>(ninstr, 1);
-        p->sorted_gather = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
-        if (force && *force) p->sorted_gather = atoi(force) != 0;
-        if (p->sorted_gather) {
-            spos.resize(padded);
-            std::vector<int32_t> r2(kSortTile), c2(kSortTile);
-            for (size_t t = 0; t < ntiles; ++t) {
-                const size_t b0 = t * kSortTile;
-                sort_tile(b0);
-                for (int q = 0; q < kSortTile; ++q) {
-                    const int k = ord[(size_t)q].second;
-                    r2[(size_t)q] = rows[b0 + (size_t)k];
-                    c2[(size_t)q] = nzc[b0 + (size_t)k];
-                    spos[b0 + (size_t)q] = (uint16_t)k;
-                }
-                std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
-                std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
-            }
-            if ((rc = dev_upload(&p->d_spos, spos))) return rc;
-        }
+        scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
     }
-    // Row windows (k_decompress_window): per tile the rows / colours its coloured entries touch.  Used when
-    // every tile's window is short, has few colours, fits LDS with >= 4 workgroups per CU, and loading the
-    // windows densely reads at most 25 % more elements than there are stored entries.
-    if (!has_dest && !p->sorted_gather && p->nnz_local > 0) {
-        const char *force = getenv("FDJAC_WINDOW");
-        const size_t ntiles = padded / kSortTile;
-        std::vector<int4> wt(ntiles);
-        int max_pairs = 0, max_ncol = 0;
+
+    // Row windows (k_decompress_window).  Per tile of T entries: the rows its coloured entries touch, clustered
+    // into at most kWinMaxWin windows (a new window starts after a gap of more than kWinGap rows), and the range of
+    // colours.  The kernel loads every window of every colour of the tile densely, so the variant is used when
+    //   * every tile has <= kWinMaxWin windows, <= kWinMaxCol consecutive colours, <= 2048 window rows in total,
+    //   * the LDS tile (colours x window rows x 8 B) leaves several workgroups per CU, and
+    //   * the dense loads bring in at most 1.25 f! values per stored entry (banded patterns: exactly 1), or, for
+    //     patterns whose gathers are scattered anyway (5-point stencils: 3), at most kWinMaxOverread -- re-reads
+    //     that are served by the L2, traded for divergence-free 16-B loads (the gather kernels are TA-bound there).
+    struct WinBuild {
+        bool ok = false;
+        int T = 0, max_slots = 0, max_ncol = 0;
+        double overread = 0;
+        std::vector<int4> wt;          // 3 x int4 per tile: {cmin, ncol, pairs, nwin}, {rmin0,end0,rmin1,end1}, {rmin2,end2,rmin3,end3}
+        std::vector<uint16_t> code;
+    };
+    auto build_windows = [&](int T, bool want_codes) {
+        WinBuild w;
+        w.T = T;
+        const size_t ntiles = padded / (size_t)T;
+        w.wt.assign(3 * ntiles, int4{0, 0, 0, 0});
+        if (want_codes) w.code.assign(padded, (uint16_t)0x8000);
+        std::vector<int32_t> rr;
         double elems = 0;
-        bool ok = !(force && *force && atoi(force) == 0);
-        for (size_t t = 0; t < ntiles && ok; ++t) {
+        for (size_t t = 0; t < ntiles; ++t) {
+            const size_t b0 = t * (size_t)T;
             int32_t rmin = std::numeric_limits<int32_t>::max(), rmax = -1, cmin = rmin, cmax = -1;
-            for (size_t e = t * kSortTile; e < (t + 1) * kSortTile; ++e) {
+            int64_t ncoloured = 0;
+            for (size_t e = b0; e < b0 + (size_t)T; ++e) {
                 if (nzc[e] < 0) continue;   // uncoloured / padding entries load nothing
                 rmin = std::min(rmin, rows[e]); rmax = std::max(rmax, rows[e]);
                 cmin = std::min(cmin, nzc[e]); cmax = std::max(cmax, nzc[e]);
+                ++ncoloured;
             }
-            if (rmax < 0) { wt[t] = int4{0, 0, 0, 0}; continue; }
-            rmin &= ~1;   // even first row => 16-B aligned pair loads
-            const int npairs = (rmax - rmin) / 2 + 1, ncol = cmax - cmin + 1;
-            if (npairs > kWinMaxKR * kBlock || ncol > kWinMaxCol) { ok = false; break; }
-            wt[t] = int4{rmin, npairs, cmin, ncol};
-            max_pairs = std::max(max_pairs, npairs);
-            max_ncol = std::max(max_ncol, ncol);
-            elems += 2.0 * npairs * ncol;
+            int32_t wr[kWinMaxWin], wn[kWinMaxWin];   // first row (even), pairs
+            int nwin = 0;
+            if (rmax >= 0) {
+                if (cmax - cmin + 1 > kWinMaxCol) return w;
+                // one window is already tight (or short): no need to look at the rows again
+                if (rmax - rmin < 2 * kWinGap || (double)(rmax - rmin + 2) * (cmax - cmin + 1) <= 1.25 * (double)ncoloured) {
+                    wr[0] = rmin & ~1;
+                    wn[0] = (rmax - wr[0]) / 2 + 1;
+                    nwin = 1;
+                } else {
+                    rr.clear();
+                    for (size_t e = b0; e < b0 + (size_t)T; ++e) if (nzc[e] >= 0) rr.push_back(rows[e]);
+                    std::sort(rr.begin(), rr.end());
+                    int32_t start = rr[0] & ~1, last = rr[0];
+                    for (size_t k = 1; k <= rr.size(); ++k) {
+                        if (k == rr.size() || rr[k] - last > kWinGap) {
+                            if (nwin == kWinMaxWin) return w;
+                            wr[nwin] = start;
+                            wn[nwin] = (last - start) / 2 + 1;
+                            ++nwin;
+                            if (k < rr.size()) start = rr[k] & ~1;
+                        }
+                        if (k < rr.size()) last = rr[k];
+                    }
+                }
+            }
+            int pairs = 0;
+            int32_t ends[kWinMaxWin];
+            for (int k = 0; k < kWinMaxWin; ++k) {
+                if (k < nwin) pairs += wn[k];
+                ends[k] = pairs;                 // unused windows are empty: end == total
+                if (k >= nwin) wr[k] = 0;
+            }
+            if (2 * pairs > 2048) return w;     // the slot field of the entry code has 11 bits
+            const int ncol = rmax >= 0 ? cmax - cmin + 1 : 0;
+            w.wt[3 * t] = int4{rmax >= 0 ? cmin : 0, ncol, pairs, nwin};
+            w.wt[3 * t + 1] = int4{wr[0], ends[0], wr[1], ends[1]};
+            w.wt[3 * t + 2] = int4{wr[2], ends[2], wr[3], ends[3]};
+            w.max_slots = std::max(w.max_slots, 2 * pairs);
+            w.max_ncol = std::max(w.max_ncol, ncol);
+            elems += 2.0 * pairs * ncol;
+            if (want_codes)
+                for (size_t e = b0; e < b0 + (size_t)T; ++e) {
+                    if (nzc[e] == -2) continue;                            // padding
+                    if (nzc[e] < 0) { w.code[e] = 0x4000; continue; }      // column without colour
+                    int k = 0;
+                    while (!(rows[e] >= wr[k] && rows[e] < wr[k] + 2 * wn[k])) ++k;
+                    const int slot = 2 * (k ? ends[k - 1] : 0) + (rows[e] - wr[k]);
+                    w.code[e] = (uint16_t)(slot | ((nzc[e] - cmin) << 11));
+                }
         }
-        p->win_overread = ok ? elems / (double)p->nnz_local : 0.0;
-        ok = ok && max_pairs > 0 && (size_t)max_pairs * 2 * (size_t)max_ncol * 8 <= (size_t)40 * 1024 &&
-             (p->win_overread <= 1.25 || (force && *force && atoi(force) == 1));
-        if (ok) {
-            p->window = true;
-            p->win_pairs = max_pairs;
-            p->win_ncol = max_ncol;
-            std::vector<uint16_t> code(padded);
-            for (size_t e = 0; e < padded; ++e) {
-                const int4 &td = wt[e / kSortTile];
-                code[e] = nzc[e] == -2 ? (uint16_t)0x8000 : nzc[e] < 0 ? (uint16_t)0x4000
-                        : (uint16_t)((rows[e] - td.x) | ((nzc[e] - td.z) << 11));
+        w.overread = elems / (double)std::max<int64_t>(p->nnz_local, 1);
+        w.ok = w.max_slots > 0;
+        return w;
+    };
+    if (!has_dest && p->nnz_local > 0) {
+        const char *fw = getenv("FDJAC_WINDOW"), *fs = getenv("FDJAC_SORTED");
+        const int force_w = (fw && *fw) ? atoi(fw) : -1, force_s = (fs && *fs) ? atoi(fs) : -1;
+        WinBuild best;
+        if (force_w != 0 && force_s != 1) {
+            const char *ft = getenv("FDJAC_WIN_TILE");   // experiment knob: force the tile size (2048, 1024 or 512)
+            const int force_t = (ft && *ft) ? atoi(ft) : 0;
+            for (int T : {2048, 1024, 512}) {
+                if (force_t && T != force_t) continue;
+                WinBuild w = build_windows(T, false);
+                if (!w.ok) continue;
+                const size_t lds = (size_t)w.max_slots * (size_t)w.max_ncol * 8;
+                if (lds > (size_t)kWinMaxLds) continue;
+                const bool cheap = w.overread <= 1.25 || (scattered && w.overread <= kWinMaxOverread);
+                if (!(cheap || force_w == 1)) continue;
+                best = std::move(w);
+                if (lds <= (size_t)32 * 1024 || T == 1024) break;   // the large tile already leaves >= 5 workgroups per CU
             }
-            if ((rc = dev_upload(&p->d_wtiles, wt))) return rc;
-            if ((rc = dev_upload(&p->d_wcode, code))) return rc;
+        }
+        p->win_overread = best.overread;
+        if (best.ok) {
+            best = build_windows(best.T, true);
+            p->window = true;
+            p->win_tile = best.T;
+            p->win_pairs = best.max_slots / 2;
+            p->win_ncol = best.max_ncol;
+            if ((rc = dev_upload(&p->d_wtiles, best.wt))) return rc;
+            if ((rc = dev_upload(&p->d_wcode, best.code))) return rc;
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
             nzc.clear();
+        } else {
+            p->sorted_gather = scattered;
+            if (force_s >= 0) p->sorted_gather = force_s != 0 && p->nnz_local >= 4 * kSortTile;
         }
+    }
+    if (p->sorted_gather) {
+        std::vector<uint16_t> spos(padded);
+        const size_t ntiles = padded / kSortTile;
+        std::vector<int32_t> r2(kSortTile), c2(kSortTile);
+        for (size_t t = 0; t < ntiles; ++t) {
+            const size_t b0 = t * kSortTile;
+            sort_tile(b0);
+            for (int q = 0; q < kSortTile; ++q) {
+                const int k = ord[(size_t)q].second;
+                r2[(size_t)q] = rows[b0 + (size_t)k];
+                c2[(size_t)q] = nzc[b0 + (size_t)k];
+                spos[b0 + (size_t)q] = (uint16_t)k;
+            }
+            std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
+            std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
+        }
+        if ((rc = dev_upload(&p->d_spos, spos))) return rc;
     }
     if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
     if ((rc = upload_colors(p, col0, nzc))) return rc;

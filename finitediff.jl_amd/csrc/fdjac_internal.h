@@ -38,8 +38,11 @@ constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many col
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
-constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many colours per tile ...
-constexpr int kWinMaxKR = 4;         //   ... and at most kWinMaxKR*kBlock row pairs per tile
+constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many consecutive colours per tile,
+constexpr int kWinMaxWin = 4;        //   this many row windows per tile (a 5-point stencil needs 3),
+constexpr int kWinGap = 64;          //   a new window starts after a gap of more than this many rows,
+constexpr int kWinMaxLds = 52 * 1024;  // this much LDS per workgroup (3 workgroups per CU),
+constexpr double kWinMaxOverread = 4.0;  // and this many f! values loaded per stored entry for scattered patterns
 
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
@@ -89,7 +92,8 @@ struct fd_plan {
     // row-window variant (locally banded patterns): per tile of kSortTile entries the rows fall into a
     // short window and few colours, so the f! values are loaded DENSELY into LDS and gathered from there
     bool window = false;
-    int4 *d_wtiles = nullptr;      //   {first row (even), row pairs, first colour, colours} per tile
+    int4 *d_wtiles = nullptr;      //   3 x int4 per tile: {first colour, colours, row pairs, windows}, 4 x {first row, end pair}
+    int win_tile = 0;              //   entries per tile (2048 or 1024)
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile

@@ -418,29 +418,38 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
 //   (src/jacobians.jl:565 / 607 / 635) once per (colour,row) into LDS, and the stored entries then
 //   gather from LDS and leave with dense 16-B stores.  For a band of width C coloured with C colours
 //   every (colour,row) quotient is used by exactly one stored entry, so nothing is loaded twice or in
-//   vain.  Because row and colour are tile-relative, the per-entry index shrinks from rowval (4 B) +
-//   colour (1 B) to ONE 16-bit code:  bits 0-10 row - rmin, bits 11-13 colour - cmin, bit 14 "column
+//   vain.  Scattered patterns (a 5-point stencil touches rows k-nx, k, k+nx) get up to four windows per
+//   tile; their re-reads are served by the L2 and replace the divergent gathers that make the gather
+//   kernels texture-addresser bound.  Because row and colour are tile-relative, the per-entry index
+//   shrinks from rowval (4 B) + colour (1 B) to ONE 16-bit code:  bits 0-10 LDS slot of the row (windows
+//   concatenated), bits 11-13 colour - cmin, bit 14 "column
 //   has no colour" (entry is written as 0), bit 15 "padding" (not a stored entry).
 //   Same operations on the same operands as k_decompress_list => bit-identical results.
-template <int MODE, int NCT, bool FXB_VEC>
+template <int MODE, int NCT, bool FXB_VEC, int U>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
                     const double *__restrict__ eps, int c_lo, int c_hi, double *__restrict__ out, int64_t n,
                     int vec_ok, int wp)
 {
-    constexpr int U = kSortTile / (kBlock * 2);   // pairs of entries per thread
-    extern __shared__ double s_win[];             // [ncol][wp] difference quotients of the tile's row window
-    const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    constexpr int T = U * kBlock * 2;             // entries per tile; U pairs of entries per thread
+    extern __shared__ double s_mem_w[];
+    double *s_eps = s_mem_w;                      // step sizes of the tile's colours (the division happens per stored entry)
+    double *s_win = s_mem_w + kWinMaxCol;         // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
+    const int64_t ntiles = (n + T - 1) / T;
     const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
     if (tile_id >= ntiles) return;
-    const int64_t t0 = tile_id * kSortTile;
-    const int4 td = wtiles[tile_id];
-    const int rmin = __builtin_amdgcn_readfirstlane(td.x);
-    const int npairs = __builtin_amdgcn_readfirstlane(td.y);
-    const int cmin = __builtin_amdgcn_readfirstlane(td.z);
+    const int64_t t0 = tile_id * T;
+    const int4 th = wtiles[3 * tile_id], wa = wtiles[3 * tile_id + 1], wb = wtiles[3 * tile_id + 2];
+    const int cmin = __builtin_amdgcn_readfirstlane(th.x);
     int cb0 = cmin;
-    int cb1 = cb0 + __builtin_amdgcn_readfirstlane(td.w);
+    int cb1 = cb0 + __builtin_amdgcn_readfirstlane(th.y);
+    const int npairs = __builtin_amdgcn_readfirstlane(th.z);          // row pairs of all windows together
+    // up to 4 row windows, concatenated in LDS: window k holds pairs [end_{k-1}, end_k) and starts at row rw_k
+    const int rw0 = __builtin_amdgcn_readfirstlane(wa.x), e0 = __builtin_amdgcn_readfirstlane(wa.y);
+    const int rw1 = __builtin_amdgcn_readfirstlane(wa.z), e1 = __builtin_amdgcn_readfirstlane(wa.w);
+    const int rw2 = __builtin_amdgcn_readfirstlane(wb.x), e2 = __builtin_amdgcn_readfirstlane(wb.y);
+    const int rw3 = __builtin_amdgcn_readfirstlane(wb.z);
     cb0 = cb0 > c_lo ? cb0 : c_lo;                // colours of this tile that belong to the current chunk
     cb1 = cb1 < c_hi ? cb1 : c_hi;
     const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;   // 0: nothing to load, entries only get their zeros
@@ -448,15 +457,17 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     // phase 1: the packed (row, colour) codes of the stored entries (in flight while the window is loaded)
     uint32_t code[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];
-    double ev[NCT];
-#pragma unroll
-    for (int cc = 0; cc < NCT; ++cc) ev[cc] = (cc < ncol) ? eps[cb0 + cc] : 1.0;
+    for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];   // two 16-bit codes
+    if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
 
-    // phase 2: dense window loads -> difference quotients -> LDS
+    // phase 2: dense window loads -> differences -> LDS.  (The quotient is formed in phase 3, once per stored
+    // entry: windows of scattered patterns hold values no entry of this tile uses, and an IEEE division is ~50
+    // cycles per wave.)
 #pragma unroll 1
     for (int i = threadIdx.x; i < npairs; i += kBlock) {
-        const int64_t row = (int64_t)rmin + 2 * i;
+        const int64_t row = i < e0 ? (int64_t)rw0 + 2 * i
+                          : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
+                          : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
         d2_t b = {0.0, 0.0};
         if (MODE == 0) {
             if (FXB_VEC) {
@@ -486,17 +497,15 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
 #pragma unroll
         for (int cc = 0; cc < NCT; ++cc) {
             if (cc < ncol) {
-                d2_t q;
-                if (MODE == 0) q = d2_t{(a[cc].x - bm[cc].x) / ev[cc], (a[cc].y - bm[cc].y) / ev[cc]};
-                else if (MODE == 1) q = d2_t{(a[cc].x - bm[cc].x) / (2 * ev[cc]), (a[cc].y - bm[cc].y) / (2 * ev[cc])};
-                else q = d2_t{a[cc].x / ev[cc], a[cc].y / ev[cc]};
-                *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = q;
+                const d2_t df = (MODE == 2) ? a[cc] : d2_t{a[cc].x - bm[cc].x, a[cc].y - bm[cc].y};
+                *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = df;
             }
         }
     }
     __syncthreads();
 
-    // phase 3 + 4: entries pick their quotient out of LDS; dense stores as in k_decompress_list
+    // phase 3 + 4: entries pick their difference out of LDS, divide by their colour's step (IEEE division, as
+    // src/jacobians.jl:565 / 607 / 635); dense stores as in k_decompress_list
     const int cshift = cmin - cb0;   // tile-relative colour -> chunk-window-relative colour
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -510,7 +519,9 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
             const bool colored = (cd & 0xC000u) == 0;
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
-            const double v = s_win[at];
+            const double df = s_win[at];
+            const double e = s_eps[valid ? cs : 0];
+            const double v = (MODE == 1) ? df / (2 * e) : df / e;
             q[h] = valid ? v : 0.0;
             w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
         }
@@ -795,18 +806,21 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
             break;
         }
         if (p->window && p->kind == K_CSC) {
-            const int64_t gw = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
+            const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
             const int wp = 2 * p->win_pairs;
-            const size_t shmw = sizeof(double) * (size_t)wp * (size_t)p->win_ncol;
+            const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)p->win_ncol + kWinMaxCol);
             const int vok = (((uintptr_t)outs[0]) & 15) == 0;
             // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
             const bool fxvec = (MODE != 0) || (fx == p->d_fx);
-#define FD_LAUNCH_WIN(NCT, FV)                                                                                   \
-            hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV>), dim3((unsigned)gw), dim3(kBlock), shmw, s,  \
-                               (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo, \
+#define FD_LAUNCH_WIN(NCT, FV, UU)                                                                                  \
+            hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
+                               (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,   \
                                c_hi, outs[0], p->nnz_local, vok, wp)
-            if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN(4, true); else FD_LAUNCH_WIN(4, false); }
-            else { if (fxvec) FD_LAUNCH_WIN(kWinMaxCol, true); else FD_LAUNCH_WIN(kWinMaxCol, false); }
+#define FD_LAUNCH_WIN_U(NCT, FV) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2); else FD_LAUNCH_WIN(NCT, FV, 1); } while (0)
+            if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true); else FD_LAUNCH_WIN_U(4, false); }
+            else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true); else FD_LAUNCH_WIN_U(6, false); }
+            else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true); else FD_LAUNCH_WIN_U(kWinMaxCol, false); }
+#undef FD_LAUNCH_WIN_U
 #undef FD_LAUNCH_WIN
             break;
         }

@@ -49,6 +49,11 @@ __global__ void __launch_bounds__(256) rd_only(const d2* __restrict__ a, double*
     d2 v = i < n ? a[i] : d2{0, 0};
     if (v.x == 1.2345e300) sink[0] = v.y;
 }
+__global__ void __launch_bounds__(256) rd_gs(const d2* __restrict__ a, double* __restrict__ sink, int64_t n) {
+    d2 acc = {0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += a[i];
+    if (acc.x == 1.2345e300) sink[0] = acc.y;
+}
 __global__ void __launch_bounds__(256) wr_only(d2* __restrict__ o, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) o[i] = d2{1.0, 2.0};
@@ -89,6 +94,13 @@ int main() {
     printf("read only 480 MB                     %8.2f us  %7.1f GB/s\n", ms * 1e3, 2.0 * nout2 * 16 / ms / 1e6);
     ms = timeit([&] { wr_only<<<(nout2 + 255) / 256, 256>>>(o, nout2); }, it);
     printf("write only 240 MB                    %8.2f us  %7.1f GB/s\n", ms * 1e3, 1.0 * nout2 * 16 / ms / 1e6);
+    for (int64_t mb : {20, 40, 80, 160, 320}) {
+        const int64_t n16 = mb * 1000000 / 16;
+        ms = timeit([&] { rd_only<<<(n16 + 255) / 256, 256>>>(big, sink, n16); }, 50);
+        printf("read only %4lld MB (1 elt/thread)        %8.2f us  %7.1f GB/s\n", (long long)mb, ms * 1e3, n16 * 16.0 / ms / 1e6);
+        ms = timeit([&] { rd_gs<<<2048, 256>>>(big, sink, n16); }, 50);
+        printf("read only %4lld MB (grid-stride 2048)    %8.2f us  %7.1f GB/s\n", (long long)mb, ms * 1e3, n16 * 16.0 / ms / 1e6);
+    }
     ms = timeit([&] { add2<<<(nout2 + 255) / 256, 256>>>(big, big + nout2, o, nout2); }, it);
     printf("add2 again                           %8.2f us  %7.1f GB/s\n", ms * 1e3, 3.0 * nout2 * 16 / ms / 1e6);
     return 0;

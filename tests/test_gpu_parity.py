@@ -489,13 +489,24 @@ def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "tridiag_f_in", "band5", "bidiag_window"])
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "tridiag_f_in", "band5", "bidiag_window",
+                                  "lap5", "lap5_chunked", "lap5_small_tile"])
 def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
     # the row-window kernel (dense f! loads -> LDS -> entries) must equal the storage-order gather kernel bit for bit
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
     N = 9001
     cap, c0, c1 = 0, None, None
-    if case == "band5":
+    fam, prm = "tridiag_nl", (N,)
+    if case.startswith("lap5"):        # three row windows per tile (rows k-nx, k, k+nx)
+        nx, ny = (128, 96) if case != "lap5_small_tile" else (1100, 12)   # 3 x 5 x (2048/5+2) rows > LDS budget -> 1024-entry tiles
+        N = nx * ny
+        colptr, rowval = P.lap5_csc(nx, ny)
+        colors = P.lap5_colors(nx, ny)
+        fam, prm = "lap5", (nx, ny)
+        cap = 700_000 if case == "lap5_chunked" else 0
+        if case == "lap5":
+            colors[[5, 777, N - 3]] = 0
+    elif case == "band5":
         colptr, rowval = P.banded_csc(N, N, 2, 2)
         colors = P.cyclic_colors(N, 5)
     elif case == "bidiag_window":      # odd column window start: the local rows begin at an odd row
@@ -520,9 +531,9 @@ def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
         plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=(c0, c1) if c0 is not None else None)
         assert plan.info(fd.lib.INFO_WINDOW) == int(forced)
         if forced == "1":
-            assert 100 <= plan.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 125
+            assert 100 <= plan.info(fd.lib.INFO_WIN_OVERREAD_X100) <= (125 if fam != "lap5" else 400)
         out = _dev(np.full(plan.out_len(0), np.nan))
-        f = fd.BuiltinF("tridiag_nl", N)
+        f = fd.BuiltinF(fam, *prm)
         plan.jacobian(f, x, [out], f_in=f_in)
         outs.append(out.cpu().numpy())
     assert not np.isnan(outs[0]).any()
@@ -541,11 +552,22 @@ def test_row_window_heuristic(monkeypatch):
     nx, ny = 400, 100
     colptr, rowval = P.lap5_csc(nx, ny)
     Jl = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
-    assert fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central").info(fd.lib.INFO_WINDOW) == 0
+    pl = fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central")
+    # 5-point stencil: scattered gathers -> three dense row windows per tile, every f! value loaded ~3 times (from L2)
+    assert pl.info(fd.lib.INFO_WINDOW) == 1 and 250 <= pl.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 400
+    # a random pattern has no row locality at all: neither windows nor ... (stays on the gather kernels)
+    rng = np.random.default_rng(3)
+    A = np.zeros((3000, 3000))
+    A[rng.integers(0, 3000, 20000), rng.integers(0, 3000, 20000)] = 1
+    cpr, rvr = P.csc_from_dense(A)
+    Jr = fd.SparseMatrixCSC(3000, 3000, cpr, rvr)
+    cr = fd.matrix_colors(Jr)
+    assert fd.make_plan(Jr, Jr, cr, "forward").info(fd.lib.INFO_WINDOW) == 0
 
 
 def test_sorted_gather_heuristic(monkeypatch):
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    monkeypatch.setenv("FDJAC_WINDOW", "0")     # the choice between the two GATHER kernels
     N = 20000
     colptr, rowval = P.tridiag_csc(N)
     Jt = fd.SparseMatrixCSC(N, N, colptr, rowval)
