@@ -211,77 +211,20 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
         }                            \
     } while (0)
 
-// Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
-static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
-                            std::vector<int32_t> &nzc, std::vector<int64_t> &dest)
+// Row windows (k_decompress_window).  Per tile of T entries: the rows its coloured entries touch, clustered
+// into at most kWinMaxWin windows (a new window starts after a gap of more than kWinGap rows), and the range of
+// colours.  The kernel loads every window of every colour of the tile densely, so the variant is used when
+//   * every tile has <= kWinMaxWin windows, <= kWinMaxCol consecutive colours, <= 2048 window rows in total,
+//   * the LDS tile (colours x window rows x 8 B) leaves several workgroups per CU, and
+//   * the dense loads bring in at most 1.25 f! values per stored entry (banded patterns: exactly 1), or, for
+//     patterns whose gathers are scattered anyway (5-point stencils: 3), at most kWinMaxOverread -- re-reads
+//     that are served by the L2, traded for divergence-free 16-B loads (the gather kernels are TA-bound there).
+// rows / nzc: row and colour (>= 0; -1 = column without colour, written as 0; -2 = padding, never written) of
+// every output slot in storage order, padded to a multiple of kListPad.  Sets p->window on success.
+static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,
+                           bool scattered)
 {
     int rc;
-    p->nnz_local = (int64_t)rows.size();
-    int64_t r0 = p->M, r1 = 0;
-    for (int32_t r : rows) {
-        if (r < r0) r0 = r;
-        if (r + 1 > r1) r1 = (int64_t)r + 1;
-    }
-    if (rows.empty()) r0 = r1 = 0;
-    p->row0 = r0;
-    p->row1 = r1;
-    // pad the lists to whole tiles: row 0, colour "pad" (-2), destination 0 -- never written
-    const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
-    const bool has_dest = !dest.empty() || p->kind != K_CSC;
-    rows.resize(padded, 0);
-    nzc.resize(padded, -2);
-    if (has_dest) dest.resize(padded, 0);
-    for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
-
-    // Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of
-    // tiles: distinct 128-B lines touched by one wave-level gather (64 lanes, the kernels' lane->entry maps).
-    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
-    auto sort_tile = [&](size_t b0) {
-        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
-        for (int k = 0; k < kSortTile; ++k) {
-            const size_t e = b0 + (size_t)k;
-            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
-            ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[e]), k};
-        }
-        std::sort(ord.begin(), ord.end());
-    };
-    bool scattered = false;
-    if (!has_dest && p->nnz_local >= 4 * kSortTile) {
-        const size_t ntiles = padded / kSortTile;
-        const size_t step = std::max<size_t>(1, ntiles / 64);
-        auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
-        double ld = 0, ls = 0;
-        size_t ninstr = 0;
-        std::vector<int64_t> keys;
-        for (size_t t = 0; t < ntiles; t += step) {
-            const size_t b0 = t * kSortTile;
-            sort_tile(b0);
-            for (int g = 0; g < kSortTile / 128; ++g)
-                for (int half = 0; half < 2; ++half) {
-                    keys.clear();
-                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)(g * 128 + 2 * l + half); keys.push_back(line_key(nzc[e], rows[e])); }
-                    std::sort(keys.begin(), keys.end());
-                    ld += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
-                    keys.clear();
-                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)ord[(size_t)(g * 128 + 64 * half + l)].second; keys.push_back(line_key(nzc[e], rows[e])); }
-                    std::sort(keys.begin(), keys.end());
-                    ls += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
-                    ++ninstr;
-                }
-        }
-        p->lines_direct = ld / std::max<size_t>(ninstr, 1);
-        p->lines_sorted = ls / std::max<size_t>(ninstr, 1);
-        scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
-    }
-
-    // Row windows (k_decompress_window).  Per tile of T entries: the rows its coloured entries touch, clustered
-    // into at most kWinMaxWin windows (a new window starts after a gap of more than kWinGap rows), and the range of
-    // colours.  The kernel loads every window of every colour of the tile densely, so the variant is used when
-    //   * every tile has <= kWinMaxWin windows, <= kWinMaxCol consecutive colours, <= 2048 window rows in total,
-    //   * the LDS tile (colours x window rows x 8 B) leaves several workgroups per CU, and
-    //   * the dense loads bring in at most 1.25 f! values per stored entry (banded patterns: exactly 1), or, for
-    //     patterns whose gathers are scattered anyway (5-point stencils: 3), at most kWinMaxOverread -- re-reads
-    //     that are served by the L2, traded for divergence-free 16-B loads (the gather kernels are TA-bound there).
     struct WinBuild {
         bool ok = false;
         int T = 0, max_slots = 0, max_ncol = 0;
@@ -362,7 +305,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         w.ok = w.max_slots > 0;
         return w;
     };
-    if (!has_dest && p->nnz_local > 0) {
+    {
         const char *fw = getenv("FDJAC_WINDOW"), *fs = getenv("FDJAC_SORTED");
         const int force_w = (fw && *fw) ? atoi(fw) : -1, force_s = (fs && *fs) ? atoi(fs) : -1;
         WinBuild best;
@@ -390,12 +333,84 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             p->win_ncol = best.max_ncol;
             if ((rc = dev_upload(&p->d_wtiles, best.wt))) return rc;
             if ((rc = dev_upload(&p->d_wcode, best.code))) return rc;
+        }
+    }
+    return FD_OK;
+}
+
+// Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
+static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
+                            std::vector<int32_t> &nzc, std::vector<int64_t> &dest)
+{
+    int rc;
+    p->nnz_local = (int64_t)rows.size();
+    int64_t r0 = p->M, r1 = 0;
+    for (int32_t r : rows) {
+        if (r < r0) r0 = r;
+        if (r + 1 > r1) r1 = (int64_t)r + 1;
+    }
+    if (rows.empty()) r0 = r1 = 0;
+    p->row0 = r0;
+    p->row1 = r1;
+    // pad the lists to whole tiles: row 0, colour "pad" (-2), destination 0 -- never written
+    const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
+    const bool has_dest = !dest.empty() || p->kind != K_CSC;
+    rows.resize(padded, 0);
+    nzc.resize(padded, -2);
+    if (has_dest) dest.resize(padded, 0);
+    for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
+
+    // Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of
+    // tiles: distinct 128-B lines touched by one wave-level gather (64 lanes, the kernels' lane->entry maps).
+    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+    auto sort_tile = [&](size_t b0) {
+        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
+        for (int k = 0; k < kSortTile; ++k) {
+            const size_t e = b0 + (size_t)k;
+            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
+            ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[e]), k};
+        }
+        std::sort(ord.begin(), ord.end());
+    };
+    bool scattered = false;
+    if (!has_dest && p->nnz_local >= 4 * kSortTile) {
+        const size_t ntiles = padded / kSortTile;
+        const size_t step = std::max<size_t>(1, ntiles / 64);
+        auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
+        double ld = 0, ls = 0;
+        size_t ninstr = 0;
+        std::vector<int64_t> keys;
+        for (size_t t = 0; t < ntiles; t += step) {
+            const size_t b0 = t * kSortTile;
+            sort_tile(b0);
+            for (int g = 0; g < kSortTile / 128; ++g)
+                for (int half = 0; half < 2; ++half) {
+                    keys.clear();
+                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)(g * 128 + 2 * l + half); keys.push_back(line_key(nzc[e], rows[e])); }
+                    std::sort(keys.begin(), keys.end());
+                    ld += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                    keys.clear();
+                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)ord[(size_t)(g * 128 + 64 * half + l)].second; keys.push_back(line_key(nzc[e], rows[e])); }
+                    std::sort(keys.begin(), keys.end());
+                    ls += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                    ++ninstr;
+                }
+        }
+        p->lines_direct = ld / std::max<size_t>(ninstr, 1);
+        p->lines_sorted = ls / std::max<size_t>(ninstr, 1);
+        scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
+    }
+
+    if (!has_dest && p->nnz_local > 0) {
+        if ((rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
+        if (p->window) {
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
             nzc.clear();
         } else {
+            const char *fs = getenv("FDJAC_SORTED");
             p->sorted_gather = scattered;
-            if (force_s >= 0) p->sorted_gather = force_s != 0 && p->nnz_local >= 4 * kSortTile;
+            if (fs && *fs) p->sorted_gather = atoi(fs) != 0 && p->nnz_local >= 4 * kSortTile;
         }
     }
     if (p->sorted_gather) {
@@ -666,9 +681,29 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
     FD_TRY(upload_colors(p, col0, {}));
     p->row0 = std::min<int64_t>(std::max<int64_t>(p->col0 - u, 0), M);
     p->row1 = std::max<int64_t>(std::min<int64_t>(p->col1 + l, M), p->row0);
-    FD_TRY(alloc_scratch(p, col0));
     p->nouts = 1;
     p->out_len[0] = (p->col1 - p->col0) * (l + u + 1);
+    {
+        // the band's column-major storage as an entry list with implicit indices (slot k of column j <-> row j-u+k;
+        // slots outside the matrix and columns without colour are written as 0): narrow bands go through the
+        // row-window kernel, exactly like a banded SparseMatrixCSC
+        const int64_t w = l + u + 1, slots = p->out_len[0];
+        if (slots > 0 && w <= 64) {
+            const size_t padded = (size_t)round_up(slots, kListPad);
+            std::vector<int32_t> rows(padded, 0), nzc(padded, -2);
+            size_t e = 0;
+            for (int64_t j = p->col0; j < p->col1; ++j)
+                for (int64_t k = 0; k < w; ++k, ++e) {
+                    const int64_t r = j - u + k;
+                    const bool in = r >= 0 && r < M && col0[(size_t)j] >= 0;
+                    rows[e] = in ? (int32_t)r : 0;
+                    nzc[e] = in ? col0[(size_t)j] : -1;
+                }
+            p->nnz_local = slots;
+            FD_TRY(try_window_plan(p, rows, nzc, padded, false));
+        }
+    }
+    FD_TRY(alloc_scratch(p, col0));
     return FD_OK;
 }
 

@@ -570,6 +570,127 @@ k_decompress_tridiag(const CT *__restrict__ color, const double *__restrict__ FX
     }
 }
 
+// K4a'  Tridiagonal J through row windows: a workgroup owns kTriTile consecutive columns [a, a+kTriTile), loads
+//   rows [a-1, a+kTriTile+1) of fx and of the (<= NCT) batched f! arrays densely into LDS as differences, and
+//   writes its slices of the three diagonals with dense 16-B stores:
+//       d[i] = D_c(i)[i],   dl[i] = D_c(i)[i+1],   du[i] = D_c(i+1)[i]      (D_c = (fx1_c - fx)/eps_c)
+//   Used when maximum(colorvec) <= NCT (a tridiagonal pattern needs 3 colours): every loaded value is then used.
+//   Same arithmetic as k_decompress_tridiag => bit-identical.
+constexpr int kTriTile = 1024;
+template <typename CT, int MODE, int NCT>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restrict__ FXa,
+                            const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps, int c_lo,
+                            int c_hi, int64_t N, int64_t j0, int64_t j1, double *__restrict__ dl,
+                            double *__restrict__ d, double *__restrict__ du, int fxb_vec, int vec_ok)
+{
+    constexpr int WP = kTriTile + 4;                 // LDS pitch (rows a-2 .. a+kTriTile+1, even start)
+    extern __shared__ double s_mem_t[];              // kWinMaxCol step sizes, then ncol x WP differences
+    double *s_eps = s_mem_t;
+    double *s_win = s_mem_t + kWinMaxCol;
+    const int none = ColorTraits<CT>::none;
+    const int64_t ntiles = (j1 - j0 + kTriTile - 1) / kTriTile;
+    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
+    if (tile_id >= ntiles) return;
+    const int64_t a = j0 + tile_id * kTriTile;       // j0 is even by construction (host), so a is even
+    const int64_t b = (a + kTriTile < j1) ? a + kTriTile : j1;
+    const int ncol = c_hi - c_lo;                    // <= NCT
+    const int64_t rbeg = a >= 2 ? a - 2 : 0;         // even; rows needed: a-1 .. b
+    const int64_t rend = (b + 1 < N) ? b + 1 : N;    // exclusive
+    const int npairs = (int)((rend - rbeg + 1) / 2);
+    if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[c_lo + threadIdx.x] : 1.0;
+#pragma unroll 1
+    for (int i = threadIdx.x; i < npairs; i += kBlock) {
+        const int64_t row = rbeg + 2 * i;
+        d2_t bb = {0.0, 0.0};
+        if (MODE == 0) {
+            if (fxb_vec) {
+                bb = *reinterpret_cast<const d2_t *>(FXb + row);
+            } else {
+                if (row < N) bb.x = FXb[row];
+                if (row + 1 < N) bb.y = FXb[row + 1];
+            }
+        }
+        d2_t av[NCT], bv[NCT];
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            const int64_t at = (int64_t)cc * ld + row;
+            av[cc] = d2_t{0.0, 0.0};
+            bv[cc] = bb;
+            if (cc < ncol) {
+                if (MODE == 2) {
+                    const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                    const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                    av[cc] = d2_t{p0.y, p1.y};
+                } else {
+                    av[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
+                    if (MODE == 1) bv[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc)
+            if (cc < ncol) {
+                const d2_t df = (MODE == 2) ? av[cc] : d2_t{av[cc].x - bv[cc].x, av[cc].y - bv[cc].y};
+                *reinterpret_cast<d2_t *>(s_win + cc * WP + 2 * i) = df;
+            }
+    }
+    __syncthreads();
+
+    const int64_t du0 = j0 > 0 ? j0 - 1 : 0;
+    auto quot = [&](int c, int64_t r) -> double {   // D_c[r] for a colour of this chunk
+        const double df = s_win[(c - c_lo) * WP + (int)(r - rbeg)];
+        const double e = s_eps[c - c_lo];
+        return (MODE == 1) ? df / (2 * e) : df / e;
+    };
+    if (a == j0 && j0 > 0 && threadIdx.x == 0) {   // du of the plan's first column (its pair partner is another rank's)
+        const int c = (int)color[j0];
+        if ((unsigned)(c - c_lo) < (unsigned)ncol) du[0] = quot(c, j0 - 1);
+        else if ((c == none) & (c_lo == 0)) du[0] = 0.0;
+    }
+#pragma unroll 1
+    for (int64_t i = a + 2 * (int64_t)threadIdx.x; i < b; i += 2 * kBlock) {
+        // colours of columns i, i+1, i+2 (i is even)
+        int c0, c1, c2 = none, c3;
+        if (i + 1 < N) load_color_pair<CT>(color + i, c0, c1); else { c0 = (int)color[i]; c1 = none; }
+        if (i + 3 < N) load_color_pair<CT>(color + i + 2, c2, c3); else if (i + 2 < N) c2 = (int)color[i + 2];
+        const bool in0 = (unsigned)(c0 - c_lo) < (unsigned)ncol, in1 = (i + 1 < b) & ((unsigned)(c1 - c_lo) < (unsigned)ncol);
+        const bool in1x = (i + 1 < N) & ((unsigned)(c1 - c_lo) < (unsigned)ncol);      // column i+1 may belong to the next tile
+        const bool in2 = (i + 2 < N) & (i + 2 < j1) & ((unsigned)(c2 - c_lo) < (unsigned)ncol);
+        const bool z0 = (c0 == none) & (c_lo == 0), z1 = (i + 1 < b) & (c1 == none) & (c_lo == 0);
+        const bool z1x = (i + 1 < N) & (i + 1 < j1) & (c1 == none) & (c_lo == 0), z2 = (i + 2 < N) & (i + 2 < j1) & (c2 == none) & (c_lo == 0);
+        // d[i], d[i+1]
+        {
+            const double q0 = in0 ? quot(c0, i) : 0.0, q1 = in1 ? quot(c1, i + 1) : 0.0;
+            const bool w0 = in0 | z0, w1 = in1 | z1;
+            double *o = d + (i - j0);
+            if (__builtin_amdgcn_ballot_w64(w0 & w1 & (vec_ok & 1)) == __builtin_amdgcn_ballot_w64(true)) {
+                *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
+            } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
+        }
+        // dl[i] (column i, row i+1), dl[i+1] (column i+1, row i+2)
+        {
+            const bool e0 = i + 1 < N, e1 = (i + 1 < b) & (i + 2 < N);
+            const double q0 = (in0 & e0) ? quot(c0, i + 1) : 0.0, q1 = (in1 & e1) ? quot(c1, i + 2) : 0.0;
+            const bool w0 = (in0 | z0) & e0, w1 = (in1 | z1) & e1;
+            double *o = dl + (i - j0);
+            if (__builtin_amdgcn_ballot_w64(w0 & w1 & ((vec_ok >> 1) & 1)) == __builtin_amdgcn_ballot_w64(true)) {
+                *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
+            } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
+        }
+        // du[i] (column i+1, row i), du[i+1] (column i+2, row i+1); columns must lie inside [j0, j1)
+        {
+            const bool e0 = (i + 1 < N) & (i + 1 < j1), e1 = (i + 1 < b) & (i + 2 < N) & (i + 2 < j1);
+            const double q0 = (in1x & e0) ? quot(c1, i) : 0.0, q1 = (in2 & e1) ? quot(c2, i + 1) : 0.0;
+            const bool w0 = (in1x | z1x) & e0, w1 = (in2 | z2) & e1;
+            double *o = du + (i - du0);
+            if (__builtin_amdgcn_ballot_w64(w0 & w1 & ((vec_ok >> 2) & 1)) == __builtin_amdgcn_ballot_w64(true)) {
+                *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
+            } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
+        }
+    }
+}
+
 // K4b  BandedMatrix J: data is (l+u+1) x N column-major; slot k of column j holds row j-u+k
 //   (ext/FiniteDiffBandedMatricesExt.jl:13-27, storage per its line 22).  One thread per data
 //   slot => dense coalesced stores, implicit indices, one colour byte per column (L1-resident).
@@ -768,6 +889,29 @@ int launch_perturb(fd_plan *p, const double *x, int c_lo, int B)
 #undef FD_DISPATCH
 }
 
+template <int MODE>
+static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, const double *FXb, int c_lo, int c_hi,
+                            double *out)
+{
+    hipStream_t s = p->ctx->stream;
+    const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
+    const int wp = 2 * p->win_pairs;
+    const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)p->win_ncol + kWinMaxCol);
+    const int vok = (((uintptr_t)out) & 15) == 0;
+    // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
+    const bool fxvec = (MODE != 0) || (fx == p->d_fx);
+#define FD_LAUNCH_WIN(NCT, FV, UU)                                                                          \
+    hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
+                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,   \
+                       c_hi, out, p->nnz_local, vok, wp)
+#define FD_LAUNCH_WIN_U(NCT, FV) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2); else FD_LAUNCH_WIN(NCT, FV, 1); } while (0)
+    if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true); else FD_LAUNCH_WIN_U(4, false); }
+    else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true); else FD_LAUNCH_WIN_U(6, false); }
+    else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true); else FD_LAUNCH_WIN_U(kWinMaxCol, false); }
+#undef FD_LAUNCH_WIN_U
+#undef FD_LAUNCH_WIN
+}
+
 template <typename CT, int MODE>
 static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs)
 {
@@ -806,22 +950,7 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
             break;
         }
         if (p->window && p->kind == K_CSC) {
-            const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
-            const int wp = 2 * p->win_pairs;
-            const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)p->win_ncol + kWinMaxCol);
-            const int vok = (((uintptr_t)outs[0]) & 15) == 0;
-            // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
-            const bool fxvec = (MODE != 0) || (fx == p->d_fx);
-#define FD_LAUNCH_WIN(NCT, FV, UU)                                                                                  \
-            hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
-                               (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,   \
-                               c_hi, outs[0], p->nnz_local, vok, wp)
-#define FD_LAUNCH_WIN_U(NCT, FV) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2); else FD_LAUNCH_WIN(NCT, FV, 1); } while (0)
-            if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true); else FD_LAUNCH_WIN_U(4, false); }
-            else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true); else FD_LAUNCH_WIN_U(6, false); }
-            else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true); else FD_LAUNCH_WIN_U(kWinMaxCol, false); }
-#undef FD_LAUNCH_WIN_U
-#undef FD_LAUNCH_WIN
+            launch_window_m<MODE>(p, fx, FXa, FXb, c_lo, c_hi, outs[0]);
             break;
         }
         const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)
@@ -849,12 +978,31 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
         break;
     }
     case K_TRIDIAG: {
+        static const int win_off = (int)env_i64("FDJAC_WINDOW", -1) == 0;
+        // row-window variant: few colours (every loaded f! value is used when C == 3), an even first column (16-B
+        // aligned pairs); otherwise the gather kernel below
+        if (!win_off && p->C <= 4 && (p->col0 % 2) == 0 && p->col1 > p->col0) {
+            const int64_t nt = (p->col1 - p->col0 + kTriTile - 1) / kTriTile;
+            const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
+            const int fxvec = (MODE != 0) || (fx == p->d_fx);
+            const int vok = ((((uintptr_t)outs[1]) & 15) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & 15) == 0 ? 2 : 0) |
+                            (((((uintptr_t)outs[2]) + 8 * (uintptr_t)(p->col0 - du0)) & 15) == 0 ? 4 : 0);
+            const size_t shmt = sizeof(double) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
+            hipLaunchKernelGGL((k_decompress_tridiag_window<CT, MODE, 4>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock),
+                               shmt, s, color, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],
+                               outs[1], outs[2], fxvec, vok);
+            break;
+        }
         const int g = grid_for(p->col1 - p->col0, kBlock, p->ctx->num_cus);
         hipLaunchKernelGGL((k_decompress_tridiag<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
                            p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0], outs[1], outs[2]);
         break;
     }
     case K_BANDED: {
+        if (p->window) {   // the band's storage order IS an entry list with implicit indices: same kernel as CSC
+            launch_window_m<MODE>(p, fx, FXa, FXb, c_lo, c_hi, outs[0]);
+            break;
+        }
         const int g = grid_for((p->col1 - p->col0) * (p->l + p->u + 1), kBlock, p->ctx->num_cus);
         hipLaunchKernelGGL((k_decompress_banded<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
                            p->ldf, p->d_eps, c_lo, c_hi, p->M, p->l, p->u, p->col0, p->col1, outs[0]);

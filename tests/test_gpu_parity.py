@@ -494,6 +494,7 @@ def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
 def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
     # the row-window kernel (dense f! loads -> LDS -> entries) must equal the storage-order gather kernel bit for bit
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
     N = 9001
     cap, c0, c1 = 0, None, None
     fam, prm = "tridiag_nl", (N,)
@@ -536,6 +537,64 @@ def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
         f = fd.BuiltinF(fam, *prm)
         plan.jacobian(f, x, [out], f_in=f_in)
         outs.append(out.cpu().numpy())
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["n1", "n2", "n3", "n1023", "n1024", "n1025", "n5003", "none", "chunked", "f_in",
+                                  "win_even", "win_odd", "win_tail", "c4", "c5_fallback"])
+def test_tridiagonal_window_kernel_bit_identical(monkeypatch, fdtype, case):
+    # Tridiagonal J: the row-window kernel (dense loads -> LDS -> three dense diagonals) vs the gather kernel
+    N = {"n1": 1, "n2": 2, "n3": 3, "n1023": 1023, "n1024": 1024, "n1025": 1025}.get(case, 5003)
+    C = 4 if case == "c4" else 5 if case == "c5_fallback" else min(3, N)
+    colors = P.cyclic_colors(N, C)
+    if case == "none":
+        colors[[0, 1, 1024, 2047, 2048, N - 1]] = 0
+    cap = 120_000 if case == "chunked" else 0
+    win = {"win_even": (1024, 4000), "win_odd": (1025, 4001), "win_tail": (2048, N)}.get(case)
+    x = _dev(np.random.default_rng(41).random(N))
+    f_in = _dev(np.random.default_rng(42).random(N + 1))[1:] if case == "f_in" else None
+    outs = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FDJAC_WINDOW", forced) if forced == "0" else monkeypatch.delenv("FDJAC_WINDOW")
+        J = fd.Tridiagonal(None, torch.empty(N, dtype=torch.float64, device="cuda"), None)
+        plan = fd.make_plan(J, None, colors, fdtype, scratch_bytes=cap, col_window=win,
+                            x_window=(max(win[0] - 2, 0), min(win[1] + 2, N)) if win else None)
+        if case == "chunked":
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        o = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3)]
+        plan.jacobian(fd.BuiltinF("tridiag_nl", N), x, o, f_in=f_in)
+        outs.append(np.concatenate([t.cpu().numpy() for t in o]))
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("l,u,M,N", [(1, 1, 5003, 5003), (2, 1, 4100, 4097), (0, 3, 2500, 3100), (3, 0, 3300, 2000), (4, 4, 3000, 3000)])
+def test_banded_window_kernel_bit_identical(monkeypatch, fdtype, l, u, M, N):
+    # BandedMatrix J through the row-window kernel (implicit indices) vs the per-slot gather kernel
+    colors = P.cyclic_colors(N, min(l + u + 1, 8)) if l + u + 1 <= 8 else P.cyclic_colors(N, l + u + 1)
+    colors[[3, N // 2]] = 0
+    x = _dev(np.random.default_rng(43).random(N))
+    A = torch.as_tensor(np.random.default_rng(44).random((M, 3)), device="cuda")
+
+    def fn(fx, xx):   # any f! with the right band: f_i = sum_k A[i,k] * x[clamp(i-1+k)]^2
+        idx = torch.arange(M, device="cuda")
+        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
+        for k in range(3):
+            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - 1 + k, 0, N - 1)] ** 2
+        fx.copy_(acc)
+
+    outs = []
+    for forced in ("0", "1"):
+        monkeypatch.setenv("FDJAC_WINDOW", forced) if forced == "0" else monkeypatch.delenv("FDJAC_WINDOW")
+        data = torch.full((N, l + u + 1), float("nan"), dtype=torch.float64, device="cuda").t()
+        J = fd.BandedMatrix(data, M, l, u)
+        plan = fd.make_plan(J, None, colors, fdtype)
+        assert plan.info(fd.lib.INFO_WINDOW) == (int(forced) if l + u + 1 <= 8 else 0)
+        plan.jacobian(fd.TorchF(fn, M, N), x, [data])
+        outs.append(data.cpu().numpy().copy())
     assert not np.isnan(outs[0]).any()
     assert np.array_equal(outs[0], outs[1])
 
