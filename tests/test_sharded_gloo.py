@@ -88,3 +88,23 @@ def test_two_rank_gather_gloo(tmp_path, oracle):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """The N>1 path of bench.py end to end on the GPU box: two ranks (sharing the one GPU, gloo transport, the
+    configuration FDJAC_BENCH_BACKEND=gloo exists for) each compute their column range with a windowed plan and
+    the gather assembles nzval; the assembled values must be the exact stencil."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", FDJAC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--size", "300001"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["gather_in_step"] is True
+    assert res["result_check_max_dev"] is not None and res["result_check_max_dev"] < 1e-7
+    assert res["ms_gather"] > 0 and res["value"] > 0
