@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--f-mode", choices=["lazy", "materialized"], default="lazy",
                     help="lazy: f! perturbs while loading (fd_f_launch_lazy); materialized: perturbed points written to HBM")
     ap.add_argument("--no-gather", action="store_true", help="leave nzval sharded (compute-only scaling)")
+    ap.add_argument("--shard", choices=["columns", "colors"], default="columns",
+                    help="N>1 decomposition: contiguous column ranges + all-gather (default; needs a row-window-capable f!), "
+                         "or colour ownership + all-reduce (any f!, at most C ranks; c4/c2 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="columns for the CPU baseline sample (0 = same as --n)")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -117,14 +120,19 @@ def main():
         colors = P.cyclic_colors(N, 3)
         colptr, rowval = P.tridiag_csc(N)
         nnz = rowval.size
-        cuts = S.partition_columns(colptr, world)
-        ranges = S.entry_ranges(colptr, cuts)
-        counts = [b - a for a, b in ranges]
-        c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
         pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
-        xw = S.x_window(cuts, rank, N, 1, 1, 1)
-        plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
-                            x_window=xw if world > 1 else None)
+        if args.shard == "colors" and world > 1:
+            ccuts = S.partition_colors(colors, world)
+            counts, c0, c1 = [nnz], 0, N
+            plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, color_range=(ccuts[rank], ccuts[rank + 1]))
+        else:
+            cuts = S.partition_columns(colptr, world)
+            ranges = S.entry_ranges(colptr, cuts)
+            counts = [b - a for a, b in ranges]
+            c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
+            xw = S.x_window(cuts, rank, N, 1, 1, 1)
+            plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
+                                x_window=xw if world > 1 else None)
         f = fd.BuiltinF("tridiag", N, ctx=ctx)
         lazy_ok = True
         # per column: SURVEY 8(d) algorithmic bytes; what this implementation must move at minimum (fx and the three
@@ -183,18 +191,28 @@ def main():
         plan.set_lazy(f)
     f_mode = "lazy" if (args.f_mode == "lazy" and lazy_ok) else "materialized"
     gather = world > 1 and not args.no_gather
+    by_color = args.shard == "colors" and world > 1 and cfg in ("c2", "c4")
     bufs = S.AllGatherBuffers(counts, dev, torch.float64)
-    out = bufs.local_view(rank)[: counts[rank]] if world > 1 else bufs.buf
+    out = bufs.local_view(rank)[: counts[rank]] if (world > 1 and not by_color) else bufs.buf
+    own = torch.zeros_like(out) if by_color else None   # colour ownership: every rank holds the whole nzval, zero
+                                                        # except for the columns of its colours; assembly = SUM
 
     host_bufs = S.AllGatherBuffers(counts, torch.device("cpu"), torch.float64) if (gather and backend != "nccl") else None
 
     def do_gather():
+        if by_color:
+            bufs.buf.copy_(own)
+            S.all_reduce_owned(bufs.buf, dist) if backend == "nccl" else bufs.buf.copy_(S.all_reduce_owned(bufs.buf.cpu(), dist))
+            return
         if backend == "nccl":
             bufs.gather(rank, dist)          # one ncclAllGather, in place in the padded buffer
         else:                                # dry run: stage through host memory
             host_bufs.local_view(rank).copy_(bufs.local_view(rank))
             host_bufs.gather(rank, dist)
             bufs.buf.copy_(host_bufs.buf)
+
+    if by_color:
+        out = own
 
     def step():
         plan.jacobian(f, x, [out], sync=False)
@@ -238,7 +256,7 @@ def main():
     ms_gather = (sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)) / args.steps) if gather else 0.0
 
     # sanity on the result of the last step (linear fixture => exact stencil), not timed
-    full = bufs.compact() if gather or world == 1 else None
+    full = (bufs.buf if by_color else bufs.compact()) if gather or world == 1 else None
     check = None
     if full is not None:
         v = full if world > 1 else out
@@ -279,7 +297,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": wl, "name": cfg, "fdtype": fdtype, "colors": C,
-                       "parallelism": "columns x%d%s" % (world, "+allgather" if gather else ""),
+                       "parallelism": ("colours x%d%s" % (world, "+allreduce" if gather else "")) if by_color else
+                                      ("columns x%d%s" % (world, "+allgather" if gather else "")),
                        "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
                                   if f_mode == "lazy" else
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),

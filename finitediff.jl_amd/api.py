@@ -349,7 +349,7 @@ class Plan:
         _l.check(rc)
 
 
-def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0):
+def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
     if col_window is not None:
@@ -357,6 +357,8 @@ def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0):
     if x_window is not None:
         o.x_begin, o.x_end = int(x_window[0]), int(x_window[1])
     o.scratch_bytes = int(scratch_bytes)
+    if color_range is not None:   # owned colours, 0-based [begin, end)
+        o.color_begin, o.color_end = int(color_range[0]), int(color_range[1])
     return o
 
 
@@ -364,14 +366,15 @@ def _vp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0):
+def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
+              color_range=None):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
     ctx = ctx or Context.default()
     L = ctx.L
     fdtype = _norm_fdtype(fdtype)
-    o = _opts(fdtype, col_window, x_window, scratch_bytes)
+    o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range)
     h = C.c_void_p()
     cv = _i64(colorvec)
     if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):

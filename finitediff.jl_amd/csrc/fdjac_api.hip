@@ -127,6 +127,14 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
         p->x1 = opts->x_end;
     }
     p->scratch_bytes = opts->scratch_bytes > 0 ? opts->scratch_bytes : ((int64_t)64 << 30);
+    p->own_c0 = 0;
+    p->own_c1 = -1;
+    if (!(opts->color_begin == 0 && opts->color_end == 0)) {
+        FD_REQUIRE(opts->color_begin >= 0 && opts->color_begin <= opts->color_end, FD_ERR_ARG,
+                   "colour range [%lld,%lld) is not a range", (long long)opts->color_begin, (long long)opts->color_end);
+        p->own_c0 = opts->color_begin;
+        p->own_c1 = opts->color_end;
+    }
     return FD_OK;
 }
 
@@ -974,9 +982,11 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
             FD_HIP_CHECK(hipMemsetAsync(outs[k], 0, sizeof(double) * (size_t)p->out_len[k], s));
     }
 
-    for (int64_t ch = 0; ch < p->nchunks; ++ch) {
-        const int c_lo = (int)(ch * p->chunkB);
-        const int c_hi = (int)std::min<int64_t>(p->C, (int64_t)c_lo + p->chunkB);
+    // colours of this plan: all of them, or the owned range (fd_plan_opts.color_begin/end), in chunks of chunkB
+    const int64_t oc0 = std::min<int64_t>(p->own_c0, p->C), oc1 = p->own_c1 < 0 ? p->C : std::min<int64_t>(p->own_c1, p->C);
+    for (int64_t cl = oc0; cl < oc1; cl += p->chunkB) {
+        const int c_lo = (int)cl;
+        const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
         const int B = c_hi - c_lo;
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);

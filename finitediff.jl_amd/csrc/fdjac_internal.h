@@ -78,6 +78,7 @@ struct fd_plan {
     int64_t C = 0;        // maximum(colorvec)
     bool color8 = true;   // colours stored as uint8 (C <= 254) else int32
     int64_t col0 = 0, col1 = 0, x0 = 0, x1 = 0, row0 = 0, row1 = 0;
+    int64_t own_c0 = 0, own_c1 = -1;   // owned colours [own_c0, own_c1), -1 = up to C (fd_plan_opts.color_begin/end)
 
     // pattern (device)
     void *d_color = nullptr;       // per column, 0-based colour, "none" = all-ones

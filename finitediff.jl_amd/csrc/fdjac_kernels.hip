@@ -927,7 +927,7 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
         if (p->nnz_local == 0) break;
         if (p->sorted_gather && p->kind == K_CSC) {
             const bool ldsq = B <= kEpsLdsMax;
-            const bool allw = (p->nchunks == 1) && !p->has_none;
+            const bool allw = (p->nchunks == 1) && !p->has_none && p->own_c0 == 0 && (p->own_c1 < 0 || p->own_c1 >= p->C);
             const int64_t gq = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
             const size_t shmq = sizeof(double) * (size_t)(kSortTile + (allw ? 0 : kSortTile / 8) + (ldsq ? B : 0));
             const int vok = (((uintptr_t)outs[0]) & 15) == 0;

@@ -36,8 +36,10 @@ struct PlanOpts
     x_begin::Int64
     x_end::Int64
     scratch_bytes::Int64
+    color_begin::Int64      # owned colours [color_begin, color_end), 0-based; 0,0 = all (multi-GPU colour sharding)
+    color_end::Int64
 end
-PlanOpts(fd) = PlanOpts(fdtype_code(fd), 0, 0, 0, 0, 0, 0)
+PlanOpts(fd) = PlanOpts(fdtype_code(fd), 0, 0, 0, 0, 0, 0, 0, 0)
 
 function check(rc::Cint)
     rc == 0 && return

@@ -53,7 +53,8 @@ EXPORTS = (
 
 class PlanOpts(C.Structure):
     _fields_ = [("fdtype", C.c_int32), ("reserved0", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
-                ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64)]
+                ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64),
+                ("color_begin", C.c_int64), ("color_end", C.c_int64)]
 
 
 class FdError(RuntimeError):

@@ -8,6 +8,13 @@ range it is.  x is replicated; every rank reduces the ful
 step sizes with the same deterministic kernel, so eps is bit-identical across ranks without
 communication.
 
+The second decomposition is **by colour** (`partition_colors`, `fd_plan_opts.color_begin/end`): rank r owns
+a contiguous range of colours, evaluates f! only at the points of those colours -- on full vectors, so ANY f!
+works, including an opaque user launcher that cannot restrict itself to a row window -- and writes only the stored
+values of the columns it owns.  That is the split for problems whose f! dominates (the usual case outside
+benchmarks); it caps at C ranks and its exchange step is one all-reduce(SUM) over outputs that start from zero
+(each stored value is non-zero on exactly one rank), or a packed gather.
+
 Nothing here touches the GPU directly: the local compute is a libfdjac plan with a column
 window (fd_plan_opts.col_begin/col_end); the gather is torch.distributed (backend "nccl" is
 RCCL on ROCm; "gloo" for the CPU tests).
@@ -24,6 +31,28 @@ def partition_columns(colptr, world):
     cuts = np.searchsorted(colptr, targets, side="left").astype(np.int64)
     cuts[0], cuts[-1] = 0, n
     return np.maximum.accumulate(np.minimum(cuts, n))
+
+
+def partition_colors(colorvec, world, weights=None):
+    """Colour cuts (world+1,), 0-based: rank r owns colours [cuts[r], cuts[r+1]).  Balanced by the number of f!
+    evaluations (one per colour), or by `weights[c]` (e.g. stored entries per colour) when given."""
+    colorvec = np.asarray(colorvec)
+    C = int(colorvec.max()) if colorvec.size else 0
+    w = np.ones(C) if weights is None else np.asarray(weights, dtype=np.float64)
+    tot = np.concatenate([[0.0], np.cumsum(w)])
+    targets = tot[-1] * np.arange(world + 1) / world
+    cuts = np.searchsorted(tot, targets, side="left").astype(np.int64)
+    cuts[0], cuts[-1] = 0, C
+    return np.maximum.accumulate(np.minimum(cuts, C))
+
+
+def all_reduce_owned(out, dist=None, group=None):
+    """Assemble outputs computed under colour ownership: every stored value is non-zero on exactly one rank
+    (`out` must have started from zero), so a SUM all-reduce is an exact assembly (x + 0 == x bit for bit)."""
+    if dist is None:
+        import torch.distributed as dist
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
 
 
 def entry_ranges(colptr, cuts):

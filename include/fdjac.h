@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 100
+#define FDJAC_VERSION 101
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -110,6 +110,13 @@ typedef struct fd_plan_opts {
     int64_t x_begin;       /* entries of x the windowed f! reads, [x_begin, x_end); 0,0 = all   */
     int64_t x_end;
     int64_t scratch_bytes; /* cap for the batched perturbed-point scratch; 0 = default (64 GiB) */
+    int64_t color_begin;   /* colour ownership [color_begin, color_end), 0-based colours; 0,0 = all colours.    */
+    int64_t color_end;     /*   Only the owned colours are perturbed / evaluated and only stored values whose   */
+                           /*   column has an owned colour are written (values of columns without colour: by    */
+                           /*   the owner of colour 0); everything else in outs is left untouched.  This is the */
+                           /*   "each GPU owns a disjoint subset of colours" split: it needs no cooperation     */
+                           /*   from f! (an opaque f! is evaluated on full vectors), caps at C ranks, and the   */
+                           /*   owners' outputs add up to the full result when outs start from zero.            */
 } fd_plan_opts;
 
 /* ---- context ------------------------------------------------------------------------- */

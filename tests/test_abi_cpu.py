@@ -25,7 +25,7 @@ def test_header_symbols_all_exported(L):
     assert declared == set(fd.lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fd_version() == 100
+    assert L.fd_version() == 101
 
 
 def test_no_gpu_fails_loudly(L):
@@ -42,8 +42,8 @@ def test_no_gpu_fails_loudly(L):
 
 
 def test_plan_opts_layout():
-    # struct fd_plan_opts: int32 x2 then five int64 (include/fdjac.h)
-    assert C.sizeof(fd.lib.PlanOpts) == 8 + 5 * 8
+    # struct fd_plan_opts: int32 x2 then seven int64 (include/fdjac.h)
+    assert C.sizeof(fd.lib.PlanOpts) == 8 + 7 * 8
     assert fd.lib.PlanOpts.col_begin.offset == 8 and fd.lib.PlanOpts.scratch_bytes.offset == 40
 
 

@@ -387,6 +387,77 @@ def test_column_window_matches_full(oracle):
         assert np.array_equal(out.cpu().numpy(), want[e0:e0 + plan.out_len(0)])
 
 
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["csc_window", "csc_list", "csc_sorted", "tridiagonal", "banded", "blockbanded", "densej"])
+def test_colour_ownership_sums_to_full(monkeypatch, fdtype, case):
+    # multi-GPU split by colour (fd_plan_opts.color_begin/end): each owner writes only its columns' stored values,
+    # leaves the rest untouched, and the owners' outputs add up to the full result bit for bit -- with an f! that
+    # is evaluated on full vectors (no row window), and fcalls = owned colours (+1 base evaluation for forward)
+    from finitediff_jl_amd import sharded as S
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    N = 4097
+    fam, prm, sp = "tridiag_nl", (N,), None
+    colors = P.cyclic_colors(N, 3)
+    colors[[7, 2048]] = 0                      # columns without colour: written (as 0) by the owner of colour 1
+    if case.startswith("csc"):
+        if case == "csc_sorted":
+            nx, ny = 96, 64
+            N = nx * ny
+            colptr, rowval = P.lap5_csc(nx, ny)
+            colors = P.lap5_colors(nx, ny)
+            fam, prm = "lap5", (nx, ny)
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+            monkeypatch.setenv("FDJAC_SORTED", "1")
+        else:
+            colptr, rowval = P.tridiag_csc(N)
+            if case == "csc_list":
+                monkeypatch.setenv("FDJAC_WINDOW", "0")
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        sp = J
+    elif case == "tridiagonal":
+        J = fd.Tridiagonal(None, torch.empty(N, dtype=torch.float64, device="cuda"), None)
+    elif case == "banded":
+        J = fd.BandedMatrix(torch.empty((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
+    elif case == "blockbanded":
+        nb, bs = 40, 8
+        N = nb * bs
+        lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+        colors = lay.colors()
+        J = fd.BlockBandedMatrix(None, lay)
+        sp = J
+        fam, prm = "blockcoupled", (nb, bs)
+    else:
+        N = 60
+        colors = P.cyclic_colors(N, 3)
+        colptr, rowval = P.tridiag_csc(N)
+        J = torch.empty((N, N), dtype=torch.float64, device="cuda").t()
+        sp = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        prm = (N,)
+    C = int(colors.max())
+    x = _dev(np.random.default_rng(51).random(N))
+    full_plan = fd.make_plan(J, sp, colors, fdtype)
+    nouts = full_plan.nouts
+    full = [_dev(np.full(full_plan.out_len(k), np.nan)) for k in range(nouts)]
+    full_plan.jacobian(fd.BuiltinF(fam, *prm), x, full)
+    world = 3 if C >= 3 else 2
+    cuts = S.partition_colors(colors, world)
+    assert cuts[0] == 0 and cuts[-1] == C and np.all(np.diff(cuts) >= 1)
+    acc = [torch.zeros_like(t) for t in full]
+    for r in range(world):
+        plan = fd.make_plan(J, sp, colors, fdtype, color_range=(cuts[r], cuts[r + 1]))
+        out = [_dev(np.zeros(plan.out_len(k))) for k in range(nouts)]
+        f = fd.BuiltinF(fam, *prm)
+        plan.jacobian(f, x, out)
+        owned = int(cuts[r + 1] - cuts[r])
+        assert f.fcalls == owned * (2 if fdtype == "central" else 1) + (1 if fdtype == "forward" else 0)
+        for a, o in zip(acc, out):
+            a += o
+    for a, w in zip(acc, full):
+        assert not torch.isnan(w).any()
+        assert torch.equal(a, w)
+
+
 def test_large_properties_headline_size():
     # BASELINE config 2/4 sizes: N = 10^6 (exact), property checks that do not need the oracle:
     # linear fixture => J is the constant stencil regardless of x; call count 1 + C; x untouched.

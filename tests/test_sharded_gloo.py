@@ -108,3 +108,57 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert res["n_gpus"] == 2 and res["config"]["gather_in_step"] is True
     assert res["result_check_max_dev"] is not None and res["result_check_max_dev"] < 1e-7
     assert res["ms_gather"] > 0 and res["value"] > 0
+
+
+def test_partition_colors():
+    for C, world in ((3, 1), (3, 2), (3, 3), (5, 2), (96, 8), (96, 5)):
+        colors = (np.arange(1000) % C) + 1
+        cuts = S.partition_colors(colors, world)
+        assert cuts[0] == 0 and cuts[-1] == C and np.all(np.diff(cuts) >= 0)
+        if C >= world:
+            assert np.all(np.diff(cuts) >= 1) and np.diff(cuts).max() - np.diff(cuts).min() <= 1
+    # more ranks than colours: the surplus ranks own nothing
+    cuts = S.partition_colors(np.array([1, 2, 3, 1, 2, 3]), 8)
+    assert cuts[0] == 0 and cuts[-1] == 3 and np.diff(cuts).sum() == 3
+    # weighted: a heavy first colour gets a rank of its own
+    assert S.partition_colors(np.array([1, 2, 3, 4]), 2, weights=[10, 1, 1, 1]).tolist() == [0, 1, 4]
+
+
+COLOR_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    import finitediff_jl_amd as fd
+    from finitediff_jl_amd import patterns as P, sharded as S
+    from oracle import oracle
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N = 600
+    x = np.random.default_rng(6).random(N)
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    cuts = S.partition_colors(colors, world)
+    full = oracle.jacobian("forward", oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON,
+                           colptr=colptr, rowval=rowval)["out"]
+    # this rank "computes" only the stored values of the columns whose colour it owns (oracle stand-in), rest zero
+    col_of = P.csc_cols(colptr) - 1
+    mine = (colors[col_of] - 1 >= cuts[rank]) & (colors[col_of] - 1 < cuts[rank + 1])
+    local = torch.from_numpy(np.where(mine, full, 0.0))
+    got = S.all_reduce_owned(local, dist).numpy()
+    assert np.array_equal(got, full), "rank %%d: assembled vector differs" %% rank
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_colour_ownership_gloo(tmp_path, oracle):
+    script = tmp_path / "cworker.py"
+    script.write_text(COLOR_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29521", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("ok") == 2
