@@ -571,9 +571,11 @@ class JVPCache:
         return self._plan[1]
 
 
-def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None, absstep=None, dir=True, ctx=None):
+def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None, absstep=None, dir=True, ctx=None,
+                            sync=True):
     """``FiniteDiff.finite_difference_jvp!(jvp, f, x, v, cache, f_in; relstep, absstep, dir)`` (src/jvp.jl:238-274);
-    cache may be a JVPCache or an fdtype name (cache-less form).  Fills jvp, returns None."""
+    cache may be a JVPCache or an fdtype name (cache-less form).  Fills jvp, returns None.
+    sync=False (device arrays only) only enqueues on the context's stream (fd_jvp_async)."""
     if not isinstance(cache, JVPCache):
         cache = JVPCache(x, "forward" if cache is None else cache)
     ctx = ctx or getattr(f, "ctx", None) or Context.default()
@@ -587,13 +589,21 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     fp, fk = None, _l.DEVICE
     if f_in is not None and cache.fdtype == "forward":
         fp, fk, _d = _ptr(f_in, "f_in")
-    rc = ctx.L.fd_jvp(h, f.fn, f.fctx, xp, vp_, xk, fp, fk, -1.0 if relstep is None else float(relstep),
-                      -1.0 if absstep is None else float(absstep), float(dir), op, ok)
+    if not sync:
+        if xk != _l.DEVICE or ok != _l.DEVICE or (fp is not None and fk != _l.DEVICE):
+            raise ValueError("the async path needs device arrays")
+        rc = ctx.L.fd_jvp_async(h, f.fn, f.fctx, xp, vp_, fp, -1.0 if relstep is None else float(relstep),
+                                -1.0 if absstep is None else float(absstep), float(dir), op)
+    else:
+        rc = ctx.L.fd_jvp(h, f.fn, f.fctx, xp, vp_, xk, fp, fk, -1.0 if relstep is None else float(relstep),
+                          -1.0 if absstep is None else float(absstep), float(dir), op, ok)
     err = getattr(f, "error", None)
     if err is not None:
         f.error = None
         raise err
     _l.check(rc)
+    if not sync:
+        return None
     e = C.c_double()
     _l.check(ctx.L.fd_jvp_get_epsilon(h, C.byref(e)))
     cache.last_epsilon = e.value

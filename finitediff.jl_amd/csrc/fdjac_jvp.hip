@@ -21,12 +21,27 @@ __device__ __forceinline__ double wave_sum_j(double v)
     return v;
 }
 
+typedef double d2j_t __attribute__((ext_vector_type(2)));
+
+// VEC: x and v are 16-B aligned -> one 16-B load per array per lane (2 elements); else scalar.  Each variant is
+// deterministic (fixed per-thread order, fixed shuffle tree, partials reduced in fixed order by k_jvp_eps).
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_dot_partial(const double *__restrict__ x, const double *__restrict__ v, int64_t n, double *__restrict__ partial)
 {
     double acc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += x[i] * v[i];
+    if (VEC) {
+        const int64_t n2 = n >> 1;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+            const d2j_t a = reinterpret_cast<const d2j_t *>(x)[i], b = reinterpret_cast<const d2j_t *>(v)[i];
+            acc += a.x * b.x;
+            acc += a.y * b.y;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * v[n - 1];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += x[i] * v[i];
+    }
     __shared__ double red[kBlock / 64];
     acc = wave_sum_j(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -60,11 +75,29 @@ k_jvp_eps(const double *__restrict__ partial, int nparts, double relstep, double
 }
 
 // forward: X[0] = x + eps v ; central: X[0] = x - eps v, X[1] = x + eps v   (src/jvp.jl:260,265,267)
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const double *__restrict__ eps, int central,
              int64_t n, double *__restrict__ X, int64_t ld)
 {
     const double e = eps[0];
+    if (VEC) {   // one pair of elements per thread (ld is a multiple of 32, X is hipMalloc'ed: 16-B aligned rows)
+        const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+        if (i + 1 < n) {
+            const d2j_t xi = *reinterpret_cast<const d2j_t *>(x + i), vi = *reinterpret_cast<const d2j_t *>(v + i);
+            const d2j_t ev = {e * vi.x, e * vi.y};
+            if (central) {
+                *reinterpret_cast<d2j_t *>(X + i) = d2j_t{xi.x - ev.x, xi.y - ev.y};
+                *reinterpret_cast<d2j_t *>(X + ld + i) = d2j_t{xi.x + ev.x, xi.y + ev.y};
+            } else {
+                *reinterpret_cast<d2j_t *>(X + i) = d2j_t{xi.x + ev.x, xi.y + ev.y};
+            }
+        } else if (i < n) {
+            const double xi = x[i], ev = e * v[i];
+            if (central) { X[i] = xi - ev; X[ld + i] = xi + ev; } else { X[i] = xi + ev; }
+        }
+        return;
+    }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const double xi = x[i], ev = e * v[i];
@@ -77,11 +110,22 @@ k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const d
     }
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_jvp_diff(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ eps, int central,
            int64_t m, double *__restrict__ out)
 {
     const double e = central ? 2 * eps[0] : eps[0];
+    if (VEC) {
+        const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+        if (i + 1 < m) {
+            const d2j_t av = *reinterpret_cast<const d2j_t *>(a + i), bv = *reinterpret_cast<const d2j_t *>(b + i);
+            *reinterpret_cast<d2j_t *>(out + i) = d2j_t{(av.x - bv.x) / e, (av.y - bv.y) / e};
+        } else if (i < m) {
+            out[i] = (a[i] - b[i]) / e;
+        }
+        return;
+    }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += stride) out[i] = (a[i] - b[i]) / e;
 }
@@ -142,32 +186,23 @@ int fd_jvp_plan_destroy(fd_jvp_plan *p)
     return FD_OK;
 }
 
-int fd_jvp(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind, const void *f_in,
-           int f_in_kind, double relstep, double absstep, double dir, void *jvp_out, int out_kind)
+static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const double *xd, const double *vd, const double *fin,
+                       double relstep, double absstep, double dir, double *out)
 {
-    FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
-    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
     const int central = p->fdtype == FD_CENTRAL;
     if (!(relstep > 0)) relstep = central ? std::cbrt(2.220446049250313e-16) : std::sqrt(2.220446049250313e-16);
     if (absstep < 0) absstep = relstep;
-    const double *xd = (const double *)x, *vd = (const double *)v, *fin = (const double *)f_in;
-    if (xv_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_xs, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_vs, v, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
-        xd = p->d_xs; vd = p->d_vs;
-    }
-    if (f_in && f_in_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_fin, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
-        fin = p->d_fin;
-    }
-    double *out = out_kind == FD_DEVICE ? (double *)jvp_out : p->d_out;
     const int g = balanced_grid((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
     const int gm = balanced_grid((p->M + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
-    hipLaunchKernelGGL(k_dot_partial, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+    const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & 15) == 0;
+    if (vx) hipLaunchKernelGGL(k_dot_partial<true>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+    else hipLaunchKernelGGL(k_dot_partial<false>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
     hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
                        central ? 0 : 1, p->d_eps);
-    hipLaunchKernelGGL(k_jvp_points, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    if (vx) hipLaunchKernelGGL(k_jvp_points<true>, dim3((unsigned)((p->N + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s,
+                               xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    else hipLaunchKernelGGL(k_jvp_points<false>, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
     FD_HIP_CHECK(hipGetLastError());
     const double *a, *b;
     int rc;
@@ -188,12 +223,49 @@ int fd_jvp(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void 
         FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
         a = p->d_FX;
     }
-    hipLaunchKernelGGL(k_jvp_diff, dim3(gm), dim3(kBlock), 0, s, a, b, p->d_eps, central, p->M, out);
+    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0)
+        hipLaunchKernelGGL(k_jvp_diff<true>, dim3((unsigned)((p->M + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s, a, b,
+                           p->d_eps, central, p->M, out);
+    else hipLaunchKernelGGL(k_jvp_diff<false>, dim3(gm), dim3(kBlock), 0, s, a, b, p->d_eps, central, p->M, out);
     FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int fd_jvp(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind, const void *f_in,
+           int f_in_kind, double relstep, double absstep, double dir, void *jvp_out, int out_kind)
+{
+    FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const double *xd = (const double *)x, *vd = (const double *)v, *fin = (const double *)f_in;
+    if (xv_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xs, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_vs, v, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        xd = p->d_xs; vd = p->d_vs;
+    }
+    if (f_in && f_in_kind == FD_HOST) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_fin, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
+        fin = p->d_fin;
+    }
+    double *out = out_kind == FD_DEVICE ? (double *)jvp_out : p->d_out;
+    const int rc = jvp_enqueue(p, f, fctx, xd, vd, p->fdtype == FD_FORWARD ? fin : nullptr, relstep, absstep, dir, out);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
     if (out_kind == FD_HOST)
         FD_HIP_CHECK(hipMemcpyAsync(jvp_out, out, sizeof(double) * (size_t)p->M, hipMemcpyDeviceToHost, s));
     FD_HIP_CHECK(hipStreamSynchronize(s));
     return FD_OK;
+}
+
+int fd_jvp_async(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void *v, const void *f_in,
+                 double relstep, double absstep, double dir, void *jvp_out)
+{
+    FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    return jvp_enqueue(p, f, fctx, (const double *)x, (const double *)v,
+                       p->fdtype == FD_FORWARD ? (const double *)f_in : nullptr, relstep, absstep, dir, (double *)jvp_out);
 }
 
 int fd_jvp_get_epsilon(fd_jvp_plan *p, double *eps_out)

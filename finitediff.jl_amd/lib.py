@@ -46,7 +46,7 @@ EXPORTS = (
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy",
-    "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_get_epsilon",
+    "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
     "fd_color_columns_greedy", "fd_color_banded",
 )
 
@@ -120,6 +120,7 @@ def load():
     L.fd_jvp_plan_create.argtypes = [vp, i64, i64, i32, pp]
     L.fd_jvp_plan_destroy.argtypes = [vp]
     L.fd_jvp.argtypes = [vp, F_LAUNCH, vp, vp, vp, i32, vp, i32, dbl, dbl, dbl, vp, i32]
+    L.fd_jvp_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, vp, dbl, dbl, dbl, vp]
     L.fd_jvp_get_epsilon.argtypes = [vp, C.POINTER(dbl)]
     L.fd_color_columns_greedy.argtypes = [i64, i64, vp, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.fd_color_banded.argtypes = [i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]

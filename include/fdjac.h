@@ -246,6 +246,9 @@ int fd_jvp_plan_destroy(fd_jvp_plan *plan);
 int fd_jvp(fd_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind,
            const void *f_in, int f_in_kind, double relstep, double absstep, double dir, void *jvp_out,
            int out_kind);
+/* Same, device pointers only, enqueues on the context's stream and returns (the inner loop of a Newton-Krylov solver). */
+int fd_jvp_async(fd_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, const void *f_in,
+                 double relstep, double absstep, double dir, void *jvp_out);
 int fd_jvp_get_epsilon(fd_jvp_plan *plan, double *eps_out);
 
 /* ---- plan-time colouring: the step BEFORE the path ------------------------- */

@@ -105,6 +105,26 @@ def main():
             run("BlockBanded %dx32x32 %s" % (nb, fdtype), plan, fd.BuiltinF("blockcoupled", nb, bs), xb, [out], alg, False)
             del plan, out
 
+    if on("jvp"):
+        import time
+        v = torch.as_tensor(np.random.default_rng(6).random(N) - 0.5, device=dev)
+        for fdtype in ("forward", "central"):
+            out = torch.empty(N, dtype=torch.float64, device=dev)
+            cache = fd.JVPCache(x, fdtype)
+            f = fd.BuiltinF("tridiag", N)
+            for _ in range(3):
+                fd.finite_difference_jvp_b(out, f, x, v, cache, sync=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.reps):
+                fd.finite_difference_jvp_b(out, f, x, v, cache, sync=False)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / a.reps * 1e6
+            # dot (x, v) 16 B + points (x, v -> X) 24/32 B + two f! evaluations 2 x 16 B + difference 24 B, per state
+            mb = (16 + (24 if fdtype == "forward" else 32) + 32 + 24) * N / 1e6
+            rows.append(("finite_difference_jvp! " + fdtype + " (whole call, wall)", "-", 0.0, 0.0, 0.0, 0.0, us, mb,
+                         mb / us * 1e3, 100 * (mb / us * 1e3) / 8000.0))
+
     print("| case | kernel variant | eps us | perturb us | f! us | diff+decompress us | whole call us | algorithmic MB | GB/s | % of 8 TB/s |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:

@@ -723,6 +723,14 @@ def test_jvp_parity(oracle, fdtype, N):
     ref = oracle.jvp(fdtype, oracle.Fixture("tridiag_nl", N), x, v)
     assert abs(cache.last_epsilon - ref["eps"]) <= 1e-12 * abs(ref["eps"])
     _tol_ok(out.cpu().numpy(), ref["jvp"], ref["eps"], 5.0, "jvp %s N=%d" % (fdtype, N))
+    # fd_jvp_async (enqueue only) gives the same bits; 8-B-aligned x / v take the scalar kernels
+    out2 = _dev(np.full(N, np.nan))
+    fd.finite_difference_jvp_b(out2, fd.BuiltinF("tridiag_nl", N), _dev(x), _dev(v), cache, sync=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    xo, vo, oo = _dev(np.concatenate([[0.0], x]))[1:], _dev(np.concatenate([[0.0], v]))[1:], _dev(np.full(N + 1, np.nan))[1:]
+    fd.finite_difference_jvp_b(oo, fd.BuiltinF("tridiag_nl", N), xo, vo, cache)
+    _tol_ok(oo.cpu().numpy(), ref["jvp"], ref["eps"], 5.0, "jvp unaligned %s N=%d" % (fdtype, N))
     # host arrays + f_in through the ABI's staging path
     if fdtype == "forward":
         xm, xp = np.concatenate([[0.0], x[:-1]]), np.concatenate([x[1:], [0.0]])
