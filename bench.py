@@ -180,6 +180,7 @@ def main():
         Jbb = fd.BlockBandedMatrix(None, lay)
         plan = fd.make_plan(Jbb, Jbb, colors, fdtype, ctx=ctx)
         f = fd.BuiltinF("blockcoupled", nb, bs, ctx=ctx)
+        lazy_ok = True
         bytes_ds = (C * N * 16 + nnz * 8) / N
         bytes_min = (nnz * 16 + nnz * 8 + N) / N                          # every stored value reads one complex f value
         bytes_call = bytes_ds + (C * N * 16 * 3 + 9 * N) / N

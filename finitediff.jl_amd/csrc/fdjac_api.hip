@@ -988,6 +988,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
         const int c_lo = (int)cl;
         const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
         const int B = c_hi - c_lo;
+        bool lazy_done = false;
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
             fd_lazy_points lp;
@@ -1002,10 +1003,21 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
             lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
             lp.reserved0 = 0;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
-            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);
-            p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
-            base_pending = false;
-        } else {
+            FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);
+            if (rc == 0) {
+                lazy_done = true;
+                p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
+                base_pending = false;
+            }
+        }
+        if (!lazy_done) {
+            if (base_pending) {   // the lazy launcher declined the batch that would have carried f(x)
+                Span sp(p, FD_STAGE_F);
+                const int rc = f(fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
+                FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+                p->fcalls_last += 1;
+                base_pending = false;
+            }
             {
                 Span sp(p, FD_STAGE_PERTURB);
                 int rc = launch_perturb(p, x_dev, c_lo, B);

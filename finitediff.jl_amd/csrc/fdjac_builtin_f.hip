@@ -522,9 +522,224 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
+// Lazy-point version of the block-coupled family.  One workgroup owns kBcG consecutive blocks: phase A forms
+// sig_b of those blocks and their two neighbours for EVERY point of the batch (x~ built in registers, the same
+// lane-order + shuffle-tree sum as k_f_block_sigma), phase B evaluates the rows.  x / colours are read once for all
+// points, sin(x) / cos(x) once per row (a point differs from the base in at most the row's own coordinate), and the
+// perturbed points are never written: the complex-step BlockBanded configuration drops from perturb 88 us + f! 596 us
+// to one ~memory-bound launch.  Bit-identical to perturb + k_f_block_sigma + k_f_block_apply.
+constexpr int kBcG = 6;
+template <typename T> __device__ __forceinline__ T tree_sum64(T acc)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        if constexpr (sizeof(T) == 8) {
+            double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+            acc = acc + *reinterpret_cast<T *>(&o);
+        } else {
+            cd *a = reinterpret_cast<cd *>(&acc);
+            cd o{__shfl_down(a->re, off, 64), __shfl_down(a->im, off, 64)};
+            acc = acc + *reinterpret_cast<T *>(&o);
+        }
+    }
+    return acc;
+}
+// lanes of ONE wave exchange data through LDS: LDS instructions of a wave execute in order, this keeps the compiler
+// from reordering them across the hand-over
+__device__ __forceinline__ void bc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int MODE> struct BcT { typedef double type; };
+template <> struct BcT<2> { typedef cd type; };
+__device__ __forceinline__ double bc_make(double x, double d, int sgn, double) { return sgn == 0 ? x + d : x - d; }
+__device__ __forceinline__ cd bc_make(double x, double d, int, cd) { return cd{x, d}; }
+
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
+                      const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nb, int bs,
+                      int64_t blk0, int64_t blk1, int64_t r0, int64_t r1)
+{
+    typedef typename BcT<MODE>::type T;
+    extern __shared__ double s_bc[];
+    constexpr int pts = MODE == 1 ? 2 : 1;
+    constexpr int NBLK = kBcG + 2;
+    const int PB = B * pts + 1;                      // last slot: the unperturbed point (base_out, forward only)
+    T *sig = reinterpret_cast<T *>(s_bc);            // [NBLK][PB]            sigma of every point
+    T *tree = sig + (size_t)NBLK * PB;               // [NBLK][128]           the batch-base summation tree (levels 0..5)
+    int *owner = reinterpret_cast<int *>(tree + (size_t)NBLK * 128);   // [waves][B]  duplicate-colour detection
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g0 = blk0 + (int64_t)blockIdx.x * kBcG;
+    const double w = (double)(lane + 1) / (double)bs;
+    const bool want_base = (MODE == 0) && (base_out != nullptr);
+    int *own = owner + wave * B;
+
+    // phase A: sig of blocks g0-1 .. g0+kBcG for every point.  A point differs from the batch's base values
+    // (x_j + 0.0) in the lanes whose colour it is -- normally ONE lane per block (the columns of a dense block all
+    // conflict), and then only the six partial sums on that leaf's path to the root of the fixed summation tree
+    // change: keep the tree of the base values in LDS and let the lane re-add along its path.  (Blocks with a repeated
+    // colour take the general path: one full tree per point.)  Same additions as k_f_block_sigma => same bits.
+    for (int lb = wave; lb < NBLK; lb += kBlock / 64) {
+        const int64_t bb = g0 - 1 + lb;
+        const bool inb = (bb >= 0) & (bb < nb);
+        const bool act = inb & (lane < bs);
+        double xj = 0.0;
+        int cj = -1;
+        if (act) {
+            xj = x[bb * bs + lane];
+            const int c = (int)color[bb * bs + lane];
+            cj = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+            if (cj >= B) cj = -1;
+        }
+        T *tr = tree + (size_t)lb * 128;
+        T *sg = sig + (size_t)lb * PB;
+        // base tree of the batch: leaves 0.0 + w*(x + 0.0) (what an unperturbed lane of any point contributes)
+        T acc = act ? zero_of<T>() + w * bc_make(xj, 0.0, 0, T{}) : zero_of<T>();
+        tr[lane] = acc;
+        int base_at = 64;
+        for (int off = 32; off > 0; off >>= 1) {
+            if constexpr (sizeof(T) == 8) {
+                double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+                acc = acc + *reinterpret_cast<T *>(&o);
+            } else {
+                cd *a = reinterpret_cast<cd *>(&acc);
+                cd o{__shfl_down(a->re, off, 64), __shfl_down(a->im, off, 64)};
+                acc = acc + *reinterpret_cast<T *>(&o);
+            }
+            if (lane < off && off > 1) tr[base_at + lane] = acc;   // level partials: 32 @64, 16 @96, 8 @112, 4 @120, 2 @124
+            base_at += off;
+        }
+        T root = acc;   // valid in lane 0
+        if constexpr (sizeof(T) == 8) {
+            double r = __shfl(*reinterpret_cast<double *>(&root), 0, 64);
+            root = *reinterpret_cast<T *>(&r);
+        } else {
+            cd *a = reinterpret_cast<cd *>(&root);
+            cd r{__shfl(a->re, 0, 64), __shfl(a->im, 0, 64)};
+            root = *reinterpret_cast<T *>(&r);
+        }
+        bc_wave_sync();   // the tree written by this wave's lanes is read by other lanes below
+        // duplicate colours inside the block?
+        for (int q = lane; q < B; q += 64) own[q] = -1;
+        bc_wave_sync();
+        if (cj >= 0) own[cj] = lane;
+        bc_wave_sync();
+        const bool dup = (cj >= 0) && (own[cj] != lane);
+        const bool any_dup = __builtin_amdgcn_ballot_w64(dup) != 0;
+        if (!any_dup) {
+            for (int q = lane; q < PB - 1; q += 64) sg[q] = inb ? root : zero_of<T>();
+            bc_wave_sync();
+            if (cj >= 0) {
+                const double e = eps[c_lo + cj];
+#pragma unroll
+                for (int sgn = 0; sgn < pts; ++sgn) {
+                    T n = zero_of<T>() + w * bc_make(xj, e, sgn, T{});
+                    int idx = lane;
+                    n = n + tr[idx ^ 32]; idx &= 31;
+                    n = n + tr[64 + (idx ^ 16)]; idx &= 15;
+                    n = n + tr[96 + (idx ^ 8)]; idx &= 7;
+                    n = n + tr[112 + (idx ^ 4)]; idx &= 3;
+                    n = n + tr[120 + (idx ^ 2)]; idx &= 1;
+                    n = n + tr[124 + (idx ^ 1)];
+                    sg[sgn * B + cj] = n;
+                }
+            }
+        } else {
+            for (int q = 0; q < PB - 1; ++q) {
+                T term = zero_of<T>();
+                if (act) {
+                    const int b = q < B ? q : q - B;
+                    const double d = (cj == b) ? eps[c_lo + b] : 0.0;
+                    term = zero_of<T>() + w * bc_make(xj, d, q < B ? 0 : 1, T{});
+                }
+                term = tree_sum64<T>(term);
+                if (lane == 0) sg[q] = inb ? term : zero_of<T>();
+            }
+        }
+        if (want_base) {   // the base evaluation f(x) uses x itself (not x + 0.0); MODE 0 only, T = double
+            double tb = act ? 0.0 + w * xj : 0.0;
+            tb = tree_sum64<double>(tb);
+            if (lane == 0) reinterpret_cast<double *>(sg)[PB - 1] = inb ? tb : 0.0;
+        }
+    }
+    __syncthreads();
+
+    for (int lb = 1 + wave; lb <= kBcG; lb += kBlock / 64) {
+        const int64_t bb = g0 - 1 + lb;
+        if (bb >= blk1 || bb >= nb) continue;
+        const int64_t k = bb * bs + lane;
+        if (!(lane < bs && k >= r0 && k < r1)) continue;
+        const double xk = x[k];
+        const int c = (int)color[k];
+        const int ck = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+        const bool mine = (ck >= 0) & (ck < B);
+        const double e = mine ? eps[c_lo + ck] : 0.0;
+        // values every point shares, and the ones of the row's own colour
+        const double x0 = xk + 0.0;                 // what an unperturbed point of the batch holds (x + 0.0)
+        double s0, sP = 0.0, sM = 0.0, c0 = 0.0, ch = 1.0, sh = 0.0;
+        const double ch0 = cosh(0.0 * xk), sh0 = sinh(0.0 * xk);   // cosh(0), sinh(0) through the same library calls
+        if (MODE == 2) {
+            s0 = sin(xk); c0 = cos(xk);
+            if (mine) { ch = cosh(e); sh = sinh(e); }
+        } else {
+            s0 = sin(x0);
+            if (mine) { sP = sin(xk + e); if (MODE == 1) sM = sin(xk - e); }
+        }
+        const T *sm = sig + (size_t)(lb - 1) * PB, *sc = sig + (size_t)lb * PB, *sp = sig + (size_t)(lb + 1) * PB;
+        for (int q = 0; q < PB - 1; ++q) {
+            const int b = q < B ? q : q - B;
+            const bool hit = mine & (ck == b);
+            const T S = (sm[q] + sc[q]) + sp[q];
+            if constexpr (MODE == 2) {
+                const cd xt{xk, hit ? e : 0.0};
+                const cd sn{s0 * (hit ? ch : ch0), c0 * (hit ? sh : sh0)};
+                const cd v = xt * S + sn;
+                *reinterpret_cast<double2 *>(fx + ((int64_t)q * fs + k) * 2) = make_double2(v.re, v.im);
+            } else {
+                const double d = hit ? e : 0.0;
+                const double xt = q < B ? xk + d : xk - d;
+                const double sn = hit ? (q < B ? sP : sM) : s0;
+                fx[(int64_t)q * fs + k] = xt * S + sn;
+            }
+        }
+        if (want_base) {
+            const double *sb = reinterpret_cast<const double *>(sig);
+            const double S = (sb[(size_t)(lb - 1) * PB + PB - 1] + sb[(size_t)lb * PB + PB - 1]) + sb[(size_t)(lb + 1) * PB + PB - 1];
+            base_out[k] = xk * S + sin(xk);
+        }
+    }
+}
+
+// LDS of k_f_blockcoupled_lazy: sigma of every point + the base summation tree, per block of the group, + owners
+static size_t bc_lds_bytes(int ncolors, int pts, bool cplx)
+{
+    const size_t el = cplx ? 16 : 8;
+    return (size_t)(kBcG + 2) * ((size_t)(ncolors * pts + 1) + 128) * el + (size_t)(kBlock / 64) * (size_t)ncolors * 4;
+}
+
+template <typename CT>
+static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, int64_t fs, int64_t r0, int64_t r1,
+                                    hipStream_t s)
+{
+    const int64_t nb = b->prm[0], bs = b->prm[1];
+    const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
+    const int64_t blk0 = r0 / bs, blk1 = (r1 - 1) / bs + 1;
+    const int64_t g = (blk1 - blk0 + kBcG - 1) / kBcG;
+    const size_t shm = bc_lds_bytes(lp->ncolors, lp->pts, mode == 2);
+#define FD_LAZY(MODE)                                                                                               \
+    hipLaunchKernelGGL((k_f_blockcoupled_lazy<CT, MODE>), dim3((unsigned)g), dim3(kBlock), shm, s, (double *)fx, fs, \
+                       (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,     \
+                       lp->ncolors, nb, (int)bs, blk0, blk1, r0, r1)
+    if (mode == 0) FD_LAZY(0); else if (mode == 1) FD_LAZY(1); else FD_LAZY(2);
+#undef FD_LAZY
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 static bool has_lazy(const BuiltinF *b)
 {
     if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
+    if (b->family == FD_F_BLOCKCOUPLED) return b->prm[1] <= 64;   // one wave per block
     return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
 }
 
@@ -537,11 +752,17 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & 15) != 0 || (fx_stride & 1)) return 7;
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + (lp->base_out ? 1 : 0);
+    // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
+    if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
+        return FD_LAZY_DECLINED;
     b->launches.fetch_add(1);
     b->points.fetch_add(npts);
     const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
     if (r1 <= r0 || lp->ncolors <= 0) return 0;
     const hipStream_t s = (hipStream_t)stream;
+    if (b->family == FD_F_BLOCKCOUPLED)
+        return lp->color_bytes == 1 ? lazy_blockcoupled_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                    : lazy_blockcoupled_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
     if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5)
         return lp->color_bytes == 1 ? lazy_stencil5_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
                                     : lazy_stencil5_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);

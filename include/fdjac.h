@@ -101,6 +101,9 @@ typedef struct fd_lazy_points {
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
+/* A lazy launcher may return FD_LAZY_DECLINED without having enqueued anything (e.g. a batch too large for its
+   on-chip staging); the library then materialises that batch's points and calls the plain fd_f_launch. */
+#define FD_LAZY_DECLINED 100
 
 typedef struct fd_plan_opts {
     int32_t fdtype;        /* enum fd_fdtype */

@@ -526,6 +526,42 @@ def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["c5_shape", "bs5_cyclic", "bs64", "bs1", "none", "chunked", "declined", "window"])
+def test_lazy_points_blockcoupled_bit_identical(fdtype, case):
+    # the block-coupled family's lazy launcher (sigma of every point formed on chip) vs perturb + sigma + apply kernels
+    nb, bs = {"c5_shape": (40, 32), "bs5_cyclic": (25, 5), "bs64": (9, 64), "bs1": (50, 1), "declined": (700, 1)}.get(case, (30, 8))
+    N = nb * bs
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    colors = lay.colors()
+    if case == "bs5_cyclic":
+        colors = P.cyclic_colors(N, 15)          # a colouring with a different structure (still valid: 3 blocks x 5)
+    if case == "declined":
+        colors = np.arange(1, N + 1)              # 700 colours: one batch does not fit the launcher's LDS -> it declines
+    if case == "none":
+        colors = colors.copy()
+        colors[[0, 9, N - 1]] = 0
+    cap = 40_000 if case == "chunked" else 0
+    win = (2 * bs + 0, N - bs) if case == "window" else None
+    x = _dev(np.random.default_rng(61).random(N) - 0.3)
+    Jb = fd.BlockBandedMatrix(None, lay)
+    outs, calls = [], []
+    for lazy in (False, True):
+        plan = fd.make_plan(Jb, Jb, colors, fdtype, scratch_bytes=cap, col_window=win)
+        f = fd.BuiltinF("blockcoupled", nb, bs)
+        if lazy:
+            plan.set_lazy(f)
+        if case == "chunked":
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out.cpu().numpy())
+        calls.append(f.fcalls)
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
+    assert calls[0] == calls[1]
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "lap5"])
 def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
     # the LDS-transposed (colour-sorted) decompression must equal the storage-order kernel bit for bit
