@@ -201,6 +201,13 @@ class BuiltinF:
         rc = self.ctx.L.fd_builtin_f_lazy(self.fctx, C.byref(fn))
         return fn if rc == 0 else None
 
+    @property
+    def lazy_caps(self):
+        """FD_LAZY_CAP_* bits of the lazy launcher (fd_builtin_f_lazy_caps)."""
+        caps = C.c_int32()
+        rc = self.ctx.L.fd_builtin_f_lazy_caps(self.fctx, C.byref(caps))
+        return caps.value if rc == 0 else 0
+
     def counts(self):
         a, b = C.c_int64(), C.c_int64()
         _l.check(self.ctx.L.fd_builtin_f_counts(self.fctx, C.byref(a), C.byref(b)))
@@ -309,13 +316,15 @@ class Plan:
         _l.check(self.ctx.L.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
-    def set_lazy(self, f):
+    def set_lazy(self, f, imag_only=True):
         """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it."""
         fn = getattr(f, "lazy_fn", None) if f is not None else None
         if f is not None and fn is None:
             raise ValueError("this f! has no lazy-point launcher")
         self._lazy_keep = fn
         _l.check(self.ctx.L.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
+        caps = int(getattr(f, "lazy_caps", 0)) if (f is not None and imag_only) else 0
+        _l.check(self.ctx.L.fd_plan_set_lazy_caps(self.handle, caps))
 
     def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
         """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""

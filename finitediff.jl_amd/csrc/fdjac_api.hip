@@ -23,7 +23,7 @@ void set_error(const char *fmt, ...)
 
 int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir);
 int launch_perturb(fd_plan *p, const double *x, int c_lo, int B);
-int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs);
+int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs, int mode);
 int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v);
 int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16);
 int balanced_grid(int64_t tiles, int64_t cap);
@@ -160,6 +160,8 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     if ((rc = dev_alloc(&p->d_finstage, p->ldf))) return rc;
 
     if (p->fdtype == FD_COMPLEX) {
+        // d_fx is not used by the complex step: keep it zero, it is the "fx" of the imag-only decompression
+        FD_HIP_CHECK(hipMemset(p->d_fx, 0, sizeof(double) * (size_t)p->ldf));
         // eps(Float64) for every colour (src/epsilons.jl:104-107, src/jacobians.jl:624)
         FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
         int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), 2.220446049250313e-16);
@@ -988,7 +990,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
         const int c_lo = (int)cl;
         const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
         const int B = c_hi - c_lo;
-        bool lazy_done = false;
+        bool lazy_done = false, imag_only = false;
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
             fd_lazy_points lp;
@@ -1001,7 +1003,9 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
             lp.ncolors = B;
             lp.pts = p->pts;
             lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
-            lp.reserved0 = 0;
+            // complex step: only imag(f) is ever used (src/jacobians.jl:635) -- a launcher that can, writes just that
+            lp.imag_only = (p->fdtype == FD_COMPLEX && (p->lazy_caps & FD_LAZY_CAP_IMAG_ONLY)) ? 1 : 0;
+            imag_only = lp.imag_only != 0;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);
             if (rc == 0) {
@@ -1031,7 +1035,9 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
         }
         {
             Span sp(p, FD_STAGE_DECOMPRESS);
-            int rc = launch_decompress(p, fx, c_lo, c_hi, outs);
+            // imaginary parts as a real array: the forward kernels with fx = 0 compute (a - 0.0)/eps == a/eps bit for bit
+            const bool io = lazy_done && imag_only;
+            int rc = launch_decompress(p, io ? p->d_fx : fx, c_lo, c_hi, outs, io ? (int)FD_FORWARD : p->fdtype);
             if (rc) return rc;
         }
     }
@@ -1095,6 +1101,14 @@ int fd_plan_set_lazy_f(fd_plan *p, fd_f_launch_lazy lazy)
 {
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     p->lazy_fn = lazy;
+    p->lazy_caps = 0;
+    return FD_OK;
+}
+
+int fd_plan_set_lazy_caps(fd_plan *p, int caps)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    p->lazy_caps = caps;
     return FD_OK;
 }
 

@@ -102,7 +102,7 @@ template <typename CT, int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
                  const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
-                 int64_t r1)
+                 int64_t r1, int imag_only)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
@@ -137,11 +137,21 @@ k_f_tridiag_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_
 #pragma unroll
                 for (int k = 0; k < 4; ++k) p[k] = cd{xv[k], d[k]};
                 const cd v0 = tridiag_row<cd, NL>(p[0], p[1], p[2]);
-                double *dst = fx + ((int64_t)b * fs + i) * 2;
-                *reinterpret_cast<double2 *>(dst) = make_double2(v0.re, v0.im);
-                if (two) {
-                    const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
-                    *reinterpret_cast<double2 *>(dst + 2) = make_double2(v1.re, v1.im);
+                if (imag_only) {   // imaginary parts as a real array (fd_lazy_points.imag_only)
+                    double *dst = fx + (int64_t)b * fs + i;
+                    if (two) {
+                        const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
+                        *reinterpret_cast<double2 *>(dst) = make_double2(v0.im, v1.im);
+                    } else {
+                        dst[0] = v0.im;
+                    }
+                } else {
+                    double *dst = fx + ((int64_t)b * fs + i) * 2;
+                    *reinterpret_cast<double2 *>(dst) = make_double2(v0.re, v0.im);
+                    if (two) {
+                        const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
+                        *reinterpret_cast<double2 *>(dst + 2) = make_double2(v1.re, v1.im);
+                    }
                 }
             } else {
 #pragma unroll
@@ -250,7 +260,7 @@ template <typename CT, int MODE, bool CLAMP>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
                   const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
-                  int64_t r0, int64_t r1)
+                  int64_t r0, int64_t r1, int imag_only)
 {
     const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
     const int64_t tile = xcd_tile(blockIdx.x, ntiles);
@@ -285,9 +295,13 @@ k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base
 #pragma unroll
             for (int m = 0; m < 8; ++m) p[m] = cd{xv[m], d[m]};
             stencil5_pair<cd, CLAMP>(p, hs, hn, hw, he, o0, o1);
-            double *dst = fx + ((int64_t)b * fs + k) * 2;
-            *reinterpret_cast<double2 *>(dst) = make_double2(o0.re, o0.im);
-            *reinterpret_cast<double2 *>(dst + 2) = make_double2(o1.re, o1.im);
+            if (imag_only) {
+                *reinterpret_cast<double2 *>(fx + (int64_t)b * fs + k) = make_double2(o0.im, o1.im);
+            } else {
+                double *dst = fx + ((int64_t)b * fs + k) * 2;
+                *reinterpret_cast<double2 *>(dst) = make_double2(o0.re, o0.im);
+                *reinterpret_cast<double2 *>(dst + 2) = make_double2(o1.re, o1.im);
+            }
         } else {
 #pragma unroll
             for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
@@ -494,7 +508,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
 #define FD_LAZY(MODE, NL)                                                                                           \
     hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (double *)fx, fs,    \
                        (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,     \
-                       lp->ncolors, b->prm[0], r0e, r1)
+                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only)
     if (mode == 0) { if (nl) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (nl) FD_LAZY(1, true); else FD_LAZY(1, false); }
     else { if (nl) FD_LAZY(2, true); else FD_LAZY(2, false); }
@@ -514,7 +528,7 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
 #define FD_LAZY(MODE, CL)                                                                                          \
     hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (double *)fx, fs,            \
                        (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,    \
-                       lp->ncolors, b->prm[0], b->prm[1], r0e, r1)
+                       lp->ncolors, b->prm[0], b->prm[1], r0e, r1, lp->imag_only)
     if (mode == 0) { if (clamp) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (clamp) FD_LAZY(1, true); else FD_LAZY(1, false); }
     else { if (clamp) FD_LAZY(2, true); else FD_LAZY(2, false); }
@@ -559,7 +573,7 @@ template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
                       const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nb, int bs,
-                      int64_t blk0, int64_t blk1, int64_t r0, int64_t r1)
+                      int64_t blk0, int64_t blk1, int64_t r0, int64_t r1, int imag_only)
 {
     typedef typename BcT<MODE>::type T;
     extern __shared__ double s_bc[];
@@ -695,7 +709,8 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
                 const cd xt{xk, hit ? e : 0.0};
                 const cd sn{s0 * (hit ? ch : ch0), c0 * (hit ? sh : sh0)};
                 const cd v = xt * S + sn;
-                *reinterpret_cast<double2 *>(fx + ((int64_t)q * fs + k) * 2) = make_double2(v.re, v.im);
+                if (imag_only) fx[(int64_t)q * fs + k] = v.im;
+                else *reinterpret_cast<double2 *>(fx + ((int64_t)q * fs + k) * 2) = make_double2(v.re, v.im);
             } else {
                 const double d = hit ? e : 0.0;
                 const double xt = q < B ? xk + d : xk - d;
@@ -730,7 +745,7 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
 #define FD_LAZY(MODE)                                                                                               \
     hipLaunchKernelGGL((k_f_blockcoupled_lazy<CT, MODE>), dim3((unsigned)g), dim3(kBlock), shm, s, (double *)fx, fs, \
                        (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,     \
-                       lp->ncolors, nb, (int)bs, blk0, blk1, r0, r1)
+                       lp->ncolors, nb, (int)bs, blk0, blk1, r0, r1, lp->imag_only)
     if (mode == 0) FD_LAZY(0); else if (mode == 1) FD_LAZY(1); else FD_LAZY(2);
 #undef FD_LAZY
     return hipGetLastError() == hipSuccess ? 0 : 4;
@@ -840,6 +855,14 @@ int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out)
         return FD_ERR_UNSUPPORTED;
     }
     *fn_out = builtin_launch_lazy;
+    return FD_OK;
+}
+
+int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
+    *caps_out = has_lazy(b) ? FD_LAZY_CAP_IMAG_ONLY : 0;
     return FD_OK;
 }
 

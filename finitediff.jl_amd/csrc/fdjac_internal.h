@@ -125,6 +125,7 @@ struct fd_plan {
     double *d_outstage[3] = {nullptr, nullptr, nullptr};
 
     fd_f_launch_lazy lazy_fn = nullptr;
+    int lazy_caps = 0;             // FD_LAZY_CAP_* of lazy_fn
     int64_t fcalls_last = 0;
     double relstep_last = 0, absstep_last = 0;
 

@@ -1027,10 +1027,10 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
     return FD_OK;
 }
 
-int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs)
+int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs, int mode)
 {
 #define FD_DISPATCH(CT)                                                                 \
-    switch (p->fdtype) {                                                                \
+    switch (mode) {                                                                \
     case FD_FORWARD: return launch_decompress_tm<CT, 0>(p, fx, c_lo, c_hi, outs);       \
     case FD_CENTRAL: return launch_decompress_tm<CT, 1>(p, fx, c_lo, c_hi, outs);       \
     default: return launch_decompress_tm<CT, 2>(p, fx, c_lo, c_hi, outs);               \

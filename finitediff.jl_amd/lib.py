@@ -32,7 +32,7 @@ F_LAUNCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C
 class LazyPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("color", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p),
                 ("color_bytes", C.c_int32), ("c_lo", C.c_int32), ("ncolors", C.c_int32), ("pts", C.c_int32),
-                ("is_complex", C.c_int32), ("reserved0", C.c_int32)]
+                ("is_complex", C.c_int32), ("imag_only", C.c_int32)]
 
 
 # int f(fctx, fx, const fd_lazy_points*, fx_stride, row_begin, row_end, stream)
@@ -45,7 +45,7 @@ EXPORTS = (
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
-    "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy",
+    "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
     "fd_color_columns_greedy", "fd_color_banded",
 )
@@ -126,6 +126,8 @@ def load():
     L.fd_color_banded.argtypes = [i64, i64, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fd_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY]
     L.fd_builtin_f_lazy.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY)]
+    L.fd_plan_set_lazy_caps.argtypes = [vp, i32]
+    L.fd_builtin_f_lazy_caps.argtypes = [vp, C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("fd_last_error", "fd_ctx_stream"):

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 101
+#define FDJAC_VERSION 102
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -97,7 +97,9 @@ typedef struct fd_lazy_points {
     int32_t ncolors;      /* colours in the batch                                             */
     int32_t pts;          /* 1 forward/complex, 2 central                                     */
     int32_t is_complex;
-    int32_t reserved0;
+    int32_t imag_only;    /* complex step only, set only for launchers registered with FD_LAZY_CAP_IMAG_ONLY: write  */
+                          /* fx[b*fx_stride + r] = imag(f(point b))[r] as a REAL array (fx_stride in doubles) -- the */
+                          /* real parts of a complex-step evaluation are never used (src/jacobians.jl:635)           */
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -210,6 +212,9 @@ int fd_jacobian_async(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, c
    plan; it shares the fctx passed to fd_jacobian.  The plain launcher is still required (it is
    used whenever the lazy one cannot be: f_in given to a central plan never happens; chunking is fine). */
 int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
+/* Optional capabilities of the installed lazy launcher (bit mask; cleared by fd_plan_set_lazy_f). */
+#define FD_LAZY_CAP_IMAG_ONLY 1   /* honours fd_lazy_points.imag_only: halves the f! output traffic of the complex step */
+int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
 int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
@@ -237,8 +242,9 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
 int fd_builtin_f_destroy(void *fctx);
 /* number of launcher invocations / points evaluated since creation (call-count parity tests) */
 int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
-/* The lazy-point launcher of a built-in family (FD_ERR_UNSUPPORTED if the family has none). */
+/* The lazy-point launcher of a built-in family (FD_ERR_UNSUPPORTED if the family has none) and its capabilities. */
 int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
+int fd_builtin_f_lazy_caps(void *fctx, int *caps_out);
 
 /* ---- Jacobian-vector products: finite_difference_jvp!, src/jvp.jl:238-274 ---- */
 typedef struct fd_jvp_plan fd_jvp_plan;

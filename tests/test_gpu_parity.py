@@ -487,17 +487,17 @@ def test_lazy_points_bit_identical(fdtype, N, C, cap):
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     outs = []
     calls = []
-    for lazy in (False, True):
+    for lazy in (False, True, "pairs"):   # materialised | lazy (complex step: imaginary parts only) | lazy (re,im) pairs
         plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
         f = fd.BuiltinF("tridiag_nl", N)
         if lazy:
-            plan.set_lazy(f)
+            plan.set_lazy(f, imag_only=(lazy is True))
         out = _dev(np.full(rowval.size, np.nan))
         plan.jacobian(f, x, [out])
         outs.append(out.cpu().numpy())
         calls.append((f.fcalls, plan.fcalls_last))
-    assert np.array_equal(outs[0], outs[1])
-    assert calls[0] == calls[1]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert calls[0] == calls[1] == calls[2]
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
@@ -511,15 +511,15 @@ def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
     colptr, rowval = P.lap5_csc(nx, ny)
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     outs = []
-    for lazy in (False, True):
+    for lazy in (False, True, "pairs"):   # materialised | lazy (complex step: imaginary parts only) | lazy (re,im) pairs
         plan = fd.make_plan(J, J, colors, fdtype)
         f = fd.BuiltinF(family, nx, ny)
         if lazy:
-            plan.set_lazy(f)
+            plan.set_lazy(f, imag_only=(lazy is True))
         out = _dev(np.full(rowval.size, np.nan))
         plan.jacobian(f, x, [out])
         outs.append(out.cpu().numpy())
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     ref = oracle.jacobian(fdtype, oracle.Fixture(family, nx, ny), xh, colors, kind=oracle.PAT_CSC_COMMON,
                           colptr=colptr, rowval=rowval)
     _tol_ok(outs[1], ref["out"], np.min(np.abs(_oracle_eps(xh, colors, fdtype))), 8.0, "lazy " + family)
@@ -545,11 +545,11 @@ def test_lazy_points_blockcoupled_bit_identical(fdtype, case):
     x = _dev(np.random.default_rng(61).random(N) - 0.3)
     Jb = fd.BlockBandedMatrix(None, lay)
     outs, calls = [], []
-    for lazy in (False, True):
+    for lazy in (False, True, "pairs"):   # materialised | lazy (complex step: imaginary parts only) | lazy (re,im) pairs
         plan = fd.make_plan(Jb, Jb, colors, fdtype, scratch_bytes=cap, col_window=win)
         f = fd.BuiltinF("blockcoupled", nb, bs)
         if lazy:
-            plan.set_lazy(f)
+            plan.set_lazy(f, imag_only=(lazy is True))
         if case == "chunked":
             assert plan.info(fd.lib.INFO_NCHUNKS) > 1
         out = _dev(np.full(plan.out_len(0), np.nan))
@@ -557,8 +557,8 @@ def test_lazy_points_blockcoupled_bit_identical(fdtype, case):
         outs.append(out.cpu().numpy())
         calls.append(f.fcalls)
     assert not np.isnan(outs[0]).any()
-    assert np.array_equal(outs[0], outs[1])
-    assert calls[0] == calls[1]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert calls[0] == calls[1] == calls[2]
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
