@@ -156,6 +156,17 @@ end
 #                            bandeddata(J.block_sizes.block_starts), J.block_sizes.block_strides, ...); outs = [J.data]
 #   BandedBlockBandedMatrix -> fd_plan_create_entries with (row, col, offset) enumerated once.
 
+# Built-in families come with a lazy-point launcher (f! perturbs while loading, fd_f_launch_lazy) that also writes only
+# imag(f) in the complex-step arm (FD_LAZY_CAP_IMAG_ONLY).  A user f! written against a lazy AbstractVector wrapper
+# registers its own launcher the same way.
+function install_lazy!(plan::Plan, f::DeviceF)
+    fn, caps = Ref{Ptr{Cvoid}}(C_NULL), Ref{Cint}(0)
+    ccall((:fd_builtin_f_lazy, libfdjac), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), f.fctx, fn) == 0 || return
+    check(ccall((:fd_plan_set_lazy_f, libfdjac), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), plan.h, fn[]))
+    ccall((:fd_builtin_f_lazy_caps, libfdjac), Cint, (Ptr{Cvoid}, Ptr{Cint}), f.fctx, caps)
+    check(ccall((:fd_plan_set_lazy_caps, libfdjac), Cint, (Ptr{Cvoid}, Cint), plan.h, caps[]))
+end
+
 outs(J::SparseMatrixCSC) = (pointer(J.nzval), C_NULL, C_NULL)
 outs(J::Matrix) = (pointer(J), C_NULL, C_NULL)
 outs(J::Tridiagonal) = (pointer(J.dl), pointer(J.d), pointer(J.du))
@@ -179,6 +190,7 @@ function FiniteDiff.finite_difference_jacobian!(
         plan = make_plan(ctx, J, sparsity, colorvec, fdtype)
         PLANS[cache] = plan
     end
+    f.builtin && install_lazy!(plan, f)
     o = outs(J)
     optr = Ptr{Cvoid}[o...]
     fin = (f_in === nothing || fdtype != Val(:forward)) ? C_NULL : pointer(f_in)
@@ -193,5 +205,36 @@ function FiniteDiff.finite_difference_jacobian!(
 end
 # With AMDGPU.jl, a method for `x::ROCVector{Float64}` / `J.nzval::ROCVector` passes device pointers
 # with FD_DEVICE (zero-copy) -- identical call, `pointer(x)` and kind flags change.
+
+# ---- finite_difference_jvp! (src/jvp.jl:238-274) ------------------------------------------------
+const JVP_PLANS = WeakKeyDict{Any,Ptr{Cvoid}}()
+function FiniteDiff.finite_difference_jvp!(
+        jvp::Vector{Float64}, f::DeviceF, x::Vector{Float64}, v::Vector{Float64},
+        cache::FiniteDiff.JVPCache{X1, FX1, fdtype}, f_in = nothing;
+        relstep = FiniteDiff.default_relstep(fdtype, eltype(x)), absstep = relstep, dir = true) where {X1, FX1, fdtype}
+    fdtype == Val(:complex) && error("finite_difference_jvp doesn't support :complex-mode finite diff")   # src/jvp.jl:248-250
+    ctx = default_ctx()
+    h = get!(JVP_PLANS, cache) do
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:fd_jvp_plan_create, libfdjac), Cint, (Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Ptr{Cvoid}}),
+                    ctx.h, length(jvp), length(x), fdtype_code(fdtype), r))
+        r[]
+    end
+    fin = (f_in === nothing || fdtype != Val(:forward)) ? C_NULL : pointer(f_in)
+    GC.@preserve jvp x v f_in begin
+        check(ccall((:fd_jvp, libfdjac), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint,
+                     Float64, Float64, Float64, Ptr{Float64}, Cint),
+                    h, f.fn, f.fctx, x, v, FD_HOST, fin, FD_HOST, Float64(relstep), Float64(absstep), Float64(dir),
+                    jvp, FD_HOST))
+    end
+    nothing
+end
+
+# ---- multi-GPU (one Julia process per GPU, MPI.jl / RCCL for the exchange) ------------------------
+# column ranges : PlanOpts(col_begin, col_end, x_begin, x_end) -> each rank fills a contiguous slice of nzval; one
+#                 all-gather assembles it (needs an f! that honours the row window it is handed).
+# colour ranges : PlanOpts(color_begin, color_end) -> each rank perturbs / evaluates only its colours with ANY f!;
+#                 outputs start from zero and one all-reduce(SUM) assembles them (the north-star's colour sharding).
 
 end # module
