@@ -102,7 +102,7 @@ def main():
             out = torch.empty(lay.data_len, dtype=torch.float64, device=dev)
             C = 96
             alg = (2 * C * nb * bs * 8 if fdtype == "forward" else C * nb * bs * 16) + lay.data_len * 8
-            run("BlockBanded %dx32x32 %s" % (nb, fdtype), plan, fd.BuiltinF("blockcoupled", nb, bs), xb, [out], alg, False)
+            run("BlockBanded %dx32x32 %s" % (nb, fdtype), plan, fd.BuiltinF("blockcoupled", nb, bs), xb, [out], alg, True)
             del plan, out
 
     if on("jvp"):
