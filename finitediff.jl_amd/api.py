@@ -127,6 +127,18 @@ class BlockBandedMatrix:
         return self.layout.N, self.layout.N
 
 
+class BandedBlockBandedMatrix:
+    """BlockBandedMatrices.BandedBlockBandedMatrix: flat data + a ``patterns.BandedBlockBandedLayout``.  The reference
+    stores through raw offsets into each block's banded data (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42); here the
+    (row, column, offset) triples are enumerated once and compiled with fd_plan_create_entries."""
+
+    def __init__(self, data, layout):
+        self.data, self.layout = data, layout
+
+    def size(self):
+        return self.layout.N, self.layout.N
+
+
 def _similar(a, n):
     if _is_torch(a):
         import torch
@@ -408,6 +420,14 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
     elif isinstance(J, BandedMatrix):
         n = cv.size
         _l.check(L.fd_plan_create_banded(ctx.handle, J.m, n, J.l, J.u, _vp(cv), 8, C.byref(o), C.byref(h)))
+    elif isinstance(J, BandedBlockBandedMatrix):
+        lay = J.layout
+        if cv.size != lay.N:
+            raise ValueError("DimensionMismatch: length(colorvec) != length(x)")
+        rows, cols, dest = lay.entries()
+        rows, cols, dest = _i64(rows), _i64(cols), _i64(dest)
+        _l.check(L.fd_plan_create_entries(ctx.handle, lay.N, lay.N, _vp(rows), _vp(cols), _vp(dest), dest.size,
+                                          lay.data_len, 8, 1, _vp(cv), 8, C.byref(o), C.byref(h)))
     elif isinstance(J, BlockBandedMatrix):
         lay = J.layout
         bs, st, sr = _i64(lay.blk_sizes), _i64(lay.block_starts), _i64(lay.block_strides)
@@ -455,7 +475,7 @@ def _outs_of(J):
         return [J.nzval]
     if isinstance(J, Tridiagonal):
         return [J.dl, J.d, J.du]
-    if isinstance(J, (BandedMatrix, BlockBandedMatrix)):
+    if isinstance(J, (BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
         return [J.data]
     return [J]
 
@@ -506,7 +526,7 @@ class JacobianCache:
 
 def _has_sparsestruct(J):
     """ArrayInterface.has_sparsestruct for the holders above."""
-    return isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix))
+    return isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix))
 
 
 def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=np.float64, f_in=None, *,
@@ -545,7 +565,7 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
     plan = cache._plan_for(J, sparsity, colorvec, ctx or getattr(f, "ctx", None))
     outs = _outs_of(J)
     staged = None
-    if not isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix)):
+    if not isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
         # dense J must be column-major for the library; stage a C-order numpy array
         if isinstance(J, np.ndarray) and not J.flags.f_contiguous:
             staged = np.zeros(J.shape, order="F")

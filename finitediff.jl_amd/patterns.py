@@ -164,6 +164,65 @@ class BlockBandedLayout:
         return np.concatenate(out).astype(np.int64)
 
 
+class BandedBlockBandedLayout:
+    """Storage of a BandedBlockBandedMatrix as the reference's extension addresses it
+    (ext/FiniteDiffBlockBandedMatricesExt.jl:29-36): every in-band block (K,J) owns a banded-data slab
+    of (lam+mu+1) x n_J values with column stride ``st``; entry (k,j) of the block (1-based) lives at
+    ``start(K,J) + (j-1)*st + mu + k - j`` (0-based offset from a 1-based start).  The slabs are laid out as
+    BlockBandedMatrices.jl does [third-party layout, taken from its documentation, not verifiable here -- the C ABI
+    receives the starts / strides explicitly, so a different layout only changes these arrays]: one
+    ((bl+bu+1)*(lam+mu+1)) x N column-major matrix, block-band d = K-J+bu occupying rows d*(lam+mu+1) ...
+    """
+
+    def __init__(self, blk_sizes, bl, bu, lam, mu):
+        bs = np.asarray(blk_sizes, np.int64)
+        nb = bs.size
+        self.blk_sizes, self.bl, self.bu, self.lam, self.mu, self.nblk = bs, int(bl), int(bu), int(lam), int(mu), nb
+        w, sw = self.bl + self.bu + 1, self.lam + self.mu + 1
+        self.N = int(bs.sum())
+        R = w * sw
+        off = np.concatenate([[0], np.cumsum(bs)])
+        starts = np.zeros((w, nb), np.int64, order="F")
+        for J in range(nb):
+            for K in range(max(0, J - bu), min(nb - 1, J + bl) + 1):
+                starts[bu + K - J, J] = 1 + off[J] * R + (bu + K - J) * sw
+        self.block_starts = starts.reshape(-1, order="F").copy()
+        self.block_strides = np.full(nb, R, np.int64)
+        self.data_len = int(R * self.N)
+        self._off = off
+
+    def entries(self):
+        """(rows, cols, dest): 1-based row / column and 0-based offset into data of every in-band entry,
+        in column order -- what the shim enumerates once for fd_plan_create_entries."""
+        bs, nb, off = self.blk_sizes, self.nblk, self._off
+        w = self.bl + self.bu + 1
+        rows, cols, dest = [], [], []
+        for J in range(nb):
+            n = int(bs[J])
+            j = np.arange(n, dtype=np.int64)
+            for K in range(max(0, J - self.bu), min(nb - 1, J + self.bl) + 1):
+                m = int(bs[K])
+                start = self.block_starts[(self.bu + K - J) + w * J] - 1
+                st = self.block_strides[J]
+                for t in range(-self.mu, self.lam + 1):        # k = j + t
+                    k = j + t
+                    ok = (k >= 0) & (k < m)
+                    rows.append(off[K] + k[ok] + 1)
+                    cols.append(off[J] + j[ok] + 1)
+                    dest.append(start + j[ok] * st + self.mu + t)
+        rows, cols, dest = np.concatenate(rows), np.concatenate(cols), np.concatenate(dest)
+        order = np.lexsort((rows, cols))
+        return rows[order], cols[order], dest[order]
+
+    def colors(self):
+        """(J mod (bl+bu+1))*(lam+mu+1) + (j mod (lam+mu+1)) + 1: a valid colouring of the pattern."""
+        w, sw = self.bl + self.bu + 1, self.lam + self.mu + 1
+        out = []
+        for J, b in enumerate(self.blk_sizes):
+            out.append(sw * (J % w) + (np.arange(b) % sw) + 1)
+        return np.concatenate(out).astype(np.int64)
+
+
 def banded_to_dense(data, M, N, l, u):
     """BandedMatrix data[(u + i - j), j] (0-based) -> dense."""
     A = np.zeros((M, N), dtype=np.asarray(data).dtype)

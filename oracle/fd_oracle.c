@@ -51,7 +51,8 @@ enum {
     FDO_PAT_COO_DENSEJ = 3,  /* rows_index/cols_index, dense J (iteration_utils.jl:25-32) */
     FDO_PAT_COO_TRIDIAG = 4, /* rows_index/cols_index, Tridiagonal J (dl,d,du) via setindex! */
     FDO_PAT_BANDED = 5,      /* BandedMatrix data (l+u+1) x N (ext/Banded:13-27) */
-    FDO_PAT_BLOCKBANDED = 6  /* BlockBandedMatrix flat data + block_starts/strides (ext/BlockBanded:44-68) */
+    FDO_PAT_BLOCKBANDED = 6, /* BlockBandedMatrix flat data + block_starts/strides (ext/BlockBanded:44-68) */
+    FDO_PAT_BANDEDBLOCKBANDED = 7 /* BandedBlockBandedMatrix: per-block banded data (ext/BlockBanded:16-42) */
 };
 
 typedef struct {
@@ -80,6 +81,10 @@ typedef struct {
     double *out1; /* dl (tridiag) */
     double *out2; /* du (tridiag) */
     int64_t out_len; /* number of stored values in out0 for fill_matrix! */
+    /* banded-block-banded: sub-block bandwidths (lambda, mu); block_starts then holds the 1-based start of the
+       BANDED data of block (K,J) (the `pointer(bandeddata(view(Jac,K,J)))` of ext/BlockBanded:29-31) and
+       block_strides[J-1] its column stride `stride(data,2)` (:32) */
+    int64_t lam, mu;
 } fdo_pattern;
 
 /* ---- src/epsilons.jl:26-29, 50-53 ---- */
@@ -209,6 +214,31 @@ static void colored_iteration(const fdo_pattern *p, const double *vfx, const int
                 }
             }
             colbase += ncolsJ;
+        }
+        break;
+    }
+    case FDO_PAT_BANDEDBLOCKBANDED: { /* ext/FiniteDiffBlockBandedMatricesExt.jl:16-42 */
+        const int64_t nb = p->nblk, lam = p->lam, mu = p->mu;
+        int64_t colbase = 0;
+        for (int64_t J = 1; J <= nb; ++J) {
+            int64_t n = p->blk_sizes[J - 1];
+            int64_t K0 = (J - p->bu > 1) ? J - p->bu : 1;   /* blockcolrange */
+            int64_t K1 = (J + p->bl < nb) ? J + p->bl : nb;
+            int64_t rowbase = 0;
+            for (int64_t K = 1; K < K0; ++K) rowbase += p->blk_sizes[K - 1];
+            for (int64_t K = K0; K <= K1; ++K) {
+                int64_t m = p->blk_sizes[K - 1];
+                int64_t start = p->block_starts[(p->bu + K - J) + (p->bl + p->bu + 1) * (J - 1)];
+                int64_t st = p->block_strides[J - 1];
+                for (int64_t j = 1; j <= n; ++j)
+                    if (colorvec[colbase + j - 1] == color_i) {
+                        int64_t k0 = (j - mu > 1) ? j - mu : 1, k1 = (j + lam < m) ? j + lam : m;
+                        for (int64_t k = k0; k <= k1; ++k)   /* unsafe_store!(p, b_v[k], (j-1)*st + mu + k - j + 1) */
+                            p->out0[(start - 1) + (j - 1) * st + mu + k - j] = vfx[rowbase + k - 1];
+                    }
+                rowbase += m;
+            }
+            colbase += n;
         }
         break;
     }

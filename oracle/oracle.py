@@ -20,7 +20,7 @@ FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
 
 (PAT_NONE, PAT_CSC_COMMON, PAT_CSC_DENSEJ, PAT_COO_DENSEJ, PAT_COO_TRIDIAG, PAT_BANDED,
- PAT_BLOCKBANDED) = range(7)
+ PAT_BLOCKBANDED, PAT_BANDEDBLOCKBANDED) = range(8)
 
 F_REAL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 F_CPLX = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
@@ -38,6 +38,7 @@ class Pattern(C.Structure):
         ("nblk", C.c_int64), ("blk_sizes", _i64p), ("bl", C.c_int64), ("bu", C.c_int64),
         ("block_starts", _i64p), ("block_strides", _i64p),
         ("out0", _f64p), ("out1", _f64p), ("out2", _f64p), ("out_len", C.c_int64),
+        ("lam", C.c_int64), ("mu", C.c_int64),
     ]
 
 
@@ -153,7 +154,7 @@ def tridiag_csc(n):
 
 def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowval=None,
              rows_index=None, cols_index=None, l=0, u=0, blk_sizes=None, bl=0, bu=0,
-             block_starts=None, block_strides=None, out_len=None, f_in=None, relstep=None,
+             block_starts=None, block_strides=None, out_len=None, lam=0, mu=0, f_in=None, relstep=None,
              absstep=None, dir=1.0, cache=None, mutate_x=False):
     """Run the cached in-place path.  Returns dict(out=..., fcalls=..., x_after=...).
 
@@ -198,7 +199,8 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
     elif kind == PAT_BANDED:
         pat.l, pat.u = l, u
         out0 = np.full((l + u + 1) * N, np.nan)
-    elif kind == PAT_BLOCKBANDED:
+    elif kind in (PAT_BLOCKBANDED, PAT_BANDEDBLOCKBANDED):
+        pat.lam, pat.mu = lam, mu
         blk_sizes, block_starts, block_strides = i64(blk_sizes), i64(block_starts), i64(block_strides)
         pat.nblk, pat.blk_sizes, pat.bl, pat.bu = blk_sizes.size, _p64(blk_sizes), bl, bu
         pat.block_starts, pat.block_strides = _p64(block_starts), _p64(block_strides)

@@ -202,6 +202,34 @@ def test_stencil_blockbanded_and_sparse(oracle, fdtype):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
+def test_stencil_bandedblockbanded(oracle, fdtype):
+    # test/coloring_tests.jl:109-115 : BandedBlockBandedMatrix J (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42) on the
+    # device through the enumerated-entries plan, vs the oracle's restatement of the same store loop
+    nx, ny = 40, 30
+    N = nx * ny
+    x = np.random.default_rng(16).random(N)
+    lay = P.BandedBlockBandedLayout(np.full(ny, nx), 1, 1, 1, 1)
+    colors = lay.colors()
+    J = fd.BandedBlockBandedMatrix(_dev(np.full(lay.data_len, np.nan)), lay)
+    f = fd.BuiltinF("clamp5", nx, ny)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors)
+    assert f.fcalls == {"forward": 10, "central": 18, "complex": 9}[fdtype]
+    ref = oracle.jacobian(fdtype, oracle.Fixture("clamp5", nx, ny), x, colors, kind=oracle.PAT_BANDEDBLOCKBANDED,
+                          blk_sizes=lay.blk_sizes, bl=1, bu=1, lam=1, mu=1, block_starts=lay.block_starts,
+                          block_strides=lay.block_strides, out_len=lay.data_len)
+    got = J.data.cpu().numpy()
+    _tol_ok(got, ref["out"], np.min(np.abs(_oracle_eps(x, colors, fdtype))), 5.0, "banded-block-banded " + fdtype)
+    # and it agrees with the sparse J of the same problem (the reference's own assertion)
+    colptr, rowval = P.lap5_csc(nx, ny)
+    Js = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(rowval.size)))
+    fd.finite_difference_jacobian_b(Js, fd.BuiltinF("clamp5", nx, ny), _dev(x), fdtype, colorvec=colors)
+    rows, cols, dest = lay.entries()
+    pos = dict(zip(zip(rows.tolist(), cols.tolist()), dest.tolist()))
+    at = np.array([pos[(int(r), int(c))] for r, c in zip(rowval, P.csc_cols(colptr))])
+    assert np.linalg.norm(got[at] - Js.nzval.cpu().numpy()) <= 1.5e-8 * np.linalg.norm(got[at]) * 10
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
 def test_nonsquare_with_cache(oracle, fdtype):
     # test/coloring_tests.jl:124-159
     n = 4

@@ -106,6 +106,34 @@ def test_stencil_blockbanded_vs_sparse(oracle):
     assert np.allclose(rs["out"][~isdiag], 1.0, rtol=0, atol=5e-7)
 
 
+def test_stencil_bandedblockbanded_vs_sparse(oracle):
+    # test/coloring_tests.jl:109-115 : Jbbb ~ Jsparse with the BandedBlockBandedMatrix store path
+    # (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42), (1,1) block bandwidths, (1,1) sub-block bandwidths, 9 colours
+    nx = ny = 100
+    N = nx * ny
+    x = RNG.random(N)
+    f = oracle.Fixture("clamp5", nx, ny)
+    colptr, rowval = P.lap5_csc(nx, ny)
+    lay = P.BandedBlockBandedLayout(np.full(ny, nx), 1, 1, 1, 1)
+    colors9 = lay.colors()
+    assert colors9.max() == 9
+    rs = oracle.jacobian("forward", f, x, colors9, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    rb = oracle.jacobian("forward", f, x, colors9, kind=oracle.PAT_BANDEDBLOCKBANDED, blk_sizes=lay.blk_sizes, bl=1, bu=1,
+                         lam=1, mu=1, block_starts=lay.block_starts, block_strides=lay.block_strides,
+                         out_len=lay.data_len)
+    assert rb["fcalls"] == 10
+    rows, cols, dest = lay.entries()
+    # the banded-block-banded pattern contains the 5-point stencil (plus the 4 diagonal neighbours, which are 0)
+    dense_at = {}
+    pos = dict(zip(zip(rows.tolist(), cols.tolist()), dest.tolist()))
+    ccols = P.csc_cols(colptr)
+    at = np.array([pos[(int(r), int(c))] for r, c in zip(rowval, ccols)])
+    assert isapprox(rb["out"][at], rs["out"])
+    rest = rb["out"].copy()
+    rest[at] = 0
+    assert np.max(np.abs(rest)) < 1e-6
+
+
 @pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
 def test_nonsquare(oracle, fdtype):
     # test/coloring_tests.jl:124-159
