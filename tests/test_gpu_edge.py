@@ -1,0 +1,196 @@
+"""Edge cases of the device path (through the C ABI): empty / ragged patterns, degenerate colourings, invalid
+inputs and their status codes, failing f! launchers, repeated and concurrent use of plans."""
+import threading
+
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+FDTYPES = ["forward", "central", "complex"]
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def _ragged_pattern(M, N, seed):
+    """Random pattern with empty columns, empty rows, a full column and single-entry columns."""
+    rng = np.random.default_rng(seed)
+    A = (rng.random((M, N)) < 0.08).astype(float)
+    A[:, [1, N // 2]] = 0          # empty columns
+    A[[0, M - 1], :] = 0           # empty rows
+    A[1:M - 1, 3] = 1              # a dense column
+    A[2, N - 1] = 1
+    return A
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("shape", [(57, 41), (41, 57), (300, 300)])
+def test_ragged_random_pattern_matches_oracle(oracle, fdtype, shape):
+    # a general sparse pattern (no band structure: the gather kernels), greedy colouring, f = A .* sin-ish coupling
+    M, N = shape
+    A = _ragged_pattern(M, N, 7 + M)
+    colptr, rowval = P.csc_from_dense(A)
+    J = fd.SparseMatrixCSC(M, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+    colors = fd.matrix_colors(J)
+    W = np.random.default_rng(3).random((M, N)) * A
+    Wt = _dev(W)
+    x = np.random.default_rng(4).random(N) + 0.2
+
+    def fn(fx, xx):      # f_i = sum_j W_ij * x_j^2   (complex-analytic)
+        fx.copy_(Wt.to(xx.dtype) @ (xx * xx))
+
+    f = fd.TorchF(fn, M, N)
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors)
+    C = int(colors.max())
+    assert f.fcalls == {"forward": C + 1, "central": 2 * C, "complex": C}[fdtype]
+    of = oracle.PyF(lambda fx, xx: fx.__setitem__(slice(None), W @ (xx * xx)), M, N)
+    ref = oracle.jacobian(fdtype, of, x, colors, M=M, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    got = J.nzval.cpu().numpy()
+    eps = 2.2e-16 if fdtype == "complex" else fd.default_relstep(fdtype)
+    atol = 16 * 2.2e-16 * float(np.abs(W @ (x * x)).max() + 1) / eps
+    assert np.all(np.abs(got - ref["out"]) <= 1e-6 * np.abs(ref["out"]) + atol)
+    exact = (2 * W * x[None, :])[A != 0]      # column-major order of the stored entries
+    assert np.allclose(P.csc_to_dense(M, N, colptr, rowval, got)[A != 0], exact, rtol=2e-5 if fdtype == "forward" else 1e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_empty_pattern_and_empty_window(fdtype):
+    # nnz = 0: nothing to write, no f! evaluation beyond what the reference does (it still loops over the colours)
+    N = 50
+    colptr = np.ones(N + 1, np.int64)
+    rowval = np.zeros(0, np.int64)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.zeros(0)))
+    f = fd.BuiltinF("tridiag", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(np.ones(N)), fdtype, colorvec=P.cyclic_colors(N, 3))
+    # an empty column window of a non-empty pattern
+    cp, rv = P.tridiag_csc(N)
+    Jf = fd.SparseMatrixCSC(N, N, cp, rv)
+    plan = fd.make_plan(Jf, Jf, P.cyclic_colors(N, 3), fdtype, col_window=(20, 20))
+    assert plan.out_len(0) == 0
+    plan.jacobian(fd.BuiltinF("tridiag", N), _dev(np.ones(N)), [_dev(np.zeros(1))[:0]])
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_all_columns_uncoloured(fdtype):
+    # maximum(colorvec) < 1: no colour loop at all; fill_matrix! leaves every stored value at zero
+    N = 40
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, _dev(np.full(rv.size, np.nan)))
+    f = fd.BuiltinF("tridiag", N)
+    fd.finite_difference_jacobian_b(J, f, _dev(np.ones(N)), fdtype, colorvec=np.zeros(N, np.int64))
+    assert torch.all(J.nzval == 0)
+    assert f.fcalls == (1 if fdtype == "forward" else 0)
+
+
+def test_single_colour_and_invalid_colouring_semantics(oracle):
+    # one colour for every column of a tridiagonal pattern is NOT a valid colouring: the reference then stores, in
+    # every entry of row r, the derivative along the all-ones direction -- assignment, not accumulation
+    # (ext/FiniteDiffSparseArraysExt.jl:38-47).  The device must reproduce exactly that.
+    N = 64
+    cp, rv = P.tridiag_csc(N)
+    x = np.random.default_rng(8).random(N)
+    colors = np.ones(N, np.int64)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, _dev(np.zeros(rv.size)))
+    fd.finite_difference_jacobian_b(J, fd.BuiltinF("tridiag_nl", N), _dev(x), "forward", colorvec=colors)
+    ref = oracle.jacobian("forward", oracle.Fixture("tridiag_nl", N), x, colors, kind=oracle.PAT_CSC_COMMON, colptr=cp, rowval=rv)
+    eps = fd.default_relstep("forward") * np.sqrt(np.linalg.norm(x))
+    assert np.all(np.abs(J.nzval.cpu().numpy() - ref["out"]) <= 1e-6 * np.abs(ref["out"]) + 16 * 2.2e-16 * 5 / eps)
+
+
+def test_status_codes_and_messages():
+    L = fd.lib.load()
+    N = 10
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv)
+    colors = P.cyclic_colors(N, 3)
+    with pytest.raises(ValueError, match="DimensionMismatch"):            # src/jacobians.jl:516
+        fd.make_plan(J, J, colors[:-1], "forward")
+    bad = rv.copy()
+    bad[4] = N + 5
+    with pytest.raises(fd.lib.FdError, match="rowval"):                   # FD_ERR_SHAPE
+        fd.make_plan(fd.SparseMatrixCSC(N, N, cp, bad), fd.SparseMatrixCSC(N, N, cp, bad), colors, "forward")
+    badp = cp.copy()
+    badp[3] = badp[4] + 1
+    with pytest.raises(fd.lib.FdError, match="monotone"):
+        fd.make_plan(fd.SparseMatrixCSC(N, N, badp, rv), fd.SparseMatrixCSC(N, N, badp, rv), colors, "forward")
+    with pytest.raises((KeyError, ValueError)):                             # fdtype_error (src/epsilons.jl:159-167)
+        fd.make_plan(J, J, colors, "hcentral")
+    with pytest.raises(fd.lib.FdError, match="colour range"):
+        fd.make_plan(J, J, colors, "forward", color_range=(2, 1))
+    with pytest.raises(fd.lib.FdError, match="window"):
+        fd.make_plan(J, J, colors, "forward", col_window=(5, 50))
+    assert L.fd_last_error()  # the message of the last failure stays readable
+
+
+def test_failing_user_launcher_is_reported_not_swallowed():
+    N = 30
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, _dev(np.zeros(rv.size)))
+
+    def boom(fx, xx):
+        raise ArithmeticError("f! failed beyond its bound")      # test/finitedifftests.jl:410: an f that throws
+
+    with pytest.raises(ArithmeticError, match="beyond its bound"):
+        fd.finite_difference_jacobian_b(J, fd.TorchF(boom, N, N), _dev(np.ones(N)), "forward", colorvec=P.cyclic_colors(N, 3))
+    # the plan / context stay usable afterwards
+    fd.finite_difference_jacobian_b(J, fd.BuiltinF("tridiag", N), _dev(np.ones(N)), "forward", colorvec=P.cyclic_colors(N, 3))
+    got = J.nzval.cpu().numpy()
+    assert np.allclose(got[rv == P.csc_cols(cp)], -2.0, atol=1e-6)
+
+
+def test_repeated_calls_new_x_same_plan(oracle):
+    # cache reuse at a new x (test/cache_reuse_tests.jl:57-62): one plan, many x, results depend only on the current x
+    N = 2000
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, _dev(np.zeros(rv.size)))
+    cache = fd.JacobianCache(_dev(np.zeros(N)), "central", colorvec=colors, sparsity=J)
+    f = fd.BuiltinF("tridiag_nl", N)
+    outs = []
+    for seed in (1, 2, 1):
+        x = np.random.default_rng(seed).random(N)
+        fd.finite_difference_jacobian_b(J, f, _dev(x), cache)
+        outs.append(J.nzval.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[2]) and not np.array_equal(outs[0], outs[1])
+    ref = oracle.jacobian("central", oracle.Fixture("tridiag_nl", N), np.random.default_rng(1).random(N), colors,
+                          kind=oracle.PAT_CSC_COMMON, colptr=cp, rowval=rv)
+    assert np.allclose(outs[0], ref["out"], rtol=1e-6, atol=1e-8)
+
+
+def test_two_plans_from_two_threads():
+    # "different plans may be used from different threads" (include/fdjac.h): each thread owns a context + plan
+    N = 200_000
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    results, errors = {}, []
+
+    def work(tag, fdtype):
+        try:
+            torch.cuda.set_device(0)
+            ctx = fd.Context(0, stream=None)      # own non-blocking stream
+            J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+            plan = fd.make_plan(J, J, colors, fdtype, ctx=ctx)
+            f = fd.BuiltinF("tridiag", N, ctx=ctx)
+            out = torch.zeros(rv.size, dtype=torch.float64, device="cuda")
+            x = _dev(np.random.default_rng(5).random(N))
+            for _ in range(20):
+                plan.jacobian(f, x, [out])
+            results[tag] = out.cpu().numpy()
+        except BaseException as e:   # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(k, fdt)) for k, fdt in enumerate(["forward", "central", "complex", "forward"])]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    isdiag = rv == P.csc_cols(cp)
+    for k, tol in ((0, 5e-7), (1, 1e-9), (2, 1e-14), (3, 5e-7)):
+        assert np.max(np.abs(results[k][isdiag] + 2.0)) < tol and np.max(np.abs(results[k][~isdiag] - 1.0)) < tol
+    assert np.array_equal(results[0], results[3])
