@@ -162,7 +162,8 @@ def main():
         bytes_min = (2 * C * 8 * N + nnz * (8 + idx_b)) / N
         bytes_call = (2 * C * 16 * N + 9 * N + 2 * C * 8 * N + 9 * N) / N + bytes_ds
         wl = "N=%d (%dx%d) 5-point Laplacian CSC (nnz=%d), colours (i+2j)%%5+1, central, x~U(0,1) seed 3" % (N, nx, ny, nnz)
-        kern = ("k_decompress_window<central>" if plan.info(fd.lib.INFO_WINDOW) else
+        kern = ("k_decompress_window2d<central>" if plan.info(fd.lib.INFO_WINDOW2D) else
+                "k_decompress_window<central>" if plan.info(fd.lib.INFO_WINDOW) else
                 "k_decompress_sorted<u8,central>" if plan.info(fd.lib.INFO_SORTED_GATHER) else "k_decompress_list<u8,central>")
         exact = (-4.0, 1.0)
         del rowval

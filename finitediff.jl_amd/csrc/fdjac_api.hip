@@ -231,6 +231,15 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
 //     that are served by the L2, traded for divergence-free 16-B loads (the gather kernels are TA-bound there).
 // rows / nzc: row and colour (>= 0; -1 = column without colour, written as 0; -2 = padding, never written) of
 // every output slot in storage order, padded to a multiple of kListPad.  Sets p->window on success.
+// LDS of one workgroup of the row-window kernels.  With LDS-DMA staging the raw windows of every array are kept
+// (the tile's colours of the perturbed points, plus fx or the minus points) in whole 1-KiB chunks.
+static size_t window_lds_bytes(int fdtype, int max_slots, int max_ncol)
+{
+    const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
+    const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
+    return wp * narr * 8 + 8 * (size_t)(kWinMaxCol + kW2Desc / 2);
+}
+
 static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,
                            bool scattered)
 {
@@ -326,7 +335,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
                 if (force_t && T != force_t) continue;
                 WinBuild w = build_windows(T, false);
                 if (!w.ok) continue;
-                const size_t lds = (size_t)w.max_slots * (size_t)w.max_ncol * 8;
+                const size_t lds = window_lds_bytes(p->fdtype, w.max_slots, w.max_ncol);
                 if (lds > (size_t)kWinMaxLds) continue;
                 const bool cheap = w.overread <= 1.25 || (scattered && w.overread <= kWinMaxOverread);
                 if (!(cheap || force_w == 1)) continue;
@@ -348,9 +357,170 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
     return FD_OK;
 }
 
+// 2-D (strided) tiles for the row-window kernel (k_decompress_window2d): 2-D stencil patterns in natural ordering.
+// Detection: apart from a few near-diagonal offsets (|row - col| <= 8) every entry sits one "stride" s away from the
+// diagonal (within +-4), the same s for (almost) the whole pattern, s >= 64.  Tiles are then R consecutive grid rows
+// (column runs s apart) x L positions; the row windows each tile needs are found from its entries as for the 1-D
+// tiles.  colstart[j - col0] = local index of the first entry of column j (size ncols + 1).
+static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc,
+                             const std::vector<int64_t> &colstart)
+{
+    int rc;
+    const char *fw = getenv("FDJAC_WINDOW2D");
+    if (fw && *fw && atoi(fw) == 0) return FD_OK;
+    const int64_t ncols = (int64_t)colstart.size() - 1;
+    if (ncols < 1024 || p->nnz_local < 8192) return FD_OK;
+    // --- the stride: most common far offset over a sample of columns
+    int64_t s = 0;
+    int ecmax = 0, halo = 0;
+    {
+        std::vector<int64_t> fars;
+        const int64_t step = std::max<int64_t>(1, ncols / 4096);
+        for (int64_t jj = 0; jj < ncols; jj += step) {
+            const int64_t j = p->col0 + jj;
+            for (int64_t e = colstart[(size_t)jj]; e < colstart[(size_t)jj + 1]; ++e) {
+                const int64_t o = (int64_t)rows[(size_t)e] - j;
+                if (o > 8 || o < -8) fars.push_back(o < 0 ? -o : o);
+            }
+        }
+        if (fars.empty()) return FD_OK;
+        std::sort(fars.begin(), fars.end());
+        s = fars[fars.size() / 2];
+        if (s < 64 || ncols < 4 * s) return FD_OK;
+        int64_t bad = 0, total = 0;
+        for (int64_t jj = 0; jj < ncols; ++jj) {
+            const int64_t j = p->col0 + jj;
+            const int cnt = (int)(colstart[(size_t)jj + 1] - colstart[(size_t)jj]);
+            ecmax = std::max(ecmax, cnt);
+            for (int64_t e = colstart[(size_t)jj]; e < colstart[(size_t)jj + 1]; ++e, ++total) {
+                int64_t o = (int64_t)rows[(size_t)e] - j;
+                if (o < 0) o = -o;
+                if (o <= 8) { halo = std::max<int>(halo, (int)o); continue; }
+                if (o < s - 4 || o > s + 4) ++bad;
+                else halo = std::max<int>(halo, (int)(o > s ? o - s : s - o));
+            }
+        }
+        if (bad * 1000 > total || ecmax < 1 || ecmax > 32) return FD_OK;   // > 0.1 % of the entries off-stride
+    }
+    const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
+    int L = (fl && *fl) ? atoi(fl) : 64;
+    L = std::max(2, L & ~1);
+    int R = (fr && *fr) ? atoi(fr) : (int)(2048 / ((int64_t)ecmax * L));
+    R = std::max(1, std::min(R, kW2MaxRun));
+    if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
+    if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
+        const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
+        while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+    }
+    if (R < 2) return FD_OK;
+
+    const int64_t g_lo = p->col0 / s, g_hi = (p->col1 - 1) / s;          // grid rows touched by the local columns
+    const int64_t nG = (g_hi - g_lo + R) / R, nI = (s + L - 1) / L;
+    std::vector<int> desc;
+    std::vector<uint16_t> code;
+    desc.reserve((size_t)(nG * nI) * kW2Desc);
+    code.reserve((size_t)p->nnz_local + (size_t)(nG * nI) * 2 * R);
+    std::vector<int32_t> rr;
+    int max_slots = 0, max_ncol = 0;
+    double elems = 0;
+    int64_t ntiles = 0, covered = 0;
+    for (int64_t G = 0; G < nG; ++G)
+        for (int64_t I = 0; I < nI; ++I) {
+            int d[kW2Desc] = {0};
+            int nruns = 0;
+            int64_t run_a[kW2MaxRun], run_b[kW2MaxRun];   // local entry ranges
+            for (int q = 0; q < R; ++q) {
+                const int64_t g = g_lo + G * R + q;
+                if (g > g_hi) break;
+                int64_t c0 = g * s + I * L, c1 = g * s + std::min<int64_t>((I + 1) * L, s);
+                c0 = std::max<int64_t>(c0, p->col0);
+                c1 = std::min<int64_t>(c1, p->col1);
+                if (c1 <= c0) continue;
+                const int64_t a = colstart[(size_t)(c0 - p->col0)], b = colstart[(size_t)(c1 - p->col0)];
+                if (b <= a) continue;
+                run_a[nruns] = a; run_b[nruns] = b; ++nruns;
+            }
+            if (nruns == 0) continue;
+            // rows / colours of the tile
+            rr.clear();
+            int32_t cmin = std::numeric_limits<int32_t>::max(), cmax = -1;
+            for (int r = 0; r < nruns; ++r)
+                for (int64_t e = run_a[r]; e < run_b[r]; ++e) {
+                    if (nzc[(size_t)e] < 0) continue;
+                    rr.push_back(rows[(size_t)e]);
+                    cmin = std::min(cmin, nzc[(size_t)e]); cmax = std::max(cmax, nzc[(size_t)e]);
+                }
+            int32_t wr[kW2MaxWin], wn[kW2MaxWin], ends[kW2MaxWin];
+            int nwin = 0;
+            if (!rr.empty()) {
+                if (cmax - cmin + 1 > kWinMaxCol) return FD_OK;
+                std::sort(rr.begin(), rr.end());
+                int32_t start = rr[0] & ~1, last = rr[0];
+                for (size_t k = 1; k <= rr.size(); ++k) {
+                    if (k == rr.size() || rr[k] - last > 16) {     // rows of one grid row are contiguous; next one is a stride away
+                        if (nwin == kW2MaxWin) return FD_OK;
+                        wr[nwin] = start; wn[nwin] = (last - start) / 2 + 1; ++nwin;
+                        if (k < rr.size()) start = rr[k] & ~1;
+                    }
+                    if (k < rr.size()) last = rr[k];
+                }
+            }
+            int pairs = 0;
+            for (int k = 0; k < nwin; ++k) { pairs += wn[k]; ends[k] = pairs; }
+            if (2 * pairs > 2048) return FD_OK;
+            const int ncol = rr.empty() ? 0 : cmax - cmin + 1;
+            d[0] = rr.empty() ? 0 : cmin; d[1] = ncol; d[2] = pairs; d[3] = nwin; d[4] = nruns;
+            const int64_t code0 = (int64_t)code.size();
+            d[6] = (int)(uint32_t)(code0 & 0xFFFFFFFFll); d[7] = (int)(code0 >> 32);
+            for (int k = 0; k < nwin; ++k) { d[8 + 2 * k] = wr[k]; d[9 + 2 * k] = ends[k]; }
+            int nent = 0;
+            for (int r = 0; r < nruns; ++r) {
+                for (int64_t e = run_a[r]; e < run_b[r]; ++e) {
+                    uint16_t c = 0x8000;
+                    if (nzc[(size_t)e] == -1) c = 0x4000;
+                    else if (nzc[(size_t)e] >= 0) {
+                        int k = 0;
+                        while (!(rows[(size_t)e] >= wr[k] && rows[(size_t)e] < wr[k] + 2 * wn[k])) ++k;
+                        const int slot = 2 * (k ? ends[k - 1] : 0) + (rows[(size_t)e] - wr[k]);
+                        c = (uint16_t)(slot | ((nzc[(size_t)e] - cmin) << 11));
+                    }
+                    code.push_back(c);
+                }
+                nent += (int)(run_b[r] - run_a[r]);
+                if (nent & 1) { code.push_back(0x8000); ++nent; }   // runs start on even code slots: pairs never straddle
+                d[32 + 3 * r] = (int)(uint32_t)(run_a[r] & 0xFFFFFFFFll); d[33 + 3 * r] = (int)(run_a[r] >> 32);
+                d[34 + 3 * r] = nent;
+                covered += run_b[r] - run_a[r];
+            }
+            if (nent > 2048 + 2 * kW2MaxRun) return FD_OK;
+            d[5] = nent;
+            desc.insert(desc.end(), d, d + kW2Desc);
+            max_slots = std::max(max_slots, 2 * pairs);
+            max_ncol = std::max(max_ncol, ncol);
+            elems += 2.0 * pairs * ncol;
+            ++ntiles;
+        }
+    if (covered != p->nnz_local) return FD_OK;   // every stored entry must belong to exactly one run
+    const double overread = elems / (double)std::max<int64_t>(p->nnz_local, 1);
+    const size_t lds = window_lds_bytes(p->fdtype, max_slots, max_ncol);
+    if (max_slots == 0 || lds > (size_t)kWinMaxLds || overread > 2.2) return FD_OK;
+    code.push_back(0x8000); code.push_back(0x8000);   // the last pair load may touch one code past the end
+    p->window = true;
+    p->window2d = true;
+    p->w2_ntiles = ntiles;
+    p->win_tile = 0;
+    p->win_pairs = max_slots / 2;
+    p->win_ncol = max_ncol;
+    p->win_overread = overread;
+    if ((rc = dev_upload(&p->d_w2desc, desc))) return rc;
+    if ((rc = dev_upload(&p->d_wcode, code))) return rc;
+    return FD_OK;
+}
+
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
 static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
-                            std::vector<int32_t> &nzc, std::vector<int64_t> &dest)
+                            std::vector<int32_t> &nzc, std::vector<int64_t> &dest,
+                            const std::vector<int64_t> *colstart = nullptr)
 {
     int rc;
     p->nnz_local = (int64_t)rows.size();
@@ -412,7 +582,10 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     }
 
     if (!has_dest && p->nnz_local > 0) {
-        if ((rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
+        const char *fw1 = getenv("FDJAC_WINDOW"), *fs1 = getenv("FDJAC_SORTED");
+        const bool win_allowed = !(fw1 && *fw1 && atoi(fw1) == 0) && !(fs1 && *fs1 && atoi(fs1) == 1);
+        if (scattered && colstart && win_allowed && (rc = try_window2d_plan(p, rows, nzc, *colstart))) return rc;
+        if (!p->window && (rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
         if (p->window) {
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
@@ -512,7 +685,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
     for (void *q : ptrs)
@@ -572,7 +745,12 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
             if (kind == K_CSC_DENSE) dest[(size_t)(q - e0)] = r + M * j;
         }
     }
-    FD_TRY(finish_list_plan(p, col0, rows, nzc, dest));
+    std::vector<int64_t> colstart;
+    if (kind == K_CSC) {
+        colstart.resize((size_t)(p->col1 - p->col0) + 1);
+        for (int64_t j = p->col0; j <= p->col1; ++j) colstart[(size_t)(j - p->col0)] = load_idx(colptr, idx_bytes, j) - idx_base - e0;
+    }
+    FD_TRY(finish_list_plan(p, col0, rows, nzc, dest, kind == K_CSC ? &colstart : nullptr));
     p->nouts = 1;
     p->out_len[0] = kind == K_CSC ? (e1 - e0) : M * N;
     return FD_OK;
@@ -843,6 +1021,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_LINES_SORTED_X100: *value = (int64_t)(p->lines_sorted * 100); break;
     case FD_INFO_WINDOW: *value = p->window ? 1 : 0; break;
     case FD_INFO_WIN_OVERREAD_X100: *value = (int64_t)(p->win_overread * 100); break;
+    case FD_INFO_WINDOW2D: *value = p->window2d ? 1 : 0; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;

@@ -43,6 +43,11 @@ constexpr int kWinMaxWin = 4;        //   this many row windows per tile (a 5-po
 constexpr int kWinGap = 64;          //   a new window starts after a gap of more than this many rows,
 constexpr int kWinMaxLds = 52 * 1024;  // this much LDS per workgroup (3 workgroups per CU),
 constexpr double kWinMaxOverread = 4.0;  // and this many f! values loaded per stored entry for scattered patterns
+// 2-D (strided) tiles of the row-window kernel, for 2-D stencil patterns in natural ordering: a tile is kW2MaxRun
+// column runs one stencil stride apart, so the row windows of neighbouring grid rows are shared inside the tile
+constexpr int kW2Desc = 64;          // ints per tile descriptor
+constexpr int kW2MaxWin = 12;        // row windows per tile
+constexpr int kW2MaxRun = 8;         // column runs per tile
 
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
@@ -95,6 +100,9 @@ struct fd_plan {
     bool window = false;
     int4 *d_wtiles = nullptr;      //   3 x int4 per tile: {first colour, colours, row pairs, windows}, 4 x {first row, end pair}
     int win_tile = 0;              //   entries per tile (2048 or 1024)
+    bool window2d = false;         //   2-D (strided) tiles: d_w2desc[kW2Desc * ntiles], codes in tile order
+    int *d_w2desc = nullptr;
+    int64_t w2_ntiles = 0;
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile

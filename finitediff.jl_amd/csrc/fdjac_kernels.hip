@@ -410,6 +410,16 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     }
 }
 
+// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane names its own 16-B global source, the wave's 64 x 16 B land
+// linearly at a wave-uniform LDS address.  No staging VGPRs, no ds_write pass, and a workgroup can put a whole tile's
+// window loads in flight back to back -- one memory round trip per tile instead of one per loop iteration.
+typedef __attribute__((address_space(3))) void fd_lds_void;
+typedef const __attribute__((address_space(1))) void fd_glb_void;
+__device__ __forceinline__ void glds16(const double *g, double *l)
+{
+    __builtin_amdgcn_global_load_lds((fd_glb_void *)g, (fd_lds_void *)l, 16, 0, 0);
+}
+
 // K3c  the same decompression for LOCALLY BANDED patterns (tridiagonal / banded CSC, block patterns
 //   with few colours per tile): the rows of a tile of kSortTile storage-ordered entries fall into a
 //   short window [rmin, rmin + 2*npairs) and use ncol <= NCT consecutive colours (both found at plan
@@ -425,7 +435,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
 //   concatenated), bits 11-13 colour - cmin, bit 14 "column
 //   has no colour" (entry is written as 0), bit 15 "padding" (not a stored entry).
 //   Same operations on the same operands as k_decompress_list => bit-identical results.
-template <int MODE, int NCT, bool FXB_VEC, int U>
+template <int MODE, int NCT, bool FXB_VEC, int U, bool DMA>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
@@ -460,45 +470,66 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];   // two 16-bit codes
     if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
 
-    // phase 2: dense window loads -> differences -> LDS.  (The quotient is formed in phase 3, once per stored
-    // entry: windows of scattered patterns hold values no entry of this tile uses, and an IEEE division is ~50
-    // cycles per wave.)
-#pragma unroll 1
-    for (int i = threadIdx.x; i < npairs; i += kBlock) {
-        const int64_t row = i < e0 ? (int64_t)rw0 + 2 * i
-                          : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
-                          : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
-        d2_t b = {0.0, 0.0};
-        if (MODE == 0) {
-            if (FXB_VEC) {
-                b = *reinterpret_cast<const d2_t *>(FXb + row);
-            } else {   // caller's f_in: no padding / alignment guarantees
-                if (row < M) b.x = FXb[row];
-                if (row + 1 < M) b.y = FXb[row + 1];
-            }
-        }
-        d2_t a[NCT], bm[NCT];
-#pragma unroll
-        for (int cc = 0; cc < NCT; ++cc) {
-            const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
-            a[cc] = d2_t{0.0, 0.0};
-            bm[cc] = b;
-            if (cc < ncol) {
-                if (MODE == 2) {
-                    const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
-                    const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
-                    a[cc] = d2_t{p0.y, p1.y};
-                } else {
-                    a[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
-                    if (MODE == 1) bm[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+    if constexpr (DMA) {
+        // phase 2 (LDS-DMA): the raw window values of every staged array -- the tile's ncol colours of FXa, then fx
+        // (forward) or the same colours of FXb (central) -- go straight to LDS, 64 row pairs (1 KiB) per instruction
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int narr = (MODE == 0) ? ncol + 1 : 2 * ncol;
+        const int nch = (npairs + 63) >> 6;
+        if (ncol > 0)
+            for (int ch = 0; ch < nch; ++ch) {
+                int i = ch * 64 + lane;
+                i = i < npairs ? i : npairs - 1;          // tail lanes re-load the last pair (their LDS slots are padding)
+                const int64_t row = i < e0 ? (int64_t)rw0 + 2 * i
+                                  : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
+                                  : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
+                for (int a = wave; a < narr; a += kBlock / 64) {
+                    const double *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
+                                    : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
+                    glds16(g, s_win + (size_t)a * wp + ch * 128);
                 }
             }
-        }
-#pragma unroll
-        for (int cc = 0; cc < NCT; ++cc) {
-            if (cc < ncol) {
-                const d2_t df = (MODE == 2) ? a[cc] : d2_t{a[cc].x - bm[cc].x, a[cc].y - bm[cc].y};
-                *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = df;
+    } else {
+    // phase 2: dense window loads -> differences -> LDS.  (The quotient is formed in phase 3, once per stored
+        // entry: windows of scattered patterns hold values no entry of this tile uses, and an IEEE division is ~50
+        // cycles per wave.)
+    #pragma unroll 1
+        for (int i = threadIdx.x; i < npairs; i += kBlock) {
+            const int64_t row = i < e0 ? (int64_t)rw0 + 2 * i
+                              : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
+                              : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
+            d2_t b = {0.0, 0.0};
+            if (MODE == 0) {
+                if (FXB_VEC) {
+                    b = *reinterpret_cast<const d2_t *>(FXb + row);
+                } else {   // caller's f_in: no padding / alignment guarantees
+                    if (row < M) b.x = FXb[row];
+                    if (row + 1 < M) b.y = FXb[row + 1];
+                }
+            }
+            d2_t a[NCT], bm[NCT];
+    #pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
+                a[cc] = d2_t{0.0, 0.0};
+                bm[cc] = b;
+                if (cc < ncol) {
+                    if (MODE == 2) {
+                        const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                        const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                        a[cc] = d2_t{p0.y, p1.y};
+                    } else {
+                        a[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
+                        if (MODE == 1) bm[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+                    }
+                }
+            }
+    #pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                if (cc < ncol) {
+                    const d2_t df = (MODE == 2) ? a[cc] : d2_t{a[cc].x - bm[cc].x, a[cc].y - bm[cc].y};
+                    *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = df;
+                }
             }
         }
     }
@@ -519,7 +550,8 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
             const bool colored = (cd & 0xC000u) == 0;
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
-            const double df = s_win[at];
+            double df = s_win[at];
+            if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];   // fx | FXb colour
             const double e = s_eps[valid ? cs : 0];
             const double v = (MODE == 1) ? df / (2 * e) : df / e;
             q[h] = valid ? v : 0.0;
@@ -527,6 +559,135 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
         }
         const bool both = w[0] & w[1] & (vec_ok != 0);
         if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
+            d2_t pk = {q[0], q[1]};
+            *reinterpret_cast<d2_t *>(out + p) = pk;
+        } else {
+            if (w[0]) out[p] = q[0];
+            if (w[1]) out[p + 1] = q[1];
+        }
+    }
+}
+
+// K3d  row windows over 2-D (strided) tiles.  For a 2-D stencil in natural ordering a storage-ordered tile needs three
+//   far-apart row windows and loads every f! value three times (two of them from L2); measured on the 5-point
+//   stencil those re-reads cost a third of the kernel (322 us vs 213 us with the far windows switched off).  Here a
+//   tile is up to kW2MaxRun COLUMN RUNS one stencil stride apart (R consecutive grid rows x L positions), so the
+//   windows of grid rows g-1 .. g+R are loaded once for R runs: (R+2)(L+2)/(RL) = 1.4 loads per value instead of 3.
+//   The stored entries of a tile are the concatenation of its runs (each contiguous in nzval); codes are stored in
+//   tile order.  Descriptor (kW2Desc ints per tile): [0] first colour [1] colours [2] window pairs [3] windows
+//   [4] runs [5] entries (runs padded to even) [6,7] first code (int64); [8+2k, 9+2k] window k: first row, end pair;
+//   [32+3r..34+3r] run r: first output position (int64), end entry.  Same arithmetic as k_decompress_window.
+template <int MODE, int NCT, bool FXB_VEC, bool DMA>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict__ desc,
+                      const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
+                      const double *__restrict__ eps, int c_lo, int c_hi, double *__restrict__ out, int64_t ntiles,
+                      int vec_ok, int wp)
+{
+    extern __shared__ double s_mem_2d[];
+    double *s_eps = s_mem_2d;                                  // kWinMaxCol step sizes
+    int *s_desc = reinterpret_cast<int *>(s_mem_2d + kWinMaxCol);   // kW2Desc ints
+    double *s_win = s_mem_2d + kWinMaxCol + kW2Desc / 2;       // [ncol][wp] differences
+    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
+    if (tile_id >= ntiles) return;
+    if (threadIdx.x < kW2Desc) s_desc[threadIdx.x] = desc[tile_id * kW2Desc + threadIdx.x];
+    __syncthreads();
+    const int cmin = s_desc[0];
+    int cb0 = cmin, cb1 = cmin + s_desc[1];
+    const int npairs = s_desc[2], nwin = s_desc[3], nruns = s_desc[4], nent = s_desc[5];
+    const int64_t code0 = ((int64_t)(uint32_t)s_desc[6]) | ((int64_t)s_desc[7] << 32);
+    cb0 = cb0 > c_lo ? cb0 : c_lo;
+    cb1 = cb1 < c_hi ? cb1 : c_hi;
+    const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;
+    if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
+
+    if constexpr (DMA) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int narr = (MODE == 0) ? ncol + 1 : 2 * ncol;
+        const int nch = (npairs + 63) >> 6;
+        if (ncol > 0)
+            for (int ch = 0; ch < nch; ++ch) {
+                int i = ch * 64 + lane;
+                i = i < npairs ? i : npairs - 1;
+                int k = 0;
+                while (k + 1 < nwin && i >= s_desc[9 + 2 * k]) ++k;
+                const int pbase = k ? s_desc[7 + 2 * k] : 0;
+                const int64_t row = (int64_t)s_desc[8 + 2 * k] + 2 * (i - pbase);
+                for (int a = wave; a < narr; a += kBlock / 64) {
+                    const double *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
+                                    : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
+                    glds16(g, s_win + (size_t)a * wp + ch * 128);
+                }
+            }
+    } else {
+#pragma unroll 1
+        for (int i = threadIdx.x; i < npairs; i += kBlock) {
+            int k = 0;
+            while (k + 1 < nwin && i >= s_desc[9 + 2 * k]) ++k;
+            const int pbase = k ? s_desc[7 + 2 * k] : 0;
+            const int64_t row = (int64_t)s_desc[8 + 2 * k] + 2 * (i - pbase);
+            d2_t b = {0.0, 0.0};
+            if (MODE == 0) {
+                if (FXB_VEC) {
+                    b = *reinterpret_cast<const d2_t *>(FXb + row);
+                } else {
+                    if (row < M) b.x = FXb[row];
+                    if (row + 1 < M) b.y = FXb[row + 1];
+                }
+            }
+            d2_t a[NCT], bm[NCT];
+    #pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
+                a[cc] = d2_t{0.0, 0.0};
+                bm[cc] = b;
+                if (cc < ncol) {
+                    if (MODE == 2) {
+                        const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                        const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                        a[cc] = d2_t{p0.y, p1.y};
+                    } else {
+                        a[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
+                        if (MODE == 1) bm[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+                    }
+                }
+            }
+    #pragma unroll
+            for (int cc = 0; cc < NCT; ++cc)
+                if (cc < ncol) {
+                    const d2_t df = (MODE == 2) ? a[cc] : d2_t{a[cc].x - bm[cc].x, a[cc].y - bm[cc].y};
+                    *reinterpret_cast<d2_t *>(s_win + (size_t)cc * wp + 2 * i) = df;
+                }
+        }
+    }
+    __syncthreads();
+
+    const int cshift = cmin - cb0;
+#pragma unroll 1
+    for (int e = 2 * (int)threadIdx.x; e < nent; e += 2 * kBlock) {
+        const uint32_t code = *reinterpret_cast<const uint32_t *>(wcode + code0 + e);
+        int r = 0;
+        while (r + 1 < nruns && e >= s_desc[34 + 3 * r]) ++r;
+        const int ebase = r ? s_desc[31 + 3 * r] : 0;
+        const int64_t o0 = ((int64_t)(uint32_t)s_desc[32 + 3 * r]) | ((int64_t)s_desc[33 + 3 * r] << 32);
+        const int64_t p = o0 + (e - ebase);
+        double q[2];
+        bool w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned cd = (code >> (16 * h)) & 0xFFFFu;
+            const int cs = (int)((cd >> 11) & 7u) + cshift;
+            const bool colored = (cd & 0xC000u) == 0;
+            const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
+            const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
+            double df = s_win[at];
+            if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];
+            const double ee = s_eps[valid ? cs : 0];
+            const double v = (MODE == 1) ? df / (2 * ee) : df / ee;
+            q[h] = valid ? v : 0.0;
+            w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
+        }
+        if (w[0] & w[1] & ((p & 1) == 0) & (vec_ok != 0)) {
             d2_t pk = {q[0], q[1]};
             *reinterpret_cast<d2_t *>(out + p) = pk;
         } else {
@@ -894,20 +1055,40 @@ static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, con
                             double *out)
 {
     hipStream_t s = p->ctx->stream;
-    const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
-    const int wp = 2 * p->win_pairs;
-    const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)p->win_ncol + kWinMaxCol);
-    const int vok = (((uintptr_t)out) & 15) == 0;
+    // LDS-DMA staging is bit-identical but measured no faster on MI355X (tridiagonal forward 123 vs 124 us) and slower
+    // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
+    static const bool dma_off = env_i64("FDJAC_DMA", 0) == 0;
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
     const bool fxvec = (MODE != 0) || (fx == p->d_fx);
-#define FD_LAUNCH_WIN(NCT, FV, UU)                                                                          \
-    hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
-                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,   \
+    const bool dma = (MODE != 2) && fxvec && !dma_off;             // LDS-DMA staging of the raw windows
+    const int wp = (2 * p->win_pairs + 127) & ~127;               // LDS pitch: whole 1-KiB DMA chunks
+    const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
+    const int vok = (((uintptr_t)out) & 15) == 0;
+    if (p->window2d) {
+        const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
+        const size_t shm2 = sizeof(double) * ((size_t)wp * (size_t)narr + kWinMaxCol + kW2Desc / 2);
+#define FD_LAUNCH_W2(NCT, FV, DM)                                                                                  \
+        hipLaunchKernelGGL((k_decompress_window2d<MODE, NCT, FV, DM>), dim3((unsigned)g2), dim3(kBlock), shm2, s,    \
+                           p->d_wcode, p->d_w2desc, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo, c_hi, out, p->w2_ntiles,  \
+                           vok, wp)
+        if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_W2(kWinMaxCol, true, true); return; } }
+        if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_W2(4, true, false); else FD_LAUNCH_W2(4, false, false); }
+        else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_W2(6, true, false); else FD_LAUNCH_W2(6, false, false); }
+        else { if (fxvec) FD_LAUNCH_W2(kWinMaxCol, true, false); else FD_LAUNCH_W2(kWinMaxCol, false, false); }
+#undef FD_LAUNCH_W2
+        return;
+    }
+    const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
+    const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)narr + kWinMaxCol);
+#define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
+    hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
+                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,       \
                        c_hi, out, p->nnz_local, vok, wp)
-#define FD_LAUNCH_WIN_U(NCT, FV) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2); else FD_LAUNCH_WIN(NCT, FV, 1); } while (0)
-    if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true); else FD_LAUNCH_WIN_U(4, false); }
-    else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true); else FD_LAUNCH_WIN_U(6, false); }
-    else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true); else FD_LAUNCH_WIN_U(kWinMaxCol, false); }
+#define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
+    if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); return; } }
+    if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }
+    else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true, false); else FD_LAUNCH_WIN_U(6, false, false); }
+    else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true, false); else FD_LAUNCH_WIN_U(kWinMaxCol, false, false); }
 #undef FD_LAUNCH_WIN_U
 #undef FD_LAUNCH_WIN
 }

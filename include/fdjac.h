@@ -190,7 +190,8 @@ enum fd_plan_info_key {
     FD_INFO_LINES_DIRECT_X100 = 15,   /* plan-time estimate, x100: 128-B lines per wave gather, storage order */
     FD_INFO_LINES_SORTED_X100 = 16,   /*   ... colour-sorted order */
     FD_INFO_WINDOW = 17,              /* 1 if the row-window (dense loads -> LDS) decompression kernel is used */
-    FD_INFO_WIN_OVERREAD_X100 = 18    /*   x100: f! values loaded per stored entry by that kernel (100 = none wasted) */
+    FD_INFO_WIN_OVERREAD_X100 = 18,   /*   x100: f! values loaded per stored entry by that kernel (100 = none wasted) */
+    FD_INFO_WINDOW2D = 19             /*   1 if its tiles are 2-D (column runs one stencil stride apart) */
 };
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 

@@ -625,7 +625,8 @@ def test_sorted_gather_kernel_bit_identical(monkeypatch, fdtype, case):
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["tridiag", "tridiag_chunked", "tridiag_none", "tridiag_f_in", "band5", "bidiag_window",
-                                  "lap5", "lap5_chunked", "lap5_small_tile"])
+                                  "lap5", "lap5_chunked", "lap5_small_tile", "lap5_2d", "lap5_2d_chunked", "lap5_2d_window",
+                                  "lap5_2d_odd"])
 def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
     # the row-window kernel (dense f! loads -> LDS -> entries) must equal the storage-order gather kernel bit for bit
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
@@ -633,15 +634,20 @@ def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
     N = 9001
     cap, c0, c1 = 0, None, None
     fam, prm = "tridiag_nl", (N,)
-    if case.startswith("lap5"):        # three row windows per tile (rows k-nx, k, k+nx)
+    if case.startswith("lap5"):        # three row windows per tile (rows k-nx, k, k+nx), or 2-D tiles (R grid rows x L columns)
         nx, ny = (128, 96) if case != "lap5_small_tile" else (1100, 12)   # 3 x 5 x (2048/5+2) rows > LDS budget -> 1024-entry tiles
+        if case == "lap5_2d_odd":
+            nx, ny = 150, 77               # nx not a multiple of the tile width, ny not a multiple of the run count
+        monkeypatch.setenv("FDJAC_WINDOW2D", "1" if "_2d" in case else "0")
         N = nx * ny
         colptr, rowval = P.lap5_csc(nx, ny)
         colors = P.lap5_colors(nx, ny)
         fam, prm = "lap5", (nx, ny)
-        cap = 700_000 if case == "lap5_chunked" else 0
-        if case == "lap5":
+        cap = 700_000 if case.endswith("_chunked") else 0
+        if case in ("lap5", "lap5_2d"):
             colors[[5, 777, N - 3]] = 0
+        if case == "lap5_2d_window":
+            c0, c1 = 3 * nx + 17, N - 2 * nx - 5    # a column window that starts / ends inside grid rows
     elif case == "band5":
         colptr, rowval = P.banded_csc(N, N, 2, 2)
         colors = P.cyclic_colors(N, 5)
@@ -668,6 +674,7 @@ def test_row_window_kernel_bit_identical(monkeypatch, fdtype, case):
         assert plan.info(fd.lib.INFO_WINDOW) == int(forced)
         if forced == "1":
             assert 100 <= plan.info(fd.lib.INFO_WIN_OVERREAD_X100) <= (125 if fam != "lap5" else 400)
+            assert plan.info(fd.lib.INFO_WINDOW2D) == int("_2d" in case)
         out = _dev(np.full(plan.out_len(0), np.nan))
         f = fd.BuiltinF(fam, *prm)
         plan.jacobian(f, x, [out], f_in=f_in)
@@ -734,9 +741,48 @@ def test_banded_window_kernel_bit_identical(monkeypatch, fdtype, l, u, M, N):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+@pytest.mark.parametrize("pattern", ["tridiag", "lap5_1d", "lap5_2d"])
+def test_lds_dma_staging_bit_identical(fdtype, pattern):
+    # FDJAC_DMA=1 (global_load_lds staging of the raw windows) is read once per process, so the variant runs in a child
+    import os
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+pattern, fdtype = %r, %r
+if pattern == "tridiag":
+    N = 9001; cp, rv = P.tridiag_csc(N); colors = P.cyclic_colors(N, 3); fam, prm = "tridiag_nl", (N,)
+else:
+    nx, ny = 150, 77; N = nx * ny; cp, rv = P.lap5_csc(nx, ny); colors = P.lap5_colors(nx, ny); fam, prm = "lap5", (nx, ny)
+x = torch.as_tensor(np.random.default_rng(71).random(N), device="cuda")
+J = fd.SparseMatrixCSC(N, N, cp, rv)
+plan = fd.make_plan(J, J, colors, fdtype)
+f = fd.BuiltinF(fam, *prm)
+plan.set_lazy(f)
+out = torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda")
+plan.jacobian(f, x, [out])
+np.save(sys.argv[1], out.cpu().numpy())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), pattern, fdtype)
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for dma in ("0", "1"):
+            env = dict(os.environ, FDJAC_DMA=dma, FDJAC_WINDOW2D="0" if pattern == "lap5_1d" else "1")
+            path = os.path.join(td, "o%s.npy" % dma)
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=240)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append(np.load(path))
+    assert not np.isnan(outs[0]).any() and np.array_equal(outs[0], outs[1])
+
+
 def test_row_window_heuristic(monkeypatch):
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
     monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    monkeypatch.delenv("FDJAC_WINDOW2D", raising=False)
     N = 20000
     colptr, rowval = P.tridiag_csc(N)
     Jt = fd.SparseMatrixCSC(N, N, colptr, rowval)
@@ -747,8 +793,14 @@ def test_row_window_heuristic(monkeypatch):
     colptr, rowval = P.lap5_csc(nx, ny)
     Jl = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
     pl = fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central")
-    # 5-point stencil: scattered gathers -> three dense row windows per tile, every f! value loaded ~3 times (from L2)
-    assert pl.info(fd.lib.INFO_WINDOW) == 1 and 250 <= pl.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 400
+    # 5-point stencil: scattered gathers -> 2-D tiles (6 grid rows x 64 columns): every f! value loaded ~1.4 times
+    assert pl.info(fd.lib.INFO_WINDOW) == 1 and pl.info(fd.lib.INFO_WINDOW2D) == 1
+    assert 120 <= pl.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 220
+    monkeypatch.setenv("FDJAC_WINDOW2D", "0")     # storage-order tiles: three row windows per tile, ~3 loads per value
+    pl1 = fd.make_plan(Jl, Jl, P.lap5_colors(nx, ny), "central")
+    assert pl1.info(fd.lib.INFO_WINDOW) == 1 and pl1.info(fd.lib.INFO_WINDOW2D) == 0
+    assert 250 <= pl1.info(fd.lib.INFO_WIN_OVERREAD_X100) <= 400
+    monkeypatch.delenv("FDJAC_WINDOW2D")
     # a random pattern has no row locality at all: neither windows nor ... (stays on the gather kernels)
     rng = np.random.default_rng(3)
     A = np.zeros((3000, 3000))
