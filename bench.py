@@ -108,6 +108,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # one dedicated (non-default) stream for everything: the library enqueues on torch's current stream, so torch ops,
+    # the RCCL collective and torch events are all ordered with the library's kernels
+    bench_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(bench_stream)
     cfg = args.config
     if cfg in ("c3", "c5") and world > 1:
         raise SystemExit("--config %s is a single-GPU line" % cfg)

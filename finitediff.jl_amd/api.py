@@ -150,7 +150,9 @@ def _similar(a, n):
 # context / f launchers / plans
 # ----------------------------------------------------------------------------------------------
 class Context:
-    """fd_ctx: a device + the stream every launch is enqueued on (torch's current stream by default)."""
+    """fd_ctx: a device + the stream every launch is enqueued on: torch's current stream by default (so torch ops,
+    NCCL collectives and torch events stay ordered with the library's kernels without extra synchronisation);
+    stream=None creates a private non-blocking stream; an integer is taken as a hipStream_t."""
 
     _default = {}
     _lock = threading.Lock()
@@ -165,7 +167,7 @@ class Context:
             if not torch.cuda.is_available():
                 raise RuntimeError("libfdjac needs an MI355X (no HIP device visible); there is no CPU fallback")
             with torch.cuda.device(device):
-                sp = torch.cuda.current_stream().cuda_stream
+                sp = torch.cuda.current_stream().cuda_stream or 1   # 0 = torch's default stream -> FD_STREAM_DEFAULT
         elif stream is not None:
             sp = int(stream)
         _l.check(L.fd_ctx_create(int(device), C.c_void_p(sp) if sp else None, C.byref(h)))

@@ -647,7 +647,10 @@ int fd_ctx_create(int device, void *stream, fd_ctx **out)
     FD_REQUIRE(c != nullptr, FD_ERR_NOMEM, "out of host memory");
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (stream) {
+    if (stream == FD_STREAM_DEFAULT) {
+        c->stream = nullptr;   // the legacy default stream
+        c->own_stream = false;
+    } else if (stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {

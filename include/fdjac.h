@@ -125,7 +125,10 @@ typedef struct fd_plan_opts {
 } fd_plan_opts;
 
 /* ---- context ------------------------------------------------------------------------- */
-/* stream: an existing hipStream_t to enqueue on (e.g. the caller's), or NULL to create one. */
+/* stream: an existing hipStream_t to enqueue on (e.g. the caller's), NULL to create a private non-blocking stream,
+   or FD_STREAM_DEFAULT for the device's legacy default (null) stream -- what a host framework whose "current stream"
+   is the default stream needs so that its own work stays ordered with the library's. */
+#define FD_STREAM_DEFAULT ((void *)(uintptr_t)1)
 int fd_ctx_create(int device, void *stream, fd_ctx **out);
 int fd_ctx_destroy(fd_ctx *ctx);
 void *fd_ctx_stream(fd_ctx *ctx);
