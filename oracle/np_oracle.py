@@ -1,0 +1,89 @@
+"""Second, independent restatement of the reference's coloured-Jacobian loop, in plain numpy.
+
+TEST INFRASTRUCTURE ONLY (see oracle/fd_oracle.c): it exists to cross-check the C oracle -- two restatements
+written separately from the same reference lines must agree to rounding.  It follows
+src/jacobians.jl:504-653 literally (mask, norm, epsilon, in-place perturbation, f!, difference, decompression,
+un-perturbation, colour by colour) and returns a dense J with the pattern's entries filled.
+"""
+import numpy as np
+
+EPS = np.finfo(np.float64).eps
+
+
+def default_relstep(fdtype):   # src/epsilons.jl:133-144
+    return {"forward": np.sqrt(EPS), "central": np.cbrt(EPS), "complex": 1.0}[fdtype]
+
+
+def compute_epsilon(fdtype, x, relstep, absstep, dir=1.0):   # src/epsilons.jl:26-29, 50-53, 104-107
+    if fdtype == "forward":
+        return max(relstep * abs(x), absstep) * dir
+    if fdtype == "central":
+        return max(relstep * abs(x), absstep)
+    return EPS
+
+
+def jacobian(f, x, colorvec, pattern, fdtype="forward", relstep=None, absstep=None, dir=1.0, f_in=None):
+    """f(fx, x) in place (numpy, real or complex); pattern: boolean M x N (structural non-zeros);
+    returns (J dense M x N, number of f calls)."""
+    x = np.array(x, dtype=np.float64)
+    M, N = pattern.shape
+    colorvec = np.asarray(colorvec)
+    assert colorvec.size == N                                   # src/jacobians.jl:516
+    relstep = default_relstep(fdtype) if relstep is None else relstep
+    absstep = relstep if absstep is None else absstep
+    J = np.zeros((M, N))                                        # fill_matrix!(J, false), :530-532
+    ncalls = 0
+    x1 = x.copy()                                               # copyto!(x1, x), :519
+    if fdtype == "forward":
+        fx = np.zeros(M)
+        if f_in is None:
+            f(fx, x)                                            # :540-545
+            ncalls += 1
+        else:
+            fx[:] = f_in
+        fx1 = np.zeros(M)
+        for c in range(1, int(colorvec.max()) + 1):             # :547
+            mask = (colorvec == c)
+            x2 = x1 * mask                                      # :559
+            eps = compute_epsilon("forward", np.sqrt(np.linalg.norm(x2)), relstep, absstep, dir)   # :560-561
+            x1 = x1 + eps * mask                                # :562
+            f(fx1, x1)
+            ncalls += 1
+            d = (fx1 - fx) / eps                                # :565
+            for j in np.nonzero(mask)[0]:                       # decompression: J[row, col] = vfx[row]
+                rows = np.nonzero(pattern[:, j])[0]
+                J[rows, j] = d[rows]
+            x1 = x1 - eps * mask                                # :584
+    elif fdtype == "central":
+        fx, fx1 = np.zeros(M), np.zeros(M)
+        xx = x                                                   # the caller's x is perturbed too (:604, :620)
+        for c in range(1, int(colorvec.max()) + 1):
+            mask = (colorvec == c)
+            x2 = x1 * mask
+            eps = compute_epsilon("central", np.sqrt(np.linalg.norm(x2)), relstep, absstep)
+            x1 = x1 + eps * mask
+            xx = xx - eps * mask
+            f(fx1, x1)
+            f(fx, xx)
+            ncalls += 2
+            d = (fx1 - fx) / (2 * eps)                          # :607
+            for j in np.nonzero(mask)[0]:
+                rows = np.nonzero(pattern[:, j])[0]
+                J[rows, j] = d[rows]
+            x1 = x1 - eps * mask
+            xx = xx + eps * mask
+    else:
+        eps = EPS                                                # :624
+        cx1 = x1.astype(np.complex128)
+        cfx = np.zeros(M, np.complex128)
+        for c in range(1, int(colorvec.max()) + 1):
+            mask = (colorvec == c)
+            cx1 = cx1 + 1j * eps * mask                          # :633
+            f(cfx, cx1)
+            ncalls += 1
+            d = cfx.imag / eps                                   # :635
+            for j in np.nonzero(mask)[0]:
+                rows = np.nonzero(pattern[:, j])[0]
+                J[rows, j] = d[rows]
+            cx1 = cx1 - 1j * eps * mask                          # :646
+    return J, ncalls

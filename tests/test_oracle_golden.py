@@ -292,3 +292,36 @@ def test_jvp_reference_fixture(oracle):
     assert np.max(np.abs(oracle.jvp("forward", f, x, vdir, f_in=fin)["jvp"] - jvp_ref)) < 1e-6
     with pytest.raises(ValueError):
         oracle.jvp("complex", f, x, vdir)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_c_oracle_agrees_with_independent_numpy_restatement(oracle, fdtype, seed):
+    # two restatements of src/jacobians.jl:504-653 written separately (C, pass-for-pass; numpy, literal) must agree
+    from oracle import np_oracle
+    rng = np.random.default_rng(100 + seed)
+    M, N = (23, 31) if seed == 0 else (40, 40) if seed == 1 else (37, 19)
+    A = (rng.random((M, N)) < 0.15)
+    A[rng.integers(0, M, N), np.arange(N)] = True
+    W = rng.random((M, N)) * A
+    x = rng.random(N) + 0.1
+    colptr, rowval = P.csc_from_dense(A.astype(float))
+    # a valid colouring by brute force: columns sharing a row get different colours
+    colors = np.zeros(N, np.int64)
+    for j in range(N):
+        used = {colors[k] for k in range(j) if np.any(A[:, k] & A[:, j])}
+        c = 1
+        while c in used:
+            c += 1
+        colors[j] = c
+
+    def fn(fx, xx):
+        fx[:] = W @ (xx * xx) + (0.5 * W) @ np.sin(xx)      # couples rows and columns only inside the pattern
+
+    Jn, calls_n = np_oracle.jacobian(fn, x, colors, A, fdtype)
+    rc = oracle.jacobian(fdtype, oracle.PyF(fn, M, N), x, colors, M=M, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    Jc = P.csc_to_dense(M, N, colptr, rowval, rc["out"])
+    assert rc["fcalls"] == calls_n
+    scale = np.abs(Jn).max()
+    tol = {"forward": 1e-7, "central": 1e-9, "complex": 1e-14}[fdtype] * scale
+    assert np.max(np.abs(Jc - Jn)) <= tol
