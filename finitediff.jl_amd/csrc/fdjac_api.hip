@@ -11,20 +11,14 @@
 
 namespace fdjac {
 
+#ifndef FDJAC_F32
 static thread_local char g_err[512] = "";
+#endif
 
-void set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
-int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir);
-int launch_perturb(fd_plan *p, const double *x, int c_lo, int B);
-int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs, int mode);
-int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v);
+int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir);
+int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B);
+int launch_decompress(fd_plan *p, const real_t *fx, int c_lo, int c_hi, real_t *const *outs, int mode);
+int launch_fill(fd_ctx *ctx, real_t *ptr, int64_t n, real_t v);
 int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16);
 int balanced_grid(int64_t tiles, int64_t cap);
 
@@ -44,13 +38,13 @@ template <typename T> static int dev_upload(T **dst, const std::vector<T> &src)
     return FD_OK;
 }
 
-static int dev_alloc(double **dst, int64_t nelem)
+template <typename T> static int dev_alloc(T **dst, int64_t nelem)
 {
     *dst = nullptr;
     if (nelem <= 0) nelem = 1;
-    hipError_t e = hipMalloc((void **)dst, sizeof(double) * (size_t)nelem);
+    hipError_t e = hipMalloc((void **)dst, sizeof(T) * (size_t)nelem);
     if (e == hipErrorOutOfMemory) {
-        set_error("hipMalloc of %lld bytes failed: out of memory", (long long)(nelem * 8));
+        set_error("hipMalloc of %lld bytes failed: out of memory", (long long)(nelem * (int64_t)sizeof(T)));
         return FD_ERR_NOMEM;
     }
     FD_HIP_CHECK(e);
@@ -145,7 +139,7 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     p->pts = p->fdtype == FD_CENTRAL ? 2 : 1;
     p->ldx = round_up(p->N, 32);
     p->ldf = round_up(p->M, 32);
-    const int64_t per_color = (int64_t)p->pts * p->cplx * 8 * (p->ldx + p->ldf);
+    const int64_t per_color = (int64_t)p->pts * p->cplx * (int64_t)sizeof(real_t) * (p->ldx + p->ldf);
     int64_t B = p->C > 0 ? p->scratch_bytes / std::max<int64_t>(per_color, 1) : 1;
     B = std::max<int64_t>(1, std::min<int64_t>(B, std::max<int64_t>(p->C, 1)));
     B = std::min<int64_t>(B, 32768);  // keeps the f! batch within one grid dimension
@@ -161,10 +155,10 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
 
     if (p->fdtype == FD_COMPLEX) {
         // d_fx is not used by the complex step: keep it zero, it is the "fx" of the imag-only decompression
-        FD_HIP_CHECK(hipMemset(p->d_fx, 0, sizeof(double) * (size_t)p->ldf));
+        FD_HIP_CHECK(hipMemset(p->d_fx, 0, sizeof(real_t) * (size_t)p->ldf));
         // eps(Float64) for every colour (src/epsilons.jl:104-107, src/jacobians.jl:624)
         FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
-        int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), 2.220446049250313e-16);
+        int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), std::numeric_limits<real_t>::epsilon());
         if (r2) return r2;
     } else if (p->C > 0 && p->kind != K_DENSE) {
         if (p->C <= kRegColors) {
@@ -626,6 +620,9 @@ using namespace fdjac;
 
 extern "C" {
 
+#ifndef FDJAC_F32   /* shared by both instantiations: defined once, by the Float64 build */
+void fdjac_set_error_v(const char *fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), fmt, ap); }
+
 int fd_version(void) { return FDJAC_VERSION; }
 const char *fd_last_error(void) { return g_err; }
 
@@ -682,6 +679,8 @@ int fd_ctx_synchronize(fd_ctx *ctx)
     FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return FD_OK;
 }
+
+#endif
 
 int fd_plan_destroy(fd_plan *p)
 {
@@ -1014,7 +1013,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_ROW_END: *value = p->row1; break;
     case FD_INFO_NCHUNKS: *value = p->nchunks; break;
     case FD_INFO_SCRATCH_BYTES:
-        *value = 8 * (p->chunkB * p->pts * p->cplx * (p->ldx + p->ldf) + 2 * p->ldf + p->ldx);
+        *value = (int64_t)sizeof(real_t) * (p->chunkB * p->pts * p->cplx * (p->ldx + p->ldf) + 2 * p->ldf + p->ldx);
         break;
     case FD_INFO_NNZ_LOCAL: *value = p->nnz_local; break;
     case FD_INFO_FCALLS_LAST: *value = p->fcalls_last; break;
@@ -1107,16 +1106,16 @@ int fd_plan_get_timings(fd_plan *p, double *ms_sum, int64_t *launches)
 }
 
 // ---- the hot path ---------------------------------------------------------------------------
-static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double *x_dev, const double *fin_dev,
-                            double relstep, double absstep, double dir, double *const *outs)
+static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t *x_dev, const real_t *fin_dev,
+                            double relstep, double absstep, double dir, real_t *const *outs)
 {
     fd_ctx *ctx = p->ctx;
     hipStream_t s = ctx->stream;
     FD_REQUIRE(f != nullptr, FD_ERR_ARG, "f launcher is NULL");
     if (!(relstep > 0)) {
         // default_relstep, src/epsilons.jl:133-144
-        const double e = 2.220446049250313e-16;
-        relstep = p->fdtype == FD_FORWARD ? std::sqrt(e) : p->fdtype == FD_CENTRAL ? std::cbrt(e) : 1.0;
+        const real_t e = std::numeric_limits<real_t>::epsilon();   // default_relstep(fdtype, eltype(x))
+        relstep = p->fdtype == FD_FORWARD ? (double)std::sqrt(e) : p->fdtype == FD_CENTRAL ? (double)std::cbrt(e) : 1.0;
     }
     if (absstep < 0) absstep = relstep;
     p->relstep_last = relstep;
@@ -1126,8 +1125,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
     Span total(p, FD_STAGE_TOTAL);
 
     // x must be 16-B aligned for the vector loads; stage it otherwise
-    if (((uintptr_t)x_dev) & 15) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x_dev, sizeof(double) * (size_t)p->N, hipMemcpyDeviceToDevice, s));
+    if (((uintptr_t)x_dev) & kPairMask) {
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x_dev, sizeof(real_t) * (size_t)p->N, hipMemcpyDeviceToDevice, s));
         x_dev = p->d_xstage;
     }
 
@@ -1140,7 +1139,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
 
     // f(x) for forward differences (src/jacobians.jl:540-545).  With a lazy-point launcher the base
     // evaluation rides along with the first perturbed batch (one launch fewer).
-    const double *fx = nullptr;
+    const real_t *fx = nullptr;
     bool base_pending = false;
     if (p->fdtype == FD_FORWARD) {
         if (fin_dev) {
@@ -1160,10 +1159,10 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const double 
     // dense J / list kinds with several chunks or uncovered entries start from zero (fill_matrix!,
     // src/jacobians.jl:530-532).  Kinds that write every stored value in one chunk skip the fill.
     if (p->kind == K_CSC_DENSE || p->kind == K_COO_DENSE) {
-        FD_HIP_CHECK(hipMemsetAsync(outs[0], 0, sizeof(double) * (size_t)p->out_len[0], s));
+        FD_HIP_CHECK(hipMemsetAsync(outs[0], 0, sizeof(real_t) * (size_t)p->out_len[0], s));
     } else if (p->C == 0) {
         for (int k = 0; k < p->nouts; ++k)
-            FD_HIP_CHECK(hipMemsetAsync(outs[k], 0, sizeof(double) * (size_t)p->out_len[k], s));
+            FD_HIP_CHECK(hipMemsetAsync(outs[k], 0, sizeof(real_t) * (size_t)p->out_len[k], s));
     }
 
     // colours of this plan: all of them, or the owned range (fd_plan_opts.color_begin/end), in chunks of chunkB
@@ -1232,9 +1231,9 @@ int fd_jacobian_async(fd_plan *p, fd_f_launch f, void *fctx, const void *x, cons
     FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
     for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
-    double *o[3] = {(double *)outs[0], p->nouts > 1 ? (double *)outs[1] : nullptr,
-                    p->nouts > 2 ? (double *)outs[2] : nullptr};
-    return jacobian_enqueue(p, f, fctx, (const double *)x, (const double *)f_in, relstep, absstep, dir, o);
+    real_t *o[3] = {(real_t *)outs[0], p->nouts > 1 ? (real_t *)outs[1] : nullptr,
+                    p->nouts > 2 ? (real_t *)outs[2] : nullptr};
+    return jacobian_enqueue(p, f, fctx, (const real_t *)x, (const real_t *)f_in, relstep, absstep, dir, o);
 }
 
 int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind, const void *f_in, int f_in_kind,
@@ -1244,20 +1243,20 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
     for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
-    const double *x_dev = (const double *)x;
+    const real_t *x_dev = (const real_t *)x;
     if (x_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x, sizeof(real_t) * (size_t)p->N, hipMemcpyHostToDevice, s));
         x_dev = p->d_xstage;
     }
-    const double *fin_dev = (const double *)f_in;
+    const real_t *fin_dev = (const real_t *)f_in;
     if (f_in && f_in_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_finstage, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_finstage, f_in, sizeof(real_t) * (size_t)p->M, hipMemcpyHostToDevice, s));
         fin_dev = p->d_finstage;
     }
-    double *o[3] = {nullptr, nullptr, nullptr};
+    real_t *o[3] = {nullptr, nullptr, nullptr};
     for (int k = 0; k < p->nouts; ++k) {
         if (out_kind == FD_DEVICE) {
-            o[k] = (double *)outs[k];
+            o[k] = (real_t *)outs[k];
         } else {
             if (!p->d_outstage[k]) {
                 int rc = dev_alloc(&p->d_outstage[k], p->out_len[k]);
@@ -1274,7 +1273,7 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
     if (out_kind == FD_HOST)
         for (int k = 0; k < p->nouts; ++k)
             if (p->out_len[k] > 0)
-                FD_HIP_CHECK(hipMemcpyAsync(outs[k], o[k], sizeof(double) * (size_t)p->out_len[k], hipMemcpyDeviceToHost, s));
+                FD_HIP_CHECK(hipMemcpyAsync(outs[k], o[k], sizeof(real_t) * (size_t)p->out_len[k], hipMemcpyDeviceToHost, s));
     FD_HIP_CHECK(hipStreamSynchronize(s));
     return FD_OK;
 }
@@ -1300,10 +1299,13 @@ int fd_plan_get_epsilons(fd_plan *p, double *eps_out)
     if (p->C == 0) return FD_OK;
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
-    FD_HIP_CHECK(hipMemcpy(eps_out, p->d_eps, sizeof(double) * (size_t)p->C, hipMemcpyDeviceToHost));
+    std::vector<real_t> tmp((size_t)p->C);
+    FD_HIP_CHECK(hipMemcpy(tmp.data(), p->d_eps, sizeof(real_t) * (size_t)p->C, hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < p->C; ++c) eps_out[c] = (double)tmp[(size_t)c];
     return FD_OK;
 }
 
+#ifndef FDJAC_F32   /* colouring and the copy probe do not depend on the element type */
 int fd_color_banded(int64_t N, int64_t l, int64_t u, int64_t *colorvec_out, int64_t *ncolors_out)
 {
     FD_REQUIRE(colorvec_out && N >= 1 && l + u + 1 >= 1, FD_ERR_ARG, "bad argument");
@@ -1393,5 +1395,7 @@ int fd_stream_copy_gbps(fd_ctx *ctx, int64_t bytes, int iters, double *gbps_out)
     *gbps_out = 2.0 * (double)n16 * 16.0 * iters / (ms * 1e-3) / 1e9;
     return FD_OK;
 }
+
+#endif
 
 }  // extern "C"

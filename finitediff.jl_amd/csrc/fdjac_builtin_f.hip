@@ -15,21 +15,22 @@
 
 namespace fdjac {
 
+constexpr real_t kTwo = 2, kFour = 4;   // literals in the element type (Julia's 2x / 4x stay in eltype(x))
 struct cd {
-    double re, im;
+    real_t re, im;
 };
 __device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cd operator*(cd a, cd b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cd operator*(double s, cd a) { return {s * a.re, s * a.im}; }
-__device__ __forceinline__ cd operator+(cd a, double s) { return {a.re + s, a.im}; }
-__device__ __forceinline__ cd operator-(cd a, double s) { return {a.re - s, a.im}; }
+__device__ __forceinline__ cd operator*(real_t s, cd a) { return {s * a.re, s * a.im}; }
+__device__ __forceinline__ cd operator+(cd a, real_t s) { return {a.re + s, a.im}; }
+__device__ __forceinline__ cd operator-(cd a, real_t s) { return {a.re - s, a.im}; }
 
 template <typename T> __device__ __forceinline__ T zero_of();
-template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ real_t zero_of<real_t>() { return 0.0; }
 template <> __device__ __forceinline__ cd zero_of<cd>() { return {0.0, 0.0}; }
 
-__device__ __forceinline__ double sin_of(double a) { return sin(a); }
+__device__ __forceinline__ real_t sin_of(real_t a) { return sin(a); }
 __device__ __forceinline__ cd sin_of(cd a)
 {
     // sin(a+ib) = sin a cosh b + i cos a sinh b
@@ -48,7 +49,7 @@ k_f_tridiag(T *__restrict__ fx, const T *__restrict__ x, int64_t n, int64_t xs, 
         const T xm = i > 0 ? xb[i - 1] : zero_of<T>();
         const T xp = i + 1 < n ? xb[i + 1] : zero_of<T>();
         const T xi = xb[i];
-        T v = (xm - 2.0 * xi) + xp;
+        T v = (xm - kTwo * xi) + xp;
         if (NL) v = v + (xi * xi) * xp;
         fb[i] = v;
     }
@@ -58,28 +59,28 @@ k_f_tridiag(T *__restrict__ fx, const T *__restrict__ x, int64_t n, int64_t xs, 
 // neighbours (L1 hits), one 16-B store.  Needs even i and 16-B aligned batch bases.
 template <bool NL>
 __global__ void __launch_bounds__(kBlock)
-k_f_tridiag_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t n, int64_t xs, int64_t fs, int64_t r0,
+k_f_tridiag_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n, int64_t xs, int64_t fs, int64_t r0,
                int64_t r1)
 {
-    const double *xb = x + (int64_t)blockIdx.y * xs;
-    double *fb = fx + (int64_t)blockIdx.y * fs;
+    const real_t *xb = x + (int64_t)blockIdx.y * xs;
+    real_t *fb = fx + (int64_t)blockIdx.y * fs;
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
         if (i + 1 < n) {
-            const double2 c = *reinterpret_cast<const double2 *>(xb + i);
-            const double xm = i > 0 ? xb[i - 1] : 0.0;
-            const double xq = i + 2 < n ? xb[i + 2] : 0.0;
-            double v0 = (xm - 2.0 * c.x) + c.y;
-            double v1 = (c.x - 2.0 * c.y) + xq;
+            const r2_t c = *reinterpret_cast<const r2_t *>(xb + i);
+            const real_t xm = i > 0 ? xb[i - 1] : 0.0;
+            const real_t xq = i + 2 < n ? xb[i + 2] : 0.0;
+            real_t v0 = (xm - kTwo * c.x) + c.y;
+            real_t v1 = (c.x - kTwo * c.y) + xq;
             if (NL) {
                 v0 = v0 + (c.x * c.x) * c.y;
                 v1 = v1 + (c.y * c.y) * xq;
             }
-            *reinterpret_cast<double2 *>(fb + i) = make_double2(v0, v1);
+            *reinterpret_cast<r2_t *>(fb + i) = r2_t{v0, v1};
         } else {
-            const double xm = i > 0 ? xb[i - 1] : 0.0;
-            const double xi = xb[i];
-            fb[i] = (xm - 2.0 * xi) + 0.0;
+            const real_t xm = i > 0 ? xb[i - 1] : 0.0;
+            const real_t xi = xb[i];
+            fb[i] = (xm - kTwo * xi) + 0.0;
         }
     }
 }
@@ -93,21 +94,21 @@ k_f_tridiag_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t n,
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool NL> __device__ __forceinline__ T tridiag_row(T xm, T xi, T xp)
 {
-    T v = (xm - 2.0 * xi) + xp;
+    T v = (xm - kTwo * xi) + xp;
     if (NL) v = v + (xi * xi) * xp;
     return v;
 }
 
 template <typename CT, int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
-k_f_tridiag_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
-                 const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
+k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
+                 const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
                  int64_t r1, int imag_only)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
         // base values x[i-1..i+2] and their colours relative to the batch (-1: never perturbed)
-        double xv[4];
+        real_t xv[4];
         int cv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -119,17 +120,17 @@ k_f_tridiag_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_
         }
         const bool two = i + 1 < n;
         if (base_out) {
-            const double b0 = tridiag_row<double, NL>(xv[0], xv[1], xv[2]);
+            const real_t b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
             if (two) {
-                const double b1 = tridiag_row<double, NL>(xv[1], xv[2], xv[3]);
-                *reinterpret_cast<double2 *>(base_out + i) = make_double2(b0, b1);
+                const real_t b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
+                *reinterpret_cast<r2_t *>(base_out + i) = r2_t{b0, b1};
             } else {
                 base_out[i] = b0;
             }
         }
         for (int b = 0; b < B; ++b) {
-            const double e = eps[c_lo + b];
-            double d[4];
+            const real_t e = eps[c_lo + b];
+            real_t d[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = (cv[k] == b) ? e : 0.0;
             if (MODE == 2) {
@@ -138,32 +139,32 @@ k_f_tridiag_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_
                 for (int k = 0; k < 4; ++k) p[k] = cd{xv[k], d[k]};
                 const cd v0 = tridiag_row<cd, NL>(p[0], p[1], p[2]);
                 if (imag_only) {   // imaginary parts as a real array (fd_lazy_points.imag_only)
-                    double *dst = fx + (int64_t)b * fs + i;
+                    real_t *dst = fx + (int64_t)b * fs + i;
                     if (two) {
                         const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
-                        *reinterpret_cast<double2 *>(dst) = make_double2(v0.im, v1.im);
+                        *reinterpret_cast<r2_t *>(dst) = r2_t{v0.im, v1.im};
                     } else {
                         dst[0] = v0.im;
                     }
                 } else {
-                    double *dst = fx + ((int64_t)b * fs + i) * 2;
-                    *reinterpret_cast<double2 *>(dst) = make_double2(v0.re, v0.im);
+                    real_t *dst = fx + ((int64_t)b * fs + i) * 2;
+                    *reinterpret_cast<r2_t *>(dst) = r2_t{v0.re, v0.im};
                     if (two) {
                         const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
-                        *reinterpret_cast<double2 *>(dst + 2) = make_double2(v1.re, v1.im);
+                        *reinterpret_cast<r2_t *>(dst + 2) = r2_t{v1.re, v1.im};
                     }
                 }
             } else {
 #pragma unroll
                 for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
-                    double p[4];
+                    real_t p[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) p[k] = sgn == 0 ? xv[k] + d[k] : xv[k] - d[k];
-                    const double v0 = tridiag_row<double, NL>(p[0], p[1], p[2]);
-                    double *dst = fx + (int64_t)(sgn * B + b) * fs + i;
+                    const real_t v0 = tridiag_row<real_t, NL>(p[0], p[1], p[2]);
+                    real_t *dst = fx + (int64_t)(sgn * B + b) * fs + i;
                     if (two) {
-                        const double v1 = tridiag_row<double, NL>(p[1], p[2], p[3]);
-                        *reinterpret_cast<double2 *>(dst) = make_double2(v0, v1);
+                        const real_t v1 = tridiag_row<real_t, NL>(p[1], p[2], p[3]);
+                        *reinterpret_cast<r2_t *>(dst) = r2_t{v0, v1};
                     } else {
                         dst[0] = v0;
                     }
@@ -194,7 +195,7 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
             const T e = i + 1 < nx ? xb[k + 1] : zero_of<T>();
             const T s = j > 0 ? xb[k - nx] : zero_of<T>();
             const T n = j + 1 < ny ? xb[k + nx] : zero_of<T>();
-            fb[k] = (((w + e) + s) + n) - 4.0 * xb[k];
+            fb[k] = (((w + e) + s) + n) - kFour * xb[k];
         }
     }
 }
@@ -205,35 +206,35 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
 // line of x enters one L2 instead of three.
 template <bool CLAMP>
 __global__ void __launch_bounds__(kBlock)
-k_f_stencil5_v2(double *__restrict__ fx, const double *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
+k_f_stencil5_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
                 int64_t r0, int64_t r1)
 {
-    const double *xb = x + (int64_t)blockIdx.y * xs;
-    double *fb = fx + (int64_t)blockIdx.y * fs;
+    const real_t *xb = x + (int64_t)blockIdx.y * xs;
+    real_t *fb = fx + (int64_t)blockIdx.y * fs;
     const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
     const int64_t tile = xcd_tile(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
     const int64_t k = r0 + tile * (2 * kBlock) + threadIdx.x * 2;   // r0 even, nx even => k, k+1 share a grid row
     if (k >= r1) return;
     const int64_t j = k / nx, i = k - j * nx;
-    const double2 c = *reinterpret_cast<const double2 *>(xb + k);
+    const r2_t c = *reinterpret_cast<const r2_t *>(xb + k);
     const bool hs = j > 0, hn = j + 1 < ny, hw = i > 0, he = i + 2 < nx;
-    double2 s = make_double2(0.0, 0.0), n = make_double2(0.0, 0.0);
-    if (hs) s = *reinterpret_cast<const double2 *>(xb + k - nx);
-    if (hn) n = *reinterpret_cast<const double2 *>(xb + k + nx);
-    const double w = hw ? xb[k - 1] : 0.0;
-    const double e = he ? xb[k + 2] : 0.0;
-    double v0, v1;
+    r2_t s = r2_t{0.0, 0.0}, n = r2_t{0.0, 0.0};
+    if (hs) s = *reinterpret_cast<const r2_t *>(xb + k - nx);
+    if (hn) n = *reinterpret_cast<const r2_t *>(xb + k + nx);
+    const real_t w = hw ? xb[k - 1] : 0.0;
+    const real_t e = he ? xb[k + 2] : 0.0;
+    real_t v0, v1;
     if (CLAMP) {
-        const double w0 = hw ? w : c.x, e1 = he ? e : c.y;
-        const double s0 = hs ? s.x : c.x, s1 = hs ? s.y : c.y, n0 = hn ? n.x : c.x, n1 = hn ? n.y : c.y;
+        const real_t w0 = hw ? w : c.x, e1 = he ? e : c.y;
+        const real_t s0 = hs ? s.x : c.x, s1 = hs ? s.y : c.y, n0 = hn ? n.x : c.x, n1 = hn ? n.y : c.y;
         v0 = (((c.x + w0) + c.y) + s0) + n0;
         v1 = (((c.y + c.x) + e1) + s1) + n1;
     } else {
-        v0 = (((w + c.y) + s.x) + n.x) - 4.0 * c.x;
-        v1 = (((c.x + e) + s.y) + n.y) - 4.0 * c.y;
+        v0 = (((w + c.y) + s.x) + n.x) - kFour * c.x;
+        v1 = (((c.x + e) + s.y) + n.y) - kFour * c.y;
     }
-    *reinterpret_cast<double2 *>(fb + k) = make_double2(v0, v1);
+    *reinterpret_cast<r2_t *>(fb + k) = r2_t{v0, v1};
 }
 
 // Lazy-point version of the 5-point stencils (see k_f_tridiag_lazy): the 8 base values a pair of rows
@@ -251,15 +252,15 @@ __device__ __forceinline__ void stencil5_pair(const T *v, bool hs, bool hn, bool
         const T z = zero_of<T>();
         const T w = hw ? v[6] : z, e = he ? v[7] : z;
         const T s0 = hs ? v[2] : z, s1 = hs ? v[3] : z, n0 = hn ? v[4] : z, n1 = hn ? v[5] : z;
-        o0 = (((w + v[1]) + s0) + n0) - 4.0 * v[0];
-        o1 = (((v[0] + e) + s1) + n1) - 4.0 * v[1];
+        o0 = (((w + v[1]) + s0) + n0) - kFour * v[0];
+        o1 = (((v[0] + e) + s1) + n1) - kFour * v[1];
     }
 }
 
 template <typename CT, int MODE, bool CLAMP>
 __global__ void __launch_bounds__(kBlock)
-k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
-                  const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
+k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
+                  const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
                   int64_t r0, int64_t r1, int imag_only)
 {
     const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
@@ -271,7 +272,7 @@ k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base
     const bool hs = j > 0, hn = j + 1 < ny, hw = i > 0, he = i + 2 < nx;
     const int64_t idx[8] = {k, k + 1, k - nx, k - nx + 1, k + nx, k + nx + 1, k - 1, k + 2};
     const bool ok[8] = {true, true, hs, hs, hn, hn, hw, he};
-    double xv[8];
+    real_t xv[8];
     int cv[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -281,13 +282,13 @@ k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base
         cv[m] = (!ok[m] || c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
     }
     if (base_out) {
-        double b0, b1;
-        stencil5_pair<double, CLAMP>(xv, hs, hn, hw, he, b0, b1);
-        *reinterpret_cast<double2 *>(base_out + k) = make_double2(b0, b1);
+        real_t b0, b1;
+        stencil5_pair<real_t, CLAMP>(xv, hs, hn, hw, he, b0, b1);
+        *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
     }
     for (int b = 0; b < B; ++b) {
-        const double e = eps[c_lo + b];
-        double d[8];
+        const real_t e = eps[c_lo + b];
+        real_t d[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) d[m] = (cv[m] == b) ? e : 0.0;
         if (MODE == 2) {
@@ -296,20 +297,20 @@ k_f_stencil5_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base
             for (int m = 0; m < 8; ++m) p[m] = cd{xv[m], d[m]};
             stencil5_pair<cd, CLAMP>(p, hs, hn, hw, he, o0, o1);
             if (imag_only) {
-                *reinterpret_cast<double2 *>(fx + (int64_t)b * fs + k) = make_double2(o0.im, o1.im);
+                *reinterpret_cast<r2_t *>(fx + (int64_t)b * fs + k) = r2_t{o0.im, o1.im};
             } else {
-                double *dst = fx + ((int64_t)b * fs + k) * 2;
-                *reinterpret_cast<double2 *>(dst) = make_double2(o0.re, o0.im);
-                *reinterpret_cast<double2 *>(dst + 2) = make_double2(o1.re, o1.im);
+                real_t *dst = fx + ((int64_t)b * fs + k) * 2;
+                *reinterpret_cast<r2_t *>(dst) = r2_t{o0.re, o0.im};
+                *reinterpret_cast<r2_t *>(dst + 2) = r2_t{o1.re, o1.im};
             }
         } else {
 #pragma unroll
             for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
-                double p[8], o0, o1;
+                real_t p[8], o0, o1;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) p[m] = sgn == 0 ? xv[m] + d[m] : xv[m] - d[m];
-                stencil5_pair<double, CLAMP>(p, hs, hn, hw, he, o0, o1);
-                *reinterpret_cast<double2 *>(fx + (int64_t)(sgn * B + b) * fs + k) = make_double2(o0, o1);
+                stencil5_pair<real_t, CLAMP>(p, hs, hn, hw, he, o0, o1);
+                *reinterpret_cast<r2_t *>(fx + (int64_t)(sgn * B + b) * fs + k) = r2_t{o0, o1};
             }
         }
     }
@@ -327,11 +328,11 @@ k_f_block_sigma(T *__restrict__ sig, const T *__restrict__ x, int64_t nb, int64_
     const int64_t nw = ((int64_t)gridDim.x * kBlock) >> 6;
     for (int64_t b = b0 + wave; b < b1; b += nw) {
         T acc = zero_of<T>();
-        for (int64_t j = lane; j < bs; j += 64) acc = acc + ((double)(j + 1) / (double)bs) * xb[b * bs + j];
+        for (int64_t j = lane; j < bs; j += 64) acc = acc + ((real_t)(j + 1) / (real_t)bs) * xb[b * bs + j];
         // serial-order-independent but fixed: tree over lanes
         for (int off = 32; off > 0; off >>= 1) {
-            if constexpr (sizeof(T) == 8) {
-                double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+            if constexpr (sizeof(T) == sizeof(real_t)) {
+                real_t o = __shfl_down(*reinterpret_cast<real_t *>(&acc), off, 64);
                 acc = acc + *reinterpret_cast<T *>(&o);
             } else {
                 cd *a = reinterpret_cast<cd *>(&acc);
@@ -412,17 +413,17 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
     case FD_F_TRIDIAG:
     case FD_F_TRIDIAG_NL: {
         const bool nl = b->family == FD_F_TRIDIAG_NL;
-        if constexpr (sizeof(T) == 8) {
-            const bool aligned = ((((uintptr_t)fx) | ((uintptr_t)x)) & 15) == 0 && (xs % 2 == 0 || nbatch == 1) &&
+        if constexpr (sizeof(T) == sizeof(real_t)) {
+            const bool aligned = ((((uintptr_t)fx) | ((uintptr_t)x)) & kPairMask) == 0 && (xs % 2 == 0 || nbatch == 1) &&
                                  (fs % 2 == 0 || nbatch == 1);
             if (aligned) {
                 const int64_t r0e = r0 & ~(int64_t)1;
                 const dim3 g2 = grid2((r1 - r0e + 1) / 2, nbatch, ncu);
                 if (nl)
-                    hipLaunchKernelGGL((k_f_tridiag_v2<true>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                    hipLaunchKernelGGL((k_f_tridiag_v2<true>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
                                        b->prm[0], xs, fs, r0e, r1);
                 else
-                    hipLaunchKernelGGL((k_f_tridiag_v2<false>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                    hipLaunchKernelGGL((k_f_tridiag_v2<false>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
                                        b->prm[0], xs, fs, r0e, r1);
                 break;
             }
@@ -436,18 +437,18 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
     case FD_F_LAP5:
     case FD_F_CLAMP5: {
         const bool clamp = b->family == FD_F_CLAMP5;
-        if constexpr (sizeof(T) == 8) {
-            const bool ok = ((((uintptr_t)fx) | ((uintptr_t)x)) & 15) == 0 && (xs % 2 == 0 || nbatch == 1) &&
+        if constexpr (sizeof(T) == sizeof(real_t)) {
+            const bool ok = ((((uintptr_t)fx) | ((uintptr_t)x)) & kPairMask) == 0 && (xs % 2 == 0 || nbatch == 1) &&
                             (fs % 2 == 0 || nbatch == 1) && (b->prm[0] % 2 == 0);
             if (ok) {
                 const int64_t r0e = r0 & ~(int64_t)1;
                 const int64_t ntiles = (r1 - r0e + 2 * kBlock - 1) / (2 * kBlock);
                 const dim3 g2((unsigned)(8 * xcd_chunks(ntiles)), (unsigned)nbatch, 1);
                 if (clamp)
-                    hipLaunchKernelGGL((k_f_stencil5_v2<true>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                    hipLaunchKernelGGL((k_f_stencil5_v2<true>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
                                        b->prm[0], b->prm[1], xs, fs, r0e, r1);
                 else
-                    hipLaunchKernelGGL((k_f_stencil5_v2<false>), g2, dim3(kBlock), 0, s, (double *)fx, (const double *)x,
+                    hipLaunchKernelGGL((k_f_stencil5_v2<false>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
                                        b->prm[0], b->prm[1], xs, fs, r0e, r1);
                 break;
             }
@@ -463,7 +464,7 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
         if (b->sig_cap < nbatch * nb) {
             if (b->d_sig) (void)hipFree(b->d_sig);
             b->d_sig = nullptr;
-            if (hipMalloc(&b->d_sig, (size_t)(nbatch * nb) * 16) != hipSuccess) return 2;
+            if (hipMalloc(&b->d_sig, (size_t)(nbatch * nb) * 2 * sizeof(real_t)) != hipSuccess) return 2;
             b->sig_cap = nbatch * nb;
         }
         const int64_t b0 = std::max<int64_t>(r0 / bs - 1, 0), b1 = std::min<int64_t>((r1 + bs - 1) / bs + 1, nb);
@@ -492,7 +493,7 @@ static int builtin_launch(void *fctx, void *fx, const void *x, int64_t nbatch, i
     const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
     if (is_complex)
         return launch_family<cd>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
-    return launch_family<double>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
+    return launch_family<real_t>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
 }
 
 template <typename CT>
@@ -506,8 +507,8 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
     const bool nl = b->family == FD_F_TRIDIAG_NL;
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
 #define FD_LAZY(MODE, NL)                                                                                           \
-    hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (double *)fx, fs,    \
-                       (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,     \
+    hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (real_t *)fx, fs,    \
+                       (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,     \
                        lp->ncolors, b->prm[0], r0e, r1, lp->imag_only)
     if (mode == 0) { if (nl) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (nl) FD_LAZY(1, true); else FD_LAZY(1, false); }
@@ -526,8 +527,8 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
     const bool clamp = b->family == FD_F_CLAMP5;
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
 #define FD_LAZY(MODE, CL)                                                                                          \
-    hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (double *)fx, fs,            \
-                       (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,    \
+    hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (real_t *)fx, fs,            \
+                       (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,    \
                        lp->ncolors, b->prm[0], b->prm[1], r0e, r1, lp->imag_only)
     if (mode == 0) { if (clamp) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (clamp) FD_LAZY(1, true); else FD_LAZY(1, false); }
@@ -546,8 +547,8 @@ constexpr int kBcG = 6;
 template <typename T> __device__ __forceinline__ T tree_sum64(T acc)
 {
     for (int off = 32; off > 0; off >>= 1) {
-        if constexpr (sizeof(T) == 8) {
-            double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+        if constexpr (sizeof(T) == sizeof(real_t)) {
+            real_t o = __shfl_down(*reinterpret_cast<real_t *>(&acc), off, 64);
             acc = acc + *reinterpret_cast<T *>(&o);
         } else {
             cd *a = reinterpret_cast<cd *>(&acc);
@@ -564,19 +565,19 @@ __device__ __forceinline__ void bc_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-template <int MODE> struct BcT { typedef double type; };
+template <int MODE> struct BcT { typedef real_t type; };
 template <> struct BcT<2> { typedef cd type; };
-__device__ __forceinline__ double bc_make(double x, double d, int sgn, double) { return sgn == 0 ? x + d : x - d; }
-__device__ __forceinline__ cd bc_make(double x, double d, int, cd) { return cd{x, d}; }
+__device__ __forceinline__ real_t bc_make(real_t x, real_t d, int sgn, real_t) { return sgn == 0 ? x + d : x - d; }
+__device__ __forceinline__ cd bc_make(real_t x, real_t d, int, cd) { return cd{x, d}; }
 
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ base_out, const double *__restrict__ x,
-                      const CT *__restrict__ color, const double *__restrict__ eps, int c_lo, int B, int64_t nb, int bs,
+k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
+                      const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t nb, int bs,
                       int64_t blk0, int64_t blk1, int64_t r0, int64_t r1, int imag_only)
 {
     typedef typename BcT<MODE>::type T;
-    extern __shared__ double s_bc[];
+    extern __shared__ real_t s_bc[];
     constexpr int pts = MODE == 1 ? 2 : 1;
     constexpr int NBLK = kBcG + 2;
     const int PB = B * pts + 1;                      // last slot: the unperturbed point (base_out, forward only)
@@ -585,7 +586,7 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
     int *owner = reinterpret_cast<int *>(tree + (size_t)NBLK * 128);   // [waves][B]  duplicate-colour detection
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t g0 = blk0 + (int64_t)blockIdx.x * kBcG;
-    const double w = (double)(lane + 1) / (double)bs;
+    const real_t w = (real_t)(lane + 1) / (real_t)bs;
     const bool want_base = (MODE == 0) && (base_out != nullptr);
     int *own = owner + wave * B;
 
@@ -598,7 +599,7 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
         const int64_t bb = g0 - 1 + lb;
         const bool inb = (bb >= 0) & (bb < nb);
         const bool act = inb & (lane < bs);
-        double xj = 0.0;
+        real_t xj = 0.0;
         int cj = -1;
         if (act) {
             xj = x[bb * bs + lane];
@@ -613,8 +614,8 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
         tr[lane] = acc;
         int base_at = 64;
         for (int off = 32; off > 0; off >>= 1) {
-            if constexpr (sizeof(T) == 8) {
-                double o = __shfl_down(*reinterpret_cast<double *>(&acc), off, 64);
+            if constexpr (sizeof(T) == sizeof(real_t)) {
+                real_t o = __shfl_down(*reinterpret_cast<real_t *>(&acc), off, 64);
                 acc = acc + *reinterpret_cast<T *>(&o);
             } else {
                 cd *a = reinterpret_cast<cd *>(&acc);
@@ -625,8 +626,8 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
             base_at += off;
         }
         T root = acc;   // valid in lane 0
-        if constexpr (sizeof(T) == 8) {
-            double r = __shfl(*reinterpret_cast<double *>(&root), 0, 64);
+        if constexpr (sizeof(T) == sizeof(real_t)) {
+            real_t r = __shfl(*reinterpret_cast<real_t *>(&root), 0, 64);
             root = *reinterpret_cast<T *>(&r);
         } else {
             cd *a = reinterpret_cast<cd *>(&root);
@@ -645,7 +646,7 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
             for (int q = lane; q < PB - 1; q += 64) sg[q] = inb ? root : zero_of<T>();
             bc_wave_sync();
             if (cj >= 0) {
-                const double e = eps[c_lo + cj];
+                const real_t e = eps[c_lo + cj];
 #pragma unroll
                 for (int sgn = 0; sgn < pts; ++sgn) {
                     T n = zero_of<T>() + w * bc_make(xj, e, sgn, T{});
@@ -664,17 +665,17 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
                 T term = zero_of<T>();
                 if (act) {
                     const int b = q < B ? q : q - B;
-                    const double d = (cj == b) ? eps[c_lo + b] : 0.0;
+                    const real_t d = (cj == b) ? eps[c_lo + b] : 0.0;
                     term = zero_of<T>() + w * bc_make(xj, d, q < B ? 0 : 1, T{});
                 }
                 term = tree_sum64<T>(term);
                 if (lane == 0) sg[q] = inb ? term : zero_of<T>();
             }
         }
-        if (want_base) {   // the base evaluation f(x) uses x itself (not x + 0.0); MODE 0 only, T = double
-            double tb = act ? 0.0 + w * xj : 0.0;
-            tb = tree_sum64<double>(tb);
-            if (lane == 0) reinterpret_cast<double *>(sg)[PB - 1] = inb ? tb : 0.0;
+        if (want_base) {   // the base evaluation f(x) uses x itself (not x + 0.0); MODE 0 only, T = real_t
+            real_t tb = act ? 0.0 + w * xj : 0.0;
+            tb = tree_sum64<real_t>(tb);
+            if (lane == 0) reinterpret_cast<real_t *>(sg)[PB - 1] = inb ? tb : 0.0;
         }
     }
     __syncthreads();
@@ -684,15 +685,15 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
         if (bb >= blk1 || bb >= nb) continue;
         const int64_t k = bb * bs + lane;
         if (!(lane < bs && k >= r0 && k < r1)) continue;
-        const double xk = x[k];
+        const real_t xk = x[k];
         const int c = (int)color[k];
         const int ck = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
         const bool mine = (ck >= 0) & (ck < B);
-        const double e = mine ? eps[c_lo + ck] : 0.0;
+        const real_t e = mine ? eps[c_lo + ck] : 0.0;
         // values every point shares, and the ones of the row's own colour
-        const double x0 = xk + 0.0;                 // what an unperturbed point of the batch holds (x + 0.0)
-        double s0, sP = 0.0, sM = 0.0, c0 = 0.0, ch = 1.0, sh = 0.0;
-        const double ch0 = cosh(0.0 * xk), sh0 = sinh(0.0 * xk);   // cosh(0), sinh(0) through the same library calls
+        const real_t x0 = xk + 0.0;                 // what an unperturbed point of the batch holds (x + 0.0)
+        real_t s0, sP = 0.0, sM = 0.0, c0 = 0.0, ch = 1.0, sh = 0.0;
+        const real_t ch0 = cosh(0.0 * xk), sh0 = sinh(0.0 * xk);   // cosh(0), sinh(0) through the same library calls
         if (MODE == 2) {
             s0 = sin(xk); c0 = cos(xk);
             if (mine) { ch = cosh(e); sh = sinh(e); }
@@ -706,21 +707,21 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
             const bool hit = mine & (ck == b);
             const T S = (sm[q] + sc[q]) + sp[q];
             if constexpr (MODE == 2) {
-                const cd xt{xk, hit ? e : 0.0};
+                const cd xt{xk, hit ? e : (real_t)0};
                 const cd sn{s0 * (hit ? ch : ch0), c0 * (hit ? sh : sh0)};
                 const cd v = xt * S + sn;
                 if (imag_only) fx[(int64_t)q * fs + k] = v.im;
-                else *reinterpret_cast<double2 *>(fx + ((int64_t)q * fs + k) * 2) = make_double2(v.re, v.im);
+                else *reinterpret_cast<r2_t *>(fx + ((int64_t)q * fs + k) * 2) = r2_t{v.re, v.im};
             } else {
-                const double d = hit ? e : 0.0;
-                const double xt = q < B ? xk + d : xk - d;
-                const double sn = hit ? (q < B ? sP : sM) : s0;
+                const real_t d = hit ? e : 0.0;
+                const real_t xt = q < B ? xk + d : xk - d;
+                const real_t sn = hit ? (q < B ? sP : sM) : s0;
                 fx[(int64_t)q * fs + k] = xt * S + sn;
             }
         }
         if (want_base) {
-            const double *sb = reinterpret_cast<const double *>(sig);
-            const double S = (sb[(size_t)(lb - 1) * PB + PB - 1] + sb[(size_t)lb * PB + PB - 1]) + sb[(size_t)(lb + 1) * PB + PB - 1];
+            const real_t *sb = reinterpret_cast<const real_t *>(sig);
+            const real_t S = (sb[(size_t)(lb - 1) * PB + PB - 1] + sb[(size_t)lb * PB + PB - 1]) + sb[(size_t)(lb + 1) * PB + PB - 1];
             base_out[k] = xk * S + sin(xk);
         }
     }
@@ -729,7 +730,7 @@ k_f_blockcoupled_lazy(double *__restrict__ fx, int64_t fs, double *__restrict__ 
 // LDS of k_f_blockcoupled_lazy: sigma of every point + the base summation tree, per block of the group, + owners
 static size_t bc_lds_bytes(int ncolors, int pts, bool cplx)
 {
-    const size_t el = cplx ? 16 : 8;
+    const size_t el = cplx ? 2 * sizeof(real_t) : sizeof(real_t);
     return (size_t)(kBcG + 2) * ((size_t)(ncolors * pts + 1) + 128) * el + (size_t)(kBlock / 64) * (size_t)ncolors * 4;
 }
 
@@ -743,8 +744,8 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
     const int64_t g = (blk1 - blk0 + kBcG - 1) / kBcG;
     const size_t shm = bc_lds_bytes(lp->ncolors, lp->pts, mode == 2);
 #define FD_LAZY(MODE)                                                                                               \
-    hipLaunchKernelGGL((k_f_blockcoupled_lazy<CT, MODE>), dim3((unsigned)g), dim3(kBlock), shm, s, (double *)fx, fs, \
-                       (double *)lp->base_out, (const double *)lp->x, (const CT *)lp->color, lp->eps, lp->c_lo,     \
+    hipLaunchKernelGGL((k_f_blockcoupled_lazy<CT, MODE>), dim3((unsigned)g), dim3(kBlock), shm, s, (real_t *)fx, fs, \
+                       (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,     \
                        lp->ncolors, nb, (int)bs, blk0, blk1, r0, r1, lp->imag_only)
     if (mode == 0) FD_LAZY(0); else if (mode == 1) FD_LAZY(1); else FD_LAZY(2);
 #undef FD_LAZY
@@ -765,7 +766,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
     if (!has_lazy(b)) return 6;
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
-    if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & 15) != 0 || (fx_stride & 1)) return 7;
+    if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + (lp->base_out ? 1 : 0);
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)

@@ -1,6 +1,47 @@
 // Internal declarations shared by the libfdjac translation units (not part of the C ABI).
+//
+// The library is built twice from the same sources: once with real_t = double (symbols fd_*) and once, through the
+// unity translation unit fdjac_f32.hip, with real_t = float (symbols fd32_*, include/fdjac.h "Float32 instantiation").
+// The second build renames everything that depends on the element type and leaves the shared pieces (contexts,
+// error text, colouring, copy probe) to the first.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#ifdef FDJAC_F32
+#define FDJAC_REAL float
+#define fdjac fdjac32
+#define fd_plan fd32_plan
+#define fd_jvp_plan fd32_jvp_plan
+#define fd_plan_create_csc fd32_plan_create_csc
+#define fd_plan_create_csc_dense fd32_plan_create_csc_dense
+#define fd_plan_create_coo_dense fd32_plan_create_coo_dense
+#define fd_plan_create_entries fd32_plan_create_entries
+#define fd_plan_create_dense fd32_plan_create_dense
+#define fd_plan_create_tridiagonal fd32_plan_create_tridiagonal
+#define fd_plan_create_banded fd32_plan_create_banded
+#define fd_plan_create_blockbanded fd32_plan_create_blockbanded
+#define fd_plan_destroy fd32_plan_destroy
+#define fd_plan_info fd32_plan_info
+#define fd_jacobian fd32_jacobian
+#define fd_jacobian_async fd32_jacobian_async
+#define fd_plan_set_lazy_f fd32_plan_set_lazy_f
+#define fd_plan_set_lazy_caps fd32_plan_set_lazy_caps
+#define fd_plan_get_epsilons fd32_plan_get_epsilons
+#define fd_plan_enable_timing fd32_plan_enable_timing
+#define fd_plan_get_timings fd32_plan_get_timings
+#define fd_builtin_f_create fd32_builtin_f_create
+#define fd_builtin_f_destroy fd32_builtin_f_destroy
+#define fd_builtin_f_counts fd32_builtin_f_counts
+#define fd_builtin_f_lazy fd32_builtin_f_lazy
+#define fd_builtin_f_lazy_caps fd32_builtin_f_lazy_caps
+#define fd_jvp_plan_create fd32_jvp_plan_create
+#define fd_jvp_plan_destroy fd32_jvp_plan_destroy
+#define fd_jvp fd32_jvp
+#define fd_jvp_async fd32_jvp_async
+#define fd_jvp_get_epsilon fd32_jvp_get_epsilon
+#else
+#define FDJAC_REAL double
+#endif
 
 #include <cstdarg>
 #include <cstdint>
@@ -9,9 +50,22 @@
 
 #include "fdjac.h"
 
+// error text: one thread-local buffer for both instantiations (defined by the Float64 build)
+extern "C" void fdjac_set_error_v(const char *fmt, va_list ap);
+
 namespace fdjac {
 
-void set_error(const char *fmt, ...);
+typedef FDJAC_REAL real_t;                                        // element type of x, f!, J
+typedef real_t r2_t __attribute__((ext_vector_type(2)));          // a pair of elements: the unit of vector access
+constexpr uintptr_t kPairMask = 2 * sizeof(real_t) - 1;           // alignment of a pair (16 B for Float64)
+
+inline void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    fdjac_set_error_v(fmt, ap);
+    va_end(ap);
+}
 
 #define FD_HIP_CHECK(expr)                                                                     \
     do {                                                                                       \
@@ -123,14 +177,15 @@ struct fd_plan {
     int64_t chunkB = 0, nchunks = 0;
     int pts = 1;                   // f! points per colour (2 for central)
     int cplx = 0;                  // elements are (re,im) pairs
-    double *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr, *d_partial = nullptr;
-    double *d_xstage = nullptr, *d_finstage = nullptr;
+    fdjac::real_t *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr;
+    double *d_partial = nullptr;   // masked sums of squares are accumulated in Float64 for either element type
+    fdjac::real_t *d_xstage = nullptr, *d_finstage = nullptr;
     int n_partial_blocks = 0;
     int64_t scratch_bytes = 0;
 
     int nouts = 1;
     int64_t out_len[3] = {0, 0, 0};
-    double *d_outstage[3] = {nullptr, nullptr, nullptr};
+    fdjac::real_t *d_outstage[3] = {nullptr, nullptr, nullptr};
 
     fd_f_launch_lazy lazy_fn = nullptr;
     int lazy_caps = 0;             // FD_LAZY_CAP_* of lazy_fn

@@ -6,6 +6,7 @@
 //   forward : jvp = (f(x + eps v) - f(x)) / eps                                     (:255-263)
 //   central : jvp = (f(x + eps v) - f(x - eps v)) / (2 eps)                         (:264-269)
 #include <cmath>
+#include <limits>
 #include <new>
 
 #include "fdjac_internal.h"
@@ -21,26 +22,26 @@ __device__ __forceinline__ double wave_sum_j(double v)
     return v;
 }
 
-typedef double d2j_t __attribute__((ext_vector_type(2)));
+typedef r2_t d2j_t;
 
 // VEC: x and v are 16-B aligned -> one 16-B load per array per lane (2 elements); else scalar.  Each variant is
 // deterministic (fixed per-thread order, fixed shuffle tree, partials reduced in fixed order by k_jvp_eps).
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
-k_dot_partial(const double *__restrict__ x, const double *__restrict__ v, int64_t n, double *__restrict__ partial)
+k_dot_partial(const real_t *__restrict__ x, const real_t *__restrict__ v, int64_t n, double *__restrict__ partial)
 {
-    double acc = 0.0;
+    double acc = 0.0;   // Float64 accumulation for either element type
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     if (VEC) {
         const int64_t n2 = n >> 1;
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
             const d2j_t a = reinterpret_cast<const d2j_t *>(x)[i], b = reinterpret_cast<const d2j_t *>(v)[i];
-            acc += a.x * b.x;
-            acc += a.y * b.y;
+            acc += (double)a.x * (double)b.x;
+            acc += (double)a.y * (double)b.y;
         }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * v[n - 1];
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += (double)x[n - 1] * (double)v[n - 1];
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += x[i] * v[i];
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += (double)x[i] * (double)v[i];
     }
     __shared__ double red[kBlock / 64];
     acc = wave_sum_j(acc);
@@ -55,7 +56,7 @@ k_dot_partial(const double *__restrict__ x, const double *__restrict__ v, int64_
 
 __global__ void __launch_bounds__(kBlock)
 k_jvp_eps(const double *__restrict__ partial, int nparts, double relstep, double absstep, double dir, int is_forward,
-          double *__restrict__ eps)
+          real_t *__restrict__ eps)
 {
     double acc = 0.0;
     for (int k = threadIdx.x; k < nparts; k += kBlock) acc += partial[k];
@@ -66,10 +67,10 @@ k_jvp_eps(const double *__restrict__ partial, int nparts, double relstep, double
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) t += red[w];
-        const double tmp = sqrt(fabs(t));
-        const double a = relstep * fabs(tmp);
-        double e = (a > absstep) ? a : absstep;   // src/epsilons.jl:26-29,50-53
-        if (is_forward) e = e * dir;
+        const real_t tmp = sqrt(fabs((real_t)t));      // the dot product in Float64, the step rule in the element type
+        const real_t a = (real_t)relstep * fabs(tmp);
+        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;   // src/epsilons.jl:26-29,50-53
+        if (is_forward) e = e * (real_t)dir;
         eps[0] = e;
     }
 }
@@ -77,10 +78,10 @@ k_jvp_eps(const double *__restrict__ partial, int nparts, double relstep, double
 // forward: X[0] = x + eps v ; central: X[0] = x - eps v, X[1] = x + eps v   (src/jvp.jl:260,265,267)
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
-k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const double *__restrict__ eps, int central,
-             int64_t n, double *__restrict__ X, int64_t ld)
+k_jvp_points(const real_t *__restrict__ x, const real_t *__restrict__ v, const real_t *__restrict__ eps, int central,
+             int64_t n, real_t *__restrict__ X, int64_t ld)
 {
-    const double e = eps[0];
+    const real_t e = eps[0];
     if (VEC) {   // one pair of elements per thread (ld is a multiple of 32, X is hipMalloc'ed: 16-B aligned rows)
         const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
         if (i + 1 < n) {
@@ -93,14 +94,14 @@ k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const d
                 *reinterpret_cast<d2j_t *>(X + i) = d2j_t{xi.x + ev.x, xi.y + ev.y};
             }
         } else if (i < n) {
-            const double xi = x[i], ev = e * v[i];
+            const real_t xi = x[i], ev = e * v[i];
             if (central) { X[i] = xi - ev; X[ld + i] = xi + ev; } else { X[i] = xi + ev; }
         }
         return;
     }
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double xi = x[i], ev = e * v[i];
+        const real_t xi = x[i], ev = e * v[i];
         if (central) {
             X[i] = xi - ev;
             X[ld + i] = xi + ev;
@@ -112,10 +113,10 @@ k_jvp_points(const double *__restrict__ x, const double *__restrict__ v, const d
 
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
-k_jvp_diff(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ eps, int central,
-           int64_t m, double *__restrict__ out)
+k_jvp_diff(const real_t *__restrict__ a, const real_t *__restrict__ b, const real_t *__restrict__ eps, int central,
+           int64_t m, real_t *__restrict__ out)
 {
-    const double e = central ? 2 * eps[0] : eps[0];
+    const real_t e = central ? 2 * eps[0] : eps[0];
     if (VEC) {
         const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
         if (i + 1 < m) {
@@ -136,8 +137,9 @@ struct fd_jvp_plan {
     fd_ctx *ctx = nullptr;
     int fdtype = 0;
     int64_t M = 0, N = 0, ldx = 0, ldf = 0;
-    double *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr, *d_partial = nullptr;
-    double *d_xs = nullptr, *d_vs = nullptr, *d_fin = nullptr, *d_out = nullptr;
+    fdjac::real_t *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr;
+    double *d_partial = nullptr;
+    fdjac::real_t *d_xs = nullptr, *d_vs = nullptr, *d_fin = nullptr, *d_out = nullptr;
     int nparts = 1;
 };
 
@@ -165,7 +167,7 @@ int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_pla
                       (void **)&p->d_xs, (void **)&p->d_vs, (void **)&p->d_fin, (void **)&p->d_out};
     const int64_t sizes[] = {pts * p->ldx, pts * p->ldf, p->ldf, 1, p->nparts, p->ldx, p->ldx, p->ldf, p->ldf};
     for (int k = 0; k < 9; ++k)
-        if (hipMalloc(slots[k], sizeof(double) * (size_t)sizes[k]) != hipSuccess) {
+        if (hipMalloc(slots[k], sizeof(double) * (size_t)sizes[k]) != hipSuccess) {   // (partials are Float64)
             set_error("hipMalloc failed in fd_jvp_plan_create");
             for (int q = 0; q < k; ++q) (void)hipFree(*slots[q]);
             delete p;
@@ -186,16 +188,19 @@ int fd_jvp_plan_destroy(fd_jvp_plan *p)
     return FD_OK;
 }
 
-static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const double *xd, const double *vd, const double *fin,
-                       double relstep, double absstep, double dir, double *out)
+static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *xd, const real_t *vd, const real_t *fin,
+                       double relstep, double absstep, double dir, real_t *out)
 {
     hipStream_t s = p->ctx->stream;
     const int central = p->fdtype == FD_CENTRAL;
-    if (!(relstep > 0)) relstep = central ? std::cbrt(2.220446049250313e-16) : std::sqrt(2.220446049250313e-16);
+    if (!(relstep > 0)) {   // default_relstep(fdtype, eltype(x)), src/epsilons.jl:133-144
+        const real_t e = std::numeric_limits<real_t>::epsilon();
+        relstep = central ? (double)std::cbrt(e) : (double)std::sqrt(e);
+    }
     if (absstep < 0) absstep = relstep;
     const int g = balanced_grid((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
     const int gm = balanced_grid((p->M + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
-    const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & 15) == 0;
+    const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & kPairMask) == 0;
     if (vx) hipLaunchKernelGGL(k_dot_partial<true>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
     else hipLaunchKernelGGL(k_dot_partial<false>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
     hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
@@ -204,7 +209,7 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const double *
                                xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
     else hipLaunchKernelGGL(k_jvp_points<false>, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
     FD_HIP_CHECK(hipGetLastError());
-    const double *a, *b;
+    const real_t *a, *b;
     int rc;
     if (central) {
         rc = f(fctx, p->d_FX, p->d_X, 2, p->ldx, p->ldf, 0, p->M, 0, (void *)s);
@@ -223,7 +228,7 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const double *
         FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
         a = p->d_FX;
     }
-    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0)
+    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & kPairMask) == 0)
         hipLaunchKernelGGL(k_jvp_diff<true>, dim3((unsigned)((p->M + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s, a, b,
                            p->d_eps, central, p->M, out);
     else hipLaunchKernelGGL(k_jvp_diff<false>, dim3(gm), dim3(kBlock), 0, s, a, b, p->d_eps, central, p->M, out);
@@ -237,24 +242,24 @@ int fd_jvp(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const void 
     FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
-    const double *xd = (const double *)x, *vd = (const double *)v, *fin = (const double *)f_in;
+    const real_t *xd = (const real_t *)x, *vd = (const real_t *)v, *fin = (const real_t *)f_in;
     if (xv_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_xs, x, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_vs, v, sizeof(double) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_xs, x, sizeof(real_t) * (size_t)p->N, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_vs, v, sizeof(real_t) * (size_t)p->N, hipMemcpyHostToDevice, s));
         xd = p->d_xs; vd = p->d_vs;
     }
     if (f_in && f_in_kind == FD_HOST) {
-        FD_HIP_CHECK(hipMemcpyAsync(p->d_fin, f_in, sizeof(double) * (size_t)p->M, hipMemcpyHostToDevice, s));
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_fin, f_in, sizeof(real_t) * (size_t)p->M, hipMemcpyHostToDevice, s));
         fin = p->d_fin;
     }
-    double *out = out_kind == FD_DEVICE ? (double *)jvp_out : p->d_out;
+    real_t *out = out_kind == FD_DEVICE ? (real_t *)jvp_out : p->d_out;
     const int rc = jvp_enqueue(p, f, fctx, xd, vd, p->fdtype == FD_FORWARD ? fin : nullptr, relstep, absstep, dir, out);
     if (rc) {
         (void)hipStreamSynchronize(s);
         return rc;
     }
     if (out_kind == FD_HOST)
-        FD_HIP_CHECK(hipMemcpyAsync(jvp_out, out, sizeof(double) * (size_t)p->M, hipMemcpyDeviceToHost, s));
+        FD_HIP_CHECK(hipMemcpyAsync(jvp_out, out, sizeof(real_t) * (size_t)p->M, hipMemcpyDeviceToHost, s));
     FD_HIP_CHECK(hipStreamSynchronize(s));
     return FD_OK;
 }
@@ -264,8 +269,8 @@ int fd_jvp_async(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const
 {
     FD_REQUIRE(p && f && x && v && jvp_out, FD_ERR_ARG, "NULL argument");
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
-    return jvp_enqueue(p, f, fctx, (const double *)x, (const double *)v,
-                       p->fdtype == FD_FORWARD ? (const double *)f_in : nullptr, relstep, absstep, dir, (double *)jvp_out);
+    return jvp_enqueue(p, f, fctx, (const real_t *)x, (const real_t *)v,
+                       p->fdtype == FD_FORWARD ? (const real_t *)f_in : nullptr, relstep, absstep, dir, (real_t *)jvp_out);
 }
 
 int fd_jvp_get_epsilon(fd_jvp_plan *p, double *eps_out)
@@ -273,7 +278,9 @@ int fd_jvp_get_epsilon(fd_jvp_plan *p, double *eps_out)
     FD_REQUIRE(p && eps_out, FD_ERR_ARG, "NULL argument");
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
-    FD_HIP_CHECK(hipMemcpy(eps_out, p->d_eps, sizeof(double), hipMemcpyDeviceToHost));
+    real_t e = 0;
+    FD_HIP_CHECK(hipMemcpy(&e, p->d_eps, sizeof(real_t), hipMemcpyDeviceToHost));
+    *eps_out = (double)e;
     return FD_OK;
 }
 

@@ -1,7 +1,7 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels of the coloured-Jacobian hot path.
 //
 // Every stage is HBM-bandwidth bound (no dense contraction => no MFMA).  Layout rules:
-//   * all streams are read / written with 16 B per lane where alignment allows (double2),
+//   * all streams are read / written with 16 B per lane where alignment allows (r2_t),
 //   * a workgroup (256 threads = 4 waves) owns a contiguous tile of its stream so that the
 //     lines it gathers from the batched f! outputs are not shared with other XCDs' L2s,
 //   * the step sizes eps[] of the current colour chunk are staged in LDS.
@@ -13,7 +13,7 @@
 
 namespace fdjac {
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef r2_t d2_t;   // a pair of elements (16 B for Float64)
 
 template <typename CT> struct ColorTraits;
 // "none": the column has no colour (stored entries are written as 0); "pad": not a stored entry at all
@@ -53,36 +53,36 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 
 template <typename CT, int NC>
 __global__ void __launch_bounds__(kBlock)
-k_eps_partial_reg(const double *__restrict__ x, const CT *__restrict__ color, int64_t n,
+k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
                   double *__restrict__ partial, int ldp)
 {
-    double acc[NC];
+    double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
 
     // block tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
     const int64_t tile = (int64_t)kEpsU * kBlock * 2;
     for (int64_t base = (int64_t)blockIdx.x * tile; base < n; base += (int64_t)gridDim.x * tile) {
-        double2 v[kEpsU];
+        r2_t v[kEpsU];
         int c0[kEpsU], c1[kEpsU];
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
             const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
             if (i + 1 < n) {
-                v[u] = *reinterpret_cast<const double2 *>(x + i);
+                v[u] = *reinterpret_cast<const r2_t *>(x + i);
                 load_color_pair<CT>(color + i, c0[u], c1[u]);
             } else if (i < n) {
-                v[u] = make_double2(x[i], 0.0);
+                v[u] = r2_t{x[i], 0.0};
                 c0[u] = color[i];
                 c1[u] = -2;
             } else {
-                v[u] = make_double2(0.0, 0.0);
+                v[u] = r2_t{0.0, 0.0};
                 c0[u] = c1[u] = -2;
             }
         }
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
-            const double s0 = v[u].x * v[u].x, s1 = v[u].y * v[u].y;
+            const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 acc[c] += (c0[u] == c) ? s0 : 0.0;
@@ -110,7 +110,7 @@ k_eps_partial_reg(const double *__restrict__ x, const CT *__restrict__ color, in
 // K1b  same reduction for many colours: block (chunk k, colour c) walks colour c's column list
 //   (perm sorted by colour, built once at plan time) -- deterministic for any C.
 __global__ void __launch_bounds__(kBlock)
-k_eps_partial_seg(const double *__restrict__ x, const int32_t *__restrict__ perm,
+k_eps_partial_seg(const real_t *__restrict__ x, const int32_t *__restrict__ perm,
                   const int64_t *__restrict__ cptr, int64_t C, int nchunks,
                   double *__restrict__ partial)
 {
@@ -124,7 +124,7 @@ k_eps_partial_seg(const double *__restrict__ x, const int32_t *__restrict__ perm
     const int64_t e = (s + per < hi) ? s + per : hi;
     double acc = 0.0;
     for (int64_t i = s + threadIdx.x; i < e; i += kBlock) {
-        const double v = x[perm[i]];
+        const double v = (double)x[perm[i]];
         acc += v * v;
     }
     __shared__ double red[kBlock / 64];
@@ -144,7 +144,7 @@ k_eps_partial_seg(const double *__restrict__ x, const int32_t *__restrict__ perm
 //   central: max(relstep*abs(sqrt(norm)), absstep)       (src/epsilons.jl:50-53; jacobians.jl:602)
 __global__ void __launch_bounds__(kBlock)
 k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double relstep,
-               double absstep, double dir, int is_forward, double *__restrict__ eps)
+               double absstep, double dir, int is_forward, real_t *__restrict__ eps)
 {
     const int c = blockIdx.x;
     double acc = 0.0;
@@ -156,11 +156,12 @@ k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double r
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) t += red[w];
-        const double nrm = sqrt(t);             // norm(x2)
-        const double xs = fabs(sqrt(nrm));      // abs(sqrt(tmp))
-        const double a = relstep * xs;
-        double e = (a > absstep) ? a : absstep;
-        if (is_forward) e = e * dir;
+        // norm(x2), sqrt and the step rule in the element type, as the reference computes them
+        const real_t nrm = (real_t)sqrt(t);                  // norm(x2)
+        const real_t xs = fabs(sqrt(nrm));                   // abs(sqrt(tmp))
+        const real_t a = (real_t)relstep * xs;
+        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
+        if (is_forward) e = e * (real_t)dir;
         eps[c] = e;
     }
 }
@@ -175,17 +176,17 @@ k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double r
 // ---------------------------------------------------------------------------------------------
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_perturb(const double *__restrict__ x, const CT *__restrict__ color,
-          const double *__restrict__ eps, int c_lo, int B, int64_t j0, int64_t j1,
-          double *__restrict__ X, int64_t ldx)
+k_perturb(const real_t *__restrict__ x, const CT *__restrict__ color,
+          const real_t *__restrict__ eps, int c_lo, int B, int64_t j0, int64_t j1,
+          real_t *__restrict__ X, int64_t ldx)
 {
     // j0 is even by construction (host rounds the window down), so pairs are 16-B aligned.
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t j = j0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; j < j1; j += stride) {
         const bool pair = (j + 1 < j1);
-        double v0, v1 = 0.0;
+        real_t v0, v1 = 0.0;
         if (pair) {
-            const double2 v = *reinterpret_cast<const double2 *>(x + j);
+            const r2_t v = *reinterpret_cast<const r2_t *>(x + j);
             v0 = v.x; v1 = v.y;
         } else {
             v0 = x[j];
@@ -200,19 +201,19 @@ k_perturb(const double *__restrict__ x, const CT *__restrict__ color,
         }
         c0 -= c_lo;
         for (int b = 0; b < B; ++b) {
-            const double e = eps[c_lo + b];
-            const double e0 = (c0 == b) ? e : 0.0, e1 = (c1 == b) ? e : 0.0;
+            const real_t e = eps[c_lo + b];
+            const real_t e0 = (c0 == b) ? e : 0.0, e1 = (c1 == b) ? e : 0.0;
             if (MODE == 2) {
-                double *dst = X + ((int64_t)b * ldx + j) * 2;
-                *reinterpret_cast<double2 *>(dst) = make_double2(v0, e0);
-                if (pair) *reinterpret_cast<double2 *>(dst + 2) = make_double2(v1, e1);
+                real_t *dst = X + ((int64_t)b * ldx + j) * 2;
+                *reinterpret_cast<r2_t *>(dst) = r2_t{v0, e0};
+                if (pair) *reinterpret_cast<r2_t *>(dst + 2) = r2_t{v1, e1};
             } else {
-                double *dp = X + (int64_t)b * ldx + j;
-                if (pair) *reinterpret_cast<double2 *>(dp) = make_double2(v0 + e0, v1 + e1);
+                real_t *dp = X + (int64_t)b * ldx + j;
+                if (pair) *reinterpret_cast<r2_t *>(dp) = r2_t{v0 + e0, v1 + e1};
                 else dp[0] = v0 + e0;
                 if (MODE == 1) {
-                    double *dm = X + (int64_t)(B + b) * ldx + j;
-                    if (pair) *reinterpret_cast<double2 *>(dm) = make_double2(v0 - e0, v1 - e1);
+                    real_t *dm = X + (int64_t)(B + b) * ldx + j;
+                    if (pair) *reinterpret_cast<r2_t *>(dm) = r2_t{v0 - e0, v1 - e1};
                     else dm[0] = v0 - e0;
                 }
             }
@@ -225,20 +226,20 @@ k_perturb(const double *__restrict__ x, const CT *__restrict__ color,
 // only at the rows the pattern needs, for the colour that owns the entry's column.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ double entry_value(const double *__restrict__ FXa,
-                                              const double *__restrict__ FXb, int64_t ld, int cb,
-                                              int64_t r, double e)
+__device__ __forceinline__ real_t entry_value(const real_t *__restrict__ FXa,
+                                              const real_t *__restrict__ FXb, int64_t ld, int cb,
+                                              int64_t r, real_t e)
 {
     if (MODE == 0) {
-        const double a = FXa[(int64_t)cb * ld + r];
-        const double b = FXb[r];
+        const real_t a = FXa[(int64_t)cb * ld + r];
+        const real_t b = FXb[r];
         return (a - b) / e;
     } else if (MODE == 1) {
-        const double a = FXa[(int64_t)cb * ld + r];
-        const double b = FXb[(int64_t)cb * ld + r];
+        const real_t a = FXa[(int64_t)cb * ld + r];
+        const real_t b = FXb[(int64_t)cb * ld + r];
         return (a - b) / (2 * e);
     } else {
-        const double a = FXa[((int64_t)cb * ld + r) * 2 + 1];
+        const real_t a = FXa[((int64_t)cb * ld + r) * 2 + 1];
         return a / e;
     }
 }
@@ -254,11 +255,11 @@ __device__ __forceinline__ double entry_value(const double *__restrict__ FXa,
 template <typename CT, int MODE, bool HAS_DEST, int U, bool LDS_EPS>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzcolor,
-                  const int64_t *__restrict__ dest, const double *__restrict__ FXa,
-                  const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
-                  int c_lo, int c_hi, double *__restrict__ out, int64_t n, int vec_ok)
+                  const int64_t *__restrict__ dest, const real_t *__restrict__ FXa,
+                  const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps,
+                  int c_lo, int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok)
 {
-    extern __shared__ double s_eps[];
+    extern __shared__ real_t s_eps[];
     const int nB = c_hi - c_lo;
     if (LDS_EPS) {
         for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
@@ -283,7 +284,7 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
     }
     // phase 2: branch-free gathers.  Entries that will not be written (another chunk's colour, a
     // column without colour, past the end) gather from slot 0 / their own valid row and are discarded.
-    double a[2 * U], b[2 * U], e[2 * U];
+    real_t a[2 * U], b[2 * U], e[2 * U];
     bool valid[2 * U];
 #pragma unroll
     for (int k = 0; k < 2 * U; ++k) {
@@ -297,10 +298,10 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
         else { a[k] = FXa[at * 2 + 1]; b[k] = 0.0; }
     }
     // phase 3: the difference (src/jacobians.jl:565 / 607 / 635), IEEE division
-    double v[2 * U];
+    real_t v[2 * U];
 #pragma unroll
     for (int k = 0; k < 2 * U; ++k) {
-        double q;
+        real_t q;
         if (MODE == 0) q = (a[k] - b[k]) / e[k];
         else if (MODE == 1) q = (a[k] - b[k]) / (2 * e[k]);
         else q = a[k] / e[k];
@@ -313,7 +314,7 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
         const int64_t p = t0 + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
         const bool w0 = valid[2 * u] | ((c[2 * u] == none) & (c_lo == 0));
         const bool w1 = valid[2 * u + 1] | ((c[2 * u + 1] == none) & (c_lo == 0));
-        double q0 = v[2 * u], q1 = v[2 * u + 1];
+        real_t q0 = v[2 * u], q1 = v[2 * u + 1];
         asm volatile("" : "+v"(q0), "+v"(q1));  // keep the divisions above the branch (no sinking / duplication)
         if (HAS_DEST) {
             if (w0) out[dest[p]] = q0;
@@ -342,17 +343,17 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
 template <typename CT, int MODE, bool LDS_EPS, bool ALLW, bool SORTED>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ scol,
-                    const uint16_t *__restrict__ spos, const double *__restrict__ FXa,
-                    const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps, int c_lo,
-                    int c_hi, double *__restrict__ out, int64_t n, int vec_ok)
+                    const uint16_t *__restrict__ spos, const real_t *__restrict__ FXa,
+                    const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps, int c_lo,
+                    int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok)
 {
     constexpr int E = kSortTile / kBlock;   // entries per thread (8); entry e of thread t is tile + e*256 + t,
                                             // so one wave-level gather covers 64 CONSECUTIVE sorted entries
-    extern __shared__ double s_mem[];
-    double *s_val = s_mem;                                             // kSortTile values
+    extern __shared__ real_t s_mem[];
+    real_t *s_val = s_mem;                                             // kSortTile values
     uint8_t *s_flag = reinterpret_cast<uint8_t *>(s_mem + kSortTile);  // kSortTile flags (ALLW: unused)
     const int nB = c_hi - c_lo;
-    double *s_eps = s_mem + kSortTile + (ALLW ? 0 : kSortTile / 8);
+    real_t *s_eps = s_mem + kSortTile + (ALLW ? 0 : kSortTile / sizeof(real_t));   // flags: one byte per entry
     if (LDS_EPS)
         for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
     const int none = ColorTraits<CT>::none;
@@ -370,7 +371,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
         c[k] = (int)scol[t0 + lq];
         pos[k] = SORTED ? (int)spos[t0 + lq] : lq;
     }
-    double a[E], b[E], e[E];
+    real_t a[E], b[E], e[E];
     bool valid[E];
 #pragma unroll
     for (int k = 0; k < E; ++k) {
@@ -385,7 +386,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-        double q;
+        real_t q;
         if (MODE == 0) q = (a[k] - b[k]) / e[k];
         else if (MODE == 1) q = (a[k] - b[k]) / (2 * e[k]);
         else q = a[k] / e[k];
@@ -415,7 +416,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
 // window loads in flight back to back -- one memory round trip per tile instead of one per loop iteration.
 typedef __attribute__((address_space(3))) void fd_lds_void;
 typedef const __attribute__((address_space(1))) void fd_glb_void;
-__device__ __forceinline__ void glds16(const double *g, double *l)
+__device__ __forceinline__ void glds16(const real_t *g, real_t *l)
 {
     __builtin_amdgcn_global_load_lds((fd_glb_void *)g, (fd_lds_void *)l, 16, 0, 0);
 }
@@ -438,14 +439,14 @@ __device__ __forceinline__ void glds16(const double *g, double *l)
 template <int MODE, int NCT, bool FXB_VEC, int U, bool DMA>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
-                    const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
-                    const double *__restrict__ eps, int c_lo, int c_hi, double *__restrict__ out, int64_t n,
+                    const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
+                    const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t n,
                     int vec_ok, int wp)
 {
     constexpr int T = U * kBlock * 2;             // entries per tile; U pairs of entries per thread
-    extern __shared__ double s_mem_w[];
-    double *s_eps = s_mem_w;                      // step sizes of the tile's colours (the division happens per stored entry)
-    double *s_win = s_mem_w + kWinMaxCol;         // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
+    extern __shared__ real_t s_mem_w[];
+    real_t *s_eps = s_mem_w;                      // step sizes of the tile's colours (the division happens per stored entry)
+    real_t *s_win = s_mem_w + kWinMaxCol;         // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
     const int64_t ntiles = (n + T - 1) / T;
     const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
     if (tile_id >= ntiles) return;
@@ -484,7 +485,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
                                   : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
                                   : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
                 for (int a = wave; a < narr; a += kBlock / 64) {
-                    const double *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
+                    const real_t *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
                                     : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
                     glds16(g, s_win + (size_t)a * wp + ch * 128);
                 }
@@ -541,7 +542,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t p = t0 + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
-        double q[2];
+        real_t q[2];
         bool w[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -550,10 +551,10 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
             const bool colored = (cd & 0xC000u) == 0;
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
-            double df = s_win[at];
+            real_t df = s_win[at];
             if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];   // fx | FXb colour
-            const double e = s_eps[valid ? cs : 0];
-            const double v = (MODE == 1) ? df / (2 * e) : df / e;
+            const real_t e = s_eps[valid ? cs : 0];
+            const real_t v = (MODE == 1) ? df / (2 * e) : df / e;
             q[h] = valid ? v : 0.0;
             w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
         }
@@ -580,14 +581,14 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
 template <int MODE, int NCT, bool FXB_VEC, bool DMA>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict__ desc,
-                      const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld, int64_t M,
-                      const double *__restrict__ eps, int c_lo, int c_hi, double *__restrict__ out, int64_t ntiles,
+                      const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
+                      const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t ntiles,
                       int vec_ok, int wp)
 {
-    extern __shared__ double s_mem_2d[];
-    double *s_eps = s_mem_2d;                                  // kWinMaxCol step sizes
+    extern __shared__ real_t s_mem_2d[];
+    real_t *s_eps = s_mem_2d;                                  // kWinMaxCol step sizes
     int *s_desc = reinterpret_cast<int *>(s_mem_2d + kWinMaxCol);   // kW2Desc ints
-    double *s_win = s_mem_2d + kWinMaxCol + kW2Desc / 2;       // [ncol][wp] differences
+    real_t *s_win = s_mem_2d + kWinMaxCol + kW2Desc * 4 / sizeof(real_t);   // [ncol][wp] differences
     const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
     if (tile_id >= ntiles) return;
     if (threadIdx.x < kW2Desc) s_desc[threadIdx.x] = desc[tile_id * kW2Desc + threadIdx.x];
@@ -614,7 +615,7 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
                 const int pbase = k ? s_desc[7 + 2 * k] : 0;
                 const int64_t row = (int64_t)s_desc[8 + 2 * k] + 2 * (i - pbase);
                 for (int a = wave; a < narr; a += kBlock / 64) {
-                    const double *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
+                    const real_t *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
                                     : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
                     glds16(g, s_win + (size_t)a * wp + ch * 128);
                 }
@@ -671,7 +672,7 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
         const int ebase = r ? s_desc[31 + 3 * r] : 0;
         const int64_t o0 = ((int64_t)(uint32_t)s_desc[32 + 3 * r]) | ((int64_t)s_desc[33 + 3 * r] << 32);
         const int64_t p = o0 + (e - ebase);
-        double q[2];
+        real_t q[2];
         bool w[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -680,10 +681,10 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             const bool colored = (cd & 0xC000u) == 0;
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
-            double df = s_win[at];
+            real_t df = s_win[at];
             if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];
-            const double ee = s_eps[valid ? cs : 0];
-            const double v = (MODE == 1) ? df / (2 * ee) : df / ee;
+            const real_t ee = s_eps[valid ? cs : 0];
+            const real_t v = (MODE == 1) ? df / (2 * ee) : df / ee;
             q[h] = valid ? v : 0.0;
             w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
         }
@@ -704,10 +705,10 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
 //   d[j-j0], dl[j-j0], du[j-1-du0] with du0 = max(j0-1,0).
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_decompress_tridiag(const CT *__restrict__ color, const double *__restrict__ FXa,
-                     const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
+k_decompress_tridiag(const CT *__restrict__ color, const real_t *__restrict__ FXa,
+                     const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps,
                      int c_lo, int c_hi, int64_t N, int64_t j0, int64_t j1,
-                     double *__restrict__ dl, double *__restrict__ d, double *__restrict__ du)
+                     real_t *__restrict__ dl, real_t *__restrict__ d, real_t *__restrict__ du)
 {
     const int none = ColorTraits<CT>::none;
     const int64_t du0 = j0 > 0 ? j0 - 1 : 0;
@@ -723,7 +724,7 @@ k_decompress_tridiag(const CT *__restrict__ color, const double *__restrict__ FX
             continue;
         }
         if (c < c_lo || c >= c_hi) continue;
-        const double e = eps[c];
+        const real_t e = eps[c];
         const int cb = c - c_lo;
         d[j - j0] = entry_value<MODE>(FXa, FXb, ld, cb, j, e);
         if (j + 1 < N) dl[j - j0] = entry_value<MODE>(FXa, FXb, ld, cb, j + 1, e);
@@ -740,15 +741,15 @@ k_decompress_tridiag(const CT *__restrict__ color, const double *__restrict__ FX
 constexpr int kTriTile = 1024;
 template <typename CT, int MODE, int NCT>
 __global__ void __launch_bounds__(kBlock)
-k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restrict__ FXa,
-                            const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps, int c_lo,
-                            int c_hi, int64_t N, int64_t j0, int64_t j1, double *__restrict__ dl,
-                            double *__restrict__ d, double *__restrict__ du, int fxb_vec, int vec_ok)
+k_decompress_tridiag_window(const CT *__restrict__ color, const real_t *__restrict__ FXa,
+                            const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps, int c_lo,
+                            int c_hi, int64_t N, int64_t j0, int64_t j1, real_t *__restrict__ dl,
+                            real_t *__restrict__ d, real_t *__restrict__ du, int fxb_vec, int vec_ok)
 {
     constexpr int WP = kTriTile + 4;                 // LDS pitch (rows a-2 .. a+kTriTile+1, even start)
-    extern __shared__ double s_mem_t[];              // kWinMaxCol step sizes, then ncol x WP differences
-    double *s_eps = s_mem_t;
-    double *s_win = s_mem_t + kWinMaxCol;
+    extern __shared__ real_t s_mem_t[];              // kWinMaxCol step sizes, then ncol x WP differences
+    real_t *s_eps = s_mem_t;
+    real_t *s_win = s_mem_t + kWinMaxCol;
     const int none = ColorTraits<CT>::none;
     const int64_t ntiles = (j1 - j0 + kTriTile - 1) / kTriTile;
     const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
@@ -799,9 +800,9 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restri
     __syncthreads();
 
     const int64_t du0 = j0 > 0 ? j0 - 1 : 0;
-    auto quot = [&](int c, int64_t r) -> double {   // D_c[r] for a colour of this chunk
-        const double df = s_win[(c - c_lo) * WP + (int)(r - rbeg)];
-        const double e = s_eps[c - c_lo];
+    auto quot = [&](int c, int64_t r) -> real_t {   // D_c[r] for a colour of this chunk
+        const real_t df = s_win[(c - c_lo) * WP + (int)(r - rbeg)];
+        const real_t e = s_eps[c - c_lo];
         return (MODE == 1) ? df / (2 * e) : df / e;
     };
     if (a == j0 && j0 > 0 && threadIdx.x == 0) {   // du of the plan's first column (its pair partner is another rank's)
@@ -822,9 +823,9 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restri
         const bool z1x = (i + 1 < N) & (i + 1 < j1) & (c1 == none) & (c_lo == 0), z2 = (i + 2 < N) & (i + 2 < j1) & (c2 == none) & (c_lo == 0);
         // d[i], d[i+1]
         {
-            const double q0 = in0 ? quot(c0, i) : 0.0, q1 = in1 ? quot(c1, i + 1) : 0.0;
+            const real_t q0 = in0 ? quot(c0, i) : 0.0, q1 = in1 ? quot(c1, i + 1) : 0.0;
             const bool w0 = in0 | z0, w1 = in1 | z1;
-            double *o = d + (i - j0);
+            real_t *o = d + (i - j0);
             if (__builtin_amdgcn_ballot_w64(w0 & w1 & (vec_ok & 1)) == __builtin_amdgcn_ballot_w64(true)) {
                 *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
             } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
@@ -832,9 +833,9 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restri
         // dl[i] (column i, row i+1), dl[i+1] (column i+1, row i+2)
         {
             const bool e0 = i + 1 < N, e1 = (i + 1 < b) & (i + 2 < N);
-            const double q0 = (in0 & e0) ? quot(c0, i + 1) : 0.0, q1 = (in1 & e1) ? quot(c1, i + 2) : 0.0;
+            const real_t q0 = (in0 & e0) ? quot(c0, i + 1) : 0.0, q1 = (in1 & e1) ? quot(c1, i + 2) : 0.0;
             const bool w0 = (in0 | z0) & e0, w1 = (in1 | z1) & e1;
-            double *o = dl + (i - j0);
+            real_t *o = dl + (i - j0);
             if (__builtin_amdgcn_ballot_w64(w0 & w1 & ((vec_ok >> 1) & 1)) == __builtin_amdgcn_ballot_w64(true)) {
                 *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
             } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
@@ -842,9 +843,9 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restri
         // du[i] (column i+1, row i), du[i+1] (column i+2, row i+1); columns must lie inside [j0, j1)
         {
             const bool e0 = (i + 1 < N) & (i + 1 < j1), e1 = (i + 1 < b) & (i + 2 < N) & (i + 2 < j1);
-            const double q0 = (in1x & e0) ? quot(c1, i) : 0.0, q1 = (in2 & e1) ? quot(c2, i + 1) : 0.0;
+            const real_t q0 = (in1x & e0) ? quot(c1, i) : 0.0, q1 = (in2 & e1) ? quot(c2, i + 1) : 0.0;
             const bool w0 = (in1x | z1x) & e0, w1 = (in2 | z2) & e1;
-            double *o = du + (i - du0);
+            real_t *o = du + (i - du0);
             if (__builtin_amdgcn_ballot_w64(w0 & w1 & ((vec_ok >> 2) & 1)) == __builtin_amdgcn_ballot_w64(true)) {
                 *reinterpret_cast<d2_t *>(o) = d2_t{q0, q1};
             } else { if (w0) o[0] = q0; if (w1) o[1] = q1; }
@@ -857,10 +858,10 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const double *__restri
 //   slot => dense coalesced stores, implicit indices, one colour byte per column (L1-resident).
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_decompress_banded(const CT *__restrict__ color, const double *__restrict__ FXa,
-                    const double *__restrict__ FXb, int64_t ld, const double *__restrict__ eps,
+k_decompress_banded(const CT *__restrict__ color, const real_t *__restrict__ FXa,
+                    const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps,
                     int c_lo, int c_hi, int64_t M, int64_t l, int64_t u, int64_t j0, int64_t j1,
-                    double *__restrict__ data)
+                    real_t *__restrict__ data)
 {
     const int none = ColorTraits<CT>::none;
     const int64_t w = l + u + 1;
@@ -889,9 +890,9 @@ template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ rlo,
                       const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
-                      const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld,
-                      const double *__restrict__ eps, int c_lo, int c_hi, int64_t j0,
-                      int64_t ncols, double *__restrict__ data)
+                      const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
+                      const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t j0,
+                      int64_t ncols, real_t *__restrict__ data)
 {
     const int none = ColorTraits<CT>::none;
     const int lane = threadIdx.x & 63;
@@ -907,7 +908,7 @@ k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ 
             continue;
         }
         if (c < c_lo || c >= c_hi) continue;
-        const double e = eps[c];
+        const real_t e = eps[c];
         for (int k = lane; k < n; k += 64)
             data[o + k] = entry_value<MODE>(FXa, FXb, ld, c - c_lo, r0 + k, e);
     }
@@ -918,13 +919,13 @@ k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ 
 //   eps_i = compute_epsilon(fdtype, x[i], relstep, absstep, dir)  (src/epsilons.jl:26-29,50-53)
 //   and J[:, i] = (f(x + eps_i e_i) - f(x)) / eps_i.
 __global__ void __launch_bounds__(kBlock)
-k_eps_element(const double *__restrict__ x, int64_t ncols, double relstep, double absstep, double dir,
-              int is_forward, double *__restrict__ eps)
+k_eps_element(const real_t *__restrict__ x, int64_t ncols, double relstep, double absstep, double dir,
+              int is_forward, real_t *__restrict__ eps)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ncols; i += stride) {
-        const double a = relstep * fabs(x[i]);
-        double e = (a > absstep) ? a : absstep;
+        const real_t a = (real_t)relstep * fabs(x[i]);
+        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
         if (is_forward) e = e * dir;
         eps[i] = e;
     }
@@ -932,8 +933,8 @@ k_eps_element(const double *__restrict__ x, int64_t ncols, double relstep, doubl
 
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
-k_decompress_dense(const double *__restrict__ FXa, const double *__restrict__ FXb, int64_t ld,
-                   const double *__restrict__ eps, int c_lo, int c_hi, int64_t M, double *__restrict__ J)
+k_decompress_dense(const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
+                   const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t M, real_t *__restrict__ J)
 {
     const int64_t total = (int64_t)(c_hi - c_lo) * M;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -945,13 +946,13 @@ k_decompress_dense(const double *__restrict__ FXa, const double *__restrict__ FX
 
 // Stream-copy ceiling probe (16 B per lane, grid-stride).
 __global__ void __launch_bounds__(kBlock)
-k_stream_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n)
+k_stream_copy(const r2_t *__restrict__ src, r2_t *__restrict__ dst, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(kBlock) k_fill(double *__restrict__ p, int64_t n, double v)
+__global__ void __launch_bounds__(kBlock) k_fill(real_t *__restrict__ p, int64_t n, real_t v)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -988,7 +989,7 @@ static inline int grid_for(int64_t work_items, int per_block, int num_cus)
 }
 
 template <typename CT>
-static int launch_eps_t(fd_plan *p, const double *x, double relstep, double absstep, double dir)
+static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double absstep, double dir)
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
@@ -1014,7 +1015,7 @@ static int launch_eps_t(fd_plan *p, const double *x, double relstep, double abss
     return FD_OK;
 }
 
-int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, double dir)
+int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir)
 {
     if (p->kind == K_DENSE) {
         hipLaunchKernelGGL(k_eps_element, dim3(grid_for(p->C, kBlock, p->ctx->num_cus)), dim3(kBlock), 0, p->ctx->stream,
@@ -1027,7 +1028,7 @@ int launch_eps(fd_plan *p, const double *x, double relstep, double absstep, doub
 }
 
 template <typename CT, int MODE>
-static int launch_perturb_tm(fd_plan *p, const double *x, int c_lo, int B)
+static int launch_perturb_tm(fd_plan *p, const real_t *x, int c_lo, int B)
 {
     const int64_t j0 = p->x0 & ~(int64_t)1;  // even start => 16-B aligned pairs
     const int64_t j1 = p->x1;
@@ -1038,7 +1039,7 @@ static int launch_perturb_tm(fd_plan *p, const double *x, int c_lo, int B)
     return FD_OK;
 }
 
-int launch_perturb(fd_plan *p, const double *x, int c_lo, int B)
+int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B)
 {
 #define FD_DISPATCH(CT)                                                        \
     switch (p->fdtype) {                                                       \
@@ -1051,8 +1052,8 @@ int launch_perturb(fd_plan *p, const double *x, int c_lo, int B)
 }
 
 template <int MODE>
-static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, const double *FXb, int c_lo, int c_hi,
-                            double *out)
+static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, const real_t *FXb, int c_lo, int c_hi,
+                            real_t *out)
 {
     hipStream_t s = p->ctx->stream;
     // LDS-DMA staging is bit-identical but measured no faster on MI355X (tridiagonal forward 123 vs 124 us) and slower
@@ -1060,13 +1061,13 @@ static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, con
     static const bool dma_off = env_i64("FDJAC_DMA", 0) == 0;
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
     const bool fxvec = (MODE != 0) || (fx == p->d_fx);
-    const bool dma = (MODE != 2) && fxvec && !dma_off;             // LDS-DMA staging of the raw windows
+    const bool dma = (MODE != 2) && fxvec && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
     const int wp = (2 * p->win_pairs + 127) & ~127;               // LDS pitch: whole 1-KiB DMA chunks
     const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
-    const int vok = (((uintptr_t)out) & 15) == 0;
+    const int vok = (((uintptr_t)out) & kPairMask) == 0;
     if (p->window2d) {
         const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
-        const size_t shm2 = sizeof(double) * ((size_t)wp * (size_t)narr + kWinMaxCol + kW2Desc / 2);
+        const size_t shm2 = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + 4 * (size_t)kW2Desc;
 #define FD_LAUNCH_W2(NCT, FV, DM)                                                                                  \
         hipLaunchKernelGGL((k_decompress_window2d<MODE, NCT, FV, DM>), dim3((unsigned)g2), dim3(kBlock), shm2, s,    \
                            p->d_wcode, p->d_w2desc, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo, c_hi, out, p->w2_ntiles,  \
@@ -1079,7 +1080,7 @@ static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, con
         return;
     }
     const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
-    const size_t shmw = sizeof(double) * ((size_t)wp * (size_t)narr + kWinMaxCol);
+    const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol);
 #define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
     hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
                        (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,       \
@@ -1094,12 +1095,12 @@ static void launch_window_m(fd_plan *p, const double *fx, const double *FXa, con
 }
 
 template <typename CT, int MODE>
-static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs)
+static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi, real_t *const *outs)
 {
     hipStream_t s = p->ctx->stream;
     const int B = c_hi - c_lo;
-    const double *FXa = p->d_FX;
-    const double *FXb = (MODE == 0) ? fx : p->d_FX + (int64_t)B * p->ldf;  // central: minus points
+    const real_t *FXa = p->d_FX;
+    const real_t *FXb = (MODE == 0) ? fx : p->d_FX + (int64_t)B * p->ldf;  // central: minus points
     const CT *color = (const CT *)p->d_color;
     switch (p->kind) {
     case K_CSC:
@@ -1110,8 +1111,8 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
             const bool ldsq = B <= kEpsLdsMax;
             const bool allw = (p->nchunks == 1) && !p->has_none && p->own_c0 == 0 && (p->own_c1 < 0 || p->own_c1 >= p->C);
             const int64_t gq = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
-            const size_t shmq = sizeof(double) * (size_t)(kSortTile + (allw ? 0 : kSortTile / 8) + (ldsq ? B : 0));
-            const int vok = (((uintptr_t)outs[0]) & 15) == 0;
+            const size_t shmq = sizeof(real_t) * (size_t)(kSortTile + (ldsq ? B : 0)) + (allw ? 0 : (size_t)kSortTile);
+            const int vok = (((uintptr_t)outs[0]) & kPairMask) == 0;
 #define FD_LAUNCH_SORTED(LL, AW, SS)                                                                                 \
             hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
                                p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
@@ -1138,8 +1139,8 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
         const int64_t tile = (int64_t)U * kBlock * 2;
         const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);
         const bool lds = B <= kEpsLdsMax;
-        const size_t shm = lds ? sizeof(double) * (size_t)B : 0;
-        const int vec_ok = (((uintptr_t)outs[0]) & 15) == 0;
+        const size_t shm = lds ? sizeof(real_t) * (size_t)B : 0;
+        const int vec_ok = (((uintptr_t)outs[0]) & kPairMask) == 0;
 #define FD_LAUNCH_LIST(HD, UU, LL, DEST, VOK)                                                                    \
         hipLaunchKernelGGL((k_decompress_list<CT, MODE, HD, UU, LL>), dim3((unsigned)g), dim3(kBlock), shm, s,   \
                            p->d_rowval, (const CT *)p->d_nzcolor, DEST, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, \
@@ -1166,9 +1167,9 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
             const int64_t nt = (p->col1 - p->col0 + kTriTile - 1) / kTriTile;
             const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
             const int fxvec = (MODE != 0) || (fx == p->d_fx);
-            const int vok = ((((uintptr_t)outs[1]) & 15) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & 15) == 0 ? 2 : 0) |
-                            (((((uintptr_t)outs[2]) + 8 * (uintptr_t)(p->col0 - du0)) & 15) == 0 ? 4 : 0);
-            const size_t shmt = sizeof(double) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
+            const int vok = ((((uintptr_t)outs[1]) & kPairMask) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 2 : 0) |
+                            (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0);
+            const size_t shmt = sizeof(real_t) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
             hipLaunchKernelGGL((k_decompress_tridiag_window<CT, MODE, 4>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock),
                                shmt, s, color, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],
                                outs[1], outs[2], fxvec, vok);
@@ -1208,7 +1209,7 @@ static int launch_decompress_tm(fd_plan *p, const double *fx, int c_lo, int c_hi
     return FD_OK;
 }
 
-int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *const *outs, int mode)
+int launch_decompress(fd_plan *p, const real_t *fx, int c_lo, int c_hi, real_t *const *outs, int mode)
 {
 #define FD_DISPATCH(CT)                                                                 \
     switch (mode) {                                                                \
@@ -1220,7 +1221,7 @@ int launch_decompress(fd_plan *p, const double *fx, int c_lo, int c_hi, double *
 #undef FD_DISPATCH
 }
 
-int launch_fill(fd_ctx *ctx, double *ptr, int64_t n, double v)
+int launch_fill(fd_ctx *ctx, real_t *ptr, int64_t n, real_t v)
 {
     if (n <= 0) return FD_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, kBlock, ctx->num_cus)), dim3(kBlock), 0, ctx->stream, ptr, n, v);
@@ -1232,7 +1233,7 @@ int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16)
 {
     // one 16-B element per thread, uncapped grid: the fastest copy geometry measured on MI355X (scripts/ubench)
     hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
-                       (const double2 *)src, (double2 *)dst, n16);
+                       (const r2_t *)src, (r2_t *)dst, n16);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }

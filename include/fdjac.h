@@ -90,7 +90,7 @@ typedef int (*fd_f_launch)(void *fctx, void *fx, const void *x, int64_t nbatch, 
 typedef struct fd_lazy_points {
     const void *x;        /* base point, double[N]                                           */
     const void *color;    /* per-column colour, 0-based; none = 0xFF (1-byte) / -1 (4-byte)  */
-    const double *eps;    /* step size per colour (device), indexed by 0-based colour         */
+    const void *eps;      /* step size per colour (device, element type of x), indexed by 0-based colour */
     void *base_out;       /* NULL or double[M] for f!(x)                                      */
     int32_t color_bytes;  /* 1 or 4                                                           */
     int32_t c_lo;         /* first colour of the batch                                        */
