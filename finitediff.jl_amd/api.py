@@ -28,10 +28,11 @@ _EPS = float(np.finfo(np.float64).eps)
 def default_relstep(fdtype, T=np.float64):
     """src/epsilons.jl:133-144"""
     fdtype = _norm_fdtype(fdtype)
+    eps = np.finfo(np.dtype(T)).eps              # eps(eltype(x)): Float32 problems take sqrt / cbrt of eps(Float32)
     if fdtype == "forward":
-        return float(np.sqrt(_EPS))
+        return float(np.sqrt(eps))
     if fdtype == "central":
-        return float(np.cbrt(_EPS))
+        return float(np.cbrt(eps))
     return 1.0
 
 
@@ -48,19 +49,29 @@ def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
-def _ptr(a, what):
-    """(pointer, FD_HOST|FD_DEVICE, keepalive) of a float64 vector-like."""
+def _dtype_of(a):
+    """numpy dtype (float64 / float32) of a torch tensor or numpy array; None for anything else."""
     if _is_torch(a):
         import torch
-        if a.dtype != torch.float64:
-            raise TypeError("%s must be float64" % what)
+        return {torch.float64: np.dtype(np.float64), torch.float32: np.dtype(np.float32)}.get(a.dtype)
+    if isinstance(a, np.ndarray) and a.dtype in (np.float64, np.float32):
+        return a.dtype
+    return None
+
+
+def _ptr(a, what, dtype=np.float64):
+    """(pointer, FD_HOST|FD_DEVICE, keepalive) of a vector-like of the plan's element type."""
+    dtype = np.dtype(dtype)
+    if _dtype_of(a) != dtype:
+        raise TypeError("%s must be a %s numpy array or torch tensor" % (what, dtype.name))
+    if _is_torch(a):
         if a.is_cuda:
             if not _colmajor_contig(a):
                 raise ValueError("%s must be contiguous (column-major for matrices)" % what)
             return a.data_ptr(), _l.DEVICE, a
         a = a.numpy()
-    if not isinstance(a, np.ndarray) or a.dtype != np.float64:
-        raise TypeError("%s must be a float64 numpy array or torch tensor" % what)
+    if not isinstance(a, np.ndarray) or a.dtype != dtype:
+        raise TypeError("%s must be a %s numpy array or torch tensor" % (what, dtype.name))
     if not (a.flags.f_contiguous or a.ndim <= 1 and a.flags.c_contiguous):
         raise ValueError("%s must be contiguous (column-major for matrices)" % what)
     return a.ctypes.data, _l.HOST, a
@@ -142,8 +153,8 @@ class BandedBlockBandedMatrix:
 def _similar(a, n):
     if _is_torch(a):
         import torch
-        return torch.zeros(n, dtype=torch.float64, device=a.device)
-    return np.zeros(n)
+        return torch.zeros(n, dtype=a.dtype, device=a.device)
+    return np.zeros(n, dtype=getattr(a, "dtype", np.float64))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -197,9 +208,10 @@ class Context:
 class BuiltinF:
     """One of libfdjac's device f! families (fd_builtin_f_create): the reference's fixtures."""
 
-    def __init__(self, family, *params, ctx=None):
+    def __init__(self, family, *params, ctx=None, dtype=np.float64):
         self.ctx = ctx or Context.default()
-        L = self.ctx.L
+        self.dtype = np.dtype(dtype)
+        L = self.Lt = _l.typed(self.ctx.L, self.dtype)
         prm = (C.c_int64 * max(len(params), 1))(*[int(p) for p in params])
         self.fn = _l.F_LAUNCH()
         self.fctx = C.c_void_p()
@@ -212,19 +224,19 @@ class BuiltinF:
     def lazy_fn(self):
         """The family's lazy-point launcher (fd_builtin_f_lazy) or None if it has none."""
         fn = _l.F_LAUNCH_LAZY()
-        rc = self.ctx.L.fd_builtin_f_lazy(self.fctx, C.byref(fn))
+        rc = self.Lt.fd_builtin_f_lazy(self.fctx, C.byref(fn))
         return fn if rc == 0 else None
 
     @property
     def lazy_caps(self):
         """FD_LAZY_CAP_* bits of the lazy launcher (fd_builtin_f_lazy_caps)."""
         caps = C.c_int32()
-        rc = self.ctx.L.fd_builtin_f_lazy_caps(self.fctx, C.byref(caps))
+        rc = self.Lt.fd_builtin_f_lazy_caps(self.fctx, C.byref(caps))
         return caps.value if rc == 0 else 0
 
     def counts(self):
         a, b = C.c_int64(), C.c_int64()
-        _l.check(self.ctx.L.fd_builtin_f_counts(self.fctx, C.byref(a), C.byref(b)))
+        _l.check(self.Lt.fd_builtin_f_counts(self.fctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     @property
@@ -235,8 +247,9 @@ class BuiltinF:
 class _DevView:
     """__cuda_array_interface__ holder so torch can view library-owned device memory."""
 
-    def __init__(self, ptr, n, complex_):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<c16" if complex_ else "<f8",
+    def __init__(self, ptr, n, complex_, f32=False):
+        ts = ("<c8" if complex_ else "<f4") if f32 else ("<c16" if complex_ else "<f8")
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": ts,
                                          "data": (int(ptr), False), "version": 2, "strides": None}
 
 
@@ -248,9 +261,11 @@ class TorchF:
     ROCArrays.  Work is enqueued on the context's stream; nothing synchronises.
     """
 
-    def __init__(self, fn, M, N, ctx=None):
+    def __init__(self, fn, M, N, ctx=None, dtype=np.float64):
         import torch
         self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        f32 = self.dtype == np.float32
         self.fn_py, self.M, self.N = fn, int(M), int(N)
         self.fcalls = 0
         self.error = None
@@ -258,12 +273,12 @@ class TorchF:
 
         def _launch(_fctx, fx, x, nbatch, xs, fs, r0, r1, is_complex, stream):
             try:
-                sz = 16 if is_complex else 8
+                sz = (8 if is_complex else 4) if f32 else (16 if is_complex else 8)
                 cm = torch.cuda.stream(ext) if ext is not None else _nullctx()
                 with cm:
                     for b in range(nbatch):
-                        xv = torch.as_tensor(_DevView(x + b * xs * sz, self.N, is_complex), device="cuda")
-                        fv = torch.as_tensor(_DevView(fx + b * fs * sz, self.M, is_complex), device="cuda")
+                        xv = torch.as_tensor(_DevView(x + b * xs * sz, self.N, is_complex, f32), device="cuda")
+                        fv = torch.as_tensor(_DevView(fx + b * fs * sz, self.M, is_complex, f32), device="cuda")
                         self.fcalls += 1
                         fn(fv, xv)
                 return 0
@@ -286,13 +301,14 @@ class _nullctx:
 class Plan:
     """fd_plan handle."""
 
-    def __init__(self, ctx, handle, fdtype):
-        self.ctx, self.handle, self.fdtype = ctx, handle, fdtype
-        self._fin = weakref.finalize(self, ctx.L.fd_plan_destroy, handle)
+    def __init__(self, ctx, handle, fdtype, dtype=np.float64):
+        self.ctx, self.handle, self.fdtype, self.dtype = ctx, handle, fdtype, np.dtype(dtype)
+        self.Lt = _l.typed(ctx.L, self.dtype)
+        self._fin = weakref.finalize(self, self.Lt.fd_plan_destroy, handle)
 
     def info(self, key):
         v = C.c_int64()
-        _l.check(self.ctx.L.fd_plan_info(self.handle, key, C.byref(v)))
+        _l.check(self.Lt.fd_plan_info(self.handle, key, C.byref(v)))
         return v.value
 
     @property
@@ -317,17 +333,17 @@ class Plan:
     def epsilons(self):
         n = self.ncolors
         buf = (C.c_double * max(n, 1))()
-        _l.check(self.ctx.L.fd_plan_get_epsilons(self.handle, buf))
+        _l.check(self.Lt.fd_plan_get_epsilons(self.handle, buf))
         return np.array(buf[:n])
 
     def enable_timing(self, level=2):
         """0 off; 1 = diff+decompress kernel and whole call only; 2 = every stage."""
-        _l.check(self.ctx.L.fd_plan_enable_timing(self.handle, int(level)))
+        _l.check(self.Lt.fd_plan_enable_timing(self.handle, int(level)))
 
     def timings(self):
         ms = (C.c_double * 5)()
         cnt = (C.c_int64 * 5)()
-        _l.check(self.ctx.L.fd_plan_get_timings(self.handle, ms, cnt))
+        _l.check(self.Lt.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
     def set_lazy(self, f, imag_only=True):
@@ -336,17 +352,17 @@ class Plan:
         if f is not None and fn is None:
             raise ValueError("this f! has no lazy-point launcher")
         self._lazy_keep = fn
-        _l.check(self.ctx.L.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
+        _l.check(self.Lt.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
         caps = int(getattr(f, "lazy_caps", 0)) if (f is not None and imag_only) else 0
-        _l.check(self.ctx.L.fd_plan_set_lazy_caps(self.handle, caps))
+        _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
         """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""
-        L = self.ctx.L
-        xp, xk, _k1 = _ptr(x, "x")
+        L = self.Lt
+        xp, xk, _k1 = _ptr(x, "x", self.dtype)
         ptrs, kinds, keep = [], set(), []
         for o in outs:
-            p, k, ka = _ptr(o, "output")
+            p, k, ka = _ptr(o, "output", self.dtype)
             ptrs.append(p)
             kinds.add(k)
             keep.append(ka)
@@ -356,7 +372,7 @@ class Plan:
         arr = (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
         fp, fk = None, _l.DEVICE
         if f_in is not None:
-            fp, fk, _k2 = _ptr(f_in, "f_in")
+            fp, fk, _k2 = _ptr(f_in, "f_in", self.dtype)
         rel = -1.0 if relstep is None else float(relstep)
         ab = -1.0 if absstep is None else float(absstep)
         if not sync:
@@ -390,12 +406,12 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None):
+              color_range=None, dtype=np.float64):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
     ctx = ctx or Context.default()
-    L = ctx.L
+    L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
     o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range)
     h = C.c_void_p()
@@ -451,7 +467,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
             if ncols > n:
                 raise IndexError("BoundsError: maximum(colorvec) > length(x)")
             _l.check(L.fd_plan_create_dense(ctx.handle, m, n, ncols, C.byref(o), C.byref(h)))
-    return Plan(ctx, h, fdtype)
+    return Plan(ctx, h, fdtype, dtype)
 
 
 def _findstructralnz(A):
@@ -515,13 +531,14 @@ class JacobianCache:
         n = int(np.prod(x1.shape))
         self.colorvec = np.arange(1, n + 1, dtype=np.int64) if colorvec is None else colorvec
         self.sparsity = sparsity
+        self.dtype = _dtype_of(x1) or np.dtype(np.float64)      # eltype(x): selects the fd_* / fd32_* instantiation
         self._plans = {}
 
     def _plan_for(self, J, sparsity, colorvec, ctx):
         key = (type(J).__name__, id(sparsity), id(colorvec), self.fdtype, tuple(getattr(J, "shape", ())))
         ent = self._plans.get(key)
         if ent is None or ent[1] is not sparsity or ent[2] is not colorvec:
-            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx), sparsity, colorvec)
+            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype), sparsity, colorvec)
             self._plans[key] = ent
         return ent[0]
 
@@ -560,17 +577,14 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
         cache = JacobianCache(x, fdtype, returntype, colorvec=colorvec, sparsity=sparsity)
     if sparsity is None and _has_sparsestruct(J):
         sparsity = J
-    if relstep is None:
-        relstep = default_relstep(cache.fdtype)
-    if absstep is None:
-        absstep = relstep
+    # relstep / absstep None -> default_relstep(fdtype, eltype(x)) and absstep = relstep, resolved by the library
     plan = cache._plan_for(J, sparsity, colorvec, ctx or getattr(f, "ctx", None))
     outs = _outs_of(J)
     staged = None
     if not isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
         # dense J must be column-major for the library; stage a C-order numpy array
         if isinstance(J, np.ndarray) and not J.flags.f_contiguous:
-            staged = np.zeros(J.shape, order="F")
+            staged = np.zeros(J.shape, dtype=J.dtype, order="F")
             outs = [staged]
     plan.jacobian(f, x, outs, f_in=f_in if cache.fdtype == "forward" else None, relstep=relstep, absstep=absstep,
                   dir=dir)
@@ -588,6 +602,7 @@ class JVPCache:
             fdtype, fx1 = fx1, None
         self.fdtype = _norm_fdtype(fdtype)
         self.x1, self.fx1 = x1, (fx1 if fx1 is not None else x1)
+        self.dtype = _dtype_of(x1) or np.dtype(np.float64)
         self._plan = None
 
     def _plan_for(self, M, N, ctx):
@@ -596,8 +611,9 @@ class JVPCache:
         key = (M, N, id(ctx))
         if self._plan is None or self._plan[0] != key:
             h = C.c_void_p()
-            _l.check(ctx.L.fd_jvp_plan_create(ctx.handle, M, N, _l.FDTYPES[self.fdtype], C.byref(h)))
-            fin = weakref.finalize(self, ctx.L.fd_jvp_plan_destroy, h)
+            Lt = _l.typed(ctx.L, self.dtype)
+            _l.check(Lt.fd_jvp_plan_create(ctx.handle, M, N, _l.FDTYPES[self.fdtype], C.byref(h)))
+            fin = weakref.finalize(self, Lt.fd_jvp_plan_destroy, h)
             self._plan = (key, h, fin, ctx)
         return self._plan[1]
 
@@ -612,21 +628,22 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     ctx = ctx or getattr(f, "ctx", None) or Context.default()
     M, N = int(np.prod(jvp.shape)), int(np.prod(x.shape))
     h = cache._plan_for(M, N, ctx)
-    xp, xk, _a = _ptr(x, "x")
-    vp_, vk, _b = _ptr(v, "v")
+    Lt = _l.typed(ctx.L, cache.dtype)
+    xp, xk, _a = _ptr(x, "x", cache.dtype)
+    vp_, vk, _b = _ptr(v, "v", cache.dtype)
     if xk != vk:
         raise ValueError("x and v must both be host or both be device arrays")
-    op, ok, _c = _ptr(jvp, "jvp")
+    op, ok, _c = _ptr(jvp, "jvp", cache.dtype)
     fp, fk = None, _l.DEVICE
     if f_in is not None and cache.fdtype == "forward":
-        fp, fk, _d = _ptr(f_in, "f_in")
+        fp, fk, _d = _ptr(f_in, "f_in", cache.dtype)
     if not sync:
         if xk != _l.DEVICE or ok != _l.DEVICE or (fp is not None and fk != _l.DEVICE):
             raise ValueError("the async path needs device arrays")
-        rc = ctx.L.fd_jvp_async(h, f.fn, f.fctx, xp, vp_, fp, -1.0 if relstep is None else float(relstep),
+        rc = Lt.fd_jvp_async(h, f.fn, f.fctx, xp, vp_, fp, -1.0 if relstep is None else float(relstep),
                                 -1.0 if absstep is None else float(absstep), float(dir), op)
     else:
-        rc = ctx.L.fd_jvp(h, f.fn, f.fctx, xp, vp_, xk, fp, fk, -1.0 if relstep is None else float(relstep),
+        rc = Lt.fd_jvp(h, f.fn, f.fctx, xp, vp_, xk, fp, fk, -1.0 if relstep is None else float(relstep),
                           -1.0 if absstep is None else float(absstep), float(dir), op, ok)
     err = getattr(f, "error", None)
     if err is not None:
@@ -636,7 +653,7 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     if not sync:
         return None
     e = C.c_double()
-    _l.check(ctx.L.fd_jvp_get_epsilon(h, C.byref(e)))
+    _l.check(Lt.fd_jvp_get_epsilon(h, C.byref(e)))
     cache.last_epsilon = e.value
     return None
 
@@ -692,7 +709,7 @@ def finite_difference_jacobian(f, x, cache_or_fdtype="forward", returntype=np.fl
         J = Tridiagonal(_similar(x, n - 1), _similar(x, n), _similar(x, n - 1))
     elif isinstance(proto, BandedMatrix):
         w = proto.l + proto.u + 1
-        J = BandedMatrix(_similar(x, w * n).reshape(n, w).T if _is_torch(x) else np.zeros((w, n), order="F"),
+        J = BandedMatrix(_similar(x, w * n).reshape(n, w).T if _is_torch(x) else np.zeros((w, n), dtype=x.dtype, order="F"),
                          proto.m, proto.l, proto.u)
     elif isinstance(proto, BlockBandedMatrix):
         J = BlockBandedMatrix(_similar(x, proto.layout.data_len), proto.layout)
@@ -705,9 +722,9 @@ def finite_difference_jacobian(f, x, cache_or_fdtype="forward", returntype=np.fl
             m, ncol = (n if M is None else int(M)), int(np.max(colorvec))
         if _is_torch(x):
             import torch
-            J = torch.zeros((ncol, m), dtype=torch.float64, device=x.device).t()   # column-major
+            J = torch.zeros((ncol, m), dtype=x.dtype, device=x.device).t()   # column-major
         else:
-            J = np.zeros((m, ncol), order="F")
+            J = np.zeros((m, ncol), dtype=x.dtype, order="F")
     sp = sparsity if sparsity is not None else (J if _has_sparsestruct(J) else None)
     if isinstance(J, SparseMatrixCSC) and isinstance(sp, SparseMatrixCSC) and sp is not J:
         sp = J if (np.array_equal(sp.colptr, J.colptr) and np.array_equal(sp.rowval, J.rowval)) else sp

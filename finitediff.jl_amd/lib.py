@@ -51,6 +51,35 @@ EXPORTS = (
 )
 
 
+# functions that exist once per element type (fd_* = Float64, fd32_* = Float32); everything else is shared
+TYPED = (
+    "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
+    "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
+    "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
+    "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
+    "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
+    "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
+)
+EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
+
+
+class TypedLib:
+    """View of the loaded library for one element type: ``typed(L, np.float32).fd_jacobian`` is ``L.fd32_jacobian``."""
+
+    def __init__(self, L, f32):
+        self._L, self._f32 = L, bool(f32)
+
+    def __getattr__(self, name):
+        if self._f32 and name in TYPED:
+            return getattr(self._L, "fd32_" + name[3:])
+        return getattr(self._L, name)
+
+
+def typed(L, dtype):
+    import numpy as np
+    return TypedLib(L, np.dtype(dtype) == np.float32)
+
+
 class PlanOpts(C.Structure):
     _fields_ = [("fdtype", C.c_int32), ("reserved0", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
                 ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64),
@@ -128,6 +157,8 @@ def load():
     L.fd_builtin_f_lazy.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY)]
     L.fd_plan_set_lazy_caps.argtypes = [vp, i32]
     L.fd_builtin_f_lazy_caps.argtypes = [vp, C.POINTER(i32)]
+    for name in TYPED:   # the Float32 instantiation has the same prototypes (values behind void*, steps stay double)
+        getattr(L, "fd32_" + name[3:]).argtypes = getattr(L, name).argtypes
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("fd_last_error", "fd_ctx_stream"):

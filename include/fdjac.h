@@ -19,7 +19,7 @@
  *   fd_plan_create_blockbanded  ext/FiniteDiffBlockBandedMatricesExt.jl:44-68
  *
  * Step sizes follow src/epsilons.jl:26-29,50-53,104-107 with the masked-norm rule of
- * src/jacobians.jl:559-561 / 600-602 / 624.  Arithmetic is Float64.
+ * src/jacobians.jl:559-561 / 600-602 / 624.  Arithmetic is Float64 (fd_*) or Float32 (fd32_*, end of this file).
  *
  * Conventions
  *   - plain C: pointers and sizes only, no exceptions, int status returns (0 = FD_OK);
@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 102
+#define FDJAC_VERSION 103
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -278,6 +278,68 @@ int fd_color_banded(int64_t N, int64_t l, int64_t u, int64_t *colorvec_out, int6
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */
 int fd_stream_copy_gbps(fd_ctx *ctx, int64_t bytes, int iters, double *gbps_out);
+
+/* ---- Float32 instantiation -------------------------------------------------------------------------------------
+ * The reference is generic in eltype(x) (JacobianCache{...,returntype}); every function above that touches values
+ * exists a second time with the prefix fd32_ for Float32 problems: x, f_in, the f! arrays and the outputs are
+ * `float` (complex step: (re,im) float pairs), step sizes follow the same rules evaluated in Float32
+ * (default_relstep = sqrt / cbrt of eps(Float32), src/epsilons.jl:133-144), relstep / absstep / dir and the reported
+ * epsilons stay `double` arguments.  Contexts (fd_ctx_*), fd_last_error, the colouring helpers, fd_plan_opts,
+ * fd_lazy_points and the launcher types are shared.  Masked norms are accumulated in Float64 in both instantiations.
+ */
+typedef struct fd32_plan fd32_plan;
+typedef struct fd32_jvp_plan fd32_jvp_plan;
+int fd32_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
+                       int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                       const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr,
+                             const void *rowval, int idx_bytes, int idx_base, const void *colorvec,
+                             int color_bytes, const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_coo_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index,
+                             const void *cols_index, int64_t nnz, int idx_bytes, int idx_base,
+                             const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                             fd32_plan **out);
+int fd32_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index,
+                           const void *cols_index, const int64_t *dest, int64_t nnz,
+                           int64_t out_len, int idx_bytes, int idx_base, const void *colorvec,
+                           int color_bytes, const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const fd_plan_opts *opts,
+                         fd32_plan **out);
+int fd32_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u,
+                          const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                          fd32_plan **out);
+int fd32_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl,
+                               int64_t bu, const void *block_starts, const void *block_strides,
+                               int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_destroy(fd32_plan *plan);
+int fd32_plan_info(const fd32_plan *plan, int key, int64_t *value);
+int fd32_jacobian(fd32_plan *plan, fd_f_launch f, void *fctx, const void *x, int x_kind,
+                const void *f_in, int f_in_kind, double relstep, double absstep, double dir,
+                void *const *outs, int out_kind);
+int fd32_jacobian_async(fd32_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *f_in,
+                      double relstep, double absstep, double dir, void *const *outs);
+int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
+int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
+int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
+int fd32_plan_enable_timing(fd32_plan *plan, int on);
+int fd32_plan_get_timings(fd32_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+int fd32_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,
+                        fd_f_launch *fn_out, void **fctx_out);
+int fd32_builtin_f_destroy(void *fctx);
+int fd32_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
+int fd32_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
+int fd32_builtin_f_lazy_caps(void *fctx, int *caps_out);
+int fd32_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd32_jvp_plan **out);
+int fd32_jvp_plan_destroy(fd32_jvp_plan *plan);
+int fd32_jvp(fd32_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, int xv_kind,
+           const void *f_in, int f_in_kind, double relstep, double absstep, double dir, void *jvp_out,
+           int out_kind);
+int fd32_jvp_async(fd32_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, const void *f_in,
+                 double relstep, double absstep, double dir, void *jvp_out);
+int fd32_jvp_get_epsilon(fd32_jvp_plan *plan, double *eps_out);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* element type: the same source is compiled twice, -DFDO_F32 gives the Float32 oracle (libfd_oracle32.so) whose
+   arithmetic, step rules and eps(T) are those of a Float32 problem in the reference */
+#ifdef FDO_F32
+typedef float fdo_real;
+typedef float complex cplx;
+#define FDO_EPS 1.1920928955078125e-07f
+#else
+typedef double fdo_real;
 typedef double complex cplx;
-typedef void (*fdo_f_real)(void *ctx, double *fx, const double *x);
+#define FDO_EPS 2.220446049250313e-16
+#endif
+typedef void (*fdo_f_real)(void *ctx, fdo_real *fx, const fdo_real *x);
 typedef void (*fdo_f_cplx)(void *ctx, cplx *fx, const cplx *x);
 
 enum { FDO_FORWARD = 0, FDO_CENTRAL = 1, FDO_COMPLEX = 2 };
@@ -77,9 +87,9 @@ typedef struct {
     const int64_t *block_starts;
     const int64_t *block_strides;
     /* outputs */
-    double *out0; /* nzval | dense J (col-major M x N) | banded data | block data | d  */
-    double *out1; /* dl (tridiag) */
-    double *out2; /* du (tridiag) */
+    fdo_real *out0; /* nzval | dense J (col-major M x N) | banded data | block data | d  */
+    fdo_real *out1; /* dl (tridiag) */
+    fdo_real *out2; /* du (tridiag) */
     int64_t out_len; /* number of stored values in out0 for fill_matrix! */
     /* banded-block-banded: sub-block bandwidths (lambda, mu); block_starts then holds the 1-based start of the
        BANDED data of block (K,J) (the `pointer(bandeddata(view(Jac,K,J)))` of ext/BlockBanded:29-31) and
@@ -88,30 +98,30 @@ typedef struct {
 } fdo_pattern;
 
 /* ---- src/epsilons.jl:26-29, 50-53 ---- */
-static inline double eps_forward(double x, double relstep, double absstep, double dir)
+static inline fdo_real eps_forward(fdo_real x, fdo_real relstep, fdo_real absstep, fdo_real dir)
 {
-    double a = relstep * fabs(x);
+    fdo_real a = relstep * fabs(x);
     return (a > absstep ? a : absstep) * dir;
 }
-static inline double eps_central(double x, double relstep, double absstep)
+static inline fdo_real eps_central(fdo_real x, fdo_real relstep, fdo_real absstep)
 {
-    double a = relstep * fabs(x);
+    fdo_real a = relstep * fabs(x);
     return (a > absstep ? a : absstep);
 }
 
 /* src/epsilons.jl:133-144 */
-double fdo_default_relstep(int fdtype)
+fdo_real fdo_default_relstep(int fdtype)
 {
-    const double e = 2.220446049250313e-16;
+    const fdo_real e = FDO_EPS;
     if (fdtype == FDO_FORWARD) return sqrt(e);
     if (fdtype == FDO_CENTRAL) return cbrt(e);
     return 1.0;
 }
 
 /* LinearAlgebra.norm restated (see header) */
-static double norm2(const double *v, int64_t n)
+static fdo_real norm2(const fdo_real *v, int64_t n)
 {
-    double s = 0.0;
+    fdo_real s = 0.0;
     for (int64_t i = 0; i < n; ++i) s += v[i] * v[i];
     return sqrt(s);
 }
@@ -126,7 +136,7 @@ static int64_t max_color(const int64_t *colorvec, int64_t n)
 
 /* J[row,col] = v for a Tridiagonal (1-based row/col); off-band stores are an
    error in Julia -- never reached for a structurally tridiagonal index list. */
-static void tridiag_setindex(const fdo_pattern *p, int64_t row, int64_t col, double v)
+static void tridiag_setindex(const fdo_pattern *p, int64_t row, int64_t col, fdo_real v)
 {
     if (row == col) p->out0[row - 1] = v;            /* d  */
     else if (row == col + 1) p->out1[col - 1] = v;   /* dl[col] = J[col+1,col] */
@@ -137,18 +147,18 @@ static void tridiag_setindex(const fdo_pattern *p, int64_t row, int64_t col, dou
 static void fill_matrix_zero(const fdo_pattern *p)
 {
     if (p->kind == FDO_PAT_COO_TRIDIAG) {
-        memset(p->out0, 0, sizeof(double) * (size_t)p->N);
+        memset(p->out0, 0, sizeof(fdo_real) * (size_t)p->N);
         if (p->N > 1) {
-            memset(p->out1, 0, sizeof(double) * (size_t)(p->N - 1));
-            memset(p->out2, 0, sizeof(double) * (size_t)(p->N - 1));
+            memset(p->out1, 0, sizeof(fdo_real) * (size_t)(p->N - 1));
+            memset(p->out2, 0, sizeof(fdo_real) * (size_t)(p->N - 1));
         }
     } else {
-        memset(p->out0, 0, sizeof(double) * (size_t)p->out_len);
+        memset(p->out0, 0, sizeof(fdo_real) * (size_t)p->out_len);
     }
 }
 
 /* One colour's decompression of vfx into J. */
-static void colored_iteration(const fdo_pattern *p, const double *vfx, const int64_t *colorvec,
+static void colored_iteration(const fdo_pattern *p, const fdo_real *vfx, const int64_t *colorvec,
                               int64_t color_i)
 {
     const int64_t M = p->M, N = p->N;
@@ -256,10 +266,10 @@ static void colored_iteration(const fdo_pattern *p, const double *vfx, const int
  * f_in may be NULL.  fcalls (optional) counts f! evaluations.
  * Returns 0, or 1 for an unsupported fdtype.
  */
-int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, double *x, double *x1,
-                        double *x2, double *fx, double *fx1, cplx *cx1, cplx *cfx,
-                        const double *f_in, const int64_t *colorvec, double relstep,
-                        double absstep, double dir, const fdo_pattern *pat, int64_t *fcalls)
+int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, fdo_real *x, fdo_real *x1,
+                        fdo_real *x2, fdo_real *fx, fdo_real *fx1, cplx *cx1, cplx *cfx,
+                        const fdo_real *f_in, const int64_t *colorvec, fdo_real relstep,
+                        fdo_real absstep, fdo_real dir, const fdo_pattern *pat, int64_t *fcalls)
 {
     const int64_t M = pat->M, N = pat->N;
     int64_t nf = 0;
@@ -268,41 +278,41 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, doub
     if (fdtype == FDO_COMPLEX) {
         for (int64_t i = 0; i < N; ++i) cx1[i] = x[i]; /* copyto!(x1,x)  :519 */
     } else {
-        memcpy(x1, x, sizeof(double) * (size_t)N);     /* :519 */
+        memcpy(x1, x, sizeof(fdo_real) * (size_t)N);     /* :519 */
     }
     if (has_sparsity) fill_matrix_zero(pat);           /* :530-532 */
 
     const int64_t ncolors = max_color(colorvec, N);    /* 1:maximum(colorvec) */
 
     if (fdtype == FDO_FORWARD) {
-        const double *vfx;
+        const fdo_real *vfx;
         if (f_in == NULL) { f(ctx, fx, x); ++nf; vfx = fx; } /* :540-545 */
         else vfx = f_in;
         for (int64_t color_i = 1; color_i <= ncolors; ++color_i) {
             if (!has_sparsity) { /* :548-557 */
-                double x1_save = x1[color_i - 1];
-                double epsilon = eps_forward(x1_save, relstep, absstep, dir);
+                fdo_real x1_save = x1[color_i - 1];
+                fdo_real epsilon = eps_forward(x1_save, relstep, absstep, dir);
                 x1[color_i - 1] = x1_save + epsilon;
                 f(ctx, fx1, x1); ++nf;
                 for (int64_t r = 0; r < M; ++r)
                     pat->out0[r + M * (color_i - 1)] = (fx1[r] - vfx[r]) / epsilon;
                 x1[color_i - 1] = x1_save;
             } else { /* :558-585 */
-                for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (double)(colorvec[i] == color_i);
-                double tmp = norm2(x2, N);
-                double epsilon = eps_forward(sqrt(tmp), relstep, absstep, dir);
-                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (double)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (fdo_real)(colorvec[i] == color_i);
+                fdo_real tmp = norm2(x2, N);
+                fdo_real epsilon = eps_forward(sqrt(tmp), relstep, absstep, dir);
+                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
                 f(ctx, fx1, x1); ++nf;
                 for (int64_t r = 0; r < M; ++r) fx1[r] = (fx1[r] - vfx[r]) / epsilon;
                 colored_iteration(pat, fx1, colorvec, color_i);
-                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (double)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
             }
         }
     } else if (fdtype == FDO_CENTRAL) {
         for (int64_t color_i = 1; color_i <= ncolors; ++color_i) {
             if (!has_sparsity) { /* :590-598 */
-                double x_save = x[color_i - 1];
-                double epsilon = eps_central(x_save, relstep, absstep);
+                fdo_real x_save = x[color_i - 1];
+                fdo_real epsilon = eps_central(x_save, relstep, absstep);
                 x1[color_i - 1] = x_save + epsilon;
                 f(ctx, fx1, x1); ++nf;
                 x1[color_i - 1] = x_save - epsilon;
@@ -311,22 +321,22 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, doub
                     pat->out0[r + M * (color_i - 1)] = (fx1[r] - fx[r]) / (2 * epsilon);
                 x1[color_i - 1] = x_save;
             } else { /* :599-621 */
-                for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (double)(colorvec[i] == color_i);
-                double tmp = norm2(x2, N);
-                double epsilon = eps_central(sqrt(tmp), relstep, absstep);
-                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (double)(colorvec[i] == color_i);
-                for (int64_t i = 0; i < N; ++i) x[i] = x[i] - epsilon * (double)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (fdo_real)(colorvec[i] == color_i);
+                fdo_real tmp = norm2(x2, N);
+                fdo_real epsilon = eps_central(sqrt(tmp), relstep, absstep);
+                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x[i] = x[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
                 f(ctx, fx1, x1); ++nf;
                 f(ctx, fx, x); ++nf;
                 for (int64_t r = 0; r < M; ++r) fx1[r] = (fx1[r] - fx[r]) / (2 * epsilon);
                 colored_iteration(pat, fx1, colorvec, color_i);
-                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (double)(colorvec[i] == color_i);
-                for (int64_t i = 0; i < N; ++i) x[i] = x[i] + epsilon * (double)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
+                for (int64_t i = 0; i < N; ++i) x[i] = x[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
             }
         }
     } else if (fdtype == FDO_COMPLEX) { /* :623-648 */
-        const double epsilon = 2.220446049250313e-16; /* eps(Float64), src/epsilons.jl:104-107 */
-        double *vre = (double *)malloc(sizeof(double) * (size_t)(M > 0 ? M : 1));
+        const fdo_real epsilon = FDO_EPS; /* eps(T), src/epsilons.jl:104-107 */
+        fdo_real *vre = (fdo_real *)malloc(sizeof(fdo_real) * (size_t)(M > 0 ? M : 1));
         for (int64_t color_i = 1; color_i <= ncolors; ++color_i) {
             if (!has_sparsity) {
                 cplx x1_save = cx1[color_i - 1];
@@ -336,12 +346,12 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, doub
                 cx1[color_i - 1] = x1_save;
             } else {
                 for (int64_t i = 0; i < N; ++i)
-                    cx1[i] = cx1[i] + CMPLX(0.0, epsilon * (double)(colorvec[i] == color_i));
+                    cx1[i] = cx1[i] + CMPLX(0.0, epsilon * (fdo_real)(colorvec[i] == color_i));
                 fc(ctx, cfx, cx1); ++nf;
                 for (int64_t r = 0; r < M; ++r) { cfx[r] = cimag(cfx[r]) / epsilon; vre[r] = creal(cfx[r]); }
                 colored_iteration(pat, vre, colorvec, color_i);
                 for (int64_t i = 0; i < N; ++i)
-                    cx1[i] = cx1[i] - CMPLX(0.0, epsilon * (double)(colorvec[i] == color_i));
+                    cx1[i] = cx1[i] - CMPLX(0.0, epsilon * (fdo_real)(colorvec[i] == color_i));
             }
         }
         free(vre);
@@ -354,18 +364,18 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, doub
 
 /* finite_difference_jvp!  (src/jvp.jl:238-274).  x1, fx1 are the cache arrays; jvp is the output.
    Returns 0, or 1 for :complex (rejected by the reference, :248-250 / :270-271). */
-int fdo_jvp(int fdtype, fdo_f_real f, void *ctx, const double *x, const double *v, int64_t M, int64_t N,
-            const double *f_in, double relstep, double absstep, double dir, double *x1, double *fx1, double *jvp,
-            double *eps_out)
+int fdo_jvp(int fdtype, fdo_f_real f, void *ctx, const fdo_real *x, const fdo_real *v, int64_t M, int64_t N,
+            const fdo_real *f_in, fdo_real relstep, fdo_real absstep, fdo_real dir, fdo_real *x1, fdo_real *fx1, fdo_real *jvp,
+            fdo_real *eps_out)
 {
     if (fdtype != FDO_FORWARD && fdtype != FDO_CENTRAL) return 1;
-    double dot = 0.0;
+    fdo_real dot = 0.0;
     for (int64_t i = 0; i < N; ++i) dot += x[i] * v[i];
-    const double tmp = sqrt(fabs(dot));                         /* :253 */
-    double epsilon;
+    const fdo_real tmp = sqrt(fabs(dot));                         /* :253 */
+    fdo_real epsilon;
     if (fdtype == FDO_FORWARD) {
         epsilon = eps_forward(tmp, relstep, absstep, dir);      /* :254 */
-        const double *b;
+        const fdo_real *b;
         if (f_in == NULL) { f(ctx, fx1, x); b = fx1; } else b = f_in;
         for (int64_t i = 0; i < N; ++i) x1[i] = x[i] + epsilon * v[i];
         f(ctx, jvp, x1);
@@ -384,7 +394,7 @@ int fdo_jvp(int fdtype, fdo_f_real f, void *ctx, const double *x, const double *
 
 /* src/jacobians.jl:473-488: column-major scan of a dense pattern matrix.
    rows/cols must hold count(A != 0) entries; returns that count. */
-int64_t fdo_findstructralnz_dense(const double *A, int64_t m, int64_t n, int64_t *rows, int64_t *cols)
+int64_t fdo_findstructralnz_dense(const fdo_real *A, int64_t m, int64_t n, int64_t *rows, int64_t *cols)
 {
     int64_t idx = 0;
     for (int64_t j = 1; j <= n; ++j)
@@ -398,18 +408,18 @@ int64_t fdo_findstructralnz_dense(const double *A, int64_t m, int64_t n, int64_t
 
 /* Out-of-place dense forward Jacobian (config 1 plumbing), src/jacobians.jl:319-331:
    per-element epsilon, J[:,i] = (f(x with x[i]+eps) - f(x)) / eps.  J is M x N col-major. */
-void fdo_jacobian_oop_dense_forward(fdo_f_real f, void *ctx, const double *x, int64_t M, int64_t N,
-                                    double relstep, double absstep, double dir, double *J)
+void fdo_jacobian_oop_dense_forward(fdo_f_real f, void *ctx, const fdo_real *x, int64_t M, int64_t N,
+                                    fdo_real relstep, fdo_real absstep, fdo_real dir, fdo_real *J)
 {
-    double *vecfx = (double *)malloc(sizeof(double) * (size_t)M);
-    double *fx1 = (double *)malloc(sizeof(double) * (size_t)M);
-    double *x1 = (double *)malloc(sizeof(double) * (size_t)N);
+    fdo_real *vecfx = (fdo_real *)malloc(sizeof(fdo_real) * (size_t)M);
+    fdo_real *fx1 = (fdo_real *)malloc(sizeof(fdo_real) * (size_t)M);
+    fdo_real *x1 = (fdo_real *)malloc(sizeof(fdo_real) * (size_t)N);
     f(ctx, vecfx, x);
     for (int64_t i = 0; i < N; ++i) {
-        double x_save = x[i];
-        double epsilon = eps_forward(x_save, relstep, absstep, dir);
+        fdo_real x_save = x[i];
+        fdo_real epsilon = eps_forward(x_save, relstep, absstep, dir);
         /* setindex(vecx, x_save+epsilon, i): x .* (i .!== 1:n) .+ v .* (i .== 1:n)  (src/FiniteDiff.jl:99-102) */
-        for (int64_t k = 0; k < N; ++k) x1[k] = x[k] * (double)(k != i) + (x_save + epsilon) * (double)(k == i);
+        for (int64_t k = 0; k < N; ++k) x1[k] = x[k] * (fdo_real)(k != i) + (x_save + epsilon) * (fdo_real)(k == i);
         f(ctx, fx1, x1);
         for (int64_t r = 0; r < M; ++r) J[r + M * i] = (fx1[r] - vecfx[r]) / epsilon;
     }
@@ -421,7 +431,7 @@ void fdo_jacobian_oop_dense_forward(fdo_f_real f, void *ctx, const double *x, in
 /* ===================================================================== */
 
 /* test/coloring_tests.jl:5-13 : second difference, zero Dirichlet ends */
-void fdo_f_tridiag(void *ctx, double *dx, const double *x)
+void fdo_f_tridiag(void *ctx, fdo_real *dx, const fdo_real *x)
 {
     int64_t n = *(const int64_t *)ctx;
     if (n == 1) { dx[0] = -2 * x[0]; return; }
@@ -440,11 +450,11 @@ void fdo_fc_tridiag(void *ctx, cplx *dx, const cplx *x)
 
 /* nonlinear tridiagonal variant: dx[i] = x[i-1] - 2x[i] + x[i+1] + x[i]^2 * x[i+1]
    (x[n] treated as 0 beyond the end) so that J depends on x. */
-void fdo_f_tridiag_nl(void *ctx, double *dx, const double *x)
+void fdo_f_tridiag_nl(void *ctx, fdo_real *dx, const fdo_real *x)
 {
     int64_t n = *(const int64_t *)ctx;
     for (int64_t i = 0; i < n; ++i) {
-        double xm = i > 0 ? x[i - 1] : 0.0, xp = i + 1 < n ? x[i + 1] : 0.0;
+        fdo_real xm = i > 0 ? x[i - 1] : 0.0, xp = i + 1 < n ? x[i + 1] : 0.0;
         dx[i] = xm - 2 * x[i] + xp + x[i] * x[i] * xp;
     }
 }
@@ -459,14 +469,14 @@ void fdo_fc_tridiag_nl(void *ctx, cplx *dx, const cplx *x)
 
 /* 2-D 5-point stencils on an nx (fast index) x ny grid; ctx = {nx, ny} */
 /* zero-Dirichlet Laplacian */
-void fdo_f_lap5(void *ctx, double *out, const double *x)
+void fdo_f_lap5(void *ctx, fdo_real *out, const fdo_real *x)
 {
     const int64_t nx = ((const int64_t *)ctx)[0], ny = ((const int64_t *)ctx)[1];
     for (int64_t j = 0; j < ny; ++j)
         for (int64_t i = 0; i < nx; ++i) {
             int64_t k = i + nx * j;
-            double w = i > 0 ? x[k - 1] : 0.0, e = i + 1 < nx ? x[k + 1] : 0.0;
-            double s = j > 0 ? x[k - nx] : 0.0, n = j + 1 < ny ? x[k + nx] : 0.0;
+            fdo_real w = i > 0 ? x[k - 1] : 0.0, e = i + 1 < nx ? x[k + 1] : 0.0;
+            fdo_real s = j > 0 ? x[k - nx] : 0.0, n = j + 1 < ny ? x[k + nx] : 0.0;
             out[k] = w + e + s + n - 4 * x[k];
         }
 }
@@ -482,7 +492,7 @@ void fdo_fc_lap5(void *ctx, cplx *out, const cplx *x)
         }
 }
 /* clamped-edge sum stencil, test/coloring_tests.jl:99-108 */
-void fdo_f_clamp5(void *ctx, double *out, const double *x)
+void fdo_f_clamp5(void *ctx, fdo_real *out, const fdo_real *x)
 {
     const int64_t nx = ((const int64_t *)ctx)[0], ny = ((const int64_t *)ctx)[1];
     for (int64_t j = 0; j < ny; ++j)
@@ -505,18 +515,18 @@ void fdo_fc_clamp5(void *ctx, cplx *out, const cplx *x)
 
 /* block-coupled dense-block f; ctx = {nblk, bs}:
    f_b[k] = x_b[k]*(sig_{b-1}+sig_b+sig_{b+1}) + sin(x_b[k]),  sig_b = sum_j w_j x_b[j], w_j=(j+1)/bs (j 0-based) */
-void fdo_f_blockcoupled(void *ctx, double *out, const double *x)
+void fdo_f_blockcoupled(void *ctx, fdo_real *out, const fdo_real *x)
 {
     const int64_t nb = ((const int64_t *)ctx)[0], bs = ((const int64_t *)ctx)[1];
-    double *sig = (double *)malloc(sizeof(double) * (size_t)nb);
+    fdo_real *sig = (fdo_real *)malloc(sizeof(fdo_real) * (size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
-        double s = 0.0;
-        for (int64_t j = 0; j < bs; ++j) s += ((double)(j + 1) / (double)bs) * x[b * bs + j];
+        fdo_real s = 0.0;
+        for (int64_t j = 0; j < bs; ++j) s += ((fdo_real)(j + 1) / (fdo_real)bs) * x[b * bs + j];
         sig[b] = s;
     }
     for (int64_t b = 0; b < nb; ++b) {
-        double sm = b > 0 ? sig[b - 1] : 0.0, sp = b + 1 < nb ? sig[b + 1] : 0.0;
-        double S = sm + sig[b] + sp;
+        fdo_real sm = b > 0 ? sig[b - 1] : 0.0, sp = b + 1 < nb ? sig[b + 1] : 0.0;
+        fdo_real S = sm + sig[b] + sp;
         for (int64_t k = 0; k < bs; ++k) out[b * bs + k] = x[b * bs + k] * S + sin(x[b * bs + k]);
     }
     free(sig);
@@ -527,7 +537,7 @@ void fdo_fc_blockcoupled(void *ctx, cplx *out, const cplx *x)
     cplx *sig = (cplx *)malloc(sizeof(cplx) * (size_t)nb);
     for (int64_t b = 0; b < nb; ++b) {
         cplx s = 0.0;
-        for (int64_t j = 0; j < bs; ++j) s += ((double)(j + 1) / (double)bs) * x[b * bs + j];
+        for (int64_t j = 0; j < bs; ++j) s += ((fdo_real)(j + 1) / (fdo_real)bs) * x[b * bs + j];
         sig[b] = s;
     }
     for (int64_t b = 0; b < nb; ++b) {
@@ -539,11 +549,11 @@ void fdo_fc_blockcoupled(void *ctx, cplx *out, const cplx *x)
 }
 
 /* test/coloring_tests.jl:124-133 : y = (x1-3)^2 + x1*x2 + (x2+4)^2 - 3 ; ctx = n (length y) */
-void fdo_f_nonsquare(void *ctx, double *y, const double *x)
+void fdo_f_nonsquare(void *ctx, fdo_real *y, const fdo_real *x)
 {
     int64_t n = *(const int64_t *)ctx;
     for (int64_t k = 0; k < n; ++k) {
-        double a = x[k], b = x[n + k];
+        fdo_real a = x[k], b = x[n + k];
         y[k] = (a - 3) * (a - 3) + a * b + (b + 4) * (b + 4) - 3;
     }
 }
@@ -557,7 +567,7 @@ void fdo_fc_nonsquare(void *ctx, cplx *y, const cplx *x)
 }
 
 /* config 1: f(x) = sin.(x) ; ctx = n */
-void fdo_f_sin(void *ctx, double *y, const double *x)
+void fdo_f_sin(void *ctx, fdo_real *y, const fdo_real *x)
 {
     int64_t n = *(const int64_t *)ctx;
     for (int64_t k = 0; k < n; ++k) y[k] = sin(x[k]);

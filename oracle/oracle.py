@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libfd_oracle.so")
+_SO32 = os.path.join(_HERE, "_build", "libfd_oracle32.so")   # the same source with element type float
 
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
@@ -27,61 +28,88 @@ F_CPLX = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
+_f32p = C.POINTER(C.c_float)
 
 
-class Pattern(C.Structure):
-    _fields_ = [
+def _pattern_fields(fp):
+    return [
         ("kind", C.c_int), ("M", C.c_int64), ("N", C.c_int64),
         ("colptr", _i64p), ("rowval", _i64p),
         ("rows_index", _i64p), ("cols_index", _i64p), ("ncoo", C.c_int64),
         ("l", C.c_int64), ("u", C.c_int64),
         ("nblk", C.c_int64), ("blk_sizes", _i64p), ("bl", C.c_int64), ("bu", C.c_int64),
         ("block_starts", _i64p), ("block_strides", _i64p),
-        ("out0", _f64p), ("out1", _f64p), ("out2", _f64p), ("out_len", C.c_int64),
+        ("out0", fp), ("out1", fp), ("out2", fp), ("out_len", C.c_int64),
         ("lam", C.c_int64), ("mu", C.c_int64),
     ]
+
+
+class Pattern(C.Structure):
+    _fields_ = _pattern_fields(_f64p)
+
+
+class Pattern32(C.Structure):
+    _fields_ = _pattern_fields(_f32p)
+
+
+class _T:
+    """ctypes / numpy types of one element type."""
+
+    def __init__(self, dtype):
+        self.f32 = np.dtype(dtype) == np.float32
+        self.real = np.float32 if self.f32 else np.float64
+        self.cplx = np.complex64 if self.f32 else np.complex128
+        self.c_real = C.c_float if self.f32 else C.c_double
+        self.fp = _f32p if self.f32 else _f64p
+        self.Pattern = Pattern32 if self.f32 else Pattern
+        self.F_REAL = C.CFUNCTYPE(None, C.c_void_p, self.fp, self.fp)
+
+    def pf(self, a):
+        return a.ctypes.data_as(self.fp) if a is not None else None
 
 
 def build(force=False):
     """Compile oracle/fd_oracle.c -> oracle/_build/libfd_oracle.so (gcc)."""
     src = os.path.join(_HERE, "fd_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    stale = [so for so in (_SO, _SO32) if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)]
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(dtype=np.float64):
+    T = _T(dtype)
+    if T.f32 not in _libs:
         build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_SO32 if T.f32 else _SO)
+        _f64p, dbl = T.fp, T.c_real          # noqa: F841  (the prototypes below are written in terms of these)
         L.fdo_jacobian_cached.restype = C.c_int
         L.fdo_jacobian_cached.argtypes = [
             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p,
-            C.c_void_p, C.c_void_p, _f64p, _i64p, C.c_double, C.c_double, C.c_double,
-            C.POINTER(Pattern), _i64p]
-        L.fdo_default_relstep.restype = C.c_double
+            C.c_void_p, C.c_void_p, _f64p, _i64p, dbl, dbl, dbl,
+            C.POINTER(T.Pattern), _i64p]
+        L.fdo_default_relstep.restype = dbl
         L.fdo_default_relstep.argtypes = [C.c_int]
         L.fdo_findstructralnz_dense.restype = C.c_int64
         L.fdo_findstructralnz_dense.argtypes = [_f64p, C.c_int64, C.c_int64, _i64p, _i64p]
         L.fdo_jacobian_oop_dense_forward.restype = None
         L.fdo_jacobian_oop_dense_forward.argtypes = [
-            C.c_void_p, C.c_void_p, _f64p, C.c_int64, C.c_int64, C.c_double, C.c_double,
-            C.c_double, _f64p]
+            C.c_void_p, C.c_void_p, _f64p, C.c_int64, C.c_int64, dbl, dbl,
+            dbl, _f64p]
         L.fdo_jvp.restype = C.c_int
-        L.fdo_jvp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, _f64p, _f64p, C.c_int64, C.c_int64, _f64p, C.c_double,
-                              C.c_double, C.c_double, _f64p, _f64p, _f64p, _f64p]
+        L.fdo_jvp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, _f64p, _f64p, C.c_int64, C.c_int64, _f64p, dbl,
+                              dbl, dbl, _f64p, _f64p, _f64p, _f64p]
         L.fdo_build_tridiag_csc.restype = None
         L.fdo_build_tridiag_csc.argtypes = [C.c_int64, _i64p, _i64p]
-        _lib = L
-    return _lib
+        _libs[T.f32] = L
+    return _libs[T.f32]
 
 
-def default_relstep(fdtype):
-    return lib().fdo_default_relstep(FDTYPES[fdtype])
+def default_relstep(fdtype, dtype=np.float64):
+    return float(lib(dtype).fdo_default_relstep(FDTYPES[fdtype]))
 
 
 def _p64(a):
@@ -95,8 +123,9 @@ def _pf(a):
 class Fixture:
     """One of the C fixture f!s: (real fn, complex fn, ctx int64 array)."""
 
-    def __init__(self, name, *ctx):
-        L = lib()
+    def __init__(self, name, *ctx, dtype=np.float64):
+        L = lib(dtype)
+        self.dtype = np.dtype(dtype)
         self.name = name
         self.ctx = np.asarray(ctx, dtype=np.int64)
         self.f = C.cast(getattr(L, "fdo_f_" + name), C.c_void_p)
@@ -112,9 +141,11 @@ class Fixture:
 class PyF:
     """A Python f!(fx, x) on numpy arrays (real and complex) as oracle callbacks."""
 
-    def __init__(self, fn, M, N):
+    def __init__(self, fn, M, N, dtype=np.float64):
         self.fn, self.M, self.N = fn, M, N
         self.calls = 0
+        self.dtype = np.dtype(dtype)
+        T = _T(dtype)
 
         def _real(_ctx, fxp, xp):
             fx = np.ctypeslib.as_array(fxp, shape=(M,))
@@ -123,12 +154,12 @@ class PyF:
             fn(fx, x)
 
         def _cplx(_ctx, fxp, xp):
-            fx = np.ctypeslib.as_array(C.cast(fxp, _f64p), shape=(2 * M,)).view(np.complex128)
-            x = np.ctypeslib.as_array(C.cast(xp, _f64p), shape=(2 * N,)).view(np.complex128)
+            fx = np.ctypeslib.as_array(C.cast(fxp, T.fp), shape=(2 * M,)).view(T.cplx)
+            x = np.ctypeslib.as_array(C.cast(xp, T.fp), shape=(2 * N,)).view(T.cplx)
             self.calls += 1
             fn(fx, x)
 
-        self._keep = (F_REAL(_real), F_CPLX(_cplx))
+        self._keep = (T.F_REAL(_real), F_CPLX(_cplx))
         self.f = C.cast(self._keep[0], C.c_void_p)
         self.fc = C.cast(self._keep[1], C.c_void_p)
         self.ctxp = None
@@ -155,24 +186,27 @@ def tridiag_csc(n):
 def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowval=None,
              rows_index=None, cols_index=None, l=0, u=0, blk_sizes=None, bl=0, bu=0,
              block_starts=None, block_strides=None, out_len=None, lam=0, mu=0, f_in=None, relstep=None,
-             absstep=None, dir=1.0, cache=None, mutate_x=False):
+             absstep=None, dir=1.0, cache=None, mutate_x=False, dtype=None):
     """Run the cached in-place path.  Returns dict(out=..., fcalls=..., x_after=...).
 
     out: nzval (CSC_COMMON) | dense col-major M x N (NONE / *_DENSEJ) | banded data (l+u+1, N)
          | flat block data | (dl, d, du) for COO_TRIDIAG.
     cache: optional dict of pre-poisoned arrays x1,x2,fx,fx1 (test/cache_reuse_tests.jl).
     """
-    L = lib()
+    dtype = np.dtype(dtype if dtype is not None else getattr(f, "dtype", np.float64))   # eltype(x): float64 | float32
+    T = _T(dtype)
+    L = lib(dtype)
+    _pf = T.pf
     fd = FDTYPES[fdtype]
-    x = np.array(x, dtype=np.float64) if not mutate_x else x
+    x = np.array(x, dtype=T.real) if not mutate_x else x
     N = x.size
     M = N if M is None else M
     colorvec = np.ascontiguousarray(colorvec, dtype=np.int64)
     assert colorvec.size == N, "DimensionMismatch (src/jacobians.jl:516)"
-    relstep = default_relstep(fdtype) if relstep is None else relstep
+    relstep = default_relstep(fdtype, dtype) if relstep is None else relstep
     absstep = relstep if absstep is None else absstep
 
-    pat = Pattern()
+    pat = T.Pattern()
     pat.kind, pat.M, pat.N = kind, M, N
     keep = []
 
@@ -186,39 +220,39 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
         colptr, rowval = i64(colptr), i64(rowval)
         pat.colptr, pat.rowval = _p64(colptr), _p64(rowval)
         nnz = int(colptr[-1] - 1)
-        out0 = np.full(nnz if kind == PAT_CSC_COMMON else M * N, np.nan)
+        out0 = np.full(nnz if kind == PAT_CSC_COMMON else M * N, np.nan, T.real)
     elif kind in (PAT_COO_DENSEJ, PAT_COO_TRIDIAG):
         rows_index, cols_index = i64(rows_index), i64(cols_index)
         pat.rows_index, pat.cols_index, pat.ncoo = _p64(rows_index), _p64(cols_index), rows_index.size
         if kind == PAT_COO_DENSEJ:
-            out0 = np.full(M * N, np.nan)
+            out0 = np.full(M * N, np.nan, T.real)
         else:
-            out0 = np.full(N, np.nan)
-            out1 = np.full(max(N - 1, 0), np.nan)
-            out2 = np.full(max(N - 1, 0), np.nan)
+            out0 = np.full(N, np.nan, T.real)
+            out1 = np.full(max(N - 1, 0), np.nan, T.real)
+            out2 = np.full(max(N - 1, 0), np.nan, T.real)
     elif kind == PAT_BANDED:
         pat.l, pat.u = l, u
-        out0 = np.full((l + u + 1) * N, np.nan)
+        out0 = np.full((l + u + 1) * N, np.nan, T.real)
     elif kind in (PAT_BLOCKBANDED, PAT_BANDEDBLOCKBANDED):
         pat.lam, pat.mu = lam, mu
         blk_sizes, block_starts, block_strides = i64(blk_sizes), i64(block_starts), i64(block_strides)
         pat.nblk, pat.blk_sizes, pat.bl, pat.bu = blk_sizes.size, _p64(blk_sizes), bl, bu
         pat.block_starts, pat.block_strides = _p64(block_starts), _p64(block_strides)
-        out0 = np.full(out_len, np.nan)
+        out0 = np.full(out_len, np.nan, T.real)
     else:
-        out0 = np.full(M * N, np.nan)
+        out0 = np.full(M * N, np.nan, T.real)
     pat.out0, pat.out_len = _pf(out0), out0.size
     if out1 is not None:
         pat.out1, pat.out2 = _pf(out1), _pf(out2)
 
     cache = cache or {}
-    x1 = np.array(cache.get("x1", np.zeros(N)), dtype=np.float64)
-    x2 = np.zeros(N)
-    fx = np.array(cache.get("fx", np.zeros(M)), dtype=np.float64)
-    fx1 = np.array(cache.get("fx1", np.zeros(M)), dtype=np.float64)
-    cx1 = np.zeros(N, np.complex128)
-    cfx = np.zeros(M, np.complex128)
-    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=np.float64)
+    x1 = np.array(cache.get("x1", np.zeros(N)), dtype=T.real)
+    x2 = np.zeros(N, T.real)
+    fx = np.array(cache.get("fx", np.zeros(M)), dtype=T.real)
+    fx1 = np.array(cache.get("fx1", np.zeros(M)), dtype=T.real)
+    cx1 = np.zeros(N, T.cplx)
+    cfx = np.zeros(M, T.cplx)
+    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=T.real)
     fcalls = np.zeros(1, np.int64)
 
     rc = L.fdo_jacobian_cached(fd, f.f, f.fc, f.ctxp, _pf(x), _pf(x1), _pf(x2), _pf(fx), _pf(fx1),
@@ -239,27 +273,33 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
 
 
 def jacobian_oop_dense_forward(f, x, M=None, relstep=None, absstep=None, dir=1.0):
-    x = np.ascontiguousarray(x, dtype=np.float64)
+    dtype = np.dtype(getattr(f, "dtype", np.float64))
+    T = _T(dtype)
+    _pf = T.pf
+    x = np.ascontiguousarray(x, dtype=T.real)
     N = x.size
     M = N if M is None else M
-    relstep = default_relstep("forward") if relstep is None else relstep
+    relstep = default_relstep("forward", dtype) if relstep is None else relstep
     absstep = relstep if absstep is None else absstep
-    J = np.empty(M * N)
-    lib().fdo_jacobian_oop_dense_forward(f.f, f.ctxp, _pf(x), M, N, relstep, absstep, float(dir), _pf(J))
+    J = np.empty(M * N, T.real)
+    lib(dtype).fdo_jacobian_oop_dense_forward(f.f, f.ctxp, _pf(x), M, N, relstep, absstep, float(dir), _pf(J))
     return J.reshape((M, N), order="F")
 
 
 def jvp(fdtype, f, x, v, M=None, f_in=None, relstep=None, absstep=None, dir=1.0):
     """finite_difference_jvp! (src/jvp.jl:238-274) -> dict(jvp=..., eps=...)."""
-    x = np.ascontiguousarray(x, dtype=np.float64)
-    v = np.ascontiguousarray(v, dtype=np.float64)
+    dtype = np.dtype(getattr(f, "dtype", np.float64))
+    T = _T(dtype)
+    _pf = T.pf
+    x = np.ascontiguousarray(x, dtype=T.real)
+    v = np.ascontiguousarray(v, dtype=T.real)
     N = x.size
     M = N if M is None else M
-    relstep = default_relstep(fdtype) if relstep is None else relstep
+    relstep = default_relstep(fdtype, dtype) if relstep is None else relstep
     absstep = relstep if absstep is None else absstep
-    x1, fx1, out, eps = np.zeros(N), np.zeros(M), np.zeros(M), np.zeros(1)
-    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=np.float64)
-    rc = lib().fdo_jvp(FDTYPES[fdtype], f.f, f.ctxp, _pf(x), _pf(v), M, N, _pf(fin), relstep, absstep, float(dir),
+    x1, fx1, out, eps = np.zeros(N, T.real), np.zeros(M, T.real), np.zeros(M, T.real), np.zeros(1, T.real)
+    fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=T.real)
+    rc = lib(dtype).fdo_jvp(FDTYPES[fdtype], f.f, f.ctxp, _pf(x), _pf(v), M, N, _pf(fin), relstep, absstep, float(dir),
                        _pf(x1), _pf(fx1), _pf(out), _pf(eps))
     if rc != 0:
         raise ValueError("finite_difference_jvp doesn't support :complex-mode finite diff")

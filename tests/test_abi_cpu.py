@@ -20,12 +20,12 @@ def L():
 
 def test_header_symbols_all_exported(L):
     hdr = open(os.path.join(ROOT, "include", "fdjac.h")).read()
-    declared = set(re.findall(r"^(?:int|void \*|const char \*)\s*(fd_[a-z0-9_]+)\(", hdr, re.M))
-    assert len(declared) >= 20
+    declared = set(re.findall(r"^(?:int|void \*|const char \*)\s*(fd(?:32)?_[a-z0-9_]+)\(", hdr, re.M))
+    assert len(declared) >= 60 and sum(n.startswith("fd32_") for n in declared) == len(fd.lib.TYPED)
     assert declared == set(fd.lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fd_version() == 102
+    assert L.fd_version() == 103
 
 
 def test_no_gpu_fails_loudly(L):
