@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--shard", choices=["columns", "colors"], default="columns",
                     help="N>1 decomposition: contiguous column ranges + all-gather (default; needs a row-window-capable f!), "
                          "or colour ownership + all-reduce (any f!, at most C ranks; c4/c2 only)")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="element type of x / f! / J: f64 is the reference's default and the headline; f32 runs the fd32_* "
+                         "instantiation (tridiagonal configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="columns for the CPU baseline sample (0 = same as --n)")
     ap.add_argument("--cpu-reps", type=int, default=64, help="upper bound; the CPU sample stops after --cpu-seconds")
@@ -117,6 +120,10 @@ def main():
     bench_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(bench_stream)
     cfg = args.config
+    np_dt = np.float32 if args.dtype == "f32" else np.float64
+    t_dt = torch.float32 if args.dtype == "f32" else torch.float64
+    if args.dtype == "f32" and cfg not in ("c2", "c4"):
+        raise SystemExit("--dtype f32 is wired for the tridiagonal configs (c2, c4)")
     if cfg in ("c3", "c5") and world > 1:
         raise SystemExit("--config %s is a single-GPU line" % cfg)
     ctx = fd.Context(local_rank)
@@ -132,7 +139,8 @@ def main():
         if args.shard == "colors" and world > 1:
             ccuts = S.partition_colors(colors, world)
             counts, c0, c1 = [nnz], 0, N
-            plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, color_range=(ccuts[rank], ccuts[rank + 1]))
+            plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, color_range=(ccuts[rank], ccuts[rank + 1]),
+                                dtype=np_dt)
         else:
             cuts = S.partition_columns(colptr, world)
             ranges = S.entry_ranges(colptr, cuts)
@@ -140,13 +148,15 @@ def main():
             c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
             xw = S.x_window(cuts, rank, N, 1, 1, 1)
             plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
-                                x_window=xw if world > 1 else None)
-        f = fd.BuiltinF("tridiag", N, ctx=ctx)
+                                x_window=xw if world > 1 else None, dtype=np_dt)
+        f = fd.BuiltinF("tridiag", N, ctx=ctx, dtype=np_dt)
         lazy_ok = True
         # per column: SURVEY 8(d) algorithmic bytes; what this implementation must move at minimum (fx and the three
         # f! arrays read once = 32 B, 3 values written = 24 B, index = 3 x 2-B packed (row,colour) codes with the
         # row-window kernel, 3 x (4-B row + 1-B colour) with the gather kernel); whole call with a streaming f!
         bytes_ds, bytes_min, bytes_call = 89.0, (62.0 if plan.info(fd.lib.INFO_WINDOW) else 71.0), 210.0
+        if args.dtype == "f32":   # the same formulas with 4-byte values: 2*C*M*4 + nnz*4 + nnz*4 + (N+1)*4 + N
+            bytes_ds, bytes_min, bytes_call = 53.0, (34.0 if plan.info(fd.lib.INFO_WINDOW) else 43.0), 114.0
         wl = "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, x~U(0,1) seed %d" % (N, seed)
         kern = "k_decompress_window<forward>" if plan.info(fd.lib.INFO_WINDOW) else "k_decompress_list<u8,forward>"
         exact = (-2.0, 1.0)
@@ -196,18 +206,18 @@ def main():
         wl = "%d dense %dx%d blocks, block-tridiagonal BlockBandedMatrix (N=%d, %d stored values), %d colours, complex step, x~U(0,1) seed 5" % (nb, bs, bs, N, nnz, C)
         kern = "k_decompress_colrange<u8,complex>"
         exact = None
-    x = torch.as_tensor(x_host, device=dev)
+    x = torch.as_tensor(x_host.astype(np_dt), device=dev)
     if args.f_mode == "lazy" and lazy_ok:
         plan.set_lazy(f)
     f_mode = "lazy" if (args.f_mode == "lazy" and lazy_ok) else "materialized"
     gather = world > 1 and not args.no_gather
     by_color = args.shard == "colors" and world > 1 and cfg in ("c2", "c4")
-    bufs = S.AllGatherBuffers(counts, dev, torch.float64)
+    bufs = S.AllGatherBuffers(counts, dev, t_dt)
     out = bufs.local_view(rank)[: counts[rank]] if (world > 1 and not by_color) else bufs.buf
     own = torch.zeros_like(out) if by_color else None   # colour ownership: every rank holds the whole nzval, zero
                                                         # except for the columns of its colours; assembly = SUM
 
-    host_bufs = S.AllGatherBuffers(counts, torch.device("cpu"), torch.float64) if (gather and backend != "nccl") else None
+    host_bufs = S.AllGatherBuffers(counts, torch.device("cpu"), t_dt) if (gather and backend != "nccl") else None
 
     def do_gather():
         if by_color:
@@ -304,7 +314,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": wl, "name": cfg, "fdtype": fdtype, "colors": C,
                        "parallelism": ("colours x%d%s" % (world, "+allreduce" if gather else "")) if by_color else
@@ -334,7 +344,7 @@ def main():
         except Exception as e:  # pragma: no cover
             res["stream_copy_gbps"] = None
             res["stream_copy_error"] = str(e)
-        if not args.no_cpu_baseline and world == 1 and cfg in ("c2", "c4"):
+        if not args.no_cpu_baseline and world == 1 and cfg in ("c2", "c4") and args.dtype == "f64":
             try:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n or N, args.cpu_reps, args.cpu_seconds)
             except Exception as e:  # pragma: no cover

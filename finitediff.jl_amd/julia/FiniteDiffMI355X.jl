@@ -206,6 +206,10 @@ end
 # With AMDGPU.jl, a method for `x::ROCVector{Float64}` / `J.nzval::ROCVector` passes device pointers
 # with FD_DEVICE (zero-copy) -- identical call, `pointer(x)` and kind flags change.
 
+# Float32 problems (`x::Vector{Float32}`, `J` with Float32 values): the same methods with every `:fd_…` symbol that
+# touches values replaced by `:fd32_…` (include/fdjac.h, "Float32 instantiation"); a thin macro over `eltype(x)`
+# generates both sets of `ccall`s.
+
 # ---- finite_difference_jvp! (src/jvp.jl:238-274) ------------------------------------------------
 const JVP_PLANS = WeakKeyDict{Any,Ptr{Cvoid}}()
 function FiniteDiff.finite_difference_jvp!(
