@@ -299,7 +299,8 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 j = json.load(open(pmc_path))
-                if int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and j.get("kernel", "") in kern:
+                if (int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and j.get("kernel", "") in kern
+                        and args.dtype == "f64"):
                     pmc = j.get("decompress_hbm_bytes_per_launch")
             except Exception:
                 pmc = None
