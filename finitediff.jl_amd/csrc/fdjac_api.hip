@@ -229,9 +229,14 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
 // (the tile's colours of the perturbed points, plus fx or the minus points) in whole 1-KiB chunks.
 static size_t window_lds_bytes(int fdtype, int max_slots, int max_ncol)
 {
-    const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
-    const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
-    return wp * narr * 8 + 8 * (size_t)(kWinMaxCol + kW2Desc / 2);
+    static const bool dma = [] { const char *v = getenv("FDJAC_DMA"); return v && *v && atoi(v) != 0; }();
+    if (dma) {   // raw windows of every staged array, whole 1-KiB chunks
+        const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
+        const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
+        return wp * narr * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc;
+    }
+    const size_t wp = (((size_t)max_slots + 31) & ~(size_t)31) + 2;   // differences, one array per colour
+    return wp * (size_t)max_ncol * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc;
 }
 
 static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,

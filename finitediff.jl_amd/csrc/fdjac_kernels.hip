@@ -1062,7 +1062,11 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
     const bool fxvec = (MODE != 0) || (fx == p->d_fx);
     const bool dma = (MODE != 2) && fxvec && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
-    const int wp = (2 * p->win_pairs + 127) & ~127;               // LDS pitch: whole 1-KiB DMA chunks
+    // LDS pitch between colours: whole 1-KiB DMA chunks, or (register path) a pitch that is 2 mod 32 elements so
+    // that neighbouring colours start 4 banks apart (entries of neighbouring columns read neighbouring rows of
+    // DIFFERENT colours; a pitch of 0 mod 32 puts them all on the same banks)
+    // (measured neutral on MI355X -- the LDS is not the bottleneck of these kernels -- but it is the smaller tile)
+    const int wp = dma ? ((2 * p->win_pairs + 127) & ~127) : (((2 * p->win_pairs + 31) & ~31) + 2);
     const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
     const int vok = (((uintptr_t)out) & kPairMask) == 0;
     if (p->window2d) {
