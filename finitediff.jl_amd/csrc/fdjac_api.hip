@@ -16,6 +16,8 @@ static thread_local char g_err[512] = "";
 #endif
 
 int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir);
+int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double absstep, double dir, int pmode,
+                             int base_row);
 int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B);
 int launch_decompress(fd_plan *p, const real_t *fx, int c_lo, int c_hi, real_t *const *outs, int mode);
 int launch_fill(fd_ctx *ctx, real_t *ptr, int64_t n, real_t v);
@@ -146,8 +148,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     p->chunkB = B;
     p->nchunks = p->C > 0 ? (p->C + B - 1) / B : 0;
     int rc;
-    if ((rc = dev_alloc(&p->d_X, B * p->pts * p->cplx * p->ldx))) return rc;
-    if ((rc = dev_alloc(&p->d_FX, B * p->pts * p->cplx * p->ldf))) return rc;
+    // (+1 row: small problems evaluate f(x) as one more member of the perturbed batch)
+    if ((rc = dev_alloc(&p->d_X, (B * p->pts + 1) * p->cplx * p->ldx))) return rc;
+    if ((rc = dev_alloc(&p->d_FX, (B * p->pts + 1) * p->cplx * p->ldf))) return rc;
     if ((rc = dev_alloc(&p->d_fx, p->ldf))) return rc;
     if ((rc = dev_alloc(&p->d_eps, std::max<int64_t>(p->C, 1)))) return rc;
     if ((rc = dev_alloc(&p->d_xstage, p->ldx))) return rc;
@@ -1135,10 +1138,25 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         x_dev = p->d_xstage;
     }
 
+    // Small problems are launch-latency bound: one single-workgroup launch computes the step sizes and, when the
+    // points are materialised, writes them too -- with x itself as one more batch member so that f(x) needs no launch
+    // of its own.  (Complex step: no step-size reduction to fuse with; large or many-coloured problems: the wide path.)
+    static const bool small_off = [] { const char *v = getenv("FDJAC_SMALL"); return v && *v && atoi(v) == 0; }();
+    const bool full_colors = p->own_c0 == 0 && (p->own_c1 < 0 || p->own_c1 >= p->C);
+    // (which reduction computes the step sizes depends on N and C only, so column windows, colour ownership and colour
+    // chunks of the same problem all see bit-identical step sizes)
+    const bool small = !small_off && p->N <= kSmallN && p->C > 0 && p->C <= kRegColors && p->kind != K_DENSE &&
+                       p->fdtype != FD_COMPLEX;
+    const bool small_points = small && !p->lazy_fn && p->nchunks == 1 && full_colors;   // points written by the fused launch
+    const bool base_in_batch = small_points && p->fdtype == FD_FORWARD && !fin_dev;
+    p->fx_batch_row = nullptr;
+
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0) {
         Span sp(p, FD_STAGE_EPS);
-        int rc = launch_eps(p, x_dev, relstep, absstep, dir);
+        int rc = small ? launch_eps_perturb_small(p, x_dev, relstep, absstep, dir, small_points ? p->fdtype : -1,
+                                                  base_in_batch ? (int)(p->C * p->pts) : -1)
+                       : launch_eps(p, x_dev, relstep, absstep, dir);
         if (rc) return rc;
     }
 
@@ -1149,6 +1167,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     if (p->fdtype == FD_FORWARD) {
         if (fin_dev) {
             fx = fin_dev;
+        } else if (base_in_batch) {
+            fx = p->fx_batch_row = p->d_FX + (int64_t)p->C * p->pts * p->ldf;
         } else if (p->lazy_fn && p->nchunks > 0) {
             base_pending = true;
             fx = p->d_fx;
@@ -1208,16 +1228,17 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 p->fcalls_last += 1;
                 base_pending = false;
             }
-            {
+            if (!small_points) {
                 Span sp(p, FD_STAGE_PERTURB);
                 int rc = launch_perturb(p, x_dev, c_lo, B);
                 if (rc) return rc;
             }
             Span sp(p, FD_STAGE_F);
-            const int rc = f(fctx, p->d_FX, p->d_X, (int64_t)B * p->pts, p->ldx, p->ldf, p->row0, p->row1,
+            const int64_t npts = (int64_t)B * p->pts + (base_in_batch ? 1 : 0);   // (+ x itself: f(x) of the forward arm)
+            const int rc = f(fctx, p->d_FX, p->d_X, npts, p->ldx, p->ldf, p->row0, p->row1,
                              p->fdtype == FD_COMPLEX ? 1 : 0, (void *)s);
             FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
-            p->fcalls_last += (int64_t)B * p->pts;
+            p->fcalls_last += npts;
         }
         {
             Span sp(p, FD_STAGE_DECOMPRESS);

@@ -91,6 +91,7 @@ constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
+constexpr int64_t kSmallN = 16384;   // below this a single-workgroup launch does step sizes (+ perturbation): launch-bound regime
 constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
 constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many consecutive colours per tile,
 constexpr int kWinMaxWin = 4;        //   this many row windows per tile (a 5-point stencil needs 3),
@@ -187,6 +188,7 @@ struct fd_plan {
     int64_t out_len[3] = {0, 0, 0};
     fdjac::real_t *d_outstage[3] = {nullptr, nullptr, nullptr};
 
+    const fdjac::real_t *fx_batch_row = nullptr;   // f(x) evaluated as one more member of the perturbed batch (small problems)
     fd_f_launch_lazy lazy_fn = nullptr;
     int lazy_caps = 0;             // FD_LAZY_CAP_* of lazy_fn
     int64_t fcalls_last = 0;

@@ -166,6 +166,102 @@ k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double r
     }
 }
 
+// K1d  small problems (N <= kSmallN, C <= kRegColors, one colour chunk): ONE single-workgroup launch does the masked
+//   sums of squares, the step sizes, and -- unless a lazy launcher perturbs on its own -- the perturbed points of
+//   every colour plus (forward differences without f_in) a copy of x as one more batch member, so that f(x) rides in
+//   the same f! launch.  A Jacobian is then three launches (this, f!, decompression) instead of five or six; below
+//   ~10^5 unknowns the call is launch-latency bound (scripts/latency_probe.py).  Same per-element arithmetic as
+//   k_eps_partial_reg / k_eps_finalize / k_perturb; the summation tree is this kernel's own (deterministic).
+//   PMODE: -1 step sizes only, 0 forward, 1 central, 2 complex-step points.
+constexpr int kSmallBlock = 1024;
+template <typename CT, int NC, int PMODE>
+__global__ void __launch_bounds__(kSmallBlock)
+k_eps_perturb_small(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n, double relstep,
+                    double absstep, double dir, int is_forward, int C, real_t *__restrict__ eps,
+                    real_t *__restrict__ X, int64_t ldx, int base_row)
+{
+    __shared__ double red[kSmallBlock / 64][NC];
+    __shared__ real_t s_eps[NC];
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    for (int64_t i = (int64_t)threadIdx.x * 2; i < n; i += (int64_t)kSmallBlock * 2) {
+        r2_t v;
+        int c0, c1 = -2;
+        if (i + 1 < n) {
+            v = *reinterpret_cast<const r2_t *>(x + i);
+            load_color_pair<CT>(color + i, c0, c1);
+        } else {
+            v = r2_t{x[i], 0};
+            c0 = color[i];
+        }
+        const double s0 = (double)v.x * (double)v.x, s1 = (double)v.y * (double)v.y;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            acc[c] += (c0 == c) ? s0 : 0.0;
+            acc[c] += (c1 == c) ? s1 : 0.0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double t = wave_sum(acc[c]);
+        if (lane == 0) red[wave][c] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NC) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kSmallBlock / 64; ++w) t += red[w][threadIdx.x];
+        const real_t nrm = (real_t)sqrt(t);
+        const real_t xs = fabs(sqrt(nrm));
+        const real_t a = (real_t)relstep * xs;
+        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
+        if (is_forward) e = e * (real_t)dir;
+        s_eps[threadIdx.x] = e;
+        if ((int)threadIdx.x < C) eps[threadIdx.x] = e;
+    }
+    if (PMODE < 0) return;
+    __syncthreads();
+    const int B = C;
+    for (int64_t j = (int64_t)threadIdx.x * 2; j < n; j += (int64_t)kSmallBlock * 2) {
+        const bool pair = j + 1 < n;
+        real_t v0, v1 = 0;
+        int c0, c1 = -1;
+        if (pair) {
+            const r2_t v = *reinterpret_cast<const r2_t *>(x + j);
+            v0 = v.x; v1 = v.y;
+            load_color_pair<CT>(color + j, c0, c1);
+        } else {
+            v0 = x[j];
+            c0 = (int)color[j];
+        }
+        for (int b = 0; b < B; ++b) {
+            const real_t e = s_eps[b];
+            const real_t e0 = (c0 == b) ? e : (real_t)0, e1 = (c1 == b) ? e : (real_t)0;
+            if (PMODE == 2) {
+                real_t *dst = X + ((int64_t)b * ldx + j) * 2;
+                *reinterpret_cast<r2_t *>(dst) = r2_t{v0, e0};
+                if (pair) *reinterpret_cast<r2_t *>(dst + 2) = r2_t{v1, e1};
+            } else {
+                real_t *dp = X + (int64_t)b * ldx + j;
+                if (pair) *reinterpret_cast<r2_t *>(dp) = r2_t{v0 + e0, v1 + e1};
+                else dp[0] = v0 + e0;
+                if (PMODE == 1) {
+                    real_t *dm = X + (int64_t)(B + b) * ldx + j;
+                    if (pair) *reinterpret_cast<r2_t *>(dm) = r2_t{v0 - e0, v1 - e1};
+                    else dm[0] = v0 - e0;
+                }
+            }
+        }
+        if (base_row >= 0) {   // x itself as one more point of the batch: f(x) comes out of the same f! launch
+            real_t *dp = X + (int64_t)base_row * ldx + j;
+            if (pair) *reinterpret_cast<r2_t *>(dp) = r2_t{v0, v1};
+            else dp[0] = v0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2  perturbed points for a whole chunk of colours, written from the pristine x:
 //   forward  X[b][j]   = x[j] + eps_b*(color[j]==b)                 (src/jacobians.jl:562)
@@ -1015,6 +1111,30 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
     return FD_OK;
 }
 
+// the fused small-problem launch (k_eps_perturb_small); pmode -1 = step sizes only
+int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double absstep, double dir, int pmode,
+                             int base_row)
+{
+    hipStream_t s = p->ctx->stream;
+    const int fwd = p->fdtype == FD_FORWARD ? 1 : 0;
+#define FD_SMALL(CT, NC, PM)                                                                                        \
+    hipLaunchKernelGGL((k_eps_perturb_small<CT, NC, PM>), dim3(1), dim3(kSmallBlock), 0, s, x, (const CT *)p->d_color, \
+                       p->N, relstep, absstep, dir, fwd, (int)p->C, p->d_eps, p->d_X, p->ldx, base_row)
+#define FD_SMALL_PM(CT, NC)                                                        \
+    switch (pmode) {                                                               \
+    case 0: FD_SMALL(CT, NC, 0); break;                                            \
+    case 1: FD_SMALL(CT, NC, 1); break;                                            \
+    case 2: FD_SMALL(CT, NC, 2); break;                                            \
+    default: FD_SMALL(CT, NC, -1); break;                                          \
+    }
+    if (p->color8) { if (p->C <= 4) { FD_SMALL_PM(uint8_t, 4) } else { FD_SMALL_PM(uint8_t, kRegColors) } }
+    else { if (p->C <= 4) { FD_SMALL_PM(int32_t, 4) } else { FD_SMALL_PM(int32_t, kRegColors) } }
+#undef FD_SMALL_PM
+#undef FD_SMALL
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
 int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir)
 {
     if (p->kind == K_DENSE) {
@@ -1060,7 +1180,7 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
     static const bool dma_off = env_i64("FDJAC_DMA", 0) == 0;
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
-    const bool fxvec = (MODE != 0) || (fx == p->d_fx);
+    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
     const bool dma = (MODE != 2) && fxvec && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
     // LDS pitch between colours: whole 1-KiB DMA chunks, or (register path) a pitch that is 2 mod 32 elements so
     // that neighbouring colours start 4 banks apart (entries of neighbouring columns read neighbouring rows of
@@ -1170,7 +1290,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         if (!win_off && p->C <= 4 && (p->col0 % 2) == 0 && p->col1 > p->col0) {
             const int64_t nt = (p->col1 - p->col0 + kTriTile - 1) / kTriTile;
             const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
-            const int fxvec = (MODE != 0) || (fx == p->d_fx);
+            const int fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
             const int vok = ((((uintptr_t)outs[1]) & kPairMask) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 2 : 0) |
                             (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0);
             const size_t shmt = sizeof(real_t) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
