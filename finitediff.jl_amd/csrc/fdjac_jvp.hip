@@ -111,6 +111,45 @@ k_jvp_points(const real_t *__restrict__ x, const real_t *__restrict__ v, const r
     }
 }
 
+// Small problems (N <= kSmallN): dot product, step size and the perturbed point(s) in ONE single-workgroup launch, with
+// x itself as one more batch member (forward arm without f_in) so that f(x) and f(x + eps v) come out of one f! launch:
+// three launches per JVP instead of six -- the inner loop of a Newton-Krylov solver is launch-latency bound.
+constexpr int kJvpSmallBlock = 1024;
+__global__ void __launch_bounds__(kJvpSmallBlock)
+k_jvp_small(const real_t *__restrict__ x, const real_t *__restrict__ v, int64_t n, double relstep, double absstep,
+            double dir, int central, int base_row, real_t *__restrict__ eps, real_t *__restrict__ X, int64_t ld)
+{
+    __shared__ double red[kJvpSmallBlock / 64];
+    __shared__ real_t s_e;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kJvpSmallBlock) acc += (double)x[i] * (double)v[i];
+    acc = wave_sum_j(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kJvpSmallBlock / 64; ++w) t += red[w];
+        const real_t tmp = sqrt(fabs((real_t)t));
+        const real_t a = (real_t)relstep * fabs(tmp);
+        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;   // src/epsilons.jl:26-29,50-53
+        if (!central) e = e * (real_t)dir;
+        eps[0] = e;
+        s_e = e;
+    }
+    __syncthreads();
+    const real_t e = s_e;
+    for (int64_t i = threadIdx.x; i < n; i += kJvpSmallBlock) {
+        const real_t xi = x[i], ev = e * v[i];
+        if (central) {
+            X[i] = xi - ev;
+            X[ld + i] = xi + ev;
+        } else {
+            X[i] = xi + ev;
+            if (base_row >= 0) X[(int64_t)base_row * ld + i] = xi;
+        }
+    }
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_jvp_diff(const real_t *__restrict__ a, const real_t *__restrict__ b, const real_t *__restrict__ eps, int central,
@@ -165,7 +204,8 @@ int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_pla
     const int pts = fdtype == FD_CENTRAL ? 2 : 1;
     void **slots[] = {(void **)&p->d_X, (void **)&p->d_FX, (void **)&p->d_fx, (void **)&p->d_eps, (void **)&p->d_partial,
                       (void **)&p->d_xs, (void **)&p->d_vs, (void **)&p->d_fin, (void **)&p->d_out};
-    const int64_t sizes[] = {pts * p->ldx, pts * p->ldf, p->ldf, 1, p->nparts, p->ldx, p->ldx, p->ldf, p->ldf};
+    // (+1 row of X / FX: small forward problems evaluate f(x) as a second member of the batch)
+    const int64_t sizes[] = {(pts + 1) * p->ldx, (pts + 1) * p->ldf, p->ldf, 1, p->nparts, p->ldx, p->ldx, p->ldf, p->ldf};
     for (int k = 0; k < 9; ++k)
         if (hipMalloc(slots[k], sizeof(double) * (size_t)sizes[k]) != hipSuccess) {   // (partials are Float64)
             set_error("hipMalloc failed in fd_jvp_plan_create");
@@ -200,14 +240,22 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *
     if (absstep < 0) absstep = relstep;
     const int g = balanced_grid((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
     const int gm = balanced_grid((p->M + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
+    static const bool small_off = [] { const char *e = getenv("FDJAC_SMALL"); return e && *e && atoi(e) == 0; }();
+    const bool small = !small_off && p->N <= kSmallN;
+    const bool base_in_batch = small && !central && !fin;
     const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & kPairMask) == 0;
-    if (vx) hipLaunchKernelGGL(k_dot_partial<true>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
-    else hipLaunchKernelGGL(k_dot_partial<false>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
-    hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
-                       central ? 0 : 1, p->d_eps);
-    if (vx) hipLaunchKernelGGL(k_jvp_points<true>, dim3((unsigned)((p->N + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s,
-                               xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
-    else hipLaunchKernelGGL(k_jvp_points<false>, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    if (small) {
+        hipLaunchKernelGGL(k_jvp_small, dim3(1), dim3(kJvpSmallBlock), 0, s, xd, vd, p->N, relstep, absstep, dir, central,
+                           base_in_batch ? 1 : -1, p->d_eps, p->d_X, p->ldx);
+    } else {
+        if (vx) hipLaunchKernelGGL(k_dot_partial<true>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+        else hipLaunchKernelGGL(k_dot_partial<false>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+        hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
+                           central ? 0 : 1, p->d_eps);
+        if (vx) hipLaunchKernelGGL(k_jvp_points<true>, dim3((unsigned)((p->N + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s,
+                                   xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+        else hipLaunchKernelGGL(k_jvp_points<false>, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    }
     FD_HIP_CHECK(hipGetLastError());
     const real_t *a, *b;
     int rc;
@@ -216,6 +264,11 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *
         FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
         a = p->d_FX + p->ldf;  // f(x + eps v)
         b = p->d_FX;           // f(x - eps v)
+    } else if (base_in_batch) {
+        rc = f(fctx, p->d_FX, p->d_X, 2, p->ldx, p->ldf, 0, p->M, 0, (void *)s);   // points: x + eps v, x
+        FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+        a = p->d_FX;
+        b = p->d_FX + p->ldf;
     } else {
         if (fin) {
             b = fin;
