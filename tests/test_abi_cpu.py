@@ -121,3 +121,17 @@ def test_matrix_colors_plan_time_colouring(L):
     # closed forms
     assert fd.matrix_colors(fd.Tridiagonal(np.zeros(9), np.zeros(10), np.zeros(9))).tolist() == [1, 2, 3, 1, 2, 3, 1, 2, 3, 1]
     assert fd.matrix_colors(fd.BandedMatrix(np.zeros((4, 6), order="F"), 6, 2, 1)).tolist() == [1, 2, 3, 4, 1, 2]
+
+
+def test_plain_c_client_builds_and_fails_loudly_without_gpu(tmp_path):
+    # the C example links against the library with nothing but gcc; without a GPU it must report FD_ERR_NODEVICE
+    import subprocess
+    import torch
+    exe = str(tmp_path / "c_abi_tridiag")
+    libdir = os.path.join(ROOT, "finitediff.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_tridiag.c"),
+                           "-o", exe, "-L" + libdir, "-lfdjac", "-lm", "-Wl,-rpath," + libdir])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself is a -m gpu test")
+    out = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "no HIP device" in out.stderr

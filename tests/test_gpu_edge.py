@@ -194,3 +194,18 @@ def test_two_plans_from_two_threads():
     for k, tol in ((0, 5e-7), (1, 1e-9), (2, 1e-14), (3, 5e-7)):
         assert np.max(np.abs(results[k][isdiag] + 2.0)) < tol and np.max(np.abs(results[k][~isdiag] - 1.0)) < tol
     assert np.array_equal(results[0], results[3])
+
+
+def test_plain_c_client(tmp_path):
+    # examples/c_abi_tridiag.c: the ABI used from plain C with Julia-style host arrays (what a ccall shim does)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_tridiag")
+    libdir = os.path.join(root, "finitediff.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_tridiag.c"),
+                           "-o", exe, "-L" + libdir, "-lfdjac", "-lm", "-Wl,-rpath," + libdir])
+    for n in ("30", "100000"):
+        out = subprocess.run([exe, n], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "f!_evaluations=4" in out.stdout
