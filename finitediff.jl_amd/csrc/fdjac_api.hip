@@ -331,7 +331,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
         const int force_w = (fw && *fw) ? atoi(fw) : -1, force_s = (fs && *fs) ? atoi(fs) : -1;
         WinBuild best;
         if (force_w != 0 && force_s != 1) {
-            const char *ft = getenv("FDJAC_WIN_TILE");   // experiment knob: force the tile size (2048, 1024 or 512)
+            const char *ft = getenv("FDJAC_WIN_TILE");   // test / tuning switch: force the tile size (2048, 1024 or 512)
             const int force_t = (ft && *ft) ? atoi(ft) : 0;
             for (int T : {2048, 1024, 512}) {
                 if (force_t && T != force_t) continue;
