@@ -1010,6 +1010,93 @@ k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ 
     }
 }
 
+// K5b  the same column-range decompression, one WORKGROUP per kCrCols consecutive columns.  A wave per column leaves
+//   a wave with ~1.5 loads of work behind two dependent round trips (column metadata, then values): the kernel runs
+//   at the latency, not the bandwidth, of the memory system.  Here the metadata of kCrCols columns is fetched with
+//   one coalesced load, and their (row, column) work items are flattened so that every thread has kCrU independent
+//   gathers in flight.
+constexpr int kCrCols = 32;
+constexpr int kCrU = 4;
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict__ rlo,
+                         const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
+                         const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
+                         const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t j0, int64_t ncols,
+                         real_t *__restrict__ data)
+{
+    __shared__ int s_c[kCrCols], s_r0[kCrCols], s_end[kCrCols + 1];
+    __shared__ int64_t s_off[kCrCols];
+    __shared__ real_t s_e[kCrCols];
+    const int none = ColorTraits<CT>::none;
+    const int64_t jb = (int64_t)blockIdx.x * kCrCols;
+    const int nloc = (int)((ncols - jb < kCrCols) ? ncols - jb : kCrCols);
+    if (threadIdx.x < kCrCols) {
+        const int t = threadIdx.x;
+        int c = none, n = 0;
+        if (t < nloc) {
+            c = (int)color[j0 + jb + t];
+            n = cnt[jb + t];
+            s_r0[t] = rlo[jb + t];
+            s_off[t] = off[jb + t];
+        }
+        const bool live = (c != none) & (c >= c_lo) & (c < c_hi);
+        const bool zero = (c == none) & (c_lo == 0) & (t < nloc);
+        s_c[t] = live ? c - c_lo : (zero ? -1 : -2);      // >= 0 colour of the chunk, -1 write zeros, -2 leave untouched
+        s_e[t] = live ? eps[c] : (real_t)1;
+        // inclusive prefix of the row counts over the 32 columns (one half-wave)
+        int incl = n;
+#pragma unroll
+        for (int d = 1; d < kCrCols; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (t >= d) incl += o;
+        }
+        s_end[t + 1] = incl;
+        if (t == 0) s_end[0] = 0;
+    }
+    __syncthreads();
+    const int total = s_end[kCrCols];
+    for (int q0 = 0; q0 < total; q0 += kBlock * kCrU) {
+        real_t a[kCrU], b[kCrU];
+        int col[kCrU], k[kCrU];
+#pragma unroll
+        for (int u = 0; u < kCrU; ++u) {
+            const int q = q0 + u * kBlock + (int)threadIdx.x;
+            a[u] = 0; b[u] = 0; col[u] = -1; k[u] = 0;
+            if (q < total) {
+                int lo = 0, hi = kCrCols;                 // column of work item q: s_end[lo] <= q < s_end[lo + 1]
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_end[mid] <= q) lo = mid; else hi = mid;
+                }
+                col[u] = lo;
+                k[u] = q - s_end[lo];
+                const int cb = s_c[lo];
+                if (cb >= 0) {
+                    const int64_t r = (int64_t)s_r0[lo] + k[u];
+                    const int64_t at = (int64_t)cb * ld + r;
+                    if (MODE == 0) { a[u] = FXa[at]; b[u] = FXb[r]; }
+                    else if (MODE == 1) { a[u] = FXa[at]; b[u] = FXb[at]; }
+                    else { a[u] = FXa[at * 2 + 1]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kCrU; ++u) {
+            if (col[u] < 0) continue;
+            const int cb = s_c[col[u]];
+            if (cb >= 0) {
+                const real_t e = s_e[col[u]];
+                const real_t v = (MODE == 0) ? (a[u] - b[u]) / e : (MODE == 1) ? (a[u] - b[u]) / (2 * e) : a[u] / e;
+                data[s_off[col[u]] + k[u]] = v;
+            } else if (cb == -1) {
+                data[s_off[col[u]] + k[u]] = (real_t)0;
+            }
+        }
+    }
+}
+
 // K6  dense, uncoloured arm (sparsity === nothing, src/jacobians.jl:548-557 / 590-598 / 626-631):
 //   "colour" i perturbs the single entry x[i] with the PER-ELEMENT step
 //   eps_i = compute_epsilon(fdtype, x[i], relstep, absstep, dir)  (src/epsilons.jl:26-29,50-53)
@@ -1321,6 +1408,15 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         break;
     }
     case K_COLRANGE: {
+        static const bool cr_wave = env_i64("FDJAC_COLRANGE_WG", 1) == 0;
+        if (!cr_wave) {   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
+            const int64_t nc = p->col1 - p->col0;
+            if (nc > 0)
+                hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE>), dim3((unsigned)((nc + kCrCols - 1) / kCrCols)), dim3(kBlock),
+                                   0, s, color, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi,
+                                   p->col0, nc, outs[0]);
+            break;
+        }
         const int g = grid_for(p->col1 - p->col0, kBlock / 64, p->ctx->num_cus);
         hipLaunchKernelGGL((k_decompress_colrange<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, p->d_cr_rlo,
                            p->d_cr_cnt, p->d_cr_off, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->col0,
