@@ -182,7 +182,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
                 if (col0[(size_t)j] >= 0) perm[(size_t)fillp[(size_t)col0[(size_t)j]]++] = (int32_t)j;
             if ((rc = dev_upload(&p->d_perm, perm))) return rc;
             if ((rc = dev_upload(&p->d_cptr, cptr))) return rc;
-            int64_t chunks = (p->N / std::max<int64_t>(p->C, 1) + 4095) / 4096;
+            // ~512 columns per workgroup: two dependent-free rounds of (index load, gather) each -- with 4096 the
+            // reduction of a many-coloured small problem ran at the latency of 16 rounds (96 colours, N = 320000: 21 us)
+            int64_t chunks = (p->N / std::max<int64_t>(p->C, 1) + 511) / 512;
             p->seg_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, 256));
             FD_REQUIRE((int64_t)p->C * p->seg_chunks < ((int64_t)1 << 31), FD_ERR_UNSUPPORTED, "too many colours");
             if ((rc = dev_alloc(&p->d_partial, (int64_t)p->seg_chunks * p->C))) return rc;
