@@ -359,6 +359,8 @@ class Plan:
     def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
         """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""
         L = self.Lt
+        if np.dtype(getattr(f, "dtype", self.dtype)) != self.dtype:
+            raise TypeError("f! launcher is built for %s, the plan for %s" % (np.dtype(f.dtype).name, self.dtype.name))
         xp, xk, _k1 = _ptr(x, "x", self.dtype)
         ptrs, kinds, keep = [], set(), []
         for o in outs:
@@ -629,6 +631,8 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     M, N = int(np.prod(jvp.shape)), int(np.prod(x.shape))
     h = cache._plan_for(M, N, ctx)
     Lt = _l.typed(ctx.L, cache.dtype)
+    if np.dtype(getattr(f, "dtype", cache.dtype)) != cache.dtype:
+        raise TypeError("f! launcher is built for %s, the cache for %s" % (np.dtype(f.dtype).name, cache.dtype.name))
     xp, xk, _a = _ptr(x, "x", cache.dtype)
     vp_, vk, _b = _ptr(v, "v", cache.dtype)
     if xk != vk:

@@ -202,6 +202,8 @@ def test_user_f_and_host_arrays_float32():
     assert np.linalg.norm(J - E) <= 5e-3 * np.linalg.norm(E)
     with pytest.raises(TypeError):      # mixing element types is an error, not a silent conversion
         fd.finite_difference_jacobian_b(np.zeros((4, 3)), f, theta, cache)
+    with pytest.raises(TypeError):      # ... also a Float64 launcher on a Float32 problem
+        fd.finite_difference_jacobian_b(J, fd.TorchF(fn, 4, 3), theta, cache)
 
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
