@@ -204,7 +204,8 @@ def main():
         bytes_min = (nnz * 16 + nnz * 8 + N) / N                          # every stored value reads one complex f value
         bytes_call = bytes_ds + (C * N * 16 * 3 + 9 * N) / N
         wl = "%d dense %dx%d blocks, block-tridiagonal BlockBandedMatrix (N=%d, %d stored values), %d colours, complex step, x~U(0,1) seed 5" % (nb, bs, bs, N, nnz, C)
-        kern = "k_decompress_colrange<u8,complex>"
+        kern = ("k_decompress_colrange_wg<u8,complex>" if os.environ.get("FDJAC_COLRANGE_WG", "1") != "0"
+                else "k_decompress_colrange<u8,complex>")
         exact = None
     x = torch.as_tensor(x_host.astype(np_dt), device=dev)
     if args.f_mode == "lazy" and lazy_ok:
@@ -234,8 +235,10 @@ def main():
     if by_color:
         out = own
 
+    enqueue = plan.bind(f, x, [out])   # pointers resolved once: one foreign call per Jacobian, as from compiled code
+
     def step():
-        plan.jacobian(f, x, [out], sync=False)
+        enqueue()
         if gather:
             do_gather()
 
@@ -248,12 +251,12 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    plan.enable_timing(1)   # HIP events around the graded kernel and the whole call, on the launch stream
+    plan.enable_timing(1)   # HIP events around the graded kernel, on the launch stream (2 per step; nothing waits on them)
     # gather time measured on its own with HIP events on torch's current stream (= the plan's stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)] if gather else []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        plan.jacobian(f, x, [out], sync=False)
+        enqueue()
         if gather:
             ev[2 * k].record()
             do_gather()
@@ -264,7 +267,7 @@ def main():
     # per-stage breakdown from a separate, untimed pass (more events => more marker packets on the stream)
     plan.enable_timing(2)
     for _ in range(min(args.steps, 10)):
-        plan.jacobian(f, x, [out], sync=False)
+        enqueue()
     torch.cuda.synchronize()
     tm_all = plan.timings()
     plan.enable_timing(0)
@@ -291,7 +294,7 @@ def main():
         dec = tm["decompress"]
         dec_ms = dec["ms_sum"] / max(dec["launches"], 1)
         achieved = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
-        tot_ms = tm["total"]["ms_sum"] / max(tm["total"]["launches"], 1)
+        tot_ms = tm_all["total"]["ms_sum"] / max(tm_all["total"]["launches"], 1)
         pmc = None
         # HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes of this same command
         # (scripts/profile.sh + scripts/make_pmc_json.py; counters cannot be read from inside the process)

@@ -337,7 +337,7 @@ class Plan:
         return np.array(buf[:n])
 
     def enable_timing(self, level=2):
-        """0 off; 1 = diff+decompress kernel and whole call only; 2 = every stage."""
+        """0 off; 1 = the diff+decompress kernel only (2 events per call); 2 = every stage and the whole call."""
         _l.check(self.Lt.fd_plan_enable_timing(self.handle, int(level)))
 
     def timings(self):
@@ -388,6 +388,46 @@ class Plan:
             f.error = None
             raise err
         _l.check(rc)
+
+
+    def bind(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True):
+        """Validate (f, x, outs) once and return a zero-argument callable that enqueues the call on the context's
+        stream (fd_jacobian_async) -- what a compiled caller of the ABI does: pointers resolved once, one foreign call
+        per Jacobian.  Device arrays only; the arrays are kept alive by the callable."""
+        L = self.Lt
+        if np.dtype(getattr(f, "dtype", self.dtype)) != self.dtype:
+            raise TypeError("f! launcher is built for %s, the plan for %s" % (np.dtype(f.dtype).name, self.dtype.name))
+        keep = [f, x, list(outs), f_in]
+        xp, xk, _k = _ptr(x, "x", self.dtype)
+        ptrs = []
+        for o in outs:
+            p, k, _k = _ptr(o, "output", self.dtype)
+            if k != _l.DEVICE:
+                raise ValueError("bind() needs device arrays")
+            ptrs.append(p)
+        fp = None
+        if f_in is not None:
+            fp, fk, _k = _ptr(f_in, "f_in", self.dtype)
+            if fk != _l.DEVICE:
+                raise ValueError("bind() needs device arrays")
+        if xk != _l.DEVICE:
+            raise ValueError("bind() needs device arrays")
+        arr = (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
+        rel = C.c_double(-1.0 if relstep is None else float(relstep))
+        ab = C.c_double(-1.0 if absstep is None else float(absstep))
+        dr = C.c_double(float(dir))
+        fn, handle, ffn, fctx, xpp, fpp = L.fd_jacobian_async, self.handle, f.fn, f.fctx, C.c_void_p(xp), C.c_void_p(fp)
+
+        def call():
+            rc = fn(handle, ffn, fctx, xpp, fpp, rel, ab, dr, arr)
+            if rc:
+                err = getattr(f, "error", None)
+                if err is not None:
+                    f.error = None
+                    raise err
+                _l.check(rc)
+        call.keep = keep
+        return call
 
 
 def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None):

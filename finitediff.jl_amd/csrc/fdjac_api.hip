@@ -1057,9 +1057,9 @@ struct Span {
     int idx = -1;
     Span(fd_plan *pl, int stage) : p(pl)
     {
-        // level 1: only the graded kernel + the whole call (2 x 2 events per call); level 2: every stage
+        // level 1: only the graded kernel (2 events per call); level 2: every stage + the whole call
         if (p->timing == 0) return;
-        if (p->timing == 1 && stage != FD_STAGE_DECOMPRESS && stage != FD_STAGE_TOTAL) return;
+        if (p->timing == 1 && stage != FD_STAGE_DECOMPRESS) return;
         fdjac::TimedSpan s{stage, take_event(p), take_event(p)};
         (void)hipEventRecord(s.a, p->ctx->stream);
         p->spans.push_back(s);
@@ -1073,11 +1073,21 @@ struct Span {
     ~Span() { stop(); }
 };
 
-static int collect_spans(fd_plan *p)
+// Reads the spans whose events have completed.  blocking = false (start of every call) never waits for the
+// device: the stream keeps running ahead of the host; spans are recorded in stream order, so the first one still
+// in flight ends the sweep.  The list is bounded by a blocking sweep once kMaxSpansInFlight are outstanding.
+static constexpr size_t kMaxSpansInFlight = 4096;
+static int collect_spans(fd_plan *p, bool blocking = true)
 {
     if (p->spans.empty()) return FD_OK;
-    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    if (!blocking && p->spans.size() >= kMaxSpansInFlight) blocking = true;
+    if (blocking) FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    size_t done = 0;
     for (auto &s : p->spans) {
+        if (!blocking && hipEventQuery(s.b) != hipSuccess) {
+            (void)hipGetLastError();   // hipErrorNotReady is not an error: keep it out of the launch checks
+            break;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             p->ms_sum[s.stage] += ms;
@@ -1085,8 +1095,9 @@ static int collect_spans(fd_plan *p)
         }
         p->event_pool.push_back(s.a);
         p->event_pool.push_back(s.b);
+        ++done;
     }
-    p->spans.clear();
+    p->spans.erase(p->spans.begin(), p->spans.begin() + (ptrdiff_t)done);
     return FD_OK;
 }
 
@@ -1131,7 +1142,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     p->relstep_last = relstep;
     p->absstep_last = absstep;
     p->fcalls_last = 0;
-    if (collect_spans(p) != FD_OK) return FD_ERR_HIP;  // keeps the event list bounded
+    if (collect_spans(p, false) != FD_OK) return FD_ERR_HIP;  // harvest finished spans, never wait for the device
     Span total(p, FD_STAGE_TOTAL);
 
     // x must be 16-B aligned for the vector loads; stage it otherwise

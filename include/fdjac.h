@@ -225,8 +225,9 @@ int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
 
 /* Per-stage GPU time of the calls made since timing was enabled (HIP events on the plan's
    stream).  stage: 0 eps-reduce, 1 perturb, 2 f!, 3 diff+decompress, 4 whole call.
-   ms_sum / launches accumulate; collect implies a stream synchronise.
-   on: 0 = off, 1 = diff+decompress and whole call only (4 events per call), 2 = every stage. */
+   ms_sum / launches accumulate; fd_plan_get_timings / fd_plan_enable_timing synchronise the stream, the calls
+   themselves never wait for the device (finished spans are harvested with hipEventQuery).
+   on: 0 = off, 1 = the diff+decompress kernel only (2 events per call), 2 = every stage and the whole call. */
 enum fd_stage { FD_STAGE_EPS = 0, FD_STAGE_PERTURB = 1, FD_STAGE_F = 2, FD_STAGE_DECOMPRESS = 3,
                 FD_STAGE_TOTAL = 4, FD_NSTAGES = 5 };
 int fd_plan_enable_timing(fd_plan *plan, int on);

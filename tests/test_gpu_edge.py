@@ -209,3 +209,54 @@ def test_plain_c_client(tmp_path):
         out = subprocess.run([exe, n], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "f!_evaluations=4" in out.stdout
+
+
+def test_stage_timings_do_not_serialise_the_stream():
+    # fd_plan_enable_timing: level 1 brackets the diff+decompress kernel only, level 2 every stage + the whole call;
+    # the calls harvest finished spans with hipEventQuery (never a stream synchronise), results are unchanged
+    N = 200_000
+    cp, rv = P.tridiag_csc(N)
+    pat = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    plan = fd.make_plan(pat, pat, P.cyclic_colors(N, 3), "forward")
+    f = fd.BuiltinF("tridiag", N)
+    x = torch.as_tensor(np.random.default_rng(0).random(N), device="cuda")
+    ref = torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda")
+    plan.jacobian(f, x, [ref])
+    out = torch.empty_like(ref)
+    plan.enable_timing(1)
+    for _ in range(50):
+        plan.jacobian(f, x, [out], sync=False)
+    tm = plan.timings()
+    assert tm["decompress"]["launches"] == 50 and tm["total"]["launches"] == 0 and tm["f"]["launches"] == 0
+    assert 0 < tm["decompress"]["ms_sum"] / 50 < 1.0
+    plan.enable_timing(2)
+    for _ in range(7):
+        plan.jacobian(f, x, [out], sync=False)
+    tm = plan.timings()
+    assert tm["total"]["launches"] == 7 and tm["decompress"]["launches"] == 7 and tm["eps"]["launches"] == 7
+    assert tm["total"]["ms_sum"] >= tm["decompress"]["ms_sum"] > 0
+    plan.enable_timing(0)
+    plan.jacobian(f, x, [out])
+    assert plan.timings()["decompress"]["launches"] == 0 and torch.equal(out, ref)
+
+
+def test_bound_call_matches_and_validates():
+    # Plan.bind: arguments resolved once, one foreign call per Jacobian; same bits as Plan.jacobian
+    N = 5000
+    cp, rv = P.tridiag_csc(N)
+    pat = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    plan = fd.make_plan(pat, pat, P.cyclic_colors(N, 3), "central")
+    f = fd.BuiltinF("tridiag_nl", N)
+    x = torch.as_tensor(np.random.default_rng(1).random(N), device="cuda")
+    ref = torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda")
+    plan.jacobian(f, x, [ref])
+    out = torch.full_like(ref, float("nan"))
+    call = plan.bind(f, x, [out])
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and f.fcalls == 4 * 6
+    with pytest.raises(ValueError):
+        plan.bind(f, x.cpu().numpy(), [out])
+    with pytest.raises(TypeError):
+        plan.bind(fd.BuiltinF("tridiag_nl", N, dtype=np.float32), x, [out])
