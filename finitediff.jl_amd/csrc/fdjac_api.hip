@@ -959,6 +959,7 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
     const int64_t w = bl + bu + 1;
     int64_t r0 = N, r1 = 0, dmin = std::numeric_limits<int64_t>::max(), dmax = 0;
     int64_t J = 0;
+    bool pairs_ok = true;   // every column: even first row, even row count, even destination -> 16-B work items
     for (int64_t j = p->col0; j < p->col1; ++j) {
         while (off[(size_t)J + 1] <= j) ++J;
         const int64_t K0 = std::max<int64_t>(J - bu, 0), K1 = std::min<int64_t>(J + bl, nblk - 1);
@@ -988,6 +989,7 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
         rlo[jj] = (int32_t)off[(size_t)K0];
         cnt[jj] = (int32_t)rows_n;
         offs[jj] = start0 + (j - off[(size_t)J]) * stride;
+        pairs_ok = pairs_ok && (((off[(size_t)K0] | rows_n) & 1) == 0);
         r0 = std::min<int64_t>(r0, off[(size_t)K0]);
         r1 = std::max<int64_t>(r1, off[(size_t)K1 + 1]);
         dmin = std::min<int64_t>(dmin, offs[jj]);
@@ -995,7 +997,11 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
     }
     if (nloc == 0) { r0 = r1 = 0; dmin = dmax = 0; }
     // outputs are relative to the first local stored value
-    for (auto &o : offs) o -= dmin;
+    for (auto &o : offs) {
+        o -= dmin;
+        pairs_ok = pairs_ok && ((o & 1) == 0);
+    }
+    p->cr_pairs = pairs_ok && nloc > 0;
     p->entry_begin = dmin;
     p->row0 = r0;
     p->row1 = r1;

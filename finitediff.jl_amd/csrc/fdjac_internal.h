@@ -168,6 +168,7 @@ struct fd_plan {
     int32_t *d_cr_rlo = nullptr;   // colrange (block-banded): first row of each local column
     int32_t *d_cr_cnt = nullptr;   //   number of contiguous rows
     int64_t *d_cr_off = nullptr;   //   destination offset of the first row
+    bool cr_pairs = false;         //   all three even for every column: the kernel works on row pairs (16 B)
     // segmented epsilon reduction (C > kRegColors)
     int32_t *d_perm = nullptr;     // columns sorted by colour
     int64_t *d_cptr = nullptr;     // C+1 offsets into perm

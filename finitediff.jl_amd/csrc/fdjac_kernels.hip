@@ -1017,7 +1017,7 @@ k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ 
 //   gathers in flight.
 constexpr int kCrCols = 32;
 constexpr int kCrU = 4;
-template <typename CT, int MODE>
+template <typename CT, int MODE, bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict__ rlo,
                          const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
@@ -1025,6 +1025,10 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
                          const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t j0, int64_t ncols,
                          real_t *__restrict__ data)
 {
+    // VEC: every column's first row, row count and destination are even (found at plan time) and the arrays are
+    // 16-B aligned -- a work item is a PAIR of rows (one 16-B load per operand, one 16-B store).
+    // FXb == nullptr: the subtrahend is identically zero (imaginary parts of the complex step, a - 0.0 == a).
+    constexpr int SH = VEC ? 1 : 0;
     __shared__ int s_c[kCrCols], s_r0[kCrCols], s_end[kCrCols + 1];
     __shared__ int64_t s_off[kCrCols];
     __shared__ real_t s_e[kCrCols];
@@ -1036,7 +1040,7 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
         int c = none, n = 0;
         if (t < nloc) {
             c = (int)color[j0 + jb + t];
-            n = cnt[jb + t];
+            n = cnt[jb + t] >> SH;
             s_r0[t] = rlo[jb + t];
             s_off[t] = off[jb + t];
         }
@@ -1044,7 +1048,7 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
         const bool zero = (c == none) & (c_lo == 0) & (t < nloc);
         s_c[t] = live ? c - c_lo : (zero ? -1 : -2);      // >= 0 colour of the chunk, -1 write zeros, -2 leave untouched
         s_e[t] = live ? eps[c] : (real_t)1;
-        // inclusive prefix of the row counts over the 32 columns (one half-wave)
+        // inclusive prefix of the work items (rows, or row pairs) over the 32 columns (one half-wave)
         int incl = n;
 #pragma unroll
         for (int d = 1; d < kCrCols; d <<= 1) {
@@ -1057,12 +1061,12 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
     __syncthreads();
     const int total = s_end[kCrCols];
     for (int q0 = 0; q0 < total; q0 += kBlock * kCrU) {
-        real_t a[kCrU], b[kCrU];
+        d2_t a[kCrU], b[kCrU];
         int col[kCrU], k[kCrU];
 #pragma unroll
         for (int u = 0; u < kCrU; ++u) {
             const int q = q0 + u * kBlock + (int)threadIdx.x;
-            a[u] = 0; b[u] = 0; col[u] = -1; k[u] = 0;
+            a[u] = d2_t{0, 0}; b[u] = d2_t{0, 0}; col[u] = -1; k[u] = 0;
             if (q < total) {
                 int lo = 0, hi = kCrCols;                 // column of work item q: s_end[lo] <= q < s_end[lo + 1]
 #pragma unroll
@@ -1071,14 +1075,26 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
                     if (s_end[mid] <= q) lo = mid; else hi = mid;
                 }
                 col[u] = lo;
-                k[u] = q - s_end[lo];
+                k[u] = (q - s_end[lo]) << SH;
                 const int cb = s_c[lo];
                 if (cb >= 0) {
                     const int64_t r = (int64_t)s_r0[lo] + k[u];
                     const int64_t at = (int64_t)cb * ld + r;
-                    if (MODE == 0) { a[u] = FXa[at]; b[u] = FXb[r]; }
-                    else if (MODE == 1) { a[u] = FXa[at]; b[u] = FXb[at]; }
-                    else { a[u] = FXa[at * 2 + 1]; }
+                    if constexpr (VEC) {
+                        if (MODE == 2) {
+                            const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                            const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                            a[u] = d2_t{p0.y, p1.y};
+                        } else {
+                            a[u] = *reinterpret_cast<const d2_t *>(FXa + at);
+                            if (MODE == 1) b[u] = *reinterpret_cast<const d2_t *>(FXb + at);
+                            else if (FXb) b[u] = *reinterpret_cast<const d2_t *>(FXb + r);
+                        }
+                    } else {
+                        if (MODE == 0) { a[u].x = FXa[at]; if (FXb) b[u].x = FXb[r]; }
+                        else if (MODE == 1) { a[u].x = FXa[at]; b[u].x = FXb[at]; }
+                        else { a[u].x = FXa[at * 2 + 1]; }
+                    }
                 }
             }
         }
@@ -1086,12 +1102,19 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
         for (int u = 0; u < kCrU; ++u) {
             if (col[u] < 0) continue;
             const int cb = s_c[col[u]];
+            real_t *dst = data + s_off[col[u]] + k[u];
             if (cb >= 0) {
                 const real_t e = s_e[col[u]];
-                const real_t v = (MODE == 0) ? (a[u] - b[u]) / e : (MODE == 1) ? (a[u] - b[u]) / (2 * e) : a[u] / e;
-                data[s_off[col[u]] + k[u]] = v;
+                const real_t v0 = (MODE == 0) ? (a[u].x - b[u].x) / e : (MODE == 1) ? (a[u].x - b[u].x) / (2 * e) : a[u].x / e;
+                if constexpr (VEC) {
+                    const real_t v1 = (MODE == 0) ? (a[u].y - b[u].y) / e : (MODE == 1) ? (a[u].y - b[u].y) / (2 * e) : a[u].y / e;
+                    *reinterpret_cast<d2_t *>(dst) = d2_t{v0, v1};
+                } else {
+                    dst[0] = v0;
+                }
             } else if (cb == -1) {
-                data[s_off[col[u]] + k[u]] = (real_t)0;
+                if constexpr (VEC) *reinterpret_cast<d2_t *>(dst) = d2_t{0, 0};
+                else dst[0] = (real_t)0;
             }
         }
     }
@@ -1411,10 +1434,20 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         static const bool cr_wave = env_i64("FDJAC_COLRANGE_WG", 1) == 0;
         if (!cr_wave) {   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
             const int64_t nc = p->col1 - p->col0;
-            if (nc > 0)
-                hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE>), dim3((unsigned)((nc + kCrCols - 1) / kCrCols)), dim3(kBlock),
-                                   0, s, color, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi,
-                                   p->col0, nc, outs[0]);
+            // the imaginary parts of an imag-only complex step arrive as a real array with fx = the zero vector
+            const real_t *fxb = (MODE == 0 && p->fdtype == FD_COMPLEX && FXb == p->d_fx) ? nullptr : FXb;
+            const bool cr_vec_off = env_i64("FDJAC_COLRANGE_VEC", 1) == 0;   // (read per launch: tests toggle it)
+            const bool vec = p->cr_pairs && !cr_vec_off && (((uintptr_t)outs[0]) & kPairMask) == 0 &&
+                             (MODE != 0 || fxb == nullptr || (((uintptr_t)fxb) & kPairMask) == 0);
+            const dim3 gcr((unsigned)((nc + kCrCols - 1) / kCrCols));
+            if (nc > 0) {
+                if (vec)
+                    hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, true>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
+                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0]);
+                else
+                    hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, false>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
+                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0]);
+            }
             break;
         }
         const int g = grid_for(p->col1 - p->col0, kBlock / 64, p->ctx->num_cus);

@@ -554,6 +554,61 @@ def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("lazy", [False, True, "pairs"])
+@pytest.mark.parametrize("case", ["bs32", "bs8_none", "bs6_window", "mixed_even", "mixed_odd"])
+def test_blockbanded_row_pair_kernel_bit_identical(monkeypatch, oracle, fdtype, lazy, case):
+    # k_decompress_colrange_wg<VEC>: columns whose first row, row count and destination are all even are processed as
+    # row pairs (16-B accesses); the scalar instantiation (FDJAC_COLRANGE_VEC=0) must give the same bits, and odd
+    # layouts must fall back by themselves
+    sizes = {"bs32": np.full(12, 32), "bs8_none": np.full(30, 8), "bs6_window": np.full(20, 6),
+             "mixed_even": np.array([4, 8, 2, 6, 10, 4, 4, 12]), "mixed_odd": np.array([4, 7, 2, 6, 9, 4, 5, 12])}[case]
+    lay = P.BlockBandedLayout(sizes, 1, 1)
+    N = int(sizes.sum())
+    colors = lay.colors()
+    if case == "bs8_none":
+        colors = colors.copy()
+        colors[[1, 40, N - 2]] = 0
+    win = (12, N - 18) if case == "bs6_window" else None
+    uniform = len(set(sizes.tolist())) == 1
+    x = _dev(np.random.default_rng(62).random(N) - 0.3)
+    Jb = fd.BlockBandedMatrix(None, lay)
+    if uniform:
+        f = fd.BuiltinF("blockcoupled", len(sizes), int(sizes[0]))
+    else:
+        if lazy:
+            pytest.skip("user f! in torch has no lazy launcher")
+        blk = torch.as_tensor(np.repeat(np.arange(len(sizes)), sizes), device="cuda")
+
+        def fn(fx, xv):   # block sums couple neighbouring blocks: block-tridiagonal with dense blocks
+            sig = torch.zeros(len(sizes), dtype=xv.dtype, device=xv.device).index_add_(0, blk, xv)
+            S = sig.clone()
+            S[1:] += sig[:-1]
+            S[:-1] += sig[1:]
+            fx.copy_(xv * S[blk] + torch.sin(xv))
+        f = fd.TorchF(fn, N, N)
+    outs = []
+    for vec in ("1", "0"):
+        monkeypatch.setenv("FDJAC_COLRANGE_VEC", vec)
+        plan = fd.make_plan(Jb, Jb, colors, fdtype, col_window=win)
+        if lazy:
+            plan.set_lazy(f, imag_only=(lazy is True))
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    if win is None:
+        assert not np.isnan(outs[0]).any()
+        if uniform:
+            ref = oracle.jacobian(fdtype, oracle.Fixture("blockcoupled", len(sizes), int(sizes[0])), x.cpu().numpy(), colors,
+                                  kind=oracle.PAT_BLOCKBANDED, blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts,
+                                  block_strides=lay.block_strides, out_len=lay.data_len)
+            if fdtype == "complex":
+                assert np.max(np.abs(outs[0] - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
+            else:
+                _tol_ok(outs[0], ref["out"], np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype))), 40.0, "bb pairs " + case)
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["c5_shape", "bs5_cyclic", "bs64", "bs1", "none", "chunked", "declined", "window"])
 def test_lazy_points_blockcoupled_bit_identical(fdtype, case):
     # the block-coupled family's lazy launcher (sigma of every point formed on chip) vs perturb + sigma + apply kernels
