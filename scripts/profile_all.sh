@@ -10,5 +10,17 @@ S=$(find $OUT/stats -name '*.db' | head -1); F=$(find $OUT/pmc_fetch -name '*.db
 python $REPO/scripts/rocpd_summary.py $S $F $W > $OUT/summary.md 2> $OUT/summary.err
 python $REPO/scripts/make_pmc_json.py $F $W $N 1 $KERN > $OUT/pmc.json 2>> $OUT/summary.err
 cd $REPO && python bench.py --config $CFG "$@" > $OUT/bench.json 2> $OUT/bench.err
+python - $OUT >> $OUT/summary.md <<'PY'
+import re, sys
+d = sys.argv[1]
+def ev(path):
+    m = re.search(r'"avg_launch_ms": ([0-9.]+)', open(path).read())
+    return float(m.group(1)) * 1e3 if m else float("nan")
+print("\n## HIP events vs rocprofv3 (same kernel)\n")
+print("HIP-event time of the graded kernel measured by `bench.py` inside the profiled process (the `--kernel-trace --stats` "
+      "pass above): **%.1f us**; in the separate, unprofiled `bench.py` run of the same command: **%.1f us**. The event "
+      "bracket contains the launch gaps the profiler adds; different processes place their buffers differently "
+      "(DESIGN section 8: +-5 %% per placement)." % (ev(d + "/stats.log"), ev(d + "/bench.json")))
+PY
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
 tail -3 $OUT/summary.err; head -12 $OUT/summary.md; cat $OUT/pmc.json | head -30
