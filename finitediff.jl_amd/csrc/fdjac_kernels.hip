@@ -544,8 +544,9 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     real_t *s_eps = s_mem_w;                      // step sizes of the tile's colours (the division happens per stored entry)
     real_t *s_win = s_mem_w + kWinMaxCol;         // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
     const int64_t ntiles = (n + T - 1) / T;
-    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
-    if (tile_id >= ntiles) return;
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
+    if (xt >= ntiles) return;
+    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
     const int64_t t0 = tile_id * T;
     const int4 th = wtiles[3 * tile_id], wa = wtiles[3 * tile_id + 1], wb = wtiles[3 * tile_id + 2];
     const int cmin = __builtin_amdgcn_readfirstlane(th.x);
@@ -654,7 +655,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
             q[h] = valid ? v : 0.0;
             w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
         }
-        const bool both = w[0] & w[1] & (vec_ok != 0);
+        const bool both = w[0] & w[1] & ((vec_ok & 1) != 0);
         if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
             d2_t pk = {q[0], q[1]};
             *reinterpret_cast<d2_t *>(out + p) = pk;
@@ -685,8 +686,9 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
     real_t *s_eps = s_mem_2d;                                  // kWinMaxCol step sizes
     int *s_desc = reinterpret_cast<int *>(s_mem_2d + kWinMaxCol);   // kW2Desc ints
     real_t *s_win = s_mem_2d + kWinMaxCol + kW2Desc * 4 / sizeof(real_t);   // [ncol][wp] differences
-    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
-    if (tile_id >= ntiles) return;
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
+    if (xt >= ntiles) return;
+    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;
     if (threadIdx.x < kW2Desc) s_desc[threadIdx.x] = desc[tile_id * kW2Desc + threadIdx.x];
     __syncthreads();
     const int cmin = s_desc[0];
@@ -784,7 +786,7 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             q[h] = valid ? v : 0.0;
             w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
         }
-        if (w[0] & w[1] & ((p & 1) == 0) & (vec_ok != 0)) {
+        if (w[0] & w[1] & ((p & 1) == 0) & ((vec_ok & 1) != 0)) {
             d2_t pk = {q[0], q[1]};
             *reinterpret_cast<d2_t *>(out + p) = pk;
         } else {
@@ -848,8 +850,9 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const real_t *__restri
     real_t *s_win = s_mem_t + kWinMaxCol;
     const int none = ColorTraits<CT>::none;
     const int64_t ntiles = (j1 - j0 + kTriTile - 1) / kTriTile;
-    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
-    if (tile_id >= ntiles) return;
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
+    if (xt >= ntiles) return;
+    const int64_t tile_id = (vec_ok & 8) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
     const int64_t a = j0 + tile_id * kTriTile;       // j0 is even by construction (host), so a is even
     const int64_t b = (a + kTriTile < j1) ? a + kTriTile : j1;
     const int ncol = c_hi - c_lo;                    // <= NCT
@@ -1173,6 +1176,13 @@ static int64_t env_i64(const char *name, int64_t dflt)
     return (v && *v) ? atoll(v) : dflt;
 }
 static int64_t g_tile = -1, g_capmult = -1;
+// The row-window kernels walk their tiles from the LAST one to the first: the f! values were written front to back
+// by the launch before, so the end of the batch is what the 256 MiB Infinity Cache still holds when the decompression
+// starts (measured in one process on the same buffers, N = 10^7: tridiagonal forward 123.9 -> 118.3 / 119.8 -> 117.4 /
+// 115.4 -> 114.5 us depending on buffer placement, 5-point central 307 -> 301 us; neutral when everything fits).
+// Same work per tile => same bits.  FDJAC_REVERSE=0 restores front-to-back order (read per launch: tests toggle it).
+static inline bool tile_order_reversed() { return env_i64("FDJAC_REVERSE", 1) != 0; }
+
 static inline int64_t tune_tile() { if (g_tile < 0) { g_tile = env_i64("FDJAC_TILE", 2); if (g_tile != 1 && g_tile != 2) g_tile = 4; } return g_tile; }
 static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
 
@@ -1298,7 +1308,7 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     // (measured neutral on MI355X -- the LDS is not the bottleneck of these kernels -- but it is the smaller tile)
     const int wp = dma ? ((2 * p->win_pairs + 127) & ~127) : (((2 * p->win_pairs + 31) & ~31) + 2);
     const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
-    const int vok = (((uintptr_t)out) & kPairMask) == 0;
+    const int vok = ((((uintptr_t)out) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
     if (p->window2d) {
         const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
         const size_t shm2 = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + 4 * (size_t)kW2Desc;
@@ -1402,7 +1412,8 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
             const int fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
             const int vok = ((((uintptr_t)outs[1]) & kPairMask) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 2 : 0) |
-                            (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0);
+                            (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0) |
+                            (tile_order_reversed() ? 8 : 0);
             const size_t shmt = sizeof(real_t) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
             hipLaunchKernelGGL((k_decompress_tridiag_window<CT, MODE, 4>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock),
                                shmt, s, color, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],

@@ -834,6 +834,51 @@ np.save(sys.argv[1], out.cpu().numpy())
     assert not np.isnan(outs[0]).any() and np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["csc", "csc_colwindow", "lap5_2d", "tridiagonal", "banded"])
+def test_reversed_tile_order_bit_identical(monkeypatch, fdtype, case):
+    # the row-window kernels walk their tiles back to front by default (Infinity Cache reuse of the f! batch);
+    # FDJAC_REVERSE=0 is the front-to-back order: same work per tile, same bits
+    N = 20011
+    colors = P.cyclic_colors(N, 3)
+    fam, prm, win = "tridiag_nl", (N,), None
+    if case in ("csc", "csc_colwindow"):
+        cp, rv = P.tridiag_csc(N)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+        win = (3000, 17001) if case == "csc_colwindow" else None
+    elif case == "lap5_2d":
+        nx, ny = 130, 90
+        N = nx * ny
+        cp, rv = P.lap5_csc(nx, ny)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+        colors = P.lap5_colors(nx, ny)
+        fam, prm = "lap5", (nx, ny)
+    elif case == "tridiagonal":
+        J = fd.Tridiagonal(_dev(np.zeros(N - 1)), _dev(np.zeros(N)), _dev(np.zeros(N - 1)))
+        sp = None
+    else:
+        J = fd.BandedMatrix(torch.zeros((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
+        sp = None
+    x = _dev(np.random.default_rng(77).random(N) + 0.2)
+    f = fd.BuiltinF(fam, *prm)
+    res = []
+    for rev in ("1", "0"):
+        monkeypatch.setenv("FDJAC_REVERSE", rev)
+        plan = fd.make_plan(J, sp, colors, fdtype, col_window=win)
+        if case == "lap5_2d":
+            assert plan.info(fd.lib.INFO_WINDOW2D) == 1
+        elif case in ("csc", "csc_colwindow", "banded"):
+            assert plan.info(fd.lib.INFO_WINDOW) == 1
+        outs = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3 if case == "tridiagonal" else 1)]
+        plan.set_lazy(f)
+        plan.jacobian(f, x, outs)
+        res.append(torch.cat(outs).cpu().numpy())
+    assert not np.isnan(res[0]).any()
+    assert np.array_equal(res[0], res[1])
+
+
 def test_row_window_heuristic(monkeypatch):
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
     monkeypatch.delenv("FDJAC_WINDOW", raising=False)
