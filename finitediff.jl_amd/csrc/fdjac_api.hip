@@ -166,7 +166,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     } else if (p->C > 0 && p->kind != K_DENSE) {
         if (p->C <= kRegColors) {
             const char *cm = getenv("FDJAC_GRID_CAP");
-            const int64_t mult = (cm && *cm) ? atoll(cm) : 8;
+            // 4 workgroups per CU: measured 31.0 us for partial + finalize at N = 10^7 (8: 34.5, 16: 33.7, 2: 36.6,
+            // uncapped 36.1 -- fewer partials for the finalize, enough loads in flight for the reduction)
+            const int64_t mult = (cm && *cm) ? atoll(cm) : 4;
             const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
             p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
             if ((rc = dev_alloc(&p->d_partial, (int64_t)p->n_partial_blocks * kRegColors))) return rc;
