@@ -365,8 +365,9 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
     // block tile = U*512 stored entries; pair u of thread t sits at tile + u*512 + 2t, so every
     // wave instruction (index load, colour load, value store) touches one dense 512-B / 1-KiB run.
     const int64_t ntiles = (n + (U * kBlock * 2) - 1) / (U * kBlock * 2);
-    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);   // XCD x walks its own contiguous range of tiles
-    if (tile_id >= ntiles) return;
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);   // XCD x walks its own contiguous range of tiles
+    if (xt >= ntiles) return;
+    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
     const int64_t t0 = tile_id * (U * kBlock * 2);
 
     // phase 1: indices and colours (independent coalesced loads; the lists are padded to whole tiles)
@@ -416,7 +417,7 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
             if (w0) out[dest[p]] = q0;
             if (w1) out[dest[p + 1]] = q1;
         } else {
-            const bool both = w0 & w1 & (vec_ok != 0);
+            const bool both = w0 & w1 & ((vec_ok & 1) != 0);
             if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
                 d2_t pk = {q0, q1};
                 *reinterpret_cast<d2_t *>(out + p) = pk;
@@ -454,8 +455,9 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
         for (int c = threadIdx.x; c < nB; c += kBlock) s_eps[c] = eps[c_lo + c];
     const int none = ColorTraits<CT>::none;
     const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
-    const int64_t tile_id = xcd_tile(blockIdx.x, ntiles);
-    if (tile_id >= ntiles) return;
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
+    if (xt >= ntiles) return;
+    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
     const int64_t t0 = tile_id * kSortTile;
     if (LDS_EPS) __syncthreads();
 
@@ -497,7 +499,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
         const d2_t pk = *reinterpret_cast<const d2_t *>(s_val + lp);
         bool w0 = p < n, w1 = p + 1 < n;
         if (!ALLW) { w0 = w0 & (s_flag[lp] != 0); w1 = w1 & (s_flag[lp + 1] != 0); }
-        const bool both = w0 & w1 & (vec_ok != 0);
+        const bool both = w0 & w1 & ((vec_ok & 1) != 0);
         if (__builtin_amdgcn_ballot_w64(both) == __builtin_amdgcn_ballot_w64(true)) {
             *reinterpret_cast<d2_t *>(out + p) = pk;
         } else {
@@ -1026,7 +1028,7 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
                          const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
                          const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
                          const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t j0, int64_t ncols,
-                         real_t *__restrict__ data)
+                         real_t *__restrict__ data, int rev)
 {
     // VEC: every column's first row, row count and destination are even (found at plan time) and the arrays are
     // 16-B aligned -- a work item is a PAIR of rows (one 16-B load per operand, one 16-B store).
@@ -1036,7 +1038,7 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
     __shared__ int64_t s_off[kCrCols];
     __shared__ real_t s_e[kCrCols];
     const int none = ColorTraits<CT>::none;
-    const int64_t jb = (int64_t)blockIdx.x * kCrCols;
+    const int64_t jb = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * kCrCols;   // see tile_order_reversed()
     const int nloc = (int)((ncols - jb < kCrCols) ? ncols - jb : kCrCols);
     if (threadIdx.x < kCrCols) {
         const int t = threadIdx.x;
@@ -1179,7 +1181,8 @@ static int64_t g_tile = -1, g_capmult = -1;
 // The row-window kernels walk their tiles from the LAST one to the first: the f! values were written front to back
 // by the launch before, so the end of the batch is what the 256 MiB Infinity Cache still holds when the decompression
 // starts (measured in one process on the same buffers, N = 10^7: tridiagonal forward 123.9 -> 118.3 / 119.8 -> 117.4 /
-// 115.4 -> 114.5 us depending on buffer placement, 5-point central 307 -> 301 us; neutral when everything fits).
+// 115.4 -> 114.5 us depending on buffer placement, 5-point central 307 -> 301 us, block-banded complex step
+// (k_decompress_colrange_wg) 112 -> 103 us; neutral when everything fits).
 // Same work per tile => same bits.  FDJAC_REVERSE=0 restores front-to-back order (read per launch: tests toggle it).
 static inline bool tile_order_reversed() { return env_i64("FDJAC_REVERSE", 1) != 0; }
 
@@ -1356,7 +1359,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             const bool allw = (p->nchunks == 1) && !p->has_none && p->own_c0 == 0 && (p->own_c1 < 0 || p->own_c1 >= p->C);
             const int64_t gq = 8 * xcd_chunks((p->nnz_local + kSortTile - 1) / kSortTile);
             const size_t shmq = sizeof(real_t) * (size_t)(kSortTile + (ldsq ? B : 0)) + (allw ? 0 : (size_t)kSortTile);
-            const int vok = (((uintptr_t)outs[0]) & kPairMask) == 0;
+            const int vok = ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
 #define FD_LAUNCH_SORTED(LL, AW, SS)                                                                                 \
             hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
                                p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
@@ -1384,7 +1387,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);
         const bool lds = B <= kEpsLdsMax;
         const size_t shm = lds ? sizeof(real_t) * (size_t)B : 0;
-        const int vec_ok = (((uintptr_t)outs[0]) & kPairMask) == 0;
+        const int vec_ok = ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
 #define FD_LAUNCH_LIST(HD, UU, LL, DEST, VOK)                                                                    \
         hipLaunchKernelGGL((k_decompress_list<CT, MODE, HD, UU, LL>), dim3((unsigned)g), dim3(kBlock), shm, s,   \
                            p->d_rowval, (const CT *)p->d_nzcolor, DEST, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, \
@@ -1397,8 +1400,8 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             else if (lds) FD_LAUNCH_LIST(false, 4, true, nullptr, vec_ok);
             else FD_LAUNCH_LIST(false, 4, false, nullptr, vec_ok);
         } else {
-            if (lds) FD_LAUNCH_LIST(true, 2, true, p->d_dest, 0);
-            else FD_LAUNCH_LIST(true, 2, false, p->d_dest, 0);
+            if (lds) FD_LAUNCH_LIST(true, 2, true, p->d_dest, vec_ok & 4);
+            else FD_LAUNCH_LIST(true, 2, false, p->d_dest, vec_ok & 4);
         }
 #undef FD_LAUNCH_LIST
         break;
@@ -1451,13 +1454,14 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             const bool vec = p->cr_pairs && !cr_vec_off && (((uintptr_t)outs[0]) & kPairMask) == 0 &&
                              (MODE != 0 || fxb == nullptr || (((uintptr_t)fxb) & kPairMask) == 0);
             const dim3 gcr((unsigned)((nc + kCrCols - 1) / kCrCols));
+            const int rev = tile_order_reversed() ? 1 : 0;
             if (nc > 0) {
                 if (vec)
                     hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, true>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
-                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0]);
+                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
                 else
                     hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, false>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
-                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0]);
+                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
             }
             break;
         }

@@ -835,18 +835,48 @@ np.save(sys.argv[1], out.cpu().numpy())
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["csc", "csc_colwindow", "lap5_2d", "tridiagonal", "banded"])
+@pytest.mark.parametrize("case", ["csc", "csc_colwindow", "lap5_2d", "tridiagonal", "banded", "csc_list", "lap5_sorted",
+                                  "blockbanded", "densej"])
 def test_reversed_tile_order_bit_identical(monkeypatch, fdtype, case):
     # the row-window kernels walk their tiles back to front by default (Infinity Cache reuse of the f! batch);
     # FDJAC_REVERSE=0 is the front-to-back order: same work per tile, same bits
     N = 20011
     colors = P.cyclic_colors(N, 3)
     fam, prm, win = "tridiag_nl", (N,), None
-    if case in ("csc", "csc_colwindow"):
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    monkeypatch.delenv("FDJAC_SORTED", raising=False)
+    if case in ("csc", "csc_colwindow", "csc_list"):
         cp, rv = P.tridiag_csc(N)
         J = fd.SparseMatrixCSC(N, N, cp, rv, None)
         sp = J
         win = (3000, 17001) if case == "csc_colwindow" else None
+        if case == "csc_list":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+    elif case == "densej":      # CSC pattern into a dense J: the gather kernel with explicit destinations
+        N = 300
+        colors = P.cyclic_colors(N, 3)
+        prm = (N,)
+        cp, rv = P.tridiag_csc(N)
+        J = torch.zeros((N, N), dtype=torch.float64, device="cuda").t()
+        sp = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    elif case == "blockbanded":
+        nb, bs = 40, 16
+        N = nb * bs
+        lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+        J = fd.BlockBandedMatrix(None, lay)
+        sp = J
+        colors = lay.colors()
+        fam, prm = "blockcoupled", (nb, bs)
+    elif case == "lap5_sorted":
+        nx, ny = 130, 90
+        N = nx * ny
+        cp, rv = P.lap5_csc(nx, ny)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+        colors = P.lap5_colors(nx, ny)
+        fam, prm = "lap5", (nx, ny)
+        monkeypatch.setenv("FDJAC_WINDOW", "0")
+        monkeypatch.setenv("FDJAC_SORTED", "1")
     elif case == "lap5_2d":
         nx, ny = 130, 90
         N = nx * ny
@@ -871,6 +901,10 @@ def test_reversed_tile_order_bit_identical(monkeypatch, fdtype, case):
             assert plan.info(fd.lib.INFO_WINDOW2D) == 1
         elif case in ("csc", "csc_colwindow", "banded"):
             assert plan.info(fd.lib.INFO_WINDOW) == 1
+        elif case == "csc_list":
+            assert plan.info(fd.lib.INFO_WINDOW) == 0
+        elif case == "lap5_sorted":
+            assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1
         outs = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3 if case == "tridiagonal" else 1)]
         plan.set_lazy(f)
         plan.jacobian(f, x, outs)
