@@ -599,7 +599,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
                               : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
                               : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
             d2_t b = {0.0, 0.0};
-            if (MODE == 0) {
+            if (MODE == 0 && FXb != nullptr) {   // nullptr: the subtrahend is identically zero (imag-only complex step)
                 if (FXB_VEC) {
                     b = *reinterpret_cast<const d2_t *>(FXb + row);
                 } else {   // caller's f_in: no padding / alignment guarantees
@@ -728,7 +728,7 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             const int pbase = k ? s_desc[7 + 2 * k] : 0;
             const int64_t row = (int64_t)s_desc[8 + 2 * k] + 2 * (i - pbase);
             d2_t b = {0.0, 0.0};
-            if (MODE == 0) {
+            if (MODE == 0 && FXb != nullptr) {   // nullptr: the subtrahend is identically zero (imag-only complex step)
                 if (FXB_VEC) {
                     b = *reinterpret_cast<const d2_t *>(FXb + row);
                 } else {
@@ -866,7 +866,7 @@ k_decompress_tridiag_window(const CT *__restrict__ color, const real_t *__restri
     for (int i = threadIdx.x; i < npairs; i += kBlock) {
         const int64_t row = rbeg + 2 * i;
         d2_t bb = {0.0, 0.0};
-        if (MODE == 0) {
+        if (MODE == 0 && FXb != nullptr) {   // nullptr: the subtrahend is identically zero (imag-only complex step)
             if (fxb_vec) {
                 bb = *reinterpret_cast<const d2_t *>(FXb + row);
             } else {
@@ -1304,7 +1304,11 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     static const bool dma_off = env_i64("FDJAC_DMA", 0) == 0;
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
     const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
-    const bool dma = (MODE != 2) && fxvec && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
+    // the imaginary parts of an imag-only complex step arrive as a real array with fx = the plan's all-zero vector:
+    // a - 0.0 == a, so the kernels are told not to load it at all
+    const bool fx_zero = (MODE == 0) && p->fdtype == FD_COMPLEX && fx == p->d_fx;
+    if (fx_zero) FXb = nullptr;
+    const bool dma = (MODE != 2) && fxvec && !fx_zero && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
     // LDS pitch between colours: whole 1-KiB DMA chunks, or (register path) a pitch that is 2 mod 32 elements so
     // that neighbouring colours start 4 banks apart (entries of neighbouring columns read neighbouring rows of
     // DIFFERENT colours; a pitch of 0 mod 32 puts them all on the same banks)
@@ -1418,8 +1422,10 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
                             (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0) |
                             (tile_order_reversed() ? 8 : 0);
             const size_t shmt = sizeof(real_t) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
+            // (imag-only complex step: fx is the all-zero vector and is not loaded, see launch_window_m)
+            const real_t *fxb_t = ((MODE == 0) && p->fdtype == FD_COMPLEX && fx == p->d_fx) ? nullptr : FXb;
             hipLaunchKernelGGL((k_decompress_tridiag_window<CT, MODE, 4>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock),
-                               shmt, s, color, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],
+                               shmt, s, color, FXa, fxb_t, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],
                                outs[1], outs[2], fxvec, vok);
             break;
         }
