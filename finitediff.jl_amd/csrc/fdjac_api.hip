@@ -409,7 +409,10 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
         if (bad * 1000 > total || ecmax < 1 || ecmax > 32) return FD_OK;   // > 0.1 % of the entries off-stride
     }
     const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
-    int L = (fl && *fl) ? atoi(fl) : 64;
+    // default shape: 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as
+    // keep the window pairs of a tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same
+    // process: 62 x 5 299 us, 62 x 6 303, 62 x 4 302, 64 x 6 310, 64 x 5 304, 94 x 3 304, 126 x 2 313
+    int L = (fl && *fl) ? atoi(fl) : 62;
     L = std::max(2, L & ~1);
     int R = (fr && *fr) ? atoi(fr) : (int)(2048 / ((int64_t)ecmax * L));
     R = std::max(1, std::min(R, kW2MaxRun));
@@ -417,6 +420,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
     if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
         const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
         while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+        while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
     }
     if (R < 2) return FD_OK;
 
