@@ -102,14 +102,25 @@ class AllGatherBuffers:
         self.maxlen = max(self.counts) if self.counts else 0
         self.buf = torch.empty(self.world * self.maxlen, dtype=dtype, device=device)
         self.uniform = all(c == self.maxlen for c in self.counts)
+        self._send = None   # only used when the backend refuses the in-place form
 
     def local_view(self, rank):
         """The rank's own padded slot: computing straight into it makes the gather in-place."""
         return self.buf[rank * self.maxlen: (rank + 1) * self.maxlen]
 
     def gather(self, rank, dist, group=None):
+        """One all-gather of the padded slots.  In place (ncclAllGather's sendbuff == recvbuff + rank*count case); if the
+        backend refuses an input that aliases the output, the slot is copied to a send buffer once per call instead."""
         if self.world > 1:
-            dist.all_gather_into_tensor(self.buf, self.local_view(rank), group=group)
+            if self._send is None:
+                try:
+                    dist.all_gather_into_tensor(self.buf, self.local_view(rank), group=group)
+                    return self.buf
+                except (RuntimeError, ValueError):
+                    import torch
+                    self._send = torch.empty(self.maxlen, dtype=self.buf.dtype, device=self.buf.device)
+            self._send.copy_(self.local_view(rank))
+            dist.all_gather_into_tensor(self.buf, self._send, group=group)
         return self.buf
 
     def compact(self):
