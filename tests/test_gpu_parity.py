@@ -913,6 +913,50 @@ def test_reversed_tile_order_bit_identical(monkeypatch, fdtype, case):
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["csc", "lap5_1d", "banded"])
+def test_window_tile_sizes_bit_identical(monkeypatch, fdtype, case):
+    # the 1-D row-window kernel has three tile sizes (2048 / 1024 / 512 stored entries = 4 / 2 / 1 entry pairs per
+    # thread); the plan picks by launch size, FDJAC_WIN_TILE forces one: same bits from all of them
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    monkeypatch.setenv("FDJAC_WINDOW2D", "0")
+    N = 30011
+    colors = P.cyclic_colors(N, 3)
+    fam, prm = "tridiag_nl", (N,)
+    if case == "csc":
+        cp, rv = P.tridiag_csc(N)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+    elif case == "lap5_1d":
+        nx, ny = 150, 110
+        N = nx * ny
+        cp, rv = P.lap5_csc(nx, ny)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+        colors = P.lap5_colors(nx, ny)
+        fam, prm = "lap5", (nx, ny)
+        monkeypatch.setenv("FDJAC_WINDOW", "1")
+    else:
+        J = fd.BandedMatrix(torch.zeros((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
+        sp = None
+    x = _dev(np.random.default_rng(78).random(N) + 0.2)
+    f = fd.BuiltinF(fam, *prm)
+    res = []
+    for tile in ("", "2048", "1024", "512"):
+        if tile:
+            monkeypatch.setenv("FDJAC_WIN_TILE", tile)
+        else:
+            monkeypatch.delenv("FDJAC_WIN_TILE", raising=False)
+        plan = fd.make_plan(J, sp, colors, fdtype)
+        assert plan.info(fd.lib.INFO_WINDOW) == 1 and plan.info(fd.lib.INFO_WINDOW2D) == 0
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        res.append(out.cpu().numpy())
+    assert not np.isnan(res[0]).any()
+    for r in res[1:]:
+        assert np.array_equal(res[0], r)
+
+
 def test_row_window_heuristic(monkeypatch):
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
     monkeypatch.delenv("FDJAC_WINDOW", raising=False)
