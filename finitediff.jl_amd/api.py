@@ -228,6 +228,13 @@ class BuiltinF:
         return fn if rc == 0 else None
 
     @property
+    def lazy_jvp_fn(self):
+        """The family's lazy-point launcher for JVPs (fd_builtin_f_lazy_jvp) or None if it has none."""
+        fn = _l.F_LAUNCH_LAZY_JVP()
+        rc = self.Lt.fd_builtin_f_lazy_jvp(self.fctx, C.byref(fn))
+        return fn if rc == 0 else None
+
+    @property
     def lazy_caps(self):
         """FD_LAZY_CAP_* bits of the lazy launcher (fd_builtin_f_lazy_caps)."""
         caps = C.c_int32()
@@ -639,13 +646,15 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
 class JVPCache:
     """FiniteDiff.JVPCache (src/jvp.jl:1-60): JVPCache(x, fdtype="forward") / JVPCache(x, fx1, fdtype)."""
 
-    def __init__(self, x1, fx1=None, fdtype="forward"):
+    def __init__(self, x1, fx1=None, fdtype="forward", lazy=True):
         if isinstance(fx1, str):
             fdtype, fx1 = fx1, None
         self.fdtype = _norm_fdtype(fdtype)
         self.x1, self.fx1 = x1, (fx1 if fx1 is not None else x1)
         self.dtype = _dtype_of(x1) or np.dtype(np.float64)
         self._plan = None
+        self.lazy = bool(lazy)     # use f!'s lazy-point JVP launcher when it has one (same bits, fewer passes)
+        self._lazy_keep = None
 
     def _plan_for(self, M, N, ctx):
         if self.fdtype == "complex":
@@ -673,6 +682,9 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     Lt = _l.typed(ctx.L, cache.dtype)
     if np.dtype(getattr(f, "dtype", cache.dtype)) != cache.dtype:
         raise TypeError("f! launcher is built for %s, the cache for %s" % (np.dtype(f.dtype).name, cache.dtype.name))
+    lz = getattr(f, "lazy_jvp_fn", None) if cache.lazy else None
+    cache._lazy_keep = lz            # (the ctypes function object must outlive the call)
+    _l.check(Lt.fd_jvp_plan_set_lazy_f(h, lz if lz is not None else _l.F_LAUNCH_LAZY_JVP()))
     xp, xk, _a = _ptr(x, "x", cache.dtype)
     vp_, vk, _b = _ptr(v, "v", cache.dtype)
     if xk != vk:

@@ -752,6 +752,123 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
+// ---- lazy-point launchers of a JVP (fd_f_launch_lazy_jvp): f at x + eps*v / x - eps*v, perturbed while loading ----
+// Points are formed as x[j] + (eps*v[j]) and x[j] - (eps*v[j]) exactly as k_jvp_points writes them, rows are evaluated
+// with the same helpers as the plain kernels => bit-identical to the materialised path.
+template <bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
+                     const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+    if (i >= n) return;
+    const real_t e = eps[0];
+    real_t xv[4], ev[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t j = i - 1 + k;
+        const bool in = (j >= 0) & (j < n);
+        xv[k] = in ? x[in ? j : 0] : 0.0;
+        ev[k] = in ? e * v[in ? j : 0] : 0.0;
+    }
+    const bool two = i + 1 < n;
+    if (base_out) {
+        const real_t b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
+        if (two) *reinterpret_cast<r2_t *>(base_out + i) = r2_t{b0, tridiag_row<real_t, NL>(xv[1], xv[2], xv[3])};
+        else base_out[i] = b0;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && !central) break;
+        // forward: member 0 = x + eps v; central: member 0 = x - eps v, member 1 = x + eps v
+        const bool minus = central && m == 0;
+        real_t p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = minus ? xv[k] - ev[k] : xv[k] + ev[k];
+        real_t *dst = fx + (int64_t)m * fs + i;
+        const real_t v0 = tridiag_row<real_t, NL>(p[0], p[1], p[2]);
+        if (two) *reinterpret_cast<r2_t *>(dst) = r2_t{v0, tridiag_row<real_t, NL>(p[1], p[2], p[3])};
+        else dst[0] = v0;
+    }
+}
+
+template <bool CLAMP>
+__global__ void __launch_bounds__(kBlock)
+k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
+                      const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t nx, int64_t ny)
+{
+    const int64_t n = nx * ny;
+    const int64_t ntiles = (n + 2 * kBlock - 1) / (2 * kBlock);
+    const int64_t tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile >= ntiles) return;
+    const int64_t k = tile * (2 * kBlock) + threadIdx.x * 2;
+    if (k >= n) return;
+    const int64_t j = k / nx, i = k - j * nx;
+    const bool hs = j > 0, hn = j + 1 < ny, hw = i > 0, he = i + 2 < nx;
+    const int64_t idx[8] = {k, k + 1, k - nx, k - nx + 1, k + nx, k + nx + 1, k - 1, k + 2};
+    const bool ok[8] = {true, true, hs, hs, hn, hn, hw, he};
+    const real_t e = eps[0];
+    real_t xv[8], ev[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int64_t at = ok[m] ? idx[m] : k;
+        xv[m] = x[at];
+        ev[m] = e * v[at];
+    }
+    if (base_out) {
+        real_t b0, b1;
+        stencil5_pair<real_t, CLAMP>(xv, hs, hn, hw, he, b0, b1);
+        *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && !central) break;
+        const bool minus = central && m == 0;
+        real_t p[8], o0, o1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = minus ? xv[q] - ev[q] : xv[q] + ev[q];
+        stencil5_pair<real_t, CLAMP>(p, hs, hn, hw, he, o0, o1);
+        *reinterpret_cast<r2_t *>(fx + (int64_t)m * fs + k) = r2_t{o0, o1};
+    }
+}
+
+static bool has_lazy_jvp(const BuiltinF *b)
+{
+    if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
+    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
+}
+
+static int builtin_launch_lazy_jvp(void *fctx, void *fx, const fd_lazy_jvp_points *lp, int64_t fx_stride, void *stream)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
+    if (!has_lazy_jvp(b)) return FD_LAZY_DECLINED;
+    if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return FD_LAZY_DECLINED;
+    b->launches.fetch_add(1);
+    b->points.fetch_add((lp->central ? 2 : 1) + (lp->base_out ? 1 : 0));
+    const hipStream_t s = (hipStream_t)stream;
+    real_t *fxp = (real_t *)fx, *base = (real_t *)lp->base_out;
+    const real_t *x = (const real_t *)lp->x, *v = (const real_t *)lp->v, *eps = (const real_t *)lp->eps;
+    if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) {
+        const int64_t n = b->prm[0];
+        const unsigned g = (unsigned)(((n + 1) / 2 + kBlock - 1) / kBlock);
+        if (b->family == FD_F_TRIDIAG_NL)
+            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<true>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n);
+        else
+            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<false>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n);
+    } else {
+        const int64_t n = b->prm[0] * b->prm[1];
+        const unsigned g = (unsigned)(8 * xcd_chunks((n + 2 * kBlock - 1) / (2 * kBlock)));
+        if (b->family == FD_F_CLAMP5)
+            hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<true>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central,
+                               b->prm[0], b->prm[1]);
+        else
+            hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<false>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central,
+                               b->prm[0], b->prm[1]);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 static bool has_lazy(const BuiltinF *b)
 {
     if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
@@ -856,6 +973,18 @@ int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out)
         return FD_ERR_UNSUPPORTED;
     }
     *fn_out = builtin_launch_lazy;
+    return FD_OK;
+}
+
+int fd_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    FD_REQUIRE(b && b->magic == 0xFD0F00D5u && fn_out, FD_ERR_ARG, "not a built-in f context");
+    if (!has_lazy_jvp(b)) {
+        set_error("family %d has no lazy JVP launcher (5-point stencils need an even nx)", b->family);
+        return FD_ERR_UNSUPPORTED;
+    }
+    *fn_out = builtin_launch_lazy_jvp;
     return FD_OK;
 }
 

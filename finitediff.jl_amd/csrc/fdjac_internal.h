@@ -39,6 +39,8 @@
 #define fd_jvp fd32_jvp
 #define fd_jvp_async fd32_jvp_async
 #define fd_jvp_get_epsilon fd32_jvp_get_epsilon
+#define fd_jvp_plan_set_lazy_f fd32_jvp_plan_set_lazy_f
+#define fd_builtin_f_lazy_jvp fd32_builtin_f_lazy_jvp
 #else
 #define FDJAC_REAL double
 #endif

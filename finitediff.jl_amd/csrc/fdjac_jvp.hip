@@ -180,6 +180,7 @@ struct fd_jvp_plan {
     double *d_partial = nullptr;
     fdjac::real_t *d_xs = nullptr, *d_vs = nullptr, *d_fin = nullptr, *d_out = nullptr;
     int nparts = 1;
+    fd_f_launch_lazy_jvp lazy_fn = nullptr;
 };
 
 using namespace fdjac;
@@ -244,7 +245,38 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *
     const bool small = !small_off && p->N <= kSmallN;
     const bool base_in_batch = small && !central && !fin;
     const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & kPairMask) == 0;
-    if (small) {
+    // Lazy-point launcher (large problems; small ones are launch-latency bound and already fused): dot product and
+    // step as usual, then ONE f! launch that perturbs while loading -- the points pass and, in the forward arm, the
+    // separate f(x) launch disappear.  A launcher that declines falls through to the materialised points.
+    if (!small && p->lazy_fn) {
+        if (vx) hipLaunchKernelGGL(k_dot_partial<true>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+        else hipLaunchKernelGGL(k_dot_partial<false>, dim3(p->nparts), dim3(kBlock), 0, s, xd, vd, p->N, p->d_partial);
+        hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
+                           central ? 0 : 1, p->d_eps);
+        FD_HIP_CHECK(hipGetLastError());
+        fd_lazy_jvp_points lp;
+        lp.x = xd;
+        lp.v = vd;
+        lp.eps = p->d_eps;
+        lp.base_out = (!central && !fin) ? p->d_fx : nullptr;
+        lp.central = central;
+        const int lrc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, (void *)s);
+        FD_REQUIRE(lrc == 0 || lrc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy JVP f! launcher returned %d", lrc);
+        if (lrc == 0) {
+            const real_t *la = central ? p->d_FX + p->ldf : p->d_FX;
+            const real_t *lb = central ? p->d_FX : (fin ? fin : p->d_fx);
+            if (((((uintptr_t)la) | ((uintptr_t)lb) | ((uintptr_t)out)) & kPairMask) == 0)
+                hipLaunchKernelGGL(k_jvp_diff<true>, dim3((unsigned)((p->M + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s,
+                                   la, lb, p->d_eps, central, p->M, out);
+            else hipLaunchKernelGGL(k_jvp_diff<false>, dim3(gm), dim3(kBlock), 0, s, la, lb, p->d_eps, central, p->M, out);
+            FD_HIP_CHECK(hipGetLastError());
+            return FD_OK;
+        }
+        // declined: the step is already on the device, only the points remain to be written
+        if (vx) hipLaunchKernelGGL(k_jvp_points<true>, dim3((unsigned)((p->N + 2 * kBlock - 1) / (2 * kBlock))), dim3(kBlock), 0, s,
+                                   xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+        else hipLaunchKernelGGL(k_jvp_points<false>, dim3(g), dim3(kBlock), 0, s, xd, vd, p->d_eps, central, p->N, p->d_X, p->ldx);
+    } else if (small) {
         hipLaunchKernelGGL(k_jvp_small, dim3(1), dim3(kJvpSmallBlock), 0, s, xd, vd, p->N, relstep, absstep, dir, central,
                            base_in_batch ? 1 : -1, p->d_eps, p->d_X, p->ldx);
     } else {
@@ -324,6 +356,13 @@ int fd_jvp_async(fd_jvp_plan *p, fd_f_launch f, void *fctx, const void *x, const
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     return jvp_enqueue(p, f, fctx, (const real_t *)x, (const real_t *)v,
                        p->fdtype == FD_FORWARD ? (const real_t *)f_in : nullptr, relstep, absstep, dir, (real_t *)jvp_out);
+}
+
+int fd_jvp_plan_set_lazy_f(fd_jvp_plan *p, fd_f_launch_lazy_jvp lazy)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    p->lazy_fn = lazy;
+    return FD_OK;
 }
 
 int fd_jvp_get_epsilon(fd_jvp_plan *p, double *eps_out)

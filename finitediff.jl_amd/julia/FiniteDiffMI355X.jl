@@ -224,6 +224,11 @@ function FiniteDiff.finite_difference_jvp!(
                     ctx.h, length(jvp), length(x), fdtype_code(fdtype), r))
         r[]
     end
+    if f.builtin   # lazy-point JVP launcher (fd_f_launch_lazy_jvp): f! forms x + eps*v while loading, no points pass
+        lz = Ref{Ptr{Cvoid}}(C_NULL)
+        ccall((:fd_builtin_f_lazy_jvp, libfdjac), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), f.fctx, lz) == 0 &&
+            check(ccall((:fd_jvp_plan_set_lazy_f, libfdjac), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, lz[]))
+    end
     fin = (f_in === nothing || fdtype != Val(:forward)) ? C_NULL : pointer(f_in)
     GC.@preserve jvp x v f_in begin
         check(ccall((:fd_jvp, libfdjac), Cint,

@@ -39,6 +39,14 @@ class LazyPoints(C.Structure):
 F_LAUNCH_LAZY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyPoints), C.c_int64, C.c_int64, C.c_int64,
                             C.c_void_p)
 
+class LazyJvpPoints(C.Structure):
+    """fd_lazy_jvp_points (include/fdjac.h)."""
+    _fields_ = [("x", C.c_void_p), ("v", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p), ("central", C.c_int)]
+
+
+# int f(fctx, fx, const fd_lazy_jvp_points*, fx_stride, stream)
+F_LAUNCH_LAZY_JVP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyJvpPoints), C.c_int64, C.c_void_p)
+
 EXPORTS = (
     "fd_version", "fd_last_error", "fd_ctx_create", "fd_ctx_destroy", "fd_ctx_stream", "fd_ctx_synchronize",
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
@@ -47,6 +55,7 @@ EXPORTS = (
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
+    "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_color_columns_greedy", "fd_color_banded",
 )
 
@@ -58,7 +67,7 @@ TYPED = (
     "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
     "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
-    "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
+    "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -157,6 +166,8 @@ def load():
     L.fd_builtin_f_lazy.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY)]
     L.fd_plan_set_lazy_caps.argtypes = [vp, i32]
     L.fd_builtin_f_lazy_caps.argtypes = [vp, C.POINTER(i32)]
+    L.fd_jvp_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY_JVP]
+    L.fd_builtin_f_lazy_jvp.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY_JVP)]
     for name in TYPED:   # the Float32 instantiation has the same prototypes (values behind void*, steps stay double)
         getattr(L, "fd32_" + name[3:]).argtypes = getattr(L, name).argtypes
     for name in EXPORTS:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 103
+#define FDJAC_VERSION 104
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -265,6 +265,26 @@ int fd_jvp_async(fd_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, co
                  double relstep, double absstep, double dir, void *jvp_out);
 int fd_jvp_get_epsilon(fd_jvp_plan *plan, double *eps_out);
 
+/* Optional lazy-point launcher of a JVP (the JVP counterpart of fd_f_launch_lazy): instead of points materialised by
+   the library (x + eps*v, src/jvp.jl:260; x -/+ eps*v, :265-267) the launcher gets x, v and the DEVICE address of
+   the step and perturbs while loading -- in Julia: the unchanged f! applied to a lazy `x .+ eps .* v` wrapper.
+   It writes f at   forward: member 0 = x + eps*v  (and f(x) into base_out when that is non-NULL);
+                    central: member 0 = x - eps*v, member 1 = x + eps*v          (member k at fx_out + k*fx_stride),
+   forming every point as  x[j] + (eps*v[j])  /  x[j] - (eps*v[j])  in the element type (=> the same bits as the
+   materialised points).  May return FD_LAZY_DECLINED; the library then materialises the points. */
+typedef struct fd_lazy_jvp_points {
+    const void *x;        /* base point, device, N elements */
+    const void *v;        /* direction, device, N elements */
+    const void *eps;      /* device address of the ONE step size (element type of the plan) */
+    void *base_out;       /* forward arm without f_in: f(x) goes here (M elements); NULL otherwise */
+    int central;          /* 0 forward (1 point), 1 central (2 points) */
+} fd_lazy_jvp_points;
+typedef int (*fd_f_launch_lazy_jvp)(void *fctx, void *fx_out, const fd_lazy_jvp_points *pts, int64_t fx_stride,
+                                    void *stream);
+int fd_jvp_plan_set_lazy_f(fd_jvp_plan *plan, fd_f_launch_lazy_jvp lazy);   /* NULL clears it */
+/* The lazy JVP launcher of a built-in family (FD_ERR_UNSUPPORTED if it has none: block-coupled, non-square). */
+int fd_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out);
+
 /* ---- plan-time colouring: the step BEFORE the path ------------------------- */
 /* Greedy distance-1 column colouring of the column intersection graph of a CSC pattern (two columns
    conflict when they share a row) -- what ArrayInterface.matrix_colors / SparseDiffTools hand to
@@ -341,6 +361,8 @@ int fd32_jvp(fd32_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, cons
 int fd32_jvp_async(fd32_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *v, const void *f_in,
                  double relstep, double absstep, double dir, void *jvp_out);
 int fd32_jvp_get_epsilon(fd32_jvp_plan *plan, double *eps_out);
+int fd32_jvp_plan_set_lazy_f(fd32_jvp_plan *plan, fd_f_launch_lazy_jvp lazy);
+int fd32_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out);
 
 #ifdef __cplusplus
 }

@@ -1037,6 +1037,50 @@ def test_jvp_parity(oracle, fdtype, N):
         _tol_ok(outh, refh["jvp"], refh["eps"], 5.0, "jvp host f_in")
 
 
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("family", ["tridiag", "tridiag_nl", "lap5", "clamp5"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_jvp_lazy_points_bit_identical(oracle, fdtype, family, dtype):
+    # fd_f_launch_lazy_jvp: f! perturbs x + eps*v while loading; same bits as the materialised points, same call count
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    if family in ("lap5", "clamp5"):
+        nx, ny = 260, 131
+        N, prm = nx * ny, (nx, ny)
+    else:
+        N, prm = 40001, (40001,)
+    rng = np.random.default_rng(5)
+    x = torch.as_tensor(rng.random(N), dtype=tdt, device="cuda")
+    v = torch.as_tensor(rng.random(N) - 0.5, dtype=tdt, device="cuda")
+    res, calls, eps = [], [], []
+    for lazy in (True, False):
+        f = fd.BuiltinF(family, *prm, dtype=dtype)
+        assert f.lazy_jvp_fn is not None
+        out = torch.full((N,), float("nan"), dtype=tdt, device="cuda")
+        cache = fd.JVPCache(x, fdtype, lazy=lazy)
+        fd.finite_difference_jvp_b(out, f, x, v, cache)
+        res.append(out.clone())
+        calls.append(f.fcalls)
+        eps.append(cache.last_epsilon)
+        launches = f.counts()[0]
+        assert launches == (1 if lazy else (2 if fdtype == "forward" else 1))
+    assert not torch.isnan(res[0]).any()
+    assert torch.equal(res[0], res[1]) and calls[0] == calls[1] == 2 and eps[0] == eps[1]
+    if dtype == np.float64 and family != "clamp5":
+        ref = oracle.jvp(fdtype, oracle.Fixture(family, *prm), x.cpu().numpy(), v.cpu().numpy())
+        _tol_ok(res[0].cpu().numpy(), ref["jvp"], ref["eps"], 8.0, "lazy jvp %s %s" % (family, fdtype))
+    if fdtype == "forward":     # f_in given: no base evaluation, one point
+        outs = []
+        for lazy in (True, False):
+            g = fd.BuiltinF(family, *prm, dtype=dtype)
+            o = torch.full((N,), float("nan"), dtype=tdt, device="cuda")
+            fd.finite_difference_jvp_b(o, g, x, v, fd.JVPCache(x, "forward", lazy=lazy), torch.ones_like(x))   # an arbitrary f_in
+            outs.append(o)
+            assert g.fcalls == 1
+        assert torch.equal(outs[0], outs[1])
+    # families without a lazy JVP launcher fall back silently
+    assert fd.BuiltinF("blockcoupled", 10, 8).lazy_jvp_fn is None and fd.BuiltinF("lap5", 7, 9).lazy_jvp_fn is None
+
+
 def test_jvp_reference_fixture_and_errors():
     # test/finitedifftests.jl:440-448 with a user f! in torch; :complex is rejected (src/jvp.jl:248-250)
     rng = np.random.default_rng(17)
