@@ -154,9 +154,11 @@ def main():
         # per column: SURVEY 8(d) algorithmic bytes; what this implementation must move at minimum (fx and the three
         # f! arrays read once = 32 B, 3 values written = 24 B, index = 3 x 2-B packed (row,colour) codes with the
         # row-window kernel, 3 x (4-B row + 1-B colour) with the gather kernel); whole call with a streaming f!
-        bytes_ds, bytes_min, bytes_call = 89.0, (62.0 if plan.info(fd.lib.INFO_WINDOW) else 71.0), 210.0
+        # (regular tiles of the row-window kernel compute their entry codes from a per-tile head: no index traffic)
+        idx = 0.0 if plan.info(fd.lib.INFO_WIN_PERIOD) else 6.0
+        bytes_ds, bytes_min, bytes_call = 89.0, (56.0 + idx if plan.info(fd.lib.INFO_WINDOW) else 71.0), 210.0
         if args.dtype == "f32":   # the same formulas with 4-byte values: 2*C*M*4 + nnz*4 + nnz*4 + (N+1)*4 + N
-            bytes_ds, bytes_min, bytes_call = 53.0, (34.0 if plan.info(fd.lib.INFO_WINDOW) else 43.0), 114.0
+            bytes_ds, bytes_min, bytes_call = 53.0, (28.0 + idx if plan.info(fd.lib.INFO_WINDOW) else 43.0), 114.0
         wl = "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, x~U(0,1) seed %d" % (N, seed)
         kern = "k_decompress_window<forward>" if plan.info(fd.lib.INFO_WINDOW) else "k_decompress_list<u8,forward>"
         exact = (-2.0, 1.0)

@@ -240,10 +240,10 @@ static size_t window_lds_bytes(int fdtype, int max_slots, int max_ncol)
     if (dma) {   // raw windows of every staged array, whole 1-KiB chunks
         const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
         const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
-        return wp * narr * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc;
+        return wp * narr * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc + kWinHeadBytes;
     }
     const size_t wp = (((size_t)max_slots + 31) & ~(size_t)31) + 2;   // differences, one array per colour
-    return wp * (size_t)max_ncol * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc;
+    return wp * (size_t)max_ncol * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc + kWinHeadBytes;
 }
 
 static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,
@@ -356,6 +356,48 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
         p->win_overread = best.overread;
         if (best.ok) {
             best = build_windows(best.T, true);
+            // Regular patterns (a band coloured cyclically: tridiagonal CSC, BandedMatrix) repeat their entry codes:
+            // code[q + P] == code[q] + S inside a tile (the slot field advances by S rows, the colour comes back).  Tiles
+            // where that holds throughout are flagged; the kernel reads only their first kWinPeriodMax codes and
+            // computes the rest -- 2 B of index traffic per stored entry less (tridiagonal: 60 of 620 MB).
+            {
+                const char *fp = getenv("FDJAC_WIN_PERIODIC");
+                const size_t T = (size_t)best.T, ntiles = padded / T;
+                int P = 0, S = 0;
+                if (!(fp && *fp && atoi(fp) == 0) && ntiles >= 3) {
+                    const uint16_t *c = &best.code[(ntiles / 2) * T];
+                    for (int cand = 1; cand <= kWinPeriodMax && !P; ++cand) {
+                        const int s0 = (int)c[cand] - (int)c[0];
+                        bool okp = true;
+                        for (size_t q = 0; q < T && okp; ++q)
+                            okp = c[q] < 0x4000 && (q + cand >= T || (int)c[q + cand] - (int)c[q] == s0);
+                        if (okp) { P = cand; S = s0; }
+                    }
+                }
+                int magic = 0;
+                if (P) {
+                    magic = (int)(((1u << 20) + (unsigned)P - 1) / (unsigned)P);
+                    for (size_t q = 0; q < T; ++q)
+                        if ((int)(((int64_t)q * magic) >> 20) != (int)(q / (size_t)P)) { P = 0; break; }
+                }
+                size_t regular = 0;
+                if (P) {
+                    for (size_t t = 0; t < ntiles; ++t) {
+                        const uint16_t *c = &best.code[t * T];
+                        bool okt = true;
+                        for (size_t q = 0; q < T && okt; ++q)
+                            okt = c[q] < 0x4000 && (q + (size_t)P >= T || (int)c[q + P] - (int)c[q] == S);
+                        if (okt) { best.wt[3 * t].w |= 0x100; ++regular; }
+                    }
+                    if (2 * regular < ntiles) {   // not worth the second code path
+                        for (size_t t = 0; t < ntiles; ++t) best.wt[3 * t].w &= ~0x100;
+                        P = 0;
+                    }
+                }
+                p->win_per_P = P;
+                p->win_per_S = P ? S : 0;
+                p->win_per_magic = P ? magic : 0;
+            }
             p->window = true;
             p->win_tile = best.T;
             p->win_pairs = best.max_slots / 2;
@@ -1050,6 +1092,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_WINDOW: *value = p->window ? 1 : 0; break;
     case FD_INFO_WIN_OVERREAD_X100: *value = (int64_t)(p->win_overread * 100); break;
     case FD_INFO_WINDOW2D: *value = p->window2d ? 1 : 0; break;
+    case FD_INFO_WIN_PERIOD: *value = p->win_per_P; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;

@@ -97,6 +97,8 @@ constexpr int64_t kSmallN = 16384;   // below this a single-workgroup launch doe
 constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
 constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many consecutive colours per tile,
 constexpr int kWinMaxWin = 4;        //   this many row windows per tile (a 5-point stencil needs 3),
+constexpr int kWinPeriodMax = 64;    //   longest period (in entries) of a regular tile's codes; its head is staged in LDS:
+constexpr int kWinHeadBytes = 128;   //   kWinPeriodMax 16-bit codes at the start of the 1-D kernel's dynamic LDS
 constexpr int kWinGap = 64;          //   a new window starts after a gap of more than this many rows,
 constexpr int kWinMaxLds = 52 * 1024;  // this much LDS per workgroup (3 workgroups per CU),
 constexpr double kWinMaxOverread = 4.0;  // and this many f! values loaded per stored entry for scattered patterns
@@ -163,6 +165,7 @@ struct fd_plan {
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile
+    int win_per_P = 0, win_per_S = 0, win_per_magic = 0;   // periodic entry codes of regular tiles (0 = none)
     double win_overread = 0;       //   dense window elements loaded per stored entry (1 = no waste)
     int64_t nnz_local = 0;
     int64_t entry_begin = 0;       // global index of the first local stored entry

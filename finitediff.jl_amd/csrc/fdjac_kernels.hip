@@ -539,12 +539,13 @@ __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
                     const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t n,
-                    int vec_ok, int wp)
+                    int vec_ok, int wp, int per_P, int per_S, int per_magic)
 {
     constexpr int T = U * kBlock * 2;             // entries per tile; U pairs of entries per thread
     extern __shared__ real_t s_mem_w[];
-    real_t *s_eps = s_mem_w;                      // step sizes of the tile's colours (the division happens per stored entry)
-    real_t *s_win = s_mem_w + kWinMaxCol;         // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
+    uint16_t *s_head = reinterpret_cast<uint16_t *>(s_mem_w);   // first kWinPeriodMax codes of a regular tile (see phase 1)
+    real_t *s_eps = reinterpret_cast<real_t *>(reinterpret_cast<char *>(s_mem_w) + kWinHeadBytes);   // step sizes of the tile's colours
+    real_t *s_win = s_eps + kWinMaxCol;           // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
     const int64_t ntiles = (n + T - 1) / T;
     const int64_t xt = xcd_tile(blockIdx.x, ntiles);
     if (xt >= ntiles) return;
@@ -564,10 +565,20 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     cb1 = cb1 < c_hi ? cb1 : c_hi;
     const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;   // 0: nothing to load, entries only get their zeros
 
-    // phase 1: the packed (row, colour) codes of the stored entries (in flight while the window is loaded)
+    // phase 1: the packed (row, colour) codes of the stored entries (in flight while the window is loaded).
+    // Regular tiles (flag in the descriptor, plan-wide period per_P and slot step per_S: code[q + P] == code[q] + S)
+    // stage only their first kWinPeriodMax codes; every entry computes its own in phase 3.
+    const bool periodic = per_P > 0 && ((__builtin_amdgcn_readfirstlane(th.w) >> 8) & 1);
     uint32_t code[U];
+    if (periodic) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];   // two 16-bit codes
+        for (int u = 0; u < U; ++u) code[u] = 0;
+        if (threadIdx.x < kWinPeriodMax / 2)
+            reinterpret_cast<uint32_t *>(s_head)[threadIdx.x] = wcode2[(t0 >> 1) + threadIdx.x];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) code[u] = wcode2[(t0 >> 1) + u * kBlock + threadIdx.x];   // two 16-bit codes
+    }
     if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
 
     if constexpr (DMA) {
@@ -645,7 +656,12 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
         bool w[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const unsigned cd = (code[u] >> (16 * h)) & 0xFFFFu;
+            unsigned cd = (code[u] >> (16 * h)) & 0xFFFFu;
+            if (periodic) {
+                const int q = u * kBlock * 2 + (int)threadIdx.x * 2 + h;     // entry index inside the tile
+                const int k = (q * per_magic) >> 20;                          // q / per_P (checked at plan time)
+                cd = (unsigned)s_head[q - k * per_P] + (unsigned)(k * per_S);
+            }
             const int cs = (int)((cd >> 11) & 7u) + cshift;
             const bool colored = (cd & 0xC000u) == 0;
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
@@ -1331,11 +1347,11 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
         return;
     }
     const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
-    const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol);
+    const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + kWinHeadBytes;
 #define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
     hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
                        (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,       \
-                       c_hi, out, p->nnz_local, vok, wp)
+                       c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic)
 #define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
     if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); return; } }
     if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }

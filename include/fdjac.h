@@ -194,7 +194,8 @@ enum fd_plan_info_key {
     FD_INFO_LINES_SORTED_X100 = 16,   /*   ... colour-sorted order */
     FD_INFO_WINDOW = 17,              /* 1 if the row-window (dense loads -> LDS) decompression kernel is used */
     FD_INFO_WIN_OVERREAD_X100 = 18,   /*   x100: f! values loaded per stored entry by that kernel (100 = none wasted) */
-    FD_INFO_WINDOW2D = 19             /*   1 if its tiles are 2-D (column runs one stencil stride apart) */
+    FD_INFO_WINDOW2D = 19,            /*   1 if its tiles are 2-D (column runs one stencil stride apart) */
+    FD_INFO_WIN_PERIOD = 20           /*   period (in stored entries) of the regular tiles' entry codes, 0 = none */
 };
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 

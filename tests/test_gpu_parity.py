@@ -957,6 +957,59 @@ def test_window_tile_sizes_bit_identical(monkeypatch, fdtype, case):
         assert np.array_equal(res[0], r)
 
 
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_none", "tridiag_window_chunked", "banded21", "banded33", "greedy", "f32"])
+def test_periodic_entry_codes_bit_identical(monkeypatch, fdtype, case):
+    # regular tiles (code[q + P] == code[q] + S) read only the head of their entry codes and compute the rest;
+    # FDJAC_WIN_PERIODIC=0 keeps every code explicit: same bits, and the detected period is the pattern's
+    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+    dtype = np.float32 if case == "f32" else np.float64
+    tdt = torch.float32 if case == "f32" else torch.float64
+    N = 50021
+    colors = P.cyclic_colors(N, 3)
+    win, cap, want_period, fam = None, 0, 9, "tridiag_nl"
+    if case in ("tridiag", "tridiag_none", "tridiag_window_chunked", "greedy", "f32"):
+        cp, rv = P.tridiag_csc(N)
+        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        sp = J
+        if case == "tridiag_none":
+            colors = colors.copy()
+            colors[[5, 20000, N - 3]] = 0          # tiles with a column without colour stay explicit
+        if case == "tridiag_window_chunked":
+            win, cap = (1001, N - 2002), 1_000_000   # a column window, colours in chunks
+        if case == "greedy":
+            rng = np.random.default_rng(3)           # a valid but irregular colouring: 6 colours picked at random
+            colors = np.empty(N, np.int64)
+            for j in range(N):
+                used = {colors[j - 1] if j > 0 else 0, colors[j - 2] if j > 1 else 0}
+                colors[j] = rng.choice([c for c in range(1, 7) if c not in used])
+            want_period = 0
+    else:
+        l, u = (2, 1) if case == "banded21" else (3, 3)
+        C = l + u + 1
+        colors = P.cyclic_colors(N, C)
+        J = fd.BandedMatrix(torch.zeros((N, C), dtype=tdt, device="cuda").t(), N, l, u)
+        sp = None
+        want_period = C * C
+        fam = "tridiag_nl"        # any f! works for a bit-identity check of the decompression
+    x = torch.as_tensor(np.random.default_rng(79).random(N) + 0.2, dtype=tdt, device="cuda")
+    f = fd.BuiltinF(fam, N, dtype=dtype)
+    res = []
+    for per in ("1", "0"):
+        monkeypatch.setenv("FDJAC_WIN_PERIODIC", per)
+        plan = fd.make_plan(J, sp, colors, fdtype, col_window=win, scratch_bytes=cap, dtype=dtype)
+        assert plan.info(fd.lib.INFO_WINDOW) == 1
+        assert plan.info(fd.lib.INFO_WIN_PERIOD) == (want_period if per == "1" else 0)
+        if case == "tridiag_window_chunked":
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=tdt, device="cuda")
+        plan.set_lazy(f)
+        plan.jacobian(f, x, [out])
+        res.append(out.cpu().numpy())
+    assert not np.isnan(res[0]).any()
+    assert np.array_equal(res[0], res[1])
+
+
 def test_row_window_heuristic(monkeypatch):
     monkeypatch.delenv("FDJAC_SORTED", raising=False)
     monkeypatch.delenv("FDJAC_WINDOW", raising=False)
