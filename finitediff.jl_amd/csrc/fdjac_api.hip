@@ -365,13 +365,17 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
                 const size_t T = (size_t)best.T, ntiles = padded / T;
                 int P = 0, S = 0;
                 if (!(fp && *fp && atoi(fp) == 0) && ntiles >= 3) {
-                    const uint16_t *c = &best.code[(ntiles / 2) * T];
-                    for (int cand = 1; cand <= kWinPeriodMax && !P; ++cand) {
-                        const int s0 = (int)c[cand] - (int)c[0];
-                        bool okp = true;
-                        for (size_t q = 0; q < T && okp; ++q)
-                            okp = c[q] < 0x4000 && (q + cand >= T || (int)c[q + cand] - (int)c[q] == s0);
-                        if (okp) { P = cand; S = s0; }
+                    // (three sample tiles: one of them may hold a column without colour)
+                    for (size_t sample : {ntiles / 2, ntiles / 4, (3 * ntiles) / 4}) {
+                        const uint16_t *c = &best.code[sample * T];
+                        for (int cand = 1; cand <= kWinPeriodMax && !P; ++cand) {
+                            const int s0 = (int)c[cand] - (int)c[0];
+                            bool okp = true;
+                            for (size_t q = 0; q < T && okp; ++q)
+                                okp = c[q] < 0x4000 && (q + cand >= T || (int)c[q + cand] - (int)c[q] == s0);
+                            if (okp) { P = cand; S = s0; }
+                        }
+                        if (P) break;
                     }
                 }
                 int magic = 0;
