@@ -276,13 +276,16 @@ class TorchF:
         self.fn_py, self.M, self.N = fn, int(M), int(N)
         self.fcalls = 0
         self.error = None
-        ext = torch.cuda.ExternalStream(self.ctx.stream, device=self.ctx.device) if self.ctx.stream else None
+        dev_index = self.ctx.device
 
         def _launch(_fctx, fx, x, nbatch, xs, fs, r0, r1, is_complex, stream):
             try:
                 sz = (8 if is_complex else 4) if f32 else (16 if is_complex else 8)
-                cm = torch.cuda.stream(ext) if ext is not None else _nullctx()
-                with cm:
+                # run the user's torch ops on the stream the LIBRARY hands over (the one its own kernels are enqueued
+                # on), whatever torch's current stream is at call time: the legacy default stream when `stream` is NULL
+                ts = (torch.cuda.ExternalStream(int(stream), device=dev_index) if stream
+                      else torch.cuda.default_stream(dev_index))
+                with torch.cuda.stream(ts):
                     for b in range(nbatch):
                         xv = torch.as_tensor(_DevView(x + b * xs * sz, self.N, is_complex, f32), device="cuda")
                         fv = torch.as_tensor(_DevView(fx + b * fs * sz, self.M, is_complex, f32), device="cuda")
@@ -295,14 +298,6 @@ class TorchF:
 
         self.fn = _l.F_LAUNCH(_launch)
         self.fctx = C.c_void_p()
-
-
-class _nullctx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
 
 
 class Plan:

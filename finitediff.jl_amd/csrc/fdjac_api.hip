@@ -123,6 +123,14 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
         p->x1 = opts->x_end;
     }
     p->scratch_bytes = opts->scratch_bytes > 0 ? opts->scratch_bytes : ((int64_t)64 << 30);
+    // test / tuning switches select between bit-identical kernel variants; they are read HERE, once per plan, so a
+    // process can build plans of both variants side by side and fd_plan_info reports which one a plan uses
+    auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+    p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
+    p->cr_wg = env_int("FDJAC_COLRANGE_WG", 1) != 0;
+    p->dma = env_int("FDJAC_DMA", 0) != 0;
+    p->list_U = env_int("FDJAC_TILE", 2);
+    if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -234,9 +242,8 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
 // every output slot in storage order, padded to a multiple of kListPad.  Sets p->window on success.
 // LDS of one workgroup of the row-window kernels.  With LDS-DMA staging the raw windows of every array are kept
 // (the tile's colours of the perturbed points, plus fx or the minus points) in whole 1-KiB chunks.
-static size_t window_lds_bytes(int fdtype, int max_slots, int max_ncol)
+static size_t window_lds_bytes(bool dma, int fdtype, int max_slots, int max_ncol)
 {
-    static const bool dma = [] { const char *v = getenv("FDJAC_DMA"); return v && *v && atoi(v) != 0; }();
     if (dma) {   // raw windows of every staged array, whole 1-KiB chunks
         const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
         const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
@@ -345,7 +352,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
                 if (!force_t && T == 2048 && prefer_small) continue;
                 WinBuild w = build_windows(T, false);
                 if (!w.ok) continue;
-                const size_t lds = window_lds_bytes(p->fdtype, w.max_slots, w.max_ncol);
+                const size_t lds = window_lds_bytes(p->dma, p->fdtype, w.max_slots, w.max_ncol);
                 if (lds > (size_t)kWinMaxLds) continue;
                 const bool cheap = w.overread <= 1.25 || (scattered && w.overread <= kWinMaxOverread);
                 if (!(cheap || force_w == 1)) continue;
@@ -469,7 +476,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
     if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
     if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
         const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
-        while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+        while (R > 2 && window_lds_bytes(p->dma, p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
         while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
     }
     if (R < 2) return FD_OK;
@@ -562,7 +569,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
         }
     if (covered != p->nnz_local) return FD_OK;   // every stored entry must belong to exactly one run
     const double overread = elems / (double)std::max<int64_t>(p->nnz_local, 1);
-    const size_t lds = window_lds_bytes(p->fdtype, max_slots, max_ncol);
+    const size_t lds = window_lds_bytes(p->dma, p->fdtype, max_slots, max_ncol);
     if (max_slots == 0 || lds > (size_t)kWinMaxLds || overread > 2.2) return FD_OK;
     code.push_back(0x8000); code.push_back(0x8000);   // the last pair load may touch one code past the end
     p->window = true;
@@ -913,6 +920,12 @@ int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int
     p->row0 = std::max<int64_t>(p->col0 - 1, 0);
     p->row1 = std::min<int64_t>(p->col1 + 1, N);
     if (p->col1 == p->col0) p->row0 = p->row1 = 0;
+    {
+        // row-window variant: few colours (every loaded f! value is used when C == 3), an even first column (16-B
+        // aligned pairs); otherwise the gather kernel.  FDJAC_WINDOW=0 forces the gather kernel.
+        const char *fw = getenv("FDJAC_WINDOW");
+        p->tri_window = !(fw && *fw && atoi(fw) == 0) && p->C <= 4 && (p->col0 % 2) == 0 && p->col1 > p->col0;
+    }
     FD_TRY(alloc_scratch(p, col0));
     p->nouts = 3;
     const int64_t j0 = p->col0, j1 = p->col1;
@@ -1093,10 +1106,16 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_SORTED_GATHER: *value = p->sorted_gather ? 1 : 0; break;
     case FD_INFO_LINES_DIRECT_X100: *value = (int64_t)(p->lines_direct * 100); break;
     case FD_INFO_LINES_SORTED_X100: *value = (int64_t)(p->lines_sorted * 100); break;
-    case FD_INFO_WINDOW: *value = p->window ? 1 : 0; break;
+    case FD_INFO_WINDOW: *value = (p->window || p->tri_window) ? 1 : 0; break;
     case FD_INFO_WIN_OVERREAD_X100: *value = (int64_t)(p->win_overread * 100); break;
     case FD_INFO_WINDOW2D: *value = p->window2d ? 1 : 0; break;
     case FD_INFO_WIN_PERIOD: *value = p->win_per_P; break;
+    case FD_INFO_COLRANGE_WG: *value = (p->kind == K_COLRANGE && p->cr_wg) ? 1 : 0; break;
+    case FD_INFO_SMALL_FUSED:
+        *value = (p->small_ok && p->N <= kSmallN && p->C > 0 && p->C <= kRegColors && p->kind != K_DENSE &&
+                  p->fdtype != FD_COMPLEX) ? 1 : 0;
+        break;
+    case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;
@@ -1217,7 +1236,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     // Small problems are launch-latency bound: one single-workgroup launch computes the step sizes and, when the
     // points are materialised, writes them too -- with x itself as one more batch member so that f(x) needs no launch
     // of its own.  (Complex step: no step-size reduction to fuse with; large or many-coloured problems: the wide path.)
-    static const bool small_off = [] { const char *v = getenv("FDJAC_SMALL"); return v && *v && atoi(v) == 0; }();
+    const bool small_off = !p->small_ok;
     const bool full_colors = p->own_c0 == 0 && (p->own_c1 < 0 || p->own_c1 >= p->C);
     // (which reduction computes the step sizes depends on N and C only, so column windows, colour ownership and colour
     // chunks of the same problem all see bit-identical step sizes)
@@ -1438,7 +1457,7 @@ int fd_color_columns_greedy(int64_t M, int64_t N, const void *colptr, const void
         std::vector<int64_t> fill(rptr.begin(), rptr.end() - 1);
         for (int64_t j = 0; j < N; ++j) {
             const int64_t a = load_idx(colptr, idx_bytes, j) - idx_base, b = load_idx(colptr, idx_bytes, j + 1) - idx_base;
-            FD_REQUIRE(a <= b && b <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
+            FD_REQUIRE(a >= 0 && a <= b && b <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
             for (int64_t q = a; q < b; ++q) rcols[(size_t)fill[(size_t)(load_idx(rowval, idx_bytes, q) - idx_base)]++] = (int32_t)j;
         }
     }

@@ -176,7 +176,8 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
 
 // 5-point stencils on an nx (fast) x ny grid.  CLAMP = false: zero-Dirichlet Laplacian
 // w + e + s + n - 4x ; CLAMP = true: the reference's clamped-edge sum x + x[i-1] + x[i+1] + x[j-1] + x[j+1].
-template <typename T, bool CLAMP>
+// (SK: 0 = Laplacian, 1 = clamped sum, 2 = Laplacian + x[k]^2 * x[k+1]: a nonlinear variant whose J depends on x.)
+template <typename T, int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
              int64_t r0, int64_t r1)
@@ -186,7 +187,7 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t k = r0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < r1; k += stride) {
         const int64_t j = k / nx, i = k - j * nx;
-        if (CLAMP) {
+        if (SK == 1) {
             const int64_t im = i > 0 ? i - 1 : 0, ip = i + 1 < nx ? i + 1 : nx - 1;
             const int64_t jm = j > 0 ? j - 1 : 0, jp = j + 1 < ny ? j + 1 : ny - 1;
             fb[k] = (((xb[k] + xb[im + nx * j]) + xb[ip + nx * j]) + xb[i + nx * jm]) + xb[i + nx * jp];
@@ -195,7 +196,9 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
             const T e = i + 1 < nx ? xb[k + 1] : zero_of<T>();
             const T s = j > 0 ? xb[k - nx] : zero_of<T>();
             const T n = j + 1 < ny ? xb[k + nx] : zero_of<T>();
-            fb[k] = (((w + e) + s) + n) - kFour * xb[k];
+            T v = (((w + e) + s) + n) - kFour * xb[k];
+            if (SK == 2) v = v + (xb[k] * xb[k]) * e;    // lap5_nl: + x[k]^2 * x[k+1] (J depends on x)
+            fb[k] = v;
         }
     }
 }
@@ -204,7 +207,7 @@ k_f_stencil5(T *__restrict__ fx, const T *__restrict__ x, int64_t nx, int64_t ny
 // scalar loads for the west / east neighbours, one 16-B store.  One-shot launch with the XCD-aware
 // tile mapping: the rows k-nx, k, k+nx that share x lines are evaluated by the same XCD, so each
 // line of x enters one L2 instead of three.
-template <bool CLAMP>
+template <int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t nx, int64_t ny, int64_t xs, int64_t fs,
                 int64_t r0, int64_t r1)
@@ -225,7 +228,7 @@ k_f_stencil5_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n
     const real_t w = hw ? xb[k - 1] : 0.0;
     const real_t e = he ? xb[k + 2] : 0.0;
     real_t v0, v1;
-    if (CLAMP) {
+    if (SK == 1) {
         const real_t w0 = hw ? w : c.x, e1 = he ? e : c.y;
         const real_t s0 = hs ? s.x : c.x, s1 = hs ? s.y : c.y, n0 = hn ? n.x : c.x, n1 = hn ? n.y : c.y;
         v0 = (((c.x + w0) + c.y) + s0) + n0;
@@ -233,6 +236,7 @@ k_f_stencil5_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n
     } else {
         v0 = (((w + c.y) + s.x) + n.x) - kFour * c.x;
         v1 = (((c.x + e) + s.y) + n.y) - kFour * c.y;
+        if (SK == 2) { v0 = v0 + (c.x * c.x) * c.y; v1 = v1 + (c.y * c.y) * e; }
     }
     *reinterpret_cast<r2_t *>(fb + k) = r2_t{v0, v1};
 }
@@ -240,10 +244,10 @@ k_f_stencil5_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n
 // Lazy-point version of the 5-point stencils (see k_f_tridiag_lazy): the 8 base values a pair of rows
 // depends on are loaded once, every point of the batch is evaluated from registers.
 // v[8] = {c0, c1, s0, s1, n0, n1, w, e} = x at {k, k+1, k-nx, k-nx+1, k+nx, k+nx+1, k-1, k+2}.
-template <typename T, bool CLAMP>
+template <typename T, int SK>
 __device__ __forceinline__ void stencil5_pair(const T *v, bool hs, bool hn, bool hw, bool he, T &o0, T &o1)
 {
-    if (CLAMP) {
+    if (SK == 1) {
         const T w0 = hw ? v[6] : v[0], e1 = he ? v[7] : v[1];
         const T s0 = hs ? v[2] : v[0], s1 = hs ? v[3] : v[1], n0 = hn ? v[4] : v[0], n1 = hn ? v[5] : v[1];
         o0 = (((v[0] + w0) + v[1]) + s0) + n0;
@@ -254,10 +258,11 @@ __device__ __forceinline__ void stencil5_pair(const T *v, bool hs, bool hn, bool
         const T s0 = hs ? v[2] : z, s1 = hs ? v[3] : z, n0 = hn ? v[4] : z, n1 = hn ? v[5] : z;
         o0 = (((w + v[1]) + s0) + n0) - kFour * v[0];
         o1 = (((v[0] + e) + s1) + n1) - kFour * v[1];
+        if (SK == 2) { o0 = o0 + (v[0] * v[0]) * v[1]; o1 = o1 + (v[1] * v[1]) * e; }
     }
 }
 
-template <typename CT, int MODE, bool CLAMP>
+template <typename CT, int MODE, int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                   const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
@@ -283,7 +288,7 @@ k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base
     }
     if (base_out) {
         real_t b0, b1;
-        stencil5_pair<real_t, CLAMP>(xv, hs, hn, hw, he, b0, b1);
+        stencil5_pair<real_t, SK>(xv, hs, hn, hw, he, b0, b1);
         *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
     }
     for (int b = 0; b < B; ++b) {
@@ -295,7 +300,7 @@ k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base
             cd p[8], o0, o1;
 #pragma unroll
             for (int m = 0; m < 8; ++m) p[m] = cd{xv[m], d[m]};
-            stencil5_pair<cd, CLAMP>(p, hs, hn, hw, he, o0, o1);
+            stencil5_pair<cd, SK>(p, hs, hn, hw, he, o0, o1);
             if (imag_only) {
                 *reinterpret_cast<r2_t *>(fx + (int64_t)b * fs + k) = r2_t{o0.im, o1.im};
             } else {
@@ -309,7 +314,7 @@ k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base
                 real_t p[8], o0, o1;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) p[m] = sgn == 0 ? xv[m] + d[m] : xv[m] - d[m];
-                stencil5_pair<real_t, CLAMP>(p, hs, hn, hw, he, o0, o1);
+                stencil5_pair<real_t, SK>(p, hs, hn, hw, he, o0, o1);
                 *reinterpret_cast<r2_t *>(fx + (int64_t)(sgn * B + b) * fs + k) = r2_t{o0, o1};
             }
         }
@@ -435,8 +440,9 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
         break;
     }
     case FD_F_LAP5:
+    case FD_F_LAP5_NL:
     case FD_F_CLAMP5: {
-        const bool clamp = b->family == FD_F_CLAMP5;
+        const int sk = b->family == FD_F_CLAMP5 ? 1 : b->family == FD_F_LAP5_NL ? 2 : 0;
         if constexpr (sizeof(T) == sizeof(real_t)) {
             const bool ok = ((((uintptr_t)fx) | ((uintptr_t)x)) & kPairMask) == 0 && (xs % 2 == 0 || nbatch == 1) &&
                             (fs % 2 == 0 || nbatch == 1) && (b->prm[0] % 2 == 0);
@@ -444,19 +450,16 @@ static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, i
                 const int64_t r0e = r0 & ~(int64_t)1;
                 const int64_t ntiles = (r1 - r0e + 2 * kBlock - 1) / (2 * kBlock);
                 const dim3 g2((unsigned)(8 * xcd_chunks(ntiles)), (unsigned)nbatch, 1);
-                if (clamp)
-                    hipLaunchKernelGGL((k_f_stencil5_v2<true>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
-                                       b->prm[0], b->prm[1], xs, fs, r0e, r1);
-                else
-                    hipLaunchKernelGGL((k_f_stencil5_v2<false>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x,
-                                       b->prm[0], b->prm[1], xs, fs, r0e, r1);
+#define FD_ST_V2(SKK) hipLaunchKernelGGL((k_f_stencil5_v2<SKK>), g2, dim3(kBlock), 0, s, (real_t *)fx, (const real_t *)x, \
+                                       b->prm[0], b->prm[1], xs, fs, r0e, r1)
+                if (sk == 1) FD_ST_V2(1); else if (sk == 2) FD_ST_V2(2); else FD_ST_V2(0);
+#undef FD_ST_V2
                 break;
             }
         }
-        if (clamp)
-            hipLaunchKernelGGL((k_f_stencil5<T, true>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
-        else
-            hipLaunchKernelGGL((k_f_stencil5<T, false>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1);
+#define FD_ST(SKK) hipLaunchKernelGGL((k_f_stencil5<T, SKK>), g, dim3(kBlock), 0, s, fxp, xp, b->prm[0], b->prm[1], xs, fs, r0, r1)
+        if (sk == 1) FD_ST(1); else if (sk == 2) FD_ST(2); else FD_ST(0);
+#undef FD_ST
         break;
     }
     case FD_F_BLOCKCOUPLED: {
@@ -524,15 +527,17 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
     const int64_t r0e = r0 & ~(int64_t)1;
     const int64_t ntiles = (r1 - r0e + 2 * kBlock - 1) / (2 * kBlock);
     const unsigned g = (unsigned)(8 * xcd_chunks(ntiles));
-    const bool clamp = b->family == FD_F_CLAMP5;
+    const int sk = b->family == FD_F_CLAMP5 ? 1 : b->family == FD_F_LAP5_NL ? 2 : 0;
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
 #define FD_LAZY(MODE, CL)                                                                                          \
     hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (real_t *)fx, fs,            \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,    \
                        lp->ncolors, b->prm[0], b->prm[1], r0e, r1, lp->imag_only)
-    if (mode == 0) { if (clamp) FD_LAZY(0, true); else FD_LAZY(0, false); }
-    else if (mode == 1) { if (clamp) FD_LAZY(1, true); else FD_LAZY(1, false); }
-    else { if (clamp) FD_LAZY(2, true); else FD_LAZY(2, false); }
+#define FD_LAZY_SK(MODE) do { if (sk == 1) FD_LAZY(MODE, 1); else if (sk == 2) FD_LAZY(MODE, 2); else FD_LAZY(MODE, 0); } while (0)
+    if (mode == 0) FD_LAZY_SK(0);
+    else if (mode == 1) FD_LAZY_SK(1);
+    else FD_LAZY_SK(2);
+#undef FD_LAZY_SK
 #undef FD_LAZY
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
@@ -792,7 +797,7 @@ k_f_tridiag_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ b
     }
 }
 
-template <bool CLAMP>
+template <int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                       const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t nx, int64_t ny)
@@ -817,7 +822,7 @@ k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
     }
     if (base_out) {
         real_t b0, b1;
-        stencil5_pair<real_t, CLAMP>(xv, hs, hn, hw, he, b0, b1);
+        stencil5_pair<real_t, SK>(xv, hs, hn, hw, he, b0, b1);
         *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
     }
 #pragma unroll
@@ -827,7 +832,7 @@ k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
         real_t p[8], o0, o1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) p[q] = minus ? xv[q] - ev[q] : xv[q] + ev[q];
-        stencil5_pair<real_t, CLAMP>(p, hs, hn, hw, he, o0, o1);
+        stencil5_pair<real_t, SK>(p, hs, hn, hw, he, o0, o1);
         *reinterpret_cast<r2_t *>(fx + (int64_t)m * fs + k) = r2_t{o0, o1};
     }
 }
@@ -835,7 +840,7 @@ k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 static bool has_lazy_jvp(const BuiltinF *b)
 {
     if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
-    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
+    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
 }
 
 static int builtin_launch_lazy_jvp(void *fctx, void *fx, const fd_lazy_jvp_points *lp, int64_t fx_stride, void *stream)
@@ -859,12 +864,10 @@ static int builtin_launch_lazy_jvp(void *fctx, void *fx, const fd_lazy_jvp_point
     } else {
         const int64_t n = b->prm[0] * b->prm[1];
         const unsigned g = (unsigned)(8 * xcd_chunks((n + 2 * kBlock - 1) / (2 * kBlock)));
-        if (b->family == FD_F_CLAMP5)
-            hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<true>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central,
-                               b->prm[0], b->prm[1]);
-        else
-            hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<false>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central,
-                               b->prm[0], b->prm[1]);
+#define FD_ST_JVP(SKK) hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<SKK>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, \
+                               lp->central, b->prm[0], b->prm[1])
+        if (b->family == FD_F_CLAMP5) FD_ST_JVP(1); else if (b->family == FD_F_LAP5_NL) FD_ST_JVP(2); else FD_ST_JVP(0);
+#undef FD_ST_JVP
     }
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
@@ -873,7 +876,7 @@ static bool has_lazy(const BuiltinF *b)
 {
     if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
     if (b->family == FD_F_BLOCKCOUPLED) return b->prm[1] <= 64;   // one wave per block
-    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
+    return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
 }
 
 static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64_t fx_stride, int64_t row_begin,
@@ -896,7 +899,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     if (b->family == FD_F_BLOCKCOUPLED)
         return lp->color_bytes == 1 ? lazy_blockcoupled_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
                                     : lazy_blockcoupled_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
-    if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5)
+    if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL)
         return lp->color_bytes == 1 ? lazy_stencil5_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
                                     : lazy_stencil5_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
     return lp->color_bytes == 1 ? lazy_tridiag_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
@@ -922,6 +925,7 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
     case FD_F_TRIDIAG:
     case FD_F_TRIDIAG_NL: need = 1; break;
     case FD_F_LAP5:
+    case FD_F_LAP5_NL:
     case FD_F_CLAMP5:
     case FD_F_BLOCKCOUPLED: need = 2; break;
     case FD_F_NONSQUARE: need = 1; break;

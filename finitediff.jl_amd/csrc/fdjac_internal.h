@@ -143,6 +143,12 @@ struct fd_plan {
     bool color8 = true;   // colours stored as uint8 (C <= 254) else int32
     int64_t col0 = 0, col1 = 0, x0 = 0, x1 = 0, row0 = 0, row1 = 0;
     int64_t own_c0 = 0, own_c1 = -1;   // owned colours [own_c0, own_c1), -1 = up to C (fd_plan_opts.color_begin/end)
+    // kernel variants, fixed at plan creation (environment switches are read there, never per process):
+    bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
+    bool cr_wg = true;             //   K_COLRANGE: one workgroup per 32 columns (FDJAC_COLRANGE_WG != 0)
+    bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
+    bool dma = false;              //   LDS-DMA staging in the row-window kernels (FDJAC_DMA=1)
+    int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
 
     // pattern (device)
     void *d_color = nullptr;       // per column, 0-based colour, "none" = all-ones

@@ -180,6 +180,7 @@ struct fd_jvp_plan {
     double *d_partial = nullptr;
     fdjac::real_t *d_xs = nullptr, *d_vs = nullptr, *d_fin = nullptr, *d_out = nullptr;
     int nparts = 1;
+    bool small_ok = true;          // fused single-workgroup launch of small problems (FDJAC_SMALL, read at plan creation)
     fd_f_launch_lazy_jvp lazy_fn = nullptr;
 };
 
@@ -200,6 +201,7 @@ int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_pla
     fd_jvp_plan *p = new (std::nothrow) fd_jvp_plan();
     FD_REQUIRE(p, FD_ERR_NOMEM, "out of host memory");
     p->ctx = ctx; p->fdtype = fdtype; p->M = M; p->N = N;
+    { const char *e = getenv("FDJAC_SMALL"); p->small_ok = !(e && *e && atoi(e) == 0); }
     p->ldx = (N + 31) / 32 * 32; p->ldf = (M + 31) / 32 * 32;
     p->nparts = balanced_grid((N + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8);
     const int pts = fdtype == FD_CENTRAL ? 2 : 1;
@@ -241,8 +243,7 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *
     if (absstep < 0) absstep = relstep;
     const int g = balanced_grid((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
     const int gm = balanced_grid((p->M + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 8);
-    static const bool small_off = [] { const char *e = getenv("FDJAC_SMALL"); return e && *e && atoi(e) == 0; }();
-    const bool small = !small_off && p->N <= kSmallN;
+    const bool small = p->small_ok && p->N <= kSmallN;   // (FDJAC_SMALL is read at plan creation)
     const bool base_in_batch = small && !central && !fin;
     const bool vx = ((((uintptr_t)xd) | ((uintptr_t)vd)) & kPairMask) == 0;
     // Lazy-point launcher (large problems; small ones are launch-latency bound and already fused): dot product and

@@ -1193,7 +1193,7 @@ static int64_t env_i64(const char *name, int64_t dflt)
     const char *v = getenv(name);
     return (v && *v) ? atoll(v) : dflt;
 }
-static int64_t g_tile = -1, g_capmult = -1;
+static int64_t g_capmult = -1;
 // The row-window kernels walk their tiles from the LAST one to the first: the f! values were written front to back
 // by the launch before, so the end of the batch is what the 256 MiB Infinity Cache still holds when the decompression
 // starts (measured in one process on the same buffers, N = 10^7: tridiagonal forward 123.9 -> 118.3 / 119.8 -> 117.4 /
@@ -1202,7 +1202,6 @@ static int64_t g_tile = -1, g_capmult = -1;
 // Same work per tile => same bits.  FDJAC_REVERSE=0 restores front-to-back order (read per launch: tests toggle it).
 static inline bool tile_order_reversed() { return env_i64("FDJAC_REVERSE", 1) != 0; }
 
-static inline int64_t tune_tile() { if (g_tile < 0) { g_tile = env_i64("FDJAC_TILE", 2); if (g_tile != 1 && g_tile != 2) g_tile = 4; } return g_tile; }
 static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
 
 // Grid for a grid-stride kernel: at most cap resident workgroups, and -- because these kernels are
@@ -1317,7 +1316,7 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     hipStream_t s = p->ctx->stream;
     // LDS-DMA staging is bit-identical but measured no faster on MI355X (tridiagonal forward 123 vs 124 us) and slower
     // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
-    static const bool dma_off = env_i64("FDJAC_DMA", 0) == 0;
+    const bool dma_off = !p->dma;   // (fixed at plan creation)
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
     const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
     // the imaginary parts of an imag-only complex step arrive as a real array with fx = the plan's all-zero vector:
@@ -1402,7 +1401,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             launch_window_m<MODE>(p, fx, FXa, FXb, c_lo, c_hi, outs[0]);
             break;
         }
-        const int U = (int)tune_tile();   // pairs per thread (FDJAC_TILE env: 1, 2 or 4)
+        const int U = p->list_U;   // pairs per thread (FDJAC_TILE at plan creation: 1, 2 or 4)
         const int64_t tile = (int64_t)U * kBlock * 2;
         const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);
         const bool lds = B <= kEpsLdsMax;
@@ -1427,10 +1426,9 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         break;
     }
     case K_TRIDIAG: {
-        static const int win_off = (int)env_i64("FDJAC_WINDOW", -1) == 0;
-        // row-window variant: few colours (every loaded f! value is used when C == 3), an even first column (16-B
-        // aligned pairs); otherwise the gather kernel below
-        if (!win_off && p->C <= 4 && (p->col0 % 2) == 0 && p->col1 > p->col0) {
+        // row-window variant (chosen at plan creation, FD_INFO_WINDOW): few colours, an even first column; otherwise
+        // the gather kernel below
+        if (p->tri_window) {
             const int64_t nt = (p->col1 - p->col0 + kTriTile - 1) / kTriTile;
             const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
             const int fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
@@ -1467,8 +1465,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         break;
     }
     case K_COLRANGE: {
-        static const bool cr_wave = env_i64("FDJAC_COLRANGE_WG", 1) == 0;
-        if (!cr_wave) {   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
+        if (p->cr_wg) {   // (chosen at plan creation, FD_INFO_COLRANGE_WG)   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
             const int64_t nc = p->col1 - p->col0;
             // the imaginary parts of an imag-only complex step arrive as a real array with fx = the zero vector
             const real_t *fxb = (MODE == 0 && p->fdtype == FD_COMPLEX && FXb == p->d_fx) ? nullptr : FXb;

@@ -195,8 +195,14 @@ enum fd_plan_info_key {
     FD_INFO_WINDOW = 17,              /* 1 if the row-window (dense loads -> LDS) decompression kernel is used */
     FD_INFO_WIN_OVERREAD_X100 = 18,   /*   x100: f! values loaded per stored entry by that kernel (100 = none wasted) */
     FD_INFO_WINDOW2D = 19,            /*   1 if its tiles are 2-D (column runs one stencil stride apart) */
-    FD_INFO_WIN_PERIOD = 20           /*   period (in stored entries) of the regular tiles' entry codes, 0 = none */
+    FD_INFO_WIN_PERIOD = 20,          /*   period (in stored entries) of the regular tiles' entry codes, 0 = none */
+    FD_INFO_COLRANGE_WG = 21,         /* block-banded plans: 1 = one workgroup per 32 columns, 0 = one wave per column */
+    FD_INFO_SMALL_FUSED = 22,         /* 1 if the plan uses the fused single-workgroup launches of small problems */
+    FD_INFO_LDS_DMA = 23              /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
 };
+/* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
+   read there, not per process and not per launch -- except FDJAC_REVERSE and FDJAC_COLRANGE_VEC, which only reorder
+   or re-vectorise the same work); FD_INFO_WINDOW also reports the row-window kernel of Tridiagonal plans. */
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
@@ -241,7 +247,8 @@ enum fd_builtin_family {
     FD_F_LAP5 = 2,         /* params {nx,ny}: zero-Dirichlet 5-point Laplacian                              */
     FD_F_CLAMP5 = 3,       /* params {nx,ny}: clamped-edge sum stencil       (test/coloring_tests.jl:99-108) */
     FD_F_BLOCKCOUPLED = 4, /* params {nblk,bs}: x_b[k]*(sig_{b-1}+sig_b+sig_{b+1}) + sin(x_b[k])            */
-    FD_F_NONSQUARE = 5     /* params {n}: (x1-3)^2 + x1*x2 + (x2+4)^2 - 3    (test/coloring_tests.jl:124-133) */
+    FD_F_NONSQUARE = 5,    /* params {n}: (x1-3)^2 + x1*x2 + (x2+4)^2 - 3    (test/coloring_tests.jl:124-133) */
+    FD_F_LAP5_NL = 6       /* params {nx,ny}: FD_F_LAP5 + x[k]^2 * x[k+1]  (same pattern; J depends on x)        */
 };
 int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,
                         fd_f_launch *fn_out, void **fctx_out);

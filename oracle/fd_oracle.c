@@ -491,6 +491,30 @@ void fdo_fc_lap5(void *ctx, cplx *out, const cplx *x)
             out[k] = w + e + s + n - 4 * x[k];
         }
 }
+/* nonlinear variant of the zero-Dirichlet Laplacian: + x[k]^2 * x[k+1] (east neighbour, 0 beyond the edge); same
+   5-point pattern, J depends on x -- the full-size parity fixture of BASELINE config 3 */
+void fdo_f_lap5_nl(void *ctx, fdo_real *out, const fdo_real *x)
+{
+    const int64_t nx = ((const int64_t *)ctx)[0], ny = ((const int64_t *)ctx)[1];
+    for (int64_t j = 0; j < ny; ++j)
+        for (int64_t i = 0; i < nx; ++i) {
+            int64_t k = i + nx * j;
+            fdo_real w = i > 0 ? x[k - 1] : 0.0, e = i + 1 < nx ? x[k + 1] : 0.0;
+            fdo_real s = j > 0 ? x[k - nx] : 0.0, n = j + 1 < ny ? x[k + nx] : 0.0;
+            out[k] = (w + e + s + n - 4 * x[k]) + x[k] * x[k] * e;
+        }
+}
+void fdo_fc_lap5_nl(void *ctx, cplx *out, const cplx *x)
+{
+    const int64_t nx = ((const int64_t *)ctx)[0], ny = ((const int64_t *)ctx)[1];
+    for (int64_t j = 0; j < ny; ++j)
+        for (int64_t i = 0; i < nx; ++i) {
+            int64_t k = i + nx * j;
+            cplx w = i > 0 ? x[k - 1] : 0.0, e = i + 1 < nx ? x[k + 1] : 0.0;
+            cplx s = j > 0 ? x[k - nx] : 0.0, n = j + 1 < ny ? x[k + nx] : 0.0;
+            out[k] = (w + e + s + n - 4 * x[k]) + x[k] * x[k] * e;
+        }
+}
 /* clamped-edge sum stencil, test/coloring_tests.jl:99-108 */
 void fdo_f_clamp5(void *ctx, fdo_real *out, const fdo_real *x)
 {

@@ -1,7 +1,13 @@
-"""BASELINE.json's configurations at their FULL sizes, through properties that need no CPU oracle.
+"""BASELINE.json's configurations at their FULL sizes.
 
-The oracle finishes N = 10^7 in minutes, so at full size the device path is checked against what the domain
-itself offers (all computed with plain torch on the device, Float64):
+Two kinds of check:
+
+1. HIP path vs the CPU oracle, EVERY stored value (`test_full_size_vs_oracle`): configs 2, 3, 4 and 5 at BASELINE's
+   exact sizes with the NONLINEAR fixtures (J depends on x, so a stale buffer or a wrong step size cannot pass), with
+   SURVEY 8(c)'s tolerance  |J_gpu - J_cpu| <= 1e-6*|J_cpu| + 16*eps(Float64)*max|f|/|eps_c|  and the step sizes to
+   1e-12 relative.  The oracle needs 0.2 s (N = 10^7 tridiagonal forward) to ~1.5 s (5-point central, block-banded
+   complex step) per Jacobian on one host core.
+2. Size-independent properties computed with plain torch on the device (independent of the oracle):
 
 * the analytic Jacobian of the seeded nonlinear fixtures (stored entry by stored entry, in storage order);
 * linear fixtures: J is the constant stencil whatever x is, and J*v == f(v) exactly up to rounding;
@@ -189,3 +195,86 @@ def test_float32_full_size_headline():
     isdiag = torch.as_tensor(rowval == P.csc_cols(colptr), device="cuda")
     # eps ~ 3.5e-4*sqrt(|x_c|) ~ 1e-2; ulp(f)/eps ~ 2.4e-7/1e-2
     assert (J.nzval[isdiag] + 2.0).abs().max().item() < 2e-3 and (J.nzval[~isdiag] - 1.0).abs().max().item() < 2e-3
+
+
+# ---- HIP path vs the CPU oracle at BASELINE's exact sizes ------------------------------------------------------------
+EPS64 = float(np.finfo(np.float64).eps)
+
+
+def _oracle_eps(x, colors, fdtype):
+    """The masked-norm step sizes (src/jacobians.jl:559-561 / 600-602 / 624) restated in numpy."""
+    C = int(colors.max())
+    if fdtype == "complex":
+        return np.full(C, EPS64)
+    rel = fd.default_relstep(fdtype)
+    ss = np.bincount(colors - 1, weights=x * x, minlength=C)      # sum of squares per colour
+    return np.maximum(rel * np.sqrt(np.sqrt(ss)), rel)
+
+
+_CASES = {}
+
+
+def _fullsize_case(name):
+    """Pattern / colours of one BASELINE configuration (built once per session: the host-side pattern generators need
+    several seconds at N = 10^7)."""
+    if name not in _CASES:
+        _CASES[name] = _build_fullsize_case(name)
+    return _CASES[name]
+
+
+def _build_fullsize_case(name):
+    if name in ("c2", "c4"):                      # BASELINE configs 2 / 4: tridiagonal CSC, forward
+        N = 10 ** 6 if name == "c2" else 10 ** 7
+        colptr, rowval = P.tridiag_csc(N)
+        return dict(N=N, seed=2 if name == "c2" else 4, fdtype="forward", colors=P.cyclic_colors(N, 3), fam="tridiag_nl",
+                    prm=(N,), kind="csc", colptr=colptr, rowval=rowval, fscale=5.0)
+    if name == "c3":                              # config 3: 4000 x 2500 5-point stencil, central
+        nx, ny = 4000, 2500
+        colptr, rowval = P.lap5_csc(nx, ny)
+        return dict(N=nx * ny, seed=3, fdtype="central", colors=P.lap5_colors(nx, ny), fam="lap5_nl", prm=(nx, ny),
+                    kind="csc", colptr=colptr, rowval=rowval, fscale=9.0)
+    nb, bs = 10 ** 4, 32                          # config 5: 10^4 dense 32x32 blocks, complex step
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    return dict(N=nb * bs, seed=5, fdtype="complex", colors=lay.colors(), fam="blockcoupled", prm=(nb, bs), kind="bb",
+                lay=lay, fscale=60.0)
+
+
+@pytest.mark.parametrize("lazy", [True, False], ids=["lazy_f", "materialized_f"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_full_size_vs_oracle(oracle, name, lazy):
+    # test/coloring_tests.jl:33-49 (tridiagonal), :99-119 (5-point stencil, block-banded) at BASELINE.json's sizes
+    cs = _fullsize_case(name)
+    N, fdtype, colors = cs["N"], cs["fdtype"], cs["colors"]
+    xh = np.random.default_rng(cs["seed"]).random(N)
+    x = torch.as_tensor(xh, device="cuda")
+    xc = x.clone()
+    f = fd.BuiltinF(cs["fam"], *cs["prm"])
+    if cs["kind"] == "csc":
+        J = fd.SparseMatrixCSC(N, N, cs["colptr"], cs["rowval"], None)
+        okw = dict(kind=oracle.PAT_CSC_COMMON, colptr=cs["colptr"], rowval=cs["rowval"])
+    else:
+        lay = cs["lay"]
+        J = fd.BlockBandedMatrix(None, lay)
+        okw = dict(kind=oracle.PAT_BLOCKBANDED, blk_sizes=lay.blk_sizes, bl=lay.bl, bu=lay.bu,
+                   block_starts=lay.block_starts, block_strides=lay.block_strides, out_len=lay.data_len)
+    plan = fd.make_plan(J, J, colors, fdtype)
+    if lazy:
+        plan.set_lazy(f)
+    out = _nan(plan.out_len(0))
+    plan.jacobian(f, x, [out])
+    C = int(colors.max())
+    assert f.fcalls == CALLS[fdtype](C) and torch.equal(x, xc) and plan.fcalls_last == CALLS[fdtype](C)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    ref = oracle.jacobian(fdtype, oracle.Fixture(cs["fam"], *cs["prm"]), xh, colors, **okw)
+    assert ref["fcalls"] == f.fcalls
+    eps = plan.epsilons()
+    assert np.allclose(eps, _oracle_eps(xh, colors, fdtype), rtol=1e-12, atol=0)
+    want = ref["out"]
+    atol = 16 * EPS64 * cs["fscale"] / float(np.min(np.abs(eps)))
+    if fdtype == "complex":
+        atol = 1e-12 * float(np.max(np.abs(want)))
+    dev = np.abs(got - want)
+    bad = dev > 1e-6 * np.abs(want) + atol
+    assert not bad.any(), "%s: %d of %d stored values off, worst %.3e (atol %.1e)" % (name, int(bad.sum()), got.size,
+                                                                                       float(dev.max()), atol)

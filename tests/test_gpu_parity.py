@@ -760,6 +760,10 @@ def test_tridiagonal_window_kernel_bit_identical(monkeypatch, fdtype, case):
                             x_window=(max(win[0] - 2, 0), min(win[1] + 2, N)) if win else None)
         if case == "chunked":
             assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        # the variant is fixed when the plan is created and reported by the plan: row windows need <= 4 colours and an
+        # even first column, so the two runs really compare k_decompress_tridiag with k_decompress_tridiag_window
+        want_window = forced == "1" and C <= 4 and (win is None or win[0] % 2 == 0)
+        assert plan.info(fd.lib.INFO_WINDOW) == int(want_window)
         o = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3)]
         plan.jacobian(fd.BuiltinF("tridiag_nl", N), x, o, f_in=f_in)
         outs.append(np.concatenate([t.cpu().numpy() for t in o]))
@@ -1219,3 +1223,42 @@ def test_out_of_place_api(oracle):
     fd.finite_difference_jacobian(fd.BuiltinF("tridiag", N), _dev(np.zeros(N)), cache, jac_prototype=sp)
     J2 = fd.finite_difference_jacobian(fd.BuiltinF("tridiag", N), _dev(x), cache, jac_prototype=sp)
     assert np.linalg.norm(P.csc_to_dense(N, N, colptr, rowval, J2.nzval.cpu().numpy()) - exact) <= 1e-6
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_colrange_wave_and_workgroup_kernels_bit_identical(monkeypatch, fdtype):
+    # FDJAC_COLRANGE_WG is read when the plan is created: both block-banded kernels live side by side in one process
+    lay = P.BlockBandedLayout(np.full(40, 32), 1, 1)
+    N = lay.N
+    colors = lay.colors()
+    x = _dev(np.random.default_rng(71).random(N))
+    Jb = fd.BlockBandedMatrix(None, lay)
+    outs = []
+    for wg in ("1", "0"):
+        monkeypatch.setenv("FDJAC_COLRANGE_WG", wg)
+        plan = fd.make_plan(Jb, Jb, colors, fdtype)
+        assert plan.info(fd.lib.INFO_COLRANGE_WG) == int(wg)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.BuiltinF("blockcoupled", 40, 32), x, [out])
+        outs.append(out.cpu().numpy())
+    assert not np.isnan(outs[0]).any() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_small_fused_launch_is_a_plan_property(monkeypatch, oracle, fdtype):
+    # FDJAC_SMALL is read at plan creation; the fused single-workgroup launch and the wide path agree with the oracle
+    N = 3000
+    colptr, rowval = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    xh = np.random.default_rng(72).random(N)
+    ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N), xh, colors, kind=oracle.PAT_CSC_COMMON,
+                          colptr=colptr, rowval=rowval)["out"]
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    for small in ("1", "0"):
+        monkeypatch.setenv("FDJAC_SMALL", small)
+        plan = fd.make_plan(J, J, colors, fdtype)
+        assert plan.info(fd.lib.INFO_SMALL_FUSED) == int(small)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.BuiltinF("tridiag_nl", N), _dev(xh), [out])
+        got = out.cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref) + 1e-7)
