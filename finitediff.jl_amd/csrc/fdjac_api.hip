@@ -131,6 +131,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->dma = env_int("FDJAC_DMA", 0) != 0;
     p->list_U = env_int("FDJAC_TILE", 2);
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
+    p->eps_nt = env_int("FDJAC_EPS_NT", 1) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -173,6 +174,15 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
         if (r2) return r2;
     } else if (p->C > 0 && p->kind != K_DENSE) {
         if (p->C <= kRegColors) {
+            // cyclic colours (mod1(j, C) and its rotations): the reduction computes them instead of reading them
+            {
+                const char *fc = getenv("FDJAC_EPS_CYCLIC");
+                bool cyc = !(fc && *fc && atoi(fc) == 0) && p->N >= 1 && col0[0] >= 0;
+                const int32_t sh = cyc ? col0[0] : 0;
+                for (int64_t j = 0; j < p->N && cyc; ++j) cyc = col0[(size_t)j] == (int32_t)((j + sh) % p->C);
+                p->cyc_C = cyc ? (int)p->C : 0;
+                p->cyc_shift = cyc ? (int)sh : 0;
+            }
             const char *cm = getenv("FDJAC_GRID_CAP");
             // 4 workgroups per CU: measured 31.0 us for partial + finalize at N = 10^7 (8: 34.5, 16: 33.7, 2: 36.6,
             // uncapped 36.1 -- fewer partials for the finalize, enough loads in flight for the reduction)
@@ -1116,6 +1126,8 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
                   p->fdtype != FD_COMPLEX) ? 1 : 0;
         break;
     case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
+    case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
+    case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;

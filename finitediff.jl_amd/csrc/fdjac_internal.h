@@ -149,6 +149,9 @@ struct fd_plan {
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
     bool dma = false;              //   LDS-DMA staging in the row-window kernels (FDJAC_DMA=1)
     int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
+    bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads (FDJAC_EPS_NT != 0)
+    int cyc_C = 0, cyc_shift = 0;  // cyclic colours: color[j] == (j + cyc_shift) mod cyc_C for every column (0 = not cyclic);
+                                   //   the reduction then computes the colours instead of reading them (FDJAC_EPS_CYCLIC=0: off)
 
     // pattern (device)
     void *d_color = nullptr;       // per column, 0-based colour, "none" = all-ones

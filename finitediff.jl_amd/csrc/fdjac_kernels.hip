@@ -51,10 +51,16 @@ template <> __device__ __forceinline__ void load_color_pair<int32_t>(const int32
 
 constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 
-template <typename CT, int NC>
+// CYC: the colours are cyclic, color[j] == (j + shift) mod C for every column (found at plan time: tridiagonal /
+//   banded patterns coloured with mod1(j, C)) -- the kernel computes them and reads x alone (8 B per column instead of 9).
+// NT:  non-temporal loads of x.  In a steady-state loop the pass follows the previous call's nzval stores; plain
+//   loads allocate in the Infinity Cache and pay for the write-back of as many dirty lines as they bring in
+//   (scripts/ubench/eps_mall_probe.hip: 26.6 us after 240 MB of stores, 21.2 us after reads only, 21.4 us with
+//   non-temporal loads after stores).  Same values, same summation order => same bits in all four variants.
+template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
-                  double *__restrict__ partial, int ldp)
+                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift)
 {
     double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
 #pragma unroll
@@ -62,18 +68,32 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
 
     // block tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
     const int64_t tile = (int64_t)kEpsU * kBlock * 2;
+    // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u and (stride mod C) per round
+    int rc = 0, du = 0, dr = 0;
+    if (CYC) {
+        rc = (int)(((int64_t)blockIdx.x * tile + threadIdx.x * 2 + cyc_shift) % cyc_C);
+        du = (kBlock * 2) % cyc_C;
+        dr = (int)((((int64_t)gridDim.x - 1) * tile + (tile - (int64_t)(kEpsU - 1) * kBlock * 2)) % cyc_C);   // last u of a round -> first u of the next
+    }
     for (int64_t base = (int64_t)blockIdx.x * tile; base < n; base += (int64_t)gridDim.x * tile) {
         r2_t v[kEpsU];
         int c0[kEpsU], c1[kEpsU];
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
             const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+            if (CYC) {
+                c0[u] = rc;
+                c1[u] = rc + 1 == cyc_C ? 0 : rc + 1;
+                rc += (u + 1 < kEpsU) ? du : dr;
+                rc = rc >= cyc_C ? rc - cyc_C : rc;
+            }
             if (i + 1 < n) {
-                v[u] = *reinterpret_cast<const r2_t *>(x + i);
-                load_color_pair<CT>(color + i, c0[u], c1[u]);
+                if (NT) v[u] = __builtin_nontemporal_load(reinterpret_cast<const r2_t *>(x + i));
+                else v[u] = *reinterpret_cast<const r2_t *>(x + i);
+                if (!CYC) load_color_pair<CT>(color + i, c0[u], c1[u]);
             } else if (i < n) {
                 v[u] = r2_t{x[i], 0.0};
-                c0[u] = color[i];
+                if (!CYC) c0[u] = color[i];
                 c1[u] = -2;
             } else {
                 v[u] = r2_t{0.0, 0.0};
@@ -1231,12 +1251,17 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
     if (C <= kRegColors) {
         nparts = p->n_partial_blocks;
         ldp = kRegColors;
-        if (C <= 4)
-            hipLaunchKernelGGL((k_eps_partial_reg<CT, 4>), dim3(nparts), dim3(kBlock), 0, s, x,
-                               (const CT *)p->d_color, p->N, p->d_partial, ldp);
-        else
-            hipLaunchKernelGGL((k_eps_partial_reg<CT, kRegColors>), dim3(nparts), dim3(kBlock), 0, s,
-                               x, (const CT *)p->d_color, p->N, p->d_partial, ldp);
+#define FD_EPS_REG(NCC, CY, NTT)                                                                                \
+        hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nparts), dim3(kBlock), 0, s, x,           \
+                           (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift)
+#define FD_EPS_REG_V(NCC)                                                                                       \
+        do {                                                                                                    \
+            if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); } \
+            else { if (p->eps_nt) FD_EPS_REG(NCC, false, true); else FD_EPS_REG(NCC, false, false); }           \
+        } while (0)
+        if (C <= 4) FD_EPS_REG_V(4); else FD_EPS_REG_V(kRegColors);
+#undef FD_EPS_REG_V
+#undef FD_EPS_REG
     } else {
         nparts = p->seg_chunks;
         ldp = C;

@@ -198,7 +198,9 @@ enum fd_plan_info_key {
     FD_INFO_WIN_PERIOD = 20,          /*   period (in stored entries) of the regular tiles' entry codes, 0 = none */
     FD_INFO_COLRANGE_WG = 21,         /* block-banded plans: 1 = one workgroup per 32 columns, 0 = one wave per column */
     FD_INFO_SMALL_FUSED = 22,         /* 1 if the plan uses the fused single-workgroup launches of small problems */
-    FD_INFO_LDS_DMA = 23              /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
+    FD_INFO_LDS_DMA = 23,             /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
+    FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
+    FD_INFO_EPS_NT = 25               /* 1 if the step-size reduction reads x with non-temporal loads */
 };
 /* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
    read there, not per process and not per launch -- except FDJAC_REVERSE and FDJAC_COLRANGE_VEC, which only reorder

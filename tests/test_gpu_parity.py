@@ -1262,3 +1262,36 @@ def test_small_fused_launch_is_a_plan_property(monkeypatch, oracle, fdtype):
         plan.jacobian(fd.BuiltinF("tridiag_nl", N), _dev(xh), [out])
         got = out.cpu().numpy()
         assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref) + 1e-7)
+
+
+@pytest.mark.parametrize("C,shift,N", [(3, 0, 100003), (3, 2, 40000), (5, 1, 70001), (8, 3, 33333), (2, 1, 4099 * 5), (4, 0, 2048 * 9 + 1)])
+def test_eps_reduction_variants_bit_identical(monkeypatch, C, shift, N):
+    # cyclic colourings: the step-size reduction computes the colours (FD_INFO_EPS_CYCLIC) instead of reading them;
+    # x is read with non-temporal loads (FD_INFO_EPS_NT).  Same values, same order: all four variants give the same bits,
+    # and they equal the masked-norm rule restated in numpy (src/jacobians.jl:559-561) to 1e-13
+    colors = ((np.arange(N) + shift) % C + 1).astype(np.int64)
+    xh = np.random.default_rng(90 + C).random(N) * 3 - 1
+    x = _dev(xh)
+    colptr, rowval = P.banded_csc(N, N, C // 2, C - 1 - C // 2)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    got = {}
+    for cyc in ("1", "0"):
+        for nt in ("1", "0"):
+            monkeypatch.setenv("FDJAC_EPS_CYCLIC", cyc)
+            monkeypatch.setenv("FDJAC_EPS_NT", nt)
+            monkeypatch.setenv("FDJAC_SMALL", "0")
+            plan = fd.make_plan(J, J, colors, "forward")
+            assert plan.info(fd.lib.INFO_EPS_CYCLIC) == (C if cyc == "1" else 0)
+            assert plan.info(fd.lib.INFO_EPS_NT) == int(nt)
+            out = _dev(np.full(plan.out_len(0), np.nan))
+            plan.jacobian(fd.TorchF(lambda fx, xx: fx.copy_(xx * xx), N, N), x, [out])
+            got[(cyc, nt)] = plan.epsilons()
+    ref = got[("0", "0")]
+    for k, v in got.items():
+        assert np.array_equal(v, ref), k
+    assert np.allclose(ref, _oracle_eps(xh, colors, "forward"), rtol=1e-13, atol=0)
+    # a colouring that is NOT cyclic falls back to reading the colours
+    monkeypatch.setenv("FDJAC_EPS_CYCLIC", "1")
+    c2 = colors.copy()
+    c2[N // 2] = c2[N // 2] % C + 1
+    assert fd.make_plan(J, J, c2, "forward").info(fd.lib.INFO_EPS_CYCLIC) == 0
