@@ -205,6 +205,73 @@ class Context:
         return out.value
 
 
+class Comm:
+    """fd_comm: the RCCL communicator behind the C ABI (one process per GPU).  Every collective is enqueued on the
+    context's stream.  Bootstrap: rank 0's ``Comm.unique_id()`` bytes reach the other ranks by whatever the host has;
+    ``Comm.from_torch_distributed`` uses an initialised torch.distributed group for exactly that and nothing else."""
+
+    def __init__(self, ctx, nranks, rank, uid):
+        self.ctx, self.L = ctx, ctx.L
+        if len(uid) != _l.COMM_ID_BYTES:
+            raise ValueError("the communicator id has %d bytes" % _l.COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), _l.COMM_ID_BYTES)
+        _l.check(self.L.fd_comm_create(ctx.handle, int(nranks), int(rank), buf, C.byref(h)))
+        self.handle, self.nranks, self.rank = h, int(nranks), int(rank)
+        self._fin = weakref.finalize(self, self.L.fd_comm_destroy, h)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_l.COMM_ID_BYTES)
+        _l.check(_l.load().fd_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, ctx, dist=None, group=None):
+        if dist is None:
+            import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(ctx, world, rank, box[0])
+
+    def info(self):
+        n, r, v = C.c_int(), C.c_int(), C.c_int()
+        _l.check(self.L.fd_comm_info(self.handle, C.byref(n), C.byref(r), C.byref(v)))
+        return {"nranks": n.value, "rank": r.value, "rccl_version": v.value,
+                "library": self.L.fd_comm_library().decode("utf-8", "replace")}
+
+    @staticmethod
+    def _dev(t, what):
+        if not (_is_torch(t) and t.is_cuda and t.is_contiguous()):
+            raise ValueError("%s must be a contiguous CUDA tensor" % what)
+        return t.data_ptr(), t.element_size()
+
+    def allgather(self, buf, slot_elems):
+        """In place: rank r's slice already sits in slot r of `buf` (nranks slots of slot_elems elements)."""
+        p, eb = self._dev(buf, "buf")
+        if buf.numel() < self.nranks * int(slot_elems):
+            raise ValueError("buf is shorter than nranks * slot_elems")
+        _l.check(self.L.fd_comm_allgather(self.handle, p, int(slot_elems), eb))
+
+    def gatherv(self, send, recv, counts, root=0):
+        """Slices of lengths counts[r] to the root, back to back in `recv` (only read on the root)."""
+        counts = _i64(counts)
+        displs = _i64(np.concatenate([[0], np.cumsum(counts)[:-1]]))
+        sp, eb = self._dev(send, "send") if send.numel() else (None, send.element_size())
+        rp = self._dev(recv, "recv")[0] if recv is not None else None
+        _l.check(self.L.fd_comm_gatherv(self.handle, sp, int(send.numel()), rp, counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        displs.ctypes.data_as(C.POINTER(C.c_int64)), eb, int(root)))
+
+    def allreduce_sum(self, buf):
+        p, eb = self._dev(buf, "buf")
+        _l.check(self.L.fd_comm_allreduce_sum(self.handle, p, buf.numel(), eb))
+
+    def broadcast(self, buf, root=0):
+        p, eb = self._dev(buf, "buf")
+        _l.check(self.L.fd_comm_broadcast(self.handle, p, buf.numel(), eb, int(root)))
+
+
 class BuiltinF:
     """One of libfdjac's device f! families (fd_builtin_f_create): the reference's fixtures."""
 
@@ -357,6 +424,28 @@ class Plan:
         _l.check(self.Lt.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
         caps = int(getattr(f, "lazy_caps", 0)) if (f is not None and imag_only) else 0
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
+
+    def set_comm(self, comm):
+        """Shard the step-size reduction over the communicator's ranks (fd_plan_set_comm); None detaches."""
+        self._comm_keep = comm
+        _l.check(self.Lt.fd_plan_set_comm(self.handle, comm.handle if comm is not None else None))
+
+    def eps_partials(self, x, shard, nshards):
+        """Enqueue shard `shard` of `nshards` of the masked sums of squares (fd_plan_eps_partials); returns
+        (device address of the partial buffer, doubles per slot)."""
+        xp, xk, _k = _ptr(x, "x", self.dtype)
+        if xk != _l.DEVICE:
+            raise ValueError("eps_partials needs a device array")
+        ptr, slot = C.c_void_p(), C.c_int64()
+        _l.check(self.Lt.fd_plan_eps_partials(self.handle, xp, int(shard), int(nshards), C.byref(ptr), C.byref(slot)))
+        return ptr.value, slot.value
+
+    def eps_finalize(self, relstep=None, absstep=None, dir=True):
+        _l.check(self.Lt.fd_plan_eps_finalize(self.handle, -1.0 if relstep is None else float(relstep),
+                                              -1.0 if absstep is None else float(absstep), float(dir)))
+
+    def set_eps_mode(self, precomputed):
+        _l.check(self.Lt.fd_plan_set_eps_mode(self.handle, _l.EPS_PRECOMPUTED if precomputed else _l.EPS_COMPUTE))
 
     def jacobian(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True, sync=True):
         """fd_jacobian / fd_jacobian_async on raw arrays (torch CUDA tensors or numpy arrays)."""

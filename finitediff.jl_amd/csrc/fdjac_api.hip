@@ -16,6 +16,9 @@ static thread_local char g_err[512] = "";
 #endif
 
 int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir);
+int launch_eps_partial(fd_plan *p, const real_t *x, int b0, int nb);
+int launch_eps_finalize(fd_plan *p, int nparts, int ldp, double relstep, double absstep, double dir);
+constexpr int kMaxEpsShards = 1024;   // the partial buffer has room for this many padded shards
 int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double absstep, double dir, int pmode,
                              int base_row);
 int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B);
@@ -189,7 +192,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
             const int64_t mult = (cm && *cm) ? atoll(cm) : 4;
             const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
             p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
-            if ((rc = dev_alloc(&p->d_partial, (int64_t)p->n_partial_blocks * kRegColors))) return rc;
+            // (+ kMaxEpsShards rows: a sharded reduction pads the grid to a whole number of blocks per shard)
+            p->partial_cap = ((int64_t)p->n_partial_blocks + kMaxEpsShards) * kRegColors;
+            if ((rc = dev_alloc(&p->d_partial, p->partial_cap))) return rc;
         } else {
             // counting sort of the columns by colour
             std::vector<int64_t> cptr((size_t)p->C + 1, 0);
@@ -1220,6 +1225,13 @@ int fd_plan_get_timings(fd_plan *p, double *ms_sum, int64_t *launches)
     return FD_OK;
 }
 
+// the register-path reduction over a global grid of blocks is the one that can be split across ranks / shards
+static bool eps_shardable(const fd_plan *p)
+{
+    return p->fdtype != FD_COMPLEX && p->kind != K_DENSE && p->C > 0 && p->C <= kRegColors &&
+           !(p->small_ok && p->N <= kSmallN) && p->d_partial != nullptr;
+}
+
 // ---- the hot path ---------------------------------------------------------------------------
 static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t *x_dev, const real_t *fin_dev,
                             double relstep, double absstep, double dir, real_t *const *outs)
@@ -1259,11 +1271,27 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     p->fx_batch_row = nullptr;
 
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
-    if (p->fdtype != FD_COMPLEX && p->C > 0) {
+    if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
+        // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current
+        FD_REQUIRE(!small_points, FD_ERR_UNSUPPORTED, "FD_EPS_PRECOMPUTED needs a plan whose reduction can be sharded");
+    } else if (p->fdtype != FD_COMPLEX && p->C > 0) {
         Span sp(p, FD_STAGE_EPS);
-        int rc = small ? launch_eps_perturb_small(p, x_dev, relstep, absstep, dir, small_points ? p->fdtype : -1,
-                                                  base_in_batch ? (int)(p->C * p->pts) : -1)
-                       : launch_eps(p, x_dev, relstep, absstep, dir);
+        int rc;
+        if (small) {
+            rc = launch_eps_perturb_small(p, x_dev, relstep, absstep, dir, small_points ? p->fdtype : -1,
+                                          base_in_batch ? (int)(p->C * p->pts) : -1);
+        } else if (p->comm && eps_shardable(p)) {   // (also with a single-rank communicator: same code path)
+            // sharded reduction: this rank's blocks of the global grid, all-gather of the partial sums (in place, padded
+            // slots), the same finalize as the unsharded call => bit-identical step sizes on every rank
+            const int W = fdjac_comm_nranks(p->comm), r = fdjac_comm_rank(p->comm);
+            const int S = (p->n_partial_blocks + W - 1) / W;
+            const int b0 = std::min(r * S, p->n_partial_blocks), nb = std::min(S, p->n_partial_blocks - b0);
+            rc = launch_eps_partial(p, x_dev, b0, nb);
+            if (!rc) rc = fdjac_comm_allgather_f64(p->comm, p->d_partial, (int64_t)S * kRegColors);
+            if (!rc) rc = launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
+        } else {
+            rc = launch_eps(p, x_dev, relstep, absstep, dir);
+        }
         if (rc) return rc;
     }
 
@@ -1423,6 +1451,55 @@ int fd_plan_set_lazy_caps(fd_plan *p, int caps)
 {
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     p->lazy_caps = caps;
+    return FD_OK;
+}
+
+int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(comm == nullptr || fdjac_comm_ctx(comm) == p->ctx, FD_ERR_ARG, "the communicator belongs to another context");
+    FD_REQUIRE(comm == nullptr || fdjac_comm_nranks(comm) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
+    p->comm = comm;
+    return FD_OK;
+}
+
+int fd_plan_eps_partials(fd_plan *p, const void *x_dev, int shard, int nshards, void **partials_out,
+                         int64_t *slot_doubles_out)
+{
+    FD_REQUIRE(p && x_dev, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(nshards >= 1 && nshards <= kMaxEpsShards && shard >= 0 && shard < nshards, FD_ERR_ARG,
+               "shard %d of %d", shard, nshards);
+    FD_REQUIRE(eps_shardable(p), FD_ERR_UNSUPPORTED,
+               "this plan's step-size reduction cannot be sharded (needs 1..8 colours, N > 16384, forward / central)");
+    FD_REQUIRE((((uintptr_t)x_dev) & kPairMask) == 0, FD_ERR_ARG, "x must be 16-byte aligned");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const int S = (p->n_partial_blocks + nshards - 1) / nshards;
+    const int b0 = std::min(shard * S, p->n_partial_blocks), nb = std::min(S, p->n_partial_blocks - b0);
+    if (partials_out) *partials_out = p->d_partial;
+    if (slot_doubles_out) *slot_doubles_out = (int64_t)S * kRegColors;
+    return launch_eps_partial(p, (const real_t *)x_dev, b0, nb);
+}
+
+int fd_plan_eps_finalize(fd_plan *p, double relstep, double absstep, double dir)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(eps_shardable(p), FD_ERR_UNSUPPORTED, "this plan's step-size reduction cannot be sharded");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (!(relstep > 0)) {
+        const real_t e = std::numeric_limits<real_t>::epsilon();
+        relstep = p->fdtype == FD_FORWARD ? (double)std::sqrt(e) : (double)std::cbrt(e);
+    }
+    if (absstep < 0) absstep = relstep;
+    return launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
+}
+
+int fd_plan_set_eps_mode(fd_plan *p, int mode)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(mode == FD_EPS_COMPUTE || mode == FD_EPS_PRECOMPUTED, FD_ERR_ARG, "unknown eps mode %d", mode);
+    FD_REQUIRE(mode == FD_EPS_COMPUTE || eps_shardable(p), FD_ERR_UNSUPPORTED,
+               "this plan's step-size reduction cannot be sharded");
+    p->eps_mode = mode;
     return FD_OK;
 }
 

@@ -1,0 +1,273 @@
+// Multi-GPU exchange steps of the coloured-Jacobian path behind the C ABI (include/fdjac.h, "multi-GPU").
+//
+// One process per GPU.  The reference is single-process, so there is no reference counterpart: this is the
+// north-star's "single RCCL gather over xGMI to assemble nzval" as plain C entry points, so that a Julia
+// process-per-GPU caller (MPI.jl only to ship the 128-byte id) needs neither torch nor a binding of RCCL.
+//
+// RCCL is loaded at run time (dlopen), not linked: libfdjac loads on boxes without RCCL, and inside a host framework
+// that already carries its own librccl (PyTorch bundles one) the SAME library instance is used (RTLD_NOLOAD first),
+// never a second copy with its own state.  Every collective is enqueued on the context's stream; nothing
+// synchronises.  xGMI is point-to-point (7 links per GPU): the assembly calls move each rank's slice exactly once
+// per destination, with no staging copy (in-place all-gather / grouped send-recv straight out of the buffer the
+// decompression kernel wrote).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "fdjac_internal.h"
+
+#ifndef FDJAC_F32   /* element-type independent: compiled once */
+
+struct fd_comm {
+    fd_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+namespace fdjac {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    char where[160] = "";
+};
+
+static Rccl g_rccl;
+static std::mutex g_rccl_mutex;
+
+// returns nullptr (and sets the error text) when RCCL cannot be found
+static const Rccl *rccl()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return &g_rccl;
+    const char *env = getenv("FDJAC_RCCL_LIB");
+    const char *names[] = {env && *env ? env : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    // the instance the process already has (a host framework's), else load one
+    for (const char *n : names)
+        if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) snprintf(g_rccl.where, sizeof(g_rccl.where), "%s (already loaded)", n);
+    for (const char *n : names)
+        if (!h && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) snprintf(g_rccl.where, sizeof(g_rccl.where), "%s", n);
+    if (!h) {
+        set_error("RCCL not found (tried librccl.so.1, librccl.so, /opt/rocm/lib; set FDJAC_RCCL_LIB): %s", dlerror());
+        return nullptr;
+    }
+    Rccl r;
+    r.handle = h;
+    memcpy(r.where, g_rccl.where, sizeof(r.where));
+#define FD_SYM(field, name)                                                     \
+    r.field = (decltype(r.field))dlsym(h, name);                                \
+    if (!r.field) {                                                             \
+        set_error("RCCL symbol %s missing in %s", name, r.where);              \
+        return nullptr;                                                         \
+    }
+    FD_SYM(GetVersion, "ncclGetVersion")
+    FD_SYM(GetUniqueId, "ncclGetUniqueId")
+    FD_SYM(CommInitRank, "ncclCommInitRank")
+    FD_SYM(CommDestroy, "ncclCommDestroy")
+    FD_SYM(GetErrorString, "ncclGetErrorString")
+    FD_SYM(AllGather, "ncclAllGather")
+    FD_SYM(AllReduce, "ncclAllReduce")
+    FD_SYM(Broadcast, "ncclBroadcast")
+    FD_SYM(Send, "ncclSend")
+    FD_SYM(Recv, "ncclRecv")
+    FD_SYM(GroupStart, "ncclGroupStart")
+    FD_SYM(GroupEnd, "ncclGroupEnd")
+#undef FD_SYM
+    g_rccl = r;
+    return &g_rccl;
+}
+
+#define FD_NCCL_CHECK(R, expr)                                                                                  \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != ncclSuccess) {                                                                                \
+            set_error("%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(_r), __FILE__, __LINE__);              \
+            return FD_ERR_COMM;                                                                                 \
+        }                                                                                                       \
+    } while (0)
+
+static bool dtype_of(int elem_bytes, ncclDataType_t *dt)
+{
+    if (elem_bytes == 8) *dt = ncclFloat64;
+    else if (elem_bytes == 4) *dt = ncclFloat32;
+    else if (elem_bytes == 1) *dt = ncclUint8;
+    else return false;
+    return true;
+}
+
+}  // namespace fdjac
+
+using namespace fdjac;
+
+extern "C" {
+
+int fd_comm_unique_id(void *id_out)
+{
+    FD_REQUIRE(id_out != nullptr, FD_ERR_ARG, "id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) == FD_COMM_ID_BYTES, "fd_comm id size");
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    ncclUniqueId id;
+    FD_NCCL_CHECK(R, R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return FD_OK;
+}
+
+int fd_comm_create(fd_ctx *ctx, int nranks, int rank, const void *id, fd_comm **out)
+{
+    FD_REQUIRE(ctx && id && out, FD_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    FD_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, FD_ERR_ARG, "rank %d outside [0,%d)", rank, nranks);
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    fd_comm *c = new (std::nothrow) fd_comm();
+    FD_REQUIRE(c != nullptr, FD_ERR_NOMEM, "out of host memory");
+    c->ctx = ctx;
+    c->nranks = nranks;
+    c->rank = rank;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclResult_t r = R->CommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank(nranks=%d, rank=%d) failed: %s", nranks, rank, R->GetErrorString(r));
+        delete c;
+        return FD_ERR_COMM;
+    }
+    *out = c;
+    return FD_OK;
+}
+
+int fd_comm_destroy(fd_comm *c)
+{
+    if (!c) return FD_OK;
+    const Rccl *R = rccl();
+    if (R && c->comm) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+        (void)R->CommDestroy(c->comm);
+    }
+    delete c;
+    return FD_OK;
+}
+
+int fd_comm_info(const fd_comm *c, int *nranks, int *rank, int *rccl_version)
+{
+    FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    if (rccl_version) {
+        const Rccl *R = rccl();
+        if (!R) return FD_ERR_COMM;
+        FD_NCCL_CHECK(R, R->GetVersion(rccl_version));
+    }
+    return FD_OK;
+}
+
+const char *fd_comm_library(void)
+{
+    const Rccl *R = rccl();
+    return R ? R->where : "";
+}
+
+int fd_comm_allgather(fd_comm *c, void *buf, int64_t slot_elems, int elem_bytes)
+{
+    FD_REQUIRE(c && (buf || slot_elems == 0), FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(slot_elems >= 0, FD_ERR_ARG, "slot_elems < 0");
+    ncclDataType_t dt;
+    FD_REQUIRE(dtype_of(elem_bytes, &dt), FD_ERR_ARG, "elem_bytes must be 1, 4 or 8");
+    if (slot_elems == 0) return FD_OK;   // (a single-rank communicator still goes through RCCL: same call path)
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    // in place: sendbuff == recvbuff + rank * sendcount (ncclAllGather's documented in-place form)
+    char *base = (char *)buf;
+    FD_NCCL_CHECK(R, R->AllGather(base + (size_t)c->rank * (size_t)slot_elems * (size_t)elem_bytes, base, (size_t)slot_elems, dt,
+                                 c->comm, c->ctx->stream));
+    return FD_OK;
+}
+
+int fd_comm_gatherv(fd_comm *c, const void *send, int64_t send_elems, void *recv, const int64_t *counts,
+                    const int64_t *displs, int elem_bytes, int root)
+{
+    FD_REQUIRE(c && counts && displs, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(root >= 0 && root < c->nranks, FD_ERR_ARG, "root %d outside [0,%d)", root, c->nranks);
+    ncclDataType_t dt;
+    FD_REQUIRE(dtype_of(elem_bytes, &dt), FD_ERR_ARG, "elem_bytes must be 1, 4 or 8");
+    FD_REQUIRE(send_elems == counts[c->rank], FD_ERR_ARG, "send_elems %lld != counts[rank] %lld", (long long)send_elems,
+               (long long)counts[c->rank]);
+    FD_REQUIRE(c->rank != root || recv != nullptr, FD_ERR_ARG, "recv is NULL on the root");
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    hipStream_t s = c->ctx->stream;
+    char *rb = (char *)recv;
+    if (c->rank == root && send_elems > 0 && send != (const void *)(rb + (size_t)displs[root] * (size_t)elem_bytes))
+        FD_HIP_CHECK(hipMemcpyAsync(rb + (size_t)displs[root] * (size_t)elem_bytes, send, (size_t)send_elems * (size_t)elem_bytes,
+                                    hipMemcpyDeviceToDevice, s));
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    // one group: every slice rides its own xGMI link into the root (7 concurrent point-to-point transfers at 8 ranks)
+    FD_NCCL_CHECK(R, R->GroupStart());
+    if (c->rank == root) {
+        for (int r = 0; r < c->nranks; ++r)
+            if (r != root && counts[r] > 0)
+                FD_NCCL_CHECK(R, R->Recv(rb + (size_t)displs[r] * (size_t)elem_bytes, (size_t)counts[r], dt, r, c->comm, s));
+    } else if (send_elems > 0) {
+        FD_NCCL_CHECK(R, R->Send(send, (size_t)send_elems, dt, root, c->comm, s));
+    }
+    FD_NCCL_CHECK(R, R->GroupEnd());
+    return FD_OK;
+}
+
+int fd_comm_allreduce_sum(fd_comm *c, void *buf, int64_t n, int elem_bytes)
+{
+    FD_REQUIRE(c && (buf || n == 0), FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (n == 0) return FD_OK;
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    FD_NCCL_CHECK(R, R->AllReduce(buf, buf, (size_t)n, elem_bytes == 8 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm,
+                                 c->ctx->stream));
+    return FD_OK;
+}
+
+int fd_comm_broadcast(fd_comm *c, void *buf, int64_t n, int elem_bytes, int root)
+{
+    FD_REQUIRE(c && (buf || n == 0), FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(root >= 0 && root < c->nranks, FD_ERR_ARG, "root %d outside [0,%d)", root, c->nranks);
+    ncclDataType_t dt;
+    FD_REQUIRE(dtype_of(elem_bytes, &dt), FD_ERR_ARG, "elem_bytes must be 1, 4 or 8");
+    if (n == 0) return FD_OK;
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    FD_NCCL_CHECK(R, R->Broadcast(buf, buf, (size_t)n, dt, root, c->comm, c->ctx->stream));
+    return FD_OK;
+}
+
+}  // extern "C"
+
+// used by the sharded step-size reduction of both element-type builds (fdjac_api.hip); not part of the public ABI
+extern "C" {
+int fdjac_comm_allgather_f64(fd_comm *c, double *buf, int64_t slot_elems) { return fd_comm_allgather(c, buf, slot_elems, 8); }
+int fdjac_comm_nranks(const fd_comm *c) { return c ? c->nranks : 1; }
+int fdjac_comm_rank(const fd_comm *c) { return c ? c->rank : 0; }
+const fd_ctx *fdjac_comm_ctx(const fd_comm *c) { return c ? c->ctx : nullptr; }
+}
+
+#endif /* FDJAC_F32 */

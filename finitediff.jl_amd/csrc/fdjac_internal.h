@@ -27,6 +27,10 @@
 #define fd_plan_set_lazy_f fd32_plan_set_lazy_f
 #define fd_plan_set_lazy_caps fd32_plan_set_lazy_caps
 #define fd_plan_get_epsilons fd32_plan_get_epsilons
+#define fd_plan_set_comm fd32_plan_set_comm
+#define fd_plan_eps_partials fd32_plan_eps_partials
+#define fd_plan_eps_finalize fd32_plan_eps_finalize
+#define fd_plan_set_eps_mode fd32_plan_set_eps_mode
 #define fd_plan_enable_timing fd32_plan_enable_timing
 #define fd_plan_get_timings fd32_plan_get_timings
 #define fd_builtin_f_create fd32_builtin_f_create
@@ -51,6 +55,12 @@
 #include <vector>
 
 #include "fdjac.h"
+
+// communicator internals shared by both element-type builds (fdjac_comm.hip)
+extern "C" int fdjac_comm_allgather_f64(fd_comm *c, double *buf, int64_t slot_elems);
+extern "C" int fdjac_comm_nranks(const fd_comm *c);
+extern "C" int fdjac_comm_rank(const fd_comm *c);
+extern "C" const fd_ctx *fdjac_comm_ctx(const fd_comm *c);
 
 // error text: one thread-local buffer for both instantiations (defined by the Float64 build)
 extern "C" void fdjac_set_error_v(const char *fmt, va_list ap);
@@ -206,6 +216,9 @@ struct fd_plan {
     const fdjac::real_t *fx_batch_row = nullptr;   // f(x) evaluated as one more member of the perturbed batch (small problems)
     fd_f_launch_lazy lazy_fn = nullptr;
     int lazy_caps = 0;             // FD_LAZY_CAP_* of lazy_fn
+    fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
+    int eps_mode = 0;              // FD_EPS_COMPUTE / FD_EPS_PRECOMPUTED
+    int64_t partial_cap = 0;       // doubles allocated behind d_partial
     int64_t fcalls_last = 0;
     double relstep_last = 0, absstep_last = 0;
 

@@ -60,8 +60,13 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
-                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift)
+                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total)
 {
+    // The reduction is defined over a GLOBAL grid of grid_total blocks; this launch runs the blocks
+    // [block_off, block_off + gridDim.x) of it (all of them on one GPU; one shard per rank when the reduction is
+    // sharded across GPUs -- the partial sums are then exchanged and finalized in the same fixed order, so the step
+    // sizes do not depend on how the blocks were distributed).
+    const int64_t gblock = (int64_t)blockIdx.x + block_off;
     double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
@@ -71,11 +76,11 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
     // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u and (stride mod C) per round
     int rc = 0, du = 0, dr = 0;
     if (CYC) {
-        rc = (int)(((int64_t)blockIdx.x * tile + threadIdx.x * 2 + cyc_shift) % cyc_C);
+        rc = (int)((gblock * tile + threadIdx.x * 2 + cyc_shift) % cyc_C);
         du = (kBlock * 2) % cyc_C;
-        dr = (int)((((int64_t)gridDim.x - 1) * tile + (tile - (int64_t)(kEpsU - 1) * kBlock * 2)) % cyc_C);   // last u of a round -> first u of the next
+        dr = (int)((((int64_t)grid_total - 1) * tile + (tile - (int64_t)(kEpsU - 1) * kBlock * 2)) % cyc_C);   // last u of a round -> first u of the next
     }
-    for (int64_t base = (int64_t)blockIdx.x * tile; base < n; base += (int64_t)gridDim.x * tile) {
+    for (int64_t base = gblock * tile; base < n; base += (int64_t)grid_total * tile) {
         r2_t v[kEpsU];
         int c0[kEpsU], c1[kEpsU];
 #pragma unroll
@@ -123,7 +128,7 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) s += red[w][threadIdx.x];
-        partial[(int64_t)blockIdx.x * ldp + threadIdx.x] = s;
+        partial[gblock * ldp + threadIdx.x] = s;
     }
 }
 
@@ -1242,36 +1247,56 @@ static inline int grid_for(int64_t work_items, int per_block, int num_cus)
     return balanced_grid(tiles, cap);
 }
 
+// step-size reduction, register path (C <= kRegColors): blocks [b0, b0 + nb) of the global grid of n_partial_blocks
+template <typename CT>
+static int launch_eps_partial_t(fd_plan *p, const real_t *x, int b0, int nb)
+{
+    hipStream_t s = p->ctx->stream;
+    const int C = (int)p->C;
+    const int ldp = kRegColors, P = p->n_partial_blocks;
+    if (nb <= 0) return FD_OK;
+#define FD_EPS_REG(NCC, CY, NTT)                                                                                \
+    hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nb), dim3(kBlock), 0, s, x,                   \
+                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P)
+#define FD_EPS_REG_V(NCC)                                                                                       \
+    do {                                                                                                        \
+        if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); }     \
+        else { if (p->eps_nt) FD_EPS_REG(NCC, false, true); else FD_EPS_REG(NCC, false, false); }               \
+    } while (0)
+    if (C <= 4) FD_EPS_REG_V(4); else FD_EPS_REG_V(kRegColors);
+#undef FD_EPS_REG_V
+#undef FD_EPS_REG
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int launch_eps_partial(fd_plan *p, const real_t *x, int b0, int nb)
+{
+    return p->color8 ? launch_eps_partial_t<uint8_t>(p, x, b0, nb) : launch_eps_partial_t<int32_t>(p, x, b0, nb);
+}
+
+int launch_eps_finalize(fd_plan *p, int nparts, int ldp, double relstep, double absstep, double dir)
+{
+    hipLaunchKernelGGL(k_eps_finalize, dim3((unsigned)p->C), dim3(kBlock), 0, p->ctx->stream, p->d_partial, nparts, ldp, relstep,
+                       absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
 template <typename CT>
 static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double absstep, double dir)
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
-    int nparts, ldp;
     if (C <= kRegColors) {
-        nparts = p->n_partial_blocks;
-        ldp = kRegColors;
-#define FD_EPS_REG(NCC, CY, NTT)                                                                                \
-        hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nparts), dim3(kBlock), 0, s, x,           \
-                           (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift)
-#define FD_EPS_REG_V(NCC)                                                                                       \
-        do {                                                                                                    \
-            if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); } \
-            else { if (p->eps_nt) FD_EPS_REG(NCC, false, true); else FD_EPS_REG(NCC, false, false); }           \
-        } while (0)
-        if (C <= 4) FD_EPS_REG_V(4); else FD_EPS_REG_V(kRegColors);
-#undef FD_EPS_REG_V
-#undef FD_EPS_REG
-    } else {
-        nparts = p->seg_chunks;
-        ldp = C;
-        hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,
-                           x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial);
+        int rc = launch_eps_partial_t<CT>(p, x, 0, p->n_partial_blocks);
+        if (rc) return rc;
+        return launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
     }
-    hipLaunchKernelGGL(k_eps_finalize, dim3(C), dim3(kBlock), 0, s, p->d_partial, nparts, ldp, relstep,
-                       absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
-    FD_HIP_CHECK(hipGetLastError());
-    return FD_OK;
+    const int nparts = p->seg_chunks;
+    hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,
+                       x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial);
+    return launch_eps_finalize(p, nparts, C, relstep, absstep, dir);
 }
 
 // the fused small-problem launch (k_eps_perturb_small); pmode -1 = step sizes only

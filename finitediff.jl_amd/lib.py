@@ -13,6 +13,9 @@ SO_PATH = os.path.join(_HERE, "lib", "libfdjac.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 FD_OK = 0
+FD_ERR_COMM = 8
+COMM_ID_BYTES = 128
+EPS_COMPUTE, EPS_PRECOMPUTED = 0, 1
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 HOST, DEVICE = 0, 1
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
@@ -58,6 +61,9 @@ EXPORTS = (
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_color_columns_greedy", "fd_color_banded",
+    "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
+    "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
 )
 
 
@@ -69,6 +75,7 @@ TYPED = (
     "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
+    "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -169,11 +176,24 @@ def load():
     L.fd_builtin_f_lazy_caps.argtypes = [vp, C.POINTER(i32)]
     L.fd_jvp_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY_JVP]
     L.fd_builtin_f_lazy_jvp.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY_JVP)]
+    L.fd_comm_unique_id.argtypes = [vp]
+    L.fd_comm_create.argtypes = [vp, i32, i32, vp, pp]
+    L.fd_comm_destroy.argtypes = [vp]
+    L.fd_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.fd_comm_library.restype = C.c_char_p
+    L.fd_comm_allgather.argtypes = [vp, vp, i64, i32]
+    L.fd_comm_gatherv.argtypes = [vp, vp, i64, vp, C.POINTER(i64), C.POINTER(i64), i32, i32]
+    L.fd_comm_allreduce_sum.argtypes = [vp, vp, i64, i32]
+    L.fd_comm_broadcast.argtypes = [vp, vp, i64, i32, i32]
+    L.fd_plan_set_comm.argtypes = [vp, vp]
+    L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]
+    L.fd_plan_eps_finalize.argtypes = [vp, dbl, dbl, dbl]
+    L.fd_plan_set_eps_mode.argtypes = [vp, i32]
     for name in TYPED:   # the Float32 instantiation has the same prototypes (values behind void*, steps stay double)
         getattr(L, "fd32_" + name[3:]).argtypes = getattr(L, name).argtypes
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("fd_last_error", "fd_ctx_stream"):
+        if name not in ("fd_last_error", "fd_ctx_stream", "fd_comm_library"):
             fn.restype = i32
     _lib = L
     return L

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 104
+#define FDJAC_VERSION 200
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -57,7 +57,8 @@ enum fd_status {
     FD_ERR_HIP = 4,         /* HIP runtime failure (message has the hipError string) */
     FD_ERR_CALLBACK = 5,    /* the f! launcher returned non-zero */
     FD_ERR_NOMEM = 6,
-    FD_ERR_NODEVICE = 7     /* no usable gfx950 device */
+    FD_ERR_NODEVICE = 7,    /* no usable gfx950 device */
+    FD_ERR_COMM = 8         /* RCCL failure, or RCCL not available (fd_comm_*) */
 };
 
 enum fd_fdtype { FD_FORWARD = 0, FD_CENTRAL = 1, FD_COMPLEX = 2 }; /* Val(:forward|:central|:complex) */
@@ -305,6 +306,55 @@ int fd_color_columns_greedy(int64_t M, int64_t N, const void *colptr, const void
 /* Closed-form colouring of a band: colorvec[j] = mod1(j, l+u+1) (valid for any matrix inside the band). */
 int fd_color_banded(int64_t N, int64_t l, int64_t u, int64_t *colorvec_out, int64_t *ncolors_out);
 
+/* ---- multi-GPU (one process per GPU): the exchange steps behind the C ABI -------------------------------------------
+ * The reference is single-process; these have no counterpart there.  A plan with a column window
+ * (fd_plan_opts.col_begin/col_end) fills a contiguous slice of nzval / band data; colour ownership
+ * (color_begin/color_end) fills the values of the owned colours.  What remains is ONE exchange, provided here on top of
+ * RCCL (loaded at run time with dlopen -- the instance a host framework already carries if there is one; libfdjac itself
+ * does not link it): every call enqueues on the context's stream and returns.
+ *   bootstrap: rank 0 calls fd_comm_unique_id and ships the FD_COMM_ID_BYTES bytes to the other ranks by whatever the
+ *   host has (MPI.jl, a torch.distributed store, a file); every rank then calls fd_comm_create. */
+typedef struct fd_comm fd_comm;
+#define FD_COMM_ID_BYTES 128
+int fd_comm_unique_id(void *id_out /* FD_COMM_ID_BYTES bytes, host */);
+int fd_comm_create(fd_ctx *ctx, int nranks, int rank, const void *id, fd_comm **out);
+int fd_comm_destroy(fd_comm *comm);
+int fd_comm_info(const fd_comm *comm, int *nranks, int *rank, int *rccl_version);   /* any out pointer may be NULL */
+const char *fd_comm_library(void);   /* which librccl was bound ("" if none could be) */
+/* Assemble the Jacobian from column-range slices, every rank gets all of it: buf holds nranks slots of slot_elems
+   elements, rank r computed its slice into slot r (pass outs[0] = buf + r*slot_elems to fd_jacobian_async); ONE in-place
+   ncclAllGather.  elem_bytes: 8 (Float64), 4 (Float32) or 1. */
+int fd_comm_allgather(fd_comm *comm, void *buf, int64_t slot_elems, int elem_bytes);
+/* Assemble on one rank ("a single RCCL gather ... to assemble nzval"): rank r sends its send_elems == counts[r] values,
+   the root receives slice r at recv + displs[r] (elements) -- one group of point-to-point transfers, each over its own
+   xGMI link.  recv is only read on the root; the root's own slice is copied unless send already points there. */
+int fd_comm_gatherv(fd_comm *comm, const void *send, int64_t send_elems, void *recv, const int64_t *counts,
+                    const int64_t *displs, int elem_bytes, int root);
+/* Assemble outputs computed under colour ownership (they start from zero; every value is non-zero on one rank only,
+   so the sum is exact): in-place ncclAllReduce(sum).  elem_bytes 8 or 4. */
+int fd_comm_allreduce_sum(fd_comm *comm, void *buf, int64_t n, int elem_bytes);
+int fd_comm_broadcast(fd_comm *comm, void *buf, int64_t n, int elem_bytes, int root);   /* e.g. a new x from rank 0 */
+
+/* Sharded step-size reduction.  By default every rank reduces the whole (replicated) x -- no communication, identical
+   step sizes everywhere.  With a communicator attached, rank r reduces only blocks r of nranks of the SAME global grid
+   of partial sums, the partials (a few KB) are all-gathered and finalized in the same fixed order: the step sizes are
+   bit-identical to the unsharded call's, and the serial part of a strong-scaled Jacobian shrinks by nranks (at the
+   price of one small-message collective on the critical path).  comm = NULL detaches.  The communicator must have been
+   created on the plan's context.  Plans whose reduction cannot be sharded (more than 8 colours, N <= 16384, dense arm,
+   complex step: no reduction at all) keep the replicated reduction. */
+int fd_plan_set_comm(fd_plan *plan, fd_comm *comm);
+/* The same reduction in explicit pieces, for callers that exchange the partial sums themselves (MPI.jl, tests):
+   fd_plan_eps_partials enqueues shard `shard` of `nshards` and returns the device address of the partial buffer
+   (nshards slots of *slot_doubles_out doubles; shard r fills slot r); after the exchange fd_plan_eps_finalize turns the
+   complete buffer into step sizes; fd_plan_set_eps_mode(plan, FD_EPS_PRECOMPUTED) makes the following fd_jacobian* calls
+   use them instead of reducing x again (FD_EPS_COMPUTE restores the default).  FD_ERR_UNSUPPORTED for plans whose
+   reduction cannot be sharded. */
+enum fd_eps_mode { FD_EPS_COMPUTE = 0, FD_EPS_PRECOMPUTED = 1 };
+int fd_plan_eps_partials(fd_plan *plan, const void *x_dev, int shard, int nshards, void **partials_out,
+                         int64_t *slot_doubles_out);
+int fd_plan_eps_finalize(fd_plan *plan, double relstep, double absstep, double dir);
+int fd_plan_set_eps_mode(fd_plan *plan, int mode);
+
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */
@@ -355,6 +405,11 @@ int fd32_jacobian_async(fd32_plan *plan, fd_f_launch f, void *fctx, const void *
 int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
+int fd32_plan_set_comm(fd32_plan *plan, fd_comm *comm);
+int fd32_plan_eps_partials(fd32_plan *plan, const void *x_dev, int shard, int nshards, void **partials_out,
+                           int64_t *slot_doubles_out);
+int fd32_plan_eps_finalize(fd32_plan *plan, double relstep, double absstep, double dir);
+int fd32_plan_set_eps_mode(fd32_plan *plan, int mode);
 int fd32_plan_enable_timing(fd32_plan *plan, int on);
 int fd32_plan_get_timings(fd32_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
 int fd32_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,

@@ -48,6 +48,17 @@ typedef double fdo_real;
 typedef double complex cplx;
 #define FDO_EPS 2.220446049250313e-16
 #endif
+/* -DFDO_OMP -fopenmp builds libfd_oracle_omp.so: the same passes with their loops split over the host's cores.  The
+   reference is single-threaded (no Threads / @simd anywhere in src/), so that build is NOT the reference's speed: it is
+   the generous "what a parallel CPU port could reach" upper bound bench.py reports next to the 1-core number
+   (SURVEY 8d).  Its masked norm is an OpenMP reduction (different summation order, eps moves by ulps). */
+#if defined(FDO_OMP) && defined(_OPENMP)
+#define FDO_PAR _Pragma("omp parallel for schedule(static)")
+#define FDO_PAR_SUM(v) _Pragma("omp parallel for schedule(static) reduction(+ : s)")
+#else
+#define FDO_PAR
+#define FDO_PAR_SUM(v)
+#endif
 typedef void (*fdo_f_real)(void *ctx, fdo_real *fx, const fdo_real *x);
 typedef void (*fdo_f_cplx)(void *ctx, cplx *fx, const cplx *x);
 
@@ -62,7 +73,10 @@ enum {
     FDO_PAT_COO_TRIDIAG = 4, /* rows_index/cols_index, Tridiagonal J (dl,d,du) via setindex! */
     FDO_PAT_BANDED = 5,      /* BandedMatrix data (l+u+1) x N (ext/Banded:13-27) */
     FDO_PAT_BLOCKBANDED = 6, /* BlockBandedMatrix flat data + block_starts/strides (ext/BlockBanded:44-68) */
-    FDO_PAT_BANDEDBLOCKBANDED = 7 /* BandedBlockBandedMatrix: per-block banded data (ext/BlockBanded:16-42) */
+    FDO_PAT_BANDEDBLOCKBANDED = 7, /* BandedBlockBandedMatrix: per-block banded data (ext/BlockBanded:16-42) */
+    FDO_PAT_COO_DENSEJ_ACCUM = 8  /* rows_index/cols_index, dense J, the BROADCAST arm taken when x1 has no fast scalar
+                                     indexing (a GPU array): fast_jacobian_setindex!, src/jacobians.jl:574-581,665-671 --
+                                     J[r,c] = J[r,c] + (color[c] == color_i) * vfx[r] over ALL listed entries, every colour */
 };
 
 typedef struct {
@@ -122,6 +136,7 @@ fdo_real fdo_default_relstep(int fdtype)
 static fdo_real norm2(const fdo_real *v, int64_t n)
 {
     fdo_real s = 0.0;
+    FDO_PAR_SUM(s)
     for (int64_t i = 0; i < n; ++i) s += v[i] * v[i];
     return sqrt(s);
 }
@@ -164,6 +179,7 @@ static void colored_iteration(const fdo_pattern *p, const fdo_real *vfx, const i
     const int64_t M = p->M, N = p->N;
     switch (p->kind) {
     case FDO_PAT_CSC_COMMON: /* ext/FiniteDiffSparseArraysExt.jl:38-47 */
+        FDO_PAR
         for (int64_t col = 1; col <= N; ++col)
             if (colorvec[col - 1] == color_i)
                 for (int64_t sp = p->colptr[col - 1]; sp <= p->colptr[col] - 1; ++sp) {
@@ -183,6 +199,15 @@ static void colored_iteration(const fdo_pattern *p, const fdo_real *vfx, const i
         for (int64_t i = 0; i < p->ncoo; ++i)
             if (colorvec[p->cols_index[i] - 1] == color_i)
                 p->out0[(p->rows_index[i] - 1) + M * (p->cols_index[i] - 1)] = vfx[p->rows_index[i] - 1];
+        break;
+    case FDO_PAT_COO_DENSEJ_ACCUM: /* src/jacobians.jl:665-671; Bool * Float64 is Julia's "strong zero":
+                                      false * v == copysign(0.0, v) even for v = NaN / Inf (base/bool.jl) */
+        for (int64_t i = 0; i < p->ncoo; ++i) {
+            const fdo_real v = vfx[p->rows_index[i] - 1];
+            const fdo_real masked = (colorvec[p->cols_index[i] - 1] == color_i) ? v : copysign((fdo_real)0.0, v);
+            fdo_real *dst = &p->out0[(p->rows_index[i] - 1) + M * (p->cols_index[i] - 1)];
+            *dst = *dst + masked;
+        }
         break;
     case FDO_PAT_COO_TRIDIAG: /* src/iteration_utils.jl:25-32 with Tridiagonal setindex! */
         for (int64_t i = 0; i < p->ncoo; ++i)
@@ -298,13 +323,17 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, fdo_
                     pat->out0[r + M * (color_i - 1)] = (fx1[r] - vfx[r]) / epsilon;
                 x1[color_i - 1] = x1_save;
             } else { /* :558-585 */
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (fdo_real)(colorvec[i] == color_i);
                 fdo_real tmp = norm2(x2, N);
                 fdo_real epsilon = eps_forward(sqrt(tmp), relstep, absstep, dir);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
                 f(ctx, fx1, x1); ++nf;
+                FDO_PAR
                 for (int64_t r = 0; r < M; ++r) fx1[r] = (fx1[r] - vfx[r]) / epsilon;
                 colored_iteration(pat, fx1, colorvec, color_i);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
             }
         }
@@ -321,16 +350,22 @@ int fdo_jacobian_cached(int fdtype, fdo_f_real f, fdo_f_cplx fc, void *ctx, fdo_
                     pat->out0[r + M * (color_i - 1)] = (fx1[r] - fx[r]) / (2 * epsilon);
                 x1[color_i - 1] = x_save;
             } else { /* :599-621 */
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x2[i] = x1[i] * (fdo_real)(colorvec[i] == color_i);
                 fdo_real tmp = norm2(x2, N);
                 fdo_real epsilon = eps_central(sqrt(tmp), relstep, absstep);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x[i] = x[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
                 f(ctx, fx1, x1); ++nf;
                 f(ctx, fx, x); ++nf;
+                FDO_PAR
                 for (int64_t r = 0; r < M; ++r) fx1[r] = (fx1[r] - fx[r]) / (2 * epsilon);
                 colored_iteration(pat, fx1, colorvec, color_i);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x1[i] = x1[i] - epsilon * (fdo_real)(colorvec[i] == color_i);
+                FDO_PAR
                 for (int64_t i = 0; i < N; ++i) x[i] = x[i] + epsilon * (fdo_real)(colorvec[i] == color_i);
             }
         }
@@ -435,6 +470,7 @@ void fdo_f_tridiag(void *ctx, fdo_real *dx, const fdo_real *x)
 {
     int64_t n = *(const int64_t *)ctx;
     if (n == 1) { dx[0] = -2 * x[0]; return; }
+    FDO_PAR
     for (int64_t i = 1; i < n - 1; ++i) dx[i] = x[i - 1] - 2 * x[i] + x[i + 1];
     dx[0] = -2 * x[0] + x[1];
     dx[n - 1] = x[n - 2] - 2 * x[n - 1];

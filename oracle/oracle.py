@@ -16,12 +16,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libfd_oracle.so")
 _SO32 = os.path.join(_HERE, "_build", "libfd_oracle32.so")   # the same source with element type float
+_SO_OMP = os.path.join(_HERE, "_build", "libfd_oracle_omp.so")   # the same passes, loops split over the host's cores
 
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
 
 (PAT_NONE, PAT_CSC_COMMON, PAT_CSC_DENSEJ, PAT_COO_DENSEJ, PAT_COO_TRIDIAG, PAT_BANDED,
- PAT_BLOCKBANDED, PAT_BANDEDBLOCKBANDED) = range(8)
+ PAT_BLOCKBANDED, PAT_BANDEDBLOCKBANDED, PAT_COO_DENSEJ_ACCUM) = range(9)
 
 F_REAL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 F_CPLX = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
@@ -71,7 +72,7 @@ class _T:
 def build(force=False):
     """Compile oracle/fd_oracle.c -> oracle/_build/libfd_oracle.so (gcc)."""
     src = os.path.join(_HERE, "fd_oracle.c")
-    stale = [so for so in (_SO, _SO32) if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)]
+    stale = [so for so in (_SO, _SO32, _SO_OMP) if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)]
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -80,11 +81,13 @@ def build(force=False):
 _libs = {}
 
 
-def lib(dtype=np.float64):
+def lib(dtype=np.float64, omp=False):
+    """The oracle for one element type; omp=True: the multi-threaded Float64 build (bench.py's upper-bound line)."""
     T = _T(dtype)
-    if T.f32 not in _libs:
+    key = "omp" if omp else T.f32
+    if key not in _libs:
         build()
-        L = C.CDLL(_SO32 if T.f32 else _SO)
+        L = C.CDLL(_SO_OMP if omp else (_SO32 if T.f32 else _SO))
         _f64p, dbl = T.fp, T.c_real          # noqa: F841  (the prototypes below are written in terms of these)
         L.fdo_jacobian_cached.restype = C.c_int
         L.fdo_jacobian_cached.argtypes = [
@@ -104,8 +107,8 @@ def lib(dtype=np.float64):
                               dbl, dbl, _f64p, _f64p, _f64p, _f64p]
         L.fdo_build_tridiag_csc.restype = None
         L.fdo_build_tridiag_csc.argtypes = [C.c_int64, _i64p, _i64p]
-        _libs[T.f32] = L
-    return _libs[T.f32]
+        _libs[key] = L
+    return _libs[key]
 
 
 def default_relstep(fdtype, dtype=np.float64):
@@ -123,8 +126,8 @@ def _pf(a):
 class Fixture:
     """One of the C fixture f!s: (real fn, complex fn, ctx int64 array)."""
 
-    def __init__(self, name, *ctx, dtype=np.float64):
-        L = lib(dtype)
+    def __init__(self, name, *ctx, dtype=np.float64, omp=False):
+        L = lib(dtype, omp=omp)
         self.dtype = np.dtype(dtype)
         self.name = name
         self.ctx = np.asarray(ctx, dtype=np.int64)
@@ -186,7 +189,7 @@ def tridiag_csc(n):
 def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowval=None,
              rows_index=None, cols_index=None, l=0, u=0, blk_sizes=None, bl=0, bu=0,
              block_starts=None, block_strides=None, out_len=None, lam=0, mu=0, f_in=None, relstep=None,
-             absstep=None, dir=1.0, cache=None, mutate_x=False, dtype=None):
+             absstep=None, dir=1.0, cache=None, mutate_x=False, dtype=None, omp=False, runner=False):
     """Run the cached in-place path.  Returns dict(out=..., fcalls=..., x_after=...).
 
     out: nzval (CSC_COMMON) | dense col-major M x N (NONE / *_DENSEJ) | banded data (l+u+1, N)
@@ -195,7 +198,7 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
     """
     dtype = np.dtype(dtype if dtype is not None else getattr(f, "dtype", np.float64))   # eltype(x): float64 | float32
     T = _T(dtype)
-    L = lib(dtype)
+    L = lib(dtype, omp=omp)
     _pf = T.pf
     fd = FDTYPES[fdtype]
     x = np.array(x, dtype=T.real) if not mutate_x else x
@@ -221,10 +224,10 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
         pat.colptr, pat.rowval = _p64(colptr), _p64(rowval)
         nnz = int(colptr[-1] - 1)
         out0 = np.full(nnz if kind == PAT_CSC_COMMON else M * N, np.nan, T.real)
-    elif kind in (PAT_COO_DENSEJ, PAT_COO_TRIDIAG):
+    elif kind in (PAT_COO_DENSEJ, PAT_COO_TRIDIAG, PAT_COO_DENSEJ_ACCUM):
         rows_index, cols_index = i64(rows_index), i64(cols_index)
         pat.rows_index, pat.cols_index, pat.ncoo = _p64(rows_index), _p64(cols_index), rows_index.size
-        if kind == PAT_COO_DENSEJ:
+        if kind in (PAT_COO_DENSEJ, PAT_COO_DENSEJ_ACCUM):
             out0 = np.full(M * N, np.nan, T.real)
         else:
             out0 = np.full(N, np.nan, T.real)
@@ -255,15 +258,22 @@ def jacobian(fdtype, f, x, colorvec, M=None, *, kind=PAT_NONE, colptr=None, rowv
     fin = None if f_in is None else np.ascontiguousarray(f_in, dtype=T.real)
     fcalls = np.zeros(1, np.int64)
 
-    rc = L.fdo_jacobian_cached(fd, f.f, f.fc, f.ctxp, _pf(x), _pf(x1), _pf(x2), _pf(fx), _pf(fx1),
-                               cx1.ctypes.data_as(C.c_void_p), cfx.ctypes.data_as(C.c_void_p),
-                               _pf(fin), _p64(colorvec), relstep, absstep, float(dir),
-                               C.byref(pat), _p64(fcalls))
+    def call():
+        """One finite_difference_jacobian! with the cache arrays above (JacobianCache reuse): only the C call."""
+        return L.fdo_jacobian_cached(fd, f.f, f.fc, f.ctxp, _pf(x), _pf(x1), _pf(x2), _pf(fx), _pf(fx1),
+                                     cx1.ctypes.data_as(C.c_void_p), cfx.ctypes.data_as(C.c_void_p),
+                                     _pf(fin), _p64(colorvec), relstep, absstep, float(dir),
+                                     C.byref(pat), _p64(fcalls))
+
+    if runner:   # timing harness: (call, output array) with everything allocated once, like a reused JacobianCache
+        call.keep = (keep, x, x1, x2, fx, fx1, cx1, cfx, fin, colorvec, fcalls, pat, out0, out1, out2, f)
+        return call, out0
+    rc = call()
     if rc != 0:
         raise ValueError("fdtype_error")
     if kind == PAT_COO_TRIDIAG:
         out = (out1, out0, out2)
-    elif kind in (PAT_NONE, PAT_CSC_DENSEJ, PAT_COO_DENSEJ):
+    elif kind in (PAT_NONE, PAT_CSC_DENSEJ, PAT_COO_DENSEJ, PAT_COO_DENSEJ_ACCUM):
         out = out0.reshape((M, N), order="F")
     elif kind == PAT_BANDED:
         out = out0.reshape((l + u + 1, N), order="F")

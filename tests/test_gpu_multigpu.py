@@ -1,0 +1,138 @@
+"""The multi-GPU pieces that one GPU can exercise: the RCCL communicator behind the C ABI (a single-rank communicator
+goes through the same RCCL calls), the sharded step-size reduction (shards run one after the other on one device must
+give the bits of the unsharded call), and the column-range + gatherv assembly.  The world_size-2 tests of the host logic
+run on CPU with gloo (tests/test_sharded_gloo.py)."""
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+from finitediff_jl_amd import sharded as S
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def _nan(n):
+    return torch.full((int(n),), float("nan"), dtype=torch.float64, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def comm1():
+    ctx = fd.Context.default()
+    return fd.Comm(ctx, 1, 0, fd.Comm.unique_id())
+
+
+def test_comm_single_rank_goes_through_rccl(comm1):
+    info = comm1.info()
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000 and "rccl" in info["library"]
+    buf = _dev(np.arange(1000.0))
+    want = buf.clone()
+    comm1.allgather(buf, 1000)           # in place, one slot
+    comm1.allreduce_sum(buf)             # sum over one rank
+    comm1.broadcast(buf, root=0)
+    send = _dev(np.arange(77.0) + 0.5)
+    recv = _nan(77)
+    comm1.gatherv(send, recv, [77], root=0)
+    comm1.ctx.synchronize()
+    assert torch.equal(buf, want) and torch.equal(recv, send)
+    f32 = torch.arange(64, dtype=torch.float32, device="cuda")
+    comm1.allreduce_sum(f32)
+    comm1.ctx.synchronize()
+    assert torch.equal(f32, torch.arange(64, dtype=torch.float32, device="cuda"))
+    with pytest.raises(fd.lib.FdError):
+        comm1.gatherv(send, recv, [76], root=0)      # counts[rank] must match the send length
+    with pytest.raises(fd.lib.FdError):
+        fd.Comm(comm1.ctx, 2, 5, fd.Comm.unique_id())  # rank outside the communicator
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("C,N", [(3, 10 ** 6 + 7), (5, 300001), (8, 123456)])
+def test_sharded_step_size_reduction_bit_identical(fdtype, C, N):
+    # fd_plan_eps_partials shard by shard (what each rank of a W-rank job runs), fd_plan_eps_finalize, FD_EPS_PRECOMPUTED:
+    # the step sizes and the Jacobian have the bits of the plain call, whatever W is
+    colors = P.cyclic_colors(N, C)
+    if C == 5:
+        colors = colors.copy()
+        colors[[10, N // 3]] = 0          # not cyclic any more: the reduction reads the colours
+    xh = np.random.default_rng(7 + C).random(N) * 2 - 0.5
+    x = _dev(xh)
+    colptr, rowval = P.banded_csc(N, N, C // 2, C - 1 - C // 2)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    fn = fd.TorchF(lambda fx, xx: fx.copy_(torch.sin(xx) + torch.roll(xx, 1) * xx), N, N)
+    ref_plan = fd.make_plan(J, J, colors, fdtype)
+    ref = _nan(ref_plan.out_len(0))
+    ref_plan.jacobian(fn, x, [ref])
+    eps_ref = ref_plan.epsilons()
+    for W in (1, 2, 3, 8):
+        plan = fd.make_plan(J, J, colors, fdtype)
+        for r in reversed(range(W)):       # any order: the slots are disjoint
+            ptr, slot = plan.eps_partials(x, r, W)
+            assert ptr and slot % 8 == 0
+        plan.eps_finalize()
+        plan.set_eps_mode(True)
+        out = _nan(plan.out_len(0))
+        plan.jacobian(fn, x, [out])
+        assert np.array_equal(plan.epsilons(), eps_ref), W
+        assert torch.equal(out, ref), W
+        plan.set_eps_mode(False)
+        out.fill_(float("nan"))
+        plan.jacobian(fn, x, [out])
+        assert torch.equal(out, ref)
+
+
+def test_plan_with_communicator_matches_plain_call(comm1):
+    # fd_plan_set_comm: partial sums of this rank's blocks -> in-place all-gather -> the same finalize
+    N = 2 * 10 ** 6 + 1
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    x = _dev(np.random.default_rng(3).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    outs = []
+    for with_comm in (False, True):
+        plan = fd.make_plan(J, J, colors, "forward")
+        plan.set_lazy(f)
+        if with_comm:
+            plan.set_comm(comm1)
+        out = _nan(plan.out_len(0))
+        plan.jacobian(f, x, [out])
+        outs.append((out, plan.epsilons()))
+        if with_comm:
+            plan.set_comm(None)
+    assert torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # plans whose reduction cannot be sharded say so
+    small = fd.make_plan(fd.SparseMatrixCSC(30, 30, *P.tridiag_csc(30)), fd.SparseMatrixCSC(30, 30, *P.tridiag_csc(30)),
+                         P.cyclic_colors(30, 3), "forward")
+    with pytest.raises(fd.lib.FdError) as e:
+        small.eps_partials(_dev(np.ones(30)), 0, 2)
+    assert e.value.code == 3   # FD_ERR_UNSUPPORTED
+
+
+def test_column_ranges_and_gatherv_assemble_the_jacobian(comm1):
+    # the data path of `bench.py --gpus W`, all W column ranges on one device: each range's plan fills its slice, the
+    # slices are assembled with fd_comm_gatherv (counts / displs as the W-rank job computes them); bits of the full call
+    N, W = 300007, 4
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+    pat = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    x = _dev(np.random.default_rng(5).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    full = _nan(rowval.size)
+    fd.make_plan(pat, pat, colors, "forward").jacobian(f, x, [full])
+    cuts = S.partition_columns(colptr, W)
+    ranges = S.entry_ranges(colptr, cuts)
+    assembled = _nan(rowval.size)
+    for r in range(W):
+        plan = fd.make_plan(pat, pat, colors, "forward", col_window=(int(cuts[r]), int(cuts[r + 1])),
+                            x_window=S.x_window(cuts, r, N, 1, 1, 1))
+        a, b = ranges[r]
+        piece = _nan(b - a)
+        plan.jacobian(f, x, [piece])
+        comm1.gatherv(piece, assembled[a:b], [b - a], root=0)    # this rank's slice lands at its displacement
+    comm1.ctx.synchronize()
+    assert torch.equal(assembled, full)
