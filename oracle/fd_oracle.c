@@ -53,9 +53,14 @@ typedef double complex cplx;
    the generous "what a parallel CPU port could reach" upper bound bench.py reports next to the 1-core number
    (SURVEY 8d).  Its masked norm is an OpenMP reduction (different summation order, eps moves by ulps). */
 #if defined(FDO_OMP) && defined(_OPENMP)
+#include <omp.h>
+void fdo_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int fdo_max_threads(void) { return omp_get_max_threads(); }
 #define FDO_PAR _Pragma("omp parallel for schedule(static)")
 #define FDO_PAR_SUM(v) _Pragma("omp parallel for schedule(static) reduction(+ : s)")
 #else
+void fdo_set_num_threads(int n) { (void)n; }
+int fdo_max_threads(void) { return 1; }
 #define FDO_PAR
 #define FDO_PAR_SUM(v)
 #endif

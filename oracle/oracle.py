@@ -111,6 +111,15 @@ def lib(dtype=np.float64, omp=False):
     return _libs[key]
 
 
+def set_omp_threads(n):
+    """Threads of the multi-threaded build (lib(omp=True)); the serial builds ignore it."""
+    L = lib(omp=True)
+    L.fdo_set_num_threads.argtypes = [C.c_int]
+    L.fdo_set_num_threads(int(n))
+    L.fdo_max_threads.restype = C.c_int
+    return int(L.fdo_max_threads())
+
+
 def default_relstep(fdtype, dtype=np.float64):
     return float(lib(dtype).fdo_default_relstep(FDTYPES[fdtype]))
 
