@@ -1,0 +1,542 @@
+/*
+ * Plain-C clients of libfdjac, ONE PER METHOD of the Julia shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl): each
+ * function below performs exactly the foreign calls of the shim method named in its comment, with Julia-layout
+ * arrays (1-based Int64 colptr / rowval / colorvec, column-major matrices) and -- as the shim's AMDGPU.jl methods do
+ * -- DEVICE pointers for x and J's storage, on the caller's own stream, through fd_jacobian_async.  Julia is not
+ * installed in the build image; these clients are what executes the shim's call sequences on the GPU box
+ * (tests/test_gpu_edge.py::test_c_clients_every_plan_kind).
+ *
+ * No HIP headers: like a Julia process, the client reaches the HIP runtime through its C entry points only.
+ *
+ *   gcc -O2 -Iinclude examples/c_abi_clients.c -o c_abi_clients -Lfinitediff.jl_amd/lib -lfdjac \
+ *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/finitediff.jl_amd/lib -Wl,-rpath,/opt/rocm/lib
+ *   ./c_abi_clients all        # or: csc csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp host
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fdjac.h"
+
+/* the five HIP runtime entry points a host language binds (AMDGPU.jl: Mem.alloc, copyto!, HIPStream, synchronize) */
+extern int hipMalloc(void **ptr, size_t size);
+extern int hipFree(void *ptr);
+extern int hipMemcpy(void *dst, const void *src, size_t size, int kind); /* 1 = host->device, 2 = device->host */
+extern int hipStreamCreate(void **stream);
+extern int hipStreamSynchronize(void *stream);
+extern int hipStreamDestroy(void *stream);
+extern int hipMemset(void *dst, int value, size_t size);
+
+#define CHECK(call)                                                                                \
+    do {                                                                                           \
+        int rc_ = (call);                                                                          \
+        if (rc_ != 0) {                                                                            \
+            fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #call, rc_, fd_last_error()); \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+static void *g_stream = NULL;   /* the caller's stream: every plan is created on a context bound to it */
+static fd_ctx *g_ctx = NULL;
+
+static void *to_dev(const void *h, size_t bytes)
+{
+    void *d = NULL;
+    if (hipMalloc(&d, bytes ? bytes : 16) != 0) return NULL;
+    if (h && bytes) hipMemcpy(d, h, bytes, 1);
+    return d;
+}
+static double *dev_nan(size_t n)
+{
+    double *h = malloc(sizeof(double) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) h[i] = NAN;
+    double *d = to_dev(h, sizeof(double) * n);
+    free(h);
+    return d;
+}
+static void from_dev(void *h, const void *d, size_t bytes) { hipMemcpy(h, d, bytes, 2); }
+
+static double *make_x(int64_t N)
+{
+    double *x = malloc(sizeof(double) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) x[j] = 0.5 + 0.25 * sin((double)(j + 1));
+    return x;
+}
+static int64_t *cyclic_colors(int64_t N, int64_t C)
+{
+    int64_t *c = malloc(sizeof(int64_t) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) c[j] = j % C + 1;   /* mod1(j, C) */
+    return c;
+}
+/* sparse(Tridiagonal(...)) pattern as Julia stores it */
+static void tridiag_csc(int64_t N, int64_t **colptr, int64_t **rowval)
+{
+    *colptr = malloc(sizeof(int64_t) * (size_t)(N + 1));
+    *rowval = malloc(sizeof(int64_t) * (size_t)(3 * N));
+    int64_t p = 0;
+    for (int64_t j = 1; j <= N; ++j) {
+        (*colptr)[j - 1] = p + 1;
+        for (int64_t r = j - 1; r <= j + 1; ++r)
+            if (r >= 1 && r <= N) (*rowval)[p++] = r;
+    }
+    (*colptr)[N] = p + 1;
+}
+/* analytic Jacobian of the tridiag_nl fixture, f_i = x[i-1] - 2x[i] + x[i+1] + x[i]^2 x[i+1] (0-based r, c) */
+static double tridiag_nl_J(const double *x, int64_t N, int64_t r, int64_t c)
+{
+    const double xp = r + 1 < N ? x[r + 1] : 0.0;
+    if (r == c) return -2.0 + 2.0 * x[r] * xp;
+    if (c == r + 1) return 1.0 + x[r] * x[r];
+    if (c + 1 == r) return 1.0;
+    return 0.0;
+}
+static int report(const char *name, double worst, double tol, int64_t fcalls, int64_t want_calls)
+{
+    const int ok = worst <= tol && fcalls == want_calls;
+    printf("%-12s max|J - analytic| = %.3e (tol %.1e)  f!_evaluations = %lld (expected %lld)  %s\n", name, worst, tol,
+           (long long)fcalls, (long long)want_calls, ok ? "ok" : "FAILED");
+    return ok ? 0 : 3;
+}
+static int new_f(int family, const int64_t *prm, int nprm, fd_f_launch *f, void **fctx)
+{
+    return fd_builtin_f_create(g_ctx, family, prm, nprm, f, fctx);
+}
+static int64_t f_points(void *fctx)
+{
+    int64_t l = 0, p = 0;
+    fd_builtin_f_counts(fctx, &l, &p);
+    return p;
+}
+/* install_lazy!(plan, f) of the shim */
+static int install_lazy(fd_plan *plan, void *fctx)
+{
+    fd_f_launch_lazy lz = NULL;
+    int caps = 0;
+    if (fd_builtin_f_lazy(fctx, &lz) != FD_OK) return 0;
+    if (fd_plan_set_lazy_f(plan, lz) != FD_OK) return 1;
+    fd_builtin_f_lazy_caps(fctx, &caps);
+    return fd_plan_set_lazy_caps(plan, caps);
+}
+
+/* shim: make_plan(::SparseMatrixCSC J, ::SparseMatrixCSC sparsity) -> fd_plan_create_csc;
+         finite_difference_jacobian!(J::ROCSparseMatrixCSC, f::DeviceF, x::ROCVector, cache) -> fd_jacobian_async */
+static int client_csc(int fdtype)
+{
+    const int64_t N = 100003;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)nnz);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const double d = fabs(nz[p] - tridiag_nl_J(x, N, rowval[p] - 1, j));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(colptr); free(rowval); free(colors);
+    const char *nm = fdtype == FD_FORWARD ? "csc/forward" : fdtype == FD_CENTRAL ? "csc/central" : "csc/complex";
+    return report(nm, worst, fdtype == FD_FORWARD ? 2e-6 : fdtype == FD_CENTRAL ? 2e-8 : 1e-13, calls,
+                  fdtype == FD_FORWARD ? 4 : fdtype == FD_CENTRAL ? 6 : 3);
+}
+
+/* shim: make_plan(::Matrix J, ::SparseMatrixCSC sparsity) -> fd_plan_create_csc_dense (ext/FiniteDiffSparseArraysExt.jl:20-28) */
+static int client_csc_dense(void)
+{
+    const int64_t N = 300;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *Jd = dev_nan((size_t)(N * N));
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_CENTRAL;
+    CHECK(fd_plan_create_csc_dense(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    void *outs[3] = {Jd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *J = malloc(sizeof(double) * (size_t)(N * N));
+    from_dev(J, Jd, sizeof(double) * (size_t)(N * N));
+    double worst = 0;
+    for (int64_t c = 0; c < N; ++c)
+        for (int64_t r = 0; r < N; ++r) {   /* entries outside the pattern are zero: fill_matrix!(J, false) */
+            const double d = fabs(J[r + N * c] - tridiag_nl_J(x, N, r, c));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(Jd); free(J); free(x); free(colptr); free(rowval); free(colors);
+    return report("csc_dense", worst, 2e-8, calls, 6);
+}
+
+/* shim: make_plan(::Matrix J, ::DenseMatrix sparsity) -> FiniteDiff._findstructralnz + fd_plan_create_coo_dense
+   (src/jacobians.jl:473-488, src/iteration_utils.jl:25-32) */
+static int client_coo_dense(void)
+{
+    const int64_t N = 200;
+    int64_t *rows = malloc(sizeof(int64_t) * (size_t)(3 * N)), *cols = malloc(sizeof(int64_t) * (size_t)(3 * N));
+    int64_t nnz = 0, *colors = cyclic_colors(N, 3);
+    for (int64_t j = 1; j <= N; ++j)            /* column-major scan of the dense 0/1 pattern matrix */
+        for (int64_t i = 1; i <= N; ++i)
+            if (i >= j - 1 && i <= j + 1) { rows[nnz] = i; cols[nnz] = j; ++nnz; }
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *Jd = dev_nan((size_t)(N * N));
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_COMPLEX;
+    CHECK(fd_plan_create_coo_dense(g_ctx, N, N, rows, cols, nnz, 8, 1, colors, 8, &o, &plan));
+    void *outs[3] = {Jd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *J = malloc(sizeof(double) * (size_t)(N * N));
+    from_dev(J, Jd, sizeof(double) * (size_t)(N * N));
+    double worst = 0;
+    for (int64_t c = 0; c < N; ++c)
+        for (int64_t r = 0; r < N; ++r) {
+            const double d = fabs(J[r + N * c] - tridiag_nl_J(x, N, r, c));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(Jd); free(J); free(x); free(rows); free(cols); free(colors);
+    return report("coo_dense", worst, 1e-13, calls, 3);
+}
+
+/* shim: make_plan_entries(J::SparseMatrixCSC, sparsity::SparseMatrixCSC) -- J stores MORE entries than the pattern
+   (a pentadiagonal J, a tridiagonal sparsity): (row, col, position in J.nzval) enumerated once, fd_plan_create_entries
+   (ext/FiniteDiffSparseArraysExt.jl:20-28 through J's setindex!) */
+static int client_entries(void)
+{
+    const int64_t N = 5000;
+    int64_t *scolptr, *srowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &scolptr, &srowval);
+    /* J: pentadiagonal CSC */
+    int64_t *jcolptr = malloc(sizeof(int64_t) * (size_t)(N + 1)), *jrowval = malloc(sizeof(int64_t) * (size_t)(5 * N));
+    int64_t q = 0;
+    for (int64_t j = 1; j <= N; ++j) {
+        jcolptr[j - 1] = q + 1;
+        for (int64_t r = j - 2; r <= j + 2; ++r) if (r >= 1 && r <= N) jrowval[q++] = r;
+    }
+    jcolptr[N] = q + 1;
+    const int64_t jnnz = q, snnz = scolptr[N] - 1;
+    int64_t *rows = malloc(sizeof(int64_t) * (size_t)snnz), *cols = malloc(sizeof(int64_t) * (size_t)snnz), *dest = malloc(sizeof(int64_t) * (size_t)snnz);
+    for (int64_t j = 1, k = 0; j <= N; ++j)
+        for (int64_t p = scolptr[j - 1]; p < scolptr[j]; ++p, ++k) {
+            rows[k] = srowval[p - 1]; cols[k] = j;
+            int64_t pos = -1;                           /* searchsortedfirst in J's column */
+            for (int64_t t = jcolptr[j - 1]; t < jcolptr[j]; ++t) if (jrowval[t - 1] == rows[k]) pos = t - 1;
+            dest[k] = pos;
+        }
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)jnnz);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_entries(g_ctx, N, N, rows, cols, dest, snnz, jnnz, 8, 1, colors, 8, &o, &plan));
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * (size_t)jnnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)jnnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = jcolptr[j] - 1; p < jcolptr[j + 1] - 1; ++p) {   /* stored entries outside the pattern: 0 */
+            const double d = fabs(nz[p] - tridiag_nl_J(x, N, jrowval[p] - 1, j));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(scolptr); free(srowval); free(jcolptr); free(jrowval); free(rows); free(cols); free(dest); free(colors);
+    return report("entries", worst, 2e-6, calls, 4);
+}
+
+/* shim: make_plan(::Matrix J, ::Nothing) -> fd_plan_create_dense: the `sparsity === nothing` arm with its per-element
+   step (src/jacobians.jl:548-557); colorvec = 1:N */
+static int client_dense(void)
+{
+    const int64_t N = 257;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *Jd = dev_nan((size_t)(N * N));
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_dense(g_ctx, N, N, N /* maximum(colorvec) */, &o, &plan));
+    void *outs[3] = {Jd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *J = malloc(sizeof(double) * (size_t)(N * N)), *eps = malloc(sizeof(double) * (size_t)N);
+    from_dev(J, Jd, sizeof(double) * (size_t)(N * N));
+    CHECK(fd_plan_get_epsilons(plan, eps));
+    double worst = 0, eworst = 0;
+    const double rel = sqrt(2.220446049250313e-16);
+    for (int64_t c = 0; c < N; ++c) {
+        const double want = fmax(rel * fabs(x[c]), rel);       /* compute_epsilon(Val(:forward), x[c], relstep, absstep, dir) */
+        eworst = fmax(eworst, fabs(eps[c] - want) / want);
+        for (int64_t r = 0; r < N; ++r) {
+            const double d = fabs(J[r + N * c] - tridiag_nl_J(x, N, r, c));
+            if (!(d <= worst)) worst = d;
+        }
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(Jd); free(J); free(eps); free(x);
+    if (eworst > 1e-15) { printf("dense: per-element step sizes off by %.3e\n", eworst); return 3; }
+    return report("dense", worst, 2e-6, calls, N + 1);
+}
+
+/* shim: make_plan(::Tridiagonal J) -> fd_plan_create_tridiagonal; outs = (dl, d, du) */
+static int client_tridiagonal(void)
+{
+    const int64_t N = 100001;
+    int64_t *colors = cyclic_colors(N, 3);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N);
+    double *dl = dev_nan((size_t)(N - 1)), *d = dev_nan((size_t)N), *du = dev_nan((size_t)(N - 1));
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_CENTRAL;
+    CHECK(fd_plan_create_tridiagonal(g_ctx, N, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {dl, d, du};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *h = malloc(sizeof(double) * (size_t)(3 * N));
+    from_dev(h, dl, sizeof(double) * (size_t)(N - 1)); from_dev(h + N, d, sizeof(double) * (size_t)N); from_dev(h + 2 * N, du, sizeof(double) * (size_t)(N - 1));
+    double worst = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        double e = fabs(h[N + i] - tridiag_nl_J(x, N, i, i));
+        if (i + 1 < N) { e = fmax(e, fabs(h[i] - tridiag_nl_J(x, N, i + 1, i))); e = fmax(e, fabs(h[2 * N + i] - tridiag_nl_J(x, N, i, i + 1))); }
+        if (!(e <= worst)) worst = e;
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(dl); hipFree(d); hipFree(du); free(h); free(x); free(colors);
+    return report("tridiagonal", worst, 2e-8, calls, 6);
+}
+
+/* shim (BandedMatrices extension): make_plan(::BandedMatrix J) -> fd_plan_create_banded; outs = (bandeddata(J),)
+   (ext/FiniteDiffBandedMatricesExt.jl:13-27) */
+static int client_banded(void)
+{
+    const int64_t N = 60001, l = 1, u = 1, w = l + u + 1;
+    int64_t *colors = malloc(sizeof(int64_t) * (size_t)N), nc = 0;
+    CHECK(fd_color_banded(N, l, u, colors, &nc));     /* matrix_colors(::BandedMatrix) */
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *dd = dev_nan((size_t)(w * N));
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_banded(g_ctx, N, N, l, u, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {dd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *data = malloc(sizeof(double) * (size_t)(w * N));
+    from_dev(data, dd, sizeof(double) * (size_t)(w * N));
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t k = 0; k < w; ++k) {                /* data[u + i - j + 1, j] = J[i, j]; slots outside the matrix: 0 */
+            const int64_t i = j - u + k;
+            const double want = (i >= 0 && i < N) ? tridiag_nl_J(x, N, i, j) : 0.0;
+            const double e = fabs(data[k + w * j] - want);
+            if (!(e <= worst)) worst = e;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(dd); free(data); free(x); free(colors);
+    return (nc == 3 ? 0 : 3) | report("banded", worst, 2e-6, calls, 4);
+}
+
+/* shim (BlockBandedMatrices extension): make_plan(::BlockBandedMatrix J) -> fd_plan_create_blockbanded with
+   blocklengths / block_starts / block_strides as BlockSkylineSizes holds them; outs = (J.data,)
+   (ext/FiniteDiffBlockBandedMatricesExt.jl:44-68).  f = block-coupled family, complex step. */
+static int client_blockbanded(void)
+{
+    const int64_t nb = 300, bs = 8, N = nb * bs, bl = 1, bu = 1, w = bl + bu + 1;
+    int64_t *sizes = malloc(sizeof(int64_t) * (size_t)nb), *starts = calloc((size_t)(w * nb), sizeof(int64_t)), *strides = malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *colors = malloc(sizeof(int64_t) * (size_t)N);
+    int64_t off = 1;
+    for (int64_t J = 0; J < nb; ++J) {
+        sizes[J] = bs;
+        const int64_t K0 = J - bu > 0 ? J - bu : 0, K1 = J + bl < nb - 1 ? J + bl : nb - 1;
+        strides[J] = (K1 - K0 + 1) * bs;
+        int64_t o = off;
+        for (int64_t K = K0; K <= K1; ++K) { starts[(bu + K - J) + w * J] = o; o += bs; }
+        off += strides[J] * bs;
+        for (int64_t j = 0; j < bs; ++j) colors[J * bs + j] = bs * (J % w) + j + 1;
+    }
+    const int64_t len = off - 1;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *dd = dev_nan((size_t)len);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[2] = {nb, bs};
+    CHECK(new_f(FD_F_BLOCKCOUPLED, prm, 2, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_COMPLEX;
+    CHECK(fd_plan_create_blockbanded(g_ctx, nb, sizes, bl, bu, starts, strides, 8, 1, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {dd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *data = malloc(sizeof(double) * (size_t)len);
+    from_dev(data, dd, sizeof(double) * (size_t)len);
+    /* f_b[k] = x_b[k]*(sig_{b-1} + sig_b + sig_{b+1}) + sin(x_b[k]), sig_b = sum_j w_j x_b[j], w_j = (j+1)/bs:
+       dF[b,k]/dx[c,j] = x_b[k]*w_j (|b-c| <= 1)  +  (b==c && k==j) * (S_b + cos(x_b[k])) */
+    double *sig = calloc((size_t)nb, sizeof(double));
+    for (int64_t b = 0; b < nb; ++b) for (int64_t j = 0; j < bs; ++j) sig[b] += (double)(j + 1) / bs * x[b * bs + j];
+    double worst = 0;
+    for (int64_t J = 0; J < nb; ++J) {
+        const int64_t K0 = J - bu > 0 ? J - bu : 0, K1 = J + bl < nb - 1 ? J + bl : nb - 1;
+        for (int64_t j = 0; j < bs; ++j)
+            for (int64_t K = K0; K <= K1; ++K)
+                for (int64_t k = 0; k < bs; ++k) {
+                    const double S = (K > 0 ? sig[K - 1] : 0) + sig[K] + (K + 1 < nb ? sig[K + 1] : 0);
+                    double want = x[K * bs + k] * (double)(j + 1) / bs;
+                    if (K == J && k == j) want += S + cos(x[K * bs + k]);
+                    const double got = data[starts[(bu + K - J) + w * J] - 1 + j * strides[J] + k];
+                    const double e = fabs(got - want) / fmax(1.0, fabs(want));
+                    if (!(e <= worst)) worst = e;
+                }
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(dd); free(data); free(sig); free(x); free(sizes); free(starts); free(strides); free(colors);
+    return report("blockbanded", worst, 1e-12, calls, 3 * bs);
+}
+
+/* shim: the Float32 methods generated by the eltype loop: x::ROCVector{Float32} -> the fd32_* symbols */
+static int client_csc_f32(void)
+{
+    const int64_t N = 50001;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    float *x = malloc(sizeof(float) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) x[j] = 0.5f + 0.25f * sinf((float)(j + 1));
+    float *xd = to_dev(x, sizeof(float) * (size_t)N);
+    float *nzd = NULL; hipMalloc((void **)&nzd, sizeof(float) * (size_t)nnz); hipMemset(nzd, 0xFF, sizeof(float) * (size_t)nnz);
+    fd_f_launch f; void *fctx; fd32_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(fd32_builtin_f_create(g_ctx, FD_F_TRIDIAG, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_CENTRAL;
+    CHECK(fd32_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd32_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    float *nz = malloc(sizeof(float) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(float) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const double e = fabs((double)nz[p] - (rowval[p] - 1 == j ? -2.0 : 1.0));   /* linear fixture: the exact stencil */
+            if (!(e <= worst)) worst = e;
+        }
+    int64_t l = 0, pts = 0;
+    fd32_builtin_f_counts(fctx, &l, &pts);
+    CHECK(fd32_plan_destroy(plan)); CHECK(fd32_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(colptr); free(rowval); free(colors);
+    return report("csc_f32", worst, 2e-3, pts, 6);
+}
+
+/* shim: finite_difference_jvp!(jvp::ROCVector, f::DeviceF, x, v, cache::JVPCache) -> fd_jvp_async (src/jvp.jl:238-274) */
+static int client_jvp(void)
+{
+    const int64_t N = 200000;
+    double *x = make_x(N), *v = malloc(sizeof(double) * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) v[j] = cos(0.37 * (double)j);
+    double *xd = to_dev(x, sizeof(double) * (size_t)N), *vd = to_dev(v, sizeof(double) * (size_t)N), *od = dev_nan((size_t)N);
+    fd_f_launch f; void *fctx; fd_jvp_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    CHECK(fd_jvp_plan_create(g_ctx, N, N, FD_CENTRAL, &plan));
+    fd_f_launch_lazy_jvp lz = NULL;
+    if (fd_builtin_f_lazy_jvp(fctx, &lz) == FD_OK) CHECK(fd_jvp_plan_set_lazy_f(plan, lz));
+    CHECK(fd_jvp_async(plan, f, fctx, xd, vd, NULL, -1.0, -1.0, 1.0, od));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *out = malloc(sizeof(double) * (size_t)N);
+    from_dev(out, od, sizeof(double) * (size_t)N);
+    double worst = 0;
+    for (int64_t r = 0; r < N; ++r) {
+        double want = tridiag_nl_J(x, N, r, r) * v[r];
+        if (r > 0) want += tridiag_nl_J(x, N, r, r - 1) * v[r - 1];
+        if (r + 1 < N) want += tridiag_nl_J(x, N, r, r + 1) * v[r + 1];
+        const double e = fabs(out[r] - want);
+        if (!(e <= worst)) worst = e;
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_jvp_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(vd); hipFree(od); free(out); free(x); free(v);
+    return report("jvp", worst, 1e-6, calls, 2);
+}
+
+/* shim: the host-array method (x::Vector{Float64}, J::SparseMatrixCSC on the host) -> fd_jacobian with FD_HOST */
+static int client_host(void)
+{
+    const int64_t N = 4001;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    double *x = make_x(N), *nz = malloc(sizeof(double) * (size_t)nnz), *fin = malloc(sizeof(double) * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) {               /* f_in = f(x), computed by the caller (src/jacobians.jl:540-545) */
+        const double xm = i > 0 ? x[i - 1] : 0.0, xp = i + 1 < N ? x[i + 1] : 0.0;
+        fin[i] = ((xm - 2 * x[i]) + xp) + (x[i] * x[i]) * xp;
+    }
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    void *outs[3] = {nz, NULL, NULL};
+    CHECK(fd_jacobian(plan, f, fctx, x, FD_HOST, fin, FD_HOST, -1.0, -1.0, 1.0, outs, FD_HOST));
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const double d = fabs(nz[p] - tridiag_nl_J(x, N, rowval[p] - 1, j));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    free(nz); free(fin); free(x); free(colptr); free(rowval); free(colors);
+    return report("host+f_in", worst, 2e-6, calls, 3);   /* f_in given: 3 evaluations, not 4 */
+}
+
+int main(int argc, char **argv)
+{
+    const char *which = argc > 1 ? argv[1] : "all";
+    if (hipStreamCreate(&g_stream) != 0) {
+        /* no device: say so through the library's own status (FD_ERR_NODEVICE), as the shim would */
+        int rc = fd_ctx_create(0, NULL, &g_ctx);
+        fprintf(stderr, "fd_ctx_create -> %d: %s\n", rc, fd_last_error());
+        return rc == FD_OK ? 1 : rc;
+    }
+    CHECK(fd_ctx_create(0, g_stream, &g_ctx));      /* Context(device; stream = AMDGPU.stream()) */
+    int bad = 0, ran = 0;
+#define RUN(name, call) if (!strcmp(which, "all") || !strcmp(which, name)) { bad |= (call); ++ran; }
+    RUN("csc", client_csc(FD_FORWARD) | client_csc(FD_CENTRAL) | client_csc(FD_COMPLEX))
+    RUN("csc_dense", client_csc_dense())
+    RUN("coo_dense", client_coo_dense())
+    RUN("entries", client_entries())
+    RUN("dense", client_dense())
+    RUN("tridiagonal", client_tridiagonal())
+    RUN("banded", client_banded())
+    RUN("blockbanded", client_blockbanded())
+    RUN("csc_f32", client_csc_f32())
+    RUN("jvp", client_jvp())
+    RUN("host", client_host())
+    CHECK(fd_ctx_destroy(g_ctx));
+    hipStreamDestroy(g_stream);
+    if (!ran) { fprintf(stderr, "unknown client %s\n", which); return 2; }
+    printf("%s\n", bad ? "SOME CLIENTS FAILED" : "all clients ok");
+    return bad ? 3 : 0;
+}

@@ -135,3 +135,19 @@ def test_plain_c_client_builds_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is present: the run itself is a -m gpu test")
     out = subprocess.run([exe, "30"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "no HIP device" in out.stderr
+
+
+def test_c_clients_build_and_fail_loudly_without_gpu(tmp_path):
+    # examples/c_abi_clients.c (one client per Julia shim method, device pointers through the ABI) links with plain gcc
+    # against libfdjac + the HIP runtime's C entry points; without a GPU it reports FD_ERR_NODEVICE and runs nothing
+    import subprocess
+    import torch
+    exe = str(tmp_path / "c_abi_clients")
+    libdir = os.path.join(ROOT, "finitediff.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_clients.c"), "-o", exe, "-L" + libdir, "-lfdjac",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself is a -m gpu test")
+    out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 7 and "no HIP device" in out.stderr      # FD_ERR_NODEVICE

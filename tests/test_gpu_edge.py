@@ -2,6 +2,8 @@
 inputs and their status codes, failing f! launchers, repeated and concurrent use of plans."""
 import threading
 
+import os
+
 import numpy as np
 import pytest
 
@@ -209,6 +211,30 @@ def test_plain_c_client(tmp_path):
         out = subprocess.run([exe, n], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "f!_evaluations=4" in out.stdout
+
+
+def _build_c_clients(root, tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_clients")
+    libdir = os.path.join(root, "finitediff.jl_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_clients.c"),
+                           "-o", exe, "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.parametrize("client", ["csc", "csc_dense", "coo_dense", "entries", "dense", "tridiagonal", "banded", "blockbanded",
+                                    "csc_f32", "jvp", "host"])
+def test_c_clients_every_plan_kind(tmp_path, client):
+    # examples/c_abi_clients.c: one plain-C client per method of the Julia shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl)
+    # -- Julia-layout arrays, DEVICE pointers for x / J's storage, the caller's own stream, fd_jacobian_async -- each
+    # checking every stored value against the analytic Jacobian and the number of f! evaluations against the reference's
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = _build_c_clients(root, tmp_path)
+    out = subprocess.run([exe, client], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all clients ok" in out.stdout and "FAILED" not in out.stdout
 
 
 def test_stage_timings_do_not_serialise_the_stream():

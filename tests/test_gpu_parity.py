@@ -1295,3 +1295,36 @@ def test_eps_reduction_variants_bit_identical(monkeypatch, C, shift, N):
     c2 = colors.copy()
     c2[N // 2] = c2[N // 2] % C + 1
     assert fd.make_plan(J, J, c2, "forward").info(fd.lib.INFO_EPS_CYCLIC) == 0
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("coloring", ["valid", "invalid_two_colours"])
+def test_device_matches_broadcast_accumulate_arm(oracle, fdtype, coloring):
+    # the reference's arm for GPU arrays (`fast_jacobian_setindex!`, src/jacobians.jl:665-671: += over all
+    # listed entries into a zeroed J).  The device path stores by assignment, which gives the accumulate arm's values for
+    # any colouring (tests/test_oracle_golden.py::test_broadcast_accumulate_arm_equals_assignment); here the HIP result
+    # is compared with the ACCUMULATE oracle directly, dense J + dense-matrix sparsity, valid and invalid colourings.
+    M, N = 45, 40
+    rng = np.random.default_rng(321)
+    A = (rng.random((M, N)) < 0.12).astype(np.float64)
+    A[np.arange(N), np.arange(N)] = 1.0
+    W = rng.random((M, N)) * A
+    Wd = _dev(W)
+    rows, cols = oracle.findstructralnz_dense(A)
+    colors = np.arange(1, N + 1, dtype=np.int64) if coloring == "valid" else (np.arange(N) % 2 + 1).astype(np.int64)
+    xh = rng.random(N) + 0.1
+
+    def fn_np(fx, x):
+        fx[:] = W @ (x * x)
+
+    def fn_t(fx, x):
+        fx.copy_(Wd.to(x.dtype) @ (x * x))
+
+    ref = oracle.jacobian(fdtype, oracle.PyF(fn_np, M, N), xh, colors, M, kind=oracle.PAT_COO_DENSEJ_ACCUM,
+                          rows_index=rows, cols_index=cols)
+    J = torch.full((N, M), float("nan"), dtype=torch.float64, device="cuda").t()      # column-major M x N
+    f = fd.TorchF(fn_t, M, N)
+    fd.finite_difference_jacobian_b(J, f, _dev(xh), fdtype, colorvec=colors, sparsity=A)
+    assert f.fcalls == ref["fcalls"]
+    eps_min = np.min(np.abs(_oracle_eps(xh, colors, fdtype)))
+    _tol_ok(J.cpu().numpy(), ref["out"], eps_min, float(np.abs(W).sum(axis=1).max()) * 1.5, "accumulate arm " + fdtype + " " + coloring)

@@ -325,3 +325,40 @@ def test_c_oracle_agrees_with_independent_numpy_restatement(oracle, fdtype, seed
     scale = np.abs(Jn).max()
     tol = {"forward": 1e-7, "central": 1e-9, "complex": 1e-14}[fdtype] * scale
     assert np.max(np.abs(Jc - Jn)) <= tol
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+@pytest.mark.parametrize("coloring", ["valid", "invalid_single_colour", "invalid_two_colours"])
+def test_broadcast_accumulate_arm_equals_assignment(oracle, fdtype, coloring):
+    # the arm the reference takes when x1 has no fast scalar indexing (a GPU array),
+    # fast_jacobian_setindex! (src/jacobians.jl:574-581, 665-671): J[r,c] += (color[c] == color_i) * vfx[r] over ALL
+    # listed entries, for every colour, into a J zeroed by fill_matrix!.  Every listed (r, c) is a distinct location and
+    # only ITS column's colour adds a non-zero term (Bool * Float64 is a strong zero: false * NaN == 0.0), so the
+    # result equals the assignment form (src/iteration_utils.jl:25-32) for ANY colouring, valid or not -- an invalid
+    # colouring corrupts the differences themselves, identically in both arms.  This pins the ABI contract: the device
+    # path implements assignment, which IS the accumulate arm's result.
+    M, N = 41, 37
+    rng = np.random.default_rng(123)
+    A = (rng.random((M, N)) < 0.15).astype(np.float64)
+    A[np.arange(N), np.arange(N)] = 1.0
+    W = rng.random((M, N)) * A
+    rows, cols = oracle.findstructralnz_dense(A)
+
+    def fn(fx, x):
+        fx[:] = W @ (x * x) + np.sin(x[:1]) * 0   # keeps complex inputs complex
+
+    if coloring == "valid":
+        colors = np.arange(1, N + 1, dtype=np.int64)
+    elif coloring == "invalid_single_colour":
+        colors = np.ones(N, dtype=np.int64)
+    else:
+        colors = (np.arange(N) % 2 + 1).astype(np.int64)
+    x = rng.random(N) + 0.1
+    f = oracle.PyF(fn, M, N)
+    a = oracle.jacobian(fdtype, f, x, colors, M, kind=oracle.PAT_COO_DENSEJ, rows_index=rows, cols_index=cols)
+    b = oracle.jacobian(fdtype, f, x, colors, M, kind=oracle.PAT_COO_DENSEJ_ACCUM, rows_index=rows, cols_index=cols)
+    assert a["fcalls"] == b["fcalls"]
+    assert np.array_equal(a["out"], b["out"])          # (== treats -0.0 and 0.0 alike: the only representable difference)
+    if coloring == "valid":
+        J = 2 * W * x[None, :]
+        assert np.allclose(a["out"], J, rtol=1e-5, atol=1e-6)
