@@ -9,10 +9,10 @@ raises if the HIP library or a GPU is missing.
 from . import patterns  # noqa: F401  (numpy-only helpers; safe without a GPU)
 from . import lib  # noqa: F401  (ctypes binding; loads libfdjac.so on first use)
 from .api import (BandedBlockBandedMatrix, BandedMatrix, BlockBandedMatrix, BuiltinF, Comm, Context, JacobianCache, Plan,  # noqa: F401
-                  SparseMatrixCSC, TorchF, Tridiagonal, JVPCache, default_relstep, finite_difference_jacobian,
+                  SparseMatrixCSC, TorchF, Tridiagonal, TridiagSolver, JVPCache, default_relstep, finite_difference_jacobian,
                   finite_difference_jacobian_b,
                   finite_difference_jvp_b, make_plan, matrix_colors)
 
 __all__ = ["patterns", "lib", "BandedBlockBandedMatrix", "BandedMatrix", "BlockBandedMatrix", "BuiltinF", "Comm", "Context", "JacobianCache", "Plan",
-           "SparseMatrixCSC", "TorchF", "Tridiagonal", "JVPCache", "default_relstep", "finite_difference_jacobian", "finite_difference_jacobian_b",
+           "SparseMatrixCSC", "TorchF", "Tridiagonal", "TridiagSolver", "JVPCache", "default_relstep", "finite_difference_jacobian", "finite_difference_jacobian_b",
            "finite_difference_jvp_b", "make_plan", "matrix_colors"]

@@ -272,6 +272,61 @@ class Comm:
         _l.check(self.L.fd_comm_broadcast(self.handle, p, buf.numel(), eb, int(root)))
 
 
+class TridiagSolver:
+    """fd_tridiag_solver: (alpha*I + beta*J) y = b on the device for a tridiagonal J in the storage the Jacobian plans
+    fill -- ``Tridiagonal`` (dl, d, du) or the nzval of a tridiagonal ``SparseMatrixCSC`` -- whole or one rank's column
+    range [rows[0], rows[1]) (then pass ``comm`` to ``solve``: the ranks solve one global system, exchanging 8 numbers
+    each).  The consumer of the Jacobian path: test/downstream/ordinarydiffeq_tridiagonal_solve.jl:18-30."""
+
+    def __init__(self, N, layout="diagonals", rows=None, ctx=None, dtype=np.float64):
+        self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        self.Lt = _l.typed(self.ctx.L, self.dtype)
+        self.layout = {"diagonals": _l.TRI_DIAGONALS, "csc": _l.TRI_CSC}[layout]
+        r0, r1 = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
+        h = C.c_void_p()
+        _l.check(self.Lt.fd_tridiag_solver_create(self.ctx.handle, int(N), r0, r1, self.layout, C.byref(h)))
+        self.handle, self.N = h, int(N)
+        self.nlocal = int(N) if rows is None else r1 - r0
+        self._fin = weakref.finalize(self, self.Lt.fd_tridiag_solver_destroy, h)
+
+    def _jptrs(self, J):
+        arrs = [J.dl, J.d, J.du] if isinstance(J, Tridiagonal) else ([J.nzval] if isinstance(J, SparseMatrixCSC) else list(J))
+        if len(arrs) != (3 if self.layout == _l.TRI_DIAGONALS else 1):
+            raise ValueError("J does not match the solver's layout")
+        ptrs = []
+        for a in arrs:
+            if a is None or (hasattr(a, "numel") and a.numel() == 0):
+                ptrs.append(None)
+                continue
+            p, k, _keep = _ptr(a, "J", self.dtype)
+            if k != _l.DEVICE:
+                raise ValueError("the solver takes device arrays")
+            ptrs.append(p)
+        return (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
+
+    def _vec(self, a, what):
+        p, k, _keep = _ptr(a, what, self.dtype)
+        if k != _l.DEVICE:
+            raise ValueError("the solver takes device arrays")
+        return p
+
+    def solve(self, J, b, y, alpha=1.0, beta=-1.0, comm=None):
+        """Enqueue y = (alpha*I + beta*J)^-1 b on the context's stream (fd_tridiag_solve_async)."""
+        _l.check(self.Lt.fd_tridiag_solve_async(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),
+                                                self._vec(y, "y"), comm.handle if comm is not None else None))
+
+    def interface(self, J, b, packet, alpha=1.0, beta=-1.0):
+        """Phase A (fd_tridiag_solve_interface): this rank's 8-double packet into the device tensor ``packet``."""
+        _l.check(self.Lt.fd_tridiag_solve_interface(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),
+                                                    packet.data_ptr()))
+
+    def finish(self, J, b, packets, rank, nranks, y, alpha=1.0, beta=-1.0):
+        """Phases B + C (fd_tridiag_solve_finish) from all ranks' packets (device tensor, nranks x 8 doubles)."""
+        _l.check(self.Lt.fd_tridiag_solve_finish(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),
+                                                 packets.data_ptr(), int(rank), int(nranks), self._vec(y, "y")))
+
+
 class BuiltinF:
     """One of libfdjac's device f! families (fd_builtin_f_create): the reference's fixtures."""
 
@@ -696,7 +751,7 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
     """
     if isinstance(cache_or_fdtype, JacobianCache):
         cache = cache_or_fdtype
-        if sparsity == "default":
+        if isinstance(sparsity, str) and sparsity == "default":
             sparsity = cache.sparsity
         if colorvec is None:
             colorvec = cache.colorvec
@@ -705,7 +760,7 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
         n = int(np.prod(x.shape))
         if colorvec is None:
             colorvec = np.arange(1, n + 1, dtype=np.int64)
-        if sparsity == "default":
+        if isinstance(sparsity, str) and sparsity == "default":
             sparsity = J if _has_sparsestruct(J) else None
         cache = JacobianCache(x, fdtype, returntype, colorvec=colorvec, sparsity=sparsity)
     if sparsity is None and _has_sparsestruct(J):

@@ -1,0 +1,579 @@
+// The consumer of the path: a device tridiagonal solve that takes the Jacobian WHERE
+// fd_jacobian_async LEFT IT -- the three diagonals of a Tridiagonal J (outs of fd_plan_create_tridiagonal) or the nzval
+// of a tridiagonal SparseMatrixCSC, whole or one rank's column range -- and solves
+//        (alpha*I + beta*J) y = b
+// the linear system of an implicit / Rosenbrock step with a `Tridiagonal` jac_prototype (downstream use of the
+// reference: test/downstream/ordinarydiffeq_tridiagonal_solve.jl:18-30, W = I - gamma*J).  No reference counterpart
+// inside FiniteDiff.jl itself: there the factorisation is LinearAlgebra's; here it is what keeps the multi-GPU Jacobian
+// sharded (no 240 MB gather over xGMI before the solve: one all-gather of 8 numbers per rank instead).
+//
+// Algorithm: Wang's partition method, applied recursively.  A level's rows are cut into chunks of kChunk rows, one per
+// thread.  A downward and an upward elimination sweep inside the chunk (registers only) leave one equation per chunk
+// that couples the LAST unknown of three neighbouring chunks: a tridiagonal system 8 times smaller.  Levels are
+// reduced until <= kTop unknowns remain (parallel cyclic reduction in LDS, one workgroup), then every level is
+// back-substituted: a thread re-reads its chunk's original rows and solves them with the two now-known boundary
+// values.  No pivoting: the method is for diagonally dominant systems (I - gamma*J of a diffusion-type J), like the
+// partitioned / cyclic-reduction tridiagonal solvers of the vendor libraries.  Level 0 reads the user's J and b once
+// in the reduction and once in the back-substitution (9 values per row in total + 1 written).
+//
+// Multi-GPU (rows = the rank's column range): the rank's block T_r of the matrix is complete in its own slice; the two
+// couplings to the neighbouring ranks are not (they live in the neighbours' columns).  SPIKE form:
+//   phase A  T_r [g v w] = [b  e_first  e_last] (3 right-hand sides through the same reduction; only the 6 tip values
+//            are back-substituted) -> packet of 8 numbers: the tips and the two couplings this rank knows FOR its
+//            neighbours; ONE all-gather of the packets (fd_comm_allgather);
+//   phase B  every rank solves the 2W x 2W interface system (one thread) and picks y just outside its rows;
+//   phase C  T_r y = b - (coupling * neighbour value) at the first / last row: a plain local solve.
+#include <new>
+
+#include "fdjac_internal.h"
+
+#ifdef FDJAC_F32
+#define fd_tridiag_solver fd32_tridiag_solver
+#define fd_tridiag_solver_create fd32_tridiag_solver_create
+#define fd_tridiag_solver_destroy fd32_tridiag_solver_destroy
+#define fd_tridiag_solve_async fd32_tridiag_solve_async
+#define fd_tridiag_solve_interface fd32_tridiag_solve_interface
+#define fd_tridiag_solve_finish fd32_tridiag_solve_finish
+#endif
+
+namespace fdjac {
+
+constexpr int kChunk = 8;        // rows per thread
+constexpr int kTop = 512;        // a level with at most this many rows is solved by one workgroup (PCR in LDS)
+constexpr int kSumVals = 12;     // per chunk: f_e b_e c_e d_e[3]  f_s b_s g_s d_s[3]
+constexpr int kMaxLevels = 12;
+constexpr int kPacket = 8;       // doubles per rank in the interface exchange
+
+struct TriRow {
+    double a, b, c, d[3];
+};
+
+// level 0: the user's matrix, shifted and scaled, restricted to the local rows [g0, g0 + n)
+struct SrcUser {
+    int layout;                 // FD_TRI_DIAGONALS / FD_TRI_CSC
+    const real_t *p0, *p1, *p2; // dl, d, du (window-relative, as the plan's outs)  |  nzval slice, -, -
+    const real_t *rhs;          // local rows
+    const double *adj;          // nullptr, or {subtract from the first row's rhs, subtract from the last row's}
+    int64_t g0, n, N;           // first global row, local rows, global size
+    int64_t e0;                 // CSC: global index of the slice's first stored value
+    double alpha, beta;
+    __device__ __forceinline__ void coef(int64_t i, double &a, double &b, double &c) const
+    {
+        const int64_t gi = g0 + i;
+        double Aa = 0, Ab, Ac = 0;
+        if (layout == FD_TRI_DIAGONALS) {
+            const int64_t du0 = g0 > 0 ? g0 - 1 : 0;
+            Ab = (double)p1[i];
+            if (i > 0) Aa = (double)p0[i - 1];                 // A[gi, gi-1] = dl[gi-1-g0]
+            if (i + 1 < n) Ac = (double)p2[gi - du0];          // A[gi, gi+1] = du[(gi+1)-1-du0]
+        } else {
+            Ab = (double)p0[3 * gi - e0];
+            if (i > 0) Aa = (double)p0[3 * gi - 2 - e0];
+            if (i + 1 < n) Ac = (double)p0[3 * gi + 2 - e0];
+        }
+        a = beta * Aa;
+        b = alpha + beta * Ab;
+        c = beta * Ac;
+    }
+    template <int NRHS> __device__ __forceinline__ TriRow load(int64_t i) const
+    {
+        TriRow r;
+        coef(i, r.a, r.b, r.c);
+        double d0 = (double)rhs[i];
+        if (adj) {
+            if (i == 0) d0 -= adj[0];
+            if (i == n - 1) d0 -= adj[1];
+        }
+        r.d[0] = d0;
+        r.d[1] = (NRHS > 1 && i == 0) ? 1.0 : 0.0;           // e_first
+        r.d[2] = (NRHS > 1 && i == n - 1) ? 1.0 : 0.0;       // e_last
+        return r;
+    }
+};
+
+// level >= 1: the reduced system defined by the chunk summaries of the level below
+struct SrcLevel {
+    const double *sum;   // [kSumVals][nc]
+    int64_t nc;          // chunks below == rows here
+    template <int NRHS> __device__ __forceinline__ TriRow load(int64_t k) const
+    {
+        TriRow r;
+        r.a = sum[0 * nc + k];
+        const double be = sum[1 * nc + k], ce = sum[2 * nc + k];
+        if (k + 1 < nc) {
+            const double t = ce / sum[7 * nc + k + 1];
+            r.b = be - t * sum[6 * nc + k + 1];
+            r.c = -t * sum[8 * nc + k + 1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r.d[q] = q < NRHS ? sum[(3 + q) * nc + k] - t * sum[(9 + q) * nc + k + 1] : 0.0;
+        } else {
+            r.b = be;
+            r.c = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r.d[q] = q < NRHS ? sum[(3 + q) * nc + k] : 0.0;
+        }
+        return r;
+    }
+};
+
+// One chunk's two elimination sweeps -> its summary (the row it contributes to the next level).
+template <typename Src, int NRHS>
+__global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, double *__restrict__ sum, int64_t nc)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nc) return;
+    const int64_t s = k * kChunk;
+    const int m = (int)((n - s < kChunk) ? n - s : kChunk);
+    double f[kChunk], b[kChunk], c[kChunk], d[kChunk][NRHS];
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+        if (i < m) {
+            const TriRow r = src.template load<NRHS>(s + i);
+            f[i] = r.a; b[i] = r.b; c[i] = r.c;
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) d[i][q] = r.d[q];
+        } else {   // padding rows of the last chunk: identity rows, never used
+            f[i] = 0; b[i] = 1; c[i] = 0;
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) d[i][q] = 0;
+        }
+    }
+    // downward: row i -= (a_i / b_{i-1}) * row(i-1); the sub-diagonal turns into a coupling f_i to the unknown before the chunk
+#pragma unroll
+    for (int i = 1; i < kChunk; ++i)
+        if (i < m) {
+            const double mult = f[i] / b[i - 1];
+            f[i] = -mult * f[i - 1];
+            b[i] -= mult * c[i - 1];
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) d[i][q] -= mult * d[i - 1][q];
+        }
+    // (selects over the unrolled rows, never a runtime index: the rows live in registers)
+    double fe = 0, be = 1, ce = 0, de[NRHS];
+    double cf = 0, cb = 1, cg = -1, cd[NRHS];   // m == 1: the chunk's only row is its last unknown: y_first = z
+#pragma unroll
+    for (int q = 0; q < NRHS; ++q) { de[q] = 0; cd[q] = 0; }
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+        if (i == m - 1) {
+            fe = f[i]; be = b[i]; ce = c[i];
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) de[q] = d[i][q];
+        }
+        if (i == m - 2) {   // start of the upward sweep: the row above the last one
+            cf = f[i]; cb = b[i]; cg = c[i];
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) cd[q] = d[i][q];
+        }
+    }
+    sum[0 * nc + k] = fe;
+    sum[1 * nc + k] = be;
+    sum[2 * nc + k] = ce;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sum[(3 + q) * nc + k] = q < NRHS ? de[q < NRHS ? q : 0] : 0.0;
+    // upward: the first row expressed through the unknown before the chunk (f) and the chunk's last unknown (g)
+#pragma unroll
+    for (int i = kChunk - 3; i >= 0; --i)
+        if (i <= m - 3) {
+            const double mult = c[i] / cb;
+            cf = f[i] - mult * cf;
+            cg = -mult * cg;
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) cd[q] = d[i][q] - mult * cd[q];
+            cb = b[i];
+        }
+    sum[6 * nc + k] = cf;
+    sum[7 * nc + k] = cb;
+    sum[8 * nc + k] = cg;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sum[(9 + q) * nc + k] = q < NRHS ? cd[q < NRHS ? q : 0] : 0.0;
+}
+
+// The top level (n <= kTop): parallel cyclic reduction in LDS, NRHS right-hand sides.  sol[q * n + i].
+template <typename Src, int NRHS>
+__global__ void __launch_bounds__(kBlock) k_tri_top(Src src, int n, double *__restrict__ sol)
+{
+    __shared__ double A[2][kTop], B[2][kTop], Cc[2][kTop], D[2][NRHS][kTop];
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const TriRow r = src.template load<NRHS>(i);
+        A[0][i] = r.a; B[0][i] = r.b; Cc[0][i] = r.c;
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) D[0][q][i] = r.d[q];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int st = 1; st < n; st <<= 1) {
+        const int nxt = cur ^ 1;
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+            const bool hl = i - st >= 0, hr = i + st < n;
+            const double k1 = hl ? A[cur][i] / B[cur][i - st] : 0.0, k2 = hr ? Cc[cur][i] / B[cur][i + st] : 0.0;
+            A[nxt][i] = hl ? -A[cur][i - st] * k1 : 0.0;
+            Cc[nxt][i] = hr ? -Cc[cur][i + st] * k2 : 0.0;
+            B[nxt][i] = B[cur][i] - (hl ? Cc[cur][i - st] * k1 : 0.0) - (hr ? A[cur][i + st] * k2 : 0.0);
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q)
+                D[nxt][q][i] = D[cur][q][i] - (hl ? D[cur][q][i - st] * k1 : 0.0) - (hr ? D[cur][q][i + st] * k2 : 0.0);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    for (int i = threadIdx.x; i < n; i += kBlock)
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) sol[(int64_t)q * n + i] = D[cur][q][i] / B[cur][i];
+}
+
+// Back-substitution of one level (1 right-hand side): z = solution of the level above (the chunks' last unknowns).
+// OutT: double for the internal levels, real_t for level 0 (the caller's y).
+template <typename Src, typename OutT>
+__global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, const double *__restrict__ z, int64_t nc,
+                                                        OutT *__restrict__ y)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nc) return;
+    const int64_t s = k * kChunk;
+    const int m = (int)((n - s < kChunk) ? n - s : kChunk);
+    const double zl = k > 0 ? z[k - 1] : 0.0, zr = z[k];
+    double cp[kChunk], dp[kChunk];
+    // Thomas on the interior rows 0 .. m-2 with the two boundary values moved to the right-hand side
+#pragma unroll
+    for (int i = 0; i < kChunk - 1; ++i)
+        if (i < m - 1) {
+            const TriRow r = src.template load<1>(s + i);
+            double di = r.d[0];
+            if (i == 0) di -= r.a * zl;
+            if (i == m - 2) di -= r.c * zr;
+            if (i == 0) {
+                cp[0] = r.c / r.b;
+                dp[0] = di / r.b;
+            } else {
+                const double den = r.b - r.a * cp[i - 1];
+                cp[i] = r.c / den;
+                dp[i] = (di - r.a * dp[i - 1]) / den;
+            }
+        }
+    double yn = zr;
+    y[s + m - 1] = (OutT)zr;
+#pragma unroll
+    for (int i = kChunk - 2; i >= 0; --i)
+        if (i < m - 1) {
+            yn = (i == m - 2) ? dp[i] : dp[i] - cp[i] * yn;
+            y[s + i] = (OutT)yn;
+        }
+}
+
+// Phase A epilogue: the six tip values (first / last local row of g, v, w).  The last row is the last unknown of every
+// level (= the top level's last); the first row needs chunk 0 of every level back-substituted: one thread.
+// lev_sum[l] = summary written by level l's reduction (defines level l+1), lev_n[l] = rows of level l; top_sol = solution
+// of the top level (3 x n_top).  Level 0 rows come from `src0`.
+struct TipArgs {
+    const double *sum[kMaxLevels];
+    int64_t n[kMaxLevels];
+    int nlev;            // levels 0 .. nlev-1; level nlev-1 is the top (solved by PCR)
+};
+// couplings this rank holds for its neighbours: beta*A[g0-1, g0] (column g0) and beta*A[g0+n, g0+n-1] (column g0+n-1)
+__global__ void k_tri_neighbour_couplings(SrcUser s, double *__restrict__ out2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cprev = 0.0, anext = 0.0;
+    const int64_t j0 = s.g0, j1 = s.g0 + s.n;
+    if (s.layout == FD_TRI_DIAGONALS) {
+        const int64_t du0 = j0 > 0 ? j0 - 1 : 0;
+        if (j0 > 0) cprev = s.beta * (double)s.p2[j0 - 1 - du0];      // du[j0-1] = A[j0-1, j0]
+        if (j1 < s.N) anext = s.beta * (double)s.p0[j1 - 1 - j0];      // dl[j1-1] = A[j1, j1-1]
+    } else {
+        if (j0 > 0) cprev = s.beta * (double)s.p0[3 * j0 - 1 - s.e0];
+        if (j1 < s.N) anext = s.beta * (double)s.p0[3 * j1 - 2 - s.e0];
+    }
+    out2[0] = cprev;
+    out2[1] = anext;
+}
+__global__ void k_tri_tips(SrcUser src0, TipArgs ta, const double *__restrict__ top_sol,
+                                          double *__restrict__ packet, const double *__restrict__ cpl)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int top = ta.nlev - 1;
+    const int64_t ntop = ta.n[top];
+    double first[3], last[3];
+    for (int q = 0; q < 3; ++q) {
+        last[q] = top_sol[(int64_t)q * ntop + ntop - 1];
+        first[q] = top_sol[(int64_t)q * ntop + 0];
+    }
+    for (int l = top - 1; l >= 0; --l) {
+        const int64_t n = ta.n[l];
+        const int m = (int)(n < kChunk ? n : kChunk);
+        if (m == 1) continue;
+        TriRow r[kChunk];
+        for (int i = 0; i < m - 1; ++i) {
+            if (l == 0) r[i] = src0.load<3>(i);
+            else { SrcLevel sl{ta.sum[l - 1], ta.n[l]}; r[i] = sl.load<3>(i); }
+        }
+        for (int q = 0; q < 3; ++q) {
+            double cp[kChunk], dp[kChunk];
+            for (int i = 0; i < m - 1; ++i) {
+                double di = r[i].d[q];
+                if (i == m - 2) di -= r[i].c * first[q];
+                if (i == 0) { cp[0] = r[0].c / r[0].b; dp[0] = di / r[0].b; }
+                else { const double den = r[i].b - r[i].a * cp[i - 1]; cp[i] = r[i].c / den; dp[i] = (di - r[i].a * dp[i - 1]) / den; }
+            }
+            double yn = dp[m - 2];
+            for (int i = m - 3; i >= 0; --i) yn = dp[i] - cp[i] * yn;
+            first[q] = yn;
+        }
+    }
+    packet[0] = first[0]; packet[1] = last[0];
+    packet[2] = first[1]; packet[3] = last[1];
+    packet[4] = first[2]; packet[5] = last[2];
+    packet[6] = cpl[0];
+    packet[7] = cpl[1];
+}
+
+// Phase B: the interface system of all ranks (unknowns p_r = first, q_r = last local value of rank r), solved by one
+// thread with banded Gaussian elimination; writes adj = {A_r * q_{r-1}, C_r * p_{r+1}} for THIS rank.
+//   p_r + A_r v_f q_{r-1} + C_r w_f p_{r+1} = g_f ,   q_r + A_r v_l q_{r-1} + C_r w_l p_{r+1} = g_l
+//   A_r = packet[r-1][7] (the previous rank knows it), C_r = packet[r+1][6].
+constexpr int kMaxRanks = 1024;
+__global__ void k_tri_interface(const double *__restrict__ packets, int W, int rank, double *__restrict__ adj,
+                                double *__restrict__ work /* 2W x 6 doubles */)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = 2 * W;
+    // band storage: row i, columns i-2 .. i+2 -> work[i*6 + (j - i + 2)], rhs at work[i*6 + 5]
+    for (int i = 0; i < n * 6; ++i) work[i] = 0.0;
+    for (int r = 0; r < W; ++r) {
+        const double *pk = packets + (size_t)r * kPacket;
+        const double Ar = r > 0 ? packets[(size_t)(r - 1) * kPacket + 7] : 0.0;
+        const double Cr = r + 1 < W ? packets[(size_t)(r + 1) * kPacket + 6] : 0.0;
+        const int ip = 2 * r, iq = 2 * r + 1;
+        work[ip * 6 + 2] = 1.0;  work[ip * 6 + 5] = pk[0];
+        work[iq * 6 + 2] = 1.0;  work[iq * 6 + 5] = pk[1];
+        if (r > 0) { work[ip * 6 + 1] = Ar * pk[2]; work[iq * 6 + 0] = Ar * pk[3]; }          // * q_{r-1} (column 2r-1)
+        if (r + 1 < W) { work[ip * 6 + 4] = Cr * pk[4]; work[iq * 6 + 3] = Cr * pk[5]; }      // * p_{r+1} (column 2r+2)
+    }
+    for (int i = 0; i < n; ++i) {            // elimination, no pivoting (unit diagonal, spikes of a dominant T are < 1)
+        const double piv = work[i * 6 + 2];
+        for (int k = 1; k <= 2 && i + k < n; ++k) {
+            const double mult = work[(i + k) * 6 + 2 - k] / piv;
+            if (mult == 0.0) continue;
+            for (int j = 0; j <= 2 && i + j < n; ++j) {
+                const int col = 2 - k + j;
+                if (col <= 4) work[(i + k) * 6 + col] -= mult * work[i * 6 + 2 + j];
+            }
+            work[(i + k) * 6 + 5] -= mult * work[i * 6 + 5];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double v = work[i * 6 + 5];
+        for (int j = 1; j <= 2 && i + j < n; ++j) v -= work[i * 6 + 2 + j] * work[(i + j) * 6 + 5];
+        work[i * 6 + 5] = v / work[i * 6 + 2];
+    }
+    const double Ar = rank > 0 ? packets[(size_t)(rank - 1) * kPacket + 7] : 0.0;
+    const double Cr = rank + 1 < W ? packets[(size_t)(rank + 1) * kPacket + 6] : 0.0;
+    adj[0] = rank > 0 ? Ar * work[(2 * rank - 1) * 6 + 5] : 0.0;          // A_r * q_{r-1}
+    adj[1] = rank + 1 < W ? Cr * work[(2 * rank + 2) * 6 + 5] : 0.0;      // C_r * p_{r+1}
+}
+
+}  // namespace fdjac
+
+struct fd_tridiag_solver {
+    fd_ctx *ctx = nullptr;
+    int layout = 0;
+    int64_t N = 0, g0 = 0, n = 0, e0 = 0;
+    int nlev = 0;
+    int64_t lev_n[fdjac::kMaxLevels] = {0};
+    double *lev_sum[fdjac::kMaxLevels] = {nullptr};   // summary written by level l's reduction (level nlev-1 has none)
+    double *lev_sol[fdjac::kMaxLevels] = {nullptr};   // solution of level l >= 1 (3 columns at the top level)
+    double *packets = nullptr;                        // kMaxRanks x kPacket (the all-gather buffer)
+    double *adj = nullptr, *cpl = nullptr, *work = nullptr;
+};
+
+using namespace fdjac;
+
+static SrcUser make_src(const fd_tridiag_solver *s, double alpha, double beta, const void *const *J, const void *rhs,
+                        const double *adj)
+{
+    SrcUser u;
+    u.layout = s->layout;
+    u.p0 = (const real_t *)J[0];
+    u.p1 = s->layout == FD_TRI_DIAGONALS ? (const real_t *)J[1] : nullptr;
+    u.p2 = s->layout == FD_TRI_DIAGONALS ? (const real_t *)J[2] : nullptr;
+    u.rhs = (const real_t *)rhs;
+    u.adj = adj;
+    u.g0 = s->g0; u.n = s->n; u.N = s->N; u.e0 = s->e0;
+    u.alpha = alpha; u.beta = beta;
+    return u;
+}
+
+template <int NRHS> static int tri_reduce_all(fd_tridiag_solver *s, const SrcUser &u)
+{
+    hipStream_t st = s->ctx->stream;
+    for (int l = 0; l + 1 < s->nlev; ++l) {
+        const int64_t nc = s->lev_n[l + 1];
+        const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
+        if (l == 0)
+            hipLaunchKernelGGL((k_tri_reduce<SrcUser, NRHS>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sum[0], nc);
+        else
+            hipLaunchKernelGGL((k_tri_reduce<SrcLevel, NRHS>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]},
+                               s->lev_n[l], s->lev_sum[l], nc);
+    }
+    const int top = s->nlev - 1;
+    if (top == 0)
+        hipLaunchKernelGGL((k_tri_top<SrcUser, NRHS>), dim3(1), dim3(kBlock), 0, st, u, (int)s->lev_n[0], s->lev_sol[0]);
+    else
+        hipLaunchKernelGGL((k_tri_top<SrcLevel, NRHS>), dim3(1), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[top - 1], s->lev_n[top]},
+                           (int)s->lev_n[top], s->lev_sol[top]);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+static int tri_backsub_all(fd_tridiag_solver *s, const SrcUser &u, real_t *y)
+{
+    hipStream_t st = s->ctx->stream;
+    for (int l = s->nlev - 2; l >= 0; --l) {
+        const int64_t nc = s->lev_n[l + 1];
+        const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
+        if (l == 0)
+            hipLaunchKernelGGL((k_tri_backsub<SrcUser, real_t>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sol[1], nc, y);
+        else
+            hipLaunchKernelGGL((k_tri_backsub<SrcLevel, double>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]},
+                               s->lev_n[l], s->lev_sol[l + 1], nc, s->lev_sol[l]);
+    }
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+__global__ void k_tri_copy_top(const double *__restrict__ sol, int n, FDJAC_REAL *__restrict__ y)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = (FDJAC_REAL)sol[i];
+}
+
+extern "C" {
+
+int fd_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
+                             fd_tridiag_solver **out)
+{
+    FD_REQUIRE(ctx && out, FD_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    FD_REQUIRE(layout == FD_TRI_DIAGONALS || layout == FD_TRI_CSC, FD_ERR_ARG, "unknown layout %d", layout);
+    FD_REQUIRE(N >= 1, FD_ERR_SHAPE, "N < 1");
+    if (row_begin == 0 && row_end == 0) row_end = N;
+    FD_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= N, FD_ERR_ARG, "rows [%lld,%lld) outside [0,%lld)",
+               (long long)row_begin, (long long)row_end, (long long)N);
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    fd_tridiag_solver *s = new (std::nothrow) fd_tridiag_solver();
+    FD_REQUIRE(s != nullptr, FD_ERR_NOMEM, "out of host memory");
+    s->ctx = ctx; s->layout = layout; s->N = N; s->g0 = row_begin; s->n = row_end - row_begin;
+    s->e0 = row_begin > 0 ? 3 * row_begin - 1 : 0;   // first stored value of column row_begin in a tridiagonal CSC
+    int64_t n = s->n;
+    int l = 0;
+    s->lev_n[0] = n;
+    while (n > kTop) {
+        n = (n + kChunk - 1) / kChunk;
+        ++l;
+        if (l >= kMaxLevels) { delete s; set_error("too many levels"); return FD_ERR_UNSUPPORTED; }
+        s->lev_n[l] = n;
+    }
+    s->nlev = l + 1;
+    bool ok = true;
+    for (int k = 0; k + 1 < s->nlev && ok; ++k)
+        ok = hipMalloc((void **)&s->lev_sum[k], sizeof(double) * (size_t)kSumVals * (size_t)s->lev_n[k + 1]) == hipSuccess;
+    for (int k = (s->nlev > 1 ? 1 : 0); k < s->nlev && ok; ++k)
+        ok = hipMalloc((void **)&s->lev_sol[k], sizeof(double) * 3 * (size_t)s->lev_n[k]) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->packets, sizeof(double) * kPacket * kMaxRanks) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->adj, sizeof(double) * 2) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->cpl, sizeof(double) * 2) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->work, sizeof(double) * 12 * kMaxRanks) == hipSuccess;
+    if (!ok) {
+        fd_tridiag_solver_destroy(s);
+        set_error("hipMalloc failed in fd_tridiag_solver_create");
+        return FD_ERR_NOMEM;
+    }
+    *out = s;
+    return FD_OK;
+}
+
+int fd_tridiag_solver_destroy(fd_tridiag_solver *s)
+{
+    if (!s) return FD_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (int k = 0; k < kMaxLevels; ++k) {
+        if (s->lev_sum[k]) (void)hipFree(s->lev_sum[k]);
+        if (s->lev_sol[k]) (void)hipFree(s->lev_sol[k]);
+    }
+    for (void *p : {(void *)s->packets, (void *)s->adj, (void *)s->cpl, (void *)s->work})
+        if (p) (void)hipFree(p);
+    delete s;
+    return FD_OK;
+}
+
+// local solve of T_r y = rhs - adj (adj = nullptr: the rows are the whole system, or the couplings are zero)
+static int tri_local_solve(fd_tridiag_solver *s, double alpha, double beta, const void *const *J, const void *rhs,
+                           const double *adj, void *y)
+{
+    const SrcUser u = make_src(s, alpha, beta, J, rhs, adj);
+    int rc = tri_reduce_all<1>(s, u);
+    if (rc) return rc;
+    if (s->nlev == 1) {
+        hipLaunchKernelGGL(k_tri_copy_top, dim3(1), dim3(kBlock), 0, s->ctx->stream, s->lev_sol[0], (int)s->n, (real_t *)y);
+        FD_HIP_CHECK(hipGetLastError());
+        return FD_OK;
+    }
+    return tri_backsub_all(s, u, (real_t *)y);
+}
+
+int fd_tridiag_solve_interface(fd_tridiag_solver *s, double alpha, double beta, const void *const *J, const void *rhs,
+                               void *packet_dev)
+{
+    FD_REQUIRE(s && J && rhs && packet_dev, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(s->layout == FD_TRI_CSC ? J[0] != nullptr : J[1] != nullptr, FD_ERR_ARG, "J's values are NULL");   // (dl / du may be empty)
+    FD_HIP_CHECK(hipSetDevice(s->ctx->device));
+    const SrcUser u = make_src(s, alpha, beta, J, rhs, nullptr);
+    int rc = tri_reduce_all<3>(s, u);
+    if (rc) return rc;
+    hipStream_t st = s->ctx->stream;
+    hipLaunchKernelGGL(k_tri_neighbour_couplings, dim3(1), dim3(64), 0, st, u, s->cpl);
+    TipArgs ta;
+    ta.nlev = s->nlev;
+    for (int l = 0; l < kMaxLevels; ++l) { ta.sum[l] = s->lev_sum[l]; ta.n[l] = s->lev_n[l]; }
+    hipLaunchKernelGGL(k_tri_tips, dim3(1), dim3(64), 0, st, u, ta, s->lev_sol[s->nlev - 1], (double *)packet_dev,
+                       s->cpl);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+int fd_tridiag_solve_finish(fd_tridiag_solver *s, double alpha, double beta, const void *const *J, const void *rhs,
+                            const void *packets_dev, int rank, int nranks, void *y)
+{
+    FD_REQUIRE(s && J && rhs && packets_dev && y, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(s->layout == FD_TRI_CSC ? J[0] != nullptr : J[1] != nullptr, FD_ERR_ARG, "J's values are NULL");
+    FD_REQUIRE(nranks >= 1 && nranks <= kMaxRanks && rank >= 0 && rank < nranks, FD_ERR_ARG, "rank %d of %d", rank, nranks);
+    FD_HIP_CHECK(hipSetDevice(s->ctx->device));
+    hipLaunchKernelGGL(k_tri_interface, dim3(1), dim3(64), 0, s->ctx->stream, (const double *)packets_dev, nranks, rank, s->adj,
+                       s->work);
+    FD_HIP_CHECK(hipGetLastError());
+    return tri_local_solve(s, alpha, beta, J, rhs, s->adj, y);
+}
+
+int fd_tridiag_solve_async(fd_tridiag_solver *s, double alpha, double beta, const void *const *J, const void *rhs, void *y,
+                           fd_comm *comm)
+{
+    FD_REQUIRE(s && J && rhs && y, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(s->layout == FD_TRI_CSC ? J[0] != nullptr : J[1] != nullptr, FD_ERR_ARG, "J's values are NULL");
+    FD_HIP_CHECK(hipSetDevice(s->ctx->device));
+    if (!comm) {
+        FD_REQUIRE(s->n == s->N, FD_ERR_ARG, "a solver for rows [%lld,%lld) of %lld needs a communicator", (long long)s->g0,
+                   (long long)(s->g0 + s->n), (long long)s->N);
+        return tri_local_solve(s, alpha, beta, J, rhs, nullptr, y);
+    }
+    FD_REQUIRE(fdjac_comm_ctx(comm) == s->ctx, FD_ERR_ARG, "the communicator belongs to another context");
+    const int W = fdjac_comm_nranks(comm), r = fdjac_comm_rank(comm);
+    FD_REQUIRE(W <= kMaxRanks, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxRanks);
+    int rc = fd_tridiag_solve_interface(s, alpha, beta, J, rhs, s->packets + (size_t)r * kPacket);
+    if (rc) return rc;
+    rc = fdjac_comm_allgather_f64(comm, s->packets, kPacket);
+    if (rc) return rc;
+    return fd_tridiag_solve_finish(s, alpha, beta, J, rhs, s->packets, r, W, y);
+}
+
+}  // extern "C"
+

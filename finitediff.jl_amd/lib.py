@@ -16,6 +16,7 @@ FD_OK = 0
 FD_ERR_COMM = 8
 COMM_ID_BYTES = 128
 EPS_COMPUTE, EPS_PRECOMPUTED = 0, 1
+TRI_DIAGONALS, TRI_CSC = 0, 1
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 HOST, DEVICE = 0, 1
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
@@ -64,6 +65,8 @@ EXPORTS = (
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
+    "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
+    "fd_tridiag_solve_finish",
 )
 
 
@@ -76,6 +79,8 @@ TYPED = (
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
+    "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
+    "fd_tridiag_solve_finish",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -189,6 +194,11 @@ def load():
     L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]
     L.fd_plan_eps_finalize.argtypes = [vp, dbl, dbl, dbl]
     L.fd_plan_set_eps_mode.argtypes = [vp, i32]
+    L.fd_tridiag_solver_create.argtypes = [vp, i64, i64, i64, i32, pp]
+    L.fd_tridiag_solver_destroy.argtypes = [vp]
+    L.fd_tridiag_solve_async.argtypes = [vp, dbl, dbl, pp, vp, vp, vp]
+    L.fd_tridiag_solve_interface.argtypes = [vp, dbl, dbl, pp, vp, vp]
+    L.fd_tridiag_solve_finish.argtypes = [vp, dbl, dbl, pp, vp, vp, i32, i32, vp]
     for name in TYPED:   # the Float32 instantiation has the same prototypes (values behind void*, steps stay double)
         getattr(L, "fd32_" + name[3:]).argtypes = getattr(L, name).argtypes
     for name in EXPORTS:

@@ -355,6 +355,33 @@ int fd_plan_eps_partials(fd_plan *plan, const void *x_dev, int shard, int nshard
 int fd_plan_eps_finalize(fd_plan *plan, double relstep, double absstep, double dir);
 int fd_plan_set_eps_mode(fd_plan *plan, int mode);
 
+/* ---- the consumer: tridiagonal solve with the Jacobian where fd_jacobian_async left it -----------
+ * Solves (alpha*I + beta*J) y = b on the device for a tridiagonal J -- the linear system of an implicit / Rosenbrock
+ * step with a Tridiagonal jac_prototype (test/downstream/ordinarydiffeq_tridiagonal_solve.jl:18-30: W = I - gamma*J).
+ * J is taken in the storage the Jacobian plans write:
+ *   FD_TRI_DIAGONALS  J = {dl, d, du}: the outs of a fd_plan_create_tridiagonal plan (window-relative for a column window)
+ *   FD_TRI_CSC        J = {nzval}: the stored values of a tridiagonal SparseMatrixCSC (3N-2 values; for a column window
+ *                     the window's slice, as a fd_plan_create_csc plan with col_begin/col_end fills it)
+ * rows [row_begin,row_end) = the columns this rank owns (0,0 = the whole matrix).  b and y hold the local rows.
+ * Recursive partition method (Wang) + parallel cyclic reduction at the top, no pivoting: for diagonally dominant
+ * systems.  With a communicator the ranks solve ONE global system: the Jacobian never leaves the GPUs that computed
+ * it -- the exchange is one all-gather of 8 numbers per rank.  Everything is enqueued on the context's stream. */
+typedef struct fd_tridiag_solver fd_tridiag_solver;
+enum fd_tridiag_layout { FD_TRI_DIAGONALS = 0, FD_TRI_CSC = 1 };
+int fd_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
+                             fd_tridiag_solver **out);
+int fd_tridiag_solver_destroy(fd_tridiag_solver *solver);
+/* comm == NULL: the solver's rows are the whole system.  J: 3 (diagonals) or 1 (CSC) device pointers; b, y device. */
+int fd_tridiag_solve_async(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
+                           void *y, fd_comm *comm);
+/* The same solve in its two local phases, for callers that exchange the 8-double packets themselves (MPI.jl, tests):
+   _interface writes this rank's packet (device, 8 doubles); after the all-gather of all ranks' packets (nranks x 8
+   doubles, device) _finish solves the interface system and the local rows. */
+int fd_tridiag_solve_interface(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
+                               void *packet_dev);
+int fd_tridiag_solve_finish(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
+                            const void *packets_dev, int rank, int nranks, void *y);
+
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */
@@ -405,6 +432,16 @@ int fd32_jacobian_async(fd32_plan *plan, fd_f_launch f, void *fctx, const void *
 int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
+typedef struct fd32_tridiag_solver fd32_tridiag_solver;
+int fd32_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
+                               fd32_tridiag_solver **out);
+int fd32_tridiag_solver_destroy(fd32_tridiag_solver *solver);
+int fd32_tridiag_solve_async(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
+                             void *y, fd_comm *comm);
+int fd32_tridiag_solve_interface(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J,
+                                 const void *b, void *packet_dev);
+int fd32_tridiag_solve_finish(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
+                              const void *packets_dev, int rank, int nranks, void *y);
 int fd32_plan_set_comm(fd32_plan *plan, fd_comm *comm);
 int fd32_plan_eps_partials(fd32_plan *plan, const void *x_dev, int shard, int nshards, void **partials_out,
                            int64_t *slot_doubles_out);
