@@ -358,6 +358,37 @@ def main():
             gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
             sys.stderr.write("[bench rank %d] gather failed: %s\n" % (rank, e))
 
+    # ---- the consumer (untimed side measurement): one implicit-Euler / Rosenbrock stage (I - gamma*J) y = b solved on the
+    # nzval the Jacobian just wrote, where it lies -- sharded across the ranks when N>1 (8 numbers per rank exchanged) --
+    consumer = None
+    if cfg in ("c2", "c4") and not by_color and args.dtype == "f64" and (world == 1 or comm is not None):
+        try:
+            solver = fd.TridiagSolver(N, "csc", rows=(c0, c1) if world > 1 else None, ctx=ctx)
+            rhs = torch.ones(c1 - c0, dtype=t_dt, device=dev)
+            ysol = torch.empty(c1 - c0, dtype=t_dt, device=dev)
+            gamma = 0.05
+            reps = max(3, min(args.steps, 10))
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps)]
+            solver.solve([out], rhs, ysol, 1.0, -gamma, comm=comm)      # warm-up
+            fence()
+            for k in range(reps):
+                evs[2 * k].record()
+                solver.solve([out], rhs, ysol, 1.0, -gamma, comm=comm)
+                evs[2 * k + 1].record()
+            fence()
+            ms_s = torch.tensor([sum(evs[2 * k].elapsed_time(evs[2 * k + 1]) for k in range(reps)) / reps], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(ms_s, op=dist.ReduceOp.MAX)
+            # residual of the local rows that do not touch a neighbour (exact stencil: J = tridiag(1, -2, 1))
+            yy = ysol.double()
+            r_in = (1.0 + 2.0 * gamma) * yy[1:-1] - gamma * (yy[:-2] + yy[2:]) - 1.0
+            consumer = {"what": "fd_tridiag_solve_async: (I - gamma*J) y = b on the sharded nzval (CSC layout), gamma = 0.05",
+                        "ms": float(ms_s.item()), "max_interior_residual": float(r_in.abs().max().item()),
+                        "exchange": "one all-gather of 8 doubles per rank" if world > 1 else None}
+        except Exception as e:
+            consumer = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("[bench rank %d] consumer failed: %s\n" % (rank, e))
+
     # ---- verification (untimed): the timed steps produced the right thing -----------------------------------------
     # (1) recompute into a NaN-filled buffer: same bits as the timed result (a step that wrote nothing would leave NaN);
     # (2) every stored value of the linear fixture equals the exact stencil weight; (3) the same plan with the NONLINEAR
@@ -402,7 +433,7 @@ def main():
             "stages_ms": stages, "plan_build_ms": plan_build_ms, "check": check,
             "rccl": comm.info() if comm is not None else None, "backend": backend if world > 1 else None,
             "eps": ("sharded" if (world > 1 and args.eps == "sharded" and comm is not None) else "replicated"),
-            "gather": gather_info}
+            "gather": gather_info, "consumer": consumer}
     sys.stderr.write("[bench rank %d] %s\n" % (rank, json.dumps(diag)))
     sys.stderr.flush()
 
@@ -475,6 +506,7 @@ def main():
                                    "of the reference's pass structure, kept for comparison only"},
             "plan_build_ms": plan_build_ms,
             "gather": gather_info,
+            "consumer": consumer,
             "value_with_gather": (N / ((ms_step + (0.0 if gather_in_step else gather_info["ms"])) * 1e-3)
                                   if (gather_info and "ms" in gather_info) else None),
             "result_check": check,

@@ -10,7 +10,7 @@
  *
  *   gcc -O2 -Iinclude examples/c_abi_clients.c -o c_abi_clients -Lfinitediff.jl_amd/lib -lfdjac \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/finitediff.jl_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   ./c_abi_clients all        # or: csc csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp host
+ *   ./c_abi_clients all        # or: csc csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host
  */
 #include <math.h>
 #include <stdio.h>
@@ -480,6 +480,43 @@ static int client_jvp(void)
     return report("jvp", worst, 1e-6, calls, 2);
 }
 
+/* shim: TridiagSolver{Float64}(N, :diagonals) + solve!(y, solver, J::Tridiagonal, b): the Jacobian a Tridiagonal plan
+   just wrote is consumed where it lies -- one Rosenbrock / implicit-Euler stage (I - gamma*J) y = b */
+static int client_solve(void)
+{
+    const int64_t N = 100001;
+    const double gamma = 0.05;
+    int64_t *colors = cyclic_colors(N, 3);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N);
+    double *dl = dev_nan((size_t)(N - 1)), *d = dev_nan((size_t)N), *du = dev_nan((size_t)(N - 1));
+    double *b = malloc(sizeof(double) * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) b[i] = cos(0.01 * (double)i);
+    double *bd = to_dev(b, sizeof(double) * (size_t)N), *yd = dev_nan((size_t)N);
+    fd_f_launch f; void *fctx; fd_plan *plan; fd_tridiag_solver *solver;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_COMPLEX;
+    CHECK(fd_plan_create_tridiagonal(g_ctx, N, colors, 8, &o, &plan));
+    CHECK(fd_tridiag_solver_create(g_ctx, N, 0, 0, FD_TRI_DIAGONALS, &solver));
+    void *outs[3] = {dl, d, du};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_tridiag_solve_async(solver, 1.0, -gamma, (const void *const *)outs, bd, yd, NULL));   /* same stream: no sync in between */
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *y = malloc(sizeof(double) * (size_t)N);
+    from_dev(y, yd, sizeof(double) * (size_t)N);
+    double worst = 0;                         /* residual with the ANALYTIC Jacobian (complex step: J exact to ~1e-16) */
+    for (int64_t i = 0; i < N; ++i) {
+        double r = (1.0 - gamma * tridiag_nl_J(x, N, i, i)) * y[i] - b[i];
+        if (i > 0) r -= gamma * tridiag_nl_J(x, N, i, i - 1) * y[i - 1];
+        if (i + 1 < N) r -= gamma * tridiag_nl_J(x, N, i, i + 1) * y[i + 1];
+        if (!(fabs(r) <= worst)) worst = fabs(r);
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_tridiag_solver_destroy(solver)); CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(dl); hipFree(d); hipFree(du); hipFree(bd); hipFree(yd); free(y); free(b); free(x); free(colors);
+    return report("solve", worst, 1e-12, calls, 3);
+}
+
 /* shim: the host-array method (x::Vector{Float64}, J::SparseMatrixCSC on the host) -> fd_jacobian with FD_HOST */
 static int client_host(void)
 {
@@ -533,6 +570,7 @@ int main(int argc, char **argv)
     RUN("blockbanded", client_blockbanded())
     RUN("csc_f32", client_csc_f32())
     RUN("jvp", client_jvp())
+    RUN("solve", client_solve())
     RUN("host", client_host())
     CHECK(fd_ctx_destroy(g_ctx));
     hipStreamDestroy(g_stream);

@@ -470,14 +470,19 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
-    def set_lazy(self, f, imag_only=True):
-        """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it."""
+    def set_lazy(self, f, imag_only=True, row_window=True):
+        """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it.  imag_only /
+        row_window=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW capability."""
         fn = getattr(f, "lazy_fn", None) if f is not None else None
         if f is not None and fn is None:
             raise ValueError("this f! has no lazy-point launcher")
         self._lazy_keep = fn
         _l.check(self.Lt.fd_plan_set_lazy_f(self.handle, fn if fn is not None else _l.F_LAUNCH_LAZY()))
-        caps = int(getattr(f, "lazy_caps", 0)) if (f is not None and imag_only) else 0
+        caps = int(getattr(f, "lazy_caps", 0)) if f is not None else 0
+        if not imag_only:
+            caps &= ~1
+        if not row_window:
+            caps &= ~2
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):

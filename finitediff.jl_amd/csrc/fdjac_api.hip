@@ -268,6 +268,60 @@ static size_t window_lds_bytes(bool dma, int fdtype, int max_slots, int max_ncol
     return wp * (size_t)max_ncol * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc + kWinHeadBytes;
 }
 
+// Row strips.  The hand-off between f! and the decompression (C+1 arrays of M values, written once and read once) is the
+// largest stream of a Jacobian and does not fit the 256 MiB Infinity Cache at BASELINE's sizes (320 MB at N = 10^7, C = 3).
+// Cutting the call into K strips of consecutive tiles, each a pair (f! on the rows the strip's tiles read, decompression of
+// those tiles) that REUSES one scratch of M/K rows per point, keeps part of that hand-off on the die
+// (scripts/ubench/stripmine_probe.hip: 177 -> 138 us per step for the same bytes at K = 2; more strips lose to launch
+// ramps).  Needs a launcher that writes only the rows it is asked for (FD_LAZY_CAP_ROW_WINDOW).  Same work per tile and per
+// row => same bits.  wt: the tile descriptors (3 x int4 per tile).
+static void plan_row_strips(fd_plan *p, const std::vector<int4> &wt, size_t ntiles)
+{
+    p->strips = 1;
+    p->strip_tile.clear(); p->strip_rlo.clear(); p->strip_rhi.clear();
+    const char *fs = getenv("FDJAC_STRIPS");
+    int K = (fs && *fs) ? atoi(fs) : -1;
+    const int64_t rows_local = std::max<int64_t>(p->row1 - p->row0, 1);
+    const int pts = p->fdtype == FD_CENTRAL ? 2 : 1;
+    // OFF unless FDJAC_STRIPS=K asks for it.  Measured in the real pipeline (N = 10^7 tridiagonal forward, same process
+    // settings, profiles/r02_b_strips_ab.txt): K = 1: 0.219 ms per Jacobian, K = 2: 0.212, K = 3: 0.221, K = 4: 0.241 --
+    // f! + decompression drop from 192 to 183 us at K = 2 (the probe's 1.29x does not carry over: these kernels are not
+    // pure streams) and the extra launches eat the rest.  Kept as a tested, bit-identical option.
+    (void)rows_local; (void)pts;
+    if (!(fs && *fs)) return;
+    const bool forced = fs && *fs;
+    K = std::max(1, std::min(K, 64));
+    if (!forced && (int64_t)ntiles < (int64_t)K * 256) K = (int)std::max<int64_t>(1, (int64_t)ntiles / 256);   // a strip must still fill the chip
+    if ((int64_t)ntiles < K) K = (int)std::max<size_t>(ntiles, 1);
+    if (K <= 1 || p->C > kRegColors) return;
+    p->strip_tile.resize((size_t)K + 1);
+    p->strip_rlo.assign((size_t)K, 0);
+    p->strip_rhi.assign((size_t)K, 0);
+    int64_t maxrows = 0;
+    for (int k = 0; k <= K; ++k) p->strip_tile[(size_t)k] = (int64_t)ntiles * k / K;
+    for (int k = 0; k < K; ++k) {
+        int64_t lo = std::numeric_limits<int64_t>::max(), hi = 0;
+        for (int64_t t = p->strip_tile[(size_t)k]; t < p->strip_tile[(size_t)k + 1]; ++t) {
+            const int4 th = wt[3 * (size_t)t], wa = wt[3 * (size_t)t + 1], wb = wt[3 * (size_t)t + 2];
+            const int nwin = th.w & 0xFF;
+            const int rw[4] = {wa.x, wa.z, wb.x, wb.z}, en[4] = {wa.y, wa.w, wb.y, wb.w};
+            for (int q = 0; q < nwin; ++q) {
+                const int pairs = en[q] - (q ? en[q - 1] : 0);
+                lo = std::min<int64_t>(lo, rw[q]);
+                hi = std::max<int64_t>(hi, (int64_t)rw[q] + 2 * (int64_t)pairs);
+            }
+        }
+        if (hi <= lo) { lo = 0; hi = 0; }            // a strip without coloured entries reads nothing
+        lo &= ~(int64_t)31;                          // 256-B aligned strip base
+        hi = std::min<int64_t>((hi + 1) & ~(int64_t)1, round_up(p->M, 2));
+        p->strip_rlo[(size_t)k] = lo;
+        p->strip_rhi[(size_t)k] = std::max(hi, lo);
+        maxrows = std::max(maxrows, p->strip_rhi[(size_t)k] - lo);
+    }
+    p->strip_ld = round_up(maxrows + 2, 32);
+    p->strips = K;
+}
+
 static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,
                            bool scattered)
 {
@@ -428,6 +482,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
             p->win_tile = best.T;
             p->win_pairs = best.max_slots / 2;
             p->win_ncol = best.max_ncol;
+            plan_row_strips(p, best.wt, padded / (size_t)best.T);
             if ((rc = dev_upload(&p->d_wtiles, best.wt))) return rc;
             if ((rc = dev_upload(&p->d_wcode, best.code))) return rc;
         }
@@ -1133,6 +1188,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
+    case FD_INFO_STRIPS: *value = (p->window && !p->window2d && p->nchunks == 1) ? p->strips : 1; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;
@@ -1332,6 +1388,48 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
         const int B = c_hi - c_lo;
         bool lazy_done = false, imag_only = false;
+        // row strips: K x (f! on the strip's rows into the shared scratch, decompression of the strip's tiles)
+        const bool strip_mode = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_ROW_WINDOW) && p->strips > 1 && p->window &&
+                                !p->window2d && p->nchunks == 1 && full_colors && (p->kind == K_CSC || p->kind == K_BANDED) &&
+                                (p->fdtype != FD_COMPLEX || (p->lazy_caps & FD_LAZY_CAP_IMAG_ONLY)) && !small;
+        if (strip_mode) {
+            const bool io = p->fdtype == FD_COMPLEX;      // (imag-only: the f! arrays are real, fx is the zero vector)
+            for (int k = 0; k < p->strips; ++k) {
+                const int64_t rlo = p->strip_rlo[(size_t)k], rhi = p->strip_rhi[(size_t)k];
+                const int64_t t0 = p->strip_tile[(size_t)k], t1 = p->strip_tile[(size_t)k + 1];
+                if (t1 <= t0) continue;
+                {
+                    Span sp(p, FD_STAGE_F);
+                    fd_lazy_points lp;
+                    lp.x = x_dev;
+                    lp.color = p->d_color;
+                    lp.eps = p->d_eps;
+                    lp.base_out = base_pending ? p->d_fx - rlo : nullptr;
+                    lp.color_bytes = p->color8 ? 1 : 4;
+                    lp.c_lo = c_lo;
+                    lp.ncolors = B;
+                    lp.pts = p->pts;
+                    lp.is_complex = io ? 1 : 0;
+                    lp.imag_only = io ? 1 : 0;
+                    lp.part = k;
+                    lp.nparts = p->strips;
+                    const int64_t r0 = std::max<int64_t>(rlo, p->row0 & ~(int64_t)1), r1 = std::min<int64_t>(rhi, p->row1);
+                    const int rc = (rhi > rlo) ? p->lazy_fn(fctx, p->d_FX - rlo, &lp, p->strip_ld, r0, r1, (void *)s) : 0;
+                    FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "lazy f! launcher returned %d for row strip %d of %d", rc, k, p->strips);
+                }
+                {
+                    Span sp(p, FD_STAGE_DECOMPRESS);
+                    p->cur_tile0 = t0; p->cur_ntl = t1 - t0; p->cur_shift = rlo; p->cur_ld = p->strip_ld;
+                    const real_t *fxs = io ? p->d_fx : (base_pending ? p->d_fx - rlo : fx);
+                    const int rc = launch_decompress(p, fxs, c_lo, c_hi, outs, io ? (int)FD_FORWARD : p->fdtype);
+                    p->cur_tile0 = 0; p->cur_ntl = -1; p->cur_shift = 0; p->cur_ld = 0;
+                    if (rc) return rc;
+                }
+            }
+            p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
+            base_pending = false;
+            continue;
+        }
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
             fd_lazy_points lp;
@@ -1346,6 +1444,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
             // complex step: only imag(f) is ever used (src/jacobians.jl:635) -- a launcher that can, writes just that
             lp.imag_only = (p->fdtype == FD_COMPLEX && (p->lazy_caps & FD_LAZY_CAP_IMAG_ONLY)) ? 1 : 0;
+            lp.part = 0;
+            lp.nparts = 1;
             imag_only = lp.imag_only != 0;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);

@@ -892,7 +892,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
         return FD_LAZY_DECLINED;
     b->launches.fetch_add(1);
-    b->points.fetch_add(npts);
+    if (lp->nparts <= 1 || lp->part == 0) b->points.fetch_add(npts);   // row strips: the parts together are ONE evaluation per point
     const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
     if (r1 <= r0 || lp->ncolors <= 0) return 0;
     const hipStream_t s = (hipStream_t)stream;
@@ -996,7 +996,9 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
 {
     BuiltinF *b = (BuiltinF *)fctx;
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
-    *caps_out = has_lazy(b) ? FD_LAZY_CAP_IMAG_ONLY : 0;
+    // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
+    // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
+    *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : FD_LAZY_CAP_ROW_WINDOW)) : 0;
     return FD_OK;
 }
 

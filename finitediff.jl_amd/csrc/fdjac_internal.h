@@ -185,6 +185,15 @@ struct fd_plan {
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile
     int win_per_P = 0, win_per_S = 0, win_per_magic = 0;   // periodic entry codes of regular tiles (0 = none)
+    // row strips (1-D row-window tiles, launchers with FD_LAZY_CAP_ROW_WINDOW): the call runs as `strips` pairs of
+    // (f! on the strip's rows, decompression of the strip's tiles) that reuse ONE scratch of strip_ld rows per point,
+    // small enough to stay in the 256 MiB Infinity Cache between the two launches
+    int strips = 1;
+    std::vector<int64_t> strip_tile;            //   strips + 1 tile boundaries
+    std::vector<int64_t> strip_rlo, strip_rhi;  //   rows each strip's tiles read: [rlo (multiple of 32), rhi (even))
+    int64_t strip_ld = 0;                       //   scratch pitch (rows per point) in strip mode
+    int64_t cur_tile0 = 0, cur_ntl = -1;        //   tile range of the decompression launch in flight (-1 = all tiles)
+    int64_t cur_shift = 0, cur_ld = 0;          //   the batched f! arrays start at d_FX - cur_shift with pitch cur_ld (0 = ldf)
     double win_overread = 0;       //   dense window elements loaded per stored entry (1 = no waste)
     int64_t nnz_local = 0;
     int64_t entry_begin = 0;       // global index of the first local stored entry

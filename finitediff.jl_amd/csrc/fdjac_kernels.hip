@@ -564,17 +564,17 @@ __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
                     const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t n,
-                    int vec_ok, int wp, int per_P, int per_S, int per_magic)
+                    int vec_ok, int wp, int per_P, int per_S, int per_magic, int64_t tile0, int64_t ntl)
 {
+    // (tile0, ntl): this launch covers the tiles [tile0, tile0 + ntl) -- all of them, or one row strip's)
     constexpr int T = U * kBlock * 2;             // entries per tile; U pairs of entries per thread
     extern __shared__ real_t s_mem_w[];
     uint16_t *s_head = reinterpret_cast<uint16_t *>(s_mem_w);   // first kWinPeriodMax codes of a regular tile (see phase 1)
     real_t *s_eps = reinterpret_cast<real_t *>(reinterpret_cast<char *>(s_mem_w) + kWinHeadBytes);   // step sizes of the tile's colours
     real_t *s_win = s_eps + kWinMaxCol;           // [ncol][wp] differences f(x+eps_c) - f(x) over the tile's row windows
-    const int64_t ntiles = (n + T - 1) / T;
-    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
-    if (xt >= ntiles) return;
-    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
+    const int64_t xt = xcd_tile(blockIdx.x, ntl);
+    if (xt >= ntl) return;
+    const int64_t tile_id = tile0 + ((vec_ok & 4) ? ntl - 1 - xt : xt);   // reversed tile order, see tile_order_reversed()
     const int64_t t0 = tile_id * T;
     const int4 th = wtiles[3 * tile_id], wa = wtiles[3 * tile_id + 1], wb = wtiles[3 * tile_id + 2];
     const int cmin = __builtin_amdgcn_readfirstlane(th.x);
@@ -1368,7 +1368,7 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
     const bool dma_off = !p->dma;   // (fixed at plan creation)
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
-    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
+    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->d_fx - p->cur_shift) || (fx == p->fx_batch_row);
     // the imaginary parts of an imag-only complex step arrive as a real array with fx = the plan's all-zero vector:
     // a - 0.0 == a, so the kernels are told not to load it at all
     const bool fx_zero = (MODE == 0) && p->fdtype == FD_COMPLEX && fx == p->d_fx;
@@ -1381,6 +1381,7 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     const int wp = dma ? ((2 * p->win_pairs + 127) & ~127) : (((2 * p->win_pairs + 31) & ~31) + 2);
     const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
     const int vok = ((((uintptr_t)out) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
+    const int64_t ldw = p->cur_ld > 0 ? p->cur_ld : p->ldf;   // pitch of the batched f! arrays (row strips: the strip scratch)
     if (p->window2d) {
         const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
         const size_t shm2 = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + 4 * (size_t)kW2Desc;
@@ -1395,12 +1396,14 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
 #undef FD_LAUNCH_W2
         return;
     }
-    const int64_t gw = 8 * xcd_chunks((p->nnz_local + p->win_tile - 1) / p->win_tile);
+    const int64_t all_tiles = (p->nnz_local + p->win_tile - 1) / p->win_tile;
+    const int64_t tile0 = p->cur_ntl >= 0 ? p->cur_tile0 : 0, ntl = p->cur_ntl >= 0 ? p->cur_ntl : all_tiles;
+    const int64_t gw = 8 * xcd_chunks(ntl);
     const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + kWinHeadBytes;
 #define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
     hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
-                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,       \
-                       c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic)
+                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, ldw, p->M, p->d_eps, c_lo,          \
+                       c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic, tile0, ntl)
 #define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
     if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); return; } }
     if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }
@@ -1415,8 +1418,10 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
 {
     hipStream_t s = p->ctx->stream;
     const int B = c_hi - c_lo;
-    const real_t *FXa = p->d_FX;
-    const real_t *FXb = (MODE == 0) ? fx : p->d_FX + (int64_t)B * p->ldf;  // central: minus points
+    // (row strips: the scratch holds rows [cur_shift, ...) of every point at pitch cur_ld; kernels index absolute rows)
+    const int64_t ld_eff = p->cur_ld > 0 ? p->cur_ld : p->ldf;
+    const real_t *FXa = p->d_FX - p->cur_shift;
+    const real_t *FXb = (MODE == 0) ? fx : FXa + (int64_t)B * ld_eff;  // central: minus points
     const CT *color = (const CT *)p->d_color;
     switch (p->kind) {
     case K_CSC:

@@ -101,6 +101,11 @@ typedef struct fd_lazy_points {
     int32_t imag_only;    /* complex step only, set only for launchers registered with FD_LAZY_CAP_IMAG_ONLY: write  */
                           /* fx[b*fx_stride + r] = imag(f(point b))[r] as a REAL array (fx_stride in doubles) -- the */
                           /* real parts of a complex-step evaluation are never used (src/jacobians.jl:635)           */
+    int32_t part;         /* row strips (launchers registered with FD_LAZY_CAP_ROW_WINDOW only): this call evaluates */
+    int32_t nparts;       /* the rows [row_begin,row_end) of the SAME points as part `part` of `nparts` calls; the   */
+                          /* parts together cover every row once (one f! evaluation per point, in pieces).  1 part   */
+                          /* otherwise.  fx / base_out then address a scratch that holds ONLY those rows: row r of   */
+                          /* point b is still fx[b*fx_stride + r], but rows outside the window must not be touched   */
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -201,7 +206,8 @@ enum fd_plan_info_key {
     FD_INFO_SMALL_FUSED = 22,         /* 1 if the plan uses the fused single-workgroup launches of small problems */
     FD_INFO_LDS_DMA = 23,             /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
     FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
-    FD_INFO_EPS_NT = 25               /* 1 if the step-size reduction reads x with non-temporal loads */
+    FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
+    FD_INFO_STRIPS = 26               /* row strips per Jacobian the plan would use with a FD_LAZY_CAP_ROW_WINDOW launcher (1 = none) */
 };
 /* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
    read there, not per process and not per launch -- except FDJAC_REVERSE and FDJAC_COLRANGE_VEC, which only reorder
@@ -228,6 +234,9 @@ int fd_jacobian_async(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, c
 int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
 /* Optional capabilities of the installed lazy launcher (bit mask; cleared by fd_plan_set_lazy_f). */
 #define FD_LAZY_CAP_IMAG_ONLY 1   /* honours fd_lazy_points.imag_only: halves the f! output traffic of the complex step */
+#define FD_LAZY_CAP_ROW_WINDOW 2  /* writes ONLY rows [row_begin & ~1, row_end + 1) of fx / base_out: the library may then  */
+                                  /* evaluate f! and decompress in row strips that reuse one cache-sized scratch            */
+                                  /* (fd_lazy_points.part / nparts; DESIGN.md "row strips")                                 */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */

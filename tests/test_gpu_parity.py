@@ -1328,3 +1328,64 @@ def test_device_matches_broadcast_accumulate_arm(oracle, fdtype, coloring):
     assert f.fcalls == ref["fcalls"]
     eps_min = np.min(np.abs(_oracle_eps(xh, colors, fdtype)))
     _tol_ok(J.cpu().numpy(), ref["out"], eps_min, float(np.abs(W).sum(axis=1).max()) * 1.5, "accumulate arm " + fdtype + " " + coloring)
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_none", "tridiag_window", "tridiag_f_in", "band5", "banded_matrix"])
+def test_row_strips_bit_identical(monkeypatch, fdtype, case):
+    # Row strips (FD_INFO_STRIPS, FD_LAZY_CAP_ROW_WINDOW): the call runs as K pairs of (f! on a strip's rows, decompression
+    # of the strip's tiles) sharing one scratch.  Same work per row and per tile: the bits of the one-piece call, whatever K;
+    # the launcher still counts ONE evaluation per point.
+    N = 300_007
+    c0 = c1 = None
+    f_in = None
+    colors = P.cyclic_colors(N, 3)
+    fam, prm = "tridiag_nl", (N,)
+    if case == "band5":
+        colptr, rowval = P.banded_csc(N, N, 2, 2)
+        colors = P.cyclic_colors(N, 5)
+        fam = "tridiag_nl"      # any f! inside the band
+    else:
+        colptr, rowval = P.tridiag_csc(N)
+    if case == "tridiag_none":
+        colors = colors.copy()
+        colors[[0, 77, 4096, N // 2, N - 1]] = 0
+    if case == "tridiag_window":
+        c0, c1 = 100_001, 250_000
+    x = _dev(np.random.default_rng(77).random(N))
+    if case == "tridiag_f_in" and fdtype == "forward":
+        f_in = _dev(np.random.default_rng(78).random(N + 1))[1:]
+    outs = {}
+    for K in ("1", "2", "3", "7"):
+        monkeypatch.setenv("FDJAC_STRIPS", K)
+        if case == "banded_matrix":
+            data = torch.full((N, 3), float("nan"), dtype=torch.float64, device="cuda").t()
+            J = fd.BandedMatrix(data, N, 1, 1)
+            plan = fd.make_plan(J, None, colors, fdtype)
+            out = data
+        else:
+            J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, col_window=(c0, c1) if c0 is not None else None,
+                                x_window=(c0 - 2, c1 + 2) if c0 is not None else None)
+            out = _dev(np.full(plan.out_len(0), np.nan))
+        assert plan.info(fd.lib.INFO_WINDOW) == 1 and plan.info(fd.lib.INFO_STRIPS) == int(K)
+        f = fd.BuiltinF(fam, *prm)
+        plan.set_lazy(f)
+        plan.jacobian(f, x, [out], f_in=f_in)
+        C = int(colors.max())
+        want_calls = {"forward": C + (0 if f_in is not None else 1), "central": 2 * C, "complex": C}[fdtype]
+        assert f.fcalls == want_calls and plan.fcalls_last == want_calls
+        outs[K] = out.cpu().numpy().copy()
+    assert not np.isnan(outs["1"]).any()
+    for K in ("2", "3", "7"):
+        assert np.array_equal(outs[K], outs["1"]), K
+    # a launcher without the capability (or a user f!) keeps the one-piece call
+    monkeypatch.setenv("FDJAC_STRIPS", "3")
+    if case == "tridiag":
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        plan = fd.make_plan(J, J, colors, fdtype)
+        f = fd.BuiltinF(fam, *prm)
+        plan.set_lazy(f, row_window=False)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        assert np.array_equal(out.cpu().numpy(), outs["1"]) and f.counts()[0] <= 2
