@@ -11,8 +11,8 @@ from . import lib  # noqa: F401  (ctypes binding; loads libfdjac.so on first use
 from .api import (BandedBlockBandedMatrix, BandedMatrix, BlockBandedMatrix, BuiltinF, Comm, Context, JacobianCache, Plan,  # noqa: F401
                   SparseMatrixCSC, TorchF, Tridiagonal, TridiagSolver, JVPCache, default_relstep, finite_difference_jacobian,
                   finite_difference_jacobian_b,
-                  finite_difference_jvp_b, make_plan, matrix_colors)
+                  finite_difference_jvp_b, make_plan, make_plan_csc_device, matrix_colors)
 
 __all__ = ["patterns", "lib", "BandedBlockBandedMatrix", "BandedMatrix", "BlockBandedMatrix", "BuiltinF", "Comm", "Context", "JacobianCache", "Plan",
            "SparseMatrixCSC", "TorchF", "Tridiagonal", "TridiagSolver", "JVPCache", "default_relstep", "finite_difference_jacobian", "finite_difference_jacobian_b",
-           "finite_difference_jvp_b", "make_plan", "matrix_colors"]
+           "finite_difference_jvp_b", "make_plan", "make_plan_csc_device", "matrix_colors"]

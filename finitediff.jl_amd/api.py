@@ -435,6 +435,12 @@ class Plan:
         _l.check(self.Lt.fd_plan_info(self.handle, key, C.byref(v)))
         return v.value
 
+    def checksum(self):
+        """fd_plan_checksum: FNV-1a of the compiled pattern (plans with equal checksums drive the kernels identically)."""
+        v = C.c_uint64()
+        _l.check(self.Lt.fd_plan_checksum(self.handle, C.byref(v)))
+        return v.value
+
     @property
     def ncolors(self):
         return self.info(_l.INFO_NCOLORS)
@@ -660,6 +666,29 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
             if ncols > n:
                 raise IndexError("BoundsError: maximum(colorvec) > length(x)")
             _l.check(L.fd_plan_create_dense(ctx.handle, m, n, ncols, C.byref(o), C.byref(h)))
+    return Plan(ctx, h, fdtype, dtype)
+
+
+def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_window=None, x_window=None,
+                         idx_base=1, dtype=np.float64):
+    """fd_plan_create_csc_device: the common-pattern CSC plan from a pattern that already lives on the device --
+    `colptr`, `rowval`, `colorvec` are torch CUDA tensors (int32 or int64; colptr / rowval `idx_base`-based, colours 1..C).
+    The plan is compiled by kernels; nothing crosses PCIe."""
+    import torch
+    ctx = ctx or Context.default()
+    L = _l.typed(ctx.L, dtype)
+    fdtype = _norm_fdtype(fdtype)
+    o = _opts(fdtype, col_window, x_window)
+    for t, what in ((colptr, "colptr"), (rowval, "rowval"), (colorvec, "colorvec")):
+        if not (_is_torch(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.int32, torch.int64)):
+            raise TypeError("%s must be a contiguous int32 / int64 CUDA tensor" % what)
+    if colptr.dtype != rowval.dtype:
+        raise TypeError("colptr and rowval must have the same integer type")
+    if colorvec.numel() != N:
+        raise ValueError("DimensionMismatch: length(colorvec) != length(x)")
+    h = C.c_void_p()
+    _l.check(L.fd_plan_create_csc_device(ctx.handle, int(M), int(N), colptr.data_ptr(), rowval.data_ptr(), colptr.element_size(),
+                                         int(idx_base), colorvec.data_ptr(), colorvec.element_size(), C.byref(o), C.byref(h)))
     return Plan(ctx, h, fdtype, dtype)
 
 

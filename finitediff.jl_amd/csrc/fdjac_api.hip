@@ -161,12 +161,11 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     p->nchunks = p->C > 0 ? (p->C + B - 1) / B : 0;
     int rc;
     // (+1 row: small problems evaluate f(x) as one more member of the perturbed batch)
-    if ((rc = dev_alloc(&p->d_X, (B * p->pts + 1) * p->cplx * p->ldx))) return rc;
+    // (the materialised points d_X and the staging copies of x / f_in are allocated on first use -- ensure_points /
+    //  ensure_stage: a lazy-point launcher with device inputs never needs them, 480 MB less at N = 10^7)
     if ((rc = dev_alloc(&p->d_FX, (B * p->pts + 1) * p->cplx * p->ldf))) return rc;
     if ((rc = dev_alloc(&p->d_fx, p->ldf))) return rc;
     if ((rc = dev_alloc(&p->d_eps, std::max<int64_t>(p->C, 1)))) return rc;
-    if ((rc = dev_alloc(&p->d_xstage, p->ldx))) return rc;
-    if ((rc = dev_alloc(&p->d_finstage, p->ldf))) return rc;
 
     if (p->fdtype == FD_COMPLEX) {
         // d_fx is not used by the complex step: keep it zero, it is the "fx" of the imag-only decompression
@@ -178,7 +177,7 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     } else if (p->C > 0 && p->kind != K_DENSE) {
         if (p->C <= kRegColors) {
             // cyclic colours (mod1(j, C) and its rotations): the reduction computes them instead of reading them
-            {
+            if (!p->built_on_device) {   // (the device builder ran the same test with wave ballots)
                 const char *fc = getenv("FDJAC_EPS_CYCLIC");
                 bool cyc = !(fc && *fc && atoi(fc) == 0) && p->N >= 1 && col0[0] >= 0;
                 const int32_t sh = cyc ? col0[0] : 0;
@@ -215,6 +214,19 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
             if ((rc = dev_alloc(&p->d_partial, (int64_t)p->seg_chunks * p->C))) return rc;
         }
     }
+    return FD_OK;
+}
+
+static int ensure_points(fd_plan *p)
+{
+    if (p->d_X) return FD_OK;
+    return dev_alloc(&p->d_X, (p->chunkB * p->pts + 1) * p->cplx * p->ldx);
+}
+static int ensure_stage(fd_plan *p, bool x, bool fin)
+{
+    int rc;
+    if (x && !p->d_xstage && (rc = dev_alloc(&p->d_xstage, p->ldx))) return rc;
+    if (fin && !p->d_finstage && (rc = dev_alloc(&p->d_finstage, p->ldf))) return rc;
     return FD_OK;
 }
 
@@ -759,6 +771,8 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
 
 }  // namespace fdjac
 
+#include "fdjac_planbuild.hip"
+
 using namespace fdjac;
 
 extern "C" {
@@ -856,7 +870,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
     fd_plan *p = *out;
     FD_TRY(apply_opts(p, opts));
     std::vector<int32_t> col0;
-    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    if (!(colorvec != nullptr && (color_bytes == 4 || color_bytes == 8))) FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));   // (reports the argument error)
     const int64_t e0 = load_idx(colptr, idx_bytes, p->col0) - idx_base;
     const int64_t e1 = load_idx(colptr, idx_bytes, p->col1) - idx_base;
     if (!(e0 >= 0 && e1 >= e0)) {
@@ -866,6 +880,40 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
         return FD_ERR_SHAPE;
     }
     p->entry_begin = e0;
+    // Large common-pattern plans are compiled on the device: the raw arrays are uploaded as they are (the caller's index
+    // width and base) and the kernels of fdjac_planbuild.hip produce the plan arrays.  FDJAC_PLAN_DEVICE=0 keeps the
+    // host loops below (the checker: tests compare both builds bit for bit); patterns the device builder declines
+    // (scattered stencils, many colours) fall through to them as well.
+    {
+        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const int want = (pd && *pd) ? atoi(pd) : -1;      // -1 auto (>= 2^17 entries), 0 never, 1 whenever possible
+        if (kind == K_CSC && want != 0 && (want == 1 || e1 - e0 >= ((int64_t)1 << 17))) {
+            const size_t ib = (size_t)idx_bytes;
+            void *d_cp = nullptr, *d_rv = nullptr, *d_cv = nullptr;
+            const int64_t ncols = p->col1 - p->col0;
+            bool ok = hipMalloc(&d_cp, ib * (size_t)(ncols + 1)) == hipSuccess && hipMalloc(&d_rv, ib * (size_t)std::max<int64_t>(e1 - e0, 1)) == hipSuccess &&
+                      hipMalloc(&d_cv, (size_t)color_bytes * (size_t)N) == hipSuccess;
+            ok = ok && hipMemcpyAsync(d_cp, (const char *)colptr + ib * (size_t)p->col0, ib * (size_t)(ncols + 1), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_rv, (const char *)rowval + ib * (size_t)e0, ib * (size_t)(e1 - e0), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_cv, colorvec, (size_t)color_bytes * (size_t)N, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            int brc = FD_OK, res = PBR_DECLINED;
+            if (ok)   // (kernels index with absolute column / entry numbers: shift the slice bases accordingly)
+                res = device_build_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base,
+                                       d_cv, color_bytes, e0, e1, &brc);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (d_cp) (void)hipFree(d_cp);
+            if (d_rv) (void)hipFree(d_rv);
+            if (d_cv) (void)hipFree(d_cv);
+            (void)hipGetLastError();
+            if (res == PBR_DONE) {
+                if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
+                p->nouts = 1;
+                p->out_len[0] = e1 - e0;
+                return FD_OK;
+            }
+        }
+    }
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
     std::vector<int32_t> rows((size_t)(e1 - e0)), nzc((size_t)(e1 - e0));
     std::vector<int64_t> dest;
     if (kind == K_CSC_DENSE) dest.resize((size_t)(e1 - e0));
@@ -906,6 +954,93 @@ int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, co
                        fd_plan **out)
 {
     return csc_common(ctx, K_CSC, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+}
+
+int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
+                              int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
+                              const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(colptr_dev && rowval_dev && colorvec_dev, FD_ERR_ARG, "NULL pattern array");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(idx_base == 0 || idx_base == 1, FD_ERR_ARG, "idx_base must be 0 or 1");
+    FD_REQUIRE(color_bytes == 4 || color_bytes == 8, FD_ERR_ARG, "color_bytes must be 4 or 8");
+    int rc = new_plan(ctx, K_CSC, M, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    // the two colptr values that bound the local columns
+    int64_t cp[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        const int64_t j = k ? p->col1 : p->col0;
+        int64_t v64 = 0;
+        int32_t v32 = 0;
+        hipError_t e = idx_bytes == 8 ? hipMemcpy(&v64, (const char *)colptr_dev + 8 * (size_t)j, 8, hipMemcpyDeviceToHost)
+                                      : hipMemcpy(&v32, (const char *)colptr_dev + 4 * (size_t)j, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("reading colptr from the device failed: %s", hipGetErrorString(e)); fd_plan_destroy(p); *out = nullptr; return FD_ERR_HIP; }
+        cp[k] = (idx_bytes == 8 ? v64 : (int64_t)v32) - idx_base;
+    }
+    if (!(cp[0] >= 0 && cp[1] >= cp[0])) { set_error("colptr is not monotone"); fd_plan_destroy(p); *out = nullptr; return FD_ERR_SHAPE; }
+    p->entry_begin = cp[0];
+    int brc = FD_OK;
+    const char *pd = getenv("FDJAC_PLAN_DEVICE");
+    int res = (pd && *pd && atoi(pd) == 0) ? (int)PBR_DECLINED
+                                           : device_build_csc(p, colptr_dev, rowval_dev, idx_bytes, idx_base, colorvec_dev, color_bytes, cp[0], cp[1], &brc);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+    if (res == PBR_DONE) {
+        if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
+        p->nouts = 1;
+        p->out_len[0] = cp[1] - cp[0];
+        return FD_OK;
+    }
+    // declined (scattered pattern, many colours, forced variants): bring the pattern to the host once and build there
+    fd_plan_destroy(p);
+    *out = nullptr;
+    const size_t ib = (size_t)idx_bytes;
+    std::vector<char> h_cp(ib * (size_t)(N + 1)), h_cv((size_t)color_bytes * (size_t)N);
+    FD_HIP_CHECK(hipMemcpy(h_cp.data(), colptr_dev, h_cp.size(), hipMemcpyDeviceToHost));
+    FD_HIP_CHECK(hipMemcpy(h_cv.data(), colorvec_dev, h_cv.size(), hipMemcpyDeviceToHost));
+    const int64_t nnz_all = load_idx(h_cp.data(), idx_bytes, N) - idx_base;
+    FD_REQUIRE(nnz_all >= 0, FD_ERR_SHAPE, "colptr is not monotone");
+    std::vector<char> h_rv(ib * (size_t)std::max<int64_t>(nnz_all, 1));
+    if (nnz_all > 0) FD_HIP_CHECK(hipMemcpy(h_rv.data(), rowval_dev, ib * (size_t)nnz_all, hipMemcpyDeviceToHost));
+    return csc_common(ctx, K_CSC, M, N, h_cp.data(), h_rv.data(), idx_bytes, idx_base, h_cv.data(), color_bytes, opts, out);
+}
+
+// FNV-1a over the plan's compiled pattern (device arrays copied back) and its scalar parameters: two plans with the
+// same checksum drive the kernels identically.  Diagnostic / test entry point (the device builder is checked against
+// the host builder with it).
+int fd_plan_checksum(fd_plan *p, uint64_t *out)
+{
+    FD_REQUIRE(p && out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *data, size_t n) {
+        const unsigned char *b = (const unsigned char *)data;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    auto mix_dev = [&](const void *d, size_t n) -> int {
+        if (!d || !n) return FD_OK;
+        std::vector<char> tmp(n);
+        FD_HIP_CHECK(hipMemcpy(tmp.data(), d, n, hipMemcpyDeviceToHost));
+        mix(tmp.data(), n);
+        return FD_OK;
+    };
+    const int64_t scal[] = {p->kind, p->fdtype, p->M, p->N, p->C, p->color8, p->col0, p->col1, p->row0, p->row1, p->nnz_local,
+                            p->entry_begin, p->window, p->window2d, p->sorted_gather, p->win_tile, p->win_pairs, p->win_ncol,
+                            p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
+                            p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6)};
+    mix(scal, sizeof scal);
+    int rc;
+    if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
+    if (p->window && !p->window2d) {
+        const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
+        if ((rc = mix_dev(p->d_wtiles, sizeof(int4) * 3 * (padded / (size_t)p->win_tile)))) return rc;
+        if ((rc = mix_dev(p->d_wcode, sizeof(uint16_t) * padded))) return rc;
+    }
+    *out = h;
+    return FD_OK;
 }
 
 int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
@@ -1188,6 +1323,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
+    case FD_INFO_BUILT_ON_DEVICE: *value = p->built_on_device ? 1 : 0; break;
     case FD_INFO_STRIPS: *value = (p->window && !p->window2d && p->nchunks == 1) ? p->strips : 1; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
@@ -1309,6 +1445,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
 
     // x must be 16-B aligned for the vector loads; stage it otherwise
     if (((uintptr_t)x_dev) & kPairMask) {
+        { const int rc = ensure_stage(p, true, false); if (rc) return rc; }
         FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x_dev, sizeof(real_t) * (size_t)p->N, hipMemcpyDeviceToDevice, s));
         x_dev = p->d_xstage;
     }
@@ -1325,6 +1462,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     const bool small_points = small && !p->lazy_fn && p->nchunks == 1 && full_colors;   // points written by the fused launch
     const bool base_in_batch = small_points && p->fdtype == FD_FORWARD && !fin_dev;
     p->fx_batch_row = nullptr;
+    if (small_points) { const int rc = ensure_points(p); if (rc) return rc; }
 
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
@@ -1463,6 +1601,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 p->fcalls_last += 1;
                 base_pending = false;
             }
+            { const int rc = ensure_points(p); if (rc) return rc; }
             if (!small_points) {
                 Span sp(p, FD_STAGE_PERTURB);
                 int rc = launch_perturb(p, x_dev, c_lo, B);
@@ -1505,6 +1644,7 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
     const real_t *x_dev = (const real_t *)x;
+    { const int rc = ensure_stage(p, x_kind == FD_HOST, f_in && f_in_kind == FD_HOST); if (rc) return rc; }
     if (x_kind == FD_HOST) {
         FD_HIP_CHECK(hipMemcpyAsync(p->d_xstage, x, sizeof(real_t) * (size_t)p->N, hipMemcpyHostToDevice, s));
         x_dev = p->d_xstage;

@@ -13,6 +13,8 @@
 #define fd_plan fd32_plan
 #define fd_jvp_plan fd32_jvp_plan
 #define fd_plan_create_csc fd32_plan_create_csc
+#define fd_plan_create_csc_device fd32_plan_create_csc_device
+#define fd_plan_checksum fd32_plan_checksum
 #define fd_plan_create_csc_dense fd32_plan_create_csc_dense
 #define fd_plan_create_coo_dense fd32_plan_create_coo_dense
 #define fd_plan_create_entries fd32_plan_create_entries
@@ -172,6 +174,7 @@ struct fd_plan {
     bool sorted_gather = false;
     uint16_t *d_spos = nullptr;    //   local output position (within the tile) of each sorted entry
     bool has_none = false;         //   some column has no colour (its entries are written as 0)
+    bool built_on_device = false;  // the pattern was compiled by the device builder (fdjac_planbuild.hip), not the host loops
     double lines_direct = 0, lines_sorted = 0;  // plan-time estimate: distinct 128-B lines per wave gather
     // row-window variant (locally banded patterns): per tile of kSortTile entries the rows fall into a
     // short window and few colours, so the f! values are loaded DENSELY into LDS and gathered from there

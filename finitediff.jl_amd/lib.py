@@ -25,7 +25,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN,
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, INFO_LDS_DMA,
- INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS) = range(27)
+ INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE) = range(28)
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
             "blockcoupled": F_BLOCKCOUPLED, "nonsquare": F_NONSQUARE, "lap5_nl": F_LAP5_NL}
@@ -66,7 +66,7 @@ EXPORTS = (
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
-    "fd_tridiag_solve_finish",
+    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum",
 )
 
 
@@ -80,7 +80,7 @@ TYPED = (
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
-    "fd_tridiag_solve_finish",
+    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -150,6 +150,8 @@ def load():
     L.fd_ctx_synchronize.argtypes = [vp]
     po = C.POINTER(PlanOpts)
     L.fd_plan_create_csc.argtypes = [vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_csc_device.argtypes = [vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_checksum.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.fd_plan_create_csc_dense.argtypes = [vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
     L.fd_plan_create_coo_dense.argtypes = [vp, i64, i64, vp, vp, i64, i32, i32, vp, i32, po, pp]
     L.fd_plan_create_entries.argtypes = [vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp, i32, po, pp]

@@ -147,6 +147,15 @@ int fd_version(void);
 int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
                        int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                        const fd_plan_opts *opts, fd_plan **out);
+/* The same plan from a pattern that ALREADY LIVES ON THE DEVICE (e.g. the colPtr / rowVal of a device sparse matrix and a
+   device colour vector, the caller's index width and base): the plan is compiled by kernels, nothing crosses PCIe
+   (fdjac_planbuild.hip).  Patterns the device builder does not handle are copied to the host once and built there. */
+int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
+                              int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
+                              const fd_plan_opts *opts, fd_plan **out);
+/* FNV-1a checksum of the plan's compiled pattern (diagnostic: equal checksums <=> the kernels are driven identically;
+   the device plan builder is tested against the host builder with it). */
+int fd_plan_checksum(fd_plan *plan, uint64_t *checksum_out);
 /* SparseMatrixCSC sparsity, dense column-major J (M x N): outs[0] = J. */
 int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr,
                              const void *rowval, int idx_bytes, int idx_base, const void *colorvec,
@@ -207,6 +216,7 @@ enum fd_plan_info_key {
     FD_INFO_LDS_DMA = 23,             /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
     FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
+    FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
     FD_INFO_STRIPS = 26               /* row strips per Jacobian the plan would use with a FD_LAZY_CAP_ROW_WINDOW launcher (1 = none) */
 };
 /* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
@@ -409,6 +419,10 @@ typedef struct fd32_jvp_plan fd32_jvp_plan;
 int fd32_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval,
                        int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                        const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
+                                int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
+                                const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_checksum(fd32_plan *plan, uint64_t *checksum_out);
 int fd32_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr,
                              const void *rowval, int idx_bytes, int idx_base, const void *colorvec,
                              int color_bytes, const fd_plan_opts *opts, fd32_plan **out);

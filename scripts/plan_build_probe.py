@@ -24,6 +24,17 @@ for N in (10 ** 6, 10 ** 7):
     J = fd.SparseMatrixCSC(N, N, cp, rv, None)
     timed("tridiagonal CSC N=%d" % N, lambda: fd.make_plan(J, J, colors, "forward"))
     timed("tridiagonal CSC N=%d (again)" % N, lambda: fd.make_plan(J, J, colors, "forward"))
+    os.environ["FDJAC_PLAN_DEVICE"] = "0"
+    timed("tridiagonal CSC N=%d, host builder" % N, lambda: fd.make_plan(J, J, colors, "forward"))
+    del os.environ["FDJAC_PLAN_DEVICE"]
+    import torch
+    dcp, drv, dcv = torch.as_tensor(cp, device="cuda"), torch.as_tensor(rv, device="cuda"), torch.as_tensor(colors, device="cuda")
+    torch.cuda.synchronize()
+    timed("tridiagonal CSC N=%d, pattern on the device (Int64)" % N, lambda: fd.make_plan_csc_device(N, N, dcp, drv, dcv, "forward"))
+    timed("tridiagonal CSC N=%d, pattern on the device (again)" % N, lambda: fd.make_plan_csc_device(N, N, dcp, drv, dcv, "forward"))
+    d32 = [torch.as_tensor((a - 1).astype(np.int32), device="cuda") for a in (cp, rv)] + [torch.as_tensor(colors.astype(np.int32), device="cuda")]
+    torch.cuda.synchronize()
+    timed("tridiagonal CSC N=%d, pattern on the device (Int32)" % N, lambda: fd.make_plan_csc_device(N, N, d32[0], d32[1], d32[2], "forward", idx_base=0))
     timed("Tridiagonal N=%d" % N, lambda: fd.make_plan(fd.Tridiagonal(None, np.empty(N), None), None, colors, "forward"))
     timed("BandedMatrix (1,1) N=%d" % N, lambda: fd.make_plan(fd.BandedMatrix(None, N, 1, 1), None, colors, "forward"))
 nx, ny = 4000, 2500
