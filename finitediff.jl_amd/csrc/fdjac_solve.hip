@@ -14,7 +14,8 @@
 // back-substituted: a thread re-reads its chunk's original rows and solves them with the two now-known boundary
 // values.  No pivoting: the method is for diagonally dominant systems (I - gamma*J of a diffusion-type J), like the
 // partitioned / cyclic-reduction tridiagonal solvers of the vendor libraries.  Level 0 reads the user's J and b once
-// in the reduction and once in the back-substitution (9 values per row in total + 1 written).
+// in the reduction and once in the back-substitution (9 values per row in total + 1 written).  Measured at N = 10^7 on
+// MI355X: 0.38 ms (Tridiagonal diagonals) / 0.44 ms (CSC nzval) per solve, 11 launches.
 //
 // Multi-GPU (rows = the rank's column range): the rank's block T_r of the matrix is complete in its own slice; the two
 // couplings to the neighbouring ranks are not (they live in the neighbours' columns).  SPIKE form:
@@ -89,6 +90,30 @@ struct SrcUser {
         r.d[2] = (NRHS > 1 && i == n - 1) ? 1.0 : 0.0;       // e_last
         return r;
     }
+    template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t i) const { return load<NRHS>(i); }
+    static constexpr bool kUnitRhs = true;    // right-hand sides 1, 2 are the unit vectors e_first, e_last: not fetched
+    // one coefficient of local row i: which = 0 a, 1 b, 2 c, 3 right-hand side
+    __device__ __forceinline__ double value(int which, int64_t i) const
+    {
+        const int64_t gi = g0 + i;
+        if (which == 3) {
+            double d0 = (double)rhs[i];
+            if (adj) {
+                if (i == 0) d0 -= adj[0];
+                if (i == n - 1) d0 -= adj[1];
+            }
+            return d0;
+        }
+        if (layout == FD_TRI_DIAGONALS) {
+            const int64_t du0 = g0 > 0 ? g0 - 1 : 0;
+            if (which == 1) return alpha + beta * (double)p1[i];
+            if (which == 0) return i > 0 ? beta * (double)p0[i - 1] : 0.0;
+            return i + 1 < n ? beta * (double)p2[gi - du0] : 0.0;
+        }
+        if (which == 1) return alpha + beta * (double)p0[3 * gi - e0];
+        if (which == 0) return i > 0 ? beta * (double)p0[3 * gi - 2 - e0] : 0.0;
+        return i + 1 < n ? beta * (double)p0[3 * gi + 2 - e0] : 0.0;
+    }
 };
 
 // level >= 1: the reduced system defined by the chunk summaries of the level below
@@ -114,21 +139,32 @@ struct SrcLevel {
         }
         return r;
     }
+    template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t k) const { return load<NRHS>(k); }
+    static constexpr bool kUnitRhs = false;
+    // one coefficient of row k: which = 0 a, 1 b, 2 c, 3 + q right-hand side q (lane-consecutive k: dense loads)
+    __device__ __forceinline__ double value(int which, int64_t k) const
+    {
+        if (which == 0) return sum[0 * nc + k];
+        const bool nxt = k + 1 < nc;
+        const double t = nxt ? sum[2 * nc + k] / sum[7 * nc + k + 1] : 0.0;
+        if (which == 1) return sum[1 * nc + k] - (nxt ? t * sum[6 * nc + k + 1] : 0.0);
+        if (which == 2) return nxt ? -t * sum[8 * nc + k + 1] : 0.0;
+        const int q = which - 3;
+        return sum[(3 + q) * nc + k] - (nxt ? t * sum[(9 + q) * nc + k + 1] : 0.0);
+    }
 };
 
 // One chunk's two elimination sweeps -> its summary (the row it contributes to the next level).
 template <typename Src, int NRHS>
-__global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, double *__restrict__ sum, int64_t nc)
+__device__ __forceinline__ void tri_reduce_chunk(const Src &src, int64_t n, double *__restrict__ sum, int64_t nc, int64_t k)
 {
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= nc) return;
     const int64_t s = k * kChunk;
     const int m = (int)((n - s < kChunk) ? n - s : kChunk);
     double f[kChunk], b[kChunk], c[kChunk], d[kChunk][NRHS];
 #pragma unroll
     for (int i = 0; i < kChunk; ++i) {
         if (i < m) {
-            const TriRow r = src.template load<NRHS>(s + i);
+            const TriRow r = src.template loadl<NRHS>(i, s + i);
             f[i] = r.a; b[i] = r.b; c[i] = r.c;
 #pragma unroll
             for (int q = 0; q < NRHS; ++q) d[i][q] = r.d[q];
@@ -170,7 +206,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
     sum[1 * nc + k] = be;
     sum[2 * nc + k] = ce;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) sum[(3 + q) * nc + k] = q < NRHS ? de[q < NRHS ? q : 0] : 0.0;
+    for (int q = 0; q < NRHS; ++q) sum[(3 + q) * nc + k] = de[q];      // (right-hand sides beyond NRHS are never read)
     // upward: the first row expressed through the unknown before the chunk (f) and the chunk's last unknown (g)
 #pragma unroll
     for (int i = kChunk - 3; i >= 0; --i)
@@ -186,7 +222,64 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
     sum[7 * nc + k] = cb;
     sum[8 * nc + k] = cg;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) sum[(9 + q) * nc + k] = q < NRHS ? cd[q < NRHS ? q : 0] : 0.0;
+    for (int q = 0; q < NRHS; ++q) sum[(9 + q) * nc + k] = cd[q];
+}
+// Rows through LDS, one coefficient array at a time.  A thread walks kChunk CONSECUTIVE rows; loading them directly makes
+// every wave instruction touch 64 different cache lines and re-fetch each line up to 8 times from the L2 (measured: 1.7
+// TB/s at level 0).  Instead the workgroup fetches one coefficient array of its tile of kBlock * kChunk rows with
+// lane-consecutive loads, parks it in LDS at index r + r/8 (a thread's rows then start 9 doubles apart: conflict-free
+// 8-byte reads), every thread copies its kChunk values to registers, and the same 18 KB of LDS serve the next array --
+// 3 + NRHS rounds (a, b, c, right-hand sides), full occupancy.  Tridiagonal diagonals and the chunk summaries of the
+// inner levels are read densely; the nzval of a tridiagonal CSC with stride 3 (each line three times).
+constexpr int kTriTileRows = kBlock * kChunk;                    // 2048 rows
+constexpr int kTriPitch = kTriTileRows + kTriTileRows / 8;       // padded
+template <int NRHS> struct SrcRegs {
+    double a[kChunk], b[kChunk], c[kChunk], d[NRHS][kChunk];
+    template <int N2> __device__ __forceinline__ TriRow loadl(int li, int64_t) const
+    {
+        TriRow t;
+        t.a = a[li]; t.b = b[li]; t.c = c[li];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t.d[q] = q < NRHS ? d[q < NRHS ? q : 0][li] : 0.0;
+        return t;
+    }
+};
+template <typename Src, int NRHS>
+__device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+{
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    constexpr int kRounds = Src::kUnitRhs ? 4 : 3 + NRHS;
+#pragma unroll
+    for (int which = 0; which < kRounds; ++which) {
+        if (which) __syncthreads();                       // the previous array has been copied out
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int r = j * kBlock + (int)threadIdx.x;  // lane-consecutive rows
+            if (r < rows) lds[r + (r >> 3)] = src.value(which, row0 + r);
+        }
+        __syncthreads();
+        double *dst = which == 0 ? R.a : which == 1 ? R.b : which == 2 ? R.c : R.d[which - 3 < NRHS ? which - 3 : 0];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) dst[q] = lds[9 * (int)threadIdx.x + q];   // rows 8t .. 8t+7 sit at 9t + q
+    }
+    if (Src::kUnitRhs && NRHS > 1) {                      // level 0: right-hand sides 1, 2 are e_first, e_last
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int64_t i = row0 + (int64_t)threadIdx.x * kChunk + q;
+            R.d[NRHS > 1 ? 1 : 0][q] = i == 0 ? 1.0 : 0.0;
+            R.d[NRHS > 2 ? 2 : 0][q] = i == n - 1 ? 1.0 : 0.0;
+        }
+    }
+}
+template <typename Src, int NRHS>
+__global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, double *__restrict__ sum, int64_t nc)
+{
+    __shared__ double lds[kTriPitch];
+    SrcRegs<NRHS> R;
+    tri_fetch_rows<Src, NRHS>(src, n, (int64_t)blockIdx.x * kTriTileRows, lds, R);
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nc) return;
+    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
 }
 
 // The top level (n <= kTop): parallel cyclic reduction in LDS, NRHS right-hand sides.  sol[q * n + i].
@@ -224,12 +317,18 @@ __global__ void __launch_bounds__(kBlock) k_tri_top(Src src, int n, double *__re
 
 // Back-substitution of one level (1 right-hand side): z = solution of the level above (the chunks' last unknowns).
 // OutT: double for the internal levels, real_t for level 0 (the caller's y).
-template <typename Src, typename OutT>
-__global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, const double *__restrict__ z, int64_t nc,
-                                                        OutT *__restrict__ y)
+template <typename T> struct TriGlobalOut {
+    T *y;
+    __device__ __forceinline__ void put(int64_t i, double v) const { y[i] = (T)v; }
+};
+struct TriLdsOut {
+    double *sd;
+    int64_t row0;
+    __device__ __forceinline__ void put(int64_t i, double v) const { const int r = (int)(i - row0); sd[r + (r >> 3)] = v; }
+};
+template <typename Src, typename Out>
+__device__ __forceinline__ void tri_backsub_chunk(const Src &src, int64_t n, const double *__restrict__ z, int64_t k, const Out &y)
 {
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= nc) return;
     const int64_t s = k * kChunk;
     const int m = (int)((n - s < kChunk) ? n - s : kChunk);
     const double zl = k > 0 ? z[k - 1] : 0.0, zr = z[k];
@@ -238,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, cons
 #pragma unroll
     for (int i = 0; i < kChunk - 1; ++i)
         if (i < m - 1) {
-            const TriRow r = src.template load<1>(s + i);
+            const TriRow r = src.template loadl<1>(i, s + i);
             double di = r.d[0];
             if (i == 0) di -= r.a * zl;
             if (i == m - 2) di -= r.c * zr;
@@ -252,13 +351,33 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, cons
             }
         }
     double yn = zr;
-    y[s + m - 1] = (OutT)zr;
+    y.put(s + m - 1, zr);
 #pragma unroll
     for (int i = kChunk - 2; i >= 0; --i)
         if (i < m - 1) {
             yn = (i == m - 2) ? dp[i] : dp[i] - cp[i] * yn;
-            y[s + i] = (OutT)yn;
+            y.put(s + i, yn);
         }
+}
+// rows fetched through LDS (see k_tri_reduce); the solution leaves through LDS too, with dense stores
+template <typename Src, typename OutT>
+__global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, const double *__restrict__ z, int64_t nc,
+                                                        OutT *__restrict__ y)
+{
+    __shared__ double lds[kTriPitch];
+    const int64_t row0 = (int64_t)blockIdx.x * kTriTileRows;
+    SrcRegs<1> R;
+    tri_fetch_rows<Src, 1>(src, n, row0, lds, R);
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    __syncthreads();                                      // every thread has copied the last array out of LDS
+    if (k < nc) tri_backsub_chunk(R, n, z, k, TriLdsOut{lds, row0});
+    __syncthreads();
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        const int r = j * kBlock + (int)threadIdx.x;
+        if (r < rows) y[row0 + r] = (OutT)lds[r + (r >> 3)];
+    }
 }
 
 // Phase A epilogue: the six tip values (first / last local row of g, v, w).  The last row is the last unknown of every
