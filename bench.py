@@ -131,6 +131,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the result JSON: RCCL prints a version banner on stdout when a communicator is
+    # created, so with several ranks everything else this process (and the libraries under it) writes to fd 1 goes to stderr
+    # and the JSON line is written to the saved descriptor
+    json_fd = None
+    if world > 1:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -522,8 +530,12 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n or N, args.cpu_reps, args.cpu_seconds)
             except Exception as e:  # pragma: no cover
                 res["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(res))
-        sys.stdout.flush()
+        line = json.dumps(res) + "\n"
+        if json_fd is not None:
+            os.write(json_fd, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
 
     # ---- untimed soak: keep the GPU in the steady-state loop long enough for an external sampler to see it ------------
     if args.soak_seconds > 0:
@@ -534,6 +546,10 @@ def main():
             torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize()
+        del enqueue, plan                 # release in dependency order: plans, then the communicator, then torch's group
+        if comm is not None:
+            comm._fin()
         dist.destroy_process_group()
     if not check["ok"]:
         raise SystemExit("bench.py: result check FAILED: %s" % json.dumps(check))

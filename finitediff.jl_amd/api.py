@@ -746,6 +746,11 @@ class JacobianCache:
         if self.fdtype == "complex" and np.dtype(returntype).kind == "c":
             # fdtype_error(returntype), src/jacobians.jl:106
             raise ValueError("Unrecognized fdtype: valid values are Val{:forward} or Val{:central}.")
+        if np.dtype(returntype).kind == "c" or (_dtype_of(x1) is None and hasattr(x1, "dtype") and "complex" in str(x1.dtype)):
+            # complex-valued x / f with forward or central differences (src/jacobians.jl:94-128, src/epsilons.jl:26-29 with
+            # abs): not built on the device -- FD_ERR_UNSUPPORTED territory, said loudly instead of computing something else
+            raise _l.FdError(3, "complex-valued x / returntype with forward or central differences is not built "
+                                "(FD_ERR_UNSUPPORTED); the complex-step arm on real x is")
         self.x1 = x1
         self.x2 = None
         self.fx = fx if fx is not None else x1

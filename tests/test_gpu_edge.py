@@ -286,3 +286,50 @@ def test_bound_call_matches_and_validates():
         plan.bind(f, x.cpu().numpy(), [out])
     with pytest.raises(TypeError):
         plan.bind(fd.BuiltinF("tridiag_nl", N, dtype=np.float32), x, [out])
+
+
+def test_complex_valued_x_is_refused_not_miscomputed():
+    # returntype <: Complex with forward / central differences (src/jacobians.jl:94-128; src/epsilons.jl:26-29 takes abs):
+    # not built on the device.  The host mirror says FD_ERR_UNSUPPORTED instead of silently treating the data as real.
+    N = 12
+    xc = torch.ones(N, dtype=torch.complex128, device="cuda")
+    for fdtype in ("forward", "central"):
+        with pytest.raises(fd.lib.FdError) as e:
+            fd.JacobianCache(xc, fdtype, np.complex128, colorvec=P.cyclic_colors(N, 3))
+        assert e.value.code == 3
+    with pytest.raises(ValueError):     # Val(:complex) with a complex returntype: fdtype_error, as the reference (src/jacobians.jl:106)
+        fd.JacobianCache(_dev(np.ones(N)), "complex", np.complex128)
+
+
+def test_hip_error_left_behind_by_a_launcher_is_reported():
+    # A launcher that provokes a HIP error and does NOT report it (returns 0): the library's launch checks pick the error up
+    # and the call returns FD_ERR_HIP instead of FD_OK.  (A genuine device fault -- an out-of-bounds write inside a user
+    # kernel -- is fatal to the process on this platform and cannot be turned into a status code by anyone.)
+    import ctypes as C
+    N = 5000
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv)
+    plan = fd.make_plan(J, J, P.cyclic_colors(N, 3), "forward")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    good = fd.BuiltinF("tridiag", N)
+
+    class Sloppy:
+        dtype = np.float64
+        fctx = good.fctx
+        error = None
+
+        def __init__(self):
+            def launch(fctx, fx, x, nbatch, xs, fs, r0, r1, is_complex, stream):
+                rc = good.fn(fctx, fx, x, nbatch, xs, fs, r0, r1, is_complex, stream)
+                hip.hipMemsetAsync(None, 0, 1 << 40, stream)     # invalid: leaves hipErrorInvalidValue behind
+                return rc                                         # ... and does not tell anybody
+            self.fn = fd.lib.F_LAUNCH(launch)
+
+    out = _dev(np.full(plan.out_len(0), np.nan))
+    with pytest.raises(fd.lib.FdError) as e:
+        plan.jacobian(Sloppy(), _dev(np.ones(N)), [out])
+    assert e.value.code == 4 and "invalid" in str(e.value).lower()          # FD_ERR_HIP with the HIP error text
+    plan.ctx.synchronize()
+    plan.jacobian(good, _dev(np.ones(N)), [out])                            # the plan / context stay usable
+    assert not torch.isnan(out).any()
