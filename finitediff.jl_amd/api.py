@@ -741,6 +741,8 @@ class JacobianCache:
             fdtype, fx = fx, None
         if isinstance(fx1, str):  # JacobianCache(x, fx, fdtype, ...)
             fdtype, fx1 = fx1, None
+        if isinstance(fx1, (type, np.dtype)):  # JacobianCache(x, fdtype, returntype): the reference's positional order
+            returntype, fx1 = fx1, None
         self.fdtype = _norm_fdtype(fdtype)
         self.returntype = returntype
         if self.fdtype == "complex" and np.dtype(returntype).kind == "c":
