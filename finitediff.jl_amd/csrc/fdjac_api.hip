@@ -427,7 +427,10 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
             const int force_t = (ft && *ft) ? atoi(ft) : 0;
             // fewer than ~24 tiles of 2048 entries per CU: the half-size tile balances the launch better (tridiagonal
             // forward, same process: N = 10^6 14.6 -> 13.5 us, N = 3*10^6 30.7 -> 30.0 us, N = 10^7 equal)
-            const bool prefer_small = p->nnz_local < (int64_t)2048 * 24 * std::max(p->ctx->num_cus, 1);
+            // round 2, N = 10^7 as well (two boxes, separate processes, 40 steps each: 111.8 / 113.2 us with 2048-entry tiles,
+            // 109.4 / 108.7 us with 1024; profiles/r02_d_win_ab.txt): the half-size tile is the default at every size,
+            // the 2048-entry tile remains for FDJAC_WIN_TILE=2048
+            const bool prefer_small = true;
             for (int T : {2048, 1024, 512}) {
                 if (force_t && T != force_t) continue;
                 if (!force_t && T == 2048 && prefer_small) continue;
