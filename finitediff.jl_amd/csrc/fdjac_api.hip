@@ -505,6 +505,96 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
     return FD_OK;
 }
 
+// Rolling row windows (k_decompress_roll) for 2-D stencil patterns in natural ordering (stride s between grid rows).
+// The 2-D tiles below load (R+2)(L+2)/(RL) = 1.4 values per stored f! value in short, line-straddling segments and are
+// bound by the request rate between the CUs and the L2, not by HBM.  Here ONE WAVE owns a column strip
+// of L = 128 - 2*hl columns and walks H grid rows down it: per grid row it loads one 1-KiB-aligned-ish window of every
+// f! array (64 lanes x one 16-B pair: a single dense request per array), keeps the differences of the last four rows in an
+// LDS ring, and emits the entries of row g from the rows g-1, g, g+1 -- every value is loaded (H+2)/H * 128/L = 1.08 times,
+// the loads of row g+2 are in flight while row g is emitted, and there is no barrier between waves.  Entries are addressed
+// by 16-bit codes as in the other window kernels: bits 0-6 offset in the window row, bits 7-8 row (g-1, g, g+1), bits 11-13
+// colour.  Segments are sized so that the whole launch is ONE round of resident waves.
+// Requirements: the whole matrix (no column window), even stride, every entry inside the three windows of its column's
+// strip; otherwise the 2-D tiles take over.
+static int try_roll_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc,
+                         const std::vector<int64_t> &colstart, int64_t s, int halo, int ecmax)
+{
+    int rc;
+    // Opt-in (FDJAC_ROLL=1): on MI355X the rolling kernel measured 302 us on the 4000x2500 5-point pattern against 267-281 us
+    // for the 2-D tiles it would replace (profiles/r02_d_win_ab.txt), so the tiles stay the default.
+    const char *fr = getenv("FDJAC_ROLL");
+    if (!(fr && *fr && atoi(fr) != 0)) return FD_OK;
+    if (p->col0 != 0 || p->col1 != p->N || (s & 1) || p->nnz_local <= 0) return FD_OK;
+    const int hl = std::max(2, (halo + 1) & ~1);
+    if (hl > 16) return FD_OK;
+    const int L = kRollW - 2 * hl;
+    if ((int64_t)ecmax * L + 2 > kRollMaxCodes) return FD_OK;
+    int32_t cmin = std::numeric_limits<int32_t>::max(), cmax = -1;
+    for (int64_t e = 0; e < p->nnz_local; ++e)
+        if (nzc[(size_t)e] >= 0) { cmin = std::min(cmin, nzc[(size_t)e]); cmax = std::max(cmax, nzc[(size_t)e]); }
+    if (cmax < 0 || cmax - cmin + 1 > kWinMaxCol) return FD_OK;
+    const int ncol = cmax - cmin + 1;
+    const int64_t nG = (p->N + s - 1) / s, nI = (s + L - 1) / L;
+    // one round of resident waves: LDS ring of 4 rows x ncol colours x 128 values per wave
+    const size_t lds_wave = sizeof(real_t) * (size_t)(4 * ncol * kRollW + kWinMaxCol);
+    const int64_t wpc = std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(150 * 1024) / (int64_t)lds_wave));
+    const int64_t resident = (int64_t)std::max(p->ctx->num_cus, 1) * wpc;
+    const char *fh = getenv("FDJAC_ROLL_H");
+    int64_t H = (fh && *fh) ? atoll(fh) : (nG * nI + resident - 1) / resident;
+    H = std::max<int64_t>(H, 4);
+    const int64_t nS = (nG + H - 1) / H;
+    std::vector<int> segs, runs;
+    std::vector<uint16_t> code;
+    segs.reserve((size_t)(nS * nI) * 4);
+    runs.reserve((size_t)(nG * nI) * 6);
+    code.reserve((size_t)p->nnz_local + (size_t)(nG * nI) * 2 + 8);
+    int64_t covered = 0;
+    for (int64_t S = 0; S < nS; ++S)
+        for (int64_t I = 0; I < nI; ++I) {
+            const int64_t ga = S * H, gb = std::min<int64_t>((S + 1) * H, nG);
+            segs.push_back((int)I); segs.push_back((int)ga); segs.push_back((int)gb); segs.push_back((int)(runs.size() / 6));
+            for (int64_t g = ga; g < gb; ++g) {
+                const int64_t ka = std::min<int64_t>(g * s + I * L, p->N), kb = std::min<int64_t>(std::min<int64_t>(g * s + (I + 1) * L, (g + 1) * s), p->N);
+                const int64_t a = ka < kb ? colstart[(size_t)ka] : 0, b = ka < kb ? colstart[(size_t)kb] : 0;
+                const int64_t pbase = a & ~(int64_t)1, code0 = (int64_t)code.size();
+                if (a & 1) code.push_back(0x8000);                    // code slot parity == output parity: 16-B pairs
+                for (int64_t e = a; e < b; ++e) {
+                    uint16_t c = 0x8000;
+                    if (nzc[(size_t)e] == -1) c = 0x4000;
+                    else if (nzc[(size_t)e] >= 0) {
+                        const int64_t w = (int64_t)rows[(size_t)e] - (I * L - hl);       // element index relative to the strip's window column 0
+                        const int64_t gr = w >= 0 ? w / s : -((-w + s - 1) / s);          // floor
+                        const int64_t off = w - gr * s, rr = gr - (g - 1);
+                        if (rr < 0 || rr > 2 || off < 0 || off >= kRollW) return FD_OK;   // not a 3-row stencil of this strip
+                        c = (uint16_t)((rr * kRollW + off) | ((nzc[(size_t)e] - cmin) << 11));
+                    }
+                    code.push_back(c);
+                }
+                if ((code.size() - (size_t)code0) & 1) code.push_back(0x8000);
+                const int64_t nent = (int64_t)code.size() - code0;
+                if (nent > kRollMaxCodes) return FD_OK;
+                runs.push_back((int)(uint32_t)(pbase & 0xFFFFFFFFll)); runs.push_back((int)(pbase >> 32));
+                runs.push_back((int)(uint32_t)(code0 & 0xFFFFFFFFll)); runs.push_back((int)(code0 >> 32));
+                runs.push_back((int)nent); runs.push_back(0);
+                covered += b - a;
+            }
+        }
+    if (covered != p->nnz_local) return FD_OK;
+    code.push_back(0x8000); code.push_back(0x8000);
+    p->window = true;
+    p->window2d = true;      // (a 2-D stencil plan: FD_INFO_WINDOW2D; FD_INFO_ROLL tells the two kernels apart)
+    p->roll = true;
+    p->roll_nseg = nS * nI; p->roll_s = s; p->roll_L = L; p->roll_hl = hl; p->roll_cmin = cmin; p->roll_ncol = ncol; p->roll_H = (int)H;
+    p->win_tile = 0;
+    p->win_pairs = kRollW / 2;
+    p->win_ncol = ncol;
+    p->win_overread = ((double)(H + 2) / (double)H) * ((double)kRollW / (double)L) * (double)p->N * ncol / (double)std::max<int64_t>(p->nnz_local, 1);
+    if ((rc = dev_upload(&p->d_rseg, segs))) return rc;
+    if ((rc = dev_upload(&p->d_rrun, runs))) return rc;
+    if ((rc = dev_upload(&p->d_wcode, code))) return rc;
+    return FD_OK;
+}
+
 // 2-D (strided) tiles for the row-window kernel (k_decompress_window2d): 2-D stencil patterns in natural ordering.
 // Detection: apart from a few near-diagonal offsets (|row - col| <= 8) every entry sits one "stride" s away from the
 // diagonal (within +-4), the same s for (almost) the whole pattern, s >= 64.  Tiles are then R consecutive grid rows
@@ -550,6 +640,8 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
         }
         if (bad * 1000 > total || ecmax < 1 || ecmax > 32) return FD_OK;   // > 0.1 % of the entries off-stride
     }
+    if ((rc = try_roll_plan(p, rows, nzc, colstart, s, halo, ecmax))) return rc;
+    if (p->roll) return FD_OK;
     const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
     // default shape: 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as
     // keep the window pairs of a tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same
@@ -847,7 +939,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_rseg, p->d_rrun, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
     for (void *q : ptrs)
@@ -1326,6 +1418,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
+    case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
     case FD_INFO_BUILT_ON_DEVICE: *value = p->built_on_device ? 1 : 0; break;
     case FD_INFO_STRIPS: *value = (p->window && !p->window2d && p->nchunks == 1) ? p->strips : 1; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;

@@ -119,6 +119,8 @@ constexpr double kWinMaxOverread = 4.0;  // and this many f! values loaded per s
 constexpr int kW2Desc = 64;          // ints per tile descriptor
 constexpr int kW2MaxWin = 12;        // row windows per tile
 constexpr int kW2MaxRun = 8;         // column runs per tile
+constexpr int kRollW = 128;          // rolling row windows: elements per window row (64 lanes x one pair)
+constexpr int kRollMaxCodes = 1024;  //   codes of one (strip, grid row) run: 8 rounds of 128
 
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
@@ -181,6 +183,11 @@ struct fd_plan {
     bool window = false;
     int4 *d_wtiles = nullptr;      //   3 x int4 per tile: {first colour, colours, row pairs, windows}, 4 x {first row, end pair}
     int win_tile = 0;              //   entries per tile (2048 or 1024)
+    bool roll = false;             //   rolling row windows (k_decompress_roll): 2-D stencils, one wave walks a column strip
+    int *d_rseg = nullptr;         //     4 ints per segment: strip, first grid row, end grid row, first run
+    int *d_rrun = nullptr;         //     6 ints per (segment, grid row): output base (int64, even), first code (int64), codes, 0
+    int64_t roll_nseg = 0, roll_s = 0;
+    int roll_L = 0, roll_hl = 0, roll_cmin = 0, roll_ncol = 0, roll_H = 0;
     bool window2d = false;         //   2-D (strided) tiles: d_w2desc[kW2Desc * ntiles], codes in tile order
     int *d_w2desc = nullptr;
     int64_t w2_ntiles = 0;

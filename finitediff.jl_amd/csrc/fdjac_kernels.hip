@@ -8,6 +8,7 @@
 //
 // Reference loops each kernel replaces are cited per kernel (paths relative to /root/reference).
 #include <cstdlib>
+#include <type_traits>
 
 #include "fdjac_internal.h"
 
@@ -742,6 +743,16 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
     cb1 = cb1 < c_hi ? cb1 : c_hi;
     const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;
     if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
+    // the packed entry codes of the whole tile, requested NOW: they travel while the windows are loaded, and the entry
+    // phase below is one straight pass instead of kW2Iter dependent (load code -> gather -> store) rounds.  A tile holds at
+    // most 2048 + 2*kW2MaxRun entries (try_window2d_plan) = kW2Iter rounds of 512.
+    constexpr int kW2Iter = (2048 + 2 * kW2MaxRun + 2 * kBlock - 1) / (2 * kBlock);
+    uint32_t tcode[kW2Iter];
+#pragma unroll
+    for (int it = 0; it < kW2Iter; ++it) {
+        const int e = 2 * (int)threadIdx.x + it * 2 * kBlock;
+        tcode[it] = e < nent ? *reinterpret_cast<const uint32_t *>(wcode + code0 + e) : 0x80008000u;
+    }
 
     if constexpr (DMA) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -805,9 +816,11 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
     __syncthreads();
 
     const int cshift = cmin - cb0;
-#pragma unroll 1
-    for (int e = 2 * (int)threadIdx.x; e < nent; e += 2 * kBlock) {
-        const uint32_t code = *reinterpret_cast<const uint32_t *>(wcode + code0 + e);
+#pragma unroll
+    for (int it = 0; it < kW2Iter; ++it) {
+        const int e = 2 * (int)threadIdx.x + it * 2 * kBlock;
+        if (e >= nent) break;
+        const uint32_t code = tcode[it];
         int r = 0;
         while (r + 1 < nruns && e >= s_desc[34 + 3 * r]) ++r;
         const int ebase = r ? s_desc[31 + 3 * r] : 0;
@@ -836,6 +849,168 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             if (w[0]) out[p] = q[0];
             if (w[1]) out[p + 1] = q[1];
         }
+    }
+}
+
+// K3e  rolling row windows (plan: try_roll_plan).  One WAVE (a 64-thread workgroup) owns a column strip of a 2-D stencil
+//   pattern and walks a segment of grid rows g0 .. g1-1 down it.  Row g' of the strip is one window of kRollW = 128
+//   consecutive f! values starting at g'*s + I*L - hl (even): lane l owns the pair 2l, 2l+1, so every array of a row is ONE
+//   dense 1-KiB wave load.  The differences of rows g-1, g, g+1 sit in an LDS ring of four rows while the loads of row g+2
+//   are in flight; the entries of row g (one contiguous run of nzval) are decoded from 16-bit codes (offset | row << 7 |
+//   colour << 11) and leave with 16-B stores (code slots and output positions share their parity).
+//   Same operations on the same operands as k_decompress_window2d / _list => bit-identical results.
+template <int MODE, int NCT, bool FXB_VEC>
+__global__ void __launch_bounds__(64)
+k_decompress_roll(const int *__restrict__ segs, const int *__restrict__ runs, const uint16_t *__restrict__ wcode,
+                  const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
+                  const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int nsegs, int64_t s, int L,
+                  int hl, int cmin, int ncol_all, int ncolp, int vec_ok)
+{
+    extern __shared__ real_t s_roll[];                 // kWinMaxCol step sizes, then ring[4][ncolp][kRollW]
+    real_t *s_eps = s_roll;
+    real_t *ring = s_roll + kWinMaxCol;
+    const int lane = threadIdx.x;
+    const int seg = (vec_ok & 4) ? nsegs - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int I = segs[4 * seg], g0 = segs[4 * seg + 1], g1 = segs[4 * seg + 2], run0 = segs[4 * seg + 3];
+    int cb0 = cmin > c_lo ? cmin : c_lo, cb1 = cmin + ncol_all < c_hi ? cmin + ncol_all : c_hi;
+    const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;        // colours of the strip that belong to the current chunk
+    const int cshift = cmin - cb0;
+    if (lane < kWinMaxCol) s_eps[lane] = (lane < ncol) ? eps[cb0 + lane] : (real_t)1;
+    const int64_t wbase = (int64_t)I * L - hl + 2 * lane;     // this lane's pair inside a window row, relative to g'*s
+
+    // kRollDepth rows in flight, each in its own register set: with one row in flight a wave spends a full memory latency
+    // per grid row (measured 7.6 us per row, 356 us for config 3); the loads of row g+1+d are issued d rows ahead
+    constexpr int kRollDepth = 3;
+    d2_t pa_[kRollDepth][NCT], pb_[kRollDepth][NCT];
+    auto issue = [&](auto K, int64_t g) {              // loads of grid row g into register set K (rows outside the vector read as zero)
+        d2_t(&pa)[NCT] = pa_[decltype(K)::value];
+        d2_t(&pb)[NCT] = pb_[decltype(K)::value];
+        const int64_t row = g * s + wbase;
+        const bool in0 = (g >= 0) & (row >= 0) & (row < M), in1 = (g >= 0) & (row + 1 >= 0) & (row + 1 < M);
+        d2_t b = {0.0, 0.0};
+        if (MODE == 0 && FXb != nullptr) {
+            if (FXB_VEC && in0 && in1) b = *reinterpret_cast<const d2_t *>(FXb + row);
+            else { if (in0) b.x = FXb[row]; if (in1) b.y = FXb[row + 1]; }
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            pa[cc] = d2_t{0.0, 0.0};
+            pb[cc] = b;
+            if (cc < ncol) {
+                const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
+                if (in0 && in1) {
+                    if (MODE == 2) {
+                        const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
+                        const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
+                        pa[cc] = d2_t{p0.y, p1.y};
+                    } else {
+                        pa[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
+                        if (MODE == 1) pb[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
+                    }
+                } else {   // the first / last pair of the vector
+                    if (in0) { pa[cc].x = MODE == 2 ? FXa[at * 2 + 1] : FXa[at]; if (MODE == 1) pb[cc].x = FXb[at]; }
+                    if (in1) { pa[cc].y = MODE == 2 ? FXa[(at + 1) * 2 + 1] : FXa[at + 1]; if (MODE == 1) pb[cc].y = FXb[at + 1]; }
+                    if (MODE == 1) { if (!in0) pb[cc].x = 0.0; if (!in1) pb[cc].y = 0.0; }
+                }
+            }
+        }
+    };
+    auto park = [&](auto K, int64_t g) {               // differences of register set K -> ring row g & 3
+        d2_t(&pa)[NCT] = pa_[decltype(K)::value];
+        d2_t(&pb)[NCT] = pb_[decltype(K)::value];
+        real_t *dst = ring + (size_t)((int)(g & 3) * ncolp) * kRollW + 2 * lane;
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc)
+            if (cc < ncol) {
+                const d2_t df = (MODE == 2) ? pa[cc] : d2_t{pa[cc].x - pb[cc].x, pa[cc].y - pb[cc].y};
+                *reinterpret_cast<d2_t *>(dst + (size_t)cc * kRollW) = df;
+            }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    issue(K0{}, (int64_t)g0 - 1); issue(K1{}, (int64_t)g0);
+    park(K0{}, (int64_t)g0 - 1);  park(K1{}, (int64_t)g0);
+    // rows g0+1, g0+2, g0+3 in flight in sets 0, 1, 2 (rows beyond g1 are never needed)
+    issue(K0{}, (int64_t)g0 + 1);
+    if (g0 + 2 <= g1) issue(K1{}, (int64_t)g0 + 2);
+    if (g0 + 3 <= g1) issue(K2{}, (int64_t)g0 + 3);
+    constexpr int kIt = kRollMaxCodes / 128;
+    // The entry codes are pipelined as well: set K holds the run descriptor and the codes of the row it emits; while row
+    // g is emitted, the codes of row g+1 (their address comes from a descriptor loaded one row earlier) and the descriptor of
+    // row g+2 are in flight.  Without this every row waited for two dependent global round trips before its first entry.
+    int ri_[kRollDepth][5];
+    uint32_t tcode_[kRollDepth][kIt];
+    auto load_info = [&](auto K, int g) {              // (wave-uniform address: scalar loads)
+        int(&ri)[5] = ri_[decltype(K)::value];
+        if (g < g1) {
+            const int *src = runs + 6 * (size_t)(run0 + (g - g0));
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ri[q] = src[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ri[q] = 0;
+        }
+    };
+    auto load_codes = [&](auto K) {
+        const int(&ri)[5] = ri_[decltype(K)::value];
+        uint32_t(&tcode)[kIt] = tcode_[decltype(K)::value];
+        const int64_t code0 = ((int64_t)(uint32_t)ri[2]) | ((int64_t)ri[3] << 32);
+        const int nent = ri[4];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int e = 2 * lane + 128 * it;
+            tcode[it] = e < nent ? *reinterpret_cast<const uint32_t *>(wcode + code0 + e) : 0x80008000u;
+        }
+    };
+    load_info(K0{}, g0); load_info(K1{}, g0 + 1);
+    load_codes(K0{});
+    // one grid row: its register set holds row g+1; after parking it, the set is reused for row g+1+kRollDepth
+    auto body = [&](auto K, auto KN, auto KNN, int g) {
+        const int(&ri)[5] = ri_[decltype(K)::value];
+        const uint32_t(&tcode)[kIt] = tcode_[decltype(K)::value];
+        const int64_t pbase = ((int64_t)(uint32_t)ri[0]) | ((int64_t)ri[1] << 32);
+        const int nent = ri[4];
+        load_codes(KN);                                // codes of row g+1 (descriptor loaded during row g-1)
+        load_info(KNN, g + 2);                         // descriptor of row g+2
+        park(K, (int64_t)g + 1);                       // waits for row g+1 (issued kRollDepth rows ago)
+        if (g + 1 + kRollDepth <= g1) issue(K, (int64_t)g + 1 + kRollDepth);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            if (128 * it >= nent) break;
+            const int e = 2 * lane + 128 * it;
+            const uint32_t code = tcode[it];
+            real_t q[2];
+            bool w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned cd = (code >> (16 * h)) & 0xFFFFu;
+                const int cs = (int)((cd >> 11) & 7u) + cshift;
+                const bool colored = (cd & 0xC000u) == 0;
+                const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
+                const int rr = (int)((cd >> 7) & 3u), off = (int)(cd & 0x7Fu);
+                const int at = valid ? ((((g - 1 + rr) & 3) * ncolp + cs) * kRollW + off) : 0;
+                const real_t df = ring[at];
+                const real_t ee = s_eps[valid ? cs : 0];
+                const real_t v = (MODE == 1) ? df / (2 * ee) : df / ee;
+                q[h] = valid ? v : 0.0;
+                w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
+            }
+            const int64_t pp = pbase + e;
+            if (w[0] & w[1] & ((vec_ok & 1) != 0)) {
+                *reinterpret_cast<d2_t *>(out + pp) = d2_t{q[0], q[1]};
+            } else {
+                if (w[0]) out[pp] = q[0];
+                if (w[1]) out[pp + 1] = q[1];
+            }
+        }
+        __syncthreads();                               // the ring slot of row g-1 is free for row g+3
+    };
+    for (int g = g0; g < g1; g += kRollDepth) {
+        body(K0{}, K1{}, K2{}, g);
+        if (g + 1 < g1) body(K1{}, K2{}, K0{}, g + 1);
+        if (g + 2 < g1) body(K2{}, K0{}, K1{}, g + 2);
     }
 }
 
@@ -1382,6 +1557,19 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
     const int vok = ((((uintptr_t)out) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
     const int64_t ldw = p->cur_ld > 0 ? p->cur_ld : p->ldf;   // pitch of the batched f! arrays (row strips: the strip scratch)
+    if (p->roll) {
+        const int ncolp = p->roll_ncol;
+        const size_t shr = sizeof(real_t) * ((size_t)4 * (size_t)ncolp * kRollW + kWinMaxCol);
+#define FD_LAUNCH_ROLL(NCT, FV)                                                                                         \
+        hipLaunchKernelGGL((k_decompress_roll<MODE, NCT, FV>), dim3((unsigned)p->roll_nseg), dim3(64), shr, s, p->d_rseg,   \
+                           p->d_rrun, p->d_wcode, FXa, FXb, ldw, p->M, p->d_eps, c_lo, c_hi, out, (int)p->roll_nseg, p->roll_s, \
+                           p->roll_L, p->roll_hl, p->roll_cmin, p->roll_ncol, ncolp, vok)
+        if (p->roll_ncol <= 4) { if (fxvec) FD_LAUNCH_ROLL(4, true); else FD_LAUNCH_ROLL(4, false); }
+        else if (p->roll_ncol <= 6) { if (fxvec) FD_LAUNCH_ROLL(6, true); else FD_LAUNCH_ROLL(6, false); }
+        else { if (fxvec) FD_LAUNCH_ROLL(kWinMaxCol, true); else FD_LAUNCH_ROLL(kWinMaxCol, false); }
+#undef FD_LAUNCH_ROLL
+        return;
+    }
     if (p->window2d) {
         const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
         const size_t shm2 = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + 4 * (size_t)kW2Desc;

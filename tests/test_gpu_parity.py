@@ -1389,3 +1389,38 @@ def test_row_strips_bit_identical(monkeypatch, fdtype, case):
         out = _dev(np.full(plan.out_len(0), np.nan))
         plan.jacobian(f, x, [out])
         assert np.array_equal(out.cpu().numpy(), outs["1"]) and f.counts()[0] <= 2
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["lap5", "lap5_nl", "clamp5", "lap5_none", "lap5_chunked", "lap5_f_in", "lap5_small_ny", "lap5_wide"])
+def test_rolling_row_windows_bit_identical(monkeypatch, fdtype, case):
+    # k_decompress_roll (one wave walks a column strip of a 2-D stencil, LDS ring of four grid rows) against the 2-D tile
+    # kernel (FDJAC_ROLL=0) and the gather kernel (FDJAC_WINDOW=0): same operations on the same operands, same bits
+    nx, ny = {"lap5_small_ny": (400, 7), "lap5_wide": (1000, 40)}.get(case, (250, 130))
+    N = nx * ny
+    fam = {"lap5_nl": "lap5_nl", "clamp5": "clamp5"}.get(case, "lap5")
+    colptr, rowval = P.lap5_csc(nx, ny)
+    colors = P.lap5_colors(nx, ny).copy()
+    if case == "lap5_none":
+        colors[[0, 3, nx - 1, nx, 5 * nx + 17, N - 1]] = 0
+    cap = 900_000 if case == "lap5_chunked" else 0
+    x = _dev(np.random.default_rng(55).random(N))
+    f_in = _dev(np.random.default_rng(56).random(N + 1))[1:] if (case == "lap5_f_in" and fdtype == "forward") else None
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    outs = {}
+    for variant in ("roll", "tiles2d", "gather"):
+        monkeypatch.setenv("FDJAC_ROLL", "1" if variant == "roll" else "0")
+        monkeypatch.setenv("FDJAC_WINDOW", "0") if variant == "gather" else monkeypatch.delenv("FDJAC_WINDOW", raising=False)
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
+        assert plan.info(fd.lib.INFO_ROLL) == int(variant == "roll")
+        assert plan.info(fd.lib.INFO_WINDOW2D) == int(variant != "gather")
+        if case == "lap5_chunked":
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        f = fd.BuiltinF(fam, nx, ny)
+        if nx % 2 == 0:
+            plan.set_lazy(f)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out], f_in=f_in)
+        outs[variant] = out.cpu().numpy()
+    assert not np.isnan(outs["gather"]).any()
+    assert np.array_equal(outs["roll"], outs["gather"]) and np.array_equal(outs["tiles2d"], outs["gather"])
