@@ -595,6 +595,29 @@ static int try_roll_plan(fd_plan *p, const std::vector<int32_t> &rows, const std
     return FD_OK;
 }
 
+// Shape of the 2-D tiles (L positions x R column runs) -- shared by the host builder below and the device builder
+// (fdjac_planbuild.hip).  false: no usable shape.
+static bool w2_shape(const fd_plan *p, int ecmax, int halo, int *L_out, int *R_out)
+{
+    int L, R;
+    const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
+    // default shape: 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as
+    // keep the window pairs of a tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same
+    // process: 62 x 5 299 us, 62 x 6 303, 62 x 4 302, 64 x 6 310, 64 x 5 304, 94 x 3 304, 126 x 2 313
+    L = (fl && *fl) ? atoi(fl) : 62;
+    L = std::max(2, L & ~1);
+    R = (fr && *fr) ? atoi(fr) : (int)(2048 / ((int64_t)ecmax * L));
+    R = std::max(1, std::min(R, kW2MaxRun));
+    if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
+    if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
+        const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
+        while (R > 2 && window_lds_bytes(p->dma, p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+        while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
+    }
+    *L_out = L; *R_out = R;
+    return R >= 2;
+}
+
 // 2-D (strided) tiles for the row-window kernel (k_decompress_window2d): 2-D stencil patterns in natural ordering.
 // Detection: apart from a few near-diagonal offsets (|row - col| <= 8) every entry sits one "stride" s away from the
 // diagonal (within +-4), the same s for (almost) the whole pattern, s >= 64.  Tiles are then R consecutive grid rows
@@ -642,21 +665,8 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
     }
     if ((rc = try_roll_plan(p, rows, nzc, colstart, s, halo, ecmax))) return rc;
     if (p->roll) return FD_OK;
-    const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
-    // default shape: 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as
-    // keep the window pairs of a tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same
-    // process: 62 x 5 299 us, 62 x 6 303, 62 x 4 302, 64 x 6 310, 64 x 5 304, 94 x 3 304, 126 x 2 313
-    int L = (fl && *fl) ? atoi(fl) : 62;
-    L = std::max(2, L & ~1);
-    int R = (fr && *fr) ? atoi(fr) : (int)(2048 / ((int64_t)ecmax * L));
-    R = std::max(1, std::min(R, kW2MaxRun));
-    if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
-    if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
-        const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
-        while (R > 2 && window_lds_bytes(p->dma, p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
-        while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
-    }
-    if (R < 2) return FD_OK;
+    int L, R;
+    if (!w2_shape(p, ecmax, halo, &L, &R)) return FD_OK;
 
     const int64_t g_lo = p->col0 / s, g_hi = (p->col1 - 1) / s;          // grid rows touched by the local columns
     const int64_t nG = (g_hi - g_lo + R) / R, nI = (s + L - 1) / L;
@@ -752,6 +762,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
     p->window = true;
     p->window2d = true;
     p->w2_ntiles = ntiles;
+    p->w2_codes = (int64_t)code.size();
     p->win_tile = 0;
     p->win_pairs = max_slots / 2;
     p->win_ncol = max_ncol;
@@ -759,6 +770,47 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
     if ((rc = dev_upload(&p->d_w2desc, desc))) return rc;
     if ((rc = dev_upload(&p->d_wcode, code))) return rc;
     return FD_OK;
+}
+
+// sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
+static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vector<std::pair<int64_t, int32_t>> &ord)
+{
+    for (int k = 0; k < kSortTile; ++k) {
+        const int64_t c = nzc[k] >= 0 ? nzc[k] : (nzc[k] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
+        ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[k]), k};
+    }
+    std::sort(ord.begin(), ord.end());
+}
+
+// Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of tiles (every step-th
+// of ntiles tiles of kSortTile entries; rows_of(t) / nzc_of(t) point at tile t's entries): distinct 128-B lines touched
+// by one wave-level gather (64 lanes, the kernels' lane->entry maps).  Shared by the host and the device builder.
+template <class RowsOf, class NzcOf>
+static void gather_coherence(size_t ntiles, size_t step, RowsOf rows_of, NzcOf nzc_of, double *lines_direct, double *lines_sorted)
+{
+    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+    auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
+    double ld = 0, ls = 0;
+    size_t ninstr = 0;
+    std::vector<int64_t> keys;
+    for (size_t t = 0; t < ntiles; t += step) {
+        const int32_t *rw = rows_of(t), *nz = nzc_of(t);
+        sort_tile_entries(rw, nz, ord);
+        for (int g = 0; g < kSortTile / 128; ++g)
+            for (int half = 0; half < 2; ++half) {
+                keys.clear();
+                for (int l = 0; l < 64; ++l) { const size_t e = (size_t)(g * 128 + 2 * l + half); keys.push_back(line_key(nz[e], rw[e])); }
+                std::sort(keys.begin(), keys.end());
+                ld += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                keys.clear();
+                for (int l = 0; l < 64; ++l) { const size_t e = (size_t)ord[(size_t)(g * 128 + 64 * half + l)].second; keys.push_back(line_key(nz[e], rw[e])); }
+                std::sort(keys.begin(), keys.end());
+                ls += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
+                ++ninstr;
+            }
+    }
+    *lines_direct = ld / std::max<size_t>(ninstr, 1);
+    *lines_sorted = ls / std::max<size_t>(ninstr, 1);
 }
 
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
@@ -784,44 +836,14 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (has_dest) dest.resize(padded, 0);
     for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
 
-    // Gather coherence of the storage order vs a (colour,row)-sorted order, estimated on a sample of
-    // tiles: distinct 128-B lines touched by one wave-level gather (64 lanes, the kernels' lane->entry maps).
     std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
-    auto sort_tile = [&](size_t b0) {
-        // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
-        for (int k = 0; k < kSortTile; ++k) {
-            const size_t e = b0 + (size_t)k;
-            const int64_t c = nzc[e] >= 0 ? nzc[e] : (nzc[e] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
-            ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[e]), k};
-        }
-        std::sort(ord.begin(), ord.end());
-    };
+    auto sort_tile = [&](size_t b0) { sort_tile_entries(rows.data() + b0, nzc.data() + b0, ord); };
     bool scattered = false;
     if (!has_dest && p->nnz_local >= 4 * kSortTile) {
         const size_t ntiles = padded / kSortTile;
         const size_t step = std::max<size_t>(1, ntiles / 64);
-        auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
-        double ld = 0, ls = 0;
-        size_t ninstr = 0;
-        std::vector<int64_t> keys;
-        for (size_t t = 0; t < ntiles; t += step) {
-            const size_t b0 = t * kSortTile;
-            sort_tile(b0);
-            for (int g = 0; g < kSortTile / 128; ++g)
-                for (int half = 0; half < 2; ++half) {
-                    keys.clear();
-                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)(g * 128 + 2 * l + half); keys.push_back(line_key(nzc[e], rows[e])); }
-                    std::sort(keys.begin(), keys.end());
-                    ld += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
-                    keys.clear();
-                    for (int l = 0; l < 64; ++l) { const size_t e = b0 + (size_t)ord[(size_t)(g * 128 + 64 * half + l)].second; keys.push_back(line_key(nzc[e], rows[e])); }
-                    std::sort(keys.begin(), keys.end());
-                    ls += (double)(std::unique(keys.begin(), keys.end()) - keys.begin());
-                    ++ninstr;
-                }
-        }
-        p->lines_direct = ld / std::max<size_t>(ninstr, 1);
-        p->lines_sorted = ls / std::max<size_t>(ninstr, 1);
+        gather_coherence(ntiles, step, [&](size_t t) { return rows.data() + t * kSortTile; },
+                         [&](size_t t) { return nzc.data() + t * kSortTile; }, &p->lines_direct, &p->lines_sorted);
         scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
     }
 
@@ -1129,6 +1151,12 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
     mix(scal, sizeof scal);
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
+    if (p->window2d) {
+        const int64_t w2[] = {p->w2_ntiles, p->w2_codes};
+        mix(w2, sizeof w2);
+        if ((rc = mix_dev(p->d_w2desc, sizeof(int) * (size_t)kW2Desc * (size_t)p->w2_ntiles))) return rc;
+        if ((rc = mix_dev(p->d_wcode, sizeof(uint16_t) * (size_t)p->w2_codes))) return rc;
+    }
     if (p->window && !p->window2d) {
         const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
         if ((rc = mix_dev(p->d_wtiles, sizeof(int4) * 3 * (padded / (size_t)p->win_tile)))) return rc;
@@ -1215,8 +1243,19 @@ int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int
     fd_plan *p = *out;
     FD_TRY(apply_opts(p, opts));
     std::vector<int32_t> col0;
-    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
-    FD_TRY(upload_colors(p, col0, {}));
+    {
+        // large problems: the colours are converted and tested on the device (FDJAC_PLAN_DEVICE=0: host loops, the checker)
+        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const int want = (pd && *pd) ? atoi(pd) : -1;
+        int res = PBR_DECLINED;
+        if (want != 0 && (want == 1 || N >= ((int64_t)1 << 17)) && colorvec && (color_bytes == 4 || color_bytes == 8))
+            res = device_colors_only(p, colorvec, color_bytes);
+        (void)hipGetLastError();
+        if (res != PBR_DONE) {
+            FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+            FD_TRY(upload_colors(p, col0, {}));
+        }
+    }
     p->row0 = std::max<int64_t>(p->col0 - 1, 0);
     p->row1 = std::min<int64_t>(p->col1 + 1, N);
     if (p->col1 == p->col0) p->row0 = p->row1 = 0;
@@ -1245,13 +1284,35 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
     p->l = l;
     p->u = u;
     FD_TRY(apply_opts(p, opts));
-    std::vector<int32_t> col0;
-    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
-    FD_TRY(upload_colors(p, col0, {}));
     p->row0 = std::min<int64_t>(std::max<int64_t>(p->col0 - u, 0), M);
     p->row1 = std::max<int64_t>(std::min<int64_t>(p->col1 + l, M), p->row0);
     p->nouts = 1;
     p->out_len[0] = (p->col1 - p->col0) * (l + u + 1);
+    {
+        // large narrow bands are compiled on the device like a banded SparseMatrixCSC (fdjac_planbuild.hip, BAND tiles:
+        // no index arrays at all); FDJAC_PLAN_DEVICE=0 keeps the host loops below, which are also its checker
+        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const int want = (pd && *pd) ? atoi(pd) : -1;
+        const int64_t w = l + u + 1, slots = p->out_len[0];
+        if (want != 0 && w <= 64 && (want == 1 ? slots > 0 : slots >= ((int64_t)1 << 17)) && colorvec && (color_bytes == 4 || color_bytes == 8)) {
+            void *d_cv = nullptr;
+            bool ok = hipMalloc(&d_cv, (size_t)color_bytes * (size_t)N) == hipSuccess &&
+                      hipMemcpyAsync(d_cv, colorvec, (size_t)color_bytes * (size_t)N, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            int brc = FD_OK, res = PBR_DECLINED;
+            const PbBand band{w, u};
+            if (ok) res = device_build_csc(p, nullptr, nullptr, 4, 0, d_cv, color_bytes, 0, slots, &brc, &band);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (d_cv) (void)hipFree(d_cv);
+            (void)hipGetLastError();
+            if (res == PBR_DONE) {
+                if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
+                return FD_OK;
+            }
+        }
+    }
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    FD_TRY(upload_colors(p, col0, {}));
     {
         // the band's column-major storage as an entry list with implicit indices (slot k of column j <-> row j-u+k;
         // slots outside the matrix and columns without colour are written as 0): narrow bands go through the

@@ -191,6 +191,7 @@ struct fd_plan {
     bool window2d = false;         //   2-D (strided) tiles: d_w2desc[kW2Desc * ntiles], codes in tile order
     int *d_w2desc = nullptr;
     int64_t w2_ntiles = 0;
+    int64_t w2_codes = 0;          //   number of 16-bit codes in d_wcode (2-D tiles)
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile

@@ -112,22 +112,25 @@ __global__ void __launch_bounds__(kBlock) k_pb_check_colptr(const void *__restri
 // Reproduces try_window_plan's build_windows for tiles whose rows form ONE window; other tiles raise PB_NEED_SORT (the
 // host builder clusters / sorts them).  Grid-wide statistics are computed by the host from the descriptors.
 constexpr int kPbMaxCols = 4096;     // columns (+1) of one tile staged in LDS; tiles spanning more (empty columns): host builder
-template <bool CODES, int T>
+// BAND: the entries are the slots of a band's column-major storage (fd_plan_create_banded): slot k of column j <-> row
+// j - bu + k, bw slots per column, no index arrays; slots outside the matrix and columns without colour are "uncoloured"
+// entries (written as 0), exactly as the host builder lists them.  tstride > 1: a sample of the tiles (descriptors only).
+template <bool CODES, int T, bool BAND>
 __global__ void __launch_bounds__(kBlock) k_pb_tiles(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
                                                      int64_t col0, int64_t col1, int64_t e0, int64_t nloc, int64_t M,
                                                      const uint8_t *__restrict__ color8, int64_t ntiles, int4 *__restrict__ wt,
-                                                     uint16_t *__restrict__ code, PbStats *st)
+                                                     uint16_t *__restrict__ code, PbStats *st, int64_t bw, int64_t bu, int64_t tstride)
 {
     constexpr int E = T / kBlock;                     // entries per thread
     __shared__ int s_cp[kPbMaxCols + 1];              // colptr of the tile's columns, relative to the tile's first entry
     __shared__ int64_t s_j[2];
     __shared__ int s_red[kBlock / 64][7];
     __shared__ int s_tile[2];
-    const int64_t t = blockIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * tstride;
     if (t >= ntiles) return;
     const int64_t b0 = t * (int64_t)T;                                    // first local entry of the tile
     const int64_t last = (b0 + T < nloc ? b0 + T : nloc) - 1;            // last REAL local entry (b0 <= last: tiles cover [0, padded))
-    if (threadIdx.x < 2) {
+    if (!BAND && threadIdx.x < 2) {
         // column of local entry q: the largest j with colptr[j] - base - e0 <= q
         const int64_t q = threadIdx.x == 0 ? b0 : last;
         int64_t lo = col0, hi = col1;                                     // invariant: cp(lo) <= q < cp(hi)  (cp(col1) = nloc > q)
@@ -138,10 +141,10 @@ __global__ void __launch_bounds__(kBlock) k_pb_tiles(const void *__restrict__ co
         s_j[threadIdx.x] = lo;
     }
     __syncthreads();
-    const int64_t jlo = s_j[0], jhi = b0 <= last ? s_j[1] : s_j[0];
+    const int64_t jlo = BAND ? 0 : s_j[0], jhi = BAND ? 0 : (b0 <= last ? s_j[1] : s_j[0]);
     const int ncols = (int)(jhi - jlo + 1);
-    const bool fits = jhi - jlo + 1 <= kPbMaxCols;
-    if (fits)
+    const bool fits = BAND || jhi - jlo + 1 <= kPbMaxCols;
+    if (!BAND && fits)
         for (int k = threadIdx.x; k <= ncols; k += kBlock) {
             int64_t v = pb_load(colptr, ib, jlo + k) - base - e0 - b0;
             v = v < -1 ? -1 : (v > T ? T : v);
@@ -155,7 +158,20 @@ __global__ void __launch_bounds__(kBlock) k_pb_tiles(const void *__restrict__ co
     for (int u = 0; u < E; ++u) {
         const int q = u * kBlock + threadIdx.x;
         row[u] = 0; col[u] = 0xFE;
-        if (fits && b0 + q < nloc) {
+        if (BAND) {
+            if (b0 + q < nloc) {
+                const int64_t jj = (b0 + q) / bw, k = (b0 + q) - jj * bw, j = col0 + jj, r = j - bu + k;
+                const int cb = color8[j];
+                const bool in = r >= 0 && r < M && cb != 0xFF;
+                row[u] = in ? (int)r : 0;
+                col[u] = in ? cb : 0xFF;
+                if (in) {
+                    rmin = row[u] < rmin ? row[u] : rmin; rmax = row[u] > rmax ? row[u] : rmax;
+                    cmin = cb < cmin ? cb : cmin; cmax = cb > cmax ? cb : cmax;
+                    ++cnt;
+                }
+            }
+        } else if (fits && b0 + q < nloc) {
             int lo = 0, hi = ncols;                   // s_cp[lo] <= q < s_cp[hi]
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -260,6 +276,316 @@ __global__ void __launch_bounds__(kBlock) k_pb_set_regular(int4 *__restrict__ wt
     if (t < ntiles && regular[t]) wt[3 * t].w |= 0x100;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 2-D (strided) tiles on the device: what try_window2d_plan (fdjac_api.hip) does with host loops.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// rows / per-entry colours of the sampled tiles (kSortTile entries each) for the gather-coherence estimate
+__global__ void __launch_bounds__(kBlock) k_pb_sample_expand(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                             int64_t col0, int64_t col1, int64_t e0, int64_t nloc,
+                                                             const uint8_t *__restrict__ color8, int64_t step,
+                                                             int32_t *__restrict__ rows_out, int32_t *__restrict__ nzc_out)
+{
+    const int64_t t = (int64_t)blockIdx.x * step;
+    for (int k = threadIdx.x; k < kSortTile; k += kBlock) {
+        const int64_t q = t * kSortTile + k;
+        int32_t r = 0, c = -2;
+        if (q < nloc) {
+            int64_t lo = col0, hi = col1;                 // cp(lo) <= q < cp(hi)
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (pb_load(colptr, ib, mid) - base - e0 <= q) lo = mid; else hi = mid;
+            }
+            r = (int32_t)(pb_load(rowval, ib, e0 + q) - base);
+            const int cc = color8[lo];
+            c = cc == 0xFF ? -1 : cc;
+        }
+        rows_out[(size_t)blockIdx.x * kSortTile + k] = r;
+        nzc_out[(size_t)blockIdx.x * kSortTile + k] = c;
+    }
+}
+
+// sampled columns for the stride: out[33 * i] = number of entries of column col0 + i * step (or -1: more than 32),
+// out[33 * i + 1 ...] = row - column of each
+__global__ void __launch_bounds__(kBlock) k_pb2_sample_cols(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                            int64_t col0, int64_t ncols, int64_t step, int nsamp, int *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nsamp) return;
+    const int64_t j = col0 + (int64_t)i * step;
+    const int64_t a = pb_load(colptr, ib, j) - base, b = pb_load(colptr, ib, j + 1) - base;
+    int *o = out + 33 * (size_t)i;
+    if (b - a > 32) { o[0] = -1; return; }
+    o[0] = (int)(b - a);
+    for (int64_t e = a; e < b; ++e) o[1 + (e - a)] = (int)(pb_load(rowval, ib, e) - base - j);
+}
+
+struct Pb2Stats {
+    unsigned long long bad;        // entries off the stride
+    unsigned long long elems;      // sum over tiles of 2 * pairs * ncol
+    int ecmax, halo;               // entries per column, reach of an entry around the diagonal / the stride
+    int row_min, row_max;
+    int max_slots, max_ncol;
+    unsigned int flags;            // PB_* (PB_BAD_ROW) | PB2_*
+    unsigned int pad;
+};
+enum { PB2_FAIL = 1u << 16 };      // a tile the 2-D kernel cannot describe (too many colours / windows / rows): host builder
+
+// every column: entries per column, off-stride entries, halo, row range, row validation
+__global__ void __launch_bounds__(kBlock) k_pb2_check(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                      int64_t col0, int64_t col1, int64_t M, int64_t s, Pb2Stats *st)
+{
+    int ecmax = 0, halo = 0, rmin = 0x7fffffff, rmax = -1;
+    unsigned long long bad = 0;
+    bool badrow = false;
+    for (int64_t j = col0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < col1; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t a = pb_load(colptr, ib, j) - base, b = pb_load(colptr, ib, j + 1) - base;
+        const int cnt = (int)(b - a);
+        ecmax = cnt > ecmax ? cnt : ecmax;
+        for (int64_t e = a; e < b; ++e) {
+            const int64_t r = pb_load(rowval, ib, e) - base;
+            if (r < 0 || r >= M) { badrow = true; continue; }
+            rmin = (int)r < rmin ? (int)r : rmin; rmax = (int)r > rmax ? (int)r : rmax;
+            int64_t o = r - j;
+            if (o < 0) o = -o;
+            if (o <= 8) { halo = (int)o > halo ? (int)o : halo; continue; }
+            if (o < s - 4 || o > s + 4) ++bad;
+            else { const int h = (int)(o > s ? o - s : s - o); halo = h > halo ? h : halo; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int a = __shfl_down(ecmax, off, 64), b = __shfl_down(halo, off, 64), c = __shfl_down(rmin, off, 64), d = __shfl_down(rmax, off, 64);
+        const unsigned long long e = __shfl_down(bad, off, 64);
+        ecmax = a > ecmax ? a : ecmax; halo = b > halo ? b : halo; rmin = c < rmin ? c : rmin; rmax = d > rmax ? d : rmax; bad += e;
+    }
+    const bool anybad = __builtin_amdgcn_ballot_w64(badrow) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (ecmax > st->ecmax) atomicMax(&st->ecmax, ecmax);
+        if (halo > st->halo) atomicMax(&st->halo, halo);
+        if (rmax >= 0 && rmin < st->row_min) atomicMin(&st->row_min, rmin);
+        if (rmax > st->row_max) atomicMax(&st->row_max, rmax);
+        if (bad) atomicAdd(&st->bad, bad);
+        if (anybad) atomicOr(&st->flags, (unsigned)PB_BAD_ROW);
+    }
+}
+
+// the column runs of tile (G, I): run r = columns [c0, c1) = local entries [a, b)
+struct Pb2Runs {
+    int n;
+    int64_t c0[kW2MaxRun], a[kW2MaxRun], b[kW2MaxRun];
+    int ncols[kW2MaxRun];
+};
+__device__ __forceinline__ void pb2_runs(Pb2Runs &rn, const void *colptr, int ib, int base, int64_t col0, int64_t col1, int64_t e0,
+                                         int64_t s, int L, int R, int64_t g_lo, int64_t g_hi, int64_t G, int64_t I)
+{
+    rn.n = 0;
+    for (int q = 0; q < R; ++q) {
+        const int64_t g = g_lo + G * R + q;
+        if (g > g_hi) break;
+        int64_t c0 = g * s + I * L, c1 = g * s + ((I + 1) * L < s ? (I + 1) * L : s);
+        c0 = c0 > col0 ? c0 : col0;
+        c1 = c1 < col1 ? c1 : col1;
+        if (c1 <= c0) continue;
+        const int64_t a = pb_load(colptr, ib, c0) - base - e0, b = pb_load(colptr, ib, c1) - base - e0;
+        if (b <= a) continue;
+        rn.c0[rn.n] = c0; rn.a[rn.n] = a; rn.b[rn.n] = b; rn.ncols[rn.n] = (int)(c1 - c0);
+        ++rn.n;
+    }
+}
+
+// pass 1: runs and (even-padded) entries per tile -> the host's prefix sums give descriptor slots and code offsets
+__global__ void __launch_bounds__(kBlock) k_pb2_count(const void *__restrict__ colptr, int ib, int base, int64_t col0, int64_t col1, int64_t e0,
+                                                      int64_t s, int L, int R, int64_t g_lo, int64_t g_hi, int64_t nG, int64_t nI,
+                                                      int2 *__restrict__ cnt)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nG * nI) return;
+    Pb2Runs rn;
+    pb2_runs(rn, colptr, ib, base, col0, col1, e0, s, L, R, g_lo, g_hi, t / nI, t % nI);
+    int nent = 0, raw = 0;
+    for (int r = 0; r < rn.n; ++r) {
+        const int len = (int)(rn.b[r] - rn.a[r]);
+        raw += len;
+        nent += len + (len & 1);
+    }
+    cnt[t] = int2{rn.n ? nent : -1, raw};
+}
+
+// pass 2: one workgroup per (non-empty) tile: row windows from a bitmap of the coloured entries' rows (a new window after
+// a gap of more than 16 rows, as the host builder's sort does), descriptor, 16-bit entry codes
+constexpr int kPb2MaxEnt = 2048 + 2 * kW2MaxRun;
+constexpr int kPb2BitWords = 8192;                 // rows spanned by one tile <= 32 * this
+__global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                      int64_t col0, int64_t col1, int64_t e0, const uint8_t *__restrict__ color8,
+                                                      int64_t s, int L, int R, int64_t g_lo, int64_t g_hi, int64_t nG, int64_t nI,
+                                                      const int *__restrict__ slot_of, const int64_t *__restrict__ code0_of,
+                                                      int *__restrict__ desc, uint16_t *__restrict__ code, Pb2Stats *st)
+{
+    __shared__ unsigned s_bits[kPb2BitWords];
+    __shared__ int s_cp[kW2MaxRun][kPbMaxCols / 32 + 1];     // colptr slices of the runs (relative to the run's first entry): L <= 128 columns
+    __shared__ int s_red[kBlock / 64][4];
+    __shared__ int s_ext[4];                                  // rmin, rmax, cmin, cmax of the coloured entries
+    __shared__ int s_nse[2];                                  // number of window starts / ends found
+    __shared__ int s_starts[kW2MaxWin + 1], s_ends[kW2MaxWin + 1];
+    __shared__ int s_wr[kW2MaxWin], s_wn[kW2MaxWin], s_cum[kW2MaxWin];
+    const int64_t t = blockIdx.x;
+    const int slot = slot_of[t];
+    if (slot < 0) return;
+    Pb2Runs rn;
+    pb2_runs(rn, colptr, ib, base, col0, col1, e0, s, L, R, g_lo, g_hi, t / nI, t % nI);
+    if (threadIdx.x == 0) { s_nse[0] = 0; s_nse[1] = 0; }
+    for (int r = 0; r < rn.n; ++r)
+        for (int k = threadIdx.x; k <= rn.ncols[r]; k += kBlock) s_cp[r][k] = (int)(pb_load(colptr, ib, rn.c0[r] + k) - base - e0 - rn.a[r]);
+    __syncthreads();
+    // ---- extent of the coloured entries
+    int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
+    bool fail = false;
+    auto for_entries = [&](auto fn) {   // fn(run, position in the tile's code list, row, colour byte)
+        int off = 0;
+        for (int r = 0; r < rn.n; ++r) {
+            const int len = (int)(rn.b[r] - rn.a[r]);
+            for (int q = threadIdx.x; q < len; q += kBlock) {
+                int lo = 0, hi = rn.ncols[r];             // s_cp[lo] <= q < s_cp[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_cp[r][mid] <= q) lo = mid; else hi = mid;
+                }
+                const int row = (int)(pb_load(rowval, ib, e0 + rn.a[r] + q) - base);
+                fn(r, off + q, row, (int)color8[rn.c0[r] + lo]);
+            }
+            off += len + (len & 1);
+        }
+    };
+    for_entries([&](int, int, int row, int cb) {
+        if (cb == 0xFF) return;
+        rmin = row < rmin ? row : rmin; rmax = row > rmax ? row : rmax;
+        cmin = cb < cmin ? cb : cmin; cmax = cb > cmax ? cb : cmax;
+    });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int a = __shfl_down(rmin, off, 64), b = __shfl_down(rmax, off, 64), c = __shfl_down(cmin, off, 64), d = __shfl_down(cmax, off, 64);
+        rmin = a < rmin ? a : rmin; rmax = b > rmax ? b : rmax; cmin = c < cmin ? c : cmin; cmax = d > cmax ? d : cmax;
+    }
+    if ((threadIdx.x & 63) == 0) { int *r = s_red[threadIdx.x >> 6]; r[0] = rmin; r[1] = rmax; r[2] = cmin; r[3] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            rmin = s_red[w][0] < rmin ? s_red[w][0] : rmin; rmax = s_red[w][1] > rmax ? s_red[w][1] : rmax;
+            cmin = s_red[w][2] < cmin ? s_red[w][2] : cmin; cmax = s_red[w][3] > cmax ? s_red[w][3] : cmax;
+        }
+        s_ext[0] = rmin; s_ext[1] = rmax; s_ext[2] = cmin; s_ext[3] = cmax;
+    }
+    __syncthreads();
+    rmin = s_ext[0]; rmax = s_ext[1]; cmin = s_ext[2]; cmax = s_ext[3];
+    const bool any = rmax >= 0;
+    int nwin = 0, pairs = 0;
+    const int ncol = any ? cmax - cmin + 1 : 0;
+    if (any) {
+        const int base_row = rmin & ~31;
+        const int nwords = (rmax - base_row) / 32 + 1;
+        if (ncol > kWinMaxCol || nwords > kPb2BitWords) fail = true;
+        if (!fail) {
+            for (int w = threadIdx.x; w < nwords; w += kBlock) s_bits[w] = 0;
+            __syncthreads();
+            for_entries([&](int, int, int row, int cb) {
+                if (cb != 0xFF) atomicOr(&s_bits[(row - base_row) >> 5], 1u << ((row - base_row) & 31));
+            });
+            __syncthreads();
+            // window starts: a set bit with no set bit in the 16 rows before it; ends: none in the 16 rows after it
+            for (int w = threadIdx.x; w < nwords; w += kBlock) {
+                const unsigned cur = s_bits[w];
+                if (!cur) continue;
+                const unsigned prev = w > 0 ? s_bits[w - 1] : 0u, next = w + 1 < nwords ? s_bits[w + 1] : 0u;
+                unsigned long long x = ((unsigned long long)cur << 16) | (unsigned long long)(prev >> 16);      // bit i+16 = row bit i
+                unsigned long long m = x; m |= m << 1; m |= m << 2; m |= m << 4; m |= m << 8;                    // shifts 0..15
+                unsigned starts = (unsigned)(((x & ~(m << 1)) >> 16) & 0xFFFFFFFFull);
+                unsigned long long y = (unsigned long long)cur | ((unsigned long long)(next & 0xFFFFu) << 32);   // bit i = row bit i
+                unsigned long long n = y; n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8;
+                unsigned ends = (unsigned)((y & ~(n >> 1)) & 0xFFFFFFFFull);
+                while (starts) {
+                    const int b = __ffs(starts) - 1; starts &= starts - 1;
+                    const int k = atomicAdd(&s_nse[0], 1);
+                    if (k < kW2MaxWin + 1) s_starts[k] = base_row + 32 * w + b;
+                }
+                while (ends) {
+                    const int b = __ffs(ends) - 1; ends &= ends - 1;
+                    const int k = atomicAdd(&s_nse[1], 1);
+                    if (k < kW2MaxWin + 1) s_ends[k] = base_row + 32 * w + b;
+                }
+            }
+            __syncthreads();
+            nwin = s_nse[0];
+            if (nwin > kW2MaxWin || s_nse[1] != nwin) fail = true;
+        }
+        if (!fail && threadIdx.x == 0) {
+            for (int i = 1; i < nwin; ++i) {              // (insertion sorts of at most 12 values)
+                int v = s_starts[i], k = i;
+                while (k > 0 && s_starts[k - 1] > v) { s_starts[k] = s_starts[k - 1]; --k; }
+                s_starts[k] = v;
+                v = s_ends[i]; k = i;
+                while (k > 0 && s_ends[k - 1] > v) { s_ends[k] = s_ends[k - 1]; --k; }
+                s_ends[k] = v;
+            }
+            int cum = 0;
+            for (int k = 0; k < nwin; ++k) {
+                s_wr[k] = s_starts[k] & ~1;
+                s_wn[k] = (s_ends[k] - s_wr[k]) / 2 + 1;
+                cum += s_wn[k];
+                s_cum[k] = cum;
+            }
+        }
+        __syncthreads();
+        if (!fail) pairs = s_cum[nwin - 1];
+        if (2 * pairs > 2048) fail = true;
+    }
+    int nent = 0;
+    for (int r = 0; r < rn.n; ++r) { const int len = (int)(rn.b[r] - rn.a[r]); nent += len + (len & 1); }
+    if (nent > kPb2MaxEnt) fail = true;
+    if (fail) {
+        if (threadIdx.x == 0) atomicOr(&st->flags, (unsigned)PB2_FAIL);
+        return;
+    }
+    // ---- descriptor
+    const int64_t code0 = code0_of[t];
+    if (threadIdx.x == 0) {
+        int *d = desc + (size_t)kW2Desc * (size_t)slot;
+        for (int k = 0; k < kW2Desc; ++k) d[k] = 0;
+        d[0] = any ? cmin : 0; d[1] = ncol; d[2] = pairs; d[3] = nwin; d[4] = rn.n; d[5] = nent;
+        d[6] = (int)(unsigned)(code0 & 0xFFFFFFFFll); d[7] = (int)(code0 >> 32);
+        for (int k = 0; k < nwin; ++k) { d[8 + 2 * k] = s_wr[k]; d[9 + 2 * k] = s_cum[k]; }
+        int acc = 0;
+        for (int r = 0; r < rn.n; ++r) {
+            const int len = (int)(rn.b[r] - rn.a[r]);
+            acc += len + (len & 1);
+            d[32 + 3 * r] = (int)(unsigned)(rn.a[r] & 0xFFFFFFFFll); d[33 + 3 * r] = (int)(rn.a[r] >> 32);
+            d[34 + 3 * r] = acc;
+        }
+        if (2 * pairs > st->max_slots) atomicMax(&st->max_slots, 2 * pairs);
+        if (ncol > st->max_ncol) atomicMax(&st->max_ncol, ncol);
+        atomicAdd(&st->elems, (unsigned long long)(2 * pairs) * (unsigned long long)ncol);
+    }
+    // ---- codes
+    for_entries([&](int, int pos, int row, int cb) {
+        uint16_t c = 0x4000;
+        if (cb != 0xFF) {
+            int k = 0;
+            while (!(row >= s_wr[k] && row < s_wr[k] + 2 * s_wn[k])) ++k;
+            const int sl = 2 * (k ? s_cum[k - 1] : 0) + (row - s_wr[k]);
+            c = (uint16_t)(sl | ((cb - cmin) << 11));
+        }
+        code[code0 + pos] = c;
+    });
+    {   // the pad slot of odd runs
+        int off = 0;
+        for (int r = 0; r < rn.n; ++r) {
+            const int len = (int)(rn.b[r] - rn.a[r]);
+            if ((len & 1) && threadIdx.x == 0) code[code0 + off + len] = 0x8000;
+            off += len + (len & 1);
+        }
+    }
+}
+
 // outcome of the device builder
 enum { PBR_DONE = 0, PBR_DECLINED = 1 };
 
@@ -282,11 +608,214 @@ struct PbTemps {
     ~PbTemps() { for (int i = 0; i < n; ++i) if (ptrs[i]) (void)hipFree(ptrs[i]); }
 };
 
+// 2-D (strided) tiles built on the device -- the decisions are try_window2d_plan's / finish_list_plan's (same helper
+// functions, same thresholds), the O(nnz) work is done by the kernels above.  PBR_DONE: p->d_w2desc / d_wcode and the
+// window fields are set (the caller finishes the plan); PBR_DECLINED: the host builder decides.
+static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t nloc,
+                           const uint8_t *d_color8, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out)
+{
+    hipStream_t s = p->ctx->stream;
+    const char *fw = getenv("FDJAC_WINDOW2D"), *fro = getenv("FDJAC_ROLL");
+    if (fw && *fw && atoi(fw) == 0) return PBR_DECLINED;
+    if (fro && *fro && atoi(fro) != 0) return PBR_DECLINED;           // rolling row windows: planned on the host
+    const int64_t ncols = p->col1 - p->col0;
+    if (ncols < 1024 || nloc < 8192 || nloc < 4 * kSortTile) return PBR_DECLINED;
+    PbTemps tmp;
+    auto sync_ok = [&]() { return hipStreamSynchronize(s) == hipSuccess; };
+    // ---- is the storage order a scattered gather? (finish_list_plan's estimate on the same sample of tiles)
+    {
+        const size_t padded = (size_t)((std::max<int64_t>(nloc, 1) + kListPad - 1) / kListPad * kListPad);
+        const size_t ntiles = padded / kSortTile, step = std::max<size_t>(1, ntiles / 64), nsamp = (ntiles + step - 1) / step;
+        int32_t *d_sr = nullptr, *d_sc = nullptr;
+        if (hipMalloc((void **)&d_sr, sizeof(int32_t) * nsamp * kSortTile) != hipSuccess) return PBR_DECLINED;
+        tmp.add(d_sr);
+        if (hipMalloc((void **)&d_sc, sizeof(int32_t) * nsamp * kSortTile) != hipSuccess) return PBR_DECLINED;
+        tmp.add(d_sc);
+        hipLaunchKernelGGL(k_pb_sample_expand, dim3((unsigned)nsamp), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, e0,
+                           nloc, d_color8, (int64_t)step, d_sr, d_sc);
+        std::vector<int32_t> sr(nsamp * kSortTile), sc(nsamp * kSortTile);
+        if (hipMemcpyAsync(sr.data(), d_sr, sizeof(int32_t) * sr.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(sc.data(), d_sc, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
+        gather_coherence(ntiles, step, [&](size_t t) { return sr.data() + (t / step) * kSortTile; },
+                         [&](size_t t) { return sc.data() + (t / step) * kSortTile; }, &p->lines_direct, &p->lines_sorted);
+        if (!(p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted)) return PBR_DECLINED;
+    }
+    tm.mark("2-D: coherence sample");
+    // ---- the stride: most common far offset over a sample of columns
+    int64_t st_s = 0;
+    {
+        const int64_t step = std::max<int64_t>(1, ncols / 4096);
+        const int nsamp = (int)((ncols + step - 1) / step);
+        int *d_o = nullptr;
+        if (hipMalloc((void **)&d_o, sizeof(int) * 33 * (size_t)nsamp) != hipSuccess) return PBR_DECLINED;
+        tmp.add(d_o);
+        hipLaunchKernelGGL(k_pb2_sample_cols, dim3((unsigned)((nsamp + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base,
+                           p->col0, ncols, step, nsamp, d_o);
+        std::vector<int> o(33 * (size_t)nsamp);
+        if (hipMemcpyAsync(o.data(), d_o, sizeof(int) * o.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
+        std::vector<int64_t> fars;
+        for (int i = 0; i < nsamp; ++i) {
+            const int cnt = o[33 * (size_t)i];
+            if (cnt < 0) return PBR_DECLINED;                        // a column with more than 32 entries
+            for (int e = 0; e < cnt; ++e) {
+                const int64_t d = o[33 * (size_t)i + 1 + e];
+                if (d > 8 || d < -8) fars.push_back(d < 0 ? -d : d);
+            }
+        }
+        if (fars.empty()) return PBR_DECLINED;
+        std::sort(fars.begin(), fars.end());
+        st_s = fars[fars.size() / 2];
+        if (st_s < 64 || ncols < 4 * st_s) return PBR_DECLINED;
+    }
+    Pb2Stats *d_st = nullptr;
+    if (hipMalloc((void **)&d_st, sizeof(Pb2Stats)) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_st);
+    Pb2Stats h;
+    memset(&h, 0, sizeof h);
+    h.row_min = 0x7fffffff; h.row_max = -1;
+    if (hipMemcpyAsync(d_st, &h, sizeof h, hipMemcpyHostToDevice, s) != hipSuccess) return PBR_DECLINED;
+    hipLaunchKernelGGL(k_pb2_check, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((ncols + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
+                       dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, p->M, st_s, d_st);
+    if (hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
+    if (h.flags & PB_BAD_ROW) {
+        set_error("colptr / rowval are inconsistent (an entry outside 1..%lld)", (long long)p->M);
+        *rc_out = FD_ERR_SHAPE;
+        return PBR_DONE;
+    }
+    const int ecmax = h.ecmax, halo = h.halo;
+    if ((int64_t)h.bad * 1000 > nloc || ecmax < 1 || ecmax > 32) return PBR_DECLINED;
+    tm.mark("2-D: stride + check");
+    int L, R;
+    if (!w2_shape(p, ecmax, halo, &L, &R) || L > 128) return PBR_DECLINED;
+    const int64_t g_lo = p->col0 / st_s, g_hi = (p->col1 - 1) / st_s;
+    const int64_t nG = (g_hi - g_lo + R) / R, nI = (st_s + L - 1) / L;
+    const int64_t ntl = nG * nI;
+    if (ntl <= 0 || ntl >= ((int64_t)1 << 30)) return PBR_DECLINED;
+    // ---- pass 1: entries per tile; prefix sums on the host (8 B per tile)
+    int2 *d_cnt = nullptr;
+    if (hipMalloc((void **)&d_cnt, sizeof(int2) * (size_t)ntl) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_cnt);
+    hipLaunchKernelGGL(k_pb2_count, dim3((unsigned)((ntl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_colptr, ib, base, p->col0, p->col1, e0,
+                       st_s, L, R, g_lo, g_hi, nG, nI, d_cnt);
+    std::vector<int2> cnt((size_t)ntl);
+    if (hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int2) * cnt.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
+    std::vector<int> slot_of((size_t)ntl);
+    std::vector<int64_t> code0_of((size_t)ntl);
+    int64_t ntiles = 0, ncode = 0, covered = 0;
+    for (int64_t t = 0; t < ntl; ++t) {
+        code0_of[(size_t)t] = ncode;
+        if (cnt[(size_t)t].x < 0) { slot_of[(size_t)t] = -1; continue; }
+        if (cnt[(size_t)t].x > kPb2MaxEnt) return PBR_DECLINED;
+        slot_of[(size_t)t] = (int)ntiles++;
+        ncode += cnt[(size_t)t].x;
+        covered += cnt[(size_t)t].y;
+    }
+    if (covered != nloc || ntiles == 0) return PBR_DECLINED;         // every stored entry must belong to exactly one run
+    // ---- pass 2: descriptors and codes
+    int *d_slot = nullptr, *d_desc = nullptr;
+    int64_t *d_code0 = nullptr;
+    uint16_t *d_code = nullptr;
+    if (hipMalloc((void **)&d_slot, sizeof(int) * (size_t)ntl) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_slot);
+    if (hipMalloc((void **)&d_code0, sizeof(int64_t) * (size_t)ntl) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_code0);
+    if (hipMalloc((void **)&d_desc, sizeof(int) * (size_t)kW2Desc * (size_t)ntiles) != hipSuccess) return PBR_DECLINED;
+    if (hipMalloc((void **)&d_code, sizeof(uint16_t) * (size_t)(ncode + 2)) != hipSuccess) { (void)hipFree(d_desc); return PBR_DECLINED; }
+    static const uint16_t tail[2] = {0x8000, 0x8000};                 // the last pair load may touch one code past the end
+    bool ok = hipMemcpyAsync(d_slot, slot_of.data(), sizeof(int) * (size_t)ntl, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_code0, code0_of.data(), sizeof(int64_t) * (size_t)ntl, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(d_code + ncode, tail, sizeof tail, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_pb2_tiles, dim3((unsigned)ntl), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, e0, d_color8,
+                           st_s, L, R, g_lo, g_hi, nG, nI, d_slot, d_code0, d_desc, d_code, d_st);
+        ok = hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && sync_ok() && hipGetLastError() == hipSuccess;
+    }
+    tm.mark("2-D: tiles");
+    const double overread = (double)h.elems / (double)std::max<int64_t>(nloc, 1);
+    if (!ok || (h.flags & PB2_FAIL) || h.max_slots == 0 || window_lds_bytes(p->dma, p->fdtype, h.max_slots, h.max_ncol) > (size_t)kWinMaxLds ||
+        overread > 2.2) {
+        (void)hipFree(d_desc); (void)hipFree(d_code);
+        return PBR_DECLINED;
+    }
+    p->window = true;
+    p->window2d = true;
+    p->w2_ntiles = ntiles;
+    p->w2_codes = ncode + 2;
+    p->win_tile = 0;
+    p->win_pairs = h.max_slots / 2;
+    p->win_ncol = h.max_ncol;
+    p->win_overread = overread;
+    p->d_w2desc = d_desc;
+    p->d_wcode = d_code;
+    *row0_out = h.row_max >= 0 ? h.row_min : 0;
+    *row1_out = h.row_max >= 0 ? h.row_max + 1 : 0;
+    return PBR_DONE;
+}
+
 // colptr / rowval / colorvec: DEVICE arrays (raw, caller's index width and base).  On PBR_DONE the plan is complete up
 // to alloc_scratch (called here); on PBR_DECLINED nothing was changed that the host builder does not overwrite.
 // *rc_out carries an error status (FD_ERR_SHAPE etc.) when the pattern is invalid.
+// Only the colours (Tridiagonal J: its three diagonals need no entry list): the caller's colorvec (host array, Int32 /
+// Int64, 1-based) -> 0-based bytes on the device, C, the cyclic test.  PBR_DECLINED: the host loops (ingest_colors).
+static int device_colors_only(fd_plan *p, const void *colorvec, int color_bytes)
+{
+    hipStream_t s = p->ctx->stream;
+    const int64_t N = p->N;
+    if (N < 1 || N >= ((int64_t)1 << 31)) return PBR_DECLINED;
+    PbTemps tmp;
+    void *d_cv = nullptr;
+    PbStats *d_st = nullptr;
+    if (hipMalloc(&d_cv, (size_t)color_bytes * (size_t)N) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_cv);
+    if (hipMalloc((void **)&d_st, sizeof(PbStats)) != hipSuccess) return PBR_DECLINED;
+    tmp.add(d_st);
+    PbStats h;
+    memset(&h, 0, sizeof h);
+    if (hipMemcpyAsync(d_cv, colorvec, (size_t)color_bytes * (size_t)N, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_st, &h, sizeof h, hipMemcpyHostToDevice, s) != hipSuccess) return PBR_DECLINED;
+    const int gN = (int)std::min<int64_t>((N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16);
+    hipLaunchKernelGGL(k_pb_colmax, dim3(gN), dim3(kBlock), 0, s, d_cv, color_bytes, N, d_st);
+    if (hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return PBR_DECLINED;
+    const int64_t C = (int64_t)h.max_color;
+    if (C < 1 || C > kRegColors) return PBR_DECLINED;
+    const int shift = h.first_color >= 1 ? (int)(h.first_color - 1) : 0;
+    uint8_t *d_color8 = nullptr;
+    if (hipMalloc((void **)&d_color8, (size_t)N) != hipSuccess) return PBR_DECLINED;
+    hipLaunchKernelGGL(k_pb_colors, dim3(gN), dim3(kBlock), 0, s, d_cv, color_bytes, N, (int)C, shift, d_color8, d_st);
+    if (hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+        (h.flags & PB_COLOR_BIG)) {
+        (void)hipFree(d_color8);
+        return PBR_DECLINED;
+    }
+    p->C = C;
+    p->color8 = true;
+    p->d_color = d_color8;
+    const char *fc = getenv("FDJAC_EPS_CYCLIC");
+    const bool cyc = !(h.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
+    p->cyc_C = cyc ? (int)C : 0;
+    p->cyc_shift = cyc ? shift : 0;
+    p->built_on_device = true;
+    return PBR_DONE;
+}
+
+static void pb_launch_tiles(bool codes, int T, bool band, int64_t grid, int64_t tstride, hipStream_t s, const void *d_colptr, const void *d_rowval,
+                            int ib, int base, const fd_plan *p, int64_t e0, int64_t nloc, const uint8_t *d_color8, int64_t ntiles, int4 *d_wt,
+                            uint16_t *d_code, PbStats *d_st, int64_t bw, int64_t bu)
+{
+#define FD_PB_TILES(CC, TT, BB)                                                                                                       \
+    hipLaunchKernelGGL((k_pb_tiles<CC, TT, BB>), dim3((unsigned)grid), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, e0, \
+                       nloc, p->M, d_color8, ntiles, d_wt, d_code, d_st, bw, bu, tstride)
+    if (!codes) { if (T == 2048) FD_PB_TILES(false, 2048, false); else if (T == 1024) FD_PB_TILES(false, 1024, false); else FD_PB_TILES(false, 512, false); }
+    else if (band) { if (T == 2048) FD_PB_TILES(true, 2048, true); else if (T == 1024) FD_PB_TILES(true, 1024, true); else FD_PB_TILES(true, 512, true); }
+    else { if (T == 2048) FD_PB_TILES(true, 2048, false); else if (T == 1024) FD_PB_TILES(true, 1024, false); else FD_PB_TILES(true, 512, false); }
+#undef FD_PB_TILES
+}
+
+// band != nullptr: the "pattern" is a band's column-major storage (fd_plan_create_banded; d_colptr / d_rowval unused,
+// entries [0, e1) = the slots of the local columns).
+struct PbBand { int64_t w, u; };
 static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowval, int idx_bytes, int idx_base,
-                            const void *d_colorvec, int color_bytes, int64_t e0, int64_t e1, int *rc_out)
+                            const void *d_colorvec, int color_bytes, int64_t e0, int64_t e1, int *rc_out, const PbBand *band = nullptr)
 {
     *rc_out = FD_OK;
     hipStream_t s = p->ctx->stream;
@@ -314,6 +843,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     if (hipMalloc((void **)&d_color8, (size_t)N) != hipSuccess) return PBR_DECLINED;
     hipLaunchKernelGGL(k_pb_colors, dim3(gN), dim3(kBlock), 0, s, d_colorvec, color_bytes, N, (int)C, shift, d_color8, d_st);
     tm.mark("colours (alloc + kernel)");
+    if (!band)
     hipLaunchKernelGGL(k_pb_check_colptr, dim3(std::max(1, (int)std::min<int64_t>((p->col1 - p->col0 + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
                        dim3(kBlock), 0, s, d_colptr, idx_bytes, idx_base, p->col0, p->col1, e0, e1, d_st);
     tm.mark("colptr check");
@@ -333,6 +863,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     HostStats best;
     std::vector<int4> wt;
     PbStats fin;
+    memset(&fin, 0, sizeof fin);
     bool declined = false, bad = false;
     for (int T : {2048, 1024, 512}) {
         if (force_t && T != force_t) continue;
@@ -347,11 +878,16 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
             cur.row_min = 0x7fffffff; cur.row_max = -1;
             (void)hipMemcpyAsync(d_st, &cur, sizeof cur, hipMemcpyHostToDevice, s);
         }
-#define FD_PB_TILES(TT)                                                                                                      \
-        hipLaunchKernelGGL((k_pb_tiles<true, TT>), dim3((unsigned)ntiles), dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, \
-                           idx_base, p->col0, p->col1, e0, nloc, p->M, d_color8, ntiles, d_wt, d_code, d_st)
-        if (T == 2048) FD_PB_TILES(2048); else if (T == 1024) FD_PB_TILES(1024); else FD_PB_TILES(512);
-#undef FD_PB_TILES
+        if (!band && !force_t) {
+            // a sample of the tiles first (descriptors only): scattered patterns are recognised without a full pass
+            const int64_t ts = std::max<int64_t>(1, ntiles / 64);
+            pb_launch_tiles(false, T, false, (ntiles + ts - 1) / ts, ts, s, d_colptr, d_rowval, idx_bytes, idx_base, p, e0, nloc, d_color8, ntiles, d_wt, d_code, d_st, 0, 0);
+            PbStats smp;
+            if (hipMemcpyAsync(&smp, d_st, sizeof smp, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { declined = true; break; }
+            if (smp.flags & PB_NEED_SORT) { fin = smp; declined = true; break; }
+        }
+        pb_launch_tiles(true, T, band != nullptr, ntiles, 1, s, d_colptr, d_rowval, idx_bytes, idx_base, p, e0, nloc, d_color8, ntiles, d_wt, d_code, d_st,
+                        band ? band->w : 0, band ? band->u : 0);
         wt.resize((size_t)(3 * ntiles));
         if (hipMemcpyAsync(wt.data(), d_wt, sizeof(int4) * wt.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipMemcpyAsync(&fin, d_st, sizeof fin, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { declined = true; break; }
@@ -383,14 +919,33 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         *rc_out = FD_ERR_SHAPE;
         return PBR_DONE;
     }
+    if (declined && !bad && !band && (fin.flags & PB_NEED_SORT)) {
+        // not a locally banded pattern: 2-D (strided) tiles, if it is a 2-D stencil in natural ordering
+        (void)hipFree(d_wt); (void)hipFree(d_code);
+        p->C = C;                                      // (w2_shape sizes the LDS tile with the number of colours)
+        int r0 = 0, r1 = 0;
+        const int res2 = device_build_2d(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, nloc, d_color8, tm, &r0, &r1, rc_out);
+        if (res2 != PBR_DONE || *rc_out != FD_OK) { (void)hipFree(d_color8); return res2; }
+        p->color8 = true;
+        p->d_color = d_color8;
+        p->has_none = (fin.flags & PB_NONE) != 0;
+        p->nnz_local = nloc;
+        p->row0 = r0;
+        p->row1 = r1;
+        const char *fc = getenv("FDJAC_EPS_CYCLIC");
+        const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
+        p->cyc_C = cyc ? (int)C : 0;
+        p->cyc_shift = cyc ? shift : 0;
+        p->built_on_device = true;
+        *rc_out = alloc_scratch(p, std::vector<int32_t>());
+        tm.mark("scratch allocation");
+        return PBR_DONE;
+    }
     if (declined || !bestT) { (void)hipFree(d_color8); (void)hipFree(d_wt); (void)hipFree(d_code); return PBR_DECLINED; }
     const int64_t ntiles = (int64_t)(padded / (size_t)bestT);
     if ((int64_t)wt.size() != 3 * ntiles) {   // the accepted tile size is not the one of the last pass: run it again
-#define FD_PB_TILES(TT)                                                                                                      \
-        hipLaunchKernelGGL((k_pb_tiles<true, TT>), dim3((unsigned)ntiles), dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, \
-                           idx_base, p->col0, p->col1, e0, nloc, p->M, d_color8, ntiles, d_wt, d_code, d_st)
-        if (bestT == 2048) FD_PB_TILES(2048); else if (bestT == 1024) FD_PB_TILES(1024); else FD_PB_TILES(512);
-#undef FD_PB_TILES
+        pb_launch_tiles(true, bestT, band != nullptr, ntiles, 1, s, d_colptr, d_rowval, idx_bytes, idx_base, p, e0, nloc, d_color8, ntiles, d_wt, d_code, d_st,
+                        band ? band->w : 0, band ? band->u : 0);
         wt.resize((size_t)(3 * ntiles));
         if (hipMemcpyAsync(wt.data(), d_wt, sizeof(int4) * wt.size(), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
             (void)hipFree(d_color8); (void)hipFree(d_wt); (void)hipFree(d_code);
@@ -447,10 +1002,12 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     p->C = C;
     p->color8 = true;
     p->d_color = d_color8;
-    p->has_none = (fin.flags & PB_NONE) != 0;
+    if (!band) p->has_none = (fin.flags & PB_NONE) != 0;        // (the banded kinds write their uncoloured slots through the entry codes)
     p->nnz_local = nloc;
-    p->row0 = fin.row_max >= 0 ? fin.row_min : 0;
-    p->row1 = fin.row_max >= 0 ? (int64_t)fin.row_max + 1 : 0;
+    if (!band) {
+        p->row0 = fin.row_max >= 0 ? fin.row_min : 0;
+        p->row1 = fin.row_max >= 0 ? (int64_t)fin.row_max + 1 : 0;
+    }
     p->window = true;
     p->win_tile = bestT;
     p->win_pairs = best.max_slots / 2;

@@ -42,6 +42,17 @@ cp, rv = P.lap5_csc(nx, ny)
 colors = P.lap5_colors(nx, ny)
 J = fd.SparseMatrixCSC(nx * ny, nx * ny, cp, rv, None)
 timed("5-point CSC 4000x2500", lambda: fd.make_plan(J, J, colors, "central"))
+timed("5-point CSC 4000x2500 (again)", lambda: fd.make_plan(J, J, colors, "central"))
+os.environ["FDJAC_PLAN_DEVICE"] = "0"
+timed("5-point CSC 4000x2500, host builder", lambda: fd.make_plan(J, J, colors, "central"))
+del os.environ["FDJAC_PLAN_DEVICE"]
+dcp, drv, dcv = torch.as_tensor(cp, device="cuda"), torch.as_tensor(rv, device="cuda"), torch.as_tensor(colors, device="cuda")
+torch.cuda.synchronize()
+timed("5-point CSC 4000x2500, pattern on the device (Int64)", lambda: fd.make_plan_csc_device(nx * ny, nx * ny, dcp, drv, dcv, "central"))
+os.environ["FDJAC_PLAN_TIMING"] = "1"
+timed("5-point CSC 4000x2500, pattern on the device (again)", lambda: fd.make_plan_csc_device(nx * ny, nx * ny, dcp, drv, dcv, "central"))
+del os.environ["FDJAC_PLAN_TIMING"]
+del dcp, drv, dcv
 lay = P.BlockBandedLayout(np.full(10 ** 4, 32), 1, 1)
 Jb = fd.BlockBandedMatrix(None, lay)
 timed("BlockBanded 1e4 x 32^2", lambda: fd.make_plan(Jb, Jb, lay.colors(), "complex"))

@@ -112,8 +112,8 @@ def test_plan_from_a_device_resident_pattern(monkeypatch, idx):
 
 def test_patterns_the_device_builder_declines_go_to_the_host_builder(monkeypatch):
     monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1")
-    nx, ny = 400, 300                              # 5-point stencil: tiles need several row windows
-    colptr, rowval = P.lap5_csc(nx, ny)
+    nx, ny = 48, 3000                              # 5-point stencil on a narrow grid (stride 48 < 64: no 2-D tiles): tiles
+    colptr, rowval = P.lap5_csc(nx, ny)            # need several row windows, clustered by the host builder
     J = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
     plan = fd.make_plan(J, J, P.lap5_colors(nx, ny), "central")
     assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == 0 and plan.info(fd.lib.INFO_WINDOW) == 1
@@ -138,3 +138,151 @@ def test_device_builder_reports_an_inconsistent_pattern(monkeypatch):
     with pytest.raises(fd.lib.FdError) as e:
         fd.make_plan(fd.SparseMatrixCSC(N, N, colptr, bad), fd.SparseMatrixCSC(N, N, colptr, bad), P.cyclic_colors(N, 3), "forward")
     assert e.value.code == 2                        # FD_ERR_SHAPE
+
+
+def _stencil_csc(nx, ny, offsets):
+    """CSC pattern of a 2-D stencil in natural ordering: column k = i + nx*j couples to rows (i+di) + nx*(j+dj)."""
+    i, j = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    cols, rows = [], []
+    for di, dj in offsets:
+        ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny)
+        cols.append((i + nx * j)[ok])
+        rows.append(((i + di) + nx * (j + dj))[ok])
+    cols, rows = np.concatenate(cols), np.concatenate(rows)
+    order = np.lexsort((rows, cols))
+    cols, rows = cols[order], rows[order]
+    colptr = np.zeros(nx * ny + 1, dtype=np.int64)
+    np.add.at(colptr, cols + 1, 1)
+    return np.cumsum(colptr) + 1, rows.astype(np.int64) + 1
+
+
+@pytest.mark.parametrize("case", ["lap5", "lap5_odd", "lap5_none", "lap5_window", "lap5_wide_rows", "nine_point", "lap5_skewed"])
+@pytest.mark.parametrize("fdtype", ["central", "forward", "complex"])
+def test_device_built_2d_tiles_equal_host_built(monkeypatch, case, fdtype):
+    # 2-D stencil patterns in natural ordering (BASELINE config 3's shape): the strided tiles of k_decompress_window2d are
+    # compiled by k_pb2_* on the device; the host builder (try_window2d_plan) is the checker -- same arrays, same Jacobian bits
+    nx, ny = {"lap5_odd": (331, 257), "lap5_wide_rows": (5000, 40), "nine_point": (300, 260)}.get(case, (400, 300))
+    N = nx * ny
+    win = None
+    if case == "nine_point":
+        colptr, rowval = _stencil_csc(nx, ny, [(di, dj) for di in (-1, 0, 1) for dj in (-1, 0, 1)])
+        ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+        colors = ((ii % 4) + 4 * (jj % 2) + 1).T.reshape(-1).astype(np.int64)      # 8 colours (not a valid colouring: a plan does not care)
+    else:
+        colptr, rowval = P.lap5_csc(nx, ny)
+        colors = P.lap5_colors(nx, ny)
+    if case == "lap5_none":
+        colors = colors.copy()
+        colors[[0, 7, nx + 3, N // 2, N - 1]] = 0
+    if case == "lap5_skewed":
+        colors = colors.copy()                      # (a plan does not care whether the colouring is valid)
+        colors[::997] = colors[::997] % 5 + 1
+    if case == "lap5_window":
+        win = (N // 7 + 1, 6 * N // 7)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    x = _dev(np.random.default_rng(5).random(N))
+    plans, outs = {}, {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", dev)
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=win, x_window=(win[0] - nx - 2, win[1] + nx + 2) if win else None)
+        assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == int(dev)
+        assert plan.info(fd.lib.INFO_WINDOW) == 1 and plan.info(fd.lib.INFO_WINDOW2D) == 1
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        f = fd.BuiltinF("lap5_nl" if case != "nine_point" else "lap5", nx, ny)
+        if getattr(f, "lazy_fn", None) is not None:     # (the built-in lazy launcher wants an even nx)
+            plan.set_lazy(f)
+        plan.jacobian(f, x, [out])
+        plans[dev], outs[dev] = plan, out
+    assert plans["0"].checksum() == plans["1"].checksum()
+    for key in (fd.lib.INFO_WIN_OVERREAD_X100, fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_NNZ_LOCAL,
+                fd.lib.INFO_ENTRY_BEGIN, fd.lib.INFO_NCOLORS, fd.lib.INFO_LINES_DIRECT_X100, fd.lib.INFO_LINES_SORTED_X100):
+        assert plans["0"].info(key) == plans["1"].info(key), key
+    # entries the colouring leaves out are zero-filled, everything else is overwritten: no NaN survives
+    assert not torch.isnan(outs["0"]).any() and torch.equal(outs["0"], outs["1"])
+
+
+def test_2d_plan_from_a_device_resident_pattern_matches_oracle(oracle):
+    nx, ny = 420, 310
+    N = nx * ny
+    colptr, rowval = P.lap5_csc(nx, ny)
+    colors = P.lap5_colors(nx, ny)
+    cp, rv = torch.as_tensor((colptr - 1).astype(np.int32), device="cuda"), torch.as_tensor((rowval - 1).astype(np.int32), device="cuda")
+    cv = torch.as_tensor(colors.astype(np.int32), device="cuda")
+    plan = fd.make_plan_csc_device(N, N, cp, rv, cv, "central", idx_base=0)
+    assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == 1 and plan.info(fd.lib.INFO_WINDOW2D) == 1
+    xh = np.random.default_rng(6).random(N)
+    out = _dev(np.full(rowval.size, np.nan))
+    f = fd.BuiltinF("lap5_nl", nx, ny)
+    plan.set_lazy(f)
+    plan.jacobian(f, _dev(xh), [out])
+    ref = oracle.jacobian("central", oracle.Fixture("lap5_nl", nx, ny), xh, colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    got = out.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    np.testing.assert_allclose(got, ref["out"], rtol=1e-6, atol=1e-4)     # central differences at eps ~ 6e-6: ~1e-10/eps absolute floor
+
+
+@pytest.mark.parametrize("l,u,M,N,special", [(1, 1, 200_003, 200_003, ""), (2, 3, 150_000, 150_000, "none"), (0, 2, 180_001, 180_001, ""),
+                                              (3, 0, 120_050, 120_000, "window"), (1, 2, 99_990, 100_000, "irregular")])
+@pytest.mark.parametrize("fdtype", ["forward", "complex"])
+def test_device_built_banded_plan_equals_host_built(monkeypatch, l, u, M, N, special, fdtype):
+    # BandedMatrix J (ext/FiniteDiffBandedMatricesExt.jl:13-27): the band's column-major storage is an entry list with
+    # implicit indices; k_pb_tiles<BAND> compiles it without any index array, the host loops are its checker
+    w = l + u + 1
+    colors = P.cyclic_colors(N, w)
+    if special == "none":
+        colors[[0, 11, N // 3, N - 1]] = 0
+    if special == "irregular":
+        colors[::1013] = colors[::1013] % w + 1
+    win = (N // 6 + 1, 5 * N // 6) if special == "window" else None
+    x = _dev(np.random.default_rng(8).random(N))
+    A = torch.as_tensor(np.random.default_rng(9).random((M, w)), device="cuda")
+
+    def fn(fx, xx):   # f_i = sum_k A[i,k] * x[i - l + k]^2 (clamped): rows i depend on columns i-l .. i+u
+        idx = torch.arange(M, device="cuda")
+        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
+        for k in range(w):
+            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - l + k, 0, N - 1)] ** 2
+        fx.copy_(acc)
+
+    plans, outs = {}, {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", dev)
+        plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype, col_window=win)
+        assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == int(dev) and plan.info(fd.lib.INFO_WINDOW) == 1
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(fn, M, N), x, [out])
+        plans[dev], outs[dev] = plan, out
+    assert plans["0"].checksum() == plans["1"].checksum()
+    for key in (fd.lib.INFO_WIN_PERIOD, fd.lib.INFO_WIN_OVERREAD_X100, fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END,
+                fd.lib.INFO_NNZ_LOCAL, fd.lib.INFO_NCOLORS):
+        assert plans["0"].info(key) == plans["1"].info(key), key
+    assert not torch.isnan(outs["0"]).any() and torch.equal(outs["0"], outs["1"])
+
+
+@pytest.mark.parametrize("special", ["", "none", "irregular", "four"])
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+def test_tridiagonal_colours_converted_on_the_device(monkeypatch, special, fdtype):
+    # Tridiagonal J (src/iteration_utils.jl:25-32 through its three diagonals): a large plan converts / tests its colours with
+    # k_pb_colmax / k_pb_colors; the host loops are the checker
+    N = 262_147
+    colors = P.cyclic_colors(N, 4 if special == "four" else 3)
+    if special == "none":
+        colors[[0, 9, N // 2, N - 1]] = 0
+    if special == "irregular":
+        colors[::1009] = colors[::1009] % 3 + 1
+    x = _dev(np.random.default_rng(10).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    plans, outs = {}, {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", dev)
+        plan = fd.make_plan(fd.Tridiagonal(None, np.empty(N), None), None, colors, fdtype)
+        assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == int(dev)
+        o = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3)]
+        plan.set_lazy(f)
+        plan.jacobian(f, x, o)
+        plans[dev], outs[dev] = plan, o
+    assert plans["0"].checksum() == plans["1"].checksum()
+    cyc = 0 if special in ("none", "irregular") or fdtype == "complex" else (4 if special == "four" else 3)     # (reports C)
+    assert plans["0"].info(fd.lib.INFO_EPS_CYCLIC) == plans["1"].info(fd.lib.INFO_EPS_CYCLIC) == cyc
+    for a, b in zip(outs["0"], outs["1"]):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
