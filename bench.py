@@ -269,6 +269,15 @@ def main():
     if args.f_mode == "lazy" and lazy_ok:
         plan.set_lazy(f)
     f_mode = "lazy" if (args.f_mode == "lazy" and lazy_ok) else "materialized"
+    # FD_LAZY_CAP_DIFF: the lazy launcher hands over f(x+d) - f(x) / f(x+d) - f(x-d) (the subtraction of
+    # src/jacobians.jl:565,607 moves into f!'s launch): C arrays instead of C+1 / 2C, no f(x) pass -- the byte models follow
+    lazy_diff = int(plan.info(fd.lib.INFO_LAZY_DIFF)) if f_mode == "lazy" else 0
+    if lazy_diff and cfg in ("c2", "c4"):
+        bytes_min = C * vs + 3 * vs + 3 * idx_b                 # 48 (f64, periodic codes)
+        bytes_call_model = (vs + (0 if cyc else 1)) + (vs + 1 + C * vs) + bytes_min
+    elif lazy_diff and cfg == "c3":
+        bytes_min = (C * 8 * N + nnz * (8 + idx_b)) / N
+        bytes_call_model = 9.0 + (9.0 + C * 8) + bytes_min
     if world > 1 and args.eps == "sharded" and comm is not None:
         plan.set_comm(comm)
     gather_in_step = world > 1 and args.gather_in_step
@@ -458,7 +467,7 @@ def main():
             try:
                 j = json.load(open(pmc_path))
                 if (int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and j.get("kernel", "") in kern
-                        and args.dtype == "f64"):
+                        and args.dtype == "f64" and int(j.get("lazy_diff", 0)) == lazy_diff):
                     pmc = j.get("decompress_hbm_bytes_per_launch")
                     pmc_src = "rocprofv3 PMC passes of this command (profiles/pmc_%s.json: FETCH_SIZE x2 + WRITE_SIZE, calibrated on the stream copy)" % cfg
             except Exception:
@@ -485,7 +494,9 @@ def main():
                        "output": ("nzval in HBM" if world == 1 else
                                   "nzval assembled on rank 0 inside the step" if gather_in_step else
                                   "nzval device-resident, sharded by column range (rank r holds its contiguous slice)"),
-                       "f_mode": ("built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
+                       "f_mode": ("built-in device f! behind fd_f_launch_lazy with FD_LAZY_CAP_DIFF (1 launch: lazily perturbed points, "
+                                  "written as differences from f(x) / from the minus point)" if (f_mode == "lazy" and lazy_diff) else
+                                  "built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
                                   if f_mode == "lazy" else
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
                        "eps_reduction": diag["eps"], "gather_in_step": bool(gather_in_step),
@@ -494,7 +505,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": traffic_src,
-                "kernel": kern + " (fused difference + decompression)",
+                "kernel": kern + (" (division + decompression of the differences handed over by the lazy f! launcher)" if lazy_diff
+                                  else " (fused difference + decompression)"),
+                "lazy_diff": lazy_diff,
                 "avg_launch_ms": dec_ms, "launches_timed": dec["launches"],
                 "hbm_bytes_per_launch_used": traffic,
                 "min_traffic_bytes_per_launch": bytes_min * n_local,

@@ -476,9 +476,10 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
-    def set_lazy(self, f, imag_only=True, row_window=True):
+    def set_lazy(self, f, imag_only=True, row_window=True, diff=True):
         """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it.  imag_only /
-        row_window=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW capability."""
+        row_window / diff=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW / FD_LAZY_CAP_DIFF
+        capability."""
         fn = getattr(f, "lazy_fn", None) if f is not None else None
         if f is not None and fn is None:
             raise ValueError("this f! has no lazy-point launcher")
@@ -489,6 +490,8 @@ class Plan:
             caps &= ~1
         if not row_window:
             caps &= ~2
+        if not diff:
+            caps &= ~4
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):

@@ -24,6 +24,7 @@ int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double
 int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B);
 int launch_decompress(fd_plan *p, const real_t *fx, int c_lo, int c_hi, real_t *const *outs, int mode);
 int launch_fill(fd_ctx *ctx, real_t *ptr, int64_t n, real_t v);
+int launch_scale(fd_ctx *ctx, real_t *dst, const real_t *src, int64_t n, real_t factor);
 int launch_stream_copy(fd_ctx *ctx, const void *src, void *dst, int64_t n16);
 int balanced_grid(int64_t tiles, int64_t cap);
 
@@ -135,6 +136,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->list_U = env_int("FDJAC_TILE", 2);
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     p->eps_nt = env_int("FDJAC_EPS_NT", 1) != 0;
+    p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -170,6 +172,7 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     if (p->fdtype == FD_COMPLEX) {
         // d_fx is not used by the complex step: keep it zero, it is the "fx" of the imag-only decompression
         FD_HIP_CHECK(hipMemset(p->d_fx, 0, sizeof(real_t) * (size_t)p->ldf));
+        p->d_zero = p->d_fx;
         // eps(Float64) for every colour (src/epsilons.jl:104-107, src/jacobians.jl:624)
         FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
         int r2 = launch_fill(p->ctx, p->d_eps, std::max<int64_t>(p->C, 1), std::numeric_limits<real_t>::epsilon());
@@ -227,6 +230,19 @@ static int ensure_stage(fd_plan *p, bool x, bool fin)
     int rc;
     if (x && !p->d_xstage && (rc = dev_alloc(&p->d_xstage, p->ldx))) return rc;
     if (fin && !p->d_finstage && (rc = dev_alloc(&p->d_finstage, p->ldf))) return rc;
+    return FD_OK;
+}
+
+// the all-zero "fx" and the doubled step sizes of decompressions that receive differences (FD_LAZY_CAP_DIFF)
+static int ensure_diff_scratch(fd_plan *p)
+{
+    int rc;
+    if (!p->d_zero_own) {
+        if ((rc = dev_alloc(&p->d_zero_own, p->ldf))) return rc;
+        FD_HIP_CHECK(hipMemsetAsync(p->d_zero_own, 0, sizeof(real_t) * (size_t)p->ldf, p->ctx->stream));
+        p->d_zero = p->d_zero_own;
+    }
+    if (p->fdtype == FD_CENTRAL && !p->d_eps2 && (rc = dev_alloc(&p->d_eps2, std::max<int64_t>(p->C, 1)))) return rc;
     return FD_OK;
 }
 
@@ -963,7 +979,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_rseg, p->d_rrun, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2]};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -1480,6 +1496,9 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
     case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
+    case FD_INFO_LAZY_DIFF:
+        *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
+        break;
     case FD_INFO_BUILT_ON_DEVICE: *value = p->built_on_device ? 1 : 0; break;
     case FD_INFO_STRIPS: *value = (p->window && !p->window2d && p->nchunks == 1) ? p->strips : 1; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
@@ -1678,6 +1697,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
 
     // colours of this plan: all of them, or the owned range (fd_plan_opts.color_begin/end), in chunks of chunkB
     const int64_t oc0 = std::min<int64_t>(p->own_c0, p->C), oc1 = p->own_c1 < 0 ? p->C : std::min<int64_t>(p->own_c1, p->C);
+    bool diff_base_counted = false;
     for (int64_t cl = oc0; cl < oc1; cl += p->chunkB) {
         const int c_lo = (int)cl;
         const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
@@ -1695,7 +1715,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 if (t1 <= t0) continue;
                 {
                     Span sp(p, FD_STAGE_F);
-                    fd_lazy_points lp;
+                    fd_lazy_points lp = {};
                     lp.x = x_dev;
                     lp.color = p->d_color;
                     lp.eps = p->d_eps;
@@ -1725,13 +1745,22 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             base_pending = false;
             continue;
         }
+        // a launcher that can, hands over DIFFERENCES (f(point) - f(x), or f(plus) - f(minus)): no f(x) pass / half the f!
+        // arrays, and the decompression reads one array per colour (the forward kernels with fx = 0 and, for central
+        // differences, the doubled step sizes: (a - 0.0) / (2 eps) -- the bits of the plain path)
+        const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
+                               !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
+        bool diff_done = false;
+        if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
-            fd_lazy_points lp;
+            fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;
             lp.eps = p->d_eps;
-            lp.base_out = base_pending ? p->d_fx : nullptr;
+            lp.base_out = (base_pending && !want_diff) ? p->d_fx : nullptr;
+            lp.diff = want_diff ? ((p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1) : 0;
+            lp.reserved0 = 0;
             lp.color_bytes = p->color8 ? 1 : 4;
             lp.c_lo = c_lo;
             lp.ncolors = B;
@@ -1744,7 +1773,11 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             imag_only = lp.imag_only != 0;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher returned %d", rc);
-            if (rc == 0) {
+            if (rc == 0 && want_diff) {
+                lazy_done = diff_done = true;          // (base_pending stays: a later batch the launcher declines needs f(x))
+                p->fcalls_last += (int64_t)B * p->pts + (lp.diff == 2 ? 1 : 0);
+                diff_base_counted = true;
+            } else if (rc == 0) {
                 lazy_done = true;
                 p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
                 base_pending = false;
@@ -1775,7 +1808,18 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             Span sp(p, FD_STAGE_DECOMPRESS);
             // imaginary parts as a real array: the forward kernels with fx = 0 compute (a - 0.0)/eps == a/eps bit for bit
             const bool io = lazy_done && imag_only;
-            int rc = launch_decompress(p, io ? p->d_fx : fx, c_lo, c_hi, outs, io ? (int)FD_FORWARD : p->fdtype);
+            int rc;
+            if (diff_done) {
+                real_t *eps_plain = p->d_eps;
+                if (p->fdtype == FD_CENTRAL) {
+                    if ((rc = launch_scale(p->ctx, p->d_eps2 + c_lo, p->d_eps + c_lo, B, (real_t)2))) return rc;
+                    p->d_eps = p->d_eps2;
+                }
+                rc = launch_decompress(p, p->d_zero, c_lo, c_hi, outs, (int)FD_FORWARD);
+                p->d_eps = eps_plain;
+            } else {
+                rc = launch_decompress(p, io ? p->d_fx : fx, c_lo, c_hi, outs, io ? (int)FD_FORWARD : p->fdtype);
+            }
             if (rc) return rc;
         }
     }

@@ -92,6 +92,13 @@ k_f_tridiag_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n,
 // points never exist in memory and x is read once for all colours.  Values are bit-identical to
 // evaluating the materialised points.  MODE 0 forward, 1 central (+ then -), 2 complex step.
 // ---------------------------------------------------------------------------------------------
+// the subtraction of fd_lazy_points.diff: an IEEE a - b of the two stored values, never contracted into a producer
+__device__ __forceinline__ real_t sub_exact(real_t a, real_t b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 template <typename T, bool NL> __device__ __forceinline__ T tridiag_row(T xm, T xi, T xp)
 {
     T v = (xm - kTwo * xi) + xp;
@@ -103,7 +110,7 @@ template <typename CT, int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                  const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
-                 int64_t r1, int imag_only)
+                 int64_t r1, int imag_only, int diff)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
@@ -119,14 +126,14 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
             cv[k] = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;   // "none" is all-ones in CT
         }
         const bool two = i + 1 < n;
+        real_t b0 = 0.0, b1 = 0.0;                    // f(x) at rows i, i+1 (written to base_out, or the subtrahend of diff)
+        if (base_out || (diff && MODE == 0)) {
+            b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
+            if (two) b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
+        }
         if (base_out) {
-            const real_t b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
-            if (two) {
-                const real_t b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
-                *reinterpret_cast<r2_t *>(base_out + i) = r2_t{b0, b1};
-            } else {
-                base_out[i] = b0;
-            }
+            if (two) *reinterpret_cast<r2_t *>(base_out + i) = r2_t{b0, b1};
+            else base_out[i] = b0;
         }
         for (int b = 0; b < B; ++b) {
             const real_t e = eps[c_lo + b];
@@ -153,6 +160,20 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
                         const cd v1 = tridiag_row<cd, NL>(p[1], p[2], p[3]);
                         *reinterpret_cast<r2_t *>(dst + 2) = r2_t{v1.re, v1.im};
                     }
+                }
+            } else if (diff) {
+                // differences (fd_lazy_points.diff): f(x + d) - f(x), or f(x + d) - f(x - d), one array per colour
+                real_t p[4], q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { p[k] = xv[k] + d[k]; q[k] = xv[k] - d[k]; }
+                const real_t s0 = MODE == 1 ? tridiag_row<real_t, NL>(q[0], q[1], q[2]) : b0;
+                const real_t v0 = sub_exact(tridiag_row<real_t, NL>(p[0], p[1], p[2]), s0);
+                real_t *dst = fx + (int64_t)b * fs + i;
+                if (two) {
+                    const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
+                    *reinterpret_cast<r2_t *>(dst) = r2_t{v0, sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1)};
+                } else {
+                    dst[0] = v0;
                 }
             } else {
 #pragma unroll
@@ -266,7 +287,7 @@ template <typename CT, int MODE, int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                   const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t nx, int64_t ny,
-                  int64_t r0, int64_t r1, int imag_only)
+                  int64_t r0, int64_t r1, int imag_only, int diff)
 {
     const int64_t ntiles = (r1 - r0 + 2 * kBlock - 1) / (2 * kBlock);
     const int64_t tile = xcd_tile(blockIdx.x, ntiles);
@@ -286,11 +307,9 @@ k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base
         const int c = (int)color[at];
         cv[m] = (!ok[m] || c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
     }
-    if (base_out) {
-        real_t b0, b1;
-        stencil5_pair<real_t, SK>(xv, hs, hn, hw, he, b0, b1);
-        *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
-    }
+    real_t b0 = 0.0, b1 = 0.0;                        // f(x) at rows k, k+1 (written to base_out, or the subtrahend of diff)
+    if (base_out || (diff && MODE == 0)) stencil5_pair<real_t, SK>(xv, hs, hn, hw, he, b0, b1);
+    if (base_out) *reinterpret_cast<r2_t *>(base_out + k) = r2_t{b0, b1};
     for (int b = 0; b < B; ++b) {
         const real_t e = eps[c_lo + b];
         real_t d[8];
@@ -308,6 +327,14 @@ k_f_stencil5_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base
                 *reinterpret_cast<r2_t *>(dst) = r2_t{o0.re, o0.im};
                 *reinterpret_cast<r2_t *>(dst + 2) = r2_t{o1.re, o1.im};
             }
+        } else if (diff) {
+            // differences (fd_lazy_points.diff): f(x + d) - f(x), or f(x + d) - f(x - d), one array per colour
+            real_t p[8], q[8], o0, o1, s0 = b0, s1 = b1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { p[m] = xv[m] + d[m]; q[m] = xv[m] - d[m]; }
+            stencil5_pair<real_t, SK>(p, hs, hn, hw, he, o0, o1);
+            if (MODE == 1) stencil5_pair<real_t, SK>(q, hs, hn, hw, he, s0, s1);
+            *reinterpret_cast<r2_t *>(fx + (int64_t)b * fs + k) = r2_t{sub_exact(o0, s0), sub_exact(o1, s1)};
         } else {
 #pragma unroll
             for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
@@ -512,7 +539,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
 #define FD_LAZY(MODE, NL)                                                                                           \
     hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (real_t *)fx, fs,    \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,     \
-                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only)
+                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0)
     if (mode == 0) { if (nl) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (nl) FD_LAZY(1, true); else FD_LAZY(1, false); }
     else { if (nl) FD_LAZY(2, true); else FD_LAZY(2, false); }
@@ -532,7 +559,7 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
 #define FD_LAZY(MODE, CL)                                                                                          \
     hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (real_t *)fx, fs,            \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,    \
-                       lp->ncolors, b->prm[0], b->prm[1], r0e, r1, lp->imag_only)
+                       lp->ncolors, b->prm[0], b->prm[1], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0)
 #define FD_LAZY_SK(MODE) do { if (sk == 1) FD_LAZY(MODE, 1); else if (sk == 2) FD_LAZY(MODE, 2); else FD_LAZY(MODE, 0); } while (0)
     if (mode == 0) FD_LAZY_SK(0);
     else if (mode == 1) FD_LAZY_SK(1);
@@ -887,7 +914,8 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     if (!has_lazy(b)) return 6;
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
-    const int64_t npts = (int64_t)lp->ncolors * lp->pts + (lp->base_out ? 1 : 0);
+    if (lp->diff && (b->family == FD_F_BLOCKCOUPLED || lp->is_complex || lp->base_out)) return 8;   // (not registered with FD_LAZY_CAP_DIFF)
+    const int64_t npts = (int64_t)lp->ncolors * lp->pts + ((lp->base_out || lp->diff == 2) ? 1 : 0);
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
         return FD_LAZY_DECLINED;
@@ -998,7 +1026,7 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
-    *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : FD_LAZY_CAP_ROW_WINDOW)) : 0;
+    *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF))) : 0;
     return FD_OK;
 }
 

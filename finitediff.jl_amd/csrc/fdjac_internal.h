@@ -236,6 +236,11 @@ struct fd_plan {
     const fdjac::real_t *fx_batch_row = nullptr;   // f(x) evaluated as one more member of the perturbed batch (small problems)
     fd_f_launch_lazy lazy_fn = nullptr;
     int lazy_caps = 0;             // FD_LAZY_CAP_* of lazy_fn
+    bool lazy_diff = true;         // ask a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never)
+    fdjac::real_t *d_zero_own = nullptr;      // an all-zero vector of ldf elements (allocated on first use by forward / central plans)
+    const fdjac::real_t *d_zero = nullptr;    // the "fx" of decompressions whose f! arrays already hold differences or imaginary
+                                              //   parts: d_fx for the complex step (never written), d_zero_own otherwise
+    fdjac::real_t *d_eps2 = nullptr;          // 2 * eps per colour (central differences handed over as f(+) - f(-))
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
     int eps_mode = 0;              // FD_EPS_COMPUTE / FD_EPS_PRECOMPUTED
     int64_t partial_cap = 0;       // doubles allocated behind d_partial

@@ -1543,10 +1543,10 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
     // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
     const bool dma_off = !p->dma;   // (fixed at plan creation)
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
-    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->d_fx - p->cur_shift) || (fx == p->fx_batch_row);
+    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->d_fx - p->cur_shift) || (fx == p->fx_batch_row) || (fx == p->d_zero);
     // the imaginary parts of an imag-only complex step arrive as a real array with fx = the plan's all-zero vector:
     // a - 0.0 == a, so the kernels are told not to load it at all
-    const bool fx_zero = (MODE == 0) && p->fdtype == FD_COMPLEX && fx == p->d_fx;
+    const bool fx_zero = (MODE == 0) && p->d_zero != nullptr && fx == p->d_zero;
     if (fx_zero) FXb = nullptr;
     const bool dma = (MODE != 2) && fxvec && !fx_zero && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
     // LDS pitch between colours: whole 1-KiB DMA chunks, or (register path) a pitch that is 2 mod 32 elements so
@@ -1674,13 +1674,13 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         if (p->tri_window) {
             const int64_t nt = (p->col1 - p->col0 + kTriTile - 1) / kTriTile;
             const int64_t du0 = p->col0 > 0 ? p->col0 - 1 : 0;
-            const int fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row);
+            const int fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row) || (fx == p->d_zero);
             const int vok = ((((uintptr_t)outs[1]) & kPairMask) == 0 ? 1 : 0) | ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 2 : 0) |
                             (((((uintptr_t)outs[2]) + sizeof(real_t) * (uintptr_t)(p->col0 - du0)) & kPairMask) == 0 ? 4 : 0) |
                             (tile_order_reversed() ? 8 : 0);
             const size_t shmt = sizeof(real_t) * ((size_t)(kTriTile + 4) * (size_t)B + kWinMaxCol);
             // (imag-only complex step: fx is the all-zero vector and is not loaded, see launch_window_m)
-            const real_t *fxb_t = ((MODE == 0) && p->fdtype == FD_COMPLEX && fx == p->d_fx) ? nullptr : FXb;
+            const real_t *fxb_t = ((MODE == 0) && p->d_zero != nullptr && fx == p->d_zero) ? nullptr : FXb;
             hipLaunchKernelGGL((k_decompress_tridiag_window<CT, MODE, 4>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock),
                                shmt, s, color, FXa, fxb_t, p->ldf, p->d_eps, c_lo, c_hi, p->N, p->col0, p->col1, outs[0],
                                outs[1], outs[2], fxvec, vok);
@@ -1711,7 +1711,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         if (p->cr_wg) {   // (chosen at plan creation, FD_INFO_COLRANGE_WG)   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
             const int64_t nc = p->col1 - p->col0;
             // the imaginary parts of an imag-only complex step arrive as a real array with fx = the zero vector
-            const real_t *fxb = (MODE == 0 && p->fdtype == FD_COMPLEX && FXb == p->d_fx) ? nullptr : FXb;
+            const real_t *fxb = (MODE == 0 && p->d_zero != nullptr && FXb == p->d_zero) ? nullptr : FXb;
             const bool cr_vec_off = env_i64("FDJAC_COLRANGE_VEC", 1) == 0;   // (read per launch: tests toggle it)
             const bool vec = p->cr_pairs && !cr_vec_off && (((uintptr_t)outs[0]) & kPairMask) == 0 &&
                              (MODE != 0 || fxb == nullptr || (((uintptr_t)fxb) & kPairMask) == 0);
@@ -1755,6 +1755,21 @@ int launch_fill(fd_ctx *ctx, real_t *ptr, int64_t n, real_t v)
 {
     if (n <= 0) return FD_OK;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, kBlock, ctx->num_cus)), dim3(kBlock), 0, ctx->stream, ptr, n, v);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+__global__ void k_scale(real_t *__restrict__ dst, const real_t *__restrict__ src, int64_t n, real_t factor)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = factor * src[i];
+}
+
+// dst[i] = factor * src[i] (the doubled step sizes of central differences handed over as f(+) - f(-): 2 eps is exact)
+int launch_scale(fd_ctx *ctx, real_t *dst, const real_t *src, int64_t n, real_t factor)
+{
+    if (n <= 0) return FD_OK;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, dst, src, n, factor);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }

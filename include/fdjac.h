@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 200
+#define FDJAC_VERSION 201
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -106,6 +106,14 @@ typedef struct fd_lazy_points {
                           /* parts together cover every row once (one f! evaluation per point, in pieces).  1 part   */
                           /* otherwise.  fx / base_out then address a scratch that holds ONLY those rows: row r of   */
                           /* point b is still fx[b*fx_stride + r], but rows outside the window must not be touched   */
+    int32_t diff;         /* forward / central only, set only for launchers registered with FD_LAZY_CAP_DIFF: write  */
+                          /* the DIFFERENCES the reference forms next (src/jacobians.jl:565,607) instead of the      */
+                          /* values -- forward: fx[b*fx_stride + r] = f(point b)[r] - f(x)[r]; central: ncolors      */
+                          /* arrays, fx[b*fx_stride + r] = f(plus point b)[r] - f(minus point b)[r] -- each an IEEE  */
+                          /* subtraction of the two values the plain path would have stored (same bits, half the     */
+                          /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
+                          /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
+    int32_t reserved0;
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -216,6 +224,7 @@ enum fd_plan_info_key {
     FD_INFO_LDS_DMA = 23,             /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
     FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
+    FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
     FD_INFO_ROLL = 28,                /* 1 if a 2-D stencil plan uses the rolling row windows (one wave walks a column strip) */
     FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
     FD_INFO_STRIPS = 26               /* row strips per Jacobian the plan would use with a FD_LAZY_CAP_ROW_WINDOW launcher (1 = none) */
@@ -248,6 +257,7 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
 #define FD_LAZY_CAP_ROW_WINDOW 2  /* writes ONLY rows [row_begin & ~1, row_end + 1) of fx / base_out: the library may then  */
                                   /* evaluate f! and decompress in row strips that reuse one cache-sized scratch            */
                                   /* (fd_lazy_points.part / nparts; DESIGN.md "row strips")                                 */
+#define FD_LAZY_CAP_DIFF 4        /* honours fd_lazy_points.diff: writes f(point) - f(x) / f(plus) - f(minus) itself         */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */

@@ -21,6 +21,7 @@ def mean_counter(db, kernel_like, counter):
 
 fetch_db, write_db, n, gpus = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 kernel = sys.argv[5] if len(sys.argv) > 5 else "k_decompress"
+lazy_diff = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # 1: the profiled run used FD_LAZY_CAP_DIFF (bench.py matches on it)
 copy_bytes = float(1 << 30)
 cf, _ = mean_counter(fetch_db, "k_stream_copy", "FETCH_SIZE")
 cw, _ = mean_counter(write_db, "k_stream_copy", "WRITE_SIZE")
@@ -29,7 +30,7 @@ kw = copy_bytes / (cw * 1024.0)  # expected 1.0
 df, nf = mean_counter(fetch_db, kernel, "FETCH_SIZE")
 dw, nw = mean_counter(write_db, kernel, "WRITE_SIZE")
 out = {
-    "n": n, "gpus": gpus, "kernel": kernel,
+    "n": n, "gpus": gpus, "kernel": kernel, "lazy_diff": lazy_diff,
     "calibration": {"kernel": "k_stream_copy (1 GiB read + 1 GiB write per launch)", "fetch_factor": kf, "write_factor": kw,
                     "fetch_kb_raw": cf, "write_kb_raw": cw},
     "decompress_fetch_kb_raw": df, "decompress_write_kb_raw": dw, "dispatches": [nf, nw],

@@ -8,7 +8,9 @@ OUT=$REPO/gpurun_out/$NAME
 bash $REPO/scripts/profile.sh $NAME --config $CFG "$@"
 S=$(find $OUT/stats -name '*.db' | head -1); F=$(find $OUT/pmc_fetch -name '*.db' | head -1); W=$(find $OUT/pmc_write -name '*.db' | head -1)
 python $REPO/scripts/rocpd_summary.py $S $F $W > $OUT/summary.md 2> $OUT/summary.err
-python $REPO/scripts/make_pmc_json.py $F $W $N 1 $KERN > $OUT/pmc.json 2>> $OUT/summary.err
+# (forward / central configs hand differences over unless FDJAC_LAZY_DIFF=0; the complex step never does)
+DIFF=1; [ "${FDJAC_LAZY_DIFF:-1}" = "0" ] && DIFF=0; [ "$CFG" = "c5" ] && DIFF=0
+python $REPO/scripts/make_pmc_json.py $F $W $N 1 $KERN $DIFF > $OUT/pmc.json 2>> $OUT/summary.err
 cd $REPO && python bench.py --config $CFG "$@" > $OUT/bench.json 2> $OUT/bench.err
 python - $OUT >> $OUT/summary.md <<'PY'
 import re, sys

@@ -1424,3 +1424,93 @@ def test_rolling_row_windows_bit_identical(monkeypatch, fdtype, case):
         outs[variant] = out.cpu().numpy()
     assert not np.isnan(outs["gather"]).any()
     assert np.array_equal(outs["roll"], outs["gather"]) and np.array_equal(outs["tiles2d"], outs["gather"])
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("case", ["tridiag_nl", "tridiag_nl_small", "tridiag_nl_chunked", "tridiag_nl_none", "tridiag_nl_window", "tridiag_nl_owned",
+                                  "tridiag_nl_gather", "tridiag_native", "banded", "lap5_nl", "lap5_nl_gather", "lap5_nl_chunked", "clamp5", "lap5"])
+def test_lazy_differences_bit_identical(monkeypatch, fdtype, case):
+    # FD_LAZY_CAP_DIFF: the lazy launcher hands over f(x + d) - f(x) / f(x + d) - f(x - d) (the subtraction of
+    # src/jacobians.jl:565,607 moved into f!'s launch), the decompression divides by eps / 2 eps.  Same bits as storing the
+    # values and subtracting in the decompression, for every kernel variant; same f! evaluation count.
+    win = own = None
+    cap = 0
+    if case.startswith("tridiag") or case == "banded":
+        N = 2001 if case == "tridiag_nl_small" else 70_001
+        colptr, rowval = P.tridiag_csc(N)
+        colors = P.cyclic_colors(N, 3)
+        fam, prm = "tridiag_nl", (N,)
+        if case == "tridiag_nl_chunked":
+            cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype == "central" else 1) * 2      # two colours per chunk
+        if case == "tridiag_nl_none":
+            colors[[0, 77, 4096, N - 1]] = 0
+        if case == "tridiag_nl_window":
+            win = (N // 5 + 1, 4 * N // 5)
+        if case == "tridiag_nl_owned":
+            own = (1, 3)
+        if case == "tridiag_nl_gather":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+    else:
+        nx, ny = 128, 96
+        N = nx * ny
+        colptr, rowval = P.lap5_csc(nx, ny)
+        colors = P.lap5_colors(nx, ny)
+        fam, prm = ("clamp5" if case == "clamp5" else "lap5" if case == "lap5" else "lap5_nl"), (nx, ny)
+        if case == "lap5_nl_gather":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+        if case == "lap5_nl_chunked":
+            cap = 8 * 2 * N * (2 if fdtype == "central" else 1) * 2 + 4096
+    x = _dev(np.random.default_rng(61).random(N))
+    outs, calls = [], []
+    for diff in (True, False, "env"):
+        monkeypatch.setenv("FDJAC_LAZY_DIFF", "0") if diff == "env" else monkeypatch.delenv("FDJAC_LAZY_DIFF", raising=False)
+        if case == "tridiag_native":
+            plan = fd.make_plan(fd.Tridiagonal(None, np.empty(N), None), None, colors, fdtype)
+        elif case == "banded":
+            plan = fd.make_plan(fd.BandedMatrix(None, N, 1, 1), None, colors, fdtype)
+        else:
+            J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, color_range=own,
+                                x_window=(max(win[0] - 3, 1), min(win[1] + 3, N)) if win else None)
+        if "chunked" in case:
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        f = fd.BuiltinF(fam, *prm)
+        assert f.lazy_caps & fd.lib.LAZY_CAP_DIFF
+        plan.set_lazy(f, diff=(diff is not False))
+        assert plan.info(fd.lib.INFO_LAZY_DIFF) == (1 if diff is True else 0)
+        o = [_dev(np.full(plan.out_len(k), 0.0 if own else np.nan)) for k in range(plan.info(fd.lib.INFO_NOUTS))]
+        plan.jacobian(f, x, o)
+        outs.append([t.cpu().numpy() for t in o])
+        calls.append((f.fcalls, plan.fcalls_last))
+    for a, b, c in zip(*outs):
+        assert not np.isnan(a).any()
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert calls[0] == calls[1] == calls[2]
+    C = int(colors.max())
+    ncol = (own[1] - own[0]) if own else C
+    assert calls[0][0] == ncol * (2 if fdtype == "central" else 1) + (1 if fdtype == "forward" else 0)
+
+
+def test_lazy_differences_respect_f_in_and_oracle(oracle):
+    # a caller-supplied f_in is the subtrahend the reference uses (src/jacobians.jl:540-545): no differences from the
+    # launcher then; without it the differences path must still match the oracle
+    N = 50_001
+    colptr, rowval = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    xh = np.random.default_rng(62).random(N)
+    x = _dev(xh)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    f = fd.BuiltinF("tridiag_nl", N)
+    plan = fd.make_plan(J, J, colors, "forward")
+    plan.set_lazy(f)
+    xp = np.concatenate([[0.0], xh, [0.0]])
+    bogus = _dev(xp[:-2] - 2 * xp[1:-1] + xp[2:] + xp[1:-1] ** 2 * xp[2:] + 1.0)     # f(x) + 1, NOT f(x): the result must show it
+    a, b = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
+    plan.jacobian(f, x, [a])
+    plan.jacobian(f, x, [b], f_in=bogus)
+    ref = oracle.jacobian("forward", oracle.Fixture("tridiag_nl", N), xh, colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    em = np.min(np.abs(_oracle_eps(xh, colors, "forward")))
+    _tol_ok(a.cpu().numpy(), ref["out"], em, 8.0, "lazy differences")
+    assert not torch.equal(a, b)
+    eps = np.abs(_oracle_eps(xh, colors, "forward"))
+    assert np.all(np.abs((a - b).cpu().numpy()) > 0.5 / eps.max())     # every entry moved by ~ 1/eps
