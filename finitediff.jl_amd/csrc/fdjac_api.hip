@@ -137,6 +137,9 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     p->eps_nt = env_int("FDJAC_EPS_NT", 1) != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
+    // opt-in: inside the pipeline the computed-index kernel measured 113-119 us against 103 us for the row windows
+    // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
+    p->band_allowed = env_int("FDJAC_BAND_DIRECT", 0) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -829,6 +832,64 @@ static void gather_coherence(size_t ntiles, size_t step, RowsOf rows_of, NzcOf n
     *lines_sorted = ls / std::max<size_t>(ninstr, 1);
 }
 
+// Uniform band with cyclic colours -> k_decompress_band for the whole tiles inside it (shared by the host and the device
+// builder).  The columns [ju0, ju1) hold w consecutive rows j - u .. j - u + w - 1 each, the first of them starts at the
+// local entry e_ju0; colours are (j + shift) mod C for every column.
+static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, int64_t ju0, int64_t ju1, int64_t C, int shift)
+{
+    p->band_ok = false;
+    if (!p->band_allowed || !p->window || p->window2d || p->win_tile <= 0 || w < 1 || w > 64 || C < 1 || C > 64 || ju1 <= ju0) return;
+    const int64_t T = p->win_tile, all_tiles = (p->nnz_local + T - 1) / T;
+    const int64_t pu0 = e_ju0, pu1 = e_ju0 + w * (ju1 - ju0);
+    const int64_t off = w * ju0 - e_ju0;
+    int64_t t0 = (pu0 + T - 1) / T, t1 = pu1 / T;
+    if (pu1 >= p->nnz_local) t1 = all_tiles;
+    if (t1 <= t0 || 2 * (t1 - t0) < all_tiles) return;                  // not worth a second kernel
+    if (off + t0 * T < 0 || off + p->nnz_local + 2 >= ((int64_t)1 << 31) || ju1 + C + 64 >= ((int64_t)1 << 31)) return;
+    if (u < -((int64_t)1 << 30) || u > ((int64_t)1 << 30)) return;
+    p->band_ok = true;
+    p->band_t0 = t0; p->band_t1 = t1; p->band_off = off; p->band_C = C;
+    p->band_w = (int)w; p->band_u = (int)u; p->band_shift = shift;
+    p->band_mw = (((uint64_t)1 << 40) + (uint64_t)w - 1) / (uint64_t)w;
+    p->band_mc = (((uint64_t)1 << 40) + (uint64_t)C - 1) / (uint64_t)C;
+}
+
+// colorvec == (j + shift) mod C for every column (no column without colour)?
+static bool colors_cyclic(const std::vector<int32_t> &col0, int64_t C, int *shift_out)
+{
+    if (col0.empty() || C < 1 || col0[0] < 0) return false;
+    const int64_t sh = col0[0];
+    for (size_t j = 0; j < col0.size(); ++j)
+        if (col0[j] != (int32_t)(((int64_t)j + sh) % C)) return false;
+    *shift_out = (int)sh;
+    return true;
+}
+
+// host detection for a common-pattern CSC plan: the largest run of columns around the middle one with the middle
+// column's number of consecutive rows and an affine colptr
+static void try_band_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows, const std::vector<int64_t> &colstart)
+{
+    if (!p->band_allowed || !p->window || p->window2d || p->col1 - p->col0 < 4) return;
+    int shift = 0;
+    if (!colors_cyclic(col0, p->C, &shift)) return;
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    auto cs = [&](int64_t j) { return colstart[(size_t)(j - p->col0)]; };
+    const int64_t w = cs(jm + 1) - cs(jm);
+    if (w < 1 || w > 64) return;
+    const int64_t u = jm - rows[(size_t)cs(jm)];
+    auto viol = [&](int64_t j) {
+        if (cs(j + 1) - cs(j) != w || cs(j) != cs(jm) + w * (j - jm)) return true;
+        for (int64_t k = 0; k < w; ++k)
+            if (rows[(size_t)(cs(j) + k)] != j - u + k) return true;
+        return false;
+    };
+    if (viol(jm)) return;
+    int64_t ju0 = jm, ju1 = jm + 1;
+    while (ju0 > p->col0 && !viol(ju0 - 1)) --ju0;
+    while (ju1 < p->col1 && !viol(ju1)) ++ju1;
+    finish_band_plan(p, w, u, cs(ju0), ju0, ju1, p->C, shift);
+}
+
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
 static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
                             std::vector<int32_t> &nzc, std::vector<int64_t> &dest,
@@ -868,6 +929,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         const bool win_allowed = !(fw1 && *fw1 && atoi(fw1) == 0) && !(fs1 && *fs1 && atoi(fs1) == 1);
         if (scattered && colstart && win_allowed && (rc = try_window2d_plan(p, rows, nzc, *colstart))) return rc;
         if (!p->window && (rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
+        if (p->window && colstart && p->kind == K_CSC) try_band_plan_csc(p, col0, rows, *colstart);
         if (p->window) {
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
@@ -1163,7 +1225,9 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
     const int64_t scal[] = {p->kind, p->fdtype, p->M, p->N, p->C, p->color8, p->col0, p->col1, p->row0, p->row1, p->nnz_local,
                             p->entry_begin, p->window, p->window2d, p->sorted_gather, p->win_tile, p->win_pairs, p->win_ncol,
                             p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
-                            p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6)};
+                            p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6),
+                            p->band_ok, p->band_t0, p->band_t1, p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
+                            (int64_t)p->band_mw, (int64_t)p->band_mc};
     mix(scal, sizeof scal);
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
@@ -1347,6 +1411,8 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
                 }
             p->nnz_local = slots;
             FD_TRY(try_window_plan(p, rows, nzc, padded, false));
+            int shift = 0;
+            if (p->window && colors_cyclic(col0, p->C, &shift)) finish_band_plan(p, w, u, 0, p->col0, p->col1, p->C, shift);
         }
     }
     FD_TRY(alloc_scratch(p, col0));
@@ -1496,6 +1562,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
     case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
+    case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
     case FD_INFO_LAZY_DIFF:
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
         break;
@@ -1640,6 +1707,12 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     p->fx_batch_row = nullptr;
     if (small_points) { const int rc = ensure_points(p); if (rc) return rc; }
 
+    // a launcher that hands over central differences: the doubled step sizes come out of the finalize launch
+    if (p->fdtype == FD_CENTRAL && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->kind != K_DENSE) {
+        const int rc = ensure_diff_scratch(p);
+        if (rc) return rc;
+    }
+    if (p->eps_mode != FD_EPS_PRECOMPUTED) p->eps2_fresh = false;
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
         // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current
@@ -1812,7 +1885,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             if (diff_done) {
                 real_t *eps_plain = p->d_eps;
                 if (p->fdtype == FD_CENTRAL) {
-                    if ((rc = launch_scale(p->ctx, p->d_eps2 + c_lo, p->d_eps + c_lo, B, (real_t)2))) return rc;
+                    if (!p->eps2_fresh && (rc = launch_scale(p->ctx, p->d_eps2 + c_lo, p->d_eps + c_lo, B, (real_t)2))) return rc;
                     p->d_eps = p->d_eps2;
                 }
                 rc = launch_decompress(p, p->d_zero, c_lo, c_hi, outs, (int)FD_FORWARD);

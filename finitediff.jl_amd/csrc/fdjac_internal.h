@@ -190,6 +190,14 @@ struct fd_plan {
     int roll_L = 0, roll_hl = 0, roll_cmin = 0, roll_ncol = 0, roll_H = 0;
     bool window2d = false;         //   2-D (strided) tiles: d_w2desc[kW2Desc * ntiles], codes in tile order
     int *d_w2desc = nullptr;
+    // uniform band with cyclic colours (k_decompress_band): the whole tiles [band_t0, band_t1) of the 1-D row-window plan
+    // are decompressed with computed indices -- local entry p <-> Q = p + band_off = band_w * j + k, row j - band_u + k,
+    // colour (j + band_shift) mod band_C; band_mw / band_mc = ceil(2^40 / band_w), ceil(2^40 / band_C)
+    bool band_allowed = false;     //   FDJAC_BAND_DIRECT=1 (opt-in: not faster inside the pipeline, see apply_opts)
+    bool band_ok = false;
+    int64_t band_t0 = 0, band_t1 = 0, band_off = 0, band_C = 0;
+    int band_w = 0, band_u = 0, band_shift = 0;
+    uint64_t band_mw = 0, band_mc = 0;
     int64_t w2_ntiles = 0;
     int64_t w2_codes = 0;          //   number of 16-bit codes in d_wcode (2-D tiles)
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15
@@ -241,6 +249,7 @@ struct fd_plan {
     const fdjac::real_t *d_zero = nullptr;    // the "fx" of decompressions whose f! arrays already hold differences or imaginary
                                               //   parts: d_fx for the complex step (never written), d_zero_own otherwise
     fdjac::real_t *d_eps2 = nullptr;          // 2 * eps per colour (central differences handed over as f(+) - f(-))
+    bool eps2_fresh = false;                  //   d_eps2 matches d_eps (written by the finalize launch; else launch_scale)
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
     int eps_mode = 0;              // FD_EPS_COMPUTE / FD_EPS_PRECOMPUTED
     int64_t partial_cap = 0;       // doubles allocated behind d_partial

@@ -170,7 +170,7 @@ k_eps_partial_seg(const real_t *__restrict__ x, const int32_t *__restrict__ perm
 //   central: max(relstep*abs(sqrt(norm)), absstep)       (src/epsilons.jl:50-53; jacobians.jl:602)
 __global__ void __launch_bounds__(kBlock)
 k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double relstep,
-               double absstep, double dir, int is_forward, real_t *__restrict__ eps)
+               double absstep, double dir, int is_forward, real_t *__restrict__ eps, real_t *__restrict__ eps2)
 {
     const int c = blockIdx.x;
     double acc = 0.0;
@@ -189,6 +189,7 @@ k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double r
         real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
         if (is_forward) e = e * (real_t)dir;
         eps[c] = e;
+        if (eps2) eps2[c] = (real_t)2 * e;                  // (central differences handed over as f(+) - f(-), see launch_scale)
     }
 }
 
@@ -1453,7 +1454,8 @@ int launch_eps_partial(fd_plan *p, const real_t *x, int b0, int nb)
 int launch_eps_finalize(fd_plan *p, int nparts, int ldp, double relstep, double absstep, double dir)
 {
     hipLaunchKernelGGL(k_eps_finalize, dim3((unsigned)p->C), dim3(kBlock), 0, p->ctx->stream, p->d_partial, nparts, ldp, relstep,
-                       absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
+                       absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps, p->d_eps2);
+    p->eps2_fresh = p->d_eps2 != nullptr;
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
@@ -1534,6 +1536,70 @@ int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B)
 #undef FD_DISPATCH
 }
 
+// ---------------------------------------------------------------------------------------------
+// Uniform bands with cyclic colours (tridiagonal / banded SparseMatrixCSC away from the corners, BandedMatrix storage):
+// local entry p <-> Q = p + off = w*j + k (column j, slot k of w), row r = j - u + k, colour (j + shift) mod C.  Nothing
+// is loaded but the f! values themselves: every thread computes the (row, colour) of its two consecutive entries,
+// gathers them (8-B loads that neighbouring lanes coalesce: consecutive entries of a column are consecutive rows of one
+// array) and stores 16-B pairs.  No descriptor, no LDS staging, no barrier.  In a hot loop of its own it runs at the speed
+// of a linear copy (scripts/ubench/band_direct_probe.hip: 81-86 us against 79 us for 480 MB at N = 10^7); INSIDE the
+// pipeline -- behind f!'s 240 MB of fresh stores -- it needs 113-119 us where the row-window kernel needs 103 us (the call is
+// bound by its total HBM traffic, and the windows' long contiguous reads use the DRAM better than 8-B gathers over
+// three arrays).  Opt-in therefore (FDJAC_BAND_DIRECT=1, FD_INFO_BAND_DIRECT).  Same operations on the same operands as
+// the row-window kernel: same bits.  Entries outside [p0, p1) (truncated corner columns) stay with the row-window kernel.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int U>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_band(const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
+                  const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t p0, int64_t p1,
+                  int64_t off, int w, int u, int C, int shift, uint64_t mw, uint64_t mc, int reversed)
+{
+    const int64_t ntiles = (p1 - p0 + 2 * kBlock * U - 1) / (2 * kBlock * U);
+    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
+    if (xt >= ntiles) return;
+    const int64_t tile = reversed ? ntiles - 1 - xt : xt;       // reversed tile order, see tile_order_reversed()
+    const int lane = threadIdx.x & 63;
+    const real_t my_eps = (lane < c_hi - c_lo) ? eps[c_lo + lane] : (real_t)1;     // (c_hi - c_lo <= 64: colour c's step size sits in lane c - c_lo)
+    real_t q[U][2];
+    bool wr[U][2];
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t p = p0 + tile * (2 * kBlock * U) + uu * (2 * kBlock) + 2 * (int64_t)threadIdx.x;
+        const uint32_t Q = (uint32_t)(p + h + off);
+        const uint32_t j = (uint32_t)(((uint64_t)Q * mw) >> 40), k = Q - j * (uint32_t)w;
+        const uint32_t cj = j + (uint32_t)shift;
+        const int c = (int)(cj - (uint32_t)(((uint64_t)cj * mc) >> 40) * (uint32_t)C);
+        const int64_t r = (int64_t)j - u + k;
+        const bool live = p + h < p1;
+        const bool inside = live & (r >= 0) & (r < M);
+        const bool mine = (c >= c_lo) & (c < c_hi);
+        const bool ld_ok = inside & mine;
+        const int64_t at = ld_ok ? (int64_t)(c - c_lo) * ld + r : 0;
+        real_t a, b = (real_t)0;
+        if (MODE == 2) a = FXa[2 * at + 1];
+        else a = FXa[at];
+        if (MODE == 0 && FXb != nullptr) b = FXb[ld_ok ? r : 0];
+        if (MODE == 1) b = FXb[at];
+        const real_t e = __shfl(my_eps, mine ? c - c_lo : 0, 64);
+        real_t v;
+        if (MODE == 0) v = (a - b) / e;
+        else if (MODE == 1) v = (a - b) / (2 * e);
+        else v = a / e;
+        q[uu][h] = ld_ok ? v : (real_t)0;
+        // slots outside the matrix (BandedMatrix corners) are written as 0 by the call that owns colour 0
+        wr[uu][h] = ld_ok | (live & !inside & (c_lo == 0));
+    }
+#pragma unroll
+    for (int uu = 0; uu < U; ++uu) {
+        const int64_t p = p0 + tile * (2 * kBlock * U) + uu * (2 * kBlock) + 2 * (int64_t)threadIdx.x;
+        if (wr[uu][0] & wr[uu][1]) *reinterpret_cast<r2_t *>(out + p) = r2_t{q[uu][0], q[uu][1]};
+        else if (wr[uu][0]) out[p] = q[uu][0];
+        else if (wr[uu][1]) out[p + 1] = q[uu][1];
+    }
+}
+
 template <int MODE>
 static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, const real_t *FXb, int c_lo, int c_hi,
                             real_t *out)
@@ -1585,7 +1651,26 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
         return;
     }
     const int64_t all_tiles = (p->nnz_local + p->win_tile - 1) / p->win_tile;
-    const int64_t tile0 = p->cur_ntl >= 0 ? p->cur_tile0 : 0, ntl = p->cur_ntl >= 0 ? p->cur_ntl : all_tiles;
+    int64_t tile0 = p->cur_ntl >= 0 ? p->cur_tile0 : 0, ntl = p->cur_ntl >= 0 ? p->cur_ntl : all_tiles;
+    // uniform band: the whole tiles [band_t0, band_t1) go through the computed-index kernel, the corner tiles below
+    int64_t tail0 = 0, tail_n = 0;
+    if (p->band_ok && p->cur_ntl < 0 && (vok & 1) && c_hi - c_lo <= 64) {
+        const int64_t pb0 = p->band_t0 * p->win_tile, pb1 = std::min<int64_t>(p->band_t1 * p->win_tile, p->nnz_local);
+        const int bu = (int)env_i64("FDJAC_BAND_U", 4);
+#define FD_LAUNCH_BAND(UU) do {                                                                                              \
+        const int64_t nt = (pb1 - pb0 + 2 * kBlock * UU - 1) / (2 * kBlock * UU);                                              \
+        hipLaunchKernelGGL((k_decompress_band<MODE, UU>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock), 0, s, FXa, FXb, ldw, p->M, \
+                           p->d_eps, c_lo, c_hi, out, pb0, pb1, p->band_off, p->band_w, p->band_u, (int)p->band_C, p->band_shift, \
+                           p->band_mw, p->band_mc, (vok & 4) ? 1 : 0); } while (0)
+        if (bu >= 8) FD_LAUNCH_BAND(8); else if (bu >= 4) FD_LAUNCH_BAND(4); else if (bu >= 2) FD_LAUNCH_BAND(2); else FD_LAUNCH_BAND(1);
+#undef FD_LAUNCH_BAND
+        tile0 = 0; ntl = p->band_t0;
+        tail0 = p->band_t1; tail_n = all_tiles - p->band_t1;
+        if (ntl == 0) { tile0 = tail0; ntl = tail_n; tail_n = 0; }
+        if (ntl == 0) return;
+    }
+    for (int part = 0; part < 2; ++part, tile0 = tail0, ntl = tail_n) {
+    if (ntl <= 0) break;
     const int64_t gw = 8 * xcd_chunks(ntl);
     const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + kWinHeadBytes;
 #define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
@@ -1593,12 +1678,13 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
                        (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, ldw, p->M, p->d_eps, c_lo,          \
                        c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic, tile0, ntl)
 #define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
-    if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); return; } }
+    if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); continue; } }
     if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }
     else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true, false); else FD_LAUNCH_WIN_U(6, false, false); }
     else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true, false); else FD_LAUNCH_WIN_U(kWinMaxCol, false, false); }
 #undef FD_LAUNCH_WIN_U
 #undef FD_LAUNCH_WIN
+    }
 }
 
 template <typename CT, int MODE>

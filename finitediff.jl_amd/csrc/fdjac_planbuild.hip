@@ -586,6 +586,39 @@ __global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ c
     }
 }
 
+// uniform-band test (try_band_plan_csc on the device): columns that do not hold the middle column's w consecutive rows
+// j - u .. or break the affine colptr; the nearest violators on either side of the middle column bound the band
+struct PbBandStat { long long lo, hi; int mid_bad; int pad; };
+__global__ void __launch_bounds__(kBlock) k_pb_band_check(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                          int64_t col0, int64_t col1, int64_t jm, int64_t cpm, int64_t w, int64_t u,
+                                                          PbBandStat *st)
+{
+    long long lo = -1, hi = 0x7fffffffffffffffll;
+    bool mid = false;
+    for (int64_t j = col0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < col1; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t a = pb_load(colptr, ib, j) - base, b = pb_load(colptr, ib, j + 1) - base;
+        bool bad = (b - a != w) || (a != cpm + w * (j - jm));
+        if (!bad)
+            for (int64_t k = 0; k < w; ++k) bad = bad || (pb_load(rowval, ib, a + k) - base != j - u + k);
+        if (bad) {
+            if (j < jm) lo = j > lo ? j : lo;
+            else if (j > jm) hi = j < hi ? j : hi;
+            else mid = true;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long a = __shfl_down(lo, off, 64), b = __shfl_down(hi, off, 64);
+        lo = a > lo ? a : lo; hi = b < hi ? b : hi;
+    }
+    const bool anymid = __builtin_amdgcn_ballot_w64(mid) != 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (lo > st->lo) atomicMax(&st->lo, lo);
+        if (hi < st->hi) atomicMin(&st->hi, hi);
+        if (anymid) st->mid_bad = 1;
+    }
+}
+
 // outcome of the device builder
 enum { PBR_DONE = 0, PBR_DECLINED = 1 };
 
@@ -1024,6 +1057,39 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
     }
+    // uniform band with cyclic colours: the computed-index kernel takes the tiles inside it (finish_band_plan)
+    if (p->band_allowed && !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
+        if (band) {
+            finish_band_plan(p, band->w, band->u, 0, p->col0, p->col1, C, shift);
+        } else if (p->col1 - p->col0 >= 4) {
+            const int64_t jm = (p->col0 + p->col1) / 2;
+            char raw[3][8];
+            const size_t ib = (size_t)idx_bytes;
+            PbBandStat hs{-1, 0x7fffffffffffffffll, 0, 0}, *d_bs = nullptr;
+            bool ok = hipMemcpyAsync(raw[0], (const char *)d_colptr + ib * (size_t)jm, 2 * ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                      hipStreamSynchronize(s) == hipSuccess;
+            const int64_t cpm = ok ? load_idx(raw[0], idx_bytes, 0) - idx_base : 0, cpm1 = ok ? load_idx(raw[0], idx_bytes, 1) - idx_base : 0;
+            const int64_t w = cpm1 - cpm;
+            ok = ok && w >= 1 && w <= 64 && cpm >= e0 && cpm1 <= e1 &&
+                 hipMemcpyAsync(raw[2], (const char *)d_rowval + ib * (size_t)cpm, ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess && hipMalloc((void **)&d_bs, sizeof(PbBandStat)) == hipSuccess;
+            if (ok) {
+                tmp.add(d_bs);
+                const int64_t u = jm - (load_idx(raw[2], idx_bytes, 0) - idx_base);
+                ok = hipMemcpyAsync(d_bs, &hs, sizeof hs, hipMemcpyHostToDevice, s) == hipSuccess;
+                if (ok) {
+                    hipLaunchKernelGGL(k_pb_band_check, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p->col1 - p->col0 + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
+                                       dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, idx_base, p->col0, p->col1, jm, cpm, w, u, d_bs);
+                    ok = hipMemcpyAsync(&hs, d_bs, sizeof hs, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                }
+                if (ok && !hs.mid_bad) {
+                    const int64_t ju0 = std::max<int64_t>(hs.lo + 1, p->col0), ju1 = std::min<int64_t>(hs.hi, p->col1);
+                    finish_band_plan(p, w, u, (cpm - e0) + w * (ju0 - jm), ju0, ju1, C, shift);
+                }
+            }
+        }
+    }
+    tm.mark("band test");
     p->built_on_device = true;
     tm.mark("descriptors to host");
     *rc_out = alloc_scratch(p, std::vector<int32_t>());     // (empty colour list: the cyclic test above stands)

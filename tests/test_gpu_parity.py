@@ -1514,3 +1514,72 @@ def test_lazy_differences_respect_f_in_and_oracle(oracle):
     assert not torch.equal(a, b)
     eps = np.abs(_oracle_eps(xh, colors, "forward"))
     assert np.all(np.abs((a - b).cpu().numpy()) > 0.5 / eps.max())     # every entry moved by ~ 1/eps
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_nodiff", "tridiag_chunked", "tridiag_owned", "tridiag_window", "tridiag_f_in", "tridiag_devplan",
+                                  "band5", "bidiag", "banded11", "banded23", "banded_rect", "tridiag_shifted", "tridiag_none"])
+def test_band_direct_kernel_bit_identical(monkeypatch, fdtype, case):
+    # Uniform bands with cyclic colours: k_decompress_band computes (row, colour) of every stored entry instead of staging
+    # row windows in LDS (FD_INFO_BAND_DIRECT); the corner tiles stay with the row-window kernel.  FDJAC_BAND_DIRECT=0 is the
+    # row-window kernel everywhere: same operations on the same operands, same bits.
+    N = M = 150_011
+    l = u = 1
+    win = own = f_in = None
+    cap = 0
+    banded = case.startswith("banded")
+    if case == "band5":
+        l = u = 2
+    if case == "bidiag":
+        l, u = 1, 0
+    if case == "banded23":
+        l, u = 2, 3
+    if case == "banded_rect":
+        l, u, M = 3, 1, N + 40
+    w = l + u + 1
+    colors = P.cyclic_colors(N, w)
+    if case == "tridiag_shifted":
+        colors = ((np.arange(N) + 2) % 3 + 1).astype(np.int64)
+    if case == "tridiag_none":
+        colors[[5, N // 2]] = 0                      # not cyclic any more: no band kernel
+    if case == "tridiag_chunked":
+        cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2
+    if case == "tridiag_owned":
+        own = (1, 3)
+    if case == "tridiag_window":
+        win = (N // 5 + 1, 4 * N // 5)
+    x = _dev(np.random.default_rng(71).random(N))
+    if case == "tridiag_f_in" and fdtype == "forward":
+        f_in = _dev(np.random.default_rng(72).random(N + 1))[1:]      # 8-B aligned only
+    A = torch.as_tensor(np.random.default_rng(73).random((M, w)), device="cuda")
+
+    def fn(fx, xx):   # f_i = sum_k A[i,k] * x[i - l + k]^2 (clamped): rows i depend on columns i-l .. i+u
+        idx = torch.arange(M, device="cuda")
+        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
+        for k in range(w):
+            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - l + k, 0, N - 1)] ** 2
+        fx.copy_(acc)
+
+    outs, infos = [], []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("FDJAC_BAND_DIRECT", direct)
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1" if case == "tridiag_devplan" else "0")
+        if banded:
+            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype)
+        else:
+            colptr, rowval = P.banded_csc(M, N, l, u)
+            J = fd.SparseMatrixCSC(M, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, color_range=own)
+        assert plan.info(fd.lib.INFO_WINDOW) == 1
+        infos.append(plan.info(fd.lib.INFO_BAND_DIRECT))
+        out = _dev(np.full(plan.out_len(0), 0.0 if own else np.nan))
+        if l == u == 1 and not banded and case != "tridiag_f_in":
+            f = fd.BuiltinF("tridiag_nl", N)
+            plan.set_lazy(f, diff=(case != "tridiag_nodiff"))
+        else:
+            f = fd.TorchF(fn, M, N)
+        plan.jacobian(f, x, [out], f_in=f_in)
+        outs.append(out.cpu().numpy())
+    assert infos == [0 if case == "tridiag_none" else 1, 0]
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
