@@ -792,11 +792,11 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
 }
 
 // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
-static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vector<std::pair<int64_t, int32_t>> &ord)
+static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vector<std::pair<uint64_t, int32_t>> &ord)
 {
     for (int k = 0; k < kSortTile; ++k) {
-        const int64_t c = nzc[k] >= 0 ? nzc[k] : (nzc[k] == -1 ? ((int64_t)1 << 31) : ((int64_t)1 << 31) + 1);
-        ord[(size_t)k] = {(c << 32) | ((int64_t)(uint32_t)rows[k]), k};
+        const uint64_t c = nzc[k] >= 0 ? (uint64_t)nzc[k] : (nzc[k] == -1 ? 0xFFFFFFFEull : 0xFFFFFFFFull);
+        ord[(size_t)k] = {(c << 32) | (uint64_t)(uint32_t)rows[k], k};
     }
     std::sort(ord.begin(), ord.end());
 }
@@ -807,7 +807,7 @@ static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vect
 template <class RowsOf, class NzcOf>
 static void gather_coherence(size_t ntiles, size_t step, RowsOf rows_of, NzcOf nzc_of, double *lines_direct, double *lines_sorted)
 {
-    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+    std::vector<std::pair<uint64_t, int32_t>> ord(kSortTile);
     auto line_key = [&](int32_t c, int32_t r) { return ((int64_t)c << 40) | (int64_t)(r >> 4); };
     double ld = 0, ls = 0;
     size_t ninstr = 0;
@@ -913,7 +913,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (has_dest) dest.resize(padded, 0);
     for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
 
-    std::vector<std::pair<int64_t, int32_t>> ord(kSortTile);
+    std::vector<std::pair<uint64_t, int32_t>> ord(kSortTile);
     auto sort_tile = [&](size_t b0) { sort_tile_entries(rows.data() + b0, nzc.data() + b0, ord); };
     bool scattered = false;
     if (!has_dest && p->nnz_local >= 4 * kSortTile) {

@@ -305,6 +305,68 @@ __global__ void __launch_bounds__(kBlock) k_pb_sample_expand(const void *__restr
     }
 }
 
+// gather_coherence (fdjac_api.hip) on the device: one workgroup per sampled tile of kSortTile entries.  out[2*t] = sum over
+// the tile's 32 wave-level gathers in STORAGE order of the distinct 128-B lines touched, out[2*t+1] = the same in
+// (colour, row, position)-sorted order (bitonic sort of the tile in LDS).  Integer counts: the host's averages follow exactly.
+__device__ __forceinline__ int pb_distinct64(long long key)
+{
+    // number of distinct keys among the 64 lanes: a lane counts if no lower lane holds its key
+    const int lane = threadIdx.x & 63;
+    bool dup = false;
+    for (int i = 0; i < 63; ++i) {
+        const long long ki = __shfl(key, i, 64);
+        dup = dup || (i < lane && ki == key);
+    }
+    return __popcll(__builtin_amdgcn_ballot_w64(!dup));
+}
+__global__ void __launch_bounds__(kBlock) k_pb_coherence(const int32_t *__restrict__ rows, const int32_t *__restrict__ nzc, int *__restrict__ out)
+{
+    __shared__ int s_row[kSortTile], s_col[kSortTile];
+    __shared__ unsigned long long s_key[kSortTile];
+    __shared__ unsigned short s_idx[kSortTile];
+    __shared__ int s_cnt[2];
+    const size_t b0 = (size_t)blockIdx.x * kSortTile;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < kSortTile; k += kBlock) {
+        const int r = rows[b0 + k], c = nzc[b0 + k];
+        s_row[k] = r; s_col[k] = c;
+        const unsigned long long cc = c >= 0 ? (unsigned long long)c : (c == -1 ? 0xFFFFFFFEull : 0xFFFFFFFFull);
+        s_key[k] = (cc << 32) | (unsigned long long)(unsigned)r;
+        s_idx[k] = (unsigned short)k;
+    }
+    __syncthreads();
+    auto line_key = [](int c, int r) { return (long long)(((unsigned long long)(long long)c << 40) | (unsigned long long)(long long)(r >> 4)); };
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int direct = 0;
+    for (int ii = wave; ii < 2 * (kSortTile / 128); ii += kBlock / 64) {
+        const int e = (ii >> 1) * 128 + 2 * lane + (ii & 1);
+        direct += pb_distinct64(line_key(s_col[e], s_row[e]));
+    }
+    // bitonic sort by (key, position)
+    for (int k = 2; k <= kSortTile; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long ka = s_key[i], kb = s_key[p];
+                    const unsigned short ia = s_idx[i], ib2 = s_idx[p];
+                    const bool a_gt_b = ka > kb || (ka == kb && ia > ib2);
+                    const bool up = (i & k) == 0;
+                    if (a_gt_b == up) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib2; s_idx[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    int sorted = 0;
+    for (int ii = wave; ii < 2 * (kSortTile / 128); ii += kBlock / 64) {
+        const int e = s_idx[(ii >> 1) * 128 + 64 * (ii & 1) + lane];
+        sorted += pb_distinct64(line_key(s_col[e], s_row[e]));
+    }
+    if (lane == 0) { atomicAdd(&s_cnt[0], direct); atomicAdd(&s_cnt[1], sorted); }
+    __syncthreads();
+    if (threadIdx.x < 2) out[2 * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
 // sampled columns for the stride: out[33 * i] = number of entries of column col0 + i * step (or -1: more than 32),
 // out[33 * i + 1 ...] = row - column of each
 __global__ void __launch_bounds__(kBlock) k_pb2_sample_cols(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
@@ -429,33 +491,59 @@ __global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ c
     __shared__ int s_nse[2];                                  // number of window starts / ends found
     __shared__ int s_starts[kW2MaxWin + 1], s_ends[kW2MaxWin + 1];
     __shared__ int s_wr[kW2MaxWin], s_wn[kW2MaxWin], s_cum[kW2MaxWin];
+    __shared__ long long s_ra[kW2MaxRun], s_rc0[kW2MaxRun];  // first local entry / first column of every run
+    __shared__ int s_rlen[kW2MaxRun], s_rnc[kW2MaxRun], s_roff[kW2MaxRun + 1], s_nrun;   // entries, columns, padded offset in the code list
     const int64_t t = blockIdx.x;
     const int slot = slot_of[t];
     if (slot < 0) return;
-    Pb2Runs rn;
-    pb2_runs(rn, colptr, ib, base, col0, col1, e0, s, L, R, g_lo, g_hi, t / nI, t % nI);
-    if (threadIdx.x == 0) { s_nse[0] = 0; s_nse[1] = 0; }
-    for (int r = 0; r < rn.n; ++r)
-        for (int k = threadIdx.x; k <= rn.ncols[r]; k += kBlock) s_cp[r][k] = (int)(pb_load(colptr, ib, rn.c0[r] + k) - base - e0 - rn.a[r]);
-    __syncthreads();
-    // ---- extent of the coloured entries
-    int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
-    bool fail = false;
-    auto for_entries = [&](auto fn) {   // fn(run, position in the tile's code list, row, colour byte)
-        int off = 0;
+    if (threadIdx.x == 0) {
+        Pb2Runs rn;
+        pb2_runs(rn, colptr, ib, base, col0, col1, e0, s, L, R, g_lo, g_hi, t / nI, t % nI);
+        int acc = 0;
         for (int r = 0; r < rn.n; ++r) {
             const int len = (int)(rn.b[r] - rn.a[r]);
-            for (int q = threadIdx.x; q < len; q += kBlock) {
-                int lo = 0, hi = rn.ncols[r];             // s_cp[lo] <= q < s_cp[hi]
+            s_ra[r] = rn.a[r]; s_rc0[r] = rn.c0[r]; s_rlen[r] = len; s_rnc[r] = rn.ncols[r]; s_roff[r] = acc;
+            acc += len + (len & 1);
+        }
+        s_roff[rn.n] = acc;
+        s_nrun = rn.n;
+        s_nse[0] = 0; s_nse[1] = 0;
+    }
+    __syncthreads();
+    const int nrun = s_nrun, nent = s_roff[nrun];
+    for (int r = 0; r < nrun; ++r)
+        for (int k = threadIdx.x; k <= s_rnc[r]; k += kBlock) s_cp[r][k] = (int)(pb_load(colptr, ib, s_rc0[r] + k) - base - e0 - s_ra[r]);
+    __syncthreads();
+    // ---- the tile's entries, once, into registers: every load of the tile is in flight together (position pos of the code
+    //      list -> run, entry of the run -> column by binary search in the run's colptr slice -> row, colour byte)
+    constexpr int E = (kPb2MaxEnt + kBlock - 1) / kBlock;
+    int e_row[E], e_cb[E];                               // e_cb: 0..253 colour, 0xFF none, 0x100 not an entry (pad slot / past the end)
+#pragma unroll
+    for (int uu = 0; uu < E; ++uu) {
+        const int pos = uu * kBlock + threadIdx.x;
+        e_row[uu] = 0; e_cb[uu] = 0x100;
+        if (pos < nent && nent <= kPb2MaxEnt) {
+            int r = 0;
+            while (r + 1 < nrun && s_roff[r + 1] <= pos) ++r;
+            const int q = pos - s_roff[r];
+            if (q < s_rlen[r]) {
+                int lo = 0, hi = s_rnc[r];                // s_cp[lo] <= q < s_cp[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (s_cp[r][mid] <= q) lo = mid; else hi = mid;
                 }
-                const int row = (int)(pb_load(rowval, ib, e0 + rn.a[r] + q) - base);
-                fn(r, off + q, row, (int)color8[rn.c0[r] + lo]);
+                e_row[uu] = (int)(pb_load(rowval, ib, e0 + s_ra[r] + q) - base);
+                e_cb[uu] = (int)color8[s_rc0[r] + lo];
             }
-            off += len + (len & 1);
         }
+    }
+    // ---- extent of the coloured entries
+    int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
+    bool fail = false;
+    auto for_entries = [&](auto fn) {   // fn(run (unused), position in the tile's code list, row, colour byte)
+#pragma unroll
+        for (int uu = 0; uu < E; ++uu)
+            if (e_cb[uu] != 0x100) fn(0, uu * kBlock + (int)threadIdx.x, e_row[uu], e_cb[uu]);
     };
     for_entries([&](int, int, int row, int cb) {
         if (cb == 0xFF) return;
@@ -539,8 +627,6 @@ __global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ c
         if (!fail) pairs = s_cum[nwin - 1];
         if (2 * pairs > 2048) fail = true;
     }
-    int nent = 0;
-    for (int r = 0; r < rn.n; ++r) { const int len = (int)(rn.b[r] - rn.a[r]); nent += len + (len & 1); }
     if (nent > kPb2MaxEnt) fail = true;
     if (fail) {
         if (threadIdx.x == 0) atomicOr(&st->flags, (unsigned)PB2_FAIL);
@@ -551,15 +637,12 @@ __global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ c
     if (threadIdx.x == 0) {
         int *d = desc + (size_t)kW2Desc * (size_t)slot;
         for (int k = 0; k < kW2Desc; ++k) d[k] = 0;
-        d[0] = any ? cmin : 0; d[1] = ncol; d[2] = pairs; d[3] = nwin; d[4] = rn.n; d[5] = nent;
+        d[0] = any ? cmin : 0; d[1] = ncol; d[2] = pairs; d[3] = nwin; d[4] = nrun; d[5] = nent;
         d[6] = (int)(unsigned)(code0 & 0xFFFFFFFFll); d[7] = (int)(code0 >> 32);
         for (int k = 0; k < nwin; ++k) { d[8 + 2 * k] = s_wr[k]; d[9 + 2 * k] = s_cum[k]; }
-        int acc = 0;
-        for (int r = 0; r < rn.n; ++r) {
-            const int len = (int)(rn.b[r] - rn.a[r]);
-            acc += len + (len & 1);
-            d[32 + 3 * r] = (int)(unsigned)(rn.a[r] & 0xFFFFFFFFll); d[33 + 3 * r] = (int)(rn.a[r] >> 32);
-            d[34 + 3 * r] = acc;
+        for (int r = 0; r < nrun; ++r) {
+            d[32 + 3 * r] = (int)(unsigned)(s_ra[r] & 0xFFFFFFFFll); d[33 + 3 * r] = (int)(s_ra[r] >> 32);
+            d[34 + 3 * r] = s_roff[r + 1];
         }
         if (2 * pairs > st->max_slots) atomicMax(&st->max_slots, 2 * pairs);
         if (ncol > st->max_ncol) atomicMax(&st->max_ncol, ncol);
@@ -576,14 +659,8 @@ __global__ void __launch_bounds__(kBlock) k_pb2_tiles(const void *__restrict__ c
         }
         code[code0 + pos] = c;
     });
-    {   // the pad slot of odd runs
-        int off = 0;
-        for (int r = 0; r < rn.n; ++r) {
-            const int len = (int)(rn.b[r] - rn.a[r]);
-            if ((len & 1) && threadIdx.x == 0) code[code0 + off + len] = 0x8000;
-            off += len + (len & 1);
-        }
-    }
+    if ((int)threadIdx.x < nrun && (s_rlen[threadIdx.x] & 1))          // the pad slot of odd runs
+        code[code0 + s_roff[threadIdx.x] + s_rlen[threadIdx.x]] = 0x8000;
 }
 
 // uniform-band test (try_band_plan_csc on the device): columns that do not hold the middle column's w consecutive rows
@@ -666,11 +743,18 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
         tmp.add(d_sc);
         hipLaunchKernelGGL(k_pb_sample_expand, dim3((unsigned)nsamp), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, e0,
                            nloc, d_color8, (int64_t)step, d_sr, d_sc);
-        std::vector<int32_t> sr(nsamp * kSortTile), sc(nsamp * kSortTile);
-        if (hipMemcpyAsync(sr.data(), d_sr, sizeof(int32_t) * sr.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipMemcpyAsync(sc.data(), d_sc, sizeof(int32_t) * sc.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
-        gather_coherence(ntiles, step, [&](size_t t) { return sr.data() + (t / step) * kSortTile; },
-                         [&](size_t t) { return sc.data() + (t / step) * kSortTile; }, &p->lines_direct, &p->lines_sorted);
+        int *d_cnt = nullptr;
+        if (hipMalloc((void **)&d_cnt, sizeof(int) * 2 * nsamp) != hipSuccess) return PBR_DECLINED;
+        tmp.add(d_cnt);
+        hipLaunchKernelGGL(k_pb_coherence, dim3((unsigned)nsamp), dim3(kBlock), 0, s, d_sr, d_sc, d_cnt);
+        std::vector<int> cnt(2 * nsamp);
+        if (hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
+        // (the host's gather_coherence: sums of per-gather line counts / number of gathers; integers, so the same doubles)
+        double ld = 0, ls = 0;
+        for (size_t t = 0; t < nsamp; ++t) { ld += (double)cnt[2 * t]; ls += (double)cnt[2 * t + 1]; }
+        const size_t ninstr = nsamp * 2 * (kSortTile / 128);
+        p->lines_direct = ld / (double)std::max<size_t>(ninstr, 1);
+        p->lines_sorted = ls / (double)std::max<size_t>(ninstr, 1);
         if (!(p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted)) return PBR_DECLINED;
     }
     tm.mark("2-D: coherence sample");
