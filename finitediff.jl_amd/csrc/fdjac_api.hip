@@ -1780,8 +1780,20 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const bool strip_mode = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_ROW_WINDOW) && p->strips > 1 && p->window &&
                                 !p->window2d && p->nchunks == 1 && full_colors && (p->kind == K_CSC || p->kind == K_BANDED) &&
                                 (p->fdtype != FD_COMPLEX || (p->lazy_caps & FD_LAZY_CAP_IMAG_ONLY)) && !small;
+        // a launcher that can, hands over DIFFERENCES (f(point) - f(x), or f(plus) - f(minus)): no f(x) pass / half the f!
+        // arrays, and the decompression reads one array per colour (the forward kernels with fx = 0 and, for central
+        // differences, the doubled step sizes: (a - 0.0) / (2 eps) -- the bits of the plain path)
+        const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
+                               !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
+        if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
         if (strip_mode) {
             const bool io = p->fdtype == FD_COMPLEX;      // (imag-only: the f! arrays are real, fx is the zero vector)
+            real_t *eps_plain = p->d_eps;
+            if (want_diff && p->fdtype == FD_CENTRAL && !p->eps2_fresh) {
+                const int rc = launch_scale(p->ctx, p->d_eps2 + c_lo, p->d_eps + c_lo, B, (real_t)2);
+                if (rc) return rc;
+            }
+            bool first_part = true;
             for (int k = 0; k < p->strips; ++k) {
                 const int64_t rlo = p->strip_rlo[(size_t)k], rhi = p->strip_rhi[(size_t)k];
                 const int64_t t0 = p->strip_tile[(size_t)k], t1 = p->strip_tile[(size_t)k + 1];
@@ -1792,7 +1804,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                     lp.x = x_dev;
                     lp.color = p->d_color;
                     lp.eps = p->d_eps;
-                    lp.base_out = base_pending ? p->d_fx - rlo : nullptr;
+                    lp.base_out = (base_pending && !want_diff) ? p->d_fx - rlo : nullptr;
                     lp.color_bytes = p->color8 ? 1 : 4;
                     lp.c_lo = c_lo;
                     lp.ncolors = B;
@@ -1801,6 +1813,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                     lp.imag_only = io ? 1 : 0;
                     lp.part = k;
                     lp.nparts = p->strips;
+                    lp.diff = want_diff ? ((p->fdtype == FD_FORWARD && first_part) ? 2 : 1) : 0;
+                    first_part = false;
                     const int64_t r0 = std::max<int64_t>(rlo, p->row0 & ~(int64_t)1), r1 = std::min<int64_t>(rhi, p->row1);
                     const int rc = (rhi > rlo) ? p->lazy_fn(fctx, p->d_FX - rlo, &lp, p->strip_ld, r0, r1, (void *)s) : 0;
                     FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "lazy f! launcher returned %d for row strip %d of %d", rc, k, p->strips);
@@ -1808,8 +1822,10 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 {
                     Span sp(p, FD_STAGE_DECOMPRESS);
                     p->cur_tile0 = t0; p->cur_ntl = t1 - t0; p->cur_shift = rlo; p->cur_ld = p->strip_ld;
-                    const real_t *fxs = io ? p->d_fx : (base_pending ? p->d_fx - rlo : fx);
-                    const int rc = launch_decompress(p, fxs, c_lo, c_hi, outs, io ? (int)FD_FORWARD : p->fdtype);
+                    const real_t *fxs = (io || want_diff) ? p->d_zero : (base_pending ? p->d_fx - rlo : fx);
+                    if (want_diff && p->fdtype == FD_CENTRAL) p->d_eps = p->d_eps2;
+                    const int rc = launch_decompress(p, fxs, c_lo, c_hi, outs, (io || want_diff) ? (int)FD_FORWARD : p->fdtype);
+                    p->d_eps = eps_plain;
                     p->cur_tile0 = 0; p->cur_ntl = -1; p->cur_shift = 0; p->cur_ld = 0;
                     if (rc) return rc;
                 }
@@ -1818,13 +1834,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             base_pending = false;
             continue;
         }
-        // a launcher that can, hands over DIFFERENCES (f(point) - f(x), or f(plus) - f(minus)): no f(x) pass / half the f!
-        // arrays, and the decompression reads one array per colour (the forward kernels with fx = 0 and, for central
-        // differences, the doubled step sizes: (a - 0.0) / (2 eps) -- the bits of the plain path)
-        const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
-                               !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
         bool diff_done = false;
-        if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
             fd_lazy_points lp = {};
