@@ -344,6 +344,37 @@ def main():
     torch.cuda.synchronize()
     tm_all = plan.timings()
     plan.enable_timing(0)
+    # ---- side measurement (single GPU, untimed): the same call with the PLAIN hand-over of the f! values (the launcher's
+    # FD_LAZY_CAP_DIFF withheld) -- the graded kernel then also forms the differences, as in round 1; must give the same bits
+    plain = None
+    if world == 1 and lazy_diff and args.dtype == "f64":
+        try:
+            plan.set_lazy(f, diff=False)
+            for _ in range(3):
+                enqueue()
+            torch.cuda.synchronize()
+            plan.enable_timing(1)
+            for _ in range(min(args.steps, 10)):
+                enqueue()
+            torch.cuda.synchronize()
+            tp = plan.timings()["decompress"]
+            plan.enable_timing(0)
+            same = bool(torch.equal(out, timed_result))
+            ms_p = tp["ms_sum"] / max(tp["launches"], 1)
+            traffic_p, src_p = None, "model: bytes this kernel must move"
+            pp = os.path.join(ROOT, "profiles", "pmc_%s_plain.json" % cfg)
+            if os.path.exists(pp):
+                j = json.load(open(pp))
+                if int(j.get("n", -1)) == N and j.get("kernel", "") in kern:
+                    traffic_p, src_p = j.get("decompress_hbm_bytes_per_launch"), "rocprofv3 PMC passes (profiles/pmc_%s_plain.json)" % cfg
+            plain = {"avg_launch_ms": ms_p, "traffic": traffic_p, "traffic_source": src_p, "bit_identical_to_timed_result": same}
+            if traffic_p and ms_p > 0:
+                plain["achieved"] = traffic_p / (ms_p * 1e-3) / 1e9
+                plain["frac"] = plain["achieved"] / HBM_PEAK_GBPS
+        except Exception as e:
+            plain = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            plan.set_lazy(f)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -517,6 +548,7 @@ def main():
                     "note": "SURVEY 8(d) algorithmic bytes / kernel time: counts index reads and per-colour re-reads of f(x) "
                             "this kernel does not perform -- an equivalent-work rate, NOT a bandwidth (it can exceed the peak)"},
             },
+            "roofline_plain_handover": plain,
             "stages_ms": stages,
             "whole_call": {"gpu_ms": tot_ms, "hbm_bytes_model": bytes_call_model * n_local,
                            "gbps": bytes_call_model * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,

@@ -461,7 +461,12 @@ static int client_jvp(void)
     CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
     CHECK(fd_jvp_plan_create(g_ctx, N, N, FD_CENTRAL, &plan));
     fd_f_launch_lazy_jvp lz = NULL;
-    if (fd_builtin_f_lazy_jvp(fctx, &lz) == FD_OK) CHECK(fd_jvp_plan_set_lazy_f(plan, lz));
+    if (fd_builtin_f_lazy_jvp(fctx, &lz) == FD_OK) {
+        int caps = 0;
+        CHECK(fd_jvp_plan_set_lazy_f(plan, lz));
+        fd_builtin_f_lazy_jvp_caps(fctx, &caps);
+        CHECK(fd_jvp_plan_set_lazy_caps(plan, caps));
+    }
     CHECK(fd_jvp_async(plan, f, fctx, xd, vd, NULL, -1.0, -1.0, 1.0, od));
     CHECK(fd_ctx_synchronize(g_ctx));
     double *out = malloc(sizeof(double) * (size_t)N);

@@ -357,6 +357,13 @@ class BuiltinF:
         return fn if rc == 0 else None
 
     @property
+    def lazy_jvp_caps(self):
+        """FD_LAZY_JVP_CAP_* bits of the lazy JVP launcher (fd_builtin_f_lazy_jvp_caps)."""
+        caps = C.c_int32()
+        rc = self.Lt.fd_builtin_f_lazy_jvp_caps(self.fctx, C.byref(caps))
+        return caps.value if rc == 0 else 0
+
+    @property
     def lazy_caps(self):
         """FD_LAZY_CAP_* bits of the lazy launcher (fd_builtin_f_lazy_caps)."""
         caps = C.c_int32()
@@ -829,7 +836,7 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
 class JVPCache:
     """FiniteDiff.JVPCache (src/jvp.jl:1-60): JVPCache(x, fdtype="forward") / JVPCache(x, fx1, fdtype)."""
 
-    def __init__(self, x1, fx1=None, fdtype="forward", lazy=True):
+    def __init__(self, x1, fx1=None, fdtype="forward", lazy=True, quotient=True):
         if isinstance(fx1, str):
             fdtype, fx1 = fx1, None
         self.fdtype = _norm_fdtype(fdtype)
@@ -837,6 +844,7 @@ class JVPCache:
         self.dtype = _dtype_of(x1) or np.dtype(np.float64)
         self._plan = None
         self.lazy = bool(lazy)     # use f!'s lazy-point JVP launcher when it has one (same bits, fewer passes)
+        self.quotient = bool(quotient)   # ... and let it write the finished quotient (FD_LAZY_JVP_CAP_QUOTIENT)
         self._lazy_keep = None
 
     def _plan_for(self, M, N, ctx):
@@ -868,6 +876,8 @@ def finite_difference_jvp_b(jvp, f, x, v, cache=None, f_in=None, *, relstep=None
     lz = getattr(f, "lazy_jvp_fn", None) if cache.lazy else None
     cache._lazy_keep = lz            # (the ctypes function object must outlive the call)
     _l.check(Lt.fd_jvp_plan_set_lazy_f(h, lz if lz is not None else _l.F_LAUNCH_LAZY_JVP()))
+    if lz is not None:
+        _l.check(Lt.fd_jvp_plan_set_lazy_caps(h, int(getattr(f, "lazy_jvp_caps", 0)) if cache.quotient else 0))
     xp, xk, _a = _ptr(x, "x", cache.dtype)
     vp_, vk, _b = _ptr(v, "v", cache.dtype)
     if xk != vk:

@@ -790,7 +790,8 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
 template <bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
-                     const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t n)
+                     const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t n,
+                     real_t *__restrict__ qout)
 {
     const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2;
     if (i >= n) return;
@@ -804,6 +805,17 @@ k_f_tridiag_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ b
         ev[k] = in ? e * v[in ? j : 0] : 0.0;
     }
     const bool two = i + 1 < n;
+    if (qout) {   // fd_lazy_jvp_points.quotient_out: (f(x + eps v) - f(x)) / eps  or  (f(x + eps v) - f(x - eps v)) / (2 eps)
+        real_t pp[4], pm[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pp[k] = xv[k] + ev[k]; pm[k] = central ? xv[k] - ev[k] : xv[k]; }
+        const real_t ed = central ? 2 * e : e;
+        const real_t q0 = sub_exact(tridiag_row<real_t, NL>(pp[0], pp[1], pp[2]), tridiag_row<real_t, NL>(pm[0], pm[1], pm[2])) / ed;
+        if (two) *reinterpret_cast<r2_t *>(qout + i) =
+                     r2_t{q0, sub_exact(tridiag_row<real_t, NL>(pp[1], pp[2], pp[3]), tridiag_row<real_t, NL>(pm[1], pm[2], pm[3])) / ed};
+        else qout[i] = q0;
+        return;
+    }
     if (base_out) {
         const real_t b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
         if (two) *reinterpret_cast<r2_t *>(base_out + i) = r2_t{b0, tridiag_row<real_t, NL>(xv[1], xv[2], xv[3])};
@@ -827,7 +839,8 @@ k_f_tridiag_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ b
 template <int SK>
 __global__ void __launch_bounds__(kBlock)
 k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
-                      const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t nx, int64_t ny)
+                      const real_t *__restrict__ v, const real_t *__restrict__ eps, int central, int64_t nx, int64_t ny,
+                      real_t *__restrict__ qout)
 {
     const int64_t n = nx * ny;
     const int64_t ntiles = (n + 2 * kBlock - 1) / (2 * kBlock);
@@ -846,6 +859,16 @@ k_f_stencil5_lazy_jvp(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
         const int64_t at = ok[m] ? idx[m] : k;
         xv[m] = x[at];
         ev[m] = e * v[at];
+    }
+    if (qout) {   // fd_lazy_jvp_points.quotient_out
+        real_t pp[8], pm[8], a0, a1, s0, s1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { pp[q] = xv[q] + ev[q]; pm[q] = central ? xv[q] - ev[q] : xv[q]; }
+        stencil5_pair<real_t, SK>(pp, hs, hn, hw, he, a0, a1);
+        stencil5_pair<real_t, SK>(pm, hs, hn, hw, he, s0, s1);
+        const real_t ed = central ? 2 * e : e;
+        *reinterpret_cast<r2_t *>(qout + k) = r2_t{sub_exact(a0, s0) / ed, sub_exact(a1, s1) / ed};
+        return;
     }
     if (base_out) {
         real_t b0, b1;
@@ -875,24 +898,24 @@ static int builtin_launch_lazy_jvp(void *fctx, void *fx, const fd_lazy_jvp_point
     BuiltinF *b = (BuiltinF *)fctx;
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
     if (!has_lazy_jvp(b)) return FD_LAZY_DECLINED;
-    if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return FD_LAZY_DECLINED;
+    if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out) | ((uintptr_t)lp->quotient_out)) & kPairMask) != 0 || (fx_stride & 1)) return FD_LAZY_DECLINED;
     b->launches.fetch_add(1);
-    b->points.fetch_add((lp->central ? 2 : 1) + (lp->base_out ? 1 : 0));
+    b->points.fetch_add((lp->central ? 2 : 1) + ((lp->base_out || (lp->quotient_out && !lp->central)) ? 1 : 0));
     const hipStream_t s = (hipStream_t)stream;
-    real_t *fxp = (real_t *)fx, *base = (real_t *)lp->base_out;
+    real_t *fxp = (real_t *)fx, *base = (real_t *)lp->base_out, *qout = (real_t *)lp->quotient_out;
     const real_t *x = (const real_t *)lp->x, *v = (const real_t *)lp->v, *eps = (const real_t *)lp->eps;
     if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) {
         const int64_t n = b->prm[0];
         const unsigned g = (unsigned)(((n + 1) / 2 + kBlock - 1) / kBlock);
         if (b->family == FD_F_TRIDIAG_NL)
-            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<true>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n);
+            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<true>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n, qout);
         else
-            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<false>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n);
+            hipLaunchKernelGGL(k_f_tridiag_lazy_jvp<false>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, lp->central, n, qout);
     } else {
         const int64_t n = b->prm[0] * b->prm[1];
         const unsigned g = (unsigned)(8 * xcd_chunks((n + 2 * kBlock - 1) / (2 * kBlock)));
 #define FD_ST_JVP(SKK) hipLaunchKernelGGL(k_f_stencil5_lazy_jvp<SKK>, dim3(g), dim3(kBlock), 0, s, fxp, fx_stride, base, x, v, eps, \
-                               lp->central, b->prm[0], b->prm[1])
+                               lp->central, b->prm[0], b->prm[1], qout)
         if (b->family == FD_F_CLAMP5) FD_ST_JVP(1); else if (b->family == FD_F_LAP5_NL) FD_ST_JVP(2); else FD_ST_JVP(0);
 #undef FD_ST_JVP
     }
@@ -1017,6 +1040,14 @@ int fd_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out)
         return FD_ERR_UNSUPPORTED;
     }
     *fn_out = builtin_launch_lazy_jvp;
+    return FD_OK;
+}
+
+int fd_builtin_f_lazy_jvp_caps(void *fctx, int *caps_out)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "bad argument");
+    *caps_out = has_lazy_jvp(b) ? FD_LAZY_JVP_CAP_QUOTIENT : 0;
     return FD_OK;
 }
 

@@ -40,6 +40,8 @@
 #define fd_builtin_f_counts fd32_builtin_f_counts
 #define fd_builtin_f_lazy fd32_builtin_f_lazy
 #define fd_builtin_f_lazy_caps fd32_builtin_f_lazy_caps
+#define fd_jvp_plan_set_lazy_caps fd32_jvp_plan_set_lazy_caps
+#define fd_builtin_f_lazy_jvp_caps fd32_builtin_f_lazy_jvp_caps
 #define fd_jvp_plan_create fd32_jvp_plan_create
 #define fd_jvp_plan_destroy fd32_jvp_plan_destroy
 #define fd_jvp fd32_jvp

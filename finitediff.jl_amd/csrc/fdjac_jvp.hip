@@ -182,6 +182,8 @@ struct fd_jvp_plan {
     int nparts = 1;
     bool small_ok = true;          // fused single-workgroup launch of small problems (FDJAC_SMALL, read at plan creation)
     fd_f_launch_lazy_jvp lazy_fn = nullptr;
+    int lazy_caps = 0;             // FD_LAZY_JVP_CAP_* of lazy_fn
+    bool lazy_diff = true;         // ask a FD_LAZY_JVP_CAP_QUOTIENT launcher for the finished quotient (FDJAC_LAZY_DIFF=0: never)
 };
 
 using namespace fdjac;
@@ -202,6 +204,7 @@ int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_pla
     FD_REQUIRE(p, FD_ERR_NOMEM, "out of host memory");
     p->ctx = ctx; p->fdtype = fdtype; p->M = M; p->N = N;
     { const char *e = getenv("FDJAC_SMALL"); p->small_ok = !(e && *e && atoi(e) == 0); }
+    { const char *e = getenv("FDJAC_LAZY_DIFF"); p->lazy_diff = !(e && *e && atoi(e) == 0); }
     p->ldx = (N + 31) / 32 * 32; p->ldf = (M + 31) / 32 * 32;
     p->nparts = balanced_grid((N + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8);
     const int pts = fdtype == FD_CENTRAL ? 2 : 1;
@@ -255,14 +258,19 @@ static int jvp_enqueue(fd_jvp_plan *p, fd_f_launch f, void *fctx, const real_t *
         hipLaunchKernelGGL(k_jvp_eps, dim3(1), dim3(kBlock), 0, s, p->d_partial, p->nparts, relstep, absstep, dir,
                            central ? 0 : 1, p->d_eps);
         FD_HIP_CHECK(hipGetLastError());
-        fd_lazy_jvp_points lp;
+        fd_lazy_jvp_points lp = {};
         lp.x = xd;
         lp.v = vd;
         lp.eps = p->d_eps;
         lp.base_out = (!central && !fin) ? p->d_fx : nullptr;
         lp.central = central;
+        // a launcher that can, subtracts and divides itself and writes the JVP where the caller wants it: the call is
+        // the step-size reduction + ONE f! launch (a caller's f_in is the subtrahend the reference uses: plain path then)
+        const bool quotient = (p->lazy_caps & FD_LAZY_JVP_CAP_QUOTIENT) && p->lazy_diff && !fin && ((((uintptr_t)out) & kPairMask) == 0);
+        if (quotient) { lp.quotient_out = out; lp.base_out = nullptr; }
         const int lrc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, (void *)s);
         FD_REQUIRE(lrc == 0 || lrc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy JVP f! launcher returned %d", lrc);
+        if (lrc == 0 && quotient) return FD_OK;
         if (lrc == 0) {
             const real_t *la = central ? p->d_FX + p->ldf : p->d_FX;
             const real_t *lb = central ? p->d_FX : (fin ? fin : p->d_fx);
@@ -363,6 +371,15 @@ int fd_jvp_plan_set_lazy_f(fd_jvp_plan *p, fd_f_launch_lazy_jvp lazy)
 {
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     p->lazy_fn = lazy;
+    p->lazy_caps = 0;
+    return FD_OK;
+}
+
+int fd_jvp_plan_set_lazy_caps(fd_jvp_plan *p, int caps)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(p->lazy_fn != nullptr || caps == 0, FD_ERR_ARG, "no lazy launcher installed");
+    p->lazy_caps = caps;
     return FD_OK;
 }
 

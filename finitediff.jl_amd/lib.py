@@ -27,6 +27,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, INFO_LDS_DMA,
  INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE, INFO_ROLL, INFO_LAZY_DIFF, INFO_BAND_DIRECT) = range(31)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF = 1, 2, 4
+LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
             "blockcoupled": F_BLOCKCOUPLED, "nonsquare": F_NONSQUARE, "lap5_nl": F_LAP5_NL}
@@ -48,7 +49,8 @@ F_LAUNCH_LAZY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyPoint
 
 class LazyJvpPoints(C.Structure):
     """fd_lazy_jvp_points (include/fdjac.h)."""
-    _fields_ = [("x", C.c_void_p), ("v", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p), ("central", C.c_int)]
+    _fields_ = [("x", C.c_void_p), ("v", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p), ("central", C.c_int),
+                ("reserved0", C.c_int), ("quotient_out", C.c_void_p)]
 
 
 # int f(fctx, fx, const fd_lazy_jvp_points*, fx_stride, stream)
@@ -62,7 +64,7 @@ EXPORTS = (
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
-    "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
+    "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
@@ -80,6 +82,7 @@ TYPED = (
     "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
+    "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum",
@@ -185,6 +188,8 @@ def load():
     L.fd_builtin_f_lazy_caps.argtypes = [vp, C.POINTER(i32)]
     L.fd_jvp_plan_set_lazy_f.argtypes = [vp, F_LAUNCH_LAZY_JVP]
     L.fd_builtin_f_lazy_jvp.argtypes = [vp, C.POINTER(F_LAUNCH_LAZY_JVP)]
+    L.fd_jvp_plan_set_lazy_caps.argtypes = [vp, i32]
+    L.fd_builtin_f_lazy_jvp_caps.argtypes = [vp, C.POINTER(i32)]
     L.fd_comm_unique_id.argtypes = [vp]
     L.fd_comm_create.argtypes = [vp, i32, i32, vp, pp]
     L.fd_comm_destroy.argtypes = [vp]

@@ -320,10 +320,19 @@ typedef struct fd_lazy_jvp_points {
     const void *eps;      /* device address of the ONE step size (element type of the plan) */
     void *base_out;       /* forward arm without f_in: f(x) goes here (M elements); NULL otherwise */
     int central;          /* 0 forward (1 point), 1 central (2 points) */
+    int reserved0;
+    void *quotient_out;   /* launchers registered with FD_LAZY_JVP_CAP_QUOTIENT only: non-NULL = write the finished       */
+                          /* difference quotient here (M elements) -- (f(x+eps v) - f(x)) / eps, or                       */
+                          /* (f(x+eps v) - f(x-eps v)) / (2 eps): the subtraction and the division of                     */
+                          /* src/jvp.jl:258,263,267,270 inside f!'s launch, each an IEEE operation on the values the plain */
+                          /* path would have stored (same bits); fx_out / base_out are not written then                   */
 } fd_lazy_jvp_points;
 typedef int (*fd_f_launch_lazy_jvp)(void *fctx, void *fx_out, const fd_lazy_jvp_points *pts, int64_t fx_stride,
                                     void *stream);
-int fd_jvp_plan_set_lazy_f(fd_jvp_plan *plan, fd_f_launch_lazy_jvp lazy);   /* NULL clears it */
+int fd_jvp_plan_set_lazy_f(fd_jvp_plan *plan, fd_f_launch_lazy_jvp lazy);   /* NULL clears it (and the capabilities) */
+#define FD_LAZY_JVP_CAP_QUOTIENT 1   /* honours fd_lazy_jvp_points.quotient_out: the whole JVP is the step-size reduction + ONE f! launch */
+int fd_jvp_plan_set_lazy_caps(fd_jvp_plan *plan, int caps);
+int fd_builtin_f_lazy_jvp_caps(void *fctx, int *caps_out);
 /* The lazy JVP launcher of a built-in family (FD_ERR_UNSUPPORTED if it has none: block-coupled, non-square). */
 int fd_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out);
 

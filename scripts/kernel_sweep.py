@@ -122,9 +122,11 @@ def main():
             us = (time.perf_counter() - t0) / a.reps * 1e6
             # materialised: dot (x, v) 16 B + points (x, v -> X) 24/32 B + two f! evaluations 2 x 16 B + difference 24 B
             # per state; with the lazy-point launcher (built-in families): dot 16 + f! (x, v -> two outputs) 32 + difference 24
+            # launcher that writes the finished quotient (FD_LAZY_JVP_CAP_QUOTIENT): dot 16 + f! (x, v -> jvp) 24
             lazy = cache.lazy and f.lazy_jvp_fn is not None
-            mb = ((16 + 32 + 24) if lazy else (16 + (24 if fdtype == "forward" else 32) + 32 + 24)) * N / 1e6
-            rows.append(("finite_difference_jvp! " + fdtype + (" (lazy f!," if lazy else " (") + " whole call, wall)", "-", 0.0, 0.0, 0.0, 0.0, us, mb,
+            quot = lazy and cache.quotient and f.lazy_jvp_caps and os.environ.get("FDJAC_LAZY_DIFF", "1") != "0"
+            mb = ((16 + 24) if quot else (16 + 32 + 24) if lazy else (16 + (24 if fdtype == "forward" else 32) + 32 + 24)) * N / 1e6
+            rows.append(("finite_difference_jvp! " + fdtype + (" (lazy f! writes the quotient," if quot else " (lazy f!," if lazy else " (") + " whole call, wall)", "-", 0.0, 0.0, 0.0, 0.0, us, mb,
                          mb / us * 1e3, 100 * (mb / us * 1e3) / 8000.0))
 
     print("| case | kernel variant | eps us | perturb us | f! us | diff+decompress us | whole call us | algorithmic MB | GB/s | % of 8 TB/s |")

@@ -1109,11 +1109,13 @@ def test_jvp_lazy_points_bit_identical(oracle, fdtype, family, dtype):
     x = torch.as_tensor(rng.random(N), dtype=tdt, device="cuda")
     v = torch.as_tensor(rng.random(N) - 0.5, dtype=tdt, device="cuda")
     res, calls, eps = [], [], []
-    for lazy in (True, False):
+    # (lazy launcher writing the finished quotient -- FD_LAZY_JVP_CAP_QUOTIENT, the default --, lazy launcher writing the
+    #  values, materialised points)
+    for lazy, quotient in ((True, True), (True, False), (False, False)):
         f = fd.BuiltinF(family, *prm, dtype=dtype)
-        assert f.lazy_jvp_fn is not None
+        assert f.lazy_jvp_fn is not None and f.lazy_jvp_caps == fd.lib.LAZY_JVP_CAP_QUOTIENT
         out = torch.full((N,), float("nan"), dtype=tdt, device="cuda")
-        cache = fd.JVPCache(x, fdtype, lazy=lazy)
+        cache = fd.JVPCache(x, fdtype, lazy=lazy, quotient=quotient)
         fd.finite_difference_jvp_b(out, f, x, v, cache)
         res.append(out.clone())
         calls.append(f.fcalls)
@@ -1121,7 +1123,8 @@ def test_jvp_lazy_points_bit_identical(oracle, fdtype, family, dtype):
         launches = f.counts()[0]
         assert launches == (1 if lazy else (2 if fdtype == "forward" else 1))
     assert not torch.isnan(res[0]).any()
-    assert torch.equal(res[0], res[1]) and calls[0] == calls[1] == 2 and eps[0] == eps[1]
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert calls[0] == calls[1] == calls[2] == 2 and eps[0] == eps[1] == eps[2]
     if dtype == np.float64 and family != "clamp5":
         ref = oracle.jvp(fdtype, oracle.Fixture(family, *prm), x.cpu().numpy(), v.cpu().numpy())
         _tol_ok(res[0].cpu().numpy(), ref["jvp"], ref["eps"], 8.0, "lazy jvp %s %s" % (family, fdtype))
