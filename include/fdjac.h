@@ -509,6 +509,8 @@ int fd32_jvp_async(fd32_jvp_plan *plan, fd_f_launch f, void *fctx, const void *x
 int fd32_jvp_get_epsilon(fd32_jvp_plan *plan, double *eps_out);
 int fd32_jvp_plan_set_lazy_f(fd32_jvp_plan *plan, fd_f_launch_lazy_jvp lazy);
 int fd32_builtin_f_lazy_jvp(void *fctx, fd_f_launch_lazy_jvp *fn_out);
+int fd32_jvp_plan_set_lazy_caps(fd32_jvp_plan *plan, int caps);
+int fd32_builtin_f_lazy_jvp_caps(void *fctx, int *caps_out);
 
 #ifdef __cplusplus
 }
