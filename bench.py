@@ -171,8 +171,13 @@ def main():
         raise SystemExit("--config %s is a single-GPU line" % cfg)
     ctx = fd.Context(dev_index)
     comm = None
+    comm_error = None
     if world > 1 and backend == "nccl":
-        comm = fd.Comm.from_torch_distributed(ctx, dist)
+        try:
+            comm = fd.Comm.from_torch_distributed(ctx, dist)
+        except Exception as e:   # the timed step has no collective in it: measure it anyway, report the failure loudly
+            comm_error = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("[bench rank %d] fd_comm_create failed (%s): the nzval assembly and the sharded solve are skipped\n" % (rank, comm_error))
     by_color = args.shard == "colors" and world > 1 and cfg in ("c2", "c4")
     lazy_ok = False
     vs = 4 if args.dtype == "f32" else 8          # bytes per value
@@ -559,6 +564,7 @@ def main():
                                    "of the reference's pass structure, kept for comparison only"},
             "plan_build_ms": plan_build_ms,
             "gather": gather_info,
+            "comm_error": comm_error,
             "consumer": consumer,
             "value_with_gather": (N / ((ms_step + (0.0 if gather_in_step else gather_info["ms"])) * 1e-3)
                                   if (gather_info and "ms" in gather_info) else None),
