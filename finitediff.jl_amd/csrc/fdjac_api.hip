@@ -448,8 +448,9 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
             // forward, same process: N = 10^6 14.6 -> 13.5 us, N = 3*10^6 30.7 -> 30.0 us, N = 10^7 equal)
             // round 2, N = 10^7 as well (two boxes, separate processes, 40 steps each: 111.8 / 113.2 us with 2048-entry tiles,
             // 109.4 / 108.7 us with 1024; profiles/r02_d_win_ab.txt): the half-size tile is the default at every size,
-            // the 2048-entry tile remains for FDJAC_WIN_TILE=2048
-            const bool prefer_small = true;
+            // the 2048-entry tile remains for FDJAC_WIN_TILE=2048.  What matters is the tile's BYTES: Float32 keeps the
+            // 2048-entry tile (N = 10^7: 52.3 vs 64.3 us with 1024 entries; Float64: 100.1 vs 98.0 us)
+            const bool prefer_small = sizeof(real_t) >= 8;
             for (int T : {2048, 1024, 512}) {
                 if (force_t && T != force_t) continue;
                 if (!force_t && T == 2048 && prefer_small) continue;

@@ -970,7 +970,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     const char *ft = getenv("FDJAC_WIN_TILE");
     const int force_t = (ft && *ft) ? atoi(ft) : 0;
     const int force_w = (fw && *fw) ? atoi(fw) : -1;
-    const bool prefer_small = true;   // (the host builder's rule, try_window_plan)
+    const bool prefer_small = sizeof(real_t) >= 8;   // (the host builder's rule, try_window_plan)
     int4 *d_wt = nullptr;
     uint16_t *d_code = nullptr;
     if (hipMalloc((void **)&d_wt, sizeof(int4) * 3 * (padded / 512)) != hipSuccess) { (void)hipFree(d_color8); return PBR_DECLINED; }
