@@ -140,6 +140,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // opt-in: inside the pipeline the computed-index kernel measured 113-119 us against 103 us for the row windows
     // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
     p->band_allowed = env_int("FDJAC_BAND_DIRECT", 0) != 0;
+    p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -836,23 +837,71 @@ static void gather_coherence(size_t ntiles, size_t step, RowsOf rows_of, NzcOf n
 // Uniform band with cyclic colours -> k_decompress_band for the whole tiles inside it (shared by the host and the device
 // builder).  The columns [ju0, ju1) hold w consecutive rows j - u .. j - u + w - 1 each, the first of them starts at the
 // local entry e_ju0; colours are (j + shift) mod C for every column.
-static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, int64_t ju0, int64_t ju1, int64_t C, int shift)
+// The descriptor the row-window kernel would load for tile t of a uniform band (fdjac_kernels.hip computes the same):
+// entries Q0 .. Q1 = w*j + k, rows j - u + k
+static inline void band_tile_desc(int64_t t, int T, int64_t nnz_local, int64_t off, int w, int u, int C, int *wr0, int *pairs)
+{
+    const int64_t q0 = t * T, q1 = std::min<int64_t>(q0 + T, nnz_local) - 1;
+    const int64_t Q0 = q0 + off, Q1 = q1 + off;
+    const int64_t j0 = Q0 / w, k0 = Q0 - j0 * w, j1 = Q1 / w, k1 = Q1 - j1 * w;
+    const int64_t rmin = j1 > j0 ? j0 - u + std::min<int64_t>(k0, 1) : j0 - u + k0;
+    const int64_t rmax = j1 > j0 ? j1 - u + std::max<int64_t>(k1, w - 2) : j1 - u + k1;
+    (void)C;
+    *wr0 = (int)(rmin & ~(int64_t)1);
+    *pairs = (int)((rmax - *wr0) / 2 + 1);
+}
+
+// Uniform band with cyclic colours (shared by the host and the device builder).  The columns [ju0, ju1) hold w consecutive
+// rows j - u .. j - u + w - 1 each, the first of them starts at the local entry e_ju0; colours are (j + shift) mod C for
+// every column.  Sets the band parameters, the tile range of the computed-index kernel (opt-in) and the tile range whose
+// descriptors the row-window kernel computes (wt_host: the plan's 1-D tile descriptors if the caller has them on the host).
+static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, int64_t ju0, int64_t ju1, int64_t C, int shift,
+                             const int4 *wt_host = nullptr)
 {
     p->band_ok = false;
-    if (!p->band_allowed || !p->window || p->window2d || p->win_tile <= 0 || w < 1 || w > 64 || C < 1 || C > 64 || ju1 <= ju0) return;
+    p->bd_t0 = p->bd_t1 = 0;
+    if (!(p->band_allowed || p->bd_allowed) || !p->window || p->window2d || p->win_tile <= 0 || w < 1 || w > 64 || C < 1 || C > 64 || ju1 <= ju0) return;
     const int64_t T = p->win_tile, all_tiles = (p->nnz_local + T - 1) / T;
     const int64_t pu0 = e_ju0, pu1 = e_ju0 + w * (ju1 - ju0);
     const int64_t off = w * ju0 - e_ju0;
     int64_t t0 = (pu0 + T - 1) / T, t1 = pu1 / T;
     if (pu1 >= p->nnz_local) t1 = all_tiles;
-    if (t1 <= t0 || 2 * (t1 - t0) < all_tiles) return;                  // not worth a second kernel
+    if (t1 <= t0) return;
     if (off + t0 * T < 0 || off + p->nnz_local + 2 >= ((int64_t)1 << 31) || ju1 + C + 64 >= ((int64_t)1 << 31)) return;
     if (u < -((int64_t)1 << 30) || u > ((int64_t)1 << 30)) return;
-    p->band_ok = true;
-    p->band_t0 = t0; p->band_t1 = t1; p->band_off = off; p->band_C = C;
+    p->band_off = off; p->band_C = C;
     p->band_w = (int)w; p->band_u = (int)u; p->band_shift = shift;
     p->band_mw = (((uint64_t)1 << 40) + (uint64_t)w - 1) / (uint64_t)w;
     p->band_mc = (((uint64_t)1 << 40) + (uint64_t)C - 1) / (uint64_t)C;
+    if (p->band_allowed && 2 * (t1 - t0) >= all_tiles) {                // (fewer tiles: not worth a second kernel)
+        p->band_ok = true;
+        p->band_t0 = t0; p->band_t1 = t1;
+    }
+    // computed descriptors: the largest run of tiles around the middle of [t0, t1) whose STORED descriptor is what
+    // band_tile_desc computes (regular tiles: periodic codes, every colour of the band, one row window)
+    if (p->bd_allowed && p->win_per_P > 0 && T >= 2 * w && (T % 2) == 0) {
+        std::vector<int4> tmp;
+        const int4 *wt = wt_host;
+        if (!wt) {
+            tmp.resize((size_t)(3 * all_tiles));
+            if (hipMemcpy(tmp.data(), p->d_wtiles, sizeof(int4) * tmp.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+            wt = tmp.data();
+        }
+        auto matches = [&](int64_t t) {
+            int wr0, pairs;
+            band_tile_desc(t, (int)T, p->nnz_local, off, (int)w, (int)u, (int)C, &wr0, &pairs);
+            const int4 a = wt[3 * t], b = wt[3 * t + 1], c = wt[3 * t + 2];
+            return a.x == 0 && a.y == (int)C && a.z == pairs && a.w == (1 | 0x100) && b.x == wr0 && b.y == pairs && b.z == 0 && b.w == pairs &&
+                   c.x == 0 && c.y == pairs && c.z == 0 && c.w == pairs;
+        };
+        const int64_t tm = (t0 + t1) / 2;
+        if (matches(tm)) {
+            int64_t a = tm, b = tm + 1;
+            while (a > t0 && matches(a - 1)) --a;
+            while (b < t1 && matches(b)) ++b;
+            p->bd_t0 = a; p->bd_t1 = b;
+        }
+    }
 }
 
 // colorvec == (j + shift) mod C for every column (no column without colour)?
@@ -870,7 +919,7 @@ static bool colors_cyclic(const std::vector<int32_t> &col0, int64_t C, int *shif
 // column's number of consecutive rows and an affine colptr
 static void try_band_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows, const std::vector<int64_t> &colstart)
 {
-    if (!p->band_allowed || !p->window || p->window2d || p->col1 - p->col0 < 4) return;
+    if (!(p->band_allowed || p->bd_allowed) || !p->window || p->window2d || p->col1 - p->col0 < 4) return;
     int shift = 0;
     if (!colors_cyclic(col0, p->C, &shift)) return;
     const int64_t jm = (p->col0 + p->col1) / 2;
@@ -1228,7 +1277,7 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
                             p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
                             p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6),
                             p->band_ok, p->band_t0, p->band_t1, p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
-                            (int64_t)p->band_mw, (int64_t)p->band_mc};
+                            (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1};
     mix(scal, sizeof scal);
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
@@ -1564,6 +1613,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
     case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
     case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
+    case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
     case FD_INFO_LAZY_DIFF:
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
         break;

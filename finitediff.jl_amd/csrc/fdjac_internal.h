@@ -200,6 +200,11 @@ struct fd_plan {
     int64_t band_t0 = 0, band_t1 = 0, band_off = 0, band_C = 0;
     int band_w = 0, band_u = 0, band_shift = 0;
     uint64_t band_mw = 0, band_mc = 0;
+    // ... and, independently of that kernel: the row-window kernel COMPUTES the descriptors of the tiles [bd_t0, bd_t1)
+    // from the same band parameters instead of loading them (verified against the stored descriptors when the plan is
+    // built) -- the descriptor load is one of two dependent global round trips of a workgroup's lifetime
+    bool bd_allowed = true;        //   FDJAC_BAND_DESC=0: always load
+    int64_t bd_t0 = 0, bd_t1 = 0;
     int64_t w2_ntiles = 0;
     int64_t w2_codes = 0;          //   number of 16-bit codes in d_wcode (2-D tiles)
     uint16_t *d_wcode = nullptr;   //   per entry: row - first row | (colour - first colour) << 11 | none << 14 | pad << 15

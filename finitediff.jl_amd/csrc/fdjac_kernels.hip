@@ -566,7 +566,8 @@ __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
                     const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t n,
-                    int vec_ok, int wp, int per_P, int per_S, int per_magic, int64_t tile0, int64_t ntl)
+                    int vec_ok, int wp, int per_P, int per_S, int per_magic, int64_t tile0, int64_t ntl,
+                    int64_t bd_t0, int64_t bd_t1, int64_t bd_off, int bd_w, int bd_u, int bd_C, uint64_t bd_mw)
 {
     // (tile0, ntl): this launch covers the tiles [tile0, tile0 + ntl) -- all of them, or one row strip's)
     constexpr int T = U * kBlock * 2;             // entries per tile; U pairs of entries per thread
@@ -578,7 +579,22 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     if (xt >= ntl) return;
     const int64_t tile_id = tile0 + ((vec_ok & 4) ? ntl - 1 - xt : xt);   // reversed tile order, see tile_order_reversed()
     const int64_t t0 = tile_id * T;
-    const int4 th = wtiles[3 * tile_id], wa = wtiles[3 * tile_id + 1], wb = wtiles[3 * tile_id + 2];
+    int4 th, wa, wb;
+    if (tile_id >= bd_t0 && tile_id < bd_t1) {
+        // Uniform band (plan-time check: these tiles' stored descriptors ARE what follows, band_tile_desc in fdjac_api.hip):
+        // entries Q0 .. Q1 = w*j + k touch the rows j - u + k -- no descriptor load in front of the window loads
+        const uint32_t Q0 = (uint32_t)(t0 + bd_off), Q1 = Q0 + (uint32_t)(T - 1);      // (full tiles only)
+        const uint32_t j0 = (uint32_t)(((uint64_t)Q0 * bd_mw) >> 40), k0 = Q0 - j0 * (uint32_t)bd_w;
+        const uint32_t j1 = (uint32_t)(((uint64_t)Q1 * bd_mw) >> 40), k1 = Q1 - j1 * (uint32_t)bd_w;
+        const int rmin = (int)j0 - bd_u + (int)(k0 < 1u ? k0 : 1u);
+        const int rmax = (int)j1 - bd_u + (int)(k1 > (uint32_t)(bd_w - 2) ? k1 : (uint32_t)(bd_w - 2));
+        const int r0 = rmin & ~1, np = (rmax - r0) / 2 + 1;
+        th = int4{0, bd_C, np, 1 | 0x100};
+        wa = int4{r0, np, 0, np};
+        wb = int4{0, np, 0, np};
+    } else {
+        th = wtiles[3 * tile_id]; wa = wtiles[3 * tile_id + 1]; wb = wtiles[3 * tile_id + 2];
+    }
     const int cmin = __builtin_amdgcn_readfirstlane(th.x);
     int cb0 = cmin;
     int cb1 = cb0 + __builtin_amdgcn_readfirstlane(th.y);
@@ -1676,7 +1692,8 @@ static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, con
 #define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
     hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
                        (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, ldw, p->M, p->d_eps, c_lo,          \
-                       c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic, tile0, ntl)
+                       c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic, tile0, ntl,  \
+                       p->bd_t0, p->bd_t1, p->band_off, p->band_w, p->band_u, (int)p->band_C, p->band_mw)
 #define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
     if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); continue; } }
     if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }

@@ -1142,9 +1142,9 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         p->cyc_shift = cyc ? shift : 0;
     }
     // uniform band with cyclic colours: the computed-index kernel takes the tiles inside it (finish_band_plan)
-    if (p->band_allowed && !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
+    if ((p->band_allowed || p->bd_allowed) && !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
         if (band) {
-            finish_band_plan(p, band->w, band->u, 0, p->col0, p->col1, C, shift);
+            finish_band_plan(p, band->w, band->u, 0, p->col0, p->col1, C, shift, wt.data());
         } else if (p->col1 - p->col0 >= 4) {
             const int64_t jm = (p->col0 + p->col1) / 2;
             char raw[3][8];
@@ -1168,7 +1168,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
                 }
                 if (ok && !hs.mid_bad) {
                     const int64_t ju0 = std::max<int64_t>(hs.lo + 1, p->col0), ju1 = std::min<int64_t>(hs.hi, p->col1);
-                    finish_band_plan(p, w, u, (cpm - e0) + w * (ju0 - jm), ju0, ju1, C, shift);
+                    finish_band_plan(p, w, u, (cpm - e0) + w * (ju0 - jm), ju0, ju1, C, shift, wt.data());
                 }
             }
         }

@@ -225,6 +225,7 @@ enum fd_plan_info_key {
     FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
     FD_INFO_BAND_DIRECT = 30,         /* 1 if a uniform band with cyclic colours is decompressed with computed indices (k_decompress_band) */
+    FD_INFO_BAND_DESC = 31,           /* number of row-window tiles whose descriptors the kernel computes instead of loading (uniform band) */
     FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
     FD_INFO_ROLL = 28,                /* 1 if a 2-D stencil plan uses the rolling row windows (one wave walks a column strip) */
     FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */

@@ -1586,3 +1586,73 @@ def test_band_direct_kernel_bit_identical(monkeypatch, fdtype, case):
     assert infos == [0 if case == "tridiag_none" else 1, 0]
     assert not np.isnan(outs[0]).any()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["tridiag", "tridiag_window", "tridiag_devplan", "tridiag_chunked", "band5", "bidiag", "banded11", "banded23",
+                                  "banded_rect", "tridiag_shifted", "tridiag_none", "tridiag_t2048", "tridiag_t512"])
+def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
+    # Uniform bands: the row-window kernel computes the descriptors of its regular tiles from the band parameters instead of
+    # loading them (FD_INFO_BAND_DESC tiles; the plan verified that the stored descriptors are what the kernel computes).
+    # FDJAC_BAND_DESC=0 loads every descriptor: same bits.
+    N = M = 150_011
+    l = u = 1
+    win = None
+    cap = 0
+    banded = case.startswith("banded")
+    if case == "band5":
+        l = u = 2
+    if case == "bidiag":
+        l, u = 1, 0
+    if case == "banded23":
+        l, u = 2, 3
+    if case == "banded_rect":
+        l, u, M = 3, 1, N + 40
+    w = l + u + 1
+    colors = P.cyclic_colors(N, w)
+    if case == "tridiag_shifted":
+        colors = ((np.arange(N) + 2) % 3 + 1).astype(np.int64)
+    if case == "tridiag_none":
+        colors[[5, N // 2]] = 0                      # not cyclic any more: every descriptor is loaded
+    if case == "tridiag_chunked":
+        cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2
+    if case == "tridiag_window":
+        win = (N // 5 + 1, 4 * N // 5)
+    if case in ("tridiag_t2048", "tridiag_t512"):
+        monkeypatch.setenv("FDJAC_WIN_TILE", case[-4:] if case.endswith("2048") else "512")
+    x = _dev(np.random.default_rng(81).random(N))
+    A = torch.as_tensor(np.random.default_rng(83).random((M, w)), device="cuda")
+
+    def fn(fx, xx):
+        idx = torch.arange(M, device="cuda")
+        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
+        for k in range(w):
+            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - l + k, 0, N - 1)] ** 2
+        fx.copy_(acc)
+
+    outs, infos = [], []
+    for comp in ("1", "0"):
+        monkeypatch.setenv("FDJAC_BAND_DESC", comp)
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1" if case == "tridiag_devplan" else "0")
+        if banded:
+            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype)
+        else:
+            colptr, rowval = P.banded_csc(M, N, l, u)
+            J = fd.SparseMatrixCSC(M, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win)
+        assert plan.info(fd.lib.INFO_WINDOW) == 1
+        infos.append(plan.info(fd.lib.INFO_BAND_DESC))
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        if l == u == 1 and not banded:
+            f = fd.BuiltinF("tridiag_nl", N)
+            plan.set_lazy(f)
+        else:
+            f = fd.TorchF(fn, M, N)
+        plan.jacobian(f, x, [out])
+        outs.append(out.cpu().numpy())
+    if case == "tridiag_none":
+        assert infos == [0, 0]
+    else:
+        assert infos[0] > 10 and infos[1] == 0      # (all but the corner tiles)
+    assert not np.isnan(outs[0]).any()
+    assert np.array_equal(outs[0], outs[1])
