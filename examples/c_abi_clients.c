@@ -10,9 +10,10 @@
  *
  *   gcc -O2 -Iinclude examples/c_abi_clients.c -o c_abi_clients -Lfinitediff.jl_amd/lib -lfdjac \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/finitediff.jl_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   ./c_abi_clients all        # or: csc csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host
+ *   ./c_abi_clients all        # or: csc csc_device csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -151,6 +152,52 @@ static int client_csc(int fdtype)
     const char *nm = fdtype == FD_FORWARD ? "csc/forward" : fdtype == FD_CENTRAL ? "csc/central" : "csc/complex";
     return report(nm, worst, fdtype == FD_FORWARD ? 2e-6 : fdtype == FD_CENTRAL ? 2e-8 : 1e-13, calls,
                   fdtype == FD_FORWARD ? 4 : fdtype == FD_CENTRAL ? 6 : 3);
+}
+
+/* shim (AMDGPU extension): make_plan(::ROCSparseMatrixCSC J, sparsity === J, colorvec::ROCVector) -> fd_plan_create_csc_device:
+   colPtr / rowVal / colorvec already live on the device (rocSPARSE CSC: Int32, 1-based); nothing crosses PCIe, the plan is
+   compiled by kernels.  Checked against the host-pattern plan through fd_plan_checksum and against the analytic Jacobian. */
+static int client_csc_device(void)
+{
+    const int64_t N = 200003;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    int32_t *cp32 = malloc(sizeof(int32_t) * (size_t)(N + 1)), *rv32 = malloc(sizeof(int32_t) * (size_t)nnz), *cv32 = malloc(sizeof(int32_t) * (size_t)N);
+    for (int64_t j = 0; j <= N; ++j) cp32[j] = (int32_t)colptr[j];
+    for (int64_t p = 0; p < nnz; ++p) rv32[p] = (int32_t)rowval[p];
+    for (int64_t j = 0; j < N; ++j) cv32[j] = (int32_t)colors[j];
+    void *cpd = to_dev(cp32, sizeof(int32_t) * (size_t)(N + 1)), *rvd = to_dev(rv32, sizeof(int32_t) * (size_t)nnz), *cvd = to_dev(cv32, sizeof(int32_t) * (size_t)N);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)nnz);
+    fd_f_launch f; void *fctx; fd_plan *plan, *ref;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_csc_device(g_ctx, N, N, cpd, rvd, 4, 1, cvd, 4, &o, &plan));
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &ref));
+    uint64_t ca = 0, cb = 1;
+    CHECK(fd_plan_checksum(plan, &ca)); CHECK(fd_plan_checksum(ref, &cb));
+    int64_t on_dev = 0;
+    CHECK(fd_plan_info(plan, FD_INFO_BUILT_ON_DEVICE, &on_dev));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const double d = fabs(nz[p] - tridiag_nl_J(x, N, rowval[p] - 1, j));
+            if (!(d <= worst)) worst = d;
+        }
+    if (ca != cb || !on_dev) { fprintf(stderr, "csc_device: plan differs from the host-pattern plan (%llx vs %llx, built on device %lld)\n",
+                                       (unsigned long long)ca, (unsigned long long)cb, (long long)on_dev); worst = INFINITY; }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_plan_destroy(ref)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); hipFree(cpd); hipFree(rvd); hipFree(cvd);
+    free(nz); free(x); free(colptr); free(rowval); free(colors); free(cp32); free(rv32); free(cv32);
+    return report("csc_device", worst, 2e-6, calls, 4);
 }
 
 /* shim: make_plan(::Matrix J, ::SparseMatrixCSC sparsity) -> fd_plan_create_csc_dense (ext/FiniteDiffSparseArraysExt.jl:20-28) */
@@ -566,6 +613,7 @@ int main(int argc, char **argv)
     int bad = 0, ran = 0;
 #define RUN(name, call) if (!strcmp(which, "all") || !strcmp(which, name)) { bad |= (call); ++ran; }
     RUN("csc", client_csc(FD_FORWARD) | client_csc(FD_CENTRAL) | client_csc(FD_COMPLEX))
+    RUN("csc_device", client_csc_device())
     RUN("csc_dense", client_csc_dense())
     RUN("coo_dense", client_coo_dense())
     RUN("entries", client_entries())
