@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--soak-seconds", type=float, default=5.5,
                     help="untimed steady-state loop AFTER the measurement so that an external utilisation sampler sees "
                          "the GPU busy (the timed region itself lasts a few milliseconds); 0 = off")
+    ap.add_argument("--no-plain-handover", action="store_true",
+                    help="skip the untimed side measurement of the plain f! hand-over (profiling runs: keeps the kernel's PMC averages clean)")
     return ap.parse_args()
 
 
@@ -352,7 +354,7 @@ def main():
     # ---- side measurement (single GPU, untimed): the same call with the PLAIN hand-over of the f! values (the launcher's
     # FD_LAZY_CAP_DIFF withheld) -- the graded kernel then also forms the differences, as in round 1; must give the same bits
     plain = None
-    if world == 1 and lazy_diff and args.dtype == "f64":
+    if world == 1 and lazy_diff and args.dtype == "f64" and not args.no_plain_handover:
         try:
             plan.set_lazy(f, diff=False)
             for _ in range(3):

@@ -10,7 +10,7 @@ shift || true
 OUT=$REPO/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-plain-handover $*"
 : > $OUT/pmc_extra.md
 i=0
 for g in "${GROUPS_[@]}"; do
