@@ -871,8 +871,13 @@ static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, in
     if (u < -((int64_t)1 << 30) || u > ((int64_t)1 << 30)) return;
     p->band_off = off; p->band_C = C;
     p->band_w = (int)w; p->band_u = (int)u; p->band_shift = shift;
-    p->band_mw = (((uint64_t)1 << 40) + (uint64_t)w - 1) / (uint64_t)w;
-    p->band_mc = (((uint64_t)1 << 40) + (uint64_t)C - 1) / (uint64_t)C;
+    p->band_mw = fd_magic31((uint32_t)w);
+    p->band_mc = fd_magic31((uint32_t)C);
+    {   // (self-check of the two dividers on the values that matter most: the ends of the range and multiples of the divisor)
+        const uint32_t top = (uint32_t)(off + p->nnz_local + 1);
+        for (uint32_t n : {0u, 1u, (uint32_t)w - 1, (uint32_t)w, top - 1, top, top / 2, 0x7FFFFFFFu, (uint32_t)((top / (uint32_t)w) * (uint32_t)w), (uint32_t)((top / (uint32_t)w) * (uint32_t)w) - 1u})
+            if (fd_div31(n, p->band_mw) != n / (uint32_t)w || fd_div31(n, p->band_mc) != n / (uint32_t)C) return;
+    }
     if (p->band_allowed && 2 * (t1 - t0) >= all_tiles) {                // (fewer tiles: not worth a second kernel)
         p->band_ok = true;
         p->band_t0 = t0; p->band_t1 = t1;

@@ -124,6 +124,20 @@ constexpr int kW2MaxRun = 8;         // column runs per tile
 constexpr int kRollW = 128;          // rolling row windows: elements per window row (64 lanes x one pair)
 constexpr int kRollMaxCodes = 1024;  //   codes of one (strip, grid row) run: 8 rounds of 128
 
+// Exact floor(n / d) for every n < 2^31 by one 64-bit multiply (Granlund-Montgomery: m = ceil(2^(31+l) / d), l = ceil(log2 d),
+// so m < 2^32 and n * m < 2^63): the multiplier and the shift travel packed in one 64-bit kernel argument.
+inline uint64_t fd_magic31(uint32_t d)
+{
+    int l = 0;
+    while (((uint64_t)1 << l) < d) ++l;
+    const uint64_t m = ((((uint64_t)1) << (31 + l)) + d - 1) / d;
+    return (m << 8) | (uint64_t)(31 + l);
+}
+__host__ __device__ inline uint32_t fd_div31(uint32_t n, uint64_t packed)
+{
+    return (uint32_t)(((uint64_t)n * (packed >> 8)) >> (packed & 0xFFu));
+}
+
 // XCD-aware tile mapping.  MI355X dispatches workgroup b to XCD b % 8 and each XCD has a private
 // 4 MiB L2.  Patterns whose gathers revisit a row from several places of the storage order
 // (5-point stencils: rows k-nx, k, k+nx) would otherwise fetch every line into up to 3 different
@@ -194,7 +208,7 @@ struct fd_plan {
     int *d_w2desc = nullptr;
     // uniform band with cyclic colours (k_decompress_band): the whole tiles [band_t0, band_t1) of the 1-D row-window plan
     // are decompressed with computed indices -- local entry p <-> Q = p + band_off = band_w * j + k, row j - band_u + k,
-    // colour (j + band_shift) mod band_C; band_mw / band_mc = ceil(2^40 / band_w), ceil(2^40 / band_C)
+    // colour (j + band_shift) mod band_C; band_mw / band_mc = fd_magic31(band_w), fd_magic31(band_C): exact dividers for n < 2^31
     bool band_allowed = false;     //   FDJAC_BAND_DIRECT=1 (opt-in: not faster inside the pipeline, see apply_opts)
     bool band_ok = false;
     int64_t band_t0 = 0, band_t1 = 0, band_off = 0, band_C = 0;

@@ -584,8 +584,8 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
         // Uniform band (plan-time check: these tiles' stored descriptors ARE what follows, band_tile_desc in fdjac_api.hip):
         // entries Q0 .. Q1 = w*j + k touch the rows j - u + k -- no descriptor load in front of the window loads
         const uint32_t Q0 = (uint32_t)(t0 + bd_off), Q1 = Q0 + (uint32_t)(T - 1);      // (full tiles only)
-        const uint32_t j0 = (uint32_t)(((uint64_t)Q0 * bd_mw) >> 40), k0 = Q0 - j0 * (uint32_t)bd_w;
-        const uint32_t j1 = (uint32_t)(((uint64_t)Q1 * bd_mw) >> 40), k1 = Q1 - j1 * (uint32_t)bd_w;
+        const uint32_t j0 = fd_div31(Q0, bd_mw), k0 = Q0 - j0 * (uint32_t)bd_w;
+        const uint32_t j1 = fd_div31(Q1, bd_mw), k1 = Q1 - j1 * (uint32_t)bd_w;
         const int rmin = (int)j0 - bd_u + (int)(k0 < 1u ? k0 : 1u);
         const int rmax = (int)j1 - bd_u + (int)(k1 > (uint32_t)(bd_w - 2) ? k1 : (uint32_t)(bd_w - 2));
         const int r0 = rmin & ~1, np = (rmax - r0) / 2 + 1;
@@ -1584,9 +1584,9 @@ k_decompress_band(const real_t *__restrict__ FXa, const real_t *__restrict__ FXb
     for (int h = 0; h < 2; ++h) {
         const int64_t p = p0 + tile * (2 * kBlock * U) + uu * (2 * kBlock) + 2 * (int64_t)threadIdx.x;
         const uint32_t Q = (uint32_t)(p + h + off);
-        const uint32_t j = (uint32_t)(((uint64_t)Q * mw) >> 40), k = Q - j * (uint32_t)w;
+        const uint32_t j = fd_div31(Q, mw), k = Q - j * (uint32_t)w;
         const uint32_t cj = j + (uint32_t)shift;
-        const int c = (int)(cj - (uint32_t)(((uint64_t)cj * mc) >> 40) * (uint32_t)C);
+        const int c = (int)(cj - fd_div31(cj, mc) * (uint32_t)C);
         const int64_t r = (int64_t)j - u + k;
         const bool live = p + h < p1;
         const bool inside = live & (r >= 0) & (r < M);

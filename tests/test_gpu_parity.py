@@ -1656,3 +1656,27 @@ def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
         assert infos[0] > 10 and infos[1] == 0      # (all but the corner tiles)
     assert not np.isnan(outs[0]).any()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_band_index_arithmetic_at_large_entry_counts(monkeypatch):
+    # the computed descriptors / computed-index kernel divide entry numbers up to 2^31 by the band width with a multiply-shift
+    # (fd_div31): a pattern whose entry numbers exceed 2^26 must give the bits of the loaded-descriptor path
+    N = 23_000_003                                      # tridiagonal: 6.9e7 stored entries
+    colptr, rowval = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    x = _dev(np.random.default_rng(91).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    outs = []
+    for comp, direct in (("1", "0"), ("0", "0"), ("0", "1")):
+        monkeypatch.setenv("FDJAC_BAND_DESC", comp)
+        monkeypatch.setenv("FDJAC_BAND_DIRECT", direct)
+        plan = fd.make_plan(J, J, colors, "forward")
+        assert (plan.info(fd.lib.INFO_BAND_DESC) > 0) == (comp == "1") and plan.info(fd.lib.INFO_BAND_DIRECT) == int(direct)
+        out = _dev(np.full(rowval.size, np.nan))
+        plan.set_lazy(f)
+        plan.jacobian(f, x, [out])
+        outs.append(out)
+        del plan
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])

@@ -286,3 +286,74 @@ def test_tridiagonal_colours_converted_on_the_device(monkeypatch, special, fdtyp
     assert plans["0"].info(fd.lib.INFO_EPS_CYCLIC) == plans["1"].info(fd.lib.INFO_EPS_CYCLIC) == cyc
     for a, b in zip(outs["0"], outs["1"]):
         assert not torch.isnan(a).any() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_patterns_device_vs_host_builder(monkeypatch, seed):
+    # Randomised sweep over what the device builders take: bands of random width / shape / colouring (cyclic, shifted,
+    # irregular, with uncoloured columns), 2-D stencils of random offsets on random grids, random column windows, CSC and
+    # BandedMatrix storage.  Whatever each builder decides (row windows, 2-D tiles, computed descriptors, host fallback),
+    # the device-built plan must be the host-built plan (checksum) and give the same Jacobian bits.
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["band", "banded_matrix", "stencil"][seed % 3]
+    fdtype = FDTYPES[int(rng.integers(0, 3))]
+    win = None
+    if kind == "stencil":
+        nx, ny = int(rng.integers(70, 700)), int(rng.integers(40, 500))
+        N = M = nx * ny
+        offs = {(0, 0), (-1, 0), (1, 0), (0, -1), (0, 1)}
+        for cand in [(-1, -1), (1, 1), (-1, 1), (1, -1), (-2, 0), (2, 0)]:
+            if rng.random() < 0.25:
+                offs.add(cand)
+        colptr, rowval = _stencil_csc(nx, ny, sorted(offs))
+        C = int(rng.integers(3, 9))
+        ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+        colors = ((ii * int(rng.integers(1, 4)) + jj * int(rng.integers(1, 4))) % C + 1).T.reshape(-1).astype(np.int64)
+        l = u = 0
+    else:
+        N = int(rng.integers(140_000, 400_000))
+        l, u = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        M = N + int(rng.integers(-30, 31)) if rng.random() < 0.3 else N
+        w = l + u + 1
+        C = w if rng.random() < 0.7 else int(rng.integers(1, 9))
+        colors = ((np.arange(N) + int(rng.integers(0, C))) % C + 1).astype(np.int64)
+        if kind == "band":
+            colptr, rowval = P.banded_csc(M, N, l, u)
+    style = rng.random()
+    if style < 0.2:
+        colors[rng.integers(0, N, size=5)] = 0
+    elif style < 0.4:
+        idx = rng.integers(0, N, size=50)
+        colors[idx] = colors[idx] % C + 1
+    if rng.random() < 0.3:
+        a = int(rng.integers(0, N // 3))
+        win = (a + 1, int(rng.integers(a + N // 3, N)))
+    x = _dev(rng.random(N))
+    wband = l + u + 1
+    A = torch.as_tensor(rng.random((M, max(wband, 1))), device="cuda")
+
+    def fn(fx, xx):     # some f! (the plan does not care whether pattern and colouring fit it: same arithmetic both ways)
+        idx = torch.arange(M, device="cuda")
+        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
+        for k in range(max(wband, 1)):
+            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - l + k, 0, N - 1)] ** 2
+        fx.copy_(acc)
+
+    plans, outs = {}, {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", dev)
+        if kind == "banded_matrix":
+            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype, col_window=win)
+        else:
+            J = fd.SparseMatrixCSC(M, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, col_window=win)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(fn, M, N), x, [out])
+        plans[dev], outs[dev] = plan, out
+    assert plans["0"].checksum() == plans["1"].checksum(), (kind, fdtype, N, l, u, C, win)
+    for key in (fd.lib.INFO_WINDOW, fd.lib.INFO_WINDOW2D, fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_BAND_DESC, fd.lib.INFO_WIN_PERIOD,
+                fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_NNZ_LOCAL, fd.lib.INFO_NCOLORS):
+        assert plans["0"].info(key) == plans["1"].info(key), key
+    assert not torch.isnan(outs["0"]).any()
+    bad = torch.nonzero(outs["0"] != outs["1"]).flatten()
+    assert bad.numel() == 0, (kind, fdtype, N, M, l, u, C, win, int(bad.numel()), bad[:8].tolist(), outs["0"][bad[:8]].tolist(), outs["1"][bad[:8]].tolist())
