@@ -586,8 +586,9 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
         const uint32_t Q0 = (uint32_t)(t0 + bd_off), Q1 = Q0 + (uint32_t)(T - 1);      // (full tiles only)
         const uint32_t j0 = fd_div31(Q0, bd_mw), k0 = Q0 - j0 * (uint32_t)bd_w;
         const uint32_t j1 = fd_div31(Q1, bd_mw), k1 = Q1 - j1 * (uint32_t)bd_w;
-        const int rmin = (int)j0 - bd_u + (int)(k0 < 1u ? k0 : 1u);
-        const int rmax = (int)j1 - bd_u + (int)(k1 > (uint32_t)(bd_w - 2) ? k1 : (uint32_t)(bd_w - 2));
+        const int wm2 = bd_w - 2;                                  // (signed: -1 for a diagonal band)
+        const int rmin = (int)j0 - bd_u + ((int)k0 < 1 ? (int)k0 : 1);
+        const int rmax = (int)j1 - bd_u + ((int)k1 > wm2 ? (int)k1 : wm2);
         const int r0 = rmin & ~1, np = (rmax - r0) / 2 + 1;
         th = int4{0, bd_C, np, 1 | 0x100};
         wa = int4{r0, np, 0, np};

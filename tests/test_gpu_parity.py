@@ -1590,7 +1590,8 @@ def test_band_direct_kernel_bit_identical(monkeypatch, fdtype, case):
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["tridiag", "tridiag_window", "tridiag_devplan", "tridiag_chunked", "band5", "bidiag", "banded11", "banded23",
-                                  "banded_rect", "tridiag_shifted", "tridiag_none", "tridiag_t2048", "tridiag_t512"])
+                                  "banded_rect", "tridiag_shifted", "tridiag_none", "tridiag_t2048", "tridiag_t512",
+                                  "diag_csc", "diag_csc_oddwin", "diag_banded_oddwin", "bidiag_oddwin", "band5_oddwin", "banded23_evenwin"])
 def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
     # Uniform bands: the row-window kernel computes the descriptors of its regular tiles from the band parameters instead of
     # loading them (FD_INFO_BAND_DESC tiles; the plan verified that the stored descriptors are what the kernel computes).
@@ -1608,6 +1609,15 @@ def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
         l, u = 2, 3
     if case == "banded_rect":
         l, u, M = 3, 1, N + 40
+    if case.startswith("diag_"):                     # a diagonal band (w = 1): the one width whose "w - 2" is negative
+        l = u = 0
+        banded = "banded" in case
+    if case == "bidiag_oddwin":
+        l, u = 1, 0
+    if case == "band5_oddwin":
+        l = u = 2
+    if case == "banded23_evenwin":
+        l, u = 2, 3
     w = l + u + 1
     colors = P.cyclic_colors(N, w)
     if case == "tridiag_shifted":
@@ -1618,6 +1628,10 @@ def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
         cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2
     if case == "tridiag_window":
         win = (N // 5 + 1, 4 * N // 5)
+    if case.endswith("_oddwin"):                     # first column of the window odd / even: the tiles' first entries move
+        win = (17_793, 126_540)
+    if case.endswith("_evenwin"):
+        win = (17_794, 126_541)
     if case in ("tridiag_t2048", "tridiag_t512"):
         monkeypatch.setenv("FDJAC_WIN_TILE", case[-4:] if case.endswith("2048") else "512")
     x = _dev(np.random.default_rng(81).random(N))
@@ -1635,7 +1649,7 @@ def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
         monkeypatch.setenv("FDJAC_BAND_DESC", comp)
         monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1" if case == "tridiag_devplan" else "0")
         if banded:
-            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype)
+            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype, col_window=win)
         else:
             colptr, rowval = P.banded_csc(M, N, l, u)
             J = fd.SparseMatrixCSC(M, N, colptr, rowval)
