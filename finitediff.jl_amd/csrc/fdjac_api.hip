@@ -354,8 +354,9 @@ static void plan_row_strips(fd_plan *p, const std::vector<int4> &wt, size_t ntil
     p->strips = K;
 }
 
+// single_only: accept a tile only if its rows form ONE window (what the device builder's k_pb_tiles can describe)
 static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc, size_t padded,
-                           bool scattered)
+                           bool scattered, bool single_only = false)
 {
     int rc;
     struct WinBuild {
@@ -393,6 +394,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
                     wn[0] = (rmax - wr[0]) / 2 + 1;
                     nwin = 1;
                 } else {
+                    if (single_only) return w;
                     rr.clear();
                     for (size_t e = b0; e < b0 + (size_t)T; ++e) if (nzc[e] >= 0) rr.push_back(rows[e]);
                     std::sort(rr.begin(), rr.end());
@@ -982,7 +984,11 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (!has_dest && p->nnz_local > 0) {
         const char *fw1 = getenv("FDJAC_WINDOW"), *fs1 = getenv("FDJAC_SORTED");
         const bool win_allowed = !(fw1 && *fw1 && atoi(fw1) == 0) && !(fs1 && *fs1 && atoi(fs1) == 1);
-        if (scattered && colstart && win_allowed && (rc = try_window2d_plan(p, rows, nzc, *colstart))) return rc;
+        // a scattered storage order whose tiles still form ONE tight row window each (2-D stencils on narrow grids) is
+        // served by the 1-D tiles -- the order in which the device builder decides, too; then 2-D (strided) tiles; then
+        // clustered / sorted windows
+        if (scattered && colstart && win_allowed && (rc = try_window_plan(p, rows, nzc, padded, false, true))) return rc;
+        if (!p->window && scattered && colstart && win_allowed && (rc = try_window2d_plan(p, rows, nzc, *colstart))) return rc;
         if (!p->window && (rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
         if (p->window && colstart && p->kind == K_CSC) try_band_plan_csc(p, col0, rows, *colstart);
         if (p->window) {
