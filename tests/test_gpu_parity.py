@@ -1694,3 +1694,74 @@ def test_band_index_arithmetic_at_large_entry_counts(monkeypatch):
         del plan
     assert not torch.isnan(outs[0]).any()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_switch_combinations_bit_identical(monkeypatch, seed):
+    # Every kernel variant / plan builder / hand-over is a different route to the same IEEE operations on the same operands.
+    # Reference: the plain gather kernel on a host-built plan with the plain hand-over of the f! values.  Variant: a random
+    # combination of the switches of DESIGN section 5 (tile size, periodic codes, computed descriptors, computed-index band
+    # kernel, rolling windows, 2-D tiles, row strips, tile order, differences hand-over, device plan builder, colour chunks,
+    # column window).  Same bits, same number of f! evaluations.
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "7000")) + seed)
+    fdtype = FDTYPES[int(rng.integers(0, 3))]
+    if seed % 2 == 0:
+        N = int(rng.integers(60_000, 330_000))
+        colptr, rowval = P.tridiag_csc(N)
+        C = 3
+        colors = ((np.arange(N) + int(rng.integers(0, 3))) % 3 + 1).astype(np.int64)
+        fam, prm, halo = "tridiag_nl", (N,), 3
+    else:
+        nx, ny = 2 * int(rng.integers(40, 260)), int(rng.integers(60, 400))
+        N = nx * ny
+        colptr, rowval = P.lap5_csc(nx, ny)
+        C = 5
+        colors = P.lap5_colors(nx, ny)
+        fam, prm, halo = ("lap5_nl" if rng.random() < 0.6 else "clamp5"), (nx, ny), nx + 2
+    if rng.random() < 0.25:
+        colors = colors.copy()
+        colors[rng.integers(0, N, size=4)] = 0
+    win = None
+    if rng.random() < 0.35:
+        a = int(rng.integers(0, N // 3))
+        win = (a + 1, int(rng.integers(a + N // 3, N)))
+    cap = 0
+    if rng.random() < 0.3:      # two colours per chunk
+        cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2 + 8192
+    x = _dev(rng.random(N))
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    xwin = (max(win[0] - halo, 1), min(win[1] + halo, N)) if win else None
+
+    def run(env, diff):
+        for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC", "FDJAC_BAND_DIRECT", "FDJAC_ROLL",
+                  "FDJAC_WINDOW2D", "FDJAC_STRIPS", "FDJAC_REVERSE", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_DMA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, x_window=xwin)
+        f = fd.BuiltinF(fam, *prm)
+        plan.set_lazy(f, diff=diff)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        return out, f.fcalls
+
+    ref, calls_ref = run({"FDJAC_WINDOW": "0", "FDJAC_SORTED": "0", "FDJAC_PLAN_DEVICE": "0"}, False)
+    env = {}
+    pick = lambda name, choices: env.__setitem__(name, str(choices[int(rng.integers(0, len(choices)))])) if rng.random() < 0.6 else None
+    pick("FDJAC_WIN_TILE", [512, 1024, 2048])
+    pick("FDJAC_WIN_PERIODIC", [0, 1])
+    pick("FDJAC_BAND_DESC", [0, 1])
+    pick("FDJAC_BAND_DIRECT", [0, 1])
+    pick("FDJAC_ROLL", [0, 1])
+    pick("FDJAC_WINDOW2D", [0, 1])
+    pick("FDJAC_STRIPS", [1, 2, 3])
+    pick("FDJAC_REVERSE", [0, 1])
+    pick("FDJAC_PLAN_DEVICE", [0, 1])
+    pick("FDJAC_SORTED", [0, 1])
+    diff = bool(rng.random() < 0.7)
+    got, calls = run(env, diff)
+    assert not torch.isnan(ref).any()
+    bad = torch.nonzero(got != ref).flatten()
+    assert bad.numel() == 0, (fam, prm, fdtype, win, cap, env, diff, int(bad.numel()), bad[:8].tolist(), got[bad[:8]].tolist(), ref[bad[:8]].tolist())
+    assert calls == calls_ref
