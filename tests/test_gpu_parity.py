@@ -1729,9 +1729,13 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     cap = 0
     if rng.random() < 0.3:      # two colours per chunk
         cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2 + 8192
-    x = _dev(rng.random(N))
+    dtype = np.float32 if rng.random() < 0.3 else np.float64          # (fd32_*: the second instantiation of every kernel)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    x = torch.as_tensor(rng.random(N), dtype=tdt, device="cuda")
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     xwin = (max(win[0] - halo, 1), min(win[1] + halo, N)) if win else None
+    if dtype == np.float32 and cap:
+        cap //= 2
 
     def run(env, diff):
         for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC", "FDJAC_BAND_DIRECT", "FDJAC_ROLL",
@@ -1739,10 +1743,10 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, x_window=xwin)
-        f = fd.BuiltinF(fam, *prm)
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, x_window=xwin, dtype=dtype)
+        f = fd.BuiltinF(fam, *prm, dtype=dtype)
         plan.set_lazy(f, diff=diff)
-        out = _dev(np.full(plan.out_len(0), np.nan))
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=tdt, device="cuda")
         plan.jacobian(f, x, [out])
         return out, f.fcalls
 
@@ -1763,5 +1767,6 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     got, calls = run(env, diff)
     assert not torch.isnan(ref).any()
     bad = torch.nonzero(got != ref).flatten()
-    assert bad.numel() == 0, (fam, prm, fdtype, win, cap, env, diff, int(bad.numel()), bad[:8].tolist(), got[bad[:8]].tolist(), ref[bad[:8]].tolist())
+    assert bad.numel() == 0, (fam, prm, fdtype, np.dtype(dtype).name, win, cap, env, diff, int(bad.numel()), bad[:8].tolist(),
+                              got[bad[:8]].tolist(), ref[bad[:8]].tolist())
     assert calls == calls_ref
