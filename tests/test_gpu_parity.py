@@ -1770,3 +1770,75 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     assert bad.numel() == 0, (fam, prm, fdtype, np.dtype(dtype).name, win, cap, env, diff, int(bad.numel()), bad[:8].tolist(),
                               got[bad[:8]].tolist(), ref[bad[:8]].tolist())
     assert calls == calls_ref
+
+
+@pytest.mark.parametrize("seed", list(range(36)))
+def test_random_storage_kinds_recover_a_linear_map(seed):
+    # f(x) = A x with a random A inside a random pattern: the coloured finite-difference Jacobian must return A's stored
+    # entries in every storage type the reference's plugins cover -- SparseMatrixCSC (common pattern), dense J with a sparse or
+    # a dense-matrix pattern, Tridiagonal, BandedMatrix (rectangular, asymmetric), BlockBandedMatrix (ragged blocks) -- for
+    # every fdtype, with a greedy colouring of the pattern (fd_color_columns_greedy).  Forward / central differences of a linear
+    # map are exact up to rounding / eps; the complex step to a few ulp.
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "5000")) + seed)
+    kind = ["csc", "dense_sparse", "dense_dense", "tridiagonal", "banded", "blockbanded"][seed % 6]
+    fdtype = FDTYPES[int(rng.integers(0, 3))]
+    tol = {"forward": 2e-6, "central": 2e-9, "complex": 1e-13}[fdtype]
+    lay = None
+    if kind == "blockbanded":
+        nb = int(rng.integers(3, 12))
+        sizes = rng.integers(1, 7, size=nb)
+        bl, bu = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        lay = P.BlockBandedLayout(sizes, bl, bu)
+        M = N = lay.N
+        mask = np.zeros((M, N), dtype=bool)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        for bi in range(nb):
+            for bj in range(nb):
+                if -bu <= bi - bj <= bl:
+                    mask[off[bi]:off[bi + 1], off[bj]:off[bj + 1]] = True
+    elif kind == "tridiagonal":
+        M = N = int(rng.integers(4, 400))
+        i, j = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+        mask = np.abs(i - j) <= 1
+    elif kind == "banded":
+        N = int(rng.integers(5, 300))
+        M = max(2, N + int(rng.integers(-4, 5)))
+        l, u = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        i, j = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+        mask = (i - j <= l) & (j - i <= u)
+    else:
+        M, N = int(rng.integers(3, 220)), int(rng.integers(3, 220))
+        mask = rng.random((M, N)) < min(0.5, 4.0 / N)
+        mask[rng.integers(0, M, size=N), np.arange(N)] = True          # no empty column
+    A = np.where(mask, rng.random((M, N)) + 0.25, 0.0)
+    x = rng.random(N)
+    colptr, rowval = P.csc_from_dense(mask.astype(float))
+    colors = fd.matrix_colors(fd.SparseMatrixCSC(M, N, colptr, rowval)) if kind != "blockbanded" else lay.colors()
+    At = _dev(A)
+    f = fd.TorchF(lambda fx, xx: fx.copy_(At.to(xx.dtype) @ xx), M, N)
+    if kind == "csc":
+        Jm = fd.SparseMatrixCSC(M, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+        fd.finite_difference_jacobian_b(Jm, f, _dev(x), fdtype, colorvec=colors, sparsity=Jm)
+        got = P.csc_to_dense(M, N, colptr, rowval, Jm.nzval.cpu().numpy())
+    elif kind in ("dense_sparse", "dense_dense"):
+        Jd = torch.full((N, M), float("nan"), dtype=torch.float64, device="cuda").t()       # column-major M x N
+        sp = fd.SparseMatrixCSC(M, N, colptr, rowval) if kind == "dense_sparse" else mask.astype(float)
+        fd.finite_difference_jacobian_b(Jd, f, _dev(x), fdtype, colorvec=colors, sparsity=sp)
+        got = Jd.cpu().numpy()
+    elif kind == "tridiagonal":
+        Jt = fd.Tridiagonal(_dev(np.full(N - 1, np.nan)), _dev(np.full(N, np.nan)), _dev(np.full(N - 1, np.nan)))
+        fd.finite_difference_jacobian_b(Jt, f, _dev(x), fdtype, colorvec=colors)
+        got = np.diag(Jt.d.cpu().numpy()) + np.diag(Jt.dl.cpu().numpy(), -1) + np.diag(Jt.du.cpu().numpy(), 1)
+    elif kind == "banded":
+        data = torch.full((N, l + u + 1), float("nan"), dtype=torch.float64, device="cuda").t()
+        fd.finite_difference_jacobian_b(fd.BandedMatrix(data, M, l, u), f, _dev(x), fdtype, colorvec=colors)
+        got = P.banded_to_dense(data.cpu().numpy(), M, N, l, u)
+    else:
+        data = _dev(np.full(lay.data_len, np.nan))
+        Jb = fd.BlockBandedMatrix(data, lay)
+        fd.finite_difference_jacobian_b(Jb, f, _dev(x), fdtype, colorvec=colors, sparsity=Jb)
+        got = lay.to_dense(data.cpu().numpy())
+    assert np.all(np.isfinite(got)), (kind, fdtype, M, N)
+    err = np.abs(got - A).max()
+    assert err <= tol * max(1.0, float(np.abs(A @ x).max())), (kind, fdtype, M, N, err)
