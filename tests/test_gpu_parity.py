@@ -1842,3 +1842,33 @@ def test_random_storage_kinds_recover_a_linear_map(seed):
     assert np.all(np.isfinite(got)), (kind, fdtype, M, N)
     err = np.abs(got - A).max()
     assert err <= tol * max(1.0, float(np.abs(A @ x).max())), (kind, fdtype, M, N, err)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_jvp_sizes_three_forms_agree(oracle, seed):
+    # finite_difference_jvp! (src/jvp.jl:238-274) at random sizes (odd, tiny, around the small-problem threshold): the lazy
+    # launcher that writes the finished quotient, the lazy launcher that writes values, and the materialised points give the same
+    # bits; the result matches the oracle
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "9000")) + seed)
+    fdtype = ["forward", "central"][int(rng.integers(0, 2))]
+    if seed % 3 == 2:
+        nx, ny = 2 * int(rng.integers(2, 150)), int(rng.integers(2, 200))
+        family, prm, N = ["lap5", "lap5_nl", "clamp5"][int(rng.integers(0, 3))], (nx, ny), nx * ny
+    else:
+        N = int([1, 2, 3, 5, 64, 16383, 16384, 16385][seed // 3]) if seed % 3 == 0 else int(rng.integers(4, 120_000))
+        family, prm = ["tridiag", "tridiag_nl"][int(rng.integers(0, 2))], (N,)
+    x = _dev(rng.random(N))
+    v = _dev(rng.random(N) - 0.5)
+    res = []
+    for lazy, quotient in ((True, True), (True, False), (False, False)):
+        f = fd.BuiltinF(family, *prm)
+        out = _dev(np.full(N, np.nan))
+        fd.finite_difference_jvp_b(out, f, x, v, fd.JVPCache(x, fdtype, lazy=lazy, quotient=quotient))
+        assert f.fcalls == 2
+        res.append(out)
+    assert not torch.isnan(res[0]).any()
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), (family, prm, fdtype)
+    if family != "clamp5":
+        ref = oracle.jvp(fdtype, oracle.Fixture(family, *prm), x.cpu().numpy(), v.cpu().numpy())
+        _tol_ok(res[0].cpu().numpy(), ref["jvp"], ref["eps"], 8.0, "jvp %s %s N=%d" % (family, fdtype, N))
