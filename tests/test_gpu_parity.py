@@ -1706,14 +1706,15 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     import os
     rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "7000")) + seed)
     fdtype = FDTYPES[int(rng.integers(0, 3))]
+    scale = float(os.environ.get("FDJAC_TEST_SIZE_SCALE", "1"))       # (exploratory runs also shrink the problems)
     if seed % 2 == 0:
-        N = int(rng.integers(60_000, 330_000))
+        N = max(3, int(rng.integers(60_000, 330_000) * scale))
         colptr, rowval = P.tridiag_csc(N)
         C = 3
         colors = ((np.arange(N) + int(rng.integers(0, 3))) % 3 + 1).astype(np.int64)
         fam, prm, halo = "tridiag_nl", (N,), 3
     else:
-        nx, ny = 2 * int(rng.integers(40, 260)), int(rng.integers(60, 400))
+        nx, ny = 2 * max(1, int(rng.integers(40, 260) * scale ** 0.5)), max(2, int(rng.integers(60, 400) * scale ** 0.5))
         N = nx * ny
         colptr, rowval = P.lap5_csc(nx, ny)
         C = 5
@@ -1723,7 +1724,7 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
         colors = colors.copy()
         colors[rng.integers(0, N, size=4)] = 0
     win = None
-    if rng.random() < 0.35:
+    if rng.random() < 0.35 and N >= 12:
         a = int(rng.integers(0, N // 3))
         win = (a + 1, int(rng.integers(a + N // 3, N)))
     cap = 0
