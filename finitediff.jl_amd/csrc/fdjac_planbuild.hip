@@ -1,24 +1,34 @@
-// Plan construction ON THE DEVICE for the common-pattern CSC path (fd_plan_create_csc / fd_plan_create_csc_device).
+// Plan construction ON THE DEVICE: common-pattern CSC plans (fd_plan_create_csc / fd_plan_create_csc_device), BandedMatrix
+// plans (fd_plan_create_banded) and the colours of Tridiagonal plans (fd_plan_create_tridiagonal).
 //
 // What a plan compiles is the per-call pattern work of the reference -- the O(nnz) pattern comparison, the O(N) colour
 // scan per colour and the colptr walk of `_colorediteration!` (src/jacobians.jl:524-535,547;
-// ext/FiniteDiffSparseArraysExt.jl:38-47,51-52) -- into tile descriptors and 16-bit entry codes.  The host builder
-// (fdjac_api.hip: csc_common / try_window_plan) does that with serial loops over nnz (0.3 s at nnz = 3*10^7).  Here the
-// same arrays are produced by kernels:
+// ext/FiniteDiffSparseArraysExt.jl:38-47,51-52; ext/FiniteDiffBandedMatricesExt.jl:13-27) -- into tile descriptors and
+// 16-bit entry codes.  The host builders (fdjac_api.hip: csc_common / try_window_plan / try_window2d_plan) do that with
+// serial loops over nnz (0.3 - 0.7 s at nnz = 3..5 * 10^7).  Here the same arrays are produced by kernels:
 //   k_pb_colmax / k_pb_colors   colorvec (Int32 / Int64, 1-based) -> 0-based uint8 colours, C = maximum(colorvec),
 //                               "some column has no colour", "colours are cyclic" (wave ballots)
-//   k_pb_tiles                  one workgroup per tile of stored entries, straight from colptr / rowval: the tile's slice
-//                               of colptr staged in LDS, every entry finds its column by binary search, down-converts its
-//                               row (the index down-conversion SURVEY section 7 asks for) and takes its column's colour;
-//                               row / colour extent by wave reductions -> tile descriptor; the 16-bit entry codes
+//   k_pb_tiles                  1-D tiles: one workgroup per tile of stored entries, straight from colptr / rowval (or, BAND,
+//                               from the implicit indices of a band's column-major storage): the tile's slice of colptr in
+//                               LDS, every entry finds its column by binary search, down-converts its row (the index
+//                               down-conversion SURVEY section 7 asks for) and takes its column's colour; row / colour
+//                               extent by wave reductions -> tile descriptor; the 16-bit entry codes
 //   k_pb_periodic               which tiles repeat their codes with the plan-wide period (ballot over the tile)
+//   k_pb_band_check             uniform-band test (affine colptr, consecutive rows) -> the tiles whose descriptors the
+//                               row-window kernel computes instead of loading
+//   k_pb_sample_expand / k_pb_coherence   the gather-coherence estimate that decides "scattered" (bitonic sort of each
+//                               sampled tile in LDS, distinct 128-B lines per wave gather by lane-to-lane comparison)
+//   k_pb2_sample_cols / k_pb2_check / k_pb2_count / k_pb2_tiles   2-D (strided) tiles of 2-D stencil patterns: the stride, its
+//                               validation, tile placement (host prefix sum over 8 B per tile), row windows from an LDS
+//                               bitmap of the tile's rows, descriptors and codes
 // No intermediate per-entry arrays, no same-address atomics in the hot kernels (grid-wide statistics are computed by the
 // host from the 48-byte tile descriptors).
 // The pattern may already live on the device (fd_plan_create_csc_device: nothing crosses PCIe) or is uploaded raw.
-// Patterns the device builder does not handle (tiles that need several row windows or a sort: scattered stencils; more
-// than 8 colours; forced kernel variants) make it step aside -- the host builder then runs as before.  The host builder
-// is also the CHECKER: tests build every plan both ways (FDJAC_PLAN_DEVICE=0/1) and compare the plan arrays bit for bit
-// (fd_plan_checksum).
+// Patterns the device builder does not handle (more than 8 colours; tiles that need clustered / sorted row windows; 2-D grids
+// narrower than 64; forced kernel variants) make it step aside -- the host builder then runs as before.  The host builders
+// are also the CHECKERS: they decide in the same order (one-window 1-D tiles, 2-D tiles, clustered windows), and the tests build
+// every plan both ways (FDJAC_PLAN_DEVICE=0/1) and compare the plan arrays bit for bit (fd_plan_checksum), fixed and
+// randomised patterns alike.
 #include <time.h>
 
 #include <algorithm>
