@@ -382,6 +382,38 @@ def main():
             plain = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             plan.set_lazy(f)
+    # ---- side measurement (single GPU, untimed, EXPERIMENTAL): the same Jacobian with FDJAC_LAZY_STORE=1 -- f!'s launch stores
+    # the finished quotients into nzval itself (include/fdjac_device.h), no decompression launch; must give the same bits
+    fused = None
+    if world == 1 and cfg in ("c2", "c4") and f_mode == "lazy" and not args.no_plain_handover:
+        try:
+            os.environ["FDJAC_LAZY_STORE"] = "1"
+            cp_s, rv_s = P.tridiag_csc(N)              # (the pattern arrays of the timed plan were released after its creation)
+            pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
+            plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
+            del cp_s, rv_s, pat_s
+            plan_s.set_lazy(f)
+            if plan_s.info(fd.lib.INFO_LAZY_STORE) == 1:
+                out_s = torch.full_like(out, float("nan"))
+                enq_s = plan_s.bind(f, x, [out_s])
+                for _ in range(3):
+                    enq_s()
+                torch.cuda.synchronize()
+                reps_s = min(args.steps, 10)
+                ts = time.perf_counter()
+                for _ in range(reps_s):
+                    enq_s()
+                torch.cuda.synchronize()
+                ms_s = (time.perf_counter() - ts) / reps_s * 1e3
+                fused = {"ms_per_step": ms_s, "value": N / (ms_s * 1e-3), "bit_identical_to_timed_result": bool(torch.equal(out_s, timed_result)),
+                         "what": "FDJAC_LAZY_STORE=1 (experimental, opt-in): eps pass + ONE launch that evaluates f!, forms the quotients and "
+                                 "stores them into nzval; not the default, not the graded path"}
+                del out_s
+            del plan_s
+        except Exception as e:
+            fused = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            os.environ.pop("FDJAC_LAZY_STORE", None)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -556,6 +588,7 @@ def main():
                             "this kernel does not perform -- an equivalent-work rate, NOT a bandwidth (it can exceed the peak)"},
             },
             "roofline_plain_handover": plain,
+            "fused_store_experimental": fused,
             "stages_ms": stages,
             "whole_call": {"gpu_ms": tot_ms, "hbm_bytes_model": bytes_call_model * n_local,
                            "gbps": bytes_call_model * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,

@@ -141,6 +141,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
     p->band_allowed = env_int("FDJAC_BAND_DIRECT", 0) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
+    p->store_allowed = env_int("FDJAC_LAZY_STORE", 0) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -947,6 +948,33 @@ static void try_band_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, cons
     finish_band_plan(p, w, u, cs(ju0), ju0, ju1, p->C, shift);
 }
 
+// EXPERIMENTAL store capability (FDJAC_LAZY_STORE=1): is the pattern EXACTLY the band (corners included) that the arithmetic of
+// include/fdjac_device.h describes, with cyclic colours and at least as many colours as the band is wide?
+static void try_store_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows, const std::vector<int64_t> &colstart)
+{
+    p->store_ok = false;
+    if (!p->store_allowed || p->col1 - p->col0 < 4 || p->nnz_local < 1) return;
+    int shift = 0;
+    if (!colors_cyclic(col0, p->C, &shift)) return;
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    auto cs = [&](int64_t j) { return colstart[(size_t)(j - p->col0)]; };
+    const int64_t w = cs(jm + 1) - cs(jm);
+    if (w < 1 || w > 64 || p->C < w) return;
+    const int64_t u = jm - rows[(size_t)cs(jm)];
+    if (u < 0 || w - 1 - u < 0) return;
+    fd_band_store d;
+    memset(&d, 0, sizeof d);
+    d.M = p->M; d.N = p->N; d.l = (int)(w - 1 - u); d.u = (int)u; d.C = (int)p->C; d.shift = shift;
+    bool ok = true;
+    for (int64_t j = p->col0; j < p->col1 && ok; ++j) {
+        const int64_t first = std::max<int64_t>(j - u, 0), last = std::min<int64_t>(p->M - 1, j + d.l);
+        ok = cs(j) + p->entry_begin == fd_band_colptr(&d, j) && cs(j + 1) - cs(j) == last - first + 1 && last >= first;
+        for (int64_t k = 0; ok && k < cs(j + 1) - cs(j); ++k) ok = rows[(size_t)(cs(j) + k)] == first + k;
+    }
+    ok = ok && cs(p->col1) + p->entry_begin == fd_band_colptr(&d, p->col1);
+    if (ok) { p->store_ok = true; p->store_l = d.l; p->store_u = d.u; p->store_C = d.C; p->store_shift = shift; }
+}
+
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
 static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
                             std::vector<int32_t> &nzc, std::vector<int64_t> &dest,
@@ -991,6 +1019,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         if (!p->window && scattered && colstart && win_allowed && (rc = try_window2d_plan(p, rows, nzc, *colstart))) return rc;
         if (!p->window && (rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
         if (p->window && colstart && p->kind == K_CSC) try_band_plan_csc(p, col0, rows, *colstart);
+        if (colstart && p->kind == K_CSC) try_store_plan_csc(p, col0, rows, *colstart);
         if (p->window) {
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
@@ -1288,7 +1317,7 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
                             p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
                             p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6),
                             p->band_ok, p->band_t0, p->band_t1, p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
-                            (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1};
+                            (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1, p->store_ok, p->store_l, p->store_u};
     mix(scal, sizeof scal);
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
@@ -1625,6 +1654,9 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
     case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
+    case FD_INFO_LAZY_STORE:
+        *value = (p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none) ? 1 : 0;
+        break;
     case FD_INFO_LAZY_DIFF:
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
         break;
@@ -1848,6 +1880,35 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
                                !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
         if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
+        // EXPERIMENTAL (FDJAC_LAZY_STORE=1, include/fdjac_device.h): the launcher stores the finished quotients into the
+        // Jacobian itself -- the exact band was verified at plan time -- and nothing is launched after f!
+        if (p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none &&
+            p->kind == K_CSC && !(p->fdtype == FD_FORWARD && !base_pending) && !small) {
+            Span sp(p, FD_STAGE_F);
+            fd_band_store bs;
+            memset(&bs, 0, sizeof bs);
+            bs.out = outs[0];
+            bs.M = p->M; bs.N = p->N; bs.entry_begin = p->entry_begin; bs.col_begin = p->col0; bs.col_end = p->col1;
+            bs.l = p->store_l; bs.u = p->store_u; bs.C = p->store_C; bs.shift = p->store_shift;
+            fd_lazy_points lp = {};
+            lp.x = x_dev;
+            lp.color = p->d_color;
+            lp.eps = p->d_eps;
+            lp.color_bytes = p->color8 ? 1 : 4;
+            lp.c_lo = c_lo;
+            lp.ncolors = B;
+            lp.pts = p->pts;
+            lp.nparts = 1;
+            lp.diff = (p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1;
+            lp.store = &bs;
+            const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (store) returned %d", rc);
+            if (rc == 0) {
+                p->fcalls_last += (int64_t)B * p->pts + (lp.diff == 2 ? 1 : 0);
+                diff_base_counted = true;
+                continue;
+            }
+        }
         if (strip_mode) {
             const bool io = p->fdtype == FD_COMPLEX;      // (imag-only: the f! arrays are real, fx is the zero vector)
             real_t *eps_plain = p->d_eps;

@@ -110,7 +110,7 @@ template <typename CT, int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                  const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
-                 int64_t r1, int imag_only, int diff)
+                 int64_t r1, int imag_only, int diff, int store, fd_band_store bst)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
@@ -168,12 +168,27 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
                 for (int k = 0; k < 4; ++k) { p[k] = xv[k] + d[k]; q[k] = xv[k] - d[k]; }
                 const real_t s0 = MODE == 1 ? tridiag_row<real_t, NL>(q[0], q[1], q[2]) : b0;
                 const real_t v0 = sub_exact(tridiag_row<real_t, NL>(p[0], p[1], p[2]), s0);
-                real_t *dst = fx + (int64_t)b * fs + i;
+                real_t v1 = 0.0;
                 if (two) {
                     const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
-                    *reinterpret_cast<r2_t *>(dst) = r2_t{v0, sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1)};
+                    v1 = sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1);
+                }
+                if (store) {
+                    // experimental (fd_lazy_points.store, include/fdjac_device.h): the finished quotients go straight into the
+                    // Jacobian's storage -- the division of src/jacobians.jl:565 / 607 and the assignment of
+                    // ext/FiniteDiffSparseArraysExt.jl:38-47 for the entry (row, colour)
+                    const real_t ed = MODE == 1 ? 2 * e : e;
+                    real_t *outp = (real_t *)bst.out;
+                    const long long d0 = fd_band_dest(&bst, i, c_lo + b);
+                    if (d0 >= 0) outp[d0] = v0 / ed;
+                    if (two) {
+                        const long long d1 = fd_band_dest(&bst, i + 1, c_lo + b);
+                        if (d1 >= 0) outp[d1] = v1 / ed;
+                    }
                 } else {
-                    dst[0] = v0;
+                    real_t *dst = fx + (int64_t)b * fs + i;
+                    if (two) *reinterpret_cast<r2_t *>(dst) = r2_t{v0, v1};
+                    else dst[0] = v0;
                 }
             } else {
 #pragma unroll
@@ -191,6 +206,93 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
                     }
                 }
             }
+        }
+    }
+}
+
+// EXPERIMENTAL (fd_lazy_points.store, include/fdjac_device.h): the tridiagonal fixture evaluated at the lazily perturbed points
+// of a batch, difference quotients formed and stored into the banded CSC Jacobian by this launch -- nothing follows it.
+// One workgroup owns 2 * kBlock consecutive rows; the storage positions of their entries form one contiguous range of nzval
+// (up to a few positions at either end that belong to the neighbours' rows), so the quotients are staged in LDS at
+// (position - first position) and written out as dense 16-B pairs.  Operations per entry: those of the plain path
+// (sub_exact, IEEE division).  Measured at N = 10^7 (profiles/r02_g_store_ab.txt): 104-110 us for this launch against
+// 60 + 100 us for f! + decompression -- 0.125 instead of 0.18 ms per Jacobian; scattered 8-B stores without the LDS staging:
+// 141 us; an output-centric variant (a workgroup per tile of stored entries, f! evaluated on the tile's row window, the
+// row-window kernel's gather after it): 168 us -- the fused launch is bound by its own dependent chain, not by bytes.
+template <typename CT, int MODE, bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_lazy_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
+                       int64_t n, int64_t r0, int64_t r1, fd_band_store bst, int cap)
+{
+    extern __shared__ real_t s_stage[];                        // [cap] quotients, then [cap] bytes "staged by this workgroup"
+    unsigned char *s_own = reinterpret_cast<unsigned char *>(s_stage + cap);
+    const int64_t R0 = r0 + (int64_t)blockIdx.x * (2 * kBlock);
+    if (R0 >= r1) return;
+    const int64_t R1 = R0 + 2 * kBlock < r1 ? R0 + 2 * kBlock : r1;
+    // first storage position any row of this workgroup can write (row R0, its first column), rounded down to a 16-B pair
+    const int64_t jf = R0 - bst.l > 0 ? R0 - bst.l : 0;
+    const int64_t ffirst = jf - bst.u > 0 ? jf - bst.u : 0;
+    const int64_t dlo = (fd_band_colptr(&bst, jf) - bst.entry_begin + (R0 - ffirst)) & ~(int64_t)1;
+    for (int k = threadIdx.x; k < cap; k += kBlock) s_own[k] = 0;
+    __syncthreads();
+    const int64_t i = R0 + 2 * (int64_t)threadIdx.x;
+    if (i < R1) {
+        real_t xv[4];
+        int cv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t j = i - 1 + k;
+            const bool in = (j >= 0) & (j < n);
+            xv[k] = in ? x[in ? j : 0] : 0.0;
+            const int c = in ? (int)color[in ? j : 0] : -1;
+            cv[k] = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+        }
+        const bool two = i + 1 < n && i + 1 < R1;
+        real_t b0 = 0.0, b1 = 0.0;
+        if (MODE == 0) {
+            b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
+            if (two) b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
+        }
+        // fd_band_dest(row, colour) with the per-row part hoisted: m = colour of the first column that can touch the row
+        // (ONE modulo per thread; row i+1's is m + 1), then per colour t = c - m (mod C) selects the column j0 + t
+        const int Cc = bst.C, wl = bst.l + bst.u;
+        const int m0 = (int)((uint32_t)(i - bst.l + bst.shift + 64 * (int64_t)Cc) % (uint32_t)Cc);     // (l <= 64)
+        const int m1 = m0 + 1 == Cc ? 0 : m0 + 1;
+        auto dest_of = [&](int64_t r, int m, int c) -> long long {
+            int t = c - m;
+            t += t < 0 ? Cc : 0;
+            const int64_t j = r - bst.l + t;
+            if (t > wl || j < bst.col_begin || j >= bst.col_end || j < 0 || j >= bst.N) return -1;
+            const int64_t first = j - bst.u > 0 ? j - bst.u : 0;
+            return fd_band_colptr(&bst, j) - bst.entry_begin + (r - first);
+        };
+        for (int b = 0; b < B; ++b) {
+            const real_t e = eps[c_lo + b];
+            real_t p[4], q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const real_t d = (cv[k] == b) ? e : 0.0; p[k] = xv[k] + d; q[k] = xv[k] - d; }
+            const real_t ed = MODE == 1 ? 2 * e : e;
+            const real_t s0 = MODE == 1 ? tridiag_row<real_t, NL>(q[0], q[1], q[2]) : b0;
+            const real_t v0 = sub_exact(tridiag_row<real_t, NL>(p[0], p[1], p[2]), s0);
+            const long long d0 = dest_of(i, m0, c_lo + b);
+            if (d0 >= 0) { s_stage[d0 - dlo] = v0 / ed; s_own[d0 - dlo] = 1; }
+            if (two) {
+                const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
+                const real_t v1 = sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1);
+                const long long d1 = dest_of(i + 1, m1, c_lo + b);
+                if (d1 >= 0) { s_stage[d1 - dlo] = v1 / ed; s_own[d1 - dlo] = 1; }
+            }
+        }
+    }
+    __syncthreads();
+    real_t *outp = (real_t *)bst.out;
+    const bool vec = ((((uintptr_t)outp) & kPairMask) == 0);
+    for (int k = 2 * threadIdx.x; k < cap; k += 2 * kBlock) {
+        const bool o0 = s_own[k] != 0, o1 = k + 1 < cap && s_own[k + 1] != 0;
+        if (o0 & o1 & vec) *reinterpret_cast<r2_t *>(outp + dlo + k) = r2_t{s_stage[k], s_stage[k + 1]};
+        else {
+            if (o0) outp[dlo + k] = s_stage[k];
+            if (o1) outp[dlo + k + 1] = s_stage[k + 1];
         }
     }
 }
@@ -539,7 +641,24 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
 #define FD_LAZY(MODE, NL)                                                                                           \
     hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (real_t *)fx, fs,    \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,     \
-                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0)
+                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0, lp->store != nullptr ? 1 : 0, bst)
+    fd_band_store bst = {};
+    if (lp->store) {
+        // (experimental) one-shot launch, one workgroup per 2 * kBlock rows, LDS staging of the quotients
+        bst = *(const fd_band_store *)lp->store;
+        const int wband = bst.l + bst.u + 1;
+        const int cap = (wband * (2 * kBlock + wband) + 4 + 1) & ~1;     // positions of 2 * kBlock rows: (rows + l + u) columns x w
+        const size_t shm = sizeof(real_t) * (size_t)cap + (size_t)cap;
+        if (shm > (size_t)60 * 1024) return FD_LAZY_DECLINED;
+        const unsigned gs = (unsigned)((r1 - r0e + 2 * kBlock - 1) / (2 * kBlock));
+#define FD_LAZY_ST(MODE, NL)                                                                                       \
+        hipLaunchKernelGGL((k_f_tridiag_lazy_store<CT, MODE, NL>), dim3(gs), dim3(kBlock), shm, s, (const real_t *)lp->x, \
+                           (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, b->prm[0], r0e, r1, bst, cap)
+        if (mode == 0) { if (nl) FD_LAZY_ST(0, true); else FD_LAZY_ST(0, false); }
+        else { if (nl) FD_LAZY_ST(1, true); else FD_LAZY_ST(1, false); }
+#undef FD_LAZY_ST
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
     if (mode == 0) { if (nl) FD_LAZY(0, true); else FD_LAZY(0, false); }
     else if (mode == 1) { if (nl) FD_LAZY(1, true); else FD_LAZY(1, false); }
     else { if (nl) FD_LAZY(2, true); else FD_LAZY(2, false); }
@@ -938,6 +1057,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
     if (lp->diff && (b->family == FD_F_BLOCKCOUPLED || lp->is_complex || lp->base_out)) return 8;   // (not registered with FD_LAZY_CAP_DIFF)
+    if (lp->store && !(lp->diff && (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL))) return 9;   // (FD_LAZY_CAP_STORE: the tridiagonal families)
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + ((lp->base_out || lp->diff == 2) ? 1 : 0);
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
@@ -1057,7 +1177,8 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
-    *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF))) : 0;
+    *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |
+                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) ? FD_LAZY_CAP_STORE : 0)) : 0;
     return FD_OK;
 }
 

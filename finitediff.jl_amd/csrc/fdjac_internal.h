@@ -59,6 +59,7 @@
 #include <vector>
 
 #include "fdjac.h"
+#include "fdjac_device.h"
 
 // communicator internals shared by both element-type builds (fdjac_comm.hip)
 extern "C" int fdjac_comm_allgather_f64(fd_comm *c, double *buf, int64_t slot_elems);
@@ -217,6 +218,10 @@ struct fd_plan {
     // ... and, independently of that kernel: the row-window kernel COMPUTES the descriptors of the tiles [bd_t0, bd_t1)
     // from the same band parameters instead of loading them (verified against the stored descriptors when the plan is
     // built) -- the descriptor load is one of two dependent global round trips of a workgroup's lifetime
+    // EXPERIMENTAL (FDJAC_LAZY_STORE=1): the pattern is verified to be the exact band include/fdjac_device.h describes; a
+    // FD_LAZY_CAP_STORE launcher then stores the quotients itself and no decompression is launched
+    bool store_allowed = false, store_ok = false;
+    int store_l = 0, store_u = 0, store_C = 0, store_shift = 0;
     bool bd_allowed = true;        //   FDJAC_BAND_DESC=0: always load
     int64_t bd_t0 = 0, bd_t1 = 0;
     int64_t w2_ntiles = 0;

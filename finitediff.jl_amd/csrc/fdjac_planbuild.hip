@@ -706,6 +706,21 @@ __global__ void __launch_bounds__(kBlock) k_pb_band_check(const void *__restrict
     }
 }
 
+// experimental store capability: is every local column exactly the band column include/fdjac_device.h describes?
+__global__ void __launch_bounds__(kBlock) k_pb_band_exact(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                          int64_t col0, int64_t col1, fd_band_store d, int *bad_out)
+{
+    bool bad = false;
+    for (int64_t j = col0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < col1; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t a = pb_load(colptr, ib, j) - base, b = pb_load(colptr, ib, j + 1) - base;
+        const int64_t first = j - d.u > 0 ? j - d.u : 0, last = d.M - 1 < j + d.l ? d.M - 1 : j + d.l;
+        bad = bad || a != fd_band_colptr(&d, j) || b != fd_band_colptr(&d, j + 1) || b - a != last - first + 1 || last < first;
+        if (!bad)
+            for (int64_t k = 0; k < b - a; ++k) bad = bad || (pb_load(rowval, ib, a + k) - base != first + k);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(bad_out, 1);
+}
+
 // outcome of the device builder
 enum { PBR_DONE = 0, PBR_DECLINED = 1 };
 
@@ -1179,6 +1194,26 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
                 if (ok && !hs.mid_bad) {
                     const int64_t ju0 = std::max<int64_t>(hs.lo + 1, p->col0), ju1 = std::min<int64_t>(hs.hi, p->col1);
                     finish_band_plan(p, w, u, (cpm - e0) + w * (ju0 - jm), ju0, ju1, C, shift, wt.data());
+                }
+            }
+        }
+    }
+    // experimental store capability (FDJAC_LAZY_STORE=1): the exact band, corners included
+    p->store_ok = false;
+    if (p->store_allowed && !band && p->band_w > 0 && C >= p->band_w && p->band_u >= 0 && p->band_w - 1 - p->band_u >= 0 &&
+        !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
+        fd_band_store d;
+        memset(&d, 0, sizeof d);
+        d.M = p->M; d.N = p->N; d.l = p->band_w - 1 - p->band_u; d.u = p->band_u; d.C = (int)C; d.shift = shift;
+        int *d_bad = nullptr, hbad = 0;
+        if (hipMalloc((void **)&d_bad, sizeof(int)) == hipSuccess) {
+            tmp.add(d_bad);
+            if (hipMemcpyAsync(d_bad, &hbad, sizeof hbad, hipMemcpyHostToDevice, s) == hipSuccess) {
+                hipLaunchKernelGGL(k_pb_band_exact, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p->col1 - p->col0 + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
+                                   dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, idx_base, p->col0, p->col1, d, d_bad);
+                hbad = 1;
+                if (hipMemcpyAsync(&hbad, d_bad, sizeof hbad, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && !hbad) {
+                    p->store_ok = true; p->store_l = d.l; p->store_u = d.u; p->store_C = d.C; p->store_shift = shift;
                 }
             }
         }

@@ -25,8 +25,8 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN,
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, INFO_LDS_DMA,
- INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE, INFO_ROLL, INFO_LAZY_DIFF, INFO_BAND_DIRECT, INFO_BAND_DESC) = range(32)
-LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF = 1, 2, 4
+ INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE, INFO_ROLL, INFO_LAZY_DIFF, INFO_BAND_DIRECT, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
+LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE = 1, 2, 4, 8
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
@@ -40,7 +40,7 @@ class LazyPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("color", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p),
                 ("color_bytes", C.c_int32), ("c_lo", C.c_int32), ("ncolors", C.c_int32), ("pts", C.c_int32),
                 ("is_complex", C.c_int32), ("imag_only", C.c_int32), ("part", C.c_int32), ("nparts", C.c_int32),
-                ("diff", C.c_int32), ("reserved0", C.c_int32)]
+                ("diff", C.c_int32), ("reserved0", C.c_int32), ("store", C.c_void_p)]
 
 
 # int f(fctx, fx, const fd_lazy_points*, fx_stride, row_begin, row_end, stream)

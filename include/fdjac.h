@@ -114,6 +114,12 @@ typedef struct fd_lazy_points {
                           /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
                           /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
     int32_t reserved0;
+    const void *store;    /* EXPERIMENTAL (FDJAC_LAZY_STORE=1), launchers registered with FD_LAZY_CAP_STORE only: non-NULL =   */
+                          /* a `fd_band_store` (include/fdjac_device.h, host memory, valid during the call): store the       */
+                          /* finished quotients into the Jacobian yourself -- out[fd_band_dest(store, r, c)] =               */
+                          /* (f(point of colour c)[r] - f(x)[r]) / eps[c]  (central: (f(+) - f(-)) / (2 eps[c])) for every   */
+                          /* row r in [row_begin, row_end) and every colour of the batch; fx / base_out are not written and  */
+                          /* no decompression follows                                                                        */
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -226,6 +232,7 @@ enum fd_plan_info_key {
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
     FD_INFO_BAND_DIRECT = 30,         /* 1 if a uniform band with cyclic colours is decompressed with computed indices (k_decompress_band) */
     FD_INFO_BAND_DESC = 31,           /* number of row-window tiles whose descriptors the kernel computes instead of loading (uniform band) */
+    FD_INFO_LAZY_STORE = 32,          /* 1 if a FD_LAZY_CAP_STORE launcher stores the Jacobian of this plan itself (experimental, FDJAC_LAZY_STORE=1) */
     FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
     FD_INFO_ROLL = 28,                /* 1 if a 2-D stencil plan uses the rolling row windows (one wave walks a column strip) */
     FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
@@ -260,6 +267,7 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* evaluate f! and decompress in row strips that reuse one cache-sized scratch            */
                                   /* (fd_lazy_points.part / nparts; DESIGN.md "row strips")                                 */
 #define FD_LAZY_CAP_DIFF 4        /* honours fd_lazy_points.diff: writes f(point) - f(x) / f(plus) - f(minus) itself         */
+#define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store (experimental; used only by plans created with FDJAC_LAZY_STORE=1) */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */

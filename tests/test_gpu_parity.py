@@ -1873,3 +1873,39 @@ def test_random_jvp_sizes_three_forms_agree(oracle, seed):
     if family != "clamp5":
         ref = oracle.jvp(fdtype, oracle.Fixture(family, *prm), x.cpu().numpy(), v.cpu().numpy())
         _tol_ok(res[0].cpu().numpy(), ref["jvp"], ref["eps"], 8.0, "jvp %s %s N=%d" % (family, fdtype, N))
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "chunked", "devplan", "none", "small_n"])
+def test_lazy_store_experimental_bit_identical(monkeypatch, fdtype, case):
+    # EXPERIMENTAL (FDJAC_LAZY_STORE=1, include/fdjac_device.h): a FD_LAZY_CAP_STORE launcher stores the finished quotients into
+    # nzval itself (exact band verified at plan time, destination of (row, colour) by arithmetic) and the library launches no
+    # decompression.  Same operations on the same operands as the default path: same bits, same f! evaluation count.
+    N = 20_001 if case == "small_n" else 150_017
+    colptr, rowval = P.tridiag_csc(N)
+    C = 4 if case == "four_colours" else 3
+    colors = ((np.arange(N) + (2 if case == "shifted" else 0)) % C + 1).astype(np.int64)
+    if case == "none":
+        colors[[7, N // 2]] = 0
+    win = {"window": (30_001, 120_000), "window_odd": (30_002, 119_999)}.get(case)
+    cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype == "central" else 1) * 2 if case == "chunked" else 0
+    x = _dev(np.random.default_rng(97).random(N))
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    outs, calls = [], []
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1" if case == "devplan" else "0")
+        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win,
+                            x_window=(max(win[0] - 3, 1), min(win[1] + 3, N)) if win else None)
+        f = fd.BuiltinF("tridiag" if case == "linear_f" else "tridiag_nl", N)
+        assert f.lazy_caps & fd.lib.LAZY_CAP_STORE
+        plan.set_lazy(f)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == (1 if (store == "1" and case != "none") else 0)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out)
+        calls.append((f.fcalls, plan.fcalls_last))
+    assert not torch.isnan(outs[0]).any()
+    bad = torch.nonzero(outs[0] != outs[1]).flatten()
+    assert bad.numel() == 0, (int(bad.numel()), bad[:8].tolist(), outs[0][bad[:8]].tolist(), outs[1][bad[:8]].tolist())
+    assert calls[0] == calls[1]
