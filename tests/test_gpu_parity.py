@@ -1740,7 +1740,7 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
 
     def run(env, diff):
         for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC", "FDJAC_BAND_DIRECT", "FDJAC_ROLL",
-                  "FDJAC_WINDOW2D", "FDJAC_STRIPS", "FDJAC_REVERSE", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_DMA"):
+                  "FDJAC_WINDOW2D", "FDJAC_STRIPS", "FDJAC_REVERSE", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_DMA", "FDJAC_LAZY_STORE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1764,6 +1764,7 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     pick("FDJAC_REVERSE", [0, 1])
     pick("FDJAC_PLAN_DEVICE", [0, 1])
     pick("FDJAC_SORTED", [0, 1])
+    pick("FDJAC_LAZY_STORE", [0, 1])
     diff = bool(rng.random() < 0.7)
     got, calls = run(env, diff)
     assert not torch.isnan(ref).any()
