@@ -219,80 +219,110 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
 // 60 + 100 us for f! + decompression -- 0.125 instead of 0.18 ms per Jacobian; scattered 8-B stores without the LDS staging:
 // 141 us; an output-centric variant (a workgroup per tile of stored entries, f! evaluated on the tile's row window, the
 // row-window kernel's gather after it): 168 us -- the fused launch is bound by its own dependent chain, not by bytes.
-template <typename CT, int MODE, bool NL>
-__global__ void __launch_bounds__(kBlock)
-k_f_tridiag_lazy_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
-                       int64_t n, int64_t r0, int64_t r1, fd_band_store bst, int cap)
+// (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
+__device__ __forceinline__ int band_colptr32(int j, int l, int u, int M)
 {
-    extern __shared__ real_t s_stage[];                        // [cap] quotients, then [cap] bytes "staged by this workgroup"
-    unsigned char *s_own = reinterpret_cast<unsigned char *>(s_stage + cap);
-    const int64_t R0 = r0 + (int64_t)blockIdx.x * (2 * kBlock);
+    const int w = l + u + 1;
+    const int nt = j < u ? j : u;
+    const int top = nt * u - nt * (nt - 1) / 2;
+    const int b0 = M - l, f0 = b0 > 0 ? b0 : 0;
+    int bot = 0;
+    if (j > f0) { const int nn = j - f0, a = f0 - b0 + 1; bot = nn * a + nn * (nn - 1) / 2; }
+    return w * j - top - bot;
+}
+// Rows are owned by workgroups (2 * kBlock each: every thread evaluates its row pair at the base and at every point of the
+// batch, differences -> LDS [colour][row], dense 16-B LDS stores); then the workgroup walks the storage positions its rows
+// occupy -- one contiguous range of nzval -- and every position finds its (column, row) by the band's arithmetic (one
+// multiply-shift in the interior, colptr's closed form in the corner workgroups), reads its difference, divides, and is
+// written with its neighbour as a dense 16-B pair; positions of that range whose row belongs to the next workgroup are
+// left to it.
+template <typename CT, int MODE, bool NL, int BS>
+__global__ void __launch_bounds__(BS)
+k_f_tridiag_lazy_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
+                       int n, int r0, int r1, real_t *__restrict__ outp, int M, int N, int eb, int cb, int ce, int l, int u, int C,
+                       int shift, int pitch, uint64_t mw, uint64_t mc)
+{
+    extern __shared__ real_t s_val[];                          // [B][pitch] differences of the workgroup's rows, then [B] divisors
+    real_t *s_ed = s_val + (size_t)B * pitch;
+    const int R0 = r0 + (int)blockIdx.x * (2 * BS);
     if (R0 >= r1) return;
-    const int64_t R1 = R0 + 2 * kBlock < r1 ? R0 + 2 * kBlock : r1;
-    // first storage position any row of this workgroup can write (row R0, its first column), rounded down to a 16-B pair
-    const int64_t jf = R0 - bst.l > 0 ? R0 - bst.l : 0;
-    const int64_t ffirst = jf - bst.u > 0 ? jf - bst.u : 0;
-    const int64_t dlo = (fd_band_colptr(&bst, jf) - bst.entry_begin + (R0 - ffirst)) & ~(int64_t)1;
-    for (int k = threadIdx.x; k < cap; k += kBlock) s_own[k] = 0;
-    __syncthreads();
-    const int64_t i = R0 + 2 * (int64_t)threadIdx.x;
+    const int R1 = R0 + 2 * BS < r1 ? R0 + 2 * BS : r1;
+    const int w = l + u + 1, top_full = u * (u + 1) / 2;
+    if ((int)threadIdx.x < B) {
+        const real_t e = eps[c_lo + threadIdx.x];
+        s_ed[threadIdx.x] = MODE == 1 ? 2 * e : e;
+    }
+    // ---- phase A
+    const int i = R0 + 2 * (int)threadIdx.x;
     if (i < R1) {
         real_t xv[4];
         int cv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t j = i - 1 + k;
+            const int j = i - 1 + k;
             const bool in = (j >= 0) & (j < n);
             xv[k] = in ? x[in ? j : 0] : 0.0;
             const int c = in ? (int)color[in ? j : 0] : -1;
             cv[k] = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
         }
-        const bool two = i + 1 < n && i + 1 < R1;
         real_t b0 = 0.0, b1 = 0.0;
         if (MODE == 0) {
             b0 = tridiag_row<real_t, NL>(xv[0], xv[1], xv[2]);
-            if (two) b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
+            b1 = tridiag_row<real_t, NL>(xv[1], xv[2], xv[3]);
         }
-        // fd_band_dest(row, colour) with the per-row part hoisted: m = colour of the first column that can touch the row
-        // (ONE modulo per thread; row i+1's is m + 1), then per colour t = c - m (mod C) selects the column j0 + t
-        const int Cc = bst.C, wl = bst.l + bst.u;
-        const int m0 = (int)((uint32_t)(i - bst.l + bst.shift + 64 * (int64_t)Cc) % (uint32_t)Cc);     // (l <= 64)
-        const int m1 = m0 + 1 == Cc ? 0 : m0 + 1;
-        auto dest_of = [&](int64_t r, int m, int c) -> long long {
-            int t = c - m;
-            t += t < 0 ? Cc : 0;
-            const int64_t j = r - bst.l + t;
-            if (t > wl || j < bst.col_begin || j >= bst.col_end || j < 0 || j >= bst.N) return -1;
-            const int64_t first = j - bst.u > 0 ? j - bst.u : 0;
-            return fd_band_colptr(&bst, j) - bst.entry_begin + (r - first);
-        };
         for (int b = 0; b < B; ++b) {
             const real_t e = eps[c_lo + b];
             real_t p[4], q[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const real_t d = (cv[k] == b) ? e : 0.0; p[k] = xv[k] + d; q[k] = xv[k] - d; }
-            const real_t ed = MODE == 1 ? 2 * e : e;
             const real_t s0 = MODE == 1 ? tridiag_row<real_t, NL>(q[0], q[1], q[2]) : b0;
-            const real_t v0 = sub_exact(tridiag_row<real_t, NL>(p[0], p[1], p[2]), s0);
-            const long long d0 = dest_of(i, m0, c_lo + b);
-            if (d0 >= 0) { s_stage[d0 - dlo] = v0 / ed; s_own[d0 - dlo] = 1; }
-            if (two) {
-                const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
-                const real_t v1 = sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1);
-                const long long d1 = dest_of(i + 1, m1, c_lo + b);
-                if (d1 >= 0) { s_stage[d1 - dlo] = v1 / ed; s_own[d1 - dlo] = 1; }
-            }
+            const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
+            *reinterpret_cast<r2_t *>(s_val + b * pitch + 2 * (int)threadIdx.x) =
+                r2_t{sub_exact(tridiag_row<real_t, NL>(p[0], p[1], p[2]), s0), sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1)};
         }
     }
     __syncthreads();
-    real_t *outp = (real_t *)bst.out;
+    // ---- phase B: the storage positions of rows [R0, R1) (local to the column range [cb, ce))
+    const int jlo = R0 - l > cb ? R0 - l : cb, jhi = R1 - 1 + u < ce - 1 ? R1 - 1 + u : ce - 1;     // columns that touch those rows
+    if (jhi < jlo) return;
+    const int plo = (band_colptr32(jlo, l, u, M) - eb) & ~1, phi = band_colptr32(jhi + 1, l, u, M) - eb;   // [plo, phi)
+    const bool interior = jlo >= u && jhi + l <= M - 1;        // no column cut off by the matrix edge
     const bool vec = ((((uintptr_t)outp) & kPairMask) == 0);
-    for (int k = 2 * threadIdx.x; k < cap; k += 2 * kBlock) {
-        const bool o0 = s_own[k] != 0, o1 = k + 1 < cap && s_own[k + 1] != 0;
-        if (o0 & o1 & vec) *reinterpret_cast<r2_t *>(outp + dlo + k) = r2_t{s_stage[k], s_stage[k + 1]};
+    auto column_of = [&](int g) -> int {
+        int j = (int)fd_div31((uint32_t)(g + top_full), mw);
+        if (j >= N) j = N - 1;
+        while (j > 0 && band_colptr32(j, l, u, M) > g) --j;
+        while (j + 1 < N && band_colptr32(j + 1, l, u, M) <= g) ++j;
+        return j;
+    };
+    for (int pp = plo + 2 * (int)threadIdx.x; pp < phi; pp += 2 * BS) {
+        real_t qv[2];
+        bool wr[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = pp + h + eb;
+            int j, row;
+            if (interior) {
+                const uint32_t Q = (uint32_t)(g + top_full);
+                const uint32_t jq = fd_div31(Q, mw);
+                j = (int)jq;
+                row = j - u + (int)(Q - jq * (uint32_t)w);
+            } else {
+                const int gg = g < phi + eb ? g : phi + eb - 1;
+                j = column_of(gg);
+                row = (j - u > 0 ? j - u : 0) + (gg - band_colptr32(j, l, u, M));
+            }
+            const uint32_t cj = (uint32_t)(j + shift);
+            const int b = (int)(cj - fd_div31(cj, mc) * (uint32_t)C) - c_lo;
+            const bool live = pp + h >= 0 && pp + h < phi && row >= R0 && row < R1 && b >= 0 && b < B && j >= cb && j < ce;
+            const int at = live ? b * pitch + (row - R0) : 0;
+            qv[h] = s_val[at] / s_ed[live ? b : 0];
+            wr[h] = live;
+        }
+        if (wr[0] & wr[1] & vec) *reinterpret_cast<r2_t *>(outp + pp) = r2_t{qv[0], qv[1]};
         else {
-            if (o0) outp[dlo + k] = s_stage[k];
-            if (o1) outp[dlo + k + 1] = s_stage[k + 1];
+            if (wr[0]) outp[pp] = qv[0];
+            if (wr[1]) outp[pp + 1] = qv[1];
         }
     }
 }
@@ -644,16 +674,21 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
                        lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0, lp->store != nullptr ? 1 : 0, bst)
     fd_band_store bst = {};
     if (lp->store) {
-        // (experimental) one-shot launch, one workgroup per 2 * kBlock rows, LDS staging of the quotients
+        // (experimental) one-shot launch, one workgroup per 2 * kBlock rows
         bst = *(const fd_band_store *)lp->store;
         const int wband = bst.l + bst.u + 1;
-        const int cap = (wband * (2 * kBlock + wband) + 4 + 1) & ~1;     // positions of 2 * kBlock rows: (rows + l + u) columns x w
-        const size_t shm = sizeof(real_t) * (size_t)cap + (size_t)cap;
-        if (shm > (size_t)60 * 1024) return FD_LAZY_DECLINED;
-        const unsigned gs = (unsigned)((r1 - r0e + 2 * kBlock - 1) / (2 * kBlock));
+        const int bs = kBlock;      // (one-wave workgroups, BS = 64, measured slower: 111-119 vs 105 us at N = 10^7)
+        const int pitch = 2 * bs + 2;
+        const size_t shm = sizeof(real_t) * ((size_t)lp->ncolors * (size_t)pitch + (size_t)lp->ncolors + 2);
+        const int64_t nnz_all = fd_band_colptr(&bst, bst.N);
+        if (shm > (size_t)60 * 1024 || nnz_all + (int64_t)wband * wband + 64 >= ((int64_t)1 << 31) || bst.N + bst.C + 64 >= ((int64_t)1 << 31) ||
+            bst.M + wband + 64 >= ((int64_t)1 << 31) || lp->ncolors > kBlock) return FD_LAZY_DECLINED;
+        const unsigned gs = (unsigned)((r1 - r0e + 2 * bs - 1) / (2 * bs));
 #define FD_LAZY_ST(MODE, NL)                                                                                       \
-        hipLaunchKernelGGL((k_f_tridiag_lazy_store<CT, MODE, NL>), dim3(gs), dim3(kBlock), shm, s, (const real_t *)lp->x, \
-                           (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, b->prm[0], r0e, r1, bst, cap)
+        hipLaunchKernelGGL((k_f_tridiag_lazy_store<CT, MODE, NL, kBlock>), dim3(gs), dim3(kBlock), shm, s, (const real_t *)lp->x, \
+                           (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, (int)b->prm[0], (int)r0e, (int)r1, \
+                           (real_t *)bst.out, (int)bst.M, (int)bst.N, (int)bst.entry_begin, (int)bst.col_begin, (int)bst.col_end,     \
+                           bst.l, bst.u, bst.C, bst.shift, pitch, fd_magic31((uint32_t)wband), fd_magic31((uint32_t)bst.C))
         if (mode == 0) { if (nl) FD_LAZY_ST(0, true); else FD_LAZY_ST(0, false); }
         else { if (nl) FD_LAZY_ST(1, true); else FD_LAZY_ST(1, false); }
 #undef FD_LAZY_ST
