@@ -212,13 +212,12 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
 
 // EXPERIMENTAL (fd_lazy_points.store, include/fdjac_device.h): the tridiagonal fixture evaluated at the lazily perturbed points
 // of a batch, difference quotients formed and stored into the banded CSC Jacobian by this launch -- nothing follows it.
-// One workgroup owns 2 * kBlock consecutive rows; the storage positions of their entries form one contiguous range of nzval
-// (up to a few positions at either end that belong to the neighbours' rows), so the quotients are staged in LDS at
-// (position - first position) and written out as dense 16-B pairs.  Operations per entry: those of the plain path
-// (sub_exact, IEEE division).  Measured at N = 10^7 (profiles/r02_g_store_ab.txt): 104-110 us for this launch against
-// 60 + 100 us for f! + decompression -- 0.125 instead of 0.18 ms per Jacobian; scattered 8-B stores without the LDS staging:
-// 141 us; an output-centric variant (a workgroup per tile of stored entries, f! evaluated on the tile's row window, the
-// row-window kernel's gather after it): 168 us -- the fused launch is bound by its own dependent chain, not by bytes.
+// Operations per entry: those of the plain path (sub_exact, IEEE division).  Measured at N = 10^7
+// (profiles/r02_g_store_ab.txt): 104-105 us for this launch against 60 + 100 us for f! + decompression -- 0.12 instead of
+// 0.18 ms per Jacobian.  Variants: 8-B stores straight from registers 141 us; quotients staged in LDS by storage position
+// (8-way bank conflicts) 104-110 us; output-centric (a workgroup per tile of stored entries, f! on the tile's row window,
+// the row-window gather after it) 168 us; one-wave workgroups 111-119 us -- the fused launch is bound by its own dependent
+// chain, not by bytes.
 // (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
 __device__ __forceinline__ int band_colptr32(int j, int l, int u, int M)
 {
