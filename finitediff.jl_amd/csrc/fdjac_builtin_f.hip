@@ -326,6 +326,55 @@ k_f_tridiag_lazy_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     }
 }
 
+// The same capability, column-centric (the form the launcher uses for an exactly tridiagonal band, l = u = 1): one thread per
+// COLUMN j evaluates the fixture on the column's three rows at x and at x +- eps_c e_j and stores the column's three
+// quotients -- contiguous in nzval, so consecutive lanes write consecutive 24-B groups: no LDS, no barrier, no position
+// arithmetic.  The points differ from the colour's point x +- eps_c * mask_c only in columns of colour c that do not touch
+// these rows (the plan verified C >= 3 cyclic colours on the exact band), so every operand -- including the "+ 0.0" of the
+// unperturbed coordinates -- and every operation is that of the coloured evaluation: same bits.  1.5 x the row evaluations
+// of the row-centric form (each row is evaluated for its three columns), none of its staging.
+template <typename CT, int MODE, bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_lazy_store_col(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
+                           int n, real_t *__restrict__ outp, int M, int eb, int cb, int ce, int reversed)
+{
+    const int ncol = ce - cb;
+    int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (t >= ncol) return;
+    const int j = reversed ? ce - 1 - t : cb + t;
+    const int c = (int)color[j];
+    const int b = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+    if (b < 0 || b >= B) return;                               // another batch's colour
+    const real_t e = eps[c_lo + b];
+    real_t xv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = j - 2 + k;
+        const bool in = (i >= 0) & (i < n);
+        xv[k] = in ? x[in ? i : 0] : 0.0;
+    }
+    // the colour's point around column j: x_j +- eps, every other coordinate x + 0.0 / x - 0.0 (as the coloured launch forms it)
+    real_t p[5], q[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const real_t d = k == 2 ? e : (real_t)0; p[k] = xv[k] + d; q[k] = xv[k] - d; }
+    const real_t ed = MODE == 1 ? 2 * e : e;
+    // first stored row of column j: max(0, j-1); position of (row j-1+k, column j): colptr(j) + (row - first)
+    const int first = j > 0 ? j - 1 : 0;
+    const int nt = j < 1 ? j : 1;                               // band_colptr32 with l = u = 1
+    const int b0m = M - 1, f0 = b0m > 0 ? b0m : 0;
+    int bot = 0;
+    if (j > f0) { const int nn = j - f0, a = f0 - b0m + 1; bot = nn * a + nn * (nn - 1) / 2; }
+    const int pos0 = 3 * j - nt - bot - eb;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int r = j - 1 + k;
+        if (r < 0 || r >= M) continue;
+        const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
+        const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(q[k], q[k + 1], q[k + 2]) : tridiag_row<real_t, NL>(xv[k], xv[k + 1], xv[k + 2]);
+        outp[pos0 + (r - first)] = sub_exact(plus, sub) / ed;
+    }
+}
+
 // 5-point stencils on an nx (fast) x ny grid.  CLAMP = false: zero-Dirichlet Laplacian
 // w + e + s + n - 4x ; CLAMP = true: the reference's clamped-edge sum x + x[i-1] + x[i+1] + x[j-1] + x[j+1].
 // (SK: 0 = Laplacian, 1 = clamped sum, 2 = Laplacian + x[k]^2 * x[k+1]: a nonlinear variant whose J depends on x.)
@@ -682,6 +731,22 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
         const int64_t nnz_all = fd_band_colptr(&bst, bst.N);
         if (shm > (size_t)60 * 1024 || nnz_all + (int64_t)wband * wband + 64 >= ((int64_t)1 << 31) || bst.N + bst.C + 64 >= ((int64_t)1 << 31) ||
             bst.M + wband + 64 >= ((int64_t)1 << 31) || lp->ncolors > kBlock) return FD_LAZY_DECLINED;
+        // column-centric for small problems (N = 10^6: 14 vs 18 us), row-owned with LDS staging for large ones (N = 10^7: 102-105
+        // vs 112-114 us: three 8-B stores per lane need the L2 to merge them); FDJAC_STORE_COLUMNS=0/1 forces one
+        const char *fsc = getenv("FDJAC_STORE_COLUMNS");
+        const bool by_columns = (fsc && *fsc) ? atoi(fsc) != 0 : (bst.col_end - bst.col_begin) <= ((int64_t)1 << 21);
+        if (bst.l == 1 && bst.u == 1 && bst.M == bst.N && by_columns) {
+            const int ncol = (int)(bst.col_end - bst.col_begin);
+            const unsigned gc = (unsigned)((ncol + kBlock - 1) / kBlock);
+#define FD_LAZY_SC(MODE, NL)                                                                                       \
+            hipLaunchKernelGGL((k_f_tridiag_lazy_store_col<CT, MODE, NL>), dim3(gc), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                               (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, (int)b->prm[0], (real_t *)bst.out, \
+                               (int)bst.M, (int)bst.entry_begin, (int)bst.col_begin, (int)bst.col_end, 1)
+            if (mode == 0) { if (nl) FD_LAZY_SC(0, true); else FD_LAZY_SC(0, false); }
+            else { if (nl) FD_LAZY_SC(1, true); else FD_LAZY_SC(1, false); }
+#undef FD_LAZY_SC
+            return hipGetLastError() == hipSuccess ? 0 : 4;
+        }
         const unsigned gs = (unsigned)((r1 - r0e + 2 * bs - 1) / (2 * bs));
 #define FD_LAZY_ST(MODE, NL)                                                                                       \
         hipLaunchKernelGGL((k_f_tridiag_lazy_store<CT, MODE, NL, kBlock>), dim3(gs), dim3(kBlock), shm, s, (const real_t *)lp->x, \

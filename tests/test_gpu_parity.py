@@ -1877,11 +1877,16 @@ def test_random_jvp_sizes_three_forms_agree(oracle, seed):
 
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
-@pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "chunked", "devplan", "none", "small_n"])
+@pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "chunked", "devplan", "none", "small_n",
+                                  "rows_plain", "rows_window_odd", "rows_chunked", "rows_four_colours"])
 def test_lazy_store_experimental_bit_identical(monkeypatch, fdtype, case):
     # EXPERIMENTAL (FDJAC_LAZY_STORE=1, include/fdjac_device.h): a FD_LAZY_CAP_STORE launcher stores the finished quotients into
     # nzval itself (exact band verified at plan time, destination of (row, colour) by arithmetic) and the library launches no
     # decompression.  Same operations on the same operands as the default path: same bits, same f! evaluation count.
+    # (two kernels behind the capability: one thread per column -- the default at these sizes -- and, "rows_*", workgroup-owned
+    #  rows with LDS staging, the default from 2^21 columns)
+    monkeypatch.setenv("FDJAC_STORE_COLUMNS", "0" if case.startswith("rows_") else "1")
+    case = case[5:] if case.startswith("rows_") else case
     N = 20_001 if case == "small_n" else 150_017
     colptr, rowval = P.tridiag_csc(N)
     C = 4 if case == "four_colours" else 3
