@@ -249,13 +249,23 @@ __device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_
 {
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
     constexpr int kRounds = Src::kUnitRhs ? 4 : 3 + NRHS;
+    // every array's global loads are issued before the first transposition: the memory latency is paid once, not once per
+    // round (the barriers below would otherwise keep round w+1's loads behind round w's LDS traffic)
+    double g[kRounds][kChunk];
+#pragma unroll
+    for (int which = 0; which < kRounds; ++which)
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int r = j * kBlock + (int)threadIdx.x;  // lane-consecutive rows
+            g[which][j] = r < rows ? src.value(which, row0 + r) : 0.0;
+        }
 #pragma unroll
     for (int which = 0; which < kRounds; ++which) {
         if (which) __syncthreads();                       // the previous array has been copied out
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
-            const int r = j * kBlock + (int)threadIdx.x;  // lane-consecutive rows
-            if (r < rows) lds[r + (r >> 3)] = src.value(which, row0 + r);
+            const int r = j * kBlock + (int)threadIdx.x;
+            if (r < rows) lds[r + (r >> 3)] = g[which][j];
         }
         __syncthreads();
         double *dst = which == 0 ? R.a : which == 1 ? R.b : which == 2 ? R.c : R.d[which - 3 < NRHS ? which - 3 : 0];
