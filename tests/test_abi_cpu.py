@@ -151,3 +151,47 @@ def test_c_clients_build_and_fail_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is present: the run itself is a -m gpu test")
     out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 7 and "no HIP device" in out.stderr      # FD_ERR_NODEVICE
+
+
+def test_device_header_band_arithmetic_matches_a_brute_force_csc(tmp_path):
+    # include/fdjac_device.h (plain C, also compiled for the host): fd_band_colptr / fd_band_dest against the band's CSC built
+    # by enumeration, for random shapes (rectangular, asymmetric bandwidths), cyclic colourings with C >= w and column ranges
+    import subprocess
+    src = tmp_path / "band.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "fdjac_device.h"
+int main(void) {
+    unsigned s = 12345u;
+    #define RND(n) ((int)((s = s * 1664525u + 1013904223u) >> 8) % (n))
+    for (int it = 0; it < 3000; ++it) {
+        fd_band_store d = {0};
+        d.l = RND(5); d.u = RND(5);
+        const int w = d.l + d.u + 1;
+        d.N = 1 + RND(60);
+        d.M = d.N + RND(9) - 4; if (d.M < 1) d.M = 1;
+        d.C = w + RND(3); d.shift = RND(d.C);
+        /* every column must hold at least one row of the band */
+        int ok = 1;
+        for (long long j = 0; j < d.N; ++j) { long long f = j - d.u > 0 ? j - d.u : 0, l = j + d.l < d.M - 1 ? j + d.l : d.M - 1; if (l < f) ok = 0; }
+        if (!ok) continue;
+        long long cp[64], nn = 0;
+        for (long long j = 0; j < d.N; ++j) { cp[j] = nn; long long f = j - d.u > 0 ? j - d.u : 0, l = j + d.l < d.M - 1 ? j + d.l : d.M - 1; nn += l - f + 1; }
+        cp[d.N] = nn;
+        for (long long j = 0; j <= d.N; ++j) if (fd_band_colptr(&d, j) != cp[j]) { printf("colptr %d\n", it); return 1; }
+        d.col_begin = RND((int)d.N); d.col_end = d.col_begin + 1 + RND((int)(d.N - d.col_begin)); d.entry_begin = cp[d.col_begin];
+        for (long long r = 0; r < d.M; ++r)
+            for (int c = 0; c < d.C; ++c) {
+                long long want = -1;
+                for (long long j = r - d.l > 0 ? r - d.l : 0; j <= r + d.u && j < d.N; ++j)
+                    if ((j + d.shift) % d.C == c && j >= d.col_begin && j < d.col_end) { long long f = j - d.u > 0 ? j - d.u : 0; want = cp[j] - d.entry_begin + (r - f); }
+                if (fd_band_dest(&d, r, c) != want) { printf("dest it=%d r=%lld c=%d\n", it, r, c); return 2; }
+            }
+    }
+    return 0;
+}
+''')
+    exe = str(tmp_path / "band")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    assert subprocess.run([exe], capture_output=True, text=True).returncode == 0
