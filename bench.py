@@ -4,9 +4,12 @@
 Workload (BASELINE.json `metric`, config "N=10^7 tridiagonal"): forward-difference Jacobian of the
 second-difference f! (test/coloring_tests.jl:5-13) at N = 10^7 states, SparseMatrixCSC pattern
 (3N-2 stored values), colorvec[i] = mod1(i,3), x ~ U(0,1) (numpy PCG64 seed 4).  A "step" is one
-complete `finite_difference_jacobian!`: step-size reduction, perturbation, 1 + 3 f! evaluations,
-fused difference + decompression into nzval; plan (pattern, colours) reused, x / nzval resident in
-HBM.
+complete `finite_difference_jacobian!`: step-size reduction, 1 + 3 f! evaluations at the lazily perturbed
+points, difference, division and decompression into nzval -- since round 3 the last three run as ONE launch
+(f!'s launch stores the Jacobian itself: include/fdjac_device.h, k_f_tridiag_store_wave); plan (pattern,
+colours) reused, x / nzval resident in HBM.  `value` comes from EXACTLY --steps calls bracketed by
+barrier + synchronize; `median_ms_per_step` / `value_median` from >= 20 individually timed calls (HIP events
+on the launch stream); --sweep DIR additionally writes the c2 / c3 / c5 lines into DIR.
 
 With --gpus P the SAME problem is split into P contiguous column ranges (strong scaling), one process per GPU.
 Every rank fills its contiguous slice of nzval; the timed step ends there, with nzval device-resident and sharded by
@@ -69,8 +72,11 @@ def parse():
     ap.add_argument("--soak-seconds", type=float, default=5.5,
                     help="untimed steady-state loop AFTER the measurement so that an external utilisation sampler sees "
                          "the GPU busy (the timed region itself lasts a few milliseconds); 0 = off")
-    ap.add_argument("--no-plain-handover", action="store_true",
-                    help="skip the untimed side measurement of the plain f! hand-over (profiling runs: keeps the kernel's PMC averages clean)")
+    ap.add_argument("--no-plain-handover", "--no-side-runs", dest="no_plain_handover", action="store_true",
+                    help="skip the untimed side measurement of the hand-over path (profiling runs: keeps the kernels' PMC averages clean)")
+    ap.add_argument("--sweep", default="", metavar="DIR",
+                    help="after the headline line, run the other BASELINE configs (c2, c3, c5; plus c4 in Float32) as child "
+                         "processes and write their JSON lines to DIR/bench_<config>.json (single GPU)")
     return ap.parse_args()
 
 
@@ -279,7 +285,14 @@ def main():
     # FD_LAZY_CAP_DIFF: the lazy launcher hands over f(x+d) - f(x) / f(x+d) - f(x-d) (the subtraction of
     # src/jacobians.jl:565,607 moves into f!'s launch): C arrays instead of C+1 / 2C, no f(x) pass -- the byte models follow
     lazy_diff = int(plan.info(fd.lib.INFO_LAZY_DIFF)) if f_mode == "lazy" else 0
-    if lazy_diff and cfg in ("c2", "c4"):
+    # FD_LAZY_CAP_STORE (the default for a verified exact band since round 3): f!'s launch also divides and stores -- the graded
+    # "diff + scatter" kernel is that launch; it reads x once and writes every stored value once
+    lazy_store = int(plan.info(fd.lib.INFO_LAZY_STORE)) if f_mode == "lazy" else 0
+    if lazy_store and cfg in ("c2", "c4"):
+        bytes_min = vs + 3 * vs                                 # 32 (f64): x in, nzval out
+        bytes_call_model = (vs + (0 if cyc else 1)) + bytes_min
+        kern = "k_f_tridiag_store_wave<0, false>"
+    elif lazy_diff and cfg in ("c2", "c4"):
         bytes_min = C * vs + 3 * vs + 3 * idx_b                 # 48 (f64, periodic codes)
         bytes_call_model = (vs + (0 if cyc else 1)) + (vs + 1 + C * vs) + bytes_min
     elif lazy_diff and cfg == "c3":
@@ -343,75 +356,48 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tm = plan.timings()
+    dec_samples = plan.timing_samples("decompress")          # the graded kernel, one HIP-event span per timed step
     timed_result = out.clone()
-    # per-stage breakdown from a separate, untimed pass (more events => more marker packets on the stream)
+    # per-stage breakdown and the MEDIAN of individually timed calls from a separate, untimed pass (every stage and the
+    # whole call bracketed by HIP events on the launch stream: more marker packets than the timed region carries)
     plan.enable_timing(2)
-    for _ in range(min(args.steps, 10)):
+    for _ in range(max(args.steps, 20)):
         enqueue()
     torch.cuda.synchronize()
     tm_all = plan.timings()
+    call_samples = plan.timing_samples("total")
     plan.enable_timing(0)
-    # ---- side measurement (single GPU, untimed): the same call with the PLAIN hand-over of the f! values (the launcher's
-    # FD_LAZY_CAP_DIFF withheld) -- the graded kernel then also forms the differences, as in round 1; must give the same bits
-    plain = None
-    if world == 1 and lazy_diff and args.dtype == "f64" and not args.no_plain_handover:
+    # ---- side measurement (single GPU, untimed): the same Jacobian through round 2's default, the HAND-OVER path
+    # (FDJAC_LAZY_STORE=0: f! writes differences, a second launch divides and decompresses) -- must give the same bits
+    handover = None
+    if world == 1 and lazy_store and cfg in ("c2", "c4") and not args.no_plain_handover:
         try:
-            plan.set_lazy(f, diff=False)
-            for _ in range(3):
-                enqueue()
-            torch.cuda.synchronize()
-            plan.enable_timing(1)
-            for _ in range(min(args.steps, 10)):
-                enqueue()
-            torch.cuda.synchronize()
-            tp = plan.timings()["decompress"]
-            plan.enable_timing(0)
-            same = bool(torch.equal(out, timed_result))
-            ms_p = tp["ms_sum"] / max(tp["launches"], 1)
-            traffic_p, src_p = None, "model: bytes this kernel must move"
-            pp = os.path.join(ROOT, "profiles", "pmc_%s_plain.json" % cfg)
-            if os.path.exists(pp):
-                j = json.load(open(pp))
-                if int(j.get("n", -1)) == N and j.get("kernel", "") in kern:
-                    traffic_p, src_p = j.get("decompress_hbm_bytes_per_launch"), "rocprofv3 PMC passes (profiles/pmc_%s_plain.json)" % cfg
-            plain = {"avg_launch_ms": ms_p, "traffic": traffic_p, "traffic_source": src_p, "bit_identical_to_timed_result": same}
-            if traffic_p and ms_p > 0:
-                plain["achieved"] = traffic_p / (ms_p * 1e-3) / 1e9
-                plain["frac"] = plain["achieved"] / HBM_PEAK_GBPS
-        except Exception as e:
-            plain = {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            plan.set_lazy(f)
-    # ---- side measurement (single GPU, untimed, EXPERIMENTAL): the same Jacobian with FDJAC_LAZY_STORE=1 -- f!'s launch stores
-    # the finished quotients into nzval itself (include/fdjac_device.h), no decompression launch; must give the same bits
-    fused = None
-    if world == 1 and cfg in ("c2", "c4") and f_mode == "lazy" and not args.no_plain_handover:
-        try:
-            os.environ["FDJAC_LAZY_STORE"] = "1"
+            os.environ["FDJAC_LAZY_STORE"] = "0"
             cp_s, rv_s = P.tridiag_csc(N)              # (the pattern arrays of the timed plan were released after its creation)
             pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
             plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
             del cp_s, rv_s, pat_s
             plan_s.set_lazy(f)
-            if plan_s.info(fd.lib.INFO_LAZY_STORE) == 1:
-                out_s = torch.full_like(out, float("nan"))
-                enq_s = plan_s.bind(f, x, [out_s])
-                for _ in range(3):
-                    enq_s()
-                torch.cuda.synchronize()
-                reps_s = min(args.steps, 10)
-                ts = time.perf_counter()
-                for _ in range(reps_s):
-                    enq_s()
-                torch.cuda.synchronize()
-                ms_s = (time.perf_counter() - ts) / reps_s * 1e3
-                fused = {"ms_per_step": ms_s, "value": N / (ms_s * 1e-3), "bit_identical_to_timed_result": bool(torch.equal(out_s, timed_result)),
-                         "what": "FDJAC_LAZY_STORE=1 (experimental, opt-in): eps pass + ONE launch that evaluates f!, forms the quotients and "
-                                 "stores them into nzval; not the default, not the graded path"}
-                del out_s
-            del plan_s
+            out_s = torch.full_like(out, float("nan"))
+            enq_s = plan_s.bind(f, x, [out_s])
+            for _ in range(3):
+                enq_s()
+            torch.cuda.synchronize()
+            plan_s.enable_timing(2)
+            for _ in range(max(args.steps, 20)):
+                enq_s()
+            torch.cuda.synchronize()
+            ts_all = plan_s.timings()
+            tot_s = plan_s.timing_samples("total")
+            plan_s.enable_timing(0)
+            handover = {"what": "FDJAC_LAZY_STORE=0: eps pass + lazy f! handing over differences + row-window division/decompression "
+                                "(round 2's default; k_decompress_window)",
+                        "median_ms_per_step": float(np.median(tot_s)) if tot_s else None,
+                        "stages_ms": {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in ts_all.items()},
+                        "bit_identical_to_timed_result": bool(torch.equal(out_s, timed_result))}
+            del out_s, plan_s, enq_s
         except Exception as e:
-            fused = {"error": "%s: %s" % (type(e).__name__, e)}
+            handover = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             os.environ.pop("FDJAC_LAZY_STORE", None)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -528,6 +514,8 @@ def main():
         n_local = c1 - c0
         dec = tm["decompress"]
         dec_ms = dec["ms_sum"] / max(dec["launches"], 1)
+        dec_med = float(np.median(dec_samples)) if dec_samples else dec_ms
+        call_med = float(np.median(call_samples)) if call_samples else None
         tot_ms = tm_all["total"]["ms_sum"] / max(tm_all["total"]["launches"], 1)
         pmc, pmc_src = None, None
         # HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes of this same command
@@ -537,13 +525,15 @@ def main():
             try:
                 j = json.load(open(pmc_path))
                 if (int(j.get("n", -1)) == N and int(j.get("gpus", 1)) == world and j.get("kernel", "") in kern
-                        and args.dtype == "f64" and int(j.get("lazy_diff", 0)) == lazy_diff):
+                        and args.dtype == "f64" and int(j.get("lazy_diff", 0)) == lazy_diff
+                        and int(j.get("lazy_store", 0)) == lazy_store):
                     pmc = j.get("decompress_hbm_bytes_per_launch")
-                    pmc_src = "rocprofv3 PMC passes of this command (profiles/pmc_%s.json: FETCH_SIZE x2 + WRITE_SIZE, calibrated on the stream copy)" % cfg
+                    pmc_src = ("builder PMC (committed): rocprofv3 --pmc passes of this command, profiles/pmc_%s.json "
+                               "(FETCH_SIZE x2 + WRITE_SIZE, calibrated on the 1 GiB stream copy of the same run); not measured in this process" % cfg)
             except Exception:
                 pmc = None
         traffic = pmc if pmc else bytes_min * n_local
-        traffic_src = pmc_src if pmc else "model: bytes this kernel must move (no committed PMC pass matches this run)"
+        traffic_src = pmc_src if pmc else "floor: the bytes this kernel must move (no committed PMC pass matches this run)"
         achieved = traffic / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         survey_gbps = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         res = {
@@ -564,7 +554,9 @@ def main():
                        "output": ("nzval in HBM" if world == 1 else
                                   "nzval assembled on rank 0 inside the step" if gather_in_step else
                                   "nzval device-resident, sharded by column range (rank r holds its contiguous slice)"),
-                       "f_mode": ("built-in device f! behind fd_f_launch_lazy with FD_LAZY_CAP_DIFF (1 launch: lazily perturbed points, "
+                       "f_mode": ("built-in device f! behind fd_f_launch_lazy with FD_LAZY_CAP_STORE (1 launch: lazily perturbed points, "
+                                  "difference quotients stored into nzval by the same launch)" if (f_mode == "lazy" and lazy_store) else
+                                  "built-in device f! behind fd_f_launch_lazy with FD_LAZY_CAP_DIFF (1 launch: lazily perturbed points, "
                                   "written as differences from f(x) / from the minus point)" if (f_mode == "lazy" and lazy_diff) else
                                   "built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
                                   if f_mode == "lazy" else
@@ -572,13 +564,21 @@ def main():
                        "eps_reduction": diag["eps"], "gather_in_step": bool(gather_in_step),
                        "collective_backend": (("rccl via libfdjac fd_comm_* (%s)" % comm.info()["library"]) if comm is not None
                                               else backend) if world > 1 else None},
+            "median_ms_per_step": call_med,
+            "value_median": (N / (call_med * 1e-3)) if call_med else None,
+            "median_note": "median GPU time of %d individually timed calls (HIP events on the launch stream around the whole call, "
+                           "separate pass); `value` / `ms_per_step` are the contract's K bracketed steps" % len(call_samples),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": traffic_src,
-                "kernel": kern + (" (division + decompression of the differences handed over by the lazy f! launcher)" if lazy_diff
-                                  else " (fused difference + decompression)"),
-                "lazy_diff": lazy_diff,
-                "avg_launch_ms": dec_ms, "launches_timed": dec["launches"],
+                "kernel": kern,
+                "kernel_role": ("f! at the lazily perturbed points + difference + division + store into nzval in ONE launch "
+                                "(fd_lazy_points.store, include/fdjac_device.h): src/jacobians.jl:563-568 for all colours" if lazy_store else
+                                "division + decompression of the differences handed over by the lazy f! launcher" if lazy_diff
+                                else "fused difference + decompression"),
+                "lazy_diff": lazy_diff, "lazy_store": lazy_store,
+                "avg_launch_ms": dec_ms, "median_launch_ms": dec_med, "launches_timed": dec["launches"],
+                "achieved_on_median": (traffic / (dec_med * 1e-3) / 1e9) if dec_med > 0 else None,
                 "hbm_bytes_per_launch_used": traffic,
                 "min_traffic_bytes_per_launch": bytes_min * n_local,
                 "algorithmic_bytes_per_launch": bytes_ds * n_local,
@@ -587,16 +587,15 @@ def main():
                     "note": "SURVEY 8(d) algorithmic bytes / kernel time: counts index reads and per-colour re-reads of f(x) "
                             "this kernel does not perform -- an equivalent-work rate, NOT a bandwidth (it can exceed the peak)"},
             },
-            "roofline_plain_handover": plain,
-            "fused_store_experimental": fused,
+            "handover_path": handover,
             "stages_ms": stages,
             "whole_call": {"gpu_ms": tot_ms, "hbm_bytes_model": bytes_call_model * n_local,
                            "gbps": bytes_call_model * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,
                            "frac_of_peak": bytes_call_model * n_local / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_ms > 0 else 0.0,
                            "survey_bytes": bytes_call_survey * n_local,
-                           "note": "hbm_bytes_model = bytes the stages of this implementation move (eps: x; lazy f!: x, colours, "
-                                   "C+1 outputs; decompression: f! outputs + values); survey_bytes = SURVEY 8(d)'s 210 B/column "
-                                   "of the reference's pass structure, kept for comparison only"},
+                           "note": "hbm_bytes_model = bytes the stages of this implementation move (eps: x; then either the storing f! "
+                                   "launch: x in, values out -- or lazy f!: x, colours, C outputs + decompression: f! outputs + values); "
+                                   "survey_bytes = SURVEY 8(d)'s 210 B/column of the reference's pass structure, kept for comparison only"},
             "plan_build_ms": plan_build_ms,
             "gather": gather_info,
             "comm_error": comm_error,
@@ -622,6 +621,20 @@ def main():
         else:
             sys.stdout.write(line)
             sys.stdout.flush()
+        if args.sweep and world == 1:
+            # the other BASELINE configs as child processes (own plans / buffers), one JSON line per file
+            import subprocess
+            os.makedirs(args.sweep, exist_ok=True)
+            with open(os.path.join(args.sweep, "bench_%s%s.json" % (cfg, "_f32" if args.dtype == "f32" else "")), "w") as fh:
+                fh.write(line)
+            for c, extra in (("c2", []), ("c3", []), ("c5", []), ("c4", ["--dtype", "f32"])):
+                if c == cfg and not extra:
+                    continue
+                cmd = [sys.executable, os.path.abspath(__file__), "--config", c, "--steps", str(args.steps), "--warmup", str(args.warmup),
+                       "--no-cpu-baseline", "--soak-seconds", "0"] + extra
+                name = "bench_%s%s.json" % (c, "_f32" if extra else "")
+                with open(os.path.join(args.sweep, name), "w") as fh, open(os.path.join(args.sweep, name.replace(".json", ".err")), "w") as eh:
+                    subprocess.run(cmd, stdout=fh, stderr=eh, timeout=600, check=False)
 
     # ---- untimed soak: keep the GPU in the steady-state loop long enough for an external sampler to see it ------------
     if args.soak_seconds > 0:

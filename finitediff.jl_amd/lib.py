@@ -70,7 +70,7 @@ EXPORTS = (
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
-    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum",
+    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
 )
 
 
@@ -85,7 +85,7 @@ TYPED = (
     "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
-    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum",
+    "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -171,6 +171,7 @@ def load():
     L.fd_plan_get_epsilons.argtypes = [vp, C.POINTER(dbl)]
     L.fd_plan_enable_timing.argtypes = [vp, i32]
     L.fd_plan_get_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.fd_plan_get_timing_samples.argtypes = [vp, i32, C.POINTER(dbl), i64, C.POINTER(i64)]
     L.fd_builtin_f_create.argtypes = [vp, i32, C.POINTER(i64), i32, C.POINTER(F_LAUNCH), pp]
     L.fd_builtin_f_destroy.argtypes = [vp]
     L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]

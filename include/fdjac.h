@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 201
+#define FDJAC_VERSION 300
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -114,12 +114,14 @@ typedef struct fd_lazy_points {
                           /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
                           /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
     int32_t reserved0;
-    const void *store;    /* EXPERIMENTAL (FDJAC_LAZY_STORE=1), launchers registered with FD_LAZY_CAP_STORE only: non-NULL =   */
-                          /* a `fd_band_store` (include/fdjac_device.h, host memory, valid during the call): store the       */
-                          /* finished quotients into the Jacobian yourself -- out[fd_band_dest(store, r, c)] =               */
-                          /* (f(point of colour c)[r] - f(x)[r]) / eps[c]  (central: (f(+) - f(-)) / (2 eps[c])) for every   */
-                          /* row r in [row_begin, row_end) and every colour of the batch; fx / base_out are not written and  */
-                          /* no decompression follows                                                                        */
+    const void *store;    /* launchers registered with FD_LAZY_CAP_STORE only: non-NULL = a `fd_band_store`                  */
+                          /* (include/fdjac_device.h, host memory, valid during the call): store the finished quotients into */
+                          /* the Jacobian yourself -- fd_band_emit(store, r, c, (f(point of colour c)[r] - f(x)[r]) / eps[c]) */
+                          /* (central: (f(+) - f(-)) / (2 eps[c])) for every row r in [row_begin, row_end) and every colour  */
+                          /* of the batch, CSC nzval / BandedMatrix data / Tridiagonal diagonals alike; fx / base_out are    */
+                          /* not written and no decompression follows.  The plan hands it out only for a verified exact band */
+                          /* with cyclic colours (the default then; FDJAC_LAZY_STORE=0: never); the launcher may still       */
+                          /* return FD_LAZY_DECLINED                                                                         */
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -232,7 +234,7 @@ enum fd_plan_info_key {
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
     FD_INFO_BAND_DIRECT = 30,         /* 1 if a uniform band with cyclic colours is decompressed with computed indices (k_decompress_band) */
     FD_INFO_BAND_DESC = 31,           /* number of row-window tiles whose descriptors the kernel computes instead of loading (uniform band) */
-    FD_INFO_LAZY_STORE = 32,          /* 1 if a FD_LAZY_CAP_STORE launcher stores the Jacobian of this plan itself (experimental, FDJAC_LAZY_STORE=1) */
+    FD_INFO_LAZY_STORE = 32,          /* 1 if a FD_LAZY_CAP_STORE launcher stores the Jacobian of this plan itself (exact band, cyclic colours; FDJAC_LAZY_STORE=0: never) */
     FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
     FD_INFO_ROLL = 28,                /* 1 if a 2-D stencil plan uses the rolling row windows (one wave walks a column strip) */
     FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
@@ -267,14 +269,15 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* evaluate f! and decompress in row strips that reuse one cache-sized scratch            */
                                   /* (fd_lazy_points.part / nparts; DESIGN.md "row strips")                                 */
 #define FD_LAZY_CAP_DIFF 4        /* honours fd_lazy_points.diff: writes f(point) - f(x) / f(plus) - f(minus) itself         */
-#define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store (experimental; used only by plans created with FDJAC_LAZY_STORE=1) */
+#define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store: f!'s launch stores the Jacobian of a verified exact band itself           */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
 int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
 
 /* Per-stage GPU time of the calls made since timing was enabled (HIP events on the plan's
-   stream).  stage: 0 eps-reduce, 1 perturb, 2 f!, 3 diff+decompress, 4 whole call.
+   stream).  stage: 0 eps-reduce, 1 perturb, 2 f!, 3 diff+decompress (a FD_LAZY_CAP_STORE launch that evaluates f!, divides
+   and stores in one kernel is recorded HERE: it is the difference + decompression), 4 whole call.
    ms_sum / launches accumulate; fd_plan_get_timings / fd_plan_enable_timing synchronise the stream, the calls
    themselves never wait for the device (finished spans are harvested with hipEventQuery).
    on: 0 = off, 1 = the diff+decompress kernel only (2 events per call), 2 = every stage and the whole call. */
@@ -282,6 +285,9 @@ enum fd_stage { FD_STAGE_EPS = 0, FD_STAGE_PERTURB = 1, FD_STAGE_F = 2, FD_STAGE
                 FD_STAGE_TOTAL = 4, FD_NSTAGES = 5 };
 int fd_plan_enable_timing(fd_plan *plan, int on);
 int fd_plan_get_timings(fd_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+/* The individual span durations behind ms_sum (most recent first dropped: the first `cap` spans since timing was enabled,
+   in call order; at most 65536 are kept per stage): what a MEDIAN over individually timed runs needs. */
+int fd_plan_get_timing_samples(fd_plan *plan, int stage, double *ms_out, int64_t cap, int64_t *n_out);
 
 /* ---- built-in device f! families (the reference's test fixtures + benchmark configs) ---- */
 enum fd_builtin_family {
@@ -502,6 +508,7 @@ int fd32_plan_eps_finalize(fd32_plan *plan, double relstep, double absstep, doub
 int fd32_plan_set_eps_mode(fd32_plan *plan, int mode);
 int fd32_plan_enable_timing(fd32_plan *plan, int on);
 int fd32_plan_get_timings(fd32_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+int fd32_plan_get_timing_samples(fd32_plan *plan, int stage, double *ms_out, int64_t cap, int64_t *n_out);
 int fd32_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,
                         fd_f_launch *fn_out, void **fctx_out);
 int fd32_builtin_f_destroy(void *fctx);

@@ -4,7 +4,8 @@
 Correction as MI355X_MICROARCH.md (HBM section) prescribes: on gfx950 FETCH_SIZE under-reports wide coalesced
 streaming reads by exactly 2x and WRITE_SIZE is uncalibrated, so both are calibrated IN THE SAME RUN against
 k_stream_copy, whose true traffic is known (bench.py's ceiling probe copies exactly 1 GiB per launch).
-usage: make_pmc_json.py pmc_fetch.db pmc_write.db N GPUS KERNEL > profiles/pmc_<config>.json   (KERNEL e.g. k_decompress_window)
+usage: make_pmc_json.py pmc_fetch.db pmc_write.db N GPUS KERNEL [LAZY_DIFF [LAZY_STORE]] > profiles/pmc_<config>.json
+       (KERNEL e.g. k_decompress_window, k_f_tridiag_store_wave)
 """
 import json
 import sqlite3
@@ -22,6 +23,7 @@ def mean_counter(db, kernel_like, counter):
 fetch_db, write_db, n, gpus = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 kernel = sys.argv[5] if len(sys.argv) > 5 else "k_decompress"
 lazy_diff = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # 1: the profiled run used FD_LAZY_CAP_DIFF (bench.py matches on it)
+lazy_store = int(sys.argv[7]) if len(sys.argv) > 7 else 0     # 1: ... FD_LAZY_CAP_STORE (the graded kernel is f!'s storing launch)
 copy_bytes = float(1 << 30)
 cf, _ = mean_counter(fetch_db, "k_stream_copy", "FETCH_SIZE")
 cw, _ = mean_counter(write_db, "k_stream_copy", "WRITE_SIZE")
@@ -30,7 +32,7 @@ kw = copy_bytes / (cw * 1024.0)  # expected 1.0
 df, nf = mean_counter(fetch_db, kernel, "FETCH_SIZE")
 dw, nw = mean_counter(write_db, kernel, "WRITE_SIZE")
 out = {
-    "n": n, "gpus": gpus, "kernel": kernel, "lazy_diff": lazy_diff,
+    "n": n, "gpus": gpus, "kernel": kernel, "lazy_diff": lazy_diff, "lazy_store": lazy_store,
     "calibration": {"kernel": "k_stream_copy (1 GiB read + 1 GiB write per launch)", "fetch_factor": kf, "write_factor": kw,
                     "fetch_kb_raw": cf, "write_kb_raw": cw},
     "decompress_fetch_kb_raw": df, "decompress_write_kb_raw": dw, "dispatches": [nf, nw],

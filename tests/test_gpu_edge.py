@@ -333,3 +333,45 @@ def test_hip_error_left_behind_by_a_launcher_is_reported():
     plan.ctx.synchronize()
     plan.jacobian(good, _dev(np.ones(N)), [out])                            # the plan / context stay usable
     assert not torch.isnan(out).any()
+
+
+def test_user_kernel_stores_the_jacobian_through_the_device_header(tmp_path, oracle):
+    # examples/user_f_store.hip: a USER's own HIP f! -- its own shared library, compiled with hipcc apart from libfdjac against
+    # include/fdjac.h + include/fdjac_device.h only -- registered with FD_LAZY_CAP_STORE stores the tridiagonal Jacobian of a
+    # nonlinear residual itself (fd_band_emit per entry, and fd_band_emit_wave: the dense-store path of the built-in launcher)
+    # into CSC nzval, BandedMatrix data and Tridiagonal diagonals.  examples/user_store_client.c (plain C) checks analytic
+    # values, bit-identity with the library-decompressed run and the f! evaluation counts; here the CSC values are also
+    # compared with the CPU oracle evaluating the same residual (src/jacobians.jl:504-586 + ext/FiniteDiffSparseArraysExt.jl:38-47).
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "finitediff.jl_amd", "lib")
+    user_so = str(tmp_path / "libuser_f.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(root, "examples", "user_f_store.hip"), "-o", user_so])
+    deps = subprocess.run(["ldd", user_so], capture_output=True, text=True).stdout
+    assert "libfdjac" not in deps                      # the user's library does not link the product library
+    exe = str(tmp_path / "user_store_client")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_store_client.c"), "-o", exe,
+                           "-L" + str(tmp_path), "-luser_f", "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    N = 20_011
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.run([exe, str(N), dump], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "user_store_client ok" in out.stdout and "FAILED" not in out.stdout
+    raw = np.fromfile(dump, dtype=np.float64)
+    assert int(np.frombuffer(raw[:1].tobytes(), dtype=np.int64)[0]) == N
+    x, got = raw[1:1 + N], raw[1 + N:]
+    colptr, rowval = P.tridiag_csc(N)
+
+    def f_py(fx, xx):
+        xm = np.concatenate([[0.0], xx[:-1]])
+        xp = np.concatenate([xx[1:], [0.0]])
+        fx[:] = ((xm - 2.0 * xx) + xp) + (0.25 * xx) * (xp - xm)
+
+    ref = oracle.jacobian("forward", oracle.PyF(f_py, N, N), x, P.cyclic_colors(N, 3), kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    assert got.size == ref["out"].size
+    colors = P.cyclic_colors(N, 3)
+    eps_min = min(max(1.4901161193847656e-8 * np.sqrt(np.linalg.norm(x * (colors == c))), 1.4901161193847656e-8) for c in (1, 2, 3))
+    atol = 16 * 2.220446049250313e-16 * 4.0 / eps_min
+    assert np.all(np.abs(got - ref["out"]) <= 1e-6 * np.abs(ref["out"]) + atol)

@@ -1877,23 +1877,24 @@ def test_random_jvp_sizes_three_forms_agree(oracle, seed):
 
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
-@pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "chunked", "devplan", "none", "small_n",
-                                  "rows_plain", "rows_window_odd", "rows_chunked", "rows_four_colours"])
-def test_lazy_store_experimental_bit_identical(monkeypatch, fdtype, case):
-    # EXPERIMENTAL (FDJAC_LAZY_STORE=1, include/fdjac_device.h): a FD_LAZY_CAP_STORE launcher stores the finished quotients into
-    # nzval itself (exact band verified at plan time, destination of (row, colour) by arithmetic) and the library launches no
-    # decompression.  Same operations on the same operands as the default path: same bits, same f! evaluation count.
-    # (two kernels behind the capability: one thread per column -- the default at these sizes -- and, "rows_*", workgroup-owned
-    #  rows with LDS staging, the default from 2^21 columns)
-    monkeypatch.setenv("FDJAC_STORE_COLUMNS", "0" if case.startswith("rows_") else "1")
+@pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "window_odd_even", "chunked", "devplan",
+                                  "none", "small_n", "tiny_n", "dir_minus", "rows_plain", "rows_window_odd", "rows_chunked", "rows_four_colours"])
+def test_lazy_store_bit_identical(monkeypatch, fdtype, case):
+    # include/fdjac_device.h, the default since round 3: a FD_LAZY_CAP_STORE launcher stores the finished quotients into nzval
+    # itself (exact band verified at plan time, destination of (row, colour) by arithmetic) and the library launches no
+    # decompression.  Same operations on the same operands as the hand-over path (FDJAC_LAZY_STORE=0): same bits, same f!
+    # evaluation count.  Two kernels behind the capability: the column-centric wave kernel (fd_band_emit_wave: wave-private LDS
+    # window, dense non-temporal stores) and, "rows_*" (FDJAC_STORE_WAVE=0; also what colour chunks fall back to), round 2's
+    # workgroup-owned rows.
+    monkeypatch.setenv("FDJAC_STORE_WAVE", "0" if case.startswith("rows_") else "1")
     case = case[5:] if case.startswith("rows_") else case
-    N = 20_001 if case == "small_n" else 150_017
+    N = {"small_n": 20_001, "tiny_n": 130}.get(case, 150_017)
     colptr, rowval = P.tridiag_csc(N)
     C = 4 if case == "four_colours" else 3
     colors = ((np.arange(N) + (2 if case == "shifted" else 0)) % C + 1).astype(np.int64)
     if case == "none":
         colors[[7, N // 2]] = 0
-    win = {"window": (30_001, 120_000), "window_odd": (30_002, 119_999)}.get(case)
+    win = {"window": (30_001, 120_000), "window_odd": (30_002, 119_999), "window_odd_even": (30_002, 120_000)}.get(case)
     cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype == "central" else 1) * 2 if case == "chunked" else 0
     x = _dev(np.random.default_rng(97).random(N))
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
@@ -1908,10 +1909,57 @@ def test_lazy_store_experimental_bit_identical(monkeypatch, fdtype, case):
         plan.set_lazy(f)
         assert plan.info(fd.lib.INFO_LAZY_STORE) == (1 if (store == "1" and case != "none") else 0)
         out = _dev(np.full(plan.out_len(0), np.nan))
-        plan.jacobian(f, x, [out])
+        plan.jacobian(f, x, [out], dir=-1.0 if case == "dir_minus" else True)
         outs.append(out)
         calls.append((f.fcalls, plan.fcalls_last))
     assert not torch.isnan(outs[0]).any()
-    bad = torch.nonzero(outs[0] != outs[1]).flatten()
+    bad = torch.nonzero(outs[0].view(torch.int64) != outs[1].view(torch.int64)).flatten()
     assert bad.numel() == 0, (int(bad.numel()), bad[:8].tolist(), outs[0][bad[:8]].tolist(), outs[1][bad[:8]].tolist())
     assert calls[0] == calls[1]
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["csc", "banded", "tridiagonal"])
+@pytest.mark.parametrize("case", ["plain", "shifted5", "window", "window_odd", "tiny"])
+def test_lazy_store_storage_types_bit_identical(monkeypatch, oracle, fdtype, dtype, kind, case):
+    # the same capability for every storage type whose band is arithmetic -- SparseMatrixCSC nzval, BandedMatrix data
+    # (ext/FiniteDiffBandedMatricesExt.jl:13-27; corner slots hold 0) and Tridiagonal dl / d / du (src/iteration_utils.jl:25-32)
+    # -- in both element types: bits of the hand-over path, and the oracle within tolerance
+    N = 131 if case == "tiny" else 70_003
+    C, shift = (5, 3) if case == "shifted5" else (3, 0)
+    colors = ((np.arange(N) + shift) % C + 1).astype(np.int64)
+    win = {"window": (10_001, 50_000), "window_odd": (10_002, 49_999)}.get(case)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    x = torch.as_tensor(np.random.default_rng(5).random(N), dtype=tdt, device="cuda")
+    colptr, rowval = P.tridiag_csc(N)
+    if kind == "csc":
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    elif kind == "banded":
+        J = fd.BandedMatrix(torch.zeros((N, 3), dtype=tdt, device="cuda").t(), N, 1, 1)
+    else:
+        J = fd.Tridiagonal(torch.zeros(N - 1, dtype=tdt, device="cuda"), torch.zeros(N, dtype=tdt, device="cuda"),
+                           torch.zeros(N - 1, dtype=tdt, device="cuda"))
+    res = []
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=win, dtype=dtype)
+        f = fd.BuiltinF("tridiag_nl", N, dtype=dtype)
+        plan.set_lazy(f)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == int(store)
+        outs = [torch.full((plan.out_len(k),), float("nan"), dtype=tdt, device="cuda") for k in range(plan.nouts)]
+        plan.jacobian(f, x, outs)
+        res.append((outs, f.fcalls, plan.fcalls_last))
+    ity = torch.int32 if dtype == np.float32 else torch.int64
+    for a, b in zip(res[0][0], res[1][0]):
+        assert not torch.isnan(a).any()
+        assert torch.equal(a.view(ity), b.view(ity)), (kind, case, int((a.view(ity) != b.view(ity)).sum()))
+    assert res[0][1:] == res[1][1:]
+    if kind == "csc" and win is None:
+        ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N, dtype=dtype), x.cpu().numpy(), colors, kind=oracle.PAT_CSC_COMMON,
+                              colptr=colptr, rowval=rowval)
+        got = res[0][0][0].cpu().numpy().astype(np.float64)
+        if dtype == np.float64:
+            _tol_ok(got, ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 16.0, "store %s %s" % (kind, fdtype))
+        else:
+            assert np.max(np.abs(got - ref["out"]) / (2e-2 * np.abs(ref["out"]) + 5e-2)) <= 1.0
