@@ -295,6 +295,10 @@ def main():
     elif lazy_diff and cfg in ("c2", "c4"):
         bytes_min = C * vs + 3 * vs + 3 * idx_b                 # 48 (f64, periodic codes)
         bytes_call_model = (vs + (0 if cyc else 1)) + (vs + 1 + C * vs) + bytes_min
+    elif lazy_store and cfg == "c3":
+        bytes_min = (8 * N + N + nnz * 8) / N                   # x in, one colour byte per column, nzval out
+        bytes_call_model = 9.0 + bytes_min
+        kern = "k_f_stencil5_store_wave<unsigned char, 1, 0, true>"
     elif lazy_diff and cfg == "c3":
         bytes_min = (C * 8 * N + nnz * (8 + idx_b)) / N
         bytes_call_model = 9.0 + (9.0 + C * 8) + bytes_min
@@ -365,15 +369,19 @@ def main():
         enqueue()
     torch.cuda.synchronize()
     tm_all = plan.timings()
+    plan.enable_timing(3)   # the whole call only (2 events per call): the individually timed runs the median is taken from
+    for _ in range(max(args.steps, 20)):
+        enqueue()
+    torch.cuda.synchronize()
     call_samples = plan.timing_samples("total")
     plan.enable_timing(0)
     # ---- side measurement (single GPU, untimed): the same Jacobian through round 2's default, the HAND-OVER path
     # (FDJAC_LAZY_STORE=0: f! writes differences, a second launch divides and decompresses) -- must give the same bits
     handover = None
-    if world == 1 and lazy_store and cfg in ("c2", "c4") and not args.no_plain_handover:
+    if world == 1 and lazy_store and cfg in ("c2", "c3", "c4") and not args.no_plain_handover:
         try:
             os.environ["FDJAC_LAZY_STORE"] = "0"
-            cp_s, rv_s = P.tridiag_csc(N)              # (the pattern arrays of the timed plan were released after its creation)
+            cp_s, rv_s = P.tridiag_csc(N) if cfg != "c3" else P.lap5_csc(nx, ny)   # (the timed plan's pattern arrays were released)
             pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
             plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
             del cp_s, rv_s, pat_s
@@ -384,10 +392,14 @@ def main():
                 enq_s()
             torch.cuda.synchronize()
             plan_s.enable_timing(2)
-            for _ in range(max(args.steps, 20)):
+            for _ in range(10):
                 enq_s()
             torch.cuda.synchronize()
             ts_all = plan_s.timings()
+            plan_s.enable_timing(3)
+            for _ in range(max(args.steps, 20)):
+                enq_s()
+            torch.cuda.synchronize()
             tot_s = plan_s.timing_samples("total")
             plan_s.enable_timing(0)
             handover = {"what": "FDJAC_LAZY_STORE=0: eps pass + lazy f! handing over differences + row-window division/decompression "

@@ -135,7 +135,12 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->dma = env_int("FDJAC_DMA", 0) != 0;
     p->list_U = env_int("FDJAC_TILE", 2);
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
-    p->eps_nt = env_int("FDJAC_EPS_NT", 1) != 0;
+    // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
+    // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
+    // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
+    // FDJAC_EPS_NT forces one, a call decides by which path it takes.
+    p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
+    p->eps_nt = p->eps_nt_forced != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     // opt-in: inside the pipeline the computed-index kernel measured 113-119 us against 103 us for the row windows
     // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
@@ -977,6 +982,51 @@ static void try_store_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, con
     if (ok) { p->store_ok = true; p->store_l = d.l; p->store_u = d.u; p->store_C = d.C; p->store_shift = shift; }
 }
 
+// ... and for the 5-point stencil on an nx x ny grid in natural ordering (fd_stencil5_store): the pattern must be exactly the
+// stencil's, colorvec a valid colouring of it (columns that share a row differ in colour)
+static void try_store_plan_stencil5(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows, const std::vector<int64_t> &colstart)
+{
+    p->store5_ok = false;
+    if (!p->store_allowed || p->store_ok || p->M != p->N || p->col1 - p->col0 < 16 || p->nnz_local < 16 || p->C < 5) return;
+    auto cs = [&](int64_t j) { return colstart[(size_t)(j - p->col0)]; };
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    if (cs(jm + 1) - cs(jm) != 5) return;
+    const int64_t nx = (int64_t)rows[(size_t)cs(jm) + 4] - jm;
+    if (nx < 4 || (nx & 1) || p->N % nx != 0 || p->N / nx < 3) return;
+    fd_stencil5_store d;
+    memset(&d, 0, sizeof d);
+    d.nx = nx; d.ny = p->N / nx;
+    bool ok = cs(p->col1) + p->entry_begin == fd_stencil5_colptr(&d, p->col1);
+    for (int64_t k = p->col0; k < p->col1 && ok; ++k) {
+        const int64_t j = k / nx, i = k - j * nx;
+        int64_t want[5];
+        int n = 0;
+        if (j > 0) want[n++] = k - nx;
+        if (i > 0) want[n++] = k - 1;
+        want[n++] = k;
+        if (i < nx - 1) want[n++] = k + 1;
+        if (j < d.ny - 1) want[n++] = k + nx;
+        ok = cs(k) + p->entry_begin == fd_stencil5_colptr(&d, k) && cs(k + 1) - cs(k) == n;
+        for (int q = 0; ok && q < n; ++q) ok = rows[(size_t)(cs(k) + q)] == want[q];
+    }
+    // valid colouring: the (up to five) columns of every row differ in colour -- every row, whoever owns its columns
+    for (int64_t r = 0; r < p->N && ok; ++r) {
+        const int64_t j = r / nx, i = r - j * nx;
+        int32_t c[5];
+        int n = 0;
+        c[n++] = col0[(size_t)r];
+        if (i > 0) c[n++] = col0[(size_t)(r - 1)];
+        if (i < nx - 1) c[n++] = col0[(size_t)(r + 1)];
+        if (j > 0) c[n++] = col0[(size_t)(r - nx)];
+        if (j < d.ny - 1) c[n++] = col0[(size_t)(r + nx)];
+        for (int a = 0; a < n && ok; ++a) {
+            if (c[a] < 0) ok = false;
+            for (int b = a + 1; b < n; ++b) if (c[a] == c[b]) ok = false;
+        }
+    }
+    if (ok) { p->store5_ok = true; p->store5_nx = nx; p->store5_ny = d.ny; }
+}
+
 // the same capability for the storage types whose band is implicit (BandedMatrix data, Tridiagonal): only the colours need
 // checking -- cyclic (the step-size reduction's test, host or device builder), at least as many as the band is wide
 static void store_caps_implicit_band(fd_plan *p, int64_t l, int64_t u)
@@ -1034,6 +1084,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         if (!p->window && (rc = try_window_plan(p, rows, nzc, padded, scattered))) return rc;
         if (p->window && colstart && p->kind == K_CSC) try_band_plan_csc(p, col0, rows, *colstart);
         if (colstart && p->kind == K_CSC) try_store_plan_csc(p, col0, rows, *colstart);
+        if (colstart && p->kind == K_CSC) try_store_plan_stencil5(p, col0, rows, *colstart);
         if (p->window) {
             // the window kernel needs neither rowval nor the per-entry colours on the device
             rows.clear();
@@ -1331,7 +1382,8 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
                             p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
                             p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6),
                             p->band_ok, p->band_t0, p->band_t1, p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
-                            (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1, p->store_ok, p->store_l, p->store_u};
+                            (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1, p->store_ok, p->store_l, p->store_u,
+                            p->store5_ok, p->store5_nx, p->store5_ny};
     mix(scal, sizeof scal);
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
@@ -1667,7 +1719,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
         break;
     case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
-    case FD_INFO_EPS_NT: *value = p->eps_nt ? 1 : 0; break;
+    case FD_INFO_EPS_NT: *value = (p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !store_active(p)) ? 1 : 0; break;
     case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
     case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
@@ -1702,9 +1754,10 @@ struct Span {
     int idx = -1;
     Span(fd_plan *pl, int stage) : p(pl)
     {
-        // level 1: only the graded kernel (2 events per call); level 2: every stage + the whole call
+        // level 1: only the graded kernel (2 events per call); level 2: every stage + the whole call; level 3: the whole call only
         if (p->timing == 0) return;
         if (p->timing == 1 && stage != FD_STAGE_DECOMPRESS) return;
+        if (p->timing == 3 && stage != FD_STAGE_TOTAL) return;
         fdjac::TimedSpan s{stage, take_event(p), take_event(p)};
         (void)hipEventRecord(s.a, p->ctx->stream);
         p->spans.push_back(s);
@@ -1752,7 +1805,7 @@ int fd_plan_enable_timing(fd_plan *p, int on)
     FD_REQUIRE(p, FD_ERR_ARG, "plan is NULL");
     int rc = collect_spans(p);
     if (rc) return rc;
-    p->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    p->timing = on < 0 ? 0 : (on > 3 ? 3 : on);
     for (int i = 0; i < FD_NSTAGES; ++i) {
         p->ms_sum[i] = 0;
         p->launches[i] = 0;
@@ -1837,6 +1890,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (rc) return rc;
     }
     if (p->eps_mode != FD_EPS_PRECOMPUTED) p->eps2_fresh = false;
+    p->eps_nt = p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !store_active(p);   // (see apply_opts)
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
         // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current
@@ -1916,7 +1970,13 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (store_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
             Span sp(p, FD_STAGE_DECOMPRESS);
             fd_band_store bs;
+            fd_stencil5_store s5;
             memset(&bs, 0, sizeof bs);
+            memset(&s5, 0, sizeof s5);
+            s5.out = outs[0];
+            s5.nx = p->store5_nx; s5.ny = p->store5_ny; s5.entry_begin = p->entry_begin; s5.col_begin = p->col0; s5.col_end = p->col1;
+            s5.color = p->d_color; s5.color_bytes = p->color8 ? 1 : 4; s5.C = (int)p->C; s5.elem_bytes = (int)sizeof(real_t);
+            const bool stencil = !p->store_ok && p->store5_ok && p->kind == K_CSC;
             bs.M = p->M; bs.N = p->N; bs.entry_begin = p->entry_begin; bs.col_begin = p->col0; bs.col_end = p->col1;
             bs.l = p->store_l; bs.u = p->store_u; bs.C = p->store_C; bs.shift = p->store_shift;
             bs.elem_bytes = (int)sizeof(real_t);
@@ -1937,7 +1997,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.pts = p->pts;
             lp.nparts = 1;
             lp.diff = (p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1;
-            lp.store = &bs;
+            lp.store = stencil ? (const void *)&s5 : (const void *)&bs;
+            lp.store_kind = stencil ? FD_STORE_STENCIL5 : FD_STORE_BAND;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (store) returned %d", rc);
             if (rc == 0) {
@@ -2003,7 +2064,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.eps = p->d_eps;
             lp.base_out = (base_pending && !want_diff) ? p->d_fx : nullptr;
             lp.diff = want_diff ? ((p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1) : 0;
-            lp.reserved0 = 0;
+            lp.store_kind = 0;
             lp.color_bytes = p->color8 ? 1 : 4;
             lp.c_lo = c_lo;
             lp.ncolors = B;

@@ -221,7 +221,7 @@ __device__ __forceinline__ r2_t ld_pair_guarded(const real_t *__restrict__ x, in
     return v;
 }
 
-template <int MODE, bool NL>
+template <int MODE, bool NL, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart, int reversed)
 {
@@ -256,7 +256,7 @@ k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ 
             q[3 * o + k] = sub_exact(plus, sub) / ed;
         }
     }
-    fd_band_emit_wave<real_t, 3>(&bst, s_win[wave], jw, q);
+    fd_band_emit_wave<real_t, 3, NT>(&bst, s_win[wave], jw, q);
 }
 
 // (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
@@ -589,6 +589,9 @@ struct BuiltinF {
     std::atomic<int64_t> launches{0}, points{0};
     void *d_sig = nullptr;  // block-coupled sigma scratch
     int64_t sig_cap = 0;    // in (re,im)-capable elements
+    // variants of the storing launch (read once, when the launcher is created): FDJAC_STORE_WAVE=0 round 2's row-owned kernel,
+    // FDJAC_STORE_NT=0 plain instead of non-temporal stores, FDJAC_STORE_REV=1 wavefronts walk the columns back to front
+    bool store_wave = true, store_nt = true, store_rev = false;
 };
 
 int balanced_grid(int64_t tiles, int64_t cap);
@@ -714,23 +717,25 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
                        lp->ncolors, b->prm[0], r0e, r1, lp->imag_only, mode != 2 ? lp->diff : 0)
     if (lp->store) {
         // the launch stores the Jacobian itself (include/fdjac_device.h); one-shot launches
+        if (lp->store_kind != FD_STORE_BAND) return FD_LAZY_DECLINED;
         const fd_band_store bst = *(const fd_band_store *)lp->store;
         if (bst.elem_bytes != (int)sizeof(real_t) || mode == 2) return FD_LAZY_DECLINED;
         const int wband = bst.l + bst.u + 1;
         // an exactly tridiagonal band with every colour in this batch: the column-centric wave kernel, any layout
         // (FDJAC_STORE_WAVE=0 keeps round 2's row-owned form for A/B runs)
-        const char *fsw = getenv("FDJAC_STORE_WAVE");
-        const bool wave_ok = !(fsw && *fsw && atoi(fsw) == 0) && bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
+        const bool wave_ok = b->store_wave && bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
                              lp->ncolors == bst.C && bst.C >= 3 && (((uintptr_t)lp->x) & kPairMask) == 0 && bst.col_end > bst.col_begin;
         if (wave_ok) {
             const int64_t jstart = bst.col_begin & ~(int64_t)1;
             const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
             const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
-#define FD_LAZY_SW(MODE, NL)                                                                                       \
-            hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
-                               (const real_t *)lp->eps, b->prm[0], bst, jstart, 0)
-            if (mode == 0) { if (nl) FD_LAZY_SW(0, true); else FD_LAZY_SW(0, false); }
-            else { if (nl) FD_LAZY_SW(1, true); else FD_LAZY_SW(1, false); }
+#define FD_LAZY_SW(MODE, NL, NT)                                                                                   \
+            hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL, NT>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
+                               (const real_t *)lp->eps, b->prm[0], bst, jstart, b->store_rev ? 1 : 0)
+#define FD_LAZY_SW2(MODE, NL) do { if (b->store_nt) FD_LAZY_SW(MODE, NL, true); else FD_LAZY_SW(MODE, NL, false); } while (0)
+            if (mode == 0) { if (nl) FD_LAZY_SW2(0, true); else FD_LAZY_SW2(0, false); }
+            else { if (nl) FD_LAZY_SW2(1, true); else FD_LAZY_SW2(1, false); }
+#undef FD_LAZY_SW2
 #undef FD_LAZY_SW
             return hipGetLastError() == hipSuccess ? 0 : 4;
         }
@@ -759,6 +764,107 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
     return hipGetLastError() == hipSuccess ? 0 : 4;
 }
 
+// fd_lazy_points.store with a fd_stencil5_store (include/fdjac_device.h): the 5-point fixtures evaluated at the lazily perturbed
+// points, difference quotients formed and stored into the CSC nzval of the stencil by this launch -- nothing follows it.
+// COLUMN-centric like k_f_tridiag_store_wave: lane t of a wavefront owns the grid columns (i, j), (i + 1, j), i = i0 + 2t,
+// loads the 6 x 5 window of x around them (11 aligned 16-B loads; the vertical re-reads come from L2: consecutive grid rows run
+// on one XCD), and evaluates the five rows each column touches at x +- eps e_k.  Seen from one of those rows the colour's point
+// x +- eps_c mask_c differs from x in column k only (the plan verified that colorvec is a valid colouring of the exact stencil),
+// so every operand -- the "+ 0.0" of the unperturbed coordinates included -- and every operation (stencil5 row, sub_exact,
+// IEEE division) is that of the colour-batched evaluation: same bits (scripts/ubench/stencil_store_probe.hip checks the form
+// against the reference's loop order on the host).  The wavefront's 128 x 5 quotients leave through fd_stencil5_emit_wave.
+template <typename T, int SK> __device__ __forceinline__ T stencil5_row(T c, T w, T e, T s, T n)
+{
+    T v = (((w + e) + s) + n) - kFour * c;
+    if (SK == 2) v = v + (c * c) * e;
+    return v;
+}
+
+template <typename CT, int MODE, int SK, bool NT>
+__global__ void __launch_bounds__(kBlock)
+k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
+{
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_STENCIL5_WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = (int)st.nx, ny = (int)st.ny;
+    const int T128 = (nx + 127) / 128;
+    const int64_t ntiles = (jrow1 - jrow0) * T128, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    const int64_t grp = xcd_tile(blockIdx.x, ngroups);
+    if (grp >= ngroups) return;
+    const int64_t wt = grp * (kBlock / 64) + wave;
+    if (wt >= ntiles) return;
+    const int j = (int)(jrow0 + wt / T128), i0 = (int)(wt % T128) * 128;
+    const int i = i0 + 2 * lane;
+    const int64_t k = (int64_t)j * nx + i;
+    const bool act = i < nx;
+    // window rows j-2 .. j+2, columns i-2 .. i+3 (zero outside the grid; rows j+-2 only the centre pair)
+    real_t W[5][6];
+#pragma unroll
+    for (int dj = -2; dj <= 2; ++dj) {
+        const bool rowok = act && j + dj >= 0 && j + dj < ny;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r2_t v = {0, 0};
+            if (!((dj == -2 || dj == 2) && c != 1)) {
+                const int ic = i + 2 * (c - 1);
+                const int64_t kc = k + (int64_t)dj * nx + 2 * (c - 1);
+                if (rowok && ic >= 0 && ic + 1 < nx) v = *reinterpret_cast<const r2_t *>(x + kc);
+                else if (rowok) { if (ic >= 0 && ic < nx) v.x = x[kc]; if (ic + 1 >= 0 && ic + 1 < nx) v.y = x[kc + 1]; }
+            }
+            W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
+        }
+    }
+    int cpair[2] = {0, 0};
+    if (act) { cpair[0] = (int)((const CT *)st.color)[k]; cpair[1] = (int)((const CT *)st.color)[k + 1]; }
+    real_t q[10];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int ii = i + o;
+        const real_t e = eps[cpair[o]];
+        const real_t ed = MODE == 1 ? 2 * e : e;
+        const real_t xc = W[2][2 + o], pc = xc + e, mc = xc - e;
+        const bool hw = ii > 0, he = ii < nx - 1, hs = j > 0, hn = j < ny - 1;
+        const real_t z = 0;
+        // PV: what the plus point holds at an unperturbed coordinate (x + 0.0); MV: the minus point (x - 0.0 == x) -- and,
+        // for forward differences, the base point x itself
+#define PV(dj, di) (W[(dj) + 2][(di) + 2 + o] + z)
+#define MV(dj, di) W[(dj) + 2][(di) + 2 + o]
+        const real_t mcc = MODE == 1 ? mc : xc;
+        {   // row (ii, j-1): its north neighbour is the perturbed coordinate
+            const bool rhs = j - 1 > 0;
+            const real_t pl = stencil5_row<real_t, SK>(PV(-1, 0), hw ? PV(-1, -1) : z, he ? PV(-1, 1) : z, rhs ? PV(-2, 0) : z, pc);
+            const real_t mi = stencil5_row<real_t, SK>(MV(-1, 0), hw ? MV(-1, -1) : z, he ? MV(-1, 1) : z, rhs ? MV(-2, 0) : z, mcc);
+            q[5 * o + 0] = sub_exact(pl, mi) / ed;
+        }
+        {   // row (ii-1, j): east
+            const bool rhw = ii - 1 > 0;
+            const real_t pl = stencil5_row<real_t, SK>(PV(0, -1), rhw ? PV(0, -2) : z, pc, hs ? PV(-1, -1) : z, hn ? PV(1, -1) : z);
+            const real_t mi = stencil5_row<real_t, SK>(MV(0, -1), rhw ? MV(0, -2) : z, mcc, hs ? MV(-1, -1) : z, hn ? MV(1, -1) : z);
+            q[5 * o + 1] = sub_exact(pl, mi) / ed;
+        }
+        {   // row (ii, j): centre
+            const real_t pl = stencil5_row<real_t, SK>(pc, hw ? PV(0, -1) : z, he ? PV(0, 1) : z, hs ? PV(-1, 0) : z, hn ? PV(1, 0) : z);
+            const real_t mi = stencil5_row<real_t, SK>(mcc, hw ? MV(0, -1) : z, he ? MV(0, 1) : z, hs ? MV(-1, 0) : z, hn ? MV(1, 0) : z);
+            q[5 * o + 2] = sub_exact(pl, mi) / ed;
+        }
+        {   // row (ii+1, j): west
+            const bool rhe = ii + 1 < nx - 1;
+            const real_t pl = stencil5_row<real_t, SK>(PV(0, 1), pc, rhe ? PV(0, 2) : z, hs ? PV(-1, 1) : z, hn ? PV(1, 1) : z);
+            const real_t mi = stencil5_row<real_t, SK>(MV(0, 1), mcc, rhe ? MV(0, 2) : z, hs ? MV(-1, 1) : z, hn ? MV(1, 1) : z);
+            q[5 * o + 3] = sub_exact(pl, mi) / ed;
+        }
+        {   // row (ii, j+1): south
+            const bool rhn = j + 1 < ny - 1;
+            const real_t pl = stencil5_row<real_t, SK>(PV(1, 0), hw ? PV(1, -1) : z, he ? PV(1, 1) : z, pc, rhn ? PV(2, 0) : z);
+            const real_t mi = stencil5_row<real_t, SK>(MV(1, 0), hw ? MV(1, -1) : z, he ? MV(1, 1) : z, mcc, rhn ? MV(2, 0) : z);
+            q[5 * o + 4] = sub_exact(pl, mi) / ed;
+        }
+#undef PV
+#undef MV
+    }
+    fd_stencil5_emit_wave<real_t, NT>(&st, s_win[wave], j, i0, q);
+}
+
 template <typename CT>
 static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, int64_t fs, int64_t r0, int64_t r1,
                                 hipStream_t s)
@@ -768,6 +874,27 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
     const unsigned g = (unsigned)(8 * xcd_chunks(ntiles));
     const int sk = b->family == FD_F_CLAMP5 ? 1 : b->family == FD_F_LAP5_NL ? 2 : 0;
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
+    if (lp->store) {
+        // the launch stores the stencil's CSC Jacobian itself (fd_stencil5_store): every colour in one batch, the Laplacian
+        // fixtures (the clamped sum's boundary rows reach themselves twice: not this pattern's arithmetic)
+        if (lp->store_kind != FD_STORE_STENCIL5 || mode == 2 || sk == 1) return FD_LAZY_DECLINED;
+        const fd_stencil5_store st = *(const fd_stencil5_store *)lp->store;
+        if (st.elem_bytes != (int)sizeof(real_t) || st.nx != b->prm[0] || st.ny != b->prm[1] || lp->c_lo != 0 || lp->ncolors != st.C ||
+            st.color_bytes != (int)sizeof(CT) || (((uintptr_t)lp->x) & kPairMask) != 0 || st.col_end <= st.col_begin || !b->store_wave)
+            return FD_LAZY_DECLINED;
+        const int64_t jrow0 = st.col_begin / st.nx, jrow1 = (st.col_end - 1) / st.nx + 1;      // grid rows with local columns
+        const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 127) / 128), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+        const unsigned gs = (unsigned)(8 * xcd_chunks(ngroups));
+#define FD_S5(MODE, SKK, NT)                                                                                        \
+        hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                           (const real_t *)lp->eps, st, jrow0, jrow1)
+#define FD_S5_NT(MODE, SKK) do { if (b->store_nt) FD_S5(MODE, SKK, true); else FD_S5(MODE, SKK, false); } while (0)
+        if (mode == 0) { if (sk == 2) FD_S5_NT(0, 2); else FD_S5_NT(0, 0); }
+        else { if (sk == 2) FD_S5_NT(1, 2); else FD_S5_NT(1, 0); }
+#undef FD_S5_NT
+#undef FD_S5
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
 #define FD_LAZY(MODE, CL)                                                                                          \
     hipLaunchKernelGGL((k_f_stencil5_lazy<CT, MODE, CL>), dim3(g), dim3(kBlock), 0, s, (real_t *)fx, fs,            \
                        (real_t *)lp->base_out, (const real_t *)lp->x, (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo,    \
@@ -1150,7 +1277,8 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
     if (lp->diff && (b->family == FD_F_BLOCKCOUPLED || lp->is_complex || lp->base_out)) return 8;   // (not registered with FD_LAZY_CAP_DIFF)
-    if (lp->store && !(lp->diff && (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL))) return 9;   // (FD_LAZY_CAP_STORE: the tridiagonal families)
+    if (lp->store && !(lp->diff && (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL)))
+        return 9;   // (FD_LAZY_CAP_STORE: the tridiagonal and Laplacian families)
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + ((lp->base_out || lp->diff == 2) ? 1 : 0);
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
     if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
@@ -1212,6 +1340,12 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
         return FD_ERR_ARG;
     }
     for (int i = 0; i < need; ++i) b->prm[i] = params[i];
+    {
+        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+        b->store_wave = env_int("FDJAC_STORE_WAVE", 1) != 0;
+        b->store_nt = env_int("FDJAC_STORE_NT", 1) != 0;
+        b->store_rev = env_int("FDJAC_STORE_REV", 0) != 0;
+    }
     for (int i = 0; i < need; ++i)
         if (b->prm[i] < 1) {
             delete b;
@@ -1279,7 +1413,7 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |
-                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) ? FD_LAZY_CAP_STORE : 0)) : 0;
+                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL) ? FD_LAZY_CAP_STORE : 0)) : 0;
     return FD_OK;
 }
 

@@ -181,7 +181,8 @@ struct fd_plan {
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
     bool dma = false;              //   LDS-DMA staging in the row-window kernels (FDJAC_DMA=1)
     int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
-    bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads (FDJAC_EPS_NT != 0)
+    bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
+    int eps_nt_forced = -1;        //   (-1: non-temporal on the hand-over path, plain when f!'s storing launch re-reads x)
     int cyc_C = 0, cyc_shift = 0;  // cyclic colours: color[j] == (j + cyc_shift) mod cyc_C for every column (0 = not cyclic);
                                    //   the reduction then computes the colours instead of reading them (FDJAC_EPS_CYCLIC=0: off)
 
@@ -224,6 +225,9 @@ struct fd_plan {
     // itself and no decompression is launched (FDJAC_LAZY_STORE=0: never)
     bool store_allowed = true, store_ok = false;
     int store_l = 0, store_u = 0, store_C = 0, store_shift = 0;
+    // ... and the 5-point stencil on an nx x ny grid (fd_stencil5_store): exact pattern + valid colouring verified
+    bool store5_ok = false;
+    int64_t store5_nx = 0, store5_ny = 0;
     bool bd_allowed = true;        //   FDJAC_BAND_DESC=0: always load
     int64_t bd_t0 = 0, bd_t1 = 0;
     int64_t w2_ntiles = 0;
@@ -295,6 +299,7 @@ struct fd_plan {
 // does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
 static inline bool store_active(const fd_plan *p)
 {
-    return p->store_ok && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) && p->fdtype != FD_COMPLEX && !p->has_none &&
+    return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) &&
+           p->fdtype != FD_COMPLEX && !p->has_none &&
            (p->kind == fdjac::K_CSC || p->kind == fdjac::K_BANDED || p->kind == fdjac::K_TRIDIAG);
 }

@@ -721,6 +721,45 @@ __global__ void __launch_bounds__(kBlock) k_pb_band_exact(const void *__restrict
     if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(bad_out, 1);
 }
 
+// the store capability of the 5-point stencil (fd_stencil5_store): every local column holds exactly the stencil's rows at the
+// closed-form position, and the columns of every row differ in colour (try_store_plan_stencil5 on the device)
+__global__ void __launch_bounds__(kBlock) k_pb_stencil5_exact(const void *__restrict__ colptr, const void *__restrict__ rowval, int ib, int base,
+                                                              int64_t col0, int64_t col1, fd_stencil5_store d, const uint8_t *__restrict__ color8,
+                                                              int *bad_out)
+{
+    bool bad = false;
+    const int64_t nx = d.nx, N = d.nx * d.ny;
+    for (int64_t k = col0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < col1; k += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = k / nx, i = k - j * nx;
+        const int64_t a = pb_load(colptr, ib, k) - base, b = pb_load(colptr, ib, k + 1) - base;
+        int64_t want[5];
+        int n = 0;
+        if (j > 0) want[n++] = k - nx;
+        if (i > 0) want[n++] = k - 1;
+        want[n++] = k;
+        if (i < nx - 1) want[n++] = k + 1;
+        if (j < d.ny - 1) want[n++] = k + nx;
+        bad = bad || a != fd_stencil5_colptr(&d, k) || b - a != n;
+        if (!bad)
+            for (int q = 0; q < n; ++q) bad = bad || (pb_load(rowval, ib, a + q) - base != want[q]);
+    }
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < N; r += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = r / nx, i = r - j * nx;
+        int c[5];
+        int n = 0;
+        c[n++] = color8[r];
+        if (i > 0) c[n++] = color8[r - 1];
+        if (i < nx - 1) c[n++] = color8[r + 1];
+        if (j > 0) c[n++] = color8[r - nx];
+        if (j < d.ny - 1) c[n++] = color8[r + nx];
+        for (int a = 0; a < n; ++a) {
+            bad = bad || c[a] == 0xFF;
+            for (int b = a + 1; b < n; ++b) bad = bad || c[a] == c[b];
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0) atomicOr(bad_out, 1);
+}
+
 // outcome of the device builder
 enum { PBR_DONE = 0, PBR_DECLINED = 1 };
 
@@ -742,6 +781,39 @@ struct PbTemps {
     template <typename T> T *add(T *p) { ptrs[n++] = (void *)p; return p; }
     ~PbTemps() { for (int i = 0; i < n; ++i) if (ptrs[i]) (void)hipFree(ptrs[i]); }
 };
+
+// device counterpart of try_store_plan_stencil5 (same decisions: the grid width from the middle column, then the exact test)
+static void device_store_stencil5(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t C,
+                                  const uint8_t *d_color8, bool has_none)
+{
+    p->store5_ok = false;
+    hipStream_t s = p->ctx->stream;
+    if (!p->store_allowed || p->store_ok || p->M != p->N || p->col1 - p->col0 < 16 || C < 5 || C > 254 || has_none) return;
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    char raw[2][16];
+    if (hipMemcpyAsync(raw[0], (const char *)d_colptr + (size_t)ib * (size_t)jm, 2 * (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return;
+    const int64_t a = load_idx(raw[0], ib, 0) - base, b = load_idx(raw[0], ib, 1) - base;
+    if (b - a != 5 || a < e0) return;
+    if (hipMemcpyAsync(raw[1], (const char *)d_rowval + (size_t)ib * (size_t)(a + 4), (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return;
+    const int64_t nx = (load_idx(raw[1], ib, 0) - base) - jm;
+    if (nx < 4 || (nx & 1) || p->N % nx != 0 || p->N / nx < 3) return;
+    fd_stencil5_store d;
+    memset(&d, 0, sizeof d);
+    d.nx = nx; d.ny = p->N / nx;
+    int *d_bad = nullptr, hbad = 0;
+    if (hipMalloc((void **)&d_bad, sizeof(int)) != hipSuccess) return;
+    if (hipMemcpyAsync(d_bad, &hbad, sizeof hbad, hipMemcpyHostToDevice, s) == hipSuccess) {
+        hipLaunchKernelGGL(k_pb_stencil5_exact, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p->N + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
+                           dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, d, d_color8, d_bad);
+        hbad = 1;
+        if (hipMemcpyAsync(&hbad, d_bad, sizeof hbad, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && !hbad) {
+            p->store5_ok = true; p->store5_nx = nx; p->store5_ny = d.ny;
+        }
+    }
+    (void)hipFree(d_bad);
+}
 
 // 2-D (strided) tiles built on the device -- the decisions are try_window2d_plan's / finish_list_plan's (same helper
 // functions, same thresholds), the O(nnz) work is done by the kernels above.  PBR_DONE: p->d_w2desc / d_wcode and the
@@ -1078,6 +1150,8 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
+        device_store_stencil5(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, C, d_color8, p->has_none);
+        tm.mark("stencil store test");
         p->built_on_device = true;
         *rc_out = alloc_scratch(p, std::vector<int32_t>());
         tm.mark("scratch allocation");
@@ -1218,6 +1292,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
             }
         }
     }
+    if (!band && !p->store_ok) device_store_stencil5(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, C, d_color8, p->has_none);
     tm.mark("band test");
     p->built_on_device = true;
     tm.mark("descriptors to host");

@@ -40,7 +40,7 @@ class LazyPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("color", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p),
                 ("color_bytes", C.c_int32), ("c_lo", C.c_int32), ("ncolors", C.c_int32), ("pts", C.c_int32),
                 ("is_complex", C.c_int32), ("imag_only", C.c_int32), ("part", C.c_int32), ("nparts", C.c_int32),
-                ("diff", C.c_int32), ("reserved0", C.c_int32), ("store", C.c_void_p)]
+                ("diff", C.c_int32), ("store_kind", C.c_int32), ("store", C.c_void_p)]
 
 
 # int f(fctx, fx, const fd_lazy_points*, fx_stride, row_begin, row_end, stream)

@@ -113,7 +113,8 @@ typedef struct fd_lazy_points {
                           /* subtraction of the two values the plain path would have stored (same bits, half the     */
                           /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
                           /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
-    int32_t reserved0;
+    int32_t store_kind;   /* what `store` points to (include/fdjac_device.h: FD_STORE_BAND a fd_band_store, FD_STORE_STENCIL5 a    */
+                          /* fd_stencil5_store); 0 when store is NULL                                                        */
     const void *store;    /* launchers registered with FD_LAZY_CAP_STORE only: non-NULL = a `fd_band_store`                  */
                           /* (include/fdjac_device.h, host memory, valid during the call): store the finished quotients into */
                           /* the Jacobian yourself -- fd_band_emit(store, r, c, (f(point of colour c)[r] - f(x)[r]) / eps[c]) */
@@ -280,7 +281,8 @@ int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
    and stores in one kernel is recorded HERE: it is the difference + decompression), 4 whole call.
    ms_sum / launches accumulate; fd_plan_get_timings / fd_plan_enable_timing synchronise the stream, the calls
    themselves never wait for the device (finished spans are harvested with hipEventQuery).
-   on: 0 = off, 1 = the diff+decompress kernel only (2 events per call), 2 = every stage and the whole call. */
+   on: 0 = off, 1 = the diff+decompress kernel only (2 events per call), 2 = every stage and the whole call, 3 = the whole
+   call only (2 events per call: what a per-call median should be taken from -- level 2's extra markers cost ~15 us per call). */
 enum fd_stage { FD_STAGE_EPS = 0, FD_STAGE_PERTURB = 1, FD_STAGE_F = 2, FD_STAGE_DECOMPRESS = 3,
                 FD_STAGE_TOTAL = 4, FD_NSTAGES = 5 };
 int fd_plan_enable_timing(fd_plan *plan, int on);

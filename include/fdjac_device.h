@@ -97,6 +97,34 @@ FD_DEVICE_FN long long fd_band_dest(const fd_band_store *d, long long r, int c)
     return fd_band_colptr(d, j) - d->entry_begin + (r - first);
 }
 
+/* ---- 5-point stencil on an nx x ny grid (natural ordering k = i + nx j, i fastest), SparseMatrixCSC nzval --------------------
+ * Column k = (i, j) holds the rows k - nx (j > 0), k - 1 (i > 0), k, k + 1 (i < nx - 1), k + nx (j < ny - 1), in that order.
+ * The plan hands this descriptor out (fd_lazy_points.store with store_kind = FD_STORE_STENCIL5) when it has verified that the
+ * pattern is exactly that and that colorvec is a VALID colouring of it (the columns that share a row have different colours:
+ * then the colour-c point seen from a row differs from x in at most one coordinate, and a column-centric evaluation -- x +- eps
+ * e_k for the rows column k touches -- forms exactly the operands of the reference's colour-batched evaluation). */
+typedef struct fd_stencil5_store {
+    void *out;                     /* nzval of the local column range, device memory */
+    long long nx, ny;              /* grid shape; M = N = nx * ny */
+    long long entry_begin;         /* global 0-based index of the first stored entry of the local column range */
+    long long col_begin, col_end;  /* local column range [col_begin, col_end) */
+    const void *color;             /* device: 0-based colour of every column (all N), color_bytes each (1 or 4) */
+    int color_bytes, C;
+    int elem_bytes, reserved0;
+} fd_stencil5_store;
+
+/* 0-based global index of the first stored entry of column k */
+FD_DEVICE_FN long long fd_stencil5_colptr(const fd_stencil5_store *d, long long k)
+{
+    const long long j = k / d->nx, i = k - j * d->nx;
+    const long long north = k - (d->ny - 1) * d->nx;           /* columns of the last grid row before k (no k + nx entry) */
+    return 5 * k - (k < d->nx ? k : d->nx)                     /* ... of the first grid row (no k - nx entry) */
+           - (j + (i > 0 ? 1 : 0)) - j                         /* first / last columns of the grid rows before k */
+           - (north > 0 ? north : 0);
+}
+
+enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2 };   /* what fd_lazy_points.store points to */
+
 #if defined(__HIPCC__) && defined(__cplusplus)
 /* ---------------------------------------------------------------------------------------------------------------------------
  * Store helpers for HIP kernels.  T = double or float (= the plan's element type, fd_band_store.elem_bytes).
@@ -162,11 +190,11 @@ template <> struct fd_band_pair_of<float> { typedef float type __attribute__((ex
  * two columns j = jw + 2t and j + 1:  q[k] = (row j - u + k, column j), q[W + k] = (row j + 1 - u + k, column j + 1),
  * k = 0 .. W-1, W = l + u + 1 (compile time; must equal the descriptor's).  jw is even and the same in all lanes.
  * Interior wavefronts (every column complete and inside the local range) place the 128 W values in `win` in storage order
- * and write them as aligned 16-byte (Float32: 8-byte) non-temporal stores, each 128-byte line exactly once; wavefronts that
+ * and write them as aligned 16-byte (Float32: 8-byte) non-temporal (NT = false: plain) stores, each 128-byte line exactly once; wavefronts that
  * touch a corner of the matrix or an end of the local column range take fd_band_emit_column.  Values of columns outside the
  * local range are ignored, quotients of rows outside the matrix are never read.
  */
-template <typename T, int W>
+template <typename T, int W, bool NT = true>
 __device__ inline void fd_band_emit_wave(const fd_band_store *d, T *win, long long jw, const T *q)
 {
     typedef typename fd_band_pair_of<T>::type pair_t;
@@ -213,11 +241,90 @@ __device__ inline void fd_band_emit_wave(const fd_band_store *d, T *win, long lo
         const int sl = 2 * (64 * a + lane);
         const pair_t v = *(const pair_t *)(win + sl);
         if (off && sl == 0) base[1] = v.y;                                     /* slot 0 belongs to the wavefront before */
-        else __builtin_nontemporal_store(v, (pair_t *)(base + sl));
+        else if (NT) __builtin_nontemporal_store(v, (pair_t *)(base + sl));
+        else *(pair_t *)(base + sl) = v;
     }
     if (off && lane == 63) base[128 * W] = q[2 * W - 1];                        /* the odd last value */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                                           /* the window may be reused */
+}
+/* the slots [lo, hi) of a wave-private LDS window, slot 0 <-> the 16-byte aligned element `base`: aligned pair stores, single
+   elements at the two ends (all 64 lanes call) */
+template <typename T, bool NT> __device__ inline void fd_wave_store_window(T *base, const T *win, int lo, int hi)
+{
+    typedef typename fd_band_pair_of<T>::type pair_t;
+    const int lane = (int)(threadIdx.x & 63);
+    for (int sl = 2 * lane; sl < hi; sl += 128) {
+        const bool l0 = sl >= lo, l1 = sl + 1 < hi;
+        if (l0 && l1) {
+            const pair_t v = *(const pair_t *)(win + sl);
+            if (NT) __builtin_nontemporal_store(v, (pair_t *)(base + sl));
+            else *(pair_t *)(base + sl) = v;
+        } else {
+            if (l0) base[sl] = win[sl];
+            if (l1 && sl + 1 >= lo) base[sl + 1] = win[sl + 1];
+        }
+    }
+}
+
+/* One column of the 5-point stencil: q[0..4] = the quotients of the rows k - nx, k - 1, k, k + 1, k + nx (those that exist). */
+template <typename T> __device__ inline void fd_stencil5_emit_column(const fd_stencil5_store *d, long long k, const T *q)
+{
+    if (k < d->col_begin || k >= d->col_end) return;
+    const long long j = k / d->nx, i = k - j * d->nx;
+    T *o = (T *)d->out + (fd_stencil5_colptr(d, k) - d->entry_begin);
+    if (j > 0) *o++ = q[0];
+    if (i > 0) *o++ = q[1];
+    *o++ = q[2];
+    if (i < d->nx - 1) *o++ = q[3];
+    if (j < d->ny - 1) *o++ = q[4];
+}
+
+#define FD_STENCIL5_WAVE_LDS 648   /* elements of the wave-private window of fd_stencil5_emit_wave (16-byte aligned) */
+
+/*
+ * 128 consecutive columns of one grid row at once: lane t of a FULL wavefront holds q[0..4] of column (i0 + 2t, j) and q[5..9]
+ * of column (i0 + 2t + 1, j), i0 even and the same in all lanes (lanes whose column lies beyond the grid row are ignored).
+ * Interior grid rows inside the local column range go through the window (the first column of a grid row has no west entry,
+ * the last no east entry: their slots close up) and out as dense aligned stores; everything else through
+ * fd_stencil5_emit_column.
+ */
+template <typename T, bool NT = true>
+__device__ inline void fd_stencil5_emit_wave(const fd_stencil5_store *d, T *win, long long j, long long i0, const T *q)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const long long nx = d->nx, i = i0 + 2 * lane, k0 = j * nx + i0;
+    const int nc = (int)(nx - i0 < 128 ? nx - i0 : 128);
+    const bool fast = j >= 1 && j <= d->ny - 2 && k0 >= d->col_begin && k0 + nc <= d->col_end &&
+                      ((((unsigned long long)d->out) & (2 * sizeof(T) - 1)) == 0);
+    if (!fast) {
+        if (i < nx) fd_stencil5_emit_column<T>(d, k0 + 2 * lane, q);
+        if (i + 1 < nx) fd_stencil5_emit_column<T>(d, k0 + 2 * lane + 1, q + 5);
+        return;
+    }
+    const long long P0 = fd_stencil5_colptr(d, k0) - d->entry_begin;
+    const int off = (int)(P0 & 1);
+    const int cnt = 5 * nc - (i0 == 0 ? 1 : 0) - (i0 + nc == nx ? 1 : 0);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const long long ii = i + o;
+        if (ii >= nx) continue;
+        const int base = off + 5 * (int)(ii - i0) - ((i0 == 0 && ii > 0) ? 1 : 0);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            if ((m == 1 && ii == 0) || (m == 3 && ii == nx - 1)) continue;
+            int sl = base + m;
+            if (ii == 0 && m > 1) sl -= 1;
+            if (ii == nx - 1 && m == 4) sl -= 1;
+            win[sl] = q[5 * o + m];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    fd_wave_store_window<T, NT>((T *)d->out + (P0 - off), win, off, off + cnt);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 #endif /* __HIPCC__ && __cplusplus */
 

@@ -1963,3 +1963,48 @@ def test_lazy_store_storage_types_bit_identical(monkeypatch, oracle, fdtype, dty
             _tol_ok(got, ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 16.0, "store %s %s" % (kind, fdtype))
         else:
             assert np.max(np.abs(got - ref["out"]) / (2e-2 * np.abs(ref["out"]) + 5e-2)) <= 1.0
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("case", ["small", "small_nl", "device_plan", "device_plan_nl", "window", "wide_colours", "invalid_colouring", "clamp5",
+                                  "ragged_width", "float32"])
+def test_lazy_store_stencil5_bit_identical(monkeypatch, oracle, fdtype, case):
+    # fd_stencil5_store (include/fdjac_device.h): for the exact 5-point stencil on an nx x ny grid with a VALID colouring the
+    # Laplacian fixtures' launch stores the CSC Jacobian itself (k_f_stencil5_store_wave, column-centric) -- bits of the hand-over
+    # path (FDJAC_LAZY_STORE=0), same f! evaluation count, oracle parity; an invalid colouring or the clamped fixture keep the
+    # hand-over path
+    nx, ny = {"device_plan": (640, 300), "device_plan_nl": (640, 300), "window": (256, 200), "ragged_width": (70, 50)}.get(case, (64, 40))
+    N = nx * ny
+    fam = "clamp5" if case == "clamp5" else ("lap5_nl" if case.endswith("_nl") else "lap5")
+    dtype = np.float32 if case == "float32" else np.float64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    colptr, rowval = P.lap5_csc(nx, ny)
+    ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    colors = P.lap5_colors(nx, ny)
+    if case == "wide_colours":
+        colors = ((ii + 3 * jj) % 7 + 1).T.reshape(-1).astype(np.int64)          # 7 colours, still distance-2 valid
+    if case == "invalid_colouring":
+        colors = ((ii + jj) % 5 + 1).T.reshape(-1).astype(np.int64)              # (i+1, j) and (i, j+1) share a colour and the row (i+1, j+1)... and (i, j)
+    win = (nx * 37 + 11, nx * 150 + 200) if case == "window" else None
+    x = torch.as_tensor(np.random.default_rng(12).random(N), dtype=tdt, device="cuda")
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    res = []
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=win, dtype=dtype)
+        f = fd.BuiltinF(fam, nx, ny, dtype=dtype)
+        plan.set_lazy(f)
+        want_store = store == "1" and case not in ("invalid_colouring", "clamp5")     # (clamp5 has no FD_LAZY_CAP_STORE)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == (1 if want_store else 0), case
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=tdt, device="cuda")
+        plan.jacobian(f, x, [out])
+        res.append((out, f.fcalls, plan.fcalls_last, plan.timings()))
+    ity = torch.int32 if dtype == np.float32 else torch.int64
+    assert not torch.isnan(res[0][0]).any()
+    bad = torch.nonzero(res[0][0].view(ity) != res[1][0].view(ity)).flatten()
+    assert bad.numel() == 0, (case, int(bad.numel()), bad[:8].tolist())
+    assert res[0][1:3] == res[1][1:3]
+    if case in ("small", "small_nl", "wide_colours") and dtype == np.float64:
+        ref = oracle.jacobian(fdtype, oracle.Fixture(fam, nx, ny), x.cpu().numpy(), colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+        _tol_ok(res[0][0].cpu().numpy(), ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 8.0, "stencil store " + case)
+        assert res[0][1] == ref["fcalls"]
