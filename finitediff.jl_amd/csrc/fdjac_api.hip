@@ -989,7 +989,10 @@ static void try_store_plan_stencil5(fd_plan *p, const std::vector<int32_t> &col0
     p->store5_ok = false;
     if (!p->store_allowed || p->store_ok || p->M != p->N || p->col1 - p->col0 < 16 || p->nnz_local < 16 || p->C < 5) return;
     auto cs = [&](int64_t j) { return colstart[(size_t)(j - p->col0)]; };
-    const int64_t jm = (p->col0 + p->col1) / 2;
+    // the grid width from a column with all five entries near the middle of the local range (the middle one itself may be the
+    // first or the last of its grid row)
+    int64_t jm = (p->col0 + p->col1) / 2;
+    for (int t = 0; t < 2 && jm + 1 < p->col1 && cs(jm + 1) - cs(jm) != 5; ++t) ++jm;
     if (cs(jm + 1) - cs(jm) != 5) return;
     const int64_t nx = (int64_t)rows[(size_t)cs(jm) + 4] - jm;
     if (nx < 4 || (nx & 1) || p->N % nx != 0 || p->N / nx < 3) return;

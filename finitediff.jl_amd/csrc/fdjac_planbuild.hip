@@ -789,11 +789,15 @@ static void device_store_stencil5(fd_plan *p, const void *d_colptr, const void *
     p->store5_ok = false;
     hipStream_t s = p->ctx->stream;
     if (!p->store_allowed || p->store_ok || p->M != p->N || p->col1 - p->col0 < 16 || C < 5 || C > 254 || has_none) return;
-    const int64_t jm = (p->col0 + p->col1) / 2;
-    char raw[2][16];
-    if (hipMemcpyAsync(raw[0], (const char *)d_colptr + (size_t)ib * (size_t)jm, 2 * (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
+    int64_t jm = (p->col0 + p->col1) / 2;
+    char raw[2][32];
+    if (jm + 3 >= p->col1) return;
+    if (hipMemcpyAsync(raw[0], (const char *)d_colptr + (size_t)ib * (size_t)jm, 4 * (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) return;
-    const int64_t a = load_idx(raw[0], ib, 0) - base, b = load_idx(raw[0], ib, 1) - base;
+    int t = 0;                                   // (the middle column may be the first or the last of its grid row)
+    while (t < 2 && load_idx(raw[0], ib, t + 1) - load_idx(raw[0], ib, t) != 5) ++t;
+    jm += t;
+    const int64_t a = load_idx(raw[0], ib, t) - base, b = load_idx(raw[0], ib, t + 1) - base;
     if (b - a != 5 || a < e0) return;
     if (hipMemcpyAsync(raw[1], (const char *)d_rowval + (size_t)ib * (size_t)(a + 4), (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) return;
