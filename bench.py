@@ -59,6 +59,11 @@ def parse():
     ap.add_argument("--eps", choices=["replicated", "sharded"], default="replicated",
                     help="N>1 step-size reduction: every rank reduces all of x (no collective on the critical path), or "
                          "each rank reduces its blocks and the partial sums are all-gathered (fd_plan_set_comm); same bits")
+    ap.add_argument("--x-layout", choices=["replicated", "sharded"], default="replicated",
+                    help="N>1: replicated = every rank holds all of x (the Jacobian of a given x: no exchange in the step); sharded = "
+                         "the time-stepping layout -- rank r holds its own part of x, every step starts with the neighbour halo "
+                         "exchange (fd_comm_halo_exchange) and the step-size reduction is sharded over contiguous ranges "
+                         "(FD_PLAN_EPS_CONTIGUOUS + fd_plan_set_comm): per step 2(l+u) values per link + one all-gather of the partial sums")
     ap.add_argument("--shard", choices=["columns", "colors"], default="columns",
                     help="N>1 decomposition: contiguous column ranges (default; needs a row-window-capable f!), "
                          "or colour ownership + all-reduce (any f!, at most C ranks; c4/c2 only)")
@@ -187,6 +192,7 @@ def main():
             comm_error = "%s: %s" % (type(e).__name__, e)
             sys.stderr.write("[bench rank %d] fd_comm_create failed (%s): the nzval assembly and the sharded solve are skipped\n" % (rank, comm_error))
     by_color = args.shard == "colors" and world > 1 and cfg in ("c2", "c4")
+    x_sharded = False
     lazy_ok = False
     vs = 4 if args.dtype == "f32" else 8          # bytes per value
     t_plan = time.perf_counter()
@@ -205,13 +211,21 @@ def main():
             plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, color_range=(ccuts[rank], ccuts[rank + 1]),
                                 dtype=np_dt)
         else:
-            cuts = S.partition_columns(colptr, world)
+            x_sharded = world > 1 and args.x_layout == "sharded"
+            if x_sharded:
+                # the time-stepping layout: cut the columns where the step-size reduction cuts x, so that every rank reduces
+                # exactly the part of x it owns (a throw-away plan tells where: the cuts depend on N and the colour count only)
+                probe = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(0, 16), dtype=np_dt, eps_contiguous=True)
+                cuts = S.partition_columns_at([probe.eps_shard_range(r, world) for r in range(world)], N)
+                del probe
+            else:
+                cuts = S.partition_columns(colptr, world)
             ranges = S.entry_ranges(colptr, cuts)
             counts = [b - a for a, b in ranges]
             c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
             xw = S.x_window(cuts, rank, N, 1, 1, 1)
             plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
-                                x_window=xw if world > 1 else None, dtype=np_dt)
+                                x_window=xw if world > 1 else None, dtype=np_dt, eps_contiguous=x_sharded)
         plan_build_ms = (time.perf_counter() - t_plan) * 1e3
         f = fd.BuiltinF("tridiag", N, ctx=ctx, dtype=np_dt)
         lazy_ok = True
@@ -302,7 +316,8 @@ def main():
     elif lazy_diff and cfg == "c3":
         bytes_min = (C * 8 * N + nnz * (8 + idx_b)) / N
         bytes_call_model = 9.0 + (9.0 + C * 8) + bytes_min
-    if world > 1 and args.eps == "sharded" and comm is not None:
+    eps_sharded = world > 1 and (args.eps == "sharded" or x_sharded) and not by_color
+    if eps_sharded and comm is not None:
         plan.set_comm(comm)
     gather_in_step = world > 1 and args.gather_in_step
 
@@ -339,7 +354,38 @@ def main():
 
     enqueue = plan.bind(f, x, [out])   # pointers resolved once: one foreign call per Jacobian, as from compiled code
 
+    # dry run (FDJAC_BENCH_BACKEND=gloo) of the sharded step-size reduction: the explicit pieces of the C ABI with the exchange
+    # staged through host memory -- fd_plan_eps_partials, all-gather of the slots, fd_plan_eps_finalize, FD_EPS_PRECOMPUTED
+    eps_host = None
+    if eps_sharded and comm is None:
+        pptr, slot = plan.eps_partials(x, rank, world)
+
+        class _Raw:   # the library's partial-sum buffer as a torch view (zero copy)
+            __cuda_array_interface__ = {"shape": (world * slot,), "typestr": "<f8", "data": (pptr, False), "version": 2}
+        eps_host = {"dev": torch.as_tensor(_Raw(), device=dev), "slot": slot, "all": torch.empty(world * slot, dtype=torch.float64)}
+        plan.set_eps_mode(True)
+
+    def pre_step():
+        """What precedes the Jacobian in a time-stepping loop whose x is sharded: the neighbour halo, then (dry run only --
+        with RCCL the library does it inside the call) the sharded reduction's exchange."""
+        if x_sharded:
+            if comm is not None:
+                comm.halo_exchange(x, c0, c1, 2)       # tridiagonal f! on the rows of the band (1,1): x[c0-2, c1+2)
+            else:
+                xh = x.cpu()
+                S.halo_exchange_host(xh, cuts, rank, 2, dist)
+                x.copy_(xh)
+        if eps_host is not None:
+            plan.eps_partials(x, rank, world)
+            sl = eps_host["slot"]
+            mine = eps_host["dev"][rank * sl:(rank + 1) * sl].cpu()
+            dist.all_gather_into_tensor(eps_host["all"], mine)
+            eps_host["dev"].copy_(eps_host["all"])
+            plan.eps_finalize()
+
     def step():
+        if x_sharded or eps_host is not None:
+            pre_step()
         enqueue()
         if gather_in_step:
             do_gather()
@@ -517,7 +563,7 @@ def main():
             "columns": [c0, c1], "stored_values": int(counts[rank] if world > 1 and not by_color else sum(counts)),
             "stages_ms": stages, "plan_build_ms": plan_build_ms, "check": check,
             "rccl": comm.info() if comm is not None else None, "backend": backend if world > 1 else None,
-            "eps": ("sharded" if (world > 1 and args.eps == "sharded" and comm is not None) else "replicated"),
+            "eps": ("sharded" if eps_sharded else "replicated"), "x_layout": "sharded (halo exchange per step)" if x_sharded else "replicated",
             "gather": gather_info, "consumer": consumer}
     sys.stderr.write("[bench rank %d] %s\n" % (rank, json.dumps(diag)))
     sys.stderr.flush()
@@ -573,7 +619,7 @@ def main():
                                   "built-in device f! behind fd_f_launch_lazy (1 launch: base + lazily perturbed points)"
                                   if f_mode == "lazy" else
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
-                       "eps_reduction": diag["eps"], "gather_in_step": bool(gather_in_step),
+                       "eps_reduction": diag["eps"], "x_layout": diag["x_layout"], "gather_in_step": bool(gather_in_step),
                        "collective_backend": (("rccl via libfdjac fd_comm_* (%s)" % comm.info()["library"]) if comm is not None
                                               else backend) if world > 1 else None},
             "median_ms_per_step": call_med,

@@ -271,6 +271,12 @@ class Comm:
         p, eb = self._dev(buf, "buf")
         _l.check(self.L.fd_comm_broadcast(self.handle, p, buf.numel(), eb, int(root)))
 
+    def halo_exchange(self, buf, own_begin, own_end, halo):
+        """fd_comm_halo_exchange: `buf` is a device vector in global indexing of which this rank owns [own_begin, own_end);
+        the `halo` values on either side of the range arrive from the neighbouring ranks (one group of <= 4 transfers)."""
+        p, eb = self._dev(buf, "buf")
+        _l.check(self.L.fd_comm_halo_exchange(self.handle, p, int(own_begin), int(own_end), int(halo), eb))
+
 
 class TridiagSolver:
     """fd_tridiag_solver: (alpha*I + beta*J) y = b on the device for a tridiagonal J in the storage the Jacobian plans
@@ -519,6 +525,12 @@ class Plan:
         self._comm_keep = comm
         _l.check(self.Lt.fd_plan_set_comm(self.handle, comm.handle if comm is not None else None))
 
+    def eps_shard_range(self, shard, nshards):
+        """fd_plan_eps_shard_range: the elements of x shard `shard` of `nshards` of the step-size reduction reads."""
+        a, b = C.c_int64(), C.c_int64()
+        _l.check(self.Lt.fd_plan_eps_shard_range(self.handle, int(shard), int(nshards), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def eps_partials(self, x, shard, nshards):
         """Enqueue shard `shard` of `nshards` of the masked sums of squares (fd_plan_eps_partials); returns
         (device address of the partial buffer, doubles per slot)."""
@@ -610,9 +622,10 @@ class Plan:
         return call
 
 
-def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None):
+def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
+    o.flags = _l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0
     if col_window is not None:
         o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
     if x_window is not None:
@@ -628,14 +641,14 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None, dtype=np.float64):
+              color_range=None, dtype=np.float64, eps_contiguous=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
     ctx = ctx or Context.default()
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
-    o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range)
+    o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous)
     h = C.c_void_p()
     cv = _i64(colorvec)
     if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):

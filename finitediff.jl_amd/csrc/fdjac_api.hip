@@ -139,6 +139,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
     // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
     // FDJAC_EPS_NT forces one, a call decides by which path it takes.
+    p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 0) != 0;
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
@@ -205,7 +206,10 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
             // uncapped 36.1 -- fewer partials for the finalize, enough loads in flight for the reduction)
             const int64_t mult = (cm && *cm) ? atoll(cm) : 4;
             const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
-            p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)p->ctx->num_cus * mult : ((int64_t)1 << 30));
+            // (a function of N alone -- 256 CUs x 4, not of the device the plan happens to live on: every rank of a sharded
+            //  reduction must cut the same blocks; fd_plan_set_comm verifies it)
+            p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)256 * mult : ((int64_t)1 << 30));
+            p->eps_tpb = p->eps_contig ? (int)((tiles + p->n_partial_blocks - 1) / p->n_partial_blocks) : 0;
             // (+ kMaxEpsShards rows: a sharded reduction pads the grid to a whole number of blocks per shard)
             p->partial_cap = ((int64_t)p->n_partial_blocks + kMaxEpsShards) * kRegColors;
             if ((rc = dev_alloc(&p->d_partial, p->partial_cap))) return rc;
@@ -2207,6 +2211,18 @@ int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     FD_REQUIRE(comm == nullptr || fdjac_comm_ctx(comm) == p->ctx, FD_ERR_ARG, "the communicator belongs to another context");
     FD_REQUIRE(comm == nullptr || fdjac_comm_nranks(comm) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
+    if (comm && eps_shardable(p)) {
+        // every rank must cut the SAME global grid of blocks (it is a function of N, the colour count and the map -- but a rank
+        // with another FDJAC_GRID_CAP / FDJAC_EPS_CONTIG would use other slots: mismatched all-gather counts hang, matched
+        // ones finalize garbage).  One tiny all-reduce at attach time settles it.
+        const double mine[4] = {(double)p->n_partial_blocks, -(double)p->n_partial_blocks, (double)p->eps_tpb, -(double)p->eps_tpb};
+        double got[4] = {0, 0, 0, 0};
+        const int rc = fdjac_comm_allreduce_max4(comm, mine, got);
+        if (rc) return rc;
+        FD_REQUIRE(got[0] == mine[0] && got[1] == mine[1] && got[2] == mine[2] && got[3] == mine[3], FD_ERR_COMM,
+                   "the ranks disagree on the step-size reduction's grid (this rank: %d blocks of %d tiles): same N, colours, "
+                   "FDJAC_GRID_CAP and FD_PLAN_EPS_CONTIGUOUS everywhere?", p->n_partial_blocks, p->eps_tpb);
+    }
     p->comm = comm;
     return FD_OK;
 }
@@ -2239,6 +2255,20 @@ int fd_plan_eps_finalize(fd_plan *p, double relstep, double absstep, double dir)
     }
     if (absstep < 0) absstep = relstep;
     return launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
+}
+
+int fd_plan_eps_shard_range(fd_plan *p, int shard, int nshards, int64_t *x_begin, int64_t *x_end)
+{
+    FD_REQUIRE(p && x_begin && x_end, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(nshards >= 1 && nshards <= kMaxEpsShards && shard >= 0 && shard < nshards, FD_ERR_ARG, "shard %d of %d", shard, nshards);
+    FD_REQUIRE(eps_shardable(p), FD_ERR_UNSUPPORTED, "this plan's step-size reduction cannot be sharded");
+    if (p->eps_tpb <= 0) { *x_begin = 0; *x_end = p->N; return FD_OK; }      // grid-stride: every block reads all over x
+    const int S = (p->n_partial_blocks + nshards - 1) / nshards;
+    const int64_t per_block = (int64_t)p->eps_tpb * 2048;                     // k_eps_partial_reg's tile: 4 x 512 elements
+    const int64_t b0 = std::min<int64_t>((int64_t)shard * S, p->n_partial_blocks), b1 = std::min<int64_t>(b0 + S, p->n_partial_blocks);
+    *x_begin = std::min<int64_t>(b0 * per_block, p->N);
+    *x_end = shard == nshards - 1 ? p->N : std::min<int64_t>(b1 * per_block, p->N);
+    return FD_OK;
 }
 
 int fd_plan_set_eps_mode(fd_plan *p, int mode)

@@ -11,7 +11,31 @@
 // per destination, with no staging copy (in-place all-gather / grouped send-recv straight out of the buffer the
 // decompression kernel wrote).
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// a build box without the RCCL headers: the handful of declarations the dlsym'd entry points need (RCCL's public ABI;
+// nothing here is linked -- the library is bound at run time or fd_comm_* returns FD_ERR_COMM)
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+ncclResult_t ncclGetVersion(int *version);
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char *ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+}
+#endif
 
 #include <cstring>
 #include <mutex>
@@ -212,24 +236,65 @@ int fd_comm_gatherv(fd_comm *c, const void *send, int64_t send_elems, void *recv
     FD_REQUIRE(send_elems == counts[c->rank], FD_ERR_ARG, "send_elems %lld != counts[rank] %lld", (long long)send_elems,
                (long long)counts[c->rank]);
     FD_REQUIRE(c->rank != root || recv != nullptr, FD_ERR_ARG, "recv is NULL on the root");
+    const Rccl *R = rccl();          // (before anything is enqueued: without RCCL nothing of the call happens)
+    if (!R) return FD_ERR_COMM;
     FD_HIP_CHECK(hipSetDevice(c->ctx->device));
     hipStream_t s = c->ctx->stream;
     char *rb = (char *)recv;
     if (c->rank == root && send_elems > 0 && send != (const void *)(rb + (size_t)displs[root] * (size_t)elem_bytes))
         FD_HIP_CHECK(hipMemcpyAsync(rb + (size_t)displs[root] * (size_t)elem_bytes, send, (size_t)send_elems * (size_t)elem_bytes,
                                     hipMemcpyDeviceToDevice, s));
+    // one group: every slice rides its own xGMI link into the root (7 concurrent point-to-point transfers at 8 ranks).
+    // The group is ALWAYS closed: a failing Send / Recv is remembered, ncclGroupEnd still runs (an open group would swallow
+    // every later collective of this thread), then the first error is reported.
+    FD_NCCL_CHECK(R, R->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    if (c->rank == root) {
+        for (int r = 0; r < c->nranks && first == ncclSuccess; ++r)
+            if (r != root && counts[r] > 0)
+                first = R->Recv(rb + (size_t)displs[r] * (size_t)elem_bytes, (size_t)counts[r], dt, r, c->comm, s);
+    } else if (send_elems > 0) {
+        first = R->Send(send, (size_t)send_elems, dt, root, c->comm, s);
+    }
+    const ncclResult_t ge = R->GroupEnd();
+    if (first == ncclSuccess) first = ge;
+    if (first != ncclSuccess) {
+        set_error("fd_comm_gatherv: RCCL point-to-point group failed: %s", R->GetErrorString(first));
+        return FD_ERR_COMM;
+    }
+    return FD_OK;
+}
+
+int fd_comm_halo_exchange(fd_comm *c, void *buf, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes)
+{
+    FD_REQUIRE(c && buf, FD_ERR_ARG, "NULL argument");
+    ncclDataType_t dt;
+    FD_REQUIRE(dtype_of(elem_bytes, &dt), FD_ERR_ARG, "elem_bytes must be 1, 4 or 8");
+    FD_REQUIRE(halo >= 0 && own_begin >= 0 && own_end >= own_begin, FD_ERR_ARG, "bad range [%lld,%lld) / halo %lld", (long long)own_begin,
+               (long long)own_end, (long long)halo);
+    FD_REQUIRE(halo == 0 || own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` = %lld elements", (long long)halo);
+    if (halo == 0 || c->nranks == 1) return FD_OK;
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
-    // one group: every slice rides its own xGMI link into the root (7 concurrent point-to-point transfers at 8 ranks)
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    hipStream_t s = c->ctx->stream;
+    char *b = (char *)buf;
+    const size_t eb = (size_t)elem_bytes, h = (size_t)halo;
+    const bool lo = c->rank > 0, hi = c->rank + 1 < c->nranks;
+    FD_REQUIRE(!lo || own_begin >= halo, FD_ERR_ARG, "no room for the lower halo below element %lld", (long long)own_begin);
+    // one group of <= 4 point-to-point transfers, each over the link to a neighbour; always closed (see fd_comm_gatherv)
     FD_NCCL_CHECK(R, R->GroupStart());
-    if (c->rank == root) {
-        for (int r = 0; r < c->nranks; ++r)
-            if (r != root && counts[r] > 0)
-                FD_NCCL_CHECK(R, R->Recv(rb + (size_t)displs[r] * (size_t)elem_bytes, (size_t)counts[r], dt, r, c->comm, s));
-    } else if (send_elems > 0) {
-        FD_NCCL_CHECK(R, R->Send(send, (size_t)send_elems, dt, root, c->comm, s));
+    ncclResult_t first = ncclSuccess;
+    if (lo && first == ncclSuccess) first = R->Send(b + (size_t)own_begin * eb, h, dt, c->rank - 1, c->comm, s);
+    if (hi && first == ncclSuccess) first = R->Send(b + ((size_t)own_end - h) * eb, h, dt, c->rank + 1, c->comm, s);
+    if (lo && first == ncclSuccess) first = R->Recv(b + ((size_t)own_begin - h) * eb, h, dt, c->rank - 1, c->comm, s);
+    if (hi && first == ncclSuccess) first = R->Recv(b + (size_t)own_end * eb, h, dt, c->rank + 1, c->comm, s);
+    const ncclResult_t ge = R->GroupEnd();
+    if (first == ncclSuccess) first = ge;
+    if (first != ncclSuccess) {
+        set_error("fd_comm_halo_exchange: RCCL point-to-point group failed: %s", R->GetErrorString(first));
+        return FD_ERR_COMM;
     }
-    FD_NCCL_CHECK(R, R->GroupEnd());
     return FD_OK;
 }
 
@@ -265,6 +330,25 @@ int fd_comm_broadcast(fd_comm *c, void *buf, int64_t n, int elem_bytes, int root
 // used by the sharded step-size reduction of both element-type builds (fdjac_api.hip); not part of the public ABI
 extern "C" {
 int fdjac_comm_allgather_f64(fd_comm *c, double *buf, int64_t slot_elems) { return fd_comm_allgather(c, buf, slot_elems, 8); }
+int fdjac_comm_allreduce_max4(fd_comm *c, const double *mine, double *out)
+{
+    FD_REQUIRE(c && mine && out, FD_ERR_ARG, "NULL argument");
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    double *d = nullptr;
+    FD_HIP_CHECK(hipMalloc((void **)&d, 4 * sizeof(double)));
+    int rc = FD_OK;
+    if (hipMemcpyAsync(d, mine, 4 * sizeof(double), hipMemcpyHostToDevice, c->ctx->stream) != hipSuccess) rc = FD_ERR_HIP;
+    if (!rc) {
+        const ncclResult_t r = R->AllReduce(d, d, 4, ncclFloat64, ncclMax, c->comm, c->ctx->stream);
+        if (r != ncclSuccess) { set_error("ncclAllReduce(max) failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
+    }
+    if (!rc && (hipMemcpyAsync(out, d, 4 * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(c->ctx->stream) != hipSuccess)) { set_error("fd_plan_set_comm: reading the grid check back failed"); rc = FD_ERR_HIP; }
+    (void)hipFree(d);
+    return rc;
+}
 int fdjac_comm_nranks(const fd_comm *c) { return c ? c->nranks : 1; }
 int fdjac_comm_rank(const fd_comm *c) { return c ? c->rank : 0; }
 const fd_ctx *fdjac_comm_ctx(const fd_comm *c) { return c ? c->ctx : nullptr; }

@@ -33,6 +33,7 @@
 #define fd_plan_eps_partials fd32_plan_eps_partials
 #define fd_plan_eps_finalize fd32_plan_eps_finalize
 #define fd_plan_set_eps_mode fd32_plan_set_eps_mode
+#define fd_plan_eps_shard_range fd32_plan_eps_shard_range
 #define fd_plan_enable_timing fd32_plan_enable_timing
 #define fd_plan_get_timings fd32_plan_get_timings
 #define fd_plan_get_timing_samples fd32_plan_get_timing_samples
@@ -64,6 +65,7 @@
 
 // communicator internals shared by both element-type builds (fdjac_comm.hip)
 extern "C" int fdjac_comm_allgather_f64(fd_comm *c, double *buf, int64_t slot_elems);
+extern "C" int fdjac_comm_allreduce_max4(fd_comm *c, const double *mine, double *out);   // host values, blocking (attach time)
 extern "C" int fdjac_comm_nranks(const fd_comm *c);
 extern "C" int fdjac_comm_rank(const fd_comm *c);
 extern "C" const fd_ctx *fdjac_comm_ctx(const fd_comm *c);
@@ -182,6 +184,9 @@ struct fd_plan {
     bool dma = false;              //   LDS-DMA staging in the row-window kernels (FDJAC_DMA=1)
     int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
     bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
+    int eps_tpb = 0;               //   > 0: the reduction's blocks sum CONTIGUOUS runs of this many tiles (FD_PLAN_EPS_CONTIGUOUS /
+                                   //   FDJAC_EPS_CONTIG=1): shard r of the reduction then reads only its own range of x
+    bool eps_contig = false;
     int eps_nt_forced = -1;        //   (-1: non-temporal on the hand-over path, plain when f!'s storing launch re-reads x)
     int cyc_C = 0, cyc_shift = 0;  // cyclic colours: color[j] == (j + cyc_shift) mod cyc_C for every column (0 = not cyclic);
                                    //   the reduction then computes the colours instead of reading them (FDJAC_EPS_CYCLIC=0: off)

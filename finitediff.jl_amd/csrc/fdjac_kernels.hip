@@ -61,7 +61,7 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
-                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total)
+                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total, int contig_tpb)
 {
     // The reduction is defined over a GLOBAL grid of grid_total blocks; this launch runs the blocks
     // [block_off, block_off + gridDim.x) of it (all of them on one GPU; one shard per rank when the reduction is
@@ -81,7 +81,18 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
         du = (kBlock * 2) % cyc_C;
         dr = (int)((((int64_t)grid_total - 1) * tile + (tile - (int64_t)(kEpsU - 1) * kBlock * 2)) % cyc_C);   // last u of a round -> first u of the next
     }
-    for (int64_t base = gblock * tile; base < n; base += (int64_t)grid_total * tile) {
+    // which tiles a block sums is part of the reduction's DEFINITION (the partial sums are added in block order): either
+    // grid-stride (block b: tiles b, b + G, ...; every block reads all over x) or, contig_tpb > 0, contiguous (block b: tiles
+    // [b * tpb, (b + 1) * tpb): a range of blocks reads a range of x -- what a rank that holds only its own part of x needs)
+    int64_t base0 = gblock * tile, base_step = (int64_t)grid_total * tile, base_end = n;
+    if (contig_tpb > 0) {
+        base0 = gblock * (int64_t)contig_tpb * tile;
+        base_step = tile;
+        const int64_t e = base0 + (int64_t)contig_tpb * tile;
+        base_end = e < n ? e : n;
+        if (CYC) { rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C); dr = du; }
+    }
+    for (int64_t base = base0; base < base_end; base += base_step) {
         r2_t v[kEpsU];
         int c0[kEpsU], c1[kEpsU];
 #pragma unroll
@@ -1450,7 +1461,7 @@ static int launch_eps_partial_t(fd_plan *p, const real_t *x, int b0, int nb)
     if (nb <= 0) return FD_OK;
 #define FD_EPS_REG(NCC, CY, NTT)                                                                                \
     hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nb), dim3(kBlock), 0, s, x,                   \
-                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P)
+                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P, p->eps_tpb)
 #define FD_EPS_REG_V(NCC)                                                                                       \
     do {                                                                                                        \
         if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); }     \

@@ -27,6 +27,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, INFO_LDS_DMA,
  INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE, INFO_ROLL, INFO_LAZY_DIFF, INFO_BAND_DIRECT, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE = 1, 2, 4, 8
+PLAN_EPS_CONTIGUOUS = 1
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
@@ -67,10 +68,11 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
+    "fd_plan_eps_shard_range",
 )
 
 
@@ -86,6 +88,7 @@ TYPED = (
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
+    "fd_plan_eps_shard_range",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -108,7 +111,7 @@ def typed(L, dtype):
 
 
 class PlanOpts(C.Structure):
-    _fields_ = [("fdtype", C.c_int32), ("reserved0", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
+    _fields_ = [("fdtype", C.c_int32), ("flags", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
                 ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64),
                 ("color_begin", C.c_int64), ("color_end", C.c_int64)]
 
@@ -200,6 +203,8 @@ def load():
     L.fd_comm_gatherv.argtypes = [vp, vp, i64, vp, C.POINTER(i64), C.POINTER(i64), i32, i32]
     L.fd_comm_allreduce_sum.argtypes = [vp, vp, i64, i32]
     L.fd_comm_broadcast.argtypes = [vp, vp, i64, i32, i32]
+    L.fd_comm_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
+    L.fd_plan_eps_shard_range.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.fd_plan_set_comm.argtypes = [vp, vp]
     L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]
     L.fd_plan_eps_finalize.argtypes = [vp, dbl, dbl, dbl]

@@ -33,6 +33,42 @@ def partition_columns(colptr, world):
     return np.maximum.accumulate(np.minimum(cuts, n))
 
 
+def partition_columns_at(bounds, n):
+    """Column cuts taken from the step-size reduction's shard ranges (`Plan.eps_shard_range(r, world)` of a plan created with
+    eps_contiguous=True): rank r then owns exactly the part of x it reduces, and a time-stepping loop keeps x sharded -- the
+    only per-step traffic is the halo (`fd_comm_halo_exchange`) and the all-gather of the partial sums."""
+    cuts = np.array([int(b[0]) for b in bounds] + [int(n)], dtype=np.int64)
+    cuts[0] = 0
+    return np.maximum.accumulate(np.minimum(cuts, n))
+
+
+def halo_exchange_host(x_full, cuts, rank, halo, dist=None, group=None):
+    """What fd_comm_halo_exchange does, on host tensors through torch.distributed point-to-point calls (gloo tests, dry runs):
+    `x_full` in global indexing, this rank owns [cuts[rank], cuts[rank+1])."""
+    if dist is None:
+        import torch.distributed as dist
+    world = len(cuts) - 1
+    a, b = int(cuts[rank]), int(cuts[rank + 1])
+    ops = []
+    if halo <= 0 or world == 1:
+        return x_full
+    send_lo = x_full[a:a + halo].clone()
+    send_hi = x_full[b - halo:b].clone()
+    recv_lo = x_full.new_empty(halo)
+    recv_hi = x_full.new_empty(halo)
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, send_lo, rank - 1, group), dist.P2POp(dist.irecv, recv_lo, rank - 1, group)]
+    if rank + 1 < world:
+        ops += [dist.P2POp(dist.isend, send_hi, rank + 1, group), dist.P2POp(dist.irecv, recv_hi, rank + 1, group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if rank > 0:
+        x_full[a - halo:a] = recv_lo
+    if rank + 1 < world:
+        x_full[b:b + halo] = recv_hi
+    return x_full
+
+
 def partition_colors(colorvec, world, weights=None):
     """Colour cuts (world+1,), 0-based: rank r owns colours [cuts[r], cuts[r+1]).  Balanced by the number of f!
     evaluations (one per colour), or by `weights[c]` (e.g. stored entries per colour) when given."""

@@ -132,7 +132,7 @@ typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *poin
 
 typedef struct fd_plan_opts {
     int32_t fdtype;        /* enum fd_fdtype */
-    int32_t reserved0;
+    int32_t flags;         /* FD_PLAN_* bits, 0 = defaults */
     int64_t col_begin;     /* column window [col_begin, col_end), 0-based; 0,0 = all columns.   */
     int64_t col_end;       /*   outputs then hold only the window's stored entries (multi-GPU)  */
     int64_t x_begin;       /* entries of x the windowed f! reads, [x_begin, x_end); 0,0 = all   */
@@ -146,6 +146,13 @@ typedef struct fd_plan_opts {
                            /*   from f! (an opaque f! is evaluated on full vectors), caps at C ranks, and the   */
                            /*   owners' outputs add up to the full result when outs start from zero.            */
 } fd_plan_opts;
+/* fd_plan_opts.flags */
+#define FD_PLAN_EPS_CONTIGUOUS 1   /* the step-size reduction's blocks sum CONTIGUOUS ranges of x (default: grid-stride).  Which   */
+                                   /* elements a block sums is part of the reduction's definition (the result differs by        */
+                                   /* rounding, ~1e-16 relative, between the two maps; each is deterministic).  With this map   */
+                                   /* shard r of a sharded reduction (fd_plan_set_comm, fd_plan_eps_partials) reads only        */
+                                   /* x[fd_plan_eps_shard_range(r)): a rank of a time-stepping loop that holds its own part of  */
+                                   /* x plus a halo needs nothing else -- no replicated x, no all-gather of x per step          */
 
 /* ---- context ------------------------------------------------------------------------- */
 /* stream: an existing hipStream_t to enqueue on (e.g. the caller's), NULL to create a private non-blocking stream,
@@ -391,6 +398,13 @@ int fd_comm_gatherv(fd_comm *comm, const void *send, int64_t send_elems, void *r
    so the sum is exact): in-place ncclAllReduce(sum).  elem_bytes 8 or 4. */
 int fd_comm_allreduce_sum(fd_comm *comm, void *buf, int64_t n, int elem_bytes);
 int fd_comm_broadcast(fd_comm *comm, void *buf, int64_t n, int elem_bytes, int root);   /* e.g. a new x from rank 0 */
+/* Neighbour exchange of the boundary values of a vector sharded by contiguous ranges -- the x of a time-stepping loop whose
+   rows are sharded like the Jacobian's columns (the sharded solve returns y by rows; the next Jacobian needs x plus the l + u
+   values beside its range, NOT all of x).  buf is a device vector in GLOBAL indexing of which this rank owns
+   [own_begin, own_end): it sends its first `halo` owned elements to rank - 1 and its last `halo` to rank + 1 and receives
+   buf[own_begin - halo, own_begin) from rank - 1 and buf[own_end, own_end + halo) from rank + 1: one group of at most four
+   point-to-point transfers (2 x halo elements per link).  The end ranks skip the neighbour they do not have. */
+int fd_comm_halo_exchange(fd_comm *comm, void *buf, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes);
 
 /* Sharded step-size reduction.  By default every rank reduces the whole (replicated) x -- no communication, identical
    step sizes everywhere.  With a communicator attached, rank r reduces only blocks r of nranks of the SAME global grid
@@ -411,6 +425,10 @@ int fd_plan_eps_partials(fd_plan *plan, const void *x_dev, int shard, int nshard
                          int64_t *slot_doubles_out);
 int fd_plan_eps_finalize(fd_plan *plan, double relstep, double absstep, double dir);
 int fd_plan_set_eps_mode(fd_plan *plan, int mode);
+/* The elements of x shard `shard` of `nshards` of the reduction reads, [*x_begin, *x_end): all of x for the default
+   grid-stride map, the shard's own contiguous range for plans created with FD_PLAN_EPS_CONTIGUOUS -- cut the column / row
+   ownership of a multi-GPU run at these boundaries and every rank reduces exactly what it owns. */
+int fd_plan_eps_shard_range(fd_plan *plan, int shard, int nshards, int64_t *x_begin, int64_t *x_end);
 
 /* ---- the consumer: tridiagonal solve with the Jacobian where fd_jacobian_async left it -----------
  * Solves (alpha*I + beta*J) y = b on the device for a tridiagonal J -- the linear system of an implicit / Rosenbrock
@@ -508,6 +526,7 @@ int fd32_plan_eps_partials(fd32_plan *plan, const void *x_dev, int shard, int ns
                            int64_t *slot_doubles_out);
 int fd32_plan_eps_finalize(fd32_plan *plan, double relstep, double absstep, double dir);
 int fd32_plan_set_eps_mode(fd32_plan *plan, int mode);
+int fd32_plan_eps_shard_range(fd32_plan *plan, int shard, int nshards, int64_t *x_begin, int64_t *x_end);
 int fd32_plan_enable_timing(fd32_plan *plan, int on);
 int fd32_plan_get_timings(fd32_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
 int fd32_plan_get_timing_samples(fd32_plan *plan, int stage, double *ms_out, int64_t cap, int64_t *n_out);

@@ -136,3 +136,57 @@ def test_column_ranges_and_gatherv_assemble_the_jacobian(comm1):
         comm1.gatherv(piece, assembled[a:b], [b - a], root=0)    # this rank's slice lands at its displacement
     comm1.ctx.synchronize()
     assert torch.equal(assembled, full)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("N", [10 ** 6 + 7, 300001])
+def test_contiguous_step_size_reduction_reads_only_the_shard(fdtype, N):
+    # FD_PLAN_EPS_CONTIGUOUS: the reduction's blocks sum contiguous ranges of x, so shard r of W reads only
+    # x[fd_plan_eps_shard_range(r, W)) -- proven by poisoning everything else with NaN -- and the step sizes / the Jacobian of
+    # the sharded reduction have the bits of the same plan's unsharded call (the map is part of the reduction's definition:
+    # against the default grid-stride map the step sizes agree to rounding)
+    C = 3
+    colors = P.cyclic_colors(N, C)
+    xh = np.random.default_rng(11).random(N) * 2 - 0.5
+    x = _dev(xh)
+    colptr, rowval = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    f = fd.BuiltinF("tridiag_nl", N)
+    ref_plan = fd.make_plan(J, J, colors, fdtype, eps_contiguous=True)
+    ref_plan.set_lazy(f)
+    ref = _nan(ref_plan.out_len(0))
+    ref_plan.jacobian(f, x, [ref])
+    eps_ref = ref_plan.epsilons()
+    strided = fd.make_plan(J, J, colors, fdtype)
+    strided.set_lazy(f)
+    tmp = _nan(strided.out_len(0))
+    strided.jacobian(f, x, [tmp])
+    assert np.allclose(strided.epsilons(), eps_ref, rtol=1e-13, atol=0)
+    assert strided.eps_shard_range(1, 4) == (0, N)            # grid-stride: every shard reads all over x
+    for W in (1, 2, 3, 8):
+        plan = fd.make_plan(J, J, colors, fdtype, eps_contiguous=True)
+        plan.set_lazy(f)
+        ranges = [plan.eps_shard_range(r, W) for r in range(W)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == N and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+        for r in reversed(range(W)):
+            a, b = ranges[r]
+            xs = torch.full_like(x, float("nan"))
+            xs[a:b] = x[a:b]                                   # this "rank" holds only its own part of x
+            plan.eps_partials(xs, r, W)
+            torch.cuda.synchronize()
+        plan.eps_finalize()
+        plan.set_eps_mode(True)
+        out = _nan(plan.out_len(0))
+        plan.jacobian(f, x, [out])
+        assert np.array_equal(plan.epsilons(), eps_ref), W
+        assert torch.equal(out, ref), W
+        # column cuts at the shard boundaries: windowed plans (all of them with the contiguous map) concatenate to the full result
+        cuts = S.partition_columns_at(ranges, N)
+        pieces = []
+        for r in range(W):
+            wp = fd.make_plan(J, J, colors, fdtype, col_window=(int(cuts[r]), int(cuts[r + 1])), eps_contiguous=True)
+            wp.set_lazy(f)
+            o = _nan(wp.out_len(0))
+            wp.jacobian(f, x, [o])
+            pieces.append(o)
+        assert torch.equal(torch.cat(pieces), ref), W

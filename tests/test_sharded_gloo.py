@@ -90,6 +90,75 @@ def test_two_rank_gather_gloo(tmp_path, oracle):
     assert out.stdout.count("ok") == 2
 
 
+HALO_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    from finitediff_jl_amd import sharded as S
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N, halo = 1000, 3
+    cuts = np.array([0, 430, 1000]) if world == 2 else S.partition_columns(np.arange(1, N + 2), world)
+    truth = torch.arange(N, dtype=torch.float64) * 0.5 + 1.0
+    x = torch.full((N,), float("nan"), dtype=torch.float64)
+    a, b = int(cuts[rank]), int(cuts[rank + 1])
+    x[a:b] = truth[a:b]                       # every rank holds its own part only
+    S.halo_exchange_host(x, cuts, rank, halo, dist)
+    lo, hi = max(a - halo, 0), min(b + halo, N)
+    assert torch.equal(x[lo:hi], truth[lo:hi]), "rank %%d: halo values wrong" %% rank
+    rest = torch.cat([x[:lo], x[hi:]])
+    assert bool(torch.isnan(rest).all()), "rank %%d: wrote outside own range + halo" %% rank
+    # the column cuts taken from the reduction's shard ranges
+    cuts2 = S.partition_columns_at([(0, 500), (500, 900), (900, 1000)], 1000)
+    assert cuts2.tolist() == [0, 500, 900, 1000]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_halo_exchange_gloo(tmp_path):
+    # the host-side mirror of fd_comm_halo_exchange (the x of a time-stepping loop stays sharded: 2 x halo values per link and step)
+    script = tmp_path / "hworker.py"
+    script.write_text(HALO_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29525", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29525", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("variant", ["x_sharded", "eps_sharded", "colors"])
+def test_bench_two_ranks_dry_run_variants(variant):
+    """bench.py's other N>1 decompositions end to end (two ranks sharing the one GPU, gloo transport): --x-layout sharded (halo
+    exchange + contiguous sharded step-size reduction before every Jacobian: the time-stepping layout), --eps sharded (the
+    explicit fd_plan_eps_partials / all-gather / fd_plan_eps_finalize pieces) and --shard colors (colour ownership +
+    all-reduce).  bench.py checks every stored value itself and exits non-zero if a check fails."""
+    import json
+    port = {"x_sharded": "29527", "eps_sharded": "29529", "colors": "29531"}[variant]
+    extra = {"x_sharded": ["--x-layout", "sharded"], "eps_sharded": ["--eps", "sharded"], "colors": ["--shard", "colors"]}[variant]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FDJAC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--size", "300001", "--soak-seconds", "0"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["result_check"]["ok"] and res["result_check"]["recomputed_from_nan_bit_identical"]
+    if variant == "x_sharded":
+        assert res["config"]["x_layout"].startswith("sharded") and res["config"]["eps_reduction"] == "sharded"
+    if variant == "eps_sharded":
+        assert res["config"]["eps_reduction"] == "sharded"
+    if variant == "colors":
+        assert res["config"]["parallelism"] == "colours x2"
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("in_step", [False, True], ids=["sharded_output", "gather_in_step"])
