@@ -132,7 +132,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
     p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
     p->cr_wg = env_int("FDJAC_COLRANGE_WG", 1) != 0;
-    p->dma = env_int("FDJAC_DMA", 0) != 0;
     p->list_U = env_int("FDJAC_TILE", 2);
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
@@ -143,9 +142,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
-    // opt-in: inside the pipeline the computed-index kernel measured 113-119 us against 103 us for the row windows
-    // (N = 10^7 tridiagonal, differences handed over), although it wins a hot loop of its own (81-86 us, scripts/ubench)
-    p->band_allowed = env_int("FDJAC_BAND_DIRECT", 0) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
     // round 3 (N = 10^7 tridiagonal: 0.18 -> 0.09 ms per Jacobian, bit-identical); FDJAC_LAZY_STORE=0 keeps the hand-over
@@ -299,71 +295,12 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
 //     that are served by the L2, traded for divergence-free 16-B loads (the gather kernels are TA-bound there).
 // rows / nzc: row and colour (>= 0; -1 = column without colour, written as 0; -2 = padding, never written) of
 // every output slot in storage order, padded to a multiple of kListPad.  Sets p->window on success.
-// LDS of one workgroup of the row-window kernels.  With LDS-DMA staging the raw windows of every array are kept
-// (the tile's colours of the perturbed points, plus fx or the minus points) in whole 1-KiB chunks.
-static size_t window_lds_bytes(bool dma, int fdtype, int max_slots, int max_ncol)
+// LDS of one workgroup of the row-window kernels: the differences of the tile's row windows, one array per colour.
+static size_t window_lds_bytes(int fdtype, int max_slots, int max_ncol)
 {
-    if (dma) {   // raw windows of every staged array, whole 1-KiB chunks
-        const size_t wp = ((size_t)max_slots + 127) & ~(size_t)127;
-        const size_t narr = fdtype == FD_CENTRAL ? 2 * (size_t)max_ncol : (size_t)max_ncol + 1;
-        return wp * narr * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc + kWinHeadBytes;
-    }
-    const size_t wp = (((size_t)max_slots + 31) & ~(size_t)31) + 2;   // differences, one array per colour
+    (void)fdtype;
+    const size_t wp = (((size_t)max_slots + 31) & ~(size_t)31) + 2;
     return wp * (size_t)max_ncol * sizeof(real_t) + sizeof(real_t) * (size_t)kWinMaxCol + 4 * (size_t)kW2Desc + kWinHeadBytes;
-}
-
-// Row strips.  The hand-off between f! and the decompression (C+1 arrays of M values, written once and read once) is the
-// largest stream of a Jacobian and does not fit the 256 MiB Infinity Cache at BASELINE's sizes (320 MB at N = 10^7, C = 3).
-// Cutting the call into K strips of consecutive tiles, each a pair (f! on the rows the strip's tiles read, decompression of
-// those tiles) that REUSES one scratch of M/K rows per point, keeps part of that hand-off on the die
-// (scripts/ubench/stripmine_probe.hip: 177 -> 138 us per step for the same bytes at K = 2; more strips lose to launch
-// ramps).  Needs a launcher that writes only the rows it is asked for (FD_LAZY_CAP_ROW_WINDOW).  Same work per tile and per
-// row => same bits.  wt: the tile descriptors (3 x int4 per tile).
-static void plan_row_strips(fd_plan *p, const std::vector<int4> &wt, size_t ntiles)
-{
-    p->strips = 1;
-    p->strip_tile.clear(); p->strip_rlo.clear(); p->strip_rhi.clear();
-    const char *fs = getenv("FDJAC_STRIPS");
-    int K = (fs && *fs) ? atoi(fs) : -1;
-    const int64_t rows_local = std::max<int64_t>(p->row1 - p->row0, 1);
-    const int pts = p->fdtype == FD_CENTRAL ? 2 : 1;
-    // OFF unless FDJAC_STRIPS=K asks for it.  Measured in the real pipeline (N = 10^7 tridiagonal forward, same process
-    // settings, profiles/r02_b_strips_ab.txt): K = 1: 0.219 ms per Jacobian, K = 2: 0.212, K = 3: 0.221, K = 4: 0.241 --
-    // f! + decompression drop from 192 to 183 us at K = 2 (the probe's 1.29x does not carry over: these kernels are not
-    // pure streams) and the extra launches eat the rest.  Kept as a tested, bit-identical option.
-    (void)rows_local; (void)pts;
-    if (!(fs && *fs)) return;
-    const bool forced = fs && *fs;
-    K = std::max(1, std::min(K, 64));
-    if (!forced && (int64_t)ntiles < (int64_t)K * 256) K = (int)std::max<int64_t>(1, (int64_t)ntiles / 256);   // a strip must still fill the chip
-    if ((int64_t)ntiles < K) K = (int)std::max<size_t>(ntiles, 1);
-    if (K <= 1 || p->C > kRegColors) return;
-    p->strip_tile.resize((size_t)K + 1);
-    p->strip_rlo.assign((size_t)K, 0);
-    p->strip_rhi.assign((size_t)K, 0);
-    int64_t maxrows = 0;
-    for (int k = 0; k <= K; ++k) p->strip_tile[(size_t)k] = (int64_t)ntiles * k / K;
-    for (int k = 0; k < K; ++k) {
-        int64_t lo = std::numeric_limits<int64_t>::max(), hi = 0;
-        for (int64_t t = p->strip_tile[(size_t)k]; t < p->strip_tile[(size_t)k + 1]; ++t) {
-            const int4 th = wt[3 * (size_t)t], wa = wt[3 * (size_t)t + 1], wb = wt[3 * (size_t)t + 2];
-            const int nwin = th.w & 0xFF;
-            const int rw[4] = {wa.x, wa.z, wb.x, wb.z}, en[4] = {wa.y, wa.w, wb.y, wb.w};
-            for (int q = 0; q < nwin; ++q) {
-                const int pairs = en[q] - (q ? en[q - 1] : 0);
-                lo = std::min<int64_t>(lo, rw[q]);
-                hi = std::max<int64_t>(hi, (int64_t)rw[q] + 2 * (int64_t)pairs);
-            }
-        }
-        if (hi <= lo) { lo = 0; hi = 0; }            // a strip without coloured entries reads nothing
-        lo &= ~(int64_t)31;                          // 256-B aligned strip base
-        hi = std::min<int64_t>((hi + 1) & ~(int64_t)1, round_up(p->M, 2));
-        p->strip_rlo[(size_t)k] = lo;
-        p->strip_rhi[(size_t)k] = std::max(hi, lo);
-        maxrows = std::max(maxrows, p->strip_rhi[(size_t)k] - lo);
-    }
-    p->strip_ld = round_up(maxrows + 2, 32);
-    p->strips = K;
 }
 
 // single_only: accept a tile only if its rows form ONE window (what the device builder's k_pb_tiles can describe)
@@ -471,7 +408,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
                 if (!force_t && T == 2048 && prefer_small) continue;
                 WinBuild w = build_windows(T, false);
                 if (!w.ok) continue;
-                const size_t lds = window_lds_bytes(p->dma, p->fdtype, w.max_slots, w.max_ncol);
+                const size_t lds = window_lds_bytes(p->fdtype, w.max_slots, w.max_ncol);
                 if (lds > (size_t)kWinMaxLds) continue;
                 const bool cheap = w.overread <= 1.25 || (scattered && w.overread <= kWinMaxOverread);
                 if (!(cheap || force_w == 1)) continue;
@@ -532,101 +469,10 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
             p->win_tile = best.T;
             p->win_pairs = best.max_slots / 2;
             p->win_ncol = best.max_ncol;
-            plan_row_strips(p, best.wt, padded / (size_t)best.T);
             if ((rc = dev_upload(&p->d_wtiles, best.wt))) return rc;
             if ((rc = dev_upload(&p->d_wcode, best.code))) return rc;
         }
     }
-    return FD_OK;
-}
-
-// Rolling row windows (k_decompress_roll) for 2-D stencil patterns in natural ordering (stride s between grid rows).
-// The 2-D tiles below load (R+2)(L+2)/(RL) = 1.4 values per stored f! value in short, line-straddling segments and are
-// bound by the request rate between the CUs and the L2, not by HBM.  Here ONE WAVE owns a column strip
-// of L = 128 - 2*hl columns and walks H grid rows down it: per grid row it loads one 1-KiB-aligned-ish window of every
-// f! array (64 lanes x one 16-B pair: a single dense request per array), keeps the differences of the last four rows in an
-// LDS ring, and emits the entries of row g from the rows g-1, g, g+1 -- every value is loaded (H+2)/H * 128/L = 1.08 times,
-// the loads of row g+2 are in flight while row g is emitted, and there is no barrier between waves.  Entries are addressed
-// by 16-bit codes as in the other window kernels: bits 0-6 offset in the window row, bits 7-8 row (g-1, g, g+1), bits 11-13
-// colour.  Segments are sized so that the whole launch is ONE round of resident waves.
-// Requirements: the whole matrix (no column window), even stride, every entry inside the three windows of its column's
-// strip; otherwise the 2-D tiles take over.
-static int try_roll_plan(fd_plan *p, const std::vector<int32_t> &rows, const std::vector<int32_t> &nzc,
-                         const std::vector<int64_t> &colstart, int64_t s, int halo, int ecmax)
-{
-    int rc;
-    // Opt-in (FDJAC_ROLL=1): on MI355X the rolling kernel measured 302 us on the 4000x2500 5-point pattern against 267-281 us
-    // for the 2-D tiles it would replace (profiles/r02_d_win_ab.txt), so the tiles stay the default.
-    const char *fr = getenv("FDJAC_ROLL");
-    if (!(fr && *fr && atoi(fr) != 0)) return FD_OK;
-    if (p->col0 != 0 || p->col1 != p->N || (s & 1) || p->nnz_local <= 0) return FD_OK;
-    const int hl = std::max(2, (halo + 1) & ~1);
-    if (hl > 16) return FD_OK;
-    const int L = kRollW - 2 * hl;
-    if ((int64_t)ecmax * L + 2 > kRollMaxCodes) return FD_OK;
-    int32_t cmin = std::numeric_limits<int32_t>::max(), cmax = -1;
-    for (int64_t e = 0; e < p->nnz_local; ++e)
-        if (nzc[(size_t)e] >= 0) { cmin = std::min(cmin, nzc[(size_t)e]); cmax = std::max(cmax, nzc[(size_t)e]); }
-    if (cmax < 0 || cmax - cmin + 1 > kWinMaxCol) return FD_OK;
-    const int ncol = cmax - cmin + 1;
-    const int64_t nG = (p->N + s - 1) / s, nI = (s + L - 1) / L;
-    // one round of resident waves: LDS ring of 4 rows x ncol colours x 128 values per wave
-    const size_t lds_wave = sizeof(real_t) * (size_t)(4 * ncol * kRollW + kWinMaxCol);
-    const int64_t wpc = std::max<int64_t>(1, std::min<int64_t>(16, (int64_t)(150 * 1024) / (int64_t)lds_wave));
-    const int64_t resident = (int64_t)std::max(p->ctx->num_cus, 1) * wpc;
-    const char *fh = getenv("FDJAC_ROLL_H");
-    int64_t H = (fh && *fh) ? atoll(fh) : (nG * nI + resident - 1) / resident;
-    H = std::max<int64_t>(H, 4);
-    const int64_t nS = (nG + H - 1) / H;
-    std::vector<int> segs, runs;
-    std::vector<uint16_t> code;
-    segs.reserve((size_t)(nS * nI) * 4);
-    runs.reserve((size_t)(nG * nI) * 6);
-    code.reserve((size_t)p->nnz_local + (size_t)(nG * nI) * 2 + 8);
-    int64_t covered = 0;
-    for (int64_t S = 0; S < nS; ++S)
-        for (int64_t I = 0; I < nI; ++I) {
-            const int64_t ga = S * H, gb = std::min<int64_t>((S + 1) * H, nG);
-            segs.push_back((int)I); segs.push_back((int)ga); segs.push_back((int)gb); segs.push_back((int)(runs.size() / 6));
-            for (int64_t g = ga; g < gb; ++g) {
-                const int64_t ka = std::min<int64_t>(g * s + I * L, p->N), kb = std::min<int64_t>(std::min<int64_t>(g * s + (I + 1) * L, (g + 1) * s), p->N);
-                const int64_t a = ka < kb ? colstart[(size_t)ka] : 0, b = ka < kb ? colstart[(size_t)kb] : 0;
-                const int64_t pbase = a & ~(int64_t)1, code0 = (int64_t)code.size();
-                if (a & 1) code.push_back(0x8000);                    // code slot parity == output parity: 16-B pairs
-                for (int64_t e = a; e < b; ++e) {
-                    uint16_t c = 0x8000;
-                    if (nzc[(size_t)e] == -1) c = 0x4000;
-                    else if (nzc[(size_t)e] >= 0) {
-                        const int64_t w = (int64_t)rows[(size_t)e] - (I * L - hl);       // element index relative to the strip's window column 0
-                        const int64_t gr = w >= 0 ? w / s : -((-w + s - 1) / s);          // floor
-                        const int64_t off = w - gr * s, rr = gr - (g - 1);
-                        if (rr < 0 || rr > 2 || off < 0 || off >= kRollW) return FD_OK;   // not a 3-row stencil of this strip
-                        c = (uint16_t)((rr * kRollW + off) | ((nzc[(size_t)e] - cmin) << 11));
-                    }
-                    code.push_back(c);
-                }
-                if ((code.size() - (size_t)code0) & 1) code.push_back(0x8000);
-                const int64_t nent = (int64_t)code.size() - code0;
-                if (nent > kRollMaxCodes) return FD_OK;
-                runs.push_back((int)(uint32_t)(pbase & 0xFFFFFFFFll)); runs.push_back((int)(pbase >> 32));
-                runs.push_back((int)(uint32_t)(code0 & 0xFFFFFFFFll)); runs.push_back((int)(code0 >> 32));
-                runs.push_back((int)nent); runs.push_back(0);
-                covered += b - a;
-            }
-        }
-    if (covered != p->nnz_local) return FD_OK;
-    code.push_back(0x8000); code.push_back(0x8000);
-    p->window = true;
-    p->window2d = true;      // (a 2-D stencil plan: FD_INFO_WINDOW2D; FD_INFO_ROLL tells the two kernels apart)
-    p->roll = true;
-    p->roll_nseg = nS * nI; p->roll_s = s; p->roll_L = L; p->roll_hl = hl; p->roll_cmin = cmin; p->roll_ncol = ncol; p->roll_H = (int)H;
-    p->win_tile = 0;
-    p->win_pairs = kRollW / 2;
-    p->win_ncol = ncol;
-    p->win_overread = ((double)(H + 2) / (double)H) * ((double)kRollW / (double)L) * (double)p->N * ncol / (double)std::max<int64_t>(p->nnz_local, 1);
-    if ((rc = dev_upload(&p->d_rseg, segs))) return rc;
-    if ((rc = dev_upload(&p->d_rrun, runs))) return rc;
-    if ((rc = dev_upload(&p->d_wcode, code))) return rc;
     return FD_OK;
 }
 
@@ -646,12 +492,13 @@ static bool w2_shape(const fd_plan *p, int ecmax, int halo, int *L_out, int *R_o
     if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
     if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
         const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
-        while (R > 2 && window_lds_bytes(p->dma, p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+        while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
         while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
     }
     *L_out = L; *R_out = R;
     return R >= 2;
 }
+
 
 // 2-D (strided) tiles for the row-window kernel (k_decompress_window2d): 2-D stencil patterns in natural ordering.
 // Detection: apart from a few near-diagonal offsets (|row - col| <= 8) every entry sits one "stride" s away from the
@@ -698,8 +545,6 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
         }
         if (bad * 1000 > total || ecmax < 1 || ecmax > 32) return FD_OK;   // > 0.1 % of the entries off-stride
     }
-    if ((rc = try_roll_plan(p, rows, nzc, colstart, s, halo, ecmax))) return rc;
-    if (p->roll) return FD_OK;
     int L, R;
     if (!w2_shape(p, ecmax, halo, &L, &R)) return FD_OK;
 
@@ -791,7 +636,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
         }
     if (covered != p->nnz_local) return FD_OK;   // every stored entry must belong to exactly one run
     const double overread = elems / (double)std::max<int64_t>(p->nnz_local, 1);
-    const size_t lds = window_lds_bytes(p->dma, p->fdtype, max_slots, max_ncol);
+    const size_t lds = window_lds_bytes(p->fdtype, max_slots, max_ncol);
     if (max_slots == 0 || lds > (size_t)kWinMaxLds || overread > 2.2) return FD_OK;
     code.push_back(0x8000); code.push_back(0x8000);   // the last pair load may touch one code past the end
     p->window = true;
@@ -867,14 +712,13 @@ static inline void band_tile_desc(int64_t t, int T, int64_t nnz_local, int64_t o
 
 // Uniform band with cyclic colours (shared by the host and the device builder).  The columns [ju0, ju1) hold w consecutive
 // rows j - u .. j - u + w - 1 each, the first of them starts at the local entry e_ju0; colours are (j + shift) mod C for
-// every column.  Sets the band parameters, the tile range of the computed-index kernel (opt-in) and the tile range whose
-// descriptors the row-window kernel computes (wt_host: the plan's 1-D tile descriptors if the caller has them on the host).
+// every column.  Sets the band parameters and the tile range whose descriptors the row-window kernel computes (wt_host: the
+// plan's 1-D tile descriptors if the caller has them on the host).
 static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, int64_t ju0, int64_t ju1, int64_t C, int shift,
                              const int4 *wt_host = nullptr)
 {
-    p->band_ok = false;
     p->bd_t0 = p->bd_t1 = 0;
-    if (!(p->band_allowed || p->bd_allowed) || !p->window || p->window2d || p->win_tile <= 0 || w < 1 || w > 64 || C < 1 || C > 64 || ju1 <= ju0) return;
+    if (!p->bd_allowed || !p->window || p->window2d || p->win_tile <= 0 || w < 1 || w > 64 || C < 1 || C > 64 || ju1 <= ju0) return;
     const int64_t T = p->win_tile, all_tiles = (p->nnz_local + T - 1) / T;
     const int64_t pu0 = e_ju0, pu1 = e_ju0 + w * (ju1 - ju0);
     const int64_t off = w * ju0 - e_ju0;
@@ -891,10 +735,6 @@ static void finish_band_plan(fd_plan *p, int64_t w, int64_t u, int64_t e_ju0, in
         const uint32_t top = (uint32_t)(off + p->nnz_local + 1);
         for (uint32_t n : {0u, 1u, (uint32_t)w - 1, (uint32_t)w, top - 1, top, top / 2, 0x7FFFFFFFu, (uint32_t)((top / (uint32_t)w) * (uint32_t)w), (uint32_t)((top / (uint32_t)w) * (uint32_t)w) - 1u})
             if (fd_div31(n, p->band_mw) != n / (uint32_t)w || fd_div31(n, p->band_mc) != n / (uint32_t)C) return;
-    }
-    if (p->band_allowed && 2 * (t1 - t0) >= all_tiles) {                // (fewer tiles: not worth a second kernel)
-        p->band_ok = true;
-        p->band_t0 = t0; p->band_t1 = t1;
     }
     // computed descriptors: the largest run of tiles around the middle of [t0, t1) whose STORED descriptor is what
     // band_tile_desc computes (regular tiles: periodic codes, every colour of the band, one row window)
@@ -938,7 +778,7 @@ static bool colors_cyclic(const std::vector<int32_t> &col0, int64_t C, int *shif
 // column's number of consecutive rows and an affine colptr
 static void try_band_plan_csc(fd_plan *p, const std::vector<int32_t> &col0, const std::vector<int32_t> &rows, const std::vector<int64_t> &colstart)
 {
-    if (!(p->band_allowed || p->bd_allowed) || !p->window || p->window2d || p->col1 - p->col0 < 4) return;
+    if (!p->bd_allowed || !p->window || p->window2d || p->col1 - p->col0 < 4) return;
     int shift = 0;
     if (!colors_cyclic(col0, p->C, &shift)) return;
     const int64_t jm = (p->col0 + p->col1) / 2;
@@ -1201,7 +1041,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_rseg, p->d_rrun, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
+    void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2};
     for (void *q : ptrs)
@@ -1217,7 +1057,7 @@ int fd_plan_destroy(fd_plan *p)
 
 static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *colptr, const void *rowval,
                       int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
-                      const fd_plan_opts *opts, fd_plan **out)
+                      const fd_plan_opts *opts, fd_plan **out, bool device_declined = false)
 {
     FD_REQUIRE(colptr && rowval, FD_ERR_ARG, "colptr/rowval is NULL");
     FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
@@ -1244,7 +1084,8 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
     {
         const char *pd = getenv("FDJAC_PLAN_DEVICE");
         const int want = (pd && *pd) ? atoi(pd) : -1;      // -1 auto (>= 2^17 entries), 0 never, 1 whenever possible
-        if (kind == K_CSC && want != 0 && (want == 1 || e1 - e0 >= ((int64_t)1 << 17))) {
+        // (device_declined: fd_plan_create_csc_device already ran the device builder on this pattern and it declined)
+        if (kind == K_CSC && want != 0 && !device_declined && (want == 1 || e1 - e0 >= ((int64_t)1 << 17))) {
             const size_t ib = (size_t)idx_bytes;
             void *d_cp = nullptr, *d_rv = nullptr, *d_cv = nullptr;
             const int64_t ncols = p->col1 - p->col0;
@@ -1361,7 +1202,7 @@ int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *col
     FD_REQUIRE(nnz_all >= 0, FD_ERR_SHAPE, "colptr is not monotone");
     std::vector<char> h_rv(ib * (size_t)std::max<int64_t>(nnz_all, 1));
     if (nnz_all > 0) FD_HIP_CHECK(hipMemcpy(h_rv.data(), rowval_dev, ib * (size_t)nnz_all, hipMemcpyDeviceToHost));
-    return csc_common(ctx, K_CSC, M, N, h_cp.data(), h_rv.data(), idx_bytes, idx_base, h_cv.data(), color_bytes, opts, out);
+    return csc_common(ctx, K_CSC, M, N, h_cp.data(), h_rv.data(), idx_bytes, idx_base, h_cv.data(), color_bytes, opts, out, true);
 }
 
 // FNV-1a over the plan's compiled pattern (device arrays copied back) and its scalar parameters: two plans with the
@@ -1386,9 +1227,9 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
     };
     const int64_t scal[] = {p->kind, p->fdtype, p->M, p->N, p->C, p->color8, p->col0, p->col1, p->row0, p->row1, p->nnz_local,
                             p->entry_begin, p->window, p->window2d, p->sorted_gather, p->win_tile, p->win_pairs, p->win_ncol,
-                            p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift, p->strips,
+                            p->win_per_P, p->win_per_S, p->win_per_magic, p->has_none, p->cyc_C, p->cyc_shift,
                             p->n_partial_blocks, p->chunkB, p->nchunks, (int64_t)(p->win_overread * 1e6),
-                            p->band_ok, p->band_t0, p->band_t1, p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
+                            p->band_off, p->band_C, p->band_w, p->band_u, p->band_shift,
                             (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1, p->store_ok, p->store_l, p->store_u,
                             p->store5_ok, p->store5_nx, p->store5_ny};
     mix(scal, sizeof scal);
@@ -1724,11 +1565,8 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
         *value = (p->small_ok && p->N <= kSmallN && p->C > 0 && p->C <= kRegColors && p->kind != K_DENSE &&
                   p->fdtype != FD_COMPLEX) ? 1 : 0;
         break;
-    case FD_INFO_LDS_DMA: *value = p->dma ? 1 : 0; break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
     case FD_INFO_EPS_NT: *value = (p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !store_active(p)) ? 1 : 0; break;
-    case FD_INFO_ROLL: *value = p->roll ? 1 : 0; break;
-    case FD_INFO_BAND_DIRECT: *value = p->band_ok ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
     case FD_INFO_LAZY_STORE:
         *value = store_active(p) ? 1 : 0;
@@ -1737,7 +1575,6 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
         break;
     case FD_INFO_BUILT_ON_DEVICE: *value = p->built_on_device ? 1 : 0; break;
-    case FD_INFO_STRIPS: *value = (p->window && !p->window2d && p->nchunks == 1) ? p->strips : 1; break;
     default: set_error("unknown info key %d", key); return FD_ERR_ARG;
     }
     return FD_OK;
@@ -1961,10 +1798,6 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const int c_hi = (int)std::min<int64_t>(oc1, cl + p->chunkB);
         const int B = c_hi - c_lo;
         bool lazy_done = false, imag_only = false;
-        // row strips: K x (f! on the strip's rows into the shared scratch, decompression of the strip's tiles)
-        const bool strip_mode = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_ROW_WINDOW) && p->strips > 1 && p->window &&
-                                !p->window2d && p->nchunks == 1 && full_colors && (p->kind == K_CSC || p->kind == K_BANDED) &&
-                                (p->fdtype != FD_COMPLEX || (p->lazy_caps & FD_LAZY_CAP_IMAG_ONLY)) && !small;
         // a launcher that can, hands over DIFFERENCES (f(point) - f(x), or f(plus) - f(minus)): no f(x) pass / half the f!
         // arrays, and the decompression reads one array per colour (the forward kernels with fx = 0 and, for central
         // differences, the doubled step sizes: (a - 0.0) / (2 eps) -- the bits of the plain path)
@@ -2013,54 +1846,6 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 diff_base_counted = true;
                 continue;
             }
-        }
-        if (strip_mode) {
-            const bool io = p->fdtype == FD_COMPLEX;      // (imag-only: the f! arrays are real, fx is the zero vector)
-            real_t *eps_plain = p->d_eps;
-            if (want_diff && p->fdtype == FD_CENTRAL && !p->eps2_fresh) {
-                const int rc = launch_scale(p->ctx, p->d_eps2 + c_lo, p->d_eps + c_lo, B, (real_t)2);
-                if (rc) return rc;
-            }
-            bool first_part = true;
-            for (int k = 0; k < p->strips; ++k) {
-                const int64_t rlo = p->strip_rlo[(size_t)k], rhi = p->strip_rhi[(size_t)k];
-                const int64_t t0 = p->strip_tile[(size_t)k], t1 = p->strip_tile[(size_t)k + 1];
-                if (t1 <= t0) continue;
-                {
-                    Span sp(p, FD_STAGE_F);
-                    fd_lazy_points lp = {};
-                    lp.x = x_dev;
-                    lp.color = p->d_color;
-                    lp.eps = p->d_eps;
-                    lp.base_out = (base_pending && !want_diff) ? p->d_fx - rlo : nullptr;
-                    lp.color_bytes = p->color8 ? 1 : 4;
-                    lp.c_lo = c_lo;
-                    lp.ncolors = B;
-                    lp.pts = p->pts;
-                    lp.is_complex = io ? 1 : 0;
-                    lp.imag_only = io ? 1 : 0;
-                    lp.part = k;
-                    lp.nparts = p->strips;
-                    lp.diff = want_diff ? ((p->fdtype == FD_FORWARD && first_part) ? 2 : 1) : 0;
-                    first_part = false;
-                    const int64_t r0 = std::max<int64_t>(rlo, p->row0 & ~(int64_t)1), r1 = std::min<int64_t>(rhi, p->row1);
-                    const int rc = (rhi > rlo) ? p->lazy_fn(fctx, p->d_FX - rlo, &lp, p->strip_ld, r0, r1, (void *)s) : 0;
-                    FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "lazy f! launcher returned %d for row strip %d of %d", rc, k, p->strips);
-                }
-                {
-                    Span sp(p, FD_STAGE_DECOMPRESS);
-                    p->cur_tile0 = t0; p->cur_ntl = t1 - t0; p->cur_shift = rlo; p->cur_ld = p->strip_ld;
-                    const real_t *fxs = (io || want_diff) ? p->d_zero : (base_pending ? p->d_fx - rlo : fx);
-                    if (want_diff && p->fdtype == FD_CENTRAL) p->d_eps = p->d_eps2;
-                    const int rc = launch_decompress(p, fxs, c_lo, c_hi, outs, (io || want_diff) ? (int)FD_FORWARD : p->fdtype);
-                    p->d_eps = eps_plain;
-                    p->cur_tile0 = 0; p->cur_ntl = -1; p->cur_shift = 0; p->cur_ld = 0;
-                    if (rc) return rc;
-                }
-            }
-            p->fcalls_last += (int64_t)B * p->pts + (base_pending ? 1 : 0);
-            base_pending = false;
-            continue;
         }
         bool diff_done = false;
         if (p->lazy_fn) {

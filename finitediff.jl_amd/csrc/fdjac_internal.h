@@ -125,8 +125,6 @@ constexpr double kWinMaxOverread = 4.0;  // and this many f! values loaded per s
 constexpr int kW2Desc = 64;          // ints per tile descriptor
 constexpr int kW2MaxWin = 12;        // row windows per tile
 constexpr int kW2MaxRun = 8;         // column runs per tile
-constexpr int kRollW = 128;          // rolling row windows: elements per window row (64 lanes x one pair)
-constexpr int kRollMaxCodes = 1024;  //   codes of one (strip, grid row) run: 8 rounds of 128
 
 // Exact floor(n / d) for every n < 2^31 by one 64-bit multiply (Granlund-Montgomery: m = ceil(2^(31+l) / d), l = ceil(log2 d),
 // so m < 2^32 and n * m < 2^63): the multiplier and the shift travel packed in one 64-bit kernel argument.
@@ -181,7 +179,6 @@ struct fd_plan {
     bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
     bool cr_wg = true;             //   K_COLRANGE: one workgroup per 32 columns (FDJAC_COLRANGE_WG != 0)
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
-    bool dma = false;              //   LDS-DMA staging in the row-window kernels (FDJAC_DMA=1)
     int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
     bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
     int eps_tpb = 0;               //   > 0: the reduction's blocks sum CONTIGUOUS runs of this many tiles (FD_PLAN_EPS_CONTIGUOUS /
@@ -207,22 +204,14 @@ struct fd_plan {
     bool window = false;
     int4 *d_wtiles = nullptr;      //   3 x int4 per tile: {first colour, colours, row pairs, windows}, 4 x {first row, end pair}
     int win_tile = 0;              //   entries per tile (2048 or 1024)
-    bool roll = false;             //   rolling row windows (k_decompress_roll): 2-D stencils, one wave walks a column strip
-    int *d_rseg = nullptr;         //     4 ints per segment: strip, first grid row, end grid row, first run
-    int *d_rrun = nullptr;         //     6 ints per (segment, grid row): output base (int64, even), first code (int64), codes, 0
-    int64_t roll_nseg = 0, roll_s = 0;
-    int roll_L = 0, roll_hl = 0, roll_cmin = 0, roll_ncol = 0, roll_H = 0;
     bool window2d = false;         //   2-D (strided) tiles: d_w2desc[kW2Desc * ntiles], codes in tile order
     int *d_w2desc = nullptr;
-    // uniform band with cyclic colours (k_decompress_band): the whole tiles [band_t0, band_t1) of the 1-D row-window plan
-    // are decompressed with computed indices -- local entry p <-> Q = p + band_off = band_w * j + k, row j - band_u + k,
-    // colour (j + band_shift) mod band_C; band_mw / band_mc = fd_magic31(band_w), fd_magic31(band_C): exact dividers for n < 2^31
-    bool band_allowed = false;     //   FDJAC_BAND_DIRECT=1 (opt-in: not faster inside the pipeline, see apply_opts)
-    bool band_ok = false;
-    int64_t band_t0 = 0, band_t1 = 0, band_off = 0, band_C = 0;
+    // uniform band with cyclic colours: local entry p <-> Q = p + band_off = band_w * j + k, row j - band_u + k, colour
+    // (j + band_shift) mod band_C; band_mw / band_mc = fd_magic31(band_w), fd_magic31(band_C): exact dividers for n < 2^31
+    int64_t band_off = 0, band_C = 0;
     int band_w = 0, band_u = 0, band_shift = 0;
     uint64_t band_mw = 0, band_mc = 0;
-    // ... and, independently of that kernel: the row-window kernel COMPUTES the descriptors of the tiles [bd_t0, bd_t1)
+    // the row-window kernel COMPUTES the descriptors of the tiles [bd_t0, bd_t1)
     // from the same band parameters instead of loading them (verified against the stored descriptors when the plan is
     // built) -- the descriptor load is one of two dependent global round trips of a workgroup's lifetime
     // the pattern is verified to be the exact band include/fdjac_device.h describes (CSC: corners included; BandedMatrix /
@@ -241,15 +230,6 @@ struct fd_plan {
     int win_pairs = 0;             //   max row pairs of any tile (LDS pitch = 2*win_pairs doubles)
     int win_ncol = 0;              //   max colours of any tile
     int win_per_P = 0, win_per_S = 0, win_per_magic = 0;   // periodic entry codes of regular tiles (0 = none)
-    // row strips (1-D row-window tiles, launchers with FD_LAZY_CAP_ROW_WINDOW): the call runs as `strips` pairs of
-    // (f! on the strip's rows, decompression of the strip's tiles) that reuse ONE scratch of strip_ld rows per point,
-    // small enough to stay in the 256 MiB Infinity Cache between the two launches
-    int strips = 1;
-    std::vector<int64_t> strip_tile;            //   strips + 1 tile boundaries
-    std::vector<int64_t> strip_rlo, strip_rhi;  //   rows each strip's tiles read: [rlo (multiple of 32), rhi (even))
-    int64_t strip_ld = 0;                       //   scratch pitch (rows per point) in strip mode
-    int64_t cur_tile0 = 0, cur_ntl = -1;        //   tile range of the decompression launch in flight (-1 = all tiles)
-    int64_t cur_shift = 0, cur_ld = 0;          //   the batched f! arrays start at d_FX - cur_shift with pitch cur_ld (0 = ldf)
     double win_overread = 0;       //   dense window elements loaded per stored entry (1 = no waste)
     int64_t nnz_local = 0;
     int64_t entry_begin = 0;       // global index of the first local stored entry

@@ -547,16 +547,6 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     }
 }
 
-// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane names its own 16-B global source, the wave's 64 x 16 B land
-// linearly at a wave-uniform LDS address.  No staging VGPRs, no ds_write pass, and a workgroup can put a whole tile's
-// window loads in flight back to back -- one memory round trip per tile instead of one per loop iteration.
-typedef __attribute__((address_space(3))) void fd_lds_void;
-typedef const __attribute__((address_space(1))) void fd_glb_void;
-__device__ __forceinline__ void glds16(const real_t *g, real_t *l)
-{
-    __builtin_amdgcn_global_load_lds((fd_glb_void *)g, (fd_lds_void *)l, 16, 0, 0);
-}
-
 // K3c  the same decompression for LOCALLY BANDED patterns (tridiagonal / banded CSC, block patterns
 //   with few colours per tile): the rows of a tile of kSortTile storage-ordered entries fall into a
 //   short window [rmin, rmin + 2*npairs) and use ncol <= NCT consecutive colours (both found at plan
@@ -572,7 +562,7 @@ __device__ __forceinline__ void glds16(const real_t *g, real_t *l)
 //   concatenated), bits 11-13 colour - cmin, bit 14 "column
 //   has no colour" (entry is written as 0), bit 15 "padding" (not a stored entry).
 //   Same operations on the same operands as k_decompress_list => bit-identical results.
-template <int MODE, int NCT, bool FXB_VEC, int U, bool DMA>
+template <int MODE, int NCT, bool FXB_VEC, int U>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict__ wtiles,
                     const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
@@ -636,26 +626,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
     }
     if (threadIdx.x < NCT) s_eps[threadIdx.x] = ((int)threadIdx.x < ncol) ? eps[cb0 + threadIdx.x] : 1.0;
 
-    if constexpr (DMA) {
-        // phase 2 (LDS-DMA): the raw window values of every staged array -- the tile's ncol colours of FXa, then fx
-        // (forward) or the same colours of FXb (central) -- go straight to LDS, 64 row pairs (1 KiB) per instruction
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int narr = (MODE == 0) ? ncol + 1 : 2 * ncol;
-        const int nch = (npairs + 63) >> 6;
-        if (ncol > 0)
-            for (int ch = 0; ch < nch; ++ch) {
-                int i = ch * 64 + lane;
-                i = i < npairs ? i : npairs - 1;          // tail lanes re-load the last pair (their LDS slots are padding)
-                const int64_t row = i < e0 ? (int64_t)rw0 + 2 * i
-                                  : i < e1 ? (int64_t)rw1 + 2 * (i - e0)
-                                  : i < e2 ? (int64_t)rw2 + 2 * (i - e1) : (int64_t)rw3 + 2 * (i - e2);
-                for (int a = wave; a < narr; a += kBlock / 64) {
-                    const real_t *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
-                                    : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
-                    glds16(g, s_win + (size_t)a * wp + ch * 128);
-                }
-            }
-    } else {
+    {
     // phase 2: dense window loads -> differences -> LDS.  (The quotient is formed in phase 3, once per stored
         // entry: windows of scattered patterns hold values no entry of this tile uses, and an IEEE division is ~50
         // cycles per wave.)
@@ -722,7 +693,6 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
             real_t df = s_win[at];
-            if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];   // fx | FXb colour
             const real_t e = s_eps[valid ? cs : 0];
             const real_t v = (MODE == 1) ? df / (2 * e) : df / e;
             q[h] = valid ? v : 0.0;
@@ -748,7 +718,7 @@ k_decompress_window(const uint32_t *__restrict__ wcode2, const int4 *__restrict_
 //   tile order.  Descriptor (kW2Desc ints per tile): [0] first colour [1] colours [2] window pairs [3] windows
 //   [4] runs [5] entries (runs padded to even) [6,7] first code (int64); [8+2k, 9+2k] window k: first row, end pair;
 //   [32+3r..34+3r] run r: first output position (int64), end entry.  Same arithmetic as k_decompress_window.
-template <int MODE, int NCT, bool FXB_VEC, bool DMA>
+template <int MODE, int NCT, bool FXB_VEC>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict__ desc,
                       const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
@@ -783,25 +753,7 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
         tcode[it] = e < nent ? *reinterpret_cast<const uint32_t *>(wcode + code0 + e) : 0x80008000u;
     }
 
-    if constexpr (DMA) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int narr = (MODE == 0) ? ncol + 1 : 2 * ncol;
-        const int nch = (npairs + 63) >> 6;
-        if (ncol > 0)
-            for (int ch = 0; ch < nch; ++ch) {
-                int i = ch * 64 + lane;
-                i = i < npairs ? i : npairs - 1;
-                int k = 0;
-                while (k + 1 < nwin && i >= s_desc[9 + 2 * k]) ++k;
-                const int pbase = k ? s_desc[7 + 2 * k] : 0;
-                const int64_t row = (int64_t)s_desc[8 + 2 * k] + 2 * (i - pbase);
-                for (int a = wave; a < narr; a += kBlock / 64) {
-                    const real_t *g = a < ncol ? FXa + (int64_t)(cb0 - c_lo + a) * ld + row
-                                    : (MODE == 0 ? FXb + row : FXb + (int64_t)(cb0 - c_lo + a - ncol) * ld + row);
-                    glds16(g, s_win + (size_t)a * wp + ch * 128);
-                }
-            }
-    } else {
+    {
 #pragma unroll 1
         for (int i = threadIdx.x; i < npairs; i += kBlock) {
             int k = 0;
@@ -865,7 +817,6 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
             const int at = valid ? cs * wp + (int)(cd & 0x7FFu) : 0;
             real_t df = s_win[at];
-            if constexpr (DMA) df = df - s_win[at + (MODE == 0 ? (ncol - (valid ? cs : 0)) : ncol) * wp];
             const real_t ee = s_eps[valid ? cs : 0];
             const real_t v = (MODE == 1) ? df / (2 * ee) : df / ee;
             q[h] = valid ? v : 0.0;
@@ -878,168 +829,6 @@ k_decompress_window2d(const uint16_t *__restrict__ wcode, const int *__restrict_
             if (w[0]) out[p] = q[0];
             if (w[1]) out[p + 1] = q[1];
         }
-    }
-}
-
-// K3e  rolling row windows (plan: try_roll_plan).  One WAVE (a 64-thread workgroup) owns a column strip of a 2-D stencil
-//   pattern and walks a segment of grid rows g0 .. g1-1 down it.  Row g' of the strip is one window of kRollW = 128
-//   consecutive f! values starting at g'*s + I*L - hl (even): lane l owns the pair 2l, 2l+1, so every array of a row is ONE
-//   dense 1-KiB wave load.  The differences of rows g-1, g, g+1 sit in an LDS ring of four rows while the loads of row g+2
-//   are in flight; the entries of row g (one contiguous run of nzval) are decoded from 16-bit codes (offset | row << 7 |
-//   colour << 11) and leave with 16-B stores (code slots and output positions share their parity).
-//   Same operations on the same operands as k_decompress_window2d / _list => bit-identical results.
-template <int MODE, int NCT, bool FXB_VEC>
-__global__ void __launch_bounds__(64)
-k_decompress_roll(const int *__restrict__ segs, const int *__restrict__ runs, const uint16_t *__restrict__ wcode,
-                  const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
-                  const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int nsegs, int64_t s, int L,
-                  int hl, int cmin, int ncol_all, int ncolp, int vec_ok)
-{
-    extern __shared__ real_t s_roll[];                 // kWinMaxCol step sizes, then ring[4][ncolp][kRollW]
-    real_t *s_eps = s_roll;
-    real_t *ring = s_roll + kWinMaxCol;
-    const int lane = threadIdx.x;
-    const int seg = (vec_ok & 4) ? nsegs - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int I = segs[4 * seg], g0 = segs[4 * seg + 1], g1 = segs[4 * seg + 2], run0 = segs[4 * seg + 3];
-    int cb0 = cmin > c_lo ? cmin : c_lo, cb1 = cmin + ncol_all < c_hi ? cmin + ncol_all : c_hi;
-    const int ncol = cb1 > cb0 ? cb1 - cb0 : 0;        // colours of the strip that belong to the current chunk
-    const int cshift = cmin - cb0;
-    if (lane < kWinMaxCol) s_eps[lane] = (lane < ncol) ? eps[cb0 + lane] : (real_t)1;
-    const int64_t wbase = (int64_t)I * L - hl + 2 * lane;     // this lane's pair inside a window row, relative to g'*s
-
-    // kRollDepth rows in flight, each in its own register set: with one row in flight a wave spends a full memory latency
-    // per grid row (measured 7.6 us per row, 356 us for config 3); the loads of row g+1+d are issued d rows ahead
-    constexpr int kRollDepth = 3;
-    d2_t pa_[kRollDepth][NCT], pb_[kRollDepth][NCT];
-    auto issue = [&](auto K, int64_t g) {              // loads of grid row g into register set K (rows outside the vector read as zero)
-        d2_t(&pa)[NCT] = pa_[decltype(K)::value];
-        d2_t(&pb)[NCT] = pb_[decltype(K)::value];
-        const int64_t row = g * s + wbase;
-        const bool in0 = (g >= 0) & (row >= 0) & (row < M), in1 = (g >= 0) & (row + 1 >= 0) & (row + 1 < M);
-        d2_t b = {0.0, 0.0};
-        if (MODE == 0 && FXb != nullptr) {
-            if (FXB_VEC && in0 && in1) b = *reinterpret_cast<const d2_t *>(FXb + row);
-            else { if (in0) b.x = FXb[row]; if (in1) b.y = FXb[row + 1]; }
-        }
-#pragma unroll
-        for (int cc = 0; cc < NCT; ++cc) {
-            pa[cc] = d2_t{0.0, 0.0};
-            pb[cc] = b;
-            if (cc < ncol) {
-                const int64_t at = (int64_t)(cb0 - c_lo + cc) * ld + row;
-                if (in0 && in1) {
-                    if (MODE == 2) {
-                        const d2_t p0 = *reinterpret_cast<const d2_t *>(FXa + at * 2);
-                        const d2_t p1 = *reinterpret_cast<const d2_t *>(FXa + at * 2 + 2);
-                        pa[cc] = d2_t{p0.y, p1.y};
-                    } else {
-                        pa[cc] = *reinterpret_cast<const d2_t *>(FXa + at);
-                        if (MODE == 1) pb[cc] = *reinterpret_cast<const d2_t *>(FXb + at);
-                    }
-                } else {   // the first / last pair of the vector
-                    if (in0) { pa[cc].x = MODE == 2 ? FXa[at * 2 + 1] : FXa[at]; if (MODE == 1) pb[cc].x = FXb[at]; }
-                    if (in1) { pa[cc].y = MODE == 2 ? FXa[(at + 1) * 2 + 1] : FXa[at + 1]; if (MODE == 1) pb[cc].y = FXb[at + 1]; }
-                    if (MODE == 1) { if (!in0) pb[cc].x = 0.0; if (!in1) pb[cc].y = 0.0; }
-                }
-            }
-        }
-    };
-    auto park = [&](auto K, int64_t g) {               // differences of register set K -> ring row g & 3
-        d2_t(&pa)[NCT] = pa_[decltype(K)::value];
-        d2_t(&pb)[NCT] = pb_[decltype(K)::value];
-        real_t *dst = ring + (size_t)((int)(g & 3) * ncolp) * kRollW + 2 * lane;
-#pragma unroll
-        for (int cc = 0; cc < NCT; ++cc)
-            if (cc < ncol) {
-                const d2_t df = (MODE == 2) ? pa[cc] : d2_t{pa[cc].x - pb[cc].x, pa[cc].y - pb[cc].y};
-                *reinterpret_cast<d2_t *>(dst + (size_t)cc * kRollW) = df;
-            }
-    };
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>;
-    issue(K0{}, (int64_t)g0 - 1); issue(K1{}, (int64_t)g0);
-    park(K0{}, (int64_t)g0 - 1);  park(K1{}, (int64_t)g0);
-    // rows g0+1, g0+2, g0+3 in flight in sets 0, 1, 2 (rows beyond g1 are never needed)
-    issue(K0{}, (int64_t)g0 + 1);
-    if (g0 + 2 <= g1) issue(K1{}, (int64_t)g0 + 2);
-    if (g0 + 3 <= g1) issue(K2{}, (int64_t)g0 + 3);
-    constexpr int kIt = kRollMaxCodes / 128;
-    // The entry codes are pipelined as well: set K holds the run descriptor and the codes of the row it emits; while row
-    // g is emitted, the codes of row g+1 (their address comes from a descriptor loaded one row earlier) and the descriptor of
-    // row g+2 are in flight.  Without this every row waited for two dependent global round trips before its first entry.
-    int ri_[kRollDepth][5];
-    uint32_t tcode_[kRollDepth][kIt];
-    auto load_info = [&](auto K, int g) {              // (wave-uniform address: scalar loads)
-        int(&ri)[5] = ri_[decltype(K)::value];
-        if (g < g1) {
-            const int *src = runs + 6 * (size_t)(run0 + (g - g0));
-#pragma unroll
-            for (int q = 0; q < 5; ++q) ri[q] = src[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) ri[q] = 0;
-        }
-    };
-    auto load_codes = [&](auto K) {
-        const int(&ri)[5] = ri_[decltype(K)::value];
-        uint32_t(&tcode)[kIt] = tcode_[decltype(K)::value];
-        const int64_t code0 = ((int64_t)(uint32_t)ri[2]) | ((int64_t)ri[3] << 32);
-        const int nent = ri[4];
-#pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int e = 2 * lane + 128 * it;
-            tcode[it] = e < nent ? *reinterpret_cast<const uint32_t *>(wcode + code0 + e) : 0x80008000u;
-        }
-    };
-    load_info(K0{}, g0); load_info(K1{}, g0 + 1);
-    load_codes(K0{});
-    // one grid row: its register set holds row g+1; after parking it, the set is reused for row g+1+kRollDepth
-    auto body = [&](auto K, auto KN, auto KNN, int g) {
-        const int(&ri)[5] = ri_[decltype(K)::value];
-        const uint32_t(&tcode)[kIt] = tcode_[decltype(K)::value];
-        const int64_t pbase = ((int64_t)(uint32_t)ri[0]) | ((int64_t)ri[1] << 32);
-        const int nent = ri[4];
-        load_codes(KN);                                // codes of row g+1 (descriptor loaded during row g-1)
-        load_info(KNN, g + 2);                         // descriptor of row g+2
-        park(K, (int64_t)g + 1);                       // waits for row g+1 (issued kRollDepth rows ago)
-        if (g + 1 + kRollDepth <= g1) issue(K, (int64_t)g + 1 + kRollDepth);
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            if (128 * it >= nent) break;
-            const int e = 2 * lane + 128 * it;
-            const uint32_t code = tcode[it];
-            real_t q[2];
-            bool w[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned cd = (code >> (16 * h)) & 0xFFFFu;
-                const int cs = (int)((cd >> 11) & 7u) + cshift;
-                const bool colored = (cd & 0xC000u) == 0;
-                const bool valid = colored & ((unsigned)cs < (unsigned)ncol);
-                const int rr = (int)((cd >> 7) & 3u), off = (int)(cd & 0x7Fu);
-                const int at = valid ? ((((g - 1 + rr) & 3) * ncolp + cs) * kRollW + off) : 0;
-                const real_t df = ring[at];
-                const real_t ee = s_eps[valid ? cs : 0];
-                const real_t v = (MODE == 1) ? df / (2 * ee) : df / ee;
-                q[h] = valid ? v : 0.0;
-                w[h] = valid | (((cd & 0x4000u) != 0) & (c_lo == 0));
-            }
-            const int64_t pp = pbase + e;
-            if (w[0] & w[1] & ((vec_ok & 1) != 0)) {
-                *reinterpret_cast<d2_t *>(out + pp) = d2_t{q[0], q[1]};
-            } else {
-                if (w[0]) out[pp] = q[0];
-                if (w[1]) out[pp + 1] = q[1];
-            }
-        }
-        __syncthreads();                               // the ring slot of row g-1 is free for row g+3
-    };
-    for (int g = g0; g < g1; g += kRollDepth) {
-        body(K0{}, K1{}, K2{}, g);
-        if (g + 1 < g1) body(K1{}, K2{}, K0{}, g + 1);
-        if (g + 2 < g1) body(K2{}, K0{}, K1{}, g + 2);
     }
 }
 
@@ -1429,7 +1218,9 @@ static int64_t g_capmult = -1;
 // 115.4 -> 114.5 us depending on buffer placement, 5-point central 307 -> 301 us, block-banded complex step
 // (k_decompress_colrange_wg) 112 -> 103 us; neutral when everything fits).
 // Same work per tile => same bits.  FDJAC_REVERSE=0 restores front-to-back order (read per launch: tests toggle it).
-static inline bool tile_order_reversed() { return env_i64("FDJAC_REVERSE", 1) != 0; }
+// every decompression kernel walks its tiles from the last one to the first: the f! batch was written front to back by the launch
+// before, so its end is what the 256 MiB Infinity Cache still holds ("tile order")
+static inline bool tile_order_reversed() { return true; }
 
 static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
 
@@ -1564,156 +1355,51 @@ int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B)
 #undef FD_DISPATCH
 }
 
-// ---------------------------------------------------------------------------------------------
-// Uniform bands with cyclic colours (tridiagonal / banded SparseMatrixCSC away from the corners, BandedMatrix storage):
-// local entry p <-> Q = p + off = w*j + k (column j, slot k of w), row r = j - u + k, colour (j + shift) mod C.  Nothing
-// is loaded but the f! values themselves: every thread computes the (row, colour) of its two consecutive entries,
-// gathers them (8-B loads that neighbouring lanes coalesce: consecutive entries of a column are consecutive rows of one
-// array) and stores 16-B pairs.  No descriptor, no LDS staging, no barrier.  In a hot loop of its own it runs at the speed
-// of a linear copy (scripts/ubench/band_direct_probe.hip: 81-86 us against 79 us for 480 MB at N = 10^7); INSIDE the
-// pipeline -- behind f!'s 240 MB of fresh stores -- it needs 113-119 us where the row-window kernel needs 103 us (the call is
-// bound by its total HBM traffic, and the windows' long contiguous reads use the DRAM better than 8-B gathers over
-// three arrays).  Opt-in therefore (FDJAC_BAND_DIRECT=1, FD_INFO_BAND_DIRECT).  Same operations on the same operands as
-// the row-window kernel: same bits.  Entries outside [p0, p1) (truncated corner columns) stay with the row-window kernel.
-// ---------------------------------------------------------------------------------------------
-template <int MODE, int U>
-__global__ void __launch_bounds__(kBlock)
-k_decompress_band(const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld, int64_t M,
-                  const real_t *__restrict__ eps, int c_lo, int c_hi, real_t *__restrict__ out, int64_t p0, int64_t p1,
-                  int64_t off, int w, int u, int C, int shift, uint64_t mw, uint64_t mc, int reversed)
-{
-    const int64_t ntiles = (p1 - p0 + 2 * kBlock * U - 1) / (2 * kBlock * U);
-    const int64_t xt = xcd_tile(blockIdx.x, ntiles);
-    if (xt >= ntiles) return;
-    const int64_t tile = reversed ? ntiles - 1 - xt : xt;       // reversed tile order, see tile_order_reversed()
-    const int lane = threadIdx.x & 63;
-    const real_t my_eps = (lane < c_hi - c_lo) ? eps[c_lo + lane] : (real_t)1;     // (c_hi - c_lo <= 64: colour c's step size sits in lane c - c_lo)
-    real_t q[U][2];
-    bool wr[U][2];
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int64_t p = p0 + tile * (2 * kBlock * U) + uu * (2 * kBlock) + 2 * (int64_t)threadIdx.x;
-        const uint32_t Q = (uint32_t)(p + h + off);
-        const uint32_t j = fd_div31(Q, mw), k = Q - j * (uint32_t)w;
-        const uint32_t cj = j + (uint32_t)shift;
-        const int c = (int)(cj - fd_div31(cj, mc) * (uint32_t)C);
-        const int64_t r = (int64_t)j - u + k;
-        const bool live = p + h < p1;
-        const bool inside = live & (r >= 0) & (r < M);
-        const bool mine = (c >= c_lo) & (c < c_hi);
-        const bool ld_ok = inside & mine;
-        const int64_t at = ld_ok ? (int64_t)(c - c_lo) * ld + r : 0;
-        real_t a, b = (real_t)0;
-        if (MODE == 2) a = FXa[2 * at + 1];
-        else a = FXa[at];
-        if (MODE == 0 && FXb != nullptr) b = FXb[ld_ok ? r : 0];
-        if (MODE == 1) b = FXb[at];
-        const real_t e = __shfl(my_eps, mine ? c - c_lo : 0, 64);
-        real_t v;
-        if (MODE == 0) v = (a - b) / e;
-        else if (MODE == 1) v = (a - b) / (2 * e);
-        else v = a / e;
-        q[uu][h] = ld_ok ? v : (real_t)0;
-        // slots outside the matrix (BandedMatrix corners) are written as 0 by the call that owns colour 0
-        wr[uu][h] = ld_ok | (live & !inside & (c_lo == 0));
-    }
-#pragma unroll
-    for (int uu = 0; uu < U; ++uu) {
-        const int64_t p = p0 + tile * (2 * kBlock * U) + uu * (2 * kBlock) + 2 * (int64_t)threadIdx.x;
-        if (wr[uu][0] & wr[uu][1]) *reinterpret_cast<r2_t *>(out + p) = r2_t{q[uu][0], q[uu][1]};
-        else if (wr[uu][0]) out[p] = q[uu][0];
-        else if (wr[uu][1]) out[p + 1] = q[uu][1];
-    }
-}
-
 template <int MODE>
 static void launch_window_m(fd_plan *p, const real_t *fx, const real_t *FXa, const real_t *FXb, int c_lo, int c_hi,
                             real_t *out)
 {
     hipStream_t s = p->ctx->stream;
-    // LDS-DMA staging is bit-identical but measured no faster on MI355X (tridiagonal forward 123 vs 124 us) and slower
-    // when it doubles the LDS tile (5-point central: 364 vs 312 us -- half the workgroups per CU): opt-in, FDJAC_DMA=1
-    const bool dma_off = !p->dma;   // (fixed at plan creation)
     // fx is the plan's own padded, 256-B aligned array unless the caller passed f_in
-    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->d_fx - p->cur_shift) || (fx == p->fx_batch_row) || (fx == p->d_zero);
+    const bool fxvec = (MODE != 0) || (fx == p->d_fx) || (fx == p->fx_batch_row) || (fx == p->d_zero);
     // the imaginary parts of an imag-only complex step arrive as a real array with fx = the plan's all-zero vector:
     // a - 0.0 == a, so the kernels are told not to load it at all
     const bool fx_zero = (MODE == 0) && p->d_zero != nullptr && fx == p->d_zero;
     if (fx_zero) FXb = nullptr;
-    const bool dma = (MODE != 2) && fxvec && !fx_zero && !dma_off && sizeof(real_t) == 8;   // LDS-DMA staging of the raw windows (16-B pairs)
-    // LDS pitch between colours: whole 1-KiB DMA chunks, or (register path) a pitch that is 2 mod 32 elements so
-    // that neighbouring colours start 4 banks apart (entries of neighbouring columns read neighbouring rows of
-    // DIFFERENT colours; a pitch of 0 mod 32 puts them all on the same banks)
-    // (measured neutral on MI355X -- the LDS is not the bottleneck of these kernels -- but it is the smaller tile)
-    const int wp = dma ? ((2 * p->win_pairs + 127) & ~127) : (((2 * p->win_pairs + 31) & ~31) + 2);
-    const int narr = dma ? (MODE == 0 ? p->win_ncol + 1 : 2 * p->win_ncol) : p->win_ncol;
-    const int vok = ((((uintptr_t)out) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
-    const int64_t ldw = p->cur_ld > 0 ? p->cur_ld : p->ldf;   // pitch of the batched f! arrays (row strips: the strip scratch)
-    if (p->roll) {
-        const int ncolp = p->roll_ncol;
-        const size_t shr = sizeof(real_t) * ((size_t)4 * (size_t)ncolp * kRollW + kWinMaxCol);
-#define FD_LAUNCH_ROLL(NCT, FV)                                                                                         \
-        hipLaunchKernelGGL((k_decompress_roll<MODE, NCT, FV>), dim3((unsigned)p->roll_nseg), dim3(64), shr, s, p->d_rseg,   \
-                           p->d_rrun, p->d_wcode, FXa, FXb, ldw, p->M, p->d_eps, c_lo, c_hi, out, (int)p->roll_nseg, p->roll_s, \
-                           p->roll_L, p->roll_hl, p->roll_cmin, p->roll_ncol, ncolp, vok)
-        if (p->roll_ncol <= 4) { if (fxvec) FD_LAUNCH_ROLL(4, true); else FD_LAUNCH_ROLL(4, false); }
-        else if (p->roll_ncol <= 6) { if (fxvec) FD_LAUNCH_ROLL(6, true); else FD_LAUNCH_ROLL(6, false); }
-        else { if (fxvec) FD_LAUNCH_ROLL(kWinMaxCol, true); else FD_LAUNCH_ROLL(kWinMaxCol, false); }
-#undef FD_LAUNCH_ROLL
-        return;
-    }
+    // LDS pitch between colours: 2 mod 32 elements, so that neighbouring colours start 4 banks apart (entries of neighbouring
+    // columns read neighbouring rows of DIFFERENT colours; a pitch of 0 mod 32 puts them all on the same banks)
+    const int wp = ((2 * p->win_pairs + 31) & ~31) + 2;
+    const int narr = p->win_ncol;
+    // (tiles are walked back to front: the end of the f! batch is what the Infinity Cache still holds -- DESIGN section 5)
+    const int vok = ((((uintptr_t)out) & kPairMask) == 0 ? 1 : 0) | 4;
     if (p->window2d) {
         const int64_t g2 = 8 * xcd_chunks(p->w2_ntiles);
         const size_t shm2 = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + 4 * (size_t)kW2Desc;
-#define FD_LAUNCH_W2(NCT, FV, DM)                                                                                  \
-        hipLaunchKernelGGL((k_decompress_window2d<MODE, NCT, FV, DM>), dim3((unsigned)g2), dim3(kBlock), shm2, s,    \
+#define FD_LAUNCH_W2(NCT, FV)                                                                                      \
+        hipLaunchKernelGGL((k_decompress_window2d<MODE, NCT, FV>), dim3((unsigned)g2), dim3(kBlock), shm2, s,        \
                            p->d_wcode, p->d_w2desc, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo, c_hi, out, p->w2_ntiles,  \
                            vok, wp)
-        if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_W2(kWinMaxCol, true, true); return; } }
-        if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_W2(4, true, false); else FD_LAUNCH_W2(4, false, false); }
-        else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_W2(6, true, false); else FD_LAUNCH_W2(6, false, false); }
-        else { if (fxvec) FD_LAUNCH_W2(kWinMaxCol, true, false); else FD_LAUNCH_W2(kWinMaxCol, false, false); }
+        if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_W2(4, true); else FD_LAUNCH_W2(4, false); }
+        else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_W2(6, true); else FD_LAUNCH_W2(6, false); }
+        else { if (fxvec) FD_LAUNCH_W2(kWinMaxCol, true); else FD_LAUNCH_W2(kWinMaxCol, false); }
 #undef FD_LAUNCH_W2
         return;
     }
-    const int64_t all_tiles = (p->nnz_local + p->win_tile - 1) / p->win_tile;
-    int64_t tile0 = p->cur_ntl >= 0 ? p->cur_tile0 : 0, ntl = p->cur_ntl >= 0 ? p->cur_ntl : all_tiles;
-    // uniform band: the whole tiles [band_t0, band_t1) go through the computed-index kernel, the corner tiles below
-    int64_t tail0 = 0, tail_n = 0;
-    if (p->band_ok && p->cur_ntl < 0 && (vok & 1) && c_hi - c_lo <= 64) {
-        const int64_t pb0 = p->band_t0 * p->win_tile, pb1 = std::min<int64_t>(p->band_t1 * p->win_tile, p->nnz_local);
-        const int bu = (int)env_i64("FDJAC_BAND_U", 4);
-#define FD_LAUNCH_BAND(UU) do {                                                                                              \
-        const int64_t nt = (pb1 - pb0 + 2 * kBlock * UU - 1) / (2 * kBlock * UU);                                              \
-        hipLaunchKernelGGL((k_decompress_band<MODE, UU>), dim3((unsigned)(8 * xcd_chunks(nt))), dim3(kBlock), 0, s, FXa, FXb, ldw, p->M, \
-                           p->d_eps, c_lo, c_hi, out, pb0, pb1, p->band_off, p->band_w, p->band_u, (int)p->band_C, p->band_shift, \
-                           p->band_mw, p->band_mc, (vok & 4) ? 1 : 0); } while (0)
-        if (bu >= 8) FD_LAUNCH_BAND(8); else if (bu >= 4) FD_LAUNCH_BAND(4); else if (bu >= 2) FD_LAUNCH_BAND(2); else FD_LAUNCH_BAND(1);
-#undef FD_LAUNCH_BAND
-        tile0 = 0; ntl = p->band_t0;
-        tail0 = p->band_t1; tail_n = all_tiles - p->band_t1;
-        if (ntl == 0) { tile0 = tail0; ntl = tail_n; tail_n = 0; }
-        if (ntl == 0) return;
-    }
-    for (int part = 0; part < 2; ++part, tile0 = tail0, ntl = tail_n) {
-    if (ntl <= 0) break;
+    const int64_t ntl = (p->nnz_local + p->win_tile - 1) / p->win_tile, tile0 = 0;
+    if (ntl <= 0) return;
     const int64_t gw = 8 * xcd_chunks(ntl);
     const size_t shmw = sizeof(real_t) * ((size_t)wp * (size_t)narr + kWinMaxCol) + kWinHeadBytes;
-#define FD_LAUNCH_WIN(NCT, FV, UU, DM)                                                                          \
-    hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU, DM>), dim3((unsigned)gw), dim3(kBlock), shmw, s, \
-                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, ldw, p->M, p->d_eps, c_lo,          \
+#define FD_LAUNCH_WIN(NCT, FV, UU)                                                                              \
+    hipLaunchKernelGGL((k_decompress_window<MODE, NCT, FV, UU>), dim3((unsigned)gw), dim3(kBlock), shmw, s,     \
+                       (const uint32_t *)p->d_wcode, p->d_wtiles, FXa, FXb, p->ldf, p->M, p->d_eps, c_lo,       \
                        c_hi, out, p->nnz_local, vok, wp, p->win_per_P, p->win_per_S, p->win_per_magic, tile0, ntl,  \
                        p->bd_t0, p->bd_t1, p->band_off, p->band_w, p->band_u, (int)p->band_C, p->band_mw)
-#define FD_LAUNCH_WIN_U(NCT, FV, DM) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4, DM); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2, DM); else FD_LAUNCH_WIN(NCT, FV, 1, DM); } while (0)
-    if constexpr (MODE != 2) { if (dma) { FD_LAUNCH_WIN_U(kWinMaxCol, true, true); continue; } }
-    if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true, false); else FD_LAUNCH_WIN_U(4, false, false); }
-    else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true, false); else FD_LAUNCH_WIN_U(6, false, false); }
-    else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true, false); else FD_LAUNCH_WIN_U(kWinMaxCol, false, false); }
+#define FD_LAUNCH_WIN_U(NCT, FV) do { if (p->win_tile == 2048) FD_LAUNCH_WIN(NCT, FV, 4); else if (p->win_tile == 1024) FD_LAUNCH_WIN(NCT, FV, 2); else FD_LAUNCH_WIN(NCT, FV, 1); } while (0)
+    if (p->win_ncol <= 4) { if (fxvec) FD_LAUNCH_WIN_U(4, true); else FD_LAUNCH_WIN_U(4, false); }
+    else if (p->win_ncol <= 6) { if (fxvec) FD_LAUNCH_WIN_U(6, true); else FD_LAUNCH_WIN_U(6, false); }
+    else { if (fxvec) FD_LAUNCH_WIN_U(kWinMaxCol, true); else FD_LAUNCH_WIN_U(kWinMaxCol, false); }
 #undef FD_LAUNCH_WIN_U
 #undef FD_LAUNCH_WIN
-    }
 }
 
 template <typename CT, int MODE>
@@ -1721,9 +1407,8 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
 {
     hipStream_t s = p->ctx->stream;
     const int B = c_hi - c_lo;
-    // (row strips: the scratch holds rows [cur_shift, ...) of every point at pitch cur_ld; kernels index absolute rows)
-    const int64_t ld_eff = p->cur_ld > 0 ? p->cur_ld : p->ldf;
-    const real_t *FXa = p->d_FX - p->cur_shift;
+    const int64_t ld_eff = p->ldf;
+    const real_t *FXa = p->d_FX;
     const real_t *FXb = (MODE == 0) ? fx : FXa + (int64_t)B * ld_eff;  // central: minus points
     const CT *color = (const CT *)p->d_color;
     switch (p->kind) {

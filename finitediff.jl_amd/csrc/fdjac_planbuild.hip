@@ -773,7 +773,7 @@ struct PbTimer {
     void mark(const char *what) { if (!on) return; (void)hipStreamSynchronize(s); const double t = now(); fprintf(stderr, "[fdjac plan] %-28s %8.3f ms\n", what, t - t0); t0 = t; }
 };
 
-// (this file is included by fdjac_api.hip after window_lds_bytes / plan_row_strips / alloc_scratch are defined)
+// (this file is included by fdjac_api.hip after window_lds_bytes / alloc_scratch are defined)
 
 struct PbTemps {
     void *ptrs[10];
@@ -826,9 +826,8 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
                            const uint8_t *d_color8, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out)
 {
     hipStream_t s = p->ctx->stream;
-    const char *fw = getenv("FDJAC_WINDOW2D"), *fro = getenv("FDJAC_ROLL");
+    const char *fw = getenv("FDJAC_WINDOW2D");
     if (fw && *fw && atoi(fw) == 0) return PBR_DECLINED;
-    if (fro && *fro && atoi(fro) != 0) return PBR_DECLINED;           // rolling row windows: planned on the host
     const int64_t ncols = p->col1 - p->col0;
     if (ncols < 1024 || nloc < 8192 || nloc < 4 * kSortTile) return PBR_DECLINED;
     PbTemps tmp;
@@ -950,7 +949,7 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
     }
     tm.mark("2-D: tiles");
     const double overread = (double)h.elems / (double)std::max<int64_t>(nloc, 1);
-    if (!ok || (h.flags & PB2_FAIL) || h.max_slots == 0 || window_lds_bytes(p->dma, p->fdtype, h.max_slots, h.max_ncol) > (size_t)kWinMaxLds ||
+    if (!ok || (h.flags & PB2_FAIL) || h.max_slots == 0 || window_lds_bytes(p->fdtype, h.max_slots, h.max_ncol) > (size_t)kWinMaxLds ||
         overread > 2.2) {
         (void)hipFree(d_desc); (void)hipFree(d_code);
         return PBR_DECLINED;
@@ -1120,7 +1119,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
             cur.elems += 2.0 * th.z * th.y;
         }
         if (cur.max_slots <= 0) continue;
-        const size_t lds = window_lds_bytes(p->dma, p->fdtype, cur.max_slots, cur.max_ncol);
+        const size_t lds = window_lds_bytes(p->fdtype, cur.max_slots, cur.max_ncol);
         if (lds > (size_t)kWinMaxLds) continue;
         const double overread = cur.elems / (double)std::max<int64_t>(nloc, 1);
         if (!(overread <= 1.25 || force_w == 1)) continue;
@@ -1218,7 +1217,6 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         }
     }
     tm.mark("periodicity");
-    // (the descriptors are already on the host: row strips are planned from them)
     p->C = C;
     p->color8 = true;
     p->d_color = d_color8;
@@ -1236,7 +1234,6 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     p->win_per_P = P; p->win_per_S = P ? S : 0; p->win_per_magic = P ? magic : 0;
     p->d_wtiles = d_wt;
     p->d_wcode = d_code;
-    plan_row_strips(p, wt, (size_t)ntiles);
     {
         const char *fc = getenv("FDJAC_EPS_CYCLIC");
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) &&
@@ -1244,45 +1241,52 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
     }
-    // uniform band with cyclic colours: the computed-index kernel takes the tiles inside it (finish_band_plan)
-    if ((p->band_allowed || p->bd_allowed) && !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
+    // uniform band with cyclic colours: width and offset from the middle column (as try_band_plan_csc / try_store_plan_csc read
+    // them on the host), then (a) the tiles whose descriptors the row-window kernel computes (finish_band_plan) and (b) the
+    // store capability -- each decided on its own, like the host builder does
+    const bool cyclic = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE));
+    int64_t mid_w = 0, mid_u = 0, mid_cp = 0;
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    bool mid_ok = false;
+    if (!band && cyclic && p->col1 - p->col0 >= 4 && (p->bd_allowed || p->store_allowed)) {
+        char raw[2][16];
+        const size_t ib = (size_t)idx_bytes;
+        mid_ok = hipMemcpyAsync(raw[0], (const char *)d_colptr + ib * (size_t)jm, 2 * ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+        mid_cp = mid_ok ? load_idx(raw[0], idx_bytes, 0) - idx_base : 0;
+        mid_w = mid_ok ? (load_idx(raw[0], idx_bytes, 1) - idx_base) - mid_cp : 0;
+        mid_ok = mid_ok && mid_w >= 1 && mid_w <= 64 && mid_cp >= e0 && mid_cp + mid_w <= e1 &&
+                 hipMemcpyAsync(raw[1], (const char *)d_rowval + ib * (size_t)mid_cp, ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+        if (mid_ok) mid_u = jm - (load_idx(raw[1], idx_bytes, 0) - idx_base);
+    }
+    if (p->bd_allowed && cyclic) {
         if (band) {
             finish_band_plan(p, band->w, band->u, 0, p->col0, p->col1, C, shift, wt.data());
-        } else if (p->col1 - p->col0 >= 4) {
-            const int64_t jm = (p->col0 + p->col1) / 2;
-            char raw[3][8];
-            const size_t ib = (size_t)idx_bytes;
+        } else if (mid_ok) {
             PbBandStat hs{-1, 0x7fffffffffffffffll, 0, 0}, *d_bs = nullptr;
-            bool ok = hipMemcpyAsync(raw[0], (const char *)d_colptr + ib * (size_t)jm, 2 * ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                      hipStreamSynchronize(s) == hipSuccess;
-            const int64_t cpm = ok ? load_idx(raw[0], idx_bytes, 0) - idx_base : 0, cpm1 = ok ? load_idx(raw[0], idx_bytes, 1) - idx_base : 0;
-            const int64_t w = cpm1 - cpm;
-            ok = ok && w >= 1 && w <= 64 && cpm >= e0 && cpm1 <= e1 &&
-                 hipMemcpyAsync(raw[2], (const char *)d_rowval + ib * (size_t)cpm, ib, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipStreamSynchronize(s) == hipSuccess && hipMalloc((void **)&d_bs, sizeof(PbBandStat)) == hipSuccess;
+            bool ok = hipMalloc((void **)&d_bs, sizeof(PbBandStat)) == hipSuccess;
             if (ok) {
                 tmp.add(d_bs);
-                const int64_t u = jm - (load_idx(raw[2], idx_bytes, 0) - idx_base);
                 ok = hipMemcpyAsync(d_bs, &hs, sizeof hs, hipMemcpyHostToDevice, s) == hipSuccess;
                 if (ok) {
                     hipLaunchKernelGGL(k_pb_band_check, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p->col1 - p->col0 + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
-                                       dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, idx_base, p->col0, p->col1, jm, cpm, w, u, d_bs);
+                                       dim3(kBlock), 0, s, d_colptr, d_rowval, idx_bytes, idx_base, p->col0, p->col1, jm, mid_cp, mid_w, mid_u, d_bs);
                     ok = hipMemcpyAsync(&hs, d_bs, sizeof hs, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
                 }
                 if (ok && !hs.mid_bad) {
                     const int64_t ju0 = std::max<int64_t>(hs.lo + 1, p->col0), ju1 = std::min<int64_t>(hs.hi, p->col1);
-                    finish_band_plan(p, w, u, (cpm - e0) + w * (ju0 - jm), ju0, ju1, C, shift, wt.data());
+                    finish_band_plan(p, mid_w, mid_u, (mid_cp - e0) + mid_w * (ju0 - jm), ju0, ju1, C, shift, wt.data());
                 }
             }
         }
     }
-    // experimental store capability (FDJAC_LAZY_STORE=1): the exact band, corners included
+    // the store capability (fd_band_store): the exact band, corners included
     p->store_ok = false;
-    if (p->store_allowed && !band && p->band_w > 0 && C >= p->band_w && p->band_u >= 0 && p->band_w - 1 - p->band_u >= 0 &&
-        !(fin.flags & (PB_NOT_CYCLIC | PB_NONE))) {
+    if (p->store_allowed && !band && mid_ok && C >= mid_w && mid_u >= 0 && mid_w - 1 - mid_u >= 0 && p->nnz_local >= 1) {
         fd_band_store d;
         memset(&d, 0, sizeof d);
-        d.M = p->M; d.N = p->N; d.l = p->band_w - 1 - p->band_u; d.u = p->band_u; d.C = (int)C; d.shift = shift;
+        d.M = p->M; d.N = p->N; d.l = (int)(mid_w - 1 - mid_u); d.u = (int)mid_u; d.C = (int)C; d.shift = shift;
         int *d_bad = nullptr, hbad = 0;
         if (hipMalloc((void **)&d_bad, sizeof(int)) == hipSuccess) {
             tmp.add(d_bad);

@@ -24,8 +24,8 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
 (INFO_M, INFO_N, INFO_NCOLORS, INFO_NOUTS, INFO_OUT0_LEN, INFO_OUT1_LEN, INFO_OUT2_LEN, INFO_ROW_BEGIN,
  INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN,
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
- INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, INFO_LDS_DMA,
- INFO_EPS_CYCLIC, INFO_EPS_NT, INFO_STRIPS, INFO_BUILT_ON_DEVICE, INFO_ROLL, INFO_LAZY_DIFF, INFO_BAND_DIRECT, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
+ INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
+ INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE = 1, 2, 4, 8
 PLAN_EPS_CONTIGUOUS = 1
 LAZY_JVP_CAP_QUOTIENT = 1

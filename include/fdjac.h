@@ -101,11 +101,8 @@ typedef struct fd_lazy_points {
     int32_t imag_only;    /* complex step only, set only for launchers registered with FD_LAZY_CAP_IMAG_ONLY: write  */
                           /* fx[b*fx_stride + r] = imag(f(point b))[r] as a REAL array (fx_stride in doubles) -- the */
                           /* real parts of a complex-step evaluation are never used (src/jacobians.jl:635)           */
-    int32_t part;         /* row strips (launchers registered with FD_LAZY_CAP_ROW_WINDOW only): this call evaluates */
-    int32_t nparts;       /* the rows [row_begin,row_end) of the SAME points as part `part` of `nparts` calls; the   */
-                          /* parts together cover every row once (one f! evaluation per point, in pieces).  1 part   */
-                          /* otherwise.  fx / base_out then address a scratch that holds ONLY those rows: row r of   */
-                          /* point b is still fx[b*fx_stride + r], but rows outside the window must not be touched   */
+    int32_t part;         /* reserved: always 0 / 1 (round 2 evaluated f! in row strips through these; measured slower,      */
+    int32_t nparts;       /* removed in round 3)                                                                             */
     int32_t diff;         /* forward / central only, set only for launchers registered with FD_LAZY_CAP_DIFF: write  */
                           /* the DIFFERENCES the reference forms next (src/jacobians.jl:565,607) instead of the      */
                           /* values -- forward: fx[b*fx_stride + r] = f(point b)[r] - f(x)[r]; central: ncolors      */
@@ -237,20 +234,18 @@ enum fd_plan_info_key {
     FD_INFO_WIN_PERIOD = 20,          /*   period (in stored entries) of the regular tiles' entry codes, 0 = none */
     FD_INFO_COLRANGE_WG = 21,         /* block-banded plans: 1 = one workgroup per 32 columns, 0 = one wave per column */
     FD_INFO_SMALL_FUSED = 22,         /* 1 if the plan uses the fused single-workgroup launches of small problems */
-    FD_INFO_LDS_DMA = 23,             /* 1 if the row-window kernels stage through LDS-DMA (global_load_lds) */
+    /* 23, 26, 28, 30: keys of round-2 kernel variants that were measured slower and removed in round 3 (LDS-DMA staging, row
+       strips, rolling row windows, the computed-index band kernel; DESIGN section 5 keeps their numbers) */
     FD_INFO_EPS_CYCLIC = 24,          /* C if colorvec is cyclic (the step-size reduction computes the colours), else 0 */
     FD_INFO_EPS_NT = 25,              /* 1 if the step-size reduction reads x with non-temporal loads */
-    FD_INFO_BAND_DIRECT = 30,         /* 1 if a uniform band with cyclic colours is decompressed with computed indices (k_decompress_band) */
     FD_INFO_BAND_DESC = 31,           /* number of row-window tiles whose descriptors the kernel computes instead of loading (uniform band) */
     FD_INFO_LAZY_STORE = 32,          /* 1 if a FD_LAZY_CAP_STORE launcher stores the Jacobian of this plan itself (exact band, cyclic colours; FDJAC_LAZY_STORE=0: never) */
     FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
-    FD_INFO_ROLL = 28,                /* 1 if a 2-D stencil plan uses the rolling row windows (one wave walks a column strip) */
-    FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
-    FD_INFO_STRIPS = 26               /* row strips per Jacobian the plan would use with a FD_LAZY_CAP_ROW_WINDOW launcher (1 = none) */
+    FD_INFO_BUILT_ON_DEVICE = 27      /* 1 if the pattern was compiled by the device plan builder */
 };
 /* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
-   read there, not per process and not per launch -- except FDJAC_REVERSE and FDJAC_COLRANGE_VEC, which only reorder
-   or re-vectorise the same work); FD_INFO_WINDOW also reports the row-window kernel of Tridiagonal plans. */
+   read there, not per process and not per launch -- except FDJAC_COLRANGE_VEC, which only re-vectorises the same work);
+   FD_INFO_WINDOW also reports the row-window kernel of Tridiagonal plans. */
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
@@ -273,9 +268,8 @@ int fd_jacobian_async(fd_plan *plan, fd_f_launch f, void *fctx, const void *x, c
 int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
 /* Optional capabilities of the installed lazy launcher (bit mask; cleared by fd_plan_set_lazy_f). */
 #define FD_LAZY_CAP_IMAG_ONLY 1   /* honours fd_lazy_points.imag_only: halves the f! output traffic of the complex step */
-#define FD_LAZY_CAP_ROW_WINDOW 2  /* writes ONLY rows [row_begin & ~1, row_end + 1) of fx / base_out: the library may then  */
-                                  /* evaluate f! and decompress in row strips that reuse one cache-sized scratch            */
-                                  /* (fd_lazy_points.part / nparts; DESIGN.md "row strips")                                 */
+#define FD_LAZY_CAP_ROW_WINDOW 2  /* writes ONLY rows [row_begin & ~1, row_end + 1) of fx / base_out (informational since round 3: */
+                                  /* the row-strip schedule that needed it was measured slower and removed)                  */
 #define FD_LAZY_CAP_DIFF 4        /* honours fd_lazy_points.diff: writes f(point) - f(x) / f(plus) - f(minus) itself         */
 #define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store: f!'s launch stores the Jacobian of a verified exact band itself           */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);

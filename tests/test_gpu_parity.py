@@ -800,123 +800,6 @@ def test_banded_window_kernel_bit_identical(monkeypatch, fdtype, l, u, M, N):
     assert np.array_equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
-@pytest.mark.parametrize("pattern", ["tridiag", "lap5_1d", "lap5_2d"])
-def test_lds_dma_staging_bit_identical(fdtype, pattern):
-    # FDJAC_DMA=1 (global_load_lds staging of the raw windows) is read once per process, so the variant runs in a child
-    import os
-    import subprocess
-    import sys
-    code = """
-import os, sys, numpy as np, torch
-sys.path.insert(0, %r)
-import finitediff_jl_amd as fd
-from finitediff_jl_amd import patterns as P
-pattern, fdtype = %r, %r
-if pattern == "tridiag":
-    N = 9001; cp, rv = P.tridiag_csc(N); colors = P.cyclic_colors(N, 3); fam, prm = "tridiag_nl", (N,)
-else:
-    nx, ny = 150, 77; N = nx * ny; cp, rv = P.lap5_csc(nx, ny); colors = P.lap5_colors(nx, ny); fam, prm = "lap5", (nx, ny)
-x = torch.as_tensor(np.random.default_rng(71).random(N), device="cuda")
-J = fd.SparseMatrixCSC(N, N, cp, rv)
-plan = fd.make_plan(J, J, colors, fdtype)
-f = fd.BuiltinF(fam, *prm)
-plan.set_lazy(f)
-out = torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda")
-plan.jacobian(f, x, [out])
-np.save(sys.argv[1], out.cpu().numpy())
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), pattern, fdtype)
-    import tempfile
-    outs = []
-    with tempfile.TemporaryDirectory() as td:
-        for dma in ("0", "1"):
-            env = dict(os.environ, FDJAC_DMA=dma, FDJAC_WINDOW2D="0" if pattern == "lap5_1d" else "1")
-            path = os.path.join(td, "o%s.npy" % dma)
-            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=240)
-            assert r.returncode == 0, r.stderr[-3000:]
-            outs.append(np.load(path))
-    assert not np.isnan(outs[0]).any() and np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["csc", "csc_colwindow", "lap5_2d", "tridiagonal", "banded", "csc_list", "lap5_sorted",
-                                  "blockbanded", "densej"])
-def test_reversed_tile_order_bit_identical(monkeypatch, fdtype, case):
-    # the row-window kernels walk their tiles back to front by default (Infinity Cache reuse of the f! batch);
-    # FDJAC_REVERSE=0 is the front-to-back order: same work per tile, same bits
-    N = 20011
-    colors = P.cyclic_colors(N, 3)
-    fam, prm, win = "tridiag_nl", (N,), None
-    monkeypatch.delenv("FDJAC_WINDOW", raising=False)
-    monkeypatch.delenv("FDJAC_SORTED", raising=False)
-    if case in ("csc", "csc_colwindow", "csc_list"):
-        cp, rv = P.tridiag_csc(N)
-        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
-        sp = J
-        win = (3000, 17001) if case == "csc_colwindow" else None
-        if case == "csc_list":
-            monkeypatch.setenv("FDJAC_WINDOW", "0")
-    elif case == "densej":      # CSC pattern into a dense J: the gather kernel with explicit destinations
-        N = 300
-        colors = P.cyclic_colors(N, 3)
-        prm = (N,)
-        cp, rv = P.tridiag_csc(N)
-        J = torch.zeros((N, N), dtype=torch.float64, device="cuda").t()
-        sp = fd.SparseMatrixCSC(N, N, cp, rv, None)
-    elif case == "blockbanded":
-        nb, bs = 40, 16
-        N = nb * bs
-        lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
-        J = fd.BlockBandedMatrix(None, lay)
-        sp = J
-        colors = lay.colors()
-        fam, prm = "blockcoupled", (nb, bs)
-    elif case == "lap5_sorted":
-        nx, ny = 130, 90
-        N = nx * ny
-        cp, rv = P.lap5_csc(nx, ny)
-        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
-        sp = J
-        colors = P.lap5_colors(nx, ny)
-        fam, prm = "lap5", (nx, ny)
-        monkeypatch.setenv("FDJAC_WINDOW", "0")
-        monkeypatch.setenv("FDJAC_SORTED", "1")
-    elif case == "lap5_2d":
-        nx, ny = 130, 90
-        N = nx * ny
-        cp, rv = P.lap5_csc(nx, ny)
-        J = fd.SparseMatrixCSC(N, N, cp, rv, None)
-        sp = J
-        colors = P.lap5_colors(nx, ny)
-        fam, prm = "lap5", (nx, ny)
-    elif case == "tridiagonal":
-        J = fd.Tridiagonal(_dev(np.zeros(N - 1)), _dev(np.zeros(N)), _dev(np.zeros(N - 1)))
-        sp = None
-    else:
-        J = fd.BandedMatrix(torch.zeros((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
-        sp = None
-    x = _dev(np.random.default_rng(77).random(N) + 0.2)
-    f = fd.BuiltinF(fam, *prm)
-    res = []
-    for rev in ("1", "0"):
-        monkeypatch.setenv("FDJAC_REVERSE", rev)
-        plan = fd.make_plan(J, sp, colors, fdtype, col_window=win)
-        if case == "lap5_2d":
-            assert plan.info(fd.lib.INFO_WINDOW2D) == 1
-        elif case in ("csc", "csc_colwindow", "banded"):
-            assert plan.info(fd.lib.INFO_WINDOW) == 1
-        elif case == "csc_list":
-            assert plan.info(fd.lib.INFO_WINDOW) == 0
-        elif case == "lap5_sorted":
-            assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1
-        outs = [_dev(np.full(plan.out_len(k), np.nan)) for k in range(3 if case == "tridiagonal" else 1)]
-        plan.set_lazy(f)
-        plan.jacobian(f, x, outs)
-        res.append(torch.cat(outs).cpu().numpy())
-    assert not np.isnan(res[0]).any()
-    assert np.array_equal(res[0], res[1])
-
-
 @pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["csc", "lap5_1d", "banded"])
 def test_window_tile_sizes_bit_identical(monkeypatch, fdtype, case):
@@ -1333,102 +1216,6 @@ def test_device_matches_broadcast_accumulate_arm(oracle, fdtype, coloring):
     _tol_ok(J.cpu().numpy(), ref["out"], eps_min, float(np.abs(W).sum(axis=1).max()) * 1.5, "accumulate arm " + fdtype + " " + coloring)
 
 
-@pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["tridiag", "tridiag_none", "tridiag_window", "tridiag_f_in", "band5", "banded_matrix"])
-def test_row_strips_bit_identical(monkeypatch, fdtype, case):
-    # Row strips (FD_INFO_STRIPS, FD_LAZY_CAP_ROW_WINDOW): the call runs as K pairs of (f! on a strip's rows, decompression
-    # of the strip's tiles) sharing one scratch.  Same work per row and per tile: the bits of the one-piece call, whatever K;
-    # the launcher still counts ONE evaluation per point.
-    N = 300_007
-    c0 = c1 = None
-    f_in = None
-    colors = P.cyclic_colors(N, 3)
-    fam, prm = "tridiag_nl", (N,)
-    if case == "band5":
-        colptr, rowval = P.banded_csc(N, N, 2, 2)
-        colors = P.cyclic_colors(N, 5)
-        fam = "tridiag_nl"      # any f! inside the band
-    else:
-        colptr, rowval = P.tridiag_csc(N)
-    if case == "tridiag_none":
-        colors = colors.copy()
-        colors[[0, 77, 4096, N // 2, N - 1]] = 0
-    if case == "tridiag_window":
-        c0, c1 = 100_001, 250_000
-    x = _dev(np.random.default_rng(77).random(N))
-    if case == "tridiag_f_in" and fdtype == "forward":
-        f_in = _dev(np.random.default_rng(78).random(N + 1))[1:]
-    outs = {}
-    for K in ("1", "2", "3", "7"):
-        monkeypatch.setenv("FDJAC_STRIPS", K)
-        if case == "banded_matrix":
-            data = torch.full((N, 3), float("nan"), dtype=torch.float64, device="cuda").t()
-            J = fd.BandedMatrix(data, N, 1, 1)
-            plan = fd.make_plan(J, None, colors, fdtype)
-            out = data
-        else:
-            J = fd.SparseMatrixCSC(N, N, colptr, rowval)
-            plan = fd.make_plan(J, J, colors, fdtype, col_window=(c0, c1) if c0 is not None else None,
-                                x_window=(c0 - 2, c1 + 2) if c0 is not None else None)
-            out = _dev(np.full(plan.out_len(0), np.nan))
-        assert plan.info(fd.lib.INFO_WINDOW) == 1 and plan.info(fd.lib.INFO_STRIPS) == int(K)
-        f = fd.BuiltinF(fam, *prm)
-        plan.set_lazy(f)
-        plan.jacobian(f, x, [out], f_in=f_in)
-        C = int(colors.max())
-        want_calls = {"forward": C + (0 if f_in is not None else 1), "central": 2 * C, "complex": C}[fdtype]
-        assert f.fcalls == want_calls and plan.fcalls_last == want_calls
-        outs[K] = out.cpu().numpy().copy()
-    assert not np.isnan(outs["1"]).any()
-    for K in ("2", "3", "7"):
-        assert np.array_equal(outs[K], outs["1"]), K
-    # a launcher without the capability (or a user f!) keeps the one-piece call
-    monkeypatch.setenv("FDJAC_STRIPS", "3")
-    if case == "tridiag":
-        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
-        plan = fd.make_plan(J, J, colors, fdtype)
-        f = fd.BuiltinF(fam, *prm)
-        plan.set_lazy(f, row_window=False)
-        out = _dev(np.full(plan.out_len(0), np.nan))
-        plan.jacobian(f, x, [out])
-        assert np.array_equal(out.cpu().numpy(), outs["1"]) and f.counts()[0] <= 2
-
-
-@pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["lap5", "lap5_nl", "clamp5", "lap5_none", "lap5_chunked", "lap5_f_in", "lap5_small_ny", "lap5_wide"])
-def test_rolling_row_windows_bit_identical(monkeypatch, fdtype, case):
-    # k_decompress_roll (one wave walks a column strip of a 2-D stencil, LDS ring of four grid rows) against the 2-D tile
-    # kernel (FDJAC_ROLL=0) and the gather kernel (FDJAC_WINDOW=0): same operations on the same operands, same bits
-    nx, ny = {"lap5_small_ny": (400, 7), "lap5_wide": (1000, 40)}.get(case, (250, 130))
-    N = nx * ny
-    fam = {"lap5_nl": "lap5_nl", "clamp5": "clamp5"}.get(case, "lap5")
-    colptr, rowval = P.lap5_csc(nx, ny)
-    colors = P.lap5_colors(nx, ny).copy()
-    if case == "lap5_none":
-        colors[[0, 3, nx - 1, nx, 5 * nx + 17, N - 1]] = 0
-    cap = 900_000 if case == "lap5_chunked" else 0
-    x = _dev(np.random.default_rng(55).random(N))
-    f_in = _dev(np.random.default_rng(56).random(N + 1))[1:] if (case == "lap5_f_in" and fdtype == "forward") else None
-    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
-    outs = {}
-    for variant in ("roll", "tiles2d", "gather"):
-        monkeypatch.setenv("FDJAC_ROLL", "1" if variant == "roll" else "0")
-        monkeypatch.setenv("FDJAC_WINDOW", "0") if variant == "gather" else monkeypatch.delenv("FDJAC_WINDOW", raising=False)
-        plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap)
-        assert plan.info(fd.lib.INFO_ROLL) == int(variant == "roll")
-        assert plan.info(fd.lib.INFO_WINDOW2D) == int(variant != "gather")
-        if case == "lap5_chunked":
-            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
-        f = fd.BuiltinF(fam, nx, ny)
-        if nx % 2 == 0:
-            plan.set_lazy(f)
-        out = _dev(np.full(plan.out_len(0), np.nan))
-        plan.jacobian(f, x, [out], f_in=f_in)
-        outs[variant] = out.cpu().numpy()
-    assert not np.isnan(outs["gather"]).any()
-    assert np.array_equal(outs["roll"], outs["gather"]) and np.array_equal(outs["tiles2d"], outs["gather"])
-
-
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("case", ["tridiag_nl", "tridiag_nl_small", "tridiag_nl_chunked", "tridiag_nl_none", "tridiag_nl_window", "tridiag_nl_owned",
                                   "tridiag_nl_gather", "tridiag_native", "banded", "lap5_nl", "lap5_nl_gather", "lap5_nl_chunked", "clamp5", "lap5"])
@@ -1520,75 +1307,6 @@ def test_lazy_differences_respect_f_in_and_oracle(oracle):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
-@pytest.mark.parametrize("case", ["tridiag", "tridiag_nodiff", "tridiag_chunked", "tridiag_owned", "tridiag_window", "tridiag_f_in", "tridiag_devplan",
-                                  "band5", "bidiag", "banded11", "banded23", "banded_rect", "tridiag_shifted", "tridiag_none"])
-def test_band_direct_kernel_bit_identical(monkeypatch, fdtype, case):
-    # Uniform bands with cyclic colours: k_decompress_band computes (row, colour) of every stored entry instead of staging
-    # row windows in LDS (FD_INFO_BAND_DIRECT); the corner tiles stay with the row-window kernel.  FDJAC_BAND_DIRECT=0 is the
-    # row-window kernel everywhere: same operations on the same operands, same bits.
-    N = M = 150_011
-    l = u = 1
-    win = own = f_in = None
-    cap = 0
-    banded = case.startswith("banded")
-    if case == "band5":
-        l = u = 2
-    if case == "bidiag":
-        l, u = 1, 0
-    if case == "banded23":
-        l, u = 2, 3
-    if case == "banded_rect":
-        l, u, M = 3, 1, N + 40
-    w = l + u + 1
-    colors = P.cyclic_colors(N, w)
-    if case == "tridiag_shifted":
-        colors = ((np.arange(N) + 2) % 3 + 1).astype(np.int64)
-    if case == "tridiag_none":
-        colors[[5, N // 2]] = 0                      # not cyclic any more: no band kernel
-    if case == "tridiag_chunked":
-        cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype != "forward" else 1) * 2
-    if case == "tridiag_owned":
-        own = (1, 3)
-    if case == "tridiag_window":
-        win = (N // 5 + 1, 4 * N // 5)
-    x = _dev(np.random.default_rng(71).random(N))
-    if case == "tridiag_f_in" and fdtype == "forward":
-        f_in = _dev(np.random.default_rng(72).random(N + 1))[1:]      # 8-B aligned only
-    A = torch.as_tensor(np.random.default_rng(73).random((M, w)), device="cuda")
-
-    def fn(fx, xx):   # f_i = sum_k A[i,k] * x[i - l + k]^2 (clamped): rows i depend on columns i-l .. i+u
-        idx = torch.arange(M, device="cuda")
-        acc = torch.zeros(M, dtype=xx.dtype, device="cuda")
-        for k in range(w):
-            acc = acc + A[:, k].to(xx.dtype) * xx[torch.clamp(idx - l + k, 0, N - 1)] ** 2
-        fx.copy_(acc)
-
-    outs, infos = [], []
-    for direct in ("1", "0"):
-        monkeypatch.setenv("FDJAC_BAND_DIRECT", direct)
-        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1" if case == "tridiag_devplan" else "0")
-        if banded:
-            plan = fd.make_plan(fd.BandedMatrix(None, M, l, u), None, colors, fdtype)
-        else:
-            colptr, rowval = P.banded_csc(M, N, l, u)
-            J = fd.SparseMatrixCSC(M, N, colptr, rowval)
-            plan = fd.make_plan(J, J, colors, fdtype, scratch_bytes=cap, col_window=win, color_range=own)
-        assert plan.info(fd.lib.INFO_WINDOW) == 1
-        infos.append(plan.info(fd.lib.INFO_BAND_DIRECT))
-        out = _dev(np.full(plan.out_len(0), 0.0 if own else np.nan))
-        if l == u == 1 and not banded and case != "tridiag_f_in":
-            f = fd.BuiltinF("tridiag_nl", N)
-            plan.set_lazy(f, diff=(case != "tridiag_nodiff"))
-        else:
-            f = fd.TorchF(fn, M, N)
-        plan.jacobian(f, x, [out], f_in=f_in)
-        outs.append(out.cpu().numpy())
-    assert infos == [0 if case == "tridiag_none" else 1, 0]
-    assert not np.isnan(outs[0]).any()
-    assert np.array_equal(outs[0], outs[1])
-
-
-@pytest.mark.parametrize("fdtype", FDTYPES)
 @pytest.mark.parametrize("case", ["tridiag", "tridiag_window", "tridiag_devplan", "tridiag_chunked", "band5", "bidiag", "banded11", "banded23",
                                   "banded_rect", "tridiag_shifted", "tridiag_none", "tridiag_t2048", "tridiag_t512",
                                   "diag_csc", "diag_csc_oddwin", "diag_banded_oddwin", "bidiag_oddwin", "band5_oddwin", "banded23_evenwin"])
@@ -1673,7 +1391,7 @@ def test_band_descriptors_computed_bit_identical(monkeypatch, fdtype, case):
 
 
 def test_band_index_arithmetic_at_large_entry_counts(monkeypatch):
-    # the computed descriptors / computed-index kernel divide entry numbers up to 2^31 by the band width with a multiply-shift
+    # the computed descriptors divide entry numbers up to 2^31 by the band width with a multiply-shift
     # (fd_div31): a pattern whose entry numbers exceed 2^26 must give the bits of the loaded-descriptor path
     N = 23_000_003                                      # tridiagonal: 6.9e7 stored entries
     colptr, rowval = P.tridiag_csc(N)
@@ -1682,27 +1400,26 @@ def test_band_index_arithmetic_at_large_entry_counts(monkeypatch):
     x = _dev(np.random.default_rng(91).random(N))
     f = fd.BuiltinF("tridiag_nl", N)
     outs = []
-    for comp, direct in (("1", "0"), ("0", "0"), ("0", "1")):
+    for comp in ("1", "0"):
         monkeypatch.setenv("FDJAC_BAND_DESC", comp)
-        monkeypatch.setenv("FDJAC_BAND_DIRECT", direct)
         plan = fd.make_plan(J, J, colors, "forward")
-        assert (plan.info(fd.lib.INFO_BAND_DESC) > 0) == (comp == "1") and plan.info(fd.lib.INFO_BAND_DIRECT) == int(direct)
+        assert (plan.info(fd.lib.INFO_BAND_DESC) > 0) == (comp == "1")
         out = _dev(np.full(rowval.size, np.nan))
         plan.set_lazy(f)
         plan.jacobian(f, x, [out])
         outs.append(out)
         del plan
     assert not torch.isnan(outs[0]).any()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("seed", list(range(40)))
 def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     # Every kernel variant / plan builder / hand-over is a different route to the same IEEE operations on the same operands.
     # Reference: the plain gather kernel on a host-built plan with the plain hand-over of the f! values.  Variant: a random
-    # combination of the switches of DESIGN section 5 (tile size, periodic codes, computed descriptors, computed-index band
-    # kernel, rolling windows, 2-D tiles, row strips, tile order, differences hand-over, device plan builder, colour chunks,
-    # column window).  Same bits, same number of f! evaluations.
+    # combination of the switches of DESIGN section 5 (tile size, periodic codes, computed descriptors, 2-D tiles, differences
+    # hand-over, the storing launch and its variants, device plan builder, colour chunks, column window).  Same bits, same
+    # number of f! evaluations.
     import os
     rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "7000")) + seed)
     fdtype = FDTYPES[int(rng.integers(0, 3))]
@@ -1739,8 +1456,8 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
         cap //= 2
 
     def run(env, diff):
-        for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC", "FDJAC_BAND_DIRECT", "FDJAC_ROLL",
-                  "FDJAC_WINDOW2D", "FDJAC_STRIPS", "FDJAC_REVERSE", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_DMA", "FDJAC_LAZY_STORE"):
+        for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC",
+                  "FDJAC_WINDOW2D", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_LAZY_STORE", "FDJAC_STORE_WAVE", "FDJAC_STORE_NT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1757,11 +1474,9 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     pick("FDJAC_WIN_TILE", [512, 1024, 2048])
     pick("FDJAC_WIN_PERIODIC", [0, 1])
     pick("FDJAC_BAND_DESC", [0, 1])
-    pick("FDJAC_BAND_DIRECT", [0, 1])
-    pick("FDJAC_ROLL", [0, 1])
     pick("FDJAC_WINDOW2D", [0, 1])
-    pick("FDJAC_STRIPS", [1, 2, 3])
-    pick("FDJAC_REVERSE", [0, 1])
+    pick("FDJAC_STORE_WAVE", [0, 1])
+    pick("FDJAC_STORE_NT", [0, 1])
     pick("FDJAC_PLAN_DEVICE", [0, 1])
     pick("FDJAC_SORTED", [0, 1])
     pick("FDJAC_LAZY_STORE", [0, 1])
