@@ -138,7 +138,10 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
     // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
     // FDJAC_EPS_NT forces one, a call decides by which path it takes.
-    p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 0) != 0;
+    // the reduction's blocks sum contiguous ranges of x: the default since round 3 (measured equal to the grid-stride map -- N = 10^7:
+    // 75.3 vs 76.0 us per Jacobian, profiles/r03_f_eps_contig_ab.txt -- and a sharded reduction then reads only the shard's own
+    // range); FDJAC_EPS_CONTIG=0 restores the grid-stride map, FD_PLAN_EPS_CONTIGUOUS insists on the contiguous one
+    p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 1) != 0;
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;

@@ -144,12 +144,13 @@ typedef struct fd_plan_opts {
                            /*   owners' outputs add up to the full result when outs start from zero.            */
 } fd_plan_opts;
 /* fd_plan_opts.flags */
-#define FD_PLAN_EPS_CONTIGUOUS 1   /* the step-size reduction's blocks sum CONTIGUOUS ranges of x (default: grid-stride).  Which   */
-                                   /* elements a block sums is part of the reduction's definition (the result differs by        */
-                                   /* rounding, ~1e-16 relative, between the two maps; each is deterministic).  With this map   */
-                                   /* shard r of a sharded reduction (fd_plan_set_comm, fd_plan_eps_partials) reads only        */
-                                   /* x[fd_plan_eps_shard_range(r)): a rank of a time-stepping loop that holds its own part of  */
-                                   /* x plus a halo needs nothing else -- no replicated x, no all-gather of x per step          */
+#define FD_PLAN_EPS_CONTIGUOUS 1   /* the step-size reduction's blocks sum CONTIGUOUS ranges of x.  This is the default map since   */
+                                   /* round 3 (FDJAC_EPS_CONTIG=0 restores the grid-stride map of rounds 1-2; the flag insists on  */
+                                   /* the contiguous one whatever the environment says).  Which elements a block sums is part of   */
+                                   /* the reduction's definition (the two maps differ by rounding, ~1e-16 relative; each is       */
+                                   /* deterministic).  With the contiguous map shard r of a sharded reduction (fd_plan_set_comm,  */
+                                   /* fd_plan_eps_partials) reads only x[fd_plan_eps_shard_range(r)): a rank of a time-stepping   */
+                                   /* loop that holds its own part of x plus a halo needs nothing else -- no replicated x          */
 
 /* ---- context ------------------------------------------------------------------------- */
 /* stream: an existing hipStream_t to enqueue on (e.g. the caller's), NULL to create a private non-blocking stream,

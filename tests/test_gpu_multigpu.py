@@ -140,8 +140,8 @@ def test_column_ranges_and_gatherv_assemble_the_jacobian(comm1):
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("N", [10 ** 6 + 7, 300001])
-def test_contiguous_step_size_reduction_reads_only_the_shard(fdtype, N):
-    # FD_PLAN_EPS_CONTIGUOUS: the reduction's blocks sum contiguous ranges of x, so shard r of W reads only
+def test_contiguous_step_size_reduction_reads_only_the_shard(monkeypatch, fdtype, N):
+    # FD_PLAN_EPS_CONTIGUOUS (the default map since round 3): the reduction's blocks sum contiguous ranges of x, so shard r of W reads only
     # x[fd_plan_eps_shard_range(r, W)) -- proven by poisoning everything else with NaN -- and the step sizes / the Jacobian of
     # the sharded reduction have the bits of the same plan's unsharded call (the map is part of the reduction's definition:
     # against the default grid-stride map the step sizes agree to rounding)
@@ -157,7 +157,9 @@ def test_contiguous_step_size_reduction_reads_only_the_shard(fdtype, N):
     ref = _nan(ref_plan.out_len(0))
     ref_plan.jacobian(f, x, [ref])
     eps_ref = ref_plan.epsilons()
+    monkeypatch.setenv("FDJAC_EPS_CONTIG", "0")              # the grid-stride map of rounds 1-2
     strided = fd.make_plan(J, J, colors, fdtype)
+    monkeypatch.delenv("FDJAC_EPS_CONTIG")
     strided.set_lazy(f)
     tmp = _nan(strided.out_len(0))
     strided.jacobian(f, x, [tmp])
