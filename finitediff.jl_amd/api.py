@@ -59,9 +59,32 @@ def _dtype_of(a):
     return None
 
 
-def _ptr(a, what, dtype=np.float64):
-    """(pointer, FD_HOST|FD_DEVICE, keepalive) of a vector-like of the plan's element type."""
+def _complex_base(a):
+    """float64 / float32 for a complex128 / complex64 torch tensor or numpy array (Complex{T} in memory = (re, im) pairs of T);
+    None for anything else."""
+    if _is_torch(a):
+        import torch
+        return {torch.complex128: np.dtype(np.float64), torch.complex64: np.dtype(np.float32)}.get(a.dtype)
+    if isinstance(a, np.ndarray) and a.dtype in (np.complex128, np.complex64):
+        return np.dtype(np.float64) if a.dtype == np.complex128 else np.dtype(np.float32)
+    return None
+
+
+def _ptr(a, what, dtype=np.float64, cx=False):
+    """(pointer, FD_HOST|FD_DEVICE, keepalive) of a vector-like of the plan's element type (cx: of complex numbers over it)."""
     dtype = np.dtype(dtype)
+    if cx:
+        if _complex_base(a) != dtype:
+            raise TypeError("%s must be a complex numpy array or torch tensor over %s" % (what, dtype.name))
+        if _is_torch(a):
+            if a.is_cuda:
+                if not _colmajor_contig(a):
+                    raise ValueError("%s must be contiguous (column-major for matrices)" % what)
+                return a.data_ptr(), _l.DEVICE, a
+            a = a.numpy()
+        if not (a.flags.f_contiguous or a.ndim <= 1 and a.flags.c_contiguous):
+            raise ValueError("%s must be contiguous (column-major for matrices)" % what)
+        return a.ctypes.data, _l.HOST, a
     if _dtype_of(a) != dtype:
         raise TypeError("%s must be a %s numpy array or torch tensor" % (what, dtype.name))
     if _is_torch(a):
@@ -438,8 +461,9 @@ class TorchF:
 class Plan:
     """fd_plan handle."""
 
-    def __init__(self, ctx, handle, fdtype, dtype=np.float64):
+    def __init__(self, ctx, handle, fdtype, dtype=np.float64, cx=False):
         self.ctx, self.handle, self.fdtype, self.dtype = ctx, handle, fdtype, np.dtype(dtype)
+        self.cx = bool(cx)      # FD_PLAN_COMPLEX_X: x / f_in / outs are complex arrays over `dtype`
         self.Lt = _l.typed(ctx.L, self.dtype)
         self._fin = weakref.finalize(self, self.Lt.fd_plan_destroy, handle)
 
@@ -553,10 +577,10 @@ class Plan:
         L = self.Lt
         if np.dtype(getattr(f, "dtype", self.dtype)) != self.dtype:
             raise TypeError("f! launcher is built for %s, the plan for %s" % (np.dtype(f.dtype).name, self.dtype.name))
-        xp, xk, _k1 = _ptr(x, "x", self.dtype)
+        xp, xk, _k1 = _ptr(x, "x", self.dtype, self.cx)
         ptrs, kinds, keep = [], set(), []
         for o in outs:
-            p, k, ka = _ptr(o, "output", self.dtype)
+            p, k, ka = _ptr(o, "output", self.dtype, self.cx)
             ptrs.append(p)
             kinds.add(k)
             keep.append(ka)
@@ -566,7 +590,7 @@ class Plan:
         arr = (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
         fp, fk = None, _l.DEVICE
         if f_in is not None:
-            fp, fk, _k2 = _ptr(f_in, "f_in", self.dtype)
+            fp, fk, _k2 = _ptr(f_in, "f_in", self.dtype, self.cx)
         rel = -1.0 if relstep is None else float(relstep)
         ab = -1.0 if absstep is None else float(absstep)
         if not sync:
@@ -641,7 +665,7 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None, dtype=np.float64, eps_contiguous=False):
+              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
@@ -649,6 +673,8 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
     o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous)
+    if complex_x:      # returntype <: Complex with forward / central differences: the library lowers it (FD_PLAN_COMPLEX_X)
+        o.flags |= _l.PLAN_COMPLEX_X
     h = C.c_void_p()
     cv = _i64(colorvec)
     if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):
@@ -702,7 +728,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
             if ncols > n:
                 raise IndexError("BoundsError: maximum(colorvec) > length(x)")
             _l.check(L.fd_plan_create_dense(ctx.handle, m, n, ncols, C.byref(o), C.byref(h)))
-    return Plan(ctx, h, fdtype, dtype)
+    return Plan(ctx, h, fdtype, dtype, cx=complex_x)
 
 
 def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_window=None, x_window=None,
@@ -784,11 +810,12 @@ class JacobianCache:
         if self.fdtype == "complex" and np.dtype(returntype).kind == "c":
             # fdtype_error(returntype), src/jacobians.jl:106
             raise ValueError("Unrecognized fdtype: valid values are Val{:forward} or Val{:central}.")
-        if np.dtype(returntype).kind == "c" or (_dtype_of(x1) is None and hasattr(x1, "dtype") and "complex" in str(x1.dtype)):
-            # complex-valued x / f with forward or central differences (src/jacobians.jl:94-128, src/epsilons.jl:26-29 with
-            # abs): not built on the device -- FD_ERR_UNSUPPORTED territory, said loudly instead of computing something else
-            raise _l.FdError(3, "complex-valued x / returntype with forward or central differences is not built "
-                                "(FD_ERR_UNSUPPORTED); the complex-step arm on real x is")
+        # complex-valued x / f with forward or central differences (src/jacobians.jl:94-128, 537-622; src/epsilons.jl:26-29 with
+        # abs of a complex number): the reference's generic loop -- masked norm over complex elements, REAL step on the real
+        # parts, complex quotient.  The library lowers it to the real problem on (re, im) pairs (FD_PLAN_COMPLEX_X).
+        self.cx = _complex_base(x1) is not None
+        if np.dtype(returntype).kind == "c" and not self.cx:
+            raise TypeError("a complex returntype needs a complex x (eltype(fx) == returntype, src/jacobians.jl:118-119)")
         self.x1 = x1
         self.x2 = None
         self.fx = fx if fx is not None else x1
@@ -796,14 +823,14 @@ class JacobianCache:
         n = int(np.prod(x1.shape))
         self.colorvec = np.arange(1, n + 1, dtype=np.int64) if colorvec is None else colorvec
         self.sparsity = sparsity
-        self.dtype = _dtype_of(x1) or np.dtype(np.float64)      # eltype(x): selects the fd_* / fd32_* instantiation
+        self.dtype = _dtype_of(x1) or _complex_base(x1) or np.dtype(np.float64)      # (real) eltype: selects the fd_* / fd32_* instantiation
         self._plans = {}
 
     def _plan_for(self, J, sparsity, colorvec, ctx):
         key = (type(J).__name__, id(sparsity), id(colorvec), self.fdtype, tuple(getattr(J, "shape", ())))
         ent = self._plans.get(key)
         if ent is None or ent[1] is not sparsity or ent[2] is not colorvec:
-            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype), sparsity, colorvec)
+            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx), sparsity, colorvec)
             self._plans[key] = ent
         return ent[0]
 

@@ -101,12 +101,16 @@ static int upload_colors(fd_plan *p, const std::vector<int32_t> &col0, const std
     return FD_OK;
 }
 
+constexpr int32_t kPlanLoweredComplexX = 1 << 16;   // internal fd_plan_opts.flags bit: this plan IS the lowered real problem of FD_PLAN_COMPLEX_X
+
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {
     FD_REQUIRE(opts != nullptr, FD_ERR_ARG, "opts is NULL");
     FD_REQUIRE(opts->fdtype == FD_FORWARD || opts->fdtype == FD_CENTRAL || opts->fdtype == FD_COMPLEX,
                FD_ERR_UNSUPPORTED,
                "Unrecognized fdtype: valid values are Val{:forward}, Val{:central} and Val{:complex}.");
+    FD_REQUIRE(!(opts->flags & FD_PLAN_COMPLEX_X), FD_ERR_UNSUPPORTED,
+               "complex-valued x (FD_PLAN_COMPLEX_X) is built for CSC, dense-J, entry-list and dense-arm plans, not for this storage type");
     p->fdtype = opts->fdtype;
     p->col0 = 0;
     p->col1 = p->N;
@@ -142,6 +146,8 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // 75.3 vs 76.0 us per Jacobian, profiles/r03_f_eps_contig_ab.txt -- and a sharded reduction then reads only the shard's own
     // range); FDJAC_EPS_CONTIG=0 restores the grid-stride map, FD_PLAN_EPS_CONTIGUOUS insists on the contiguous one
     p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 1) != 0;
+    p->cx = (opts->flags & kPlanLoweredComplexX) != 0;   // (set by lower_complex_x only)
+    if (p->cx) p->small_ok = false;                      // the fused small-problem launch has ONE colour rule for norm and perturbation
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
@@ -1150,10 +1156,92 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
     return FD_OK;
 }
 
+// ---- complex-valued x (FD_PLAN_COMPLEX_X; returntype <: Complex with Val(:forward) / Val(:central), src/jacobians.jl:94-128,
+// 537-622, test/finitedifftests.jl:480-513).  The reference's loop is generic in eltype(x): the masked norm is over complex
+// elements (|x_j|^2), epsilon is REAL, x1 .+= epsilon * mask perturbs the real parts, f! runs on complex arrays, the quotient is a
+// complex number divided by a real one, J is complex.  Seen as reals that IS a real problem of twice the size: element 2j / 2j+1 =
+// re / im of x_j, row 2r / 2r+1 = re / im of f_r; only the even columns carry colours; the stored entry (r, j) becomes the two
+// entries (2r, 2j), (2r+1, 2j) -- consecutive in every storage order the plans write, i.e. exactly the (re, im) layout of a
+// Complex nzval / dense J.  So the plan is built for that real problem (the flag kPlanLoweredComplexX marks it: pair norms in
+// the step-size kernels, f! called with is_complex = 1) and every kernel of the real path serves it unchanged.
+struct LoweredCx {
+    std::vector<int64_t> colptr, rows, cols, dest, colors;
+    fd_plan_opts opts;
+};
+static int lower_colors_opts(int64_t N, const void *colorvec, int color_bytes, const fd_plan_opts *opts, LoweredCx &L)
+{
+    FD_REQUIRE(opts != nullptr, FD_ERR_ARG, "opts is NULL");
+    FD_REQUIRE(opts->fdtype != FD_COMPLEX, FD_ERR_UNSUPPORTED, "fdtype_error: Val(:complex) needs a real returntype (src/jacobians.jl:106)");
+    FD_REQUIRE(colorvec != nullptr && (color_bytes == 4 || color_bytes == 8), FD_ERR_ARG, "colorvec is NULL / color_bytes must be 4 or 8");
+    L.colors.assign((size_t)(2 * N), 0);
+    for (int64_t j = 0; j < N; ++j) L.colors[(size_t)(2 * j)] = load_idx(colorvec, color_bytes, j);   // (odd = imaginary parts: colour 0, never perturbed)
+    L.opts = *opts;
+    L.opts.flags = (opts->flags & ~FD_PLAN_COMPLEX_X) | kPlanLoweredComplexX;
+    L.opts.col_begin *= 2; L.opts.col_end *= 2; L.opts.x_begin *= 2; L.opts.x_end *= 2;
+    return FD_OK;
+}
+static int lowered_csc(fd_ctx *ctx, int kind_dense, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes, int idx_base,
+                       const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(colptr && rowval && out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    LoweredCx L;
+    int rc = lower_colors_opts(N, colorvec, color_bytes, opts, L);
+    if (rc) return rc;
+    const int64_t nnz = load_idx(colptr, idx_bytes, N) - idx_base;
+    FD_REQUIRE(nnz >= 0, FD_ERR_SHAPE, "colptr is not monotone");
+    if (!kind_dense) {   // common-pattern CSC: column 2j holds (2r, 2r+1) for every row r of column j, column 2j+1 nothing
+        L.colptr.resize((size_t)(2 * N + 1));
+        L.rows.resize((size_t)(2 * nnz));
+        for (int64_t j = 0; j < N; ++j) {
+            const int64_t a = load_idx(colptr, idx_bytes, j) - idx_base, b = load_idx(colptr, idx_bytes, j + 1) - idx_base;
+            FD_REQUIRE(a >= 0 && a <= b && b <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
+            L.colptr[(size_t)(2 * j)] = 2 * a;
+            L.colptr[(size_t)(2 * j + 1)] = 2 * b;
+            for (int64_t q = a; q < b; ++q) {
+                const int64_t r = load_idx(rowval, idx_bytes, q) - idx_base;
+                FD_REQUIRE(r >= 0 && r < M, FD_ERR_SHAPE, "rowval[%lld] outside 1..%lld", (long long)q, (long long)M);
+                L.rows[(size_t)(2 * q)] = 2 * r;
+                L.rows[(size_t)(2 * q + 1)] = 2 * r + 1;
+            }
+        }
+        L.colptr[(size_t)(2 * N)] = 2 * nnz;
+        return csc_common(ctx, K_CSC, 2 * M, 2 * N, L.colptr.data(), L.rows.data(), 8, 0, L.colors.data(), 8, &L.opts, out, true);
+    }
+    // dense complex J (M x N column-major = 2M x N reals): explicit destinations
+    L.rows.resize((size_t)(2 * nnz)); L.cols.resize((size_t)(2 * nnz)); L.dest.resize((size_t)(2 * nnz));
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t q = load_idx(colptr, idx_bytes, j) - idx_base; q < load_idx(colptr, idx_bytes, j + 1) - idx_base; ++q) {
+            const int64_t r = load_idx(rowval, idx_bytes, q) - idx_base;
+            FD_REQUIRE(q >= 0 && q < nnz && r >= 0 && r < M, FD_ERR_SHAPE, "inconsistent pattern");
+            for (int h = 0; h < 2; ++h) { L.rows[(size_t)(2 * q + h)] = 2 * r + h; L.cols[(size_t)(2 * q + h)] = 2 * j; L.dest[(size_t)(2 * q + h)] = 2 * r + h + 2 * M * j; }
+        }
+    return fd_plan_create_entries(ctx, 2 * M, 2 * N, L.rows.data(), L.cols.data(), L.dest.data(), 2 * nnz, 2 * M * N, 8, 0, L.colors.data(), 8, &L.opts, out);
+}
+static int lowered_coo(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index, const int64_t *dest, int64_t nnz,
+                       int64_t out_len, int idx_bytes, int idx_base, const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE((rows_index && cols_index) || nnz == 0, FD_ERR_ARG, "NULL index list");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    LoweredCx L;
+    int rc = lower_colors_opts(N, colorvec, color_bytes, opts, L);
+    if (rc) return rc;
+    L.rows.resize((size_t)(2 * nnz)); L.cols.resize((size_t)(2 * nnz)); L.dest.resize((size_t)(2 * nnz));
+    for (int64_t q = 0; q < nnz; ++q) {
+        const int64_t r = load_idx(rows_index, idx_bytes, q) - idx_base, c = load_idx(cols_index, idx_bytes, q) - idx_base;
+        FD_REQUIRE(r >= 0 && r < M && c >= 0 && c < N, FD_ERR_SHAPE, "entry %lld outside the matrix", (long long)q);
+        const int64_t d = dest ? dest[q] : r + M * c;       // (complex elements)
+        for (int h = 0; h < 2; ++h) { L.rows[(size_t)(2 * q + h)] = 2 * r + h; L.cols[(size_t)(2 * q + h)] = 2 * c; L.dest[(size_t)(2 * q + h)] = 2 * d + h; }
+    }
+    return fd_plan_create_entries(ctx, 2 * M, 2 * N, L.rows.data(), L.cols.data(), L.dest.data(), 2 * nnz, 2 * out_len, 8, 0, L.colors.data(), 8, &L.opts, out);
+}
+
 int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes,
                        int idx_base, const void *colorvec, int color_bytes, const fd_plan_opts *opts,
                        fd_plan **out)
 {
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+        return lowered_csc(ctx, 0, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
     return csc_common(ctx, K_CSC, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
 }
 
@@ -1261,6 +1349,8 @@ int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colp
         set_error("column windows are not supported for dense J");
         return FD_ERR_UNSUPPORTED;
     }
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+        return lowered_csc(ctx, 1, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
     return csc_common(ctx, K_CSC_DENSE, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
 }
 
@@ -1309,6 +1399,8 @@ int fd_plan_create_coo_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *rows
                              int64_t nnz, int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                              const fd_plan_opts *opts, fd_plan **out)
 {
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+        return lowered_coo(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
     return entries_common(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec,
                           color_bytes, opts, out);
 }
@@ -1318,6 +1410,8 @@ int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_i
                            const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
     FD_REQUIRE(dest || nnz == 0, FD_ERR_ARG, "dest is NULL");
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+        return lowered_coo(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
     return entries_common(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec,
                           color_bytes, opts, out);
 }
@@ -1431,7 +1525,15 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
 
 int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const fd_plan_opts *opts, fd_plan **out)
 {
-    FD_REQUIRE(ncols >= 0 && ncols <= N, FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X)) {   // complex-valued x: the same arm on (re, im) pairs
+        fd_plan_opts o = *opts;
+        FD_REQUIRE(o.fdtype != FD_COMPLEX, FD_ERR_UNSUPPORTED, "fdtype_error: Val(:complex) needs a real returntype (src/jacobians.jl:106)");
+        FD_REQUIRE(ncols >= 0 && ncols <= N, FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
+        o.flags = (o.flags & ~FD_PLAN_COMPLEX_X) | kPlanLoweredComplexX;
+        o.col_begin *= 2; o.col_end *= 2; o.x_begin *= 2; o.x_end *= 2;
+        return fd_plan_create_dense(ctx, 2 * M, 2 * N, ncols, &o, out);
+    }
+    FD_REQUIRE(ncols >= 0 && ncols <= (opts && (opts->flags & kPlanLoweredComplexX) ? N / 2 : N), FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
     if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
         set_error("column windows are not supported for the dense arm");
         return FD_ERR_UNSUPPORTED;
@@ -1443,6 +1545,8 @@ int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const
     // "colour" i == column i: identity colours drive the shared perturbation kernel
     std::vector<int32_t> col0((size_t)N);
     for (int64_t j = 0; j < N; ++j) col0[(size_t)j] = j < ncols ? (int32_t)j : -1;
+    if (p->cx)   // lowered complex-valued x: column i perturbs re(x_i) = element 2i; imaginary parts are never perturbed
+        for (int64_t j = 0; j < N; ++j) col0[(size_t)j] = ((j & 1) == 0 && j / 2 < ncols) ? (int32_t)(j / 2) : -1;
     p->C = ncols;
     p->color8 = false;
     FD_TRY(upload_colors(p, col0, {}));
@@ -1691,6 +1795,15 @@ static bool eps_shardable(const fd_plan *p)
            !(p->small_ok && p->N <= kSmallN) && p->d_partial != nullptr;
 }
 
+// The plain f! launcher.  For a plan of the lowered complex-valued-x problem the arrays hold (re, im) pairs: the launcher is
+// called as the header promises for complex elements -- is_complex = 1, strides and rows counted in complex elements.
+static inline int call_f(const fd_plan *p, fd_f_launch f, void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride,
+                         int64_t fx_stride, int64_t row_begin, int64_t row_end, int is_complex, void *stream)
+{
+    if (!p->cx) return f(fctx, fx, x, nbatch, x_stride, fx_stride, row_begin, row_end, is_complex, stream);
+    return f(fctx, fx, x, nbatch, x_stride / 2, fx_stride / 2, row_begin / 2, (row_end + 1) / 2, 1, stream);
+}
+
 // ---- the hot path ---------------------------------------------------------------------------
 static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t *x_dev, const real_t *fin_dev,
                             double relstep, double absstep, double dir, real_t *const *outs)
@@ -1777,7 +1890,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             fx = p->d_fx;
         } else {
             Span sp(p, FD_STAGE_F);
-            const int rc = f(fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
+            const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
             FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
             p->fcalls_last += 1;
             fx = p->d_fx;
@@ -1885,7 +1998,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (!lazy_done) {
             if (base_pending) {   // the lazy launcher declined the batch that would have carried f(x)
                 Span sp(p, FD_STAGE_F);
-                const int rc = f(fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
+                const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
                 FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
                 p->fcalls_last += 1;
                 base_pending = false;
@@ -1898,7 +2011,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             }
             Span sp(p, FD_STAGE_F);
             const int64_t npts = (int64_t)B * p->pts + (base_in_batch ? 1 : 0);   // (+ x itself: f(x) of the forward arm)
-            const int rc = f(fctx, p->d_FX, p->d_X, npts, p->ldx, p->ldf, p->row0, p->row1,
+            const int rc = call_f(p, f, fctx, p->d_FX, p->d_X, npts, p->ldx, p->ldf, p->row0, p->row1,
                              p->fdtype == FD_COMPLEX ? 1 : 0, (void *)s);
             FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
             p->fcalls_last += npts;
@@ -1982,7 +2095,7 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
 int fd_plan_set_lazy_f(fd_plan *p, fd_f_launch_lazy lazy)
 {
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
-    p->lazy_fn = lazy;
+    p->lazy_fn = p->cx ? nullptr : lazy;   // (complex-valued x: materialised points only -- the lazy protocol describes real points)
     p->lazy_caps = 0;
     return FD_OK;
 }

@@ -591,7 +591,11 @@ struct BuiltinF {
     int64_t sig_cap = 0;    // in (re,im)-capable elements
     // variants of the storing launch (read once, when the launcher is created): FDJAC_STORE_WAVE=0 round 2's row-owned kernel,
     // FDJAC_STORE_NT=0 plain instead of non-temporal stores, FDJAC_STORE_REV=1 wavefronts walk the columns back to front
-    bool store_wave = true, store_nt = true, store_rev = false;
+    // FDJAC_STORE_FASTDIV=0: IEEE division per quotient instead of the shared-reciprocal correctly rounded form (same bits)
+    // FDJAC_STORE_INTERIOR=0: the 5-point kernel keeps its boundary guards in interior tiles too
+    bool store_wave = true, store_nt = true, store_rev = false, store_fastdiv = true, store_interior = true;
+    int store_cpl = 2;      // FDJAC_STORE_CPL=1: the 5-point kernel owns one column per lane (8-B loads, half the registers)
+    int store_waves = 6;    // FDJAC_STORE_WAVES=1: ... compiled without a register budget (4 waves per SIMD instead of 6)
 };
 
 int balanced_grid(int64_t tiles, int64_t cap);
@@ -780,89 +784,133 @@ template <typename T, int SK> __device__ __forceinline__ T stencil5_row(T c, T w
     return v;
 }
 
-template <typename CT, int MODE, int SK, bool NT>
-__global__ void __launch_bounds__(kBlock)
+// a / b for a divisor shared by several quotients, y = 1 / b computed once: one multiplication and two FMA correction steps give
+// the CORRECTLY ROUNDED quotient (Markstein: q1 is a faithful rounding of a / b, so q2 = RN(a / b) when nothing over- or
+// underflows; zero, tiny, huge and non-finite operands take the true division) -- the bits of IEEE a / b, about half its
+// instructions (scripts/ubench/exact_div_probe.hip: 5e10 random and next-to-tie operand pairs, 0 mismatches).  Float64 only.
+template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y)
+{
+    if constexpr (FAST && sizeof(real_t) == 8) {
+        const double q0 = a * y;
+        const double m = fabs(q0), ma = fabs(a);
+        if (!(m >= 0x1p-900 && m <= 0x1p900 && ma >= 0x1p-900 && ma <= 0x1p900)) return a / b;
+        const double r0 = __builtin_fma(-b, q0, a);
+        const double q1 = __builtin_fma(r0, y, q0);
+        const double r1 = __builtin_fma(-b, q1, a);
+        return __builtin_fma(r1, y, q1);
+    } else {
+        return a / b;
+    }
+}
+
+// the five quotients of column (ii, j) from the window W (rows j-2 .. j+2, columns i-2 .. i+3 of x, zero outside the grid), o =
+// ii - i.  INTERIOR: every neighbour of every evaluated row exists (no guards).
+template <int MODE, int SK, bool INTERIOR, bool FASTDIV, int WC>
+__device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][WC], int o, int ii, int j, int nx, int ny, real_t e, real_t *q)
+{
+    const real_t ed = MODE == 1 ? 2 * e : e;
+    const real_t yd = (FASTDIV && sizeof(real_t) == 8) ? (real_t)1 / ed : (real_t)0;
+    const real_t xc = W[2][2 + o], pc = xc + e, mc = xc - e;
+    const bool hw = INTERIOR || ii > 0, he = INTERIOR || ii < nx - 1, hs = INTERIOR || j > 0, hn = INTERIOR || j < ny - 1;
+    const real_t z = 0;
+    // PV: what the plus point holds at an unperturbed coordinate (x + 0.0); MV: the minus point (x - 0.0 == x) -- and, for
+    // forward differences, the base point x itself
+#define PV(dj, di) (W[(dj) + 2][(di) + 2 + o] + z)
+#define MV(dj, di) W[(dj) + 2][(di) + 2 + o]
+    const real_t mcc = MODE == 1 ? mc : xc;
+    {   // row (ii, j-1): its north neighbour is the perturbed coordinate
+        const bool rhs = INTERIOR || j - 1 > 0;
+        const real_t pl = stencil5_row<real_t, SK>(PV(-1, 0), hw ? PV(-1, -1) : z, he ? PV(-1, 1) : z, rhs ? PV(-2, 0) : z, pc);
+        const real_t mi = stencil5_row<real_t, SK>(MV(-1, 0), hw ? MV(-1, -1) : z, he ? MV(-1, 1) : z, rhs ? MV(-2, 0) : z, mcc);
+        q[0] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+    }
+    {   // row (ii-1, j): east
+        const bool rhw = INTERIOR || ii - 1 > 0;
+        const real_t pl = stencil5_row<real_t, SK>(PV(0, -1), rhw ? PV(0, -2) : z, pc, hs ? PV(-1, -1) : z, hn ? PV(1, -1) : z);
+        const real_t mi = stencil5_row<real_t, SK>(MV(0, -1), rhw ? MV(0, -2) : z, mcc, hs ? MV(-1, -1) : z, hn ? MV(1, -1) : z);
+        q[1] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+    }
+    {   // row (ii, j): centre
+        const real_t pl = stencil5_row<real_t, SK>(pc, hw ? PV(0, -1) : z, he ? PV(0, 1) : z, hs ? PV(-1, 0) : z, hn ? PV(1, 0) : z);
+        const real_t mi = stencil5_row<real_t, SK>(mcc, hw ? MV(0, -1) : z, he ? MV(0, 1) : z, hs ? MV(-1, 0) : z, hn ? MV(1, 0) : z);
+        q[2] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+    }
+    {   // row (ii+1, j): west
+        const bool rhe = INTERIOR || ii + 1 < nx - 1;
+        const real_t pl = stencil5_row<real_t, SK>(PV(0, 1), pc, rhe ? PV(0, 2) : z, hs ? PV(-1, 1) : z, hn ? PV(1, 1) : z);
+        const real_t mi = stencil5_row<real_t, SK>(MV(0, 1), mcc, rhe ? MV(0, 2) : z, hs ? MV(-1, 1) : z, hn ? MV(1, 1) : z);
+        q[3] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+    }
+    {   // row (ii, j+1): south
+        const bool rhn = INTERIOR || j + 1 < ny - 1;
+        const real_t pl = stencil5_row<real_t, SK>(PV(1, 0), hw ? PV(1, -1) : z, he ? PV(1, 1) : z, pc, rhn ? PV(2, 0) : z);
+        const real_t mi = stencil5_row<real_t, SK>(MV(1, 0), hw ? MV(1, -1) : z, he ? MV(1, 1) : z, mcc, rhn ? MV(2, 0) : z);
+        q[4] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+    }
+#undef PV
+#undef MV
+}
+
+template <typename CT, int MODE, int SK, bool NT, bool FASTDIV, bool INTSPEC, int CPL, int WV>
+__global__ void __launch_bounds__(kBlock, WV)      // WV: waves per SIMD the register allocation aims at
 k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
 {
-    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_STENCIL5_WAVE_LDS];
+    // CPL = columns per lane: 2 (aligned 16-B loads of x, 128 columns per wavefront) or 1 (8-B loads, 64 columns, half the registers)
+    constexpr int TW = 64 * CPL, WC = 4 + CPL;
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][CPL == 2 ? FD_STENCIL5_WAVE_LDS : FD_STENCIL5_WAVE_LDS / 2 + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nx = (int)st.nx, ny = (int)st.ny;
-    const int T128 = (nx + 127) / 128;
-    const int64_t ntiles = (jrow1 - jrow0) * T128, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    const int TPR = (nx + TW - 1) / TW;
+    const int64_t ntiles = (jrow1 - jrow0) * TPR, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
     const int64_t grp = xcd_tile(blockIdx.x, ngroups);
     if (grp >= ngroups) return;
     const int64_t wt = grp * (kBlock / 64) + wave;
     if (wt >= ntiles) return;
-    const int j = (int)(jrow0 + wt / T128), i0 = (int)(wt % T128) * 128;
-    const int i = i0 + 2 * lane;
+    const int j = (int)(jrow0 + wt / TPR), i0 = (int)(wt % TPR) * TW;
+    const int i = i0 + CPL * lane;
     const int64_t k = (int64_t)j * nx + i;
     const bool act = i < nx;
-    // window rows j-2 .. j+2, columns i-2 .. i+3 (zero outside the grid; rows j+-2 only the centre pair)
-    real_t W[5][6];
+    // a tile whose whole neighbourhood lies inside the grid needs no guards (wave-uniform)
+    const bool interior = INTSPEC && j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
+    // window rows j-2 .. j+2, columns i-2 .. i+CPL+1 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
+    real_t W[5][WC];
 #pragma unroll
     for (int dj = -2; dj <= 2; ++dj) {
-        const bool rowok = act && j + dj >= 0 && j + dj < ny;
+        const bool rowok = interior || (act && j + dj >= 0 && j + dj < ny);
+        if constexpr (CPL == 2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            r2_t v = {0, 0};
-            if (!((dj == -2 || dj == 2) && c != 1)) {
-                const int ic = i + 2 * (c - 1);
-                const int64_t kc = k + (int64_t)dj * nx + 2 * (c - 1);
-                if (rowok && ic >= 0 && ic + 1 < nx) v = *reinterpret_cast<const r2_t *>(x + kc);
-                else if (rowok) { if (ic >= 0 && ic < nx) v.x = x[kc]; if (ic + 1 >= 0 && ic + 1 < nx) v.y = x[kc + 1]; }
+            for (int c = 0; c < 3; ++c) {
+                r2_t v = {0, 0};
+                if (!((dj == -2 || dj == 2) && c != 1)) {
+                    const int ic = i + 2 * (c - 1);
+                    const int64_t kc = k + (int64_t)dj * nx + 2 * (c - 1);
+                    if (interior || (rowok && ic >= 0 && ic + 1 < nx)) v = *reinterpret_cast<const r2_t *>(x + kc);
+                    else if (rowok) { if (ic >= 0 && ic < nx) v.x = x[kc]; if (ic + 1 >= 0 && ic + 1 < nx) v.y = x[kc + 1]; }
+                }
+                W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
             }
-            W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                real_t v = 0;
+                const int adj = dj < 0 ? -dj : dj, adc = c < 2 ? 2 - c : c - 2;
+                if (adj + adc <= 2) {                              // the 13-point diamond
+                    const int ic = i + c - 2;
+                    if (interior || (rowok && ic >= 0 && ic < nx)) v = x[k + (int64_t)dj * nx + (c - 2)];
+                }
+                W[dj + 2][c] = v;
+            }
         }
     }
     int cpair[2] = {0, 0};
-    if (act) { cpair[0] = (int)((const CT *)st.color)[k]; cpair[1] = (int)((const CT *)st.color)[k + 1]; }
-    real_t q[10];
+    if (act) { cpair[0] = (int)((const CT *)st.color)[k]; if (CPL == 2) cpair[1] = (int)((const CT *)st.color)[k + 1]; }
+    real_t q[5 * CPL];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int ii = i + o;
-        const real_t e = eps[cpair[o]];
-        const real_t ed = MODE == 1 ? 2 * e : e;
-        const real_t xc = W[2][2 + o], pc = xc + e, mc = xc - e;
-        const bool hw = ii > 0, he = ii < nx - 1, hs = j > 0, hn = j < ny - 1;
-        const real_t z = 0;
-        // PV: what the plus point holds at an unperturbed coordinate (x + 0.0); MV: the minus point (x - 0.0 == x) -- and,
-        // for forward differences, the base point x itself
-#define PV(dj, di) (W[(dj) + 2][(di) + 2 + o] + z)
-#define MV(dj, di) W[(dj) + 2][(di) + 2 + o]
-        const real_t mcc = MODE == 1 ? mc : xc;
-        {   // row (ii, j-1): its north neighbour is the perturbed coordinate
-            const bool rhs = j - 1 > 0;
-            const real_t pl = stencil5_row<real_t, SK>(PV(-1, 0), hw ? PV(-1, -1) : z, he ? PV(-1, 1) : z, rhs ? PV(-2, 0) : z, pc);
-            const real_t mi = stencil5_row<real_t, SK>(MV(-1, 0), hw ? MV(-1, -1) : z, he ? MV(-1, 1) : z, rhs ? MV(-2, 0) : z, mcc);
-            q[5 * o + 0] = sub_exact(pl, mi) / ed;
-        }
-        {   // row (ii-1, j): east
-            const bool rhw = ii - 1 > 0;
-            const real_t pl = stencil5_row<real_t, SK>(PV(0, -1), rhw ? PV(0, -2) : z, pc, hs ? PV(-1, -1) : z, hn ? PV(1, -1) : z);
-            const real_t mi = stencil5_row<real_t, SK>(MV(0, -1), rhw ? MV(0, -2) : z, mcc, hs ? MV(-1, -1) : z, hn ? MV(1, -1) : z);
-            q[5 * o + 1] = sub_exact(pl, mi) / ed;
-        }
-        {   // row (ii, j): centre
-            const real_t pl = stencil5_row<real_t, SK>(pc, hw ? PV(0, -1) : z, he ? PV(0, 1) : z, hs ? PV(-1, 0) : z, hn ? PV(1, 0) : z);
-            const real_t mi = stencil5_row<real_t, SK>(mcc, hw ? MV(0, -1) : z, he ? MV(0, 1) : z, hs ? MV(-1, 0) : z, hn ? MV(1, 0) : z);
-            q[5 * o + 2] = sub_exact(pl, mi) / ed;
-        }
-        {   // row (ii+1, j): west
-            const bool rhe = ii + 1 < nx - 1;
-            const real_t pl = stencil5_row<real_t, SK>(PV(0, 1), pc, rhe ? PV(0, 2) : z, hs ? PV(-1, 1) : z, hn ? PV(1, 1) : z);
-            const real_t mi = stencil5_row<real_t, SK>(MV(0, 1), mcc, rhe ? MV(0, 2) : z, hs ? MV(-1, 1) : z, hn ? MV(1, 1) : z);
-            q[5 * o + 3] = sub_exact(pl, mi) / ed;
-        }
-        {   // row (ii, j+1): south
-            const bool rhn = j + 1 < ny - 1;
-            const real_t pl = stencil5_row<real_t, SK>(PV(1, 0), hw ? PV(1, -1) : z, he ? PV(1, 1) : z, pc, rhn ? PV(2, 0) : z);
-            const real_t mi = stencil5_row<real_t, SK>(MV(1, 0), hw ? MV(1, -1) : z, he ? MV(1, 1) : z, mcc, rhn ? MV(2, 0) : z);
-            q[5 * o + 4] = sub_exact(pl, mi) / ed;
-        }
-#undef PV
-#undef MV
+    for (int o = 0; o < CPL; ++o) {
+        if (INTSPEC && interior) stencil5_column_quotients<MODE, SK, true, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
+        else stencil5_column_quotients<MODE, SK, false, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
     }
-    fd_stencil5_emit_wave<real_t, NT>(&st, s_win[wave], j, i0, q);
+    fd_stencil5_emit_wave<real_t, NT, CPL>(&st, s_win[wave], j, i0, q);
 }
 
 template <typename CT>
@@ -883,15 +931,23 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
             st.color_bytes != (int)sizeof(CT) || (((uintptr_t)lp->x) & kPairMask) != 0 || st.col_end <= st.col_begin || !b->store_wave)
             return FD_LAZY_DECLINED;
         const int64_t jrow0 = st.col_begin / st.nx, jrow1 = (st.col_end - 1) / st.nx + 1;      // grid rows with local columns
-        const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 127) / 128), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+        const int cpl = b->store_cpl == 1 ? 1 : 2;
+        const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 64 * cpl - 1) / (64 * cpl)), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
         const unsigned gs = (unsigned)(8 * xcd_chunks(ngroups));
-#define FD_S5(MODE, SKK, NT)                                                                                        \
-        hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+#define FD_S5(MODE, SKK, NT, FDV, INS, CPLL, WVV)                                                                   \
+        hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT, FDV, INS, CPLL, WVV>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)
-#define FD_S5_NT(MODE, SKK) do { if (b->store_nt) FD_S5(MODE, SKK, true); else FD_S5(MODE, SKK, false); } while (0)
+#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)
+#define FD_S5_C(MODE, SKK, NT, FDV, INS) do { if (cpl == 1) FD_S5_W(MODE, SKK, NT, FDV, INS, 1); else FD_S5_W(MODE, SKK, NT, FDV, INS, 2); } while (0)
+#define FD_S5_I(MODE, SKK, NT, FDV) do { if (b->store_interior) FD_S5_C(MODE, SKK, NT, FDV, true); else FD_S5_C(MODE, SKK, NT, FDV, false); } while (0)
+#define FD_S5_NT(MODE, SKK) do { if (b->store_fastdiv) { if (b->store_nt) FD_S5_I(MODE, SKK, true, true); else FD_S5_I(MODE, SKK, false, true); } \
+                                 else { if (b->store_nt) FD_S5_I(MODE, SKK, true, false); else FD_S5_I(MODE, SKK, false, false); } } while (0)
         if (mode == 0) { if (sk == 2) FD_S5_NT(0, 2); else FD_S5_NT(0, 0); }
         else { if (sk == 2) FD_S5_NT(1, 2); else FD_S5_NT(1, 0); }
 #undef FD_S5_NT
+#undef FD_S5_I
+#undef FD_S5_C
+#undef FD_S5_W
 #undef FD_S5
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
@@ -1345,6 +1401,10 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
         b->store_wave = env_int("FDJAC_STORE_WAVE", 1) != 0;
         b->store_nt = env_int("FDJAC_STORE_NT", 1) != 0;
         b->store_rev = env_int("FDJAC_STORE_REV", 0) != 0;
+        b->store_fastdiv = env_int("FDJAC_STORE_FASTDIV", 1) != 0;
+        b->store_interior = env_int("FDJAC_STORE_INTERIOR", 1) != 0;
+        b->store_cpl = env_int("FDJAC_STORE_CPL", 2);
+        b->store_waves = env_int("FDJAC_STORE_WAVES", 6);
     }
     for (int i = 0; i < need; ++i)
         if (b->prm[i] < 1) {

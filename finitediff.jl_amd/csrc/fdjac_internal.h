@@ -184,6 +184,9 @@ struct fd_plan {
     int eps_tpb = 0;               //   > 0: the reduction's blocks sum CONTIGUOUS runs of this many tiles (FD_PLAN_EPS_CONTIGUOUS /
                                    //   FDJAC_EPS_CONTIG=1): shard r of the reduction then reads only its own range of x
     bool eps_contig = false;
+    bool cx = false;               // complex-valued x (FD_PLAN_COMPLEX_X): this plan is the lowered REAL problem -- element 2j / 2j+1 =
+                                   //   re / im of x_j, only the real parts carry colours (are perturbed), a coloured element's masked
+                                   //   norm includes its imaginary partner (|x_j|^2), f! is called with is_complex = 1
     int eps_nt_forced = -1;        //   (-1: non-temporal on the hand-over path, plain when f!'s storing launch re-reads x)
     int cyc_C = 0, cyc_shift = 0;  // cyclic colours: color[j] == (j + cyc_shift) mod cyc_C for every column (0 = not cyclic);
                                    //   the reduction then computes the colours instead of reading them (FDJAC_EPS_CYCLIC=0: off)

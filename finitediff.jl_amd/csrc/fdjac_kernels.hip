@@ -61,7 +61,7 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
-                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total, int contig_tpb)
+                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total, int contig_tpb, int pair)
 {
     // The reduction is defined over a GLOBAL grid of grid_total blocks; this launch runs the blocks
     // [block_off, block_off + gridDim.x) of it (all of them on one GPU; one shard per rank when the reduction is
@@ -119,6 +119,7 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
         }
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
+            if (pair) c1[u] = c0[u];     // complex-valued x: (re, im) of one coloured element -- |x_j|^2 = re^2 + im^2
             const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -149,7 +150,7 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_seg(const real_t *__restrict__ x, const int32_t *__restrict__ perm,
                   const int64_t *__restrict__ cptr, int64_t C, int nchunks,
-                  double *__restrict__ partial)
+                  double *__restrict__ partial, int pair)
 {
     const int64_t b = blockIdx.x;
     const int64_t c = b / nchunks;
@@ -163,6 +164,7 @@ k_eps_partial_seg(const real_t *__restrict__ x, const int32_t *__restrict__ perm
     for (int64_t i = s + threadIdx.x; i < e; i += kBlock) {
         const double v = (double)x[perm[i]];
         acc += v * v;
+        if (pair) { const double w = (double)x[perm[i] + 1]; acc += w * w; }   // complex-valued x: + im^2
     }
     __shared__ double red[kBlock / 64];
     acc = wave_sum(acc);
@@ -1165,11 +1167,13 @@ k_decompress_colrange_wg(const CT *__restrict__ color, const int32_t *__restrict
 //   and J[:, i] = (f(x + eps_i e_i) - f(x)) / eps_i.
 __global__ void __launch_bounds__(kBlock)
 k_eps_element(const real_t *__restrict__ x, int64_t ncols, double relstep, double absstep, double dir,
-              int is_forward, real_t *__restrict__ eps)
+              int is_forward, real_t *__restrict__ eps, int pair)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ncols; i += stride) {
-        const real_t a = (real_t)relstep * fabs(x[i]);
+        // abs(x_i): of a complex element (complex-valued x) the modulus
+        const real_t ax = pair ? (real_t)hypot((double)x[2 * i], (double)x[2 * i + 1]) : (real_t)fabs(x[i]);
+        const real_t a = (real_t)relstep * ax;
         real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
         if (is_forward) e = e * dir;
         eps[i] = e;
@@ -1252,7 +1256,7 @@ static int launch_eps_partial_t(fd_plan *p, const real_t *x, int b0, int nb)
     if (nb <= 0) return FD_OK;
 #define FD_EPS_REG(NCC, CY, NTT)                                                                                \
     hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nb), dim3(kBlock), 0, s, x,                   \
-                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P, p->eps_tpb)
+                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P, p->eps_tpb, p->cx ? 1 : 0)
 #define FD_EPS_REG_V(NCC)                                                                                       \
     do {                                                                                                        \
         if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); }     \
@@ -1291,7 +1295,7 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
     }
     const int nparts = p->seg_chunks;
     hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,
-                       x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial);
+                       x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial, p->cx ? 1 : 0);
     return launch_eps_finalize(p, nparts, C, relstep, absstep, dir);
 }
 
@@ -1323,7 +1327,7 @@ int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, doub
 {
     if (p->kind == K_DENSE) {
         hipLaunchKernelGGL(k_eps_element, dim3(grid_for(p->C, kBlock, p->ctx->num_cus)), dim3(kBlock), 0, p->ctx->stream,
-                           x, p->C, relstep, absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps);
+                           x, p->C, relstep, absstep, dir, p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps, p->cx ? 1 : 0);
         FD_HIP_CHECK(hipGetLastError());
         return FD_OK;
     }

@@ -152,6 +152,16 @@ typedef struct fd_plan_opts {
                                    /* fd_plan_eps_partials) reads only x[fd_plan_eps_shard_range(r)): a rank of a time-stepping   */
                                    /* loop that holds its own part of x plus a halo needs nothing else -- no replicated x          */
 
+#define FD_PLAN_COMPLEX_X 2         /* x, the f! values and J are COMPLEX (returntype <: Complex with Val(:forward) / Val(:central):  */
+                                   /* src/jacobians.jl:94-128, 537-622; test/finitedifftests.jl:480-513).  M, N, the pattern and     */
+                                   /* colorvec are given in complex elements, as the reference has them; x / f_in / outs are        */
+                                   /* (re, im) pairs (Complex{T} arrays as they lie in memory); the launcher is called with         */
+                                   /* is_complex = 1.  The masked norm is over complex elements, the step REAL, the real parts are   */
+                                   /* perturbed, the quotient is complex / real -- the reference's generic loop.  Plan kinds: CSC    */
+                                   /* (common pattern), dense J with a CSC / index-list pattern, entry lists, the dense arm; no     */
+                                   /* lazy launchers; fd_plan_info reports lengths in REAL numbers (2 x the complex counts).       */
+                                   /* Val(:complex) with this flag is the reference's fdtype_error (FD_ERR_UNSUPPORTED).            */
+
 /* ---- context ------------------------------------------------------------------------- */
 /* stream: an existing hipStream_t to enqueue on (e.g. the caller's), NULL to create a private non-blocking stream,
    or FD_STREAM_DEFAULT for the device's legacy default (null) stream -- what a host framework whose "current stream"

@@ -283,30 +283,31 @@ template <typename T> __device__ inline void fd_stencil5_emit_column(const fd_st
 #define FD_STENCIL5_WAVE_LDS 648   /* elements of the wave-private window of fd_stencil5_emit_wave (16-byte aligned) */
 
 /*
- * 128 consecutive columns of one grid row at once: lane t of a FULL wavefront holds q[0..4] of column (i0 + 2t, j) and q[5..9]
- * of column (i0 + 2t + 1, j), i0 even and the same in all lanes (lanes whose column lies beyond the grid row are ignored).
- * Interior grid rows inside the local column range go through the window (the first column of a grid row has no west entry,
- * the last no east entry: their slots close up) and out as dense aligned stores; everything else through
- * fd_stencil5_emit_column.
+ * 64 * CPL consecutive columns of one grid row at once (CPL = columns per lane, 1 or 2): lane t of a FULL wavefront holds
+ * q[0..4] of column (i0 + CPL t, j) and, CPL = 2, q[5..9] of the column after it; i0 is a multiple of CPL and the same in all lanes
+ * (lanes whose column lies beyond the grid row are ignored).  Interior grid rows inside the local column range go through the
+ * window (the first column of a grid row has no west entry, the last no east entry: their slots close up) and out as dense
+ * aligned stores; everything else through fd_stencil5_emit_column.
  */
-template <typename T, bool NT = true>
+template <typename T, bool NT = true, int CPL = 2>
 __device__ inline void fd_stencil5_emit_wave(const fd_stencil5_store *d, T *win, long long j, long long i0, const T *q)
 {
     const int lane = (int)(threadIdx.x & 63);
-    const long long nx = d->nx, i = i0 + 2 * lane, k0 = j * nx + i0;
-    const int nc = (int)(nx - i0 < 128 ? nx - i0 : 128);
+    const long long nx = d->nx, i = i0 + CPL * lane, k0 = j * nx + i0;
+    const int nc = (int)(nx - i0 < 64 * CPL ? nx - i0 : 64 * CPL);
     const bool fast = j >= 1 && j <= d->ny - 2 && k0 >= d->col_begin && k0 + nc <= d->col_end &&
                       ((((unsigned long long)d->out) & (2 * sizeof(T) - 1)) == 0);
     if (!fast) {
-        if (i < nx) fd_stencil5_emit_column<T>(d, k0 + 2 * lane, q);
-        if (i + 1 < nx) fd_stencil5_emit_column<T>(d, k0 + 2 * lane + 1, q + 5);
+#pragma unroll
+        for (int o = 0; o < CPL; ++o)
+            if (i + o < nx) fd_stencil5_emit_column<T>(d, k0 + CPL * lane + o, q + 5 * o);
         return;
     }
     const long long P0 = fd_stencil5_colptr(d, k0) - d->entry_begin;
     const int off = (int)(P0 & 1);
     const int cnt = 5 * nc - (i0 == 0 ? 1 : 0) - (i0 + nc == nx ? 1 : 0);
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
+    for (int o = 0; o < CPL; ++o) {
         const long long ii = i + o;
         if (ii >= nx) continue;
         const int base = off + 5 * (int)(ii - i0) - ((i0 == 0 && ii > 0) ? 1 : 0);

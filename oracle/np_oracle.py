@@ -87,3 +87,72 @@ def jacobian(f, x, colorvec, pattern, fdtype="forward", relstep=None, absstep=No
                 J[rows, j] = d[rows]
             cx1 = cx1 - 1j * eps * mask                          # :646
     return J, ncalls
+
+
+def jacobian_complex_x(f, x, colorvec, pattern=None, fdtype="forward", relstep=None, absstep=None, dir=1.0, f_in=None):
+    """The same loop for COMPLEX-valued x (returntype <: Complex with Val(:forward) / Val(:central)): the reference's code is
+    generic in eltype(x) -- src/jacobians.jl:94-128 (cache), 537-622 (loop) -- so this is the loop above with complex arrays:
+    the masked norm runs over complex elements (np.linalg.norm of a complex vector = sqrt(sum |x_j|^2)), epsilon is real
+    (src/epsilons.jl:26-29, 50-53: abs of a complex number), `x1 .+= epsilon * mask` moves the real parts, the quotient is a
+    complex vector over a real number.  pattern=None is the dense arm (sparsity === nothing, :548-557 / :590-598: column i
+    perturbs x[i] alone with compute_epsilon(fdtype, x[i], ...)).  Known answer: test/finitedifftests.jl:480-513.
+    Returns (J dense complex M x N, number of f calls)."""
+    assert fdtype in ("forward", "central")                     # Val(:complex) with a complex returntype: fdtype_error (:106)
+    x = np.array(x, dtype=np.complex128)
+    N = x.size
+    colorvec = np.asarray(colorvec)
+    assert colorvec.size == N
+    relstep = default_relstep(fdtype) if relstep is None else relstep
+    absstep = relstep if absstep is None else absstep
+    probe = np.zeros(0 if pattern is None else pattern.shape[0], np.complex128)
+    M = N if pattern is None and f_in is None else (len(f_in) if pattern is None else pattern.shape[0])
+    del probe
+    J = np.zeros((M, N), np.complex128)
+    ncalls = 0
+    x1 = x.copy()
+    fx, fx1 = np.zeros(M, np.complex128), np.zeros(M, np.complex128)
+    if fdtype == "forward":
+        if f_in is None:
+            f(fx, x)
+            ncalls += 1
+        else:
+            fx[:] = f_in
+    xx = x.copy()
+    for c in range(1, int(colorvec.max()) + 1):
+        if pattern is None:                                      # dense arm: colour index == column index
+            i = c - 1
+            save = x1[i]
+            eps = compute_epsilon(fdtype, save, relstep, absstep, dir)
+            x1[i] = save + eps
+            f(fx1, x1)
+            ncalls += 1
+            if fdtype == "central":
+                x1[i] = save - eps
+                f(fx, x1)
+                ncalls += 1
+                J[:, i] = (fx1 - fx) / (2 * eps)
+            else:
+                J[:, i] = (fx1 - fx) / eps
+            x1[i] = save
+            continue
+        mask = (colorvec == c)
+        x2 = x1 * mask
+        eps = compute_epsilon(fdtype, np.sqrt(np.linalg.norm(x2)), relstep, absstep, dir)
+        x1 = x1 + eps * mask
+        if fdtype == "central":
+            xx = xx - eps * mask
+            f(fx1, x1)
+            f(fx, xx)
+            ncalls += 2
+            d = (fx1 - fx) / (2 * eps)
+        else:
+            f(fx1, x1)
+            ncalls += 1
+            d = (fx1 - fx) / eps
+        for j in np.nonzero(mask)[0]:
+            rows = np.nonzero(pattern[:, j])[0]
+            J[rows, j] = d[rows]
+        x1 = x1 - eps * mask
+        if fdtype == "central":
+            xx = xx + eps * mask
+    return J, ncalls

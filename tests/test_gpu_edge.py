@@ -288,17 +288,99 @@ def test_bound_call_matches_and_validates():
         plan.bind(fd.BuiltinF("tridiag_nl", N, dtype=np.float32), x, [out])
 
 
-def test_complex_valued_x_is_refused_not_miscomputed():
-    # returntype <: Complex with forward / central differences (src/jacobians.jl:94-128; src/epsilons.jl:26-29 takes abs):
-    # not built on the device.  The host mirror says FD_ERR_UNSUPPORTED instead of silently treating the data as real.
-    N = 12
-    xc = torch.ones(N, dtype=torch.complex128, device="cuda")
-    for fdtype in ("forward", "central"):
-        with pytest.raises(fd.lib.FdError) as e:
-            fd.JacobianCache(xc, fdtype, np.complex128, colorvec=P.cyclic_colors(N, 3))
-        assert e.value.code == 3
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_complex_valued_x_reference_known_answer_dense_arm(fdtype):
+    # returntype <: Complex with forward / central differences (src/jacobians.jl:94-128, 537-622), the reference's own fixture
+    # test/finitedifftests.jl:480-513 (iipf : C^2 -> C^2, analytic J_ref, err < 1e-4 / 1e-8): dense arm on the device through
+    # FD_PLAN_COMPLEX_X, a user f! written in torch on complex tensors; also against the numpy restatement, and f_in
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(480)
+    xh = rng.random(2) + 1j * rng.random(2)
+    x = torch.as_tensor(xh, device="cuda")
+
+    def iipf_t(fv, xx):
+        fv[0] = (1j * xx[0] + 3) * (xx[1] ** 3 - 7) + 18
+        fv[1] = torch.sin(xx[1] * torch.exp(xx[0]) - 1)
+
+    def iipf_n(fv, xx):
+        fv[0] = (1j * xx[0] + 3) * (xx[1] ** 3 - 7) + 18
+        fv[1] = np.sin(xx[1] * np.exp(xx[0]) - 1)
+
+    J_ref = np.array([[1j * (-7 + xh[1] ** 3), 3 * (3 + 1j * xh[0]) * xh[1] ** 2],
+                      [np.exp(xh[0]) * xh[1] * np.cos(1 - np.exp(xh[0]) * xh[1]), np.exp(xh[0]) * np.cos(1 - np.exp(xh[0]) * xh[1])]])
+    tol = 1e-4 if fdtype == "forward" else 1e-8
+    f = fd.TorchF(iipf_t, 2, 2)
+    cache = fd.JacobianCache(x, fdtype, np.complex128)
+    J = torch.full((2, 2), complex(float("nan"), float("nan")), dtype=torch.complex128, device="cuda").t()      # column-major
+    fd.finite_difference_jacobian_b(J, f, x, cache)
+    got = J.cpu().numpy()
+    assert np.abs(got - J_ref).max() < tol
+    assert f.fcalls == (3 if fdtype == "forward" else 4)
+    Jo, _n = O.jacobian_complex_x(iipf_n, xh, np.arange(1, 3), None, fdtype)
+    assert np.abs(got - Jo).max() <= 1e-6 * np.abs(Jo).max() + 1e-7
+    if fdtype == "forward":          # f_in: one evaluation fewer, same values to rounding
+        y = torch.zeros(2, dtype=torch.complex128, device="cuda")
+        iipf_t(y, x)
+        J2 = torch.zeros((2, 2), dtype=torch.complex128, device="cuda").t()
+        f2 = fd.TorchF(iipf_t, 2, 2)
+        fd.finite_difference_jacobian_b(J2, f2, x, cache, f_in=y)
+        assert f2.fcalls == 2 and np.abs(J2.cpu().numpy() - J_ref).max() < tol
     with pytest.raises(ValueError):     # Val(:complex) with a complex returntype: fdtype_error, as the reference (src/jacobians.jl:106)
-        fd.JacobianCache(_dev(np.ones(N)), "complex", np.complex128)
+        fd.JacobianCache(_dev(np.ones(12)), "complex", np.complex128)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("kind", ["csc", "dense_sparse", "dense_dense", "builtin_csc"])
+def test_complex_valued_x_coloured_paths(fdtype, kind):
+    # the coloured sparse arm with complex x: the masked norm is over complex elements, the step real, the real parts are
+    # perturbed, J is complex -- CSC nzval (Complex nzval = (re, im) pairs in storage order), dense J with a CSC / dense-matrix
+    # pattern, and the built-in tridiagonal fixture evaluated on complex points (is_complex = 1), against the numpy restatement
+    from oracle import np_oracle as O
+    N = 40_000 if kind == "builtin_csc" else 300
+    rng = np.random.default_rng(77)
+    xh = rng.random(N) + 1j * (rng.random(N) - 0.5)
+    x = torch.as_tensor(xh, device="cuda")
+    colors = P.cyclic_colors(N, 3)
+    colptr, rowval = P.tridiag_csc(N)
+
+    def f_t(fv, xx):
+        z = torch.zeros(1, dtype=xx.dtype, device=xx.device)
+        xm, xp = torch.cat([z, xx[:-1]]), torch.cat([xx[1:], z])
+        fv.copy_((xm - 2 * xx) + xp + (xx * xx) * xp)
+
+    def f_n(fv, xx):
+        xm, xp = np.concatenate([[0], xx[:-1]]), np.concatenate([xx[1:], [0]])
+        fv[:] = (xm - 2 * xx) + xp + (xx * xx) * xp
+
+    f = fd.BuiltinF("tridiag_nl", N) if kind == "builtin_csc" else fd.TorchF(f_t, N, N)
+    xp_ = np.concatenate([xh[1:], [0]])
+    want_dense = None
+    if N <= 1000:
+        pat = np.abs(np.subtract.outer(np.arange(N), np.arange(N))) <= 1
+        want_dense, ncalls = O.jacobian_complex_x(f_n, xh, colors, pat, fdtype)
+    tol = 2e-6 if fdtype == "forward" else 2e-9
+    if kind in ("csc", "builtin_csc"):
+        Jm = fd.SparseMatrixCSC(N, N, colptr, rowval, torch.full((rowval.size,), complex(float("nan"), float("nan")), dtype=torch.complex128, device="cuda"))
+        fd.finite_difference_jacobian_b(Jm, f, x, fdtype, np.complex128, colorvec=colors, sparsity=Jm)
+        got = Jm.nzval.cpu().numpy()
+        col = (np.arange(rowval.size) + 1) // 3
+        row = rowval - 1
+        analytic = np.where(row == col, -2 + 2 * xh[col] * xp_[col], np.where(row + 1 == col, 1 + xh[row] ** 2, 1.0 + 0j))
+        assert np.abs(got - analytic).max() < tol * 4
+        if want_dense is not None:
+            assert np.abs(got - want_dense[row, col]).max() <= 1e-6 * np.abs(want_dense).max() + 1e-7
+    else:
+        Jd = torch.full((N, N), complex(float("nan"), float("nan")), dtype=torch.complex128, device="cuda").t()
+        sp = fd.SparseMatrixCSC(N, N, colptr, rowval) if kind == "dense_sparse" else pat.astype(float)
+        fd.finite_difference_jacobian_b(Jd, f, x, fdtype, np.complex128, colorvec=colors, sparsity=sp)
+        got = Jd.cpu().numpy()
+        assert np.all(got[~pat] == 0)                                   # fill_matrix!: entries outside the pattern are zero
+        assert np.abs(got - want_dense).max() <= 1e-6 * np.abs(want_dense).max() + 1e-7
+    assert f.fcalls == (4 if fdtype == "forward" else 6)
+    with pytest.raises(fd.lib.FdError) as e:                            # storage types the lowering is not built for say so
+        fd.finite_difference_jacobian_b(fd.Tridiagonal(torch.zeros(N - 1, dtype=torch.complex128, device="cuda"), torch.zeros(N, dtype=torch.complex128, device="cuda"),
+                                                       torch.zeros(N - 1, dtype=torch.complex128, device="cuda")), f, x, fdtype, np.complex128, colorvec=colors)
+    assert e.value.code == 3
 
 
 def test_hip_error_left_behind_by_a_launcher_is_reported():

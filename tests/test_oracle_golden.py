@@ -362,3 +362,43 @@ def test_broadcast_accumulate_arm_equals_assignment(oracle, fdtype, coloring):
     if coloring == "valid":
         J = 2 * W * x[None, :]
         assert np.allclose(a["out"], J, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("fdtype,tol", [("forward", 1e-4), ("central", 1e-8)])
+def test_complex_valued_x_oracle_meets_the_reference_known_answer(fdtype, tol):
+    # test/finitedifftests.jl:480-513 ("f : C^N -> C^N"): iipf, the analytic J_ref and the tolerances of the reference's own test,
+    # on the numpy restatement's complex-valued-x arm (oracle/np_oracle.py::jacobian_complex_x) -- dense arm, cache-less call,
+    # with f_in, with relstep = sqrt(eps) -- plus a coloured sparse case against the analytic Jacobian
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(480)
+    x = rng.random(2) + 1j * rng.random(2)
+
+    def iipf(fv, xx):
+        fv[0] = (1j * xx[0] + 3) * (xx[1] ** 3 - 7) + 18
+        fv[1] = np.sin(xx[1] * np.exp(xx[0]) - 1)
+
+    J_ref = np.array([[1j * (-7 + x[1] ** 3), 3 * (3 + 1j * x[0]) * x[1] ** 2],
+                      [np.exp(x[0]) * x[1] * np.cos(1 - np.exp(x[0]) * x[1]), np.exp(x[0]) * np.cos(1 - np.exp(x[0]) * x[1])]])
+    y = np.zeros(2, complex)
+    iipf(y, x)
+    for kw in ({}, {"relstep": np.sqrt(np.finfo(float).eps)}, {"f_in": y}):
+        if fdtype == "central" and kw:
+            continue
+        J, ncalls = O.jacobian_complex_x(iipf, x, np.arange(1, 3), None, fdtype, **kw)
+        assert np.abs(J - J_ref).max() < tol
+        assert ncalls == (4 if fdtype == "central" else (2 if "f_in" in kw else 3))
+    # coloured sparse arm: tridiagonal, complex-analytic f_i = (i x_{i-1} - 2 x_i) + x_{i+1} + x_i^2 x_{i+1}
+    N = 30
+    xs = rng.random(N) + 1j * rng.random(N)
+    pat = np.abs(np.subtract.outer(np.arange(N), np.arange(N))) <= 1
+
+    def f_tri(fv, xx):
+        xm = np.concatenate([[0], xx[:-1]])
+        xp = np.concatenate([xx[1:], [0]])
+        fv[:] = (1j * xm - 2 * xx) + xp + xx * xx * xp
+
+    J, ncalls = O.jacobian_complex_x(f_tri, xs, (np.arange(N) % 3) + 1, pat, fdtype)
+    xp = np.concatenate([xs[1:], [0]])
+    want = np.diag(-2 + 2 * xs * xp) + np.diag(1 + xs[:-1] ** 2, 1) + np.diag(np.full(N - 1, 1j), -1)
+    assert np.abs(J - want).max() < (2e-6 if fdtype == "forward" else 2e-9)
+    assert ncalls == (4 if fdtype == "forward" else 6)
