@@ -10,7 +10,7 @@
  *
  *   gcc -O2 -Iinclude examples/c_abi_clients.c -o c_abi_clients -Lfinitediff.jl_amd/lib -lfdjac \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/finitediff.jl_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   ./c_abi_clients all        # or: csc csc_device csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host
+ *   ./c_abi_clients all        # or: csc csc_device csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host complex_x resize
  */
 #include <math.h>
 #include <stdint.h>
@@ -600,6 +600,87 @@ static int client_host(void)
     return report("host+f_in", worst, 2e-6, calls, 3);   /* f_in given: 3 evaluations, not 4 */
 }
 
+/* shim: finite_difference_jacobian!(J::SparseMatrixCSC{ComplexF64}, f, x::Vector{ComplexF64}, cache{returntype = ComplexF64}) ->
+   PlanOpts(flags = FD_PLAN_COMPLEX_X), fd_plan_create_csc, fd_jacobian_async: complex-valued x with forward / central differences
+   (src/jacobians.jl:94-128, 537-622; test/finitedifftests.jl:480-513).  x, nzval are Complex{Float64} arrays as they lie in
+   memory ((re, im) pairs); the built-in fixture is evaluated on complex points (is_complex = 1). */
+static int client_complex_x(int fdtype)
+{
+    const int64_t N = 60001;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    double *x = malloc(sizeof(double) * 2 * (size_t)N);                       /* (re, im) */
+    for (int64_t j = 0; j < N; ++j) { x[2 * j] = 0.5 + 0.25 * sin((double)(j + 1)); x[2 * j + 1] = 0.3 * cos(0.7 * (double)(j + 1)); }
+    double *xd = to_dev(x, sizeof(double) * 2 * (size_t)N), *nzd = dev_nan(2 * (size_t)nnz);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = FD_PLAN_COMPLEX_X;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    int64_t len = 0;
+    CHECK(fd_plan_info(plan, FD_INFO_OUT0_LEN, &len));
+    if (len != 2 * nnz) { printf("complex_x: out length %lld, expected %lld  FAILED\n", (long long)len, (long long)(2 * nnz)); return 3; }
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * 2 * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * 2 * (size_t)nnz);
+    /* analytic Jacobian of f_i = x[i-1] - 2x[i] + x[i+1] + x[i]^2 x[i+1] at complex x (holomorphic: d/dx along the real axis) */
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const int64_t r = rowval[p] - 1;
+            const double xr = x[2 * r], xi = x[2 * r + 1];
+            const double pr = r + 1 < N ? x[2 * (r + 1)] : 0.0, pi = r + 1 < N ? x[2 * (r + 1) + 1] : 0.0;
+            double wr, wi;
+            if (r == j) { wr = -2.0 + 2.0 * (xr * pr - xi * pi); wi = 2.0 * (xr * pi + xi * pr); }
+            else if (j == r + 1) { wr = 1.0 + (xr * xr - xi * xi); wi = 2.0 * xr * xi; }
+            else { wr = 1.0; wi = 0.0; }
+            const double d = fmax(fabs(nz[2 * p] - wr), fabs(nz[2 * p + 1] - wi));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(colptr); free(rowval); free(colors);
+    return report(fdtype == FD_FORWARD ? "complex_x/fwd" : "complex_x/cen", worst, fdtype == FD_FORWARD ? 4e-6 : 4e-8, calls, fdtype == FD_FORWARD ? 4 : 6);
+}
+
+/* shim: Base.resize!(cache, i) (src/jacobians.jl:655-661) followed by the next finite_difference_jacobian!: the shim's plans are
+   keyed on the CONTENT of (J's pattern, sparsity, colorvec, fdtype), so the resized cache (colorvec = 1:i, new lengths) simply
+   compiles a new plan and the old one is released -- plan, call, destroy, plan for the new size, call.  Dense arm, as resize!
+   sets colorvec = 1:i. */
+static int client_resize(void)
+{
+    int bad = 0;
+    const int64_t sizes[2] = {700, 1300};
+    for (int s = 0; s < 2; ++s) {
+        const int64_t N = sizes[s];
+        double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *Jd = dev_nan((size_t)(N * N));
+        fd_f_launch f; void *fctx; fd_plan *plan;
+        const int64_t prm[1] = {N};
+        CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+        fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+        CHECK(fd_plan_create_dense(g_ctx, N, N, N, &o, &plan));
+        void *outs[3] = {Jd, NULL, NULL};
+        CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+        CHECK(fd_ctx_synchronize(g_ctx));
+        double *J = malloc(sizeof(double) * (size_t)(N * N));
+        from_dev(J, Jd, sizeof(double) * (size_t)(N * N));
+        double worst = 0;
+        for (int64_t c = 0; c < N; ++c)
+            for (int64_t r = 0; r < N; ++r) {
+                const double d = fabs(J[r + N * c] - tridiag_nl_J(x, N, r, c));
+                if (!(d <= worst)) worst = d;
+            }
+        const int64_t calls = f_points(fctx);
+        CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+        hipFree(xd); hipFree(Jd); free(J); free(x);
+        bad |= report(s == 0 ? "resize/700" : "resize/1300", worst, 2e-6, calls, N + 1);
+    }
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     const char *which = argc > 1 ? argv[1] : "all";
@@ -625,6 +706,8 @@ int main(int argc, char **argv)
     RUN("jvp", client_jvp())
     RUN("solve", client_solve())
     RUN("host", client_host())
+    RUN("complex_x", client_complex_x(FD_FORWARD) | client_complex_x(FD_CENTRAL))
+    RUN("resize", client_resize())
     CHECK(fd_ctx_destroy(g_ctx));
     hipStreamDestroy(g_stream);
     if (!ran) { fprintf(stderr, "unknown client %s\n", which); return 2; }

@@ -937,7 +937,7 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
 #define FD_S5(MODE, SKK, NT, FDV, INS, CPLL, WVV)                                                                   \
         hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT, FDV, INS, CPLL, WVV>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)
-#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)
+#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6 && FDV && CPLL == 2) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)   /* (the register budget spills with the IEEE division sequence or one column per lane: 337 / 237 vs 121 us) */
 #define FD_S5_C(MODE, SKK, NT, FDV, INS) do { if (cpl == 1) FD_S5_W(MODE, SKK, NT, FDV, INS, 1); else FD_S5_W(MODE, SKK, NT, FDV, INS, 2); } while (0)
 #define FD_S5_I(MODE, SKK, NT, FDV) do { if (b->store_interior) FD_S5_C(MODE, SKK, NT, FDV, true); else FD_S5_C(MODE, SKK, NT, FDV, false); } while (0)
 #define FD_S5_NT(MODE, SKK) do { if (b->store_fastdiv) { if (b->store_nt) FD_S5_I(MODE, SKK, true, true); else FD_S5_I(MODE, SKK, false, true); } \
