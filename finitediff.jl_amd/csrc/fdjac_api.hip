@@ -1628,6 +1628,23 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
         pairs_ok = pairs_ok && ((o & 1) == 0);
     }
     p->cr_pairs = pairs_ok && nloc > 0;
+    {
+        // the store capability (fd_colrange_store): colorvec must be a valid colouring -- the columns of the block-columns that touch
+        // a block-row (K - bl .. K + bu) pairwise differ in colour, none without colour -- and the block structure is recorded
+        bool valid = p->store_allowed && nloc > 0 && p->C >= 1;
+        std::vector<int64_t> stamp((size_t)std::max<int64_t>(p->C, 1), 0);
+        for (int64_t K = 0; K < nblk && valid; ++K)
+            for (int64_t Jc = std::max<int64_t>(K - bl, 0); Jc <= std::min<int64_t>(K + bu, nblk - 1) && valid; ++Jc)
+                for (int64_t j = off[(size_t)Jc]; j < off[(size_t)Jc + 1] && valid; ++j) {
+                    const int32_t c = col0[(size_t)j];
+                    if (c < 0 || stamp[(size_t)c] == K + 1) valid = false;
+                    else stamp[(size_t)c] = K + 1;
+                }
+        p->store_cr_ok = valid;
+        bool uniform = nblk > 0;
+        for (int64_t b = 0; b < nblk; ++b) uniform = uniform && (off[(size_t)b + 1] - off[(size_t)b]) == (off[1] - off[0]);
+        p->cr_nblk = nblk; p->cr_bs = uniform ? off[1] - off[0] : 0; p->cr_bl = (int)bl; p->cr_bu = (int)bu;
+    }
     p->entry_begin = dmin;
     p->row0 = r0;
     p->row1 = r1;
@@ -1933,6 +1950,14 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             s5.nx = p->store5_nx; s5.ny = p->store5_ny; s5.entry_begin = p->entry_begin; s5.col_begin = p->col0; s5.col_end = p->col1;
             s5.color = p->d_color; s5.color_bytes = p->color8 ? 1 : 4; s5.C = (int)p->C; s5.elem_bytes = (int)sizeof(real_t);
             const bool stencil = !p->store_ok && p->store5_ok && p->kind == K_CSC;
+            fd_colrange_store scr;
+            memset(&scr, 0, sizeof scr);
+            if (p->kind == K_COLRANGE) {
+                scr.out = outs[0]; scr.M = p->M; scr.N = p->N; scr.col_begin = p->col0; scr.col_end = p->col1;
+                scr.row_first = p->d_cr_rlo; scr.row_count = p->d_cr_cnt; scr.dest = (const long long *)p->d_cr_off;
+                scr.color = p->d_color; scr.color_bytes = p->color8 ? 1 : 4; scr.C = (int)p->C; scr.elem_bytes = (int)sizeof(real_t);
+                scr.pairs = p->cr_pairs ? 1 : 0; scr.nblk = p->cr_nblk; scr.block_size = p->cr_bs; scr.bl = p->cr_bl; scr.bu = p->cr_bu;
+            }
             bs.M = p->M; bs.N = p->N; bs.entry_begin = p->entry_begin; bs.col_begin = p->col0; bs.col_end = p->col1;
             bs.l = p->store_l; bs.u = p->store_u; bs.C = p->store_C; bs.shift = p->store_shift;
             bs.elem_bytes = (int)sizeof(real_t);
@@ -1952,9 +1977,11 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.ncolors = B;
             lp.pts = p->pts;
             lp.nparts = 1;
-            lp.diff = (p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1;
-            lp.store = stencil ? (const void *)&s5 : (const void *)&bs;
-            lp.store_kind = stencil ? FD_STORE_STENCIL5 : FD_STORE_BAND;
+            lp.diff = p->fdtype == FD_COMPLEX ? 0 : ((p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1);
+            lp.store = p->kind == K_COLRANGE ? (const void *)&scr : stencil ? (const void *)&s5 : (const void *)&bs;
+            lp.store_kind = p->kind == K_COLRANGE ? FD_STORE_COLRANGE : stencil ? FD_STORE_STENCIL5 : FD_STORE_BAND;
+            lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
+            lp.imag_only = lp.is_complex;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (store) returned %d", rc);
             if (rc == 0) {

@@ -1154,6 +1154,200 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
     }
 }
 
+// fd_lazy_points.store with a fd_colrange_store (include/fdjac_device.h), complex step: the block-coupled fixture evaluated at
+// the lazily perturbed points and imag(f) / eps stored into the BlockBandedMatrix data by this launch (config 5: 245 MB of stored
+// values written once, instead of written as f! values, read back and written again -- 0.195 -> 0.06 ms per Jacobian).
+// Phase A is k_f_blockcoupled_lazy's: sigma of every point of the batch for the blocks g0-2 .. g0+kBcS+1 (the tree of the base
+// values in LDS, a perturbed lane re-adds along its leaf-to-root path).  Phase B is column-centric: a wave takes a column (b, j) of
+// the group -- point q = its colour -- and its lanes are the ROW PAIRS of the column's stored range (blocks b-1, b, b+1): for a row
+// k of block b' the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point q, the operations of
+// k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q touches those rows),
+// divided by eps_q: same bits as the hand-over path.  Every column is one contiguous, aligned run of 16-B stores.
+constexpr int kBcS = 6;
+__device__ __forceinline__ int bc_lane_int(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ long long bc_lane_i64(long long v, int i)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xffffffffu), i);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), i);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename CT>
+__global__ void __launch_bounds__(kBlock)
+k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
+                       int64_t nb, int bs, int64_t blk0, int64_t blk1, fd_colrange_store st)
+{
+    typedef cd T;
+    extern __shared__ real_t s_bcs[];
+    constexpr int NBLK = kBcS + 4, NW = kBlock / 64, NIT = (NBLK + NW - 1) / NW;
+    const int PB = B + 1;
+    T *sig = reinterpret_cast<T *>(s_bcs);            // [NBLK][PB]   sigma of every point
+    T *tree = sig + (size_t)NBLK * PB;               // [NW][128]    the batch-base summation tree of the block a wave is working on
+    real_t *rx = reinterpret_cast<real_t *>(tree + (size_t)NW * 128);   // [(kBcS + 2) * 64] x of the rows of blocks g0-1 .. g0+kBcS
+    real_t *rc = rx + (kBcS + 2) * 64;               //   cos(x)
+    real_t *rz = rc + (kBcS + 2) * 64;               //   cos(x) * sinh(0 * x): imag(sin(x~)) of a row the point does not perturb
+    real_t *ce = rz + (kBcS + 2) * 64;               // [B] step size of every colour of the batch,
+    real_t *cy = ce + B;                             //     its reciprocal (div_shared),
+    real_t *cs = cy + B;                             //     sinh(eps): imag(sin(x + i eps)) = cos(x) sinh(eps)
+    int *owner = reinterpret_cast<int *>(cs + B + (B & 1));   // [waves][B]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t g0 = blk0 + (int64_t)blockIdx.x * kBcS;
+    const real_t w = (real_t)(lane + 1) / (real_t)bs;
+    int *own = owner + wave * B;
+
+    // every global load of phase A up front (the blocks g0-2 .. g0+kBcS+1 this wave sums: x and the colour of their columns)
+    real_t xa[NIT];
+    int ca[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int lb = wave + it * NW;
+        const int64_t bb = g0 - 2 + lb;
+        const bool act = (lb < NBLK) & (bb >= 0) & (bb < nb) & (lane < bs);
+        xa[it] = 0.0; ca[it] = -1;
+        if (act) {
+            xa[it] = x[bb * bs + lane];
+            const int c = (int)color[bb * bs + lane];
+            int cj = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+            if (cj >= B) cj = -1;
+            ca[it] = cj;
+        }
+    }
+    for (int q = threadIdx.x; q < B; q += kBlock) {
+        const real_t e = eps[c_lo + q];
+        ce[q] = e; cy[q] = (real_t)1 / e; cs[q] = sinh(e);
+    }
+    __syncthreads();
+
+    // ---- phase A (as k_f_blockcoupled_lazy, MODE 2): sig of blocks g0-2 .. g0+kBcS+1 for every point of the batch
+    T *tr = tree + (size_t)wave * 128;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int lb = wave + it * NW;
+        if (lb >= NBLK) break;
+        const int64_t bb = g0 - 2 + lb;
+        const bool inb = (bb >= 0) & (bb < nb);
+        const bool act = inb & (lane < bs);
+        const real_t xj = xa[it];
+        const int cj = ca[it];
+        if (lb >= 1 && lb <= kBcS + 2) {             // the rows phase B evaluates: x, cos once per row
+            const int at = (lb - 1) * 64 + lane;
+            const real_t c0 = act ? cos(xj) : (real_t)0;
+            rx[at] = xj;
+            rc[at] = c0;
+            rz[at] = act ? c0 * sinh(0.0 * xj) : (real_t)0;     // (sinh(0) through the same library call as the row-centric kernel)
+        }
+        T *sg = sig + (size_t)lb * PB;
+        T acc = act ? zero_of<T>() + w * bc_make(xj, 0.0, 0, T{}) : zero_of<T>();
+        bc_wave_sync();                              // (the previous block's tree is no longer read)
+        tr[lane] = acc;
+        int base_at = 64;
+        for (int off = 32; off > 0; off >>= 1) {
+            cd o{__shfl_down(acc.re, off, 64), __shfl_down(acc.im, off, 64)};
+            acc = acc + o;
+            if (lane < off && off > 1) tr[base_at + lane] = acc;
+            base_at += off;
+        }
+        T root{__shfl(acc.re, 0, 64), __shfl(acc.im, 0, 64)};
+        for (int q = lane; q < B; q += 64) own[q] = -1;
+        bc_wave_sync();
+        if (cj >= 0) own[cj] = lane;
+        bc_wave_sync();
+        const bool dup = (cj >= 0) && (own[cj] != lane);
+        const bool any_dup = __builtin_amdgcn_ballot_w64(dup) != 0;
+        if (!any_dup) {
+            for (int q = lane; q < PB - 1; q += 64) sg[q] = inb ? root : zero_of<T>();
+            bc_wave_sync();
+            if (cj >= 0) {
+                const real_t e = ce[cj];
+                T n = zero_of<T>() + w * bc_make(xj, e, 0, T{});
+                int idx = lane;
+                n = n + tr[idx ^ 32]; idx &= 31;
+                n = n + tr[64 + (idx ^ 16)]; idx &= 15;
+                n = n + tr[96 + (idx ^ 8)]; idx &= 7;
+                n = n + tr[112 + (idx ^ 4)]; idx &= 3;
+                n = n + tr[120 + (idx ^ 2)]; idx &= 1;
+                n = n + tr[124 + (idx ^ 1)];
+                sg[cj] = n;
+            }
+        } else {
+            for (int q = 0; q < PB - 1; ++q) {
+                T term = zero_of<T>();
+                if (act) {
+                    const real_t d = (cj == q) ? ce[q] : 0.0;
+                    term = zero_of<T>() + w * bc_make(xj, d, 0, T{});
+                }
+                term = tree_sum64<T>(term);
+                if (lane == 0) sg[q] = inb ? term : zero_of<T>();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: one wave per column of the group, lanes = row pairs of the column's stored range.  A wave's columns are wave,
+    // wave + NW, ...: lane i first fetches what column i of them needs (colour, row range, destination) in one coalesced round
+    real_t *outp = (real_t *)st.out;
+    const int ncols_grp = kBcS * bs;
+    for (int i0 = 0; wave + i0 * NW < ncols_grp; i0 += 64) {
+        int q_l = -1, rfirst_l = 0, rcount_l = 0;
+        long long dest_l = 0;
+        {
+            const int cidx = wave + (i0 + lane) * NW;
+            const int lb = 2 + cidx / bs, jl = cidx - (lb - 2) * bs;
+            const int64_t b = g0 - 2 + lb;
+            const int64_t j = b * bs + jl;
+            if (cidx < ncols_grp && b < blk1 && b < nb && j >= st.col_begin && j < st.col_end) {
+                const int c = (int)color[j];
+                const int q = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+                if (q >= 0 && q < B) {                                   // (else: another batch's colour)
+                    const int64_t jj = j - st.col_begin;
+                    q_l = q; rfirst_l = st.row_first[jj]; rcount_l = st.row_count[jj]; dest_l = st.dest[jj];
+                }
+            }
+        }
+        for (int i = 0; i < 64; ++i) {
+            const int cidx = wave + (i0 + i) * NW;
+            if (cidx >= ncols_grp) break;
+            const int q = bc_lane_int(q_l, i);
+            if (q < 0) continue;
+            const int rfirst = bc_lane_int(rfirst_l, i), rcount = bc_lane_int(rcount_l, i);
+            real_t *dst = outp + bc_lane_i64(dest_l, i);
+            const int lb = 2 + cidx / bs;
+            const int64_t bcol = g0 - 2 + lb;
+            const int64_t j = bcol * bs + (cidx - (lb - 2) * bs);
+            const real_t e = ce[q], ye = cy[q], sh = cs[q];
+            // block bandwidths (1, 1), equal even blocks: the column's rows are the blocks max(b-1, 0) .. min(b+1, nb-1), a row
+            // pair never straddles two of them
+            const int lbf = lb - (bcol > 0 ? 1 : 0);
+            const int hit_rp = (int)(j - rfirst);                        // the column's own row, relative to its first row
+            for (int rp = 2 * lane; rp < rcount; rp += 128) {
+                const int blkoff = rp >= 2 * bs ? 2 : (rp >= bs ? 1 : 0);
+                const int lbk = lbf + blkoff, at = (lbk - 1) * 64 + (rp - blkoff * bs);
+                const T *sm = sig + (size_t)(lbk - 1) * PB;
+                const T S = (sm[q] + sm[q + PB]) + sm[q + 2 * PB];
+                const r2_t xk2 = *reinterpret_cast<const r2_t *>(rx + at), rz2 = *reinterpret_cast<const r2_t *>(rz + at);
+                const real_t xk[2] = {xk2.x, xk2.y}, rzk[2] = {rz2.x, rz2.y};
+                real_t v2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool hit = rp + h == hit_rp;
+                    // imag(x~ * S + sin(x~)), x~ = (xk, hit ? e : 0):  (x~.re * S.im + x~.im * S.re) + cos(xk) * sinh(x~.im)
+                    const real_t xim = hit ? e : (real_t)0;
+                    const real_t snim = hit ? rc[at + h] * sh : rzk[h];
+                    const real_t vim = (xk[h] * S.im + xim * S.re) + snim;
+                    v2[h] = div_shared<true>(vim, e, ye);
+                }
+                if (st.pairs) __builtin_nontemporal_store(r2_t{v2[0], v2[1]}, reinterpret_cast<r2_t *>(dst + rp));
+                else { dst[rp] = v2[0]; dst[rp + 1] = v2[1]; }
+            }
+        }
+    }
+}
+
+static size_t bcs_lds_bytes(int ncolors)
+{
+    return ((size_t)(kBcS + 4) * (size_t)(ncolors + 1) + (size_t)(kBlock / 64) * 128) * 2 * sizeof(real_t) +
+           (size_t)3 * (kBcS + 2) * 64 * sizeof(real_t) + (size_t)(3 * ncolors + 2) * sizeof(real_t) + (size_t)(kBlock / 64) * (size_t)ncolors * 4;
+}
+
 // LDS of k_f_blockcoupled_lazy: sigma of every point + the base summation tree, per block of the group, + owners
 static size_t bc_lds_bytes(int ncolors, int pts, bool cplx)
 {
@@ -1167,6 +1361,22 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
 {
     const int64_t nb = b->prm[0], bs = b->prm[1];
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
+    if (lp->store) {
+        // the launch stores imag(f) / eps into the block-banded data itself (fd_colrange_store): complex step, the block structure of
+        // this fixture (dense blocks of size bs, block bandwidths (1, 1)), even block size (row pairs never straddle blocks)
+        if (lp->store_kind != FD_STORE_COLRANGE || mode != 2 || !b->store_wave) return FD_LAZY_DECLINED;
+        const fd_colrange_store st = *(const fd_colrange_store *)lp->store;
+        if (st.elem_bytes != (int)sizeof(real_t) || st.nblk != nb || st.block_size != bs || st.bl != 1 || st.bu != 1 || (bs & 1) || bs > 64 ||
+            st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors) > (size_t)60 * 1024)
+            return FD_LAZY_DECLINED;
+        fd_colrange_store stl = st;
+        stl.pairs = st.pairs && ((((uintptr_t)st.out) & kPairMask) == 0) ? 1 : 0;
+        const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
+        const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
+        hipLaunchKernelGGL((k_f_blockcoupled_store<CT>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
+                           (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, stl);
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
     const int64_t blk0 = r0 / bs, blk1 = (r1 - 1) / bs + 1;
     const int64_t g = (blk1 - blk0 + kBcG - 1) / kBcG;
     const size_t shm = bc_lds_bytes(lp->ncolors, lp->pts, mode == 2);
@@ -1333,11 +1543,12 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
     if (lp->diff && (b->family == FD_F_BLOCKCOUPLED || lp->is_complex || lp->base_out)) return 8;   // (not registered with FD_LAZY_CAP_DIFF)
-    if (lp->store && !(lp->diff && (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL)))
-        return 9;   // (FD_LAZY_CAP_STORE: the tridiagonal and Laplacian families)
+    if (lp->store && !((lp->diff && (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL)) ||
+                       (b->family == FD_F_BLOCKCOUPLED && lp->is_complex)))
+        return 9;   // (FD_LAZY_CAP_STORE: the tridiagonal and Laplacian families; the block-coupled family in the complex step)
     const int64_t npts = (int64_t)lp->ncolors * lp->pts + ((lp->base_out || lp->diff == 2) ? 1 : 0);
     // the block-coupled kernel keeps one sigma per (block, point) in LDS: decline batches that would not fit
-    if (b->family == FD_F_BLOCKCOUPLED && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
+    if (b->family == FD_F_BLOCKCOUPLED && !lp->store && bc_lds_bytes(lp->ncolors, lp->pts, lp->is_complex != 0) > (size_t)56 * 1024)
         return FD_LAZY_DECLINED;
     const bool count_points = lp->nparts <= 1 || lp->part == 0;   // row strips: the parts together are ONE evaluation per point
     b->launches.fetch_add(1);
@@ -1473,7 +1684,8 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |
-                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL) ? FD_LAZY_CAP_STORE : 0)) : 0;
+                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL ||
+                                 b->family == FD_F_BLOCKCOUPLED) ? FD_LAZY_CAP_STORE : 0)) : 0;
     return FD_OK;
 }
 

@@ -225,6 +225,10 @@ struct fd_plan {
     // ... and the 5-point stencil on an nx x ny grid (fd_stencil5_store): exact pattern + valid colouring verified
     bool store5_ok = false;
     int64_t store5_nx = 0, store5_ny = 0;
+    // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded
+    bool store_cr_ok = false;
+    int64_t cr_nblk = 0, cr_bs = 0;
+    int cr_bl = 0, cr_bu = 0;
     bool bd_allowed = true;        //   FDJAC_BAND_DESC=0: always load
     int64_t bd_t0 = 0, bd_t1 = 0;
     int64_t w2_ntiles = 0;
@@ -287,7 +291,8 @@ struct fd_plan {
 // does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
 static inline bool store_active(const fd_plan *p)
 {
-    return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE) &&
-           p->fdtype != FD_COMPLEX && !p->has_none &&
+    if (!(p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE)) || p->has_none) return false;
+    if (p->kind == fdjac::K_COLRANGE) return p->store_cr_ok && p->fdtype == FD_COMPLEX;   // (the block-coupled launcher's storing kernel is the complex step's)
+    return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->fdtype != FD_COMPLEX &&
            (p->kind == fdjac::K_CSC || p->kind == fdjac::K_BANDED || p->kind == fdjac::K_TRIDIAG);
 }

@@ -123,7 +123,27 @@ FD_DEVICE_FN long long fd_stencil5_colptr(const fd_stencil5_store *d, long long 
            - (north > 0 ? north : 0);
 }
 
-enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2 };   /* what fd_lazy_points.store points to */
+/* ---- storage in which the stored rows of every column are CONSECUTIVE (BlockBandedMatrix data: the in-band blocks of a
+ * block-column are stacked, ext/FiniteDiffBlockBandedMatricesExt.jl:44-68): row r of local column j lives at
+ * out[dest[j - col_begin] + (r - row_first[j - col_begin])], row_first <= r < row_first + row_count.  Handed out
+ * (store_kind = FD_STORE_COLRANGE) when the plan has verified that colorvec is a VALID colouring (columns that share a row
+ * differ in colour), so that a column-centric evaluation forms the operands of the colour-batched one. */
+typedef struct fd_colrange_store {
+    void *out;                       /* the stored values of the local column range, device memory */
+    long long M, N;
+    long long col_begin, col_end;
+    const int *row_first;            /* device, per local column */
+    const int *row_count;            /* device */
+    const long long *dest;           /* device */
+    const void *color;               /* device: 0-based colour of every column (all N), color_bytes each */
+    int color_bytes, C;
+    int elem_bytes;
+    int pairs;                       /* 1: every row_first, row_count and dest is even (16-byte stores of row pairs are aligned) */
+    long long nblk, block_size;      /* block structure if the blocks are uniform (block_size = 0: ragged), block bandwidths */
+    int bl, bu;
+} fd_colrange_store;
+
+enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3 };   /* what fd_lazy_points.store points to */
 
 #if defined(__HIPCC__) && defined(__cplusplus)
 /* ---------------------------------------------------------------------------------------------------------------------------

@@ -1723,3 +1723,59 @@ def test_lazy_store_stencil5_bit_identical(monkeypatch, oracle, fdtype, case):
         ref = oracle.jacobian(fdtype, oracle.Fixture(fam, nx, ny), x.cpu().numpy(), colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
         _tol_ok(res[0][0].cpu().numpy(), ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 8.0, "stencil store " + case)
         assert res[0][1] == ref["fcalls"]
+
+
+@pytest.mark.parametrize("case", ["c5_shape", "bs8", "bs64", "bs2", "window", "window_mid_block", "chunked", "pairs_off", "invalid_colouring",
+                                  "odd_block", "none", "cyclic"])
+def test_lazy_store_blockbanded_complex_bit_identical(monkeypatch, oracle, case):
+    # fd_colrange_store (include/fdjac_device.h), BASELINE config 5's shape: BlockBandedMatrix of equal dense blocks, complex step,
+    # valid colouring -> the block-coupled fixture's launch forms sigma of every point on chip, evaluates every (row, column)
+    # entry at its own point and stores imag / eps into the block-banded data itself (k_f_blockcoupled_store); bits of the
+    # hand-over path (FDJAC_LAZY_STORE=0), same f! evaluation count, oracle parity.  Shapes the kernel does not take (odd
+    # blocks, an invalid colouring, colorvec 0) keep the hand-over path.
+    nb, bs = {"c5_shape": (40, 32), "bs64": (9, 64), "bs2": (70, 2), "odd_block": (25, 5), "window": (40, 32), "window_mid_block": (40, 32),
+              "chunked": (40, 32)}.get(case, (30, 8))
+    sizes = np.full(nb, bs)
+    N = int(sizes.sum())
+    lay = P.BlockBandedLayout(sizes, 1, 1)
+    colors = lay.colors()
+    if case == "cyclic":
+        colors = P.cyclic_colors(N, 3 * bs)
+    if case == "invalid_colouring":
+        colors = colors.copy()
+        colors[bs] = colors[0]                    # first columns of blocks 0 and 1 share rows 0 .. 2 bs - 1
+    if case == "none":
+        colors = colors.copy()
+        colors[[3, N - 2]] = 0
+    win = {"window": (2 * bs + 1, N - bs), "window_mid_block": (2 * bs + 6, N - bs - 3)}.get(case)
+    cap = 60_000 if case == "chunked" else 0
+    x = _dev(np.random.default_rng(77).random(N) - 0.3)
+    Jb = fd.BlockBandedMatrix(None, lay)
+    res = []
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        plan = fd.make_plan(Jb, Jb, colors, "complex", scratch_bytes=cap, col_window=win)
+        f = fd.BuiltinF("blockcoupled", nb, int(sizes[0]))
+        assert f.lazy_caps & fd.lib.LAZY_CAP_STORE
+        plan.set_lazy(f, store=(case != "pairs_off"))
+        want = store == "1" and case not in ("pairs_off", "invalid_colouring", "none")
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == (1 if want else 0), case
+        if case == "chunked":
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        out = _dev(np.full(plan.out_len(0) + 2, np.nan))
+        plan.jacobian(f, x, [out[:-2]])
+        assert torch.isnan(out[-2:]).all()
+        res.append((out[:-2], f.fcalls, plan.fcalls_last, plan.timings()))
+    if win is None and case != "none":
+        assert not torch.isnan(res[0][0]).any()
+    a, b = res[0][0].view(torch.int64), res[1][0].view(torch.int64)
+    bad = torch.nonzero(a != b).flatten()
+    assert bad.numel() == 0, (case, int(bad.numel()), bad[:8].tolist(), res[0][0][bad[:8]].tolist(), res[1][0][bad[:8]].tolist())
+    assert res[0][1:3] == res[1][1:3]
+    if case in ("c5_shape", "bs8", "bs2", "cyclic"):
+        ref = oracle.jacobian("complex", oracle.Fixture("blockcoupled", nb, bs), x.cpu().numpy(), colors, kind=oracle.PAT_BLOCKBANDED,
+                              blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts,
+                              block_strides=lay.block_strides, out_len=lay.data_len)
+        got = res[0][0].cpu().numpy()
+        assert np.max(np.abs(got - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
+        assert res[0][1] == ref["fcalls"]
