@@ -1158,11 +1158,10 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 // the lazily perturbed points and imag(f) / eps stored into the BlockBandedMatrix data by this launch (config 5: 245 MB of stored
 // values written once, instead of written as f! values, read back and written again -- 0.195 -> 0.06 ms per Jacobian).
 // Phase A is k_f_blockcoupled_lazy's: sigma of every point of the batch for the blocks g0-2 .. g0+kBcS+1 (the tree of the base
-// values in LDS, a perturbed lane re-adds along its leaf-to-root path).  Phase B is column-centric: a wave takes a column (b, j) of
-// the group -- point q = its colour -- and its lanes are the ROW PAIRS of the column's stored range (blocks b-1, b, b+1): for a row
-// k of block b' the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point q, the operations of
-// k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q touches those rows),
-// divided by eps_q: same bits as the hand-over path.  Every column is one contiguous, aligned run of 16-B stores.
+// values in LDS, a perturbed lane re-adds along its leaf-to-root path).  Phase B is column-centric: for column (b, j) -- point q = its
+// colour -- and a row k of block b' in b-1 .. b+1 the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point
+// q, the operations of k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q
+// touches those rows), divided by eps_q: same bits as the hand-over path.
 constexpr int kBcS = 6;
 __device__ __forceinline__ int bc_lane_int(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
@@ -1171,7 +1170,7 @@ __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), i);
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-template <typename CT>
+template <typename CT, bool TWO>
 __global__ void __launch_bounds__(kBlock)
 k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
                        int64_t nb, int bs, int64_t blk0, int64_t blk1, fd_colrange_store st)
@@ -1182,7 +1181,8 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     const int PB = B + 1;
     T *sig = reinterpret_cast<T *>(s_bcs);            // [NBLK][PB]   sigma of every point
     T *tree = sig + (size_t)NBLK * PB;               // [NW][128]    the batch-base summation tree of the block a wave is working on
-    real_t *rx = reinterpret_cast<real_t *>(tree + (size_t)NW * 128);   // [(kBcS + 2) * 64] x of the rows of blocks g0-1 .. g0+kBcS
+    T *ssum = tree + (size_t)NW * 128;               // [kBcS + 2][B] (sig[k-1] + sig[k]) + sig[k+1] of the row blocks g0-1 .. g0+kBcS
+    real_t *rx = reinterpret_cast<real_t *>(ssum + (size_t)(kBcS + 2) * B);   // [(kBcS + 2) * 64] x of the rows of those blocks
     real_t *rc = rx + (kBcS + 2) * 64;               //   cos(x)
     real_t *rz = rc + (kBcS + 2) * 64;               //   cos(x) * sinh(0 * x): imag(sin(x~)) of a row the point does not perturb
     real_t *ce = rz + (kBcS + 2) * 64;               // [B] step size of every colour of the batch,
@@ -1282,61 +1282,70 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     }
     __syncthreads();
 
-    // ---- phase B: one wave per column of the group, lanes = row pairs of the column's stored range.  A wave's columns are wave,
-    // wave + NW, ...: lane i first fetches what column i of them needs (colour, row range, destination) in one coalesced round
+    // S of every (row block, point): (sig[k-1] + sig[k]) + sig[k+1], the sum k_f_blockcoupled_lazy's phase B forms, once per group
+    for (int idx = threadIdx.x; idx < (kBcS + 2) * B; idx += kBlock) {
+        const int lbk = 1 + idx / B, q = idx - (lbk - 1) * B;
+        const T *sm = sig + (size_t)(lbk - 1) * PB + q;
+        ssum[idx] = (sm[0] + sm[PB]) + sm[2 * PB];
+    }
+    __syncthreads();
+
+    // ---- phase B, column-centric.  A wave takes a unit = half of the columns of one block-column; a lane is a ROW of the block (and,
+    // TWO: blocks of <= 32 rows, one of two adjacent columns): it keeps x, cos(x) sinh(0 x) of its row in the three row blocks
+    // b-1, b, b+1 in registers across the unit's columns and per column evaluates its three entries at the column's own point and
+    // stores them (32 lanes = 256 contiguous bytes per row block; a column is one contiguous run).
     real_t *outp = (real_t *)st.out;
-    const int ncols_grp = kBcS * bs;
-    for (int i0 = 0; wave + i0 * NW < ncols_grp; i0 += 64) {
-        int q_l = -1, rfirst_l = 0, rcount_l = 0;
+    const int half = TWO ? lane >> 5 : 0, r = TWO ? lane & 31 : lane;
+    const bool ract = r < bs;
+    const int ucols = (bs + 1) / 2;                                      // columns of a unit
+    for (int u = wave; u < 2 * kBcS; u += NW) {
+        const int lb = 2 + (u >> 1), cstart = (u & 1) * ucols, ncol = min(bs, cstart + ucols) - cstart;
+        const int64_t bcol = g0 - 2 + lb;
+        if (bcol >= blk1 || bcol >= nb || ncol <= 0) continue;
+        // lane i: colour and destination of column i of the unit, one coalesced round
+        int q_l = -1;
         long long dest_l = 0;
-        {
-            const int cidx = wave + (i0 + lane) * NW;
-            const int lb = 2 + cidx / bs, jl = cidx - (lb - 2) * bs;
-            const int64_t b = g0 - 2 + lb;
-            const int64_t j = b * bs + jl;
-            if (cidx < ncols_grp && b < blk1 && b < nb && j >= st.col_begin && j < st.col_end) {
+        if (lane < ncol) {
+            const int64_t j = bcol * bs + cstart + lane;
+            if (j >= st.col_begin && j < st.col_end) {
                 const int c = (int)color[j];
                 const int q = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
-                if (q >= 0 && q < B) {                                   // (else: another batch's colour)
-                    const int64_t jj = j - st.col_begin;
-                    q_l = q; rfirst_l = st.row_first[jj]; rcount_l = st.row_count[jj]; dest_l = st.dest[jj];
-                }
+                if (q >= 0 && q < B) { q_l = q; dest_l = st.dest[j - st.col_begin]; }      // (else: another batch's colour)
             }
         }
-        for (int i = 0; i < 64; ++i) {
-            const int cidx = wave + (i0 + i) * NW;
-            if (cidx >= ncols_grp) break;
-            const int q = bc_lane_int(q_l, i);
-            if (q < 0) continue;
-            const int rfirst = bc_lane_int(rfirst_l, i), rcount = bc_lane_int(rcount_l, i);
-            real_t *dst = outp + bc_lane_i64(dest_l, i);
-            const int lb = 2 + cidx / bs;
-            const int64_t bcol = g0 - 2 + lb;
-            const int64_t j = bcol * bs + (cidx - (lb - 2) * bs);
-            const real_t e = ce[q], ye = cy[q], sh = cs[q];
-            // block bandwidths (1, 1), equal even blocks: the column's rows are the blocks max(b-1, 0) .. min(b+1, nb-1), a row
-            // pair never straddles two of them
-            const int lbf = lb - (bcol > 0 ? 1 : 0);
-            const int hit_rp = (int)(j - rfirst);                        // the column's own row, relative to its first row
-            for (int rp = 2 * lane; rp < rcount; rp += 128) {
-                const int blkoff = rp >= 2 * bs ? 2 : (rp >= bs ? 1 : 0);
-                const int lbk = lbf + blkoff, at = (lbk - 1) * 64 + (rp - blkoff * bs);
-                const T *sm = sig + (size_t)(lbk - 1) * PB;
-                const T S = (sm[q] + sm[q + PB]) + sm[q + 2 * PB];
-                const r2_t xk2 = *reinterpret_cast<const r2_t *>(rx + at), rz2 = *reinterpret_cast<const r2_t *>(rz + at);
-                const real_t xk[2] = {xk2.x, xk2.y}, rzk[2] = {rz2.x, rz2.y};
-                real_t v2[2];
+        // the lane's rows: block bcol - 1 + m, row r of it (block bandwidths (1, 1), equal blocks)
+        real_t xk[3], rzk[3];
+        bool mv[3];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bool hit = rp + h == hit_rp;
-                    // imag(x~ * S + sin(x~)), x~ = (xk, hit ? e : 0):  (x~.re * S.im + x~.im * S.re) + cos(xk) * sinh(x~.im)
-                    const real_t xim = hit ? e : (real_t)0;
-                    const real_t snim = hit ? rc[at + h] * sh : rzk[h];
-                    const real_t vim = (xk[h] * S.im + xim * S.re) + snim;
-                    v2[h] = div_shared<true>(vim, e, ye);
-                }
-                if (st.pairs) __builtin_nontemporal_store(r2_t{v2[0], v2[1]}, reinterpret_cast<r2_t *>(dst + rp));
-                else { dst[rp] = v2[0]; dst[rp + 1] = v2[1]; }
+        for (int m = 0; m < 3; ++m) {
+            const int64_t kb = bcol - 1 + m;
+            mv[m] = ract & (kb >= 0) & (kb < nb);
+            const int at = (lb - 2 + m) * 64 + r;
+            xk[m] = rx[at]; rzk[m] = rz[at];
+        }
+        const real_t rcm = rc[(lb - 1) * 64 + r];
+        const int first = bcol > 0 ? 0 : 1;                               // the column's stored rows start at block max(bcol - 1, 0)
+        const T *su = ssum + (size_t)(lb - 2) * B;
+        for (int it = 0; it * (TWO ? 2 : 1) < ncol; ++it) {
+            const int ci = TWO ? 2 * it + half : it;                      // column of the unit
+            const int src = ci < ncol ? ci : 0;
+            const int q = __shfl(q_l, src, 64);
+            const unsigned dlo = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l & 0xffffffffu), src, 64);
+            const unsigned dhi = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l >> 32), src, 64);
+            if (ci >= ncol || q < 0) continue;
+            real_t *dst = outp + (long long)(((unsigned long long)dhi << 32) | dlo) + r;
+            const real_t e = ce[q], ye = cy[q], sh = cs[q];
+            const int jl = cstart + ci;                                   // the column's own row is row jl of the middle block
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (!mv[m]) continue;
+                const T S = su[(size_t)m * B + q];
+                const bool hit = (m == 1) & (r == jl);
+                // imag(x~ * S + sin(x~)), x~ = (xk, hit ? e : 0):  (x~.re * S.im + x~.im * S.re) + cos(xk) * sinh(x~.im)
+                const real_t xim = hit ? e : (real_t)0;
+                const real_t snim = hit ? rcm * sh : rzk[m];
+                const real_t vim = (xk[m] * S.im + xim * S.re) + snim;
+                __builtin_nontemporal_store(div_shared<true>(vim, e, ye), dst + (m - first) * bs);
             }
         }
     }
@@ -1344,7 +1353,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
 
 static size_t bcs_lds_bytes(int ncolors)
 {
-    return ((size_t)(kBcS + 4) * (size_t)(ncolors + 1) + (size_t)(kBlock / 64) * 128) * 2 * sizeof(real_t) +
+    return ((size_t)(kBcS + 4) * (size_t)(ncolors + 1) + (size_t)(kBlock / 64) * 128 + (size_t)(kBcS + 2) * (size_t)ncolors) * 2 * sizeof(real_t) +
            (size_t)3 * (kBcS + 2) * 64 * sizeof(real_t) + (size_t)(3 * ncolors + 2) * sizeof(real_t) + (size_t)(kBlock / 64) * (size_t)ncolors * 4;
 }
 
@@ -1363,18 +1372,20 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
     const int mode = lp->is_complex ? 2 : (lp->pts == 2 ? 1 : 0);
     if (lp->store) {
         // the launch stores imag(f) / eps into the block-banded data itself (fd_colrange_store): complex step, the block structure of
-        // this fixture (dense blocks of size bs, block bandwidths (1, 1)), even block size (row pairs never straddle blocks)
+        // this fixture (dense blocks of bs <= 64 rows, block bandwidths (1, 1))
         if (lp->store_kind != FD_STORE_COLRANGE || mode != 2 || !b->store_wave) return FD_LAZY_DECLINED;
         const fd_colrange_store st = *(const fd_colrange_store *)lp->store;
-        if (st.elem_bytes != (int)sizeof(real_t) || st.nblk != nb || st.block_size != bs || st.bl != 1 || st.bu != 1 || (bs & 1) || bs > 64 ||
-            st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors) > (size_t)60 * 1024)
+        if (st.elem_bytes != (int)sizeof(real_t) || st.nblk != nb || st.block_size != bs || st.bl != 1 || st.bu != 1 || bs > 64 ||
+            st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors) > (size_t)64 * 1024)
             return FD_LAZY_DECLINED;
-        fd_colrange_store stl = st;
-        stl.pairs = st.pairs && ((((uintptr_t)st.out) & kPairMask) == 0) ? 1 : 0;
         const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
         const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
-        hipLaunchKernelGGL((k_f_blockcoupled_store<CT>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
-                           (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, stl);
+        if (bs <= 32)
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
+                               (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
+        else
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, false>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
+                               (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
     const int64_t blk0 = r0 / bs, blk1 = (r1 - 1) / bs + 1;
