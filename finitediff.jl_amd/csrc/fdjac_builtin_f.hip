@@ -1163,6 +1163,12 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 // q, the operations of k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q
 // touches those rows), divided by eps_q: same bits as the hand-over path.
 constexpr int kBcS = 6;
+// complex items of the LDS region phase A uses for its trees and owners and phase B for the S sums
+__host__ __device__ constexpr size_t bcs_shared_items(int B)
+{
+    const size_t a = (size_t)(kBcS + 2) * (size_t)B, b = (size_t)(kBlock / 64) * 128 + ((size_t)(kBlock / 64) * (size_t)B * 4 + 15) / 16;
+    return a > b ? a : b;
+}
 __device__ __forceinline__ int bc_lane_int(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
 {
@@ -1179,20 +1185,23 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     extern __shared__ real_t s_bcs[];
     constexpr int NBLK = kBcS + 4, NW = kBlock / 64, NIT = (NBLK + NW - 1) / NW;
     const int PB = B + 1;
+    constexpr int RS = TWO ? 32 : 64;                // rows of a block in the row arrays
+    constexpr int NU = (2 * kBcS + NW - 1) / NW;     // units of phase B per wave
     T *sig = reinterpret_cast<T *>(s_bcs);            // [NBLK][PB]   sigma of every point
-    T *tree = sig + (size_t)NBLK * PB;               // [NW][128]    the batch-base summation tree of the block a wave is working on
-    T *ssum = tree + (size_t)NW * 128;               // [kBcS + 2][B] (sig[k-1] + sig[k]) + sig[k+1] of the row blocks g0-1 .. g0+kBcS
-    real_t *rx = reinterpret_cast<real_t *>(ssum + (size_t)(kBcS + 2) * B);   // [(kBcS + 2) * 64] x of the rows of those blocks
-    real_t *rc = rx + (kBcS + 2) * 64;               //   cos(x)
-    real_t *rz = rc + (kBcS + 2) * 64;               //   cos(x) * sinh(0 * x): imag(sin(x~)) of a row the point does not perturb
-    real_t *ce = rz + (kBcS + 2) * 64;               // [B] step size of every colour of the batch,
+    T *ssum = sig + (size_t)NBLK * PB;               // [kBcS + 2][B] (sig[k-1] + sig[k]) + sig[k+1] of the row blocks g0-1 .. g0+kBcS;
+    T *tree = ssum;                                  //   before that, phase A's [NW][128] batch-base summation trees
+    int *owner = reinterpret_cast<int *>(tree + (size_t)NW * 128);      //   and [NW][B] owners
+    real_t *rx = reinterpret_cast<real_t *>(ssum + bcs_shared_items(B));   // [(kBcS + 2) * RS] x of the rows of those blocks
+    real_t *rc = rx + (kBcS + 2) * RS;               //   cos(x)
+    real_t *rz = rc + (kBcS + 2) * RS;               //   cos(x) * sinh(0 * x): imag(sin(x~)) of a row the point does not perturb
+    real_t *ce = rz + (kBcS + 2) * RS;               // [B] step size of every colour of the batch,
     real_t *cy = ce + B;                             //     its reciprocal (div_shared),
     real_t *cs = cy + B;                             //     sinh(eps): imag(sin(x + i eps)) = cos(x) sinh(eps)
-    int *owner = reinterpret_cast<int *>(cs + B + (B & 1));   // [waves][B]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t g0 = blk0 + (int64_t)blockIdx.x * kBcS;
     const real_t w = (real_t)(lane + 1) / (real_t)bs;
     int *own = owner + wave * B;
+    const int ucols = (bs + 1) / 2;                  // columns of a unit of phase B (half a block-column)
 
     // every global load of phase A up front (the blocks g0-2 .. g0+kBcS+1 this wave sums: x and the colour of their columns)
     real_t xa[NIT];
@@ -1209,6 +1218,24 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             int cj = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
             if (cj >= B) cj = -1;
             ca[it] = cj;
+        }
+    }
+    // ... and of phase B: lane i holds the colour and the destination of column i of each unit the wave will store
+    int uq[NU];
+    long long ud[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = wave + k * NW;
+        const int cstart = (u & 1) * ucols, ncol = min(bs, cstart + ucols) - cstart;
+        const int64_t bcol = g0 + (u >> 1);
+        uq[k] = -1; ud[k] = 0;
+        if (u < 2 * kBcS && bcol < blk1 && bcol < nb && lane < ncol) {
+            const int64_t j = bcol * bs + cstart + lane;
+            if (j >= st.col_begin && j < st.col_end) {
+                const int c = (int)color[j];
+                const int q = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
+                if (q >= 0 && q < B) { uq[k] = q; ud[k] = st.dest[j - st.col_begin]; }       // (else: another batch's colour)
+            }
         }
     }
     for (int q = threadIdx.x; q < B; q += kBlock) {
@@ -1229,11 +1256,14 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
         const real_t xj = xa[it];
         const int cj = ca[it];
         if (lb >= 1 && lb <= kBcS + 2) {             // the rows phase B evaluates: x, cos once per row
-            const int at = (lb - 1) * 64 + lane;
+            const int at = (lb - 1) * RS + lane;
             const real_t c0 = act ? cos(xj) : (real_t)0;
+            if (lane < RS) {
             rx[at] = xj;
             rc[at] = c0;
-            rz[at] = act ? c0 * sinh(0.0 * xj) : (real_t)0;     // (sinh(0) through the same library call as the row-centric kernel)
+            const real_t z = 0.0 * xj;                          // +-0 for a finite x: sinh(+-0) = +-0 (non-finite x: the library call)
+            rz[at] = act ? c0 * (z == (real_t)0 ? z : sinh(z)) : (real_t)0;
+            }
         }
         T *sg = sig + (size_t)lb * PB;
         T acc = act ? zero_of<T>() + w * bc_make(xj, 0.0, 0, T{}) : zero_of<T>();
@@ -1297,22 +1327,15 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     real_t *outp = (real_t *)st.out;
     const int half = TWO ? lane >> 5 : 0, r = TWO ? lane & 31 : lane;
     const bool ract = r < bs;
-    const int ucols = (bs + 1) / 2;                                      // columns of a unit
-    for (int u = wave; u < 2 * kBcS; u += NW) {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = wave + k * NW;
+        if (u >= 2 * kBcS) break;
         const int lb = 2 + (u >> 1), cstart = (u & 1) * ucols, ncol = min(bs, cstart + ucols) - cstart;
         const int64_t bcol = g0 - 2 + lb;
         if (bcol >= blk1 || bcol >= nb || ncol <= 0) continue;
-        // lane i: colour and destination of column i of the unit, one coalesced round
-        int q_l = -1;
-        long long dest_l = 0;
-        if (lane < ncol) {
-            const int64_t j = bcol * bs + cstart + lane;
-            if (j >= st.col_begin && j < st.col_end) {
-                const int c = (int)color[j];
-                const int q = (c == (int)(CT)(-1) || c < 0) ? -1 : c - c_lo;
-                if (q >= 0 && q < B) { q_l = q; dest_l = st.dest[j - st.col_begin]; }      // (else: another batch's colour)
-            }
-        }
+        const int q_l = uq[k];
+        const long long dest_l = ud[k];
         // the lane's rows: block bcol - 1 + m, row r of it (block bandwidths (1, 1), equal blocks)
         real_t xk[3], rzk[3];
         bool mv[3];
@@ -1320,41 +1343,64 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
         for (int m = 0; m < 3; ++m) {
             const int64_t kb = bcol - 1 + m;
             mv[m] = ract & (kb >= 0) & (kb < nb);
-            const int at = (lb - 2 + m) * 64 + r;
+            const int at = (lb - 2 + m) * RS + r;
             xk[m] = rx[at]; rzk[m] = rz[at];
         }
-        const real_t rcm = rc[(lb - 1) * 64 + r];
+        const real_t rcm = rc[(lb - 1) * RS + r];
         const int first = bcol > 0 ? 0 : 1;                               // the column's stored rows start at block max(bcol - 1, 0)
         const T *su = ssum + (size_t)(lb - 2) * B;
+#pragma unroll 2
         for (int it = 0; it * (TWO ? 2 : 1) < ncol; ++it) {
             const int ci = TWO ? 2 * it + half : it;                      // column of the unit
             const int src = ci < ncol ? ci : 0;
-            const int q = __shfl(q_l, src, 64);
+            const int qs = __shfl(q_l, src, 64);
             const unsigned dlo = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l & 0xffffffffu), src, 64);
             const unsigned dhi = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l >> 32), src, 64);
-            if (ci >= ncol || q < 0) continue;
+            const bool cv = (ci < ncol) & (qs >= 0);
+            const int q = cv ? qs : 0;
             real_t *dst = outp + (long long)(((unsigned long long)dhi << 32) | dlo) + r;
             const real_t e = ce[q], ye = cy[q], sh = cs[q];
             const int jl = cstart + ci;                                   // the column's own row is row jl of the middle block
+            // the three entries of the lane as independent chains (nothing but the stores is predicated)
+            real_t vim[3], qv[3];
+            bool fast = sizeof(real_t) == 8;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                if (!mv[m]) continue;
                 const T S = su[(size_t)m * B + q];
                 const bool hit = (m == 1) & (r == jl);
                 // imag(x~ * S + sin(x~)), x~ = (xk, hit ? e : 0):  (x~.re * S.im + x~.im * S.re) + cos(xk) * sinh(x~.im)
                 const real_t xim = hit ? e : (real_t)0;
                 const real_t snim = hit ? rcm * sh : rzk[m];
-                const real_t vim = (xk[m] * S.im + xim * S.re) + snim;
-                __builtin_nontemporal_store(div_shared<true>(vim, e, ye), dst + (m - first) * bs);
+                vim[m] = (xk[m] * S.im + xim * S.re) + snim;
+                qv[m] = vim[m] * ye;
+                const real_t mq = fabs(qv[m]), ma = fabs(vim[m]);
+                fast = fast & (!mv[m] | ((mq >= (real_t)0x1p-900) & (mq <= (real_t)0x1p900) & (ma >= (real_t)0x1p-900) & (ma <= (real_t)0x1p900)));
             }
+            // vim / e: div_shared's correctly rounded quotient (two FMA corrections of vim * (1 / e)); true division out of its range
+            if (fast) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const real_t r0 = __builtin_fma(-e, qv[m], vim[m]);
+                    const real_t q1 = __builtin_fma(r0, ye, qv[m]);
+                    const real_t r1 = __builtin_fma(-e, q1, vim[m]);
+                    qv[m] = __builtin_fma(r1, ye, q1);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) qv[m] = vim[m] / e;
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (cv & mv[m]) __builtin_nontemporal_store(qv[m], dst + (m - first) * bs);
         }
     }
 }
 
-static size_t bcs_lds_bytes(int ncolors)
+static size_t bcs_lds_bytes(int ncolors, int bs)
 {
-    return ((size_t)(kBcS + 4) * (size_t)(ncolors + 1) + (size_t)(kBlock / 64) * 128 + (size_t)(kBcS + 2) * (size_t)ncolors) * 2 * sizeof(real_t) +
-           (size_t)3 * (kBcS + 2) * 64 * sizeof(real_t) + (size_t)(3 * ncolors + 2) * sizeof(real_t) + (size_t)(kBlock / 64) * (size_t)ncolors * 4;
+    const size_t rs = bs <= 32 ? 32 : 64;
+    return ((size_t)(kBcS + 4) * (size_t)(ncolors + 1) + bcs_shared_items(ncolors)) * 2 * sizeof(real_t) +
+           (size_t)3 * (kBcS + 2) * rs * sizeof(real_t) + (size_t)(3 * ncolors + 2) * sizeof(real_t);
 }
 
 // LDS of k_f_blockcoupled_lazy: sigma of every point + the base summation tree, per block of the group, + owners
@@ -1376,15 +1422,15 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
         if (lp->store_kind != FD_STORE_COLRANGE || mode != 2 || !b->store_wave) return FD_LAZY_DECLINED;
         const fd_colrange_store st = *(const fd_colrange_store *)lp->store;
         if (st.elem_bytes != (int)sizeof(real_t) || st.nblk != nb || st.block_size != bs || st.bl != 1 || st.bu != 1 || bs > 64 ||
-            st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors) > (size_t)64 * 1024)
+            st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors, (int)bs) > (size_t)64 * 1024)
             return FD_LAZY_DECLINED;
         const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
         const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
         if (bs <= 32)
-            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         else
-            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, false>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors), s, (const real_t *)lp->x,
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, false>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
