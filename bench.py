@@ -428,13 +428,16 @@ def main():
     # ---- side measurement (single GPU, untimed): the same Jacobian through round 2's default, the HAND-OVER path
     # (FDJAC_LAZY_STORE=0: f! writes differences, a second launch divides and decompresses) -- must give the same bits
     handover = None
-    if world == 1 and lazy_store and cfg in ("c2", "c3", "c4") and not args.no_plain_handover:
+    if world == 1 and lazy_store and not args.no_plain_handover:
         try:
             os.environ["FDJAC_LAZY_STORE"] = "0"
-            cp_s, rv_s = P.tridiag_csc(N) if cfg != "c3" else P.lap5_csc(nx, ny)   # (the timed plan's pattern arrays were released)
-            pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
-            plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
-            del cp_s, rv_s, pat_s
+            if cfg == "c5":
+                plan_s = fd.make_plan(Jbb, Jbb, colors, fdtype, ctx=ctx)
+            else:
+                cp_s, rv_s = P.tridiag_csc(N) if cfg != "c3" else P.lap5_csc(nx, ny)   # (the timed plan's pattern arrays were released)
+                pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
+                plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
+                del cp_s, rv_s, pat_s
             plan_s.set_lazy(f)
             out_s = torch.full_like(out, float("nan"))
             enq_s = plan_s.bind(f, x, [out_s])
@@ -452,8 +455,8 @@ def main():
             torch.cuda.synchronize()
             tot_s = plan_s.timing_samples("total")
             plan_s.enable_timing(0)
-            handover = {"what": "FDJAC_LAZY_STORE=0: eps pass + lazy f! handing over differences + row-window division/decompression "
-                                "(round 2's default; k_decompress_window)",
+            handover = {"what": "FDJAC_LAZY_STORE=0 (round 2's default): eps pass + lazy f! handing over differences (c5: imaginary parts) + "
+                                "a second launch dividing and decompressing (k_decompress_window / k_decompress_colrange_wg)",
                         "median_ms_per_step": float(np.median(tot_s)) if tot_s else None,
                         "stages_ms": {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in ts_all.items()},
                         "bit_identical_to_timed_result": bool(torch.equal(out_s, timed_result))}

@@ -1162,7 +1162,10 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 // colour -- and a row k of block b' in b-1 .. b+1 the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point
 // q, the operations of k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q
 // touches those rows), divided by eps_q: same bits as the hand-over path.
-constexpr int kBcS = 6;
+#ifndef FD_BCS
+#define FD_BCS 4
+#endif
+constexpr int kBcS = FD_BCS;
 // complex items of the LDS region phase A uses for its trees and owners and phase B for the S sums
 __host__ __device__ constexpr size_t bcs_shared_items(int B)
 {
@@ -1245,7 +1248,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     __syncthreads();
 
     // ---- phase A (as k_f_blockcoupled_lazy, MODE 2): sig of blocks g0-2 .. g0+kBcS+1 for every point of the batch
-    T *tr = tree + (size_t)wave * 128;
+    real_t *tr = reinterpret_cast<real_t *>(tree) + (size_t)wave * 128;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int lb = wave + it * NW;
@@ -1266,17 +1269,18 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             }
         }
         T *sg = sig + (size_t)lb * PB;
-        T acc = act ? zero_of<T>() + w * bc_make(xj, 0.0, 0, T{}) : zero_of<T>();
+        // the base tree holds REAL parts only: the imaginary part of every base leaf is 0.0 + w * 0.0 = +0 and so is every partial
+        // sum of them, and v + (+0) = v for the v = 0.0 + w * eps a perturbed lane starts from -- the bits of the complex tree
+        real_t acc = act ? (real_t)0 + w * xj : (real_t)0;
         bc_wave_sync();                              // (the previous block's tree is no longer read)
         tr[lane] = acc;
         int base_at = 64;
         for (int off = 32; off > 0; off >>= 1) {
-            cd o{__shfl_down(acc.re, off, 64), __shfl_down(acc.im, off, 64)};
-            acc = acc + o;
+            acc = acc + __shfl_down(acc, off, 64);
             if (lane < off && off > 1) tr[base_at + lane] = acc;
             base_at += off;
         }
-        T root{__shfl(acc.re, 0, 64), __shfl(acc.im, 0, 64)};
+        const T root{__shfl(acc, 0, 64), (real_t)0};
         for (int q = lane; q < B; q += 64) own[q] = -1;
         bc_wave_sync();
         if (cj >= 0) own[cj] = lane;
@@ -1288,7 +1292,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             bc_wave_sync();
             if (cj >= 0) {
                 const real_t e = ce[cj];
-                T n = zero_of<T>() + w * bc_make(xj, e, 0, T{});
+                real_t n = (real_t)0 + w * xj;
                 int idx = lane;
                 n = n + tr[idx ^ 32]; idx &= 31;
                 n = n + tr[64 + (idx ^ 16)]; idx &= 15;
@@ -1296,7 +1300,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
                 n = n + tr[112 + (idx ^ 4)]; idx &= 3;
                 n = n + tr[120 + (idx ^ 2)]; idx &= 1;
                 n = n + tr[124 + (idx ^ 1)];
-                sg[cj] = n;
+                sg[cj] = T{n, (real_t)0 + w * e};
             }
         } else {
             for (int q = 0; q < PB - 1; ++q) {
@@ -1391,7 +1395,11 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             }
 #pragma unroll
             for (int m = 0; m < 3; ++m)
+#ifdef FD_BCS_NOSTORE
+                if (cv & mv[m] & (qv[m] == (real_t)12345.678)) __builtin_nontemporal_store(qv[m], dst + (m - first) * bs);
+#else
                 if (cv & mv[m]) __builtin_nontemporal_store(qv[m], dst + (m - first) * bs);
+#endif
         }
     }
 }
