@@ -292,6 +292,81 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
     tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
 }
 
+// Level 0 on the nzval of a tridiagonal CSC.  Column j stores (du_j, d_j, dl_j) = A[j-1,j], A[j,j], A[j+1,j] at 3j-1, 3j, 3j+1, so
+// row i's coefficients sit at 3i-2, 3i, 3i+2: fetched coefficient by coefficient (tri_fetch_rows) every line is requested by three
+// different instructions and comes from memory three times (rocprofv3: 780 MB fetched for 320 MB of J and b at N = 10^7).  Here the
+// tile's span of nzval -- 3 * 2048 + 2 consecutive values -- is loaded ONCE with lane-consecutive loads into LDS (slot q + q/24: a
+// thread's 26 values then start 25 doubles apart, conflict-free) and every thread picks its 8 rows' a, b, c out of it, with coef()'s
+// arithmetic; the right-hand side follows through the same LDS as before.
+constexpr int kTriRawVals = 3 * kTriTileRows + 2;
+constexpr int kTriRawSlots = kTriRawVals + kTriRawVals / 24 + 2;
+template <int NRHS>
+__device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+{
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    // raw value q of the tile <-> nzval[lo + q]; row r (tile-local): a at 3r, b at 3r + 2, c at 3r + 4
+    const int64_t lo = 3 * (src.g0 + row0) - src.e0 - 2;
+    const int64_t qmin = lo < 0 ? -lo : 0;                                        // (the slice starts at its first row's diagonal or du)
+    const int64_t qmax = 3 * rows + 1 - ((row0 + rows == n) ? 2 : 0);             // (the last local row's c is not in the slice)
+    constexpr int kPer = (kTriRawVals + kBlock - 1) / kBlock;
+    real_t g[kPer];
+    double gr[kChunk];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int64_t q = (int64_t)j * kBlock + threadIdx.x;
+        g[j] = (q >= qmin && q <= qmax) ? src.p0[lo + q] : (real_t)0;
+    }
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {                    // the right-hand side's loads are in flight behind them
+        const int r = j * kBlock + (int)threadIdx.x;
+        gr[j] = r < rows ? src.value(3, row0 + r) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int q = j * kBlock + (int)threadIdx.x;
+        if (q < kTriRawVals) lds[q + q / 24] = (double)g[j];
+    }
+    __syncthreads();
+    const int base = 25 * (int)threadIdx.x;               // slot of raw value 24 t
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        const int64_t i = row0 + (int64_t)threadIdx.x * kChunk + j;
+        const double Aa = lds[base + 3 * j + (3 * j >= 24 ? 1 : 0)];
+        const double Ab = lds[base + 3 * j + 2 + (3 * j + 2 >= 24 ? 1 : 0)];
+        const double Ac = lds[base + 3 * j + 4 + (3 * j + 4 >= 24 ? 1 : 0)];
+        R.a[j] = src.beta * (i > 0 ? Aa : 0.0);
+        R.b[j] = src.alpha + src.beta * Ab;
+        R.c[j] = src.beta * (i + 1 < n ? Ac : 0.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        const int r = j * kBlock + (int)threadIdx.x;
+        if (r < rows) lds[r + (r >> 3)] = gr[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) R.d[0][q] = lds[9 * (int)threadIdx.x + q];
+    if (NRHS > 1) {
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const int64_t i = row0 + (int64_t)threadIdx.x * kChunk + q;
+            R.d[NRHS > 1 ? 1 : 0][q] = i == 0 ? 1.0 : 0.0;
+            R.d[NRHS > 2 ? 2 : 0][q] = i == n - 1 ? 1.0 : 0.0;
+        }
+    }
+}
+template <int NRHS>
+__global__ void __launch_bounds__(kBlock) k_tri_reduce_csc(SrcUser src, int64_t n, double *__restrict__ sum, int64_t nc)
+{
+    __shared__ double lds[kTriRawSlots];
+    SrcRegs<NRHS> R;
+    tri_fetch_rows_csc<NRHS>(src, n, (int64_t)blockIdx.x * kTriTileRows, lds, R);
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nc) return;
+    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
+}
+
 // The top level (n <= kTop): parallel cyclic reduction in LDS, NRHS right-hand sides.  sol[q * n + i].
 template <typename Src, int NRHS>
 __global__ void __launch_bounds__(kBlock) k_tri_top(Src src, int n, double *__restrict__ sol)
@@ -380,6 +455,29 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, cons
     tri_fetch_rows<Src, 1>(src, n, row0, lds, R);
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     __syncthreads();                                      // every thread has copied the last array out of LDS
+    if (k < nc) tri_backsub_chunk(R, n, z, k, TriLdsOut{lds, row0});
+    __syncthreads();
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        const int r = j * kBlock + (int)threadIdx.x;
+        if (r < rows) y[row0 + r] = (OutT)lds[r + (r >> 3)];
+    }
+}
+
+// level 0 on CSC nzval (tri_fetch_rows_csc).  The tiles are walked from the LAST to the first: the reduction read J and b front to
+// back just before, so their tail is what the Infinity Cache still holds.
+template <typename OutT>
+__global__ void __launch_bounds__(kBlock) k_tri_backsub_csc(SrcUser src, int64_t n, const double *__restrict__ z, int64_t nc,
+                                                            OutT *__restrict__ y)
+{
+    __shared__ double lds[kTriRawSlots];
+    const int64_t tile = (int64_t)gridDim.x - 1 - blockIdx.x;
+    const int64_t row0 = tile * kTriTileRows;
+    SrcRegs<1> R;
+    tri_fetch_rows_csc<1>(src, n, row0, lds, R);
+    const int64_t k = tile * kBlock + threadIdx.x;
+    __syncthreads();
     if (k < nc) tri_backsub_chunk(R, n, z, k, TriLdsOut{lds, row0});
     __syncthreads();
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
@@ -538,7 +636,9 @@ template <int NRHS> static int tri_reduce_all(fd_tridiag_solver *s, const SrcUse
     for (int l = 0; l + 1 < s->nlev; ++l) {
         const int64_t nc = s->lev_n[l + 1];
         const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
-        if (l == 0)
+        if (l == 0 && u.layout == FD_TRI_CSC)
+            hipLaunchKernelGGL((k_tri_reduce_csc<NRHS>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sum[0], nc);
+        else if (l == 0)
             hipLaunchKernelGGL((k_tri_reduce<SrcUser, NRHS>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sum[0], nc);
         else
             hipLaunchKernelGGL((k_tri_reduce<SrcLevel, NRHS>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]},
@@ -560,7 +660,9 @@ static int tri_backsub_all(fd_tridiag_solver *s, const SrcUser &u, real_t *y)
     for (int l = s->nlev - 2; l >= 0; --l) {
         const int64_t nc = s->lev_n[l + 1];
         const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
-        if (l == 0)
+        if (l == 0 && u.layout == FD_TRI_CSC)
+            hipLaunchKernelGGL((k_tri_backsub_csc<real_t>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sol[1], nc, y);
+        else if (l == 0)
             hipLaunchKernelGGL((k_tri_backsub<SrcUser, real_t>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sol[1], nc, y);
         else
             hipLaunchKernelGGL((k_tri_backsub<SrcLevel, double>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]},
