@@ -1169,7 +1169,8 @@ constexpr int kBcS = FD_BCS;
 // complex items of the LDS region phase A uses for its trees and owners and phase B for the S sums
 __host__ __device__ constexpr size_t bcs_shared_items(int B)
 {
-    const size_t a = (size_t)(kBcS + 2) * (size_t)B, b = (size_t)(kBlock / 64) * 128 + ((size_t)(kBlock / 64) * (size_t)B * 4 + 15) / 16;
+    const size_t item = 2 * sizeof(real_t);
+    const size_t a = (size_t)(kBcS + 2) * (size_t)B, b = (size_t)(kBlock / 64) * 128 + ((size_t)(kBlock / 64) * (size_t)B * 4 + item - 1) / item;
     return a > b ? a : b;
 }
 __device__ __forceinline__ int bc_lane_int(int v, int i) { return __builtin_amdgcn_readlane(v, i); }

@@ -111,7 +111,9 @@ typedef struct fd_lazy_points {
                           /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
                           /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
     int32_t store_kind;   /* what `store` points to (include/fdjac_device.h: FD_STORE_BAND a fd_band_store, FD_STORE_STENCIL5 a    */
-                          /* fd_stencil5_store); 0 when store is NULL                                                        */
+                          /* fd_stencil5_store, FD_STORE_COLRANGE a fd_colrange_store -- BlockBandedMatrix, complex step:    */
+                          /* store imag(f(point of the column's colour)[r]) / eps, is_complex = imag_only = 1); 0 when store  */
+                          /* is NULL                                                                                         */
     const void *store;    /* launchers registered with FD_LAZY_CAP_STORE only: non-NULL = a `fd_band_store`                  */
                           /* (include/fdjac_device.h, host memory, valid during the call): store the finished quotients into */
                           /* the Jacobian yourself -- fd_band_emit(store, r, c, (f(point of colour c)[r] - f(x)[r]) / eps[c]) */

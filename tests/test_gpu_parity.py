@@ -1726,14 +1726,16 @@ def test_lazy_store_stencil5_bit_identical(monkeypatch, oracle, fdtype, case):
 
 
 @pytest.mark.parametrize("case", ["c5_shape", "bs8", "bs64", "bs2", "window", "window_mid_block", "chunked", "pairs_off", "invalid_colouring",
-                                  "odd_block", "none", "cyclic"])
+                                  "odd_block", "none", "cyclic", "float32", "float32_bs64"])
 def test_lazy_store_blockbanded_complex_bit_identical(monkeypatch, oracle, case):
     # fd_colrange_store (include/fdjac_device.h), BASELINE config 5's shape: BlockBandedMatrix of equal dense blocks, complex step,
     # valid colouring -> the block-coupled fixture's launch forms sigma of every point on chip, evaluates every (row, column)
     # entry at its own point and stores imag / eps into the block-banded data itself (k_f_blockcoupled_store); bits of the
     # hand-over path (FDJAC_LAZY_STORE=0), same f! evaluation count, oracle parity.  Shapes the kernel does not take (odd
     # blocks, an invalid colouring, colorvec 0) keep the hand-over path.
-    nb, bs = {"c5_shape": (40, 32), "bs64": (9, 64), "bs2": (70, 2), "odd_block": (25, 5), "window": (40, 32), "window_mid_block": (40, 32),
+    dtype = np.float32 if case.startswith("float32") else np.float64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    nb, bs = {"c5_shape": (40, 32), "float32": (40, 32), "float32_bs64": (9, 64), "bs64": (9, 64), "bs2": (70, 2), "odd_block": (25, 5), "window": (40, 32), "window_mid_block": (40, 32),
               "chunked": (40, 32)}.get(case, (30, 8))
     sizes = np.full(nb, bs)
     N = int(sizes.sum())
@@ -1749,26 +1751,27 @@ def test_lazy_store_blockbanded_complex_bit_identical(monkeypatch, oracle, case)
         colors[[3, N - 2]] = 0
     win = {"window": (2 * bs + 1, N - bs), "window_mid_block": (2 * bs + 6, N - bs - 3)}.get(case)
     cap = 60_000 if case == "chunked" else 0
-    x = _dev(np.random.default_rng(77).random(N) - 0.3)
+    x = torch.as_tensor(np.random.default_rng(77).random(N) - 0.3, dtype=tdt, device="cuda")
     Jb = fd.BlockBandedMatrix(None, lay)
     res = []
     for store in ("1", "0"):
         monkeypatch.setenv("FDJAC_LAZY_STORE", store)
-        plan = fd.make_plan(Jb, Jb, colors, "complex", scratch_bytes=cap, col_window=win)
-        f = fd.BuiltinF("blockcoupled", nb, int(sizes[0]))
+        plan = fd.make_plan(Jb, Jb, colors, "complex", scratch_bytes=cap, col_window=win, dtype=dtype)
+        f = fd.BuiltinF("blockcoupled", nb, int(sizes[0]), dtype=dtype)
         assert f.lazy_caps & fd.lib.LAZY_CAP_STORE
         plan.set_lazy(f, store=(case != "pairs_off"))
         want = store == "1" and case not in ("pairs_off", "invalid_colouring", "none")
         assert plan.info(fd.lib.INFO_LAZY_STORE) == (1 if want else 0), case
         if case == "chunked":
             assert plan.info(fd.lib.INFO_NCHUNKS) > 1
-        out = _dev(np.full(plan.out_len(0) + 2, np.nan))
+        out = torch.full((plan.out_len(0) + 2,), float("nan"), dtype=tdt, device="cuda")
         plan.jacobian(f, x, [out[:-2]])
         assert torch.isnan(out[-2:]).all()
         res.append((out[:-2], f.fcalls, plan.fcalls_last, plan.timings()))
     if win is None and case != "none":
         assert not torch.isnan(res[0][0]).any()
-    a, b = res[0][0].view(torch.int64), res[1][0].view(torch.int64)
+    ity = torch.int32 if dtype == np.float32 else torch.int64
+    a, b = res[0][0].view(ity), res[1][0].view(ity)
     bad = torch.nonzero(a != b).flatten()
     assert bad.numel() == 0, (case, int(bad.numel()), bad[:8].tolist(), res[0][0][bad[:8]].tolist(), res[1][0][bad[:8]].tolist())
     assert res[0][1:3] == res[1][1:3]
