@@ -68,8 +68,10 @@ def _csc_nzval_fast(dl, d, du):
 
 
 @pytest.mark.parametrize("layout", ["diagonals", "csc"])
-@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 32769, 100003, 10 ** 6])
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 2113, 4095, 4096, 4097, 16385, 32769,
+                               100003, 262143, 262144, 262145, 10 ** 6, 3 * 10 ** 6 + 1])
 def test_tridiagonal_solve_matches_scipy(layout, N):
+    # sizes around every tile / level boundary (tiles of 2048 rows, a factor of 8 per level, <= 512 rows at the top)
     dl, d, du, b, alpha, beta = _system(N, 100 + N)
     want = _reference(dl, d, du, b, alpha, beta)
     y = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
