@@ -1782,3 +1782,99 @@ def test_lazy_store_blockbanded_complex_bit_identical(monkeypatch, oracle, case)
         got = res[0][0].cpu().numpy()
         assert np.max(np.abs(got - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
         assert res[0][1] == ref["fcalls"]
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("grid", [(1, 9), (9, 1), (2, 7), (7, 2), (3, 3), (4, 4), (5, 5), (130, 3), (3, 130), (128, 5), (129, 4), (256, 2), (2, 256),
+                                  (127, 6), (131, 131)])
+def test_lazy_store_stencil5_degenerate_grids(monkeypatch, oracle, fdtype, grid):
+    # grids thinner than the stencil, one column / one row wide, a tile wide plus / minus one: whatever the plan decides (store the
+    # Jacobian from f!'s launch, as a band, as a stencil, or hand over), the bits are those of the hand-over path and the oracle agrees
+    nx, ny = grid
+    N = nx * ny
+    colptr, rowval = P.lap5_csc(nx, ny)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    colors = fd.matrix_colors(J)
+    x = _dev(np.random.default_rng(nx * 1000 + ny).random(N))
+    res = []
+    for fam in ("lap5", "lap5_nl"):
+        outs = []
+        for store in ("1", "0"):
+            monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+            plan = fd.make_plan(J, J, colors, fdtype)
+            f = fd.BuiltinF(fam, nx, ny)
+            if getattr(f, "lazy_fn", None) is not None:      # (the fixtures' lazy launchers need a grid of at least 2 x 2 tiles' worth)
+                plan.set_lazy(f)
+            out = _dev(np.full(plan.out_len(0) + 2, np.nan))
+            plan.jacobian(f, x, [out[:-2]])
+            assert torch.isnan(out[-2:]).all() and not torch.isnan(out[:-2]).any()
+            outs.append((out[:-2], f.fcalls, int(plan.info(fd.lib.INFO_LAZY_STORE))))
+        assert torch.equal(outs[0][0].view(torch.int64), outs[1][0].view(torch.int64)), (grid, fam, outs[0][2])
+        assert outs[0][1] == outs[1][1]
+        ref = oracle.jacobian(fdtype, oracle.Fixture(fam, nx, ny), x.cpu().numpy(), colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+        _tol_ok(outs[0][0].cpu().numpy(), ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 8.0, "degenerate grid %dx%d %s" % (nx, ny, fam))
+        assert outs[0][1] == ref["fcalls"]
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("kind", ["csc", "banded", "tridiagonal"])
+def test_lazy_store_tridiagonal_small_sizes(monkeypatch, oracle, fdtype, kind):
+    # every small N around the wave / tile sizes of k_f_tridiag_store_wave (128 columns per wavefront, 512 per workgroup), each
+    # storage type: bits of the hand-over path, the oracle within tolerance, nothing written past the end
+    for N in (1, 2, 3, 4, 5, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1025):
+        colors = (np.arange(N) % 3 + 1).astype(np.int64)
+        colptr, rowval = P.tridiag_csc(N)
+        x = _dev(np.random.default_rng(N).random(N))
+        res = []
+        for store in ("1", "0"):
+            monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+            if kind == "csc":
+                J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+            elif kind == "banded":
+                J = fd.BandedMatrix(torch.zeros((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
+            else:
+                J = fd.Tridiagonal(torch.zeros(max(N - 1, 0), dtype=torch.float64, device="cuda"), torch.zeros(N, dtype=torch.float64, device="cuda"),
+                                   torch.zeros(max(N - 1, 0), dtype=torch.float64, device="cuda"))
+            plan = fd.make_plan(J, J, colors, fdtype)
+            f = fd.BuiltinF("tridiag_nl", N)
+            if getattr(f, "lazy_fn", None) is not None:
+                plan.set_lazy(f)
+            outs = [torch.full((plan.out_len(k) + 2,), float("nan"), dtype=torch.float64, device="cuda") for k in range(plan.nouts)]
+            plan.jacobian(f, x, [o[:o.numel() - 2] for o in outs])
+            for o in outs:
+                assert torch.isnan(o[-2:]).all() and not torch.isnan(o[:-2]).any(), (N, kind)
+            res.append(([o[:-2] for o in outs], f.fcalls))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (N, kind)
+        assert res[0][1] == res[1][1]
+        if kind == "csc":
+            ref = oracle.jacobian(fdtype, oracle.Fixture("tridiag_nl", N), x.cpu().numpy(), colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+            _tol_ok(res[0][0][0].cpu().numpy(), ref["out"], float(np.min(np.abs(_oracle_eps(x.cpu().numpy(), colors, fdtype)))), 16.0, "small N %d" % N)
+
+
+@pytest.mark.parametrize("shape", [(1, 2), (1, 32), (2, 32), (3, 32), (4, 32), (5, 32), (9, 32), (2, 1), (7, 3), (3, 64), (13, 16), (4, 6), (6, 4)])
+def test_lazy_store_blockbanded_small_shapes(monkeypatch, oracle, shape):
+    # one to a few block-columns (the groups of k_f_blockcoupled_store hold 4, with 2 halo blocks on either side), block sizes
+    # 1 .. 64: bits of the hand-over path, oracle parity
+    nb, bs = shape
+    N = nb * bs
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    colors = lay.colors()
+    x = _dev(np.random.default_rng(nb * 100 + bs).random(N) - 0.4)
+    Jb = fd.BlockBandedMatrix(None, lay)
+    res = []
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        plan = fd.make_plan(Jb, Jb, colors, "complex")
+        f = fd.BuiltinF("blockcoupled", nb, bs)
+        plan.set_lazy(f)
+        out = _dev(np.full(plan.out_len(0) + 2, np.nan))
+        plan.jacobian(f, x, [out[:-2]])
+        assert torch.isnan(out[-2:]).all() and not torch.isnan(out[:-2]).any()
+        res.append((out[:-2], f.fcalls))
+    assert torch.equal(res[0][0].view(torch.int64), res[1][0].view(torch.int64)), shape
+    assert res[0][1] == res[1][1]
+    ref = oracle.jacobian("complex", oracle.Fixture("blockcoupled", nb, bs), x.cpu().numpy(), colors, kind=oracle.PAT_BLOCKBANDED,
+                          blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts, block_strides=lay.block_strides,
+                          out_len=lay.data_len)
+    assert np.max(np.abs(res[0][0].cpu().numpy() - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
