@@ -457,3 +457,51 @@ def test_user_kernel_stores_the_jacobian_through_the_device_header(tmp_path, ora
     eps_min = min(max(1.4901161193847656e-8 * np.sqrt(np.linalg.norm(x * (colors == c))), 1.4901161193847656e-8) for c in (1, 2, 3))
     atol = 16 * 2.220446049250313e-16 * 4.0 / eps_min
     assert np.all(np.abs(got - ref["out"]) <= 1e-6 * np.abs(ref["out"]) + atol)
+
+
+@pytest.mark.parametrize("kind", ["csc_store", "csc_handover", "blockbanded_complex"])
+def test_jacobian_call_captures_into_a_hip_graph(monkeypatch, kind):
+    # fd_jacobian_async enqueues kernels only -- no allocation, no synchronisation, no host read-back once the plan has run once --
+    # so a time-stepping loop may capture it into a HIP graph: the replay gives the bits of the stream launches, also for new
+    # contents of x (scripts/graph_probe.py has the timings: replay is no faster than three stream launches on this runtime)
+    monkeypatch.setenv("FDJAC_LAZY_STORE", "0" if kind == "csc_handover" else "1")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = fd.Context(0)
+        if kind == "blockbanded_complex":
+            nb, bs = 24, 16
+            N = nb * bs
+            lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+            J = fd.BlockBandedMatrix(None, lay)
+            plan = fd.make_plan(J, J, lay.colors(), "complex", ctx=ctx)
+            f = fd.BuiltinF("blockcoupled", nb, bs, ctx=ctx)
+        else:
+            N = 30_011
+            cp, rv = P.tridiag_csc(N)
+            J = fd.SparseMatrixCSC(N, N, cp, rv)
+            plan = fd.make_plan(J, J, P.cyclic_colors(N, 3), "forward", ctx=ctx)
+            f = fd.BuiltinF("tridiag_nl", N, ctx=ctx)
+        plan.set_lazy(f)
+        x = torch.rand(N, dtype=torch.float64, device="cuda")
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=torch.float64, device="cuda")
+        enq = plan.bind(f, x, [out])
+        enq()
+        torch.cuda.synchronize()
+        ref = out.clone()
+        out.fill_(float("nan"))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            enq()
+        torch.cuda.synchronize()
+        for scale in (1.0, 0.5, 3.0):
+            x.mul_(scale)
+            out.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            out.fill_(float("nan"))
+            enq()
+            torch.cuda.synchronize()
+            assert not torch.isnan(got).any() and torch.equal(got.view(torch.int64), out.view(torch.int64))
+            if scale == 1.0:
+                assert torch.equal(got.view(torch.int64), ref.view(torch.int64))
