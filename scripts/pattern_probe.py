@@ -28,6 +28,7 @@ def stencil7_csc(nx, ny, nz):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=8_000_000)
+    ap.add_argument("--only", choices=["stencil", "band"], default=None, help="one pattern only (PMC passes: one kernel population per run)")
     a = ap.parse_args()
     import torch
     import finitediff_jl_amd as fd
@@ -61,10 +62,14 @@ def main():
         out_rows.append((name, N, rowval.size, C, kern, plan.info(fd.lib.INFO_WIN_OVERREAD_X100) / 100.0, us, real / 1e6,
                          real / us / 1e3))
 
+    fd.Context.default().stream_copy_gbps(1 << 30, 4)     # k_stream_copy: the PMC calibration kernel of the same run (1 GiB read + written)
     n3 = int(round(a.n ** (1 / 3)))
-    cp, rv, col = stencil7_csc(n3, n3, n3)
-    run("3-D 7-point stencil %d^3" % n3, cp, rv, col, n3 ** 3)
-    del cp, rv, col
+    if a.only in (None, "stencil"):
+        cp, rv, col = stencil7_csc(n3, n3, n3)
+        run("3-D 7-point stencil %d^3" % n3, cp, rv, col, n3 ** 3)
+        del cp, rv, col
+    if a.only == "stencil":
+        return report(out_rows)
     # random banded: 6 entries per column at random rows within +-300 of the diagonal, greedy colouring
     N = min(a.n, 2_000_000)
     rng = np.random.default_rng(1)
@@ -82,6 +87,10 @@ def main():
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     colors = fd.matrix_colors(J)
     run("random band (+-300), 6 per column", colptr, rowval, colors, N)
+    report(out_rows)
+
+
+def report(out_rows):
     print("| pattern | N | nnz | colours | kernel | over-read | diff+decompress us | real MB | GB/s (real traffic) |")
     print("|---|---|---|---|---|---|---|---|---|")
     for r in out_rows:
