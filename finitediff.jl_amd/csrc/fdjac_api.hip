@@ -951,6 +951,20 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             if (fs && *fs) p->sorted_gather = atoi(fs) != 0 && p->nnz_local >= 4 * kSortTile;
         }
     }
+    // (far-band tile order, below: the reach D = max |row - column| and every tile's first column, from the storage order)
+    std::vector<int64_t> tcol;
+    int64_t reach = 0;
+    if (p->sorted_gather && colstart) {
+        const size_t ntl = padded / kSortTile;
+        tcol.resize(ntl);
+        size_t jc = 0;
+        for (int64_t e = 0; e < p->nnz_local; ++e) {
+            while (jc + 1 < colstart->size() && (*colstart)[jc + 1] <= e) ++jc;
+            if ((e % kSortTile) == 0) tcol[(size_t)(e / kSortTile)] = (int64_t)jc;
+            if (nzc[(size_t)e] >= 0) reach = std::max<int64_t>(reach, std::llabs((int64_t)rows[(size_t)e] - (p->col0 + (int64_t)jc)));
+        }
+        for (size_t t = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile); t < ntl; ++t) tcol[t] = (int64_t)colstart->size() - 2;
+    }
     if (p->sorted_gather) {
         std::vector<uint16_t> spos(padded);
         const size_t ntiles = padded / kSortTile;
@@ -968,6 +982,34 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
         }
         if ((rc = dev_upload(&p->d_spos, spos))) return rc;
+        // Tile ORDER for patterns with a far band (3-D stencils: offsets 0, +-1, +-nx, +-nx*ny).  A tile's gathers reach the rows a
+        // whole "plane" D = max |row - column| away; walking the tiles in storage order the three planes in use are 3 * C * D * 8
+        // bytes (6.7 MB for 200^3, 7 colours) against 4 MB of L2 per XCD, and the plane above / below is fetched through the
+        // fabric a second and third time (rocprofv3: 2.2 x the distinct bytes).  Walk instead: for each in-plane region of Rg
+        // columns, all planes in turn -- the three-plane working set of a region is 3 * C * Rg * 8 bytes <= 2 MiB.  Pure
+        // scheduling: which workgroup takes which tile (results do not depend on it).
+        const char *to = getenv("FDJAC_TILE_ORDER");
+        const int want = (to && *to) ? atoi(to) : 1;
+        if (colstart && want != 0 && ntiles >= (want == 2 ? 16u : 256u)) {
+            const int64_t ncols = (int64_t)colstart->size() - 1;
+            const int64_t D = reach;
+            const int64_t cpt = std::max<int64_t>(1, ncols / (int64_t)ntiles);
+            if (D >= (want == 2 ? 2 : 16) * cpt && D < ncols) {
+                int64_t Rg = ((int64_t)2 << 20) / (3 * std::max<int64_t>(p->C, 1) * (int64_t)sizeof(real_t));
+                Rg = std::max<int64_t>(4 * cpt, std::min<int64_t>(Rg, D / 2));
+                std::vector<int32_t> order(ntiles);
+                for (size_t t = 0; t < ntiles; ++t) order[t] = (int32_t)t;
+                std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                    const int64_t ua = tcol[(size_t)a] % D, ub = tcol[(size_t)b] % D;
+                    const int64_t ka = ua / Rg, kb = ub / Rg;
+                    if (ka != kb) return ka < kb;
+                    const int64_t la = tcol[(size_t)a] / D, lb = tcol[(size_t)b] / D;
+                    if (la != lb) return la < lb;
+                    return ua < ub;
+                });
+                if ((rc = dev_upload(&p->d_tile_order, order))) return rc;
+            }
+        }
     }
     if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
     if ((rc = upload_colors(p, col0, nzc))) return rc;
@@ -1052,7 +1094,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {

@@ -256,6 +256,7 @@ struct fd_plan {
     int pts = 1;                   // f! points per colour (2 for central)
     int cplx = 0;                  // elements are (re,im) pairs
     fdjac::real_t *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr;
+    int32_t *d_tile_order = nullptr;   // sorted-gather plans with a far band: the order in which the tiles are walked (else storage order)
     double *d_partial = nullptr;   // masked sums of squares are accumulated in Float64 for either element type
     fdjac::real_t *d_xstage = nullptr, *d_finstage = nullptr;
     int n_partial_blocks = 0;

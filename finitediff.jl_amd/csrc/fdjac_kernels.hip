@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(kBlock)
 k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ scol,
                     const uint16_t *__restrict__ spos, const real_t *__restrict__ FXa,
                     const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps, int c_lo,
-                    int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok)
+                    int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok, const int32_t *__restrict__ tile_order)
 {
     constexpr int E = kSortTile / kBlock;   // entries per thread (8); entry e of thread t is tile + e*256 + t,
                                             // so one wave-level gather covers 64 CONSECUTIVE sorted entries
@@ -497,7 +497,8 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     const int64_t ntiles = (n + kSortTile - 1) / kSortTile;
     const int64_t xt = xcd_tile(blockIdx.x, ntiles);
     if (xt >= ntiles) return;
-    const int64_t tile_id = (vec_ok & 4) ? ntiles - 1 - xt : xt;   // reversed tile order, see tile_order_reversed()
+    const int64_t rank = (vec_ok & 4) ? ntiles - 1 - xt : xt;      // reversed tile order, see tile_order_reversed()
+    const int64_t tile_id = tile_order ? (int64_t)tile_order[rank] : rank;   // (far-band patterns: region by region across the planes)
     const int64_t t0 = tile_id * kSortTile;
     if (LDS_EPS) __syncthreads();
 
@@ -1429,7 +1430,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
 #define FD_LAUNCH_SORTED(LL, AW, SS)                                                                                 \
             hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
                                p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
-                               c_hi, outs[0], p->nnz_local, vok)
+                               c_hi, outs[0], p->nnz_local, vok, p->d_tile_order)
             if (p->sorted_gather) {
                 if (ldsq && allw) FD_LAUNCH_SORTED(true, true, true);
                 else if (ldsq) FD_LAUNCH_SORTED(true, false, true);

@@ -1878,3 +1878,55 @@ def test_lazy_store_blockbanded_small_shapes(monkeypatch, oracle, shape):
                           blk_sizes=lay.blk_sizes, bl=1, bu=1, block_starts=lay.block_starts, block_strides=lay.block_strides,
                           out_len=lay.data_len)
     assert np.max(np.abs(res[0][0].cpu().numpy() - ref["out"])) <= 1e-12 * max(1.0, np.max(np.abs(ref["out"])))
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_far_band_tile_order_is_pure_scheduling(monkeypatch, oracle, fdtype):
+    # sorted-gather plans of patterns with a far band (3-D 7-point stencil: offsets +-1, +-nx, +-nx*ny) walk their tiles region by
+    # region across the planes instead of in storage order (fdjac_api.hip, "Tile ORDER"): the same values in the same places
+    n = 36
+    N = n ** 3
+    k = np.arange(N, dtype=np.int64)
+    i, j, l = k % n, (k // n) % n, k // (n * n)
+    has = np.stack([l > 0, j > 0, i > 0, np.ones(N, bool), i < n - 1, j < n - 1, l < n - 1], axis=1)
+    rows = np.stack([k - n * n, k - n, k - 1, k, k + 1, k + n, k + n * n], axis=1)
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(has.sum(axis=1), out=colptr[1:])
+    colptr[1:] += 1
+    rowval = (rows[has] + 1).astype(np.int64)
+    colors = ((i + 2 * j + 3 * l) % 7 + 1).astype(np.int64)
+    x = _dev(np.random.default_rng(9).random(N))
+
+    def f_t(fv, xx):        # a 3-D stencil residual with a different weight per neighbour (no coupling across grid lines / planes)
+        X = xx.view(n, n, n)                        # [l, j, i]
+        F = X * X
+        F[:, :, 1:] += 1.0 * X[:, :, :-1]
+        F[:, :, :-1] += 0.5 * X[:, :, 1:]
+        F[:, 1:, :] += 0.25 * X[:, :-1, :]
+        F[:, :-1, :] += 0.125 * X[:, 1:, :]
+        F[1:] += 2.0 * X[:-1]
+        F[:-1] += 3.0 * X[1:]
+        fv.copy_(F.reshape(-1))
+
+    outs = []
+    for order in ("2", "0"):
+        monkeypatch.setenv("FDJAC_TILE_ORDER", order)
+        monkeypatch.setenv("FDJAC_SORTED", "1")
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        plan = fd.make_plan(J, J, colors, fdtype)
+        assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1
+        f = fd.TorchF(f_t, N, N)
+        out = _dev(np.full(rowval.size, np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0].view(torch.int64), outs[1].view(torch.int64))
+    # against the analytic Jacobian of f_t
+    got = outs[0].cpu().numpy()
+    col = P.csc_cols(colptr) - 1
+    row = rowval - 1
+    xh = x.cpu().numpy()
+    want = np.select([row == col, row == col + 1, row == col - 1, row == col + n, row == col - n, row == col + n * n, row == col - n * n],
+                     [2 * xh[col], 1.0, 0.5, 0.25, 0.125, 2.0, 3.0])
+    assert np.max(np.abs(got - want)) < (2e-6 if fdtype == "forward" else 2e-8)
