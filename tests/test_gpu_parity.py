@@ -1930,3 +1930,65 @@ def test_far_band_tile_order_is_pure_scheduling(monkeypatch, oracle, fdtype):
     want = np.select([row == col, row == col + 1, row == col - 1, row == col + n, row == col - n, row == col + n * n, row == col - n * n],
                      [2 * xh[col], 1.0, 0.5, 0.25, 0.125, 2.0, 3.0])
     assert np.max(np.abs(got - want)) < (2e-6 if fdtype == "forward" else 2e-8)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed):
+    # the block-banded routes -- materialised points, the lazy launcher (imaginary parts or (re, im) pairs), the storing launch,
+    # one wave / one workgroup per column range in the decompression -- are different schedules of the same operations: random
+    # shapes, block sizes, column windows, colour chunks, element types; same bits, same number of f! evaluations
+    rng = np.random.default_rng(9100 + seed)
+    fdtype = FDTYPES[int(rng.integers(0, 3))] if seed % 3 else "complex"
+    bs = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 33, 48, 64]))
+    nb = int(rng.integers(1, max(2, min(400, 20000 // bs))))
+    N = nb * bs
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    colors = lay.colors()
+    if rng.random() < 0.3:
+        perm = rng.permutation(int(colors.max())) + 1          # another valid colouring: the colours renamed
+        colors = perm[colors - 1].astype(np.int64)
+    if rng.random() < 0.15:
+        colors = colors.copy()
+        colors[rng.integers(0, N, size=2)] = 0
+    win = None
+    if rng.random() < 0.35 and N >= 12:
+        a = int(rng.integers(0, N // 3))
+        win = (a + 1, int(rng.integers(a + N // 3, N)))
+    dtype = np.float32 if rng.random() < 0.3 else np.float64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    cap = 0
+    if rng.random() < 0.3:      # a few colours per chunk
+        per = (N + 31) // 32 * 32 * (2 if fdtype != "forward" else 1) * (2 if fdtype == "complex" else 1) * dtype().itemsize * 2
+        cap = per * int(rng.integers(2, 9)) + 8192
+    x = torch.as_tensor(rng.random(N) - 0.25, dtype=tdt, device="cuda")
+    Jb = fd.BlockBandedMatrix(None, lay)
+
+    def run(env, lazy, imag_only, store):
+        for k in ("FDJAC_LAZY_STORE", "FDJAC_COLRANGE_WG", "FDJAC_STORE_WAVE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = fd.make_plan(Jb, Jb, colors, fdtype, scratch_bytes=cap, col_window=win, dtype=dtype)
+        f = fd.BuiltinF("blockcoupled", nb, bs, dtype=dtype)
+        if lazy:
+            plan.set_lazy(f, imag_only=imag_only, store=store)
+        out = torch.full((plan.out_len(0) + 2,), float("nan"), dtype=tdt, device="cuda")
+        plan.jacobian(f, x, [out[:-2]])
+        assert torch.isnan(out[-2:]).all()
+        return out[:-2], f.fcalls
+
+    ref, calls_ref = run({"FDJAC_LAZY_STORE": "0"}, False, True, False)
+    env = {}
+    if rng.random() < 0.5:
+        env["FDJAC_COLRANGE_WG"] = str(int(rng.integers(0, 2)))
+    if rng.random() < 0.3:
+        env["FDJAC_STORE_WAVE"] = str(int(rng.integers(0, 2)))
+    if rng.random() < 0.3:
+        env["FDJAC_LAZY_STORE"] = "0"
+    got, calls = run(env, True, bool(rng.random() < 0.6), bool(rng.random() < 0.8))
+    ity = torch.int32 if dtype == np.float32 else torch.int64
+    both_nan = torch.isnan(ref) & torch.isnan(got)            # (outside a column window nothing is written by either)
+    bad = torch.nonzero((got.view(ity) != ref.view(ity)) & ~both_nan).flatten()
+    assert bad.numel() == 0, (nb, bs, fdtype, np.dtype(dtype).name, win, cap, env, int(bad.numel()), bad[:8].tolist(), got[bad[:8]].tolist(),
+                              ref[bad[:8]].tolist())
+    assert calls == calls_ref
