@@ -866,7 +866,9 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     if (grp >= ngroups) return;
     const int64_t wt = grp * (kBlock / 64) + wave;
     if (wt >= ntiles) return;
-    const int j = (int)(jrow0 + wt / TPR), i0 = (int)(wt % TPR) * TW;
+    // (32-bit division: the launcher declines grids with 2^31 tiles or more; a 64-bit one is ~150 instructions per wavefront)
+    const unsigned wrow = (unsigned)wt / (unsigned)TPR;
+    const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
     const int i = i0 + CPL * lane;
     const int64_t k = (int64_t)j * nx + i;
     const bool act = i < nx;
@@ -934,6 +936,7 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
         const int cpl = b->store_cpl == 1 ? 1 : 2;
         const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 64 * cpl - 1) / (64 * cpl)), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
         const unsigned gs = (unsigned)(8 * xcd_chunks(ngroups));
+        if (ntiles >= ((int64_t)1 << 31) || st.nx * st.ny >= ((int64_t)1 << 31)) return FD_LAZY_DECLINED;   // (32-bit tile / grid arithmetic in the kernel)
 #define FD_S5(MODE, SKK, NT, FDV, INS, CPLL, WVV)                                                                   \
         hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT, FDV, INS, CPLL, WVV>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)
