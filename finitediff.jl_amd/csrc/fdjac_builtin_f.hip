@@ -1165,10 +1165,7 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 // colour -- and a row k of block b' in b-1 .. b+1 the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point
 // q, the operations of k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q
 // touches those rows), divided by eps_q: same bits as the hand-over path.
-#ifndef FD_BCS
-#define FD_BCS 4
-#endif
-constexpr int kBcS = FD_BCS;
+constexpr int kBcS = 4;          // block-columns per workgroup (2 / 3 / 4 / 6 / 8 / 10 measured: 57 / 62 / 57 / 63 / 67 / 75 us on config 5)
 // complex items of the LDS region phase A uses for its trees and owners and phase B for the S sums
 __host__ __device__ constexpr size_t bcs_shared_items(int B)
 {
@@ -1399,11 +1396,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             }
 #pragma unroll
             for (int m = 0; m < 3; ++m)
-#ifdef FD_BCS_NOSTORE
-                if (cv & mv[m] & (qv[m] == (real_t)12345.678)) __builtin_nontemporal_store(qv[m], dst + (m - first) * bs);
-#else
                 if (cv & mv[m]) __builtin_nontemporal_store(qv[m], dst + (m - first) * bs);
-#endif
         }
     }
 }
