@@ -982,6 +982,43 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
         }
         if ((rc = dev_upload(&p->d_spos, spos))) return rc;
+        // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
+        {
+            const char *fl = getenv("FDJAC_FX_LDS");
+            if (p->fdtype == FD_FORWARD && !(fl && *fl && atoi(fl) == 0)) {
+                std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0), tr;
+                std::vector<std::pair<int32_t, int32_t>> runs, gaps;
+                size_t eligible = 0;
+                for (size_t t = 0; t < ntiles; ++t) {
+                    int32_t *w = fxw.data() + t * 2 * kFxWin;
+                    tr.clear();
+                    for (size_t q = t * kSortTile; q < (t + 1) * kSortTile; ++q)
+                        if (nzc[q] >= 0) tr.push_back(rows[q]);
+                    w[0] = -1;
+                    if (tr.empty()) continue;
+                    std::sort(tr.begin(), tr.end());
+                    runs.clear();
+                    runs.push_back({tr[0], tr[0]});
+                    for (int32_t r : tr) {
+                        if (r <= runs.back().second + 16) runs.back().second = std::max(runs.back().second, r);   // (gaps of <= 15 rows stay inside a run)
+                        else runs.push_back({r, r});
+                    }
+                    while (runs.size() > (size_t)kFxWin) {        // too many runs: close the smallest gap
+                        size_t best = 1;
+                        for (size_t i = 2; i < runs.size(); ++i)
+                            if (runs[i].first - runs[i - 1].second < runs[best].first - runs[best - 1].second) best = i;
+                        runs[best - 1].second = runs[best].second;
+                        runs.erase(runs.begin() + (ptrdiff_t)best);
+                    }
+                    int64_t total = 0;
+                    for (auto &ru : runs) total += (int64_t)ru.second - ru.first + 1;
+                    if (total > kFxRows) continue;
+                    for (size_t i = 0; i < runs.size(); ++i) { w[2 * i] = runs[i].first; w[2 * i + 1] = runs[i].second - runs[i].first + 1; }
+                    ++eligible;
+                }
+                if (eligible * 2 >= ntiles && (rc = dev_upload(&p->d_fxwin, fxw))) return rc;
+            }
+        }
         // Tile ORDER for patterns with a far band (3-D stencils: offsets 0, +-1, +-nx, +-nx*ny).  A tile's gathers reach the rows a
         // whole "plane" D = max |row - column| away; walking the tiles in storage order the three planes in use are 3 * C * D * 8
         // bytes (6.7 MB for 200^3, 7 colours) against 4 MB of L2 per XCD, and the plane above / below is fetched through the
@@ -1094,7 +1131,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {

@@ -113,6 +113,8 @@ constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of 
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 constexpr int64_t kSmallN = 16384;   // below this a single-workgroup launch does step sizes (+ perturbation): launch-bound regime
 constexpr int kSortTile = 2048;      // entries per workgroup of the sorted-gather (LDS-transposed) decompression
+constexpr int kFxWin = 8;            // ... its tiles' runs of rows whose f(x) is staged in LDS (forward differences): at most this many,
+constexpr int kFxRows = kSortTile;   //     this many rows in total (the staging area is the tile's value area)
 constexpr int kWinMaxCol = 8;        // row-window decompression: at most this many consecutive colours per tile,
 constexpr int kWinMaxWin = 4;        //   this many row windows per tile (a 5-point stencil needs 3),
 constexpr int kWinPeriodMax = 64;    //   longest period (in entries) of a regular tile's codes; its head is staged in LDS:
@@ -256,6 +258,7 @@ struct fd_plan {
     int pts = 1;                   // f! points per colour (2 for central)
     int cplx = 0;                  // elements are (re,im) pairs
     fdjac::real_t *d_X = nullptr, *d_FX = nullptr, *d_fx = nullptr, *d_eps = nullptr;
+    int32_t *d_fxwin = nullptr;        // sorted-gather plans: per tile kFxWin x (first row, rows) of the runs its entries' rows lie in (first < 0: none)
     int32_t *d_tile_order = nullptr;   // sorted-gather plans with a far band: the order in which the tiles are walked (else storage order)
     double *d_partial = nullptr;   // masked sums of squares are accumulated in Float64 for either element type
     fdjac::real_t *d_xstage = nullptr, *d_finstage = nullptr;

@@ -477,12 +477,17 @@ k_decompress_list(const int32_t *__restrict__ rowval, const CT *__restrict__ nzc
 //   dense 16-B stores.  This is the north-star's "LDS staging + sparse scatter", done per tile.
 //   spos[q] = position (0..kSortTile-1) of sorted entry q inside its tile.
 //   ALLW: every entry of every tile is written (single colour chunk, no uncoloured column) -> no flags.
-template <typename CT, int MODE, bool LDS_EPS, bool ALLW, bool SORTED>
+//   FXL (forward differences): f(x) is not gathered.  The rows a tile touches lie in a few runs (plan time: at most kFxWin
+//   windows, kFxRows rows in total -- a band tile has one, a 3-D stencil tile five); the workgroup loads those runs of f(x)
+//   densely into LDS (the area the values are transposed in afterwards) and every entry looks its row up there: one global
+//   gather per entry instead of two.  A tile whose rows do not fit (fxwin[0] < 0) gathers as before.
+template <typename CT, int MODE, bool LDS_EPS, bool ALLW, bool SORTED, bool FXL = false>
 __global__ void __launch_bounds__(kBlock)
 k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ scol,
                     const uint16_t *__restrict__ spos, const real_t *__restrict__ FXa,
                     const real_t *__restrict__ FXb, int64_t ld, const real_t *__restrict__ eps, int c_lo,
-                    int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok, const int32_t *__restrict__ tile_order)
+                    int c_hi, real_t *__restrict__ out, int64_t n, int vec_ok, const int32_t *__restrict__ tile_order,
+                    const int32_t *__restrict__ fxwin)
 {
     constexpr int E = kSortTile / kBlock;   // entries per thread (8); entry e of thread t is tile + e*256 + t,
                                             // so one wave-level gather covers 64 CONSECUTIVE sorted entries
@@ -512,6 +517,36 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
     }
     real_t a[E], b[E], e[E];
     bool valid[E];
+    bool fxl = false;
+    if constexpr (FXL && MODE == 0) {
+        // the tile's runs of f(x) into LDS (s_val's area: it is written only after every lane has taken its f(x) values out)
+        const int32_t *fw = fxwin + tile_id * (2 * kFxWin);
+        int ws[kFxWin], wl[kFxWin];
+#pragma unroll
+        for (int w = 0; w < kFxWin; ++w) { ws[w] = fw[2 * w]; wl[w] = fw[2 * w + 1]; }
+        fxl = ws[0] >= 0;
+        if (fxl) {
+            int wo = 0;
+#pragma unroll
+            for (int w = 0; w < kFxWin; ++w) {
+                for (int i = threadIdx.x; i < wl[w]; i += kBlock) s_val[wo + i] = FXb[(int64_t)ws[w] + i];
+                wo += wl[w];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                int slot = 0, wo2 = 0;
+#pragma unroll
+                for (int w = 0; w < kFxWin; ++w) {
+                    const unsigned d = (unsigned)(r[k] - ws[w]);
+                    slot = d < (unsigned)wl[w] ? wo2 + (int)d : slot;
+                    wo2 += wl[w];
+                }
+                b[k] = s_val[slot];
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         const int cb = c[k] - c_lo;
@@ -519,7 +554,7 @@ k_decompress_sorted(const int32_t *__restrict__ srow, const CT *__restrict__ sco
         const int cs = valid[k] ? cb : 0;
         const int64_t at = (int64_t)cs * ld + r[k];
         e[k] = LDS_EPS ? s_eps[cs] : eps[c_lo + cs];
-        if (MODE == 0) { a[k] = FXa[at]; b[k] = FXb[r[k]]; }
+        if (MODE == 0) { a[k] = FXa[at]; if (!(FXL && fxl)) b[k] = FXb[r[k]]; }
         else if (MODE == 1) { a[k] = FXa[at]; b[k] = FXb[at]; }
         else { a[k] = FXa[at * 2 + 1]; b[k] = 0.0; }
     }
@@ -1428,9 +1463,14 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             const size_t shmq = sizeof(real_t) * (size_t)(kSortTile + (ldsq ? B : 0)) + (allw ? 0 : (size_t)kSortTile);
             const int vok = ((((uintptr_t)outs[0]) & kPairMask) == 0 ? 1 : 0) | (tile_order_reversed() ? 4 : 0);
 #define FD_LAUNCH_SORTED(LL, AW, SS)                                                                                 \
-            hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
+            do { if (MODE == 0 && p->d_fxwin)                                                                          \
+                hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS, true>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
                                p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
-                               c_hi, outs[0], p->nnz_local, vok, p->d_tile_order)
+                               c_hi, outs[0], p->nnz_local, vok, p->d_tile_order, p->d_fxwin);                         \
+            else                                                                                                       \
+                hipLaunchKernelGGL((k_decompress_sorted<CT, MODE, LL, AW, SS, false>), dim3((unsigned)gq), dim3(kBlock), shmq, s, \
+                               p->d_rowval, (const CT *)p->d_nzcolor, p->d_spos, FXa, FXb, p->ldf, p->d_eps, c_lo,    \
+                               c_hi, outs[0], p->nnz_local, vok, p->d_tile_order, (const int32_t *)nullptr); } while (0)
             if (p->sorted_gather) {
                 if (ldsq && allw) FD_LAUNCH_SORTED(true, true, true);
                 else if (ldsq) FD_LAUNCH_SORTED(true, false, true);

@@ -1992,3 +1992,86 @@ def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed)
     assert bad.numel() == 0, (nb, bs, fdtype, np.dtype(dtype).name, win, cap, env, int(bad.numel()), bad[:8].tolist(), got[bad[:8]].tolist(),
                               ref[bad[:8]].tolist())
     assert calls == calls_ref
+
+
+@pytest.mark.parametrize("case", ["stencil3d", "random_band", "lap5_forced", "stencil3d_none", "random_band_window", "random_band_chunked"])
+def test_sorted_gather_fx_through_lds_bit_identical(monkeypatch, oracle, case):
+    # forward differences on the colour-sorted gather kernel: f(x) of the rows a tile touches is staged in LDS (at most 8 runs of
+    # rows per tile, found at plan time) instead of gathered per entry -- FDJAC_FX_LDS=0 gathers; same bits, oracle parity
+    rng = np.random.default_rng(31)
+    if case.startswith("stencil3d"):
+        n = 30
+        N = n ** 3
+        k = np.arange(N, dtype=np.int64)
+        i, j, l = k % n, (k // n) % n, k // (n * n)
+        has = np.stack([l > 0, j > 0, i > 0, np.ones(N, bool), i < n - 1, j < n - 1, l < n - 1], axis=1)
+        rws = np.stack([k - n * n, k - n, k - 1, k, k + 1, k + n, k + n * n], axis=1)
+        colptr = np.empty(N + 1, np.int64); colptr[0] = 1
+        np.cumsum(has.sum(axis=1), out=colptr[1:]); colptr[1:] += 1
+        rowval = (rws[has] + 1).astype(np.int64)
+        colors = ((i + 2 * j + 3 * l) % 7 + 1).astype(np.int64)
+    elif case.startswith("random_band"):
+        N = 60_000
+        offs = np.sort(rng.integers(-300, 301, size=(N, 6)), axis=1)
+        rws = np.sort(np.clip(np.arange(N)[:, None] + offs, 0, N - 1), axis=1)
+        keep = np.ones_like(rws, bool); keep[:, 1:] = rws[:, 1:] != rws[:, :-1]
+        colptr = np.empty(N + 1, np.int64); colptr[0] = 1
+        np.cumsum(keep.sum(axis=1), out=colptr[1:]); colptr[1:] += 1
+        rowval = (rws[keep] + 1).astype(np.int64)
+        colors = fd.matrix_colors(fd.SparseMatrixCSC(N, N, colptr, rowval))
+    else:
+        nx, ny = 150, 90
+        N = nx * ny
+        colptr, rowval = P.lap5_csc(nx, ny)
+        colors = P.lap5_colors(nx, ny)
+    if case.endswith("_none"):
+        colors = colors.copy(); colors[rng.integers(0, N, 5)] = 0
+    win = (N // 5, N - N // 7) if case.endswith("_window") else None
+    C = int(colors.max())
+    cap = 8 * 2 * ((N + 31) // 32 * 32) * max(2, C // 5) + 8192 if case.endswith("_chunked") else 0
+    xh = rng.random(N)
+    x = _dev(xh)
+    col = P.csc_cols(colptr) - 1
+    wts = (0.3 + ((rowval * 7 + col * 3) % 11) / 11.0)               # one weight per stored entry: f = A_w * (x + x^2 / 2)
+    # (row-wise in a fixed order -- ELL layout -- so that f! is deterministic: atomics would not be)
+    order = np.lexsort((col, rowval - 1))
+    r_s, c_s, w_s = (rowval - 1)[order], col[order], wts[order]
+    first = np.searchsorted(r_s, np.arange(N))
+    slot = np.arange(r_s.size) - first[r_s]
+    K = int(slot.max()) + 1
+    ell_c, ell_w = np.zeros((K, N), np.int64), np.zeros((K, N))
+    ell_c[slot, r_s], ell_w[slot, r_s] = c_s, w_s
+    ell_c_t, ell_w_t = _dev(ell_c).long(), _dev(ell_w)
+
+    def f_t(fv, xx):
+        g = xx + 0.5 * xx * xx
+        acc = ell_w_t[0] * g[ell_c_t[0]]
+        for kk in range(1, K):
+            acc = acc + ell_w_t[kk] * g[ell_c_t[kk]]
+        fv.copy_(acc)
+
+    outs = []
+    for fxl in ("1", "0"):
+        monkeypatch.setenv("FDJAC_FX_LDS", fxl)
+        monkeypatch.setenv("FDJAC_SORTED", "1")
+        monkeypatch.setenv("FDJAC_WINDOW", "0")
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        plan = fd.make_plan(J, J, colors, "forward", scratch_bytes=cap, col_window=win)
+        assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1
+        if cap:
+            assert plan.info(fd.lib.INFO_NCHUNKS) > 1
+        f = fd.TorchF(f_t, N, N)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int64), outs[1].view(torch.int64))
+    got = outs[0].cpu().numpy()
+    want = wts * (1.0 + xh[col])
+    if win is not None:
+        e0, e1 = colptr[win[0]] - 1, colptr[win[1]] - 1            # (column window [a, b), 0-based)
+        want = want[e0:e1]
+    keep_e = (colors[col] != 0)
+    if win is not None:
+        keep_e = keep_e[e0:e1]
+    assert not np.isnan(got[keep_e]).any()
+    assert np.max(np.abs(got[keep_e] - want[keep_e])) < 5e-6
