@@ -7,6 +7,8 @@
 #include <limits>
 #include <new>
 
+#include <atomic>
+#include <thread>
 #include "fdjac_internal.h"
 
 namespace fdjac {
@@ -662,6 +664,23 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
 }
 
 // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
+// Host loops over independent tiles, on up to 32 host threads (a plan for 5.6e7 entries sorts 27 000 tiles: 2.4 s on one core).
+template <class F> static void parallel_tiles(size_t ntiles, F body)      // body(first_tile, last_tile)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    const char *pt = getenv("FDJAC_PLAN_THREADS");
+    if (pt && *pt) hw = (unsigned)std::max(1, atoi(pt));
+    const size_t nthr = std::min<size_t>({(size_t)std::max(1u, hw), (size_t)32, (ntiles + 63) / 64});
+    if (nthr <= 1) { body((size_t)0, ntiles); return; }
+    std::vector<std::thread> th;
+    const size_t per = (ntiles + nthr - 1) / nthr;
+    for (size_t k = 0; k < nthr; ++k) {
+        const size_t a = k * per, b = std::min(ntiles, a + per);
+        if (a < b) th.emplace_back([=, &body] { body(a, b); });
+    }
+    for (auto &t : th) t.join();
+}
+
 static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vector<std::pair<uint64_t, int32_t>> &ord)
 {
     for (int k = 0; k < kSortTile; ++k) {
@@ -968,28 +987,33 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (p->sorted_gather) {
         std::vector<uint16_t> spos(padded);
         const size_t ntiles = padded / kSortTile;
-        std::vector<int32_t> r2(kSortTile), c2(kSortTile);
-        for (size_t t = 0; t < ntiles; ++t) {
-            const size_t b0 = t * kSortTile;
-            sort_tile(b0);
-            for (int q = 0; q < kSortTile; ++q) {
-                const int k = ord[(size_t)q].second;
-                r2[(size_t)q] = rows[b0 + (size_t)k];
-                c2[(size_t)q] = nzc[b0 + (size_t)k];
-                spos[b0 + (size_t)q] = (uint16_t)k;
+        parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
+            std::vector<std::pair<uint64_t, int32_t>> ordl(kSortTile);
+            std::vector<int32_t> r2(kSortTile), c2(kSortTile);
+            for (size_t t = ta; t < tb; ++t) {
+                const size_t b0 = t * kSortTile;
+                sort_tile_entries(rows.data() + b0, nzc.data() + b0, ordl);
+                for (int q = 0; q < kSortTile; ++q) {
+                    const int k = ordl[(size_t)q].second;
+                    r2[(size_t)q] = rows[b0 + (size_t)k];
+                    c2[(size_t)q] = nzc[b0 + (size_t)k];
+                    spos[b0 + (size_t)q] = (uint16_t)k;
+                }
+                std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
+                std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
             }
-            std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
-            std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
-        }
+        });
         if ((rc = dev_upload(&p->d_spos, spos))) return rc;
         // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
         {
             const char *fl = getenv("FDJAC_FX_LDS");
             if (p->fdtype == FD_FORWARD && !(fl && *fl && atoi(fl) == 0)) {
-                std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0), tr;
-                std::vector<std::pair<int32_t, int32_t>> runs, gaps;
-                size_t eligible = 0;
-                for (size_t t = 0; t < ntiles; ++t) {
+                std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0);
+                std::atomic<size_t> eligible{0};
+                parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
+                std::vector<int32_t> tr;
+                std::vector<std::pair<int32_t, int32_t>> runs;
+                for (size_t t = ta; t < tb; ++t) {
                     int32_t *w = fxw.data() + t * 2 * kFxWin;
                     tr.clear();
                     for (size_t q = t * kSortTile; q < (t + 1) * kSortTile; ++q)
@@ -1016,7 +1040,8 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
                     for (size_t i = 0; i < runs.size(); ++i) { w[2 * i] = runs[i].first; w[2 * i + 1] = runs[i].second - runs[i].first + 1; }
                     ++eligible;
                 }
-                if (eligible * 2 >= ntiles && (rc = dev_upload(&p->d_fxwin, fxw))) return rc;
+                });
+                if (eligible.load() * 2 >= ntiles && (rc = dev_upload(&p->d_fxwin, fxw))) return rc;
             }
         }
         // Tile ORDER for patterns with a far band (3-D stencils: offsets 0, +-1, +-nx, +-nx*ny).  A tile's gathers reach the rows a

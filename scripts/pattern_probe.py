@@ -38,7 +38,10 @@ def main():
 
     def run(name, colptr, rowval, colors, N, fdtype="forward"):
         J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+        import time
+        t0 = time.perf_counter()
         plan = fd.make_plan(J, J, colors, fdtype)
+        print("plan build (%s): %.0f ms" % (name, (time.perf_counter() - t0) * 1e3), file=sys.stderr)
         f = fd.TorchF(lambda fx, xx: fx.copy_(xx), N, N)
         x = torch.rand(N, dtype=torch.float64, device=dev)
         out = torch.empty(rowval.size, dtype=torch.float64, device=dev)
