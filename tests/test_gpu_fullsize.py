@@ -278,3 +278,81 @@ def test_full_size_vs_oracle(oracle, name, lazy):
     bad = dev > 1e-6 * np.abs(want) + atol
     assert not bad.any(), "%s: %d of %d stored values off, worst %.3e (atol %.1e)" % (name, int(bad.sum()), got.size,
                                                                                        float(dev.max()), atol)
+
+
+@pytest.mark.parametrize("kernel", ["auto", "sorted"])
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_large_rectangular_random_pattern_vs_oracle(monkeypatch, oracle, fdtype, kernel):
+    # a general pattern at N = 10^6 (1.2e6 x 1.0e6, ~6 entries per column around a slanted "diagonal" plus a few far ones, greedy
+    # colouring): the colour-sorted gather path with its plan-time extras (f(x) runs staged in LDS for forward differences, the
+    # far-band tile order where it applies, host plan loops on threads) against the CPU oracle, every stored value
+    if kernel == "sorted":
+        monkeypatch.setenv("FDJAC_SORTED", "1")
+    M, N = 1_200_000, 1_000_000
+    rng = np.random.default_rng(1234)
+    centre = (np.arange(N) * (M / N)).astype(np.int64)
+    rws = centre[:, None] + rng.integers(-3000, 3001, size=(N, 6))
+    far = rng.random(N) < 0.03
+    rws[far, 0] = rng.integers(0, M, size=int(far.sum()))
+    rws = np.abs(rws)                                              # (reflected at the matrix edges: clipping would pile thousands
+    rws = np.sort(np.where(rws > M - 1, 2 * (M - 1) - rws, rws), axis=1)   #  of entries onto the first and last row)
+    keep = np.ones_like(rws, bool)
+    keep[:, 1:] = rws[:, 1:] != rws[:, :-1]
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(keep.sum(axis=1), out=colptr[1:])
+    colptr[1:] += 1
+    rowval = (rws[keep] + 1).astype(np.int64)
+    col = np.repeat(np.arange(N), keep.sum(axis=1))
+    J = fd.SparseMatrixCSC(M, N, colptr, rowval)
+    colors = fd.matrix_colors(J)
+    C = int(colors.max())
+    assert C < 64
+    wts = 0.3 + ((rowval * 7 + col * 3) % 11) / 11.0
+    # f = A_w (x + x^2 / 2), row-wise in a fixed order (ELL) so that it is deterministic on the device and the same sum on the host
+    order = np.lexsort((col, rowval - 1))
+    r_s, c_s, w_s = (rowval - 1)[order], col[order], wts[order]
+    first = np.searchsorted(r_s, np.arange(M))
+    slot = np.arange(r_s.size) - first[r_s]
+    K = int(slot.max()) + 1
+    ell_c, ell_w = np.zeros((K, M), np.int64), np.zeros((K, M))
+    ell_c[slot, r_s], ell_w[slot, r_s] = c_s, w_s
+    ell_c_t, ell_w_t = torch.as_tensor(ell_c, device="cuda"), torch.as_tensor(ell_w, device="cuda")
+
+    def f_t(fv, xx):
+        g = xx + 0.5 * xx * xx
+        acc = ell_w_t[0] * g[ell_c_t[0]]
+        for kk in range(1, K):
+            acc = acc + ell_w_t[kk] * g[ell_c_t[kk]]
+        fv.copy_(acc)
+
+    def f_n(fv, xx):
+        g = xx + 0.5 * xx * xx
+        acc = ell_w[0] * g[ell_c[0]]
+        for kk in range(1, K):
+            acc = acc + ell_w[kk] * g[ell_c[kk]]
+        fv[:] = acc
+
+    xh = rng.random(N)
+    x = torch.as_tensor(xh, device="cuda")
+    plan = fd.make_plan(J, J, colors, fdtype)
+    kern = ("window2d" if plan.info(fd.lib.INFO_WINDOW2D) else "window" if plan.info(fd.lib.INFO_WINDOW)
+            else "sorted" if plan.info(fd.lib.INFO_SORTED_GATHER) else "list")
+    print("decompression kernel:", kern, "colours:", C)
+    assert kernel == "auto" or kern == "sorted"
+    f = fd.TorchF(f_t, M, N)
+    out = _nan(plan.out_len(0))
+    plan.jacobian(f, x, [out])
+    assert f.fcalls == CALLS[fdtype](C)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    want = wts * (1.0 + xh[col])                                   # the analytic Jacobian
+    assert np.max(np.abs(got - want)) < (2e-5 if fdtype == "forward" else 2e-8)
+    ref = oracle.jacobian(fdtype, oracle.PyF(f_n, M, N), xh, colors, M=M, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    assert ref["fcalls"] == f.fcalls
+    eps = plan.epsilons()
+    assert np.allclose(eps, _oracle_eps(xh, colors, fdtype), rtol=1e-12, atol=0)
+    atol = 16 * EPS64 * 8.0 / float(np.min(np.abs(eps)))
+    dev = np.abs(got - ref["out"])
+    bad = dev > 1e-6 * np.abs(ref["out"]) + atol
+    assert not bad.any(), "%d of %d stored values off, worst %.3e (atol %.1e)" % (int(bad.sum()), got.size, float(dev.max()), atol)
