@@ -195,3 +195,33 @@ int main(void) {
     exe = str(tmp_path / "band")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
     assert subprocess.run([exe], capture_output=True, text=True).returncode == 0
+
+
+def test_device_header_stencil5_arithmetic_matches_a_brute_force_csc(tmp_path):
+    # include/fdjac_device.h: fd_stencil5_colptr / fd_stencil5_colptr_ij (the form the kernels call: no 64-bit division) against
+    # the 5-point stencil's CSC built by enumeration, for every grid shape up to 12 x 12 incl. one column / one row wide
+    import subprocess
+    src = tmp_path / "stencil.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "fdjac_device.h"
+int main(void) {
+    for (long long nx = 1; nx <= 12; ++nx)
+        for (long long ny = 1; ny <= 12; ++ny) {
+            fd_stencil5_store d = {0};
+            d.nx = nx; d.ny = ny;
+            long long nn = 0;
+            for (long long k = 0; k <= nx * ny; ++k) {
+                const long long j = k / nx, i = k % nx;
+                if (fd_stencil5_colptr(&d, k) != nn) { printf("colptr %lldx%lld k=%lld: %lld != %lld\n", nx, ny, k, fd_stencil5_colptr(&d, k), nn); return 1; }
+                if (k < nx * ny && fd_stencil5_colptr_ij(&d, i, j) != nn) { printf("colptr_ij %lldx%lld k=%lld\n", nx, ny, k); return 2; }
+                if (k < nx * ny) nn += 1 + (j > 0) + (i > 0) + (i < nx - 1) + (j < ny - 1);
+            }
+        }
+    return 0;
+}
+''')
+    exe = str(tmp_path / "stencil")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
