@@ -15,6 +15,7 @@
  * a colour touches a row).  The first part of this header is plain C, usable from HIP kernels and from the host (the plan's
  * verification runs it there); the second part (HIP C++) holds the store helpers:
  *     fd_band_emit<T>            one entry, any layout (an 8-byte store per entry: simple, not bandwidth-optimal)
+ *     fd_colrange_emit<T>        one entry of a column-range storage (BlockBandedMatrix data), given (row, column)
  *     fd_band_emit_wave<T, W>    a wavefront's 128 columns at once, staged through a wave-private LDS window and written
  *                                back as dense, aligned, non-temporal 16-byte stores -- what the built-in tridiagonal
  *                                launcher uses (N = 10^7, Float64: 320 MB in 53-60 us, 0.67-0.76 of the 8 TB/s peak)
@@ -358,6 +359,15 @@ __device__ inline void fd_stencil5_emit_wave(const fd_stencil5_store *d, T *win,
     fd_wave_store_window<T, NT>((T *)d->out + (P0 - off), win, off, off + cnt);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+/* One entry of a column-range storage (fd_colrange_store): the value of (row r, column j).  Entries outside the local column
+   range or outside the column's stored rows are ignored. */
+template <typename T> __device__ inline void fd_colrange_emit(const fd_colrange_store *d, long long j, long long r, T value)
+{
+    if (j < d->col_begin || j >= d->col_end) return;
+    const long long jj = j - d->col_begin, k = r - d->row_first[jj];
+    if (k < 0 || k >= d->row_count[jj]) return;
+    ((T *)d->out)[d->dest[jj] + k] = value;
 }
 #endif /* __HIPCC__ && __cplusplus */
 

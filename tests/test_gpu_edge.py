@@ -459,6 +459,29 @@ def test_user_kernel_stores_the_jacobian_through_the_device_header(tmp_path, ora
     assert np.all(np.abs(got - ref["out"]) <= 1e-6 * np.abs(ref["out"]) + atol)
 
 
+@pytest.mark.parametrize("shape", [(150, 12), (7, 33), (2, 5)])
+def test_user_kernel_stores_a_blockbanded_jacobian_through_the_device_header(tmp_path, shape):
+    # examples/user_bb_store.hip: a USER's own HIP f! with a block-tridiagonal Jacobian of dense blocks -- its own shared library,
+    # compiled apart from libfdjac -- registered with FD_LAZY_CAP_STORE receives a fd_colrange_store (the plan verified the
+    # colouring) and stores imag(f) / eps into BlockBandedMatrix data with fd_colrange_emit (complex step, src/jacobians.jl:624-637,
+    # ext/FiniteDiffBlockBandedMatricesExt.jl:44-68).  examples/user_bb_client.c checks the analytic values, agreement with the
+    # plan driven through the user's plain launcher + the library's decompression, and the f! evaluation counts.
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "finitediff.jl_amd", "lib")
+    user_so = str(tmp_path / "libuser_bb.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(root, "examples", "user_bb_store.hip"), "-o", user_so])
+    assert "libfdjac" not in subprocess.run(["ldd", user_so], capture_output=True, text=True).stdout
+    exe = str(tmp_path / "user_bb_client")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_bb_client.c"), "-o", exe,
+                           "-L" + str(tmp_path), "-luser_bb", "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "user_bb_client ok" in out.stdout and "FAILED" not in out.stdout
+
+
 @pytest.mark.parametrize("kind", ["csc_store", "csc_handover", "blockbanded_complex"])
 def test_jacobian_call_captures_into_a_hip_graph(monkeypatch, kind):
     # fd_jacobian_async enqueues kernels only -- no allocation, no synchronisation, no host read-back once the plan has run once --
