@@ -225,3 +225,19 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_user_examples_cross_compile_against_the_public_headers_only(tmp_path):
+    # examples/user_f_store.hip and user_bb_store.hip (a USER's kernels that store the Jacobian themselves) build for gfx950 with
+    # nothing but include/fdjac.h + include/fdjac_device.h on the include path and do not link libfdjac; their plain-C drivers
+    # compile with gcc (hipcc cross-compiles without a GPU; the -m gpu tests run them)
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for name in ("user_f_store", "user_bb_store"):
+        so = str(tmp_path / ("lib%s.so" % name))
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
+                               os.path.join(ROOT, "examples", name + ".hip"), "-o", so])
+        assert "libfdjac" not in subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    for name in ("user_store_client", "user_bb_client"):
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + inc, "-c", os.path.join(ROOT, "examples", name + ".c"),
+                               "-o", str(tmp_path / (name + ".o"))])
