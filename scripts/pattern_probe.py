@@ -54,6 +54,7 @@ def main():
         torch.cuda.synchronize()
         tm = plan.timings()
         us = tm["decompress"]["ms_sum"] / max(tm["decompress"]["launches"], 1) * 1e3
+        print("stages (%s): " % name + ", ".join("%s %.1f us" % (k, v["ms_sum"] / max(v["launches"], 1) * 1e3) for k, v in tm.items()), file=sys.stderr)
         C = int(colors.max())
         kern = ("window2d" if plan.info(fd.lib.INFO_WINDOW2D) else "window" if plan.info(fd.lib.INFO_WINDOW)
                 else "sorted" if plan.info(fd.lib.INFO_SORTED_GATHER) else "list")
