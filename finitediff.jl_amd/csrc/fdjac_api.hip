@@ -674,10 +674,16 @@ template <class F> static void parallel_tiles(size_t ntiles, F body)      // bod
     if (nthr <= 1) { body((size_t)0, ntiles); return; }
     std::vector<std::thread> th;
     const size_t per = (ntiles + nthr - 1) / nthr;
-    for (size_t k = 0; k < nthr; ++k) {
-        const size_t a = k * per, b = std::min(ntiles, a + per);
-        if (a < b) th.emplace_back([=, &body] { body(a, b); });
+    size_t done_to = 0;                      // tiles [0, done_to) have a thread; the rest run here if a thread cannot be started
+    try {
+        for (size_t k = 0; k < nthr; ++k) {
+            const size_t a = k * per, b = std::min(ntiles, a + per);
+            if (a < b) th.emplace_back([=, &body] { body(a, b); });
+            done_to = b;
+        }
+    } catch (...) {
     }
+    if (done_to < ntiles) body(done_to, ntiles);
     for (auto &t : th) t.join();
 }
 
