@@ -943,8 +943,6 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (has_dest) dest.resize(padded, 0);
     for (int32_t c : col0) if (c < 0) { p->has_none = true; break; }
 
-    std::vector<std::pair<uint64_t, int32_t>> ord(kSortTile);
-    auto sort_tile = [&](size_t b0) { sort_tile_entries(rows.data() + b0, nzc.data() + b0, ord); };
     bool scattered = false;
     if (!has_dest && p->nnz_local >= 4 * kSortTile) {
         const size_t ntiles = padded / kSortTile;

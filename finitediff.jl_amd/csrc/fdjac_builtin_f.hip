@@ -1354,7 +1354,6 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
         const real_t rcm = rc[(lb - 1) * RS + r];
         const int first = bcol > 0 ? 0 : 1;                               // the column's stored rows start at block max(bcol - 1, 0)
         const T *su = ssum + (size_t)(lb - 2) * B;
-#pragma unroll 2
         for (int it = 0; it * (TWO ? 2 : 1) < ncol; ++it) {
             const int ci = TWO ? 2 * it + half : it;                      // column of the unit
             const int src = ci < ncol ? ci : 0;
