@@ -103,7 +103,14 @@ static int upload_colors(fd_plan *p, const std::vector<int32_t> &col0, const std
     return FD_OK;
 }
 
-constexpr int32_t kPlanLoweredComplexX = 1 << 16;   // internal fd_plan_opts.flags bit: this plan IS the lowered real problem of FD_PLAN_COMPLEX_X
+// "The plan being created IS the lowered real problem of FD_PLAN_COMPLEX_X": set by the lowering functions around their inner
+// plan_create call (LoweredScope), read by apply_opts.  Internal state, deliberately NOT a bit of the public fd_plan_opts.flags.
+static thread_local bool t_lowered_cx = false;
+struct LoweredScope {
+    LoweredScope() { t_lowered_cx = true; }
+    ~LoweredScope() { t_lowered_cx = false; }
+};
+constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X;
 
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {
@@ -111,6 +118,8 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     FD_REQUIRE(opts->fdtype == FD_FORWARD || opts->fdtype == FD_CENTRAL || opts->fdtype == FD_COMPLEX,
                FD_ERR_UNSUPPORTED,
                "Unrecognized fdtype: valid values are Val{:forward}, Val{:central} and Val{:complex}.");
+    FD_REQUIRE((opts->flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x (zero the struct before filling it)",
+               (unsigned)(opts->flags & ~kPlanKnownFlags));
     FD_REQUIRE(!(opts->flags & FD_PLAN_COMPLEX_X), FD_ERR_UNSUPPORTED,
                "complex-valued x (FD_PLAN_COMPLEX_X) is built for CSC, dense-J, entry-list and dense-arm plans, not for this storage type");
     p->fdtype = opts->fdtype;
@@ -148,7 +157,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // 75.3 vs 76.0 us per Jacobian, profiles/r03_f_eps_contig_ab.txt -- and a sharded reduction then reads only the shard's own
     // range); FDJAC_EPS_CONTIG=0 restores the grid-stride map, FD_PLAN_EPS_CONTIGUOUS insists on the contiguous one
     p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 1) != 0;
-    p->cx = (opts->flags & kPlanLoweredComplexX) != 0;   // (set by lower_complex_x only)
+    p->cx = t_lowered_cx;                                // (inside a LoweredScope only)
     if (p->cx) p->small_ok = false;                      // the fused small-problem launch has ONE colour rule for norm and perturbation
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
@@ -665,26 +674,39 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
 
 // sort key of an entry: colour first (uncoloured, then padding, last), row second, storage position third
 // Host loops over independent tiles, on up to 32 host threads (a plan for 5.6e7 entries sorts 27 000 tiles: 2.4 s on one core).
-template <class F> static void parallel_tiles(size_t ntiles, F body)      // body(first_tile, last_tile)
+template <class F> static int parallel_tiles(size_t ntiles, F body)      // body(first_tile, last_tile); FD_OK or FD_ERR_NOMEM
 {
     unsigned hw = std::thread::hardware_concurrency();
     const char *pt = getenv("FDJAC_PLAN_THREADS");
     if (pt && *pt) hw = (unsigned)std::max(1, atoi(pt));
     const size_t nthr = std::min<size_t>({(size_t)std::max(1u, hw), (size_t)32, (ntiles + 63) / 64});
-    if (nthr <= 1) { body((size_t)0, ntiles); return; }
-    std::vector<std::thread> th;
-    const size_t per = (ntiles + nthr - 1) / nthr;
-    size_t done_to = 0;                      // tiles [0, done_to) have a thread; the rest run here if a thread cannot be started
-    try {
-        for (size_t k = 0; k < nthr; ++k) {
-            const size_t a = k * per, b = std::min(ntiles, a + per);
-            if (a < b) th.emplace_back([=, &body] { body(a, b); });
-            done_to = b;
+    // an exception inside a worker (std::bad_alloc of a tile's vectors) must not reach std::terminate, nor cross the C ABI
+    std::atomic<bool> failed{false};
+    auto guarded = [&](size_t a, size_t b) {
+        try { body(a, b); } catch (...) { failed.store(true); }
+    };
+    if (nthr <= 1) {
+        guarded((size_t)0, ntiles);
+    } else {
+        std::vector<std::thread> th;
+        const size_t per = (ntiles + nthr - 1) / nthr;
+        size_t done_to = 0;                  // tiles [0, done_to) have a thread; the rest run here if a thread cannot be started
+        try {
+            for (size_t k = 0; k < nthr; ++k) {
+                const size_t a = k * per, b = std::min(ntiles, a + per);
+                if (a < b) th.emplace_back([=, &guarded] { guarded(a, b); });
+                done_to = b;
+            }
+        } catch (...) {
         }
-    } catch (...) {
+        if (done_to < ntiles) guarded(done_to, ntiles);
+        for (auto &t : th) t.join();
     }
-    if (done_to < ntiles) body(done_to, ntiles);
-    for (auto &t : th) t.join();
+    if (failed.load()) {
+        set_error("out of host memory while compiling the plan's tiles");
+        return FD_ERR_NOMEM;
+    }
+    return FD_OK;
 }
 
 static void sort_tile_entries(const int32_t *rows, const int32_t *nzc, std::vector<std::pair<uint64_t, int32_t>> &ord)
@@ -991,7 +1013,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
     if (p->sorted_gather) {
         std::vector<uint16_t> spos(padded);
         const size_t ntiles = padded / kSortTile;
-        parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
+        if ((rc = parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
             std::vector<std::pair<uint64_t, int32_t>> ordl(kSortTile);
             std::vector<int32_t> r2(kSortTile), c2(kSortTile);
             for (size_t t = ta; t < tb; ++t) {
@@ -1006,7 +1028,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
                 std::copy(r2.begin(), r2.end(), rows.begin() + (ptrdiff_t)b0);
                 std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
             }
-        });
+        }))) return rc;
         if ((rc = dev_upload(&p->d_spos, spos))) return rc;
         // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
         {
@@ -1014,7 +1036,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             if (p->fdtype == FD_FORWARD && !(fl && *fl && atoi(fl) == 0)) {
                 std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0);
                 std::atomic<size_t> eligible{0};
-                parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
+                if ((rc = parallel_tiles(ntiles, [&](size_t ta, size_t tb) {
                 std::vector<int32_t> tr;
                 std::vector<std::pair<int32_t, int32_t>> runs;
                 for (size_t t = ta; t < tb; ++t) {
@@ -1044,7 +1066,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
                     for (size_t i = 0; i < runs.size(); ++i) { w[2 * i] = runs[i].first; w[2 * i + 1] = runs[i].second - runs[i].first + 1; }
                     ++eligible;
                 }
-                });
+                }))) return rc;
                 if (eligible.load() * 2 >= ntiles && (rc = dev_upload(&p->d_fxwin, fxw))) return rc;
             }
         }
@@ -1063,8 +1085,11 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             if (D >= (want == 2 ? 2 : 16) * cpt && D < ncols) {
                 int64_t Rg = ((int64_t)2 << 20) / (3 * std::max<int64_t>(p->C, 1) * (int64_t)sizeof(real_t));
                 Rg = std::max<int64_t>(4 * cpt, std::min<int64_t>(Rg, D / 2));
-                std::vector<int32_t> order(ntiles);
-                for (size_t t = 0; t < ntiles; ++t) order[t] = (int32_t)t;
+                // only the tiles the kernel walks: ceil(nnz_local / kSortTile) -- the lists are padded to kListPad (two tiles), and
+                // an all-padding tile in the order would displace a real one (its values would never be written)
+                const size_t nreal = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile);
+                std::vector<int32_t> order(nreal);
+                for (size_t t = 0; t < nreal; ++t) order[t] = (int32_t)t;
                 std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
                     const int64_t ua = tcol[(size_t)a] % D, ub = tcol[(size_t)b] % D;
                     const int64_t ka = ua / Rg, kb = ub / Rg;
@@ -1270,7 +1295,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
 // complex number divided by a real one, J is complex.  Seen as reals that IS a real problem of twice the size: element 2j / 2j+1 =
 // re / im of x_j, row 2r / 2r+1 = re / im of f_r; only the even columns carry colours; the stored entry (r, j) becomes the two
 // entries (2r, 2j), (2r+1, 2j) -- consecutive in every storage order the plans write, i.e. exactly the (re, im) layout of a
-// Complex nzval / dense J.  So the plan is built for that real problem (the flag kPlanLoweredComplexX marks it: pair norms in
+// Complex nzval / dense J.  So the plan is built for that real problem (the thread-local marker t_lowered_cx says so: pair norms in
 // the step-size kernels, f! called with is_complex = 1) and every kernel of the real path serves it unchanged.
 struct LoweredCx {
     std::vector<int64_t> colptr, rows, cols, dest, colors;
@@ -1284,7 +1309,8 @@ static int lower_colors_opts(int64_t N, const void *colorvec, int color_bytes, c
     L.colors.assign((size_t)(2 * N), 0);
     for (int64_t j = 0; j < N; ++j) L.colors[(size_t)(2 * j)] = load_idx(colorvec, color_bytes, j);   // (odd = imaginary parts: colour 0, never perturbed)
     L.opts = *opts;
-    L.opts.flags = (opts->flags & ~FD_PLAN_COMPLEX_X) | kPlanLoweredComplexX;
+    FD_REQUIRE((opts->flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x", (unsigned)(opts->flags & ~kPlanKnownFlags));
+    L.opts.flags = opts->flags & ~FD_PLAN_COMPLEX_X;
     L.opts.col_begin *= 2; L.opts.col_end *= 2; L.opts.x_begin *= 2; L.opts.x_end *= 2;
     return FD_OK;
 }
@@ -1314,6 +1340,7 @@ static int lowered_csc(fd_ctx *ctx, int kind_dense, int64_t M, int64_t N, const 
             }
         }
         L.colptr[(size_t)(2 * N)] = 2 * nnz;
+        LoweredScope lowered;
         return csc_common(ctx, K_CSC, 2 * M, 2 * N, L.colptr.data(), L.rows.data(), 8, 0, L.colors.data(), 8, &L.opts, out, true);
     }
     // dense complex J (M x N column-major = 2M x N reals): explicit destinations
@@ -1324,6 +1351,7 @@ static int lowered_csc(fd_ctx *ctx, int kind_dense, int64_t M, int64_t N, const 
             FD_REQUIRE(q >= 0 && q < nnz && r >= 0 && r < M, FD_ERR_SHAPE, "inconsistent pattern");
             for (int h = 0; h < 2; ++h) { L.rows[(size_t)(2 * q + h)] = 2 * r + h; L.cols[(size_t)(2 * q + h)] = 2 * j; L.dest[(size_t)(2 * q + h)] = 2 * r + h + 2 * M * j; }
         }
+    LoweredScope lowered;
     return fd_plan_create_entries(ctx, 2 * M, 2 * N, L.rows.data(), L.cols.data(), L.dest.data(), 2 * nnz, 2 * M * N, 8, 0, L.colors.data(), 8, &L.opts, out);
 }
 static int lowered_coo(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index, const int64_t *dest, int64_t nnz,
@@ -1341,6 +1369,7 @@ static int lowered_coo(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index
         const int64_t d = dest ? dest[q] : r + M * c;       // (complex elements)
         for (int h = 0; h < 2; ++h) { L.rows[(size_t)(2 * q + h)] = 2 * r + h; L.cols[(size_t)(2 * q + h)] = 2 * c; L.dest[(size_t)(2 * q + h)] = 2 * d + h; }
     }
+    LoweredScope lowered;
     return fd_plan_create_entries(ctx, 2 * M, 2 * N, L.rows.data(), L.cols.data(), L.dest.data(), 2 * nnz, 2 * out_len, 8, 0, L.colors.data(), 8, &L.opts, out);
 }
 
@@ -1637,11 +1666,13 @@ int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const
         fd_plan_opts o = *opts;
         FD_REQUIRE(o.fdtype != FD_COMPLEX, FD_ERR_UNSUPPORTED, "fdtype_error: Val(:complex) needs a real returntype (src/jacobians.jl:106)");
         FD_REQUIRE(ncols >= 0 && ncols <= N, FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
-        o.flags = (o.flags & ~FD_PLAN_COMPLEX_X) | kPlanLoweredComplexX;
+        FD_REQUIRE((o.flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x", (unsigned)(o.flags & ~kPlanKnownFlags));
+        o.flags &= ~FD_PLAN_COMPLEX_X;
         o.col_begin *= 2; o.col_end *= 2; o.x_begin *= 2; o.x_end *= 2;
+        LoweredScope lowered;
         return fd_plan_create_dense(ctx, 2 * M, 2 * N, ncols, &o, out);
     }
-    FD_REQUIRE(ncols >= 0 && ncols <= (opts && (opts->flags & kPlanLoweredComplexX) ? N / 2 : N), FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
+    FD_REQUIRE(ncols >= 0 && ncols <= (t_lowered_cx ? N / 2 : N), FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
     if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
         set_error("column windows are not supported for the dense arm");
         return FD_ERR_UNSUPPORTED;
@@ -2247,17 +2278,22 @@ int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     FD_REQUIRE(comm == nullptr || fdjac_comm_ctx(comm) == p->ctx, FD_ERR_ARG, "the communicator belongs to another context");
     FD_REQUIRE(comm == nullptr || fdjac_comm_nranks(comm) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
-    if (comm && eps_shardable(p)) {
+    if (comm) {
         // every rank must cut the SAME global grid of blocks (it is a function of N, the colour count and the map -- but a rank
         // with another FDJAC_GRID_CAP / FDJAC_EPS_CONTIG would use other slots: mismatched all-gather counts hang, matched
-        // ones finalize garbage).  One tiny all-reduce at attach time settles it.
-        const double mine[4] = {(double)p->n_partial_blocks, -(double)p->n_partial_blocks, (double)p->eps_tpb, -(double)p->eps_tpb};
+        // ones finalize garbage), and every rank must agree on WHETHER its reduction is sharded at all (a rank whose plan keeps
+        // the replicated reduction would skip the per-call all-gather the others enter).  One tiny all-reduce at attach time
+        // settles both; it is unconditional -- every rank enters it whatever its own plan looks like.
+        const bool sh = eps_shardable(p);
+        const double nb = sh ? (double)p->n_partial_blocks : -1.0, tp = sh ? (double)p->eps_tpb : -1.0;
+        const double mine[4] = {nb, -nb, tp, -tp};
         double got[4] = {0, 0, 0, 0};
         const int rc = fdjac_comm_allreduce_max4(comm, mine, got);
         if (rc) return rc;
         FD_REQUIRE(got[0] == mine[0] && got[1] == mine[1] && got[2] == mine[2] && got[3] == mine[3], FD_ERR_COMM,
-                   "the ranks disagree on the step-size reduction's grid (this rank: %d blocks of %d tiles): same N, colours, "
-                   "FDJAC_GRID_CAP and FD_PLAN_EPS_CONTIGUOUS everywhere?", p->n_partial_blocks, p->eps_tpb);
+                   "the ranks disagree on the step-size reduction (this rank: %s, %d blocks of %d tiles): same N, colours, fdtype, "
+                   "FDJAC_SMALL, FDJAC_GRID_CAP and FD_PLAN_EPS_CONTIGUOUS everywhere?", sh ? "sharded" : "replicated",
+                   p->n_partial_blocks, p->eps_tpb);
     }
     p->comm = comm;
     return FD_OK;

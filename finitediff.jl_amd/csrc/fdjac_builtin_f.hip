@@ -724,6 +724,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
         if (lp->store_kind != FD_STORE_BAND) return FD_LAZY_DECLINED;
         const fd_band_store bst = *(const fd_band_store *)lp->store;
         if (bst.elem_bytes != (int)sizeof(real_t) || mode == 2) return FD_LAZY_DECLINED;
+        if (bst.N != b->prm[0] || bst.M != b->prm[0]) return FD_LAZY_DECLINED;   // a plan of another problem size than this fixture's
         const int wband = bst.l + bst.u + 1;
         // an exactly tridiagonal band with every colour in this batch: the column-centric wave kernel, any layout
         // (FDJAC_STORE_WAVE=0 keeps round 2's row-owned form for A/B runs)

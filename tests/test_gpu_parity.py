@@ -1932,6 +1932,59 @@ def test_far_band_tile_order_is_pure_scheduling(monkeypatch, oracle, fdtype):
     assert np.max(np.abs(got - want)) < (2e-6 if fdtype == "forward" else 2e-8)
 
 
+def test_far_band_tile_order_with_a_padding_tile_in_a_column_window(monkeypatch):
+    # the index lists are padded to 4096 entries = TWO tiles of the sorted-gather kernel, which walks ceil(nnz_local / 2048) tiles:
+    # when nnz_local mod 4096 is in (0, 2048] the padded lists hold one all-padding tile that must not take a real tile's place in
+    # the far-band order (round-3 advisor finding: a column window of a 3-D stencil dropped 2048 stored values)
+    n = 36
+    N = n ** 3
+    k = np.arange(N, dtype=np.int64)
+    i, j, l = k % n, (k // n) % n, k // (n * n)
+    has = np.stack([l > 0, j > 0, i > 0, np.ones(N, bool), i < n - 1, j < n - 1, l < n - 1], axis=1)
+    rows = np.stack([k - n * n, k - n, k - 1, k, k + 1, k + n, k + n * n], axis=1)
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(has.sum(axis=1), out=colptr[1:])
+    colptr[1:] += 1
+    rowval = (rows[has] + 1).astype(np.int64)
+    colors = ((i + 2 * j + 3 * l) % 7 + 1).astype(np.int64)
+    x = _dev(np.random.default_rng(19).random(N))
+
+    def f_t(fv, xx):
+        X = xx.view(n, n, n)
+        F = X * X
+        F[:, :, 1:] += 1.0 * X[:, :, :-1]
+        F[:, :, :-1] += 0.5 * X[:, :, 1:]
+        F[:, 1:, :] += 0.25 * X[:, :-1, :]
+        F[:, :-1, :] += 0.125 * X[:, 1:, :]
+        F[1:] += 2.0 * X[:-1]
+        F[:-1] += 3.0 * X[1:]
+        fv.copy_(F.reshape(-1))
+
+    a = 5000
+    checked = 0
+    for b in range(N - 9000, N - 2000, 97):          # windows whose last column is NOT the largest key of the order
+        nloc = int(colptr[b] - colptr[a])
+        if not (0 < nloc % 4096 <= 2048):
+            continue
+        outs = []
+        for order in ("2", "0"):
+            monkeypatch.setenv("FDJAC_TILE_ORDER", order)
+            monkeypatch.setenv("FDJAC_SORTED", "1")
+            J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, "forward", col_window=(a, b))
+            assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1 and plan.out_len() == nloc
+            out = _dev(np.full(nloc, np.nan))
+            plan.jacobian(fd.TorchF(f_t, N, N), x, [out])
+            outs.append(out)
+        assert not torch.isnan(outs[0]).any(), (b, int(torch.isnan(outs[0]).sum()))
+        assert torch.equal(outs[0].view(torch.int64), outs[1].view(torch.int64))
+        checked += 1
+        if checked == 3:
+            break
+    assert checked == 3
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed):
     # the block-banded routes -- materialised points, the lazy launcher (imaginary parts or (re, im) pairs), the storing launch,
