@@ -465,6 +465,138 @@ def main():
             handover = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             os.environ.pop("FDJAC_LAZY_STORE", None)
+    # ---- side measurement (single GPU, untimed): the OPAQUE-f! call -- what an unmodified f!(fx, x) closure gets (the shim's
+    # `device_f`): no lazy launcher, so the library materialises the perturbed points (ONE launch for all colours), f! runs on
+    # them as one batched launch (+ f(x)), and k_decompress_window forms (fx1 - fx) / eps and decompresses, reading fx / fx1
+    # once -- SURVEY 8(d)'s diff + scatter kernel with its 89 B / column model.  src/jacobians.jl:562-568.
+    opaque = None
+    if world == 1 and f_mode == "lazy" and not args.no_plain_handover and cfg in ("c2", "c3", "c4"):
+        try:
+            cp_s, rv_s = P.tridiag_csc(N) if cfg != "c3" else P.lap5_csc(nx, ny)
+            pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
+            plan_o = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)      # no set_lazy: the plain fd_f_launch only
+            del cp_s, rv_s, pat_s
+            out_o = torch.full_like(out, float("nan"))
+            enq_o = plan_o.bind(f, x, [out_o])
+            for _ in range(3):
+                enq_o()
+            torch.cuda.synchronize()
+            plan_o.enable_timing(2)
+            for _ in range(10):
+                enq_o()
+            torch.cuda.synchronize()
+            to_all = plan_o.timings()
+            plan_o.enable_timing(3)
+            for _ in range(max(args.steps, 20)):
+                enq_o()
+            torch.cuda.synchronize()
+            tot_o = plan_o.timing_samples("total")
+            plan_o.enable_timing(1)
+            for _ in range(max(args.steps, 20)):
+                enq_o()
+            torch.cuda.synchronize()
+            dec_o = plan_o.timing_samples("decompress")
+            plan_o.enable_timing(0)
+            st_o = {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in to_all.items()}
+            dec_med_o = float(np.median(dec_o)) if dec_o else None
+            pts_o = 2 if fdtype == "central" else 1
+            model_o = ((2 * C * vs * N + nnz * (vs + 4) + 4 * (N + 1) + N) if cfg != "c3" else bytes_ds * N)   # C*2*M*s + nnz*(s+4) + (N+1)*4 + N
+            opaque = {"what": "no lazy launcher (an unmodified f!): eps pass + k_perturb (all colours, one launch) + batched f! on materialised "
+                              "points + k_decompress_* (difference, division, decompression; fx / fx1 read once)",
+                      "median_ms_per_step": float(np.median(tot_o)) if tot_o else None, "stages_ms": st_o,
+                      "f_evaluations": int(plan_o.fcalls_last), "points_per_colour": pts_o,
+                      "kernel": ("k_decompress_window2d" if plan_o.info(fd.lib.INFO_WINDOW2D) else "k_decompress_window" if plan_o.info(fd.lib.INFO_WINDOW)
+                                 else "k_decompress_sorted" if plan_o.info(fd.lib.INFO_SORTED_GATHER) else "k_decompress_list"),
+                      "decompress_median_ms": dec_med_o,
+                      "roofline_survey_model": ({"algorithmic_bytes_per_launch": float(model_o), "gbps": model_o / (dec_med_o * 1e-3) / 1e9,
+                                                 "frac": model_o / (dec_med_o * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                 "note": "SURVEY 8(d) bytes of the diff + scatter kernel (fx and fx1 of every colour, rowval, colptr, "
+                                                         "colours in; every value out) / this kernel's median time -- the model's index reads and per-colour "
+                                                         "fx re-reads are NOT performed (16-bit entry codes, fx read once), so this is an equivalent-work rate"}
+                                                if dec_med_o else None),
+                      "bit_identical_to_timed_result": bool(torch.equal(out_o, timed_result))}
+            del out_o, plan_o, enq_o
+        except Exception as e:
+            opaque = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- side measurement (single GPU, untimed): the DROP-IN call -- the sequence every existing FiniteDiff.jl call site
+    # goes through (julia/FiniteDiffMI355X.jl, mirrored by api.py and examples/c_abi_clients.c::client_dropin):
+    # cache -> plan lookup (O(1) identity key; optional fd_plan_matches content check) -> fd_jacobian_async.
+    dropin = None
+    if world == 1 and f_mode == "lazy" and not args.no_plain_handover and cfg in ("c2", "c4") and args.dtype == "f64":
+        try:
+            reps = max(args.steps, 20)
+            cp_s, rv_s = P.tridiag_csc(N)
+            out_d = torch.full_like(out, float("nan"))
+
+            def measure(Jd, cvd, check):
+                cache = fd.JacobianCache(x, fdtype, colorvec=cvd, sparsity=Jd)
+                cache.pattern_check = check
+                for _ in range(3):
+                    fd.finite_difference_jacobian_b(Jd, f, x, cache)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fd.finite_difference_jacobian_b(Jd, f, x, cache)
+                t_enq = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                t_all = time.perf_counter() - t0
+                pl = cache.last_plan
+                pl.enable_timing(3)
+                for _ in range(reps):
+                    fd.finite_difference_jacobian_b(Jd, f, x, cache)
+                torch.cuda.synchronize()
+                gs = pl.timing_samples("total")
+                pl.enable_timing(0)
+                return {"ms": t_all / reps * 1e3, "host_enqueue_ms": t_enq / reps * 1e3,
+                        "gpu_median_ms": float(np.median(gs)) if gs else None,
+                        "bit_identical_to_timed_result": bool(torch.equal(Jd.nzval, timed_result)),
+                        "lazy_store": int(pl.info(fd.lib.INFO_LAZY_STORE))}
+
+            J_host = fd.SparseMatrixCSC(N, N, cp_s, rv_s, out_d)
+            res_d = {"host_pattern_identity": measure(J_host, colors, "identity")}
+            out_d.fill_(float("nan"))
+            res_d["host_pattern_content_check"] = measure(J_host, colors, "content")
+            out_d.fill_(float("nan"))
+            J_dev = fd.DevicePatternCSC(N, N, torch.as_tensor(cp_s.astype(np.int32), device=dev), torch.as_tensor(rv_s.astype(np.int32), device=dev), out_d)
+            cv_dev = torch.as_tensor(np.asarray(colors).astype(np.int32), device=dev)
+            res_d["device_pattern_identity"] = measure(J_dev, cv_dev, "identity")
+            out_d.fill_(float("nan"))
+            res_d["device_pattern_content_check"] = measure(J_dev, cv_dev, "content")
+            # the same loop on the pre-bound callable (what `value` times): the yardstick of the lookup's cost
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                enqueue()
+            torch.cuda.synchronize()
+            res_d["bound_call_loop_ms"] = (time.perf_counter() - t0) / reps * 1e3
+            dropin = {"what": "fd.finite_difference_jacobian_b(J, f, x, cache): cache -> plan lookup (identity key) [-> fd_plan_matches] -> "
+                              "fd_jacobian_async; ms = wall-clock of %d back-to-back calls / %d (synchronised at the end), host_enqueue_ms = the "
+                              "host's share, gpu_median_ms = HIP-event span of the call" % (reps, reps),
+                      "ms": res_d["host_pattern_identity"]["ms"], "median_ms_per_step": None,
+                      "variants": res_d}
+            del J_host, J_dev, cv_dev, out_d, cp_s, rv_s
+        except Exception as e:
+            dropin = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the compiled client of the same sequence (what a Julia ccall costs: no interpreter in the loop)
+        try:
+            import subprocess
+            import tempfile
+            exe = os.path.join(tempfile.gettempdir(), "fdjac_c_abi_clients_%d" % os.getpid())
+            libdir = os.path.join(ROOT, "finitediff.jl_amd", "lib")
+            subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_clients.c"), "-o", exe,
+                                   "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            cp = subprocess.run([exe, "dropin", str(N), "20"], capture_output=True, text=True, timeout=600)
+            os.unlink(exe)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("dropin N=")]
+            if dropin is None or "error" in dropin:
+                dropin = dropin or {}
+            dropin["c_client"] = {"what": "examples/c_abi_clients.c::client_dropin, same sequence compiled (rc %d)" % cp.returncode, "lines": lines}
+        except Exception as e:
+            if dropin is not None:
+                dropin["c_client"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -609,6 +741,12 @@ def main():
         traffic_src = pmc_src if pmc else "floor: the bytes this kernel must move (no committed PMC pass matches this run)"
         achieved = traffic / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         survey_gbps = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        if dropin and "ms" in dropin and call_med:
+            dropin["median_ms_per_step"] = call_med
+            dropin["ratio_to_median_ms_per_step"] = dropin["ms"] / call_med
+            for v in dropin.get("variants", {}).values():
+                if isinstance(v, dict) and "ms" in v:
+                    v["ratio_to_median_ms_per_step"] = v["ms"] / call_med
         res = {
             "metric": "Jacobian columns/s (coloured sparse finite-difference Jacobian; headline config N=10^7 tridiagonal forward)",
             "value": N / (ms_step * 1e-3),
@@ -661,6 +799,8 @@ def main():
                             "this kernel does not perform -- an equivalent-work rate, NOT a bandwidth (it can exceed the peak)"},
             },
             "handover_path": handover,
+            "opaque_f_path": opaque,
+            "dropin_call": dropin,
             "stages_ms": stages,
             "whole_call": {"gpu_ms": tot_ms, "hbm_bytes_model": bytes_call_model * n_local,
                            "gbps": bytes_call_model * n_local / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,

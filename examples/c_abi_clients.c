@@ -10,7 +10,7 @@
  *
  *   gcc -O2 -Iinclude examples/c_abi_clients.c -o c_abi_clients -Lfinitediff.jl_amd/lib -lfdjac \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/finitediff.jl_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   ./c_abi_clients all        # or: csc csc_device csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host complex_x resize
+ *   ./c_abi_clients all        # or: csc csc_device csc_dense coo_dense entries dense tridiagonal banded blockbanded csc_f32 jvp solve host complex_x resize dropin [N reps]
  */
 #include <math.h>
 #include <stdint.h>
@@ -647,7 +647,7 @@ static int client_complex_x(int fdtype)
 }
 
 /* shim: Base.resize!(cache, i) (src/jacobians.jl:655-661) followed by the next finite_difference_jacobian!: the shim's plans are
-   keyed on the CONTENT of (J's pattern, sparsity, colorvec, fdtype), so the resized cache (colorvec = 1:i, new lengths) simply
+   keyed on the identity (address, LENGTH) of the arrays plus J's shape and fdtype, so the resized cache (colorvec = 1:i, new lengths) simply
    compiles a new plan and the old one is released -- plan, call, destroy, plan for the new size, call.  Dense arm, as resize!
    sets colorvec = 1:i. */
 static int client_resize(void)
@@ -681,6 +681,145 @@ static int client_resize(void)
     return bad;
 }
 
+/* shim: plan_for(cache, J, x, f, sparsity, colorvec, fdtype) + the drop-in method -- the cache -> plan lookup EVERY call goes
+   through, then fd_jacobian_async.  The lookup is O(1): the key is the identity (address + length) of colptr / rowval / colorvec,
+   J's shape, the fdtype and f; a changed key compiles a new plan.  An in-place edit of colorvec does not change the key: the
+   caller says invalidate!(cache) -- or runs with PATTERN_CHECK[] = :content, where plans carry fingerprints
+   (FD_PLAN_FINGERPRINT) and every call asks fd_plan_matches (content compared by the library: host threads for host arrays,
+   kernels for device arrays).  Both policies are executed here, on a host-resident (Int64) and on a device-resident (Int32)
+   pattern, and the per-call cost of the lookup is measured against calling fd_jacobian_async on a plan held in a variable. */
+#include <time.h>
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+typedef struct shim_cache {       /* PLANS[cache]: the plan and the key it was compiled for */
+    fd_plan *plan;
+    const void *colptr, *rowval, *colorvec, *fctx;
+    int64_t len_colptr, len_rowval, len_colorvec, M, N;
+    int fdtype, content, device;
+    int plans_built;
+} shim_cache;
+static int dropin_call(shim_cache *c, int64_t M, int64_t N, const void *colptr, int64_t len_cp, const void *rowval, int64_t len_rv,
+                       int idx_bytes, const void *colorvec, int64_t len_cv, int color_bytes, int device_pattern, int fdtype,
+                       fd_f_launch f, void *fctx, const void *xd, void *nzd)
+{
+    int hit = c->plan && c->colptr == colptr && c->rowval == rowval && c->colorvec == colorvec && c->len_colptr == len_cp &&
+              c->len_rowval == len_rv && c->len_colorvec == len_cv && c->M == M && c->N == N && c->fdtype == fdtype && c->fctx == fctx &&
+              c->device == device_pattern;
+    if (hit && c->content) {      /* PATTERN_CHECK[] = :content */
+        fd_pattern_arrays pa;
+        memset(&pa, 0, sizeof pa);
+        pa.idx_a = colptr; pa.len_a = len_cp; pa.idx_b = rowval; pa.len_b = len_rv; pa.colorvec = colorvec; pa.len_color = len_cv;
+        pa.idx_bytes = idx_bytes; pa.idx_base = 1; pa.color_bytes = color_bytes; pa.memkind = device_pattern ? FD_DEVICE : FD_HOST;
+        int m = 0;
+        CHECK(fd_plan_matches(c->plan, &pa, &m));
+        hit = m;
+    }
+    if (!hit) {
+        if (c->plan) CHECK(fd_plan_destroy(c->plan));     /* (the shim: the old Plan's finalizer) */
+        c->plan = NULL;
+        fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = c->content ? FD_PLAN_FINGERPRINT : 0;
+        if (device_pattern) CHECK(fd_plan_create_csc_device(g_ctx, M, N, colptr, rowval, idx_bytes, 1, colorvec, color_bytes, &o, &c->plan));
+        else CHECK(fd_plan_create_csc(g_ctx, M, N, colptr, rowval, idx_bytes, 1, colorvec, color_bytes, &o, &c->plan));
+        CHECK(install_lazy(c->plan, fctx));
+        c->colptr = colptr; c->rowval = rowval; c->colorvec = colorvec; c->fctx = fctx; c->len_colptr = len_cp; c->len_rowval = len_rv;
+        c->len_colorvec = len_cv; c->M = M; c->N = N; c->fdtype = fdtype; c->device = device_pattern;
+        ++c->plans_built;
+    }
+    void *outs[3] = {nzd, NULL, NULL};
+    return fd_jacobian_async(c->plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs);
+}
+static void dropin_invalidate(shim_cache *c)    /* invalidate!(cache) */
+{
+    if (c->plan) fd_plan_destroy(c->plan);
+    c->plan = NULL;
+}
+static int client_dropin(int64_t N, int reps)
+{
+    int bad = 0;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    int32_t *cp32 = malloc(sizeof(int32_t) * (size_t)(N + 1)), *rv32 = malloc(sizeof(int32_t) * (size_t)nnz), *cv32 = malloc(sizeof(int32_t) * (size_t)N);
+    for (int64_t j = 0; j <= N; ++j) cp32[j] = (int32_t)colptr[j];
+    for (int64_t p = 0; p < nnz; ++p) rv32[p] = (int32_t)rowval[p];
+    for (int64_t j = 0; j < N; ++j) cv32[j] = (int32_t)colors[j];
+    void *cpd = to_dev(cp32, sizeof(int32_t) * (size_t)(N + 1)), *rvd = to_dev(rv32, sizeof(int32_t) * (size_t)nnz), *cvd = to_dev(cv32, sizeof(int32_t) * (size_t)N);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)nnz);
+    double *nz = malloc(sizeof(double) * (size_t)nnz);
+    fd_f_launch f; void *fctx;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    const int64_t jz = N / 2;     /* the column whose colour the in-place edit removes: its stored values become 0 (fill_matrix!) */
+    for (int device = 0; device < 2; ++device)
+        for (int content = 0; content < 2; ++content) {
+            shim_cache c;
+            memset(&c, 0, sizeof c);
+            c.content = content;
+            const void *cp = device ? cpd : (void *)colptr, *rv = device ? rvd : (void *)rowval, *cv = device ? cvd : (void *)colors;
+            const int ib = device ? 4 : 8;
+#define DROPIN() dropin_call(&c, N, N, cp, N + 1, rv, nnz, ib, cv, N, ib, device, FD_FORWARD, f, fctx, xd, nzd)
+            CHECK(DROPIN());
+            CHECK(DROPIN());                                   /* the second call finds the plan */
+            CHECK(fd_ctx_synchronize(g_ctx));
+            int ok = c.plans_built == 1;
+            from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+            double worst = 0;
+            for (int64_t j = 0; j < N; ++j)
+                for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+                    const double d = fabs(nz[p] - tridiag_nl_J(x, N, rowval[p] - 1, j));
+                    if (!(d <= worst)) worst = d;
+                }
+            ok = ok && worst <= 2e-6;
+            /* in-place edit of colorvec: column jz loses its colour */
+            if (device) { const int32_t zero = 0; hipMemcpy((char *)cvd + 4 * (size_t)jz, &zero, 4, 1); }
+            else colors[jz] = 0;
+            CHECK(DROPIN());
+            CHECK(fd_ctx_synchronize(g_ctx));
+            from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+            const double djz = nz[colptr[jz] - 1 + 1];         /* the diagonal entry of column jz */
+            if (content) ok = ok && c.plans_built == 2 && djz == 0.0;      /* the library saw the edit */
+            else {
+                ok = ok && c.plans_built == 1 && djz != 0.0;               /* identity: the snapshot stands ... */
+                dropin_invalidate(&c);                                     /* ... until invalidate!(cache) */
+                CHECK(DROPIN());
+                CHECK(fd_ctx_synchronize(g_ctx));
+                from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+                ok = ok && c.plans_built == 2 && nz[colptr[jz] - 1 + 1] == 0.0;
+            }
+            /* restore the colouring (another in-place edit), then time the lookup */
+            if (device) { const int32_t v = (int32_t)(jz % 3 + 1); hipMemcpy((char *)cvd + 4 * (size_t)jz, &v, 4, 1); }
+            else colors[jz] = jz % 3 + 1;
+            dropin_invalidate(&c);
+            for (int k = 0; k < 3; ++k) CHECK(DROPIN());
+            CHECK(fd_ctx_synchronize(g_ctx));
+            const int built = c.plans_built;
+            double t0 = now_ms();
+            for (int k = 0; k < reps; ++k) CHECK(DROPIN());
+            CHECK(fd_ctx_synchronize(g_ctx));
+            const double ms_dropin = (now_ms() - t0) / reps;
+            void *outs[3] = {nzd, NULL, NULL};
+            t0 = now_ms();
+            for (int k = 0; k < reps; ++k) CHECK(fd_jacobian_async(c.plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+            CHECK(fd_ctx_synchronize(g_ctx));
+            const double ms_direct = (now_ms() - t0) / reps;
+            ok = ok && c.plans_built == built;
+            printf("dropin N=%lld pattern=%s check=%s  ms_per_call: dropin %.4f direct %.4f ratio %.3f  plans_built %d  %s\n", (long long)N,
+                   device ? "device(Int32)" : "host(Int64)", content ? "content" : "identity", ms_dropin, ms_direct, ms_dropin / ms_direct,
+                   c.plans_built, ok ? "ok" : "FAILED");
+            bad |= ok ? 0 : 3;
+            dropin_invalidate(&c);
+#undef DROPIN
+        }
+    CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); hipFree(cpd); hipFree(rvd); hipFree(cvd);
+    free(nz); free(x); free(colptr); free(rowval); free(colors); free(cp32); free(rv32); free(cv32);
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     const char *which = argc > 1 ? argv[1] : "all";
@@ -708,6 +847,7 @@ int main(int argc, char **argv)
     RUN("host", client_host())
     RUN("complex_x", client_complex_x(FD_FORWARD) | client_complex_x(FD_CENTRAL))
     RUN("resize", client_resize())
+    RUN("dropin", client_dropin(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     CHECK(fd_ctx_destroy(g_ctx));
     hipStreamDestroy(g_stream);
     if (!ran) { fprintf(stderr, "unknown client %s\n", which); return 2; }

@@ -129,6 +129,18 @@ class SparseMatrixCSC:
                                                                                    self.rowval.size))
 
 
+class DevicePatternCSC:
+    """A CSC Jacobian whose PATTERN lives on the device as well (the shim's `DevicePatternCSC`: colPtr / rowVal of a
+    ROCSparseMatrixCSC; int32 or int64 torch CUDA tensors, `idx_base`-based) -- the plan is compiled by kernels
+    (fd_plan_create_csc_device), nothing crosses PCIe; `colorvec` must be a CUDA tensor too.  It is its own sparsity pattern."""
+
+    def __init__(self, m, n, colptr, rowval, nzval=None, idx_base=1):
+        self.m, self.n, self.colptr, self.rowval, self.nzval, self.idx_base = int(m), int(n), colptr, rowval, nzval, int(idx_base)
+
+    def size(self):
+        return (self.m, self.n)
+
+
 class Tridiagonal:
     """LinearAlgebra.Tridiagonal: dl (n-1), d (n), du (n-1)."""
 
@@ -478,6 +490,50 @@ class Plan:
         _l.check(self.Lt.fd_plan_checksum(self.handle, C.byref(v)))
         return v.value
 
+    def matches(self, idx_a=None, idx_b=None, colorvec=None, idx_base=1):
+        """fd_plan_matches: do these arrays still hold the content the plan was compiled from?  `idx_a` / `idx_b` are colptr /
+        rowval (CSC plans) or rows_index / cols_index (index-list plans), `colorvec` the colours; numpy arrays (host threads) or
+        torch CUDA tensors (kernels), int32 or int64, all on the same side; None = not compared.  Needs a plan created with
+        ``fingerprint=True`` (FD_PLAN_FINGERPRINT)."""
+        pa = _l.PatternArrays()
+        kinds = set()
+        keep = []
+        for name, a, lenf, ptrf in (("idx_a", idx_a, "len_a", "idx_a"), ("idx_b", idx_b, "len_b", "idx_b"),
+                                    ("colorvec", colorvec, "len_color", "colorvec")):
+            if a is None:
+                continue
+            if _is_torch(a):
+                import torch
+                if not (a.is_contiguous() and a.dtype in (torch.int32, torch.int64)):
+                    raise TypeError("%s must be a contiguous int32 / int64 array" % name)
+                ptr, n, nb, kind = a.data_ptr(), a.numel(), a.element_size(), (_l.DEVICE if a.is_cuda else _l.HOST)
+            else:
+                a = np.ascontiguousarray(a)
+                if a.dtype not in (np.int32, np.int64):
+                    a = a.astype(np.int64)
+                ptr, n, nb, kind = a.ctypes.data, a.size, a.itemsize, _l.HOST
+            keep.append(a)
+            kinds.add(kind)
+            setattr(pa, ptrf, ptr)
+            setattr(pa, lenf, n)
+            if name == "colorvec":
+                pa.color_bytes = nb
+            else:
+                if pa.idx_bytes not in (0, nb):
+                    raise TypeError("idx_a and idx_b must have the same integer type")
+                pa.idx_bytes = nb
+        if len(kinds) > 1:
+            raise ValueError("the arrays must all be host or all be device arrays")
+        pa.memkind = kinds.pop() if kinds else _l.HOST
+        pa.idx_base = int(idx_base)
+        if pa.idx_bytes == 0:
+            pa.idx_bytes = 8
+        if pa.color_bytes == 0:
+            pa.color_bytes = 8
+        m = C.c_int(0)
+        _l.check(self.Lt.fd_plan_matches(self.handle, C.byref(pa), C.byref(m)))
+        return bool(m.value)
+
     @property
     def ncolors(self):
         return self.info(_l.INFO_NCOLORS)
@@ -646,10 +702,10 @@ class Plan:
         return call
 
 
-def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False):
+def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False, fingerprint=False):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
-    o.flags = _l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0
+    o.flags = (_l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0) | (_l.PLAN_FINGERPRINT if fingerprint else 0)
     if col_window is not None:
         o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
     if x_window is not None:
@@ -665,16 +721,23 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False):
+              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
     ctx = ctx or Context.default()
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
-    o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous)
+    o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous, fingerprint)
     if complex_x:      # returntype <: Complex with forward / central differences: the library lowers it (FD_PLAN_COMPLEX_X)
         o.flags |= _l.PLAN_COMPLEX_X
+    if isinstance(J, DevicePatternCSC):
+        if not (sparsity is J or sparsity is None):
+            raise ValueError("a DevicePatternCSC is its own sparsity pattern")
+        if complex_x:
+            raise NotImplementedError("complex-valued x with a device-resident pattern")
+        return make_plan_csc_device(J.m, J.n, J.colptr, J.rowval, colorvec, fdtype, ctx, col_window, x_window, J.idx_base, dtype,
+                                    fingerprint=fingerprint)
     h = C.c_void_p()
     cv = _i64(colorvec)
     if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):
@@ -732,7 +795,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
 
 
 def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_window=None, x_window=None,
-                         idx_base=1, dtype=np.float64):
+                         idx_base=1, dtype=np.float64, fingerprint=False):
     """fd_plan_create_csc_device: the common-pattern CSC plan from a pattern that already lives on the device --
     `colptr`, `rowval`, `colorvec` are torch CUDA tensors (int32 or int64; colptr / rowval `idx_base`-based, colours 1..C).
     The plan is compiled by kernels; nothing crosses PCIe."""
@@ -740,7 +803,7 @@ def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_w
     ctx = ctx or Context.default()
     L = _l.typed(ctx.L, dtype)
     fdtype = _norm_fdtype(fdtype)
-    o = _opts(fdtype, col_window, x_window)
+    o = _opts(fdtype, col_window, x_window, fingerprint=fingerprint)
     for t, what in ((colptr, "colptr"), (rowval, "rowval"), (colorvec, "colorvec")):
         if not (_is_torch(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.int32, torch.int64)):
             raise TypeError("%s must be a contiguous int32 / int64 CUDA tensor" % what)
@@ -773,7 +836,7 @@ def _csc_positions(J, rows, cols):
 
 
 def _outs_of(J):
-    if isinstance(J, SparseMatrixCSC):
+    if isinstance(J, (SparseMatrixCSC, DevicePatternCSC)):
         return [J.nzval]
     if isinstance(J, Tridiagonal):
         return [J.dl, J.d, J.du]
@@ -825,19 +888,68 @@ class JacobianCache:
         self.sparsity = sparsity
         self.dtype = _dtype_of(x1) or _complex_base(x1) or np.dtype(np.float64)      # (real) eltype: selects the fd_* / fd32_* instantiation
         self._plans = {}
+        self._bound = {}
+        self.lazy = True       # built-in f! families: install their lazy-point launcher on new plans (the shim's install_lazy!)
+        # How a cached call finds out that `colorvec` / `sparsity` changed (the reference re-reads both on every call,
+        # src/jacobians.jl:512-513):  "identity" (default) -- O(1): the plan is keyed on the identity (object, data pointer,
+        # length) of the arrays; a new array object / a resize makes a new plan, an IN-PLACE edit needs `invalidate()`;
+        # "content" -- identity, then fd_plan_matches compares the arrays' content with what the plan was compiled from
+        # (kernels for device arrays, host threads for host arrays: the reference's semantics, at the reference's O(N + nnz)).
+        self.pattern_check = "identity"
 
-    def _plan_for(self, J, sparsity, colorvec, ctx):
-        key = (type(J).__name__, id(sparsity), id(colorvec), self.fdtype, tuple(getattr(J, "shape", ())))
+    def invalidate(self):
+        """Forget the compiled plans: the next call re-reads `colorvec` / `sparsity` (after an in-place edit of either)."""
+        self._plans.clear()
+        self._bound.clear()
+
+    @staticmethod
+    def _ident(a):
+        """O(1) identity of a pattern / colour holder: which object, where its data lies, how long it is."""
+        if a is None:
+            return None
+        if isinstance(a, (SparseMatrixCSC, DevicePatternCSC)):
+            return (id(a), JacobianCache._ident(a.colptr), JacobianCache._ident(a.rowval), a.size())
+        if isinstance(a, np.ndarray):
+            return (id(a), a.ctypes.data, a.size)
+        if _is_torch(a):
+            return (id(a), a.data_ptr(), a.numel())
+        if isinstance(a, range):
+            return ("range", a.start, a.stop, a.step)
+        return (id(a),)
+
+    def _plan_for(self, J, sparsity, colorvec, ctx, f=None):
+        """The plan of (J's type and shape, sparsity, colorvec, fdtype) -- the sequence of the Julia shim's `plan_for`
+        (julia/FiniteDiffMI355X.jl) and of examples/c_abi_clients.c::client_dropin: an O(1) identity lookup, an optional content
+        check, a new plan (+ the built-in family's lazy launcher, as `install_lazy!` does) only when something changed."""
+        jshape = tuple(J.shape) if (isinstance(J, np.ndarray) or _is_torch(J)) else tuple(J.size())
+        key = (type(J).__name__, jshape, self.fdtype, self._ident(sparsity), self._ident(colorvec), id(f) if self.lazy else None)
+        content = self.pattern_check == "content"
         ent = self._plans.get(key)
-        if ent is None or ent[1] is not sparsity or ent[2] is not colorvec:
-            ent = (make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx), sparsity, colorvec)
-            self._plans[key] = ent
-        return ent[0]
+        if ent is not None and ent[3] == content:
+            if not content or self._content_matches(ent[0], sparsity, colorvec):
+                return ent[0]
+        self._bound.clear()
+        if len(self._plans) >= 8:
+            self._plans.clear()
+        plan = make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx, fingerprint=content)
+        if self.lazy and isinstance(f, BuiltinF) and not self.cx and f.lazy_fn is not None:
+            plan.set_lazy(f)          # built-in families: f! perturbs while loading / stores the Jacobian itself (shim: install_lazy!)
+        self._plans[key] = (plan, sparsity, colorvec, content)     # (the arrays are kept alive: their ids stay theirs)
+        return plan
+
+    @staticmethod
+    def _content_matches(plan, sparsity, colorvec):
+        cv = colorvec if (_is_torch(colorvec) or isinstance(colorvec, np.ndarray)) else _i64(colorvec)
+        if isinstance(sparsity, DevicePatternCSC):
+            return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=sparsity.idx_base)
+        if isinstance(sparsity, SparseMatrixCSC):
+            return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=1)
+        return plan.matches(None, None, cv)      # structural patterns (Tridiagonal, BandedMatrix, ...): the colours
 
 
 def _has_sparsestruct(J):
     """ArrayInterface.has_sparsestruct for the holders above."""
-    return isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix))
+    return isinstance(J, (SparseMatrixCSC, DevicePatternCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix))
 
 
 def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=np.float64, f_in=None, *,
@@ -870,19 +982,38 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
     if sparsity is None and _has_sparsestruct(J):
         sparsity = J
     # relstep / absstep None -> default_relstep(fdtype, eltype(x)) and absstep = relstep, resolved by the library
-    plan = cache._plan_for(J, sparsity, colorvec, ctx or getattr(f, "ctx", None))
+    plan = cache._plan_for(J, sparsity, colorvec, ctx or getattr(f, "ctx", None), f)
+    cache.last_plan = plan
     outs = _outs_of(J)
+    fin = f_in if cache.fdtype == "forward" else None
+    # Device arrays: the call only ENQUEUES on the context's stream (fd_jacobian_async, as the shim's AMDGPU methods do) through a
+    # callable whose pointers were resolved once per (plan, f, arrays, steps) -- one foreign call per Jacobian.
+    if not plan.cx and _is_torch(x) and x.is_cuda and all(_is_torch(o) and o.is_cuda for o in outs) and \
+            (fin is None or (_is_torch(fin) and fin.is_cuda)):
+        bkey = (id(plan), id(f), x.data_ptr(), tuple(o.data_ptr() for o in outs), None if fin is None else fin.data_ptr(),
+                relstep, absstep, dir)
+        call = cache._bound.get(bkey)
+        if call is None:
+            try:
+                call = plan.bind(f, x, outs, fin, relstep, absstep, dir)
+            except (TypeError, ValueError):
+                call = None                 # (non-contiguous / mismatched arrays: the general path below reports or stages them)
+            if call is not None:
+                if len(cache._bound) >= 16:
+                    cache._bound.clear()
+                cache._bound[bkey] = call
+        if call is not None:
+            call()
+            return None
     staged = None
-    if not isinstance(J, (SparseMatrixCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
+    if not isinstance(J, (SparseMatrixCSC, DevicePatternCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
         # dense J must be column-major for the library; stage a C-order numpy array
         if isinstance(J, np.ndarray) and not J.flags.f_contiguous:
             staged = np.zeros(J.shape, dtype=J.dtype, order="F")
             outs = [staged]
-    plan.jacobian(f, x, outs, f_in=f_in if cache.fdtype == "forward" else None, relstep=relstep, absstep=absstep,
-                  dir=dir)
+    plan.jacobian(f, x, outs, f_in=fin, relstep=relstep, absstep=absstep, dir=dir)
     if staged is not None:
         J[...] = staged
-    cache.last_plan = plan
     return None
 
 

@@ -110,7 +110,7 @@ struct LoweredScope {
     LoweredScope() { t_lowered_cx = true; }
     ~LoweredScope() { t_lowered_cx = false; }
 };
-constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X;
+constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT;
 
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {
@@ -175,6 +175,26 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
         p->own_c1 = opts->color_end;
     }
     return FD_OK;
+}
+
+// FD_PLAN_FINGERPRINT: after a successful build, record the content fingerprints of the CALLER's arrays (fdjac_match.hip) -- at
+// the public entry points, so that a lowered (complex-valued x) plan is fingerprinted in the caller's units, not the lowered ones.
+static int finish_fingerprint(int rc, fd_plan **out, const fd_plan_opts *opts, int idx_kind, const void *a, int64_t len_a, const void *b,
+                              int64_t len_b, int idx_bytes, int idx_base, const void *colorvec, int color_bytes, int64_t len_color,
+                              int memkind, int64_t N)
+{
+    if (rc || !opts || !(opts->flags & FD_PLAN_FINGERPRINT) || !out || !*out) return rc;
+    fd_pattern_arrays src;
+    memset(&src, 0, sizeof src);
+    src.idx_a = a; src.len_a = len_a; src.idx_b = b; src.len_b = len_b; src.colorvec = colorvec; src.len_color = len_color;
+    src.idx_bytes = idx_bytes ? idx_bytes : 8; src.idx_base = idx_base; src.color_bytes = color_bytes; src.memkind = memkind;
+    const bool all = opts->col_begin == 0 && opts->col_end == 0;
+    rc = plan_record_fingerprint(*out, idx_kind, &src, all ? 0 : opts->col_begin, all ? N : opts->col_end);
+    if (rc) {
+        fd_plan_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 // Scratch for the batched perturbed points / f! values and the epsilon reduction.
@@ -1185,7 +1205,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -1310,7 +1330,7 @@ static int lower_colors_opts(int64_t N, const void *colorvec, int color_bytes, c
     for (int64_t j = 0; j < N; ++j) L.colors[(size_t)(2 * j)] = load_idx(colorvec, color_bytes, j);   // (odd = imaginary parts: colour 0, never perturbed)
     L.opts = *opts;
     FD_REQUIRE((opts->flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x", (unsigned)(opts->flags & ~kPlanKnownFlags));
-    L.opts.flags = opts->flags & ~FD_PLAN_COMPLEX_X;
+    L.opts.flags = opts->flags & ~(FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT);   // (fingerprints: of the caller's arrays, by the public entry point)
     L.opts.col_begin *= 2; L.opts.col_end *= 2; L.opts.x_begin *= 2; L.opts.x_end *= 2;
     return FD_OK;
 }
@@ -1377,14 +1397,16 @@ int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, co
                        int idx_base, const void *colorvec, int color_bytes, const fd_plan_opts *opts,
                        fd_plan **out)
 {
-    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
-        return lowered_csc(ctx, 0, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
-    return csc_common(ctx, K_CSC, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    const int rc = (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+                       ? lowered_csc(ctx, 0, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out)
+                       : csc_common(ctx, K_CSC, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 1, colptr, N + 1, rowval, std::numeric_limits<int64_t>::max(), idx_bytes, idx_base, colorvec,
+                              color_bytes, N, FD_HOST, N);
 }
 
-int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
-                              int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
-                              const fd_plan_opts *opts, fd_plan **out)
+static int csc_device_impl(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
+                           int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
+                           const fd_plan_opts *opts, fd_plan **out)
 {
     FD_REQUIRE(colptr_dev && rowval_dev && colorvec_dev, FD_ERR_ARG, "NULL pattern array");
     FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
@@ -1486,9 +1508,11 @@ int fd_plan_create_csc_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *colp
         set_error("column windows are not supported for dense J");
         return FD_ERR_UNSUPPORTED;
     }
-    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
-        return lowered_csc(ctx, 1, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
-    return csc_common(ctx, K_CSC_DENSE, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    const int rc = (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+                       ? lowered_csc(ctx, 1, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out)
+                       : csc_common(ctx, K_CSC_DENSE, M, N, colptr, rowval, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 1, colptr, N + 1, rowval, std::numeric_limits<int64_t>::max(), idx_bytes, idx_base, colorvec,
+                              color_bytes, N, FD_HOST, N);
 }
 
 static int entries_common(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index,
@@ -1536,10 +1560,10 @@ int fd_plan_create_coo_dense(fd_ctx *ctx, int64_t M, int64_t N, const void *rows
                              int64_t nnz, int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                              const fd_plan_opts *opts, fd_plan **out)
 {
-    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
-        return lowered_coo(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
-    return entries_common(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec,
-                          color_bytes, opts, out);
+    const int rc = (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+                       ? lowered_coo(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec, color_bytes, opts, out)
+                       : entries_common(ctx, M, N, rows_index, cols_index, nullptr, nnz, M * N, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 2, rows_index, nnz, cols_index, nnz, idx_bytes, idx_base, colorvec, color_bytes, N, FD_HOST, N);
 }
 
 int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index, const void *cols_index,
@@ -1547,14 +1571,13 @@ int fd_plan_create_entries(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_i
                            const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
     FD_REQUIRE(dest || nnz == 0, FD_ERR_ARG, "dest is NULL");
-    if (opts && (opts->flags & FD_PLAN_COMPLEX_X))
-        return lowered_coo(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
-    return entries_common(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec,
-                          color_bytes, opts, out);
+    const int rc = (opts && (opts->flags & FD_PLAN_COMPLEX_X))
+                       ? lowered_coo(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec, color_bytes, opts, out)
+                       : entries_common(ctx, M, N, rows_index, cols_index, dest, nnz, out_len, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 2, rows_index, nnz, cols_index, nnz, idx_bytes, idx_base, colorvec, color_bytes, N, FD_HOST, N);
 }
 
-int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
-                               const fd_plan_opts *opts, fd_plan **out)
+static int tridiagonal_impl(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
     int rc = new_plan(ctx, K_TRIDIAG, N, N, out);
     if (rc) return rc;
@@ -1593,8 +1616,8 @@ int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int
     return FD_OK;
 }
 
-int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, const void *colorvec,
-                          int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+static int banded_impl(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, const void *colorvec,
+                       int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
     FD_REQUIRE(l + u + 1 >= 1 && l > -N && u > -M, FD_ERR_ARG, "bad bandwidths (%lld,%lld)", (long long)l, (long long)u);
     int rc = new_plan(ctx, K_BANDED, M, N, out);
@@ -1667,10 +1690,14 @@ int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const
         FD_REQUIRE(o.fdtype != FD_COMPLEX, FD_ERR_UNSUPPORTED, "fdtype_error: Val(:complex) needs a real returntype (src/jacobians.jl:106)");
         FD_REQUIRE(ncols >= 0 && ncols <= N, FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
         FD_REQUIRE((o.flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x", (unsigned)(o.flags & ~kPlanKnownFlags));
-        o.flags &= ~FD_PLAN_COMPLEX_X;
+        o.flags &= ~(FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT);
         o.col_begin *= 2; o.col_end *= 2; o.x_begin *= 2; o.x_end *= 2;
-        LoweredScope lowered;
-        return fd_plan_create_dense(ctx, 2 * M, 2 * N, ncols, &o, out);
+        int rc;
+        {
+            LoweredScope lowered;
+            rc = fd_plan_create_dense(ctx, 2 * M, 2 * N, ncols, &o, out);
+        }
+        return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, nullptr, 8, 0, FD_HOST, N);
     }
     FD_REQUIRE(ncols >= 0 && ncols <= (t_lowered_cx ? N / 2 : N), FD_ERR_ARG, "ncols = maximum(colorvec) must be in 0..N");
     if (opts && !(opts->col_begin == 0 && opts->col_end == 0) && !(opts->col_begin == 0 && opts->col_end == N)) {
@@ -1694,12 +1721,12 @@ int fd_plan_create_dense(fd_ctx *ctx, int64_t M, int64_t N, int64_t ncols, const
     FD_TRY(alloc_scratch(p, col0));
     p->nouts = 1;
     p->out_len[0] = M * ncols;
-    return FD_OK;
+    return finish_fingerprint(FD_OK, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, nullptr, 8, 0, FD_HOST, N);   // (no arrays: always matches)
 }
 
-int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu,
-                               const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
-                               const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+static int blockbanded_impl(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu,
+                            const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
+                            const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
     FD_REQUIRE(blk_sizes && block_starts && block_strides, FD_ERR_ARG, "NULL block layout array");
     FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
@@ -1794,6 +1821,39 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
     p->nouts = 1;
     p->out_len[0] = dmax - dmin;
     return FD_OK;
+}
+
+// The remaining public constructors: the implementation above, then (FD_PLAN_FINGERPRINT) the fingerprints of the caller's arrays.
+int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr_dev, const void *rowval_dev,
+                              int idx_bytes, int idx_base, const void *colorvec_dev, int color_bytes,
+                              const fd_plan_opts *opts, fd_plan **out)
+{
+    const int rc = csc_device_impl(ctx, M, N, colptr_dev, rowval_dev, idx_bytes, idx_base, colorvec_dev, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 1, colptr_dev, N + 1, rowval_dev, std::numeric_limits<int64_t>::max(), idx_bytes, idx_base,
+                              colorvec_dev, color_bytes, N, FD_DEVICE, N);
+}
+
+int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
+                               const fd_plan_opts *opts, fd_plan **out)
+{
+    const int rc = tridiagonal_impl(ctx, N, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
+}
+
+int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, const void *colorvec,
+                          int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    const int rc = banded_impl(ctx, M, N, l, u, colorvec, color_bytes, opts, out);
+    return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
+}
+
+int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu,
+                               const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
+                               const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    const int rc = blockbanded_impl(ctx, nblk, blk_sizes, bl, bu, block_starts, block_strides, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    const int64_t N = (rc == FD_OK && out && *out) ? (*out)->N : 0;
+    return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
 }
 
 int fd_plan_info(const fd_plan *p, int key, int64_t *value)

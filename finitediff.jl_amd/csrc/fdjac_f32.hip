@@ -4,6 +4,7 @@
 #define FDJAC_F32 1
 #include "fdjac_kernels.hip"
 #include "fdjac_api.hip"
+#include "fdjac_match.hip"
 #include "fdjac_builtin_f.hip"
 #include "fdjac_jvp.hip"
 #include "fdjac_solve.hip"

@@ -23,6 +23,7 @@
 #define fd_plan_create_banded fd32_plan_create_banded
 #define fd_plan_create_blockbanded fd32_plan_create_blockbanded
 #define fd_plan_destroy fd32_plan_destroy
+#define fd_plan_matches fd32_plan_matches
 #define fd_plan_info fd32_plan_info
 #define fd_jacobian fd32_jacobian
 #define fd_jacobian_async fd32_jacobian_async
@@ -161,6 +162,15 @@ struct TimedSpan {
 
 }  // namespace fdjac
 
+// content fingerprints of the arrays a plan was compiled from (FD_PLAN_FINGERPRINT, fdjac_match.hip), in the caller's units
+struct fd_fingerprint {
+    bool valid = false;
+    int idx_kind = 0;                 // 0 structural (colours only), 1 CSC (a = colptr, b = rowval), 2 index lists (a = rows, b = cols)
+    uint64_t h_a = 0, h_b = 0, h_color = 0;
+    int64_t len_a = 0, len_b = 0, len_color = 0;   // the arrays' lengths at plan creation
+    int64_t a0 = 0, an = 0, b0 = 0, bn = 0;        // the ranges that were hashed
+};
+
 struct fd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -284,6 +294,9 @@ struct fd_plan {
     int64_t fcalls_last = 0;
     double relstep_last = 0, absstep_last = 0;
 
+    fd_fingerprint fp;                          // FD_PLAN_FINGERPRINT: what fd_plan_matches compares against
+    unsigned long long *d_fp = nullptr;         //   three device words for the fingerprint kernels (allocated on first use)
+
     int timing = 0;   // 0 off, 1 decompress + total, 2 all stages
     std::vector<fdjac::TimedSpan> spans;       // recorded, not yet collected
     std::vector<hipEvent_t> event_pool;
@@ -291,6 +304,10 @@ struct fd_plan {
     int64_t launches[FD_NSTAGES] = {0, 0, 0, 0, 0};
     std::vector<float> samples[FD_NSTAGES];    // the individual spans (fd_plan_get_timing_samples), capped
 };
+
+namespace fdjac {
+int plan_record_fingerprint(fd_plan *p, int idx_kind, const fd_pattern_arrays *src, int64_t col0, int64_t col1);   // fdjac_match.hip
+}
 
 // does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
 static inline bool store_active(const fd_plan *p)

@@ -1,0 +1,229 @@
+// fd_plan_matches: is this plan still the plan of THESE pattern / colour arrays?
+//
+// The reference keeps `colorvec` and `sparsity` BY REFERENCE and re-reads them on every call (src/jacobians.jl:512-513, the
+// O(nnz) pattern comparison of ext/FiniteDiffSparseArraysExt.jl:51-52): an in-place edit takes effect on the next call.  A plan
+// is compiled from a snapshot.  A host shim therefore finds its plan in O(1) by the IDENTITY of the arrays (pointer + length)
+// and offers an explicit invalidate; callers that want the reference's re-read semantics ask the library to compare CONTENT --
+// with kernels when the arrays live on the device (nothing crosses PCIe, nothing is allocated), with host threads otherwise --
+// never by copying the arrays or by a sampled hash.
+//
+// A plan created with FD_PLAN_FINGERPRINT records one 64-bit fingerprint per array it was compiled from:
+//     F(a) = sum_i mix64(value_i + i * K)   (mod 2^64; value_i = a[i0 + i] - index base, widened to 64 bits)
+// -- commutative, so blocks / threads add their partial sums in any order and the result is deterministic; position-dependent,
+// so permuted or shifted contents differ.  fd_plan_matches recomputes the fingerprints of the caller's current arrays over
+// the same ranges (the plan's column window for colptr / rowval) and compares.
+#include "fdjac_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#ifndef FDJAC_F32   /* shared by both instantiations: defined once, by the Float64 build */
+
+namespace {
+
+__host__ __device__ inline uint64_t fp_mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t fp_term(int64_t v, int64_t i)
+{
+    return fp_mix((uint64_t)v + (uint64_t)i * 0xD6E8FEB86659FD93ull);
+}
+
+// one wave reads 64 consecutive elements per step; grid-stride over the array; one atomic per workgroup
+template <typename IT> __global__ void __launch_bounds__(256) k_fingerprint(const IT *__restrict__ a, int64_t i0, int64_t n, int64_t base,
+                                                                              unsigned long long *__restrict__ out)
+{
+    uint64_t s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += fp_term((int64_t)a[i0 + i] - base, i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
+    __shared__ uint64_t s_w[4];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]));
+}
+
+template <typename IT> uint64_t host_range(const IT *a, int64_t i0, int64_t lo, int64_t hi, int64_t base)
+{
+    uint64_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += fp_term((int64_t)a[i0 + i] - base, i);
+    return s;
+}
+
+uint64_t host_fingerprint(const void *a, int bytes, int64_t i0, int64_t n, int64_t base)
+{
+    auto range = [&](int64_t lo, int64_t hi) {
+        return bytes == 8 ? host_range((const int64_t *)a, i0, lo, hi, base) : host_range((const int32_t *)a, i0, lo, hi, base);
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    const int64_t nthr = std::min<int64_t>({(int64_t)std::max(1u, hw), (int64_t)32, n >> 18});   // >= 2^18 elements per thread
+    if (nthr <= 1) return range(0, n);
+    std::vector<uint64_t> part((size_t)nthr, 0);
+    std::vector<std::thread> th;
+    const int64_t per = (n + nthr - 1) / nthr;
+    int64_t done_to = 0;
+    try {
+        for (int64_t k = 0; k < nthr; ++k) {
+            const int64_t lo = k * per, hi = std::min(n, lo + per);
+            if (lo < hi) th.emplace_back([&part, &range, k, lo, hi] { part[(size_t)k] = range(lo, hi); });
+            done_to = hi;
+        }
+    } catch (...) {
+    }
+    uint64_t s = done_to < n ? range(done_to, n) : 0;      // (a thread could not be started: the rest runs here)
+    for (auto &t : th) t.join();
+    for (uint64_t v : part) s += v;
+    return s;
+}
+
+}  // namespace
+
+// Fingerprints of up to three index arrays in one go.  Device arrays: one kernel per array accumulating into acc_dev[k] (3
+// device words owned by the caller), ONE read-back.  Host arrays: host threads.  n[k] == 0 or a[k] == NULL skips array k (0).
+extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n,
+                                  const int64_t *base, int memkind, unsigned long long *acc_dev, uint64_t *out)
+{
+    out[0] = out[1] = out[2] = 0;
+    if (memkind == FD_HOST) {
+        for (int k = 0; k < 3; ++k)
+            if (a[k] && n[k] > 0) out[k] = host_fingerprint(a[k], bytes[k], i0[k], n[k], base[k]);
+        return FD_OK;
+    }
+    hipStream_t s = ctx->stream;
+    FD_HIP_CHECK(hipMemsetAsync(acc_dev, 0, 3 * sizeof(unsigned long long), s));
+    for (int k = 0; k < 3; ++k) {
+        if (!(a[k] && n[k] > 0)) continue;
+        const int64_t blocks = std::min<int64_t>((n[k] + 255) / 256, (int64_t)ctx->num_cus * 8);
+        if (bytes[k] == 8)
+            hipLaunchKernelGGL((k_fingerprint<int64_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const int64_t *)a[k], i0[k], n[k], base[k], acc_dev + k);
+        else
+            hipLaunchKernelGGL((k_fingerprint<int32_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)a[k], i0[k], n[k], base[k], acc_dev + k);
+    }
+    FD_HIP_CHECK(hipGetLastError());
+    unsigned long long h[3] = {0, 0, 0};
+    FD_HIP_CHECK(hipMemcpyAsync(h, acc_dev, sizeof h, hipMemcpyDeviceToHost, s));
+    FD_HIP_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < 3; ++k) out[k] = h[k];
+    return FD_OK;
+}
+
+#else
+extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n,
+                                  const int64_t *base, int memkind, unsigned long long *acc_dev, uint64_t *out);
+#endif
+
+namespace fdjac {
+
+static int read_index(const void *a, int bytes, int64_t i, int memkind, int64_t *v)
+{
+    if (memkind == FD_HOST) {
+        *v = bytes == 8 ? ((const int64_t *)a)[i] : (int64_t)((const int32_t *)a)[i];
+        return FD_OK;
+    }
+    int64_t v64 = 0;
+    int32_t v32 = 0;
+    if (bytes == 8) FD_HIP_CHECK(hipMemcpy(&v64, (const char *)a + 8 * (size_t)i, 8, hipMemcpyDeviceToHost));
+    else FD_HIP_CHECK(hipMemcpy(&v32, (const char *)a + 4 * (size_t)i, 4, hipMemcpyDeviceToHost));
+    *v = bytes == 8 ? v64 : (int64_t)v32;
+    return FD_OK;
+}
+
+// The ranges a plan's fingerprints cover, in the CALLER's units (complex elements for FD_PLAN_COMPLEX_X plans).
+//   idx_kind 1 (CSC): a = colptr[col0 .. col1] (col1 - col0 + 1 values), b = rowval[e0 .. e1) with e = colptr - base
+//   idx_kind 2 (index lists): a = rows_index[0 .. nnz), b = cols_index[0 .. nnz)
+//   idx_kind 0: the pattern is structural (Tridiagonal, BandedMatrix, BlockBandedMatrix, the dense arm): colours only
+static int fingerprint_now(fd_plan *p, const fd_pattern_arrays *now, int64_t a0, int64_t an, uint64_t h[3], int64_t *b0_out, int64_t *bn_out)
+{
+    const fd_fingerprint &fp = p->fp;
+    const void *arr[3] = {fp.idx_kind ? now->idx_a : nullptr, fp.idx_kind ? now->idx_b : nullptr, now->colorvec};
+    int bytes[3] = {now->idx_bytes, now->idx_bytes, now->color_bytes};
+    int64_t i0[3] = {a0, 0, 0}, n[3] = {arr[0] ? an : 0, 0, arr[2] ? now->len_color : 0}, base[3] = {now->idx_base, now->idx_base, 0};
+    int64_t b0 = 0, bn = 0;
+    if (fp.idx_kind == 1 && arr[0]) {
+        int64_t e0 = 0, e1 = 0;
+        int rc = read_index(arr[0], bytes[0], a0, now->memkind, &e0);
+        if (!rc) rc = read_index(arr[0], bytes[0], a0 + an - 1, now->memkind, &e1);
+        if (rc) return rc;
+        b0 = e0 - now->idx_base;
+        bn = e1 - e0;
+        if (b0 < 0 || bn < 0 || b0 + bn > now->len_b) { b0 = 0; bn = -1; }   // cannot be the plan's pattern (reported as a mismatch)
+    } else if (fp.idx_kind == 2) {
+        bn = now->len_b;
+    }
+    i0[1] = b0;
+    n[1] = (arr[1] && bn > 0) ? bn : 0;
+    *b0_out = b0;
+    *bn_out = bn;
+    if (now->memkind == FD_DEVICE && !p->d_fp) FD_HIP_CHECK(hipMalloc((void **)&p->d_fp, 3 * sizeof(unsigned long long)));
+    return fdjac_fingerprint3(p->ctx, arr, bytes, i0, n, base, now->memkind, p->d_fp, h);
+}
+
+static int check_arrays(const fd_pattern_arrays *now)
+{
+    FD_REQUIRE(now != nullptr, FD_ERR_ARG, "the array description is NULL");
+    FD_REQUIRE(now->memkind == FD_HOST || now->memkind == FD_DEVICE, FD_ERR_ARG, "memkind must be FD_HOST or FD_DEVICE");
+    FD_REQUIRE((!now->idx_a && !now->idx_b) || now->idx_bytes == 4 || now->idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(now->idx_base == 0 || now->idx_base == 1, FD_ERR_ARG, "idx_base must be 0 or 1");
+    FD_REQUIRE(!now->colorvec || now->color_bytes == 4 || now->color_bytes == 8, FD_ERR_ARG, "color_bytes must be 4 or 8");
+    FD_REQUIRE(now->len_a >= 0 && now->len_b >= 0 && now->len_color >= 0, FD_ERR_ARG, "negative array length");
+    return FD_OK;
+}
+
+// Called by the public fd_plan_create_* functions after a plan was built from `src` with FD_PLAN_FINGERPRINT set.
+int plan_record_fingerprint(fd_plan *p, int idx_kind, const fd_pattern_arrays *src, int64_t col0, int64_t col1)
+{
+    int rc = check_arrays(src);
+    if (rc) return rc;
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    fd_fingerprint &fp = p->fp;
+    fp = fd_fingerprint();
+    fp.idx_kind = idx_kind;
+    fp.len_a = src->len_a;
+    fp.len_b = src->len_b;
+    fp.len_color = src->len_color;
+    fp.a0 = idx_kind == 1 ? col0 : 0;
+    fp.an = idx_kind == 1 ? col1 - col0 + 1 : (idx_kind == 2 ? src->len_a : 0);
+    uint64_t h[3];
+    rc = fingerprint_now(p, src, fp.a0, fp.an, h, &fp.b0, &fp.bn);
+    if (rc) return rc;
+    FD_REQUIRE(fp.bn >= 0, FD_ERR_SHAPE, "colptr does not describe a range of rowval");
+    fp.h_a = h[0];
+    fp.h_b = h[1];
+    fp.h_color = h[2];
+    fp.valid = true;
+    return FD_OK;
+}
+
+}  // namespace fdjac
+
+extern "C" int fd_plan_matches(fd_plan *p, const fd_pattern_arrays *now, int *matches_out)
+{
+    using namespace fdjac;
+    FD_REQUIRE(p && matches_out, FD_ERR_ARG, "NULL argument");
+    *matches_out = 0;
+    int rc = check_arrays(now);
+    if (rc) return rc;
+    const fd_fingerprint &fp = p->fp;
+    FD_REQUIRE(fp.valid, FD_ERR_UNSUPPORTED, "the plan was created without FD_PLAN_FINGERPRINT");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    // lengths first: a resized array cannot be the plan's (and must not be read with the plan's ranges)
+    if (now->colorvec && now->len_color != fp.len_color) return FD_OK;
+    if (fp.idx_kind && now->idx_a && now->len_a != fp.len_a) return FD_OK;
+    if (fp.idx_kind == 2 && now->idx_b && now->len_b != fp.len_b) return FD_OK;   // (a CSC rowval may be longer than nnz: bounds only)
+    uint64_t h[3];
+    int64_t b0 = 0, bn = 0;
+    rc = fingerprint_now(p, now, fp.a0, fp.an, h, &b0, &bn);
+    if (rc) return rc;
+    bool same = true;
+    if (now->colorvec) same = same && h[2] == fp.h_color;
+    if (fp.idx_kind && now->idx_a) same = same && h[0] == fp.h_a && (fp.idx_kind != 1 || (b0 == fp.b0 && bn == fp.bn));
+    if (fp.idx_kind && now->idx_b && (fp.idx_kind == 2 || now->idx_a)) same = same && h[1] == fp.h_b;
+    *matches_out = same ? 1 : 0;
+    return FD_OK;
+}

@@ -27,7 +27,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
  INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE = 1, 2, 4, 8
-PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X = 1, 2
+PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT = 1, 2, 4
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
@@ -72,7 +72,7 @@ EXPORTS = (
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range",
+    "fd_plan_eps_shard_range", "fd_plan_matches",
 )
 
 
@@ -88,7 +88,7 @@ TYPED = (
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range",
+    "fd_plan_eps_shard_range", "fd_plan_matches",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -114,6 +114,13 @@ class PlanOpts(C.Structure):
     _fields_ = [("fdtype", C.c_int32), ("flags", C.c_int32), ("col_begin", C.c_int64), ("col_end", C.c_int64),
                 ("x_begin", C.c_int64), ("x_end", C.c_int64), ("scratch_bytes", C.c_int64),
                 ("color_begin", C.c_int64), ("color_end", C.c_int64)]
+
+
+class PatternArrays(C.Structure):
+    """fd_pattern_arrays (include/fdjac.h): the arrays fd_plan_matches compares with what a plan was compiled from."""
+    _fields_ = [("idx_a", C.c_void_p), ("len_a", C.c_int64), ("idx_b", C.c_void_p), ("len_b", C.c_int64),
+                ("colorvec", C.c_void_p), ("len_color", C.c_int64), ("idx_bytes", C.c_int32), ("idx_base", C.c_int32),
+                ("color_bytes", C.c_int32), ("memkind", C.c_int32)]
 
 
 class FdError(RuntimeError):
@@ -168,6 +175,7 @@ def load():
     L.fd_plan_create_banded.argtypes = [vp, i64, i64, i64, i64, vp, i32, po, pp]
     L.fd_plan_create_blockbanded.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
     L.fd_plan_destroy.argtypes = [vp]
+    L.fd_plan_matches.argtypes = [vp, C.POINTER(PatternArrays), C.POINTER(i32)]
     L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]
     L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
     L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]

@@ -25,7 +25,7 @@ def test_header_symbols_all_exported(L):
     assert declared == set(fd.lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fd_version() == 300
+    assert L.fd_version() == 400
 
 
 def test_no_gpu_fails_loudly(L):
@@ -241,3 +241,49 @@ def test_user_examples_cross_compile_against_the_public_headers_only(tmp_path):
     for name in ("user_store_client", "user_bb_client"):
         subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + inc, "-c", os.path.join(ROOT, "examples", name + ".c"),
                                "-o", str(tmp_path / (name + ".o"))])
+
+
+def _np_fingerprint(values, base=0):
+    # F(a) = sum_i mix64(value_i + i*K) mod 2^64 (csrc/fdjac_match.hip), restated with numpy uint64 arithmetic
+    with np.errstate(over="ignore"):
+        v = (np.asarray(values, dtype=np.int64) - base).astype(np.uint64)
+        i = np.arange(v.size, dtype=np.uint64)
+        z = v + i * np.uint64(0xD6E8FEB86659FD93)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(np.sum(z, dtype=np.uint64))
+
+
+def test_pattern_fingerprint_host_path(L):
+    # the host side of fd_plan_matches (content fingerprints of index arrays): deterministic, independent of the thread split and of
+    # the index width / base, sensitive to a single in-place edit -- unlike a sampled hash (Julia's hash(::AbstractArray) reads
+    # O(log n) elements of a long array)
+    assert C.sizeof(fd.lib.PatternArrays) == 6 * 8 + 4 * 4
+    fp3 = L.fdjac_fingerprint3
+    fp3.restype = C.c_int
+    vp = C.c_void_p
+
+    def run(arrs, bytes_, i0, n, base):
+        a = (vp * 3)(*[x.ctypes.data if x is not None else None for x in arrs])
+        out = (C.c_uint64 * 3)()
+        rc = fp3(None, a, (C.c_int * 3)(*bytes_), (C.c_int64 * 3)(*i0), (C.c_int64 * 3)(*n), (C.c_int64 * 3)(*base), 0, None, out)
+        assert rc == 0
+        return [int(v) for v in out]
+
+    rng = np.random.default_rng(5)
+    big = rng.integers(1, 1 << 40, size=(1 << 21) + 13, dtype=np.int64)        # long enough for the threaded split
+    small = rng.integers(1, 100, size=1000, dtype=np.int64)
+    h = run([big, small, None], [8, 8, 8], [0, 0, 0], [big.size, small.size, 0], [1, 0, 0])
+    assert h[0] == _np_fingerprint(big, 1) and h[1] == _np_fingerprint(small) and h[2] == 0
+    # the same values as Int32, 0-based: the same fingerprint
+    s32 = (small - 1).astype(np.int32)
+    assert run([s32, None, None], [4, 8, 8], [0, 0, 0], [s32.size, 0, 0], [0, 0, 0])[0] == _np_fingerprint(small, 1)
+    # a window [i0, i0 + n): positions count from the window's start
+    assert run([big, None, None], [8, 8, 8], [77, 0, 0], [5000, 0, 0], [0, 0, 0])[0] == _np_fingerprint(big[77:5077])
+    # one edited element in the middle of a long array changes it; swapping two elements changes it
+    e = big.copy(); e[big.size // 2 + 1] += 1
+    assert run([e, None, None], [8, 8, 8], [0, 0, 0], [e.size, 0, 0], [1, 0, 0])[0] != h[0]
+    w = small.copy(); w[[3, 500]] = w[[500, 3]]
+    assert (w[3] != small[3]) and run([w, None, None], [8, 8, 8], [0, 0, 0], [w.size, 0, 0], [0, 0, 0])[0] != h[1]

@@ -224,7 +224,7 @@ def _build_c_clients(root, tmp_path):
 
 
 @pytest.mark.parametrize("client", ["csc", "csc_device", "csc_dense", "coo_dense", "entries", "dense", "tridiagonal", "banded", "blockbanded",
-                                    "csc_f32", "jvp", "solve", "host", "complex_x", "resize"])
+                                    "csc_f32", "jvp", "solve", "host", "complex_x", "resize", "dropin"])
 def test_c_clients_every_plan_kind(tmp_path, client):
     # examples/c_abi_clients.c: one plain-C client per method of the Julia shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl)
     # -- Julia-layout arrays, DEVICE pointers for x / J's storage, the caller's own stream, fd_jacobian_async -- each
@@ -528,3 +528,154 @@ def test_jacobian_call_captures_into_a_hip_graph(monkeypatch, kind):
             assert not torch.isnan(got).any() and torch.equal(got.view(torch.int64), out.view(torch.int64))
             if scale == 1.0:
                 assert torch.equal(got.view(torch.int64), ref.view(torch.int64))
+
+
+# ---- the drop-in call's cache -> plan lookup (round 4): identity key + invalidate, or the library's content check -------------
+def _tridiag_dropin(N, device_pattern=False):
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    nz = _dev(np.full(rv.size, np.nan))
+    if device_pattern:
+        J = fd.DevicePatternCSC(N, N, torch.as_tensor(cp.astype(np.int32), device="cuda"), torch.as_tensor(rv.astype(np.int32), device="cuda"), nz)
+        colors = torch.as_tensor(colors.astype(np.int32), device="cuda")
+    else:
+        J = fd.SparseMatrixCSC(N, N, cp, rv, nz)
+    return J, colors, cp
+
+
+@pytest.mark.parametrize("device_pattern", [False, True])
+@pytest.mark.parametrize("check", ["identity", "content"])
+def test_dropin_plan_lookup_sees_an_in_place_edit_of_colorvec(check, device_pattern):
+    # The reference re-reads colorvec on every call (src/jacobians.jl:512): removing a column's colour IN PLACE zeroes its stored
+    # values on the next call.  The drop-in lookup is O(1) on identities: with pattern_check = "identity" the compiled plan stands
+    # until cache.invalidate(); with "content" the library compares the arrays with the plan's fingerprints (fd_plan_matches) and
+    # the edit takes effect by itself -- on host arrays (host threads) and on device arrays (kernels) alike.
+    N = 20011
+    J, colors, cp = _tridiag_dropin(N, device_pattern)
+    x = _dev(np.random.default_rng(3).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    cache = fd.JacobianCache(x, "forward", colorvec=colors, sparsity=J)
+    cache.pattern_check = check
+    fd.finite_difference_jacobian_b(J, f, x, cache)
+    p0 = cache.last_plan
+    fd.finite_difference_jacobian_b(J, f, x, cache)
+    assert cache.last_plan is p0                                   # the second call found the plan
+    first = J.nzval.clone()
+    jz = N // 2
+    d = int(cp[jz] - 1 + 1)                                        # the diagonal entry of column jz
+    assert float(first[d]) != 0.0
+    colors[jz] = 0                                                 # in-place edit (numpy array / CUDA tensor)
+    fd.finite_difference_jacobian_b(J, f, x, cache)
+    if check == "content":
+        assert cache.last_plan is not p0 and float(J.nzval[d]) == 0.0
+    else:
+        assert cache.last_plan is p0 and torch.equal(J.nzval, first)   # the snapshot
+        cache.invalidate()
+        fd.finite_difference_jacobian_b(J, f, x, cache)
+        assert cache.last_plan is not p0 and float(J.nzval[d]) == 0.0
+    # every other stored value is what it was
+    keep = torch.ones_like(first, dtype=torch.bool)
+    keep[int(cp[jz] - 1):int(cp[jz + 1] - 1)] = False
+    assert torch.equal(J.nzval[keep], first[keep])
+    # a NEW colour array (same content as the edited one) is a new identity: new plan without being told
+    p1 = cache.last_plan
+    colors2 = colors.clone() if torch.is_tensor(colors) else colors.copy()
+    fd.finite_difference_jacobian_b(J, f, x, cache, colorvec=colors2)
+    assert cache.last_plan is not p1 and float(J.nzval[d]) == 0.0
+
+
+def test_plan_matches_compares_content_not_identity():
+    # fd_plan_matches on host arrays, device arrays, either index width; column windows compare their own slice only
+    N = 50021
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    pat = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    plan = fd.make_plan(pat, pat, colors, "forward", fingerprint=True)
+    assert plan.matches(cp, rv, colors)
+    assert plan.matches(cp.copy(), rv.copy(), colors.copy())                    # other objects, same content
+    assert plan.matches(cp.astype(np.int32), rv.astype(np.int32), colors.astype(np.int32))     # other width, same values
+    dcp, drv, dcv = (torch.as_tensor(a.astype(np.int32), device="cuda") for a in (cp, rv, colors))
+    assert plan.matches(dcp, drv, dcv)                                          # the same content on the device (kernels)
+    assert plan.matches(colorvec=colors) and plan.matches(cp, rv)               # members left out are not compared
+    c2 = colors.copy(); c2[N // 3] = 1 + c2[N // 3] % 3
+    assert not plan.matches(cp, rv, c2) and not plan.matches(colorvec=c2)
+    r2 = rv.copy(); r2[[7, 8]] = r2[[8, 7]]
+    assert not plan.matches(cp, r2, colors)
+    drv2 = drv.clone(); drv2[1000] += 1
+    assert not plan.matches(dcp, drv2, dcv)
+    assert not plan.matches(cp[:-1], rv, colors)                                # another length is a mismatch, nothing is read
+    with pytest.raises(fd.lib.FdError):
+        fd.make_plan(pat, pat, colors, "forward").matches(cp, rv, colors)       # no FD_PLAN_FINGERPRINT
+    # a column window fingerprints its own slice of colptr / rowval
+    w = fd.make_plan(pat, pat, colors, "forward", col_window=(1000, 30000), fingerprint=True)
+    r3 = rv.copy(); r3[5] += 1                                                  # outside the window's entries
+    assert w.matches(cp, r3, colors)
+    r3[int(cp[2000])] += 1                                                      # inside
+    assert not w.matches(cp, r3, colors)
+    # the device-built plan of a device-resident pattern
+    pd = fd.make_plan_csc_device(N, N, dcp, drv, dcv, "forward", fingerprint=True)
+    assert pd.matches(dcp, drv, dcv) and pd.matches(cp, rv, colors) and not pd.matches(dcp, drv2, dcv)
+
+
+def test_plan_matches_structural_and_list_plans():
+    N = 3001
+    colors = P.cyclic_colors(N, 3)
+    tri = fd.Tridiagonal(_dev(np.zeros(N - 1)), _dev(np.zeros(N)), _dev(np.zeros(N - 1)))
+    pt = fd.make_plan(tri, tri, colors, "central", fingerprint=True)
+    c2 = colors.copy(); c2[5] = 0
+    assert pt.matches(colorvec=colors) and not pt.matches(colorvec=c2)
+    assert pt.matches(np.arange(4), np.arange(4), colors)                       # index arrays are ignored by structural plans
+    # dense J with a dense-matrix pattern: the (I, J) lists of _findstructralnz
+    A = (np.random.default_rng(1).random((40, 30)) < 0.2).astype(float)
+    cv = np.arange(1, 31, dtype=np.int64)
+    Jd = torch.zeros((30, 40), dtype=torch.float64, device="cuda").t()
+    pl = fd.make_plan(Jd, A, cv, "forward", fingerprint=True)
+    cols, rows = np.nonzero(A.T)
+    assert pl.matches(rows + 1, cols + 1, cv)
+    assert not pl.matches(rows + 1, np.roll(cols + 1, 1), cv)
+    # Float32 instantiation and the lowered complex-valued x (fingerprints in the CALLER's units)
+    cp, rv = P.tridiag_csc(N)
+    pat = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    p32 = fd.make_plan(pat, pat, colors, "forward", dtype=np.float32, fingerprint=True)
+    assert p32.matches(cp, rv, colors) and not p32.matches(cp, rv, c2)
+    pcx = fd.make_plan(pat, pat, colors, "forward", complex_x=True, fingerprint=True)
+    assert pcx.matches(cp, rv, colors) and not pcx.matches(cp, rv, c2)
+
+
+def test_unknown_plan_flags_are_rejected():
+    # fd_plan_opts.flags: only the documented bits (round-3 advisor: an internal marker lived in this field, unvalidated)
+    import ctypes as C
+    N = 64
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    ctx = fd.Context.default()
+    for bad in (1 << 16, 8, 1 << 30):
+        o = fd.lib.PlanOpts()
+        o.fdtype = 0
+        o.flags = bad
+        h = C.c_void_p()
+        rc = ctx.L.fd_plan_create_csc(ctx.handle, N, N, cp.ctypes.data, rv.ctypes.data, 8, 1, colors.ctypes.data, 8, C.byref(o), C.byref(h))
+        assert rc == 1 and b"flags" in ctx.L.fd_last_error() and not h.value       # FD_ERR_ARG
+        rc = ctx.L.fd_plan_create_tridiagonal(ctx.handle, N, colors.ctypes.data, 8, C.byref(o), C.byref(h))
+        assert rc == 1 and not h.value
+        o.flags = bad | fd.lib.PLAN_COMPLEX_X
+        rc = ctx.L.fd_plan_create_csc(ctx.handle, N, N, cp.ctypes.data, rv.ctypes.data, 8, 1, colors.ctypes.data, 8, C.byref(o), C.byref(h))
+        assert rc == 1 and not h.value
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_dropin_installs_the_lazy_launcher_like_the_shim(fdtype):
+    # install_lazy!(plan, f) of the shim: the drop-in call of a built-in family runs the lazy / storing launches; cache.lazy = False
+    # keeps the materialised points.  Same bits, same number of f! evaluations.
+    N = 40009
+    res = []
+    for lazy in (True, False):
+        J, colors, _cp = _tridiag_dropin(N)
+        x = _dev(np.random.default_rng(8).random(N))
+        f = fd.BuiltinF("tridiag_nl", N)
+        cache = fd.JacobianCache(x, fdtype, colorvec=colors, sparsity=J)
+        cache.lazy = lazy
+        fd.finite_difference_jacobian_b(J, f, x, cache)
+        res.append((J.nzval.clone(), f.fcalls, cache.last_plan.info(fd.lib.INFO_LAZY_STORE)))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert res[0][2] == (0 if fdtype == "complex" else 1) and res[1][2] == 0
