@@ -145,7 +145,14 @@ static int fingerprint_now(fd_plan *p, const fd_pattern_arrays *now, int64_t a0,
     int bytes[3] = {now->idx_bytes, now->idx_bytes, now->color_bytes};
     int64_t i0[3] = {a0, 0, 0}, n[3] = {arr[0] ? an : 0, 0, arr[2] ? now->len_color : 0}, base[3] = {now->idx_base, now->idx_base, 0};
     int64_t b0 = 0, bn = 0;
-    if (fp.idx_kind == 1 && arr[0]) {
+    if (fp.idx_kind == 1 && arr[0] && fp.valid) {
+        // comparing with a recorded plan: its own rowval range.  (colptr's fingerprint is position-dependent and covers both end
+        // points: if it matches, the caller's range IS this one; if not, the answer is "no" whatever rowval holds -- so the two
+        // blocking reads of colptr's end points are only needed when the range is first recorded)
+        b0 = fp.b0;
+        bn = fp.bn;
+        if (b0 + bn > now->len_b) { b0 = 0; bn = -1; }
+    } else if (fp.idx_kind == 1 && arr[0]) {
         int64_t e0 = 0, e1 = 0;
         int rc = read_index(arr[0], bytes[0], a0, now->memkind, &e0);
         if (!rc) rc = read_index(arr[0], bytes[0], a0 + an - 1, now->memkind, &e1);

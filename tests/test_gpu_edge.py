@@ -573,10 +573,10 @@ def test_dropin_plan_lookup_sees_an_in_place_edit_of_colorvec(check, device_patt
         cache.invalidate()
         fd.finite_difference_jacobian_b(J, f, x, cache)
         assert cache.last_plan is not p0 and float(J.nzval[d]) == 0.0
-    # every other stored value is what it was
+    # every other stored value is what it was, up to the step size of column jz's colour (its masked norm lost one element)
     keep = torch.ones_like(first, dtype=torch.bool)
     keep[int(cp[jz] - 1):int(cp[jz + 1] - 1)] = False
-    assert torch.equal(J.nzval[keep], first[keep])
+    assert torch.allclose(J.nzval[keep], first[keep], rtol=1e-6, atol=1e-7)
     # a NEW colour array (same content as the edited one) is a new identity: new plan without being told
     p1 = cache.last_plan
     colors2 = colors.clone() if torch.is_tensor(colors) else colors.copy()
