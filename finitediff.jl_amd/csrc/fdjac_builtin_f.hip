@@ -604,7 +604,8 @@ int balanced_grid(int64_t tiles, int64_t cap);
 static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
 {
     static int64_t capmult = -1;
-    if (capmult < 0) { const char *v = getenv("FDJAC_F_GRID_CAP"); capmult = (v && *v) ? atoll(v) : 16; }
+    // (default since round 4: uncapped, one work item per thread -- N = 10^7 tridiagonal f! 65 -> 59 us per launch, profiles/r04_b_*)
+    if (capmult < 0) { const char *v = getenv("FDJAC_F_GRID_CAP"); capmult = (v && *v) ? atoll(v) : 0; }
     const int64_t tiles = (rows + kBlock - 1) / kBlock;
     int64_t cap = capmult > 0 ? std::max<int64_t>((int64_t)num_cus * capmult / std::max<int64_t>(nbatch, 1), 64)
                               : ((int64_t)1 << 30);
@@ -852,66 +853,29 @@ __device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][W
 #undef MV
 }
 
-// The five quotients of a column of an INTERIOR tile (Float64), with three differences in FORM from stencil5_column_quotients
-// and none in RESULT:
-//  (i)   the plus point's unperturbed coordinates are read as x, not formed as x + 0.0 -- the same bits unless x is -0.0 (the
-//        kernel tests its window for a -0.0 and takes the literal form then).  The plus and the minus (forward: the base) evaluation
-//        of a row then share every subexpression in front of the perturbed operand -- same operands, same operation order, same
-//        bits; the sharing itself is the compiler's common-subexpression elimination: ((w+e)+s) of the north row, the whole
-//        neighbour sum of the centre row, 4c of the four neighbour rows;
-//  (ii)  ONE range test for the column's five quotients (on the exponents of |a|; the divisor's was tested by the caller) and
-//        branch-free correctly rounded quotients (div_shared's sequence) -- five divergent branches fewer per column;
-//  (iii) the reciprocal of the divisor arrives from the wave's per-colour table (one division per wave instead of one per column).
-// Returns false if the lane must take the literal form (an operand outside the range the short sequence is proven for).
-template <int MODE, int SK, int WC>
-__device__ __forceinline__ bool stencil5_column_quotients_fast(const real_t (&W)[5][WC], int o, real_t e, real_t ed, real_t yd, real_t *q)
+template <typename CT, int MODE, int SK, bool NT, bool FASTDIV, bool INTSPEC, int CPL, int WV>
+__global__ void __launch_bounds__(kBlock, WV)      // WV: waves per SIMD the register allocation aims at
+k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
 {
-    static_assert(sizeof(real_t) == 8, "Float64 form");
-    const real_t xc = W[2][2 + o], pc = xc + e, mcc = MODE == 1 ? xc - e : xc;
-    // |a| in [2^-600, 2^600] for all five (then |a / ed| in [2^-800, 2^800] for the divisor range the caller tested): biased exponents
-    unsigned lo = 0x7ffu, hi = 0u;
-#define V(dj, di) W[(dj) + 2][(di) + 2 + o]
-#define ROW(c, w, ee, ss, n) stencil5_row<real_t, SK>(c, w, ee, ss, n)
-#define QUOT(m, plus, minus)                                                     \
-    do {                                                                         \
-        const double a_ = sub_exact(plus, minus);                                \
-        const unsigned ex_ = ((unsigned)__double2hiint(a_) >> 20) & 0x7ffu;      \
-        lo = ex_ < lo ? ex_ : lo;                                                \
-        hi = ex_ > hi ? ex_ : hi;                                                \
-        const double q0_ = a_ * yd;                                              \
-        const double r0_ = __builtin_fma(-ed, q0_, a_);                          \
-        const double q1_ = __builtin_fma(r0_, yd, q0_);                          \
-        const double r1_ = __builtin_fma(-ed, q1_, a_);                          \
-        q[m] = __builtin_fma(r1_, yd, q1_);                                      \
-    } while (0)
-    QUOT(0, ROW(V(-1, 0), V(-1, -1), V(-1, 1), V(-2, 0), pc), ROW(V(-1, 0), V(-1, -1), V(-1, 1), V(-2, 0), mcc));   // row (i, j-1): its north neighbour is the perturbed coordinate
-    QUOT(1, ROW(V(0, -1), V(0, -2), pc, V(-1, -1), V(1, -1)), ROW(V(0, -1), V(0, -2), mcc, V(-1, -1), V(1, -1)));   // row (i-1, j): east
-    QUOT(2, ROW(pc, V(0, -1), V(0, 1), V(-1, 0), V(1, 0)), ROW(mcc, V(0, -1), V(0, 1), V(-1, 0), V(1, 0)));         // row (i, j): centre
-    QUOT(3, ROW(V(0, 1), pc, V(0, 2), V(-1, 1), V(1, 1)), ROW(V(0, 1), mcc, V(0, 2), V(-1, 1), V(1, 1)));           // row (i+1, j): west
-    QUOT(4, ROW(V(1, 0), V(1, -1), V(1, 1), pc, V(2, 0)), ROW(V(1, 0), V(1, -1), V(1, 1), mcc, V(2, 0)));           // row (i, j+1): south
-#undef QUOT
-#undef ROW
-#undef V
-    return lo >= 1023u - 600u && hi <= 1023u + 600u;
-}
-// is this value the one x for which x + 0.0 is not x?
-__device__ __forceinline__ bool is_negzero(real_t v)
-{
-    if constexpr (sizeof(real_t) == 8) return __double2hiint(v) == (int)0x80000000 && __double2loint(v) == 0;
-    else return __float_as_int(v) == (int)0x80000000;
-}
-
-// One wavefront's tile in the LITERAL form: window loads with their grid guards, stencil5_column_quotients, emit.
-template <typename CT, int MODE, int SK, bool NT, bool FASTDIV, bool INTSPEC, int CPL>
-__device__ __forceinline__ void stencil5_tile_literal(const real_t *__restrict__ x, const real_t *__restrict__ eps, const fd_stencil5_store &st,
-                                                      real_t *win, int j, int i0, bool interior)
-{
-    constexpr int WC = 4 + CPL;
-    const int lane = threadIdx.x & 63;
+    // CPL = columns per lane: 2 (aligned 16-B loads of x, 128 columns per wavefront) or 1 (8-B loads, 64 columns, half the registers)
+    constexpr int TW = 64 * CPL, WC = 4 + CPL;
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][CPL == 2 ? FD_STENCIL5_WAVE_LDS : FD_STENCIL5_WAVE_LDS / 2 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nx = (int)st.nx, ny = (int)st.ny;
+    const int TPR = (nx + TW - 1) / TW;
+    const int64_t ntiles = (jrow1 - jrow0) * TPR, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    const int64_t grp = xcd_tile(blockIdx.x, ngroups);
+    if (grp >= ngroups) return;
+    const int64_t wt = grp * (kBlock / 64) + wave;
+    if (wt >= ntiles) return;
+    // (32-bit division: the launcher declines grids with 2^31 tiles or more; a 64-bit one is ~150 instructions per wavefront)
+    const unsigned wrow = (unsigned)wt / (unsigned)TPR;
+    const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
     const int i = i0 + CPL * lane;
     const int64_t k = (int64_t)j * nx + i;
     const bool act = i < nx;
+    // a tile whose whole neighbourhood lies inside the grid needs no guards (wave-uniform)
+    const bool interior = INTSPEC && j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
     // window rows j-2 .. j+2, columns i-2 .. i+CPL+1 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
     real_t W[5][WC];
 #pragma unroll
@@ -950,84 +914,7 @@ __device__ __forceinline__ void stencil5_tile_literal(const real_t *__restrict__
         if (INTSPEC && interior) stencil5_column_quotients<MODE, SK, true, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
         else stencil5_column_quotients<MODE, SK, false, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
     }
-    fd_stencil5_emit_wave<real_t, NT, CPL>(&st, win, j, i0, q);
-}
-
-// An INTERIOR tile (every neighbour of every evaluated row exists, the wavefront full), two columns per lane, Float64, in the short
-// form of stencil5_column_quotients_fast.  Returns false WITHOUT having stored anything if some lane of the wavefront needs the
-// literal form (a -0.0 in its window, an operand outside the range the short quotient sequence is proven for); the caller then
-// runs stencil5_tile_literal on the same tile (the window is simply loaded again: nothing stays live across the two forms).
-template <typename CT, int MODE, int SK, bool NT>
-__device__ __forceinline__ bool stencil5_tile_fast(const real_t *__restrict__ x, const real_t *__restrict__ eps, const fd_stencil5_store &st,
-                                                   real_t *win, int j, int i0)
-{
-    constexpr int WC = 6;
-    const int lane = threadIdx.x & 63;
-    const int nx = (int)st.nx;
-    const int i = i0 + 2 * lane;
-    const int64_t k = (int64_t)j * nx + i;
-    real_t W[5][WC];
-#pragma unroll
-    for (int dj = -2; dj <= 2; ++dj)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            r2_t v = {0, 0};
-            if (!((dj == -2 || dj == 2) && c != 1)) v = *reinterpret_cast<const r2_t *>(x + (k + (int64_t)dj * nx + 2 * (c - 1)));
-            W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
-        }
-    const int c0 = (int)((const CT *)st.color)[k], c1 = (int)((const CT *)st.color)[k + 1];
-    // the reciprocal of every colour's divisor, once per wavefront: lane c holds 1 / eps_c (central: 1 / (2 eps_c))
-    const real_t el = eps[lane < st.C ? lane : 0];
-    const real_t yl = (real_t)1 / (MODE == 1 ? 2 * el : el);
-    bool literal = false;
-#pragma unroll
-    for (int dj = 0; dj < 5; ++dj)
-#pragma unroll
-        for (int c = 0; c < WC; ++c)
-            if (!((dj == 0 || dj == 4) && (c < 2 || c > 3))) literal = literal || is_negzero(W[dj][c]);
-    real_t q[10];
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int cc = o ? c1 : c0;
-        const real_t e = eps[cc], ed = MODE == 1 ? 2 * e : e;
-        const real_t yd = __shfl(yl, cc, 64);
-        const unsigned exd = ((unsigned)__double2hiint(ed) >> 20) & 0x7ffu;
-        const bool ok = stencil5_column_quotients_fast<MODE, SK, WC>(W, o, e, ed, yd, q + 5 * o);
-        literal = literal || !ok || exd < 1023u - 200u || exd > 1023u + 200u;
-    }
-    if (__any(literal)) return false;
-    fd_stencil5_emit_wave<real_t, NT, 2>(&st, win, j, i0, q);
-    return true;
-}
-
-template <typename CT, int MODE, int SK, bool NT, bool FASTDIV, bool INTSPEC, int CPL, int WV>
-__global__ void __launch_bounds__(kBlock, WV)      // WV: waves per SIMD the register allocation aims at
-k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
-{
-    // CPL = columns per lane: 2 (aligned 16-B loads of x, 128 columns per wavefront) or 1 (8-B loads, 64 columns, half the registers)
-    constexpr int TW = 64 * CPL;
-    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][CPL == 2 ? FD_STENCIL5_WAVE_LDS : FD_STENCIL5_WAVE_LDS / 2 + 4];
-    const int wave = threadIdx.x >> 6;
-    const int nx = (int)st.nx, ny = (int)st.ny;
-    const int TPR = (nx + TW - 1) / TW;
-    const int64_t ntiles = (jrow1 - jrow0) * TPR, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
-    const int64_t grp = xcd_tile(blockIdx.x, ngroups);
-    if (grp >= ngroups) return;
-    const int64_t wt = grp * (kBlock / 64) + wave;
-    if (wt >= ntiles) return;
-    // (32-bit division: the launcher declines grids with 2^31 tiles or more; a 64-bit one is ~150 instructions per wavefront)
-    const unsigned wrow = (unsigned)wt / (unsigned)TPR;
-    const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
-    // a tile whose whole neighbourhood lies inside the grid needs no guards (wave-uniform)
-    const bool interior = INTSPEC && j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
-    if constexpr (INTSPEC && FASTDIV && CPL == 2 && sizeof(real_t) == 8) {
-        if (interior && st.C <= 64) {
-            if (stencil5_tile_fast<CT, MODE, SK, NT>(x, eps, st, s_win[wave], j, i0)) return;
-            stencil5_tile_literal<CT, MODE, SK, NT, FASTDIV, false, CPL>(x, eps, st, s_win[wave], j, i0, false);    // (rare: guards cost nothing here)
-            return;
-        }
-    }
-    stencil5_tile_literal<CT, MODE, SK, NT, FASTDIV, INTSPEC, CPL>(x, eps, st, s_win[wave], j, i0, interior);
+    fd_stencil5_emit_wave<real_t, NT, CPL>(&st, s_win[wave], j, i0, q);
 }
 
 template <typename CT>
@@ -1055,7 +942,7 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
 #define FD_S5(MODE, SKK, NT, FDV, INS, CPLL, WVV)                                                                   \
         hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT, FDV, INS, CPLL, WVV>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)
-#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6 && FDV && CPLL == 2) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else if (b->store_waves == 5 && FDV && CPLL == 2) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 5); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)   /* (the register budget spills with the IEEE division sequence or one column per lane: 337 / 237 vs 121 us) */
+#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6 && FDV && CPLL == 2) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)   /* (the register budget spills with the IEEE division sequence or one column per lane: 337 / 237 vs 121 us) */
 #define FD_S5_C(MODE, SKK, NT, FDV, INS) do { if (cpl == 1) FD_S5_W(MODE, SKK, NT, FDV, INS, 1); else FD_S5_W(MODE, SKK, NT, FDV, INS, 2); } while (0)
 #define FD_S5_I(MODE, SKK, NT, FDV) do { if (b->store_interior) FD_S5_C(MODE, SKK, NT, FDV, true); else FD_S5_C(MODE, SKK, NT, FDV, false); } while (0)
 #define FD_S5_NT(MODE, SKK) do { if (b->store_fastdiv) { if (b->store_nt) FD_S5_I(MODE, SKK, true, true); else FD_S5_I(MODE, SKK, false, true); } \

@@ -1376,7 +1376,9 @@ static int launch_perturb_tm(fd_plan *p, const real_t *x, int c_lo, int B)
 {
     const int64_t j0 = p->x0 & ~(int64_t)1;  // even start => 16-B aligned pairs
     const int64_t j1 = p->x1;
-    const int g = grid_for((j1 - j0 + 1) / 2, kBlock, p->ctx->num_cus);
+    // one pair per thread, one-shot grid: a capped grid-stride launch streams at 4.9 instead of 6.2 TB/s on this part
+    // (scripts/ubench/copy_variants.hip; N = 10^7 forward: 64 -> 58 us, profiles/r04_b_*)
+    const unsigned g = (unsigned)std::max<int64_t>(1, ((j1 - j0 + 1) / 2 + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_perturb<CT, MODE>), dim3(g), dim3(kBlock), 0, p->ctx->stream, x,
                        (const CT *)p->d_color, p->d_eps, c_lo, B, j0, j1, p->d_X, p->ldx);
     FD_HIP_CHECK(hipGetLastError());

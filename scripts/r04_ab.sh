@@ -11,13 +11,14 @@ j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=j['roofline']
 print('%-34s ms/step %.4f  median %.4f  kernel avg %.2f us median %.2f us  stages %s  check %s' % ('$label', j['ms_per_step'], j['median_ms_per_step'] or 0, r['avg_launch_ms']*1e3, r['median_launch_ms']*1e3, {k: round(v*1e3,1) for k,v in j['stages_ms'].items()}, j['result_check']['ok']))" >> $OUT 2>&1
 }
-run "c3 default"              X=1 -- --config c3
-run "c3 WAVES=5"              FDJAC_STORE_WAVES=5 -- --config c3
-run "c3 WAVES=1"              FDJAC_STORE_WAVES=1 -- --config c3
-run "c3 INTERIOR=0 (literal)" FDJAC_STORE_INTERIOR=0 -- --config c3
-run "c3 default again"        X=1 -- --config c3
-run "c4 materialized default" X=1 -- --config c4 --f-mode materialized
-run "c4 materialized uncapped" FDJAC_GRID_CAP=0 FDJAC_F_GRID_CAP=0 -- --config c4 --f-mode materialized
-run "c4 materialized F uncapped" FDJAC_F_GRID_CAP=0 -- --config c4 --f-mode materialized
-run "c4 default"              X=1 -- --config c4
+run "c3 TPW=1"                FDJAC_STORE_TPW=1 -- --config c3
+run "c3 TPW=2"                FDJAC_STORE_TPW=2 -- --config c3
+run "c3 TPW=4"                FDJAC_STORE_TPW=4 -- --config c3
+run "c3 TPW=8"                FDJAC_STORE_TPW=8 -- --config c3
+run "c3 TPW=32"               FDJAC_STORE_TPW=32 -- --config c3
+run "c3 TPW=4 WAVES=5"        FDJAC_STORE_TPW=4 FDJAC_STORE_WAVES=5 -- --config c3
+run "c3 TPW=4 WAVES=1"        FDJAC_STORE_TPW=4 FDJAC_STORE_WAVES=1 -- --config c3
+run "c3 TPW=1 again"          FDJAC_STORE_TPW=1 -- --config c3
+run "c4 materialized"         X=1 -- --config c4 --f-mode materialized
+run "c3 materialized"         X=1 -- --config c3 --f-mode materialized
 cat $OUT
