@@ -584,8 +584,9 @@ struct BuiltinF {
     uint32_t magic = 0xFD0F00D5u;
     fd_ctx *ctx = nullptr;
     int family = 0;
-    int64_t prm[2] = {0, 0};
+    int64_t prm[3] = {0, 0, 0};
     int64_t M = 0, N = 0;
+    int32_t *d_srow = nullptr, *d_scol = nullptr;   // FD_F_SPARSE: the pattern by rows (rowptr[M + 1], ascending columns), device
     std::atomic<int64_t> launches{0}, points{0};
     void *d_sig = nullptr;  // block-coupled sigma scratch
     int64_t sig_cap = 0;    // in (re,im)-capable elements
@@ -612,11 +613,14 @@ static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
     return dim3((unsigned)balanced_grid(tiles, cap), (unsigned)nbatch, 1);
 }
 
+#include "fdjac_rowlist_f.hip"
+
 template <typename T>
 static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0,
                          int64_t r1, hipStream_t s)
 {
     if (r1 <= r0) return 0;
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) return rowlist_family_launch<T>(b, fx, x, nbatch, xs, fs, r0, r1, s);
     const int ncu = b->ctx->num_cus;
     T *fxp = (T *)fx;
     const T *xp = (const T *)x;
@@ -1592,7 +1596,7 @@ static int builtin_launch_lazy_jvp(void *fctx, void *fx, const fd_lazy_jvp_point
 
 static bool has_lazy(const BuiltinF *b)
 {
-    if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) return true;
+    if (b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) return true;
     if (b->family == FD_F_BLOCKCOUPLED) return b->prm[1] <= 64;   // one wave per block
     return (b->family == FD_F_LAP5 || b->family == FD_F_CLAMP5 || b->family == FD_F_LAP5_NL) && (b->prm[0] % 2 == 0);  // pairs must not straddle grid rows
 }
@@ -1603,6 +1607,14 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     BuiltinF *b = (BuiltinF *)fctx;
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
     if (!has_lazy(b)) return 6;
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // row-centric families: the destination-table store, or nothing
+        const int rc = lp->color_bytes == 1 ? rowlist_family_lazy<uint8_t>(b, lp, (hipStream_t)stream) : rowlist_family_lazy<int32_t>(b, lp, (hipStream_t)stream);
+        if (rc == 0) {
+            b->launches.fetch_add(1);
+            b->points.fetch_add((int64_t)lp->ncolors * lp->pts + (lp->diff == 2 ? 1 : 0));
+        }
+        return rc;
+    }
     // 16-B vector accesses: bases are hipMalloc/torch allocations, fx_stride is a multiple of 32 elements
     if (((((uintptr_t)fx) | ((uintptr_t)lp->base_out)) & kPairMask) != 0 || (fx_stride & 1)) return 7;
     if (lp->diff && (b->family == FD_F_BLOCKCOUPLED || lp->is_complex || lp->base_out)) return 8;   // (not registered with FD_LAZY_CAP_DIFF)
@@ -1659,9 +1671,10 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
     case FD_F_CLAMP5:
     case FD_F_BLOCKCOUPLED: need = 2; break;
     case FD_F_NONSQUARE: need = 1; break;
+    case FD_F_LAP7: need = 3; break;
     default:
         delete b;
-        set_error("unknown built-in f family %d", family);
+        set_error(family == FD_F_SPARSE ? "FD_F_SPARSE is created by fd_builtin_f_create_sparse" : "unknown built-in f family %d", family);
         return FD_ERR_ARG;
     }
     if (nparams < need) {
@@ -1690,7 +1703,66 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
     case FD_F_TRIDIAG:
     case FD_F_TRIDIAG_NL: b->M = b->N = b->prm[0]; break;
     case FD_F_NONSQUARE: b->M = b->prm[0]; b->N = 2 * b->prm[0]; break;
+    case FD_F_LAP7:
+        b->M = b->N = b->prm[0] * b->prm[1] * b->prm[2];
+        if (b->prm[0] * b->prm[1] >= ((int64_t)1 << 31) || b->M / (b->prm[0] * b->prm[1]) >= ((int64_t)1 << 31)) {
+            delete b;
+            set_error("grid too large for the 7-point family");
+            return FD_ERR_ARG;
+        }
+        break;
     default: b->M = b->N = b->prm[0] * b->prm[1]; break;
+    }
+    *fn_out = builtin_launch;
+    *fctx_out = b;
+    return FD_OK;
+}
+
+// FD_F_SPARSE: the pattern arrives as the CSC pattern of the Jacobian; the launcher keeps its transpose (rows, ascending columns)
+int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes, int idx_base,
+                               fd_f_launch *fn_out, void **fctx_out)
+{
+    FD_REQUIRE(ctx && colptr && rowval && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(idx_base == 0 || idx_base == 1, FD_ERR_ARG, "idx_base must be 0 or 1");
+    FD_REQUIRE(M >= 1 && N >= 1 && M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), FD_ERR_ARG, "bad shape");
+    auto ld = [&](const void *p, int64_t i) { return idx_bytes == 8 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i]; };
+    const int64_t nnz = ld(colptr, N) - idx_base;
+    FD_REQUIRE(nnz >= 0 && nnz < ((int64_t)1 << 31), FD_ERR_SHAPE, "colptr is not monotone / too many entries");
+    std::vector<int32_t> srow((size_t)M + 1, 0), scol((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t j = 0; j < N; ++j) {
+        const int64_t a = ld(colptr, j) - idx_base, b2 = ld(colptr, j + 1) - idx_base;
+        FD_REQUIRE(a >= 0 && a <= b2 && b2 <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
+        for (int64_t q = a; q < b2; ++q) {
+            const int64_t r = ld(rowval, q) - idx_base;
+            FD_REQUIRE(r >= 0 && r < M, FD_ERR_SHAPE, "rowval[%lld] outside the matrix", (long long)q);
+            ++srow[(size_t)r + 1];
+        }
+    }
+    for (int64_t r = 0; r < M; ++r) srow[(size_t)r + 1] += srow[(size_t)r];
+    {
+        std::vector<int32_t> cur(srow.begin(), srow.end() - 1);
+        for (int64_t j = 0; j < N; ++j)       // columns ascending: every row's entries end up in ascending column order
+            for (int64_t q = ld(colptr, j) - idx_base; q < ld(colptr, j + 1) - idx_base; ++q) scol[(size_t)cur[(size_t)(ld(rowval, q) - idx_base)]++] = (int32_t)j;
+    }
+    BuiltinF *b = new (std::nothrow) BuiltinF();
+    FD_REQUIRE(b != nullptr, FD_ERR_NOMEM, "out of host memory");
+    b->ctx = ctx;
+    b->family = FD_F_SPARSE;
+    b->M = M;
+    b->N = N;
+    b->prm[0] = M; b->prm[1] = N; b->prm[2] = nnz;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_srow, sizeof(int32_t) * srow.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_scol, sizeof(int32_t) * scol.size());
+    if (e == hipSuccess) e = hipMemcpy(b->d_srow, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_scol, scol.data(), sizeof(int32_t) * scol.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("uploading the pattern of the sparse family failed: %s", hipGetErrorString(e));
+        if (b->d_srow) (void)hipFree(b->d_srow);
+        if (b->d_scol) (void)hipFree(b->d_scol);
+        delete b;
+        return FD_ERR_HIP;
     }
     *fn_out = builtin_launch;
     *fctx_out = b;
@@ -1703,6 +1775,8 @@ int fd_builtin_f_destroy(void *fctx)
     if (!b) return FD_OK;
     FD_REQUIRE(b->magic == 0xFD0F00D5u, FD_ERR_ARG, "not a built-in f context");
     if (b->d_sig) (void)hipFree(b->d_sig);
+    if (b->d_srow) (void)hipFree(b->d_srow);
+    if (b->d_scol) (void)hipFree(b->d_scol);
     b->magic = 0;
     delete b;
     return FD_OK;
@@ -1746,6 +1820,10 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // row-centric families: the destination-table store only
+        *caps_out = FD_LAZY_CAP_STORE_ROWLIST;
+        return FD_OK;
+    }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |
                                ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL ||
                                  b->family == FD_F_BLOCKCOUPLED) ? FD_LAZY_CAP_STORE : 0)) : 0;

@@ -39,6 +39,7 @@
 #define fd_plan_get_timings fd32_plan_get_timings
 #define fd_plan_get_timing_samples fd32_plan_get_timing_samples
 #define fd_builtin_f_create fd32_builtin_f_create
+#define fd_builtin_f_create_sparse fd32_builtin_f_create_sparse
 #define fd_builtin_f_destroy fd32_builtin_f_destroy
 #define fd_builtin_f_counts fd32_builtin_f_counts
 #define fd_builtin_f_lazy fd32_builtin_f_lazy
@@ -237,6 +238,12 @@ struct fd_plan {
     // ... and the 5-point stencil on an nx x ny grid (fd_stencil5_store): exact pattern + valid colouring verified
     bool store5_ok = false;
     int64_t store5_nx = 0, store5_ny = 0;
+    // ... and ANY pattern through the per-(row, colour) destination table (fd_rowlist_store; FD_PLAN_STORE_TABLE, valid colouring verified)
+    bool want_table = false, store_rl_ok = false;
+    int32_t *d_rl_rowptr = nullptr, *d_rl_dest = nullptr;
+    void *d_rl_ecolor = nullptr;
+    int64_t rl_row0 = 0, rl_row1 = 0, rl_entries = 0;
+    int rl_maxrow = 0;
     // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded
     bool store_cr_ok = false;
     int64_t cr_nblk = 0, cr_bs = 0;
@@ -310,6 +317,12 @@ int plan_record_fingerprint(fd_plan *p, int idx_kind, const fd_pattern_arrays *s
 }
 
 // does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
+// ... through the destination table of a general pattern (any column window, colour chunk, ownership; columns without colour too)
+static inline bool store_table_active(const fd_plan *p)
+{
+    return p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE_ROWLIST) && p->store_rl_ok && p->kind == fdjac::K_CSC && p->fdtype != FD_COMPLEX &&
+           p->store_allowed;
+}
 static inline bool store_active(const fd_plan *p)
 {
     if (!(p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE)) || p->has_none) return false;

@@ -25,13 +25,13 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN,
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
- INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE) = range(33)
-LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE = 1, 2, 4, 8
-PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT = 1, 2, 4
+ INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE, INFO_STORE_TABLE) = range(34)
+LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_ROWLIST = 1, 2, 4, 8, 16
+PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_TABLE = 1, 2, 4, 8
 LAZY_JVP_CAP_QUOTIENT = 1
-(F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL) = range(7)
+(F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL, F_LAP7, F_SPARSE) = range(9)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
-            "blockcoupled": F_BLOCKCOUPLED, "nonsquare": F_NONSQUARE, "lap5_nl": F_LAP5_NL}
+            "blockcoupled": F_BLOCKCOUPLED, "nonsquare": F_NONSQUARE, "lap5_nl": F_LAP5_NL, "lap7": F_LAP7}
 
 # int f(fctx, fx, x, nbatch, x_stride, fx_stride, row_begin, row_end, is_complex, stream)
 F_LAUNCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
@@ -72,7 +72,7 @@ EXPORTS = (
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse",
 )
 
 
@@ -88,7 +88,7 @@ TYPED = (
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -185,6 +185,7 @@ def load():
     L.fd_plan_get_timing_samples.argtypes = [vp, i32, C.POINTER(dbl), i64, C.POINTER(i64)]
     L.fd_builtin_f_create.argtypes = [vp, i32, C.POINTER(i64), i32, C.POINTER(F_LAUNCH), pp]
     L.fd_builtin_f_destroy.argtypes = [vp]
+    L.fd_builtin_f_create_sparse.argtypes = [vp, i64, i64, vp, vp, i32, i32, C.POINTER(F_LAUNCH), pp]
     L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.fd_stream_copy_gbps.argtypes = [vp, i64, i32, C.POINTER(dbl)]
     L.fd_jvp_plan_create.argtypes = [vp, i64, i64, i32, pp]

@@ -1,0 +1,261 @@
+"""The storing launch for GENERAL SparseMatrixCSC patterns (round 4): the plan's per-(row, colour) destination table
+(FD_PLAN_STORE_TABLE, fd_rowlist_store in include/fdjac_device.h) and the row-centric built-in families that store through it
+(FD_F_LAP7: 3-D 7-point stencil; FD_F_SPARSE: any pattern).  Every case is checked three ways: bit for bit against the hand-over
+path (materialised points -> plain f! -> k_decompress_*: the same operations on the same operands), against the CPU oracle within
+the stated tolerance, and the number of f! evaluations against the reference's (1 + C / 2C).
+Reference: src/jacobians.jl:559-568, 600-609; ext/FiniteDiffSparseArraysExt.jl:38-47."""
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+EPS64 = np.finfo(np.float64).eps
+
+
+def _dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def stencil7_csc(nx, ny, nz):
+    N = nx * ny * nz
+    k = np.arange(N, dtype=np.int64)
+    i, j, l = k % nx, (k // nx) % ny, k // (nx * ny)
+    has = np.stack([l > 0, j > 0, i > 0, np.ones(N, bool), i < nx - 1, j < ny - 1, l < nz - 1], axis=1)
+    rows = np.stack([k - nx * ny, k - nx, k - 1, k, k + 1, k + nx, k + nx * ny], axis=1)
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(has.sum(axis=1), out=colptr[1:])
+    colptr[1:] += 1
+    return colptr, (rows[has] + 1).astype(np.int64), ((i + 2 * j + 3 * l) % 7 + 1).astype(np.int64)
+
+
+def lap7_np(fx, xx, nx, ny, nz):
+    """FD_F_LAP7 in numpy, the kernel's operation order (real or complex)."""
+    X = xx.reshape(nz, ny, nx)
+    Z = np.zeros_like(X)
+    d, s, w, e, n, u = (Z.copy() for _ in range(6))
+    d[1:] = X[:-1]
+    u[:-1] = X[1:]
+    s[:, 1:] = X[:, :-1]
+    n[:, :-1] = X[:, 1:]
+    w[:, :, 1:] = X[:, :, :-1]
+    e[:, :, :-1] = X[:, :, 1:]
+    fx[:] = (((((((d + s) + w) + e) + n) + u) - 6 * X) + (X * X) * e).reshape(-1)
+
+
+def sparse_np_factory(M, N, colptr, rowval):
+    """FD_F_SPARSE in numpy: f_r = sum over the entries (r, j), ascending j, left to right, of w(r, j) phi(x_j)."""
+    cols = P.csc_cols(colptr) - 1
+    rows = rowval - 1
+    order = np.lexsort((cols, rows))             # by row, then by column
+    rs, cs = rows[order], cols[order]
+    cnt = np.bincount(rs, minlength=M)
+    start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+    maxlen = int(cnt.max()) if cnt.size else 0
+    w = 1.0 + 0.125 * ((rs + 3 * cs) & 7)
+
+    def f(fx, xx):
+        t = w * (xx[cs] + (0.25 * xx[cs]) * xx[cs])
+        out = np.zeros(M, dtype=xx.dtype)
+        for k in range(maxlen):
+            sel = np.nonzero(cnt > k)[0]
+            out[sel] = t[start[sel] + k] if k == 0 else out[sel] + t[start[sel] + k]
+        fx[:] = out
+    return f
+
+
+def _tol_ok(g, c, eps_min, fscale, what, rtol=1e-6):
+    atol = 16 * EPS64 * fscale / abs(eps_min)
+    bad = np.abs(g - c) > rtol * np.abs(c) + atol
+    assert not bad.any(), "%s: %d entries off, worst %.3e (atol %.1e)" % (what, int(bad.sum()), float(np.max(np.abs(g - c))), atol)
+
+
+def _run_pair(J, colors, fdtype, f, x, nnz, **plan_kw):
+    """The same Jacobian through the table store and through the hand-over path; returns (stored, handed over, plans)."""
+    p_store = fd.make_plan(J, J, colors, fdtype, store_table=True, **plan_kw)
+    p_store.set_lazy(f)
+    p_hand = fd.make_plan(J, J, colors, fdtype, **plan_kw)
+    a = _dev(np.full(nnz, np.nan))
+    b = _dev(np.full(nnz, np.nan))
+    n0 = f.fcalls
+    p_store.jacobian(f, x, [a])
+    n1 = f.fcalls
+    p_hand.jacobian(f, x, [b])
+    n2 = f.fcalls
+    return a, b, p_store, p_hand, (n1 - n0, n2 - n1)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("shape", [(20, 20, 20), (7, 5, 3), (33, 4, 9), (1, 1, 40), (64, 64, 2)])
+def test_lap7_table_store_bit_identical_and_oracle(oracle, fdtype, shape):
+    nx, ny, nz = shape
+    N = nx * ny * nz
+    colptr, rowval, colors = stencil7_csc(nx, ny, nz)
+    x = np.random.default_rng(nx + 10 * ny + 100 * nz).random(N)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    f = fd.BuiltinF("lap7", nx, ny, nz)
+    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_ROWLIST
+    a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
+    C = int(colors.max())
+    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert ph.info(fd.lib.INFO_STORE_TABLE) == 0 and ph.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert calls[0] == calls[1] == (C + 1 if fdtype == "forward" else 2 * C)
+    assert not torch.isnan(a).any()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    of = oracle.PyF(lambda fx, xx: lap7_np(fx, xx, nx, ny, nz), N, N)
+    ref = oracle.jacobian(fdtype, of, x, colors, M=N, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    _tol_ok(a.cpu().numpy(), ref["out"], np.min(np.abs(ps.epsilons())), 14.0, "lap7 " + fdtype)
+
+
+def _random_pattern(M, N, per_col, reach, seed):
+    """`per_col` entries per column at random rows within +-reach of the scaled diagonal (duplicates removed), some empty columns."""
+    rng = np.random.default_rng(seed)
+    centre = (np.arange(N) * (M / N)).astype(np.int64)
+    rows = np.clip(centre[:, None] + rng.integers(-reach, reach + 1, size=(N, per_col)), 0, M - 1)
+    rows = np.sort(rows, axis=1)
+    keep = np.ones_like(rows, bool)
+    keep[:, 1:] = rows[:, 1:] != rows[:, :-1]
+    keep[rng.random(N) < 0.03] = False           # empty columns
+    cnt = keep.sum(axis=1)
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(cnt, out=colptr[1:])
+    colptr[1:] += 1
+    return colptr, (rows[keep] + 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("case", [(300, 300, 4, 9, 1), (257, 411, 3, 20, 2), (411, 257, 5, 6, 3), (5000, 5000, 6, 300, 4), (40, 40, 1, 0, 5)])
+def test_sparse_family_table_store_bit_identical_and_oracle(oracle, fdtype, case):
+    M, N, per_col, reach, seed = case
+    colptr, rowval = _random_pattern(M, N, per_col, reach, seed)
+    J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    x = np.random.default_rng(seed).random(N) + 0.1
+    f = fd.BuiltinF.sparse(M, N, colptr, rowval)
+    a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
+    C = int(colors.max())
+    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert calls[0] == calls[1] == (C + 1 if fdtype == "forward" else 2 * C)
+    assert not torch.isnan(a).any()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    of = oracle.PyF(sparse_np_factory(M, N, colptr, rowval), M, N)
+    ref = oracle.jacobian(fdtype, of, x, colors, M=M, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    fs = float(np.abs(ref["fx"]).max()) if "fx" in ref else 10.0 * per_col
+    _tol_ok(a.cpu().numpy(), ref["out"], np.min(np.abs(ps.epsilons())), max(fs, 1.0), "sparse " + fdtype)
+    # and the analytic Jacobian: d f_r / d x_j = w(r, j) (1 + 0.5 x_j)
+    cols = P.csc_cols(colptr) - 1
+    want = (1.0 + 0.125 * (((rowval - 1) + 3 * cols) & 7)) * (1.0 + 0.5 * x[cols])
+    assert np.max(np.abs(a.cpu().numpy() - want)) < (5e-6 if fdtype == "forward" else 5e-8) * 10
+
+
+def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
+    # column windows (multi-GPU shards), colour chunks, colour ownership, columns without a colour, an INVALID colouring (the table
+    # is not built: the hand-over path serves the plan) -- always the bits of the hand-over path
+    M = N = 4000
+    colptr, rowval = _random_pattern(M, N, 5, 40, 11)
+    J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    C = int(colors.max())
+    x = _dev(np.random.default_rng(12).random(N) + 0.1)
+    f = fd.BuiltinF.sparse(M, N, colptr, rowval)
+    full = _dev(np.full(rowval.size, np.nan))
+    ph = fd.make_plan(J, J, colors, "forward")
+    ph.jacobian(f, x, [full])
+    # column windows
+    for (c0, c1) in [(0, 1000), (1000, 1001), (1234, 3999), (3999, 4000)]:
+        p = fd.make_plan(J, J, colors, "forward", store_table=True, col_window=(c0, c1))
+        p.set_lazy(f)
+        n = int(colptr[c1] - colptr[c0])
+        out = _dev(np.full(n, np.nan))
+        p.jacobian(f, x, [out])
+        assert p.info(fd.lib.INFO_STORE_TABLE) == n and (n == 0 or p.info(fd.lib.INFO_LAZY_STORE) == 1)
+        assert torch.equal(out.view(torch.int64), full[int(colptr[c0] - 1):int(colptr[c1] - 1)].view(torch.int64))
+    # colour chunks (a scratch cap that holds 2 colours at a time) and colour ownership
+    p = fd.make_plan(J, J, colors, "central", store_table=True, scratch_bytes=2 * 2 * 2 * N * 8 + 4096)
+    p.set_lazy(f)
+    pc = fd.make_plan(J, J, colors, "central")
+    o1, o2 = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
+    p.jacobian(f, x, [o1])
+    pc.jacobian(f, x, [o2])
+    assert p.info(fd.lib.INFO_NCHUNKS) > 1 and torch.equal(o1.view(torch.int64), o2.view(torch.int64))
+    acc = torch.zeros(rowval.size, dtype=torch.float64, device="cuda")
+    for (a0, a1) in [(0, 2), (2, C)]:
+        po = fd.make_plan(J, J, colors, "forward", store_table=True, color_range=(a0, a1))
+        po.set_lazy(f)
+        part = torch.zeros_like(acc)
+        po.jacobian(f, x, [part])
+        acc += part
+    assert torch.equal(acc.view(torch.int64), full.view(torch.int64))
+    # columns without a colour: their stored values are 0, everything else as the hand-over path computes it
+    c2 = colors.copy()
+    c2[[5, 77, 1999]] = 0
+    a, b, ps, _ph, _calls = _run_pair(J, c2, "forward", f, x, rowval.size)
+    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    for j in (5, 77, 1999):
+        assert torch.all(a[int(colptr[j] - 1):int(colptr[j + 1] - 1)] == 0)
+    # an invalid colouring (two columns of one row share a colour): no table, the results of the hand-over path (whatever they are)
+    bad = np.ones(N, dtype=np.int64)
+    a, b, ps, _ph, _calls = _run_pair(J, bad, "forward", f, x, rowval.size)
+    assert ps.info(fd.lib.INFO_STORE_TABLE) == 0 and ps.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+
+
+def test_table_store_float32_device_pattern_and_dropin():
+    nx, ny, nz = 24, 10, 6
+    N = nx * ny * nz
+    colptr, rowval, colors = stencil7_csc(nx, ny, nz)
+    x64 = np.random.default_rng(3).random(N)
+    # Float32 instantiation
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    f32 = fd.BuiltinF("lap7", nx, ny, nz, dtype=np.float32)
+    x32 = _dev(x64, torch.float32)
+    p1 = fd.make_plan(J, J, colors, "central", store_table=True, dtype=np.float32)
+    p1.set_lazy(f32)
+    p2 = fd.make_plan(J, J, colors, "central", dtype=np.float32)
+    o1 = torch.full((rowval.size,), float("nan"), dtype=torch.float32, device="cuda")
+    o2 = o1.clone()
+    p1.jacobian(f32, x32, [o1])
+    p2.jacobian(f32, x32, [o2])
+    assert p1.info(fd.lib.INFO_LAZY_STORE) == 1 and torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+    # a device-resident pattern (Int32, as rocSPARSE holds it): the table is compiled from the device arrays
+    f = fd.BuiltinF("lap7", nx, ny, nz)
+    x = _dev(x64)
+    nz_d = _dev(np.full(rowval.size, np.nan))
+    Jd = fd.DevicePatternCSC(N, N, torch.as_tensor(colptr.astype(np.int32), device="cuda"), torch.as_tensor(rowval.astype(np.int32), device="cuda"), nz_d)
+    cache = fd.JacobianCache(x, "forward", colorvec=torch.as_tensor(colors.astype(np.int32), device="cuda"), sparsity=Jd)
+    fd.finite_difference_jacobian_b(Jd, f, x, cache)          # the drop-in call asks for the table by itself (f can store)
+    assert cache.last_plan.info(fd.lib.INFO_STORE_TABLE) == rowval.size and cache.last_plan.info(fd.lib.INFO_LAZY_STORE) == 1
+    ref = _dev(np.full(rowval.size, np.nan))
+    fd.make_plan(J, J, colors, "forward").jacobian(f, x, [ref])
+    assert torch.equal(nz_d.view(torch.int64), ref.view(torch.int64))
+    # the complex step has no table store: the family's plain launcher on materialised complex points
+    Jc = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
+    fd.finite_difference_jacobian_b(Jc, f, x, "complex", colorvec=colors)
+    assert torch.allclose(Jc.nzval, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(61, 47), (3, 3), (200, 5)])
+def test_user_kernel_stores_a_general_pattern_through_the_table(tmp_path, shape):
+    # examples/user_rowlist_store.hip: a USER's residual on the nine-point stencil, written once as a device functor f(r, X) and
+    # compiled apart from libfdjac against the two public headers; inside fd_rowlist_store_rows (include/fdjac_device.h) it stores
+    # the Jacobian through the plan's destination table.  examples/user_rowlist_client.c (plain C) checks: table built and used,
+    # bit-identical to the same plan through the user's plain launcher + the library's decompression, analytic values, f! counts.
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "finitediff.jl_amd", "lib")
+    user_so = str(tmp_path / "libuser_rl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(root, "examples", "user_rowlist_store.hip"), "-o", user_so])
+    assert "libfdjac" not in subprocess.run(["ldd", user_so], capture_output=True, text=True).stdout
+    exe = str(tmp_path / "user_rowlist_client")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_rowlist_client.c"), "-o", exe,
+                           "-L" + str(tmp_path), "-luser_rl", "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "user_rowlist_client ok" in out.stdout and "FAILED" not in out.stdout
