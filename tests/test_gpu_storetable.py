@@ -114,10 +114,9 @@ def _random_pattern(M, N, per_col, reach, seed):
     """`per_col` entries per column at random rows within +-reach of the scaled diagonal (duplicates removed), some empty columns."""
     rng = np.random.default_rng(seed)
     centre = (np.arange(N) * (M / N)).astype(np.int64)
-    rows = np.clip(centre[:, None] + rng.integers(-reach, reach + 1, size=(N, per_col)), 0, M - 1)
-    rows = np.sort(rows, axis=1)
-    keep = np.ones_like(rows, bool)
-    keep[:, 1:] = rows[:, 1:] != rows[:, :-1]
+    rows = np.sort(centre[:, None] + rng.integers(-reach, reach + 1, size=(N, per_col)), axis=1)
+    keep = (rows >= 0) & (rows < M)              # (entries outside the matrix are dropped, not clipped: clipping would pile them into dense rows)
+    keep[:, 1:] &= rows[:, 1:] != rows[:, :-1]
     keep[rng.random(N) < 0.03] = False           # empty columns
     cnt = keep.sum(axis=1)
     colptr = np.empty(N + 1, np.int64)
@@ -197,6 +196,14 @@ def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
     assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and torch.equal(a.view(torch.int64), b.view(torch.int64))
     for j in (5, 77, 1999):
         assert torch.all(a[int(colptr[j] - 1):int(colptr[j + 1] - 1)] == 0)
+    # a dense row (more entries than the table's per-row limit): no table, the hand-over path
+    cpd, rvd = _random_pattern(300, 300, 3, 5, 21)
+    dense = np.zeros((300, 300)); dense[(rvd - 1), P.csc_cols(cpd) - 1] = 1; dense[7, :] = 1
+    cpd, rvd = P.csc_from_dense(dense)
+    Jd = fd.SparseMatrixCSC(300, 300, cpd, rvd, None)
+    fdn = fd.BuiltinF.sparse(300, 300, cpd, rvd)
+    a, b, ps, _ph, _calls = _run_pair(Jd, fd.matrix_colors(Jd), "forward", fdn, _dev(np.random.default_rng(5).random(300) + 0.1), rvd.size)
+    assert ps.info(fd.lib.INFO_STORE_TABLE) == 0 and torch.equal(a.view(torch.int64), b.view(torch.int64))
     # an invalid colouring (two columns of one row share a colour): no table, the results of the hand-over path (whatever they are)
     bad = np.ones(N, dtype=np.int64)
     a, b, ps, _ph, _calls = _run_pair(J, bad, "forward", f, x, rowval.size)
