@@ -1,11 +1,11 @@
 /*
- * Drives examples/user_rowlist_store.hip through the C ABI: a user's residual on the nine-point (Moore) stencil -- a pattern
- * without a closed-form layout -- whose launch stores the Jacobian itself through the plan's destination table
- * (FD_PLAN_STORE_TABLE + FD_LAZY_CAP_STORE_ROWLIST).  Checks: the table was built and is used; the stored values are
+ * Drives examples/user_csc_store.hip through the C ABI: a user's residual on the nine-point (Moore) stencil -- a pattern
+ * without a closed-form layout -- whose launch stores the Jacobian itself, column by column, through the plan's compact copy of
+ * the pattern (FD_PLAN_STORE_CSC + FD_LAZY_CAP_STORE_CSC).  Checks: the copy was built and is used; the stored values are
  * bit-identical to the same plan driven through the user's PLAIN launcher + the library's decompression; they agree with the
  * analytic Jacobian; the f! evaluation counts are the reference's (1 + C forward, 2C central).
  *
- *   gcc -O2 -Iinclude examples/user_rowlist_client.c -o user_rowlist_client -L. -luser_rl -Lfinitediff.jl_amd/lib -lfdjac \
+ *   gcc -O2 -Iinclude examples/user_csc_client.c -o user_csc_client -L. -luser_rl -Lfinitediff.jl_amd/lib -lfdjac \
  *       -L/opt/rocm/lib -lamdhip64 -lm
  */
 #include <math.h>
@@ -58,15 +58,15 @@ int main(int argc, char **argv)
     user_rl_init(nx, ny);
     int bad = 0;
     for (int fdtype = FD_FORWARD; fdtype <= FD_CENTRAL; ++fdtype) {
-        fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = FD_PLAN_STORE_TABLE;
+        fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = FD_PLAN_STORE_CSC;
         fd_plan *ps = NULL, *ph = NULL;
         CHECK(fd_plan_create_csc(ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &ps));
         CHECK(fd_plan_set_lazy_f(ps, user_rl_launch_lazy));
-        CHECK(fd_plan_set_lazy_caps(ps, FD_LAZY_CAP_STORE_ROWLIST));
+        CHECK(fd_plan_set_lazy_caps(ps, FD_LAZY_CAP_STORE_CSC));
         o.flags = 0;
         CHECK(fd_plan_create_csc(ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &ph));
         int64_t table = 0, active = 0;
-        CHECK(fd_plan_info(ps, FD_INFO_STORE_TABLE, &table));
+        CHECK(fd_plan_info(ps, FD_INFO_STORE_CSC, &table));
         CHECK(fd_plan_info(ps, FD_INFO_LAZY_STORE, &active));
         void *outs1[3] = {o1, NULL, NULL}, *outs2[3] = {o2, NULL, NULL};
         const int64_t n0 = user_rl_points();
@@ -87,7 +87,7 @@ int main(int argc, char **argv)
         const int same = memcmp(a, b, sizeof(double) * (size_t)nnz) == 0;
         const int64_t want_calls = fdtype == FD_FORWARD ? 10 : 18;
         const int ok = table == nnz && active == 1 && same && worst <= (fdtype == FD_FORWARD ? 2e-6 : 2e-8) && n1 - n0 == want_calls && n2 - n1 == want_calls;
-        printf("user_rowlist %s: table %lld of %lld entries, storing launch %s, bit-identical to the hand-over path %s, max|J - analytic| %.3e, "
+        printf("user_csc %s: pattern copy %lld of %lld entries, storing launch %s, bit-identical to the hand-over path %s, max|J - analytic| %.3e, "
                "f! evaluations %lld / %lld (expected %lld)  %s\n", fdtype == FD_FORWARD ? "forward" : "central", (long long)table, (long long)nnz,
                active ? "on" : "OFF", same ? "yes" : "NO", worst, (long long)(n1 - n0), (long long)(n2 - n1), (long long)want_calls, ok ? "ok" : "FAILED");
         bad |= !ok;
@@ -97,6 +97,6 @@ int main(int argc, char **argv)
     free(a); free(b); free(x); free(colptr); free(rowval); free(colors);
     CHECK(fd_ctx_destroy(ctx));
     hipStreamDestroy(stream);
-    printf("%s\n", bad ? "user_rowlist_client FAILED" : "user_rowlist_client ok");
+    printf("%s\n", bad ? "user_csc_client FAILED" : "user_csc_client ok");
     return bad ? 3 : 0;
 }

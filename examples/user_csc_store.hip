@@ -1,8 +1,8 @@
 /*
- * A USER's f! on a pattern with NO closed-form layout, storing the Jacobian itself through the plan's per-(row, colour)
- * destination table -- compiled apart from libfdjac, against the two public headers only:
+ * A USER's f! on a pattern with NO closed-form layout, storing the Jacobian itself, column by column, through the plan's compact
+ * copy of the pattern -- compiled apart from libfdjac, against the two public headers only:
  *
- *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -Iinclude examples/user_rowlist_store.hip -o libuser_rl.so
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -Iinclude examples/user_csc_store.hip -o libuser_rl.so
  *
  * The problem: a reaction-diffusion residual on an nx x ny grid with the NINE-point (Moore) neighbourhood,
  *     f_k(x) = sum over the 8 neighbours n of k (in the order SW, S, SE, W, E, NW, N, NE; outside the grid: 0) of 0.5 x_n
@@ -10,12 +10,12 @@
  * whose Jacobian has 9 entries per row: neither a band nor the 5-point stencil, so the library has no closed-form store
  * descriptor for it.  The user writes the residual ONCE, as a device functor  f(r, X)  that reads coordinate j as X(j):
  *   user_rl_launch        fd_f_launch: the functor on `nbatch` materialised points (X(j) = x[j])
- *   user_rl_launch_lazy   fd_f_launch_lazy registered with FD_LAZY_CAP_STORE_ROWLIST: the SAME functor inside
- *                         fd_rowlist_store_rows (include/fdjac_device.h) -- X(j) = x[j] + eps_c (color[j] == c) -- evaluates
- *                         every row at the base point and at the point of each colour that touches it, divides and stores
- *                         into nzval where the plan's table says (src/jacobians.jl:562-568 +
- *                         ext/FiniteDiffSparseArraysExt.jl:38-47 in one launch).  Any other request is declined.
- * examples/user_rowlist_client.c drives it through the C ABI (tests/test_gpu_storetable.py runs that client).
+ *   user_rl_launch_lazy   fd_f_launch_lazy registered with FD_LAZY_CAP_STORE_CSC: the SAME functor inside
+ *                         fd_csc_store_cols (include/fdjac_device.h) -- X(j) = x[j] + eps_c (color[j] == c) -- evaluates, for
+ *                         every stored entry of every column, the entry's row at the column's colour point, subtracts f(x)
+ *                         (computed once by user_rl_launch), divides and stores into nzval in storage order
+ *                         (src/jacobians.jl:562-568 + ext/FiniteDiffSparseArraysExt.jl:38-47).  Any other request is declined.
+ * examples/user_csc_client.c drives it through the C ABI (tests/test_gpu_storetable.py runs that client).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -87,18 +87,18 @@ int user_rl_launch(void *fctx, void *fx, const void *x, int64_t nbatch, int64_t 
 int user_rl_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64_t fx_stride, int64_t row_begin, int64_t row_end, void *stream)
 {
     (void)fctx; (void)fx; (void)fx_stride; (void)row_begin; (void)row_end;
-    if (!lp->store || lp->store_kind != FD_STORE_ROWLIST || lp->is_complex) return FD_LAZY_DECLINED;
-    const fd_rowlist_store st = *(const fd_rowlist_store *)lp->store;
-    if (st.elem_bytes != 8 || st.row_end <= st.row_begin) return FD_LAZY_DECLINED;
-    const unsigned g = (unsigned)((st.row_end - st.row_begin + kBlock - 1) / kBlock);
+    if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
+    const fd_csc_store st = *(const fd_csc_store *)lp->store;
+    if (st.elem_bytes != 8 || st.col_end <= st.col_begin || (lp->pts == 1 && !st.fx_base)) return FD_LAZY_DECLINED;
+    const unsigned g = (unsigned)((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const hipStream_t s = (hipStream_t)stream;
     const double *x = (const double *)lp->x, *eps = (const double *)lp->eps;
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
-#define LAUNCH(CT, MODE) hipLaunchKernelGGL((fd_rowlist_store_rows<double, CT, MODE, Moore9>), dim3(g), dim3(kBlock), 0, s, g_f, x, eps, c_lo, c_hi, st)
+#define LAUNCH(CT, MODE) hipLaunchKernelGGL((fd_csc_store_cols<double, CT, MODE, Moore9>), dim3(g), dim3(kBlock), 0, s, g_f, x, eps, c_lo, c_hi, st)
     if (st.color_bytes == 1) { if (lp->pts == 2) LAUNCH(unsigned char, 1); else LAUNCH(unsigned char, 0); }
     else { if (lp->pts == 2) LAUNCH(int, 1); else LAUNCH(int, 0); }
 #undef LAUNCH
-    g_points += (int64_t)lp->ncolors * lp->pts + (lp->diff == 2 ? 1 : 0);
+    g_points += (int64_t)lp->ncolors * lp->pts;      /* (f(x) of a forward difference was one call of user_rl_launch) */
     return hipGetLastError() == hipSuccess ? 0 : 23;
 }
 

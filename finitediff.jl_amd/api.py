@@ -614,7 +614,7 @@ class Plan:
         if not diff:
             caps &= ~4
         if not (diff if store is None else store):
-            caps &= ~(8 | 16)      # FD_LAZY_CAP_STORE and FD_LAZY_CAP_STORE_ROWLIST
+            caps &= ~(8 | 16)      # FD_LAZY_CAP_STORE and FD_LAZY_CAP_STORE_CSC
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):
@@ -720,11 +720,11 @@ class Plan:
 
 
 def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False, fingerprint=False,
-          store_table=False):
+          store_csc=False):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
     o.flags = ((_l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0) | (_l.PLAN_FINGERPRINT if fingerprint else 0) |
-               (_l.PLAN_STORE_TABLE if store_table else 0))
+               (_l.PLAN_STORE_CSC if store_csc else 0))
     if col_window is not None:
         o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
     if x_window is not None:
@@ -740,7 +740,7 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False, store_table=False):
+              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False, store_csc=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
@@ -748,7 +748,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
     o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous, fingerprint,
-              store_table and not complex_x and isinstance(J, SparseMatrixCSC))
+              store_csc and not complex_x and isinstance(J, SparseMatrixCSC))
     if complex_x:      # returntype <: Complex with forward / central differences: the library lowers it (FD_PLAN_COMPLEX_X)
         o.flags |= _l.PLAN_COMPLEX_X
     if isinstance(J, DevicePatternCSC):
@@ -757,7 +757,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
         if complex_x:
             raise NotImplementedError("complex-valued x with a device-resident pattern")
         return make_plan_csc_device(J.m, J.n, J.colptr, J.rowval, colorvec, fdtype, ctx, col_window, x_window, J.idx_base, dtype,
-                                    fingerprint=fingerprint, store_table=store_table)
+                                    fingerprint=fingerprint, store_csc=store_csc)
     h = C.c_void_p()
     cv = _i64(colorvec)
     if isinstance(J, SparseMatrixCSC) and isinstance(sparsity, SparseMatrixCSC):
@@ -815,7 +815,7 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
 
 
 def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_window=None, x_window=None,
-                         idx_base=1, dtype=np.float64, fingerprint=False, store_table=False):
+                         idx_base=1, dtype=np.float64, fingerprint=False, store_csc=False):
     """fd_plan_create_csc_device: the common-pattern CSC plan from a pattern that already lives on the device --
     `colptr`, `rowval`, `colorvec` are torch CUDA tensors (int32 or int64; colptr / rowval `idx_base`-based, colours 1..C).
     The plan is compiled by kernels; nothing crosses PCIe."""
@@ -823,7 +823,7 @@ def make_plan_csc_device(M, N, colptr, rowval, colorvec, fdtype, ctx=None, col_w
     ctx = ctx or Context.default()
     L = _l.typed(ctx.L, dtype)
     fdtype = _norm_fdtype(fdtype)
-    o = _opts(fdtype, col_window, x_window, fingerprint=fingerprint, store_table=store_table)
+    o = _opts(fdtype, col_window, x_window, fingerprint=fingerprint, store_csc=store_csc)
     for t, what in ((colptr, "colptr"), (rowval, "rowval"), (colorvec, "colorvec")):
         if not (_is_torch(t) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.int32, torch.int64)):
             raise TypeError("%s must be a contiguous int32 / int64 CUDA tensor" % what)
@@ -951,10 +951,10 @@ class JacobianCache:
         self._bound.clear()
         if len(self._plans) >= 8:
             self._plans.clear()
-        want_table = (self.lazy and isinstance(f, BuiltinF) and not self.cx and (f.lazy_caps & (_l.LAZY_CAP_STORE | _l.LAZY_CAP_STORE_ROWLIST)) != 0
-                      and self.fdtype != "complex")      # (the shim: PlanOpts(...; store_table = f can store) -- general patterns get the table)
+        want_csc = (self.lazy and isinstance(f, BuiltinF) and not self.cx and (f.lazy_caps & _l.LAZY_CAP_STORE_CSC) != 0
+                    and self.fdtype != "complex")      # (the shim: PlanOpts(...; store_csc = f can store column by column))
         plan = make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx, fingerprint=content,
-                         store_table=want_table)
+                         store_csc=want_csc)
         if self.lazy and isinstance(f, BuiltinF) and not self.cx and f.lazy_fn is not None:
             plan.set_lazy(f)          # built-in families: f! perturbs while loading / stores the Jacobian itself (shim: install_lazy!)
         self._plans[key] = (plan, sparsity, colorvec, content)     # (the arrays are kept alive: their ids stay theirs)

@@ -110,7 +110,7 @@ struct LoweredScope {
     LoweredScope() { t_lowered_cx = true; }
     ~LoweredScope() { t_lowered_cx = false; }
 };
-constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_TABLE;
+constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_CSC;
 
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {
@@ -166,7 +166,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
     // round 3 (N = 10^7 tridiagonal: 0.18 -> 0.09 ms per Jacobian, bit-identical); FDJAC_LAZY_STORE=0 keeps the hand-over
     p->store_allowed = env_int("FDJAC_LAZY_STORE", 1) != 0;
-    p->want_table = (opts->flags & FD_PLAN_STORE_TABLE) != 0;   // the per-(row, colour) destination table of a general CSC pattern
+    p->want_store_csc = (opts->flags & FD_PLAN_STORE_CSC) != 0;   // a compact device copy of the pattern for column-centric storing launches
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -1207,7 +1207,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_rl_rowptr, p->d_rl_dest, p->d_rl_ecolor};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -1263,8 +1263,8 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
                 res = device_build_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base,
                                        d_cv, color_bytes, e0, e1, &brc);
             (void)hipStreamSynchronize(ctx->stream);
-            if (res == PBR_DONE && brc == FD_OK)   // (the raw arrays are still on the device: the destination table comes from them)
-                brc = build_store_table(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base);
+            if (res == PBR_DONE && brc == FD_OK)   // (the raw arrays are still on the device: the compact copy comes from them)
+                brc = build_store_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base);
             if (d_cp) (void)hipFree(d_cp);
             if (d_rv) (void)hipFree(d_rv);
             if (d_cv) (void)hipFree(d_cv);
@@ -1308,7 +1308,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
         for (int64_t j = p->col0; j <= p->col1; ++j) colstart[(size_t)(j - p->col0)] = load_idx(colptr, idx_bytes, j) - idx_base - e0;
     }
     FD_TRY(finish_list_plan(p, col0, rows, nzc, dest, kind == K_CSC ? &colstart : nullptr));
-    if (kind == K_CSC) FD_TRY(build_store_table_host(p, colptr, rowval, idx_bytes, idx_base));
+    if (kind == K_CSC) FD_TRY(build_store_csc_host(p, colptr, rowval, idx_bytes, idx_base));
     p->nouts = 1;
     p->out_len[0] = kind == K_CSC ? (e1 - e0) : M * N;
     return FD_OK;
@@ -1441,7 +1441,7 @@ static int csc_device_impl(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipGetLastError();
     if (res == PBR_DONE) {
-        if (brc == FD_OK) brc = build_store_table(p, colptr_dev, rowval_dev, idx_bytes, idx_base);
+        if (brc == FD_OK) brc = build_store_csc(p, colptr_dev, rowval_dev, idx_bytes, idx_base);
         if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
         p->nouts = 1;
         p->out_len[0] = cp[1] - cp[0];
@@ -1898,10 +1898,10 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_EPS_NT: *value = (p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !store_active(p)) ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
     case FD_INFO_LAZY_STORE:
-        *value = (store_active(p) || store_table_active(p)) ? 1 : 0;
+        *value = (store_active(p) || store_csc_active(p)) ? 1 : 0;
         break;
-    case FD_INFO_STORE_TABLE:
-        *value = p->store_rl_ok ? p->rl_entries : 0;
+    case FD_INFO_STORE_CSC:
+        *value = p->store_csc_ok ? p->sc_entries : 0;
         break;
     case FD_INFO_LAZY_DIFF:
         *value = (p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX && p->kind != K_DENSE) ? 1 : 0;
@@ -2075,7 +2075,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (rc) return rc;
     }
     if (p->eps_mode != FD_EPS_PRECOMPUTED) p->eps2_fresh = false;
-    p->eps_nt = p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !(store_active(p) || store_table_active(p));   // (see apply_opts)
+    p->eps_nt = p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !(store_active(p) || store_csc_active(p));   // (see apply_opts)
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
         // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current
@@ -2142,7 +2142,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         // a launcher that can, hands over DIFFERENCES (f(point) - f(x), or f(plus) - f(minus)): no f(x) pass / half the f!
         // arrays, and the decompression reads one array per colour (the forward kernels with fx = 0 and, for central
         // differences, the doubled step sizes: (a - 0.0) / (2 eps) -- the bits of the plain path)
-        const bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
+        bool want_diff = p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->fdtype != FD_COMPLEX &&
                                !(p->fdtype == FD_FORWARD && !base_pending) && p->kind != K_DENSE;
         if (want_diff) { const int rc = ensure_diff_scratch(p); if (rc) return rc; }
         // the launcher stores the finished quotients into the Jacobian itself (include/fdjac_device.h) -- the exact band was
@@ -2198,34 +2198,43 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 continue;
             }
         }
-        // ... or, for ANY pattern with a valid colouring, through the plan's per-(row, colour) destination table (FD_PLAN_STORE_TABLE,
-        // fd_rowlist_store): a row-centric launcher registered with FD_LAZY_CAP_STORE_ROWLIST stores every entry its rows feed
-        if (store_table_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
+        // ... or, for ANY pattern and colouring, column by column through the compact copy of the pattern (FD_PLAN_STORE_CSC,
+        // fd_csc_store): a launcher registered with FD_LAZY_CAP_STORE_CSC evaluates the row of every stored entry at its column's
+        // colour point and stores the quotient.  Forward differences subtract f(x): the caller's f_in, or ONE plain evaluation
+        // (src/jacobians.jl:540-545) -- M + nnz row evaluations instead of (1 + C) M.
+        if (store_csc_active(p)) {
+            if (base_pending) {
+                Span sp(p, FD_STAGE_F);
+                const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
+                FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+                p->fcalls_last += 1;
+                base_pending = false;
+            }
             Span sp(p, FD_STAGE_DECOMPRESS);
-            fd_rowlist_store rl;
-            memset(&rl, 0, sizeof rl);
-            rl.out = outs[0]; rl.M = p->M; rl.N = p->N; rl.row_begin = p->rl_row0; rl.row_end = p->rl_row1;
-            rl.rowptr = p->d_rl_rowptr; rl.dest = p->d_rl_dest; rl.ecolor = p->d_rl_ecolor; rl.color = p->d_color;
-            rl.color_bytes = p->color8 ? 1 : 4; rl.C = (int)p->C; rl.elem_bytes = (int)sizeof(real_t); rl.max_row_entries = p->rl_maxrow;
+            fd_csc_store sc;
+            memset(&sc, 0, sizeof sc);
+            sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
+            sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.color = p->d_color; sc.fx_base = p->fdtype == FD_FORWARD ? fx : nullptr;
+            sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t);
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;
             lp.eps = p->d_eps;
-            lp.color_bytes = rl.color_bytes;
+            lp.color_bytes = sc.color_bytes;
             lp.c_lo = c_lo;
             lp.ncolors = B;
             lp.pts = p->pts;
             lp.nparts = 1;
-            lp.diff = (p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1;
-            lp.store = &rl;
-            lp.store_kind = FD_STORE_ROWLIST;
+            lp.diff = 1;
+            lp.store = &sc;
+            lp.store_kind = FD_STORE_CSC;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
-            FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (store table) returned %d", rc);
+            FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (column store) returned %d", rc);
             if (rc == 0) {
-                p->fcalls_last += (int64_t)B * p->pts + (lp.diff == 2 ? 1 : 0);
-                diff_base_counted = true;
+                p->fcalls_last += (int64_t)B * p->pts;
                 continue;
             }
+            if (p->fdtype == FD_FORWARD) want_diff = false;      // (declined: f(x) exists already -- plain values are handed over below)
         }
         bool diff_done = false;
         if (p->lazy_fn) {

@@ -1607,11 +1607,11 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     BuiltinF *b = (BuiltinF *)fctx;
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
     if (!has_lazy(b)) return 6;
-    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // row-centric families: the destination-table store, or nothing
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store, or nothing
         const int rc = lp->color_bytes == 1 ? rowlist_family_lazy<uint8_t>(b, lp, (hipStream_t)stream) : rowlist_family_lazy<int32_t>(b, lp, (hipStream_t)stream);
         if (rc == 0) {
             b->launches.fetch_add(1);
-            b->points.fetch_add((int64_t)lp->ncolors * lp->pts + (lp->diff == 2 ? 1 : 0));
+            b->points.fetch_add((int64_t)lp->ncolors * lp->pts);      // (f(x) of a forward difference: one plain launch, counted there)
         }
         return rc;
     }
@@ -1820,8 +1820,8 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u && caps_out, FD_ERR_ARG, "not a built-in f context");
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
-    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // row-centric families: the destination-table store only
-        *caps_out = FD_LAZY_CAP_STORE_ROWLIST;
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store only
+        *caps_out = FD_LAZY_CAP_STORE_CSC;
         return FD_OK;
     }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |

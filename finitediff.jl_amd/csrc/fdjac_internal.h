@@ -238,12 +238,10 @@ struct fd_plan {
     // ... and the 5-point stencil on an nx x ny grid (fd_stencil5_store): exact pattern + valid colouring verified
     bool store5_ok = false;
     int64_t store5_nx = 0, store5_ny = 0;
-    // ... and ANY pattern through the per-(row, colour) destination table (fd_rowlist_store; FD_PLAN_STORE_TABLE, valid colouring verified)
-    bool want_table = false, store_rl_ok = false;
-    int32_t *d_rl_rowptr = nullptr, *d_rl_dest = nullptr;
-    void *d_rl_ecolor = nullptr;
-    int64_t rl_row0 = 0, rl_row1 = 0, rl_entries = 0;
-    int rl_maxrow = 0;
+    // ... and ANY pattern, column by column, through a compact device copy of the local pattern (fd_csc_store; FD_PLAN_STORE_CSC)
+    bool want_store_csc = false, store_csc_ok = false;
+    int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
+    int64_t sc_entries = 0;
     // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded
     bool store_cr_ok = false;
     int64_t cr_nblk = 0, cr_bs = 0;
@@ -317,10 +315,11 @@ int plan_record_fingerprint(fd_plan *p, int idx_kind, const fd_pattern_arrays *s
 }
 
 // does this plan let a FD_LAZY_CAP_STORE launcher store the Jacobian itself (fd_lazy_points.store)?
-// ... through the destination table of a general pattern (any column window, colour chunk, ownership; columns without colour too)
-static inline bool store_table_active(const fd_plan *p)
+// ... column by column through the compact pattern copy of a general pattern (any colouring, column window, colour chunk, ownership;
+// columns without colour too; forward differences take f(x) from f_in or from one plain evaluation)
+static inline bool store_csc_active(const fd_plan *p)
 {
-    return p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE_ROWLIST) && p->store_rl_ok && p->kind == fdjac::K_CSC && p->fdtype != FD_COMPLEX &&
+    return p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE_CSC) && p->store_csc_ok && p->kind == fdjac::K_CSC && p->fdtype != FD_COMPLEX &&
            p->store_allowed;
 }
 static inline bool store_active(const fd_plan *p)

@@ -111,7 +111,7 @@ typedef struct fd_lazy_points {
                           /* f! output traffic for central differences, no f(x) pass for forward ones).  base_out is */
                           /* NULL then.  2 = as 1, and f(x) counts as evaluated by this call (bookkeeping only)      */
     int32_t store_kind;   /* what `store` points to (include/fdjac_device.h: FD_STORE_BAND a fd_band_store, FD_STORE_STENCIL5 a    */
-                          /* fd_stencil5_store, FD_STORE_ROWLIST a fd_rowlist_store -- any pattern, row-centric;                  */
+                          /* fd_stencil5_store, FD_STORE_CSC a fd_csc_store -- any pattern, column by column;                     */
                           /* fd_stencil5_store, FD_STORE_COLRANGE a fd_colrange_store -- BlockBandedMatrix, complex step:    */
                           /* store imag(f(point of the column's colour)[r]) / eps, is_complex = imag_only = 1); 0 when store  */
                           /* is NULL                                                                                         */
@@ -165,12 +165,12 @@ typedef struct fd_plan_opts {
                                    /* lazy launchers; fd_plan_info reports lengths in REAL numbers (2 x the complex counts).       */
                                    /* Val(:complex) with this flag is the reference's fdtype_error (FD_ERR_UNSUPPORTED).            */
 
-#define FD_PLAN_STORE_TABLE 8        /* SparseMatrixCSC common-pattern plans: also compile the per-(row, colour) destination table of       */
-                                   /* include/fdjac_device.h (fd_rowlist_store) so that a launcher registered with                      */
-                                   /* FD_LAZY_CAP_STORE_ROWLIST can store the Jacobian of ANY pattern itself.  Needs a valid colouring   */
-                                   /* (verified; an invalid one simply keeps the hand-over path) and fewer than 2^31 local entries.     */
-                                   /* 5 bytes of device memory per stored value; plans of an exact band / 5-point stencil skip it       */
-                                   /* (their closed-form descriptors are cheaper).  FD_INFO_STORE_TABLE reports whether it was built.   */
+#define FD_PLAN_STORE_CSC 8          /* SparseMatrixCSC common-pattern plans: keep a compact copy of the local pattern on the device      */
+                                   /* (fd_csc_store, include/fdjac_device.h: 4 bytes per stored entry + 4 per column) so that a launcher  */
+                                   /* registered with FD_LAZY_CAP_STORE_CSC can store the Jacobian of ANY pattern itself, column by       */
+                                   /* column.  No requirement on the colouring.  Needs fewer than 2^31 local entries; plans of an exact   */
+                                   /* band / 5-point stencil skip it (their closed-form descriptors are cheaper).  FD_INFO_STORE_CSC      */
+                                   /* reports whether it was built.                                                                      */
 #define FD_PLAN_FINGERPRINT 4        /* record 64-bit content fingerprints of the pattern / colour arrays the plan is compiled from, so  */
                                    /* that fd_plan_matches can later tell whether the caller's arrays still hold that content        */
 
@@ -290,7 +290,7 @@ enum fd_plan_info_key {
     FD_INFO_LAZY_STORE = 32,          /* 1 if a FD_LAZY_CAP_STORE launcher stores the Jacobian of this plan itself (exact band, cyclic colours; FDJAC_LAZY_STORE=0: never) */
     FD_INFO_LAZY_DIFF = 29,           /* 1 if the plan asks a FD_LAZY_CAP_DIFF launcher for differences (FDJAC_LAZY_DIFF=0: never) */
     FD_INFO_BUILT_ON_DEVICE = 27,     /* 1 if the pattern was compiled by the device plan builder */
-    FD_INFO_STORE_TABLE = 33          /* number of entries of the per-(row, colour) destination table (FD_PLAN_STORE_TABLE), 0 = none */
+    FD_INFO_STORE_CSC = 33            /* number of local entries of the compact pattern copy of FD_PLAN_STORE_CSC, 0 = none */
 };
 /* Kernel variants are chosen when the plan is created (the FDJAC_* environment switches of DESIGN.md section 5 are
    read there, not per process and not per launch -- except FDJAC_COLRANGE_VEC, which only re-vectorises the same work);
@@ -321,8 +321,8 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* the row-strip schedule that needed it was measured slower and removed)                  */
 #define FD_LAZY_CAP_DIFF 4        /* honours fd_lazy_points.diff: writes f(point) - f(x) / f(plus) - f(minus) itself         */
 #define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store: f!'s launch stores the Jacobian of a verified exact band itself           */
-#define FD_LAZY_CAP_STORE_ROWLIST 16   /* honours fd_lazy_points.store with store_kind = FD_STORE_ROWLIST (fd_rowlist_store): the launch stores */
-                                  /* the Jacobian of ANY pattern through the plan's per-(row, colour) destination table (FD_PLAN_STORE_TABLE) */
+#define FD_LAZY_CAP_STORE_CSC 16  /* honours fd_lazy_points.store with store_kind = FD_STORE_CSC (fd_csc_store): the launch stores the Jacobian  */
+                                  /* of ANY pattern column by column through the plan's compact copy of the pattern (FD_PLAN_STORE_CSC)       */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
@@ -361,7 +361,7 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
 /* A residual with ANY sparsity pattern (FD_F_SPARSE): given the CSC pattern of its Jacobian (M x N, host arrays, the caller's
    index width and base), f_r(x) = sum over the stored entries (r, j) of row r, by ascending j, of w(r, j) * phi(x_j), summed left
    to right, with phi(t) = t + 0.25 t^2 and w(r, j) = 1 + 0.125 ((r + 3 j) mod 8) (0-based r, j).  The launcher keeps the
-   transposed pattern on the device.  Its lazy launcher stores the Jacobian through the destination table (FD_LAZY_CAP_STORE_ROWLIST). */
+   transposed pattern on the device.  Its lazy launcher stores the Jacobian column by column (FD_LAZY_CAP_STORE_CSC). */
 int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes, int idx_base,
                                fd_f_launch *fn_out, void **fctx_out);
 int fd_builtin_f_destroy(void *fctx);

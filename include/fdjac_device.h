@@ -151,32 +151,36 @@ typedef struct fd_colrange_store {
     int bl, bu;
 } fd_colrange_store;
 
-/* ---- ANY SparseMatrixCSC pattern with a VALID colouring: the per-(row, colour) destination table -----------------------------
- * The three descriptors above need a closed form for "where does the entry of row r and colour c live".  For a general pattern
- * the plan tabulates it (fd_plan_opts.flags & FD_PLAN_STORE_TABLE): the stored entries of the local column range, grouped BY ROW
- * (the transpose of the CSC pattern, rows ascending, a row's entries by ascending column), each with the 0-based colour of its
- * column and its position in nzval.  A valid colouring (the plan verifies it: the columns of a row's entries differ in colour)
- * means the colour-c point, seen from row r, differs from x in exactly the one coordinate that entry's column stands for -- so
- *     for every entry e of row r:   nzval[dest[e]] = (f(x + eps_c m_c)[r] - f(x)[r]) / eps_c,   c = ecolor[e]
- * is src/jacobians.jl:565-568 + ext/FiniteDiffSparseArraysExt.jl:38-47 for that entry, and a ROW-centric kernel -- one that has
- * row r's inputs at hand anyway -- can do it for all of the row's entries: 5 bytes of table per stored value instead of the
- * 16 (8 written + 8 read back) of the f! -> decompression hand-off.  Entries of columns without a colour hold ecolor = "none"
- * (0xFF / -1): their value is 0 (fill_matrix!, src/jacobians.jl:530-532).  store_kind = FD_STORE_ROWLIST; handed to launchers
- * registered with FD_LAZY_CAP_STORE_ROWLIST. */
-typedef struct fd_rowlist_store {
+/* ---- ANY SparseMatrixCSC pattern, ANY colouring: the column-centric store -------------------------------------------------------
+ * The three descriptors above need a closed form for "where does the entry of row r and colour c live".  A general pattern has
+ * none -- but the reference's decompression (ext/FiniteDiffSparseArraysExt.jl:38-47) never asks that question: it walks the
+ * stored entries of every column j of the current colour and assigns  nzval[q] = (f(x + eps_c m_c)[r] - f(x)[r]) / eps_c  for
+ * q = (r, j), c = colorvec[j].  A kernel that can evaluate ONE row of the residual at a colour's point does exactly that, column by
+ * column: thread j walks column j's entries, evaluates each entry's row at the point of ITS colour and stores -- the values land in
+ * storage order (a thread's entries are contiguous in nzval, neighbouring threads' runs follow each other: the L2 merges them into
+ * whole lines), no hand-off arrays, and no requirement on the colouring at all (the point is formed for the whole colour, so an
+ * invalid colouring gives what the reference gives).  The plan keeps a compact copy of the local pattern for it
+ * (fd_plan_opts.flags & FD_PLAN_STORE_CSC: 4 bytes per stored entry + 4 per column) and hands this descriptor
+ * (store_kind = FD_STORE_CSC) to launchers registered with FD_LAZY_CAP_STORE_CSC.  Forward differences: f(x) is evaluated ONCE by
+ * the plain launcher (or is the caller's f_in) and arrives as `fx_base`; the launch evaluates one row per stored entry
+ * (central: two) -- M + nnz row evaluations instead of the (1 + C) M of the colour-by-colour loop.
+ * (Measured alternative, round 4: a ROW-centric kernel with a per-(row, colour) destination table needs a valid colouring and
+ * scatters 8-byte stores over nzval -- every one a 32-byte read-modify-write at the memory side: 1.8 GB written for 446 MB of
+ * values on the 200^3 7-point pattern, profiles/r04_g_rowcentric_store_pmc_*.md.) */
+typedef struct fd_csc_store {
     void *out;                     /* nzval of the local column range, device memory */
     long long M, N;
-    long long row_begin, row_end;  /* the rows that hold a local entry lie in [row_begin, row_end) */
-    const int *rowptr;             /* device, row_end - row_begin + 1 offsets: entries [rowptr[r - row_begin], rowptr[r - row_begin + 1]) belong to row r */
-    const int *dest;               /* device, per entry: index into out */
-    const void *ecolor;            /* device, per entry: 0-based colour of its column, color_bytes each; "none" = 0xFF / -1 */
-    const void *color;             /* device: 0-based colour of every column (all N), color_bytes each -- what a kernel needs to form the points */
+    long long col_begin, col_end;  /* local column range */
+    const int *colptr;             /* device, col_end - col_begin + 1 offsets into out / rowval: column j holds [colptr[j - col_begin], colptr[j - col_begin + 1]) */
+    const int *rowval;             /* device, per local entry: 0-based row */
+    const void *color;             /* device: 0-based colour of every column (all N), color_bytes each; "none" = 0xFF / -1 */
+    const void *fx_base;           /* device: f(x) (M elements) for forward differences; NULL for central differences */
     int color_bytes, C;
     int elem_bytes;
-    int max_row_entries;           /* longest row (a kernel may size its per-row staging by it) */
-} fd_rowlist_store;
+    int reserved0;
+} fd_csc_store;
 
-enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_ROWLIST = 4 };   /* what fd_lazy_points.store points to */
+enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4 };   /* what fd_lazy_points.store points to */
 
 #if defined(__HIPCC__) && defined(__cplusplus)
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -394,53 +398,52 @@ template <typename T> __device__ inline void fd_colrange_emit(const fd_colrange_
     if (k < 0 || k >= d->row_count[jj]) return;
     ((T *)d->out)[d->dest[jj] + k] = value;
 }
-/* ---- fd_rowlist_store: the ten-line storing launch for ANY residual written row by row --------------------------------------
+/* ---- fd_csc_store: the ten-line storing launch for ANY residual that can evaluate one row ---------------------------------------
  * `F` is a callable  T f(long long r, const P &X)  returning row r of the residual at the point X, where X(j) yields coordinate j
- * (call X(j) for every coordinate the row reads, in whatever order the residual's arithmetic needs -- the kernel evaluates the
- * row once at x and once (central: twice) per entry of the row, each time at the colour's own point x +- eps_c m_c, formed
- * exactly as the reference forms it: x[j] + eps_c * (color[j] == c), i.e. x[j] + 0.0 elsewhere).  One thread per row.
- *     hipLaunchKernelGGL((fd_rowlist_store_rows<double, unsigned char, 0, F>), grid, 256, 0, stream, f, x, eps, c_lo, c_hi, st);
- * MODE 0: forward, 1: central.  Colours outside [c_lo, c_hi) are skipped (colour chunks / ownership); entries without a colour
- * are written as 0 when c_lo == 0.  This is the simple form (every evaluation re-reads its inputs through the caches); the
- * built-in families keep a row's inputs in registers (csrc/fdjac_rowlist_f.hip). */
+ * (call X(j) for every coordinate the row reads, in the order the residual's arithmetic needs).  The kernel hands it the colour's
+ * own point, formed exactly as the reference forms it: x[j] + eps_c * (color[j] == c), i.e. x[j] + 0.0 elsewhere (minus point of a
+ * central difference: x[j] - eps_c * ..., x[j] - 0.0 == x[j] elsewhere).  One thread per local column.
+ *     hipLaunchKernelGGL((fd_csc_store_cols<double, unsigned char, 0, F>), grid, 256, 0, stream, f, x, eps, c_lo, c_hi, st);
+ * MODE 0: forward (st.fx_base = f(x)), 1: central.  Columns whose colour lies outside [c_lo, c_hi) are skipped (colour chunks /
+ * ownership); columns without a colour are written as 0 when c_lo == 0 (fill_matrix!, src/jacobians.jl:530-532). */
 template <typename T, typename CT> struct fd_colour_point {
     const T *x;
     const CT *color;
-    int c;          /* 0-based colour of the point, -1: the base point x */
+    int c;          /* 0-based colour of the point */
     T e;            /* step */
     int minus;      /* 0: the plus point x + e m (x + 0.0 elsewhere); 1: the minus point x - e m (x - 0.0 == x elsewhere) */
     __device__ T operator()(long long j) const
     {
         const T v = x[j];
-        if (c < 0) return v;
         const bool hit = (int)color[j] == c;
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
 };
 template <typename T, typename CT, int MODE, class F>
-__global__ void __launch_bounds__(256) fd_rowlist_store_rows(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi,
-                                                             fd_rowlist_store st)
+__global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
-    const long long r = st.row_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= st.row_end) return;
-    const int e0 = st.rowptr[r - st.row_begin], e1 = st.rowptr[r - st.row_begin + 1];
-    if (e0 == e1) return;
+    const long long j = st.col_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= st.col_end) return;
+    const int a = st.colptr[j - st.col_begin], b = st.colptr[j - st.col_begin + 1];
     const CT *color = (const CT *)st.color;
-    const CT *ecolor = (const CT *)st.ecolor;
-    const int none = (int)(CT)(-1);
-    fd_colour_point<T, CT> P = {x, color, -1, (T)0, 0};
-    T base = (T)0;
-    if (MODE == 0) base = f(r, P);
-    for (int e = e0; e < e1; ++e) {
-        const int c = (int)ecolor[e];
-        if (c == none) { if (c_lo == 0) ((T *)st.out)[st.dest[e]] = (T)0; continue; }
-        if (c < c_lo || c >= c_hi) continue;
-        const T h = eps[c];
-        P.c = c; P.e = h; P.minus = 0;
+    const int c = (int)color[j];
+    T *out = (T *)st.out;
+    if (c == (int)(CT)(-1)) {                        /* "none" is all-ones in CT */
+        if (c_lo == 0) for (int q = a; q < b; ++q) out[q] = (T)0;
+        return;
+    }
+    if (c < c_lo || c >= c_hi) return;
+    const T h = eps[c];
+    const T *base = (const T *)st.fx_base;
+    fd_colour_point<T, CT> P = {x, color, c, h, 0};
+    for (int q = a; q < b; ++q) {
+        const long long r = st.rowval[q];
+        P.minus = 0;
         const T vp = f(r, P);
-        T vm = base, div = h;
+        T vm, div = h;
         if (MODE == 1) { P.minus = 1; vm = f(r, P); div = 2 * h; }
-        ((T *)st.out)[st.dest[e]] = (vp - vm) / div;
+        else vm = base[r];
+        out[q] = (vp - vm) / div;
     }
 }
 #endif /* __HIPCC__ && __cplusplus */

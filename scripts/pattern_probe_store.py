@@ -34,7 +34,7 @@ def main():
         outs = {}
         for path in ("store", "handover"):
             t0 = time.perf_counter()
-            plan = fd.make_plan(J, J, colors, fdtype, store_table=(path == "store"))
+            plan = fd.make_plan(J, J, colors, fdtype, store_csc=(path == "store"))
             torch.cuda.synchronize()
             build_ms = (time.perf_counter() - t0) * 1e3
             if path == "store":
@@ -56,7 +56,7 @@ def main():
             torch.cuda.synchronize()
             tot = plan.timing_samples("total")
             plan.enable_timing(0)
-            res[path] = (float(np.median(tot)) * 1e3, st, nl, build_ms, int(plan.info(fd.lib.INFO_LAZY_STORE)), int(plan.info(fd.lib.INFO_STORE_TABLE)))
+            res[path] = (float(np.median(tot)) * 1e3, st, nl, build_ms, int(plan.info(fd.lib.INFO_LAZY_STORE)), int(plan.info(fd.lib.INFO_STORE_CSC)))
             outs[path] = out
             del plan, call
         same = bool(torch.equal(outs["store"].view(torch.int64), outs["handover"].view(torch.int64)))

@@ -1,5 +1,5 @@
-"""The storing launch for GENERAL SparseMatrixCSC patterns (round 4): the plan's per-(row, colour) destination table
-(FD_PLAN_STORE_TABLE, fd_rowlist_store in include/fdjac_device.h) and the row-centric built-in families that store through it
+"""The storing launch for GENERAL SparseMatrixCSC patterns (round 4): the plan's compact copy of the pattern (FD_PLAN_STORE_CSC,
+fd_csc_store in include/fdjac_device.h) and the functor families that store column by column through it
 (FD_F_LAP7: 3-D 7-point stencil; FD_F_SPARSE: any pattern).  Every case is checked three ways: bit for bit against the hand-over
 path (materialised points -> plain f! -> k_decompress_*: the same operations on the same operands), against the CPU oracle within
 the stated tolerance, and the number of f! evaluations against the reference's (1 + C / 2C).
@@ -74,8 +74,8 @@ def _tol_ok(g, c, eps_min, fscale, what, rtol=1e-6):
 
 
 def _run_pair(J, colors, fdtype, f, x, nnz, **plan_kw):
-    """The same Jacobian through the table store and through the hand-over path; returns (stored, handed over, plans)."""
-    p_store = fd.make_plan(J, J, colors, fdtype, store_table=True, **plan_kw)
+    """The same Jacobian through the column-centric store and through the hand-over path; returns (stored, handed over, plans)."""
+    p_store = fd.make_plan(J, J, colors, fdtype, store_csc=True, **plan_kw)
     p_store.set_lazy(f)
     p_hand = fd.make_plan(J, J, colors, fdtype, **plan_kw)
     a = _dev(np.full(nnz, np.nan))
@@ -90,18 +90,18 @@ def _run_pair(J, colors, fdtype, f, x, nnz, **plan_kw):
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("shape", [(20, 20, 20), (7, 5, 3), (33, 4, 9), (1, 1, 40), (64, 64, 2)])
-def test_lap7_table_store_bit_identical_and_oracle(oracle, fdtype, shape):
+def test_lap7_column_store_bit_identical_and_oracle(oracle, fdtype, shape):
     nx, ny, nz = shape
     N = nx * ny * nz
     colptr, rowval, colors = stencil7_csc(nx, ny, nz)
     x = np.random.default_rng(nx + 10 * ny + 100 * nz).random(N)
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     f = fd.BuiltinF("lap7", nx, ny, nz)
-    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_ROWLIST
+    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_CSC
     a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
     C = int(colors.max())
-    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
-    assert ph.info(fd.lib.INFO_STORE_TABLE) == 0 and ph.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert ph.info(fd.lib.INFO_STORE_CSC) == 0 and ph.info(fd.lib.INFO_LAZY_STORE) == 0
     assert calls[0] == calls[1] == (C + 1 if fdtype == "forward" else 2 * C)
     assert not torch.isnan(a).any()
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
@@ -128,7 +128,7 @@ def _random_pattern(M, N, per_col, reach, seed):
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("case", [(300, 300, 4, 9, 1), (257, 411, 3, 20, 2), (411, 257, 5, 6, 3), (5000, 5000, 6, 300, 4), (40, 40, 1, 0, 5)])
-def test_sparse_family_table_store_bit_identical_and_oracle(oracle, fdtype, case):
+def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, case):
     M, N, per_col, reach, seed = case
     colptr, rowval = _random_pattern(M, N, per_col, reach, seed)
     J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
@@ -137,7 +137,7 @@ def test_sparse_family_table_store_bit_identical_and_oracle(oracle, fdtype, case
     f = fd.BuiltinF.sparse(M, N, colptr, rowval)
     a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
     C = int(colors.max())
-    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
     assert calls[0] == calls[1] == (C + 1 if fdtype == "forward" else 2 * C)
     assert not torch.isnan(a).any()
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
@@ -151,9 +151,9 @@ def test_sparse_family_table_store_bit_identical_and_oracle(oracle, fdtype, case
     assert np.max(np.abs(a.cpu().numpy() - want)) < (5e-6 if fdtype == "forward" else 5e-8) * 10
 
 
-def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
-    # column windows (multi-GPU shards), colour chunks, colour ownership, columns without a colour, an INVALID colouring (the table
-    # is not built: the hand-over path serves the plan) -- always the bits of the hand-over path
+def test_column_store_windows_chunks_uncoloured_and_invalid_colourings():
+    # column windows (multi-GPU shards), colour chunks, colour ownership, columns without a colour, an INVALID colouring, a dense
+    # row -- always the bits of the hand-over path
     M = N = 4000
     colptr, rowval = _random_pattern(M, N, 5, 40, 11)
     J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
@@ -166,15 +166,15 @@ def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
     ph.jacobian(f, x, [full])
     # column windows
     for (c0, c1) in [(0, 1000), (1000, 1001), (1234, 3999), (3999, 4000)]:
-        p = fd.make_plan(J, J, colors, "forward", store_table=True, col_window=(c0, c1))
+        p = fd.make_plan(J, J, colors, "forward", store_csc=True, col_window=(c0, c1))
         p.set_lazy(f)
         n = int(colptr[c1] - colptr[c0])
         out = _dev(np.full(n, np.nan))
         p.jacobian(f, x, [out])
-        assert p.info(fd.lib.INFO_STORE_TABLE) == n and (n == 0 or p.info(fd.lib.INFO_LAZY_STORE) == 1)
+        assert p.info(fd.lib.INFO_STORE_CSC) == n and (n == 0 or p.info(fd.lib.INFO_LAZY_STORE) == 1)
         assert torch.equal(out.view(torch.int64), full[int(colptr[c0] - 1):int(colptr[c1] - 1)].view(torch.int64))
     # colour chunks (a scratch cap that holds 2 colours at a time) and colour ownership
-    p = fd.make_plan(J, J, colors, "central", store_table=True, scratch_bytes=2 * 2 * 2 * N * 8 + 4096)
+    p = fd.make_plan(J, J, colors, "central", store_csc=True, scratch_bytes=2 * 2 * 2 * N * 8 + 4096)
     p.set_lazy(f)
     pc = fd.make_plan(J, J, colors, "central")
     o1, o2 = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
@@ -183,7 +183,7 @@ def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
     assert p.info(fd.lib.INFO_NCHUNKS) > 1 and torch.equal(o1.view(torch.int64), o2.view(torch.int64))
     acc = torch.zeros(rowval.size, dtype=torch.float64, device="cuda")
     for (a0, a1) in [(0, 2), (2, C)]:
-        po = fd.make_plan(J, J, colors, "forward", store_table=True, color_range=(a0, a1))
+        po = fd.make_plan(J, J, colors, "forward", store_csc=True, color_range=(a0, a1))
         po.set_lazy(f)
         part = torch.zeros_like(acc)
         po.jacobian(f, x, [part])
@@ -193,25 +193,26 @@ def test_table_store_windows_chunks_uncoloured_and_invalid_colourings():
     c2 = colors.copy()
     c2[[5, 77, 1999]] = 0
     a, b, ps, _ph, _calls = _run_pair(J, c2, "forward", f, x, rowval.size)
-    assert ps.info(fd.lib.INFO_STORE_TABLE) == rowval.size and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and torch.equal(a.view(torch.int64), b.view(torch.int64))
     for j in (5, 77, 1999):
         assert torch.all(a[int(colptr[j] - 1):int(colptr[j + 1] - 1)] == 0)
-    # a dense row (more entries than the table's per-row limit): no table, the hand-over path
+    # a dense row
     cpd, rvd = _random_pattern(300, 300, 3, 5, 21)
     dense = np.zeros((300, 300)); dense[(rvd - 1), P.csc_cols(cpd) - 1] = 1; dense[7, :] = 1
     cpd, rvd = P.csc_from_dense(dense)
     Jd = fd.SparseMatrixCSC(300, 300, cpd, rvd, None)
     fdn = fd.BuiltinF.sparse(300, 300, cpd, rvd)
     a, b, ps, _ph, _calls = _run_pair(Jd, fd.matrix_colors(Jd), "forward", fdn, _dev(np.random.default_rng(5).random(300) + 0.1), rvd.size)
-    assert ps.info(fd.lib.INFO_STORE_TABLE) == 0 and torch.equal(a.view(torch.int64), b.view(torch.int64))
-    # an invalid colouring (two columns of one row share a colour): no table, the results of the hand-over path (whatever they are)
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rvd.size and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    # an INVALID colouring (every column the same colour): the column-centric store forms the whole colour's point, as the
+    # reference does -- the same (meaningless) values as the hand-over path, bit for bit
     bad = np.ones(N, dtype=np.int64)
     a, b, ps, _ph, _calls = _run_pair(J, bad, "forward", f, x, rowval.size)
-    assert ps.info(fd.lib.INFO_STORE_TABLE) == 0 and ps.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
 
 
-def test_table_store_float32_device_pattern_and_dropin():
+def test_column_store_float32_device_pattern_and_dropin():
     nx, ny, nz = 24, 10, 6
     N = nx * ny * nz
     colptr, rowval, colors = stencil7_csc(nx, ny, nz)
@@ -220,7 +221,7 @@ def test_table_store_float32_device_pattern_and_dropin():
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     f32 = fd.BuiltinF("lap7", nx, ny, nz, dtype=np.float32)
     x32 = _dev(x64, torch.float32)
-    p1 = fd.make_plan(J, J, colors, "central", store_table=True, dtype=np.float32)
+    p1 = fd.make_plan(J, J, colors, "central", store_csc=True, dtype=np.float32)
     p1.set_lazy(f32)
     p2 = fd.make_plan(J, J, colors, "central", dtype=np.float32)
     o1 = torch.full((rowval.size,), float("nan"), dtype=torch.float32, device="cuda")
@@ -228,28 +229,28 @@ def test_table_store_float32_device_pattern_and_dropin():
     p1.jacobian(f32, x32, [o1])
     p2.jacobian(f32, x32, [o2])
     assert p1.info(fd.lib.INFO_LAZY_STORE) == 1 and torch.equal(o1.view(torch.int32), o2.view(torch.int32))
-    # a device-resident pattern (Int32, as rocSPARSE holds it): the table is compiled from the device arrays
+    # a device-resident pattern (Int32, as rocSPARSE holds it): the pattern copy is made from the device arrays
     f = fd.BuiltinF("lap7", nx, ny, nz)
     x = _dev(x64)
     nz_d = _dev(np.full(rowval.size, np.nan))
     Jd = fd.DevicePatternCSC(N, N, torch.as_tensor(colptr.astype(np.int32), device="cuda"), torch.as_tensor(rowval.astype(np.int32), device="cuda"), nz_d)
     cache = fd.JacobianCache(x, "forward", colorvec=torch.as_tensor(colors.astype(np.int32), device="cuda"), sparsity=Jd)
-    fd.finite_difference_jacobian_b(Jd, f, x, cache)          # the drop-in call asks for the table by itself (f can store)
-    assert cache.last_plan.info(fd.lib.INFO_STORE_TABLE) == rowval.size and cache.last_plan.info(fd.lib.INFO_LAZY_STORE) == 1
+    fd.finite_difference_jacobian_b(Jd, f, x, cache)          # the drop-in call asks for the pattern copy by itself (f can store)
+    assert cache.last_plan.info(fd.lib.INFO_STORE_CSC) == rowval.size and cache.last_plan.info(fd.lib.INFO_LAZY_STORE) == 1
     ref = _dev(np.full(rowval.size, np.nan))
     fd.make_plan(J, J, colors, "forward").jacobian(f, x, [ref])
     assert torch.equal(nz_d.view(torch.int64), ref.view(torch.int64))
-    # the complex step has no table store: the family's plain launcher on materialised complex points
+    # the complex step has no column store: the family's plain launcher on materialised complex points
     Jc = fd.SparseMatrixCSC(N, N, colptr, rowval, _dev(np.full(rowval.size, np.nan)))
     fd.finite_difference_jacobian_b(Jc, f, x, "complex", colorvec=colors)
     assert torch.allclose(Jc.nzval, ref, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("shape", [(61, 47), (3, 3), (200, 5)])
-def test_user_kernel_stores_a_general_pattern_through_the_table(tmp_path, shape):
-    # examples/user_rowlist_store.hip: a USER's residual on the nine-point stencil, written once as a device functor f(r, X) and
-    # compiled apart from libfdjac against the two public headers; inside fd_rowlist_store_rows (include/fdjac_device.h) it stores
-    # the Jacobian through the plan's destination table.  examples/user_rowlist_client.c (plain C) checks: table built and used,
+def test_user_kernel_stores_a_general_pattern_column_by_column(tmp_path, shape):
+    # examples/user_csc_store.hip: a USER's residual on the nine-point stencil, written once as a device functor f(r, X) and
+    # compiled apart from libfdjac against the two public headers; inside fd_csc_store_cols (include/fdjac_device.h) it stores
+    # the Jacobian column by column.  examples/user_csc_client.c (plain C) checks: pattern copy built and used,
     # bit-identical to the same plan through the user's plain launcher + the library's decompression, analytic values, f! counts.
     import os
     import subprocess
@@ -257,12 +258,12 @@ def test_user_kernel_stores_a_general_pattern_through_the_table(tmp_path, shape)
     inc, libdir = os.path.join(root, "include"), os.path.join(root, "finitediff.jl_amd", "lib")
     user_so = str(tmp_path / "libuser_rl.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
-                           os.path.join(root, "examples", "user_rowlist_store.hip"), "-o", user_so])
+                           os.path.join(root, "examples", "user_csc_store.hip"), "-o", user_so])
     assert "libfdjac" not in subprocess.run(["ldd", user_so], capture_output=True, text=True).stdout
-    exe = str(tmp_path / "user_rowlist_client")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_rowlist_client.c"), "-o", exe,
+    exe = str(tmp_path / "user_csc_client")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_csc_client.c"), "-o", exe,
                            "-L" + str(tmp_path), "-luser_rl", "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
                            "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "user_rowlist_client ok" in out.stdout and "FAILED" not in out.stdout
+    assert "user_csc_client ok" in out.stdout and "FAILED" not in out.stdout
