@@ -1705,7 +1705,7 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
     case FD_F_NONSQUARE: b->M = b->prm[0]; b->N = 2 * b->prm[0]; break;
     case FD_F_LAP7:
         b->M = b->N = b->prm[0] * b->prm[1] * b->prm[2];
-        if (b->prm[0] * b->prm[1] >= ((int64_t)1 << 31) || b->M / (b->prm[0] * b->prm[1]) >= ((int64_t)1 << 31)) {
+        if (b->prm[0] * b->prm[1] >= ((int64_t)1 << 31) || b->M >= ((int64_t)1 << 31)) {      // (32-bit grid arithmetic in the kernels)
             delete b;
             set_error("grid too large for the 7-point family");
             return FD_ERR_ARG;

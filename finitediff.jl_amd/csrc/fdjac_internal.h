@@ -242,6 +242,7 @@ struct fd_plan {
     bool want_store_csc = false, store_csc_ok = false;
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
     int64_t sc_entries = 0;
+    bool sc_valid = false;         //   colorvec verified to be a valid colouring of the local pattern (kernels may perturb one coordinate)
     // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded
     bool store_cr_ok = false;
     int64_t cr_nblk = 0, cr_bs = 0;

@@ -18,20 +18,95 @@ template <typename T> struct PlainPoint {      // a materialised point
 };
 
 // ---- FD_F_LAP7 -----------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T lap7_row(T c, T d, T s, T w, T e, T n, T u)
+{
+    return ((((((d + s) + w) + e) + n) + u) - kSix * c) + (c * c) * e;
+}
 struct Lap7F {
     int nx, ny, nz;
+    uint64_t m_pl, m_nx;       // fd_magic31(nx * ny), fd_magic31(nx): exact 32-bit divisions by one multiply (N < 2^31)
     template <typename T, class P> __device__ __forceinline__ T row(int64_t k, const P &X) const
     {
-        const int64_t pl = (int64_t)nx * ny;
-        const int l = (int)(k / pl), rem = (int)(k - (int64_t)l * pl), j = rem / nx, i = rem - j * nx;
+        const int pl = nx * ny;
+        const int l = (int)fd_div31((uint32_t)k, m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, m_nx), i = rem - j * nx;
         const T z = zero_of<T>();
         const T c = X(k);
         const T d = l > 0 ? X(k - pl) : z, s = j > 0 ? X(k - nx) : z, w = i > 0 ? X(k - 1) : z, e = i < nx - 1 ? X(k + 1) : z,
                 n = j < ny - 1 ? X(k + nx) : z, u = l < nz - 1 ? X(k + pl) : z;
-        return ((((((d + s) + w) + e) + n) + u) - kSix * c) + (c * c) * e;
+        return lap7_row<T>(c, d, s, w, e, n, u);
     }
     template <class P> __device__ __forceinline__ real_t operator()(long long k, const P &X) const { return row<real_t>(k, X); }
 };
+
+// The column-centric storing launch of the 7-point family with the column's neighbourhood IN REGISTERS: thread k loads the 25
+// coordinates within L1 distance 2 of grid point k once (what the seven rows k, k +- 1, k +- nx, k +- nx ny read; 0 outside the
+// grid, as the residual defines it), and evaluates every stored entry whose row is one of those seven from the window, at
+// x + eps e_k (valid colouring: fd_csc_store.valid_coloring) -- 25 loads per column instead of 7 per evaluated row.  Entries of any
+// other row (a pattern that is a superset of the stencil) go through the functor.  Same operands, same operations: same bits.
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
+{
+    const int64_t k = st.col_begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= st.col_end) return;
+    const int a = st.colptr[k - st.col_begin], b = st.colptr[k - st.col_begin + 1];
+    const int c = (int)((const CT *)st.color)[k];
+    real_t *out = (real_t *)st.out;
+    if (c == (int)(CT)(-1)) {
+        if (c_lo == 0) for (int q = a; q < b; ++q) out[q] = 0;
+        return;
+    }
+    if (c < c_lo || c >= c_hi) return;
+    const real_t h = eps[c];
+    const int nx = f.nx, ny = f.ny, nz = f.nz, pl = nx * ny;
+    const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
+    // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
+    auto ld = [&](int dl, int dj, int di) -> real_t {
+        const bool ok = (unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz;
+        return ok ? x[k + (int64_t)dl * pl + dj * nx + di] : (real_t)0;
+    };
+    const real_t c0 = ld(0, 0, 0);
+    const real_t xm1 = ld(0, 0, -1), xp1 = ld(0, 0, 1), xm2 = ld(0, 0, -2), xp2 = ld(0, 0, 2);
+    const real_t ym1 = ld(0, -1, 0), yp1 = ld(0, 1, 0), ym2 = ld(0, -2, 0), yp2 = ld(0, 2, 0);
+    const real_t zm1 = ld(-1, 0, 0), zp1 = ld(1, 0, 0), zm2 = ld(-2, 0, 0), zp2 = ld(2, 0, 0);
+    const real_t xmym = ld(0, -1, -1), xpym = ld(0, -1, 1), xmyp = ld(0, 1, -1), xpyp = ld(0, 1, 1);
+    const real_t xmzm = ld(-1, 0, -1), xpzm = ld(-1, 0, 1), xmzp = ld(1, 0, -1), xpzp = ld(1, 0, 1);
+    const real_t ymzm = ld(-1, -1, 0), ypzm = ld(-1, 1, 0), ymzp = ld(1, -1, 0), ypzp = ld(1, 1, 0);
+    const real_t *base = (const real_t *)st.fx_base;
+    const real_t z0 = 0;
+    for (int q = a; q < b; ++q) {
+        const int r = st.rowval[q], d = r - (int)k;
+        real_t vp, vm = 0;
+        // the row's seven inputs (centre, down, south, west, east, north, up) with coordinate k replaced by P
+#define FD_ROWS(P, Z)                                                                                                                      \
+        (d == 0     ? lap7_row<real_t>(P, zm1 Z, ym1 Z, xm1 Z, xp1 Z, yp1 Z, zp1 Z)                                                            \
+         : d == -1  ? lap7_row<real_t>(xm1 Z, xmzm Z, xmym Z, xm2 Z, P, xmyp Z, xmzp Z)                                                        \
+         : d == 1   ? lap7_row<real_t>(xp1 Z, xpzm Z, xpym Z, P, xp2 Z, xpyp Z, xpzp Z)                                                        \
+         : d == -nx ? lap7_row<real_t>(ym1 Z, ymzm Z, ym2 Z, xmym Z, xpym Z, P, ymzp Z)                                                        \
+         : d == nx  ? lap7_row<real_t>(yp1 Z, ypzm Z, P, xmyp Z, xpyp Z, yp2 Z, ypzp Z)                                                        \
+         : d == -pl ? lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, P)                                                        \
+                    : lap7_row<real_t>(zp1 Z, P, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z))
+        const bool known = d == 0 || ((d == -1 || d == 1) && nx > 1) || ((d == -nx || d == nx) && nx > 1 && ny > 1 && pl != nx) || d == -pl || d == pl;
+        // (degenerate grids -- nx == 1, ny == 1: offsets coincide -- and rows that are not stencil neighbours: the functor)
+        const bool regular = known && nx > 2 && ny > 2 && (nz > 2 || nz == 1) && pl != nx && nx != 1;
+        if (regular && (d == 0 || (d == -1 && i > 0) || (d == 1 && i < nx - 1) || (d == -nx && j > 0) || (d == nx && j < ny - 1) || (d == -pl && l > 0) ||
+                        (d == pl && l < nz - 1))) {
+            // (the plus point holds x + 0.0 at its unperturbed coordinates, the minus point x - 0.0 == x: literally, for the -0.0 case;
+            //  a coordinate outside the grid is the constant 0 of the residual, not a coordinate: inside FD_IN it stays 0 + 0.0 == 0)
+            vp = FD_ROWS(c0 + h, +z0);
+            if (MODE == 1) vm = FD_ROWS(c0 - h, );
+        } else {
+            fd_column_point<real_t> X = {x, k, h, 0};
+            vp = f(r, X);
+            if (MODE == 1) { X.minus = 1; vm = f(r, X); }
+        }
+#undef FD_ROWS
+        real_t div = h;
+        if (MODE == 1) div = 2 * h;
+        else vm = base[r];
+        out[q] = sub_exact(vp, vm) / div;
+    }
+}
 
 // ---- FD_F_SPARSE ----------------------------------------------------------------------------------------------------------------
 struct SparseF {
@@ -66,7 +141,7 @@ static int rowlist_family_launch(BuiltinF *b, void *fx, const void *x, int64_t n
 {
     const dim3 g((unsigned)((r1 - r0 + kBlock - 1) / kBlock), (unsigned)nbatch, 1);
     if (b->family == FD_F_LAP7) {
-        const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2]};
+        const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2], fd_magic31((uint32_t)(b->prm[0] * b->prm[1])), fd_magic31((uint32_t)b->prm[0])};
         hipLaunchKernelGGL((k_f_rows<T, Lap7F>), g, dim3(kBlock), 0, s, (T *)fx, (const T *)x, f, xs, fs, r0, r1);
     } else {
         const SparseF f = {b->d_srow, b->d_scol};
@@ -94,8 +169,13 @@ static int rowlist_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         else hipLaunchKernelGGL((fd_csc_store_cols<real_t, CT, 0, FT>), dim3(g), dim3(kBlock), 0, s, fobj, x, eps, c_lo, c_hi, st);              \
     } while (0)
     if (b->family == FD_F_LAP7) {
-        const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2]};
-        FD_COLS(Lap7F, f);
+        const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2], fd_magic31((uint32_t)(b->prm[0] * b->prm[1])), fd_magic31((uint32_t)b->prm[0])};
+        if (st.valid_coloring) {      // the neighbourhood in registers (one perturbed coordinate per column)
+            if (lp->pts == 2) hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 1>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
+            else hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 0>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
+        } else {
+            FD_COLS(Lap7F, f);
+        }
     } else {
         const SparseF f = {b->d_srow, b->d_scol};
         FD_COLS(SparseF, f);

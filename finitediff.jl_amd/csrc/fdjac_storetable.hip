@@ -20,6 +20,27 @@ __global__ void __launch_bounds__(kBlock) k_csc_compact_rowval(const IT *__restr
     if (q < n) out[q] = (int)((int64_t)rowval[e0 + q] - base);
 }
 
+// Is colorvec a VALID colouring of the local pattern -- do the columns that share a row differ in colour?  One thread per local
+// column sets its colour's bit in the mask of every row it touches; a bit that was set already is a conflict.  (Columns without a
+// colour conflict with nothing.)  Knowing it lets a storing kernel perturb ONE coordinate instead of testing colours.
+template <typename CT>
+__global__ void __launch_bounds__(kBlock) k_csc_valid_coloring(const int *__restrict__ colptr, const int *__restrict__ rowval, int64_t col0, int64_t ncols,
+                                                               const CT *__restrict__ color, int64_t row0, int words,
+                                                               unsigned long long *__restrict__ mask, int *__restrict__ conflict)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ncols) return;
+    const int c = (int)color[col0 + k];
+    if (c == (int)(CT)(-1)) return;
+    const unsigned long long bit = 1ull << (c & 63);
+    bool bad = false;
+    for (int q = colptr[k]; q < colptr[k + 1]; ++q) {
+        const unsigned long long old = atomicOr(mask + ((int64_t)rowval[q] - row0) * words + (c >> 6), bit);
+        bad = bad || (old & bit) != 0;
+    }
+    if (bad) atomicOr(conflict, 1);
+}
+
 // colptr_dev / rowval_dev: device pointers addressed with ABSOLUTE column / entry indices (as device_build_csc takes them).
 template <typename IT>
 static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_dev, int idx_base)
@@ -34,6 +55,32 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
         hipLaunchKernelGGL((k_csc_compact_rowval<IT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, rowval_dev, (int64_t)idx_base,
                            p->entry_begin, n, p->d_sc_rowval);
     FD_HIP_CHECK(hipGetLastError());
+    // valid colouring?  (row masks: ceil(C / 64) words per local row; skipped -- "not verified" -- beyond 1 GiB of masks)
+    p->sc_valid = false;
+    const int64_t R = p->row1 - p->row0;
+    const int words = (int)((std::max<int64_t>(p->C, 1) + 63) / 64);
+    if (n > 0 && R > 0 && R * words * 8 <= ((int64_t)1 << 30)) {
+        unsigned long long *d_mask = nullptr;
+        int *d_conflict = nullptr;
+        if (hipMalloc((void **)&d_mask, (size_t)(R * words) * 8) == hipSuccess && hipMalloc((void **)&d_conflict, sizeof(int)) == hipSuccess) {
+            (void)hipMemsetAsync(d_mask, 0, (size_t)(R * words) * 8, s);
+            (void)hipMemsetAsync(d_conflict, 0, sizeof(int), s);
+            const unsigned g = (unsigned)((ncols + kBlock - 1) / kBlock);
+            if (p->color8)
+                hipLaunchKernelGGL((k_csc_valid_coloring<uint8_t>), dim3(g), dim3(kBlock), 0, s, p->d_sc_colptr, p->d_sc_rowval, p->col0, ncols,
+                                   (const uint8_t *)p->d_color, p->row0, words, d_mask, d_conflict);
+            else
+                hipLaunchKernelGGL((k_csc_valid_coloring<int32_t>), dim3(g), dim3(kBlock), 0, s, p->d_sc_colptr, p->d_sc_rowval, p->col0, ncols,
+                                   (const int32_t *)p->d_color, p->row0, words, d_mask, d_conflict);
+            int conflict = 1;
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&conflict, d_conflict, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess)
+                p->sc_valid = conflict == 0;
+        }
+        if (d_mask) (void)hipFree(d_mask);
+        if (d_conflict) (void)hipFree(d_conflict);
+        (void)hipGetLastError();
+    }
     FD_HIP_CHECK(hipStreamSynchronize(s));
     p->sc_entries = n;
     p->store_csc_ok = true;

@@ -177,7 +177,9 @@ typedef struct fd_csc_store {
     const void *fx_base;           /* device: f(x) (M elements) for forward differences; NULL for central differences */
     int color_bytes, C;
     int elem_bytes;
-    int reserved0;
+    int valid_coloring;            /* 1: the plan has verified that the columns sharing a row differ in colour -- then, seen from the row of a */
+                                   /* stored entry (r, j), the colour's point differs from x in coordinate j ONLY, and a kernel may form it as */
+                                   /* x[i] + eps * (i == j) without reading colours; 0: not verified (form the whole colour's point)          */
 } fd_csc_store;
 
 enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4 };   /* what fd_lazy_points.store points to */
@@ -419,6 +421,34 @@ template <typename T, typename CT> struct fd_colour_point {
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
 };
+/* the same point when the colouring is known to be valid (fd_csc_store.valid_coloring): only coordinate j is perturbed */
+template <typename T> struct fd_column_point {
+    const T *x;
+    long long j;
+    T e;
+    int minus;
+    __device__ T operator()(long long i) const
+    {
+        const T v = x[i];
+        const bool hit = i == j;
+        return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
+    }
+};
+template <typename T, int MODE, class F, class P>
+__device__ inline void fd_csc_store_column(const F &f, P &X, const fd_csc_store &st, int a, int b, T h)
+{
+    T *out = (T *)st.out;
+    const T *base = (const T *)st.fx_base;
+    for (int q = a; q < b; ++q) {
+        const long long r = st.rowval[q];
+        X.minus = 0;
+        const T vp = f(r, X);
+        T vm, div = h;
+        if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
+        else vm = base[r];
+        out[q] = (vp - vm) / div;
+    }
+}
 template <typename T, typename CT, int MODE, class F>
 __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
@@ -427,23 +457,18 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
     const int a = st.colptr[j - st.col_begin], b = st.colptr[j - st.col_begin + 1];
     const CT *color = (const CT *)st.color;
     const int c = (int)color[j];
-    T *out = (T *)st.out;
     if (c == (int)(CT)(-1)) {                        /* "none" is all-ones in CT */
-        if (c_lo == 0) for (int q = a; q < b; ++q) out[q] = (T)0;
+        if (c_lo == 0) for (int q = a; q < b; ++q) ((T *)st.out)[q] = (T)0;
         return;
     }
     if (c < c_lo || c >= c_hi) return;
     const T h = eps[c];
-    const T *base = (const T *)st.fx_base;
-    fd_colour_point<T, CT> P = {x, color, c, h, 0};
-    for (int q = a; q < b; ++q) {
-        const long long r = st.rowval[q];
-        P.minus = 0;
-        const T vp = f(r, P);
-        T vm, div = h;
-        if (MODE == 1) { P.minus = 1; vm = f(r, P); div = 2 * h; }
-        else vm = base[r];
-        out[q] = (vp - vm) / div;
+    if (st.valid_coloring) {
+        fd_column_point<T> X = {x, j, h, 0};
+        fd_csc_store_column<T, MODE>(f, X, st, a, b, h);
+    } else {
+        fd_colour_point<T, CT> X = {x, color, c, h, 0};
+        fd_csc_store_column<T, MODE>(f, X, st, a, b, h);
     }
 }
 #endif /* __HIPCC__ && __cplusplus */
