@@ -74,38 +74,50 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     const real_t ymzm = ld(-1, -1, 0), ypzm = ld(-1, 1, 0), ymzp = ld(1, -1, 0), ypzp = ld(1, 1, 0);
     const real_t *base = (const real_t *)st.fx_base;
     const real_t z0 = 0;
-    for (int q = a; q < b; ++q) {
-        const int r = st.rowval[q], d = r - (int)k;
-        real_t vp, vm = 0;
-        // the row's seven inputs (centre, down, south, west, east, north, up) with coordinate k replaced by P
-#define FD_ROWS(P, Z)                                                                                                                      \
-        (d == 0     ? lap7_row<real_t>(P, zm1 Z, ym1 Z, xm1 Z, xp1 Z, yp1 Z, zp1 Z)                                                            \
-         : d == -1  ? lap7_row<real_t>(xm1 Z, xmzm Z, xmym Z, xm2 Z, P, xmyp Z, xmzp Z)                                                        \
-         : d == 1   ? lap7_row<real_t>(xp1 Z, xpzm Z, xpym Z, P, xp2 Z, xpyp Z, xpzp Z)                                                        \
-         : d == -nx ? lap7_row<real_t>(ym1 Z, ymzm Z, ym2 Z, xmym Z, xpym Z, P, ymzp Z)                                                        \
-         : d == nx  ? lap7_row<real_t>(yp1 Z, ypzm Z, P, xmyp Z, xpyp Z, yp2 Z, ypzp Z)                                                        \
-         : d == -pl ? lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, P)                                                        \
-                    : lap7_row<real_t>(zp1 Z, P, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z))
-        const bool known = d == 0 || ((d == -1 || d == 1) && nx > 1) || ((d == -nx || d == nx) && nx > 1 && ny > 1 && pl != nx) || d == -pl || d == pl;
-        // (degenerate grids -- nx == 1, ny == 1: offsets coincide -- and rows that are not stencil neighbours: the functor)
-        const bool regular = known && nx > 2 && ny > 2 && (nz > 2 || nz == 1) && pl != nx && nx != 1;
-        if (regular && (d == 0 || (d == -1 && i > 0) || (d == 1 && i < nx - 1) || (d == -nx && j > 0) || (d == nx && j < ny - 1) || (d == -pl && l > 0) ||
-                        (d == pl && l < nz - 1))) {
-            // (the plus point holds x + 0.0 at its unperturbed coordinates, the minus point x - 0.0 == x: literally, for the -0.0 case;
-            //  a coordinate outside the grid is the constant 0 of the residual, not a coordinate: inside FD_IN it stays 0 + 0.0 == 0)
-            vp = FD_ROWS(c0 + h, +z0);
-            if (MODE == 1) vm = FD_ROWS(c0 - h, );
-        } else {
-            fd_column_point<real_t> X = {x, k, h, 0};
-            vp = f(r, X);
-            if (MODE == 1) { X.minus = 1; vm = f(r, X); }
-        }
-#undef FD_ROWS
-        real_t div = h;
-        if (MODE == 1) div = 2 * h;
+    const real_t cp = c0 + h, cm = c0 - h;
+    // an entry whose row is not handled from the window (rows that are no stencil neighbours, degenerate grids): the functor
+    auto generic = [&](int q) {
+        const int r = st.rowval[q];
+        fd_column_point<real_t> X = {x, k, h, 0};
+        const real_t vp = f(r, X);
+        real_t vm, div = h;
+        if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
         else vm = base[r];
         out[q] = sub_exact(vp, vm) / div;
-    }
+    };
+    const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
+    int q = a;
+    // the seven stencil rows in ascending order (= the order of a column's entries); `plus` / `minus`: the row at x + h e_k / x - h e_k.
+    // The plus point holds x + 0.0 at its unperturbed coordinates, the minus point x - 0.0 == x: literally (the -0.0 case); a
+    // coordinate outside the grid is the constant 0 of the residual (0 + 0.0 == 0).
+#define FD_ENTRY(off, guard, plus, minus)                                                              \
+    do {                                                                                               \
+        const int want = (int)k + (off);                                                               \
+        while (q < b && st.rowval[q] < want) { generic(q); ++q; }                                      \
+        if (q < b && st.rowval[q] == want) {                                                           \
+            if (regular && (guard)) {                                                                  \
+                const real_t vp = (plus);                                                              \
+                real_t vm, div = h;                                                                    \
+                if (MODE == 1) { vm = (minus); div = 2 * h; }                                          \
+                else vm = base[want];                                                                  \
+                out[q] = sub_exact(vp, vm) / div;                                                      \
+            } else {                                                                                   \
+                generic(q);                                                                            \
+            }                                                                                          \
+            ++q;                                                                                       \
+        }                                                                                              \
+    } while (0)
+#define Z +z0
+    FD_ENTRY(-pl, l > 0, lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, cp), lap7_row<real_t>(zm1, zm2, ymzm, xmzm, xpzm, ypzm, cm));
+    FD_ENTRY(-nx, j > 0, lap7_row<real_t>(ym1 Z, ymzm Z, ym2 Z, xmym Z, xpym Z, cp, ymzp Z), lap7_row<real_t>(ym1, ymzm, ym2, xmym, xpym, cm, ymzp));
+    FD_ENTRY(-1, i > 0, lap7_row<real_t>(xm1 Z, xmzm Z, xmym Z, xm2 Z, cp, xmyp Z, xmzp Z), lap7_row<real_t>(xm1, xmzm, xmym, xm2, cm, xmyp, xmzp));
+    FD_ENTRY(0, true, lap7_row<real_t>(cp, zm1 Z, ym1 Z, xm1 Z, xp1 Z, yp1 Z, zp1 Z), lap7_row<real_t>(cm, zm1, ym1, xm1, xp1, yp1, zp1));
+    FD_ENTRY(1, i < nx - 1, lap7_row<real_t>(xp1 Z, xpzm Z, xpym Z, cp, xp2 Z, xpyp Z, xpzp Z), lap7_row<real_t>(xp1, xpzm, xpym, cm, xp2, xpyp, xpzp));
+    FD_ENTRY(nx, j < ny - 1, lap7_row<real_t>(yp1 Z, ypzm Z, cp, xmyp Z, xpyp Z, yp2 Z, ypzp Z), lap7_row<real_t>(yp1, ypzm, cm, xmyp, xpyp, yp2, ypzp));
+    FD_ENTRY(pl, l < nz - 1, lap7_row<real_t>(zp1 Z, cp, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z), lap7_row<real_t>(zp1, cm, ymzp, xmzp, xpzp, ypzp, zp2));
+#undef Z
+#undef FD_ENTRY
+    while (q < b) { generic(q); ++q; }
 }
 
 // ---- FD_F_SPARSE ----------------------------------------------------------------------------------------------------------------
