@@ -47,16 +47,20 @@ template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
-    const int64_t k = st.col_begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= st.col_end) return;
-    const int a = st.colptr[k - st.col_begin], b = st.colptr[k - st.col_begin + 1];
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_CSC_WAVE_CAP];
+    const int64_t kk = st.col_begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool in = kk < st.col_end;
+    const int64_t k = in ? kk : st.col_end - 1;      // (lanes beyond the range idle on the last column: they take part in the wave's stores only)
+    const int a = in ? st.colptr[k - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[k - st.col_begin + 1] : a;
     const int c = (int)((const CT *)st.color)[k];
-    real_t *out = (real_t *)st.out;
-    if (c == (int)(CT)(-1)) {
-        if (c_lo == 0) for (int q = a; q < b; ++q) out[q] = 0;
-        return;
-    }
-    if (c < c_lo || c >= c_hi) return;
+    const bool none = in && c == (int)(CT)(-1);
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    fd_csc_wave_run<real_t> run;
+    run.begin((real_t *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0));
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) run.put(q, (real_t)0);
+    if (mine) {                     // (all lanes meet again at the flush below: the staged values leave in one wave-wide pass)
     const real_t h = eps[c];
     const int nx = f.nx, ny = f.ny, nz = f.nz, pl = nx * ny;
     const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
@@ -83,7 +87,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         real_t vm, div = h;
         if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
         else vm = base[r];
-        out[q] = sub_exact(vp, vm) / div;
+        run.put(q, sub_exact(vp, vm) / div);
     };
     const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
     int q = a;
@@ -100,7 +104,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
                 real_t vm, div = h;                                                                    \
                 if (MODE == 1) { vm = (minus); div = 2 * h; }                                          \
                 else vm = base[want];                                                                  \
-                out[q] = sub_exact(vp, vm) / div;                                                      \
+                run.put(q, sub_exact(vp, vm) / div);                                                   \
             } else {                                                                                   \
                 generic(q);                                                                            \
             }                                                                                          \
@@ -118,6 +122,8 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
 #undef Z
 #undef FD_ENTRY
     while (q < b) { generic(q); ++q; }
+    }
+    run.template flush<true>();
 }
 
 // ---- FD_F_SPARSE ----------------------------------------------------------------------------------------------------------------

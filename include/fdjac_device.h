@@ -434,10 +434,53 @@ template <typename T> struct fd_column_point {
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
 };
+/* Where a wavefront's values go.  The entries of 64 consecutive columns are ONE contiguous run of nzval; lane t holds the pieces
+ * of column j0 + t, i.e. 8-byte stores at a lane stride of the column length -- partial lines the L2 does not merge well (measured:
+ * 1.0 TB/s on the 7-point pattern).  When every lane of the wavefront writes its whole column (no colour chunk skips one) and the
+ * run fits, the values are staged in a wave-private LDS window in storage order and leave as dense, aligned 16-byte stores
+ * (fd_wave_store_window); otherwise each value is stored directly.  All 64 lanes call begin and flush. */
+#define FD_CSC_WAVE_CAP 1024      /* elements of the window per wavefront */
+template <typename T> struct fd_csc_wave_run {
+    T *out;
+    T *win;
+    int q0a;        /* even position that slot 0 of the window stands for */
+    int lo, hi;     /* slots that hold values */
+    bool staged;
+    /* a, b: the lane's entry range (a == b for a lane without a column); writes: the lane will write ALL of [a, b) */
+    __device__ void begin(T *out_, T *win_, int a, int b, bool writes)
+    {
+        out = out_; win = win_;
+        int qmin = a, qmax = b;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(qmin, o, 64), M = __shfl_xor(qmax, o, 64);
+            qmin = m < qmin ? m : qmin;
+            qmax = M > qmax ? M : qmax;
+        }
+        q0a = qmin & ~1;
+        lo = qmin - q0a;
+        hi = qmax - q0a;
+        staged = __all(writes) && hi <= FD_CSC_WAVE_CAP && ((((unsigned long long)out_) & (2 * sizeof(T) - 1)) == 0);
+    }
+    __device__ void put(int q, T v) const
+    {
+        if (staged) win[q - q0a] = v;
+        else out[q] = v;
+    }
+    template <bool NT> __device__ void flush() const
+    {
+        if (!staged) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        fd_wave_store_window<T, NT>(out + q0a, win, lo, hi);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
 template <typename T, int MODE, class F, class P>
-__device__ inline void fd_csc_store_column(const F &f, P &X, const fd_csc_store &st, int a, int b, T h)
+__device__ inline void fd_csc_store_column(const F &f, P &X, const fd_csc_store &st, const fd_csc_wave_run<T> &run, int a, int b, T h)
 {
-    T *out = (T *)st.out;
     const T *base = (const T *)st.fx_base;
     for (int q = a; q < b; ++q) {
         const long long r = st.rowval[q];
@@ -446,30 +489,36 @@ __device__ inline void fd_csc_store_column(const F &f, P &X, const fd_csc_store 
         T vm, div = h;
         if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
         else vm = base[r];
-        out[q] = (vp - vm) / div;
+        run.put(q, (vp - vm) / div);
     }
 }
 template <typename T, typename CT, int MODE, class F>
 __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
+    __shared__ __attribute__((aligned(16))) T s_win[256 / 64][FD_CSC_WAVE_CAP];
     const long long j = st.col_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= st.col_end) return;
-    const int a = st.colptr[j - st.col_begin], b = st.colptr[j - st.col_begin + 1];
+    const bool in = j < st.col_end;
+    const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[j - st.col_begin + 1] : a;
     const CT *color = (const CT *)st.color;
-    const int c = (int)color[j];
-    if (c == (int)(CT)(-1)) {                        /* "none" is all-ones in CT */
-        if (c_lo == 0) for (int q = a; q < b; ++q) ((T *)st.out)[q] = (T)0;
-        return;
+    const int c = in ? (int)color[j] : 0;
+    const bool none = in && c == (int)(CT)(-1);                           /* "none" is all-ones in CT */
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    fd_csc_wave_run<T> run;
+    run.begin((T *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0));
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) run.put(q, (T)0);
+    if (mine) {
+        const T h = eps[c];
+        if (st.valid_coloring) {
+            fd_column_point<T> X = {x, j, h, 0};
+            fd_csc_store_column<T, MODE>(f, X, st, run, a, b, h);
+        } else {
+            fd_colour_point<T, CT> X = {x, color, c, h, 0};
+            fd_csc_store_column<T, MODE>(f, X, st, run, a, b, h);
+        }
     }
-    if (c < c_lo || c >= c_hi) return;
-    const T h = eps[c];
-    if (st.valid_coloring) {
-        fd_column_point<T> X = {x, j, h, 0};
-        fd_csc_store_column<T, MODE>(f, X, st, a, b, h);
-    } else {
-        fd_colour_point<T, CT> X = {x, color, c, h, 0};
-        fd_csc_store_column<T, MODE>(f, X, st, a, b, h);
-    }
+    run.template flush<true>();
 }
 #endif /* __HIPCC__ && __cplusplus */
 
