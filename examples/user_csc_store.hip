@@ -90,7 +90,7 @@ int user_rl_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64_t 
     if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
     const fd_csc_store st = *(const fd_csc_store *)lp->store;
     if (st.elem_bytes != 8 || st.col_end <= st.col_begin || (lp->pts == 1 && !st.fx_base)) return FD_LAZY_DECLINED;
-    const unsigned g = (unsigned)((st.col_end - st.col_begin + kBlock - 1) / kBlock);
+    const unsigned g = fd_xcd_grid((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const hipStream_t s = (hipStream_t)stream;
     const double *x = (const double *)lp->x, *eps = (const double *)lp->eps;
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;

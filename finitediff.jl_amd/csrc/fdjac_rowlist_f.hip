@@ -48,7 +48,9 @@ __global__ void __launch_bounds__(kBlock)
 k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
     __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_CSC_WAVE_CAP];
-    const int64_t kk = st.col_begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t nblk = (st.col_end - st.col_begin + kBlock - 1) / kBlock, blk = fd_xcd_block(blockIdx.x, nblk);
+    if (blk >= nblk) return;
+    const int64_t kk = st.col_begin + blk * kBlock + threadIdx.x;
     const bool in = kk < st.col_end;
     const int64_t k = in ? kk : st.col_end - 1;      // (lanes beyond the range idle on the last column: they take part in the wave's stores only)
     const int a = in ? st.colptr[k - st.col_begin] : st.colptr[st.col_end - st.col_begin];
@@ -178,7 +180,7 @@ static int rowlist_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
     if (st.elem_bytes != (int)sizeof(real_t) || st.color_bytes != (int)sizeof(CT) || st.M != b->M || st.N != b->N || st.col_end <= st.col_begin ||
         (lp->pts == 1 && !st.fx_base))
         return FD_LAZY_DECLINED;
-    const unsigned g = (unsigned)((st.col_end - st.col_begin + kBlock - 1) / kBlock);
+    const unsigned g = fd_xcd_grid((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
     const real_t *x = (const real_t *)lp->x, *eps = (const real_t *)lp->eps;
 #define FD_COLS(FT, fobj)                                                                                                                  \

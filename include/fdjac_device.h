@@ -405,7 +405,8 @@ template <typename T> __device__ inline void fd_colrange_emit(const fd_colrange_
  * (call X(j) for every coordinate the row reads, in the order the residual's arithmetic needs).  The kernel hands it the colour's
  * own point, formed exactly as the reference forms it: x[j] + eps_c * (color[j] == c), i.e. x[j] + 0.0 elsewhere (minus point of a
  * central difference: x[j] - eps_c * ..., x[j] - 0.0 == x[j] elsewhere).  One thread per local column.
- *     hipLaunchKernelGGL((fd_csc_store_cols<double, unsigned char, 0, F>), grid, 256, 0, stream, f, x, eps, c_lo, c_hi, st);
+ *     hipLaunchKernelGGL((fd_csc_store_cols<double, unsigned char, 0, F>), fd_xcd_grid((st.col_end - st.col_begin + 255) / 256), 256, 0, stream,
+ *                        f, x, eps, c_lo, c_hi, st);
  * MODE 0: forward (st.fx_base = f(x)), 1: central.  Columns whose colour lies outside [c_lo, c_hi) are skipped (colour chunks /
  * ownership); columns without a colour are written as 0 when c_lo == 0 (fill_matrix!, src/jacobians.jl:530-532). */
 template <typename T, typename CT> struct fd_colour_point {
@@ -434,6 +435,13 @@ template <typename T> struct fd_column_point {
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
 };
+/* MI355X dispatches workgroup b to XCD b % 8, and every XCD has its own L2: consecutive workgroups that share inputs (a stencil's
+ * neighbouring columns) would pull them into eight L2s.  Launch 8 * ceil(n / 8) workgroups and let workgroup b work on block
+ * fd_xcd_block(b, n) -- XCD x then owns the contiguous block range [x * ceil(n / 8), (x + 1) * ceil(n / 8)); blocks >= n do
+ * nothing.  A performance assumption only: results never depend on placement. */
+__device__ inline long long fd_xcd_block(long long b, long long n) { return (b & 7) * ((n + 7) / 8) + (b >> 3); }
+__host__ inline unsigned fd_xcd_grid(long long n) { return (unsigned)(8 * ((n + 7) / 8)); }
+
 /* Where a wavefront's values go.  The entries of 64 consecutive columns are ONE contiguous run of nzval; lane t holds the pieces
  * of column j0 + t, i.e. 8-byte stores at a lane stride of the column length -- partial lines the L2 does not merge well (measured:
  * 1.0 TB/s on the 7-point pattern).  When every lane of the wavefront writes its whole column (no colour chunk skips one) and the
@@ -496,7 +504,9 @@ template <typename T, typename CT, int MODE, class F>
 __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
     __shared__ __attribute__((aligned(16))) T s_win[256 / 64][FD_CSC_WAVE_CAP];
-    const long long j = st.col_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nblk = (st.col_end - st.col_begin + 255) / 256, blk = fd_xcd_block(blockIdx.x, nblk);      /* launch fd_xcd_grid(nblk) workgroups */
+    if (blk >= nblk) return;
+    const long long j = st.col_begin + blk * 256 + threadIdx.x;
     const bool in = j < st.col_end;
     const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
     const int b = in ? st.colptr[j - st.col_begin + 1] : a;
