@@ -81,6 +81,18 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     const real_t *base = (const real_t *)st.fx_base;
     const real_t z0 = 0;
     const real_t cp = c0 + h, cm = c0 - h;
+    // forward differences: f(x) of the seven rows, fetched up front with the window (a load per entry inside the loop would put
+    // seven dependent memory round trips on every wavefront's critical path: 470 -> measured below, profiles/r04_*)
+    real_t bz0 = 0, by0 = 0, bx0 = 0, bc = 0, bx1 = 0, by1 = 0, bz1 = 0;
+    if (MODE == 0) {
+        bc = base[k];
+        if (l > 0) bz0 = base[k - pl];
+        if (j > 0) by0 = base[k - nx];
+        if (i > 0) bx0 = base[k - 1];
+        if (i < nx - 1) bx1 = base[k + 1];
+        if (j < ny - 1) by1 = base[k + nx];
+        if (l < nz - 1) bz1 = base[k + pl];
+    }
     // an entry whose row is not handled from the window (rows that are no stencil neighbours, degenerate grids): the functor
     auto generic = [&](int q) {
         const int r = st.rowval[q];
@@ -96,7 +108,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     // the seven stencil rows in ascending order (= the order of a column's entries); `plus` / `minus`: the row at x + h e_k / x - h e_k.
     // The plus point holds x + 0.0 at its unperturbed coordinates, the minus point x - 0.0 == x: literally (the -0.0 case); a
     // coordinate outside the grid is the constant 0 of the residual (0 + 0.0 == 0).
-#define FD_ENTRY(off, guard, plus, minus)                                                              \
+#define FD_ENTRY(off, guard, plus, minus, bv)                                                          \
     do {                                                                                               \
         const int want = (int)k + (off);                                                               \
         while (q < b && st.rowval[q] < want) { generic(q); ++q; }                                      \
@@ -105,7 +117,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
                 const real_t vp = (plus);                                                              \
                 real_t vm, div = h;                                                                    \
                 if (MODE == 1) { vm = (minus); div = 2 * h; }                                          \
-                else vm = base[want];                                                                  \
+                else vm = (bv);                                                                        \
                 run.put(q, sub_exact(vp, vm) / div);                                                   \
             } else {                                                                                   \
                 generic(q);                                                                            \
@@ -114,13 +126,50 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         }                                                                                              \
     } while (0)
 #define Z +z0
-    FD_ENTRY(-pl, l > 0, lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, cp), lap7_row<real_t>(zm1, zm2, ymzm, xmzm, xpzm, ypzm, cm));
-    FD_ENTRY(-nx, j > 0, lap7_row<real_t>(ym1 Z, ymzm Z, ym2 Z, xmym Z, xpym Z, cp, ymzp Z), lap7_row<real_t>(ym1, ymzm, ym2, xmym, xpym, cm, ymzp));
-    FD_ENTRY(-1, i > 0, lap7_row<real_t>(xm1 Z, xmzm Z, xmym Z, xm2 Z, cp, xmyp Z, xmzp Z), lap7_row<real_t>(xm1, xmzm, xmym, xm2, cm, xmyp, xmzp));
-    FD_ENTRY(0, true, lap7_row<real_t>(cp, zm1 Z, ym1 Z, xm1 Z, xp1 Z, yp1 Z, zp1 Z), lap7_row<real_t>(cm, zm1, ym1, xm1, xp1, yp1, zp1));
-    FD_ENTRY(1, i < nx - 1, lap7_row<real_t>(xp1 Z, xpzm Z, xpym Z, cp, xp2 Z, xpyp Z, xpzp Z), lap7_row<real_t>(xp1, xpzm, xpym, cm, xp2, xpyp, xpzp));
-    FD_ENTRY(nx, j < ny - 1, lap7_row<real_t>(yp1 Z, ypzm Z, cp, xmyp Z, xpyp Z, yp2 Z, ypzp Z), lap7_row<real_t>(yp1, ypzm, cm, xmyp, xpyp, yp2, ypzp));
-    FD_ENTRY(pl, l < nz - 1, lap7_row<real_t>(zp1 Z, cp, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z), lap7_row<real_t>(zp1, cm, ymzp, xmzp, xpzp, ypzp, zp2));
+#define FD_R0P lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, cp)
+#define FD_R0M lap7_row<real_t>(zm1, zm2, ymzm, xmzm, xpzm, ypzm, cm)
+#define FD_R1P lap7_row<real_t>(ym1 Z, ymzm Z, ym2 Z, xmym Z, xpym Z, cp, ymzp Z)
+#define FD_R1M lap7_row<real_t>(ym1, ymzm, ym2, xmym, xpym, cm, ymzp)
+#define FD_R2P lap7_row<real_t>(xm1 Z, xmzm Z, xmym Z, xm2 Z, cp, xmyp Z, xmzp Z)
+#define FD_R2M lap7_row<real_t>(xm1, xmzm, xmym, xm2, cm, xmyp, xmzp)
+#define FD_R3P lap7_row<real_t>(cp, zm1 Z, ym1 Z, xm1 Z, xp1 Z, yp1 Z, zp1 Z)
+#define FD_R3M lap7_row<real_t>(cm, zm1, ym1, xm1, xp1, yp1, zp1)
+#define FD_R4P lap7_row<real_t>(xp1 Z, xpzm Z, xpym Z, cp, xp2 Z, xpyp Z, xpzp Z)
+#define FD_R4M lap7_row<real_t>(xp1, xpzm, xpym, cm, xp2, xpyp, xpzp)
+#define FD_R5P lap7_row<real_t>(yp1 Z, ypzm Z, cp, xmyp Z, xpyp Z, yp2 Z, ypzp Z)
+#define FD_R5M lap7_row<real_t>(yp1, ypzm, cm, xmyp, xpyp, yp2, ypzp)
+#define FD_R6P lap7_row<real_t>(zp1 Z, cp, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z)
+#define FD_R6M lap7_row<real_t>(zp1, cm, ymzp, xmzp, xpzp, ypzp, zp2)
+    // an interior grid point whose column holds exactly the seven stencil rows (the common case): the row indices are fetched up
+    // front and compared once, then seven straight-line evaluations -- no dependent load between them
+    bool all7 = false;
+    if (regular && b - a == 7 && l > 0 && j > 0 && i > 0 && i < nx - 1 && j < ny - 1 && l < nz - 1) {
+        const int r0 = st.rowval[a], r1 = st.rowval[a + 1], r2 = st.rowval[a + 2], r3 = st.rowval[a + 3], r4 = st.rowval[a + 4], r5 = st.rowval[a + 5],
+                  r6 = st.rowval[a + 6];
+        const int kk32 = (int)k;
+        all7 = r0 == kk32 - pl && r1 == kk32 - nx && r2 == kk32 - 1 && r3 == kk32 && r4 == kk32 + 1 && r5 == kk32 + nx && r6 == kk32 + pl;
+    }
+    if (all7) {
+        const real_t div = MODE == 1 ? 2 * h : h;
+#define FD_FAST(t, plus, minus, bv) run.put(a + (t), sub_exact((plus), MODE == 1 ? (minus) : (bv)) / div)
+        FD_FAST(0, FD_R0P, FD_R0M, bz0);
+        FD_FAST(1, FD_R1P, FD_R1M, by0);
+        FD_FAST(2, FD_R2P, FD_R2M, bx0);
+        FD_FAST(3, FD_R3P, FD_R3M, bc);
+        FD_FAST(4, FD_R4P, FD_R4M, bx1);
+        FD_FAST(5, FD_R5P, FD_R5M, by1);
+        FD_FAST(6, FD_R6P, FD_R6M, bz1);
+#undef FD_FAST
+        q = b;
+    } else {
+    FD_ENTRY(-pl, l > 0, FD_R0P, FD_R0M, bz0);
+    FD_ENTRY(-nx, j > 0, FD_R1P, FD_R1M, by0);
+    FD_ENTRY(-1, i > 0, FD_R2P, FD_R2M, bx0);
+    FD_ENTRY(0, true, FD_R3P, FD_R3M, bc);
+    FD_ENTRY(1, i < nx - 1, FD_R4P, FD_R4M, bx1);
+    FD_ENTRY(nx, j < ny - 1, FD_R5P, FD_R5M, by1);
+    FD_ENTRY(pl, l < nz - 1, FD_R6P, FD_R6M, bz1);
+    }
 #undef Z
 #undef FD_ENTRY
     while (q < b) { generic(q); ++q; }
