@@ -11,6 +11,7 @@
 // Included by fdjac_builtin_f.hip (namespace fdjac, after BuiltinF).
 
 constexpr real_t kSix = 6, kQuarter = 0.25, kEighth = 0.125;
+template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y);   // (fdjac_builtin_f.hip, below the include)
 
 template <typename T> struct PlainPoint {      // a materialised point
     const T *x;
@@ -67,8 +68,10 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     const int nx = f.nx, ny = f.ny, nz = f.nz, pl = nx * ny;
     const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
     // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
+    // (a grid point at least two cells away from every face: no bounds tests -- the guards are ~200 vector instructions per column)
+    const bool deep = i >= 2 && i < nx - 2 && j >= 2 && j < ny - 2 && l >= 2 && l < nz - 2;
     auto ld = [&](int dl, int dj, int di) -> real_t {
-        const bool ok = (unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz;
+        const bool ok = deep || ((unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz);
         return ok ? x[k + (int64_t)dl * pl + dj * nx + di] : (real_t)0;
     };
     const real_t c0 = ld(0, 0, 0);
@@ -150,8 +153,10 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         all7 = r0 == kk32 - pl && r1 == kk32 - nx && r2 == kk32 - 1 && r3 == kk32 && r4 == kk32 + 1 && r5 == kk32 + nx && r6 == kk32 + pl;
     }
     if (all7) {
+        // seven quotients by ONE divisor: its reciprocal once, then the correctly rounded quotients of div_shared (the bits of IEEE a / b)
         const real_t div = MODE == 1 ? 2 * h : h;
-#define FD_FAST(t, plus, minus, bv) run.put(a + (t), sub_exact((plus), MODE == 1 ? (minus) : (bv)) / div)
+        const real_t yd = sizeof(real_t) == 8 ? (real_t)1 / div : (real_t)0;
+#define FD_FAST(t, plus, minus, bv) run.put(a + (t), div_shared<true>(sub_exact((plus), MODE == 1 ? (minus) : (bv)), div, yd))
         FD_FAST(0, FD_R0P, FD_R0M, bz0);
         FD_FAST(1, FD_R1P, FD_R1M, by0);
         FD_FAST(2, FD_R2P, FD_R2M, bx0);
