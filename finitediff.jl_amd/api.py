@@ -313,6 +313,71 @@ class Comm:
         _l.check(self.L.fd_comm_halo_exchange(self.handle, p, int(own_begin), int(own_end), int(halo), eb))
 
 
+    def enable_p2p(self, slot_bytes=1 << 16):
+        """fd_comm_enable_p2p: map every rank's mailbox (handles exchanged over RCCL) and route this communicator's small
+        messages -- all-gathers / halo exchanges up to `slot_bytes`, hence the sharded step-size reduction and the sharded
+        solve -- through direct peer-to-peer stores.  Collective; raises if the peers cannot be mapped."""
+        _l.check(self.L.fd_comm_enable_p2p(self.handle, int(slot_bytes)))
+
+
+class P2P:
+    """fd_p2p: small-message exchange by direct stores into the peers' HBM (one node, one process per GPU) -- the mailbox on
+    its own, bootstrapped by the host (``from_torch_distributed`` ships the 64-byte handles through torch.distributed and
+    nothing else).  Exchanges are enqueued on the context's stream; ``status()`` tells whether a wait ever timed out."""
+
+    def __init__(self, ctx, nranks, rank, slot_bytes=1 << 16):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        _l.check(self.L.fd_p2p_create(ctx.handle, int(nranks), int(rank), int(slot_bytes), C.byref(h)))
+        self.handle, self.nranks, self.rank = h, int(nranks), int(rank)
+        self._fin = weakref.finalize(self, self.L.fd_p2p_destroy, h)
+
+    def local_handle(self):
+        buf = C.create_string_buffer(_l.P2P_HANDLE_BYTES)
+        _l.check(self.L.fd_p2p_local_handle(self.handle, buf))
+        return buf.raw
+
+    def connect(self, handles):
+        blob = b"".join(handles)
+        if len(blob) != self.nranks * _l.P2P_HANDLE_BYTES:
+            raise ValueError("need one %d-byte handle per rank" % _l.P2P_HANDLE_BYTES)
+        _l.check(self.L.fd_p2p_connect(self.handle, C.create_string_buffer(blob, len(blob))))
+
+    @classmethod
+    def from_torch_distributed(cls, ctx, dist=None, group=None, slot_bytes=1 << 16):
+        if dist is None:
+            import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self = cls(ctx, world, rank, slot_bytes)
+        handles = [None] * world
+        dist.all_gather_object(handles, self.local_handle(), group=group)
+        self.connect(handles)
+        dist.barrier(group=group)          # every rank has mapped every mailbox before anybody stores into one
+        return self
+
+    def info(self):
+        n, r, sb, u = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        _l.check(self.L.fd_p2p_info(self.handle, C.byref(n), C.byref(r), C.byref(sb), C.byref(u)))
+        return {"nranks": n.value, "rank": r.value, "slot_bytes": sb.value, "uncached": bool(u.value)}
+
+    def status(self):
+        """0, or 1 + r once a wait for rank r timed out (FDJAC_P2P_TIMEOUT_MS, default 2000)."""
+        v = C.c_int()
+        _l.check(self.L.fd_p2p_status(self.handle, C.byref(v)))
+        return v.value
+
+    def allgather(self, buf, slot_elems):
+        """In place, like Comm.allgather: rank r's data sits in slot r of `buf` (nranks slots of slot_elems elements)."""
+        p, eb = Comm._dev(buf, "buf")
+        if buf.numel() < self.nranks * int(slot_elems):
+            raise ValueError("buf is shorter than nranks * slot_elems")
+        _l.check(self.L.fd_p2p_allgather(self.handle, p, int(slot_elems) * eb))
+
+    def halo_exchange(self, buf, own_begin, own_end, halo):
+        p, eb = Comm._dev(buf, "buf")
+        _l.check(self.L.fd_p2p_halo_exchange(self.handle, p, int(own_begin), int(own_end), int(halo), eb))
+
+
 class TridiagSolver:
     """fd_tridiag_solver: (alpha*I + beta*J) y = b on the device for a tridiagonal J in the storage the Jacobian plans
     fill -- ``Tridiagonal`` (dl, d, du) or the nzval of a tridiagonal ``SparseMatrixCSC`` -- whole or one rank's column

@@ -40,6 +40,7 @@ ncclResult_t ncclGroupEnd(void);
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "fdjac_internal.h"
 
@@ -49,7 +50,9 @@ struct fd_comm {
     fd_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    fd_p2p *p2p = nullptr;        // fd_comm_enable_p2p: small messages go through the peer-to-peer mailbox (fdjac_p2p.hip), owned by the communicator
 };
+extern "C" int64_t fdjac_p2p_slot_bytes(const fd_p2p *p);
 
 namespace fdjac {
 
@@ -186,7 +189,45 @@ int fd_comm_destroy(fd_comm *c)
         (void)hipStreamSynchronize(c->ctx->stream);
         (void)R->CommDestroy(c->comm);
     }
+    if (c->p2p) (void)fd_p2p_destroy(c->p2p);
     delete c;
+    return FD_OK;
+}
+
+int fd_comm_enable_p2p(fd_comm *c, int64_t slot_bytes)
+{
+    FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");
+    FD_REQUIRE(c->p2p == nullptr, FD_ERR_ARG, "the communicator has a mailbox already");
+    const Rccl *R = rccl();
+    if (!R) return FD_ERR_COMM;
+    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    fd_p2p *p = nullptr;
+    int rc = fd_p2p_create(c->ctx, c->nranks, c->rank, slot_bytes, &p);
+    if (rc) return rc;
+    // the handles travel over the communicator itself: one small in-place all-gather
+    char *d_h = nullptr;
+    std::vector<char> h((size_t)c->nranks * FD_P2P_HANDLE_BYTES);
+    hipError_t e = hipMalloc((void **)&d_h, h.size());
+    if (e == hipSuccess) rc = fd_p2p_local_handle(p, h.data() + (size_t)c->rank * FD_P2P_HANDLE_BYTES);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(d_h, h.data(), h.size(), hipMemcpyHostToDevice, c->ctx->stream);
+    if (e == hipSuccess && !rc) {
+        const ncclResult_t r = R->AllGather(d_h + (size_t)c->rank * FD_P2P_HANDLE_BYTES, d_h, FD_P2P_HANDLE_BYTES, ncclUint8, c->comm, c->ctx->stream);
+        if (r != ncclSuccess) { set_error("exchanging the mailbox handles failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
+    }
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(h.data(), d_h, h.size(), hipMemcpyDeviceToHost, c->ctx->stream);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->ctx->stream);
+    if (d_h) (void)hipFree(d_h);
+    if (e != hipSuccess && !rc) { set_error("exchanging the mailbox handles failed: %s", hipGetErrorString(e)); rc = FD_ERR_HIP; }
+    if (!rc) rc = fd_p2p_connect(p, h.data());
+    // every rank must have mapped every peer before anybody stores into a mailbox: agree on success (a rank that failed makes all fall back)
+    double mine[4] = {rc ? 1.0 : 0.0, 0, 0, 0}, got[4] = {0, 0, 0, 0};
+    const int rc2 = fdjac_comm_allreduce_max4(c, mine, got);
+    if (rc || rc2 || got[0] != 0.0) {
+        (void)fd_p2p_destroy(p);
+        if (!rc && !rc2) { set_error("another rank could not map the mailboxes: the communicator keeps using RCCL for small messages"); return FD_ERR_COMM; }
+        return rc ? rc : rc2;
+    }
+    c->p2p = p;
     return FD_OK;
 }
 
@@ -216,6 +257,8 @@ int fd_comm_allgather(fd_comm *c, void *buf, int64_t slot_elems, int elem_bytes)
     ncclDataType_t dt;
     FD_REQUIRE(dtype_of(elem_bytes, &dt), FD_ERR_ARG, "elem_bytes must be 1, 4 or 8");
     if (slot_elems == 0) return FD_OK;   // (a single-rank communicator still goes through RCCL: same call path)
+    if (c->p2p && c->nranks > 1 && slot_elems * elem_bytes <= fdjac_p2p_slot_bytes(c->p2p) && (slot_elems * elem_bytes) % 8 == 0)
+        return fd_p2p_allgather(c->p2p, buf, slot_elems * elem_bytes);      // small message: direct peer-to-peer stores
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
     FD_HIP_CHECK(hipSetDevice(c->ctx->device));
@@ -274,6 +317,8 @@ int fd_comm_halo_exchange(fd_comm *c, void *buf, int64_t own_begin, int64_t own_
                (long long)own_end, (long long)halo);
     FD_REQUIRE(halo == 0 || own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` = %lld elements", (long long)halo);
     if (halo == 0 || c->nranks == 1) return FD_OK;
+    if (c->p2p && 2 * halo * elem_bytes <= fdjac_p2p_slot_bytes(c->p2p) && (halo * elem_bytes) % 8 == 0)
+        return fd_p2p_halo_exchange(c->p2p, buf, own_begin, own_end, halo, elem_bytes);
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
     FD_HIP_CHECK(hipSetDevice(c->ctx->device));

@@ -1,0 +1,336 @@
+// Small-message exchange by direct peer-to-peer stores (include/fdjac.h, fd_p2p_*).
+//
+// A Newton / Rosenbrock step on P GPUs exchanges, per Jacobian: the halo of x (2 (l + u) values per link), the partial sums of the
+// step-size reduction (62 KB in total) and the interface packets of the sharded tridiagonal solve (64 B per rank).  As RCCL
+// collectives these are three launches of a general-purpose machine (proxy thread, channel setup, flag protocol) for a few
+// kilobytes: 10-25 us each on comparable parts, against 6.5 us of sharded compute.  xGMI is a load / store
+// fabric: a kernel can write a peer's HBM directly.  So every rank owns a MAILBOX in its HBM, maps the mailboxes of all peers
+// (hipIpc handles, exchanged once by whatever the host has -- or by RCCL itself, fd_comm_enable_p2p), and an exchange is
+//     put    one workgroup per peer copies this rank's slot into the peer's mailbox, fences at system scope and then raises this
+//            rank's flag in the peer's mailbox to the exchange's epoch (a release store at system scope);
+//     wait   one workgroup per sender polls that sender's flag in the LOCAL mailbox (system-scope acquire loads, bounded by a
+//            wall-clock timeout that raises an error word instead of hanging the GPU), then copies the sender's slot out.
+// Two kernels on the caller's stream, no host involvement, no proxy.  Slots are double-buffered by epoch parity: a rank can only
+// reach exchange e + 2 after every peer has released e + 1, i.e. after it has finished reading e (stream order on the peer).
+// RCCL stays for what it is good at: the bulk assembly of nzval (fd_comm_gatherv / fd_comm_allgather of MBs).
+//
+// What can be executed in the build environment: two PROCESSES sharing one GPU (tests/test_gpu_multigpu.py::test_p2p_*): the IPC
+// mapping, the epoch / parity protocol, timeouts.  Ordering of remote stores over xGMI between two devices cannot (one GPU per
+// box): the code uses the documented recipe -- data stores, __threadfence_system(), flag store with system-scope release; the
+// reader acquires at system scope and reads the payload with system-scope loads (no stale L2 lines) -- and times out loudly.
+#include "fdjac_internal.h"
+
+#include <cstring>
+#include <new>
+
+#ifndef FDJAC_F32   /* element-type independent: compiled once */
+
+constexpr int kP2PMaxRanks = 64;
+constexpr int64_t kP2PFlagStride = 128;      // one line per sender
+
+struct fd_p2p {
+    fd_ctx *ctx = nullptr;
+    int nranks = 1, rank = 0;
+    int64_t slot_bytes = 0;                   // capacity per rank per exchange (a multiple of 128)
+    char *local = nullptr;                    // this rank's mailbox, TWO channels (0: all-gathers -- every rank waits for every rank; 1: halo
+                                              // exchanges -- neighbours only; each with its own epochs, so that the parity argument holds per
+                                              // channel): [flags: nranks x 128 B][parity 0: nranks slots][parity 1: nranks slots] each
+    char *peer[kP2PMaxRanks] = {};            // the mailboxes as mapped here (peer[rank] == local)
+    bool mapped[kP2PMaxRanks] = {};
+    char **d_peer = nullptr;                  // device copy of peer[]
+    int *d_err = nullptr;                     // device error word (pinned host memory mapped to the device: readable without a sync)
+    int *h_err = nullptr;
+    uint64_t epoch[2] = {0, 0};
+    bool connected = false;
+    bool uncached = false;
+};
+
+namespace fdjac {
+
+__device__ __forceinline__ void p2p_copy_out(char *dst, const char *src, int64_t bytes)
+{
+    // payload written by a peer: read it at system scope (never from a stale L2 line), 8 bytes per lane
+    for (int64_t o = (int64_t)threadIdx.x * 8; o < bytes; o += (int64_t)blockDim.x * 8) {
+        const unsigned long long v = __hip_atomic_load((const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *(unsigned long long *)(dst + o) = v;
+    }
+}
+__device__ __forceinline__ void p2p_copy_in(char *dst, const char *src, int64_t bytes)
+{
+    for (int64_t o = (int64_t)threadIdx.x * 8; o < bytes; o += (int64_t)blockDim.x * 8)
+        __hip_atomic_store((unsigned long long *)(dst + o), *(const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// targets[b]: the peer workgroup b writes to; src_off[b] / dst_sub[b]: where in `buf` its payload starts and at which byte of this
+// rank's slot in the peer's mailbox it lands
+struct P2PPut {
+    int target[4];
+    int64_t src_off[4], dst_sub[4], bytes[4];
+    int n;
+};
+__global__ void __launch_bounds__(kBlock) k_p2p_put(char *const *__restrict__ peer, const char *__restrict__ buf, P2PPut put, int nranks, int rank,
+                                                    int64_t slot_bytes, uint64_t epoch, int all, int64_t chan_off)
+{
+    // all != 0: the all-gather form -- workgroup b serves peer b (b != rank), payload = this rank's slot of buf
+    int target;
+    int64_t src_off, dst_sub, bytes;
+    if (all) {
+        target = blockIdx.x;
+        if (target == rank) return;
+        src_off = put.src_off[0];
+        dst_sub = 0;
+        bytes = put.bytes[0];
+    } else {
+        if ((int)blockIdx.x >= put.n) return;
+        target = put.target[blockIdx.x];
+        src_off = put.src_off[blockIdx.x];
+        dst_sub = put.dst_sub[blockIdx.x];
+        bytes = put.bytes[blockIdx.x];
+    }
+    char *mb = peer[target] + chan_off;
+    char *slot = mb + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + rank) * slot_bytes + dst_sub;
+    p2p_copy_in(slot, buf + src_off, bytes);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)      // this rank's flag in the peer's mailbox: "my slot of exchange `epoch` is complete"
+        __hip_atomic_store((unsigned long long *)(mb + (int64_t)rank * kP2PFlagStride), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct P2PGet {
+    int sender[4];
+    int64_t dst_off[4], src_sub[4], bytes[4];
+    int n;
+};
+__global__ void __launch_bounds__(kBlock) k_p2p_wait(char *__restrict__ local_base, char *__restrict__ buf, P2PGet get, int nranks, int rank, int64_t slot_bytes,
+                                                     uint64_t epoch, int all, int64_t timeout_ticks, int *__restrict__ err, int64_t chan_off)
+{
+    char *local = local_base + chan_off;
+    int sender;
+    int64_t dst_off, src_sub, bytes;
+    if (all) {
+        sender = blockIdx.x;
+        if (sender == rank) return;
+        dst_off = (int64_t)sender * get.bytes[0];
+        src_sub = 0;
+        bytes = get.bytes[0];
+    } else {
+        if ((int)blockIdx.x >= get.n) return;
+        sender = get.sender[blockIdx.x];
+        dst_off = get.dst_off[blockIdx.x];
+        src_sub = get.src_sub[blockIdx.x];
+        bytes = get.bytes[blockIdx.x];
+    }
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        const unsigned long long *flag = (const unsigned long long *)(local + (int64_t)sender * kP2PFlagStride);
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) __hip_atomic_store(err, 1 + sender, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // "rank `sender` never arrived"
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const char *slot = local + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + sender) * slot_bytes + src_sub;
+    p2p_copy_out(buf + dst_off, slot, bytes);
+}
+
+}  // namespace fdjac
+
+using namespace fdjac;
+
+extern "C" {
+
+int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p **out)
+{
+    FD_REQUIRE(ctx && out, FD_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    FD_REQUIRE(nranks >= 1 && nranks <= kP2PMaxRanks && rank >= 0 && rank < nranks, FD_ERR_ARG, "rank %d of %d (at most %d ranks)", rank, nranks, kP2PMaxRanks);
+    FD_REQUIRE(slot_bytes >= 8 && slot_bytes <= ((int64_t)1 << 24), FD_ERR_ARG, "slot_bytes must be in 8 .. 16 MiB (small messages only)");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    fd_p2p *p = new (std::nothrow) fd_p2p();
+    FD_REQUIRE(p != nullptr, FD_ERR_NOMEM, "out of host memory");
+    p->ctx = ctx;
+    p->nranks = nranks;
+    p->rank = rank;
+    p->slot_bytes = (slot_bytes + 127) / 128 * 128;
+    const size_t bytes = 2 * ((size_t)nranks * kP2PFlagStride + 2 * (size_t)nranks * (size_t)p->slot_bytes);      // two channels
+    // fine-grained (uncached) device memory if the runtime shares it between processes, else plain device memory (all accesses to the
+    // mailbox are system-scope atomics either way)
+    void *mem = nullptr;
+    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
+        hipIpcMemHandle_t probe;
+        if (hipIpcGetMemHandle(&probe, mem) == hipSuccess) p->uncached = true;
+        else { (void)hipFree(mem); mem = nullptr; }
+    }
+    (void)hipGetLastError();
+    if (!mem) {
+        hipError_t e = hipMalloc(&mem, bytes);
+        if (e != hipSuccess) { set_error("hipMalloc of the mailbox failed: %s", hipGetErrorString(e)); delete p; return FD_ERR_HIP; }
+    }
+    p->local = (char *)mem;
+    p->peer[rank] = p->local;
+    hipError_t e = hipMemset(p->local, 0, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_err, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *p->h_err = 0; e = hipHostGetDevicePointer((void **)&p->d_err, p->h_err, 0); }
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_peer, sizeof(char *) * kP2PMaxRanks);
+    if (e != hipSuccess) {
+        set_error("setting up the mailbox failed: %s", hipGetErrorString(e));
+        if (p->h_err) (void)hipHostFree(p->h_err);
+        (void)hipFree(p->local);
+        delete p;
+        return FD_ERR_HIP;
+    }
+    if (nranks == 1) {
+        (void)hipMemcpy(p->d_peer, p->peer, sizeof(char *) * kP2PMaxRanks, hipMemcpyHostToDevice);
+        p->connected = true;
+    }
+    *out = p;
+    return FD_OK;
+}
+
+int fd_p2p_local_handle(fd_p2p *p, void *handle_out)
+{
+    FD_REQUIRE(p && handle_out, FD_ERR_ARG, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == FD_P2P_HANDLE_BYTES, "fd_p2p handle size");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    hipIpcMemHandle_t h;
+    FD_HIP_CHECK(hipIpcGetMemHandle(&h, p->local));
+    memcpy(handle_out, &h, sizeof h);
+    return FD_OK;
+}
+
+int fd_p2p_connect(fd_p2p *p, const void *handles)
+{
+    FD_REQUIRE(p && handles, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(!p->connected || p->nranks == 1, FD_ERR_ARG, "already connected");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    for (int r = 0; r < p->nranks; ++r) {
+        if (r == p->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)r * FD_P2P_HANDLE_BYTES, sizeof h);
+        void *ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            set_error("hipIpcOpenMemHandle of rank %d's mailbox failed: %s (one process per GPU on ONE node; HSA_ENABLE_IPC_MODE_LEGACY=0)", r,
+                      hipGetErrorString(e));
+            return FD_ERR_COMM;
+        }
+        p->peer[r] = (char *)ptr;
+        p->mapped[r] = true;
+    }
+    FD_HIP_CHECK(hipMemcpy(p->d_peer, p->peer, sizeof(char *) * kP2PMaxRanks, hipMemcpyHostToDevice));
+    p->connected = true;
+    return FD_OK;
+}
+
+int fd_p2p_destroy(fd_p2p *p)
+{
+    if (!p) return FD_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (int r = 0; r < p->nranks; ++r)
+        if (p->mapped[r] && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
+    if (p->d_peer) (void)hipFree(p->d_peer);
+    if (p->h_err) (void)hipHostFree(p->h_err);
+    if (p->local) (void)hipFree(p->local);
+    delete p;
+    return FD_OK;
+}
+
+int fd_p2p_info(const fd_p2p *p, int *nranks, int *rank, int64_t *slot_bytes, int *uncached)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "p2p is NULL");
+    if (nranks) *nranks = p->nranks;
+    if (rank) *rank = p->rank;
+    if (slot_bytes) *slot_bytes = p->slot_bytes;
+    if (uncached) *uncached = p->uncached ? 1 : 0;
+    return FD_OK;
+}
+
+// 0 while every exchange completed; 1 + r once a wait for rank r timed out (sticky; readable at any time: the word is host memory)
+int fd_p2p_status(const fd_p2p *p, int *timed_out_rank_plus_1)
+{
+    FD_REQUIRE(p && timed_out_rank_plus_1, FD_ERR_ARG, "NULL argument");
+    *timed_out_rank_plus_1 = *(volatile int *)p->h_err;
+    return FD_OK;
+}
+
+static int64_t p2p_timeout_ticks()
+{
+    // wall_clock64() counts at 100 MHz on gfx9; FDJAC_P2P_TIMEOUT_MS bounds every wait (default 2 s)
+    const char *v = getenv("FDJAC_P2P_TIMEOUT_MS");
+    const int64_t ms = (v && *v) ? atoll(v) : 2000;
+    return (ms < 1 ? 1 : ms) * 100000;
+}
+
+// in place, like fd_comm_allgather: buf holds nranks slots of `bytes` bytes, this rank's data in slot `rank`
+int fd_p2p_allgather(fd_p2p *p, void *buf, int64_t bytes)
+{
+    FD_REQUIRE(p && (buf || bytes == 0), FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(bytes >= 0 && bytes % 8 == 0 && bytes <= p->slot_bytes, FD_ERR_ARG, "bytes = %lld must be a multiple of 8, at most the mailbox slot (%lld)",
+               (long long)bytes, (long long)p->slot_bytes);
+    FD_REQUIRE(p->connected, FD_ERR_COMM, "fd_p2p_connect has not been called");
+    if (bytes == 0 || p->nranks == 1) return FD_OK;
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const uint64_t epoch = ++p->epoch[0];
+    P2PPut put = {};
+    put.src_off[0] = (int64_t)p->rank * bytes;
+    put.bytes[0] = bytes;
+    P2PGet get = {};
+    get.bytes[0] = bytes;
+    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)p->nranks), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank,
+                       p->slot_bytes, epoch, 1, (int64_t)0);
+    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)p->nranks), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank, p->slot_bytes,
+                       epoch, 1, p2p_timeout_ticks(), p->d_err, (int64_t)0);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+// like fd_comm_halo_exchange: buf in GLOBAL indexing, this rank owns [own_begin, own_end)
+int fd_p2p_halo_exchange(fd_p2p *p, void *buf, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes)
+{
+    FD_REQUIRE(p && buf, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 4 or 8");
+    FD_REQUIRE(halo >= 0 && own_begin >= 0 && own_end >= own_begin, FD_ERR_ARG, "bad range / halo");
+    FD_REQUIRE(halo == 0 || own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` elements");
+    const int64_t hb = halo * elem_bytes;
+    FD_REQUIRE(hb % 8 == 0 && 2 * hb <= p->slot_bytes, FD_ERR_ARG, "halo of %lld bytes: must be a multiple of 8 and fit twice into the mailbox slot", (long long)hb);
+    FD_REQUIRE(p->connected, FD_ERR_COMM, "fd_p2p_connect has not been called");
+    if (halo == 0 || p->nranks == 1) return FD_OK;
+    const bool lo = p->rank > 0, hi = p->rank + 1 < p->nranks;
+    FD_REQUIRE(!lo || own_begin >= halo, FD_ERR_ARG, "no room for the lower halo");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const uint64_t epoch = ++p->epoch[1];
+    const int64_t chan1 = (int64_t)p->nranks * kP2PFlagStride + 2 * (int64_t)p->nranks * p->slot_bytes;
+    // my first `halo` elements go to rank - 1 (sub-slot 1: "from above"), my last to rank + 1 (sub-slot 0: "from below")
+    P2PPut put = {};
+    P2PGet get = {};
+    if (lo) {
+        put.target[put.n] = p->rank - 1; put.src_off[put.n] = own_begin * elem_bytes; put.dst_sub[put.n] = hb; put.bytes[put.n] = hb; ++put.n;
+        get.sender[get.n] = p->rank - 1; get.dst_off[get.n] = (own_begin - halo) * elem_bytes; get.src_sub[get.n] = 0; get.bytes[get.n] = hb; ++get.n;
+    }
+    if (hi) {
+        put.target[put.n] = p->rank + 1; put.src_off[put.n] = (own_end - halo) * elem_bytes; put.dst_sub[put.n] = 0; put.bytes[put.n] = hb; ++put.n;
+        get.sender[get.n] = p->rank + 1; get.dst_off[get.n] = own_end * elem_bytes; get.src_sub[get.n] = hb; get.bytes[get.n] = hb; ++get.n;
+    }
+    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)put.n), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank, p->slot_bytes,
+                       epoch, 0, chan1);
+    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)get.n), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank, p->slot_bytes, epoch, 0,
+                       p2p_timeout_ticks(), p->d_err, chan1);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+}  // extern "C"
+
+// internals for fdjac_comm.hip (a communicator with an attached mailbox routes its small messages here)
+extern "C" int64_t fdjac_p2p_slot_bytes(const fd_p2p *p) { return p ? p->slot_bytes : 0; }
+extern "C" const fd_ctx *fdjac_p2p_ctx(const fd_p2p *p) { return p ? p->ctx : nullptr; }
+extern "C" int fdjac_p2p_nranks(const fd_p2p *p) { return p ? p->nranks : 0; }
+extern "C" int fdjac_p2p_rank(const fd_p2p *p) { return p ? p->rank : -1; }
+
+#endif /* FDJAC_F32 */

@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 FD_OK = 0
 FD_ERR_COMM = 8
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
 EPS_COMPUTE, EPS_PRECOMPUTED = 0, 1
 TRI_DIAGONALS, TRI_CSC = 0, 1
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
@@ -68,7 +69,9 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p",
+    "fd_p2p_create", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
+    "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
@@ -213,6 +216,15 @@ def load():
     L.fd_comm_allreduce_sum.argtypes = [vp, vp, i64, i32]
     L.fd_comm_broadcast.argtypes = [vp, vp, i64, i32, i32]
     L.fd_comm_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
+    L.fd_comm_enable_p2p.argtypes = [vp, i64]
+    L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
+    L.fd_p2p_local_handle.argtypes = [vp, vp]
+    L.fd_p2p_connect.argtypes = [vp, vp]
+    L.fd_p2p_destroy.argtypes = [vp]
+    L.fd_p2p_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
+    L.fd_p2p_status.argtypes = [vp, C.POINTER(i32)]
+    L.fd_p2p_allgather.argtypes = [vp, vp, i64]
+    L.fd_p2p_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
     L.fd_plan_eps_shard_range.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.fd_plan_set_comm.argtypes = [vp, vp]
     L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]

@@ -460,6 +460,35 @@ int fd_comm_broadcast(fd_comm *comm, void *buf, int64_t n, int elem_bytes, int r
    point-to-point transfers (2 x halo elements per link).  The end ranks skip the neighbour they do not have. */
 int fd_comm_halo_exchange(fd_comm *comm, void *buf, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes);
 
+/* ---- small messages by direct peer-to-peer stores (one node, one process per GPU) ----------------------------------------------
+ * The per-step exchanges of a time-stepping loop -- the halo of x, the partial sums of the step-size reduction (62 KB), the
+ * interface packets of the sharded solve (64 B per rank) -- are a few kilobytes each: as RCCL collectives they cost a
+ * general-purpose machine's latency (10-25 us each), as stores into a peer's HBM over xGMI a few microseconds.  Every rank owns a
+ * MAILBOX in its HBM and maps its peers' (hipIpc handles); an exchange is two kernels on the context's stream: put (copy into the
+ * peers' mailboxes, system-scope fence, raise a flag) and wait (poll the flags, bounded by FDJAC_P2P_TIMEOUT_MS = 2000 by default
+ * -- a missing peer raises fd_p2p_status instead of hanging the GPU -- then copy out).  RCCL stays for the bulk assembly of nzval.
+ *   bootstrap: fd_p2p_create on every rank; every rank's fd_p2p_local_handle (FD_P2P_HANDLE_BYTES bytes) reaches every rank by
+ *   whatever the host has (MPI.jl Allgather, a torch.distributed store); fd_p2p_connect(all handles in rank order) -- or
+ *   fd_comm_enable_p2p, which does all of that over the RCCL communicator and routes the communicator's small messages
+ *   (fd_comm_allgather / fd_comm_halo_exchange up to slot_bytes, hence the sharded step-size reduction and the sharded solve)
+ *   through the mailbox from then on. */
+typedef struct fd_p2p fd_p2p;
+#define FD_P2P_HANDLE_BYTES 64
+int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes /* per rank per exchange, <= 16 MiB */, fd_p2p **out);
+int fd_p2p_local_handle(fd_p2p *p2p, void *handle_out /* FD_P2P_HANDLE_BYTES bytes, host */);
+int fd_p2p_connect(fd_p2p *p2p, const void *handles /* nranks x FD_P2P_HANDLE_BYTES bytes, rank order, host */);
+int fd_p2p_destroy(fd_p2p *p2p);
+int fd_p2p_info(const fd_p2p *p2p, int *nranks, int *rank, int64_t *slot_bytes, int *uncached);   /* any out pointer may be NULL */
+/* 0 while every exchange completed; 1 + r once a wait for rank r timed out (sticky; no synchronisation needed to read it) */
+int fd_p2p_status(const fd_p2p *p2p, int *timed_out_rank_plus_1);
+/* in place, like fd_comm_allgather: buf holds nranks slots of `bytes` bytes (a multiple of 8, <= slot_bytes), this rank's in slot `rank` */
+int fd_p2p_allgather(fd_p2p *p2p, void *buf, int64_t bytes);
+/* like fd_comm_halo_exchange (halo * elem_bytes a multiple of 8, twice that <= slot_bytes) */
+int fd_p2p_halo_exchange(fd_p2p *p2p, void *buf, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes);
+/* Create a mailbox for the communicator's ranks, exchange the handles over RCCL and route the communicator's small messages
+   through it (collective: every rank calls it; blocking).  FD_ERR_COMM if the peers cannot be mapped (ranks on several nodes). */
+int fd_comm_enable_p2p(fd_comm *comm, int64_t slot_bytes);
+
 /* Sharded step-size reduction.  By default every rank reduces the whole (replicated) x -- no communication, identical
    step sizes everywhere.  With a communicator attached, rank r reduces only blocks r of nranks of the SAME global grid
    of partial sums, the partials (a few KB) are all-gathered and finalized in the same fixed order: the step sizes are

@@ -1,0 +1,99 @@
+"""Two processes, ONE GPU: the peer-to-peer mailbox (fd_p2p_*, csrc/fdjac_p2p.hip) end to end -- IPC mapping of the other
+process's mailbox, epochs / parity double-buffering over many exchanges, the halo channel, the sharded step-size reduction with
+its partial sums exchanged through the mailbox (bit-identical step sizes), and the timeout of a wait whose peer never arrives.
+Launched by tests/test_gpu_multigpu.py::test_p2p_mailbox_two_processes_one_gpu through torch.distributed.run (gloo is only the
+out-of-band channel for the 64-byte handles and the barriers)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import finitediff_jl_amd as fd
+    from finitediff_jl_amd import patterns as P
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = fd.Context(0)
+    p2p = fd.P2P.from_torch_distributed(ctx, dist, slot_bytes=1 << 16)
+    info = p2p.info()
+    assert info["nranks"] == world and info["rank"] == rank and info["slot_bytes"] >= 1 << 16
+
+    # (1) all-gather channel: many exchanges back to back, new payload every time, nothing synchronises in between
+    S = 1000
+    bufs = []
+    for it in range(64):
+        buf = torch.zeros(world * S, dtype=torch.float64, device=dev)
+        buf[rank * S:(rank + 1) * S] = torch.arange(S, dtype=torch.float64, device=dev) + 1e6 * rank + it
+        p2p.allgather(buf, S)
+        bufs.append(buf)
+    torch.cuda.synchronize()
+    for it, buf in enumerate(bufs):
+        want = torch.cat([torch.arange(S, dtype=torch.float64, device=dev) + 1e6 * r + it for r in range(world)])
+        assert torch.equal(buf, want), ("allgather", it)
+    assert p2p.status() == 0
+
+    # (2) halo channel, interleaved with all-gathers (independent epochs per channel)
+    N, halo = 4096, 2
+    cuts = [0, N // 2, N] if world == 2 else list(np.linspace(0, N, world + 1).astype(int))
+    a, b = int(cuts[rank]), int(cuts[rank + 1])
+    for it in range(10):
+        x = torch.full((N,), float("nan"), dtype=torch.float64, device=dev)
+        x[a:b] = torch.arange(a, b, dtype=torch.float64, device=dev) * (it + 1)
+        p2p.halo_exchange(x, a, b, halo)
+        g = torch.zeros(world * 8, dtype=torch.float64, device=dev)
+        g[rank * 8:(rank + 1) * 8] = rank + it
+        p2p.allgather(g, 8)
+        torch.cuda.synchronize()
+        lo, hi = max(a - halo, 0), min(b + halo, N)
+        assert torch.equal(x[lo:hi], torch.arange(lo, hi, dtype=torch.float64, device=dev) * (it + 1)), ("halo", it)
+        assert torch.isnan(x[:lo]).all() and torch.isnan(x[hi:]).all()
+        assert torch.equal(g, torch.arange(world, dtype=torch.float64, device=dev).repeat_interleave(8) + it)
+
+    # (3) the sharded step-size reduction with its partial sums exchanged through the mailbox: the bits of the unsharded call
+    Nn = 300_001
+    cp, rv = P.tridiag_csc(Nn)
+    colors = P.cyclic_colors(Nn, 3)
+    pat = fd.SparseMatrixCSC(Nn, Nn, cp, rv, None)
+    xs = torch.as_tensor(np.random.default_rng(5).random(Nn), device=dev)
+    f = fd.BuiltinF("tridiag_nl", Nn, ctx=ctx)
+    ref_plan = fd.make_plan(pat, pat, colors, "forward", ctx=ctx)
+    out_ref = torch.empty(rv.size, dtype=torch.float64, device=dev)
+    ref_plan.jacobian(f, xs, [out_ref])
+    eps_ref = ref_plan.epsilons()
+    plan = fd.make_plan(pat, pat, colors, "forward", ctx=ctx)
+    pptr, slot = plan.eps_partials(xs, rank, world)
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (world * slot,), "typestr": "<f8", "data": (pptr, False), "version": 2}
+    part = torch.as_tensor(_Raw(), device=dev)
+    p2p.allgather(part, slot)
+    plan.eps_finalize()
+    plan.set_eps_mode(True)
+    out = torch.empty_like(out_ref)
+    plan.jacobian(f, xs, [out])
+    assert np.array_equal(plan.epsilons(), eps_ref) and torch.equal(out, out_ref)
+    assert p2p.status() == 0
+    dist.barrier()
+
+    # (4) a peer that never arrives: the wait gives up after FDJAC_P2P_TIMEOUT_MS and raises the status word -- no hang
+    os.environ["FDJAC_P2P_TIMEOUT_MS"] = "150"
+    if rank == 0:
+        g = torch.zeros(world * 8, dtype=torch.float64, device=dev)
+        p2p.allgather(g, 8)
+        torch.cuda.synchronize()
+        assert p2p.status() == 2, p2p.status()          # 1 + (rank 1)
+    dist.barrier()
+    print("p2p rank %d ok (uncached mailbox: %s)" % (rank, info["uncached"]))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -192,3 +192,21 @@ def test_contiguous_step_size_reduction_reads_only_the_shard(monkeypatch, fdtype
             wp.jacobian(f, x, [o])
             pieces.append(o)
         assert torch.equal(torch.cat(pieces), ref), W
+
+
+@pytest.mark.timeout(300)
+def test_p2p_mailbox_two_processes_one_gpu():
+    # fd_p2p_*: small-message exchange by direct stores into the peers' mailboxes (csrc/fdjac_p2p.hip).  Two processes share the one
+    # GPU of the box: the IPC mapping, epochs / parity over many exchanges, the halo channel, the sharded step-size reduction with
+    # its partial sums exchanged through the mailbox (bit-identical), a wait that times out instead of hanging.  (What two GPUs
+    # would add -- the ordering of remote stores over xGMI -- cannot be executed here.)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "tests", "p2p_two_ranks.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
+    assert out.stdout.count("p2p rank") == 2
