@@ -64,6 +64,13 @@ def parse():
                          "the time-stepping layout -- rank r holds its own part of x, every step starts with the neighbour halo "
                          "exchange (fd_comm_halo_exchange) and the step-size reduction is sharded over contiguous ranges "
                          "(FD_PLAN_EPS_CONTIGUOUS + fd_plan_set_comm): per step 2(l+u) values per link + one all-gather of the partial sums")
+    ap.add_argument("--small-messages", choices=["rccl", "p2p"], default="rccl",
+                    help="N>1: how the per-step small messages travel (halo of x, partial sums of the sharded step-size reduction, solve "
+                         "interface): RCCL collectives, or direct peer-to-peer stores into the ranks' mailboxes (fd_comm_enable_p2p / "
+                         "fd_p2p_*: hipIpc-mapped HBM, two kernels per exchange, no proxy); the bulk nzval gather is RCCL either way")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: weak scaling -- N = gpus x 10^7 columns (each rank keeps the single-GPU problem size) instead of "
+                         "splitting the fixed N = 10^7 problem; the line says scaling = weak")
     ap.add_argument("--shard", choices=["columns", "colors"], default="columns",
                     help="N>1 decomposition: contiguous column ranges (default; needs a row-window-capable f!), "
                          "or colour ownership + all-reduce (any f!, at most C ranks; c4/c2 only)")
@@ -191,13 +198,26 @@ def main():
         except Exception as e:   # the timed step has no collective in it: measure it anyway, report the failure loudly
             comm_error = "%s: %s" % (type(e).__name__, e)
             sys.stderr.write("[bench rank %d] fd_comm_create failed (%s): the nzval assembly and the sharded solve are skipped\n" % (rank, comm_error))
+    p2p = None
+    p2p_note = None
+    if world > 1 and args.small_messages == "p2p":
+        try:
+            if comm is not None:
+                comm.enable_p2p(1 << 17)       # the communicator's small messages go through the mailboxes from here on
+                p2p_note = "fd_comm_enable_p2p: mailboxes mapped over hipIpc, handles exchanged over RCCL"
+            else:
+                p2p = fd.P2P.from_torch_distributed(ctx, dist, slot_bytes=1 << 17)
+                p2p_note = "fd_p2p_* (handles exchanged through torch.distributed; %s mailbox)" % ("uncached" if p2p.info()["uncached"] else "device")
+        except Exception as e:
+            p2p_note = "FAILED, small messages stay on %s: %s: %s" % ("RCCL" if comm is not None else "the host", type(e).__name__, e)
+            sys.stderr.write("[bench rank %d] peer-to-peer mailboxes unavailable (%s)\n" % (rank, p2p_note))
     by_color = args.shard == "colors" and world > 1 and cfg in ("c2", "c4")
     x_sharded = False
     lazy_ok = False
     vs = 4 if args.dtype == "f32" else 8          # bytes per value
     t_plan = time.perf_counter()
     if cfg in ("c2", "c4"):
-        N = args.n or (10 ** 6 if cfg == "c2" else 10 ** 7)
+        N = args.n or (10 ** 6 if cfg == "c2" else 10 ** 7) * (world if args.weak else 1)
         seed, fdtype, C = (2 if cfg == "c2" else 4), "forward", 3
         x_host = np.random.default_rng(seed).random(N)
         colors = P.cyclic_colors(N, 3)
@@ -375,11 +395,17 @@ def main():
         if x_sharded:
             if comm is not None:
                 comm.halo_exchange(x, c0, c1, 2)       # tridiagonal f! on the rows of the band (1,1): x[c0-2, c1+2)
+            elif p2p is not None:
+                p2p.halo_exchange(x, c0, c1, 2)        # (dry run on shared GPUs: the mailbox path without RCCL)
             else:
                 xh = x.cpu()
                 S.halo_exchange_host(xh, cuts, rank, 2, dist)
                 x.copy_(xh)
-        if eps_host is not None:
+        if eps_host is not None and p2p is not None:
+            plan.eps_partials(x, rank, world)
+            p2p.allgather(eps_host["dev"], eps_host["slot"])
+            plan.eps_finalize()
+        elif eps_host is not None:
             plan.eps_partials(x, rank, world)
             sl = eps_host["slot"]
             mine = eps_host["dev"][rank * sl:(rank + 1) * sl].cpu()
@@ -756,7 +782,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if (args.weak and world > 1) else "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
@@ -773,6 +799,8 @@ def main():
                                   if f_mode == "lazy" else
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
                        "eps_reduction": diag["eps"], "x_layout": diag["x_layout"], "gather_in_step": bool(gather_in_step),
+                       "small_messages": (p2p_note or "rccl") if world > 1 else None,
+                       "problem": ("N = %d = %d x 10^7 columns (weak scaling)" % (N, world)) if (args.weak and world > 1) else None,
                        "collective_backend": (("rccl via libfdjac fd_comm_* (%s)" % comm.info()["library"]) if comm is not None
                                               else backend) if world > 1 else None},
             "median_ms_per_step": call_med,

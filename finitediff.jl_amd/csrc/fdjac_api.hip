@@ -121,7 +121,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     FD_REQUIRE((opts->flags & ~kPlanKnownFlags) == 0, FD_ERR_ARG, "unknown fd_plan_opts.flags bits 0x%x (zero the struct before filling it)",
                (unsigned)(opts->flags & ~kPlanKnownFlags));
     FD_REQUIRE(!(opts->flags & FD_PLAN_COMPLEX_X), FD_ERR_UNSUPPORTED,
-               "complex-valued x (FD_PLAN_COMPLEX_X) is built for CSC, dense-J, entry-list and dense-arm plans, not for this storage type");
+               "complex-valued x (FD_PLAN_COMPLEX_X) reaches this plan kind through its lowering only");
     p->fdtype = opts->fdtype;
     p->col0 = 0;
     p->col1 = p->N;
@@ -1207,7 +1207,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_split};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -1396,6 +1396,18 @@ static int lowered_coo(fd_ctx *ctx, int64_t M, int64_t N, const void *rows_index
     }
     LoweredScope lowered;
     return fd_plan_create_entries(ctx, 2 * M, 2 * N, L.rows.data(), L.cols.data(), L.dest.data(), 2 * nnz, 2 * out_len, 8, 0, L.colors.data(), 8, &L.opts, out);
+}
+
+// Complex-valued x on STRUCTURED storage (Tridiagonal, BandedMatrix, BlockBandedMatrix: src/jacobians.jl:94-128, 537-622 are generic in
+// the matrix type too): the storage is enumerated once as (row, column, position) triples in complex elements and lowered like any
+// entry list; a Tridiagonal's three arrays are one concatenated output (dl | d | du) that the call splits afterwards.
+static int lowered_structured(fd_ctx *ctx, int64_t M, int64_t N, const std::vector<int64_t> &rows, const std::vector<int64_t> &cols,
+                              const std::vector<int64_t> &dest, int64_t out_len, const void *colorvec, int color_bytes, const fd_plan_opts *opts,
+                              fd_plan **out)
+{
+    FD_REQUIRE(opts->col_begin == 0 && (opts->col_end == 0 || opts->col_end == N), FD_ERR_UNSUPPORTED,
+               "column windows are not supported for complex-valued x on structured storage");
+    return lowered_coo(ctx, M, N, rows.data(), cols.data(), dest.data(), (int64_t)rows.size(), out_len, 8, 0, colorvec, color_bytes, opts, out);
 }
 
 int fd_plan_create_csc(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr, const void *rowval, int idx_bytes,
@@ -1842,14 +1854,46 @@ int fd_plan_create_csc_device(fd_ctx *ctx, int64_t M, int64_t N, const void *col
 int fd_plan_create_tridiagonal(fd_ctx *ctx, int64_t N, const void *colorvec, int color_bytes,
                                const fd_plan_opts *opts, fd_plan **out)
 {
-    const int rc = tridiagonal_impl(ctx, N, colorvec, color_bytes, opts, out);
+    int rc;
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X)) {
+        // J[j+1, j] -> dl[j], J[j, j] -> d[j], J[j-1, j] -> du[j-1]; the concatenated output is (dl | d | du) in complex elements
+        FD_REQUIRE(N >= 1, FD_ERR_ARG, "N < 1");
+        std::vector<int64_t> rows, cols, dest;
+        rows.reserve((size_t)(3 * N)); cols.reserve((size_t)(3 * N)); dest.reserve((size_t)(3 * N));
+        for (int64_t j = 0; j < N; ++j) {
+            if (j > 0) { rows.push_back(j - 1); cols.push_back(j); dest.push_back((N - 1) + N + (j - 1)); }
+            rows.push_back(j); cols.push_back(j); dest.push_back((N - 1) + j);
+            if (j + 1 < N) { rows.push_back(j + 1); cols.push_back(j); dest.push_back(j); }
+        }
+        rc = lowered_structured(ctx, N, N, rows, cols, dest, 3 * N - 2, colorvec, color_bytes, opts, out);
+        if (rc == FD_OK) {
+            fd_plan *p = *out;
+            p->split_n = 3;
+            p->split_len[0] = 2 * (N - 1); p->split_len[1] = 2 * N; p->split_len[2] = 2 * (N - 1);
+        }
+    } else {
+        rc = tridiagonal_impl(ctx, N, colorvec, color_bytes, opts, out);
+    }
     return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
 }
 
 int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, const void *colorvec,
                           int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
-    const int rc = banded_impl(ctx, M, N, l, u, colorvec, color_bytes, opts, out);
+    int rc;
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X)) {
+        // data[(u + r - j) + (l + u + 1) j] = J[r, j]; the slots of rows outside the matrix are zero (the entry-list plan zero-fills)
+        FD_REQUIRE(l + u + 1 >= 1 && l > -N && u > -M && M >= 1 && N >= 1, FD_ERR_ARG, "bad shape / bandwidths (%lld,%lld)", (long long)l, (long long)u);
+        const int64_t w = l + u + 1;
+        std::vector<int64_t> rows, cols, dest;
+        for (int64_t j = 0; j < N; ++j)
+            for (int64_t r = std::max<int64_t>(j - u, 0); r <= std::min<int64_t>(j + l, M - 1); ++r) {
+                rows.push_back(r); cols.push_back(j); dest.push_back((u + r - j) + w * j);
+            }
+        rc = lowered_structured(ctx, M, N, rows, cols, dest, w * N, colorvec, color_bytes, opts, out);
+    } else {
+        rc = banded_impl(ctx, M, N, l, u, colorvec, color_bytes, opts, out);
+    }
     return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
 }
 
@@ -1857,8 +1901,38 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
                                const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
                                const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
 {
-    const int rc = blockbanded_impl(ctx, nblk, blk_sizes, bl, bu, block_starts, block_strides, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
-    const int64_t N = (rc == FD_OK && out && *out) ? (*out)->N : 0;
+    int rc;
+    if (opts && (opts->flags & FD_PLAN_COMPLEX_X)) {
+        // every in-band block (K, J) is dense: row t of the block, local column c -> data[block_starts(K, J) + t + block_strides[J] c]
+        FD_REQUIRE(blk_sizes && block_starts && block_strides, FD_ERR_ARG, "NULL block layout array");
+        FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+        FD_REQUIRE(nblk >= 1 && bl >= 0 && bu >= 0, FD_ERR_ARG, "bad block structure");
+        std::vector<int64_t> off((size_t)nblk + 1, 0);
+        for (int64_t b = 0; b < nblk; ++b) {
+            const int64_t sz = load_idx(blk_sizes, idx_bytes, b);
+            FD_REQUIRE(sz >= 0, FD_ERR_SHAPE, "negative block size");
+            off[(size_t)b + 1] = off[(size_t)b] + sz;
+        }
+        const int64_t Nn = off[(size_t)nblk], w = bl + bu + 1;
+        std::vector<int64_t> rows, cols, dest;
+        int64_t out_len = 0;
+        for (int64_t J = 0; J < nblk; ++J) {
+            const int64_t stride = load_idx(block_strides, idx_bytes, J);
+            for (int64_t K = std::max<int64_t>(J - bu, 0); K <= std::min<int64_t>(J + bl, nblk - 1); ++K) {
+                const int64_t st = load_idx(block_starts, idx_bytes, (bu + K - J) + w * J) - idx_base;
+                FD_REQUIRE(st >= 0 && stride >= off[(size_t)K + 1] - off[(size_t)K], FD_ERR_SHAPE, "inconsistent block layout at block (%lld,%lld)", (long long)K, (long long)J);
+                for (int64_t c = 0; c < off[(size_t)J + 1] - off[(size_t)J]; ++c)
+                    for (int64_t t = 0; t < off[(size_t)K + 1] - off[(size_t)K]; ++t) {
+                        rows.push_back(off[(size_t)K] + t); cols.push_back(off[(size_t)J] + c); dest.push_back(st + t + stride * c);
+                        out_len = std::max<int64_t>(out_len, st + t + stride * c + 1);
+                    }
+            }
+        }
+        rc = lowered_structured(ctx, Nn, Nn, rows, cols, dest, out_len, colorvec, color_bytes, opts, out);
+    } else {
+        rc = blockbanded_impl(ctx, nblk, blk_sizes, bl, bu, block_starts, block_strides, idx_bytes, idx_base, colorvec, color_bytes, opts, out);
+    }
+    const int64_t N = (rc == FD_OK && out && *out) ? ((*out)->cx ? (*out)->N / 2 : (*out)->N) : 0;
     return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
 }
 
@@ -1869,10 +1943,10 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_M: *value = p->M; break;
     case FD_INFO_N: *value = p->N; break;
     case FD_INFO_NCOLORS: *value = p->C; break;
-    case FD_INFO_NOUTS: *value = p->nouts; break;
-    case FD_INFO_OUT0_LEN: *value = p->out_len[0]; break;
-    case FD_INFO_OUT1_LEN: *value = p->out_len[1]; break;
-    case FD_INFO_OUT2_LEN: *value = p->out_len[2]; break;
+    case FD_INFO_NOUTS: *value = p->split_n ? p->split_n : p->nouts; break;
+    case FD_INFO_OUT0_LEN: *value = p->split_n ? p->split_len[0] : p->out_len[0]; break;
+    case FD_INFO_OUT1_LEN: *value = p->split_n ? p->split_len[1] : p->out_len[1]; break;
+    case FD_INFO_OUT2_LEN: *value = p->split_n ? p->split_len[2] : p->out_len[2]; break;
     case FD_INFO_ROW_BEGIN: *value = p->row0; break;
     case FD_INFO_ROW_END: *value = p->row1; break;
     case FD_INFO_NCHUNKS: *value = p->nchunks; break;
@@ -2311,10 +2385,36 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     return FD_OK;
 }
 
+// complex-valued x on Tridiagonal storage: the lowered plan fills ONE concatenated array (dl | d | du), copied into the caller's three
+static int jacobian_split(fd_plan *p, bool async, fd_f_launch f, void *fctx, const void *x, int x_kind, const void *f_in, int f_in_kind, double relstep,
+                          double absstep, double dir, void *const *outs, int out_kind)
+{
+    for (int k = 0; k < p->split_n; ++k) FD_REQUIRE(outs[k] || p->split_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (!p->d_split) { const int rc = dev_alloc(&p->d_split, p->out_len[0]); if (rc) return rc; }
+    void *one[3] = {p->d_split, nullptr, nullptr};
+    const int n = p->split_n;
+    p->split_n = 0;                 // (the inner call sees the plan's one output)
+    const int rc = async ? fd_jacobian_async(p, f, fctx, x, f_in, relstep, absstep, dir, one)
+                         : fd_jacobian(p, f, fctx, x, x_kind, f_in, f_in_kind, relstep, absstep, dir, one, FD_DEVICE);
+    p->split_n = n;
+    if (rc) return rc;
+    int64_t off = 0;
+    for (int k = 0; k < n; ++k) {
+        if (p->split_len[k] > 0)
+            FD_HIP_CHECK(hipMemcpyAsync(outs[k], p->d_split + off, sizeof(real_t) * (size_t)p->split_len[k],
+                                        out_kind == FD_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, p->ctx->stream));
+        off += p->split_len[k];
+    }
+    if (!async) FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    return FD_OK;
+}
+
 int fd_jacobian_async(fd_plan *p, fd_f_launch f, void *fctx, const void *x, const void *f_in, double relstep,
                       double absstep, double dir, void *const *outs)
 {
     FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
+    if (p->split_n) return jacobian_split(p, true, f, fctx, x, FD_DEVICE, f_in, FD_DEVICE, relstep, absstep, dir, outs, FD_DEVICE);
     for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     real_t *o[3] = {(real_t *)outs[0], p->nouts > 1 ? (real_t *)outs[1] : nullptr,
@@ -2326,6 +2426,7 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
                 double relstep, double absstep, double dir, void *const *outs, int out_kind)
 {
     FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
+    if (p->split_n) return jacobian_split(p, false, f, fctx, x, x_kind, f_in, f_in_kind, relstep, absstep, dir, outs, out_kind);
     for (int k = 0; k < p->nouts; ++k) FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;

@@ -283,6 +283,11 @@ struct fd_plan {
 
     int nouts = 1;
     int64_t out_len[3] = {0, 0, 0};
+    // complex-valued x on Tridiagonal storage: the lowered plan writes ONE concatenated array (dl | d | du) into d_split, which
+    // the call then copies into the caller's three arrays (split_n = 3, split_len in reals)
+    int split_n = 0;
+    int64_t split_len[3] = {0, 0, 0};
+    fdjac::real_t *d_split = nullptr;
     fdjac::real_t *d_outstage[3] = {nullptr, nullptr, nullptr};
 
     const fdjac::real_t *fx_batch_row = nullptr;   // f(x) evaluated as one more member of the perturbed batch (small problems)

@@ -377,10 +377,71 @@ def test_complex_valued_x_coloured_paths(fdtype, kind):
         assert np.all(got[~pat] == 0)                                   # fill_matrix!: entries outside the pattern are zero
         assert np.abs(got - want_dense).max() <= 1e-6 * np.abs(want_dense).max() + 1e-7
     assert f.fcalls == (4 if fdtype == "forward" else 6)
-    with pytest.raises(fd.lib.FdError) as e:                            # storage types the lowering is not built for say so
-        fd.finite_difference_jacobian_b(fd.Tridiagonal(torch.zeros(N - 1, dtype=torch.complex128, device="cuda"), torch.zeros(N, dtype=torch.complex128, device="cuda"),
-                                                       torch.zeros(N - 1, dtype=torch.complex128, device="cuda")), f, x, fdtype, np.complex128, colorvec=colors)
-    assert e.value.code == 3
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_complex_valued_x_structured_storage(fdtype):
+    # complex-valued x with J::Tridiagonal / BandedMatrix / BlockBandedMatrix (the reference's loop is generic in the matrix type:
+    # src/jacobians.jl:94-128, 537-622 with src/iteration_utils.jl:25-32, ext/FiniteDiffBandedMatricesExt.jl:13-27,
+    # ext/FiniteDiffBlockBandedMatricesExt.jl:44-68).  Every stored entry must be the value the dense-J complex path (checked
+    # against the numpy restatement in test_complex_valued_x_coloured_paths) puts at that (row, column): same arithmetic, same bits.
+    cnan = complex(float("nan"), float("nan"))
+
+    def cfull(*shape):
+        return torch.full(shape, cnan, dtype=torch.complex128, device="cuda")
+
+    # --- Tridiagonal and BandedMatrix(1, 1): the tridiagonal fixture
+    N = 257
+    rng = np.random.default_rng(91)
+    xh = rng.random(N) + 1j * (rng.random(N) - 0.5)
+    x = torch.as_tensor(xh, device="cuda")
+    colors = P.cyclic_colors(N, 3)
+
+    def f_t(fv, xx):
+        z = torch.zeros(1, dtype=xx.dtype, device=xx.device)
+        xm, xp = torch.cat([z, xx[:-1]]), torch.cat([xx[1:], z])
+        fv.copy_((xm - 2 * xx) + xp + (xx * xx) * xp)
+
+    f = fd.TorchF(f_t, N, N)
+    pat = (np.abs(np.subtract.outer(np.arange(N), np.arange(N))) <= 1).astype(float)
+    Jd = cfull(N, N).t()
+    fd.finite_difference_jacobian_b(Jd, f, x, fdtype, np.complex128, colorvec=colors, sparsity=pat)
+    ref = Jd.cpu().numpy()
+    tri = fd.Tridiagonal(cfull(N - 1), cfull(N), cfull(N - 1))
+    n0 = f.fcalls
+    fd.finite_difference_jacobian_b(tri, f, x, fdtype, np.complex128, colorvec=colors)
+    assert f.fcalls - n0 == (4 if fdtype == "forward" else 6)
+    assert np.array_equal(tri.d.cpu().numpy(), np.diag(ref)) and np.array_equal(tri.dl.cpu().numpy(), np.diag(ref, -1))
+    assert np.array_equal(tri.du.cpu().numpy(), np.diag(ref, 1))
+    band = fd.BandedMatrix(cfull(N, 3).t(), N, 1, 1)                     # (l + u + 1) x N, column-major
+    fd.finite_difference_jacobian_b(band, f, x, fdtype, np.complex128, colorvec=colors)
+    data = band.data.cpu().numpy()
+    for j in range(N):
+        for r in range(max(j - 1, 0), min(j + 1, N - 1) + 1):
+            assert data[1 + r - j, j] == ref[r, j]
+    assert data[0, 0] == 0 and data[2, N - 1] == 0                      # the slots of rows outside the matrix hold 0
+    # --- BlockBandedMatrix: dense blocks, block-tridiagonal, f = B x + x .* x with a dense block-tridiagonal B
+    lay = P.BlockBandedLayout(np.array([3, 5, 4, 2, 6]), 1, 1)
+    Nb = lay.N
+    colors_b = lay.colors()
+    off = np.concatenate([[0], np.cumsum(lay.blk_sizes)])
+    mask = np.zeros((Nb, Nb), bool)
+    for K in range(lay.nblk):
+        for Jb in range(max(K - 1, 0), min(K + 1, lay.nblk - 1) + 1):
+            mask[off[K]:off[K + 1], off[Jb]:off[Jb + 1]] = True
+    B = (rng.random((Nb, Nb)) + 1j * rng.random((Nb, Nb))) * mask
+    Bt = torch.as_tensor(B, device="cuda")
+    xb = torch.as_tensor(rng.random(Nb) + 1j * (rng.random(Nb) - 0.5), device="cuda")
+    fb = fd.TorchF(lambda fv, xx: fv.copy_(Bt @ xx + xx * xx), Nb, Nb)
+    Jdb = cfull(Nb, Nb).t()
+    fd.finite_difference_jacobian_b(Jdb, fb, xb, fdtype, np.complex128, colorvec=colors_b, sparsity=mask.astype(float))
+    refb = Jdb.cpu().numpy()
+    Jbb = fd.BlockBandedMatrix(cfull(lay.data_len), lay)
+    fd.finite_difference_jacobian_b(Jbb, fb, xb, fdtype, np.complex128, colorvec=colors_b)
+    got = lay.to_dense(Jbb.data.cpu().numpy()) if hasattr(lay, "to_dense") else None
+    if got is not None:
+        assert np.array_equal(got[mask], refb[mask])
+    assert np.abs(refb[mask] - (B + np.diag(2 * xb.cpu().numpy()))[mask]).max() < (2e-6 if fdtype == "forward" else 2e-9) * 4
 
 
 def test_hip_error_left_behind_by_a_launcher_is_reported():

@@ -132,15 +132,18 @@ def test_two_rank_halo_exchange_gloo(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize("variant", ["x_sharded", "eps_sharded", "colors"])
+@pytest.mark.parametrize("variant", ["x_sharded", "eps_sharded", "colors", "x_sharded_p2p", "weak"])
 def test_bench_two_ranks_dry_run_variants(variant):
     """bench.py's other N>1 decompositions end to end (two ranks sharing the one GPU, gloo transport): --x-layout sharded (halo
     exchange + contiguous sharded step-size reduction before every Jacobian: the time-stepping layout), --eps sharded (the
     explicit fd_plan_eps_partials / all-gather / fd_plan_eps_finalize pieces) and --shard colors (colour ownership +
     all-reduce).  bench.py checks every stored value itself and exits non-zero if a check fails."""
     import json
-    port = {"x_sharded": "29527", "eps_sharded": "29529", "colors": "29531"}[variant]
-    extra = {"x_sharded": ["--x-layout", "sharded"], "eps_sharded": ["--eps", "sharded"], "colors": ["--shard", "colors"]}[variant]
+    port = {"x_sharded": "29527", "eps_sharded": "29529", "colors": "29531", "x_sharded_p2p": "29533", "weak": "29535"}[variant]
+    extra = {"x_sharded": ["--x-layout", "sharded"], "eps_sharded": ["--eps", "sharded"], "colors": ["--shard", "colors"],
+             # the time-stepping layout with the halo and the partial sums travelling through the peer-to-peer mailboxes (fd_p2p_*, on the GPU)
+             "x_sharded_p2p": ["--x-layout", "sharded", "--small-messages", "p2p"],
+             "weak": ["--weak"]}[variant]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FDJAC_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
@@ -157,6 +160,10 @@ def test_bench_two_ranks_dry_run_variants(variant):
         assert res["config"]["eps_reduction"] == "sharded"
     if variant == "colors":
         assert res["config"]["parallelism"] == "colours x2"
+    if variant == "x_sharded_p2p":
+        assert res["config"]["x_layout"].startswith("sharded") and res["config"]["small_messages"].startswith("fd_p2p_")
+    if variant == "weak":
+        assert res["scaling"] == "weak"
 
 
 @pytest.mark.gpu
