@@ -332,7 +332,7 @@ def main():
     elif lazy_store and cfg == "c3":
         bytes_min = (8 * N + N + nnz * 8) / N                   # x in, one colour byte per column, nzval out
         bytes_call_model = 9.0 + bytes_min
-        kern = "k_f_stencil5_store_wave<unsigned char, 1, 0, true>"
+        kern = "k_f_stencil5_store_wave<unsigned char, 1, 0>"
     elif lazy_store and cfg == "c5":
         bytes_min = (8 * N + N + 16 * N + nnz * 8) / N          # x in, one colour byte + the (row range, destination) of a column, data out
         bytes_call_model = 9.0 + bytes_min

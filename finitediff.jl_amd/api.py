@@ -422,6 +422,12 @@ class TridiagSolver:
         _l.check(self.Lt.fd_tridiag_solve_async(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),
                                                 self._vec(y, "y"), comm.handle if comm is not None else None))
 
+    def status(self):
+        """fd_tridiag_solver_status: bit 0 = the last solve met a row that is not diagonally dominant (no pivoting: result not guaranteed)."""
+        v = C.c_int()
+        _l.check(self.Lt.fd_tridiag_solver_status(self.handle, C.byref(v)))
+        return v.value
+
     def interface(self, J, b, packet, alpha=1.0, beta=-1.0):
         """Phase A (fd_tridiag_solve_interface): this rank's 8-double packet into the device tensor ``packet``."""
         _l.check(self.Lt.fd_tridiag_solve_interface(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),

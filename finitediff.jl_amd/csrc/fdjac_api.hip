@@ -146,7 +146,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // process can build plans of both variants side by side and fd_plan_info reports which one a plan uses
     auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
     p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
-    p->cr_wg = env_int("FDJAC_COLRANGE_WG", 1) != 0;
     p->list_U = env_int("FDJAC_TILE", 2);
     if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
@@ -521,21 +520,16 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
 // (fdjac_planbuild.hip).  false: no usable shape.
 static bool w2_shape(const fd_plan *p, int ecmax, int halo, int *L_out, int *R_out)
 {
-    int L, R;
-    const char *fl = getenv("FDJAC_2D_L"), *fr = getenv("FDJAC_2D_R");
-    // default shape: 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as
-    // keep the window pairs of a tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same
-    // process: 62 x 5 299 us, 62 x 6 303, 62 x 4 302, 64 x 6 310, 64 x 5 304, 94 x 3 304, 126 x 2 313
-    L = (fl && *fl) ? atoi(fl) : 62;
-    L = std::max(2, L & ~1);
-    R = (fr && *fr) ? atoi(fr) : (int)(2048 / ((int64_t)ecmax * L));
+    // 62 positions (a window row of L + 2*halo (+ alignment) values = 33 row pairs) and as many runs as keep the window pairs of a
+    // tile within ONE load round of the 256 threads -- 5-point central at N = 10^7, same process: 62 x 5 299 us, 62 x 6 303,
+    // 62 x 4 302, 64 x 6 310, 64 x 5 304, 94 x 3 304, 126 x 2 313
+    const int L = 62;
+    int R = (int)(2048 / ((int64_t)ecmax * L));
     R = std::max(1, std::min(R, kW2MaxRun));
-    if (!(fr && *fr) && (int64_t)R * L * ecmax > 2048) R = std::max<int>(1, (int)(2048 / ((int64_t)ecmax * L)));
-    if (!(fr && *fr)) {   // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
-        const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
-        while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
-        while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
-    }
+    // keep the LDS tile (R+2 windows of L+2*halo rows, every staged array) near 32 KB
+    const int ncol_guess = std::min<int>((int)std::max<int64_t>(p->C, 1), kWinMaxCol);
+    while (R > 2 && window_lds_bytes(p->fdtype, (R + 2) * (L + 2 * halo + 2), ncol_guess) > (size_t)36 * 1024) --R;
+    while (R > 2 && (R + 2) * ((L + 2 * halo + 2) / 2) > kBlock) --R;   // one load round
     *L_out = L; *R_out = R;
     return R >= 2;
 }
@@ -1963,7 +1957,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
     case FD_INFO_WIN_OVERREAD_X100: *value = (int64_t)(p->win_overread * 100); break;
     case FD_INFO_WINDOW2D: *value = p->window2d ? 1 : 0; break;
     case FD_INFO_WIN_PERIOD: *value = p->win_per_P; break;
-    case FD_INFO_COLRANGE_WG: *value = (p->kind == K_COLRANGE && p->cr_wg) ? 1 : 0; break;
+    case FD_INFO_COLRANGE_WG: *value = p->kind == K_COLRANGE ? 1 : 0; break;
     case FD_INFO_SMALL_FUSED:
         *value = (p->small_ok && p->N <= kSmallN && p->C > 0 && p->C <= kRegColors && p->kind != K_DENSE &&
                   p->fdtype != FD_COMPLEX) ? 1 : 0;

@@ -221,16 +221,15 @@ __device__ __forceinline__ r2_t ld_pair_guarded(const real_t *__restrict__ x, in
     return v;
 }
 
-template <int MODE, bool NL, bool NT>
+template <int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
-k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart, int reversed)
+k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart)
 {
     __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_BAND_WAVE_LDS(3)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
-    int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave;
     if (gw >= nwaves) return;
-    if (reversed) gw = nwaves - 1 - gw;
     const int64_t jw = jstart + gw * 128;                    // even: the x pairs are 16-B aligned
     const int64_t j = jw + 2 * lane;
     const r2_t Cc = ld_pair_guarded(x, j, n), L = ld_pair_guarded(x, j - 2, n), R = ld_pair_guarded(x, j + 2, n);
@@ -256,7 +255,7 @@ k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ 
             q[3 * o + k] = sub_exact(plus, sub) / ed;
         }
     }
-    fd_band_emit_wave<real_t, 3, NT>(&bst, s_win[wave], jw, q);
+    fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);      // (non-temporal: nothing re-reads nzval in this call)
 }
 
 // (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
@@ -590,13 +589,6 @@ struct BuiltinF {
     std::atomic<int64_t> launches{0}, points{0};
     void *d_sig = nullptr;  // block-coupled sigma scratch
     int64_t sig_cap = 0;    // in (re,im)-capable elements
-    // variants of the storing launch (read once, when the launcher is created): FDJAC_STORE_WAVE=0 round 2's row-owned kernel,
-    // FDJAC_STORE_NT=0 plain instead of non-temporal stores, FDJAC_STORE_REV=1 wavefronts walk the columns back to front
-    // FDJAC_STORE_FASTDIV=0: IEEE division per quotient instead of the shared-reciprocal correctly rounded form (same bits)
-    // FDJAC_STORE_INTERIOR=0: the 5-point kernel keeps its boundary guards in interior tiles too
-    bool store_wave = true, store_nt = true, store_rev = false, store_fastdiv = true, store_interior = true;
-    int store_cpl = 2;      // FDJAC_STORE_CPL=1: the 5-point kernel owns one column per lane (8-B loads, half the registers)
-    int store_waves = 6;    // FDJAC_STORE_WAVES=1: ... compiled without a register budget (4 waves per SIMD instead of 6)
 };
 
 int balanced_grid(int64_t tiles, int64_t cap);
@@ -731,21 +723,19 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
         if (bst.elem_bytes != (int)sizeof(real_t) || mode == 2) return FD_LAZY_DECLINED;
         if (bst.N != b->prm[0] || bst.M != b->prm[0]) return FD_LAZY_DECLINED;   // a plan of another problem size than this fixture's
         const int wband = bst.l + bst.u + 1;
-        // an exactly tridiagonal band with every colour in this batch: the column-centric wave kernel, any layout
-        // (FDJAC_STORE_WAVE=0 keeps round 2's row-owned form for A/B runs)
-        const bool wave_ok = b->store_wave && bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
+        // an exactly tridiagonal band with every colour in this batch: the column-centric wave kernel, any layout; colour chunks,
+        // colour ownership and wider bands take the row-owned kernel below
+        const bool wave_ok = bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
                              lp->ncolors == bst.C && bst.C >= 3 && (((uintptr_t)lp->x) & kPairMask) == 0 && bst.col_end > bst.col_begin;
         if (wave_ok) {
             const int64_t jstart = bst.col_begin & ~(int64_t)1;
             const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
             const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
-#define FD_LAZY_SW(MODE, NL, NT)                                                                                   \
-            hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL, NT>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
-                               (const real_t *)lp->eps, b->prm[0], bst, jstart, b->store_rev ? 1 : 0)
-#define FD_LAZY_SW2(MODE, NL) do { if (b->store_nt) FD_LAZY_SW(MODE, NL, true); else FD_LAZY_SW(MODE, NL, false); } while (0)
-            if (mode == 0) { if (nl) FD_LAZY_SW2(0, true); else FD_LAZY_SW2(0, false); }
-            else { if (nl) FD_LAZY_SW2(1, true); else FD_LAZY_SW2(1, false); }
-#undef FD_LAZY_SW2
+#define FD_LAZY_SW(MODE, NL)                                                                                       \
+            hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
+                               (const real_t *)lp->eps, b->prm[0], bst, jstart)
+            if (mode == 0) { if (nl) FD_LAZY_SW(0, true); else FD_LAZY_SW(0, false); }
+            else { if (nl) FD_LAZY_SW(1, true); else FD_LAZY_SW(1, false); }
 #undef FD_LAZY_SW
             return hipGetLastError() == hipSuccess ? 0 : 4;
         }
@@ -857,13 +847,14 @@ __device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][W
 #undef MV
 }
 
-template <typename CT, int MODE, int SK, bool NT, bool FASTDIV, bool INTSPEC, int CPL, int WV>
-__global__ void __launch_bounds__(kBlock, WV)      // WV: waves per SIMD the register allocation aims at
+template <typename CT, int MODE, int SK>
+__global__ void __launch_bounds__(kBlock, 6)       // a register budget for six waves per SIMD (78 VGPRs, no spills: 128 -> 121 us in round 3)
 k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
 {
-    // CPL = columns per lane: 2 (aligned 16-B loads of x, 128 columns per wavefront) or 1 (8-B loads, 64 columns, half the registers)
-    constexpr int TW = 64 * CPL, WC = 4 + CPL;
-    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][CPL == 2 ? FD_STENCIL5_WAVE_LDS : FD_STENCIL5_WAVE_LDS / 2 + 4];
+    // two columns per lane: aligned 16-B loads of x, 128 columns per wavefront
+    constexpr int TW = 128, WC = 6;
+    constexpr bool FASTDIV = true;      // the shared-reciprocal exact division (the IEEE sequence spills under the register budget: 337 us)
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_STENCIL5_WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nx = (int)st.nx, ny = (int)st.ny;
     const int TPR = (nx + TW - 1) / TW;
@@ -875,50 +866,37 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     // (32-bit division: the launcher declines grids with 2^31 tiles or more; a 64-bit one is ~150 instructions per wavefront)
     const unsigned wrow = (unsigned)wt / (unsigned)TPR;
     const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
-    const int i = i0 + CPL * lane;
+    const int i = i0 + 2 * lane;
     const int64_t k = (int64_t)j * nx + i;
     const bool act = i < nx;
     // a tile whose whole neighbourhood lies inside the grid needs no guards (wave-uniform)
-    const bool interior = INTSPEC && j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
-    // window rows j-2 .. j+2, columns i-2 .. i+CPL+1 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
+    const bool interior = j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
+    // window rows j-2 .. j+2, columns i-2 .. i+3 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
     real_t W[5][WC];
 #pragma unroll
     for (int dj = -2; dj <= 2; ++dj) {
         const bool rowok = interior || (act && j + dj >= 0 && j + dj < ny);
-        if constexpr (CPL == 2) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                r2_t v = {0, 0};
-                if (!((dj == -2 || dj == 2) && c != 1)) {
-                    const int ic = i + 2 * (c - 1);
-                    const int64_t kc = k + (int64_t)dj * nx + 2 * (c - 1);
-                    if (interior || (rowok && ic >= 0 && ic + 1 < nx)) v = *reinterpret_cast<const r2_t *>(x + kc);
-                    else if (rowok) { if (ic >= 0 && ic < nx) v.x = x[kc]; if (ic + 1 >= 0 && ic + 1 < nx) v.y = x[kc + 1]; }
-                }
-                W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
+        for (int c = 0; c < 3; ++c) {
+            r2_t v = {0, 0};
+            if (!((dj == -2 || dj == 2) && c != 1)) {
+                const int ic = i + 2 * (c - 1);
+                const int64_t kc = k + (int64_t)dj * nx + 2 * (c - 1);
+                if (interior || (rowok && ic >= 0 && ic + 1 < nx)) v = *reinterpret_cast<const r2_t *>(x + kc);
+                else if (rowok) { if (ic >= 0 && ic < nx) v.x = x[kc]; if (ic + 1 >= 0 && ic + 1 < nx) v.y = x[kc + 1]; }
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                real_t v = 0;
-                const int adj = dj < 0 ? -dj : dj, adc = c < 2 ? 2 - c : c - 2;
-                if (adj + adc <= 2) {                              // the 13-point diamond
-                    const int ic = i + c - 2;
-                    if (interior || (rowok && ic >= 0 && ic < nx)) v = x[k + (int64_t)dj * nx + (c - 2)];
-                }
-                W[dj + 2][c] = v;
-            }
+            W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
         }
     }
     int cpair[2] = {0, 0};
-    if (act) { cpair[0] = (int)((const CT *)st.color)[k]; if (CPL == 2) cpair[1] = (int)((const CT *)st.color)[k + 1]; }
-    real_t q[5 * CPL];
+    if (act) { cpair[0] = (int)((const CT *)st.color)[k]; cpair[1] = (int)((const CT *)st.color)[k + 1]; }
+    real_t q[10];
 #pragma unroll
-    for (int o = 0; o < CPL; ++o) {
-        if (INTSPEC && interior) stencil5_column_quotients<MODE, SK, true, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
+    for (int o = 0; o < 2; ++o) {
+        if (interior) stencil5_column_quotients<MODE, SK, true, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
         else stencil5_column_quotients<MODE, SK, false, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
     }
-    fd_stencil5_emit_wave<real_t, NT, CPL>(&st, s_win[wave], j, i0, q);
+    fd_stencil5_emit_wave<real_t, true, 2>(&st, s_win[wave], j, i0, q);
 }
 
 template <typename CT>
@@ -936,27 +914,19 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
         if (lp->store_kind != FD_STORE_STENCIL5 || mode == 2 || sk == 1) return FD_LAZY_DECLINED;
         const fd_stencil5_store st = *(const fd_stencil5_store *)lp->store;
         if (st.elem_bytes != (int)sizeof(real_t) || st.nx != b->prm[0] || st.ny != b->prm[1] || lp->c_lo != 0 || lp->ncolors != st.C ||
-            st.color_bytes != (int)sizeof(CT) || (((uintptr_t)lp->x) & kPairMask) != 0 || st.col_end <= st.col_begin || !b->store_wave)
+            st.color_bytes != (int)sizeof(CT) || (((uintptr_t)lp->x) & kPairMask) != 0 || st.col_end <= st.col_begin)
             return FD_LAZY_DECLINED;
         const int64_t jrow0 = st.col_begin / st.nx, jrow1 = (st.col_end - 1) / st.nx + 1;      // grid rows with local columns
-        const int cpl = b->store_cpl == 1 ? 1 : 2;
-        const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 64 * cpl - 1) / (64 * cpl)), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+        const int64_t ntiles = (jrow1 - jrow0) * ((st.nx + 127) / 128), ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
         const unsigned gs = (unsigned)(8 * xcd_chunks(ngroups));
         if (ntiles >= ((int64_t)1 << 31) || st.nx * st.ny >= ((int64_t)1 << 31)) return FD_LAZY_DECLINED;   // (32-bit tile / grid arithmetic in the kernel)
-#define FD_S5(MODE, SKK, NT, FDV, INS, CPLL, WVV)                                                                   \
-        hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK, NT, FDV, INS, CPLL, WVV>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+        // ONE form (round 3 measured the others, profiles/r03_h_stencil_store_ab.txt; the probes live in scripts/ubench/): two columns per
+        // lane, non-temporal stores, the shared-reciprocal exact division, guard-free interior tiles, a register budget for six waves per SIMD
+#define FD_S5(MODE, SKK)                                                                                            \
+        hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)
-#define FD_S5_W(MODE, SKK, NT, FDV, INS, CPLL) do { if (b->store_waves >= 6 && FDV && CPLL == 2) FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 6); else FD_S5(MODE, SKK, NT, FDV, INS, CPLL, 1); } while (0)   /* (the register budget spills with the IEEE division sequence or one column per lane: 337 / 237 vs 121 us) */
-#define FD_S5_C(MODE, SKK, NT, FDV, INS) do { if (cpl == 1) FD_S5_W(MODE, SKK, NT, FDV, INS, 1); else FD_S5_W(MODE, SKK, NT, FDV, INS, 2); } while (0)
-#define FD_S5_I(MODE, SKK, NT, FDV) do { if (b->store_interior) FD_S5_C(MODE, SKK, NT, FDV, true); else FD_S5_C(MODE, SKK, NT, FDV, false); } while (0)
-#define FD_S5_NT(MODE, SKK) do { if (b->store_fastdiv) { if (b->store_nt) FD_S5_I(MODE, SKK, true, true); else FD_S5_I(MODE, SKK, false, true); } \
-                                 else { if (b->store_nt) FD_S5_I(MODE, SKK, true, false); else FD_S5_I(MODE, SKK, false, false); } } while (0)
-        if (mode == 0) { if (sk == 2) FD_S5_NT(0, 2); else FD_S5_NT(0, 0); }
-        else { if (sk == 2) FD_S5_NT(1, 2); else FD_S5_NT(1, 0); }
-#undef FD_S5_NT
-#undef FD_S5_I
-#undef FD_S5_C
-#undef FD_S5_W
+        if (mode == 0) { if (sk == 2) FD_S5(0, 2); else FD_S5(0, 0); }
+        else { if (sk == 2) FD_S5(1, 2); else FD_S5(1, 0); }
 #undef FD_S5
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }
@@ -1429,7 +1399,7 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
     if (lp->store) {
         // the launch stores imag(f) / eps into the block-banded data itself (fd_colrange_store): complex step, the block structure of
         // this fixture (dense blocks of bs <= 64 rows, block bandwidths (1, 1))
-        if (lp->store_kind != FD_STORE_COLRANGE || mode != 2 || !b->store_wave) return FD_LAZY_DECLINED;
+        if (lp->store_kind != FD_STORE_COLRANGE || mode != 2) return FD_LAZY_DECLINED;
         const fd_colrange_store st = *(const fd_colrange_store *)lp->store;
         if (st.elem_bytes != (int)sizeof(real_t) || st.nblk != nb || st.block_size != bs || st.bl != 1 || st.bu != 1 || bs > 64 ||
             st.color_bytes != (int)sizeof(CT) || st.col_end <= st.col_begin || bcs_lds_bytes(lp->ncolors, (int)bs) > (size_t)64 * 1024)
@@ -1683,16 +1653,6 @@ int fd_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int npar
         return FD_ERR_ARG;
     }
     for (int i = 0; i < need; ++i) b->prm[i] = params[i];
-    {
-        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
-        b->store_wave = env_int("FDJAC_STORE_WAVE", 1) != 0;
-        b->store_nt = env_int("FDJAC_STORE_NT", 1) != 0;
-        b->store_rev = env_int("FDJAC_STORE_REV", 0) != 0;
-        b->store_fastdiv = env_int("FDJAC_STORE_FASTDIV", 1) != 0;
-        b->store_interior = env_int("FDJAC_STORE_INTERIOR", 1) != 0;
-        b->store_cpl = env_int("FDJAC_STORE_CPL", 2);
-        b->store_waves = env_int("FDJAC_STORE_WAVES", 6);
-    }
     for (int i = 0; i < need; ++i)
         if (b->prm[i] < 1) {
             delete b;

@@ -190,7 +190,6 @@ struct fd_plan {
     int64_t own_c0 = 0, own_c1 = -1;   // owned colours [own_c0, own_c1), -1 = up to C (fd_plan_opts.color_begin/end)
     // kernel variants, fixed at plan creation (environment switches are read there, never per process):
     bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
-    bool cr_wg = true;             //   K_COLRANGE: one workgroup per 32 columns (FDJAC_COLRANGE_WG != 0)
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
     int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
     bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it

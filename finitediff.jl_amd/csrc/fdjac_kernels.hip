@@ -1055,37 +1055,6 @@ k_decompress_banded(const CT *__restrict__ color, const real_t *__restrict__ FXa
     }
 }
 
-// K5  column-range patterns (BlockBandedMatrix with dense in-band blocks): local column jj owns
-//   the contiguous rows [rlo, rlo+cnt) stored contiguously at off
-//   (ext/FiniteDiffBlockBandedMatricesExt.jl:44-68: V[k,j] = b_v[k] over blockcolrange).
-//   One wave per column: 64 lanes sweep the rows => contiguous 512-B stores and gathers.
-template <typename CT, int MODE>
-__global__ void __launch_bounds__(kBlock)
-k_decompress_colrange(const CT *__restrict__ color, const int32_t *__restrict__ rlo,
-                      const int32_t *__restrict__ cnt, const int64_t *__restrict__ off,
-                      const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
-                      const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t j0,
-                      int64_t ncols, real_t *__restrict__ data)
-{
-    const int none = ColorTraits<CT>::none;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
-    for (int64_t jj = wave; jj < ncols; jj += nwaves) {
-        const int c = color[j0 + jj];
-        const int64_t o = off[jj];
-        const int r0 = rlo[jj], n = cnt[jj];
-        if (c == none) {
-            if (c_lo == 0)
-                for (int k = lane; k < n; k += 64) data[o + k] = 0.0;
-            continue;
-        }
-        if (c < c_lo || c >= c_hi) continue;
-        const real_t e = eps[c];
-        for (int k = lane; k < n; k += 64)
-            data[o + k] = entry_value<MODE>(FXa, FXb, ld, c - c_lo, r0 + k, e);
-    }
-}
 
 // K5b  the same column-range decompression, one WORKGROUP per kCrCols consecutive columns.  A wave per column leaves
 //   a wave with ~1.5 loads of work behind two dependent round trips (column metadata, then values): the kernel runs
@@ -1555,29 +1524,22 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         break;
     }
     case K_COLRANGE: {
-        if (p->cr_wg) {   // (chosen at plan creation, FD_INFO_COLRANGE_WG)   // one workgroup per 32 columns (default); FDJAC_COLRANGE_WG=0: one wave per column
-            const int64_t nc = p->col1 - p->col0;
-            // the imaginary parts of an imag-only complex step arrive as a real array with fx = the zero vector
-            const real_t *fxb = (MODE == 0 && p->d_zero != nullptr && FXb == p->d_zero) ? nullptr : FXb;
-            const bool cr_vec_off = env_i64("FDJAC_COLRANGE_VEC", 1) == 0;   // (read per launch: tests toggle it)
-            const bool vec = p->cr_pairs && !cr_vec_off && (((uintptr_t)outs[0]) & kPairMask) == 0 &&
-                             (MODE != 0 || fxb == nullptr || (((uintptr_t)fxb) & kPairMask) == 0);
-            const dim3 gcr((unsigned)((nc + kCrCols - 1) / kCrCols));
-            const int rev = tile_order_reversed() ? 1 : 0;
-            if (nc > 0) {
-                if (vec)
-                    hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, true>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
-                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
-                else
-                    hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, false>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
-                                       p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
-            }
-            break;
+        // one workgroup per 32 columns (one wave per column measured slower in round 2: 158 vs 127 us on config 5; the scalar
+        // instantiation serves layouts whose rows / destinations are not all even)
+        const int64_t nc = p->col1 - p->col0;
+        // the imaginary parts of an imag-only complex step arrive as a real array with fx = the zero vector
+        const real_t *fxb = (MODE == 0 && p->d_zero != nullptr && FXb == p->d_zero) ? nullptr : FXb;
+        const bool vec = p->cr_pairs && (((uintptr_t)outs[0]) & kPairMask) == 0 && (MODE != 0 || fxb == nullptr || (((uintptr_t)fxb) & kPairMask) == 0);
+        const dim3 gcr((unsigned)((nc + kCrCols - 1) / kCrCols));
+        const int rev = tile_order_reversed() ? 1 : 0;
+        if (nc > 0) {
+            if (vec)
+                hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, true>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
+                                   p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
+            else
+                hipLaunchKernelGGL((k_decompress_colrange_wg<CT, MODE, false>), gcr, dim3(kBlock), 0, s, color, p->d_cr_rlo,
+                                   p->d_cr_cnt, p->d_cr_off, FXa, fxb, p->ldf, p->d_eps, c_lo, c_hi, p->col0, nc, outs[0], rev);
         }
-        const int g = grid_for(p->col1 - p->col0, kBlock / 64, p->ctx->num_cus);
-        hipLaunchKernelGGL((k_decompress_colrange<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, p->d_cr_rlo,
-                           p->d_cr_cnt, p->d_cr_off, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->col0,
-                           p->col1 - p->col0, outs[0]);
         break;
     }
     default: break;

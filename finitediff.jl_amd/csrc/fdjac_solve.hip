@@ -32,6 +32,7 @@
 #define fd_tridiag_solver fd32_tridiag_solver
 #define fd_tridiag_solver_create fd32_tridiag_solver_create
 #define fd_tridiag_solver_destroy fd32_tridiag_solver_destroy
+#define fd_tridiag_solver_status fd32_tridiag_solver_status
 #define fd_tridiag_solve_async fd32_tridiag_solve_async
 #define fd_tridiag_solve_interface fd32_tridiag_solve_interface
 #define fd_tridiag_solve_finish fd32_tridiag_solve_finish
@@ -58,6 +59,7 @@ struct SrcUser {
     int64_t g0, n, N;           // first global row, local rows, global size
     int64_t e0;                 // CSC: global index of the slice's first stored value
     double alpha, beta;
+    int *nd_flag;               // raised when a row is not diagonally dominant (|b| < |a| + |c|): the elimination does not pivot
     __device__ __forceinline__ void coef(int64_t i, double &a, double &b, double &c) const
     {
         const int64_t gi = g0 + i;
@@ -244,6 +246,21 @@ template <int NRHS> struct SrcRegs {
         return t;
     }
 };
+// The elimination does not pivot (LinearAlgebra's Tridiagonal \ does): it is accurate for diagonally dominant systems -- W = I - gamma J
+// of diffusion-type problems.  Level 0 checks every row it fetches anyway and raises the solver's status word otherwise
+// (fd_tridiag_solver_status): three absolute values and a compare per row, no extra traffic.
+template <int NRHS>
+__device__ __forceinline__ void tri_guard_rows(const SrcRegs<NRHS> &R, int64_t n, int64_t row0, int *nd_flag)
+{
+    if (!nd_flag) return;
+    bool nd = false;
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) {
+        const int64_t i = row0 + (int64_t)threadIdx.x * kChunk + q;
+        nd = nd || (i < n && !(fabs(R.b[q]) >= fabs(R.a[q]) + fabs(R.c[q])));
+    }
+    if (nd) atomicOr(nd_flag, 1);
+}
 template <typename Src, int NRHS>
 __device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
 {
@@ -287,6 +304,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
     __shared__ double lds[kTriPitch];
     SrcRegs<NRHS> R;
     tri_fetch_rows<Src, NRHS>(src, n, (int64_t)blockIdx.x * kTriTileRows, lds, R);
+    if constexpr (Src::kUnitRhs) tri_guard_rows<NRHS>(R, n, (int64_t)blockIdx.x * kTriTileRows, src.nd_flag);      // (level 0 only)
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= nc) return;
     tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
@@ -362,6 +380,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce_csc(SrcUser src, int64_t 
     __shared__ double lds[kTriRawSlots];
     SrcRegs<NRHS> R;
     tri_fetch_rows_csc<NRHS>(src, n, (int64_t)blockIdx.x * kTriTileRows, lds, R);
+    tri_guard_rows<NRHS>(R, n, (int64_t)blockIdx.x * kTriTileRows, src.nd_flag);
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= nc) return;
     tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
@@ -611,6 +630,7 @@ struct fd_tridiag_solver {
     double *lev_sol[fdjac::kMaxLevels] = {nullptr};   // solution of level l >= 1 (3 columns at the top level)
     double *packets = nullptr;                        // kMaxRanks x kPacket (the all-gather buffer)
     double *adj = nullptr, *cpl = nullptr, *work = nullptr;
+    int *status = nullptr;                            // device word: bit 0 = the last solve met a row that is not diagonally dominant
 };
 
 using namespace fdjac;
@@ -627,6 +647,7 @@ static SrcUser make_src(const fd_tridiag_solver *s, double alpha, double beta, c
     u.adj = adj;
     u.g0 = s->g0; u.n = s->n; u.N = s->N; u.e0 = s->e0;
     u.alpha = alpha; u.beta = beta;
+    u.nd_flag = s->status;
     return u;
 }
 
@@ -713,12 +734,24 @@ int fd_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t 
     ok = ok && hipMalloc((void **)&s->adj, sizeof(double) * 2) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->cpl, sizeof(double) * 2) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->work, sizeof(double) * 12 * kMaxRanks) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->status, sizeof(int)) == hipSuccess && hipMemset(s->status, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
         fd_tridiag_solver_destroy(s);
         set_error("hipMalloc failed in fd_tridiag_solver_create");
         return FD_ERR_NOMEM;
     }
     *out = s;
+    return FD_OK;
+}
+
+// bit 0: the last solve met a row with |alpha + beta J[i,i]| < |beta J[i,i-1]| + |beta J[i,i+1]| -- the elimination does not pivot, its
+// result is then not guaranteed (LinearAlgebra's Tridiagonal \ pivots).  Synchronises the context's stream.
+int fd_tridiag_solver_status(fd_tridiag_solver *s, int *flags_out)
+{
+    FD_REQUIRE(s && flags_out, FD_ERR_ARG, "NULL argument");
+    FD_HIP_CHECK(hipSetDevice(s->ctx->device));
+    FD_HIP_CHECK(hipMemcpyAsync(flags_out, s->status, sizeof(int), hipMemcpyDeviceToHost, s->ctx->stream));
+    FD_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
     return FD_OK;
 }
 
@@ -731,7 +764,7 @@ int fd_tridiag_solver_destroy(fd_tridiag_solver *s)
         if (s->lev_sum[k]) (void)hipFree(s->lev_sum[k]);
         if (s->lev_sol[k]) (void)hipFree(s->lev_sol[k]);
     }
-    for (void *p : {(void *)s->packets, (void *)s->adj, (void *)s->cpl, (void *)s->work})
+    for (void *p : {(void *)s->packets, (void *)s->adj, (void *)s->cpl, (void *)s->work, (void *)s->status})
         if (p) (void)hipFree(p);
     delete s;
     return FD_OK;
@@ -758,6 +791,7 @@ int fd_tridiag_solve_interface(fd_tridiag_solver *s, double alpha, double beta, 
     FD_REQUIRE(s && J && rhs && packet_dev, FD_ERR_ARG, "NULL argument");
     FD_REQUIRE(s->layout == FD_TRI_CSC ? J[0] != nullptr : J[1] != nullptr, FD_ERR_ARG, "J's values are NULL");   // (dl / du may be empty)
     FD_HIP_CHECK(hipSetDevice(s->ctx->device));
+    (void)hipMemsetAsync(s->status, 0, sizeof(int), s->ctx->stream);      // (the dominance guard of this solve)
     const SrcUser u = make_src(s, alpha, beta, J, rhs, nullptr);
     int rc = tri_reduce_all<3>(s, u);
     if (rc) return rc;
@@ -794,6 +828,7 @@ int fd_tridiag_solve_async(fd_tridiag_solver *s, double alpha, double beta, cons
     if (!comm) {
         FD_REQUIRE(s->n == s->N, FD_ERR_ARG, "a solver for rows [%lld,%lld) of %lld needs a communicator", (long long)s->g0,
                    (long long)(s->g0 + s->n), (long long)s->N);
+        (void)hipMemsetAsync(s->status, 0, sizeof(int), s->ctx->stream);      // (the dominance guard of this solve)
         return tri_local_solve(s, alpha, beta, J, rhs, nullptr, y);
     }
     FD_REQUIRE(fdjac_comm_ctx(comm) == s->ctx, FD_ERR_ARG, "the communicator belongs to another context");

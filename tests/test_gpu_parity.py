@@ -558,8 +558,7 @@ def test_lazy_points_stencil_bit_identical(oracle, fdtype, family):
 @pytest.mark.parametrize("case", ["bs32", "bs8_none", "bs6_window", "mixed_even", "mixed_odd"])
 def test_blockbanded_row_pair_kernel_bit_identical(monkeypatch, oracle, fdtype, lazy, case):
     # k_decompress_colrange_wg<VEC>: columns whose first row, row count and destination are all even are processed as
-    # row pairs (16-B accesses); the scalar instantiation (FDJAC_COLRANGE_VEC=0) must give the same bits, and odd
-    # layouts must fall back by themselves
+    # row pairs (16-B accesses); the scalar instantiation (unaligned output, odd layouts) must give the same bits
     sizes = {"bs32": np.full(12, 32), "bs8_none": np.full(30, 8), "bs6_window": np.full(20, 6),
              "mixed_even": np.array([4, 8, 2, 6, 10, 4, 4, 12]), "mixed_odd": np.array([4, 7, 2, 6, 9, 4, 5, 12])}[case]
     lay = P.BlockBandedLayout(sizes, 1, 1)
@@ -587,12 +586,15 @@ def test_blockbanded_row_pair_kernel_bit_identical(monkeypatch, oracle, fdtype, 
             fx.copy_(xv * S[blk] + torch.sin(xv))
         f = fd.TorchF(fn, N, N)
     outs = []
-    for vec in ("1", "0"):
-        monkeypatch.setenv("FDJAC_COLRANGE_VEC", vec)
+    for unaligned in (False, True):
+        # the row-pair instantiation needs a 16-byte aligned output: an output that starts one element later takes the scalar
+        # instantiation of the same kernel (what layouts with odd rows / destinations always take)
+        monkeypatch.setenv("FDJAC_LAZY_STORE", "0")
         plan = fd.make_plan(Jb, Jb, colors, fdtype, col_window=win)
         if lazy:
             plan.set_lazy(f, imag_only=(lazy is True))
-        out = _dev(np.full(plan.out_len(0), np.nan))
+        buf = _dev(np.full(plan.out_len(0) + 1, np.nan))
+        out = buf[1:] if unaligned else buf[:-1]
         plan.jacobian(f, x, [out])
         outs.append(out.cpu().numpy())
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
@@ -1111,25 +1113,6 @@ def test_out_of_place_api(oracle):
     assert np.linalg.norm(P.csc_to_dense(N, N, colptr, rowval, J2.nzval.cpu().numpy()) - exact) <= 1e-6
 
 
-@pytest.mark.parametrize("fdtype", FDTYPES)
-def test_colrange_wave_and_workgroup_kernels_bit_identical(monkeypatch, fdtype):
-    # FDJAC_COLRANGE_WG is read when the plan is created: both block-banded kernels live side by side in one process
-    lay = P.BlockBandedLayout(np.full(40, 32), 1, 1)
-    N = lay.N
-    colors = lay.colors()
-    x = _dev(np.random.default_rng(71).random(N))
-    Jb = fd.BlockBandedMatrix(None, lay)
-    outs = []
-    for wg in ("1", "0"):
-        monkeypatch.setenv("FDJAC_COLRANGE_WG", wg)
-        plan = fd.make_plan(Jb, Jb, colors, fdtype)
-        assert plan.info(fd.lib.INFO_COLRANGE_WG) == int(wg)
-        out = _dev(np.full(plan.out_len(0), np.nan))
-        plan.jacobian(fd.BuiltinF("blockcoupled", 40, 32), x, [out])
-        outs.append(out.cpu().numpy())
-    assert not np.isnan(outs[0]).any() and np.array_equal(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 def test_small_fused_launch_is_a_plan_property(monkeypatch, oracle, fdtype):
     # FDJAC_SMALL is read at plan creation; the fused single-workgroup launch and the wide path agree with the oracle
@@ -1457,7 +1440,7 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
 
     def run(env, diff):
         for k in ("FDJAC_WINDOW", "FDJAC_SORTED", "FDJAC_WIN_TILE", "FDJAC_WIN_PERIODIC", "FDJAC_BAND_DESC",
-                  "FDJAC_WINDOW2D", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_LAZY_STORE", "FDJAC_STORE_WAVE", "FDJAC_STORE_NT"):
+                  "FDJAC_WINDOW2D", "FDJAC_PLAN_DEVICE", "FDJAC_LAZY_DIFF", "FDJAC_LAZY_STORE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1475,8 +1458,6 @@ def test_random_switch_combinations_bit_identical(monkeypatch, seed):
     pick("FDJAC_WIN_PERIODIC", [0, 1])
     pick("FDJAC_BAND_DESC", [0, 1])
     pick("FDJAC_WINDOW2D", [0, 1])
-    pick("FDJAC_STORE_WAVE", [0, 1])
-    pick("FDJAC_STORE_NT", [0, 1])
     pick("FDJAC_PLAN_DEVICE", [0, 1])
     pick("FDJAC_SORTED", [0, 1])
     pick("FDJAC_LAZY_STORE", [0, 1])
@@ -1593,16 +1574,16 @@ def test_random_jvp_sizes_three_forms_agree(oracle, seed):
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("case", ["plain", "linear_f", "shifted", "four_colours", "window", "window_odd", "window_odd_even", "chunked", "devplan",
-                                  "none", "small_n", "tiny_n", "dir_minus", "rows_plain", "rows_window_odd", "rows_chunked", "rows_four_colours"])
+                                  "none", "small_n", "tiny_n", "dir_minus", "chunked_window_odd", "chunked_four_colours", "chunked_shifted"])
 def test_lazy_store_bit_identical(monkeypatch, fdtype, case):
     # include/fdjac_device.h, the default since round 3: a FD_LAZY_CAP_STORE launcher stores the finished quotients into nzval
     # itself (exact band verified at plan time, destination of (row, colour) by arithmetic) and the library launches no
     # decompression.  Same operations on the same operands as the hand-over path (FDJAC_LAZY_STORE=0): same bits, same f!
     # evaluation count.  Two kernels behind the capability: the column-centric wave kernel (fd_band_emit_wave: wave-private LDS
-    # window, dense non-temporal stores) and, "rows_*" (FDJAC_STORE_WAVE=0; also what colour chunks fall back to), round 2's
+    # window, dense non-temporal stores) and, when the colours arrive in chunks ("chunked*": a scratch cap), round 2's
     # workgroup-owned rows.
-    monkeypatch.setenv("FDJAC_STORE_WAVE", "0" if case.startswith("rows_") else "1")
-    case = case[5:] if case.startswith("rows_") else case
+    chunked = case.startswith("chunked")
+    case = case[8:] if case.startswith("chunked_") else case
     N = {"small_n": 20_001, "tiny_n": 130}.get(case, 150_017)
     colptr, rowval = P.tridiag_csc(N)
     C = 4 if case == "four_colours" else 3
@@ -1610,7 +1591,7 @@ def test_lazy_store_bit_identical(monkeypatch, fdtype, case):
     if case == "none":
         colors[[7, N // 2]] = 0
     win = {"window": (30_001, 120_000), "window_odd": (30_002, 119_999), "window_odd_even": (30_002, 120_000)}.get(case)
-    cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype == "central" else 1) * 2 if case == "chunked" else 0
+    cap = 8 * 2 * ((N + 31) // 32 * 32) * (2 if fdtype == "central" else 1) * 2 if chunked else 0
     x = _dev(np.random.default_rng(97).random(N))
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     outs, calls = [], []
@@ -2017,7 +1998,7 @@ def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed)
     Jb = fd.BlockBandedMatrix(None, lay)
 
     def run(env, lazy, imag_only, store):
-        for k in ("FDJAC_LAZY_STORE", "FDJAC_COLRANGE_WG", "FDJAC_STORE_WAVE"):
+        for k in ("FDJAC_LAZY_STORE",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -2032,10 +2013,6 @@ def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed)
 
     ref, calls_ref = run({"FDJAC_LAZY_STORE": "0"}, False, True, False)
     env = {}
-    if rng.random() < 0.5:
-        env["FDJAC_COLRANGE_WG"] = str(int(rng.integers(0, 2)))
-    if rng.random() < 0.3:
-        env["FDJAC_STORE_WAVE"] = str(int(rng.integers(0, 2)))
     if rng.random() < 0.3:
         env["FDJAC_LAZY_STORE"] = "0"
     got, calls = run(env, True, bool(rng.random() < 0.6), bool(rng.random() < 0.8))
