@@ -188,3 +188,24 @@ def test_float32_solver():
     y = torch.full((N,), float("nan"), dtype=f32, device="cuda")
     solver.solve(fd.Tridiagonal(_dev(dl, f32), _dev(d, f32), _dev(du, f32)), _dev(b, f32), y, alpha, beta)
     assert np.max(np.abs(y.cpu().numpy().astype(np.float64) - want)) <= 2e-6 * max(1.0, np.max(np.abs(want)))
+
+
+def test_solver_flags_systems_that_are_not_diagonally_dominant():
+    # the elimination does not pivot: a solve whose matrix has a row with |b| < |a| + |c| raises the solver's status word
+    # (fd_tridiag_solver_status); the Rosenbrock matrix I - gamma J of the diffusion fixture does not
+    N = 100_003
+    dl = torch.ones(N - 1, dtype=torch.float64, device="cuda")
+    d = torch.full((N,), -2.0, dtype=torch.float64, device="cuda")
+    du = torch.ones(N - 1, dtype=torch.float64, device="cuda")
+    b = torch.ones(N, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(b)
+    s = fd.TridiagSolver(N, "diagonals")
+    s.solve([dl, d, du], b, y, alpha=1.0, beta=-0.05)          # I + 0.05 * tridiag(-1, 2, -1): dominant
+    assert s.status() == 0
+    s.solve([dl, d, du], b, y, alpha=0.0, beta=1.0)            # tridiag(1, -2, 1) itself: |b| == |a| + |c|, weakly dominant -> fine
+    assert s.status() == 0
+    d2 = d.clone(); d2[N // 2] = 0.5
+    s.solve([dl, d2, du], b, y, alpha=0.0, beta=1.0)           # one row with |0.5| < 2
+    assert s.status() == 1
+    s.solve([dl, d, du], b, y, alpha=1.0, beta=-0.05)          # the flag belongs to the LAST solve
+    assert s.status() == 0
