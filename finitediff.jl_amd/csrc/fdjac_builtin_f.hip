@@ -605,14 +605,14 @@ static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
     return dim3((unsigned)balanced_grid(tiles, cap), (unsigned)nbatch, 1);
 }
 
-#include "fdjac_rowlist_f.hip"
+#include "fdjac_functor_f.hip"
 
 template <typename T>
 static int launch_family(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0,
                          int64_t r1, hipStream_t s)
 {
     if (r1 <= r0) return 0;
-    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) return rowlist_family_launch<T>(b, fx, x, nbatch, xs, fs, r0, r1, s);
+    if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) return functor_family_launch<T>(b, fx, x, nbatch, xs, fs, r0, r1, s);
     const int ncu = b->ctx->num_cus;
     T *fxp = (T *)fx;
     const T *xp = (const T *)x;
@@ -1578,7 +1578,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
     if (!b || b->magic != 0xFD0F00D5u || !lp) return 1;
     if (!has_lazy(b)) return 6;
     if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store, or nothing
-        const int rc = lp->color_bytes == 1 ? rowlist_family_lazy<uint8_t>(b, lp, (hipStream_t)stream) : rowlist_family_lazy<int32_t>(b, lp, (hipStream_t)stream);
+        const int rc = lp->color_bytes == 1 ? functor_family_lazy<uint8_t>(b, lp, (hipStream_t)stream) : functor_family_lazy<int32_t>(b, lp, (hipStream_t)stream);
         if (rc == 0) {
             b->launches.fetch_add(1);
             b->points.fetch_add((int64_t)lp->ncolors * lp->pts);      // (f(x) of a forward difference: one plain launch, counted there)

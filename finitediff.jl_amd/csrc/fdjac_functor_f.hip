@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kBlock) k_f_rows(T *__restrict__ fx, const T *
 
 // ---- launchers --------------------------------------------------------------------------------------------------------------
 template <typename T>
-static int rowlist_family_launch(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0, int64_t r1, hipStream_t s)
+static int functor_family_launch(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0, int64_t r1, hipStream_t s)
 {
     const dim3 g((unsigned)((r1 - r0 + kBlock - 1) / kBlock), (unsigned)nbatch, 1);
     if (b->family == FD_F_LAP7) {
@@ -227,7 +227,7 @@ static int rowlist_family_launch(BuiltinF *b, void *fx, const void *x, int64_t n
 // the lazy launcher of these families serves exactly one request: store column by column (forward / central); everything else is
 // declined (the library materialises the points and calls the plain launcher)
 template <typename CT>
-static int rowlist_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_t s)
+static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_t s)
 {
     if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
     const fd_csc_store st = *(const fd_csc_store *)lp->store;
