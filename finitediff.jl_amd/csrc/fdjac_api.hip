@@ -211,10 +211,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     p->chunkB = B;
     p->nchunks = p->C > 0 ? (p->C + B - 1) / B : 0;
     int rc;
-    // (+1 row: small problems evaluate f(x) as one more member of the perturbed batch)
-    // (the materialised points d_X and the staging copies of x / f_in are allocated on first use -- ensure_points /
-    //  ensure_stage: a lazy-point launcher with device inputs never needs them, 480 MB less at N = 10^7)
-    if ((rc = dev_alloc(&p->d_FX, (B * p->pts + 1) * p->cplx * p->ldf))) return rc;
+    // (the batched f! values d_FX, the materialised points d_X and the staging copies of x / f_in are allocated on first use --
+    //  ensure_values / ensure_points / ensure_stage: a storing launch needs none of them (config 5: 0.5 GB less, and a plan that
+    //  is ready milliseconds earlier), a lazy-point launcher with device inputs no points)
     if ((rc = dev_alloc(&p->d_fx, p->ldf))) return rc;
     if ((rc = dev_alloc(&p->d_eps, std::max<int64_t>(p->C, 1)))) return rc;
 
@@ -272,6 +271,12 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
     return FD_OK;
 }
 
+static int ensure_values(fd_plan *p)
+{
+    if (p->d_FX) return FD_OK;
+    // (+1 row: small problems evaluate f(x) as one more member of the perturbed batch)
+    return dev_alloc(&p->d_FX, (p->chunkB * p->pts + 1) * p->cplx * p->ldf);
+}
 static int ensure_points(fd_plan *p)
 {
     if (p->d_X) return FD_OK;
@@ -624,7 +629,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     const bool small_points = small && !p->lazy_fn && p->nchunks == 1 && full_colors;   // points written by the fused launch
     const bool base_in_batch = small_points && p->fdtype == FD_FORWARD && !fin_dev;
     p->fx_batch_row = nullptr;
-    if (small_points) { const int rc = ensure_points(p); if (rc) return rc; }
+    if (small_points) { int rc = ensure_points(p); if (!rc) rc = ensure_values(p); if (rc) return rc; }
 
     // a launcher that hands over central differences: the doubled step sizes come out of the finalize launch
     if (p->fdtype == FD_CENTRAL && p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_DIFF) && p->lazy_diff && p->kind != K_DENSE) {
@@ -793,6 +798,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             }
             if (p->fdtype == FD_FORWARD) want_diff = false;      // (declined: f(x) exists already -- plain values are handed over below)
         }
+        { const int rc = ensure_values(p); if (rc) return rc; }      // (from here on the f! values are handed over through d_FX)
         bool diff_done = false;
         if (p->lazy_fn) {
             Span sp(p, FD_STAGE_F);
