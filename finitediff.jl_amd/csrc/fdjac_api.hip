@@ -335,6 +335,7 @@ static int new_plan(fd_ctx *ctx, int kind, int64_t M, int64_t N, fd_plan **out)
 }  // namespace fdjac
 
 #include "fdjac_planbuild.hip"
+#include "fdjac_planbuild_lists.hip"
 #include "fdjac_store_csc.hip"
 
 using namespace fdjac;

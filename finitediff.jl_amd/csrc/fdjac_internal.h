@@ -55,8 +55,10 @@
 #define fd_builtin_f_lazy_jvp fd32_builtin_f_lazy_jvp
 #else
 #define FDJAC_REAL double
+
 #endif
 
+#include <time.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -334,3 +336,13 @@ static inline bool store_active(const fd_plan *p)
     return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->fdtype != FD_COMPLEX &&
            (p->kind == fdjac::K_CSC || p->kind == fdjac::K_BANDED || p->kind == fdjac::K_TRIDIAG);
 }
+
+// FDJAC_PLAN_TIMING=1: wall-clock of the builder's sections on stderr (each mark synchronises the stream)
+struct PbTimer {
+    bool on;
+    hipStream_t s;
+    double t0;
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    PbTimer(hipStream_t st) : s(st) { const char *v = getenv("FDJAC_PLAN_TIMING"); on = v && *v && atoi(v) != 0; t0 = on ? now() : 0; }
+    void mark(const char *what) { if (!on) return; (void)hipStreamSynchronize(s); const double t = now(); fprintf(stderr, "[fdjac plan] %-28s %8.3f ms\n", what, t - t0); t0 = t; }
+};

@@ -12,6 +12,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
     if (rc) return rc;
     fd_plan *p = *out;
     FD_TRY(apply_opts(p, opts));
+    PbTimer tm(ctx->stream);
     std::vector<int32_t> col0;
     if (!(colorvec != nullptr && (color_bytes == 4 || color_bytes == 8))) FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));   // (reports the argument error)
     const int64_t e0 = load_idx(colptr, idx_bytes, p->col0) - idx_base;
@@ -45,6 +46,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
                 res = device_build_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base,
                                        d_cv, color_bytes, e0, e1, &brc);
             (void)hipStreamSynchronize(ctx->stream);
+            tm.mark(res == PBR_DONE ? "csc: device builder" : "csc: device builder declined");
             if (res == PBR_DONE && brc == FD_OK)   // (the raw arrays are still on the device: the compact copy comes from them)
                 brc = build_store_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base);
             if (d_cp) (void)hipFree(d_cp);
@@ -60,6 +62,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
         }
     }
     FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    tm.mark("csc: colours (host)");
     std::vector<int32_t> rows((size_t)(e1 - e0)), nzc((size_t)(e1 - e0));
     std::vector<int64_t> dest;
     if (kind == K_CSC_DENSE) dest.resize((size_t)(e1 - e0));
@@ -89,8 +92,11 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
         colstart.resize((size_t)(p->col1 - p->col0) + 1);
         for (int64_t j = p->col0; j <= p->col1; ++j) colstart[(size_t)(j - p->col0)] = load_idx(colptr, idx_bytes, j) - idx_base - e0;
     }
+    tm.mark("csc: entry lists (host)");
     FD_TRY(finish_list_plan(p, col0, rows, nzc, dest, kind == K_CSC ? &colstart : nullptr));
+    tm.mark("csc: list plan (total)");
     if (kind == K_CSC) FD_TRY(build_store_csc_host(p, colptr, rowval, idx_bytes, idx_base));
+    tm.mark("csc: compact pattern copy");
     p->nouts = 1;
     p->out_len[0] = kind == K_CSC ? (e1 - e0) : M * N;
     return FD_OK;
@@ -268,11 +274,16 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
         const unsigned char *b = (const unsigned char *)data;
         for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     };
+    const char *tr = getenv("FDJAC_CHECKSUM_TRACE");      // the running hash after every array, on stderr (which array differs?)
+    const bool trace = tr && *tr && atoi(tr) != 0;
+    int part = 0;
     auto mix_dev = [&](const void *d, size_t n) -> int {
+        ++part;
         if (!d || !n) return FD_OK;
         std::vector<char> tmp(n);
         FD_HIP_CHECK(hipMemcpy(tmp.data(), d, n, hipMemcpyDeviceToHost));
         mix(tmp.data(), n);
+        if (trace) fprintf(stderr, "[fdjac checksum] array %d (%zu bytes): %016llx\n", part, n, (unsigned long long)h);
         return FD_OK;
     };
     const int64_t scal[] = {p->kind, p->fdtype, p->M, p->N, p->C, p->color8, p->col0, p->col1, p->row0, p->row1, p->nnz_local,
@@ -283,6 +294,11 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
                             (int64_t)p->band_mw, (int64_t)p->band_mc, p->bd_t0, p->bd_t1, p->store_ok, p->store_l, p->store_u,
                             p->store5_ok, p->store5_nx, p->store5_ny};
     mix(scal, sizeof scal);
+    if (trace) {
+        fprintf(stderr, "[fdjac checksum] scalars: %016llx :", (unsigned long long)h);
+        for (int64_t v : scal) fprintf(stderr, " %lld", (long long)v);
+        fprintf(stderr, "\n");
+    }
     int rc;
     if ((rc = mix_dev(p->d_color, (size_t)p->N * (p->color8 ? 1 : 4)))) return rc;
     if (p->window2d) {
@@ -295,6 +311,18 @@ int fd_plan_checksum(fd_plan *p, uint64_t *out)
         const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad);
         if ((rc = mix_dev(p->d_wtiles, sizeof(int4) * 3 * (padded / (size_t)p->win_tile)))) return rc;
         if ((rc = mix_dev(p->d_wcode, sizeof(uint16_t) * padded))) return rc;
+    }
+    if (!p->window && p->kind == K_CSC && p->d_rowval) {          // index lists (sorted-gather or plain)
+        const size_t padded = (size_t)round_up(std::max<int64_t>(p->nnz_local, 1), kListPad), ntiles = padded / kSortTile;
+        const size_t nreal = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile);
+        const int64_t have[] = {p->d_spos != nullptr, p->d_fxwin != nullptr, p->d_tile_order != nullptr, (int64_t)(p->lines_direct * 1e6),
+                                (int64_t)(p->lines_sorted * 1e6)};
+        mix(have, sizeof have);
+        if ((rc = mix_dev(p->d_rowval, sizeof(int32_t) * padded))) return rc;
+        if ((rc = mix_dev(p->d_nzcolor, (size_t)(p->color8 ? 1 : 4) * padded))) return rc;
+        if ((rc = mix_dev(p->d_spos, sizeof(uint16_t) * padded))) return rc;
+        if ((rc = mix_dev(p->d_fxwin, sizeof(int32_t) * 2 * kFxWin * ntiles))) return rc;
+        if ((rc = mix_dev(p->d_tile_order, sizeof(int32_t) * nreal))) return rc;
     }
     *out = h;
     return FD_OK;
@@ -542,18 +570,22 @@ static int blockbanded_impl(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, in
     if (rc) return rc;
     fd_plan *p = *out;
     FD_TRY(apply_opts(p, opts));
+    PbTimer tm(ctx->stream);
     std::vector<int32_t> col0;
     FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    tm.mark("blockbanded: colours (host)");
     FD_TRY(upload_colors(p, col0, {}));
+    tm.mark("blockbanded: colour upload");
     const int64_t nloc = p->col1 - p->col0;
     std::vector<int32_t> rlo((size_t)nloc), cnt((size_t)nloc);
     std::vector<int64_t> offs((size_t)nloc);
     const int64_t w = bl + bu + 1;
     int64_t r0 = N, r1 = 0, dmin = std::numeric_limits<int64_t>::max(), dmax = 0;
-    int64_t J = 0;
     bool pairs_ok = true;   // every column: even first row, even row count, even destination -> 16-B work items
-    for (int64_t j = p->col0; j < p->col1; ++j) {
-        while (off[(size_t)J + 1] <= j) ++J;
+    // (one pass over the block-columns that meet the local column range; the columns of a block-column share everything but their offset)
+    for (int64_t J = 0; J < nblk; ++J) {
+        const int64_t ja = std::max<int64_t>(off[(size_t)J], p->col0), jb = std::min<int64_t>(off[(size_t)J + 1], p->col1);
+        if (ja >= jb) continue;
         const int64_t K0 = std::max<int64_t>(J - bu, 0), K1 = std::min<int64_t>(J + bl, nblk - 1);
         const int64_t stride = load_idx(block_strides, idx_bytes, J);
         const int64_t start0 = load_idx(block_starts, idx_bytes, (bu + K0 - J) + w * J) - idx_base;
@@ -577,15 +609,19 @@ static int blockbanded_impl(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, in
             *out = nullptr;
             return FD_ERR_SHAPE;
         }
-        const size_t jj = (size_t)(j - p->col0);
-        rlo[jj] = (int32_t)off[(size_t)K0];
-        cnt[jj] = (int32_t)rows_n;
-        offs[jj] = start0 + (j - off[(size_t)J]) * stride;
+        const int32_t lo32 = (int32_t)off[(size_t)K0], n32 = (int32_t)rows_n;
+        int64_t o = start0 + (ja - off[(size_t)J]) * stride;
+        for (int64_t j = ja; j < jb; ++j, o += stride) {
+            const size_t jj = (size_t)(j - p->col0);
+            rlo[jj] = lo32;
+            cnt[jj] = n32;
+            offs[jj] = o;
+        }
         pairs_ok = pairs_ok && (((off[(size_t)K0] | rows_n) & 1) == 0);
         r0 = std::min<int64_t>(r0, off[(size_t)K0]);
         r1 = std::max<int64_t>(r1, off[(size_t)K1 + 1]);
-        dmin = std::min<int64_t>(dmin, offs[jj]);
-        dmax = std::max<int64_t>(dmax, offs[jj] + rows_n);
+        dmin = std::min<int64_t>(dmin, start0 + (ja - off[(size_t)J]) * stride);
+        dmax = std::max<int64_t>(dmax, start0 + (jb - 1 - off[(size_t)J]) * stride + rows_n);
     }
     if (nloc == 0) { r0 = r1 = 0; dmin = dmax = 0; }
     // outputs are relative to the first local stored value
@@ -594,6 +630,7 @@ static int blockbanded_impl(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, in
         pairs_ok = pairs_ok && ((o & 1) == 0);
     }
     p->cr_pairs = pairs_ok && nloc > 0;
+    tm.mark("blockbanded: column ranges");
     {
         // the store capability (fd_colrange_store): colorvec must be a valid colouring -- the columns of the block-columns that touch
         // a block-row (K - bl .. K + bu) pairwise differ in colour, none without colour -- and the block structure is recorded
@@ -614,10 +651,13 @@ static int blockbanded_impl(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, in
     p->entry_begin = dmin;
     p->row0 = r0;
     p->row1 = r1;
+    tm.mark("blockbanded: colouring check");
     FD_TRY(dev_upload(&p->d_cr_rlo, rlo));
     FD_TRY(dev_upload(&p->d_cr_cnt, cnt));
     FD_TRY(dev_upload(&p->d_cr_off, offs));
+    tm.mark("blockbanded: uploads");
     FD_TRY(alloc_scratch(p, col0));
+    tm.mark("blockbanded: scratch");
     p->nouts = 1;
     p->out_len[0] = dmax - dmin;
     return FD_OK;

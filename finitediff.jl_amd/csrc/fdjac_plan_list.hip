@@ -635,12 +635,52 @@ static void store_caps_implicit_band(fd_plan *p, int64_t l, int64_t u)
     p->store_l = (int)l; p->store_u = (int)u; p->store_C = p->cyc_C; p->store_shift = p->cyc_shift;
 }
 
+// Tile ORDER of a sorted-gather plan whose pattern has a far band (3-D stencils: offsets 0, +-1, +-nx, +-nx*ny).  A tile's gathers
+// reach the rows a whole "plane" D = max |row - column| away; walking the tiles in storage order the three planes in use are
+// 3 * C * D * 8 bytes (6.7 MB for 200^3, 7 colours) against 4 MB of L2 per XCD, and the plane above / below is fetched through the
+// fabric a second and third time (rocprofv3: 2.2 x the distinct bytes).  Walk instead: for each in-plane region of Rg columns, all
+// planes in turn -- the three-plane working set of a region is 3 * C * Rg * 8 bytes <= 2 MiB.  Pure scheduling: which workgroup
+// takes which tile (results do not depend on it).  tcol[t] = local column of tile t's first entry, reach = D.  Shared by the host
+// and the device builder.  Empty result: storage order.
+static std::vector<int32_t> far_band_tile_order(const fd_plan *p, const std::vector<int64_t> &tcol, int64_t reach, int64_t ncols, size_t ntiles)
+{
+    std::vector<int32_t> order;
+    const char *to = getenv("FDJAC_TILE_ORDER");
+    const int want = (to && *to) ? atoi(to) : 1;
+    if (want == 0 || ntiles < (want == 2 ? 16u : 256u)) return order;
+    const int64_t D = reach;
+    const int64_t cpt = std::max<int64_t>(1, ncols / (int64_t)ntiles);
+    if (!(D >= (want == 2 ? 2 : 16) * cpt && D < ncols)) return order;
+    int64_t Rg = ((int64_t)2 << 20) / (3 * std::max<int64_t>(p->C, 1) * (int64_t)sizeof(real_t));
+    Rg = std::max<int64_t>(4 * cpt, std::min<int64_t>(Rg, D / 2));
+    // only the tiles the kernel walks: ceil(nnz_local / kSortTile) -- the lists are padded to kListPad (two tiles), and
+    // an all-padding tile in the order would displace a real one (its values would never be written)
+    const size_t nreal = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile);
+    // (region, plane, position in the plane, tile): the tile number last makes the order that of a stable sort
+    struct Key { int64_t k, l, u; int32_t t; };
+    std::vector<Key> keys(nreal);
+    for (size_t t = 0; t < nreal; ++t) {
+        const int64_t u = tcol[t] % D;
+        keys[t] = Key{u / Rg, tcol[t] / D, u, (int32_t)t};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.k != b.k) return a.k < b.k;
+        if (a.l != b.l) return a.l < b.l;
+        if (a.u != b.u) return a.u < b.u;
+        return a.t < b.t;
+    });
+    order.resize(nreal);
+    for (size_t t = 0; t < nreal; ++t) order[t] = keys[t].t;
+    return order;
+}
+
 // Shared by the three index-list kinds: local entries [e0,e1) with rows, columns (0-based).
 static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::vector<int32_t> &rows,
                             std::vector<int32_t> &nzc, std::vector<int64_t> &dest,
                             const std::vector<int64_t> *colstart = nullptr)
 {
     int rc;
+    PbTimer tm(p->ctx->stream);
     p->nnz_local = (int64_t)rows.size();
     int64_t r0 = p->M, r1 = 0;
     for (int32_t r : rows) {
@@ -667,6 +707,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
     }
 
+    tm.mark("list: rows, padding, coherence");
     if (!has_dest && p->nnz_local > 0) {
         const char *fw1 = getenv("FDJAC_WINDOW"), *fs1 = getenv("FDJAC_SORTED");
         const bool win_allowed = !(fw1 && *fw1 && atoi(fw1) == 0) && !(fs1 && *fs1 && atoi(fs1) == 1);
@@ -689,6 +730,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             if (fs && *fs) p->sorted_gather = atoi(fs) != 0 && p->nnz_local >= 4 * kSortTile;
         }
     }
+    tm.mark("list: window / store attempts");
     // (far-band tile order, below: the reach D = max |row - column| and every tile's first column, from the storage order)
     std::vector<int64_t> tcol;
     int64_t reach = 0;
@@ -703,6 +745,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         }
         for (size_t t = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile); t < ntl; ++t) tcol[t] = (int64_t)colstart->size() - 2;
     }
+    tm.mark("list: reach, tile columns");
     if (p->sorted_gather) {
         std::vector<uint16_t> spos(padded);
         const size_t ntiles = padded / kSortTile;
@@ -722,7 +765,9 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
                 std::copy(c2.begin(), c2.end(), nzc.begin() + (ptrdiff_t)b0);
             }
         }))) return rc;
+        tm.mark("list: tile sorts");
         if ((rc = dev_upload(&p->d_spos, spos))) return rc;
+        tm.mark("list: upload positions");
         // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
         {
             const char *fl = getenv("FDJAC_FX_LDS");
@@ -763,41 +808,18 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
                 if (eligible.load() * 2 >= ntiles && (rc = dev_upload(&p->d_fxwin, fxw))) return rc;
             }
         }
-        // Tile ORDER for patterns with a far band (3-D stencils: offsets 0, +-1, +-nx, +-nx*ny).  A tile's gathers reach the rows a
-        // whole "plane" D = max |row - column| away; walking the tiles in storage order the three planes in use are 3 * C * D * 8
-        // bytes (6.7 MB for 200^3, 7 colours) against 4 MB of L2 per XCD, and the plane above / below is fetched through the
-        // fabric a second and third time (rocprofv3: 2.2 x the distinct bytes).  Walk instead: for each in-plane region of Rg
-        // columns, all planes in turn -- the three-plane working set of a region is 3 * C * Rg * 8 bytes <= 2 MiB.  Pure
-        // scheduling: which workgroup takes which tile (results do not depend on it).
-        const char *to = getenv("FDJAC_TILE_ORDER");
-        const int want = (to && *to) ? atoi(to) : 1;
-        if (colstart && want != 0 && ntiles >= (want == 2 ? 16u : 256u)) {
-            const int64_t ncols = (int64_t)colstart->size() - 1;
-            const int64_t D = reach;
-            const int64_t cpt = std::max<int64_t>(1, ncols / (int64_t)ntiles);
-            if (D >= (want == 2 ? 2 : 16) * cpt && D < ncols) {
-                int64_t Rg = ((int64_t)2 << 20) / (3 * std::max<int64_t>(p->C, 1) * (int64_t)sizeof(real_t));
-                Rg = std::max<int64_t>(4 * cpt, std::min<int64_t>(Rg, D / 2));
-                // only the tiles the kernel walks: ceil(nnz_local / kSortTile) -- the lists are padded to kListPad (two tiles), and
-                // an all-padding tile in the order would displace a real one (its values would never be written)
-                const size_t nreal = (size_t)((p->nnz_local + kSortTile - 1) / kSortTile);
-                std::vector<int32_t> order(nreal);
-                for (size_t t = 0; t < nreal; ++t) order[t] = (int32_t)t;
-                std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-                    const int64_t ua = tcol[(size_t)a] % D, ub = tcol[(size_t)b] % D;
-                    const int64_t ka = ua / Rg, kb = ub / Rg;
-                    if (ka != kb) return ka < kb;
-                    const int64_t la = tcol[(size_t)a] / D, lb = tcol[(size_t)b] / D;
-                    if (la != lb) return la < lb;
-                    return ua < ub;
-                });
-                if ((rc = dev_upload(&p->d_tile_order, order))) return rc;
-            }
+        if (colstart) {
+            const std::vector<int32_t> order = far_band_tile_order(p, tcol, reach, (int64_t)colstart->size() - 1, ntiles);
+            if (!order.empty() && (rc = dev_upload(&p->d_tile_order, order))) return rc;
         }
     }
+    tm.mark("list: tile order");
     if ((rc = dev_upload(&p->d_rowval, rows))) return rc;
     if ((rc = upload_colors(p, col0, nzc))) return rc;
     if (has_dest && (rc = dev_upload(&p->d_dest, dest))) return rc;
-    return alloc_scratch(p, col0);
+    tm.mark("list: uploads (rows, colours)");
+    rc = alloc_scratch(p, col0);
+    tm.mark("list: scratch");
+    return rc;
 }
 

@@ -763,15 +763,6 @@ __global__ void __launch_bounds__(kBlock) k_pb_stencil5_exact(const void *__rest
 // outcome of the device builder
 enum { PBR_DONE = 0, PBR_DECLINED = 1 };
 
-// FDJAC_PLAN_TIMING=1: wall-clock of the builder's sections on stderr (each mark synchronises the stream)
-struct PbTimer {
-    bool on;
-    hipStream_t s;
-    double t0;
-    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
-    PbTimer(hipStream_t st) : s(st) { const char *v = getenv("FDJAC_PLAN_TIMING"); on = v && *v && atoi(v) != 0; t0 = on ? now() : 0; }
-    void mark(const char *what) { if (!on) return; (void)hipStreamSynchronize(s); const double t = now(); fprintf(stderr, "[fdjac plan] %-28s %8.3f ms\n", what, t - t0); t0 = t; }
-};
 
 // (this file is included by fdjac_api.hip after window_lds_bytes / alloc_scratch are defined)
 
@@ -819,44 +810,63 @@ static void device_store_stencil5(fd_plan *p, const void *d_colptr, const void *
     (void)hipFree(d_bad);
 }
 
+static bool pb_coherence_sample(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t nloc,
+                                const uint8_t *d_color8);       // (fdjac_planbuild_lists.hip)
+
+// device counterpart of try_store_plan_csc for plans without row windows (same decisions: width and offset from the middle column,
+// then the exact band, corners included)
+static void device_store_band(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t e1, int64_t C,
+                              int shift, bool cyclic)
+{
+    p->store_ok = false;
+    hipStream_t s = p->ctx->stream;
+    if (!p->store_allowed || !cyclic || p->col1 - p->col0 < 4 || p->nnz_local < 1) return;
+    const int64_t jm = (p->col0 + p->col1) / 2;
+    char raw[2][16];
+    if (hipMemcpyAsync(raw[0], (const char *)d_colptr + (size_t)ib * (size_t)jm, 2 * (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return;
+    const int64_t cp = load_idx(raw[0], ib, 0) - base, w = (load_idx(raw[0], ib, 1) - base) - cp;
+    if (w < 1 || w > 64 || C < w || cp < e0 || cp + w > e1) return;
+    if (hipMemcpyAsync(raw[1], (const char *)d_rowval + (size_t)ib * (size_t)cp, (size_t)ib, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return;
+    const int64_t u = jm - (load_idx(raw[1], ib, 0) - base);
+    if (u < 0 || w - 1 - u < 0) return;
+    fd_band_store d;
+    memset(&d, 0, sizeof d);
+    d.M = p->M; d.N = p->N; d.l = (int)(w - 1 - u); d.u = (int)u; d.C = (int)C; d.shift = shift;
+    int *d_bad = nullptr, hbad = 0;
+    if (hipMalloc((void **)&d_bad, sizeof(int)) != hipSuccess) return;
+    if (hipMemcpyAsync(d_bad, &hbad, sizeof hbad, hipMemcpyHostToDevice, s) == hipSuccess) {
+        hipLaunchKernelGGL(k_pb_band_exact, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p->col1 - p->col0 + kBlock - 1) / kBlock, (int64_t)p->ctx->num_cus * 16))),
+                           dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, d, d_bad);
+        hbad = 1;
+        if (hipMemcpyAsync(&hbad, d_bad, sizeof hbad, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && !hbad) {
+            p->store_ok = true; p->store_l = d.l; p->store_u = d.u; p->store_C = d.C; p->store_shift = shift;
+        }
+    }
+    (void)hipFree(d_bad);
+}
+
 // 2-D (strided) tiles built on the device -- the decisions are try_window2d_plan's / finish_list_plan's (same helper
 // functions, same thresholds), the O(nnz) work is done by the kernels above.  PBR_DONE: p->d_w2desc / d_wcode and the
 // window fields are set (the caller finishes the plan); PBR_DECLINED: the host builder decides.
 static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t nloc,
-                           const uint8_t *d_color8, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out)
+                           const uint8_t *d_color8, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out, bool *host_too)
 {
+    // *host_too: declined for a reason try_window2d_plan shares (the host builder would not build 2-D tiles either) -- as opposed
+    // to a limit of this builder alone (memory, tile counts)
+    *host_too = false;
+    auto no2d = [&]() { *host_too = true; return (int)PBR_DECLINED; };
     hipStream_t s = p->ctx->stream;
     const char *fw = getenv("FDJAC_WINDOW2D");
-    if (fw && *fw && atoi(fw) == 0) return PBR_DECLINED;
+    if (fw && *fw && atoi(fw) == 0) return no2d();
     const int64_t ncols = p->col1 - p->col0;
-    if (ncols < 1024 || nloc < 8192 || nloc < 4 * kSortTile) return PBR_DECLINED;
+    if (ncols < 1024 || nloc < 8192 || nloc < 4 * kSortTile) return no2d();
     PbTemps tmp;
     auto sync_ok = [&]() { return hipStreamSynchronize(s) == hipSuccess; };
     // ---- is the storage order a scattered gather? (finish_list_plan's estimate on the same sample of tiles)
-    {
-        const size_t padded = (size_t)((std::max<int64_t>(nloc, 1) + kListPad - 1) / kListPad * kListPad);
-        const size_t ntiles = padded / kSortTile, step = std::max<size_t>(1, ntiles / 64), nsamp = (ntiles + step - 1) / step;
-        int32_t *d_sr = nullptr, *d_sc = nullptr;
-        if (hipMalloc((void **)&d_sr, sizeof(int32_t) * nsamp * kSortTile) != hipSuccess) return PBR_DECLINED;
-        tmp.add(d_sr);
-        if (hipMalloc((void **)&d_sc, sizeof(int32_t) * nsamp * kSortTile) != hipSuccess) return PBR_DECLINED;
-        tmp.add(d_sc);
-        hipLaunchKernelGGL(k_pb_sample_expand, dim3((unsigned)nsamp), dim3(kBlock), 0, s, d_colptr, d_rowval, ib, base, p->col0, p->col1, e0,
-                           nloc, d_color8, (int64_t)step, d_sr, d_sc);
-        int *d_cnt = nullptr;
-        if (hipMalloc((void **)&d_cnt, sizeof(int) * 2 * nsamp) != hipSuccess) return PBR_DECLINED;
-        tmp.add(d_cnt);
-        hipLaunchKernelGGL(k_pb_coherence, dim3((unsigned)nsamp), dim3(kBlock), 0, s, d_sr, d_sc, d_cnt);
-        std::vector<int> cnt(2 * nsamp);
-        if (hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, s) != hipSuccess || !sync_ok()) return PBR_DECLINED;
-        // (the host's gather_coherence: sums of per-gather line counts / number of gathers; integers, so the same doubles)
-        double ld = 0, ls = 0;
-        for (size_t t = 0; t < nsamp; ++t) { ld += (double)cnt[2 * t]; ls += (double)cnt[2 * t + 1]; }
-        const size_t ninstr = nsamp * 2 * (kSortTile / 128);
-        p->lines_direct = ld / (double)std::max<size_t>(ninstr, 1);
-        p->lines_sorted = ls / (double)std::max<size_t>(ninstr, 1);
-        if (!(p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted)) return PBR_DECLINED;
-    }
+    if (!pb_coherence_sample(p, d_colptr, d_rowval, ib, base, e0, nloc, d_color8)) return PBR_DECLINED;
+    if (!(p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted)) return no2d();
     tm.mark("2-D: coherence sample");
     // ---- the stride: most common far offset over a sample of columns
     int64_t st_s = 0;
@@ -873,16 +883,16 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
         std::vector<int64_t> fars;
         for (int i = 0; i < nsamp; ++i) {
             const int cnt = o[33 * (size_t)i];
-            if (cnt < 0) return PBR_DECLINED;                        // a column with more than 32 entries
+            if (cnt < 0) return no2d();                              // a column with more than 32 entries
             for (int e = 0; e < cnt; ++e) {
                 const int64_t d = o[33 * (size_t)i + 1 + e];
                 if (d > 8 || d < -8) fars.push_back(d < 0 ? -d : d);
             }
         }
-        if (fars.empty()) return PBR_DECLINED;
+        if (fars.empty()) return no2d();
         std::sort(fars.begin(), fars.end());
         st_s = fars[fars.size() / 2];
-        if (st_s < 64 || ncols < 4 * st_s) return PBR_DECLINED;
+        if (st_s < 64 || ncols < 4 * st_s) return no2d();
     }
     Pb2Stats *d_st = nullptr;
     if (hipMalloc((void **)&d_st, sizeof(Pb2Stats)) != hipSuccess) return PBR_DECLINED;
@@ -900,10 +910,11 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
         return PBR_DONE;
     }
     const int ecmax = h.ecmax, halo = h.halo;
-    if ((int64_t)h.bad * 1000 > nloc || ecmax < 1 || ecmax > 32) return PBR_DECLINED;
+    if ((int64_t)h.bad * 1000 > nloc || ecmax < 1 || ecmax > 32) return no2d();
     tm.mark("2-D: stride + check");
     int L, R;
-    if (!w2_shape(p, ecmax, halo, &L, &R) || L > 128) return PBR_DECLINED;
+    if (!w2_shape(p, ecmax, halo, &L, &R)) return no2d();
+    if (L > 128) return PBR_DECLINED;
     const int64_t g_lo = p->col0 / st_s, g_hi = (p->col1 - 1) / st_s;
     const int64_t nG = (g_hi - g_lo + R) / R, nI = (st_s + L - 1) / L;
     const int64_t ntl = nG * nI;
@@ -1028,6 +1039,9 @@ static void pb_launch_tiles(bool codes, int T, bool band, int64_t grid, int64_t 
 #undef FD_PB_TILES
 }
 
+static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t nloc,
+                              const uint8_t *d_color8, int64_t C, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out);
+
 // band != nullptr: the "pattern" is a band's column-major storage (fd_plan_create_banded; d_colptr / d_rowval unused,
 // entries [0, e1) = the slots of the local columns).
 struct PbBand { int64_t w, u; };
@@ -1141,7 +1155,11 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         (void)hipFree(d_wt); (void)hipFree(d_code);
         p->C = C;                                      // (w2_shape sizes the LDS tile with the number of colours)
         int r0 = 0, r1 = 0;
-        const int res2 = device_build_2d(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, nloc, d_color8, tm, &r0, &r1, rc_out);
+        bool host_too = false;
+        int res2 = device_build_2d(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, nloc, d_color8, tm, &r0, &r1, rc_out, &host_too);
+        // not a 2-D stencil either: index lists (sorted tiles for a scattered storage order), if no window tile size can work
+        if (res2 == PBR_DECLINED && host_too && *rc_out == FD_OK)
+            res2 = device_build_lists(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, nloc, d_color8, C, tm, &r0, &r1, rc_out);
         if (res2 != PBR_DONE || *rc_out != FD_OK) { (void)hipFree(d_color8); return res2; }
         p->color8 = true;
         p->d_color = d_color8;
@@ -1153,8 +1171,10 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
-        device_store_stencil5(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, C, d_color8, p->has_none);
-        tm.mark("stencil store test");
+        // (an exact band whose colours outnumber what a window tile holds ends up here too: its store capability, as in the main path)
+        device_store_band(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, e1, C, shift, !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)));
+        if (!p->store_ok) device_store_stencil5(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, C, d_color8, p->has_none);
+        tm.mark("store tests");
         p->built_on_device = true;
         *rc_out = alloc_scratch(p, std::vector<int32_t>());
         tm.mark("scratch allocation");

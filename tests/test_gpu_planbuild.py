@@ -359,7 +359,13 @@ def test_random_patterns_device_vs_host_builder(monkeypatch, seed):
         out = _dev(np.full(plan.out_len(0), np.nan))
         plan.jacobian(fd.TorchF(fn, M, N), x, [out])
         plans[dev], outs[dev] = plan, out
-    assert plans["0"].checksum() == plans["1"].checksum(), (kind, fdtype, N, l, u, C, win)
+    if plans["0"].checksum() != plans["1"].checksum():
+        monkeypatch.setenv("FDJAC_CHECKSUM_TRACE", "1")
+        plans["0"].checksum(), plans["1"].checksum()
+        print("PLANS", kind, fdtype, N, M, l, u, C, win, [[plans[d].info(k) for k in (fd.lib.INFO_BUILT_ON_DEVICE, fd.lib.INFO_WINDOW, fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_LINES_DIRECT_X100, fd.lib.INFO_LINES_SORTED_X100, fd.lib.INFO_NNZ_LOCAL, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_EPS_CYCLIC)] for d in ("0", "1")])
+    assert plans["0"].checksum() == plans["1"].checksum(), (kind, fdtype, N, l, u, C, win, [
+        (plans[d].info(fd.lib.INFO_BUILT_ON_DEVICE), plans[d].info(fd.lib.INFO_WINDOW), plans[d].info(fd.lib.INFO_SORTED_GATHER),
+         plans[d].info(fd.lib.INFO_LINES_DIRECT_X100), plans[d].info(fd.lib.INFO_LINES_SORTED_X100)) for d in ("0", "1")])
     for key in (fd.lib.INFO_WINDOW, fd.lib.INFO_WINDOW2D, fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_BAND_DESC, fd.lib.INFO_WIN_PERIOD,
                 fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_NNZ_LOCAL, fd.lib.INFO_NCOLORS):
         assert plans["0"].info(key) == plans["1"].info(key), key
@@ -368,3 +374,161 @@ def test_random_patterns_device_vs_host_builder(monkeypatch, seed):
         bad = torch.nonzero(outs[dev] != outs["ref"]).flatten()
         assert bad.numel() == 0, (dev, kind, fdtype, N, M, l, u, C, win, int(bad.numel()), bad[:8].tolist(),
                                   outs[dev][bad[:8]].tolist(), outs["ref"][bad[:8]].tolist())
+
+
+def _lap7_csc(n1, n2, n3):
+    N = n1 * n2 * n3
+    k = np.arange(N, dtype=np.int64)
+    i, j, l = k % n1, (k // n1) % n2, k // (n1 * n2)
+    has = np.stack([l > 0, j > 0, i > 0, np.ones(N, bool), i < n1 - 1, j < n2 - 1, l < n3 - 1], axis=1)
+    rows = np.stack([k - n1 * n2, k - n1, k - 1, k, k + 1, k + n1, k + n1 * n2], axis=1)
+    colptr = np.concatenate([[0], np.cumsum(has.sum(axis=1))]).astype(np.int64) + 1
+    return colptr, (rows[has] + 1).astype(np.int64), ((i + 2 * j + 3 * l) % 7 + 1).astype(np.int64)
+
+
+def _offsets_csc(N, offsets, rng=None, jitter=0):
+    cols, rows = [], []
+    j = np.arange(N, dtype=np.int64)
+    per = []
+    for o in offsets:
+        r = j + o + (rng.integers(-jitter, jitter + 1, size=N) if jitter else 0)
+        per.append(np.where((r >= 0) & (r < N), r, -1))
+    R = np.sort(np.stack(per, axis=1), axis=1)
+    keep = R >= 0
+    keep[:, 1:] &= R[:, 1:] != R[:, :-1]                 # (a column lists a row once)
+    colptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int64) + 1
+    return colptr, (R[keep] + 1).astype(np.int64)
+
+
+@pytest.mark.parametrize("case", ["lap7", "lap7_flat", "lap7_none", "lap7_window", "far_offsets", "far_jitter", "random_rows", "lap7_int32_device"])
+@pytest.mark.parametrize("fdtype", FDTYPES)
+def test_index_list_plans_built_on_the_device_equal_host_built(monkeypatch, case, fdtype):
+    # Patterns no row-window form describes -- 3-D stencils, far offsets, random rows: the device builder compiles the index lists
+    # (tiles sorted by colour and row, their output positions, the f(x) runs of the forward kernel, the far-band tile order) with
+    # kernels; the host builder's loops are the checker: same plan arrays (checksum), same Jacobian bits as the plain gather kernels.
+    rng = np.random.default_rng(77)
+    win = None
+    if case.startswith("lap7"):
+        n1, n2, n3 = (97, 31, 53) if case == "lap7_flat" else (83, 47, 41)
+        colptr, rowval, colors = _lap7_csc(n1, n2, n3)
+        N = n1 * n2 * n3
+        if case == "lap7_none":
+            colors = colors.copy()
+            colors[rng.integers(0, N, size=40)] = 0
+        if case == "lap7_window":
+            win = (N // 7 + 1, 5 * N // 7)
+    elif case == "random_rows":
+        N = 150_000
+        rows = np.sort(rng.integers(0, N, size=(N, 5)), axis=1)
+        keep = np.ones_like(rows, bool)
+        keep[:, 1:] = rows[:, 1:] != rows[:, :-1]
+        colptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int64) + 1
+        rowval = (rows[keep] + 1).astype(np.int64)
+        colors = rng.integers(1, 7, size=N).astype(np.int64)
+    else:
+        N = 180_007
+        colptr, rowval = _offsets_csc(N, [-N // 3, -4099, -257, -1, 0, 1, 257, 4099, N // 3], rng, 3 if case == "far_jitter" else 0)
+        colors = ((np.arange(N) * 3) % 8 + 1).astype(np.int64)
+    x = _dev(rng.random(N))
+
+    def fn(fx, xx):
+        fx.copy_(xx.roll(1) ** 2 + 3 * xx + xx.roll(-5) * xx)
+
+    plans, outs = {}, {}
+    for dev in ("0", "1", "ref"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "0" if dev == "ref" else dev)
+        if dev == "ref":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+            monkeypatch.setenv("FDJAC_SORTED", "0")
+        if case == "lap7_int32_device" and dev == "1":
+            d = [torch.as_tensor((a - 1).astype(np.int32), device="cuda") for a in (colptr, rowval)] + [torch.as_tensor(colors.astype(np.int32), device="cuda")]
+            plan = fd.make_plan_csc_device(N, N, d[0], d[1], d[2], fdtype, idx_base=0)
+        else:
+            J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+            plan = fd.make_plan(J, J, colors, fdtype, col_window=win)
+        if dev != "ref":
+            assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == int(dev), case
+            assert plan.info(fd.lib.INFO_WINDOW) == 0
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(fn, N, N), x, [out])
+        plans[dev], outs[dev] = plan, out
+    assert plans["0"].checksum() == plans["1"].checksum(), case
+    for key in (fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_NNZ_LOCAL,
+                fd.lib.INFO_NCOLORS, fd.lib.INFO_LINES_DIRECT_X100):
+        assert plans["0"].info(key) == plans["1"].info(key), key
+    if case != "random_rows":
+        assert plans["1"].info(fd.lib.INFO_SORTED_GATHER) == 1
+    assert not torch.isnan(outs["ref"]).any()
+    for dev in ("0", "1"):
+        assert torch.equal(outs[dev], outs["ref"]), (dev, case)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scattered_patterns_device_vs_host_builder(monkeypatch, seed):
+    # Randomised: 3-D stencils on random grids, random far-offset sets (with and without jitter), random rows; random colourings
+    # (cyclic, affine in the grid indices, irregular, with uncoloured columns), random column windows, every fdtype.  Whatever the
+    # builders decide -- row windows after all, sorted lists, plain lists -- the device-built plan must be the host-built plan.
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "5000")) + seed)
+    kind = ["lap7", "offsets", "jitter", "rows"][seed % 4]
+    fdtype = FDTYPES[int(rng.integers(0, 3))]
+    C = int(rng.integers(2, 9))
+    if kind == "lap7":
+        n1, n2, n3 = int(rng.integers(20, 130)), int(rng.integers(8, 70)), int(rng.integers(8, 60))
+        colptr, rowval, _ = _lap7_csc(n1, n2, n3)
+        N = n1 * n2 * n3
+        k = np.arange(N)
+        a, b, c = (int(v) for v in rng.integers(1, 4, size=3))
+        colors = ((a * (k % n1) + b * ((k // n1) % n2) + c * (k // (n1 * n2))) % C + 1).astype(np.int64)
+    elif kind == "rows":
+        N = int(rng.integers(60_000, 200_000))
+        per = int(rng.integers(2, 7))
+        rows = np.sort(rng.integers(0, N, size=(N, per)), axis=1)
+        keep = np.ones_like(rows, bool)
+        keep[:, 1:] = rows[:, 1:] != rows[:, :-1]
+        colptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int64) + 1
+        rowval = (rows[keep] + 1).astype(np.int64)
+        colors = rng.integers(1, C + 1, size=N).astype(np.int64)
+    else:
+        N = int(rng.integers(100_000, 300_000))
+        offs = {0}
+        for cand in (1, 2, int(rng.integers(20, 100)), int(rng.integers(100, 2000)), int(rng.integers(2000, N // 4)), N // int(rng.integers(2, 5))):
+            if rng.random() < 0.7:
+                offs.add(cand)
+            if rng.random() < 0.7:
+                offs.add(-cand)
+        colptr, rowval = _offsets_csc(N, sorted(offs), rng, int(rng.integers(1, 6)) if kind == "jitter" else 0)
+        colors = ((np.arange(N) * int(rng.integers(1, 4)) + int(rng.integers(0, C))) % C + 1).astype(np.int64)
+    style = rng.random()
+    if style < 0.25:
+        colors[rng.integers(0, N, size=7)] = 0
+    elif style < 0.5:
+        idx = rng.integers(0, N, size=60)
+        colors[idx] = colors[idx] % C + 1
+    win = None
+    if rng.random() < 0.35:
+        a = int(rng.integers(0, N // 3))
+        win = (a + 1, int(rng.integers(a + N // 3, N)))
+    x = _dev(rng.random(N))
+
+    def fn(fx, xx):
+        fx.copy_(xx.roll(1) ** 2 + 3 * xx + xx.roll(-5) * xx)
+
+    plans, outs = {}, {}
+    for dev in ("0", "1", "ref"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "0" if dev == "ref" else dev)
+        if dev == "ref":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+            monkeypatch.setenv("FDJAC_SORTED", "0")
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=win)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(fn, N, N), x, [out])
+        plans[dev], outs[dev] = plan, out
+    what = (kind, fdtype, N, C, win, [[plans[d].info(k) for k in (fd.lib.INFO_BUILT_ON_DEVICE, fd.lib.INFO_WINDOW, fd.lib.INFO_SORTED_GATHER)] for d in ("0", "1")])
+    assert plans["0"].checksum() == plans["1"].checksum(), what
+    for key in (fd.lib.INFO_WINDOW, fd.lib.INFO_WINDOW2D, fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END,
+                fd.lib.INFO_NNZ_LOCAL, fd.lib.INFO_NCOLORS):
+        assert plans["0"].info(key) == plans["1"].info(key), (key, what)
+    assert not torch.isnan(outs["ref"]).any()
+    for dev in ("0", "1"):
+        assert torch.equal(outs[dev], outs["ref"]), (dev, what)
