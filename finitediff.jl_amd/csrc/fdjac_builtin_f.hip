@@ -258,6 +258,59 @@ k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ 
     fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);      // (non-temporal: nothing re-reads nzval in this call)
 }
 
+#ifdef FDJAC_F32
+// Float32: the same kernel with FOUR columns per lane -- x as three aligned 16-B quads, twelve quotients, fd_band_emit_wave4's 16-B
+// stores (a wavefront of the pair form moves 1.5 KB, half of the Float64 wavefront's bytes for the same instructions: N = 10^7
+// 34.6 us for 160 MB).  Same operations per entry as the pair form: same bits.
+typedef real_t r4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ r4_t ld_quad_guarded(const real_t *__restrict__ x, int64_t a, int64_t n)
+{
+    if (a >= 0 && a + 3 < n) return *reinterpret_cast<const r4_t *>(x + a);
+    r4_t v = {0, 0, 0, 0};
+    if (a >= 0 && a < n) v.x = x[a];
+    if (a + 1 >= 0 && a + 1 < n) v.y = x[a + 1];
+    if (a + 2 >= 0 && a + 2 < n) v.z = x[a + 2];
+    if (a + 3 >= 0 && a + 3 < n) v.w = x[a + 3];
+    return v;
+}
+template <int MODE, bool NL>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_store_wave4(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart)
+{
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_BAND_WAVE4_LDS(3)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    if (gw >= nwaves) return;
+    const int64_t jw = jstart + gw * 256;                    // a multiple of 4: the x quads are 16-B aligned
+    const int64_t j = jw + 4 * lane;
+    const r4_t Cc = ld_quad_guarded(x, j, n), L = ld_quad_guarded(x, j - 4, n), R = ld_quad_guarded(x, j + 4, n);
+    const int c0w = (int)((jw + bst.shift) % bst.C);
+    int cc = (int)((uint32_t)(c0w + 4 * lane) % (uint32_t)bst.C);
+    real_t ev[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { ev[o] = eps[cc]; cc = cc + 1 == bst.C ? 0 : cc + 1; }
+    const real_t xv[8] = {L.z, L.w, Cc.x, Cc.y, Cc.z, Cc.w, R.x, R.y};      // x[j - 2 .. j + 5]
+    real_t q[12];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
+        const real_t e = ev[o];
+        const real_t ed = MODE == 1 ? 2 * e : e;
+        real_t p[5], m[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
+            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
+                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
+            q[3 * o + k] = sub_exact(plus, sub) / ed;
+        }
+    }
+    fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
+}
+#endif
+
 // (32-bit index arithmetic: the launcher checked that every entry / row / column number is below 2^31)
 __device__ __forceinline__ int band_colptr32(int j, int l, int u, int M)
 {
@@ -727,6 +780,20 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
         // colour ownership and wider bands take the row-owned kernel below
         const bool wave_ok = bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
                              lp->ncolors == bst.C && bst.C >= 3 && (((uintptr_t)lp->x) & kPairMask) == 0 && bst.col_end > bst.col_begin;
+#ifdef FDJAC_F32
+        if (wave_ok && (((uintptr_t)lp->x) & 15) == 0) {      // Float32: four columns per lane
+            const int64_t jstart = bst.col_begin & ~(int64_t)3;
+            const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
+            const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
+#define FD_LAZY_SW4(MODE, NL)                                                                                      \
+            hipLaunchKernelGGL((k_f_tridiag_store_wave4<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                               (const real_t *)lp->eps, b->prm[0], bst, jstart)
+            if (mode == 0) { if (nl) FD_LAZY_SW4(0, true); else FD_LAZY_SW4(0, false); }
+            else { if (nl) FD_LAZY_SW4(1, true); else FD_LAZY_SW4(1, false); }
+#undef FD_LAZY_SW4
+            return hipGetLastError() == hipSuccess ? 0 : 4;
+        }
+#endif
         if (wave_ok) {
             const int64_t jstart = bst.col_begin & ~(int64_t)1;
             const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
@@ -1141,12 +1208,19 @@ k_f_blockcoupled_lazy(real_t *__restrict__ fx, int64_t fs, real_t *__restrict__ 
 // colour -- and a row k of block b' in b-1 .. b+1 the value is imag(x~_k * (sig_{b'-1} + sig_{b'} + sig_{b'+1}) + sin(x~_k)) at point
 // q, the operations of k_f_blockcoupled_lazy's phase B on the same operands (the plan verified that no other column of colour q
 // touches those rows), divided by eps_q: same bits as the hand-over path.
-constexpr int kBcS = 4;          // block-columns per workgroup (2 / 3 / 4 / 6 / 8 / 10 measured: 57 / 62 / 57 / 63 / 67 / 75 us on config 5)
+#ifndef FD_BCS
+#define FD_BCS 4
+#endif
+#ifndef FD_BCT
+#define FD_BCT 512
+#endif
+constexpr int kBcT = FD_BCT;      // threads per workgroup
+constexpr int kBcS = FD_BCS;      // block-columns per workgroup (2 / 3 / 4 / 6 / 8 / 10 measured: 57 / 62 / 57 / 63 / 67 / 75 us on config 5)
 // complex items of the LDS region phase A uses for its trees and owners and phase B for the S sums
 __host__ __device__ constexpr size_t bcs_shared_items(int B)
 {
     const size_t item = 2 * sizeof(real_t);
-    const size_t a = (size_t)(kBcS + 2) * (size_t)B, b = (size_t)(kBlock / 64) * 128 + ((size_t)(kBlock / 64) * (size_t)B * 4 + item - 1) / item;
+    const size_t a = (size_t)(kBcS + 2) * (size_t)B, b = (size_t)(kBcT / 64) * 128 + ((size_t)(kBcT / 64) * (size_t)B * 4 + item - 1) / item;
     return a > b ? a : b;
 }
 __device__ __forceinline__ int bc_lane_int(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
@@ -1157,13 +1231,13 @@ __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 template <typename CT, bool TWO>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBcT)
 k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
                        int64_t nb, int bs, int64_t blk0, int64_t blk1, fd_colrange_store st)
 {
     typedef cd T;
     extern __shared__ real_t s_bcs[];
-    constexpr int NBLK = kBcS + 4, NW = kBlock / 64, NIT = (NBLK + NW - 1) / NW;
+    constexpr int NBLK = kBcS + 4, NW = kBcT / 64, NIT = (NBLK + NW - 1) / NW;
     const int PB = B + 1;
     constexpr int RS = TWO ? 32 : 64;                // rows of a block in the row arrays
     constexpr int NU = (2 * kBcS + NW - 1) / NW;     // units of phase B per wave
@@ -1218,7 +1292,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             }
         }
     }
-    for (int q = threadIdx.x; q < B; q += kBlock) {
+    for (int q = threadIdx.x; q < B; q += kBcT) {
         const real_t e = eps[c_lo + q];
         ce[q] = e; cy[q] = (real_t)1 / e; cs[q] = sinh(e);
     }
@@ -1294,7 +1368,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     __syncthreads();
 
     // S of every (row block, point): (sig[k-1] + sig[k]) + sig[k+1], the sum k_f_blockcoupled_lazy's phase B forms, once per group
-    for (int idx = threadIdx.x; idx < (kBcS + 2) * B; idx += kBlock) {
+    for (int idx = threadIdx.x; idx < (kBcS + 2) * B; idx += kBcT) {
         const int lbk = 1 + idx / B, q = idx - (lbk - 1) * B;
         const T *sm = sig + (size_t)(lbk - 1) * PB + q;
         ssum[idx] = (sm[0] + sm[PB]) + sm[2 * PB];
@@ -1407,10 +1481,10 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
         const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
         const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
         if (bs <= 32)
-            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBcT), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         else
-            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, false>), dim3((unsigned)gs), dim3(kBlock), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, false>), dim3((unsigned)gs), dim3(kBcT), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         return hipGetLastError() == hipSuccess ? 0 : 4;
     }

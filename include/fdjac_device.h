@@ -307,6 +307,78 @@ __device__ inline void fd_band_emit_wave(const fd_band_store *d, T *win, long lo
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                                           /* the window may be reused */
 }
+/*
+ * The same for 4-byte elements with FOUR columns per lane: a wavefront's 256 columns, written as 16-byte stores (a Float32 pair
+ * store moves 512 B per instruction, half of what the memory pipeline takes).  Lane t of a FULL wavefront holds the quotients of the
+ * columns j = jw + 4t .. j + 3:  q[c W + k] = (row j + c - u + k, column j + c), c = 0 .. 3, k = 0 .. W-1.  jw is a multiple of 4
+ * and the same in all lanes.  Window: FD_BAND_WAVE4_LDS(W) elements, 16-byte aligned.  Interior wavefronts of the CSC / BANDED
+ * layouts with a 16-byte aligned `out` stage and store quads (the first and the last quad of a wavefront whose first value is not
+ * on a quad boundary are shared with its neighbours: single elements there); a Tridiagonal's three diagonals are written as quads
+ * directly; everything else takes fd_band_emit_column.
+ */
+#define FD_BAND_WAVE4_LDS(W) (256 * (W) + 8)
+template <typename T> struct fd_band_quad_of;
+template <> struct fd_band_quad_of<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct fd_band_quad_of<double> { typedef double type __attribute__((ext_vector_type(4))); };
+template <typename T, int W, bool NT = true>
+__device__ inline void fd_band_emit_wave4(const fd_band_store *d, T *win, long long jw, const T *q)
+{
+    typedef typename fd_band_quad_of<T>::type quad_t;
+    const int lane = (int)(threadIdx.x & 63);
+    const long long j = jw + 4 * lane;
+    const long long jlast = jw + 255;
+    const bool inside = jw >= d->col_begin && jlast < d->col_end && jlast < d->N;
+    const unsigned long long qmask = 4 * sizeof(T) - 1;
+    bool fast = inside && d->layout != FD_BAND_TRIDIAGONAL && ((((unsigned long long)d->out) & qmask) == 0) &&
+                jw >= d->u && jlast + d->l <= d->M - 1;                         /* no column cut by the matrix edge */
+    if (W == 3 && d->layout == FD_BAND_TRIDIAGONAL && inside && jw >= 1 && jlast + 1 <= d->M - 1) {
+        /* three dense diagonals: d and dl quads are aligned with the column quad, du is one element behind */
+        T *pd = (T *)d->out + (j - d->col_begin), *pl = (T *)d->out_dl + (j - d->col_begin);
+        const long long du0 = d->col_begin > 0 ? d->col_begin - 1 : 0;
+        T *pu = (T *)d->out_du + (j - du0);                                   /* du[j]: the entry of column j + 1 */
+        const T nq0 = __shfl_down(q[0], 1, 64);                               /* du[j + 3]: the next lane's first quotient */
+        const quad_t vd = {q[1], q[W + 1], q[2 * W + 1], q[3 * W + 1]}, vl = {q[2], q[W + 2], q[2 * W + 2], q[3 * W + 2]};
+        const quad_t vu = {q[W], q[2 * W], q[3 * W], nq0};
+        if ((((unsigned long long)pd) & qmask) == 0) { if (NT) __builtin_nontemporal_store(vd, (quad_t *)pd); else *(quad_t *)pd = vd; }
+        else { pd[0] = vd.x; pd[1] = vd.y; pd[2] = vd.z; pd[3] = vd.w; }
+        if ((((unsigned long long)pl) & qmask) == 0) { if (NT) __builtin_nontemporal_store(vl, (quad_t *)pl); else *(quad_t *)pl = vl; }
+        else { pl[0] = vl.x; pl[1] = vl.y; pl[2] = vl.z; pl[3] = vl.w; }
+        if (lane == 0) pu[-1] = q[0];
+        if (lane < 63 && (((unsigned long long)pu) & qmask) == 0) { if (NT) __builtin_nontemporal_store(vu, (quad_t *)pu); else *(quad_t *)pu = vu; }
+        else { pu[0] = vu.x; pu[1] = vu.y; pu[2] = vu.z; if (lane < 63) pu[3] = vu.w; }
+        return;
+    }
+    if (!fast) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fd_band_emit_column<T>(d, j + c, q + c * W);
+        return;
+    }
+    /* local index of the wave's first value: slot `off` of the window holds it, so that slot 0 is on a quad boundary */
+    const long long P0 = d->layout == FD_BAND_BANDED ? (long long)W * (jw - d->col_begin)
+                                                     : (long long)W * jw - (long long)d->u * (d->u + 1) / 2 - d->entry_begin;
+    const int off = (int)(P0 & 3);
+#pragma unroll
+    for (int m = 0; m < 4 * W; ++m) win[off + 4 * W * lane + m] = q[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T *base = (T *)d->out + (P0 - off);                                        /* slot 0 <-> a local index that is a multiple of 4 */
+#pragma unroll
+    for (int a = 0; a < W; ++a) {
+        const int sl = 4 * (64 * a + lane);
+        const quad_t v = *(const quad_t *)(win + sl);
+        if (off && sl == 0) {                                                  /* the slots before `off` belong to the wavefront before */
+            if (off <= 1) base[1] = v.y;
+            if (off <= 2) base[2] = v.z;
+            base[3] = v.w;
+        } else if (NT) __builtin_nontemporal_store(v, (quad_t *)(base + sl));
+        else *(quad_t *)(base + sl) = v;
+    }
+    if (lane < off) base[256 * W + lane] = win[256 * W + lane];                /* the values past the last whole quad */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                           /* the window may be reused */
+}
+
 /* the slots [lo, hi) of a wave-private LDS window, slot 0 <-> the 16-byte aligned element `base`: aligned pair stores, single
    elements at the two ends (all 64 lanes call) */
 template <typename T, bool NT> __device__ inline void fd_wave_store_window(T *base, const T *win, int lo, int hi)

@@ -232,3 +232,49 @@ def test_headline_shape_float32_properties():
     got = J.nzval.cpu().numpy()
     isdiag = rv == P.csc_cols(cp)
     assert np.max(np.abs(got[isdiag] + 2.0)) < 0.2 and np.max(np.abs(got[~isdiag] - 1.0)) < 0.2   # eps ~ 0.01 at this norm
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("layout", ["csc", "csc_window0", "csc_window1", "csc_window2", "csc_window3", "banded", "banded_window", "tridiagonal",
+                                    "tridiagonal_unaligned"])
+def test_tridiagonal_store_four_columns_per_lane_float32(monkeypatch, fdtype, layout):
+    # Float32: the storing launch of the tridiagonal fixture takes four columns per lane and writes 16-byte quads
+    # (k_f_tridiag_store_wave4 / fd_band_emit_wave4).  Every position of a wavefront's first value relative to a quad boundary
+    # (column windows starting at 4k, 4k+1, 4k+2, 4k+3), the three storage layouts, an output that is not 16-byte aligned:
+    # the same bits as the hand-over path (f! values -> decompression kernel).
+    N = 70_003
+    colors = P.cyclic_colors(N, 3)
+    x = _dev(np.random.default_rng(12).random(N) + 0.1)
+    win = None
+    if layout.startswith("csc"):
+        cp, rv = P.tridiag_csc(N)
+        J = fd.SparseMatrixCSC(N, N, cp, rv)
+        if "window" in layout:
+            a = 1000 + int(layout[-1])
+            win = (a + 1, N - 777)
+    elif layout.startswith("banded"):
+        J = fd.BandedMatrix(None, N, 1, 1)
+        if "window" in layout:
+            win = (1002 + 1, N - 5)
+    else:
+        J = fd.Tridiagonal(None, np.empty(N, np.float32), None)
+    outs = {}
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        sp = J if not layout.startswith("tridiagonal") and not layout.startswith("banded") else None
+        plan = fd.make_plan(J, sp, colors, fdtype, dtype=F32, col_window=win)
+        f = fd.BuiltinF("tridiag_nl", N, dtype=F32)
+        plan.set_lazy(f)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == int(store)
+        bufs = []
+        for k in range(plan.nouts):
+            n = plan.out_len(k)
+            if layout == "tridiagonal_unaligned":
+                bufs.append(torch.full((n + 1,), float("nan"), dtype=torch.float32, device="cuda")[1:])
+            else:
+                bufs.append(torch.full((n,), float("nan"), dtype=torch.float32, device="cuda"))
+        plan.jacobian(f, x, bufs)
+        outs[store] = [b.cpu().numpy() for b in bufs]
+    for a, b in zip(outs["1"], outs["0"]):
+        assert not np.isnan(b).any()
+        assert np.array_equal(a, b), layout
