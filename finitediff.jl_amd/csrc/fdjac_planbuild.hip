@@ -1042,6 +1042,19 @@ static void pb_launch_tiles(bool codes, int T, bool band, int64_t grid, int64_t 
 static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_rowval, int ib, int base, int64_t e0, int64_t nloc,
                               const uint8_t *d_color8, int64_t C, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out);
 
+// alloc_scratch for a device-built plan: the cyclic test was made by the kernels; only the many-colour reduction needs the colours
+static int device_alloc_scratch(fd_plan *p, const uint8_t *d_color8)
+{
+    std::vector<int32_t> col0;
+    if (p->C > kRegColors && p->fdtype != FD_COMPLEX) {
+        std::vector<uint8_t> c8((size_t)p->N);
+        FD_HIP_CHECK(hipMemcpy(c8.data(), d_color8, (size_t)p->N, hipMemcpyDeviceToHost));
+        col0.resize((size_t)p->N);
+        for (int64_t j = 0; j < p->N; ++j) col0[(size_t)j] = c8[(size_t)j] == 0xFF ? -1 : (int32_t)c8[(size_t)j];
+    }
+    return alloc_scratch(p, col0);
+}
+
 // band != nullptr: the "pattern" is a band's column-major storage (fd_plan_create_banded; d_colptr / d_rowval unused,
 // entries [0, e1) = the slots of the local columns).
 struct PbBand { int64_t w, u; };
@@ -1067,7 +1080,9 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     hipLaunchKernelGGL(k_pb_colmax, dim3(gN), dim3(kBlock), 0, s, d_colorvec, color_bytes, N, d_st);
     if (hipMemcpyAsync(&h, d_st, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return PBR_DECLINED;
     const int64_t C = (int64_t)h.max_color;
-    if (C < 1 || C > kRegColors) return PBR_DECLINED;            // many colours: segmented reduction lists are built on the host
+    // (more than kRegColors colours: the step-size reduction walks per-colour column lists -- built by alloc_scratch's counting sort from
+    //  the colours copied back, N bytes; a BandedMatrix with that many colours stays with the host builder)
+    if (C < 1 || C > 253 || (C > kRegColors && band)) return PBR_DECLINED;
     tm.mark("colour maximum");
     const int shift = h.first_color >= 1 ? (int)(h.first_color - 1) : 0;
     uint8_t *d_color8 = nullptr;
@@ -1150,8 +1165,9 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         *rc_out = FD_ERR_SHAPE;
         return PBR_DONE;
     }
-    if (declined && !bad && !band && (fin.flags & PB_NEED_SORT)) {
-        // not a locally banded pattern: 2-D (strided) tiles, if it is a 2-D stencil in natural ordering
+    if (!bad && !band && ((declined && (fin.flags & PB_NEED_SORT)) || (!declined && !bestT))) {
+        // not a locally banded pattern (or one whose tiles hold too many colours / rows for a window): 2-D (strided) tiles, if it is a
+        // 2-D stencil in natural ordering
         (void)hipFree(d_wt); (void)hipFree(d_code);
         p->C = C;                                      // (w2_shape sizes the LDS tile with the number of colours)
         int r0 = 0, r1 = 0;
@@ -1168,7 +1184,8 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         p->row0 = r0;
         p->row1 = r1;
         const char *fc = getenv("FDJAC_EPS_CYCLIC");
-        const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
+        const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX &&
+                         C <= kRegColors;       // (computed colours are the register reduction's: alloc_scratch)
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
         // (an exact band whose colours outnumber what a window tile holds ends up here too: its store capability, as in the main path)
@@ -1176,7 +1193,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         if (!p->store_ok) device_store_stencil5(p, d_colptr, d_rowval, idx_bytes, idx_base, e0, C, d_color8, p->has_none);
         tm.mark("store tests");
         p->built_on_device = true;
-        *rc_out = alloc_scratch(p, std::vector<int32_t>());
+        *rc_out = device_alloc_scratch(p, d_color8);
         tm.mark("scratch allocation");
         return PBR_DONE;
     }
@@ -1257,7 +1274,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     {
         const char *fc = getenv("FDJAC_EPS_CYCLIC");
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) &&
-                         p->fdtype != FD_COMPLEX;   // (the complex step has no step-size reduction)
+                         p->fdtype != FD_COMPLEX && C <= kRegColors;   // (the complex step has no step-size reduction; many colours: its lists)
         p->cyc_C = cyc ? (int)C : 0;
         p->cyc_shift = cyc ? shift : 0;
     }
@@ -1324,7 +1341,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     tm.mark("band test");
     p->built_on_device = true;
     tm.mark("descriptors to host");
-    *rc_out = alloc_scratch(p, std::vector<int32_t>());     // (empty colour list: the cyclic test above stands)
+    *rc_out = device_alloc_scratch(p, d_color8);            // (the cyclic test above stands)
     tm.mark("scratch allocation");
     return PBR_DONE;
 }

@@ -333,7 +333,7 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
     if (fl && *fl && atoi(fl) == 0) return PBR_DECLINED;
     const char *fw1 = getenv("FDJAC_WINDOW");
     if (fw1 && *fw1) return PBR_DECLINED;                             // (forced kernel variants: the host builder)
-    if (C > kWinMaxCol || nloc < 1 || p->kind != K_CSC) return PBR_DECLINED;
+    if (nloc < 1 || p->kind != K_CSC) return PBR_DECLINED;
     const size_t padded = (size_t)((std::max<int64_t>(nloc, 1) + kListPad - 1) / kListPad * kListPad);
     const size_t ntiles = padded / kSortTile;
     // finish_list_plan's "scattered"

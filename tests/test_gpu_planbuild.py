@@ -119,16 +119,69 @@ def test_patterns_the_device_builder_declines_go_to_the_host_builder(monkeypatch
     J = fd.SparseMatrixCSC(nx * ny, nx * ny, colptr, rowval)
     plan = fd.make_plan(J, J, P.lap5_colors(nx, ny), "central")
     assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == 0 and plan.info(fd.lib.INFO_WINDOW) == 1
-    N = 200_000                                    # many colours: the segmented reduction lists are built on the host
-    colptr, rowval = P.banded_csc(N, N, 6, 6)
-    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
-    plan = fd.make_plan(J, J, P.cyclic_colors(N, 13), "forward")
+    N = 200_000                                    # a BandedMatrix with more colours than a window tile holds: host builder
+    plan = fd.make_plan(fd.BandedMatrix(None, N, 6, 6), None, P.cyclic_colors(N, 13), "forward")
     assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == 0
-    # the same through the device-pointer entry point: copied back once, built on the host, same plan
-    cp, rv = torch.as_tensor(colptr, device="cuda"), torch.as_tensor(rowval, device="cuda")
-    cv = torch.as_tensor(P.cyclic_colors(N, 13), device="cuda")
-    plan2 = fd.make_plan_csc_device(N, N, cp, rv, cv, "forward")
-    assert plan2.info(fd.lib.INFO_BUILT_ON_DEVICE) == 0 and plan2.checksum() == plan.checksum()
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["band13", "band13_none", "band13_window", "band5_c11", "lap7_c12"])
+def test_many_colours_built_on_the_device(monkeypatch, case, fdtype):
+    # More than 8 colours (round 4): the entry lists come from the device builder, the per-colour column lists of the step-size
+    # reduction from the colours copied back (N bytes).  Same plan as the host builder's, same Jacobian bits as the plain gather kernels.
+    win = None
+    if case.startswith("band13"):
+        N = 200_000
+        colptr, rowval = P.banded_csc(N, N, 6, 6)
+        colors = P.cyclic_colors(N, 13)
+        if case == "band13_none":
+            colors = colors.copy()
+            colors[[3, 777, N // 2, N - 2]] = 0
+        if case == "band13_window":
+            win = (N // 5 + 1, 4 * N // 5)
+    elif case == "band5_c11":
+        N = 260_003
+        colptr, rowval = P.banded_csc(N, N, 2, 2)
+        colors = ((np.arange(N) * 7) % 11 + 1).astype(np.int64)
+    else:
+        n1, n2, n3 = 83, 47, 41
+        colptr, rowval, _ = _lap7_csc(n1, n2, n3)
+        N = n1 * n2 * n3
+        k = np.arange(N)
+        colors = (((k % n1) + 2 * ((k // n1) % n2) + 3 * (k // (n1 * n2))) % 12 + 1).astype(np.int64)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    x = _dev(np.random.default_rng(9).random(N) + 0.1)
+
+    def fn(fx, xx):
+        fx.copy_(xx.roll(1) ** 2 + 3 * xx + xx.roll(-5) * xx)
+
+    plans, outs = {}, {}
+    for dev in ("0", "1", "ref"):
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "0" if dev == "ref" else dev)
+        if dev == "ref":
+            monkeypatch.setenv("FDJAC_WINDOW", "0")
+            monkeypatch.setenv("FDJAC_SORTED", "0")
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=win)
+        if dev != "ref":
+            assert plan.info(fd.lib.INFO_BUILT_ON_DEVICE) == int(dev), case
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(fn, N, N), x, [out])
+        plans[dev], outs[dev] = plan, out
+    assert plans["0"].checksum() == plans["1"].checksum(), case
+    for key in (fd.lib.INFO_WINDOW, fd.lib.INFO_SORTED_GATHER, fd.lib.INFO_EPS_CYCLIC, fd.lib.INFO_ROW_BEGIN, fd.lib.INFO_ROW_END, fd.lib.INFO_NNZ_LOCAL,
+                fd.lib.INFO_NCOLORS, fd.lib.INFO_LAZY_STORE):
+        assert plans["0"].info(key) == plans["1"].info(key), key
+    assert np.array_equal(plans["0"].epsilons(), plans["1"].epsilons())
+    assert not torch.isnan(outs["ref"]).any()
+    for dev in ("0", "1"):
+        assert torch.equal(outs[dev], outs["ref"]), (dev, case)
+    if case == "band13":    # the same through the device-pointer entry point: nothing crosses PCIe but the N colour bytes
+        monkeypatch.setenv("FDJAC_PLAN_DEVICE", "1")
+        monkeypatch.delenv("FDJAC_WINDOW")
+        monkeypatch.delenv("FDJAC_SORTED")
+        cp, rv = torch.as_tensor(colptr, device="cuda"), torch.as_tensor(rowval, device="cuda")
+        plan2 = fd.make_plan_csc_device(N, N, cp, rv, torch.as_tensor(colors, device="cuda"), fdtype)
+        assert plan2.info(fd.lib.INFO_BUILT_ON_DEVICE) == 1 and plan2.checksum() == plans["0"].checksum()
 
 
 def test_device_builder_reports_an_inconsistent_pattern(monkeypatch):
