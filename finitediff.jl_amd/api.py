@@ -667,7 +667,7 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_timing_samples(self.handle, k, buf, n.value, C.byref(n)))
         return [buf[i] for i in range(n.value)]
 
-    def set_lazy(self, f, imag_only=True, row_window=True, diff=True, store=None):
+    def set_lazy(self, f, imag_only=True, row_window=True, diff=True, store=None, csc_base=True):
         """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it.  imag_only /
         row_window / diff / store=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW /
         FD_LAZY_CAP_DIFF / FD_LAZY_CAP_STORE capability (store defaults to diff: a launcher that may not even subtract
@@ -685,7 +685,9 @@ class Plan:
         if not diff:
             caps &= ~4
         if not (diff if store is None else store):
-            caps &= ~(8 | 16)      # FD_LAZY_CAP_STORE and FD_LAZY_CAP_STORE_CSC
+            caps &= ~(8 | 16 | 32)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC and FD_LAZY_CAP_STORE_CSC_BASE
+        if not csc_base:
+            caps &= ~32                 # (the column store takes f(x) from ONE plain evaluation instead of forming it itself)
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):

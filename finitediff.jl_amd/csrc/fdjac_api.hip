@@ -766,7 +766,9 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         // colour point and stores the quotient.  Forward differences subtract f(x): the caller's f_in, or ONE plain evaluation
         // (src/jacobians.jl:540-545) -- M + nnz row evaluations instead of (1 + C) M.
         if (store_csc_active(p)) {
-            if (base_pending) {
+            // (a launcher with FD_LAZY_CAP_STORE_CSC_BASE evaluates the unperturbed rows itself: no plain evaluation, fx_base = NULL)
+            const bool own_base = base_pending && (p->lazy_caps & FD_LAZY_CAP_STORE_CSC_BASE) != 0;
+            if (base_pending && !own_base) {
                 Span sp(p, FD_STAGE_F);
                 const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
                 FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
@@ -777,7 +779,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             fd_csc_store sc;
             memset(&sc, 0, sizeof sc);
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
-            sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.color = p->d_color; sc.fx_base = p->fdtype == FD_FORWARD ? fx : nullptr;
+            sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
             sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0;
             fd_lazy_points lp = {};
             lp.x = x_dev;
@@ -794,10 +796,11 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (column store) returned %d", rc);
             if (rc == 0) {
-                p->fcalls_last += (int64_t)B * p->pts;
+                p->fcalls_last += (int64_t)B * p->pts + ((own_base && !diff_base_counted) ? 1 : 0);      // (f(x): once, inside the launch)
+                if (own_base) diff_base_counted = true;
                 continue;
             }
-            if (p->fdtype == FD_FORWARD) want_diff = false;      // (declined: f(x) exists already -- plain values are handed over below)
+            if (p->fdtype == FD_FORWARD && !own_base) want_diff = false;      // (declined: f(x) exists already -- plain values are handed over below)
         }
         { const int rc = ensure_values(p); if (rc) return rc; }      // (from here on the f! values are handed over through d_FX)
         bool diff_done = false;

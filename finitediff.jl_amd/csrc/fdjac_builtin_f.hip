@@ -1655,7 +1655,10 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
         const int rc = lp->color_bytes == 1 ? functor_family_lazy<uint8_t>(b, lp, (hipStream_t)stream) : functor_family_lazy<int32_t>(b, lp, (hipStream_t)stream);
         if (rc == 0) {
             b->launches.fetch_add(1);
-            b->points.fetch_add((int64_t)lp->ncolors * lp->pts);      // (f(x) of a forward difference: one plain launch, counted there)
+            // (f(x) of a forward difference: one plain launch, counted there -- or, FD_LAZY_CAP_STORE_CSC_BASE without f_in, formed
+            //  inside this launch: counted with the first colour chunk)
+            const bool own_base = lp->pts == 1 && lp->store && !((const fd_csc_store *)lp->store)->fx_base && lp->c_lo == 0;
+            b->points.fetch_add((int64_t)lp->ncolors * lp->pts + (own_base ? 1 : 0));
         }
         return rc;
     }
@@ -1855,7 +1858,8 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
     if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store only
-        *caps_out = FD_LAZY_CAP_STORE_CSC;
+        // (a 7-point row costs less than the gather of its f(x): that family evaluates the unperturbed rows inside the storing launch)
+        *caps_out = FD_LAZY_CAP_STORE_CSC | (b->family == FD_F_LAP7 ? FD_LAZY_CAP_STORE_CSC_BASE : 0);
         return FD_OK;
     }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |

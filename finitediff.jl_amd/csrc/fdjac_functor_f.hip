@@ -44,90 +44,104 @@ struct Lap7F {
 // grid, as the residual defines it), and evaluates every stored entry whose row is one of those seven from the window, at
 // x + eps e_k (valid colouring: fd_csc_store.valid_coloring) -- 25 loads per column instead of 7 per evaluated row.  Entries of any
 // other row (a pattern that is a superset of the stencil) go through the functor.  Same operands, same operations: same bits.
+#ifdef LAP7_WAVES
+#define FD_LAP7_OCC __attribute__((amdgpu_waves_per_eu(LAP7_WAVES, LAP7_WAVES)))
+#else
+#define FD_LAP7_OCC
+#endif
 template <typename CT, int MODE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) FD_LAP7_OCC
 k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
-    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_CSC_WAVE_CAP];
+    // (a stencil column holds at most 7 entries: 448 per wavefront -- half of the general window, twice the resident workgroups)
+    constexpr int kCap = 512;
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][kCap];
     const int64_t nblk = (st.col_end - st.col_begin + kBlock - 1) / kBlock, blk = fd_xcd_block(blockIdx.x, nblk);
     if (blk >= nblk) return;
     const int64_t kk = st.col_begin + blk * kBlock + threadIdx.x;
     const bool in = kk < st.col_end;
     const int64_t k = in ? kk : st.col_end - 1;      // (lanes beyond the range idle on the last column: they take part in the wave's stores only)
+    // (everything that depends on the thread index alone first: the window's loads are in flight while colptr, the colour and the row
+    //  indices arrive -- a lane whose column turns out to belong to another colour chunk has loaded in vain, nothing else)
+    __shared__ real_t s_eps[32];
+    if ((int)threadIdx.x < c_hi - c_lo && threadIdx.x < 32) s_eps[threadIdx.x] = eps[c_lo + threadIdx.x];
+    const int nx = f.nx, ny = f.ny, nz = f.nz, pl = nx * ny;
+    const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
+    // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
+    // (a grid point at least two cells away from every face: no bounds tests -- the guards are ~200 vector instructions per column)
+    const bool deep = i >= 2 && i < nx - 2 && j >= 2 && j < ny - 2 && l >= 2 && l < nz - 2;
+    // Every load below is issued unconditionally and the whole window is waited for ONCE.  (Loads inside per-lane conditionals
+    // are waited for one by one at the joins: 25 + 7 serial memory round trips made a forward-difference wavefront live 14 us,
+    // profiles/r04_y_lap7_taken_apart.md.)  A wavefront of deep grid points -- two cells from every face, the common case -- adds
+    // wave-uniform offsets to the pointer (scalar unit) and indexes with ONE 32-bit lane offset; other wavefronts load from a
+    // clamped address and select 0 for the coordinates outside the grid.
+    const bool wave_deep = __all(deep) && st.N < ((long long)1 << 28);
+    const uint32_t kb = (uint32_t)k * (uint32_t)sizeof(real_t);
+    const real_t *base = (const real_t *)st.fx_base;
+    real_t c0, xm1, xp1, xm2, xp2, ym1, yp1, ym2, yp2, zm1, zp1, zm2, zp2, xmym, xpym, xmyp, xpyp, xmzm, xpzm, xmzp, xpzp, ymzm, ypzm, ymzp, ypzp;
+    // forward differences: f(x) of the seven rows, fetched with the window
+    real_t bz0 = 0, by0 = 0, bx0 = 0, bc = 0, bx1 = 0, by1 = 0, bz1 = 0;
+#ifdef LAP7_NOX
+#define FD_LDX(p, off) ((real_t)(k + (off)) * (real_t)1e-7)
+#else
+#define FD_LDX(p, off) (*(const real_t *)((const char *)((p) + (off)) + kb))
+#endif
+    if (wave_deep) {
+        c0 = FD_LDX(x, 0);
+        xm1 = FD_LDX(x, -1); xp1 = FD_LDX(x, 1); xm2 = FD_LDX(x, -2); xp2 = FD_LDX(x, 2);
+        ym1 = FD_LDX(x, -nx); yp1 = FD_LDX(x, nx); ym2 = FD_LDX(x, -2 * nx); yp2 = FD_LDX(x, 2 * nx);
+        zm1 = FD_LDX(x, -pl); zp1 = FD_LDX(x, pl); zm2 = FD_LDX(x, -2 * pl); zp2 = FD_LDX(x, 2 * pl);
+        xmym = FD_LDX(x, -nx - 1); xpym = FD_LDX(x, -nx + 1); xmyp = FD_LDX(x, nx - 1); xpyp = FD_LDX(x, nx + 1);
+        xmzm = FD_LDX(x, -pl - 1); xpzm = FD_LDX(x, -pl + 1); xmzp = FD_LDX(x, pl - 1); xpzp = FD_LDX(x, pl + 1);
+        ymzm = FD_LDX(x, -pl - nx); ypzm = FD_LDX(x, -pl + nx); ymzp = FD_LDX(x, pl - nx); ypzp = FD_LDX(x, pl + nx);
+        if (MODE == 0 && base) {
+            bc = FD_LDX(base, 0);
+            bz0 = FD_LDX(base, -pl); by0 = FD_LDX(base, -nx); bx0 = FD_LDX(base, -1);
+            bx1 = FD_LDX(base, 1); by1 = FD_LDX(base, nx); bz1 = FD_LDX(base, pl);
+        }
+    } else {
+        // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
+        auto ld = [&](const real_t *p, int dl, int dj, int di) -> real_t {
+            const bool ok = deep || ((unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz);
+            const int off = ok ? dl * pl + dj * nx + di : 0;
+#ifdef LAP7_NOX
+            const real_t v = (real_t)(k + off) * (real_t)1e-7;
+#else
+            const real_t v = p[k + off];
+#endif
+            return ok ? v : (real_t)0;
+        };
+        c0 = ld(x, 0, 0, 0);
+        xm1 = ld(x, 0, 0, -1); xp1 = ld(x, 0, 0, 1); xm2 = ld(x, 0, 0, -2); xp2 = ld(x, 0, 0, 2);
+        ym1 = ld(x, 0, -1, 0); yp1 = ld(x, 0, 1, 0); ym2 = ld(x, 0, -2, 0); yp2 = ld(x, 0, 2, 0);
+        zm1 = ld(x, -1, 0, 0); zp1 = ld(x, 1, 0, 0); zm2 = ld(x, -2, 0, 0); zp2 = ld(x, 2, 0, 0);
+        xmym = ld(x, 0, -1, -1); xpym = ld(x, 0, -1, 1); xmyp = ld(x, 0, 1, -1); xpyp = ld(x, 0, 1, 1);
+        xmzm = ld(x, -1, 0, -1); xpzm = ld(x, -1, 0, 1); xmzp = ld(x, 1, 0, -1); xpzp = ld(x, 1, 0, 1);
+        ymzm = ld(x, -1, -1, 0); ypzm = ld(x, -1, 1, 0); ymzp = ld(x, 1, -1, 0); ypzp = ld(x, 1, 1, 0);
+        if (MODE == 0 && base) {       // (a row outside the grid does not exist: its value is never used)
+            bc = ld(base, 0, 0, 0);
+            bz0 = ld(base, -1, 0, 0); by0 = ld(base, 0, -1, 0); bx0 = ld(base, 0, 0, -1);
+            bx1 = ld(base, 0, 0, 1); by1 = ld(base, 0, 1, 0); bz1 = ld(base, 1, 0, 0);
+        }
+    }
+#undef FD_LDX
     const int a = in ? st.colptr[k - st.col_begin] : st.colptr[st.col_end - st.col_begin];
     const int b = in ? st.colptr[k - st.col_begin + 1] : a;
     const int c = (int)((const CT *)st.color)[k];
     const bool none = in && c == (int)(CT)(-1);
     const bool mine = in && !none && c >= c_lo && c < c_hi;
     fd_csc_wave_run<real_t> run;
-    run.begin((real_t *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0));
+    run.begin((real_t *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0), kCap);
+    __syncthreads();                // (s_eps)
     if (none && c_lo == 0)
         for (int q = a; q < b; ++q) run.put(q, (real_t)0);
     if (mine) {                     // (all lanes meet again at the flush below: the staged values leave in one wave-wide pass)
-    const real_t h = eps[c];
-    const int nx = f.nx, ny = f.ny, nz = f.nz, pl = nx * ny;
-    const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
-    // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
-    // (a grid point at least two cells away from every face: no bounds tests -- the guards are ~200 vector instructions per column)
-    const bool deep = i >= 2 && i < nx - 2 && j >= 2 && j < ny - 2 && l >= 2 && l < nz - 2;
-    auto ld = [&](int dl, int dj, int di) -> real_t {
-        const bool ok = deep || ((unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz);
-        return ok ? x[k + (int64_t)dl * pl + dj * nx + di] : (real_t)0;
-    };
-    const real_t c0 = ld(0, 0, 0);
-    const real_t xm1 = ld(0, 0, -1), xp1 = ld(0, 0, 1), xm2 = ld(0, 0, -2), xp2 = ld(0, 0, 2);
-    const real_t ym1 = ld(0, -1, 0), yp1 = ld(0, 1, 0), ym2 = ld(0, -2, 0), yp2 = ld(0, 2, 0);
-    const real_t zm1 = ld(-1, 0, 0), zp1 = ld(1, 0, 0), zm2 = ld(-2, 0, 0), zp2 = ld(2, 0, 0);
-    const real_t xmym = ld(0, -1, -1), xpym = ld(0, -1, 1), xmyp = ld(0, 1, -1), xpyp = ld(0, 1, 1);
-    const real_t xmzm = ld(-1, 0, -1), xpzm = ld(-1, 0, 1), xmzp = ld(1, 0, -1), xpzp = ld(1, 0, 1);
-    const real_t ymzm = ld(-1, -1, 0), ypzm = ld(-1, 1, 0), ymzp = ld(1, -1, 0), ypzp = ld(1, 1, 0);
-    const real_t *base = (const real_t *)st.fx_base;
+    const real_t h = c - c_lo < 32 ? s_eps[c - c_lo] : eps[c];
     const real_t z0 = 0;
     const real_t cp = c0 + h, cm = c0 - h;
-    // forward differences: f(x) of the seven rows, fetched up front with the window (a load per entry inside the loop would put
-    // seven dependent memory round trips on every wavefront's critical path: 470 -> measured below, profiles/r04_*)
-    real_t bz0 = 0, by0 = 0, bx0 = 0, bc = 0, bx1 = 0, by1 = 0, bz1 = 0;
-    if (MODE == 0) {
-        bc = base[k];
-        if (l > 0) bz0 = base[k - pl];
-        if (j > 0) by0 = base[k - nx];
-        if (i > 0) bx0 = base[k - 1];
-        if (i < nx - 1) bx1 = base[k + 1];
-        if (j < ny - 1) by1 = base[k + nx];
-        if (l < nz - 1) bz1 = base[k + pl];
-    }
-    // an entry whose row is not handled from the window (rows that are no stencil neighbours, degenerate grids): the functor
-    auto generic = [&](int q) {
-        const int r = st.rowval[q];
-        fd_column_point<real_t> X = {x, k, h, 0};
-        const real_t vp = f(r, X);
-        real_t vm, div = h;
-        if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
-        else vm = base[r];
-        run.put(q, sub_exact(vp, vm) / div);
-    };
-    const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
-    int q = a;
-    // the seven stencil rows in ascending order (= the order of a column's entries); `plus` / `minus`: the row at x + h e_k / x - h e_k.
+    // The seven stencil rows in ascending order (= the order of a column's entries); `plus` / `minus`: the row at x + h e_k / x - h e_k.
     // The plus point holds x + 0.0 at its unperturbed coordinates, the minus point x - 0.0 == x: literally (the -0.0 case); a
     // coordinate outside the grid is the constant 0 of the residual (0 + 0.0 == 0).
-#define FD_ENTRY(off, guard, plus, minus, bv)                                                          \
-    do {                                                                                               \
-        const int want = (int)k + (off);                                                               \
-        while (q < b && st.rowval[q] < want) { generic(q); ++q; }                                      \
-        if (q < b && st.rowval[q] == want) {                                                           \
-            if (regular && (guard)) {                                                                  \
-                const real_t vp = (plus);                                                              \
-                real_t vm, div = h;                                                                    \
-                if (MODE == 1) { vm = (minus); div = 2 * h; }                                          \
-                else vm = (bv);                                                                        \
-                run.put(q, sub_exact(vp, vm) / div);                                                   \
-            } else {                                                                                   \
-                generic(q);                                                                            \
-            }                                                                                          \
-            ++q;                                                                                       \
-        }                                                                                              \
-    } while (0)
 #define Z +z0
 #define FD_R0P lap7_row<real_t>(zm1 Z, zm2 Z, ymzm Z, xmzm Z, xpzm Z, ypzm Z, cp)
 #define FD_R0M lap7_row<real_t>(zm1, zm2, ymzm, xmzm, xpzm, ypzm, cm)
@@ -143,42 +157,63 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
 #define FD_R5M lap7_row<real_t>(yp1, ypzm, cm, xmyp, xpyp, yp2, ypzp)
 #define FD_R6P lap7_row<real_t>(zp1 Z, cp, ymzp Z, xmzp Z, xpzp Z, ypzp Z, zp2 Z)
 #define FD_R6M lap7_row<real_t>(zp1, cm, ymzp, xmzp, xpzp, ypzp, zp2)
-    // an interior grid point whose column holds exactly the seven stencil rows (the common case): the row indices are fetched up
-    // front and compared once, then seven straight-line evaluations -- no dependent load between them
-    bool all7 = false;
-    if (regular && b - a == 7 && l > 0 && j > 0 && i > 0 && i < nx - 1 && j < ny - 1 && l < nz - 1) {
-        const int r0 = st.rowval[a], r1 = st.rowval[a + 1], r2 = st.rowval[a + 2], r3 = st.rowval[a + 3], r4 = st.rowval[a + 4], r5 = st.rowval[a + 5],
-                  r6 = st.rowval[a + 6];
-        const int kk32 = (int)k;
-        all7 = r0 == kk32 - pl && r1 == kk32 - nx && r2 == kk32 - 1 && r3 == kk32 && r4 == kk32 + 1 && r5 == kk32 + nx && r6 == kk32 + pl;
+    // ONE straight-line path for interior and boundary columns alike (a wavefront of 64 consecutive grid points meets a face of the
+    // grid two times out of three: a separate boundary path would be the common case).  Stencil row t exists or not (ex[t]); the
+    // existing ones are the column's entries in this order if the pattern is the stencil's: entry at[t] = number of existing rows
+    // before t.  Every lane fetches the row index at its own position for each t (no dependent loads, no divergence), compares, and
+    // stages the quotients of the rows that exist.  A column whose entries are anything else goes through the functor, entry by entry.
+    const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
+    const bool ex[7] = {l > 0, j > 0, i > 0, true, i < nx - 1, j < ny - 1, l < nz - 1};
+    const int off7[7] = {-pl, -nx, -1, 0, 1, nx, pl};
+    const int cnt = b - a, lastq = cnt > 0 ? cnt - 1 : 0;
+    int at[7], npos = 0;
+    bool okp = regular;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { at[t] = npos < lastq ? npos : lastq; npos += ex[t] ? 1 : 0; }
+    int rv7[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) rv7[t] = st.rowval[a + at[t]];          // (unconditional: at[t] is inside the column -- an empty one reads the pad)
+    // all quotients by ONE divisor: its reciprocal once, then the correctly rounded quotients of div_shared (the bits of IEEE a / b).
+    // Evaluated before the row indices are back (the comparison only decides where the values go).
+    const real_t div = MODE == 1 ? 2 * h : h;
+    const real_t yd = sizeof(real_t) == 8 ? (real_t)1 / div : (real_t)0;
+    // (forward differences without fx_base: f(x) of the row from the window -- the plain launcher's operands and operations)
+    const bool own = MODE == 0 && !base;
+    if (own) {
+        const real_t cb = c0;
+#define cm cb
+        bz0 = FD_R0M; by0 = FD_R1M; bx0 = FD_R2M; bc = FD_R3M; bx1 = FD_R4M; by1 = FD_R5M; bz1 = FD_R6M;
+#undef cm
     }
-    if (all7) {
-        // seven quotients by ONE divisor: its reciprocal once, then the correctly rounded quotients of div_shared (the bits of IEEE a / b)
-        const real_t div = MODE == 1 ? 2 * h : h;
-        const real_t yd = sizeof(real_t) == 8 ? (real_t)1 / div : (real_t)0;
-#define FD_FAST(t, plus, minus, bv) run.put(a + (t), div_shared<true>(sub_exact((plus), MODE == 1 ? (minus) : (bv)), div, yd))
-        FD_FAST(0, FD_R0P, FD_R0M, bz0);
-        FD_FAST(1, FD_R1P, FD_R1M, by0);
-        FD_FAST(2, FD_R2P, FD_R2M, bx0);
-        FD_FAST(3, FD_R3P, FD_R3M, bc);
-        FD_FAST(4, FD_R4P, FD_R4M, bx1);
-        FD_FAST(5, FD_R5P, FD_R5M, by1);
-        FD_FAST(6, FD_R6P, FD_R6M, bz1);
+#define FD_FAST(plus, minus, bv) div_shared<true>(sub_exact((plus), MODE == 1 ? (minus) : (bv)), div, yd)
+    const real_t v7[7] = {FD_FAST(FD_R0P, FD_R0M, bz0), FD_FAST(FD_R1P, FD_R1M, by0), FD_FAST(FD_R2P, FD_R2M, bx0), FD_FAST(FD_R3P, FD_R3M, bc),
+                          FD_FAST(FD_R4P, FD_R4M, bx1), FD_FAST(FD_R5P, FD_R5M, by1), FD_FAST(FD_R6P, FD_R6M, bz1)};
 #undef FD_FAST
-        q = b;
+    okp = okp && npos == cnt;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) okp = okp && (!ex[t] || rv7[t] == (int)k + off7[t]);
+    if (okp) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (ex[t]) run.put(a + at[t], v7[t]);
     } else {
-    FD_ENTRY(-pl, l > 0, FD_R0P, FD_R0M, bz0);
-    FD_ENTRY(-nx, j > 0, FD_R1P, FD_R1M, by0);
-    FD_ENTRY(-1, i > 0, FD_R2P, FD_R2M, bx0);
-    FD_ENTRY(0, true, FD_R3P, FD_R3M, bc);
-    FD_ENTRY(1, i < nx - 1, FD_R4P, FD_R4M, bx1);
-    FD_ENTRY(nx, j < ny - 1, FD_R5P, FD_R5M, by1);
-    FD_ENTRY(pl, l < nz - 1, FD_R6P, FD_R6M, bz1);
+        // rows that are no stencil neighbours, degenerate grids: every entry through the functor
+        for (int q = a; q < b; ++q) {
+            const int r = st.rowval[q];
+            fd_column_point<real_t> X = {x, k, h, 0};
+            const real_t vp = f(r, X);
+            real_t vm, div = h;
+            if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
+            else if (base) vm = base[r];
+            else { X.minus = 2; vm = f(r, X); }
+            run.put(q, sub_exact(vp, vm) / div);
+        }
     }
 #undef Z
-#undef FD_ENTRY
-    while (q < b) { generic(q); ++q; }
     }
+#ifdef LAP7_NOSTORE
+    if (st.M < 0)
+#endif
     run.template flush<true>();
 }
 
@@ -232,7 +267,7 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
     if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
     const fd_csc_store st = *(const fd_csc_store *)lp->store;
     if (st.elem_bytes != (int)sizeof(real_t) || st.color_bytes != (int)sizeof(CT) || st.M != b->M || st.N != b->N || st.col_end <= st.col_begin ||
-        (lp->pts == 1 && !st.fx_base))
+        (lp->pts == 1 && !st.fx_base && b->family != FD_F_LAP7))
         return FD_LAZY_DECLINED;
     const unsigned g = fd_xcd_grid((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;

@@ -323,6 +323,8 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
 #define FD_LAZY_CAP_STORE 8       /* honours fd_lazy_points.store: f!'s launch stores the Jacobian of a verified exact band itself           */
 #define FD_LAZY_CAP_STORE_CSC 16  /* honours fd_lazy_points.store with store_kind = FD_STORE_CSC (fd_csc_store): the launch stores the Jacobian  */
                                   /* of ANY pattern column by column through the plan's compact copy of the pattern (FD_PLAN_STORE_CSC)       */
+#define FD_LAZY_CAP_STORE_CSC_BASE 32  /* ... and evaluates f(x) of the rows it needs itself: forward differences without a caller's f_in run NO */
+                                  /* plain evaluation before the storing launch (fd_csc_store.fx_base is NULL then; with f_in it is f_in)        */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */

@@ -163,7 +163,9 @@ typedef struct fd_colrange_store {
  * (fd_plan_opts.flags & FD_PLAN_STORE_CSC: 4 bytes per stored entry + 4 per column) and hands this descriptor
  * (store_kind = FD_STORE_CSC) to launchers registered with FD_LAZY_CAP_STORE_CSC.  Forward differences: f(x) is evaluated ONCE by
  * the plain launcher (or is the caller's f_in) and arrives as `fx_base`; the launch evaluates one row per stored entry
- * (central: two) -- M + nnz row evaluations instead of the (1 + C) M of the colour-by-colour loop.
+ * (central: two) -- M + nnz row evaluations instead of the (1 + C) M of the colour-by-colour loop.  A launcher that also declares
+ * FD_LAZY_CAP_STORE_CSC_BASE evaluates the unperturbed row itself when `fx_base` is NULL (no plain evaluation, no f(x) array: worth
+ * it when a row is cheap next to a gather -- the 7-point family; fd_csc_store_cols does it for any functor).
  * (Measured alternative, round 4: a ROW-centric kernel with a per-(row, colour) destination table needs a valid colouring and
  * scatters 8-byte stores over nzval -- every one a 32-byte read-modify-write at the memory side: 1.8 GB written for 446 MB of
  * values on the 200^3 7-point pattern, profiles/r04_g_rowcentric_store_pmc_*.md.) */
@@ -486,10 +488,11 @@ template <typename T, typename CT> struct fd_colour_point {
     const CT *color;
     int c;          /* 0-based colour of the point */
     T e;            /* step */
-    int minus;      /* 0: the plus point x + e m (x + 0.0 elsewhere); 1: the minus point x - e m (x - 0.0 == x elsewhere) */
+    int minus;      /* 0: the plus point x + e m (x + 0.0 elsewhere); 1: the minus point x - e m (x - 0.0 == x elsewhere); 2: x itself */
     __device__ T operator()(long long j) const
     {
         const T v = x[j];
+        if (minus == 2) return v;
         const bool hit = (int)color[j] == c;
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
@@ -503,6 +506,7 @@ template <typename T> struct fd_column_point {
     __device__ T operator()(long long i) const
     {
         const T v = x[i];
+        if (minus == 2) return v;                        /* (x itself) */
         const bool hit = i == j;
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
@@ -527,7 +531,8 @@ template <typename T> struct fd_csc_wave_run {
     int lo, hi;     /* slots that hold values */
     bool staged;
     /* a, b: the lane's entry range (a == b for a lane without a column); writes: the lane will write ALL of [a, b) */
-    __device__ void begin(T *out_, T *win_, int a, int b, bool writes)
+    /* cap: elements of `win` (FD_CSC_WAVE_CAP, or less for a kernel that knows its columns are short) */
+    __device__ void begin(T *out_, T *win_, int a, int b, bool writes, int cap = FD_CSC_WAVE_CAP)
     {
         out = out_; win = win_;
         int qmin = a, qmax = b;
@@ -540,7 +545,7 @@ template <typename T> struct fd_csc_wave_run {
         q0a = qmin & ~1;
         lo = qmin - q0a;
         hi = qmax - q0a;
-        staged = __all(writes) && hi <= FD_CSC_WAVE_CAP && ((((unsigned long long)out_) & (2 * sizeof(T) - 1)) == 0);
+        staged = __all(writes) && hi <= cap && ((((unsigned long long)out_) & (2 * sizeof(T) - 1)) == 0);
     }
     __device__ void put(int q, T v) const
     {
@@ -568,7 +573,8 @@ __device__ inline void fd_csc_store_column(const F &f, P &X, const fd_csc_store 
         const T vp = f(r, X);
         T vm, div = h;
         if (MODE == 1) { X.minus = 1; vm = f(r, X); div = 2 * h; }
-        else vm = base[r];
+        else if (base) vm = base[r];
+        else { X.minus = 2; vm = f(r, X); }                                /* (the unperturbed point: FD_LAZY_CAP_STORE_CSC_BASE) */
         run.put(q, (vp - vm) / div);
     }
 }

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=8_000_000)
     ap.add_argument("--only", choices=["stencil", "band"], default=None)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--store-only", action="store_true", help="skip the hand-over path (kernel experiments)")
     a = ap.parse_args()
     import torch
     import finitediff_jl_amd as fd
@@ -32,7 +33,8 @@ def main():
         x = torch.rand(N, dtype=torch.float64, device=dev) + 0.1
         res = {}
         outs = {}
-        for path in ("store", "handover"):
+        paths = ("store",) if a.store_only else ("store", "handover")
+        for path in paths:
             t0 = time.perf_counter()
             plan = fd.make_plan(J, J, colors, fdtype, store_csc=(path == "store"))
             torch.cuda.synchronize()
@@ -59,10 +61,10 @@ def main():
             res[path] = (float(np.median(tot)) * 1e3, st, nl, build_ms, int(plan.info(fd.lib.INFO_LAZY_STORE)), int(plan.info(fd.lib.INFO_STORE_CSC)))
             outs[path] = out
             del plan, call
-        same = bool(torch.equal(outs["store"].view(torch.int64), outs["handover"].view(torch.int64)))
+        same = a.store_only or bool(torch.equal(outs["store"].view(torch.int64), outs["handover"].view(torch.int64)))
         C = int(colors.max())
         nnz = rowval.size
-        for path in ("store", "handover"):
+        for path in paths:
             us, st, nl, build_ms, active, table = res[path]
             if path == "store":      # x, colours, the table (4 B rowptr per row + 5 B per entry), every value out
                 model = N * 8 + N + (M + 1) * 4 + nnz * 5 + nnz * 8

@@ -97,8 +97,27 @@ def test_lap7_column_store_bit_identical_and_oracle(oracle, fdtype, shape):
     x = np.random.default_rng(nx + 10 * ny + 100 * nz).random(N)
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     f = fd.BuiltinF("lap7", nx, ny, nz)
-    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_CSC
+    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_CSC | fd.lib.LAZY_CAP_STORE_CSC_BASE
     a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
+    if fdtype == "forward":
+        # FD_LAZY_CAP_STORE_CSC_BASE: no plain f(x) launch, the storing launch forms the unperturbed rows itself -- one launcher
+        # invocation in all, the same 1 + C evaluations counted; withheld: one plain evaluation first; a caller's f_in: used as it is
+        l0 = f.counts()[0]
+        out1 = _dev(np.full(rowval.size, np.nan))
+        ps.jacobian(f, _dev(x), [out1])
+        assert f.counts()[0] - l0 == 1
+        ps.set_lazy(f, csc_base=False)
+        l0 = f.counts()[0]
+        out2 = _dev(np.full(rowval.size, np.nan))
+        ps.jacobian(f, _dev(x), [out2])
+        assert f.counts()[0] - l0 == 2
+        assert torch.equal(out1.view(torch.int64), a.view(torch.int64)) and torch.equal(out2.view(torch.int64), a.view(torch.int64))
+        ps.set_lazy(f)
+        fin = _dev(np.random.default_rng(5).random(N))          # (an arbitrary f_in: the subtrahend the reference would use)
+        o3, o4 = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
+        ps.jacobian(f, _dev(x), [o3], f_in=fin)
+        ph.jacobian(f, _dev(x), [o4], f_in=fin)
+        assert torch.equal(o3.view(torch.int64), o4.view(torch.int64)) and not torch.equal(o3.view(torch.int64), a.view(torch.int64))
     C = int(colors.max())
     assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1
     assert ph.info(fd.lib.INFO_STORE_CSC) == 0 and ph.info(fd.lib.INFO_LAZY_STORE) == 0
