@@ -646,6 +646,93 @@ static int client_complex_x(int fdtype)
     return report(fdtype == FD_FORWARD ? "complex_x/fwd" : "complex_x/cen", worst, fdtype == FD_FORWARD ? 4e-6 : 4e-8, calls, fdtype == FD_FORWARD ? 4 : 6);
 }
 
+/* shim: make_plan(ctx, J::Tridiagonal{Complex{T}} | BandedMatrix{Complex{T}}, ...; PlanOpts(complex_x = true)): complex-valued x on
+   structured storage (round 4).  The outputs are Complex arrays as they lie in memory: dl / d / du of a Tridiagonal (three arrays),
+   the (l + u + 1) x n data of a BandedMatrix (one).  kind 0: Tridiagonal, 1: BandedMatrix(1, 1). */
+static int client_complex_structured(int kind, int fdtype)
+{
+    const int64_t N = 50003;
+    int64_t *colors = cyclic_colors(N, 3);
+    double *x = malloc(sizeof(double) * 2 * (size_t)N);
+    for (int64_t j = 0; j < N; ++j) { x[2 * j] = 0.5 + 0.25 * sin((double)(j + 1)); x[2 * j + 1] = 0.3 * cos(0.7 * (double)(j + 1)); }
+    double *xd = to_dev(x, sizeof(double) * 2 * (size_t)N);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = FD_PLAN_COMPLEX_X;
+    if (kind == 0) CHECK(fd_plan_create_tridiagonal(g_ctx, N, colors, 8, &o, &plan));
+    else CHECK(fd_plan_create_banded(g_ctx, N, N, 1, 1, colors, 8, &o, &plan));
+    int64_t nouts = 0, len[3] = {0, 0, 0};
+    CHECK(fd_plan_info(plan, FD_INFO_NOUTS, &nouts));
+    void *outs[3] = {NULL, NULL, NULL};
+    for (int k = 0; k < nouts; ++k) { CHECK(fd_plan_info(plan, FD_INFO_OUT0_LEN + k, &len[k])); outs[k] = dev_nan((size_t)len[k]); }
+    const int64_t want0 = kind == 0 ? 2 * (N - 1) : 2 * 3 * N;
+    if (nouts != (kind == 0 ? 3 : 1) || len[0] != want0) { printf("complex_structured: %lld outputs, first %lld  FAILED\n", (long long)nouts, (long long)len[0]); return 3; }
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *h[3] = {NULL, NULL, NULL};
+    for (int k = 0; k < nouts; ++k) { h[k] = malloc(sizeof(double) * (size_t)len[k]); from_dev(h[k], outs[k], sizeof(double) * (size_t)len[k]); }
+    /* analytic entries of f_i = x[i-1] - 2x[i] + x[i+1] + x[i]^2 x[i+1]: (r, j) for j = r - 1, r, r + 1 */
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t r = j > 0 ? j - 1 : 0; r <= (j + 1 < N ? j + 1 : N - 1); ++r) {
+            const double xr = x[2 * r], xi = x[2 * r + 1];
+            const double pr = r + 1 < N ? x[2 * (r + 1)] : 0.0, pi = r + 1 < N ? x[2 * (r + 1) + 1] : 0.0;
+            double wr, wi;
+            if (r == j) { wr = -2.0 + 2.0 * (xr * pr - xi * pi); wi = 2.0 * (xr * pi + xi * pr); }
+            else if (j == r + 1) { wr = 1.0 + (xr * xr - xi * xi); wi = 2.0 * xr * xi; }
+            else { wr = 1.0; wi = 0.0; }
+            const double *v;
+            if (kind == 0) v = r == j + 1 ? h[0] + 2 * j : (r == j ? h[1] + 2 * j : h[2] + 2 * (j - 1));     /* dl[j], d[j], du[j-1] */
+            else v = h[0] + 2 * ((1 + r - j) + 3 * j);                                                          /* data[u + r - j, j]   */
+            const double d = fmax(fabs(v[0] - wr), fabs(v[1] - wi));
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    for (int k = 0; k < nouts; ++k) { hipFree(outs[k]); free(h[k]); }
+    hipFree(xd); free(x); free(colors);
+    char name[64];
+    snprintf(name, sizeof name, "complex_%s/%s", kind == 0 ? "tridiagonal" : "banded", fdtype == FD_FORWARD ? "fwd" : "cen");
+    return report(name, worst, fdtype == FD_FORWARD ? 4e-6 : 4e-8, calls, fdtype == FD_FORWARD ? 4 : 6);
+}
+
+/* shim: FiniteDiff.finite_difference_jacobian(f, x, cache; jac_prototype) (src/jacobians.jl:277-429, the out-of-place method): J is
+   allocated like the prototype NEXT TO x -- on the device -- and filled by the in-place call; the caller gets the new J back. */
+static int client_out_of_place(void)
+{
+    const int64_t N = 40001;
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_FORWARD;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    double *nzd = NULL;                                         /* similar_J(jac_prototype, x): a fresh nzval of the prototype's length */
+    if (hipMalloc((void **)&nzd, sizeof(double) * (size_t)nnz) != 0) return 4;
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const int64_t r = rowval[p] - 1;
+            const double xn = r + 1 < N ? x[r + 1] : 0.0;
+            const double w = r == j ? -2.0 + 2.0 * x[r] * xn : (j == r + 1 ? 1.0 + x[r] * x[r] : 1.0);
+            const double d = fabs(nz[p] - w);
+            if (!(d <= worst)) worst = d;
+        }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(colptr); free(rowval); free(colors);
+    return report("out_of_place", worst, 4e-6, calls, 4);
+}
+
 /* shim: Base.resize!(cache, i) (src/jacobians.jl:655-661) followed by the next finite_difference_jacobian!: the shim's plans are
    keyed on the identity (address, LENGTH) of the arrays plus J's shape and fdtype, so the resized cache (colorvec = 1:i, new lengths) simply
    compiles a new plan and the old one is released -- plan, call, destroy, plan for the new size, call.  Dense arm, as resize!
@@ -846,6 +933,9 @@ int main(int argc, char **argv)
     RUN("solve", client_solve())
     RUN("host", client_host())
     RUN("complex_x", client_complex_x(FD_FORWARD) | client_complex_x(FD_CENTRAL))
+    RUN("complex_structured", client_complex_structured(0, FD_FORWARD) | client_complex_structured(0, FD_CENTRAL) |
+                              client_complex_structured(1, FD_FORWARD) | client_complex_structured(1, FD_CENTRAL))
+    RUN("out_of_place", client_out_of_place())
     RUN("resize", client_resize())
     RUN("dropin", client_dropin(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     CHECK(fd_ctx_destroy(g_ctx));

@@ -44,13 +44,9 @@ struct Lap7F {
 // grid, as the residual defines it), and evaluates every stored entry whose row is one of those seven from the window, at
 // x + eps e_k (valid colouring: fd_csc_store.valid_coloring) -- 25 loads per column instead of 7 per evaluated row.  Entries of any
 // other row (a pattern that is a superset of the stencil) go through the functor.  Same operands, same operations: same bits.
-#ifdef LAP7_WAVES
-#define FD_LAP7_OCC __attribute__((amdgpu_waves_per_eu(LAP7_WAVES, LAP7_WAVES)))
-#else
-#define FD_LAP7_OCC
-#endif
+// (no register budget: 96 / 80 VGPRs for 5 / 6 wavefronts per SIMD spill -- 365 / 579 us against 297, profiles/r04_y_lap7_taken_apart.md)
 template <typename CT, int MODE>
-__global__ void __launch_bounds__(kBlock) FD_LAP7_OCC
+__global__ void __launch_bounds__(kBlock)
 k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
     // (a stencil column holds at most 7 entries: 448 per wavefront -- half of the general window, twice the resident workgroups)
