@@ -329,8 +329,6 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
                               const uint8_t *d_color8, int64_t C, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out)
 {
     hipStream_t s = p->ctx->stream;
-    const char *fl = getenv("FDJAC_PLAN_DEVICE_LISTS");
-    if (fl && *fl && atoi(fl) == 0) return PBR_DECLINED;
     const char *fw1 = getenv("FDJAC_WINDOW");
     if (fw1 && *fw1) return PBR_DECLINED;                             // (forced kernel variants: the host builder)
     if (nloc < 1 || p->kind != K_CSC) return PBR_DECLINED;
