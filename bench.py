@@ -325,7 +325,7 @@ def main():
     if lazy_store and cfg in ("c2", "c4"):
         bytes_min = vs + 3 * vs                                 # 32 (f64): x in, nzval out
         bytes_call_model = (vs + (0 if cyc else 1)) + bytes_min
-        kern = "k_f_tridiag_store_wave<0, false>"
+        kern = "k_f_tridiag_store_wave<0, false>" if vs == 8 else "k_f_tridiag_store_wave4<0, false>"      # (Float32: four columns per lane)
     elif lazy_diff and cfg in ("c2", "c4"):
         bytes_min = C * vs + 3 * vs + 3 * idx_b                 # 48 (f64, periodic codes)
         bytes_call_model = (vs + (0 if cyc else 1)) + (vs + 1 + C * vs) + bytes_min
