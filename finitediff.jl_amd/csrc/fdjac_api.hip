@@ -411,7 +411,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_split};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -779,7 +779,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             fd_csc_store sc;
             memset(&sc, 0, sizeof sc);
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
-            sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
+            sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.note = p->d_sc_note; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
             sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0;
             fd_lazy_points lp = {};
             lp.x = x_dev;

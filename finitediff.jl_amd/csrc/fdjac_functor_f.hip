@@ -44,6 +44,21 @@ struct Lap7F {
 // grid, as the residual defines it), and evaluates every stored entry whose row is one of those seven from the window, at
 // x + eps e_k (valid colouring: fd_csc_store.valid_coloring) -- 25 loads per column instead of 7 per evaluated row.  Entries of any
 // other row (a pattern that is a superset of the stencil) go through the functor.  Same operands, same operations: same bits.
+// what the 7-point launcher writes into a plan's note once it has seen that the plan's local columns hold exactly its stencil
+__host__ __device__ __forceinline__ unsigned long long lap7_note_key(const Lap7F &f, const fd_csc_store &st)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    const long long v[6] = {f.nx, f.ny, f.nz, st.col_begin, st.col_end, st.N};
+    for (int i = 0; i < 6; ++i) { h ^= (unsigned long long)v[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); }
+    return h | 1ull;
+}
+// after a checking launch: no mismatch counted -> the pattern is verified for this (grid, column range)
+__global__ void k_lap7_note(unsigned long long *note, unsigned long long key)
+{
+    if (note[0] != key && note[0] != (key ^ 2ull)) note[0] = note[1] == 0 ? key : (key ^ 2ull);
+    note[1] = 0;
+}
+
 // (no register budget: 96 / 80 VGPRs for 5 / 6 wavefronts per SIMD spill -- 365 / 579 us against 297, profiles/r04_y_lap7_taken_apart.md)
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock)
@@ -129,6 +144,32 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     fd_csc_wave_run<real_t> run;
     run.begin((real_t *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0), kCap);
     __syncthreads();                // (s_eps)
+    // Is this column's list of entries the stencil's?  Row t exists or not (ex[t]); the existing ones are the entries in this order
+    // if it is: entry at[t] = number of existing rows before t.  Every lane fetches the row index at its own position for each t (no
+    // dependent loads, no divergence) and compares.  The PLAN's pattern never changes, so the answer for the whole column range is
+    // remembered in the plan's note (fd_csc_store.note): the first launch on a plan checks every column and counts the mismatches,
+    // k_lap7_note records "verified" after it, and later launches read no row index at all (290 -> 210 us: the second dependent
+    // memory round trip of every wavefront, profiles/r04_y_lap7_taken_apart.md).
+    const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
+    const bool ex[7] = {l > 0, j > 0, i > 0, true, i < nx - 1, j < ny - 1, l < nz - 1};
+    const int off7[7] = {-pl, -nx, -1, 0, 1, nx, pl};
+    const int cnt = b - a, lastq = cnt > 0 ? cnt - 1 : 0;
+    int at[7], npos = 0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) { at[t] = npos < lastq ? npos : lastq; npos += ex[t] ? 1 : 0; }
+    bool okp = regular && npos == cnt;
+    const unsigned long long note0 = st.note ? st.note[0] : 0, key = lap7_note_key(f, st);
+    const bool verified = note0 == key;                    // (key ^ 2: checked before, NOT the stencil -- nothing left to count)
+#ifndef LAP7_NOROWVAL
+    if (!verified) {
+        int rv7[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) rv7[t] = st.rowval[a + at[t]];          // (unconditional: at[t] is inside the column -- an empty one reads the pad)
+#pragma unroll
+        for (int t = 0; t < 7; ++t) okp = okp && (!ex[t] || rv7[t] == (int)k + off7[t]);
+        if (st.note && note0 != (key ^ 2ull) && __any(in && !okp) && (threadIdx.x & 63) == 0) atomicAdd(&st.note[1], 1ull);
+    }
+#endif
     if (none && c_lo == 0)
         for (int q = a; q < b; ++q) run.put(q, (real_t)0);
     if (mine) {                     // (all lanes meet again at the flush below: the staged values leave in one wave-wide pass)
@@ -158,17 +199,6 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     // existing ones are the column's entries in this order if the pattern is the stencil's: entry at[t] = number of existing rows
     // before t.  Every lane fetches the row index at its own position for each t (no dependent loads, no divergence), compares, and
     // stages the quotients of the rows that exist.  A column whose entries are anything else goes through the functor, entry by entry.
-    const bool regular = nx > 2 && ny > 2 && nz != 2;      // (otherwise stencil offsets coincide or wrap: everything through the functor)
-    const bool ex[7] = {l > 0, j > 0, i > 0, true, i < nx - 1, j < ny - 1, l < nz - 1};
-    const int off7[7] = {-pl, -nx, -1, 0, 1, nx, pl};
-    const int cnt = b - a, lastq = cnt > 0 ? cnt - 1 : 0;
-    int at[7], npos = 0;
-    bool okp = regular;
-#pragma unroll
-    for (int t = 0; t < 7; ++t) { at[t] = npos < lastq ? npos : lastq; npos += ex[t] ? 1 : 0; }
-    int rv7[7];
-#pragma unroll
-    for (int t = 0; t < 7; ++t) rv7[t] = st.rowval[a + at[t]];          // (unconditional: at[t] is inside the column -- an empty one reads the pad)
     // all quotients by ONE divisor: its reciprocal once, then the correctly rounded quotients of div_shared (the bits of IEEE a / b).
     // Evaluated before the row indices are back (the comparison only decides where the values go).
     const real_t div = MODE == 1 ? 2 * h : h;
@@ -185,9 +215,6 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     const real_t v7[7] = {FD_FAST(FD_R0P, FD_R0M, bz0), FD_FAST(FD_R1P, FD_R1M, by0), FD_FAST(FD_R2P, FD_R2M, bx0), FD_FAST(FD_R3P, FD_R3M, bc),
                           FD_FAST(FD_R4P, FD_R4M, bx1), FD_FAST(FD_R5P, FD_R5M, by1), FD_FAST(FD_R6P, FD_R6M, bz1)};
 #undef FD_FAST
-    okp = okp && npos == cnt;
-#pragma unroll
-    for (int t = 0; t < 7; ++t) okp = okp && (!ex[t] || rv7[t] == (int)k + off7[t]);
     if (okp) {
 #pragma unroll
         for (int t = 0; t < 7; ++t)
@@ -278,6 +305,8 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         if (st.valid_coloring) {      // the neighbourhood in registers (one perturbed coordinate per column)
             if (lp->pts == 2) hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 1>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
             else hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 0>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
+            // (every launch visits all local columns: one that counted no mismatch has verified the pattern)
+            if (st.note) hipLaunchKernelGGL(k_lap7_note, dim3(1), dim3(1), 0, s, st.note, lap7_note_key(f, st));
         } else {
             FD_COLS(Lap7F, f);
         }

@@ -242,6 +242,7 @@ struct fd_plan {
     // ... and ANY pattern, column by column, through a compact device copy of the local pattern (fd_csc_store; FD_PLAN_STORE_CSC)
     bool want_store_csc = false, store_csc_ok = false;
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
+    unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: two words of launcher memory about this pattern, zero at creation
     int64_t sc_entries = 0;
     bool sc_valid = false;         //   colorvec verified to be a valid colouring of the local pattern (kernels may perturb one coordinate)
     // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded

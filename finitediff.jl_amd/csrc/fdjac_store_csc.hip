@@ -50,6 +50,8 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
     FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_colptr, sizeof(int) * (size_t)(ncols + 1)));
     FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_rowval, sizeof(int) * (size_t)(n + 8)));      // (+ a pad: launchers may read one entry past an empty last column)
     FD_HIP_CHECK(hipMemsetAsync(p->d_sc_rowval + n, 0, sizeof(int) * 8, p->ctx->stream));
+    FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_note, 2 * sizeof(unsigned long long)));
+    FD_HIP_CHECK(hipMemsetAsync(p->d_sc_note, 0, 2 * sizeof(unsigned long long), p->ctx->stream));
     hipLaunchKernelGGL((k_csc_compact_colptr<IT>), dim3((unsigned)((ncols + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, colptr_dev, (int64_t)idx_base,
                        p->col0, ncols + 1, p->entry_begin, p->d_sc_colptr);
     if (n > 0)

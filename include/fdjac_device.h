@@ -182,6 +182,9 @@ typedef struct fd_csc_store {
     int valid_coloring;            /* 1: the plan has verified that the columns sharing a row differ in colour -- then, seen from the row of a */
                                    /* stored entry (r, j), the colour's point differs from x in coordinate j ONLY, and a kernel may form it as */
                                    /* x[i] + eps * (i == j) without reading colours; 0: not verified (form the whole colour's point)          */
+    unsigned long long *note;      /* device, 2 words owned by the PLAN and zero when it is created: a launcher's memory about THIS pattern   */
+                                   /* (which never changes while the plan lives) -- e.g. "verified on an earlier call: it is exactly my stencil, */
+                                   /* the row indices need not be read again" (the 7-point family: 290 -> 210 us).  May be NULL.              */
 } fd_csc_store;
 
 enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4 };   /* what fd_lazy_points.store points to */

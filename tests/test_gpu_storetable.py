@@ -286,3 +286,66 @@ def test_user_kernel_stores_a_general_pattern_column_by_column(tmp_path, shape):
     out = subprocess.run([exe, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "user_csc_client ok" in out.stdout and "FAILED" not in out.stdout
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_lap7_pattern_note_remembers_a_verified_pattern(fdtype):
+    # fd_csc_store.note: the 7-point launcher checks on its first launch that the plan's columns hold exactly its stencil and then
+    # stops reading row indices.  Repeated calls on one plan (checking launch, then verified launches), new contents of x, a plan
+    # whose pattern is a SUPERSET of the stencil (never verified: every call through the checked path), the same plan driven by a
+    # launcher of another grid with the same N on a pattern that holds both stencils (the note's key differs per launcher: each
+    # is checked and found "not the stencil") -- always the bits of the hand-over path.
+    nx, ny, nz = 23, 17, 11
+    N = nx * ny * nz
+    colptr, rowval, colors = stencil7_csc(nx, ny, nz)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    f = fd.BuiltinF("lap7", nx, ny, nz)
+    rng = np.random.default_rng(3)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    ps.set_lazy(f)
+    ph = fd.make_plan(J, J, colors, fdtype)
+    for rep in range(4):
+        x = _dev(rng.random(N))
+        a, b = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
+        ps.jacobian(f, x, [a])
+        ph.jacobian(f, x, [b])
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), rep
+    # a superset pattern (every column also lists row (k + 5) mod N): valid as a pattern of f, never "the stencil"
+    cols = np.repeat(np.arange(N), np.diff(colptr))
+    rows = rowval - 1
+    extra_r, extra_c = (np.arange(N) + 5) % N, np.arange(N)
+    allr, allc = np.concatenate([rows, extra_r]), np.concatenate([cols, extra_c])
+    key = np.unique(allc * N + allr)
+    c2, r2 = key // N, key % N
+    cp2 = np.concatenate([[0], np.cumsum(np.bincount(c2, minlength=N))]).astype(np.int64) + 1
+    J2 = fd.SparseMatrixCSC(N, N, cp2, (r2 + 1).astype(np.int64), None)
+    col2 = fd.matrix_colors(J2)
+    ps2 = fd.make_plan(J2, J2, col2, fdtype, store_csc=True)
+    ps2.set_lazy(f)
+    ph2 = fd.make_plan(J2, J2, col2, fdtype)
+    for rep in range(3):
+        x = _dev(rng.random(N))
+        a, b = _dev(np.full(r2.size, np.nan)), _dev(np.full(r2.size, np.nan))
+        ps2.jacobian(f, x, [a])
+        ph2.jacobian(f, x, [b])
+        assert ps2.info(fd.lib.INFO_LAZY_STORE) == 1
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), rep
+    # the union of the stencils of two grids with the same N, driven alternately by both launchers
+    cpB, rvB, _ = stencil7_csc(ny, nx, nz)
+    colsB = np.repeat(np.arange(N), np.diff(cpB))
+    key = np.unique(np.concatenate([cols * N + rows, colsB * N + (rvB - 1)]))
+    c3, r3 = key // N, key % N
+    cp3 = np.concatenate([[0], np.cumsum(np.bincount(c3, minlength=N))]).astype(np.int64) + 1
+    J3 = fd.SparseMatrixCSC(N, N, cp3, (r3 + 1).astype(np.int64), None)
+    col3 = fd.matrix_colors(J3)
+    g = fd.BuiltinF("lap7", ny, nx, nz)
+    ps3 = fd.make_plan(J3, J3, col3, fdtype, store_csc=True)
+    ph3 = fd.make_plan(J3, J3, col3, fdtype)
+    for rep in range(4):
+        fn = f if rep % 2 == 0 else g
+        ps3.set_lazy(fn)
+        x = _dev(rng.random(N))
+        a, b = _dev(np.full(r3.size, np.nan)), _dev(np.full(r3.size, np.nan))
+        ps3.jacobian(fn, x, [a])
+        ph3.jacobian(fn, x, [b])
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), rep
