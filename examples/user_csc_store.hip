@@ -38,7 +38,11 @@ struct Moore9 {
             for (int di = -1; di <= 1; ++di) {
                 if (di == 0 && dj == 0) continue;
                 const long long ii = i + di, jj = j + dj;
-                const double v = (ii >= 0 && ii < nx && jj >= 0 && jj < ny) ? 0.5 * X(jj * nx + ii) : 0.0;
+                // (the coordinate is fetched unconditionally, from a clamped index, and selected away outside the grid: a load inside a
+                //  per-lane conditional is waited for on its own -- eight serial memory round trips per row instead of one)
+                const bool in = ii >= 0 && ii < nx && jj >= 0 && jj < ny;
+                const double xv = X(in ? jj * nx + ii : k);
+                const double v = in ? 0.5 * xv : 0.0;
                 s = first ? v : s + v;
                 first = false;
             }

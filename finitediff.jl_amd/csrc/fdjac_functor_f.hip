@@ -31,9 +31,13 @@ struct Lap7F {
         const int pl = nx * ny;
         const int l = (int)fd_div31((uint32_t)k, m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, m_nx), i = rem - j * nx;
         const T z = zero_of<T>();
+        // (every coordinate is fetched unconditionally -- from a clamped index -- and a neighbour outside the grid selected away: loads
+        //  inside per-lane conditionals are waited for one at a time, seven serial round trips per row)
+        const bool hd = l > 0, hs = j > 0, hw = i > 0, he = i < nx - 1, hn = j < ny - 1, hu = l < nz - 1;
         const T c = X(k);
-        const T d = l > 0 ? X(k - pl) : z, s = j > 0 ? X(k - nx) : z, w = i > 0 ? X(k - 1) : z, e = i < nx - 1 ? X(k + 1) : z,
-                n = j < ny - 1 ? X(k + nx) : z, u = l < nz - 1 ? X(k + pl) : z;
+        const T vd = X(hd ? k - pl : k), vs = X(hs ? k - nx : k), vw = X(hw ? k - 1 : k), ve = X(he ? k + 1 : k), vn = X(hn ? k + nx : k),
+                vu = X(hu ? k + pl : k);
+        const T d = hd ? vd : z, s = hs ? vs : z, w = hw ? vw : z, e = he ? ve : z, n = hn ? vn : z, u = hu ? vu : z;
         return lap7_row<T>(c, d, s, w, e, n, u);
     }
     template <class P> __device__ __forceinline__ real_t operator()(long long k, const P &X) const { return row<real_t>(k, X); }
@@ -302,7 +306,11 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
     } while (0)
     if (b->family == FD_F_LAP7) {
         const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2], fd_magic31((uint32_t)(b->prm[0] * b->prm[1])), fd_magic31((uint32_t)b->prm[0])};
+#ifdef LAP7_GENERIC
+        if (false) {
+#else
         if (st.valid_coloring) {      // the neighbourhood in registers (one perturbed coordinate per column)
+#endif
             if (lp->pts == 2) hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 1>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
             else hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 0>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
             // (every launch visits all local columns: one that counted no mismatch has verified the pattern)
