@@ -462,6 +462,58 @@ static int client_blockbanded(void)
     return report("blockbanded", worst, 1e-12, calls, 3 * bs);
 }
 
+/* shim: make_plan(ctx, J::BandedBlockBandedMatrix, ...) (BlockBandedMatrices ext, round 4): the structural plan of
+   ext/FiniteDiffBlockBandedMatricesExt.jl:16-42 -- blocklengths, blockbandwidths, subblockbandwidths, and per in-band block the start
+   of bandeddata(view(J, K, J)) in J.data with its column stride; no entry list.  The 2-D 5-point Laplacian on an nx x ny grid IS
+   such a matrix: ny blocks of nx, block bandwidths (1, 1), sub-block bandwidths (1, 1). */
+static int client_bandedblockbanded(void)
+{
+    const int64_t nx = 64, ny = 50, nb = ny, N = nx * ny, bl = 1, bu = 1, lam = 1, mu = 1, w = bl + bu + 1, sw = lam + mu + 1, R = w * sw;
+    int64_t *sizes = malloc(sizeof(int64_t) * (size_t)nb), *starts = calloc((size_t)(w * nb), sizeof(int64_t)), *strides = malloc(sizeof(int64_t) * (size_t)nb);
+    int64_t *colors = malloc(sizeof(int64_t) * (size_t)N);
+    for (int64_t J = 0; J < nb; ++J) {
+        sizes[J] = nx;
+        strides[J] = R;
+        for (int64_t K = (J - bu > 0 ? J - bu : 0); K <= (J + bl < nb - 1 ? J + bl : nb - 1); ++K)
+            starts[(bu + K - J) + w * J] = 1 + J * nx * R + (bu + K - J) * sw;          /* 1-based, BlockBandedMatrices' layout */
+        for (int64_t j = 0; j < nx; ++j) colors[J * nx + j] = sw * (J % w) + (j % sw) + 1;
+    }
+    const int64_t len = R * N;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *dd = dev_nan((size_t)len);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    const int64_t prm[2] = {nx, ny};
+    CHECK(new_f(FD_F_LAP5, prm, 2, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_CENTRAL;
+    CHECK(fd_plan_create_bandedblockbanded(g_ctx, nb, sizes, bl, bu, lam, mu, starts, strides, len, 8, 1, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {dd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *data = malloc(sizeof(double) * (size_t)len);
+    from_dev(data, dd, sizeof(double) * (size_t)len);
+    /* the Laplacian's Jacobian: -4 on the diagonal, 1 for the four neighbours; every other slot of every slab 0 (also the slabs
+       reserved for blocks outside the matrix) */
+    double worst = 0;
+    for (int64_t J = 0; J < nb; ++J)
+        for (int64_t j = 0; j < nx; ++j)
+            for (int64_t d = 0; d < w; ++d)
+                for (int64_t t = 0; t < sw; ++t) {
+                    const int64_t K = J + d - bu, k = j + t - mu;
+                    double want = 0.0;
+                    if (K >= 0 && K < nb && k >= 0 && k < nx) {
+                        if (K == J) want = k == j ? -4.0 : 1.0;
+                        else want = k == j ? 1.0 : 0.0;
+                    }
+                    const double got = data[J * nx * R + j * R + d * sw + t];
+                    const double e = fabs(got - want);
+                    if (!(e <= worst)) worst = e;
+                }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(dd); free(data); free(x); free(sizes); free(starts); free(strides); free(colors);
+    return report("bandedblockbanded", worst, 1e-6, calls, 2 * 9);
+}
+
 /* shim: the Float32 methods generated by the eltype loop: x::ROCVector{Float32} -> the fd32_* symbols */
 static int client_csc_f32(void)
 {
@@ -928,6 +980,7 @@ int main(int argc, char **argv)
     RUN("tridiagonal", client_tridiagonal())
     RUN("banded", client_banded())
     RUN("blockbanded", client_blockbanded())
+    RUN("bandedblockbanded", client_bandedblockbanded())
     RUN("csc_f32", client_csc_f32())
     RUN("jvp", client_jvp())
     RUN("solve", client_solve())

@@ -175,11 +175,13 @@ class BlockBandedMatrix:
 
 class BandedBlockBandedMatrix:
     """BlockBandedMatrices.BandedBlockBandedMatrix: flat data + a ``patterns.BandedBlockBandedLayout``.  The reference
-    stores through raw offsets into each block's banded data (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42); here the
-    (row, column, offset) triples are enumerated once and compiled with fd_plan_create_entries."""
+    stores through raw offsets into each block's banded data (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42); the plan is
+    structural (fd_plan_create_bandedblockbanded: block sizes, bandwidths, slab starts and strides -- no entry list).
+    ``as_entries=True`` keeps round 3's form: the (row, column, offset) triples enumerated once and compiled with
+    fd_plan_create_entries (what complex-valued x and column windows still use; the tests compare the two)."""
 
-    def __init__(self, data, layout):
-        self.data, self.layout = data, layout
+    def __init__(self, data, layout, as_entries=False):
+        self.data, self.layout, self.as_entries = data, layout, as_entries
 
     def size(self):
         return self.layout.N, self.layout.N
@@ -859,10 +861,15 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
         lay = J.layout
         if cv.size != lay.N:
             raise ValueError("DimensionMismatch: length(colorvec) != length(x)")
-        rows, cols, dest = lay.entries()
-        rows, cols, dest = _i64(rows), _i64(cols), _i64(dest)
-        _l.check(L.fd_plan_create_entries(ctx.handle, lay.N, lay.N, _vp(rows), _vp(cols), _vp(dest), dest.size,
-                                          lay.data_len, 8, 1, _vp(cv), 8, C.byref(o), C.byref(h)))
+        if J.as_entries or col_window is not None or (o.flags & 2):
+            rows, cols, dest = lay.entries()
+            rows, cols, dest = _i64(rows), _i64(cols), _i64(dest)
+            _l.check(L.fd_plan_create_entries(ctx.handle, lay.N, lay.N, _vp(rows), _vp(cols), _vp(dest), dest.size,
+                                              lay.data_len, 8, 1, _vp(cv), 8, C.byref(o), C.byref(h)))
+        else:
+            bs, st, sr = _i64(lay.blk_sizes), _i64(lay.block_starts), _i64(lay.block_strides)
+            _l.check(L.fd_plan_create_bandedblockbanded(ctx.handle, lay.nblk, _vp(bs), lay.bl, lay.bu, lay.lam, lay.mu, _vp(st), _vp(sr), lay.data_len, 8, 1,
+                                                        _vp(cv), 8, C.byref(o), C.byref(h)))
     elif isinstance(J, BlockBandedMatrix):
         lay = J.layout
         bs, st, sr = _i64(lay.blk_sizes), _i64(lay.block_starts), _i64(lay.block_strides)

@@ -411,7 +411,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &sp : p->spans) {
@@ -687,7 +687,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
 
     // dense J / list kinds with several chunks or uncovered entries start from zero (fill_matrix!,
     // src/jacobians.jl:530-532).  Kinds that write every stored value in one chunk skip the fill.
-    if (p->kind == K_CSC_DENSE || p->kind == K_COO_DENSE) {
+    if (p->kind == K_CSC_DENSE || p->kind == K_COO_DENSE || (p->kind == K_BBB && p->bbb_fill)) {
         FD_HIP_CHECK(hipMemsetAsync(outs[0], 0, sizeof(real_t) * (size_t)p->out_len[0], s));
     } else if (p->C == 0) {
         for (int k = 0; k < p->nouts; ++k)

@@ -22,6 +22,7 @@
 #define fd_plan_create_tridiagonal fd32_plan_create_tridiagonal
 #define fd_plan_create_banded fd32_plan_create_banded
 #define fd_plan_create_blockbanded fd32_plan_create_blockbanded
+#define fd_plan_create_bandedblockbanded fd32_plan_create_bandedblockbanded
 #define fd_plan_destroy fd32_plan_destroy
 #define fd_plan_matches fd32_plan_matches
 #define fd_plan_info fd32_plan_info
@@ -109,7 +110,7 @@ inline void set_error(const char *fmt, ...)
         }                                    \
     } while (0)
 
-enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLRANGE, K_DENSE };
+enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLRANGE, K_DENSE, K_BBB };
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
@@ -241,6 +242,14 @@ struct fd_plan {
     int64_t store5_nx = 0, store5_ny = 0;
     // ... and ANY pattern, column by column, through a compact device copy of the local pattern (fd_csc_store; FD_PLAN_STORE_CSC)
     bool want_store_csc = false, store_csc_ok = false;
+    // BandedBlockBandedMatrix (K_BBB): block structure and the banded-data slab of every in-band block
+    int64_t bbb_nb = 0;
+    int bbb_bl = 0, bbb_bu = 0, bbb_lam = 0, bbb_mu = 0;
+    bool bbb_fill = false;             // some slots of data belong to no slab: zero-fill before the launch
+    int32_t *d_bbb_off = nullptr;      // [nb + 1] first row / column of every block
+    int32_t *d_bbb_blk = nullptr;      // [N] block of every column
+    int64_t *d_bbb_start = nullptr;    // [(bl + bu + 1) * nb] 0-based start of block (K, J)'s slab in data, -1: not in the band
+    int64_t *d_bbb_stride = nullptr;   // [nb] column stride of the slabs of block-column J
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
     unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: two words of launcher memory about this pattern, zero at creation
     int64_t sc_entries = 0;

@@ -1056,6 +1056,46 @@ k_decompress_banded(const CT *__restrict__ color, const real_t *__restrict__ FXa
 }
 
 
+// K4c  BandedBlockBandedMatrix J (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42): every in-band block (K, J) owns a slab of banded
+//   data, (lam + mu + 1) x n_J values with column stride st_J; the reference stores entry (k, j) of the block at
+//   start(K, J) + j st + mu + k - j (its lines 29-36).  One thread per slot (column j, block-band d = K - J + bu, sub-band t = mu + k - j):
+//   implicit indices -- an int32 block number per column and the per-block tables are all the index data there is (the entry-list
+//   plan moved 13 B of index per 8-B value) --, lane-consecutive slots of a column, dense stores in BlockBandedMatrices' own layout.
+//   Slots of rows outside their block and columns without colour are written as 0 (the reference's prologue zero-fills J,
+//   src/jacobians.jl:530-532).
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_decompress_bbb(const CT *__restrict__ color, const real_t *__restrict__ FXa, const real_t *__restrict__ FXb, int64_t ld,
+                 const real_t *__restrict__ eps, int c_lo, int c_hi, int64_t N, int64_t nb, int bl, int bu, int lam, int mu,
+                 const int32_t *__restrict__ off, const int32_t *__restrict__ blk, const int64_t *__restrict__ start,
+                 const int64_t *__restrict__ stride, real_t *__restrict__ data)
+{
+    const int none = ColorTraits<CT>::none;
+    const int w = bl + bu + 1, sw = lam + mu + 1, R = w * sw;
+    const int64_t total = N * R;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += step) {
+        const int64_t j = e / R;
+        const int s = (int)(e - j * R), d = s / sw, t = s - d * sw;
+        const int J = blk[j];
+        const int64_t K = (int64_t)J + d - bu;
+        const bool kin = K >= 0 && K < nb;
+        const int64_t st0 = start[(int64_t)d + (int64_t)w * J];
+        if (st0 < 0) continue;                                     // no such block and no slab reserved for it
+        // (a layout that reserves the slab of a block outside the matrix -- BlockBandedMatrices' own: (bl+bu+1)(lam+mu+1) rows per
+        //  column -- gets its zeros here; the plan zero-fills other layouts before the launch)
+        const int jj = (int)(j - off[J]), k = jj + t - mu, m = kin ? off[K + 1] - off[K] : 0;
+        real_t *o = data + st0 + (int64_t)jj * stride[J] + t;
+        const int c = color[j];
+        if (k < 0 || k >= m || c == none) {
+            if (c_lo == 0) *o = 0.0;
+            continue;
+        }
+        if (c < c_lo || c >= c_hi) continue;
+        *o = entry_value<MODE>(FXa, FXb, ld, c - c_lo, (int64_t)off[kin ? K : 0] + k, eps[c]);
+    }
+}
+
 // K5b  the same column-range decompression, one WORKGROUP per kCrCols consecutive columns.  A wave per column leaves
 //   a wave with ~1.5 loads of work behind two dependent round trips (column metadata, then values): the kernel runs
 //   at the latency, not the bandwidth, of the memory system.  Here the metadata of kCrCols columns is fetched with
@@ -1515,6 +1555,14 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
         const int g = grid_for((p->col1 - p->col0) * (p->l + p->u + 1), kBlock, p->ctx->num_cus);
         hipLaunchKernelGGL((k_decompress_banded<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb,
                            p->ldf, p->d_eps, c_lo, c_hi, p->M, p->l, p->u, p->col0, p->col1, outs[0]);
+        break;
+    }
+    case K_BBB: {
+        const int64_t slots = p->N * (int64_t)(p->bbb_bl + p->bbb_bu + 1) * (p->bbb_lam + p->bbb_mu + 1);
+        const int g = grid_for(slots, kBlock, p->ctx->num_cus);
+        hipLaunchKernelGGL((k_decompress_bbb<CT, MODE>), dim3(g), dim3(kBlock), 0, s, color, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, p->N,
+                           p->bbb_nb, p->bbb_bl, p->bbb_bu, p->bbb_lam, p->bbb_mu, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride,
+                           outs[0]);
         break;
     }
     case K_DENSE: {

@@ -719,6 +719,91 @@ int fd_plan_create_banded(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t 
     return finish_fingerprint(rc, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
 }
 
+// BandedBlockBandedMatrix J (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42): a structural plan -- block sizes, block bandwidths
+// (bl, bu), sub-block bandwidths (lam, mu), the start of every in-band block's banded-data slab and the slabs' column stride per
+// block-column, as the reference reads them (pointer(bandeddata(view(J, K, J))), stride(data, 2)).  No entry list is built.
+int fd_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu, int64_t lam, int64_t mu,
+                                     const void *block_starts, const void *block_strides, int64_t data_len, int idx_bytes, int idx_base,
+                                     const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)
+{
+    FD_REQUIRE(blk_sizes && block_starts && block_strides && out, FD_ERR_ARG, "NULL block layout array");
+    FD_REQUIRE(idx_bytes == 4 || idx_bytes == 8, FD_ERR_ARG, "idx_bytes must be 4 or 8");
+    FD_REQUIRE(nblk >= 1 && bl >= 0 && bu >= 0 && lam >= 0 && mu >= 0 && bl + bu + 1 <= 1024 && lam + mu + 1 <= 1024, FD_ERR_ARG, "bad block structure");
+    FD_REQUIRE(!(opts && (opts->flags & FD_PLAN_COMPLEX_X)), FD_ERR_UNSUPPORTED, "complex-valued x on BandedBlockBandedMatrix storage: use fd_plan_create_entries");
+    std::vector<int32_t> off((size_t)nblk + 1, 0);
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t sz = load_idx(blk_sizes, idx_bytes, b);
+        FD_REQUIRE(sz >= 0 && (int64_t)off[(size_t)b] + sz < ((int64_t)1 << 31), FD_ERR_SHAPE, "bad block size");
+        off[(size_t)b + 1] = off[(size_t)b] + (int32_t)sz;
+    }
+    const int64_t N = off[(size_t)nblk];
+    int rc = new_plan(ctx, K_BBB, N, N, out);
+    if (rc) return rc;
+    fd_plan *p = *out;
+    FD_TRY(apply_opts(p, opts));
+    if (!(p->col0 == 0 && p->col1 == N)) {
+        set_error("column windows are not supported for BandedBlockBandedMatrix storage");
+        fd_plan_destroy(p);
+        *out = nullptr;
+        return FD_ERR_UNSUPPORTED;
+    }
+    std::vector<int32_t> col0;
+    FD_TRY(ingest_colors(p, colorvec, color_bytes, col0));
+    FD_TRY(upload_colors(p, col0, {}));
+    const int64_t w = bl + bu + 1, sw = lam + mu + 1;
+    std::vector<int32_t> blk((size_t)N);
+    std::vector<int64_t> start((size_t)(w * nblk), -1), stride((size_t)nblk, 0);
+    int64_t out_len = 0, covered = 0;
+    bool dense = true;      // every column owns (bl+bu+1)(lam+mu+1) consecutive slots: the slabs of blocks outside the matrix are reserved too
+    for (int64_t J = 0; J < nblk; ++J) {
+        const int64_t nJ = off[(size_t)J + 1] - off[(size_t)J];
+        for (int64_t j = off[(size_t)J]; j < off[(size_t)J + 1]; ++j) blk[(size_t)j] = (int32_t)J;
+        stride[(size_t)J] = load_idx(block_strides, idx_bytes, J);
+        for (int64_t K = std::max<int64_t>(J - bu, 0); K <= std::min<int64_t>(J + bl, nblk - 1); ++K) {
+            const int64_t st = load_idx(block_starts, idx_bytes, (bu + K - J) + w * J) - idx_base;
+            if (!(st >= 0 && (nJ == 0 || stride[(size_t)J] >= sw))) {
+                set_error("inconsistent slab of block (%lld,%lld): start %lld, column stride %lld < %lld", (long long)K, (long long)J,
+                          (long long)st, (long long)stride[(size_t)J], (long long)sw);
+                fd_plan_destroy(p);
+                *out = nullptr;
+                return FD_ERR_SHAPE;
+            }
+            start[(size_t)((bu + K - J) + w * J)] = st;
+            if (nJ > 0) out_len = std::max<int64_t>(out_len, st + (nJ - 1) * stride[(size_t)J] + sw);
+        }
+        // BlockBandedMatrices' layout: slab d of block-column J at base_J + d (lam+mu+1), column stride >= (bl+bu+1)(lam+mu+1)
+        int64_t base = -1;
+        bool ok = stride[(size_t)J] >= w * sw;
+        for (int64_t d = 0; d < w && ok; ++d) {
+            const int64_t st = start[(size_t)(d + w * J)];
+            if (st < 0) continue;
+            if (base < 0) base = st - d * sw;
+            ok = st - d * sw == base && base >= 0;
+        }
+        if (ok && base >= 0 && nJ > 0) {
+            for (int64_t d = 0; d < w; ++d)
+                if (start[(size_t)(d + w * J)] < 0) start[(size_t)(d + w * J)] = base + d * sw;      // (a reserved slab: zeros)
+            out_len = std::max<int64_t>(out_len, base + (nJ - 1) * stride[(size_t)J] + w * sw);
+            covered += nJ * w * sw;
+        } else if (nJ > 0) {
+            dense = false;
+        }
+    }
+    FD_REQUIRE(data_len >= out_len, FD_ERR_SHAPE, "data_len %lld < the end of the last slab %lld", (long long)data_len, (long long)out_len);
+    p->bbb_fill = !(dense && covered == data_len);      // (slots no slab reaches: zero-filled before every launch, as fill!(J, 0) does)
+    p->bbb_nb = nblk; p->bbb_bl = (int)bl; p->bbb_bu = (int)bu; p->bbb_lam = (int)lam; p->bbb_mu = (int)mu;
+    p->row0 = 0;
+    p->row1 = N;
+    FD_TRY(dev_upload(&p->d_bbb_off, off));
+    FD_TRY(dev_upload(&p->d_bbb_blk, blk));
+    FD_TRY(dev_upload(&p->d_bbb_start, start));
+    FD_TRY(dev_upload(&p->d_bbb_stride, stride));
+    FD_TRY(alloc_scratch(p, col0));
+    p->nouts = 1;
+    p->out_len[0] = data_len;
+    return finish_fingerprint(FD_OK, out, opts, 0, nullptr, 0, nullptr, 0, 8, 0, colorvec, color_bytes, N, FD_HOST, N);
+}
+
 int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu,
                                const void *block_starts, const void *block_strides, int idx_bytes, int idx_base,
                                const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out)

@@ -61,7 +61,8 @@ F_LAUNCH_LAZY_JVP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(LazyJ
 EXPORTS = (
     "fd_version", "fd_last_error", "fd_ctx_create", "fd_ctx_destroy", "fd_ctx_stream", "fd_ctx_synchronize",
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
-    "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded", "fd_plan_destroy",
+    "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
+    "fd_plan_create_bandedblockbanded", "fd_plan_destroy",
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
@@ -83,7 +84,7 @@ EXPORTS = (
 TYPED = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
-    "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
+    "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
     "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
@@ -177,6 +178,7 @@ def load():
     L.fd_plan_create_dense.argtypes = [vp, i64, i64, i64, po, pp]
     L.fd_plan_create_banded.argtypes = [vp, i64, i64, i64, i64, vp, i32, po, pp]
     L.fd_plan_create_blockbanded.argtypes = [vp, i64, vp, i64, i64, vp, vp, i32, i32, vp, i32, po, pp]
+    L.fd_plan_create_bandedblockbanded.argtypes = [vp, i64, vp, i64, i64, i64, i64, vp, vp, i64, i32, i32, vp, i32, po, pp]
     L.fd_plan_destroy.argtypes = [vp]
     L.fd_plan_matches.argtypes = [vp, C.POINTER(PatternArrays), C.POINTER(i32)]
     L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]

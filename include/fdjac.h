@@ -17,6 +17,7 @@
  *   fd_plan_create_dense        sparsity === nothing: src/jacobians.jl:548-557,590-598,626-631
  *   fd_plan_create_banded       ext/FiniteDiffBandedMatricesExt.jl:13-27
  *   fd_plan_create_blockbanded  ext/FiniteDiffBlockBandedMatricesExt.jl:44-68
+ *   fd_plan_create_bandedblockbanded  ext/FiniteDiffBlockBandedMatricesExt.jl:16-42
  *
  * Step sizes follow src/epsilons.jl:26-29,50-53,104-107 with the masked-norm rule of
  * src/jacobians.jl:559-561 / 600-602 / 624.  Arithmetic is Float64 (fd_*) or Float32 (fd32_*, end of this file).
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 400
+#define FDJAC_VERSION 401
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;
@@ -240,6 +241,15 @@ int fd_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes,
                                int64_t bu, const void *block_starts, const void *block_strides,
                                int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                                const fd_plan_opts *opts, fd_plan **out);
+/* BandedBlockBandedMatrix J (round 4): square block structure blk_sizes[nblk], block bandwidths (bl, bu), sub-block bandwidths
+   (lam, mu); block_starts[(bu + K - J) + (bl+bu+1)*J] = idx_base-based start of block (K, J)'s banded-data slab in data
+   (pointer(bandeddata(view(J, K, J)))), block_strides[J] = its column stride: entry (k, j) of the block (0-based) lives at
+   start + j*stride + mu + k - j (ext/FiniteDiffBlockBandedMatricesExt.jl:29-36).  outs[0] = data; every slot of every in-band
+   slab is written: the quotient, or 0 for rows outside the block / columns without colour; data_len = length of data (slots no
+   slab reaches are zero-filled, as the reference's fill!(J, 0) leaves them).  Whole column range only. */
+int fd_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu, int64_t lam, int64_t mu,
+                                     const void *block_starts, const void *block_strides, int64_t data_len, int idx_bytes, int idx_base,
+                                     const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd_plan **out);
 int fd_plan_destroy(fd_plan *plan);
 
 /* Is `plan` still the plan of THESE arrays?  The reference holds colorvec / sparsity by reference and re-reads them on every
@@ -590,6 +600,9 @@ int fd32_plan_create_blockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_size
                                int64_t bu, const void *block_starts, const void *block_strides,
                                int idx_bytes, int idx_base, const void *colorvec, int color_bytes,
                                const fd_plan_opts *opts, fd32_plan **out);
+int fd32_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_sizes, int64_t bl, int64_t bu, int64_t lam, int64_t mu,
+                                       const void *block_starts, const void *block_strides, int64_t data_len, int idx_bytes, int idx_base,
+                                       const void *colorvec, int color_bytes, const fd_plan_opts *opts, fd32_plan **out);
 int fd32_plan_destroy(fd32_plan *plan);
 int fd32_plan_matches(fd32_plan *plan, const fd_pattern_arrays *now, int *matches_out);
 int fd32_plan_info(const fd32_plan *plan, int key, int64_t *value);

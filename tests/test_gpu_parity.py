@@ -230,6 +230,58 @@ def test_stencil_bandedblockbanded(oracle, fdtype):
 
 
 @pytest.mark.parametrize("fdtype", FDTYPES)
+@pytest.mark.parametrize("case", ["uniform", "ragged", "wide_subbands", "none_and_chunks", "float32"])
+def test_bandedblockbanded_structural_plan(oracle, fdtype, case):
+    # fd_plan_create_bandedblockbanded (round 4): the plan holds block sizes, bandwidths and slab starts / strides -- no entry list --
+    # and k_decompress_bbb finds every slot's row and block by arithmetic.  Same bits as the enumerated-entries plan of the same
+    # matrix (round 3's form), and the oracle's restatement of ext/FiniteDiffBlockBandedMatricesExt.jl:16-42.
+    rng = np.random.default_rng(41)
+    if case == "ragged":
+        blk, bl, bu, lam, mu = rng.integers(3, 40, size=37), 2, 1, 2, 3
+    elif case == "wide_subbands":
+        blk, bl, bu, lam, mu = np.full(25, 12), 0, 2, 5, 4
+    else:
+        blk, bl, bu, lam, mu = np.full(30, 40), 1, 1, 1, 1
+    lay = P.BandedBlockBandedLayout(blk, bl, bu, lam, mu)
+    N = lay.N
+    colors = lay.colors()
+    kw = {}
+    if case == "none_and_chunks":
+        colors = colors.copy()
+        colors[[0, 7, N // 2, N - 1]] = 0
+        kw = dict(scratch_bytes=4 * 2 * 16 * N)          # room for a few colours at a time
+    dtype = np.float32 if case == "float32" else np.float64
+    tdt = torch.float32 if case == "float32" else torch.float64
+    x = torch.as_tensor(rng.random(N) + 0.1, dtype=tdt, device="cuda")
+    A = torch.as_tensor(rng.random((N, 3)), dtype=tdt, device="cuda")
+
+    def fn(fx, xx):     # some f! (the plan does not care whether the pattern fits it: same arithmetic both ways)
+        fx.copy_(A[:, 0].to(xx.dtype) * xx ** 2 + A[:, 1].to(xx.dtype) * xx.roll(1) + A[:, 2].to(xx.dtype) * xx.roll(-3) * xx)
+
+    outs = []
+    for as_entries in (False, True):
+        J = fd.BandedBlockBandedMatrix(None, lay, as_entries=as_entries)
+        plan = fd.make_plan(J, J, colors, fdtype, dtype=dtype, **kw)
+        assert plan.out_len(0) == lay.data_len
+        out = torch.full((lay.data_len,), float("nan"), dtype=tdt, device="cuda")
+        plan.jacobian(fd.TorchF(fn, N, N, dtype=dtype), x, [out])
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1]), case
+    if case in ("uniform", "ragged") and dtype == np.float64:
+        nx = 40
+        if case == "uniform":      # the reference's fixture on this layout, against the oracle
+            f = fd.BuiltinF("clamp5", nx, 30)
+            Jd = fd.BandedBlockBandedMatrix(_dev(np.full(lay.data_len, np.nan)), lay)
+            xh = rng.random(N)
+            fd.finite_difference_jacobian_b(Jd, f, _dev(xh), fdtype, colorvec=lay.colors())
+            ref = oracle.jacobian(fdtype, oracle.Fixture("clamp5", nx, 30), xh, lay.colors(), kind=oracle.PAT_BANDEDBLOCKBANDED,
+                                  blk_sizes=lay.blk_sizes, bl=1, bu=1, lam=1, mu=1, block_starts=lay.block_starts,
+                                  block_strides=lay.block_strides, out_len=lay.data_len)
+            _tol_ok(Jd.data.cpu().numpy(), ref["out"], np.min(np.abs(_oracle_eps(xh, lay.colors(), fdtype))), 5.0, "bbb structural " + fdtype)
+
+
+@pytest.mark.parametrize("fdtype", FDTYPES)
 def test_nonsquare_with_cache(oracle, fdtype):
     # test/coloring_tests.jl:124-159
     n = 4
