@@ -146,8 +146,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // process can build plans of both variants side by side and fd_plan_info reports which one a plan uses
     auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
     p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
-    p->list_U = env_int("FDJAC_TILE", 2);
-    if (p->list_U != 1 && p->list_U != 2) p->list_U = 4;
     // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
     // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
@@ -236,10 +234,9 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
                 p->cyc_C = cyc ? (int)p->C : 0;
                 p->cyc_shift = cyc ? (int)sh : 0;
             }
-            const char *cm = getenv("FDJAC_GRID_CAP");
             // 4 workgroups per CU: measured 31.0 us for partial + finalize at N = 10^7 (8: 34.5, 16: 33.7, 2: 36.6,
             // uncapped 36.1 -- fewer partials for the finalize, enough loads in flight for the reduction)
-            const int64_t mult = (cm && *cm) ? atoll(cm) : 4;
+            const int64_t mult = 4;
             const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
             // (a function of N alone -- 256 CUs x 4, not of the device the plan happens to live on: every rank of a sharded
             //  reduction must cut the same blocks; fd_plan_set_comm verifies it)
@@ -981,7 +978,7 @@ int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
     FD_REQUIRE(comm == nullptr || fdjac_comm_nranks(comm) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
     if (comm) {
         // every rank must cut the SAME global grid of blocks (it is a function of N, the colour count and the map -- but a rank
-        // with another FDJAC_GRID_CAP / FDJAC_EPS_CONTIG would use other slots: mismatched all-gather counts hang, matched
+        // with another FDJAC_EPS_CONTIG would use other slots: mismatched all-gather counts hang, matched
         // ones finalize garbage), and every rank must agree on WHETHER its reduction is sharded at all (a rank whose plan keeps
         // the replicated reduction would skip the per-call all-gather the others enter).  One tiny all-reduce at attach time
         // settles both; it is unconditional -- every rank enters it whatever its own plan looks like.
@@ -993,7 +990,7 @@ int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
         if (rc) return rc;
         FD_REQUIRE(got[0] == mine[0] && got[1] == mine[1] && got[2] == mine[2] && got[3] == mine[3], FD_ERR_COMM,
                    "the ranks disagree on the step-size reduction (this rank: %s, %d blocks of %d tiles): same N, colours, fdtype, "
-                   "FDJAC_SMALL, FDJAC_GRID_CAP and FD_PLAN_EPS_CONTIGUOUS everywhere?", sh ? "sharded" : "replicated",
+                   "FDJAC_SMALL and FD_PLAN_EPS_CONTIGUOUS everywhere?", sh ? "sharded" : "replicated",
                    p->n_partial_blocks, p->eps_tpb);
     }
     p->comm = comm;

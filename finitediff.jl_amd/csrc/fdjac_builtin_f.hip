@@ -649,13 +649,10 @@ int balanced_grid(int64_t tiles, int64_t cap);
 // grid.x covers `rows` work items of one point, grid.y = points; whole rounds (see balanced_grid)
 static inline dim3 grid2(int64_t rows, int64_t nbatch, int num_cus)
 {
-    static int64_t capmult = -1;
-    // (default since round 4: uncapped, one work item per thread -- N = 10^7 tridiagonal f! 65 -> 59 us per launch, profiles/r04_b_*)
-    if (capmult < 0) { const char *v = getenv("FDJAC_F_GRID_CAP"); capmult = (v && *v) ? atoll(v) : 0; }
+    // one work item per thread, uncapped (N = 10^7 tridiagonal f!: 65 -> 59 us per launch against a capped grid, profiles/r04_b_*)
+    (void)num_cus;
     const int64_t tiles = (rows + kBlock - 1) / kBlock;
-    int64_t cap = capmult > 0 ? std::max<int64_t>((int64_t)num_cus * capmult / std::max<int64_t>(nbatch, 1), 64)
-                              : ((int64_t)1 << 30);
-    return dim3((unsigned)balanced_grid(tiles, cap), (unsigned)nbatch, 1);
+    return dim3((unsigned)balanced_grid(tiles, (int64_t)1 << 30), (unsigned)nbatch, 1);
 }
 
 #include "fdjac_functor_f.hip"

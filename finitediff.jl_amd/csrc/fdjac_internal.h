@@ -194,7 +194,6 @@ struct fd_plan {
     // kernel variants, fixed at plan creation (environment switches are read there, never per process):
     bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
-    int list_U = 2;                //   pairs per thread of the storage-order gather kernel (FDJAC_TILE: 1, 2 or 4)
     bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
     int eps_tpb = 0;               //   > 0: the reduction's blocks sum CONTIGUOUS runs of this many tiles (FD_PLAN_EPS_CONTIGUOUS /
                                    //   FDJAC_EPS_CONTIG=1): shard r of the reduction then reads only its own range of x

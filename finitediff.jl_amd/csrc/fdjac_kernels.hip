@@ -1255,12 +1255,6 @@ __global__ void __launch_bounds__(kBlock) k_fill(real_t *__restrict__ p, int64_t
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from fdjac_api.hip)
 // ---------------------------------------------------------------------------------------------
-static int64_t env_i64(const char *name, int64_t dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoll(v) : dflt;
-}
-static int64_t g_capmult = -1;
 // The row-window kernels walk their tiles from the LAST one to the first: the f! values were written front to back
 // by the launch before, so the end of the batch is what the 256 MiB Infinity Cache still holds when the decompression
 // starts (measured in one process on the same buffers, N = 10^7: tridiagonal forward 123.9 -> 118.3 / 119.8 -> 117.4 /
@@ -1271,7 +1265,7 @@ static int64_t g_capmult = -1;
 // before, so its end is what the 256 MiB Infinity Cache still holds ("tile order")
 static inline bool tile_order_reversed() { return true; }
 
-static inline int64_t tune_capmult() { if (g_capmult < 0) g_capmult = env_i64("FDJAC_GRID_CAP", 8); return g_capmult; }
+constexpr int64_t kGridCapMult = 8;      // resident workgroups per CU of the grid-stride kernels
 
 // Grid for a grid-stride kernel: at most cap resident workgroups, and -- because these kernels are
 // bandwidth bound with identical work per tile -- a block count that divides the tiles into whole
@@ -1287,7 +1281,7 @@ int balanced_grid(int64_t tiles, int64_t cap)
 static inline int grid_for(int64_t work_items, int per_block, int num_cus)
 {
     const int64_t tiles = (work_items + per_block - 1) / per_block;
-    const int64_t cap = tune_capmult() > 0 ? (int64_t)num_cus * tune_capmult() : ((int64_t)1 << 30);
+    const int64_t cap = (int64_t)num_cus * kGridCapMult;
     return balanced_grid(tiles, cap);
 }
 
@@ -1500,7 +1494,7 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
             launch_window_m<MODE>(p, fx, FXa, FXb, c_lo, c_hi, outs[0]);
             break;
         }
-        const int U = p->list_U;   // pairs per thread (FDJAC_TILE at plan creation: 1, 2 or 4)
+        constexpr int U = 2;       // pairs per thread
         const int64_t tile = (int64_t)U * kBlock * 2;
         const int64_t g = 8 * xcd_chunks((p->nnz_local + tile - 1) / tile);
         const bool lds = B <= kEpsLdsMax;
@@ -1511,12 +1505,8 @@ static int launch_decompress_tm(fd_plan *p, const real_t *fx, int c_lo, int c_hi
                            p->d_rowval, (const CT *)p->d_nzcolor, DEST, FXa, FXb, p->ldf, p->d_eps, c_lo, c_hi, \
                            outs[0], p->nnz_local, VOK)
         if (p->kind == K_CSC) {
-            if (U == 1 && lds) FD_LAUNCH_LIST(false, 1, true, nullptr, vec_ok);
-            else if (U == 1) FD_LAUNCH_LIST(false, 1, false, nullptr, vec_ok);
-            else if (U == 2 && lds) FD_LAUNCH_LIST(false, 2, true, nullptr, vec_ok);
-            else if (U == 2) FD_LAUNCH_LIST(false, 2, false, nullptr, vec_ok);
-            else if (lds) FD_LAUNCH_LIST(false, 4, true, nullptr, vec_ok);
-            else FD_LAUNCH_LIST(false, 4, false, nullptr, vec_ok);
+            if (lds) FD_LAUNCH_LIST(false, 2, true, nullptr, vec_ok);
+            else FD_LAUNCH_LIST(false, 2, false, nullptr, vec_ok);
         } else {
             if (lds) FD_LAUNCH_LIST(true, 2, true, p->d_dest, vec_ok & 4);
             else FD_LAUNCH_LIST(true, 2, false, p->d_dest, vec_ok & 4);
