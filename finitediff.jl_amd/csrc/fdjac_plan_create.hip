@@ -47,8 +47,14 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
                                        d_cv, color_bytes, e0, e1, &brc);
             (void)hipStreamSynchronize(ctx->stream);
             tm.mark(res == PBR_DONE ? "csc: device builder" : "csc: device builder declined");
-            if (res == PBR_DONE && brc == FD_OK)   // (the raw arrays are still on the device: the compact copy comes from them)
-                brc = build_store_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base);
+            if (res == PBR_DONE && brc == FD_OK) {
+                // (the raw arrays are still on the device: the compact copy comes from them -- unless the plan has a column window: its
+                //  colouring is checked against ALL columns, which only the host holds here)
+                if (p->col0 == 0 && p->col1 == p->N)
+                    brc = build_store_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base, true);
+                else
+                    brc = build_store_csc_host(p, colptr, rowval, idx_bytes, idx_base);
+            }
             if (d_cp) (void)hipFree(d_cp);
             if (d_rv) (void)hipFree(d_rv);
             if (d_cv) (void)hipFree(d_cv);
@@ -241,7 +247,7 @@ static int csc_device_impl(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipGetLastError();
     if (res == PBR_DONE) {
-        if (brc == FD_OK) brc = build_store_csc(p, colptr_dev, rowval_dev, idx_bytes, idx_base);
+        if (brc == FD_OK) brc = build_store_csc(p, colptr_dev, rowval_dev, idx_bytes, idx_base, true);
         if (brc != FD_OK) { fd_plan_destroy(p); *out = nullptr; return brc; }
         p->nouts = 1;
         p->out_len[0] = cp[1] - cp[0];

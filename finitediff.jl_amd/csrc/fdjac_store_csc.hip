@@ -41,9 +41,34 @@ __global__ void __launch_bounds__(kBlock) k_csc_valid_coloring(const int *__rest
     if (bad) atomicOr(conflict, 1);
 }
 
+// The same question for a plan with a COLUMN WINDOW: the colour's point perturbs every column of the colour, also those outside the
+// window, so a column outside that shares a LOCAL row with a local column of its colour makes the colouring invalid for this plan
+// too (found by the randomised sweep: a locally valid, globally invalid colouring stored single-coordinate differences where the
+// reference's columns collide).  All N columns of the caller's raw arrays, rows of the local row range only.
+template <typename IT, typename CT>
+__global__ void __launch_bounds__(kBlock) k_csc_valid_coloring_raw(const IT *__restrict__ colptr, const IT *__restrict__ rowval, int64_t base, int64_t N,
+                                                                   const CT *__restrict__ color, int64_t row0, int64_t row1, int words,
+                                                                   unsigned long long *__restrict__ mask, int *__restrict__ conflict)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    const int c = (int)color[j];
+    if (c == (int)(CT)(-1)) return;
+    const unsigned long long bit = 1ull << (c & 63);
+    bool bad = false;
+    for (int64_t q = (int64_t)colptr[j] - base; q < (int64_t)colptr[j + 1] - base; ++q) {
+        const int64_t r = (int64_t)rowval[q] - base;
+        if (r < row0 || r >= row1) continue;
+        const unsigned long long old = atomicOr(mask + (r - row0) * words + (c >> 6), bit);
+        bad = bad || (old & bit) != 0;
+    }
+    if (bad) atomicOr(conflict, 1);
+}
+
 // colptr_dev / rowval_dev: device pointers addressed with ABSOLUTE column / entry indices (as device_build_csc takes them).
+// full: ALL columns / entries of the pattern are behind them (not only the local slice).
 template <typename IT>
-static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_dev, int idx_base)
+static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_dev, int idx_base, bool full)
 {
     hipStream_t s = p->ctx->stream;
     const int64_t n = p->nnz_local, ncols = p->col1 - p->col0;
@@ -62,14 +87,21 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
     p->sc_valid = false;
     const int64_t R = p->row1 - p->row0;
     const int words = (int)((std::max<int64_t>(p->C, 1) + 63) / 64);
-    if (n > 0 && R > 0 && R * words * 8 <= ((int64_t)1 << 30)) {
+    const bool windowed = !(p->col0 == 0 && p->col1 == p->N);
+    if (n > 0 && R > 0 && R * words * 8 <= ((int64_t)1 << 30) && (!windowed || full)) {
         unsigned long long *d_mask = nullptr;
         int *d_conflict = nullptr;
         if (hipMalloc((void **)&d_mask, (size_t)(R * words) * 8) == hipSuccess && hipMalloc((void **)&d_conflict, sizeof(int)) == hipSuccess) {
             (void)hipMemsetAsync(d_mask, 0, (size_t)(R * words) * 8, s);
             (void)hipMemsetAsync(d_conflict, 0, sizeof(int), s);
-            const unsigned g = (unsigned)((ncols + kBlock - 1) / kBlock);
-            if (p->color8)
+            const unsigned g = (unsigned)((ncols + kBlock - 1) / kBlock), gN = (unsigned)((p->N + kBlock - 1) / kBlock);
+            if (windowed && p->color8)
+                hipLaunchKernelGGL((k_csc_valid_coloring_raw<IT, uint8_t>), dim3(gN), dim3(kBlock), 0, s, colptr_dev, rowval_dev, (int64_t)idx_base, p->N,
+                                   (const uint8_t *)p->d_color, p->row0, p->row1, words, d_mask, d_conflict);
+            else if (windowed)
+                hipLaunchKernelGGL((k_csc_valid_coloring_raw<IT, int32_t>), dim3(gN), dim3(kBlock), 0, s, colptr_dev, rowval_dev, (int64_t)idx_base, p->N,
+                                   (const int32_t *)p->d_color, p->row0, p->row1, words, d_mask, d_conflict);
+            else if (p->color8)
                 hipLaunchKernelGGL((k_csc_valid_coloring<uint8_t>), dim3(g), dim3(kBlock), 0, s, p->d_sc_colptr, p->d_sc_rowval, p->col0, ncols,
                                    (const uint8_t *)p->d_color, p->row0, words, d_mask, d_conflict);
             else
@@ -96,30 +128,33 @@ static bool store_csc_wanted(const fd_plan *p)
            p->nnz_local < ((int64_t)1 << 31) && p->M < ((int64_t)1 << 31) && p->d_color != nullptr;
 }
 
-static int build_store_csc(fd_plan *p, const void *colptr_dev, const void *rowval_dev, int idx_bytes, int idx_base)
+static int build_store_csc(fd_plan *p, const void *colptr_dev, const void *rowval_dev, int idx_bytes, int idx_base, bool full)
 {
     if (!store_csc_wanted(p)) return FD_OK;
-    return idx_bytes == 8 ? build_store_csc_t<int64_t>(p, (const int64_t *)colptr_dev, (const int64_t *)rowval_dev, idx_base)
-                          : build_store_csc_t<int32_t>(p, (const int32_t *)colptr_dev, (const int32_t *)rowval_dev, idx_base);
+    return idx_bytes == 8 ? build_store_csc_t<int64_t>(p, (const int64_t *)colptr_dev, (const int64_t *)rowval_dev, idx_base, full)
+                          : build_store_csc_t<int32_t>(p, (const int32_t *)colptr_dev, (const int32_t *)rowval_dev, idx_base, full);
 }
 
-// the same from HOST arrays: the local slices are uploaded first
+// the same from HOST arrays: the local slices are uploaded first -- all of the pattern for a plan with a column window (its
+// colouring is checked against every column, see k_csc_valid_coloring_raw)
 static int build_store_csc_host(fd_plan *p, const void *colptr, const void *rowval, int idx_bytes, int idx_base)
 {
     if (!store_csc_wanted(p)) return FD_OK;
     const size_t ib = (size_t)idx_bytes;
-    const int64_t ncols = p->col1 - p->col0, e0 = p->entry_begin, n = p->nnz_local;
+    const bool windowed = !(p->col0 == 0 && p->col1 == p->N);
+    const int64_t c0 = windowed ? 0 : p->col0, c1 = windowed ? p->N : p->col1;
+    const int64_t e0 = load_idx(colptr, idx_bytes, c0) - idx_base, e1 = load_idx(colptr, idx_bytes, c1) - idx_base;
     void *d_cp = nullptr, *d_rv = nullptr;
-    hipError_t e = hipMalloc(&d_cp, ib * (size_t)(ncols + 1));
-    if (e == hipSuccess) e = hipMalloc(&d_rv, ib * (size_t)n);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cp, (const char *)colptr + ib * (size_t)p->col0, ib * (size_t)(ncols + 1), hipMemcpyHostToDevice, p->ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rv, (const char *)rowval + ib * (size_t)e0, ib * (size_t)n, hipMemcpyHostToDevice, p->ctx->stream);
+    hipError_t e = hipMalloc(&d_cp, ib * (size_t)(c1 - c0 + 1));
+    if (e == hipSuccess) e = hipMalloc(&d_rv, ib * (size_t)std::max<int64_t>(e1 - e0, 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cp, (const char *)colptr + ib * (size_t)c0, ib * (size_t)(c1 - c0 + 1), hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess && e1 > e0) e = hipMemcpyAsync(d_rv, (const char *)rowval + ib * (size_t)e0, ib * (size_t)(e1 - e0), hipMemcpyHostToDevice, p->ctx->stream);
     int rc = FD_OK;
     if (e != hipSuccess) {
         set_error("uploading the pattern for the storing launch failed: %s", hipGetErrorString(e));
         rc = FD_ERR_HIP;
     } else {
-        rc = build_store_csc(p, (const char *)d_cp - ib * (size_t)p->col0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base);
+        rc = build_store_csc(p, (const char *)d_cp - ib * (size_t)c0, (const char *)d_rv - ib * (size_t)e0, idx_bytes, idx_base, windowed);
     }
     (void)hipStreamSynchronize(p->ctx->stream);
     if (d_cp) (void)hipFree(d_cp);

@@ -4,6 +4,7 @@ fd_csc_store in include/fdjac_device.h) and the functor families that store colu
 path (materialised points -> plain f! -> k_decompress_*: the same operations on the same operands), against the CPU oracle within
 the stated tolerance, and the number of f! evaluations against the reference's (1 + C / 2C).
 Reference: src/jacobians.jl:559-568, 600-609; ext/FiniteDiffSparseArraysExt.jl:38-47."""
+import os
 import numpy as np
 import pytest
 
@@ -349,3 +350,70 @@ def test_lap7_pattern_note_remembers_a_verified_pattern(fdtype):
         ps3.jacobian(fn, x, [a])
         ph3.jacobian(fn, x, [b])
         assert torch.equal(a.view(torch.int64), b.view(torch.int64)), rep
+
+
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_random_grids_through_the_7_point_column_kernel(seed):
+    # Randomised: grids of random shape (thin, flat, degenerate: a dimension of 1 or 2), random column windows, colour chunks,
+    # uncoloured columns, valid and invalid colourings, forward (f(x) rows formed inside the launch / from f_in) and central
+    # differences, repeated calls on one plan (checking launch, then launches that trust the plan's note) -- the window kernel, its
+    # boundary path and the functor fallback must give the bits of the hand-over path every time.  (A grid that degenerates to an
+    # exact band -- nx x 1 x 1 -- keeps the band's own store capability, which this launcher does not have: the hand-over path.)
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "7000")) + seed)
+    shapes = [(int(rng.integers(3, 40)), int(rng.integers(3, 30)), int(rng.integers(3, 20))), (int(rng.integers(1, 4)), int(rng.integers(1, 60)), int(rng.integers(1, 60))),
+              (int(rng.integers(3, 200)), int(rng.integers(1, 3)), int(rng.integers(1, 8))), (int(rng.integers(2, 70)), int(rng.integers(2, 70)), 2)]
+    nx, ny, nz = shapes[seed % 4]
+    N = nx * ny * nz
+    colptr, rowval, colors = stencil7_csc(nx, ny, nz)
+    style = rng.random()
+    if style < 0.2:
+        colors = colors.copy()
+        colors[rng.integers(0, N, size=min(5, N))] = 0
+    elif style < 0.35:
+        colors = np.ones(N, dtype=np.int64)                 # invalid: every column one colour
+    elif style < 0.5:
+        colors = (np.arange(N) % 11 + 1).astype(np.int64)   # invalid for most grids
+    fdtype = "forward" if rng.random() < 0.5 else "central"
+    kw = {}
+    if rng.random() < 0.35 and N > 8:
+        a = int(rng.integers(0, N // 2))
+        kw["col_window"] = (a, int(rng.integers(a + 1, N + 1)))
+    C = int(colors.max())
+    if rng.random() < 0.3 and C > 2:
+        kw["scratch_bytes"] = 2 * 2 * 2 * N * 8 + 4096       # two colours per chunk
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    f = fd.BuiltinF("lap7", nx, ny, nz)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, **kw)
+    ps.set_lazy(f)
+    ph = fd.make_plan(J, J, colors, fdtype, **kw)
+    n = ps.out_len(0)
+    assert n == ph.out_len(0)
+    for rep in range(3):
+        x = _dev(rng.random(N) + 0.05)
+        fin = _dev(rng.random(N)) if (fdtype == "forward" and rep == 2) else None
+        a, b = _dev(np.full(n, np.nan)), _dev(np.full(n, np.nan))
+        ps.jacobian(f, x, [a], f_in=fin)
+        ph.jacobian(f, x, [b], f_in=fin)
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (nx, ny, nz, fdtype, kw, rep, style)
+
+
+def test_window_plan_checks_its_colouring_against_all_columns():
+    # Found by the sweep above: a colouring that is valid among the columns of a column window but not against the columns outside
+    # it (which the colour's point perturbs too).  The plan must not call it valid -- single-coordinate differences would differ
+    # from what the reference's colliding columns give.  Grid 87 x 1 x 3, colours k mod 11 + 1, columns [98, 132).
+    nx, ny, nz = 87, 1, 3
+    N = nx * ny * nz
+    colptr, rowval, _ = stencil7_csc(nx, ny, nz)
+    colors = (np.arange(N) % 11 + 1).astype(np.int64)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    f = fd.BuiltinF("lap7", nx, ny, nz)
+    x = _dev(np.random.default_rng(2).random(N) + 0.05)
+    for fdtype in ("forward", "central"):
+        ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, col_window=(98, 132))
+        ps.set_lazy(f)
+        ph = fd.make_plan(J, J, colors, fdtype, col_window=(98, 132))
+        a, b = _dev(np.full(ps.out_len(0), np.nan)), _dev(np.full(ps.out_len(0), np.nan))
+        ps.jacobian(f, x, [a])
+        ph.jacobian(f, x, [b])
+        assert ps.info(fd.lib.INFO_LAZY_STORE) == 1
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), fdtype
