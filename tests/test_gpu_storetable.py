@@ -382,10 +382,18 @@ def test_random_grids_through_the_7_point_column_kernel(seed):
     if rng.random() < 0.3 and C > 2:
         kw["scratch_bytes"] = 2 * 2 * 2 * N * 8 + 4096       # two colours per chunk
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
-    f = fd.BuiltinF("lap7", nx, ny, nz)
-    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, **kw)
+    dtype = np.float32 if rng.random() < 0.3 else np.float64        # (fd32_*: the second instantiation of every kernel)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    if dtype == np.float32 and "scratch_bytes" in kw:
+        kw["scratch_bytes"] //= 2
+
+    def _dev(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=tdt, device="cuda")
+
+    f = fd.BuiltinF("lap7", nx, ny, nz, dtype=dtype)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, dtype=dtype, **kw)
     ps.set_lazy(f)
-    ph = fd.make_plan(J, J, colors, fdtype, **kw)
+    ph = fd.make_plan(J, J, colors, fdtype, dtype=dtype, **kw)
     n = ps.out_len(0)
     assert n == ph.out_len(0)
     for rep in range(3):
@@ -394,7 +402,8 @@ def test_random_grids_through_the_7_point_column_kernel(seed):
         a, b = _dev(np.full(n, np.nan)), _dev(np.full(n, np.nan))
         ps.jacobian(f, x, [a], f_in=fin)
         ph.jacobian(f, x, [b], f_in=fin)
-        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (nx, ny, nz, fdtype, kw, rep, style)
+        assert not torch.isnan(b).any() or n == 0
+        assert torch.equal(a, b), (nx, ny, nz, fdtype, kw, rep, style, dtype)
 
 
 def test_window_plan_checks_its_colouring_against_all_columns():
