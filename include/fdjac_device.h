@@ -526,7 +526,9 @@ __host__ inline unsigned fd_xcd_grid(long long n) { return (unsigned)(8 * ((n + 
  * 1.0 TB/s on the 7-point pattern).  When every lane of the wavefront writes its whole column (no colour chunk skips one) and the
  * run fits, the values are staged in a wave-private LDS window in storage order and leave as dense, aligned 16-byte stores
  * (fd_wave_store_window); otherwise each value is stored directly.  All 64 lanes call begin and flush. */
+#ifndef FD_CSC_WAVE_CAP
 #define FD_CSC_WAVE_CAP 1024      /* elements of the window per wavefront */
+#endif
 template <typename T> struct fd_csc_wave_run {
     T *out;
     T *win;
