@@ -40,6 +40,25 @@ def main():
         assert torch.equal(buf, want), ("allgather", it)
     assert p2p.status() == 0
 
+    # (1b) what one exchange costs here (two processes sharing ONE GPU -- launch + flag polling, no xGMI hop): printed, not asserted
+    t_us = {}
+    for nS in (8, 1000, 7750):                          # 64 B, 8 KB, 62 KB per rank (the c4 step-size partials are 62 KB)
+        buf = torch.zeros(world * nS, dtype=torch.float64, device=dev)
+        for _ in range(20):
+            p2p.allgather(buf, nS)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            p2p.allgather(buf, nS)
+        e1.record()
+        torch.cuda.synchronize()
+        t_us[nS * 8] = e0.elapsed_time(e1) * 1e3 / 200
+    assert p2p.status() == 0
+    if rank == 0:
+        print("p2p allgather per exchange (2 processes, 1 GPU): " + ", ".join("%d B: %.1f us" % kv for kv in t_us.items()))
+
     # (2) halo channel, interleaved with all-gathers (independent epochs per channel)
     N, halo = 4096, 2
     cuts = [0, N // 2, N] if world == 2 else list(np.linspace(0, N, world + 1).astype(int))
