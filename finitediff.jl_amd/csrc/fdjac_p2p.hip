@@ -38,6 +38,7 @@ struct fd_p2p {
     char *peer[kP2PMaxRanks] = {};            // the mailboxes as mapped here (peer[rank] == local)
     bool mapped[kP2PMaxRanks] = {};
     char **d_peer = nullptr;                  // device copy of peer[]
+    unsigned *d_arrived = nullptr;            // per-peer share counters of a put split over several workgroups (zero between launches)
     int *d_err = nullptr;                     // device error word (pinned host memory mapped to the device: readable without a sync)
     int *h_err = nullptr;
     uint64_t epoch[2] = {0, 0};
@@ -47,18 +48,43 @@ struct fd_p2p {
 
 namespace fdjac {
 
+// Both copies keep FOUR 8-byte system-scope accesses per lane in flight (one round trip through fine-grained memory per 8 KB of
+// a workgroup's share instead of one per 2 KB: the 62 KB step-size partials took 31 dependent round trips before).
 __device__ __forceinline__ void p2p_copy_out(char *dst, const char *src, int64_t bytes)
 {
     // payload written by a peer: read it at system scope (never from a stale L2 line), 8 bytes per lane
-    for (int64_t o = (int64_t)threadIdx.x * 8; o < bytes; o += (int64_t)blockDim.x * 8) {
-        const unsigned long long v = __hip_atomic_load((const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        *(unsigned long long *)(dst + o) = v;
+    const int64_t step = (int64_t)blockDim.x * 8;
+    int64_t o = (int64_t)threadIdx.x * 8;
+    for (; o + 3 * step < bytes; o += 4 * step) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load((const unsigned long long *)(src + o + u * step), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(unsigned long long *)(dst + o + u * step) = v[u];
     }
+    for (; o < bytes; o += step)
+        *(unsigned long long *)(dst + o) = __hip_atomic_load((const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void p2p_copy_in(char *dst, const char *src, int64_t bytes)
 {
-    for (int64_t o = (int64_t)threadIdx.x * 8; o < bytes; o += (int64_t)blockDim.x * 8)
+    const int64_t step = (int64_t)blockDim.x * 8;
+    int64_t o = (int64_t)threadIdx.x * 8;
+    for (; o + 3 * step < bytes; o += 4 * step) {
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const unsigned long long *)(src + o + u * step);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __hip_atomic_store((unsigned long long *)(dst + o + u * step), v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (; o < bytes; o += step)
         __hip_atomic_store((unsigned long long *)(dst + o), *(const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// workgroup `part` of `parts` serving one peer copies [lo, hi) of the payload (8-byte granules)
+__device__ __forceinline__ void p2p_part(int64_t bytes, int part, int parts, int64_t &lo, int64_t &hi)
+{
+    const int64_t per = ((bytes / 8 + parts - 1) / parts) * 8;
+    lo = (int64_t)part * per < bytes ? (int64_t)part * per : bytes;
+    hi = lo + per < bytes ? lo + per : bytes;
 }
 
 // targets[b]: the peer workgroup b writes to; src_off[b] / dst_sub[b]: where in `buf` its payload starts and at which byte of this
@@ -69,31 +95,45 @@ struct P2PPut {
     int n;
 };
 __global__ void __launch_bounds__(kBlock) k_p2p_put(char *const *__restrict__ peer, const char *__restrict__ buf, P2PPut put, int nranks, int rank,
-                                                    int64_t slot_bytes, uint64_t epoch, int all, int64_t chan_off)
+                                                    int64_t slot_bytes, uint64_t epoch, int all, int64_t chan_off, int parts, unsigned *__restrict__ arrived)
 {
-    // all != 0: the all-gather form -- workgroup b serves peer b (b != rank), payload = this rank's slot of buf
+    // all != 0: the all-gather form -- workgroups b*parts .. b*parts + parts-1 serve peer b (b != rank), payload = this rank's slot
+    // of buf, split into `parts` shares; the LAST share to land raises the flag (arrived[b]: a counter in this rank's own memory)
+    const int b = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
     int target;
     int64_t src_off, dst_sub, bytes;
     if (all) {
-        target = blockIdx.x;
+        target = b;
         if (target == rank) return;
         src_off = put.src_off[0];
         dst_sub = 0;
         bytes = put.bytes[0];
     } else {
-        if ((int)blockIdx.x >= put.n) return;
-        target = put.target[blockIdx.x];
-        src_off = put.src_off[blockIdx.x];
-        dst_sub = put.dst_sub[blockIdx.x];
-        bytes = put.bytes[blockIdx.x];
+        if (b >= put.n) return;
+        target = put.target[b];
+        src_off = put.src_off[b];
+        dst_sub = put.dst_sub[b];
+        bytes = put.bytes[b];
     }
     char *mb = peer[target] + chan_off;
     char *slot = mb + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + rank) * slot_bytes + dst_sub;
-    p2p_copy_in(slot, buf + src_off, bytes);
+    int64_t lo, hi;
+    p2p_part(bytes, part, parts, lo, hi);
+    p2p_copy_in(slot + lo, buf + src_off + lo, hi - lo);
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0)      // this rank's flag in the peer's mailbox: "my slot of exchange `epoch` is complete"
-        __hip_atomic_store((unsigned long long *)(mb + (int64_t)rank * kP2PFlagStride), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        bool last = true;
+        if (parts > 1) {
+            last = __hip_atomic_fetch_add(arrived + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(parts - 1);
+            if (last) {
+                __hip_atomic_store(arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
+                __threadfence_system();
+            }
+        }
+        if (last)              // this rank's flag in the peer's mailbox: "my slot of exchange `epoch` is complete"
+            __hip_atomic_store((unsigned long long *)(mb + (int64_t)rank * kP2PFlagStride), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct P2PGet {
@@ -102,23 +142,25 @@ struct P2PGet {
     int n;
 };
 __global__ void __launch_bounds__(kBlock) k_p2p_wait(char *__restrict__ local_base, char *__restrict__ buf, P2PGet get, int nranks, int rank, int64_t slot_bytes,
-                                                     uint64_t epoch, int all, int64_t timeout_ticks, int *__restrict__ err, int64_t chan_off)
+                                                     uint64_t epoch, int all, int64_t timeout_ticks, int *__restrict__ err, int64_t chan_off, int parts)
 {
+    // `parts` workgroups per sender: each polls the sender's flag itself, then copies its share of the slot
     char *local = local_base + chan_off;
+    const int b = (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
     int sender;
     int64_t dst_off, src_sub, bytes;
     if (all) {
-        sender = blockIdx.x;
+        sender = b;
         if (sender == rank) return;
         dst_off = (int64_t)sender * get.bytes[0];
         src_sub = 0;
         bytes = get.bytes[0];
     } else {
-        if ((int)blockIdx.x >= get.n) return;
-        sender = get.sender[blockIdx.x];
-        dst_off = get.dst_off[blockIdx.x];
-        src_sub = get.src_sub[blockIdx.x];
-        bytes = get.bytes[blockIdx.x];
+        if (b >= get.n) return;
+        sender = get.sender[b];
+        dst_off = get.dst_off[b];
+        src_sub = get.src_sub[b];
+        bytes = get.bytes[b];
     }
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
@@ -135,7 +177,9 @@ __global__ void __launch_bounds__(kBlock) k_p2p_wait(char *__restrict__ local_ba
     __syncthreads();
     if (!s_ok) return;
     const char *slot = local + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + sender) * slot_bytes + src_sub;
-    p2p_copy_out(buf + dst_off, slot, bytes);
+    int64_t lo, hi;
+    p2p_part(bytes, part, parts, lo, hi);
+    p2p_copy_out(buf + dst_off + lo, slot + lo, hi - lo);
 }
 
 }  // namespace fdjac
@@ -177,9 +221,13 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_err, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *p->h_err = 0; e = hipHostGetDevicePointer((void **)&p->d_err, p->h_err, 0); }
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_peer, sizeof(char *) * kP2PMaxRanks);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_arrived, sizeof(unsigned) * kP2PMaxRanks);
+    if (e == hipSuccess) e = hipMemset(p->d_arrived, 0, sizeof(unsigned) * kP2PMaxRanks);
     if (e != hipSuccess) {
         set_error("setting up the mailbox failed: %s", hipGetErrorString(e));
         if (p->h_err) (void)hipHostFree(p->h_err);
+        if (p->d_peer) (void)hipFree(p->d_peer);
+        if (p->d_arrived) (void)hipFree(p->d_arrived);
         (void)hipFree(p->local);
         delete p;
         return FD_ERR_HIP;
@@ -235,6 +283,7 @@ int fd_p2p_destroy(fd_p2p *p)
     for (int r = 0; r < p->nranks; ++r)
         if (p->mapped[r] && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
     if (p->d_peer) (void)hipFree(p->d_peer);
+    if (p->d_arrived) (void)hipFree(p->d_arrived);
     if (p->h_err) (void)hipHostFree(p->h_err);
     if (p->local) (void)hipFree(p->local);
     delete p;
@@ -282,10 +331,12 @@ int fd_p2p_allgather(fd_p2p *p, void *buf, int64_t bytes)
     put.bytes[0] = bytes;
     P2PGet get = {};
     get.bytes[0] = bytes;
-    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)p->nranks), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank,
-                       p->slot_bytes, epoch, 1, (int64_t)0);
-    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)p->nranks), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank, p->slot_bytes,
-                       epoch, 1, p2p_timeout_ticks(), p->d_err, (int64_t)0);
+    // 8 KB per workgroup (one pass of four accesses per lane), at most 16 workgroups per peer
+    const int parts = (int)std::min<int64_t>(std::max<int64_t>((bytes + 8191) / 8192, 1), 16);
+    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)(p->nranks * parts)), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank,
+                       p->slot_bytes, epoch, 1, (int64_t)0, parts, p->d_arrived);
+    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)(p->nranks * parts)), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank,
+                       p->slot_bytes, epoch, 1, p2p_timeout_ticks(), p->d_err, (int64_t)0, parts);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
@@ -318,9 +369,9 @@ int fd_p2p_halo_exchange(fd_p2p *p, void *buf, int64_t own_begin, int64_t own_en
         get.sender[get.n] = p->rank + 1; get.dst_off[get.n] = own_end * elem_bytes; get.src_sub[get.n] = hb; get.bytes[get.n] = hb; ++get.n;
     }
     hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)put.n), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank, p->slot_bytes,
-                       epoch, 0, chan1);
+                       epoch, 0, chan1, 1, p->d_arrived);
     hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)get.n), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank, p->slot_bytes, epoch, 0,
-                       p2p_timeout_ticks(), p->d_err, chan1);
+                       p2p_timeout_ticks(), p->d_err, chan1, 1);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
