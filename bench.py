@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--small-messages", choices=["rccl", "p2p"], default="rccl",
                     help="N>1: how the per-step small messages travel (halo of x, partial sums of the sharded step-size reduction, solve "
                          "interface): RCCL collectives, or direct peer-to-peer stores into the ranks' mailboxes (fd_comm_enable_p2p / "
-                         "fd_p2p_*: hipIpc-mapped HBM, two kernels per exchange, no proxy); the bulk nzval gather is RCCL either way")
+                         "fd_p2p_*: hipIpc-mapped HBM, one kernel per exchange, no proxy); the bulk nzval gather is RCCL either way")
     ap.add_argument("--weak", action="store_true",
                     help="N>1: weak scaling -- N = gpus x 10^7 columns (each rank keeps the single-GPU problem size) instead of "
                          "splitting the fixed N = 10^7 problem; the line says scaling = weak")

@@ -6,11 +6,13 @@
 // kilobytes: 10-25 us each on comparable parts, against 6.5 us of sharded compute.  xGMI is a load / store
 // fabric: a kernel can write a peer's HBM directly.  So every rank owns a MAILBOX in its HBM, maps the mailboxes of all peers
 // (hipIpc handles, exchanged once by whatever the host has -- or by RCCL itself, fd_comm_enable_p2p), and an exchange is
-//     put    one workgroup per peer copies this rank's slot into the peer's mailbox, fences at system scope and then raises this
-//            rank's flag in the peer's mailbox to the exchange's epoch (a release store at system scope);
-//     wait   one workgroup per sender polls that sender's flag in the LOCAL mailbox (system-scope acquire loads, bounded by a
-//            wall-clock timeout that raises an error word instead of hanging the GPU), then copies the sender's slot out.
-// Two kernels on the caller's stream, no host involvement, no proxy.  Slots are double-buffered by epoch parity: a rank can only
+//     put    per peer, one workgroup per 8 KB share of this rank's slot copies it into the peer's mailbox and fences at system
+//            scope; the last share to land raises this rank's flag in the peer's mailbox to the exchange's epoch (a release
+//            store at system scope);
+//     wait   the same workgroup then polls that peer's flag in the LOCAL mailbox (system-scope acquire loads, bounded by a
+//            wall-clock timeout that raises an error word instead of hanging the GPU) and copies its share of the peer's slot out.
+// ONE kernel on the caller's stream (k_p2p_exchange; as two launches an exchange took 2 us longer,
+// profiles/r04_zzz_p2p_mailbox_latency.md), no host involvement, no proxy.  Slots are double-buffered by epoch parity: a rank can only
 // reach exchange e + 2 after every peer has released e + 1, i.e. after it has finished reading e (stream order on the peer).
 // RCCL stays for what it is good at: the bulk assembly of nzval (fd_comm_gatherv / fd_comm_allgather of MBs).
 //
@@ -94,7 +96,7 @@ struct P2PPut {
     int64_t src_off[4], dst_sub[4], bytes[4];
     int n;
 };
-__global__ void __launch_bounds__(kBlock) k_p2p_put(char *const *__restrict__ peer, const char *__restrict__ buf, P2PPut put, int nranks, int rank,
+__device__ __forceinline__ void p2p_put_part(char *const *__restrict__ peer, const char *__restrict__ buf, P2PPut put, int nranks, int rank,
                                                     int64_t slot_bytes, uint64_t epoch, int all, int64_t chan_off, int parts, unsigned *__restrict__ arrived)
 {
     // all != 0: the all-gather form -- workgroups b*parts .. b*parts + parts-1 serve peer b (b != rank), payload = this rank's slot
@@ -141,7 +143,7 @@ struct P2PGet {
     int64_t dst_off[4], src_sub[4], bytes[4];
     int n;
 };
-__global__ void __launch_bounds__(kBlock) k_p2p_wait(char *__restrict__ local_base, char *__restrict__ buf, P2PGet get, int nranks, int rank, int64_t slot_bytes,
+__device__ __forceinline__ void p2p_wait_part(char *__restrict__ local_base, char *__restrict__ buf, P2PGet get, int nranks, int rank, int64_t slot_bytes,
                                                      uint64_t epoch, int all, int64_t timeout_ticks, int *__restrict__ err, int64_t chan_off, int parts)
 {
     // `parts` workgroups per sender: each polls the sender's flag itself, then copies its share of the slot
@@ -180,6 +182,17 @@ __global__ void __launch_bounds__(kBlock) k_p2p_wait(char *__restrict__ local_ba
     int64_t lo, hi;
     p2p_part(bytes, part, parts, lo, hi);
     p2p_copy_out(buf + dst_off + lo, slot + lo, hi - lo);
+}
+
+// One exchange = ONE launch: every workgroup first delivers its share to its peer, then waits for the same peer's share of the
+// same exchange.  No workgroup waits for another workgroup of its own launch, and a peer's puts never wait for anything, so the
+// order is free of cycles whatever the residency.
+__global__ void __launch_bounds__(kBlock) k_p2p_exchange(char *const *__restrict__ peer, char *__restrict__ local_base, char *__restrict__ buf, P2PPut put,
+                                                         P2PGet get, int nranks, int rank, int64_t slot_bytes, uint64_t epoch, int all, int64_t chan_off,
+                                                         int parts, unsigned *__restrict__ arrived, int64_t timeout_ticks, int *__restrict__ err)
+{
+    p2p_put_part(peer, buf, put, nranks, rank, slot_bytes, epoch, all, chan_off, parts, arrived);
+    p2p_wait_part(local_base, buf, get, nranks, rank, slot_bytes, epoch, all, timeout_ticks, err, chan_off, parts);
 }
 
 }  // namespace fdjac
@@ -333,10 +346,8 @@ int fd_p2p_allgather(fd_p2p *p, void *buf, int64_t bytes)
     get.bytes[0] = bytes;
     // 8 KB per workgroup (one pass of four accesses per lane), at most 16 workgroups per peer
     const int parts = (int)std::min<int64_t>(std::max<int64_t>((bytes + 8191) / 8192, 1), 16);
-    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)(p->nranks * parts)), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank,
-                       p->slot_bytes, epoch, 1, (int64_t)0, parts, p->d_arrived);
-    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)(p->nranks * parts)), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank,
-                       p->slot_bytes, epoch, 1, p2p_timeout_ticks(), p->d_err, (int64_t)0, parts);
+    hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)(p->nranks * parts)), dim3(kBlock), 0, p->ctx->stream, p->d_peer, p->local, (char *)buf, put, get, p->nranks,
+                       p->rank, p->slot_bytes, epoch, 1, (int64_t)0, parts, p->d_arrived, p2p_timeout_ticks(), p->d_err);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
@@ -368,10 +379,8 @@ int fd_p2p_halo_exchange(fd_p2p *p, void *buf, int64_t own_begin, int64_t own_en
         put.target[put.n] = p->rank + 1; put.src_off[put.n] = (own_end - halo) * elem_bytes; put.dst_sub[put.n] = 0; put.bytes[put.n] = hb; ++put.n;
         get.sender[get.n] = p->rank + 1; get.dst_off[get.n] = own_end * elem_bytes; get.src_sub[get.n] = hb; get.bytes[get.n] = hb; ++get.n;
     }
-    hipLaunchKernelGGL(k_p2p_put, dim3((unsigned)put.n), dim3(kBlock), 0, p->ctx->stream, p->d_peer, (const char *)buf, put, p->nranks, p->rank, p->slot_bytes,
-                       epoch, 0, chan1, 1, p->d_arrived);
-    hipLaunchKernelGGL(k_p2p_wait, dim3((unsigned)get.n), dim3(kBlock), 0, p->ctx->stream, p->local, (char *)buf, get, p->nranks, p->rank, p->slot_bytes, epoch, 0,
-                       p2p_timeout_ticks(), p->d_err, chan1, 1);
+    hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)put.n), dim3(kBlock), 0, p->ctx->stream, p->d_peer, p->local, (char *)buf, put, get, p->nranks, p->rank,
+                       p->slot_bytes, epoch, 0, chan1, 1, p->d_arrived, p2p_timeout_ticks(), p->d_err);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }

@@ -476,9 +476,9 @@ int fd_comm_halo_exchange(fd_comm *comm, void *buf, int64_t own_begin, int64_t o
  * The per-step exchanges of a time-stepping loop -- the halo of x, the partial sums of the step-size reduction (62 KB), the
  * interface packets of the sharded solve (64 B per rank) -- are a few kilobytes each: as RCCL collectives they cost a
  * general-purpose machine's latency (10-25 us each), as stores into a peer's HBM over xGMI a few microseconds.  Every rank owns a
- * MAILBOX in its HBM and maps its peers' (hipIpc handles); an exchange is two kernels on the context's stream: put (copy into the
- * peers' mailboxes, system-scope fence, raise a flag) and wait (poll the flags, bounded by FDJAC_P2P_TIMEOUT_MS = 2000 by default
- * -- a missing peer raises fd_p2p_status instead of hanging the GPU -- then copy out).  RCCL stays for the bulk assembly of nzval.
+ * MAILBOX in its HBM and maps its peers' (hipIpc handles); an exchange is ONE kernel on the context's stream: every workgroup first puts (copies its
+ * share into its peer's mailbox, system-scope fence, the last share raises a flag), then waits (polls the same peer's flag, bounded
+ * by FDJAC_P2P_TIMEOUT_MS = 2000 by default -- a missing peer raises fd_p2p_status instead of hanging the GPU -- then copies out).  RCCL stays for the bulk assembly of nzval.
  *   bootstrap: fd_p2p_create on every rank; every rank's fd_p2p_local_handle (FD_P2P_HANDLE_BYTES bytes) reaches every rank by
  *   whatever the host has (MPI.jl Allgather, a torch.distributed store); fd_p2p_connect(all handles in rank order) -- or
  *   fd_comm_enable_p2p, which does all of that over the RCCL communicator and routes the communicator's small messages
