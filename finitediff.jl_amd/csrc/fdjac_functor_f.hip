@@ -63,9 +63,10 @@ __global__ void k_lap7_note(unsigned long long *note, unsigned long long key)
     note[1] = 0;
 }
 
-// (no register budget: 96 / 80 VGPRs for 5 / 6 wavefronts per SIMD spill -- 365 / 579 us against 297, profiles/r04_y_lap7_taken_apart.md)
+// (five wavefronts per SIMD: the kernel needs 97 / 100 VGPRs unconstrained -- four wavefronts by eight registers -- and fits 96 with
+//  0 / 2 spilled: 193 -> 180 us; six -- 80 VGPRs -- spill the window: 305-317 / 223 us, profiles/r04_y_lap7_taken_apart.md)
 template <typename CT, int MODE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 5)
 k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
 {
     // (a stencil column holds at most 7 entries: 448 per wavefront -- half of the general window, twice the resident workgroups)
@@ -84,13 +85,16 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     const int l = (int)fd_div31((uint32_t)k, f.m_pl), rem = (int)k - l * pl, j = (int)fd_div31((uint32_t)rem, f.m_nx), i = rem - j * nx;
     // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid
     // (a grid point at least two cells away from every face: no bounds tests -- the guards are ~200 vector instructions per column)
-    const bool deep = i >= 2 && i < nx - 2 && j >= 2 && j < ny - 2 && l >= 2 && l < nz - 2;
+    const bool jl_deep = j >= 2 && j < ny - 2 && l >= 2 && l < nz - 2;
+    const bool deep = i >= 2 && i < nx - 2 && jl_deep;
     // Every load below is issued unconditionally and the whole window is waited for ONCE.  (Loads inside per-lane conditionals
     // are waited for one by one at the joins: 25 + 7 serial memory round trips made a forward-difference wavefront live 14 us,
-    // profiles/r04_y_lap7_taken_apart.md.)  A wavefront of deep grid points -- two cells from every face, the common case -- adds
-    // wave-uniform offsets to the pointer (scalar unit) and indexes with ONE 32-bit lane offset; other wavefronts load from a
-    // clamped address and select 0 for the coordinates outside the grid.
-    const bool wave_deep = __all(deep) && st.N < ((long long)1 << 28);
+    // profiles/r04_y_lap7_taken_apart.md.)  A wavefront whose grid points are two cells from the j and l faces -- the common case --
+    // adds wave-uniform offsets to the pointer (scalar unit) and indexes with ONE 32-bit lane offset: every address is inside the
+    // array, also where the wavefront runs across the end of a grid row (one wavefront in three at nx = 200); there the twelve
+    // coordinates with an i offset are selected to 0 where they lie outside the grid.  Other wavefronts load from a clamped address
+    // and select 0 for the coordinates outside the grid.
+    const bool wave_fast = __all(jl_deep) && st.N < ((long long)1 << 28);
     const uint32_t kb = (uint32_t)k * (uint32_t)sizeof(real_t);
     const real_t *base = (const real_t *)st.fx_base;
     real_t c0, xm1, xp1, xm2, xp2, ym1, yp1, ym2, yp2, zm1, zp1, zm2, zp2, xmym, xpym, xmyp, xpyp, xmzm, xpzm, xmzp, xpzp, ymzm, ypzm, ymzp, ypzp;
@@ -101,7 +105,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
 #else
 #define FD_LDX(p, off) (*(const real_t *)((const char *)((p) + (off)) + kb))
 #endif
-    if (wave_deep) {
+    if (wave_fast) {
         c0 = FD_LDX(x, 0);
         xm1 = FD_LDX(x, -1); xp1 = FD_LDX(x, 1); xm2 = FD_LDX(x, -2); xp2 = FD_LDX(x, 2);
         ym1 = FD_LDX(x, -nx); yp1 = FD_LDX(x, nx); ym2 = FD_LDX(x, -2 * nx); yp2 = FD_LDX(x, 2 * nx);
@@ -109,10 +113,17 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         xmym = FD_LDX(x, -nx - 1); xpym = FD_LDX(x, -nx + 1); xmyp = FD_LDX(x, nx - 1); xpyp = FD_LDX(x, nx + 1);
         xmzm = FD_LDX(x, -pl - 1); xpzm = FD_LDX(x, -pl + 1); xmzp = FD_LDX(x, pl - 1); xpzp = FD_LDX(x, pl + 1);
         ymzm = FD_LDX(x, -pl - nx); ypzm = FD_LDX(x, -pl + nx); ymzp = FD_LDX(x, pl - nx); ypzp = FD_LDX(x, pl + nx);
-        if (MODE == 0 && base) {
+        if (MODE == 0 && base) {       // (a row outside the grid does not exist: its value is never used)
             bc = FD_LDX(base, 0);
             bz0 = FD_LDX(base, -pl); by0 = FD_LDX(base, -nx); bx0 = FD_LDX(base, -1);
             bx1 = FD_LDX(base, 1); by1 = FD_LDX(base, nx); bz1 = FD_LDX(base, pl);
+        }
+        if (!__all(deep)) {            // the wavefront crosses the end of a grid row
+            const real_t z = 0;
+            const bool m1 = i >= 1, m2 = i >= 2, p1 = i < nx - 1, p2 = i < nx - 2;
+            xm1 = m1 ? xm1 : z; xm2 = m2 ? xm2 : z; xp1 = p1 ? xp1 : z; xp2 = p2 ? xp2 : z;
+            xmym = m1 ? xmym : z; xmyp = m1 ? xmyp : z; xmzm = m1 ? xmzm : z; xmzp = m1 ? xmzp : z;
+            xpym = p1 ? xpym : z; xpyp = p1 ? xpyp : z; xpzm = p1 ? xpzm : z; xpzp = p1 ? xpzp : z;
         }
     } else {
         // W(dl, dj, di) = x at grid point (i + di, j + dj, l + dl) for |dl| + |dj| + |di| <= 2, 0 outside the grid

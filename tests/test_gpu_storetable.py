@@ -90,7 +90,8 @@ def _run_pair(J, colors, fdtype, f, x, nnz, **plan_kw):
 
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
-@pytest.mark.parametrize("shape", [(20, 20, 20), (7, 5, 3), (33, 4, 9), (1, 1, 40), (64, 64, 2)])
+# (100, 6, 5): wavefronts of all three kinds -- two cells from every face, across the end of a grid row, on a j / l face
+@pytest.mark.parametrize("shape", [(20, 20, 20), (7, 5, 3), (33, 4, 9), (1, 1, 40), (64, 64, 2), (100, 6, 5)])
 def test_lap7_column_store_bit_identical_and_oracle(oracle, fdtype, shape):
     nx, ny, nz = shape
     N = nx * ny * nz
