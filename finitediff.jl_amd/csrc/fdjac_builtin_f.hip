@@ -937,6 +937,28 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     const bool interior = j >= 2 && j + 2 < ny && i0 >= 2 && i0 + TW + 2 <= nx;
     // window rows j-2 .. j+2, columns i-2 .. i+3 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
     real_t W[5][WC];
+    // The first and the last tile of a grid row (2 of 32 at nx = 4000) with two rows above and three below: every address of the
+    // window is inside the array, so the loads stay unconditional (an idle lane reads the tile's first column) and the coordinates
+    // outside the grid are SELECTED to 0 -- loads inside per-lane conditionals are waited for one by one (the 7-point kernel's
+    // lesson, profiles/r04_y_lap7_taken_apart.md).
+    const bool edge_tile = !interior && j >= 2 && j + 3 < ny;
+    if (edge_tile) {
+        const int64_t kl = act ? k : (int64_t)j * nx + i0;
+#pragma unroll
+        for (int dj = -2; dj <= 2; ++dj) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                r2_t v = {0, 0};
+                if (!((dj == -2 || dj == 2) && c != 1)) {
+                    const int ic = i + 2 * (c - 1);
+                    const r2_t w = *reinterpret_cast<const r2_t *>(x + (kl + (int64_t)dj * nx + 2 * (c - 1)));
+                    v.x = (act && ic >= 0 && ic < nx) ? w.x : (real_t)0;
+                    v.y = (act && ic + 1 >= 0 && ic + 1 < nx) ? w.y : (real_t)0;
+                }
+                W[dj + 2][2 * c] = v.x; W[dj + 2][2 * c + 1] = v.y;
+            }
+        }
+    } else
 #pragma unroll
     for (int dj = -2; dj <= 2; ++dj) {
         const bool rowok = interior || (act && j + dj >= 0 && j + dj < ny);
