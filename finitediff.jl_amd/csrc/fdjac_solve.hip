@@ -94,27 +94,37 @@ struct SrcUser {
     }
     template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t i) const { return load<NRHS>(i); }
     static constexpr bool kUnitRhs = true;    // right-hand sides 1, 2 are the unit vectors e_first, e_last: not fetched
-    // one coefficient of local row i: which = 0 a, 1 b, 2 c, 3 right-hand side
+    // the right-hand side of row i once its stored value d0 is there (the interface corrections of a sharded solve)
+    __device__ __forceinline__ double rhs_fix(int64_t i, double d0) const
+    {
+        if (adj) {
+            const double a0 = adj[0], a1 = adj[1];
+            d0 = i == 0 ? d0 - a0 : d0;
+            d0 = i == n - 1 ? d0 - a1 : d0;
+        }
+        return d0;
+    }
+    // (tri_fetch_rows issues every raw() of a tile before the first fix(): nothing consumes a load while others can still be issued)
+    __device__ __forceinline__ double raw(int which, int64_t i) const { return which == 3 ? (double)rhs[i] : value(which, i); }
+    __device__ __forceinline__ double fix(int which, int64_t i, double v) const { return which == 3 ? rhs_fix(i, v) : v; }
+    // one coefficient of local row i: which = 0 a, 1 b, 2 c, 3 right-hand side.  Every load is unconditional -- a coefficient that
+    // does not exist (a of the first row, c of the last) is fetched from the row's own diagonal entry and selected away: a load
+    // inside a per-lane conditional is waited for at the join, and tri_fetch_rows wants ALL of a tile's loads in flight at once.
     __device__ __forceinline__ double value(int which, int64_t i) const
     {
         const int64_t gi = g0 + i;
-        if (which == 3) {
-            double d0 = (double)rhs[i];
-            if (adj) {
-                if (i == 0) d0 -= adj[0];
-                if (i == n - 1) d0 -= adj[1];
-            }
-            return d0;
-        }
+        if (which == 3) return rhs_fix(i, (double)rhs[i]);
+        const bool has = which == 0 ? i > 0 : i + 1 < n;
+        const real_t *at;
         if (layout == FD_TRI_DIAGONALS) {
             const int64_t du0 = g0 > 0 ? g0 - 1 : 0;
-            if (which == 1) return alpha + beta * (double)p1[i];
-            if (which == 0) return i > 0 ? beta * (double)p0[i - 1] : 0.0;
-            return i + 1 < n ? beta * (double)p2[gi - du0] : 0.0;
+            at = which == 1 ? p1 + i : which == 0 ? (has ? p0 + (i - 1) : p1 + i) : (has ? p2 + (gi - du0) : p1 + i);
+        } else {
+            at = p0 + (3 * gi - e0 + (which == 1 || !has ? 0 : which == 0 ? -2 : 2));
         }
-        if (which == 1) return alpha + beta * (double)p0[3 * gi - e0];
-        if (which == 0) return i > 0 ? beta * (double)p0[3 * gi - 2 - e0] : 0.0;
-        return i + 1 < n ? beta * (double)p0[3 * gi + 2 - e0] : 0.0;
+        const double v = (double)*at;
+        if (which == 1) return alpha + beta * v;
+        return has ? beta * v : 0.0;
     }
 };
 
@@ -143,16 +153,21 @@ struct SrcLevel {
     }
     template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t k) const { return load<NRHS>(k); }
     static constexpr bool kUnitRhs = false;
-    // one coefficient of row k: which = 0 a, 1 b, 2 c, 3 + q right-hand side q (lane-consecutive k: dense loads)
+    __device__ __forceinline__ double raw(int which, int64_t k) const { return value(which, k); }
+    __device__ __forceinline__ double fix(int, int64_t, double v) const { return v; }
+    // one coefficient of row k: which = 0 a, 1 b, 2 c, 3 + q right-hand side q (lane-consecutive k: dense loads; all of them
+    // unconditional -- the last row reads its own summary in place of the next one's and selects the result away)
     __device__ __forceinline__ double value(int which, int64_t k) const
     {
         if (which == 0) return sum[0 * nc + k];
         const bool nxt = k + 1 < nc;
-        const double t = nxt ? sum[2 * nc + k] / sum[7 * nc + k + 1] : 0.0;
-        if (which == 1) return sum[1 * nc + k] - (nxt ? t * sum[6 * nc + k + 1] : 0.0);
-        if (which == 2) return nxt ? -t * sum[8 * nc + k + 1] : 0.0;
+        const int64_t kn = nxt ? k + 1 : k;
+        const double t = sum[2 * nc + k] / sum[7 * nc + kn];
+        if (which == 1) { const double s1 = sum[1 * nc + k], s6 = sum[6 * nc + kn]; return s1 - (nxt ? t * s6 : 0.0); }
+        if (which == 2) { const double s8 = sum[8 * nc + kn]; return nxt ? -t * s8 : 0.0; }
         const int q = which - 3;
-        return sum[(3 + q) * nc + k] - (nxt ? t * sum[(9 + q) * nc + k + 1] : 0.0);
+        const double sq = sum[(3 + q) * nc + k], s9 = sum[(9 + q) * nc + kn];
+        return sq - (nxt ? t * s9 : 0.0);
     }
 };
 
@@ -274,7 +289,14 @@ __device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             const int r = j * kBlock + (int)threadIdx.x;  // lane-consecutive rows
-            g[which][j] = r < rows ? src.value(which, row0 + r) : 0.0;
+            g[which][j] = src.raw(which, row0 + (r < rows ? r : (int)rows - 1));      // (unconditional: the tile's last row again)
+        }
+#pragma unroll
+    for (int which = 0; which < kRounds; ++which)
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int r = j * kBlock + (int)threadIdx.x;
+            g[which][j] = r < rows ? src.fix(which, row0 + r, g[which][j]) : 0.0;
         }
 #pragma unroll
     for (int which = 0; which < kRounds; ++which) {
@@ -332,12 +354,23 @@ __device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int64_t q = (int64_t)j * kBlock + threadIdx.x;
-        g[j] = (q >= qmin && q <= qmax) ? src.p0[lo + q] : (real_t)0;
+        g[j] = src.p0[lo + (q < qmin ? qmin : q > qmax ? qmax : q)];      // (unconditional, from a clamped position)
     }
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {                    // the right-hand side's loads are in flight behind them
         const int r = j * kBlock + (int)threadIdx.x;
-        gr[j] = r < rows ? src.value(3, row0 + r) : 0.0;
+        gr[j] = (double)src.rhs[row0 + (r < rows ? r : (int)rows - 1)];
+    }
+    // (the selects only after every load has been issued)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int64_t q = (int64_t)j * kBlock + threadIdx.x;
+        if (!(q >= qmin && q <= qmax)) g[j] = (real_t)0;
+    }
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+        const int r = j * kBlock + (int)threadIdx.x;
+        gr[j] = r < rows ? src.rhs_fix(row0 + r, gr[j]) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
