@@ -256,17 +256,30 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
 }
 
 // ---- FD_F_SPARSE ----------------------------------------------------------------------------------------------------------------
+#ifndef FD_SPARSE_U
+#define FD_SPARSE_U 4
+#endif
 struct SparseF {
     const int32_t *srow, *scol;      // the pattern by rows, ascending columns (device)
     template <typename T, class P> __device__ __forceinline__ T row(int64_t r, const P &X) const
     {
+        // FD_SPARSE_U entries at a time: their column indices first (one round trip, from positions clamped into the row), then their
+        // coordinates (a second one), then the terms in the row's order -- entry by entry every term costs two dependent round trips
+        // (the generic column kernel spent 81 of its 100 loads waiting for exactly one load each)
         const int a0 = srow[r], a1 = srow[r + 1];
         T s = zero_of<T>();
-        for (int a = a0; a < a1; ++a) {
-            const int64_t j = scol[a];
-            const T v = X(j);
-            const T t = ((real_t)1 + kEighth * (real_t)(int)((r + 3 * j) & 7)) * (v + (kQuarter * v) * v);
-            s = a == a0 ? t : s + t;
+        for (int a = a0; a < a1; a += FD_SPARSE_U) {
+            int64_t j[FD_SPARSE_U];
+            T v[FD_SPARSE_U];
+#pragma unroll
+            for (int u = 0; u < FD_SPARSE_U; ++u) j[u] = scol[a + u < a1 ? a + u : a1 - 1];
+#pragma unroll
+            for (int u = 0; u < FD_SPARSE_U; ++u) v[u] = X(j[u]);
+#pragma unroll
+            for (int u = 0; u < FD_SPARSE_U; ++u) {
+                const T t = ((real_t)1 + kEighth * (real_t)(int)((r + 3 * j[u]) & 7)) * (v[u] + (kQuarter * v[u]) * v[u]);
+                if (a + u < a1) s = a + u == a0 ? t : s + t;
+            }
         }
         return s;
     }
