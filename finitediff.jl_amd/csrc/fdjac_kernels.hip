@@ -1074,25 +1074,34 @@ k_decompress_bbb(const CT *__restrict__ color, const real_t *__restrict__ FXa, c
     const int w = bl + bu + 1, sw = lam + mu + 1, R = w * sw;
     const int64_t total = N * R;
     const int64_t step = (int64_t)gridDim.x * kBlock;
+    // Three round trips per slot instead of six: (block number, colour) -> (slab start, block offsets, stride, step size) -> f! values.
+    // Every load is unconditional, from an index clamped to something that exists; what does not apply is selected away afterwards.
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += step) {
         const int64_t j = e / R;
         const int s = (int)(e - j * R), d = s / sw, t = s - d * sw;
         const int J = blk[j];
+        const int c = color[j];
         const int64_t K = (int64_t)J + d - bu;
         const bool kin = K >= 0 && K < nb;
+        const int64_t Kc = kin ? K : 0;
+        const bool cin = c != none && c >= c_lo && c < c_hi;
+        const int cc = cin ? c : c_lo;
         const int64_t st0 = start[(int64_t)d + (int64_t)w * J];
+        const int oJ = off[J], oK = off[Kc], oK1 = off[Kc + 1];
+        const int64_t sJ = stride[J];
+        const real_t ec = eps[cc];
+        const int jj = (int)(j - oJ), k = jj + t - mu, m = kin ? oK1 - oK : 0;
+        const bool inb = k >= 0 && k < m;
+        const real_t v = entry_value<MODE>(FXa, FXb, ld, cc - c_lo, (int64_t)oK + (inb ? k : 0), ec);
         if (st0 < 0) continue;                                     // no such block and no slab reserved for it
         // (a layout that reserves the slab of a block outside the matrix -- BlockBandedMatrices' own: (bl+bu+1)(lam+mu+1) rows per
         //  column -- gets its zeros here; the plan zero-fills other layouts before the launch)
-        const int jj = (int)(j - off[J]), k = jj + t - mu, m = kin ? off[K + 1] - off[K] : 0;
-        real_t *o = data + st0 + (int64_t)jj * stride[J] + t;
-        const int c = color[j];
-        if (k < 0 || k >= m || c == none) {
+        real_t *o = data + st0 + (int64_t)jj * sJ + t;
+        if (!inb || c == none) {
             if (c_lo == 0) *o = 0.0;
             continue;
         }
-        if (c < c_lo || c >= c_hi) continue;
-        *o = entry_value<MODE>(FXa, FXb, ld, c - c_lo, (int64_t)off[kin ? K : 0] + k, eps[c]);
+        if (cin) *o = v;
     }
 }
 
