@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+JSON_FD = None              # N>1: the descriptor the ONE result line goes to (stdout proper; fd 1 is pointed at stderr)
 
 
 def parse():
@@ -86,10 +87,86 @@ def parse():
                          "the GPU busy (the timed region itself lasts a few milliseconds); 0 = off")
     ap.add_argument("--no-plain-handover", "--no-side-runs", dest="no_plain_handover", action="store_true",
                     help="skip the untimed side measurement of the hand-over path (profiling runs: keeps the kernels' PMC averages clean)")
+    ap.add_argument("--variant", choices=["auto", "flags"], default="auto",
+                    help="N>1 (c4 / c2): auto = time all four combinations of scaling (strong N = 10^7 / weak N = gpus x 10^7) and layout "
+                         "(x and step sizes replicated: no exchange in the step / x sharded: ONE exchange of halo + group sums per step, "
+                         "through the peer-to-peer mailboxes with automatic fall-back to RCCL) in this one run, report the fastest as "
+                         "`value` (named in config.variant) and all of them in `variants`; flags = exactly what --weak / --x-layout / "
+                         "--eps / --small-messages say (giving any of those flags implies it)")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="--gpus N without a launcher: give up on the spawned ranks after this many seconds")
     ap.add_argument("--sweep", default="", metavar="DIR",
                     help="after the headline line, run the other BASELINE configs (c2, c3, c5; plus c4 in Float32) as child "
                          "processes and write their JSON lines to DIR/bench_<config>.json (single GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    explicit = any(a.split("=")[0] in ("--weak", "--x-layout", "--eps", "--small-messages", "--shard", "--gather-in-step") for a in sys.argv[1:])
+    if explicit or args.config not in ("c2", "c4"):
+        args.variant = "flags"
+    return args
+
+
+def emit_failure(args, what, json_fd=None):
+    """The contract's ONE JSON line even when nothing could be measured: value null, the reason in `error` / `comm_error`."""
+    line = json.dumps({"metric": "Jacobian columns/s (coloured sparse finite-difference Jacobian; headline config N=10^7 tridiagonal forward)",
+                       "value": None, "unit": "columns/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                       "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": args.dtype,
+                       "data": "synthetic", "config": {"workload": "not measured", "name": args.config}, "error": what, "comm_error": what}) + "\n"
+    if json_fd is not None:
+        os.write(json_fd, line.encode())
+    else:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1 at a free port) and pass rank 0's ONE JSON line through.  Whatever happens to the ranks -- a crash, a hang
+    in a collective -- this process still prints one line (value null, the reason in `error`) instead of running into the caller's timeout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    try:
+        cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=args.spawn_timeout)
+        lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+        if lines:
+            sys.stdout.write(lines[-1] + "\n")
+            sys.stdout.flush()
+            return cp.returncode
+        emit_failure(args, "the %d spawned ranks ended (rc %d) without a result line" % (args.gpus, cp.returncode))
+        return cp.returncode or 1
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if lines:
+            sys.stdout.write(lines[-1] + "\n")
+            sys.stdout.flush()
+            return 0
+        emit_failure(args, "the %d spawned ranks did not finish within %.0f s (a rank hung in a collective?)" % (args.gpus, args.spawn_timeout))
+        return 1
+
+
+def tridiag_device_pattern(torch, N, dev):
+    """The tridiagonal SparseMatrixCSC pattern and colorvec = mod1(i, 3) built ON the device (1-based Int32, as a device sparse
+    matrix carries them): colptr[j] = 3j (j >= 1), rowval[p] = (p + 1) div 3 + (p + 1) mod 3.  For the weak-scaling problem sizes
+    (N = gpus x 10^7) nothing of size nnz is built on the host or crosses PCIe."""
+    colptr = torch.arange(N + 1, device=dev, dtype=torch.int64) * 3
+    colptr[0] = 1
+    colptr[N] = 3 * N - 1
+    q = torch.arange(1, 3 * N - 1, device=dev, dtype=torch.int64)            # p + 1 for p = 0 .. 3N - 3
+    rowval = (q // 3 + q % 3).to(torch.int32)
+    del q
+    colors = (torch.arange(N, device=dev, dtype=torch.int32) % 3 + 1).to(torch.int32)
+    return colptr.to(torch.int32), rowval, colors
+
+
+def tridiag_entry_begin(c, N):
+    """0-based index of column c's first stored value in the tridiagonal CSC nzval (c = N: nnz)."""
+    return 0 if c <= 0 else (3 * N - 2 if c >= N else 3 * c - 1)
 
 
 def cpu_baseline(n, reps, seconds=10.0):
@@ -142,6 +219,8 @@ def cpu_baseline(n, reps, seconds=10.0):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args))
     import torch
     import torch.distributed as dist
     import finitediff_jl_amd as fd
@@ -154,15 +233,15 @@ def main():
     # stdout carries exactly ONE line, the result JSON: RCCL prints a version banner on stdout when a communicator is
     # created, so with several ranks everything else this process (and the libraries under it) writes to fd 1 goes to stderr
     # and the JSON line is written to the saved descriptor
+    global JSON_FD
     json_fd = None
     if world > 1:
         sys.stdout.flush()
-        json_fd = os.dup(1)
+        json_fd = JSON_FD = os.dup(1)
         os.dup2(2, 1)
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
+        if rank == 0:
+            emit_failure(args, "no GPU visible: bench.py needs an MI355X; there is no CPU fallback for the product path", json_fd)
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
     # FDJAC_BENCH_BACKEND=gloo is a functional dry run of the N>1 path on fewer GPUs than ranks (ranks share devices,
     # the assembly is staged through host memory by torch.distributed); the measured configuration is "nccl": RCCL,
@@ -200,7 +279,7 @@ def main():
             sys.stderr.write("[bench rank %d] fd_comm_create failed (%s): the nzval assembly and the sharded solve are skipped\n" % (rank, comm_error))
     p2p = None
     p2p_note = None
-    if world > 1 and args.small_messages == "p2p":
+    if world > 1 and (args.small_messages == "p2p" or args.variant == "auto"):
         try:
             if comm is not None:
                 comm.enable_p2p(1 << 17)       # the communicator's small messages go through the mailboxes from here on
@@ -215,39 +294,161 @@ def main():
     x_sharded = False
     lazy_ok = False
     vs = 4 if args.dtype == "f32" else 8          # bytes per value
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def p2p_status():
+        """1 + r once a mailbox wait for rank r timed out on ANY rank (sticky), else 0."""
+        mine = 0
+        try:
+            mine = comm.p2p_status() if comm is not None else (p2p.status() if p2p is not None else 0)
+        except Exception:
+            mine = 0
+        t = torch.tensor([float(mine)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def build_tridiag(N, seed, sharded, on_device):
+        """This rank's share of the N-column tridiagonal forward problem: the plan of its column range, x, its output slice.
+        sharded = the time-stepping layout: the rank holds ONLY x[c0 - 2, c1 + 2) (everything else is NaN here, to prove it),
+        columns cut where the step-size reduction's groups are cut; every call exchanges halo + group sums itself (ONE launch through
+        the mailboxes, else RCCL / the host).  on_device = the pattern is built on the device (weak-scaling sizes)."""
+        pb = {"N": N, "sharded": bool(sharded and world > 1)}
+        x_host = np.random.default_rng(seed).random(N)
+        cuts = S.eps_shard_cuts(N, world) if world > 1 else np.array([0, N], dtype=np.int64)
+        if world > 1 and not sharded and not on_device and args.variant == "flags":
+            cuts = None          # (flags mode, replicated layout: the cuts balanced by stored values, as in rounds 1-4)
+        t0 = time.perf_counter()
+        if on_device:
+            cp_d, rv_d, cv_d = tridiag_device_pattern(torch, N, dev)
+            pattern = fd.DevicePatternCSC(N, N, cp_d, rv_d, None)
+            colors = cv_d
+            nnz = 3 * N - 2
+        else:
+            colors = P.cyclic_colors(N, 3)
+            colptr, rowval = P.tridiag_csc(N)
+            nnz = rowval.size
+            pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+            if cuts is None:
+                cuts = S.partition_columns(colptr, world)
+        counts = [tridiag_entry_begin(int(b), N) - tridiag_entry_begin(int(a), N) for a, b in zip(cuts[:-1], cuts[1:])]
+        c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
+        xw = S.x_window(cuts, rank, N, 1, 1, 1)
+        t_plan = time.perf_counter()
+        plan = fd.make_plan(pattern, pattern, colors, "forward", ctx=ctx, col_window=(c0, c1) if world > 1 else None,
+                            x_window=xw if world > 1 else None, dtype=np_dt)
+        pb["plan_build_ms"] = (time.perf_counter() - t_plan) * 1e3
+        pb["setup_ms"] = (time.perf_counter() - t0) * 1e3
+        f = fd.BuiltinF("tridiag", N, ctx=ctx, dtype=np_dt)
+        x = torch.as_tensor(x_host.astype(np_dt), device=dev)
+        if pb["sharded"]:
+            lo, hi = max(c0 - 2, 0), min(c1 + 2, N)
+            x_full = x
+            x = torch.full_like(x_full, float("nan"))
+            x[c0:c1] = x_full[c0:c1]                 # the halo cells arrive with the first call
+            pb["x_full_window"] = (lo, hi, x_full[lo:hi].clone())
+            del x_full
+        if not on_device:
+            pattern.rowval = None
+        pb.update(plan=plan, f=f, x=x, cuts=cuts, counts=counts, c0=c0, c1=c1, nnz=nnz, colors=colors, pattern=pattern)
+        return pb
+
+    def attach_exchange(pb):
+        """Sharded layout: hand the per-step exchange to the library (returns a description), or None if it has to be staged through the host."""
+        plan = pb["plan"]
+        if comm is not None:
+            plan.set_comm(comm)
+            plan.set_halo(pb["c0"], pb["c1"], 2)
+            return "inside the call: " + ("ONE launch through the peer-to-peer mailboxes (halo + group sums + step sizes)" if comm.has_p2p() else
+                                          "RCCL (grouped send / recv of the halo, all-gather of the group sums)")
+        if p2p is not None:
+            plan.set_p2p(p2p)
+            plan.set_halo(pb["c0"], pb["c1"], 2)
+            return "inside the call: ONE launch through the peer-to-peer mailboxes (halo + group sums + step sizes)"
+        return None
+
+    variants = None
+    if world > 1 and args.variant == "auto" and cfg in ("c2", "c4"):
+        # ---- every combination of scaling and layout timed in this one run; the fastest becomes the reported step ----
+        base_n = args.n or (10 ** 6 if cfg == "c2" else 10 ** 7)
+        variants = []
+        for weak in (False, True):
+            for sharded in (False, True):
+                name = "%s-%s" % ("weak" if weak else "strong", "sharded" if sharded else "replicated")
+                v = {"name": name, "scaling": "weak" if weak else "strong", "N": base_n * (world if weak else 1),
+                     "layout": ("x sharded: every rank holds its own part + halo; ONE exchange per step" if sharded else
+                                "x replicated: every rank reduces all of x, no exchange in the step")}
+                try:
+                    pb = build_tridiag(v["N"], 2 if cfg == "c2" else 4, sharded, weak)
+                    v["plan_build_ms"], v["setup_ms"] = pb["plan_build_ms"], pb["setup_ms"]
+                    if sharded:
+                        v["exchange"] = attach_exchange(pb)
+                        if v["exchange"] is None:
+                            raise RuntimeError("no device-side transport for the per-step exchange (neither RCCL nor mailboxes)")
+                    pb["plan"].set_lazy(pb["f"])
+                    outv = torch.empty(pb["counts"][rank], dtype=t_dt, device=dev)
+                    call = pb["plan"].bind(pb["f"], pb["x"], [outv])
+                    for _ in range(max(args.warmup, 2)):
+                        call()
+                    fence()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        call()
+                    fence()
+                    tv = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+                    v["ms_per_step"] = float(tv.item()) / args.steps * 1e3
+                    v["value"] = v["N"] / (v["ms_per_step"] * 1e-3)
+                    st = p2p_status()
+                    if st:
+                        raise RuntimeError("a mailbox wait for rank %d timed out" % (st - 1))
+                    del call, outv, pb
+                except Exception as e:
+                    v["error"] = "%s: %s" % (type(e).__name__, e)
+                    sys.stderr.write("[bench rank %d] variant %s failed: %s\n" % (rank, name, v["error"]))
+                # every rank must agree on which variants count (a failure on one rank only disqualifies it everywhere)
+                bad = torch.tensor([1.0 if "error" in v else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if bad.item() and "error" not in v:
+                    v["error"] = "failed on another rank"
+                variants.append(v)
+                torch.cuda.empty_cache()
+        good = [v for v in variants if "error" not in v]
+        best = max(good, key=lambda v: v["value"]) if good else variants[0]
+        args.weak = best["scaling"] == "weak"
+        args.x_layout = "sharded" if best["name"].endswith("sharded") else "replicated"
+        if rank == 0:
+            sys.stderr.write("[bench] variants: %s -> %s\n" % (json.dumps(variants), best["name"]))
     t_plan = time.perf_counter()
     if cfg in ("c2", "c4"):
-        N = args.n or (10 ** 6 if cfg == "c2" else 10 ** 7) * (world if args.weak else 1)
+        N = (args.n or (10 ** 6 if cfg == "c2" else 10 ** 7)) * (world if args.weak else 1)
         seed, fdtype, C = (2 if cfg == "c2" else 4), "forward", 3
-        x_host = np.random.default_rng(seed).random(N)
-        colors = P.cyclic_colors(N, 3)
-        colptr, rowval = P.tridiag_csc(N)
-        nnz = rowval.size
-        pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
-        t_plan = time.perf_counter()
         if by_color:
+            x_host = np.random.default_rng(seed).random(N)
+            colors = P.cyclic_colors(N, 3)
+            colptr, rowval = P.tridiag_csc(N)
+            nnz = rowval.size
+            pattern = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+            t_plan = time.perf_counter()
             ccuts = S.partition_colors(colors, world)
             counts, c0, c1 = [nnz], 0, N
             plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, color_range=(ccuts[rank], ccuts[rank + 1]),
                                 dtype=np_dt)
+            plan_build_ms = (time.perf_counter() - t_plan) * 1e3
+            f = fd.BuiltinF("tridiag", N, ctx=ctx, dtype=np_dt)
+            x = torch.as_tensor(x_host.astype(np_dt), device=dev)
+            del rowval
+            pattern.rowval = None
         else:
             x_sharded = world > 1 and args.x_layout == "sharded"
-            if x_sharded:
-                # the time-stepping layout: cut the columns where the step-size reduction cuts x, so that every rank reduces
-                # exactly the part of x it owns (a throw-away plan tells where: the cuts depend on N and the colour count only)
-                probe = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(0, 16), dtype=np_dt, eps_contiguous=True)
-                cuts = S.partition_columns_at([probe.eps_shard_range(r, world) for r in range(world)], N)
-                del probe
-            else:
-                cuts = S.partition_columns(colptr, world)
-            ranges = S.entry_ranges(colptr, cuts)
-            counts = [b - a for a, b in ranges]
-            c0, c1 = int(cuts[rank]), int(cuts[rank + 1])
-            xw = S.x_window(cuts, rank, N, 1, 1, 1)
-            plan = fd.make_plan(pattern, pattern, colors, fdtype, ctx=ctx, col_window=(c0, c1) if world > 1 else None,
-                                x_window=xw if world > 1 else None, dtype=np_dt, eps_contiguous=x_sharded)
-        plan_build_ms = (time.perf_counter() - t_plan) * 1e3
-        f = fd.BuiltinF("tridiag", N, ctx=ctx, dtype=np_dt)
+            pb = build_tridiag(N, seed, x_sharded, world > 1 and args.weak)
+            plan, f, x, cuts, counts, c0, c1, nnz, colors, pattern = (pb[k] for k in ("plan", "f", "x", "cuts", "counts", "c0", "c1", "nnz", "colors", "pattern"))
+            plan_build_ms = pb["plan_build_ms"]
         lazy_ok = True
         win, per = plan.info(fd.lib.INFO_WINDOW), plan.info(fd.lib.INFO_WIN_PERIOD)
         idx_b = (0.0 if per else 2.0) if win else 5.0          # index bytes per stored value this plan's kernel reads
@@ -262,8 +463,6 @@ def main():
         bytes_call_survey = 210.0 if args.dtype == "f64" else 114.0
         wl = "N=%d tridiagonal CSC (nnz=3N-2), colorvec=mod1(i,3), forward, f!=second difference, x~U(0,1) seed %d" % (N, seed)
         kern = "k_decompress_window<forward>" if win else "k_decompress_list<u8,forward>"
-        del rowval
-        pattern.rowval = None
     elif cfg == "c3":
         nx, ny = (4000, 2500) if not args.n else (int(args.n ** 0.5), int(args.n ** 0.5))
         N = nx * ny
@@ -312,7 +511,8 @@ def main():
         bytes_call_survey = bytes_ds + (C * N * 16 * 3 + 9 * N) / N
         wl = "%d dense %dx%d blocks, block-tridiagonal BlockBandedMatrix (N=%d, %d stored values), %d colours, complex step, x~U(0,1) seed 5" % (nb, bs, bs, N, nnz, C)
         kern = "k_decompress_colrange_wg<u8,complex>" if plan.info(fd.lib.INFO_COLRANGE_WG) else "k_decompress_colrange<u8,complex>"
-    x = torch.as_tensor(x_host.astype(np_dt), device=dev)
+    if cfg in ("c3", "c5"):
+        x = torch.as_tensor(x_host.astype(np_dt), device=dev)
     if args.f_mode == "lazy" and lazy_ok:
         plan.set_lazy(f)
     f_mode = "lazy" if (args.f_mode == "lazy" and lazy_ok) else "materialized"
@@ -341,8 +541,18 @@ def main():
         bytes_min = (C * 8 * N + nnz * (8 + idx_b)) / N
         bytes_call_model = 9.0 + (9.0 + C * 8) + bytes_min
     eps_sharded = world > 1 and (args.eps == "sharded" or x_sharded) and not by_color
-    if eps_sharded and comm is not None:
+    # the per-step exchange of the sharded layouts is the library's business when a device-side transport exists: fd_plan_set_comm /
+    # fd_plan_set_p2p (+ fd_plan_set_halo for a sharded x) -- the call then reduces its own groups of x, exchanges halo + group sums
+    # (ONE launch through the mailboxes, else RCCL) and finishes the step sizes.  Only the gloo dry run stages it through the host.
+    in_call = None
+    if x_sharded:
+        in_call = attach_exchange(pb)
+    elif eps_sharded and comm is not None:
         plan.set_comm(comm)
+        in_call = "inside the call: group sums " + ("through the peer-to-peer mailboxes" if comm.has_p2p() else "all-gathered by RCCL")
+    elif eps_sharded and p2p is not None:
+        plan.set_p2p(p2p)
+        in_call = "inside the call: group sums through the peer-to-peer mailboxes"
     gather_in_step = world > 1 and args.gather_in_step
 
     # output buffers: rank r fills out = its slice; rank 0 also owns the assembled nzval (root gather) / every rank the
@@ -378,34 +588,25 @@ def main():
 
     enqueue = plan.bind(f, x, [out])   # pointers resolved once: one foreign call per Jacobian, as from compiled code
 
-    # dry run (FDJAC_BENCH_BACKEND=gloo) of the sharded step-size reduction: the explicit pieces of the C ABI with the exchange
-    # staged through host memory -- fd_plan_eps_partials, all-gather of the slots, fd_plan_eps_finalize, FD_EPS_PRECOMPUTED
+    # dry run (FDJAC_BENCH_BACKEND=gloo, no mailboxes) of the sharded step-size reduction: the explicit pieces of the C ABI with the
+    # exchange staged through host memory -- fd_plan_eps_partials, all-gather of the slots, fd_plan_eps_finalize, FD_EPS_PRECOMPUTED
     eps_host = None
-    if eps_sharded and comm is None:
+    if eps_sharded and in_call is None:
         pptr, slot = plan.eps_partials(x, rank, world)
 
-        class _Raw:   # the library's partial-sum buffer as a torch view (zero copy)
+        class _Raw:   # the library's group-sum buffer as a torch view (zero copy)
             __cuda_array_interface__ = {"shape": (world * slot,), "typestr": "<f8", "data": (pptr, False), "version": 2}
         eps_host = {"dev": torch.as_tensor(_Raw(), device=dev), "slot": slot, "all": torch.empty(world * slot, dtype=torch.float64)}
         plan.set_eps_mode(True)
 
     def pre_step():
-        """What precedes the Jacobian in a time-stepping loop whose x is sharded: the neighbour halo, then (dry run only --
-        with RCCL the library does it inside the call) the sharded reduction's exchange."""
+        """Dry run only: what the library does inside the call when it has a transport -- the neighbour halo of a sharded x, then
+        the exchange of the sharded reduction's group sums -- staged through the host."""
         if x_sharded:
-            if comm is not None:
-                comm.halo_exchange(x, c0, c1, 2)       # tridiagonal f! on the rows of the band (1,1): x[c0-2, c1+2)
-            elif p2p is not None:
-                p2p.halo_exchange(x, c0, c1, 2)        # (dry run on shared GPUs: the mailbox path without RCCL)
-            else:
-                xh = x.cpu()
-                S.halo_exchange_host(xh, cuts, rank, 2, dist)
-                x.copy_(xh)
-        if eps_host is not None and p2p is not None:
-            plan.eps_partials(x, rank, world)
-            p2p.allgather(eps_host["dev"], eps_host["slot"])
-            plan.eps_finalize()
-        elif eps_host is not None:
+            xh = x.cpu()
+            S.halo_exchange_host(xh, cuts, rank, 2, dist)
+            x.copy_(xh)
+        if eps_host is not None:
             plan.eps_partials(x, rank, world)
             sl = eps_host["slot"]
             mine = eps_host["dev"][rank * sl:(rank + 1) * sl].cpu()
@@ -414,17 +615,11 @@ def main():
             plan.eps_finalize()
 
     def step():
-        if x_sharded or eps_host is not None:
+        if in_call is None and (x_sharded or eps_host is not None):
             pre_step()
         enqueue()
         if gather_in_step:
             do_gather()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -754,6 +949,15 @@ def main():
         ok = ok and check["max_dev_from_exact_stencil_all_entries"] <= (1e-6 if args.dtype == "f64" else 1e-2)
     check["ok"] = bool(ok)
 
+    p2p_st = p2p_status() if world > 1 else 0
+    if p2p_st:
+        check["ok"] = False
+        check["p2p_timeout_waiting_for_rank"] = p2p_st - 1
+    if x_sharded and cfg in ("c2", "c4") and not by_color:
+        # the sharded layout: this rank's x holds its own part and the halo the calls brought in -- and nothing else
+        lo, hi, xw_true = pb["x_full_window"]
+        check["sharded_x_holds_own_part_and_halo_only"] = bool(torch.equal(x[lo:hi], xw_true) and torch.isnan(x[:lo]).all() and torch.isnan(x[hi:]).all())
+        check["ok"] = bool(check["ok"] and check["sharded_x_holds_own_part_and_halo_only"])
     # ---- per-rank diagnostics (stderr): which device / RCCL each rank saw and where its time went ---------------------
     stages = {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in tm_all.items()}
     diag = {"rank": rank, "world": world, "device": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
@@ -824,6 +1028,9 @@ def main():
                                   "built-in device f! behind fd_f_launch (materialised points, one batched launch)"),
                        "eps_reduction": diag["eps"], "x_layout": diag["x_layout"], "gather_in_step": bool(gather_in_step),
                        "small_messages": (p2p_note or "rccl") if world > 1 else None,
+                       "variant": ((("weak" if args.weak else "strong") + "-" + ("sharded" if x_sharded else "replicated")) if (world > 1 and not by_color) else None),
+                       "variant_selection": ("fastest of the four timed in this run (see `variants`)" if variants else "as the flags say") if world > 1 else None,
+                       "step_exchange": in_call if world > 1 else None,
                        "problem": ("N = %d = %d x 10^7 columns (weak scaling)" % (N, world)) if (args.weak and world > 1) else None,
                        "collective_backend": (("rccl via libfdjac fd_comm_* (%s)" % comm.info()["library"]) if comm is not None
                                               else backend) if world > 1 else None},
@@ -865,6 +1072,8 @@ def main():
             "plan_build_ms": plan_build_ms,
             "gather": gather_info,
             "comm_error": comm_error,
+            "variants": variants,
+            "p2p_status": (p2p_st if world > 1 else None),
             "consumer": consumer,
             "value_with_gather": (N / ((ms_step + (0.0 if gather_in_step else gather_info["ms"])) * 1e-3)
                                   if (gather_info and "ms" in gather_info) else None),
@@ -905,10 +1114,15 @@ def main():
     # ---- untimed soak: keep the GPU in the steady-state loop long enough for an external sampler to see it ------------
     if args.soak_seconds > 0:
         t_end = time.perf_counter() + args.soak_seconds
-        while time.perf_counter() < t_end:
+        while True:
             for _ in range(200):
                 enqueue()
             torch.cuda.synchronize()
+            go = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64, device=dev)
+            if world > 1:       # (calls that exchange inside must be made the same number of times on every rank)
+                dist.all_reduce(go, op=dist.ReduceOp.MIN)
+            if not go.item():
+                break
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -921,4 +1135,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # whatever went wrong: rank 0 still prints the contract's one line, then the failure is reported as usual
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            try:
+                emit_failure(parse(), "%s: %s" % (type(e).__name__, e), JSON_FD)
+            except Exception:
+                pass
+        raise SystemExit(1)

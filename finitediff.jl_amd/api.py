@@ -321,6 +321,17 @@ class Comm:
         solve -- through direct peer-to-peer stores.  Collective; raises if the peers cannot be mapped."""
         _l.check(self.L.fd_comm_enable_p2p(self.handle, int(slot_bytes)))
 
+    def has_p2p(self):
+        en = C.c_int()
+        _l.check(self.L.fd_comm_p2p_status(self.handle, C.byref(en), None))
+        return bool(en.value)
+
+    def p2p_status(self):
+        """0, or 1 + r once a mailbox wait for rank r timed out (fd_comm_p2p_status)."""
+        v = C.c_int()
+        _l.check(self.L.fd_comm_p2p_status(self.handle, None, C.byref(v)))
+        return v.value
+
 
 class P2P:
     """fd_p2p: small-message exchange by direct stores into the peers' HBM (one node, one process per GPU) -- the mailbox on
@@ -696,6 +707,16 @@ class Plan:
         """Shard the step-size reduction over the communicator's ranks (fd_plan_set_comm); None detaches."""
         self._comm_keep = comm
         _l.check(self.Lt.fd_plan_set_comm(self.handle, comm.handle if comm is not None else None))
+
+    def set_p2p(self, p2p):
+        """The same with a bare mailbox (fd_plan_set_p2p: callers without RCCL); None detaches."""
+        self._p2p_keep = p2p
+        _l.check(self.Lt.fd_plan_set_p2p(self.handle, p2p.handle if p2p is not None else None))
+
+    def set_halo(self, own_begin, own_end, halo):
+        """x is sharded (fd_plan_set_halo): every following call exchanges `halo` elements of x with the neighbour ranks itself, in
+        the launch that carries the step-size reduction's group sums.  halo = 0 turns it off."""
+        _l.check(self.Lt.fd_plan_set_halo(self.handle, int(own_begin), int(own_end), int(halo)))
 
     def eps_shard_range(self, shard, nshards):
         """fd_plan_eps_shard_range: the elements of x shard `shard` of `nshards` of the step-size reduction reads."""

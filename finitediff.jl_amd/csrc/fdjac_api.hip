@@ -18,9 +18,9 @@ static thread_local char g_err[512] = "";
 #endif
 
 int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir);
-int launch_eps_partial(fd_plan *p, const real_t *x, int b0, int nb);
-int launch_eps_finalize(fd_plan *p, int nparts, int ldp, double relstep, double absstep, double dir);
-constexpr int kMaxEpsShards = 1024;   // the partial buffer has room for this many padded shards
+int launch_eps_groups(fd_plan *p, const real_t *x, int g0, int ng, bool final, double relstep, double absstep, double dir);
+int launch_eps_final(fd_plan *p, double relstep, double absstep, double dir);
+constexpr int kMaxEpsShards = kEpsGroups;   // a shard of the reduction is a whole number of groups
 int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double absstep, double dir, int pmode,
                              int base_row);
 int launch_perturb(fd_plan *p, const real_t *x, int c_lo, int B);
@@ -150,10 +150,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
     // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
     // FDJAC_EPS_NT forces one, a call decides by which path it takes.
-    // the reduction's blocks sum contiguous ranges of x: the default since round 3 (measured equal to the grid-stride map -- N = 10^7:
-    // 75.3 vs 76.0 us per Jacobian, profiles/r03_f_eps_contig_ab.txt -- and a sharded reduction then reads only the shard's own
-    // range); FDJAC_EPS_CONTIG=0 restores the grid-stride map, FD_PLAN_EPS_CONTIGUOUS insists on the contiguous one
-    p->eps_contig = (opts->flags & FD_PLAN_EPS_CONTIGUOUS) != 0 || env_int("FDJAC_EPS_CONTIG", 1) != 0;
     p->cx = t_lowered_cx;                                // (inside a LoweredScope only)
     if (p->cx) p->small_ok = false;                      // the fused small-problem launch has ONE colour rule for norm and perturbation
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
@@ -234,17 +230,23 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
                 p->cyc_C = cyc ? (int)p->C : 0;
                 p->cyc_shift = cyc ? (int)sh : 0;
             }
-            // 4 workgroups per CU: measured 31.0 us for partial + finalize at N = 10^7 (8: 34.5, 16: 33.7, 2: 36.6,
-            // uncapped 36.1 -- fewer partials for the finalize, enough loads in flight for the reduction)
-            const int64_t mult = 4;
-            const int64_t tiles = (p->N + 2047) / 2048;  // k_eps_partial_reg: 4 x 512 elements per block round
-            // (a function of N alone -- 256 CUs x 4, not of the device the plan happens to live on: every rank of a sharded
-            //  reduction must cut the same blocks; fd_plan_set_comm verifies it)
-            p->n_partial_blocks = balanced_grid(tiles, mult > 0 ? (int64_t)256 * mult : ((int64_t)1 << 30));
-            p->eps_tpb = p->eps_contig ? (int)((tiles + p->n_partial_blocks - 1) / p->n_partial_blocks) : 0;
-            // (+ kMaxEpsShards rows: a sharded reduction pads the grid to a whole number of blocks per shard)
-            p->partial_cap = ((int64_t)p->n_partial_blocks + kMaxEpsShards) * kRegColors;
+            // the two-level grid (k_eps_partial_reg): 64 groups of tpg tiles, each summed by bpg <= 16 blocks of tpb tiles -- about
+            // 4 workgroups per CU at large N (measured best in round 2: fewer partials, enough loads in flight).  A function of N
+            // alone, not of the device: every rank of a sharded reduction must cut the same groups (fd_plan_set_comm verifies it)
+            const int64_t tiles = (p->N + 2047) / 2048;  // 4 x 512 elements per block round
+            const int64_t tpg = (tiles + kEpsGroups - 1) / kEpsGroups;
+            const int64_t tpb = (tpg + kEpsBlocksPerGroup - 1) / kEpsBlocksPerGroup;
+            FD_REQUIRE(tpg < ((int64_t)1 << 24), FD_ERR_UNSUPPORTED, "N too large for the step-size reduction's grid");
+            p->eps_tpg = (int)tpg;
+            p->eps_tpb = (int)tpb;
+            p->eps_bpg = (int)((tpg + tpb - 1) / tpb);
+            p->n_partial_blocks = kEpsGroups * p->eps_bpg;
+            p->partial_cap = (int64_t)p->n_partial_blocks * kRegColors;
             if ((rc = dev_alloc(&p->d_partial, p->partial_cap))) return rc;
+            if ((rc = dev_alloc(&p->d_gsum, (int64_t)2 * kEpsGroups * kRegColors))) return rc;
+            if ((rc = dev_alloc(&p->d_tick, (int64_t)kEpsGroups + 1))) return rc;
+            FD_HIP_CHECK(hipMemsetAsync(p->d_gsum, 0, sizeof(double) * 2 * kEpsGroups * kRegColors, p->ctx->stream));
+            FD_HIP_CHECK(hipMemsetAsync(p->d_tick, 0, sizeof(unsigned) * (kEpsGroups + 1), p->ctx->stream));
         } else {
             // counting sort of the columns by colour
             std::vector<int64_t> cptr((size_t)p->C + 1, 0);
@@ -407,7 +409,7 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
-                    p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_xstage,
+                    p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -580,6 +582,38 @@ static bool eps_shardable(const fd_plan *p)
            !(p->small_ok && p->N <= kSmallN) && p->d_partial != nullptr;
 }
 
+// which shard of the sharded reduction this rank runs (a bare mailbox, or the communicator's ranks)
+static void eps_shard_of(const fd_plan *p, int *W, int *r)
+{
+    if (p->p2p) { *W = fdjac_p2p_nranks(p->p2p); *r = fdjac_p2p_rank(p->p2p); }
+    else { *W = fdjac_comm_nranks(p->comm); *r = fdjac_comm_rank(p->comm); }
+}
+
+// the per-step exchange of a sharded call: every rank's group sums (+ the halo of a sharded x), then level 2 of the reduction
+static int eps_exchange(fd_plan *p, real_t *x_dev, int S, double relstep, double absstep, double dir)
+{
+    fd_p2p *mb = p->p2p ? p->p2p : (p->comm ? fdjac_comm_p2p(p->comm) : nullptr);
+    if (mb && fdjac_p2p_nranks(mb) > 1) {
+        fdjac_eps_final fin;
+        fin.gsum = p->d_gsum; fin.ldp = kRegColors; fin.ngroups = kEpsGroups; fin.C = (int)p->C;
+        fin.relstep = relstep; fin.absstep = absstep; fin.dir = dir; fin.is_forward = p->fdtype == FD_FORWARD ? 1 : 0;
+        fin.eps = p->d_eps; fin.eps2 = p->d_eps2; fin.elem_bytes = (int)sizeof(real_t);
+        const int rc = fdjac_p2p_step(mb, p->halo > 0 ? (void *)x_dev : nullptr, p->halo_own0, p->halo_own1, p->halo, (int)sizeof(real_t),
+                                      p->d_gsum, (int64_t)S * kRegColors * (int64_t)sizeof(double), &fin);
+        if (rc != FD_ERR_UNSUPPORTED) {        // (UNSUPPORTED: the payload does not fit the mailbox slot -- RCCL below)
+            if (!rc) p->eps2_fresh = p->d_eps2 != nullptr;
+            return rc;
+        }
+    }
+    int rc = FD_OK;
+    if (p->comm) {
+        if (p->halo > 0) rc = fd_comm_halo_exchange(p->comm, x_dev, p->halo_own0, p->halo_own1, p->halo, (int)sizeof(real_t));
+        if (!rc) rc = fdjac_comm_allgather_f64(p->comm, p->d_gsum, (int64_t)S * kRegColors);
+    }
+    if (!rc) rc = launch_eps_final(p, relstep, absstep, dir);
+    return rc;
+}
+
 // The plain f! launcher.  For a plan of the lowered complex-valued-x problem the arrays hold (re, im) pairs: the launcher is
 // called as the header promises for complex elements -- is_complex = 1, strides and rows counted in complex elements.
 static inline int call_f(const fd_plan *p, fd_f_launch f, void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride,
@@ -646,15 +680,18 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (small) {
             rc = launch_eps_perturb_small(p, x_dev, relstep, absstep, dir, small_points ? p->fdtype : -1,
                                           base_in_batch ? (int)(p->C * p->pts) : -1);
-        } else if (p->comm && eps_shardable(p)) {   // (also with a single-rank communicator: same code path)
-            // sharded reduction: this rank's blocks of the global grid, all-gather of the partial sums (in place, padded
-            // slots), the same finalize as the unsharded call => bit-identical step sizes on every rank
-            const int W = fdjac_comm_nranks(p->comm), r = fdjac_comm_rank(p->comm);
-            const int S = (p->n_partial_blocks + W - 1) / W;
-            const int b0 = std::min(r * S, p->n_partial_blocks), nb = std::min(S, p->n_partial_blocks - b0);
-            rc = launch_eps_partial(p, x_dev, b0, nb);
-            if (!rc) rc = fdjac_comm_allgather_f64(p->comm, p->d_partial, (int64_t)S * kRegColors);
-            if (!rc) rc = launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
+        } else if ((p->comm || p->p2p) && eps_shardable(p)) {   // (also with a single-rank communicator: same code path)
+            // sharded reduction: this rank's GROUPS of the two-level sum (the part of x it owns), then ONE exchange -- the group sums
+            // of every rank (64 / W x 8 doubles each) and, for a sharded x (fd_plan_set_halo), the halo of x ride in the same
+            // launch, whose last workgroup adds the 64 group sums in order and writes the step sizes (mailbox: fdjac_p2p_step);
+            // without a mailbox: halo by RCCL send / recv, in-place all-gather of the group sums, k_eps_final.  Same bits as the
+            // unsharded call on every rank.
+            int W, r;
+            eps_shard_of(p, &W, &r);
+            const int S = (kEpsGroups + W - 1) / W;
+            const int g0 = std::min(r * S, kEpsGroups), ng = std::min(S, kEpsGroups - g0);
+            rc = launch_eps_groups(p, x_dev, g0, ng, false, relstep, absstep, dir);
+            if (!rc) rc = eps_exchange(p, const_cast<real_t *>(x_dev), S, relstep, absstep, dir);
         } else {
             rc = launch_eps(p, x_dev, relstep, absstep, dir);
         }
@@ -983,17 +1020,41 @@ int fd_plan_set_comm(fd_plan *p, fd_comm *comm)
         // the replicated reduction would skip the per-call all-gather the others enter).  One tiny all-reduce at attach time
         // settles both; it is unconditional -- every rank enters it whatever its own plan looks like.
         const bool sh = eps_shardable(p);
-        const double nb = sh ? (double)p->n_partial_blocks : -1.0, tp = sh ? (double)p->eps_tpb : -1.0;
+        const double nb = sh ? (double)p->eps_tpg : -1.0, tp = sh ? (double)p->eps_bpg * 65536.0 + (double)p->eps_tpb : -1.0;
         const double mine[4] = {nb, -nb, tp, -tp};
         double got[4] = {0, 0, 0, 0};
         const int rc = fdjac_comm_allreduce_max4(comm, mine, got);
         if (rc) return rc;
         FD_REQUIRE(got[0] == mine[0] && got[1] == mine[1] && got[2] == mine[2] && got[3] == mine[3], FD_ERR_COMM,
-                   "the ranks disagree on the step-size reduction (this rank: %s, %d blocks of %d tiles): same N, colours, fdtype, "
-                   "FDJAC_SMALL and FD_PLAN_EPS_CONTIGUOUS everywhere?", sh ? "sharded" : "replicated",
-                   p->n_partial_blocks, p->eps_tpb);
+                   "the ranks disagree on the step-size reduction (this rank: %s, 64 groups of %d tiles in %d blocks): same N, colours, "
+                   "fdtype and FDJAC_SMALL everywhere?", sh ? "sharded" : "replicated", p->eps_tpg, p->eps_bpg);
     }
     p->comm = comm;
+    return FD_OK;
+}
+
+int fd_plan_set_p2p(fd_plan *p, fd_p2p *p2p)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(p2p == nullptr || fdjac_p2p_ctx(p2p) == p->ctx, FD_ERR_ARG, "the mailbox belongs to another context");
+    FD_REQUIRE(p2p == nullptr || fdjac_p2p_nranks(p2p) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
+    p->p2p = p2p;
+    return FD_OK;
+}
+
+int fd_plan_set_halo(fd_plan *p, int64_t own_begin, int64_t own_end, int64_t halo)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(halo >= 0 && own_begin >= 0 && own_end >= own_begin && own_end <= p->N, FD_ERR_ARG, "bad range [%lld,%lld) / halo %lld",
+               (long long)own_begin, (long long)own_end, (long long)halo);
+    FD_REQUIRE(halo == 0 || own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` = %lld elements", (long long)halo);
+    FD_REQUIRE(halo == 0 || (halo * (int64_t)sizeof(real_t)) % 8 == 0, FD_ERR_ARG, "the halo must be a multiple of 8 bytes");
+    FD_REQUIRE(halo == 0 || eps_shardable(p), FD_ERR_UNSUPPORTED,
+               "the halo rides with the sharded step-size reduction: this plan's reduction cannot be sharded (needs 1..8 colours, N > 16384, "
+               "forward / central) -- exchange the halo with fd_comm_halo_exchange before the call");
+    p->halo = halo;
+    p->halo_own0 = own_begin;
+    p->halo_own1 = own_end;
     return FD_OK;
 }
 
@@ -1002,16 +1063,16 @@ int fd_plan_eps_partials(fd_plan *p, const void *x_dev, int shard, int nshards, 
 {
     FD_REQUIRE(p && x_dev, FD_ERR_ARG, "NULL argument");
     FD_REQUIRE(nshards >= 1 && nshards <= kMaxEpsShards && shard >= 0 && shard < nshards, FD_ERR_ARG,
-               "shard %d of %d", shard, nshards);
+               "shard %d of %d (at most %d shards)", shard, nshards, kMaxEpsShards);
     FD_REQUIRE(eps_shardable(p), FD_ERR_UNSUPPORTED,
                "this plan's step-size reduction cannot be sharded (needs 1..8 colours, N > 16384, forward / central)");
     FD_REQUIRE((((uintptr_t)x_dev) & kPairMask) == 0, FD_ERR_ARG, "x must be 16-byte aligned");
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
-    const int S = (p->n_partial_blocks + nshards - 1) / nshards;
-    const int b0 = std::min(shard * S, p->n_partial_blocks), nb = std::min(S, p->n_partial_blocks - b0);
-    if (partials_out) *partials_out = p->d_partial;
+    const int S = (kEpsGroups + nshards - 1) / nshards;
+    const int g0 = std::min(shard * S, kEpsGroups), ng = std::min(S, kEpsGroups - g0);
+    if (partials_out) *partials_out = p->d_gsum;
     if (slot_doubles_out) *slot_doubles_out = (int64_t)S * kRegColors;
-    return launch_eps_partial(p, (const real_t *)x_dev, b0, nb);
+    return launch_eps_groups(p, (const real_t *)x_dev, g0, ng, false, 0.0, 0.0, 1.0);
 }
 
 int fd_plan_eps_finalize(fd_plan *p, double relstep, double absstep, double dir)
@@ -1024,7 +1085,7 @@ int fd_plan_eps_finalize(fd_plan *p, double relstep, double absstep, double dir)
         relstep = p->fdtype == FD_FORWARD ? (double)std::sqrt(e) : (double)std::cbrt(e);
     }
     if (absstep < 0) absstep = relstep;
-    return launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
+    return launch_eps_final(p, relstep, absstep, dir);
 }
 
 int fd_plan_eps_shard_range(fd_plan *p, int shard, int nshards, int64_t *x_begin, int64_t *x_end)
@@ -1032,12 +1093,11 @@ int fd_plan_eps_shard_range(fd_plan *p, int shard, int nshards, int64_t *x_begin
     FD_REQUIRE(p && x_begin && x_end, FD_ERR_ARG, "NULL argument");
     FD_REQUIRE(nshards >= 1 && nshards <= kMaxEpsShards && shard >= 0 && shard < nshards, FD_ERR_ARG, "shard %d of %d", shard, nshards);
     FD_REQUIRE(eps_shardable(p), FD_ERR_UNSUPPORTED, "this plan's step-size reduction cannot be sharded");
-    if (p->eps_tpb <= 0) { *x_begin = 0; *x_end = p->N; return FD_OK; }      // grid-stride: every block reads all over x
-    const int S = (p->n_partial_blocks + nshards - 1) / nshards;
-    const int64_t per_block = (int64_t)p->eps_tpb * 2048;                     // k_eps_partial_reg's tile: 4 x 512 elements
-    const int64_t b0 = std::min<int64_t>((int64_t)shard * S, p->n_partial_blocks), b1 = std::min<int64_t>(b0 + S, p->n_partial_blocks);
-    *x_begin = std::min<int64_t>(b0 * per_block, p->N);
-    *x_end = shard == nshards - 1 ? p->N : std::min<int64_t>(b1 * per_block, p->N);
+    const int S = (kEpsGroups + nshards - 1) / nshards;
+    const int64_t per_group = (int64_t)p->eps_tpg * 2048;                     // k_eps_partial_reg's tile: 4 x 512 elements
+    const int64_t g0 = std::min<int64_t>((int64_t)shard * S, kEpsGroups), g1 = std::min<int64_t>(g0 + S, kEpsGroups);
+    *x_begin = std::min<int64_t>(g0 * per_group, p->N);
+    *x_end = shard == nshards - 1 ? p->N : std::min<int64_t>(g1 * per_group, p->N);
     return FD_OK;
 }
 

@@ -201,33 +201,50 @@ int fd_comm_enable_p2p(fd_comm *c, int64_t slot_bytes)
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
     FD_HIP_CHECK(hipSetDevice(c->ctx->device));
+    // collective: a rank whose local set-up fails still takes part in the two exchanges below (carrying its failure in rc), so that
+    // no rank is left waiting inside RCCL and every rank falls back together
     fd_p2p *p = nullptr;
     int rc = fd_p2p_create(c->ctx, c->nranks, c->rank, slot_bytes, &p);
-    if (rc) return rc;
+    char first_error[512];
+    snprintf(first_error, sizeof first_error, "%s", rc ? fd_last_error() : "");
     // the handles travel over the communicator itself: one small in-place all-gather
     char *d_h = nullptr;
-    std::vector<char> h((size_t)c->nranks * FD_P2P_HANDLE_BYTES);
+    std::vector<char> h((size_t)c->nranks * FD_P2P_HANDLE_BYTES, 0);
     hipError_t e = hipMalloc((void **)&d_h, h.size());
-    if (e == hipSuccess) rc = fd_p2p_local_handle(p, h.data() + (size_t)c->rank * FD_P2P_HANDLE_BYTES);
-    if (e == hipSuccess && !rc) e = hipMemcpyAsync(d_h, h.data(), h.size(), hipMemcpyHostToDevice, c->ctx->stream);
-    if (e == hipSuccess && !rc) {
+    if (e != hipSuccess) { set_error("fd_comm_enable_p2p: hipMalloc failed: %s", hipGetErrorString(e)); if (p) (void)fd_p2p_destroy(p); return FD_ERR_HIP; }
+    if (!rc) rc = fd_p2p_local_handle(p, h.data() + (size_t)c->rank * FD_P2P_HANDLE_BYTES);
+    e = hipMemcpyAsync(d_h, h.data(), h.size(), hipMemcpyHostToDevice, c->ctx->stream);
+    {
         const ncclResult_t r = R->AllGather(d_h + (size_t)c->rank * FD_P2P_HANDLE_BYTES, d_h, FD_P2P_HANDLE_BYTES, ncclUint8, c->comm, c->ctx->stream);
-        if (r != ncclSuccess) { set_error("exchanging the mailbox handles failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
+        if (r != ncclSuccess && !rc) { set_error("exchanging the mailbox handles failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
     }
-    if (e == hipSuccess && !rc) e = hipMemcpyAsync(h.data(), d_h, h.size(), hipMemcpyDeviceToHost, c->ctx->stream);
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->ctx->stream);
-    if (d_h) (void)hipFree(d_h);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_h, h.size(), hipMemcpyDeviceToHost, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    (void)hipFree(d_h);
     if (e != hipSuccess && !rc) { set_error("exchanging the mailbox handles failed: %s", hipGetErrorString(e)); rc = FD_ERR_HIP; }
     if (!rc) rc = fd_p2p_connect(p, h.data());
+    if (rc && !first_error[0]) snprintf(first_error, sizeof first_error, "%s", fd_last_error());
     // every rank must have mapped every peer before anybody stores into a mailbox: agree on success (a rank that failed makes all fall back)
     double mine[4] = {rc ? 1.0 : 0.0, 0, 0, 0}, got[4] = {0, 0, 0, 0};
     const int rc2 = fdjac_comm_allreduce_max4(c, mine, got);
     if (rc || rc2 || got[0] != 0.0) {
-        (void)fd_p2p_destroy(p);
-        if (!rc && !rc2) { set_error("another rank could not map the mailboxes: the communicator keeps using RCCL for small messages"); return FD_ERR_COMM; }
-        return rc ? rc : rc2;
+        if (p) (void)fd_p2p_destroy(p);
+        if (rc) { set_error("%s", first_error); return rc; }
+        if (!rc2) { set_error("another rank could not map the mailboxes: the communicator keeps using RCCL for small messages"); return FD_ERR_COMM; }
+        return rc2;
     }
     c->p2p = p;
+    return FD_OK;
+}
+
+int fd_comm_p2p_status(const fd_comm *c, int *enabled, int *timed_out_rank_plus_1)
+{
+    FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");
+    if (enabled) *enabled = c->p2p ? 1 : 0;
+    if (timed_out_rank_plus_1) {
+        *timed_out_rank_plus_1 = 0;
+        if (c->p2p) return fd_p2p_status(c->p2p, timed_out_rank_plus_1);
+    }
     return FD_OK;
 }
 
@@ -317,7 +334,11 @@ int fd_comm_halo_exchange(fd_comm *c, void *buf, int64_t own_begin, int64_t own_
                (long long)own_end, (long long)halo);
     FD_REQUIRE(halo == 0 || own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` = %lld elements", (long long)halo);
     if (halo == 0 || c->nranks == 1) return FD_OK;
-    if (c->p2p && 2 * halo * elem_bytes <= fdjac_p2p_slot_bytes(c->p2p) && (halo * elem_bytes) % 8 == 0)
+    // (every per-rank check happens BEFORE the routing decision, so that all ranks take the same path: a check that fails on one rank
+    //  only must not leave the others waiting in the other transport)
+    const bool lo = c->rank > 0, hi = c->rank + 1 < c->nranks;
+    FD_REQUIRE(!lo || own_begin >= halo, FD_ERR_ARG, "no room for the lower halo below element %lld", (long long)own_begin);
+    if (c->p2p && (elem_bytes == 4 || elem_bytes == 8) && 2 * halo * elem_bytes <= fdjac_p2p_slot_bytes(c->p2p) && (halo * elem_bytes) % 8 == 0)
         return fd_p2p_halo_exchange(c->p2p, buf, own_begin, own_end, halo, elem_bytes);
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
@@ -325,8 +346,6 @@ int fd_comm_halo_exchange(fd_comm *c, void *buf, int64_t own_begin, int64_t own_
     hipStream_t s = c->ctx->stream;
     char *b = (char *)buf;
     const size_t eb = (size_t)elem_bytes, h = (size_t)halo;
-    const bool lo = c->rank > 0, hi = c->rank + 1 < c->nranks;
-    FD_REQUIRE(!lo || own_begin >= halo, FD_ERR_ARG, "no room for the lower halo below element %lld", (long long)own_begin);
     // one group of <= 4 point-to-point transfers, each over the link to a neighbour; always closed (see fd_comm_gatherv)
     FD_NCCL_CHECK(R, R->GroupStart());
     ncclResult_t first = ncclSuccess;
@@ -397,6 +416,7 @@ int fdjac_comm_allreduce_max4(fd_comm *c, const double *mine, double *out)
 int fdjac_comm_nranks(const fd_comm *c) { return c ? c->nranks : 1; }
 int fdjac_comm_rank(const fd_comm *c) { return c ? c->rank : 0; }
 const fd_ctx *fdjac_comm_ctx(const fd_comm *c) { return c ? c->ctx : nullptr; }
+fd_p2p *fdjac_comm_p2p(const fd_comm *c) { return c ? c->p2p : nullptr; }
 }
 
 #endif /* FDJAC_F32 */

@@ -32,6 +32,8 @@
 #define fd_plan_set_lazy_caps fd32_plan_set_lazy_caps
 #define fd_plan_get_epsilons fd32_plan_get_epsilons
 #define fd_plan_set_comm fd32_plan_set_comm
+#define fd_plan_set_p2p fd32_plan_set_p2p
+#define fd_plan_set_halo fd32_plan_set_halo
 #define fd_plan_eps_partials fd32_plan_eps_partials
 #define fd_plan_eps_finalize fd32_plan_eps_finalize
 #define fd_plan_set_eps_mode fd32_plan_set_eps_mode
@@ -74,6 +76,22 @@ extern "C" int fdjac_comm_allreduce_max4(fd_comm *c, const double *mine, double 
 extern "C" int fdjac_comm_nranks(const fd_comm *c);
 extern "C" int fdjac_comm_rank(const fd_comm *c);
 extern "C" const fd_ctx *fdjac_comm_ctx(const fd_comm *c);
+extern "C" fd_p2p *fdjac_comm_p2p(const fd_comm *c);       // the communicator's own mailbox (fd_comm_enable_p2p), or NULL
+extern "C" const fd_ctx *fdjac_p2p_ctx(const fd_p2p *p);
+extern "C" int fdjac_p2p_nranks(const fd_p2p *p);
+extern "C" int fdjac_p2p_rank(const fd_p2p *p);
+// level 2 of the step-size reduction, run by the last workgroup of the step exchange (fdjac_p2p.hip: element-type independent)
+struct fdjac_eps_final {
+    double *gsum;
+    int ldp, ngroups, C, is_forward, elem_bytes;
+    double relstep, absstep, dir;
+    void *eps, *eps2;
+};
+// ONE launch per step of a sharded call: this rank's slot of `gsum` (slot_bytes bytes at rank * slot_bytes) to every peer, the
+// halo of x to the neighbours (x = NULL / halo = 0: none), every peer's slot and the neighbours' halos received, then fin.
+// FD_ERR_UNSUPPORTED (nothing enqueued) when the payload does not fit the mailbox slot.
+extern "C" int fdjac_p2p_step(fd_p2p *p, void *x, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes, double *gsum,
+                              int64_t slot_bytes, const fdjac_eps_final *fin);
 
 // error text: one thread-local buffer for both instantiations (defined by the Float64 build)
 extern "C" void fdjac_set_error_v(const char *fmt, va_list ap);
@@ -114,6 +132,8 @@ enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLR
 
 constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
+constexpr int kEpsGroups = 64;       // ... and is defined over this many contiguous groups of x (the unit a rank of a sharded reduction owns)
+constexpr int kEpsBlocksPerGroup = 16;   //   each summed by at most this many workgroups (64 x 16 = 4 per CU)
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 constexpr int64_t kSmallN = 16384;   // below this a single-workgroup launch does step sizes (+ perturbation): launch-bound regime
@@ -159,6 +179,20 @@ __device__ inline int64_t xcd_tile(int64_t block, int64_t ntiles)
     return (block & 7) * xcd_chunks(ntiles) + (block >> 3);
 }
 
+// the step rule applied to a masked sum of squares t = sum_{color[j] == c} x[j]^2 (every step-size kernel ends in this)
+template <typename T> __device__ __forceinline__ T eps_rule(double t, double relstep, double absstep, double dir, int is_forward)
+{
+    // norm(x2), sqrt and the step rule in the element type, as the reference computes them:
+    //   forward: max(relstep*abs(sqrt(norm)), absstep)*dir   (src/epsilons.jl:26-29; the sqrt of the 2-norm is src/jacobians.jl:561)
+    //   central: max(relstep*abs(sqrt(norm)), absstep)       (src/epsilons.jl:50-53; jacobians.jl:602)
+    const T nrm = (T)sqrt(t);                  // norm(x2)
+    const T xs = fabs(sqrt(nrm));              // abs(sqrt(tmp))
+    const T a = (T)relstep * xs;
+    T e = (a > (T)absstep) ? a : (T)absstep;
+    if (is_forward) e = e * (T)dir;
+    return e;
+}
+
 struct TimedSpan {
     int stage;
     hipEvent_t a, b;
@@ -195,9 +229,8 @@ struct fd_plan {
     bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
     bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
-    int eps_tpb = 0;               //   > 0: the reduction's blocks sum CONTIGUOUS runs of this many tiles (FD_PLAN_EPS_CONTIGUOUS /
-                                   //   FDJAC_EPS_CONTIG=1): shard r of the reduction then reads only its own range of x
-    bool eps_contig = false;
+    int eps_tpg = 0, eps_bpg = 0, eps_tpb = 0;   // the two-level reduction's grid (k_eps_partial_reg): tiles per group, blocks per group, tiles
+                                   //   per block -- functions of N alone, so every rank / window / shard of one problem cuts x the same way
     bool cx = false;               // complex-valued x (FD_PLAN_COMPLEX_X): this plan is the lowered REAL problem -- element 2j / 2j+1 =
                                    //   re / im of x_j, only the real parts carry colours (are perturbed), a coloured element's masked
                                    //   norm includes its imaginary partner (|x_j|^2), f! is called with is_complex = 1
@@ -287,6 +320,10 @@ struct fd_plan {
     int32_t *d_fxwin = nullptr;        // sorted-gather plans: per tile kFxWin x (first row, rows) of the runs its entries' rows lie in (first < 0: none)
     int32_t *d_tile_order = nullptr;   // sorted-gather plans with a far band: the order in which the tiles are walked (else storage order)
     double *d_partial = nullptr;   // masked sums of squares are accumulated in Float64 for either element type
+    double *d_gsum = nullptr;      //   [2 * kEpsGroups][kRegColors] group sums of the two-level reduction (the second half: padding of the
+                                   //   last rank's slot when the groups do not divide by the rank count)
+    unsigned *d_tick = nullptr;    //   [kEpsGroups + 1] arrival tickets (zero between launches)
+    int64_t halo = 0, halo_own0 = 0, halo_own1 = 0;   // fd_plan_set_halo: x is sharded -- the call exchanges `halo` elements with the neighbour ranks
     fdjac::real_t *d_xstage = nullptr, *d_finstage = nullptr;
     int n_partial_blocks = 0;
     int64_t scratch_bytes = 0;
@@ -310,6 +347,8 @@ struct fd_plan {
     fdjac::real_t *d_eps2 = nullptr;          // 2 * eps per colour (central differences handed over as f(+) - f(-))
     bool eps2_fresh = false;                  //   d_eps2 matches d_eps (written by the finalize launch; else launch_scale)
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
+    fd_p2p *p2p = nullptr;         //   ... its group sums (and the halo of x) travel through this mailbox in ONE launch (fd_plan_set_p2p, or the
+                                   //   communicator's own mailbox)
     int eps_mode = 0;              // FD_EPS_COMPUTE / FD_EPS_PRECOMPUTED
     int64_t partial_cap = 0;       // doubles allocated behind d_partial
     int64_t fcalls_last = 0;

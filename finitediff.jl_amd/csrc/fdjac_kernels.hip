@@ -58,41 +58,51 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 //   loads allocate in the Infinity Cache and pay for the write-back of as many dirty lines as they bring in
 //   (scripts/ubench/eps_mall_probe.hip: 26.6 us after 240 MB of stores, 21.2 us after reads only, 21.4 us with
 //   non-temporal loads after stores).  Same values, same summation order => same bits in all four variants.
+// The reduction is DEFINED as a rank-aligned two-level sum (round 5), a function of N alone:
+//   level 0  x is cut into kEpsGroups = 64 contiguous groups of tpg tiles (tile = 2048 elements); a group into bpg blocks of tpb
+//            consecutive tiles; a block sums its tiles per thread, then the fixed shuffle tree, then its 4 waves in order;
+//   level 1  group sum[g][c]  = the group's bpg block sums added in block order;
+//   level 2  S[c] = the 64 group sums added in group order;  eps[c] from S[c] (eps_rule).
+// A rank of a W-rank job owns whole groups (ceil(64 / W) each): it exchanges 64 / W x C doubles instead of every block's
+// partial sums, and any split gives the bits of the unsharded call.  The levels run inside THIS launch: the last block of a
+// group to arrive (agent-scope ticket) adds the group's block sums, the last group to finish adds the group sums and writes
+// eps -- no finalize launch.  Hand-off between workgroups: 8-byte agent-scope atomic stores and loads on both sides with
+// the stores drained before the ticket (MI355X_MICROARCH.md, inter-workgroup visibility); which block does the adding never
+// changes what is added in which order.  final_groups = 0: stop after level 1 (a shard: its group sums are exchanged).
+struct EpsGrid {
+    int tpg, bpg, tpb;          // tiles per group, blocks per group, tiles per block
+    int final_groups;           // > 0: this launch covers that many groups = all of them: its last group writes eps
+    int C, is_forward;
+    double relstep, absstep, dir;
+};
+
 template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
-                  double *__restrict__ partial, int ldp, int cyc_C, int cyc_shift, int block_off, int grid_total, int contig_tpb, int pair)
+                  double *__restrict__ partial, double *__restrict__ gsum, unsigned *__restrict__ tick, int ldp, int cyc_C, int cyc_shift,
+                  int block_off, EpsGrid eg, int pair, real_t *__restrict__ eps, real_t *__restrict__ eps2)
 {
-    // The reduction is defined over a GLOBAL grid of grid_total blocks; this launch runs the blocks
-    // [block_off, block_off + gridDim.x) of it (all of them on one GPU; one shard per rank when the reduction is
-    // sharded across GPUs -- the partial sums are then exchanged and finalized in the same fixed order, so the step
-    // sizes do not depend on how the blocks were distributed).
-    const int64_t gblock = (int64_t)blockIdx.x + block_off;
+    const int gblock = (int)blockIdx.x + block_off;
+    const int grp = gblock / eg.bpg, kb = gblock - grp * eg.bpg;
     double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0;
 
-    // block tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
+    // tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
     const int64_t tile = (int64_t)kEpsU * kBlock * 2;
-    // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u and (stride mod C) per round
-    int rc = 0, du = 0, dr = 0;
+    const int64_t t0 = (int64_t)grp * eg.tpg + (int64_t)kb * eg.tpb;
+    int64_t t1 = t0 + eg.tpb;
+    if (t1 > (int64_t)(grp + 1) * eg.tpg) t1 = (int64_t)(grp + 1) * eg.tpg;
+    const int64_t base0 = t0 * tile;
+    int64_t base_end = t1 * tile;
+    if (base_end > n) base_end = n;
+    // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u
+    int rc = 0, du = 0;
     if (CYC) {
-        rc = (int)((gblock * tile + threadIdx.x * 2 + cyc_shift) % cyc_C);
+        rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C);
         du = (kBlock * 2) % cyc_C;
-        dr = (int)((((int64_t)grid_total - 1) * tile + (tile - (int64_t)(kEpsU - 1) * kBlock * 2)) % cyc_C);   // last u of a round -> first u of the next
     }
-    // which tiles a block sums is part of the reduction's DEFINITION (the partial sums are added in block order): either
-    // grid-stride (block b: tiles b, b + G, ...; every block reads all over x) or, contig_tpb > 0, contiguous (block b: tiles
-    // [b * tpb, (b + 1) * tpb): a range of blocks reads a range of x -- what a rank that holds only its own part of x needs)
-    int64_t base0 = gblock * tile, base_step = (int64_t)grid_total * tile, base_end = n;
-    if (contig_tpb > 0) {
-        base0 = gblock * (int64_t)contig_tpb * tile;
-        base_step = tile;
-        const int64_t e = base0 + (int64_t)contig_tpb * tile;
-        base_end = e < n ? e : n;
-        if (CYC) { rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C); dr = du; }
-    }
-    for (int64_t base = base0; base < base_end; base += base_step) {
+    for (int64_t base = base0; base < base_end; base += tile) {
         r2_t v[kEpsU];
         int c0[kEpsU], c1[kEpsU];
 #pragma unroll
@@ -101,7 +111,7 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
             if (CYC) {
                 c0[u] = rc;
                 c1[u] = rc + 1 == cyc_C ? 0 : rc + 1;
-                rc += (u + 1 < kEpsU) ? du : dr;
+                rc += du;
                 rc = rc >= cyc_C ? rc - cyc_C : rc;
             }
             if (i + 1 < n) {
@@ -137,12 +147,58 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
         if (lane == 0) red[wave][c] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NC) {
+    if (wave != 0) return;
+    // ---- level 0 result of this block, then the hand-off (wave 0 only; lanes < NC carry one colour each) ----
+    if (lane < NC) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += red[w][threadIdx.x];
-        partial[gblock * ldp + threadIdx.x] = s;
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
+        __hip_atomic_store(partial + (int64_t)gblock * ldp + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the block sums have left this CU before the ticket is drawn
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if (t != (unsigned)(eg.bpg - 1)) return;
+    // ---- level 1: this block arrived last in its group -- every block sum of the group is in memory ----
+    if (lane < NC) {
+        double gs = 0.0;
+        const double *pg = partial + (int64_t)grp * eg.bpg * ldp + lane;
+        for (int k = 0; k < eg.bpg; ++k) gs += __hip_atomic_load(pg + (int64_t)k * ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gsum + (int64_t)grp * ldp + lane, gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
+    if (eg.final_groups <= 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t2 = 0;
+    if (lane == 0) t2 = __hip_atomic_fetch_add(tick + kEpsGroups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t2 = (unsigned)__builtin_amdgcn_readfirstlane((int)t2);
+    if (t2 != (unsigned)(eg.final_groups - 1)) return;
+    // ---- level 2: the last group -- every group sum is in memory ----
+    if (lane < NC) {
+        double tot = 0.0;
+        for (int g = 0; g < kEpsGroups; ++g) tot += __hip_atomic_load(gsum + (int64_t)g * ldp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < eg.C) {
+            const real_t e = eps_rule<real_t>(tot, eg.relstep, eg.absstep, eg.dir, eg.is_forward);
+            eps[lane] = e;
+            if (eps2) eps2[lane] = (real_t)2 * e;           // (central differences handed over as f(+) - f(-), see launch_scale)
+        }
+    }
+    if (lane == 0) __hip_atomic_store(tick + kEpsGroups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// level 2 on its own: a sharded reduction's group sums have been exchanged (fd_plan_eps_finalize; with RCCL after the all-gather)
+__global__ void __launch_bounds__(64)
+k_eps_final(const double *__restrict__ gsum, int ldp, int C, double relstep, double absstep, double dir, int is_forward,
+            real_t *__restrict__ eps, real_t *__restrict__ eps2)
+{
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double tot = 0.0;
+    for (int g = 0; g < kEpsGroups; ++g) tot += gsum[(int64_t)g * ldp + c];
+    const real_t e = eps_rule<real_t>(tot, relstep, absstep, dir, is_forward);
+    eps[c] = e;
+    if (eps2) eps2[c] = (real_t)2 * e;
 }
 
 // K1b  same reduction for many colours: block (chunk k, colour c) walks colour c's column list
@@ -195,12 +251,7 @@ k_eps_finalize(const double *__restrict__ partial, int nparts, int ldp, double r
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < kBlock / 64; ++w) t += red[w];
-        // norm(x2), sqrt and the step rule in the element type, as the reference computes them
-        const real_t nrm = (real_t)sqrt(t);                  // norm(x2)
-        const real_t xs = fabs(sqrt(nrm));                   // abs(sqrt(tmp))
-        const real_t a = (real_t)relstep * xs;
-        real_t e = (a > (real_t)absstep) ? a : (real_t)absstep;
-        if (is_forward) e = e * (real_t)dir;
+        const real_t e = eps_rule<real_t>(t, relstep, absstep, dir, is_forward);
         eps[c] = e;
         if (eps2) eps2[c] = (real_t)2 * e;                  // (central differences handed over as f(+) - f(-), see launch_scale)
     }
@@ -1294,17 +1345,24 @@ static inline int grid_for(int64_t work_items, int per_block, int num_cus)
     return balanced_grid(tiles, cap);
 }
 
-// step-size reduction, register path (C <= kRegColors): blocks [b0, b0 + nb) of the global grid of n_partial_blocks
+// step-size reduction, register path (C <= kRegColors): the groups [g0, g0 + ng) of the two-level reduction.  final = the launch
+// covers all kEpsGroups groups and writes eps itself; otherwise it stops at the group sums (d_gsum) -- a shard.
 template <typename CT>
-static int launch_eps_partial_t(fd_plan *p, const real_t *x, int b0, int nb)
+static int launch_eps_groups_t(fd_plan *p, const real_t *x, int g0, int ng, bool final, double relstep, double absstep, double dir)
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
-    const int ldp = kRegColors, P = p->n_partial_blocks;
-    if (nb <= 0) return FD_OK;
+    const int ldp = kRegColors;
+    if (ng <= 0) return FD_OK;
+    EpsGrid eg;
+    eg.tpg = p->eps_tpg; eg.bpg = p->eps_bpg; eg.tpb = p->eps_tpb;
+    eg.final_groups = final ? ng : 0;
+    eg.C = C; eg.is_forward = p->fdtype == FD_FORWARD ? 1 : 0;
+    eg.relstep = relstep; eg.absstep = absstep; eg.dir = dir;
 #define FD_EPS_REG(NCC, CY, NTT)                                                                                \
-    hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3(nb), dim3(kBlock), 0, s, x,                   \
-                       (const CT *)p->d_color, p->N, p->d_partial, ldp, p->cyc_C, p->cyc_shift, b0, P, p->eps_tpb, p->cx ? 1 : 0)
+    hipLaunchKernelGGL((k_eps_partial_reg<CT, NCC, CY, NTT>), dim3((unsigned)(ng * eg.bpg)), dim3(kBlock), 0, s, x,  \
+                       (const CT *)p->d_color, p->N, p->d_partial, p->d_gsum, p->d_tick, ldp, p->cyc_C, p->cyc_shift, g0 * eg.bpg, eg, \
+                       p->cx ? 1 : 0, p->d_eps, p->d_eps2)
 #define FD_EPS_REG_V(NCC)                                                                                       \
     do {                                                                                                        \
         if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); }     \
@@ -1313,15 +1371,28 @@ static int launch_eps_partial_t(fd_plan *p, const real_t *x, int b0, int nb)
     if (C <= 4) FD_EPS_REG_V(4); else FD_EPS_REG_V(kRegColors);
 #undef FD_EPS_REG_V
 #undef FD_EPS_REG
+    if (final) p->eps2_fresh = p->d_eps2 != nullptr;
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
 
-int launch_eps_partial(fd_plan *p, const real_t *x, int b0, int nb)
+int launch_eps_groups(fd_plan *p, const real_t *x, int g0, int ng, bool final, double relstep, double absstep, double dir)
 {
-    return p->color8 ? launch_eps_partial_t<uint8_t>(p, x, b0, nb) : launch_eps_partial_t<int32_t>(p, x, b0, nb);
+    return p->color8 ? launch_eps_groups_t<uint8_t>(p, x, g0, ng, final, relstep, absstep, dir)
+                     : launch_eps_groups_t<int32_t>(p, x, g0, ng, final, relstep, absstep, dir);
 }
 
+// level 2 of the two-level reduction on its own (after an exchange of the group sums)
+int launch_eps_final(fd_plan *p, double relstep, double absstep, double dir)
+{
+    hipLaunchKernelGGL(k_eps_final, dim3(1), dim3(64), 0, p->ctx->stream, p->d_gsum, kRegColors, (int)p->C, relstep, absstep, dir,
+                       p->fdtype == FD_FORWARD ? 1 : 0, p->d_eps, p->d_eps2);
+    p->eps2_fresh = p->d_eps2 != nullptr;
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+// (the many-colour path's second stage: one block per colour over the chunk partials)
 int launch_eps_finalize(fd_plan *p, int nparts, int ldp, double relstep, double absstep, double dir)
 {
     hipLaunchKernelGGL(k_eps_finalize, dim3((unsigned)p->C), dim3(kBlock), 0, p->ctx->stream, p->d_partial, nparts, ldp, relstep,
@@ -1336,11 +1407,7 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
-    if (C <= kRegColors) {
-        int rc = launch_eps_partial_t<CT>(p, x, 0, p->n_partial_blocks);
-        if (rc) return rc;
-        return launch_eps_finalize(p, p->n_partial_blocks, kRegColors, relstep, absstep, dir);
-    }
+    if (C <= kRegColors) return launch_eps_groups_t<CT>(p, x, 0, kEpsGroups, true, relstep, absstep, dir);
     const int nparts = p->seg_chunks;
     hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,
                        x, p->d_perm, p->d_cptr, (int64_t)C, nparts, p->d_partial, p->cx ? 1 : 0);

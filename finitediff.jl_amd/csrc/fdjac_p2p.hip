@@ -40,7 +40,8 @@ struct fd_p2p {
     char *peer[kP2PMaxRanks] = {};            // the mailboxes as mapped here (peer[rank] == local)
     bool mapped[kP2PMaxRanks] = {};
     char **d_peer = nullptr;                  // device copy of peer[]
-    unsigned *d_arrived = nullptr;            // per-peer share counters of a put split over several workgroups (zero between launches)
+    unsigned *d_arrived = nullptr;            // per-peer share counters of a put split over several workgroups (zero between launches);
+                                              // [kP2PMaxRanks]: the arrival ticket of the step exchange's workgroups
     int *d_err = nullptr;                     // device error word (pinned host memory mapped to the device: readable without a sync)
     int *h_err = nullptr;
     uint64_t epoch[2] = {0, 0};
@@ -195,6 +196,89 @@ __global__ void __launch_bounds__(kBlock) k_p2p_exchange(char *const *__restrict
     p2p_wait_part(local_base, buf, get, nranks, rank, slot_bytes, epoch, all, timeout_ticks, err, chan_off, parts);
 }
 
+// ---- the per-step exchange of a sharded Jacobian call: ONE launch (fdjac_p2p_step) ---------------------------------------------
+// Workgroup b serves peer b: it stores this rank's group sums of the step-size reduction -- and, if b is a neighbour, the halo of x
+// b needs -- into b's mailbox (one slot, one flag), then waits for b's slot of the same exchange and copies b's group sums (and
+// halo) out.  The last workgroup to finish (agent-scope ticket; the group sums were copied out with agent-scope stores and are
+// read with agent-scope loads) adds the 64 group sums in group order and writes the step sizes: level 2 of the reduction as
+// k_eps_partial_reg defines it -- the bits of the unsharded call.  All-to-all on channel 0, so the parity argument of the all-gather
+// holds.  A rank's own group sums come from the launch before (stream order).
+struct P2PStep {
+    char *x;                    // NULL: no halo
+    int64_t own_begin, own_end, halo;
+    int elem_bytes;
+    char *gsum;                 // nranks slots of gs_bytes
+    int64_t gs_bytes;
+    fdjac_eps_final fin;
+};
+__device__ __forceinline__ void p2p_copy_out_agent(char *dst, const char *src, int64_t bytes)
+{
+    for (int64_t o = (int64_t)threadIdx.x * 8; o < bytes; o += (int64_t)blockDim.x * 8)
+        __hip_atomic_store((unsigned long long *)(dst + o),
+                           __hip_atomic_load((const unsigned long long *)(src + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(kBlock) k_p2p_step(char *const *__restrict__ peer, char *__restrict__ local, P2PStep st, int nranks, int rank,
+                                                     int64_t slot_bytes, uint64_t epoch, unsigned *__restrict__ ticket, int64_t timeout_ticks,
+                                                     int *__restrict__ err)
+{
+    const int b = (int)blockIdx.x;
+    const int64_t hb = st.x ? st.halo * st.elem_bytes : 0;
+    const bool below = st.x && b == rank - 1, above = st.x && b == rank + 1;
+    __shared__ int s_ok;
+    if (b != rank) {
+        char *mb = peer[b];
+        char *slot = mb + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + rank) * slot_bytes;
+        p2p_copy_in(slot, st.gsum + (int64_t)rank * st.gs_bytes, st.gs_bytes);
+        if (below) p2p_copy_in(slot + st.gs_bytes, st.x + st.own_begin * st.elem_bytes, hb);               // my first elements: b's upper halo
+        if (above) p2p_copy_in(slot + st.gs_bytes, st.x + (st.own_end - st.halo) * st.elem_bytes, hb);     // my last elements: b's lower halo
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store((unsigned long long *)(mb + (int64_t)rank * kP2PFlagStride), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long *flag = (const unsigned long long *)(local + (int64_t)b * kP2PFlagStride);
+            const long long t0 = wall_clock64();
+            int ok = 1;
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) __hip_atomic_store(err, 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // "rank b never arrived"
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (s_ok) {
+            const char *in = local + (int64_t)nranks * kP2PFlagStride + ((int64_t)(epoch & 1) * nranks + b) * slot_bytes;
+            p2p_copy_out_agent(st.gsum + (int64_t)b * st.gs_bytes, in, st.gs_bytes);
+            if (below) p2p_copy_out(st.x + (st.own_begin - st.halo) * st.elem_bytes, in + st.gs_bytes, hb);
+            if (above) p2p_copy_out(st.x + st.own_end * st.elem_bytes, in + st.gs_bytes, hb);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this workgroup's copies have left the CU before its ticket is drawn
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    unsigned t = 0;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if (t != (unsigned)(nranks - 1)) return;
+    const fdjac_eps_final &f = st.fin;
+    const int c = threadIdx.x;
+    if (c < f.C) {
+        double tot = 0.0;
+        for (int g = 0; g < f.ngroups; ++g) tot += __hip_atomic_load(f.gsum + (int64_t)g * f.ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.elem_bytes == 4) {
+            const float e = eps_rule<float>(tot, f.relstep, f.absstep, f.dir, f.is_forward);
+            ((float *)f.eps)[c] = e;
+            if (f.eps2) ((float *)f.eps2)[c] = 2.0f * e;
+        } else {
+            const double e = eps_rule<double>(tot, f.relstep, f.absstep, f.dir, f.is_forward);
+            ((double *)f.eps)[c] = e;
+            if (f.eps2) ((double *)f.eps2)[c] = 2.0 * e;
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
+}
+
 }  // namespace fdjac
 
 using namespace fdjac;
@@ -230,12 +314,13 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     }
     p->local = (char *)mem;
     p->peer[rank] = p->local;
-    hipError_t e = hipMemset(p->local, 0, bytes);
+    hipError_t e = hipMemset(p->local, 0, bytes);       // (blocking, on the null stream: complete before the handle is published)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_err, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *p->h_err = 0; e = hipHostGetDevicePointer((void **)&p->d_err, p->h_err, 0); }
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_peer, sizeof(char *) * kP2PMaxRanks);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_arrived, sizeof(unsigned) * kP2PMaxRanks);
-    if (e == hipSuccess) e = hipMemset(p->d_arrived, 0, sizeof(unsigned) * kP2PMaxRanks);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_arrived, sizeof(unsigned) * (kP2PMaxRanks + 1));
+    if (e == hipSuccess) e = hipMemset(p->d_arrived, 0, sizeof(unsigned) * (kP2PMaxRanks + 1));
     if (e != hipSuccess) {
         set_error("setting up the mailbox failed: %s", hipGetErrorString(e));
         if (p->h_err) (void)hipHostFree(p->h_err);
@@ -386,6 +471,32 @@ int fd_p2p_halo_exchange(fd_p2p *p, void *buf, int64_t own_begin, int64_t own_en
 }
 
 }  // extern "C"
+
+
+extern "C" int fdjac_p2p_step(fd_p2p *p, void *x, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes, double *gsum,
+                              int64_t gs_bytes, const fdjac_eps_final *fin)
+{
+    FD_REQUIRE(p && gsum && fin, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(p->connected, FD_ERR_COMM, "fd_p2p_connect has not been called");
+    const bool with_halo = x != nullptr && halo > 0;
+    const int64_t hb = with_halo ? halo * elem_bytes : 0;
+    if (gs_bytes % 8 != 0 || hb % 8 != 0 || gs_bytes + hb > p->slot_bytes) return FD_ERR_UNSUPPORTED;      // (the caller falls back to RCCL)
+    if (with_halo) {
+        FD_REQUIRE(own_end - own_begin >= halo, FD_ERR_ARG, "this rank owns fewer than `halo` elements");
+        FD_REQUIRE(p->rank == 0 || own_begin >= halo, FD_ERR_ARG, "no room for the lower halo");
+    }
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    const uint64_t epoch = ++p->epoch[0];
+    P2PStep st;
+    st.x = with_halo ? (char *)x : nullptr;
+    st.own_begin = own_begin; st.own_end = own_end; st.halo = halo; st.elem_bytes = elem_bytes;
+    st.gsum = (char *)gsum; st.gs_bytes = gs_bytes;
+    st.fin = *fin;
+    hipLaunchKernelGGL(k_p2p_step, dim3((unsigned)p->nranks), dim3(kBlock), 0, p->ctx->stream, p->d_peer, p->local, st, p->nranks, p->rank, p->slot_bytes,
+                       epoch, p->d_arrived + kP2PMaxRanks, p2p_timeout_ticks(), p->d_err);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
 
 // internals for fdjac_comm.hip (a communicator with an attached mailbox routes its small messages here)
 extern "C" int64_t fdjac_p2p_slot_bytes(const fd_p2p *p) { return p ? p->slot_bytes : 0; }

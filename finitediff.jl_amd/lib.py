@@ -70,10 +70,10 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status",
     "fd_p2p_create", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
-    "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
+    "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
     "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
@@ -89,7 +89,7 @@ TYPED = (
     "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
-    "fd_plan_set_comm", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
+    "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
     "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
@@ -219,6 +219,7 @@ def load():
     L.fd_comm_broadcast.argtypes = [vp, vp, i64, i32, i32]
     L.fd_comm_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
     L.fd_comm_enable_p2p.argtypes = [vp, i64]
+    L.fd_comm_p2p_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
     L.fd_p2p_local_handle.argtypes = [vp, vp]
     L.fd_p2p_connect.argtypes = [vp, vp]
@@ -229,6 +230,8 @@ def load():
     L.fd_p2p_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
     L.fd_plan_eps_shard_range.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.fd_plan_set_comm.argtypes = [vp, vp]
+    L.fd_plan_set_p2p.argtypes = [vp, vp]
+    L.fd_plan_set_halo.argtypes = [vp, i64, i64, i64]
     L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]
     L.fd_plan_eps_finalize.argtypes = [vp, dbl, dbl, dbl]
     L.fd_plan_set_eps_mode.argtypes = [vp, i32]

@@ -33,10 +33,24 @@ def partition_columns(colptr, world):
     return np.maximum.accumulate(np.minimum(cuts, n))
 
 
+EPS_GROUPS, EPS_TILE = 64, 2048       # csrc/fdjac_internal.h kEpsGroups; k_eps_partial_reg's tile of 4 x 512 elements
+
+
+def eps_shard_cuts(n, world):
+    """Column cuts (world+1,) where the step-size reduction cuts x between the ranks: the reduction is defined over 64
+    contiguous groups of ceil(ceil(n / 2048) / 64) tiles, rank r owns groups [r * ceil(64 / world), ...).  The formula of
+    fd_plan_eps_shard_range (a function of n and world alone: no plan needed; tests pin the two against each other)."""
+    tiles = (int(n) + EPS_TILE - 1) // EPS_TILE
+    per_group = ((tiles + EPS_GROUPS - 1) // EPS_GROUPS) * EPS_TILE
+    s = (EPS_GROUPS + world - 1) // world
+    cuts = np.array([min(min(r * s, EPS_GROUPS) * per_group, n) for r in range(world)] + [int(n)], dtype=np.int64)
+    return np.maximum.accumulate(cuts)
+
+
 def partition_columns_at(bounds, n):
-    """Column cuts taken from the step-size reduction's shard ranges (`Plan.eps_shard_range(r, world)` of a plan created with
-    eps_contiguous=True): rank r then owns exactly the part of x it reduces, and a time-stepping loop keeps x sharded -- the
-    only per-step traffic is the halo (`fd_comm_halo_exchange`) and the all-gather of the partial sums."""
+    """Column cuts taken from the step-size reduction's shard ranges (`Plan.eps_shard_range(r, world)`): rank r then owns exactly
+    the part of x it reduces, and a time-stepping loop keeps x sharded -- the only per-step traffic is ONE exchange of the halo
+    and the reduction's group sums (`fd_plan_set_halo`)."""
     cuts = np.array([int(b[0]) for b in bounds] + [int(n)], dtype=np.int64)
     cuts[0] = 0
     return np.maximum.accumulate(np.minimum(cuts, n))

@@ -148,13 +148,8 @@ typedef struct fd_plan_opts {
                            /*   owners' outputs add up to the full result when outs start from zero.            */
 } fd_plan_opts;
 /* fd_plan_opts.flags */
-#define FD_PLAN_EPS_CONTIGUOUS 1   /* the step-size reduction's blocks sum CONTIGUOUS ranges of x.  This is the default map since   */
-                                   /* round 3 (FDJAC_EPS_CONTIG=0 restores the grid-stride map of rounds 1-2; the flag insists on  */
-                                   /* the contiguous one whatever the environment says).  Which elements a block sums is part of   */
-                                   /* the reduction's definition (the two maps differ by rounding, ~1e-16 relative; each is       */
-                                   /* deterministic).  With the contiguous map shard r of a sharded reduction (fd_plan_set_comm,  */
-                                   /* fd_plan_eps_partials) reads only x[fd_plan_eps_shard_range(r)): a rank of a time-stepping   */
-                                   /* loop that holds its own part of x plus a halo needs nothing else -- no replicated x          */
+#define FD_PLAN_EPS_CONTIGUOUS 1   /* accepted and ignored since round 5: the step-size reduction always sums contiguous groups of x    */
+                                   /* (see "Sharded step-size reduction" below)                                                     */
 
 #define FD_PLAN_COMPLEX_X 2         /* x, the f! values and J are COMPLEX (returntype <: Complex with Val(:forward) / Val(:central):  */
                                    /* src/jacobians.jl:94-128, 537-622; test/finitedifftests.jl:480-513).  M, N, the pattern and     */
@@ -500,17 +495,29 @@ int fd_p2p_halo_exchange(fd_p2p *p2p, void *buf, int64_t own_begin, int64_t own_
 /* Create a mailbox for the communicator's ranks, exchange the handles over RCCL and route the communicator's small messages
    through it (collective: every rank calls it; blocking).  FD_ERR_COMM if the peers cannot be mapped (ranks on several nodes). */
 int fd_comm_enable_p2p(fd_comm *comm, int64_t slot_bytes);
+/* does the communicator route its small messages through a mailbox (*enabled), and has a wait of it ever timed out (as fd_p2p_status)? */
+int fd_comm_p2p_status(const fd_comm *comm, int *enabled, int *timed_out_rank_plus_1);
 
-/* Sharded step-size reduction.  By default every rank reduces the whole (replicated) x -- no communication, identical
-   step sizes everywhere.  With a communicator attached, rank r reduces only blocks r of nranks of the SAME global grid
-   of partial sums, the partials (a few KB) are all-gathered and finalized in the same fixed order: the step sizes are
-   bit-identical to the unsharded call's, and the serial part of a strong-scaled Jacobian shrinks by nranks (at the
-   price of one small-message collective on the critical path).  comm = NULL detaches.  The communicator must have been
-   created on the plan's context.  Plans whose reduction cannot be sharded (more than 8 colours, N <= 16384, dense arm,
-   complex step: no reduction at all) keep the replicated reduction. */
+/* Sharded step-size reduction (src/jacobians.jl:559-561 / 600-602 across ranks).  The reduction is DEFINED as a two-level sum that
+   depends on N alone: x is cut into 64 contiguous groups, a group's blocks are added in block order, the 64 group sums in group order.
+   By default every rank reduces the whole (replicated) x in one launch -- no communication, identical step sizes everywhere.  With a
+   communicator (or a bare mailbox) attached, rank r of W reduces only ITS groups -- groups [r * ceil(64 / W), ...): the part of x
+   that fd_plan_eps_shard_range reports, so cut the column ownership there -- and the ranks exchange their group sums (64 / W x 8
+   doubles each: 512 B at W = 8), then add the 64 group sums in the same order: bit-identical step sizes on every rank, whatever W.
+   With a mailbox (fd_comm_enable_p2p, or fd_plan_set_p2p for callers without RCCL) the exchange is ONE launch per call, whose last
+   workgroup writes the step sizes; without, an in-place all-gather + one tiny launch.  comm / p2p = NULL detaches.  Both must live on
+   the plan's context.  Plans whose reduction cannot be sharded (more than 8 colours, N <= 16384, dense arm, complex step: no reduction
+   at all) keep the replicated reduction. */
 int fd_plan_set_comm(fd_plan *plan, fd_comm *comm);
-/* The same reduction in explicit pieces, for callers that exchange the partial sums themselves (MPI.jl, tests):
-   fd_plan_eps_partials enqueues shard `shard` of `nshards` and returns the device address of the partial buffer
+int fd_plan_set_p2p(fd_plan *plan, fd_p2p *p2p);
+/* x is SHARDED too (a time-stepping loop: rank r holds x[own_begin, own_end) of the global vector it addresses, plus `halo` elements
+   either side that f! reads): every following fd_jacobian* call of a plan with a communicator / mailbox exchanges the halo with the
+   neighbour ranks itself -- it rides in the same launch as the group sums (mailbox) or as one grouped send / recv (RCCL) -- and
+   WRITES x[own_begin - halo, own_begin) and x[own_end, own_end + halo) although x is declared const.  halo = 0 turns it off.
+   FD_ERR_UNSUPPORTED for plans whose reduction cannot be sharded (exchange the halo with fd_comm_halo_exchange then). */
+int fd_plan_set_halo(fd_plan *plan, int64_t own_begin, int64_t own_end, int64_t halo);
+/* The same reduction in explicit pieces, for callers that exchange the group sums themselves (MPI.jl, tests):
+   fd_plan_eps_partials enqueues shard `shard` of `nshards` (<= 64) and returns the device address of the group-sum buffer
    (nshards slots of *slot_doubles_out doubles; shard r fills slot r); after the exchange fd_plan_eps_finalize turns the
    complete buffer into step sizes; fd_plan_set_eps_mode(plan, FD_EPS_PRECOMPUTED) makes the following fd_jacobian* calls
    use them instead of reducing x again (FD_EPS_COMPUTE restores the default).  FD_ERR_UNSUPPORTED for plans whose
@@ -520,9 +527,8 @@ int fd_plan_eps_partials(fd_plan *plan, const void *x_dev, int shard, int nshard
                          int64_t *slot_doubles_out);
 int fd_plan_eps_finalize(fd_plan *plan, double relstep, double absstep, double dir);
 int fd_plan_set_eps_mode(fd_plan *plan, int mode);
-/* The elements of x shard `shard` of `nshards` of the reduction reads, [*x_begin, *x_end): all of x for the default
-   grid-stride map, the shard's own contiguous range for plans created with FD_PLAN_EPS_CONTIGUOUS -- cut the column / row
-   ownership of a multi-GPU run at these boundaries and every rank reduces exactly what it owns. */
+/* The elements of x shard `shard` of `nshards` of the reduction reads, [*x_begin, *x_end): the shard's groups -- cut the column /
+   row ownership of a multi-GPU run at these boundaries and every rank reduces exactly what it owns. */
 int fd_plan_eps_shard_range(fd_plan *plan, int shard, int nshards, int64_t *x_begin, int64_t *x_end);
 
 /* ---- the consumer: tridiagonal solve with the Jacobian where fd_jacobian_async left it -----------
@@ -626,6 +632,8 @@ int fd32_tridiag_solve_interface(fd32_tridiag_solver *solver, double alpha, doub
 int fd32_tridiag_solve_finish(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
                               const void *packets_dev, int rank, int nranks, void *y);
 int fd32_plan_set_comm(fd32_plan *plan, fd_comm *comm);
+int fd32_plan_set_p2p(fd32_plan *plan, fd_p2p *p2p);
+int fd32_plan_set_halo(fd32_plan *plan, int64_t own_begin, int64_t own_end, int64_t halo);
 int fd32_plan_eps_partials(fd32_plan *plan, const void *x_dev, int shard, int nshards, void **partials_out,
                            int64_t *slot_doubles_out);
 int fd32_plan_eps_finalize(fd32_plan *plan, double relstep, double absstep, double dir);

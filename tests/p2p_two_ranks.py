@@ -102,6 +102,58 @@ def main():
     assert p2p.status() == 0
     dist.barrier()
 
+    # (3b) the per-step exchange of a sharded call as ONE launch (fd_plan_set_p2p + fd_plan_set_halo): each rank holds only its own part
+    # of x (NaN elsewhere), cut where the reduction's groups are cut; the call exchanges the halo and the group sums and finishes the
+    # step sizes itself.  Many steps back to back with a new x each time and unequal work between the ranks (rank 1 does extra launches:
+    # a stale group sum or halo from the step before would show); the bits of the unsharded call on the full x.
+    from finitediff_jl_amd import sharded as S
+    ranges = [ref_plan.eps_shard_range(r, world) for r in range(world)]
+    cuts3 = S.partition_columns_at(ranges, Nn)
+    c0, c1 = int(cuts3[rank]), int(cuts3[rank + 1])
+    ent = S.entry_ranges(cp, cuts3)
+    e0, e1 = ent[rank]
+    wplan = fd.make_plan(pat, pat, colors, "forward", ctx=ctx, col_window=(c0, c1), x_window=S.x_window(cuts3, rank, Nn, 1, 1, 1))
+    wplan.set_lazy(f)
+    wplan.set_p2p(p2p)
+    wplan.set_halo(c0, c1, 2)
+    ref_plan.set_lazy(f)
+    rng = np.random.default_rng(77)
+    lo, hi = max(c0 - 2, 0), min(c1 + 2, Nn)
+    junk = torch.zeros(1 << 22, dtype=torch.float64, device=dev)
+    for it in range(40):
+        xfull = torch.as_tensor(rng.random(Nn) * (1.0 + it), device=dev)
+        xmine = torch.full((Nn,), float("nan"), dtype=torch.float64, device=dev)
+        xmine[c0:c1] = xfull[c0:c1]
+        if rank == 1 and it % 3 == 0:
+            for _ in range(5):
+                junk.add_(1.0)                       # unequal load: this rank arrives late
+        piece = torch.full((e1 - e0,), float("nan"), dtype=torch.float64, device=dev)
+        wplan.jacobian(f, xmine, [piece], sync=False)
+        ref_plan.jacobian(f, xfull, [out_ref])
+        torch.cuda.synchronize()
+        assert np.array_equal(wplan.epsilons(), ref_plan.epsilons()), ("step eps", it)
+        assert torch.equal(piece, out_ref[e0:e1]), ("step", it)
+        assert torch.equal(xmine[lo:hi], xfull[lo:hi]) and torch.isnan(xmine[:lo]).all() and torch.isnan(xmine[hi:]).all(), ("step halo", it)
+    assert p2p.status() == 0
+    xmine[c0:c1] = xfull[c0:c1]
+    dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    call = wplan.bind(f, xmine, [piece])
+    for _ in range(10):
+        call()
+    torch.cuda.synchronize()
+    dist.barrier()
+    ev0.record()
+    for _ in range(200):
+        call()
+    ev1.record()
+    torch.cuda.synchronize()
+    assert p2p.status() == 0
+    if rank == 0:
+        print("sharded call with the one-launch step exchange (2 processes, 1 GPU, N = %d): %.1f us per call" % (Nn, ev0.elapsed_time(ev1) * 1e3 / 200))
+    wplan.set_p2p(None)
+    dist.barrier()
+
     # (4) a peer that never arrives: the wait gives up after FDJAC_P2P_TIMEOUT_MS and raises the status word -- no hang
     os.environ["FDJAC_P2P_TIMEOUT_MS"] = "150"
     if rank == 0:

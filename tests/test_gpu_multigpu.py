@@ -53,8 +53,8 @@ def test_comm_single_rank_goes_through_rccl(comm1):
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("C,N", [(3, 10 ** 6 + 7), (5, 300001), (8, 123456)])
 def test_sharded_step_size_reduction_bit_identical(fdtype, C, N):
-    # fd_plan_eps_partials shard by shard (what each rank of a W-rank job runs), fd_plan_eps_finalize, FD_EPS_PRECOMPUTED:
-    # the step sizes and the Jacobian have the bits of the plain call, whatever W is
+    # fd_plan_eps_partials shard by shard (what each rank of a W-rank job runs: its groups of the two-level sum), fd_plan_eps_finalize,
+    # FD_EPS_PRECOMPUTED: the step sizes and the Jacobian have the bits of the plain call, whatever W is
     colors = P.cyclic_colors(N, C)
     if C == 5:
         colors = colors.copy()
@@ -68,7 +68,7 @@ def test_sharded_step_size_reduction_bit_identical(fdtype, C, N):
     ref = _nan(ref_plan.out_len(0))
     ref_plan.jacobian(fn, x, [ref])
     eps_ref = ref_plan.epsilons()
-    for W in (1, 2, 3, 8):
+    for W in (1, 2, 3, 8, 64):
         plan = fd.make_plan(J, J, colors, fdtype)
         for r in reversed(range(W)):       # any order: the slots are disjoint
             ptr, slot = plan.eps_partials(x, r, W)
@@ -85,8 +85,36 @@ def test_sharded_step_size_reduction_bit_identical(fdtype, C, N):
         assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("C,N", [(3, 10 ** 6 + 7), (5, 300001), (8, 123456), (3, 16385), (2, 3 * 10 ** 6)])
+def test_step_sizes_have_the_bits_of_the_defined_summation_order(dtype, fdtype, C, N):
+    # the step sizes are a DEFINED function of x: tests/eps_order.py restates the two-level summation order in numpy, IEEE operation
+    # for operation -- the device must give its bits (one launch, every level inside it: the last block of a group adds the group,
+    # the last group adds the groups), call after call with a new x each time (a stale block / group sum would show)
+    import eps_order
+    colors = P.cyclic_colors(N, C)
+    if C == 5:
+        colors = colors.copy()
+        colors[[10, N // 3]] = 0          # not cyclic: the reduction reads the colours; two columns without colour
+    colptr, rowval = P.banded_csc(N, N, C // 2, C - 1 - C // 2)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval)
+    t_dt = torch.float64 if dtype == np.float64 else torch.float32
+    fn = fd.TorchF(lambda fx, xx: fx.copy_(torch.sin(xx)), N, N, dtype=dtype)
+    plan = fd.make_plan(J, J, colors, fdtype, dtype=dtype)
+    out = torch.empty(plan.out_len(0), dtype=t_dt, device="cuda")
+    rng = np.random.default_rng(100 + C)
+    for it in range(4):
+        xh = ((rng.random(N) * 2 - 0.5) * (1 + 10 * it)).astype(dtype)
+        x = torch.as_tensor(xh, device="cuda")
+        plan.jacobian(fn, x, [out])
+        want = eps_order.epsilons(xh, np.asarray(colors, dtype=np.int64) - 1, C, fdtype, dtype=dtype)
+        got = plan.epsilons()
+        assert np.array_equal(got, want.astype(np.float64)), (it, got, want)
+
+
 def test_plan_with_communicator_matches_plain_call(comm1):
-    # fd_plan_set_comm: partial sums of this rank's blocks -> in-place all-gather -> the same finalize
+    # fd_plan_set_comm: group sums of this rank's groups -> in-place all-gather -> level 2 of the same sum
     N = 2 * 10 ** 6 + 1
     colors = P.cyclic_colors(N, 3)
     colptr, rowval = P.tridiag_csc(N)
@@ -141,10 +169,9 @@ def test_column_ranges_and_gatherv_assemble_the_jacobian(comm1):
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 @pytest.mark.parametrize("N", [10 ** 6 + 7, 300001])
 def test_contiguous_step_size_reduction_reads_only_the_shard(monkeypatch, fdtype, N):
-    # FD_PLAN_EPS_CONTIGUOUS (the default map since round 3): the reduction's blocks sum contiguous ranges of x, so shard r of W reads only
+    # the reduction sums contiguous GROUPS of x (64 of them; a shard = whole groups), so shard r of W reads only
     # x[fd_plan_eps_shard_range(r, W)) -- proven by poisoning everything else with NaN -- and the step sizes / the Jacobian of
-    # the sharded reduction have the bits of the same plan's unsharded call (the map is part of the reduction's definition:
-    # against the default grid-stride map the step sizes agree to rounding)
+    # the sharded reduction have the bits of the same plan's unsharded call
     C = 3
     colors = P.cyclic_colors(N, C)
     xh = np.random.default_rng(11).random(N) * 2 - 0.5
@@ -152,23 +179,16 @@ def test_contiguous_step_size_reduction_reads_only_the_shard(monkeypatch, fdtype
     colptr, rowval = P.tridiag_csc(N)
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     f = fd.BuiltinF("tridiag_nl", N)
-    ref_plan = fd.make_plan(J, J, colors, fdtype, eps_contiguous=True)
+    ref_plan = fd.make_plan(J, J, colors, fdtype)
     ref_plan.set_lazy(f)
     ref = _nan(ref_plan.out_len(0))
     ref_plan.jacobian(f, x, [ref])
     eps_ref = ref_plan.epsilons()
-    monkeypatch.setenv("FDJAC_EPS_CONTIG", "0")              # the grid-stride map of rounds 1-2
-    strided = fd.make_plan(J, J, colors, fdtype)
-    monkeypatch.delenv("FDJAC_EPS_CONTIG")
-    strided.set_lazy(f)
-    tmp = _nan(strided.out_len(0))
-    strided.jacobian(f, x, [tmp])
-    assert np.allclose(strided.epsilons(), eps_ref, rtol=1e-13, atol=0)
-    assert strided.eps_shard_range(1, 4) == (0, N)            # grid-stride: every shard reads all over x
-    for W in (1, 2, 3, 8):
-        plan = fd.make_plan(J, J, colors, fdtype, eps_contiguous=True)
+    for W in (1, 2, 3, 8, 64):
+        plan = fd.make_plan(J, J, colors, fdtype)
         plan.set_lazy(f)
         ranges = [plan.eps_shard_range(r, W) for r in range(W)]
+        assert S.eps_shard_cuts(N, W).tolist() == [a for a, _b in ranges] + [N]      # the host-side formula bench.py cuts with
         assert ranges[0][0] == 0 and ranges[-1][1] == N and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
         for r in reversed(range(W)):
             a, b = ranges[r]
@@ -185,8 +205,10 @@ def test_contiguous_step_size_reduction_reads_only_the_shard(monkeypatch, fdtype
         # column cuts at the shard boundaries: windowed plans (all of them with the contiguous map) concatenate to the full result
         cuts = S.partition_columns_at(ranges, N)
         pieces = []
+        if W > 8:
+            continue
         for r in range(W):
-            wp = fd.make_plan(J, J, colors, fdtype, col_window=(int(cuts[r]), int(cuts[r + 1])), eps_contiguous=True)
+            wp = fd.make_plan(J, J, colors, fdtype, col_window=(int(cuts[r]), int(cuts[r + 1])))
             wp.set_lazy(f)
             o = _nan(wp.out_len(0))
             wp.jacobian(f, x, [o])

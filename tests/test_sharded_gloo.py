@@ -167,6 +167,53 @@ def test_bench_two_ranks_dry_run_variants(variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_spawns_its_own_ranks_and_times_every_variant():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses for --gpus 1): bench.py starts the ranks itself, times
+    all four variants (strong / weak x replicated / sharded with the one-launch exchange through the mailboxes -- two processes
+    sharing the one GPU, gloo for the barriers), reports the fastest as `value` and the rest in `variants`; ONE JSON line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FDJAC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "300001", "--soak-seconds", "0.3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["result_check"]["ok"], res["result_check"]
+    names = [v["name"] for v in res["variants"]]
+    assert names == ["strong-replicated", "strong-sharded", "weak-replicated", "weak-sharded"]
+    assert all("error" not in v and v["ms_per_step"] > 0 for v in res["variants"]), res["variants"]
+    assert res["config"]["variant"] in names and res["scaling"] == res["config"]["variant"].split("-")[0]
+    sh = [v for v in res["variants"] if v["name"].endswith("sharded")]
+    assert all("ONE launch through the peer-to-peer mailboxes" in v["exchange"] for v in sh)
+    assert res["p2p_status"] == 0
+
+
+@pytest.mark.timeout(120)
+def test_bench_without_gpu_still_prints_one_line():
+    """Whatever goes wrong, the contract's ONE JSON line is printed: here a 2-rank self-spawn on a box without a GPU (the CPU container) --
+    and on a GPU box a spawn whose ranks cannot finish in time."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "300001", "--soak-seconds", "0"]
+    if has_gpu:
+        cmd += ["--spawn-timeout", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads(lines[0])
+    assert res["value"] is None and res["error"] and res["n_gpus"] == 2
+    assert out.returncode != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(400)
 @pytest.mark.parametrize("in_step", [False, True], ids=["sharded_output", "gather_in_step"])
 def test_bench_two_ranks_share_one_gpu(tmp_path, in_step):
@@ -180,7 +227,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, in_step):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FDJAC_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--size", "300001", "--soak-seconds", "0"] + (["--gather-in-step"] if in_step else [])
+           "--warmup", "1", "--size", "300001", "--soak-seconds", "0", "--variant", "flags"] + (["--gather-in-step"] if in_step else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
