@@ -247,15 +247,22 @@ def main():
     # the assembly is staged through host memory by torch.distributed); the measured configuration is "nccl": RCCL,
     # called by libfdjac itself (fd_comm_*), torch.distributed only for the barrier / max-over-ranks / id broadcast.
     backend = os.environ.get("FDJAC_BENCH_BACKEND", "nccl")
+    shared_devices = None
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        # fewer GPUs than ranks: RCCL refuses two ranks on one device (and may hang finding out) -- run the dry-run transport and say so
+        backend = "gloo"
+        shared_devices = "%d ranks on %d GPU(s): ranks share devices, RCCL is impossible -- gloo dry run, NOT a scaling measurement" % (world, torch.cuda.device_count())
+        sys.stderr.write("[bench rank %d] %s\n" % (rank, shared_devices))
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     # one dedicated (non-default) stream for everything: the library enqueues on torch's current stream, so torch ops,
     # the RCCL collectives and torch events are all ordered with the library's kernels
@@ -270,7 +277,7 @@ def main():
         raise SystemExit("--config %s is a single-GPU line" % cfg)
     ctx = fd.Context(dev_index)
     comm = None
-    comm_error = None
+    comm_error = shared_devices
     if world > 1 and backend == "nccl":
         try:
             comm = fd.Comm.from_torch_distributed(ctx, dist)
