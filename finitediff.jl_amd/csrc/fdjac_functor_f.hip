@@ -284,6 +284,63 @@ struct SparseF {
         return s;
     }
     template <class P> __device__ __forceinline__ real_t operator()(long long r, const P &X) const { return row<real_t>(r, X); }
+
+    // fd_csc_store_cols_win (include/fdjac_device.h): the row pattern of the rows [r_lo, r_hi) a workgroup's columns can touch, kept in
+    // LDS -- the rows' offsets (int32, r_hi - r_lo + 1 of them) and up to `cap` of their column indices as 16-bit distances from the
+    // workgroup's x window (0xFFFF: not representable -> the index is read from memory).  Rows / entries that were not staged are
+    // served from memory: same indices, same order, same bits.
+    struct Staged {
+        const int32_t *srow, *scol;
+        const int32_t *l_row;        // LDS: srow[r_lo .. r_hi]
+        const uint16_t *l_col;       // LDS: codes of the entries [e_lo, e_lo + e_n)
+        int64_t r_lo, r_hi, w0;
+        int e_lo, e_n;
+        __device__ __forceinline__ int64_t col_of(int a) const
+        {
+            const int k = a - e_lo;
+            if (k >= 0 && k < e_n) {
+                const unsigned cde = l_col[k];
+                if (cde != 0xFFFFu) return w0 + (int64_t)cde;
+            }
+            return scol[a];
+        }
+        template <typename T, class P> __device__ __forceinline__ T row(int64_t r, const P &X) const
+        {
+            const bool st = r >= r_lo && r < r_hi;
+            const int a0 = st ? l_row[r - r_lo] : srow[r], a1 = st ? l_row[r - r_lo + 1] : srow[r + 1];
+            T s = zero_of<T>();
+            for (int a = a0; a < a1; a += FD_SPARSE_U) {
+                int64_t j[FD_SPARSE_U];
+                T v[FD_SPARSE_U];
+#pragma unroll
+                for (int u = 0; u < FD_SPARSE_U; ++u) j[u] = col_of(a + u < a1 ? a + u : a1 - 1);
+#pragma unroll
+                for (int u = 0; u < FD_SPARSE_U; ++u) v[u] = X(j[u]);
+#pragma unroll
+                for (int u = 0; u < FD_SPARSE_U; ++u) {
+                    const T t = ((real_t)1 + kEighth * (real_t)(int)((r + 3 * j[u]) & 7)) * (v[u] + (kQuarter * v[u]) * v[u]);
+                    if (a + u < a1) s = a + u == a0 ? t : s + t;
+                }
+            }
+            return s;
+        }
+        template <class P> __device__ __forceinline__ real_t operator()(long long r, const P &X) const { return row<real_t>(r, X); }
+    };
+    static size_t stage_bytes(int64_t rows, int cap) { return ((size_t)(rows + 2) * 4 + 15) / 16 * 16 + (size_t)cap * 2 + 16; }
+    __device__ __forceinline__ Staged stage(void *lds, long long r_lo, long long r_hi, long long w0, int cap) const
+    {
+        int32_t *l_row = (int32_t *)lds;
+        const int nr = (int)(r_hi - r_lo);
+        uint16_t *l_col = (uint16_t *)((unsigned char *)lds + ((size_t)(nr + 2) * 4 + 15) / 16 * 16);
+        for (int i = threadIdx.x; i <= nr; i += blockDim.x) l_row[i] = srow[r_lo + i];
+        const int e_lo = srow[r_lo], e_hi = srow[r_hi];
+        const int e_n = e_hi - e_lo < cap ? e_hi - e_lo : cap;
+        for (int k = threadIdx.x; k < e_n; k += blockDim.x) {
+            const int64_t d = (int64_t)scol[e_lo + k] - w0;
+            l_col[k] = (d >= 0 && d < 0xFFFF) ? (uint16_t)d : (uint16_t)0xFFFFu;
+        }
+        return Staged{srow, scol, l_row, l_col, r_lo, r_hi, w0, e_lo, e_n};
+    }
 };
 
 template <typename T, class F>
@@ -344,7 +401,24 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         }
     } else {
         const SparseF f = {b->d_srow, b->d_scol};
-        FD_COLS(SparseF, f);
+        // a locally banded pattern (the plan measured its reach) with a verified colouring: the workgroup's window of x, f(x) of its
+        // rows and the rows' pattern are staged in LDS (fd_csc_store_cols_win); otherwise the plain column kernel
+        const int64_t reach = st.reach;
+        bool win = st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N;
+        if (win) {
+            const int64_t rows = fd_csc_win_rlen(reach);
+            const double per_row = b->M > 0 ? (double)b->prm[2] / (double)b->M : 1.0;
+            const int cap = (int)std::min<int64_t>((int64_t)(rows * per_row * 1.25) + 256, 16384);
+            const size_t sb = SparseF::stage_bytes(rows, cap);
+            const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
+            if (lds <= 64 * 1024) {
+                if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 1, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
+                else hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 0, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
+            } else {
+                win = false;
+            }
+        }
+        if (!win) FD_COLS(SparseF, f);
     }
 #undef FD_COLS
     return hipGetLastError() == hipSuccess ? 0 : 4;

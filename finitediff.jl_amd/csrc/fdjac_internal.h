@@ -285,6 +285,7 @@ struct fd_plan {
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
     unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: two words of launcher memory about this pattern, zero at creation
     int64_t sc_entries = 0;
+    int64_t sc_reach = -1;         //   max |row - column| over the local entries (fd_csc_store.reach), -1: not computed
     bool sc_valid = false;         //   colorvec verified to be a valid colouring of the local pattern (kernels may perturb one coordinate)
     // ... and block-banded storage (fd_colrange_store): valid colouring verified; uniform block structure recorded
     bool store_cr_ok = false;

@@ -161,10 +161,22 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
     if (t != (unsigned)(eg.bpg - 1)) return;
     // ---- level 1: this block arrived last in its group -- every block sum of the group is in memory ----
+    // (the loads of all addends are issued together, one or a few per lane, and parked in LDS; lane c then adds its colour's in the
+    //  defined order -- a chain of dependent agent-scope loads would cost one memory round trip per addend)
+    __shared__ double stage[kEpsGroups * kRegColors];
+    {
+        const double *pg = partial + (int64_t)grp * eg.bpg * ldp;
+        const int cnt = eg.bpg * ldp;                          // <= 16 x 8 doubles
+        double v0 = 0.0, v1 = 0.0;
+        if (lane < cnt) v0 = __hip_atomic_load(pg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane + 64 < cnt) v1 = __hip_atomic_load(pg + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stage[lane] = v0;
+        stage[lane + 64] = v1;
+    }
+    __builtin_amdgcn_wave_barrier();     // (one wave: its LDS instructions execute in order)
     if (lane < NC) {
         double gs = 0.0;
-        const double *pg = partial + (int64_t)grp * eg.bpg * ldp + lane;
-        for (int k = 0; k < eg.bpg; ++k) gs += __hip_atomic_load(pg + (int64_t)k * ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < eg.bpg; ++k) gs += stage[k * ldp + lane];
         __hip_atomic_store(gsum + (int64_t)grp * ldp + lane, gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
@@ -175,9 +187,18 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
     t2 = (unsigned)__builtin_amdgcn_readfirstlane((int)t2);
     if (t2 != (unsigned)(eg.final_groups - 1)) return;
     // ---- level 2: the last group -- every group sum is in memory ----
+    __builtin_amdgcn_wave_barrier();
+    {
+        double v[kRegColors];
+#pragma unroll
+        for (int u = 0; u < kRegColors; ++u) v[u] = __hip_atomic_load(gsum + u * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < kRegColors; ++u) stage[u * 64 + lane] = v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
     if (lane < NC) {
         double tot = 0.0;
-        for (int g = 0; g < kEpsGroups; ++g) tot += __hip_atomic_load(gsum + (int64_t)g * ldp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int g = 0; g < kEpsGroups; ++g) tot += stage[g * ldp + lane];
         if (lane < eg.C) {
             const real_t e = eps_rule<real_t>(tot, eg.relstep, eg.absstep, eg.dir, eg.is_forward);
             eps[lane] = e;

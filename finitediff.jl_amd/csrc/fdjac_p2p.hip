@@ -263,9 +263,18 @@ __global__ void __launch_bounds__(kBlock) k_p2p_step(char *const *__restrict__ p
     if (t != (unsigned)(nranks - 1)) return;
     const fdjac_eps_final &f = st.fin;
     const int c = threadIdx.x;
+    // (all addends loaded together, a few per lane, parked in LDS; lane c then adds its colour's 64 group sums in group order)
+    __shared__ double stage[kEpsGroups * kRegColors];
+    const int cnt = f.ngroups * f.ldp;                         // 64 x 8
+    double v[kRegColors];
+#pragma unroll
+    for (int u = 0; u < kRegColors; ++u) v[u] = (u * 64 + c < cnt) ? __hip_atomic_load(f.gsum + u * 64 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int u = 0; u < kRegColors; ++u) stage[u * 64 + c] = v[u];
+    __builtin_amdgcn_wave_barrier();
     if (c < f.C) {
         double tot = 0.0;
-        for (int g = 0; g < f.ngroups; ++g) tot += __hip_atomic_load(f.gsum + (int64_t)g * f.ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int g = 0; g < f.ngroups; ++g) tot += stage[g * f.ldp + c];
         if (f.elem_bytes == 4) {
             const float e = eps_rule<float>(tot, f.relstep, f.absstep, f.dir, f.is_forward);
             ((float *)f.eps)[c] = e;

@@ -233,8 +233,11 @@ static int csc_device_impl(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr
         const int64_t j = k ? p->col1 : p->col0;
         int64_t v64 = 0;
         int32_t v32 = 0;
-        hipError_t e = idx_bytes == 8 ? hipMemcpy(&v64, (const char *)colptr_dev + 8 * (size_t)j, 8, hipMemcpyDeviceToHost)
-                                      : hipMemcpy(&v32, (const char *)colptr_dev + 4 * (size_t)j, 4, hipMemcpyDeviceToHost);
+        // (on the context's stream: the caller's kernels that PRODUCE the pattern on that stream are then complete -- a blocking
+        //  hipMemcpy runs on the null stream, which a non-blocking stream does not wait for)
+        hipError_t e = idx_bytes == 8 ? hipMemcpyAsync(&v64, (const char *)colptr_dev + 8 * (size_t)j, 8, hipMemcpyDeviceToHost, ctx->stream)
+                                      : hipMemcpyAsync(&v32, (const char *)colptr_dev + 4 * (size_t)j, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { set_error("reading colptr from the device failed: %s", hipGetErrorString(e)); fd_plan_destroy(p); *out = nullptr; return FD_ERR_HIP; }
         cp[k] = (idx_bytes == 8 ? v64 : (int64_t)v32) - idx_base;
     }

@@ -20,6 +20,27 @@ __global__ void __launch_bounds__(kBlock) k_csc_compact_rowval(const IT *__restr
     if (q < n) out[q] = (int)((int64_t)rowval[e0 + q] - base);
 }
 
+// max |row - column| over the local entries (fd_csc_store.reach: how far a workgroup's columns reach into the rows, hence how much of
+// x a staging kernel keeps in LDS)
+__global__ void __launch_bounds__(kBlock) k_csc_reach(const int *__restrict__ colptr, const int *__restrict__ rowval, int64_t col0, int64_t ncols,
+                                                      int *__restrict__ reach)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int m = 0;
+    if (k < ncols) {
+        const int a = colptr[k], b = colptr[k + 1];
+        if (b > a) {       // (rows ascend within a column: the first and the last entry bound the column's reach)
+            const int64_t d0 = (int64_t)rowval[a] - (col0 + k), d1 = (int64_t)rowval[b - 1] - (col0 + k);
+            const int64_t m0 = d0 < 0 ? -d0 : d0, m1 = d1 < 0 ? -d1 : d1;
+            m = (int)(m0 > m1 ? m0 : m1);
+            for (int q = a + 1; q + 1 < b; ++q) { const int64_t d = (int64_t)rowval[q] - (col0 + k); const int md = (int)(d < 0 ? -d : d); m = md > m ? md : m; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(reach, m);
+}
+
 // Is colorvec a VALID colouring of the local pattern -- do the columns that share a row differ in colour?  One thread per local
 // column sets its colour's bit in the mask of every row it touches; a bit that was set already is a conflict.  (Columns without a
 // colour conflict with nothing.)  Knowing it lets a storing kernel perturb ONE coordinate instead of testing colours.
@@ -114,6 +135,20 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
         }
         if (d_mask) (void)hipFree(d_mask);
         if (d_conflict) (void)hipFree(d_conflict);
+        (void)hipGetLastError();
+    }
+    p->sc_reach = -1;
+    if (n > 0) {
+        int *d_reach = nullptr;
+        if (hipMalloc((void **)&d_reach, sizeof(int)) == hipSuccess) {
+            int r = 0;
+            (void)hipMemsetAsync(d_reach, 0, sizeof(int), s);
+            hipLaunchKernelGGL(k_csc_reach, dim3((unsigned)((ncols + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, p->d_sc_colptr, p->d_sc_rowval, p->col0, ncols, d_reach);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&r, d_reach, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess)
+                p->sc_reach = r;
+            (void)hipFree(d_reach);
+        }
         (void)hipGetLastError();
     }
     FD_HIP_CHECK(hipStreamSynchronize(s));

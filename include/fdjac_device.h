@@ -185,6 +185,10 @@ typedef struct fd_csc_store {
     unsigned long long *note;      /* device, 2 words owned by the PLAN and zero when it is created: a launcher's memory about THIS pattern   */
                                    /* (which never changes while the plan lives) -- e.g. "verified on an earlier call: it is exactly my stencil, */
                                    /* the row indices need not be read again" (the 7-point family: 290 -> 210 us).  May be NULL.              */
+    long long reach;               /* max |row - column| over the local stored entries (<= 0: not computed / diagonal).  A HINT for staging: the rows a    */
+                                   /* workgroup's 256 columns touch lie within `reach` of them, and -- for a residual whose rows read the     */
+                                   /* columns of the Jacobian's own pattern -- the coordinates those rows read within 2 * reach               */
+                                   /* (fd_csc_store_cols_win keeps that window of x in LDS; anything outside it is read from memory)         */
 } fd_csc_store;
 
 enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4 };   /* what fd_lazy_points.store points to */
@@ -624,6 +628,127 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
             fd_colour_point<T, CT> X = {x, color, c, h, 0};
             fd_csc_store_column<T, MODE>(f, X, st, run, a, b, h);
         }
+    }
+    run.template flush<true>();
+}
+
+/* ---- the same launch with the workgroup's window of x in LDS (round 5) -------------------------------------------------------------
+ * fd_csc_store_cols spends its time in the address path: every stored entry evaluates one row, every row reads a handful of
+ * coordinates -- ~20 scattered 8-byte loads per entry, each to an address some neighbouring lane also reads (random band, 6 entries
+ * per column: 283 us for 246 MB, 0.11 of the peak).  When the pattern is locally banded (st.reach known and small) the coordinates a
+ * workgroup's rows read lie in ONE short window of x: it is loaded once, coalesced, into LDS and X(i) is served from there; f(x) of
+ * the touched rows (forward differences) likewise.  Coordinates outside the window are read from memory as before -- the window is a
+ * cache, never a requirement, so ANY functor and pattern give the bits of fd_csc_store_cols.
+ * A functor may keep its own per-row data in LDS too: if it has a member
+ *     Staged stage(void *lds, long long r_lo, long long r_hi, long long w0, int cap) const      (device; called by all 256 threads)
+ * the kernel calls it with `stage_bytes` bytes of LDS (16-byte aligned) for the rows [r_lo, r_hi) its columns can touch and uses the
+ * returned object (same call operator) instead of the functor; the launcher sizes stage_bytes / cap.
+ * Dynamic LDS: fd_csc_win_lds_bytes<T>(reach, forward_with_base) + stage_bytes.  Launch as fd_csc_store_cols; needs
+ * st.valid_coloring (one perturbed coordinate per column) -- the launcher falls back to fd_csc_store_cols otherwise. */
+#ifndef FD_CSC_WIN_WAVE_CAP
+#define FD_CSC_WIN_WAVE_CAP 512
+#endif
+template <typename T> struct fd_window_column_point {
+    const T *x;         /* global x */
+    const T *wx;        /* LDS copy of x[w0, w1) */
+    long long w0, w1;
+    long long j;        /* the perturbed coordinate */
+    T e;
+    int minus;
+    __device__ T operator()(long long i) const
+    {
+        const T v = (i >= w0 && i < w1) ? wx[i - w0] : x[i];
+        if (minus == 2) return v;
+        const bool hit = i == j;
+        return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
+    }
+};
+template <class F, class = void> struct fd_has_stage { static constexpr bool value = false; };
+template <class F> struct fd_has_stage<F, decltype((void)&F::stage, void())> { static constexpr bool value = true; };
+__host__ __device__ inline long long fd_csc_win_xlen(long long reach) { return 256 + 4 * reach + 2; }       /* elements of the x window (even start) */
+__host__ __device__ inline long long fd_csc_win_rlen(long long reach) { return 256 + 2 * reach; }           /* rows a workgroup's columns can touch */
+template <typename T> __host__ __device__ inline size_t fd_csc_win_lds_bytes(long long reach, bool with_base)
+{
+    return sizeof(T) * (size_t)(4 * FD_CSC_WIN_WAVE_CAP + fd_csc_win_xlen(reach) + (with_base ? fd_csc_win_rlen(reach) + 1 : 0)) + 16;
+}
+template <typename T, int MODE, class F, class P>
+__device__ inline void fd_csc_store_column_win(const F &f, P &X, const fd_csc_store &st, const fd_csc_wave_run<T> &run, int a, int b, T h,
+                                               const T *wb, long long r_lo, long long r_hi)
+{
+    const T *base = (const T *)st.fx_base;
+    constexpr int U = 4;
+    for (int q0 = a; q0 < b; q0 += U) {
+        long long r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = st.rowval[q0 + u < b ? q0 + u : b - 1];
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u >= b) { v[u] = 0; continue; }
+            X.minus = 0;
+            const T vp = f(r[u], X);
+            T vm, div = h;
+            if (MODE == 1) { X.minus = 1; vm = f(r[u], X); div = 2 * h; }
+            else if (base) vm = (r[u] >= r_lo && r[u] < r_hi) ? wb[r[u] - r_lo] : base[r[u]];
+            else { X.minus = 2; vm = f(r[u], X); }
+            v[u] = (vp - vm) / div;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u < b) run.put(q0 + u, v[u]);
+    }
+}
+template <typename T, typename CT, int MODE, class F>
+__global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st,
+                                                             int reach, int stage_bytes, int stage_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_csc_lds[];
+    T *s_win = (T *)fd_csc_lds;                                        /* 4 wave windows of the output */
+    T *s_x = s_win + 4 * FD_CSC_WIN_WAVE_CAP;                          /* x[w0, w1) */
+    const long long nblk = (st.col_end - st.col_begin + 255) / 256, blk = fd_xcd_block(blockIdx.x, nblk);      /* launch fd_xcd_grid(nblk) workgroups */
+    if (blk >= nblk) return;
+    const long long j0 = st.col_begin + blk * 256, jn = j0 + 256 < st.col_end ? j0 + 256 : st.col_end;
+    const long long r_lo = j0 - reach > 0 ? j0 - reach : 0, r_hi = jn + reach < st.M ? jn + reach : st.M;
+    long long w0 = r_lo - reach > 0 ? r_lo - reach : 0, w1 = r_hi + reach < st.N ? r_hi + reach : st.N;
+    w0 &= ~1ll;
+    const bool with_base = MODE == 0 && st.fx_base != nullptr;
+    T *s_b = s_x + fd_csc_win_xlen(reach);                             /* f(x)[r_lo, r_hi) */
+    unsigned char *s_f = (unsigned char *)(s_b + (with_base ? fd_csc_win_rlen(reach) + 1 : 0));
+    s_f = (unsigned char *)(((unsigned long long)s_f + 15) & ~15ull);
+    /* coalesced fills: 16-byte pairs of x (w0 is even, x is 16-byte aligned), f(x) element by element */
+    for (long long i = 2 * (long long)threadIdx.x; i < w1 - w0; i += 512) {
+        if (i + 1 < w1 - w0) {
+            const T a0 = x[w0 + i], a1 = x[w0 + i + 1];
+            s_x[i] = a0; s_x[i + 1] = a1;
+        } else {
+            s_x[i] = x[w0 + i];
+        }
+    }
+    if (with_base) {
+        const T *base = (const T *)st.fx_base;
+        for (long long i = threadIdx.x; i < r_hi - r_lo; i += 256) s_b[i] = base[r_lo + i];
+    }
+    const long long j = j0 + threadIdx.x;
+    const bool in = j < st.col_end;
+    const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[j - st.col_begin + 1] : a;
+    const CT *color = (const CT *)st.color;
+    const int c = in ? (int)color[j] : 0;
+    const bool none = in && c == (int)(CT)(-1);                           /* "none" is all-ones in CT */
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    fd_csc_wave_run<T> run;
+    run.begin((T *)st.out, s_win + (threadIdx.x >> 6) * FD_CSC_WIN_WAVE_CAP, a, b, !in || mine || (none && c_lo == 0), FD_CSC_WIN_WAVE_CAP);
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) run.put(q, (T)0);
+    const T h = mine ? eps[c] : (T)1;
+    fd_window_column_point<T> X = {x, s_x, w0, w1, j, h, 0};
+    if constexpr (fd_has_stage<F>::value) {
+        const auto fs = f.stage(s_f, r_lo, r_hi, w0, stage_cap);
+        __syncthreads();
+        if (mine) fd_csc_store_column_win<T, MODE>(fs, X, st, run, a, b, h, s_b, r_lo, r_hi);
+    } else {
+        __syncthreads();
+        if (mine) fd_csc_store_column_win<T, MODE>(f, X, st, run, a, b, h, s_b, r_lo, r_hi);
     }
     run.template flush<true>();
 }
