@@ -332,12 +332,47 @@ struct SparseF {
         int32_t *l_row = (int32_t *)lds;
         const int nr = (int)(r_hi - r_lo);
         uint16_t *l_col = (uint16_t *)((unsigned char *)lds + ((size_t)(nr + 2) * 4 + 15) / 16 * 16);
-        for (int i = threadIdx.x; i <= nr; i += blockDim.x) l_row[i] = srow[r_lo + i];
+        // (batches of loads issued together: one memory round trip per batch, not per element)
+        for (int i0 = 0; i0 <= nr; i0 += 4 * kBlock) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + (int)threadIdx.x; v[u] = i <= nr ? srow[r_lo + i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + (int)threadIdx.x; if (i <= nr) l_row[i] = v[u]; }
+        }
         const int e_lo = srow[r_lo], e_hi = srow[r_hi];
         const int e_n = e_hi - e_lo < cap ? e_hi - e_lo : cap;
-        for (int k = threadIdx.x; k < e_n; k += blockDim.x) {
-            const int64_t d = (int64_t)scol[e_lo + k] - w0;
-            l_col[k] = (d >= 0 && d < 0xFFFF) ? (uint16_t)d : (uint16_t)0xFFFFu;
+        // the column indices as aligned 16-byte quads (scol comes from hipMalloc: index alignment = address alignment); the quad that
+        // would read past the staged range's end falls back to single loads
+        const int q_lo = e_lo >> 2, q_hi = (e_lo + e_n + 3) >> 2;           // quads [q_lo, q_hi) cover the entries [e_lo, e_lo + e_n)
+        for (int q0 = q_lo; q0 < q_hi; q0 += 4 * kBlock) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * kBlock + (int)threadIdx.x;
+                v[u] = int4{0, 0, 0, 0};
+                if (q < q_hi) {
+                    if (4 * q + 3 < e_lo + e_n) v[u] = *reinterpret_cast<const int4 *>(scol + 4 * (int64_t)q);
+                    else {
+                        if (4 * q + 0 < e_lo + e_n) v[u].x = scol[4 * (int64_t)q + 0];
+                        if (4 * q + 1 < e_lo + e_n) v[u].y = scol[4 * (int64_t)q + 1];
+                        if (4 * q + 2 < e_lo + e_n) v[u].z = scol[4 * (int64_t)q + 2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * kBlock + (int)threadIdx.x;
+                if (q >= q_hi) continue;
+                const int vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = 4 * q + t - e_lo;
+                    if (k < 0 || k >= e_n) continue;
+                    const int64_t d = (int64_t)vv[t] - w0;
+                    l_col[k] = (d >= 0 && d < 0xFFFF) ? (uint16_t)d : (uint16_t)0xFFFFu;
+                }
+            }
         }
         return Staged{srow, scol, l_row, l_col, r_lo, r_hi, w0, e_lo, e_n};
     }

@@ -715,18 +715,30 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
     T *s_b = s_x + fd_csc_win_xlen(reach);                             /* f(x)[r_lo, r_hi) */
     unsigned char *s_f = (unsigned char *)(s_b + (with_base ? fd_csc_win_rlen(reach) + 1 : 0));
     s_f = (unsigned char *)(((unsigned long long)s_f + 15) & ~15ull);
-    /* coalesced fills: 16-byte pairs of x (w0 is even, x is 16-byte aligned), f(x) element by element */
-    for (long long i = 2 * (long long)threadIdx.x; i < w1 - w0; i += 512) {
-        if (i + 1 < w1 - w0) {
-            const T a0 = x[w0 + i], a1 = x[w0 + i + 1];
-            s_x[i] = a0; s_x[i + 1] = a1;
-        } else {
-            s_x[i] = x[w0 + i];
-        }
-    }
-    if (with_base) {
+    /* coalesced fills, every load of a batch issued before the first is used (a loop of load-then-store costs one memory round trip
+       per iteration and workgroup -- the first form of this kernel spent 30 of them): x as 16-byte pairs (w0 is even, x 16-byte
+       aligned), f(x) of the rows element by element */
+    {
+        typedef T fd_pair_t __attribute__((ext_vector_type(2)));
+        const long long nx = w1 - w0, npair = nx / 2, nb = with_base ? r_hi - r_lo : 0;
         const T *base = (const T *)st.fx_base;
-        for (long long i = threadIdx.x; i < r_hi - r_lo; i += 256) s_b[i] = base[r_lo + i];
+        for (long long i0 = 0; i0 < npair || i0 < nb; i0 += 4 * 256) {
+            fd_pair_t vx[4];
+            T vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = i0 + u * 256 + threadIdx.x;
+                if (i < npair) vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0 + 2 * i);
+                if (i < nb) vb[u] = base[r_lo + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long i = i0 + u * 256 + threadIdx.x;
+                if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; }
+                if (i < nb) s_b[i] = vb[u];
+            }
+        }
+        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
     }
     const long long j = j0 + threadIdx.x;
     const bool in = j < st.col_end;
