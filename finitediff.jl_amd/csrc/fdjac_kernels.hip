@@ -64,11 +64,12 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 //   level 1  group sum[g][c]  = the group's bpg block sums added in block order;
 //   level 2  S[c] = the 64 group sums added in group order;  eps[c] from S[c] (eps_rule).
 // A rank of a W-rank job owns whole groups (ceil(64 / W) each): it exchanges 64 / W x C doubles instead of every block's
-// partial sums, and any split gives the bits of the unsharded call.  The levels run inside THIS launch: the block that arrives
-// last (ONE agent-scope ticket per launch) adds every group's block sums and then the group sums and writes eps -- no finalize
-// launch.  Hand-off between workgroups: 8-byte agent-scope atomic stores and loads on both sides with the stores drained
-// before the ticket (MI355X_MICROARCH.md, inter-workgroup visibility); which block does the adding never changes what is
-// added in which order.  final_groups = 0: stop after level 1 (a shard: its group sums are exchanged).
+// partial sums, and any split gives the bits of the unsharded call.  The levels run inside THIS launch: the last block of a
+// group to arrive (agent-scope ticket) adds the group's block sums, the last group to finish adds the group sums and writes
+// eps -- no finalize launch (ONE ticket for the whole launch was measured too: 1024 arrivals on one address cost 6 us more than
+// 64 x 16 + 64).  Hand-off between workgroups: 8-byte agent-scope atomic stores and loads on both sides with
+// the stores drained before the ticket (MI355X_MICROARCH.md, inter-workgroup visibility); which block does the adding never
+// changes what is added in which order.  final_groups = 0: stop after level 1 (a shard: its group sums are exchanged).
 struct EpsGrid {
     int tpg, bpg, tpb;          // tiles per group, blocks per group, tiles per block
     int final_groups;           // > 0: this launch covers that many groups = all of them: its last group writes eps
@@ -140,7 +141,6 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
     }
 
     __shared__ double red[kBlock / 64][NC];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -148,47 +148,65 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
         if (lane == 0) red[wave][c] = s;
     }
     __syncthreads();
-    // ---- level 0 result of this block, then ONE arrival ticket per launch (wave 0; lanes < NC carry one colour each) ----
-    if (wave == 0) {
-        if (lane < NC) {
-            double s = 0.0;
+    if (wave != 0) return;
+    // ---- level 0 result of this block, then the hand-off (wave 0 only; lanes < NC carry one colour each) ----
+    if (lane < NC) {
+        double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
-            __hip_atomic_store(partial + (int64_t)gblock * ldp + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the block sums have left this CU before the ticket is drawn
-        if (lane == 0) s_last = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
+        __hip_atomic_store(partial + (int64_t)gblock * ldp + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- levels 1 and 2 by the block that arrived last: every block sum of the launch is in memory.  All addends of a group are
-    // requested together (agent-scope loads, 16 in flight per thread) and added in block order; thread (g, c) owns one group sum. ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the block sums have left this CU before the ticket is drawn
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if (t != (unsigned)(eg.bpg - 1)) return;
+    // ---- level 1: this block arrived last in its group -- every block sum of the group is in memory ----
+    // (the loads of all addends are issued together, one or a few per lane, and parked in LDS; lane c then adds its colour's in the
+    //  defined order -- a chain of dependent agent-scope loads would cost one memory round trip per addend)
     __shared__ double stage[kEpsGroups * kRegColors];
-    const int g_first = block_off / eg.bpg, ng = (int)gridDim.x / eg.bpg;
-#pragma unroll
-    for (int h = 0; h < (kEpsGroups * kRegColors) / kBlock; ++h) {
-        const int pr = h * kBlock + (int)threadIdx.x, gl = pr / kRegColors, c = pr - gl * kRegColors;
-        if (gl >= ng) continue;
-        const double *pg = partial + ((int64_t)(g_first + gl) * eg.bpg) * ldp + c;
-        double v[kEpsBlocksPerGroup];
-#pragma unroll
-        for (int k = 0; k < kEpsBlocksPerGroup; ++k) v[k] = k < eg.bpg ? __hip_atomic_load(pg + (int64_t)k * ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    {
+        const double *pg = partial + (int64_t)grp * eg.bpg * ldp;
+        const int cnt = eg.bpg * ldp;                          // <= 16 x 8 doubles
+        double v0 = 0.0, v1 = 0.0;
+        if (lane < cnt) v0 = __hip_atomic_load(pg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane + 64 < cnt) v1 = __hip_atomic_load(pg + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stage[lane] = v0;
+        stage[lane + 64] = v1;
+    }
+    __builtin_amdgcn_wave_barrier();     // (one wave: its LDS instructions execute in order)
+    if (lane < NC) {
         double gs = 0.0;
-#pragma unroll
-        for (int k = 0; k < kEpsBlocksPerGroup; ++k) if (k < eg.bpg) gs += v[k];
-        stage[gl * kRegColors + c] = gs;
-        gsum[(int64_t)(g_first + gl) * ldp + c] = gs;
+        for (int k = 0; k < eg.bpg; ++k) gs += stage[k * ldp + lane];
+        __hip_atomic_store(gsum + (int64_t)grp * ldp + lane, gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
+    if (lane == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (launches on the stream are ordered)
     if (eg.final_groups <= 0) return;
-    __syncthreads();
-    if ((int)threadIdx.x < eg.C) {
-        double tot = 0.0;
-        for (int g = 0; g < kEpsGroups; ++g) tot += stage[g * kRegColors + (int)threadIdx.x];
-        const real_t e = eps_rule<real_t>(tot, eg.relstep, eg.absstep, eg.dir, eg.is_forward);
-        eps[threadIdx.x] = e;
-        if (eps2) eps2[threadIdx.x] = (real_t)2 * e;           // (central differences handed over as f(+) - f(-), see launch_scale)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t2 = 0;
+    if (lane == 0) t2 = __hip_atomic_fetch_add(tick + kEpsGroups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t2 = (unsigned)__builtin_amdgcn_readfirstlane((int)t2);
+    if (t2 != (unsigned)(eg.final_groups - 1)) return;
+    // ---- level 2: the last group -- every group sum is in memory ----
+    __builtin_amdgcn_wave_barrier();
+    {
+        double v[kRegColors];
+#pragma unroll
+        for (int u = 0; u < kRegColors; ++u) v[u] = __hip_atomic_load(gsum + u * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < kRegColors; ++u) stage[u * 64 + lane] = v[u];
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NC) {
+        double tot = 0.0;
+        for (int g = 0; g < kEpsGroups; ++g) tot += stage[g * ldp + lane];
+        if (lane < eg.C) {
+            const real_t e = eps_rule<real_t>(tot, eg.relstep, eg.absstep, eg.dir, eg.is_forward);
+            eps[lane] = e;
+            if (eps2) eps2[lane] = (real_t)2 * e;           // (central differences handed over as f(+) - f(-), see launch_scale)
+        }
+    }
+    if (lane == 0) __hip_atomic_store(tick + kEpsGroups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // level 2 on its own: a sharded reduction's group sums have been exchanged (fd_plan_eps_finalize; with RCCL after the all-gather)
