@@ -291,8 +291,8 @@ struct SparseF {
     // served from memory: same indices, same order, same bits.
     struct Staged {
         const int32_t *srow, *scol;
-        const int32_t *l_row;        // LDS: srow[r_lo .. r_hi]
-        const uint16_t *l_col;       // LDS: codes of the entries [e_lo, e_lo + e_n)
+        const FD_LDS_PTR(int32_t) l_row;        // LDS: srow[r_lo .. r_hi]
+        const FD_LDS_PTR(uint16_t) l_col;       // LDS: codes of the entries [e_lo, e_lo + e_n)
         int64_t r_lo, r_hi, w0;
         int e_lo, e_n;
         __device__ __forceinline__ int64_t col_of(int a) const
@@ -309,6 +309,26 @@ struct SparseF {
             const bool st = r >= r_lo && r < r_hi;
             const int a0 = st ? l_row[r - r_lo] : srow[r], a1 = st ? l_row[r - r_lo + 1] : srow[r + 1];
             T s = zero_of<T>();
+            if (st && a1 <= e_lo + e_n) {
+                // the whole row is staged: codes and coordinates from LDS, 32-bit arithmetic, two entries at a time (the terms and
+                // their order are those of SparseF::row -- same bits)
+                const int r7 = (int)(r & 7), w7 = (int)(w0 & 7);
+                for (int a = a0; a < a1; a += 2) {
+                    const bool two = a + 1 < a1;
+                    const unsigned c0 = l_col[a - e_lo], c1 = l_col[(two ? a + 1 : a) - e_lo];
+                    int64_t j0 = 0, j1 = 0;
+                    if (c0 == 0xFFFFu) j0 = scol[a];
+                    if (c1 == 0xFFFFu) j1 = scol[two ? a + 1 : a];
+                    const T v0 = c0 != 0xFFFFu ? X.at(c0) : X(j0), v1 = c1 != 0xFFFFu ? X.at(c1) : X(j1);
+                    const int m0 = c0 != 0xFFFFu ? (r7 + 3 * (w7 + (int)c0)) & 7 : (int)((r + 3 * j0) & 7);
+                    const int m1 = c1 != 0xFFFFu ? (r7 + 3 * (w7 + (int)c1)) & 7 : (int)((r + 3 * j1) & 7);
+                    const T t0 = ((real_t)1 + kEighth * (real_t)m0) * (v0 + (kQuarter * v0) * v0);
+                    const T t1 = ((real_t)1 + kEighth * (real_t)m1) * (v1 + (kQuarter * v1) * v1);
+                    s = a == a0 ? t0 : s + t0;
+                    if (two) s = s + t1;
+                }
+                return s;
+            }
             for (int a = a0; a < a1; a += FD_SPARSE_U) {
                 int64_t j[FD_SPARSE_U];
                 T v[FD_SPARSE_U];
@@ -327,11 +347,11 @@ struct SparseF {
         template <class P> __device__ __forceinline__ real_t operator()(long long r, const P &X) const { return row<real_t>(r, X); }
     };
     static size_t stage_bytes(int64_t rows, int cap) { return ((size_t)(rows + 2) * 4 + 15) / 16 * 16 + (size_t)cap * 2 + 16; }
-    __device__ __forceinline__ Staged stage(void *lds, long long r_lo, long long r_hi, long long w0, int cap) const
+    __device__ __forceinline__ Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, int cap) const
     {
-        int32_t *l_row = (int32_t *)lds;
+        FD_LDS_PTR(int32_t) l_row = (FD_LDS_PTR(int32_t))lds;
         const int nr = (int)(r_hi - r_lo);
-        uint16_t *l_col = (uint16_t *)((unsigned char *)lds + ((size_t)(nr + 2) * 4 + 15) / 16 * 16);
+        FD_LDS_PTR(uint16_t) l_col = (FD_LDS_PTR(uint16_t))(lds + (((unsigned)(nr + 2) * 4u + 15u) / 16u * 16u));
         // (batches of loads issued together: one memory round trip per batch, not per element)
         for (int i0 = 0; i0 <= nr; i0 += 4 * kBlock) {
             int v[4];

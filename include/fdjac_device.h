@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
  * the touched rows (forward differences) likewise.  Coordinates outside the window are read from memory as before -- the window is a
  * cache, never a requirement, so ANY functor and pattern give the bits of fd_csc_store_cols.
  * A functor may keep its own per-row data in LDS too: if it has a member
- *     Staged stage(void *lds, long long r_lo, long long r_hi, long long w0, int cap) const      (device; called by all 256 threads)
+ *     Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, int cap) const    (device; all 256 threads)
  * the kernel calls it with `stage_bytes` bytes of LDS (16-byte aligned) for the rows [r_lo, r_hi) its columns can touch and uses the
  * returned object (same call operator) instead of the functor; the launcher sizes stage_bytes / cap.
  * Dynamic LDS: fd_csc_win_lds_bytes<T>(reach, forward_with_base) + stage_bytes.  Launch as fd_csc_store_cols; needs
@@ -648,18 +648,30 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
 #ifndef FD_CSC_WIN_WAVE_CAP
 #define FD_CSC_WIN_WAVE_CAP 512
 #endif
+/* pointers into LDS carry their address space: a generic pointer makes the compiler emit flat_load -- the memory pipeline with an
+   aperture check -- where ds_read is meant (measured: the first form of this kernel issued 140 flat loads and 3 LDS reads) */
+#define FD_LDS_PTR(T) __attribute__((address_space(3))) T *
 template <typename T> struct fd_window_column_point {
     const T *x;         /* global x */
-    const T *wx;        /* LDS copy of x[w0, w1) */
+    const FD_LDS_PTR(T) wx;        /* LDS copy of x[w0, w1) */
     long long w0, w1;
     long long j;        /* the perturbed coordinate */
     T e;
     int minus;
+    unsigned joff;      /* j - w0 if j lies in the window, else 0xFFFFFFFF */
     __device__ T operator()(long long i) const
     {
         const T v = (i >= w0 && i < w1) ? wx[i - w0] : x[i];
         if (minus == 2) return v;
         const bool hit = i == j;
+        return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
+    }
+    /* coordinate w0 + off, known to lie in the window (a functor that staged its indices as window offsets: 32-bit arithmetic only) */
+    __device__ T at(unsigned off) const
+    {
+        const T v = wx[off];
+        if (minus == 2) return v;
+        const bool hit = off == joff;
         return minus ? (hit ? v - e : v) : v + (hit ? e : (T)0);
     }
 };
@@ -673,29 +685,35 @@ template <typename T> __host__ __device__ inline size_t fd_csc_win_lds_bytes(lon
 }
 template <typename T, int MODE, class F, class P>
 __device__ inline void fd_csc_store_column_win(const F &f, P &X, const fd_csc_store &st, const fd_csc_wave_run<T> &run, int a, int b, T h,
-                                               const T *wb, long long r_lo, long long r_hi)
+                                               const FD_LDS_PTR(T) wb, long long r_lo, long long r_hi)
 {
     const T *base = (const T *)st.fx_base;
-    constexpr int U = 4;
+    /* the row indices of up to eight entries in one round trip, then the entries two at a time (the rows come out of LDS: short
+       chains; a deeper unroll only grows the code) */
+    constexpr int U = 8;
     for (int q0 = a; q0 < b; q0 += U) {
-        long long r[U];
+        int r[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) r[u] = st.rowval[q0 + u < b ? q0 + u : b - 1];
-        T v[U];
+#pragma unroll 1
+        for (int u0 = 0; u0 < U && q0 + u0 < b; u0 += 2) {
+            T v[2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (q0 + u >= b) { v[u] = 0; continue; }
-            X.minus = 0;
-            const T vp = f(r[u], X);
-            T vm, div = h;
-            if (MODE == 1) { X.minus = 1; vm = f(r[u], X); div = 2 * h; }
-            else if (base) vm = (r[u] >= r_lo && r[u] < r_hi) ? wb[r[u] - r_lo] : base[r[u]];
-            else { X.minus = 2; vm = f(r[u], X); }
-            v[u] = (vp - vm) / div;
+            for (int d = 0; d < 2; ++d) {
+                const int u = u0 + d;
+                const long long rr = u == 0 ? r[0] : u == 1 ? r[1] : u == 2 ? r[2] : u == 3 ? r[3] : u == 4 ? r[4] : u == 5 ? r[5] : u == 6 ? r[6] : r[7];
+                if (q0 + u >= b) { v[d] = 0; continue; }
+                X.minus = 0;
+                const T vp = f(rr, X);
+                T vm, div = h;
+                if (MODE == 1) { X.minus = 1; vm = f(rr, X); div = 2 * h; }
+                else if (base) vm = (rr >= r_lo && rr < r_hi) ? wb[rr - r_lo] : base[rr];
+                else { X.minus = 2; vm = f(rr, X); }
+                v[d] = (vp - vm) / div;
+            }
+            run.put(q0 + u0, v[0]);
+            if (q0 + u0 + 1 < b) run.put(q0 + u0 + 1, v[1]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (q0 + u < b) run.put(q0 + u, v[u]);
     }
 }
 template <typename T, typename CT, int MODE, class F>
@@ -704,7 +722,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_csc_lds[];
     T *s_win = (T *)fd_csc_lds;                                        /* 4 wave windows of the output */
-    T *s_x = s_win + 4 * FD_CSC_WIN_WAVE_CAP;                          /* x[w0, w1) */
+    FD_LDS_PTR(T) s_x = (FD_LDS_PTR(T))(s_win + 4 * FD_CSC_WIN_WAVE_CAP);     /* x[w0, w1) */
     const long long nblk = (st.col_end - st.col_begin + 255) / 256, blk = fd_xcd_block(blockIdx.x, nblk);      /* launch fd_xcd_grid(nblk) workgroups */
     if (blk >= nblk) return;
     const long long j0 = st.col_begin + blk * 256, jn = j0 + 256 < st.col_end ? j0 + 256 : st.col_end;
@@ -712,9 +730,9 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
     long long w0 = r_lo - reach > 0 ? r_lo - reach : 0, w1 = r_hi + reach < st.N ? r_hi + reach : st.N;
     w0 &= ~1ll;
     const bool with_base = MODE == 0 && st.fx_base != nullptr;
-    T *s_b = s_x + fd_csc_win_xlen(reach);                             /* f(x)[r_lo, r_hi) */
-    unsigned char *s_f = (unsigned char *)(s_b + (with_base ? fd_csc_win_rlen(reach) + 1 : 0));
-    s_f = (unsigned char *)(((unsigned long long)s_f + 15) & ~15ull);
+    FD_LDS_PTR(T) s_b = s_x + fd_csc_win_xlen(reach);                  /* f(x)[r_lo, r_hi) */
+    const unsigned f_off = (unsigned)(sizeof(T) * (size_t)(4 * FD_CSC_WIN_WAVE_CAP + fd_csc_win_xlen(reach) + (with_base ? fd_csc_win_rlen(reach) + 1 : 0)) + 15) & ~15u;
+    FD_LDS_PTR(unsigned char) s_f = (FD_LDS_PTR(unsigned char))fd_csc_lds + f_off;      /* the functor's own staging area, 16-byte aligned */
     /* coalesced fills, every load of a batch issued before the first is used (a loop of load-then-store costs one memory round trip
        per iteration and workgroup -- the first form of this kernel spent 30 of them): x as 16-byte pairs (w0 is even, x 16-byte
        aligned), f(x) of the rows element by element */
@@ -753,7 +771,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
     if (none && c_lo == 0)
         for (int q = a; q < b; ++q) run.put(q, (T)0);
     const T h = mine ? eps[c] : (T)1;
-    fd_window_column_point<T> X = {x, s_x, w0, w1, j, h, 0};
+    fd_window_column_point<T> X = {x, s_x, w0, w1, j, h, 0, (j >= w0 && j < w1) ? (unsigned)(j - w0) : 0xFFFFFFFFu};
     if constexpr (fd_has_stage<F>::value) {
         const auto fs = f.stage(s_f, r_lo, r_hi, w0, stage_cap);
         __syncthreads();
