@@ -287,12 +287,14 @@ struct SparseF {
 
     // fd_csc_store_cols_win (include/fdjac_device.h): the row pattern of the rows [r_lo, r_hi) a workgroup's columns can touch, kept in
     // LDS -- the rows' offsets (int32, r_hi - r_lo + 1 of them) and up to `cap` of their column indices as 16-bit distances from the
-    // workgroup's x window (0xFFFF: not representable -> the index is read from memory).  Rows / entries that were not staged are
-    // served from memory: same indices, same order, same bits.
+    // start of the workgroup's x window (0xFFFF: the column lies outside the window -> index and coordinate are read from memory).  A row whose entries are ALL staged with valid codes is flagged "fast":
+    // its evaluation is a straight line of LDS reads and 32-bit arithmetic.  Anything else is served from memory: same indices, same
+    // order, same bits.
     struct Staged {
         const int32_t *srow, *scol;
         const FD_LDS_PTR(int32_t) l_row;        // LDS: srow[r_lo .. r_hi]
         const FD_LDS_PTR(uint16_t) l_col;       // LDS: codes of the entries [e_lo, e_lo + e_n)
+        const FD_LDS_PTR(uint8_t) l_fast;       // LDS: 1 = every entry of the row has a valid code
         int64_t r_lo, r_hi, w0;
         int e_lo, e_n;
         __device__ __forceinline__ int64_t col_of(int a) const
@@ -307,23 +309,18 @@ struct SparseF {
         template <typename T, class P> __device__ __forceinline__ T row(int64_t r, const P &X) const
         {
             const bool st = r >= r_lo && r < r_hi;
-            const int a0 = st ? l_row[r - r_lo] : srow[r], a1 = st ? l_row[r - r_lo + 1] : srow[r + 1];
+            const int ri = st ? (int)(r - r_lo) : 0;
+            const int a0 = st ? l_row[ri] : srow[r], a1 = st ? l_row[ri + 1] : srow[r + 1];
             T s = zero_of<T>();
-            if (st && a1 <= e_lo + e_n) {
-                // the whole row is staged: codes and coordinates from LDS, 32-bit arithmetic, two entries at a time (the terms and
-                // their order are those of SparseF::row -- same bits)
-                const int r7 = (int)(r & 7), w7 = (int)(w0 & 7);
+            if (st && l_fast[ri]) {
+                // (the terms and their order are those of SparseF::row -- same bits; (r + 3 j) mod 8 from the low bits alone)
+                const unsigned rw = (unsigned)((r + 3 * w0) & 7);
                 for (int a = a0; a < a1; a += 2) {
                     const bool two = a + 1 < a1;
                     const unsigned c0 = l_col[a - e_lo], c1 = l_col[(two ? a + 1 : a) - e_lo];
-                    int64_t j0 = 0, j1 = 0;
-                    if (c0 == 0xFFFFu) j0 = scol[a];
-                    if (c1 == 0xFFFFu) j1 = scol[two ? a + 1 : a];
-                    const T v0 = c0 != 0xFFFFu ? X.at(c0) : X(j0), v1 = c1 != 0xFFFFu ? X.at(c1) : X(j1);
-                    const int m0 = c0 != 0xFFFFu ? (r7 + 3 * (w7 + (int)c0)) & 7 : (int)((r + 3 * j0) & 7);
-                    const int m1 = c1 != 0xFFFFu ? (r7 + 3 * (w7 + (int)c1)) & 7 : (int)((r + 3 * j1) & 7);
-                    const T t0 = ((real_t)1 + kEighth * (real_t)m0) * (v0 + (kQuarter * v0) * v0);
-                    const T t1 = ((real_t)1 + kEighth * (real_t)m1) * (v1 + (kQuarter * v1) * v1);
+                    const T v0 = X.at(c0), v1 = X.at(c1);
+                    const T t0 = ((real_t)1 + kEighth * (real_t)(int)((rw + 3 * c0) & 7)) * (v0 + (kQuarter * v0) * v0);
+                    const T t1 = ((real_t)1 + kEighth * (real_t)(int)((rw + 3 * c1) & 7)) * (v1 + (kQuarter * v1) * v1);
                     s = a == a0 ? t0 : s + t0;
                     if (two) s = s + t1;
                 }
@@ -346,12 +343,14 @@ struct SparseF {
         }
         template <class P> __device__ __forceinline__ real_t operator()(long long r, const P &X) const { return row<real_t>(r, X); }
     };
-    static size_t stage_bytes(int64_t rows, int cap) { return ((size_t)(rows + 2) * 4 + 15) / 16 * 16 + (size_t)cap * 2 + 16; }
-    __device__ __forceinline__ Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, int cap) const
+    static size_t stage_bytes(int64_t rows, int cap) { return ((size_t)(rows + 2) * 4 + 15) / 16 * 16 + ((size_t)cap * 2 + 15) / 16 * 16 + (size_t)rows + 32; }
+    __device__ __forceinline__ Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, long long w1, int cap) const
     {
         FD_LDS_PTR(int32_t) l_row = (FD_LDS_PTR(int32_t))lds;
         const int nr = (int)(r_hi - r_lo);
-        FD_LDS_PTR(uint16_t) l_col = (FD_LDS_PTR(uint16_t))(lds + (((unsigned)(nr + 2) * 4u + 15u) / 16u * 16u));
+        const unsigned col_off = ((unsigned)(nr + 2) * 4u + 15u) / 16u * 16u;
+        FD_LDS_PTR(uint16_t) l_col = (FD_LDS_PTR(uint16_t))(lds + col_off);
+        FD_LDS_PTR(uint8_t) l_fast = (FD_LDS_PTR(uint8_t))(lds + col_off + ((unsigned)cap * 2u + 15u) / 16u * 16u);
         // (batches of loads issued together: one memory round trip per batch, not per element)
         for (int i0 = 0; i0 <= nr; i0 += 4 * kBlock) {
             int v[4];
@@ -362,6 +361,7 @@ struct SparseF {
         }
         const int e_lo = srow[r_lo], e_hi = srow[r_hi];
         const int e_n = e_hi - e_lo < cap ? e_hi - e_lo : cap;
+        const int64_t wlen = w1 - w0 < 0xFFFF ? w1 - w0 : 0xFFFF;
         // the column indices as aligned 16-byte quads (scol comes from hipMalloc: index alignment = address alignment); the quad that
         // would read past the staged range's end falls back to single loads
         const int q_lo = e_lo >> 2, q_hi = (e_lo + e_n + 3) >> 2;           // quads [q_lo, q_hi) cover the entries [e_lo, e_lo + e_n)
@@ -390,11 +390,18 @@ struct SparseF {
                     const int k = 4 * q + t - e_lo;
                     if (k < 0 || k >= e_n) continue;
                     const int64_t d = (int64_t)vv[t] - w0;
-                    l_col[k] = (d >= 0 && d < 0xFFFF) ? (uint16_t)d : (uint16_t)0xFFFFu;
+                    l_col[k] = (d >= 0 && d < wlen) ? (uint16_t)d : (uint16_t)0xFFFFu;      // (only coordinates INSIDE the staged window get a code)
                 }
             }
         }
-        return Staged{srow, scol, l_row, l_col, r_lo, r_hi, w0, e_lo, e_n};
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr; i += kBlock) {
+            const int a0 = l_row[i], a1 = l_row[i + 1];
+            bool ok = a1 <= e_lo + e_n;
+            for (int a = a0; ok && a < a1; ++a) ok = l_col[a - e_lo] != 0xFFFFu;
+            l_fast[i] = ok ? 1 : 0;
+        }
+        return Staged{srow, scol, l_row, l_col, l_fast, r_lo, r_hi, w0, e_lo, e_n};
     }
 };
 

@@ -640,7 +640,8 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
  * the touched rows (forward differences) likewise.  Coordinates outside the window are read from memory as before -- the window is a
  * cache, never a requirement, so ANY functor and pattern give the bits of fd_csc_store_cols.
  * A functor may keep its own per-row data in LDS too: if it has a member
- *     Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, int cap) const    (device; all 256 threads)
+ *     Staged stage(FD_LDS_PTR(unsigned char) lds, long long r_lo, long long r_hi, long long w0, long long w1, int cap) const   (device; all 256 threads;
+ *                  [w0, w1) = the staged window of x: X.at(i - w0) serves coordinate i from it)
  * the kernel calls it with `stage_bytes` bytes of LDS (16-byte aligned) for the rows [r_lo, r_hi) its columns can touch and uses the
  * returned object (same call operator) instead of the functor; the launcher sizes stage_bytes / cap.
  * Dynamic LDS: fd_csc_win_lds_bytes<T>(reach, forward_with_base) + stage_bytes.  Launch as fd_csc_store_cols; needs
@@ -683,11 +684,30 @@ template <typename T> __host__ __device__ inline size_t fd_csc_win_lds_bytes(lon
 {
     return sizeof(T) * (size_t)(4 * FD_CSC_WIN_WAVE_CAP + fd_csc_win_xlen(reach) + (with_base ? fd_csc_win_rlen(reach) + 1 : 0)) + 16;
 }
+/* a / b for a divisor shared by several quotients, y = 1 / b computed once: one multiplication and two FMA correction steps give the
+   CORRECTLY ROUNDED quotient (Markstein: q1 is a faithful rounding of a / b, so q2 = RN(a / b) when nothing over- or underflows;
+   zero, tiny, huge and non-finite operands take the true division) -- the bits of IEEE a / b at about a third of its instructions
+   (scripts/ubench/exact_div_probe.hip: 5e10 random and next-to-tie operand pairs, 0 mismatches).  Float64; Float32 divides. */
+template <typename T> __device__ inline T fd_div_shared(T a, T b, T y)
+{
+    if constexpr (sizeof(T) == 8) {
+        const double q0 = a * y;
+        const double m = __builtin_fabs(q0), ma = __builtin_fabs(a);
+        if (!(m >= 0x1p-900 && m <= 0x1p900 && ma >= 0x1p-900 && ma <= 0x1p900)) return a / b;
+        const double r0 = __builtin_fma(-b, q0, a);
+        const double q1 = __builtin_fma(r0, y, q0);
+        const double r1 = __builtin_fma(-b, q1, a);
+        return __builtin_fma(r1, y, q1);
+    } else {
+        return a / b;
+    }
+}
 template <typename T, int MODE, class F, class P>
 __device__ inline void fd_csc_store_column_win(const F &f, P &X, const fd_csc_store &st, const fd_csc_wave_run<T> &run, int a, int b, T h,
                                                const FD_LDS_PTR(T) wb, long long r_lo, long long r_hi)
 {
     const T *base = (const T *)st.fx_base;
+    const T dv = MODE == 1 ? 2 * h : h, yd = (T)1 / dv;          /* every quotient of the column has this divisor */
     /* the row indices of up to eight entries in one round trip, then the entries two at a time (the rows come out of LDS: short
        chains; a deeper unroll only grows the code) */
     constexpr int U = 8;
@@ -705,11 +725,11 @@ __device__ inline void fd_csc_store_column_win(const F &f, P &X, const fd_csc_st
                 if (q0 + u >= b) { v[d] = 0; continue; }
                 X.minus = 0;
                 const T vp = f(rr, X);
-                T vm, div = h;
-                if (MODE == 1) { X.minus = 1; vm = f(rr, X); div = 2 * h; }
+                T vm;
+                if (MODE == 1) { X.minus = 1; vm = f(rr, X); }
                 else if (base) vm = (rr >= r_lo && rr < r_hi) ? wb[rr - r_lo] : base[rr];
                 else { X.minus = 2; vm = f(rr, X); }
-                v[d] = (vp - vm) / div;
+                v[d] = fd_div_shared<T>(vp - vm, dv, yd);
             }
             run.put(q0 + u0, v[0]);
             if (q0 + u0 + 1 < b) run.put(q0 + u0 + 1, v[1]);
@@ -773,7 +793,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
     const T h = mine ? eps[c] : (T)1;
     fd_window_column_point<T> X = {x, s_x, w0, w1, j, h, 0, (j >= w0 && j < w1) ? (unsigned)(j - w0) : 0xFFFFFFFFu};
     if constexpr (fd_has_stage<F>::value) {
-        const auto fs = f.stage(s_f, r_lo, r_hi, w0, stage_cap);
+        const auto fs = f.stage(s_f, r_lo, r_hi, w0, w1, stage_cap);
         __syncthreads();
         if (mine) fd_csc_store_column_win<T, MODE>(fs, X, st, run, a, b, h, s_b, r_lo, r_hi);
     } else {
