@@ -815,6 +815,8 @@ def main():
             res_d["device_pattern_identity"] = measure(J_dev, cv_dev, "identity")
             out_d.fill_(float("nan"))
             res_d["device_pattern_content_check"] = measure(J_dev, cv_dev, "content")
+            out_d.fill_(float("nan"))
+            res_d["device_pattern_content_check_deferred"] = measure(J_dev, cv_dev, "content_async")
             # the same loop on the pre-bound callable (what `value` times): the yardstick of the lookup's cost
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -822,7 +824,8 @@ def main():
                 enqueue()
             torch.cuda.synchronize()
             res_d["bound_call_loop_ms"] = (time.perf_counter() - t0) / reps * 1e3
-            dropin = {"what": "fd.finite_difference_jacobian_b(J, f, x, cache): cache -> plan lookup (identity key) [-> fd_plan_matches] -> "
+            dropin = {"what": "fd.finite_difference_jacobian_b(J, f, x, cache): cache -> plan lookup (identity key) [-> fd_plan_matches, or the deferred "
+                              "fd_plan_matches_async: one fused kernel, no copy back, no synchronisation] -> "
                               "fd_jacobian_async; ms = wall-clock of %d back-to-back calls / %d (synchronised at the end), host_enqueue_ms = the "
                               "host's share, gpu_median_ms = HIP-event span of the call" % (reps, reps),
                       "ms": res_d["host_pattern_identity"]["ms"], "median_ms_per_step": None,

@@ -522,6 +522,43 @@ class BuiltinF:
         return self.counts()[1]
 
 
+class JitF:
+    """A row functor given as SOURCE and compiled at run time (fd_f_compile_rows; hiprtc against include/fdjac_device.h,
+    -ffp-contract=off): the shim's `DeviceF(src::String)`.  `source` defines a functor type `name` with
+        template <class P> __device__ real_t operator()(long long r, const P &X) const     // row r at the point X, X(j) = coordinate j
+    `params` = the functor object's bytes (b"" for an empty struct; e.g. struct.pack("q", n) for `struct F { long long n; ... }`).
+    With a plan created with store_csc=True (store_csc_always=True on banded patterns) and `plan.set_lazy(f)` the whole Jacobian is
+    the step-size launch + ONE launch of the column store instantiated for the functor -- what the built-in families get."""
+
+    def __init__(self, source, name, M, N, params=b"", ctx=None, dtype=np.float64):
+        self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        L = self.L = self.ctx.L
+        self.fn = _l.F_LAUNCH()
+        self._lazy = _l.F_LAUNCH_LAZY()
+        self.fctx = C.c_void_p()
+        caps = C.c_int32()
+        params = bytes(params)
+        buf = C.create_string_buffer(params, len(params)) if params else None
+        rc = L.fd_f_compile_rows(self.ctx.handle, source.encode(), name.encode(), buf, len(params), int(M), int(N), self.dtype.itemsize,
+                                 C.byref(self.fn), C.byref(self._lazy), C.byref(caps), C.byref(self.fctx))
+        self.log = (L.fd_f_compile_log() or b"").decode("utf-8", "replace")
+        _l.check(rc)
+        self.lazy_caps = caps.value
+        self.M, self.N = int(M), int(N)
+        self._fin = weakref.finalize(self, L.fd_f_compiled_destroy, self.fctx)
+
+    @property
+    def lazy_fn(self):
+        return self._lazy
+
+    @property
+    def launches(self):
+        n = C.c_int64()
+        _l.check(self.L.fd_f_compiled_counts(self.fctx, C.byref(n)))
+        return n.value
+
+
 class _DevView:
     """__cuda_array_interface__ holder so torch can view library-owned device memory."""
 
@@ -591,8 +628,16 @@ class Plan:
         _l.check(self.Lt.fd_plan_checksum(self.handle, C.byref(v)))
         return v.value
 
-    def matches(self, idx_a=None, idx_b=None, colorvec=None, idx_base=1):
-        """fd_plan_matches: do these arrays still hold the content the plan was compiled from?  `idx_a` / `idx_b` are colptr /
+    def stale(self):
+        """fd_plan_stale: has a completed deferred check (``matches(..., deferred=True)``) found a mismatch?  Non-blocking, sticky."""
+        v = C.c_int(0)
+        _l.check(self.Lt.fd_plan_stale(self.handle, C.byref(v)))
+        return bool(v.value)
+
+    def matches(self, idx_a=None, idx_b=None, colorvec=None, idx_base=1, deferred=False):
+        """fd_plan_matches: do these arrays still hold the content the plan was compiled from?  deferred=True (device arrays):
+        fd_plan_matches_async -- ONE fused kernel, the verdict raised on the device and reported by ``stale()`` / as FD_ERR_STALE by the
+        next call on the plan / by ``Context.synchronize()``; returns None at once.  `idx_a` / `idx_b` are colptr /
         rowval (CSC plans) or rows_index / cols_index (index-list plans), `colorvec` the colours; numpy arrays (host threads) or
         torch CUDA tensors (kernels), int32 or int64, all on the same side; None = not compared.  Needs a plan created with
         ``fingerprint=True`` (FD_PLAN_FINGERPRINT)."""
@@ -631,6 +676,9 @@ class Plan:
             pa.idx_bytes = 8
         if pa.color_bytes == 0:
             pa.color_bytes = 8
+        if deferred:
+            _l.check(self.Lt.fd_plan_matches_async(self.handle, C.byref(pa)))
+            return None
         m = C.c_int(0)
         _l.check(self.Lt.fd_plan_matches(self.handle, C.byref(pa), C.byref(m)))
         return bool(m.value)
@@ -816,11 +864,11 @@ class Plan:
 
 
 def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False, fingerprint=False,
-          store_csc=False):
+          store_csc=False, store_csc_always=False):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
     o.flags = ((_l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0) | (_l.PLAN_FINGERPRINT if fingerprint else 0) |
-               (_l.PLAN_STORE_CSC if store_csc else 0))
+               (_l.PLAN_STORE_CSC if (store_csc or store_csc_always) else 0) | (_l.PLAN_STORE_CSC_ALWAYS if store_csc_always else 0))
     if col_window is not None:
         o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
     if x_window is not None:
@@ -836,7 +884,8 @@ def _vp(a):
 
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
-              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False, store_csc=False):
+              color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False, store_csc=False,
+              store_csc_always=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
@@ -844,7 +893,8 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
     o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous, fingerprint,
-              store_csc and not complex_x and isinstance(J, SparseMatrixCSC))
+              (store_csc or store_csc_always) and not complex_x and isinstance(J, SparseMatrixCSC),
+              store_csc_always and not complex_x and isinstance(J, SparseMatrixCSC))
     if complex_x:      # returntype <: Complex with forward / central differences: the library lowers it (FD_PLAN_COMPLEX_X)
         o.flags |= _l.PLAN_COMPLEX_X
     if isinstance(J, DevicePatternCSC):
@@ -1012,11 +1062,15 @@ class JacobianCache:
         self._bound = {}
         self.lazy = True       # built-in f! families: install their lazy-point launcher on new plans (the shim's install_lazy!)
         # How a cached call finds out that `colorvec` / `sparsity` changed (the reference re-reads both on every call,
-        # src/jacobians.jl:512-513):  "identity" (default) -- O(1): the plan is keyed on the identity (object, data pointer,
+        # src/jacobians.jl:512-513):  "identity" -- O(1): the plan is keyed on the identity (object, data pointer,
         # length) of the arrays; a new array object / a resize makes a new plan, an IN-PLACE edit needs `invalidate()`;
-        # "content" -- identity, then fd_plan_matches compares the arrays' content with what the plan was compiled from
-        # (kernels for device arrays, host threads for host arrays: the reference's semantics, at the reference's O(N + nnz)).
-        self.pattern_check = "identity"
+        # "content" (default since round 5: the reference's semantics -- a silently stale plan is a wrong Jacobian) -- identity,
+        # then fd_plan_matches compares the arrays' content with what the plan was compiled from
+        # (kernels for device arrays, host threads for host arrays: the reference's semantics, at the reference's O(N + nnz));
+        # "content_async" -- device arrays: the same comparison as ONE fused kernel ahead of the Jacobian, nothing copied back, the
+        # stream never stopped; an edit is reported one call late (the stale plan's call is recomputed by the call that finds out)
+        # or by Context.synchronize() -- FD_ERR_STALE.  Host arrays fall back to "content".
+        self.pattern_check = "content"
 
     def invalidate(self):
         """Forget the compiled plans: the next call re-reads `colorvec` / `sparsity` (after an in-place edit of either)."""
@@ -1044,10 +1098,17 @@ class JacobianCache:
         check, a new plan (+ the built-in family's lazy launcher, as `install_lazy!` does) only when something changed."""
         jshape = tuple(J.shape) if (isinstance(J, np.ndarray) or _is_torch(J)) else tuple(J.size())
         key = (type(J).__name__, jshape, self.fdtype, self._ident(sparsity), self._ident(colorvec), id(f) if self.lazy else None)
-        content = self.pattern_check == "content"
+        content = self.pattern_check in ("content", "content_async")
+        deferred = self.pattern_check == "content_async" and self._all_device(sparsity, colorvec)
         ent = self._plans.get(key)
         if ent is not None and ent[3] == content:
-            if not content or self._content_matches(ent[0], sparsity, colorvec):
+            if not content:
+                return ent[0]
+            if deferred:
+                if not ent[0].stale():           # (the verdict of the check enqueued by the call before, if it has run)
+                    self._content_matches(ent[0], sparsity, colorvec, deferred=True)
+                    return ent[0]
+            elif self._content_matches(ent[0], sparsity, colorvec):
                 return ent[0]
         self._bound.clear()
         if len(self._plans) >= 8:
@@ -1062,13 +1123,18 @@ class JacobianCache:
         return plan
 
     @staticmethod
-    def _content_matches(plan, sparsity, colorvec):
+    def _all_device(sparsity, colorvec):
+        return (_is_torch(colorvec) and colorvec.is_cuda and
+                (isinstance(sparsity, DevicePatternCSC) or not isinstance(sparsity, (SparseMatrixCSC, np.ndarray))))
+
+    @staticmethod
+    def _content_matches(plan, sparsity, colorvec, deferred=False):
         cv = colorvec if (_is_torch(colorvec) or isinstance(colorvec, np.ndarray)) else _i64(colorvec)
         if isinstance(sparsity, DevicePatternCSC):
-            return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=sparsity.idx_base)
+            return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=sparsity.idx_base, deferred=deferred)
         if isinstance(sparsity, SparseMatrixCSC):
             return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=1)
-        return plan.matches(None, None, cv)      # structural patterns (Tridiagonal, BandedMatrix, ...): the colours
+        return plan.matches(None, None, cv, deferred=deferred)      # structural patterns (Tridiagonal, BandedMatrix, ...): the colours
 
 
 def _has_sparsestruct(J):

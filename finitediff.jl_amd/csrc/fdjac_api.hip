@@ -159,7 +159,8 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
     // round 3 (N = 10^7 tridiagonal: 0.18 -> 0.09 ms per Jacobian, bit-identical); FDJAC_LAZY_STORE=0 keeps the hand-over
     p->store_allowed = env_int("FDJAC_LAZY_STORE", 1) != 0;
-    p->want_store_csc = (opts->flags & FD_PLAN_STORE_CSC) != 0;   // a compact device copy of the pattern for column-centric storing launches
+    p->want_store_csc = (opts->flags & FD_PLAN_STORE_CSC) != 0;
+    p->store_csc_always = (opts->flags & FD_PLAN_STORE_CSC_ALWAYS) != 0;   // a compact device copy of the pattern for column-centric storing launches
     p->own_c0 = 0;
     p->own_c1 = -1;
     if (!(opts->color_begin == 0 && opts->color_end == 0)) {
@@ -388,6 +389,7 @@ int fd_ctx_destroy(fd_ctx *ctx)
 {
     if (!ctx) return FD_OK;
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_stale) (void)hipHostFree(ctx->h_stale);
     delete ctx;
     return FD_OK;
 }
@@ -398,6 +400,12 @@ int fd_ctx_synchronize(fd_ctx *ctx)
 {
     FD_REQUIRE(ctx != nullptr, FD_ERR_ARG, "ctx is NULL");
     FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_stale && *(volatile int *)ctx->h_stale) {       // a deferred content check (fd_plan_matches_async) found a stale plan
+        *ctx->h_stale = 0;
+        set_error("a deferred content check found that a plan no longer matches the caller's pattern / colour arrays (fd_plan_stale tells "
+                  "which): results enqueued since that check are those of the old arrays");
+        return FD_ERR_STALE;
+    }
     return FD_OK;
 }
 
@@ -409,10 +417,11 @@ int fd_plan_destroy(fd_plan *p)
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
-                    p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_xstage,
+                    p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_fpx, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->h_pstale) (void)hipHostFree(p->h_pstale);
     for (auto &sp : p->spans) {
         p->event_pool.push_back(sp.a);
         p->event_pool.push_back(sp.b);
@@ -640,6 +649,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     p->absstep_last = absstep;
     p->fcalls_last = 0;
     if (collect_spans(p, false) != FD_OK) return FD_ERR_HIP;  // harvest finished spans, never wait for the device
+    FD_REQUIRE(!(p->h_pstale && *(volatile int *)p->h_pstale), FD_ERR_STALE,
+               "a deferred content check (fd_plan_matches_async) found that this plan no longer matches the caller's pattern / colour arrays");
     Span total(p, FD_STAGE_TOTAL);
 
     // x must be 16-B aligned for the vector loads; stage it otherwise

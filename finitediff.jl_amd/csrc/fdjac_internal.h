@@ -25,6 +25,8 @@
 #define fd_plan_create_bandedblockbanded fd32_plan_create_bandedblockbanded
 #define fd_plan_destroy fd32_plan_destroy
 #define fd_plan_matches fd32_plan_matches
+#define fd_plan_matches_async fd32_plan_matches_async
+#define fd_plan_stale fd32_plan_stale
 #define fd_plan_info fd32_plan_info
 #define fd_jacobian fd32_jacobian
 #define fd_jacobian_async fd32_jacobian_async
@@ -214,6 +216,9 @@ struct fd_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
+    // fd_plan_matches_async: a sticky "some plan was found stale" word in pinned host memory mapped to the device -- a kernel raises
+    // it, the host reads it without a synchronisation (fd_ctx_synchronize / the next fd_jacobian* of that plan report FD_ERR_STALE)
+    int *h_stale = nullptr, *d_stale = nullptr;
 };
 
 struct fd_plan {
@@ -273,7 +278,7 @@ struct fd_plan {
     bool store5_ok = false;
     int64_t store5_nx = 0, store5_ny = 0;
     // ... and ANY pattern, column by column, through a compact device copy of the local pattern (fd_csc_store; FD_PLAN_STORE_CSC)
-    bool want_store_csc = false, store_csc_ok = false;
+    bool want_store_csc = false, store_csc_always = false, store_csc_ok = false;
     // BandedBlockBandedMatrix (K_BBB): block structure and the banded-data slab of every in-band block
     int64_t bbb_nb = 0;
     int bbb_bl = 0, bbb_bu = 0, bbb_lam = 0, bbb_mu = 0;
@@ -357,6 +362,8 @@ struct fd_plan {
 
     fd_fingerprint fp;                          // FD_PLAN_FINGERPRINT: what fd_plan_matches compares against
     unsigned long long *d_fp = nullptr;         //   three device words for the fingerprint kernels (allocated on first use)
+    unsigned long long *d_fpx = nullptr;        //   fd_plan_matches_async: [0..2] accumulators, [3..5] the plan's fingerprints, [6] ticket
+    int *h_pstale = nullptr, *d_pstale = nullptr;   //   ... this plan's own sticky stale word (pinned host memory mapped to the device)
 
     int timing = 0;   // 0 off, 1 decompress + total, 2 all stages
     std::vector<fdjac::TimedSpan> spans;       // recorded, not yet collected

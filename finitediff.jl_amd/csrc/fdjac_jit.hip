@@ -1,0 +1,333 @@
+// Runtime compilation of a caller's ROW FUNCTOR (include/fdjac.h, fd_f_compile_rows).
+//
+// The reference calls any Julia callable as f! (src/jacobians.jl:541,563,605-606,634).  The one-launch path of this library needs f!
+// as device code: a functor  T f(long long r, const P &X)  that evaluates ONE row r of the residual at the point X (X(j) = coordinate
+// j) -- inside fd_csc_store_cols (include/fdjac_device.h) it evaluates, for every stored entry of every column, the entry's row at
+// the column's colour point, subtracts the row at x, divides by the step and stores into nzval (src/jacobians.jl:562-568 +
+// ext/FiniteDiffSparseArraysExt.jl:38-47 in one launch).  A caller without an offline toolchain (a Julia process) hands the functor
+// over as SOURCE: it is compiled here with hiprtc against the embedded include/fdjac_device.h, -ffp-contract=off as the library
+// itself is built (the reference never fuses a*b+c), for the device's gfx950, cached by content for the life of the process.
+//
+// hiprtc is bound at run time (dlopen), like RCCL: libfdjac loads on boxes without it and fd_f_compile_rows says so.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fdjac_internal.h"
+
+#ifndef FDJAC_F32   /* element-type independent (the element type is a parameter of the compilation): compiled once */
+
+namespace fdjac {
+
+static const char kDeviceHeader[] =
+#include "fdjac_device_h.inc"
+    ;
+
+struct Hiprtc {
+    void *handle = nullptr;
+    decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+    decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+    decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+    decltype(&hiprtcAddNameExpression) AddNameExpression = nullptr;
+    decltype(&hiprtcGetLoweredName) GetLoweredName = nullptr;
+    decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+    decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+    decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+    decltype(&hiprtcGetCode) GetCode = nullptr;
+    decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+};
+static Hiprtc g_rtc;
+static std::mutex g_jit_mutex;
+static thread_local std::string t_log;
+
+static const Hiprtc *hiprtc()
+{
+    if (g_rtc.handle) return &g_rtc;
+    const char *env = getenv("FDJAC_HIPRTC_LIB");
+    const char *names[] = {env && *env ? env : "libhiprtc.so", "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        set_error("hiprtc not found (tried libhiprtc.so, /opt/rocm/lib; set FDJAC_HIPRTC_LIB): %s", dlerror());
+        return nullptr;
+    }
+    Hiprtc r;
+    r.handle = h;
+#define FD_SYM(field, name)                                            \
+    r.field = (decltype(r.field))dlsym(h, name);                       \
+    if (!r.field) {                                                    \
+        set_error("hiprtc symbol %s missing", name);                   \
+        return nullptr;                                                \
+    }
+    FD_SYM(CreateProgram, "hiprtcCreateProgram")
+    FD_SYM(DestroyProgram, "hiprtcDestroyProgram")
+    FD_SYM(CompileProgram, "hiprtcCompileProgram")
+    FD_SYM(AddNameExpression, "hiprtcAddNameExpression")
+    FD_SYM(GetLoweredName, "hiprtcGetLoweredName")
+    FD_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize")
+    FD_SYM(GetProgramLog, "hiprtcGetProgramLog")
+    FD_SYM(GetCodeSize, "hiprtcGetCodeSize")
+    FD_SYM(GetCode, "hiprtcGetCode")
+    FD_SYM(GetErrorString, "hiprtcGetErrorString")
+#undef FD_SYM
+    g_rtc = r;
+    return &g_rtc;
+}
+
+// one compiled translation unit: the plain row launcher and the storing kernels of one functor type / element type
+struct JitModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t rows = nullptr;
+    hipFunction_t store[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [colour bytes == 4][central]
+    hipFunction_t store_win[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    unsigned sizeof_f = 0;
+    int refs = 0;
+    std::string key;
+};
+static std::map<std::string, JitModule *> g_modules;
+
+}  // namespace fdjac
+
+struct fd_jit_f {
+    fd_ctx *ctx = nullptr;
+    fdjac::JitModule *m = nullptr;
+    int elem_bytes = 8;
+    int64_t M = 0, N = 0;
+    std::vector<unsigned char> params;      // the functor object, byte for byte (sizeof(F) bytes)
+    int64_t launches = 0;
+};
+
+namespace fdjac {
+
+static const char kJitTail[] = R"FDJIT(
+typedef FDJIT_FUNCTOR fdjit_F;
+struct fdjit_plain {
+    const real_t *x;
+    __device__ real_t operator()(long long j) const { return x[j]; }
+};
+extern "C" __global__ void __launch_bounds__(256) fdjit_rows(real_t *__restrict__ fx, const real_t *__restrict__ x, fdjit_F f, long long xs,
+                                                             long long fs, long long r0, long long r1)
+{
+    const long long r = r0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= r1) return;
+    const fdjit_plain P = {x + (long long)blockIdx.y * xs};
+    fx[(long long)blockIdx.y * fs + r] = f(r, P);
+}
+extern "C" __device__ __attribute__((used)) const unsigned fdjit_sizeof_f = sizeof(fdjit_F);
+)FDJIT";
+
+static int jit_launch(void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride, int64_t fx_stride, int64_t row_begin,
+                      int64_t row_end, int is_complex, void *stream)
+{
+    fd_jit_f *j = (fd_jit_f *)fctx;
+    if (is_complex || row_end <= row_begin || nbatch < 1) return is_complex ? 3 : 0;
+    long long xs = x_stride, fs = fx_stride, r0 = row_begin, r1 = row_end;
+    void *args[] = {&fx, (void *)&x, (void *)j->params.data(), &xs, &fs, &r0, &r1};
+    const unsigned gx = (unsigned)((row_end - row_begin + 255) / 256);
+    if (hipModuleLaunchKernel(j->m->rows, gx, (unsigned)nbatch, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+    j->launches += 1;
+    return 0;
+}
+
+// the lazy launcher serves exactly one request: store column by column (forward / central, real); everything else is declined
+static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64_t fx_stride, int64_t row_begin, int64_t row_end, void *stream)
+{
+    (void)fx; (void)fx_stride; (void)row_begin; (void)row_end;
+    fd_jit_f *j = (fd_jit_f *)fctx;
+    if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
+    fd_csc_store st = *(const fd_csc_store *)lp->store;
+    if (st.elem_bytes != j->elem_bytes || (st.color_bytes != 1 && st.color_bytes != 4) || st.M != j->M || st.N != j->N || st.col_end <= st.col_begin)
+        return FD_LAZY_DECLINED;
+    const long long nblk = (st.col_end - st.col_begin + 255) / 256;
+    const unsigned g = (unsigned)(8 * ((nblk + 7) / 8));
+    int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
+    const void *x = lp->x, *eps = lp->eps;
+    const int cb = st.color_bytes == 4 ? 1 : 0, central = lp->pts == 2 ? 1 : 0;
+    // a locally banded pattern with a verified colouring: the workgroup's window of x (and f(x)) in LDS, fd_csc_store_cols_win
+    const int64_t reach = st.reach;
+    const bool wb = !central && st.fx_base != nullptr;
+    const size_t lds = !(reach > 0 && reach <= 700) ? 0 : j->elem_bytes == 8 ? fd_csc_win_lds_bytes<double>(reach, wb) : fd_csc_win_lds_bytes<float>(reach, wb);
+    if (st.valid_coloring && lds > 0 && lds <= 64 * 1024 && st.M == st.N && j->m->store_win[cb][central]) {
+        int ireach = (int)reach, sb = 0, cap = 0;
+        void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st, &ireach, &sb, &cap};
+        if (hipModuleLaunchKernel(j->m->store_win[cb][central], g, 1, 1, 256, 1, 1, (unsigned)lds, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+    } else {
+        void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st};
+        if (hipModuleLaunchKernel(j->m->store[cb][central], g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+    }
+    j->launches += 1;
+    return 0;
+}
+
+static void release_module(JitModule *m)
+{
+    if (!m) return;
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    if (--m->refs > 0) return;
+    g_modules.erase(m->key);
+    if (m->mod) (void)hipModuleUnload(m->mod);
+    delete m;
+}
+
+}  // namespace fdjac
+
+using namespace fdjac;
+
+extern "C" {
+
+const char *fd_f_compile_log(void) { return t_log.c_str(); }
+
+int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, const void *params, int64_t params_bytes, int64_t M, int64_t N,
+                      int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out)
+{
+    FD_REQUIRE(ctx && source && functor && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 8 (Float64) or 4 (Float32)");
+    FD_REQUIRE(M >= 1 && N >= 1, FD_ERR_ARG, "bad shape");
+    FD_REQUIRE(params_bytes >= 0 && (params || params_bytes == 0), FD_ERR_ARG, "bad functor parameters");
+    for (const char *c = functor; *c; ++c)
+        FD_REQUIRE((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_' || *c == ':' || *c == '<' || *c == '>' || *c == ',' ||
+                       *c == ' ',
+                   FD_ERR_ARG, "functor must be a type name");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    t_log.clear();
+    const char *real = elem_bytes == 8 ? "double" : "float";
+    std::string src = "#include <hip/hip_runtime.h>\n";
+    src += kDeviceHeader;
+    src += "\ntypedef ";
+    src += real;
+    src += " real_t;\n#line 1 \"functor\"\n";
+    src += source;
+    src += "\n#define FDJIT_FUNCTOR ";
+    src += functor;
+    src += "\n";
+    src += kJitTail;
+    JitModule *m = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        auto it = g_modules.find(src);
+        if (it != g_modules.end()) { m = it->second; m->refs += 1; }
+    }
+    if (!m) {
+        const Hiprtc *R = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_jit_mutex);
+            R = hiprtc();
+        }
+        if (!R) return FD_ERR_UNSUPPORTED;
+        hiprtcProgram prog = nullptr;
+        hiprtcResult rr = R->CreateProgram(&prog, src.c_str(), "fdjac_jit.hip", 0, nullptr, nullptr);
+        FD_REQUIRE(rr == HIPRTC_SUCCESS, FD_ERR_HIP, "hiprtcCreateProgram failed: %s", R->GetErrorString(rr));
+        // the kernels of include/fdjac_device.h instantiated for this functor, found by their lowered names
+        std::string names[2][2][2];
+        const char *ct[2] = {"unsigned char", "int"};
+        for (int w = 0; w < 2; ++w)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int md = 0; md < 2; ++md) {
+                    names[w][cb][md] = std::string(w ? "fd_csc_store_cols_win<" : "fd_csc_store_cols<") + real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
+                    (void)R->AddNameExpression(prog, names[w][cb][md].c_str());
+                }
+        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
+        rr = R->CompileProgram(prog, 5, opts);
+        size_t ls = 0;
+        if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+            t_log.resize(ls);
+            (void)R->GetProgramLog(prog, &t_log[0]);
+        }
+        if (rr != HIPRTC_SUCCESS) {
+            set_error("compiling the functor failed (%s); the compiler's messages: fd_f_compile_log().  First lines: %.300s", R->GetErrorString(rr), t_log.c_str());
+            (void)R->DestroyProgram(&prog);
+            return FD_ERR_ARG;
+        }
+        size_t cs = 0;
+        std::vector<char> code;
+        if (R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS) { code.resize(cs); rr = R->GetCode(prog, code.data()); }
+        std::string low[2][2][2];
+        for (int w = 0; w < 2; ++w)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int md = 0; md < 2; ++md) {
+                    const char *ln = nullptr;
+                    if (R->GetLoweredName(prog, names[w][cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[w][cb][md] = ln;
+                }
+        (void)R->DestroyProgram(&prog);
+        FD_REQUIRE(rr == HIPRTC_SUCCESS && cs > 0, FD_ERR_HIP, "hiprtcGetCode failed");
+        m = new (std::nothrow) JitModule();
+        FD_REQUIRE(m != nullptr, FD_ERR_NOMEM, "out of host memory");
+        hipError_t e = hipModuleLoadData(&m->mod, code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->rows, m->mod, "fdjit_rows");
+        for (int cb = 0; cb < 2 && e == hipSuccess; ++cb)
+            for (int md = 0; md < 2 && e == hipSuccess; ++md) {
+                e = low[0][cb][md].empty() ? hipErrorNotFound : hipModuleGetFunction(&m->store[cb][md], m->mod, low[0][cb][md].c_str());
+                if (e == hipSuccess && !low[1][cb][md].empty() && hipModuleGetFunction(&m->store_win[cb][md], m->mod, low[1][cb][md].c_str()) != hipSuccess)
+                    m->store_win[cb][md] = nullptr;       // (the windowed form is an optimisation: the plain one serves)
+            }
+        if (e == hipSuccess) {
+            hipDeviceptr_t dp = nullptr;
+            size_t bytes = 0;
+            e = hipModuleGetGlobal(&dp, &bytes, m->mod, "fdjit_sizeof_f");
+            if (e == hipSuccess) e = hipMemcpy(&m->sizeof_f, dp, sizeof(unsigned), hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            set_error("loading the compiled functor failed: %s", hipGetErrorString(e));
+            if (m->mod) (void)hipModuleUnload(m->mod);
+            delete m;
+            return FD_ERR_HIP;
+        }
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        auto it = g_modules.find(src);
+        if (it != g_modules.end()) {       // (another thread compiled the same text meanwhile: keep theirs)
+            (void)hipModuleUnload(m->mod);
+            delete m;
+            m = it->second;
+        } else {
+            m->key = src;
+            g_modules[src] = m;
+        }
+        m->refs += 1;
+    }
+    // an empty functor has sizeof 1; otherwise the caller's bytes ARE the functor object
+    if (!((params_bytes == 0 && m->sizeof_f == 1) || (int64_t)m->sizeof_f == params_bytes)) {
+        set_error("the functor %s is %u bytes, %lld bytes of parameters were given", functor, m->sizeof_f, (long long)params_bytes);
+        release_module(m);
+        return FD_ERR_ARG;
+    }
+    fd_jit_f *j = new (std::nothrow) fd_jit_f();
+    if (!j) { release_module(m); set_error("out of host memory"); return FD_ERR_NOMEM; }
+    j->ctx = ctx; j->m = m; j->elem_bytes = elem_bytes; j->M = M; j->N = N;
+    j->params.assign(std::max<size_t>(m->sizeof_f, 16), 0);
+    if (params_bytes > 0) memcpy(j->params.data(), params, (size_t)params_bytes);
+    *fn_out = jit_launch;
+    if (lazy_out) *lazy_out = jit_launch_lazy;
+    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE;
+    *fctx_out = j;
+    return FD_OK;
+}
+
+int fd_f_compiled_destroy(void *fctx)
+{
+    fd_jit_f *j = (fd_jit_f *)fctx;
+    if (!j) return FD_OK;
+    (void)hipSetDevice(j->ctx->device);
+    (void)hipStreamSynchronize(j->ctx->stream);
+    release_module(j->m);
+    delete j;
+    return FD_OK;
+}
+
+int fd_f_compiled_counts(void *fctx, int64_t *launches)
+{
+    FD_REQUIRE(fctx && launches, FD_ERR_ARG, "NULL argument");
+    *launches = ((fd_jit_f *)fctx)->launches;
+    return FD_OK;
+}
+
+}  // extern "C"
+
+#endif /* FDJAC_F32 */

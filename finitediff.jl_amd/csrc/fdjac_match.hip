@@ -49,6 +49,52 @@ template <typename IT> __global__ void __launch_bounds__(256) k_fingerprint(cons
     if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]));
 }
 
+// fd_plan_matches_async: the three arrays in ONE launch -- workgroups [0, g0) fingerprint array 0, [g0, g0 + g1) array 1, the rest
+// array 2 -- and the verdict on the device: the workgroup that arrives last (agent-scope ticket) compares the three sums with the
+// plan's words fpx[3..5] and raises the two sticky stale words (pinned host memory); then it clears the accumulators and the ticket
+// for the next check.  No copy back, no synchronisation.
+struct Fp3 {
+    const void *a[3];
+    int bytes[3];
+    long long i0[3], n[3], base[3];
+    int g[3];
+};
+__global__ void __launch_bounds__(256) k_fingerprint3_check(Fp3 f, unsigned long long *__restrict__ fpx, int *__restrict__ stale_plan, int *__restrict__ stale_ctx)
+{
+    int k = 0, b = (int)blockIdx.x;
+    if (b >= f.g[0]) { b -= f.g[0]; k = 1; if (b >= f.g[1]) { b -= f.g[1]; k = 2; } }
+    uint64_t s = 0;
+    const long long n = f.n[k], stride = (long long)f.g[k] * 256;
+    if (f.bytes[k] == 8) {
+        const int64_t *a = (const int64_t *)f.a[k];
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += stride) s += fp_term((int64_t)a[f.i0[k] + i] - f.base[k], i);
+    } else {
+        const int32_t *a = (const int32_t *)f.a[k];
+        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += stride) s += fp_term((int64_t)a[f.i0[k] + i] - f.base[k], i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
+    __shared__ uint64_t s_w[4];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __hip_atomic_fetch_add(fpx + k, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t = __hip_atomic_fetch_add(fpx + 6, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != (unsigned long long)gridDim.x - 1) return;
+    bool same = true;
+    for (int q = 0; q < 3; ++q) {
+        const unsigned long long got = __hip_atomic_load(fpx + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.g[q] > 0 && got != fpx[3 + q]) same = false;
+        __hip_atomic_store(fpx + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(fpx + 6, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!same) {
+        __hip_atomic_store(stale_plan, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(stale_ctx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <typename IT> uint64_t host_range(const IT *a, int64_t i0, int64_t lo, int64_t hi, int64_t base)
 {
     uint64_t s = 0;
@@ -113,9 +159,28 @@ extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const
     return FD_OK;
 }
 
+// the fused check (see k_fingerprint3_check): expected words already in fpx[3..5]
+extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n, const int64_t *base,
+                                        unsigned long long *fpx, int *stale_plan, int *stale_ctx)
+{
+    Fp3 f;
+    int total = 0;
+    for (int k = 0; k < 3; ++k) {
+        f.a[k] = a[k]; f.bytes[k] = bytes[k]; f.i0[k] = i0[k]; f.n[k] = (a[k] && n[k] > 0) ? n[k] : 0; f.base[k] = base[k];
+        f.g[k] = f.n[k] > 0 ? (int)std::min<int64_t>((f.n[k] + 2047) / 2048, (int64_t)ctx->num_cus * 4) : 0;     // (>= 8 elements per thread)
+        total += f.g[k];
+    }
+    if (total == 0) return FD_OK;
+    hipLaunchKernelGGL(k_fingerprint3_check, dim3((unsigned)total), dim3(256), 0, ctx->stream, f, fpx, stale_plan, stale_ctx);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
 #else
 extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n,
                                   const int64_t *base, int memkind, unsigned long long *acc_dev, uint64_t *out);
+extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n, const int64_t *base,
+                                        unsigned long long *fpx, int *stale_plan, int *stale_ctx);
 #endif
 
 namespace fdjac {
@@ -145,7 +210,7 @@ static int fingerprint_now(fd_plan *p, const fd_pattern_arrays *now, int64_t a0,
     int bytes[3] = {now->idx_bytes, now->idx_bytes, now->color_bytes};
     int64_t i0[3] = {a0, 0, 0}, n[3] = {arr[0] ? an : 0, 0, arr[2] ? now->len_color : 0}, base[3] = {now->idx_base, now->idx_base, 0};
     int64_t b0 = 0, bn = 0;
-    if (fp.idx_kind == 1 && arr[0] && fp.valid) {
+    if (fp.idx_kind == 1 && fp.valid) {
         // comparing with a recorded plan: its own rowval range.  (colptr's fingerprint is position-dependent and covers both end
         // points: if it matches, the caller's range IS this one; if not, the answer is "no" whatever rowval holds -- so the two
         // blocking reads of colptr's end points are only needed when the range is first recorded)
@@ -230,7 +295,58 @@ extern "C" int fd_plan_matches(fd_plan *p, const fd_pattern_arrays *now, int *ma
     bool same = true;
     if (now->colorvec) same = same && h[2] == fp.h_color;
     if (fp.idx_kind && now->idx_a) same = same && h[0] == fp.h_a && (fp.idx_kind != 1 || (b0 == fp.b0 && bn == fp.bn));
-    if (fp.idx_kind && now->idx_b && (fp.idx_kind == 2 || now->idx_a)) same = same && h[1] == fp.h_b;
+    if (fp.idx_kind && now->idx_b) same = same && h[1] == fp.h_b;      // (a CSC plan knows its rowval range: compared with or without colptr)
     *matches_out = same ? 1 : 0;
+    return FD_OK;
+}
+
+// the deferred form: one fused launch, the verdict raised on the device (see k_fingerprint3_check)
+extern "C" int fd_plan_matches_async(fd_plan *p, const fd_pattern_arrays *now)
+{
+    using namespace fdjac;
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    int rc = check_arrays(now);
+    if (rc) return rc;
+    FD_REQUIRE(now->memkind == FD_DEVICE, FD_ERR_ARG, "fd_plan_matches_async compares device arrays (host arrays: fd_plan_matches)");
+    const fd_fingerprint &fp = p->fp;
+    FD_REQUIRE(fp.valid, FD_ERR_UNSUPPORTED, "the plan was created without FD_PLAN_FINGERPRINT");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    fd_ctx *ctx = p->ctx;
+    if (!ctx->h_stale) {
+        FD_HIP_CHECK(hipHostMalloc((void **)&ctx->h_stale, sizeof(int), hipHostMallocMapped));
+        *ctx->h_stale = 0;
+        FD_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->d_stale, ctx->h_stale, 0));
+    }
+    if (!p->d_fpx) {
+        FD_HIP_CHECK(hipHostMalloc((void **)&p->h_pstale, sizeof(int), hipHostMallocMapped));
+        *p->h_pstale = 0;
+        FD_HIP_CHECK(hipHostGetDevicePointer((void **)&p->d_pstale, p->h_pstale, 0));
+        FD_HIP_CHECK(hipMalloc((void **)&p->d_fpx, 8 * sizeof(unsigned long long)));
+        const unsigned long long init[8] = {0, 0, 0, fp.h_a, fp.h_b, fp.h_color, 0, 0};
+        FD_HIP_CHECK(hipMemcpyAsync(p->d_fpx, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // (once per plan: `init` lives on this stack)
+    }
+    // what the host can see at once: a resized array cannot be the plan's (and must not be read with the plan's ranges)
+    bool host_mismatch = (now->colorvec && now->len_color != fp.len_color) || (fp.idx_kind && now->idx_a && now->len_a != fp.len_a) ||
+                         (fp.idx_kind == 2 && now->idx_b && now->len_b != fp.len_b) ||
+                         (fp.idx_kind == 1 && now->idx_b && fp.b0 + fp.bn > now->len_b);
+    if (host_mismatch) {
+        *p->h_pstale = 1;
+        set_error("the arrays have other lengths than the ones this plan was compiled from");
+        return FD_ERR_STALE;
+    }
+    const bool use_a = fp.idx_kind && now->idx_a, use_b = fp.idx_kind && now->idx_b;
+    const void *arr[3] = {use_a ? now->idx_a : nullptr, use_b ? now->idx_b : nullptr, now->colorvec};
+    const int bytes[3] = {now->idx_bytes, now->idx_bytes, now->color_bytes};
+    const int64_t i0[3] = {fp.a0, fp.idx_kind == 1 ? fp.b0 : 0, 0};
+    const int64_t n[3] = {use_a ? fp.an : 0, use_b ? (fp.idx_kind == 1 ? fp.bn : now->len_b) : 0, now->colorvec ? now->len_color : 0};
+    const int64_t base[3] = {now->idx_base, now->idx_base, 0};
+    return fdjac_fingerprint3_check(ctx, arr, bytes, i0, n, base, p->d_fpx, p->d_pstale, ctx->d_stale);
+}
+
+extern "C" int fd_plan_stale(fd_plan *p, int *stale_out)
+{
+    FD_REQUIRE(p && stale_out, FD_ERR_ARG, "NULL argument");
+    *stale_out = p->h_pstale ? *(volatile int *)p->h_pstale : 0;
     return FD_OK;
 }

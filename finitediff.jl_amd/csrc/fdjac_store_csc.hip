@@ -159,7 +159,7 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
 
 static bool store_csc_wanted(const fd_plan *p)
 {
-    return p->want_store_csc && p->kind == K_CSC && !p->cx && !p->store_ok && !p->store5_ok && p->store_allowed && p->nnz_local > 0 &&
+    return p->want_store_csc && p->kind == K_CSC && !p->cx && (p->store_csc_always || (!p->store_ok && !p->store5_ok)) && p->store_allowed && p->nnz_local > 0 &&
            p->nnz_local < ((int64_t)1 << 31) && p->M < ((int64_t)1 << 31) && p->d_color != nullptr;
 }
 

@@ -28,7 +28,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total")
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
  INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE, INFO_STORE_CSC) = range(34)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE = 1, 2, 4, 8, 16, 32
-PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC = 1, 2, 4, 8
+PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC, PLAN_STORE_CSC_ALWAYS = 1, 2, 4, 8, 16
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL, F_LAP7, F_SPARSE) = range(9)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
@@ -70,13 +70,13 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_f_compile_rows", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
     "fd_p2p_create", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
 )
 
 
@@ -92,7 +92,7 @@ TYPED = (
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -181,6 +181,8 @@ def load():
     L.fd_plan_create_bandedblockbanded.argtypes = [vp, i64, vp, i64, i64, i64, i64, vp, vp, i64, i32, i32, vp, i32, po, pp]
     L.fd_plan_destroy.argtypes = [vp]
     L.fd_plan_matches.argtypes = [vp, C.POINTER(PatternArrays), C.POINTER(i32)]
+    L.fd_plan_matches_async.argtypes = [vp, C.POINTER(PatternArrays)]
+    L.fd_plan_stale.argtypes = [vp, C.POINTER(i32)]
     L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]
     L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
     L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
@@ -220,6 +222,10 @@ def load():
     L.fd_comm_halo_exchange.argtypes = [vp, vp, i64, i64, i64, i32]
     L.fd_comm_enable_p2p.argtypes = [vp, i64]
     L.fd_comm_p2p_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fd_f_compile_rows.argtypes = [vp, C.c_char_p, C.c_char_p, vp, i64, i64, i64, i32, C.POINTER(F_LAUNCH), C.POINTER(F_LAUNCH_LAZY), C.POINTER(i32), pp]
+    L.fd_f_compiled_destroy.argtypes = [vp]
+    L.fd_f_compiled_counts.argtypes = [vp, C.POINTER(i64)]
+    L.fd_f_compile_log.restype = C.c_char_p
     L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
     L.fd_p2p_local_handle.argtypes = [vp, vp]
     L.fd_p2p_connect.argtypes = [vp, vp]
@@ -245,7 +251,7 @@ def load():
         getattr(L, "fd32_" + name[3:]).argtypes = getattr(L, name).argtypes
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("fd_last_error", "fd_ctx_stream", "fd_comm_library"):
+        if name not in ("fd_last_error", "fd_ctx_stream", "fd_comm_library", "fd_f_compile_log"):
             fn.restype = i32
     _lib = L
     return L

@@ -59,7 +59,9 @@ enum fd_status {
     FD_ERR_CALLBACK = 5,    /* the f! launcher returned non-zero */
     FD_ERR_NOMEM = 6,
     FD_ERR_NODEVICE = 7,    /* no usable gfx950 device */
-    FD_ERR_COMM = 8         /* RCCL failure, or RCCL not available (fd_comm_*) */
+    FD_ERR_COMM = 8,        /* RCCL failure, or RCCL not available (fd_comm_*) */
+    FD_ERR_STALE = 9        /* a deferred content check (fd_plan_matches_async) found that the plan is no longer the plan of the caller's */
+                            /* arrays: results enqueued since that check are those of the OLD pattern / colours -- recompile, recompute  */
 };
 
 enum fd_fdtype { FD_FORWARD = 0, FD_CENTRAL = 1, FD_COMPLEX = 2 }; /* Val(:forward|:central|:complex) */
@@ -167,6 +169,8 @@ typedef struct fd_plan_opts {
                                    /* column.  No requirement on the colouring.  Needs fewer than 2^31 local entries; plans of an exact   */
                                    /* band / 5-point stencil skip it (their closed-form descriptors are cheaper).  FD_INFO_STORE_CSC      */
                                    /* reports whether it was built.                                                                      */
+#define FD_PLAN_STORE_CSC_ALWAYS 16   /* (with FD_PLAN_STORE_CSC) build that copy for exact bands / 5-point stencils too: for launchers that store     */
+                                   /* through fd_csc_store ONLY -- runtime-compiled functors (fd_f_compile_rows) on a banded pattern             */
 #define FD_PLAN_FINGERPRINT 4        /* record 64-bit content fingerprints of the pattern / colour arrays the plan is compiled from, so  */
                                    /* that fd_plan_matches can later tell whether the caller's arrays still hold that content        */
 
@@ -271,6 +275,15 @@ typedef struct fd_pattern_arrays {
     int32_t memkind;       /* FD_HOST or FD_DEVICE: where ALL the arrays live */
 } fd_pattern_arrays;
 int fd_plan_matches(fd_plan *plan, const fd_pattern_arrays *now, int *matches_out);
+/* The same comparison WITHOUT stopping the stream (device arrays only): ONE fused kernel fingerprints the three arrays and compares
+   with the plan's words on the device; a mismatch raises a sticky status in pinned host memory -- no copy back, no synchronisation,
+   the call returns at once and the Jacobian calls behind it keep the stream full (fd_plan_matches costs 3 launches, a copy and a
+   hipStreamSynchronize per call).  The verdict is DEFERRED: it is reported as FD_ERR_STALE by the next fd_jacobian* call on this plan
+   and by fd_ctx_synchronize -- whichever the host reaches first after the kernel ran -- and by fd_plan_stale at any time.  Results
+   enqueued between the check and the report came from the stale plan: on FD_ERR_STALE drop the plan, compile a new one, recompute.
+   (A mismatch the HOST can see -- another length -- is reported immediately: FD_ERR_STALE from this call.)  */
+int fd_plan_matches_async(fd_plan *plan, const fd_pattern_arrays *now);
+int fd_plan_stale(fd_plan *plan, int *stale_out);          /* non-blocking; 1 once a completed check of this plan found a mismatch (sticky) */
 
 /* Introspection: what[] selectors for fd_plan_info. */
 enum fd_plan_info_key {
@@ -562,6 +575,25 @@ int fd_tridiag_solve_interface(fd_tridiag_solver *solver, double alpha, double b
 int fd_tridiag_solve_finish(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
                             const void *packets_dev, int rank, int nranks, void *y);
 
+/* ---- runtime compilation of a row functor (hiprtc) --------------------------------------------------------------------------------
+ * The reference accepts ANY callable as f! (src/jacobians.jl:541,563,605-606,634).  The one-launch call of this library needs f! as
+ * device code; a caller without an offline toolchain (a Julia process) hands it over as SOURCE: a functor type
+ *     struct MyF { <parameters>;  template <class P> __device__ real_t operator()(long long r, const P &X) const { ... } };
+ * that returns row r of the residual at the point X (X(j) = coordinate j; `real_t` is the element type: double / float).  It is
+ * compiled against include/fdjac_device.h (embedded in the library) with -O3 -ffp-contract=off for gfx950 and cached by content for
+ * the life of the process.  `params` = the functor OBJECT byte for byte (params_bytes == sizeof(MyF); 0 for an empty struct).
+ * Out: the plain launcher (rows at materialised points), the lazy launcher -- FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE: for a
+ * plan created with FD_PLAN_STORE_CSC (| FD_PLAN_STORE_CSC_ALWAYS on banded patterns) the whole Jacobian is the step-size launch + ONE
+ * launch of fd_csc_store_cols / fd_csc_store_cols_win instantiated for the functor -- and the context for both.
+ * FD_ERR_ARG when the source does not compile (the compiler's messages: fd_f_compile_log(), this thread's last compilation);
+ * FD_ERR_UNSUPPORTED when libhiprtc cannot be loaded.  Register the pair as
+ *     fd_plan_set_lazy_f(plan, lazy); fd_plan_set_lazy_caps(plan, caps);          (fd32_* for elem_bytes == 4) */
+int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor_type, const void *params, int64_t params_bytes, int64_t M,
+                      int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out);
+int fd_f_compiled_destroy(void *fctx);
+int fd_f_compiled_counts(void *fctx, int64_t *launches);
+const char *fd_f_compile_log(void);
+
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
    16 B/lane kernel and returns the achieved GB/s (read + write bytes) -- the measured roofline
    the achieved figures are quoted against. */
@@ -632,6 +664,8 @@ int fd32_tridiag_solve_interface(fd32_tridiag_solver *solver, double alpha, doub
 int fd32_tridiag_solve_finish(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
                               const void *packets_dev, int rank, int nranks, void *y);
 int fd32_plan_set_comm(fd32_plan *plan, fd_comm *comm);
+int fd32_plan_matches_async(fd32_plan *plan, const fd_pattern_arrays *now);
+int fd32_plan_stale(fd32_plan *plan, int *stale_out);
 int fd32_plan_set_p2p(fd32_plan *plan, fd_p2p *p2p);
 int fd32_plan_set_halo(fd32_plan *plan, int64_t own_begin, int64_t own_end, int64_t halo);
 int fd32_plan_eps_partials(fd32_plan *plan, const void *x_dev, int shard, int nshards, void **partials_out,

@@ -224,7 +224,7 @@ def _build_c_clients(root, tmp_path):
 
 
 @pytest.mark.parametrize("client", ["csc", "csc_device", "csc_dense", "coo_dense", "entries", "dense", "tridiagonal", "banded", "blockbanded", "bandedblockbanded",
-                                    "csc_f32", "jvp", "solve", "host", "complex_x", "complex_structured", "out_of_place", "resize", "dropin"])
+                                    "csc_f32", "jvp", "solve", "host", "complex_x", "complex_structured", "out_of_place", "resize", "dropin", "jit"])
 def test_c_clients_every_plan_kind(tmp_path, client):
     # examples/c_abi_clients.c: one plain-C client per method of the Julia shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl)
     # -- Julia-layout arrays, DEVICE pointers for x / J's storage, the caller's own stream, fd_jacobian_async -- each
@@ -643,6 +643,51 @@ def test_dropin_plan_lookup_sees_an_in_place_edit_of_colorvec(check, device_patt
     colors2 = colors.clone() if torch.is_tensor(colors) else colors.copy()
     fd.finite_difference_jacobian_b(J, f, x, cache, colorvec=colors2)
     assert cache.last_plan is not p1 and float(J.nzval[d]) == 0.0
+
+
+def test_dropin_deferred_content_check_reports_an_edit_one_call_late():
+    # pattern_check = "content_async" (fd_plan_matches_async): ONE fused kernel ahead of every Jacobian compares the device arrays with
+    # the plan's fingerprints and raises a sticky status on the device -- nothing is copied back, the stream is never stopped.  The
+    # verdict is deferred: the call right after an in-place edit still runs on the old plan; Context.synchronize() reports FD_ERR_STALE,
+    # Plan.stale() turns true, and the next call recompiles and computes with the edited colours.
+    N = 20011
+    J, colors, cp = _tridiag_dropin(N, True)
+    x = _dev(np.random.default_rng(3).random(N))
+    f = fd.BuiltinF("tridiag_nl", N)
+    cache = fd.JacobianCache(x, "forward", colorvec=colors, sparsity=J)
+    cache.pattern_check = "content_async"
+    ctx = fd.Context.default()
+    for _ in range(3):
+        fd.finite_difference_jacobian_b(J, f, x, cache)
+    ctx.synchronize()
+    p0 = cache.last_plan
+    assert not p0.stale()
+    first = J.nzval.clone()
+    jz = N // 2
+    d = int(cp[jz] - 1 + 1)
+    colors[jz] = 0                                                 # in-place edit of the CUDA tensor
+    fd.finite_difference_jacobian_b(J, f, x, cache)                # check enqueued, then the Jacobian of the OLD plan
+    assert cache.last_plan is p0
+    with pytest.raises(fd.lib.FdError) as e:
+        ctx.synchronize()                                          # the deferred verdict
+    assert e.value.code == 9 and p0.stale()                        # FD_ERR_STALE
+    assert torch.equal(J.nzval, first)                             # (what the stale plan computed)
+    with pytest.raises(fd.lib.FdError) as e2:                      # the stale plan refuses further calls
+        p0.jacobian(f, x, [J.nzval])
+    assert e2.value.code == 9
+    fd.finite_difference_jacobian_b(J, f, x, cache)                # the lookup sees the verdict: new plan, edited colours
+    ctx.synchronize()
+    assert cache.last_plan is not p0 and float(J.nzval[d]) == 0.0 and not cache.last_plan.stale()
+    # unedited arrays: many calls, never stale; and a pattern edit (rowval) is seen as well
+    for _ in range(20):
+        fd.finite_difference_jacobian_b(J, f, x, cache)
+    ctx.synchronize()
+    p1 = cache.last_plan
+    assert not p1.stale()
+    J.rowval[5] = J.rowval[5]                                      # a write that changes nothing
+    fd.finite_difference_jacobian_b(J, f, x, cache)
+    ctx.synchronize()
+    assert cache.last_plan is p1 and not p1.stale()
 
 
 def test_plan_matches_compares_content_not_identity():

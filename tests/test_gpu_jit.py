@@ -1,0 +1,136 @@
+"""Runtime-compiled row functors (fd_f_compile_rows, csrc/fdjac_jit.hip): a residual given as SOURCE reaches the one-launch call --
+the step-size launch + the column store instantiated for the functor -- and reproduces the bits of the built-in family / the oracle."""
+import struct
+
+import numpy as np
+import pytest
+
+import finitediff_jl_amd as fd
+from finitediff_jl_amd import patterns as P
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TRIDIAG_NL = """
+// test/coloring_tests.jl:5-13 with the nonlinear term of the tridiag_nl fixture: (x[i-1] - 2 x[i]) + x[i+1] + (x[i] x[i]) x[i+1]
+struct TridiagNL {
+    long long n;
+    template <class P> __device__ real_t operator()(long long i, const P &X) const
+    {
+        // (every coordinate is fetched unconditionally from a clamped index and selected away outside: no load inside a per-lane branch)
+        const real_t xi = X(i), xm = X(i > 0 ? i - 1 : i), xp = X(i + 1 < n ? i + 1 : i);
+        const real_t a = i > 0 ? xm : (real_t)0, b = i + 1 < n ? xp : (real_t)0;
+        real_t v = (a - (real_t)2 * xi) + b;
+        v = v + (xi * xi) * b;
+        return v;
+    }
+};
+"""
+
+
+def _dev(a, dt=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_jit_tridiag_nl_reproduces_the_builtin_bits(fdtype):
+    N = 200_003
+    colptr, rowval = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    x = _dev(np.random.default_rng(1).random(N))
+    fb = fd.BuiltinF("tridiag_nl", N)
+    ref_plan = fd.make_plan(J, J, colors, fdtype)
+    ref_plan.set_lazy(fb)
+    ref = _dev(np.full(rowval.size, np.nan))
+    ref_plan.jacobian(fb, x, [ref])
+    fj = fd.JitF(TRIDIAG_NL, "TridiagNL", N, N, params=struct.pack("q", N))
+    # (1) the opaque route: the compiled functor as a plain fd_f_launch (materialised points)
+    p1 = fd.make_plan(J, J, colors, fdtype)
+    o1 = _dev(np.full(rowval.size, np.nan))
+    p1.jacobian(fj, x, [o1])
+    assert torch.equal(o1.view(torch.int64), ref.view(torch.int64))
+    # (2) the one-launch route: the column store instantiated for the functor (FD_PLAN_STORE_CSC_ALWAYS: the pattern is a band)
+    p2 = fd.make_plan(J, J, colors, fdtype, store_csc_always=True)
+    p2.set_lazy(fj)
+    o2 = _dev(np.full(rowval.size, np.nan))
+    n0 = fj.launches
+    p2.jacobian(fj, x, [o2])
+    assert p2.info(fd.lib.INFO_STORE_CSC) == rowval.size and p2.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert fj.launches - n0 == 1                       # ONE launch of the functor: no f(x) pass, no hand-over
+    assert p2.fcalls_last == (1 + 3 if fdtype == "forward" else 6)
+    assert torch.equal(o2.view(torch.int64), ref.view(torch.int64))
+    # the same source again: served from the cache (same module), a second functor object works independently
+    fj2 = fd.JitF(TRIDIAG_NL, "TridiagNL", N, N, params=struct.pack("q", N))
+    o3 = _dev(np.full(rowval.size, np.nan))
+    p2.set_lazy(fj2)
+    p2.jacobian(fj2, x, [o3])
+    assert torch.equal(o3.view(torch.int64), ref.view(torch.int64))
+
+
+def test_jit_on_a_general_pattern_matches_the_analytic_jacobian_and_float32():
+    # a functor on a scattered pattern (the sparse family's residual restated in source form would need its tables; here a 2-D 9-point
+    # Moore-neighbourhood residual on a small grid, pattern built on the host): oracle parity to the stated tolerance, Float32 too
+    nx, ny = 37, 23
+    N = nx * ny
+    src = """
+    struct Moore {
+        long long nx, ny;
+        template <class P> __device__ real_t operator()(long long k, const P &X) const
+        {
+            const long long j = k / nx, i = k - j * nx;
+            real_t s = 0;
+            bool first = true;
+            for (int dj = -1; dj <= 1; ++dj)
+                for (int di = -1; di <= 1; ++di) {
+                    if (di == 0 && dj == 0) continue;
+                    const long long ii = i + di, jj = j + dj;
+                    const bool in = ii >= 0 && ii < nx && jj >= 0 && jj < ny;
+                    const real_t xv = X(in ? jj * nx + ii : k);
+                    const real_t v = in ? (real_t)0.5 * xv : (real_t)0;
+                    s = first ? v : s + v;
+                    first = false;
+                }
+            const real_t c = X(k);
+            return (s - (real_t)4 * c) + (c * c) * c;
+        }
+    };
+    """
+    dense = np.zeros((N, N))
+    for k in range(N):
+        j, i = divmod(k, nx)
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                ii, jj = i + di, j + dj
+                if 0 <= ii < nx and 0 <= jj < ny:
+                    dense[k, jj * nx + ii] = 1
+    colptr, rowval = P.csc_from_dense(dense)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    xh = np.random.default_rng(2).random(N) + 0.2
+    # analytic Jacobian: 0.5 at the neighbours, -4 + 3 x_k^2 on the diagonal
+    want = np.where(np.eye(N, dtype=bool), -4.0 + 3.0 * xh[None, :] ** 2, 0.5 * dense)
+    cols = P.csc_cols(colptr) - 1
+    want_nz = want[rowval - 1, cols]
+    for dtype, tol in ((np.float64, 2e-6), (np.float32, 2e-2)):
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        fj = fd.JitF(src, "Moore", N, N, params=struct.pack("qq", nx, ny), dtype=dtype)
+        x = _dev(xh, tdt)
+        for store in (False, True):
+            plan = fd.make_plan(J, J, colors, "forward", dtype=dtype, store_csc=store)
+            if store:
+                plan.set_lazy(fj)
+            out = torch.full((rowval.size,), float("nan"), dtype=tdt, device="cuda")
+            plan.jacobian(fj, x, [out])
+            if store:
+                assert plan.info(fd.lib.INFO_LAZY_STORE) == 1
+            assert np.max(np.abs(out.cpu().numpy().astype(np.float64) - want_nz)) < tol
+
+
+def test_jit_errors_are_reported():
+    with pytest.raises(fd.lib.FdError) as e:
+        fd.JitF("struct Broken { template <class P> __device__ real_t operator()(long long r, const P &X) const { return nonsense; } };",
+                "Broken", 10, 10)
+    assert e.value.code == 1 and "compil" in str(e.value)
+    with pytest.raises(fd.lib.FdError):       # the parameter bytes must be the functor object
+        fd.JitF(TRIDIAG_NL, "TridiagNL", 10, 10, params=b"\x00" * 3)
