@@ -198,7 +198,7 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     FD_HIP_CHECK(hipSetDevice(ctx->device));
     t_log.clear();
     const char *real = elem_bytes == 8 ? "double" : "float";
-    std::string src = "#include <hip/hip_runtime.h>\n";
+    std::string src;      // (hiprtc declares the HIP runtime itself: no include)
     src += kDeviceHeader;
     src += "\ntypedef ";
     src += real;

@@ -8,9 +8,13 @@
 // never by copying the arrays or by a sampled hash.
 //
 // A plan created with FD_PLAN_FINGERPRINT records one 64-bit fingerprint per array it was compiled from:
-//     F(a) = sum_i mix64(value_i + i * K)   (mod 2^64; value_i = a[i0 + i] - index base, widened to 64 bits)
+//     F(a) = sum_k mix(value_2k + (value_2k+1 << 32) + k * K)   (mod 2^64; value_i = a[i0 + i] - index base, widened to 64 bits;
+//                                                                a missing last partner counts as 0x7fffffff)
+//     mix(z) = (z ^ (z >> 29)) * C, then ^ (>> 32)
 // -- commutative, so blocks / threads add their partial sums in any order and the result is deterministic; position-dependent,
-// so permuted or shifted contents differ.  fd_plan_matches recomputes the fingerprints of the caller's current arrays over
+// so permuted or shifted contents differ; a function of the VALUES, not of the index width.  (Round 4 mixed every element with
+// three 64-bit multiplications: the comparison of a 200 MB pattern was bound by the integer multiplier, 100 us; one multiplication
+// per PAIR leaves it to the memory system.)  fd_plan_matches recomputes the fingerprints of the caller's current arrays over
 // the same ranges (the plan's column window for colptr / rowval) and compares.
 #include "fdjac_internal.h"
 
@@ -22,25 +26,45 @@
 
 namespace {
 
-__host__ __device__ inline uint64_t fp_mix(uint64_t z)
+constexpr uint64_t kFpK = 0xD6E8FEB86659FD93ull;      // odd: k -> k * K is a bijection mod 2^64
+__host__ __device__ inline uint64_t fp_pair(int64_t v0, int64_t v1, uint64_t kK)      // kK = k * K (advanced incrementally)
 {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    uint64_t z = (uint64_t)v0 + ((uint64_t)v1 << 32) + kK;
+    z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 32);
 }
-__host__ __device__ inline uint64_t fp_term(int64_t v, int64_t i)
+// the pairs [k0, k0 + stride, ...) below npairs = ceil(n / 2) of the range a[i0 .. i0 + n), values minus `base`
+template <typename IT> __host__ __device__ inline uint64_t fp_pairs(const IT *__restrict__ a, long long i0, long long n, long long base, long long k0, long long stride)
 {
-    return fp_mix((uint64_t)v + (uint64_t)i * 0xD6E8FEB86659FD93ull);
+    const long long npairs = (n + 1) / 2;
+    uint64_t s = 0, kK = (uint64_t)k0 * kFpK;
+    const uint64_t dK = (uint64_t)stride * kFpK;
+    long long k = k0;
+    for (; k + 3 * stride < npairs; k += 4 * stride) {       // four pairs' loads in flight
+        int64_t v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = 2 * (k + u * stride);
+            v0[u] = (int64_t)a[i0 + i];
+            v1[u] = i + 1 < n ? (int64_t)a[i0 + i + 1] : (int64_t)0x7fffffff + base;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += fp_pair(v0[u] - base, v1[u] - base, kK); kK += dK; }
+    }
+    for (; k < npairs; k += stride) {
+        const long long i = 2 * k;
+        const int64_t v0 = (int64_t)a[i0 + i], v1 = i + 1 < n ? (int64_t)a[i0 + i + 1] : (int64_t)0x7fffffff + base;
+        s += fp_pair(v0 - base, v1 - base, kK);
+        kK += dK;
+    }
+    return s;
 }
 
 // one wave reads 64 consecutive elements per step; grid-stride over the array; one atomic per workgroup
 template <typename IT> __global__ void __launch_bounds__(256) k_fingerprint(const IT *__restrict__ a, int64_t i0, int64_t n, int64_t base,
                                                                               unsigned long long *__restrict__ out)
 {
-    uint64_t s = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        s += fp_term((int64_t)a[i0 + i] - base, i);
+    uint64_t s = fp_pairs<IT>(a, i0, n, base, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
     __shared__ uint64_t s_w[4];
@@ -63,15 +87,9 @@ __global__ void __launch_bounds__(256) k_fingerprint3_check(Fp3 f, unsigned long
 {
     int k = 0, b = (int)blockIdx.x;
     if (b >= f.g[0]) { b -= f.g[0]; k = 1; if (b >= f.g[1]) { b -= f.g[1]; k = 2; } }
-    uint64_t s = 0;
-    const long long n = f.n[k], stride = (long long)f.g[k] * 256;
-    if (f.bytes[k] == 8) {
-        const int64_t *a = (const int64_t *)f.a[k];
-        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += stride) s += fp_term((int64_t)a[f.i0[k] + i] - f.base[k], i);
-    } else {
-        const int32_t *a = (const int32_t *)f.a[k];
-        for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += stride) s += fp_term((int64_t)a[f.i0[k] + i] - f.base[k], i);
-    }
+    const long long n = f.n[k], stride = (long long)f.g[k] * 256, k0 = (long long)b * 256 + threadIdx.x;
+    uint64_t s = f.bytes[k] == 8 ? fp_pairs<int64_t>((const int64_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride)
+                                 : fp_pairs<int32_t>((const int32_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
     __shared__ uint64_t s_w[4];
@@ -95,34 +113,41 @@ __global__ void __launch_bounds__(256) k_fingerprint3_check(Fp3 f, unsigned long
     }
 }
 
-template <typename IT> uint64_t host_range(const IT *a, int64_t i0, int64_t lo, int64_t hi, int64_t base)
+// the pairs [klo, khi) of the range (host threads split the PAIRS)
+template <typename IT> uint64_t host_range(const IT *a, int64_t i0, int64_t n, int64_t klo, int64_t khi, int64_t base)
 {
-    uint64_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += fp_term((int64_t)a[i0 + i] - base, i);
+    uint64_t s = 0, kK = (uint64_t)klo * kFpK;
+    for (int64_t k = klo; k < khi; ++k) {
+        const int64_t i = 2 * k;
+        const int64_t v0 = (int64_t)a[i0 + i], v1 = i + 1 < n ? (int64_t)a[i0 + i + 1] : (int64_t)0x7fffffff + base;
+        s += fp_pair(v0 - base, v1 - base, kK);
+        kK += kFpK;
+    }
     return s;
 }
 
 uint64_t host_fingerprint(const void *a, int bytes, int64_t i0, int64_t n, int64_t base)
 {
+    const int64_t np = (n + 1) / 2;      // pairs
     auto range = [&](int64_t lo, int64_t hi) {
-        return bytes == 8 ? host_range((const int64_t *)a, i0, lo, hi, base) : host_range((const int32_t *)a, i0, lo, hi, base);
+        return bytes == 8 ? host_range((const int64_t *)a, i0, n, lo, hi, base) : host_range((const int32_t *)a, i0, n, lo, hi, base);
     };
     unsigned hw = std::thread::hardware_concurrency();
-    const int64_t nthr = std::min<int64_t>({(int64_t)std::max(1u, hw), (int64_t)32, n >> 18});   // >= 2^18 elements per thread
-    if (nthr <= 1) return range(0, n);
+    const int64_t nthr = std::min<int64_t>({(int64_t)std::max(1u, hw), (int64_t)32, np >> 17});   // >= 2^18 elements per thread
+    if (nthr <= 1) return range(0, np);
     std::vector<uint64_t> part((size_t)nthr, 0);
     std::vector<std::thread> th;
-    const int64_t per = (n + nthr - 1) / nthr;
+    const int64_t per = (np + nthr - 1) / nthr;
     int64_t done_to = 0;
     try {
         for (int64_t k = 0; k < nthr; ++k) {
-            const int64_t lo = k * per, hi = std::min(n, lo + per);
+            const int64_t lo = k * per, hi = std::min(np, lo + per);
             if (lo < hi) th.emplace_back([&part, &range, k, lo, hi] { part[(size_t)k] = range(lo, hi); });
             done_to = hi;
         }
     } catch (...) {
     }
-    uint64_t s = done_to < n ? range(done_to, n) : 0;      // (a thread could not be started: the rest runs here)
+    uint64_t s = done_to < np ? range(done_to, np) : 0;      // (a thread could not be started: the rest runs here)
     for (auto &t : th) t.join();
     for (uint64_t v : part) s += v;
     return s;
@@ -167,7 +192,7 @@ extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a,
     int total = 0;
     for (int k = 0; k < 3; ++k) {
         f.a[k] = a[k]; f.bytes[k] = bytes[k]; f.i0[k] = i0[k]; f.n[k] = (a[k] && n[k] > 0) ? n[k] : 0; f.base[k] = base[k];
-        f.g[k] = f.n[k] > 0 ? (int)std::min<int64_t>((f.n[k] + 2047) / 2048, (int64_t)ctx->num_cus * 4) : 0;     // (>= 8 elements per thread)
+        f.g[k] = f.n[k] > 0 ? (int)std::min<int64_t>((f.n[k] + 2047) / 2048, (int64_t)ctx->num_cus * 8) : 0;     // (>= 8 elements per thread)
         total += f.g[k];
     }
     if (total == 0) return FD_OK;
