@@ -435,8 +435,13 @@ class TridiagSolver:
         _l.check(self.Lt.fd_tridiag_solve_async(self.handle, float(alpha), float(beta), self._jptrs(J), self._vec(b, "b"),
                                                 self._vec(y, "y"), comm.handle if comm is not None else None))
 
+    def set_policy(self, trust_non_dominant):
+        """fd_tridiag_solver_set_policy: False (default) = a solve that meets a row without diagonal dominance writes NaN instead of a
+        solution the pivot-free elimination cannot vouch for; True = the result anyway (the status flag is raised either way)."""
+        _l.check(self.Lt.fd_tridiag_solver_set_policy(self.handle, 1 if trust_non_dominant else 0))
+
     def status(self):
-        """fd_tridiag_solver_status: bit 0 = the last solve met a row that is not diagonally dominant (no pivoting: result not guaranteed)."""
+        """fd_tridiag_solver_status: bit 0 = the last solve met a row that is not diagonally dominant (no pivoting: y is NaN unless trusted)."""
         v = C.c_int()
         _l.check(self.Lt.fd_tridiag_solver_status(self.handle, C.byref(v)))
         return v.value

@@ -33,6 +33,7 @@
 #define fd_tridiag_solver_create fd32_tridiag_solver_create
 #define fd_tridiag_solver_destroy fd32_tridiag_solver_destroy
 #define fd_tridiag_solver_status fd32_tridiag_solver_status
+#define fd_tridiag_solver_set_policy fd32_tridiag_solver_set_policy
 #define fd_tridiag_solve_async fd32_tridiag_solve_async
 #define fd_tridiag_solve_interface fd32_tridiag_solve_interface
 #define fd_tridiag_solve_finish fd32_tridiag_solve_finish
@@ -60,6 +61,7 @@ struct SrcUser {
     int64_t e0;                 // CSC: global index of the slice's first stored value
     double alpha, beta;
     int *nd_flag;               // raised when a row is not diagonally dominant (|b| < |a| + |c|): the elimination does not pivot
+    int refuse;                 // 1 (default): a solve that raised the flag writes NaN instead of its unreliable solution
     __device__ __forceinline__ void coef(int64_t i, double &a, double &b, double &c) const
     {
         const int64_t gi = g0 + i;
@@ -426,6 +428,8 @@ __global__ void __launch_bounds__(kBlock) k_tri_top(Src src, int n, double *__re
     __shared__ double A[2][kTop], B[2][kTop], Cc[2][kTop], D[2][NRHS][kTop];
     for (int i = threadIdx.x; i < n; i += kBlock) {
         const TriRow r = src.template load<NRHS>(i);
+        if constexpr (Src::kUnitRhs)       // (a system small enough to start at the top level: the dominance guard of level 0 sits here)
+            if (src.nd_flag && !(fabs(r.b) >= fabs(r.a) + fabs(r.c))) atomicOr(src.nd_flag, 1);
         A[0][i] = r.a; B[0][i] = r.b; Cc[0][i] = r.c;
 #pragma unroll
         for (int q = 0; q < NRHS; ++q) D[0][q][i] = r.d[q];
@@ -510,10 +514,12 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub(Src src, int64_t n, cons
     if (k < nc) tri_backsub_chunk(R, n, z, k, TriLdsOut{lds, row0});
     __syncthreads();
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    bool poison = false;
+    if constexpr (Src::kUnitRhs) poison = src.refuse && src.nd_flag && *src.nd_flag != 0;      // (level 0: the reduction has checked every row)
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
         const int r = j * kBlock + (int)threadIdx.x;
-        if (r < rows) y[row0 + r] = (OutT)lds[r + (r >> 3)];
+        if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[r + (r >> 3)];
     }
 }
 
@@ -533,10 +539,11 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub_csc(SrcUser src, int64_t
     if (k < nc) tri_backsub_chunk(R, n, z, k, TriLdsOut{lds, row0});
     __syncthreads();
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    const bool poison = src.refuse && src.nd_flag && *src.nd_flag != 0;
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
         const int r = j * kBlock + (int)threadIdx.x;
-        if (r < rows) y[row0 + r] = (OutT)lds[r + (r >> 3)];
+        if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[r + (r >> 3)];
     }
 }
 
@@ -664,6 +671,7 @@ struct fd_tridiag_solver {
     double *packets = nullptr;                        // kMaxRanks x kPacket (the all-gather buffer)
     double *adj = nullptr, *cpl = nullptr, *work = nullptr;
     int *status = nullptr;                            // device word: bit 0 = the last solve met a row that is not diagonally dominant
+    int refuse = 1;                                   // fd_tridiag_solver_set_policy: such a solve writes NaN (default) / its solution anyway
 };
 
 using namespace fdjac;
@@ -681,6 +689,7 @@ static SrcUser make_src(const fd_tridiag_solver *s, double alpha, double beta, c
     u.g0 = s->g0; u.n = s->n; u.N = s->N; u.e0 = s->e0;
     u.alpha = alpha; u.beta = beta;
     u.nd_flag = s->status;
+    u.refuse = s->refuse;
     return u;
 }
 
@@ -726,9 +735,10 @@ static int tri_backsub_all(fd_tridiag_solver *s, const SrcUser &u, real_t *y)
     return FD_OK;
 }
 
-__global__ void k_tri_copy_top(const double *__restrict__ sol, int n, FDJAC_REAL *__restrict__ y)
+__global__ void k_tri_copy_top(const double *__restrict__ sol, int n, FDJAC_REAL *__restrict__ y, const int *__restrict__ nd_flag, int refuse)
 {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = (FDJAC_REAL)sol[i];
+    const bool poison = refuse && nd_flag && *nd_flag != 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = poison ? (FDJAC_REAL)__builtin_nan("") : (FDJAC_REAL)sol[i];
 }
 
 extern "C" {
@@ -788,6 +798,13 @@ int fd_tridiag_solver_status(fd_tridiag_solver *s, int *flags_out)
     return FD_OK;
 }
 
+int fd_tridiag_solver_set_policy(fd_tridiag_solver *s, int trust_non_dominant)
+{
+    FD_REQUIRE(s != nullptr, FD_ERR_ARG, "solver is NULL");
+    s->refuse = trust_non_dominant ? 0 : 1;
+    return FD_OK;
+}
+
 int fd_tridiag_solver_destroy(fd_tridiag_solver *s)
 {
     if (!s) return FD_OK;
@@ -811,7 +828,7 @@ static int tri_local_solve(fd_tridiag_solver *s, double alpha, double beta, cons
     int rc = tri_reduce_all<1>(s, u);
     if (rc) return rc;
     if (s->nlev == 1) {
-        hipLaunchKernelGGL(k_tri_copy_top, dim3(1), dim3(kBlock), 0, s->ctx->stream, s->lev_sol[0], (int)s->n, (real_t *)y);
+        hipLaunchKernelGGL(k_tri_copy_top, dim3(1), dim3(kBlock), 0, s->ctx->stream, s->lev_sol[0], (int)s->n, (real_t *)y, (const int *)s->status, s->refuse);
         FD_HIP_CHECK(hipGetLastError());
         return FD_OK;
     }

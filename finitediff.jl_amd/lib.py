@@ -76,7 +76,7 @@ EXPORTS = (
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status", "fd_tridiag_solver_set_policy",
 )
 
 
@@ -92,7 +92,7 @@ TYPED = (
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
-    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status",
+    "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status", "fd_tridiag_solver_set_policy",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -244,6 +244,7 @@ def load():
     L.fd_tridiag_solver_create.argtypes = [vp, i64, i64, i64, i32, pp]
     L.fd_tridiag_solver_destroy.argtypes = [vp]
     L.fd_tridiag_solver_status.argtypes = [vp, C.POINTER(i32)]
+    L.fd_tridiag_solver_set_policy.argtypes = [vp, i32]
     L.fd_tridiag_solve_async.argtypes = [vp, dbl, dbl, pp, vp, vp, vp]
     L.fd_tridiag_solve_interface.argtypes = [vp, dbl, dbl, pp, vp, vp]
     L.fd_tridiag_solve_finish.argtypes = [vp, dbl, dbl, pp, vp, vp, i32, i32, vp]

@@ -560,9 +560,14 @@ enum fd_tridiag_layout { FD_TRI_DIAGONALS = 0, FD_TRI_CSC = 1 };
 int fd_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
                              fd_tridiag_solver **out);
 int fd_tridiag_solver_destroy(fd_tridiag_solver *solver);
-/* The elimination does not pivot (LinearAlgebra's Tridiagonal \ does).  Every solve checks the rows it fetches: *flags_out bit 0 is set
-   when the last solve met a row that is not diagonally dominant (|alpha + beta J[i,i]| < |beta J[i,i-1]| + |beta J[i,i+1]|; systems of
-   more than 512 rows per rank) -- its result is then not guaranteed.  Synchronises the context's stream. */
+/* The elimination does not pivot (LinearAlgebra's Tridiagonal \ does: test/downstream/ordinarydiffeq_tridiagonal_solve.jl:18-30).
+   Every solve checks every row it fetches: a row that is not diagonally dominant (|alpha + beta J[i,i]| < |beta J[i,i-1]| +
+   |beta J[i,i+1]|) raises bit 0 of the solver's status word, and -- the REFUSAL policy, default -- that solve writes NaN into y instead
+   of a solution it cannot vouch for: a non-dominant I - gamma J never returns silently wrong numbers (a Rosenbrock / implicit step
+   then fails as loudly as a NaN residual does, and fd_tridiag_solver_status says why).  fd_tridiag_solver_set_policy(solver, 1) turns
+   the refusal off for callers who know their matrix is fine without dominance (symmetric positive definite, M-matrices): the flag is
+   still raised, y is the elimination's result.  fd_tridiag_solver_status synchronises the context's stream. */
+int fd_tridiag_solver_set_policy(fd_tridiag_solver *solver, int trust_non_dominant);
 int fd_tridiag_solver_status(fd_tridiag_solver *solver, int *flags_out);
 /* comm == NULL: the solver's rows are the whole system.  J: 3 (diagonals) or 1 (CSC) device pointers; b, y device. */
 int fd_tridiag_solve_async(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
@@ -656,6 +661,7 @@ typedef struct fd32_tridiag_solver fd32_tridiag_solver;
 int fd32_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
                                fd32_tridiag_solver **out);
 int fd32_tridiag_solver_destroy(fd32_tridiag_solver *solver);
+int fd32_tridiag_solver_set_policy(fd32_tridiag_solver *solver, int trust_non_dominant);
 int fd32_tridiag_solver_status(fd32_tridiag_solver *solver, int *flags_out);
 int fd32_tridiag_solve_async(fd32_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
                              void *y, fd_comm *comm);

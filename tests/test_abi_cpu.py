@@ -244,15 +244,17 @@ def test_user_examples_cross_compile_against_the_public_headers_only(tmp_path):
 
 
 def _np_fingerprint(values, base=0):
-    # F(a) = sum_i mix64(value_i + i*K) mod 2^64 (csrc/fdjac_match.hip), restated with numpy uint64 arithmetic
+    # F(a) = sum_k mix(v_2k + (v_2k+1 << 32) + k*K) mod 2^64, mix(z) = (z ^ z >> 29) * C, ^ >> 32; a missing last partner = 0x7fffffff
+    # (csc/fdjac_match.hip), restated with numpy uint64 arithmetic
     with np.errstate(over="ignore"):
         v = (np.asarray(values, dtype=np.int64) - base).astype(np.uint64)
-        i = np.arange(v.size, dtype=np.uint64)
-        z = v + i * np.uint64(0xD6E8FEB86659FD93)
-        z = z + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
+        if v.size % 2:
+            v = np.concatenate([v, np.array([0x7fffffff], dtype=np.uint64)])
+        v0, v1 = v[0::2], v[1::2]
+        k = np.arange(v0.size, dtype=np.uint64)
+        z = v0 + (v1 << np.uint64(32)) + k * np.uint64(0xD6E8FEB86659FD93)
+        z = (z ^ (z >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = z ^ (z >> np.uint64(32))
         return int(np.sum(z, dtype=np.uint64))
 
 

@@ -206,6 +206,17 @@ def test_solver_flags_systems_that_are_not_diagonally_dominant():
     assert s.status() == 0
     d2 = d.clone(); d2[N // 2] = 0.5
     s.solve([dl, d2, du], b, y, alpha=0.0, beta=1.0)           # one row with |0.5| < 2
-    assert s.status() == 1
+    assert s.status() == 1 and bool(torch.isnan(y).all())      # refused: never a silently wrong solution
+    s.set_policy(True)                                         # the caller vouches for the matrix: the elimination's result
+    s.solve([dl, d2, du], b, y, alpha=0.0, beta=1.0)
+    assert s.status() == 1 and not bool(torch.isnan(y).any())
+    s.set_policy(False)
+    tiny = fd.TridiagSolver(100, "diagonals")                  # a system that starts at the top level is guarded too
+    yt = torch.empty(100, dtype=torch.float64, device="cuda")
+    dd = d[:100].clone(); dd[50] = 0.5
+    tiny.solve([dl[:99], dd, du[:99]], b[:100], yt, alpha=0.0, beta=1.0)
+    assert tiny.status() == 1 and bool(torch.isnan(yt).all())
+    tiny.solve([dl[:99], d[:100].clone(), du[:99]], b[:100], yt, alpha=1.0, beta=-0.05)
+    assert tiny.status() == 0 and not bool(torch.isnan(yt).any())
     s.solve([dl, d, du], b, y, alpha=1.0, beta=-0.05)          # the flag belongs to the LAST solve
     assert s.status() == 0
