@@ -110,7 +110,7 @@ struct LoweredScope {
     LoweredScope() { t_lowered_cx = true; }
     ~LoweredScope() { t_lowered_cx = false; }
 };
-constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_CSC;
+constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ALWAYS;
 
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {

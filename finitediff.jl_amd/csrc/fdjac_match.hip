@@ -33,9 +33,11 @@ __host__ __device__ inline uint64_t fp_pair(int64_t v0, int64_t v1, uint64_t kK)
     z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
     return z ^ (z >> 32);
 }
-// the pairs [k0, k0 + stride, ...) below npairs = ceil(n / 2) of the range a[i0 .. i0 + n), values minus `base`
-template <typename IT> __host__ __device__ inline uint64_t fp_pairs(const IT *__restrict__ a, long long i0, long long n, long long base, long long k0, long long stride)
+// the pairs [k0, k0 + stride, ...) below npairs = ceil(n / 2) of the range a[i0 .. i0 + n), values minus `base`.  VEC: the range starts
+// at an address aligned to two elements -- a pair is ONE load (8 / 16 bytes per lane, lane-consecutive) instead of two half-used ones.
+template <typename IT, bool VEC> __device__ inline uint64_t fp_pairs(const IT *__restrict__ a, long long i0, long long n, long long base, long long k0, long long stride)
 {
+    typedef IT pair_t __attribute__((ext_vector_type(2)));
     const long long npairs = (n + 1) / 2;
     uint64_t s = 0, kK = (uint64_t)k0 * kFpK;
     const uint64_t dK = (uint64_t)stride * kFpK;
@@ -45,8 +47,13 @@ template <typename IT> __host__ __device__ inline uint64_t fp_pairs(const IT *__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long i = 2 * (k + u * stride);
-            v0[u] = (int64_t)a[i0 + i];
-            v1[u] = i + 1 < n ? (int64_t)a[i0 + i + 1] : (int64_t)0x7fffffff + base;
+            if (VEC && i + 1 < n) {
+                const pair_t p = *reinterpret_cast<const pair_t *>(a + i0 + i);
+                v0[u] = (int64_t)p.x; v1[u] = (int64_t)p.y;
+            } else {
+                v0[u] = (int64_t)a[i0 + i];
+                v1[u] = i + 1 < n ? (int64_t)a[i0 + i + 1] : (int64_t)0x7fffffff + base;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { s += fp_pair(v0[u] - base, v1[u] - base, kK); kK += dK; }
@@ -59,12 +66,17 @@ template <typename IT> __host__ __device__ inline uint64_t fp_pairs(const IT *__
     }
     return s;
 }
+template <typename IT> __device__ inline uint64_t fp_pairs_any(const IT *a, long long i0, long long n, long long base, long long k0, long long stride)
+{
+    const bool vec = (((unsigned long long)(a + i0)) & (2 * sizeof(IT) - 1)) == 0;
+    return vec ? fp_pairs<IT, true>(a, i0, n, base, k0, stride) : fp_pairs<IT, false>(a, i0, n, base, k0, stride);
+}
 
 // one wave reads 64 consecutive elements per step; grid-stride over the array; one atomic per workgroup
 template <typename IT> __global__ void __launch_bounds__(256) k_fingerprint(const IT *__restrict__ a, int64_t i0, int64_t n, int64_t base,
                                                                               unsigned long long *__restrict__ out)
 {
-    uint64_t s = fp_pairs<IT>(a, i0, n, base, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+    uint64_t s = fp_pairs_any<IT>(a, i0, n, base, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
     __shared__ uint64_t s_w[4];
@@ -88,8 +100,8 @@ __global__ void __launch_bounds__(256) k_fingerprint3_check(Fp3 f, unsigned long
     int k = 0, b = (int)blockIdx.x;
     if (b >= f.g[0]) { b -= f.g[0]; k = 1; if (b >= f.g[1]) { b -= f.g[1]; k = 2; } }
     const long long n = f.n[k], stride = (long long)f.g[k] * 256, k0 = (long long)b * 256 + threadIdx.x;
-    uint64_t s = f.bytes[k] == 8 ? fp_pairs<int64_t>((const int64_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride)
-                                 : fp_pairs<int32_t>((const int32_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride);
+    uint64_t s = f.bytes[k] == 8 ? fp_pairs_any<int64_t>((const int64_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride)
+                                 : fp_pairs_any<int32_t>((const int32_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
     __shared__ uint64_t s_w[4];
@@ -190,9 +202,14 @@ extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a,
 {
     Fp3 f;
     int total = 0;
+    // about 4 workgroups per CU in ALL (every workgroup ends in an arrival ticket on one address: thousands of them queue up there),
+    // shared out between the arrays by their bytes
+    double all_bytes = 0;
+    for (int k = 0; k < 3; ++k) all_bytes += (a[k] && n[k] > 0) ? (double)n[k] * bytes[k] : 0.0;
     for (int k = 0; k < 3; ++k) {
         f.a[k] = a[k]; f.bytes[k] = bytes[k]; f.i0[k] = i0[k]; f.n[k] = (a[k] && n[k] > 0) ? n[k] : 0; f.base[k] = base[k];
-        f.g[k] = f.n[k] > 0 ? (int)std::min<int64_t>((f.n[k] + 2047) / 2048, (int64_t)ctx->num_cus * 8) : 0;     // (>= 8 elements per thread)
+        const int64_t share = f.n[k] > 0 ? (int64_t)((double)ctx->num_cus * 4 * ((double)f.n[k] * bytes[k] / all_bytes)) + 1 : 0;
+        f.g[k] = f.n[k] > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>((f.n[k] + 2047) / 2048, share)) : 0;
         total += f.g[k];
     }
     if (total == 0) return FD_OK;
