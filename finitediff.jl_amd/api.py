@@ -751,7 +751,7 @@ class Plan:
         if not diff:
             caps &= ~4
         if not (diff if store is None else store):
-            caps &= ~(8 | 16 | 32)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC and FD_LAZY_CAP_STORE_CSC_BASE
+            caps &= ~(8 | 16 | 32 | 64)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC, _BASE and _COMPLEX
         if not csc_base:
             caps &= ~32                 # (the column store takes f(x) from ONE plain evaluation instead of forming it itself)
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
@@ -1118,11 +1118,11 @@ class JacobianCache:
         self._bound.clear()
         if len(self._plans) >= 8:
             self._plans.clear()
-        want_csc = (self.lazy and isinstance(f, BuiltinF) and not self.cx and (f.lazy_caps & _l.LAZY_CAP_STORE_CSC) != 0
-                    and self.fdtype != "complex")      # (the shim: PlanOpts(...; store_csc = f can store column by column))
+        want_csc = (self.lazy and isinstance(f, (BuiltinF, JitF)) and not self.cx and (f.lazy_caps & _l.LAZY_CAP_STORE_CSC) != 0
+                    and (self.fdtype != "complex" or (f.lazy_caps & _l.LAZY_CAP_STORE_CSC_COMPLEX) != 0))      # (the shim: PlanOpts(...; store_csc = f can store column by column))
         plan = make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx, fingerprint=content,
-                         store_csc=want_csc)
-        if self.lazy and isinstance(f, BuiltinF) and not self.cx and f.lazy_fn is not None:
+                         store_csc=want_csc, store_csc_always=want_csc and isinstance(f, JitF))
+        if self.lazy and isinstance(f, (BuiltinF, JitF)) and not self.cx and f.lazy_fn is not None:
             plan.set_lazy(f)          # built-in families: f! perturbs while loading / stores the Jacobian itself (shim: install_lazy!)
         self._plans[key] = (plan, sparsity, colorvec, content)     # (the arrays are kept alive: their ids stay theirs)
         return plan

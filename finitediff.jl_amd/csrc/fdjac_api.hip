@@ -835,7 +835,9 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.ncolors = B;
             lp.pts = p->pts;
             lp.nparts = 1;
-            lp.diff = 1;
+            lp.diff = p->fdtype == FD_COMPLEX ? 0 : 1;
+            lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;      // (the complex step: imag(f(x + i eps e_j)) / eps stored -- FD_LAZY_CAP_STORE_CSC_COMPLEX)
+            lp.imag_only = lp.is_complex;
             lp.store = &sc;
             lp.store_kind = FD_STORE_CSC;
             const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);

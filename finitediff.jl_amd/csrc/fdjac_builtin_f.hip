@@ -1878,7 +1878,7 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
     if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store only
         // (a 7-point row costs less than the gather of its f(x): that family evaluates the unperturbed rows inside the storing launch)
-        *caps_out = FD_LAZY_CAP_STORE_CSC | (b->family == FD_F_LAP7 ? FD_LAZY_CAP_STORE_CSC_BASE : 0);
+        *caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_COMPLEX | (b->family == FD_F_LAP7 ? FD_LAZY_CAP_STORE_CSC_BASE : 0);
         return FD_OK;
     }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |

@@ -414,6 +414,66 @@ __global__ void __launch_bounds__(kBlock) k_f_rows(T *__restrict__ fx, const T *
     fx[(int64_t)blockIdx.y * fs + r] = f.template row<T>(r, P);
 }
 
+// ---- the complex step through the column store (FD_LAZY_CAP_STORE_CSC_COMPLEX) ----------------------------------------------------------
+// Every stored entry (r, j): row r at the complex point x + i eps_c m_c, imag / eps_c stored (src/jacobians.jl:633-635 +
+// ext/FiniteDiffSparseArraysExt.jl:38-47).  With a verified colouring the point differs from x in coordinate j only as far as row r can
+// see; otherwise the whole colour's point is formed.  The operations of the functor's row<cd> on materialised points: same bits as the
+// hand-over path (whose decompression divides imag by eps the same way).
+template <typename CT> struct CplxColourPoint {
+    const real_t *x;
+    const CT *color;
+    int c;
+    real_t e;
+    __device__ __forceinline__ cd operator()(int64_t j) const { return cd{x[j], ((int)color[j] == c) ? e : (real_t)0}; }
+};
+struct CplxColumnPoint {
+    const real_t *x;
+    int64_t j;
+    real_t e;
+    __device__ __forceinline__ cd operator()(int64_t i) const { return cd{x[i], i == j ? e : (real_t)0}; }
+};
+template <typename CT, class F>
+__global__ void __launch_bounds__(kBlock) k_csc_store_cols_cplx(F f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
+{
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_CSC_WAVE_CAP];
+    const long long nblk = (st.col_end - st.col_begin + kBlock - 1) / kBlock, blk = fd_xcd_block(blockIdx.x, nblk);
+    if (blk >= nblk) return;
+    const long long j = st.col_begin + blk * kBlock + threadIdx.x;
+    const bool in = j < st.col_end;
+    const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[j - st.col_begin + 1] : a;
+    const CT *color = (const CT *)st.color;
+    const int c = in ? (int)color[j] : 0;
+    const bool none = in && c == (int)(CT)(-1);
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    fd_csc_wave_run<real_t> run;
+    run.begin((real_t *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0));
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) run.put(q, (real_t)0);
+    if (mine) {
+        const real_t h = eps[c];
+        constexpr int U = 4;
+        for (int q0 = a; q0 < b; q0 += U) {
+            long long r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = st.rowval[q0 + u < b ? q0 + u : b - 1];
+            real_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u >= b) { v[u] = 0; continue; }
+                cd w;
+                if (st.valid_coloring) { const CplxColumnPoint X = {x, j, h}; w = f.template row<cd>(r[u], X); }
+                else { const CplxColourPoint<CT> X = {x, color, c, h}; w = f.template row<cd>(r[u], X); }
+                v[u] = w.im / h;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q0 + u < b) run.put(q0 + u, v[u]);
+        }
+    }
+    run.template flush<true>();
+}
+
 // ---- launchers --------------------------------------------------------------------------------------------------------------
 template <typename T>
 static int functor_family_launch(BuiltinF *b, void *fx, const void *x, int64_t nbatch, int64_t xs, int64_t fs, int64_t r0, int64_t r1, hipStream_t s)
@@ -434,14 +494,24 @@ static int functor_family_launch(BuiltinF *b, void *fx, const void *x, int64_t n
 template <typename CT>
 static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_t s)
 {
-    if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
+    if (!lp->store || lp->store_kind != FD_STORE_CSC) return FD_LAZY_DECLINED;
     const fd_csc_store st = *(const fd_csc_store *)lp->store;
     if (st.elem_bytes != (int)sizeof(real_t) || st.color_bytes != (int)sizeof(CT) || st.M != b->M || st.N != b->N || st.col_end <= st.col_begin ||
-        (lp->pts == 1 && !st.fx_base && b->family != FD_F_LAP7))
+        (!lp->is_complex && lp->pts == 1 && !st.fx_base && b->family != FD_F_LAP7))
         return FD_LAZY_DECLINED;
     const unsigned g = fd_xcd_grid((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
     const real_t *x = (const real_t *)lp->x, *eps = (const real_t *)lp->eps;
+    if (lp->is_complex) {       // the complex step: imag(row at x + i eps e_j) / eps, stored by this launch
+        if (b->family == FD_F_LAP7) {
+            const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2], fd_magic31((uint32_t)(b->prm[0] * b->prm[1])), fd_magic31((uint32_t)b->prm[0])};
+            hipLaunchKernelGGL((k_csc_store_cols_cplx<CT, Lap7F>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
+        } else {
+            const SparseF f = {b->d_srow, b->d_scol};
+            hipLaunchKernelGGL((k_csc_store_cols_cplx<CT, SparseF>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 4;
+    }
 #define FD_COLS(FT, fobj)                                                                                                                  \
     do {                                                                                                                                   \
         if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols<real_t, CT, 1, FT>), dim3(g), dim3(kBlock), 0, s, fobj, x, eps, c_lo, c_hi, st); \

@@ -382,8 +382,8 @@ int plan_record_fingerprint(fd_plan *p, int idx_kind, const fd_pattern_arrays *s
 // columns without colour too; forward differences take f(x) from f_in or from one plain evaluation)
 static inline bool store_csc_active(const fd_plan *p)
 {
-    return p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE_CSC) && p->store_csc_ok && p->kind == fdjac::K_CSC && p->fdtype != FD_COMPLEX &&
-           p->store_allowed;
+    return p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE_CSC) && p->store_csc_ok && p->kind == fdjac::K_CSC &&
+           (p->fdtype != FD_COMPLEX || (p->lazy_caps & FD_LAZY_CAP_STORE_CSC_COMPLEX)) && p->store_allowed;
 }
 static inline bool store_active(const fd_plan *p)
 {

@@ -42,10 +42,11 @@ template <typename IT, bool VEC> __device__ inline uint64_t fp_pairs(const IT *_
     uint64_t s = 0, kK = (uint64_t)k0 * kFpK;
     const uint64_t dK = (uint64_t)stride * kFpK;
     long long k = k0;
-    for (; k + 3 * stride < npairs; k += 4 * stride) {       // four pairs' loads in flight
-        int64_t v0[4], v1[4];
+    constexpr int U = 8;                                      // pairs (loads) in flight per thread
+    for (; k + (U - 1) * stride < npairs; k += U * stride) {
+        int64_t v0[U], v1[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const long long i = 2 * (k + u * stride);
             if (VEC && i + 1 < n) {
                 const pair_t p = *reinterpret_cast<const pair_t *>(a + i0 + i);
@@ -56,7 +57,7 @@ template <typename IT, bool VEC> __device__ inline uint64_t fp_pairs(const IT *_
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s += fp_pair(v0[u] - base, v1[u] - base, kK); kK += dK; }
+        for (int u = 0; u < U; ++u) { s += fp_pair(v0[u] - base, v1[u] - base, kK); kK += dK; }
     }
     for (; k < npairs; k += stride) {
         const long long i = 2 * k;
@@ -202,13 +203,13 @@ extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a,
 {
     Fp3 f;
     int total = 0;
-    // about 4 workgroups per CU in ALL (every workgroup ends in an arrival ticket on one address: thousands of them queue up there),
+    // about 8 workgroups per CU in ALL (every workgroup ends in an arrival ticket on one address: thousands of them queue up there),
     // shared out between the arrays by their bytes
     double all_bytes = 0;
     for (int k = 0; k < 3; ++k) all_bytes += (a[k] && n[k] > 0) ? (double)n[k] * bytes[k] : 0.0;
     for (int k = 0; k < 3; ++k) {
         f.a[k] = a[k]; f.bytes[k] = bytes[k]; f.i0[k] = i0[k]; f.n[k] = (a[k] && n[k] > 0) ? n[k] : 0; f.base[k] = base[k];
-        const int64_t share = f.n[k] > 0 ? (int64_t)((double)ctx->num_cus * 4 * ((double)f.n[k] * bytes[k] / all_bytes)) + 1 : 0;
+        const int64_t share = f.n[k] > 0 ? (int64_t)((double)ctx->num_cus * 8 * ((double)f.n[k] * bytes[k] / all_bytes)) + 1 : 0;
         f.g[k] = f.n[k] > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>((f.n[k] + 2047) / 2048, share)) : 0;
         total += f.g[k];
     }

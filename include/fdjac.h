@@ -343,6 +343,10 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* of ANY pattern column by column through the plan's compact copy of the pattern (FD_PLAN_STORE_CSC)       */
 #define FD_LAZY_CAP_STORE_CSC_BASE 32  /* ... and evaluates f(x) of the rows it needs itself: forward differences without a caller's f_in run NO */
                                   /* plain evaluation before the storing launch (fd_csc_store.fx_base is NULL then; with f_in it is f_in)        */
+#define FD_LAZY_CAP_STORE_CSC_COMPLEX 64  /* ... and serves the COMPLEX step through the column store too (fd_lazy_points.is_complex = 1 with   */
+                                  /* store_kind = FD_STORE_CSC): every stored entry's row at x + i eps e_j, imag / eps stored                   */
+                                  /* (src/jacobians.jl:623-648 + ext/FiniteDiffSparseArraysExt.jl:38-47 in one launch); without the bit a       */
+                                  /* complex-step plan hands the values over as before                                                          */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */

@@ -99,7 +99,7 @@ def test_lap7_column_store_bit_identical_and_oracle(oracle, fdtype, shape):
     x = np.random.default_rng(nx + 10 * ny + 100 * nz).random(N)
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     f = fd.BuiltinF("lap7", nx, ny, nz)
-    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_CSC | fd.lib.LAZY_CAP_STORE_CSC_BASE
+    assert f.lazy_caps == fd.lib.LAZY_CAP_STORE_CSC | fd.lib.LAZY_CAP_STORE_CSC_BASE | fd.lib.LAZY_CAP_STORE_CSC_COMPLEX
     a, b, ps, ph, calls = _run_pair(J, colors, fdtype, f, _dev(x), rowval.size)
     if fdtype == "forward":
         # FD_LAZY_CAP_STORE_CSC_BASE: no plain f(x) launch, the storing launch forms the unperturbed rows itself -- one launcher
@@ -170,6 +170,39 @@ def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, cas
     cols = P.csc_cols(colptr) - 1
     want = (1.0 + 0.125 * (((rowval - 1) + 3 * cols) & 7)) * (1.0 + 0.5 * x[cols])
     assert np.max(np.abs(a.cpu().numpy() - want)) < (5e-6 if fdtype == "forward" else 5e-8) * 10
+
+
+@pytest.mark.parametrize("family", ["sparse", "lap7"])
+def test_complex_step_column_store_bit_identical_and_oracle(oracle, family):
+    # FD_LAZY_CAP_STORE_CSC_COMPLEX: the complex step through the column store -- every stored entry's row at x + i eps e_j,
+    # imag / eps stored by the one launch (src/jacobians.jl:623-648 + ext/FiniteDiffSparseArraysExt.jl:38-47); the bits of the
+    # hand-over path (complex points materialised, imag parts decompressed), the oracle to a few ulp, C evaluations
+    if family == "sparse":
+        M = N = 30011
+        colptr, rowval = _random_pattern(M, N, 6, 50, 5)
+        f = fd.BuiltinF.sparse(M, N, colptr, rowval)
+        J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
+        colors = fd.matrix_colors(J)
+    else:
+        nx, ny, nz = 23, 11, 7
+        M = N = nx * ny * nz
+        colptr, rowval, colors = stencil7_csc(nx, ny, nz)
+        f = fd.BuiltinF("lap7", nx, ny, nz)
+        J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    x = np.random.default_rng(9).random(N) + 0.1
+    a, b, ps, ph, calls = _run_pair(J, colors, "complex", f, _dev(x), rowval.size)
+    C = int(colors.max())
+    assert ps.info(fd.lib.INFO_STORE_CSC) == rowval.size and ps.info(fd.lib.INFO_LAZY_STORE) == 1 and ph.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert ps.fcalls_last == C and ph.fcalls_last == C
+    assert not torch.isnan(a).any() and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    if family == "sparse":
+        cols = P.csc_cols(colptr) - 1
+        want = (1.0 + 0.125 * (((rowval - 1) + 3 * cols) & 7)) * (1.0 + 0.5 * x[cols])
+        assert np.max(np.abs(a.cpu().numpy() - want)) < 1e-13
+    # an INVALID colouring: the whole colour's point is formed, as the reference does -- same (meaningless) values as the hand-over path
+    bad = np.ones(N, dtype=np.int64)
+    a2, b2, ps2, _ph2, _c = _run_pair(J, bad, "complex", f, _dev(x), rowval.size)
+    assert ps2.info(fd.lib.INFO_LAZY_STORE) == 1 and torch.equal(a2.view(torch.int64), b2.view(torch.int64))
 
 
 def test_column_store_windows_chunks_uncoloured_and_invalid_colourings():
