@@ -707,11 +707,10 @@ def main():
         except Exception as e:
             placements = {"error": repr(e)}
     # ---- side measurement (single GPU, untimed): the same Jacobian through round 2's default, the HAND-OVER path
-    # (FDJAC_LAZY_STORE=0: f! writes differences, a second launch divides and decompresses) -- must give the same bits
+    # (the launcher's FD_LAZY_CAP_STORE withheld: f! writes differences, a second launch divides and decompresses) -- must give the same bits
     handover = None
     if world == 1 and lazy_store and not args.no_plain_handover:
         try:
-            os.environ["FDJAC_LAZY_STORE"] = "0"
             if cfg == "c5":
                 plan_s = fd.make_plan(Jbb, Jbb, colors, fdtype, ctx=ctx, dtype=np_dt)
             else:
@@ -719,7 +718,7 @@ def main():
                 pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
                 plan_s = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx, dtype=np_dt)
                 del cp_s, rv_s, pat_s
-            plan_s.set_lazy(f)
+            plan_s.set_lazy(f, store=False)          # (FD_LAZY_CAP_STORE withheld: the launcher hands differences over)
             out_s = torch.full_like(out, float("nan"))
             enq_s = plan_s.bind(f, x, [out_s])
             for _ in range(3):
@@ -736,7 +735,7 @@ def main():
             torch.cuda.synchronize()
             tot_s = plan_s.timing_samples("total")
             plan_s.enable_timing(0)
-            handover = {"what": "FDJAC_LAZY_STORE=0 (round 2's default): eps pass + lazy f! handing over differences (c5: imaginary parts) + "
+            handover = {"what": "FD_LAZY_CAP_STORE withheld (round 2's default): eps pass + lazy f! handing over differences (c5: imaginary parts) + "
                                 "a second launch dividing and decompressing (k_decompress_window / k_decompress_colrange_wg)",
                         "median_ms_per_step": float(np.median(tot_s)) if tot_s else None,
                         "stages_ms": {k: (v["ms_sum"] / max(v["launches"], 1)) for k, v in ts_all.items()},
@@ -744,8 +743,6 @@ def main():
             del out_s, plan_s, enq_s
         except Exception as e:
             handover = {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            os.environ.pop("FDJAC_LAZY_STORE", None)
     # ---- side measurement (single GPU, untimed): the OPAQUE-f! call -- what an unmodified f!(fx, x) closure gets (the shim's
     # `device_f`): no lazy launcher, so the library materialises the perturbed points (ONE launch for all colours), f! runs on
     # them as one batched launch (+ f(x)), and k_decompress_window forms (fx1 - fx) / eps and decompresses, reading fx / fx1

@@ -144,7 +144,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->scratch_bytes = opts->scratch_bytes > 0 ? opts->scratch_bytes : ((int64_t)64 << 30);
     // test / tuning switches select between bit-identical kernel variants; they are read HERE, once per plan, so a
     // process can build plans of both variants side by side and fd_plan_info reports which one a plan uses
-    auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+    auto env_int = [](const char *name, int dflt) { const char *v = fdjac::test_switch(name); return (v && *v) ? atoi(v) : dflt; };
     p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
     // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
@@ -224,7 +224,7 @@ static int alloc_scratch(fd_plan *p, const std::vector<int32_t> &col0)
         if (p->C <= kRegColors) {
             // cyclic colours (mod1(j, C) and its rotations): the reduction computes them instead of reading them
             if (!p->built_on_device) {   // (the device builder ran the same test with wave ballots)
-                const char *fc = getenv("FDJAC_EPS_CYCLIC");
+                const char *fc = fdjac::test_switch("FDJAC_EPS_CYCLIC");
                 bool cyc = !(fc && *fc && atoi(fc) == 0) && p->N >= 1 && col0[0] >= 0;
                 const int32_t sh = cyc ? col0[0] : 0;
                 for (int64_t j = 0; j < p->N && cyc; ++j) cyc = col0[(size_t)j] == (int32_t)((j + sh) % p->C);

@@ -100,11 +100,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     real_t c0, xm1, xp1, xm2, xp2, ym1, yp1, ym2, yp2, zm1, zp1, zm2, zp2, xmym, xpym, xmyp, xpyp, xmzm, xpzm, xmzp, xpzp, ymzm, ypzm, ymzp, ypzp;
     // forward differences: f(x) of the seven rows, fetched with the window
     real_t bz0 = 0, by0 = 0, bx0 = 0, bc = 0, bx1 = 0, by1 = 0, bz1 = 0;
-#ifdef LAP7_NOX
-#define FD_LDX(p, off) ((real_t)(k + (off)) * (real_t)1e-7)
-#else
 #define FD_LDX(p, off) (*(const real_t *)((const char *)((p) + (off)) + kb))
-#endif
     if (wave_fast) {
         c0 = FD_LDX(x, 0);
         xm1 = FD_LDX(x, -1); xp1 = FD_LDX(x, 1); xm2 = FD_LDX(x, -2); xp2 = FD_LDX(x, 2);
@@ -130,11 +126,7 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         auto ld = [&](const real_t *p, int dl, int dj, int di) -> real_t {
             const bool ok = deep || ((unsigned)(i + di) < (unsigned)nx && (unsigned)(j + dj) < (unsigned)ny && (unsigned)(l + dl) < (unsigned)nz);
             const int off = ok ? dl * pl + dj * nx + di : 0;
-#ifdef LAP7_NOX
-            const real_t v = (real_t)(k + off) * (real_t)1e-7;
-#else
             const real_t v = p[k + off];
-#endif
             return ok ? v : (real_t)0;
         };
         c0 = ld(x, 0, 0, 0);
@@ -175,7 +167,6 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     bool okp = regular && npos == cnt;
     const unsigned long long note0 = st.note ? st.note[0] : 0, key = lap7_note_key(f, st);
     const bool verified = note0 == key;                    // (key ^ 2: checked before, NOT the stencil -- nothing left to count)
-#ifndef LAP7_NOROWVAL
     if (!verified) {
         int rv7[7];
 #pragma unroll
@@ -184,7 +175,6 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
         for (int t = 0; t < 7; ++t) okp = okp && (!ex[t] || rv7[t] == (int)k + off7[t]);
         if (st.note && note0 != (key ^ 2ull) && __any(in && !okp) && (threadIdx.x & 63) == 0) atomicAdd(&st.note[1], 1ull);
     }
-#endif
     if (none && c_lo == 0)
         for (int q = a; q < b; ++q) run.put(q, (real_t)0);
     if (mine) {                     // (all lanes meet again at the flush below: the staged values leave in one wave-wide pass)
@@ -249,9 +239,6 @@ k_f_lap7_store_cols(Lap7F f, const real_t *__restrict__ x, const real_t *__restr
     }
 #undef Z
     }
-#ifdef LAP7_NOSTORE
-    if (st.M < 0)
-#endif
     run.template flush<true>();
 }
 
@@ -519,11 +506,7 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
     } while (0)
     if (b->family == FD_F_LAP7) {
         const Lap7F f = {(int)b->prm[0], (int)b->prm[1], (int)b->prm[2], fd_magic31((uint32_t)(b->prm[0] * b->prm[1])), fd_magic31((uint32_t)b->prm[0])};
-#ifdef LAP7_GENERIC
-        if (false) {
-#else
         if (st.valid_coloring) {      // the neighbourhood in registers (one perturbed coordinate per column)
-#endif
             if (lp->pts == 2) hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 1>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
             else hipLaunchKernelGGL((k_f_lap7_store_cols<CT, 0>), dim3(g), dim3(kBlock), 0, s, f, x, eps, c_lo, c_hi, st);
             // (every launch visits all local columns: one that counted no mismatch has verified the pattern)

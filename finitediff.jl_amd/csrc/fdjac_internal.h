@@ -65,6 +65,7 @@
 
 #include <time.h>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
@@ -193,6 +194,21 @@ template <typename T> __device__ __forceinline__ T eps_rule(double t, double rel
     T e = (a > (T)absstep) ? a : (T)absstep;
     if (is_forward) e = e * (T)dir;
     return e;
+}
+
+// TEST SWITCHES.  A handful of FDJAC_* environment variables select between bit-identical kernel variants / plan builders so that the
+// tests can run both sides of every "same bits" claim (tests/test_gpu_parity.py, test_gpu_planbuild.py, ...):
+//   FDJAC_SMALL (fused single-workgroup launches of small problems), FDJAC_LAZY_DIFF / FDJAC_LAZY_STORE (hand-over forms of the lazy
+//   launchers), FDJAC_EPS_NT / FDJAC_EPS_CYCLIC (step-size reduction's load form / computed colours), FDJAC_BAND_DESC (computed tile
+//   descriptors), FDJAC_PLAN_DEVICE (host vs device plan builder), FDJAC_WINDOW / FDJAC_WINDOW2D / FDJAC_SORTED / FDJAC_WIN_TILE /
+//   FDJAC_WIN_PERIODIC / FDJAC_TILE_ORDER / FDJAC_FX_LDS (which decompression kernel a hand-over plan compiles to).
+// They are read through this ONE function, and only in a process that opted in with FDJAC_TEST_SWITCHES=1 (tests/conftest.py sets it):
+// a production process ignores them altogether -- there every choice is the plan builder's.  (Operational variables are not gated:
+// FDJAC_RCCL_LIB, FDJAC_HIPRTC_LIB, FDJAC_P2P_TIMEOUT_MS, FDJAC_PLAN_THREADS, FDJAC_PLAN_TIMING.)
+inline const char *test_switch(const char *name)
+{
+    static const bool on = [] { const char *v = getenv("FDJAC_TEST_SWITCHES"); return v && *v && atoi(v) != 0; }();
+    return on ? getenv(name) : nullptr;
 }
 
 struct TimedSpan {

@@ -203,8 +203,8 @@ int fd_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd_jvp_pla
     fd_jvp_plan *p = new (std::nothrow) fd_jvp_plan();
     FD_REQUIRE(p, FD_ERR_NOMEM, "out of host memory");
     p->ctx = ctx; p->fdtype = fdtype; p->M = M; p->N = N;
-    { const char *e = getenv("FDJAC_SMALL"); p->small_ok = !(e && *e && atoi(e) == 0); }
-    { const char *e = getenv("FDJAC_LAZY_DIFF"); p->lazy_diff = !(e && *e && atoi(e) == 0); }
+    { const char *e = fdjac::test_switch("FDJAC_SMALL"); p->small_ok = !(e && *e && atoi(e) == 0); }
+    { const char *e = fdjac::test_switch("FDJAC_LAZY_DIFF"); p->lazy_diff = !(e && *e && atoi(e) == 0); }
     p->ldx = (N + 31) / 32 * 32; p->ldf = (M + 31) / 32 * 32;
     p->nparts = balanced_grid((N + kBlock - 1) / kBlock, (int64_t)ctx->num_cus * 8);
     const int pts = fdtype == FD_CENTRAL ? 2 : 1;

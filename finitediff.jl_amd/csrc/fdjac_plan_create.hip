@@ -29,7 +29,7 @@ static int csc_common(fd_ctx *ctx, int kind, int64_t M, int64_t N, const void *c
     // host loops below (the checker: tests compare both builds bit for bit); patterns the device builder declines
     // (scattered stencils, many colours) fall through to them as well.
     {
-        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const char *pd = fdjac::test_switch("FDJAC_PLAN_DEVICE");
         const int want = (pd && *pd) ? atoi(pd) : -1;      // -1 auto (>= 2^17 entries), 0 never, 1 whenever possible
         // (device_declined: fd_plan_create_csc_device already ran the device builder on this pattern and it declined)
         if (kind == K_CSC && want != 0 && !device_declined && (want == 1 || e1 - e0 >= ((int64_t)1 << 17))) {
@@ -244,7 +244,7 @@ static int csc_device_impl(fd_ctx *ctx, int64_t M, int64_t N, const void *colptr
     if (!(cp[0] >= 0 && cp[1] >= cp[0])) { set_error("colptr is not monotone"); fd_plan_destroy(p); *out = nullptr; return FD_ERR_SHAPE; }
     p->entry_begin = cp[0];
     int brc = FD_OK;
-    const char *pd = getenv("FDJAC_PLAN_DEVICE");
+    const char *pd = fdjac::test_switch("FDJAC_PLAN_DEVICE");
     int res = (pd && *pd && atoi(pd) == 0) ? (int)PBR_DECLINED
                                            : device_build_csc(p, colptr_dev, rowval_dev, idx_bytes, idx_base, colorvec_dev, color_bytes, cp[0], cp[1], &brc);
     (void)hipStreamSynchronize(ctx->stream);
@@ -423,7 +423,7 @@ static int tridiagonal_impl(fd_ctx *ctx, int64_t N, const void *colorvec, int co
     std::vector<int32_t> col0;
     {
         // large problems: the colours are converted and tested on the device (FDJAC_PLAN_DEVICE=0: host loops, the checker)
-        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const char *pd = fdjac::test_switch("FDJAC_PLAN_DEVICE");
         const int want = (pd && *pd) ? atoi(pd) : -1;
         int res = PBR_DECLINED;
         if (want != 0 && (want == 1 || N >= ((int64_t)1 << 17)) && colorvec && (color_bytes == 4 || color_bytes == 8))
@@ -440,7 +440,7 @@ static int tridiagonal_impl(fd_ctx *ctx, int64_t N, const void *colorvec, int co
     {
         // row-window variant: few colours (every loaded f! value is used when C == 3), an even first column (16-B
         // aligned pairs); otherwise the gather kernel.  FDJAC_WINDOW=0 forces the gather kernel.
-        const char *fw = getenv("FDJAC_WINDOW");
+        const char *fw = fdjac::test_switch("FDJAC_WINDOW");
         p->tri_window = !(fw && *fw && atoi(fw) == 0) && p->C <= 4 && (p->col0 % 2) == 0 && p->col1 > p->col0;
     }
     FD_TRY(alloc_scratch(p, col0));
@@ -470,7 +470,7 @@ static int banded_impl(fd_ctx *ctx, int64_t M, int64_t N, int64_t l, int64_t u, 
     {
         // large narrow bands are compiled on the device like a banded SparseMatrixCSC (fdjac_planbuild.hip, BAND tiles:
         // no index arrays at all); FDJAC_PLAN_DEVICE=0 keeps the host loops below, which are also its checker
-        const char *pd = getenv("FDJAC_PLAN_DEVICE");
+        const char *pd = fdjac::test_switch("FDJAC_PLAN_DEVICE");
         const int want = (pd && *pd) ? atoi(pd) : -1;
         const int64_t w = l + u + 1, slots = p->out_len[0];
         if (want != 0 && w <= 64 && (want == 1 ? slots > 0 : slots >= ((int64_t)1 << 17)) && colorvec && (color_bytes == 4 || color_bytes == 8)) {

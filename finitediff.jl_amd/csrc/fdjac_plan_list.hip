@@ -108,11 +108,11 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
         return w;
     };
     {
-        const char *fw = getenv("FDJAC_WINDOW"), *fs = getenv("FDJAC_SORTED");
+        const char *fw = fdjac::test_switch("FDJAC_WINDOW"), *fs = fdjac::test_switch("FDJAC_SORTED");
         const int force_w = (fw && *fw) ? atoi(fw) : -1, force_s = (fs && *fs) ? atoi(fs) : -1;
         WinBuild best;
         if (force_w != 0 && force_s != 1) {
-            const char *ft = getenv("FDJAC_WIN_TILE");   // test / tuning switch: force the tile size (2048, 1024 or 512)
+            const char *ft = fdjac::test_switch("FDJAC_WIN_TILE");   // test / tuning switch: force the tile size (2048, 1024 or 512)
             const int force_t = (ft && *ft) ? atoi(ft) : 0;
             // fewer than ~24 tiles of 2048 entries per CU: the half-size tile balances the launch better (tridiagonal
             // forward, same process: N = 10^6 14.6 -> 13.5 us, N = 3*10^6 30.7 -> 30.0 us, N = 10^7 equal)
@@ -142,7 +142,7 @@ static int try_window_plan(fd_plan *p, const std::vector<int32_t> &rows, const s
             // where that holds throughout are flagged; the kernel reads only their first kWinPeriodMax codes and
             // computes the rest -- 2 B of index traffic per stored entry less (tridiagonal: 60 of 620 MB).
             {
-                const char *fp = getenv("FDJAC_WIN_PERIODIC");
+                const char *fp = fdjac::test_switch("FDJAC_WIN_PERIODIC");
                 const size_t T = (size_t)best.T, ntiles = padded / T;
                 int P = 0, S = 0;
                 if (!(fp && *fp && atoi(fp) == 0) && ntiles >= 3) {
@@ -222,7 +222,7 @@ static int try_window2d_plan(fd_plan *p, const std::vector<int32_t> &rows, const
                              const std::vector<int64_t> &colstart)
 {
     int rc;
-    const char *fw = getenv("FDJAC_WINDOW2D");
+    const char *fw = fdjac::test_switch("FDJAC_WINDOW2D");
     if (fw && *fw && atoi(fw) == 0) return FD_OK;
     const int64_t ncols = (int64_t)colstart.size() - 1;
     if (ncols < 1024 || p->nnz_local < 8192) return FD_OK;
@@ -645,7 +645,7 @@ static void store_caps_implicit_band(fd_plan *p, int64_t l, int64_t u)
 static std::vector<int32_t> far_band_tile_order(const fd_plan *p, const std::vector<int64_t> &tcol, int64_t reach, int64_t ncols, size_t ntiles)
 {
     std::vector<int32_t> order;
-    const char *to = getenv("FDJAC_TILE_ORDER");
+    const char *to = fdjac::test_switch("FDJAC_TILE_ORDER");
     const int want = (to && *to) ? atoi(to) : 1;
     if (want == 0 || ntiles < (want == 2 ? 16u : 256u)) return order;
     const int64_t D = reach;
@@ -709,7 +709,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
 
     tm.mark("list: rows, padding, coherence");
     if (!has_dest && p->nnz_local > 0) {
-        const char *fw1 = getenv("FDJAC_WINDOW"), *fs1 = getenv("FDJAC_SORTED");
+        const char *fw1 = fdjac::test_switch("FDJAC_WINDOW"), *fs1 = fdjac::test_switch("FDJAC_SORTED");
         const bool win_allowed = !(fw1 && *fw1 && atoi(fw1) == 0) && !(fs1 && *fs1 && atoi(fs1) == 1);
         // a scattered storage order whose tiles still form ONE tight row window each (2-D stencils on narrow grids) is
         // served by the 1-D tiles -- the order in which the device builder decides, too; then 2-D (strided) tiles; then
@@ -725,7 +725,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
             rows.clear();
             nzc.clear();
         } else {
-            const char *fs = getenv("FDJAC_SORTED");
+            const char *fs = fdjac::test_switch("FDJAC_SORTED");
             p->sorted_gather = scattered;
             if (fs && *fs) p->sorted_gather = atoi(fs) != 0 && p->nnz_local >= 4 * kSortTile;
         }
@@ -770,7 +770,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         tm.mark("list: upload positions");
         // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
         {
-            const char *fl = getenv("FDJAC_FX_LDS");
+            const char *fl = fdjac::test_switch("FDJAC_FX_LDS");
             if (p->fdtype == FD_FORWARD && !(fl && *fl && atoi(fl) == 0)) {
                 std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0);
                 std::atomic<size_t> eligible{0};

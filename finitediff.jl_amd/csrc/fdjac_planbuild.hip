@@ -858,7 +858,7 @@ static int device_build_2d(fd_plan *p, const void *d_colptr, const void *d_rowva
     *host_too = false;
     auto no2d = [&]() { *host_too = true; return (int)PBR_DECLINED; };
     hipStream_t s = p->ctx->stream;
-    const char *fw = getenv("FDJAC_WINDOW2D");
+    const char *fw = fdjac::test_switch("FDJAC_WINDOW2D");
     if (fw && *fw && atoi(fw) == 0) return no2d();
     const int64_t ncols = p->col1 - p->col0;
     if (ncols < 1024 || nloc < 8192 || nloc < 4 * kSortTile) return no2d();
@@ -1018,7 +1018,7 @@ static int device_colors_only(fd_plan *p, const void *colorvec, int color_bytes)
     p->C = C;
     p->color8 = true;
     p->d_color = d_color8;
-    const char *fc = getenv("FDJAC_EPS_CYCLIC");
+    const char *fc = fdjac::test_switch("FDJAC_EPS_CYCLIC");
     const bool cyc = !(h.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX;
     p->cyc_C = cyc ? (int)C : 0;
     p->cyc_shift = cyc ? shift : 0;
@@ -1064,7 +1064,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     *rc_out = FD_OK;
     hipStream_t s = p->ctx->stream;
     const int64_t N = p->N, nloc = e1 - e0;
-    const char *fw = getenv("FDJAC_WINDOW"), *fso = getenv("FDJAC_SORTED");
+    const char *fw = fdjac::test_switch("FDJAC_WINDOW"), *fso = fdjac::test_switch("FDJAC_SORTED");
     if ((fw && *fw && atoi(fw) == 0) || (fso && *fso && atoi(fso) == 1)) return PBR_DECLINED;   // forced gather kernels
     if (nloc <= 0 || N >= ((int64_t)1 << 31)) return PBR_DECLINED;
     PbTemps tmp;
@@ -1096,7 +1096,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     const size_t padded = (size_t)((std::max<int64_t>(nloc, 1) + kListPad - 1) / kListPad * kListPad);
     // tile size: the host builder's rule (try_window_plan).  Every candidate is ONE fused pass (expand + extent + codes);
     // the statistics the rule needs are computed on the host from the descriptors (48 B per tile).
-    const char *ft = getenv("FDJAC_WIN_TILE");
+    const char *ft = fdjac::test_switch("FDJAC_WIN_TILE");
     const int force_t = (ft && *ft) ? atoi(ft) : 0;
     const int force_w = (fw && *fw) ? atoi(fw) : -1;
     const bool prefer_small = sizeof(real_t) >= 8;   // (the host builder's rule, try_window_plan)
@@ -1183,7 +1183,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
         p->nnz_local = nloc;
         p->row0 = r0;
         p->row1 = r1;
-        const char *fc = getenv("FDJAC_EPS_CYCLIC");
+        const char *fc = fdjac::test_switch("FDJAC_EPS_CYCLIC");
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) && p->fdtype != FD_COMPLEX &&
                          C <= kRegColors;       // (computed colours are the register reduction's: alloc_scratch)
         p->cyc_C = cyc ? (int)C : 0;
@@ -1211,7 +1211,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     // periodic codes: the period is found on three sample tiles on the host (a few KB), every tile is tested on the device
     int P = 0, S = 0, magic = 0;
     {
-        const char *fp = getenv("FDJAC_WIN_PERIODIC");
+        const char *fp = fdjac::test_switch("FDJAC_WIN_PERIODIC");
         if (!(fp && *fp && atoi(fp) == 0) && ntiles >= 3) {
             std::vector<uint16_t> smp((size_t)bestT);
             for (int64_t sample : {ntiles / 2, ntiles / 4, (3 * ntiles) / 4}) {
@@ -1272,7 +1272,7 @@ static int device_build_csc(fd_plan *p, const void *d_colptr, const void *d_rowv
     p->d_wtiles = d_wt;
     p->d_wcode = d_code;
     {
-        const char *fc = getenv("FDJAC_EPS_CYCLIC");
+        const char *fc = fdjac::test_switch("FDJAC_EPS_CYCLIC");
         const bool cyc = !(fin.flags & (PB_NOT_CYCLIC | PB_NONE)) && !(fc && *fc && atoi(fc) == 0) &&
                          p->fdtype != FD_COMPLEX && C <= kRegColors;   // (the complex step has no step-size reduction; many colours: its lists)
         p->cyc_C = cyc ? (int)C : 0;

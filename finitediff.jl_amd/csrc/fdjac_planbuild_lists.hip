@@ -329,7 +329,7 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
                               const uint8_t *d_color8, int64_t C, PbTimer &tm, int *row0_out, int *row1_out, int *rc_out)
 {
     hipStream_t s = p->ctx->stream;
-    const char *fw1 = getenv("FDJAC_WINDOW");
+    const char *fw1 = fdjac::test_switch("FDJAC_WINDOW");
     if (fw1 && *fw1) return PBR_DECLINED;                             // (forced kernel variants: the host builder)
     if (nloc < 1 || p->kind != K_CSC) return PBR_DECLINED;
     const size_t padded = (size_t)((std::max<int64_t>(nloc, 1) + kListPad - 1) / kListPad * kListPad);
@@ -340,11 +340,11 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
         if (!(p->lines_direct > 0) && !pb_coherence_sample(p, d_colptr, d_rowval, ib, base, e0, nloc, d_color8)) return PBR_DECLINED;
         scattered = p->lines_direct > 16.0 && p->lines_direct > 1.5 * p->lines_sorted;
     }
-    const char *fs = getenv("FDJAC_SORTED");
+    const char *fs = fdjac::test_switch("FDJAC_SORTED");
     bool sorted = scattered;
     if (fs && *fs) sorted = atoi(fs) != 0 && nloc >= 4 * kSortTile;
     // the window tile sizes try_window_plan would try
-    const char *ft = getenv("FDJAC_WIN_TILE");
+    const char *ft = fdjac::test_switch("FDJAC_WIN_TILE");
     const int force_t = (ft && *ft) ? atoi(ft) : 0;
     int tmask = 0;
     for (int T : {2048, 1024, 512}) {
@@ -353,7 +353,7 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
         tmask |= 1 << (T == 2048 ? 0 : T == 1024 ? 1 : 2);
     }
     const bool want_fx = [&] {
-        const char *fx = getenv("FDJAC_FX_LDS");
+        const char *fx = fdjac::test_switch("FDJAC_FX_LDS");
         return sorted && p->fdtype == FD_FORWARD && !(fx && *fx && atoi(fx) == 0);
     }();
     PbTemps tmp;                                                      // (freed on every return; ownership moves to the plan at the end)

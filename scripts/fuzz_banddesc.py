@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import finitediff_jl_amd as fd

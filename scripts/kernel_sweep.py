@@ -7,6 +7,7 @@ its SURVEY 8(d) algorithmic bytes, the implied GB/s, and the other stages.  Outp
 """
 import argparse
 import os
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import sys
 
 import numpy as np

@@ -1,6 +1,7 @@
 """Decompression time of the storage-order gather (k_decompress_list) vs the colour-sorted gather (k_decompress_sorted, f(x) in LDS)
 on a random rectangular pattern (1.2e6 x 1.0e6, ~6 per column within +-3000 rows + 3 % far entries), forward differences."""
 import os, sys, time
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import finitediff_jl_amd as fd

@@ -1,5 +1,6 @@
 """Host cost of building a plan (pattern ingestion, colour lookup, tile descriptors, uploads) at BASELINE sizes."""
 import os
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import sys
 import time
 

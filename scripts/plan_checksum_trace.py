@@ -2,6 +2,7 @@
 """Which part of a plan differs between the host and the device builder?  (FDJAC_CHECKSUM_TRACE=1: running hash per array on stderr)
     python scripts/plan_checksum_trace.py band13 forward"""
 import os
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import sys
 
 import numpy as np

@@ -4,6 +4,7 @@ quoted: the BlockBandedMatrix configuration (10^4 blocks of 32 x 32, complex ste
     python scripts/plan_time_probe.py [--n 200]"""
 import argparse
 import os
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")   # (the library honours its variant switches only on request)
 import sys
 import time
 

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the library's variant switches (FDJAC_WINDOW, FDJAC_LAZY_STORE, ...) are honoured only in a process that opts in: the tests do, to run
+# both sides of every "same bits" claim (csrc/fdjac_internal.h, test_switch)
+os.environ.setdefault("FDJAC_TEST_SWITCHES", "1")
 
 
 def pytest_configure(config):
