@@ -1249,7 +1249,10 @@ __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), i);
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-template <typename CT, bool TWO>
+// QUAD (round 5; Float64, blocks of exactly 32 rows, even destinations: fd_colrange_store.pairs): a lane of phase B is a ROW PAIR of one of
+// FOUR adjacent columns -- every store is 16 bytes per lane, 256 contiguous bytes per 16 lanes, half the store instructions of the
+// two-column form; the same operations per element, so the same bits.
+template <typename CT, bool TWO, bool QUAD = false>
 __global__ void __launch_bounds__(kBcT)
 k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
                        int64_t nb, int bs, int64_t blk0, int64_t blk1, fd_colrange_store st)
@@ -1399,6 +1402,78 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     // b-1, b, b+1 in registers across the unit's columns and per column evaluates its three entries at the column's own point and
     // stores them (32 lanes = 256 contiguous bytes per row block; a column is one contiguous run).
     real_t *outp = (real_t *)st.out;
+    if constexpr (QUAD) {
+        const int cq = lane >> 4, r2 = lane & 15;                         // column of the iteration's four, row pair (2 r2, 2 r2 + 1)
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int u = wave + k * NW;
+            if (u >= 2 * kBcS) break;
+            const int lb = 2 + (u >> 1), cstart = (u & 1) * ucols, ncol = min(bs, cstart + ucols) - cstart;
+            const int64_t bcol = g0 - 2 + lb;
+            if (bcol >= blk1 || bcol >= nb || ncol <= 0) continue;
+            const int q_l = uq[k];
+            const long long dest_l = ud[k];
+            real_t xk[3][2], rzk[3][2];
+            bool mv[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int64_t kb = bcol - 1 + m;
+                mv[m] = (kb >= 0) & (kb < nb);
+                const int at = (lb - 2 + m) * RS + 2 * r2;
+                xk[m][0] = rx[at]; xk[m][1] = rx[at + 1];
+                rzk[m][0] = rz[at]; rzk[m][1] = rz[at + 1];
+            }
+            const real_t rcm[2] = {rc[(lb - 1) * RS + 2 * r2], rc[(lb - 1) * RS + 2 * r2 + 1]};
+            const int first = bcol > 0 ? 0 : 1;
+            const T *su = ssum + (size_t)(lb - 2) * B;
+            for (int it = 0; 4 * it < ncol; ++it) {
+                const int ci = 4 * it + cq;
+                const int src = ci < ncol ? ci : 0;
+                const int qs = __shfl(q_l, src, 64);
+                const unsigned dlo = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l & 0xffffffffu), src, 64);
+                const unsigned dhi = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l >> 32), src, 64);
+                const bool cv = (ci < ncol) & (qs >= 0);
+                const int q = cv ? qs : 0;
+                real_t *dst = outp + (long long)(((unsigned long long)dhi << 32) | dlo) + 2 * r2;
+                const real_t e = ce[q], ye = cy[q], sh = cs[q];
+                const int jl = cstart + ci;
+                real_t vim[3][2], qv[3][2];
+                bool fast = true;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const T S = su[(size_t)m * B + q];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool hit = (m == 1) & (2 * r2 + h == jl);
+                        const real_t xim = hit ? e : (real_t)0;
+                        const real_t snim = hit ? rcm[h] * sh : rzk[m][h];
+                        vim[m][h] = (xk[m][h] * S.im + xim * S.re) + snim;
+                        qv[m][h] = vim[m][h] * ye;
+                        const real_t mq = fabs(qv[m][h]), ma = fabs(vim[m][h]);
+                        fast = fast & (!mv[m] | ((mq >= (real_t)0x1p-900) & (mq <= (real_t)0x1p900) & (ma >= (real_t)0x1p-900) & (ma <= (real_t)0x1p900)));
+                    }
+                }
+                if (fast) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const real_t r0 = __builtin_fma(-e, qv[m][h], vim[m][h]);
+                            const real_t q1 = __builtin_fma(r0, ye, qv[m][h]);
+                            const real_t r1 = __builtin_fma(-e, q1, vim[m][h]);
+                            qv[m][h] = __builtin_fma(r1, ye, q1);
+                        }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) { qv[m][0] = vim[m][0] / e; qv[m][1] = vim[m][1] / e; }
+                }
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    if (cv & mv[m]) __builtin_nontemporal_store(r2_t{qv[m][0], qv[m][1]}, reinterpret_cast<r2_t *>(dst + (m - first) * bs));
+            }
+        }
+        return;
+    }
     const int half = TWO ? lane >> 5 : 0, r = TWO ? lane & 31 : lane;
     const bool ract = r < bs;
 #pragma unroll
@@ -1499,7 +1574,10 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
             return FD_LAZY_DECLINED;
         const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
         const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
-        if (bs <= 32)
+        if (bs == 32 && st.pairs && sizeof(real_t) == 8 && (((uintptr_t)st.out) & 15) == 0)
+            hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true, true>), dim3((unsigned)gs), dim3(kBcT), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
+                               (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
+        else if (bs <= 32)
             hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true>), dim3((unsigned)gs), dim3(kBcT), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         else
