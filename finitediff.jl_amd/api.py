@@ -152,6 +152,68 @@ class Tridiagonal:
         return n, n
 
 
+class _ThreeDiagonals(Tridiagonal):
+    """LinearAlgebra's other structured types the reference's generic loop serves (`src/jacobians.jl:524-525`,
+    `src/iteration_utils.jl:25-32`: `J[rows_index[i], cols_index[i]] = vfx[rows_index[i]]` over `findstructralnz(J)`): compiled as the
+    Tridiagonal plan -- the diagonals the type does not store are computed into scratch and dropped."""
+
+    def _scratch(self, like, n):
+        key = (n, str(getattr(like, "dtype", None)), str(getattr(like, "device", "")))
+        cache = self.__dict__.setdefault("_sc", {})
+        if key not in cache:
+            cache[key] = _similar(like, n)
+        return cache[key]
+
+    def _finish(self, colorvec):
+        pass
+
+
+class Bidiagonal(_ThreeDiagonals):
+    """LinearAlgebra.Bidiagonal(dv, ev, uplo): J[i,i] -> dv[i]; uplo = 'U': J[i,i+1] -> ev[i], 'L': J[i+1,i] -> ev[i]."""
+
+    def __init__(self, dv, ev, uplo="U"):
+        self.dv, self.ev, self.uplo = dv, ev, uplo.upper()[0]
+        self.d = dv
+        n = int(dv.shape[0])
+        sc = self._scratch(dv, max(n - 1, 1))[: n - 1]
+        self.dl, self.du = (sc, ev) if self.uplo == "U" else (ev, sc)
+
+
+class Diagonal(_ThreeDiagonals):
+    """LinearAlgebra.Diagonal(diag)."""
+
+    def __init__(self, diag):
+        self.diag = self.d = diag
+        n = int(diag.shape[0])
+        self.dl = self._scratch(diag, max(n - 1, 1))[: n - 1]
+        self.du = _similar(diag, max(n - 1, 1))[: n - 1]
+
+
+class SymTridiagonal(_ThreeDiagonals):
+    """LinearAlgebra.SymTridiagonal(dv, ev): `setindex!` sends BOTH J[i+1,i] and J[i,i+1] to ev[i].  The reference's loop runs colour by
+    colour, so what ev[i] holds afterwards is the LATER colour's write: the upper entry (column i+1) if colorvec[i+1] > colorvec[i],
+    else the lower one (column i) -- reproduced by `_finish` (both are the same number for a symmetric Jacobian, up to the error of the
+    difference quotient)."""
+
+    def __init__(self, dv, ev):
+        self.dv, self.ev = dv, ev
+        self.d = dv
+        n = int(dv.shape[0])
+        self.dl = self._scratch(dv, max(n - 1, 1))[: n - 1]
+        self.du = _similar(dv, max(n - 1, 1))[: n - 1]
+
+    def _finish(self, colorvec):
+        cv = colorvec
+        if _is_torch(self.ev):
+            import torch
+            c = cv if _is_torch(cv) else torch.as_tensor(np.asarray(cv), device=self.ev.device)
+            c = c.to(self.ev.device)
+            self.ev.copy_(torch.where(c[1:] > c[:-1], self.du, self.dl))
+        else:
+            c = np.asarray(cv)
+            self.ev[...] = np.where(c[1:] > c[:-1], self.du, self.dl)
+
+
 class BandedMatrix:
     """BandedMatrices.BandedMatrix: data is (l+u+1) x n column-major, data[u+i-j, j] = A[i,j] (0-based)."""
 
@@ -1199,6 +1261,8 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
                 cache._bound[bkey] = call
         if call is not None:
             call()
+            if isinstance(J, _ThreeDiagonals):
+                J._finish(colorvec)
             return None
     staged = None
     if not isinstance(J, (SparseMatrixCSC, DevicePatternCSC, Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
@@ -1209,6 +1273,8 @@ def finite_difference_jacobian_b(J, f, x, cache_or_fdtype="forward", returntype=
     plan.jacobian(f, x, outs, f_in=fin, relstep=relstep, absstep=absstep, dir=dir)
     if staged is not None:
         J[...] = staged
+    if isinstance(J, _ThreeDiagonals):
+        J._finish(colorvec)
     return None
 
 

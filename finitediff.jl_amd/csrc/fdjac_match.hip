@@ -49,7 +49,7 @@ template <typename IT, bool VEC> __device__ inline uint64_t fp_pairs(const IT *_
         for (int u = 0; u < U; ++u) {
             const long long i = 2 * (k + u * stride);
             if (VEC && i + 1 < n) {
-                const pair_t p = *reinterpret_cast<const pair_t *>(a + i0 + i);
+                const pair_t p = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(a + i0 + i));
                 v0[u] = (int64_t)p.x; v1[u] = (int64_t)p.y;
             } else {
                 v0[u] = (int64_t)a[i0 + i];
@@ -76,11 +76,12 @@ __device__ inline uint64_t fp_quads32(const int32_t *__restrict__ a, long long i
     uint64_t s = 0, kK = (uint64_t)(2 * q0) * kFpK;
     const uint64_t dK = (uint64_t)(2 * stride) * kFpK;
     constexpr int U = 4;
+    typedef int fp_i4 __attribute__((ext_vector_type(4)));
     long long q = q0;
     for (; q + (U - 1) * stride < nquads; q += U * stride) {
-        int4 v[U];
+        fp_i4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const int4 *>(a + i0 + 4 * (q + u * stride));
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const fp_i4 *>(a + i0 + 4 * (q + u * stride)));      // (read once: keep x / nzval in the caches)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             s += fp_pair((int64_t)v[u].x - base, (int64_t)v[u].y - base, kK) + fp_pair((int64_t)v[u].z - base, (int64_t)v[u].w - base, kK + kFpK);

@@ -136,6 +136,73 @@ def test_tridiagonal_type(oracle, fdtype, ncalls):
         _tol_ok(got.cpu().numpy(), want, em, 4.0, "Tridiagonal." + nm)
 
 
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+@pytest.mark.parametrize("kind", ["bidiag_U", "bidiag_L", "diagonal", "symtridiag"])
+def test_other_structured_types_of_the_generic_loop(oracle, kind, fdtype):
+    # Bidiagonal / Diagonal / SymTridiagonal J (src/jacobians.jl:524-525 + src/iteration_utils.jl:25-32 through their setindex!): the
+    # oracle's generic COO loop over the type's structural non-zeros; SymTridiagonal's ev[i] receives BOTH J[i+1,i] and J[i,i+1] -- the
+    # later colour's write stays (restated literally below)
+    N = 257
+    rng = np.random.default_rng(21)
+    x = rng.random(N) + 0.2
+    a, b = rng.random(N) + 0.5, rng.random(N) + 0.5
+    at, bt = _dev(a), _dev(b)
+    if kind == "bidiag_U":
+        C = 2
+        fn = lambda fx, xx: fx.copy_(at.to(xx.dtype) * xx * xx + bt.to(xx.dtype) * xx * torch.cat([xx[1:], torch.zeros_like(xx[:1])]))
+        fnp = lambda fx, xx: fx.__setitem__(slice(None), a * xx * xx + b * xx * np.concatenate([xx[1:], np.zeros(1, xx.dtype)]))
+        rows = np.concatenate([np.arange(N), np.arange(N - 1)]) + 1
+        cols = np.concatenate([np.arange(N), np.arange(1, N)]) + 1
+    elif kind == "bidiag_L":
+        C = 2
+        fn = lambda fx, xx: fx.copy_(at.to(xx.dtype) * xx * xx + bt.to(xx.dtype) * xx * torch.cat([torch.zeros_like(xx[:1]), xx[:-1]]))
+        fnp = lambda fx, xx: fx.__setitem__(slice(None), a * xx * xx + b * xx * np.concatenate([np.zeros(1, xx.dtype), xx[:-1]]))
+        rows = np.concatenate([np.arange(N), np.arange(1, N)]) + 1
+        cols = np.concatenate([np.arange(N), np.arange(N - 1)]) + 1
+    elif kind == "diagonal":
+        C = 1
+        fn = lambda fx, xx: fx.copy_(at.to(xx.dtype) * xx * xx * xx)
+        fnp = lambda fx, xx: fx.__setitem__(slice(None), a * xx * xx * xx)
+        rows = cols = np.arange(N) + 1
+    else:
+        C = 3
+        fn = fnp = None
+        colptr, rowval = P.tridiag_csc(N)
+        rows, cols = rowval, P.csc_cols(colptr)
+    colors = P.cyclic_colors(N, C)
+    order = np.lexsort((rows, cols))            # findstructralnz order: column-major
+    rows, cols = np.asarray(rows)[order], np.asarray(cols)[order]
+    f = fd.BuiltinF("tridiag_nl", N) if kind == "symtridiag" else fd.TorchF(fn, N, N)
+    of = oracle.Fixture("tridiag_nl", N) if kind == "symtridiag" else oracle.PyF(fnp, N, N)
+    ref = oracle.jacobian(fdtype, of, x, colors, kind=oracle.PAT_COO_TRIDIAG, rows_index=rows, cols_index=cols)
+    dl_w, d_w, du_w = ref["out"]
+    nan = lambda n: _dev(np.full(n, np.nan))
+    if kind.startswith("bidiag"):
+        J = fd.Bidiagonal(nan(N), nan(N - 1), kind[-1])
+        want = {"dv": d_w, "ev": du_w if kind[-1] == "U" else dl_w}
+    elif kind == "diagonal":
+        J = fd.Diagonal(nan(N))
+        want = {"diag": d_w}
+    else:
+        J = fd.SymTridiagonal(nan(N), nan(N - 1))
+        ev = np.full(N - 1, np.nan)
+        for color in range(1, C + 1):               # the reference's loop order: colour by colour, entries in storage order
+            for r, c in zip(rows, cols):
+                if colors[c - 1] == color and r != c:
+                    ev[min(r, c) - 1] = (dl_w if r > c else du_w)[min(r, c) - 1]
+        want = {"dv": d_w, "ev": ev}
+    fd.finite_difference_jacobian_b(J, f, _dev(x), fdtype, colorvec=colors)
+    em = np.min(np.abs(_oracle_eps(x, colors, fdtype)))
+    for nm, w in want.items():
+        _tol_ok(getattr(J, nm).cpu().numpy(), w, em, 8.0, kind + "." + nm)
+    # the cached form finds its plan again and gives the same bits
+    cache = fd.JacobianCache(_dev(x), fdtype, colorvec=colors, sparsity=J)
+    first = {nm: getattr(J, nm).clone() for nm in want}
+    for _ in range(2):
+        fd.finite_difference_jacobian_b(J, f, _dev(x), cache)
+    assert all(torch.equal(getattr(J, nm), first[nm]) for nm in want)
+
+
 @pytest.mark.parametrize("l,u,M,N", [(1, 1, 30, 30), (2, 1, 40, 37), (0, 3, 25, 31), (3, 0, 33, 20)])
 def test_banded(oracle, l, u, M, N):
     # test/coloring_tests.jl:90-92 plus rectangular / asymmetric bands
