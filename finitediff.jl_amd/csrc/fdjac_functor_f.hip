@@ -401,6 +401,130 @@ __global__ void __launch_bounds__(kBlock) k_f_rows(T *__restrict__ fx, const T *
     fx[(int64_t)blockIdx.y * fs + r] = f.template row<T>(r, P);
 }
 
+// ---- the sparse family's column store, ENTRY-BALANCED (round 5) ---------------------------------------------------------------------
+// fd_csc_store_cols_win gives every lane a column: the lane evaluates its column's ~6 rows one after the other, and a wavefront runs
+// as long as its longest (row lengths of a scattered pattern are Poisson-like: the max over 64 lanes is about twice the mean -- 2447
+// VALU instructions per wavefront, profiles/r05_band_store.md).  Here the workgroup's stored entries -- one contiguous run of nzval --
+// are the work items: they are counting-sorted by the length of their row in LDS (which order the entries are evaluated in changes
+// nothing: every entry is computed on its own), and lane i of round k takes sorted entry 256 k + i, so the lanes of a wavefront
+// evaluate rows of (nearly) equal length.  Everything an entry needs comes from LDS: the window of x and the rows' pattern as in
+// fd_csc_store_cols_win (SparseF::stage), the entry's column (one byte), its column's step and reciprocal.  Same operations per entry
+// as the column kernels: same bits.
+constexpr int kSpChunk = 2304;       // entries sorted at a time (9 per column on average; longer runs go in several chunks)
+static size_t sparse_sorted_lds_bytes(int64_t reach, int cap)
+{
+    return sizeof(real_t) * (size_t)(fd_csc_win_xlen(reach) + 2 * kBlock) + (size_t)kSpChunk * 3 + 72 * 4 + 64 + SparseF::stage_bytes(fd_csc_win_rlen(reach), cap) + 32;
+}
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi,
+                                                                  fd_csc_store st, int reach, int stage_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    const long long nblk = (st.col_end - st.col_begin + kBlock - 1) / kBlock, blk = fd_xcd_block(blockIdx.x, nblk);
+    if (blk >= nblk) return;
+    const long long j0 = st.col_begin + blk * kBlock, jn = j0 + kBlock < st.col_end ? j0 + kBlock : st.col_end;
+    const long long r_lo = j0 - reach > 0 ? j0 - reach : 0, r_hi = jn + reach < st.M ? jn + reach : st.M;
+    long long w0 = r_lo - reach > 0 ? r_lo - reach : 0, w1 = r_hi + reach < st.N ? r_hi + reach : st.N;
+    w0 &= ~1ll;
+    // LDS: [x window][step of every column][its reciprocal][sorted entry ids u16][entry -> column u8][histogram: 32 counts, 32 bucket
+    // cursors, the total][the functor's rows]
+    FD_LDS_PTR(real_t) s_x = (FD_LDS_PTR(real_t))sp_lds;
+    FD_LDS_PTR(real_t) s_h = s_x + fd_csc_win_xlen(reach);
+    FD_LDS_PTR(real_t) s_y = s_h + kBlock;
+    FD_LDS_PTR(uint16_t) s_sorted = (FD_LDS_PTR(uint16_t))(s_y + kBlock);
+    FD_LDS_PTR(uint8_t) s_ecol = (FD_LDS_PTR(uint8_t))(s_sorted + kSpChunk);
+    FD_LDS_PTR(int) s_hist = (FD_LDS_PTR(int))(((FD_LDS_PTR(unsigned char))(s_ecol + kSpChunk)) + ((4 - ((kSpChunk * 3) & 3)) & 3));
+    const unsigned f_off = ((unsigned)(sizeof(real_t) * (size_t)(fd_csc_win_xlen(reach) + 2 * kBlock)) + (unsigned)kSpChunk * 3u + 4u + 72u * 4u + 15u) & ~15u;
+    FD_LDS_PTR(unsigned char) s_f = (FD_LDS_PTR(unsigned char))sp_lds + f_off;
+    {   // the window of x: 16-byte pairs, every load of a batch in flight together
+        const long long nx = w1 - w0, npair = nx / 2;
+        for (long long i0 = 0; i0 < npair; i0 += 4 * kBlock) {
+            r2_t vx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + u * kBlock + threadIdx.x; if (i < npair) vx[u] = *reinterpret_cast<const r2_t *>(x + w0 + 2 * i); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + u * kBlock + threadIdx.x; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+        }
+        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
+    }
+    // this thread's column: its entries, colour, step
+    const long long j = j0 + threadIdx.x;
+    const bool in = j < st.col_end;
+    const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[j - st.col_begin + 1] : a;
+    const CT *color = (const CT *)st.color;
+    const int c = in ? (int)color[j] : 0;
+    const bool none = in && c == (int)(CT)(-1);
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    const real_t h = mine ? eps[c] : (real_t)0;
+    const real_t dv = MODE == 1 ? 2 * h : h;
+    s_h[threadIdx.x] = h;                                              // (0: the column's entries are not this launch's)
+    s_y[threadIdx.x] = mine ? (real_t)1 / dv : (real_t)0;
+    real_t *out = (real_t *)st.out;
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) out[q] = (real_t)0;
+    const auto fs = f.stage(s_f, r_lo, r_hi, w0, w1, stage_cap);     // (ends with the rows' flags; the barrier below publishes everything)
+    const int qa = st.colptr[j0 - st.col_begin], qb = st.colptr[jn - st.col_begin];
+    const real_t *base = (const real_t *)st.fx_base;
+    for (int q0 = qa; q0 < qb; q0 += kSpChunk) {
+        const int Ec = qb - q0 < kSpChunk ? qb - q0 : kSpChunk;
+        __syncthreads();                                               // (LDS of the chunk before is no longer read; the staging is complete)
+        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+        // entry -> column: every column marks its own entries of this chunk
+        for (int q = (a > q0 ? a : q0); q < b && q < q0 + Ec; ++q) s_ecol[q - q0] = (uint8_t)threadIdx.x;
+        __syncthreads();
+        // row lengths (clamped to 31) -> histogram; entries of columns that are not this launch's get no slot
+        int len[(kSpChunk + kBlock - 1) / kBlock], rr[(kSpChunk + kBlock - 1) / kBlock];
+#pragma unroll
+        for (int k = 0; k < (kSpChunk + kBlock - 1) / kBlock; ++k) {
+            const int e = k * kBlock + (int)threadIdx.x;
+            rr[k] = e < Ec ? st.rowval[q0 + e] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < (kSpChunk + kBlock - 1) / kBlock; ++k) {
+            const int e = k * kBlock + (int)threadIdx.x;
+            len[k] = -1;
+            if (e < Ec && s_h[s_ecol[e]] != (real_t)0) {
+                const int r = rr[k];
+                const bool stg = r >= r_lo && r < r_hi;
+                const int n = stg ? fs.l_row[r - r_lo + 1] - fs.l_row[r - r_lo] : f.srow[r + 1] - f.srow[r];
+                len[k] = n > 31 ? 31 : n;
+                atomicAdd((int *)(s_hist + len[k]), 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {      // exclusive prefix, LONGEST rows first (one wavefront)
+            const int idx = 31 - (int)threadIdx.x;
+            int v = (threadIdx.x < 32) ? s_hist[idx] : 0, incl = v;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+            if (threadIdx.x < 32) s_hist[32 + idx] = incl - v;          // start of the bucket
+            if (threadIdx.x == 31) s_hist[64] = incl;                   // the number of sorted entries
+        }
+        __syncthreads();
+        const int nsorted = s_hist[64];
+#pragma unroll
+        for (int k = 0; k < (kSpChunk + kBlock - 1) / kBlock; ++k) {
+            const int e = k * kBlock + (int)threadIdx.x;
+            if (len[k] >= 0) s_sorted[atomicAdd((int *)(s_hist + 32 + len[k]), 1)] = (uint16_t)e;
+        }
+        __syncthreads();
+        // the entries, in sorted order: lane i of round k takes sorted entry 256 k + i
+        for (int i = threadIdx.x; i < nsorted; i += kBlock) {
+            const int e = s_sorted[i], tc = s_ecol[e];
+            const long long r = st.rowval[q0 + e];
+            const real_t he = s_h[tc], ye = s_y[tc];
+            const long long jc = j0 + tc;
+            fd_window_column_point<real_t> X = {x, s_x, w0, w1, jc, he, 0, (jc >= w0 && jc < w1) ? (unsigned)(jc - w0) : 0xFFFFFFFFu};
+            const real_t vp = fs.template row<real_t>(r, X);
+            real_t vm;
+            if (MODE == 1) { X.minus = 1; vm = fs.template row<real_t>(r, X); }
+            else vm = base[r];
+            out[q0 + e] = fd_div_shared<real_t>(vp - vm, MODE == 1 ? 2 * he : he, ye);
+        }
+    }
+}
+
 // ---- the complex step through the column store (FD_LAZY_CAP_STORE_CSC_COMPLEX) ----------------------------------------------------------
 // Every stored entry (r, j): row r at the complex point x + i eps_c m_c, imag / eps_c stored (src/jacobians.jl:633-635 +
 // ext/FiniteDiffSparseArraysExt.jl:38-47).  With a verified colouring the point differs from x in coordinate j only as far as row r can
@@ -526,7 +650,11 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
             const int cap = (int)std::min<int64_t>((int64_t)(rows * per_row * 1.25) + 256, 16384);
             const size_t sb = SparseF::stage_bytes(rows, cap);
             const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
-            if (lds <= 64 * 1024) {
+            const size_t lds_s = sparse_sorted_lds_bytes(reach, cap);
+            if (lds_s <= 64 * 1024 && (lp->pts == 2 || st.fx_base != nullptr)) {      // the entry-balanced form (see k_f_sparse_store_sorted)
+                if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 1>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap);
+                else hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 0>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap);
+            } else if (lds <= 64 * 1024) {
                 if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 1, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
                 else hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 0, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
             } else {
