@@ -647,7 +647,7 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         if (win) {
             const int64_t rows = fd_csc_win_rlen(reach);
             const double per_row = b->M > 0 ? (double)b->prm[2] / (double)b->M : 1.0;
-            const int cap = (int)std::min<int64_t>((int64_t)(rows * per_row * 1.25) + 256, 16384);
+            const int cap = (int)std::min<int64_t>((int64_t)(rows * per_row * 1.10) + 128, 16384);      // (a window's rows hold rows x per_row entries +- a few per cent; what does not fit is read from memory)
             const size_t sb = SparseF::stage_bytes(rows, cap);
             const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
             const size_t lds_s = sparse_sorted_lds_bytes(reach, cap);
