@@ -509,17 +509,30 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, con
             if (len[k] >= 0) s_sorted[atomicAdd((int *)(s_hist + 32 + len[k]), 1)] = (uint16_t)e;
         }
         __syncthreads();
-        // the entries, in sorted order: lane i of round k takes sorted entry 256 k + i
-        for (int i = threadIdx.x; i < nsorted; i += kBlock) {
-            const int e = s_sorted[i], tc = s_ecol[e];
-            const long long r = st.rowval[q0 + e];
+        // the entries, in sorted order: lane i of round k takes sorted entry 256 k + i.  Row index and f(x) of every round are requested
+        // up front (two memory round trips in all; taken entry by entry they were two DEPENDENT round trips per entry, 12 per thread --
+        // the first form of this kernel spent most of its 21 us per workgroup there)
+        constexpr int K = (kSpChunk + kBlock - 1) / kBlock;
+        int ee[K];
+        long long rw[K];
+        real_t bv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const int i = k * kBlock + (int)threadIdx.x; ee[k] = i < nsorted ? (int)s_sorted[i] : -1; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) rw[k] = st.rowval[q0 + (ee[k] >= 0 ? ee[k] : 0)];
+#pragma unroll
+        for (int k = 0; k < K; ++k) bv[k] = (MODE == 0) ? base[rw[k]] : (real_t)0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (ee[k] < 0) continue;
+            const int e = ee[k], tc = s_ecol[e];
+            const long long r = rw[k];
             const real_t he = s_h[tc], ye = s_y[tc];
             const long long jc = j0 + tc;
             fd_window_column_point<real_t> X = {x, s_x, w0, w1, jc, he, 0, (jc >= w0 && jc < w1) ? (unsigned)(jc - w0) : 0xFFFFFFFFu};
             const real_t vp = fs.template row<real_t>(r, X);
-            real_t vm;
+            real_t vm = bv[k];
             if (MODE == 1) { X.minus = 1; vm = fs.template row<real_t>(r, X); }
-            else vm = base[r];
             out[q0 + e] = fd_div_shared<real_t>(vp - vm, MODE == 1 ? 2 * he : he, ye);
         }
     }
