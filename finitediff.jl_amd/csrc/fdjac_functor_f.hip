@@ -289,7 +289,7 @@ struct SparseF {
             const int k = a - e_lo;
             if (k >= 0 && k < e_n) {
                 const unsigned cde = l_col[k];
-                if (cde != 0xFFFFu) return w0 + (int64_t)(cde & 0x1FFFu);
+                if (cde != 0xFFFFu) return w0 + (int64_t)cde;
             }
             return scol[a];
         }
@@ -300,13 +300,14 @@ struct SparseF {
             const int a0 = st ? l_row[ri] : srow[r], a1 = st ? l_row[ri + 1] : srow[r + 1];
             T s = zero_of<T>();
             if (st && l_fast[ri]) {
-                // (the terms and their order are those of SparseF::row -- same bits; (r + 3 j) mod 8 rides in the code's top bits)
+                // (the terms and their order are those of SparseF::row -- same bits; (r + 3 j) mod 8 from the low bits alone)
+                const unsigned rw = (unsigned)((r + 3 * w0) & 7);
                 for (int a = a0; a < a1; a += 2) {
                     const bool two = a + 1 < a1;
                     const unsigned c0 = l_col[a - e_lo], c1 = l_col[(two ? a + 1 : a) - e_lo];
-                    const T v0 = X.at(c0 & 0x1FFFu), v1 = X.at(c1 & 0x1FFFu);
-                    const T t0 = ((real_t)1 + kEighth * (real_t)(int)(c0 >> 13)) * (v0 + (kQuarter * v0) * v0);
-                    const T t1 = ((real_t)1 + kEighth * (real_t)(int)(c1 >> 13)) * (v1 + (kQuarter * v1) * v1);
+                    const T v0 = X.at(c0), v1 = X.at(c1);
+                    const T t0 = ((real_t)1 + kEighth * (real_t)(int)((rw + 3 * c0) & 7)) * (v0 + (kQuarter * v0) * v0);
+                    const T t1 = ((real_t)1 + kEighth * (real_t)(int)((rw + 3 * c1) & 7)) * (v1 + (kQuarter * v1) * v1);
                     s = a == a0 ? t0 : s + t0;
                     if (two) s = s + t1;
                 }
@@ -347,7 +348,7 @@ struct SparseF {
         }
         const int e_lo = srow[r_lo], e_hi = srow[r_hi];
         const int e_n = e_hi - e_lo < cap ? e_hi - e_lo : cap;
-        const int64_t wlen = w1 - w0 < 0x1FFF ? w1 - w0 : 0x1FFF;      // (13 bits of offset; bits 13-15 of a fast row's codes: the term's weight index)
+        const int64_t wlen = w1 - w0 < 0xFFFF ? w1 - w0 : 0xFFFF;
         // the column indices as aligned 16-byte quads (scol comes from hipMalloc: index alignment = address alignment); the quad that
         // would read past the staged range's end falls back to single loads
         const int q_lo = e_lo >> 2, q_hi = (e_lo + e_n + 3) >> 2;           // quads [q_lo, q_hi) cover the entries [e_lo, e_lo + e_n)
@@ -375,22 +376,17 @@ struct SparseF {
                 for (int t = 0; t < 4; ++t) {
                     const int k = 4 * q + t - e_lo;
                     if (k < 0 || k >= e_n) continue;
-                        const int64_t d = (int64_t)vv[t] - w0;
+                    const int64_t d = (int64_t)vv[t] - w0;
                     l_col[k] = (d >= 0 && d < wlen) ? (uint16_t)d : (uint16_t)0xFFFFu;      // (only coordinates INSIDE the staged window get a code)
                 }
             }
         }
         __syncthreads();
-        // a row whose entries are all staged with a valid code is "fast"; its codes then also get the term's (r + 3 j) mod 8 in bits 13-15
         for (int i = threadIdx.x; i < nr; i += kBlock) {
             const int a0 = l_row[i], a1 = l_row[i + 1];
             bool ok = a1 <= e_lo + e_n;
             for (int a = a0; ok && a < a1; ++a) ok = l_col[a - e_lo] != 0xFFFFu;
             l_fast[i] = ok ? 1 : 0;
-            if (ok) {
-                const unsigned rw = (unsigned)((r_lo + i + 3 * w0) & 7);
-                for (int a = a0; a < a1; ++a) { const unsigned cde = l_col[a - e_lo]; l_col[a - e_lo] = (uint16_t)(cde | (((rw + 3 * cde) & 7) << 13)); }
-            }
         }
         return Staged{srow, scol, l_row, l_col, l_fast, r_lo, r_hi, w0, e_lo, e_n};
     }
@@ -451,7 +447,6 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, con
         }
         if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
     }
-    // (s_x is overwritten below, after the barrier inside stage(), by phi(x) = x + (x / 4) x: what every term of this family reads)
     // this thread's column: its entries, colour, step
     const long long j = j0 + threadIdx.x;
     const bool in = j < st.col_end;
@@ -469,9 +464,6 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, con
     if (none && c_lo == 0)
         for (int q = a; q < b; ++q) out[q] = (real_t)0;
     const auto fs = f.stage(s_f, r_lo, r_hi, w0, w1, stage_cap);     // (ends with the rows' flags; the barrier below publishes everything)
-    // the window holds phi(x_i) from here on (own elements only: every thread rewrites what it loaded -- no barrier needed in between
-    // would be wrong: stage() has one inside, after which nobody reads s_x as x any more in this kernel's fast path)
-    for (long long i = threadIdx.x; i < w1 - w0; i += kBlock) { const real_t v = s_x[i]; s_x[i] = v + (kQuarter * v) * v; }
     const int qa = st.colptr[j0 - st.col_begin], qb = st.colptr[jn - st.col_begin];
     const real_t *base = (const real_t *)st.fx_base;
     for (int q0 = qa; q0 < qb; q0 += kSpChunk) {
@@ -528,58 +520,20 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, con
         for (int k = 0; k < K; ++k) { const int i = k * kBlock + (int)threadIdx.x; ee[k] = i < nsorted ? (int)s_sorted[i] : -1; }
 #pragma unroll
         for (int k = 0; k < K; ++k) rw[k] = st.rowval[q0 + (ee[k] >= 0 ? ee[k] : 0)];
-        real_t xv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) bv[k] = (MODE == 0) ? base[rw[k]] : (real_t)0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            bv[k] = (MODE == 0) ? base[rw[k]] : (real_t)0;
-            xv[k] = x[j0 + s_ecol[ee[k] >= 0 ? ee[k] : 0]];             // the entry's own coordinate (the only perturbed one its row sees)
-        }
-#pragma unroll 1
-        for (int k = 0; k < K; ++k) {
-            if (k * kBlock >= nsorted) break;                          // (workgroup-uniform)
-            const bool act = ee[k] >= 0;
-            const int e = act ? ee[k] : 0, tc = s_ecol[e];
+            if (ee[k] < 0) continue;
+            const int e = ee[k], tc = s_ecol[e];
             const long long r = rw[k];
             const real_t he = s_h[tc], ye = s_y[tc];
             const long long jc = j0 + tc;
-            const bool stg = act && r >= r_lo && r < r_hi;
-            const int ri = stg ? (int)(r - r_lo) : 0;
-            const bool fast = stg && fs.l_fast[ri] != 0 && jc >= w0 && jc < w1;
-            real_t vp = 0, vm = bv[k];
-            // fast rows (all of them on a banded pattern): a STRAIGHT-LINE loop over the wavefront's longest row -- the lanes' rows have
-            // (nearly) the same length after the sort; shorter ones re-read their last entry and discard it.  No per-lane branch inside.
-            const int a0 = fs.l_row[ri] - fs.e_lo, n = fast ? fs.l_row[ri + 1] - fs.l_row[ri] : 0;
-            int nmax = n;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
-            nmax = __builtin_amdgcn_readfirstlane(nmax);
-            const unsigned joff = (unsigned)(jc - w0);
-            const real_t xp = xv[k] + he, xm = xv[k] - he;             // x_j +- eps, as the column points form them
-            const real_t phip = xp + (kQuarter * xp) * xp, phim = xm + (kQuarter * xm) * xm;
-            real_t sm = 0;
-            for (int t = 0; t < nmax; ++t) {
-                const int tt = t < n ? t : (n > 0 ? n - 1 : 0);
-                const unsigned cde = fs.l_col[a0 + tt];
-                const unsigned off = cde & 0x1FFFu;
-                const bool hit = off == joff;
-                const real_t ph0 = s_x[off];
-                const real_t cf = (real_t)1 + kEighth * (real_t)(int)(cde >> 13);
-                const real_t tp = cf * (hit ? phip : ph0);
-                const real_t sn = t == 0 ? tp : vp + tp;
-                vp = t < n ? sn : vp;
-                if (MODE == 1) {
-                    const real_t tm = cf * (hit ? phim : ph0);
-                    const real_t snm = t == 0 ? tm : sm + tm;
-                    sm = t < n ? snm : sm;
-                }
-            }
-            if (MODE == 1) vm = sm;
-            if (act && !fast) {       // anything else (rows cut by the staging): the family's plain evaluator, everything from memory
-                fd_column_point<real_t> Xg = {x, jc, he, 0};
-                vp = f.template row<real_t>(r, Xg);
-                if (MODE == 1) { Xg.minus = 1; vm = f.template row<real_t>(r, Xg); }
-            }
-            if (act) out[q0 + e] = fd_div_shared<real_t>(vp - vm, MODE == 1 ? 2 * he : he, ye);
+            fd_window_column_point<real_t> X = {x, s_x, w0, w1, jc, he, 0, (jc >= w0 && jc < w1) ? (unsigned)(jc - w0) : 0xFFFFFFFFu};
+            const real_t vp = fs.template row<real_t>(r, X);
+            real_t vm = bv[k];
+            if (MODE == 1) { X.minus = 1; vm = fs.template row<real_t>(r, X); }
+            out[q0 + e] = fd_div_shared<real_t>(vp - vm, MODE == 1 ? 2 * he : he, ye);
         }
     }
 }
