@@ -248,6 +248,8 @@ def main():
     # called by libfdjac itself (fd_comm_*), torch.distributed only for the barrier / max-over-ranks / id broadcast.
     backend = os.environ.get("FDJAC_BENCH_BACKEND", "nccl")
     shared_devices = None
+    if world > 1:
+        os.environ.setdefault("FDJAC_P2P_TIMEOUT_MS", "500")      # (a mailbox wait that does not complete gives up after this long, loudly)
     if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
         # fewer GPUs than ranks: RCCL refuses two ranks on one device (and may hang finding out) -- run the dry-run transport and say so
         backend = "gloo"
@@ -398,6 +400,20 @@ def main():
                     pb["plan"].set_lazy(pb["f"])
                     outv = torch.empty(pb["counts"][rank], dtype=t_dt, device=dev)
                     call = pb["plan"].bind(pb["f"], pb["x"], [outv])
+                    call()                                   # first contact: one step, then ask every rank how its waits went
+                    fence()
+                    st = p2p_status() if sharded else 0
+                    if st and comm is not None:
+                        # stores into a peer's mailbox did not arrive (in time): every rank drops the mailboxes and the SAME layout is
+                        # timed through RCCL instead (send / recv of the halo, all-gather of the group sums) -- not a timeout per step
+                        v["p2p_error"] = "a mailbox wait for rank %d timed out on the first step: small messages back on RCCL" % (st - 1)
+                        sys.stderr.write("[bench rank %d] %s\n" % (rank, v["p2p_error"]))
+                        comm.disable_p2p()
+                        v["exchange"] = attach_exchange(pb)
+                        call()
+                        fence()
+                    elif st:
+                        raise RuntimeError("a mailbox wait for rank %d timed out on the first step" % (st - 1))
                     for _ in range(max(args.warmup, 2)):
                         call()
                     fence()

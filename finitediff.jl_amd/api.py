@@ -383,6 +383,10 @@ class Comm:
         solve -- through direct peer-to-peer stores.  Collective; raises if the peers cannot be mapped."""
         _l.check(self.L.fd_comm_enable_p2p(self.handle, int(slot_bytes)))
 
+    def disable_p2p(self):
+        """fd_comm_disable_p2p: back to RCCL for the small messages (every rank calls it)."""
+        _l.check(self.L.fd_comm_disable_p2p(self.handle))
+
     def has_p2p(self):
         en = C.c_int()
         _l.check(self.L.fd_comm_p2p_status(self.handle, C.byref(en), None))

@@ -237,6 +237,18 @@ int fd_comm_enable_p2p(fd_comm *c, int64_t slot_bytes)
     return FD_OK;
 }
 
+// Back to RCCL for the small messages (every rank calls it, e.g. after fd_comm_p2p_status reported a timed-out wait: peer-to-peer stores that
+// do not arrive must not cost a timeout per step).  Plans attached to the communicator follow at their next call.
+int fd_comm_disable_p2p(fd_comm *c)
+{
+    FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");
+    if (c->p2p) {
+        (void)fd_p2p_destroy(c->p2p);
+        c->p2p = nullptr;
+    }
+    return FD_OK;
+}
+
 int fd_comm_p2p_status(const fd_comm *c, int *enabled, int *timed_out_rank_plus_1)
 {
     FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");

@@ -1165,7 +1165,9 @@ k_decompress_bbb(const CT *__restrict__ color, const real_t *__restrict__ FXa, c
         const real_t ec = eps[cc];
         const int jj = (int)(j - oJ), k = jj + t - mu, m = kin ? oK1 - oK : 0;
         const bool inb = k >= 0 && k < m;
-        const real_t v = entry_value<MODE>(FXa, FXb, ld, cc - c_lo, (int64_t)oK + (inb ? k : 0), ec);
+        // (a slot outside its block reads SOME row of f -- its value is discarded: row oK, clamped into the vector for an empty last block)
+        const int64_t rsafe = (int64_t)oK + (inb ? k : 0);
+        const real_t v = entry_value<MODE>(FXa, FXb, ld, cc - c_lo, rsafe < N ? rsafe : N - 1, ec);
         if (st0 < 0) continue;                                     // no such block and no slab reserved for it
         // (a layout that reserves the slab of a block outside the matrix -- BlockBandedMatrices' own: (bl+bu+1)(lam+mu+1) rows per
         //  column -- gets its zeros here; the plan zero-fills other layouts before the launch)

@@ -798,7 +798,12 @@ int fd_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_
             dense = false;
         }
     }
-    FD_REQUIRE(data_len >= out_len, FD_ERR_SHAPE, "data_len %lld < the end of the last slab %lld", (long long)data_len, (long long)out_len);
+    if (data_len < out_len) {
+        set_error("data_len %lld < the end of the last slab %lld", (long long)data_len, (long long)out_len);
+        fd_plan_destroy(p);
+        *out = nullptr;
+        return FD_ERR_SHAPE;
+    }
     p->bbb_fill = !(dense && covered == data_len);      // (slots no slab reaches: zero-filled before every launch, as fill!(J, 0) does)
     p->bbb_nb = nblk; p->bbb_bl = (int)bl; p->bbb_bu = (int)bu; p->bbb_lam = (int)lam; p->bbb_mu = (int)mu;
     p->row0 = 0;

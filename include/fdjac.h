@@ -514,6 +514,8 @@ int fd_p2p_halo_exchange(fd_p2p *p2p, void *buf, int64_t own_begin, int64_t own_
 int fd_comm_enable_p2p(fd_comm *comm, int64_t slot_bytes);
 /* does the communicator route its small messages through a mailbox (*enabled), and has a wait of it ever timed out (as fd_p2p_status)? */
 int fd_comm_p2p_status(const fd_comm *comm, int *enabled, int *timed_out_rank_plus_1);
+/* drop the mailbox again: the communicator's small messages go back to RCCL (every rank calls it -- e.g. after a timed-out wait) */
+int fd_comm_disable_p2p(fd_comm *comm);
 
 /* Sharded step-size reduction (src/jacobians.jl:559-561 / 600-602 across ranks).  The reduction is DEFINED as a two-level sum that
    depends on N alone: x is cut into 64 contiguous groups, a group's blocks are added in block order, the 64 group sums in group order.
