@@ -756,7 +756,28 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         // the launcher stores the finished quotients into the Jacobian itself (include/fdjac_device.h) -- the exact band was
         // verified at plan time -- and nothing is launched after f!: this launch IS the difference + decompression
         // (src/jacobians.jl:565-568), so its span is recorded as the graded stage
-        if (store_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
+        if (p->kind == K_BBB && store_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
+            // BandedBlockBandedMatrix storage: the launcher fills every slab itself (fd_bbb_store)
+            Span sp(p, FD_STAGE_DECOMPRESS);
+            fd_bbb_store bb;
+            memset(&bb, 0, sizeof bb);
+            bb.out = outs[0]; bb.N = p->N; bb.nblk = p->bbb_nb; bb.block_size = p->bbb_bs;
+            bb.bl = p->bbb_bl; bb.bu = p->bbb_bu; bb.lam = p->bbb_lam; bb.mu = p->bbb_mu;
+            bb.start = (const long long *)p->d_bbb_start; bb.stride = (const long long *)p->d_bbb_stride;
+            bb.color = p->d_color; bb.color_bytes = p->color8 ? 1 : 4; bb.C = (int)p->C; bb.elem_bytes = (int)sizeof(real_t);
+            fd_lazy_points lp = {};
+            lp.x = x_dev; lp.color = p->d_color; lp.eps = p->d_eps; lp.color_bytes = bb.color_bytes;
+            lp.c_lo = c_lo; lp.ncolors = B; lp.pts = p->pts; lp.nparts = 1;
+            lp.diff = (p->fdtype == FD_FORWARD && !diff_base_counted) ? 2 : 1;
+            lp.store = &bb; lp.store_kind = FD_STORE_BBB;
+            const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (BBB store) returned %d", rc);
+            if (rc == 0) {
+                p->fcalls_last += (int64_t)B * p->pts + (lp.diff == 2 ? 1 : 0);
+                diff_base_counted = true;
+                continue;
+            }
+        } else if (store_active(p) && !(p->fdtype == FD_FORWARD && !base_pending)) {
             Span sp(p, FD_STAGE_DECOMPRESS);
             fd_band_store bs;
             fd_stencil5_store s5;

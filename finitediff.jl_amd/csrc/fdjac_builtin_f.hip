@@ -985,6 +985,57 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     fd_stencil5_emit_wave<real_t, true, 2>(&st, s_win[wave], j, i0, q);
 }
 
+// fd_bbb_store (round 5): the 5-point families on an nx x ny grid storing into BandedBlockBandedMatrix data -- ny blocks of nx rows,
+// block bandwidths (1, 1), sub-block bandwidths (1, 1): the reference's own fixture (test/coloring_tests.jl:99-115;
+// ext/FiniteDiffBlockBandedMatricesExt.jl:16-42).  Thread k = (i, j) owns column k: it loads the 13 coordinates its five rows read, forms
+// the five quotients exactly as the CSC storing kernel does (stencil5_column_quotients) and writes the NINE slots of its column -- block
+// j-1: (0, q_S, 0), block j: (q_W, q_C, q_E), block j+1: (0, q_N, 0); slots of rows outside their block and whole columns without a colour
+// are 0, as k_decompress_bbb writes them.  A slot whose row does not depend on the column is exactly 0 in the hand-over path too (the
+// plan verified that the colouring is valid for the nine-point BBB pattern: no perturbed column reaches such a row).
+template <typename CT, int MODE, int SK>
+__global__ void __launch_bounds__(kBlock) k_f_stencil5_store_bbb(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_bbb_store st, int nx, int ny)
+{
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= st.N) return;
+    const int j = (int)(k / nx), i = (int)(k - (int64_t)j * nx);
+    real_t W[5][5];
+#pragma unroll
+    for (int dj = -2; dj <= 2; ++dj)
+#pragma unroll
+        for (int di = -2; di <= 2; ++di) {
+            W[dj + 2][di + 2] = 0;
+            if ((dj < 0 ? -dj : dj) + (di < 0 ? -di : di) > 2) continue;      // (only the 13 points within L1 distance 2 are read)
+            const int ii = i + di, jj = j + dj;
+            const bool in = ii >= 0 && ii < nx && jj >= 0 && jj < ny;
+            const real_t v = x[in ? (int64_t)jj * nx + ii : k];              // (unconditional load from a clamped index)
+            W[dj + 2][di + 2] = in ? v : (real_t)0;
+        }
+    const int c = (int)((const CT *)st.color)[k];
+    const bool none = c == (int)(CT)(-1);
+    real_t q[5] = {0, 0, 0, 0, 0};
+    const real_t e = none ? (real_t)1 : eps[c];
+    if (!none) stencil5_column_quotients<MODE, SK, false, true, 5>(W, 0, i, j, nx, ny, e, q);
+    // an in-block row that does not depend on the column: the hand-over path divides an exact +0.0 difference by the step -- the sign
+    // of that zero follows the step's (dir = -1)
+    const real_t zq = (real_t)0 / (MODE == 1 ? 2 * e : e);
+    // rows k - nx, k - 1, k, k + 1, k + nx; those that do not exist hold garbage in q: they are never stored
+    real_t *out = (real_t *)st.out;
+    const long long sJ = st.stride[j];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const long long st0 = st.start[d + 3 * (long long)j];
+        if (st0 < 0) continue;
+        const int K = j + d - 1;                                          // (bu = 1)
+        const bool kin = K >= 0 && K < ny;
+        real_t *o = out + st0 + (long long)i * sJ;                         // slots t = 0, 1, 2 <-> rows i - 1, i, i + 1 of block K (mu = 1)
+        const real_t mid = d == 0 ? q[0] : d == 1 ? q[2] : q[4];
+        const real_t lo = d == 1 ? q[1] : zq, hi = d == 1 ? q[3] : zq;
+        o[0] = (kin && !none && i - 1 >= 0) ? lo : (real_t)0;
+        o[1] = (kin && !none) ? mid : (real_t)0;
+        o[2] = (kin && !none && i + 1 < nx) ? hi : (real_t)0;
+    }
+}
+
 template <typename CT>
 static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, int64_t fs, int64_t r0, int64_t r1,
                                 hipStream_t s)
@@ -997,6 +1048,21 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
     if (lp->store) {
         // the launch stores the stencil's CSC Jacobian itself (fd_stencil5_store): every colour in one batch, the Laplacian
         // fixtures (the clamped sum's boundary rows reach themselves twice: not this pattern's arithmetic)
+        if (lp->store_kind == FD_STORE_BBB && mode != 2 && sk != 1) {
+            // BandedBlockBandedMatrix data: ny blocks of nx rows, (1, 1) / (1, 1) bandwidths -- the structure of this family's Jacobian
+            const fd_bbb_store bb = *(const fd_bbb_store *)lp->store;
+            if (bb.elem_bytes != (int)sizeof(real_t) || bb.block_size != b->prm[0] || bb.nblk != b->prm[1] || bb.bl != 1 || bb.bu != 1 || bb.lam != 1 ||
+                bb.mu != 1 || lp->c_lo != 0 || lp->ncolors != bb.C || bb.color_bytes != (int)sizeof(CT) || bb.N >= ((int64_t)1 << 31))
+                return FD_LAZY_DECLINED;
+            const unsigned gb = (unsigned)((bb.N + kBlock - 1) / kBlock);
+#define FD_S5B(MODE, SKK)                                                                                                  \
+            hipLaunchKernelGGL((k_f_stencil5_store_bbb<CT, MODE, SKK>), dim3(gb), dim3(kBlock), 0, s, (const real_t *)lp->x,     \
+                               (const real_t *)lp->eps, bb, (int)b->prm[0], (int)b->prm[1])
+            if (mode == 0) { if (sk == 2) FD_S5B(0, 2); else FD_S5B(0, 0); }
+            else { if (sk == 2) FD_S5B(1, 2); else FD_S5B(1, 0); }
+#undef FD_S5B
+            return hipGetLastError() == hipSuccess ? 0 : 4;
+        }
         if (lp->store_kind != FD_STORE_STENCIL5 || mode == 2 || sk == 1) return FD_LAZY_DECLINED;
         const fd_stencil5_store st = *(const fd_stencil5_store *)lp->store;
         if (st.elem_bytes != (int)sizeof(real_t) || st.nx != b->prm[0] || st.ny != b->prm[1] || lp->c_lo != 0 || lp->ncolors != st.C ||

@@ -299,6 +299,8 @@ struct fd_plan {
     int64_t bbb_nb = 0;
     int bbb_bl = 0, bbb_bu = 0, bbb_lam = 0, bbb_mu = 0;
     bool bbb_fill = false;             // some slots of data belong to no slab: zero-fill before the launch
+    bool store_bbb_ok = false;         // uniform blocks + a colouring verified VALID for the BBB pattern: a FD_LAZY_CAP_STORE launcher may store
+    int64_t bbb_bs = 0;                //   (fd_bbb_store); the uniform block size
     int32_t *d_bbb_off = nullptr;      // [nb + 1] first row / column of every block
     int32_t *d_bbb_blk = nullptr;      // [N] block of every column
     int64_t *d_bbb_start = nullptr;    // [(bl + bu + 1) * nb] 0-based start of block (K, J)'s slab in data, -1: not in the band
@@ -405,6 +407,8 @@ static inline bool store_active(const fd_plan *p)
 {
     if (!(p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE)) || p->has_none) return false;
     if (p->kind == fdjac::K_COLRANGE) return p->store_cr_ok && p->fdtype == FD_COMPLEX;   // (the block-coupled launcher's storing kernel is the complex step's)
+    if (p->kind == fdjac::K_BBB) return p->store_bbb_ok && p->fdtype != FD_COMPLEX && p->store_allowed && p->nchunks == 1 && p->own_c0 == 0 &&
+                                        (p->own_c1 < 0 || p->own_c1 >= p->C);
     return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->fdtype != FD_COMPLEX &&
            (p->kind == fdjac::K_CSC || p->kind == fdjac::K_BANDED || p->kind == fdjac::K_TRIDIAG);
 }

@@ -808,6 +808,29 @@ int fd_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *blk_
     p->bbb_nb = nblk; p->bbb_bl = (int)bl; p->bbb_bu = (int)bu; p->bbb_lam = (int)lam; p->bbb_mu = (int)mu;
     p->row0 = 0;
     p->row1 = N;
+    {
+        // may a FD_LAZY_CAP_STORE launcher fill the slabs itself (fd_bbb_store)?  Uniform blocks, and colorvec a VALID colouring of
+        // the BBB pattern: the columns that share a row -- blocks J in [K - bl, K + bu], in-block columns [k - lam, k + mu] -- differ in
+        // colour.  Then a slot whose row does not depend on its column holds exactly 0 in the reference too.
+        const int64_t bs0 = nblk > 0 ? (int64_t)off[1] - off[0] : 0;
+        bool ok = bs0 > 0 && !p->cx;
+        for (int64_t b = 0; b < nblk && ok; ++b) ok = (int64_t)off[(size_t)b + 1] - off[(size_t)b] == bs0;
+        if (ok) {
+            std::vector<int64_t> stamp((size_t)std::max<int64_t>(p->C, 1), -1);
+            for (int64_t r = 0; r < N && ok; ++r) {
+                const int64_t K = r / bs0, k = r - K * bs0;
+                for (int64_t J = std::max<int64_t>(K - bl, 0); J <= std::min<int64_t>(K + bu, nblk - 1) && ok; ++J)
+                    for (int64_t jj = std::max<int64_t>(k - lam, 0); jj <= std::min<int64_t>(k + mu, bs0 - 1); ++jj) {
+                        const int32_t c = col0[(size_t)(J * bs0 + jj)];
+                        if (c < 0) continue;
+                        if (stamp[(size_t)c] == r) { ok = false; break; }
+                        stamp[(size_t)c] = r;
+                    }
+            }
+        }
+        p->store_bbb_ok = ok;
+        p->bbb_bs = ok ? bs0 : 0;
+    }
     FD_TRY(dev_upload(&p->d_bbb_off, off));
     FD_TRY(dev_upload(&p->d_bbb_blk, blk));
     FD_TRY(dev_upload(&p->d_bbb_start, start));

@@ -191,7 +191,24 @@ typedef struct fd_csc_store {
                                    /* (fd_csc_store_cols_win keeps that window of x in LDS; anything outside it is read from memory)         */
 } fd_csc_store;
 
-enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4 };   /* what fd_lazy_points.store points to */
+/* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------
+ * Block (K, J) of the block band (-bu <= K - J <= bl) owns a slab of banded data: entry (k, j) of the block (0-based, -mu <= k - j <= lam)
+ * lives at  start[(bu + K - J) + (bl + bu + 1) J] + j stride[J] + mu + k - j  (the reference's raw offsets, its lines 29-36).  A launcher
+ * that knows its residual's structure writes every slot of every in-band slab of its columns itself -- the quotient where the row
+ * depends on the column, 0 elsewhere (for a colouring that is valid for the BBB pattern, which the plan verified, the reference's
+ * difference of an independent row is exactly 0) -- and nothing is launched after f!.  Whole column range, all colours in one batch. */
+typedef struct fd_bbb_store {
+    void *out;                     /* J.data, device */
+    long long N, nblk, block_size; /* N = nblk * block_size */
+    int bl, bu, lam, mu;
+    const long long *start;        /* device, (bl + bu + 1) * nblk slab starts (0-based), -1: no slab */
+    const long long *stride;       /* device, nblk column strides */
+    const void *color;             /* device: 0-based colour of every column, color_bytes each; "none" = 0xFF / -1 */
+    int color_bytes, C;
+    int elem_bytes;
+} fd_bbb_store;
+
+enum fd_store_kind { FD_STORE_NONE = 0, FD_STORE_BAND = 1, FD_STORE_STENCIL5 = 2, FD_STORE_COLRANGE = 3, FD_STORE_CSC = 4, FD_STORE_BBB = 5 };   /* what fd_lazy_points.store points to */
 
 #if defined(__HIPCC__) && defined(__cplusplus)
 /* ---------------------------------------------------------------------------------------------------------------------------

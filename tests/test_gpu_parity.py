@@ -136,6 +136,57 @@ def test_tridiagonal_type(oracle, fdtype, ncalls):
         _tol_ok(got.cpu().numpy(), want, em, 4.0, "Tridiagonal." + nm)
 
 
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("family,nx,ny", [("lap5", 40, 30), ("lap5_nl", 37, 11), ("lap5", 5, 3), ("lap5_nl", 1, 9), ("lap5", 300, 200)])
+def test_storing_launch_into_bandedblockbanded_data(oracle, fdtype, family, nx, ny):
+    # fd_bbb_store (round 5): the 5-point families fill BandedBlockBandedMatrix data -- ny blocks of nx rows, (1,1)/(1,1) bandwidths, the
+    # reference's own layout (test/coloring_tests.jl:109-115; ext/FiniteDiffBlockBandedMatricesExt.jl:16-42) -- in f!'s own launch:
+    # bits of the decompression path (k_decompress_bbb after the lazy hand-over), oracle parity, 1 + C / 2 C evaluations, dir = -1,
+    # columns without a colour (zeros), and an INVALID colouring (the store must not be taken: the plan refuses it)
+    lay = P.BandedBlockBandedLayout(np.full(ny, nx), 1, 1, 1, 1)
+    N = lay.N
+    colors = lay.colors()
+    C = int(colors.max())
+    xh = np.random.default_rng(nx * 7 + ny).random(N) + 0.1
+    x = _dev(xh)
+    f = fd.BuiltinF(family, nx, ny)
+
+    def run(cv, store, dir=True):
+        J = fd.BandedBlockBandedMatrix(None, lay)
+        plan = fd.make_plan(J, J, cv, fdtype)
+        plan.set_lazy(f, store=store)
+        out = _dev(np.full(lay.data_len, np.nan))
+        plan.jacobian(f, x, [out], dir=dir)
+        return out, plan
+
+    a, pa = run(colors, True)
+    b, pb = run(colors, False)
+    assert pa.info(fd.lib.INFO_LAZY_STORE) == 1 and pb.info(fd.lib.INFO_LAZY_STORE) == 0
+    assert pa.fcalls_last == pb.fcalls_last == (1 + C if fdtype == "forward" else 2 * C)
+    assert not torch.isnan(a).any() and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    if family == "lap5" and fdtype == "forward":
+        a2, _ = run(colors, True, dir=-1)
+        b2, _ = run(colors, False, dir=-1)
+        assert torch.equal(a2.view(torch.int64), b2.view(torch.int64))
+    if nx * ny <= 2000:
+        ref = oracle.jacobian(fdtype, oracle.Fixture(family, nx, ny), xh, colors, kind=oracle.PAT_BANDEDBLOCKBANDED,
+                              blk_sizes=lay.blk_sizes, bl=1, bu=1, lam=1, mu=1, block_starts=lay.block_starts, block_strides=lay.block_strides,
+                              out_len=lay.data_len)
+        em = np.min(np.abs(_oracle_eps(xh, colors, fdtype)))
+        _tol_ok(a.cpu().numpy(), ref["out"], em, 8.0, "BBB store " + family)
+    # columns without a colour: zeros, everything else unchanged in kind
+    cv = colors.copy()
+    cv[[0, N // 2, N - 1]] = 0
+    a3, _ = run(cv, True)
+    b3, _ = run(cv, False)
+    assert torch.equal(a3.view(torch.int64), b3.view(torch.int64))
+    # an invalid colouring (every column the same colour): the plan does not allow the store
+    bad = np.ones(N, dtype=np.int64)
+    a4, p4 = run(bad, True)
+    b4, _ = run(bad, False)
+    assert p4.info(fd.lib.INFO_LAZY_STORE) == 0 and torch.equal(a4.view(torch.int64), b4.view(torch.int64))
+
+
 @pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
 @pytest.mark.parametrize("kind", ["bidiag_U", "bidiag_L", "diagonal", "symtridiag"])
 def test_other_structured_types_of_the_generic_loop(oracle, kind, fdtype):
