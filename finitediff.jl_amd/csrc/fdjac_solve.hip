@@ -15,7 +15,8 @@
 // values.  No pivoting: the method is for diagonally dominant systems (I - gamma*J of a diffusion-type J), like the
 // partitioned / cyclic-reduction tridiagonal solvers of the vendor libraries.  Level 0 reads the user's J and b once
 // in the reduction and once in the back-substitution (9 values per row in total + 1 written).  Measured at N = 10^7 on
-// MI355X: 0.38 ms (Tridiagonal diagonals) / 0.44 ms (CSC nzval) per solve, 11 launches.
+// MI355X: 0.21 ms (Tridiagonal diagonals, 5 launches) / 0.22 ms (CSC nzval, 7 launches) per solve -- the small levels two per
+// launch (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2 below), profiles/r05_p_solve.md.
 //
 // Multi-GPU (rows = the rank's column range): the rank's block T_r of the matrix is complete in its own slice; the two
 // couplings to the neighbouring ranks are not (they live in the neighbours' columns).  SPIKE form:
@@ -173,9 +174,15 @@ struct SrcLevel {
     }
 };
 
+// where a chunk's summary goes: the level's array in memory, or (two levels per launch, below) a table in LDS
+struct SumGlobal {
+    double *__restrict__ sum;
+    int64_t nc;
+    __device__ __forceinline__ void put(int v, int64_t k, double x) const { sum[v * nc + k] = x; }
+};
 // One chunk's two elimination sweeps -> its summary (the row it contributes to the next level).
-template <typename Src, int NRHS>
-__device__ __forceinline__ void tri_reduce_chunk(const Src &src, int64_t n, double *__restrict__ sum, int64_t nc, int64_t k)
+template <typename Src, int NRHS, typename Sink>
+__device__ __forceinline__ void tri_reduce_chunk(const Src &src, int64_t n, const Sink &sink, int64_t k)
 {
     const int64_t s = k * kChunk;
     const int m = (int)((n - s < kChunk) ? n - s : kChunk);
@@ -221,11 +228,11 @@ __device__ __forceinline__ void tri_reduce_chunk(const Src &src, int64_t n, doub
             for (int q = 0; q < NRHS; ++q) cd[q] = d[i][q];
         }
     }
-    sum[0 * nc + k] = fe;
-    sum[1 * nc + k] = be;
-    sum[2 * nc + k] = ce;
+    sink.put(0, k, fe);
+    sink.put(1, k, be);
+    sink.put(2, k, ce);
 #pragma unroll
-    for (int q = 0; q < NRHS; ++q) sum[(3 + q) * nc + k] = de[q];      // (right-hand sides beyond NRHS are never read)
+    for (int q = 0; q < NRHS; ++q) sink.put(3 + q, k, de[q]);      // (right-hand sides beyond NRHS are never read)
     // upward: the first row expressed through the unknown before the chunk (f) and the chunk's last unknown (g)
 #pragma unroll
     for (int i = kChunk - 3; i >= 0; --i)
@@ -237,11 +244,11 @@ __device__ __forceinline__ void tri_reduce_chunk(const Src &src, int64_t n, doub
             for (int q = 0; q < NRHS; ++q) cd[q] = d[i][q] - mult * cd[q];
             cb = b[i];
         }
-    sum[6 * nc + k] = cf;
-    sum[7 * nc + k] = cb;
-    sum[8 * nc + k] = cg;
+    sink.put(6, k, cf);
+    sink.put(7, k, cb);
+    sink.put(8, k, cg);
 #pragma unroll
-    for (int q = 0; q < NRHS; ++q) sum[(9 + q) * nc + k] = cd[q];
+    for (int q = 0; q < NRHS; ++q) sink.put(9 + q, k, cd[q]);
 }
 // Rows through LDS, one coefficient array at a time.  A thread walks kChunk CONSECUTIVE rows; loading them directly makes
 // every wave instruction touch 64 different cache lines and re-fetch each line up to 8 times from the L2 (measured: 1.7
@@ -278,27 +285,38 @@ __device__ __forceinline__ void tri_guard_rows(const SrcRegs<NRHS> &R, int64_t n
     }
     if (nd) atomicOr(nd_flag, 1);
 }
+// (in two halves: the loads of a tile can be issued long before they are consumed -- the persistent kernels below keep the NEXT
+// tile's loads in flight while they work on the current one)
+template <typename Src, int NRHS> struct TriLoads {
+    static constexpr int kRounds = Src::kUnitRhs ? 4 : 3 + NRHS;
+    double g[kRounds][kChunk];
+};
 template <typename Src, int NRHS>
-__device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+__device__ __forceinline__ void tri_issue_rows(const Src &src, int64_t n, int64_t row0, TriLoads<Src, NRHS> &L)
 {
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
-    constexpr int kRounds = Src::kUnitRhs ? 4 : 3 + NRHS;
+    constexpr int kRounds = TriLoads<Src, NRHS>::kRounds;
     // every array's global loads are issued before the first transposition: the memory latency is paid once, not once per
     // round (the barriers below would otherwise keep round w+1's loads behind round w's LDS traffic)
-    double g[kRounds][kChunk];
 #pragma unroll
     for (int which = 0; which < kRounds; ++which)
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             const int r = j * kBlock + (int)threadIdx.x;  // lane-consecutive rows
-            g[which][j] = src.raw(which, row0 + (r < rows ? r : (int)rows - 1));      // (unconditional: the tile's last row again)
+            L.g[which][j] = src.raw(which, row0 + (r < rows ? r : (int)rows - 1));      // (unconditional: the tile's last row again)
         }
+}
+template <typename Src, int NRHS>
+__device__ __forceinline__ void tri_land_rows(const Src &src, int64_t n, int64_t row0, TriLoads<Src, NRHS> &L, double *lds, SrcRegs<NRHS> &R)
+{
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    constexpr int kRounds = TriLoads<Src, NRHS>::kRounds;
 #pragma unroll
     for (int which = 0; which < kRounds; ++which)
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             const int r = j * kBlock + (int)threadIdx.x;
-            g[which][j] = r < rows ? src.fix(which, row0 + r, g[which][j]) : 0.0;
+            L.g[which][j] = r < rows ? src.fix(which, row0 + r, L.g[which][j]) : 0.0;
         }
 #pragma unroll
     for (int which = 0; which < kRounds; ++which) {
@@ -306,7 +324,7 @@ __device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             const int r = j * kBlock + (int)threadIdx.x;
-            if (r < rows) lds[r + (r >> 3)] = g[which][j];
+            if (r < rows) lds[r + (r >> 3)] = L.g[which][j];
         }
         __syncthreads();
         double *dst = which == 0 ? R.a : which == 1 ? R.b : which == 2 ? R.c : R.d[which - 3 < NRHS ? which - 3 : 0];
@@ -323,6 +341,13 @@ __device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_
     }
 }
 template <typename Src, int NRHS>
+__device__ __forceinline__ void tri_fetch_rows(const Src &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+{
+    TriLoads<Src, NRHS> L;
+    tri_issue_rows<Src, NRHS>(src, n, row0, L);
+    tri_land_rows<Src, NRHS>(src, n, row0, L, lds, R);
+}
+template <typename Src, int NRHS>
 __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, double *__restrict__ sum, int64_t nc)
 {
     __shared__ double lds[kTriPitch];
@@ -331,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
     if constexpr (Src::kUnitRhs) tri_guard_rows<NRHS>(R, n, (int64_t)blockIdx.x * kTriTileRows, src.nd_flag);      // (level 0 only)
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= nc) return;
-    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
+    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, SumGlobal{sum, nc}, k);
 }
 
 // Level 0 on the nzval of a tridiagonal CSC.  Column j stores (du_j, d_j, dl_j) = A[j-1,j], A[j,j], A[j+1,j] at 3j-1, 3j, 3j+1, so
@@ -342,42 +367,55 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce(Src src, int64_t n, doubl
 // arithmetic; the right-hand side follows through the same LDS as before.
 constexpr int kTriRawVals = 3 * kTriTileRows + 2;
 constexpr int kTriRawSlots = kTriRawVals + kTriRawVals / 24 + 2;
-template <int NRHS>
-__device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+constexpr int kTriRawPer = (kTriRawVals + kBlock - 1) / kBlock;
+struct TriLoadsCsc {
+    real_t g[kTriRawPer];
+    double gr[kChunk];
+};
+__device__ __forceinline__ void tri_issue_rows_csc(const SrcUser &src, int64_t n, int64_t row0, TriLoadsCsc &L)
 {
     const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
     // raw value q of the tile <-> nzval[lo + q]; row r (tile-local): a at 3r, b at 3r + 2, c at 3r + 4
     const int64_t lo = 3 * (src.g0 + row0) - src.e0 - 2;
     const int64_t qmin = lo < 0 ? -lo : 0;                                        // (the slice starts at its first row's diagonal or du)
     const int64_t qmax = 3 * rows + 1 - ((row0 + rows == n) ? 2 : 0);             // (the last local row's c is not in the slice)
-    constexpr int kPer = (kTriRawVals + kBlock - 1) / kBlock;
-    real_t g[kPer];
-    double gr[kChunk];
+    // (a uniform base + a 32-bit lane offset: one address register per load, not two)
+    const real_t *__restrict__ base = src.p0 + (lo + qmin);
+    const unsigned qspan = (unsigned)(qmax - qmin);
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int64_t q = (int64_t)j * kBlock + threadIdx.x;
-        g[j] = src.p0[lo + (q < qmin ? qmin : q > qmax ? qmax : q)];      // (unconditional, from a clamped position)
+    for (int j = 0; j < kTriRawPer; ++j) {
+        const int q = j * kBlock + (int)threadIdx.x - (int)qmin;
+        L.g[j] = base[q < 0 ? 0u : (unsigned)q > qspan ? qspan : (unsigned)q];      // (unconditional, from a clamped position)
     }
+    const real_t *__restrict__ rbase = src.rhs + row0;
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {                    // the right-hand side's loads are in flight behind them
-        const int r = j * kBlock + (int)threadIdx.x;
-        gr[j] = (double)src.rhs[row0 + (r < rows ? r : (int)rows - 1)];
+        const unsigned r = (unsigned)(j * kBlock) + threadIdx.x;
+        L.gr[j] = (double)rbase[r < (unsigned)rows ? r : (unsigned)rows - 1u];
     }
+}
+template <int NRHS>
+__device__ __forceinline__ void tri_land_rows_csc(const SrcUser &src, int64_t n, int64_t row0, TriLoadsCsc &L, double *lds, SrcRegs<NRHS> &R)
+{
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    const int64_t lo = 3 * (src.g0 + row0) - src.e0 - 2;
+    const int64_t qmin = lo < 0 ? -lo : 0;
+    const int64_t qmax = 3 * rows + 1 - ((row0 + rows == n) ? 2 : 0);
     // (the selects only after every load has been issued)
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
+    for (int j = 0; j < kTriRawPer; ++j) {
         const int64_t q = (int64_t)j * kBlock + threadIdx.x;
-        if (!(q >= qmin && q <= qmax)) g[j] = (real_t)0;
+        if (!(q >= qmin && q <= qmax)) L.g[j] = (real_t)0;
     }
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
         const int r = j * kBlock + (int)threadIdx.x;
-        gr[j] = r < rows ? src.rhs_fix(row0 + r, gr[j]) : 0.0;
+        L.gr[j] = r < rows ? src.rhs_fix(row0 + r, L.gr[j]) : 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
+    for (int j = 0; j < kTriRawPer; ++j) {
         const int q = j * kBlock + (int)threadIdx.x;
-        if (q < kTriRawVals) lds[q + q / 24] = (double)g[j];
+        if (q < kTriRawVals) lds[q + q / 24] = (double)L.g[j];
     }
     __syncthreads();
     const int base = 25 * (int)threadIdx.x;               // slot of raw value 24 t
@@ -395,7 +433,7 @@ __device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
         const int r = j * kBlock + (int)threadIdx.x;
-        if (r < rows) lds[r + (r >> 3)] = gr[j];
+        if (r < rows) lds[r + (r >> 3)] = L.gr[j];
     }
     __syncthreads();
 #pragma unroll
@@ -410,6 +448,13 @@ __device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n
     }
 }
 template <int NRHS>
+__device__ __forceinline__ void tri_fetch_rows_csc(const SrcUser &src, int64_t n, int64_t row0, double *lds, SrcRegs<NRHS> &R)
+{
+    TriLoadsCsc L;
+    tri_issue_rows_csc(src, n, row0, L);
+    tri_land_rows_csc<NRHS>(src, n, row0, L, lds, R);
+}
+template <int NRHS>
 __global__ void __launch_bounds__(kBlock) k_tri_reduce_csc(SrcUser src, int64_t n, double *__restrict__ sum, int64_t nc)
 {
     __shared__ double lds[kTriRawSlots];
@@ -418,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reduce_csc(SrcUser src, int64_t 
     tri_guard_rows<NRHS>(R, n, (int64_t)blockIdx.x * kTriTileRows, src.nd_flag);
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= nc) return;
-    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, sum, nc, k);
+    tri_reduce_chunk<SrcRegs<NRHS>, NRHS>(R, n, SumGlobal{sum, nc}, k);
 }
 
 // The top level (n <= kTop): parallel cyclic reduction in LDS, NRHS right-hand sides.  sol[q * n + i].
@@ -468,11 +513,10 @@ struct TriLdsOut {
     __device__ __forceinline__ void put(int64_t i, double v) const { const int r = (int)(i - row0); sd[r + (r >> 3)] = v; }
 };
 template <typename Src, typename Out>
-__device__ __forceinline__ void tri_backsub_chunk(const Src &src, int64_t n, const double *__restrict__ z, int64_t k, const Out &y)
+__device__ __forceinline__ void tri_backsub_chunk_v(const Src &src, int64_t n, double zl, double zr, int64_t k, const Out &y)
 {
     const int64_t s = k * kChunk;
     const int m = (int)((n - s < kChunk) ? n - s : kChunk);
-    const double zl = k > 0 ? z[k - 1] : 0.0, zr = z[k];
     double cp[kChunk], dp[kChunk];
     // Thomas on the interior rows 0 .. m-2 with the two boundary values moved to the right-hand side
 #pragma unroll
@@ -499,6 +543,11 @@ __device__ __forceinline__ void tri_backsub_chunk(const Src &src, int64_t n, con
             yn = (i == m - 2) ? dp[i] : dp[i] - cp[i] * yn;
             y.put(s + i, yn);
         }
+}
+template <typename Src, typename Out>
+__device__ __forceinline__ void tri_backsub_chunk(const Src &src, int64_t n, const double *__restrict__ z, int64_t k, const Out &y)
+{
+    tri_backsub_chunk_v(src, n, k > 0 ? z[k - 1] : 0.0, z[k], k, y);
 }
 // rows fetched through LDS (see k_tri_reduce); the solution leaves through LDS too, with dense stores
 template <typename Src, typename OutT>
@@ -545,6 +594,323 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub_csc(SrcUser src, int64_t
         const int r = j * kBlock + (int)threadIdx.x;
         if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[r + (r >> 3)];
     }
+}
+
+// ---- Two levels per launch (one right-hand side) ----------------------------------------------------------------------------
+// The reduction of a level writes 12 doubles per chunk and the next level's reads them back: at N = 10^7 that is 120 MB out and in
+// again between levels 0 and 1, and seven launches of ~7 us each further up (profiles/r05_h_solve_trace.md).  Here a workgroup
+// reduces its tile of 2048 rows to 256 chunk summaries IN LDS, forms the 256 rows of the next level from them (the row of a
+// tile's last chunk needs the first-row equation of the NEXT tile's first chunk: those 8 rows are fetched as a halo, one value
+// per lane, and reduced by one thread), and 32 threads reduce these to 32 summaries two levels up -- the only thing written.
+// The back-substitution re-derives the summaries from the rows it fetches anyway (arithmetic instead of 240 MB of traffic),
+// solves the 256 middle-level rows in LDS with the 32 + 1 values from two levels up, then the tile's own rows.  The arithmetic
+// is the one-level kernels' (same chunk routines, same formulas): the solution has the same bits.
+constexpr int kSup = kBlock / kChunk;            // rows two levels up per tile
+constexpr int kSVals = 8;                        // of a summary's 12 values, the 8 one right-hand side uses
+template <int P> struct SumLds {                 // summary table in LDS: S[slot][chunk - k0], pitch P
+    double *S;
+    int64_t k0;
+    __device__ __forceinline__ void put(int v, int64_t k, double x) const { S[(v < 6 ? v : v - 2) * P + (int)(k - k0)] = x; }
+};
+template <int P> struct SrcLdsLevel {            // the rows those summaries define (SrcLevel::load on the table)
+    const double *S;
+    int64_t k0, nc;
+    template <int NRHS> __device__ __forceinline__ TriRow load(int64_t k) const
+    {
+        const int j = (int)(k - k0);
+        TriRow r;
+        r.a = S[0 * P + j];
+        const double be = S[1 * P + j], ce = S[2 * P + j];
+        if (k + 1 < nc) {
+            const double t = ce / S[5 * P + j + 1];
+            r.b = be - t * S[4 * P + j + 1];
+            r.c = -t * S[6 * P + j + 1];
+            r.d[0] = S[3 * P + j] - t * S[7 * P + j + 1];
+        } else {
+            r.b = be;
+            r.c = 0.0;
+            r.d[0] = S[3 * P + j];
+        }
+        r.d[1] = r.d[2] = 0.0;
+        return r;
+    }
+    template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t k) const { return load<NRHS>(k); }
+};
+template <int P> struct TriLdsZ {                // a level's unknowns of one tile: Z[1 + (i - k0)] (Z[0]: the one before the tile)
+    double *Z;
+    int64_t k0;
+    __device__ __forceinline__ void put(int64_t i, double v) const { Z[1 + (int)(i - k0)] = v; }
+};
+// the halo: lane t < 32 holds coefficient t / 8 of row rowh + t % 8 (issued before the tile's loads, consumed after them)
+template <typename Src> __device__ __forceinline__ double tri_halo_issue(const Src &src, int64_t n, int64_t rowh)
+{
+    const int64_t i = rowh + (threadIdx.x & 7);
+    return src.raw((threadIdx.x >> 3) & 3, i < n ? i : n - 1);
+}
+template <typename Src> __device__ __forceinline__ void tri_halo_store(const Src &src, int64_t n, int64_t rowh, double hv, double *halo)
+{
+    const int64_t i = rowh + (threadIdx.x & 7);
+    if (threadIdx.x < 32) halo[threadIdx.x] = i < n ? src.fix((threadIdx.x >> 3) & 3, i, hv) : 0.0;
+}
+// A workgroup owns `tpb` CONSECUTIVE tiles and keeps the next tile's loads in flight (registers) while it works on the current one:
+// the three dependent stages of a tile (chunks, middle level, store) would otherwise leave the memory pipe idle most of a
+// workgroup's life (measured without: 91 + 105 us for the two level-0 launches -- no faster than four one-level launches).
+// The reduction walks its tiles from the last to the first: the halo of tile i is chunk 0 of tile i + 1, reduced one iteration
+// earlier by thread 0 -- kept in LDS and published (hsum: 4 doubles per tile) for the back-substitution.  Only a workgroup's
+// first iteration fetches and reduces a real halo.
+// The arithmetic of the two-level kernels.  The one-level kernels above spend ~45 instructions per row (two IEEE divisions of ~14
+// instructions each, every step under an `i < m` branch) and are, at ~1000 instructions per thread, already close to issue-bound;
+// two levels per launch with the same routines measured NO faster than four launches (instruction issue, not memory).  Here:
+//   * one reciprocal per row (v_rcp_f64 + two Newton steps: ~1 ulp), shared by the downward sweep, the upward sweep and the
+//     back-substitution; explicit fused multiply-adds (the solver has no bit-for-bit reference: LinearAlgebra pivots);
+//   * chunks are always 8 rows: rows past the level's end are identity rows (the system extended by y = 0 unknowns), so no step
+//     is conditional.
+// The sweep works IN PLACE on the rows in registers: a becomes the coupling f to the unknown before the chunk, b its RECIPROCAL;
+// what is left is exactly what the back-substitution needs -- no second elimination.
+__device__ __forceinline__ double tri_rcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+struct SumNone {
+    __device__ __forceinline__ void put(int, int64_t, double) const {}
+};
+__device__ __forceinline__ void tri_pad_rows(SrcRegs<1> &R, int64_t n, int64_t k)
+{
+    const int64_t s = k * kChunk;
+    if (s + kChunk > n) {                                 // (the level's last chunk only)
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i)
+            if (s + i >= n) { R.a[i] = 0; R.b[i] = 1; R.c[i] = 0; R.d[0][i] = 0; }
+    }
+}
+template <typename Sink> __device__ __forceinline__ void tri_sweep(SrcRegs<1> &R, const Sink &sink, int64_t k)
+{
+    const double b0 = R.b[0];
+    double bl = b0;
+    R.b[0] = tri_rcp(b0);
+#pragma unroll
+    for (int i = 1; i < kChunk; ++i) {
+        const double mult = R.a[i] * R.b[i - 1];
+        R.a[i] = -mult * R.a[i - 1];
+        bl = __builtin_fma(-mult, R.c[i - 1], R.b[i]);
+        R.d[0][i] = __builtin_fma(-mult, R.d[0][i - 1], R.d[0][i]);
+        R.b[i] = tri_rcp(bl);
+    }
+    sink.put(0, k, R.a[kChunk - 1]);
+    sink.put(1, k, bl);
+    sink.put(2, k, R.c[kChunk - 1]);
+    sink.put(3, k, R.d[0][kChunk - 1]);
+    // upward: the first row expressed through the unknown before the chunk (f) and the chunk's last unknown (g)
+    double cf = R.a[kChunk - 2], cg = R.c[kChunk - 2], cd = R.d[0][kChunk - 2], cr = R.b[kChunk - 2];
+#pragma unroll
+    for (int i = kChunk - 3; i >= 0; --i) {
+        const double mult = R.c[i] * cr;
+        cf = __builtin_fma(-mult, cf, R.a[i]);
+        cg = -mult * cg;
+        cd = __builtin_fma(-mult, cd, R.d[0][i]);
+        cr = R.b[i];
+    }
+    sink.put(6, k, cf);
+    sink.put(7, k, b0);
+    sink.put(8, k, cg);
+    sink.put(9, k, cd);
+}
+// the chunk's unknowns from its swept rows  f_i zl + y_i / r_i + c_i y_{i+1} = d_i  and its last unknown zr
+template <typename Out>
+__device__ __forceinline__ void tri_backsub_swept(const SrcRegs<1> &R, double zl, double zr, int64_t k, const Out &y)
+{
+    const int64_t s = k * kChunk;
+    double yn = zr;
+    y.put(s + kChunk - 1, zr);
+#pragma unroll
+    for (int i = kChunk - 2; i >= 0; --i) {
+        yn = __builtin_fma(-R.c[i], yn, __builtin_fma(-R.a[i], zl, R.d[0][i])) * R.b[i];
+        y.put(s + i, yn);
+    }
+}
+// the 8 rows of chunk k2 of the middle level, from the summary table of the tile (SrcLevel::load's formulas)
+template <int P> __device__ __forceinline__ void tri_level_rows(const double *S, int64_t k0, int64_t nc, int64_t k2, SrcRegs<1> &R)
+{
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) {
+        const int64_t k = k2 * kChunk + i;
+        const int j = (int)(k - k0);
+        if (k < nc) {
+            const bool nxt = k + 1 < nc;
+            const double t = nxt ? S[2 * P + j] * tri_rcp(S[5 * P + j + 1]) : 0.0;
+            R.a[i] = S[0 * P + j];
+            R.b[i] = __builtin_fma(-t, nxt ? S[4 * P + j + 1] : 0.0, S[1 * P + j]);
+            R.c[i] = nxt ? -t * S[6 * P + j + 1] : 0.0;
+            R.d[0][i] = __builtin_fma(-t, nxt ? S[7 * P + j + 1] : 0.0, S[3 * P + j]);
+        } else {
+            R.a[i] = 0; R.b[i] = 1; R.c[i] = 0; R.d[0][i] = 0;
+        }
+    }
+}
+template <typename Src, bool CSC> struct TriTileLoads;
+template <typename Src> struct TriTileLoads<Src, false> {
+    TriLoads<Src, 1> L;
+    __device__ __forceinline__ void issue(const Src &src, int64_t n, int64_t row0) { tri_issue_rows<Src, 1>(src, n, row0, L); }
+    __device__ __forceinline__ void land(const Src &src, int64_t n, int64_t row0, double *lds, SrcRegs<1> &R) { tri_land_rows<Src, 1>(src, n, row0, L, lds, R); }
+};
+template <> struct TriTileLoads<SrcUser, true> {
+    TriLoadsCsc L;
+    __device__ __forceinline__ void issue(const SrcUser &src, int64_t n, int64_t row0) { tri_issue_rows_csc(src, n, row0, L); }
+    __device__ __forceinline__ void land(const SrcUser &src, int64_t n, int64_t row0, double *lds, SrcRegs<1> &R) { tri_land_rows_csc<1>(src, n, row0, L, lds, R); }
+};
+template <typename Src, bool CSC>
+__global__ void __launch_bounds__(kBlock, 2) k_tri_reduce2(Src src, int64_t n, int64_t nc1, double *__restrict__ sum2, int64_t nc2,
+                                                        double *__restrict__ hsum, int ntiles, int tpb)
+{
+    constexpr int P = kBlock + 1;
+    __shared__ double lds[CSC ? kTriRawSlots : kTriPitch];
+    __shared__ double halo[32];
+    __shared__ double nexts[4];
+    static_assert(kSVals * P <= kTriPitch, "the summary table reuses the fetch buffer");
+    const int t_lo = (int)blockIdx.x * tpb, t_hi = t_lo + tpb < ntiles ? t_lo + tpb : ntiles;
+    int tile = t_hi - 1;
+    const double hv = tri_halo_issue(src, n, (int64_t)(tile + 1) * kTriTileRows);
+    TriTileLoads<Src, CSC> G;
+    G.issue(src, n, (int64_t)tile * kTriTileRows);
+    for (bool first = true; tile >= t_lo; --tile, first = false) {
+        const int64_t row0 = (int64_t)tile * kTriTileRows, k0 = (int64_t)tile * kBlock;
+        SrcRegs<1> R;
+        G.land(src, n, row0, lds, R);
+        if (tile > t_lo) G.issue(src, n, row0 - kTriTileRows);
+        if constexpr (Src::kUnitRhs) tri_guard_rows<1>(R, n, row0, src.nd_flag);
+        if (first) tri_halo_store(src, n, row0 + kTriTileRows, hv, halo);
+        __syncthreads();                                  // every thread has copied the last array out of the buffer
+        const SumLds<P> S{lds, k0};
+        const int64_t k = k0 + threadIdx.x;
+        if (k < nc1) {
+            tri_pad_rows(R, n, k);
+            tri_sweep(R, S, k);
+        }
+        if (first) {
+            if (threadIdx.x == kBlock - 1 && k0 + kBlock < nc1) {        // the halo chunk (R is free again)
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) { R.a[i] = halo[i]; R.b[i] = halo[8 + i]; R.c[i] = halo[16 + i]; R.d[0][i] = halo[24 + i]; }
+                tri_pad_rows(R, n, k0 + kBlock);
+                tri_sweep(R, S, k0 + kBlock);
+            }
+        } else if (threadIdx.x < 4) {
+            lds[(4 + threadIdx.x) * P + kBlock] = nexts[threadIdx.x];      // chunk 0 of the tile after this one (previous iteration)
+        }
+        __syncthreads();
+        const int64_t k2 = (int64_t)tile * kSup + threadIdx.x;
+        if (threadIdx.x < kSup && k2 < nc2) {
+            tri_level_rows<P>(lds, k0, nc1, k2, R);
+            tri_sweep(R, SumGlobal{sum2, nc2}, k2);
+        }
+        double mine = 0.0;
+        if (threadIdx.x < 4) mine = lds[(4 + threadIdx.x) * P];             // this tile's chunk 0: its first-row equation
+        __syncthreads();                                  // the table has been read: the next tile may land in the buffer
+        if (threadIdx.x < 4) {
+            nexts[threadIdx.x] = mine;
+            hsum[(int64_t)tile * 4 + threadIdx.x] = mine;
+        }
+    }
+}
+template <typename Src, bool CSC, typename OutT>
+__global__ void __launch_bounds__(kBlock, 2) k_tri_backsub2(Src src, int64_t n, int64_t nc1, const double *__restrict__ z2, int64_t nc2,
+                                                         OutT *__restrict__ y, const double *__restrict__ hsum, int ntiles, int tpb)
+{
+    constexpr int P = kBlock + 1;
+    constexpr int kFetch = CSC ? kTriRawSlots : kTriPitch;
+    constexpr int kZOff = kSVals * P, kOutOff = (kZOff + P + 7) / 8 * 8;
+    constexpr int kLds = kFetch > kOutOff + kTriPitch ? kFetch : kOutOff + kTriPitch;
+    __shared__ double lds[kLds];
+    bool poison = false;
+    if constexpr (Src::kUnitRhs) poison = src.refuse && src.nd_flag && *src.nd_flag != 0;      // (the reduction has checked every row)
+    // (tiles first to last: the reduction read a workgroup's tiles last to first just before, the front is what the caches hold)
+    const int t_lo = (int)blockIdx.x * tpb, t_hi = t_lo + tpb < ntiles ? t_lo + tpb : ntiles;
+    const int lane2 = threadIdx.x & (kSup - 1);
+    TriTileLoads<Src, CSC> G;
+    double zl_n, zr_n, hs_n;
+    auto issue = [&](int t) {
+        const int64_t k2 = (int64_t)t * kSup + lane2, k2c = k2 < nc2 ? k2 : nc2 - 1;
+        zr_n = z2[k2c];
+        zl_n = z2[k2c > 0 ? k2c - 1 : 0];
+        hs_n = hsum[(int64_t)(t + 1 < ntiles ? t + 1 : t) * 4 + (threadIdx.x & 3)];
+        G.issue(src, n, (int64_t)t * kTriTileRows);
+    };
+    issue(t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int64_t row0 = (int64_t)tile * kTriTileRows, k0 = (int64_t)tile * kBlock;
+        const double zl2 = zl_n, zr2 = zr_n, hs = hs_n;
+        SrcRegs<1> R;
+        G.land(src, n, row0, lds, R);
+        __syncthreads();
+        const SumLds<P> S{lds, k0};
+        const int64_t k = k0 + threadIdx.x;
+        if (k < nc1) {
+            tri_pad_rows(R, n, k);
+            tri_sweep(R, S, k);
+        }
+        if (threadIdx.x < 4) lds[(4 + threadIdx.x) * P + kBlock] = hs;      // chunk 0 of the next tile (from the reduction)
+        __syncthreads();
+        double *Z = lds + kZOff;
+        const int64_t k2 = (int64_t)tile * kSup + threadIdx.x;
+        if (threadIdx.x < kSup && k2 < nc2) {
+            SrcRegs<1> R2;
+            tri_level_rows<P>(lds, k0, nc1, k2, R2);
+            tri_sweep(R2, SumNone{}, k2);
+            tri_backsub_swept(R2, k2 > 0 ? zl2 : 0.0, zr2, k2, TriLdsZ<P>{Z, k0});
+        }
+        if (threadIdx.x == 0) Z[0] = k2 > 0 ? zl2 : 0.0;  // the unknown before the tile = the last unknown of the chunk before
+        if (tile + 1 < t_hi) issue(tile + 1);             // (not earlier: the middle level's rows need the registers)
+        __syncthreads();
+        if (k < nc1) tri_backsub_swept(R, Z[threadIdx.x], Z[threadIdx.x + 1], k, TriLdsOut{lds + kOutOff, row0});
+        __syncthreads();
+        const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            const int r = j * kBlock + (int)threadIdx.x;
+            if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[kOutOff + r + (r >> 3)];
+        }
+        __syncthreads();                                  // the tile has left the buffer: the next one may land
+    }
+}
+// The top of the two-level schedule: a level of at most kTop2 rows, one workgroup: a chunk per thread -> <= 512 rows -> parallel
+// cyclic reduction -> the chunks' rows.  (Rows come straight from the summaries below: a few thousand rows, latency not bandwidth.)
+constexpr int kTop2Block = 512;
+constexpr int kTop2 = kTop2Block * kChunk;
+__global__ void __launch_bounds__(kTop2Block) k_tri_top2(SrcLevel src, int n, double *__restrict__ sol)
+{
+    constexpr int P = kTop2Block + 1;
+    __shared__ double S[kSVals * P];
+    __shared__ double A[2][kTop2Block], B[2][kTop2Block], Cc[2][kTop2Block], D[2][kTop2Block];
+    __shared__ double Z[P];
+    const int k = threadIdx.x, nc = (n + kChunk - 1) / kChunk;
+    if (k < nc) tri_reduce_chunk<SrcLevel, 1>(src, n, SumLds<P>{S, 0}, k);
+    __syncthreads();
+    if (k < nc) {
+        const TriRow r = SrcLdsLevel<P>{S, 0, nc}.load<1>(k);
+        A[0][k] = r.a; B[0][k] = r.b; Cc[0][k] = r.c; D[0][k] = r.d[0];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int st = 1; st < nc; st <<= 1) {
+        const int nxt = cur ^ 1;
+        if (k < nc) {
+            const bool hl = k - st >= 0, hr = k + st < nc;
+            const double k1 = hl ? A[cur][k] / B[cur][k - st] : 0.0, kk2 = hr ? Cc[cur][k] / B[cur][k + st] : 0.0;
+            A[nxt][k] = hl ? -A[cur][k - st] * k1 : 0.0;
+            Cc[nxt][k] = hr ? -Cc[cur][k + st] * kk2 : 0.0;
+            B[nxt][k] = B[cur][k] - (hl ? Cc[cur][k - st] * k1 : 0.0) - (hr ? A[cur][k + st] * kk2 : 0.0);
+            D[nxt][k] = D[cur][k] - (hl ? D[cur][k - st] * k1 : 0.0) - (hr ? D[cur][k + st] * kk2 : 0.0);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    if (k < nc) Z[1 + k] = D[cur][k] / B[cur][k];
+    if (k == 0) Z[0] = 0.0;
+    __syncthreads();
+    if (k < nc) tri_backsub_chunk_v(src, n, Z[k], Z[k + 1], k, TriGlobalOut<double>{sol});
 }
 
 // Phase A epilogue: the six tip values (first / last local row of g, v, w).  The last row is the last unknown of every
@@ -668,6 +1034,7 @@ struct fd_tridiag_solver {
     int64_t lev_n[fdjac::kMaxLevels] = {0};
     double *lev_sum[fdjac::kMaxLevels] = {nullptr};   // summary written by level l's reduction (level nlev-1 has none)
     double *lev_sol[fdjac::kMaxLevels] = {nullptr};   // solution of level l >= 1 (3 columns at the top level)
+    double *lev_halo[fdjac::kMaxLevels] = {nullptr};  // two levels per launch: chunk 0's first-row equation of every tile of level l (4 doubles)
     double *packets = nullptr;                        // kMaxRanks x kPacket (the all-gather buffer)
     double *adj = nullptr, *cpl = nullptr, *work = nullptr;
     int *status = nullptr;                            // device word: bit 0 = the last solve met a row that is not diagonally dominant
@@ -713,6 +1080,66 @@ template <int NRHS> static int tri_reduce_all(fd_tridiag_solver *s, const SrcUse
     else
         hipLaunchKernelGGL((k_tri_top<SrcLevel, NRHS>), dim3(1), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[top - 1], s->lev_n[top]},
                            (int)s->lev_n[top], s->lev_sol[top]);
+    FD_HIP_CHECK(hipGetLastError());
+    return FD_OK;
+}
+
+// One right-hand side: levels `from` and up two per launch (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2), the levels below one per
+// launch.  Measured at N = 10^7 (profiles/r05_p_solve.md): the five small levels (seven ~7 us launches, 56 us) become three
+// launches (39 us) either way.  The two big levels: the two-level kernels move 2/3 of the bytes but, with a tile being worked on
+// and one in flight in 256 registers, only two workgroups fit a compute unit -- 3.9 TB/s against the one-level kernels' 5.8:
+// diagonals 84 + 87 us against 90 + 90 (from = 0 wins: 213 us against 231 / 245), CSC 82 + 162 us (the back-substitution
+// spills) against 88 + 88 (from = 2 wins: 221 us against 288 / 236).
+static int tri_two_level_from(const fd_tridiag_solver *s)
+{
+    const char *e = fdjac::test_switch("FDJAC_SOLVE_TWO_LEVEL");      // -1: never, 0 / 2: from that level
+    const int from = (e && *e) ? atoi(e) : s->layout == FD_TRI_CSC ? 2 : 0;
+    return (from == 0 || from == 2) && from + 2 < s->nlev && s->lev_n[from] > kTop2 ? from : -1;
+}
+static int tri_solve_two_level(fd_tridiag_solver *s, const SrcUser &u, real_t *y, int from)
+{
+    hipStream_t st = s->ctx->stream;
+    const bool csc = u.layout == FD_TRI_CSC;
+    // tiles per workgroup: about two workgroups per compute unit in flight (their registers hold a tile being worked on and one in flight)
+    const char *tp = fdjac::test_switch("FDJAC_SOLVE_TPB");
+    const int tp_forced = (tp && *tp) ? atoi(tp) : 0;
+    auto tiles_per_block = [&](int ntiles) { const int want = 2 * s->ctx->num_cus; return tp_forced > 0 ? tp_forced : (ntiles + want - 1) / want; };
+    for (int l = 0; l < from; ++l) {                      // one level per launch
+        const int64_t nc = s->lev_n[l + 1];
+        const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_reduce_csc<1>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sum[0], nc);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_reduce<SrcUser, 1>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sum[0], nc);
+        else hipLaunchKernelGGL((k_tri_reduce<SrcLevel, 1>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]}, s->lev_n[l], s->lev_sum[l], nc);
+    }
+    int l = from;
+    for (; s->lev_n[l] > kTop2; l += 2) {                 // (levels l + 1, l + 2 exist: the schedule runs down to <= kTop < kTop2 / 8)
+        const int64_t n = s->lev_n[l], nc1 = s->lev_n[l + 1], nc2 = s->lev_n[l + 2];
+        const int ntiles = (int)((nc1 + kBlock - 1) / kBlock), tpb = tiles_per_block(ntiles);
+        const unsigned g = (unsigned)((ntiles + tpb - 1) / tpb);
+        double *hs = s->lev_halo[l];
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, true>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs, ntiles, tpb);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, false>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs, ntiles, tpb);
+        else hipLaunchKernelGGL((k_tri_reduce2<SrcLevel, false>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sum[l + 1], nc2, hs, ntiles, tpb);
+    }
+    const SrcLevel top{s->lev_sum[l - 1], s->lev_n[l]};
+    if (s->lev_n[l] <= kTop) hipLaunchKernelGGL((k_tri_top<SrcLevel, 1>), dim3(1), dim3(kBlock), 0, st, top, (int)s->lev_n[l], s->lev_sol[l]);
+    else hipLaunchKernelGGL(k_tri_top2, dim3(1), dim3(kTop2Block), 0, st, top, (int)s->lev_n[l], s->lev_sol[l]);
+    for (l -= 2; l >= from; l -= 2) {
+        const int64_t n = s->lev_n[l], nc1 = s->lev_n[l + 1], nc2 = s->lev_n[l + 2];
+        const int ntiles = (int)((nc1 + kBlock - 1) / kBlock), tpb = tiles_per_block(ntiles);
+        const unsigned g = (unsigned)((ntiles + tpb - 1) / tpb);
+        const double *hs = s->lev_halo[l];
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, true, real_t>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs, ntiles, tpb);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, false, real_t>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs, ntiles, tpb);
+        else hipLaunchKernelGGL((k_tri_backsub2<SrcLevel, false, double>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sol[l + 2], nc2, s->lev_sol[l], hs, ntiles, tpb);
+    }
+    for (l = from - 1; l >= 0; --l) {                     // one level per launch
+        const int64_t nc = s->lev_n[l + 1];
+        const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_backsub_csc<real_t>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sol[1], nc, y);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_backsub<SrcUser, real_t>), dim3(g), dim3(kBlock), 0, st, u, s->lev_n[0], s->lev_sol[1], nc, y);
+        else hipLaunchKernelGGL((k_tri_backsub<SrcLevel, double>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], s->lev_n[l]}, s->lev_n[l], s->lev_sol[l + 1], nc, s->lev_sol[l]);
+    }
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
@@ -773,6 +1200,8 @@ int fd_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t 
         ok = hipMalloc((void **)&s->lev_sum[k], sizeof(double) * (size_t)kSumVals * (size_t)s->lev_n[k + 1]) == hipSuccess;
     for (int k = (s->nlev > 1 ? 1 : 0); k < s->nlev && ok; ++k)
         ok = hipMalloc((void **)&s->lev_sol[k], sizeof(double) * 3 * (size_t)s->lev_n[k]) == hipSuccess;
+    for (int k = 0; k + 2 < s->nlev && ok; ++k)
+        ok = hipMalloc((void **)&s->lev_halo[k], sizeof(double) * 4 * (size_t)((s->lev_n[k + 1] + kBlock - 1) / kBlock)) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->packets, sizeof(double) * kPacket * kMaxRanks) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->adj, sizeof(double) * 2) == hipSuccess;
     ok = ok && hipMalloc((void **)&s->cpl, sizeof(double) * 2) == hipSuccess;
@@ -813,6 +1242,7 @@ int fd_tridiag_solver_destroy(fd_tridiag_solver *s)
     for (int k = 0; k < kMaxLevels; ++k) {
         if (s->lev_sum[k]) (void)hipFree(s->lev_sum[k]);
         if (s->lev_sol[k]) (void)hipFree(s->lev_sol[k]);
+        if (s->lev_halo[k]) (void)hipFree(s->lev_halo[k]);
     }
     for (void *p : {(void *)s->packets, (void *)s->adj, (void *)s->cpl, (void *)s->work, (void *)s->status})
         if (p) (void)hipFree(p);
@@ -825,6 +1255,7 @@ static int tri_local_solve(fd_tridiag_solver *s, double alpha, double beta, cons
                            const double *adj, void *y)
 {
     const SrcUser u = make_src(s, alpha, beta, J, rhs, adj);
+    if (const int from = tri_two_level_from(s); from >= 0) return tri_solve_two_level(s, u, (real_t *)y, from);
     int rc = tri_reduce_all<1>(s, u);
     if (rc) return rc;
     if (s->nlev == 1) {

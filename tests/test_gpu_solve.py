@@ -93,6 +93,37 @@ def test_tridiagonal_solve_matches_scipy(layout, N):
 
 
 @pytest.mark.parametrize("layout", ["diagonals", "csc"])
+@pytest.mark.parametrize("N", [4097, 4104, 4105, 16384, 16385, 16392, 16393, 32768 + 9, 131072, 131073, 262144, 262145, 262152, 262153, 262209,
+                               2 ** 21 + 65, 10 ** 6 + 3, 16777216 + 520])
+@pytest.mark.parametrize("start", ["0", "2"])
+def test_two_levels_per_launch_against_one_level_per_launch(layout, N, start, monkeypatch):
+    # the default schedule (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2: two levels per launch, the middle level only in LDS, persistent
+    # workgroups) against the one-level kernels: the same reduction (same bits up to the top), a back-substitution from the swept rows
+    # instead of a second elimination -- rounding-level differences only; sizes around tile (2048 rows), halo (8 rows), 64:1, top (4096)
+    # and tiles-per-workgroup boundaries
+    dl, d, du, b, alpha, beta = _system(N, 300 + N % 1000)
+    J = fd.Tridiagonal(_dev(dl), _dev(d), _dev(du)) if layout == "diagonals" else [_dev(_csc_nzval_fast(dl, d, du))]
+    bd = _dev(b)
+    solver = fd.TridiagSolver(N, layout)
+    monkeypatch.setenv("FDJAC_SOLVE_TWO_LEVEL", start)      # two levels per launch from level 0 (everything) / 2 (the default)
+    y2 = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+    solver.solve(J, bd, y2, alpha, beta)
+    monkeypatch.setenv("FDJAC_SOLVE_TWO_LEVEL", "-1")
+    y1 = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+    solver.solve(J, bd, y1, alpha, beta)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(y1).any()) and not bool(torch.isnan(y2).any())
+    assert float((y1 - y2).abs().max()) <= 1e-13 * max(1.0, float(y1.abs().max()))
+    y3 = torch.full_like(y2, float("nan"))
+    monkeypatch.setenv("FDJAC_SOLVE_TWO_LEVEL", start)
+    solver.solve(J, bd, y3, alpha, beta)
+    assert torch.equal(y3, y2)                            # run to run: the same bits
+    if N <= 3 * 10 ** 6:
+        want = _reference(dl, d, du, b, alpha, beta)
+        assert np.max(np.abs(y2.cpu().numpy() - want)) <= 1e-11 * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize("layout", ["diagonals", "csc"])
 @pytest.mark.parametrize("N,W", [(40, 2), (1000, 3), (5003, 8), (300007, 4), (10 ** 6 + 1, 8), (17, 8)])
 def test_sharded_solve_equals_global_solve(layout, N, W):
     # each "rank" owns a column range and holds only its slice of J (as the column-window Jacobian plans leave it),
