@@ -75,7 +75,7 @@ __device__ inline uint64_t fp_quads32(const int32_t *__restrict__ a, long long i
     const long long nquads = n / 4;               // whole quads; the tail (n mod 4 elements = up to 2 pairs) is added by the caller
     uint64_t s = 0, kK = (uint64_t)(2 * q0) * kFpK;
     const uint64_t dK = (uint64_t)(2 * stride) * kFpK;
-    constexpr int U = 4;
+    constexpr int U = 8;
     typedef int fp_i4 __attribute__((ext_vector_type(4)));
     long long q = q0;
     for (; q + (U - 1) * stride < nquads; q += U * stride) {
@@ -128,9 +128,12 @@ template <typename IT> __global__ void __launch_bounds__(256) k_fingerprint(cons
 }
 
 // fd_plan_matches_async: the three arrays in ONE launch -- workgroups [0, g0) fingerprint array 0, [g0, g0 + g1) array 1, the rest
-// array 2 -- and the verdict on the device: the workgroup that arrives last (agent-scope ticket) compares the three sums with the
-// plan's words fpx[3..5] and raises the two sticky stale words (pinned host memory); then it clears the accumulators and the ticket
-// for the next check.  No copy back, no synchronisation.
+// array 2 -- and the verdict on the device.  Every workgroup stores its sum in its own slot and takes a ticket of its GROUP (32
+// groups, a line each: thousands of arrivals on ONE address were what the first version of this kernel spent its time on); the last
+// arrival of a group takes the final ticket, the last of those adds the slots per array, compares with the plan's words fpx[3..5]
+// and raises the two sticky stale words (pinned host memory).  No copy back, no synchronisation.  Layout of fpx (8-byte words):
+// [3..5] the plan's fingerprints, [6] final ticket, [kFpGroup0 + 16 g] ticket of group g, [kFpPart0 + b] sum of workgroup b.
+constexpr int kFpGroups = 32, kFpGroup0 = 16, kFpPart0 = kFpGroup0 + 16 * kFpGroups;
 struct Fp3 {
     const void *a[3];
     int bytes[3];
@@ -146,21 +149,43 @@ __global__ void __launch_bounds__(256) k_fingerprint3_check(Fp3 f, unsigned long
                                  : fp_pairs_any<int32_t>((const int32_t *)f.a[k], f.i0[k], n, f.base[k], k0, stride);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down((unsigned long long)s, o, 64);
-    __shared__ uint64_t s_w[4];
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __shared__ uint64_t s_w[4][3];
+    __shared__ int s_last;
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][0] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(fpx + kFpPart0 + blockIdx.x, (unsigned long long)(s_w[0][0] + s_w[1][0] + s_w[2][0] + s_w[3][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot is out before the ticket is taken
+        const int G = (int)gridDim.x < kFpGroups ? (int)gridDim.x : kFpGroups, grp = (int)blockIdx.x % G;
+        const unsigned long long in_group = ((unsigned long long)gridDim.x - grp + G - 1) / G;
+        int last = 0;
+        if (__hip_atomic_fetch_add(fpx + kFpGroup0 + 16 * grp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1) {
+            __hip_atomic_store(fpx + kFpGroup0 + 16 * grp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(fpx + 6, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)G - 1) {
+                __hip_atomic_store(fpx + 6, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    uint64_t t[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        const unsigned long long v = __hip_atomic_load(fpx + kFpPart0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t[i < f.g[0] ? 0 : i < f.g[0] + f.g[1] ? 1 : 2] += v;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t[q] += __shfl_down((unsigned long long)t[q], o, 64);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][q] = t[q];
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    __hip_atomic_fetch_add(fpx + k, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long t = __hip_atomic_fetch_add(fpx + 6, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t != (unsigned long long)gridDim.x - 1) return;
     bool same = true;
-    for (int q = 0; q < 3; ++q) {
-        const unsigned long long got = __hip_atomic_load(fpx + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f.g[q] > 0 && got != fpx[3 + q]) same = false;
-        __hip_atomic_store(fpx + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __hip_atomic_store(fpx + 6, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = 0; q < 3; ++q)
+        if (f.g[q] > 0 && s_w[0][q] + s_w[1][q] + s_w[2][q] + s_w[3][q] != fpx[3 + q]) same = false;
     if (!same) {
         __hip_atomic_store(stale_plan, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(stale_ctx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -224,7 +249,7 @@ extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const
     FD_HIP_CHECK(hipMemsetAsync(acc_dev, 0, 3 * sizeof(unsigned long long), s));
     for (int k = 0; k < 3; ++k) {
         if (!(a[k] && n[k] > 0)) continue;
-        const int64_t blocks = std::min<int64_t>((n[k] + 255) / 256, (int64_t)ctx->num_cus * 8);
+        const int64_t blocks = std::min<int64_t>((n[k] + 255) / 256, (int64_t)ctx->num_cus * 2);      // (see fdjac_fingerprint3_check)
         if (bytes[k] == 8)
             hipLaunchKernelGGL((k_fingerprint<int64_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const int64_t *)a[k], i0[k], n[k], base[k], acc_dev + k);
         else
@@ -239,18 +264,27 @@ extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const
 }
 
 // the fused check (see k_fingerprint3_check): expected words already in fpx[3..5]
+static int fp3_blocks_per_cu()
+{
+    const char *fb = fdjac::test_switch("FDJAC_FP_BLOCKS");
+    const int v = (fb && *fb) ? atoi(fb) : 4;
+    return v < 1 ? 1 : v > 16 ? 16 : v;
+}
+extern "C" size_t fdjac_fingerprint3_check_words(const fd_ctx *ctx) { return (size_t)kFpPart0 + (size_t)ctx->num_cus * 16 + 8; }
 extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n, const int64_t *base,
                                         unsigned long long *fpx, int *stale_plan, int *stale_ctx)
 {
     Fp3 f;
     int total = 0;
-    // about 8 workgroups per CU in ALL (every workgroup ends in an arrival ticket on one address: thousands of them queue up there),
-    // shared out between the arrays by their bytes
+    // a few workgroups per CU in ALL, shared out between the arrays by their bytes.  (With ONE ticket and three accumulators on one
+    // line for all workgroups, N = 10^7 -- 200 MB of Int32 pattern -- took 48 / 44 / 47 / 53 / 70 / 112 us at 1 / 2 / 3 / 4 / 8 / 16
+    // workgroups per CU: the arrivals queued up; hence the slots and the group tickets.)
     double all_bytes = 0;
     for (int k = 0; k < 3; ++k) all_bytes += (a[k] && n[k] > 0) ? (double)n[k] * bytes[k] : 0.0;
+    const int per_cu = fp3_blocks_per_cu();
     for (int k = 0; k < 3; ++k) {
         f.a[k] = a[k]; f.bytes[k] = bytes[k]; f.i0[k] = i0[k]; f.n[k] = (a[k] && n[k] > 0) ? n[k] : 0; f.base[k] = base[k];
-        const int64_t share = f.n[k] > 0 ? (int64_t)((double)ctx->num_cus * 8 * ((double)f.n[k] * bytes[k] / all_bytes)) + 1 : 0;
+        const int64_t share = f.n[k] > 0 ? (int64_t)((double)ctx->num_cus * per_cu * ((double)f.n[k] * bytes[k] / all_bytes)) + 1 : 0;
         f.g[k] = f.n[k] > 0 ? (int)std::max<int64_t>(1, std::min<int64_t>((f.n[k] + 2047) / 2048, share)) : 0;
         total += f.g[k];
     }
@@ -265,6 +299,7 @@ extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const
                                   const int64_t *base, int memkind, unsigned long long *acc_dev, uint64_t *out);
 extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n, const int64_t *base,
                                         unsigned long long *fpx, int *stale_plan, int *stale_ctx);
+extern "C" size_t fdjac_fingerprint3_check_words(const fd_ctx *ctx);
 #endif
 
 namespace fdjac {
@@ -405,7 +440,9 @@ extern "C" int fd_plan_matches_async(fd_plan *p, const fd_pattern_arrays *now)
         FD_HIP_CHECK(hipHostMalloc((void **)&p->h_pstale, sizeof(int), hipHostMallocMapped));
         *p->h_pstale = 0;
         FD_HIP_CHECK(hipHostGetDevicePointer((void **)&p->d_pstale, p->h_pstale, 0));
-        FD_HIP_CHECK(hipMalloc((void **)&p->d_fpx, 8 * sizeof(unsigned long long)));
+        const size_t words = fdjac_fingerprint3_check_words(ctx);
+        FD_HIP_CHECK(hipMalloc((void **)&p->d_fpx, words * sizeof(unsigned long long)));
+        FD_HIP_CHECK(hipMemsetAsync(p->d_fpx, 0, words * sizeof(unsigned long long), ctx->stream));      // (tickets start at 0 and reset themselves)
         const unsigned long long init[8] = {0, 0, 0, fp.h_a, fp.h_b, fp.h_color, 0, 0};
         FD_HIP_CHECK(hipMemcpyAsync(p->d_fpx, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
         FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // (once per plan: `init` lives on this stack)
