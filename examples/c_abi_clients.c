@@ -154,6 +154,54 @@ static int client_csc(int fdtype)
                   fdtype == FD_FORWARD ? 4 : fdtype == FD_CENTRAL ? 6 : 3);
 }
 
+/* shim: make_plan(J::SparseMatrixCSC, ...; store_csc = true) with a residual of ANY pattern (fd_builtin_f_create_sparse): the column
+   store -- every stored entry evaluates its own row at the point perturbed in its column, differences, divides and stores, column
+   by column, in ONE launch after the step sizes -- for forward, central and the complex step (FD_LAZY_CAP_STORE_CSC_COMPLEX).
+   Pattern: column j holds rows j-5, j-2, j, j+3, j+7 (13 cyclic colours); f_r = sum_j w(r, j) (x_j + x_j^2 / 4). */
+static int client_csc_store_cols(int fdtype)
+{
+    const int64_t N = 20011, C = 13;
+    static const int64_t off[5] = {-5, -2, 0, 3, 7};
+    int64_t *colptr = malloc(sizeof(int64_t) * (size_t)(N + 1)), *rowval = malloc(sizeof(int64_t) * (size_t)(5 * N)), *colors = cyclic_colors(N, C);
+    int64_t p = 0;
+    for (int64_t j = 0; j < N; ++j) {
+        colptr[j] = p + 1;
+        for (int q = 0; q < 5; ++q)
+            if (j + off[q] >= 0 && j + off[q] < N) rowval[p++] = j + off[q] + 1;
+    }
+    colptr[N] = p + 1;
+    const int64_t nnz = p;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)nnz);
+    fd_f_launch f; void *fctx; fd_plan *plan;
+    CHECK(fd_builtin_f_create_sparse(g_ctx, N, N, colptr, rowval, 8, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype; o.flags = FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ALWAYS;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &plan));
+    CHECK(install_lazy(plan, fctx));
+    void *outs[3] = {nzd, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    int64_t table = 0, stored = 0;
+    CHECK(fd_plan_info(plan, FD_INFO_STORE_CSC, &table));
+    CHECK(fd_plan_info(plan, FD_INFO_LAZY_STORE, &stored));
+    double *nz = malloc(sizeof(double) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; ++q) {
+            const int64_t r = rowval[q] - 1;
+            const double want = (1.0 + 0.125 * (double)((r + 3 * j) % 8)) * (1.0 + 0.5 * x[j]);
+            const double d = fabs(nz[q] - want);
+            if (!(d <= worst)) worst = d;
+        }
+    if (!(table > 0 && stored == 1)) { printf("csc_store_cols: the column store did not run (table %lld, stored %lld)\n", (long long)table, (long long)stored); worst = NAN; }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(nzd); free(nz); free(x); free(colptr); free(rowval); free(colors);
+    const char *nm = fdtype == FD_FORWARD ? "cols/forward" : fdtype == FD_CENTRAL ? "cols/central" : "cols/complex";
+    return report(nm, worst, fdtype == FD_FORWARD ? 2e-6 : fdtype == FD_CENTRAL ? 2e-8 : 1e-13, calls,
+                  fdtype == FD_FORWARD ? 1 + C : fdtype == FD_CENTRAL ? 2 * C : C);
+}
+
 /* shim: DeviceF(src::String, functor, params) -> fd_f_compile_rows: the residual handed over as SOURCE, compiled by the library with
    hiprtc; make_plan(...; store_csc_always = true) + install of the compiled lazy launcher: the Jacobian is the step-size launch + ONE
    launch of the column store instantiated for the functor.  Checked against the analytic Jacobian and, bit for bit, against the
@@ -545,7 +593,7 @@ static int client_blockbanded(void)
    ext/FiniteDiffBlockBandedMatricesExt.jl:16-42 -- blocklengths, blockbandwidths, subblockbandwidths, and per in-band block the start
    of bandeddata(view(J, K, J)) in J.data with its column stride; no entry list.  The 2-D 5-point Laplacian on an nx x ny grid IS
    such a matrix: ny blocks of nx, block bandwidths (1, 1), sub-block bandwidths (1, 1). */
-static int client_bandedblockbanded(void)
+static int client_bandedblockbanded(int fdtype)
 {
     const int64_t nx = 64, ny = 50, nb = ny, N = nx * ny, bl = 1, bu = 1, lam = 1, mu = 1, w = bl + bu + 1, sw = lam + mu + 1, R = w * sw;
     int64_t *sizes = malloc(sizeof(int64_t) * (size_t)nb), *starts = calloc((size_t)(w * nb), sizeof(int64_t)), *strides = malloc(sizeof(int64_t) * (size_t)nb);
@@ -562,7 +610,7 @@ static int client_bandedblockbanded(void)
     fd_f_launch f; void *fctx; fd_plan *plan;
     const int64_t prm[2] = {nx, ny};
     CHECK(new_f(FD_F_LAP5, prm, 2, &f, &fctx));
-    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_CENTRAL;
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype;
     CHECK(fd_plan_create_bandedblockbanded(g_ctx, nb, sizes, bl, bu, lam, mu, starts, strides, len, 8, 1, colors, 8, &o, &plan));
     CHECK(install_lazy(plan, fctx));
     void *outs[3] = {dd, NULL, NULL};
@@ -587,10 +635,14 @@ static int client_bandedblockbanded(void)
                     const double e = fabs(got - want);
                     if (!(e <= worst)) worst = e;
                 }
+    /* uniform blocks + a valid colouring: f!, difference, division and the store into the slabs are ONE launch (fd_bbb_store) */
+    int64_t stored = 0;
+    CHECK(fd_plan_info(plan, FD_INFO_LAZY_STORE, &stored));
+    if (stored != 1) { printf("bandedblockbanded: the storing launch did not run\n"); worst = NAN; }
     const int64_t calls = f_points(fctx);
     CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
     hipFree(xd); hipFree(dd); free(data); free(x); free(sizes); free(starts); free(strides); free(colors);
-    return report("bandedblockbanded", worst, 1e-6, calls, 2 * 9);
+    return report(fdtype == FD_CENTRAL ? "bbb/central" : "bbb/forward", worst, 1e-6, calls, fdtype == FD_CENTRAL ? 2 * 9 : 1 + 9);
 }
 
 /* shim: the Float32 methods generated by the eltype loop: x::ROCVector{Float32} -> the fd32_* symbols */
@@ -1051,6 +1103,7 @@ int main(int argc, char **argv)
     int bad = 0, ran = 0;
 #define RUN(name, call) if (!strcmp(which, "all") || !strcmp(which, name)) { bad |= (call); ++ran; }
     RUN("csc", client_csc(FD_FORWARD) | client_csc(FD_CENTRAL) | client_csc(FD_COMPLEX))
+    RUN("csc_store_cols", client_csc_store_cols(FD_FORWARD) | client_csc_store_cols(FD_CENTRAL) | client_csc_store_cols(FD_COMPLEX))
     RUN("csc_device", client_csc_device())
     RUN("csc_dense", client_csc_dense())
     RUN("coo_dense", client_coo_dense())
@@ -1059,7 +1112,7 @@ int main(int argc, char **argv)
     RUN("tridiagonal", client_tridiagonal())
     RUN("banded", client_banded())
     RUN("blockbanded", client_blockbanded())
-    RUN("bandedblockbanded", client_bandedblockbanded())
+    RUN("bandedblockbanded", client_bandedblockbanded(FD_CENTRAL) | client_bandedblockbanded(FD_FORWARD))
     RUN("csc_f32", client_csc_f32())
     RUN("jvp", client_jvp())
     RUN("solve", client_solve())

@@ -1820,7 +1820,7 @@ static int builtin_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, i
             b->launches.fetch_add(1);
             // (f(x) of a forward difference: one plain launch, counted there -- or, FD_LAZY_CAP_STORE_CSC_BASE without f_in, formed
             //  inside this launch: counted with the first colour chunk)
-            const bool own_base = lp->pts == 1 && lp->store && !((const fd_csc_store *)lp->store)->fx_base && lp->c_lo == 0;
+            const bool own_base = lp->pts == 1 && !lp->is_complex && lp->store && !((const fd_csc_store *)lp->store)->fx_base && lp->c_lo == 0;
             b->points.fetch_add((int64_t)lp->ncolors * lp->pts + (own_base ? 1 : 0));
         }
         return rc;
