@@ -15,8 +15,8 @@
 // values.  No pivoting: the method is for diagonally dominant systems (I - gamma*J of a diffusion-type J), like the
 // partitioned / cyclic-reduction tridiagonal solvers of the vendor libraries.  Level 0 reads the user's J and b once
 // in the reduction and once in the back-substitution (9 values per row in total + 1 written).  Measured at N = 10^7 on
-// MI355X: 0.21 ms (Tridiagonal diagonals, 5 launches) / 0.22 ms (CSC nzval, 7 launches) per solve -- the small levels two per
-// launch (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2 below), profiles/r05_p_solve.md.
+// MI355X: 0.19 ms per solve, 5 launches -- two levels per launch (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2 below),
+// profiles/r05_p_solve.md.
 //
 // Multi-GPU (rows = the rank's column range): the rank's block T_r of the matrix is complete in its own slice; the two
 // couplings to the neighbouring ranks are not (they live in the neighbours' columns).  SPIKE form:
@@ -597,44 +597,24 @@ __global__ void __launch_bounds__(kBlock) k_tri_backsub_csc(SrcUser src, int64_t
 }
 
 // ---- Two levels per launch (one right-hand side) ----------------------------------------------------------------------------
-// The reduction of a level writes 12 doubles per chunk and the next level's reads them back: at N = 10^7 that is 120 MB out and in
-// again between levels 0 and 1, and seven launches of ~7 us each further up (profiles/r05_h_solve_trace.md).  Here a workgroup
-// reduces its tile of 2048 rows to 256 chunk summaries IN LDS, forms the 256 rows of the next level from them (the row of a
-// tile's last chunk needs the first-row equation of the NEXT tile's first chunk: those 8 rows are fetched as a halo, one value
-// per lane, and reduced by one thread), and 32 threads reduce these to 32 summaries two levels up -- the only thing written.
+// The reduction of a level writes 8 doubles per chunk and the next level's reads them back: at N = 10^7 that is 80 MB out and in
+// again (twice) between levels 0 and 1, and seven launches of ~7 us each further up (profiles/r05_h_solve_trace.md).  Here a
+// workgroup reduces its tile of 2048 rows to 256 chunk summaries IN LDS, forms the 256 rows of the next level from them (the row
+// of a tile's last chunk needs the first-row equation of the NEXT tile's first chunk: those 8 rows are fetched as a halo, one
+// value per lane, and swept by one thread), and 32 threads reduce these to 32 summaries two levels up -- the only thing written
+// (+ 4 doubles per tile: its chunk 0's first-row equation, which is the halo of the tile before in the back-substitution).
 // The back-substitution re-derives the summaries from the rows it fetches anyway (arithmetic instead of 240 MB of traffic),
-// solves the 256 middle-level rows in LDS with the 32 + 1 values from two levels up, then the tile's own rows.  The arithmetic
-// is the one-level kernels' (same chunk routines, same formulas): the solution has the same bits.
+// solves the 256 middle-level rows in LDS with the 32 + 1 values from two levels up, then the tile's own rows.
+// What made it pay (profiles/r05_p_solve.md): the one-level routines' arithmetic did NOT (91 + 105 us for the two level-0
+// launches against 90 + 90: instruction issue); neither did persistent workgroups with the next tile's loads in flight in
+// registers (two workgroups per compute unit: 82 + 87 us, 3.9 TB/s); one tile per workgroup with the lean arithmetic below at
+// three workgroups per compute unit does: 73 + 70 us.
 constexpr int kSup = kBlock / kChunk;            // rows two levels up per tile
 constexpr int kSVals = 8;                        // of a summary's 12 values, the 8 one right-hand side uses
 template <int P> struct SumLds {                 // summary table in LDS: S[slot][chunk - k0], pitch P
     double *S;
     int64_t k0;
     __device__ __forceinline__ void put(int v, int64_t k, double x) const { S[(v < 6 ? v : v - 2) * P + (int)(k - k0)] = x; }
-};
-template <int P> struct SrcLdsLevel {            // the rows those summaries define (SrcLevel::load on the table)
-    const double *S;
-    int64_t k0, nc;
-    template <int NRHS> __device__ __forceinline__ TriRow load(int64_t k) const
-    {
-        const int j = (int)(k - k0);
-        TriRow r;
-        r.a = S[0 * P + j];
-        const double be = S[1 * P + j], ce = S[2 * P + j];
-        if (k + 1 < nc) {
-            const double t = ce / S[5 * P + j + 1];
-            r.b = be - t * S[4 * P + j + 1];
-            r.c = -t * S[6 * P + j + 1];
-            r.d[0] = S[3 * P + j] - t * S[7 * P + j + 1];
-        } else {
-            r.b = be;
-            r.c = 0.0;
-            r.d[0] = S[3 * P + j];
-        }
-        r.d[1] = r.d[2] = 0.0;
-        return r;
-    }
-    template <int NRHS> __device__ __forceinline__ TriRow loadl(int, int64_t k) const { return load<NRHS>(k); }
 };
 template <int P> struct TriLdsZ {                // a level's unknowns of one tile: Z[1 + (i - k0)] (Z[0]: the one before the tile)
     double *Z;
@@ -652,12 +632,6 @@ template <typename Src> __device__ __forceinline__ void tri_halo_store(const Src
     const int64_t i = rowh + (threadIdx.x & 7);
     if (threadIdx.x < 32) halo[threadIdx.x] = i < n ? src.fix((threadIdx.x >> 3) & 3, i, hv) : 0.0;
 }
-// A workgroup owns `tpb` CONSECUTIVE tiles and keeps the next tile's loads in flight (registers) while it works on the current one:
-// the three dependent stages of a tile (chunks, middle level, store) would otherwise leave the memory pipe idle most of a
-// workgroup's life (measured without: 91 + 105 us for the two level-0 launches -- no faster than four one-level launches).
-// The reduction walks its tiles from the last to the first: the halo of tile i is chunk 0 of tile i + 1, reduced one iteration
-// earlier by thread 0 -- kept in LDS and published (hsum: 4 doubles per tile) for the back-substitution.  Only a workgroup's
-// first iteration fetches and reduces a real halo.
 // The arithmetic of the two-level kernels.  The one-level kernels above spend ~45 instructions per row (two IEEE divisions of ~14
 // instructions each, every step under an `i < m` branch) and are, at ~1000 instructions per thread, already close to issue-bound;
 // two levels per launch with the same routines measured NO faster than four launches (instruction issue, not memory).  Here:
@@ -762,62 +736,47 @@ template <> struct TriTileLoads<SrcUser, true> {
     __device__ __forceinline__ void issue(const SrcUser &src, int64_t n, int64_t row0) { tri_issue_rows_csc(src, n, row0, L); }
     __device__ __forceinline__ void land(const SrcUser &src, int64_t n, int64_t row0, double *lds, SrcRegs<1> &R) { tri_land_rows_csc<1>(src, n, row0, L, lds, R); }
 };
-template <typename Src, bool CSC>
-__global__ void __launch_bounds__(kBlock, 2) k_tri_reduce2(Src src, int64_t n, int64_t nc1, double *__restrict__ sum2, int64_t nc2,
-                                                        double *__restrict__ hsum, int ntiles, int tpb)
+// WPC: workgroups per compute unit the registers are budgeted for (3 with the CSC fetch buffer's 51 KB of LDS)
+template <typename Src, bool CSC, int WPC>
+__global__ void __launch_bounds__(kBlock, WPC) k_tri_reduce2(Src src, int64_t n, int64_t nc1, double *__restrict__ sum2, int64_t nc2,
+                                                             double *__restrict__ hsum)
 {
     constexpr int P = kBlock + 1;
     __shared__ double lds[CSC ? kTriRawSlots : kTriPitch];
     __shared__ double halo[32];
-    __shared__ double nexts[4];
     static_assert(kSVals * P <= kTriPitch, "the summary table reuses the fetch buffer");
-    const int t_lo = (int)blockIdx.x * tpb, t_hi = t_lo + tpb < ntiles ? t_lo + tpb : ntiles;
-    int tile = t_hi - 1;
-    const double hv = tri_halo_issue(src, n, (int64_t)(tile + 1) * kTriTileRows);
+    const int64_t tile = blockIdx.x, row0 = tile * kTriTileRows, k0 = tile * kBlock;
+    const double hv = tri_halo_issue(src, n, row0 + kTriTileRows);
     TriTileLoads<Src, CSC> G;
-    G.issue(src, n, (int64_t)tile * kTriTileRows);
-    for (bool first = true; tile >= t_lo; --tile, first = false) {
-        const int64_t row0 = (int64_t)tile * kTriTileRows, k0 = (int64_t)tile * kBlock;
-        SrcRegs<1> R;
-        G.land(src, n, row0, lds, R);
-        if (tile > t_lo) G.issue(src, n, row0 - kTriTileRows);
-        if constexpr (Src::kUnitRhs) tri_guard_rows<1>(R, n, row0, src.nd_flag);
-        if (first) tri_halo_store(src, n, row0 + kTriTileRows, hv, halo);
-        __syncthreads();                                  // every thread has copied the last array out of the buffer
-        const SumLds<P> S{lds, k0};
-        const int64_t k = k0 + threadIdx.x;
-        if (k < nc1) {
-            tri_pad_rows(R, n, k);
-            tri_sweep(R, S, k);
-        }
-        if (first) {
-            if (threadIdx.x == kBlock - 1 && k0 + kBlock < nc1) {        // the halo chunk (R is free again)
-#pragma unroll
-                for (int i = 0; i < kChunk; ++i) { R.a[i] = halo[i]; R.b[i] = halo[8 + i]; R.c[i] = halo[16 + i]; R.d[0][i] = halo[24 + i]; }
-                tri_pad_rows(R, n, k0 + kBlock);
-                tri_sweep(R, S, k0 + kBlock);
-            }
-        } else if (threadIdx.x < 4) {
-            lds[(4 + threadIdx.x) * P + kBlock] = nexts[threadIdx.x];      // chunk 0 of the tile after this one (previous iteration)
-        }
-        __syncthreads();
-        const int64_t k2 = (int64_t)tile * kSup + threadIdx.x;
-        if (threadIdx.x < kSup && k2 < nc2) {
-            tri_level_rows<P>(lds, k0, nc1, k2, R);
-            tri_sweep(R, SumGlobal{sum2, nc2}, k2);
-        }
-        double mine = 0.0;
-        if (threadIdx.x < 4) mine = lds[(4 + threadIdx.x) * P];             // this tile's chunk 0: its first-row equation
-        __syncthreads();                                  // the table has been read: the next tile may land in the buffer
-        if (threadIdx.x < 4) {
-            nexts[threadIdx.x] = mine;
-            hsum[(int64_t)tile * 4 + threadIdx.x] = mine;
-        }
+    G.issue(src, n, row0);
+    SrcRegs<1> R;
+    G.land(src, n, row0, lds, R);
+    if constexpr (Src::kUnitRhs) tri_guard_rows<1>(R, n, row0, src.nd_flag);
+    tri_halo_store(src, n, row0 + kTriTileRows, hv, halo);
+    __syncthreads();                                      // every thread has copied the last array out of the buffer
+    const SumLds<P> S{lds, k0};
+    const int64_t k = k0 + threadIdx.x;
+    if (k < nc1) {
+        tri_pad_rows(R, n, k);
+        tri_sweep(R, S, k);
     }
+    if (threadIdx.x == kBlock - 1 && k0 + kBlock < nc1) {                // the halo chunk (R is free again)
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) { R.a[i] = halo[i]; R.b[i] = halo[8 + i]; R.c[i] = halo[16 + i]; R.d[0][i] = halo[24 + i]; }
+        tri_pad_rows(R, n, k0 + kBlock);
+        tri_sweep(R, S, k0 + kBlock);
+    }
+    __syncthreads();
+    const int64_t k2 = tile * kSup + threadIdx.x;
+    if (threadIdx.x < kSup && k2 < nc2) {
+        tri_level_rows<P>(lds, k0, nc1, k2, R);
+        tri_sweep(R, SumGlobal{sum2, nc2}, k2);
+    }
+    if (threadIdx.x < 4) hsum[tile * 4 + threadIdx.x] = lds[(4 + threadIdx.x) * P];      // this tile's chunk 0: its first-row equation
 }
-template <typename Src, bool CSC, typename OutT>
-__global__ void __launch_bounds__(kBlock, 2) k_tri_backsub2(Src src, int64_t n, int64_t nc1, const double *__restrict__ z2, int64_t nc2,
-                                                         OutT *__restrict__ y, const double *__restrict__ hsum, int ntiles, int tpb)
+template <typename Src, bool CSC, typename OutT, int WPC>
+__global__ void __launch_bounds__(kBlock, WPC) k_tri_backsub2(Src src, int64_t n, int64_t nc1, const double *__restrict__ z2, int64_t nc2,
+                                                              OutT *__restrict__ y, const double *__restrict__ hsum)
 {
     constexpr int P = kBlock + 1;
     constexpr int kFetch = CSC ? kTriRawSlots : kTriPitch;
@@ -826,71 +785,97 @@ __global__ void __launch_bounds__(kBlock, 2) k_tri_backsub2(Src src, int64_t n, 
     __shared__ double lds[kLds];
     bool poison = false;
     if constexpr (Src::kUnitRhs) poison = src.refuse && src.nd_flag && *src.nd_flag != 0;      // (the reduction has checked every row)
-    // (tiles first to last: the reduction read a workgroup's tiles last to first just before, the front is what the caches hold)
-    const int t_lo = (int)blockIdx.x * tpb, t_hi = t_lo + tpb < ntiles ? t_lo + tpb : ntiles;
-    const int lane2 = threadIdx.x & (kSup - 1);
+    // level 0 walks the tiles from the last to the first (the reduction has just read J and b front to back: the tail is what the
+    // Infinity Cache still holds)
+    const int64_t ntiles = gridDim.x, tile = Src::kUnitRhs ? ntiles - 1 - blockIdx.x : (int64_t)blockIdx.x;
+    const int64_t row0 = tile * kTriTileRows, k0 = tile * kBlock;
+    const int64_t k2 = tile * kSup + (threadIdx.x & (kSup - 1)), k2c = k2 < nc2 ? k2 : nc2 - 1;
+    // (needed two stages further down: in flight with the rows)
+    const double zr2 = z2[k2c], zl2 = z2[k2c > 0 ? k2c - 1 : 0];
+    const double hs = hsum[(tile + 1 < ntiles ? tile + 1 : tile) * 4 + (threadIdx.x & 3)];
     TriTileLoads<Src, CSC> G;
-    double zl_n, zr_n, hs_n;
-    auto issue = [&](int t) {
-        const int64_t k2 = (int64_t)t * kSup + lane2, k2c = k2 < nc2 ? k2 : nc2 - 1;
-        zr_n = z2[k2c];
-        zl_n = z2[k2c > 0 ? k2c - 1 : 0];
-        hs_n = hsum[(int64_t)(t + 1 < ntiles ? t + 1 : t) * 4 + (threadIdx.x & 3)];
-        G.issue(src, n, (int64_t)t * kTriTileRows);
-    };
-    issue(t_lo);
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        const int64_t row0 = (int64_t)tile * kTriTileRows, k0 = (int64_t)tile * kBlock;
-        const double zl2 = zl_n, zr2 = zr_n, hs = hs_n;
-        SrcRegs<1> R;
-        G.land(src, n, row0, lds, R);
-        __syncthreads();
-        const SumLds<P> S{lds, k0};
-        const int64_t k = k0 + threadIdx.x;
-        if (k < nc1) {
-            tri_pad_rows(R, n, k);
-            tri_sweep(R, S, k);
-        }
-        if (threadIdx.x < 4) lds[(4 + threadIdx.x) * P + kBlock] = hs;      // chunk 0 of the next tile (from the reduction)
-        __syncthreads();
-        double *Z = lds + kZOff;
-        const int64_t k2 = (int64_t)tile * kSup + threadIdx.x;
-        if (threadIdx.x < kSup && k2 < nc2) {
-            SrcRegs<1> R2;
-            tri_level_rows<P>(lds, k0, nc1, k2, R2);
-            tri_sweep(R2, SumNone{}, k2);
-            tri_backsub_swept(R2, k2 > 0 ? zl2 : 0.0, zr2, k2, TriLdsZ<P>{Z, k0});
-        }
-        if (threadIdx.x == 0) Z[0] = k2 > 0 ? zl2 : 0.0;  // the unknown before the tile = the last unknown of the chunk before
-        if (tile + 1 < t_hi) issue(tile + 1);             // (not earlier: the middle level's rows need the registers)
-        __syncthreads();
-        if (k < nc1) tri_backsub_swept(R, Z[threadIdx.x], Z[threadIdx.x + 1], k, TriLdsOut{lds + kOutOff, row0});
-        __syncthreads();
-        const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
+    G.issue(src, n, row0);
+    SrcRegs<1> R;
+    G.land(src, n, row0, lds, R);
+    __syncthreads();
+    const SumLds<P> S{lds, k0};
+    const int64_t k = k0 + threadIdx.x;
+    if (k < nc1) {
+        tri_pad_rows(R, n, k);
+        tri_sweep(R, S, k);
+    }
+    if (threadIdx.x < 4) lds[(4 + threadIdx.x) * P + kBlock] = hs;          // chunk 0 of the next tile (from the reduction)
+    __syncthreads();
+    double *Z = lds + kZOff;
+    if (threadIdx.x < kSup && k2 < nc2) {
+        SrcRegs<1> R2;
+        tri_level_rows<P>(lds, k0, nc1, k2, R2);
+        tri_sweep(R2, SumNone{}, k2);
+        tri_backsub_swept(R2, k2 > 0 ? zl2 : 0.0, zr2, k2, TriLdsZ<P>{Z, k0});
+    }
+    if (threadIdx.x == 0) Z[0] = k2 > 0 ? zl2 : 0.0;      // the unknown before the tile = the last unknown of the chunk before
+    __syncthreads();
+    if (k < nc1) tri_backsub_swept(R, Z[threadIdx.x], Z[threadIdx.x + 1], k, TriLdsOut{lds + kOutOff, row0});
+    __syncthreads();
+    const int64_t rows = (n - row0 < kTriTileRows) ? n - row0 : kTriTileRows;
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j) {
-            const int r = j * kBlock + (int)threadIdx.x;
-            if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[kOutOff + r + (r >> 3)];
-        }
-        __syncthreads();                                  // the tile has left the buffer: the next one may land
+    for (int j = 0; j < kChunk; ++j) {
+        const int r = j * kBlock + (int)threadIdx.x;
+        if (r < rows) y[row0 + r] = poison ? (OutT)__builtin_nan("") : (OutT)lds[kOutOff + r + (r >> 3)];
     }
 }
-// The top of the two-level schedule: a level of at most kTop2 rows, one workgroup: a chunk per thread -> <= 512 rows -> parallel
-// cyclic reduction -> the chunks' rows.  (Rows come straight from the summaries below: a few thousand rows, latency not bandwidth.)
+// The top of the two-level schedule: a level of at most kTop2 rows, one workgroup: a chunk per thread (swept in registers, the
+// sweeps' arithmetic) -> <= 512 rows -> parallel cyclic reduction in LDS (one reciprocal per row and step) -> the chunks' rows from
+// the swept registers.  Rows come straight from the summaries below (a few thousand rows: latency, not bandwidth).
 constexpr int kTop2Block = 512;
 constexpr int kTop2 = kTop2Block * kChunk;
+struct TriBoundedOut {
+    double *y;
+    int64_t n;
+    __device__ __forceinline__ void put(int64_t i, double v) const { if (i < n) y[i] = v; }
+};
 __global__ void __launch_bounds__(kTop2Block) k_tri_top2(SrcLevel src, int n, double *__restrict__ sol)
 {
     constexpr int P = kTop2Block + 1;
     __shared__ double S[kSVals * P];
-    __shared__ double A[2][kTop2Block], B[2][kTop2Block], Cc[2][kTop2Block], D[2][kTop2Block];
+    __shared__ double A[2][kTop2Block], RB[2][kTop2Block], Cc[2][kTop2Block], D[2][kTop2Block];
     __shared__ double Z[P];
     const int k = threadIdx.x, nc = (n + kChunk - 1) / kChunk;
-    if (k < nc) tri_reduce_chunk<SrcLevel, 1>(src, n, SumLds<P>{S, 0}, k);
-    __syncthreads();
+    SrcRegs<1> R;
     if (k < nc) {
-        const TriRow r = SrcLdsLevel<P>{S, 0, nc}.load<1>(k);
-        A[0][k] = r.a; B[0][k] = r.b; Cc[0][k] = r.c; D[0][k] = r.d[0];
+        // (SrcLevel::load's formulas with the sweeps' reciprocal; every load of the chunk issued before the first use)
+        const double *sum = src.sum;
+        const int64_t ncl = src.nc;
+        double s0[kChunk], s1[kChunk], s2[kChunk], s3[kChunk], n6[kChunk], n7[kChunk], n8[kChunk], n9[kChunk];
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int64_t r = (int64_t)k * kChunk + i, rc = r < n ? r : n - 1, rn = rc + 1 < ncl ? rc + 1 : rc;
+            s0[i] = sum[0 * ncl + rc]; s1[i] = sum[1 * ncl + rc]; s2[i] = sum[2 * ncl + rc]; s3[i] = sum[3 * ncl + rc];
+            n6[i] = sum[6 * ncl + rn]; n7[i] = sum[7 * ncl + rn]; n8[i] = sum[8 * ncl + rn]; n9[i] = sum[9 * ncl + rn];
+        }
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int64_t r = (int64_t)k * kChunk + i;
+            const bool nxt = r + 1 < ncl;
+            const double t = nxt ? s2[i] * tri_rcp(n7[i]) : 0.0;
+            R.a[i] = s0[i];
+            R.b[i] = __builtin_fma(-t, nxt ? n6[i] : 0.0, s1[i]);
+            R.c[i] = nxt ? -t * n8[i] : 0.0;
+            R.d[0][i] = __builtin_fma(-t, nxt ? n9[i] : 0.0, s3[i]);
+        }
+        tri_pad_rows(R, n, k);
+        tri_sweep(R, SumLds<P>{S, 0}, k);
+    }
+    __syncthreads();
+    double Bk = 1.0;
+    if (k < nc) {
+        const bool nxt = k + 1 < nc;
+        const double t = nxt ? S[2 * P + k] * tri_rcp(S[5 * P + k + 1]) : 0.0;
+        Bk = __builtin_fma(-t, nxt ? S[4 * P + k + 1] : 0.0, S[1 * P + k]);
+        A[0][k] = S[0 * P + k];
+        Cc[0][k] = nxt ? -t * S[6 * P + k + 1] : 0.0;
+        D[0][k] = __builtin_fma(-t, nxt ? S[7 * P + k + 1] : 0.0, S[3 * P + k]);
+        RB[0][k] = tri_rcp(Bk);
     }
     __syncthreads();
     int cur = 0;
@@ -898,19 +883,23 @@ __global__ void __launch_bounds__(kTop2Block) k_tri_top2(SrcLevel src, int n, do
         const int nxt = cur ^ 1;
         if (k < nc) {
             const bool hl = k - st >= 0, hr = k + st < nc;
-            const double k1 = hl ? A[cur][k] / B[cur][k - st] : 0.0, kk2 = hr ? Cc[cur][k] / B[cur][k + st] : 0.0;
-            A[nxt][k] = hl ? -A[cur][k - st] * k1 : 0.0;
-            Cc[nxt][k] = hr ? -Cc[cur][k + st] * kk2 : 0.0;
-            B[nxt][k] = B[cur][k] - (hl ? Cc[cur][k - st] * k1 : 0.0) - (hr ? A[cur][k + st] * kk2 : 0.0);
-            D[nxt][k] = D[cur][k] - (hl ? D[cur][k - st] * k1 : 0.0) - (hr ? D[cur][k + st] * kk2 : 0.0);
+            const int il = hl ? k - st : k, ir = hr ? k + st : k;
+            const double k1 = hl ? A[cur][k] * RB[cur][il] : 0.0, kk2 = hr ? Cc[cur][k] * RB[cur][ir] : 0.0;
+            const double a2 = -A[cur][il] * k1, c2 = -Cc[cur][ir] * kk2;
+            Bk = __builtin_fma(-A[cur][ir], kk2, __builtin_fma(-Cc[cur][il], k1, Bk));
+            const double d2 = __builtin_fma(-D[cur][ir], kk2, __builtin_fma(-D[cur][il], k1, D[cur][k]));
+            A[nxt][k] = hl ? a2 : 0.0;
+            Cc[nxt][k] = hr ? c2 : 0.0;
+            D[nxt][k] = d2;
+            RB[nxt][k] = tri_rcp(Bk);
         }
         __syncthreads();
         cur = nxt;
     }
-    if (k < nc) Z[1 + k] = D[cur][k] / B[cur][k];
+    if (k < nc) Z[1 + k] = D[cur][k] * RB[cur][k];
     if (k == 0) Z[0] = 0.0;
     __syncthreads();
-    if (k < nc) tri_backsub_chunk_v(src, n, Z[k], Z[k + 1], k, TriGlobalOut<double>{sol});
+    if (k < nc) tri_backsub_swept(R, Z[k], Z[k + 1], k, TriBoundedOut{sol, n});
 }
 
 // Phase A epilogue: the six tip values (first / last local row of g, v, w).  The last row is the last unknown of every
@@ -1085,25 +1074,18 @@ template <int NRHS> static int tri_reduce_all(fd_tridiag_solver *s, const SrcUse
 }
 
 // One right-hand side: levels `from` and up two per launch (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2), the levels below one per
-// launch.  Measured at N = 10^7 (profiles/r05_p_solve.md): the five small levels (seven ~7 us launches, 56 us) become three
-// launches (39 us) either way.  The two big levels: the two-level kernels move 2/3 of the bytes but, with a tile being worked on
-// and one in flight in 256 registers, only two workgroups fit a compute unit -- 3.9 TB/s against the one-level kernels' 5.8:
-// diagonals 84 + 87 us against 90 + 90 (from = 0 wins: 213 us against 231 / 245), CSC 82 + 162 us (the back-substitution
-// spills) against 88 + 88 (from = 2 wins: 221 us against 288 / 236).
+// launch (from = 2: a test hook that keeps the one-level kernels on the two big levels).  N = 10^7: 5 launches instead of 13,
+// 235 -> 185 us (profiles/r05_p_solve.md).
 static int tri_two_level_from(const fd_tridiag_solver *s)
 {
     const char *e = fdjac::test_switch("FDJAC_SOLVE_TWO_LEVEL");      // -1: never, 0 / 2: from that level
-    const int from = (e && *e) ? atoi(e) : s->layout == FD_TRI_CSC ? 2 : 0;
+    const int from = (e && *e) ? atoi(e) : 0;
     return (from == 0 || from == 2) && from + 2 < s->nlev && s->lev_n[from] > kTop2 ? from : -1;
 }
 static int tri_solve_two_level(fd_tridiag_solver *s, const SrcUser &u, real_t *y, int from)
 {
     hipStream_t st = s->ctx->stream;
     const bool csc = u.layout == FD_TRI_CSC;
-    // tiles per workgroup: about two workgroups per compute unit in flight (their registers hold a tile being worked on and one in flight)
-    const char *tp = fdjac::test_switch("FDJAC_SOLVE_TPB");
-    const int tp_forced = (tp && *tp) ? atoi(tp) : 0;
-    auto tiles_per_block = [&](int ntiles) { const int want = 2 * s->ctx->num_cus; return tp_forced > 0 ? tp_forced : (ntiles + want - 1) / want; };
     for (int l = 0; l < from; ++l) {                      // one level per launch
         const int64_t nc = s->lev_n[l + 1];
         const unsigned g = (unsigned)((nc + kBlock - 1) / kBlock);
@@ -1114,24 +1096,22 @@ static int tri_solve_two_level(fd_tridiag_solver *s, const SrcUser &u, real_t *y
     int l = from;
     for (; s->lev_n[l] > kTop2; l += 2) {                 // (levels l + 1, l + 2 exist: the schedule runs down to <= kTop < kTop2 / 8)
         const int64_t n = s->lev_n[l], nc1 = s->lev_n[l + 1], nc2 = s->lev_n[l + 2];
-        const int ntiles = (int)((nc1 + kBlock - 1) / kBlock), tpb = tiles_per_block(ntiles);
-        const unsigned g = (unsigned)((ntiles + tpb - 1) / tpb);
+        const unsigned g = (unsigned)((nc1 + kBlock - 1) / kBlock);
         double *hs = s->lev_halo[l];
-        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, true>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs, ntiles, tpb);
-        else if (l == 0) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, false>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs, ntiles, tpb);
-        else hipLaunchKernelGGL((k_tri_reduce2<SrcLevel, false>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sum[l + 1], nc2, hs, ntiles, tpb);
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, true, 3>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_reduce2<SrcUser, false, 4>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sum[1], nc2, hs);
+        else hipLaunchKernelGGL((k_tri_reduce2<SrcLevel, false, 3>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sum[l + 1], nc2, hs);
     }
     const SrcLevel top{s->lev_sum[l - 1], s->lev_n[l]};
     if (s->lev_n[l] <= kTop) hipLaunchKernelGGL((k_tri_top<SrcLevel, 1>), dim3(1), dim3(kBlock), 0, st, top, (int)s->lev_n[l], s->lev_sol[l]);
     else hipLaunchKernelGGL(k_tri_top2, dim3(1), dim3(kTop2Block), 0, st, top, (int)s->lev_n[l], s->lev_sol[l]);
     for (l -= 2; l >= from; l -= 2) {
         const int64_t n = s->lev_n[l], nc1 = s->lev_n[l + 1], nc2 = s->lev_n[l + 2];
-        const int ntiles = (int)((nc1 + kBlock - 1) / kBlock), tpb = tiles_per_block(ntiles);
-        const unsigned g = (unsigned)((ntiles + tpb - 1) / tpb);
+        const unsigned g = (unsigned)((nc1 + kBlock - 1) / kBlock);
         const double *hs = s->lev_halo[l];
-        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, true, real_t>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs, ntiles, tpb);
-        else if (l == 0) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, false, real_t>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs, ntiles, tpb);
-        else hipLaunchKernelGGL((k_tri_backsub2<SrcLevel, false, double>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sol[l + 2], nc2, s->lev_sol[l], hs, ntiles, tpb);
+        if (l == 0 && csc) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, true, real_t, 3>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs);
+        else if (l == 0) hipLaunchKernelGGL((k_tri_backsub2<SrcUser, false, real_t, 3>), dim3(g), dim3(kBlock), 0, st, u, n, nc1, s->lev_sol[2], nc2, y, hs);
+        else hipLaunchKernelGGL((k_tri_backsub2<SrcLevel, false, double, 3>), dim3(g), dim3(kBlock), 0, st, SrcLevel{s->lev_sum[l - 1], n}, n, nc1, s->lev_sol[l + 2], nc2, s->lev_sol[l], hs);
     }
     for (l = from - 1; l >= 0; --l) {                     // one level per launch
         const int64_t nc = s->lev_n[l + 1];

@@ -97,10 +97,9 @@ def test_tridiagonal_solve_matches_scipy(layout, N):
                                2 ** 21 + 65, 10 ** 6 + 3, 16777216 + 520])
 @pytest.mark.parametrize("start", ["0", "2"])
 def test_two_levels_per_launch_against_one_level_per_launch(layout, N, start, monkeypatch):
-    # the default schedule (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2: two levels per launch, the middle level only in LDS, persistent
-    # workgroups) against the one-level kernels: the same reduction (same bits up to the top), a back-substitution from the swept rows
-    # instead of a second elimination -- rounding-level differences only; sizes around tile (2048 rows), halo (8 rows), 64:1, top (4096)
-    # and tiles-per-workgroup boundaries
+    # the default schedule (k_tri_reduce2 / k_tri_top2 / k_tri_backsub2: two levels per launch, the middle level only in LDS) against
+    # the one-level kernels: another arithmetic (one reciprocal per row, identity-padded chunks, back-substitution from the swept rows)
+    # -- rounding-level differences only; sizes around tile (2048 rows), halo (8 rows), 64:1 and top (4096) boundaries
     dl, d, du, b, alpha, beta = _system(N, 300 + N % 1000)
     J = fd.Tridiagonal(_dev(dl), _dev(d), _dev(du)) if layout == "diagonals" else [_dev(_csc_nzval_fast(dl, d, du))]
     bd = _dev(b)
