@@ -592,6 +592,12 @@ class BuiltinF:
     def fcalls(self):
         return self.counts()[1]
 
+    def row_stores(self):
+        """Storing launches of the sparse family that went row by row (FD_F_INFO_ROW_STORES)."""
+        v = C.c_int64()
+        _l.check(self.Lt.fd_builtin_f_info(self.fctx, 1, C.byref(v)))
+        return v.value
+
 
 class JitF:
     """A row functor given as SOURCE and compiled at run time (fd_f_compile_rows; hiprtc against include/fdjac_device.h,

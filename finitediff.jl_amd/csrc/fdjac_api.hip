@@ -846,7 +846,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             memset(&sc, 0, sizeof sc);
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
             sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.note = p->d_sc_note; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
-            sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0; sc.reach = p->sc_reach;
+            sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0; sc.reach = p->sc_reach; sc.plan_serial = p->sc_serial;
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;

@@ -9,7 +9,10 @@
 // for bit.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 #include "fdjac_internal.h"
 
@@ -639,6 +642,17 @@ struct BuiltinF {
     int64_t prm[3] = {0, 0, 0};
     int64_t M = 0, N = 0;
     int32_t *d_srow = nullptr, *d_scol = nullptr;   // FD_F_SPARSE: the pattern by rows (rowptr[M + 1], ascending columns), device
+    int32_t *d_sdest = nullptr;                     //   per entry of that list: its slot in the CSC order it was built from (k_f_sparse_store_rows)
+    std::vector<int32_t> h_colptr;                  //   that CSC pattern's column offsets (0-based), host
+    struct RowsMemo {                               //   what the launcher knows about a plan (fd_csc_store.plan_serial): is its pattern mine?
+        int verdict = 0;
+        bool pending = false;
+        hipEvent_t ev = nullptr;
+        unsigned long long *h_note = nullptr;       //   pinned
+    };
+    std::atomic<int64_t> row_stores{0};
+    std::unordered_map<unsigned long long, RowsMemo> rows_memo;
+    std::mutex rows_mutex;
     std::atomic<int64_t> launches{0}, points{0};
     void *d_sig = nullptr;  // block-coupled sigma scratch
     int64_t sig_cap = 0;    // in (re,im)-capable elements
@@ -1929,10 +1943,12 @@ int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *co
     auto ld = [&](const void *p, int64_t i) { return idx_bytes == 8 ? ((const int64_t *)p)[i] : (int64_t)((const int32_t *)p)[i]; };
     const int64_t nnz = ld(colptr, N) - idx_base;
     FD_REQUIRE(nnz >= 0 && nnz < ((int64_t)1 << 31), FD_ERR_SHAPE, "colptr is not monotone / too many entries");
-    std::vector<int32_t> srow((size_t)M + 1, 0), scol((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<int32_t> srow((size_t)M + 1, 0), scol((size_t)std::max<int64_t>(nnz, 1)), sdest((size_t)std::max<int64_t>(nnz, 1)), hcp((size_t)N + 1);
     for (int64_t j = 0; j < N; ++j) {
         const int64_t a = ld(colptr, j) - idx_base, b2 = ld(colptr, j + 1) - idx_base;
         FD_REQUIRE(a >= 0 && a <= b2 && b2 <= nnz, FD_ERR_SHAPE, "colptr is not monotone at column %lld", (long long)j);
+        hcp[(size_t)j] = (int32_t)a;
+        hcp[(size_t)j + 1] = (int32_t)b2;
         for (int64_t q = a; q < b2; ++q) {
             const int64_t r = ld(rowval, q) - idx_base;
             FD_REQUIRE(r >= 0 && r < M, FD_ERR_SHAPE, "rowval[%lld] outside the matrix", (long long)q);
@@ -1943,7 +1959,11 @@ int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *co
     {
         std::vector<int32_t> cur(srow.begin(), srow.end() - 1);
         for (int64_t j = 0; j < N; ++j)       // columns ascending: every row's entries end up in ascending column order
-            for (int64_t q = ld(colptr, j) - idx_base; q < ld(colptr, j + 1) - idx_base; ++q) scol[(size_t)cur[(size_t)(ld(rowval, q) - idx_base)]++] = (int32_t)j;
+            for (int64_t q = ld(colptr, j) - idx_base; q < ld(colptr, j + 1) - idx_base; ++q) {
+                const size_t at = (size_t)cur[(size_t)(ld(rowval, q) - idx_base)]++;
+                scol[at] = (int32_t)j;
+                sdest[at] = (int32_t)q;
+            }
     }
     BuiltinF *b = new (std::nothrow) BuiltinF();
     FD_REQUIRE(b != nullptr, FD_ERR_NOMEM, "out of host memory");
@@ -1955,15 +1975,19 @@ int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *co
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_srow, sizeof(int32_t) * srow.size());
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_scol, sizeof(int32_t) * scol.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_sdest, sizeof(int32_t) * sdest.size());
+    if (e == hipSuccess) e = hipMemcpy(b->d_sdest, sdest.data(), sizeof(int32_t) * sdest.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_srow, srow.data(), sizeof(int32_t) * srow.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_scol, scol.data(), sizeof(int32_t) * scol.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("uploading the pattern of the sparse family failed: %s", hipGetErrorString(e));
         if (b->d_srow) (void)hipFree(b->d_srow);
         if (b->d_scol) (void)hipFree(b->d_scol);
+        if (b->d_sdest) (void)hipFree(b->d_sdest);
         delete b;
         return FD_ERR_HIP;
     }
+    b->h_colptr.swap(hcp);
     *fn_out = builtin_launch;
     *fctx_out = b;
     return FD_OK;
@@ -1977,6 +2001,12 @@ int fd_builtin_f_destroy(void *fctx)
     if (b->d_sig) (void)hipFree(b->d_sig);
     if (b->d_srow) (void)hipFree(b->d_srow);
     if (b->d_scol) (void)hipFree(b->d_scol);
+    if (b->d_sdest) (void)hipFree(b->d_sdest);
+    for (auto &kv : b->rows_memo) {
+        if (kv.second.pending) (void)hipEventSynchronize(kv.second.ev);      // (a copy into the pinned word may still be in flight)
+        if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+        if (kv.second.h_note) (void)hipHostFree(kv.second.h_note);
+    }
     b->magic = 0;
     delete b;
     return FD_OK;
@@ -2037,6 +2067,15 @@ int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points)
     FD_REQUIRE(b && b->magic == 0xFD0F00D5u, FD_ERR_ARG, "not a built-in f context");
     if (launches) *launches = b->launches.load();
     if (points) *points = b->points.load();
+    return FD_OK;
+}
+
+int fd_builtin_f_info(void *fctx, int key, int64_t *value)
+{
+    BuiltinF *b = (BuiltinF *)fctx;
+    FD_REQUIRE(b && b->magic == 0xFD0F00D5u && value, FD_ERR_ARG, "not a built-in f context");
+    FD_REQUIRE(key == FD_F_INFO_ROW_STORES, FD_ERR_ARG, "unknown key %d", key);
+    *value = b->row_stores.load();
     return FD_OK;
 }
 

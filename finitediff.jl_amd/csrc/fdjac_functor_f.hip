@@ -417,9 +417,10 @@ static size_t sparse_sorted_lds_bytes(int64_t reach, int cap)
 }
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, const real_t *__restrict__ x, const real_t *__restrict__ eps, int c_lo, int c_hi,
-                                                                  fd_csc_store st, int reach, int stage_cap)
+                                                                  fd_csc_store st, int reach, int stage_cap, unsigned long long rows_key)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    if (rows_key && st.note && st.note[0] == rows_key) return;        // the row-wise launch that follows stores this plan's Jacobian (k_f_sparse_store_rows)
     const long long nblk = (st.col_end - st.col_begin + kBlock - 1) / kBlock, blk = fd_xcd_block(blockIdx.x, nblk);
     if (blk >= nblk) return;
     const long long j0 = st.col_begin + blk * kBlock, jn = j0 + kBlock < st.col_end ? j0 + kBlock : st.col_end;
@@ -536,6 +537,204 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_sorted(SparseF f, con
             out[q0 + e] = fd_div_shared<real_t>(vp - vm, MODE == 1 ? 2 * he : he, ye);
         }
     }
+}
+
+// ---- the sparse family's store, ROW BY ROW (round 5) ---------------------------------------------------------------------------------
+// The column kernels give every stored entry (r, j) its own evaluation of row r: nnz x (row length) terms -- 36 per column of the
+// random band, each with its index decode, window lookup and perturbation select: instruction issue, 196 us.  But the L entries of
+// a row share everything except ONE term: a thread that owns row r forms the row's L plain terms once (keeps them in LDS, their
+// left-to-right sum is f(x)_r), then for entry k the sum  (t_0 + .. + t_{k-1}) + t'_k + t_{k+1} + .. + t_{L-1}  -- the prefix
+// carried from entry to entry, the perturbed term evaluated once, the suffix added from LDS: the additions of the full evaluation
+// in the same order, so the same bits, with 2 L term evaluations and L (L - 1) / 2 additions per row instead of L^2 evaluations.
+// The quotient goes to the entry's slot in J's CSC storage: `sdest`, the functor's own map from its row-major list to the CSC
+// order it was BUILT from.  That must be the plan's pattern: the first launch on a plan only checks (every entry's slot holds its row
+// and lies in its column; the entry counts agree) while the column kernel stores; the last workgroup to report records the verdict in
+// the plan's note, and from then on this kernel stores and the column kernel returns at once (or the other way round: a different
+// pattern).  The launcher reads the verdict back asynchronously (never a synchronisation) and then launches only the one that works.
+// x and the colours of the rows' window [r0 - reach, r1 + reach) and the tile's run of the row-major lists (columns, slots: one
+// contiguous range) are staged in LDS with lane-consecutive loads; what does not fit or lies outside is read from memory.
+constexpr int kRowRegs = 14;         // entries of a row k_f_sparse_store_rows keeps in registers
+__device__ __forceinline__ real_t sparse_weight(unsigned k)          // 1 + k / 8, k < 8: the three leading mantissa bits
+{
+    if constexpr (sizeof(real_t) == 8) return __hiloint2double((int)(0x3FF00000u | (k << 17)), 0);
+    else return __uint_as_float(0x3F800000u | (k << 20));
+}
+__device__ __forceinline__ real_t sparse_term(unsigned k, real_t v) { return sparse_weight(k) * (v + (kQuarter * v) * v); }
+// LDS: [x window][step, reciprocal per colour of the batch][column, slot of the tile's entries][colours of the window]
+static size_t sparse_rows_lds_bytes(int64_t reach, int ncol, int cap)
+{
+    const size_t xlen = (size_t)(kBlock + 2 * reach + 2);
+    return sizeof(real_t) * (xlen + 2 * (size_t)ncol) + 4 * (2 * (size_t)cap + xlen) + 64;
+}
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(kBlock) k_f_sparse_store_rows(SparseF f, const int32_t *__restrict__ sdest, long long e_base, const real_t *__restrict__ x,
+                                                                const real_t *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach, int cap,
+                                                                long long row_lo, long long row_hi, unsigned long long key, long long expect, int known)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sr_lds[];
+    const long long ntile = (row_hi - row_lo + kBlock - 1) / kBlock, tile = fd_xcd_block(blockIdx.x, ntile);
+    if (tile >= ntile) return;
+    const unsigned long long note0 = known ? key : st.note[0];          // (known: the launcher has read the verdict -- one memory round trip less)
+    if (note0 == (key ^ 2ull)) return;                                  // another pattern: the column kernel has stored
+    const long long R0 = row_lo + tile * kBlock, R1 = R0 + kBlock < row_hi ? R0 + kBlock : row_hi;
+    const long long r = R0 + threadIdx.x;
+    const bool in = r < R1;
+    const int a0 = in ? f.srow[r] : 0, a1 = in ? f.srow[r + 1] : 0, L = a1 - a0;
+    const long long cb = st.col_begin, ce = st.col_end;
+    if (note0 != key) {                                                 // first launch on this plan: check, store nothing
+        bool bad = false;
+        for (int a = a0; a < a1; ++a) {
+            const long long j = f.scol[a];
+            if (j < cb || j >= ce) continue;
+            const long long q = (long long)sdest[a] - e_base;
+            const int qa = st.colptr[j - cb], qb = st.colptr[j - cb + 1];
+            bad = bad || !(q >= qa && q < qb) || st.rowval[q >= qa && q < qb ? q : qa] != (int)r;
+        }
+        // note[2]: workgroups that have reported (low word) and that met a mismatch (high word); the last one records the verdict
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        if (threadIdx.x == 0) {
+            const unsigned long long add = 1ull + (any_bad ? (1ull << 32) : 0ull);
+            const unsigned long long old = atomicAdd(&st.note[2], add);
+            if ((old & 0xFFFFFFFFull) + 1 == (unsigned long long)ntile) {
+                const bool same = ((old + add) >> 32) == 0 && (long long)st.colptr[ce - cb] == expect;
+                st.note[2] = 0;
+                st.note[0] = same ? key : (key ^ 2ull);
+            }
+        }
+        return;
+    }
+    long long w0 = R0 - reach > 0 ? R0 - reach : 0, w1 = R1 + reach < st.N ? R1 + reach : st.N;
+    w0 &= ~1ll;
+    const int xlen = kBlock + 2 * reach + 2, nchunk = c_hi - c_lo;
+    FD_LDS_PTR(real_t) s_x = (FD_LDS_PTR(real_t))sr_lds;
+    FD_LDS_PTR(real_t) s_h = s_x + xlen;                                // step of colour c_lo + i
+    FD_LDS_PTR(real_t) s_y = s_h + nchunk;                              // 1 / (step or 2 step)
+    FD_LDS_PTR(int) s_j = (FD_LDS_PTR(int))(s_y + nchunk);              // column of the tile's i-th entry
+    FD_LDS_PTR(int) s_q = s_j + cap;                                    // its slot in the plan's nzval
+    FD_LDS_PTR(int) s_c = s_q + cap;                                    // colour of column w0 + i (-1: none)
+    const CT *color = (const CT *)st.color;
+    // the tile's entries are one contiguous run of the functor's row-major lists: staged with lane-consecutive loads -- after the
+    // window of x and of the colours, whose loads do not depend on the row offsets and travel with them
+    const int A0 = f.srow[R0], A1 = f.srow[R1];
+    {
+        const long long nx = w1 - w0, npair = nx / 2;
+        for (long long i0 = 0; i0 < npair; i0 += 4 * kBlock) {
+            r2_t vx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + u * kBlock + threadIdx.x; if (i < npair) vx[u] = *reinterpret_cast<const r2_t *>(x + w0 + 2 * i); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long long i = i0 + u * kBlock + threadIdx.x; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+        }
+        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
+        for (long long i = threadIdx.x; i < nx; i += kBlock) { const CT c = color[w0 + i]; s_c[i] = c == (CT)(-1) ? -1 : (int)c; }
+        for (int i = threadIdx.x; i < nchunk; i += kBlock) { const real_t h = eps[c_lo + i]; s_h[i] = h; s_y[i] = (real_t)1 / (MODE == 1 ? 2 * h : h); }
+    }
+    const int nst = A1 - A0 < cap ? A1 - A0 : cap;
+    for (int i0 = 0; i0 < nst; i0 += 4 * kBlock) {
+        int vj[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + (int)threadIdx.x; const int ic = i < nst ? i : nst - 1; vj[u] = f.scol[A0 + ic]; vq[u] = sdest[A0 + ic]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + (int)threadIdx.x; if (i < nst) { s_j[i] = vj[u]; s_q[i] = vq[u]; } }
+    }
+    __syncthreads();
+    if (!in || L == 0) return;
+    const unsigned wlen = (unsigned)(w1 - w0);
+    const unsigned rw = (unsigned)r & 7u;
+    const int b0 = a0 - A0;                                             // the row's entries are the tile's [b0, b0 + L)
+    real_t *out = (real_t *)st.out;
+    // PURE: the whole run is staged and every column is local (so inside the window): the loops below then contain no load from
+    // memory at all.  That matters more than it looks: this target counts loads and stores in ONE counter, and a loop body that MAY
+    // load makes the compiler wait for everything outstanding -- the store of the iteration before -- on every trip: 12 trips x a
+    // store's round trip = the 19 us a wavefront of the first form of this kernel lived (56 % of its cycles in s_waitcnt, 240 us).
+    auto work = [&](auto pure_tag) {
+        constexpr bool PURE = decltype(pure_tag)::value;
+        auto coord = [&](long long j) -> real_t {
+            const unsigned off = (unsigned)(j - w0);
+            if constexpr (PURE) return s_x[off];
+            else return off < wlen ? (real_t)s_x[off] : x[j];
+        };
+        auto col_of = [&](int i) -> int { if constexpr (PURE) return s_j[i]; else return i < nst ? (int)s_j[i] : f.scol[A0 + i]; };
+        auto plain = [&](int i) -> real_t {                             // the tile's i-th entry's term at x
+            const long long j = col_of(i);
+            return sparse_term((rw + 3u * (unsigned)j) & 7u, coord(j));
+        };
+        if constexpr (PURE) {
+            // rows of at most kRowRegs entries (all but one in a thousand of a Poisson(6) pattern): columns, slots, coordinates, colours
+            // and plain terms in REGISTERS, every loop unrolled and predicated -- the loops over LDS below pay one LDS round trip per
+            // term added (the suffix sums alone: 66 dependent trips for a wavefront whose longest row has 12 entries)
+            constexpr int RL = kRowRegs;
+            if (L <= RL) {
+                int jj[RL], qq[RL];
+                real_t tt[RL];
+#pragma unroll
+                for (int u = 0; u < RL; ++u) { const int i = b0 + (u < L ? u : L - 1); jj[u] = s_j[i]; qq[u] = s_q[i]; }
+                real_t fx = 0;
+#pragma unroll
+                for (int u = 0; u < RL; ++u) {
+                    tt[u] = sparse_term((rw + 3u * (unsigned)jj[u]) & 7u, s_x[(unsigned)(jj[u] - (int)w0)]);
+                    fx = u == 0 ? tt[0] : (u < L ? fx + tt[u] : fx);
+                }
+                real_t pre = 0;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) {
+                    if (k < L) {
+                        const unsigned off = (unsigned)(jj[k] - (int)w0);
+                        const int c = s_c[off];
+                        const real_t v = s_x[off];
+                        const long long q = (long long)qq[k] - e_base;
+                        if (c < 0) {
+                            if (c_lo == 0) out[q] = (real_t)0;
+                        } else if (c >= c_lo && c < c_hi) {
+                            const real_t h = s_h[c - c_lo], y = s_y[c - c_lo];
+                            const unsigned wk = (rw + 3u * (unsigned)jj[k]) & 7u;
+                            real_t sp = sparse_term(wk, v + h), sm = MODE == 1 ? sparse_term(wk, v - h) : (real_t)0;
+                            if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+#pragma unroll
+                            for (int u = k + 1; u < RL; ++u)
+                                if (u < L) { sp = sp + tt[u]; if (MODE == 1) sm = sm + tt[u]; }
+                            out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : fx), MODE == 1 ? 2 * h : h, y);
+                        }
+                        pre = k == 0 ? tt[0] : pre + tt[k];
+                    }
+                }
+                return;
+            }
+        }
+        real_t fx = 0;
+        for (int u = 0; u < L; ++u) {
+            const int j = col_of(b0 + u);
+            const real_t t = sparse_term((rw + 3u * (unsigned)j) & 7u, coord(j));
+            fx = u == 0 ? t : fx + t;
+        }
+        real_t pre = 0;
+        for (int k = 0; k < L; ++k) {
+            const long long j = col_of(b0 + k);
+            long long q;
+            if constexpr (PURE) q = (long long)s_q[b0 + k] - e_base;
+            else q = (long long)(b0 + k < nst ? (int)s_q[b0 + k] : sdest[a0 + k]) - e_base;
+            const real_t tk = plain(b0 + k);
+            if (PURE || (j >= cb && j < ce)) {
+                const unsigned off = (unsigned)(j - w0);
+                int c;
+                if constexpr (PURE) c = s_c[off];
+                else c = off < wlen ? (int)s_c[off] : (color[j] == (CT)(-1) ? -1 : (int)color[j]);
+                if (c < 0) {
+                    if (c_lo == 0) out[q] = (real_t)0;
+                } else if (c >= c_lo && c < c_hi) {
+                    const real_t h = s_h[c - c_lo], y = s_y[c - c_lo], v = coord(j);
+                    const unsigned wk = (rw + 3u * (unsigned)j) & 7u;
+                    real_t sp = sparse_term(wk, v + h), sm = MODE == 1 ? sparse_term(wk, v - h) : (real_t)0;
+                    if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+                    for (int u = k + 1; u < L; ++u) { const real_t t = plain(b0 + u); sp = sp + t; if (MODE == 1) sm = sm + t; }
+                    out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : fx), MODE == 1 ? 2 * h : h, y);
+                }
+            }
+            pre = k == 0 ? tk : pre + tk;
+        }
+    };
+    if (A1 - A0 <= cap && cb == 0 && ce == st.N) work(std::true_type{});
+    else work(std::false_type{});
 }
 
 // ---- the complex step through the column store (FD_LAZY_CAP_STORE_CSC_COMPLEX) ----------------------------------------------------------
@@ -665,8 +864,51 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
             const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
             const size_t lds_s = sparse_sorted_lds_bytes(reach, cap);
             if (lds_s <= 64 * 1024 && (lp->pts == 2 || st.fx_base != nullptr)) {      // the entry-balanced form (see k_f_sparse_store_sorted)
-                if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 1>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap);
-                else hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 0>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap);
+                // ... and the row-wise store (k_f_sparse_store_rows).  Until the plan's verdict is known on the host both are enqueued and
+                // the plan's note decides on the device which one works; afterwards only that one is launched.
+                const int cap_r = (int)std::min<int64_t>((int64_t)(kBlock * per_row * 1.25) + 64, 3072);
+                const size_t lds_r = sparse_rows_lds_bytes(reach, lp->ncolors, cap_r);
+                const char *rs = fdjac::test_switch("FDJAC_SPARSE_ROWS");
+                const bool rows = st.note != nullptr && st.plan_serial != 0 && lds_r <= 64 * 1024 && b->d_sdest && !(rs && *rs && atoi(rs) == 0);
+                const long long e_base = b->h_colptr[(size_t)st.col_begin], expect = (long long)b->h_colptr[(size_t)st.col_end] - e_base;
+                const unsigned long long key = rows ? ((0x5BA25E0000000000ull ^ ((unsigned long long)(uintptr_t)b->d_sdest << 3) ^ ((unsigned long long)st.col_begin * 0x9E3779B97F4A7C15ull) ^
+                                                        (unsigned long long)st.col_end) & ~2ull) | 4ull : 0ull;
+                int verdict = 0;                       // 0 unknown, 1 the plan's pattern is the functor's, 2 it is not
+                BuiltinF::RowsMemo *memo = nullptr;
+                if (rows) {
+                    std::lock_guard<std::mutex> lock(b->rows_mutex);
+                    memo = &b->rows_memo[st.plan_serial];
+                    if (memo->verdict == 0 && memo->pending && hipEventQuery(memo->ev) == hipSuccess) {
+                        memo->pending = false;
+                        memo->verdict = *memo->h_note == key ? 1 : *memo->h_note == (key ^ 2ull) ? 2 : 0;
+                    }
+                    verdict = memo->verdict;
+                }
+                if (verdict != 1) {
+                    const unsigned long long gate = verdict == 2 ? 0ull : key;
+                    if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 1>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap, gate);
+                    else hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 0>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap, gate);
+                }
+                if (verdict == 1) b->row_stores.fetch_add(1);
+                if (rows && verdict != 2) {
+                    const long long row_lo = std::max<long long>(0, st.col_begin - reach), row_hi = std::min<long long>(st.M, st.col_end + reach);
+                    const unsigned gr = fd_xcd_grid((row_hi - row_lo + kBlock - 1) / kBlock);
+                    if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 1>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
+                    else hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 0>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
+                    if (verdict == 0) {
+                        std::lock_guard<std::mutex> lock(b->rows_mutex);
+                        if (!memo->pending) {                        // the verdict on its way to the host: read at a later call, never waited for
+                            if (!memo->h_note && hipHostMalloc((void **)&memo->h_note, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) memo->h_note = nullptr;
+                            if (memo->h_note && !memo->ev && hipEventCreateWithFlags(&memo->ev, hipEventDisableTiming) != hipSuccess) memo->ev = nullptr;
+                            if (memo->h_note && memo->ev) {
+                                *memo->h_note = 0;
+                                if (hipMemcpyAsync(memo->h_note, st.note, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                                    hipEventRecord(memo->ev, s) == hipSuccess)
+                                    memo->pending = true;
+                            }
+                        }
+                    }
+                }
             } else if (lds <= 64 * 1024) {
                 if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 1, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
                 else hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 0, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);

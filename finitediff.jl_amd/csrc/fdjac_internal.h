@@ -47,6 +47,7 @@
 #define fd_builtin_f_create_sparse fd32_builtin_f_create_sparse
 #define fd_builtin_f_destroy fd32_builtin_f_destroy
 #define fd_builtin_f_counts fd32_builtin_f_counts
+#define fd_builtin_f_info fd32_builtin_f_info
 #define fd_builtin_f_lazy fd32_builtin_f_lazy
 #define fd_builtin_f_lazy_caps fd32_builtin_f_lazy_caps
 #define fd_jvp_plan_set_lazy_caps fd32_jvp_plan_set_lazy_caps
@@ -306,7 +307,8 @@ struct fd_plan {
     int64_t *d_bbb_start = nullptr;    // [(bl + bu + 1) * nb] 0-based start of block (K, J)'s slab in data, -1: not in the band
     int64_t *d_bbb_stride = nullptr;   // [nb] column stride of the slabs of block-column J
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
-    unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: two words of launcher memory about this pattern, zero at creation
+    unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: four words of launcher memory about this pattern, zero at creation
+    unsigned long long sc_serial = 0;            // fd_csc_store.plan_serial
     int64_t sc_entries = 0;
     int64_t sc_reach = -1;         //   max |row - column| over the local entries (fd_csc_store.reach), -1: not computed
     bool sc_valid = false;         //   colorvec verified to be a valid colouring of the local pattern (kernels may perturb one coordinate)

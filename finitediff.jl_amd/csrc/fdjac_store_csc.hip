@@ -1,3 +1,4 @@
+#include <atomic>
 // The compact device copy of a plan's local CSC pattern (FD_PLAN_STORE_CSC; fd_csc_store in include/fdjac_device.h): int32 column
 // offsets relative to the local column range and int32 0-based rows, converted ON THE DEVICE from the caller's colptr / rowval (any
 // index width / base).  A column-centric f! kernel walks it to store the Jacobian of ANY pattern itself (the reference's
@@ -96,8 +97,12 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
     FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_colptr, sizeof(int) * (size_t)(ncols + 1)));
     FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_rowval, sizeof(int) * (size_t)(n + 8)));      // (+ a pad: launchers may read one entry past an empty last column)
     FD_HIP_CHECK(hipMemsetAsync(p->d_sc_rowval + n, 0, sizeof(int) * 8, p->ctx->stream));
-    FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_note, 2 * sizeof(unsigned long long)));
-    FD_HIP_CHECK(hipMemsetAsync(p->d_sc_note, 0, 2 * sizeof(unsigned long long), p->ctx->stream));
+    FD_HIP_CHECK(hipMalloc((void **)&p->d_sc_note, 4 * sizeof(unsigned long long)));
+    FD_HIP_CHECK(hipMemsetAsync(p->d_sc_note, 0, 4 * sizeof(unsigned long long), p->ctx->stream));
+    {
+        static std::atomic<unsigned long long> serial{0};
+        p->sc_serial = ++serial;
+    }
     hipLaunchKernelGGL((k_csc_compact_colptr<IT>), dim3((unsigned)((ncols + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, colptr_dev, (int64_t)idx_base,
                        p->col0, ncols + 1, p->entry_begin, p->d_sc_colptr);
     if (n > 0)

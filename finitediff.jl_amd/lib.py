@@ -64,7 +64,7 @@ EXPORTS = (
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
     "fd_plan_create_bandedblockbanded", "fd_plan_destroy",
     "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
-    "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts",
+    "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts", "fd_builtin_f_info",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
@@ -86,7 +86,7 @@ TYPED = (
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
     "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
     "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
-    "fd_builtin_f_counts", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
+    "fd_builtin_f_counts", "fd_builtin_f_info", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
@@ -194,6 +194,7 @@ def load():
     L.fd_builtin_f_destroy.argtypes = [vp]
     L.fd_builtin_f_create_sparse.argtypes = [vp, i64, i64, vp, vp, i32, i32, C.POINTER(F_LAUNCH), pp]
     L.fd_builtin_f_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.fd_builtin_f_info.argtypes = [vp, C.c_int, C.POINTER(i64)]
     L.fd_stream_copy_gbps.argtypes = [vp, i64, i32, C.POINTER(dbl)]
     L.fd_jvp_plan_create.argtypes = [vp, i64, i64, i32, pp]
     L.fd_jvp_plan_destroy.argtypes = [vp]

@@ -391,6 +391,10 @@ int fd_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *co
 int fd_builtin_f_destroy(void *fctx);
 /* number of launcher invocations / points evaluated since creation (call-count parity tests) */
 int fd_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
+/* introspection of a built-in family.  FD_F_INFO_ROW_STORES: storing launches of the sparse family that went row by row
+   (k_f_sparse_store_rows: the plan's pattern known to be the one the residual was created from) instead of column by column. */
+enum fd_builtin_f_info_key { FD_F_INFO_ROW_STORES = 1 };
+int fd_builtin_f_info(void *fctx, int key, int64_t *value);
 /* The lazy-point launcher of a built-in family (FD_ERR_UNSUPPORTED if the family has none) and its capabilities. */
 int fd_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
 int fd_builtin_f_lazy_caps(void *fctx, int *caps_out);
@@ -694,6 +698,7 @@ int fd32_builtin_f_create_sparse(fd_ctx *ctx, int64_t M, int64_t N, const void *
                                  fd_f_launch *fn_out, void **fctx_out);
 int fd32_builtin_f_destroy(void *fctx);
 int fd32_builtin_f_counts(void *fctx, int64_t *launches, int64_t *points);
+int fd32_builtin_f_info(void *fctx, int key, int64_t *value);
 int fd32_builtin_f_lazy(void *fctx, fd_f_launch_lazy *fn_out);
 int fd32_builtin_f_lazy_caps(void *fctx, int *caps_out);
 int fd32_jvp_plan_create(fd_ctx *ctx, int64_t M, int64_t N, int fdtype, fd32_jvp_plan **out);

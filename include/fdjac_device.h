@@ -182,13 +182,14 @@ typedef struct fd_csc_store {
     int valid_coloring;            /* 1: the plan has verified that the columns sharing a row differ in colour -- then, seen from the row of a */
                                    /* stored entry (r, j), the colour's point differs from x in coordinate j ONLY, and a kernel may form it as */
                                    /* x[i] + eps * (i == j) without reading colours; 0: not verified (form the whole colour's point)          */
-    unsigned long long *note;      /* device, 2 words owned by the PLAN and zero when it is created: a launcher's memory about THIS pattern   */
+    unsigned long long *note;      /* device, 4 words owned by the PLAN and zero when it is created: a launcher's memory about THIS pattern   */
                                    /* (which never changes while the plan lives) -- e.g. "verified on an earlier call: it is exactly my stencil, */
                                    /* the row indices need not be read again" (the 7-point family: 290 -> 210 us).  May be NULL.              */
     long long reach;               /* max |row - column| over the local stored entries (<= 0: not computed / diagonal).  A HINT for staging: the rows a    */
                                    /* workgroup's 256 columns touch lie within `reach` of them, and -- for a residual whose rows read the     */
                                    /* columns of the Jacobian's own pattern -- the coordinates those rows read within 2 * reach               */
                                    /* (fd_csc_store_cols_win keeps that window of x in LDS; anything outside it is read from memory)         */
+    unsigned long long plan_serial;/* unique per plan (never reused): what a launcher may key its own HOST-side memory about the plan on      */
 } fd_csc_store;
 
 /* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------

@@ -172,6 +172,55 @@ def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, cas
     assert np.max(np.abs(a.cpu().numpy() - want)) < (5e-6 if fdtype == "forward" else 5e-8) * 10
 
 
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+# (3000, 12, 40): ~12 entries per row -- more than a tile's staged run holds: the overflow rows read their lists from memory
+@pytest.mark.parametrize("case", [(300, 4, 9, 1), (5000, 6, 300, 4), (70001, 6, 300, 7), (3000, 12, 40, 8), (2000, 3, 700, 9)])
+def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case):
+    # k_f_sparse_store_rows: the first launch on a plan only CHECKS that the plan's pattern is the one the residual was created from (the
+    # column kernel stores); once the verdict has reached the host (read back asynchronously) the launches go row by row -- every row's
+    # plain terms once, prefix carried, suffix added: the additions of the full evaluation in the same order => the hand-over path's bits.
+    N, per_col, reach, seed = case
+    colptr, rowval = _random_pattern(N, N, per_col, reach, seed)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    f = fd.BuiltinF.sparse(N, N, colptr, rowval)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    ps.set_lazy(f)
+    ph = fd.make_plan(J, J, colors, fdtype)
+    rng = np.random.default_rng(seed)
+    n_rows = []
+    for it in range(5):
+        x = _dev(rng.random(N) + 0.1 * (it + 1))
+        a, b = _dev(np.full(rowval.size, np.nan)), _dev(np.full(rowval.size, np.nan))
+        ps.jacobian(f, x, [a])
+        ph.jacobian(f, x, [b])
+        torch.cuda.synchronize()
+        assert not torch.isnan(a).any() and torch.equal(a.view(torch.int64), b.view(torch.int64)), it
+        n_rows.append(f.row_stores())
+    assert n_rows[0] == 0 and n_rows[-1] >= 3, n_rows          # (the first call checks; the verdict is on the host by the third at the latest)
+    # another plan, whose pattern is NOT the residual's (one more stored entry per column 0: a structural zero of this f): the check
+    # fails, the column kernel keeps storing -- correct values, no row-wise launch
+    cp2, rv2 = colptr.copy(), rowval.copy()
+    extra = int(np.setdiff1d(np.arange(1, min(N, 50) + 1), rowval[cp2[0] - 1:cp2[1] - 1])[0])
+    col0 = np.sort(np.append(rowval[cp2[0] - 1:cp2[1] - 1], extra))
+    rv2 = np.concatenate([col0, rowval[cp2[1] - 1:]])
+    cp2[1:] += 1
+    J2 = fd.SparseMatrixCSC(N, N, cp2, rv2, None)
+    colors2 = fd.matrix_colors(J2)
+    ps2 = fd.make_plan(J2, J2, colors2, fdtype, store_csc=True)
+    ps2.set_lazy(f)
+    ph2 = fd.make_plan(J2, J2, colors2, fdtype)
+    before = f.row_stores()
+    for it in range(4):
+        x = _dev(rng.random(N) + 0.2)
+        a, b = _dev(np.full(rv2.size, np.nan)), _dev(np.full(rv2.size, np.nan))
+        ps2.jacobian(f, x, [a])
+        ph2.jacobian(f, x, [b])
+        torch.cuda.synchronize()
+        assert not torch.isnan(a).any() and torch.equal(a.view(torch.int64), b.view(torch.int64)), it
+    assert f.row_stores() == before
+
+
 @pytest.mark.parametrize("family", ["sparse", "lap7"])
 def test_complex_step_column_store_bit_identical_and_oracle(oracle, family):
     # FD_LAZY_CAP_STORE_CSC_COMPLEX: the complex step through the column store -- every stored entry's row at x + i eps e_j,
