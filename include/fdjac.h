@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FDJAC_VERSION 401
+#define FDJAC_VERSION 500
 
 typedef struct fd_ctx fd_ctx;
 typedef struct fd_plan fd_plan;

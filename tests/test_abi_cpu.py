@@ -25,7 +25,7 @@ def test_header_symbols_all_exported(L):
     assert declared == set(fd.lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.fd_version() == 401
+    assert L.fd_version() == 500
 
 
 def test_no_gpu_fails_loudly(L):
