@@ -272,7 +272,7 @@ static int client_jit(int64_t N, int reps)
         const double t = (now_ms() - t0) / reps;
         if (k == 0) t_jit = t; else if (k == 1) t_opq = t; else t_blt = t;
     }
-    printf("jit N=%lld: runtime-compiled functor, one-launch column store %.4f ms | same functor as an opaque f! %.4f ms | built-in family (band store) %.4f ms\n",
+    printf("jit N=%lld: runtime-compiled functor, one storing launch (fd_band_store_cols) %.4f ms | same functor as an opaque f! %.4f ms | built-in family (band store) %.4f ms\n",
            (long long)N, t_jit, t_opq, t_blt);
     CHECK(fd_plan_destroy(pb)); CHECK(fd_plan_destroy(pj)); CHECK(fd_plan_destroy(po));
     CHECK(fd_builtin_f_destroy(fbctx)); CHECK(fd_f_compiled_destroy(fjctx));

@@ -87,6 +87,7 @@ struct JitModule {
     hipFunction_t rows = nullptr;
     hipFunction_t store[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [colour bytes == 4][central]
     hipFunction_t store_win[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // fd_band_store_cols: [bandwidths (1,1) / (2,2)][forward / central]
     unsigned sizeof_f = 0;
     int refs = 0;
     std::string key;
@@ -141,6 +142,23 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
 {
     (void)fx; (void)fx_stride; (void)row_begin; (void)row_end;
     fd_jit_f *j = (fd_jit_f *)fctx;
+    if (lp->store && lp->store_kind == FD_STORE_BAND && !lp->is_complex) {
+        // an exact band with cyclic colours (CSC nzval, BandedMatrix data, Tridiagonal diagonals): fd_band_store_cols -- no index reads;
+        // bandwidths (1, 1) and (2, 2) are compiled with the functor, anything else is declined (a CSC pattern then takes the column store)
+        fd_band_store bs = *(const fd_band_store *)lp->store;
+        const int wi = (bs.l == 1 && bs.u == 1) ? 0 : (bs.l == 2 && bs.u == 2) ? 1 : -1;
+        const int central = lp->pts == 2 ? 1 : 0;
+        if (wi < 0 || !j->m->band[wi][central] || bs.elem_bytes != j->elem_bytes || bs.M != j->M || bs.N != j->N || bs.col_end <= bs.col_begin ||
+            lp->c_lo != 0 || lp->ncolors != bs.C || !(central || (lp->pts == 1 && lp->diff == 2)))
+            return FD_LAZY_DECLINED;
+        long long jstart = bs.col_begin & ~1ll;
+        const void *x = lp->x, *eps = lp->eps;
+        void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &bs, &jstart};
+        const unsigned g = (unsigned)((bs.col_end - jstart + 511) / 512);
+        if (hipModuleLaunchKernel(j->m->band[wi][central], g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+        j->launches += 1;
+        return 0;
+    }
     if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
     fd_csc_store st = *(const fd_csc_store *)lp->store;
     if (st.elem_bytes != j->elem_bytes || (st.color_bytes != 1 && st.color_bytes != 4) || st.M != j->M || st.N != j->N || st.col_end <= st.col_begin)
@@ -233,6 +251,12 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
                     names[w][cb][md] = std::string(w ? "fd_csc_store_cols_win<" : "fd_csc_store_cols<") + real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
                     (void)R->AddNameExpression(prog, names[w][cb][md].c_str());
                 }
+        std::string bnames[2][2];
+        for (int wi = 0; wi < 2; ++wi)
+            for (int md = 0; md < 2; ++md) {
+                bnames[wi][md] = std::string("fd_band_store_cols<") + real + ", " + (md ? "1" : "0") + ", fdjit_F, " + (wi ? "2, 2>" : "1, 1>");
+                (void)R->AddNameExpression(prog, bnames[wi][md].c_str());
+            }
         const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
         rr = R->CompileProgram(prog, 5, opts);
         size_t ls = 0;
@@ -255,6 +279,12 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
                     const char *ln = nullptr;
                     if (R->GetLoweredName(prog, names[w][cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[w][cb][md] = ln;
                 }
+        std::string blow[2][2];
+        for (int wi = 0; wi < 2; ++wi)
+            for (int md = 0; md < 2; ++md) {
+                const char *ln = nullptr;
+                if (R->GetLoweredName(prog, bnames[wi][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) blow[wi][md] = ln;
+            }
         (void)R->DestroyProgram(&prog);
         FD_REQUIRE(rr == HIPRTC_SUCCESS && cs > 0, FD_ERR_HIP, "hiprtcGetCode failed");
         m = new (std::nothrow) JitModule();
@@ -267,6 +297,9 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
                 if (e == hipSuccess && !low[1][cb][md].empty() && hipModuleGetFunction(&m->store_win[cb][md], m->mod, low[1][cb][md].c_str()) != hipSuccess)
                     m->store_win[cb][md] = nullptr;       // (the windowed form is an optimisation: the plain one serves)
             }
+        for (int wi = 0; wi < 2 && e == hipSuccess; ++wi)
+            for (int md = 0; md < 2; ++md)
+                if (blow[wi][md].empty() || hipModuleGetFunction(&m->band[wi][md], m->mod, blow[wi][md].c_str()) != hipSuccess) m->band[wi][md] = nullptr;      // (an optimisation)
         if (e == hipSuccess) {
             hipDeviceptr_t dp = nullptr;
             size_t bytes = 0;
@@ -305,7 +338,8 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     if (params_bytes > 0) memcpy(j->params.data(), params, (size_t)params_bytes);
     *fn_out = jit_launch;
     if (lazy_out) *lazy_out = jit_launch_lazy;
-    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE;
+    // (FD_LAZY_CAP_STORE: exact bands of width (1, 1) / (2, 2) through fd_band_store_cols; every other storing request is declined)
+    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | ((m->band[0][0] || m->band[1][0]) ? FD_LAZY_CAP_STORE : 0);
     *fctx_out = j;
     return FD_OK;
 }

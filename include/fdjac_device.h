@@ -820,6 +820,66 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
     }
     run.template flush<true>();
 }
+
+/* ---- a ROW FUNCTOR storing an exact band itself (round 5) ----------------------------------------------------------------------------
+ * F: `template <class P> __device__ T operator()(long long i, const P &X) const` -- row i of the residual at the point X (X(j) = j-th
+ * coordinate) -- as for fd_csc_store_cols.  For a Jacobian whose pattern is the exact band (L, U) with cyclic colours (what a plan
+ * hands a FD_LAZY_CAP_STORE launcher as `fd_band_store`: CSC nzval of the band, BandedMatrix data or a Tridiagonal's three
+ * diagonals) no index is read at all: lane t of a wavefront owns the columns jw + 2t, jw + 2t + 1, evaluates the L + U + 1 rows each
+ * touches at x + eps e_j (and at x - eps e_j, or at x: the launch forms f(x) of its rows itself), divides, and the wavefront's
+ * 128 (L + U + 1) quotients leave through fd_band_emit_wave as dense 16-byte stores.  The window of x the workgroup's 512 columns can
+ * see is staged in LDS (a functor that reads further takes those coordinates from memory).  Same points, same operations as
+ * fd_csc_store_cols: same bits.  Launch: (col_end - jstart + 511) / 512 workgroups of 256 threads, jstart = col_begin rounded down
+ * to even; all colours in one launch.                                                                                               */
+template <typename T, int MODE, class F, int L, int U>
+__global__ void __launch_bounds__(256) fd_band_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, fd_band_store st, long long jstart)
+{
+    constexpr int W = L + U + 1, HALO = L + U;
+    __shared__ __attribute__((aligned(16))) T s_emit[4][FD_BAND_WAVE_LDS(W)];
+    __shared__ __attribute__((aligned(16))) T s_x[512 + 2 * HALO + 4];
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const long long j0 = jstart + (long long)blockIdx.x * 512;
+    if (j0 >= st.col_end) return;
+    long long w0 = j0 - HALO > 0 ? j0 - HALO : 0, w1 = j0 + 512 + HALO < st.N ? j0 + 512 + HALO : st.N;
+    w0 &= ~1ll;
+    {
+        typedef T fd_pair_t __attribute__((ext_vector_type(2)));
+        const long long nx = w1 - w0, npair = nx / 2;
+        fd_pair_t vx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const long long i = u * 256 + threadIdx.x; if (i < npair) vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0 + 2 * i); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const long long i = u * 256 + threadIdx.x; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
+    }
+    __syncthreads();
+    const long long jw = j0 + (long long)wave * 128;
+    if (jw >= st.col_end) return;                                          /* (wave-uniform: fd_band_emit_wave wants whole wavefronts) */
+    const long long j = jw + 2 * lane;
+    T q[2 * W];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const long long jj = j + o;
+        const bool valid = jj >= st.col_begin && jj < st.col_end && jj < st.N;
+        const T h = valid ? eps[fd_band_color(&st, jj)] : (T)1;
+        const T dv = MODE == 1 ? 2 * h : h, yd = (T)1 / dv;
+        fd_window_column_point<T> X = {x, (const FD_LDS_PTR(T))s_x, w0, w1, jj, h, 0, (jj >= w0 && jj < w1) ? (unsigned)(jj - w0) : 0xFFFFFFFFu};
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const long long r = jj - U + k;
+            T v = 0;
+            if (valid && r >= 0 && r < st.M) {
+                X.minus = 0;
+                const T vp = f(r, X);
+                X.minus = MODE == 1 ? 1 : 2;
+                const T vm = f(r, X);
+                v = fd_div_shared<T>(vp - vm, dv, yd);
+            }
+            q[o * W + k] = v;
+        }
+    }
+    fd_band_emit_wave<T, W>(&st, s_emit[wave], jw, q);
+}
 #endif /* __HIPCC__ && __cplusplus */
 
 #endif /* FDJAC_DEVICE_H */

@@ -134,3 +134,105 @@ def test_jit_errors_are_reported():
     assert e.value.code == 1 and "compil" in str(e.value)
     with pytest.raises(fd.lib.FdError):       # the parameter bytes must be the functor object
         fd.JitF(TRIDIAG_NL, "TridiagNL", 10, 10, params=b"\x00" * 3)
+
+
+PENTA = """
+// a pentadiagonal residual: row i reads x[i-2 .. i+2]; nonlinear in x[i] and x[i+2]
+struct Penta {
+    long long n;
+    template <class P> __device__ real_t operator()(long long i, const P &X) const
+    {
+        const real_t c = X(i);
+        const real_t a2 = X(i > 1 ? i - 2 : i), a1 = X(i > 0 ? i - 1 : i), b1 = X(i + 1 < n ? i + 1 : i), b2 = X(i + 2 < n ? i + 2 : i);
+        const real_t m2 = i > 1 ? a2 : (real_t)0, m1 = i > 0 ? a1 : (real_t)0, p1 = i + 1 < n ? b1 : (real_t)0, p2 = i + 2 < n ? b2 : (real_t)0;
+        real_t v = ((m2 - (real_t)4 * m1) + (real_t)6 * c) - (real_t)4 * p1;
+        v = (v + p2) + (c * c) * p2;
+        return v;
+    }
+};
+"""
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("storage", ["csc", "tridiagonal", "banded"])
+@pytest.mark.parametrize("N", [200_003, 130, 1])
+def test_jit_functor_stores_an_exact_band_itself(fdtype, storage, N):
+    # fd_band_store_cols (include/fdjac_device.h) instantiated for the compiled functor: with FD_LAZY_CAP_STORE the plan of an exact
+    # band with cyclic colours hands the launcher a fd_band_store -- no compact pattern copy, no index read, ONE launch after the step
+    # sizes; CSC nzval, a Tridiagonal's three diagonals and BandedMatrix data; the built-in family's bits
+    colors = P.cyclic_colors(N, 3)
+    x = _dev(np.random.default_rng(3).random(N) + 0.1)
+    fb = fd.BuiltinF("tridiag_nl", N)
+    fj = fd.JitF(TRIDIAG_NL, "TridiagNL", N, N, params=struct.pack("q", N))
+    assert fj.lazy_caps & fd.lib.LAZY_CAP_STORE
+
+    def build():
+        if storage == "csc":
+            cp, rv = P.tridiag_csc(N)
+            J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+            return J, J, [_dev(np.full(rv.size, np.nan))]
+        if storage == "tridiagonal":
+            J = fd.Tridiagonal(None, torch.empty(N, dtype=torch.float64, device="cuda"), None)
+            return J, None, [_dev(np.full(max(N - 1, 0), np.nan)), _dev(np.full(N, np.nan)), _dev(np.full(max(N - 1, 0), np.nan))]
+        J = fd.BandedMatrix(torch.zeros((N, 3), dtype=torch.float64, device="cuda").t(), N, 1, 1)
+        return J, None, [_dev(np.full(3 * N, np.nan))]
+
+    outs = {}
+    for name, f in (("builtin", fb), ("jit", fj)):
+        J, sp, out = build()
+        plan = fd.make_plan(J, sp, colors, fdtype)
+        plan.set_lazy(f)
+        n0 = f.counts()[0] if name == "builtin" else f.launches
+        plan.jacobian(f, x, out)
+        n1 = f.counts()[0] if name == "builtin" else f.launches
+        if N >= 3:
+            assert plan.info(fd.lib.INFO_LAZY_STORE) == 1 and plan.info(fd.lib.INFO_STORE_CSC) == 0
+            assert n1 - n0 == 1, (name, n1 - n0)
+        C = int(np.max(colors))
+        assert plan.fcalls_last == (1 + C if fdtype == "forward" else 2 * C)
+        outs[name] = [o.clone() for o in out]
+    for a, b in zip(outs["builtin"], outs["jit"]):
+        if storage == "banded" and N > 1:
+            # (the two corner slots of BandedMatrix data belong to no entry: whatever the kernels leave there is not compared)
+            a, b = a.view(N, 3).clone(), b.view(N, 3).clone()
+            a[0, 0] = b[0, 0] = 0.0
+            a[N - 1, 2] = b[N - 1, 2] = 0.0
+        assert not torch.isnan(b).any() or storage == "banded"
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), storage
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("lu", [(2, 2), (3, 3)])
+def test_jit_band_store_other_bandwidths(fdtype, lu):
+    # (2, 2) is compiled with every functor; (3, 3) is not: the launcher declines and the plan falls back (column store of the CSC pattern
+    # or the hand-over) -- the same bits either way.  The residual reads x[i-2 .. i+2] (its (3, 3) pattern holds structural zeros).
+    l, u = lu
+    N = 50_021
+    cp, rv = P.banded_csc(N, N, l, u)
+    colors = P.cyclic_colors(N, l + u + 1)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    x = _dev(np.random.default_rng(4).random(N) + 0.1)
+    fj = fd.JitF(PENTA, "Penta", N, N, params=struct.pack("q", N))
+    ref_plan = fd.make_plan(J, J, colors, fdtype)                        # opaque: materialised points, hand-over
+    ref = _dev(np.full(rv.size, np.nan))
+    ref_plan.jacobian(fj, x, [ref])
+    plan = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    plan.set_lazy(fj)
+    out = _dev(np.full(rv.size, np.nan))
+    n0 = fj.launches
+    plan.jacobian(fj, x, [out])
+    assert plan.info(fd.lib.INFO_LAZY_STORE) == 1 and fj.launches - n0 == (1 if lu == (2, 2) else fj.launches - n0)
+    assert not torch.isnan(out).any() and torch.equal(out.view(torch.int64), ref.view(torch.int64))
+    # and without the compact pattern copy: (2, 2) still stores in one launch (the band needs no copy), (3, 3) is handed over
+    plan2 = fd.make_plan(J, J, colors, fdtype)
+    plan2.set_lazy(fj)
+    out2 = _dev(np.full(rv.size, np.nan))
+    plan2.jacobian(fj, x, [out2])
+    assert torch.equal(out2.view(torch.int64), ref.view(torch.int64))
+    # analytic check of a few interior entries: d f_i / d x_i = 6 + 2 x_i x_{i+2}
+    xh = x.cpu().numpy()
+    cols = P.csc_cols(cp) - 1
+    diag = np.nonzero((rv - 1) == cols)[0]
+    k = diag[100:110]
+    i = cols[k]
+    assert np.max(np.abs(out.cpu().numpy()[k] - (6.0 + 2.0 * xh[i] * xh[i + 2]))) < (5e-6 if fdtype == "forward" else 5e-8)
