@@ -813,6 +813,49 @@ def main():
         except Exception as e:
             opaque = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- side measurement (single GPU, untimed): the same residual given as SOURCE and compiled at run time (fd_f_compile_rows,
+    # hiprtc) -- what a caller without an offline toolchain gets: eps + ONE launch of fd_band_store_cols instantiated for the functor
+    # (an exact band needs no index read), and the same functor as an opaque f! (materialised points) for comparison.
+    jit_path = None
+    if world == 1 and f_mode == "lazy" and not args.no_plain_handover and cfg in ("c2", "c4") and args.dtype == "f64":
+        try:
+            import struct as _struct
+            src = ("struct BenchTridiag {\n    long long n;\n"
+                   "    template <class P> __device__ real_t operator()(long long i, const P &X) const\n    {\n"
+                   "        const real_t xi = X(i), xm = X(i > 0 ? i - 1 : i), xp = X(i + 1 < n ? i + 1 : i);\n"
+                   "        const real_t a = i > 0 ? xm : (real_t)0, b = i + 1 < n ? xp : (real_t)0;\n"
+                   "        return (a - (real_t)2 * xi) + b;\n    }\n};\n")
+            t0 = time.perf_counter()
+            fj = fd.JitF(src, "BenchTridiag", N, N, params=_struct.pack("q", N), ctx=ctx)
+            compile_ms = (time.perf_counter() - t0) * 1e3
+            cp_s, rv_s = P.tridiag_csc(N)
+            pat_s = fd.SparseMatrixCSC(N, N, cp_s, rv_s, None)
+            res_j = {}
+            for name, lazy in (("one_launch", True), ("opaque", False)):
+                plan_j = fd.make_plan(pat_s, pat_s, colors, fdtype, ctx=ctx)
+                if lazy:
+                    plan_j.set_lazy(fj)
+                out_j = torch.full_like(out, float("nan"))
+                enq_j = plan_j.bind(fj, x, [out_j])
+                for _ in range(3):
+                    enq_j()
+                torch.cuda.synchronize()
+                plan_j.enable_timing(3)
+                for _ in range(max(args.steps, 20)):
+                    enq_j()
+                torch.cuda.synchronize()
+                tj = plan_j.timing_samples("total")
+                plan_j.enable_timing(0)
+                res_j[name] = {"median_ms_per_step": float(np.median(tj)) if tj else None, "lazy_store": int(plan_j.info(fd.lib.INFO_LAZY_STORE)),
+                               "bit_identical_to_timed_result": bool(torch.equal(out_j, timed_result))}
+                del plan_j, out_j, enq_j
+            jit_path = {"what": "the residual as a source string -> fd_f_compile_rows (hiprtc, gfx950, -ffp-contract=off); one_launch: eps + "
+                                "fd_band_store_cols<double, MODE, F, 1, 1>; opaque: the compiled functor behind a plain fd_f_launch",
+                        "compile_ms": compile_ms, **res_j}
+            del cp_s, rv_s, pat_s, fj
+        except Exception as e:
+            jit_path = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- side measurement (single GPU, untimed): the DROP-IN call -- the sequence every existing FiniteDiff.jl call site
     # goes through (julia/FiniteDiffMI355X.jl, mirrored by api.py and examples/c_abi_clients.c::client_dropin):
     # cache -> plan lookup (O(1) identity key; optional fd_plan_matches content check) -> fd_jacobian_async.
@@ -1119,6 +1162,7 @@ def main():
             "handover_path": handover,
             "rotating_x": rotating,
             "opaque_f_path": opaque,
+            "jit_functor_path": jit_path,
             "dropin_call": dropin,
             "stages_ms": stages,
             "whole_call": {"gpu_ms": tot_ms, "hbm_bytes_model": bytes_call_model * n_local,
