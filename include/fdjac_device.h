@@ -857,6 +857,17 @@ __global__ void __launch_bounds__(256) fd_band_store_cols(F f, const T *__restri
     if (jw >= st.col_end) return;                                          /* (wave-uniform: fd_band_emit_wave wants whole wavefronts) */
     const long long j = jw + 2 * lane;
     T q[2 * W];
+    /* forward differences: f(x) of the W + 1 rows the lane's two columns touch, once (row j - U + m <-> base[m]) */
+    T base[W + 1];
+    if (MODE == 0) {
+        const bool any = j < st.col_end && j + 1 >= st.col_begin && j < st.N;
+        fd_window_column_point<T> X0 = {x, (const FD_LDS_PTR(T))s_x, w0, w1, j, (T)0, 2, 0xFFFFFFFFu};
+#pragma unroll
+        for (int m = 0; m <= W; ++m) {
+            const long long r = j - U + m;
+            base[m] = (any && r >= 0 && r < st.M) ? f(r, X0) : (T)0;
+        }
+    }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const long long jj = j + o;
@@ -871,8 +882,9 @@ __global__ void __launch_bounds__(256) fd_band_store_cols(F f, const T *__restri
             if (valid && r >= 0 && r < st.M) {
                 X.minus = 0;
                 const T vp = f(r, X);
-                X.minus = MODE == 1 ? 1 : 2;
-                const T vm = f(r, X);
+                T vm;
+                if (MODE == 1) { X.minus = 1; vm = f(r, X); }
+                else vm = base[o + k];
                 v = fd_div_shared<T>(vp - vm, dv, yd);
             }
             q[o * W + k] = v;
