@@ -862,6 +862,25 @@ template <typename T, int SK> __device__ __forceinline__ T stencil5_row(T c, T w
 // the CORRECTLY ROUNDED quotient (Markstein: q1 is a faithful rounding of a / b, so q2 = RN(a / b) when nothing over- or
 // underflows; zero, tiny, huge and non-finite operands take the true division) -- the bits of IEEE a / b, about half its
 // instructions (scripts/ubench/exact_div_probe.hip: 5e10 random and next-to-tie operand pairs, 0 mismatches).  Float64 only.
+// `bok` = div_shared_ok(b), tested ONCE per divisor: with |b| in [2^-100, 2^100] and |a| in [2^-800, 2^800] the first quotient lies in
+// [2^-900, 2^900] by itself -- two comparisons per quotient instead of four.  A/B on one box (scripts/ab_c5.sh, ab_c3.sh): the
+// block-coupled kernel 49.9 -> 48.5 us (used there); the 5-point kernel 98 -> 100 us (not used there).
+__device__ __forceinline__ bool div_shared_ok(real_t b) { const real_t mb = fabs(b); return mb >= (real_t)0x1p-100 && mb <= (real_t)0x1p100; }
+template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y);
+template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y, bool bok)
+{
+    if constexpr (FAST && sizeof(real_t) == 8) {
+        const double ma = fabs(a);
+        if (!(bok && ma >= 0x1p-800 && ma <= 0x1p800)) return a / b;
+        const double q0 = a * y;
+        const double r0 = __builtin_fma(-b, q0, a);
+        const double q1 = __builtin_fma(r0, y, q0);
+        const double r1 = __builtin_fma(-b, q1, a);
+        return __builtin_fma(r1, y, q1);
+    } else {
+        return a / b;
+    }
+}
 template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y)
 {
     if constexpr (FAST && sizeof(real_t) == 8) {
@@ -1518,7 +1537,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
                 const real_t e = ce[q], ye = cy[q], sh = cs[q];
                 const int jl = cstart + ci;
                 real_t vim[3][2], qv[3][2];
-                bool fast = true;
+                bool fast = div_shared_ok(e);
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const T S = su[(size_t)m * B + q];
@@ -1529,8 +1548,8 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
                         const real_t snim = hit ? rcm[h] * sh : rzk[m][h];
                         vim[m][h] = (xk[m][h] * S.im + xim * S.re) + snim;
                         qv[m][h] = vim[m][h] * ye;
-                        const real_t mq = fabs(qv[m][h]), ma = fabs(vim[m][h]);
-                        fast = fast & (!mv[m] | ((mq >= (real_t)0x1p-900) & (mq <= (real_t)0x1p900) & (ma >= (real_t)0x1p-900) & (ma <= (real_t)0x1p900)));
+                        const real_t ma = fabs(vim[m][h]);            // (the divisor's range is tested once per column: div_shared_ok)
+                        fast = fast & (!mv[m] | ((ma >= (real_t)0x1p-800) & (ma <= (real_t)0x1p800)));
                     }
                 }
                 if (fast) {
@@ -1591,7 +1610,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             const int jl = cstart + ci;                                   // the column's own row is row jl of the middle block
             // the three entries of the lane as independent chains (nothing but the stores is predicated)
             real_t vim[3], qv[3];
-            bool fast = sizeof(real_t) == 8;
+            bool fast = sizeof(real_t) == 8 && div_shared_ok(e);
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const T S = su[(size_t)m * B + q];
@@ -1601,8 +1620,8 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
                 const real_t snim = hit ? rcm * sh : rzk[m];
                 vim[m] = (xk[m] * S.im + xim * S.re) + snim;
                 qv[m] = vim[m] * ye;
-                const real_t mq = fabs(qv[m]), ma = fabs(vim[m]);
-                fast = fast & (!mv[m] | ((mq >= (real_t)0x1p-900) & (mq <= (real_t)0x1p900) & (ma >= (real_t)0x1p-900) & (ma <= (real_t)0x1p900)));
+                const real_t ma = fabs(vim[m]);
+                fast = fast & (!mv[m] | ((ma >= (real_t)0x1p-800) & (ma <= (real_t)0x1p800)));
             }
             // vim / e: div_shared's correctly rounded quotient (two FMA corrections of vim * (1 / e)); true division out of its range
             if (fast) {

@@ -12,6 +12,8 @@
 
 constexpr real_t kSix = 6, kQuarter = 0.25, kEighth = 0.125;
 template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y);   // (fdjac_builtin_f.hip, below the include)
+template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real_t b, real_t y, bool bok);
+__device__ __forceinline__ bool div_shared_ok(real_t b);
 
 template <typename T> struct PlainPoint {      // a materialised point
     const T *x;

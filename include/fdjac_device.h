@@ -706,6 +706,27 @@ template <typename T> __host__ __device__ inline size_t fd_csc_win_lds_bytes(lon
    CORRECTLY ROUNDED quotient (Markstein: q1 is a faithful rounding of a / b, so q2 = RN(a / b) when nothing over- or underflows;
    zero, tiny, huge and non-finite operands take the true division) -- the bits of IEEE a / b at about a third of its instructions
    (scripts/ubench/exact_div_probe.hip: 5e10 random and next-to-tie operand pairs, 0 mismatches).  Float64; Float32 divides. */
+/* the same with the divisor's range tested ONCE by the caller (b_ok = fd_div_shared_ok(b)): |b| in [2^-100, 2^100] and |a| in
+   [2^-800, 2^800] put the first quotient inside [2^-900, 2^900] by themselves -- two comparisons per quotient instead of four */
+template <typename T> __device__ inline bool fd_div_shared_ok(T b)
+{
+    const T mb = b < 0 ? -b : b;
+    return mb >= (T)0x1p-100 && mb <= (T)0x1p100;
+}
+template <typename T> __device__ inline T fd_div_shared(T a, T b, T y, bool b_ok)
+{
+    if constexpr (sizeof(T) == 8) {
+        const double ma = __builtin_fabs(a);
+        if (!(b_ok && ma >= 0x1p-800 && ma <= 0x1p800)) return a / b;
+        const double q0 = a * y;
+        const double r0 = __builtin_fma(-b, q0, a);
+        const double q1 = __builtin_fma(r0, y, q0);
+        const double r1 = __builtin_fma(-b, q1, a);
+        return __builtin_fma(r1, y, q1);
+    } else {
+        return a / b;
+    }
+}
 template <typename T> __device__ inline T fd_div_shared(T a, T b, T y)
 {
     if constexpr (sizeof(T) == 8) {
@@ -874,7 +895,7 @@ __global__ void __launch_bounds__(256) fd_band_store_cols(F f, const T *__restri
         const bool valid = jj >= st.col_begin && jj < st.col_end && jj < st.N;
         const T h = valid ? eps[fd_band_color(&st, jj)] : (T)1;
         const T dv = MODE == 1 ? 2 * h : h, yd = (T)1 / dv;
-        fd_window_column_point<T> X = {x, (const FD_LDS_PTR(T))s_x, w0, w1, jj, h, 0, (jj >= w0 && jj < w1) ? (unsigned)(jj - w0) : 0xFFFFFFFFu};
+            fd_window_column_point<T> X = {x, (const FD_LDS_PTR(T))s_x, w0, w1, jj, h, 0, (jj >= w0 && jj < w1) ? (unsigned)(jj - w0) : 0xFFFFFFFFu};
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const long long r = jj - U + k;
