@@ -285,8 +285,7 @@ __device__ __forceinline__ void tri_guard_rows(const SrcRegs<NRHS> &R, int64_t n
     }
     if (nd) atomicOr(nd_flag, 1);
 }
-// (in two halves: the loads of a tile can be issued long before they are consumed -- the persistent kernels below keep the NEXT
-// tile's loads in flight while they work on the current one)
+// (in two halves, issue and land: the two-level kernels below issue a tile's loads together with its halo's and land them later)
 template <typename Src, int NRHS> struct TriLoads {
     static constexpr int kRounds = Src::kUnitRhs ? 4 : 3 + NRHS;
     double g[kRounds][kChunk];
