@@ -2070,8 +2070,9 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     // the tridiagonal and 5-point kernels write exactly the (pair-rounded) row window they are handed; the block-coupled
     // kernel writes whole blocks, so it does not claim FD_LAZY_CAP_ROW_WINDOW
     if (b->family == FD_F_LAP7 || b->family == FD_F_SPARSE) {      // functor families: the column-by-column store only
-        // (a 7-point row costs less than the gather of its f(x): that family evaluates the unperturbed rows inside the storing launch)
-        *caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_COMPLEX | (b->family == FD_F_LAP7 ? FD_LAZY_CAP_STORE_CSC_BASE : 0);
+        // (a 7-point row costs less than the gather of its f(x), and the sparse family's row-wise store has f(x) of its rows anyway: both
+        //  evaluate the unperturbed rows inside the storing launch)
+        *caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_COMPLEX | FD_LAZY_CAP_STORE_CSC_BASE;
         return FD_OK;
     }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |

@@ -821,8 +821,7 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
 {
     if (!lp->store || lp->store_kind != FD_STORE_CSC) return FD_LAZY_DECLINED;
     const fd_csc_store st = *(const fd_csc_store *)lp->store;
-    if (st.elem_bytes != (int)sizeof(real_t) || st.color_bytes != (int)sizeof(CT) || st.M != b->M || st.N != b->N || st.col_end <= st.col_begin ||
-        (!lp->is_complex && lp->pts == 1 && !st.fx_base && b->family != FD_F_LAP7))
+    if (st.elem_bytes != (int)sizeof(real_t) || st.color_bytes != (int)sizeof(CT) || st.M != b->M || st.N != b->N || st.col_end <= st.col_begin)
         return FD_LAZY_DECLINED;
     const unsigned g = fd_xcd_grid((st.col_end - st.col_begin + kBlock - 1) / kBlock);
     const int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
@@ -855,70 +854,73 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
     } else {
         const SparseF f = {b->d_srow, b->d_scol};
         // a locally banded pattern (the plan measured its reach) with a verified colouring: the workgroup's window of x, f(x) of its
-        // rows and the rows' pattern are staged in LDS (fd_csc_store_cols_win); otherwise the plain column kernel
+        // rows and the rows' pattern are staged in LDS (column kernels), or the Jacobian is stored row by row (k_f_sparse_store_rows);
+        // otherwise the plain column kernel.  Forward differences without fx_base (FD_LAZY_CAP_STORE_CSC_BASE): the row-wise kernel has
+        // f(x) of its rows anyway; the generic column kernels evaluate the unperturbed row themselves.
         const int64_t reach = st.reach;
-        bool win = st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N;
-        if (win) {
-            const int64_t rows = fd_csc_win_rlen(reach);
-            const double per_row = b->M > 0 ? (double)b->prm[2] / (double)b->M : 1.0;
-            const int cap = (int)std::min<int64_t>((int64_t)(rows * per_row * 1.10) + 128, 16384);      // (a window's rows hold rows x per_row entries +- a few per cent; what does not fit is read from memory)
-            const size_t sb = SparseF::stage_bytes(rows, cap);
-            const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
-            const size_t lds_s = sparse_sorted_lds_bytes(reach, cap);
-            if (lds_s <= 64 * 1024 && (lp->pts == 2 || st.fx_base != nullptr)) {      // the entry-balanced form (see k_f_sparse_store_sorted)
-                // ... and the row-wise store (k_f_sparse_store_rows).  Until the plan's verdict is known on the host both are enqueued and
-                // the plan's note decides on the device which one works; afterwards only that one is launched.
-                const int cap_r = (int)std::min<int64_t>((int64_t)(kBlock * per_row * 1.25) + 64, 3072);
-                const size_t lds_r = sparse_rows_lds_bytes(reach, lp->ncolors, cap_r);
-                const char *rs = fdjac::test_switch("FDJAC_SPARSE_ROWS");
-                const bool rows = st.note != nullptr && st.plan_serial != 0 && lds_r <= 64 * 1024 && b->d_sdest && !(rs && *rs && atoi(rs) == 0);
-                const long long e_base = b->h_colptr[(size_t)st.col_begin], expect = (long long)b->h_colptr[(size_t)st.col_end] - e_base;
-                const unsigned long long key = rows ? ((0x5BA25E0000000000ull ^ ((unsigned long long)(uintptr_t)b->d_sdest << 3) ^ ((unsigned long long)st.col_begin * 0x9E3779B97F4A7C15ull) ^
-                                                        (unsigned long long)st.col_end) & ~2ull) | 4ull : 0ull;
-                int verdict = 0;                       // 0 unknown, 1 the plan's pattern is the functor's, 2 it is not
-                BuiltinF::RowsMemo *memo = nullptr;
-                if (rows) {
-                    std::lock_guard<std::mutex> lock(b->rows_mutex);
-                    memo = &b->rows_memo[st.plan_serial];
-                    if (memo->verdict == 0 && memo->pending && hipEventQuery(memo->ev) == hipSuccess) {
-                        memo->pending = false;
-                        memo->verdict = *memo->h_note == key ? 1 : *memo->h_note == (key ^ 2ull) ? 2 : 0;
-                    }
-                    verdict = memo->verdict;
-                }
-                if (verdict != 1) {
-                    const unsigned long long gate = verdict == 2 ? 0ull : key;
+        const bool win = st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N;
+        const double per_row = b->M > 0 ? (double)b->prm[2] / (double)b->M : 1.0;
+        // the row-wise store: whichever of the two kernels the plan's note names does the work; until the verdict is known on the host
+        // both are enqueued (they store the same bits), afterwards only the one that works
+        const int cap_r = (int)std::min<int64_t>((int64_t)(kBlock * per_row * 1.25) + 64, 3072);
+        const size_t lds_r = win ? sparse_rows_lds_bytes(reach, lp->ncolors, cap_r) : 0;
+        const char *rs = fdjac::test_switch("FDJAC_SPARSE_ROWS");
+        const bool rows = win && st.note != nullptr && st.plan_serial != 0 && lds_r <= 64 * 1024 && b->d_sdest && !(rs && *rs && atoi(rs) == 0);
+        const long long e_base = b->h_colptr[(size_t)st.col_begin], expect = (long long)b->h_colptr[(size_t)st.col_end] - e_base;
+        const unsigned long long key = rows ? ((0x5BA25E0000000000ull ^ ((unsigned long long)(uintptr_t)b->d_sdest << 3) ^ ((unsigned long long)st.col_begin * 0x9E3779B97F4A7C15ull) ^
+                                                (unsigned long long)st.col_end) & ~2ull) | 4ull : 0ull;
+        int verdict = 0;                       // 0 unknown, 1 the plan's pattern is the functor's, 2 it is not
+        BuiltinF::RowsMemo *memo = nullptr;
+        if (rows) {
+            std::lock_guard<std::mutex> lock(b->rows_mutex);
+            memo = &b->rows_memo[st.plan_serial];
+            if (memo->verdict == 0 && memo->pending && hipEventQuery(memo->ev) == hipSuccess) {
+                memo->pending = false;
+                memo->verdict = *memo->h_note == key ? 1 : *memo->h_note == (key ^ 2ull) ? 2 : 0;
+            }
+            verdict = memo->verdict;
+        }
+        if (verdict != 1) {                    // a column kernel
+            bool done = false;
+            if (win) {
+                const int64_t wrows = fd_csc_win_rlen(reach);
+                const int cap = (int)std::min<int64_t>((int64_t)(wrows * per_row * 1.10) + 128, 16384);      // (a window's rows hold rows x per_row entries +- a few per cent; what does not fit is read from memory)
+                const size_t sb = SparseF::stage_bytes(wrows, cap);
+                const size_t lds = fd_csc_win_lds_bytes<real_t>(reach, lp->pts == 1 && st.fx_base != nullptr) + sb;
+                const size_t lds_s = sparse_sorted_lds_bytes(reach, cap);
+                if (lds_s <= 64 * 1024 && (lp->pts == 2 || st.fx_base != nullptr)) {      // the entry-balanced form (see k_f_sparse_store_sorted)
+                    const unsigned long long gate = (rows && verdict == 0) ? key : 0ull;
                     if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 1>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap, gate);
                     else hipLaunchKernelGGL((k_f_sparse_store_sorted<CT, 0>), dim3(g), dim3(kBlock), lds_s, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap, gate);
+                    done = true;
+                } else if (lds <= 64 * 1024) {
+                    if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 1, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
+                    else hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 0, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
+                    done = true;
                 }
-                if (verdict == 1) b->row_stores.fetch_add(1);
-                if (rows && verdict != 2) {
-                    const long long row_lo = std::max<long long>(0, st.col_begin - reach), row_hi = std::min<long long>(st.M, st.col_end + reach);
-                    const unsigned gr = fd_xcd_grid((row_hi - row_lo + kBlock - 1) / kBlock);
-                    if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 1>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
-                    else hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 0>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
-                    if (verdict == 0) {
-                        std::lock_guard<std::mutex> lock(b->rows_mutex);
-                        if (!memo->pending) {                        // the verdict on its way to the host: read at a later call, never waited for
-                            if (!memo->h_note && hipHostMalloc((void **)&memo->h_note, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) memo->h_note = nullptr;
-                            if (memo->h_note && !memo->ev && hipEventCreateWithFlags(&memo->ev, hipEventDisableTiming) != hipSuccess) memo->ev = nullptr;
-                            if (memo->h_note && memo->ev) {
-                                *memo->h_note = 0;
-                                if (hipMemcpyAsync(memo->h_note, st.note, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess &&
-                                    hipEventRecord(memo->ev, s) == hipSuccess)
-                                    memo->pending = true;
-                            }
-                        }
+            }
+            if (!done) FD_COLS(SparseF, f);
+        }
+        if (verdict == 1) b->row_stores.fetch_add(1);
+        if (rows && verdict != 2) {
+            const long long row_lo = std::max<long long>(0, st.col_begin - reach), row_hi = std::min<long long>(st.M, st.col_end + reach);
+            const unsigned gr = fd_xcd_grid((row_hi - row_lo + kBlock - 1) / kBlock);
+            if (lp->pts == 2) hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 1>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
+            else hipLaunchKernelGGL((k_f_sparse_store_rows<CT, 0>), dim3(gr), dim3(kBlock), lds_r, s, f, b->d_sdest, e_base, x, eps, c_lo, c_hi, st, (int)reach, cap_r, row_lo, row_hi, key, expect, verdict == 1 ? 1 : 0);
+            if (verdict == 0) {
+                std::lock_guard<std::mutex> lock(b->rows_mutex);
+                if (!memo->pending) {                        // the verdict on its way to the host: read at a later call, never waited for
+                    if (!memo->h_note && hipHostMalloc((void **)&memo->h_note, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) memo->h_note = nullptr;
+                    if (memo->h_note && !memo->ev && hipEventCreateWithFlags(&memo->ev, hipEventDisableTiming) != hipSuccess) memo->ev = nullptr;
+                    if (memo->h_note && memo->ev) {
+                        *memo->h_note = 0;
+                        if (hipMemcpyAsync(memo->h_note, st.note, sizeof(unsigned long long), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                            hipEventRecord(memo->ev, s) == hipSuccess)
+                            memo->pending = true;
                     }
                 }
-            } else if (lds <= 64 * 1024) {
-                if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 1, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
-                else hipLaunchKernelGGL((fd_csc_store_cols_win<real_t, CT, 0, SparseF>), dim3(g), dim3(kBlock), lds, s, f, x, eps, c_lo, c_hi, st, (int)reach, (int)sb, cap);
-            } else {
-                win = false;
             }
         }
-        if (!win) FD_COLS(SparseF, f);
     }
 #undef FD_COLS
     return hipGetLastError() == hipSuccess ? 0 : 4;
