@@ -645,6 +645,10 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_rows(SparseF f, const
     const unsigned rw = (unsigned)r & 7u;
     const int b0 = a0 - A0;                                             // the row's entries are the tile's [b0, b0 + L)
     real_t *out = (real_t *)st.out;
+    // forward differences: the subtrahend is what the plan hands over (the caller's f_in, or f(x) from a plain evaluation) -- or,
+    // without one (FD_LAZY_CAP_STORE_CSC_BASE), the row's own plain sum
+    const bool given = MODE == 0 && st.fx_base != nullptr;
+    const real_t fx_given = given ? ((const real_t *)st.fx_base)[r] : (real_t)0;
     // PURE: the whole run is staged and every column is local (so inside the window): the loops below then contain no load from
     // memory at all.  That matters more than it looks: this target counts loads and stores in ONE counter, and a loop body that MAY
     // load makes the compiler wait for everything outstanding -- the store of the iteration before -- on every trip: 12 trips x a
@@ -695,7 +699,7 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_rows(SparseF f, const
 #pragma unroll
                             for (int u = k + 1; u < RL; ++u)
                                 if (u < L) { sp = sp + tt[u]; if (MODE == 1) sm = sm + tt[u]; }
-                            out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : fx), MODE == 1 ? 2 * h : h, y);
+                            out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
                         }
                         pre = k == 0 ? tt[0] : pre + tt[k];
                     }
@@ -729,7 +733,7 @@ __global__ void __launch_bounds__(kBlock) k_f_sparse_store_rows(SparseF f, const
                     real_t sp = sparse_term(wk, v + h), sm = MODE == 1 ? sparse_term(wk, v - h) : (real_t)0;
                     if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
                     for (int u = k + 1; u < L; ++u) { const real_t t = plain(b0 + u); sp = sp + t; if (MODE == 1) sm = sm + t; }
-                    out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : fx), MODE == 1 ? 2 * h : h, y);
+                    out[q] = fd_div_shared<real_t>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
                 }
             }
             pre = k == 0 ? tk : pre + tk;

@@ -489,6 +489,57 @@ def test_random_grids_through_the_7_point_column_kernel(seed):
         assert torch.equal(a, b), (nx, ny, nz, fdtype, kw, rep, style, dtype)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_sparse_family_row_wise_store_randomised(seed):
+    # the row-wise store (k_f_sparse_store_rows) under everything a plan can ask of it: column windows (other ranks' columns are terms
+    # of its rows but not its entries), colour chunks and colour ownership, uncoloured columns, a caller's f_in, Float32, rows longer
+    # than a tile's staged run or than the register path -- five calls per plan (check, then row-wise), the hand-over path's bits
+    rng = np.random.default_rng(int(os.environ.get("FDJAC_TEST_SEED_BASE", "9000")) + seed)
+    N = int(rng.choice([257, 1000, 4097, 30011]))
+    per_col = int(rng.choice([1, 3, 6, 11, 18]))
+    reach = int(rng.choice([1, 7, 60, 300, 650]))
+    colptr, rowval = _random_pattern(N, N, per_col, reach, 100 + seed)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    if rng.random() < 0.3:
+        colors = colors.copy()
+        colors[rng.integers(0, N, size=5)] = 0                     # uncoloured columns: zeros
+    C = int(colors.max())
+    fdtype = "forward" if rng.random() < 0.6 else "central"
+    kw = {}
+    if rng.random() < 0.4:
+        a = int(rng.integers(0, N // 2))
+        kw["col_window"] = (a, int(rng.integers(a + 1, N + 1)))
+    if rng.random() < 0.3 and C > 3:
+        kw["scratch_bytes"] = 2 * 2 * 2 * N * 8 + 4096             # a few colours per chunk
+    if rng.random() < 0.25 and C > 2:
+        c0 = int(rng.integers(0, C - 1))
+        kw["color_range"] = (c0, int(rng.integers(c0 + 1, C + 1)))  # colour ownership: the other colours' entries stay untouched
+    dtype = np.float32 if rng.random() < 0.25 else np.float64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    if dtype == np.float32 and "scratch_bytes" in kw:
+        kw["scratch_bytes"] //= 2
+
+    def dev(a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=tdt, device="cuda")
+
+    f = fd.BuiltinF.sparse(N, N, colptr, rowval, dtype=dtype)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, dtype=dtype, **kw)
+    ps.set_lazy(f)
+    ph = fd.make_plan(J, J, colors, fdtype, dtype=dtype, **kw)
+    n = ps.out_len(0)
+    assert n == ph.out_len(0)
+    for rep in range(5):
+        x = dev(rng.random(N) + 0.05)
+        fin = dev(rng.random(N)) if (fdtype == "forward" and rep == 3) else None
+        fill = float(rep) + 0.5                                     # (entries of colours this plan does not own keep what was there)
+        a, b = dev(np.full(n, fill)), dev(np.full(n, fill))
+        ps.jacobian(f, x, [a], f_in=fin)
+        ph.jacobian(f, x, [b], f_in=fin)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (N, per_col, reach, fdtype, kw, rep, dtype)
+
+
 def test_window_plan_checks_its_colouring_against_all_columns():
     # Found by the sweep above: a colouring that is valid among the columns of a column window but not against the columns outside
     # it (which the colour's point perturbs too).  The plan must not call it valid -- single-coordinate differences would differ
