@@ -236,3 +236,27 @@ def test_jit_band_store_other_bandwidths(fdtype, lu):
     k = diag[100:110]
     i = cols[k]
     assert np.max(np.abs(out.cpu().numpy()[k] - (6.0 + 2.0 * xh[i] * xh[i + 2]))) < (5e-6 if fdtype == "forward" else 5e-8)
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("window", [(0, 1000), (1, 999), (333, 5000), (4999, 20011), (20010, 20011), (127, 129)])
+def test_jit_band_store_on_a_column_window(fdtype, window):
+    # a rank's column range (odd and even ends, a single column, ranges inside one wavefront): the compiled functor's band store writes
+    # exactly its slice -- the built-in family's bits on the same window
+    N = 20011
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    colors = P.cyclic_colors(N, 3)
+    x = _dev(np.random.default_rng(8).random(N) + 0.1)
+    fb = fd.BuiltinF("tridiag_nl", N)
+    fj = fd.JitF(TRIDIAG_NL, "TridiagNL", N, N, params=struct.pack("q", N))
+    outs = []
+    for f in (fb, fj):
+        plan = fd.make_plan(J, J, colors, fdtype, col_window=window)
+        plan.set_lazy(f)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(f, x, [out])
+        if window[1] - window[0] >= 3:
+            assert plan.info(fd.lib.INFO_LAZY_STORE) == 1
+        outs.append(out)
+    assert not torch.isnan(outs[1]).any() and torch.equal(outs[0].view(torch.int64), outs[1].view(torch.int64))
