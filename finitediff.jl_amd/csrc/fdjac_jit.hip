@@ -88,11 +88,58 @@ struct JitModule {
     hipFunction_t store[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [colour bytes == 4][central]
     hipFunction_t store_win[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // fd_band_store_cols: [bandwidths (1,1) / (2,2)][forward / central]
+    // other bandwidths: compiled when a plan first hands this functor such a band (fd_band_store_cols<.., L, U>), kept with the module
+    struct BandExtra {
+        hipModule_t mod = nullptr;
+        hipFunction_t fn[2] = {nullptr, nullptr};      // forward / central
+        bool failed = false;
+    };
+    std::map<std::pair<int, int>, BandExtra> extra;
+    std::string real;                                  // "double" / "float"
     unsigned sizeof_f = 0;
     int refs = 0;
     std::string key;
 };
 static std::map<std::string, JitModule *> g_modules;
+
+// fd_band_store_cols for the bandwidths (l, u) of this module's functor: the precompiled pair, or one more small compilation
+// (the same text, two name expressions) on first use -- about a second, once per functor text and bandwidth pair
+static hipFunction_t band_function(JitModule *m, int l, int u, int central)
+{
+    if (l == 1 && u == 1) return m->band[0][central];
+    if (l == 2 && u == 2) return m->band[1][central];
+    if (l < 0 || u < 0 || l + u > 8) return nullptr;                  // (2 (l + u + 1) quotients per lane live in registers)
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    JitModule::BandExtra &x = m->extra[std::make_pair(l, u)];
+    if (x.fn[central] || x.failed) return x.fn[central];
+    x.failed = true;                                                  // (until everything below has worked)
+    const Hiprtc *R = hiprtc();
+    if (!R) return nullptr;
+    hiprtcProgram prog = nullptr;
+    if (R->CreateProgram(&prog, m->key.c_str(), "fdjac_jit_band.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
+    std::string names[2];
+    for (int md = 0; md < 2; ++md) {
+        names[md] = "fd_band_store_cols<" + m->real + ", " + (md ? "1" : "0") + ", fdjit_F, " + std::to_string(l) + ", " + std::to_string(u) + ">";
+        (void)R->AddNameExpression(prog, names[md].c_str());
+    }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
+    bool ok = R->CompileProgram(prog, 5, opts) == HIPRTC_SUCCESS;
+    size_t cs = 0;
+    std::vector<char> code;
+    if (ok && R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) { code.resize(cs); ok = R->GetCode(prog, code.data()) == HIPRTC_SUCCESS; } else ok = false;
+    std::string low[2];
+    for (int md = 0; md < 2 && ok; ++md) {
+        const char *ln = nullptr;
+        if (R->GetLoweredName(prog, names[md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[md] = ln; else ok = false;
+    }
+    (void)R->DestroyProgram(&prog);
+    if (!ok || hipModuleLoadData(&x.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    for (int md = 0; md < 2; ++md)
+        if (hipModuleGetFunction(&x.fn[md], x.mod, low[md].c_str()) != hipSuccess) { x.fn[md] = nullptr; ok = false; }
+    if (!ok) { (void)hipGetLastError(); return nullptr; }
+    x.failed = false;
+    return x.fn[central];
+}
 
 }  // namespace fdjac
 
@@ -144,18 +191,20 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
     fd_jit_f *j = (fd_jit_f *)fctx;
     if (lp->store && lp->store_kind == FD_STORE_BAND && !lp->is_complex) {
         // an exact band with cyclic colours (CSC nzval, BandedMatrix data, Tridiagonal diagonals): fd_band_store_cols -- no index reads;
-        // bandwidths (1, 1) and (2, 2) are compiled with the functor, anything else is declined (a CSC pattern then takes the column store)
+        // bandwidths (1, 1) and (2, 2) are compiled with the functor, others (l + u <= 8) on first use; wider bands are declined (a CSC
+        // pattern then takes the column store)
         fd_band_store bs = *(const fd_band_store *)lp->store;
-        const int wi = (bs.l == 1 && bs.u == 1) ? 0 : (bs.l == 2 && bs.u == 2) ? 1 : -1;
         const int central = lp->pts == 2 ? 1 : 0;
-        if (wi < 0 || !j->m->band[wi][central] || bs.elem_bytes != j->elem_bytes || bs.M != j->M || bs.N != j->N || bs.col_end <= bs.col_begin ||
-            lp->c_lo != 0 || lp->ncolors != bs.C || !(central || (lp->pts == 1 && lp->diff == 2)))
+        if (bs.elem_bytes != j->elem_bytes || bs.M != j->M || bs.N != j->N || bs.col_end <= bs.col_begin || lp->c_lo != 0 || lp->ncolors != bs.C ||
+            !(central || (lp->pts == 1 && lp->diff == 2)))
             return FD_LAZY_DECLINED;
+        hipFunction_t bf = band_function(j->m, bs.l, bs.u, central);
+        if (!bf) return FD_LAZY_DECLINED;
         long long jstart = bs.col_begin & ~1ll;
         const void *x = lp->x, *eps = lp->eps;
         void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &bs, &jstart};
         const unsigned g = (unsigned)((bs.col_end - jstart + 511) / 512);
-        if (hipModuleLaunchKernel(j->m->band[wi][central], g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+        if (hipModuleLaunchKernel(bf, g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
         j->launches += 1;
         return 0;
     }
@@ -190,6 +239,8 @@ static void release_module(JitModule *m)
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     if (--m->refs > 0) return;
     g_modules.erase(m->key);
+    for (auto &kv : m->extra)
+        if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
     if (m->mod) (void)hipModuleUnload(m->mod);
     delete m;
 }
@@ -321,6 +372,7 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
             m = it->second;
         } else {
             m->key = src;
+            m->real = real;
             g_modules[src] = m;
         }
         m->refs += 1;

@@ -201,41 +201,64 @@ def test_jit_functor_stores_an_exact_band_itself(fdtype, storage, N):
         assert torch.equal(a.view(torch.int64), b.view(torch.int64)), storage
 
 
+BANDF = """
+// a residual whose Jacobian is the exact band (l, u): row i = sum over c = i - l .. i + u of w(i, c) (x_c + x_c^2 / 4), left to right
+struct BandF {
+    long long n;
+    int l, u;
+    template <class P> __device__ real_t operator()(long long i, const P &X) const
+    {
+        real_t s = 0;
+        bool first = true;
+        for (long long c = i - l; c <= i + u; ++c) {
+            const bool in = c >= 0 && c < n;
+            const real_t v = X(in ? c : i);
+            const real_t t = ((real_t)1 + (real_t)0.125 * (real_t)(int)((i + 3 * c) & 7)) * (v + ((real_t)0.25 * v) * v);
+            if (in) { s = first ? t : s + t; first = false; }
+        }
+        return s;
+    }
+};
+"""
+
+
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
-@pytest.mark.parametrize("lu", [(2, 2), (3, 3)])
-def test_jit_band_store_other_bandwidths(fdtype, lu):
-    # (2, 2) is compiled with every functor; (3, 3) is not: the launcher declines and the plan falls back (column store of the CSC pattern
-    # or the hand-over) -- the same bits either way.  The residual reads x[i-2 .. i+2] (its (3, 3) pattern holds structural zeros).
+@pytest.mark.parametrize("storage", ["csc", "banded"])
+@pytest.mark.parametrize("lu", [(2, 2), (3, 3), (2, 1), (1, 0), (0, 1), (0, 0), (4, 4), (5, 4)])
+def test_jit_band_store_other_bandwidths(fdtype, storage, lu):
+    # (1, 1) and (2, 2) are compiled with every functor; other bandwidths with l + u <= 8 on first use (one more small compilation);
+    # wider bands are declined and the plan falls back (column store of a CSC pattern, or the hand-over) -- the same bits either way
     l, u = lu
-    N = 50_021
-    cp, rv = P.banded_csc(N, N, l, u)
-    colors = P.cyclic_colors(N, l + u + 1)
-    J = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    N = 30_011
+    C = l + u + 1
+    colors = P.cyclic_colors(N, C)
     x = _dev(np.random.default_rng(4).random(N) + 0.1)
-    fj = fd.JitF(PENTA, "Penta", N, N, params=struct.pack("q", N))
-    ref_plan = fd.make_plan(J, J, colors, fdtype)                        # opaque: materialised points, hand-over
-    ref = _dev(np.full(rv.size, np.nan))
+    fj = fd.JitF(BANDF, "BandF", N, N, params=struct.pack("qii", N, l, u))
+    if storage == "csc":
+        cp, rv = P.banded_csc(N, N, l, u)
+        J = sp = fd.SparseMatrixCSC(N, N, cp, rv, None)
+        n_out = rv.size
+    else:
+        J, sp = fd.BandedMatrix(torch.zeros((N, C), dtype=torch.float64, device="cuda").t(), N, l, u), None
+        n_out = C * N
+    ref_plan = fd.make_plan(J, sp, colors, fdtype)                       # opaque: materialised points, hand-over
+    ref = _dev(np.zeros(n_out))
     ref_plan.jacobian(fj, x, [ref])
-    plan = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    plan = fd.make_plan(J, sp, colors, fdtype)
     plan.set_lazy(fj)
-    out = _dev(np.full(rv.size, np.nan))
+    out = _dev(np.zeros(n_out))
     n0 = fj.launches
     plan.jacobian(fj, x, [out])
-    assert plan.info(fd.lib.INFO_LAZY_STORE) == 1 and fj.launches - n0 == (1 if lu == (2, 2) else fj.launches - n0)
-    assert not torch.isnan(out).any() and torch.equal(out.view(torch.int64), ref.view(torch.int64))
-    # and without the compact pattern copy: (2, 2) still stores in one launch (the band needs no copy), (3, 3) is handed over
-    plan2 = fd.make_plan(J, J, colors, fdtype)
-    plan2.set_lazy(fj)
-    out2 = _dev(np.full(rv.size, np.nan))
-    plan2.jacobian(fj, x, [out2])
-    assert torch.equal(out2.view(torch.int64), ref.view(torch.int64))
-    # analytic check of a few interior entries: d f_i / d x_i = 6 + 2 x_i x_{i+2}
-    xh = x.cpu().numpy()
-    cols = P.csc_cols(cp) - 1
-    diag = np.nonzero((rv - 1) == cols)[0]
-    k = diag[100:110]
-    i = cols[k]
-    assert np.max(np.abs(out.cpu().numpy()[k] - (6.0 + 2.0 * xh[i] * xh[i + 2]))) < (5e-6 if fdtype == "forward" else 5e-8)
+    # (a BandedMatrix plan recognises cyclic colours through the step-size reduction's test: up to 8 of them)
+    if (storage == "csc" and l + u <= 8) or (storage == "banded" and l + u + 1 <= 8):
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == 1 and fj.launches - n0 == 1
+    assert torch.equal(out.view(torch.int64), ref.view(torch.int64)), (lu, storage)
+    if storage == "csc":
+        # analytic: d f_r / d x_c = w(r, c) (1 + x_c / 2)
+        xh = x.cpu().numpy()
+        cols = P.csc_cols(cp) - 1
+        want = (1.0 + 0.125 * (((rv - 1) + 3 * cols) & 7)) * (1.0 + 0.5 * xh[cols])
+        assert np.max(np.abs(out.cpu().numpy() - want)) < (5e-5 if fdtype == "forward" else 5e-7)
 
 
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
