@@ -877,6 +877,16 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         BuiltinF::RowsMemo *memo = nullptr;
         if (rows) {
             std::lock_guard<std::mutex> lock(b->rows_mutex);
+            if (b->rows_memo.size() > 1024 && !b->rows_memo.count(st.plan_serial)) {
+                // (a process that keeps creating plans for one residual: forget the plans nothing is in flight for -- one that is
+                //  still alive is simply checked again)
+                for (auto it = b->rows_memo.begin(); it != b->rows_memo.end();) {
+                    if (it->second.pending) { ++it; continue; }
+                    if (it->second.ev) (void)hipEventDestroy(it->second.ev);
+                    if (it->second.h_note) (void)hipHostFree(it->second.h_note);
+                    it = b->rows_memo.erase(it);
+                }
+            }
             memo = &b->rows_memo[st.plan_serial];
             if (memo->verdict == 0 && memo->pending && hipEventQuery(memo->ev) == hipSuccess) {
                 memo->pending = false;
