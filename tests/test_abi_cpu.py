@@ -289,3 +289,60 @@ def test_pattern_fingerprint_host_path(L):
     assert run([e, None, None], [8, 8, 8], [0, 0, 0], [e.size, 0, 0], [1, 0, 0])[0] != h[0]
     w = small.copy(); w[[3, 500]] = w[[500, 3]]
     assert (w[3] != small[3]) and run([w, None, None], [8, 8, 8], [0, 0, 0], [w.size, 0, 0], [0, 0, 0])[0] != h[1]
+
+
+def test_julia_shim_structure_and_foreign_calls():
+    # No `julia` in the image: the shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl) cannot be run or even parsed here.  What CAN be
+    # checked: its blocks / brackets balance (scripts/jl_balance.py), and every ccall names a symbol include/fdjac.h declares and the
+    # library exports, with as many argument types as the C prototype has parameters.
+    import re
+    import subprocess
+    import sys
+    shim = os.path.join(ROOT, "finitediff.jl_amd", "julia", "FiniteDiffMI355X.jl")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "jl_balance.py"), shim], capture_output=True, text=True)
+    assert out.returncode == 0 and "depth () 0 [] 0, unclosed blocks: []" in out.stdout, out.stdout + out.stderr
+    src = open(shim).read()
+    hdr = open(os.path.join(ROOT, "include", "fdjac.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char \*|size_t|void)\s*(fd(?:32)?_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+
+    def split_top(s):
+        parts, depth, cur = [], 0, ""
+        for ch in s:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur)
+        return parts
+
+    checked = 0
+    for m in re.finditer(r"ccall\(\(\s*(:fd_[a-z0-9_]+|\$\(P \* \"([a-z0-9_]+)\"\))\s*,\s*libfdjac\)\s*,\s*\w+\s*,\s*\(", src):
+        names = [m.group(1)[1:]] if m.group(2) is None else ["fd_" + m.group(2), "fd32_" + m.group(2)]
+        # the argument-type tuple: from the "(" that ends the match to its matching ")"
+        i = m.end()
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        ntypes = len([p for p in split_top(src[i:j - 1]) if p.strip()])
+        for nm in names:
+            assert nm in protos, "the shim calls %s, which include/fdjac.h does not declare" % nm
+            assert protos[nm] == ntypes, "%s: %d argument types in the shim, %d parameters in the header" % (nm, ntypes, protos[nm])
+            checked += 1
+    assert checked > 60, checked
+    lib = os.path.join(ROOT, "finitediff.jl_amd", "lib", "libfdjac.so")
+    if os.path.exists(lib):
+        syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+        exported = set(re.findall(r" T (fd(?:32)?_[a-z0-9_]+)", syms))
+        for m in re.finditer(r"ccall\(\(\s*:(fd_[a-z0-9_]+)", src):
+            assert m.group(1) in exported, m.group(1)
