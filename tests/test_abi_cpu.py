@@ -294,7 +294,7 @@ def test_pattern_fingerprint_host_path(L):
 def test_julia_shim_structure_and_foreign_calls():
     # No `julia` in the image: the shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl) cannot be run or even parsed here.  What CAN be
     # checked: its blocks / brackets balance (scripts/jl_balance.py), and every ccall names a symbol include/fdjac.h declares and the
-    # library exports, with as many argument types as the C prototype has parameters.
+    # library exports, and passes what the C prototype takes, parameter by parameter (pointer / 32-bit / 64-bit integer / double).
     import re
     import subprocess
     import sys
@@ -304,10 +304,7 @@ def test_julia_shim_structure_and_foreign_calls():
     src = open(shim).read()
     hdr = open(os.path.join(ROOT, "include", "fdjac.h")).read()
     hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
-    protos = {}
-    for m in re.finditer(r"\b(?:int|const char \*|size_t|void)\s*(fd(?:32)?_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
-        args = m.group(2).strip()
-        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    fn_typedefs = set(re.findall(r"typedef\s+\w+\s*\(\s*\*\s*(\w+)\s*\)", hdr))
 
     def split_top(s):
         parts, depth, cur = [], 0, ""
@@ -325,6 +322,28 @@ def test_julia_shim_structure_and_foreign_calls():
             parts.append(cur)
         return parts
 
+    def c_class(t):           # what the parameter is at the ABI: a pointer, a 32-bit integer, a 64-bit integer, a double
+        t = t.strip()
+        if "*" in t or "[" in t:
+            return "ptr"
+        words = t.replace("const ", "").split()
+        ty = " ".join(words[:-1]) if len(words) > 1 else words[0]
+        if ty in fn_typedefs:
+            return "ptr"
+        return {"int": "i32", "unsigned": "i32", "unsigned int": "i32", "int32_t": "i32", "int64_t": "i64", "long long": "i64", "uint64_t": "i64",
+                "unsigned long long": "i64", "size_t": "i64", "double": "f64", "float": "f32"}.get(ty, "?" + ty)
+
+    def jl_class(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Cuint": "i32", "UInt32": "i32", "Int64": "i64", "Clonglong": "i64", "UInt64": "i64", "Culonglong": "i64",
+                "Csize_t": "i64", "Cdouble": "f64", "Float64": "f64", "Cfloat": "f32", "Float32": "f32"}.get(t, "?" + t)
+
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char \*|size_t|void)\s*(fd(?:32)?_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = [] if args in ("", "void") else [c_class(a) for a in split_top(args)]
     checked = 0
     for m in re.finditer(r"ccall\(\(\s*(:fd_[a-z0-9_]+|\$\(P \* \"([a-z0-9_]+)\"\))\s*,\s*libfdjac\)\s*,\s*\w+\s*,\s*\(", src):
         names = [m.group(1)[1:]] if m.group(2) is None else ["fd_" + m.group(2), "fd32_" + m.group(2)]
@@ -334,10 +353,10 @@ def test_julia_shim_structure_and_foreign_calls():
         while depth:
             depth += {"(": 1, ")": -1}.get(src[j], 0)
             j += 1
-        ntypes = len([p for p in split_top(src[i:j - 1]) if p.strip()])
+        jl = [jl_class(p) for p in split_top(src[i:j - 1]) if p.strip()]
         for nm in names:
             assert nm in protos, "the shim calls %s, which include/fdjac.h does not declare" % nm
-            assert protos[nm] == ntypes, "%s: %d argument types in the shim, %d parameters in the header" % (nm, ntypes, protos[nm])
+            assert protos[nm] == jl, "%s: the shim passes %s, the header takes %s" % (nm, jl, protos[nm])
             checked += 1
     assert checked > 60, checked
     lib = os.path.join(ROOT, "finitediff.jl_amd", "lib", "libfdjac.so")
