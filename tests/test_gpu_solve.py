@@ -157,6 +157,50 @@ def test_sharded_solve_equals_global_solve(layout, N, W):
     assert np.max(np.abs(got - want)) <= 1e-11 * max(1.0, np.max(np.abs(want)))
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_solver_randomised(seed):
+    # random sizes (around every tile / level boundary by chance), layouts, shifts and rank counts with UNEVEN cuts: whole and sharded
+    # solves against SciPy's banded solve; the sharded pieces go through the two-levels-per-launch schedule whenever a rank's rows allow
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.choice([rng.integers(1, 70), rng.integers(500, 5000), rng.integers(4000, 70000), rng.integers(250000, 600000)]))
+    layout = "csc" if rng.random() < 0.5 else "diagonals"
+    dl, d, du, b, alpha, beta = _system(N, 900 + seed, dominance=float(rng.choice([0.05, 0.2, 2.0])))
+    want = _reference(dl, d, du, b, alpha, beta)
+    nz = _csc_nzval_fast(dl, d, du)
+    tol = 1e-11 * max(1.0, np.max(np.abs(want)))
+    # whole
+    solver = fd.TridiagSolver(N, layout)
+    J = fd.Tridiagonal(_dev(dl), _dev(d), _dev(du)) if layout == "diagonals" else [_dev(nz)]
+    y = torch.full((N,), float("nan"), dtype=torch.float64, device="cuda")
+    solver.solve(J, _dev(b), y, alpha, beta)
+    assert np.max(np.abs(y.cpu().numpy() - want)) <= tol
+    # sharded, uneven cuts
+    W = int(rng.integers(2, 6))
+    if N < 2 * W:
+        return
+    cuts = np.concatenate([[0], np.sort(rng.choice(np.arange(1, N), size=W - 1, replace=False)), [N]]).astype(np.int64)
+    packets = torch.full((W, 8), float("nan"), dtype=torch.float64, device="cuda")
+    ranks = []
+    for r in range(W):
+        c0, c1 = int(cuts[r]), int(cuts[r + 1])
+        if layout == "diagonals":
+            Jr = fd.Tridiagonal(_dev(dl[c0:min(c1, N - 1)]), _dev(d[c0:c1]), _dev(du[max(c0 - 1, 0):c1 - 1]))
+        else:
+            e0 = 3 * c0 - 1 if c0 > 0 else 0
+            e1 = 3 * c1 - 1 if c1 < N else 3 * N - 2
+            Jr = [_dev(nz[e0:e1])]
+        sr = fd.TridiagSolver(N, layout, rows=(c0, c1))
+        bl = _dev(b[c0:c1])
+        sr.interface(Jr, bl, packets[r], alpha, beta)
+        ranks.append((sr, Jr, bl, c0, c1))
+    got = np.full(N, np.nan)
+    for r, (sr, Jr, bl, c0, c1) in enumerate(ranks):
+        yl = torch.full((c1 - c0,), float("nan"), dtype=torch.float64, device="cuda")
+        sr.finish(Jr, bl, packets, r, W, yl, alpha, beta)
+        got[c0:c1] = yl.cpu().numpy()
+    assert not np.isnan(got).any() and np.max(np.abs(got - want)) <= tol, (N, layout, W, cuts)
+
+
 def test_solve_through_a_single_rank_communicator():
     N = 20011
     dl, d, du, b, alpha, beta = _system(N, 5)
