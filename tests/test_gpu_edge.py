@@ -690,6 +690,66 @@ def test_dropin_deferred_content_check_reports_an_edit_one_call_late():
     assert cache.last_plan is p1 and not p1.stale()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_deferred_and_blocking_content_checks_agree_randomised(seed):
+    # fd_plan_matches_async (one fused kernel, per-workgroup slots, group tickets) against fd_plan_matches (three kernels + copy) and the
+    # truth: random sizes, index widths, column windows, and ONE edited element at a random place of a random array (or none)
+    rng = np.random.default_rng(3100 + seed)
+    N = int(rng.choice([7, 300, 5000, 70001, 400003]))
+    per_col = int(rng.integers(1, 6))
+    rows = np.sort(np.minimum(np.arange(N)[:, None] + rng.integers(0, 9, size=(N, per_col)), N - 1), axis=1)
+    keep = np.ones_like(rows, dtype=bool)
+    keep[:, 1:] = rows[:, 1:] != rows[:, :-1]
+    cnt = keep.sum(axis=1)
+    cp = np.empty(N + 1, np.int64)
+    cp[0] = 1
+    np.cumsum(cnt, out=cp[1:])
+    cp[1:] += 1
+    rv = (rows[keep] + 1).astype(np.int64)
+    pat = fd.SparseMatrixCSC(N, N, cp, rv, None)
+    colors = fd.matrix_colors(pat)
+    kw = {}
+    if rng.random() < 0.4 and N > 20:
+        a = int(rng.integers(0, N // 2))
+        kw["col_window"] = (a, int(rng.integers(a + 1, N + 1)))
+    plan = fd.make_plan(pat, pat, colors, "forward", fingerprint=True, **kw)
+    it = torch.int32 if rng.random() < 0.5 else torch.int64
+    dcp, drv = torch.as_tensor(cp, device="cuda").to(it), torch.as_tensor(rv, device="cuda").to(it)
+    dcv = torch.as_tensor(np.asarray(colors), device="cuda").to(torch.int32 if rng.random() < 0.5 else torch.int64)
+    ctx = fd.Context.default()
+    assert plan.matches(dcp, drv, dcv)
+    plan.matches(dcp, drv, dcv, deferred=True)
+    ctx.synchronize()
+    assert not plan.stale()
+    which = int(rng.integers(0, 4))                                 # 0: nothing edited
+    c0, c1 = kw.get("col_window", (0, N))
+    inside = True
+    if which == 1:
+        j = int(rng.integers(0, N))
+        dcv[j] = dcv[j] % int(colors.max()) + 1 if int(colors.max()) > 1 else 0
+    elif which == 2:
+        q = int(rng.integers(0, rv.size))
+        drv[q] = drv[q] % N + 1 if N > 1 else 1
+        inside = int(cp[c0]) - 1 <= q < int(cp[c1]) - 1             # (a window plan compares its own slice of rowval)
+        if N == 1:
+            which = 0
+    elif which == 3 and N > 1:
+        j = int(rng.integers(c0, c1 + 1))
+        dcp[j] = dcp[j] + 1
+    elif which == 3:
+        which = 0
+    want_same = which == 0 or not inside
+    assert bool(plan.matches(dcp, drv, dcv)) == want_same
+    plan.matches(dcp, drv, dcv, deferred=True)
+    if want_same:
+        ctx.synchronize()
+        assert not plan.stale()
+    else:
+        with pytest.raises(fd.lib.FdError) as e:
+            ctx.synchronize()
+        assert e.value.code == 9 and plan.stale()
+
+
 def test_plan_matches_compares_content_not_identity():
     # fd_plan_matches on host arrays, device arrays, either index width; column windows compare their own slice only
     N = 50021
