@@ -411,6 +411,22 @@ class P2P:
         self.handle, self.nranks, self.rank = h, int(nranks), int(rank)
         self._fin = weakref.finalize(self, self.L.fd_p2p_destroy, h)
 
+    @classmethod
+    def loopback(cls, ctx, nranks, rank, slot_bytes=1 << 16):
+        """fd_p2p_create_loopback: rank `rank` of an `nranks`-rank job alone on one device (peers = a local sink, no wait spins);
+        ``fill(sender, offset, tensor)`` puts what `sender` would have delivered into its slot."""
+        self = cls.__new__(cls)
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        _l.check(self.L.fd_p2p_create_loopback(ctx.handle, int(nranks), int(rank), int(slot_bytes), C.byref(h)))
+        self.handle, self.nranks, self.rank = h, int(nranks), int(rank)
+        self._fin = weakref.finalize(self, self.L.fd_p2p_destroy, h)
+        return self
+
+    def fill(self, sender, offset, data):
+        p, eb = Comm._dev(data, "data")
+        _l.check(self.L.fd_p2p_loopback_fill(self.handle, int(sender), int(offset), p, int(data.numel()) * eb))
+
     def local_handle(self):
         buf = C.create_string_buffer(_l.P2P_HANDLE_BYTES)
         _l.check(self.L.fd_p2p_local_handle(self.handle, buf))
@@ -785,13 +801,28 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_epsilons(self.handle, buf))
         return np.array(buf[:n])
 
+    def fused_trace(self):
+        """fd_plan_fused_trace: the device-clock marks of the last fused launch, in microseconds relative to its first mark."""
+        m = (C.c_longlong * 16)()
+        _l.check(self.Lt.fd_plan_fused_trace(self.handle, m))
+        names = ("eps_first_start", "eps_last_published", "finisher_start", "finisher_has_sums", "eps_published", "store_first_start",
+                 "store_first_has_eps", "store_last_has_eps", "store_last_done", "store_last_start")
+        v = [m[i] for i in range(10)]
+        t0 = min(x for x in v if x > 0)
+        return {n: (x - t0) / 100.0 for n, x in zip(names, v)}
+
     def enable_timing(self, level=2):
-        """0 off; 1 = the diff+decompress kernel only (2 events per call); 2 = every stage and the whole call."""
+        """0 off; 1 = the diff+decompress kernel only (2 events per call); 2 = every stage and the whole call; 3 = the whole call
+        only; 4 = every stage without the whole-call markers."""
         _l.check(self.Lt.fd_plan_enable_timing(self.handle, int(level)))
 
+    def set_timing_stride(self, stride):
+        """Level-1 timing on every `stride`-th call only (fd_plan_set_timing_stride): a pair of events costs ~8 us of stream time."""
+        _l.check(self.Lt.fd_plan_set_timing_stride(self.handle, int(stride)))
+
     def timings(self):
-        ms = (C.c_double * 5)()
-        cnt = (C.c_int64 * 5)()
+        ms = (C.c_double * len(_l.STAGES))()
+        cnt = (C.c_int64 * len(_l.STAGES))()
         _l.check(self.Lt.fd_plan_get_timings(self.handle, ms, cnt))
         return {s: {"ms_sum": ms[i], "launches": cnt[i]} for i, s in enumerate(_l.STAGES)}
 
@@ -805,7 +836,7 @@ class Plan:
         _l.check(self.Lt.fd_plan_get_timing_samples(self.handle, k, buf, n.value, C.byref(n)))
         return [buf[i] for i in range(n.value)]
 
-    def set_lazy(self, f, imag_only=True, row_window=True, diff=True, store=None, csc_base=True):
+    def set_lazy(self, f, imag_only=True, row_window=True, diff=True, store=None, csc_base=True, fused=True):
         """Use f's lazy-point launcher (fd_plan_set_lazy_f) for the perturbed batches; f=None clears it.  imag_only /
         row_window / diff / store=False withhold the launcher's FD_LAZY_CAP_IMAG_ONLY / FD_LAZY_CAP_ROW_WINDOW /
         FD_LAZY_CAP_DIFF / FD_LAZY_CAP_STORE capability (store defaults to diff: a launcher that may not even subtract
@@ -826,6 +857,8 @@ class Plan:
             caps &= ~(8 | 16 | 32 | 64)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC, _BASE and _COMPLEX
         if not csc_base:
             caps &= ~32                 # (the column store takes f(x) from ONE plain evaluation instead of forming it itself)
+        if not fused:
+            caps &= ~128                # FD_LAZY_CAP_FUSED_EPS withheld: the step sizes come from the library's own launch
         _l.check(self.Lt.fd_plan_set_lazy_caps(self.handle, caps))
 
     def set_comm(self, comm):

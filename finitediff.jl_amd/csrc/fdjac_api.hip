@@ -10,6 +10,7 @@
 #include <atomic>
 #include <thread>
 #include "fdjac_internal.h"
+#include "fdjac_eps_dev.h"
 
 namespace fdjac {
 
@@ -154,6 +155,8 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     if (p->cx) p->small_ok = false;                      // the fused small-problem launch has ONE colour rule for norm and perturbation
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
+    { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
+    p->eps_form = env_int("FDJAC_EPS_FORM", 0);
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
@@ -422,6 +425,10 @@ int fd_plan_destroy(fd_plan *p)
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pstale) (void)hipHostFree(p->h_pstale);
+    if (p->h_fz_err) (void)hipHostFree(p->h_fz_err);
+    if (p->d_fz_part) (void)hipFree(p->d_fz_part);
+    if (p->d_fz_eps) (void)hipFree(p->d_fz_eps);
+    if (p->d_fz_trace) (void)hipFree(p->d_fz_trace);
     for (auto &sp : p->spans) {
         p->event_pool.push_back(sp.a);
         p->event_pool.push_back(sp.b);
@@ -504,6 +511,8 @@ struct Span {
         // level 1: only the graded kernel (2 events per call); level 2: every stage + the whole call; level 3: the whole call only
         if (p->timing == 0) return;
         if (p->timing == 1 && stage != FD_STAGE_DECOMPRESS) return;
+        if (p->timing == 1 && p->timing_stride > 1 && ((p->timing_calls - 1) % p->timing_stride) != 0) return;      // (sampled: see fd_plan_set_timing_stride)
+        if (p->timing == 4 && stage == FD_STAGE_TOTAL) return;       // level 4: every stage, not the whole call (its markers would sit between the stages)
         if (p->timing == 3 && stage != FD_STAGE_TOTAL) return;
         fdjac::TimedSpan s{stage, take_event(p), take_event(p)};
         (void)hipEventRecord(s.a, p->ctx->stream);
@@ -552,12 +561,20 @@ int fd_plan_enable_timing(fd_plan *p, int on)
     FD_REQUIRE(p, FD_ERR_ARG, "plan is NULL");
     int rc = collect_spans(p);
     if (rc) return rc;
-    p->timing = on < 0 ? 0 : (on > 3 ? 3 : on);
+    p->timing = on < 0 ? 0 : (on > 4 ? 4 : on);
     for (int i = 0; i < FD_NSTAGES; ++i) {
         p->ms_sum[i] = 0;
         p->launches[i] = 0;
         p->samples[i].clear();
     }
+    return FD_OK;
+}
+
+int fd_plan_set_timing_stride(fd_plan *p, int stride)
+{
+    FD_REQUIRE(p && stride >= 1, FD_ERR_ARG, "bad argument");
+    p->timing_stride = stride;
+    p->timing_calls = 0;
     return FD_OK;
 }
 
@@ -632,6 +649,39 @@ static inline int call_f(const fd_plan *p, fd_f_launch f, void *fctx, void *fx, 
     return f(fctx, fx, x, nbatch, x_stride / 2, fx_stride / 2, row_begin / 2, (row_end + 1) / 2, 1, stream);
 }
 
+// ---- the fused step: buffers (allocated on first use; every slot starts as the sentinel) ----
+static int fused_reset(fd_plan *p)
+{
+    const size_t np = 2 * (size_t)p->n_partial_blocks * kRegColors, ne = 2 * (size_t)kFzReplicas * kFzPitch;
+    std::vector<unsigned long long> hp(np, kFzSentinel64);
+    std::vector<rbits_t> he(ne, FzBits<real_t>::sentinel);
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    FD_HIP_CHECK(hipMemcpy(p->d_fz_part, hp.data(), np * 8, hipMemcpyHostToDevice));
+    FD_HIP_CHECK(hipMemcpy(p->d_fz_eps, he.data(), ne * sizeof(rbits_t), hipMemcpyHostToDevice));
+    FD_HIP_CHECK(hipDeviceSynchronize());
+    *p->h_fz_err = 0;
+    p->fz_parity = 0;
+    return FD_OK;
+}
+static int ensure_fused(fd_plan *p)
+{
+    if (p->d_fz_part) return FD_OK;
+    FD_HIP_CHECK(hipHostMalloc((void **)&p->h_fz_err, sizeof(int), hipHostMallocMapped));
+    *p->h_fz_err = 0;
+    FD_HIP_CHECK(hipHostGetDevicePointer((void **)&p->d_fz_err, p->h_fz_err, 0));
+    FD_HIP_CHECK(hipMalloc((void **)&p->d_fz_eps, 2 * (size_t)kFzReplicas * kFzPitch * sizeof(rbits_t)));
+    FD_HIP_CHECK(hipMalloc((void **)&p->d_fz_part, 2 * (size_t)p->n_partial_blocks * kRegColors * sizeof(double)));
+    { const char *v = fdjac::test_switch("FDJAC_FUSED_TRACE"); if (v && atoi(v) != 0) FD_HIP_CHECK(hipMalloc((void **)&p->d_fz_trace, 16 * sizeof(long long))); }
+    return fused_reset(p);
+}
+static int64_t fused_timeout_ticks()
+{
+    // wall_clock64() counts at 100 MHz on gfx9; FDJAC_P2P_TIMEOUT_MS bounds every device-side wait (default 2 s)
+    const char *v = getenv("FDJAC_P2P_TIMEOUT_MS");
+    const int64_t ms = (v && *v) ? atoll(v) : 2000;
+    return (ms < 1 ? 1 : ms) * 100000;
+}
+
 // ---- the hot path ---------------------------------------------------------------------------
 static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t *x_dev, const real_t *fin_dev,
                             double relstep, double absstep, double dir, real_t *const *outs)
@@ -651,6 +701,13 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     if (collect_spans(p, false) != FD_OK) return FD_ERR_HIP;  // harvest finished spans, never wait for the device
     FD_REQUIRE(!(p->h_pstale && *(volatile int *)p->h_pstale), FD_ERR_STALE,
                "a deferred content check (fd_plan_matches_async) found that this plan no longer matches the caller's pattern / colour arrays");
+    if (p->h_fz_err && *(volatile int *)p->h_fz_err) {
+        const int what = *(volatile int *)p->h_fz_err;
+        (void)fused_reset(p);
+        FD_REQUIRE(false, FD_ERR_COMM, "the previous fused step of this plan timed out (%s never arrived; FDJAC_P2P_TIMEOUT_MS): its "
+                   "output holds NaNs", what == 1 ? "a block sum of the step-size reduction" : "the step sizes");
+    }
+    ++p->timing_calls;
     Span total(p, FD_STAGE_TOTAL);
 
     // x must be 16-B aligned for the vector loads; stage it otherwise
@@ -679,12 +736,43 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const int rc = ensure_diff_scratch(p);
         if (rc) return rc;
     }
+    // the fused step: the storing launch of a FD_LAZY_CAP_FUSED_EPS launcher runs the reduction itself (one launch per Jacobian)
+    bool fuse = !small && p->fdtype != FD_COMPLEX && p->C > 0 && p->C <= kRegColors && p->cyc_C > 0 && p->eps_mode == FD_EPS_COMPUTE &&
+                p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_FUSED_EPS) && store_active(p) && p->store_ok &&
+                (p->kind == K_CSC || p->kind == K_BANDED || p->kind == K_TRIDIAG) && p->nchunks == 1 && full_colors &&
+                !(p->fdtype == FD_FORWARD && fin_dev) && !p->comm && !p->p2p && p->N <= p->fz_max_n && p->d_partial != nullptr;
+    FusedEps fz_job;
+    if (fuse) {
+        const int rc = ensure_fused(p);
+        if (rc) return rc;
+        memset(&fz_job, 0, sizeof fz_job);
+        fz_job.eg.tpg = p->eps_tpg; fz_job.eg.bpg = p->eps_bpg; fz_job.eg.tpb = p->eps_tpb; fz_job.eg.final_groups = kEpsGroups;
+        fz_job.eg.C = (int)p->C; fz_job.eg.is_forward = p->fdtype == FD_FORWARD ? 1 : 0;
+        fz_job.eg.relstep = relstep; fz_job.eg.absstep = absstep; fz_job.eg.dir = dir;
+        fz_job.nblocks = kEpsGroups * p->eps_bpg;
+        fz_job.cyc_C = p->cyc_C; fz_job.cyc_shift = p->cyc_shift; fz_job.pair = p->cx ? 1 : 0;
+        const size_t hp = (size_t)p->n_partial_blocks * kRegColors, he = (size_t)kFzReplicas * kFzPitch;
+        fz_job.part = p->d_fz_part + (p->fz_parity ? hp : 0);
+        fz_job.part_next = p->d_fz_part + (p->fz_parity ? 0 : hp);
+        fz_job.epsr = (rbits_t *)p->d_fz_eps + (p->fz_parity ? he : 0);
+        fz_job.epsr_next = (rbits_t *)p->d_fz_eps + (p->fz_parity ? 0 : he);
+        fz_job.eps = p->d_eps; fz_job.eps2 = p->d_eps2;
+        fz_job.err = p->d_fz_err;
+        fz_job.timeout_ticks = fused_timeout_ticks();
+        fz_job.trace = p->d_fz_trace;
+        if (p->d_fz_trace) {      // (diagnostic runs only: minima start at all-ones, maxima at zero)
+            static const long long init[16] = {-1, 0, 0, 0, 0, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            FD_HIP_CHECK(hipMemcpyAsync(p->d_fz_trace, init, sizeof init, hipMemcpyHostToDevice, s));
+        }
+    }
     if (p->eps_mode != FD_EPS_PRECOMPUTED) p->eps2_fresh = false;
     p->eps_nt = p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !(store_active(p) || store_csc_active(p));   // (see apply_opts)
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
         // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current
         FD_REQUIRE(!small_points, FD_ERR_UNSUPPORTED, "FD_EPS_PRECOMPUTED needs a plan whose reduction can be sharded");
+    } else if (fuse) {
+        // (nothing here: the storing launch below computes the step sizes)
     } else if (p->fdtype != FD_COMPLEX && p->C > 0) {
         Span sp(p, FD_STAGE_EPS);
         int rc;
@@ -702,7 +790,10 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             const int S = (kEpsGroups + W - 1) / W;
             const int g0 = std::min(r * S, kEpsGroups), ng = std::min(S, kEpsGroups - g0);
             rc = launch_eps_groups(p, x_dev, g0, ng, false, relstep, absstep, dir);
-            if (!rc) rc = eps_exchange(p, const_cast<real_t *>(x_dev), S, relstep, absstep, dir);
+            if (!rc) {
+                Span se(p, FD_STAGE_EXCHANGE);
+                rc = eps_exchange(p, const_cast<real_t *>(x_dev), S, relstep, absstep, dir);
+            }
         } else {
             rc = launch_eps(p, x_dev, relstep, absstep, dir);
         }
@@ -819,7 +910,19 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.store_kind = p->kind == K_COLRANGE ? FD_STORE_COLRANGE : stencil ? FD_STORE_STENCIL5 : FD_STORE_BAND;
             lp.is_complex = p->fdtype == FD_COMPLEX ? 1 : 0;
             lp.imag_only = lp.is_complex;
-            const int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            lp.eps_job = fuse ? &fz_job : nullptr;
+            int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            if (fuse && rc == 0) {
+                p->fz_parity ^= 1u;
+                p->eps2_fresh = p->d_eps2 != nullptr;
+            } else if (fuse) {      // (declined with the reduction attached: the library's own launch, then the plain storing launch)
+                fuse = false;
+                sp.stop();
+                { Span se(p, FD_STAGE_EPS); const int re = launch_eps(p, x_dev, relstep, absstep, dir); if (re) return re; }
+                Span sp2(p, FD_STAGE_DECOMPRESS);
+                lp.eps_job = nullptr;
+                if (rc == FD_LAZY_DECLINED) rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
+            }
             FD_REQUIRE(rc == 0 || rc == FD_LAZY_DECLINED, FD_ERR_CALLBACK, "lazy f! launcher (store) returned %d", rc);
             if (rc == 0) {
                 p->fcalls_last += (int64_t)B * p->pts + (lp.diff == 2 ? 1 : 0);
@@ -869,6 +972,12 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 continue;
             }
             if (p->fdtype == FD_FORWARD && !own_base) want_diff = false;      // (declined: f(x) exists already -- plain values are handed over below)
+        }
+        if (fuse) {      // (the storing launch did not happen: the hand-over path needs the step sizes first)
+            fuse = false;
+            Span se(p, FD_STAGE_EPS);
+            const int re = launch_eps(p, x_dev, relstep, absstep, dir);
+            if (re) return re;
         }
         { const int rc = ensure_values(p); if (rc) return rc; }      // (from here on the f! values are handed over through d_FX)
         bool diff_done = false;
@@ -1024,6 +1133,10 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
             if (p->out_len[k] > 0)
                 FD_HIP_CHECK(hipMemcpyAsync(outs[k], o[k], sizeof(real_t) * (size_t)p->out_len[k], hipMemcpyDeviceToHost, s));
     FD_HIP_CHECK(hipStreamSynchronize(s));
+    if (p->h_fz_err && *(volatile int *)p->h_fz_err) {
+        (void)fused_reset(p);
+        FD_REQUIRE(false, FD_ERR_COMM, "the fused step timed out (FDJAC_P2P_TIMEOUT_MS): the output holds NaNs");
+    }
     return FD_OK;
 }
 
@@ -1142,6 +1255,17 @@ int fd_plan_set_eps_mode(fd_plan *p, int mode)
     FD_REQUIRE(mode == FD_EPS_COMPUTE || eps_shardable(p), FD_ERR_UNSUPPORTED,
                "this plan's step-size reduction cannot be sharded");
     p->eps_mode = mode;
+    return FD_OK;
+}
+
+// diagnostic (FDJAC_TEST_SWITCHES=1 FDJAC_FUSED_TRACE=1): the wall_clock64 marks (100 MHz) of the plan's last fused launch
+int fd_plan_fused_trace(fd_plan *p, long long *marks16)
+{
+    FD_REQUIRE(p && marks16, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(p->d_fz_trace != nullptr, FD_ERR_UNSUPPORTED, "no trace: FDJAC_FUSED_TRACE=1 (with FDJAC_TEST_SWITCHES=1) before the plan's first fused call");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    FD_HIP_CHECK(hipMemcpy(marks16, p->d_fz_trace, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return FD_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "fdjac_internal.h"
+#include "fdjac_eps_dev.h"
 
 namespace fdjac {
 
@@ -224,6 +225,28 @@ __device__ __forceinline__ r2_t ld_pair_guarded(const real_t *__restrict__ x, in
     return v;
 }
 
+// the six quotients of a lane's two columns (rows j-1 .. j+1 of column j, then of column j + 1)
+template <int MODE, bool NL>
+__device__ __forceinline__ void tridiag_pair_quotients(const r2_t &L, const r2_t &Cc, const r2_t &R, real_t ea, real_t eb, real_t (&q)[6])
+{
+    const real_t xv[6] = {L.x, L.y, Cc.x, Cc.y, R.x, R.y};
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
+        const real_t e = o == 0 ? ea : eb;
+        const real_t ed = MODE == 1 ? 2 * e : e;
+        real_t p[5], m[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
+            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
+                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
+            q[3 * o + k] = sub_exact(plus, sub) / ed;      // (the shared-reciprocal division measured 2 % slower here: bandwidth, not issue, bounds this kernel)
+        }
+    }
+}
+
 template <int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart)
@@ -241,24 +264,55 @@ k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ 
     const int c0 = (int)((uint32_t)(c0w + 2 * lane) % (uint32_t)bst.C);
     const int c1 = c0 + 1 == bst.C ? 0 : c0 + 1;
     const real_t ea = eps[c0], eb = eps[c1];
-    const real_t xv[6] = {L.x, L.y, Cc.x, Cc.y, R.x, R.y};
     real_t q[6];
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
-        const real_t e = o == 0 ? ea : eb;
-        const real_t ed = MODE == 1 ? 2 * e : e;
-        real_t p[5], m[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
-            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
-                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
-            q[3 * o + k] = sub_exact(plus, sub) / ed;      // (the shared-reciprocal division measured 2 % slower here: bandwidth, not issue, bounds this kernel)
+    tridiag_pair_quotients<MODE, NL>(L, Cc, R, ea, eb, q);
+    fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);      // (non-temporal: nothing re-reads nzval in this call)
+}
+
+// THE FUSED STEP (round 6): the whole Jacobian in ONE launch -- blockIdx 0 is the finisher of the step-size reduction, blockIdx
+// 1 .. nblocks are its reduction workgroups (fdjac_eps_dev.h), everything after that stores: the wavefronts of k_f_tridiag_store_wave,
+// which load their x, then wait for the step sizes of their colours to be published.  Same operations per value as the two-launch
+// form: same bits.  N = 10^6: one launch instead of two, and a hand-off of two memory round trips instead of six.
+template <int MODE, bool NL, int NC>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, int64_t jstart, FusedEps fz)
+{
+    // one LDS area, carved by role: storing workgroups (4 wave windows + the step sizes), reduction workgroups, finishers
+    constexpr int kWinBytes = (kBlock / 64) * FD_BAND_WAVE_LDS(3) * (int)sizeof(real_t);
+    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + kEpsGroups + 2) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + kEpsGroups + 2) * 8;
+    __shared__ __attribute__((aligned(16))) char s_lds[kLdsBytes];
+    real_t (*s_win)[FD_BAND_WAVE_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE_LDS(3)]>(s_lds);
+    double *s_red = reinterpret_cast<double *>(s_lds);
+    const int b = (int)blockIdx.x, nfin = fz.eg.C;
+    if (b < nfin) { fused_finisher(fz, b, s_red); return; }
+    if (b < nfin + fz.nblocks) { fused_eps_block<NC>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
+    // a storing workgroup: its wavefronts walk the 128-column tiles gw, gw + stride, ... (the launcher keeps the whole grid resident,
+    // so nobody is dispatched after the step sizes are out); the first tile's x is in flight while the workgroup waits
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = b - nfin - fz.nblocks;
+    const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
+    const int64_t gstride = (int64_t)((int)gridDim.x - nfin - fz.nblocks) * (kBlock / 64);
+    int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
+    int64_t jw = jstart + gw * 128, j = jw + 2 * lane;
+    r2_t Cc = {0, 0}, L = {0, 0}, R = {0, 0};
+    if (gw < nwaves) { Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n); }
+    real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
+    if (wave == 0) fused_wait_eps(fz, cb, s_eps);
+    __syncthreads();
+    for (; gw < nwaves; gw += gstride) {
+        const int c0w = (int)((jw + bst.shift) % bst.C);
+        const int c0 = (int)((uint32_t)(c0w + 2 * lane) % (uint32_t)bst.C);
+        const int c1 = c0 + 1 == bst.C ? 0 : c0 + 1;
+        real_t q[6];
+        tridiag_pair_quotients<MODE, NL>(L, Cc, R, s_eps[c0], s_eps[c1], q);
+        fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);
+        if (gw + gstride < nwaves) {
+            jw = jstart + (gw + gstride) * 128;
+            j = jw + 2 * lane;
+            Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n);
         }
     }
-    fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);      // (non-temporal: nothing re-reads nzval in this call)
+    if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }
 
 #ifdef FDJAC_F32
@@ -277,6 +331,26 @@ __device__ __forceinline__ r4_t ld_quad_guarded(const real_t *__restrict__ x, in
     return v;
 }
 template <int MODE, bool NL>
+__device__ __forceinline__ void tridiag_quad_quotients(const r4_t &L, const r4_t &Cc, const r4_t &R, const real_t (&ev)[4], real_t (&q)[12])
+{
+    const real_t xv[8] = {L.z, L.w, Cc.x, Cc.y, Cc.z, Cc.w, R.x, R.y};      // x[j - 2 .. j + 5]
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
+        const real_t e = ev[o];
+        const real_t ed = MODE == 1 ? 2 * e : e;
+        real_t p[5], m[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
+            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
+                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
+            q[3 * o + k] = sub_exact(plus, sub) / ed;
+        }
+    }
+}
+template <int MODE, bool NL>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_store_wave4(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart)
 {
@@ -293,24 +367,50 @@ k_f_tridiag_store_wave4(const real_t *__restrict__ x, const real_t *__restrict__
     real_t ev[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) { ev[o] = eps[cc]; cc = cc + 1 == bst.C ? 0 : cc + 1; }
-    const real_t xv[8] = {L.z, L.w, Cc.x, Cc.y, Cc.z, Cc.w, R.x, R.y};      // x[j - 2 .. j + 5]
     real_t q[12];
+    tridiag_quad_quotients<MODE, NL>(L, Cc, R, ev, q);
+    fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
+}
+// the fused step (k_f_tridiag_fused), four columns per lane
+template <int MODE, bool NL, int NC>
+__global__ void __launch_bounds__(kBlock)
+k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, int64_t jstart, FusedEps fz)
+{
+    constexpr int kWinBytes = (kBlock / 64) * FD_BAND_WAVE4_LDS(3) * (int)sizeof(real_t);
+    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + kEpsGroups + 2) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + kEpsGroups + 2) * 8;
+    __shared__ __attribute__((aligned(16))) char s_lds[kLdsBytes];
+    real_t (*s_win)[FD_BAND_WAVE4_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE4_LDS(3)]>(s_lds);
+    double *s_red = reinterpret_cast<double *>(s_lds);
+    const int b = (int)blockIdx.x, nfin = fz.eg.C;
+    if (b < nfin) { fused_finisher(fz, b, s_red); return; }
+    if (b < nfin + fz.nblocks) { fused_eps_block<NC>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = b - nfin - fz.nblocks;
+    const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
+    const int64_t gstride = (int64_t)((int)gridDim.x - nfin - fz.nblocks) * (kBlock / 64);
+    int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
+    int64_t jw = jstart + gw * 256, j = jw + 4 * lane;
+    r4_t Cc = {0, 0, 0, 0}, L = {0, 0, 0, 0}, R = {0, 0, 0, 0};
+    if (gw < nwaves) { Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n); }
+    real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
+    if (wave == 0) fused_wait_eps(fz, cb, s_eps);
+    __syncthreads();
+    for (; gw < nwaves; gw += gstride) {
+        const int c0w = (int)((jw + bst.shift) % bst.C);
+        int c = (int)((uint32_t)(c0w + 4 * lane) % (uint32_t)bst.C);
+        real_t ev[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {                             // column j + o: x[j + o] +- e, every other coordinate x + 0.0 / x - 0.0
-        const real_t e = ev[o];
-        const real_t ed = MODE == 1 ? 2 * e : e;
-        real_t p[5], m[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { const real_t dlt = k == 2 ? e : (real_t)0; p[k] = xv[o + k] + dlt; m[k] = xv[o + k] - dlt; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const real_t plus = tridiag_row<real_t, NL>(p[k], p[k + 1], p[k + 2]);
-            const real_t sub = MODE == 1 ? tridiag_row<real_t, NL>(m[k], m[k + 1], m[k + 2])
-                                         : tridiag_row<real_t, NL>(xv[o + k], xv[o + k + 1], xv[o + k + 2]);
-            q[3 * o + k] = sub_exact(plus, sub) / ed;
+        for (int o = 0; o < 4; ++o) { ev[o] = s_eps[c]; c = c + 1 == bst.C ? 0 : c + 1; }
+        real_t q[12];
+        tridiag_quad_quotients<MODE, NL>(L, Cc, R, ev, q);
+        fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
+        if (gw + gstride < nwaves) {
+            jw = jstart + (gw + gstride) * 256;
+            j = jw + 4 * lane;
+            Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n);
         }
     }
-    fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
+    if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }
 #endif
 
@@ -766,6 +866,19 @@ static int builtin_launch(void *fctx, void *fx, const void *x, int64_t nbatch, i
     return launch_family<real_t>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
 }
 
+// storing workgroups of a fused launch: as many as tiles, but never more than fit on the device next to the reduction's
+// (8 workgroups of 4 wavefronts per CU): a workgroup dispatched only after others have left would start its life after the step sizes
+// are out -- a second round of memory latency at the end of the launch
+static unsigned fused_store_blocks(unsigned tiles_wg, int nblocks)
+{
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int64_t room = (int64_t)cus * 8 - nblocks;
+    const int64_t cap = room > cus ? room : cus;
+    if ((int64_t)tiles_wg <= cap) return tiles_wg;
+    const int64_t rounds = ((int64_t)tiles_wg + cap - 1) / cap;
+    return (unsigned)(((int64_t)tiles_wg + rounds - 1) / rounds);
+}
+
 template <typename CT>
 static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, int64_t fs, int64_t r0, int64_t r1,
                                hipStream_t s)
@@ -796,6 +909,19 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
             const int64_t jstart = bst.col_begin & ~(int64_t)3;
             const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
             const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
+            if (lp->eps_job) {
+                const FusedEps fz = *(const FusedEps *)lp->eps_job;
+                const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
+#define FD_LAZY_FZ4(MODE, NL)                                                                                                              \
+                do { if (fz.eg.C <= 4) hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, 4>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                                                          b->prm[0], bst, jstart, fz);                                                    \
+                     else hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, kRegColors>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x,    \
+                                             b->prm[0], bst, jstart, fz); } while (0)
+                if (mode == 0) { if (nl) FD_LAZY_FZ4(0, true); else FD_LAZY_FZ4(0, false); }
+                else { if (nl) FD_LAZY_FZ4(1, true); else FD_LAZY_FZ4(1, false); }
+#undef FD_LAZY_FZ4
+                return hipGetLastError() == hipSuccess ? 0 : 4;
+            }
 #define FD_LAZY_SW4(MODE, NL)                                                                                      \
             hipLaunchKernelGGL((k_f_tridiag_store_wave4<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                                (const real_t *)lp->eps, b->prm[0], bst, jstart)
@@ -809,6 +935,20 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
             const int64_t jstart = bst.col_begin & ~(int64_t)1;
             const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
             const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
+            if (lp->eps_job) {
+                // the fused step: this launch also runs the step-size reduction (finisher + reduction workgroups first, see k_f_tridiag_fused)
+                const FusedEps fz = *(const FusedEps *)lp->eps_job;
+                const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
+#define FD_LAZY_FZ(MODE, NL)                                                                                                              \
+                do { if (fz.eg.C <= 4) hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, 4>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                                                          b->prm[0], bst, jstart, fz);                                                    \
+                     else hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, kRegColors>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x,    \
+                                             b->prm[0], bst, jstart, fz); } while (0)
+                if (mode == 0) { if (nl) FD_LAZY_FZ(0, true); else FD_LAZY_FZ(0, false); }
+                else { if (nl) FD_LAZY_FZ(1, true); else FD_LAZY_FZ(1, false); }
+#undef FD_LAZY_FZ
+                return hipGetLastError() == hipSuccess ? 0 : 4;
+            }
 #define FD_LAZY_SW(MODE, NL)                                                                                       \
             hipLaunchKernelGGL((k_f_tridiag_store_wave<MODE, NL>), dim3(gw), dim3(kBlock), 0, s, (const real_t *)lp->x,  \
                                (const real_t *)lp->eps, b->prm[0], bst, jstart)
@@ -817,6 +957,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
 #undef FD_LAZY_SW
             return hipGetLastError() == hipSuccess ? 0 : 4;
         }
+        if (lp->eps_job) return FD_LAZY_DECLINED;      // (the fused step exists for the wave kernels only: the library runs the reduction itself)
         if (bst.layout != FD_BAND_CSC) return FD_LAZY_DECLINED;
         const int bs = kBlock;      // (one-wave workgroups, BS = 64, measured slower: 111-119 vs 105 us at N = 10^7)
         const int pitch = 2 * bs + 2;
@@ -2077,7 +2218,8 @@ int fd_builtin_f_lazy_caps(void *fctx, int *caps_out)
     }
     *caps_out = has_lazy(b) ? (FD_LAZY_CAP_IMAG_ONLY | (b->family == FD_F_BLOCKCOUPLED ? 0 : (FD_LAZY_CAP_ROW_WINDOW | FD_LAZY_CAP_DIFF)) |
                                ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL || b->family == FD_F_LAP5 || b->family == FD_F_LAP5_NL ||
-                                 b->family == FD_F_BLOCKCOUPLED) ? FD_LAZY_CAP_STORE : 0)) : 0;
+                                 b->family == FD_F_BLOCKCOUPLED) ? FD_LAZY_CAP_STORE : 0) |
+                               ((b->family == FD_F_TRIDIAG || b->family == FD_F_TRIDIAG_NL) ? FD_LAZY_CAP_FUSED_EPS : 0)) : 0;
     return FD_OK;
 }
 

@@ -1,0 +1,296 @@
+// Device code of the step-size reduction shared by its own launches (fdjac_kernels.hip) and by the FUSED step of the built-in storing
+// launchers (fdjac_builtin_f.hip): level 0 of the defined two-level sum as a function, and the pieces of the one-launch Jacobian
+// (round 6) -- reduction workgroups, ONE finisher workgroup, storing wavefronts that wait for the step sizes.
+//
+// The fused step hands values from workgroup to workgroup WITHOUT tickets or fences: every handed-over value is its own flag.  A slot
+// holds a sentinel (a quiet NaN with a payload no arithmetic produces) until its producer overwrites it with ONE 8-byte (4-byte)
+// agent-scope atomic store; the consumer polls the slot with agent-scope atomic loads until it reads something else.  No second word has
+// to become visible in order, so nothing is drained and nothing is counted: the dependent chain of the round-5 form (block sum -> drain ->
+// ticket -> load -> group sum -> drain -> ticket -> load -> eps: ~6 round trips through memory) shrinks to two (block sums -> finisher,
+// step sizes -> storing wavefronts).  Slots are double-buffered by call parity: the finisher of call k resets the slots of call k + 1
+// (nobody reads them any more: call k - 1 has completed on the stream).  The ORDER in which values are added is the reduction's
+// definition (k_eps_partial_reg) and does not change: same bits.
+//
+// Progress: reduction workgroups and the finisher occupy the LOWEST block indices of the launch and never wait for a storing
+// wavefront; storing wavefronts wait only for the finisher.  Workgroups are dispatched in index order, so everything a waiting
+// wavefront depends on is resident or done; every wait is bounded by a wall-clock timeout that raises the plan's error word
+// (FD_ERR_COMM from the next call) and stores NaNs instead of hanging the device.
+#pragma once
+#include "fdjac_internal.h"
+
+namespace fdjac {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <typename CT> __device__ __forceinline__ void load_color_pair(const CT *p, int &c0, int &c1);
+template <> __device__ __forceinline__ void load_color_pair<uint8_t>(const uint8_t *p, int &c0, int &c1)
+{
+    const unsigned v = *reinterpret_cast<const uint16_t *>(p);  // p is 2-B aligned (even index)
+    c0 = (int)(v & 0xFF);
+    c1 = (int)(v >> 8);
+}
+template <> __device__ __forceinline__ void load_color_pair<int32_t>(const int32_t *p, int &c0, int &c1)
+{
+    const int2 v = *reinterpret_cast<const int2 *>(p);
+    c0 = v.x;
+    c1 = v.y;
+}
+
+constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
+
+// The reduction is DEFINED as a rank-aligned two-level sum, a function of N alone (see k_eps_partial_reg, fdjac_kernels.hip).
+struct EpsGrid {
+    int tpg, bpg, tpb;          // tiles per group, blocks per group, tiles per block
+    int final_groups;           // > 0: this launch covers that many groups = all of them: its last group writes eps
+    int C, is_forward;
+    double relstep, absstep, dir;
+};
+
+// Level 0 for workgroup `gblock` of the global grid: per-thread accumulation over the block's tiles, the fixed 64-lane shuffle tree,
+// the 4 waves in order.  Returns true on wave 0 only; there lane c < NC holds the block's sum of colour c in `s`.
+template <typename CT, int NC, bool CYC, bool NT>
+__device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n, int cyc_C, int cyc_shift,
+                                              int gblock, const EpsGrid &eg, int pair, double (*red)[NC], double &s)
+{
+    const int grp = gblock / eg.bpg, kb = gblock - grp * eg.bpg;
+    double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+
+    // tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
+    const int64_t tile = (int64_t)kEpsU * kBlock * 2;
+    const int64_t t0 = (int64_t)grp * eg.tpg + (int64_t)kb * eg.tpb;
+    int64_t t1 = t0 + eg.tpb;
+    if (t1 > (int64_t)(grp + 1) * eg.tpg) t1 = (int64_t)(grp + 1) * eg.tpg;
+    const int64_t base0 = t0 * tile;
+    int64_t base_end = t1 * tile;
+    if (base_end > n) base_end = n;
+    // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u
+    int rc = 0, du = 0;
+    if (CYC) {
+        rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C);
+        du = (kBlock * 2) % cyc_C;
+    }
+    for (int64_t base = base0; base < base_end; base += tile) {
+        r2_t v[kEpsU];
+        int c0[kEpsU], c1[kEpsU];
+#pragma unroll
+        for (int u = 0; u < kEpsU; ++u) {
+            const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
+            if (CYC) {
+                c0[u] = rc;
+                c1[u] = rc + 1 == cyc_C ? 0 : rc + 1;
+                rc += du;
+                rc = rc >= cyc_C ? rc - cyc_C : rc;
+            }
+            if (i + 1 < n) {
+                if (NT) v[u] = __builtin_nontemporal_load(reinterpret_cast<const r2_t *>(x + i));
+                else v[u] = *reinterpret_cast<const r2_t *>(x + i);
+                if (!CYC) load_color_pair<CT>(color + i, c0[u], c1[u]);
+            } else if (i < n) {
+                v[u] = r2_t{x[i], 0.0};
+                if (!CYC) c0[u] = color[i];
+                c1[u] = -2;
+            } else {
+                v[u] = r2_t{0.0, 0.0};
+                c0[u] = c1[u] = -2;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kEpsU; ++u) {
+            if (pair) c1[u] = c0[u];     // complex-valued x: (re, im) of one coloured element -- |x_j|^2 = re^2 + im^2
+            const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                acc[c] += (c0[u] == c) ? s0 : 0.0;
+                acc[c] += (c1[u] == c) ? s1 : 0.0;
+            }
+        }
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double w = wave_sum(acc[c]);
+        if (lane == 0) red[wave][c] = w;
+    }
+    __syncthreads();
+    if (wave != 0) return false;
+    s = 0.0;
+    if (lane < NC) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// the fused step
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kFzSentinel64 = 0x7FF85EEDFD1AC0DEull;   // quiet NaNs with a payload: never the result of arithmetic on
+constexpr unsigned kFzSentinel32 = 0x7FC5EED1u;                       //   ordinary inputs (an input NaN of exactly this payload: timeout)
+constexpr int kFzReplicas = 64;      // the step sizes are published in this many places (one 256-B line each for Float64) so that the
+constexpr int kFzPitch = 32;         //   polling wavefronts do not all hammer one memory channel
+
+template <typename T> struct FzBits;
+template <> struct FzBits<double> {
+    typedef unsigned long long u_t;
+    static constexpr u_t sentinel = kFzSentinel64;
+};
+template <> struct FzBits<float> {
+    typedef unsigned u_t;
+    static constexpr u_t sentinel = kFzSentinel32;
+};
+typedef FzBits<real_t>::u_t rbits_t;
+__device__ __forceinline__ real_t fz_from_bits(rbits_t b)
+{
+    real_t r;
+    __builtin_memcpy(&r, &b, sizeof r);
+    return r;
+}
+__device__ __forceinline__ rbits_t fz_to_bits(real_t r)
+{
+    rbits_t b;
+    __builtin_memcpy(&b, &r, sizeof r);
+    return b;
+}
+
+struct FusedEps {
+    EpsGrid eg;
+    int nblocks;                     // reduction workgroups of this launch (blockIdx C .. C + nblocks; blockIdx c < C: the finisher of colour c)
+    int cyc_C, cyc_shift, pair;
+    double *part, *part_next;        // [C][nblocks] block sums, colour-major: this call's parity / the next call's (reset here)
+    rbits_t *epsr, *epsr_next;       // [kFzReplicas][kFzPitch] published step sizes, same double buffering
+    real_t *eps, *eps2;              // the plan's plain arrays (fd_plan_get_epsilons; later launches of the call)
+    int *err;                        // the plan's error word (pinned host memory)
+    long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
+    long long *trace;                // NULL, or 16 words of wall_clock64 marks (fd_plan_fused_trace: where a launch's time goes)
+};
+// trace slots: 0 first reduction workgroup starts (min), 1 last block sum published (max), 2 finisher starts, 3 finisher has every block
+// sum, 4 step sizes published, 5 first storing workgroup starts (min), 6 / 7 first / last storing workgroup has the step sizes, 8 last
+// storing wavefront done (max), 9 last storing workgroup starts (max)
+__device__ __forceinline__ void fz_mark_min(const FusedEps &fz, int k)
+{
+    if (fz.trace && (threadIdx.x & 63) == 0 && ((blockIdx.x & 31) < 2 || blockIdx.x < kRegColors)) atomicMin((unsigned long long *)fz.trace + k, (unsigned long long)wall_clock64());      // (one workgroup in 16 is sampled)
+}
+__device__ __forceinline__ void fz_mark_max(const FusedEps &fz, int k)
+{
+    if (fz.trace && (threadIdx.x & 63) == 0 && ((blockIdx.x & 31) < 2 || blockIdx.x < kRegColors)) atomicMax((unsigned long long *)fz.trace + k, (unsigned long long)wall_clock64());
+}
+
+// a reduction workgroup of the fused step: level 0, published value by value (colour-major: the finisher of colour c reads
+// part[c][0 .. nblocks) with dense loads)
+template <int NC>
+__device__ __forceinline__ void fused_eps_block(const real_t *__restrict__ x, int64_t n, const FusedEps &fz, int gblock, double (*red)[NC])
+{
+    double s;
+    if (threadIdx.x == 0) fz_mark_min(fz, 0);
+    if (!eps_block_sum<uint8_t, NC, true, false>(x, nullptr, n, fz.cyc_C, fz.cyc_shift, gblock, fz.eg, fz.pair, red, s)) return;
+    const int lane = threadIdx.x & 63;
+    if (lane < fz.eg.C) __hip_atomic_store(fz.part + (int64_t)lane * fz.nblocks + gblock, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fz_mark_max(fz, 1);
+}
+
+// the finisher of colour c (one workgroup of kBlock threads per colour: blockIdx c): waits for the colour's block sums -- dense loads,
+// every thread a few, all in flight together --, parks them in LDS, thread g adds group g's in block order (level 1), thread 0 the 64
+// group sums in group order (level 2) and forms eps[c]; the workgroup publishes it and resets the next call's slots of its colour.
+// (One workgroup for all colours, thread (group, colour pair) loading its own addends, took 3 us for the wait alone at N = 10^6: 1024
+// scattered 8-byte requests through one CU's memory pipeline.)  lds: kFzMaxBlocks + kEpsGroups + 2 doubles.
+constexpr int kFzMaxBlocks = kEpsGroups * kEpsBlocksPerGroup;      // 1024
+__device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double *lds)
+{
+    const int t = threadIdx.x, nb = fz.nblocks, bpg = fz.eg.bpg;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(fz.part + (int64_t)c * nb);
+    constexpr int M = kFzMaxBlocks / kBlock;       // 4
+    unsigned long long v[M];
+    int ok = 1;
+    if (t == 0) fz_mark_max(fz, 2);
+    {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                v[m] = 0;
+                if (t + m * kBlock < nb) {
+                    v[m] = __hip_atomic_load(src + t + m * kBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    all = all && v[m] != kFzSentinel64;
+                }
+            }
+            if (all) break;
+            if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (t + m * kBlock < nb) lds[t + m * kBlock] = __longlong_as_double((long long)v[m]);
+    __shared__ int s_bad;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    if (t == 0) fz_mark_max(fz, 3);
+    if (!ok) s_bad = 1;
+    double *gs = lds + kFzMaxBlocks;
+    if (t < kEpsGroups) {
+        double g = 0.0;
+        for (int k = 0; k < bpg; ++k) g += lds[t * bpg + k];
+        gs[t] = g;
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    real_t *s_e = reinterpret_cast<real_t *>(gs + kEpsGroups);
+    if (t == 0) {
+        if (bad) __hip_atomic_store(fz.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        double tot = 0.0;
+#pragma unroll 16
+        for (int gg = 0; gg < kEpsGroups; ++gg) tot += gs[gg];
+        real_t e = eps_rule<real_t>(tot, fz.eg.relstep, fz.eg.absstep, fz.eg.dir, fz.eg.is_forward);
+        if (bad) e = fz_from_bits(FzBits<real_t>::sentinel ^ 1);      // (a NaN that is not the sentinel: the storing wavefronts go on and store NaNs)
+        s_e[0] = e;
+        fz.eps[c] = e;
+        if (fz.eps2) fz.eps2[c] = (real_t)2 * e;
+    }
+    __syncthreads();
+    if (t < kFzReplicas) {
+        __hip_atomic_store(fz.epsr + t * kFzPitch + c, fz_to_bits(s_e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fz.epsr_next + t * kFzPitch + c, FzBits<real_t>::sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == 0) fz_mark_max(fz, 4);
+    unsigned long long *pn = reinterpret_cast<unsigned long long *>(fz.part_next + (int64_t)c * nb);
+    for (int i = t; i < nb; i += kBlock) __hip_atomic_store(pn + i, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a storing workgroup's wait for the step sizes: ONE wavefront polls (lane c its colour's slot of the workgroup's replica) and parks
+// them in LDS; the caller's barrier releases the others.  (Every wavefront polling for itself -- 7 800 of them at N = 10^6 -- kept the
+// memory system busy enough to delay what they were waiting for: 18 us per launch instead of 14.)
+__device__ __forceinline__ void fused_wait_eps(const FusedEps &fz, int wg_id, real_t *s_eps)
+{
+    const int lane = threadIdx.x & 63;
+    const rbits_t *E = fz.epsr + (wg_id & (kFzReplicas - 1)) * kFzPitch;
+    const int c = lane < fz.eg.C ? lane : 0;
+    long long t0 = 0;
+    rbits_t b = 0;
+    fz_mark_min(fz, 5);
+    fz_mark_max(fz, 9);
+    for (int spin = 0;; ++spin) {
+        b = __hip_atomic_load(E + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(b != FzBits<real_t>::sentinel)) break;
+        if (spin == 0) t0 = wall_clock64();
+        if ((spin & 15) == 15 && wall_clock64() - t0 > fz.timeout_ticks) {
+            if (lane == 0) __hip_atomic_store(fz.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = FzBits<real_t>::sentinel ^ 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (lane < kRegColors) s_eps[lane] = fz_from_bits(b);
+    fz_mark_min(fz, 6);
+    fz_mark_max(fz, 7);
+}
+
+}  // namespace fdjac

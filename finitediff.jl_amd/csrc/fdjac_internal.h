@@ -33,6 +33,7 @@
 #define fd_plan_set_lazy_f fd32_plan_set_lazy_f
 #define fd_plan_set_lazy_caps fd32_plan_set_lazy_caps
 #define fd_plan_get_epsilons fd32_plan_get_epsilons
+#define fd_plan_fused_trace fd32_plan_fused_trace
 #define fd_plan_set_comm fd32_plan_set_comm
 #define fd_plan_set_p2p fd32_plan_set_p2p
 #define fd_plan_set_halo fd32_plan_set_halo
@@ -41,6 +42,7 @@
 #define fd_plan_set_eps_mode fd32_plan_set_eps_mode
 #define fd_plan_eps_shard_range fd32_plan_eps_shard_range
 #define fd_plan_enable_timing fd32_plan_enable_timing
+#define fd_plan_set_timing_stride fd32_plan_set_timing_stride
 #define fd_plan_get_timings fd32_plan_get_timings
 #define fd_plan_get_timing_samples fd32_plan_get_timing_samples
 #define fd_builtin_f_create fd32_builtin_f_create
@@ -372,6 +374,15 @@ struct fd_plan {
                                               //   parts: d_fx for the complex step (never written), d_zero_own otherwise
     fdjac::real_t *d_eps2 = nullptr;          // 2 * eps per colour (central differences handed over as f(+) - f(-))
     bool eps2_fresh = false;                  //   d_eps2 matches d_eps (written by the finalize launch; else launch_scale)
+    // the fused step (fdjac_eps_dev.h): block sums and published step sizes, each double-buffered by call parity and holding a
+    // sentinel until written; an error word in pinned host memory (a wait timed out: FD_ERR_COMM from the next call)
+    double *d_fz_part = nullptr;              // [2][n_partial_blocks][kRegColors]
+    void *d_fz_eps = nullptr;                 // [2][kFzReplicas][kFzPitch] elements
+    int *h_fz_err = nullptr, *d_fz_err = nullptr;
+    unsigned fz_parity = 0;
+    long long *d_fz_trace = nullptr;          // FDJAC_FUSED_TRACE=1: wall_clock64 marks of the last fused launch (fd_plan_fused_trace)
+    int eps_form = 0;                         // the library's own reduction: 0 = all levels in one launch, 1 = levels 0 + 1, then k_eps_final (same bits)
+    int64_t fz_max_n = (int64_t)1 << 21;      // single GPU: problems up to this size take the fused step (FDJAC_FUSED_MAX_N; 0 = never)
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
     fd_p2p *p2p = nullptr;         //   ... its group sums (and the halo of x) travel through this mailbox in ONE launch (fd_plan_set_p2p, or the
                                    //   communicator's own mailbox)
@@ -386,10 +397,12 @@ struct fd_plan {
     int *h_pstale = nullptr, *d_pstale = nullptr;   //   ... this plan's own sticky stale word (pinned host memory mapped to the device)
 
     int timing = 0;   // 0 off, 1 decompress + total, 2 all stages
+    int timing_stride = 1;      // level 1: only every timing_stride-th call carries the two events (fd_plan_set_timing_stride)
+    int64_t timing_calls = 0;
     std::vector<fdjac::TimedSpan> spans;       // recorded, not yet collected
     std::vector<hipEvent_t> event_pool;
-    double ms_sum[FD_NSTAGES] = {0, 0, 0, 0, 0};
-    int64_t launches[FD_NSTAGES] = {0, 0, 0, 0, 0};
+    double ms_sum[FD_NSTAGES] = {};
+    int64_t launches[FD_NSTAGES] = {};
     std::vector<float> samples[FD_NSTAGES];    // the individual spans (fd_plan_get_timing_samples), capped
 };
 

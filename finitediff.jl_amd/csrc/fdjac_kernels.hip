@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "fdjac_internal.h"
+#include "fdjac_eps_dev.h"
 
 namespace fdjac {
 
@@ -22,13 +23,6 @@ template <typename CT> struct ColorTraits;
 template <> struct ColorTraits<uint8_t> { static constexpr int none = 0xFF; static constexpr int pad = 0xFE; };
 template <> struct ColorTraits<int32_t> { static constexpr int none = -1; static constexpr int pad = -2; };
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1a  masked sums of squares for ALL colours in one pass over x (C <= kRegColors).
 //   Replaces, for every colour at once:  @. x2 = x1*(_color==color_i); tmp = norm(x2)
@@ -36,22 +30,6 @@ __device__ __forceinline__ double wave_sum(double v)
 //   shuffle tree, per-block partials reduced by k_eps_finalize in fixed order.
 //   partial layout: partial[block * ldp + c].
 // ---------------------------------------------------------------------------------------------
-template <typename CT> __device__ __forceinline__ void load_color_pair(const CT *p, int &c0, int &c1);
-template <> __device__ __forceinline__ void load_color_pair<uint8_t>(const uint8_t *p, int &c0, int &c1)
-{
-    const unsigned v = *reinterpret_cast<const uint16_t *>(p);  // p is 2-B aligned (even index)
-    c0 = (int)(v & 0xFF);
-    c1 = (int)(v >> 8);
-}
-template <> __device__ __forceinline__ void load_color_pair<int32_t>(const int32_t *p, int &c0, int &c1)
-{
-    const int2 v = *reinterpret_cast<const int2 *>(p);
-    c0 = v.x;
-    c1 = v.y;
-}
-
-constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
-
 // CYC: the colours are cyclic, color[j] == (j + shift) mod C for every column (found at plan time: tridiagonal /
 //   banded patterns coloured with mod1(j, C)) -- the kernel computes them and reads x alone (8 B per column instead of 9).
 // NT:  non-temporal loads of x.  In a steady-state loop the pass follows the previous call's nzval stores; plain
@@ -70,13 +48,6 @@ constexpr int kEpsU = 4;  // independent 16-B loads in flight per thread
 // 64 x 16 + 64).  Hand-off between workgroups: 8-byte agent-scope atomic stores and loads on both sides with
 // the stores drained before the ticket (MI355X_MICROARCH.md, inter-workgroup visibility); which block does the adding never
 // changes what is added in which order.  final_groups = 0: stop after level 1 (a shard: its group sums are exchanged).
-struct EpsGrid {
-    int tpg, bpg, tpb;          // tiles per group, blocks per group, tiles per block
-    int final_groups;           // > 0: this launch covers that many groups = all of them: its last group writes eps
-    int C, is_forward;
-    double relstep, absstep, dir;
-};
-
 template <typename CT, int NC, bool CYC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n,
@@ -84,78 +55,13 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
                   int block_off, EpsGrid eg, int pair, real_t *__restrict__ eps, real_t *__restrict__ eps2)
 {
     const int gblock = (int)blockIdx.x + block_off;
-    const int grp = gblock / eg.bpg, kb = gblock - grp * eg.bpg;
-    double acc[NC];   // sums of squares are accumulated in Float64 whatever the element type
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-
-    // tile = kEpsU * 512 elements; pair u of thread t sits at tile + u*512 + 2t (dense per instruction)
-    const int64_t tile = (int64_t)kEpsU * kBlock * 2;
-    const int64_t t0 = (int64_t)grp * eg.tpg + (int64_t)kb * eg.tpb;
-    int64_t t1 = t0 + eg.tpb;
-    if (t1 > (int64_t)(grp + 1) * eg.tpg) t1 = (int64_t)(grp + 1) * eg.tpg;
-    const int64_t base0 = t0 * tile;
-    int64_t base_end = t1 * tile;
-    if (base_end > n) base_end = n;
-    // cyclic colours: colour of this thread's first element, then advanced by (512 mod C) per u
-    int rc = 0, du = 0;
-    if (CYC) {
-        rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C);
-        du = (kBlock * 2) % cyc_C;
-    }
-    for (int64_t base = base0; base < base_end; base += tile) {
-        r2_t v[kEpsU];
-        int c0[kEpsU], c1[kEpsU];
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
-            if (CYC) {
-                c0[u] = rc;
-                c1[u] = rc + 1 == cyc_C ? 0 : rc + 1;
-                rc += du;
-                rc = rc >= cyc_C ? rc - cyc_C : rc;
-            }
-            if (i + 1 < n) {
-                if (NT) v[u] = __builtin_nontemporal_load(reinterpret_cast<const r2_t *>(x + i));
-                else v[u] = *reinterpret_cast<const r2_t *>(x + i);
-                if (!CYC) load_color_pair<CT>(color + i, c0[u], c1[u]);
-            } else if (i < n) {
-                v[u] = r2_t{x[i], 0.0};
-                if (!CYC) c0[u] = color[i];
-                c1[u] = -2;
-            } else {
-                v[u] = r2_t{0.0, 0.0};
-                c0[u] = c1[u] = -2;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            if (pair) c1[u] = c0[u];     // complex-valued x: (re, im) of one coloured element -- |x_j|^2 = re^2 + im^2
-            const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                acc[c] += (c0[u] == c) ? s0 : 0.0;
-                acc[c] += (c1[u] == c) ? s1 : 0.0;
-            }
-        }
-    }
-
+    const int grp = gblock / eg.bpg;
     __shared__ double red[kBlock / 64][NC];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double s = wave_sum(acc[c]);
-        if (lane == 0) red[wave][c] = s;
-    }
-    __syncthreads();
-    if (wave != 0) return;
+    double s;
+    if (!eps_block_sum<CT, NC, CYC, NT>(x, color, n, cyc_C, cyc_shift, gblock, eg, pair, red, s)) return;
+    const int lane = threadIdx.x & 63;
     // ---- level 0 result of this block, then the hand-off (wave 0 only; lanes < NC carry one colour each) ----
-    if (lane < NC) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
-        __hip_atomic_store(partial + (int64_t)gblock * ldp + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane < NC) __hip_atomic_store(partial + (int64_t)gblock * ldp + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the block sums have left this CU before the ticket is drawn
     unsigned t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1431,6 +1337,10 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
+    if (C <= kRegColors && p->eps_form == 1) {
+        const int rc = launch_eps_groups_t<CT>(p, x, 0, kEpsGroups, false, relstep, absstep, dir);
+        return rc ? rc : launch_eps_final(p, relstep, absstep, dir);
+    }
     if (C <= kRegColors) return launch_eps_groups_t<CT>(p, x, 0, kEpsGroups, true, relstep, absstep, dir);
     const int nparts = p->seg_chunks;
     hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,

@@ -24,6 +24,7 @@
 
 #include <cstring>
 #include <new>
+#include <vector>
 
 #ifndef FDJAC_F32   /* element-type independent: compiled once */
 
@@ -47,6 +48,7 @@ struct fd_p2p {
     uint64_t epoch[2] = {0, 0};
     bool connected = false;
     bool uncached = false;
+    char *sink = nullptr;                     // loop-back mailbox (fd_p2p_create_loopback): what every peer's mailbox is mapped to
 };
 
 namespace fdjac {
@@ -382,11 +384,58 @@ int fd_p2p_connect(fd_p2p *p, const void *handles)
     return FD_OK;
 }
 
+// A mailbox whose peers are all THIS device (rank-share measurements and tests on one GPU): every peer's mailbox is
+// mapped to one local sink, the flags of every sender stand at the largest epoch (no wait ever spins) and the senders' slots hold what
+// fd_p2p_loopback_fill put there -- rank `rank` of `nranks` then runs its step exactly as in the W-rank job: the same launches, the
+// same stores (into local HBM instead of across xGMI), the same copies out of its own mailbox.
+int fd_p2p_create_loopback(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p **out)
+{
+    int rc = fd_p2p_create(ctx, nranks, rank, slot_bytes, out);
+    if (rc) return rc;
+    fd_p2p *p = *out;
+    const size_t chan = (size_t)nranks * kP2PFlagStride + 2 * (size_t)nranks * (size_t)p->slot_bytes;
+    hipError_t e = hipMalloc((void **)&p->sink, 2 * chan);
+    if (e == hipSuccess) e = hipMemset(p->sink, 0, 2 * chan);
+    std::vector<unsigned long long> flags((size_t)nranks * (kP2PFlagStride / 8), ~0ull);
+    for (int ch = 0; ch < 2 && e == hipSuccess; ++ch)
+        e = hipMemcpy(p->local + ch * chan, flags.data(), flags.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("setting up the loop-back mailbox failed: %s", hipGetErrorString(e));
+        (void)fd_p2p_destroy(p);
+        *out = nullptr;
+        return FD_ERR_HIP;
+    }
+    for (int r = 0; r < nranks; ++r) p->peer[r] = r == rank ? p->local : p->sink;
+    FD_HIP_CHECK(hipMemcpy(p->d_peer, p->peer, sizeof(char *) * kP2PMaxRanks, hipMemcpyHostToDevice));
+    FD_HIP_CHECK(hipDeviceSynchronize());
+    p->connected = true;
+    return FD_OK;
+}
+
+// what `sender` would have delivered: `bytes` bytes (device or host memory) at byte `offset` of its slot, both parities of the
+// all-gather / step channel
+int fd_p2p_loopback_fill(fd_p2p *p, int sender, int64_t offset, const void *data, int64_t bytes)
+{
+    FD_REQUIRE(p && p->sink, FD_ERR_ARG, "not a loop-back mailbox");
+    FD_REQUIRE(sender >= 0 && sender < p->nranks && sender != p->rank, FD_ERR_ARG, "sender %d", sender);
+    FD_REQUIRE(data && offset >= 0 && bytes >= 0 && offset + bytes <= p->slot_bytes, FD_ERR_ARG, "offset %lld + %lld bytes do not fit the slot (%lld)",
+               (long long)offset, (long long)bytes, (long long)p->slot_bytes);
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    for (int par = 0; par < 2; ++par) {
+        char *slot = p->local + (int64_t)p->nranks * kP2PFlagStride + ((int64_t)par * p->nranks + sender) * p->slot_bytes + offset;
+        FD_HIP_CHECK(hipMemcpy(slot, data, (size_t)bytes, hipMemcpyDefault));
+    }
+    FD_HIP_CHECK(hipDeviceSynchronize());
+    return FD_OK;
+}
+
 int fd_p2p_destroy(fd_p2p *p)
 {
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->sink) (void)hipFree(p->sink);
     for (int r = 0; r < p->nranks; ++r)
         if (p->mapped[r] && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
     if (p->d_peer) (void)hipFree(p->d_peer);

@@ -21,13 +21,13 @@ TRI_DIAGONALS, TRI_CSC = 0, 1
 FORWARD, CENTRAL, COMPLEX = 0, 1, 2
 HOST, DEVICE = 0, 1
 FDTYPES = {"forward": FORWARD, "central": CENTRAL, "complex": COMPLEX}
-STAGES = ("eps", "perturb", "f", "decompress", "total")
+STAGES = ("eps", "perturb", "f", "decompress", "total", "exchange")
 (INFO_M, INFO_N, INFO_NCOLORS, INFO_NOUTS, INFO_OUT0_LEN, INFO_OUT1_LEN, INFO_OUT2_LEN, INFO_ROW_BEGIN,
  INFO_ROW_END, INFO_NCHUNKS, INFO_SCRATCH_BYTES, INFO_NNZ_LOCAL, INFO_FCALLS_LAST, INFO_ENTRY_BEGIN,
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
  INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE, INFO_STORE_CSC) = range(34)
-LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE, LAZY_CAP_STORE_CSC_COMPLEX = 1, 2, 4, 8, 16, 32, 64
+LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE, LAZY_CAP_STORE_CSC_COMPLEX, LAZY_CAP_FUSED_EPS = 1, 2, 4, 8, 16, 32, 64, 128
 PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC, PLAN_STORE_CSC_ALWAYS = 1, 2, 4, 8, 16
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL, F_LAP7, F_SPARSE) = range(9)
@@ -42,7 +42,7 @@ class LazyPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("color", C.c_void_p), ("eps", C.c_void_p), ("base_out", C.c_void_p),
                 ("color_bytes", C.c_int32), ("c_lo", C.c_int32), ("ncolors", C.c_int32), ("pts", C.c_int32),
                 ("is_complex", C.c_int32), ("imag_only", C.c_int32), ("part", C.c_int32), ("nparts", C.c_int32),
-                ("diff", C.c_int32), ("store_kind", C.c_int32), ("store", C.c_void_p)]
+                ("diff", C.c_int32), ("store_kind", C.c_int32), ("store", C.c_void_p), ("eps_job", C.c_void_p)]
 
 
 # int f(fctx, fx, const fd_lazy_points*, fx_stride, row_begin, row_end, stream)
@@ -63,7 +63,7 @@ EXPORTS = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
     "fd_plan_create_bandedblockbanded", "fd_plan_destroy",
-    "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_enable_timing",
+    "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts", "fd_builtin_f_info",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
@@ -71,7 +71,7 @@ EXPORTS = (
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
-    "fd_p2p_create", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
+    "fd_p2p_create", "fd_p2p_create_loopback", "fd_p2p_loopback_fill", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
@@ -85,7 +85,7 @@ TYPED = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
     "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
-    "fd_plan_get_epsilons", "fd_plan_enable_timing", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
+    "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_info", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
     "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
@@ -187,7 +187,9 @@ def load():
     L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
     L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
     L.fd_plan_get_epsilons.argtypes = [vp, C.POINTER(dbl)]
+    L.fd_plan_fused_trace.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.fd_plan_enable_timing.argtypes = [vp, i32]
+    L.fd_plan_set_timing_stride.argtypes = [vp, i32]
     L.fd_plan_get_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.fd_plan_get_timing_samples.argtypes = [vp, i32, C.POINTER(dbl), i64, C.POINTER(i64)]
     L.fd_builtin_f_create.argtypes = [vp, i32, C.POINTER(i64), i32, C.POINTER(F_LAUNCH), pp]
@@ -229,6 +231,8 @@ def load():
     L.fd_f_compiled_counts.argtypes = [vp, C.POINTER(i64)]
     L.fd_f_compile_log.restype = C.c_char_p
     L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
+    L.fd_p2p_create_loopback.argtypes = [vp, i32, i32, i64, pp]
+    L.fd_p2p_loopback_fill.argtypes = [vp, i32, i64, vp, i64]
     L.fd_p2p_local_handle.argtypes = [vp, vp]
     L.fd_p2p_connect.argtypes = [vp, vp]
     L.fd_p2p_destroy.argtypes = [vp]

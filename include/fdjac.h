@@ -126,6 +126,11 @@ typedef struct fd_lazy_points {
                           /* not written and no decompression follows.  The plan hands it out only for a verified exact band */
                           /* with cyclic colours (the default then; FDJAC_LAZY_STORE=0: never); the launcher may still       */
                           /* return FD_LAZY_DECLINED                                                                         */
+    const void *eps_job;  /* launchers registered with FD_LAZY_CAP_FUSED_EPS only (the library's built-in families): non-NULL = */
+                          /* the step sizes have NOT been computed -- this launch runs the step-size reduction too (its first   */
+                          /* workgroups) and the storing wavefronts wait for the published step sizes: the whole Jacobian in    */
+                          /* ONE launch (N <= 2^21 on one GPU; every sharded call).  `eps` is written by that launch.  A        */
+                          /* launcher that returns FD_LAZY_DECLINED is called again after the library's own reduction.         */
 } fd_lazy_points;
 typedef int (*fd_f_launch_lazy)(void *fctx, void *fx, const fd_lazy_points *points, int64_t fx_stride,
                                 int64_t row_begin, int64_t row_end, void *stream);
@@ -347,10 +352,16 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* store_kind = FD_STORE_CSC): every stored entry's row at x + i eps e_j, imag / eps stored                   */
                                   /* (src/jacobians.jl:623-648 + ext/FiniteDiffSparseArraysExt.jl:38-47 in one launch); without the bit a       */
                                   /* complex-step plan hands the values over as before                                                          */
+#define FD_LAZY_CAP_FUSED_EPS 128 /* honours fd_lazy_points.eps_job (library-internal protocol of the built-in storing launchers)               */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 
 /* The step sizes of the last call, eps[c] for colours 1..C (host array of C doubles). */
 int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
+/* Diagnostic: wall_clock64 marks (100 MHz ticks) of the plan's last FUSED launch -- 0 first reduction workgroup starts, 1 last block sum
+   published, 2 finisher starts, 3 finisher has every block sum, 4 step sizes published, 5 first storing workgroup starts, 6 / 7 first / last
+   storing workgroup has the step sizes, 8 last storing wavefront done, 9 last storing workgroup starts.  Only in a process that set
+   FDJAC_TEST_SWITCHES=1 and FDJAC_FUSED_TRACE=1 before the plan's first fused call (FD_ERR_UNSUPPORTED otherwise). */
+int fd_plan_fused_trace(fd_plan *plan, long long *marks16);
 
 /* Per-stage GPU time of the calls made since timing was enabled (HIP events on the plan's
    stream).  stage: 0 eps-reduce, 1 perturb, 2 f!, 3 diff+decompress (a FD_LAZY_CAP_STORE launch that evaluates f!, divides
@@ -358,11 +369,18 @@ int fd_plan_get_epsilons(fd_plan *plan, double *eps_out);
    ms_sum / launches accumulate; fd_plan_get_timings / fd_plan_enable_timing synchronise the stream, the calls
    themselves never wait for the device (finished spans are harvested with hipEventQuery).
    on: 0 = off, 1 = the diff+decompress kernel only (2 events per call), 2 = every stage and the whole call, 3 = the whole
-   call only (2 events per call: what a per-call median should be taken from -- level 2's extra markers cost ~15 us per call). */
+   call only (2 events per call: what a per-call median should be taken from -- level 2's extra markers cost ~15 us per call),
+   4 = every stage without the whole-call markers. */
 enum fd_stage { FD_STAGE_EPS = 0, FD_STAGE_PERTURB = 1, FD_STAGE_F = 2, FD_STAGE_DECOMPRESS = 3,
-                FD_STAGE_TOTAL = 4, FD_NSTAGES = 5 };
+                FD_STAGE_TOTAL = 4, FD_STAGE_EXCHANGE = 5 /* sharded calls: halo + group sums + step sizes (inside FD_STAGE_EPS's span) */,
+                FD_NSTAGES = 6 };
 int fd_plan_enable_timing(fd_plan *plan, int on);
 int fd_plan_get_timings(fd_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+/* Level 1 on a SAMPLE of the calls: only every stride-th call (the first after this call, then every stride-th) carries the two events.
+   A pair of events costs ~8 us of stream time per call on MI355X (two marker packets that keep consecutive launches from overlapping
+   their start-up: scripts/ubench/ext_launch_probe.hip) -- 10 % of a 75-us Jacobian, 40 % of a 20-us one; sampled, a timed loop runs at
+   its untimed speed and the graded kernel is still measured inside it. */
+int fd_plan_set_timing_stride(fd_plan *plan, int stride);
 /* The individual span durations behind ms_sum (most recent first dropped: the first `cap` spans since timing was enabled,
    in call order; at most 65536 are kept per stage): what a MEDIAN over individually timed runs needs. */
 int fd_plan_get_timing_samples(fd_plan *plan, int stage, double *ms_out, int64_t cap, int64_t *n_out);
@@ -506,6 +524,13 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes /* per r
 int fd_p2p_local_handle(fd_p2p *p2p, void *handle_out /* FD_P2P_HANDLE_BYTES bytes, host */);
 int fd_p2p_connect(fd_p2p *p2p, const void *handles /* nranks x FD_P2P_HANDLE_BYTES bytes, rank order, host */);
 int fd_p2p_destroy(fd_p2p *p2p);
+/* A LOOP-BACK mailbox: rank `rank` of an `nranks`-rank job on ONE device.  Every peer's mailbox is mapped to a local sink, no wait
+   ever spins, and the senders' slots hold what fd_p2p_loopback_fill put there (`bytes` bytes of device or host memory at byte
+   `offset` of `sender`'s slot: its group sums, then its halo of x -- the layout of the per-step exchange).  A plan with this mailbox
+   attached runs one rank's share of the sharded step -- the same launches and stores -- with nobody else present: bench.py's
+   `rank_share` measurement and the single-GPU tests of the sharded call (no connect step). */
+int fd_p2p_create_loopback(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p **out);
+int fd_p2p_loopback_fill(fd_p2p *p2p, int sender, int64_t offset, const void *data, int64_t bytes);
 int fd_p2p_info(const fd_p2p *p2p, int *nranks, int *rank, int64_t *slot_bytes, int *uncached);   /* any out pointer may be NULL */
 /* 0 while every exchange completed; 1 + r once a wait for rank r timed out (sticky; no synchronisation needed to read it) */
 int fd_p2p_status(const fd_p2p *p2p, int *timed_out_rank_plus_1);
@@ -667,6 +692,7 @@ int fd32_jacobian_async(fd32_plan *plan, fd_f_launch f, void *fctx, const void *
 int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
+int fd32_plan_fused_trace(fd32_plan *plan, long long *marks16);
 typedef struct fd32_tridiag_solver fd32_tridiag_solver;
 int fd32_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
                                fd32_tridiag_solver **out);
@@ -691,6 +717,7 @@ int fd32_plan_set_eps_mode(fd32_plan *plan, int mode);
 int fd32_plan_eps_shard_range(fd32_plan *plan, int shard, int nshards, int64_t *x_begin, int64_t *x_end);
 int fd32_plan_enable_timing(fd32_plan *plan, int on);
 int fd32_plan_get_timings(fd32_plan *plan, double *ms_sum /*[FD_NSTAGES]*/, int64_t *launches /*[FD_NSTAGES]*/);
+int fd32_plan_set_timing_stride(fd32_plan *plan, int stride);
 int fd32_plan_get_timing_samples(fd32_plan *plan, int stage, double *ms_out, int64_t cap, int64_t *n_out);
 int fd32_builtin_f_create(fd_ctx *ctx, int family, const int64_t *params, int nparams,
                         fd_f_launch *fn_out, void **fctx_out);
