@@ -579,8 +579,10 @@ def main():
     # output buffers: rank r fills out = its slice; rank 0 also owns the assembled nzval (root gather) / every rank the
     # padded slots (all-gather)
     bufs = S.AllGatherBuffers(counts, dev, t_dt)
+    asm_owned = None
     if by_color:
         out = torch.zeros(nnz, dtype=t_dt, device=dev)      # every rank: whole nzval, zero except its colours' columns
+        asm_owned = torch.full((nnz,), float("nan"), dtype=t_dt, device=dev)      # ... and the assembled Jacobian (do_gather)
     elif world > 1:
         out = bufs.local_view(rank)[: counts[rank]]
     else:
@@ -591,11 +593,12 @@ def main():
     def do_gather():
         """Assemble nzval.  nccl: libfdjac's own RCCL calls (fd_comm_gatherv / fd_comm_allgather / fd_comm_allreduce_sum)."""
         if by_color:
-            if comm is not None:
-                comm.allreduce_sum(out)
-            else:
-                out.copy_(S.all_reduce_owned(out.cpu(), dist))
-            return out
+            # colour ownership: the assembly is the library's (fd_jacobian_owned_async: zero-fill, this rank's colours, ONE all-reduce) --
+            # summing the outputs of plain calls is right only on a fresh buffer (entries this rank does not own keep the previous sum)
+            plan.jacobian_owned(f, x, [asm_owned], comm=comm)
+            if comm is None:
+                asm_owned.copy_(S.all_reduce_owned(asm_owned.cpu(), dist))
+            return asm_owned
         if comm is not None:
             if args.gather == "root":
                 comm.gatherv(out, full, counts, root=0)
@@ -964,7 +967,7 @@ def main():
             ms_g = torch.tensor([sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(gs)) / gs], dtype=torch.float64, device=dev)
             dist.all_reduce(ms_g, op=dist.ReduceOp.MAX)
             gbytes = float(sum(counts) - counts[0]) * vs if (args.gather == "root" and not by_color) else float(sum(counts)) * vs
-            gather_info = {"kind": ("all-reduce(sum) of colour-owned outputs" if by_color else
+            gather_info = {"kind": ("fd_jacobian_owned_async: zero-fill + this rank's colours + all-reduce(sum)" if by_color else
                                     "fd_comm_gatherv to rank 0 (grouped ncclSend/ncclRecv)" if args.gather == "root" else
                                     "fd_comm_allgather (in-place ncclAllGather)") if comm is not None else "gloo dry run",
                            "ms": float(ms_g.item()), "bytes_over_links": gbytes, "in_timed_step": bool(gather_in_step)}
@@ -1039,6 +1042,12 @@ def main():
         check["nonlinear_fixture_max_abs_err_vs_analytic"] = float((nl.double() - want).abs().max().item())
         check["nonlinear_fixture_tolerance"] = 2e-6 if args.dtype == "f64" else 2e-2
         plan.set_lazy(f if f_mode == "lazy" else None)
+    if assembled is not None and by_color and "error" not in (gather_info or {}):
+        # the assembly has run gs + 1 >= 4 times on the same buffer by now: every stored value must still be the exact stencil weight
+        pa = torch.arange(assembled.numel(), device=dev, dtype=torch.int64)
+        exact_a = torch.where((pa % 3) == 0, torch.full_like(assembled, -2.0), torch.ones_like(assembled))
+        check["assembled_after_repeated_gathers_max_dev_from_exact"] = float((assembled - exact_a).abs().max().item())
+        check["assembled_ok"] = check["assembled_after_repeated_gathers_max_dev_from_exact"] <= (1e-6 if args.dtype == "f64" else 1e-2)
     if assembled is not None and rank == 0 and not by_color and "error" not in (gather_info or {}):
         a = assembled if args.gather == "root" or comm is None else bufs.compact()
         check["assembled_slice_matches_local"] = bool(torch.equal(a[: counts[0]], timed_result))
@@ -1046,6 +1055,8 @@ def main():
     if "nonlinear_fixture_max_abs_err_vs_analytic" in check:
         ok = ok and check["nonlinear_fixture_max_abs_err_vs_analytic"] <= check["nonlinear_fixture_tolerance"]
         ok = ok and check["max_dev_from_exact_stencil_all_entries"] <= (1e-6 if args.dtype == "f64" else 1e-2)
+    if "assembled_ok" in check:
+        ok = ok and check["assembled_ok"]
     check["ok"] = bool(ok)
 
     p2p_st = p2p_status() if world > 1 else 0

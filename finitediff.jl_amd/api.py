@@ -427,6 +427,16 @@ class P2P:
         p, eb = Comm._dev(data, "data")
         _l.check(self.L.fd_p2p_loopback_fill(self.handle, int(sender), int(offset), p, int(data.numel()) * eb))
 
+    def fill_fused(self, gsum64x8, halo_lo=None, halo_hi=None):
+        """fd_p2p_loopback_fill_fused: the 64 x 8 group sums (float64 CUDA tensor of 512) and the neighbours' halos for the fused step."""
+        p, _ = Comm._dev(gsum64x8, "gsum64x8")
+        if gsum64x8.numel() != 512 or gsum64x8.element_size() != 8:
+            raise ValueError("gsum64x8 must hold 64 x 8 doubles")
+        lo = Comm._dev(halo_lo, "halo_lo") if halo_lo is not None else (None, 0)
+        hi = Comm._dev(halo_hi, "halo_hi") if halo_hi is not None else (None, 0)
+        hb = max(halo_lo.numel() * lo[1] if halo_lo is not None else 0, halo_hi.numel() * hi[1] if halo_hi is not None else 0)
+        _l.check(self.L.fd_p2p_loopback_fill_fused(self.handle, p, lo[0], hi[0], int(hb)))
+
     def local_handle(self):
         buf = C.create_string_buffer(_l.P2P_HANDLE_BYTES)
         _l.check(self.L.fd_p2p_local_handle(self.handle, buf))
@@ -932,6 +942,35 @@ class Plan:
             raise err
         _l.check(rc)
 
+
+    def jacobian_owned(self, f, x, outs, comm=None, f_in=None, relstep=None, absstep=None, dir=True):
+        """fd_jacobian_owned_async: the call of a colour-owning plan (make_plan(..., color_range=...)) with its assembly -- zero-fill,
+        this rank's colours, ONE in-place all-reduce per output over `comm` (None: the caller sums the ranks' outputs).  Device arrays;
+        enqueues and returns.  Right call after call on the same buffers, which summing the outputs of plain calls is not."""
+        L = self.Lt
+        xp, xk, _k1 = _ptr(x, "x", self.dtype, self.cx)
+        ptrs, keep = [], []
+        for o in outs:
+            p, k, ka = _ptr(o, "output", self.dtype, self.cx)
+            if k != _l.DEVICE:
+                raise ValueError("jacobian_owned() needs device arrays")
+            ptrs.append(p)
+            keep.append(ka)
+        if xk != _l.DEVICE:
+            raise ValueError("jacobian_owned() needs device arrays")
+        arr = (C.c_void_p * 3)(*(ptrs + [None] * (3 - len(ptrs))))
+        fp = None
+        if f_in is not None:
+            fp, fk, _k2 = _ptr(f_in, "f_in", self.dtype, self.cx)
+            if fk != _l.DEVICE:
+                raise ValueError("jacobian_owned() needs device arrays")
+        rc = L.fd_jacobian_owned_async(self.handle, comm.handle if comm is not None else None, f.fn, f.fctx, xp, fp,
+                                       -1.0 if relstep is None else float(relstep), -1.0 if absstep is None else float(absstep), float(dir), arr)
+        err = getattr(f, "error", None)
+        if err is not None:
+            f.error = None
+            raise err
+        _l.check(rc)
 
     def bind(self, f, x, outs, f_in=None, relstep=None, absstep=None, dir=True):
         """Validate (f, x, outs) once and return a zero-argument callable that enqueues the call on the context's

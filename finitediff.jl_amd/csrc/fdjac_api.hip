@@ -156,6 +156,8 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
+    p->fz_sharded_ok = env_int("FDJAC_FUSED_SHARDED", 1) != 0;
+    p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
     p->eps_form = env_int("FDJAC_EPS_FORM", 0);
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
@@ -649,6 +651,25 @@ static inline int call_f(const fd_plan *p, fd_f_launch f, void *fctx, void *fx, 
     return f(fctx, fx, x, nbatch, x_stride / 2, fx_stride / 2, row_begin / 2, (row_end + 1) / 2, 1, stream);
 }
 
+// the step sizes of a sharded call in separate launches (what a call does when its storing launch cannot carry the reduction):
+// this rank's GROUPS of the two-level sum (the part of x it owns), then ONE exchange -- the group sums of every rank (64 / W x 8
+// doubles each) and, for a sharded x (fd_plan_set_halo), the halo of x ride in the same launch, whose last workgroup adds the 64 group
+// sums in order and writes the step sizes (mailbox: fdjac_p2p_step); without a mailbox: halo by RCCL send / recv, in-place all-gather of
+// the group sums, k_eps_final.  Same bits as the unsharded call on every rank.
+static int eps_sharded_classic(fd_plan *p, const real_t *x_dev, double relstep, double absstep, double dir)
+{
+    int W, r;
+    eps_shard_of(p, &W, &r);
+    const int S = (kEpsGroups + W - 1) / W;
+    const int g0 = std::min(r * S, kEpsGroups), ng = std::min(S, kEpsGroups - g0);
+    int rc = launch_eps_groups(p, x_dev, g0, ng, false, relstep, absstep, dir);
+    if (!rc) {
+        Span se(p, FD_STAGE_EXCHANGE);
+        rc = eps_exchange(p, const_cast<real_t *>(x_dev), S, relstep, absstep, dir);
+    }
+    return rc;
+}
+
 // ---- the fused step: buffers (allocated on first use; every slot starts as the sentinel) ----
 static int fused_reset(fd_plan *p)
 {
@@ -707,6 +728,12 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         FD_REQUIRE(false, FD_ERR_COMM, "the previous fused step of this plan timed out (%s never arrived; FDJAC_P2P_TIMEOUT_MS): its "
                    "output holds NaNs", what == 1 ? "a block sum of the step-size reduction" : "the step sizes");
     }
+    {
+        fd_p2p *mbq = p->p2p ? p->p2p : (p->comm ? fdjac_comm_p2p(p->comm) : nullptr);
+        const int st = mbq ? fdjac_p2p_failed(mbq) : 0;
+        FD_REQUIRE(st == 0, FD_ERR_COMM, "an earlier exchange through this plan's mailbox timed out (code %d: a peer's data never arrived; "
+                   "fd_p2p_status / fd_comm_p2p_status; FDJAC_P2P_TIMEOUT_MS): step sizes and halo of that call are not to be trusted", st);
+    }
     ++p->timing_calls;
     Span total(p, FD_STAGE_TOTAL);
 
@@ -736,11 +763,27 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const int rc = ensure_diff_scratch(p);
         if (rc) return rc;
     }
-    // the fused step: the storing launch of a FD_LAZY_CAP_FUSED_EPS launcher runs the reduction itself (one launch per Jacobian)
+    // the fused step: the storing launch of a FD_LAZY_CAP_FUSED_EPS launcher runs the reduction itself (one launch per Jacobian) -- on one
+    // GPU up to fz_max_n columns; in a sharded call (mailbox attached) always: its finishers exchange the group sums and the halo too
+    fd_p2p *fz_mb = p->p2p ? p->p2p : (p->comm ? fdjac_comm_p2p(p->comm) : nullptr);
+    const bool shard_ctx = p->comm != nullptr || p->p2p != nullptr;
     bool fuse = !small && p->fdtype != FD_COMPLEX && p->C > 0 && p->C <= kRegColors && p->cyc_C > 0 && p->eps_mode == FD_EPS_COMPUTE &&
                 p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_FUSED_EPS) && store_active(p) && p->store_ok &&
                 (p->kind == K_CSC || p->kind == K_BANDED || p->kind == K_TRIDIAG) && p->nchunks == 1 && full_colors &&
-                !(p->fdtype == FD_FORWARD && fin_dev) && !p->comm && !p->p2p && p->N <= p->fz_max_n && p->d_partial != nullptr;
+                !(p->fdtype == FD_FORWARD && fin_dev) && p->d_partial != nullptr;
+    bool fuse_sharded = false;
+    int fzW = 1, fzr = 0;
+    if (fuse && shard_ctx) {
+        if (fz_mb) { fzW = fdjac_p2p_nranks(fz_mb); fzr = fdjac_p2p_rank(fz_mb); }
+        // the halo cells are polled by the lanes that own the first / last pair (quad) of the rank's columns
+        const bool halo_ok = p->halo == 0 || (p->halo == 2 && p->halo_own0 == p->col0 && p->halo_own1 == p->col1 && p->halo_own0 % 4 == 0 &&
+                                              (p->halo_own1 % 4 == 0 || fzr == fzW - 1));
+        // (ranks sharing ONE device -- tests, dry runs: a launch full of wavefronts that wait for a peer would keep the peer from running)
+        fuse = fuse_sharded = fz_mb != nullptr && fzW > 1 && p->fz_sharded_ok && eps_shardable(p) && halo_ok &&
+                              (!fdjac_p2p_shared_device(fz_mb) || p->fz_shared_ok);
+    } else if (fuse) {
+        fuse = p->N <= p->fz_max_n;
+    }
     FusedEps fz_job;
     if (fuse) {
         const int rc = ensure_fused(p);
@@ -749,7 +792,18 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         fz_job.eg.tpg = p->eps_tpg; fz_job.eg.bpg = p->eps_bpg; fz_job.eg.tpb = p->eps_tpb; fz_job.eg.final_groups = kEpsGroups;
         fz_job.eg.C = (int)p->C; fz_job.eg.is_forward = p->fdtype == FD_FORWARD ? 1 : 0;
         fz_job.eg.relstep = relstep; fz_job.eg.absstep = absstep; fz_job.eg.dir = dir;
-        fz_job.nblocks = kEpsGroups * p->eps_bpg;
+        fz_job.nranks = 1; fz_job.rank = 0; fz_job.g0 = 0; fz_job.ng = kEpsGroups;
+        if (fuse_sharded) {
+            const int S = (kEpsGroups + fzW - 1) / fzW;
+            fz_job.nranks = fzW; fz_job.rank = fzr;
+            fz_job.g0 = std::min(fzr * S, kEpsGroups); fz_job.ng = std::min(S, kEpsGroups - fz_job.g0);
+            fdjac_p2p_fused mbv;
+            const int rm = fdjac_p2p_fused_begin(fz_mb, &mbv);
+            if (rm) return rm;
+            fz_job.peer = mbv.peer; fz_job.local = mbv.local; fz_job.fz_off = mbv.fz_off; fz_job.buf = mbv.buf; fz_job.buf_reset = mbv.buf_reset;
+            if (p->halo > 0) { fz_job.xw = const_cast<real_t *>(x_dev); fz_job.own_begin = p->halo_own0; fz_job.own_end = p->halo_own1; fz_job.halo = (int)p->halo; }
+        }
+        fz_job.nblocks = fz_job.ng * p->eps_bpg;
         fz_job.cyc_C = p->cyc_C; fz_job.cyc_shift = p->cyc_shift; fz_job.pair = p->cx ? 1 : 0;
         const size_t hp = (size_t)p->n_partial_blocks * kRegColors, he = (size_t)kFzReplicas * kFzPitch;
         fz_job.part = p->d_fz_part + (p->fz_parity ? hp : 0);
@@ -757,7 +811,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         fz_job.epsr = (rbits_t *)p->d_fz_eps + (p->fz_parity ? he : 0);
         fz_job.epsr_next = (rbits_t *)p->d_fz_eps + (p->fz_parity ? 0 : he);
         fz_job.eps = p->d_eps; fz_job.eps2 = p->d_eps2;
-        fz_job.err = p->d_fz_err;
+        fz_job.err = fuse_sharded ? fdjac_p2p_err_word(fz_mb) : p->d_fz_err;
         fz_job.timeout_ticks = fused_timeout_ticks();
         fz_job.trace = p->d_fz_trace;
         if (p->d_fz_trace) {      // (diagnostic runs only: minima start at all-ones, maxima at zero)
@@ -780,20 +834,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             rc = launch_eps_perturb_small(p, x_dev, relstep, absstep, dir, small_points ? p->fdtype : -1,
                                           base_in_batch ? (int)(p->C * p->pts) : -1);
         } else if ((p->comm || p->p2p) && eps_shardable(p)) {   // (also with a single-rank communicator: same code path)
-            // sharded reduction: this rank's GROUPS of the two-level sum (the part of x it owns), then ONE exchange -- the group sums
-            // of every rank (64 / W x 8 doubles each) and, for a sharded x (fd_plan_set_halo), the halo of x ride in the same
-            // launch, whose last workgroup adds the 64 group sums in order and writes the step sizes (mailbox: fdjac_p2p_step);
-            // without a mailbox: halo by RCCL send / recv, in-place all-gather of the group sums, k_eps_final.  Same bits as the
-            // unsharded call on every rank.
-            int W, r;
-            eps_shard_of(p, &W, &r);
-            const int S = (kEpsGroups + W - 1) / W;
-            const int g0 = std::min(r * S, kEpsGroups), ng = std::min(S, kEpsGroups - g0);
-            rc = launch_eps_groups(p, x_dev, g0, ng, false, relstep, absstep, dir);
-            if (!rc) {
-                Span se(p, FD_STAGE_EXCHANGE);
-                rc = eps_exchange(p, const_cast<real_t *>(x_dev), S, relstep, absstep, dir);
-            }
+            rc = eps_sharded_classic(p, x_dev, relstep, absstep, dir);
         } else {
             rc = launch_eps(p, x_dev, relstep, absstep, dir);
         }
@@ -913,12 +954,13 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             lp.eps_job = fuse ? &fz_job : nullptr;
             int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             if (fuse && rc == 0) {
+                if (fuse_sharded) fdjac_p2p_fused_commit(fz_mb);
                 p->fz_parity ^= 1u;
                 p->eps2_fresh = p->d_eps2 != nullptr;
-            } else if (fuse) {      // (declined with the reduction attached: the library's own launch, then the plain storing launch)
+            } else if (fuse) {      // (declined with the reduction attached: the library's own launch(es), then the plain storing launch)
                 fuse = false;
                 sp.stop();
-                { Span se(p, FD_STAGE_EPS); const int re = launch_eps(p, x_dev, relstep, absstep, dir); if (re) return re; }
+                { Span se(p, FD_STAGE_EPS); const int re = fuse_sharded ? eps_sharded_classic(p, x_dev, relstep, absstep, dir) : launch_eps(p, x_dev, relstep, absstep, dir); if (re) return re; }
                 Span sp2(p, FD_STAGE_DECOMPRESS);
                 lp.eps_job = nullptr;
                 if (rc == FD_LAZY_DECLINED) rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
@@ -976,7 +1018,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (fuse) {      // (the storing launch did not happen: the hand-over path needs the step sizes first)
             fuse = false;
             Span se(p, FD_STAGE_EPS);
-            const int re = launch_eps(p, x_dev, relstep, absstep, dir);
+            const int re = fuse_sharded ? eps_sharded_classic(p, x_dev, relstep, absstep, dir) : launch_eps(p, x_dev, relstep, absstep, dir);
             if (re) return re;
         }
         { const int rc = ensure_values(p); if (rc) return rc; }      // (from here on the f! values are handed over through d_FX)
@@ -1138,6 +1180,27 @@ int fd_jacobian(fd_plan *p, fd_f_launch f, void *fctx, const void *x, int x_kind
         FD_REQUIRE(false, FD_ERR_COMM, "the fused step timed out (FDJAC_P2P_TIMEOUT_MS): the output holds NaNs");
     }
     return FD_OK;
+}
+
+// Colour ownership, assembled (fd_plan_opts.color_begin / color_end): a plan that owns a range of colours writes only the stored values
+// of its colours' columns and leaves everything else in outs untouched -- summing the ranks' outputs is an exact assembly only if
+// the untouched entries are ZERO, which is true for a fresh buffer and false from the second call on (they hold the previous sum).
+// This entry point owns the whole sequence: zero-fill, the call, ONE in-place all-reduce per output (comm = NULL: the caller sums).
+int fd_jacobian_owned_async(fd_plan *p, fd_comm *comm, fd_f_launch f, void *fctx, const void *x, const void *f_in, double relstep,
+                            double absstep, double dir, void *const *outs)
+{
+    FD_REQUIRE(p && x && outs, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(comm == nullptr || fdjac_comm_ctx(comm) == p->ctx, FD_ERR_ARG, "the communicator belongs to another context");
+    FD_REQUIRE(p->split_n == 0, FD_ERR_UNSUPPORTED, "colour ownership of a lowered complex-valued Tridiagonal plan");
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    for (int k = 0; k < p->nouts; ++k) {
+        FD_REQUIRE(outs[k] || p->out_len[k] == 0, FD_ERR_ARG, "outs[%d] is NULL", k);
+        if (p->out_len[k] > 0) FD_HIP_CHECK(hipMemsetAsync(outs[k], 0, sizeof(real_t) * (size_t)p->out_len[k], p->ctx->stream));
+    }
+    int rc = fd_jacobian_async(p, f, fctx, x, f_in, relstep, absstep, dir, outs);
+    for (int k = 0; k < p->nouts && !rc && comm; ++k)
+        if (p->out_len[k] > 0) rc = fd_comm_allreduce_sum(comm, outs[k], p->out_len[k], (int)sizeof(real_t));
+    return rc;
 }
 
 int fd_plan_set_lazy_f(fd_plan *p, fd_f_launch_lazy lazy)

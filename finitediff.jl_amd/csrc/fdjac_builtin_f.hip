@@ -273,7 +273,7 @@ k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ 
 // 1 .. nblocks are its reduction workgroups (fdjac_eps_dev.h), everything after that stores: the wavefronts of k_f_tridiag_store_wave,
 // which load their x, then wait for the step sizes of their colours to be published.  Same operations per value as the two-launch
 // form: same bits.  N = 10^6: one launch instead of two, and a hand-off of two memory round trips instead of six.
-template <int MODE, bool NL, int NC>
+template <int MODE, bool NL, int NC, bool PIPE>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, int64_t jstart, FusedEps fz)
 {
@@ -285,7 +285,7 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
     double *s_red = reinterpret_cast<double *>(s_lds);
     const int b = (int)blockIdx.x, nfin = fz.eg.C;
     if (b < nfin) { fused_finisher(fz, b, s_red); return; }
-    if (b < nfin + fz.nblocks) { fused_eps_block<NC>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
+    if (b < nfin + fz.nblocks) { fused_eps_block<NC, PIPE>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
     // a storing workgroup: its wavefronts walk the 128-column tiles gw, gw + stride, ... (the launcher keeps the whole grid resident,
     // so nobody is dispatched after the step sizes are out); the first tile's x is in flight while the workgroup waits
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -295,7 +295,15 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
     int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
     int64_t jw = jstart + gw * 128, j = jw + 2 * lane;
     r2_t Cc = {0, 0}, L = {0, 0}, R = {0, 0};
-    if (gw < nwaves) { Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n); }
+    // (a sharded x: the two lanes at the edges of the rank's columns take the neighbours' halo from the mailbox cells)
+    auto load_x = [&]() {
+        Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n);
+        if (fz.xw && fz.nranks > 1) {
+            if (j == fz.own_begin && fz.rank > 0) { L.x = fused_halo(fz, 0, 0); L.y = fused_halo(fz, 0, 1); }
+            if (j + 2 == fz.own_end && fz.rank + 1 < fz.nranks) { R.x = fused_halo(fz, 1, 0); R.y = fused_halo(fz, 1, 1); }
+        }
+    };
+    if (gw < nwaves) load_x();
     real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
@@ -309,7 +317,7 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
         if (gw + gstride < nwaves) {
             jw = jstart + (gw + gstride) * 128;
             j = jw + 2 * lane;
-            Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n);
+            load_x();
         }
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
@@ -372,7 +380,7 @@ k_f_tridiag_store_wave4(const real_t *__restrict__ x, const real_t *__restrict__
     fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
 }
 // the fused step (k_f_tridiag_fused), four columns per lane
-template <int MODE, bool NL, int NC>
+template <int MODE, bool NL, int NC, bool PIPE>
 __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, int64_t jstart, FusedEps fz)
 {
@@ -383,7 +391,7 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
     double *s_red = reinterpret_cast<double *>(s_lds);
     const int b = (int)blockIdx.x, nfin = fz.eg.C;
     if (b < nfin) { fused_finisher(fz, b, s_red); return; }
-    if (b < nfin + fz.nblocks) { fused_eps_block<NC>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
+    if (b < nfin + fz.nblocks) { fused_eps_block<NC, PIPE>(x, n, fz, b - nfin, reinterpret_cast<double (*)[NC]>(s_red)); return; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = b - nfin - fz.nblocks;
     const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
@@ -391,7 +399,14 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
     int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
     int64_t jw = jstart + gw * 256, j = jw + 4 * lane;
     r4_t Cc = {0, 0, 0, 0}, L = {0, 0, 0, 0}, R = {0, 0, 0, 0};
-    if (gw < nwaves) { Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n); }
+    auto load_x = [&]() {
+        Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n);
+        if (fz.xw && fz.nranks > 1) {
+            if (j == fz.own_begin && fz.rank > 0) { L.z = fused_halo(fz, 0, 0); L.w = fused_halo(fz, 0, 1); }
+            if (j + 4 == fz.own_end && fz.rank + 1 < fz.nranks) { R.x = fused_halo(fz, 1, 0); R.y = fused_halo(fz, 1, 1); }
+        }
+    };
+    if (gw < nwaves) load_x();
     real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
@@ -407,7 +422,7 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
         if (gw + gstride < nwaves) {
             jw = jstart + (gw + gstride) * 256;
             j = jw + 4 * lane;
-            Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n);
+            load_x();
         }
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
@@ -912,14 +927,14 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
             if (lp->eps_job) {
                 const FusedEps fz = *(const FusedEps *)lp->eps_job;
                 const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
+#define FD_LAZY_FZ4P(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, NCC, PP>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
 #define FD_LAZY_FZ4(MODE, NL)                                                                                                              \
-                do { if (fz.eg.C <= 4) hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, 4>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, \
-                                                          b->prm[0], bst, jstart, fz);                                                    \
-                     else hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, kRegColors>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x,    \
-                                             b->prm[0], bst, jstart, fz); } while (0)
+                do { if (fz.eg.C <= 4) { if (fz.eg.tpb > 2) FD_LAZY_FZ4P(MODE, NL, 4, true); else FD_LAZY_FZ4P(MODE, NL, 4, false); }               \
+                     else { if (fz.eg.tpb > 2) FD_LAZY_FZ4P(MODE, NL, kRegColors, true); else FD_LAZY_FZ4P(MODE, NL, kRegColors, false); } } while (0)
                 if (mode == 0) { if (nl) FD_LAZY_FZ4(0, true); else FD_LAZY_FZ4(0, false); }
                 else { if (nl) FD_LAZY_FZ4(1, true); else FD_LAZY_FZ4(1, false); }
 #undef FD_LAZY_FZ4
+#undef FD_LAZY_FZ4P
                 return hipGetLastError() == hipSuccess ? 0 : 4;
             }
 #define FD_LAZY_SW4(MODE, NL)                                                                                      \
@@ -939,14 +954,14 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
                 // the fused step: this launch also runs the step-size reduction (finisher + reduction workgroups first, see k_f_tridiag_fused)
                 const FusedEps fz = *(const FusedEps *)lp->eps_job;
                 const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
+#define FD_LAZY_FZP(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, NCC, PP>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
 #define FD_LAZY_FZ(MODE, NL)                                                                                                              \
-                do { if (fz.eg.C <= 4) hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, 4>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, \
-                                                          b->prm[0], bst, jstart, fz);                                                    \
-                     else hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, kRegColors>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x,    \
-                                             b->prm[0], bst, jstart, fz); } while (0)
+                do { if (fz.eg.C <= 4) { if (fz.eg.tpb > 2) FD_LAZY_FZP(MODE, NL, 4, true); else FD_LAZY_FZP(MODE, NL, 4, false); }               \
+                     else { if (fz.eg.tpb > 2) FD_LAZY_FZP(MODE, NL, kRegColors, true); else FD_LAZY_FZP(MODE, NL, kRegColors, false); } } while (0)
                 if (mode == 0) { if (nl) FD_LAZY_FZ(0, true); else FD_LAZY_FZ(0, false); }
                 else { if (nl) FD_LAZY_FZ(1, true); else FD_LAZY_FZ(1, false); }
 #undef FD_LAZY_FZ
+#undef FD_LAZY_FZP
                 return hipGetLastError() == hipSuccess ? 0 : 4;
             }
 #define FD_LAZY_SW(MODE, NL)                                                                                       \

@@ -11,6 +11,12 @@
 // (nobody reads them any more: call k - 1 has completed on the stream).  The ORDER in which values are added is the reduction's
 // definition (k_eps_partial_reg) and does not change: same bits.
 //
+// The SHARDED step (one process per GPU) is the same launch: a rank reduces its own groups, its finishers store the group sums straight
+// into every peer's mailbox cells (system-scope stores over xGMI) and poll their own mailbox for the peers' -- again every cell its own
+// flag, THREE buffers by epoch: a rank resets, in step e, its cells of step e + 2; a peer can be at most one step ahead (it cannot
+// finish e + 1 without this rank's e + 1 sums), so it writes buffers e and e + 1 only, and it starts e + 2 only after this rank's
+// launch e + 1 -- hence after launch e with its resets -- has completed.  The halo of a sharded x travels the same way.
+//
 // Progress: reduction workgroups and the finisher occupy the LOWEST block indices of the launch and never wait for a storing
 // wavefront; storing wavefronts wait only for the finisher.  Workgroups are dispatched in index order, so everything a waiting
 // wavefront depends on is resident or done; every wait is bounded by a wall-clock timeout that raises the plan's error word
@@ -53,7 +59,7 @@ struct EpsGrid {
 
 // Level 0 for workgroup `gblock` of the global grid: per-thread accumulation over the block's tiles, the fixed 64-lane shuffle tree,
 // the 4 waves in order.  Returns true on wave 0 only; there lane c < NC holds the block's sum of colour c in `s`.
-template <typename CT, int NC, bool CYC, bool NT>
+template <typename CT, int NC, bool CYC, bool NT, bool PIPE = true>
 __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, const CT *__restrict__ color, int64_t n, int cyc_C, int cyc_shift,
                                               int gblock, const EpsGrid &eg, int pair, double (*red)[NC], double &s)
 {
@@ -76,9 +82,9 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
         rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C);
         du = (kBlock * 2) % cyc_C;
     }
-    for (int64_t base = base0; base < base_end; base += tile) {
-        r2_t v[kEpsU];
-        int c0[kEpsU], c1[kEpsU];
+    // (software-pipelined: the loads of tile k + 1 are in flight while tile k is accumulated -- a block of a sharded reduction walks
+    //  up to 5 tiles, and one tile's 16 KB per workgroup in flight left the pass latency-bound; the ORDER of the additions is untouched)
+    auto load_tile = [&](int64_t base, r2_t (&v)[kEpsU], int (&c0)[kEpsU], int (&c1)[kEpsU]) {
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
             const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
@@ -101,6 +107,10 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
                 c0[u] = c1[u] = -2;
             }
         }
+    };
+    r2_t va[kEpsU], vb[kEpsU];
+    int a0[kEpsU], a1[kEpsU], b0[kEpsU], b1[kEpsU];
+    auto accumulate = [&](const r2_t (&v)[kEpsU], int (&c0)[kEpsU], int (&c1)[kEpsU]) {
 #pragma unroll
         for (int u = 0; u < kEpsU; ++u) {
             if (pair) c1[u] = c0[u];     // complex-valued x: (re, im) of one coloured element -- |x_j|^2 = re^2 + im^2
@@ -111,6 +121,22 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
                 acc[c] += (c1[u] == c) ? s1 : 0.0;
             }
         }
+    };
+    if (!PIPE) {      // (one tile in flight: 32 registers fewer -- the fused single-GPU step, whose blocks have one or two tiles)
+        for (int64_t base = base0; base < base_end; base += tile) {
+            load_tile(base, va, a0, a1);
+            accumulate(va, a0, a1);
+        }
+    } else {
+    if (base0 < base_end) load_tile(base0, va, a0, a1);
+    for (int64_t base = base0; base < base_end; base += 2 * tile) {
+        const bool more1 = base + tile < base_end;
+        if (more1) load_tile(base + tile, vb, b0, b1);
+        accumulate(va, a0, a1);
+        if (!more1) break;
+        if (base + 2 * tile < base_end) load_tile(base + 2 * tile, va, a0, a1);
+        accumulate(vb, b0, b1);
+    }
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,19 +158,17 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
 // ---------------------------------------------------------------------------------------------------------------------------------
 // the fused step
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr unsigned long long kFzSentinel64 = 0x7FF85EEDFD1AC0DEull;   // quiet NaNs with a payload: never the result of arithmetic on
-constexpr unsigned kFzSentinel32 = 0x7FC5EED1u;                       //   ordinary inputs (an input NaN of exactly this payload: timeout)
 constexpr int kFzReplicas = 64;      // the step sizes are published in this many places (one 256-B line each for Float64) so that the
 constexpr int kFzPitch = 32;         //   polling wavefronts do not all hammer one memory channel
 
 template <typename T> struct FzBits;
 template <> struct FzBits<double> {
     typedef unsigned long long u_t;
-    static constexpr u_t sentinel = kFzSentinel64;
+    static constexpr u_t sentinel = kFzSentinel64, halo_sentinel = kFzSentinelHalo64;
 };
 template <> struct FzBits<float> {
     typedef unsigned u_t;
-    static constexpr u_t sentinel = kFzSentinel32;
+    static constexpr u_t sentinel = kFzSentinel32, halo_sentinel = kFzSentinel32;
 };
 typedef FzBits<real_t>::u_t rbits_t;
 __device__ __forceinline__ real_t fz_from_bits(rbits_t b)
@@ -170,7 +194,18 @@ struct FusedEps {
     int *err;                        // the plan's error word (pinned host memory)
     long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
     long long *trace;                // NULL, or 16 words of wall_clock64 marks (fd_plan_fused_trace: where a launch's time goes)
+    // the SHARDED step (nranks > 1): this launch reduces the groups [g0, g0 + ng) of rank `rank`; their sums go straight into the peers'
+    // mailboxes and the peers' arrive in this rank's (cells of buffer `buf`, every one its own flag); the halo of a sharded x likewise
+    int nranks, rank, g0, ng;
+    char *const *peer;               // the peers' mailboxes as mapped here
+    char *local;                     // this rank's mailbox
+    long long fz_off;                // the fused step's cells inside a mailbox
+    int buf, buf_reset;              // this step's buffer; the one it resets for the step after next (-1: loop-back, none)
+    real_t *xw;                      // NULL, or x: sharded -- the halo cells [own_begin - halo, own_begin), [own_end, own_end + halo) arrive with the launch
+    long long own_begin, own_end;
+    int halo;
 };
+__device__ __forceinline__ char *fz_cells(char *mailbox, const FusedEps &fz, int buf) { return mailbox + fz.fz_off + (long long)buf * kFzBufBytes; }
 // trace slots: 0 first reduction workgroup starts (min), 1 last block sum published (max), 2 finisher starts, 3 finisher has every block
 // sum, 4 step sizes published, 5 first storing workgroup starts (min), 6 / 7 first / last storing workgroup has the step sizes, 8 last
 // storing wavefront done (max), 9 last storing workgroup starts (max)
@@ -185,12 +220,13 @@ __device__ __forceinline__ void fz_mark_max(const FusedEps &fz, int k)
 
 // a reduction workgroup of the fused step: level 0, published value by value (colour-major: the finisher of colour c reads
 // part[c][0 .. nblocks) with dense loads)
-template <int NC>
+template <int NC, bool PIPE>
 __device__ __forceinline__ void fused_eps_block(const real_t *__restrict__ x, int64_t n, const FusedEps &fz, int gblock, double (*red)[NC])
 {
     double s;
     if (threadIdx.x == 0) fz_mark_min(fz, 0);
-    if (!eps_block_sum<uint8_t, NC, true, false>(x, nullptr, n, fz.cyc_C, fz.cyc_shift, gblock, fz.eg, fz.pair, red, s)) return;
+    // (gblock counts this launch's reduction workgroups; the block of the GLOBAL grid it reduces starts at the rank's first group)
+    if (!eps_block_sum<uint8_t, NC, true, false, PIPE>(x, nullptr, n, fz.cyc_C, fz.cyc_shift, fz.g0 * fz.eg.bpg + gblock, fz.eg, fz.pair, red, s)) return;
     const int lane = threadIdx.x & 63;
     if (lane < fz.eg.C) __hip_atomic_store(fz.part + (int64_t)lane * fz.nblocks + gblock, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fz_mark_max(fz, 1);
@@ -205,27 +241,36 @@ constexpr int kFzMaxBlocks = kEpsGroups * kEpsBlocksPerGroup;      // 1024
 __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double *lds)
 {
     const int t = threadIdx.x, nb = fz.nblocks, bpg = fz.eg.bpg;
+    const bool sharded = fz.nranks > 1;
+    // a sharded x: this rank's boundary elements into the neighbours' halo cells, first thing (finisher 0, threads 64 ..)
+    if (sharded && c == 0 && fz.xw && t >= 64 && t < 64 + 2 * fz.halo) {
+        const int h = (t - 64) % fz.halo, up = (t - 64) / fz.halo;      // up: to rank + 1 (my last elements = its lower halo); else to rank - 1
+        const int target = up ? fz.rank + 1 : fz.rank - 1;
+        if (target >= 0 && target < fz.nranks) {
+            const real_t v = up ? fz.xw[fz.own_end - fz.halo + h] : fz.xw[fz.own_begin + h];
+            rbits_t *cell = reinterpret_cast<rbits_t *>(fz_cells(fz.peer[target], fz, fz.buf) + kFzGsumBytes + (up ? 0 : kFzHaloBytes)) + h;
+            __hip_atomic_store(cell, fz_to_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(fz.part + (int64_t)c * nb);
     constexpr int M = kFzMaxBlocks / kBlock;       // 4
     unsigned long long v[M];
     int ok = 1;
     if (t == 0) fz_mark_max(fz, 2);
-    {
-        const long long t0 = wall_clock64();
-        for (;;) {
-            bool all = true;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool all = true;
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                v[m] = 0;
-                if (t + m * kBlock < nb) {
-                    v[m] = __hip_atomic_load(src + t + m * kBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    all = all && v[m] != kFzSentinel64;
-                }
+        for (int m = 0; m < M; ++m) {
+            v[m] = 0;
+            if (t + m * kBlock < nb) {
+                v[m] = __hip_atomic_load(src + t + m * kBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && v[m] != kFzSentinel64;
             }
-            if (all) break;
-            if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
         }
+        if (all) break;
+        if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m)
@@ -234,13 +279,32 @@ __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double
     if (t == 0) s_bad = 0;
     __syncthreads();
     if (t == 0) fz_mark_max(fz, 3);
-    if (!ok) s_bad = 1;
     double *gs = lds + kFzMaxBlocks;
     if (t < kEpsGroups) {
         double g = 0.0;
-        for (int k = 0; k < bpg; ++k) g += lds[t * bpg + k];
+        if (t >= fz.g0 && t < fz.g0 + fz.ng) {
+            // level 1 of an own group; a sharded step stores it into every peer's cell (t, c) of this step's buffer
+            for (int k = 0; k < bpg; ++k) g += lds[(t - fz.g0) * bpg + k];
+            if (sharded)
+                for (int b = 0; b < fz.nranks; ++b)
+                    if (b != fz.rank)
+                        __hip_atomic_store(reinterpret_cast<double *>(fz_cells(fz.peer[b], fz, fz.buf)) + t * kRegColors + c, g, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            // a peer's group: its owner stores the sum into this rank's cell (t, c)
+            const unsigned long long *cell = reinterpret_cast<const unsigned long long *>(fz_cells(fz.local, fz, fz.buf)) + t * kRegColors + c;
+            unsigned long long w;
+            for (;;) {
+                w = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w != kFzSentinel64) break;
+                if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            g = __longlong_as_double((long long)w);
+        }
         gs[t] = g;
     }
+    if (!ok) s_bad = 1;
     __syncthreads();
     const bool bad = s_bad != 0;
     real_t *s_e = reinterpret_cast<real_t *>(gs + kEpsGroups);
@@ -263,6 +327,35 @@ __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double
     if (t == 0) fz_mark_max(fz, 4);
     unsigned long long *pn = reinterpret_cast<unsigned long long *>(fz.part_next + (int64_t)c * nb);
     for (int i = t; i < nb; i += kBlock) __hip_atomic_store(pn + i, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this rank's cells of the step after next (nobody writes them before this launch is over: see the header)
+    if (sharded && fz.buf_reset >= 0) {
+        unsigned long long *cells = reinterpret_cast<unsigned long long *>(fz_cells(fz.local, fz, fz.buf_reset));
+        if (t < kEpsGroups) __hip_atomic_store(cells + t * kRegColors + c, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c == 0 && t >= 64 && t < 64 + (int)(2 * kFzHaloBytes / 8))
+            __hip_atomic_store(cells + kFzGsumBytes / 8 + (t - 64), kFzSentinelHalo64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the halo of a sharded x as a storing wavefront at the edge of the rank's columns gets it: element h of the lower (which = 0) / upper
+// (1) halo, polled from this rank's own cell (the neighbour's finisher stores it there) and written into x as fd_plan_set_halo promises
+__device__ __forceinline__ real_t fused_halo(const FusedEps &fz, int which, int h)
+{
+    const rbits_t *cell = reinterpret_cast<const rbits_t *>(fz_cells(fz.local, fz, fz.buf) + kFzGsumBytes + (which ? kFzHaloBytes : 0)) + h;
+    const long long t0 = wall_clock64();
+    rbits_t b;
+    for (;;) {
+        b = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (b != FzBits<real_t>::halo_sentinel) break;
+        if (wall_clock64() - t0 > fz.timeout_ticks) {
+            __hip_atomic_store(fz.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            b = FzBits<real_t>::sentinel ^ 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const real_t v = fz_from_bits(b);
+    fz.xw[which ? fz.own_end + h : fz.own_begin - fz.halo + h] = v;
+    return v;
 }
 
 // a storing workgroup's wait for the step sizes: ONE wavefront polls (lane c its colour's slot of the workgroup's replica) and parks

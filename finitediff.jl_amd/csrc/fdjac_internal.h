@@ -30,6 +30,7 @@
 #define fd_plan_info fd32_plan_info
 #define fd_jacobian fd32_jacobian
 #define fd_jacobian_async fd32_jacobian_async
+#define fd_jacobian_owned_async fd32_jacobian_owned_async
 #define fd_plan_set_lazy_f fd32_plan_set_lazy_f
 #define fd_plan_set_lazy_caps fd32_plan_set_lazy_caps
 #define fd_plan_get_epsilons fd32_plan_get_epsilons
@@ -98,6 +99,29 @@ struct fdjac_eps_final {
 // FD_ERR_UNSUPPORTED (nothing enqueued) when the payload does not fit the mailbox slot.
 extern "C" int fdjac_p2p_step(fd_p2p *p, void *x, int64_t own_begin, int64_t own_end, int64_t halo, int elem_bytes, double *gsum,
                               int64_t slot_bytes, const fdjac_eps_final *fin);
+
+// the fused step's cells in a mailbox (csrc/fdjac_eps_dev.h, fdjac_p2p.hip): a cell holds a sentinel until its ONE writer stores the
+// value; three buffers by epoch, each [64 groups x 8 colours group sums][lower halo][upper halo]
+constexpr int kFzBufs = 3;
+constexpr int64_t kFzGsumBytes = 64 * 8 * 8, kFzHaloBytes = 64, kFzBufBytes = kFzGsumBytes + 2 * kFzHaloBytes;
+constexpr unsigned long long kFzSentinel64 = 0x7FF85EEDFD1AC0DEull;   // quiet NaNs with a payload: never the result of arithmetic on
+constexpr unsigned kFzSentinel32 = 0x7FC5EED1u;                       //   ordinary inputs (an input NaN of exactly this payload: timeout)
+constexpr unsigned long long kFzSentinelHalo64 = 0x7FC5EED17FC5EED1ull;      // halo cells: two Float32 sentinels = the Float64 halo sentinel
+
+// the mailbox as the fused step of a sharded call sees it (fdjac_p2p_fused_begin advances the mailbox's epoch)
+struct fdjac_p2p_fused {
+    char *const *peer;       // device array of the peers' mailbox bases
+    char *local;             // this rank's mailbox
+    int64_t fz_off;          // offset of the fused step's cells in a mailbox
+    int buf, buf_reset;      // this step's buffer; the buffer it resets (-1: loop-back, none)
+    int *err;
+    int nranks, rank;
+};
+extern "C" int fdjac_p2p_fused_begin(fd_p2p *p, fdjac_p2p_fused *out);      // (the step's buffer; the epoch advances with fdjac_p2p_fused_commit)
+extern "C" void fdjac_p2p_fused_commit(fd_p2p *p);
+extern "C" int fdjac_p2p_shared_device(const fd_p2p *p);      // 1: some peer lives on this rank's device (no fused sharded step then)
+extern "C" int fdjac_p2p_failed(const fd_p2p *p);
+extern "C" int *fdjac_p2p_err_word(const fd_p2p *p);    // (device address)       // the mailbox's sticky error word (a wait timed out)
 
 // error text: one thread-local buffer for both instantiations (defined by the Float64 build)
 extern "C" void fdjac_set_error_v(const char *fmt, va_list ap);
@@ -382,6 +406,8 @@ struct fd_plan {
     unsigned fz_parity = 0;
     long long *d_fz_trace = nullptr;          // FDJAC_FUSED_TRACE=1: wall_clock64 marks of the last fused launch (fd_plan_fused_trace)
     int eps_form = 0;                         // the library's own reduction: 0 = all levels in one launch, 1 = levels 0 + 1, then k_eps_final (same bits)
+    bool fz_sharded_ok = true;                // sharded calls with a mailbox take the fused step (FDJAC_FUSED_SHARDED=0: the three-launch form)
+    bool fz_shared_ok = false;                //   ... even when ranks share this device (FDJAC_FUSED_SHARED=1: small test problems only)
     int64_t fz_max_n = (int64_t)1 << 21;      // single GPU: problems up to this size take the fused step (FDJAC_FUSED_MAX_N; 0 = never)
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x
     fd_p2p *p2p = nullptr;         //   ... its group sums (and the halo of x) travel through this mailbox in ONE launch (fd_plan_set_p2p, or the

@@ -23,13 +23,44 @@
 #include "fdjac_internal.h"
 
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #ifndef FDJAC_F32   /* element-type independent: compiled once */
 
 constexpr int kP2PMaxRanks = 64;
 constexpr int64_t kP2PFlagStride = 128;      // one line per sender
+// Fine-grained ("uncached") device allocations are never handed back to the runtime's allocator: on ROCm 7.0 / MI355X memory that was
+// once allocated with hipDeviceMallocUncached, freed and then recycled into ORDINARY allocations misbehaved -- kernels reading freshly
+// uploaded arrays there saw other data (plan builds failing their consistency checks, wrong group sums; gone with FDJAC_P2P_UNCACHED=0 --
+// profiles/NOTES.md, round 6).  A mailbox that is destroyed parks its block here and the next mailbox of that size takes it.
+static std::mutex g_unc_mutex;
+static std::vector<std::pair<size_t, void *>> g_unc_pool;
+static void *unc_take(size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_unc_mutex);
+    for (size_t k = 0; k < g_unc_pool.size(); ++k)
+        if (g_unc_pool[k].first == bytes) {
+            void *m = g_unc_pool[k].second;
+            g_unc_pool.erase(g_unc_pool.begin() + (ptrdiff_t)k);
+            return m;
+        }
+    return nullptr;
+}
+static void unc_park(size_t bytes, void *mem)
+{
+    std::lock_guard<std::mutex> lock(g_unc_mutex);
+    g_unc_pool.emplace_back(bytes, mem);
+}
+
+static void fz_region_image(std::vector<unsigned long long> &img)
+{
+    img.assign((size_t)(kFzBufs * kFzBufBytes / 8), kFzSentinel64);
+    for (int q = 0; q < kFzBufs; ++q)
+        for (int64_t k = kFzGsumBytes / 8; k < kFzBufBytes / 8; ++k) img[(size_t)(q * kFzBufBytes / 8 + k)] = kFzSentinelHalo64;
+}
 
 struct fd_p2p {
     fd_ctx *ctx = nullptr;
@@ -49,6 +80,12 @@ struct fd_p2p {
     bool connected = false;
     bool uncached = false;
     char *sink = nullptr;                     // loop-back mailbox (fd_p2p_create_loopback): what every peer's mailbox is mapped to
+    int64_t fz_off = 0;                       // the FUSED step's region of a mailbox (after the two channels): kFzBufs buffers of
+                                              // [64 groups x 8 colours group sums][lower halo][upper halo], every cell its own flag
+    uint64_t fz_epoch = 0;                    // fused steps enqueued so far (buffer = epoch mod 3)
+    size_t local_bytes = 0;                   // size of `local` (an uncached block goes back to the pool, not to the allocator)
+    bool shared_device = false;               // some peer's mailbox lies on THIS device (ranks sharing a GPU: tests, dry runs) -- a launch that
+                                              // fills the device with wavefronts waiting for a peer would keep that peer from running
 };
 
 namespace fdjac {
@@ -309,14 +346,19 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     p->nranks = nranks;
     p->rank = rank;
     p->slot_bytes = (slot_bytes + 127) / 128 * 128;
-    const size_t bytes = 2 * ((size_t)nranks * kP2PFlagStride + 2 * (size_t)nranks * (size_t)p->slot_bytes);      // two channels
+    p->fz_off = 2 * ((int64_t)nranks * kP2PFlagStride + 2 * (int64_t)nranks * p->slot_bytes);                     // two channels,
+    const size_t bytes = (size_t)p->fz_off + (size_t)(kFzBufs * kFzBufBytes);                                           // then the fused step's cells
     // fine-grained (uncached) device memory if the runtime shares it between processes, else plain device memory (all accesses to the
     // mailbox are system-scope atomics either way)
     void *mem = nullptr;
-    if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
+    const char *unc = getenv("FDJAC_P2P_UNCACHED");
+    p->local_bytes = bytes;
+    if (!(unc && *unc == '0') && (mem = unc_take(bytes)) != nullptr) {
+        p->uncached = true;
+    } else if (!(unc && *unc == '0') && hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
         hipIpcMemHandle_t probe;
         if (hipIpcGetMemHandle(&probe, mem) == hipSuccess) p->uncached = true;
-        else { (void)hipFree(mem); mem = nullptr; }
+        else { unc_park(bytes, mem); mem = nullptr; }
     }
     (void)hipGetLastError();
     if (!mem) {
@@ -326,6 +368,11 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     p->local = (char *)mem;
     p->peer[rank] = p->local;
     hipError_t e = hipMemset(p->local, 0, bytes);       // (blocking, on the null stream: complete before the handle is published)
+    if (e == hipSuccess) {
+        std::vector<unsigned long long> img;
+        fz_region_image(img);
+        e = hipMemcpy(p->local + p->fz_off, img.data(), img.size() * 8, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_err, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *p->h_err = 0; e = hipHostGetDevicePointer((void **)&p->d_err, p->h_err, 0); }
@@ -337,7 +384,7 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
         if (p->h_err) (void)hipHostFree(p->h_err);
         if (p->d_peer) (void)hipFree(p->d_peer);
         if (p->d_arrived) (void)hipFree(p->d_arrived);
-        (void)hipFree(p->local);
+        if (p->uncached) unc_park(p->local_bytes, p->local); else (void)hipFree(p->local);
         delete p;
         return FD_ERR_HIP;
     }
@@ -378,6 +425,9 @@ int fd_p2p_connect(fd_p2p *p, const void *handles)
         }
         p->peer[r] = (char *)ptr;
         p->mapped[r] = true;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.device == p->ctx->device) p->shared_device = true;
+        (void)hipGetLastError();
     }
     FD_HIP_CHECK(hipMemcpy(p->d_peer, p->peer, sizeof(char *) * kP2PMaxRanks, hipMemcpyHostToDevice));
     p->connected = true;
@@ -394,8 +444,8 @@ int fd_p2p_create_loopback(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes
     if (rc) return rc;
     fd_p2p *p = *out;
     const size_t chan = (size_t)nranks * kP2PFlagStride + 2 * (size_t)nranks * (size_t)p->slot_bytes;
-    hipError_t e = hipMalloc((void **)&p->sink, 2 * chan);
-    if (e == hipSuccess) e = hipMemset(p->sink, 0, 2 * chan);
+    hipError_t e = hipMalloc((void **)&p->sink, 2 * chan + (size_t)(kFzBufs * kFzBufBytes));
+    if (e == hipSuccess) e = hipMemset(p->sink, 0, 2 * chan + (size_t)(kFzBufs * kFzBufBytes));
     std::vector<unsigned long long> flags((size_t)nranks * (kP2PFlagStride / 8), ~0ull);
     for (int ch = 0; ch < 2 && e == hipSuccess; ++ch)
         e = hipMemcpy(p->local + ch * chan, flags.data(), flags.size() * 8, hipMemcpyHostToDevice);
@@ -430,6 +480,24 @@ int fd_p2p_loopback_fill(fd_p2p *p, int sender, int64_t offset, const void *data
     return FD_OK;
 }
 
+// the same for the FUSED step's cells: all 64 x 8 group sums (the rank's own groups are ignored) and the two halos as the lower /
+// upper neighbour would deliver them (halo_bytes each, <= 64; NULL: none), into all three buffers -- which a loop-back step never resets
+int fd_p2p_loopback_fill_fused(fd_p2p *p, const void *gsum64x8, const void *halo_lo, const void *halo_hi, int64_t halo_bytes)
+{
+    FD_REQUIRE(p && p->sink && gsum64x8, FD_ERR_ARG, "not a loop-back mailbox / NULL argument");
+    FD_REQUIRE(halo_bytes >= 0 && halo_bytes <= kFzHaloBytes, FD_ERR_ARG, "halo of %lld bytes (at most %lld)", (long long)halo_bytes, (long long)kFzHaloBytes);
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    for (int q = 0; q < kFzBufs; ++q) {
+        char *b = p->local + p->fz_off + q * kFzBufBytes;
+        FD_HIP_CHECK(hipMemcpy(b, gsum64x8, (size_t)kFzGsumBytes, hipMemcpyDefault));
+        if (halo_lo && halo_bytes) FD_HIP_CHECK(hipMemcpy(b + kFzGsumBytes, halo_lo, (size_t)halo_bytes, hipMemcpyDefault));
+        if (halo_hi && halo_bytes) FD_HIP_CHECK(hipMemcpy(b + kFzGsumBytes + kFzHaloBytes, halo_hi, (size_t)halo_bytes, hipMemcpyDefault));
+    }
+    FD_HIP_CHECK(hipDeviceSynchronize());
+    return FD_OK;
+}
+
 int fd_p2p_destroy(fd_p2p *p)
 {
     if (!p) return FD_OK;
@@ -441,7 +509,7 @@ int fd_p2p_destroy(fd_p2p *p)
     if (p->d_peer) (void)hipFree(p->d_peer);
     if (p->d_arrived) (void)hipFree(p->d_arrived);
     if (p->h_err) (void)hipHostFree(p->h_err);
-    if (p->local) (void)hipFree(p->local);
+    if (p->local) { if (p->uncached) unc_park(p->local_bytes, p->local); else (void)hipFree(p->local); }
     delete p;
     return FD_OK;
 }
@@ -555,6 +623,27 @@ extern "C" int fdjac_p2p_step(fd_p2p *p, void *x, int64_t own_begin, int64_t own
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }
+
+// the fused step of a sharded call (csrc/fdjac_eps_dev.h) takes its next buffer here: everything the launch needs to know of the mailbox
+extern "C" int fdjac_p2p_fused_begin(fd_p2p *p, fdjac_p2p_fused *out)
+{
+    FD_REQUIRE(p && out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(p->connected, FD_ERR_COMM, "fd_p2p_connect has not been called");
+    const uint64_t e = p->fz_epoch;
+    out->peer = p->d_peer;
+    out->local = p->local;
+    out->fz_off = p->fz_off;
+    out->buf = (int)(e % kFzBufs);
+    out->buf_reset = p->sink ? -1 : (int)((e + 2) % kFzBufs);
+    out->err = p->d_err;
+    out->nranks = p->nranks;
+    out->rank = p->rank;
+    return FD_OK;
+}
+extern "C" void fdjac_p2p_fused_commit(fd_p2p *p) { if (p) ++p->fz_epoch; }
+extern "C" int fdjac_p2p_shared_device(const fd_p2p *p) { return (p && p->shared_device) ? 1 : 0; }
+extern "C" int *fdjac_p2p_err_word(const fd_p2p *p) { return p ? p->d_err : nullptr; }
+extern "C" int fdjac_p2p_failed(const fd_p2p *p) { return (p && p->h_err) ? *(volatile int *)p->h_err : 0; }
 
 // internals for fdjac_comm.hip (a communicator with an attached mailbox routes its small messages here)
 extern "C" int64_t fdjac_p2p_slot_bytes(const fd_p2p *p) { return p ? p->slot_bytes : 0; }

@@ -63,7 +63,7 @@ EXPORTS = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
     "fd_plan_create_bandedblockbanded", "fd_plan_destroy",
-    "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride",
+    "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_jacobian_owned_async", "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride",
     "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy", "fd_builtin_f_counts", "fd_builtin_f_info",
     "fd_stream_copy_gbps", "fd_plan_set_lazy_f", "fd_builtin_f_lazy", "fd_plan_set_lazy_caps", "fd_builtin_f_lazy_caps",
     "fd_jvp_plan_create", "fd_jvp_plan_destroy", "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon",
@@ -71,7 +71,7 @@ EXPORTS = (
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
     "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
-    "fd_p2p_create", "fd_p2p_create_loopback", "fd_p2p_loopback_fill", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
+    "fd_p2p_create", "fd_p2p_create_loopback", "fd_p2p_loopback_fill", "fd_p2p_loopback_fill_fused", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
     "fd_tridiag_solver_create", "fd_tridiag_solver_destroy", "fd_tridiag_solve_async", "fd_tridiag_solve_interface",
@@ -84,7 +84,7 @@ EXPORTS = (
 TYPED = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
-    "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
+    "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_jacobian_owned_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
     "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_info", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
@@ -186,6 +186,7 @@ def load():
     L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]
     L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
     L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
+    L.fd_jacobian_owned_async.argtypes = [vp, vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
     L.fd_plan_get_epsilons.argtypes = [vp, C.POINTER(dbl)]
     L.fd_plan_fused_trace.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.fd_plan_enable_timing.argtypes = [vp, i32]
@@ -233,6 +234,7 @@ def load():
     L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
     L.fd_p2p_create_loopback.argtypes = [vp, i32, i32, i64, pp]
     L.fd_p2p_loopback_fill.argtypes = [vp, i32, i64, vp, i64]
+    L.fd_p2p_loopback_fill_fused.argtypes = [vp, vp, vp, vp, i64]
     L.fd_p2p_local_handle.argtypes = [vp, vp]
     L.fd_p2p_connect.argtypes = [vp, vp]
     L.fd_p2p_destroy.argtypes = [vp]

@@ -497,6 +497,15 @@ int fd_comm_gatherv(fd_comm *comm, const void *send, int64_t send_elems, void *r
 /* Assemble outputs computed under colour ownership (they start from zero; every value is non-zero on one rank only,
    so the sum is exact): in-place ncclAllReduce(sum).  elem_bytes 8 or 4. */
 int fd_comm_allreduce_sum(fd_comm *comm, void *buf, int64_t n, int elem_bytes);
+/* Colour ownership, assembled -- north_star's split ("each GPU owns a disjoint subset of colours ... a single RCCL gather to assemble
+   nzval") as ONE entry point that is right call after call: a plan created with fd_plan_opts.color_begin / color_end writes only the
+   stored values of its colours' columns (ext/FiniteDiffSparseArraysExt.jl:38-47 for those colours) and leaves the rest of outs
+   untouched, so summing the ranks' outputs is exact only while the untouched entries are zero -- true for a fresh buffer, false from
+   the second call on.  This call zero-fills outs, runs fd_jacobian_async on the plan's colours and sums every output over the
+   communicator's ranks in place (one ncclAllReduce per output; every stored value is non-zero on exactly one rank: x + 0 == x).
+   comm = NULL: no collective -- the caller sums (MPI.jl, a host transport). */
+int fd_jacobian_owned_async(fd_plan *plan, fd_comm *comm, fd_f_launch f, void *fctx, const void *x, const void *f_in,
+                            double relstep, double absstep, double dir, void *const *outs);
 int fd_comm_broadcast(fd_comm *comm, void *buf, int64_t n, int elem_bytes, int root);   /* e.g. a new x from rank 0 */
 /* Neighbour exchange of the boundary values of a vector sharded by contiguous ranges -- the x of a time-stepping loop whose
    rows are sharded like the Jacobian's columns (the sharded solve returns y by rows; the next Jacobian needs x plus the l + u
@@ -531,6 +540,10 @@ int fd_p2p_destroy(fd_p2p *p2p);
    `rank_share` measurement and the single-GPU tests of the sharded call (no connect step). */
 int fd_p2p_create_loopback(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p **out);
 int fd_p2p_loopback_fill(fd_p2p *p2p, int sender, int64_t offset, const void *data, int64_t bytes);
+/* ... and for the FUSED sharded step (one launch per Jacobian, every exchanged value its own flag): all 64 x 8 group sums of the
+   reduction (doubles, group-major; the rank's own groups are ignored) and what the lower / upper neighbour would deliver as halo
+   (halo_bytes each, <= 64; NULL: none). */
+int fd_p2p_loopback_fill_fused(fd_p2p *p2p, const void *gsum64x8, const void *halo_lo, const void *halo_hi, int64_t halo_bytes);
 int fd_p2p_info(const fd_p2p *p2p, int *nranks, int *rank, int64_t *slot_bytes, int *uncached);   /* any out pointer may be NULL */
 /* 0 while every exchange completed; 1 + r once a wait for rank r timed out (sticky; no synchronisation needed to read it) */
 int fd_p2p_status(const fd_p2p *p2p, int *timed_out_rank_plus_1);
@@ -689,6 +702,8 @@ int fd32_jacobian(fd32_plan *plan, fd_f_launch f, void *fctx, const void *x, int
                 void *const *outs, int out_kind);
 int fd32_jacobian_async(fd32_plan *plan, fd_f_launch f, void *fctx, const void *x, const void *f_in,
                       double relstep, double absstep, double dir, void *const *outs);
+int fd32_jacobian_owned_async(fd32_plan *plan, fd_comm *comm, fd_f_launch f, void *fctx, const void *x, const void *f_in,
+                              double relstep, double absstep, double dir, void *const *outs);
 int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);

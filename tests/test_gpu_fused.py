@@ -92,11 +92,13 @@ def test_fused_step_matches_the_oracle(oracle):
         assert np.allclose(plan.epsilons(), want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("W", [2, 3, 8])
-def test_rank_share_through_a_loopback_mailbox_has_the_bits_of_the_unsharded_slice(dtype, W):
+def test_rank_share_through_a_loopback_mailbox_has_the_bits_of_the_unsharded_slice(dtype, W, fused):
     # rank r of W alone on this GPU: its groups of the reduction, ONE exchange launch against a mailbox whose peers' slots hold the
-    # true group sums and halos (fd_p2p_create_loopback), the storing launch on its columns -- every rank's slice of the unsharded call
+    # true group sums and halos (fd_p2p_create_loopback), the storing launch on its columns -- every rank's slice of the unsharded call.
+    # fused: all of that in ONE launch (the finishers store the rank's group sums into the peers' cells and poll their own)
     N = 700001
     t = _tdt(dtype)
     colors = P.cyclic_colors(N, 3)
@@ -124,7 +126,7 @@ def test_rank_share_through_a_loopback_mailbox_has_the_bits_of_the_unsharded_sli
         e0 = 0 if c0 <= 0 else 3 * c0 - 1
         e1 = 3 * N - 2 if c1 >= N else 3 * c1 - 1
         plan = fd.make_plan(pattern, pattern, colors, "forward", col_window=(c0, c1), x_window=S.x_window(cuts, r, N, 1, 1, 1), dtype=dtype)
-        plan.set_lazy(f)
+        plan.set_lazy(f, fused=fused)
         mb = fd.P2P.loopback(ctx, W, r, 1 << 16)
         for b in range(W):
             if b == r:
@@ -134,17 +136,28 @@ def test_rank_share_through_a_loopback_mailbox_has_the_bits_of_the_unsharded_sli
                 mb.fill(b, slot * 8, x_full[c0 - halo:c0].contiguous())
             if b == r + 1:
                 mb.fill(b, slot * 8, x_full[c1:c1 + halo].contiguous())
+        mb.fill_fused(gsum[:512].contiguous(), x_full[c0 - halo:c0].contiguous() if r > 0 else None,
+                      x_full[c1:c1 + halo].contiguous() if r + 1 < W else None)
         plan.set_p2p(mb)
         plan.set_halo(c0, c1, halo)
         x = torch.full_like(x_full, float("nan"))
         x[c0:c1] = x_full[c0:c1]
         out = torch.full((e1 - e0,), float("nan"), dtype=t, device="cuda")
-        for _ in range(3):
+        for _ in range(4):
             out.fill_(float("nan"))
+            x[:c0] = float("nan")
+            x[c1:] = float("nan")
+            plan.enable_timing(2)
             plan.jacobian(f, x, [out])
+            tm = plan.timings()
+            plan.enable_timing(0)
+            assert tm["eps"]["launches"] == (0 if fused else 1) and tm["exchange"]["launches"] == (0 if fused else 1), tm
             assert mb.status() == 0
             assert np.array_equal(plan.epsilons(), eps1), (W, r)
-            assert torch.equal(out, out1[e0:e1]), (W, r)
+            if not torch.equal(out, out1[e0:e1]):      # (say what differs: a missing store, a wrong halo, a wrong step size ...)
+                d = torch.nonzero((out != out1[e0:e1]) | torch.isnan(out)).flatten()
+                raise AssertionError((W, r, _, int(d.numel()), d[:4].tolist(), d[-2:].tolist(), int(torch.isnan(out).sum()), out[d[:4]].tolist(),
+                                      out1[e0:e1][d[:4]].tolist(), x[c0 - halo:c0 + 1].tolist() if r > 0 else None))
         # the halo cells of x arrived with the call
         if r > 0:
             assert torch.equal(x[c0 - halo:c0], x_full[c0 - halo:c0])
