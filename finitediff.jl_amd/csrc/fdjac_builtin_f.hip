@@ -279,7 +279,7 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
 {
     // one LDS area, carved by role: storing workgroups (4 wave windows + the step sizes), reduction workgroups, finishers
     constexpr int kWinBytes = (kBlock / 64) * FD_BAND_WAVE_LDS(3) * (int)sizeof(real_t);
-    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + kEpsGroups + 2) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + kEpsGroups + 2) * 8;
+    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + 2 * kEpsGroups) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + 2 * kEpsGroups) * 8;
     __shared__ __attribute__((aligned(16))) char s_lds[kLdsBytes];
     real_t (*s_win)[FD_BAND_WAVE_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE_LDS(3)]>(s_lds);
     double *s_red = reinterpret_cast<double *>(s_lds);
@@ -293,32 +293,34 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
     const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
     const int64_t gstride = (int64_t)((int)gridDim.x - nfin - fz.nblocks) * (kBlock / 64);
     int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
-    int64_t jw = jstart + gw * 128, j = jw + 2 * lane;
+    int64_t jw = jstart + gw * 128;
     r2_t Cc = {0, 0}, L = {0, 0}, R = {0, 0};
     // (a sharded x: the two lanes at the edges of the rank's columns take the neighbours' halo from the mailbox cells)
-    auto load_x = [&]() {
-        Cc = ld_pair_guarded(x, j, n); L = ld_pair_guarded(x, j - 2, n); R = ld_pair_guarded(x, j + 2, n);
+    auto load_x = [&](int64_t jt, r2_t &c_, r2_t &l_, r2_t &r_) {
+        const int64_t j = jt + 2 * lane;
+        c_ = ld_pair_guarded(x, j, n); l_ = ld_pair_guarded(x, j - 2, n); r_ = ld_pair_guarded(x, j + 2, n);
         if (fz.xw && fz.nranks > 1) {
-            if (j == fz.own_begin && fz.rank > 0) { L.x = fused_halo(fz, 0, 0); L.y = fused_halo(fz, 0, 1); }
-            if (j + 2 == fz.own_end && fz.rank + 1 < fz.nranks) { R.x = fused_halo(fz, 1, 0); R.y = fused_halo(fz, 1, 1); }
+            if (j == fz.own_begin && fz.rank > 0) { l_.x = fused_halo(fz, 0, 0); l_.y = fused_halo(fz, 0, 1); }
+            if (j + 2 == fz.own_end && fz.rank + 1 < fz.nranks) { r_.x = fused_halo(fz, 1, 0); r_.y = fused_halo(fz, 1, 1); }
         }
     };
-    if (gw < nwaves) load_x();
+    if (gw < nwaves) load_x(jw, Cc, L, R);
     real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
     for (; gw < nwaves; gw += gstride) {
+        // the next tile's x is requested before this tile is computed and stored
+        const bool more = gw + gstride < nwaves;
+        const int64_t jn = jstart + (gw + gstride) * 128;
+        r2_t nC = {0, 0}, nL = {0, 0}, nR = {0, 0};
+        if (more) load_x(jn, nC, nL, nR);
         const int c0w = (int)((jw + bst.shift) % bst.C);
         const int c0 = (int)((uint32_t)(c0w + 2 * lane) % (uint32_t)bst.C);
         const int c1 = c0 + 1 == bst.C ? 0 : c0 + 1;
         real_t q[6];
         tridiag_pair_quotients<MODE, NL>(L, Cc, R, s_eps[c0], s_eps[c1], q);
         fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);
-        if (gw + gstride < nwaves) {
-            jw = jstart + (gw + gstride) * 128;
-            j = jw + 2 * lane;
-            load_x();
-        }
+        Cc = nC; L = nL; R = nR; jw = jn;
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }
@@ -385,7 +387,7 @@ __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, int64_t jstart, FusedEps fz)
 {
     constexpr int kWinBytes = (kBlock / 64) * FD_BAND_WAVE4_LDS(3) * (int)sizeof(real_t);
-    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + kEpsGroups + 2) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + kEpsGroups + 2) * 8;
+    constexpr int kLdsBytes = kWinBytes + 64 > (kFzMaxBlocks + 2 * kEpsGroups) * 8 ? kWinBytes + 64 : (kFzMaxBlocks + 2 * kEpsGroups) * 8;
     __shared__ __attribute__((aligned(16))) char s_lds[kLdsBytes];
     real_t (*s_win)[FD_BAND_WAVE4_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE4_LDS(3)]>(s_lds);
     double *s_red = reinterpret_cast<double *>(s_lds);
@@ -397,20 +399,25 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
     const int64_t nwaves = (bst.col_end - jstart + 255) / 256;
     const int64_t gstride = (int64_t)((int)gridDim.x - nfin - fz.nblocks) * (kBlock / 64);
     int64_t gw = (int64_t)cb * (kBlock / 64) + wave;
-    int64_t jw = jstart + gw * 256, j = jw + 4 * lane;
+    int64_t jw = jstart + gw * 256;
     r4_t Cc = {0, 0, 0, 0}, L = {0, 0, 0, 0}, R = {0, 0, 0, 0};
-    auto load_x = [&]() {
-        Cc = ld_quad_guarded(x, j, n); L = ld_quad_guarded(x, j - 4, n); R = ld_quad_guarded(x, j + 4, n);
+    auto load_x = [&](int64_t jt, r4_t &c_, r4_t &l_, r4_t &r_) {
+        const int64_t j = jt + 4 * lane;
+        c_ = ld_quad_guarded(x, j, n); l_ = ld_quad_guarded(x, j - 4, n); r_ = ld_quad_guarded(x, j + 4, n);
         if (fz.xw && fz.nranks > 1) {
-            if (j == fz.own_begin && fz.rank > 0) { L.z = fused_halo(fz, 0, 0); L.w = fused_halo(fz, 0, 1); }
-            if (j + 4 == fz.own_end && fz.rank + 1 < fz.nranks) { R.x = fused_halo(fz, 1, 0); R.y = fused_halo(fz, 1, 1); }
+            if (j == fz.own_begin && fz.rank > 0) { l_.z = fused_halo(fz, 0, 0); l_.w = fused_halo(fz, 0, 1); }
+            if (j + 4 == fz.own_end && fz.rank + 1 < fz.nranks) { r_.x = fused_halo(fz, 1, 0); r_.y = fused_halo(fz, 1, 1); }
         }
     };
-    if (gw < nwaves) load_x();
+    if (gw < nwaves) load_x(jw, Cc, L, R);
     real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kWinBytes);
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
     for (; gw < nwaves; gw += gstride) {
+        const bool more = gw + gstride < nwaves;
+        const int64_t jn = jstart + (gw + gstride) * 256;
+        r4_t nC = {0, 0, 0, 0}, nL = {0, 0, 0, 0}, nR = {0, 0, 0, 0};
+        if (more) load_x(jn, nC, nL, nR);
         const int c0w = (int)((jw + bst.shift) % bst.C);
         int c = (int)((uint32_t)(c0w + 4 * lane) % (uint32_t)bst.C);
         real_t ev[4];
@@ -419,11 +426,7 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
         real_t q[12];
         tridiag_quad_quotients<MODE, NL>(L, Cc, R, ev, q);
         fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
-        if (gw + gstride < nwaves) {
-            jw = jstart + (gw + gstride) * 256;
-            j = jw + 4 * lane;
-            load_x();
-        }
+        Cc = nC; L = nL; R = nR; jw = jn;
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }

@@ -218,6 +218,23 @@ __device__ __forceinline__ void fz_mark_max(const FusedEps &fz, int k)
     if (fz.trace && (threadIdx.x & 63) == 0 && ((blockIdx.x & 31) < 2 || blockIdx.x < kRegColors)) atomicMax((unsigned long long *)fz.trace + k, (unsigned long long)wall_clock64());
 }
 
+// eight agent-scope 8-byte loads in flight together
+__device__ __forceinline__ void fz_load8_agent(const unsigned long long *const (&p)[8], unsigned long long *v)
+{
+    asm volatile("global_load_dwordx2 %0, %8, off sc1\n\t"
+                 "global_load_dwordx2 %1, %9, off sc1\n\t"
+                 "global_load_dwordx2 %2, %10, off sc1\n\t"
+                 "global_load_dwordx2 %3, %11, off sc1\n\t"
+                 "global_load_dwordx2 %4, %12, off sc1\n\t"
+                 "global_load_dwordx2 %5, %13, off sc1\n\t"
+                 "global_load_dwordx2 %6, %14, off sc1\n\t"
+                 "global_load_dwordx2 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
+}
+
 // a reduction workgroup of the fused step: level 0, published value by value (colour-major: the finisher of colour c reads
 // part[c][0 .. nblocks) with dense loads)
 template <int NC, bool PIPE>
@@ -232,107 +249,129 @@ __device__ __forceinline__ void fused_eps_block(const real_t *__restrict__ x, in
     fz_mark_max(fz, 1);
 }
 
-// the finisher of colour c (one workgroup of kBlock threads per colour: blockIdx c): waits for the colour's block sums -- dense loads,
-// every thread a few, all in flight together --, parks them in LDS, thread g adds group g's in block order (level 1), thread 0 the 64
-// group sums in group order (level 2) and forms eps[c]; the workgroup publishes it and resets the next call's slots of its colour.
-// (One workgroup for all colours, thread (group, colour pair) loading its own addends, took 3 us for the wait alone at N = 10^6: 1024
-// scattered 8-byte requests through one CU's memory pipeline.)  lds: kFzMaxBlocks + kEpsGroups + 2 doubles.
+// the finisher of colour c (blockIdx c), by wavefront:
+//   0  waits for the colour's block sums -- DENSE loads, lane l takes part[c][l + 64 m], all in flight together -- parks them in its
+//      private LDS window, lane g adds group g's in block order (level 1); a sharded step stores every own group's sum into every
+//      peer's cell (c, g) right away (a rank must send before it can receive: all ranks run this code);
+//   1  (sharded) meanwhile waits for the peers' cells (c, .) of this rank's mailbox -- one dense 512-byte load per poll;
+//   2, 3  housekeeping: the next step's slots back to the sentinel, the halo of a sharded x into the neighbours' cells;
+//   then ONE barrier, and wavefront 0 adds the 64 group sums in group order (level 2), forms eps[c] and publishes it.
+// (Round-6 measurements, N = 10^6 / a rank of 8 at N = 10^7, time from the last block sum to the published step size: one workgroup
+//  for all colours, thread (group, colour pair) loading its own addends: 4.1 us / - (1024 scattered 8-byte requests through one CU's
+//  memory pipeline); one workgroup per colour, dense loads, two barriers, mailbox polled after the first: 2.0 / 4.0 us; ONE wavefront
+//  per colour with per-lane address lists: 3.6 / 6-9 us (scattered again); this form: profiles/r06_fused_trace.md.)
+// lds: kFzMaxBlocks + 2 * kEpsGroups doubles.
 constexpr int kFzMaxBlocks = kEpsGroups * kEpsBlocksPerGroup;      // 1024
 __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double *lds)
 {
-    const int t = threadIdx.x, nb = fz.nblocks, bpg = fz.eg.bpg;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nb = fz.nblocks, bpg = fz.eg.bpg;
     const bool sharded = fz.nranks > 1;
-    // a sharded x: this rank's boundary elements into the neighbours' halo cells, first thing (finisher 0, threads 64 ..)
-    if (sharded && c == 0 && fz.xw && t >= 64 && t < 64 + 2 * fz.halo) {
-        const int h = (t - 64) % fz.halo, up = (t - 64) / fz.halo;      // up: to rank + 1 (my last elements = its lower halo); else to rank - 1
-        const int target = up ? fz.rank + 1 : fz.rank - 1;
-        if (target >= 0 && target < fz.nranks) {
-            const real_t v = up ? fz.xw[fz.own_end - fz.halo + h] : fz.xw[fz.own_begin + h];
-            rbits_t *cell = reinterpret_cast<rbits_t *>(fz_cells(fz.peer[target], fz, fz.buf) + kFzGsumBytes + (up ? 0 : kFzHaloBytes)) + h;
-            __hip_atomic_store(cell, fz_to_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(fz.part + (int64_t)c * nb);
-    constexpr int M = kFzMaxBlocks / kBlock;       // 4
-    unsigned long long v[M];
+    double *gs_peer = lds + kFzMaxBlocks;        // [64] the peers' group sums (wavefront 1)
+    int *s_bad = reinterpret_cast<int *>(gs_peer + kEpsGroups);
+    if (t == 0) *s_bad = 0;
+    double gs = 0.0;
     int ok = 1;
-    if (t == 0) fz_mark_max(fz, 2);
     const long long t0 = wall_clock64();
-    for (;;) {
-        bool all = true;
+    if (wave == 0) {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(fz.part + (int64_t)c * nb);
+        constexpr int M = kFzMaxBlocks / 64;       // 16
+        unsigned long long v[M];
+        if (t == 0) fz_mark_max(fz, 2);
+        const unsigned long long my_peer = (sharded && lane < fz.nranks) ? (unsigned long long)fz.peer[lane] : 0ull;
+        for (;;) {
+            // (eight loads per statement, ONE wait: the compiler waits behind every __hip_atomic_load -- eight dependent round trips
+            //  instead of one, measured: 3.8 us for 512 block sums; lanes past the end re-read the colour's first slot)
+            bool all = true;
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            v[m] = 0;
-            if (t + m * kBlock < nb) {
-                v[m] = __hip_atomic_load(src + t + m * kBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                all = all && v[m] != kFzSentinel64;
+            for (int m0 = 0; m0 < M; m0 += 8) {
+                if (m0 * 64 >= nb) break;
+                const unsigned long long *q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = src + ((lane + 64 * (m0 + u) < nb) ? lane + 64 * (m0 + u) : 0);
+                fz_load8_agent(q, &v[m0]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) all = all && v[m0 + u] != kFzSentinel64;
             }
+            if (__all(all)) break;
+            if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (all) break;
-        if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
 #pragma unroll
-    for (int m = 0; m < M; ++m)
-        if (t + m * kBlock < nb) lds[t + m * kBlock] = __longlong_as_double((long long)v[m]);
-    __shared__ int s_bad;
-    if (t == 0) s_bad = 0;
-    __syncthreads();
-    if (t == 0) fz_mark_max(fz, 3);
-    double *gs = lds + kFzMaxBlocks;
-    if (t < kEpsGroups) {
-        double g = 0.0;
-        if (t >= fz.g0 && t < fz.g0 + fz.ng) {
-            // level 1 of an own group; a sharded step stores it into every peer's cell (t, c) of this step's buffer
-            for (int k = 0; k < bpg; ++k) g += lds[(t - fz.g0) * bpg + k];
+        for (int m = 0; m < M; ++m)
+            if (lane + 64 * m < nb) lds[lane + 64 * m] = __longlong_as_double((long long)v[m]);
+        __builtin_amdgcn_wave_barrier();     // (one wavefront: its LDS instructions execute in order)
+        if (t == 0) fz_mark_max(fz, 3);
+        {
+            // (the group's block sums: all LDS reads first, then the additions in block order -- "+ 0.0" past the last block changes nothing)
+            const bool own = lane >= fz.g0 && lane < fz.g0 + fz.ng;
+            double w[kEpsBlocksPerGroup];
+#pragma unroll
+            for (int k = 0; k < kEpsBlocksPerGroup; ++k) w[k] = (own && k < bpg) ? lds[(lane - fz.g0) * bpg + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < kEpsBlocksPerGroup; ++k) gs += w[k];
             if (sharded)
-                for (int b = 0; b < fz.nranks; ++b)
-                    if (b != fz.rank)
-                        __hip_atomic_store(reinterpret_cast<double *>(fz_cells(fz.peer[b], fz, fz.buf)) + t * kRegColors + c, g, __ATOMIC_RELAXED,
+                for (int b = 0; b < fz.nranks; ++b) {
+                    // (the peers' mailbox addresses were requested before the wait: lane b holds peer b's)
+                    char *pb = reinterpret_cast<char *>(__shfl((unsigned long long)my_peer, b, 64));
+                    if (own && b != fz.rank)
+                        __hip_atomic_store(reinterpret_cast<double *>(fz_cells(pb, fz, fz.buf)) + c * kEpsGroups + lane, gs, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
-            // a peer's group: its owner stores the sum into this rank's cell (t, c)
-            const unsigned long long *cell = reinterpret_cast<const unsigned long long *>(fz_cells(fz.local, fz, fz.buf)) + t * kRegColors + c;
-            unsigned long long w;
+                }
+        }
+    } else if (wave == 1) {
+        if (sharded) {
+            const bool own = lane >= fz.g0 && lane < fz.g0 + fz.ng;
+            const unsigned long long *cell = reinterpret_cast<const unsigned long long *>(fz_cells(fz.local, fz, fz.buf)) + c * kEpsGroups + lane;
+            unsigned long long w = 0;
             for (;;) {
                 w = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (w != kFzSentinel64) break;
+                if (__all(own || w != kFzSentinel64)) break;
                 if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            g = __longlong_as_double((long long)w);
+            gs_peer[lane] = __longlong_as_double((long long)w);
         }
-        gs[t] = g;
+    } else {
+        // ---- wavefronts 2, 3: housekeeping, no dependence on anything ----
+        const int u = t - 128;
+        if (sharded && c == 0 && fz.xw && u < 2 * fz.halo) {
+            const int h = u % fz.halo, up = u / fz.halo;      // up: to rank + 1 (my last elements = its lower halo); else to rank - 1
+            const int target = up ? fz.rank + 1 : fz.rank - 1;
+            if (target >= 0 && target < fz.nranks) {
+                const real_t v = up ? fz.xw[fz.own_end - fz.halo + h] : fz.xw[fz.own_begin + h];
+                rbits_t *cell = reinterpret_cast<rbits_t *>(fz_cells(fz.peer[target], fz, fz.buf) + kFzGsumBytes + (up ? 0 : kFzHaloBytes)) + h;
+                __hip_atomic_store(cell, fz_to_bits(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        unsigned long long *pn = reinterpret_cast<unsigned long long *>(fz.part_next + (int64_t)c * nb);
+        for (int i = u; i < nb; i += 128) __hip_atomic_store(pn + i, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (u < kFzReplicas) __hip_atomic_store(fz.epsr_next + u * kFzPitch + c, FzBits<real_t>::sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sharded && fz.buf_reset >= 0) {      // this rank's cells of the step after next (nobody writes them before this launch is over)
+            unsigned long long *cells = reinterpret_cast<unsigned long long *>(fz_cells(fz.local, fz, fz.buf_reset));
+            if (u < kEpsGroups) __hip_atomic_store(cells + c * kEpsGroups + u, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (c == 0 && u >= 64 && u < 64 + (int)(2 * kFzHaloBytes / 8))
+                __hip_atomic_store(cells + kFzGsumBytes / 8 + (u - 64), kFzSentinelHalo64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (!ok) s_bad = 1;
-    __syncthreads();
-    const bool bad = s_bad != 0;
-    real_t *s_e = reinterpret_cast<real_t *>(gs + kEpsGroups);
+    if (!ok) *s_bad = 1;
+    // (a bare barrier behind the LDS writes: __syncthreads() is also a fence -- it would wait for the acknowledgement of every store
+    //  above, the system-scope stores into the peers' cells among them: 2 us on the way to the step sizes, measured)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave != 0) return;
+    const bool bad = *s_bad != 0;
+    // level 2: the 64 group sums in group order (every lane forms the same total)
+    if (!(lane >= fz.g0 && lane < fz.g0 + fz.ng)) gs = gs_peer[lane];
+    double tot = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < kEpsGroups; ++gg) tot += __shfl(gs, gg, 64);
+    real_t e = eps_rule<real_t>(tot, fz.eg.relstep, fz.eg.absstep, fz.eg.dir, fz.eg.is_forward);
+    if (bad) e = fz_from_bits(FzBits<real_t>::sentinel ^ 1);      // (a NaN that is not the sentinel: the storing wavefronts go on and store NaNs)
+    __hip_atomic_store(fz.epsr + lane * kFzPitch + c, fz_to_bits(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // replica `lane`
     if (t == 0) {
         if (bad) __hip_atomic_store(fz.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        double tot = 0.0;
-#pragma unroll 16
-        for (int gg = 0; gg < kEpsGroups; ++gg) tot += gs[gg];
-        real_t e = eps_rule<real_t>(tot, fz.eg.relstep, fz.eg.absstep, fz.eg.dir, fz.eg.is_forward);
-        if (bad) e = fz_from_bits(FzBits<real_t>::sentinel ^ 1);      // (a NaN that is not the sentinel: the storing wavefronts go on and store NaNs)
-        s_e[0] = e;
         fz.eps[c] = e;
         if (fz.eps2) fz.eps2[c] = (real_t)2 * e;
-    }
-    __syncthreads();
-    if (t < kFzReplicas) {
-        __hip_atomic_store(fz.epsr + t * kFzPitch + c, fz_to_bits(s_e[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(fz.epsr_next + t * kFzPitch + c, FzBits<real_t>::sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (t == 0) fz_mark_max(fz, 4);
-    unsigned long long *pn = reinterpret_cast<unsigned long long *>(fz.part_next + (int64_t)c * nb);
-    for (int i = t; i < nb; i += kBlock) __hip_atomic_store(pn + i, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // this rank's cells of the step after next (nobody writes them before this launch is over: see the header)
-    if (sharded && fz.buf_reset >= 0) {
-        unsigned long long *cells = reinterpret_cast<unsigned long long *>(fz_cells(fz.local, fz, fz.buf_reset));
-        if (t < kEpsGroups) __hip_atomic_store(cells + t * kRegColors + c, kFzSentinel64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (c == 0 && t >= 64 && t < 64 + (int)(2 * kFzHaloBytes / 8))
-            __hip_atomic_store(cells + kFzGsumBytes / 8 + (t - 64), kFzSentinelHalo64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fz_mark_max(fz, 4);
     }
 }
 

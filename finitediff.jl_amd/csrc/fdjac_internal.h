@@ -101,7 +101,7 @@ extern "C" int fdjac_p2p_step(fd_p2p *p, void *x, int64_t own_begin, int64_t own
                               int64_t slot_bytes, const fdjac_eps_final *fin);
 
 // the fused step's cells in a mailbox (csrc/fdjac_eps_dev.h, fdjac_p2p.hip): a cell holds a sentinel until its ONE writer stores the
-// value; three buffers by epoch, each [64 groups x 8 colours group sums][lower halo][upper halo]
+// value; three buffers by epoch, each [8 colours x 64 groups group sums][lower halo][upper halo]
 constexpr int kFzBufs = 3;
 constexpr int64_t kFzGsumBytes = 64 * 8 * 8, kFzHaloBytes = 64, kFzBufBytes = kFzGsumBytes + 2 * kFzHaloBytes;
 constexpr unsigned long long kFzSentinel64 = 0x7FF85EEDFD1AC0DEull;   // quiet NaNs with a payload: never the result of arithmetic on
@@ -163,7 +163,8 @@ enum PlanKind { K_CSC = 0, K_CSC_DENSE, K_COO_DENSE, K_TRIDIAG, K_BANDED, K_COLR
 constexpr int kBlock = 256;          // 4 wave64 per workgroup
 constexpr int kRegColors = 8;        // epsilon reduction keeps <= this many colour sums in registers
 constexpr int kEpsGroups = 64;       // ... and is defined over this many contiguous groups of x (the unit a rank of a sharded reduction owns)
-constexpr int kEpsBlocksPerGroup = 16;   //   each summed by at most this many workgroups (64 x 16 = 4 per CU)
+constexpr int kEpsBlocksPerGroup = 16;   //   each summed by at most this many workgroups (64 x 16 = 4 per CU; 64 per group was measured in round 6: a shard's
+                                         //   pass 6.2 -> 4.7 us, but the unsharded N = 10^7 pass 24 -> 33 us -- 2496 workgroups and 39 arrivals per ticket)
 constexpr int64_t kListPad = 4096;   // index lists are padded to a multiple of this many entries (>= largest tile)
 constexpr int kEpsLdsMax = 2048;     // stage eps[] in LDS up to this many colours per chunk
 constexpr int64_t kSmallN = 16384;   // below this a single-workgroup launch does step sizes (+ perturbation): launch-bound regime

@@ -74,11 +74,12 @@ k_eps_partial_reg(const real_t *__restrict__ x, const CT *__restrict__ color, in
     {
         const double *pg = partial + (int64_t)grp * eg.bpg * ldp;
         const int cnt = eg.bpg * ldp;                          // <= 16 x 8 doubles
-        double v0 = 0.0, v1 = 0.0;
-        if (lane < cnt) v0 = __hip_atomic_load(pg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane + 64 < cnt) v1 = __hip_atomic_load(pg + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stage[lane] = v0;
-        stage[lane + 64] = v1;
+        constexpr int kLv = kEpsBlocksPerGroup * kRegColors / 64;      // 8 loads per lane, all in flight together
+        double v[kLv];
+#pragma unroll
+        for (int u = 0; u < kLv; ++u) v[u] = (lane + 64 * u < cnt) ? __hip_atomic_load(pg + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int u = 0; u < kLv; ++u) stage[lane + 64 * u] = v[u];
     }
     __builtin_amdgcn_wave_barrier();     // (one wave: its LDS instructions execute in order)
     if (lane < NC) {

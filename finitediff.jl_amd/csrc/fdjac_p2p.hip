@@ -81,7 +81,7 @@ struct fd_p2p {
     bool uncached = false;
     char *sink = nullptr;                     // loop-back mailbox (fd_p2p_create_loopback): what every peer's mailbox is mapped to
     int64_t fz_off = 0;                       // the FUSED step's region of a mailbox (after the two channels): kFzBufs buffers of
-                                              // [64 groups x 8 colours group sums][lower halo][upper halo], every cell its own flag
+                                              // [8 colours x 64 groups group sums][lower halo][upper halo], every cell its own flag
     uint64_t fz_epoch = 0;                    // fused steps enqueued so far (buffer = epoch mod 3)
     size_t local_bytes = 0;                   // size of `local` (an uncached block goes back to the pool, not to the allocator)
     bool shared_device = false;               // some peer's mailbox lies on THIS device (ranks sharing a GPU: tests, dry runs) -- a launch that
@@ -488,9 +488,14 @@ int fd_p2p_loopback_fill_fused(fd_p2p *p, const void *gsum64x8, const void *halo
     FD_REQUIRE(halo_bytes >= 0 && halo_bytes <= kFzHaloBytes, FD_ERR_ARG, "halo of %lld bytes (at most %lld)", (long long)halo_bytes, (long long)kFzHaloBytes);
     FD_HIP_CHECK(hipSetDevice(p->ctx->device));
     FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    // (the cells are colour-major -- cell (c, g) at c * 64 + g: a finisher polls its colour's 64 cells with one dense load)
+    std::vector<double> gm(512), cm(512);
+    FD_HIP_CHECK(hipMemcpy(gm.data(), gsum64x8, (size_t)kFzGsumBytes, hipMemcpyDefault));
+    for (int g = 0; g < 64; ++g)
+        for (int c = 0; c < 8; ++c) cm[(size_t)(c * 64 + g)] = gm[(size_t)(g * 8 + c)];
     for (int q = 0; q < kFzBufs; ++q) {
         char *b = p->local + p->fz_off + q * kFzBufBytes;
-        FD_HIP_CHECK(hipMemcpy(b, gsum64x8, (size_t)kFzGsumBytes, hipMemcpyDefault));
+        FD_HIP_CHECK(hipMemcpy(b, cm.data(), (size_t)kFzGsumBytes, hipMemcpyHostToDevice));
         if (halo_lo && halo_bytes) FD_HIP_CHECK(hipMemcpy(b + kFzGsumBytes, halo_lo, (size_t)halo_bytes, hipMemcpyDefault));
         if (halo_hi && halo_bytes) FD_HIP_CHECK(hipMemcpy(b + kFzGsumBytes + kFzHaloBytes, halo_hi, (size_t)halo_bytes, hipMemcpyDefault));
     }

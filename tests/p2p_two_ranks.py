@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    os.environ["FDJAC_TEST_SWITCHES"] = "1"      # (read once, by the first plan: ranks sharing a device take the fused sharded step on request only)
+    os.environ["FDJAC_FUSED_SHARED"] = "1"
     import torch
     import torch.distributed as dist
     import finitediff_jl_amd as fd
@@ -112,15 +114,20 @@ def main():
     c0, c1 = int(cuts3[rank]), int(cuts3[rank + 1])
     ent = S.entry_ranges(cp, cuts3)
     e0, e1 = ent[rank]
+    # ... in BOTH forms: three launches (reduction, ONE exchange launch, store) and the FUSED step -- one launch per rank whose finishers
+    # store the group sums straight into the peer's mailbox cells and poll their own, every cell its own flag, three buffers by epoch.
+    # (Ranks sharing a device take the fused step only on request, FDJAC_FUSED_SHARED=1: this problem is small enough for both ranks'
+    # launches to be resident together.)
     wplan = fd.make_plan(pat, pat, colors, "forward", ctx=ctx, col_window=(c0, c1), x_window=S.x_window(cuts3, rank, Nn, 1, 1, 1))
-    wplan.set_lazy(f)
     wplan.set_p2p(p2p)
     wplan.set_halo(c0, c1, 2)
-    ref_plan.set_lazy(f)
+    ref_plan.set_lazy(f, fused=False)
     rng = np.random.default_rng(77)
     lo, hi = max(c0 - 2, 0), min(c1 + 2, Nn)
     junk = torch.zeros(1 << 22, dtype=torch.float64, device=dev)
-    for it in range(40):
+    for it in range(80):
+        fused = it >= 40 or it % 7 == 3          # (and a few fused steps in between the others: the two forms keep separate epochs)
+        wplan.set_lazy(f, fused=fused)
         xfull = torch.as_tensor(rng.random(Nn) * (1.0 + it), device=dev)
         xmine = torch.full((Nn,), float("nan"), dtype=torch.float64, device=dev)
         xmine[c0:c1] = xfull[c0:c1]
@@ -128,29 +135,37 @@ def main():
             for _ in range(5):
                 junk.add_(1.0)                       # unequal load: this rank arrives late
         piece = torch.full((e1 - e0,), float("nan"), dtype=torch.float64, device=dev)
+        wplan.enable_timing(2)
         wplan.jacobian(f, xmine, [piece], sync=False)
         ref_plan.jacobian(f, xfull, [out_ref])
         torch.cuda.synchronize()
+        tm = wplan.timings()
+        wplan.enable_timing(0)
+        assert tm["exchange"]["launches"] == (0 if fused else 1), (it, fused, tm)         # the fused step really is ONE launch
         assert np.array_equal(wplan.epsilons(), ref_plan.epsilons()), ("step eps", it)
         assert torch.equal(piece, out_ref[e0:e1]), ("step", it)
         assert torch.equal(xmine[lo:hi], xfull[lo:hi]) and torch.isnan(xmine[:lo]).all() and torch.isnan(xmine[hi:]).all(), ("step halo", it)
     assert p2p.status() == 0
     xmine[c0:c1] = xfull[c0:c1]
     dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    call = wplan.bind(f, xmine, [piece])
-    for _ in range(10):
-        call()
-    torch.cuda.synchronize()
-    dist.barrier()
-    ev0.record()
-    for _ in range(200):
-        call()
-    ev1.record()
-    torch.cuda.synchronize()
-    assert p2p.status() == 0
-    if rank == 0:
-        print("sharded call with the one-launch step exchange (2 processes, 1 GPU, N = %d): %.1f us per call" % (Nn, ev0.elapsed_time(ev1) * 1e3 / 200))
+    for fused in (False, True):
+        wplan.set_lazy(f, fused=fused)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        call = wplan.bind(f, xmine, [piece])
+        for _ in range(10):
+            call()
+        torch.cuda.synchronize()
+        dist.barrier()
+        ev0.record()
+        for _ in range(200):
+            call()
+        ev1.record()
+        torch.cuda.synchronize()
+        assert p2p.status() == 0
+        if rank == 0:
+            print("sharded call, %s (2 processes, 1 GPU, N = %d): %.1f us per call" % ("fused: ONE launch" if fused else "three launches", Nn, ev0.elapsed_time(ev1) * 1e3 / 200))
+        del call
+        dist.barrier()
     wplan.set_p2p(None)
     dist.barrier()
 
