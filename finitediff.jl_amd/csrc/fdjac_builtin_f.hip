@@ -309,18 +309,16 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
     for (; gw < nwaves; gw += gstride) {
-        // the next tile's x is requested before this tile is computed and stored
-        const bool more = gw + gstride < nwaves;
-        const int64_t jn = jstart + (gw + gstride) * 128;
-        r2_t nC = {0, 0}, nL = {0, 0}, nR = {0, 0};
-        if (more) load_x(jn, nC, nL, nR);
         const int c0w = (int)((jw + bst.shift) % bst.C);
         const int c0 = (int)((uint32_t)(c0w + 2 * lane) % (uint32_t)bst.C);
         const int c1 = c0 + 1 == bst.C ? 0 : c0 + 1;
         real_t q[6];
         tridiag_pair_quotients<MODE, NL>(L, Cc, R, s_eps[c0], s_eps[c1], q);
         fd_band_emit_wave<real_t, 3, true>(&bst, s_win[wave], jw, q);
-        Cc = nC; L = nL; R = nR; jw = jn;
+        // (the next tile's x requested BEFORE this tile is computed was measured: 12 more registers -- 6 instead of 8 wavefronts per
+        //  SIMD -- for 0.3 us of a rank's 7.5-us storing phase, and 0.8 us lost at N = 10^6)
+        jw = jstart + (gw + gstride) * 128;
+        if (gw + gstride < nwaves) load_x(jw, Cc, L, R);
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }
@@ -414,10 +412,6 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
     if (wave == 0) fused_wait_eps(fz, cb, s_eps);
     __syncthreads();
     for (; gw < nwaves; gw += gstride) {
-        const bool more = gw + gstride < nwaves;
-        const int64_t jn = jstart + (gw + gstride) * 256;
-        r4_t nC = {0, 0, 0, 0}, nL = {0, 0, 0, 0}, nR = {0, 0, 0, 0};
-        if (more) load_x(jn, nC, nL, nR);
         const int c0w = (int)((jw + bst.shift) % bst.C);
         int c = (int)((uint32_t)(c0w + 4 * lane) % (uint32_t)bst.C);
         real_t ev[4];
@@ -426,7 +420,8 @@ k_f_tridiag_fused4(const real_t *__restrict__ x, int64_t n, fd_band_store bst, i
         real_t q[12];
         tridiag_quad_quotients<MODE, NL>(L, Cc, R, ev, q);
         fd_band_emit_wave4<real_t, 3, true>(&bst, s_win[wave], jw, q);
-        Cc = nC; L = nL; R = nR; jw = jn;
+        jw = jstart + (gw + gstride) * 256;
+        if (gw + gstride < nwaves) load_x(jw, Cc, L, R);
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
 }
@@ -884,17 +879,32 @@ static int builtin_launch(void *fctx, void *fx, const void *x, int64_t nbatch, i
     return launch_family<real_t>(b, fx, x, nbatch, x_stride, fx_stride, r0, r1, (hipStream_t)stream);
 }
 
-// storing workgroups of a fused launch: as many as tiles, but never more than fit on the device next to the reduction's
-// (8 workgroups of 4 wavefronts per CU): a workgroup dispatched only after others have left would start its life after the step sizes
-// are out -- a second round of memory latency at the end of the launch
-static unsigned fused_store_blocks(unsigned tiles_wg, int nblocks)
+// storing workgroups of a fused launch: as many as tiles, but never more than fit on the device next to the reduction's (what the
+// kernel's registers and LDS allow per CU, asked of the runtime once per kernel): a workgroup dispatched only after others have left
+// would start its life after the step sizes are out -- a second round of memory latency at the end of the launch
+template <typename K>
+static unsigned fused_grid(K kernel, unsigned tiles_wg, int prefix)
 {
     static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const int64_t room = (int64_t)cus * 8 - nblocks;
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> per_cu;
+    int occ = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = per_cu.find((const void *)kernel);
+        if (it == per_cu.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+            (void)hipGetLastError();
+            it = per_cu.emplace((const void *)kernel, nb).first;
+        }
+        occ = it->second;
+    }
+    const int64_t room = (int64_t)cus * occ - prefix;
     const int64_t cap = room > cus ? room : cus;
-    if ((int64_t)tiles_wg <= cap) return tiles_wg;
+    if ((int64_t)tiles_wg <= cap) return (unsigned)prefix + tiles_wg;
     const int64_t rounds = ((int64_t)tiles_wg + cap - 1) / cap;
-    return (unsigned)(((int64_t)tiles_wg + rounds - 1) / rounds);
+    return (unsigned)prefix + (unsigned)(((int64_t)tiles_wg + rounds - 1) / rounds);
 }
 
 template <typename CT>
@@ -929,8 +939,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
             const unsigned gw = (unsigned)((nwaves + kBlock / 64 - 1) / (kBlock / 64));
             if (lp->eps_job) {
                 const FusedEps fz = *(const FusedEps *)lp->eps_job;
-                const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
-#define FD_LAZY_FZ4P(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, NCC, PP>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
+#define FD_LAZY_FZ4P(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused4<MODE, NL, NCC, PP>), dim3(fused_grid(k_f_tridiag_fused4<MODE, NL, NCC, PP>, gw, fz.eg.C + fz.nblocks)), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
 #define FD_LAZY_FZ4(MODE, NL)                                                                                                              \
                 do { if (fz.eg.C <= 4) { if (fz.eg.tpb > 2) FD_LAZY_FZ4P(MODE, NL, 4, true); else FD_LAZY_FZ4P(MODE, NL, 4, false); }               \
                      else { if (fz.eg.tpb > 2) FD_LAZY_FZ4P(MODE, NL, kRegColors, true); else FD_LAZY_FZ4P(MODE, NL, kRegColors, false); } } while (0)
@@ -956,8 +965,7 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
             if (lp->eps_job) {
                 // the fused step: this launch also runs the step-size reduction (finisher + reduction workgroups first, see k_f_tridiag_fused)
                 const FusedEps fz = *(const FusedEps *)lp->eps_job;
-                const unsigned gf = (unsigned)fz.eg.C + (unsigned)fz.nblocks + fused_store_blocks(gw, fz.eg.C + fz.nblocks);
-#define FD_LAZY_FZP(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, NCC, PP>), dim3(gf), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
+#define FD_LAZY_FZP(MODE, NL, NCC, PP) hipLaunchKernelGGL((k_f_tridiag_fused<MODE, NL, NCC, PP>), dim3(fused_grid(k_f_tridiag_fused<MODE, NL, NCC, PP>, gw, fz.eg.C + fz.nblocks)), dim3(kBlock), 0, s, (const real_t *)lp->x, b->prm[0], bst, jstart, fz)
 #define FD_LAZY_FZ(MODE, NL)                                                                                                              \
                 do { if (fz.eg.C <= 4) { if (fz.eg.tpb > 2) FD_LAZY_FZP(MODE, NL, 4, true); else FD_LAZY_FZP(MODE, NL, 4, false); }               \
                      else { if (fz.eg.tpb > 2) FD_LAZY_FZP(MODE, NL, kRegColors, true); else FD_LAZY_FZP(MODE, NL, kRegColors, false); } } while (0)

@@ -274,41 +274,41 @@ __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double
     const long long t0 = wall_clock64();
     if (wave == 0) {
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(fz.part + (int64_t)c * nb);
-        constexpr int M = kFzMaxBlocks / 64;       // 16
-        unsigned long long v[M];
         if (t == 0) fz_mark_max(fz, 2);
         const unsigned long long my_peer = (sharded && lane < fz.nranks) ? (unsigned long long)fz.peer[lane] : 0ull;
-        for (;;) {
-            // (eight loads per statement, ONE wait: the compiler waits behind every __hip_atomic_load -- eight dependent round trips
-            //  instead of one, measured: 3.8 us for 512 block sums; lanes past the end re-read the colour's first slot)
-            bool all = true;
+        // (eight loads per statement, ONE wait: the compiler waits behind every __hip_atomic_load -- eight dependent round trips instead of
+        //  one, measured: 3.8 us for 512 block sums; lanes past the end re-read the colour's first slot.  512 block sums per round.)
+        for (int m0 = 0; m0 * 64 < nb; m0 += 8) {
+            unsigned long long v[8];
+            const unsigned long long *q[8];
 #pragma unroll
-            for (int m0 = 0; m0 < M; m0 += 8) {
-                if (m0 * 64 >= nb) break;
-                const unsigned long long *q[8];
+            for (int u = 0; u < 8; ++u) q[u] = src + ((lane + 64 * (m0 + u) < nb) ? lane + 64 * (m0 + u) : 0);
+            for (;;) {
+                fz_load8_agent(q, v);
+                bool all = true;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) q[u] = src + ((lane + 64 * (m0 + u) < nb) ? lane + 64 * (m0 + u) : 0);
-                fz_load8_agent(q, &v[m0]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) all = all && v[m0 + u] != kFzSentinel64;
+                for (int u = 0; u < 8; ++u) all = all && v[u] != kFzSentinel64;
+                if (__all(all)) break;
+                if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (__all(all)) break;
-            if (wall_clock64() - t0 > fz.timeout_ticks) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-            if (lane + 64 * m < nb) lds[lane + 64 * m] = __longlong_as_double((long long)v[m]);
+            for (int u = 0; u < 8; ++u)
+                if (lane + 64 * (m0 + u) < nb) lds[lane + 64 * (m0 + u)] = __longlong_as_double((long long)v[u]);
+        }
         __builtin_amdgcn_wave_barrier();     // (one wavefront: its LDS instructions execute in order)
         if (t == 0) fz_mark_max(fz, 3);
         {
             // (the group's block sums: all LDS reads first, then the additions in block order -- "+ 0.0" past the last block changes nothing)
             const bool own = lane >= fz.g0 && lane < fz.g0 + fz.ng;
-            double w[kEpsBlocksPerGroup];
 #pragma unroll
-            for (int k = 0; k < kEpsBlocksPerGroup; ++k) w[k] = (own && k < bpg) ? lds[(lane - fz.g0) * bpg + k] : 0.0;
+            for (int k0 = 0; k0 < kEpsBlocksPerGroup; k0 += 8) {
+                double w[8];
 #pragma unroll
-            for (int k = 0; k < kEpsBlocksPerGroup; ++k) gs += w[k];
+                for (int k = 0; k < 8; ++k) w[k] = (own && k0 + k < bpg) ? lds[(lane - fz.g0) * bpg + k0 + k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gs += w[k];
+            }
             if (sharded)
                 for (int b = 0; b < fz.nranks; ++b) {
                     // (the peers' mailbox addresses were requested before the wait: lane b holds peer b's)
@@ -361,9 +361,17 @@ __device__ __forceinline__ void fused_finisher(const FusedEps &fz, int c, double
     const bool bad = *s_bad != 0;
     // level 2: the 64 group sums in group order (every lane forms the same total)
     if (!(lane >= fz.g0 && lane < fz.g0 + fz.ng)) gs = gs_peer[lane];
+    gs_peer[lane] = gs;                       // (all 64 group sums side by side: every lane reads them back as broadcasts -- the reads
+    __builtin_amdgcn_wave_barrier();          //  pipeline, 64 cross-lane shuffles do not)
     double tot = 0.0;
 #pragma unroll
-    for (int gg = 0; gg < kEpsGroups; ++gg) tot += __shfl(gs, gg, 64);
+    for (int k0 = 0; k0 < kEpsGroups; k0 += 16) {
+        double w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = gs_peer[k0 + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += w[k];
+    }
     real_t e = eps_rule<real_t>(tot, fz.eg.relstep, fz.eg.absstep, fz.eg.dir, fz.eg.is_forward);
     if (bad) e = fz_from_bits(FzBits<real_t>::sentinel ^ 1);      // (a NaN that is not the sentinel: the storing wavefronts go on and store NaNs)
     __hip_atomic_store(fz.epsr + lane * kFzPitch + c, fz_to_bits(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // replica `lane`
