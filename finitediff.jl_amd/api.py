@@ -190,10 +190,11 @@ class Diagonal(_ThreeDiagonals):
 
 
 class SymTridiagonal(_ThreeDiagonals):
-    """LinearAlgebra.SymTridiagonal(dv, ev): `setindex!` sends BOTH J[i+1,i] and J[i,i+1] to ev[i].  The reference's loop runs colour by
-    colour, so what ev[i] holds afterwards is the LATER colour's write: the upper entry (column i+1) if colorvec[i+1] > colorvec[i],
-    else the lower one (column i) -- reproduced by `_finish` (both are the same number for a symmetric Jacobian, up to the error of the
-    difference quotient)."""
+    """LinearAlgebra.SymTridiagonal(dv, ev) -- an EXTENSION, not reference behaviour: `setindex!(::SymTridiagonal, v, i, j)` throws for
+    i != j, so the reference's generic loop (src/iteration_utils.jl:25-32) cannot fill such a J at all.  Here the two off-diagonal
+    quotients J[i+1,i] and J[i,i+1] are both taken as assignments to ev[i] in the loop's order (colour by colour): ev[i] ends up with the
+    LATER colour's -- the upper entry (column i+1) if colorvec[i+1] > colorvec[i], else the lower one (`_finish`).  For a symmetric
+    Jacobian the two agree up to the error of the difference quotient."""
 
     def __init__(self, dv, ev):
         self.dv, self.ev = dv, ev

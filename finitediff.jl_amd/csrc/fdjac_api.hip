@@ -771,6 +771,13 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                 p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_FUSED_EPS) && store_active(p) && p->store_ok &&
                 (p->kind == K_CSC || p->kind == K_BANDED || p->kind == K_TRIDIAG) && p->nchunks == 1 && full_colors &&
                 !(p->fdtype == FD_FORWARD && fin_dev) && p->d_partial != nullptr;
+    if (shard_ctx && p->halo > 0) {      // (fd_plan_set_halo may run before the mailbox is attached: the rank is known only now)
+        int W = 1, r = 0;
+        eps_shard_of(p, &W, &r);
+        FD_REQUIRE(r == 0 || p->halo_own0 >= p->halo, FD_ERR_ARG, "no room for the lower halo: x[%lld - %lld, ...) starts before 0", (long long)p->halo_own0, (long long)p->halo);
+        FD_REQUIRE(r + 1 >= W || p->halo_own1 + p->halo <= p->N, FD_ERR_ARG, "no room for the upper halo: x[..., %lld + %lld) ends behind N = %lld",
+                   (long long)p->halo_own1, (long long)p->halo, (long long)p->N);
+    }
     bool fuse_sharded = false;
     int fzW = 1, fzr = 0;
     if (fuse && shard_ctx) {
@@ -1248,6 +1255,23 @@ int fd_plan_set_p2p(fd_plan *p, fd_p2p *p2p)
     FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
     FD_REQUIRE(p2p == nullptr || fdjac_p2p_ctx(p2p) == p->ctx, FD_ERR_ARG, "the mailbox belongs to another context");
     FD_REQUIRE(p2p == nullptr || fdjac_p2p_nranks(p2p) <= kMaxEpsShards, FD_ERR_UNSUPPORTED, "more than %d ranks", kMaxEpsShards);
+    if (p2p) {
+        // as fd_plan_set_comm: every rank must cut the SAME global grid and agree on WHETHER its reduction is sharded at all, and -- new in
+        // round 6 -- on whether the step is the fused ONE-launch form (a rank that ran three launches against peers that run one would
+        // wait for data that never comes: its peers write other mailbox cells).  Collective: every rank attaches, in the same order.
+        const bool sh = eps_shardable(p);
+        double mine[8] = {sh ? (double)p->eps_tpg : -1.0, sh ? (double)p->eps_bpg * 65536.0 + (double)p->eps_tpb : -1.0, (double)p->N, (double)p->C,
+                          (double)p->fdtype, (double)sizeof(real_t), 0.0, 0.0};
+        std::vector<double> all((size_t)8 * (size_t)fdjac_p2p_nranks(p2p));
+        const int rc = fdjac_p2p_agree8(p2p, mine, all.data());
+        if (rc) return rc;
+        for (int r = 0; r < fdjac_p2p_nranks(p2p); ++r)
+            for (int k = 0; k < 6; ++k)
+                FD_REQUIRE(all[(size_t)(8 * r + k)] == mine[k], FD_ERR_COMM,
+                           "rank %d disagrees on the step-size reduction (this rank: %s, N = %lld, %lld colours, 64 groups of %d tiles in %d blocks): "
+                           "same N, colours, fdtype, element type and FDJAC_SMALL everywhere?", r, sh ? "sharded" : "replicated", (long long)p->N,
+                           (long long)p->C, p->eps_tpg, p->eps_bpg);
+    }
     p->p2p = p2p;
     return FD_OK;
 }

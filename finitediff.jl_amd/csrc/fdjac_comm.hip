@@ -51,6 +51,8 @@ struct fd_comm {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     fd_p2p *p2p = nullptr;        // fd_comm_enable_p2p: small messages go through the peer-to-peer mailbox (fdjac_p2p.hip), owned by the communicator
+    char *d_small = nullptr;      // nranks x 64 bytes of device scratch (>= 64), allocated with the communicator: the collectives of the attach-time
+                                  // agreements never allocate, so no rank can drop out of one between its peers' calls
 };
 extern "C" int64_t fdjac_p2p_slot_bytes(const fd_p2p *p);
 
@@ -168,11 +170,16 @@ int fd_comm_create(fd_ctx *ctx, int nranks, int rank, const void *id, fd_comm **
     c->ctx = ctx;
     c->nranks = nranks;
     c->rank = rank;
+    {
+        const hipError_t e = hipMalloc((void **)&c->d_small, (size_t)(nranks > 1 ? nranks : 1) * FD_P2P_HANDLE_BYTES);
+        if (e != hipSuccess) { set_error("fd_comm_create: hipMalloc failed: %s", hipGetErrorString(e)); delete c; return FD_ERR_HIP; }
+    }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     ncclResult_t r = R->CommInitRank(&c->comm, nranks, uid, rank);
     if (r != ncclSuccess) {
         set_error("ncclCommInitRank(nranks=%d, rank=%d) failed: %s", nranks, rank, R->GetErrorString(r));
+        (void)hipFree(c->d_small);
         delete c;
         return FD_ERR_COMM;
     }
@@ -190,6 +197,7 @@ int fd_comm_destroy(fd_comm *c)
         (void)R->CommDestroy(c->comm);
     }
     if (c->p2p) (void)fd_p2p_destroy(c->p2p);
+    if (c->d_small) (void)hipFree(c->d_small);
     delete c;
     return FD_OK;
 }
@@ -199,28 +207,27 @@ int fd_comm_enable_p2p(fd_comm *c, int64_t slot_bytes)
     FD_REQUIRE(c != nullptr, FD_ERR_ARG, "comm is NULL");
     FD_REQUIRE(c->p2p == nullptr, FD_ERR_ARG, "the communicator has a mailbox already");
     const Rccl *R = rccl();
-    if (!R) return FD_ERR_COMM;
-    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
-    // collective: a rank whose local set-up fails still takes part in the two exchanges below (carrying its failure in rc), so that
-    // no rank is left waiting inside RCCL and every rank falls back together
+    if (!R) return FD_ERR_COMM;      // (a communicator exists only where RCCL was found: every rank or none)
+    // collective: a rank whose local set-up fails -- selecting the device, creating its mailbox -- still takes part in the two
+    // exchanges below (carrying its failure in rc), so that no rank is left waiting inside RCCL and every rank falls back together;
+    // nothing is allocated on the way (the communicator's own scratch carries the handles)
     fd_p2p *p = nullptr;
-    int rc = fd_p2p_create(c->ctx, c->nranks, c->rank, slot_bytes, &p);
+    int rc = FD_OK;
+    if (hipSetDevice(c->ctx->device) != hipSuccess) { set_error("fd_comm_enable_p2p: hipSetDevice(%d) failed", c->ctx->device); rc = FD_ERR_HIP; }
+    if (!rc) rc = fd_p2p_create(c->ctx, c->nranks, c->rank, slot_bytes, &p);
     char first_error[512];
     snprintf(first_error, sizeof first_error, "%s", rc ? fd_last_error() : "");
     // the handles travel over the communicator itself: one small in-place all-gather
-    char *d_h = nullptr;
+    char *d_h = c->d_small;
     std::vector<char> h((size_t)c->nranks * FD_P2P_HANDLE_BYTES, 0);
-    hipError_t e = hipMalloc((void **)&d_h, h.size());
-    if (e != hipSuccess) { set_error("fd_comm_enable_p2p: hipMalloc failed: %s", hipGetErrorString(e)); if (p) (void)fd_p2p_destroy(p); return FD_ERR_HIP; }
     if (!rc) rc = fd_p2p_local_handle(p, h.data() + (size_t)c->rank * FD_P2P_HANDLE_BYTES);
-    e = hipMemcpyAsync(d_h, h.data(), h.size(), hipMemcpyHostToDevice, c->ctx->stream);
+    hipError_t e = hipMemcpyAsync(d_h, h.data(), h.size(), hipMemcpyHostToDevice, c->ctx->stream);
     {
         const ncclResult_t r = R->AllGather(d_h + (size_t)c->rank * FD_P2P_HANDLE_BYTES, d_h, FD_P2P_HANDLE_BYTES, ncclUint8, c->comm, c->ctx->stream);
         if (r != ncclSuccess && !rc) { set_error("exchanging the mailbox handles failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_h, h.size(), hipMemcpyDeviceToHost, c->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
-    (void)hipFree(d_h);
     if (e != hipSuccess && !rc) { set_error("exchanging the mailbox handles failed: %s", hipGetErrorString(e)); rc = FD_ERR_HIP; }
     if (!rc) rc = fd_p2p_connect(p, h.data());
     if (rc && !first_error[0]) snprintf(first_error, sizeof first_error, "%s", fd_last_error());
@@ -411,18 +418,17 @@ int fdjac_comm_allreduce_max4(fd_comm *c, const double *mine, double *out)
     FD_REQUIRE(c && mine && out, FD_ERR_ARG, "NULL argument");
     const Rccl *R = rccl();
     if (!R) return FD_ERR_COMM;
-    FD_HIP_CHECK(hipSetDevice(c->ctx->device));
-    double *d = nullptr;
-    FD_HIP_CHECK(hipMalloc((void **)&d, 4 * sizeof(double)));
+    // (no early return and no allocation before the collective: every rank enters it, whatever happened to it locally)
     int rc = FD_OK;
+    if (hipSetDevice(c->ctx->device) != hipSuccess) rc = FD_ERR_HIP;
+    double *d = reinterpret_cast<double *>(c->d_small);
     if (hipMemcpyAsync(d, mine, 4 * sizeof(double), hipMemcpyHostToDevice, c->ctx->stream) != hipSuccess) rc = FD_ERR_HIP;
-    if (!rc) {
+    {
         const ncclResult_t r = R->AllReduce(d, d, 4, ncclFloat64, ncclMax, c->comm, c->ctx->stream);
-        if (r != ncclSuccess) { set_error("ncclAllReduce(max) failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
+        if (r != ncclSuccess && !rc) { set_error("ncclAllReduce(max) failed: %s", R->GetErrorString(r)); rc = FD_ERR_COMM; }
     }
     if (!rc && (hipMemcpyAsync(out, d, 4 * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(c->ctx->stream) != hipSuccess)) { set_error("fd_plan_set_comm: reading the grid check back failed"); rc = FD_ERR_HIP; }
-    (void)hipFree(d);
     return rc;
 }
 int fdjac_comm_nranks(const fd_comm *c) { return c ? c->nranks : 1; }

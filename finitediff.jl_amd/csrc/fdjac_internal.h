@@ -121,7 +121,8 @@ extern "C" int fdjac_p2p_fused_begin(fd_p2p *p, fdjac_p2p_fused *out);      // (
 extern "C" void fdjac_p2p_fused_commit(fd_p2p *p);
 extern "C" int fdjac_p2p_shared_device(const fd_p2p *p);      // 1: some peer lives on this rank's device (no fused sharded step then)
 extern "C" int fdjac_p2p_failed(const fd_p2p *p);
-extern "C" int *fdjac_p2p_err_word(const fd_p2p *p);    // (device address)       // the mailbox's sticky error word (a wait timed out)
+extern "C" int *fdjac_p2p_err_word(const fd_p2p *p);    // (device address)
+extern "C" int fdjac_p2p_agree8(fd_p2p *p, const double *mine, double *out);      // blocking all-gather of 8 doubles per rank (host arrays)       // the mailbox's sticky error word (a wait timed out)
 
 // error text: one thread-local buffer for both instantiations (defined by the Float64 build)
 extern "C" void fdjac_set_error_v(const char *fmt, va_list ap);

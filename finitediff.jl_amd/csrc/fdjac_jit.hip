@@ -98,7 +98,9 @@ struct JitModule {
     std::string real;                                  // "double" / "float"
     unsigned sizeof_f = 0;
     int refs = 0;
-    std::string key;
+    std::string key;              // device ordinal + '\n' + source: a hipModule_t belongs to the device that was current when it was loaded
+    std::string text;             // the source alone (band_function compiles more instantiations from it)
+    int device = 0;
 };
 static std::map<std::string, JitModule *> g_modules;
 
@@ -116,7 +118,8 @@ static hipFunction_t band_function(JitModule *m, int l, int u, int central)
     const Hiprtc *R = hiprtc();
     if (!R) return nullptr;
     hiprtcProgram prog = nullptr;
-    if (R->CreateProgram(&prog, m->key.c_str(), "fdjac_jit_band.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
+    if (hipSetDevice(m->device) != hipSuccess) return nullptr;       // (the extra module must live where the functor's first module does)
+    if (R->CreateProgram(&prog, m->text.c_str(), "fdjac_jit_band.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return nullptr;
     std::string names[2];
     for (int md = 0; md < 2; ++md) {
         names[md] = "fd_band_store_cols<" + m->real + ", " + (md ? "1" : "0") + ", fdjit_F, " + std::to_string(l) + ", " + std::to_string(u) + ">";
@@ -277,10 +280,12 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     src += functor;
     src += "\n";
     src += kJitTail;
+    // (modules are per DEVICE: a second context on another GPU compiling the same text must not get device 0's functions)
+    const std::string key = std::to_string(ctx->device) + "\n" + src;
     JitModule *m = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_jit_mutex);
-        auto it = g_modules.find(src);
+        auto it = g_modules.find(key);
         if (it != g_modules.end()) { m = it->second; m->refs += 1; }
     }
     if (!m) {
@@ -365,15 +370,17 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
         }
         (void)hipGetLastError();
         std::lock_guard<std::mutex> lock(g_jit_mutex);
-        auto it = g_modules.find(src);
+        auto it = g_modules.find(key);
         if (it != g_modules.end()) {       // (another thread compiled the same text meanwhile: keep theirs)
             (void)hipModuleUnload(m->mod);
             delete m;
             m = it->second;
         } else {
-            m->key = src;
+            m->key = key;
+            m->text = src;
+            m->device = ctx->device;
             m->real = real;
-            g_modules[src] = m;
+            g_modules[key] = m;
         }
         m->refs += 1;
     }

@@ -72,6 +72,7 @@ struct fd_p2p {
     char *peer[kP2PMaxRanks] = {};            // the mailboxes as mapped here (peer[rank] == local)
     bool mapped[kP2PMaxRanks] = {};
     char **d_peer = nullptr;                  // device copy of peer[]
+    double *d_scratch = nullptr;              // nranks x 8 doubles: the attach-time agreement of the plans (fd_plan_set_p2p) is exchanged through it
     unsigned *d_arrived = nullptr;            // per-peer share counters of a put split over several workgroups (zero between launches);
                                               // [kP2PMaxRanks]: the arrival ticket of the step exchange's workgroups
     int *d_err = nullptr;                     // device error word (pinned host memory mapped to the device: readable without a sync)
@@ -377,6 +378,7 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_err, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *p->h_err = 0; e = hipHostGetDevicePointer((void **)&p->d_err, p->h_err, 0); }
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_peer, sizeof(char *) * kP2PMaxRanks);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_scratch, sizeof(double) * 8 * (size_t)nranks);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_arrived, sizeof(unsigned) * (kP2PMaxRanks + 1));
     if (e == hipSuccess) e = hipMemset(p->d_arrived, 0, sizeof(unsigned) * (kP2PMaxRanks + 1));
     if (e != hipSuccess) {
@@ -384,6 +386,7 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
         if (p->h_err) (void)hipHostFree(p->h_err);
         if (p->d_peer) (void)hipFree(p->d_peer);
         if (p->d_arrived) (void)hipFree(p->d_arrived);
+        if (p->d_scratch) (void)hipFree(p->d_scratch);
         if (p->uncached) unc_park(p->local_bytes, p->local); else (void)hipFree(p->local);
         delete p;
         return FD_ERR_HIP;
@@ -513,6 +516,7 @@ int fd_p2p_destroy(fd_p2p *p)
         if (p->mapped[r] && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
     if (p->d_peer) (void)hipFree(p->d_peer);
     if (p->d_arrived) (void)hipFree(p->d_arrived);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->h_err) (void)hipHostFree(p->h_err);
     if (p->local) { if (p->uncached) unc_park(p->local_bytes, p->local); else (void)hipFree(p->local); }
     delete p;
@@ -647,6 +651,25 @@ extern "C" int fdjac_p2p_fused_begin(fd_p2p *p, fdjac_p2p_fused *out)
 }
 extern "C" void fdjac_p2p_fused_commit(fd_p2p *p) { if (p) ++p->fz_epoch; }
 extern "C" int fdjac_p2p_shared_device(const fd_p2p *p) { return (p && p->shared_device) ? 1 : 0; }
+// every rank's 8 doubles to every rank (blocking; the attach-time agreement of fd_plan_set_p2p): out = nranks x 8 doubles, host.
+// A loop-back mailbox has nobody to agree with: out is filled with `mine`.
+extern "C" int fdjac_p2p_agree8(fd_p2p *p, const double *mine, double *out)
+{
+    FD_REQUIRE(p && mine && out, FD_ERR_ARG, "NULL argument");
+    if (p->sink || p->nranks == 1) {
+        for (int r = 0; r < p->nranks; ++r) memcpy(out + 8 * r, mine, 64);
+        return FD_OK;
+    }
+    FD_HIP_CHECK(hipSetDevice(p->ctx->device));
+    FD_HIP_CHECK(hipMemcpyAsync(p->d_scratch + 8 * p->rank, mine, 64, hipMemcpyHostToDevice, p->ctx->stream));
+    const int rc = fd_p2p_allgather(p, p->d_scratch, 64);
+    if (rc) return rc;
+    FD_HIP_CHECK(hipMemcpyAsync(out, p->d_scratch, 64 * (size_t)p->nranks, hipMemcpyDeviceToHost, p->ctx->stream));
+    FD_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));
+    const int st = *(volatile int *)p->h_err;
+    FD_REQUIRE(st == 0, FD_ERR_COMM, "rank %d never took part in the agreement (is fd_plan_set_p2p called on every rank, in the same order?)", st - 1);
+    return FD_OK;
+}
 extern "C" int *fdjac_p2p_err_word(const fd_p2p *p) { return p ? p->d_err : nullptr; }
 extern "C" int fdjac_p2p_failed(const fd_p2p *p) { return (p && p->h_err) ? *(volatile int *)p->h_err : 0; }
 

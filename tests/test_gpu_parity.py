@@ -191,8 +191,9 @@ def test_storing_launch_into_bandedblockbanded_data(oracle, fdtype, family, nx, 
 @pytest.mark.parametrize("kind", ["bidiag_U", "bidiag_L", "diagonal", "symtridiag"])
 def test_other_structured_types_of_the_generic_loop(oracle, kind, fdtype):
     # Bidiagonal / Diagonal / SymTridiagonal J (src/jacobians.jl:524-525 + src/iteration_utils.jl:25-32 through their setindex!): the
-    # oracle's generic COO loop over the type's structural non-zeros; SymTridiagonal's ev[i] receives BOTH J[i+1,i] and J[i,i+1] -- the
-    # later colour's write stays (restated literally below)
+    # oracle's generic COO loop over the type's structural non-zeros.  SymTridiagonal is this library's EXTENSION (LinearAlgebra's
+    # setindex! throws off the diagonal: the reference cannot fill one): ev[i] receives BOTH J[i+1,i] and J[i,i+1] in the loop's order --
+    # the later colour's write stays (the rule is restated literally below; there is no reference behaviour to compare with)
     N = 257
     rng = np.random.default_rng(21)
     x = rng.random(N) + 0.2
