@@ -9,6 +9,8 @@
 
 #include <atomic>
 #include <thread>
+#include <string>
+
 #include "fdjac_internal.h"
 #include "fdjac_eps_dev.h"
 
@@ -647,9 +649,19 @@ static int eps_exchange(fd_plan *p, real_t *x_dev, int S, double relstep, double
 static inline int call_f(const fd_plan *p, fd_f_launch f, void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride,
                          int64_t fx_stride, int64_t row_begin, int64_t row_end, int is_complex, void *stream)
 {
+    set_error("%s", "");      // (a launcher of this library says WHY it failed in the error text: FD_F_CHECK passes it on)
     if (!p->cx) return f(fctx, fx, x, nbatch, x_stride, fx_stride, row_begin, row_end, is_complex, stream);
     return f(fctx, fx, x, nbatch, x_stride / 2, fx_stride / 2, row_begin / 2, (row_end + 1) / 2, 1, stream);
 }
+// a failed f! launch: its return code and, if the launcher left one (the runtime-compiled functors do), its own message
+#define FD_F_CHECK(rc)                                                                                                      \
+    do {                                                                                                                    \
+        if ((rc) != 0) {                                                                                                    \
+            const std::string _why = fd_last_error();                                                                       \
+            set_error("f! launcher returned %d%s%s", (int)(rc), _why.empty() ? "" : ": ", _why.c_str());                    \
+            return FD_ERR_CALLBACK;                                                                                         \
+        }                                                                                                                   \
+    } while (0)
 
 // the step sizes of a sharded call in separate launches (what a call does when its storing launch cannot carry the reduction):
 // this rank's GROUPS of the two-level sum (the part of x it owns), then ONE exchange -- the group sums of every rank (64 / W x 8
@@ -863,7 +875,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         } else {
             Span sp(p, FD_STAGE_F);
             const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
-            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+            FD_F_CHECK(rc);
             p->fcalls_last += 1;
             fx = p->d_fx;
         }
@@ -989,7 +1001,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             if (base_pending && !own_base) {
                 Span sp(p, FD_STAGE_F);
                 const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
-                FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+                FD_F_CHECK(rc);
                 p->fcalls_last += 1;
                 base_pending = false;
             }
@@ -1065,7 +1077,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             if (base_pending) {   // the lazy launcher declined the batch that would have carried f(x)
                 Span sp(p, FD_STAGE_F);
                 const int rc = call_f(p, f, fctx, p->d_fx, x_dev, 1, p->N, p->ldf, p->row0, p->row1, 0, (void *)s);
-                FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+                FD_F_CHECK(rc);
                 p->fcalls_last += 1;
                 base_pending = false;
             }
@@ -1079,7 +1091,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             const int64_t npts = (int64_t)B * p->pts + (base_in_batch ? 1 : 0);   // (+ x itself: f(x) of the forward arm)
             const int rc = call_f(p, f, fctx, p->d_FX, p->d_X, npts, p->ldx, p->ldf, p->row0, p->row1,
                              p->fdtype == FD_COMPLEX ? 1 : 0, (void *)s);
-            FD_REQUIRE(rc == 0, FD_ERR_CALLBACK, "f! launcher returned %d", rc);
+            FD_F_CHECK(rc);
             p->fcalls_last += npts;
         }
         {

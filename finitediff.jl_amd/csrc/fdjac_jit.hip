@@ -95,6 +95,15 @@ struct JitModule {
         bool failed = false;
     };
     std::map<std::pair<int, int>, BandExtra> extra;
+    // the complex step (src/jacobians.jl:623-648): the functor instantiated on fd_cplx<T> -- compiled when first asked for (a functor that
+    // names the element type explicitly is fine for forward / central differences and fails HERE, with the compiler's message)
+    struct Cplx {
+        hipModule_t mod = nullptr;
+        hipFunction_t rows = nullptr;                  // fdjit_rows_cplx: the plain launcher on materialised complex points
+        hipFunction_t store[2] = {nullptr, nullptr};   // fd_csc_store_cols_cplx: [colour bytes == 4]
+        bool tried = false, ok = false;
+        std::string log;
+    } cplx;
     std::string real;                                  // "double" / "float"
     unsigned sizeof_f = 0;
     int refs = 0;
@@ -144,6 +153,58 @@ static hipFunction_t band_function(JitModule *m, int l, int u, int central)
     return x.fn[central];
 }
 
+static const char kJitTailCplx[] = R"FDJIT(
+extern "C" __global__ void __launch_bounds__(256) fdjit_rows_cplx(real_t *__restrict__ fx, const real_t *__restrict__ x, fdjit_F f, long long xs,
+                                                                  long long fs, long long r0, long long r1)
+{
+    const long long r = r0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= r1) return;
+    const fd_cplx_plain_point<real_t> P = {x + 2 * (long long)blockIdx.y * xs};
+    const fd_cplx<real_t> v = f(r, P);
+    fx[2 * ((long long)blockIdx.y * fs + r)] = v.re;
+    fx[2 * ((long long)blockIdx.y * fs + r) + 1] = v.im;
+}
+)FDJIT";
+
+// the complex instantiation of the module's functor (one more compilation, kept with the module); nullptr-safe: m->cplx.ok says whether it exists
+static bool cplx_functions(JitModule *m)
+{
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    JitModule::Cplx &x = m->cplx;
+    if (x.tried) return x.ok;
+    x.tried = true;
+    const Hiprtc *R = hiprtc();
+    if (!R || hipSetDevice(m->device) != hipSuccess) return false;
+    const std::string src = m->text + kJitTailCplx;
+    hiprtcProgram prog = nullptr;
+    if (R->CreateProgram(&prog, src.c_str(), "fdjac_jit_cplx.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
+    const char *ct[2] = {"unsigned char", "int"};
+    std::string names[2];
+    for (int cb = 0; cb < 2; ++cb) {
+        names[cb] = "fd_csc_store_cols_cplx<" + m->real + ", " + ct[cb] + ", fdjit_F>";
+        (void)R->AddNameExpression(prog, names[cb].c_str());
+    }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
+    bool ok = R->CompileProgram(prog, 5, opts) == HIPRTC_SUCCESS;
+    size_t ls = 0;
+    if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { x.log.resize(ls); (void)R->GetProgramLog(prog, &x.log[0]); }
+    size_t cs = 0;
+    std::vector<char> code;
+    if (ok && R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) { code.resize(cs); ok = R->GetCode(prog, code.data()) == HIPRTC_SUCCESS; } else ok = false;
+    std::string low[2];
+    for (int cb = 0; cb < 2 && ok; ++cb) {
+        const char *ln = nullptr;
+        if (R->GetLoweredName(prog, names[cb].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[cb] = ln; else ok = false;
+    }
+    (void)R->DestroyProgram(&prog);
+    if (!ok || hipModuleLoadData(&x.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ok = hipModuleGetFunction(&x.rows, x.mod, "fdjit_rows_cplx") == hipSuccess;
+    for (int cb = 0; cb < 2 && ok; ++cb) ok = hipModuleGetFunction(&x.store[cb], x.mod, low[cb].c_str()) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    x.ok = ok;
+    return ok;
+}
+
 }  // namespace fdjac
 
 struct fd_jit_f {
@@ -160,6 +221,7 @@ namespace fdjac {
 static const char kJitTail[] = R"FDJIT(
 typedef FDJIT_FUNCTOR fdjit_F;
 struct fdjit_plain {
+    typedef real_t value_type;
     const real_t *x;
     __device__ real_t operator()(long long j) const { return x[j]; }
 };
@@ -178,11 +240,17 @@ static int jit_launch(void *fctx, void *fx, const void *x, int64_t nbatch, int64
                       int64_t row_end, int is_complex, void *stream)
 {
     fd_jit_f *j = (fd_jit_f *)fctx;
-    if (is_complex || row_end <= row_begin || nbatch < 1) return is_complex ? 3 : 0;
-    long long xs = x_stride, fs = fx_stride, r0 = row_begin, r1 = row_end;
+    if (row_end <= row_begin || nbatch < 1) return 0;
+    if (is_complex && !cplx_functions(j->m)) {
+        set_error("the functor does not compile for the complex step -- write its call operator on `typename P::value_type` (include/fdjac_device.h, "
+                  "\"the complex step for row functors\").  Compiler: %.300s", j->m->cplx.log.c_str());
+        t_log = j->m->cplx.log;
+        return 3;
+    }
+    long long xs = x_stride, fs = fx_stride, r0 = row_begin, r1 = row_end;      // (complex points: strides and rows in complex elements)
     void *args[] = {&fx, (void *)&x, (void *)j->params.data(), &xs, &fs, &r0, &r1};
     const unsigned gx = (unsigned)((row_end - row_begin + 255) / 256);
-    if (hipModuleLaunchKernel(j->m->rows, gx, (unsigned)nbatch, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+    if (hipModuleLaunchKernel(is_complex ? j->m->cplx.rows : j->m->rows, gx, (unsigned)nbatch, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
     j->launches += 1;
     return 0;
 }
@@ -211,7 +279,22 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
         j->launches += 1;
         return 0;
     }
-    if (!lp->store || lp->store_kind != FD_STORE_CSC || lp->is_complex) return FD_LAZY_DECLINED;
+    if (!lp->store || lp->store_kind != FD_STORE_CSC) return FD_LAZY_DECLINED;
+    if (lp->is_complex) {
+        // the complex step through the column store (FD_LAZY_CAP_STORE_CSC_COMPLEX): every stored entry's row at x + i eps e_j, imag / eps
+        fd_csc_store stc = *(const fd_csc_store *)lp->store;
+        if (stc.elem_bytes != j->elem_bytes || (stc.color_bytes != 1 && stc.color_bytes != 4) || stc.M != j->M || stc.N != j->N || stc.col_end <= stc.col_begin)
+            return FD_LAZY_DECLINED;
+        if (!cplx_functions(j->m)) return FD_LAZY_DECLINED;      // (the hand-over path's plain launcher then reports why)
+        const long long nb = (stc.col_end - stc.col_begin + 255) / 256;
+        int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
+        const void *xq = lp->x, *eq = lp->eps;
+        void *args[] = {(void *)j->params.data(), (void *)&xq, (void *)&eq, &c_lo, &c_hi, &stc};
+        if (hipModuleLaunchKernel(j->m->cplx.store[stc.color_bytes == 4 ? 1 : 0], (unsigned)(8 * ((nb + 7) / 8)), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args,
+                                  nullptr) != hipSuccess) return 4;
+        j->launches += 1;
+        return 0;
+    }
     fd_csc_store st = *(const fd_csc_store *)lp->store;
     if (st.elem_bytes != j->elem_bytes || (st.color_bytes != 1 && st.color_bytes != 4) || st.M != j->M || st.N != j->N || st.col_end <= st.col_begin)
         return FD_LAZY_DECLINED;
@@ -244,6 +327,7 @@ static void release_module(JitModule *m)
     g_modules.erase(m->key);
     for (auto &kv : m->extra)
         if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    if (m->cplx.mod) (void)hipModuleUnload(m->cplx.mod);
     if (m->mod) (void)hipModuleUnload(m->mod);
     delete m;
 }
@@ -398,7 +482,7 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     *fn_out = jit_launch;
     if (lazy_out) *lazy_out = jit_launch_lazy;
     // (FD_LAZY_CAP_STORE: exact bands of width (1, 1) / (2, 2) through fd_band_store_cols; every other storing request is declined)
-    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | ((m->band[0][0] || m->band[1][0]) ? FD_LAZY_CAP_STORE : 0);
+    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | FD_LAZY_CAP_STORE_CSC_COMPLEX | ((m->band[0][0] || m->band[1][0]) ? FD_LAZY_CAP_STORE : 0);
     *fctx_out = j;
     return FD_OK;
 }

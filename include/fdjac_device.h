@@ -509,6 +509,7 @@ template <typename T> __device__ inline void fd_colrange_emit(const fd_colrange_
  * MODE 0: forward (st.fx_base = f(x)), 1: central.  Columns whose colour lies outside [c_lo, c_hi) are skipped (colour chunks /
  * ownership); columns without a colour are written as 0 when c_lo == 0 (fill_matrix!, src/jacobians.jl:530-532). */
 template <typename T, typename CT> struct fd_colour_point {
+    typedef T value_type;      /* what X(j) yields: a functor generic in it (`typename P::value_type`, `auto`) also serves the complex step */
     const T *x;
     const CT *color;
     int c;          /* 0-based colour of the point */
@@ -524,6 +525,7 @@ template <typename T, typename CT> struct fd_colour_point {
 };
 /* the same point when the colouring is known to be valid (fd_csc_store.valid_coloring): only coordinate j is perturbed */
 template <typename T> struct fd_column_point {
+    typedef T value_type;
     const T *x;
     long long j;
     T e;
@@ -671,6 +673,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols(F f, const T *__restric
    aperture check -- where ds_read is meant (measured: the first form of this kernel issued 140 flat loads and 3 LDS reads) */
 #define FD_LDS_PTR(T) __attribute__((address_space(3))) T *
 template <typename T> struct fd_window_column_point {
+    typedef T value_type;
     const T *x;         /* global x */
     const FD_LDS_PTR(T) wx;        /* LDS copy of x[w0, w1) */
     long long w0, w1;
@@ -912,6 +915,98 @@ __global__ void __launch_bounds__(256) fd_band_store_cols(F f, const T *__restri
         }
     }
     fd_band_emit_wave<T, W>(&st, s_emit[wave], jw, q);
+}
+
+/* ---- the complex step for row functors (src/jacobians.jl:623-648) ---------------------------------------------------------------------
+ * J[:, j] = imag(f(x + i eps e_j)) / eps with eps = eps(T), no subtraction.  A functor serves it if its call operator is generic in the
+ * VALUE TYPE of the point -- `template <class P> __device__ typename P::value_type operator()(long long r, const P &X) const`, its
+ * arithmetic written on `typename P::value_type` instead of the element type: X(j) then yields fd_cplx<T> and the row is evaluated in
+ * complex arithmetic (the operators below: the products and sums of Julia's Complex; sin / cos / exp by their real formulas).
+ * fd_csc_store_cols_cplx is fd_csc_store_cols for that step: every stored entry's row at x + i eps e_j (any colouring: at the colour's
+ * point), imag / eps stored.  Launch as fd_csc_store_cols.  A functor that names the element type explicitly still compiles for
+ * forward / central differences; the complex instantiation is compiled separately (fd_f_compile_rows: on first use). */
+template <typename T> struct fd_cplx { T re, im; };
+template <typename T> __device__ inline fd_cplx<T> operator+(fd_cplx<T> a, fd_cplx<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator-(fd_cplx<T> a, fd_cplx<T> b) { return {a.re - b.re, a.im - b.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator-(fd_cplx<T> a) { return {-a.re, -a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator*(fd_cplx<T> a, fd_cplx<T> b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <typename T> __device__ inline fd_cplx<T> operator/(fd_cplx<T> a, fd_cplx<T> b)
+{
+    const T d = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+template <typename T> __device__ inline fd_cplx<T> operator+(fd_cplx<T> a, T s) { return {a.re + s, a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator+(T s, fd_cplx<T> a) { return {s + a.re, a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator-(fd_cplx<T> a, T s) { return {a.re - s, a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator-(T s, fd_cplx<T> a) { return {s - a.re, -a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator*(T s, fd_cplx<T> a) { return {s * a.re, s * a.im}; }
+template <typename T> __device__ inline fd_cplx<T> operator*(fd_cplx<T> a, T s) { return {a.re * s, a.im * s}; }
+template <typename T> __device__ inline fd_cplx<T> operator/(fd_cplx<T> a, T s) { return {a.re / s, a.im / s}; }
+template <typename T> __device__ inline fd_cplx<T> sin(fd_cplx<T> a) { return {sin(a.re) * cosh(a.im), cos(a.re) * sinh(a.im)}; }
+template <typename T> __device__ inline fd_cplx<T> cos(fd_cplx<T> a) { return {cos(a.re) * cosh(a.im), -(sin(a.re) * sinh(a.im))}; }
+template <typename T> __device__ inline fd_cplx<T> exp(fd_cplx<T> a) { const T m = exp(a.re); return {m * cos(a.im), m * sin(a.im)}; }
+/* the colour's complex point x + i e m_c; with a valid colouring only coordinate j carries the step */
+template <typename T, typename CT> struct fd_cplx_colour_point {
+    typedef fd_cplx<T> value_type;
+    const T *x;
+    const CT *color;
+    int c;
+    T e;
+    __device__ fd_cplx<T> operator()(long long j) const { return fd_cplx<T>{x[j], ((int)color[j] == c) ? e : (T)0}; }
+};
+template <typename T> struct fd_cplx_column_point {
+    typedef fd_cplx<T> value_type;
+    const T *x;
+    long long j;
+    T e;
+    __device__ fd_cplx<T> operator()(long long i) const { return fd_cplx<T>{x[i], i == j ? e : (T)0}; }
+};
+/* a materialised complex point: (re, im) pairs */
+template <typename T> struct fd_cplx_plain_point {
+    typedef fd_cplx<T> value_type;
+    const T *x;
+    __device__ fd_cplx<T> operator()(long long j) const { return fd_cplx<T>{x[2 * j], x[2 * j + 1]}; }
+};
+template <typename T, typename CT, class F>
+__global__ void __launch_bounds__(256) fd_csc_store_cols_cplx(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st)
+{
+    __shared__ __attribute__((aligned(16))) T s_win[256 / 64][FD_CSC_WAVE_CAP];
+    const long long nblk = (st.col_end - st.col_begin + 255) / 256, blk = fd_xcd_block(blockIdx.x, nblk);
+    if (blk >= nblk) return;
+    const long long j = st.col_begin + blk * 256 + threadIdx.x;
+    const bool in = j < st.col_end;
+    const int a = in ? st.colptr[j - st.col_begin] : st.colptr[st.col_end - st.col_begin];
+    const int b = in ? st.colptr[j - st.col_begin + 1] : a;
+    const CT *color = (const CT *)st.color;
+    const int c = in ? (int)color[j] : 0;
+    const bool none = in && c == (int)(CT)(-1);
+    const bool mine = in && !none && c >= c_lo && c < c_hi;
+    fd_csc_wave_run<T> run;
+    run.begin((T *)st.out, s_win[threadIdx.x >> 6], a, b, !in || mine || (none && c_lo == 0));
+    if (none && c_lo == 0)
+        for (int q = a; q < b; ++q) run.put(q, (T)0);
+    if (mine) {
+        const T h = eps[c];
+        constexpr int U = 4;
+        for (int q0 = a; q0 < b; q0 += U) {
+            long long r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = st.rowval[q0 + u < b ? q0 + u : b - 1];
+            T v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u >= b) { v[u] = 0; continue; }
+                fd_cplx<T> w;
+                if (st.valid_coloring) { const fd_cplx_column_point<T> X = {x, j, h}; w = f(r[u], X); }
+                else { const fd_cplx_colour_point<T, CT> X = {x, color, c, h}; w = f(r[u], X); }
+                v[u] = w.im / h;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q0 + u < b) run.put(q0 + u, v[u]);
+        }
+    }
+    run.template flush<true>();
 }
 #endif /* __HIPCC__ && __cplusplus */
 

@@ -283,3 +283,78 @@ def test_jit_band_store_on_a_column_window(fdtype, window):
             assert plan.info(fd.lib.INFO_LAZY_STORE) == 1
         outs.append(out)
     assert not torch.isnan(outs[1]).any() and torch.equal(outs[0].view(torch.int64), outs[1].view(torch.int64))
+
+
+TRIDIAG_NL_GENERIC = """
+// the same residual, generic in the VALUE TYPE of the point (include/fdjac_device.h, "the complex step for row functors"): X(j) yields
+// real_t for forward / central differences and fd_cplx<real_t> for the complex step
+struct TridiagNLg {
+    long long n;
+    template <class P> __device__ typename P::value_type operator()(long long i, const P &X) const
+    {
+        typedef typename P::value_type V;
+        const V xi = X(i), xm = X(i > 0 ? i - 1 : i), xp = X(i + 1 < n ? i + 1 : i);
+        const V a = i > 0 ? xm : V{}, b = i + 1 < n ? xp : V{};
+        V v = (a - (real_t)2 * xi) + b;
+        v = v + (xi * xi) * b;
+        return v;
+    }
+};
+"""
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_jit_complex_step_opaque_and_column_store(oracle, dtype):
+    # src/jacobians.jl:623-648 for a runtime-compiled functor: the functor's complex instantiation is compiled on first use -- as a
+    # plain launcher on materialised complex points (the opaque route) and as fd_csc_store_cols_cplx (ONE launch: every stored entry's
+    # row at x + i eps e_j, imag / eps).  Bits of the built-in family's complex step; the oracle to the stated tolerance; the same
+    # functor still serves forward differences; a functor that names real_t explicitly is refused for the complex step with a message.
+    N = 100_003
+    t = torch.float64 if dtype == np.float64 else torch.float32
+    colptr, rowval = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    xh = np.random.default_rng(8).random(N).astype(dtype)
+    x = torch.as_tensor(xh, device="cuda")
+    fb = fd.BuiltinF("tridiag_nl", N, dtype=dtype)
+    ref_plan = fd.make_plan(J, J, colors, "complex", dtype=dtype)
+    ref_plan.set_lazy(fb)
+    ref = torch.full((rowval.size,), float("nan"), dtype=t, device="cuda")
+    ref_plan.jacobian(fb, x, [ref])
+    fj = fd.JitF(TRIDIAG_NL_GENERIC, "TridiagNLg", N, N, params=struct.pack("q", N), dtype=dtype)
+    assert fj.lazy_caps & fd.lib.LAZY_CAP_STORE_CSC_COMPLEX
+    # (1) opaque
+    p1 = fd.make_plan(J, J, colors, "complex", dtype=dtype)
+    o1 = torch.full_like(ref, float("nan"))
+    p1.jacobian(fj, x, [o1])
+    assert p1.fcalls_last == 3
+    assert torch.equal(o1, ref)
+    # (2) ONE launch through the column store
+    p2 = fd.make_plan(J, J, colors, "complex", dtype=dtype, store_csc_always=True)
+    p2.set_lazy(fj)
+    o2 = torch.full_like(ref, float("nan"))
+    n0 = fj.launches
+    p2.jacobian(fj, x, [o2])
+    assert fj.launches - n0 == 1 and p2.fcalls_last == 3
+    assert torch.equal(o2, ref)
+    # the oracle (Float64: the complex step is exact to rounding)
+    if dtype == np.float64:
+        want = oracle.jacobian("complex", oracle.Fixture("tridiag_nl", N), xh, colors, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)["out"]
+        assert np.max(np.abs(o2.cpu().numpy() - want) / (1e-12 * np.abs(want) + 1e-300)) <= 1.0 or np.allclose(o2.cpu().numpy(), want, rtol=1e-12, atol=1e-14)
+    # forward differences with the same (generic) functor: the bits of the built-in family
+    pf = fd.make_plan(J, J, colors, "forward", dtype=dtype, store_csc_always=True)
+    pf.set_lazy(fj)
+    of = torch.full_like(ref, float("nan"))
+    pf.jacobian(fj, x, [of])
+    rf_plan = fd.make_plan(J, J, colors, "forward", dtype=dtype)
+    rf_plan.set_lazy(fb)
+    rf = torch.full_like(ref, float("nan"))
+    rf_plan.jacobian(fb, x, [rf])
+    assert torch.equal(of, rf)
+    # a functor written on real_t: fine for forward differences, refused for the complex step -- loudly, with the reason
+    fr = fd.JitF(TRIDIAG_NL, "TridiagNL", N, N, params=struct.pack("q", N), dtype=dtype)
+    p3 = fd.make_plan(J, J, colors, "complex", dtype=dtype, store_csc_always=True)
+    p3.set_lazy(fr)
+    with pytest.raises(fd.lib.FdError) as ei:
+        p3.jacobian(fr, x, [torch.full_like(ref, float("nan"))])
+    assert "value_type" in str(ei.value)
