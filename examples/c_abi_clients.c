@@ -1090,6 +1090,77 @@ static int client_dropin(int64_t N, int reps)
     return bad;
 }
 
+/* A row function handed over as LLVM BITCODE (fd_f_link_rows_bitcode): the file named on the command line was produced OFFLINE by
+   `hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fgpu-rdc -emit-llvm --offload-device-only -c tests/bitcode_user_tridiag_nl.hip`
+   (what AMDGPU.jl / GPUCompiler emit for a Julia closure takes the same road).  Forward, central and complex step, each as an opaque f!,
+   through the column store and -- forward / central -- the band store: the bits of the built-in family; and what the routes cost. */
+static int client_bitcode(const char *path, int64_t N, int reps)
+{
+    FILE *fh = fopen(path, "rb");
+    if (!fh) { fprintf(stderr, "cannot open %s\n", path); return 3; }
+    fseek(fh, 0, SEEK_END);
+    const long nb = ftell(fh);
+    fseek(fh, 0, SEEK_SET);
+    char *bc = malloc((size_t)nb);
+    if (fread(bc, 1, (size_t)nb, fh) != (size_t)nb) { fclose(fh); return 3; }
+    fclose(fh);
+    int64_t *colptr, *rowval, *colors = cyclic_colors(N, 3);
+    tridiag_csc(N, &colptr, &rowval);
+    const int64_t nnz = colptr[N] - 1;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *outd = dev_nan((size_t)nnz), *refd = dev_nan((size_t)nnz);
+    double *out = malloc(sizeof(double) * (size_t)nnz), *ref = malloc(sizeof(double) * (size_t)nnz);
+    fd_f_launch fb, fu; void *fbctx, *fuctx; fd_f_launch_lazy lz = NULL; int caps = 0;
+    const int64_t prm[1] = {N};
+    const long long params[1] = {(long long)N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &fb, &fbctx));
+    int rc = fd_f_link_rows_bitcode(g_ctx, bc, nb, params, sizeof params, N, N, 8, &fu, &lz, &caps, &fuctx);
+    if (rc != FD_OK) { fprintf(stderr, "fd_f_link_rows_bitcode -> %d: %s\n%s\n", rc, fd_last_error(), fd_f_compile_log()); return 3; }
+    int bad = 0;
+    double t_route[3][3];
+    const char *fdn[3] = {"forward", "central", "complex"};
+    for (int fdt = 0; fdt < 3; ++fdt) {
+        fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdt;
+        fd_plan *pb, *pl[3];
+        CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &pb));
+        CHECK(install_lazy(pb, fbctx));
+        CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &pl[0]));          /* opaque: no lazy launcher */
+        CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &pl[2]));          /* the band store */
+        CHECK(fd_plan_set_lazy_f(pl[2], lz));
+        CHECK(fd_plan_set_lazy_caps(pl[2], caps));
+        o.flags = FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ALWAYS;
+        CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &pl[1]));          /* the column store */
+        CHECK(fd_plan_set_lazy_f(pl[1], lz));
+        CHECK(fd_plan_set_lazy_caps(pl[1], caps & ~FD_LAZY_CAP_STORE));
+        void *outr[3] = {refd, NULL, NULL}, *outs[3] = {outd, NULL, NULL};
+        CHECK(fd_jacobian_async(pb, fb, fbctx, xd, NULL, -1.0, -1.0, 1.0, outr));
+        CHECK(fd_ctx_synchronize(g_ctx));
+        from_dev(ref, refd, sizeof(double) * (size_t)nnz);
+        for (int k = 0; k < 3; ++k) {
+            t_route[fdt][k] = -1;
+            if (k == 2 && fdt == 2) continue;                       /* (the complex step of a band goes through the column store) */
+            hipMemset(outd, 0xFF, sizeof(double) * (size_t)nnz);
+            for (int r = 0; r < 3; ++r) CHECK(fd_jacobian_async(pl[k], fu, fuctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+            CHECK(fd_ctx_synchronize(g_ctx));
+            from_dev(out, outd, sizeof(double) * (size_t)nnz);
+            if (memcmp(out, ref, sizeof(double) * (size_t)nnz) != 0) { printf("bitcode      %s route %d: bits differ from the built-in family  FAILED\n", fdn[fdt], k); bad = 1; }
+            const double t0 = now_ms();
+            for (int r = 0; r < reps; ++r) CHECK(fd_jacobian_async(pl[k], fu, fuctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+            CHECK(fd_ctx_synchronize(g_ctx));
+            t_route[fdt][k] = (now_ms() - t0) / reps;
+        }
+        CHECK(fd_plan_destroy(pb));
+        for (int k = 0; k < 3; ++k) CHECK(fd_plan_destroy(pl[k]));
+    }
+    for (int fdt = 0; fdt < 3; ++fdt)
+        printf("bitcode N=%lld %s: linked row function as an opaque f! %.4f ms | column store (one launch) %.4f ms | band store (one launch) %.4f ms\n", (long long)N,
+               fdn[fdt], t_route[fdt][0], t_route[fdt][1], t_route[fdt][2]);
+    CHECK(fd_builtin_f_destroy(fbctx)); CHECK(fd_f_compiled_destroy(fuctx));
+    hipFree(xd); hipFree(outd); hipFree(refd); free(out); free(ref); free(x); free(colptr); free(rowval); free(colors); free(bc);
+    if (bad) return 3;
+    printf("bitcode      forward / central / complex x opaque / column store / band store: the built-in family's bits  ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const char *which = argc > 1 ? argv[1] : "all";
@@ -1122,6 +1193,7 @@ int main(int argc, char **argv)
                               client_complex_structured(1, FD_FORWARD) | client_complex_structured(1, FD_CENTRAL))
     RUN("out_of_place", client_out_of_place())
     RUN("resize", client_resize())
+    RUN("bitcode", argc > 2 ? client_bitcode(argv[2], argc > 3 ? atoll(argv[3]) : 300007, argc > 4 ? atoi(argv[4]) : 20) : 0)
     RUN("jit", client_jit(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     RUN("dropin", client_dropin(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     CHECK(fd_ctx_destroy(g_ctx));

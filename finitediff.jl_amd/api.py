@@ -663,6 +663,32 @@ class JitF:
         return n.value
 
 
+class BitcodeF(JitF):
+    """A row function given as LLVM BITCODE (fd_f_link_rows_bitcode): what AMDGPU.jl / GPUCompiler emit for a Julia closure -- the shim's
+    `DeviceF(f::Function, M, N)` -- or `hipcc -fgpu-rdc -emit-llvm --offload-device-only -c`.  The bitcode defines
+    `fdjac_user_row(params, r, X)` (and `fdjac_user_row_c` for the complex step) and reads the point with `fdjac_point_get(X, j)`;
+    `params` are handed to it as they are.  Everything a `JitF` gets: the column store, the band store, the complex step."""
+
+    def __init__(self, bitcode, M, N, params=b"", ctx=None, dtype=np.float64):
+        self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        L = self.L = self.ctx.L
+        self.fn = _l.F_LAUNCH()
+        self._lazy = _l.F_LAUNCH_LAZY()
+        self.fctx = C.c_void_p()
+        caps = C.c_int32()
+        bitcode, params = bytes(bitcode), bytes(params)
+        bbuf = C.create_string_buffer(bitcode, len(bitcode))
+        pbuf = C.create_string_buffer(params, len(params)) if params else None
+        rc = L.fd_f_link_rows_bitcode(self.ctx.handle, bbuf, len(bitcode), pbuf, len(params), int(M), int(N), self.dtype.itemsize,
+                                      C.byref(self.fn), C.byref(self._lazy), C.byref(caps), C.byref(self.fctx))
+        self.log = (L.fd_f_compile_log() or b"").decode("utf-8", "replace")
+        _l.check(rc)
+        self.lazy_caps = caps.value
+        self.M, self.N = int(M), int(N)
+        self._fin = weakref.finalize(self, L.fd_f_compiled_destroy, self.fctx)
+
+
 class _DevView:
     """__cuda_array_interface__ holder so torch can view library-owned device memory."""
 

@@ -41,6 +41,13 @@ struct Hiprtc {
     decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
     decltype(&hiprtcGetCode) GetCode = nullptr;
     decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+    // linking a caller's LLVM bitcode in (fd_f_link_rows_bitcode): optional -- an older hiprtc without them serves source functors only
+    decltype(&hiprtcGetBitcodeSize) GetBitcodeSize = nullptr;
+    decltype(&hiprtcGetBitcode) GetBitcode = nullptr;
+    decltype(&hiprtcLinkCreate) LinkCreate = nullptr;
+    decltype(&hiprtcLinkAddData) LinkAddData = nullptr;
+    decltype(&hiprtcLinkComplete) LinkComplete = nullptr;
+    decltype(&hiprtcLinkDestroy) LinkDestroy = nullptr;
 };
 static Hiprtc g_rtc;
 static std::mutex g_jit_mutex;
@@ -77,6 +84,12 @@ static const Hiprtc *hiprtc()
     FD_SYM(GetCode, "hiprtcGetCode")
     FD_SYM(GetErrorString, "hiprtcGetErrorString")
 #undef FD_SYM
+    r.GetBitcodeSize = (decltype(r.GetBitcodeSize))dlsym(h, "hiprtcGetBitcodeSize");
+    r.GetBitcode = (decltype(r.GetBitcode))dlsym(h, "hiprtcGetBitcode");
+    r.LinkCreate = (decltype(r.LinkCreate))dlsym(h, "hiprtcLinkCreate");
+    r.LinkAddData = (decltype(r.LinkAddData))dlsym(h, "hiprtcLinkAddData");
+    r.LinkComplete = (decltype(r.LinkComplete))dlsym(h, "hiprtcLinkComplete");
+    r.LinkDestroy = (decltype(r.LinkDestroy))dlsym(h, "hiprtcLinkDestroy");
     g_rtc = r;
     return &g_rtc;
 }
@@ -104,6 +117,7 @@ struct JitModule {
         bool tried = false, ok = false;
         std::string log;
     } cplx;
+    std::vector<char> bitcode;                         // fd_f_link_rows_bitcode: the caller's LLVM bitcode, linked into every program of this functor
     std::string real;                                  // "double" / "float"
     unsigned sizeof_f = 0;
     int refs = 0;
@@ -112,6 +126,39 @@ struct JitModule {
     int device = 0;
 };
 static std::map<std::string, JitModule *> g_modules;
+
+// a compiled program as a loaded module.  bitcode empty: the program's code object; else the program (compiled with -fgpu-rdc) and the
+// caller's bitcode linked into one code object first (hiprtcLink*, LLVM bitcode inputs: the caller's row function is inlined into the
+// kernels like a source functor's call operator)
+static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-fgpu-rdc"};
+static hipError_t load_program(const Hiprtc *R, hiprtcProgram prog, const std::vector<char> &bitcode, hipModule_t *mod, std::string *why)
+{
+    if (bitcode.empty()) {
+        size_t cs = 0;
+        std::vector<char> code;
+        if (R->GetCodeSize(prog, &cs) != HIPRTC_SUCCESS || cs == 0) { *why = "hiprtcGetCodeSize failed"; return hipErrorUnknown; }
+        code.resize(cs);
+        if (R->GetCode(prog, code.data()) != HIPRTC_SUCCESS) { *why = "hiprtcGetCode failed"; return hipErrorUnknown; }
+        return hipModuleLoadData(mod, code.data());
+    }
+    if (!R->GetBitcode || !R->GetBitcodeSize || !R->LinkCreate || !R->LinkAddData || !R->LinkComplete || !R->LinkDestroy) { *why = "this hiprtc has no link interface"; return hipErrorNotSupported; }
+    size_t bs = 0;
+    if (R->GetBitcodeSize(prog, &bs) != HIPRTC_SUCCESS || bs == 0) { *why = "hiprtcGetBitcodeSize failed"; return hipErrorUnknown; }
+    std::vector<char> glue(bs), user(bitcode);
+    if (R->GetBitcode(prog, glue.data()) != HIPRTC_SUCCESS) { *why = "hiprtcGetBitcode failed"; return hipErrorUnknown; }
+    hiprtcLinkState ls = nullptr;
+    if (R->LinkCreate(0, nullptr, nullptr, &ls) != HIPRTC_SUCCESS) { *why = "hiprtcLinkCreate failed"; return hipErrorUnknown; }
+    hipError_t e = hipErrorUnknown;
+    void *bin = nullptr;
+    size_t sz = 0;
+    hiprtcResult r = R->LinkAddData(ls, HIPRTC_JIT_INPUT_LLVM_BITCODE, glue.data(), glue.size(), "fdjac kernels", 0, nullptr, nullptr);
+    if (r == HIPRTC_SUCCESS) r = R->LinkAddData(ls, HIPRTC_JIT_INPUT_LLVM_BITCODE, user.data(), user.size(), "caller's row function", 0, nullptr, nullptr);
+    if (r == HIPRTC_SUCCESS) r = R->LinkComplete(ls, &bin, &sz);
+    if (r == HIPRTC_SUCCESS && bin && sz) e = hipModuleLoadData(mod, bin);
+    else *why = std::string("linking the caller's bitcode failed (") + R->GetErrorString(r) + "): does it define fdjac_user_row (and fdjac_user_row_c for the complex step) for gfx950?";
+    (void)R->LinkDestroy(ls);
+    return e;
+}
 
 // fd_band_store_cols for the bandwidths (l, u) of this module's functor: the precompiled pair, or one more small compilation
 // (the same text, two name expressions) on first use -- about a second, once per functor text and bandwidth pair
@@ -134,18 +181,16 @@ static hipFunction_t band_function(JitModule *m, int l, int u, int central)
         names[md] = "fd_band_store_cols<" + m->real + ", " + (md ? "1" : "0") + ", fdjit_F, " + std::to_string(l) + ", " + std::to_string(u) + ">";
         (void)R->AddNameExpression(prog, names[md].c_str());
     }
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
-    bool ok = R->CompileProgram(prog, 5, opts) == HIPRTC_SUCCESS;
-    size_t cs = 0;
-    std::vector<char> code;
-    if (ok && R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) { code.resize(cs); ok = R->GetCode(prog, code.data()) == HIPRTC_SUCCESS; } else ok = false;
+    bool ok = R->CompileProgram(prog, m->bitcode.empty() ? 5 : 6, kJitOpts) == HIPRTC_SUCCESS;
     std::string low[2];
     for (int md = 0; md < 2 && ok; ++md) {
         const char *ln = nullptr;
         if (R->GetLoweredName(prog, names[md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[md] = ln; else ok = false;
     }
+    std::string why;
+    if (ok) ok = load_program(R, prog, m->bitcode, &x.mod, &why) == hipSuccess;
     (void)R->DestroyProgram(&prog);
-    if (!ok || hipModuleLoadData(&x.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!ok) { (void)hipGetLastError(); return nullptr; }
     for (int md = 0; md < 2; ++md)
         if (hipModuleGetFunction(&x.fn[md], x.mod, low[md].c_str()) != hipSuccess) { x.fn[md] = nullptr; ok = false; }
     if (!ok) { (void)hipGetLastError(); return nullptr; }
@@ -184,20 +229,21 @@ static bool cplx_functions(JitModule *m)
         names[cb] = "fd_csc_store_cols_cplx<" + m->real + ", " + ct[cb] + ", fdjit_F>";
         (void)R->AddNameExpression(prog, names[cb].c_str());
     }
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
-    bool ok = R->CompileProgram(prog, 5, opts) == HIPRTC_SUCCESS;
+    bool ok = R->CompileProgram(prog, m->bitcode.empty() ? 5 : 6, kJitOpts) == HIPRTC_SUCCESS;
     size_t ls = 0;
     if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { x.log.resize(ls); (void)R->GetProgramLog(prog, &x.log[0]); }
-    size_t cs = 0;
-    std::vector<char> code;
-    if (ok && R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) { code.resize(cs); ok = R->GetCode(prog, code.data()) == HIPRTC_SUCCESS; } else ok = false;
     std::string low[2];
     for (int cb = 0; cb < 2 && ok; ++cb) {
         const char *ln = nullptr;
         if (R->GetLoweredName(prog, names[cb].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[cb] = ln; else ok = false;
     }
+    if (ok) {
+        std::string why;
+        ok = load_program(R, prog, m->bitcode, &x.mod, &why) == hipSuccess;
+        if (!ok) x.log += why;
+    }
     (void)R->DestroyProgram(&prog);
-    if (!ok || hipModuleLoadData(&x.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!ok) { (void)hipGetLastError(); return false; }
     ok = hipModuleGetFunction(&x.rows, x.mod, "fdjit_rows_cplx") == hipSuccess;
     for (int cb = 0; cb < 2 && ok; ++cb) ok = hipModuleGetFunction(&x.store[cb], x.mod, low[cb].c_str()) == hipSuccess;
     if (!ok) (void)hipGetLastError();
@@ -340,32 +386,14 @@ extern "C" {
 
 const char *fd_f_compile_log(void) { return t_log.c_str(); }
 
-int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, const void *params, int64_t params_bytes, int64_t M, int64_t N,
-                      int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out)
+// the shared back half of fd_f_compile_rows / fd_f_link_rows_bitcode: `src` is the complete translation unit (device header, element
+// type, the functor -- source text, or the shim around the caller's bitcode --, the kernels), `bitcode` the caller's LLVM bitcode or empty
+static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char> &bitcode, const char *real, const char *functor, const void *params,
+                     int64_t params_bytes, int64_t M, int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out,
+                     void **fctx_out)
 {
-    FD_REQUIRE(ctx && source && functor && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
-    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 8 (Float64) or 4 (Float32)");
-    FD_REQUIRE(M >= 1 && N >= 1, FD_ERR_ARG, "bad shape");
-    FD_REQUIRE(params_bytes >= 0 && (params || params_bytes == 0), FD_ERR_ARG, "bad functor parameters");
-    for (const char *c = functor; *c; ++c)
-        FD_REQUIRE((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_' || *c == ':' || *c == '<' || *c == '>' || *c == ',' ||
-                       *c == ' ',
-                   FD_ERR_ARG, "functor must be a type name");
-    FD_HIP_CHECK(hipSetDevice(ctx->device));
-    t_log.clear();
-    const char *real = elem_bytes == 8 ? "double" : "float";
-    std::string src;      // (hiprtc declares the HIP runtime itself: no include)
-    src += kDeviceHeader;
-    src += "\ntypedef ";
-    src += real;
-    src += " real_t;\n#line 1 \"functor\"\n";
-    src += source;
-    src += "\n#define FDJIT_FUNCTOR ";
-    src += functor;
-    src += "\n";
-    src += kJitTail;
     // (modules are per DEVICE: a second context on another GPU compiling the same text must not get device 0's functions)
-    const std::string key = std::to_string(ctx->device) + "\n" + src;
+    const std::string key = std::to_string(ctx->device) + "\n" + src + std::string(bitcode.begin(), bitcode.end());
     JitModule *m = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_jit_mutex);
@@ -397,8 +425,7 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
                 bnames[wi][md] = std::string("fd_band_store_cols<") + real + ", " + (md ? "1" : "0") + ", fdjit_F, " + (wi ? "2, 2>" : "1, 1>");
                 (void)R->AddNameExpression(prog, bnames[wi][md].c_str());
             }
-        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno"};
-        rr = R->CompileProgram(prog, 5, opts);
+        rr = R->CompileProgram(prog, bitcode.empty() ? 5 : 6, kJitOpts);
         size_t ls = 0;
         if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
             t_log.resize(ls);
@@ -409,9 +436,6 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
             (void)R->DestroyProgram(&prog);
             return FD_ERR_ARG;
         }
-        size_t cs = 0;
-        std::vector<char> code;
-        if (R->GetCodeSize(prog, &cs) == HIPRTC_SUCCESS) { code.resize(cs); rr = R->GetCode(prog, code.data()); }
         std::string low[2][2][2];
         for (int w = 0; w < 2; ++w)
             for (int cb = 0; cb < 2; ++cb)
@@ -425,11 +449,18 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
                 const char *ln = nullptr;
                 if (R->GetLoweredName(prog, bnames[wi][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) blow[wi][md] = ln;
             }
-        (void)R->DestroyProgram(&prog);
-        FD_REQUIRE(rr == HIPRTC_SUCCESS && cs > 0, FD_ERR_HIP, "hiprtcGetCode failed");
         m = new (std::nothrow) JitModule();
-        FD_REQUIRE(m != nullptr, FD_ERR_NOMEM, "out of host memory");
-        hipError_t e = hipModuleLoadData(&m->mod, code.data());
+        if (!m) { (void)R->DestroyProgram(&prog); FD_REQUIRE(false, FD_ERR_NOMEM, "out of host memory"); }
+        std::string why;
+        hipError_t e = load_program(R, prog, bitcode, &m->mod, &why);
+        (void)R->DestroyProgram(&prog);
+        if (e != hipSuccess && !why.empty()) {
+            set_error("%s", why.c_str());
+            t_log += why;
+            delete m;
+            (void)hipGetLastError();
+            return FD_ERR_ARG;
+        }
         if (e == hipSuccess) e = hipModuleGetFunction(&m->rows, m->mod, "fdjit_rows");
         for (int cb = 0; cb < 2 && e == hipSuccess; ++cb)
             for (int md = 0; md < 2 && e == hipSuccess; ++md) {
@@ -462,6 +493,7 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
         } else {
             m->key = key;
             m->text = src;
+            m->bitcode = bitcode;
             m->device = ctx->device;
             m->real = real;
             g_modules[key] = m;
@@ -485,6 +517,127 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | FD_LAZY_CAP_STORE_CSC_COMPLEX | ((m->band[0][0] || m->band[1][0]) ? FD_LAZY_CAP_STORE : 0);
     *fctx_out = j;
     return FD_OK;
+}
+
+int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, const void *params, int64_t params_bytes, int64_t M, int64_t N,
+                      int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out)
+{
+    FD_REQUIRE(ctx && source && functor && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 8 (Float64) or 4 (Float32)");
+    FD_REQUIRE(M >= 1 && N >= 1, FD_ERR_ARG, "bad shape");
+    FD_REQUIRE(params_bytes >= 0 && (params || params_bytes == 0), FD_ERR_ARG, "bad functor parameters");
+    for (const char *c = functor; *c; ++c)
+        FD_REQUIRE((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_' || *c == ':' || *c == '<' || *c == '>' || *c == ',' ||
+                       *c == ' ',
+                   FD_ERR_ARG, "functor must be a type name");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    t_log.clear();
+    const char *real = elem_bytes == 8 ? "double" : "float";
+    std::string src;      // (hiprtc declares the HIP runtime itself: no include)
+    src += kDeviceHeader;
+    src += "\ntypedef ";
+    src += real;
+    src += " real_t;\n#line 1 \"functor\"\n";
+    src += source;
+    src += "\n#define FDJIT_FUNCTOR ";
+    src += functor;
+    src += "\n";
+    src += kJitTail;
+    return jit_build(ctx, src, std::vector<char>(), real, functor, params, params_bytes, M, N, elem_bytes, fn_out, lazy_out, lazy_caps_out, fctx_out);
+}
+
+
+// ---- a row function given as LLVM BITCODE (fd_f_link_rows_bitcode) ------------------------------------------------------------------
+// What a caller without C++ hands over: AMDGPU.jl / GPUCompiler emit bitcode for a Julia closure, `hipcc -emit-llvm --offload-device-only
+// -fgpu-rdc -c` for a C function.  The bitcode defines, for the element type T of the call,
+//     extern "C" __device__ T    fdjac_user_row  (const void *params, long long r, const fd_cpoint *X);                 (required)
+//     extern "C" __device__ void fdjac_user_row_c(const void *params, long long r, const fd_cpoint *X, T *re_im);     (complex step: optional)
+// and reads the point through what THIS side of the link defines:
+//     extern "C" __device__ T    fdjac_point_get  (const fd_cpoint *X, long long j);
+//     extern "C" __device__ void fdjac_point_get_c(const fd_cpoint *X, long long j, T *re_im);
+// fd_cpoint is {int kind; const void *obj;}: which of the kernels' point types it stands for.  After the link-time inlining the kind is
+// a constant in every kernel and the switch is gone: the kernels are those of a source functor.
+static const char kExternHead[] = R"FDJIT(
+struct fd_cpoint { int kind; const void *obj; };
+struct fdjit_plain;
+template <class P> struct fd_cpoint_kind;
+template <> struct fd_cpoint_kind<fd_column_point<real_t>> { static constexpr int value = 0; };
+template <> struct fd_cpoint_kind<fd_colour_point<real_t, unsigned char>> { static constexpr int value = 1; };
+template <> struct fd_cpoint_kind<fd_colour_point<real_t, int>> { static constexpr int value = 2; };
+template <> struct fd_cpoint_kind<fd_window_column_point<real_t>> { static constexpr int value = 3; };
+template <> struct fd_cpoint_kind<fdjit_plain> { static constexpr int value = 4; };
+template <> struct fd_cpoint_kind<fd_cplx_column_point<real_t>> { static constexpr int value = 5; };
+template <> struct fd_cpoint_kind<fd_cplx_colour_point<real_t, unsigned char>> { static constexpr int value = 6; };
+template <> struct fd_cpoint_kind<fd_cplx_colour_point<real_t, int>> { static constexpr int value = 7; };
+template <> struct fd_cpoint_kind<fd_cplx_plain_point<real_t>> { static constexpr int value = 8; };
+extern "C" __device__ real_t fdjac_user_row(const void *params, long long r, const fd_cpoint *X);
+extern "C" __device__ void fdjac_user_row_c(const void *params, long long r, const fd_cpoint *X, real_t *re_im);
+struct fd_extern_F {
+    unsigned char params[FDJIT_NPARAMS];
+    template <class P> __device__ real_t call(long long r, const P &X, real_t *) const
+    {
+        const fd_cpoint c = {fd_cpoint_kind<P>::value, &X};
+        return fdjac_user_row(params, r, &c);
+    }
+    template <class P> __device__ fd_cplx<real_t> call(long long r, const P &X, fd_cplx<real_t> *) const
+    {
+        const fd_cpoint c = {fd_cpoint_kind<P>::value, &X};
+        real_t o[2];
+        fdjac_user_row_c(params, r, &c, o);
+        return fd_cplx<real_t>{o[0], o[1]};
+    }
+    template <class P> __device__ typename P::value_type operator()(long long r, const P &X) const { return call(r, X, (typename P::value_type *)nullptr); }
+};
+)FDJIT";
+static const char kExternTail[] = R"FDJIT(
+extern "C" __device__ real_t fdjac_point_get(const fd_cpoint *X, long long j)
+{
+    switch (X->kind) {
+    case 0: return (*(const fd_column_point<real_t> *)X->obj)(j);
+    case 1: return (*(const fd_colour_point<real_t, unsigned char> *)X->obj)(j);
+    case 2: return (*(const fd_colour_point<real_t, int> *)X->obj)(j);
+    case 3: return (*(const fd_window_column_point<real_t> *)X->obj)(j);
+    default: return (*(const fdjit_plain *)X->obj)(j);
+    }
+}
+extern "C" __device__ void fdjac_point_get_c(const fd_cpoint *X, long long j, real_t *re_im)
+{
+    fd_cplx<real_t> v;
+    switch (X->kind) {
+    case 5: v = (*(const fd_cplx_column_point<real_t> *)X->obj)(j); break;
+    case 6: v = (*(const fd_cplx_colour_point<real_t, unsigned char> *)X->obj)(j); break;
+    case 7: v = (*(const fd_cplx_colour_point<real_t, int> *)X->obj)(j); break;
+    default: v = (*(const fd_cplx_plain_point<real_t> *)X->obj)(j); break;
+    }
+    re_im[0] = v.re;
+    re_im[1] = v.im;
+}
+)FDJIT";
+
+int fd_f_link_rows_bitcode(fd_ctx *ctx, const void *bitcode, int64_t bitcode_bytes, const void *params, int64_t params_bytes, int64_t M, int64_t N,
+                           int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out)
+{
+    FD_REQUIRE(ctx && bitcode && bitcode_bytes > 0 && fn_out && fctx_out, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 8 (Float64) or 4 (Float32)");
+    FD_REQUIRE(M >= 1 && N >= 1, FD_ERR_ARG, "bad shape");
+    FD_REQUIRE(params_bytes >= 0 && params_bytes <= 4096 && (params || params_bytes == 0), FD_ERR_ARG, "bad parameters (at most 4096 bytes: they travel as a kernel argument)");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    t_log.clear();
+    const char *real = elem_bytes == 8 ? "double" : "float";
+    const int64_t np = params_bytes > 0 ? params_bytes : 1;
+    std::string src;
+    src += kDeviceHeader;
+    src += "\ntypedef ";
+    src += real;
+    src += " real_t;\n#define FDJIT_NPARAMS " + std::to_string((long long)np) + "\n";
+    src += kExternHead;
+    src += "\n#define FDJIT_FUNCTOR fd_extern_F\n";
+    src += kJitTail;
+    src += kExternTail;
+    const std::vector<char> bc((const char *)bitcode, (const char *)bitcode + bitcode_bytes);
+    // (an empty parameter block is one byte of padding: the functor object cannot be empty)
+    const unsigned char zero = 0;
+    return jit_build(ctx, src, bc, real, "fd_extern_F", params_bytes > 0 ? params : &zero, np, M, N, elem_bytes, fn_out, lazy_out, lazy_caps_out, fctx_out);
 }
 
 int fd_f_compiled_destroy(void *fctx)

@@ -70,7 +70,7 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_link_rows_bitcode", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
     "fd_p2p_create", "fd_p2p_create_loopback", "fd_p2p_loopback_fill", "fd_p2p_loopback_fill_fused", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
@@ -228,6 +228,7 @@ def load():
     L.fd_comm_p2p_status.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.fd_comm_disable_p2p.argtypes = [vp]
     L.fd_f_compile_rows.argtypes = [vp, C.c_char_p, C.c_char_p, vp, i64, i64, i64, i32, C.POINTER(F_LAUNCH), C.POINTER(F_LAUNCH_LAZY), C.POINTER(i32), pp]
+    L.fd_f_link_rows_bitcode.argtypes = [vp, vp, i64, vp, i64, i64, i64, i32, C.POINTER(F_LAUNCH), C.POINTER(F_LAUNCH_LAZY), C.POINTER(i32), pp]
     L.fd_f_compiled_destroy.argtypes = [vp]
     L.fd_f_compiled_counts.argtypes = [vp, C.POINTER(i64)]
     L.fd_f_compile_log.restype = C.c_char_p

@@ -643,6 +643,21 @@ int fd_tridiag_solve_finish(fd_tridiag_solver *solver, double alpha, double beta
  *     fd_plan_set_lazy_f(plan, lazy); fd_plan_set_lazy_caps(plan, caps);          (fd32_* for elem_bytes == 4) */
 int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor_type, const void *params, int64_t params_bytes, int64_t M,
                       int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out);
+/* The same for a row function given as LLVM BITCODE -- what AMDGPU.jl / GPUCompiler emit for a Julia closure (the reference's "any
+ * callable", src/jacobians.jl:563,634, on the one-launch path), or `hipcc --offload-arch=gfx950 -fgpu-rdc -emit-llvm
+ * --offload-device-only -c` for a C function.  The bitcode defines, for the element type T of the call,
+ *     extern "C" __device__ T    fdjac_user_row  (const void *params, long long r, const fd_cpoint *X);               (required)
+ *     extern "C" __device__ void fdjac_user_row_c(const void *params, long long r, const fd_cpoint *X, T *re_im);   (complex step; optional)
+ * and reads coordinate j of the point through the library's side of the link:
+ *     extern "C" __device__ T    fdjac_point_get  (const fd_cpoint *X, long long j);
+ *     extern "C" __device__ void fdjac_point_get_c(const fd_cpoint *X, long long j, T *re_im);
+ * (`struct fd_cpoint { int kind; const void *obj; }` -- opaque to the caller).  The library compiles its kernels for a functor that
+ * calls fdjac_user_row, links the two (hiprtcLink*, LLVM bitcode inputs; the row function is inlined into the kernels) and returns the
+ * launchers of fd_f_compile_rows: the plain one, and the lazy one with the column store (any pattern), the band store (exact bands) and
+ * -- if fdjac_user_row_c is defined -- the complex step.  `params`: up to 4096 bytes handed to the row function as they are.
+ * FD_ERR_ARG when the link fails (fd_f_compile_log()), FD_ERR_UNSUPPORTED without libhiprtc. */
+int fd_f_link_rows_bitcode(fd_ctx *ctx, const void *bitcode, int64_t bitcode_bytes, const void *params, int64_t params_bytes, int64_t M,
+                           int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out);
 int fd_f_compiled_destroy(void *fctx);
 int fd_f_compiled_counts(void *fctx, int64_t *launches);
 const char *fd_f_compile_log(void);

@@ -237,6 +237,24 @@ def test_c_clients_every_plan_kind(tmp_path, client):
     assert "all clients ok" in out.stdout and "FAILED" not in out.stdout
 
 
+def test_c_client_links_a_row_function_given_as_bitcode(tmp_path):
+    # fd_f_link_rows_bitcode end to end as a caller without C++ sees it: tests/bitcode_user_tridiag_nl.hip (the C interface only, no
+    # library header) compiled OFFLINE to LLVM bitcode by hipcc, handed to the library by a plain-C process that uses /opt/rocm's own
+    # runtime and hiprtc (the LLVM that wrote the bitcode reads it), linked into the library's kernels at run time: forward, central and
+    # complex step x opaque f! / column store / band store -- every one the built-in family's bits
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    bc = str(tmp_path / "user.bc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fgpu-rdc", "-emit-llvm", "--offload-device-only", "-c",
+                    os.path.join(root, "tests", "bitcode_user_tridiag_nl.hip"), "-o", bc], check=True, capture_output=True)
+    exe = _build_c_clients(root, tmp_path)
+    out = subprocess.run([exe, "bitcode", bc, "300007", "20"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "the built-in family's bits  ok" in out.stdout and "FAILED" not in out.stdout, out.stdout
+
+
 def test_stage_timings_do_not_serialise_the_stream():
     # fd_plan_enable_timing: level 1 brackets the diff+decompress kernel only, level 2 every stage + the whole call;
     # the calls harvest finished spans with hipEventQuery (never a stream synchronise), results are unchanged
