@@ -141,6 +141,70 @@ class DevicePatternCSC:
         return (self.m, self.n)
 
 
+class _Edit:
+    """`with holder.edit(): ...` -- the arrays are writable inside, the holder's generation is bumped on the way out."""
+
+    def __init__(self, owner, arrays):
+        self.owner, self.arrays = owner, arrays
+
+    def __enter__(self):
+        for a in self.arrays:
+            a.flags.writeable = True
+        return self.arrays[0] if len(self.arrays) == 1 else self.arrays
+
+    def __exit__(self, *exc):
+        for a in self.arrays:
+            a.flags.writeable = False
+        self.owner.generation += 1
+        return False
+
+
+class TrackedCSC(SparseMatrixCSC):
+    """A host SparseMatrixCSC pattern whose EDITS are visible in O(1): colptr / rowval are read-only arrays, changed only inside
+    `with A.edit() as (colptr, rowval): ...`, which bumps `A.generation`.  A cached call (JacobianCache, pattern_check "auto" /
+    "content") compares generations instead of re-hashing 400 MB of Int64 indices per call (3 ms at N = 10^7: 42 x the Jacobian) --
+    the reference re-reads the pattern on every call (src/jacobians.jl:512-513) because it has no way to know; a wrapper that owns
+    the mutation does.  The shim's `TrackedCSC` is the same thing for Julia callers."""
+
+    def __init__(self, m, n, colptr, rowval, nzval=None):
+        super().__init__(m, n, np.array(colptr, dtype=np.int64), np.array(rowval, dtype=np.int64), nzval)
+        self.generation = 0
+        self.colptr.flags.writeable = False
+        self.rowval.flags.writeable = False
+
+    def edit(self):
+        return _Edit(self, [self.colptr, self.rowval])
+
+
+class TrackedVector:
+    """The same for a host colour vector: `data` is read-only outside `with v.edit() as a: ...`."""
+
+    def __init__(self, data):
+        self.data = np.array(data, dtype=np.int64)
+        self.data.flags.writeable = False
+        self.generation = 0
+
+    def edit(self):
+        return _Edit(self, [self.data])
+
+    def __array__(self, dtype=None, copy=None):
+        return self.data if dtype is None else self.data.astype(dtype)
+
+    def __len__(self):
+        return int(self.data.size)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def size(self):
+        return self.data.size
+
+    def max(self):
+        return self.data.max()
+
+
 class Tridiagonal:
     """LinearAlgebra.Tridiagonal: dl (n-1), d (n), du (n-1)."""
 
@@ -1246,7 +1310,10 @@ class JacobianCache:
         # "content_async" -- device arrays: the same comparison as ONE fused kernel ahead of the Jacobian, nothing copied back, the
         # stream never stopped; an edit is reported one call late (the stale plan's call is recomputed by the call that finds out)
         # or by Context.synchronize() -- FD_ERR_STALE.  Host arrays fall back to "content".
-        self.pattern_check = "content"
+        # "auto" (default since round 6): device arrays -> "content_async", whose kernel now runs on a side stream BESIDE the Jacobian;
+        # host arrays -> "content", which for TrackedCSC / TrackedVector holders is a comparison of generation counters (the arrays are
+        # re-hashed only after an edit).
+        self.pattern_check = "auto"
 
     def invalidate(self):
         """Forget the compiled plans: the next call re-reads `colorvec` / `sparsity` (after an in-place edit of either)."""
@@ -1260,6 +1327,8 @@ class JacobianCache:
             return None
         if isinstance(a, (SparseMatrixCSC, DevicePatternCSC)):
             return (id(a), JacobianCache._ident(a.colptr), JacobianCache._ident(a.rowval), a.size())
+        if isinstance(a, TrackedVector):
+            return (id(a), a.data.ctypes.data, a.data.size)
         if isinstance(a, np.ndarray):
             return (id(a), a.ctypes.data, a.size)
         if _is_torch(a):
@@ -1274,8 +1343,12 @@ class JacobianCache:
         check, a new plan (+ the built-in family's lazy launcher, as `install_lazy!` does) only when something changed."""
         jshape = tuple(J.shape) if (isinstance(J, np.ndarray) or _is_torch(J)) else tuple(J.size())
         key = (type(J).__name__, jshape, self.fdtype, self._ident(sparsity), self._ident(colorvec), id(f) if self.lazy else None)
-        content = self.pattern_check in ("content", "content_async")
-        deferred = self.pattern_check == "content_async" and self._all_device(sparsity, colorvec)
+        mode = self.pattern_check
+        if mode == "auto":
+            mode = "content_async" if self._all_device(sparsity, colorvec) else "content"
+        content = mode in ("content", "content_async")
+        deferred = mode == "content_async" and self._all_device(sparsity, colorvec)
+        gen = self._generations(sparsity, colorvec)      # not None: every host array involved owns its mutation (Tracked*)
         ent = self._plans.get(key)
         if ent is not None and ent[3] == content:
             if not content:
@@ -1284,7 +1357,10 @@ class JacobianCache:
                 if not ent[0].stale():           # (the verdict of the check enqueued by the call before, if it has run)
                     self._content_matches(ent[0], sparsity, colorvec, deferred=True)
                     return ent[0]
+            elif gen is not None and ent[4] == gen:
+                return ent[0]                    # nothing was edited since the content was last compared
             elif self._content_matches(ent[0], sparsity, colorvec):
+                self._plans[key] = ent[:4] + (gen,)
                 return ent[0]
         self._bound.clear()
         if len(self._plans) >= 8:
@@ -1295,8 +1371,22 @@ class JacobianCache:
                          store_csc=want_csc, store_csc_always=want_csc and isinstance(f, JitF))
         if self.lazy and isinstance(f, (BuiltinF, JitF)) and not self.cx and f.lazy_fn is not None:
             plan.set_lazy(f)          # built-in families: f! perturbs while loading / stores the Jacobian itself (shim: install_lazy!)
-        self._plans[key] = (plan, sparsity, colorvec, content)     # (the arrays are kept alive: their ids stay theirs)
+        self._plans[key] = (plan, sparsity, colorvec, content, gen)     # (the arrays are kept alive: their ids stay theirs)
         return plan
+
+    @staticmethod
+    def _generations(sparsity, colorvec):
+        """(generation of the pattern, generation of the colours) when every HOST array of the pair is a Tracked* holder (a device array
+        or a structural pattern has none to offer: None for it), else None -- then only the content tells."""
+        gs = []
+        for a in (sparsity, colorvec):
+            if isinstance(a, (TrackedCSC, TrackedVector)):
+                gs.append(a.generation)
+            elif a is None or isinstance(a, range) or isinstance(a, (Tridiagonal, BandedMatrix, BlockBandedMatrix, BandedBlockBandedMatrix)):
+                gs.append(None)
+            else:
+                return None
+        return tuple(gs)
 
     @staticmethod
     def _all_device(sparsity, colorvec):
@@ -1305,6 +1395,8 @@ class JacobianCache:
 
     @staticmethod
     def _content_matches(plan, sparsity, colorvec, deferred=False):
+        if isinstance(colorvec, TrackedVector):
+            colorvec = colorvec.data
         cv = colorvec if (_is_torch(colorvec) or isinstance(colorvec, np.ndarray)) else _i64(colorvec)
         if isinstance(sparsity, DevicePatternCSC):
             return plan.matches(sparsity.colptr, sparsity.rowval, cv, idx_base=sparsity.idx_base, deferred=deferred)

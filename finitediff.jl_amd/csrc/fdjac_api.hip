@@ -395,6 +395,8 @@ int fd_ctx_create(int device, void *stream, fd_ctx **out)
 int fd_ctx_destroy(fd_ctx *ctx)
 {
     if (!ctx) return FD_OK;
+    if (ctx->check_stream) { (void)hipStreamSynchronize(ctx->check_stream); (void)hipStreamDestroy(ctx->check_stream); }
+    if (ctx->check_event) (void)hipEventDestroy(ctx->check_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_stale) (void)hipHostFree(ctx->h_stale);
     delete ctx;
@@ -407,6 +409,7 @@ int fd_ctx_synchronize(fd_ctx *ctx)
 {
     FD_REQUIRE(ctx != nullptr, FD_ERR_ARG, "ctx is NULL");
     FD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->check_stream) FD_HIP_CHECK(hipStreamSynchronize(ctx->check_stream));      // (the deferred content checks run beside the main stream)
     if (ctx->h_stale && *(volatile int *)ctx->h_stale) {       // a deferred content check (fd_plan_matches_async) found a stale plan
         *ctx->h_stale = 0;
         set_error("a deferred content check found that a plan no longer matches the caller's pattern / colour arrays (fd_plan_stale tells "
@@ -423,6 +426,7 @@ int fd_plan_destroy(fd_plan *p)
     if (!p) return FD_OK;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->ctx->check_stream && p->d_fpx) (void)hipStreamSynchronize(p->ctx->check_stream);      // (a deferred check of this plan may still be reading d_fpx)
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_fpx, p->d_xstage,
                     p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
@@ -789,6 +793,13 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         FD_REQUIRE(r == 0 || p->halo_own0 >= p->halo, FD_ERR_ARG, "no room for the lower halo: x[%lld - %lld, ...) starts before 0", (long long)p->halo_own0, (long long)p->halo);
         FD_REQUIRE(r + 1 >= W || p->halo_own1 + p->halo <= p->N, FD_ERR_ARG, "no room for the upper halo: x[..., %lld + %lld) ends behind N = %lld",
                    (long long)p->halo_own1, (long long)p->halo, (long long)p->N);
+    }
+    if (fuse) {
+        // (a call being CAPTURED into a HIP graph is replayed with the arguments of the capture: the fused step's buffer parity / mailbox
+        //  epoch are host state that must advance per launch -- such a call takes the separate launches, which carry no such state)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) fuse = false;
     }
     bool fuse_sharded = false;
     int fzW = 1, fzr = 0;

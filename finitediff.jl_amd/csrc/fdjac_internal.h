@@ -264,6 +264,11 @@ struct fd_ctx {
     // fd_plan_matches_async: a sticky "some plan was found stale" word in pinned host memory mapped to the device -- a kernel raises
     // it, the host reads it without a synchronisation (fd_ctx_synchronize / the next fd_jacobian* of that plan report FD_ERR_STALE)
     int *h_stale = nullptr, *d_stale = nullptr;
+    // ... and the side stream those checks run on (round 6): the fused fingerprint kernel reads the caller's arrays BESIDE the Jacobian
+    // instead of ahead of it; it starts behind an event of the main stream (the arrays' producers) and nothing waits for it but
+    // fd_ctx_synchronize / the plan's destruction
+    hipStream_t check_stream = nullptr;
+    hipEvent_t check_event = nullptr;
 };
 
 struct fd_plan {

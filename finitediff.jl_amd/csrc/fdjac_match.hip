@@ -289,7 +289,16 @@ extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a,
         total += f.g[k];
     }
     if (total == 0) return FD_OK;
-    hipLaunchKernelGGL(k_fingerprint3_check, dim3((unsigned)total), dim3(256), 0, ctx->stream, f, fpx, stale_plan, stale_ctx);
+    // beside the Jacobian, not ahead of it: the check's own stream, started behind whatever the main stream has enqueued so far (the
+    // producers of the caller's arrays); checks of one context follow each other on that stream (they share tickets per plan)
+    fd_ctx *c = const_cast<fd_ctx *>(ctx);
+    if (!c->check_stream) {
+        FD_HIP_CHECK(hipStreamCreateWithFlags(&c->check_stream, hipStreamNonBlocking));
+        FD_HIP_CHECK(hipEventCreateWithFlags(&c->check_event, hipEventDisableTiming));
+    }
+    FD_HIP_CHECK(hipEventRecord(c->check_event, c->stream));
+    FD_HIP_CHECK(hipStreamWaitEvent(c->check_stream, c->check_event, 0));
+    hipLaunchKernelGGL(k_fingerprint3_check, dim3((unsigned)total), dim3(256), 0, c->check_stream, f, fpx, stale_plan, stale_ctx);
     FD_HIP_CHECK(hipGetLastError());
     return FD_OK;
 }

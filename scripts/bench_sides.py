@@ -352,6 +352,12 @@ def side_runs(L):
             res_d["device_pattern_content_check"] = measure(J_dev, cv_dev, "content")
             out_d.fill_(float("nan"))
             res_d["device_pattern_content_check_deferred"] = measure(J_dev, cv_dev, "content_async")
+            out_d.fill_(float("nan"))
+            res_d["device_pattern_default"] = measure(J_dev, cv_dev, "auto")          # (= content_async: the check runs beside the call)
+            out_d.fill_(float("nan"))
+            J_trk = fd.TrackedCSC(N, N, cp_s, rv_s, out_d)                             # host Int64 arrays in holders that own their mutation
+            res_d["host_tracked_default"] = measure(J_trk, fd.TrackedVector(colors), "auto")
+            del J_trk
             # the same loop on the pre-bound callable (what `value` times): the yardstick of the lookup's cost
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -863,3 +863,65 @@ def test_dropin_installs_the_lazy_launcher_like_the_shim(fdtype):
         res.append((J.nzval.clone(), f.fcalls, cache.last_plan.info(fd.lib.INFO_LAZY_STORE)))
     assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
     assert res[0][2] == (0 if fdtype == "complex" else 1) and res[1][2] == 0
+
+
+def test_dropin_default_checks_device_arrays_beside_the_call_and_tracked_host_arrays_by_generation():
+    # round 6 defaults (pattern_check "auto"): DEVICE pattern / colours -> the fused fingerprint kernel on the context's side stream,
+    # verdict one call late; HOST arrays in Tracked holders -> generations (no re-hash until an edit); plain host arrays -> content.
+    N = 60_000
+    cp, rv = P.tridiag_csc(N)
+    colors = P.cyclic_colors(N, 3)
+    x = torch.as_tensor(np.random.default_rng(3).random(N), device="cuda")
+    f = fd.BuiltinF("tridiag_nl", N)
+    # ---- device arrays ----
+    cpd, rvd = torch.as_tensor(cp.astype(np.int32), device="cuda"), torch.as_tensor(rv.astype(np.int32), device="cuda")
+    cvd = torch.as_tensor(colors.astype(np.int32), device="cuda")
+    Jd = fd.DevicePatternCSC(N, N, cpd, rvd, torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda"))
+    cache = fd.JacobianCache(x, "forward", colorvec=cvd, sparsity=Jd)
+    assert cache.pattern_check == "auto"
+    for _ in range(3):
+        fd.finite_difference_jacobian_b(Jd, f, x, cache)
+    torch.cuda.synchronize()
+    ref = Jd.nzval.clone()
+    plan0 = cache.last_plan
+    # an in-place edit of the colours (a valid recolouring: shifted by one): found by the check that runs beside the NEXT call, acted on
+    # by the call after it -- a new plan, the Jacobian of the new colours
+    cvd.copy_(torch.as_tensor(((np.arange(N) + 1) % 3 + 1).astype(np.int32), device="cuda"))
+    fd.finite_difference_jacobian_b(Jd, f, x, cache)          # (still the old plan; its check sees the edit)
+    cache.last_plan.ctx.synchronize() if False else torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    while not plan0.stale() and time.time() - t0 < 5:
+        time.sleep(0.01)
+    assert plan0.stale()
+    fd.finite_difference_jacobian_b(Jd, f, x, cache)
+    torch.cuda.synchronize()
+    assert cache.last_plan is not plan0
+    assert torch.allclose(Jd.nzval, ref, rtol=1e-5, atol=1e-6)      # (a relabelling of the same three column sets: the same Jacobian)
+    # ---- tracked host arrays ----
+    A = fd.TrackedCSC(N, N, cp, rv, torch.full((rv.size,), float("nan"), dtype=torch.float64, device="cuda"))
+    cv = fd.TrackedVector(colors)
+    cache2 = fd.JacobianCache(x, "forward", colorvec=cv, sparsity=A)
+    fd.finite_difference_jacobian_b(A, f, x, cache2)
+    p1 = cache2.last_plan
+    calls = {"n": 0}
+    real = fd.JacobianCache._content_matches
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    fd.JacobianCache._content_matches = staticmethod(counting)
+    try:
+        for _ in range(5):
+            fd.finite_difference_jacobian_b(A, f, x, cache2)
+        assert calls["n"] == 0 and cache2.last_plan is p1            # unedited: generations only
+        with cv.edit() as a:
+            a[:] = (np.arange(N) + 1) % 3 + 1
+        fd.finite_difference_jacobian_b(A, f, x, cache2)
+        assert calls["n"] == 1 and cache2.last_plan is not p1        # edited: the content was compared, the plan rebuilt
+        fd.finite_difference_jacobian_b(A, f, x, cache2)
+        assert calls["n"] == 1
+    finally:
+        fd.JacobianCache._content_matches = staticmethod(real)
+    torch.cuda.synchronize()
+    assert torch.allclose(A.nzval, ref, rtol=1e-5, atol=1e-6)
