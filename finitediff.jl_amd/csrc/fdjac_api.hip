@@ -160,7 +160,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
     p->fz_sharded_ok = env_int("FDJAC_FUSED_SHARDED", 1) != 0;
     p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
-    p->eps_form = env_int("FDJAC_EPS_FORM", 0);
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since

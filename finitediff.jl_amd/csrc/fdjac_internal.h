@@ -412,7 +412,6 @@ struct fd_plan {
     int *h_fz_err = nullptr, *d_fz_err = nullptr;
     unsigned fz_parity = 0;
     long long *d_fz_trace = nullptr;          // FDJAC_FUSED_TRACE=1: wall_clock64 marks of the last fused launch (fd_plan_fused_trace)
-    int eps_form = 0;                         // the library's own reduction: 0 = all levels in one launch, 1 = levels 0 + 1, then k_eps_final (same bits)
     bool fz_sharded_ok = true;                // sharded calls with a mailbox take the fused step (FDJAC_FUSED_SHARDED=0: the three-launch form)
     bool fz_shared_ok = false;                //   ... even when ranks share this device (FDJAC_FUSED_SHARED=1: small test problems only)
     int64_t fz_max_n = (int64_t)1 << 21;      // single GPU: problems up to this size take the fused step (FDJAC_FUSED_MAX_N; 0 = never)

@@ -1251,7 +1251,7 @@ __global__ void __launch_bounds__(kBlock) k_fill(real_t *__restrict__ p, int64_t
 // starts (measured in one process on the same buffers, N = 10^7: tridiagonal forward 123.9 -> 118.3 / 119.8 -> 117.4 /
 // 115.4 -> 114.5 us depending on buffer placement, 5-point central 307 -> 301 us, block-banded complex step
 // (k_decompress_colrange_wg) 112 -> 103 us; neutral when everything fits).
-// Same work per tile => same bits.  FDJAC_REVERSE=0 restores front-to-back order (read per launch: tests toggle it).
+// Same work per tile => same bits.
 // every decompression kernel walks its tiles from the last one to the first: the f! batch was written front to back by the launch
 // before, so its end is what the 256 MiB Infinity Cache still holds ("tile order")
 static inline bool tile_order_reversed() { return true; }
@@ -1338,10 +1338,6 @@ static int launch_eps_t(fd_plan *p, const real_t *x, double relstep, double abss
 {
     hipStream_t s = p->ctx->stream;
     const int C = (int)p->C;
-    if (C <= kRegColors && p->eps_form == 1) {
-        const int rc = launch_eps_groups_t<CT>(p, x, 0, kEpsGroups, false, relstep, absstep, dir);
-        return rc ? rc : launch_eps_final(p, relstep, absstep, dir);
-    }
     if (C <= kRegColors) return launch_eps_groups_t<CT>(p, x, 0, kEpsGroups, true, relstep, absstep, dir);
     const int nparts = p->seg_chunks;
     hipLaunchKernelGGL(k_eps_partial_seg, dim3((unsigned)((int64_t)C * nparts)), dim3(kBlock), 0, s,

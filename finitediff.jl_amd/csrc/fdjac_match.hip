@@ -264,12 +264,7 @@ extern "C" int fdjac_fingerprint3(const fd_ctx *ctx, const void *const *a, const
 }
 
 // the fused check (see k_fingerprint3_check): expected words already in fpx[3..5]
-static int fp3_blocks_per_cu()
-{
-    const char *fb = fdjac::test_switch("FDJAC_FP_BLOCKS");
-    const int v = (fb && *fb) ? atoi(fb) : 4;
-    return v < 1 ? 1 : v > 16 ? 16 : v;
-}
+static int fp3_blocks_per_cu() { return 4; }      // (1 .. 16 measured in round 5: see fdjac_fingerprint3_check)
 extern "C" size_t fdjac_fingerprint3_check_words(const fd_ctx *ctx) { return (size_t)kFpPart0 + (size_t)ctx->num_cus * 16 + 8; }
 extern "C" int fdjac_fingerprint3_check(const fd_ctx *ctx, const void *const *a, const int *bytes, const int64_t *i0, const int64_t *n, const int64_t *base,
                                         unsigned long long *fpx, int *stale_plan, int *stale_ctx)
