@@ -965,6 +965,11 @@ __global__ void k_tri_tips(SrcUser src0, TipArgs ta, const double *__restrict__ 
     packet[4] = first[2]; packet[5] = last[2];
     packet[6] = cpl[0];
     packet[7] = cpl[1];
+    // a rank whose rows failed the dominance guard REFUSES for everybody: its packet carries NaN, so every rank's interface system --
+    // and with it every rank's y -- is poisoned, and every rank's status says so (k_tri_interface).  (Until round 6 only the rank that
+    // owned the offending rows refused; its neighbours finished with interface values from its unreliable elimination.)
+    if (src0.refuse && src0.nd_flag && *src0.nd_flag != 0)
+        for (int k = 0; k < 6; ++k) packet[k] = __longlong_as_double(0x7FF8000000000000ll);
 }
 
 // Phase B: the interface system of all ranks (unknowns p_r = first, q_r = last local value of rank r), solved by one
@@ -973,10 +978,17 @@ __global__ void k_tri_tips(SrcUser src0, TipArgs ta, const double *__restrict__ 
 //   A_r = packet[r-1][7] (the previous rank knows it), C_r = packet[r+1][6].
 constexpr int kMaxRanks = 1024;
 __global__ void k_tri_interface(const double *__restrict__ packets, int W, int rank, double *__restrict__ adj,
-                                double *__restrict__ work /* 2W x 6 doubles */)
+                                double *__restrict__ work /* 2W x 6 doubles */, int *__restrict__ nd_flag)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int n = 2 * W;
+    // (a peer that refused -- NaN in its packet -- refuses for this rank too: status bit 2, and the NaN runs through the system below)
+    if (nd_flag) {
+        bool peer_nd = false;
+        for (int r = 0; r < W; ++r)
+            for (int k = 0; k < 6; ++k) peer_nd = peer_nd || packets[(size_t)r * kPacket + k] != packets[(size_t)r * kPacket + k];
+        if (peer_nd) atomicOr(nd_flag, 2);
+    }
     // band storage: row i, columns i-2 .. i+2 -> work[i*6 + (j - i + 2)], rhs at work[i*6 + 5]
     for (int i = 0; i < n * 6; ++i) work[i] = 0.0;
     for (int r = 0; r < W; ++r) {
@@ -1274,7 +1286,7 @@ int fd_tridiag_solve_finish(fd_tridiag_solver *s, double alpha, double beta, con
     FD_REQUIRE(nranks >= 1 && nranks <= kMaxRanks && rank >= 0 && rank < nranks, FD_ERR_ARG, "rank %d of %d", rank, nranks);
     FD_HIP_CHECK(hipSetDevice(s->ctx->device));
     hipLaunchKernelGGL(k_tri_interface, dim3(1), dim3(64), 0, s->ctx->stream, (const double *)packets_dev, nranks, rank, s->adj,
-                       s->work);
+                       s->work, s->refuse ? s->status : nullptr);
     FD_HIP_CHECK(hipGetLastError());
     return tri_local_solve(s, alpha, beta, J, rhs, s->adj, y);
 }

@@ -614,7 +614,9 @@ int fd_tridiag_solver_destroy(fd_tridiag_solver *solver);
    of a solution it cannot vouch for: a non-dominant I - gamma J never returns silently wrong numbers (a Rosenbrock / implicit step
    then fails as loudly as a NaN residual does, and fd_tridiag_solver_status says why).  fd_tridiag_solver_set_policy(solver, 1) turns
    the refusal off for callers who know their matrix is fine without dominance (symmetric positive definite, M-matrices): the flag is
-   still raised, y is the elimination's result.  fd_tridiag_solver_status synchronises the context's stream. */
+   still raised, y is the elimination's result.  In a MULTI-RANK solve a rank that refuses does so for every rank: its interface packet
+   carries NaN, every rank's y is poisoned and every rank's status has bit 1 set ("a peer refused"; bit 0 stays with the rank that owns the
+   offending rows).  fd_tridiag_solver_status synchronises the context's stream. */
 int fd_tridiag_solver_set_policy(fd_tridiag_solver *solver, int trust_non_dominant);
 int fd_tridiag_solver_status(fd_tridiag_solver *solver, int *flags_out);
 /* comm == NULL: the solver's rows are the whole system.  J: 3 (diagonals) or 1 (CSC) device pointers; b, y device. */

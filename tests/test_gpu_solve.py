@@ -294,3 +294,31 @@ def test_solver_flags_systems_that_are_not_diagonally_dominant():
     assert tiny.status() == 0 and not bool(torch.isnan(yt).any())
     s.solve([dl, d, du], b, y, alpha=1.0, beta=-0.05)          # the flag belongs to the LAST solve
     assert s.status() == 0
+
+
+def test_a_rank_that_refuses_refuses_for_every_rank():
+    # the multi-rank solve in its two phases, three "ranks" on this GPU: ONE rank's rows contain a row that is not diagonally dominant.
+    # Its packet carries NaN: every rank's y is NaN and every rank's status says why -- bit 0 on the rank that owns the row, bit 1
+    # ("a peer refused") on all of them.  (Until round 6 the other ranks returned ordinary numbers computed from the refused rank's
+    # unreliable interface values, with status 0.)
+    N, W = 90_000, 3
+    dl, d, du, b, alpha, beta = _system(N, 9, dominance=1.0)
+    d = d.copy()
+    cuts = [0, 30_000, 60_000, N]
+    bad_row = 45_000                                   # rank 1's
+    d[bad_row] = (abs(beta * dl[bad_row - 1]) + abs(beta * du[bad_row])) * 0.25 / beta - alpha / beta      # |alpha + beta d| = a quarter of the off-diagonal sum
+    packets = torch.full((W, 8), float("nan"), dtype=torch.float64, device="cuda")
+    ranks = []
+    for r in range(W):
+        c0, c1 = cuts[r], cuts[r + 1]
+        J = fd.Tridiagonal(_dev(dl[c0:min(c1, N - 1)]), _dev(d[c0:c1]), _dev(du[max(c0 - 1, 0):c1 - 1]))
+        solver = fd.TridiagSolver(N, "diagonals", rows=(c0, c1))
+        bl = _dev(b[c0:c1])
+        solver.interface(J, bl, packets[r], alpha, beta)
+        ranks.append((solver, J, bl, c0, c1))
+    for r, (solver, J, bl, c0, c1) in enumerate(ranks):
+        yl = torch.zeros(c1 - c0, dtype=torch.float64, device="cuda")
+        solver.finish(J, bl, packets, r, W, yl, alpha, beta)
+        st = solver.status()
+        assert bool(torch.isnan(yl).all()), r
+        assert st == (3 if r == 1 else 2), (r, st)
