@@ -808,7 +808,10 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         const bool halo_ok = p->halo == 0 || (p->halo == 2 && p->halo_own0 == p->col0 && p->halo_own1 == p->col1 && p->halo_own0 % 4 == 0 &&
                                               (p->halo_own1 % 4 == 0 || fzr == fzW - 1));
         // (ranks sharing ONE device -- tests, dry runs: a launch full of wavefronts that wait for a peer would keep the peer from running)
-        fuse = fuse_sharded = fz_mb != nullptr && fzW > 1 && p->fz_sharded_ok && eps_shardable(p) && halo_ok &&
+        // (and only for shards up to fz_max_n columns -- measured with the loop-back rank share at N = 10^7: 8 ranks 18.3 us fused against
+        //  22.4 in three launches, 4 ranks 28.7 / 30.2, 2 ranks 82 / 45: a launch whose storing wavefronts do not all fit on the device
+        //  keeps the rest queued behind wavefronts that wait)
+        fuse = fuse_sharded = fz_mb != nullptr && fzW > 1 && p->fz_sharded_ok && eps_shardable(p) && halo_ok && p->col1 - p->col0 <= p->fz_max_n &&
                               (!fdjac_p2p_shared_device(fz_mb) || p->fz_shared_ok);
     } else if (fuse) {
         fuse = p->N <= p->fz_max_n;
