@@ -811,7 +811,8 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         // (and only for shards up to fz_max_n columns -- measured with the loop-back rank share at N = 10^7: 8 ranks 18.3 us fused against
         //  22.4 in three launches, 4 ranks 28.7 / 30.2, 2 ranks 82 / 45: a launch whose storing wavefronts do not all fit on the device
         //  keeps the rest queued behind wavefronts that wait)
-        fuse = fuse_sharded = fz_mb != nullptr && fzW > 1 && p->fz_sharded_ok && eps_shardable(p) && halo_ok && p->col1 - p->col0 <= p->fz_max_n &&
+        fuse = fuse_sharded = fz_mb != nullptr && fzW > 1 && p->fz_sharded_ok && eps_shardable(p) && halo_ok &&
+                              (int64_t)((kEpsGroups + fzW - 1) / fzW) * p->eps_tpg * 2048 <= p->fz_max_n &&      // (the LARGEST shard: the same verdict on every rank)
                               (!fdjac_p2p_shared_device(fz_mb) || p->fz_shared_ok);
     } else if (fuse) {
         fuse = p->N <= p->fz_max_n;
