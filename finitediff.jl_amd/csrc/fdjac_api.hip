@@ -1287,12 +1287,12 @@ int fd_plan_set_p2p(fd_plan *p, fd_p2p *p2p)
         // wait for data that never comes: its peers write other mailbox cells).  Collective: every rank attaches, in the same order.
         const bool sh = eps_shardable(p);
         double mine[8] = {sh ? (double)p->eps_tpg : -1.0, sh ? (double)p->eps_bpg * 65536.0 + (double)p->eps_tpb : -1.0, (double)p->N, (double)p->C,
-                          (double)p->fdtype, (double)sizeof(real_t), 0.0, 0.0};
+                          (double)p->fdtype, (double)sizeof(real_t), p->fz_sharded_ok ? (double)p->fz_max_n : -1.0, 0.0};
         std::vector<double> all((size_t)8 * (size_t)fdjac_p2p_nranks(p2p));
         const int rc = fdjac_p2p_agree8(p2p, mine, all.data());
         if (rc) return rc;
         for (int r = 0; r < fdjac_p2p_nranks(p2p); ++r)
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 7; ++k)
                 FD_REQUIRE(all[(size_t)(8 * r + k)] == mine[k], FD_ERR_COMM,
                            "rank %d disagrees on the step-size reduction (this rank: %s, N = %lld, %lld colours, 64 groups of %d tiles in %d blocks): "
                            "same N, colours, fdtype, element type and FDJAC_SMALL everywhere?", r, sh ? "sharded" : "replicated", (long long)p->N,
