@@ -894,6 +894,9 @@ def test_dropin_default_checks_device_arrays_beside_the_call_and_tracked_host_ar
     while not plan0.stale() and time.time() - t0 < 5:
         time.sleep(0.01)
     assert plan0.stale()
+    with pytest.raises(fd.lib.FdError):          # the context's own sticky word: reported (and cleared) by the next fd_ctx_synchronize
+        f.ctx.synchronize()
+    f.ctx.synchronize()
     fd.finite_difference_jacobian_b(Jd, f, x, cache)
     torch.cuda.synchronize()
     assert cache.last_plan is not plan0
