@@ -679,6 +679,13 @@ def main():
     torch.cuda.synchronize()
     call_samples = plan.timing_samples("total")
     plan.enable_timing(0)
+    # the FUSED step (round 6; one GPU: N <= 2^21): no launch of its own for the step sizes -- the storing launch carries the reduction
+    # (its first workgroups) and reads x twice
+    fused_step = bool(lazy_store and cfg in ("c2", "c4") and tm_all["eps"]["launches"] == 0 and tm_all["decompress"]["launches"] > 0)
+    if fused_step:
+        kern = "k_f_tridiag_fused<0, false, 4, false>" if vs == 8 else "k_f_tridiag_fused4<0, false, 4, false>"
+        bytes_min = 2 * vs + 3 * vs
+        bytes_call_model = bytes_min
     # ---- side measurement (single GPU, untimed): a DIFFERENT x every call.  The timed steps re-use one x, which then sits in the
     # 256 MiB Infinity Cache when the next call starts (the state a time-stepping loop is in, too: x was just written); here four
     # copies of x (more than the cache holds at the headline size) are walked round-robin, so every call finds its x cold
@@ -942,7 +949,7 @@ def main():
                                 "(fd_lazy_points.store, include/fdjac_device.h): src/jacobians.jl:563-568 for all colours" if lazy_store else
                                 "division + decompression of the differences handed over by the lazy f! launcher" if lazy_diff
                                 else "fused difference + decompression"),
-                "lazy_diff": lazy_diff, "lazy_store": lazy_store,
+                "lazy_diff": lazy_diff, "lazy_store": lazy_store, "fused_step": fused_step,
                 "avg_launch_ms": dec_ms, "median_launch_ms": dec_med, "launches_timed": dec["launches"],
                 "achieved_on_median": (traffic / (dec_med * 1e-3) / 1e9) if dec_med > 0 else None,
                 "hbm_bytes_per_launch_used": traffic,
