@@ -11,7 +11,7 @@ python $REPO/scripts/rocpd_summary.py $S $F $W > $OUT/summary.md 2> $OUT/summary
 # (forward / central configs hand differences over unless FDJAC_LAZY_DIFF=0; the complex step never does)
 DIFF=1; [ "${FDJAC_LAZY_DIFF:-1}" = "0" ] && DIFF=0; [ "$CFG" = "c5" ] && DIFF=0
 # (a storing f! launch is the graded kernel of the exact-band configs unless FDJAC_LAZY_STORE=0)
-STORE=0; case "$KERN" in *store*) STORE=1;; esac
+STORE=0; case "$KERN" in *store*|*fused*) STORE=1;; esac
 python $REPO/scripts/make_pmc_json.py $F $W $N 1 $KERN $DIFF $STORE > $OUT/pmc.json 2>> $OUT/summary.err
 cd $REPO && python bench.py --config $CFG "$@" > $OUT/bench.json 2> $OUT/bench.err
 python - $OUT >> $OUT/summary.md <<'PY'
