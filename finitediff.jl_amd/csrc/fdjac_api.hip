@@ -160,7 +160,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
     p->fz_sharded_ok = env_int("FDJAC_FUSED_SHARDED", 1) != 0;
     p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
-    p->fz_held_ok = env_int("FDJAC_FUSED_HELD", 1) != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
@@ -372,7 +371,6 @@ int fd_ctx_create(int device, void *stream, fd_ctx **out)
     fd_ctx *c = new (std::nothrow) fd_ctx();
     FD_REQUIRE(c != nullptr, FD_ERR_NOMEM, "out of host memory");
     c->device = device;
-    fdjac_held_ctx(device, +1);
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream == FD_STREAM_DEFAULT) {
         c->stream = nullptr;   // the legacy default stream
@@ -383,7 +381,6 @@ int fd_ctx_create(int device, void *stream, fd_ctx **out)
     } else {
         hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (se != hipSuccess) {
-            fdjac_held_ctx(device, -1);
             delete c;
             set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
             return FD_ERR_HIP;
@@ -401,7 +398,6 @@ int fd_ctx_destroy(fd_ctx *ctx)
     if (ctx->check_event) (void)hipEventDestroy(ctx->check_event);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_stale) (void)hipHostFree(ctx->h_stale);
-    fdjac_held_ctx(ctx->device, -1);
     delete ctx;
     return FD_OK;
 }
@@ -804,7 +800,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
         if (cs != hipStreamCaptureStatusNone) fuse = false;
     }
-    bool fuse_sharded = false, fuse_held = false;
+    bool fuse_sharded = false;
     int fzW = 1, fzr = 0;
     if (fuse && shard_ctx) {
         if (fz_mb) { fzW = fdjac_p2p_nranks(fz_mb); fzr = fdjac_p2p_rank(fz_mb); }
@@ -819,13 +815,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
                               (int64_t)((kEpsGroups + fzW - 1) / fzW) * p->eps_tpg * 2048 <= p->fz_max_n &&      // (the LARGEST shard: the same verdict on every rank)
                               (!fdjac_p2p_shared_device(fz_mb) || p->fz_shared_ok);
     } else if (fuse) {
-        // larger problems whose x still fits the chip's registers: the held step (every workgroup keeps its block of x between the
-        // reduction and the stores -- k_f_tridiag_held); it needs the whole matrix in one launch and the device to itself
-        if (p->N > p->fz_max_n) {
-            fuse_held = p->fz_held_ok && p->eps_tpb <= kFzHeldTiles + 1 && p->col0 == 0 && p->col1 == p->N && p->M == p->N && !p->cx &&
-                        p->n_partial_blocks == kEpsGroups * p->eps_bpg && fdjac_held_admit(ctx, ctx->device) != 0;
-            fuse = fuse_held;
-        }
+        fuse = p->N <= p->fz_max_n;
     }
     FusedEps fz_job;
     if (fuse) {
@@ -847,7 +837,6 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             if (p->halo > 0) { fz_job.xw = const_cast<real_t *>(x_dev); fz_job.own_begin = p->halo_own0; fz_job.own_end = p->halo_own1; fz_job.halo = (int)p->halo; }
         }
         fz_job.nblocks = fz_job.ng * p->eps_bpg;
-        fz_job.held = fuse_held ? 1 : 0;
         fz_job.cyc_C = p->cyc_C; fz_job.cyc_shift = p->cyc_shift; fz_job.pair = p->cx ? 1 : 0;
         const size_t hp = (size_t)p->n_partial_blocks * kRegColors, he = (size_t)kFzReplicas * kFzPitch;
         fz_job.part = p->d_fz_part + (p->fz_parity ? hp : 0);
@@ -999,7 +988,6 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             int rc = p->lazy_fn(fctx, p->d_FX, &lp, p->ldf, p->row0, p->row1, (void *)s);
             if (fuse && rc == 0) {
                 if (fuse_sharded) fdjac_p2p_fused_commit(fz_mb);
-                if (fuse_held) fdjac_held_launched(ctx, ctx->device, (void *)s);
                 p->fz_parity ^= 1u;
                 p->eps2_fresh = p->d_eps2 != nullptr;
             } else if (fuse) {      // (declined with the reduction attached: the library's own launch(es), then the plain storing launch)

@@ -252,10 +252,6 @@ __global__ void __launch_bounds__(kBlock)
 k_f_tridiag_store_wave(const real_t *__restrict__ x, const real_t *__restrict__ eps, int64_t n, fd_band_store bst, int64_t jstart)
 {
     __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_BAND_WAVE_LDS(3)];
-#ifdef FD_OCC_PAD      // (occupancy experiments: scripts/build_variant.sh)
-    __shared__ char s_pad[FD_OCC_PAD];
-    if (n == -12345) s_pad[threadIdx.x] = 1;
-#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t nwaves = (bst.col_end - jstart + 127) / 128;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + wave;
@@ -325,178 +321,6 @@ k_f_tridiag_fused(const real_t *__restrict__ x, int64_t n, fd_band_store bst, in
         if (gw + gstride < nwaves) load_x(jw, Cc, L, R);
     }
     if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
-}
-
-// THE HELD STEP (round 6): the fused step for problems whose x fits on the chip -- N <= 5 * 2048 * 1024 = 10.4 M columns.  The launch IS
-// the reduction's grid (64 groups x bpg blocks, all resident: 4 workgroups per CU at 128 registers per lane); workgroup b reduces block
-// b of x exactly as k_eps_partial_reg does, KEEPS it -- the first kFzHeldTiles tiles in registers, a fifth in LDS -- publishes its
-// block sum, waits for the step sizes and stores its own columns: x crosses the memory bus once, 320 MB per Jacobian at N = 10^7
-// instead of 400, one launch instead of two.  The finisher of colour c is the LAST block of group c (the shortest of its group); it
-// keeps nothing (its registers go to the finisher's work) and reads its columns again, four wave tiles in flight.
-// A lane's neighbours' pairs come from the adjacent lanes; the first and last lane of a wavefront take them from a small LDS table the
-// workgroup fills while it reduces (the workgroup's own outer neighbours: two loads).  Same operations per value: same bits.
-// Every workgroup waits for all others: the launcher launches this form only if the device holds the whole grid, and the library only
-// while no other context of the process has such a launch in flight (fdjac_held_admit).
-constexpr int kHeldWinBytes = (kBlock / 64) * FD_BAND_WAVE_LDS(3) * (int)sizeof(real_t);
-constexpr int kHeldFinBytes = (kFzMaxBlocks + 2 * kEpsGroups) * 8 + 16;
-constexpr int kHeldABytes = kHeldWinBytes > kHeldFinBytes ? kHeldWinBytes : kHeldFinBytes;      // wave windows / the finisher's area
-constexpr int kHeldSegs = kFzHeldTiles * 16;
-constexpr int kHeldEdgeOff = kHeldABytes + 320;                                                 // (256 B of wave sums, 64 B of step sizes before it)
-constexpr int kHeldTileOff = kHeldEdgeOff + 2 * (kHeldSegs + 2) * 2 * (int)sizeof(real_t);
-constexpr int kHeldLdsBytes = kHeldTileOff + (2048 + 4) * (int)sizeof(real_t);
-
-template <int MODE, bool NL>
-__device__ __forceinline__ void tridiag_held_emit(const fd_band_store &bst, real_t *win, const real_t *s_eps, uint32_t c0w, int lane, int64_t jw,
-                                                  const r2_t &L, const r2_t &Cc, const r2_t &R)
-{
-    const uint32_t C = (uint32_t)bst.C;
-    const int c0 = (int)((c0w + 2u * (uint32_t)lane) % C);
-    const int c1 = c0 + 1 == (int)C ? 0 : c0 + 1;
-    real_t q[6];
-    tridiag_pair_quotients<MODE, NL>(L, Cc, R, s_eps[c0], s_eps[c1], q);
-    fd_band_emit_wave<real_t, 3, true>(&bst, win, jw, q);
-}
-
-// a workgroup that keeps its block
-template <int MODE, bool NL, int NC>
-__device__ __forceinline__ void tridiag_held_keep(const real_t *__restrict__ x, int64_t n, const fd_band_store &bst, const FusedEps &fz, char *s_lds)
-{
-    constexpr int HT = kFzHeldTiles;
-    real_t (*s_win)[FD_BAND_WAVE_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE_LDS(3)]>(s_lds);
-    double (*s_red)[NC] = reinterpret_cast<double (*)[NC]>(s_lds + kHeldABytes);
-    real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kHeldABytes + 256);
-    r2_t *s_last = reinterpret_cast<r2_t *>(s_lds + kHeldEdgeOff);       // [kHeldSegs + 2]: slot g + 1 = the last pair of wave tile g of the kept tiles
-    r2_t *s_first = s_last + kHeldSegs + 2;                              //                  its first pair; slots 0 / kHeldSegs + 1: the neighbours outside
-    r2_t *s_t5 = reinterpret_cast<r2_t *>(s_lds + kHeldTileOff);         // [1 + 1024 + 1]: the fifth tile between its two neighbour pairs
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), b = (int)blockIdx.x;
-    typename HeldRegs<HT>::type xq[kEpsU];
-    int64_t base0 = 0, base_end = 0;
-    double s = 0.0;
-    if (threadIdx.x == 0) fz_mark_min(fz, 0);
-    const bool w0 = eps_block_sum_held<NC, HT>(x, n, fz.cyc_C, fz.cyc_shift, b, fz.eg, fz.pair, s_red, s, xq, base0, base_end, s_t5 + 1);
-    if (w0 && lane < fz.eg.C) __hip_atomic_store(fz.part + (int64_t)lane * fz.nblocks + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w0) fz_mark_max(fz, 1);
-    int64_t jlim = base_end < bst.col_end ? base_end : bst.col_end;
-    if (jlim > bst.N) jlim = bst.N;
-    // the edges of the kept wave tiles and the workgroup's outer neighbours, for the storing phase
-#pragma unroll
-    for (int k = 0; k < HT; ++k)
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            const int g = k * 16 + u * 4 + wave;
-            const r2_t v = {xq[u][2 * k], xq[u][2 * k + 1]};
-            if (lane == 0) s_first[g + 1] = v;
-            if (lane == 63) s_last[g + 1] = v;
-        }
-    if (threadIdx.x == 0) s_last[0] = ld_pair_guarded(x, base0 - 2, n);
-    if (threadIdx.x == kBlock - 1) {
-        s_t5[0] = r2_t{xq[kEpsU - 1][2 * HT - 2], xq[kEpsU - 1][2 * HT - 1]};
-        s_t5[1025] = ld_pair_guarded(x, base0 + (int64_t)(HT + 1) * 2048, n);
-    }
-    if (threadIdx.x == kBlock - 2) s_first[kHeldSegs + 1] = ld_pair_guarded(x, base0 + (int64_t)HT * 2048, n);
-    if (wave == 0) fused_wait_eps(fz, b, s_eps);
-    __syncthreads();
-    const uint32_t C = (uint32_t)bst.C;
-    const uint32_t cw0 = (uint32_t)((base0 + wave * 128 + bst.shift) % bst.C);      // colour of the wavefront's first column in the block
-#pragma unroll 1
-    for (int h = 0; h < HT; ++h) {
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            const int g = h * 16 + u * 4 + wave;
-            const int off = h * 2048 + u * 512;
-            const int64_t jw = base0 + off + wave * 128;
-            if (jw < jlim) {
-                const r2_t Cc = {xq[u][2 * h], xq[u][2 * h + 1]};      // (indexed register reads: h is uniform)
-                r2_t L, R;
-                L.x = __shfl_up(Cc.x, 1, 64); L.y = __shfl_up(Cc.y, 1, 64);
-                R.x = __shfl_down(Cc.x, 1, 64); R.y = __shfl_down(Cc.y, 1, 64);
-                if (lane == 0) L = s_last[g];
-                if (lane == 63) R = s_first[g + 2];
-                tridiag_held_emit<MODE, NL>(bst, s_win[wave], s_eps, (cw0 + (uint32_t)off) % C, lane, jw, L, Cc, R);
-            }
-        }
-    }
-#pragma unroll 1
-    for (int u = 0; u < kEpsU; ++u) {      // the fifth tile, out of LDS with its neighbours
-        const int off = HT * 2048 + u * 512;
-        const int64_t jw = base0 + off + wave * 128;
-        if (jw >= jlim) break;
-        const r2_t *q5 = s_t5 + 1 + u * 256 + wave * 64 + lane;
-        const r2_t L = q5[-1], Cc = q5[0], R = q5[1];
-        tridiag_held_emit<MODE, NL>(bst, s_win[wave], s_eps, (cw0 + (uint32_t)off) % C, lane, jw, L, Cc, R);
-    }
-    if (fz.trace && (blockIdx.x & 31) < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fz_mark_max(fz, 8); }
-}
-
-// the finisher of colour `c`: an ordinary reduction block, the finisher's work, then its columns read again (D wave tiles in flight)
-template <int MODE, bool NL, int NC>
-__device__ __forceinline__ void tridiag_held_finisher(const real_t *__restrict__ x, int64_t n, const fd_band_store &bst, const FusedEps &fz, char *s_lds, int c)
-{
-    constexpr int D = 4;
-    real_t (*s_win)[FD_BAND_WAVE_LDS(3)] = reinterpret_cast<real_t (*)[FD_BAND_WAVE_LDS(3)]>(s_lds);
-    double (*s_red)[NC] = reinterpret_cast<double (*)[NC]>(s_lds + kHeldABytes);
-    real_t *s_eps = reinterpret_cast<real_t *>(s_lds + kHeldABytes + 256);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), b = (int)blockIdx.x;
-    const int grp = b / fz.eg.bpg, kb = b - grp * fz.eg.bpg;
-    const int64_t t0 = (int64_t)grp * fz.eg.tpg + (int64_t)kb * fz.eg.tpb;
-    int64_t t1 = t0 + fz.eg.tpb;
-    if (t1 > (int64_t)(grp + 1) * fz.eg.tpg) t1 = (int64_t)(grp + 1) * fz.eg.tpg;
-    const int64_t base0 = t0 * 2048, base_end = t1 * 2048 < n ? t1 * 2048 : n;
-    double s = 0.0;
-    const bool w0 = eps_block_sum<uint8_t, NC, true, false, true>(x, nullptr, n, fz.cyc_C, fz.cyc_shift, b, fz.eg, fz.pair, s_red, s);
-    if (w0 && lane < fz.eg.C) __hip_atomic_store(fz.part + (int64_t)lane * fz.nblocks + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fused_finisher(fz, c, reinterpret_cast<double *>(s_lds));
-    int64_t jlim = base_end < bst.col_end ? base_end : bst.col_end;
-    if (jlim > bst.N) jlim = bst.N;
-    auto load_x = [&](int64_t jt, r2_t &c_, r2_t &l_, r2_t &r_) {
-        const int64_t j = jt + 2 * lane;
-        c_ = ld_pair_guarded(x, j, n); l_ = ld_pair_guarded(x, j - 2, n); r_ = ld_pair_guarded(x, j + 2, n);
-    };
-    // this wavefront's wave tiles in order: item i = pair u = i % 4 of tile i / 4
-    const int64_t sbase = base0 + wave * 128;
-    auto item_off = [&](int i) -> int { return (i >> 2) * 2048 + (i & 3) * 512; };
-    r2_t sL[D], sC[D], sR[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        sL[d] = sC[d] = sR[d] = r2_t{0, 0};
-        if (sbase + item_off(d) < jlim) load_x(sbase + item_off(d), sC[d], sL[d], sR[d]);
-    }
-    if (wave == 0) fused_wait_eps(fz, b, s_eps);
-    __syncthreads();
-    const uint32_t C = (uint32_t)bst.C;
-    const uint32_t cw0 = (uint32_t)((sbase + bst.shift) % bst.C);
-    for (int r = 0;; ++r) {
-        bool any = false;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int i = r * D + d;
-            const int64_t jw = sbase + item_off(i);
-            if (jw < jlim) {
-                any = true;
-                tridiag_held_emit<MODE, NL>(bst, s_win[wave], s_eps, (cw0 + (uint32_t)item_off(i)) % C, lane, jw, sL[d], sC[d], sR[d]);
-                const int64_t jn = sbase + item_off(i + D);
-                if (jn < jlim) load_x(jn, sC[d], sL[d], sR[d]);
-            }
-        }
-        if (!any) break;
-    }
-}
-
-template <int MODE, bool NL, int NC>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_f_tridiag_held(const real_t *__restrict__ x, int64_t n, fd_band_store bst, FusedEps fz)
-{
-    __shared__ __attribute__((aligned(16))) char s_lds[kHeldLdsBytes];
-    const int b = (int)blockIdx.x, grp = b / fz.eg.bpg;
-    const bool fin = b - grp * fz.eg.bpg == fz.eg.bpg - 1 && grp < fz.eg.C;
-#if FDJAC_HELD_PROBE == 1
-    tridiag_held_keep<MODE, NL, NC>(x, n, bst, fz, s_lds);
-#elif FDJAC_HELD_PROBE == 2
-    tridiag_held_finisher<MODE, NL, NC>(x, n, bst, fz, s_lds, grp);
-#else
-    if (fin) tridiag_held_finisher<MODE, NL, NC>(x, n, bst, fz, s_lds, grp);
-    else tridiag_held_keep<MODE, NL, NC>(x, n, bst, fz, s_lds);
-#endif
 }
 
 #ifdef FDJAC_F32
@@ -1058,33 +882,24 @@ static int builtin_launch(void *fctx, void *fx, const void *x, int64_t nbatch, i
 // storing workgroups of a fused launch: as many as tiles, but never more than fit on the device next to the reduction's (what the
 // kernel's registers and LDS allow per CU, asked of the runtime once per kernel): a workgroup dispatched only after others have left
 // would start its life after the step sizes are out -- a second round of memory latency at the end of the launch
-static int fused_cus()
-{
-    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    return cus;
-}
-// workgroups of `kernel` a CU holds at once (0: the runtime would not say)
-template <typename K>
-static int fused_wgs_per_cu(K kernel)
-{
-    static std::mutex mu;
-    static std::unordered_map<const void *, int> per_cu;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = per_cu.find((const void *)kernel);
-    if (it == per_cu.end()) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 0;
-        (void)hipGetLastError();
-        it = per_cu.emplace((const void *)kernel, nb).first;
-    }
-    return it->second;
-}
 template <typename K>
 static unsigned fused_grid(K kernel, unsigned tiles_wg, int prefix)
 {
-    const int cus = fused_cus();
-    int occ = fused_wgs_per_cu(kernel);
-    if (occ < 1) occ = 4;
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> per_cu;
+    int occ = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = per_cu.find((const void *)kernel);
+        if (it == per_cu.end()) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+            (void)hipGetLastError();
+            it = per_cu.emplace((const void *)kernel, nb).first;
+        }
+        occ = it->second;
+    }
     const int64_t room = (int64_t)cus * occ - prefix;
     const int64_t cap = room > cus ? room : cus;
     if ((int64_t)tiles_wg <= cap) return (unsigned)prefix + tiles_wg;
@@ -1117,23 +932,6 @@ static int lazy_tridiag_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp, 
         // colour ownership and wider bands take the row-owned kernel below
         const bool wave_ok = bst.l == 1 && bst.u == 1 && bst.M == bst.N && lp->c_lo == 0 &&
                              lp->ncolors == bst.C && bst.C >= 3 && (((uintptr_t)lp->x) & kPairMask) == 0 && bst.col_end > bst.col_begin;
-        if (wave_ok && lp->eps_job && ((const FusedEps *)lp->eps_job)->held) {
-            // the held step: the launch is the reduction's grid, every workgroup keeps its block of x (k_f_tridiag_held) -- only if the
-            // device holds the whole grid at once (every workgroup waits for all others)
-            const FusedEps fz = *(const FusedEps *)lp->eps_job;
-            if (bst.col_begin != 0 || bst.col_end != bst.N || fz.nranks > 1 || fz.g0 != 0 || fz.eg.tpb > kFzHeldTiles + 1 ||
-                fz.nblocks != fz.eg.bpg * kEpsGroups || fz.nblocks > kFzMaxBlocks) return FD_LAZY_DECLINED;
-#define FD_LAZY_HELDP(MODE, NL, NCC)                                                                                                       \
-            do { if ((int64_t)fused_wgs_per_cu(k_f_tridiag_held<MODE, NL, NCC>) * fused_cus() < fz.nblocks) return FD_LAZY_DECLINED;          \
-                 hipLaunchKernelGGL((k_f_tridiag_held<MODE, NL, NCC>), dim3((unsigned)fz.nblocks), dim3(kBlock), 0, s, (const real_t *)lp->x, \
-                                    b->prm[0], bst, fz); } while (0)
-#define FD_LAZY_HELD(MODE, NL) do { if (fz.eg.C <= 4) FD_LAZY_HELDP(MODE, NL, 4); else FD_LAZY_HELDP(MODE, NL, kRegColors); } while (0)
-            if (mode == 0) { if (nl) FD_LAZY_HELD(0, true); else FD_LAZY_HELD(0, false); }
-            else { if (nl) FD_LAZY_HELD(1, true); else FD_LAZY_HELD(1, false); }
-#undef FD_LAZY_HELD
-#undef FD_LAZY_HELDP
-            return hipGetLastError() == hipSuccess ? 0 : 4;
-        }
 #ifdef FDJAC_F32
         if (wave_ok && (((uintptr_t)lp->x) & 15) == 0) {      // Float32: four columns per lane
             const int64_t jstart = bst.col_begin & ~(int64_t)3;

@@ -155,109 +155,6 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
     return true;
 }
 
-// the kept tiles of the held step: ONE register tuple per pair position u, element 2k / 2k + 1 = the pair of tile k -- the storing
-// phase walks the tiles in a loop whose body exists once and picks tile h's pair with an INDEXED register read (h is wave-uniform:
-// s_set_gpr_idx / v_movrel, four moves); an array indexed by h would live in scratch, an unrolled loop is 90 KB of code
-template <int HT> struct HeldRegs { typedef real_t type __attribute__((ext_vector_type(2 * HT))); };
-
-// Level 0 with the block's first HT tiles KEPT in registers (the held step, k_f_tridiag_held): the loads, the additions and their order
-// are eps_block_sum's (cyclic colours, plain loads).  (xq[u][2k], xq[u][2k+1]) = pair u of tile k of this thread, loaded whether or not tile k still
-// belongs to the block (the last block of a group is shorter: its neighbours' tiles are kept for the storing phase's edges, never added).
-// The tile behind the kept ones goes to LDS (lds_tile).  base0 / base_end: the block's elements [base0, base_end).
-template <int NC, int HT>
-__device__ __forceinline__ bool eps_block_sum_held(const real_t *__restrict__ x, int64_t n, int cyc_C, int cyc_shift, int gblock, const EpsGrid &eg,
-                                                   int pair, double (*red)[NC], double &s, typename HeldRegs<HT>::type (&xq)[kEpsU], int64_t &base0,
-                                                   int64_t &base_end, r2_t *lds_tile)
-{
-    const int grp = gblock / eg.bpg, kb = gblock - grp * eg.bpg;
-    double acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-    const int64_t tile = (int64_t)kEpsU * kBlock * 2;
-    const int64_t t0 = (int64_t)grp * eg.tpg + (int64_t)kb * eg.tpb;
-    int64_t t1 = t0 + eg.tpb;
-    if (t1 > (int64_t)(grp + 1) * eg.tpg) t1 = (int64_t)(grp + 1) * eg.tpg;
-    base0 = t0 * tile;
-    base_end = t1 * tile;
-    if (base_end > n) base_end = n;
-    int rc = (int)((base0 + threadIdx.x * 2 + cyc_shift) % cyc_C);
-    const int du = (kBlock * 2) % cyc_C;
-    auto load_pair = [&](int64_t i) -> r2_t {
-        if (i + 1 < n) return *reinterpret_cast<const r2_t *>(x + i);
-        if (i < n) return r2_t{x[i], 0.0};
-        return r2_t{0.0, 0.0};
-    };
-    auto accumulate = [&](int64_t base, const r2_t (&v)[kEpsU]) {
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
-            int c0 = rc, c1 = rc + 1 == cyc_C ? 0 : rc + 1;
-            rc += du;
-            rc = rc >= cyc_C ? rc - cyc_C : rc;
-            if (i + 1 >= n) c1 = -2;
-            if (i >= n) c0 = -2;
-            if (pair) c1 = c0;
-            const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                acc[c] += (c0 == c) ? s0 : 0.0;
-                acc[c] += (c1 == c) ? s1 : 0.0;
-            }
-        }
-    };
-    // every kept tile is requested before anything is added: 4 HT 16-byte loads in flight per thread
-#pragma unroll
-    for (int k = 0; k < HT; ++k)
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) {
-            const r2_t v = load_pair(base0 + (int64_t)k * tile + (int64_t)u * kBlock * 2 + threadIdx.x * 2);
-            xq[u][2 * k] = v.x;
-            xq[u][2 * k + 1] = v.y;
-        }
-    r2_t va[kEpsU];
-    int64_t bs = base0 + (int64_t)HT * tile;
-    bool more = bs < base_end;
-    if (more) {
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) va[u] = load_pair(bs + (int64_t)u * kBlock * 2 + threadIdx.x * 2);
-    }
-#pragma unroll
-    for (int k = 0; k < HT; ++k)
-        if (base0 + (int64_t)k * tile < base_end) {
-            r2_t vk[kEpsU];
-#pragma unroll
-            for (int u = 0; u < kEpsU; ++u) vk[u] = r2_t{xq[u][2 * k], xq[u][2 * k + 1]};
-            accumulate(base0 + (int64_t)k * tile, vk);
-        }
-    if (more) {      // tile HT is kept in LDS (pair p of the tile at lds_tile[p])
-#pragma unroll
-        for (int u = 0; u < kEpsU; ++u) lds_tile[u * kBlock + threadIdx.x] = va[u];
-    }
-    while (more) {
-        accumulate(bs, va);
-        bs += tile;
-        more = bs < base_end;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < kEpsU; ++u) va[u] = load_pair(bs + (int64_t)u * kBlock * 2 + threadIdx.x * 2);
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const double w = wave_sum(acc[c]);
-        if (lane == 0) red[wave][c] = w;
-    }
-    __syncthreads();
-    if (wave != 0) return false;
-    s = 0.0;
-    if (lane < NC) {
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) s += red[w][lane];
-    }
-    return true;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // the fused step
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -307,10 +204,7 @@ struct FusedEps {
     real_t *xw;                      // NULL, or x: sharded -- the halo cells [own_begin - halo, own_begin), [own_end, own_end + halo) arrive with the launch
     long long own_begin, own_end;
     int halo;
-    int held;                        // 1: the HELD step (k_f_tridiag_held) -- every workgroup reduces its block of x, keeps it in registers and stores
-                                     //   its columns once the step sizes are out: x is read once.  One GPU, the whole matrix, tpb <= kFzHeldTiles + 1.
 };
-constexpr int kFzHeldTiles = 4;      // tiles of 2048 elements a workgroup of the held step keeps (64 of its 128 registers per lane for Float64)
 __device__ __forceinline__ char *fz_cells(char *mailbox, const FusedEps &fz, int buf) { return mailbox + fz.fz_off + (long long)buf * kFzBufBytes; }
 // trace slots: 0 first reduction workgroup starts (min), 1 last block sum published (max), 2 finisher starts, 3 finisher has every block
 // sum, 4 step sizes published, 5 first storing workgroup starts (min), 6 / 7 first / last storing workgroup has the step sizes, 8 last

@@ -120,9 +120,6 @@ struct fdjac_p2p_fused {
 extern "C" int fdjac_p2p_fused_begin(fd_p2p *p, fdjac_p2p_fused *out);      // (the step's buffer; the epoch advances with fdjac_p2p_fused_commit)
 extern "C" void fdjac_p2p_fused_commit(fd_p2p *p);
 extern "C" int fdjac_p2p_shared_device(const fd_p2p *p);      // 1: some peer lives on this rank's device (no fused sharded step then)
-extern "C" void fdjac_held_ctx(int device, int delta);                        // a context on `device` is created (+1) / destroyed (-1)
-extern "C" int fdjac_held_admit(const void *ctx_key, int device);             // 1: no other context's held launch is in flight on `device`
-extern "C" void fdjac_held_launched(const void *ctx_key, int device, void *stream);
 extern "C" int fdjac_p2p_failed(const fd_p2p *p);
 extern "C" int *fdjac_p2p_err_word(const fd_p2p *p);    // (device address)
 extern "C" int fdjac_p2p_agree8(fd_p2p *p, const double *mine, double *out);      // blocking all-gather of 8 doubles per rank (host arrays)       // the mailbox's sticky error word (a wait timed out)
@@ -416,7 +413,6 @@ struct fd_plan {
     unsigned fz_parity = 0;
     long long *d_fz_trace = nullptr;          // FDJAC_FUSED_TRACE=1: wall_clock64 marks of the last fused launch (fd_plan_fused_trace)
     bool fz_sharded_ok = true;                // sharded calls with a mailbox take the fused step (FDJAC_FUSED_SHARDED=0: the three-launch form)
-    bool fz_held_ok = true;                   // one GPU, fz_max_n < N <= 10.4 M: the held step, x read once (FDJAC_FUSED_HELD=0: two launches)
     bool fz_shared_ok = false;                //   ... even when ranks share this device (FDJAC_FUSED_SHARED=1: small test problems only)
     int64_t fz_max_n = (int64_t)1 << 21;      // single GPU: problems up to this size take the fused step (FDJAC_FUSED_MAX_N; 0 = never)
     fd_comm *comm = nullptr;       // sharded step-size reduction (fd_plan_set_comm); nullptr = every rank reduces all of x

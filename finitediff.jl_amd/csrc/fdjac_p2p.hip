@@ -36,52 +36,6 @@ constexpr int64_t kP2PFlagStride = 128;      // one line per sender
 // once allocated with hipDeviceMallocUncached, freed and then recycled into ORDINARY allocations misbehaved -- kernels reading freshly
 // uploaded arrays there saw other data (plan builds failing their consistency checks, wrong group sums; gone with FDJAC_P2P_UNCACHED=0 --
 // profiles/NOTES.md, round 6).  A mailbox that is destroyed parks its block here and the next mailbox of that size takes it.
-// ---- the held step's admission (fdjac_api.hip, k_f_tridiag_held) --------------------------------------------------------------------
-// A held launch fills the device with workgroups that wait for each other.  Two of them in flight at once -- two contexts of this
-// process on one device -- could each hold half of the device and wait for the other half forever (until the wait's time-out).  One
-// launch at a time per device is admitted across contexts: a context that finds another context's held launch still running takes the
-// separate launches for that call.  (With one context per device nothing is recorded.  Other PROCESSES on the device are not seen:
-// the waits' time-out, FD_ERR_COMM, is what they get.)
-namespace {
-struct HeldDev { const void *owner = nullptr; hipEvent_t ev = nullptr; bool pending = false; int live = 0; };
-std::mutex g_held_mutex;
-HeldDev g_held[64];
-}
-extern "C" void fdjac_held_ctx(int device, int delta)
-{
-    if (device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lock(g_held_mutex);
-    HeldDev &h = g_held[device];
-    h.live += delta;
-    // a second context appears while the first may have an unrecorded held launch in flight: let the device drain once
-    if (delta > 0 && h.live > 1 && h.owner && !h.pending) { (void)hipDeviceSynchronize(); h.owner = nullptr; }
-    if (h.live <= 0) { h.live = 0; h.owner = nullptr; h.pending = false; }
-}
-extern "C" int fdjac_held_admit(const void *ctx_key, int device)
-{
-    if (device < 0 || device >= 64) return 0;
-    std::lock_guard<std::mutex> lock(g_held_mutex);
-    HeldDev &h = g_held[device];
-    if (!h.owner || h.owner == ctx_key) return 1;
-    if (!h.pending) return 1;
-    if (hipEventQuery(h.ev) == hipSuccess) { h.pending = false; return 1; }
-    (void)hipGetLastError();
-    return 0;
-}
-extern "C" void fdjac_held_launched(const void *ctx_key, int device, void *stream)
-{
-    if (device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lock(g_held_mutex);
-    HeldDev &h = g_held[device];
-    h.owner = ctx_key;
-    h.pending = false;
-    if (h.live > 1) {
-        if (!h.ev && hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); h.ev = nullptr; }
-        if (h.ev && hipEventRecord(h.ev, (hipStream_t)stream) == hipSuccess) h.pending = true;
-        else (void)hipDeviceSynchronize();      // (no event: nothing may overlap this launch)
-    }
-}
-
 static std::mutex g_unc_mutex;
 static std::vector<std::pair<size_t, void *>> g_unc_pool;
 static void *unc_take(size_t bytes)

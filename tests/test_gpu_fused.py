@@ -163,40 +163,3 @@ def test_rank_share_through_a_loopback_mailbox_has_the_bits_of_the_unsharded_sli
             assert torch.equal(x[c0 - halo:c0], x_full[c0 - halo:c0])
         if r + 1 < W:
             assert torch.equal(x[c1:c1 + halo], x_full[c1:c1 + halo])
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("fdtype,kind,family,C,N", [
-    ("forward", "csc", "tridiag_nl", 3, 10 ** 7),           # the headline: 5 tiles per block (4 kept in registers, the fifth in LDS)
-    ("central", "banded", "tridiag", 4, 2 ** 21 + 4097),    # 2 tiles per block, the last blocks of the groups empty or short
-    ("forward", "tridiagonal", "tridiag_nl", 7, 5 * 10 ** 6 + 3),
-    ("central", "csc", "tridiag_nl", 3, 10 * 2 ** 20),      # the largest problem that takes the held step: every block full
-])
-def test_held_step_has_the_bits_of_the_two_launch_call(dtype, fdtype, kind, family, C, N):
-    # the held step (k_f_tridiag_held): x read ONCE -- every workgroup of the reduction keeps its block and stores its columns itself
-    colors = P.cyclic_colors(N, C)
-    f = fd.BuiltinF(family, N, dtype=dtype)
-    rng = np.random.default_rng(N % 1000 + C)
-    xs = [torch.as_tensor(((rng.random(N) * 2 - 0.5) * (1 + 3 * it)).astype(dtype), device="cuda") for it in range(2)]
-    res = {}
-    for fused in (False, True):
-        J = _storage(kind, N, dtype)
-        plan = fd.make_plan(J, J, colors, fdtype, dtype=dtype)
-        plan.set_lazy(f, fused=fused)
-        got = []
-        for it in range(3):
-            for o in _outs(J):
-                o.fill_(float("nan"))
-            plan.enable_timing(2)
-            plan.jacobian(f, xs[it % 2], _outs(J))
-            tm = plan.timings()
-            plan.enable_timing(0)
-            assert tm["eps"]["launches"] == (0 if fused else 1), (fused, tm)
-            got.append(([o.clone() for o in _outs(J)], plan.epsilons()))
-        res[fused] = got
-        del J, plan
-    for (oa, ea), (ob, eb) in zip(res[False], res[True]):
-        assert np.array_equal(ea, eb)
-        for a, b in zip(oa, ob):
-            assert not torch.isnan(b).any()
-            assert torch.equal(a, b)
