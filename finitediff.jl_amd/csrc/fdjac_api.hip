@@ -23,6 +23,7 @@ static thread_local char g_err[512] = "";
 int launch_eps(fd_plan *p, const real_t *x, double relstep, double absstep, double dir);
 int launch_eps_groups(fd_plan *p, const real_t *x, int g0, int ng, bool final, double relstep, double absstep, double dir);
 int launch_eps_final(fd_plan *p, double relstep, double absstep, double dir);
+int launch_eps_flags(fd_plan *p, const real_t *x, const FusedEps &fz);
 constexpr int kMaxEpsShards = kEpsGroups;   // a shard of the reduction is a whole number of groups
 int launch_eps_perturb_small(fd_plan *p, const real_t *x, double relstep, double absstep, double dir, int pmode,
                              int base_row);
@@ -160,6 +161,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
     p->fz_sharded_ok = env_int("FDJAC_FUSED_SHARDED", 1) != 0;
     p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
+    p->fz_flags_ok = env_int("FDJAC_EPS_FLAGS", 1) != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;
     p->bd_allowed = env_int("FDJAC_BAND_DESC", 1) != 0;
     // a FD_LAZY_CAP_STORE launcher stores the Jacobian of a verified exact band itself (include/fdjac_device.h): default since
@@ -817,8 +819,17 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
     } else if (fuse) {
         fuse = p->N <= p->fz_max_n;
     }
+    // the reduction as its own launch takes the fused step's hand-offs too (k_eps_flags: finishers instead of tickets) -- one GPU, <= 8 colours
+    bool eps_flags = !fuse && p->fz_flags_ok && !small && !shard_ctx && p->fdtype != FD_COMPLEX && p->C > 0 && p->C <= kRegColors &&
+                     p->kind != K_DENSE && p->eps_mode == FD_EPS_COMPUTE && p->d_partial != nullptr &&
+                     p->n_partial_blocks == kEpsGroups * p->eps_bpg && p->n_partial_blocks <= kFzMaxBlocks;
+    if (eps_flags) {      // (a captured call is replayed with the capture's buffer parity: the ticket form carries no host state)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) eps_flags = false;
+    }
     FusedEps fz_job;
-    if (fuse) {
+    if (fuse || eps_flags) {
         const int rc = ensure_fused(p);
         if (rc) return rc;
         memset(&fz_job, 0, sizeof fz_job);
@@ -860,6 +871,11 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         FD_REQUIRE(!small_points, FD_ERR_UNSUPPORTED, "FD_EPS_PRECOMPUTED needs a plan whose reduction can be sharded");
     } else if (fuse) {
         // (nothing here: the storing launch below computes the step sizes)
+    } else if (eps_flags) {
+        Span sp(p, FD_STAGE_EPS);
+        const int rc = launch_eps_flags(p, x_dev, fz_job);
+        if (rc) return rc;
+        p->fz_parity ^= 1u;
     } else if (p->fdtype != FD_COMPLEX && p->C > 0) {
         Span sp(p, FD_STAGE_EPS);
         int rc;

@@ -237,13 +237,14 @@ __device__ __forceinline__ void fz_load8_agent(const unsigned long long *const (
 
 // a reduction workgroup of the fused step: level 0, published value by value (colour-major: the finisher of colour c reads
 // part[c][0 .. nblocks) with dense loads)
-template <int NC, bool PIPE>
-__device__ __forceinline__ void fused_eps_block(const real_t *__restrict__ x, int64_t n, const FusedEps &fz, int gblock, double (*red)[NC])
+template <int NC, bool PIPE, typename CT = uint8_t, bool CYC = true, bool NT = false>
+__device__ __forceinline__ void fused_eps_block(const real_t *__restrict__ x, int64_t n, const FusedEps &fz, int gblock, double (*red)[NC],
+                                                const CT *__restrict__ color = nullptr)
 {
     double s;
     if (threadIdx.x == 0) fz_mark_min(fz, 0);
     // (gblock counts this launch's reduction workgroups; the block of the GLOBAL grid it reduces starts at the rank's first group)
-    if (!eps_block_sum<uint8_t, NC, true, false, PIPE>(x, nullptr, n, fz.cyc_C, fz.cyc_shift, fz.g0 * fz.eg.bpg + gblock, fz.eg, fz.pair, red, s)) return;
+    if (!eps_block_sum<CT, NC, CYC, NT, PIPE>(x, color, n, fz.cyc_C, fz.cyc_shift, fz.g0 * fz.eg.bpg + gblock, fz.eg, fz.pair, red, s)) return;
     const int lane = threadIdx.x & 63;
     if (lane < fz.eg.C) __hip_atomic_store(fz.part + (int64_t)lane * fz.nblocks + gblock, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fz_mark_max(fz, 1);
