@@ -222,6 +222,54 @@ def cpu_baseline(n, reps, seconds=10.0):
     return res
 
 
+def live_pmc(cfg, dtype, kernel_like, timeout_s=150.0):
+    """HBM bytes per launch of the graded kernel, measured NOW: two bounded rocprofv3 passes (--pmc FETCH_SIZE / WRITE_SIZE with
+    --kernel-trace only) of a short run of this same command, corrected as MI355X_MICROARCH.md prescribes -- both counters calibrated on
+    the 1 GiB stream copy the run itself contains (FETCH_SIZE comes out x2 on gfx950).  None when rocprofv3 is not on the box, when this
+    process is itself being profiled, or when a pass fails / times out: the caller then falls back to the committed PMC file."""
+    import shutil, sqlite3, subprocess, tempfile
+    if os.environ.get("FDJAC_BENCH_LIVE_PMC", "1") == "0" or os.environ.get("FDJAC_BENCH_PMC_CHILD"):
+        return None, "live PMC switched off"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is being profiled"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "no rocprofv3 on this box"
+    out = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="fdjac_pmc_", dir="/tmp") as tmp:
+        env = dict(os.environ, FDJAC_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--dtype", dtype, "--steps", "5", "--warmup", "2",
+               "--no-cpu-baseline", "--soak-seconds", "0", "--no-plain-handover"]
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            try:
+                subprocess.run(["timeout", "-k", "5", str(int(timeout_s)), exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "run", "--"] + cmd,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s + 15, check=False)
+            except Exception as e:
+                return None, "rocprofv3 pass failed: %s" % type(e).__name__
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, "rocprofv3 pass wrote no database"
+            try:
+                cur = sqlite3.connect(dbs[0]).cursor()
+                def mean(like):
+                    cur.execute("select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", ("%" + like + "%", counter))
+                    v, n = cur.fetchone()
+                    return (v or 0.0), (n or 0)
+                cal, ncal = mean("k_stream_copy")
+                val, nval = mean(kernel_like)
+            except Exception as e:
+                return None, "counter database unreadable: %s" % type(e).__name__
+            if not (ncal > 0 and nval > 0 and cal > 0):
+                return None, "kernel or calibration copy not found in the %s pass" % counter
+            out[counter] = {"raw_kb": val, "factor": float(1 << 30) / (cal * 1024.0), "dispatches": nval}
+    rd = out["FETCH_SIZE"]["raw_kb"] * 1024.0 * out["FETCH_SIZE"]["factor"]
+    wr = out["WRITE_SIZE"]["raw_kb"] * 1024.0 * out["WRITE_SIZE"]["factor"]
+    return {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "fetch_factor": out["FETCH_SIZE"]["factor"], "write_factor": out["WRITE_SIZE"]["factor"],
+            "dispatches": [out["FETCH_SIZE"]["dispatches"], out["WRITE_SIZE"]["dispatches"]], "seconds": time.perf_counter() - t0}, None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -888,8 +936,22 @@ def main():
                                "(FETCH_SIZE x2 + WRITE_SIZE, calibrated on the 1 GiB stream copy of the same run); not measured in this process" % cfg)
             except Exception:
                 pmc = None
+        # ... or measured now, when rocprofv3 is on the box (one GPU, the default run: two short passes of this command)
+        pmc_live = None
+        if world == 1 and not args.no_plain_handover and not os.environ.get("FDJAC_BENCH_PMC_CHILD"):
+            klike = kern.split("<")[0]
+            pmc_live, why = live_pmc(cfg, args.dtype, klike)
+            if pmc_live:
+                pmc = pmc_live["bytes"]
+                pmc_src = ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of a 5-step run of this command, started by "
+                           "this bench.py; calibrated on the 1 GiB stream copy of the same run (fetch x%.3f, write x%.3f)" % (pmc_live["fetch_factor"], pmc_live["write_factor"]))
+            elif pmc_src:
+                pmc_src += "; live pass: " + str(why)
+            why_live = why
+        else:
+            why_live = "not attempted (side runs off / several GPUs)"
         traffic = pmc if pmc else bytes_min * n_local
-        traffic_src = pmc_src if pmc else "floor: the bytes this kernel must move (no committed PMC pass matches this run)"
+        traffic_src = pmc_src if pmc else "floor: the bytes this kernel must move (no committed PMC pass matches this run; live pass: %s)" % why_live
         achieved = traffic / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         survey_gbps = bytes_ds * n_local / (dec_ms * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         if dropin and "ms" in dropin and call_med:
@@ -943,7 +1005,7 @@ def main():
                            "separate pass); `value` / `ms_per_step` are the contract's K bracketed steps" % len(call_samples),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": traffic_src, "traffic_live": pmc_live,
                 "kernel": kern,
                 "kernel_role": ("f! at the lazily perturbed points + difference + division + store into nzval in ONE launch "
                                 "(fd_lazy_points.store, include/fdjac_device.h): src/jacobians.jl:563-568 for all colours" if lazy_store else
