@@ -548,6 +548,42 @@ class P2P:
         _l.check(self.L.fd_p2p_halo_exchange(self.handle, p, int(own_begin), int(own_end), int(halo), eb))
 
 
+class BandedSolver:
+    """fd_banded_solver: (alpha*I + beta*J) y = b on the device for a BANDED J (0 <= l, u <= 4) in the storage the banded plans fill --
+    ``BandedMatrix`` data ((l+u+1) x N column-major) or the nzval of the exact band as ``SparseMatrixCSC``.  Block cyclic reduction,
+    no pivoting: a system with a row that is not diagonally dominant is refused (NaN, ``status()`` bit 0) unless ``set_policy(True)``.
+    The consumer of the Jacobian path for a ``BandedMatrix`` jac_prototype."""
+
+    def __init__(self, N, l, u, layout="banded", ctx=None, dtype=np.float64):
+        self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        self.Lt = _l.typed(self.ctx.L, self.dtype)
+        self.layout = {"banded": 0, "csc": 1}[layout]
+        h = C.c_void_p()
+        _l.check(self.Lt.fd_banded_solver_create(self.ctx.handle, int(N), int(l), int(u), self.layout, C.byref(h)))
+        self.handle, self.N, self.l, self.u = h, int(N), int(l), int(u)
+        self._fin = weakref.finalize(self, self.Lt.fd_banded_solver_destroy, h)
+
+    def _dev(self, a, what):
+        p, k, _keep = _ptr(a, what, self.dtype)
+        if k != _l.DEVICE:
+            raise ValueError("the solver takes device arrays")
+        return p
+
+    def solve(self, J, b, y, alpha=1.0, beta=-1.0):
+        """Enqueue y = (alpha*I + beta*J)^-1 b on the context's stream (fd_banded_solve_async)."""
+        vals = J.data if isinstance(J, BandedMatrix) else (J.nzval if isinstance(J, SparseMatrixCSC) else J)
+        _l.check(self.Lt.fd_banded_solve_async(self.handle, float(alpha), float(beta), self._dev(vals, "J"), self._dev(b, "b"), self._dev(y, "y")))
+
+    def set_policy(self, trust_non_dominant):
+        _l.check(self.Lt.fd_banded_solver_set_policy(self.handle, 1 if trust_non_dominant else 0))
+
+    def status(self):
+        v = C.c_int()
+        _l.check(self.Lt.fd_banded_solver_status(self.handle, C.byref(v)))
+        return v.value
+
+
 class TridiagSolver:
     """fd_tridiag_solver: (alpha*I + beta*J) y = b on the device for a tridiagonal J in the storage the Jacobian plans
     fill -- ``Tridiagonal`` (dl, d, du) or the nzval of a tridiagonal ``SparseMatrixCSC`` -- whole or one rank's column

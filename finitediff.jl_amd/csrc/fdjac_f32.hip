@@ -8,3 +8,4 @@
 #include "fdjac_builtin_f.hip"
 #include "fdjac_jvp.hip"
 #include "fdjac_solve.hip"
+#include "fdjac_bandsolve.hip"

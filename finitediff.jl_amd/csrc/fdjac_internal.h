@@ -55,6 +55,12 @@
 #define fd_builtin_f_lazy_caps fd32_builtin_f_lazy_caps
 #define fd_jvp_plan_set_lazy_caps fd32_jvp_plan_set_lazy_caps
 #define fd_builtin_f_lazy_jvp_caps fd32_builtin_f_lazy_jvp_caps
+#define fd_banded_solver fd32_banded_solver
+#define fd_banded_solver_create fd32_banded_solver_create
+#define fd_banded_solver_destroy fd32_banded_solver_destroy
+#define fd_banded_solver_set_policy fd32_banded_solver_set_policy
+#define fd_banded_solver_status fd32_banded_solver_status
+#define fd_banded_solve_async fd32_banded_solve_async
 #define fd_jvp_plan_create fd32_jvp_plan_create
 #define fd_jvp_plan_destroy fd32_jvp_plan_destroy
 #define fd_jvp fd32_jvp

@@ -630,6 +630,24 @@ int fd_tridiag_solve_interface(fd_tridiag_solver *solver, double alpha, double b
 int fd_tridiag_solve_finish(fd_tridiag_solver *solver, double alpha, double beta, const void *const *J, const void *b,
                             const void *packets_dev, int rank, int nranks, void *y);
 
+/* ---- the consumer for wider bands: (alpha*I + beta*J) y = b for a BANDED J, 0 <= l, u <= 4 (round 6) --------------------------------
+ * The linear system of an implicit / Rosenbrock step whose jac_prototype is a BandedMatrix (pentadiagonal, ...), on J's own device
+ * storage as the banded plans write it:
+ *   FD_BAND_SOLVE_BANDED  J = BandedMatrix data, (l+u+1) x N column-major (the out of a fd_plan_create_banded plan)
+ *   FD_BAND_SOLVE_CSC     J = nzval of the exact band as SparseMatrixCSC (the out of a fd_plan_create_csc plan of that pattern)
+ * Block cyclic reduction with K x K blocks, K = max(l, u), no pivoting, Float64 arithmetic whatever the element type; level 0 is
+ * read straight from J and b.  One GPU, the whole matrix (the tridiagonal case, l = u = 1, also has the faster and shardable
+ * fd_tridiag_solve_async).  Policy and status as for the tridiagonal solver: every row of alpha*I + beta*J is checked for diagonal
+ * dominance; a solve that meets a row that is not raises status bit 0 and REFUSES (y = NaN) unless
+ * fd_banded_solver_set_policy(solver, 1).  Everything is enqueued on the context's stream; fd_banded_solver_status synchronises it. */
+typedef struct fd_banded_solver fd_banded_solver;
+enum fd_banded_solve_layout { FD_BAND_SOLVE_BANDED = 0, FD_BAND_SOLVE_CSC = 1 };
+int fd_banded_solver_create(fd_ctx *ctx, int64_t N, int l, int u, int layout, fd_banded_solver **out);
+int fd_banded_solver_destroy(fd_banded_solver *solver);
+int fd_banded_solver_set_policy(fd_banded_solver *solver, int trust_non_dominant);
+int fd_banded_solver_status(fd_banded_solver *solver, int *flags_out);
+int fd_banded_solve_async(fd_banded_solver *solver, double alpha, double beta, const void *J, const void *b, void *y);
+
 /* ---- runtime compilation of a row functor (hiprtc) --------------------------------------------------------------------------------
  * The reference accepts ANY callable as f! (src/jacobians.jl:541,563,605-606,634).  The one-launch call of this library needs f! as
  * device code; a caller without an offline toolchain (a Julia process) hands it over as SOURCE: a functor type
@@ -725,6 +743,12 @@ int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
 int fd32_plan_fused_trace(fd32_plan *plan, long long *marks16);
+typedef struct fd32_banded_solver fd32_banded_solver;
+int fd32_banded_solver_create(fd_ctx *ctx, int64_t N, int l, int u, int layout, fd32_banded_solver **out);
+int fd32_banded_solver_destroy(fd32_banded_solver *solver);
+int fd32_banded_solver_set_policy(fd32_banded_solver *solver, int trust_non_dominant);
+int fd32_banded_solver_status(fd32_banded_solver *solver, int *flags_out);
+int fd32_banded_solve_async(fd32_banded_solver *solver, double alpha, double beta, const void *J, const void *b, void *y);
 typedef struct fd32_tridiag_solver fd32_tridiag_solver;
 int fd32_tridiag_solver_create(fd_ctx *ctx, int64_t N, int64_t row_begin, int64_t row_end, int layout,
                                fd32_tridiag_solver **out);
