@@ -752,6 +752,43 @@ static int client_solve(void)
     return report("solve", worst, 1e-12, calls, 3);
 }
 
+/* shim: BandedSolver -- the consumer for a BandedMatrix jac_prototype: the Jacobian lands in BandedMatrix data, W y = b is solved there */
+static int client_bandsolve(void)
+{
+    const int64_t N = 100001;
+    const double gamma = 0.05;
+    int64_t *colors = cyclic_colors(N, 3);
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N);
+    double *data = dev_nan((size_t)(3 * N));                  /* BandedMatrix data, (l + u + 1) x N column-major, l = u = 1 */
+    double *b = malloc(sizeof(double) * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) b[i] = cos(0.01 * (double)i);
+    double *bd = to_dev(b, sizeof(double) * (size_t)N), *yd = dev_nan((size_t)N);
+    fd_f_launch f; void *fctx; fd_plan *plan; fd_banded_solver *solver;
+    const int64_t prm[1] = {N};
+    CHECK(new_f(FD_F_TRIDIAG_NL, prm, 1, &f, &fctx));
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = FD_COMPLEX;
+    CHECK(fd_plan_create_banded(g_ctx, N, N, 1, 1, colors, 8, &o, &plan));
+    CHECK(fd_banded_solver_create(g_ctx, N, 1, 1, FD_BAND_SOLVE_BANDED, &solver));
+    void *outs[3] = {data, NULL, NULL};
+    CHECK(fd_jacobian_async(plan, f, fctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_banded_solve_async(solver, 1.0, -gamma, data, bd, yd));      /* same stream: no sync in between */
+    int flags = -1;
+    CHECK(fd_banded_solver_status(solver, &flags));
+    double *y = malloc(sizeof(double) * (size_t)N);
+    from_dev(y, yd, sizeof(double) * (size_t)N);
+    double worst = flags == 0 ? 0 : 1;        /* residual with the ANALYTIC Jacobian (complex step: J exact to ~1e-16) */
+    for (int64_t i = 0; i < N; ++i) {
+        double r = (1.0 - gamma * tridiag_nl_J(x, N, i, i)) * y[i] - b[i];
+        if (i > 0) r -= gamma * tridiag_nl_J(x, N, i, i - 1) * y[i - 1];
+        if (i + 1 < N) r -= gamma * tridiag_nl_J(x, N, i, i + 1) * y[i + 1];
+        if (!(fabs(r) <= worst)) worst = fabs(r);
+    }
+    const int64_t calls = f_points(fctx);
+    CHECK(fd_banded_solver_destroy(solver)); CHECK(fd_plan_destroy(plan)); CHECK(fd_builtin_f_destroy(fctx));
+    hipFree(xd); hipFree(data); hipFree(bd); hipFree(yd); free(y); free(b); free(x); free(colors);
+    return report("bandsolve", worst, 1e-12, calls, 3);
+}
+
 /* shim: the host-array method (x::Vector{Float64}, J::SparseMatrixCSC on the host) -> fd_jacobian with FD_HOST */
 static int client_host(void)
 {
@@ -1187,6 +1224,7 @@ int main(int argc, char **argv)
     RUN("csc_f32", client_csc_f32())
     RUN("jvp", client_jvp())
     RUN("solve", client_solve())
+    RUN("bandsolve", client_bandsolve())
     RUN("host", client_host())
     RUN("complex_x", client_complex_x(FD_FORWARD) | client_complex_x(FD_CENTRAL))
     RUN("complex_structured", client_complex_structured(0, FD_FORWARD) | client_complex_structured(0, FD_CENTRAL) |
