@@ -159,7 +159,6 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
     p->eps_nt = p->eps_nt_forced != 0;
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
-    p->fz_sharded_ok = env_int("FDJAC_FUSED_SHARDED", 1) != 0;
     p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
     p->fz_flags_ok = env_int("FDJAC_EPS_FLAGS", 1) != 0;
     p->lazy_diff = env_int("FDJAC_LAZY_DIFF", 1) != 0;

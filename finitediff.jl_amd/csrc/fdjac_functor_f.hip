@@ -868,8 +868,7 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         // both are enqueued (they store the same bits), afterwards only the one that works
         const int cap_r = (int)std::min<int64_t>((int64_t)(kBlock * per_row * 1.25) + 64, 3072);
         const size_t lds_r = win ? sparse_rows_lds_bytes(reach, lp->ncolors, cap_r) : 0;
-        const char *rs = fdjac::test_switch("FDJAC_SPARSE_ROWS");
-        const bool rows = win && st.note != nullptr && st.plan_serial != 0 && lds_r <= 64 * 1024 && b->d_sdest && !(rs && *rs && atoi(rs) == 0);
+        const bool rows = win && st.note != nullptr && st.plan_serial != 0 && lds_r <= 64 * 1024 && b->d_sdest;
         const long long e_base = b->h_colptr[(size_t)st.col_begin], expect = (long long)b->h_colptr[(size_t)st.col_end] - e_base;
         const unsigned long long key = rows ? ((0x5BA25E0000000000ull ^ ((unsigned long long)(uintptr_t)b->d_sdest << 3) ^ ((unsigned long long)st.col_begin * 0x9E3779B97F4A7C15ull) ^
                                                 (unsigned long long)st.col_end) & ~2ull) | 4ull : 0ull;

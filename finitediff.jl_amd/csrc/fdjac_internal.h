@@ -418,7 +418,7 @@ struct fd_plan {
     int *h_fz_err = nullptr, *d_fz_err = nullptr;
     unsigned fz_parity = 0;
     long long *d_fz_trace = nullptr;          // FDJAC_FUSED_TRACE=1: wall_clock64 marks of the last fused launch (fd_plan_fused_trace)
-    bool fz_sharded_ok = true;                // sharded calls with a mailbox take the fused step (FDJAC_FUSED_SHARDED=0: the three-launch form)
+    bool fz_sharded_ok = true;                // sharded calls with a mailbox take the fused step (shards up to fz_max_n columns)
     bool fz_flags_ok = true;                  // the reduction's own launch in the flag form (k_eps_flags; FDJAC_EPS_FLAGS=0: tickets, k_eps_partial_reg)
     bool fz_shared_ok = false;                //   ... even when ranks share this device (FDJAC_FUSED_SHARED=1: small test problems only)
     int64_t fz_max_n = (int64_t)1 << 21;      // single GPU: problems up to this size take the fused step (FDJAC_FUSED_MAX_N; 0 = never)

@@ -1314,7 +1314,7 @@ static int launch_eps_groups_t(fd_plan *p, const real_t *x, int g0, int ng, bool
         if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_REG(NCC, true, true); else FD_EPS_REG(NCC, true, false); }     \
         else { if (p->eps_nt) FD_EPS_REG(NCC, false, true); else FD_EPS_REG(NCC, false, false); }               \
     } while (0)
-    if (C <= 4) FD_EPS_REG_V(4); else FD_EPS_REG_V(kRegColors);
+    if (C <= 4) FD_EPS_REG_V(4); else if (C <= 6) FD_EPS_REG_V(6); else FD_EPS_REG_V(kRegColors);      // (colour sums kept per thread: 4, 6 or 8 -- c3's five colours: 30 -> 26 us)
 #undef FD_EPS_REG_V
 #undef FD_EPS_REG
     if (final) p->eps2_fresh = p->d_eps2 != nullptr;
@@ -1334,7 +1334,7 @@ static int launch_eps_flags_t(fd_plan *p, const real_t *x, const FusedEps &fz)
         if (p->cyc_C > 0) { if (p->eps_nt) FD_EPS_FZ(NCC, true, true); else FD_EPS_FZ(NCC, true, false); }       \
         else { if (p->eps_nt) FD_EPS_FZ(NCC, false, true); else FD_EPS_FZ(NCC, false, false); }                 \
     } while (0)
-    if (fz.eg.C <= 4) FD_EPS_FZ_V(4); else FD_EPS_FZ_V(kRegColors);
+    if (fz.eg.C <= 4) FD_EPS_FZ_V(4); else if (fz.eg.C <= 6) FD_EPS_FZ_V(6); else FD_EPS_FZ_V(kRegColors);
 #undef FD_EPS_FZ_V
 #undef FD_EPS_FZ
     p->eps2_fresh = p->d_eps2 != nullptr;

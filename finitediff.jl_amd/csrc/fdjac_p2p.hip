@@ -34,7 +34,7 @@ constexpr int kP2PMaxRanks = 64;
 constexpr int64_t kP2PFlagStride = 128;      // one line per sender
 // Fine-grained ("uncached") device allocations are never handed back to the runtime's allocator: on ROCm 7.0 / MI355X memory that was
 // once allocated with hipDeviceMallocUncached, freed and then recycled into ORDINARY allocations misbehaved -- kernels reading freshly
-// uploaded arrays there saw other data (plan builds failing their consistency checks, wrong group sums; gone with FDJAC_P2P_UNCACHED=0 --
+// uploaded arrays there saw other data (plan builds failing their consistency checks, wrong group sums; gone with plain hipMalloc mailboxes --
 // profiles/NOTES.md, round 6).  A mailbox that is destroyed parks its block here and the next mailbox of that size takes it.
 static std::mutex g_unc_mutex;
 static std::vector<std::pair<size_t, void *>> g_unc_pool;
@@ -352,11 +352,10 @@ int fd_p2p_create(fd_ctx *ctx, int nranks, int rank, int64_t slot_bytes, fd_p2p 
     // fine-grained (uncached) device memory if the runtime shares it between processes, else plain device memory (all accesses to the
     // mailbox are system-scope atomics either way)
     void *mem = nullptr;
-    const char *unc = getenv("FDJAC_P2P_UNCACHED");
     p->local_bytes = bytes;
-    if (!(unc && *unc == '0') && (mem = unc_take(bytes)) != nullptr) {
+    if ((mem = unc_take(bytes)) != nullptr) {
         p->uncached = true;
-    } else if (!(unc && *unc == '0') && hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
+    } else if (hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached) == hipSuccess) {
         hipIpcMemHandle_t probe;
         if (hipIpcGetMemHandle(&probe, mem) == hipSuccess) p->uncached = true;
         else { unc_park(bytes, mem); mem = nullptr; }
