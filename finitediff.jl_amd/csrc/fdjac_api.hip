@@ -152,12 +152,11 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     p->small_ok = env_int("FDJAC_SMALL", 1) != 0;
     // non-temporal loads of x in the step-size reduction: right when 240 MB of plain nzval stores are still draining (the
     // hand-over path, round 2); WRONG when f!'s storing launch follows (round 3): that launch re-reads x, which the reduction's
-    // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  Unless
-    // FDJAC_EPS_NT forces one, a call decides by which path it takes.
+    // plain loads leave in the 256 MiB Infinity Cache -- N = 10^7: 75 instead of 82 us per Jacobian (profiles/r03_c_*).  A call
+    // decides by which path it takes.
     p->cx = t_lowered_cx;                                // (inside a LoweredScope only)
     if (p->cx) p->small_ok = false;                      // the fused small-problem launch has ONE colour rule for norm and perturbation
-    p->eps_nt_forced = env_int("FDJAC_EPS_NT", -1);
-    p->eps_nt = p->eps_nt_forced != 0;
+    p->eps_nt = true;
     { const char *v = fdjac::test_switch("FDJAC_FUSED_MAX_N"); if (v && *v) p->fz_max_n = atoll(v); }
     p->fz_shared_ok = env_int("FDJAC_FUSED_SHARED", 0) != 0;
     p->fz_flags_ok = env_int("FDJAC_EPS_FLAGS", 1) != 0;
@@ -481,7 +480,7 @@ int fd_plan_info(const fd_plan *p, int key, int64_t *value)
                   p->fdtype != FD_COMPLEX) ? 1 : 0;
         break;
     case FD_INFO_EPS_CYCLIC: *value = p->cyc_C; break;
-    case FD_INFO_EPS_NT: *value = (p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !store_active(p)) ? 1 : 0; break;
+    case FD_INFO_EPS_NT: *value = !(store_active(p) || store_csc_active(p)) ? 1 : 0; break;
     case FD_INFO_BAND_DESC: *value = p->bd_t1 - p->bd_t0; break;
     case FD_INFO_LAZY_STORE:
         *value = (store_active(p) || store_csc_active(p)) ? 1 : 0;
@@ -863,7 +862,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
         }
     }
     if (p->eps_mode != FD_EPS_PRECOMPUTED) p->eps2_fresh = false;
-    p->eps_nt = p->eps_nt_forced >= 0 ? p->eps_nt_forced != 0 : !(store_active(p) || store_csc_active(p));   // (see apply_opts)
+    p->eps_nt = !(store_active(p) || store_csc_active(p));   // (see apply_opts)
     // step sizes for every colour (one pass over x), src/jacobians.jl:559-561 / 600-602
     if (p->fdtype != FD_COMPLEX && p->C > 0 && p->eps_mode == FD_EPS_PRECOMPUTED) {
         // the caller ran fd_plan_eps_partials / exchanged / fd_plan_eps_finalize: p->d_eps is current

@@ -234,9 +234,9 @@ template <typename T> __device__ __forceinline__ T eps_rule(double t, double rel
 // TEST SWITCHES.  A handful of FDJAC_* environment variables select between bit-identical kernel variants / plan builders so that the
 // tests can run both sides of every "same bits" claim (tests/test_gpu_parity.py, test_gpu_planbuild.py, ...):
 //   FDJAC_SMALL (fused single-workgroup launches of small problems), FDJAC_LAZY_DIFF / FDJAC_LAZY_STORE (hand-over forms of the lazy
-//   launchers), FDJAC_EPS_NT / FDJAC_EPS_CYCLIC (step-size reduction's load form / computed colours), FDJAC_BAND_DESC (computed tile
+//   launchers), FDJAC_EPS_CYCLIC (the step-size reduction's computed colours), FDJAC_BAND_DESC (computed tile
 //   descriptors), FDJAC_PLAN_DEVICE (host vs device plan builder), FDJAC_WINDOW / FDJAC_WINDOW2D / FDJAC_SORTED / FDJAC_WIN_TILE /
-//   FDJAC_WIN_PERIODIC / FDJAC_TILE_ORDER / FDJAC_FX_LDS (which decompression kernel a hand-over plan compiles to).
+//   FDJAC_WIN_PERIODIC / FDJAC_TILE_ORDER (which decompression kernel a hand-over plan compiles to).
 // They are read through this ONE function, and only in a process that opted in with FDJAC_TEST_SWITCHES=1 (tests/conftest.py sets it):
 // a production process ignores them altogether -- there every choice is the plan builder's.  (Operational variables are not gated:
 // FDJAC_RCCL_LIB, FDJAC_HIPRTC_LIB, FDJAC_P2P_TIMEOUT_MS, FDJAC_PLAN_THREADS, FDJAC_PLAN_TIMING.)
@@ -289,13 +289,12 @@ struct fd_plan {
     // kernel variants, fixed at plan creation (environment switches are read there, never per process):
     bool tri_window = false;       //   K_TRIDIAG: row-window kernel (FDJAC_WINDOW != 0, C <= 4, even first column)
     bool small_ok = true;          //   fused single-workgroup launches of small problems allowed (FDJAC_SMALL != 0)
-    bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: per call, unless FDJAC_EPS_NT forces it
+    bool eps_nt = true;            //   step-size reduction reads x with non-temporal loads: decided per call
     int eps_tpg = 0, eps_bpg = 0, eps_tpb = 0;   // the two-level reduction's grid (k_eps_partial_reg): tiles per group, blocks per group, tiles
                                    //   per block -- functions of N alone, so every rank / window / shard of one problem cuts x the same way
     bool cx = false;               // complex-valued x (FD_PLAN_COMPLEX_X): this plan is the lowered REAL problem -- element 2j / 2j+1 =
                                    //   re / im of x_j, only the real parts carry colours (are perturbed), a coloured element's masked
                                    //   norm includes its imaginary partner (|x_j|^2), f! is called with is_complex = 1
-    int eps_nt_forced = -1;        //   (-1: non-temporal on the hand-over path, plain when f!'s storing launch re-reads x)
     int cyc_C = 0, cyc_shift = 0;  // cyclic colours: color[j] == (j + cyc_shift) mod cyc_C for every column (0 = not cyclic);
                                    //   the reduction then computes the colours instead of reading them (FDJAC_EPS_CYCLIC=0: off)
 

@@ -770,8 +770,7 @@ static int finish_list_plan(fd_plan *p, const std::vector<int32_t> &col0, std::v
         tm.mark("list: upload positions");
         // f(x) through LDS (forward differences, k_decompress_sorted FXL): the runs of rows every tile touches
         {
-            const char *fl = fdjac::test_switch("FDJAC_FX_LDS");
-            if (p->fdtype == FD_FORWARD && !(fl && *fl && atoi(fl) == 0)) {
+            if (p->fdtype == FD_FORWARD) {
                 std::vector<int32_t> fxw(ntiles * 2 * kFxWin, 0);
                 std::atomic<size_t> eligible{0};
                 if ((rc = parallel_tiles(ntiles, [&](size_t ta, size_t tb) {

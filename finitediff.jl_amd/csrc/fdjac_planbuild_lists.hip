@@ -352,10 +352,7 @@ static int device_build_lists(fd_plan *p, const void *d_colptr, const void *d_ro
         if (!force_t && T == 2048 && sizeof(real_t) >= 8) continue;
         tmask |= 1 << (T == 2048 ? 0 : T == 1024 ? 1 : 2);
     }
-    const bool want_fx = [&] {
-        const char *fx = fdjac::test_switch("FDJAC_FX_LDS");
-        return sorted && p->fdtype == FD_FORWARD && !(fx && *fx && atoi(fx) == 0);
-    }();
+    const bool want_fx = sorted && p->fdtype == FD_FORWARD;
     PbTemps tmp;                                                      // (freed on every return; ownership moves to the plan at the end)
     int32_t *d_rows = nullptr, *d_fxw = nullptr;
     uint8_t *d_nzc = nullptr;

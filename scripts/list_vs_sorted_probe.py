@@ -23,8 +23,8 @@ colors = fd.matrix_colors(J)
 x = torch.rand(N, dtype=torch.float64, device="cuda")
 f = fd.TorchF(lambda fv, xx: fv.copy_(torch.cat([xx, xx[: M - N]])), M, N)
 for fdtype in ("forward", "central"):
-    for env in ({}, {"FDJAC_SORTED": "1"}, {"FDJAC_SORTED": "1", "FDJAC_FX_LDS": "0"}):
-        for k in ("FDJAC_SORTED", "FDJAC_FX_LDS"):
+    for env in ({}, {"FDJAC_SORTED": "1"}):
+        for k in ("FDJAC_SORTED",):
             os.environ.pop(k, None)
         os.environ.update(env)
         plan = fd.make_plan(J, J, colors, fdtype)

@@ -1307,7 +1307,7 @@ def test_small_fused_launch_is_a_plan_property(monkeypatch, oracle, fdtype):
 @pytest.mark.parametrize("C,shift,N", [(3, 0, 100003), (3, 2, 40000), (5, 1, 70001), (8, 3, 33333), (2, 1, 4099 * 5), (4, 0, 2048 * 9 + 1)])
 def test_eps_reduction_variants_bit_identical(monkeypatch, C, shift, N):
     # cyclic colourings: the step-size reduction computes the colours (FD_INFO_EPS_CYCLIC) instead of reading them;
-    # x is read with non-temporal loads (FD_INFO_EPS_NT).  Same values, same order: all four variants give the same bits,
+    # (x is read with non-temporal loads when the hand-over path follows, plain loads otherwise).  Same values, same order: same bits,
     # and they equal the masked-norm rule restated in numpy (src/jacobians.jl:559-561) to 1e-13
     colors = ((np.arange(N) + shift) % C + 1).astype(np.int64)
     xh = np.random.default_rng(90 + C).random(N) * 3 - 1
@@ -1316,17 +1316,14 @@ def test_eps_reduction_variants_bit_identical(monkeypatch, C, shift, N):
     J = fd.SparseMatrixCSC(N, N, colptr, rowval)
     got = {}
     for cyc in ("1", "0"):
-        for nt in ("1", "0"):
-            monkeypatch.setenv("FDJAC_EPS_CYCLIC", cyc)
-            monkeypatch.setenv("FDJAC_EPS_NT", nt)
-            monkeypatch.setenv("FDJAC_SMALL", "0")
-            plan = fd.make_plan(J, J, colors, "forward")
-            assert plan.info(fd.lib.INFO_EPS_CYCLIC) == (C if cyc == "1" else 0)
-            assert plan.info(fd.lib.INFO_EPS_NT) == int(nt)
-            out = _dev(np.full(plan.out_len(0), np.nan))
-            plan.jacobian(fd.TorchF(lambda fx, xx: fx.copy_(xx * xx), N, N), x, [out])
-            got[(cyc, nt)] = plan.epsilons()
-    ref = got[("0", "0")]
+        monkeypatch.setenv("FDJAC_EPS_CYCLIC", cyc)
+        monkeypatch.setenv("FDJAC_SMALL", "0")
+        plan = fd.make_plan(J, J, colors, "forward")
+        assert plan.info(fd.lib.INFO_EPS_CYCLIC) == (C if cyc == "1" else 0)
+        out = _dev(np.full(plan.out_len(0), np.nan))
+        plan.jacobian(fd.TorchF(lambda fx, xx: fx.copy_(xx * xx), N, N), x, [out])
+        got[cyc] = plan.epsilons()
+    ref = got["0"]
     for k, v in got.items():
         assert np.array_equal(v, ref), k
     assert np.allclose(ref, _oracle_eps(xh, colors, "forward"), rtol=1e-13, atol=0)
@@ -2198,7 +2195,7 @@ def test_random_blockbanded_switch_combinations_bit_identical(monkeypatch, seed)
 @pytest.mark.parametrize("case", ["stencil3d", "random_band", "lap5_forced", "stencil3d_none", "random_band_window", "random_band_chunked"])
 def test_sorted_gather_fx_through_lds_bit_identical(monkeypatch, oracle, case):
     # forward differences on the colour-sorted gather kernel: f(x) of the rows a tile touches is staged in LDS (at most 8 runs of
-    # rows per tile, found at plan time) instead of gathered per entry -- FDJAC_FX_LDS=0 gathers; same bits, oracle parity
+    # rows per tile, found at plan time) instead of gathered per entry as the list kernel does; same bits, oracle parity
     rng = np.random.default_rng(31)
     if case.startswith("stencil3d"):
         n = 30
@@ -2252,13 +2249,12 @@ def test_sorted_gather_fx_through_lds_bit_identical(monkeypatch, oracle, case):
         fv.copy_(acc)
 
     outs = []
-    for fxl in ("1", "0"):
-        monkeypatch.setenv("FDJAC_FX_LDS", fxl)
-        monkeypatch.setenv("FDJAC_SORTED", "1")
+    for srt in ("1", "0"):            # the sorted gather (f(x) through LDS) against the list kernel (f(x) gathered per entry)
+        monkeypatch.setenv("FDJAC_SORTED", srt)
         monkeypatch.setenv("FDJAC_WINDOW", "0")
         J = fd.SparseMatrixCSC(N, N, colptr, rowval)
         plan = fd.make_plan(J, J, colors, "forward", scratch_bytes=cap, col_window=win)
-        assert plan.info(fd.lib.INFO_SORTED_GATHER) == 1
+        assert plan.info(fd.lib.INFO_SORTED_GATHER) == int(srt)
         if cap:
             assert plan.info(fd.lib.INFO_NCHUNKS) > 1
         f = fd.TorchF(f_t, N, N)
