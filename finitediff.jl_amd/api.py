@@ -584,6 +584,41 @@ class BandedSolver:
         return v.value
 
 
+class BlockTridiagSolver:
+    """fd_blocktridiag_solver: (alpha*I + beta*J) y = b on the device for a block-tridiagonal J of ``nblk`` dense ``b x b`` blocks
+    (b <= 32) in ``BlockBandedMatrix`` data (block bandwidths (1, 1), uniform block sizes) -- the storage a block-banded plan fills
+    (BASELINE's config 5).  Block cyclic reduction, no pivoting: a system with a row that is not diagonally dominant is refused (NaN,
+    ``status()`` bit 0) unless ``set_policy(True)``."""
+
+    def __init__(self, nblk, block_size, ctx=None, dtype=np.float64):
+        self.ctx = ctx or Context.default()
+        self.dtype = np.dtype(dtype)
+        self.Lt = _l.typed(self.ctx.L, self.dtype)
+        h = C.c_void_p()
+        _l.check(self.Lt.fd_blocktridiag_solver_create(self.ctx.handle, int(nblk), int(block_size), C.byref(h)))
+        self.handle, self.nblk, self.b = h, int(nblk), int(block_size)
+        self._fin = weakref.finalize(self, self.Lt.fd_blocktridiag_solver_destroy, h)
+
+    def _dev(self, a, what):
+        p, k, _keep = _ptr(a, what, self.dtype)
+        if k != _l.DEVICE:
+            raise ValueError("the solver takes device arrays")
+        return p
+
+    def solve(self, J, b, y, alpha=1.0, beta=-1.0):
+        """Enqueue y = (alpha*I + beta*J)^-1 b on the context's stream (fd_blocktridiag_solve_async)."""
+        vals = J.data if isinstance(J, BlockBandedMatrix) else J
+        _l.check(self.Lt.fd_blocktridiag_solve_async(self.handle, float(alpha), float(beta), self._dev(vals, "J"), self._dev(b, "b"), self._dev(y, "y")))
+
+    def set_policy(self, trust_non_dominant):
+        _l.check(self.Lt.fd_blocktridiag_solver_set_policy(self.handle, 1 if trust_non_dominant else 0))
+
+    def status(self):
+        v = C.c_int()
+        _l.check(self.Lt.fd_blocktridiag_solver_status(self.handle, C.byref(v)))
+        return v.value
+
+
 class TridiagSolver:
     """fd_tridiag_solver: (alpha*I + beta*J) y = b on the device for a tridiagonal J in the storage the Jacobian plans
     fill -- ``Tridiagonal`` (dl, d, du) or the nzval of a tridiagonal ``SparseMatrixCSC`` -- whole or one rank's column

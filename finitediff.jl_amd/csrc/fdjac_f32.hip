@@ -9,3 +9,4 @@
 #include "fdjac_jvp.hip"
 #include "fdjac_solve.hip"
 #include "fdjac_bandsolve.hip"
+#include "fdjac_blocksolve.hip"

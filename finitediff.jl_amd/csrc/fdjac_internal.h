@@ -55,6 +55,12 @@
 #define fd_builtin_f_lazy_caps fd32_builtin_f_lazy_caps
 #define fd_jvp_plan_set_lazy_caps fd32_jvp_plan_set_lazy_caps
 #define fd_builtin_f_lazy_jvp_caps fd32_builtin_f_lazy_jvp_caps
+#define fd_blocktridiag_solver fd32_blocktridiag_solver
+#define fd_blocktridiag_solver_create fd32_blocktridiag_solver_create
+#define fd_blocktridiag_solver_destroy fd32_blocktridiag_solver_destroy
+#define fd_blocktridiag_solver_set_policy fd32_blocktridiag_solver_set_policy
+#define fd_blocktridiag_solver_status fd32_blocktridiag_solver_status
+#define fd_blocktridiag_solve_async fd32_blocktridiag_solve_async
 #define fd_banded_solver fd32_banded_solver
 #define fd_banded_solver_create fd32_banded_solver_create
 #define fd_banded_solver_destroy fd32_banded_solver_destroy

@@ -78,6 +78,8 @@ EXPORTS = (
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
     "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status", "fd_tridiag_solver_set_policy",
     "fd_banded_solver_create", "fd_banded_solver_destroy", "fd_banded_solver_set_policy", "fd_banded_solver_status", "fd_banded_solve_async",
+    "fd_blocktridiag_solver_create", "fd_blocktridiag_solver_destroy", "fd_blocktridiag_solver_set_policy", "fd_blocktridiag_solver_status",
+    "fd_blocktridiag_solve_async",
 )
 
 
@@ -95,6 +97,8 @@ TYPED = (
     "fd_tridiag_solve_finish", "fd_plan_create_csc_device", "fd_plan_checksum", "fd_plan_get_timing_samples",
     "fd_plan_eps_shard_range", "fd_plan_matches", "fd_plan_matches_async", "fd_plan_stale", "fd_builtin_f_create_sparse", "fd_tridiag_solver_status", "fd_tridiag_solver_set_policy",
     "fd_banded_solver_create", "fd_banded_solver_destroy", "fd_banded_solver_set_policy", "fd_banded_solver_status", "fd_banded_solve_async",
+    "fd_blocktridiag_solver_create", "fd_blocktridiag_solver_destroy", "fd_blocktridiag_solver_set_policy", "fd_blocktridiag_solver_status",
+    "fd_blocktridiag_solve_async",
 )
 EXPORTS = EXPORTS + tuple("fd32_" + n[3:] for n in TYPED)
 
@@ -252,6 +256,11 @@ def load():
     L.fd_plan_eps_partials.argtypes = [vp, vp, i32, i32, pp, C.POINTER(i64)]
     L.fd_plan_eps_finalize.argtypes = [vp, dbl, dbl, dbl]
     L.fd_plan_set_eps_mode.argtypes = [vp, i32]
+    L.fd_blocktridiag_solver_create.argtypes = [vp, i64, i32, pp]
+    L.fd_blocktridiag_solver_destroy.argtypes = [vp]
+    L.fd_blocktridiag_solver_set_policy.argtypes = [vp, i32]
+    L.fd_blocktridiag_solver_status.argtypes = [vp, C.POINTER(i32)]
+    L.fd_blocktridiag_solve_async.argtypes = [vp, dbl, dbl, vp, vp, vp]
     L.fd_banded_solver_create.argtypes = [vp, i64, i32, i32, i32, pp]
     L.fd_banded_solver_destroy.argtypes = [vp]
     L.fd_banded_solver_set_policy.argtypes = [vp, i32]

@@ -648,6 +648,20 @@ int fd_banded_solver_set_policy(fd_banded_solver *solver, int trust_non_dominant
 int fd_banded_solver_status(fd_banded_solver *solver, int *flags_out);
 int fd_banded_solve_async(fd_banded_solver *solver, double alpha, double beta, const void *J, const void *b, void *y);
 
+/* ---- the consumer for block-banded Jacobians: (alpha*I + beta*J) y = b for a BLOCK-TRIDIAGONAL J (round 6) ---------------------------
+ * J = nblk x nblk dense blocks of block_size x block_size (<= 32), block bandwidths (1, 1), in BlockBandedMatrix data as a
+ * fd_plan_create_blockbanded plan of uniform block sizes fills it (block column J's in-band blocks stacked into one column-major
+ * panel, the panels one after the other: ext/FiniteDiffBlockBandedMatricesExt.jl:44-68) -- BASELINE's config 5.  Block cyclic
+ * reduction, one workgroup per block row, Gauss-Jordan in LDS, no pivoting, Float64 arithmetic.  One GPU.  Policy and status as for the
+ * other consumers: a row of alpha*I + beta*J without diagonal dominance raises status bit 0 and the solve REFUSES (y = NaN) unless
+ * fd_blocktridiag_solver_set_policy(solver, 1). */
+typedef struct fd_blocktridiag_solver fd_blocktridiag_solver;
+int fd_blocktridiag_solver_create(fd_ctx *ctx, int64_t nblk, int block_size, fd_blocktridiag_solver **out);
+int fd_blocktridiag_solver_destroy(fd_blocktridiag_solver *solver);
+int fd_blocktridiag_solver_set_policy(fd_blocktridiag_solver *solver, int trust_non_dominant);
+int fd_blocktridiag_solver_status(fd_blocktridiag_solver *solver, int *flags_out);
+int fd_blocktridiag_solve_async(fd_blocktridiag_solver *solver, double alpha, double beta, const void *data, const void *b, void *y);
+
 /* ---- runtime compilation of a row functor (hiprtc) --------------------------------------------------------------------------------
  * The reference accepts ANY callable as f! (src/jacobians.jl:541,563,605-606,634).  The one-launch call of this library needs f! as
  * device code; a caller without an offline toolchain (a Julia process) hands it over as SOURCE: a functor type
@@ -743,6 +757,12 @@ int fd32_plan_set_lazy_f(fd32_plan *plan, fd_f_launch_lazy lazy);
 int fd32_plan_set_lazy_caps(fd32_plan *plan, int caps);
 int fd32_plan_get_epsilons(fd32_plan *plan, double *eps_out);
 int fd32_plan_fused_trace(fd32_plan *plan, long long *marks16);
+typedef struct fd32_blocktridiag_solver fd32_blocktridiag_solver;
+int fd32_blocktridiag_solver_create(fd_ctx *ctx, int64_t nblk, int block_size, fd32_blocktridiag_solver **out);
+int fd32_blocktridiag_solver_destroy(fd32_blocktridiag_solver *solver);
+int fd32_blocktridiag_solver_set_policy(fd32_blocktridiag_solver *solver, int trust_non_dominant);
+int fd32_blocktridiag_solver_status(fd32_blocktridiag_solver *solver, int *flags_out);
+int fd32_blocktridiag_solve_async(fd32_blocktridiag_solver *solver, double alpha, double beta, const void *data, const void *b, void *y);
 typedef struct fd32_banded_solver fd32_banded_solver;
 int fd32_banded_solver_create(fd_ctx *ctx, int64_t N, int l, int u, int layout, fd32_banded_solver **out);
 int fd32_banded_solver_destroy(fd32_banded_solver *solver);
