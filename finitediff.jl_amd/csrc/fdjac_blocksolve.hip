@@ -6,7 +6,7 @@
 // Method: block cyclic reduction without pivoting, ONE WORKGROUP per kept block row.  The workgroup brings a neighbour's row
 // [B | A | C | d] into LDS, reduces it to [I | B^-1 A | B^-1 C | B^-1 d] by Gauss-Jordan (one barrier per pivot: the pivot row is
 // left unscaled until the end, so a step reads row p and column p and writes neither), multiplies by its own coupling block and
-// accumulates B', d' in LDS; A', C' go straight to the next level (rows of 3 b^2 + b doubles, one contiguous piece per row).  The
+// accumulates B', d' in LDS; A', C' go straight to the next level (rows of 3 b^2 + b doubles, column-major blocks, one contiguous piece per row).  The
 // back-substitution solves an eliminated row from its two known neighbours the same way.  Level 0 is read from the caller's data and
 // b; all arithmetic in Float64.  Rows of alpha I + beta J without diagonal dominance: the solve refuses (NaN, status bit 0) unless
 // the caller vouches for the matrix -- the policy of the other two consumers.
@@ -45,27 +45,50 @@ __device__ __forceinline__ long long btd_pos(const BtdSrc &s, long long K, long 
     return pstart + (K - K0) * b + (long long)c * stride + r;
 }
 
-// block `which` (0: A = (row, row-1), 1: B = (row, row), 2: C = (row, row+1)) of block row `row` of level l into LDS: dst[r * pitch + c]
-__device__ __forceinline__ void btd_load_block(const BtdSrc &s, const double *pool, const BtdLevels &lv, int l, long long row, int which,
-                                               double *dst, int pitch)
+// block `which` (0: A = (row, row-1), 1: B = (row, row), 2: C = (row, row+1)) of block row `row` of level l: this thread's (up to) four
+// elements e = t, t + 256, ... of the column-major block into registers -- ALL loads of a phase are issued before the first value is
+// used (a load inside the loop that stores it to LDS is waited for trip by trip) -- and from there into LDS: dst[r * pitch + c]
+struct BtdFrag { double v[4]; };
+__device__ __forceinline__ BtdFrag btd_fetch_block(const BtdSrc &s, const double *pool, const BtdLevels &lv, int l, long long row, int which)
 {
     const int b = s.b, t = threadIdx.x;
+    BtdFrag f;
     if (l == 0) {
         const long long J = row + which - 1;
         const bool exists = J >= 0 && J < s.nblk;
-        for (int e = t; e < b * b; e += kBtdThreads) {
-            const int c = e / b, r = e - c * b;                 // (column-major in the source: lane-consecutive addresses)
-            double v = 0.0;
-            if (exists) v = s.beta * (double)s.data[btd_pos(s, row, J, r, c)] + ((which == 1 && r == c) ? s.alpha : 0.0);
-            dst[r * pitch + c] = v;
+        const long long Jc = exists ? J : row;
+        real_t raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + u * kBtdThreads, ec = e < b * b ? e : 0;
+            const int c = ec / b, r = ec - c * b;                 // (column-major in the source: lane-consecutive addresses)
+            raw[u] = s.data[btd_pos(s, row, Jc, r, c)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + u * kBtdThreads, c = e / b, r = e - c * b;
+            f.v[u] = exists ? s.beta * (double)raw[u] + ((which == 1 && r == c) ? s.alpha : 0.0) : 0.0;
         }
     } else {
         const double *p = pool + lv.off[l] + row * (long long)(3 * b * b + b) + (long long)which * b * b;
-        for (int e = t; e < b * b; e += kBtdThreads) {
-            const int r = e / b, c = e - r * b;
-            dst[r * pitch + c] = p[e];
-        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = t + u * kBtdThreads; f.v[u] = p[e < b * b ? e : 0]; }
     }
+    return f;
+}
+__device__ __forceinline__ void btd_put_block(const BtdFrag &f, int b, double *dst, int pitch)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + u * kBtdThreads;
+        if (e < b * b) { const int c = e / b, r = e - c * b; dst[r * pitch + c] = f.v[u]; }      // (lanes walk down a column: with the odd pitch every lane hits its own bank)
+    }
+}
+__device__ __forceinline__ void btd_load_block(const BtdSrc &s, const double *pool, const BtdLevels &lv, int l, long long row, int which,
+                                               double *dst, int pitch)
+{
+    const BtdFrag f = btd_fetch_block(s, pool, lv, l, row, which);
+    btd_put_block(f, s.b, dst, pitch);
 }
 __device__ __forceinline__ void btd_load_rhs(const BtdSrc &s, const double *pool, const BtdLevels &lv, int l, long long row, double *dst, int pitch)
 {
@@ -73,25 +96,48 @@ __device__ __forceinline__ void btd_load_rhs(const BtdSrc &s, const double *pool
     if (t < b) dst[t * pitch] = l == 0 ? (double)s.rhs[row * b + t] : pool[lv.off[l] + row * (long long)(3 * b * b + b) + 3LL * b * b + t];
 }
 
-// Gauss-Jordan without pivoting on M = [B | R] (b rows, b + nr columns, row pitch kBtdPitch): afterwards the R part holds B^-1 R.
-// One barrier per pivot; s_inv: b doubles.  Every thread of the workgroup calls.
-__device__ __forceinline__ void btd_gauss_jordan(double *M, double *s_inv, int b, int nr)
+// Gauss-Jordan without pivoting on M = [B | R] (b rows, W = b + nr columns, row pitch kBtdPitch): afterwards the R part holds B^-1 R.
+// The matrix lives in REGISTERS while it is reduced -- thread (q, g) = (t & 31, t >> 5) keeps row q's columns g, g + 8, ... (NE of
+// them) -- and a pivot step exchanges only what it must through LDS: the pivot row (its owners' NE values each) and column p (one value
+// per row), double-buffered so that ONE barrier per pivot suffices; every thread then updates its NE elements from NE + 2 independent
+// LDS reads (profiles/r06_blocksolve.md).  The pivot row stays unscaled until the end.  s_x: 2 x (32 + 8 NE) doubles.  Every thread calls.
+template <int NE>
+__device__ __forceinline__ void btd_gauss_jordan(double *M, double *s_x, int b, int nr)
 {
-    const int t = threadIdx.x, q = t >> 3, c8 = t & 7;           // 32 rows x 8 threads per row
+    const int t = threadIdx.x, q = t & 31, g = t >> 5;
     const int W = b + nr;
+    constexpr int kBuf = 32 + 8 * NE;
+    double m[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { const int c = g + 8 * j; m[j] = (q < b && c < W) ? M[q * kBtdPitch + c] : 0.0; }
+    double inv_q = 0.0;                      // 1 / pivot of this thread's row, met at step p == q
     for (int p = 0; p < b; ++p) {
-        const double inv = 1.0 / M[p * kBtdPitch + p];
-        if (t == 0) s_inv[p] = inv;
-        if (q < b && q != p) {
-            const double f = M[q * kBtdPitch + p] * inv;
-            for (int c = p + 1 + c8; c < W; c += 8) M[q * kBtdPitch + c] -= f * M[p * kBtdPitch + c];
+        double *fcol = s_x + (p & 1) * kBuf, *prow = fcol + 32;
+        if (g == (p & 7)) {                  // this column group owns column p: element j = p >> 3 of every row
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) v = (j == (p >> 3)) ? m[j] : v;
+            fcol[q] = v;
+        }
+        if (q == p) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) prow[g + 8 * j] = m[j];
         }
         __syncthreads();
+        const double inv = 1.0 / prow[p];
+        if (q == p) inv_q = inv;
+        const double f = fcol[q] * inv;
+        double pr[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) pr[j] = prow[g + 8 * j];
+        if (q != p) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) m[j] = (g + 8 * j > p) ? m[j] - f * pr[j] : m[j];
+        }
     }
-    if (q < b) {
-        const double inv = s_inv[q];
-        for (int c = b + c8; c < W; c += 8) M[q * kBtdPitch + c] *= inv;
-    }
+    // the reduced right-hand sides back into LDS, scaled by the row's pivot
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { const int c = g + 8 * j; if (q < b && c >= b && c < W) M[q * kBtdPitch + c] = m[j] * inv_q; }
     __syncthreads();
 }
 
@@ -101,8 +147,8 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_reduce(BtdSrc src, double *
     __shared__ double s_M[kBtdMaxB * kBtdPitch];                  // a neighbour's [B | A | C | d]
     __shared__ double s_P[kBtdMaxB * (kBtdMaxB + 1)];             // this row's coupling block to that neighbour
     __shared__ double s_B[kBtdMaxB * (kBtdMaxB + 1)];             // B' (accumulated)
-    __shared__ double s_d[kBtdMaxB], s_inv[kBtdMaxB];
-    const int b = src.b, t = threadIdx.x, r = t >> 3, c8 = t & 7;
+    __shared__ double s_d[kBtdMaxB], s_x[2 * (32 + 8 * 13)];
+    const int b = src.b, t = threadIdx.x, r = t & 31, c8 = t >> 5;
     const long long m = blockIdx.x, i = 2 * m + 1, n = lv.n[l];
     double *out = pool + lv.off[l + 1] + m * (long long)(3 * b * b + b);
     btd_load_block(src, pool, lv, l, i, 1, s_B, kBtdMaxB + 1);
@@ -113,21 +159,25 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_reduce(BtdSrc src, double *
             for (int e = t; e < b * b; e += kBtdThreads) out[2LL * b * b + e] = 0.0;
             break;
         }
-        btd_load_block(src, pool, lv, l, nb_row, 1, s_M, kBtdPitch);
-        btd_load_block(src, pool, lv, l, nb_row, 0, s_M + b, kBtdPitch);
-        btd_load_block(src, pool, lv, l, nb_row, 2, s_M + 2 * b, kBtdPitch);
-        btd_load_rhs(src, pool, lv, l, nb_row, s_M + 3 * b, kBtdPitch);
-        btd_load_block(src, pool, lv, l, i, side == 0 ? 0 : 2, s_P, kBtdMaxB + 1);
+        {   // (sixteen loads in flight per thread, then the LDS writes)
+            const BtdFrag fB = btd_fetch_block(src, pool, lv, l, nb_row, 1), fA = btd_fetch_block(src, pool, lv, l, nb_row, 0),
+                          fC = btd_fetch_block(src, pool, lv, l, nb_row, 2), fP = btd_fetch_block(src, pool, lv, l, i, side == 0 ? 0 : 2);
+            btd_load_rhs(src, pool, lv, l, nb_row, s_M + 3 * b, kBtdPitch);
+            btd_put_block(fB, b, s_M, kBtdPitch);
+            btd_put_block(fA, b, s_M + b, kBtdPitch);
+            btd_put_block(fC, b, s_M + 2 * b, kBtdPitch);
+            btd_put_block(fP, b, s_P, kBtdMaxB + 1);
+        }
         __syncthreads();
-        btd_gauss_jordan(s_M, s_inv, b, 2 * b + 1);
+        btd_gauss_jordan<13>(s_M, s_x, b, 2 * b + 1);
         // Z_A = s_M[:, b .. 2b), Z_C = s_M[:, 2b .. 3b), Z_d = s_M[:, 3b]
         if (r < b) {
             const double *Pr = s_P + r * (kBtdMaxB + 1);
             for (int c = c8; c < b; c += 8) {
                 double sa = 0.0, sc = 0.0;
                 for (int k = 0; k < b; ++k) { const double pk = Pr[k]; sa += pk * s_M[k * kBtdPitch + b + c]; sc += pk * s_M[k * kBtdPitch + 2 * b + c]; }
-                if (side == 0) { out[r * b + c] = -sa; s_B[r * (kBtdMaxB + 1) + c] -= sc; }             // A' = -A Z_A;  B' -= A Z_C
-                else { out[2LL * b * b + r * b + c] = -sc; s_B[r * (kBtdMaxB + 1) + c] -= sa; }         // C' = -C Z_C;  B' -= C Z_A
+                if (side == 0) { out[c * b + r] = -sa; s_B[r * (kBtdMaxB + 1) + c] -= sc; }             // A' = -A Z_A;  B' -= A Z_C
+                else { out[2LL * b * b + c * b + r] = -sc; s_B[r * (kBtdMaxB + 1) + c] -= sa; }         // C' = -C Z_C;  B' -= C Z_A
             }
             if (c8 == 0) {
                 double sd = 0.0;
@@ -137,7 +187,7 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_reduce(BtdSrc src, double *
         }
         __syncthreads();
     }
-    for (int e = t; e < b * b; e += kBtdThreads) { const int rr = e / b, cc = e - rr * b; out[(long long)b * b + e] = s_B[rr * (kBtdMaxB + 1) + cc]; }
+    for (int e = t; e < b * b; e += kBtdThreads) { const int cc = e / b, rr = e - cc * b; out[(long long)b * b + e] = s_B[rr * (kBtdMaxB + 1) + cc]; }
     if (t < b) out[3LL * b * b + t] = s_d[t];
 }
 
@@ -146,7 +196,7 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_reduce(BtdSrc src, double *
 __global__ void __launch_bounds__(kBtdThreads) k_btd_back(BtdSrc src, double *pool, double *xpool, BtdLevels lv, int l, real_t *y, int refuse)
 {
     __shared__ double s_M[kBtdMaxB * kBtdPitch];
-    __shared__ double s_x[2 * kBtdMaxB], s_inv[kBtdMaxB];
+    __shared__ double s_x[2 * kBtdMaxB], s_gj[2 * (32 + 8 * 5)];
     const int b = src.b, t = threadIdx.x;
     const long long m = blockIdx.x, i = 2 * m, n = lv.n[l];
     const bool last = l == lv.nlev - 1;
@@ -156,10 +206,13 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_back(BtdSrc src, double *po
         s_x[t] = hl ? xn[(m - 1) * b + t] : 0.0;
         s_x[kBtdMaxB + t] = hh ? xn[m * b + t] : 0.0;
     }
-    btd_load_block(src, pool, lv, l, i, 1, s_M, kBtdPitch);
-    btd_load_block(src, pool, lv, l, i, 0, s_M + b, kBtdPitch);
-    btd_load_block(src, pool, lv, l, i, 2, s_M + 2 * b, kBtdPitch);
-    btd_load_rhs(src, pool, lv, l, i, s_M + 3 * b, kBtdPitch);
+    {
+        const BtdFrag fB = btd_fetch_block(src, pool, lv, l, i, 1), fA = btd_fetch_block(src, pool, lv, l, i, 0), fC = btd_fetch_block(src, pool, lv, l, i, 2);
+        btd_load_rhs(src, pool, lv, l, i, s_M + 3 * b, kBtdPitch);
+        btd_put_block(fB, b, s_M, kBtdPitch);
+        btd_put_block(fA, b, s_M + b, kBtdPitch);
+        btd_put_block(fC, b, s_M + 2 * b, kBtdPitch);
+    }
     __syncthreads();
     if (t < b) {       // rhs = d - A x_lo - C x_hi, into column b of [B | rhs]
         double v = s_M[t * kBtdPitch + 3 * b];
@@ -169,7 +222,7 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_back(BtdSrc src, double *po
     __syncthreads();
     if (t < b) s_M[t * kBtdPitch + b] = s_M[t * kBtdPitch + 3 * b];
     __syncthreads();
-    btd_gauss_jordan(s_M, s_inv, b, 1);
+    btd_gauss_jordan<5>(s_M, s_gj, b, 1);
     if (t < b) {
         const double x = s_M[t * kBtdPitch + b];
         if (l == 0) {
