@@ -111,28 +111,33 @@ __device__ __forceinline__ void btd_gauss_jordan(double *M, double *s_x, int b, 
 #pragma unroll
     for (int j = 0; j < NE; ++j) { const int c = g + 8 * j; m[j] = (q < b && c < W) ? M[q * kBtdPitch + c] : 0.0; }
     double inv_q = 0.0;                      // 1 / pivot of this thread's row, met at step p == q
-    for (int p = 0; p < b; ++p) {
-        double *fcol = s_x + (p & 1) * kBuf, *prow = fcol + 32;
-        if (g == (p & 7)) {                  // this column group owns column p: element j = p >> 3 of every row
-            double v = 0.0;
+    // (the pivot loop is unrolled completely: p >> 3 -- which of a thread's elements lies in column p -- and the comparisons
+    //  "column > p" are then compile-time, the select chains and half of the updates disappear)
 #pragma unroll
-            for (int j = 0; j < NE; ++j) v = (j == (p >> 3)) ? m[j] : v;
-            fcol[q] = v;
-        }
-        if (q == p) {
+    for (int p = 0; p < kBtdMaxB; ++p) {
+        if (p < b) {
+            double *fcol = s_x + (p & 1) * kBuf, *prow = fcol + 32;
+            if (g == (p & 7)) fcol[q] = m[p >> 3];            // this column group owns column p
+            if (q == p) {
 #pragma unroll
-            for (int j = 0; j < NE; ++j) prow[g + 8 * j] = m[j];
-        }
-        __syncthreads();
-        const double inv = 1.0 / prow[p];
-        if (q == p) inv_q = inv;
-        const double f = fcol[q] * inv;
-        double pr[NE];
+                for (int j = p >> 3; j < NE; ++j) prow[g + 8 * j] = m[j];
+            }
+            __syncthreads();
+            // 1 / pivot: the hardware's reciprocal and two Newton steps (full Float64 accuracy; the IEEE division sequence is three
+            // times as long and sits on the critical path of every pivot step)
+            const double pv = prow[p];
+            double inv = __builtin_amdgcn_rcp(pv);
+            inv = __builtin_fma(__builtin_fma(-pv, inv, 1.0), inv, inv);
+            inv = __builtin_fma(__builtin_fma(-pv, inv, 1.0), inv, inv);
+            if (q == p) inv_q = inv;
+            const double f = fcol[q] * inv;
+            double pr[NE];
 #pragma unroll
-        for (int j = 0; j < NE; ++j) pr[j] = prow[g + 8 * j];
-        if (q != p) {
+            for (int j = p >> 3; j < NE; ++j) pr[j] = prow[g + 8 * j];
+            if (q != p) {
 #pragma unroll
-            for (int j = 0; j < NE; ++j) m[j] = (g + 8 * j > p) ? m[j] - f * pr[j] : m[j];
+                for (int j = p >> 3; j < NE; ++j) m[j] = (g + 8 * j > p) ? m[j] - f * pr[j] : m[j];
+            }
         }
     }
     // the reduced right-hand sides back into LDS, scaled by the row's pivot
