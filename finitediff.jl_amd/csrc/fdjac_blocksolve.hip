@@ -176,7 +176,39 @@ __global__ void __launch_bounds__(kBtdThreads) k_btd_reduce(BtdSrc src, double *
         __syncthreads();
         btd_gauss_jordan<13>(s_M, s_x, b, 2 * b + 1);
         // Z_A = s_M[:, b .. 2b), Z_C = s_M[:, 2b .. 3b), Z_d = s_M[:, 3b]
-        if (r < b) {
+        if (b == 32) {
+            // 32 x 32 blocks: the two 32^3 products on the Float64 matrix cores -- v_mfma_f64_16x16x4, one 16 x 16 tile of both
+            // products per wavefront, 16 instructions (A: lane l holds P[i = l & 15][k = l >> 4], B: Z[k = l >> 4][j = l & 15], D: column
+            // l & 15, rows (l >> 4) + 4 reg).  The products are staged in s_P (free once every wavefront has read it) and leave as
+            // dense column-major pieces.
+            typedef double d4_t __attribute__((ext_vector_type(4)));
+            const int lane = t & 63, w = t >> 6, ti = w >> 1, tj = w & 1, li = lane & 15, lk = lane >> 4;
+            d4_t accA = {0, 0, 0, 0}, accC = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const double a = s_P[(16 * ti + li) * (kBtdMaxB + 1) + 4 * ks + lk];
+                const double zA = s_M[(4 * ks + lk) * kBtdPitch + 32 + 16 * tj + li], zC = s_M[(4 * ks + lk) * kBtdPitch + 64 + 16 * tj + li];
+                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zA, accA, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(a, zC, accC, 0, 0, 0);
+            }
+            if (c8 == 0) {       // (the matrix-vector product P Z_d stays on the vector unit)
+                const double *Pr = s_P + r * (kBtdMaxB + 1);
+                double sd = 0.0;
+                for (int k = 0; k < 32; ++k) sd += Pr[k] * s_M[k * kBtdPitch + 96];
+                s_d[r] -= sd;
+            }
+            __syncthreads();     // every wavefront has read s_P
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = 16 * ti + lk + 4 * reg, cc = 16 * tj + li;
+                const double keep = side == 0 ? accA[reg] : accC[reg], acc = side == 0 ? accC[reg] : accA[reg];
+                s_P[rr * (kBtdMaxB + 1) + cc] = -keep;                  // A' = -A Z_A  /  C' = -C Z_C
+                s_B[rr * (kBtdMaxB + 1) + cc] -= acc;                   // B' -= A Z_C  /  B' -= C Z_A
+            }
+            __syncthreads();
+            double *o = out + (side == 0 ? 0 : 2LL * b * b);
+            for (int e = t; e < 32 * 32; e += kBtdThreads) o[e] = s_P[(e & 31) * (kBtdMaxB + 1) + (e >> 5)];
+        } else if (r < b) {
             const double *Pr = s_P + r * (kBtdMaxB + 1);
             for (int c = c8; c < b; c += 8) {
                 double sa = 0.0, sc = 0.0;
