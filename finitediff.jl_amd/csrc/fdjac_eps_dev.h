@@ -85,7 +85,10 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
     // (software-pipelined: the loads of tile k + 1 are in flight while tile k is accumulated -- a block of a sharded reduction walks
     //  up to 5 tiles, and one tile's 16 KB per workgroup in flight left the pass latency-bound; the ORDER of the additions is untouched)
     auto load_tile = [&](int64_t base, r2_t (&v)[kEpsU], int (&c0)[kEpsU], int (&c1)[kEpsU]) {
-        if (base + tile <= n) {          // the whole tile lies inside x (wave-uniform): no load inside a per-lane branch
+        if (base + tile <= n) {          // the whole tile lies inside x (wave-uniform; all but the last tile): no load inside a per-lane
+                                         // branch -- inside one they are waited for one by one, and with them everything in flight
+                                         // (c2 0.0172 -> 0.0166 ms, c3's reduction 26.5 -> 25.4 us, same box; THREE tiles in flight for
+                                         // computed colours was measured too: the rank's reduction 6.1 -> 5.6 us but c4's 21.2 -> 23.7)
 #pragma unroll
             for (int u = 0; u < kEpsU; ++u) {
                 const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
@@ -138,65 +141,7 @@ __device__ __forceinline__ bool eps_block_sum(const real_t *__restrict__ x, cons
             }
         }
     };
-    if constexpr (CYC && PIPE) {
-        // computed colours: the buffers hold VALUES only -- the colour of an element (and whether it lies before the end of x) is
-        // worked out when its tile is added, in the same order as before -- so THREE tiles are in flight in the registers two tiles
-        // with their colours took: a block of five tiles (a rank of eight at N = 10^7) waits for two memory round trips instead of
-        // three.  The additions and their order are unchanged.  (With the loads of whole tiles outside every per-lane branch: the rank's reduction
-        // 6.1 -> 5.6 us, the 512 one-tile blocks of N = 10^6 3.8 -> 3.1 us -- profiles/r06_fused_trace.md.)
-        auto load_vals = [&](int64_t base, r2_t (&v)[kEpsU]) {
-            if (base + tile <= n) {      // the whole tile lies inside x (wave-uniform; all but the last tile): loads outside any per-lane
-                                         // branch -- inside one they are waited for one by one, and with them everything in flight
-#pragma unroll
-                for (int u = 0; u < kEpsU; ++u) {
-                    const r2_t *pv = reinterpret_cast<const r2_t *>(x + base + (int64_t)u * kBlock * 2 + threadIdx.x * 2);
-                    v[u] = NT ? __builtin_nontemporal_load(pv) : *pv;
-                }
-                return;
-            }
-#pragma unroll
-            for (int u = 0; u < kEpsU; ++u) {
-                const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
-                if (i + 1 < n) {
-                    if (NT) v[u] = __builtin_nontemporal_load(reinterpret_cast<const r2_t *>(x + i));
-                    else v[u] = *reinterpret_cast<const r2_t *>(x + i);
-                } else if (i < n) v[u] = r2_t{x[i], 0.0};
-                else v[u] = r2_t{0.0, 0.0};
-            }
-        };
-        auto add_tile = [&](int64_t base, const r2_t (&v)[kEpsU]) {
-#pragma unroll
-            for (int u = 0; u < kEpsU; ++u) {
-                const int64_t i = base + (int64_t)u * kBlock * 2 + threadIdx.x * 2;
-                int c0 = rc, c1 = rc + 1 == cyc_C ? 0 : rc + 1;
-                rc += du;
-                rc = rc >= cyc_C ? rc - cyc_C : rc;
-                if (i + 1 >= n) c1 = -2;
-                if (i >= n) c0 = -2;
-                if (pair) c1 = c0;
-                const double s0 = (double)v[u].x * (double)v[u].x, s1 = (double)v[u].y * (double)v[u].y;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    acc[c] += (c0 == c) ? s0 : 0.0;
-                    acc[c] += (c1 == c) ? s1 : 0.0;
-                }
-            }
-        };
-        r2_t v0[kEpsU], v1[kEpsU], v2[kEpsU];
-        if (base0 < base_end) load_vals(base0, v0);
-        if (base0 + tile < base_end) load_vals(base0 + tile, v1);
-        if (base0 + 2 * tile < base_end) load_vals(base0 + 2 * tile, v2);
-        for (int64_t b = base0; b < base_end; b += 3 * tile) {
-            add_tile(b, v0);
-            if (b + 3 * tile < base_end) load_vals(b + 3 * tile, v0);
-            if (b + tile >= base_end) break;
-            add_tile(b + tile, v1);
-            if (b + 4 * tile < base_end) load_vals(b + 4 * tile, v1);
-            if (b + 2 * tile >= base_end) break;
-            add_tile(b + 2 * tile, v2);
-            if (b + 5 * tile < base_end) load_vals(b + 5 * tile, v2);
-        }
-    } else if (!PIPE) {      // (one tile in flight: 32 registers fewer -- the fused single-GPU step, whose blocks have one or two tiles)
+    if (!PIPE) {      // (one tile in flight: 32 registers fewer -- the fused single-GPU step, whose blocks have one or two tiles)
         for (int64_t base = base0; base < base_end; base += tile) {
             load_tile(base, va, a0, a1);
             accumulate(va, a0, a1);

@@ -8,6 +8,6 @@ name=$1; shift
 mkdir -p ../lib/variants
 # only the translation units that see the kernels are rebuilt with the flags; the rest are copied from the product build
 mkdir -p _obj_$name
-for o in _obj/*.o; do b=$(basename $o); case $b in fdjac_builtin_f.o|fdjac_f32.o|fdjac_blocksolve.o|fdjac_bandsolve.o) ;; *) cp -u $o _obj_$name/$b;; esac; done
+for o in _obj/*.o; do b=$(basename $o); case $b in fdjac_builtin_f.o|fdjac_f32.o|fdjac_blocksolve.o|fdjac_bandsolve.o|fdjac_kernels.o|fdjac_api.o) ;; *) cp -u $o _obj_$name/$b;; esac; done
 make -j4 OBJDIR=_obj_$name OUT=$(pwd)/../lib/variants/libfdjac_$name.so EXTRA="$*" 2>&1 | grep -E "error|warning" -A4 || true
 ls -la ../lib/variants/libfdjac_$name.so
