@@ -8,11 +8,11 @@ raises if the HIP library or a GPU is missing.
 """
 from . import patterns  # noqa: F401  (numpy-only helpers; safe without a GPU)
 from . import lib  # noqa: F401  (ctypes binding; loads libfdjac.so on first use)
-from .api import (BandedBlockBandedMatrix, BandedMatrix, BlockBandedMatrix, Bidiagonal, BuiltinF, Comm, Context, DevicePatternCSC, Diagonal, JacobianCache, JitF, BitcodeF, TrackedCSC, TrackedVector, P2P, Plan, SymTridiagonal,  # noqa: F401
+from .api import (BandedBlockBandedMatrix, BandedMatrix, BlockBandedMatrix, Bidiagonal, BuiltinF, Comm, Context, DevicePatternCSC, Diagonal, JacobianCache, JitF, JitTerms, BitcodeF, TrackedCSC, TrackedVector, P2P, Plan, SymTridiagonal,  # noqa: F401
                   SparseMatrixCSC, TorchF, Tridiagonal, TridiagSolver, BandedSolver, BlockTridiagSolver, JVPCache, default_relstep, finite_difference_jacobian,
                   finite_difference_jacobian_b,
                   finite_difference_jvp_b, make_plan, make_plan_csc_device, matrix_colors)
 
-__all__ = ["patterns", "lib", "BandedBlockBandedMatrix", "BandedMatrix", "BlockBandedMatrix", "Bidiagonal", "BuiltinF", "Comm", "Context", "DevicePatternCSC", "Diagonal", "JacobianCache", "JitF", "BitcodeF", "TrackedCSC", "TrackedVector", "P2P", "Plan", "SymTridiagonal",
+__all__ = ["patterns", "lib", "BandedBlockBandedMatrix", "BandedMatrix", "BlockBandedMatrix", "Bidiagonal", "BuiltinF", "Comm", "Context", "DevicePatternCSC", "Diagonal", "JacobianCache", "JitF", "JitTerms", "BitcodeF", "TrackedCSC", "TrackedVector", "P2P", "Plan", "SymTridiagonal",
            "SparseMatrixCSC", "TorchF", "Tridiagonal", "TridiagSolver", "BandedSolver", "BlockTridiagSolver", "JVPCache", "default_relstep", "finite_difference_jacobian", "finite_difference_jacobian_b",
            "finite_difference_jvp_b", "make_plan", "make_plan_csc_device", "matrix_colors"]

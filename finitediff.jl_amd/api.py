@@ -798,6 +798,41 @@ class JitF:
         return n.value
 
 
+class JitTerms(JitF):
+    """A SEPARABLE residual given by its TERM alone (fd_f_compile_terms; include/fdjac_device.h "SEPARABLE residuals"): row r of f is the
+    left-to-right sum, over the stored entries (r, j) of the plan's own pattern in ascending j, of `term(r, j, x[j])`.  `source` defines
+        struct Name { <parameters>;  template <class T> __device__ T term(long long r, long long j, T v) const { ... } };
+    `plan`: made with store_rows=True -- the functor reads that plan's row lists (the plan must outlive it).  Everything a `JitF` gets,
+    all from `term`, plus the ROW-WISE store on that plan: 2 L term evaluations per row of L entries instead of L^2, same bits."""
+
+    def __init__(self, source, name, plan, params=b"", dtype=None):
+        self.ctx = plan.ctx
+        self.dtype = np.dtype(dtype if dtype is not None else plan.dtype)
+        self.plan = plan                       # (keeps the lists alive)
+        L = self.L = self.ctx.L
+        rl = plan.row_lists()
+        M, N = plan.info(_l.INFO_M), plan.info(_l.INFO_N)
+        self.fn = _l.F_LAUNCH()
+        self._lazy = _l.F_LAUNCH_LAZY()
+        self.fctx = C.c_void_p()
+        caps = C.c_int32()
+        params = bytes(params)
+        buf = C.create_string_buffer(params, len(params)) if params else None
+        rc = L.fd_f_compile_terms(self.ctx.handle, source.encode(), name.encode(), buf, len(params), int(M), int(N), self.dtype.itemsize,
+                                  rl["row_ptr"], rl["row_col"], rl["serial"], C.byref(self.fn), C.byref(self._lazy), C.byref(caps), C.byref(self.fctx))
+        self.log = (L.fd_f_compile_log() or b"").decode("utf-8", "replace")
+        _l.check(rc)
+        self.lazy_caps = caps.value
+        self.M, self.N = int(M), int(N)
+        self._fin = weakref.finalize(self, L.fd_f_compiled_destroy, self.fctx)
+
+    @property
+    def row_stores(self):
+        n = C.c_int64()
+        _l.check(self.L.fd_f_compiled_row_stores(self.fctx, C.byref(n)))
+        return n.value
+
+
 class BitcodeF(JitF):
     """A row function given as LLVM BITCODE (fd_f_link_rows_bitcode): what AMDGPU.jl / GPUCompiler emit for a Julia closure -- the shim's
     `DeviceF(f::Function, M, N)` -- or `hipcc -fgpu-rdc -emit-llvm --offload-device-only -c`.  The bitcode defines
@@ -886,6 +921,14 @@ class Plan:
         v = C.c_int64()
         _l.check(self.Lt.fd_plan_info(self.handle, key, C.byref(v)))
         return v.value
+
+    def row_lists(self):
+        """The plan's pattern BY ROWS on the device (fd_plan_row_lists; plans made with store_rows=True): device addresses of row_ptr,
+        row_col, row_slot, the number of stored entries and the plan's serial.  Owned by the plan."""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, ser = C.c_int64(), C.c_uint64()
+        _l.check(self.Lt.fd_plan_row_lists(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(n), C.byref(ser)))
+        return {"row_ptr": a.value, "row_col": b.value, "row_slot": c.value, "entries": n.value, "serial": ser.value}
 
     def checksum(self):
         """fd_plan_checksum: FNV-1a of the compiled pattern (plans with equal checksums drive the kernels identically)."""
@@ -1175,11 +1218,12 @@ class Plan:
 
 
 def _opts(fdtype, col_window=None, x_window=None, scratch_bytes=0, color_range=None, eps_contiguous=False, fingerprint=False,
-          store_csc=False, store_csc_always=False):
+          store_csc=False, store_csc_always=False, store_rows=False):
     o = _l.PlanOpts()
     o.fdtype = _l.FDTYPES[_norm_fdtype(fdtype)]
     o.flags = ((_l.PLAN_EPS_CONTIGUOUS if eps_contiguous else 0) | (_l.PLAN_FINGERPRINT if fingerprint else 0) |
-               (_l.PLAN_STORE_CSC if (store_csc or store_csc_always) else 0) | (_l.PLAN_STORE_CSC_ALWAYS if store_csc_always else 0))
+               (_l.PLAN_STORE_CSC if (store_csc or store_csc_always or store_rows) else 0) | (_l.PLAN_STORE_CSC_ALWAYS if store_csc_always else 0) |
+               (_l.PLAN_STORE_CSC_ROWS if store_rows else 0))
     if col_window is not None:
         o.col_begin, o.col_end = int(col_window[0]), int(col_window[1])
     if x_window is not None:
@@ -1196,7 +1240,7 @@ def _vp(a):
 
 def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window=None, scratch_bytes=0,
               color_range=None, dtype=np.float64, eps_contiguous=False, complex_x=False, fingerprint=False, store_csc=False,
-              store_csc_always=False):
+              store_csc_always=False, store_rows=False):
     """Compile (J type, sparsity, colorvec) into a device plan -- the dispatch the reference performs
     per call through `_colorediteration!` / `_use_findstructralnz` / `_use_sparseCSC_common_sparsity`
     (src/jacobians.jl:524-535; ext/*.jl)."""
@@ -1204,8 +1248,9 @@ def make_plan(J, sparsity, colorvec, fdtype, ctx=None, col_window=None, x_window
     L = _l.typed(ctx.L, dtype)      # fd_* for Float64, fd32_* for Float32 (eltype(x) in the reference)
     fdtype = _norm_fdtype(fdtype)
     o = _opts(fdtype, col_window, x_window, scratch_bytes, color_range, eps_contiguous, fingerprint,
-              (store_csc or store_csc_always) and not complex_x and isinstance(J, SparseMatrixCSC),
-              store_csc_always and not complex_x and isinstance(J, SparseMatrixCSC))
+              (store_csc or store_csc_always or store_rows) and not complex_x and isinstance(J, SparseMatrixCSC),
+              store_csc_always and not complex_x and isinstance(J, SparseMatrixCSC),
+              store_rows and not complex_x and isinstance(J, SparseMatrixCSC))
     if complex_x:      # returntype <: Complex with forward / central differences: the library lowers it (FD_PLAN_COMPLEX_X)
         o.flags |= _l.PLAN_COMPLEX_X
     if isinstance(J, DevicePatternCSC):

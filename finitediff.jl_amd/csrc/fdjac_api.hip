@@ -114,7 +114,7 @@ struct LoweredScope {
     LoweredScope() { t_lowered_cx = true; }
     ~LoweredScope() { t_lowered_cx = false; }
 };
-constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ALWAYS;
+constexpr int32_t kPlanKnownFlags = FD_PLAN_EPS_CONTIGUOUS | FD_PLAN_COMPLEX_X | FD_PLAN_FINGERPRINT | FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ALWAYS | FD_PLAN_STORE_CSC_ROWS;
 
 static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
 {
@@ -166,6 +166,7 @@ static int apply_opts(fd_plan *p, const fd_plan_opts *opts)
     // round 3 (N = 10^7 tridiagonal: 0.18 -> 0.09 ms per Jacobian, bit-identical); FDJAC_LAZY_STORE=0 keeps the hand-over
     p->store_allowed = env_int("FDJAC_LAZY_STORE", 1) != 0;
     p->want_store_csc = (opts->flags & FD_PLAN_STORE_CSC) != 0;
+    p->want_store_rows = (opts->flags & FD_PLAN_STORE_CSC_ROWS) != 0;
     p->store_csc_always = (opts->flags & FD_PLAN_STORE_CSC_ALWAYS) != 0;   // a compact device copy of the pattern for column-centric storing launches
     p->own_c0 = 0;
     p->own_c1 = -1;
@@ -428,7 +429,7 @@ int fd_plan_destroy(fd_plan *p)
     if (p->ctx->check_stream && p->d_fpx) (void)hipStreamSynchronize(p->ctx->check_stream);      // (a deferred check of this plan may still be reading d_fpx)
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_fpx, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_sr_ptr, p->d_sr_col, p->d_sr_slot, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pstale) (void)hipHostFree(p->h_pstale);
@@ -446,6 +447,19 @@ int fd_plan_destroy(fd_plan *p)
 }
 
 #include "fdjac_plan_create.hip"
+
+int fd_plan_row_lists(const fd_plan *p, const void **row_ptr_dev, const void **row_col_dev, const void **row_slot_dev, int64_t *entries, uint64_t *plan_serial)
+{
+    FD_REQUIRE(p != nullptr, FD_ERR_ARG, "plan is NULL");
+    FD_REQUIRE(p->store_csc_ok && p->d_sr_ptr != nullptr, FD_ERR_UNSUPPORTED,
+               "this plan keeps no row lists: create it with FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ROWS (a SparseMatrixCSC common-pattern plan that holds every column)");
+    if (row_ptr_dev) *row_ptr_dev = p->d_sr_ptr;
+    if (row_col_dev) *row_col_dev = p->d_sr_col;
+    if (row_slot_dev) *row_slot_dev = p->d_sr_slot;
+    if (entries) *entries = p->sc_entries;
+    if (plan_serial) *plan_serial = p->sc_serial;
+    return FD_OK;
+}
 
 int fd_plan_info(const fd_plan *p, int key, int64_t *value)
 {
@@ -1039,6 +1053,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
             sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.note = p->d_sc_note; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
             sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0; sc.reach = p->sc_reach; sc.plan_serial = p->sc_serial;
+            sc.row_ptr = p->d_sr_ptr; sc.row_col = p->d_sr_col; sc.row_slot = p->d_sr_slot;
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;

@@ -28,6 +28,7 @@
 #define fd_plan_matches_async fd32_plan_matches_async
 #define fd_plan_stale fd32_plan_stale
 #define fd_plan_info fd32_plan_info
+#define fd_plan_row_lists fd32_plan_row_lists
 #define fd_jacobian fd32_jacobian
 #define fd_jacobian_async fd32_jacobian_async
 #define fd_jacobian_owned_async fd32_jacobian_owned_async
@@ -351,6 +352,8 @@ struct fd_plan {
     int64_t *d_bbb_start = nullptr;    // [(bl + bu + 1) * nb] 0-based start of block (K, J)'s slab in data, -1: not in the band
     int64_t *d_bbb_stride = nullptr;   // [nb] column stride of the slabs of block-column J
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
+    bool want_store_rows = false;                // FD_PLAN_STORE_CSC_ROWS: the same pattern by rows (fd_csc_store.row_ptr / row_col / row_slot), full column range only
+    int32_t *d_sr_ptr = nullptr, *d_sr_col = nullptr, *d_sr_slot = nullptr;
     unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: four words of launcher memory about this pattern, zero at creation
     unsigned long long sc_serial = 0;            // fd_csc_store.plan_serial
     int64_t sc_entries = 0;

@@ -100,6 +100,8 @@ struct JitModule {
     hipFunction_t rows = nullptr;
     hipFunction_t store[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [colour bytes == 4][central]
     hipFunction_t store_win[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t store_rows[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // fd_csc_store_rows (separable functors, fd_f_compile_terms): [colour bytes == 4][central]
+    unsigned lists_offset = 0, terms_bytes = 0;       // fd_sep_rows<TF>: where its two list pointers sit, sizeof(TF)
     hipFunction_t band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // fd_band_store_cols: [bandwidths (1,1) / (2,2)][forward / central]
     // other bandwidths: compiled when a plan first hands this functor such a band (fd_band_store_cols<.., L, U>), kept with the module
     struct BandExtra {
@@ -260,6 +262,9 @@ struct fd_jit_f {
     int64_t M = 0, N = 0;
     std::vector<unsigned char> params;      // the functor object, byte for byte (sizeof(F) bytes)
     int64_t launches = 0;
+    bool sep = false;                       // fd_f_compile_terms: a separable functor bound to the row lists of one plan
+    unsigned long long plan_serial = 0;     //   that plan's serial (fd_csc_store.plan_serial): only there the row-wise store is taken
+    int64_t row_stores = 0, entries = 0;    // launches of the row-wise store; stored entries of that plan's pattern
 };
 
 namespace fdjac {
@@ -280,6 +285,8 @@ extern "C" __global__ void __launch_bounds__(256) fdjit_rows(real_t *__restrict_
     fx[(long long)blockIdx.y * fs + r] = f(r, P);
 }
 extern "C" __device__ __attribute__((used)) const unsigned fdjit_sizeof_f = sizeof(fdjit_F);
+extern "C" __device__ __attribute__((used)) const unsigned fdjit_lists_offset = fd_sep_rows_layout<fdjit_F>::lists_offset;
+extern "C" __device__ __attribute__((used)) const unsigned fdjit_terms_bytes = fd_sep_rows_layout<fdjit_F>::terms_bytes;
 )FDJIT";
 
 static int jit_launch(void *fctx, void *fx, const void *x, int64_t nbatch, int64_t x_stride, int64_t fx_stride, int64_t row_begin,
@@ -349,8 +356,26 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
     int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
     const void *x = lp->x, *eps = lp->eps;
     const int cb = st.color_bytes == 4 ? 1 : 0, central = lp->pts == 2 ? 1 : 0;
-    // a locally banded pattern with a verified colouring: the workgroup's window of x (and f(x)) in LDS, fd_csc_store_cols_win
     const int64_t reach = st.reach;
+    // a separable functor on the plan its lists came from: the Jacobian row by row (fd_csc_store_rows) -- verified colouring, a locally
+    // banded square pattern, every column local; anything else takes the column kernels below (same bits)
+    if (j->sep && st.row_ptr && st.plan_serial == j->plan_serial && st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N && st.N >= 2 &&
+        st.col_begin == 0 && st.col_end == st.N && j->m->store_rows[cb][central]) {
+        // (the tile's share of the lists kept in LDS: the mean row length x 1.25 + slack; longer tiles read the rest from memory)
+        const double per_row = (double)j->entries / (double)st.M;
+        int cap = (int)std::min<int64_t>((int64_t)(256 * per_row * 1.25) + 64, 3072);
+        int ireach = (int)reach;
+        const size_t lds_r = j->elem_bytes == 8 ? fd_csc_rows_lds_bytes<double>(reach, lp->ncolors, cap) : fd_csc_rows_lds_bytes<float>(reach, lp->ncolors, cap);
+        if (lds_r <= 64 * 1024) {
+            void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st, &ireach, &cap};
+            const unsigned gr = (unsigned)(8 * (((st.M + 255) / 256 + 7) / 8));
+            if (hipModuleLaunchKernel(j->m->store_rows[cb][central], gr, 1, 1, 256, 1, 1, (unsigned)lds_r, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+            j->launches += 1;
+            j->row_stores += 1;
+            return 0;
+        }
+    }
+    // a locally banded pattern with a verified colouring: the workgroup's window of x (and f(x)) in LDS, fd_csc_store_cols_win
     const bool wb = !central && st.fx_base != nullptr;
     const size_t lds = !(reach > 0 && reach <= 700) ? 0 : j->elem_bytes == 8 ? fd_csc_win_lds_bytes<double>(reach, wb) : fd_csc_win_lds_bytes<float>(reach, wb);
     if (st.valid_coloring && lds > 0 && lds <= 64 * 1024 && st.M == st.N && j->m->store_win[cb][central]) {
@@ -390,8 +415,9 @@ const char *fd_f_compile_log(void) { return t_log.c_str(); }
 // type, the functor -- source text, or the shim around the caller's bitcode --, the kernels), `bitcode` the caller's LLVM bitcode or empty
 static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char> &bitcode, const char *real, const char *functor, const void *params,
                      int64_t params_bytes, int64_t M, int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out,
-                     void **fctx_out)
+                     void **fctx_out, const void *const *sep_lists = nullptr, unsigned long long sep_serial = 0)
 {
+    const bool sep = sep_lists != nullptr;      // fd_f_compile_terms: FDJIT_FUNCTOR is fd_sep_rows<terms>, sep_lists = {row_ptr, row_col} on the device
     // (modules are per DEVICE: a second context on another GPU compiling the same text must not get device 0's functions)
     const std::string key = std::to_string(ctx->device) + "\n" + src + std::string(bitcode.begin(), bitcode.end());
     JitModule *m = nullptr;
@@ -425,6 +451,13 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
                 bnames[wi][md] = std::string("fd_band_store_cols<") + real + ", " + (md ? "1" : "0") + ", fdjit_F, " + (wi ? "2, 2>" : "1, 1>");
                 (void)R->AddNameExpression(prog, bnames[wi][md].c_str());
             }
+        std::string rnames[2][2];
+        if (sep)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int md = 0; md < 2; ++md) {
+                    rnames[cb][md] = std::string("fd_csc_store_rows<") + real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
+                    (void)R->AddNameExpression(prog, rnames[cb][md].c_str());
+                }
         rr = R->CompileProgram(prog, bitcode.empty() ? 5 : 6, kJitOpts);
         size_t ls = 0;
         if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
@@ -449,6 +482,13 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
                 const char *ln = nullptr;
                 if (R->GetLoweredName(prog, bnames[wi][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) blow[wi][md] = ln;
             }
+        std::string rlow[2][2];
+        if (sep)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int md = 0; md < 2; ++md) {
+                    const char *ln = nullptr;
+                    if (R->GetLoweredName(prog, rnames[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) rlow[cb][md] = ln;
+                }
         m = new (std::nothrow) JitModule();
         if (!m) { (void)R->DestroyProgram(&prog); FD_REQUIRE(false, FD_ERR_NOMEM, "out of host memory"); }
         std::string why;
@@ -471,11 +511,18 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
         for (int wi = 0; wi < 2 && e == hipSuccess; ++wi)
             for (int md = 0; md < 2; ++md)
                 if (blow[wi][md].empty() || hipModuleGetFunction(&m->band[wi][md], m->mod, blow[wi][md].c_str()) != hipSuccess) m->band[wi][md] = nullptr;      // (an optimisation)
+        for (int cb = 0; cb < 2 && e == hipSuccess && sep; ++cb)
+            for (int md = 0; md < 2; ++md)
+                if (rlow[cb][md].empty() || hipModuleGetFunction(&m->store_rows[cb][md], m->mod, rlow[cb][md].c_str()) != hipSuccess) m->store_rows[cb][md] = nullptr;      // (an optimisation)
         if (e == hipSuccess) {
             hipDeviceptr_t dp = nullptr;
             size_t bytes = 0;
             e = hipModuleGetGlobal(&dp, &bytes, m->mod, "fdjit_sizeof_f");
             if (e == hipSuccess) e = hipMemcpy(&m->sizeof_f, dp, sizeof(unsigned), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipModuleGetGlobal(&dp, &bytes, m->mod, "fdjit_lists_offset");
+            if (e == hipSuccess) e = hipMemcpy(&m->lists_offset, dp, sizeof(unsigned), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipModuleGetGlobal(&dp, &bytes, m->mod, "fdjit_terms_bytes");
+            if (e == hipSuccess) e = hipMemcpy(&m->terms_bytes, dp, sizeof(unsigned), hipMemcpyDeviceToHost);
         }
         if (e != hipSuccess) {
             set_error("loading the compiled functor failed: %s", hipGetErrorString(e));
@@ -500,9 +547,16 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
         }
         m->refs += 1;
     }
-    // an empty functor has sizeof 1; otherwise the caller's bytes ARE the functor object
-    if (!((params_bytes == 0 && m->sizeof_f == 1) || (int64_t)m->sizeof_f == params_bytes)) {
-        set_error("the functor %s is %u bytes, %lld bytes of parameters were given", functor, m->sizeof_f, (long long)params_bytes);
+    // an empty functor has sizeof 1; otherwise the caller's bytes ARE the functor object (a separable functor: the TERMS object, the
+    // library appends the list pointers where fd_sep_rows keeps them)
+    const unsigned want_bytes = sep ? m->terms_bytes : m->sizeof_f;
+    if (sep && (m->lists_offset == 0 || m->lists_offset + 2 * sizeof(void *) > m->sizeof_f)) {
+        set_error("internal: fd_sep_rows layout not reported by the compiled module");
+        release_module(m);
+        return FD_ERR_HIP;
+    }
+    if (!((params_bytes == 0 && want_bytes == 1) || (int64_t)want_bytes == params_bytes)) {
+        set_error("the functor %s is %u bytes, %lld bytes of parameters were given", functor, want_bytes, (long long)params_bytes);
         release_module(m);
         return FD_ERR_ARG;
     }
@@ -511,6 +565,15 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
     j->ctx = ctx; j->m = m; j->elem_bytes = elem_bytes; j->M = M; j->N = N;
     j->params.assign(std::max<size_t>(m->sizeof_f, 16), 0);
     if (params_bytes > 0) memcpy(j->params.data(), params, (size_t)params_bytes);
+    if (sep) {
+        memcpy(j->params.data() + m->lists_offset, &sep_lists[0], sizeof(void *));
+        memcpy(j->params.data() + m->lists_offset + sizeof(void *), &sep_lists[1], sizeof(void *));
+        j->sep = true;
+        j->plan_serial = sep_serial;
+        int last = 0;      // (row_ptr[M] = the pattern's stored entries: sizes the row-wise store's staging)
+        if (hipMemcpy(&last, (const int *)sep_lists[0] + M, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); last = (int)M; }
+        j->entries = last;
+    }
     *fn_out = jit_launch;
     if (lazy_out) *lazy_out = jit_launch_lazy;
     // (FD_LAZY_CAP_STORE: exact bands of width (1, 1) / (2, 2) through fd_band_store_cols; every other storing request is declined)
@@ -544,6 +607,39 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor, cons
     src += "\n";
     src += kJitTail;
     return jit_build(ctx, src, std::vector<char>(), real, functor, params, params_bytes, M, N, elem_bytes, fn_out, lazy_out, lazy_caps_out, fctx_out);
+}
+
+// A SEPARABLE residual from its term (include/fdjac.h): the terms type wrapped into fd_sep_rows (include/fdjac_device.h), which reads
+// the pattern by rows from the lists of the plan the functor is made for.
+int fd_f_compile_terms(fd_ctx *ctx, const char *source, const char *terms, const void *params, int64_t params_bytes, int64_t M, int64_t N,
+                       int elem_bytes, const void *row_ptr_dev, const void *row_col_dev, uint64_t plan_serial, fd_f_launch *fn_out,
+                       fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out)
+{
+    FD_REQUIRE(ctx && source && terms && fn_out && fctx_out && row_ptr_dev && row_col_dev, FD_ERR_ARG, "NULL argument");
+    FD_REQUIRE(elem_bytes == 8 || elem_bytes == 4, FD_ERR_ARG, "elem_bytes must be 8 (Float64) or 4 (Float32)");
+    FD_REQUIRE(M >= 1 && N >= 1 && M < ((int64_t)1 << 31), FD_ERR_ARG, "bad shape");
+    FD_REQUIRE(params_bytes >= 0 && (params || params_bytes == 0), FD_ERR_ARG, "bad functor parameters");
+    for (const char *c = terms; *c; ++c)
+        FD_REQUIRE((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_' || *c == ':' || *c == '<' || *c == '>' || *c == ',' ||
+                       *c == ' ',
+                   FD_ERR_ARG, "terms_type must be a type name");
+    FD_HIP_CHECK(hipSetDevice(ctx->device));
+    t_log.clear();
+    const char *real = elem_bytes == 8 ? "double" : "float";
+    std::string src;
+    src += kDeviceHeader;
+    src += "\ntypedef ";
+    src += real;
+    src += " real_t;\n#line 1 \"functor\"\n";
+    src += source;
+    src += "\n#define FDJIT_FUNCTOR fd_sep_rows<";
+    src += terms;
+    src += " >\n";
+    src += kJitTail;
+    const void *lists[2] = {row_ptr_dev, row_col_dev};
+    const std::string name = std::string("fd_sep_rows<") + terms + " >";
+    return jit_build(ctx, src, std::vector<char>(), real, name.c_str(), params, params_bytes, M, N, elem_bytes, fn_out, lazy_out, lazy_caps_out, fctx_out, lists,
+                     (unsigned long long)plan_serial);
 }
 
 
@@ -655,6 +751,13 @@ int fd_f_compiled_counts(void *fctx, int64_t *launches)
 {
     FD_REQUIRE(fctx && launches, FD_ERR_ARG, "NULL argument");
     *launches = ((fd_jit_f *)fctx)->launches;
+    return FD_OK;
+}
+
+int fd_f_compiled_row_stores(void *fctx, int64_t *row_stores)
+{
+    FD_REQUIRE(fctx && row_stores, FD_ERR_ARG, "NULL argument");
+    *row_stores = ((fd_jit_f *)fctx)->row_stores;
     return FD_OK;
 }
 

@@ -157,6 +157,34 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
         (void)hipGetLastError();
     }
     FD_HIP_CHECK(hipStreamSynchronize(s));
+    // the pattern by rows (FD_PLAN_STORE_CSC_ROWS): a counting sort of the compact copy on the host -- walking the columns in order
+    // leaves every row's entries in ascending column order; plan time, once
+    if (p->want_store_rows && !windowed && n > 0 && p->M > 0) {
+        std::vector<int> cp((size_t)ncols + 1), rv((size_t)n), rp((size_t)p->M + 1, 0), rc((size_t)n), rs((size_t)n);
+        FD_HIP_CHECK(hipMemcpy(cp.data(), p->d_sc_colptr, sizeof(int) * cp.size(), hipMemcpyDeviceToHost));
+        FD_HIP_CHECK(hipMemcpy(rv.data(), p->d_sc_rowval, sizeof(int) * rv.size(), hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (int64_t q = 0; q < n; ++q) {
+            if (rv[(size_t)q] < 0 || rv[(size_t)q] >= p->M) { ok = false; break; }
+            rp[(size_t)rv[(size_t)q] + 1] += 1;
+        }
+        if (ok) {
+            for (int64_t r = 0; r < p->M; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+            std::vector<int> cur(rp.begin(), rp.end() - 1);
+            for (int64_t j = 0; j < ncols; ++j)
+                for (int q = cp[(size_t)j]; q < cp[(size_t)j + 1]; ++q) {
+                    const int at = cur[(size_t)rv[(size_t)q]]++;
+                    rc[(size_t)at] = (int)j;
+                    rs[(size_t)at] = q;
+                }
+            FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_ptr, sizeof(int) * rp.size()));
+            FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_col, sizeof(int) * rc.size()));
+            FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_slot, sizeof(int) * rs.size()));
+            FD_HIP_CHECK(hipMemcpy(p->d_sr_ptr, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice));
+            FD_HIP_CHECK(hipMemcpy(p->d_sr_col, rc.data(), sizeof(int) * rc.size(), hipMemcpyHostToDevice));
+            FD_HIP_CHECK(hipMemcpy(p->d_sr_slot, rs.data(), sizeof(int) * rs.size(), hipMemcpyHostToDevice));
+        }
+    }
     p->sc_entries = n;
     p->store_csc_ok = true;
     return FD_OK;

@@ -28,7 +28,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total", "exchange")
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
  INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE, INFO_STORE_CSC) = range(34)
 LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE, LAZY_CAP_STORE_CSC_COMPLEX, LAZY_CAP_FUSED_EPS = 1, 2, 4, 8, 16, 32, 64, 128
-PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC, PLAN_STORE_CSC_ALWAYS = 1, 2, 4, 8, 16
+PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC, PLAN_STORE_CSC_ALWAYS, PLAN_STORE_CSC_ROWS = 1, 2, 4, 8, 16, 32
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL, F_LAP7, F_SPARSE) = range(9)
 FAMILIES = {"tridiag": F_TRIDIAG, "tridiag_nl": F_TRIDIAG_NL, "lap5": F_LAP5, "clamp5": F_CLAMP5,
@@ -70,7 +70,7 @@ EXPORTS = (
     "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp", "fd_jvp_plan_set_lazy_caps", "fd_builtin_f_lazy_jvp_caps",
     "fd_color_columns_greedy", "fd_color_banded",
     "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy", "fd_comm_info", "fd_comm_library", "fd_comm_allgather",
-    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_link_rows_bitcode", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log",
+    "fd_comm_gatherv", "fd_comm_allreduce_sum", "fd_comm_broadcast", "fd_comm_halo_exchange", "fd_comm_enable_p2p", "fd_comm_p2p_status", "fd_comm_disable_p2p", "fd_f_compile_rows", "fd_f_link_rows_bitcode", "fd_f_compiled_destroy", "fd_f_compiled_counts", "fd_f_compile_log", "fd_f_compile_terms", "fd_f_compiled_row_stores", "fd_plan_row_lists",
     "fd_p2p_create", "fd_p2p_create_loopback", "fd_p2p_loopback_fill", "fd_p2p_loopback_fill_fused", "fd_p2p_local_handle", "fd_p2p_connect", "fd_p2p_destroy", "fd_p2p_info", "fd_p2p_status", "fd_p2p_allgather",
     "fd_p2p_halo_exchange",
     "fd_plan_set_comm", "fd_plan_set_p2p", "fd_plan_set_halo", "fd_plan_eps_partials", "fd_plan_eps_finalize", "fd_plan_set_eps_mode",
@@ -87,7 +87,7 @@ EXPORTS = (
 TYPED = (
     "fd_plan_create_csc", "fd_plan_create_csc_dense", "fd_plan_create_coo_dense", "fd_plan_create_entries",
     "fd_plan_create_dense", "fd_plan_create_tridiagonal", "fd_plan_create_banded", "fd_plan_create_blockbanded",
-    "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_jacobian", "fd_jacobian_async", "fd_jacobian_owned_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
+    "fd_plan_create_bandedblockbanded", "fd_plan_destroy", "fd_plan_info", "fd_plan_row_lists", "fd_jacobian", "fd_jacobian_async", "fd_jacobian_owned_async", "fd_plan_set_lazy_f", "fd_plan_set_lazy_caps",
     "fd_plan_get_epsilons", "fd_plan_fused_trace", "fd_plan_enable_timing", "fd_plan_set_timing_stride", "fd_plan_get_timings", "fd_builtin_f_create", "fd_builtin_f_destroy",
     "fd_builtin_f_counts", "fd_builtin_f_info", "fd_builtin_f_lazy", "fd_builtin_f_lazy_caps", "fd_jvp_plan_create", "fd_jvp_plan_destroy",
     "fd_jvp", "fd_jvp_async", "fd_jvp_get_epsilon", "fd_jvp_plan_set_lazy_f", "fd_builtin_f_lazy_jvp",
@@ -190,6 +190,7 @@ def load():
     L.fd_plan_matches_async.argtypes = [vp, C.POINTER(PatternArrays)]
     L.fd_plan_stale.argtypes = [vp, C.POINTER(i32)]
     L.fd_plan_info.argtypes = [vp, i32, C.POINTER(i64)]
+    L.fd_plan_row_lists.argtypes = [vp, pp, pp, pp, C.POINTER(i64), C.POINTER(C.c_uint64)]
     L.fd_jacobian.argtypes = [vp, F_LAUNCH, vp, vp, i32, vp, i32, dbl, dbl, dbl, pp, i32]
     L.fd_jacobian_async.argtypes = [vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
     L.fd_jacobian_owned_async.argtypes = [vp, vp, F_LAUNCH, vp, vp, vp, dbl, dbl, dbl, pp]
@@ -237,6 +238,8 @@ def load():
     L.fd_f_link_rows_bitcode.argtypes = [vp, vp, i64, vp, i64, i64, i64, i32, C.POINTER(F_LAUNCH), C.POINTER(F_LAUNCH_LAZY), C.POINTER(i32), pp]
     L.fd_f_compiled_destroy.argtypes = [vp]
     L.fd_f_compiled_counts.argtypes = [vp, C.POINTER(i64)]
+    L.fd_f_compiled_row_stores.argtypes = [vp, C.POINTER(i64)]
+    L.fd_f_compile_terms.argtypes = [vp, C.c_char_p, C.c_char_p, vp, i64, i64, i64, i32, vp, vp, C.c_uint64, C.POINTER(F_LAUNCH), C.POINTER(F_LAUNCH_LAZY), C.POINTER(i32), pp]
     L.fd_f_compile_log.restype = C.c_char_p
     L.fd_p2p_create.argtypes = [vp, i32, i32, i64, pp]
     L.fd_p2p_create_loopback.argtypes = [vp, i32, i32, i64, pp]

@@ -176,6 +176,10 @@ typedef struct fd_plan_opts {
                                    /* reports whether it was built.                                                                      */
 #define FD_PLAN_STORE_CSC_ALWAYS 16   /* (with FD_PLAN_STORE_CSC) build that copy for exact bands / 5-point stencils too: for launchers that store     */
                                    /* through fd_csc_store ONLY -- runtime-compiled functors (fd_f_compile_rows) on a banded pattern             */
+#define FD_PLAN_STORE_CSC_ROWS 32     /* (with FD_PLAN_STORE_CSC, plans that hold every column) also keep the pattern BY ROWS on the device --  */
+                                   /* per row its entries' columns and their slots in nzval (fd_csc_store.row_ptr / row_col / row_slot, 8 bytes */
+                                   /* per stored entry + 4 per row) -- for the row-wise store of SEPARABLE residuals (fd_csc_store_rows,       */
+                                   /* include/fdjac_device.h; fd_f_compile_terms); fd_plan_row_lists hands the lists out                     */
 #define FD_PLAN_FINGERPRINT 4        /* record 64-bit content fingerprints of the pattern / colour arrays the plan is compiled from, so  */
                                    /* that fd_plan_matches can later tell whether the caller's arrays still hold that content        */
 
@@ -319,6 +323,12 @@ enum fd_plan_info_key {
    read there, not per process and not per launch -- except FDJAC_COLRANGE_VEC, which only re-vectorises the same work);
    FD_INFO_WINDOW also reports the row-window kernel of Tridiagonal plans. */
 int fd_plan_info(const fd_plan *plan, int key, int64_t *value);
+/* The plan's pattern BY ROWS on the device (FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ROWS; ext/FiniteDiffSparseArraysExt.jl:38-47 walks the
+   same entries column by column): row_ptr (M + 1 int32 offsets), row_col (per entry its 0-based column, ascending within a row), row_slot
+   (per entry its index in nzval), the number of entries and the plan's serial (fd_csc_store.plan_serial).  Owned by the plan.
+   FD_ERR_UNSUPPORTED when the plan has no such lists (flag not given, a column window, a pattern the storing copy is skipped for). */
+int fd_plan_row_lists(const fd_plan *plan, const void **row_ptr_dev, const void **row_col_dev, const void **row_slot_dev, int64_t *entries,
+                      uint64_t *plan_serial);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 /*
@@ -692,8 +702,23 @@ int fd_f_compile_rows(fd_ctx *ctx, const char *source, const char *functor_type,
  * FD_ERR_ARG when the link fails (fd_f_compile_log()), FD_ERR_UNSUPPORTED without libhiprtc. */
 int fd_f_link_rows_bitcode(fd_ctx *ctx, const void *bitcode, int64_t bitcode_bytes, const void *params, int64_t params_bytes, int64_t M,
                            int64_t N, int elem_bytes, fd_f_launch *fn_out, fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out);
+/* A SEPARABLE residual from its TERM alone (round 6; include/fdjac_device.h, "SEPARABLE residuals"): row r of f is the left-to-right
+ * sum, over the stored entries (r, j) of the Jacobian's own pattern in ascending j, of a term of ONE coordinate.  `source` defines
+ *     struct MyTerms { <parameters>;  template <class T> __device__ T term(long long r, long long j, T v) const { ... } };
+ * (generic in T: the complex step instantiates it on fd_cplx<real_t>).  row_ptr_dev / row_col_dev: the pattern by rows on the device --
+ * the lists of the plan the functor will be used with (fd_plan_row_lists of a plan created with FD_PLAN_STORE_CSC |
+ * FD_PLAN_STORE_CSC_ROWS), which must outlive the functor; plan_serial: that plan's serial.  The library wraps the terms into
+ * fd_sep_rows<MyTerms> and returns the launchers of fd_f_compile_rows -- plain evaluation, column store, complex step, all from `term`
+ * -- plus the ROW-WISE store: on the plan the lists came from (verified colouring, reach <= 700, M == N) the Jacobian is ONE launch of
+ * fd_csc_store_rows, 2 L term evaluations per row of L entries instead of L^2, bit-identical to the column store.  Any other plan takes
+ * the column store.  `params` = the MyTerms object byte for byte (0 bytes for an empty struct). */
+int fd_f_compile_terms(fd_ctx *ctx, const char *source, const char *terms_type, const void *params, int64_t params_bytes, int64_t M, int64_t N,
+                       int elem_bytes, const void *row_ptr_dev, const void *row_col_dev, uint64_t plan_serial, fd_f_launch *fn_out,
+                       fd_f_launch_lazy *lazy_out, int *lazy_caps_out, void **fctx_out);
 int fd_f_compiled_destroy(void *fctx);
 int fd_f_compiled_counts(void *fctx, int64_t *launches);
+/* launches of the ROW-WISE store among them (fd_f_compile_terms functors; 0 for the others) */
+int fd_f_compiled_row_stores(void *fctx, int64_t *row_stores);
 const char *fd_f_compile_log(void);
 
 /* Device stream-copy ceiling probe: copies `bytes` device-to-device `iters` times with a
@@ -746,6 +771,8 @@ int fd32_plan_create_bandedblockbanded(fd_ctx *ctx, int64_t nblk, const void *bl
 int fd32_plan_destroy(fd32_plan *plan);
 int fd32_plan_matches(fd32_plan *plan, const fd_pattern_arrays *now, int *matches_out);
 int fd32_plan_info(const fd32_plan *plan, int key, int64_t *value);
+int fd32_plan_row_lists(const fd32_plan *plan, const void **row_ptr_dev, const void **row_col_dev, const void **row_slot_dev, int64_t *entries,
+                        uint64_t *plan_serial);
 int fd32_jacobian(fd32_plan *plan, fd_f_launch f, void *fctx, const void *x, int x_kind,
                 const void *f_in, int f_in_kind, double relstep, double absstep, double dir,
                 void *const *outs, int out_kind);

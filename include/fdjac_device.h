@@ -190,6 +190,10 @@ typedef struct fd_csc_store {
                                    /* columns of the Jacobian's own pattern -- the coordinates those rows read within 2 * reach               */
                                    /* (fd_csc_store_cols_win keeps that window of x in LDS; anything outside it is read from memory)         */
     unsigned long long plan_serial;/* unique per plan (never reused): what a launcher may key its own HOST-side memory about the plan on      */
+    /* the same pattern BY ROWS (plans created with FD_PLAN_STORE_CSC_ROWS that hold every column; else NULL): what fd_csc_store_rows walks   */
+    const int *row_ptr;            /* device, M + 1 offsets: row r's stored entries are [row_ptr[r], row_ptr[r + 1]) of the two lists below   */
+    const int *row_col;            /* device, per entry in row-major order: its 0-based column (ascending within a row)                       */
+    const int *row_slot;           /* device, per entry in row-major order: its index in out / rowval (the entry's slot in J's CSC storage)   */
 } fd_csc_store;
 
 /* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------
@@ -843,6 +847,236 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_win(F f, const T *__res
         if (mine) fd_csc_store_column_win<T, MODE>(f, X, st, run, a, b, h, s_b, r_lo, r_hi);
     }
     run.template flush<true>();
+}
+
+/* ---- SEPARABLE residuals: the Jacobian stored ROW BY ROW (round 6) ---------------------------------------------------------------------
+ * The column kernels above give every stored entry (r, j) its own evaluation of row r: nnz x (row length) terms.  Many residuals on a
+ * general pattern are sums of ONE-coordinate terms over the pattern's own entries (a graph Laplacian with nonlinear edge terms, a reaction
+ * network, a finite-volume flux sum):
+ *     f(x)_r = t(r, j_0, x[j_0]) + t(r, j_1, x[j_1]) + ...      over the stored entries (r, j_k) of J's row r, j_0 < j_1 < ..., added left to right.
+ * Such a residual is SEPARABLE on the pattern, and its functor says so:
+ *     struct MyTerms { static constexpr bool fd_separable = true;  <parameters>
+ *                      template <class T> __device__ T term(long long r, long long j, T v) const { ... } };
+ * Then the L entries of a row share everything but one term: the thread that owns row r forms the row's L plain terms once, and for
+ * entry k the sum (t_0 + .. + t_{k-1}) + t'_k + t_{k+1} + .. + t_{L-1} with the perturbed term t'_k = t(r, j_k, x[j_k] +- eps) -- the
+ * additions of the full evaluation at the colour's point (ext/FiniteDiffSparseArraysExt.jl:38-47 on the f! values of
+ * src/jacobians.jl:562-568 / 602-609) in the same order, so THE SAME BITS as fd_csc_store_cols, with 2 L term evaluations per row
+ * instead of L^2.  Needs a colouring the plan has verified (st.valid_coloring) and the plan's row lists (st.row_ptr: FD_PLAN_STORE_CSC_ROWS).
+ * fd_sep_rows<TF> makes the row functor the other kernels take (plain evaluation, column store, complex step) out of the same terms and
+ * the same lists, so one `term` serves every route.
+ * Launch: fd_xcd_grid((M + 255) / 256) workgroups of 256 threads, fd_csc_rows_lds_bytes<T>(reach, c_hi - c_lo, cap) bytes of LDS,
+ * reach = st.reach (1 .. 700), M == N >= 2, every column local, cap = entries of a 256-row tile kept in LDS (a tile with more reads the
+ * rest from memory).  The window of x and of the colours, the step sizes and the tile's run of the row lists are requested up front --
+ * every load of the prologue in flight at once -- and parked in LDS; the loops after the barrier touch memory only to store. */
+template <class TF> struct fd_sep_rows {
+    static constexpr bool fd_separable = true;
+    TF t;
+    const int *row_ptr, *row_col;
+    template <class T> __device__ T term(long long r, long long j, T v) const { return t.term(r, j, v); }
+    template <class P> __device__ typename P::value_type operator()(long long r, const P &X) const
+    {
+        typedef typename P::value_type V;
+        const int a = row_ptr[r], b = row_ptr[r + 1];
+        V s = V();
+        /* four entries at a time: their columns in one round trip (from positions clamped into the row), their coordinates in a second */
+        for (int k0 = a; k0 < b; k0 += 4) {
+            long long j[4];
+            V v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) j[u] = row_col[k0 + u < b ? k0 + u : b - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = X(j[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const V w = t.term(r, j[u], v[u]);
+                if (k0 + u < b) s = k0 + u == a ? w : s + w;
+            }
+        }
+        return s;
+    }
+};
+template <class F, class = void> struct fd_is_separable { static constexpr bool value = false; };
+template <class F> struct fd_is_separable<F, decltype((void)F::fd_separable, void())> { static constexpr bool value = F::fd_separable; };
+/* where fd_sep_rows keeps its two list pointers (a host that assembles the functor object byte for byte needs the offset) */
+template <class F> struct fd_sep_rows_layout { static constexpr unsigned lists_offset = 0, terms_bytes = 0; };
+template <class TF> struct fd_sep_rows_layout<fd_sep_rows<TF>> {
+    static constexpr unsigned lists_offset = (unsigned)__builtin_offsetof(fd_sep_rows<TF>, row_ptr), terms_bytes = (unsigned)sizeof(TF);
+};
+#define FD_CSC_ROWS_REGS 14        /* entries of a row fd_csc_store_rows keeps in registers (longer rows loop over LDS) */
+/* LDS: [x window][step, reciprocal per colour of the batch][column, slot of the tile's entries][colours of the window] */
+template <typename T> __host__ __device__ inline size_t fd_csc_rows_lds_bytes(long long reach, int ncolors, int cap)
+{
+    const size_t xlen = (size_t)(256 + 2 * reach + 2);
+    return sizeof(T) * (xlen + 2 * (size_t)ncolors) + 4 * (2 * (size_t)cap + xlen) + 64;
+}
+template <typename T, typename CT, int MODE, class F>
+__global__ void __launch_bounds__(256) fd_csc_store_rows(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach,
+                                                         int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_rows_lds[];
+    typedef T fd_pair_t __attribute__((ext_vector_type(2)));
+    const long long ntile = (st.M + 255) / 256, tile = fd_xcd_block(blockIdx.x, ntile);
+    if (tile >= ntile) return;
+    const long long R0 = tile * 256, R1 = R0 + 256 < st.M ? R0 + 256 : st.M;
+    const long long r = R0 + threadIdx.x;
+    const bool in = r < R1;
+    const int a0 = st.row_ptr[in ? r : R1], a1 = st.row_ptr[in ? r + 1 : R1], L = a1 - a0;
+    const int A0 = st.row_ptr[R0], A1 = st.row_ptr[R1];
+    long long w0 = R0 - reach > 0 ? R0 - reach : 0;
+    const long long w1 = R1 + reach < st.N ? R1 + reach : st.N;
+    w0 &= ~1ll;
+    const int xlen = 256 + 2 * reach + 2, nchunk = c_hi - c_lo;
+    FD_LDS_PTR(T) s_x = (FD_LDS_PTR(T))fd_rows_lds;
+    FD_LDS_PTR(T) s_h = s_x + xlen;                                    /* step of colour c_lo + i */
+    FD_LDS_PTR(T) s_y = s_h + nchunk;                                  /* 1 / (step or 2 step) */
+    FD_LDS_PTR(int) s_j = (FD_LDS_PTR(int))(s_y + nchunk);             /* column of the tile's i-th entry */
+    FD_LDS_PTR(int) s_q = s_j + cap;                                   /* its slot in out */
+    FD_LDS_PTR(int) s_c = s_q + cap;                                   /* colour of column w0 + i (-1: none) */
+    const CT *color = (const CT *)st.color;
+    const int nx = (int)(w1 - w0), npair = nx >> 1;
+    const int nst = A1 - A0 < cap ? A1 - A0 : cap;
+    {
+        /* every load of the prologue is requested before the first is used, from indices clamped into range (no load inside a
+           per-lane branch); a batch the window does not reach is skipped by a wave-uniform test */
+        constexpr int XP = 4, XC = 8, XL = 8;      /* 2048 coordinates, 2048 colours, 2048 entries per trip */
+        fd_pair_t vx[XP];
+        int vc[XC], vj[XL], vq[XL];
+#pragma unroll
+        for (int u = 0; u < XP; ++u)
+            if (u * 256 < npair) { const int i = u * 256 + (int)threadIdx.x; vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0 + 2 * (i < npair ? i : npair - 1)); }
+#pragma unroll
+        for (int u = 0; u < XC; ++u)
+            if (u * 256 < nx) { const int i = u * 256 + (int)threadIdx.x; const CT c = color[w0 + (i < nx ? i : nx - 1)]; vc[u] = c == (CT)(-1) ? -1 : (int)c; }
+#pragma unroll
+        for (int u = 0; u < XL; ++u)
+            if (u * 256 < nst) { const int i = u * 256 + (int)threadIdx.x, ic = A0 + (i < nst ? i : nst - 1); vj[u] = st.row_col[ic]; vq[u] = st.row_slot[ic]; }
+        for (int i = threadIdx.x; i < nchunk; i += 256) { const T h = eps[c_lo + i]; s_h[i] = h; s_y[i] = (T)1 / (MODE == 1 ? 2 * h : h); }
+        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
+#pragma unroll
+        for (int u = 0; u < XP; ++u)
+            if (u * 256 < npair) { const int i = u * 256 + (int)threadIdx.x; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+#pragma unroll
+        for (int u = 0; u < XC; ++u)
+            if (u * 256 < nx) { const int i = u * 256 + (int)threadIdx.x; if (i < nx) s_c[i] = vc[u]; }
+#pragma unroll
+        for (int u = 0; u < XL; ++u)
+            if (u * 256 < nst) { const int i = u * 256 + (int)threadIdx.x; if (i < nst) { s_j[i] = vj[u]; s_q[i] = vq[u]; } }
+        for (int i0 = XL * 256; i0 < nst; i0 += 256) {                  /* (a tile with more than 2048 staged entries: the rest, trip by trip) */
+            const int i = i0 + (int)threadIdx.x;
+            if (i < nst) { s_j[i] = st.row_col[A0 + i]; s_q[i] = st.row_slot[A0 + i]; }
+        }
+    }
+    __syncthreads();
+    if (!in || L == 0) return;
+    const int b0 = a0 - A0;                                            /* the row's entries are the tile's [b0, b0 + L) */
+    T *out = (T *)st.out;
+    /* forward differences: the subtrahend is what the plan hands over (the caller's f_in, or f(x) from a plain evaluation) -- or,
+       without one (FD_LAZY_CAP_STORE_CSC_BASE), the row's own plain sum */
+    const bool given = MODE == 0 && st.fx_base != nullptr;
+    const T fx_given = given ? ((const T *)st.fx_base)[r] : (T)0;
+    if (A1 - A0 <= cap) {
+        /* the whole tile is staged, and every column of a row lies in the window (|r - j| <= reach): no load from memory below.  That
+           matters more than it looks: this target counts loads and stores in ONE counter, and a loop body that MAY load makes the
+           compiler wait for everything outstanding -- the store of the iteration before -- on every trip */
+        constexpr int RL = FD_CSC_ROWS_REGS;
+        if (L <= RL) {
+            /* the row in REGISTERS, every loop unrolled and predicated */
+            int jj[RL], qq[RL];
+            T tt[RL];
+#pragma unroll
+            for (int u = 0; u < RL; ++u) { const int i = b0 + (u < L ? u : L - 1); jj[u] = s_j[i]; qq[u] = s_q[i]; }
+            T fx = 0;
+#pragma unroll
+            for (int u = 0; u < RL; ++u) {
+                tt[u] = f.term(r, (long long)jj[u], (T)s_x[(unsigned)(jj[u] - (int)w0)]);
+                fx = u == 0 ? tt[0] : (u < L ? fx + tt[u] : fx);
+            }
+            T pre = 0;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                if (k < L) {
+                    const unsigned off = (unsigned)(jj[k] - (int)w0);
+                    const int c = s_c[off];
+                    const T v = s_x[off];
+                    if (c < 0) {
+                        if (c_lo == 0) out[qq[k]] = (T)0;
+                    } else if (c >= c_lo && c < c_hi) {
+                        const T h = s_h[c - c_lo], y = s_y[c - c_lo];
+                        T sp = f.term(r, (long long)jj[k], v + h), sm = MODE == 1 ? f.term(r, (long long)jj[k], v - h) : (T)0;
+                        if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+#pragma unroll
+                        for (int u = k + 1; u < RL; ++u)
+                            if (u < L) { sp = sp + tt[u]; if (MODE == 1) sm = sm + tt[u]; }
+                        out[qq[k]] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
+                    }
+                    pre = k == 0 ? tt[0] : pre + tt[k];
+                }
+            }
+            return;
+        }
+        T fx = 0;
+        for (int u = 0; u < L; ++u) {
+            const int j = s_j[b0 + u];
+            const T t = f.term(r, (long long)j, (T)s_x[(unsigned)(j - (int)w0)]);
+            fx = u == 0 ? t : fx + t;
+        }
+        T pre = 0;
+        for (int k = 0; k < L; ++k) {
+            const int j = s_j[b0 + k], q = s_q[b0 + k];
+            const unsigned off = (unsigned)(j - (int)w0);
+            const int c = s_c[off];
+            const T v = s_x[off];
+            const T tk = f.term(r, (long long)j, v);
+            if (c < 0) {
+                if (c_lo == 0) out[q] = (T)0;
+            } else if (c >= c_lo && c < c_hi) {
+                const T h = s_h[c - c_lo], y = s_y[c - c_lo];
+                T sp = f.term(r, (long long)j, v + h), sm = MODE == 1 ? f.term(r, (long long)j, v - h) : (T)0;
+                if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+                for (int u = k + 1; u < L; ++u) {
+                    const int ju = s_j[b0 + u];
+                    const T t = f.term(r, (long long)ju, (T)s_x[(unsigned)(ju - (int)w0)]);
+                    sp = sp + t;
+                    if (MODE == 1) sm = sm + t;
+                }
+                out[q] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
+            }
+            pre = k == 0 ? tk : pre + tk;
+        }
+        return;
+    }
+    /* a tile with more entries than fit: the lists beyond the staged part are read from memory (same indices, same order, same bits) */
+    auto col_of = [&](int i) -> int { return i < nst ? (int)s_j[i] : st.row_col[A0 + i]; };
+    auto slot_of = [&](int i) -> int { return i < nst ? (int)s_q[i] : st.row_slot[A0 + i]; };
+    T fx = 0;
+    for (int u = 0; u < L; ++u) {
+        const int j = col_of(b0 + u);
+        const T t = f.term(r, (long long)j, (T)s_x[(unsigned)(j - (int)w0)]);
+        fx = u == 0 ? t : fx + t;
+    }
+    T pre = 0;
+    for (int k = 0; k < L; ++k) {
+        const int j = col_of(b0 + k), q = slot_of(b0 + k);
+        const unsigned off = (unsigned)(j - (int)w0);
+        const int c = s_c[off];
+        const T v = s_x[off];
+        const T tk = f.term(r, (long long)j, v);
+        if (c < 0) {
+            if (c_lo == 0) out[q] = (T)0;
+        } else if (c >= c_lo && c < c_hi) {
+            const T h = s_h[c - c_lo], y = s_y[c - c_lo];
+            T sp = f.term(r, (long long)j, v + h), sm = MODE == 1 ? f.term(r, (long long)j, v - h) : (T)0;
+            if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+            for (int u = k + 1; u < L; ++u) {
+                const int ju = col_of(b0 + u);
+                const T t = f.term(r, (long long)ju, (T)s_x[(unsigned)(ju - (int)w0)]);
+                sp = sp + t;
+                if (MODE == 1) sm = sm + t;
+            }
+            out[q] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
+        }
+        pre = k == 0 ? tk : pre + tk;
+    }
 }
 
 /* ---- a ROW FUNCTOR storing an exact band itself (round 5) ----------------------------------------------------------------------------

@@ -419,3 +419,155 @@ def test_row_function_given_as_llvm_bitcode(tmp_path, dtype):
             p2.jacobian(fu, x, [o2])
             assert fu.launches - n0 == 1
             assert torch.equal(o2, ref), (fdtype, "band store")
+
+
+# ---- separable residuals from their TERM alone (fd_f_compile_terms): the row-wise store for user functors ---------------------------
+SPARSE_TERMS = """
+// the sparse family's term (csrc/fdjac_functor_f.hip, SparseF): w(r, j) * (v + (v / 4) v), w = 1 + ((r + 3 j) mod 8) / 8
+struct SparseTerms {
+    template <class T> __device__ T term(long long r, long long j, T v) const
+    {
+        return ((real_t)1 + (real_t)0.125 * (real_t)(int)((r + 3 * j) & 7)) * (v + ((real_t)0.25 * v) * v);
+    }
+};
+"""
+SCALED_TERMS = """
+struct ScaledTerms {
+    double a; long long shift;      // (parameters travel byte for byte)
+    template <class T> __device__ T term(long long r, long long j, T v) const
+    {
+        return ((real_t)a + (real_t)0.125 * (real_t)(int)((r + 3 * j + shift) & 7)) * (v + ((real_t)0.25 * v) * v);
+    }
+};
+"""
+
+
+def _random_band(M, N, per_col, reach, seed, empty=0.03):
+    rng = np.random.default_rng(seed)
+    centre = (np.arange(N) * M) // max(N, 1)
+    offs = np.sort(rng.integers(-reach, reach + 1, size=(N, per_col)), axis=1)
+    rows = centre[:, None] + offs
+    keep = (rows >= 0) & (rows < M)
+    keep[:, 1:] &= rows[:, 1:] != rows[:, :-1]
+    keep[rng.random(N) < empty] = False
+    cnt = keep.sum(axis=1)
+    colptr = np.empty(N + 1, np.int64)
+    colptr[0] = 1
+    np.cumsum(cnt, out=colptr[1:])
+    colptr[1:] += 1
+    return colptr, (rows[keep] + 1).astype(np.int64)
+
+
+def _sparse_np(M, N, colptr, rowval, a=1.0, shift=0):
+    cols = P.csc_cols(colptr) - 1
+    rows = rowval - 1
+    order = np.lexsort((cols, rows))
+    rs, cs = rows[order], cols[order]
+    cnt = np.bincount(rs, minlength=M)
+    start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+    maxlen = int(cnt.max()) if cnt.size else 0
+    w = a + 0.125 * ((rs + 3 * cs + shift) & 7)
+
+    def f(fx, xx):
+        t = w * (xx[cs] + (0.25 * xx[cs]) * xx[cs])
+        out = np.zeros(M, dtype=xx.dtype)
+        for k in range(maxlen):
+            sel = np.nonzero(cnt > k)[0]
+            out[sel] = t[start[sel] + k] if k == 0 else out[sel] + t[start[sel] + k]
+        fx[:] = out
+    return f
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+# (3000, 12, 40): more entries per tile than its staged run holds; (2000, 3, 700): the widest window; (300, 4, 9): one partial tile
+@pytest.mark.parametrize("case", [(300, 4, 9, 1), (5000, 6, 300, 4), (70001, 6, 300, 7), (3000, 12, 40, 8), (2000, 3, 700, 9), (4100, 20, 30, 10)])
+def test_terms_functor_row_wise_store_has_the_bits_of_every_other_route_and_the_oracle(oracle, fdtype, case):
+    N, per_col, reach, seed = case
+    colptr, rowval = _random_band(N, N, per_col, reach, seed)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    x = np.random.default_rng(seed).random(N) + 0.1
+    xd = _dev(x)
+    # the reference bits: the built-in sparse family through the hand-over path (oracle-checked in tests/test_gpu_storetable.py)
+    fb = fd.BuiltinF.sparse(N, N, colptr, rowval)
+    ph = fd.make_plan(J, J, colors, fdtype)
+    ref = _dev(np.full(rowval.size, np.nan))
+    ph.jacobian(fb, xd, [ref])
+    # the terms functor on a plan that keeps its pattern by rows: ONE launch, row by row
+    pr = fd.make_plan(J, J, colors, fdtype, store_rows=True)
+    rl = pr.row_lists()
+    assert rl["entries"] == rowval.size and rl["row_ptr"] and rl["row_col"] and rl["row_slot"]
+    ft = fd.JitTerms(SPARSE_TERMS, "SparseTerms", pr)
+    pr.set_lazy(ft)
+    a = _dev(np.full(rowval.size, np.nan))
+    n0, r0 = ft.launches, ft.row_stores
+    pr.jacobian(ft, xd, [a])
+    assert pr.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert ft.launches - n0 == 1 and ft.row_stores - r0 == 1            # one launch, and it was the row-wise store
+    assert torch.equal(a.view(torch.int64), ref.view(torch.int64))
+    # the same functor through the column store (a plan without row lists: another serial) and through the opaque route
+    pc = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    pc.set_lazy(ft)
+    b = _dev(np.full(rowval.size, np.nan))
+    r1 = ft.row_stores
+    pc.jacobian(ft, xd, [b])
+    assert ft.row_stores == r1 and pc.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert torch.equal(b.view(torch.int64), ref.view(torch.int64))
+    po = fd.make_plan(J, J, colors, fdtype)
+    c = _dev(np.full(rowval.size, np.nan))
+    po.jacobian(ft, xd, [c])
+    assert torch.equal(c.view(torch.int64), ref.view(torch.int64))
+    # and the oracle itself, directly (the reference's loop on the numpy restatement of the residual)
+    of = oracle.PyF(_sparse_np(N, N, colptr, rowval), N, N)
+    want = oracle.jacobian(fdtype, of, x, colors, M=N, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+    g = a.cpu().numpy()
+    fs = max(float(np.abs(want["fx"]).max()) if "fx" in want else 10.0 * per_col, 1.0)
+    atol = 16 * np.finfo(np.float64).eps * fs / float(np.min(np.abs(pr.epsilons())))      # tolerance: 16 ulp of f over the smallest step
+    assert np.all(np.abs(g - want["out"]) <= 1e-6 * np.abs(want["out"]) + atol)
+
+
+def test_terms_functor_parameters_float32_complex_step_and_refusals(oracle):
+    N, per_col, reach, seed = 6000, 5, 120, 3
+    colptr, rowval = _random_band(N, N, per_col, reach, seed)
+    J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    x = np.random.default_rng(seed).random(N) + 0.1
+    prm = struct.pack("dq", 1.5, 5)
+    # parameters, Float64: row-wise store == column store == opaque, and the oracle on the restated residual
+    for dtype, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        xd = _dev(x, tdt)
+        pr = fd.make_plan(J, J, colors, "forward", dtype=dtype, store_rows=True)
+        ft = fd.JitTerms(SCALED_TERMS, "ScaledTerms", pr, params=prm)
+        pr.set_lazy(ft)
+        a = torch.full((rowval.size,), float("nan"), dtype=tdt, device="cuda")
+        pr.jacobian(ft, xd, [a])
+        assert ft.row_stores == 1
+        po = fd.make_plan(J, J, colors, "forward", dtype=dtype)
+        c = torch.full((rowval.size,), float("nan"), dtype=tdt, device="cuda")
+        po.jacobian(ft, xd, [c])
+        it = torch.int64 if dtype == np.float64 else torch.int32
+        assert torch.equal(a.view(it), c.view(it))
+        cols = P.csc_cols(colptr) - 1
+        analytic = (1.5 + 0.125 * (((rowval - 1) + 3 * cols + 5) & 7)) * (1.0 + 0.5 * x[cols])
+        assert np.max(np.abs(a.cpu().numpy().astype(np.float64) - analytic)) < (1e-5 if dtype == np.float64 else 5e-2)
+        if dtype == np.float64:
+            of = oracle.PyF(_sparse_np(N, N, colptr, rowval, 1.5, 5), N, N)
+            want = oracle.jacobian("forward", of, x, colors, M=N, kind=oracle.PAT_CSC_COMMON, colptr=colptr, rowval=rowval)
+            atol = 16 * np.finfo(np.float64).eps * max(float(np.abs(want["fx"]).max()), 1.0) / float(np.min(np.abs(pr.epsilons())))
+            assert np.all(np.abs(a.cpu().numpy() - want["out"]) <= 1e-6 * np.abs(want["out"]) + atol)
+            # the complex step: the term instantiated on the complex type, through the column store; exact to rounding
+            pz = fd.make_plan(J, J, colors, "complex", store_rows=True)
+            fz = fd.JitTerms(SCALED_TERMS, "ScaledTerms", pz, params=prm)
+            pz.set_lazy(fz)
+            z = _dev(np.full(rowval.size, np.nan))
+            pz.jacobian(fz, xd, [z])
+            assert np.max(np.abs(z.cpu().numpy() - analytic)) < 1e-13
+    # refusals: a plan without row lists; a parameter block of the wrong size
+    p0 = fd.make_plan(J, J, colors, "forward", store_csc=True)
+    with pytest.raises(fd.lib.FdError):
+        p0.row_lists()
+    pr = fd.make_plan(J, J, colors, "forward", store_rows=True)
+    with pytest.raises(fd.lib.FdError):
+        fd.JitTerms(SCALED_TERMS, "ScaledTerms", pr, params=b"\x00" * 3)
+    with pytest.raises(fd.lib.FdError):
+        fd.JitTerms("struct Bad { template <class T> __device__ T term(long long r, long long j, T v) const { return nonsense; } };", "Bad", pr)
