@@ -273,6 +273,12 @@ struct SparseF {
         return s;
     }
     template <class P> __device__ __forceinline__ real_t operator()(long long r, const P &X) const { return row<real_t>(r, X); }
+    // the residual is SEPARABLE on its pattern (include/fdjac_device.h): entry (r, j)'s term -- the one `row` adds, the same bits
+    static constexpr bool fd_separable = true;
+    template <typename T> __device__ __forceinline__ T term(long long r, long long j, T v) const
+    {
+        return ((real_t)1 + kEighth * (real_t)(int)((r + 3 * j) & 7)) * (v + (kQuarter * v) * v);
+    }
 
     // fd_csc_store_cols_win (include/fdjac_device.h): the row pattern of the rows [r_lo, r_hi) a workgroup's columns can touch, kept in
     // LDS -- the rows' offsets (int32, r_hi - r_lo + 1 of them) and up to `cap` of their column indices as 16-bit distances from the
@@ -892,6 +898,17 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
                 memo->verdict = *memo->h_note == key ? 1 : *memo->h_note == (key ^ 2ull) ? 2 : 0;
             }
             verdict = memo->verdict;
+        }
+        // the plan's pattern IS the residual's (verdict 1) and the plan keeps it by rows, sorted tile by tile (FD_PLAN_STORE_CSC_ROWS): the
+        // row-wise store every separable functor gets (fd_csc_store_rows, include/fdjac_device.h) on the plan's lists
+        if (verdict == 1 && st.row_ptr && st.row_pack && st.row_tile && st.col_begin == 0 && st.col_end == st.N && st.N >= 2 &&
+            fd_csc_rows_lds_bytes<real_t>(reach, lp->ncolors, cap_r) <= 64 * 1024) {
+            const unsigned gr = fd_xcd_grid((st.M + kBlock - 1) / kBlock);
+            const size_t lds_g = fd_csc_rows_lds_bytes<real_t>(reach, lp->ncolors, cap_r);
+            if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_rows<real_t, CT, 1, SparseF>), dim3(gr), dim3(kBlock), lds_g, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap_r);
+            else hipLaunchKernelGGL((fd_csc_store_rows<real_t, CT, 0, SparseF>), dim3(gr), dim3(kBlock), lds_g, s, f, x, eps, c_lo, c_hi, st, (int)reach, cap_r);
+            b->row_stores.fetch_add(1);
+            return hipGetLastError() == hipSuccess ? 0 : 4;
         }
         if (verdict != 1) {                    // a column kernel
             bool done = false;

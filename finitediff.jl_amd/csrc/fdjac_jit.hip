@@ -359,7 +359,7 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
     const int64_t reach = st.reach;
     // a separable functor on the plan its lists came from: the Jacobian row by row (fd_csc_store_rows) -- verified colouring, a locally
     // banded square pattern, every column local; anything else takes the column kernels below (same bits)
-    if (j->sep && st.row_ptr && st.plan_serial == j->plan_serial && st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N && st.N >= 2 &&
+    if (j->sep && st.row_ptr && st.row_pack && st.row_tile && st.plan_serial == j->plan_serial && st.valid_coloring && reach > 0 && reach <= 700 && st.M == st.N && st.N >= 2 &&
         st.col_begin == 0 && st.col_end == st.N && j->m->store_rows[cb][central]) {
         // (the tile's share of the lists kept in LDS: the mean row length x 1.25 + slack; longer tiles read the rest from memory)
         const double per_row = (double)j->entries / (double)st.M;

@@ -1,3 +1,4 @@
+#include <algorithm>
 #include <atomic>
 // The compact device copy of a plan's local CSC pattern (FD_PLAN_STORE_CSC; fd_csc_store in include/fdjac_device.h): int32 column
 // offsets relative to the local column range and int32 0-based rows, converted ON THE DEVICE from the caller's colptr / rowval (any
@@ -177,6 +178,29 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
                     rc[(size_t)at] = (int)j;
                     rs[(size_t)at] = q;
                 }
+            // ... and, tile of 256 rows by tile, the rows in order of DESCENDING length (stable): fd_csc_store_rows gives a wavefront 64
+            // rows of similar length -- a thread per row idles while the longest row of its wavefront is worked through
+            std::vector<int> ro((size_t)p->M);
+            for (int64_t t0 = 0; t0 < p->M; t0 += 256) {
+                const int64_t t1 = std::min<int64_t>(t0 + 256, p->M);
+                for (int64_t r = t0; r < t1; ++r) ro[(size_t)r] = (int)r;
+                std::stable_sort(ro.begin() + t0, ro.begin() + t1, [&](int a, int b) { return rp[(size_t)a + 1] - rp[(size_t)a] > rp[(size_t)b + 1] - rp[(size_t)b]; });
+            }
+            // what a thread of fd_csc_store_rows needs about its row in ONE load, and what a tile needs about its run of the lists in
+            // one load from a table small enough to stay in the L2 (both instead of chains through row_ptr: round trips of the prologue)
+            const int64_t ntile = (p->M + 255) / 256;
+            std::vector<int> pack(2 * (size_t)p->M), tptr((size_t)ntile + 1);
+            for (int64_t t = 0; t <= ntile; ++t) tptr[(size_t)t] = rp[(size_t)std::min<int64_t>(256 * t, p->M)];
+            for (int64_t q = 0; q < p->M; ++q) {
+                const int r = ro[(size_t)q];
+                const int64_t b0 = (int64_t)rp[(size_t)r] - tptr[(size_t)(q / 256)], len = (int64_t)rp[(size_t)r + 1] - rp[(size_t)r];
+                pack[2 * (size_t)q] = r;
+                pack[2 * (size_t)q + 1] = (int)(std::min<int64_t>(b0, 65535) | (std::min<int64_t>(len, 32767) << 16));
+            }
+            FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_order, sizeof(int) * pack.size()));
+            FD_HIP_CHECK(hipMemcpy(p->d_sr_order, pack.data(), sizeof(int) * pack.size(), hipMemcpyHostToDevice));
+            FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_tile, sizeof(int) * tptr.size()));
+            FD_HIP_CHECK(hipMemcpy(p->d_sr_tile, tptr.data(), sizeof(int) * tptr.size(), hipMemcpyHostToDevice));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_ptr, sizeof(int) * rp.size()));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_col, sizeof(int) * rc.size()));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_slot, sizeof(int) * rs.size()));

@@ -194,6 +194,10 @@ typedef struct fd_csc_store {
     const int *row_ptr;            /* device, M + 1 offsets: row r's stored entries are [row_ptr[r], row_ptr[r + 1]) of the two lists below   */
     const int *row_col;            /* device, per entry in row-major order: its 0-based column (ascending within a row)                       */
     const int *row_slot;           /* device, per entry in row-major order: its index in out / rowval (the entry's slot in J's CSC storage)   */
+    const int *row_pack;           /* device, 2 ints per row, tile of 256 rows by tile, the tile's rows by DESCENDING length (the order        */
+                                   /* fd_csc_store_rows hands them to its threads in: a wavefront then holds rows of similar length):          */
+                                   /* {row, (its first entry's place in the tile's run of the lists, <= 65535) | (its length, <= 32767) << 16} */
+    const int *row_tile;           /* device, ceil(M / 256) + 1 offsets: tile t's run of the lists is [row_tile[t], row_tile[t + 1])           */
 } fd_csc_store;
 
 /* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------
@@ -909,8 +913,46 @@ template <typename T> __host__ __device__ inline size_t fd_csc_rows_lds_bytes(lo
     const size_t xlen = (size_t)(256 + 2 * reach + 2);
     return sizeof(T) * (xlen + 2 * (size_t)ncolors) + 4 * (2 * (size_t)cap + xlen) + 64;
 }
+/* one row of 1 .. RL entries in REGISTERS, every loop unrolled and predicated */
+template <typename T, int MODE, int RL, class F>
+__device__ __attribute__((always_inline)) inline void fd_csc_rows_regs(const F &f, long long r, int b0, int L, const FD_LDS_PTR(int) s_j, const FD_LDS_PTR(int) s_q, const FD_LDS_PTR(T) s_x,
+                                        const FD_LDS_PTR(int) s_c, const FD_LDS_PTR(T) s_h, const FD_LDS_PTR(T) s_y, int w0, int c_lo, int c_hi, T *out,
+                                        bool given, T fx_given)
+{
+    int jj[RL], qq[RL];
+    T tt[RL];
+#pragma unroll
+    for (int u = 0; u < RL; ++u) { const int i = b0 + (u < L ? u : L - 1); jj[u] = s_j[i]; qq[u] = s_q[i]; }
+    T fx = 0;
+#pragma unroll
+    for (int u = 0; u < RL; ++u) {
+        tt[u] = f.term(r, (long long)jj[u], (T)s_x[(unsigned)(jj[u] - w0)]);
+        fx = u == 0 ? tt[0] : (u < L ? fx + tt[u] : fx);
+    }
+    T pre = 0;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+        if (k < L) {
+            const unsigned off = (unsigned)(jj[k] - w0);
+            const int c = s_c[off];
+            const T v = s_x[off];
+            if (c < 0) {
+                if (c_lo == 0) out[qq[k]] = (T)0;
+            } else if (c >= c_lo && c < c_hi) {
+                const T h = s_h[c - c_lo], y = s_y[c - c_lo];
+                T sp = f.term(r, (long long)jj[k], v + h), sm = MODE == 1 ? f.term(r, (long long)jj[k], v - h) : (T)0;
+                if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
+#pragma unroll
+                for (int u = k + 1; u < RL; ++u)
+                    if (u < L) { sp = sp + tt[u]; if (MODE == 1) sm = sm + tt[u]; }
+                out[qq[k]] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
+            }
+            pre = k == 0 ? tt[0] : pre + tt[k];
+        }
+    }
+}
 template <typename T, typename CT, int MODE, class F>
-__global__ void __launch_bounds__(256) fd_csc_store_rows(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach,
+__global__ void __launch_bounds__(256, 4) fd_csc_store_rows(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach,
                                                          int cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fd_rows_lds[];
@@ -918,10 +960,15 @@ __global__ void __launch_bounds__(256) fd_csc_store_rows(F f, const T *__restric
     const long long ntile = (st.M + 255) / 256, tile = fd_xcd_block(blockIdx.x, ntile);
     if (tile >= ntile) return;
     const long long R0 = tile * 256, R1 = R0 + 256 < st.M ? R0 + 256 : st.M;
-    const long long r = R0 + threadIdx.x;
-    const bool in = r < R1;
-    const int a0 = st.row_ptr[in ? r : R1], a1 = st.row_ptr[in ? r + 1 : R1], L = a1 - a0;
-    const int A0 = st.row_ptr[R0], A1 = st.row_ptr[R1];
+    /* thread -> row through the plan's order (the tile's rows by descending length: the 64 rows of a wavefront are alike, and the
+       unrolled row code below is taken in the size the wavefront's longest row needs); which quarter of the order a wavefront takes
+       rotates with the tile, so that the long rows do not always land on the same SIMD */
+    const long long pos = R0 + (((int)threadIdx.x + 64 * (int)(tile & 3)) & 255);
+    const bool in = pos < R1;
+    typedef int fd_int2_t __attribute__((ext_vector_type(2)));
+    const fd_int2_t pk = *reinterpret_cast<const fd_int2_t *>(st.row_pack + 2 * (in ? pos : R0));      /* (one load, no chain through row_ptr) */
+    const long long r = pk.x;
+    const int A0 = st.row_tile[tile], A1 = st.row_tile[tile + 1];
     long long w0 = R0 - reach > 0 ? R0 - reach : 0;
     const long long w1 = R1 + reach < st.N ? R1 + reach : st.N;
     w0 &= ~1ll;
@@ -967,53 +1014,31 @@ __global__ void __launch_bounds__(256) fd_csc_store_rows(F f, const T *__restric
         }
     }
     __syncthreads();
-    if (!in || L == 0) return;
-    const int b0 = a0 - A0;                                            /* the row's entries are the tile's [b0, b0 + L) */
+    int b0 = pk.y & 0xFFFF, L = in ? (int)((unsigned)pk.y >> 16) : 0;   /* the row's entries are the tile's [b0, b0 + L) */
     T *out = (T *)st.out;
     /* forward differences: the subtrahend is what the plan hands over (the caller's f_in, or f(x) from a plain evaluation) -- or,
        without one (FD_LAZY_CAP_STORE_CSC_BASE), the row's own plain sum */
     const bool given = MODE == 0 && st.fx_base != nullptr;
-    const T fx_given = given ? ((const T *)st.fx_base)[r] : (T)0;
+    const T fx_given = (given && in) ? ((const T *)st.fx_base)[r] : (T)0;
     if (A1 - A0 <= cap) {
         /* the whole tile is staged, and every column of a row lies in the window (|r - j| <= reach): no load from memory below.  That
            matters more than it looks: this target counts loads and stores in ONE counter, and a loop body that MAY load makes the
            compiler wait for everything outstanding -- the store of the iteration before -- on every trip */
-        constexpr int RL = FD_CSC_ROWS_REGS;
-        if (L <= RL) {
-            /* the row in REGISTERS, every loop unrolled and predicated */
-            int jj[RL], qq[RL];
-            T tt[RL];
+        int Lmax = L;                                                  /* the wavefront's longest row (wave-uniform) */
 #pragma unroll
-            for (int u = 0; u < RL; ++u) { const int i = b0 + (u < L ? u : L - 1); jj[u] = s_j[i]; qq[u] = s_q[i]; }
-            T fx = 0;
-#pragma unroll
-            for (int u = 0; u < RL; ++u) {
-                tt[u] = f.term(r, (long long)jj[u], (T)s_x[(unsigned)(jj[u] - (int)w0)]);
-                fx = u == 0 ? tt[0] : (u < L ? fx + tt[u] : fx);
-            }
-            T pre = 0;
-#pragma unroll
-            for (int k = 0; k < RL; ++k) {
-                if (k < L) {
-                    const unsigned off = (unsigned)(jj[k] - (int)w0);
-                    const int c = s_c[off];
-                    const T v = s_x[off];
-                    if (c < 0) {
-                        if (c_lo == 0) out[qq[k]] = (T)0;
-                    } else if (c >= c_lo && c < c_hi) {
-                        const T h = s_h[c - c_lo], y = s_y[c - c_lo];
-                        T sp = f.term(r, (long long)jj[k], v + h), sm = MODE == 1 ? f.term(r, (long long)jj[k], v - h) : (T)0;
-                        if (k > 0) { sp = pre + sp; if (MODE == 1) sm = pre + sm; }
-#pragma unroll
-                        for (int u = k + 1; u < RL; ++u)
-                            if (u < L) { sp = sp + tt[u]; if (MODE == 1) sm = sm + tt[u]; }
-                        out[qq[k]] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
-                    }
-                    pre = k == 0 ? tt[0] : pre + tt[k];
-                }
-            }
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(Lmax, o, 64); Lmax = t > Lmax ? t : Lmax; }
+        Lmax = __builtin_amdgcn_readfirstlane(Lmax);
+        if (Lmax <= FD_CSC_ROWS_REGS) {
+#define FD_ROWS_REGS(RL) do { if (L > 0) fd_csc_rows_regs<T, MODE, RL>(f, r, b0, L, s_j, s_q, s_x, s_c, s_h, s_y, (int)w0, c_lo, c_hi, out, given, fx_given); } while (0)
+            if (Lmax <= 4) FD_ROWS_REGS(4);
+            else if (Lmax <= 6) FD_ROWS_REGS(6);
+            else if (Lmax <= 8) FD_ROWS_REGS(8);
+            else if (Lmax <= 10) FD_ROWS_REGS(10);
+            else FD_ROWS_REGS(FD_CSC_ROWS_REGS);
+#undef FD_ROWS_REGS
             return;
         }
+        if (L == 0) return;
         T fx = 0;
         for (int u = 0; u < L; ++u) {
             const int j = s_j[b0 + u];
@@ -1045,7 +1070,12 @@ __global__ void __launch_bounds__(256) fd_csc_store_rows(F f, const T *__restric
         }
         return;
     }
-    /* a tile with more entries than fit: the lists beyond the staged part are read from memory (same indices, same order, same bits) */
+    /* a tile with more entries than fit: the lists beyond the staged part are read from memory (same indices, same order, same bits);
+       the packed place / length may be clamped here: the row's own offsets say */
+    if (!in) return;
+    b0 = st.row_ptr[r] - A0;
+    L = st.row_ptr[r + 1] - st.row_ptr[r];
+    if (L == 0) return;
     auto col_of = [&](int i) -> int { return i < nst ? (int)s_j[i] : st.row_col[A0 + i]; };
     auto slot_of = [&](int i) -> int { return i < nst ? (int)s_q[i] : st.row_slot[A0 + i]; };
     T fx = 0;

@@ -50,11 +50,11 @@ def main():
     outs = {}
     print("| route | N | nnz | colours | whole call us (median) | storing launch us | eps us | row-wise launches |")
     print("|---|---|---|---|---|---|---|---|")
-    for route in ("builtin", "terms", "cols"):
+    for route in ("builtin", "builtin_own", "terms", "cols"):
         if a.only and a.only != route:
             continue
-        plan = fd.make_plan(J, J, colors, a.fdtype, store_csc=True, store_rows=(route == "terms"))
-        if route == "builtin":
+        plan = fd.make_plan(J, J, colors, a.fdtype, store_csc=True, store_rows=(route in ("terms", "builtin")))
+        if route in ("builtin", "builtin_own"):      # (builtin_own: a plan without row lists -- the family's own kernel, k_f_sparse_store_rows)
             f = fd.BuiltinF.sparse(N, N, colptr, rowval)
         else:
             src = fd.make_plan(J, J, colors, a.fdtype, store_rows=True) if route == "cols" else plan      # (cols: lists of ANOTHER plan -> column store)
@@ -76,7 +76,7 @@ def main():
         torch.cuda.synchronize()
         tot = plan.timing_samples("total")
         plan.enable_timing(0)
-        nrow = f.row_stores() if route == "builtin" else f.row_stores
+        nrow = f.row_stores() if route.startswith("builtin") else f.row_stores
         outs[route] = out
         print("| %s | %d | %d | %d | %.1f | %.1f | %.1f | %d |" % (route, N, rowval.size, int(colors.max()), float(np.median(tot)) * 1e3, st["decompress"], st["eps"], nrow))
     ks = list(outs)

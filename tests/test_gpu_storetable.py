@@ -175,7 +175,8 @@ def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, cas
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 # (3000, 12, 40): ~12 entries per row -- more than a tile's staged run holds: the overflow rows read their lists from memory
 @pytest.mark.parametrize("case", [(300, 4, 9, 1), (5000, 6, 300, 4), (70001, 6, 300, 7), (3000, 12, 40, 8), (2000, 3, 700, 9)])
-def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case):
+@pytest.mark.parametrize("lists", [False, True])      # True: the plan keeps its pattern by rows (store_rows) -- then the verified launches are fd_csc_store_rows on the plan's lists
+def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case, lists):
     # k_f_sparse_store_rows: the first launch on a plan only CHECKS that the plan's pattern is the one the residual was created from (the
     # column kernel stores); once the verdict has reached the host (read back asynchronously) the launches go row by row -- every row's
     # plain terms once, prefix carried, suffix added: the additions of the full evaluation in the same order => the hand-over path's bits.
@@ -184,7 +185,7 @@ def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case):
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     colors = fd.matrix_colors(J)
     f = fd.BuiltinF.sparse(N, N, colptr, rowval)
-    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, store_rows=lists)
     ps.set_lazy(f)
     ph = fd.make_plan(J, J, colors, fdtype)
     rng = np.random.default_rng(seed)
@@ -207,7 +208,7 @@ def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case):
     cp2[1:] += 1
     J2 = fd.SparseMatrixCSC(N, N, cp2, rv2, None)
     colors2 = fd.matrix_colors(J2)
-    ps2 = fd.make_plan(J2, J2, colors2, fdtype, store_csc=True)
+    ps2 = fd.make_plan(J2, J2, colors2, fdtype, store_csc=True, store_rows=lists)
     ps2.set_lazy(f)
     ph2 = fd.make_plan(J2, J2, colors2, fdtype)
     before = f.row_stores()
@@ -524,7 +525,9 @@ def test_sparse_family_row_wise_store_randomised(seed):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=tdt, device="cuda")
 
     f = fd.BuiltinF.sparse(N, N, colptr, rowval, dtype=dtype)
-    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, dtype=dtype, **kw)
+    # (odd seeds: the plan keeps its pattern by rows -- without a column window the verified launches are then fd_csc_store_rows,
+    #  the kernel every separable user functor gets, on the plan's lists)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, store_rows=(seed % 2 == 1), dtype=dtype, **kw)
     ps.set_lazy(f)
     ph = fd.make_plan(J, J, colors, fdtype, dtype=dtype, **kw)
     n = ps.out_len(0)
