@@ -281,6 +281,73 @@ static int client_jit(int64_t N, int reps)
     return report("jit", worst, 2e-6, fc, 4);
 }
 
+/* shim: DeviceF{T}(src, terms, plan, M, N) on a plan made with PlanOpts(fd; store_rows = true) -> fd_plan_row_lists + fd_f_compile_terms:
+   a residual that is SEPARABLE on the Jacobian's pattern, given by its term alone; the Jacobian is the step-size launch + ONE
+   row-wise launch (fd_csc_store_rows).  Pattern: column j holds the rows j - 3, j, j + 2 that exist (not an exact band: a general
+   CSC plan), colours mod1(j, 6) (columns sharing a row differ by 2, 3 or 5).  f_r = sum over the entries (r, j), ascending j, of
+   w(r, j) (x_j + x_j^2 / 4), w = 1 + ((r + 3 j) mod 8) / 8 -- the built-in sparse family's residual, so the hand-over path of that
+   family is the bit reference; analytic: J[r, j] = w(r, j) (1 + x_j / 2). */
+static const char kTermsSource[] =
+    "struct SparseTerms {\n"
+    "    template <class T> __device__ T term(long long r, long long j, T v) const\n"
+    "    { return ((real_t)1 + (real_t)0.125 * (real_t)(int)((r + 3 * j) & 7)) * (v + ((real_t)0.25 * v) * v); }\n"
+    "};\n";
+static int client_terms(int64_t N, int fdtype)
+{
+    int64_t *colptr = malloc(sizeof(int64_t) * (size_t)(N + 1)), *rowval = malloc(sizeof(int64_t) * (size_t)(3 * N)), *colors = cyclic_colors(N, 6);
+    int64_t nnz = 0;
+    const int64_t offs[3] = {-3, 0, 2};
+    for (int64_t j = 0; j < N; ++j) {
+        colptr[j] = nnz + 1;
+        for (int t = 0; t < 3; ++t)
+            if (j + offs[t] >= 0 && j + offs[t] < N) rowval[nnz++] = j + offs[t] + 1;
+    }
+    colptr[N] = nnz + 1;
+    double *x = make_x(N), *xd = to_dev(x, sizeof(double) * (size_t)N), *nzd = dev_nan((size_t)nnz), *refd = dev_nan((size_t)nnz);
+    fd_f_launch fb, ft; void *fbctx, *ftctx; fd_f_launch_lazy lz = NULL; int caps = 0;
+    fd_plan *pr, *ph;
+    fd_plan_opts o; memset(&o, 0, sizeof o); o.fdtype = fdtype;
+    CHECK(fd_builtin_f_create_sparse(g_ctx, N, N, colptr, rowval, 8, 1, &fb, &fbctx));
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &ph));           /* the reference bits: hand-over path */
+    o.flags = FD_PLAN_STORE_CSC | FD_PLAN_STORE_CSC_ROWS;
+    CHECK(fd_plan_create_csc(g_ctx, N, N, colptr, rowval, 8, 1, colors, 8, &o, &pr));
+    const void *row_ptr = NULL, *row_col = NULL, *row_slot = NULL; int64_t entries = 0; uint64_t serial = 0;
+    CHECK(fd_plan_row_lists(pr, &row_ptr, &row_col, &row_slot, &entries, &serial));
+    int rc = fd_f_compile_terms(g_ctx, kTermsSource, "SparseTerms", NULL, 0, N, N, 8, row_ptr, row_col, serial, &ft, &lz, &caps, &ftctx);
+    if (rc != FD_OK) { fprintf(stderr, "fd_f_compile_terms -> %d: %s\n%s\n", rc, fd_last_error(), fd_f_compile_log()); return 3; }
+    CHECK(fd_plan_set_lazy_f(pr, lz));
+    CHECK(fd_plan_set_lazy_caps(pr, caps));
+    void *outs[3] = {nzd, NULL, NULL}, *outr[3] = {refd, NULL, NULL};
+    CHECK(fd_jacobian_async(ph, fb, fbctx, xd, NULL, -1.0, -1.0, 1.0, outr));
+    CHECK(fd_jacobian_async(pr, ft, ftctx, xd, NULL, -1.0, -1.0, 1.0, outs));
+    CHECK(fd_ctx_synchronize(g_ctx));
+    double *nz = malloc(sizeof(double) * (size_t)nnz), *ref = malloc(sizeof(double) * (size_t)nnz);
+    from_dev(nz, nzd, sizeof(double) * (size_t)nnz);
+    from_dev(ref, refd, sizeof(double) * (size_t)nnz);
+    double worst = 0;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p) {
+            const int64_t r = rowval[p] - 1;
+            const double want = (1.0 + 0.125 * (double)((r + 3 * j) & 7)) * (1.0 + 0.5 * x[j]);
+            const double d = fabs(nz[p] - want);
+            if (!(d <= worst)) worst = d;
+        }
+    const int same = memcmp(nz, ref, sizeof(double) * (size_t)nnz) == 0;
+    int64_t info_store = 0, fc = 0, rows = 0;
+    fd_plan_info(pr, FD_INFO_LAZY_STORE, &info_store);
+    fd_plan_info(pr, FD_INFO_FCALLS_LAST, &fc);
+    CHECK(fd_f_compiled_row_stores(ftctx, &rows));
+    CHECK(fd_plan_destroy(pr)); CHECK(fd_plan_destroy(ph));
+    CHECK(fd_builtin_f_destroy(fbctx)); CHECK(fd_f_compiled_destroy(ftctx));
+    hipFree(xd); hipFree(nzd); hipFree(refd); free(nz); free(ref); free(x); free(colptr); free(rowval); free(colors);
+    if (!same || !info_store || rows != 1 || entries != nnz) {
+        printf("terms        bits differ from the hand-over path / row-wise store not taken (same %d, store %lld, row-wise launches %lld, entries %lld)  FAILED\n",
+               same, (long long)info_store, (long long)rows, (long long)entries);
+        return 3;
+    }
+    return report("terms", worst, fdtype == FD_CENTRAL ? 1e-8 : 2e-6, fc, fdtype == FD_CENTRAL ? 12 : 7);
+}
+
 /* shim (AMDGPU extension): make_plan(::ROCSparseMatrixCSC J, sparsity === J, colorvec::ROCVector) -> fd_plan_create_csc_device:
    colPtr / rowVal / colorvec already live on the device (rocSPARSE CSC: Int32, 1-based); nothing crosses PCIe, the plan is
    compiled by kernels.  Checked against the host-pattern plan through fd_plan_checksum and against the analytic Jacobian. */
@@ -1232,6 +1299,7 @@ int main(int argc, char **argv)
     RUN("out_of_place", client_out_of_place())
     RUN("resize", client_resize())
     RUN("bitcode", argc > 2 ? client_bitcode(argv[2], argc > 3 ? atoll(argv[3]) : 300007, argc > 4 ? atoi(argv[4]) : 20) : 0)
+    RUN("terms", client_terms(argc > 2 ? atoll(argv[2]) : 100003, FD_FORWARD) | client_terms(argc > 2 ? atoll(argv[2]) : 100003, FD_CENTRAL))
     RUN("jit", client_jit(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     RUN("dropin", client_dropin(argc > 2 ? atoll(argv[2]) : 300007, argc > 3 ? atoi(argv[3]) : 20))
     CHECK(fd_ctx_destroy(g_ctx));

@@ -224,7 +224,7 @@ def _build_c_clients(root, tmp_path):
 
 
 @pytest.mark.parametrize("client", ["csc", "csc_store_cols", "csc_device", "csc_dense", "coo_dense", "entries", "dense", "tridiagonal", "banded", "blockbanded", "bandedblockbanded",
-                                    "csc_f32", "jvp", "solve", "bandsolve", "host", "complex_x", "complex_structured", "out_of_place", "resize", "dropin", "jit"])
+                                    "csc_f32", "jvp", "solve", "bandsolve", "host", "complex_x", "complex_structured", "out_of_place", "resize", "dropin", "jit", "terms"])
 def test_c_clients_every_plan_kind(tmp_path, client):
     # examples/c_abi_clients.c: one plain-C client per method of the Julia shim (finitediff.jl_amd/julia/FiniteDiffMI355X.jl)
     # -- Julia-layout arrays, DEVICE pointers for x / J's storage, the caller's own stream, fd_jacobian_async -- each
