@@ -1069,7 +1069,7 @@ class Plan:
         if not diff:
             caps &= ~4
         if not (diff if store is None else store):
-            caps &= ~(8 | 16 | 32 | 64)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC, _BASE and _COMPLEX
+            caps &= ~(8 | 16 | 32 | 64 | 256)      # FD_LAZY_CAP_STORE, FD_LAZY_CAP_STORE_CSC, _BASE, _COMPLEX and FD_LAZY_CAP_STORE_COLRANGE
         if not csc_base:
             caps &= ~32                 # (the column store takes f(x) from ONE plain evaluation instead of forming it itself)
         if not fused:

@@ -468,7 +468,8 @@ static inline bool store_csc_active(const fd_plan *p)
 static inline bool store_active(const fd_plan *p)
 {
     if (!(p->lazy_fn && (p->lazy_caps & FD_LAZY_CAP_STORE)) || p->has_none) return false;
-    if (p->kind == fdjac::K_COLRANGE) return p->store_cr_ok && p->fdtype == FD_COMPLEX;   // (the block-coupled launcher's storing kernel is the complex step's)
+    // (the block-coupled launcher's storing kernel is the complex step's; a launcher with FD_LAZY_CAP_STORE_COLRANGE -- a compiled functor -- serves all three)
+    if (p->kind == fdjac::K_COLRANGE) return p->store_cr_ok && (p->fdtype == FD_COMPLEX || (p->lazy_caps & FD_LAZY_CAP_STORE_COLRANGE) != 0);
     if (p->kind == fdjac::K_BBB) return p->store_bbb_ok && p->fdtype != FD_COMPLEX && p->store_allowed && p->nchunks == 1 && p->own_c0 == 0 &&
                                         (p->own_c1 < 0 || p->own_c1 >= p->C);
     return (p->store_ok || (p->store5_ok && p->kind == fdjac::K_CSC)) && p->fdtype != FD_COMPLEX &&

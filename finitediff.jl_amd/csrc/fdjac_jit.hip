@@ -116,9 +116,16 @@ struct JitModule {
         hipModule_t mod = nullptr;
         hipFunction_t rows = nullptr;                  // fdjit_rows_cplx: the plain launcher on materialised complex points
         hipFunction_t store[2] = {nullptr, nullptr};   // fd_csc_store_cols_cplx: [colour bytes == 4]
+        hipFunction_t colrange[2] = {nullptr, nullptr};   // fd_colrange_store_cols<.., 2, ..>: [colour bytes == 4] (BlockBandedMatrix data)
         bool tried = false, ok = false;
         std::string log;
     } cplx;
+    // column-range storage (BlockBandedMatrix data) for forward / central differences: fd_colrange_store_cols, compiled on first use
+    struct ColRange {
+        hipModule_t mod = nullptr;
+        hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [colour bytes == 4][central]
+        bool tried = false, ok = false;
+    } cr;
     std::vector<char> bitcode;                         // fd_f_link_rows_bitcode: the caller's LLVM bitcode, linked into every program of this functor
     std::string real;                                  // "double" / "float"
     unsigned sizeof_f = 0;
@@ -226,18 +233,21 @@ static bool cplx_functions(JitModule *m)
     hiprtcProgram prog = nullptr;
     if (R->CreateProgram(&prog, src.c_str(), "fdjac_jit_cplx.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
     const char *ct[2] = {"unsigned char", "int"};
-    std::string names[2];
+    std::string names[2], cnames[2];
     for (int cb = 0; cb < 2; ++cb) {
         names[cb] = "fd_csc_store_cols_cplx<" + m->real + ", " + ct[cb] + ", fdjit_F>";
         (void)R->AddNameExpression(prog, names[cb].c_str());
+        cnames[cb] = "fd_colrange_store_cols<" + m->real + ", " + ct[cb] + ", 2, fdjit_F>";
+        (void)R->AddNameExpression(prog, cnames[cb].c_str());
     }
     bool ok = R->CompileProgram(prog, m->bitcode.empty() ? 5 : 6, kJitOpts) == HIPRTC_SUCCESS;
     size_t ls = 0;
     if (R->GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { x.log.resize(ls); (void)R->GetProgramLog(prog, &x.log[0]); }
-    std::string low[2];
+    std::string low[2], clow[2];
     for (int cb = 0; cb < 2 && ok; ++cb) {
         const char *ln = nullptr;
         if (R->GetLoweredName(prog, names[cb].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[cb] = ln; else ok = false;
+        if (ok && R->GetLoweredName(prog, cnames[cb].c_str(), &ln) == HIPRTC_SUCCESS && ln) clow[cb] = ln;
     }
     if (ok) {
         std::string why;
@@ -248,6 +258,43 @@ static bool cplx_functions(JitModule *m)
     if (!ok) { (void)hipGetLastError(); return false; }
     ok = hipModuleGetFunction(&x.rows, x.mod, "fdjit_rows_cplx") == hipSuccess;
     for (int cb = 0; cb < 2 && ok; ++cb) ok = hipModuleGetFunction(&x.store[cb], x.mod, low[cb].c_str()) == hipSuccess;
+    for (int cb = 0; cb < 2 && ok; ++cb)
+        if (clow[cb].empty() || hipModuleGetFunction(&x.colrange[cb], x.mod, clow[cb].c_str()) != hipSuccess) x.colrange[cb] = nullptr;      // (an optimisation)
+    if (!ok) (void)hipGetLastError();
+    x.ok = ok;
+    return ok;
+}
+
+// fd_colrange_store_cols for forward / central differences (one more small compilation, kept with the module)
+static bool colrange_functions(JitModule *m)
+{
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    JitModule::ColRange &x = m->cr;
+    if (x.tried) return x.ok;
+    x.tried = true;
+    const Hiprtc *R = hiprtc();
+    if (!R || hipSetDevice(m->device) != hipSuccess) return false;
+    hiprtcProgram prog = nullptr;
+    if (R->CreateProgram(&prog, m->text.c_str(), "fdjac_jit_colrange.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
+    const char *ct[2] = {"unsigned char", "int"};
+    std::string names[2][2];
+    for (int cb = 0; cb < 2; ++cb)
+        for (int md = 0; md < 2; ++md) {
+            names[cb][md] = "fd_colrange_store_cols<" + m->real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
+            (void)R->AddNameExpression(prog, names[cb][md].c_str());
+        }
+    bool ok = R->CompileProgram(prog, m->bitcode.empty() ? 5 : 6, kJitOpts) == HIPRTC_SUCCESS;
+    std::string low[2][2];
+    for (int cb = 0; cb < 2 && ok; ++cb)
+        for (int md = 0; md < 2 && ok; ++md) {
+            const char *ln = nullptr;
+            if (R->GetLoweredName(prog, names[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[cb][md] = ln; else ok = false;
+        }
+    std::string why;
+    if (ok) ok = load_program(R, prog, m->bitcode, &x.mod, &why) == hipSuccess;
+    (void)R->DestroyProgram(&prog);
+    for (int cb = 0; cb < 2 && ok; ++cb)
+        for (int md = 0; md < 2 && ok; ++md) ok = hipModuleGetFunction(&x.fn[cb][md], x.mod, low[cb][md].c_str()) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     x.ok = ok;
     return ok;
@@ -264,6 +311,7 @@ struct fd_jit_f {
     int64_t launches = 0;
     bool sep = false;                       // fd_f_compile_terms: a separable functor bound to the row lists of one plan
     unsigned long long plan_serial = 0;     //   that plan's serial (fd_csc_store.plan_serial): only there the row-wise store is taken
+    void *d_base = nullptr;                 // f(x) of all rows for the column-range store's forward differences (allocated on first use)
     int64_t row_stores = 0, entries = 0;    // launches of the row-wise store; stored entries of that plan's pattern
 };
 
@@ -329,6 +377,40 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
         void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &bs, &jstart};
         const unsigned g = (unsigned)((bs.col_end - jstart + 511) / 512);
         if (hipModuleLaunchKernel(bf, g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+        j->launches += 1;
+        return 0;
+    }
+    if (lp->store && lp->store_kind == FD_STORE_COLRANGE) {
+        // column-range storage (BlockBandedMatrix data): eight columns per workgroup, their rows dealt out flat (fd_colrange_store_cols);
+        // forward / central differences (FD_LAZY_CAP_STORE_COLRANGE: the launch forms f(x) of its rows itself) and the complex step
+        fd_colrange_store cr = *(const fd_colrange_store *)lp->store;
+        const int central = lp->pts == 2 ? 1 : 0, cbi = cr.color_bytes == 4 ? 1 : 0;
+        if (cr.elem_bytes != j->elem_bytes || (cr.color_bytes != 1 && cr.color_bytes != 4) || cr.M != j->M || cr.N != j->N || cr.col_end <= cr.col_begin ||
+            !(lp->is_complex || central || (lp->pts == 1 && lp->diff == 2)))
+            return FD_LAZY_DECLINED;
+        hipFunction_t fn = nullptr;
+        if (lp->is_complex) { if (cplx_functions(j->m)) fn = j->m->cplx.colrange[cbi]; }
+        else if (colrange_functions(j->m)) fn = j->m->cr.fn[cbi][central];
+        if (!fn) return FD_LAZY_DECLINED;
+        int c_lo = lp->c_lo, c_hi = lp->c_lo + lp->ncolors;
+        const void *xq = lp->x, *eq = lp->eps;
+        const void *base = nullptr;
+        if (!lp->is_complex && !central) {
+            // forward differences: f(x) of all rows ONCE (the plain launcher's kernel into the functor's own buffer) -- the columns of
+            // a dense block share their rows, forming f(x) inside the storing launch would double the row evaluations
+            if (!j->d_base && hipMalloc(&j->d_base, (size_t)j->M * (size_t)j->elem_bytes) != hipSuccess) { (void)hipGetLastError(); j->d_base = nullptr; }
+            if (j->d_base) {
+                void *fxp = j->d_base;
+                long long xs = 0, fs = 0, r0 = 0, r1 = j->M;
+                void *ra[] = {&fxp, (void *)&xq, (void *)j->params.data(), &xs, &fs, &r0, &r1};
+                if (hipModuleLaunchKernel(j->m->rows, (unsigned)((j->M + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, ra, nullptr) != hipSuccess) return 4;
+                j->launches += 1;
+                base = j->d_base;
+            }
+        }
+        void *args[] = {(void *)j->params.data(), (void *)&xq, (void *)&eq, &c_lo, &c_hi, &cr, (void *)&base};
+        const long long nw = (cr.col_end - cr.col_begin + 7) / 8;
+        if (hipModuleLaunchKernel(fn, (unsigned)(8 * ((nw + 7) / 8)), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
         j->launches += 1;
         return 0;
     }
@@ -399,6 +481,7 @@ static void release_module(JitModule *m)
     for (auto &kv : m->extra)
         if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
     if (m->cplx.mod) (void)hipModuleUnload(m->cplx.mod);
+    if (m->cr.mod) (void)hipModuleUnload(m->cr.mod);
     if (m->mod) (void)hipModuleUnload(m->mod);
     delete m;
 }
@@ -577,7 +660,8 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
     *fn_out = jit_launch;
     if (lazy_out) *lazy_out = jit_launch_lazy;
     // (FD_LAZY_CAP_STORE: exact bands of width (1, 1) / (2, 2) through fd_band_store_cols; every other storing request is declined)
-    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | FD_LAZY_CAP_STORE_CSC_COMPLEX | ((m->band[0][0] || m->band[1][0]) ? FD_LAZY_CAP_STORE : 0);
+    //  ... and column-range storage through fd_colrange_store_cols, compiled on first use)
+    if (lazy_caps_out) *lazy_caps_out = FD_LAZY_CAP_STORE_CSC | FD_LAZY_CAP_STORE_CSC_BASE | FD_LAZY_CAP_STORE_CSC_COMPLEX | FD_LAZY_CAP_STORE | FD_LAZY_CAP_STORE_COLRANGE;
     *fctx_out = j;
     return FD_OK;
 }
@@ -743,6 +827,7 @@ int fd_f_compiled_destroy(void *fctx)
     (void)hipSetDevice(j->ctx->device);
     (void)hipStreamSynchronize(j->ctx->stream);
     release_module(j->m);
+    if (j->d_base) (void)hipFree(j->d_base);
     delete j;
     return FD_OK;
 }

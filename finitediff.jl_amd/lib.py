@@ -27,7 +27,7 @@ STAGES = ("eps", "perturb", "f", "decompress", "total", "exchange")
  INFO_SORTED_GATHER, INFO_LINES_DIRECT_X100, INFO_LINES_SORTED_X100, INFO_WINDOW,
  INFO_WIN_OVERREAD_X100, INFO_WINDOW2D, INFO_WIN_PERIOD, INFO_COLRANGE_WG, INFO_SMALL_FUSED, _INFO_23,
  INFO_EPS_CYCLIC, INFO_EPS_NT, _INFO_26, INFO_BUILT_ON_DEVICE, _INFO_28, INFO_LAZY_DIFF, _INFO_30, INFO_BAND_DESC, INFO_LAZY_STORE, INFO_STORE_CSC) = range(34)
-LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE, LAZY_CAP_STORE_CSC_COMPLEX, LAZY_CAP_FUSED_EPS = 1, 2, 4, 8, 16, 32, 64, 128
+LAZY_CAP_IMAG_ONLY, LAZY_CAP_ROW_WINDOW, LAZY_CAP_DIFF, LAZY_CAP_STORE, LAZY_CAP_STORE_CSC, LAZY_CAP_STORE_CSC_BASE, LAZY_CAP_STORE_CSC_COMPLEX, LAZY_CAP_FUSED_EPS, LAZY_CAP_STORE_COLRANGE = 1, 2, 4, 8, 16, 32, 64, 128, 256
 PLAN_EPS_CONTIGUOUS, PLAN_COMPLEX_X, PLAN_FINGERPRINT, PLAN_STORE_CSC, PLAN_STORE_CSC_ALWAYS, PLAN_STORE_CSC_ROWS = 1, 2, 4, 8, 16, 32
 LAZY_JVP_CAP_QUOTIENT = 1
 (F_TRIDIAG, F_TRIDIAG_NL, F_LAP5, F_CLAMP5, F_BLOCKCOUPLED, F_NONSQUARE, F_LAP5_NL, F_LAP7, F_SPARSE) = range(9)

@@ -362,6 +362,9 @@ int fd_plan_set_lazy_f(fd_plan *plan, fd_f_launch_lazy lazy);
                                   /* store_kind = FD_STORE_CSC): every stored entry's row at x + i eps e_j, imag / eps stored                   */
                                   /* (src/jacobians.jl:623-648 + ext/FiniteDiffSparseArraysExt.jl:38-47 in one launch); without the bit a       */
                                   /* complex-step plan hands the values over as before                                                          */
+#define FD_LAZY_CAP_STORE_COLRANGE 256  /* (with FD_LAZY_CAP_STORE) serves store_kind = FD_STORE_COLRANGE (BlockBandedMatrix data) for FORWARD and  */
+                                       /* CENTRAL differences too, forming f(x) of its rows itself -- runtime-compiled functors                  */
+                                       /* (fd_colrange_store_cols); without it a column-range plan offers the store to the complex step only     */
 #define FD_LAZY_CAP_FUSED_EPS 128 /* honours fd_lazy_points.eps_job (library-internal protocol of the built-in storing launchers)               */
 int fd_plan_set_lazy_caps(fd_plan *plan, int caps);
 

@@ -1272,6 +1272,68 @@ __global__ void __launch_bounds__(256) fd_csc_store_cols_cplx(F f, const T *__re
     }
     run.template flush<true>();
 }
+/* ---- a ROW FUNCTOR storing COLUMN-RANGE storage itself (BlockBandedMatrix data; round 6) ------------------------------------------------
+ * fd_colrange_store: column j holds the contiguous rows [row_first, row_first + row_count) at out + dest (ext/FiniteDiffBlockBandedMatricesExt.jl:
+ * 44-68 assigns exactly those).  A workgroup takes EIGHT columns and deals their rows out to its 256 threads as one flat list (a column of
+ * 96 rows alone would leave a quarter of the lanes idle): consecutive threads take consecutive rows of a column -- the values leave as
+ * dense runs, and rows of a block read mostly the same coordinates (broadcast loads).  F as for fd_csc_store_cols; the plan offers this
+ * descriptor only with a colouring it has verified, so the point is x +- eps e_j (MODE 0 forward: the row at x is evaluated beside it;
+ * 1 central; 2 the complex step: imag(f(x + i eps e_j)) / eps, src/jacobians.jl:633-635).  Same points, same operations as the
+ * hand-over path: same bits.  `base`: f(x) of all M rows for MODE 0 (a dense block column shares its rows with bs - 1 others: evaluating
+ * f(x) once halves the row evaluations), or NULL.  Launch fd_xcd_grid((col_end - col_begin + 7) / 8) workgroups of 256 threads. */
+template <typename T, typename CT, int MODE, class F>
+__global__ void __launch_bounds__(256) fd_colrange_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_colrange_store st,
+                                                              const T *__restrict__ base)
+{
+    constexpr int G = 8;                         /* columns per workgroup */
+    __shared__ int s_pre[G + 1], s_rlo[G];
+    __shared__ long long s_dst[G];
+    __shared__ T s_e[G];
+    const long long ncol = st.col_end - st.col_begin, nw = (ncol + G - 1) / G, wg = fd_xcd_block(blockIdx.x, nw);
+    if (wg >= nw) return;
+    if (threadIdx.x < G) {
+        const long long jl = wg * G + threadIdx.x;
+        int cnt = 0;
+        if (jl < ncol) {
+            const int c = (int)((const CT *)st.color)[st.col_begin + jl];
+            if (c != (int)(CT)(-1) && c >= c_lo && c < c_hi) {      /* (a column of another colour chunk, or without a colour: none of its rows) */
+                cnt = st.row_count[jl];
+                s_rlo[threadIdx.x] = st.row_first[jl];
+                s_dst[threadIdx.x] = st.dest[jl];
+                s_e[threadIdx.x] = eps[c];
+            }
+        }
+        s_pre[threadIdx.x + 1] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_pre[0] = 0;
+        for (int g = 0; g < G; ++g) s_pre[g + 1] += s_pre[g];
+    }
+    __syncthreads();
+    const int total = s_pre[G];
+    for (int idx = (int)threadIdx.x; idx < total; idx += 256) {
+        int g = 0;
+#pragma unroll
+        for (int u = 1; u < G; ++u) g += idx >= s_pre[u] ? 1 : 0;
+        const int t = idx - s_pre[g];
+        const long long j = st.col_begin + wg * G + g, r = (long long)s_rlo[g] + t;
+        const T e = s_e[g];
+        T *out = (T *)st.out + s_dst[g];
+        if constexpr (MODE == 2) {
+            const fd_cplx_column_point<T> X = {x, j, e};
+            const fd_cplx<T> w = f(r, X);
+            out[t] = w.im / e;
+        } else {
+            fd_column_point<T> X = {x, j, e, 0};
+            const T vp = f(r, X);
+            T vm;
+            if (MODE == 0 && base) vm = base[r];                           /* f(x), evaluated once for all columns */
+            else { X.minus = MODE == 1 ? 1 : 2; vm = f(r, X); }
+            out[t] = (vp - vm) / (MODE == 1 ? 2 * e : e);
+        }
+    }
+}
 #endif /* __HIPCC__ && __cplusplus */
 
 #endif /* FDJAC_DEVICE_H */

@@ -571,3 +571,81 @@ def test_terms_functor_parameters_float32_complex_step_and_refusals(oracle):
         fd.JitTerms(SCALED_TERMS, "ScaledTerms", pr, params=b"\x00" * 3)
     with pytest.raises(fd.lib.FdError):
         fd.JitTerms("struct Bad { template <class T> __device__ T term(long long r, long long j, T v) const { return nonsense; } };", "Bad", pr)
+
+
+# ---- a compiled row functor storing BlockBandedMatrix data itself (fd_colrange_store_cols) -------------------------------------------
+BLOCK_COUPLED = """
+// row k of block b: x_k (S_{b-1} + S_b + S_{b+1}) + sin(x_k), S = the block's coordinates added left to right (blocks outside the matrix: none)
+struct BlockCoupled {
+    long long nb, bs;
+    template <class P> __device__ typename P::value_type operator()(long long k, const P &X) const
+    {
+        typedef typename P::value_type V;
+        const long long b = k / bs;
+        V tot = V();
+        bool first = true;
+        for (long long bb = b - 1; bb <= b + 1; ++bb) {
+            if (bb < 0 || bb >= nb) continue;
+            V s = V();
+            for (long long i = 0; i < bs; ++i) { const V v = X(bb * bs + i); s = i == 0 ? v : s + v; }
+            tot = first ? s : tot + s;
+            first = false;
+        }
+        const V xk = X(k);
+        return xk * tot + sin(xk);
+    }
+};
+"""
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central", "complex"])
+@pytest.mark.parametrize("case", [(13, 8), (40, 32), (7, 70)])
+def test_jit_functor_stores_blockbanded_data_itself(oracle, fdtype, case):
+    # BlockBandedMatrix storage (ext/FiniteDiffBlockBandedMatricesExt.jl:44-68): a compiled functor's lazy launcher takes the plan's
+    # column-range descriptor -- one wavefront per column, the column's rows across the lanes -- for all three fdtypes; the same
+    # functor as an opaque f! (materialised points, decompression launch) gives the bit reference; then the oracle and the analytic J
+    nb, bs = case
+    N = nb * bs
+    lay = P.BlockBandedLayout(np.full(nb, bs), 1, 1)
+    colors = lay.colors()
+    xh = np.random.default_rng(12).random(N) - 0.3
+    x = _dev(xh)
+    Jb = fd.BlockBandedMatrix(None, lay)
+    fj = fd.JitF(BLOCK_COUPLED, "BlockCoupled", N, N, params=struct.pack("qq", nb, bs))
+    assert fj.lazy_caps & fd.lib.LAZY_CAP_STORE_COLRANGE
+    po = fd.make_plan(Jb, Jb, colors, fdtype)
+    ref = _dev(np.full(po.out_len(0), np.nan))
+    n0 = fj.launches
+    po.jacobian(fj, x, [ref])
+    opaque_launches = fj.launches - n0
+    ps = fd.make_plan(Jb, Jb, colors, fdtype)
+    ps.set_lazy(fj)
+    out = _dev(np.full(ps.out_len(0), np.nan))
+    n0 = fj.launches
+    ps.jacobian(fj, x, [out])
+    assert ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    # ONE storing launch of the functor (forward: + one plain evaluation of f(x) that every column shares); no perturbation, no
+    # materialised points, no decompression launch
+    assert fj.launches - n0 == (2 if fdtype == "forward" else 1) and opaque_launches >= 1
+    assert not torch.isnan(out).any()
+    assert torch.equal(out.view(torch.int64), ref.view(torch.int64))
+    # the oracle on the numpy restatement of the residual
+    blk = np.repeat(np.arange(nb), bs)
+
+    def f_np(fx, xx):
+        sig = np.zeros(nb, dtype=xx.dtype)
+        for i in range(bs):                                             # (left to right within a block, as the functor adds)
+            sig = xx[i::bs][:nb] if i == 0 else sig + xx[i::bs][:nb]
+        S = sig.copy()
+        S[1:] = sig[:-1] + sig[1:]
+        S[:-1] = S[:-1] + sig[1:]
+        fx[:] = xx * S[blk] + np.sin(xx)
+    want = oracle.jacobian(fdtype, oracle.PyF(f_np, N, N), xh, colors, kind=oracle.PAT_BLOCKBANDED, blk_sizes=lay.blk_sizes, bl=1, bu=1,
+                           block_starts=lay.block_starts, block_strides=lay.block_strides, out_len=lay.data_len)
+    g = out.cpu().numpy()
+    if fdtype == "complex":
+        assert np.max(np.abs(g - want["out"])) <= 1e-12 * max(1.0, np.max(np.abs(want["out"])))       # (no cancellation: a few ulp of |J|)
+    else:
+        fs = float(np.max(np.abs(xh)) * 3 * bs + 1)
+        atol = 16 * np.finfo(np.float64).eps * fs / float(np.min(np.abs(ps.epsilons())))                 # 16 ulp of f over the smallest step
+        assert np.all(np.abs(g - want["out"]) <= 1e-5 * np.abs(want["out"]) + atol)
