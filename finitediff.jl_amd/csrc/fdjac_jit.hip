@@ -124,6 +124,7 @@ struct JitModule {
     struct ColRange {
         hipModule_t mod = nullptr;
         hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [colour bytes == 4][central]
+        hipFunction_t bbb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // fd_bbb_store_cols (BandedBlockBandedMatrix data), same indices
         bool tried = false, ok = false;
     } cr;
     std::vector<char> bitcode;                         // fd_f_link_rows_bitcode: the caller's LLVM bitcode, linked into every program of this functor
@@ -277,24 +278,28 @@ static bool colrange_functions(JitModule *m)
     hiprtcProgram prog = nullptr;
     if (R->CreateProgram(&prog, m->text.c_str(), "fdjac_jit_colrange.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
     const char *ct[2] = {"unsigned char", "int"};
-    std::string names[2][2];
+    std::string names[2][2], bnames[2][2];
     for (int cb = 0; cb < 2; ++cb)
         for (int md = 0; md < 2; ++md) {
             names[cb][md] = "fd_colrange_store_cols<" + m->real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
             (void)R->AddNameExpression(prog, names[cb][md].c_str());
+            bnames[cb][md] = "fd_bbb_store_cols<" + m->real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
+            (void)R->AddNameExpression(prog, bnames[cb][md].c_str());
         }
     bool ok = R->CompileProgram(prog, m->bitcode.empty() ? 5 : 6, kJitOpts) == HIPRTC_SUCCESS;
-    std::string low[2][2];
+    std::string low[2][2], blow[2][2];
     for (int cb = 0; cb < 2 && ok; ++cb)
         for (int md = 0; md < 2 && ok; ++md) {
             const char *ln = nullptr;
             if (R->GetLoweredName(prog, names[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) low[cb][md] = ln; else ok = false;
+            if (ok && R->GetLoweredName(prog, bnames[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) blow[cb][md] = ln; else ok = false;
         }
     std::string why;
     if (ok) ok = load_program(R, prog, m->bitcode, &x.mod, &why) == hipSuccess;
     (void)R->DestroyProgram(&prog);
     for (int cb = 0; cb < 2 && ok; ++cb)
-        for (int md = 0; md < 2 && ok; ++md) ok = hipModuleGetFunction(&x.fn[cb][md], x.mod, low[cb][md].c_str()) == hipSuccess;
+        for (int md = 0; md < 2 && ok; ++md)
+            ok = hipModuleGetFunction(&x.fn[cb][md], x.mod, low[cb][md].c_str()) == hipSuccess && hipModuleGetFunction(&x.bbb[cb][md], x.mod, blow[cb][md].c_str()) == hipSuccess;
     if (!ok) (void)hipGetLastError();
     x.ok = ok;
     return ok;
@@ -377,6 +382,33 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
         void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &bs, &jstart};
         const unsigned g = (unsigned)((bs.col_end - jstart + 511) / 512);
         if (hipModuleLaunchKernel(bf, g, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+        j->launches += 1;
+        return 0;
+    }
+    if (lp->store && lp->store_kind == FD_STORE_BBB && !lp->is_complex) {
+        // BandedBlockBandedMatrix data with uniform blocks: one thread per (column, slot), fd_bbb_store_cols -- every slot of every in-band
+        // slab; forward differences take f(x) from one plain evaluation into the functor's own buffer
+        fd_bbb_store bb = *(const fd_bbb_store *)lp->store;
+        const int central = lp->pts == 2 ? 1 : 0, cbi = bb.color_bytes == 4 ? 1 : 0;
+        if (bb.elem_bytes != j->elem_bytes || (bb.color_bytes != 1 && bb.color_bytes != 4) || bb.N != j->N || j->M != j->N || bb.block_size < 1 || lp->c_lo != 0 ||
+            lp->ncolors != bb.C || !(central || (lp->pts == 1 && lp->diff == 2)) || !colrange_functions(j->m) || !j->m->cr.bbb[cbi][central])
+            return FD_LAZY_DECLINED;
+        const long long slots = bb.N * (bb.bl + bb.bu + 1) * (bb.lam + bb.mu + 1);
+        if (slots <= 0 || (slots + 255) / 256 >= ((long long)1 << 31)) return FD_LAZY_DECLINED;
+        const void *xq = lp->x, *eq = lp->eps, *base = nullptr;
+        if (!central) {
+            if (!j->d_base && hipMalloc(&j->d_base, (size_t)j->M * (size_t)j->elem_bytes) != hipSuccess) { (void)hipGetLastError(); j->d_base = nullptr; }
+            if (j->d_base) {
+                void *fxp = j->d_base;
+                long long xs = 0, fs = 0, r0 = 0, r1 = j->M;
+                void *ra[] = {&fxp, (void *)&xq, (void *)j->params.data(), &xs, &fs, &r0, &r1};
+                if (hipModuleLaunchKernel(j->m->rows, (unsigned)((j->M + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, ra, nullptr) != hipSuccess) return 4;
+                j->launches += 1;
+                base = j->d_base;
+            }
+        }
+        void *args[] = {(void *)j->params.data(), (void *)&xq, (void *)&eq, &bb, (void *)&base};
+        if (hipModuleLaunchKernel(j->m->cr.bbb[cbi][central], (unsigned)((slots + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
         j->launches += 1;
         return 0;
     }

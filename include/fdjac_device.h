@@ -1334,6 +1334,37 @@ __global__ void __launch_bounds__(256) fd_colrange_store_cols(F f, const T *__re
         }
     }
 }
+/* ---- a ROW FUNCTOR storing BandedBlockBandedMatrix data itself (uniform blocks; round 6) -------------------------------------------------
+ * fd_bbb_store: every slot of every in-band slab of every column (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42 assigns the rows inside
+ * their block's sub-band and leaves the others 0).  One thread per (column, slot), consecutive threads on consecutive slots of a
+ * column: slot (d, t) of column j = block J's local column jj is row k = jj + t - mu of block K = J + d - bu; a row inside its block gets
+ * (f(x + eps e_j)[r] - f(x)[r]) / eps (central: the two-sided quotient) -- exactly +-0 when the row does not depend on the column, as
+ * the hand-over path has it -- every other slot 0.  The plan offers the descriptor only with a colouring it has verified for the
+ * BBB pattern, all colours in one batch.  F as for fd_csc_store_cols; MODE 0 forward (base: f(x) of all rows, or NULL = evaluated
+ * here), 1 central.  Launch (N * (bl + bu + 1) * (lam + mu + 1) + 255) / 256 workgroups of 256 threads. */
+template <typename T, typename CT, int MODE, class F>
+__global__ void __launch_bounds__(256) fd_bbb_store_cols(F f, const T *__restrict__ x, const T *__restrict__ eps, fd_bbb_store st, const T *__restrict__ base)
+{
+    const int w = st.bl + st.bu + 1, sw = st.lam + st.mu + 1, R = w * sw;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= st.N * R) return;
+    const long long j = e / R, bs = st.block_size;
+    const int s = (int)(e - j * R), d = s / sw, t = s - d * sw;
+    const long long J = j / bs, K = J + d - st.bu, jj = j - J * bs, k = jj + t - st.mu;
+    const long long st0 = st.start[d + (long long)w * J];
+    if (st0 < 0) return;                                             /* no such block and no slab reserved for it */
+    T *o = (T *)st.out + st0 + jj * st.stride[J] + t;
+    const int c = (int)((const CT *)st.color)[j];
+    if (!(K >= 0 && K < st.nblk && k >= 0 && k < bs) || c == (int)(CT)(-1)) { *o = (T)0; return; }
+    const long long r = K * bs + k;
+    const T h = eps[c];
+    fd_column_point<T> X = {x, j, h, 0};
+    const T vp = f(r, X);
+    T vm;
+    if (MODE == 0 && base) vm = base[r];
+    else { X.minus = MODE == 1 ? 1 : 2; vm = f(r, X); }
+    *o = (vp - vm) / (MODE == 1 ? 2 * h : h);
+}
 #endif /* __HIPCC__ && __cplusplus */
 
 #endif /* FDJAC_DEVICE_H */

@@ -649,3 +649,79 @@ def test_jit_functor_stores_blockbanded_data_itself(oracle, fdtype, case):
         fs = float(np.max(np.abs(xh)) * 3 * bs + 1)
         atol = 16 * np.finfo(np.float64).eps * fs / float(np.min(np.abs(ps.epsilons())))                 # 16 ulp of f over the smallest step
         assert np.all(np.abs(g - want["out"]) <= 1e-5 * np.abs(want["out"]) + atol)
+
+
+# ---- a compiled row functor storing BandedBlockBandedMatrix data itself (fd_bbb_store_cols) ----------------------------------------------
+GRID_NL = """
+// an nx x ny grid, row k = (i, j): neighbours within `reach` along the grid row and the points straight above / below, nonlinear in x_k
+struct GridNL {
+    long long nx, ny, reach;
+    template <class P> __device__ typename P::value_type operator()(long long k, const P &X) const
+    {
+        typedef typename P::value_type V;
+        const long long j = k / nx, i = k - j * nx;
+        const V c = X(k);
+        V s = c * c;
+        for (long long d = 1; d <= reach; ++d) {
+            const bool hw = i - d >= 0, he = i + d < nx;
+            const V w = X(hw ? k - d : k), e = X(he ? k + d : k);
+            s = s + (hw ? (real_t)(0.5 / d) * w : (real_t)0);
+            s = s + (he ? (real_t)(0.25 * d) * e * c : (real_t)0);
+        }
+        const bool hs = j > 0, hn = j + 1 < ny;
+        const V sv = X(hs ? k - nx : k), nv = X(hn ? k + nx : k);
+        s = s + (hs ? sv : (real_t)0);
+        s = s + (hn ? (real_t)2 * nv : (real_t)0);
+        return s;
+    }
+};
+"""
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("case", [(40, 30, 1), (23, 17, 3), (64, 5, 2)])
+def test_jit_functor_stores_bandedblockbanded_data_itself(oracle, fdtype, case):
+    # BandedBlockBandedMatrix storage with uniform blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42): a compiled functor's lazy launcher
+    # fills every slot of every in-band slab in one launch (fd_bbb_store_cols) -- the bits of the same functor as an opaque f! (perturb,
+    # batched rows, k_decompress_bbb), oracle parity on the numpy restatement
+    nx, ny, reach = case
+    N = nx * ny
+    lay = P.BandedBlockBandedLayout(np.full(ny, nx), 1, 1, reach, reach)
+    colors = lay.colors()
+    xh = np.random.default_rng(21).random(N) + 0.1
+    x = _dev(xh)
+    fj = fd.JitF(GRID_NL, "GridNL", N, N, params=struct.pack("qqq", nx, ny, reach))
+    J = fd.BandedBlockBandedMatrix(None, lay)
+    po = fd.make_plan(J, J, colors, fdtype)
+    ref = _dev(np.full(lay.data_len, np.nan))
+    po.jacobian(fj, x, [ref])
+    ps = fd.make_plan(J, J, colors, fdtype)
+    ps.set_lazy(fj)
+    out = _dev(np.full(lay.data_len, np.nan))
+    n0 = fj.launches
+    ps.jacobian(fj, x, [out])
+    assert ps.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert fj.launches - n0 == (2 if fdtype == "forward" else 1)          # the storing launch (+ one plain evaluation of f(x) for forward)
+    assert not torch.isnan(out).any()
+    assert torch.equal(out.view(torch.int64), ref.view(torch.int64))
+
+    def f_np(fx, xx):
+        X = xx.reshape(ny, nx)
+        s = X * X
+        for d in range(1, reach + 1):
+            w = np.zeros_like(X)
+            e = np.zeros_like(X)
+            w[:, d:] = X[:, :-d]
+            e[:, :-d] = X[:, d:]
+            s = s + (0.5 / d) * w
+            s = s + (0.25 * d) * e * X
+        sv = np.zeros_like(X)
+        nv = np.zeros_like(X)
+        sv[1:] = X[:-1]
+        nv[:-1] = X[1:]
+        fx[:] = ((s + sv) + 2 * nv).reshape(-1)
+    want = oracle.jacobian(fdtype, oracle.PyF(f_np, N, N), xh, colors, kind=oracle.PAT_BANDEDBLOCKBANDED, blk_sizes=lay.blk_sizes, bl=1, bu=1,
+                           lam=reach, mu=reach, block_starts=lay.block_starts, block_strides=lay.block_strides, out_len=lay.data_len)
+    g = out.cpu().numpy()
+    atol = 16 * np.finfo(np.float64).eps * 10.0 / float(np.min(np.abs(ps.epsilons())))                  # 16 ulp of f (|f| < 10) over the smallest step
+    assert np.all(np.abs(g - want["out"]) <= 1e-5 * np.abs(want["out"]) + atol)
