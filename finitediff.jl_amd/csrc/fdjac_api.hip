@@ -429,7 +429,7 @@ int fd_plan_destroy(fd_plan *p)
     if (p->ctx->check_stream && p->d_fpx) (void)hipStreamSynchronize(p->ctx->check_stream);      // (a deferred check of this plan may still be reading d_fpx)
     void *ptrs[] = {p->d_color, p->d_rowval, p->d_nzcolor, p->d_dest, p->d_spos, p->d_wtiles, p->d_wcode, p->d_w2desc, p->d_cr_rlo, p->d_cr_cnt, p->d_cr_off,
                     p->d_perm, p->d_cptr, p->d_X, p->d_FX, p->d_fx, p->d_eps, p->d_partial, p->d_gsum, p->d_tick, p->d_fpx, p->d_xstage,
-                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_sr_ptr, p->d_sr_col, p->d_sr_slot, p->d_sr_order, p->d_sr_tile, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
+                    p->d_finstage, p->d_outstage[0], p->d_outstage[1], p->d_outstage[2], p->d_zero_own, p->d_eps2, p->d_tile_order, p->d_fxwin, p->d_fp, p->d_sc_colptr, p->d_sc_rowval, p->d_sc_note, p->d_sr_ptr, p->d_sr_col, p->d_sr_slot, p->d_sr_order, p->d_sr_tile, p->d_se_col, p->d_se_slot, p->d_se_info, p->d_split, p->d_bbb_off, p->d_bbb_blk, p->d_bbb_start, p->d_bbb_stride};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pstale) (void)hipHostFree(p->h_pstale);
@@ -1053,7 +1053,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
             sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.note = p->d_sc_note; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
             sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0; sc.reach = p->sc_reach; sc.plan_serial = p->sc_serial;
-            sc.row_ptr = p->d_sr_ptr; sc.row_col = p->d_sr_col; sc.row_slot = p->d_sr_slot; sc.row_pack = p->d_sr_order; sc.row_tile = p->d_sr_tile;
+            sc.row_ptr = p->d_sr_ptr; sc.row_col = p->d_sr_col; sc.row_slot = p->d_sr_slot; sc.row_pack = p->d_sr_order; sc.row_tile = p->d_sr_tile; sc.ent_col = p->d_se_col; sc.ent_slot = p->d_se_slot; sc.ent_info = p->d_se_info;
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;

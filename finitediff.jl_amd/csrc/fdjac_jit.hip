@@ -100,6 +100,7 @@ struct JitModule {
     hipFunction_t rows = nullptr;
     hipFunction_t store[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [colour bytes == 4][central]
     hipFunction_t store_win[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t store_ents[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // fd_csc_store_ents, same indices (a thread per entry)
     hipFunction_t store_rows[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // fd_csc_store_rows (separable functors, fd_f_compile_terms): [colour bytes == 4][central]
     unsigned lists_offset = 0, terms_bytes = 0;       // fd_sep_rows<TF>: where its two list pointers sit, sizeof(TF)
     hipFunction_t band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // fd_band_store_cols: [bandwidths (1,1) / (2,2)][forward / central]
@@ -479,6 +480,17 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
         const double per_row = (double)j->entries / (double)st.M;
         int cap = (int)std::min<int64_t>((int64_t)(256 * per_row * 1.25) + 64, 3072);
         int ireach = (int)reach;
+        // a thread per entry where the plan has the entries in its tiles' row order (fd_csc_store_ents; FDJAC_ROWS_ENTS=0: a thread per row)
+        const size_t lds_e = j->elem_bytes == 8 ? fd_csc_ents_lds_bytes<double>(reach, lp->ncolors) : fd_csc_ents_lds_bytes<float>(reach, lp->ncolors);
+        const char *sw = test_switch("FDJAC_ROWS_ENTS");
+        if (st.ent_col && st.ent_slot && st.ent_info && j->m->store_ents[cb][central] && lds_e <= 64 * 1024 && !(sw && *sw == '0')) {
+            void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st, &ireach};
+            const unsigned gr = (unsigned)(8 * (((st.M + 255) / 256 + 7) / 8));
+            if (hipModuleLaunchKernel(j->m->store_ents[cb][central], gr, 1, 1, 256, 1, 1, (unsigned)lds_e, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;
+            j->launches += 1;
+            j->row_stores += 1;
+            return 0;
+        }
         const size_t lds_r = j->elem_bytes == 8 ? fd_csc_rows_lds_bytes<double>(reach, lp->ncolors, cap) : fd_csc_rows_lds_bytes<float>(reach, lp->ncolors, cap);
         if (lds_r <= 64 * 1024) {
             void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st, &ireach, &cap};
@@ -566,12 +578,14 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
                 bnames[wi][md] = std::string("fd_band_store_cols<") + real + ", " + (md ? "1" : "0") + ", fdjit_F, " + (wi ? "2, 2>" : "1, 1>");
                 (void)R->AddNameExpression(prog, bnames[wi][md].c_str());
             }
-        std::string rnames[2][2];
+        std::string rnames[2][2], enames[2][2];
         if (sep)
             for (int cb = 0; cb < 2; ++cb)
                 for (int md = 0; md < 2; ++md) {
                     rnames[cb][md] = std::string("fd_csc_store_rows<") + real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
                     (void)R->AddNameExpression(prog, rnames[cb][md].c_str());
+                    enames[cb][md] = std::string("fd_csc_store_ents<") + real + ", " + ct[cb] + ", " + (md ? "1" : "0") + ", fdjit_F>";
+                    (void)R->AddNameExpression(prog, enames[cb][md].c_str());
                 }
         rr = R->CompileProgram(prog, bitcode.empty() ? 5 : 6, kJitOpts);
         size_t ls = 0;
@@ -597,12 +611,13 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
                 const char *ln = nullptr;
                 if (R->GetLoweredName(prog, bnames[wi][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) blow[wi][md] = ln;
             }
-        std::string rlow[2][2];
+        std::string rlow[2][2], elow[2][2];
         if (sep)
             for (int cb = 0; cb < 2; ++cb)
                 for (int md = 0; md < 2; ++md) {
                     const char *ln = nullptr;
                     if (R->GetLoweredName(prog, rnames[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) rlow[cb][md] = ln;
+                    if (R->GetLoweredName(prog, enames[cb][md].c_str(), &ln) == HIPRTC_SUCCESS && ln) elow[cb][md] = ln;
                 }
         m = new (std::nothrow) JitModule();
         if (!m) { (void)R->DestroyProgram(&prog); FD_REQUIRE(false, FD_ERR_NOMEM, "out of host memory"); }
@@ -628,7 +643,10 @@ static int jit_build(fd_ctx *ctx, const std::string &src, const std::vector<char
                 if (blow[wi][md].empty() || hipModuleGetFunction(&m->band[wi][md], m->mod, blow[wi][md].c_str()) != hipSuccess) m->band[wi][md] = nullptr;      // (an optimisation)
         for (int cb = 0; cb < 2 && e == hipSuccess && sep; ++cb)
             for (int md = 0; md < 2; ++md)
+            {
                 if (rlow[cb][md].empty() || hipModuleGetFunction(&m->store_rows[cb][md], m->mod, rlow[cb][md].c_str()) != hipSuccess) m->store_rows[cb][md] = nullptr;      // (an optimisation)
+                if (elow[cb][md].empty() || hipModuleGetFunction(&m->store_ents[cb][md], m->mod, elow[cb][md].c_str()) != hipSuccess) m->store_ents[cb][md] = nullptr;
+            }
         if (e == hipSuccess) {
             hipDeviceptr_t dp = nullptr;
             size_t bytes = 0;

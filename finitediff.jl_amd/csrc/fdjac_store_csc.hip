@@ -201,6 +201,33 @@ static int build_store_csc_t(fd_plan *p, const IT *colptr_dev, const IT *rowval_
             FD_HIP_CHECK(hipMemcpy(p->d_sr_order, pack.data(), sizeof(int) * pack.size(), hipMemcpyHostToDevice));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_tile, sizeof(int) * tptr.size()));
             FD_HIP_CHECK(hipMemcpy(p->d_sr_tile, tptr.data(), sizeof(int) * tptr.size(), hipMemcpyHostToDevice));
+            // ... and the ENTRIES of every tile in that order of the rows (fd_csc_store_ents: a thread per entry; 64 consecutive entries are
+            // then entries of rows of one length, so the loop over a row's terms runs the same number of trips in every lane): column,
+            // slot, and {the row's place in the tile's order | the entry's place in its row << 8 | the row's length << 16}.  Only when
+            // every tile's entries fit the kernel's registers (8 per thread) and every row has at most 255 entries.
+            {
+                int64_t max_tile = 0;
+                int max_len = 0;
+                for (int64_t t = 0; t < ntile; ++t) max_tile = std::max<int64_t>(max_tile, (int64_t)tptr[(size_t)t + 1] - tptr[(size_t)t]);
+                for (int64_t r = 0; r < p->M; ++r) max_len = std::max(max_len, rp[(size_t)r + 1] - rp[(size_t)r]);
+                if (max_tile <= 2048 && max_len <= 255) {
+                    std::vector<int> ec((size_t)n), es((size_t)n), ei((size_t)n);
+                    for (int64_t q = 0, at = 0; q < p->M; ++q) {
+                        const int r = ro[(size_t)q], len = rp[(size_t)r + 1] - rp[(size_t)r];
+                        for (int k = 0; k < len; ++k, ++at) {
+                            ec[(size_t)at] = rc[(size_t)rp[(size_t)r] + k];
+                            es[(size_t)at] = rs[(size_t)rp[(size_t)r] + k];
+                            ei[(size_t)at] = (int)(q & 255) | (k << 8) | (len << 16);
+                        }
+                    }
+                    FD_HIP_CHECK(hipMalloc((void **)&p->d_se_col, sizeof(int) * ec.size()));
+                    FD_HIP_CHECK(hipMalloc((void **)&p->d_se_slot, sizeof(int) * es.size()));
+                    FD_HIP_CHECK(hipMalloc((void **)&p->d_se_info, sizeof(int) * ei.size()));
+                    FD_HIP_CHECK(hipMemcpy(p->d_se_col, ec.data(), sizeof(int) * ec.size(), hipMemcpyHostToDevice));
+                    FD_HIP_CHECK(hipMemcpy(p->d_se_slot, es.data(), sizeof(int) * es.size(), hipMemcpyHostToDevice));
+                    FD_HIP_CHECK(hipMemcpy(p->d_se_info, ei.data(), sizeof(int) * ei.size(), hipMemcpyHostToDevice));
+                }
+            }
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_ptr, sizeof(int) * rp.size()));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_col, sizeof(int) * rc.size()));
             FD_HIP_CHECK(hipMalloc((void **)&p->d_sr_slot, sizeof(int) * rs.size()));

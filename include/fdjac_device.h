@@ -198,6 +198,11 @@ typedef struct fd_csc_store {
                                    /* fd_csc_store_rows hands them to its threads in: a wavefront then holds rows of similar length):          */
                                    /* {row, (its first entry's place in the tile's run of the lists, <= 65535) | (its length, <= 32767) << 16} */
     const int *row_tile;           /* device, ceil(M / 256) + 1 offsets: tile t's run of the lists is [row_tile[t], row_tile[t + 1])           */
+    /* the ENTRIES tile by tile in the order of row_pack (or NULL: a tile with more than 2048 entries, a row with more than 255): what     */
+    /* fd_csc_store_ents walks -- a thread per entry; tile t's entries are [row_tile[t], row_tile[t + 1]) of these lists too                  */
+    const int *ent_col;            /* device, per entry: its 0-based column                                                                    */
+    const int *ent_slot;           /* device, per entry: its index in out / rowval                                                             */
+    const int *ent_info;           /* device, per entry: (its row's place in the tile's order) | (its place in the row) << 8 | (the row's length) << 16 */
 } fd_csc_store;
 
 /* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------
@@ -982,34 +987,34 @@ __global__ void __launch_bounds__(256, 4) fd_csc_store_rows(F f, const T *__rest
     const CT *color = (const CT *)st.color;
     const int nx = (int)(w1 - w0), npair = nx >> 1;
     const int nst = A1 - A0 < cap ? A1 - A0 : cap;
+    if (nst <= 0) return;                                              /* (a tile of empty rows) */
     {
-        /* every load of the prologue is requested before the first is used, from indices clamped into range (no load inside a
-           per-lane branch); a batch the window does not reach is skipped by a wave-uniform test */
-        constexpr int XP = 4, XC = 8, XL = 8;      /* 2048 coordinates, 2048 colours, 2048 entries per trip */
+        /* STRAIGHT-LINE: every load unconditional, from an index clamped into range (a batch the tile does not need re-reads its last
+           element), all in flight together and waited for once -- a load inside a branch, even a wave-uniform one, is waited for
+           with everything outstanding at the first use of its value (see fd_csc_store_ents) */
+        constexpr int XP = 4, XC = 8, XL = 8;      /* 2048 coordinates, 2048 colours, 2048 entries */
+        const int tid = (int)threadIdx.x;
         fd_pair_t vx[XP];
-        int vc[XC], vj[XL], vq[XL];
+        CT vc[XC];
+        int vj[XL], vq[XL];
 #pragma unroll
-        for (int u = 0; u < XP; ++u)
-            if (u * 256 < npair) { const int i = u * 256 + (int)threadIdx.x; vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0 + 2 * (i < npair ? i : npair - 1)); }
+        for (int u = 0; u < XP; ++u) { const int i = u * 256 + tid; vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0 + 2 * (i < npair ? i : npair - 1)); }
 #pragma unroll
-        for (int u = 0; u < XC; ++u)
-            if (u * 256 < nx) { const int i = u * 256 + (int)threadIdx.x; const CT c = color[w0 + (i < nx ? i : nx - 1)]; vc[u] = c == (CT)(-1) ? -1 : (int)c; }
+        for (int u = 0; u < XC; ++u) { const int i = u * 256 + tid; vc[u] = color[w0 + (i < nx ? i : nx - 1)]; }
 #pragma unroll
-        for (int u = 0; u < XL; ++u)
-            if (u * 256 < nst) { const int i = u * 256 + (int)threadIdx.x, ic = A0 + (i < nst ? i : nst - 1); vj[u] = st.row_col[ic]; vq[u] = st.row_slot[ic]; }
-        for (int i = threadIdx.x; i < nchunk; i += 256) { const T h = eps[c_lo + i]; s_h[i] = h; s_y[i] = (T)1 / (MODE == 1 ? 2 * h : h); }
-        if ((nx & 1) && threadIdx.x == 0) s_x[nx - 1] = x[w0 + nx - 1];
+        for (int u = 0; u < XL; ++u) { const int i = u * 256 + tid, ic = A0 + (i < nst ? i : nst - 1); vj[u] = st.row_col[ic]; vq[u] = st.row_slot[ic]; }
+        const T hmine = eps[c_lo + (tid < nchunk ? tid : 0)];
 #pragma unroll
-        for (int u = 0; u < XP; ++u)
-            if (u * 256 < npair) { const int i = u * 256 + (int)threadIdx.x; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+        for (int u = 0; u < XP; ++u) { const int i = u * 256 + tid; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+        if ((nx & 1) && tid == 0) s_x[nx - 1] = x[w0 + nx - 1];
 #pragma unroll
-        for (int u = 0; u < XC; ++u)
-            if (u * 256 < nx) { const int i = u * 256 + (int)threadIdx.x; if (i < nx) s_c[i] = vc[u]; }
+        for (int u = 0; u < XC; ++u) { const int i = u * 256 + tid; if (i < nx) s_c[i] = vc[u] == (CT)(-1) ? -1 : (int)vc[u]; }
 #pragma unroll
-        for (int u = 0; u < XL; ++u)
-            if (u * 256 < nst) { const int i = u * 256 + (int)threadIdx.x; if (i < nst) { s_j[i] = vj[u]; s_q[i] = vq[u]; } }
+        for (int u = 0; u < XL; ++u) { const int i = u * 256 + tid; if (i < nst) { s_j[i] = vj[u]; s_q[i] = vq[u]; } }
+        if (tid < nchunk) { s_h[tid] = hmine; s_y[tid] = (T)1 / (MODE == 1 ? 2 * hmine : hmine); }
+        for (int i = 256 + tid; i < nchunk; i += 256) { const T h = eps[c_lo + i]; s_h[i] = h; s_y[i] = (T)1 / (MODE == 1 ? 2 * h : h); }      /* (more than 256 colours in a batch) */
         for (int i0 = XL * 256; i0 < nst; i0 += 256) {                  /* (a tile with more than 2048 staged entries: the rest, trip by trip) */
-            const int i = i0 + (int)threadIdx.x;
+            const int i = i0 + tid;
             if (i < nst) { s_j[i] = st.row_col[A0 + i]; s_q[i] = st.row_slot[A0 + i]; }
         }
     }
@@ -1106,6 +1111,127 @@ __global__ void __launch_bounds__(256, 4) fd_csc_store_rows(F f, const T *__rest
             out[q] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fx_given : fx), MODE == 1 ? 2 * h : h, y);
         }
         pre = k == 0 ? tk : pre + tk;
+    }
+}
+
+/* ---- the same store, a thread per ENTRY (round 6) ------------------------------------------------------------------------------------------
+ * fd_csc_store_rows gives a thread a ROW: the lanes of a wavefront idle while its longest row is worked through, and the unrolled row
+ * code wants 120 registers.  Here a thread takes ENTRIES -- tile t's entries in the plan's order of the rows (descending length:
+ * fd_csc_store.ent_*), entry i = u 256 + thread -- so that the 64 lanes of a wavefront hold entries of rows of one length:
+ *   1. every entry's plain term t(r, j, x_j) once, into LDS;
+ *   2. every entry (r, j_k) then adds its row's terms left to right with its own replaced by t(r, j_k, x_j +- eps) -- the L - 1
+ *      additions of the full evaluation at the colour's point, the same in every lane of the wavefront (and, for forward differences
+ *      without a given f(x), the row's plain sum beside them) -- divides and stores.
+ * Same additions in the same order as fd_csc_store_rows / fd_csc_store_cols: same bits; no register arrays (twice the resident
+ * wavefronts).  Needs st.ent_* (every tile <= 2048 entries, rows <= 255 entries) on top of what fd_csc_store_rows needs; same launch
+ * shape; LDS fd_csc_ents_lds_bytes<T>(reach, c_hi - c_lo). */
+#define FD_CSC_ENTS_PER_THREAD 8
+template <typename T> __host__ __device__ inline size_t fd_csc_ents_lds_bytes(long long reach, int ncolors)
+{
+    const size_t xlen = (size_t)(256 + 2 * reach + 2);
+    return sizeof(T) * (xlen + 2 * (size_t)ncolors + 256 * FD_CSC_ENTS_PER_THREAD) + 4 * (xlen + 256) + 64;
+}
+template <typename T, typename CT, int MODE, class F>
+__global__ void __launch_bounds__(256) fd_csc_store_ents(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fd_ents_lds[];
+    typedef T fd_pair_t __attribute__((ext_vector_type(2)));
+    constexpr int NE = FD_CSC_ENTS_PER_THREAD;
+    const long long ntile = (st.M + 255) / 256, tile = fd_xcd_block(blockIdx.x, ntile);
+    if (tile >= ntile) return;
+    const long long R0 = tile * 256, R1 = R0 + 256 < st.M ? R0 + 256 : st.M;
+    const int A0 = st.row_tile[tile], nst = st.row_tile[tile + 1] - A0;
+    if (nst <= 0) return;                                              /* (a tile of empty rows) */
+    long long w0l = R0 - reach > 0 ? R0 - reach : 0;
+    const long long w1 = R1 + reach < st.N ? R1 + reach : st.N;
+    w0l &= ~1ll;
+    const int w0 = (int)w0l, xlen = 256 + 2 * reach + 2, nchunk = c_hi - c_lo;
+    FD_LDS_PTR(T) s_x = (FD_LDS_PTR(T))fd_ents_lds;
+    FD_LDS_PTR(T) s_h = s_x + xlen;                                    /* step of colour c_lo + i */
+    FD_LDS_PTR(T) s_y = s_h + nchunk;                                  /* 1 / (step or 2 step) */
+    FD_LDS_PTR(T) s_t = s_y + nchunk;                                  /* plain term of the tile's i-th entry */
+    FD_LDS_PTR(int) s_c = (FD_LDS_PTR(int))(s_t + 256 * NE);           /* colour of column w0 + i (-1: none) */
+    FD_LDS_PTR(int) s_r = s_c + xlen;                                  /* the row at place p of the tile's order */
+    const CT *color = (const CT *)st.color;
+    const int nx = (int)(w1 - w0l), npair = nx >> 1;
+    const int tid = (int)threadIdx.x;
+    /* The prologue is STRAIGHT-LINE code: every load unconditional, from an index clamped into range (a batch the tile does not need
+       re-reads its last element), all in flight together and waited for once.  A load inside a branch -- even a wave-uniform one --
+       leaves the compiler unsure on some path whether it has been waited for: it then waits for EVERYTHING outstanding at the first use
+       of the value, and in the loop below that includes the store of the pass before (one counter for loads and stores on this target):
+       a store round trip per pass made the first form of this kernel 105 us instead of 60. */
+    constexpr int XP = 4, XC = 8;
+    fd_pair_t vx[XP];
+    CT vc[XC];
+    int ej[NE], eq[NE], ei[NE];
+    const long long pos = R0 + tid;
+    const int myrow = st.row_pack[2 * (pos < R1 ? pos : R1 - 1)];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) { const int i = u * 256 + tid; vx[u] = *reinterpret_cast<const fd_pair_t *>(x + w0l + 2 * (i < npair ? i : npair - 1)); }
+#pragma unroll
+    for (int u = 0; u < XC; ++u) { const int i = u * 256 + tid; vc[u] = color[w0l + (i < nx ? i : nx - 1)]; }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int i = u * 256 + tid, ic = A0 + (i < nst ? i : nst - 1);
+        ej[u] = st.ent_col[ic]; eq[u] = st.ent_slot[ic]; ei[u] = st.ent_info[ic];
+    }
+    const T hmine = eps[c_lo + (tid < nchunk ? tid : 0)];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) { const int i = u * 256 + tid; if (i < npair) { s_x[2 * i] = vx[u].x; s_x[2 * i + 1] = vx[u].y; } }
+    if ((nx & 1) && tid == 0) s_x[nx - 1] = x[w0l + nx - 1];
+#pragma unroll
+    for (int u = 0; u < XC; ++u) { const int i = u * 256 + tid; if (i < nx) s_c[i] = vc[u] == (CT)(-1) ? -1 : (int)vc[u]; }
+    s_r[tid] = myrow;
+    if (tid < nchunk) { s_h[tid] = hmine; s_y[tid] = (T)1 / (MODE == 1 ? 2 * hmine : hmine); }
+    for (int i = 256 + tid; i < nchunk; i += 256) { const T h = eps[c_lo + i]; s_h[i] = h; s_y[i] = (T)1 / (MODE == 1 ? 2 * h : h); }      /* (more than 256 colours in a batch) */
+    __syncthreads();
+    const bool given = MODE == 0 && st.fx_base != nullptr;
+    /* 1: plain terms (and, where f(x) is handed over, the row's value: requested here, unconditionally, before any store of this thread) */
+    T fxg[NE];
+    int rr[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) rr[u] = s_r[ei[u] & 255];
+    if (given) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) fxg[u] = ((const T *)st.fx_base)[rr[u]];
+    } else {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) fxg[u] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        if (u * 256 < nst) {
+            const int i = u * 256 + tid;
+            const T t = f.term((long long)rr[u], (long long)ej[u], (T)s_x[(unsigned)(ej[u] - w0)]);
+            if (i < nst) s_t[i] = t;
+        }
+    }
+    __syncthreads();
+    /* 2: every entry's quotient */
+    T *out = (T *)st.out;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        if (u * 256 >= nst) break;
+        const int i = u * 256 + tid;
+        if (i >= nst) continue;
+        const unsigned off = (unsigned)(ej[u] - w0);
+        const int c = s_c[off];
+        if (c < 0) { if (c_lo == 0) out[eq[u]] = (T)0; continue; }
+        if (c < c_lo || c >= c_hi) continue;
+        const int k = (ei[u] >> 8) & 255, L = (ei[u] >> 16) & 255, b = i - k;
+        const long long r = rr[u];
+        const T h = s_h[c - c_lo], y = s_y[c - c_lo], v = s_x[off];
+        const T tp = f.term(r, (long long)ej[u], v + h), tm = MODE == 1 ? f.term(r, (long long)ej[u], v - h) : (T)0;
+        const T t0 = s_t[b];
+        T sp = k == 0 ? tp : t0, sm = k == 0 ? tm : t0, sa = t0;
+        for (int uu = 1; uu < L; ++uu) {
+            const T tv = s_t[b + uu];
+            const bool me = uu == k;
+            sp = sp + (me ? tp : tv);
+            if (MODE == 1) sm = sm + (me ? tm : tv);
+            if (MODE == 0 && !given) sa = sa + tv;
+        }
+        out[eq[u]] = fd_div_shared<T>(sp - (MODE == 1 ? sm : given ? fxg[u] : sa), MODE == 1 ? 2 * h : h, y);
     }
 }
 
