@@ -1053,7 +1053,7 @@ static int jacobian_enqueue(fd_plan *p, fd_f_launch f, void *fctx, const real_t 
             sc.out = outs[0]; sc.M = p->M; sc.N = p->N; sc.col_begin = p->col0; sc.col_end = p->col1;
             sc.colptr = p->d_sc_colptr; sc.rowval = p->d_sc_rowval; sc.note = p->d_sc_note; sc.color = p->d_color; sc.fx_base = (p->fdtype == FD_FORWARD && !own_base) ? fx : nullptr;
             sc.color_bytes = p->color8 ? 1 : 4; sc.C = (int)p->C; sc.elem_bytes = (int)sizeof(real_t); sc.valid_coloring = p->sc_valid ? 1 : 0; sc.reach = p->sc_reach; sc.plan_serial = p->sc_serial;
-            sc.row_ptr = p->d_sr_ptr; sc.row_col = p->d_sr_col; sc.row_slot = p->d_sr_slot; sc.row_pack = p->d_sr_order; sc.row_tile = p->d_sr_tile; sc.ent_col = p->d_se_col; sc.ent_slot = p->d_se_slot; sc.ent_info = p->d_se_info;
+            sc.row_ptr = p->d_sr_ptr; sc.row_col = p->d_sr_col; sc.row_slot = p->d_sr_slot; sc.row_pack = p->d_sr_order; sc.row_tile = p->d_sr_tile; sc.ent_col = p->d_se_col; sc.ent_slot = p->d_se_slot; sc.ent_info = p->d_se_info; sc.ent_tile_max = p->se_tile_max;
             fd_lazy_points lp = {};
             lp.x = x_dev;
             lp.color = p->d_color;

@@ -904,9 +904,9 @@ static int functor_family_lazy(BuiltinF *b, const fd_lazy_points *lp, hipStream_
         if (verdict == 1 && st.row_ptr && st.row_pack && st.row_tile && st.col_begin == 0 && st.col_end == st.N && st.N >= 2 &&
             fd_csc_rows_lds_bytes<real_t>(reach, lp->ncolors, cap_r) <= 64 * 1024) {
             const unsigned gr = fd_xcd_grid((st.M + kBlock - 1) / kBlock);
-            const size_t lds_e = fd_csc_ents_lds_bytes<real_t>(reach, lp->ncolors);
+            const size_t lds_e = fd_csc_ents_lds_bytes<real_t>(reach, lp->ncolors, st.ent_tile_max);
             const char *sw = test_switch("FDJAC_ROWS_ENTS");
-            if (st.ent_col && st.ent_slot && st.ent_info && lds_e <= 64 * 1024 && !(sw && *sw == '0')) {      // a thread per entry (fd_csc_store_ents)
+            if (st.ent_col && st.ent_slot && st.ent_info && lds_e <= 64 * 1024 && (sw && *sw == '1')) {      // a thread per entry (fd_csc_store_ents)
                 if (lp->pts == 2) hipLaunchKernelGGL((fd_csc_store_ents<real_t, CT, 1, SparseF>), dim3(gr), dim3(kBlock), lds_e, s, f, x, eps, c_lo, c_hi, st, (int)reach);
                 else hipLaunchKernelGGL((fd_csc_store_ents<real_t, CT, 0, SparseF>), dim3(gr), dim3(kBlock), lds_e, s, f, x, eps, c_lo, c_hi, st, (int)reach);
                 b->row_stores.fetch_add(1);

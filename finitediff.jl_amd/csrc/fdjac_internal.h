@@ -354,6 +354,7 @@ struct fd_plan {
     int32_t *d_sc_colptr = nullptr, *d_sc_rowval = nullptr;
     bool want_store_rows = false;                // FD_PLAN_STORE_CSC_ROWS: the same pattern by rows (fd_csc_store.row_ptr / row_col / row_slot), full column range only
     int32_t *d_sr_ptr = nullptr, *d_sr_col = nullptr, *d_sr_slot = nullptr, *d_sr_order = nullptr, *d_sr_tile = nullptr;
+    int se_tile_max = 0;
     int32_t *d_se_col = nullptr, *d_se_slot = nullptr, *d_se_info = nullptr;      // the entries in the tiles' row order (fd_csc_store.ent_*), or none
     unsigned long long *d_sc_note = nullptr;     // fd_csc_store.note: four words of launcher memory about this pattern, zero at creation
     unsigned long long sc_serial = 0;            // fd_csc_store.plan_serial

@@ -480,10 +480,10 @@ static int jit_launch_lazy(void *fctx, void *fx, const fd_lazy_points *lp, int64
         const double per_row = (double)j->entries / (double)st.M;
         int cap = (int)std::min<int64_t>((int64_t)(256 * per_row * 1.25) + 64, 3072);
         int ireach = (int)reach;
-        // a thread per entry where the plan has the entries in its tiles' row order (fd_csc_store_ents; FDJAC_ROWS_ENTS=0: a thread per row)
-        const size_t lds_e = j->elem_bytes == 8 ? fd_csc_ents_lds_bytes<double>(reach, lp->ncolors) : fd_csc_ents_lds_bytes<float>(reach, lp->ncolors);
+        // a thread per entry where the plan has the entries in its tiles' row order (fd_csc_store_ents; FDJAC_ROWS_ENTS=1; default: a thread per row)
+        const size_t lds_e = j->elem_bytes == 8 ? fd_csc_ents_lds_bytes<double>(reach, lp->ncolors, st.ent_tile_max) : fd_csc_ents_lds_bytes<float>(reach, lp->ncolors, st.ent_tile_max);
         const char *sw = test_switch("FDJAC_ROWS_ENTS");
-        if (st.ent_col && st.ent_slot && st.ent_info && j->m->store_ents[cb][central] && lds_e <= 64 * 1024 && !(sw && *sw == '0')) {
+        if (st.ent_col && st.ent_slot && st.ent_info && j->m->store_ents[cb][central] && lds_e <= 64 * 1024 && (sw && *sw == '1')) {
             void *args[] = {(void *)j->params.data(), (void *)&x, (void *)&eps, &c_lo, &c_hi, &st, &ireach};
             const unsigned gr = (unsigned)(8 * (((st.M + 255) / 256 + 7) / 8));
             if (hipModuleLaunchKernel(j->m->store_ents[cb][central], gr, 1, 1, 256, 1, 1, (unsigned)lds_e, (hipStream_t)stream, args, nullptr) != hipSuccess) return 4;

@@ -203,6 +203,7 @@ typedef struct fd_csc_store {
     const int *ent_col;            /* device, per entry: its 0-based column                                                                    */
     const int *ent_slot;           /* device, per entry: its index in out / rowval                                                             */
     const int *ent_info;           /* device, per entry: (its row's place in the tile's order) | (its place in the row) << 8 | (the row's length) << 16 */
+    int ent_tile_max;              /* the largest number of entries a tile holds (<= 2048): sizes fd_csc_store_ents' LDS                       */
 } fd_csc_store;
 
 /* ---- BandedBlockBandedMatrix storage with UNIFORM blocks (ext/FiniteDiffBlockBandedMatricesExt.jl:16-42, round 5) --------------------
@@ -1114,7 +1115,8 @@ __global__ void __launch_bounds__(256, 4) fd_csc_store_rows(F f, const T *__rest
     }
 }
 
-/* ---- the same store, a thread per ENTRY (round 6) ------------------------------------------------------------------------------------------
+/* ---- the same store, a thread per ENTRY (round 6; measured EQUAL to the row form on the random band -- neither is bound by its arithmetic,
+ *      profiles/NOTES.md -- so the plans build its lists only on request: test switch FDJAC_ROWS_ENTS=1) ------------------------------------------------------------------------------------------
  * fd_csc_store_rows gives a thread a ROW: the lanes of a wavefront idle while its longest row is worked through, and the unrolled row
  * code wants 120 registers.  Here a thread takes ENTRIES -- tile t's entries in the plan's order of the rows (descending length:
  * fd_csc_store.ent_*), entry i = u 256 + thread -- so that the 64 lanes of a wavefront hold entries of rows of one length:
@@ -1124,12 +1126,13 @@ __global__ void __launch_bounds__(256, 4) fd_csc_store_rows(F f, const T *__rest
  *      without a given f(x), the row's plain sum beside them) -- divides and stores.
  * Same additions in the same order as fd_csc_store_rows / fd_csc_store_cols: same bits; no register arrays (twice the resident
  * wavefronts).  Needs st.ent_* (every tile <= 2048 entries, rows <= 255 entries) on top of what fd_csc_store_rows needs; same launch
- * shape; LDS fd_csc_ents_lds_bytes<T>(reach, c_hi - c_lo). */
+ * shape; LDS fd_csc_ents_lds_bytes<T>(reach, c_hi - c_lo, st.ent_tile_max).  (A budget of six wavefronts per SIMD -- 76 registers, no spill -- measured
+ * SLOWER: 103-110 us against 98-101.) */
 #define FD_CSC_ENTS_PER_THREAD 8
-template <typename T> __host__ __device__ inline size_t fd_csc_ents_lds_bytes(long long reach, int ncolors)
+template <typename T> __host__ __device__ inline size_t fd_csc_ents_lds_bytes(long long reach, int ncolors, int tile_max)
 {
-    const size_t xlen = (size_t)(256 + 2 * reach + 2);
-    return sizeof(T) * (xlen + 2 * (size_t)ncolors + 256 * FD_CSC_ENTS_PER_THREAD) + 4 * (xlen + 256) + 64;
+    const size_t xlen = (size_t)(256 + 2 * reach + 2), nt = ((size_t)tile_max + 63) & ~(size_t)63;      /* (as the kernel lays it out) */
+    return sizeof(T) * (xlen + 2 * (size_t)ncolors + nt) + 4 * (xlen + 256) + 64;
 }
 template <typename T, typename CT, int MODE, class F>
 __global__ void __launch_bounds__(256) fd_csc_store_ents(F f, const T *__restrict__ x, const T *__restrict__ eps, int c_lo, int c_hi, fd_csc_store st, int reach)
@@ -1150,7 +1153,7 @@ __global__ void __launch_bounds__(256) fd_csc_store_ents(F f, const T *__restric
     FD_LDS_PTR(T) s_h = s_x + xlen;                                    /* step of colour c_lo + i */
     FD_LDS_PTR(T) s_y = s_h + nchunk;                                  /* 1 / (step or 2 step) */
     FD_LDS_PTR(T) s_t = s_y + nchunk;                                  /* plain term of the tile's i-th entry */
-    FD_LDS_PTR(int) s_c = (FD_LDS_PTR(int))(s_t + 256 * NE);           /* colour of column w0 + i (-1: none) */
+    FD_LDS_PTR(int) s_c = (FD_LDS_PTR(int))(s_t + ((st.ent_tile_max + 63) & ~63));      /* colour of column w0 + i (-1: none) */
     FD_LDS_PTR(int) s_r = s_c + xlen;                                  /* the row at place p of the tile's order */
     const CT *color = (const CT *)st.color;
     const int nx = (int)(w1 - w0l), npair = nx >> 1;

@@ -175,8 +175,12 @@ def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, cas
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 # (3000, 12, 40): ~12 entries per row -- more than a tile's staged run holds: the overflow rows read their lists from memory
 @pytest.mark.parametrize("case", [(300, 4, 9, 1), (5000, 6, 300, 4), (70001, 6, 300, 7), (3000, 12, 40, 8), (2000, 3, 700, 9)])
-@pytest.mark.parametrize("lists", [False, True])      # True: the plan keeps its pattern by rows (store_rows) -- then the verified launches are fd_csc_store_rows on the plan's lists
-def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case, lists):
+# True: the plan keeps its pattern by rows (store_rows) -- then the verified launches are fd_csc_store_rows on the plan's lists; "ents": the
+# entry-parallel form of the same store (fd_csc_store_ents, plans built with the test switch FDJAC_ROWS_ENTS=1)
+@pytest.mark.parametrize("lists", [False, True, "ents"])
+def test_sparse_family_row_wise_store_after_the_first_call(monkeypatch, fdtype, case, lists):
+    if lists == "ents":
+        monkeypatch.setenv("FDJAC_ROWS_ENTS", "1")
     # k_f_sparse_store_rows: the first launch on a plan only CHECKS that the plan's pattern is the one the residual was created from (the
     # column kernel stores); once the verdict has reached the host (read back asynchronously) the launches go row by row -- every row's
     # plain terms once, prefix carried, suffix added: the additions of the full evaluation in the same order => the hand-over path's bits.
@@ -185,7 +189,7 @@ def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case, lists):
     J = fd.SparseMatrixCSC(N, N, colptr, rowval, None)
     colors = fd.matrix_colors(J)
     f = fd.BuiltinF.sparse(N, N, colptr, rowval)
-    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, store_rows=lists)
+    ps = fd.make_plan(J, J, colors, fdtype, store_csc=True, store_rows=bool(lists))
     ps.set_lazy(f)
     ph = fd.make_plan(J, J, colors, fdtype)
     rng = np.random.default_rng(seed)
@@ -208,7 +212,7 @@ def test_sparse_family_row_wise_store_after_the_first_call(fdtype, case, lists):
     cp2[1:] += 1
     J2 = fd.SparseMatrixCSC(N, N, cp2, rv2, None)
     colors2 = fd.matrix_colors(J2)
-    ps2 = fd.make_plan(J2, J2, colors2, fdtype, store_csc=True, store_rows=lists)
+    ps2 = fd.make_plan(J2, J2, colors2, fdtype, store_csc=True, store_rows=bool(lists))
     ps2.set_lazy(f)
     ph2 = fd.make_plan(J2, J2, colors2, fdtype)
     before = f.row_stores()
@@ -491,7 +495,9 @@ def test_random_grids_through_the_7_point_column_kernel(seed):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_sparse_family_row_wise_store_randomised(seed):
+def test_sparse_family_row_wise_store_randomised(monkeypatch, seed):
+    if seed % 4 == 3:
+        monkeypatch.setenv("FDJAC_ROWS_ENTS", "1")      # (the entry-parallel form of the row-wise store on a quarter of the seeds)
     # the row-wise store (k_f_sparse_store_rows) under everything a plan can ask of it: column windows (other ranks' columns are terms
     # of its rows but not its entries), colour chunks and colour ownership, uncoloured columns, a caller's f_in, Float32, rows longer
     # than a tile's staged run or than the register path -- five calls per plan (check, then row-wise), the hand-over path's bits
