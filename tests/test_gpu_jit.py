@@ -727,3 +727,26 @@ def test_jit_functor_stores_bandedblockbanded_data_itself(oracle, fdtype, case):
     g = out.cpu().numpy()
     atol = 16 * np.finfo(np.float64).eps * 10.0 / float(np.min(np.abs(ps.epsilons())))                  # 16 ulp of f (|f| < 10) over the smallest step
     assert np.all(np.abs(g - want["out"]) <= 1e-5 * np.abs(want["out"]) + atol)
+
+
+@pytest.mark.parametrize("shape", [(257, 411), (411, 257)])
+def test_terms_functor_on_a_non_square_pattern_takes_the_column_store(shape):
+    # the row-wise kernel keeps the window of x by ROW index (square, locally banded patterns); any other shape: the same term through
+    # fd_sep_rows in the column store -- the bits of the built-in sparse family's hand-over path
+    M, N = shape
+    colptr, rowval = _random_band(M, N, 4, 9, 31)
+    J = fd.SparseMatrixCSC(M, N, colptr, rowval, None)
+    colors = fd.matrix_colors(J)
+    x = _dev(np.random.default_rng(31).random(N) + 0.1)
+    fb = fd.BuiltinF.sparse(M, N, colptr, rowval)
+    ph = fd.make_plan(J, J, colors, "forward")
+    ref = _dev(np.full(rowval.size, np.nan))
+    ph.jacobian(fb, x, [ref])
+    pr = fd.make_plan(J, J, colors, "forward", store_rows=True)
+    assert pr.row_lists()["entries"] == rowval.size
+    ft = fd.JitTerms(SPARSE_TERMS, "SparseTerms", pr)
+    pr.set_lazy(ft)
+    out = _dev(np.full(rowval.size, np.nan))
+    pr.jacobian(ft, x, [out])
+    assert ft.row_stores == 0 and pr.info(fd.lib.INFO_LAZY_STORE) == 1
+    assert torch.equal(out.view(torch.int64), ref.view(torch.int64))
