@@ -1484,7 +1484,8 @@ class JacobianCache:
         want_csc = (self.lazy and isinstance(f, (BuiltinF, JitF)) and not self.cx and (f.lazy_caps & _l.LAZY_CAP_STORE_CSC) != 0
                     and (self.fdtype != "complex" or (f.lazy_caps & _l.LAZY_CAP_STORE_CSC_COMPLEX) != 0))      # (the shim: PlanOpts(...; store_csc = f can store column by column))
         plan = make_plan(J, sparsity, colorvec, self.fdtype, ctx, dtype=self.dtype, complex_x=self.cx, fingerprint=content,
-                         store_csc=want_csc, store_csc_always=want_csc and isinstance(f, JitF))
+                         store_csc=want_csc, store_csc_always=want_csc and isinstance(f, JitF),
+                         store_rows=want_csc and getattr(f, "family", None) == "sparse")      # (the separable built-in family: row lists -> the row-wise store)
         if self.lazy and isinstance(f, (BuiltinF, JitF)) and not self.cx and f.lazy_fn is not None:
             plan.set_lazy(f)          # built-in families: f! perturbs while loading / stores the Jacobian itself (shim: install_lazy!)
         self._plans[key] = (plan, sparsity, colorvec, content, gen)     # (the arrays are kept alive: their ids stay theirs)
