@@ -172,6 +172,29 @@ def test_sparse_family_column_store_bit_identical_and_oracle(oracle, fdtype, cas
     assert np.max(np.abs(a.cpu().numpy() - want)) < (5e-6 if fdtype == "forward" else 5e-8) * 10
 
 
+@pytest.mark.parametrize("shape", [(61, 47), (3, 3), (200, 5)])
+def test_user_kernel_stores_a_general_pattern_row_by_row(tmp_path, shape):
+    # examples/user_terms_store.hip: a USER's separable residual (nine-point stencil, given by its term) compiled apart from libfdjac
+    # against the two public headers; on the plan whose row lists it was bound to (FD_PLAN_STORE_CSC_ROWS, fd_plan_row_lists) its lazy
+    # launcher runs fd_csc_store_rows, on another plan fd_csc_store_cols.  examples/user_terms_client.c (plain C) checks: the lists, which
+    # kernel ran, both bit-identical to the plain launcher + the library's decompression, analytic values, f! counts.
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "finitediff.jl_amd", "lib")
+    user_so = str(tmp_path / "libuser_tm.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(root, "examples", "user_terms_store.hip"), "-o", user_so])
+    assert "libfdjac" not in subprocess.run(["ldd", user_so], capture_output=True, text=True).stdout
+    exe = str(tmp_path / "user_terms_client")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + inc, os.path.join(root, "examples", "user_terms_client.c"), "-o", exe,
+                           "-L" + str(tmp_path), "-luser_tm", "-L" + libdir, "-lfdjac", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(shape[0]), str(shape[1])], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "user_terms_client ok" in out.stdout and "FAILED" not in out.stdout
+
+
 @pytest.mark.parametrize("fdtype", ["forward", "central"])
 # (3000, 12, 40): ~12 entries per row -- more than a tile's staged run holds: the overflow rows read their lists from memory
 @pytest.mark.parametrize("case", [(300, 4, 9, 1), (5000, 6, 300, 4), (70001, 6, 300, 7), (3000, 12, 40, 8), (2000, 3, 700, 9)])
