@@ -1078,7 +1078,8 @@ template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real
 
 // the five quotients of column (ii, j) from the window W (rows j-2 .. j+2, columns i-2 .. i+3 of x, zero outside the grid), o =
 // ii - i.  INTERIOR: every neighbour of every evaluated row exists (no guards).
-template <int MODE, int SK, bool INTERIOR, bool FASTDIV, int WC>
+// NUMER: q receives the five DIFFERENCES (the caller divides: k_f_stencil5_store_wave4).
+template <int MODE, int SK, bool INTERIOR, bool FASTDIV, int WC, bool NUMER = false>
 __device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][WC], int o, int ii, int j, int nx, int ny, real_t e, real_t *q)
 {
     const real_t ed = MODE == 1 ? 2 * e : e;
@@ -1095,30 +1096,30 @@ __device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][W
         const bool rhs = INTERIOR || j - 1 > 0;
         const real_t pl = stencil5_row<real_t, SK>(PV(-1, 0), hw ? PV(-1, -1) : z, he ? PV(-1, 1) : z, rhs ? PV(-2, 0) : z, pc);
         const real_t mi = stencil5_row<real_t, SK>(MV(-1, 0), hw ? MV(-1, -1) : z, he ? MV(-1, 1) : z, rhs ? MV(-2, 0) : z, mcc);
-        q[0] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+        q[0] = NUMER ? sub_exact(pl, mi) : div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
     }
     {   // row (ii-1, j): east
         const bool rhw = INTERIOR || ii - 1 > 0;
         const real_t pl = stencil5_row<real_t, SK>(PV(0, -1), rhw ? PV(0, -2) : z, pc, hs ? PV(-1, -1) : z, hn ? PV(1, -1) : z);
         const real_t mi = stencil5_row<real_t, SK>(MV(0, -1), rhw ? MV(0, -2) : z, mcc, hs ? MV(-1, -1) : z, hn ? MV(1, -1) : z);
-        q[1] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+        q[1] = NUMER ? sub_exact(pl, mi) : div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
     }
     {   // row (ii, j): centre
         const real_t pl = stencil5_row<real_t, SK>(pc, hw ? PV(0, -1) : z, he ? PV(0, 1) : z, hs ? PV(-1, 0) : z, hn ? PV(1, 0) : z);
         const real_t mi = stencil5_row<real_t, SK>(mcc, hw ? MV(0, -1) : z, he ? MV(0, 1) : z, hs ? MV(-1, 0) : z, hn ? MV(1, 0) : z);
-        q[2] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+        q[2] = NUMER ? sub_exact(pl, mi) : div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
     }
     {   // row (ii+1, j): west
         const bool rhe = INTERIOR || ii + 1 < nx - 1;
         const real_t pl = stencil5_row<real_t, SK>(PV(0, 1), pc, rhe ? PV(0, 2) : z, hs ? PV(-1, 1) : z, hn ? PV(1, 1) : z);
         const real_t mi = stencil5_row<real_t, SK>(MV(0, 1), mcc, rhe ? MV(0, 2) : z, hs ? MV(-1, 1) : z, hn ? MV(1, 1) : z);
-        q[3] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+        q[3] = NUMER ? sub_exact(pl, mi) : div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
     }
     {   // row (ii, j+1): south
         const bool rhn = INTERIOR || j + 1 < ny - 1;
         const real_t pl = stencil5_row<real_t, SK>(PV(1, 0), hw ? PV(1, -1) : z, he ? PV(1, 1) : z, pc, rhn ? PV(2, 0) : z);
         const real_t mi = stencil5_row<real_t, SK>(MV(1, 0), hw ? MV(1, -1) : z, he ? MV(1, 1) : z, mcc, rhn ? MV(2, 0) : z);
-        q[4] = div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
+        q[4] = NUMER ? sub_exact(pl, mi) : div_shared<FASTDIV>(sub_exact(pl, mi), ed, yd);
     }
 #undef PV
 #undef MV
@@ -1197,6 +1198,113 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     }
     fd_stencil5_emit_wave<real_t, true, 2>(&st, s_win[wave], j, i0, q);
 }
+
+#ifdef FDJAC_F32
+// Float32 (round 6): FOUR columns per lane -- 16-byte loads of x and 16-byte stores of the values (a Float32 pair moves 512 B per
+// instruction, half of what the memory pipeline takes), 256 columns per wavefront -- and the division through Float64:
+//   (float)((double)a * (1.0 / (double)b))  has the bits of the Float32  a / b  whenever that quotient is a NORMAL number: the double
+// product is within 2^-52 of a / b, and a quotient of two 24-bit significands that is not itself a Float32 lies at least 2^-49 (relative)
+// from every rounding boundary (scripts/ubench/exact_div32_probe.hip: 5e10 pairs, 0 mismatches; denormal quotients can differ).  The
+// reciprocal belongs to the COLOUR: lane c of every wavefront forms 1 / (double)(2 eps_c) once and the columns fetch theirs by
+// ds_bpermute; a column whose five quotients are not all normal numbers (zero, denormal, infinite, NaN -- or a step outside
+// [2^-100, 2^100], whose reciprocal is handed out as NaN) takes the true divisions.  Three conversions / products and a class test
+// per quotient instead of the ten instructions of v_div_scale .. v_div_fixup.
+__device__ __forceinline__ void div5_through_f64(const float (&a)[5], float b, double y, float *q)
+{
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const float v = (float)((double)a[m] * y);
+        q[m] = v;
+        ok = ok && __builtin_amdgcn_classf(v, 0x108);          // -normal | +normal
+    }
+    if (!ok) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) q[m] = a[m] / b;
+    }
+}
+template <typename CT, int MODE, int SK>
+__global__ void __launch_bounds__(kBlock, 4)
+k_f_stencil5_store_wave4(const real_t *__restrict__ x, const real_t *__restrict__ eps, fd_stencil5_store st, int64_t jrow0, int64_t jrow1)
+{
+    constexpr int TW = 256, WC = 8;
+    __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_STENCIL5_WAVE4_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = (int)st.nx, ny = (int)st.ny;                 // nx is a multiple of 4 (launcher): a lane's four columns share a grid row
+    const int TPR = (nx + TW - 1) / TW;
+    const int64_t ntiles = (jrow1 - jrow0) * TPR, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    const int64_t grp = xcd_tile(blockIdx.x, ngroups);
+    if (grp >= ngroups) return;
+    const int64_t wt = grp * (kBlock / 64) + wave;
+    if (wt >= ntiles) return;
+    const unsigned wrow = (unsigned)wt / (unsigned)TPR;
+    const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
+    const int i = i0 + 4 * lane;
+    const int64_t k = (int64_t)j * nx + i;
+    const bool act = i < nx;
+    // the colours' steps and reciprocals, one colour per lane (st.C <= 64: launcher)
+    real_t e_l = 1;
+    double y_l = 0;
+    if (lane < st.C) {
+        e_l = eps[lane];
+        const real_t ed = MODE == 1 ? 2 * e_l : e_l, mb = fabsf(ed);
+        y_l = (mb >= 0x1p-100f && mb <= 0x1p100f) ? 1.0 / (double)ed : __builtin_nan("");
+    }
+    const bool interior = j >= 2 && j + 2 < ny && i0 >= 4 && i0 + TW + 4 <= nx;
+    // window rows j-2 .. j+2, columns i-2 .. i+5 (zero outside the grid; of rows j+-2 only the lane's own columns are used)
+    real_t W[5][WC];
+    const bool edge_tile = !interior && j >= 2 && j + 3 < ny;   // every address below is inside the array: unconditional loads + selects
+    if (interior || edge_tile) {
+        const int64_t kl = act ? k : (int64_t)j * nx + i0;
+#pragma unroll
+        for (int dj = -2; dj <= 2; ++dj) {
+            const real_t *row = x + (kl + (int64_t)dj * nx);
+            const r4_t B = *reinterpret_cast<const r4_t *>(row);
+            r4_t A = {0, 0, 0, 0}, Cq = {0, 0, 0, 0};
+            if (dj >= -1 && dj <= 1) { A = *reinterpret_cast<const r4_t *>(row - 4); Cq = *reinterpret_cast<const r4_t *>(row + 4); }
+            const bool okA = interior || (act && i >= 4), okB = interior || act, okC = interior || (act && i + 4 < nx);
+            W[dj + 2][0] = okA ? A.z : (real_t)0; W[dj + 2][1] = okA ? A.w : (real_t)0;
+            W[dj + 2][2] = okB ? B.x : (real_t)0; W[dj + 2][3] = okB ? B.y : (real_t)0;
+            W[dj + 2][4] = okB ? B.z : (real_t)0; W[dj + 2][5] = okB ? B.w : (real_t)0;
+            W[dj + 2][6] = okC ? Cq.x : (real_t)0; W[dj + 2][7] = okC ? Cq.y : (real_t)0;
+        }
+    } else {
+        // the two first and the three last grid rows: every coordinate guarded
+#pragma unroll
+        for (int dj = -2; dj <= 2; ++dj) {
+            const bool rowok = act && j + dj >= 0 && j + dj < ny;
+#pragma unroll
+            for (int c = 0; c < WC; ++c) {
+                const int ic = i + c - 2;
+                real_t v = 0;
+                if (rowok && ic >= 0 && ic < nx && !((dj == -2 || dj == 2) && (c < 2 || c > 5))) v = x[k + (int64_t)dj * nx + (c - 2)];
+                W[dj + 2][c] = v;
+            }
+        }
+    }
+    int cq[4] = {0, 0, 0, 0};
+    if (act) {
+        if constexpr (sizeof(CT) == 1) {
+            const unsigned cw = *reinterpret_cast<const unsigned *>((const unsigned char *)st.color + k);       // (k is a multiple of 4)
+            cq[0] = (int)(cw & 255u); cq[1] = (int)((cw >> 8) & 255u); cq[2] = (int)((cw >> 16) & 255u); cq[3] = (int)(cw >> 24);
+        } else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) cq[o] = (int)((const CT *)st.color)[k + o];
+        }
+    }
+    real_t q[20];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const real_t e = __shfl(e_l, cq[o], 64);
+        const double y = __shfl(y_l, cq[o], 64);
+        real_t num[5];
+        if (interior) stencil5_column_quotients<MODE, SK, true, false, WC, true>(W, o, i + o, j, nx, ny, e, num);
+        else stencil5_column_quotients<MODE, SK, false, false, WC, true>(W, o, i + o, j, nx, ny, e, num);
+        div5_through_f64(num, MODE == 1 ? 2 * e : e, y, q + 5 * o);
+    }
+    fd_stencil5_emit_wave4<real_t, true>(&st, s_win[wave], j, i0, q);
+}
+#endif
 
 // fd_bbb_store (round 5): the 5-point families on an nx x ny grid storing into BandedBlockBandedMatrix data -- ny blocks of nx rows,
 // block bandwidths (1, 1), sub-block bandwidths (1, 1): the reference's own fixture (test/coloring_tests.jl:99-115;
@@ -1287,6 +1395,24 @@ static int lazy_stencil5_launch(BuiltinF *b, void *fx, const fd_lazy_points *lp,
         if (ntiles >= ((int64_t)1 << 31) || st.nx * st.ny >= ((int64_t)1 << 31)) return FD_LAZY_DECLINED;   // (32-bit tile / grid arithmetic in the kernel)
         // ONE form (round 3 measured the others, profiles/r03_h_stencil_store_ab.txt; the probes live in scripts/ubench/): two columns per
         // lane, non-temporal stores, the shared-reciprocal exact division, guard-free interior tiles, a register budget for six waves per SIMD
+#ifdef FDJAC_F32
+        {   // Float32: four columns per lane, the division through Float64 (k_f_stencil5_store_wave4)
+            const char *sw = fdjac::test_switch("FDJAC_S5_WAVE4");
+            const bool quad_ok = st.nx % 4 == 0 && st.C <= 64 && (((uintptr_t)lp->x) & 15) == 0 && (((uintptr_t)st.color) & 3) == 0 &&
+                                 !(sw && *sw && atoi(sw) == 0);
+            const int64_t nt4 = (jrow1 - jrow0) * ((st.nx + 255) / 256), ng4 = (nt4 + kBlock / 64 - 1) / (kBlock / 64);
+            if (quad_ok) {
+                const unsigned g4 = (unsigned)(8 * xcd_chunks(ng4));
+#define FD_S54(MODE, SKK)                                                                                            \
+                hipLaunchKernelGGL((k_f_stencil5_store_wave4<CT, MODE, SKK>), dim3(g4), dim3(kBlock), 0, s, (const real_t *)lp->x, \
+                                   (const real_t *)lp->eps, st, jrow0, jrow1)
+                if (mode == 0) { if (sk == 2) FD_S54(0, 2); else FD_S54(0, 0); }
+                else { if (sk == 2) FD_S54(1, 2); else FD_S54(1, 0); }
+#undef FD_S54
+                return hipGetLastError() == hipSuccess ? 0 : 4;
+            }
+        }
+#endif
 #define FD_S5(MODE, SKK)                                                                                            \
         hipLaunchKernelGGL((k_f_stencil5_store_wave<CT, MODE, SKK>), dim3(gs), dim3(kBlock), 0, s, (const real_t *)lp->x, \
                            (const real_t *)lp->eps, st, jrow0, jrow1)

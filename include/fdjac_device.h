@@ -504,6 +504,72 @@ __device__ inline void fd_stencil5_emit_wave(const fd_stencil5_store *d, T *win,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+/*
+ * The same with FOUR columns per lane (round 6; Float32, where a pair store moves only 512 B per instruction): lane t of a FULL
+ * wavefront holds q[5 o + m], o = 0 .. 3, of the columns (i0 + 4 t + o, j); i0 is a multiple of 4 and the same in all lanes.  Interior
+ * grid rows inside the local column range with a 16-byte aligned `out` leave as aligned 16-byte stores (single elements at the two
+ * ends, which share their quad with the neighbouring wavefronts); everything else through fd_stencil5_emit_column.
+ * Window: FD_STENCIL5_WAVE4_LDS elements, 16-byte aligned.
+ */
+#define FD_STENCIL5_WAVE4_LDS 1288
+template <typename T, bool NT = true>
+__device__ inline void fd_stencil5_emit_wave4(const fd_stencil5_store *d, T *win, long long j, long long i0, const T *q)
+{
+    typedef typename fd_band_quad_of<T>::type quad_t;
+    const int lane = (int)(threadIdx.x & 63);
+    const long long nx = d->nx, i = i0 + 4 * lane, k0 = j * nx + i0;
+    const int nc = (int)(nx - i0 < 256 ? nx - i0 : 256);
+    const bool fast = j >= 1 && j <= d->ny - 2 && k0 >= d->col_begin && k0 + nc <= d->col_end &&
+                      ((((unsigned long long)d->out) & (4 * sizeof(T) - 1)) == 0);
+    if (!fast) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (i + o < nx) fd_stencil5_emit_column_ij<T>(d, i + o, j, q + 5 * o);
+        return;
+    }
+    const long long P0 = fd_stencil5_colptr_ij(d, i0, j) - d->entry_begin;
+    const int off = (int)(P0 & 3);
+    const int lo = off, hi = off + 5 * nc - (i0 == 0 ? 1 : 0) - (i0 + nc == nx ? 1 : 0);
+    if (i0 > 0 && i0 + nc < nx) {
+        /* no column of the tile is the first or the last of its grid row: 20 consecutive slots per lane */
+        if (i < nx) {
+#pragma unroll
+            for (int m = 0; m < 20; ++m) win[off + 20 * lane + m] = q[m];
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const long long ii = i + o;
+            if (ii >= nx) continue;
+            const int base = off + 5 * (int)(ii - i0) - ((i0 == 0 && ii > 0) ? 1 : 0);
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                if ((m == 1 && ii == 0) || (m == 3 && ii == nx - 1)) continue;
+                int sl = base + m;
+                if (ii == 0 && m > 1) sl -= 1;
+                if (ii == nx - 1 && m == 4) sl -= 1;
+                win[sl] = q[5 * o + m];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T *base = (T *)d->out + (P0 - off);                  /* slot 0 <-> a local index that is a multiple of 4 */
+    for (int sl = 4 * lane; sl < hi; sl += 256) {
+        if (sl >= lo && sl + 3 < hi) {
+            const quad_t v = *(const quad_t *)(win + sl);
+            if (NT) __builtin_nontemporal_store(v, (quad_t *)(base + sl));
+            else *(quad_t *)(base + sl) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sl + e >= lo && sl + e < hi) base[sl + e] = win[sl + e];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 /* One entry of a column-range storage (fd_colrange_store): the value of (row r, column j).  Entries outside the local column
    range or outside the column's stored rows are ignored. */
 template <typename T> __device__ inline void fd_colrange_emit(const fd_colrange_store *d, long long j, long long r, T value)

@@ -278,3 +278,42 @@ def test_tridiagonal_store_four_columns_per_lane_float32(monkeypatch, fdtype, la
     for a, b in zip(outs["1"], outs["0"]):
         assert not np.isnan(b).any()
         assert np.array_equal(a, b), layout
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+@pytest.mark.parametrize("fam", ["lap5", "lap5_nl"])
+@pytest.mark.parametrize("shape", [(256, 9), (260, 8), (1028, 7), (1536, 6), (64, 12), (516, 5, "window"), (1028, 7, "special")])
+def test_stencil5_store_four_columns_per_lane_float32(monkeypatch, fdtype, fam, shape):
+    # Float32: the storing launch of the 5-point fixtures takes four columns per lane, writes 16-byte quads and divides through
+    # Float64 (k_f_stencil5_store_wave4 / fd_stencil5_emit_wave4).  Tiles at the two ends of a grid row, partial last tiles, interior
+    # tiles, the first / last grid rows, a column window that cuts grid rows, and operands that send whole columns to the true division
+    # (huge, zero and overflowing differences): the bits of the two-columns-per-lane kernel and of the hand-over path.
+    nx, ny = shape[0], shape[1]
+    what = shape[2] if len(shape) > 2 else ""
+    N = nx * ny
+    cp, rv = P.lap5_csc(nx, ny)
+    colors = P.lap5_colors(nx, ny)
+    J = fd.SparseMatrixCSC(N, N, cp, rv)
+    xh = (np.random.default_rng(5).random(N) + 0.1).astype(F32)
+    if what == "special":
+        xh[3 * nx + 300] = 1e30
+        xh[3 * nx + 700] = 3e38
+        xh[2 * nx + 900: 2 * nx + 910] = 0.0
+        xh[4 * nx + 20] = 1e-30
+    x = _dev(xh)
+    win = (nx + 37 + 1, N - nx - 5) if what == "window" else None
+    outs = {}
+    for form in ("wave4", "wave2", "handover"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", "0" if form == "handover" else "1")
+        monkeypatch.setenv("FDJAC_S5_WAVE4", "0" if form == "wave2" else "1")
+        plan = fd.make_plan(J, J, colors, fdtype, dtype=F32, col_window=win)
+        f = fd.BuiltinF(fam, nx, ny, dtype=F32)
+        plan.set_lazy(f)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == (0 if form == "handover" else 1)
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=torch.float32, device="cuda")
+        plan.jacobian(f, x, [out])
+        outs[form] = out.cpu().numpy()
+    if what != "special":
+        assert not np.isnan(outs["handover"]).any()
+    for form in ("wave4", "wave2"):
+        assert np.array_equal(outs[form].view(np.uint32), outs["handover"].view(np.uint32)), form
