@@ -1079,11 +1079,13 @@ template <bool FAST> __device__ __forceinline__ real_t div_shared(real_t a, real
 // the five quotients of column (ii, j) from the window W (rows j-2 .. j+2, columns i-2 .. i+3 of x, zero outside the grid), o =
 // ii - i.  INTERIOR: every neighbour of every evaluated row exists (no guards).
 // NUMER: q receives the five DIFFERENCES (the caller divides: k_f_stencil5_store_wave4).
-template <int MODE, int SK, bool INTERIOR, bool FASTDIV, int WC, bool NUMER = false>
-__device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][WC], int o, int ii, int j, int nx, int ny, real_t e, real_t *q)
+// YGIVEN: the caller hands in yd = 1 / ed (one reciprocal per COLOUR, fetched from the colour's lane, instead of one per column).
+template <int MODE, int SK, bool INTERIOR, bool FASTDIV, int WC, bool NUMER = false, bool YGIVEN = false>
+__device__ __forceinline__ void stencil5_column_quotients(const real_t (&W)[5][WC], int o, int ii, int j, int nx, int ny, real_t e, real_t *q,
+                                                          real_t yd_in = 0)
 {
     const real_t ed = MODE == 1 ? 2 * e : e;
-    const real_t yd = (FASTDIV && sizeof(real_t) == 8) ? (real_t)1 / ed : (real_t)0;
+    const real_t yd = YGIVEN ? yd_in : (FASTDIV && sizeof(real_t) == 8) ? (real_t)1 / ed : (real_t)0;
     const real_t xc = W[2][2 + o], pc = xc + e, mc = xc - e;
     const bool hw = INTERIOR || ii > 0, he = INTERIOR || ii < nx - 1, hs = INTERIOR || j > 0, hn = INTERIOR || j < ny - 1;
     const real_t z = 0;
@@ -1191,6 +1193,7 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     int cpair[2] = {0, 0};
     if (act) { cpair[0] = (int)((const CT *)st.color)[k]; cpair[1] = (int)((const CT *)st.color)[k + 1]; }
     real_t q[10];
+    // (one reciprocal per COLOUR fetched from the colour's lane, as the Float32 kernel below does: 101 -> 105 us here, scripts/ab_c3.sh)
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         if (interior) stencil5_column_quotients<MODE, SK, true, FASTDIV, WC>(W, o, i + o, j, nx, ny, eps[cpair[o]], q + 5 * o);
@@ -1654,9 +1657,27 @@ __device__ __forceinline__ long long bc_lane_i64(long long v, int i)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), i);
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-// QUAD (round 5; Float64, blocks of exactly 32 rows, even destinations: fd_colrange_store.pairs): a lane of phase B is a ROW PAIR of one of
+#ifndef FD_BC_RPL32
+#define FD_BC_RPL32 2      // Float32: row pairs of four columns (29.2 us at config 5) or row quads of eight (29.9 us), same box
+#endif
+// RPL consecutive rows of one column: one 16-byte store (Float64 pair / Float32 quad; a Float32 destination that is only 8-byte aligned: two pairs)
+template <int RPL> __device__ __forceinline__ void bc_store_rows(real_t *d, const real_t (&v)[RPL], bool al)
+{
+    if constexpr (RPL == 2) {
+        __builtin_nontemporal_store(r2_t{v[0], v[1]}, reinterpret_cast<r2_t *>(d));
+    } else {
+        typedef real_t rq_t __attribute__((ext_vector_type(4)));
+        if (al) __builtin_nontemporal_store(rq_t{v[0], v[1], v[2], v[3]}, reinterpret_cast<rq_t *>(d));
+        else {
+            __builtin_nontemporal_store(r2_t{v[0], v[1]}, reinterpret_cast<r2_t *>(d));
+            __builtin_nontemporal_store(r2_t{v[2], v[3]}, reinterpret_cast<r2_t *>(d + 2));
+        }
+    }
+}
+// QUAD (round 5; blocks of exactly 32 rows, even destinations: fd_colrange_store.pairs): a lane of phase B is a ROW PAIR of one of
 // FOUR adjacent columns -- every store is 16 bytes per lane, 256 contiguous bytes per 16 lanes, half the store instructions of the
-// two-column form; the same operations per element, so the same bits.
+// two-column form; the same operations per element, so the same bits.  Float32 (round 6): row pairs too (8-byte stores, 33.8 -> 29.2 us
+// at config 5; FD_BC_RPL32 = 4 makes it a ROW QUAD of one of EIGHT adjacent columns, 16-byte stores: 29.9 us on the same box).
 template <typename CT, bool TWO, bool QUAD = false>
 __global__ void __launch_bounds__(kBcT)
 k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ color, const real_t *__restrict__ eps, int c_lo, int B,
@@ -1814,7 +1835,9 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     // stores them (32 lanes = 256 contiguous bytes per row block; a column is one contiguous run).
     real_t *outp = (real_t *)st.out;
     if constexpr (QUAD) {
-        const int cq = lane >> 4, r2 = lane & 15;                         // column of the iteration's four, row pair (2 r2, 2 r2 + 1)
+        // RPL rows per lane: a row pair of one of FOUR columns (Float64) or a row quad of one of EIGHT columns (Float32) -- 16 bytes per store
+        constexpr int RPL = sizeof(real_t) == 4 ? FD_BC_RPL32 : 2, LPC = 32 / RPL, CPI = 64 / LPC;
+        const int cq = lane / LPC, r2 = lane % LPC;                       // column of the iteration's CPI, rows RPL r2 .. RPL r2 + RPL - 1
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
             const int u = wave + k * NW;
@@ -1824,38 +1847,39 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             if (bcol >= blk1 || bcol >= nb || ncol <= 0) continue;
             const int q_l = uq[k];
             const long long dest_l = ud[k];
-            real_t xk[3][2], rzk[3][2];
+            real_t xk[3][RPL], rzk[3][RPL], rcm[RPL];
             bool mv[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const int64_t kb = bcol - 1 + m;
                 mv[m] = (kb >= 0) & (kb < nb);
-                const int at = (lb - 2 + m) * RS + 2 * r2;
-                xk[m][0] = rx[at]; xk[m][1] = rx[at + 1];
-                rzk[m][0] = rz[at]; rzk[m][1] = rz[at + 1];
+                const int at = (lb - 2 + m) * RS + RPL * r2;
+#pragma unroll
+                for (int h = 0; h < RPL; ++h) { xk[m][h] = rx[at + h]; rzk[m][h] = rz[at + h]; }
             }
-            const real_t rcm[2] = {rc[(lb - 1) * RS + 2 * r2], rc[(lb - 1) * RS + 2 * r2 + 1]};
+#pragma unroll
+            for (int h = 0; h < RPL; ++h) rcm[h] = rc[(lb - 1) * RS + RPL * r2 + h];
             const int first = bcol > 0 ? 0 : 1;
             const T *su = ssum + (size_t)(lb - 2) * B;
-            for (int it = 0; 4 * it < ncol; ++it) {
-                const int ci = 4 * it + cq;
+            for (int it = 0; CPI * it < ncol; ++it) {
+                const int ci = CPI * it + cq;
                 const int src = ci < ncol ? ci : 0;
                 const int qs = __shfl(q_l, src, 64);
                 const unsigned dlo = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l & 0xffffffffu), src, 64);
                 const unsigned dhi = (unsigned)__shfl((int)(unsigned)((unsigned long long)dest_l >> 32), src, 64);
                 const bool cv = (ci < ncol) & (qs >= 0);
                 const int q = cv ? qs : 0;
-                real_t *dst = outp + (long long)(((unsigned long long)dhi << 32) | dlo) + 2 * r2;
+                real_t *dst = outp + (long long)(((unsigned long long)dhi << 32) | dlo) + RPL * r2;
                 const real_t e = ce[q], ye = cy[q], sh = cs[q];
                 const int jl = cstart + ci;
-                real_t vim[3][2], qv[3][2];
-                bool fast = p2all || div_shared_ok(e);
+                real_t vim[3][RPL], qv[3][RPL];
+                bool fast = p2all || (sizeof(real_t) == 8 && div_shared_ok(e));
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const T S = su[(size_t)m * B + q];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const bool hit = (m == 1) & (2 * r2 + h == jl);
+                    for (int h = 0; h < RPL; ++h) {
+                        const bool hit = (m == 1) & (RPL * r2 + h == jl);
                         const real_t xim = hit ? e : (real_t)0;
                         const real_t snim = hit ? rcm[h] * sh : rzk[m][h];
                         vim[m][h] = (xk[m][h] * S.im + xim * S.re) + snim;
@@ -1872,7 +1896,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                        for (int h = 0; h < RPL; ++h) {
                             const real_t r0 = __builtin_fma(-e, qv[m][h], vim[m][h]);
                             const real_t q1 = __builtin_fma(r0, ye, qv[m][h]);
                             const real_t r1 = __builtin_fma(-e, q1, vim[m][h]);
@@ -1880,11 +1904,17 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
                         }
                 } else {
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) { qv[m][0] = vim[m][0] / e; qv[m][1] = vim[m][1] / e; }
+                    for (int m = 0; m < 3; ++m)
+#pragma unroll
+                        for (int h = 0; h < RPL; ++h) qv[m][h] = vim[m][h] / e;
                 }
+                // (Float32: a destination that is even but not a multiple of four -- pairs there)
+                const bool al = RPL == 2 || (dlo & 3u) == 0;
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
-                    if (cv & mv[m]) __builtin_nontemporal_store(r2_t{qv[m][0], qv[m][1]}, reinterpret_cast<r2_t *>(dst + (m - first) * bs));
+                    if (cv & mv[m]) {
+                        bc_store_rows<RPL>(dst + (m - first) * bs, qv[m], al);
+                    }
             }
         }
         return;
@@ -1993,7 +2023,7 @@ static int lazy_blockcoupled_launch(BuiltinF *b, void *fx, const fd_lazy_points 
             return FD_LAZY_DECLINED;
         const int64_t cb0 = st.col_begin / bs, cb1 = (st.col_end - 1) / bs + 1;      // blocks with local columns
         const int64_t gs = (cb1 - cb0 + kBcS - 1) / kBcS;
-        if (bs == 32 && st.pairs && sizeof(real_t) == 8 && (((uintptr_t)st.out) & 15) == 0)
+                if (bs == 32 && st.pairs && (((uintptr_t)st.out) & (sizeof(real_t) == 4 ? 4 * FD_BC_RPL32 - 1 : 15)) == 0)      // row pairs (or Float32 row quads)
             hipLaunchKernelGGL((k_f_blockcoupled_store<CT, true, true>), dim3((unsigned)gs), dim3(kBcT), bcs_lds_bytes(lp->ncolors, (int)bs), s, (const real_t *)lp->x,
                                (const CT *)lp->color, (const real_t *)lp->eps, lp->c_lo, lp->ncolors, nb, (int)bs, cb0, cb1, st);
         else if (bs <= 32)

@@ -9,8 +9,8 @@ print("%-10s ms/step %.4f  kernel %s avg %.4f ms median %.4f ms  frac %.3f  chec
 PY
 }
 for rep in 1 2; do
-python bench.py --config c3 --soak-seconds 0 --no-cpu-baseline --no-plain-handover > gpurun_out/ab_base.json 2>/dev/null; show base gpurun_out/ab_base.json
+python bench.py --config c3 $BENCH_EXTRA --soak-seconds 0 --no-cpu-baseline --no-plain-handover > gpurun_out/ab_base.json 2>/dev/null; show base gpurun_out/ab_base.json
 for v in "$@"; do
-  scripts/with_variant.sh $v python bench.py --config c3 --soak-seconds 0 --no-cpu-baseline --no-plain-handover > gpurun_out/ab_$v.json 2>/dev/null; show $v gpurun_out/ab_$v.json
+  scripts/with_variant.sh $v python bench.py --config c3 $BENCH_EXTRA --soak-seconds 0 --no-cpu-baseline --no-plain-handover > gpurun_out/ab_$v.json 2>/dev/null; show $v gpurun_out/ab_$v.json
 done
 done
