@@ -317,3 +317,28 @@ def test_stencil5_store_four_columns_per_lane_float32(monkeypatch, fdtype, fam, 
         assert not np.isnan(outs["handover"]).any()
     for form in ("wave4", "wave2"):
         assert np.array_equal(outs[form].view(np.uint32), outs["handover"].view(np.uint32)), form
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "central"])
+def test_tridiagonal_store_float32_special_operands(monkeypatch, fdtype):
+    # zero differences next to huge coordinates, overflow, tiny values in the four-columns-per-lane storing launch: the bits of the
+    # hand-over path everywhere (the division through Float64 of the 5-point kernel measured no gain here -- 30.6 against 30.6 us,
+    # the kernel is bound by its stores -- and is not used)
+    N = 50_000
+    colors = P.cyclic_colors(N, 3)
+    xh = (np.random.default_rng(8).random(N) + 0.1).astype(F32)
+    xh[1000] = 1e30; xh[2000] = 3e38; xh[3000:3010] = 0.0; xh[4000] = 1e-30; xh[5000] = -1e20; xh[6000:6004] = 1e-38
+    x = _dev(xh)
+    cp, rv = P.tridiag_csc(N)
+    J = fd.SparseMatrixCSC(N, N, cp, rv)
+    outs = {}
+    for store in ("1", "0"):
+        monkeypatch.setenv("FDJAC_LAZY_STORE", store)
+        plan = fd.make_plan(J, J, colors, fdtype, dtype=F32)
+        f = fd.BuiltinF("tridiag_nl", N, dtype=F32)
+        plan.set_lazy(f)
+        assert plan.info(fd.lib.INFO_LAZY_STORE) == int(store)
+        out = torch.full((plan.out_len(0),), float("nan"), dtype=torch.float32, device="cuda")
+        plan.jacobian(f, x, [out])
+        outs[store] = out.cpu().numpy()
+    assert np.array_equal(outs["1"].view(np.uint32), outs["0"].view(np.uint32))
