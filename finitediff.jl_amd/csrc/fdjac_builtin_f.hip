@@ -96,6 +96,12 @@ k_f_tridiag_v2(real_t *__restrict__ fx, const real_t *__restrict__ x, int64_t n,
 // points never exist in memory and x is read once for all colours.  Values are bit-identical to
 // evaluating the materialised points.  MODE 0 forward, 1 central (+ then -), 2 complex step.
 // ---------------------------------------------------------------------------------------------
+// the wavefront's index in its workgroup, told to the compiler as the wave-uniform value it is: tile numbers, row starts, interior / edge
+// verdicts and base addresses derived from it then live in scalar registers and are computed by the scalar unit.  One box, events
+// (scripts/ab_all.sh): block-coupled store 49.6 -> 48.1 us (Float32 29.4 -> 28.9), Float32 5-point store 57.9 -> 57.2 -- used there;
+// the Float64 5-point store 100 -> 127-132 us (its interior / edge / boundary window loads become real branches) and the tridiagonal
+// stores unchanged -- not used there.
+__device__ __forceinline__ int wave_index_scalar() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // the subtraction of fd_lazy_points.diff: an IEEE a - b of the two stored values, never contracted into a producer
 __device__ __forceinline__ real_t sub_exact(real_t a, real_t b)
 {
@@ -1146,6 +1152,7 @@ k_f_stencil5_store_wave(const real_t *__restrict__ x, const real_t *__restrict__
     // (32-bit division: the launcher declines grids with 2^31 tiles or more; a 64-bit one is ~150 instructions per wavefront)
     const unsigned wrow = (unsigned)wt / (unsigned)TPR;
     const int j = (int)(jrow0 + wrow), i0 = (int)((unsigned)wt - wrow * (unsigned)TPR) * TW;
+    // (scalar copies of j and i0 for the addresses alone -- readfirstlane -- measured no change: 100.6 / 103.0 us, scripts/ab_c3.sh)
     const int i = i0 + 2 * lane;
     const int64_t k = (int64_t)j * nx + i;
     const bool act = i < nx;
@@ -1232,7 +1239,7 @@ k_f_stencil5_store_wave4(const real_t *__restrict__ x, const real_t *__restrict_
 {
     constexpr int TW = 256, WC = 8;
     __shared__ __attribute__((aligned(16))) real_t s_win[kBlock / 64][FD_STENCIL5_WAVE4_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index_scalar();
     const int nx = (int)st.nx, ny = (int)st.ny;                 // nx is a multiple of 4 (launcher): a lane's four columns share a grid row
     const int TPR = (nx + TW - 1) / TW;
     const int64_t ntiles = (jrow1 - jrow0) * TPR, ngroups = (ntiles + kBlock / 64 - 1) / (kBlock / 64);
@@ -1699,7 +1706,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     real_t *ce = rz + (kBcS + 2) * RS;               // [B] step size of every colour of the batch,
     real_t *cy = ce + B;                             //     its reciprocal (div_shared),
     real_t *cs = cy + B;                             //     sinh(eps): imag(sin(x + i eps)) = cos(x) sinh(eps)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_index_scalar();
     const int64_t g0 = blk0 + (int64_t)blockIdx.x * kBcS;
     const real_t w = (real_t)(lane + 1) / (real_t)bs;
     int *own = owner + wave * B;
@@ -1721,6 +1728,19 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
             if (cj >= B) cj = -1;
             ca[it] = cj;
         }
+    }
+    // PACK (Float32, blocks of <= 32 rows): x, cos(x), cos(x) sinh(0 x) of the rows phase B evaluates -- blocks g0-1 .. g0+kBcS -- are formed
+    // by FULL wavefronts, two blocks each (lanes 0-31 / 32-63), instead of by the half-empty wavefront that sums the block: half the wave
+    // instructions of the library cosine; the same function of the same operand: same bits.  One box, events (scripts/ab_c5.sh): Float32
+    // 29.0 -> 25.8 us at config 5 -- used; Float64 48.2 -> 50.8 us -- not used.
+    constexpr bool PACK = TWO && sizeof(real_t) == 4;
+    real_t xr = 0;
+    bool actr = false;
+    const int lbr = 1 + 2 * wave + (lane >> 5);
+    if constexpr (PACK) {
+        const int64_t bbr = g0 - 2 + lbr;
+        actr = (lbr <= kBcS + 2) & (bbr >= 0) & (bbr < nb) & ((lane & 31) < bs);
+        if (actr) xr = x[bbr * bs + (lane & 31)];
     }
     // ... and of phase B: lane i holds the colour and the destination of column i of each unit the wave will store
     int uq[NU];
@@ -1752,6 +1772,16 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
     const bool p2all = sizeof(real_t) == 4 && __syncthreads_or(notp2) == 0;
     if (sizeof(real_t) != 4) __syncthreads();
 
+    if constexpr (PACK) {
+        if (lbr <= kBcS + 2) {                         // (wave-uniform up to the two halves: the wavefronts 0 .. (kBcS + 1) / 2)
+            const int at = (lbr - 1) * RS + (lane & 31);
+            const real_t c0 = actr ? cos(xr) : (real_t)0;
+            rx[at] = xr;
+            rc[at] = c0;
+            const real_t z = 0.0 * xr;                          // +-0 for a finite x: sinh(+-0) = +-0 (non-finite x: the library call)
+            rz[at] = actr ? c0 * (z == (real_t)0 ? z : sinh(z)) : (real_t)0;
+        }
+    }
     // ---- phase A (as k_f_blockcoupled_lazy, MODE 2): sig of blocks g0-2 .. g0+kBcS+1 for every point of the batch
     real_t *tr = reinterpret_cast<real_t *>(tree) + (size_t)wave * 128;
 #pragma unroll
@@ -1763,7 +1793,7 @@ k_f_blockcoupled_store(const real_t *__restrict__ x, const CT *__restrict__ colo
         const bool act = inb & (lane < bs);
         const real_t xj = xa[it];
         const int cj = ca[it];
-        if (lb >= 1 && lb <= kBcS + 2) {             // the rows phase B evaluates: x, cos once per row
+        if (!PACK && lb >= 1 && lb <= kBcS + 2) {    // the rows phase B evaluates: x, cos once per row
             const int at = (lb - 1) * RS + lane;
             const real_t c0 = act ? cos(xj) : (real_t)0;
             if (lane < RS) {
