@@ -606,7 +606,7 @@ def main():
     elif lazy_store and cfg == "c3":
         bytes_min = (vs * N + N + nnz * vs) / N                 # x in, one colour byte per column, nzval out
         bytes_call_model = (vs + 1.0) + bytes_min
-        kern = "k_f_stencil5_store_wave<unsigned char, 1, 0>"
+        kern = "k_f_stencil5_store_wave<unsigned char, 1, 0>" if vs == 8 else "k_f_stencil5_store_wave4<unsigned char, 1, 0>"   # (Float32: four columns per lane)
     elif lazy_store and cfg == "c5":
         bytes_min = (vs * N + N + 16 * N + nnz * vs) / N        # x in, one colour byte + the (row range, destination) of a column, data out
         bytes_call_model = (vs + 1.0) + bytes_min

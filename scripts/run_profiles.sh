@@ -15,6 +15,7 @@ for cfg in $CFGS; do
     c4) N=10000000; KERN=k_f_tridiag_store_wave;; c2) N=1000000; KERN=k_f_tridiag_fused;; c3) N=10000000; KERN=k_f_stencil5_store_wave;; c5) N=320000; KERN=k_f_blockcoupled_store;;
   esac
   [ "$cfg" = "c4_f32" ] && KERN=k_f_tridiag_store_wave4
+  [ "$cfg" = "c3_f32" ] && KERN=k_f_stencil5_store_wave4
   [ "$cfg" = "c2_f32" ] && KERN=k_f_tridiag_fused4
   name=r06_${TAG}_$cfg
   /usr/local/graft/bin/gpurun --timeout 900 -- "bash scripts/profile_all.sh $name $base $N $KERN $extra" > gpurun_out/$name.log 2>&1 || true
